@@ -1,0 +1,39 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    import torch
+
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    return {k: (z[k] if k == "meta" else torch.from_numpy(z[k])) for k in z.files}
+
+
+def rel_err(a, b):
+    """max|a-b| / max|b| -- the rel-err the north_star tolerance (1e-3) is stated in."""
+    a, b = a.double(), b.double()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def rms_ratio(a, b):
+    """fla's RMS error ratio (mhla_nlp/fla/utils.py:76-79)."""
+    a, b = a.double(), b.double()
+    return ((a - b).square().mean().sqrt() / b.square().mean().sqrt().clamp_min(1e-30)).item()
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return load_golden
