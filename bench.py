@@ -1,0 +1,169 @@
+#!/usr/bin/env python
+"""MHLA operator bench: fwd+bwd tokens/s at (B, N, H, D) on MI355X, with roofline and CPU baseline.
+
+  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+A "step" is one forward + backward of the block-mixing MHLA operator over one synthetic batch
+resident in HBM.  Workload at every N (weak scaling, per GPU): BASELINE.json configs[1]
+"Synthetic MHLA op micro-bench B=8 N=4096 H=16 D=64 bf16" with M = 64 blocks of S = 64 tokens.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured float4 copy)
+MFMA_BF16_PEAK_TFLOPS = 2500.0
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=30)
+    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--B", type=int, default=8)
+    p.add_argument("--N", type=int, default=4096)
+    p.add_argument("--H", type=int, default=16)
+    p.add_argument("--D", type=int, default=64)
+    p.add_argument("--M", type=int, default=64)
+    p.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "f16"])
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    return p.parse_args()
+
+
+def make_inputs(a, device, seed):
+    from mhla_amd import block_distance_weights
+    dt = {"bf16": torch.bfloat16, "f32": torch.float32, "f16": torch.float16}[a.dtype]
+    g = torch.Generator().manual_seed(seed)
+    shape = (a.B, a.N, a.H, a.D)
+    q = (torch.relu(torch.randn(shape, generator=g)) + 1e-6).to(dt).to(device)
+    k = (torch.relu(torch.randn(shape, generator=g)) + 1e-6).to(dt).to(device)
+    v = torch.randn(shape, generator=g).to(dt).to(device)
+    do = torch.randn(shape, generator=g).to(dt).to(device)
+    side = int(round(a.M ** 0.5))
+    W = block_distance_weights((side, side) if side * side == a.M else (a.M,), "linear").to(device)
+    return q, k, v, W, do
+
+
+def cpu_baseline(a, budget_s=12.0):
+    """The oracle (eager PyTorch restatement of the reference op sequence, fp32) timed on the host cores
+    on a bounded sample: fwd+bwd over B_s = 1 sample of the same (N, H, D, M) workload."""
+    from oracle import mhla_oracle as orc
+    torch.set_num_threads(os.cpu_count() or 1)
+    g = torch.Generator().manual_seed(1234)
+    Bs = 1
+    shape = (Bs, a.N, a.H, a.D)
+    q = (torch.relu(torch.randn(shape, generator=g)) + 1e-6).requires_grad_(True)
+    k = (torch.relu(torch.randn(shape, generator=g)) + 1e-6).requires_grad_(True)
+    v = torch.randn(shape, generator=g).requires_grad_(True)
+    do = torch.randn(shape, generator=g)
+    side = int(round(a.M ** 0.5))
+    W = orc.block_distance_weights((side, side) if side * side == a.M else (a.M,), "linear").requires_grad_(True)
+
+    def it():
+        out = orc.blockmix_fwd(q, k, v, W, 1e-6)
+        (out * do).sum().backward()
+        q.grad = k.grad = v.grad = W.grad = None
+
+    it()   # warm-up
+    times = []
+    t_end = time.perf_counter() + budget_s
+    while len(times) < 3 or (time.perf_counter() < t_end and len(times) < 20):
+        t0 = time.perf_counter()
+        it()
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": Bs * a.N / med, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle (eager PyTorch fp32, autograd bwd) fwd+bwd on B=1 x N={a.N} x H={a.H} x D={a.D}, "
+                      f"M={a.M}; median of {len(times)} iterations ({med * 1e3:.0f} ms each)"}
+
+
+def main():
+    a = parse()
+    from mhla_amd import dist as mdist
+    rank, local, world = mdist.init_from_env()
+    if world != a.gpus and rank == 0:
+        print(f"[bench] note: --gpus {a.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback for the product path)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import mhla_amd
+    lib = mhla_amd._lib.load()
+
+    q, k, v, W, do = make_inputs(a, dev, 1234 + rank)
+    for t in (q, k, v, W):
+        t.requires_grad_(True)
+
+    def step():
+        out = mhla_amd.mhla_blockmix(q, k, v, W, eps=1e-6)
+        out.backward(do)
+        mdist.allreduce_mean_(W.grad)      # the one real exchange of a data-parallel step on this path (dW)
+        q.grad = k.grad = v.grad = W.grad = None
+
+    sync = torch.cuda.synchronize
+    el = mdist.timed_steps(step, a.steps, a.warmup, sync)
+    ms_per_step = el / a.steps * 1e3
+    tokens_per_step = a.B * a.N * world
+    value = tokens_per_step / (el / a.steps)
+
+    # ---- per-kernel durations, measured live with HIP events on the launch stream ----
+    lib.mhla_prof_enable(1)
+    for _ in range(a.steps):
+        step()
+    sync()
+    lib.mhla_prof_enable(0)
+    import ctypes
+    buf = ctypes.create_string_buffer(1 << 16)
+    lib.mhla_prof_report(buf, len(buf))
+    kernels = {}
+    for line in buf.value.decode().splitlines():
+        name, cnt, tot = line.rsplit(" ", 2)
+        kernels[name] = {"launches_per_step": int(cnt) / a.steps, "avg_us": float(tot) / int(cnt) * 1e3,
+                         "us_per_step": float(tot) / a.steps * 1e3}
+    gpu_us = sum(kv["us_per_step"] for kv in kernels.values())
+    dom = max(kernels, key=lambda n: kernels[n]["us_per_step"]) if kernels else None
+
+    esz = {"bf16": 2, "f16": 2, "f32": 4}[a.dtype]
+    alg_bytes = 12 * a.B * a.H * a.N * a.D * esz            # fwd 4 NDe + bwd 8 NDe per (b, h)
+    alg_flops = a.B * a.H * (12 * a.N * a.D * a.D + 6 * a.M * a.M * a.D * a.D)
+    achieved = alg_bytes / (gpu_us * 1e-6) / 1e9 if gpu_us else None
+
+    if rank == 0:
+        res = {
+            "metric": "MHLA fwd+bwd tokens/sec at (B,N,H,D)",
+            "value": value, "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": f"block-mix MHLA op fwd+bwd, per GPU B={a.B} N={a.N} H={a.H} D={a.D} "
+                                   f"M={a.M} S={a.N // a.M} {a.dtype} (BASELINE.json configs[1])",
+                       "global_batch": a.B * world, "parallelism": f"dp{world} (batch shards, dW all-reduce only)"},
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS if achieved else None, "traffic": None,
+                "scope": "whole fwd+bwd step: algorithmic bytes 12*B*H*N*D*e over the sum of all kernel "
+                         "durations (HIP events per launch)",
+                "algorithmic_bytes_per_step": alg_bytes, "gpu_us_per_step": gpu_us,
+                "dominant_kernel": dom, "kernels": kernels,
+                "mfma_frac_of_bf16_peak": alg_flops / (gpu_us * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS if gpu_us else None,
+            },
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(a)
+            res["gpu_over_cpu"] = value / res["cpu_baseline"]["value"]
+        print(json.dumps(res))
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,166 @@
+/*
+ * mhla_hip.h -- C ABI of libmhla_hip.so: the MI355X (gfx950) MHLA operator.
+ *
+ * This is the drop-in boundary for the MHLA hot path.  The reference
+ * (DAGroup-PKU/MHLA) has no FFI / plugin registry: its boundary is plain Python
+ * class substitution, and the operator itself is a handful of eager
+ * torch.matmul / 1x1-conv calls.  Each entry point below names the reference
+ * lines it replaces (paths relative to the reference tree).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer; the library owns no memory, all
+ *     buffers (inputs, outputs, workspaces) belong to the caller;
+ *   - all work is enqueued on the caller's `stream` (a hipStream_t passed as
+ *     void*), nothing synchronises, no global mutable state: re-entrant;
+ *   - token tensors are token-major `[B, N, H, D]` with ELEMENT strides
+ *     (sb, sn, sh) and unit stride along D, so heads can be read in place from
+ *     a fused QKV projection output; D and every stride must be multiples of 4
+ *     elements and base pointers 16-byte aligned;
+ *   - tokens are in block-major order (token p = m*S + s is offset s of block
+ *     m); `block_index` (int32[N], may be NULL) maps block-major position p to
+ *     the token's row in memory, which realises the reference's
+ *     `rearrange(... "(fb p1 hb p2 wb p3) -> (fb hb wb) (p1 p2 p3)")` gather
+ *     without a copy;
+ *   - returns 0 on success, a negative MHLA_E* code otherwise (outputs
+ *     untouched); mhla_last_error() gives a thread-local message.
+ */
+#ifndef MHLA_HIP_H
+#define MHLA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MHLA_ABI_VERSION 1
+
+enum { MHLA_F32 = 0, MHLA_BF16 = 1, MHLA_F16 = 2 };
+
+enum {
+    MHLA_OK = 0,
+    MHLA_EINVAL = -22,   /* bad shape / stride / alignment / flag combination */
+    MHLA_ENOTSUP = -95,  /* shape outside what the kernels cover */
+    MHLA_ELAUNCH = -5    /* HIP launch error */
+};
+
+/* flags */
+#define MHLA_FLAG_RELU_EPS 1u /* apply relu(x)+eps to q,k while loading (mhla_dit/mhla/mhla.py:229-230) */
+
+/* A token-major view [B, N, H, D]: element strides, D contiguous. */
+typedef struct {
+    const void* ptr;
+    int64_t sb, sn, sh;
+} mhla_view;
+
+typedef struct {
+    void* ptr;
+    int64_t sb, sn, sh;
+} mhla_mview;
+
+int mhla_abi_version(void);
+const char* mhla_last_error(void);
+
+/* Profiling aid (used by bench.py): when enabled, every kernel launch is bracketed by hipEvents on
+ * its own stream; mhla_prof_report waits for them, writes one "kernel_name count total_ms" line per
+ * kernel into buf (NUL-terminated, truncated to cap) and clears the records.  Off by default. */
+void mhla_prof_enable(int on);
+int mhla_prof_report(char* buf, size_t cap);
+
+/* ---- block-mixing (non-causal) MHLA: DiT / ViT / Wan ------------------- */
+
+/* Bytes of fp32 workspace mhla_blockmix_fwd / _bwd need (bwd >= fwd). */
+size_t mhla_blockmix_fwd_ws_bytes(int B, int H, int M, int S, int D);
+size_t mhla_blockmix_bwd_ws_bytes(int B, int H, int M, int S, int D);
+
+/*
+ * Forward.  Replaces mhla_dit/mhla/mhla.py:262-268 (identical:
+ * mhla_image_classification/models/modules/attention/mhla.py:275-282) and
+ * mhla_videogen/diffusion/model/wan/mhla_utils.py:331-341:
+ *   KV_j = K_j^T V_j ; G_i = sum_j W[i,j] KV_j ;
+ *   z_j[s] = Qd_j[s] . sum_s' Kd_j[s'] ; n_i[s] = sum_j W[i,j] z_j[s] + eps ;
+ *   O_i = (Q_i G_i) / n_i          (no division when q_den.ptr == NULL).
+ * q_num/k_num feed KV and the numerator, q_den/k_den the normaliser (Wan passes
+ * roped / un-roped pairs); q_den may alias q_num (same ptr) -- the DiT/ViT case.
+ * W is [M, M] fp32 row-major (row = output block i, col = input block j), ldw
+ * its row stride.
+ */
+int mhla_blockmix_fwd(mhla_view q_num, mhla_view k_num, mhla_view v,
+                      mhla_view q_den, mhla_view k_den,
+                      const float* W, int ldw, mhla_mview out,
+                      const int32_t* block_index, void* ws, size_t ws_bytes,
+                      int B, int H, int M, int S, int D,
+                      int dtype, float eps, unsigned flags, void* stream);
+
+/*
+ * Backward (autograd of the forward above; hand-derived).
+ * Recomputes the block summaries (stateless: needs only the forward's inputs,
+ * its output `out` and the upstream gradient `dout`).  dq_den/dk_den are
+ * written only when q_den does not alias q_num; otherwise both parts are summed
+ * into dq_num/dk_num.  dW is [M, M] fp32 (ld = M), overwritten (not
+ * accumulated), reduced over (b, h) in a fixed order: deterministic.
+ */
+int mhla_blockmix_bwd(mhla_view q_num, mhla_view k_num, mhla_view v,
+                      mhla_view q_den, mhla_view k_den,
+                      const float* W, int ldw, mhla_view out, mhla_view dout,
+                      mhla_mview dq_num, mhla_mview dk_num, mhla_mview dv,
+                      mhla_mview dq_den, mhla_mview dk_den, float* dW,
+                      const int32_t* block_index, void* ws, size_t ws_bytes,
+                      int B, int H, int M, int S, int D,
+                      int dtype, float eps, unsigned flags, void* stream);
+
+/* ---- causal chunk-mixing MHLA: fla ------------------------------------- */
+
+size_t mhla_causal_fwd_ws_bytes(int B, int T, int H, int K, int V, int chunk);
+size_t mhla_causal_bwd_ws_bytes(int B, int T, int H, int K, int V, int chunk);
+
+/*
+ * Forward.  Replaces naive_chunk_simple_mhla_fixed
+ * (mhla_nlp/fla/ops/mhla/naive.py:10-83): fp32 compute, q scaled by `scale`
+ * (the reference always uses K^-0.5), T right-padded with zeros to a multiple
+ * of `chunk`, S_j = K_j^T V_j,
+ *   O_i = Q_i (sum_{j<i} mix[i,j] S_j) + mix[i,i] tril(Q_i K_i^T) V_i.
+ * q,k: [B,T,H,K]  v,out: [B,T,H,V]  mix: fp32 [n.., n..] row stride ldmix,
+ * n = ceil(T/chunk) rows/cols are read.  chunk must be 64.
+ */
+int mhla_causal_fwd(mhla_view q, mhla_view k, mhla_view v, const float* mix, int ldmix,
+                    mhla_mview out, void* ws, size_t ws_bytes,
+                    int B, int T, int H, int K, int V, int chunk,
+                    float scale, int dtype, void* stream);
+
+/* Backward.  dmix is [n, n] fp32 with row stride lddmix;
+ * only the lower triangle (incl. diagonal) of the leading n x n is written. */
+int mhla_causal_bwd(mhla_view q, mhla_view k, mhla_view v, const float* mix, int ldmix,
+                    mhla_view dout, mhla_mview dq, mhla_mview dk, mhla_mview dv,
+                    float* dmix, int lddmix, void* ws, size_t ws_bytes,
+                    int B, int T, int H, int K, int V, int chunk,
+                    float scale, int dtype, void* stream);
+
+/* ---- epilogue: per-head RMSNorm (x optional swish gate) ----------------- */
+
+/*
+ * y = x * rsqrt(mean_d(x^2) + eps) * w[d]  [ * g * sigmoid(g) ]   per (token, head).
+ * Replaces FusedRMSNormGated (mhla_nlp/fla/modules/fused_norm_gate.py:77-99,
+ * used at mhla_nlp/fla/layers/mhla.py:351-355) and Wan's per-head g_norm
+ * [x SiLU gate] (mhla_videogen/diffusion/model/wan/mhla_utils.py:357-362).
+ * x, g, y: [rows, D] with row strides (elements); g.ptr NULL => no gate.
+ * rstd (fp32 [rows], may be NULL) is saved for the backward.
+ */
+int mhla_rmsnorm_gate_fwd(const void* x, int64_t ldx, const void* g, int64_t ldg,
+                          const float* w, void* y, int64_t ldy, float* rstd,
+                          int64_t rows, int D, float eps, int dtype, void* stream);
+
+/* dx, dg (when gated) and a per-row-block partial of dw: dw_partial is fp32
+ * [mhla_rmsnorm_gate_dw_rows(rows), D]; the caller sums it over dim 0. */
+int64_t mhla_rmsnorm_gate_dw_rows(int64_t rows);
+int mhla_rmsnorm_gate_bwd(const void* x, int64_t ldx, const void* g, int64_t ldg,
+                          const float* w, const void* dy, int64_t lddy,
+                          void* dx, int64_t lddx, void* dg, int64_t lddg,
+                          float* dw_partial, int64_t rows, int D, float eps,
+                          int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MHLA_HIP_H */

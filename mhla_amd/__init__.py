@@ -1,0 +1,13 @@
+"""mhla_amd -- the MHLA attention operator for AMD MI355X (gfx950 / CDNA4).
+
+Hand-written HIP kernels behind a C ABI (include/mhla_hip.h, libmhla_hip.so), the autograd
+operators over it (mhla_amd.ops) and drop-in attention modules for the DiT, timm-ViT, Wan2.1 and
+flash-linear-attention hosts (mhla_amd.modules).  No CPU / eager fallback.
+"""
+from . import _lib
+from .ops import mhla_blockmix, mhla_causal, naive_chunk_simple_mhla_fixed, rmsnorm_gate
+from .weights import block_distance_weights, block_index_2d, block_index_3d, causal_mixing_init
+
+__all__ = ["mhla_blockmix", "mhla_causal", "naive_chunk_simple_mhla_fixed", "rmsnorm_gate",
+           "block_distance_weights", "block_index_2d", "block_index_3d", "causal_mixing_init", "_lib"]
+__version__ = "0.1.0"

@@ -1,0 +1,79 @@
+"""ctypes binding of libmhla_hip.so (C ABI: include/mhla_hip.h).  No CPU fallback: if the
+library is missing the product path raises."""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_uint, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmhla_hip.so")
+
+ABI_VERSION = 1
+F32, BF16, F16 = 0, 1, 2
+FLAG_RELU_EPS = 1
+
+
+class View(Structure):
+    """mhla_view / mhla_mview: token-major [B, N, H, D], element strides, D contiguous."""
+    _fields_ = [("ptr", c_void_p), ("sb", c_int64), ("sn", c_int64), ("sh", c_int64)]
+
+
+NULL_VIEW = View(None, 0, 0, 0)
+
+# name -> (restype, argtypes); every symbol include/mhla_hip.h declares
+SIGNATURES = {
+    "mhla_abi_version": (c_int, []),
+    "mhla_last_error": (c_char_p, []),
+    "mhla_prof_enable": (None, [c_int]),
+    "mhla_prof_report": (c_int, [c_char_p, c_size_t]),
+    "mhla_blockmix_fwd_ws_bytes": (c_size_t, [c_int] * 5),
+    "mhla_blockmix_bwd_ws_bytes": (c_size_t, [c_int] * 5),
+    "mhla_blockmix_fwd": (c_int, [View, View, View, View, View, c_void_p, c_int, View, c_void_p, c_void_p, c_size_t,
+                                  c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_uint, c_void_p]),
+    "mhla_blockmix_bwd": (c_int, [View, View, View, View, View, c_void_p, c_int, View, View, View, View, View, View,
+                                  View, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int,
+                                  c_int, c_float, c_uint, c_void_p]),
+    "mhla_causal_fwd_ws_bytes": (c_size_t, [c_int] * 6),
+    "mhla_causal_bwd_ws_bytes": (c_size_t, [c_int] * 6),
+    "mhla_causal_fwd": (c_int, [View, View, View, c_void_p, c_int, View, c_void_p, c_size_t, c_int, c_int, c_int,
+                                c_int, c_int, c_int, c_float, c_int, c_void_p]),
+    "mhla_causal_bwd": (c_int, [View, View, View, c_void_p, c_int, View, View, View, View, c_void_p, c_int, c_void_p,
+                                c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
+    "mhla_rmsnorm_gate_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p,
+                                      c_int64, c_int, c_float, c_int, c_void_p]),
+    "mhla_rmsnorm_gate_dw_rows": (c_int64, [c_int64]),
+    "mhla_rmsnorm_gate_bwd": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p,
+                                      c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_float, c_int, c_void_p]),
+}
+
+_lib = None
+
+
+class MhlaLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libmhla_hip.so (once).  Raises MhlaLibraryError when it is not built -- never falls back."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MhlaLibraryError(
+            f"{LIB_PATH} is missing: build it with `python -m mhla_amd.build` (hipcc --offload-arch=gfx950). "
+            "mhla_amd has no CPU / eager fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.mhla_abi_version()
+    if v != ABI_VERSION:
+        raise MhlaLibraryError(f"libmhla_hip.so ABI version {v} != expected {ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().mhla_last_error().decode(errors="replace")
+        raise RuntimeError(f"{what} failed (code {rc}): {msg}")

@@ -1,0 +1,47 @@
+"""Build libmhla_hip.so for gfx950 in-tree (mhla_amd/lib/), with hipcc.
+
+`python -m mhla_amd.build` or `mhla_amd.build.build()`.  hipcc cross-compiles without a GPU.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "csrc", "capi.hip")
+LIB_DIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIB_DIR, "libmhla_hip.so")
+DEPS = [os.path.join(HERE, "csrc", f) for f in ("capi.hip", "common.cuh", "blockmix.cuh", "causal.cuh", "epilogue.cuh",
+                                               "fused.cuh")] + [os.path.join(os.path.dirname(HERE), "include", "mhla_hip.h")]
+
+
+def hipcc_path() -> str:
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (looked at $HIPCC, /opt/rocm/bin/hipcc, PATH)")
+
+
+def is_stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in DEPS)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    if not force and not is_stale():
+        return LIB
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++20", "-shared", "-fPIC", "-Wall",
+           "-Wno-unused-function", SRC, "-o", LIB + ".tmp"]
+    if verbose:
+        print("[mhla_amd.build]", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    os.replace(LIB + ".tmp", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(LIB)

@@ -1,0 +1,425 @@
+// C ABI of libmhla_hip.so (see include/mhla_hip.h).  Validates arguments, carves the caller's
+// workspace, picks template instantiations and enqueues kernels on the caller's stream.
+#include "../../include/mhla_hip.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "blockmix.cuh"
+#include "causal.cuh"
+#include "epilogue.cuh"
+
+using namespace mhla;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+inline size_t al4(size_t n) { return (n + 3) & ~(size_t)3; }
+
+// Optional per-launch timing (mhla_prof_*): hipEvents recorded on the launch stream around every
+// kernel, so bench.py can report each kernel's average duration live (not only rocprof offline).
+struct ProfRec { const char* name; hipEvent_t e0, e1; };
+std::mutex g_prof_mu;
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+
+template <typename K>
+int launch(K kernel, dim3 grid, dim3 block, size_t smem, hipStream_t stream, const char* name, auto... args) {
+    if (smem > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return fail(MHLA_ELAUNCH, "%s: hipFuncSetAttribute(%zu B LDS): %s", name, smem, hipGetErrorString(e));
+    }
+    ProfRec rec{name, nullptr, nullptr};
+    const bool prof = g_prof_on;
+    if (prof) {
+        (void)hipEventCreate(&rec.e0);
+        (void)hipEventCreate(&rec.e1);
+        (void)hipEventRecord(rec.e0, stream);
+    }
+    hipLaunchKernelGGL(kernel, grid, block, smem, stream, args...);
+    if (prof) {
+        (void)hipEventRecord(rec.e1, stream);
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        g_prof.push_back(rec);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(MHLA_ELAUNCH, "%s: launch failed: %s", name, hipGetErrorString(e));
+    return MHLA_OK;
+}
+
+View cv(const mhla_view& v) { return View{v.ptr, (long)v.sb, (long)v.sn, (long)v.sh}; }
+MView cmv(const mhla_mview& v) { return MView{v.ptr, (long)v.sb, (long)v.sn, (long)v.sh}; }
+
+int check_view(const char* name, const void* ptr, int64_t sb, int64_t sn, int64_t sh, int dtype) {
+    if (!ptr) return fail(MHLA_EINVAL, "%s: null pointer", name);
+    const int esz = dtype == MHLA_F32 ? 4 : 2;
+    if (((uintptr_t)ptr) % (4 * esz) != 0) return fail(MHLA_EINVAL, "%s: pointer not %d-byte aligned", name, 4 * esz);
+    if ((sb | sn | sh) & 3) return fail(MHLA_EINVAL, "%s: strides (%lld, %lld, %lld) must be multiples of 4 elements", name,
+                                        (long long)sb, (long long)sn, (long long)sh);
+    return MHLA_OK;
+}
+#define CHECK_VIEW(v) do { int rc_ = check_view(#v, (v).ptr, (v).sb, (v).sn, (v).sh, dtype); if (rc_) return rc_; } while (0)
+#define RC(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
+
+int dt_for(int D) { return D <= 32 ? 2 : D <= 64 ? 4 : D <= 80 ? 5 : D <= 96 ? 6 : D <= 128 ? 8 : 0; }
+
+// dispatch on (dtype, DT)
+#define DISPATCH_T(dtype, ...)                                                   \
+    switch (dtype) {                                                             \
+        case MHLA_F32: { using ET = float; __VA_ARGS__; break; }                  \
+        case MHLA_BF16: { using ET = bf16_t; __VA_ARGS__; break; }                \
+        case MHLA_F16: { using ET = f16_t; __VA_ARGS__; break; }                  \
+        default: return fail(MHLA_EINVAL, "unknown dtype %d", dtype);            \
+    }
+#define DISPATCH_DT(dt, ...)                                                     \
+    switch (dt) {                                                                \
+        case 2: { constexpr int DT = 2; __VA_ARGS__; break; }                    \
+        case 4: { constexpr int DT = 4; __VA_ARGS__; break; }                    \
+        case 5: { constexpr int DT = 5; __VA_ARGS__; break; }                    \
+        case 6: { constexpr int DT = 6; __VA_ARGS__; break; }                    \
+        case 8: { constexpr int DT = 8; __VA_ARGS__; break; }                    \
+        default: return fail(MHLA_ENOTSUP, "head dim tile %d not supported", dt);\
+    }
+
+struct BmWs {
+    float *kv, *g, *z, *ksum, *dg, *dkv, *dn, *dwp;
+    size_t total_fwd, total_bwd;
+};
+BmWs bm_carve(void* ws, int B, int H, int M, int S, int D) {
+    const size_t bh = (size_t)B * H, st = al4(bh * M * D * D), zs = al4(bh * M * S), ks = al4(bh * M * D);
+    float* p = (float*)ws;
+    BmWs w;
+    w.kv = p; p += st;
+    w.g = p; p += st;
+    w.z = p; p += zs;
+    w.ksum = p; p += ks;
+    w.total_fwd = (size_t)(p - (float*)ws) * 4;
+    w.dg = p; p += st;
+    w.dkv = p; p += st;
+    w.dn = p; p += zs;
+    w.dwp = p; p += al4(bh * M * M);
+    w.total_bwd = (size_t)(p - (float*)ws) * 4;
+    return w;
+}
+
+int bm_check(int B, int H, int M, int S, int D, int dtype, unsigned flags, bool normalize, bool split) {
+    if (B <= 0 || H <= 0 || M <= 0 || S <= 0 || D <= 0) return fail(MHLA_EINVAL, "non-positive dimension B=%d H=%d M=%d S=%d D=%d", B, H, M, S, D);
+    if (D % 4) return fail(MHLA_EINVAL, "D=%d must be a multiple of 4", D);
+    if (!dt_for(D)) return fail(MHLA_ENOTSUP, "block-mix head dim D=%d > 128 not supported", D);
+    if (dtype < 0 || dtype > 2) return fail(MHLA_EINVAL, "unknown dtype %d", dtype);
+    if (flags & ~MHLA_FLAG_RELU_EPS) return fail(MHLA_EINVAL, "unknown flags 0x%x", flags);
+    if ((flags & MHLA_FLAG_RELU_EPS) && split) return fail(MHLA_EINVAL, "MHLA_FLAG_RELU_EPS needs q_den/k_den to alias q_num/k_num");
+    if ((size_t)B * H > 65535) return fail(MHLA_ENOTSUP, "B*H=%zu exceeds grid limit 65535", (size_t)B * H);
+    (void)normalize;
+    return MHLA_OK;
+}
+
+// KV/ksum/z, G for the forward and the recompute leg of the backward.
+template <typename T, int DT>
+int bm_state_and_mix(const mhla_view& q_num, const mhla_view& k_num, const mhla_view& v, const mhla_view& q_den,
+                     const mhla_view& k_den, const float* W, int ldw, const int32_t* idx, const BmWs& w, int B, int H,
+                     int M, int S, int D, float eps, unsigned flags, bool normalize, bool split, hipStream_t st) {
+    (void)q_num;
+    StateArgs a{};
+    a.x = cv(k_num); a.y = cv(v); a.kd = cv(k_den); a.qd = cv(q_den); a.idx = idx;
+    a.out = w.kv; a.ksum = w.ksum; a.zo = w.z;
+    a.H = H; a.M = M; a.S = S; a.D = D; a.eps = eps;
+    a.relu = (flags & MHLA_FLAG_RELU_EPS) ? 1 : 0; a.normalize = normalize; a.split = split;
+    RC(launch(k_bm_state<T, DT, 0>, dim3(M, B * H), dim3(NTHREADS), state_smem_floats<DT>() * 4, st, "k_bm_state<0>", a));
+    MixArgs m{W, ldw, w.kv, w.g, M, (long)D * D};
+    dim3 grid((unsigned)((m.E + MIX_TE - 1) / MIX_TE), (M + MIX_TI - 1) / MIX_TI, B * H);
+    RC(launch(k_mix<0, 0>, grid, dim3(NTHREADS), MIX_SMEM_FLOATS * 4, st, "k_mix<0,0>", m));
+    return MHLA_OK;
+}
+
+struct CsWs {
+    float *S, *P, *dP, *dS, *dwp, *diag;
+    size_t total_fwd, total_bwd;
+};
+CsWs cs_carve(void* ws, int B, int T, int H, int K, int V, int chunk) {
+    const size_t bh = (size_t)B * H, n = (size_t)(T + chunk - 1) / chunk, st = al4(bh * n * K * V);
+    float* p = (float*)ws;
+    CsWs w;
+    w.S = p; p += st;
+    w.P = p; p += st;
+    w.total_fwd = (size_t)(p - (float*)ws) * 4;
+    w.dP = p; p += st;
+    w.dS = p; p += st;
+    w.dwp = p; p += al4(bh * n * n);
+    w.diag = p; p += al4(bh * n);
+    w.total_bwd = (size_t)(p - (float*)ws) * 4;
+    return w;
+}
+int cs_check(int B, int T, int H, int K, int V, int chunk, int dtype) {
+    if (B <= 0 || T <= 0 || H <= 0 || K <= 0 || V <= 0) return fail(MHLA_EINVAL, "non-positive dimension B=%d T=%d H=%d K=%d V=%d", B, T, H, K, V);
+    if (chunk != 64) return fail(MHLA_ENOTSUP, "chunk=%d: only 64 is supported", chunk);
+    if ((K | V) & 3) return fail(MHLA_EINVAL, "K=%d and V=%d must be multiples of 4", K, V);
+    if (dtype < 0 || dtype > 2) return fail(MHLA_EINVAL, "unknown dtype %d", dtype);
+    if ((size_t)B * H > 65535) return fail(MHLA_ENOTSUP, "B*H=%zu exceeds grid limit 65535", (size_t)B * H);
+    return MHLA_OK;
+}
+
+// S_j (or dP_i) = alpha X_j^T Y_j with 64x64 strips
+template <typename T>
+int cs_xty(const mhla_view& x, const mhla_view& y, float* out, float alpha, int B, int T_, int H, int n, int DX,
+                  int DY, hipStream_t st) {
+    StateArgs a{};
+    a.x = cv(x); a.y = cv(y); a.out = out; a.H = H; a.M = n; a.S = CS; a.D = 64; a.DX = DX; a.DY = DY; a.T = T_;
+    a.alpha = alpha;
+    const int strips = ((DX + 63) / 64) * ((DY + 63) / 64);
+    return launch(k_bm_state<T, 4, 2>, dim3(n, B * H, strips), dim3(NTHREADS), state_smem_floats<4>() * 4, st, "k_bm_state<2>", a);
+}
+
+int norm_check(const void* x, const void* y, int64_t rows, int D, int dtype) {
+    if (!x || !y) return fail(MHLA_EINVAL, "null pointer");
+    if (rows <= 0 || D <= 0 || (D & 3) || D > 512) return fail(MHLA_EINVAL, "rows=%lld D=%d: need D %% 4 == 0 and D <= 512", (long long)rows, D);
+    if (dtype < 0 || dtype > 2) return fail(MHLA_EINVAL, "unknown dtype %d", dtype);
+    return MHLA_OK;
+}
+int norm_grid(int64_t rows) {
+    int64_t g = (rows + 3) / 4;
+    return (int)(g < 2048 ? g : 2048);
+}
+
+}  // namespace
+
+extern "C" {
+
+int mhla_abi_version(void) { return MHLA_ABI_VERSION; }
+
+void mhla_prof_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_on = on != 0;
+}
+
+// Waits for the recorded events, writes "name count total_ms" lines (one per kernel name) and clears.
+int mhla_prof_report(char* buf, size_t cap) {
+    std::vector<ProfRec> recs;
+    {
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        recs.swap(g_prof);
+    }
+    std::map<std::string, std::pair<long, double>> agg;
+    for (auto& r : recs) {
+        float ms = 0.f;
+        (void)hipEventSynchronize(r.e1);
+        (void)hipEventElapsedTime(&ms, r.e0, r.e1);
+        auto& a = agg[r.name];
+        a.first += 1;
+        a.second += ms;
+        (void)hipEventDestroy(r.e0);
+        (void)hipEventDestroy(r.e1);
+    }
+    std::string out;
+    char line[256];
+    for (auto& kv : agg) {
+        snprintf(line, sizeof(line), "%s %ld %.6f\n", kv.first.c_str(), kv.second.first, kv.second.second);
+        out += line;
+    }
+    if (!buf || cap == 0) return (int)out.size();
+    const size_t n = out.size() < cap - 1 ? out.size() : cap - 1;
+    memcpy(buf, out.data(), n);
+    buf[n] = 0;
+    return (int)n;
+}
+const char* mhla_last_error(void) { return g_err; }
+
+size_t mhla_blockmix_fwd_ws_bytes(int B, int H, int M, int S, int D) { return bm_carve(nullptr, B, H, M, S, D).total_fwd; }
+size_t mhla_blockmix_bwd_ws_bytes(int B, int H, int M, int S, int D) { return bm_carve(nullptr, B, H, M, S, D).total_bwd; }
+
+int mhla_blockmix_fwd(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q_den, mhla_view k_den, const float* W,
+                      int ldw, mhla_mview out, const int32_t* block_index, void* ws, size_t ws_bytes, int B, int H,
+                      int M, int S, int D, int dtype, float eps, unsigned flags, void* stream) {
+    const bool normalize = q_den.ptr != nullptr;
+    const bool split = normalize && (q_den.ptr != q_num.ptr || k_den.ptr != k_num.ptr);
+    RC(bm_check(B, H, M, S, D, dtype, flags, normalize, split));
+    CHECK_VIEW(q_num); CHECK_VIEW(k_num); CHECK_VIEW(v); CHECK_VIEW(out);
+    if (normalize) { CHECK_VIEW(q_den); CHECK_VIEW(k_den); }
+    if (!W || ldw < M) return fail(MHLA_EINVAL, "W null or ldw=%d < M=%d", ldw, M);
+    const BmWs w = bm_carve(ws, B, H, M, S, D);
+    if (!ws || ws_bytes < w.total_fwd) return fail(MHLA_EINVAL, "workspace too small: %zu < %zu bytes", ws_bytes, w.total_fwd);
+    if (((uintptr_t)ws) % 16) return fail(MHLA_EINVAL, "workspace not 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    if (!normalize) { q_den = q_num; k_den = k_num; }
+    const int dt = dt_for(D);
+    DISPATCH_T(dtype, DISPATCH_DT(dt, {
+        RC((bm_state_and_mix<ET, DT>(q_num, k_num, v, q_den, k_den, W, ldw, block_index, w, B, H, M, S, D, eps, flags, normalize, split, st)));
+        OutArgs o{};
+        o.q = cv(q_num); o.o = cmv(out); o.idx = block_index; o.W = W; o.ldw = ldw; o.g = w.g; o.z = w.z;
+        o.H = H; o.M = M; o.S = S; o.D = D; o.eps = eps;
+        o.relu = (flags & MHLA_FLAG_RELU_EPS) ? 1 : 0; o.normalize = normalize;
+        RC(launch(k_bm_out<ET, DT>, dim3(M, B * H), dim3(NTHREADS), out_smem_floats<DT>() * 4, st, "k_bm_out", o));
+    }));
+    return MHLA_OK;
+}
+
+int mhla_blockmix_bwd(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q_den, mhla_view k_den, const float* W,
+                      int ldw, mhla_view out, mhla_view dout, mhla_mview dq_num, mhla_mview dk_num, mhla_mview dv,
+                      mhla_mview dq_den, mhla_mview dk_den, float* dW, const int32_t* block_index, void* ws,
+                      size_t ws_bytes, int B, int H, int M, int S, int D, int dtype, float eps, unsigned flags,
+                      void* stream) {
+    const bool normalize = q_den.ptr != nullptr;
+    const bool split = normalize && (q_den.ptr != q_num.ptr || k_den.ptr != k_num.ptr);
+    RC(bm_check(B, H, M, S, D, dtype, flags, normalize, split));
+    CHECK_VIEW(q_num); CHECK_VIEW(k_num); CHECK_VIEW(v); CHECK_VIEW(dout);
+    CHECK_VIEW(dq_num); CHECK_VIEW(dk_num); CHECK_VIEW(dv);
+    if (normalize) { CHECK_VIEW(q_den); CHECK_VIEW(k_den); CHECK_VIEW(out); }
+    if (split) { CHECK_VIEW(dq_den); CHECK_VIEW(dk_den); }
+    if (!W || ldw < M || !dW) return fail(MHLA_EINVAL, "W/dW null or ldw=%d < M=%d", ldw, M);
+    const BmWs w = bm_carve(ws, B, H, M, S, D);
+    if (!ws || ws_bytes < w.total_bwd) return fail(MHLA_EINVAL, "workspace too small: %zu < %zu bytes", ws_bytes, w.total_bwd);
+    if (((uintptr_t)ws) % 16) return fail(MHLA_EINVAL, "workspace not 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    if (!normalize) { q_den = q_num; k_den = k_num; }
+    const int dt = dt_for(D);
+    const int relu = (flags & MHLA_FLAG_RELU_EPS) ? 1 : 0;
+    DISPATCH_T(dtype, DISPATCH_DT(dt, {
+        RC((bm_state_and_mix<ET, DT>(q_num, k_num, v, q_den, k_den, W, ldw, block_index, w, B, H, M, S, D, eps, flags, normalize, split, st)));
+        // dG_i = Q_i^T (dO_i / n_i), dn_i
+        StateArgs a{};
+        a.x = cv(q_num); a.y = cv(dout); a.o = cv(out); a.idx = block_index; a.W = W; a.ldw = ldw; a.z = w.z;
+        a.out = w.dg; a.dn = w.dn; a.H = H; a.M = M; a.S = S; a.D = D; a.eps = eps;
+        a.relu = relu; a.normalize = normalize; a.split = split;
+        RC(launch(k_bm_state<ET, DT, 1>, dim3(M, B * H), dim3(NTHREADS), state_smem_floats<DT>() * 4, st, "k_bm_state<1>", a));
+        // dKV = W^T dG
+        MixArgs m{W, ldw, w.dg, w.dkv, M, (long)D * D};
+        dim3 mgrid((unsigned)((m.E + MIX_TE - 1) / MIX_TE), (M + MIX_TI - 1) / MIX_TI, B * H);
+        RC(launch(k_mix<1, 0>, mgrid, dim3(NTHREADS), MIX_SMEM_FLOATS * 4, st, "k_mix<1,0>", m));
+        // dW = sum_bh (<dG_i, KV_j> + <dn_i, z_j>)
+        const int tiles = (M + 63) / 64;
+        DwArgs d{w.dg, w.kv, (long)D * D, normalize ? w.dn : nullptr, normalize ? w.z : nullptr, (long)S, w.dwp, M, tiles};
+        RC(launch(k_dw<0>, dim3(tiles * tiles, B * H), dim3(NTHREADS), DW_SMEM_FLOATS * 4, st, "k_dw", d));
+        RC(launch(k_dw_reduce<0>, dim3((M * M + 255) / 256), dim3(256), 0, st, "k_dw_reduce", (const float*)w.dwp,
+                  (const float*)nullptr, dW, M, M, B * H));
+        // dQ, dK, dV
+        TokArgs t{};
+        t.q = cv(q_num); t.k = cv(k_num); t.v = cv(v); t.qd = cv(q_den); t.kd = cv(k_den); t.dout = cv(dout);
+        t.dq = cmv(dq_num); t.dk = cmv(dk_num); t.dv = cmv(dv); t.dqd = cmv(dq_den); t.dkd = cmv(dk_den);
+        t.idx = block_index; t.W = W; t.ldw = ldw; t.g = w.g; t.dkv = w.dkv; t.z = w.z; t.dn = w.dn; t.ksum = w.ksum;
+        t.H = H; t.M = M; t.S = S; t.D = D; t.eps = eps; t.relu = relu; t.normalize = normalize; t.split = split;
+        RC(launch(k_bm_bwd_tok<ET, DT>, dim3(M, B * H), dim3(NTHREADS), tok_smem_floats<DT>() * 4, st, "k_bm_bwd_tok", t));
+    }));
+    return MHLA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// causal
+// ---------------------------------------------------------------------------------------------
+size_t mhla_causal_fwd_ws_bytes(int B, int T, int H, int K, int V, int chunk) { return cs_carve(nullptr, B, T, H, K, V, chunk).total_fwd; }
+size_t mhla_causal_bwd_ws_bytes(int B, int T, int H, int K, int V, int chunk) { return cs_carve(nullptr, B, T, H, K, V, chunk).total_bwd; }
+
+int mhla_causal_fwd(mhla_view q, mhla_view k, mhla_view v, const float* mix, int ldmix, mhla_mview out, void* ws,
+                    size_t ws_bytes, int B, int T, int H, int K, int V, int chunk, float scale, int dtype, void* stream) {
+    RC(cs_check(B, T, H, K, V, chunk, dtype));
+    CHECK_VIEW(q); CHECK_VIEW(k); CHECK_VIEW(v); CHECK_VIEW(out);
+    const int n = (T + chunk - 1) / chunk;
+    if (!mix || ldmix < n) return fail(MHLA_EINVAL, "mix null or ldmix=%d < n=%d chunks (T=%d)", ldmix, n, T);
+    const CsWs w = cs_carve(ws, B, T, H, K, V, chunk);
+    if (!ws || ws_bytes < w.total_fwd) return fail(MHLA_EINVAL, "workspace too small: %zu < %zu bytes", ws_bytes, w.total_fwd);
+    if (((uintptr_t)ws) % 16) return fail(MHLA_EINVAL, "workspace not 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_T(dtype, {
+        RC(cs_xty<ET>(k, v, w.S, 1.f, B, T, H, n, K, V, st));
+        MixArgs m{mix, ldmix, w.S, w.P, n, (long)K * V};
+        dim3 mgrid((unsigned)((m.E + MIX_TE - 1) / MIX_TE), (n + MIX_TI - 1) / MIX_TI, B * H);
+        RC(launch(k_mix<0, 1>, mgrid, dim3(NTHREADS), MIX_SMEM_FLOATS * 4, st, "k_mix<0,1>", m));
+        CsOutArgs o{cv(q), cv(k), cv(v), cmv(out), mix, ldmix, w.P, H, n, K, V, (long)T, scale};
+        RC(launch(k_cs_out<ET>, dim3(n, B * H, (V + 63) / 64), dim3(NTHREADS), CS_OUT_SMEM_FLOATS * 4, st, "k_cs_out", o));
+    });
+    return MHLA_OK;
+}
+
+int mhla_causal_bwd(mhla_view q, mhla_view k, mhla_view v, const float* mix, int ldmix, mhla_view dout, mhla_mview dq,
+                    mhla_mview dk, mhla_mview dv, float* dmix, int lddmix, void* ws, size_t ws_bytes, int B, int T,
+                    int H, int K, int V, int chunk, float scale, int dtype, void* stream) {
+    RC(cs_check(B, T, H, K, V, chunk, dtype));
+    CHECK_VIEW(q); CHECK_VIEW(k); CHECK_VIEW(v); CHECK_VIEW(dout); CHECK_VIEW(dq); CHECK_VIEW(dk); CHECK_VIEW(dv);
+    const int n = (T + chunk - 1) / chunk;
+    if (!mix || ldmix < n || !dmix || lddmix < n) return fail(MHLA_EINVAL, "mix/dmix null or leading dim < n=%d chunks", n);
+    const CsWs w = cs_carve(ws, B, T, H, K, V, chunk);
+    if (!ws || ws_bytes < w.total_bwd) return fail(MHLA_EINVAL, "workspace too small: %zu < %zu bytes", ws_bytes, w.total_bwd);
+    if (((uintptr_t)ws) % 16) return fail(MHLA_EINVAL, "workspace not 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_T(dtype, {
+        RC(cs_xty<ET>(k, v, w.S, 1.f, B, T, H, n, K, V, st));
+        MixArgs m{mix, ldmix, w.S, w.P, n, (long)K * V};
+        dim3 mgrid((unsigned)((m.E + MIX_TE - 1) / MIX_TE), (n + MIX_TI - 1) / MIX_TI, B * H);
+        RC(launch(k_mix<0, 1>, mgrid, dim3(NTHREADS), MIX_SMEM_FLOATS * 4, st, "k_mix<0,1>", m));
+        RC(cs_xty<ET>(q, dout, w.dP, scale, B, T, H, n, K, V, st));
+        MixArgs mt{mix, ldmix, w.dP, w.dS, n, (long)K * V};
+        RC(launch(k_mix<1, 1>, mgrid, dim3(NTHREADS), MIX_SMEM_FLOATS * 4, st, "k_mix<1,1>", mt));
+        CsTokArgs t{cv(q), cv(k), cv(v), cv(dout), cmv(dq), cmv(dk), cmv(dv), mix, ldmix, w.P, w.dS, w.diag, H, n, K, V, (long)T, scale};
+        RC(launch(k_cs_bwd_tok<ET>, dim3(n, B * H), dim3(NTHREADS), CS_TOK_SMEM_FLOATS * 4, st, "k_cs_bwd_tok", t));
+        const int tiles = (n + 63) / 64;
+        DwArgs d{w.dP, w.S, (long)K * V, nullptr, nullptr, 0, w.dwp, n, tiles};
+        RC(launch(k_dw<1>, dim3(tiles * tiles, B * H), dim3(NTHREADS), DW_SMEM_FLOATS * 4, st, "k_dw<1>", d));
+        RC(launch(k_dw_reduce<1>, dim3((n * n + 255) / 256), dim3(256), 0, st, "k_dw_reduce<1>", (const float*)w.dwp,
+                  (const float*)w.diag, dmix, lddmix, n, B * H));
+    });
+    return MHLA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-head RMSNorm x gate
+// ---------------------------------------------------------------------------------------------
+int64_t mhla_rmsnorm_gate_dw_rows(int64_t rows) { return norm_grid(rows); }
+
+int mhla_rmsnorm_gate_fwd(const void* x, int64_t ldx, const void* g, int64_t ldg, const float* w, void* y, int64_t ldy,
+                          float* rstd, int64_t rows, int D, float eps, int dtype, void* stream) {
+    RC(norm_check(x, y, rows, D, dtype));
+    if ((ldx | ldy | (g ? ldg : 0)) & 3) return fail(MHLA_EINVAL, "row strides must be multiples of 4");
+    NormArgs a{};
+    a.x = x; a.ldx = ldx; a.g = g; a.ldg = ldg; a.w = w; a.y = y; a.ldy = ldy; a.rstd = rstd; a.rows = rows; a.D = D; a.eps = eps;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(norm_grid(rows));
+    DISPATCH_T(dtype, {
+        if (D <= 256) {
+            if (g) RC(launch(k_rmsnorm_gate_fwd<ET, 1, true>, grid, dim3(256), 0, st, "k_rmsnorm_gate_fwd", a));
+            else   RC(launch(k_rmsnorm_gate_fwd<ET, 1, false>, grid, dim3(256), 0, st, "k_rmsnorm_gate_fwd", a));
+        } else {
+            if (g) RC(launch(k_rmsnorm_gate_fwd<ET, 2, true>, grid, dim3(256), 0, st, "k_rmsnorm_gate_fwd", a));
+            else   RC(launch(k_rmsnorm_gate_fwd<ET, 2, false>, grid, dim3(256), 0, st, "k_rmsnorm_gate_fwd", a));
+        }
+    });
+    return MHLA_OK;
+}
+
+int mhla_rmsnorm_gate_bwd(const void* x, int64_t ldx, const void* g, int64_t ldg, const float* w, const void* dy,
+                          int64_t lddy, void* dx, int64_t lddx, void* dg, int64_t lddg, float* dw_partial, int64_t rows,
+                          int D, float eps, int dtype, void* stream) {
+    RC(norm_check(x, dx, rows, D, dtype));
+    if (!dy || !dw_partial || (g && !dg)) return fail(MHLA_EINVAL, "null pointer");
+    if ((ldx | lddy | lddx | (g ? (ldg | lddg) : 0)) & 3) return fail(MHLA_EINVAL, "row strides must be multiples of 4");
+    NormArgs a{};
+    a.x = x; a.ldx = ldx; a.g = g; a.ldg = ldg; a.w = w; a.dy = dy; a.lddy = lddy; a.dx = dx; a.lddx = lddx;
+    a.dg = dg; a.lddg = lddg; a.dwp = dw_partial; a.rows = rows; a.D = D; a.eps = eps;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(norm_grid(rows));
+    DISPATCH_T(dtype, {
+        if (D <= 256) {
+            if (g) RC(launch(k_rmsnorm_gate_bwd<ET, 1, true>, grid, dim3(256), 0, st, "k_rmsnorm_gate_bwd", a));
+            else   RC(launch(k_rmsnorm_gate_bwd<ET, 1, false>, grid, dim3(256), 0, st, "k_rmsnorm_gate_bwd", a));
+        } else {
+            if (g) RC(launch(k_rmsnorm_gate_bwd<ET, 2, true>, grid, dim3(256), 0, st, "k_rmsnorm_gate_bwd", a));
+            else   RC(launch(k_rmsnorm_gate_bwd<ET, 2, false>, grid, dim3(256), 0, st, "k_rmsnorm_gate_bwd", a));
+        }
+    });
+    return MHLA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,159 @@
+// Shared device helpers for the gfx950 MHLA kernels (wave64, MFMA, LDS tiles).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mhla {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+struct bf16_t { unsigned short v; };
+struct f16_t { _Float16 v; };
+
+__device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) {   // round-to-nearest-even, NaN preserved
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+
+// 4-element vector I/O per dtype (16 B for f32, 8 B for 16-bit types).
+template <typename T> struct Io;
+template <> struct Io<float> {
+    static __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+    static __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+};
+template <> struct Io<bf16_t> {
+    static __device__ __forceinline__ f32x4 ld4(const bf16_t* p) {
+        uint2 r = *reinterpret_cast<const uint2*>(p);
+        f32x4 v;
+        v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
+        v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
+        return v;
+    }
+    static __device__ __forceinline__ void st4(bf16_t* p, f32x4 v) {
+        uint2 r;
+        r.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+        r.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+        *reinterpret_cast<uint2*>(p) = r;
+    }
+};
+template <> struct Io<f16_t> {
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ f32x4 ld4(const f16_t* p) {
+        h4 r = *reinterpret_cast<const h4*>(p);
+        f32x4 v; v[0] = (float)r[0]; v[1] = (float)r[1]; v[2] = (float)r[2]; v[3] = (float)r[3];
+        return v;
+    }
+    static __device__ __forceinline__ void st4(f16_t* p, f32x4 v) {
+        h4 r; r[0] = (_Float16)v[0]; r[1] = (_Float16)v[1]; r[2] = (_Float16)v[2]; r[3] = (_Float16)v[3];
+        *reinterpret_cast<h4*>(p) = r;
+    }
+};
+
+// Token-major view [B, N, H, D]; element strides; D contiguous.
+struct View {
+    const void* ptr;
+    long sb, sn, sh;
+};
+struct MView {
+    void* ptr;
+    long sb, sn, sh;
+};
+
+// LDS leading dimensions (in floats) for fp32 16x16x4 MFMA operand reads with ds_read_b32:
+//  k-major tile  T[k][x]  (lanes 0-15 walk x, lane>>4 walks k):  ld % 32 == 16  -> conflict-free
+//  x-major tile  T[x][k]  (lanes 0-15 walk rows x, lane>>4 walks k): ld == 2*odd -> conflict-free
+__host__ __device__ constexpr int ld_kmajor(int dp) { return ((dp + 15) / 32) * 32 + 16; }
+__host__ __device__ constexpr int ld_xmajor(int dp) { return dp + 2; }
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Row of block-major position p in memory.
+__device__ __forceinline__ long tok_row(const int* __restrict__ idx, long p) { return idx ? (long)idx[p] : p; }
+
+// Load a [rows x (DP/4 vec4)] tile of a token view into LDS as fp32.
+//   dst[r*ld + c]  r < rows_fill (rows >= rows_valid zero), c < DP (cols >= cols_valid zero)
+// base points at (b, token 0, h, d0).  `p0` is the block-major position of row 0.
+template <typename T, int DP, bool RELU>
+__device__ __forceinline__ void load_tile(float* __restrict__ dst, int ld, const T* __restrict__ base, long sn,
+                                          const int* __restrict__ idx, long p0, int rows_valid, int rows_fill,
+                                          int cols_valid, float eps, int tid, int nthreads) {
+    constexpr int CV = DP / 4;
+    for (int v = tid; v < rows_fill * CV; v += nthreads) {
+        const int r = v / CV, c = (v - r * CV) * 4;
+        f32x4 x = {0.f, 0.f, 0.f, 0.f};
+        if (r < rows_valid && c < cols_valid) {
+            x = Io<T>::ld4(base + tok_row(idx, p0 + r) * sn + c);
+            if (RELU) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) x[i] = fmaxf(x[i], 0.f) + eps;
+            }
+        }
+        float* d = dst + r * ld + c;
+        if ((ld & 3) == 0) {
+            *reinterpret_cast<f32x4*>(d) = x;
+        } else {
+            f32x2 lo = {x[0], x[1]}, hi = {x[2], x[3]};
+            *reinterpret_cast<f32x2*>(d) = lo;
+            *reinterpret_cast<f32x2*>(d + 2) = hi;
+        }
+    }
+}
+
+// Load a [rows x cols] fp32 matrix (row stride lds_src) into LDS, zero padded to [rows_fill x DP].
+template <int DP>
+__device__ __forceinline__ void load_mat_f32(float* __restrict__ dst, int ld, const float* __restrict__ src,
+                                             long src_ld, int rows_valid, int rows_fill, int cols_valid, int tid,
+                                             int nthreads, bool vec_ok) {
+    constexpr int CV = DP / 4;
+    for (int v = tid; v < rows_fill * CV; v += nthreads) {
+        const int r = v / CV, c = (v - r * CV) * 4;
+        f32x4 x = {0.f, 0.f, 0.f, 0.f};
+        if (r < rows_valid && c < cols_valid) {
+            const float* s = src + (long)r * src_ld + c;
+            if (vec_ok && c + 3 < cols_valid) {
+                x = *reinterpret_cast<const f32x4*>(s);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (c + i < cols_valid) x[i] = s[i];
+            }
+        }
+        float* d = dst + r * ld + c;
+        if ((ld & 3) == 0) {
+            *reinterpret_cast<f32x4*>(d) = x;
+        } else {
+            f32x2 lo = {x[0], x[1]}, hi = {x[2], x[3]};
+            *reinterpret_cast<f32x2*>(d) = lo;
+            *reinterpret_cast<f32x2*>(d + 2) = hi;
+        }
+    }
+}
+
+// Store a staged fp32 tile (ld multiple of 4) to a token view with dtype conversion.
+template <typename T, int DP>
+__device__ __forceinline__ void store_tile(T* __restrict__ base, long sn, const int* __restrict__ idx, long p0,
+                                           const float* __restrict__ src, int ld, int rows_valid, int cols_valid,
+                                           int tid, int nthreads) {
+    constexpr int CV = DP / 4;
+    for (int v = tid; v < rows_valid * CV; v += nthreads) {
+        const int r = v / CV, c = (v - r * CV) * 4;
+        if (c < cols_valid) {
+            f32x4 x = *reinterpret_cast<const f32x4*>(src + r * ld + c);
+            Io<T>::st4(base + tok_row(idx, p0 + r) * sn + c, x);
+        }
+    }
+}
+
+}  // namespace mhla

@@ -1,0 +1,141 @@
+// Per-head RMSNorm (x optional swish gate) -- the step right after the MHLA operator in the fla layer
+// (mhla_nlp/fla/modules/fused_norm_gate.py:77-99, used at mhla_nlp/fla/layers/mhla.py:351-355) and in
+// Wan's MHLA_Video_Uni (g_norm [x SiLU(g)], mhla_videogen/diffusion/model/wan/mhla_utils.py:357-362).
+// One wave per row (token, head); fp32 math; HBM-bound streaming kernel with 4-wide vector I/O.
+#pragma once
+#include "common.cuh"
+
+namespace mhla {
+
+struct NormArgs {
+    const void* x;
+    long ldx;
+    const void* g;
+    long ldg;
+    const float* w;
+    void* y;
+    long ldy;
+    float* rstd;
+    const void* dy;
+    long lddy;
+    void* dx;
+    long lddx;
+    void* dg;
+    long lddg;
+    float* dwp;
+    long rows;
+    int D;
+    float eps;
+};
+
+// NV: vec4 per lane (D <= 256 * NV)
+template <typename T, int NV, bool GATE>
+__global__ __launch_bounds__(256) void k_rmsnorm_gate_fwd(const NormArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long nw = (long)gridDim.x * 4;
+    for (long row = (long)blockIdx.x * 4 + wave; row < a.rows; row += nw) {
+        const T* xr = (const T*)a.x + row * a.ldx;
+        f32x4 xv[NV];
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (lane + 64 * i) * 4;
+            xv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (c < a.D) xv[i] = Io<T>::ld4(xr + c);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) ss += xv[i][t] * xv[i][t];
+        }
+        ss = wave_sum(ss);
+        const float rstd = 1.f / sqrtf(ss / (float)a.D + a.eps);
+        if (a.rstd && lane == 0) a.rstd[row] = rstd;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (lane + 64 * i) * 4;
+            if (c < a.D) {
+                f32x4 y = xv[i] * rstd;
+                if (a.w) y *= *reinterpret_cast<const f32x4*>(a.w + c);
+                if (GATE) {
+                    f32x4 gv = Io<T>::ld4((const T*)a.g + row * a.ldg + c);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) y[t] *= gv[t] / (1.f + __expf(-gv[t]));
+                }
+                Io<T>::st4((T*)a.y + row * a.ldy + c, y);
+            }
+        }
+    }
+}
+
+template <typename T, int NV, bool GATE>
+__global__ __launch_bounds__(256) void k_rmsnorm_gate_bwd(const NormArgs a) {
+    __shared__ float red[4][NV * 256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long nw = (long)gridDim.x * 4;
+    f32x4 dwacc[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) dwacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (long row = (long)blockIdx.x * 4 + wave; row < a.rows; row += nw) {
+        f32x4 xv[NV], uv[NV], sv[NV], dyv[NV], gv[NV];
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (lane + 64 * i) * 4;
+            xv[i] = dyv[i] = gv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (c < a.D) {
+                xv[i] = Io<T>::ld4((const T*)a.x + row * a.ldx + c);
+                dyv[i] = Io<T>::ld4((const T*)a.dy + row * a.lddy + c);
+                if (GATE) gv[i] = Io<T>::ld4((const T*)a.g + row * a.ldg + c);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) ss += xv[i][t] * xv[i][t];
+        }
+        ss = wave_sum(ss);
+        const float rstd = 1.f / sqrtf(ss / (float)a.D + a.eps);
+        float dot = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (lane + 64 * i) * 4;
+            f32x4 w = {1.f, 1.f, 1.f, 1.f};
+            if (a.w && c < a.D) w = *reinterpret_cast<const f32x4*>(a.w + c);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                float s = 1.f;
+                if (GATE) s = gv[i][t] / (1.f + __expf(-gv[i][t]));
+                sv[i][t] = s;
+                const float xhat = xv[i][t] * rstd;
+                uv[i][t] = dyv[i][t] * w[t] * s;
+                dot += uv[i][t] * xhat;
+                dwacc[i][t] += dyv[i][t] * xhat * s;
+            }
+        }
+        dot = wave_sum(dot) / (float)a.D;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (lane + 64 * i) * 4;
+            if (c < a.D) {
+                f32x4 dx, dg;
+                f32x4 w = {1.f, 1.f, 1.f, 1.f};
+                if (a.w) w = *reinterpret_cast<const f32x4*>(a.w + c);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float xhat = xv[i][t] * rstd;
+                    dx[t] = rstd * (uv[i][t] - xhat * dot);
+                    if (GATE) {
+                        const float sg = 1.f / (1.f + __expf(-gv[i][t]));
+                        dg[t] = dyv[i][t] * xhat * w[t] * sg * (1.f + gv[i][t] * (1.f - sg));
+                    }
+                }
+                Io<T>::st4((T*)a.dx + row * a.lddx + c, dx);
+                if (GATE) Io<T>::st4((T*)a.dg + row * a.lddg + c, dg);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) red[wave][(lane + 64 * i) * 4 + t] = dwacc[i][t];
+    __syncthreads();
+    for (int c = threadIdx.x; c < a.D; c += 256)
+        a.dwp[(long)blockIdx.x * a.D + c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+}
+
+}  // namespace mhla

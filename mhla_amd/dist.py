@@ -1,0 +1,65 @@
+"""Multi-GPU harness for the operator bench: one process per GPU, batch sharded across ranks
+(the operator is independent per (batch, head)), no data-path collective.  The only
+exchange a data-parallel step has on this path is the all-reduce of the mixing-weight gradient dW
+(an ordinary parameter gradient that DDP would all-reduce) -- issued here with torch.distributed
+("nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests)."""
+import os
+import time
+from typing import Callable, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
+    """(rank, local_rank, world).  Initialises the default process group when WORLD_SIZE > 1."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local, world
+
+
+def shard_batch(global_batch: int, rank: int, world: int) -> Tuple[int, int]:
+    """[start, stop) of this rank's samples; remainders go to the first ranks."""
+    base, rem = divmod(global_batch, world)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def allreduce_mean_(t: torch.Tensor) -> torch.Tensor:
+    """In-place mean over ranks (what DDP does to parameter gradients)."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        t.div_(dist.get_world_size())
+    return t
+
+
+def timed_steps(step: Callable[[], None], steps: int, warmup: int, sync: Callable[[], None]) -> float:
+    """W untimed warm-up steps, then exactly K steps bracketed by barrier + device sync on both sides.
+    Returns the MAX over ranks of the elapsed seconds."""
+    for _ in range(warmup):
+        step()
+    sync()
+    if dist.is_initialized():
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync()
+    if dist.is_initialized():
+        dist.barrier()
+    sync()
+    el = time.perf_counter() - t0
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dev = "cuda" if (torch.cuda.is_available() and dist.get_backend() == "nccl") else "cpu"
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    return el

@@ -1,0 +1,182 @@
+"""Drop-in for the fla attention layer `MHLA` (mhla_nlp/fla/layers/mhla.py:29-365).
+
+Same constructor, `forward(hidden_states, attention_mask, past_key_values, use_cache,
+output_attentions, **kw) -> (o, None, past_key_values)` and parameter names
+(`q_proj/k_proj/v_proj/g_proj/o_proj.weight`, `mixing_matrix [32,32,1,1,1,1]`,
+`g_norm_swish_gate.weight`).  The causal operator and the per-head RMSNorm x swish gate run as HIP
+kernels; rotary is plain tensor math (NeoX half rotation, rotary.py:20-32) -- no Triton.
+
+Deviations, all documented in SURVEY.md: sequences of <= 64 tokens use the single-chunk case of the
+chunk operator (the reference's token-recurrent form equals it only on the first chunk and ignores
+its initial state); `use_short_conv=True` is not supported (the reference's ShortConvolution is a
+separate fla module outside the MHLA path).
+"""
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from ..ops import mhla_causal, rmsnorm_gate
+from ..weights import causal_mixing_init
+
+
+class FusedRMSNormGated(nn.Module):
+    """Parameter holder + HIP kernel call (fused_norm_gate.py:997-1058)."""
+
+    def __init__(self, hidden_size, elementwise_affine=True, eps=1e-5, activation="swish"):
+        super().__init__()
+        if activation not in ("swish", "silu"):
+            raise ValueError(f"Unsupported activation: {activation}")
+        self.hidden_size = hidden_size
+        self.eps = eps
+        self.activation = activation
+        if elementwise_affine:
+            self.weight = nn.Parameter(torch.ones(hidden_size))
+        else:
+            self.register_parameter("weight", None)
+        self.register_parameter("bias", None)
+
+    def forward(self, x, g):
+        return rmsnorm_gate(x, g, self.weight, self.eps)
+
+
+class RotaryEmbedding(nn.Module):
+    """NeoX-style rotary, non-interleaved, base 10000 (rotary.py:330-431): fp32 inv_freq, cos/sin cached
+    in the activation dtype."""
+
+    def __init__(self, dim: int, base: float = 10000.0):
+        super().__init__()
+        self.dim = dim
+        self.base = base
+        self._cache: Optional[Tuple] = None
+
+    def _tables(self, seqlen: int, device, dtype):
+        c = self._cache
+        if c is None or c[0] < seqlen or c[1] != device or c[2] != dtype:
+            inv_freq = 1.0 / (self.base ** (torch.arange(0, self.dim, 2, device=device, dtype=torch.float32) / self.dim))
+            t = torch.arange(seqlen, device=device, dtype=torch.float32)
+            fr = torch.outer(t, inv_freq)
+            c = (seqlen, device, dtype, torch.cos(fr).to(dtype), torch.sin(fr).to(dtype))
+            self._cache = c
+        return c[3], c[4]
+
+    def forward(self, q, k, seqlen_offset: int = 0, max_seqlen: Optional[int] = None, cu_seqlens=None):
+        T = q.shape[1]
+        cos, sin = self._tables(max(max_seqlen or 0, T + seqlen_offset), q.device, q.dtype)
+        cos = cos[seqlen_offset:seqlen_offset + T][None, :, None, :]
+        sin = sin[seqlen_offset:seqlen_offset + T][None, :, None, :]
+
+        def rot(x):
+            x1, x2 = x.chunk(2, dim=-1)
+            return torch.cat((x1 * cos - x2 * sin, x2 * cos + x1 * sin), dim=-1)
+
+        return rot(q), rot(k)
+
+
+def _elu1(x):
+    return F.elu(x) + 1
+
+
+class MHLA(nn.Module):
+    def __init__(self, mode: str = "chunk", hidden_size: int = 1024, expand_k: float = 0.5, expand_v: float = 1.0,
+                 num_heads: int = 4, num_kv_heads: Optional[int] = None, feature_map: Optional[str] = None,
+                 use_short_conv: bool = False, conv_size: int = 4, conv_bias: bool = False,
+                 use_output_gate: bool = True, gate_fn: str = "swish", elementwise_affine: Optional[bool] = True,
+                 norm_eps: float = 1e-5, gate_logit_normalizer: int = 16, gate_low_rank_dim: int = 16,
+                 clamp_min: Optional[float] = None, fuse_norm: bool = True, layer_idx: int = None):
+        super().__init__()
+        self.mode = mode
+        self.hidden_size = hidden_size
+        self.expand_k = expand_k
+        self.expand_v = expand_v
+        self.num_heads = num_heads
+        self.num_kv_heads = num_kv_heads if num_kv_heads is not None else num_heads
+        self.num_kv_groups = self.num_heads // self.num_kv_heads
+        self.key_dim = int(hidden_size * expand_k)
+        self.value_dim = int(hidden_size * expand_v)
+        self.key_dim_per_group = self.key_dim // self.num_kv_groups
+        self.value_dim_per_group = self.value_dim // self.num_kv_groups
+        self.clamp_min = clamp_min
+        self.layer_idx = layer_idx
+        self.use_output_gate = use_output_gate
+        assert mode in ["chunk", "fused_recurrent", "fused_chunk"], f"Not supported mode `{mode}`."
+        assert self.key_dim % num_heads == 0, f"key dim must be divisible by num_heads of {num_heads}"
+        assert self.value_dim % num_heads == 0, f"value dim must be divisible by num_heads of {num_heads}"
+        self.head_k_dim = self.key_dim // num_heads
+        self.head_v_dim = self.value_dim // num_heads
+
+        if feature_map == "relu":
+            self.feature_map_q = self.feature_map_k = nn.ReLU()
+        elif feature_map == "identity":
+            self.feature_map_q = self.feature_map_k = nn.Identity()
+        elif feature_map == "elu":
+            self.feature_map_q = self.feature_map_k = _elu1
+        else:
+            raise NotImplementedError(f"Not supported feature map `{feature_map}`.")
+        if use_short_conv:
+            raise NotImplementedError("use_short_conv=True is outside the MHLA path built here")
+        self.use_short_conv = False
+
+        self.q_proj = nn.Linear(hidden_size, self.key_dim, bias=False)
+        self.k_proj = nn.Linear(hidden_size, self.key_dim_per_group, bias=False)
+        self.v_proj = nn.Linear(hidden_size, self.value_dim_per_group, bias=False)
+        if self.use_output_gate:
+            self.g_proj = nn.Linear(hidden_size, self.value_dim, bias=False)
+        self.mixing_matrix = nn.Parameter(causal_mixing_init(32))           # layers/mhla.py:196-200
+        self.o_proj = nn.Linear(self.value_dim, hidden_size, bias=False)
+        self.fuse_norm_and_gate = gate_fn == "swish" and fuse_norm and use_output_gate
+        if self.fuse_norm_and_gate:
+            self.g_norm_swish_gate = FusedRMSNormGated(self.head_v_dim, elementwise_affine, norm_eps)
+        else:
+            self.g_norm = FusedRMSNormGated(self.head_v_dim, elementwise_affine, norm_eps)
+            self.gate_fn = {"swish": F.silu, "silu": F.silu, "sigmoid": torch.sigmoid, "relu": F.relu,
+                            "gelu": F.gelu}[gate_fn]
+        self.gate_logit_normalizer = gate_logit_normalizer
+        assert self.head_k_dim <= 256, "head_k_dim must be less than or equal to 256"
+        self.rotary = RotaryEmbedding(dim=self.head_k_dim)
+
+    def forward(self, hidden_states: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
+                past_key_values=None, use_cache: Optional[bool] = False, output_attentions: Optional[bool] = False,
+                **kwargs: Dict):
+        # clamp + tril of the mixing weights at the start of every forward, on .data (layers/mhla.py:237)
+        self.mixing_matrix.data = torch.clamp(self.mixing_matrix.data, 1e-5, 1).tril()
+        if attention_mask is not None:
+            assert len(attention_mask.shape) == 2, (
+                "Expected attention_mask as a 0-1 matrix with shape [batch_size, seq_len] for padding purposes "
+                "(0 indicating padding). Arbitrary attention masks of shape [batch_size, seq_len, seq_len] are not allowed.")
+        batch_size, q_len, _ = hidden_states.shape
+        indices = None
+        if attention_mask is not None:                                       # layers/mhla.py:253-256
+            indices = torch.nonzero(attention_mask[:, -q_len:].flatten(), as_tuple=False).flatten()
+            hidden_states = hidden_states.reshape(batch_size * q_len, -1).index_select(0, indices).unsqueeze(0)
+        B, T, _ = hidden_states.shape
+        q = self.q_proj(hidden_states).reshape(B, T, self.num_heads, self.head_k_dim)
+        k = self.k_proj(hidden_states)
+        v = self.v_proj(hidden_states)
+        if self.num_kv_groups > 1:                                           # :290-292
+            k = k.reshape(B, T, self.num_kv_heads, 1, self.head_k_dim).expand(-1, -1, -1, self.num_kv_groups, -1)
+            v = v.reshape(B, T, self.num_kv_heads, 1, self.head_v_dim).expand(-1, -1, -1, self.num_kv_groups, -1)
+        k = k.reshape(B, T, self.num_heads, self.head_k_dim)
+        v = v.reshape(B, T, self.num_heads, self.head_v_dim)
+        q, k = self.feature_map_q(q), self.feature_map_k(k)                  # :297-299
+        seqlen_offset = 0
+        if past_key_values is not None and hasattr(past_key_values, "get_seq_length"):
+            seqlen_offset = past_key_values.get_seq_length(self.layer_idx)
+        q, k = self.rotary(q, k, seqlen_offset=seqlen_offset)                # :311
+        o = mhla_causal(q, k, v, self.mixing_matrix)                         # :318-337 (T <= 64: single chunk)
+        if self.use_output_gate:
+            g = self.g_proj(hidden_states)
+            if self.fuse_norm_and_gate:
+                o = self.g_norm_swish_gate(o, g.reshape(B, T, self.num_heads, self.head_v_dim))   # :351-355
+                o = o.reshape(B, T, self.value_dim)
+            else:
+                o = self.g_norm(o, None).reshape(B, T, self.value_dim) * self.gate_fn(g)
+        else:
+            o = self.g_norm(o, None).reshape(B, T, self.value_dim)
+        o = self.o_proj(o)
+        if indices is not None:                                              # pad_input, :362-363
+            full = o.new_zeros(batch_size * q_len, o.shape[-1])
+            full.index_copy_(0, indices, o.squeeze(0))
+            o = full.reshape(batch_size, q_len, -1)
+        return o, None, past_key_values

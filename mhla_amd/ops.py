@@ -1,0 +1,271 @@
+"""Operator-level API: torch.autograd Functions over the C ABI (libmhla_hip.so).
+
+PyTorch is plumbing here (device memory, streams, autograd graph); every FLOP of the operator
+runs in the hand-written HIP kernels.  There is no eager / CPU fallback: tensors must live on
+a ROCm device and the library must be built, otherwise these functions raise.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import NULL_VIEW, View
+
+_DTYPES = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16, torch.float16: _lib.F16}
+
+
+def _dtype_code(t: torch.Tensor) -> int:
+    try:
+        return _DTYPES[t.dtype]
+    except KeyError:
+        raise TypeError(f"mhla_amd: unsupported dtype {t.dtype} (float32 / bfloat16 / float16)") from None
+
+
+def _require_gpu(*ts: torch.Tensor):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "mhla_amd operators run only on a ROCm GPU through libmhla_hip.so; got a "
+                f"{t.device} tensor (there is no CPU fallback)")
+
+
+def _view(t: torch.Tensor) -> View:
+    """[B, N, H, D] tensor -> mhla_view (element strides; D must be contiguous)."""
+    if t.dim() != 4:
+        raise ValueError(f"expected a [B, N, H, D] tensor, got shape {tuple(t.shape)}")
+    if t.stride(3) != 1:
+        raise ValueError("last dim must be contiguous")
+    return View(t.data_ptr(), t.stride(0), t.stride(1), t.stride(2))
+
+
+def _strided_ok(t: torch.Tensor) -> bool:
+    esz = t.element_size()
+    return (t.dim() == 4 and t.stride(3) == 1 and all(s % 4 == 0 for s in t.stride()[:3])
+            and t.data_ptr() % (4 * esz) == 0)
+
+
+def _prep(t: torch.Tensor) -> torch.Tensor:
+    """Use the tensor in place when the kernels can address it, otherwise make it contiguous."""
+    return t if _strided_ok(t) else t.contiguous()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ws(nbytes: int, device) -> torch.Tensor:
+    return torch.empty(max(nbytes, 16) // 4 + 4, dtype=torch.float32, device=device)
+
+
+# ------------------------------------------------------------------------------------------
+# block-mixing MHLA (DiT / ViT / Wan)
+# ------------------------------------------------------------------------------------------
+class _BlockMix(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, W, q_den, k_den, block_index, eps, normalize, relu_eps):
+        lib = _lib.load()
+        _require_gpu(q, k, v, W, q_den, k_den, block_index)
+        B, N, H, D = q.shape
+        M = W.shape[0]
+        if N % M:
+            raise ValueError(f"N={N} tokens not divisible into M={M} blocks")
+        S = N // M
+        split = q_den is not None
+        if split and not normalize:
+            raise ValueError("q_den/k_den given but normalize=False")
+        q, k, v = _prep(q), _prep(k), _prep(v)
+        if split:
+            q_den, k_den = _prep(q_den), _prep(k_den)
+        Wf = W.detach().reshape(M, M).to(torch.float32).contiguous()
+        out = torch.empty((B, N, H, D), dtype=q.dtype, device=q.device)
+        ws = _ws(lib.mhla_blockmix_fwd_ws_bytes(B, H, M, S, D), q.device)
+        qv, kv = _view(q), _view(k)
+        if normalize:
+            qd, kd = (_view(q_den), _view(k_den)) if split else (qv, kv)
+        else:
+            qd, kd = NULL_VIEW, NULL_VIEW
+        flags = _lib.FLAG_RELU_EPS if relu_eps else 0
+        idx_ptr = block_index.data_ptr() if block_index is not None else None
+        rc = lib.mhla_blockmix_fwd(qv, kv, _view(v), qd, kd, Wf.data_ptr(), M, _view(out), idx_ptr,
+                                   ws.data_ptr(), ws.numel() * 4, B, H, M, S, D, _dtype_code(q), float(eps), flags,
+                                   _stream())
+        _lib.check(rc, "mhla_blockmix_fwd")
+        ctx.save_for_backward(q, k, v, Wf, out, q_den if split else None, k_den if split else None, block_index)
+        ctx.cfg = (float(eps), bool(normalize), bool(relu_eps), split, W.shape, W.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        q, k, v, Wf, out, q_den, k_den, block_index = ctx.saved_tensors
+        eps, normalize, relu_eps, split, w_shape, w_dtype = ctx.cfg
+        B, N, H, D = q.shape
+        M = Wf.shape[0]
+        S = N // M
+        dout = _prep(dout.to(q.dtype))
+        dq = torch.empty((B, N, H, D), dtype=q.dtype, device=q.device)
+        dk = torch.empty_like(dq)
+        dv = torch.empty_like(dq)
+        dW = torch.empty((M, M), dtype=torch.float32, device=q.device)
+        dqd = dkd = None
+        if split:
+            dqd, dkd = torch.empty_like(dq), torch.empty_like(dq)
+        ws = _ws(lib.mhla_blockmix_bwd_ws_bytes(B, H, M, S, D), q.device)
+        qv, kv = _view(q), _view(k)
+        if normalize:
+            qd, kd = (_view(q_den), _view(k_den)) if split else (qv, kv)
+        else:
+            qd, kd = NULL_VIEW, NULL_VIEW
+        flags = _lib.FLAG_RELU_EPS if relu_eps else 0
+        idx_ptr = block_index.data_ptr() if block_index is not None else None
+        rc = lib.mhla_blockmix_bwd(qv, kv, _view(v), qd, kd, Wf.data_ptr(), M, _view(out), _view(dout),
+                                   _view(dq), _view(dk), _view(dv),
+                                   _view(dqd) if split else NULL_VIEW, _view(dkd) if split else NULL_VIEW,
+                                   dW.data_ptr(), idx_ptr, ws.data_ptr(), ws.numel() * 4, B, H, M, S, D,
+                                   _dtype_code(q), eps, flags, _stream())
+        _lib.check(rc, "mhla_blockmix_bwd")
+        return dq, dk, dv, dW.reshape(w_shape).to(w_dtype), dqd, dkd, None, None, None, None
+
+
+def mhla_blockmix(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, W: torch.Tensor, *, eps: float = 1e-6,
+                  q_den: Optional[torch.Tensor] = None, k_den: Optional[torch.Tensor] = None,
+                  normalize: bool = True, block_index: Optional[torch.Tensor] = None,
+                  relu_eps: bool = False) -> torch.Tensor:
+    """Block-mixing MHLA operator (mhla_dit/mhla/mhla.py:262-268; wan/mhla_utils.py:331-341).
+
+    q, k, v : [B, N, H, D] token-major (any batch/token/head strides, e.g. views into a fused QKV
+              projection), tokens in block-major order -- or in any order with `block_index`
+              (int32[N]: block-major position -> token row).
+    W       : [M, M] (or the conv weight [M, M, 1, 1]); W[i, j] mixes block j's KV summary into block i.
+    q_den, k_den : optional separate pair for the normaliser (Wan: un-roped q, k).
+    normalize    : False skips the division (Wan `normalize_out=False`).
+    relu_eps     : apply relu(x)+eps to q and k inside the kernels (mhla.py:229-230) -- q, k are then
+                   the raw projections and receive the masked gradient.
+    Returns [B, N, H, D] contiguous, same dtype; differentiable w.r.t. q, k, v, W (and q_den, k_den).
+    """
+    if (q_den is None) != (k_den is None):
+        raise ValueError("q_den and k_den must be given together")
+    if block_index is not None and (block_index.dtype != torch.int32 or not block_index.is_contiguous()):
+        raise TypeError("block_index must be a contiguous int32 tensor")
+    return _BlockMix.apply(q, k, v, W, q_den, k_den, block_index, eps, normalize, relu_eps)
+
+
+# ------------------------------------------------------------------------------------------
+# causal chunk-mixing MHLA (fla)
+# ------------------------------------------------------------------------------------------
+class _Causal(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, mix, chunk_size, scale):
+        lib = _lib.load()
+        _require_gpu(q, k, v, mix)
+        B, T, H, K = q.shape
+        V = v.shape[-1]
+        n = (T + chunk_size - 1) // chunk_size
+        L = mix.shape[0]
+        if n > L:
+            raise IndexError(f"sequence of {T} tokens needs {n} chunks but mixing_matrix has only {L} rows")
+        q, k, v = _prep(q), _prep(k), _prep(v)
+        mixf = mix.detach().reshape(L, mix.shape[1]).to(torch.float32).contiguous()
+        out = torch.empty((B, T, H, V), dtype=q.dtype, device=q.device)
+        ws = _ws(lib.mhla_causal_fwd_ws_bytes(B, T, H, K, V, chunk_size), q.device)
+        rc = lib.mhla_causal_fwd(_view(q), _view(k), _view(v), mixf.data_ptr(), mixf.shape[1], _view(out),
+                                 ws.data_ptr(), ws.numel() * 4, B, T, H, K, V, chunk_size, float(scale),
+                                 _dtype_code(q), _stream())
+        _lib.check(rc, "mhla_causal_fwd")
+        ctx.save_for_backward(q, k, v, mixf)
+        ctx.cfg = (chunk_size, float(scale), mix.shape, mix.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        q, k, v, mixf = ctx.saved_tensors
+        chunk_size, scale, mix_shape, mix_dtype = ctx.cfg
+        B, T, H, K = q.shape
+        V = v.shape[-1]
+        dout = _prep(dout.to(q.dtype))
+        dq, dk, dv = torch.empty_like(q, memory_format=torch.contiguous_format), None, None
+        dk = torch.empty((B, T, H, K), dtype=q.dtype, device=q.device)
+        dv = torch.empty((B, T, H, V), dtype=q.dtype, device=q.device)
+        dq = torch.empty((B, T, H, K), dtype=q.dtype, device=q.device)
+        dmix = torch.zeros(mixf.shape, dtype=torch.float32, device=q.device)
+        ws = _ws(lib.mhla_causal_bwd_ws_bytes(B, T, H, K, V, chunk_size), q.device)
+        rc = lib.mhla_causal_bwd(_view(q), _view(k), _view(v), mixf.data_ptr(), mixf.shape[1], _view(dout),
+                                 _view(dq), _view(dk), _view(dv), dmix.data_ptr(), dmix.shape[1],
+                                 ws.data_ptr(), ws.numel() * 4, B, T, H, K, V, chunk_size, scale, _dtype_code(q),
+                                 _stream())
+        _lib.check(rc, "mhla_causal_bwd")
+        return dq, dk, dv, dmix.reshape(mix_shape).to(mix_dtype), None, None
+
+
+def mhla_causal(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mixing_matrix: torch.Tensor,
+                chunk_size: int = 64, scale: Optional[float] = None) -> torch.Tensor:
+    """Causal chunk-mixing MHLA operator (naive_chunk_simple_mhla_fixed,
+    mhla_nlp/fla/ops/mhla/naive.py:10-83).  q, k: [B, T, H, K]; v: [B, T, H, V];
+    mixing_matrix: [L, L] or [L, L, 1, 1, 1, 1], L >= ceil(T / chunk_size).  fp32 compute, output in
+    the dtype of q; `scale` defaults to K**-0.5 as in the reference (naive.py:42)."""
+    if q.dim() != 4 or v.dim() != 4:
+        raise ValueError("q, k: [B, T, H, K], v: [B, T, H, V]")
+    if scale is None:
+        scale = q.shape[-1] ** -0.5
+    return _Causal.apply(q, k, v, mixing_matrix, int(chunk_size), scale)
+
+
+def naive_chunk_simple_mhla_fixed(q, k, v, mixing_matrix, output_final_state: bool = False, chunk_size: int = 64,
+                                  *args, **kwargs):
+    """Drop-in for the reference op function of the same name (naive.py:11): same arguments,
+    returns only `o` (the reference discards the state, naive.py:80)."""
+    return mhla_causal(q, k, v, mixing_matrix, chunk_size)
+
+
+# ------------------------------------------------------------------------------------------
+# per-head RMSNorm x swish gate
+# ------------------------------------------------------------------------------------------
+class _RmsNormGate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, g, weight, eps):
+        lib = _lib.load()
+        _require_gpu(x, g, weight)
+        D = x.shape[-1]
+        xc = x.contiguous()
+        gc = g.contiguous().to(x.dtype) if g is not None else None
+        wf = weight.detach().to(torch.float32).contiguous() if weight is not None else None
+        rows = xc.numel() // D
+        y = torch.empty_like(xc)
+        rc = lib.mhla_rmsnorm_gate_fwd(xc.data_ptr(), D, gc.data_ptr() if gc is not None else None, D,
+                                       wf.data_ptr() if wf is not None else None, y.data_ptr(), D, None, rows, D,
+                                       float(eps), _dtype_code(xc), _stream())
+        _lib.check(rc, "mhla_rmsnorm_gate_fwd")
+        ctx.save_for_backward(xc, gc, wf)
+        ctx.cfg = (float(eps), weight.dtype if weight is not None else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        xc, gc, wf = ctx.saved_tensors
+        eps, wdtype = ctx.cfg
+        D = xc.shape[-1]
+        rows = xc.numel() // D
+        dyc = dy.contiguous().to(xc.dtype)
+        dx = torch.empty_like(xc)
+        dg = torch.empty_like(xc) if gc is not None else None
+        nrows = lib.mhla_rmsnorm_gate_dw_rows(rows)
+        dwp = torch.empty((nrows, D), dtype=torch.float32, device=xc.device)
+        rc = lib.mhla_rmsnorm_gate_bwd(xc.data_ptr(), D, gc.data_ptr() if gc is not None else None, D,
+                                       wf.data_ptr() if wf is not None else None, dyc.data_ptr(), D, dx.data_ptr(), D,
+                                       dg.data_ptr() if dg is not None else None, D, dwp.data_ptr(), rows, D, eps,
+                                       _dtype_code(xc), _stream())
+        _lib.check(rc, "mhla_rmsnorm_gate_bwd")
+        dw = dwp.sum(0).to(wdtype) if wf is not None else None
+        return dx, dg, dw, None
+
+
+def rmsnorm_gate(x: torch.Tensor, g: Optional[torch.Tensor], weight: Optional[torch.Tensor],
+                 eps: float = 1e-5) -> torch.Tensor:
+    """y = x * rsqrt(mean(x^2, -1) + eps) * weight [* g * sigmoid(g)] over the last dim (<= 512).
+    FusedRMSNormGated math (mhla_nlp/fla/modules/fused_norm_gate.py:77-99); with g=None it is Wan's
+    per-head g_norm (wan/model.py:181-196)."""
+    return _RmsNormGate.apply(x, g, weight, eps)

@@ -1,0 +1,49 @@
+"""Shared helpers for the -m gpu parity tests: seeded inputs and oracle calls."""
+import torch
+
+from conftest import rel_err, rms_ratio
+from oracle import mhla_oracle as orc
+
+DEV = "cuda"
+# north_star: outputs within 1e-3 rel-err (max|a-b| / max|b|) of the reference in fp32-accumulate,
+# fp32-output mode.  bf16 / fp16 OUTPUT adds one rounding of the result (2^-9 / 2^-11 elementwise).
+TOL = {torch.float32: 1e-3, torch.bfloat16: 6e-3, torch.float16: 2e-3}
+GTOL = {torch.float32: 1e-3, torch.bfloat16: 1.2e-2, torch.float16: 3e-3}
+
+
+def make_blockmix_inputs(B, H, M, S, D, dtype, seed=1234, w="linear", split=False):
+    g = torch.Generator().manual_seed(seed)
+    N = M * S
+    q = (torch.relu(torch.randn(B, N, H, D, generator=g)) + 1e-6).to(dtype)
+    k = (torch.relu(torch.randn(B, N, H, D, generator=g)) + 1e-6).to(dtype)
+    v = torch.randn(B, N, H, D, generator=g).to(dtype)
+    do = torch.randn(B, N, H, D, generator=g).to(dtype)
+    if w == "rand":
+        W = torch.rand(M, M, generator=g)
+    else:
+        side = int(round(M ** 0.5))
+        layout = (side, side) if side * side == M else (M,)
+        W = orc.block_distance_weights(layout, "linear") if M > 1 else torch.ones(1, 1)
+    qd = kd = None
+    if split:   # numerator pair with signs (like roped q, k), positive denominator pair
+        qd, kd = q, k
+        q = (q.float() * torch.sign(torch.randn(B, N, H, D, generator=g))).to(dtype)
+        k = (k.float() * torch.sign(torch.randn(B, N, H, D, generator=g))).to(dtype)
+    return q, k, v, W, do, qd, kd
+
+
+def oracle_blockmix(q, k, v, W, do, qd, kd, eps, normalize):
+    f = lambda t: None if t is None else t.float()
+    out = orc.blockmix_fwd(f(q), f(k), f(v), W, eps, f(qd), f(kd), normalize)
+    grads = orc.blockmix_bwd(f(q), f(k), f(v), W, f(do), eps, f(qd), f(kd), normalize)
+    return out, grads
+
+
+def to_dev(*ts):
+    return [None if t is None else t.to(DEV) for t in ts]
+
+
+def check(name, got, want, tol):
+    e, r = rel_err(got.float().cpu(), want.float()), rms_ratio(got.float().cpu(), want.float())
+    assert e < tol, f"{name}: rel_err {e:.3e} (rms ratio {r:.3e}) exceeds {tol:.1e}"
+    return e

@@ -1,0 +1,176 @@
+"""GPU parity: block-mixing MHLA operator (HIP, through the C ABI) vs the CPU oracle and the golden fixtures."""
+import pytest
+import torch
+
+from conftest import load_golden
+from gpu_util import DEV, GTOL, TOL, check, make_blockmix_inputs, oracle_blockmix, to_dev
+from oracle import mhla_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def run_case(B, H, M, S, D, dtype, normalize=True, split=False, w="linear", idx=None, seed=1234):
+    import mhla_amd
+    q, k, v, W, do, qd, kd = make_blockmix_inputs(B, H, M, S, D, dtype, seed, w, split)
+    want, wg = oracle_blockmix(q, k, v, W, do, qd, kd, 1e-6, normalize)
+    if idx is not None:   # scatter tokens so that block-major position p lives at row idx[p]
+        def scat(t):
+            if t is None:
+                return None
+            r = torch.empty_like(t)
+            r[:, idx.long()] = t
+            return r
+        q, k, v, do, qd, kd = (scat(t) for t in (q, k, v, do, qd, kd))
+    dq_, dk_, dv_, dW_, ddo, dqd, dkd = to_dev(q, k, v, W, do, qd, kd)
+    leaves = [t.requires_grad_(True) for t in (dq_, dk_, dv_, dW_)]
+    if split:
+        dqd.requires_grad_(True)
+        dkd.requires_grad_(True)
+    out = mhla_amd.mhla_blockmix(dq_, dk_, dv_, dW_, eps=1e-6, q_den=dqd, k_den=dkd, normalize=normalize,
+                                 block_index=None if idx is None else idx.to(DEV))
+    out.backward(ddo)
+    torch.cuda.synchronize()
+
+    def gather(t):
+        return t if idx is None else t[:, idx.long().to(t.device)]
+    check("out", gather(out), want, TOL[dtype])
+    check("dq", gather(leaves[0].grad), wg["dq"], GTOL[dtype])
+    check("dk", gather(leaves[1].grad), wg["dk"], GTOL[dtype])
+    check("dv", gather(leaves[2].grad), wg["dv"], GTOL[dtype])
+    check("dW", leaves[3].grad, wg["dW"], GTOL[dtype])
+    if split and normalize:
+        check("dq_den", gather(dqd.grad), wg["dq_den"], GTOL[dtype])
+        check("dk_den", gather(dkd.grad), wg["dk_den"], GTOL[dtype])
+
+
+@pytest.mark.parametrize("tag", ["dit_a", "dit_b", "vit_a"])
+def test_golden_op(tag):
+    import mhla_amd
+    g = load_golden("blockmix2d_" + tag)
+    q, k, v, W, do = (g[n].to(DEV) for n in ("q", "k", "v", "W", "dout"))
+    for t in (q, k, v, W):
+        t.requires_grad_(True)
+    out = mhla_amd.mhla_blockmix(q, k, v, W, eps=1e-6)
+    out.backward(do)
+    check("out", out, g["out"], 1e-4)
+    for n, t in (("dq", q), ("dk", k), ("dv", v), ("dW", W)):
+        check(n, t.grad, g[n], 2e-4)
+
+
+@pytest.mark.parametrize("M,S,D", [(16, 16, 64), (16, 16, 72), (4, 49, 64), (9, 49, 72), (64, 64, 64), (1, 64, 32),
+                                   (16, 256, 64), (150, 14, 128), (6, 210, 128), (25, 20, 96), (4, 16, 16)])
+def test_shapes_fp32(M, S, D):
+    run_case(2, 2, M, S, D, torch.float32, w="rand")
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,S,D", [(16, 16, 72), (64, 64, 64), (6, 210, 128)])
+def test_shapes_lowp(M, S, D, dtype):
+    run_case(2, 2, M, S, D, dtype)
+
+
+@pytest.mark.parametrize("normalize,split", [(False, False), (True, True)])
+@pytest.mark.parametrize("M,S,D", [(16, 16, 64), (24, 8, 128)])
+def test_wan_modes(M, S, D, normalize, split):
+    run_case(1, 3, M, S, D, torch.float32, normalize=normalize, split=split, w="rand")
+
+
+def test_block_index_gather():
+    idx = orc.block_index_3d((4, 6, 8), (2, 3, 4)).int()
+    run_case(1, 2, 24, 8, 64, torch.float32, split=True, idx=idx)
+    idx2 = orc.block_index_2d(4, 4).int()
+    run_case(2, 1, 16, 16, 72, torch.bfloat16, idx=idx2)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_golden_wan_op(tag):
+    import mhla_amd
+    g = load_golden("wan_" + tag)
+    B, H, D, M, S, fb, hb, wb, F_, H_, W_, normalize, gated = [int(x) for x in g["meta"]]
+    idx = orc.block_index_3d((F_, H_, W_), (fb, hb, wb)).int().to(DEV)
+    qr, kr, v, q, k, W, do = (g[n].to(DEV).requires_grad_(True) for n in ("q_rope", "k_rope", "v", "q", "k", "W", "dout"))
+    if normalize:
+        out = mhla_amd.mhla_blockmix(qr, kr, v, W, eps=1e-6, q_den=q, k_den=k, block_index=idx)
+    else:
+        out = mhla_amd.mhla_blockmix(qr, kr, v, W, eps=1e-6, normalize=False, block_index=idx)
+    out.backward(do.detach())
+    check("out", out, g["out"], 1e-4)
+    check("dq_rope", qr.grad, g["dq_rope"], 2e-4)
+    check("dk_rope", kr.grad, g["dk_rope"], 2e-4)
+    check("dv", v.grad, g["dv"], 2e-4)
+    check("dW", W.grad, g["dW"], 2e-4)
+
+
+def test_fused_qkv_views_and_relu_prologue():
+    """q, k, v read in place from a fused [B, N, 3, H, D] projection output; relu(x)+eps applied in-kernel."""
+    import mhla_amd
+    B, N, H, D, M = 2, 256, 4, 72, 16
+    g = torch.Generator().manual_seed(7)
+    qkv = torch.randn(B, N, 3, H, D, generator=g)
+    W = orc.block_distance_weights((4, 4), "linear")
+    do = torch.randn(B, N, H, D, generator=g)
+    ref = qkv.clone().requires_grad_(True)
+    Wr = W.clone().requires_grad_(True)
+    o_ref = orc.blockmix_fwd(orc.relu_eps(ref[:, :, 0]), orc.relu_eps(ref[:, :, 1]), ref[:, :, 2], Wr, 1e-6)
+    (o_ref * do).sum().backward()
+    dev = qkv.to(DEV).requires_grad_(True)
+    Wd = W.to(DEV).requires_grad_(True)
+    out = mhla_amd.mhla_blockmix(dev[:, :, 0], dev[:, :, 1], dev[:, :, 2], Wd, eps=1e-6, relu_eps=True)
+    out.backward(do.to(DEV))
+    check("out", out, o_ref.detach(), 1e-4)
+    check("dqkv", dev.grad, ref.grad, 2e-4)
+    check("dW", Wd.grad, Wr.grad, 2e-4)
+
+
+def test_errors_fail_loudly():
+    import mhla_amd
+    q = torch.randn(1, 64, 2, 64, device=DEV)
+    W = torch.eye(4, device=DEV)
+    with pytest.raises(RuntimeError):
+        mhla_amd.mhla_blockmix(q.cpu(), q.cpu(), q.cpu(), W.cpu())            # no CPU fallback
+    with pytest.raises(ValueError):
+        mhla_amd.mhla_blockmix(q, q, q, torch.eye(5, device=DEV))             # N not divisible by M
+    big = torch.randn(1, 64, 2, 192, device=DEV)
+    with pytest.raises(RuntimeError, match="not supported"):
+        mhla_amd.mhla_blockmix(big, big, big, W)                              # D > 128
+    with pytest.raises(TypeError):
+        mhla_amd.mhla_blockmix(q.double(), q.double(), q.double(), W)
+
+
+def test_full_size_c2_properties_and_sampled_heads():
+    """BASELINE config C2 (B=8, N=4096, H=16, D=64, bf16, M=S=64): sampled (b, h) slices vs the oracle,
+    plus size-independent properties: linearity in v, and W = I decouples blocks."""
+    import mhla_amd
+    B, N, H, D, M = 8, 4096, 16, 64, 64
+    q, k, v, W, do, _, _ = make_blockmix_inputs(B, H, M, N // M, D, torch.bfloat16, seed=1234)
+    dq, dk, dv, dW, ddo = to_dev(q, k, v, W, do)
+    for t in (dq, dk, dv, dW):
+        t.requires_grad_(True)
+    out = mhla_amd.mhla_blockmix(dq, dk, dv, dW)
+    out.backward(ddo)
+    for (b, h) in [(0, 0), (3, 7), (7, 15)]:
+        sl = lambda t: t[b:b + 1, :, h:h + 1]
+        want, wg = oracle_blockmix(sl(q), sl(k), sl(v), W, sl(do), None, None, 1e-6, True)
+        check("out", sl(out), want, TOL[torch.bfloat16])
+        check("dq", sl(dq.grad), wg["dq"], GTOL[torch.bfloat16])
+        check("dk", sl(dk.grad), wg["dk"], GTOL[torch.bfloat16])
+        check("dv", sl(dv.grad), wg["dv"], GTOL[torch.bfloat16])
+    # linearity in v (fp32 so the property is tight)
+    qf, kf, vf = dq.detach().float(), dk.detach().float(), dv.detach().float()
+    v2 = torch.randn_like(vf)
+    o1 = mhla_amd.mhla_blockmix(qf, kf, vf, dW.detach())
+    o2 = mhla_amd.mhla_blockmix(qf, kf, v2, dW.detach())
+    o12 = mhla_amd.mhla_blockmix(qf, kf, vf + 2 * v2, dW.detach())
+    check("linearity", o12, (o1 + 2 * o2).cpu(), 1e-4)
+    # W = I: changing block 5's k, v must not change any other block's output
+    eye = torch.eye(M, device=DEV)
+    oa = mhla_amd.mhla_blockmix(qf, kf, vf, eye)
+    k2, v3 = kf.clone(), vf.clone()
+    S = N // M
+    k2[:, 5 * S:6 * S] += 1.0
+    v3[:, 5 * S:6 * S] *= -2.0
+    ob = mhla_amd.mhla_blockmix(qf, k2, v3, eye)
+    mask = torch.ones(N, dtype=torch.bool, device=DEV)
+    mask[5 * S:6 * S] = False
+    assert torch.equal(oa[:, mask], ob[:, mask])
+    assert not torch.equal(oa[:, ~mask], ob[:, ~mask])

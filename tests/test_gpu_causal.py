@@ -1,0 +1,113 @@
+"""GPU parity: causal chunk-mixing MHLA operator + per-head RMSNorm x gate vs oracle and golden fixtures."""
+import pytest
+import torch
+
+from conftest import load_golden
+from gpu_util import DEV, GTOL, TOL, check
+from oracle import mhla_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def causal_inputs(B, T, H, K, V, L, dtype, seed=1234, random_mix=True):
+    g = torch.Generator().manual_seed(seed)
+    q = (torch.relu(torch.randn(B, T, H, K, generator=g)) * torch.sign(torch.randn(B, T, H, K, generator=g))).to(dtype)
+    k = (torch.relu(torch.randn(B, T, H, K, generator=g)) * torch.sign(torch.randn(B, T, H, K, generator=g))).to(dtype)
+    v = torch.randn(B, T, H, V, generator=g).to(dtype)
+    do = torch.randn(B, T, H, V, generator=g).to(dtype)
+    mix = torch.tril(torch.rand(L, L, generator=g).clamp(1e-5, 1)) if random_mix else orc.causal_mixing_init(L)
+    return q, k, v, mix, do
+
+
+def run_causal(B, T, H, K, V, L, dtype, seed=1234):
+    import mhla_amd
+    q, k, v, mix, do = causal_inputs(B, T, H, K, V, L, dtype, seed)
+    want = orc.causal_fwd(q.float(), k.float(), v.float(), mix)
+    wg = orc.causal_bwd(q.float(), k.float(), v.float(), mix, do.float())
+    dq, dk, dv, dm = (t.to(DEV).requires_grad_(True) for t in (q, k, v, mix.view(L, L, 1, 1, 1, 1)))
+    out = mhla_amd.naive_chunk_simple_mhla_fixed(q=dq, k=dk, v=dv, mixing_matrix=dm)
+    assert out.dtype == dtype and out.shape == (B, T, H, V)
+    out.backward(do.to(DEV))
+    check("out", out, want, TOL[dtype])
+    check("dq", dq.grad, wg["dq"], GTOL[dtype])
+    check("dk", dk.grad, wg["dk"], GTOL[dtype])
+    check("dv", dv.grad, wg["dv"], GTOL[dtype])
+    check("dmix", dm.grad.reshape(L, L), wg["dmix"], GTOL[dtype])
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+def test_golden_causal(tag):
+    import mhla_amd
+    g = load_golden("causal_" + tag)
+    bf16 = tag == "d"
+    cast = (lambda t: t.bfloat16()) if bf16 else (lambda t: t)
+    q, k, v = (cast(g[n]).to(DEV).requires_grad_(True) for n in ("q", "k", "v"))
+    mix = g["mix"].to(DEV).requires_grad_(True)
+    out = mhla_amd.mhla_causal(q, k, v, mix)
+    out.backward(cast(g["dout"]).to(DEV))
+    tol = 1e-2 if bf16 else 1e-4
+    check("out", out, g["out"], tol)
+    for n, t in (("dq", q), ("dk", k), ("dv", v), ("dmix", mix)):
+        check(n, t.grad, g[n], 1.5e-2 if bf16 else 2e-4)
+
+
+@pytest.mark.parametrize("T,K,V", [(256, 64, 64), (200, 32, 16), (50, 16, 24), (64, 128, 256), (1000, 128, 128),
+                                   (129, 256, 512), (4096, 16, 16)])
+def test_causal_shapes_fp32(T, K, V):
+    run_causal(1 if K * V > 16384 else 2, T, 2, K, V, max(4, (T + 63) // 64), torch.float32)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_causal_lowp(dtype):
+    run_causal(2, 512, 4, 128, 256, 8, dtype)
+
+
+def test_causal_is_causal_and_recurrent_first_chunk():
+    """Future tokens never influence earlier outputs; with T <= 64 the op is the single-chunk
+    (token-recurrent) case."""
+    import mhla_amd
+    q, k, v, mix, _ = causal_inputs(1, 300, 2, 32, 32, 8, torch.float32)
+    dq, dk, dv, dm = (t.to(DEV) for t in (q, k, v, mix))
+    o1 = mhla_amd.mhla_causal(dq, dk, dv, dm)
+    k2, v2 = dk.clone(), dv.clone()
+    k2[:, 200:] = 7.0
+    v2[:, 200:] = -3.0
+    o2 = mhla_amd.mhla_causal(dq, k2, v2, dm)
+    assert torch.equal(o1[:, :200], o2[:, :200])
+    with pytest.raises(IndexError):
+        mhla_amd.mhla_causal(dq, dk, dv, dm[:4, :4])     # 300 tokens need 5 chunks
+
+
+@pytest.mark.parametrize("gate", [True, False])
+@pytest.mark.parametrize("D,dtype", [(256, torch.float32), (128, torch.bfloat16), (512, torch.float32), (24, torch.float32)])
+def test_rmsnorm_gate(D, dtype, gate):
+    import mhla_amd
+    g_ = torch.Generator().manual_seed(5)
+    x = torch.randn(3, 37, 4, D, generator=g_).to(dtype)
+    g = torch.randn(3, 37, 4, D, generator=g_).to(dtype) if gate else None
+    w = torch.rand(D, generator=g_) + 0.5
+    dy = torch.randn(3, 37, 4, D, generator=g_).to(dtype)
+    xr, wr = x.float().requires_grad_(True), w.clone().requires_grad_(True)
+    gr = g.float().requires_grad_(True) if gate else None
+    if gate:
+        yr = orc.rms_norm_swish_gate(xr, gr, wr, 1e-5)
+    else:
+        yr = xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + 1e-5) * wr
+    (yr * dy.float()).sum().backward()
+    xd, wd = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+    gd = g.to(DEV).requires_grad_(True) if gate else None
+    y = mhla_amd.rmsnorm_gate(xd, gd, wd, 1e-5)
+    y.backward(dy.to(DEV))
+    lo = dtype != torch.float32
+    check("y", y, yr.detach(), 8e-3 if lo else 1e-5)
+    check("dx", xd.grad, xr.grad, 2e-2 if lo else 1e-4)
+    check("dw", wd.grad, wr.grad, 2e-2 if lo else 1e-4)
+    if gate:
+        check("dg", gd.grad, gr.grad, 2e-2 if lo else 1e-4)
+
+
+def test_golden_fla_neighbours_gate():
+    import mhla_amd
+    g = load_golden("fla_neighbours")
+    y = mhla_amd.rmsnorm_gate(g["o"].to(DEV), g["g"].to(DEV), g["w"].to(DEV), 1e-5)
+    check("gated", y, g["gated"], 1e-5)

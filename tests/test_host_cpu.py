@@ -1,0 +1,165 @@
+"""CPU (-m "not gpu"): host logic, C-ABI surface, drop-in module contracts, and the world_size-2 gloo path."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from conftest import ROOT, load_golden
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    from mhla_amd import build as b, _lib
+    b.build()
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "mhla_hip.h")).read()
+    declared = set(re.findall(r"\b(mhla_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/mhla_hip.h but not exported"
+    assert lib.mhla_abi_version() == 1
+    # workspace sizing is pure host arithmetic: callable without a GPU
+    fwd = lib.mhla_blockmix_fwd_ws_bytes(8, 16, 64, 64, 64)
+    bwd = lib.mhla_blockmix_bwd_ws_bytes(8, 16, 64, 64, 64)
+    assert 0 < fwd < bwd
+    assert lib.mhla_causal_bwd_ws_bytes(1, 8192, 4, 128, 256, 64) > lib.mhla_causal_fwd_ws_bytes(1, 8192, 4, 128, 256, 64) > 0
+
+
+def test_argument_validation_without_gpu():
+    """Shape / alignment errors are reported by code + message before anything touches the device."""
+    from mhla_amd import _lib
+    lib = _lib.load()
+    V = _lib.View
+    bad = V(8, 64, 64, 64)          # misaligned pointer
+    ok = V(1 << 20, 64 * 16, 64, 64)
+    rc = lib.mhla_blockmix_fwd(bad, ok, ok, ok, ok, 1 << 20, 4, ok, None, 1 << 20, 1 << 30, 1, 1, 4, 16, 64, 0, 1e-6, 0, None)
+    assert rc == -22 and b"aligned" in lib.mhla_last_error()
+    rc = lib.mhla_blockmix_fwd(ok, ok, ok, ok, ok, 1 << 20, 4, ok, None, 1 << 20, 1 << 30, 1, 1, 4, 16, 192, 0, 1e-6, 0, None)
+    assert rc == -95
+    rc = lib.mhla_blockmix_fwd(ok, ok, ok, ok, ok, 1 << 20, 4, ok, None, 1 << 20, 16, 1, 1, 4, 16, 64, 0, 1e-6, 0, None)
+    assert rc == -22 and b"workspace" in lib.mhla_last_error()
+    rc = lib.mhla_causal_fwd(ok, ok, ok, 1 << 20, 4, ok, 1 << 20, 1 << 30, 1, 128, 1, 64, 64, 32, 0.125, 0, None)
+    assert rc == -95 and b"chunk" in lib.mhla_last_error()
+
+
+@pytest.mark.parametrize("tr", ["linear", "cos", "exp", "gaussian", "local"])
+def test_weight_init_matches_reference(tr):
+    from mhla_amd import block_distance_weights
+    g = load_golden("weight_init")
+    for key, layout in ((f"w2d_{tr}_16_16", (4, 4)), (f"w2d_{tr}_21_49", (3, 3)), (f"w2d_{tr}_16_4", (8, 8)),
+                        (f"w3d_{tr}_3_5_10", (3, 5, 10)), (f"w3d_{tr}_2_3_4", (2, 3, 4)), (f"w3d_{tr}_1_4_4", (1, 4, 4))):
+        w = block_distance_weights(layout, tr)
+        assert torch.allclose(w, g[key], atol=2e-6), key
+
+
+def test_block_index_maps_match_oracle():
+    from mhla_amd import block_index_2d, block_index_3d
+    from oracle import mhla_oracle as orc
+    assert torch.equal(block_index_2d(4, 4).long(), orc.block_index_2d(4, 4))
+    assert torch.equal(block_index_3d((3, 10, 20), (3, 5, 10)).long(), orc.block_index_3d((3, 10, 20), (3, 5, 10)))
+    with pytest.raises(ValueError):
+        block_index_3d((3, 10, 21), (3, 5, 10))
+
+
+def test_module_state_dicts_are_reference_compatible():
+    from mhla_amd import modules
+    for tag, cls, kw in (
+        ("dit_a", modules.MHLA4DiT, dict(heads=2, dim_head=32, block_size=16, embed_len=256, qkv_bias=True)),
+        ("vit_a", modules.MHLA_Normed_Torch, dict(heads=2, dim_head=64, window_size=16, embed_len=256, qk_norm=True)),
+    ):
+        g = load_golden("blockmix2d_" + tag)
+        sd = {k[3:]: v for k, v in g.items() if k.startswith("sd.")}
+        m = cls(kw["heads"] * kw["dim_head"], **kw)
+        assert set(m.state_dict()) == set(sd)
+        m.load_state_dict(sd, strict=True)
+    g = load_golden("wan_b")
+    sd = {k[3:]: v for k, v in g.items() if k.startswith("sd.")}
+    m = modules.MHLA_Video_Uni(64, num_heads=2, block_layout=(3, 5, 10), is_gated=True, normalize_out=False)
+    assert set(m.state_dict()) == set(sd)
+    f = modules.MHLA(hidden_size=256, num_heads=2, feature_map="relu")
+    assert set(f.state_dict()) == {"q_proj.weight", "k_proj.weight", "v_proj.weight", "g_proj.weight", "o_proj.weight",
+                                   "mixing_matrix", "g_norm_swish_gate.weight"}
+    assert f.mixing_matrix.shape == (32, 32, 1, 1, 1, 1)
+    from oracle import mhla_oracle as orc
+    assert torch.equal(f.mixing_matrix.detach().reshape(32, 32), orc.causal_mixing_init(32))
+
+
+def test_product_path_has_no_cpu_fallback():
+    import mhla_amd
+    from mhla_amd import modules
+    q = torch.randn(1, 64, 2, 64)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        mhla_amd.mhla_blockmix(q, q, q, torch.eye(4))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        mhla_amd.mhla_causal(q, q, q, torch.eye(4))
+    m = modules.MHLA4DiT(128, heads=2, block_size=16, embed_len=256)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.randn(1, 16, 16, 128))
+    # and nothing in the product package imports the oracle
+    pkg = os.path.join(ROOT, "mhla_amd")
+    for dp, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith(".py"):
+                src = open(os.path.join(dp, fn)).read()
+                assert "oracle" not in src.replace("no CPU", ""), f"{fn} mentions the oracle"
+
+
+def test_wan_rope_and_fla_rotary_host_math_match_golden():
+    from mhla_amd.modules import wan, fla
+    g = load_golden("wan_a")
+    B, H, D, M, S, fb, hb, wb, F_, H_, W_, normalize, gated = [int(x) for x in g["meta"]]
+    cos, sin = wan._rope_table(wan.wan_freqs(D), (F_, H_, W_), "cpu")
+    y = wan.rope_apply(g["q"], cos, sin)
+    assert (y - g["q_rope"]).abs().max() < 1e-5
+    gn = load_golden("fla_neighbours")
+    r = fla.RotaryEmbedding(32)
+    q, _ = r(gn["x"], gn["x"])
+    assert (q - gn["rot"]).abs().max() < 1e-6
+
+
+WORKER = r'''
+import os, sys, torch
+sys.path.insert(0, os.environ["MHLA_ROOT"])
+import torch.distributed as dist
+from mhla_amd import dist as mdist
+from oracle import mhla_oracle as orc
+rank, local, world = mdist.init_from_env("gloo")
+assert world == 2
+# global batch of 6 samples sharded over 2 ranks; per-rank dW (oracle stands in for the GPU op here:
+# this test covers the sharding + dW all-reduce + timing harness, not the kernels)
+g = torch.Generator().manual_seed(0)
+B, N, H, D, M = 6, 64, 2, 16, 4
+q = torch.relu(torch.randn(B, N, H, D, generator=g)) + 1e-6
+k = torch.relu(torch.randn(B, N, H, D, generator=g)) + 1e-6
+v = torch.randn(B, N, H, D, generator=g)
+do = torch.randn(B, N, H, D, generator=g)
+W = orc.block_distance_weights((2, 2), "linear")
+lo, hi = mdist.shard_batch(B, rank, world)
+assert (lo, hi) == ((0, 3) if rank == 0 else (3, 6))
+dW_local = orc.blockmix_bwd(q[lo:hi], k[lo:hi], v[lo:hi], W, do[lo:hi])["dW"]
+dW = mdist.allreduce_mean_(dW_local.clone())
+full = orc.blockmix_bwd(q, k, v, W, do)["dW"] / world
+assert torch.allclose(dW, full, rtol=1e-4, atol=1e-6), (dW - full).abs().max()
+calls = []
+el = mdist.timed_steps(lambda: calls.append(1), steps=4, warmup=2, sync=lambda: None)
+assert len(calls) == 6 and el >= 0
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_world_size_2_gloo_sharding_and_dw_allreduce(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MHLA_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29611", WORLD_SIZE="2", OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=180)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+    from mhla_amd.dist import shard_batch
+    assert [shard_batch(7, r, 3) for r in range(3)] == [(0, 3), (3, 5), (5, 7)]
