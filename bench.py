@@ -56,7 +56,8 @@ def cpu_baseline(a, budget_s=12.0):
     """The oracle (eager PyTorch restatement of the reference op sequence, fp32) timed on the host cores
     on a bounded sample: fwd+bwd over B_s = 1 sample of the same (N, H, D, M) workload."""
     from oracle import mhla_oracle as orc
-    torch.set_num_threads(os.cpu_count() or 1)
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    torch.set_num_threads(max(1, min(ncpu, 64)))
     g = torch.Generator().manual_seed(1234)
     Bs = 1
     shape = (Bs, a.N, a.H, a.D)

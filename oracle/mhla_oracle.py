@@ -464,7 +464,9 @@ def fla_layer_forward(sd: dict, x: torch.Tensor, heads: int, head_k: int, head_v
     """``MHLA.forward`` (fla layer, ``feature_map='relu'``, fused swish gate, no
     short conv, no cache) -- ``mhla_nlp/fla/layers/mhla.py:226-365``."""
     B, T, C = x.shape
-    mix = torch.clamp(sd["mixing_matrix"].reshape(sd["mixing_matrix"].shape[0], -1), 1e-5, 1).tril()  # :237
+    # :237 -- clamp(...).tril() on the [L, L, 1, 1, 1, 1] parameter: tril acts on the trailing 1x1 dims, a no-op;
+    # the op reads only j <= i anyway
+    mix = torch.clamp(sd["mixing_matrix"], 1e-5, 1).tril().reshape(sd["mixing_matrix"].shape[0], -1)
     q = F.linear(x, sd["q_proj.weight"]).reshape(B, T, heads, head_k)             # :281-295
     k = F.linear(x, sd["k_proj.weight"]).reshape(B, T, heads, head_k)
     v = F.linear(x, sd["v_proj.weight"]).reshape(B, T, heads, head_v)

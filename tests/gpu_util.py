@@ -43,7 +43,11 @@ def to_dev(*ts):
     return [None if t is None else t.to(DEV) for t in ts]
 
 
-def check(name, got, want, tol):
-    e, r = rel_err(got.float().cpu(), want.float()), rms_ratio(got.float().cpu(), want.float())
+def check(name, got, want, tol, atol=0.0):
+    """rel-err = max|got - want| / max|want| < tol (or max|got - want| < atol for ~zero references)."""
+    g, w = got.float().cpu(), want.float()
+    if atol and (g - w).abs().max().item() < atol:
+        return 0.0
+    e, r = rel_err(g, w), rms_ratio(g, w)
     assert e < tol, f"{name}: rel_err {e:.3e} (rms ratio {r:.3e}) exceeds {tol:.1e}"
     return e

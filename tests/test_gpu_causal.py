@@ -87,8 +87,8 @@ def test_rmsnorm_gate(D, dtype, gate):
     g = torch.randn(3, 37, 4, D, generator=g_).to(dtype) if gate else None
     w = torch.rand(D, generator=g_) + 0.5
     dy = torch.randn(3, 37, 4, D, generator=g_).to(dtype)
-    xr, wr = x.float().requires_grad_(True), w.clone().requires_grad_(True)
-    gr = g.float().requires_grad_(True) if gate else None
+    xr, wr = x.float().clone().requires_grad_(True), w.clone().requires_grad_(True)
+    gr = g.float().clone().requires_grad_(True) if gate else None
     if gate:
         yr = orc.rms_norm_swish_gate(xr, gr, wr, 1e-5)
     else:

@@ -80,9 +80,10 @@ def test_fla_layer_matches_oracle_restatement():
     check("o", o, want, 1e-4)
     o.sum().backward()
     assert m.mixing_matrix.grad is not None
-    # forward clamps + trils the mixing weights in place (layers/mhla.py:237)
+    # forward clamps the mixing weights in place on .data (layers/mhla.py:237); the reference's .tril() there
+    # acts on the trailing 1x1 dims of the [32,32,1,1,1,1] parameter, i.e. it is a no-op, reproduced as is
     mm = m.mixing_matrix.detach().reshape(32, 32)
-    assert torch.equal(mm, mm.tril()) and mm.diagonal().min() >= 1e-5
+    assert mm.min() >= 1e-5 and mm.max() <= 1
     # short sequences (T <= 64) and padded batches run too
     o2, _, _ = m(xd[:, :50])
     want2 = orc.fla_layer_forward(sd, x[:, :50], 2, 64, 128, norm_eps=1e-6)
