@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MHLA_ABI_VERSION 1
+#define MHLA_ABI_VERSION 2
 
 enum { MHLA_F32 = 0, MHLA_BF16 = 1, MHLA_F16 = 2 };
 
@@ -46,7 +46,8 @@ enum {
 };
 
 /* flags */
-#define MHLA_FLAG_RELU_EPS 1u /* apply relu(x)+eps to q,k while loading (mhla_dit/mhla/mhla.py:229-230) */
+#define MHLA_FLAG_RELU_EPS 1u      /* apply relu(x)+eps to q,k while loading (mhla_dit/mhla/mhla.py:229-230) */
+#define MHLA_FLAG_FORCE_GENERIC 2u /* testing aid: take the generic fp32-MFMA path even where the bf16 fast path applies */
 
 /* A token-major view [B, N, H, D]: element strides, D contiguous. */
 typedef struct {
@@ -70,9 +71,10 @@ int mhla_prof_report(char* buf, size_t cap);
 
 /* ---- block-mixing (non-causal) MHLA: DiT / ViT / Wan ------------------- */
 
-/* Bytes of fp32 workspace mhla_blockmix_fwd / _bwd need (bwd >= fwd). */
-size_t mhla_blockmix_fwd_ws_bytes(int B, int H, int M, int S, int D);
-size_t mhla_blockmix_bwd_ws_bytes(int B, int H, int M, int S, int D);
+/* Bytes of workspace mhla_blockmix_fwd / _bwd need for this problem (dtype: MHLA_F32/BF16/F16;
+ * split: 1 when q_den/k_den do not alias q_num/k_num). */
+size_t mhla_blockmix_fwd_ws_bytes(int B, int H, int M, int S, int D, int dtype, int split);
+size_t mhla_blockmix_bwd_ws_bytes(int B, int H, int M, int S, int D, int dtype, int split);
 
 /*
  * Forward.  Replaces mhla_dit/mhla/mhla.py:262-268 (identical:
@@ -95,8 +97,10 @@ int mhla_blockmix_fwd(mhla_view q_num, mhla_view k_num, mhla_view v,
 
 /*
  * Backward (autograd of the forward above; hand-derived).
- * Recomputes the block summaries (stateless: needs only the forward's inputs,
- * its output `out` and the upstream gradient `dout`).  dq_den/dk_den are
+ * Needs only the forward's inputs, its output `out` and the upstream gradient
+ * `dout`: the block summaries are recomputed -- unless the caller kept the
+ * forward's workspace and passes it as `fwd_ws` (same call arguments, contents
+ * untouched since mhla_blockmix_fwd returned; NULL = recompute).  dq_den/dk_den are
  * written only when q_den does not alias q_num; otherwise both parts are summed
  * into dq_num/dk_num.  dW is [M, M] fp32 (ld = M), overwritten (not
  * accumulated), reduced over (b, h) in a fixed order: deterministic.
@@ -107,6 +111,7 @@ int mhla_blockmix_bwd(mhla_view q_num, mhla_view k_num, mhla_view v,
                       mhla_mview dq_num, mhla_mview dk_num, mhla_mview dv,
                       mhla_mview dq_den, mhla_mview dk_den, float* dW,
                       const int32_t* block_index, void* ws, size_t ws_bytes,
+                      const void* fwd_ws,
                       int B, int H, int M, int S, int D,
                       int dtype, float eps, unsigned flags, void* stream);
 

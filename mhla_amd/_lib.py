@@ -7,9 +7,10 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmhla_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 F32, BF16, F16 = 0, 1, 2
 FLAG_RELU_EPS = 1
+FLAG_FORCE_GENERIC = 2
 
 
 class View(Structure):
@@ -25,13 +26,13 @@ SIGNATURES = {
     "mhla_last_error": (c_char_p, []),
     "mhla_prof_enable": (None, [c_int]),
     "mhla_prof_report": (c_int, [c_char_p, c_size_t]),
-    "mhla_blockmix_fwd_ws_bytes": (c_size_t, [c_int] * 5),
-    "mhla_blockmix_bwd_ws_bytes": (c_size_t, [c_int] * 5),
+    "mhla_blockmix_fwd_ws_bytes": (c_size_t, [c_int] * 7),
+    "mhla_blockmix_bwd_ws_bytes": (c_size_t, [c_int] * 7),
     "mhla_blockmix_fwd": (c_int, [View, View, View, View, View, c_void_p, c_int, View, c_void_p, c_void_p, c_size_t,
                                   c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_uint, c_void_p]),
     "mhla_blockmix_bwd": (c_int, [View, View, View, View, View, c_void_p, c_int, View, View, View, View, View, View,
-                                  View, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int,
-                                  c_int, c_float, c_uint, c_void_p]),
+                                  View, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_int, c_int, c_int, c_int,
+                                  c_int, c_int, c_float, c_uint, c_void_p]),
     "mhla_causal_fwd_ws_bytes": (c_size_t, [c_int] * 6),
     "mhla_causal_bwd_ws_bytes": (c_size_t, [c_int] * 6),
     "mhla_causal_fwd": (c_int, [View, View, View, c_void_p, c_int, View, c_void_p, c_size_t, c_int, c_int, c_int,

@@ -13,6 +13,7 @@
 #include "blockmix.cuh"
 #include "causal.cuh"
 #include "epilogue.cuh"
+#include "fused.cuh"
 
 using namespace mhla;
 
@@ -117,12 +118,38 @@ BmWs bm_carve(void* ws, int B, int H, int M, int S, int D) {
     return w;
 }
 
+// ---- fast path (bf16, D = 64, M <= 64, q_den aliasing q_num): see fused.cuh ----
+struct FastWs {
+    fast::u16 *state, *dstate;
+    float *z, *ksum, *dn, *dwp;
+    size_t total_fwd, total_bwd;
+    int njg;
+};
+FastWs fast_carve(void* ws, int B, int H, int M, int S) {
+    const size_t bh = (size_t)B * H;
+    FastWs w;
+    w.njg = (M + fast::IT - 1) / fast::IT;
+    const size_t st = bh * w.njg * fast::FE * fast::IT * 2;   // bytes, multiple of 16
+    char* p = (char*)ws;
+    w.state = (fast::u16*)p; p += st;
+    w.z = (float*)p; p += al4(bh * M * S) * 4;
+    w.ksum = (float*)p; p += al4(bh * M * 64) * 4;
+    w.total_fwd = (size_t)(p - (char*)ws);
+    w.dstate = (fast::u16*)p; p += st;
+    w.dn = (float*)p; p += al4(bh * M * S) * 4;
+    w.dwp = (float*)p; p += bh * 4 * 4096 * 4;
+    w.total_bwd = (size_t)(p - (char*)ws);
+    return w;
+}
+bool view_ok16(const mhla_view& v) { return v.ptr && ((uintptr_t)v.ptr % 16) == 0 && ((v.sb | v.sn | v.sh) & 7) == 0; }
+bool fast_shape_ok(int M, int D, int dtype, bool split) { return dtype == MHLA_BF16 && D == 64 && M <= 64 && !split; }
+
 int bm_check(int B, int H, int M, int S, int D, int dtype, unsigned flags, bool normalize, bool split) {
     if (B <= 0 || H <= 0 || M <= 0 || S <= 0 || D <= 0) return fail(MHLA_EINVAL, "non-positive dimension B=%d H=%d M=%d S=%d D=%d", B, H, M, S, D);
     if (D % 4) return fail(MHLA_EINVAL, "D=%d must be a multiple of 4", D);
     if (!dt_for(D)) return fail(MHLA_ENOTSUP, "block-mix head dim D=%d > 128 not supported", D);
     if (dtype < 0 || dtype > 2) return fail(MHLA_EINVAL, "unknown dtype %d", dtype);
-    if (flags & ~MHLA_FLAG_RELU_EPS) return fail(MHLA_EINVAL, "unknown flags 0x%x", flags);
+    if (flags & ~(MHLA_FLAG_RELU_EPS | MHLA_FLAG_FORCE_GENERIC)) return fail(MHLA_EINVAL, "unknown flags 0x%x", flags);
     if ((flags & MHLA_FLAG_RELU_EPS) && split) return fail(MHLA_EINVAL, "MHLA_FLAG_RELU_EPS needs q_den/k_den to alias q_num/k_num");
     if ((size_t)B * H > 65535) return fail(MHLA_ENOTSUP, "B*H=%zu exceeds grid limit 65535", (size_t)B * H);
     (void)normalize;
@@ -239,8 +266,15 @@ int mhla_prof_report(char* buf, size_t cap) {
 }
 const char* mhla_last_error(void) { return g_err; }
 
-size_t mhla_blockmix_fwd_ws_bytes(int B, int H, int M, int S, int D) { return bm_carve(nullptr, B, H, M, S, D).total_fwd; }
-size_t mhla_blockmix_bwd_ws_bytes(int B, int H, int M, int S, int D) { return bm_carve(nullptr, B, H, M, S, D).total_bwd; }
+// Upper bound over the paths the library may take for this problem (the fast path needs less).
+size_t mhla_blockmix_fwd_ws_bytes(int B, int H, int M, int S, int D, int dtype, int split) {
+    if (fast_shape_ok(M, D, dtype, split != 0)) return fast_carve(nullptr, B, H, M, S).total_fwd;
+    return bm_carve(nullptr, B, H, M, S, D).total_fwd;
+}
+size_t mhla_blockmix_bwd_ws_bytes(int B, int H, int M, int S, int D, int dtype, int split) {
+    if (fast_shape_ok(M, D, dtype, split != 0)) return fast_carve(nullptr, B, H, M, S).total_bwd;
+    return bm_carve(nullptr, B, H, M, S, D).total_bwd;
+}
 
 int mhla_blockmix_fwd(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q_den, mhla_view k_den, const float* W,
                       int ldw, mhla_mview out, const int32_t* block_index, void* ws, size_t ws_bytes, int B, int H,
@@ -251,11 +285,27 @@ int mhla_blockmix_fwd(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q
     CHECK_VIEW(q_num); CHECK_VIEW(k_num); CHECK_VIEW(v); CHECK_VIEW(out);
     if (normalize) { CHECK_VIEW(q_den); CHECK_VIEW(k_den); }
     if (!W || ldw < M) return fail(MHLA_EINVAL, "W null or ldw=%d < M=%d", ldw, M);
-    const BmWs w = bm_carve(ws, B, H, M, S, D);
-    if (!ws || ws_bytes < w.total_fwd) return fail(MHLA_EINVAL, "workspace too small: %zu < %zu bytes", ws_bytes, w.total_fwd);
-    if (((uintptr_t)ws) % 16) return fail(MHLA_EINVAL, "workspace not 16-byte aligned");
+    if (!ws || ((uintptr_t)ws) % 16) return fail(MHLA_EINVAL, "workspace null or not 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     if (!normalize) { q_den = q_num; k_den = k_num; }
+    const int relu = (flags & MHLA_FLAG_RELU_EPS) ? 1 : 0;
+    const mhla_view outv{out.ptr, out.sb, out.sn, out.sh};
+    if (fast_shape_ok(M, D, dtype, split) && !(flags & MHLA_FLAG_FORCE_GENERIC) && view_ok16(q_num) && view_ok16(k_num) &&
+        view_ok16(v) && view_ok16(outv)) {
+        const FastWs f = fast_carve(ws, B, H, M, S);
+        if (ws_bytes < f.total_fwd) return fail(MHLA_EINVAL, "workspace too small: %zu < %zu bytes", ws_bytes, f.total_fwd);
+        fast::FsStateArgs sa{};
+        sa.x = cv(k_num); sa.y = cv(v); sa.t = cv(q_num); sa.idx = block_index; sa.state = f.state; sa.ksum = f.ksum;
+        sa.z_out = f.z; sa.H = H; sa.M = M; sa.S = S; sa.eps = eps; sa.relu = relu; sa.normalize = normalize;
+        RC(launch(fast::k_fs_state<0>, dim3(f.njg, B * H), dim3(fast::FT), fast::FS_STATE_SMEM, st, "k_fs_state<0>", sa));
+        fast::FsOutArgs oa{};
+        oa.q = cv(q_num); oa.o = cmv(out); oa.idx = block_index; oa.W = W; oa.ldw = ldw; oa.state = f.state; oa.z = f.z;
+        oa.H = H; oa.M = M; oa.S = S; oa.njg = f.njg; oa.eps = eps; oa.relu = relu; oa.normalize = normalize;
+        RC(launch(fast::k_fs_out, dim3(f.njg, B * H), dim3(fast::FT), fast::FS_OUT_SMEM, st, "k_fs_out", oa));
+        return MHLA_OK;
+    }
+    const BmWs w = bm_carve(ws, B, H, M, S, D);
+    if (ws_bytes < w.total_fwd) return fail(MHLA_EINVAL, "workspace too small: %zu < %zu bytes", ws_bytes, w.total_fwd);
     const int dt = dt_for(D);
     DISPATCH_T(dtype, DISPATCH_DT(dt, {
         RC((bm_state_and_mix<ET, DT>(q_num, k_num, v, q_den, k_den, W, ldw, block_index, w, B, H, M, S, D, eps, flags, normalize, split, st)));
@@ -271,8 +321,8 @@ int mhla_blockmix_fwd(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q
 int mhla_blockmix_bwd(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q_den, mhla_view k_den, const float* W,
                       int ldw, mhla_view out, mhla_view dout, mhla_mview dq_num, mhla_mview dk_num, mhla_mview dv,
                       mhla_mview dq_den, mhla_mview dk_den, float* dW, const int32_t* block_index, void* ws,
-                      size_t ws_bytes, int B, int H, int M, int S, int D, int dtype, float eps, unsigned flags,
-                      void* stream) {
+                      size_t ws_bytes, const void* fwd_ws, int B, int H, int M, int S, int D, int dtype, float eps,
+                      unsigned flags, void* stream) {
     const bool normalize = q_den.ptr != nullptr;
     const bool split = normalize && (q_den.ptr != q_num.ptr || k_den.ptr != k_num.ptr);
     RC(bm_check(B, H, M, S, D, dtype, flags, normalize, split));
@@ -281,13 +331,48 @@ int mhla_blockmix_bwd(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q
     if (normalize) { CHECK_VIEW(q_den); CHECK_VIEW(k_den); CHECK_VIEW(out); }
     if (split) { CHECK_VIEW(dq_den); CHECK_VIEW(dk_den); }
     if (!W || ldw < M || !dW) return fail(MHLA_EINVAL, "W/dW null or ldw=%d < M=%d", ldw, M);
-    const BmWs w = bm_carve(ws, B, H, M, S, D);
-    if (!ws || ws_bytes < w.total_bwd) return fail(MHLA_EINVAL, "workspace too small: %zu < %zu bytes", ws_bytes, w.total_bwd);
-    if (((uintptr_t)ws) % 16) return fail(MHLA_EINVAL, "workspace not 16-byte aligned");
+    if (!ws || ((uintptr_t)ws) % 16) return fail(MHLA_EINVAL, "workspace null or not 16-byte aligned");
+    if (fwd_ws && ((uintptr_t)fwd_ws) % 16) return fail(MHLA_EINVAL, "fwd_ws not 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     if (!normalize) { q_den = q_num; k_den = k_num; }
     const int dt = dt_for(D);
     const int relu = (flags & MHLA_FLAG_RELU_EPS) ? 1 : 0;
+    {
+        const mhla_view dqv{dq_num.ptr, dq_num.sb, dq_num.sn, dq_num.sh}, dkv_{dk_num.ptr, dk_num.sb, dk_num.sn, dk_num.sh},
+            dvv{dv.ptr, dv.sb, dv.sn, dv.sh};
+        if (fast_shape_ok(M, D, dtype, split) && !(flags & MHLA_FLAG_FORCE_GENERIC) && view_ok16(q_num) && view_ok16(k_num) &&
+            view_ok16(v) && view_ok16(dout) && (!normalize || view_ok16(out)) && view_ok16(dqv) && view_ok16(dkv_) && view_ok16(dvv)) {
+            const FastWs f = fast_carve(ws, B, H, M, S);
+            if (ws_bytes < f.total_bwd) return fail(MHLA_EINVAL, "workspace too small: %zu < %zu bytes", ws_bytes, f.total_bwd);
+            const fast::u16* state = f.state;
+            const float *z = f.z, *ksum = f.ksum;
+            if (fwd_ws) {   // forward workspace retained by the caller: reuse KV^T, z, ksum
+                const FastWs ff = fast_carve(const_cast<void*>(fwd_ws), B, H, M, S);
+                state = ff.state; z = ff.z; ksum = ff.ksum;
+            } else {
+                fast::FsStateArgs sa{};
+                sa.x = cv(k_num); sa.y = cv(v); sa.t = cv(q_num); sa.idx = block_index; sa.state = f.state; sa.ksum = f.ksum;
+                sa.z_out = f.z; sa.H = H; sa.M = M; sa.S = S; sa.eps = eps; sa.relu = relu; sa.normalize = normalize;
+                RC(launch(fast::k_fs_state<0>, dim3(f.njg, B * H), dim3(fast::FT), fast::FS_STATE_SMEM, st, "k_fs_state<0>", sa));
+            }
+            fast::FsStateArgs ga{};
+            ga.x = cv(q_num); ga.y = cv(dout); ga.t = cv(out); ga.idx = block_index; ga.W = W; ga.ldw = ldw; ga.z_in = z;
+            ga.state = f.dstate; ga.dn = f.dn; ga.H = H; ga.M = M; ga.S = S; ga.eps = eps; ga.relu = relu; ga.normalize = normalize;
+            RC(launch(fast::k_fs_state<1>, dim3(f.njg, B * H), dim3(fast::FT), fast::FS_STATE_SMEM, st, "k_fs_state<1>", ga));
+            fast::FsDwArgs da{f.dstate, state, normalize ? f.dn : nullptr, z, f.dwp, M, S, f.njg};
+            RC(launch(fast::k_fs_dw, dim3(4, B * H), dim3(fast::FT), fast::FS_DW_SMEM, st, "k_fs_dw", da));
+            RC(launch(fast::k_fs_dw_reduce, dim3((M * M + 255) / 256), dim3(256), 0, st, "k_fs_dw_reduce", (const float*)f.dwp, dW, M, B * H * 4));
+            fast::FsTokArgs ta{};
+            ta.q = cv(q_num); ta.k = cv(k_num); ta.v = cv(v); ta.dout = cv(dout); ta.dq = cmv(dq_num); ta.dk = cmv(dk_num);
+            ta.dv = cmv(dv); ta.idx = block_index; ta.W = W; ta.ldw = ldw; ta.state = state; ta.dstate = f.dstate; ta.z = z;
+            ta.dn = f.dn; ta.ksum = ksum; ta.H = H; ta.M = M; ta.S = S; ta.njg = f.njg; ta.eps = eps; ta.relu = relu;
+            ta.normalize = normalize;
+            RC(launch(fast::k_fs_bwd_tok, dim3(f.njg, B * H), dim3(fast::FT), fast::FS_TOK_SMEM, st, "k_fs_bwd_tok", ta));
+            return MHLA_OK;
+        }
+    }
+    const BmWs w = bm_carve(ws, B, H, M, S, D);
+    if (ws_bytes < w.total_bwd) return fail(MHLA_EINVAL, "workspace too small: %zu < %zu bytes", ws_bytes, w.total_bwd);
     DISPATCH_T(dtype, DISPATCH_DT(dt, {
         RC((bm_state_and_mix<ET, DT>(q_num, k_num, v, q_den, k_den, W, ldw, block_index, w, B, H, M, S, D, eps, flags, normalize, split, st)));
         // dG_i = Q_i^T (dO_i / n_i), dn_i

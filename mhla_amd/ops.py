@@ -13,6 +13,9 @@ import torch
 from . import _lib
 from ._lib import NULL_VIEW, View
 
+# forward workspaces up to this size are kept alive for the backward (bf16 block summaries of the fast path)
+KEEP_STATE_LIMIT_BYTES = 1 << 30
+
 _DTYPES = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16, torch.float16: _lib.F16}
 
 
@@ -64,7 +67,7 @@ def _ws(nbytes: int, device) -> torch.Tensor:
 # ------------------------------------------------------------------------------------------
 class _BlockMix(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q, k, v, W, q_den, k_den, block_index, eps, normalize, relu_eps):
+    def forward(ctx, q, k, v, W, q_den, k_den, block_index, eps, normalize, relu_eps, force_generic):
         lib = _lib.load()
         _require_gpu(q, k, v, W, q_den, k_den, block_index)
         B, N, H, D = q.shape
@@ -80,27 +83,31 @@ class _BlockMix(torch.autograd.Function):
             q_den, k_den = _prep(q_den), _prep(k_den)
         Wf = W.detach().reshape(M, M).to(torch.float32).contiguous()
         out = torch.empty((B, N, H, D), dtype=q.dtype, device=q.device)
-        ws = _ws(lib.mhla_blockmix_fwd_ws_bytes(B, H, M, S, D), q.device)
+        dt = _dtype_code(q)
+        ws = _ws(lib.mhla_blockmix_fwd_ws_bytes(B, H, M, S, D, dt, int(split)), q.device)
         qv, kv = _view(q), _view(k)
         if normalize:
             qd, kd = (_view(q_den), _view(k_den)) if split else (qv, kv)
         else:
             qd, kd = NULL_VIEW, NULL_VIEW
-        flags = _lib.FLAG_RELU_EPS if relu_eps else 0
+        flags = (_lib.FLAG_RELU_EPS if relu_eps else 0) | (_lib.FLAG_FORCE_GENERIC if force_generic else 0)
         idx_ptr = block_index.data_ptr() if block_index is not None else None
         rc = lib.mhla_blockmix_fwd(qv, kv, _view(v), qd, kd, Wf.data_ptr(), M, _view(out), idx_ptr,
-                                   ws.data_ptr(), ws.numel() * 4, B, H, M, S, D, _dtype_code(q), float(eps), flags,
-                                   _stream())
+                                   ws.data_ptr(), ws.numel() * 4, B, H, M, S, D, dt, float(eps), flags, _stream())
         _lib.check(rc, "mhla_blockmix_fwd")
-        ctx.save_for_backward(q, k, v, Wf, out, q_den if split else None, k_den if split else None, block_index)
-        ctx.cfg = (float(eps), bool(normalize), bool(relu_eps), split, W.shape, W.dtype)
+        # keep the forward's block summaries for the backward when they are the compact bf16 ones (fast path)
+        keep = (not force_generic and dt == _lib.BF16 and D == 64 and M <= 64 and not split
+                and ws.numel() * 4 <= KEEP_STATE_LIMIT_BYTES)
+        ctx.save_for_backward(q, k, v, Wf, out, q_den if split else None, k_den if split else None, block_index,
+                              ws if keep else None)
+        ctx.cfg = (float(eps), bool(normalize), bool(relu_eps), split, W.shape, W.dtype, bool(force_generic))
         return out
 
     @staticmethod
     def backward(ctx, dout):
         lib = _lib.load()
-        q, k, v, Wf, out, q_den, k_den, block_index = ctx.saved_tensors
-        eps, normalize, relu_eps, split, w_shape, w_dtype = ctx.cfg
+        q, k, v, Wf, out, q_den, k_den, block_index, fwd_ws = ctx.saved_tensors
+        eps, normalize, relu_eps, split, w_shape, w_dtype, force_generic = ctx.cfg
         B, N, H, D = q.shape
         M = Wf.shape[0]
         S = N // M
@@ -112,27 +119,29 @@ class _BlockMix(torch.autograd.Function):
         dqd = dkd = None
         if split:
             dqd, dkd = torch.empty_like(dq), torch.empty_like(dq)
-        ws = _ws(lib.mhla_blockmix_bwd_ws_bytes(B, H, M, S, D), q.device)
+        dt = _dtype_code(q)
+        ws = _ws(lib.mhla_blockmix_bwd_ws_bytes(B, H, M, S, D, dt, int(split)), q.device)
         qv, kv = _view(q), _view(k)
         if normalize:
             qd, kd = (_view(q_den), _view(k_den)) if split else (qv, kv)
         else:
             qd, kd = NULL_VIEW, NULL_VIEW
-        flags = _lib.FLAG_RELU_EPS if relu_eps else 0
+        flags = (_lib.FLAG_RELU_EPS if relu_eps else 0) | (_lib.FLAG_FORCE_GENERIC if force_generic else 0)
         idx_ptr = block_index.data_ptr() if block_index is not None else None
         rc = lib.mhla_blockmix_bwd(qv, kv, _view(v), qd, kd, Wf.data_ptr(), M, _view(out), _view(dout),
                                    _view(dq), _view(dk), _view(dv),
                                    _view(dqd) if split else NULL_VIEW, _view(dkd) if split else NULL_VIEW,
-                                   dW.data_ptr(), idx_ptr, ws.data_ptr(), ws.numel() * 4, B, H, M, S, D,
-                                   _dtype_code(q), eps, flags, _stream())
+                                   dW.data_ptr(), idx_ptr, ws.data_ptr(), ws.numel() * 4,
+                                   fwd_ws.data_ptr() if fwd_ws is not None else None, B, H, M, S, D,
+                                   dt, eps, flags, _stream())
         _lib.check(rc, "mhla_blockmix_bwd")
-        return dq, dk, dv, dW.reshape(w_shape).to(w_dtype), dqd, dkd, None, None, None, None
+        return dq, dk, dv, dW.reshape(w_shape).to(w_dtype), dqd, dkd, None, None, None, None, None
 
 
 def mhla_blockmix(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, W: torch.Tensor, *, eps: float = 1e-6,
                   q_den: Optional[torch.Tensor] = None, k_den: Optional[torch.Tensor] = None,
                   normalize: bool = True, block_index: Optional[torch.Tensor] = None,
-                  relu_eps: bool = False) -> torch.Tensor:
+                  relu_eps: bool = False, force_generic: bool = False) -> torch.Tensor:
     """Block-mixing MHLA operator (mhla_dit/mhla/mhla.py:262-268; wan/mhla_utils.py:331-341).
 
     q, k, v : [B, N, H, D] token-major (any batch/token/head strides, e.g. views into a fused QKV
@@ -143,13 +152,14 @@ def mhla_blockmix(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, W: torch.Te
     normalize    : False skips the division (Wan `normalize_out=False`).
     relu_eps     : apply relu(x)+eps to q and k inside the kernels (mhla.py:229-230) -- q, k are then
                    the raw projections and receive the masked gradient.
+    force_generic: testing aid -- take the generic fp32-MFMA kernels where the bf16 fast path would apply.
     Returns [B, N, H, D] contiguous, same dtype; differentiable w.r.t. q, k, v, W (and q_den, k_den).
     """
     if (q_den is None) != (k_den is None):
         raise ValueError("q_den and k_den must be given together")
     if block_index is not None and (block_index.dtype != torch.int32 or not block_index.is_contiguous()):
         raise TypeError("block_index must be a contiguous int32 tensor")
-    return _BlockMix.apply(q, k, v, W, q_den, k_den, block_index, eps, normalize, relu_eps)
+    return _BlockMix.apply(q, k, v, W, q_den, k_den, block_index, eps, normalize, relu_eps, force_generic)
 
 
 # ------------------------------------------------------------------------------------------

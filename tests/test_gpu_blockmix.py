@@ -9,7 +9,7 @@ from oracle import mhla_oracle as orc
 pytestmark = pytest.mark.gpu
 
 
-def run_case(B, H, M, S, D, dtype, normalize=True, split=False, w="linear", idx=None, seed=1234):
+def run_case(B, H, M, S, D, dtype, normalize=True, split=False, w="linear", idx=None, seed=1234, **opkw):
     import mhla_amd
     q, k, v, W, do, qd, kd = make_blockmix_inputs(B, H, M, S, D, dtype, seed, w, split)
     want, wg = oracle_blockmix(q, k, v, W, do, qd, kd, 1e-6, normalize)
@@ -27,7 +27,7 @@ def run_case(B, H, M, S, D, dtype, normalize=True, split=False, w="linear", idx=
         dqd.requires_grad_(True)
         dkd.requires_grad_(True)
     out = mhla_amd.mhla_blockmix(dq_, dk_, dv_, dW_, eps=1e-6, q_den=dqd, k_den=dkd, normalize=normalize,
-                                 block_index=None if idx is None else idx.to(DEV))
+                                 block_index=None if idx is None else idx.to(DEV), **opkw)
     out.backward(ddo)
     torch.cuda.synchronize()
 
@@ -68,6 +68,32 @@ def test_shapes_fp32(M, S, D):
 @pytest.mark.parametrize("M,S,D", [(16, 16, 72), (64, 64, 64), (6, 210, 128)])
 def test_shapes_lowp(M, S, D, dtype):
     run_case(2, 2, M, S, D, dtype)
+
+
+@pytest.mark.parametrize("M,S", [(64, 64), (16, 16), (16, 256), (4, 49), (5, 64), (33, 32), (40, 80), (1, 128), (64, 8)])
+def test_fast_path_bf16_d64(M, S):
+    """bf16, D = 64, M <= 64: the bf16-MFMA fast path (interleaved bf16 block summaries, fused mix + output)."""
+    run_case(2, 3, M, S, 64, torch.bfloat16, w="rand")
+
+
+@pytest.mark.parametrize("normalize", [True, False])
+def test_fast_path_options(normalize):
+    idx = orc.block_index_2d(4, 4).int()
+    run_case(2, 2, 16, 16, 64, torch.bfloat16, normalize=normalize, idx=idx)
+    run_case(1, 2, 64, 64, 64, torch.bfloat16, normalize=normalize, force_generic=True)   # same shape, generic kernels
+
+
+def test_fast_vs_generic_agree():
+    import mhla_amd
+    q, k, v, W, do, _, _ = make_blockmix_inputs(2, 4, 64, 64, 64, torch.bfloat16, seed=5, w="rand")
+    res = []
+    for fg in (False, True):
+        t = [x.clone().requires_grad_(True) for x in to_dev(q, k, v, W)]
+        out = mhla_amd.mhla_blockmix(*t, force_generic=fg)
+        out.backward(do.to(DEV))
+        res.append([out] + [x.grad for x in t])
+    for name, a, b in zip(("out", "dq", "dk", "dv", "dW"), res[0], res[1]):
+        check(name, a, b.float().cpu(), 1.2e-2)
 
 
 @pytest.mark.parametrize("normalize,split", [(False, False), (True, True)])
@@ -121,6 +147,21 @@ def test_fused_qkv_views_and_relu_prologue():
     check("out", out, o_ref.detach(), 1e-4)
     check("dqkv", dev.grad, ref.grad, 2e-4)
     check("dW", Wd.grad, Wr.grad, 2e-4)
+    # same through the bf16 fast path (D = 64)
+    B, N, H, D, M = 2, 256, 4, 64, 16
+    qkv = torch.randn(B, N, 3, H, D, generator=g).bfloat16()
+    do = torch.randn(B, N, H, D, generator=g).bfloat16()
+    ref = qkv.float().requires_grad_(True)
+    Wr = W.clone().requires_grad_(True)
+    o_ref = orc.blockmix_fwd(orc.relu_eps(ref[:, :, 0]), orc.relu_eps(ref[:, :, 1]), ref[:, :, 2], Wr, 1e-6)
+    (o_ref * do.float()).sum().backward()
+    dev = qkv.to(DEV).requires_grad_(True)
+    Wd = W.to(DEV).requires_grad_(True)
+    out = mhla_amd.mhla_blockmix(dev[:, :, 0], dev[:, :, 1], dev[:, :, 2], Wd, eps=1e-6, relu_eps=True)
+    out.backward(do.to(DEV))
+    check("out_bf16", out, o_ref.detach(), TOL[torch.bfloat16])
+    check("dqkv_bf16", dev.grad, ref.grad, GTOL[torch.bfloat16])
+    check("dW_bf16", Wd.grad, Wr.grad, GTOL[torch.bfloat16])
 
 
 def test_errors_fail_loudly():
