@@ -72,9 +72,9 @@ int mhla_prof_report(char* buf, size_t cap);
 /* ---- block-mixing (non-causal) MHLA: DiT / ViT / Wan ------------------- */
 
 /* Bytes of workspace mhla_blockmix_fwd / _bwd need for this problem (dtype: MHLA_F32/BF16/F16;
- * split: 1 when q_den/k_den do not alias q_num/k_num). */
-size_t mhla_blockmix_fwd_ws_bytes(int B, int H, int M, int S, int D, int dtype, int split);
-size_t mhla_blockmix_bwd_ws_bytes(int B, int H, int M, int S, int D, int dtype, int split);
+ * split: 1 when q_den/k_den do not alias q_num/k_num; flags: the flags of the call). */
+size_t mhla_blockmix_fwd_ws_bytes(int B, int H, int M, int S, int D, int dtype, int split, unsigned flags);
+size_t mhla_blockmix_bwd_ws_bytes(int B, int H, int M, int S, int D, int dtype, int split, unsigned flags);
 
 /*
  * Forward.  Replaces mhla_dit/mhla/mhla.py:262-268 (identical:

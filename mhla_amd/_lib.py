@@ -26,8 +26,8 @@ SIGNATURES = {
     "mhla_last_error": (c_char_p, []),
     "mhla_prof_enable": (None, [c_int]),
     "mhla_prof_report": (c_int, [c_char_p, c_size_t]),
-    "mhla_blockmix_fwd_ws_bytes": (c_size_t, [c_int] * 7),
-    "mhla_blockmix_bwd_ws_bytes": (c_size_t, [c_int] * 7),
+    "mhla_blockmix_fwd_ws_bytes": (c_size_t, [c_int] * 7 + [c_uint]),
+    "mhla_blockmix_bwd_ws_bytes": (c_size_t, [c_int] * 7 + [c_uint]),
     "mhla_blockmix_fwd": (c_int, [View, View, View, View, View, c_void_p, c_int, View, c_void_p, c_void_p, c_size_t,
                                   c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_uint, c_void_p]),
     "mhla_blockmix_bwd": (c_int, [View, View, View, View, View, c_void_p, c_int, View, View, View, View, View, View,

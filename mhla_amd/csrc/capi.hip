@@ -121,7 +121,7 @@ BmWs bm_carve(void* ws, int B, int H, int M, int S, int D) {
 // ---- fast path (bf16, D = 64, M <= 64, q_den aliasing q_num): see fused.cuh ----
 struct FastWs {
     fast::u16 *state, *dstate;
-    float *z, *ksum, *dn, *dwp;
+    float *z, *ksum, *dn, *dwp, *dwt, *dksum;
     size_t total_fwd, total_bwd;
     int njg;
 };
@@ -137,7 +137,9 @@ FastWs fast_carve(void* ws, int B, int H, int M, int S) {
     w.total_fwd = (size_t)(p - (char*)ws);
     w.dstate = (fast::u16*)p; p += st;
     w.dn = (float*)p; p += al4(bh * M * S) * 4;
+    w.dksum = (float*)p; p += al4(bh * M * 64) * 4;
     w.dwp = (float*)p; p += bh * 4 * 4096 * 4;
+    w.dwt = (float*)p; p += ((bh * 4 + fast::DWR_G - 1) / fast::DWR_G) * 4096 * 4;
     w.total_bwd = (size_t)(p - (char*)ws);
     return w;
 }
@@ -267,12 +269,12 @@ int mhla_prof_report(char* buf, size_t cap) {
 const char* mhla_last_error(void) { return g_err; }
 
 // Upper bound over the paths the library may take for this problem (the fast path needs less).
-size_t mhla_blockmix_fwd_ws_bytes(int B, int H, int M, int S, int D, int dtype, int split) {
-    if (fast_shape_ok(M, D, dtype, split != 0)) return fast_carve(nullptr, B, H, M, S).total_fwd;
+size_t mhla_blockmix_fwd_ws_bytes(int B, int H, int M, int S, int D, int dtype, int split, unsigned flags) {
+    if (fast_shape_ok(M, D, dtype, split != 0) && !(flags & MHLA_FLAG_FORCE_GENERIC)) return fast_carve(nullptr, B, H, M, S).total_fwd;
     return bm_carve(nullptr, B, H, M, S, D).total_fwd;
 }
-size_t mhla_blockmix_bwd_ws_bytes(int B, int H, int M, int S, int D, int dtype, int split) {
-    if (fast_shape_ok(M, D, dtype, split != 0)) return fast_carve(nullptr, B, H, M, S).total_bwd;
+size_t mhla_blockmix_bwd_ws_bytes(int B, int H, int M, int S, int D, int dtype, int split, unsigned flags) {
+    if (fast_shape_ok(M, D, dtype, split != 0) && !(flags & MHLA_FLAG_FORCE_GENERIC)) return fast_carve(nullptr, B, H, M, S).total_bwd;
     return bm_carve(nullptr, B, H, M, S, D).total_bwd;
 }
 
@@ -301,7 +303,7 @@ int mhla_blockmix_fwd(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q
         fast::FsOutArgs oa{};
         oa.q = cv(q_num); oa.o = cmv(out); oa.idx = block_index; oa.W = W; oa.ldw = ldw; oa.state = f.state; oa.z = f.z;
         oa.H = H; oa.M = M; oa.S = S; oa.njg = f.njg; oa.eps = eps; oa.relu = relu; oa.normalize = normalize;
-        RC(launch(fast::k_fs_out, dim3(f.njg, B * H), dim3(fast::FT), fast::FS_OUT_SMEM, st, "k_fs_out", oa));
+        RC(launch(fast::k_fs_out, dim3(f.njg * B * H), dim3(fast::FT), fast::FS_OUT_SMEM, st, "k_fs_out", oa));
         return MHLA_OK;
     }
     const BmWs w = bm_carve(ws, B, H, M, S, D);
@@ -361,13 +363,17 @@ int mhla_blockmix_bwd(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q
             RC(launch(fast::k_fs_state<1>, dim3(f.njg, B * H), dim3(fast::FT), fast::FS_STATE_SMEM, st, "k_fs_state<1>", ga));
             fast::FsDwArgs da{f.dstate, state, normalize ? f.dn : nullptr, z, f.dwp, M, S, f.njg};
             RC(launch(fast::k_fs_dw, dim3(4, B * H), dim3(fast::FT), fast::FS_DW_SMEM, st, "k_fs_dw", da));
-            RC(launch(fast::k_fs_dw_reduce, dim3((M * M + 255) / 256), dim3(256), 0, st, "k_fs_dw_reduce", (const float*)f.dwp, dW, M, B * H * 4));
+            const int nparts = B * H * 4, ngroups = (nparts + fast::DWR_G - 1) / fast::DWR_G;
+            RC(launch(fast::k_fs_dw_reduce1, dim3(16, ngroups), dim3(256), 0, st, "k_fs_dw_reduce1", (const float*)f.dwp, f.dwt, nparts));
+            RC(launch(fast::k_fs_dw_reduce2, dim3((M * M + 255) / 256), dim3(256), 0, st, "k_fs_dw_reduce2", (const float*)f.dwt, dW, M, ngroups));
             fast::FsTokArgs ta{};
             ta.q = cv(q_num); ta.k = cv(k_num); ta.v = cv(v); ta.dout = cv(dout); ta.dq = cmv(dq_num); ta.dk = cmv(dk_num);
             ta.dv = cmv(dv); ta.idx = block_index; ta.W = W; ta.ldw = ldw; ta.state = state; ta.dstate = f.dstate; ta.z = z;
             ta.dn = f.dn; ta.ksum = ksum; ta.H = H; ta.M = M; ta.S = S; ta.njg = f.njg; ta.eps = eps; ta.relu = relu;
             ta.normalize = normalize;
-            RC(launch(fast::k_fs_bwd_tok, dim3(f.njg, B * H), dim3(fast::FT), fast::FS_TOK_SMEM, st, "k_fs_bwd_tok", ta));
+            ta.dksum = f.dksum;
+            RC(launch(fast::k_fs_bwd_dq, dim3(f.njg * B * H), dim3(fast::FT), fast::FS_TOK_SMEM, st, "k_fs_bwd_dq", ta));
+            RC(launch(fast::k_fs_bwd_dkv, dim3(f.njg * B * H), dim3(fast::FT), fast::FS_TOK_SMEM, st, "k_fs_bwd_dkv", ta));
             return MHLA_OK;
         }
     }

@@ -11,7 +11,7 @@
 // mixing weights keep ~16 mantissa bits.  All contractions: v_mfma_f32_16x16x32_bf16, fp32 accumulate.
 //
 //   forward : k_fs_state<0> (KV^T, ksum, z)  ->  k_fs_out (mix + n + O)
-//   backward: k_fs_state<1> (dG^T, dn)  ->  k_fs_dw (dW partials)  ->  k_fs_bwd_tok (mix G, dQ; mix dKV, dK, dV)
+//   backward: k_fs_state<1> (dG^T, dn) -> k_fs_dw (dW partials) -> k_fs_bwd_dq (mix G; dQ, dksum) -> k_fs_bwd_dkv (mix dKV; dK, dV)
 #pragma once
 #include "common.cuh"
 
@@ -292,22 +292,134 @@ __device__ __forceinline__ void mix_tile_to_lds(u16* __restrict__ Gt, const u16*
     }
 }
 
-// A operand (16 rows x 32 k) straight from a token view: lane (m = lane & 15, kg = lane >> 4) loads
-// row (p0 + m), columns k0 + 8 kg .. + 7.  Rows >= rv give zeros.
+// XCD-aware logical work index (bijective): workgroups that share a (b,h)'s summaries land on one XCD's L2.
+__device__ __forceinline__ int xcd_swizzle(int wg, int nwg) {
+    const int xcd = wg & 7, slot = wg >> 3, q = nwg >> 3, r = nwg & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+}
+
+// A operands of a 64-row chunk straight from a token view: a[st][ks] = rows 16 st + (lane & 15),
+// columns 32 ks + 8 (lane >> 4) .. + 7.  Rows >= rv give zeros.
 template <bool RELU>
-__device__ __forceinline__ bf16x8 load_a_rows(const u16* __restrict__ base, long sn, const int* __restrict__ idx,
-                                              long p0, int rv, int k0, float eps, int lane) {
+__device__ __forceinline__ void load_a64(bf16x8 (&a)[4][2], const u16* __restrict__ base, long sn,
+                                         const int* __restrict__ idx, long p0, int rv, float eps, int lane) {
     const int m = lane & 15, kg = lane >> 4;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (m < rv) {
-        v = *reinterpret_cast<const uint4*>(base + tok_row(idx, p0 + m) * sn + k0 + kg * 8);
-        if (RELU) v = relu_eps8(v, eps);
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+        const int row = st * 16 + m;
+        const u16* src = base + (row < rv ? tok_row(idx, p0 + row) : 0) * sn + kg * 8;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (row < rv) {
+                v = *reinterpret_cast<const uint4*>(src + ks * 32);
+                if (RELU) v = relu_eps8(v, eps);
+            }
+            a[st][ks] = __builtin_bit_cast(bf16x8, v);
+        }
     }
-    return __builtin_bit_cast(bf16x8, v);
+}
+
+// acc[st][tn] += A[st] x B  with B from one mixed summary Gb[d2][d1] (GLD stride):
+//   TRB false: B[k = d1][n = d2] = Gb[n][k]  (k contiguous: plain 16-byte LDS reads)
+//   TRB true : B[k = d2][n = d1] = Gb[k][n]  (hardware transpose reads)
+template <bool TRB>
+__device__ __forceinline__ void chunk_times_gt(f32x4 (&acc)[4][4], const bf16x8 (&a)[4][2], const u16* __restrict__ Gb, int lane) {
+    const int n = lane & 15, kg = lane >> 4;
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const bf16x8 bv = TRB ? tr_read8(Gb, GLD, ks * 32, tn * 16, lane)
+                                  : *reinterpret_cast<const bf16x8*>(Gb + (tn * 16 + n) * GLD + ks * 32 + kg * 8);
+#pragma unroll
+            for (int st = 0; st < 4; ++st) acc[st][tn] = mfma_bf16(a[st][ks], bv, acc[st][tn]);
+        }
+    }
+}
+
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// Wave-private staging of a 64 x 64 fp32 result (C layout: row = 16 st + 4 (lane >> 4) + r, col = 16 tn + (lane & 15))
+__device__ __forceinline__ void stage64(u16* __restrict__ Os, const f32x4 (&acc)[4][4], int lane) {
+    const int n = lane & 15, kg = lane >> 4;
+#pragma unroll
+    for (int st = 0; st < 4; ++st)
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Os[(st * 16 + kg * 4 + r) * GLD + tn * 16 + n] = f32_to_bf16(acc[st][tn][r]);
+}
+
+// zero the bf16 lanes of v where the corresponding element of m is <= 0 (relu gradient mask)
+__device__ __forceinline__ uint4 mask_pos8(uint4 v, uint4 m) {
+    unsigned vv[4] = {v.x, v.y, v.z, v.w}, mm[4] = {m.x, m.y, m.z, m.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned lo = mm[i] & 0xffffu, hi = mm[i] >> 16;
+        unsigned keep = 0;
+        if ((lo & 0x7fffu) != 0 && !(lo & 0x8000u)) keep |= 0x0000ffffu;
+        if ((hi & 0x7fffu) != 0 && !(hi & 0x8000u)) keep |= 0xffff0000u;
+        vv[i] &= keep;
+    }
+    return make_uint4(vv[0], vv[1], vv[2], vv[3]);
+}
+
+// One wave stores a staged 64 x 64 bf16 tile: 8 passes of 8 full 128-byte rows.
+template <bool MASK>
+__device__ __forceinline__ void store64(u16* __restrict__ base, long sn, const int* __restrict__ idx, long p0, int rv,
+                                        const u16* __restrict__ Os, const u16* __restrict__ mbase, long msn, int lane) {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const int row = p * 8 + (lane >> 3), c = (lane & 7) * 8;
+        if (row < rv) {
+            const long tr = tok_row(idx, p0 + row);
+            uint4 v = *reinterpret_cast<const uint4*>(Os + row * GLD + c);
+            if (MASK) v = mask_pos8(v, *reinterpret_cast<const uint4*>(mbase + tr * msn + c));
+            *reinterpret_cast<uint4*>(base + tr * sn + c) = v;
+        }
+    }
+}
+// narrow fallback (no free staging slot): direct stores from the C layout
+template <bool MASK>
+__device__ __forceinline__ void store64_direct(u16* __restrict__ base, long sn, const int* __restrict__ idx, long p0, int rv,
+                                               const f32x4 (&acc)[4][4], const u16* __restrict__ mbase, long msn, int lane) {
+    const int n = lane & 15, kg = lane >> 4;
+#pragma unroll
+    for (int st = 0; st < 4; ++st)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = st * 16 + kg * 4 + r;
+            if (row < rv) {
+                const long tr = tok_row(idx, p0 + row);
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn) {
+                    float v = acc[st][tn][r];
+                    if (MASK && !(bf(mbase[tr * msn + tn * 16 + n]) > 0.f)) v = 0.f;
+                    base[tr * sn + tn * 16 + n] = f32_to_bf16(v);
+                }
+            }
+        }
+}
+
+// lane = row of the chunk: sum_j w[j * wstride] * x[j * S + s]
+__device__ __forceinline__ float col_dot(const float* __restrict__ w, long wstride, const float* __restrict__ x, int M, int S,
+                                         int s, bool valid) {
+    float acc = 0.f;
+    if (valid) {
+#pragma unroll 8
+        for (int j = 0; j < M; ++j) acc += w[(long)j * wstride] * x[(long)j * S + s];
+    }
+    return acc;
 }
 
 // -------------------------------------------------------------------------------------------------
-// k_fs_out: per (tile it, bh): mix 8 summaries into LDS, then O_i = (Q_i G_i) / n_i for the 8 blocks.
+// k_fs_out: per (tile it, bh): all 4 waves mix the 8 summaries of the tile into LDS; then each wave owns
+// 2 blocks: O_i = (Q_i G_i) / n_i, staged in the block's own (dead) Gt slot -- no block-level barriers.
 // -------------------------------------------------------------------------------------------------
 struct FsOutArgs {
     View q;
@@ -322,108 +434,56 @@ struct FsOutArgs {
     int relu, normalize;
 };
 constexpr int FS_GT_BYTES = IT * FD * GLD * 2;
-constexpr int FS_OUT_SMEM = FS_GT_BYTES + 256 * 4;
+constexpr int FS_OUT_SMEM = FS_GT_BYTES;
 
-// one 64-row chunk of one block: acc[tn] = A(rows 16 wave ..) x Gt-block (B, k = d1 contiguous)
-__device__ __forceinline__ void rows_times_gt(f32x4 (&acc)[4], const bf16x8 (&a)[2], const u16* __restrict__ Gb, int lane) {
-    const int n = lane & 15, kg = lane >> 4;
-#pragma unroll
-    for (int tn = 0; tn < 4; ++tn) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const bf16x8 bv = *reinterpret_cast<const bf16x8*>(Gb + (tn * 16 + n) * GLD + ks * 32 + kg * 8);
-            acc[tn] = mfma_bf16(a[ks], bv, acc[tn]);
-        }
-    }
-}
-// same with the B operand transposed: B[k = row of Gt][n = column of Gt] (hardware transpose read)
-__device__ __forceinline__ void rows_times_gt_t(f32x4 (&acc)[4], const bf16x8 (&a)[2], const u16* __restrict__ Gb, int lane) {
-#pragma unroll
-    for (int tn = 0; tn < 4; ++tn) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) acc[tn] = mfma_bf16(a[ks], tr_read8(Gb, GLD, ks * 32, tn * 16, lane), acc[tn]);
-    }
-}
-
-// stage a wave's 16 x 64 fp32 result tile (C layout) as bf16 into Os[row][GLD] and store 64 rows coalesced
-__device__ __forceinline__ void stage_c_tile(u16* __restrict__ Os, const f32x4 (&acc)[4], int wave, int lane) {
-    const int n = lane & 15, kg = lane >> 4;
-#pragma unroll
-    for (int tn = 0; tn < 4; ++tn)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Os[(wave * 16 + kg * 4 + r) * GLD + tn * 16 + n] = f32_to_bf16(acc[tn][r]);
-}
-__device__ __forceinline__ void store_rows(u16* __restrict__ base, long sn, const int* __restrict__ idx, long p0, int rv,
-                                           const u16* __restrict__ Os, int tid) {
-    const int r = tid >> 2, c = (tid & 3) * 16;
-    if (r < rv) {
-        u16* dst = base + tok_row(idx, p0 + r) * sn + c;
-        *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(Os + r * GLD + c);
-        *reinterpret_cast<uint4*>(dst + 8) = *reinterpret_cast<const uint4*>(Os + r * GLD + c + 8);
-    }
-}
-
-__global__ __launch_bounds__(FT) void k_fs_out(const FsOutArgs a) {
+__global__ __launch_bounds__(FT, 2) void k_fs_out(const FsOutArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    u16* Gt = reinterpret_cast<u16*>(smem_raw);                  // [8][64 d2][72]
-    float* part = reinterpret_cast<float*>(smem_raw + FS_GT_BYTES);   // [4][64] partials of n
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int it = blockIdx.x, bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
+    u16* Gt = reinterpret_cast<u16*>(smem_raw);   // [8][64 d2][72]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, kg = lane >> 4;
+    const int L = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int bh = L / a.njg, it = L - bh * a.njg, b = bh / a.H, h = bh - b * a.H;
     const int S = a.S, M = a.M;
     const u16* qb = (const u16*)a.q.ptr + b * a.q.sb + h * a.q.sh;
     u16* ob = (u16*)a.o.ptr + b * a.o.sb + h * a.o.sh;
-    const u16* state_bh = a.state + (long)bh * a.njg * FE * IT;
+    const float* z_bh = a.z + (long)bh * M * S;
 
-    mix_tile_to_lds<0>(Gt, state_bh, a.njg, a.W, a.ldw, M, it * IT, tid);
+    mix_tile_to_lds<0>(Gt, a.state + (long)bh * a.njg * FE * IT, a.njg, a.W, a.ldw, M, it * IT, tid);
     __syncthreads();
 
-    for (int ii = 0; ii < IT; ++ii) {
-        const int i = it * IT + ii;
-        if (i >= M) break;
-        u16* Gb = Gt + ii * FD * GLD;
+    for (int bi = wave; bi < IT; bi += 4) {
+        const int i = it * IT + bi;
+        if (i >= M) continue;
+        u16* Gb = Gt + bi * FD * GLD;
         for (int c0 = 0; c0 < S; c0 += 64) {
             const long p0 = (long)i * S + c0;
             const int rv = min(64, S - c0);
-            if (a.normalize)
-                part[tid] = wz_partial(a.W + (long)i * a.ldw, 1, a.z + (long)bh * M * S, M, S, c0 + (tid & 63), (tid & 63) < rv, tid >> 6);
-            bf16x8 av[2];
-            const int rvw = rv - wave * 16;
+            bf16x8 av[4][2];
+            if (a.relu) load_a64<true>(av, qb, a.q.sn, a.idx, p0, rv, a.eps, lane);
+            else        load_a64<false>(av, qb, a.q.sn, a.idx, p0, rv, a.eps, lane);
+            float ninv = 1.f;
+            if (a.normalize) ninv = 1.f / (a.eps + col_dot(a.W + (long)i * a.ldw, 1, z_bh, M, S, c0 + lane, lane < rv));
+            f32x4 acc[4][4];
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-                av[ks] = a.relu ? load_a_rows<true>(qb, a.q.sn, a.idx, p0 + wave * 16, rvw, ks * 32, a.eps, lane)
-                                : load_a_rows<false>(qb, a.q.sn, a.idx, p0 + wave * 16, rvw, ks * 32, a.eps, lane);
-            f32x4 acc[4];
+            for (int st = 0; st < 4; ++st)
 #pragma unroll
-            for (int tn = 0; tn < 4; ++tn) acc[tn] = f32x4{0.f, 0.f, 0.f, 0.f};
-            rows_times_gt(acc, av, Gb, lane);
-            __syncthreads();   // partials of n ready; on the last chunk every wave is done reading Gb
-            const bool last = c0 + 64 >= S;
-            // the last chunk stages into this block's (now dead) Gt slot; earlier chunks into the previous block's slot
-            u16* Os = last ? Gb : (ii > 0 ? Gb - FD * GLD : nullptr);
-            const int kg = lane >> 4;
-            if (a.normalize) {
+                for (int tn = 0; tn < 4; ++tn) acc[st][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+            chunk_times_gt<false>(acc, av, Gb, lane);
+#pragma unroll
+            for (int st = 0; st < 4; ++st)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float ni = 1.f / (a.eps + wz_sum(part, wave * 16 + kg * 4 + r));
+                    const float ni = __shfl(ninv, st * 16 + kg * 4 + r, 64);
 #pragma unroll
-                    for (int tn = 0; tn < 4; ++tn) acc[tn][r] *= ni;
+                    for (int tn = 0; tn < 4; ++tn) acc[st][tn][r] *= ni;
                 }
+            if (c0 + 64 >= S) {   // last chunk of the block: its Gt slot is dead for this wave -> staging buffer
+                wave_lds_fence();
+                stage64(Gb, acc, lane);
+                wave_lds_fence();
+                store64<false>(ob, a.o.sn, a.idx, p0, rv, Gb, nullptr, 0, lane);
+            } else {
+                store64_direct<false>(ob, a.o.sn, a.idx, p0, rv, acc, nullptr, 0, lane);
             }
-            if (Os) {
-                stage_c_tile(Os, acc, wave, lane);
-                __syncthreads();
-                store_rows(ob, a.o.sn, a.idx, p0, rv, Os, tid);
-            } else {   // multi-chunk first block: no free slot yet -> direct (narrow) stores
-                const int n = lane & 15;
-#pragma unroll
-                for (int tn = 0; tn < 4; ++tn)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = wave * 16 + kg * 4 + r;
-                        if (row < rv) ob[tok_row(a.idx, p0 + row) * a.o.sn + tn * 16 + n] = f32_to_bf16(acc[tn][r]);
-                    }
-            }
-            __syncthreads();
         }
     }
 }
@@ -473,36 +533,63 @@ __global__ __launch_bounds__(FT) void k_fs_dw(const FsDwArgs a) {
         }
         __syncthreads();
     }
+    // <dn_i, z_j> term (quarter 0): stage dn[64][S<=64 chunk] and z[64][chunk] in LDS as fp32
+    if (qtr == 0 && a.dn) {
+        float* dns = reinterpret_cast<float*>(smem_raw);     // [64][65]
+        float* zs = dns + 64 * 65;                           // [64][65]
+        for (int c0 = 0; c0 < a.S; c0 += 64) {
+            const int rv = min(64, a.S - c0);
+            __syncthreads();
+            for (int v = tid; v < 2 * 64 * 64; v += FT) {
+                const int which = v >> 12, row = (v >> 6) & 63, col = v & 63;
+                float x = 0.f;
+                if (row < M && col < rv) x = (which ? a.z : a.dn)[((long)bh * M + row) * a.S + c0 + col];
+                (which ? zs : dns)[row * 65 + col] = x;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = wave * 16 + kg * 4 + r, j = tn * 16 + n;
+                    float v = 0.f;
+#pragma unroll 4
+                    for (int c = 0; c < 64; ++c) v += dns[i * 65 + c] * zs[j * 65 + c];
+                    acc[tn][r] += v;
+                }
+        }
+    }
     float* out = a.dwp + ((long)bh * 4 + qtr) * 64 * 64;
 #pragma unroll
     for (int tn = 0; tn < 4; ++tn)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int i = wave * 16 + kg * 4 + r, j = tn * 16 + n;
-            float v = acc[tn][r];
-            if (qtr == 0 && a.dn && i < M && j < M) {
-                const float* dr = a.dn + ((long)bh * M + i) * a.S;
-                const float* zr = a.z + ((long)bh * M + j) * a.S;
-                for (int s = 0; s < a.S; ++s) v += dr[s] * zr[s];
-            }
-            out[i * 64 + j] = v;
-        }
+        for (int r = 0; r < 4; ++r) out[(wave * 16 + kg * 4 + r) * 64 + tn * 16 + n] = acc[tn][r];
 }
 
-// dW[i][j] = sum over (bh, quarter) of dWp  (fixed order: deterministic)
-__global__ void k_fs_dw_reduce(const float* __restrict__ dwp, float* __restrict__ dW, int M, int nparts) {
+// Deterministic two-stage reduction of the partials: stage 1 sums groups of DWR_G partials (grid (16, ngroups)),
+// stage 2 (MODE 1) sums the group results into dW[M][M].
+constexpr int DWR_G = 16;
+__global__ void k_fs_dw_reduce1(const float* __restrict__ dwp, float* __restrict__ tmp, int nparts) {
+    const int e = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y;
+    float s = 0.f;
+    const int p1 = min(nparts, (g + 1) * DWR_G);
+#pragma unroll 4
+    for (int p = g * DWR_G; p < p1; ++p) s += dwp[(long)p * 4096 + e];
+    tmp[(long)g * 4096 + e] = s;
+}
+__global__ void k_fs_dw_reduce2(const float* __restrict__ tmp, float* __restrict__ dW, int M, int ngroups) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= M * M) return;
     const int i = e / M, j = e - i * M;
     float s = 0.f;
-    for (int p = 0; p < nparts; ++p) s += dwp[(long)p * 4096 + i * 64 + j];
+    for (int g = 0; g < ngroups; ++g) s += tmp[(long)g * 4096 + i * 64 + j];
     dW[(long)i * M + j] = s;
 }
 
 // -------------------------------------------------------------------------------------------------
-// k_fs_bwd_tok: per (tile jg, bh):
-//   phase 1: Gt = mix(W, KV)        -> dQ_j = (dO_j G_j^T) / n_j + dz_j (x) ksum_j     (relu mask)
-//   phase 2: Gt = mix(W^T, dG)      -> dK_j = V_j dKV_j^T + 1 dksum_j^T (relu mask) ; dV_j = K_j dKV_j
+// k_fs_bwd_tok: per (tile jg, bh); mixing by all 4 waves, then each wave owns 2 blocks (no block barriers):
+//   phase 1: Gt = mix(W, KV)    -> dQ_j = (dO_j G_j^T) / n_j + dz_j (x) ksum_j  (relu mask) ; dksum_j
+//   phase 2: Gt = mix(W^T, dG)  -> dK_j = V_j dKV_j^T + 1 dksum_j^T (relu mask) ; dV_j = K_j dKV_j
 // -------------------------------------------------------------------------------------------------
 struct FsTokArgs {
     View q, k, v, dout;
@@ -515,183 +602,201 @@ struct FsTokArgs {
     const float* z;
     const float* dn;
     const float* ksum;
+    float* dksum;       // [bh][M][64]: written by k_fs_bwd_dq, read by k_fs_bwd_dkv
     int H, M, S, njg;
     float eps;
     int relu, normalize;
 };
-constexpr int FS_TOK_SMEM = FS_GT_BYTES + (256 + 256 + 64 + 64 + 256) * 4;
+constexpr int FS_TOK_SMEM = FS_GT_BYTES;
 
-__global__ __launch_bounds__(FT) void k_fs_bwd_tok(const FsTokArgs a) {
+__global__ __launch_bounds__(FT, 2) void k_fs_bwd_dq(const FsTokArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u16* Gt = reinterpret_cast<u16*>(smem_raw);
-    float* pn = reinterpret_cast<float*>(smem_raw + FS_GT_BYTES);     // [4][64] partials of n
-    float* pz = pn + 256;                                             // [4][64] partials of dz
-    float* ksum_s = pz + 256;                                         // [64]
-    float* dks = ksum_s + 64;                                         // [64]
-    float* part = dks + 64;                                           // [4 waves][64] dksum partials
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 15, kg = lane >> 4;
-    part[tid] = 0.f;
-    const int jgx = blockIdx.x, bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
+    const int L = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int bh = L / a.njg, jgx = L - bh * a.njg, b = bh / a.H, h = bh - b * a.H;
     const int S = a.S, M = a.M;
     auto base = [&](const View& w) { return (const u16*)w.ptr + b * w.sb + h * w.sh; };
     auto mbase = [&](const MView& w) { return (u16*)w.ptr + b * w.sb + h * w.sh; };
-    const u16 *qb = base(a.q), *kb = base(a.k), *vb = base(a.v), *gb = base(a.dout);
-    u16 *dqb = mbase(a.dq), *dkb = mbase(a.dk), *dvb = mbase(a.dv);
+    const u16 *qb = base(a.q), *gb = base(a.dout);
+    u16* dqb = mbase(a.dq);
     const long sofs = (long)bh * a.njg * FE * IT;
     const float* z_bh = a.z + (long)bh * M * S;
     const float* dn_bh = a.dn + (long)bh * M * S;
 
-    // ---------------- phase 1: dQ ----------------
+    // ---------------- phase 1: dQ, dksum ----------------
     mix_tile_to_lds<0>(Gt, a.state + sofs, a.njg, a.W, a.ldw, M, jgx * IT, tid);
     __syncthreads();
-    // dksum per block is accumulated here and kept for phase 2 in registers of threads < 64 (8 blocks)
-    float dks_keep[IT];
-#pragma unroll
-    for (int jj = 0; jj < IT; ++jj) dks_keep[jj] = 0.f;
-#pragma unroll
-    for (int jj = 0; jj < IT; ++jj) {
-        const int j = jgx * IT + jj;
+    for (int bi = wave; bi < IT; bi += 4) {
+        const int j = jgx * IT + bi;
         if (j >= M) continue;
-        u16* Gb = Gt + jj * FD * GLD;
-        if (tid < 64) ksum_s[tid] = a.normalize ? a.ksum[((long)bh * M + j) * 64 + tid] : 0.f;
+        u16* Gb = Gt + bi * FD * GLD;
+        const float ksum_l = a.normalize ? a.ksum[((long)bh * M + j) * 64 + lane] : 0.f;   // lane = column d1
+        float dks_acc[2][8];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int t = 0; t < 8; ++t) dks_acc[ks][t] = 0.f;
         for (int c0 = 0; c0 < S; c0 += 64) {
             const long p0 = (long)j * S + c0;
-            const int rv = min(64, S - c0), rvw = rv - wave * 16;
+            const int rv = min(64, S - c0);
+            bf16x8 gv[4][2];
+            load_a64<false>(gv, gb, a.dout.sn, a.idx, p0, rv, 0.f, lane);
+            float ninv = 1.f, dzv = 0.f;
             if (a.normalize) {
-                const bool ok = (tid & 63) < rv;
-                pn[tid] = wz_partial(a.W + (long)j * a.ldw, 1, z_bh, M, S, c0 + (tid & 63), ok, tid >> 6);
-                pz[tid] = wz_partial(a.W + j, a.ldw, dn_bh, M, S, c0 + (tid & 63), ok, tid >> 6);
+                ninv = 1.f / (a.eps + col_dot(a.W + (long)j * a.ldw, 1, z_bh, M, S, c0 + lane, lane < rv));
+                dzv = col_dot(a.W + j, a.ldw, dn_bh, M, S, c0 + lane, lane < rv);
             }
-            bf16x8 av[2], qv[2];
+            f32x4 acc[4][4];
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                av[ks] = load_a_rows<false>(gb, a.dout.sn, a.idx, p0 + wave * 16, rvw, ks * 32, 0.f, lane);
-                qv[ks] = a.relu ? load_a_rows<true>(qb, a.q.sn, a.idx, p0 + wave * 16, rvw, ks * 32, a.eps, lane)
-                                : load_a_rows<false>(qb, a.q.sn, a.idx, p0 + wave * 16, rvw, ks * 32, a.eps, lane);
-            }
-            f32x4 acc[4];
+            for (int st = 0; st < 4; ++st)
 #pragma unroll
-            for (int tn = 0; tn < 4; ++tn) acc[tn] = f32x4{0.f, 0.f, 0.f, 0.f};
-            rows_times_gt_t(acc, av, Gb, lane);      // (dO G^T)[s][d1] : B[k = d2][n = d1] = Gt[d2][d1]
-            __syncthreads();                         // partials ready; all waves done with Gb on the last chunk
-            // dksum[d] += sum_s dz[s] q[s][d] : lane holds q[row = 16 wave + n][cols ks*32 + 8 kg ..]
+                for (int tn = 0; tn < 4; ++tn) acc[st][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+            chunk_times_gt<true>(acc, gv, Gb, lane);   // (dO G^T)[s][d1] : B[k = d2][n = d1] = Gt[d2][d1]
+            __builtin_amdgcn_sched_barrier(0);         // keep the q loads below the MFMAs (register pressure)
             if (a.normalize) {
-                const float dzr = wz_sum(pz, wave * 16 + n);
+                bf16x8 qv[4][2];
+                if (a.relu) load_a64<true>(qv, qb, a.q.sn, a.idx, p0, rv, a.eps, lane);
+                else        load_a64<false>(qv, qb, a.q.sn, a.idx, p0, rv, a.eps, lane);
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    const s16x8 qs = __builtin_bit_cast(s16x8, qv[ks]);
+                for (int st = 0; st < 4; ++st) {
+                    const float dzr = __shfl(dzv, st * 16 + n, 64);
 #pragma unroll
-                    for (int t = 0; t < 8; ++t) {
-                        float v = dzr * bf((u16)qs[t]);
-                        v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64);
-                        v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-                        if (n == 0) part[wave * 64 + ks * 32 + kg * 8 + t] += v;
+                    for (int ks = 0; ks < 2; ++ks) {
+                        const s16x8 qs = __builtin_bit_cast(s16x8, qv[st][ks]);
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) dks_acc[ks][t] += dzr * bf((u16)qs[t]);
                     }
                 }
-            }
-            const bool last = c0 + 64 >= S;
-            u16* Os = last ? Gb : (jj > 0 ? Gb - FD * GLD : nullptr);
-            // epilogue in C layout: row s = 16 wave + 4 kg + r, col d1 = 16 tn + n
-            if (a.normalize) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = wave * 16 + kg * 4 + r;
-                    const float ni = 1.f / (a.eps + wz_sum(pn, row)), dzr = wz_sum(pz, row);
-#pragma unroll
-                    for (int tn = 0; tn < 4; ++tn) acc[tn][r] = acc[tn][r] * ni + dzr * ksum_s[tn * 16 + n];
-                }
-            }
-            if (a.relu) {   // mask by q > 0: re-read q in C layout from global (L1/L2 hot)
-#pragma unroll
-                for (int tn = 0; tn < 4; ++tn)
+                for (int st = 0; st < 4; ++st)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int row = wave * 16 + kg * 4 + r;
-                        if (row < rv && !(bf(qb[tok_row(a.idx, p0 + row) * a.q.sn + tn * 16 + n]) > 0.f)) acc[tn][r] = 0.f;
+                        const int row = st * 16 + kg * 4 + r;
+                        const float ni = __shfl(ninv, row, 64), dzr = __shfl(dzv, row, 64);
+#pragma unroll
+                        for (int tn = 0; tn < 4; ++tn) acc[st][tn][r] = acc[st][tn][r] * ni + dzr * __shfl(ksum_l, tn * 16 + n, 64);
                     }
             }
-            if (Os) {
-                stage_c_tile(Os, acc, wave, lane);
-                __syncthreads();
-                store_rows(dqb, a.dq.sn, a.idx, p0, rv, Os, tid);
+            if (c0 + 64 >= S) {
+                wave_lds_fence();
+                stage64(Gb, acc, lane);
+                wave_lds_fence();
+                if (a.relu) store64<true>(dqb, a.dq.sn, a.idx, p0, rv, Gb, qb, a.q.sn, lane);
+                else        store64<false>(dqb, a.dq.sn, a.idx, p0, rv, Gb, nullptr, 0, lane);
             } else {
-#pragma unroll
-                for (int tn = 0; tn < 4; ++tn)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = wave * 16 + kg * 4 + r;
-                        if (row < rv) dqb[tok_row(a.idx, p0 + row) * a.dq.sn + tn * 16 + n] = f32_to_bf16(acc[tn][r]);
-                    }
+                if (a.relu) store64_direct<true>(dqb, a.dq.sn, a.idx, p0, rv, acc, qb, a.q.sn, lane);
+                else        store64_direct<false>(dqb, a.dq.sn, a.idx, p0, rv, acc, nullptr, 0, lane);
             }
-            __syncthreads();
         }
-        if (a.normalize) {
-            if (tid < 64) {
-                dks_keep[jj] = part[tid] + part[64 + tid] + part[128 + tid] + part[192 + tid];
+        // dksum[col]: reduce the per-lane partials over the 16 rows-lanes (n), columns = 32 ks + 8 kg + t
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                float v = dks_acc[ks][t];
+                v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64);
+                v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+                if (n == 0) a.dksum[((long)bh * M + j) * 64 + ks * 32 + kg * 8 + t] = v;
             }
-            __syncthreads();
-        }
-        if (tid < 256) part[tid] = 0.f;
-        __syncthreads();
     }
 
-    // ---------------- phase 2: dK, dV ----------------
-    __syncthreads();
+}
+
+__global__ __launch_bounds__(FT, 2) void k_fs_bwd_dkv(const FsTokArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u16* Gt = reinterpret_cast<u16*>(smem_raw);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 15, kg = lane >> 4;
+    const int L = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int bh = L / a.njg, jgx = L - bh * a.njg, b = bh / a.H, h = bh - b * a.H;
+    const int S = a.S, M = a.M;
+    auto base = [&](const View& w) { return (const u16*)w.ptr + b * w.sb + h * w.sh; };
+    auto mbase = [&](const MView& w) { return (u16*)w.ptr + b * w.sb + h * w.sh; };
+    const u16 *kb = base(a.k), *vb = base(a.v);
+    u16 *dkb = mbase(a.dk), *dvb = mbase(a.dv);
+    const long sofs = (long)bh * a.njg * FE * IT;
     mix_tile_to_lds<1>(Gt, a.dstate + sofs, a.njg, a.W, a.ldw, M, jgx * IT, tid);
     __syncthreads();
-#pragma unroll
-    for (int jj = 0; jj < IT; ++jj) {
-        const int j = jgx * IT + jj;
+    for (int bi = wave; bi < IT; bi += 4) {
+        const int j = jgx * IT + bi;
         if (j >= M) continue;
-        u16* Gb = Gt + jj * FD * GLD;
-        if (tid < 64) dks[tid] = dks_keep[jj];
+        u16* Gb = Gt + bi * FD * GLD;
         for (int c0 = 0; c0 < S; c0 += 64) {
             const long p0 = (long)j * S + c0;
-            const int rv = min(64, S - c0), rvw = rv - wave * 16;
-            bf16x8 vv[2], kv[2];
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                vv[ks] = load_a_rows<false>(vb, a.v.sn, a.idx, p0 + wave * 16, rvw, ks * 32, 0.f, lane);
-                kv[ks] = a.relu ? load_a_rows<true>(kb, a.k.sn, a.idx, p0 + wave * 16, rvw, ks * 32, a.eps, lane)
-                                : load_a_rows<false>(kb, a.k.sn, a.idx, p0 + wave * 16, rvw, ks * 32, a.eps, lane);
-            }
-            f32x4 accK[4], accV[4];
-#pragma unroll
-            for (int tn = 0; tn < 4; ++tn) accK[tn] = accV[tn] = f32x4{0.f, 0.f, 0.f, 0.f};
-            rows_times_gt_t(accK, vv, Gb, lane);   // dK[s][d1] = sum_d2 V[s][d2] dKVt[d2][d1]
-            rows_times_gt(accV, kv, Gb, lane);     // dV[s][d2] = sum_d1 K[s][d1] dKVt[d2][d1]
-            __syncthreads();
+            const int rv = min(64, S - c0);
             const bool last = c0 + 64 >= S;
-            u16* Os = last ? Gb : (jj > 0 ? Gb - FD * GLD : nullptr);
+            // dV first, kept packed as bf16 pairs while dK is computed (both need the intact Gb)
+            unsigned pv[4][4][2];
+            {
+                f32x4 accV[4][4];
 #pragma unroll
-            for (int tn = 0; tn < 4; ++tn)
+                for (int st = 0; st < 4; ++st)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = wave * 16 + kg * 4 + r;
-                    accK[tn][r] += dks[tn * 16 + n];
-                    if (a.relu && row < rv && !(bf(kb[tok_row(a.idx, p0 + row) * a.k.sn + tn * 16 + n]) > 0.f)) accK[tn][r] = 0.f;
+                    for (int tn = 0; tn < 4; ++tn) accV[st][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+                bf16x8 kv[4][2];
+                if (a.relu) load_a64<true>(kv, kb, a.k.sn, a.idx, p0, rv, a.eps, lane);
+                else        load_a64<false>(kv, kb, a.k.sn, a.idx, p0, rv, a.eps, lane);
+                chunk_times_gt<false>(accV, kv, Gb, lane);   // dV[s][d2] = sum_d1 K[s][d1] dKVt[d2][d1]
+#pragma unroll
+                for (int st = 0; st < 4; ++st)
+#pragma unroll
+                    for (int tn = 0; tn < 4; ++tn) {
+                        pv[st][tn][0] = (unsigned)f32_to_bf16(accV[st][tn][0]) | ((unsigned)f32_to_bf16(accV[st][tn][1]) << 16);
+                        pv[st][tn][1] = (unsigned)f32_to_bf16(accV[st][tn][2]) | ((unsigned)f32_to_bf16(accV[st][tn][3]) << 16);
+                    }
+            }
+            f32x4 accK[4][4];
+#pragma unroll
+            for (int st = 0; st < 4; ++st)
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn) accK[st][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+            {
+                bf16x8 vv[4][2];
+                load_a64<false>(vv, vb, a.v.sn, a.idx, p0, rv, 0.f, lane);
+                chunk_times_gt<true>(accK, vv, Gb, lane);    // dK[s][d1] = sum_d2 V[s][d2] dKVt[d2][d1]
+            }
+            if (a.normalize) {
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn) {
+                    const float dk = a.dksum[((long)bh * M + j) * 64 + tn * 16 + n];
+#pragma unroll
+                    for (int st = 0; st < 4; ++st)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) accK[st][tn][r] += dk;
                 }
-            if (Os) {
-                stage_c_tile(Os, accK, wave, lane);
-                __syncthreads();
-                store_rows(dkb, a.dk.sn, a.idx, p0, rv, Os, tid);
-                __syncthreads();
-                stage_c_tile(Os, accV, wave, lane);
-                __syncthreads();
-                store_rows(dvb, a.dv.sn, a.idx, p0, rv, Os, tid);
-            } else {
+            }
+            if (last) {
+                wave_lds_fence();
+                stage64(Gb, accK, lane);
+                wave_lds_fence();
+                if (a.relu) store64<true>(dkb, a.dk.sn, a.idx, p0, rv, Gb, kb, a.k.sn, lane);
+                else        store64<false>(dkb, a.dk.sn, a.idx, p0, rv, Gb, nullptr, 0, lane);
+                wave_lds_fence();
 #pragma unroll
-                for (int tn = 0; tn < 4; ++tn)
+                for (int st = 0; st < 4; ++st)
+#pragma unroll
+                    for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            Gb[(st * 16 + kg * 4 + r) * GLD + tn * 16 + n] = (u16)(pv[st][tn][r >> 1] >> ((r & 1) * 16));
+                wave_lds_fence();
+                store64<false>(dvb, a.dv.sn, a.idx, p0, rv, Gb, nullptr, 0, lane);
+            } else {
+                if (a.relu) store64_direct<true>(dkb, a.dk.sn, a.idx, p0, rv, accK, kb, a.k.sn, lane);
+                else        store64_direct<false>(dkb, a.dk.sn, a.idx, p0, rv, accK, nullptr, 0, lane);
+#pragma unroll
+                for (int st = 0; st < 4; ++st)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int row = wave * 16 + kg * 4 + r;
+                        const int row = st * 16 + kg * 4 + r;
                         if (row < rv) {
-                            dkb[tok_row(a.idx, p0 + row) * a.dk.sn + tn * 16 + n] = f32_to_bf16(accK[tn][r]);
-                            dvb[tok_row(a.idx, p0 + row) * a.dv.sn + tn * 16 + n] = f32_to_bf16(accV[tn][r]);
+                            const long tr = tok_row(a.idx, p0 + row);
+#pragma unroll
+                            for (int tn = 0; tn < 4; ++tn)
+                                dvb[tr * a.dv.sn + tn * 16 + n] = (u16)(pv[st][tn][r >> 1] >> ((r & 1) * 16));
                         }
                     }
             }
-            __syncthreads();
         }
     }
 }

@@ -84,13 +84,13 @@ class _BlockMix(torch.autograd.Function):
         Wf = W.detach().reshape(M, M).to(torch.float32).contiguous()
         out = torch.empty((B, N, H, D), dtype=q.dtype, device=q.device)
         dt = _dtype_code(q)
-        ws = _ws(lib.mhla_blockmix_fwd_ws_bytes(B, H, M, S, D, dt, int(split)), q.device)
+        flags = (_lib.FLAG_RELU_EPS if relu_eps else 0) | (_lib.FLAG_FORCE_GENERIC if force_generic else 0)
+        ws = _ws(lib.mhla_blockmix_fwd_ws_bytes(B, H, M, S, D, dt, int(split), flags), q.device)
         qv, kv = _view(q), _view(k)
         if normalize:
             qd, kd = (_view(q_den), _view(k_den)) if split else (qv, kv)
         else:
             qd, kd = NULL_VIEW, NULL_VIEW
-        flags = (_lib.FLAG_RELU_EPS if relu_eps else 0) | (_lib.FLAG_FORCE_GENERIC if force_generic else 0)
         idx_ptr = block_index.data_ptr() if block_index is not None else None
         rc = lib.mhla_blockmix_fwd(qv, kv, _view(v), qd, kd, Wf.data_ptr(), M, _view(out), idx_ptr,
                                    ws.data_ptr(), ws.numel() * 4, B, H, M, S, D, dt, float(eps), flags, _stream())
@@ -120,13 +120,13 @@ class _BlockMix(torch.autograd.Function):
         if split:
             dqd, dkd = torch.empty_like(dq), torch.empty_like(dq)
         dt = _dtype_code(q)
-        ws = _ws(lib.mhla_blockmix_bwd_ws_bytes(B, H, M, S, D, dt, int(split)), q.device)
+        flags = (_lib.FLAG_RELU_EPS if relu_eps else 0) | (_lib.FLAG_FORCE_GENERIC if force_generic else 0)
+        ws = _ws(lib.mhla_blockmix_bwd_ws_bytes(B, H, M, S, D, dt, int(split), flags), q.device)
         qv, kv = _view(q), _view(k)
         if normalize:
             qd, kd = (_view(q_den), _view(k_den)) if split else (qv, kv)
         else:
             qd, kd = NULL_VIEW, NULL_VIEW
-        flags = (_lib.FLAG_RELU_EPS if relu_eps else 0) | (_lib.FLAG_FORCE_GENERIC if force_generic else 0)
         idx_ptr = block_index.data_ptr() if block_index is not None else None
         rc = lib.mhla_blockmix_bwd(qv, kv, _view(v), qd, kd, Wf.data_ptr(), M, _view(out), _view(dout),
                                    _view(dq), _view(dk), _view(dv),

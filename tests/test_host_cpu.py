@@ -23,9 +23,9 @@ def test_library_builds_and_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/mhla_hip.h but not exported"
     assert lib.mhla_abi_version() == 2
     # workspace sizing is pure host arithmetic: callable without a GPU
-    fwd = lib.mhla_blockmix_fwd_ws_bytes(8, 16, 64, 64, 64, 0, 0)
-    bwd = lib.mhla_blockmix_bwd_ws_bytes(8, 16, 64, 64, 64, 0, 0)
-    assert lib.mhla_blockmix_fwd_ws_bytes(8, 16, 64, 64, 64, 1, 0) < fwd   # bf16 fast path: compact summaries
+    fwd = lib.mhla_blockmix_fwd_ws_bytes(8, 16, 64, 64, 64, 0, 0, 0)
+    bwd = lib.mhla_blockmix_bwd_ws_bytes(8, 16, 64, 64, 64, 0, 0, 0)
+    assert lib.mhla_blockmix_fwd_ws_bytes(8, 16, 64, 64, 64, 1, 0, 0) < fwd   # bf16 fast path: compact summaries
     assert 0 < fwd < bwd
     assert lib.mhla_causal_bwd_ws_bytes(1, 8192, 4, 128, 256, 64) > lib.mhla_causal_fwd_ws_bytes(1, 8192, 4, 128, 256, 64) > 0
 
