@@ -121,7 +121,7 @@ BmWs bm_carve(void* ws, int B, int H, int M, int S, int D) {
 // ---- fast path (bf16, D = 64, M <= 64, q_den aliasing q_num): see fused.cuh ----
 struct FastWs {
     fast::u16 *state, *dstate;
-    float *z, *ksum, *dn, *dwp, *dwt, *dksum;
+    float *z, *ksum, *ninv, *dn, *dz, *dwp, *dwt, *dksum;
     size_t total_fwd, total_bwd;
     int njg;
 };
@@ -134,12 +134,14 @@ FastWs fast_carve(void* ws, int B, int H, int M, int S) {
     w.state = (fast::u16*)p; p += st;
     w.z = (float*)p; p += al4(bh * M * S) * 4;
     w.ksum = (float*)p; p += al4(bh * M * 64) * 4;
+    w.ninv = (float*)p; p += al4(bh * M * S) * 4;
     w.total_fwd = (size_t)(p - (char*)ws);
     w.dstate = (fast::u16*)p; p += st;
     w.dn = (float*)p; p += al4(bh * M * S) * 4;
+    w.dz = (float*)p; p += al4(bh * M * S) * 4;
     w.dksum = (float*)p; p += al4(bh * M * 64) * 4;
-    w.dwp = (float*)p; p += bh * 4 * 4096 * 4;
-    w.dwt = (float*)p; p += ((bh * 4 + fast::DWR_G - 1) / fast::DWR_G) * 4096 * 4;
+    w.dwp = (float*)p; p += bh * fast::DW_SPLIT * 4096 * 4;
+    w.dwt = (float*)p; p += ((bh * fast::DW_SPLIT + fast::DWR_G - 1) / fast::DWR_G) * 4096 * 4;
     w.total_bwd = (size_t)(p - (char*)ws);
     return w;
 }
@@ -300,8 +302,10 @@ int mhla_blockmix_fwd(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q
         sa.x = cv(k_num); sa.y = cv(v); sa.t = cv(q_num); sa.idx = block_index; sa.state = f.state; sa.ksum = f.ksum;
         sa.z_out = f.z; sa.H = H; sa.M = M; sa.S = S; sa.eps = eps; sa.relu = relu; sa.normalize = normalize;
         RC(launch(fast::k_fs_state<0>, dim3(f.njg, B * H), dim3(fast::FT), fast::FS_STATE_SMEM, st, "k_fs_state<0>", sa));
+        if (normalize)
+            RC(launch(fast::k_fs_wz<0>, dim3((S + 63) / 64, B * H), dim3(fast::FT), 0, st, "k_fs_wz<0>", W, ldw, (const float*)f.z, f.ninv, M, S, eps));
         fast::FsOutArgs oa{};
-        oa.q = cv(q_num); oa.o = cmv(out); oa.idx = block_index; oa.W = W; oa.ldw = ldw; oa.state = f.state; oa.z = f.z;
+        oa.q = cv(q_num); oa.o = cmv(out); oa.idx = block_index; oa.W = W; oa.ldw = ldw; oa.state = f.state; oa.ninv = f.ninv;
         oa.H = H; oa.M = M; oa.S = S; oa.njg = f.njg; oa.eps = eps; oa.relu = relu; oa.normalize = normalize;
         RC(launch(fast::k_fs_out, dim3(f.njg * B * H), dim3(fast::FT), fast::FS_OUT_SMEM, st, "k_fs_out", oa));
         return MHLA_OK;
@@ -347,29 +351,33 @@ int mhla_blockmix_bwd(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q
             const FastWs f = fast_carve(ws, B, H, M, S);
             if (ws_bytes < f.total_bwd) return fail(MHLA_EINVAL, "workspace too small: %zu < %zu bytes", ws_bytes, f.total_bwd);
             const fast::u16* state = f.state;
-            const float *z = f.z, *ksum = f.ksum;
-            if (fwd_ws) {   // forward workspace retained by the caller: reuse KV^T, z, ksum
+            const float *z = f.z, *ksum = f.ksum, *ninv = f.ninv;
+            if (fwd_ws) {   // forward workspace retained by the caller: reuse KV^T, z, ksum, 1/n
                 const FastWs ff = fast_carve(const_cast<void*>(fwd_ws), B, H, M, S);
-                state = ff.state; z = ff.z; ksum = ff.ksum;
+                state = ff.state; z = ff.z; ksum = ff.ksum; ninv = ff.ninv;
             } else {
                 fast::FsStateArgs sa{};
                 sa.x = cv(k_num); sa.y = cv(v); sa.t = cv(q_num); sa.idx = block_index; sa.state = f.state; sa.ksum = f.ksum;
                 sa.z_out = f.z; sa.H = H; sa.M = M; sa.S = S; sa.eps = eps; sa.relu = relu; sa.normalize = normalize;
                 RC(launch(fast::k_fs_state<0>, dim3(f.njg, B * H), dim3(fast::FT), fast::FS_STATE_SMEM, st, "k_fs_state<0>", sa));
+                if (normalize)
+                    RC(launch(fast::k_fs_wz<0>, dim3((S + 63) / 64, B * H), dim3(fast::FT), 0, st, "k_fs_wz<0>", W, ldw, (const float*)f.z, f.ninv, M, S, eps));
             }
             fast::FsStateArgs ga{};
-            ga.x = cv(q_num); ga.y = cv(dout); ga.t = cv(out); ga.idx = block_index; ga.W = W; ga.ldw = ldw; ga.z_in = z;
+            ga.x = cv(q_num); ga.y = cv(dout); ga.t = cv(out); ga.idx = block_index; ga.W = W; ga.ldw = ldw; ga.ninv = ninv;
             ga.state = f.dstate; ga.dn = f.dn; ga.H = H; ga.M = M; ga.S = S; ga.eps = eps; ga.relu = relu; ga.normalize = normalize;
             RC(launch(fast::k_fs_state<1>, dim3(f.njg, B * H), dim3(fast::FT), fast::FS_STATE_SMEM, st, "k_fs_state<1>", ga));
             fast::FsDwArgs da{f.dstate, state, normalize ? f.dn : nullptr, z, f.dwp, M, S, f.njg};
-            RC(launch(fast::k_fs_dw, dim3(4, B * H), dim3(fast::FT), fast::FS_DW_SMEM, st, "k_fs_dw", da));
-            const int nparts = B * H * 4, ngroups = (nparts + fast::DWR_G - 1) / fast::DWR_G;
+            if (normalize)
+                RC(launch(fast::k_fs_wz<1>, dim3((S + 63) / 64, B * H), dim3(fast::FT), 0, st, "k_fs_wz<1>", W, ldw, (const float*)f.dn, f.dz, M, S, 0.f));
+            RC(launch(fast::k_fs_dw, dim3(fast::DW_SPLIT, B * H), dim3(fast::FT), fast::FS_DW_SMEM, st, "k_fs_dw", da));
+            const int nparts = B * H * fast::DW_SPLIT, ngroups = (nparts + fast::DWR_G - 1) / fast::DWR_G;
             RC(launch(fast::k_fs_dw_reduce1, dim3(16, ngroups), dim3(256), 0, st, "k_fs_dw_reduce1", (const float*)f.dwp, f.dwt, nparts));
             RC(launch(fast::k_fs_dw_reduce2, dim3((M * M + 255) / 256), dim3(256), 0, st, "k_fs_dw_reduce2", (const float*)f.dwt, dW, M, ngroups));
             fast::FsTokArgs ta{};
             ta.q = cv(q_num); ta.k = cv(k_num); ta.v = cv(v); ta.dout = cv(dout); ta.dq = cmv(dq_num); ta.dk = cmv(dk_num);
-            ta.dv = cmv(dv); ta.idx = block_index; ta.W = W; ta.ldw = ldw; ta.state = state; ta.dstate = f.dstate; ta.z = z;
-            ta.dn = f.dn; ta.ksum = ksum; ta.H = H; ta.M = M; ta.S = S; ta.njg = f.njg; ta.eps = eps; ta.relu = relu;
+            ta.dv = cmv(dv); ta.idx = block_index; ta.W = W; ta.ldw = ldw; ta.state = state; ta.dstate = f.dstate; ta.ninv = ninv;
+            ta.dz = f.dz; ta.ksum = ksum; ta.H = H; ta.M = M; ta.S = S; ta.njg = f.njg; ta.eps = eps; ta.relu = relu;
             ta.normalize = normalize;
             ta.dksum = f.dksum;
             RC(launch(fast::k_fs_bwd_dq, dim3(f.njg * B * H), dim3(fast::FT), fast::FS_TOK_SMEM, st, "k_fs_bwd_dq", ta));

@@ -97,6 +97,35 @@ __device__ __forceinline__ float wz_sum(const float* __restrict__ part, int row)
 }
 
 // -------------------------------------------------------------------------------------------------
+// k_fs_wz: the two small [M x M] x [M x S] products per (b,h), done once instead of per consumer wave:
+//   MODE 0: ninv[i][s] = 1 / (eps + sum_j W[i][j] z[j][s])         (normaliser, mhla.py:266)
+//   MODE 1: dz[j][s]   = sum_i W[i][j] dn[i][s]
+// grid (ceil(S / 64), bh), M <= 64.
+// -------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(FT) void k_fs_wz(const float* __restrict__ W, int ldw, const float* __restrict__ x,
+                                              float* __restrict__ out, int M, int S, float eps) {
+    __shared__ float Ws[64 * 65];
+    __shared__ float xs[64 * 64];
+    const int tid = threadIdx.x, c0 = blockIdx.x * 64, bh = blockIdx.y, rv = min(64, S - c0);
+    for (int v = tid; v < 64 * 64; v += FT) {
+        const int r = v >> 6, c = v & 63;
+        float w = 0.f;
+        if (r < M && c < M) w = MODE ? W[(long)c * ldw + r] : W[(long)r * ldw + c];
+        Ws[r * 65 + c] = w;
+        xs[r * 64 + c] = (r < M && c < rv) ? x[((long)bh * M + r) * S + c0 + c] : 0.f;
+    }
+    __syncthreads();
+    const int sc = tid & 63;
+    for (int r = tid >> 6; r < M; r += 4) {
+        float acc = 0.f;
+#pragma unroll 8
+        for (int c = 0; c < 64; ++c) acc += Ws[r * 65 + c] * xs[c * 64 + sc];
+        if (sc < rv) out[((long)bh * M + r) * S + c0 + sc] = MODE ? acc : 1.f / (eps + acc);
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
 // k_fs_state: per (block group jg, bh): 8 block summaries in the interleaved transposed layout.
 //   MODE 0 (forward) : state = V_j^T K_j ; ksum_j ; z_j[s] = Q_j[s] . ksum_j
 //   MODE 1 (backward): state = dP_i^T Q_i with dP = dO / n ; dn_i[s] = -(dO_i[s] . O_i[s]) / n_i[s]
@@ -108,7 +137,7 @@ struct FsStateArgs {
     const int* idx;
     const float* W;
     int ldw;
-    const float* z_in;   // MODE 1: [bh][M][S]
+    const float* ninv;   // MODE 1: [bh][M][S]  1 / n  (k_fs_wz<0>)
     u16* state;          // [bh][njg][4096][8]
     float* ksum;         // MODE 0: [bh][M][64]
     float* z_out;        // MODE 0: [bh][M][S]
@@ -118,6 +147,8 @@ struct FsStateArgs {
     int relu, normalize;
 };
 constexpr int FS_STATE_SMEM = 3 * 64 * TLD * 2 + (4 * 64 + 64) * 4;
+
+struct TileRegs { uint4 x0, x1, y0, y1, t0, t1; };
 
 template <int MODE>
 __global__ __launch_bounds__(FT) void k_fs_state(const FsStateArgs a) {
@@ -134,12 +165,55 @@ __global__ __launch_bounds__(FT) void k_fs_state(const FsStateArgs a) {
     const u16* yb = (const u16*)a.y.ptr + b * a.y.sb + h * a.y.sh;
     const u16* tb = a.normalize ? (const u16*)a.t.ptr + b * a.t.sb + h * a.t.sh : nullptr;
     const bool single = S <= 64;
+    const int srow = tid >> 2, scol = (tid & 3) * 16;        // staging: thread -> (row, 16 columns)
+
+    // global -> registers for one 64-row chunk (rows >= rv give zeros); registers -> LDS separately so that
+    // the next chunk's loads are in flight while the current one is being multiplied
+    auto issue = [&](long p, int rv, bool with_t, TileRegs& R) {
+        const uint4 zero = make_uint4(0, 0, 0, 0);
+        R.x0 = R.x1 = R.y0 = R.y1 = R.t0 = R.t1 = zero;
+        if (srow < rv) {
+            const long tr = tok_row(a.idx, p + srow);
+            const u16* px = xb + tr * a.x.sn + scol;
+            const u16* py = yb + tr * a.y.sn + scol;
+            R.x0 = *reinterpret_cast<const uint4*>(px);
+            R.x1 = *reinterpret_cast<const uint4*>(px + 8);
+            R.y0 = *reinterpret_cast<const uint4*>(py);
+            R.y1 = *reinterpret_cast<const uint4*>(py + 8);
+            if (with_t) {
+                const u16* pt = tb + tr * a.t.sn + scol;
+                R.t0 = *reinterpret_cast<const uint4*>(pt);
+                R.t1 = *reinterpret_cast<const uint4*>(pt + 8);
+            }
+        }
+    };
+    auto commit = [&](const TileRegs& R, int rv, int rfill, bool with_t) {
+        if (srow < rfill) {
+            uint4 x0 = R.x0, x1 = R.x1, t0 = R.t0, t1 = R.t1;
+            if (a.relu && srow < rv) {
+                x0 = relu_eps8(x0, a.eps); x1 = relu_eps8(x1, a.eps);
+                if (MODE == 0 && with_t) { t0 = relu_eps8(t0, a.eps); t1 = relu_eps8(t1, a.eps); }
+            }
+            *reinterpret_cast<uint4*>(Xs + srow * TLD + scol) = x0;
+            *reinterpret_cast<uint4*>(Xs + srow * TLD + scol + 8) = x1;
+            *reinterpret_cast<uint4*>(Ys + srow * TLD + scol) = R.y0;
+            *reinterpret_cast<uint4*>(Ys + srow * TLD + scol + 8) = R.y1;
+            if (with_t) {
+                *reinterpret_cast<uint4*>(Ts + srow * TLD + scol) = t0;
+                *reinterpret_cast<uint4*>(Ts + srow * TLD + scol + 8) = t1;
+            }
+        }
+    };
 
     f32x4 acc[IT][4];
 #pragma unroll
     for (int jj = 0; jj < IT; ++jj)
 #pragma unroll
         for (int tn = 0; tn < 4; ++tn) acc[jj][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const bool tile_t = a.normalize && (MODE == 1 || single);   // third tile staged with the chunk
+    TileRegs R;
+    if (jg * IT < M) issue((long)jg * IT * S, min(64, S), tile_t, R);
 
 #pragma unroll
     for (int jj = 0; jj < IT; ++jj) {
@@ -149,23 +223,21 @@ __global__ __launch_bounds__(FT) void k_fs_state(const FsStateArgs a) {
         float ks = 0.f;
         for (int c0 = 0; c0 < S; c0 += 64) {
             const int rv = min(64, S - c0), rfill = (rv + 31) & ~31;
-            if (a.relu) stage_rows<true>(Xs, xb, a.x.sn, a.idx, p0 + c0, rv, rfill, a.eps, tid);
-            else        stage_rows<false>(Xs, xb, a.x.sn, a.idx, p0 + c0, rv, rfill, a.eps, tid);
-            stage_rows<false>(Ys, yb, a.y.sn, a.idx, p0 + c0, rv, rfill, 0.f, tid);
-            if (a.normalize && (MODE == 1 || single)) {
-                if (MODE == 0 && a.relu) stage_rows<true>(Ts, tb, a.t.sn, a.idx, p0 + c0, rv, rfill, a.eps, tid);
-                else                     stage_rows<false>(Ts, tb, a.t.sn, a.idx, p0 + c0, rv, rfill, 0.f, tid);
+            commit(R, rv, rfill, tile_t);
+            {   // prefetch the next chunk (same block, or the next block of the group)
+                long pn = -1;
+                int rvn = 0;
+                if (c0 + 64 < S) { pn = p0 + c0 + 64; rvn = min(64, S - c0 - 64); }
+                else if (jj + 1 < IT && j + 1 < M) { pn = (long)(j + 1) * S; rvn = min(64, S); }
+                if (pn >= 0) issue(pn, rvn, tile_t, R);
             }
-            if (MODE == 1 && a.normalize)
-                part[tid] = wz_partial(a.W + (long)j * a.ldw, 1, a.z_in + (long)bh * M * S, M, S, c0 + (tid & 63),
-                                       (tid & 63) < rv, tid >> 6);
             __syncthreads();
             if (MODE == 0 && a.normalize) {   // column sums of K
                 const int col = tid & 63, pr = tid >> 6;
                 for (int r = pr * 16; r < min(rv, pr * 16 + 16); ++r) ks += bf(Xs[r * TLD + col]);
             }
             if (MODE == 1 && a.normalize) {   // dn and dP = dO / n (rounded to bf16)
-                const int r = tid >> 2, cq = (tid & 3) * 16;
+                const int r = srow, cq = scol;
                 float d = 0.f;
                 if (r < rv) {
 #pragma unroll
@@ -174,7 +246,7 @@ __global__ __launch_bounds__(FT) void k_fs_state(const FsStateArgs a) {
                 d += __shfl_xor(d, 1, 64);
                 d += __shfl_xor(d, 2, 64);
                 if (r < rv) {
-                    const float ni = 1.f / (a.eps + wz_sum(part, r));
+                    const float ni = a.ninv[((long)bh * M + j) * S + c0 + r];
                     if ((tid & 3) == 0) a.dn[((long)bh * M + j) * S + c0 + r] = -d * ni;
 #pragma unroll
                     for (int c = 0; c < 16; ++c) Ys[r * TLD + cq + c] = f32_to_bf16(bf(Ys[r * TLD + cq + c]) * ni);
@@ -186,33 +258,32 @@ __global__ __launch_bounds__(FT) void k_fs_state(const FsStateArgs a) {
 #pragma unroll
                 for (int tn = 0; tn < 4; ++tn) acc[jj][tn] = mfma_bf16(av, tr_read8(Xs, TLD, k0, tn * 16, lane), acc[jj][tn]);
             }
-            __syncthreads();
+            if (!(MODE == 0 && a.normalize && single)) __syncthreads();   // (single: the z pass below syncs)
         }
         if (MODE == 0 && a.normalize) {
             part[(tid >> 6) * 64 + (tid & 63)] = ks;
             __syncthreads();
             if (tid < 64) {
-                const float s = part[tid] + part[64 + tid] + part[128 + tid] + part[192 + tid];
-                ksum_s[tid] = s;
-                a.ksum[((long)bh * M + j) * 64 + tid] = s;
+                const float sacc = part[tid] + part[64 + tid] + part[128 + tid] + part[192 + tid];
+                ksum_s[tid] = sacc;
+                a.ksum[((long)bh * M + j) * 64 + tid] = sacc;
             }
             __syncthreads();
             for (int c0 = 0; c0 < S; c0 += 64) {
                 const int rv = min(64, S - c0);
-                if (!single) {
+                if (!single) {   // (rare) multi-chunk blocks: second pass over Q, synchronous
                     if (a.relu) stage_rows<true>(Ts, tb, a.t.sn, a.idx, p0 + c0, rv, rv, a.eps, tid);
                     else        stage_rows<false>(Ts, tb, a.t.sn, a.idx, p0 + c0, rv, rv, 0.f, tid);
                     __syncthreads();
                 }
-                const int r = tid >> 2, cq = (tid & 3) * 16;
                 float d = 0.f;
-                if (r < rv) {
+                if (srow < rv) {
 #pragma unroll
-                    for (int c = 0; c < 16; ++c) d += bf(Ts[r * TLD + cq + c]) * ksum_s[cq + c];
+                    for (int c = 0; c < 16; ++c) d += bf(Ts[srow * TLD + scol + c]) * ksum_s[scol + c];
                 }
                 d += __shfl_xor(d, 1, 64);
                 d += __shfl_xor(d, 2, 64);
-                if (r < rv && (tid & 3) == 0) a.z_out[((long)bh * M + j) * S + c0 + r] = d;
+                if (srow < rv && (tid & 3) == 0) a.z_out[((long)bh * M + j) * S + c0 + srow] = d;
                 __syncthreads();
             }
         }
@@ -428,7 +499,7 @@ struct FsOutArgs {
     const float* W;
     int ldw;
     const u16* state;   // [bh][njg][4096][8]
-    const float* z;     // [bh][M][S]
+    const float* ninv;  // [bh][M][S]  1 / n  (k_fs_wz<0>)
     int H, M, S, njg;
     float eps;
     int relu, normalize;
@@ -445,7 +516,7 @@ __global__ __launch_bounds__(FT, 2) void k_fs_out(const FsOutArgs a) {
     const int S = a.S, M = a.M;
     const u16* qb = (const u16*)a.q.ptr + b * a.q.sb + h * a.q.sh;
     u16* ob = (u16*)a.o.ptr + b * a.o.sb + h * a.o.sh;
-    const float* z_bh = a.z + (long)bh * M * S;
+    const float* ninv_bh = a.ninv + (long)bh * M * S;
 
     mix_tile_to_lds<0>(Gt, a.state + (long)bh * a.njg * FE * IT, a.njg, a.W, a.ldw, M, it * IT, tid);
     __syncthreads();
@@ -461,7 +532,7 @@ __global__ __launch_bounds__(FT, 2) void k_fs_out(const FsOutArgs a) {
             if (a.relu) load_a64<true>(av, qb, a.q.sn, a.idx, p0, rv, a.eps, lane);
             else        load_a64<false>(av, qb, a.q.sn, a.idx, p0, rv, a.eps, lane);
             float ninv = 1.f;
-            if (a.normalize) ninv = 1.f / (a.eps + col_dot(a.W + (long)i * a.ldw, 1, z_bh, M, S, c0 + lane, lane < rv));
+            if (a.normalize && lane < rv) ninv = ninv_bh[(long)i * S + c0 + lane];
             f32x4 acc[4][4];
 #pragma unroll
             for (int st = 0; st < 4; ++st)
@@ -491,17 +562,18 @@ __global__ __launch_bounds__(FT, 2) void k_fs_out(const FsOutArgs a) {
 // -------------------------------------------------------------------------------------------------
 // k_fs_dw: dWp[bh][q][i][j] = sum_{e' in quarter q} dG[i][e'] KV[j][e']   (both in the interleaved layout)
 // LDS images [e'][64 blocks] built from 16-byte pieces; both MFMA operands via transpose reads.
-// grid (4 quarters, bh).  The <dn_i, z_j> term is added by quarter 0 with VALU.
+// grid (DW_SPLIT, bh).  The <dn_i, z_j> term is added by split 0 from LDS tiles.
 // -------------------------------------------------------------------------------------------------
 struct FsDwArgs {
     const u16* dg;
     const u16* kv;
     const float* dn;   // [bh][M][S] or null
     const float* z;
-    float* dwp;        // [bh][4][64][64]
+    float* dwp;        // [bh][DW_SPLIT][64][64]
     int M, S, njg;
 };
-constexpr int DW_EC = 256;                       // e' rows per LDS image
+constexpr int DW_EC = 128;                       // e' rows per LDS image
+constexpr int DW_SPLIT = 8;                      // e' splits per (b,h)
 constexpr int DW_LDI = 72;
 constexpr int FS_DW_SMEM = 2 * DW_EC * DW_LDI * 2;
 
@@ -516,8 +588,8 @@ __global__ __launch_bounds__(FT) void k_fs_dw(const FsDwArgs a) {
     f32x4 acc[4];
 #pragma unroll
     for (int tn = 0; tn < 4; ++tn) acc[tn] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int ec = 0; ec < FE / 4; ec += DW_EC) {
-        const long e0 = (long)qtr * (FE / 4) + ec;
+    for (int ec = 0; ec < FE / DW_SPLIT; ec += DW_EC) {
+        const long e0 = (long)qtr * (FE / DW_SPLIT) + ec;
         // 2 images x 256 rows x 8 groups of 16 bytes
         for (int v = tid; v < 2 * DW_EC * 8; v += FT) {
             const int which = v / (DW_EC * 8), rem = v - which * DW_EC * 8, g = rem / DW_EC, r = rem - g * DW_EC;
@@ -536,7 +608,7 @@ __global__ __launch_bounds__(FT) void k_fs_dw(const FsDwArgs a) {
     // <dn_i, z_j> term (quarter 0): stage dn[64][S<=64 chunk] and z[64][chunk] in LDS as fp32
     if (qtr == 0 && a.dn) {
         float* dns = reinterpret_cast<float*>(smem_raw);     // [64][65]
-        float* zs = dns + 64 * 65;                           // [64][65]
+        float* zs = dns + 64 * 65;                           // [64][65]   (2 x 16.6 KB <= the image buffers)
         for (int c0 = 0; c0 < a.S; c0 += 64) {
             const int rv = min(64, a.S - c0);
             __syncthreads();
@@ -559,7 +631,7 @@ __global__ __launch_bounds__(FT) void k_fs_dw(const FsDwArgs a) {
                 }
         }
     }
-    float* out = a.dwp + ((long)bh * 4 + qtr) * 64 * 64;
+    float* out = a.dwp + ((long)bh * DW_SPLIT + qtr) * 64 * 64;
 #pragma unroll
     for (int tn = 0; tn < 4; ++tn)
 #pragma unroll
@@ -599,8 +671,8 @@ struct FsTokArgs {
     int ldw;
     const u16* state;   // KV^T
     const u16* dstate;  // dG^T
-    const float* z;
-    const float* dn;
+    const float* ninv;  // [bh][M][S]
+    const float* dz;    // [bh][M][S]  (k_fs_wz<1>)
     const float* ksum;
     float* dksum;       // [bh][M][64]: written by k_fs_bwd_dq, read by k_fs_bwd_dkv
     int H, M, S, njg;
@@ -621,8 +693,6 @@ __global__ __launch_bounds__(FT, 2) void k_fs_bwd_dq(const FsTokArgs a) {
     const u16 *qb = base(a.q), *gb = base(a.dout);
     u16* dqb = mbase(a.dq);
     const long sofs = (long)bh * a.njg * FE * IT;
-    const float* z_bh = a.z + (long)bh * M * S;
-    const float* dn_bh = a.dn + (long)bh * M * S;
 
     // ---------------- phase 1: dQ, dksum ----------------
     mix_tile_to_lds<0>(Gt, a.state + sofs, a.njg, a.W, a.ldw, M, jgx * IT, tid);
@@ -643,9 +713,9 @@ __global__ __launch_bounds__(FT, 2) void k_fs_bwd_dq(const FsTokArgs a) {
             bf16x8 gv[4][2];
             load_a64<false>(gv, gb, a.dout.sn, a.idx, p0, rv, 0.f, lane);
             float ninv = 1.f, dzv = 0.f;
-            if (a.normalize) {
-                ninv = 1.f / (a.eps + col_dot(a.W + (long)j * a.ldw, 1, z_bh, M, S, c0 + lane, lane < rv));
-                dzv = col_dot(a.W + j, a.ldw, dn_bh, M, S, c0 + lane, lane < rv);
+            if (a.normalize && lane < rv) {
+                ninv = a.ninv[((long)bh * M + j) * S + c0 + lane];
+                dzv = a.dz[((long)bh * M + j) * S + c0 + lane];
             }
             f32x4 acc[4][4];
 #pragma unroll
