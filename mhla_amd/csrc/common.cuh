@@ -19,6 +19,14 @@ __device__ __forceinline__ unsigned short f32_to_bf16(float f) {   // round-to-n
     return (unsigned short)(u >> 16);
 }
 
+// hardware conversions (gfx950: v_cvt_pk_bf16_f32, round-to-nearest-even)
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ __forceinline__ unsigned short cvt_bf16(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+
 // 4-element vector I/O per dtype (16 B for f32, 8 B for 16-bit types).
 template <typename T> struct Io;
 template <> struct Io<float> {
@@ -35,8 +43,8 @@ template <> struct Io<bf16_t> {
     }
     static __device__ __forceinline__ void st4(bf16_t* p, f32x4 v) {
         uint2 r;
-        r.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-        r.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+        r.x = pack_bf16x2(v[0], v[1]);
+        r.y = pack_bf16x2(v[2], v[3]);
         *reinterpret_cast<uint2*>(p) = r;
     }
 };

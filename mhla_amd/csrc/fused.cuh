@@ -56,7 +56,7 @@ __device__ __forceinline__ uint4 relu_eps8(uint4 v, float eps) {
     for (int i = 0; i < 4; ++i) {
         const float lo = fmaxf(__uint_as_float(w[i] << 16), 0.f) + eps;
         const float hi = fmaxf(__uint_as_float(w[i] & 0xffff0000u), 0.f) + eps;
-        w[i] = (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+        w[i] = pack_bf16x2(lo, hi);
     }
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
@@ -108,6 +108,7 @@ __global__ __launch_bounds__(FT) void k_fs_wz(const float* __restrict__ W, int l
     __shared__ float Ws[64 * 65];
     __shared__ float xs[64 * 64];
     const int tid = threadIdx.x, c0 = blockIdx.x * 64, bh = blockIdx.y, rv = min(64, S - c0);
+#pragma unroll
     for (int v = tid; v < 64 * 64; v += FT) {
         const int r = v >> 6, c = v & 63;
         float w = 0.f;
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(FT) void k_fs_state(const FsStateArgs a) {
                     const float ni = a.ninv[((long)bh * M + j) * S + c0 + r];
                     if ((tid & 3) == 0) a.dn[((long)bh * M + j) * S + c0 + r] = -d * ni;
 #pragma unroll
-                    for (int c = 0; c < 16; ++c) Ys[r * TLD + cq + c] = f32_to_bf16(bf(Ys[r * TLD + cq + c]) * ni);
+                    for (int c = 0; c < 16; ++c) Ys[r * TLD + cq + c] = cvt_bf16(bf(Ys[r * TLD + cq + c]) * ni);
                 }
                 __syncthreads();
             }
@@ -299,7 +300,7 @@ __global__ __launch_bounds__(FT) void k_fs_state(const FsStateArgs a) {
             unsigned w[4];
 #pragma unroll
             for (int p = 0; p < 4; ++p)
-                w[p] = (unsigned)f32_to_bf16(acc[2 * p][tn][r]) | ((unsigned)f32_to_bf16(acc[2 * p + 1][tn][r]) << 16);
+                w[p] = pack_bf16x2(acc[2 * p][tn][r], acc[2 * p + 1][tn][r]);
             *reinterpret_cast<uint4*>(sb + ((long)d2 * FD + d1) * IT) = make_uint4(w[0], w[1], w[2], w[3]);
         }
 }
@@ -323,24 +324,25 @@ __device__ __forceinline__ void mix_tile_to_lds(u16* __restrict__ Gt, const u16*
             const int j = ks * 32 + kg * 8 + t, i = i0 + n;
             float w = 0.f;
             if (n < IT && i < M && j < M) w = TRANSW ? W[(long)j * ldw + i] : W[(long)i * ldw + j];
-            const u16 h = f32_to_bf16(w);
+            const u16 h = cvt_bf16(w);
             hi[t] = (short)h;
-            lo[t] = (short)f32_to_bf16(w - bf(h));
+            lo[t] = (short)cvt_bf16(w - bf(h));
         }
         bhi[ks] = __builtin_bit_cast(bf16x8, hi);
         blo[ks] = __builtin_bit_cast(bf16x8, lo);
     }
     const bool two = njg > 4;
-    constexpr int UN = 8;
-    for (int et0 = wave * UN; et0 < FE / 16; et0 += 4 * UN) {
-        uint4 av[UN][2];
+    constexpr int UN = 4;   // tiles per batch; two batches in flight (software double buffer)
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    auto load_batch = [&](uint4 (&av)[UN][2], int et0) {
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const long e = (long)(et0 + u) * 16 + n;
-            av[u][0] = (kg < njg) ? *reinterpret_cast<const uint4*>(state_bh + ((long)kg * FE + e) * IT) : make_uint4(0, 0, 0, 0);
-            av[u][1] = (two && 4 + kg < njg) ? *reinterpret_cast<const uint4*>(state_bh + ((long)(4 + kg) * FE + e) * IT)
-                                             : make_uint4(0, 0, 0, 0);
+            av[u][0] = (kg < njg) ? *reinterpret_cast<const uint4*>(state_bh + ((long)kg * FE + e) * IT) : zero4;
+            av[u][1] = (two && 4 + kg < njg) ? *reinterpret_cast<const uint4*>(state_bh + ((long)(4 + kg) * FE + e) * IT) : zero4;
         }
+    };
+    auto do_batch = [&](const uint4 (&av)[UN][2], int et0) {
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             f32x4 c = {0.f, 0.f, 0.f, 0.f};
@@ -355,11 +357,22 @@ __device__ __forceinline__ void mix_tile_to_lds(u16* __restrict__ Gt, const u16*
             if (n < IT) {
                 const int et = et0 + u, d2 = et >> 2, d1 = (et & 3) * 16 + kg * 4;
                 uint2 pk;
-                pk.x = (unsigned)f32_to_bf16(c[0]) | ((unsigned)f32_to_bf16(c[1]) << 16);
-                pk.y = (unsigned)f32_to_bf16(c[2]) | ((unsigned)f32_to_bf16(c[3]) << 16);
+                pk.x = pack_bf16x2(c[0], c[1]);
+                pk.y = pack_bf16x2(c[2], c[3]);
                 *reinterpret_cast<uint2*>(Gt + ((long)(n * FD + d2)) * GLD + d1) = pk;
             }
         }
+    };
+    // wave w owns tiles et = 4 UN (w + 4 b) .. : 64 tiles per wave in 16 batches of UN
+    constexpr int NB = FE / 16 / 4 / UN;
+    uint4 bufA[UN][2], bufB[UN][2];
+    load_batch(bufA, wave * UN);
+#pragma unroll 1
+    for (int bt = 0; bt < NB; bt += 2) {
+        load_batch(bufB, (wave + 4 * (bt + 1)) * UN);
+        do_batch(bufA, (wave + 4 * bt) * UN);
+        if (bt + 2 < NB) load_batch(bufA, (wave + 4 * (bt + 2)) * UN);
+        do_batch(bufB, (wave + 4 * (bt + 1)) * UN);
     }
 }
 
@@ -423,7 +436,7 @@ __device__ __forceinline__ void stage64(u16* __restrict__ Os, const f32x4 (&acc)
 #pragma unroll
         for (int tn = 0; tn < 4; ++tn)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) Os[(st * 16 + kg * 4 + r) * GLD + tn * 16 + n] = f32_to_bf16(acc[st][tn][r]);
+            for (int r = 0; r < 4; ++r) Os[(st * 16 + kg * 4 + r) * GLD + tn * 16 + n] = cvt_bf16(acc[st][tn][r]);
 }
 
 // zero the bf16 lanes of v where the corresponding element of m is <= 0 (relu gradient mask)
@@ -471,7 +484,7 @@ __device__ __forceinline__ void store64_direct(u16* __restrict__ base, long sn, 
                 for (int tn = 0; tn < 4; ++tn) {
                     float v = acc[st][tn][r];
                     if (MASK && !(bf(mbase[tr * msn + tn * 16 + n]) > 0.f)) v = 0.f;
-                    base[tr * sn + tn * 16 + n] = f32_to_bf16(v);
+                    base[tr * sn + tn * 16 + n] = cvt_bf16(v);
                 }
             }
         }
@@ -591,6 +604,7 @@ __global__ __launch_bounds__(FT) void k_fs_dw(const FsDwArgs a) {
     for (int ec = 0; ec < FE / DW_SPLIT; ec += DW_EC) {
         const long e0 = (long)qtr * (FE / DW_SPLIT) + ec;
         // 2 images x 256 rows x 8 groups of 16 bytes
+#pragma unroll
         for (int v = tid; v < 2 * DW_EC * 8; v += FT) {
             const int which = v / (DW_EC * 8), rem = v - which * DW_EC * 8, g = rem / DW_EC, r = rem - g * DW_EC;
             uint4 x = make_uint4(0, 0, 0, 0);
@@ -640,12 +654,12 @@ __global__ __launch_bounds__(FT) void k_fs_dw(const FsDwArgs a) {
 
 // Deterministic two-stage reduction of the partials: stage 1 sums groups of DWR_G partials (grid (16, ngroups)),
 // stage 2 (MODE 1) sums the group results into dW[M][M].
-constexpr int DWR_G = 16;
+constexpr int DWR_G = 64;
 __global__ void k_fs_dw_reduce1(const float* __restrict__ dwp, float* __restrict__ tmp, int nparts) {
     const int e = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y;
     float s = 0.f;
     const int p1 = min(nparts, (g + 1) * DWR_G);
-#pragma unroll 4
+#pragma unroll 16
     for (int p = g * DWR_G; p < p1; ++p) s += dwp[(long)p * 4096 + e];
     tmp[(long)g * 4096 + e] = s;
 }
@@ -811,8 +825,8 @@ __global__ __launch_bounds__(FT, 2) void k_fs_bwd_dkv(const FsTokArgs a) {
                 for (int st = 0; st < 4; ++st)
 #pragma unroll
                     for (int tn = 0; tn < 4; ++tn) {
-                        pv[st][tn][0] = (unsigned)f32_to_bf16(accV[st][tn][0]) | ((unsigned)f32_to_bf16(accV[st][tn][1]) << 16);
-                        pv[st][tn][1] = (unsigned)f32_to_bf16(accV[st][tn][2]) | ((unsigned)f32_to_bf16(accV[st][tn][3]) << 16);
+                        pv[st][tn][0] = pack_bf16x2(accV[st][tn][0], accV[st][tn][1]);
+                        pv[st][tn][1] = pack_bf16x2(accV[st][tn][2], accV[st][tn][3]);
                     }
             }
             f32x4 accK[4][4];
