@@ -106,23 +106,44 @@ template <int MODE>
 __global__ __launch_bounds__(FT) void k_fs_wz(const float* __restrict__ W, int ldw, const float* __restrict__ x,
                                               float* __restrict__ out, int M, int S, float eps) {
     __shared__ float Ws[64 * 65];
-    __shared__ float xs[64 * 64];
+    __shared__ __attribute__((aligned(16))) float xs[64 * 64];
     const int tid = threadIdx.x, c0 = blockIdx.x * 64, bh = blockIdx.y, rv = min(64, S - c0);
+    // all global loads first (16 + 16 per thread in flight), LDS writes after
+    float wreg[16], xreg[16];
 #pragma unroll
-    for (int v = tid; v < 64 * 64; v += FT) {
-        const int r = v >> 6, c = v & 63;
-        float w = 0.f;
-        if (r < M && c < M) w = MODE ? W[(long)c * ldw + r] : W[(long)r * ldw + c];
-        Ws[r * 65 + c] = w;
-        xs[r * 64 + c] = (r < M && c < rv) ? x[((long)bh * M + r) * S + c0 + c] : 0.f;
+    for (int t = 0; t < 16; ++t) {
+        const int v = tid + t * FT, r = v >> 6, c = v & 63;
+        wreg[t] = (r < M && c < M) ? (MODE ? W[(long)c * ldw + r] : W[(long)r * ldw + c]) : 0.f;
+        xreg[t] = (r < M && c < rv) ? x[((long)bh * M + r) * S + c0 + c] : 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const int v = tid + t * FT, r = v >> 6, c = v & 63;
+        Ws[r * 65 + c] = wreg[t];
+        xs[r * 64 + c] = xreg[t];
     }
     __syncthreads();
-    const int sc = tid & 63;
-    for (int r = tid >> 6; r < M; r += 4) {
-        float acc = 0.f;
-#pragma unroll 8
-        for (int c = 0; c < 64; ++c) acc += Ws[r * 65 + c] * xs[c * 64 + sc];
-        if (sc < rv) out[((long)bh * M + r) * S + c0 + sc] = MODE ? acc : 1.f / (eps + acc);
+    // thread -> 4 rows (r0, r0 + 16, ...) x 4 columns (4 sq ..): W element reused for 4 columns, x read as float4
+    const int sq = tid & 15, r0 = tid >> 4;
+    f32x4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int c = 0; c < 64; ++c) {
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(xs + c * 64 + sq * 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] += Ws[(r0 + 16 * i) * 65 + c] * xv;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + 16 * i;
+        if (r < M) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int sc = sq * 4 + t;
+                if (sc < rv) out[((long)bh * M + r) * S + c0 + sc] = MODE ? acc[i][t] : 1.f / (eps + acc[i][t]);
+            }
+        }
     }
 }
 
@@ -604,12 +625,18 @@ __global__ __launch_bounds__(FT) void k_fs_dw(const FsDwArgs a) {
     for (int ec = 0; ec < FE / DW_SPLIT; ec += DW_EC) {
         const long e0 = (long)qtr * (FE / DW_SPLIT) + ec;
         // 2 images x 256 rows x 8 groups of 16 bytes
+        uint4 pr[2 * DW_EC * 8 / FT];
 #pragma unroll
-        for (int v = tid; v < 2 * DW_EC * 8; v += FT) {
+        for (int t = 0; t < 2 * DW_EC * 8 / FT; ++t) {
+            const int v = tid + t * FT;
             const int which = v / (DW_EC * 8), rem = v - which * DW_EC * 8, g = rem / DW_EC, r = rem - g * DW_EC;
-            uint4 x = make_uint4(0, 0, 0, 0);
-            if (g < njg) x = *reinterpret_cast<const uint4*>((which ? kv : dg) + ((long)g * FE + e0 + r) * IT);
-            *reinterpret_cast<uint4*>((which ? Bi : Ai) + r * DW_LDI + g * 8) = x;
+            pr[t] = (g < njg) ? *reinterpret_cast<const uint4*>((which ? kv : dg) + ((long)g * FE + e0 + r) * IT) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < 2 * DW_EC * 8 / FT; ++t) {
+            const int v = tid + t * FT;
+            const int which = v / (DW_EC * 8), rem = v - which * DW_EC * 8, g = rem / DW_EC, r = rem - g * DW_EC;
+            *reinterpret_cast<uint4*>((which ? Bi : Ai) + r * DW_LDI + g * 8) = pr[t];
         }
         __syncthreads();
         for (int k0 = 0; k0 < DW_EC; k0 += 32) {
@@ -626,11 +653,16 @@ __global__ __launch_bounds__(FT) void k_fs_dw(const FsDwArgs a) {
         for (int c0 = 0; c0 < a.S; c0 += 64) {
             const int rv = min(64, a.S - c0);
             __syncthreads();
-            for (int v = tid; v < 2 * 64 * 64; v += FT) {
-                const int which = v >> 12, row = (v >> 6) & 63, col = v & 63;
-                float x = 0.f;
-                if (row < M && col < rv) x = (which ? a.z : a.dn)[((long)bh * M + row) * a.S + c0 + col];
-                (which ? zs : dns)[row * 65 + col] = x;
+            float zr[32];
+#pragma unroll
+            for (int t = 0; t < 32; ++t) {
+                const int v = tid + t * FT, which = v >> 12, row = (v >> 6) & 63, col = v & 63;
+                zr[t] = (row < M && col < rv) ? (which ? a.z : a.dn)[((long)bh * M + row) * a.S + c0 + col] : 0.f;
+            }
+#pragma unroll
+            for (int t = 0; t < 32; ++t) {
+                const int v = tid + t * FT, which = v >> 12, row = (v >> 6) & 63, col = v & 63;
+                (which ? zs : dns)[row * 65 + col] = zr[t];
             }
             __syncthreads();
 #pragma unroll
