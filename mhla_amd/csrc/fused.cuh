@@ -552,43 +552,66 @@ __global__ __launch_bounds__(FT, 2) void k_fs_out(const FsOutArgs a) {
     u16* ob = (u16*)a.o.ptr + b * a.o.sb + h * a.o.sh;
     const float* ninv_bh = a.ninv + (long)bh * M * S;
 
-    mix_tile_to_lds<0>(Gt, a.state + (long)bh * a.njg * FE * IT, a.njg, a.W, a.ldw, M, it * IT, tid);
-    __syncthreads();
+    const u16* state_bh = a.state + (long)bh * a.njg * FE * IT;
+    auto load_blk = [&](bf16x8 (&av)[4][2], float& ninv, int i, int c0, int rv) {
+        const long p0 = (long)i * S + c0;
+        if (a.relu) load_a64<true>(av, qb, a.q.sn, a.idx, p0, rv, a.eps, lane);
+        else        load_a64<false>(av, qb, a.q.sn, a.idx, p0, rv, a.eps, lane);
+        ninv = (a.normalize && lane < rv) ? ninv_bh[(long)i * S + c0 + lane] : 1.f;
+    };
+    auto compute_store = [&](const bf16x8 (&av)[4][2], float ninv, int bi, int i, int c0, int rv) {
+        const long p0 = (long)i * S + c0;
+        u16* Gb = Gt + bi * FD * GLD;
+        f32x4 acc[4][4];
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn) acc[st][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+        chunk_times_gt<false>(acc, av, Gb, lane);
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float ni = __shfl(ninv, st * 16 + kg * 4 + r, 64);
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn) acc[st][tn][r] *= ni;
+            }
+        if (c0 + 64 >= S) {   // last chunk of the block: its Gt slot is dead for this wave -> staging buffer
+            wave_lds_fence();
+            stage64(Gb, acc, lane);
+            wave_lds_fence();
+            store64<false>(ob, a.o.sn, a.idx, p0, rv, Gb, nullptr, 0, lane);
+        } else {
+            store64_direct<false>(ob, a.o.sn, a.idx, p0, rv, acc, nullptr, 0, lane);
+        }
+    };
 
+    if (S <= 64) {
+        // each wave owns blocks (wave, wave + 4): the first block's operands are fetched before the mixing,
+        // the second block's while the first is being multiplied
+        const int iA = it * IT + wave, iB = iA + 4;
+        bf16x8 avA[4][2], avB[4][2];
+        float ninvA = 1.f, ninvB = 1.f;
+        if (iA < M) load_blk(avA, ninvA, iA, 0, S);
+        mix_tile_to_lds<0>(Gt, state_bh, a.njg, a.W, a.ldw, M, it * IT, tid);
+        __syncthreads();
+        if (iB < M) load_blk(avB, ninvB, iB, 0, S);
+        if (iA < M) compute_store(avA, ninvA, wave, iA, 0, S);
+        if (iB < M) compute_store(avB, ninvB, wave + 4, iB, 0, S);
+        return;
+    }
+
+    mix_tile_to_lds<0>(Gt, state_bh, a.njg, a.W, a.ldw, M, it * IT, tid);
+    __syncthreads();
     for (int bi = wave; bi < IT; bi += 4) {
         const int i = it * IT + bi;
         if (i >= M) continue;
-        u16* Gb = Gt + bi * FD * GLD;
         for (int c0 = 0; c0 < S; c0 += 64) {
-            const long p0 = (long)i * S + c0;
             const int rv = min(64, S - c0);
             bf16x8 av[4][2];
-            if (a.relu) load_a64<true>(av, qb, a.q.sn, a.idx, p0, rv, a.eps, lane);
-            else        load_a64<false>(av, qb, a.q.sn, a.idx, p0, rv, a.eps, lane);
-            float ninv = 1.f;
-            if (a.normalize && lane < rv) ninv = ninv_bh[(long)i * S + c0 + lane];
-            f32x4 acc[4][4];
-#pragma unroll
-            for (int st = 0; st < 4; ++st)
-#pragma unroll
-                for (int tn = 0; tn < 4; ++tn) acc[st][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
-            chunk_times_gt<false>(acc, av, Gb, lane);
-#pragma unroll
-            for (int st = 0; st < 4; ++st)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float ni = __shfl(ninv, st * 16 + kg * 4 + r, 64);
-#pragma unroll
-                    for (int tn = 0; tn < 4; ++tn) acc[st][tn][r] *= ni;
-                }
-            if (c0 + 64 >= S) {   // last chunk of the block: its Gt slot is dead for this wave -> staging buffer
-                wave_lds_fence();
-                stage64(Gb, acc, lane);
-                wave_lds_fence();
-                store64<false>(ob, a.o.sn, a.idx, p0, rv, Gb, nullptr, 0, lane);
-            } else {
-                store64_direct<false>(ob, a.o.sn, a.idx, p0, rv, acc, nullptr, 0, lane);
-            }
+            float ninv;
+            load_blk(av, ninv, i, c0, rv);
+            compute_store(av, ninv, bi, i, c0, rv);
         }
     }
 }
@@ -622,22 +645,26 @@ __global__ __launch_bounds__(FT) void k_fs_dw(const FsDwArgs a) {
     f32x4 acc[4];
 #pragma unroll
     for (int tn = 0; tn < 4; ++tn) acc[tn] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int ec = 0; ec < FE / DW_SPLIT; ec += DW_EC) {
-        const long e0 = (long)qtr * (FE / DW_SPLIT) + ec;
-        // 2 images x 256 rows x 8 groups of 16 bytes
-        uint4 pr[2 * DW_EC * 8 / FT];
+    constexpr int NP = 2 * DW_EC * 8 / FT;   // 16-byte pieces per thread per chunk
+    uint4 pr[NP];
+    auto issue = [&](long e0) {
 #pragma unroll
-        for (int t = 0; t < 2 * DW_EC * 8 / FT; ++t) {
+        for (int t = 0; t < NP; ++t) {
             const int v = tid + t * FT;
             const int which = v / (DW_EC * 8), rem = v - which * DW_EC * 8, g = rem / DW_EC, r = rem - g * DW_EC;
             pr[t] = (g < njg) ? *reinterpret_cast<const uint4*>((which ? kv : dg) + ((long)g * FE + e0 + r) * IT) : make_uint4(0, 0, 0, 0);
         }
+    };
+    const long ebase = (long)qtr * (FE / DW_SPLIT);
+    issue(ebase);
+    for (int ec = 0; ec < FE / DW_SPLIT; ec += DW_EC) {
 #pragma unroll
-        for (int t = 0; t < 2 * DW_EC * 8 / FT; ++t) {
+        for (int t = 0; t < NP; ++t) {
             const int v = tid + t * FT;
             const int which = v / (DW_EC * 8), rem = v - which * DW_EC * 8, g = rem / DW_EC, r = rem - g * DW_EC;
             *reinterpret_cast<uint4*>((which ? Bi : Ai) + r * DW_LDI + g * 8) = pr[t];
         }
+        if (ec + DW_EC < FE / DW_SPLIT) issue(ebase + ec + DW_EC);   // next chunk in flight during the MFMAs
         __syncthreads();
         for (int k0 = 0; k0 < DW_EC; k0 += 32) {
             const bf16x8 av = tr_read8(Ai, DW_LDI, k0, wave * 16, lane);
@@ -740,72 +767,64 @@ __global__ __launch_bounds__(FT, 2) void k_fs_bwd_dq(const FsTokArgs a) {
     u16* dqb = mbase(a.dq);
     const long sofs = (long)bh * a.njg * FE * IT;
 
-    // ---------------- phase 1: dQ, dksum ----------------
-    mix_tile_to_lds<0>(Gt, a.state + sofs, a.njg, a.W, a.ldw, M, jgx * IT, tid);
-    __syncthreads();
-    for (int bi = wave; bi < IT; bi += 4) {
-        const int j = jgx * IT + bi;
-        if (j >= M) continue;
+    struct Side { float ninv, dz, ksum; };
+    auto load_blk = [&](bf16x8 (&gv)[4][2], Side& sd, int j, int c0, int rv) {
+        load_a64<false>(gv, gb, a.dout.sn, a.idx, (long)j * S + c0, rv, 0.f, lane);
+        sd.ninv = 1.f; sd.dz = 0.f;
+        sd.ksum = a.normalize ? a.ksum[((long)bh * M + j) * 64 + lane] : 0.f;   // lane = column d1
+        if (a.normalize && lane < rv) {
+            sd.ninv = a.ninv[((long)bh * M + j) * S + c0 + lane];
+            sd.dz = a.dz[((long)bh * M + j) * S + c0 + lane];
+        }
+    };
+    // one 64-row chunk: dQ rows, and the chunk's contribution to dksum (per-lane partials in the A layout)
+    auto compute_store = [&](const bf16x8 (&gv)[4][2], const Side& sd, float (&dks_acc)[2][8], int bi, int j, int c0, int rv) {
+        const long p0 = (long)j * S + c0;
         u16* Gb = Gt + bi * FD * GLD;
-        const float ksum_l = a.normalize ? a.ksum[((long)bh * M + j) * 64 + lane] : 0.f;   // lane = column d1
-        float dks_acc[2][8];
+        f32x4 acc[4][4];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int st = 0; st < 4; ++st)
 #pragma unroll
-            for (int t = 0; t < 8; ++t) dks_acc[ks][t] = 0.f;
-        for (int c0 = 0; c0 < S; c0 += 64) {
-            const long p0 = (long)j * S + c0;
-            const int rv = min(64, S - c0);
-            bf16x8 gv[4][2];
-            load_a64<false>(gv, gb, a.dout.sn, a.idx, p0, rv, 0.f, lane);
-            float ninv = 1.f, dzv = 0.f;
-            if (a.normalize && lane < rv) {
-                ninv = a.ninv[((long)bh * M + j) * S + c0 + lane];
-                dzv = a.dz[((long)bh * M + j) * S + c0 + lane];
+            for (int tn = 0; tn < 4; ++tn) acc[st][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+        chunk_times_gt<true>(acc, gv, Gb, lane);   // (dO G^T)[s][d1] : B[k = d2][n = d1] = Gt[d2][d1]
+        __builtin_amdgcn_sched_barrier(0);         // keep the q loads below the MFMAs (register pressure)
+        if (a.normalize) {
+            bf16x8 qv[4][2];
+            if (a.relu) load_a64<true>(qv, qb, a.q.sn, a.idx, p0, rv, a.eps, lane);
+            else        load_a64<false>(qv, qb, a.q.sn, a.idx, p0, rv, a.eps, lane);
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const float dzr = __shfl(sd.dz, st * 16 + n, 64);
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const s16x8 qs = __builtin_bit_cast(s16x8, qv[st][ks]);
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) dks_acc[ks][t] += dzr * bf((u16)qs[t]);
+                }
             }
-            f32x4 acc[4][4];
 #pragma unroll
             for (int st = 0; st < 4; ++st)
 #pragma unroll
-                for (int tn = 0; tn < 4; ++tn) acc[st][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
-            chunk_times_gt<true>(acc, gv, Gb, lane);   // (dO G^T)[s][d1] : B[k = d2][n = d1] = Gt[d2][d1]
-            __builtin_amdgcn_sched_barrier(0);         // keep the q loads below the MFMAs (register pressure)
-            if (a.normalize) {
-                bf16x8 qv[4][2];
-                if (a.relu) load_a64<true>(qv, qb, a.q.sn, a.idx, p0, rv, a.eps, lane);
-                else        load_a64<false>(qv, qb, a.q.sn, a.idx, p0, rv, a.eps, lane);
+                for (int r = 0; r < 4; ++r) {
+                    const int row = st * 16 + kg * 4 + r;
+                    const float ni = __shfl(sd.ninv, row, 64), dzr = __shfl(sd.dz, row, 64);
 #pragma unroll
-                for (int st = 0; st < 4; ++st) {
-                    const float dzr = __shfl(dzv, st * 16 + n, 64);
-#pragma unroll
-                    for (int ks = 0; ks < 2; ++ks) {
-                        const s16x8 qs = __builtin_bit_cast(s16x8, qv[st][ks]);
-#pragma unroll
-                        for (int t = 0; t < 8; ++t) dks_acc[ks][t] += dzr * bf((u16)qs[t]);
-                    }
+                    for (int tn = 0; tn < 4; ++tn) acc[st][tn][r] = acc[st][tn][r] * ni + dzr * __shfl(sd.ksum, tn * 16 + n, 64);
                 }
-#pragma unroll
-                for (int st = 0; st < 4; ++st)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = st * 16 + kg * 4 + r;
-                        const float ni = __shfl(ninv, row, 64), dzr = __shfl(dzv, row, 64);
-#pragma unroll
-                        for (int tn = 0; tn < 4; ++tn) acc[st][tn][r] = acc[st][tn][r] * ni + dzr * __shfl(ksum_l, tn * 16 + n, 64);
-                    }
-            }
-            if (c0 + 64 >= S) {
-                wave_lds_fence();
-                stage64(Gb, acc, lane);
-                wave_lds_fence();
-                if (a.relu) store64<true>(dqb, a.dq.sn, a.idx, p0, rv, Gb, qb, a.q.sn, lane);
-                else        store64<false>(dqb, a.dq.sn, a.idx, p0, rv, Gb, nullptr, 0, lane);
-            } else {
-                if (a.relu) store64_direct<true>(dqb, a.dq.sn, a.idx, p0, rv, acc, qb, a.q.sn, lane);
-                else        store64_direct<false>(dqb, a.dq.sn, a.idx, p0, rv, acc, nullptr, 0, lane);
-            }
         }
-        // dksum[col]: reduce the per-lane partials over the 16 rows-lanes (n), columns = 32 ks + 8 kg + t
+        if (c0 + 64 >= S) {
+            wave_lds_fence();
+            stage64(Gb, acc, lane);
+            wave_lds_fence();
+            if (a.relu) store64<true>(dqb, a.dq.sn, a.idx, p0, rv, Gb, qb, a.q.sn, lane);
+            else        store64<false>(dqb, a.dq.sn, a.idx, p0, rv, Gb, nullptr, 0, lane);
+        } else {
+            if (a.relu) store64_direct<true>(dqb, a.dq.sn, a.idx, p0, rv, acc, qb, a.q.sn, lane);
+            else        store64_direct<false>(dqb, a.dq.sn, a.idx, p0, rv, acc, nullptr, 0, lane);
+        }
+    };
+    // dksum[col]: reduce the per-lane partials over the 16 row-lanes (n); columns = 32 ks + 8 kg + t
+    auto finish_dks = [&](const float (&dks_acc)[2][8], int j) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -815,8 +834,43 @@ __global__ __launch_bounds__(FT, 2) void k_fs_bwd_dq(const FsTokArgs a) {
                 v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
                 if (n == 0) a.dksum[((long)bh * M + j) * 64 + ks * 32 + kg * 8 + t] = v;
             }
-    }
+    };
+    auto zero_dks = [](float (&d)[2][8]) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int t = 0; t < 8; ++t) d[ks][t] = 0.f;
+    };
 
+    if (S <= 64) {   // operands of the wave's first block are fetched before the mixing
+        const int jA = jgx * IT + wave, jB = jA + 4;
+        bf16x8 gvA[4][2], gvB[4][2];
+        Side sA, sB;
+        if (jA < M) load_blk(gvA, sA, jA, 0, S);
+        mix_tile_to_lds<0>(Gt, a.state + sofs, a.njg, a.W, a.ldw, M, jgx * IT, tid);
+        __syncthreads();
+        if (jB < M) load_blk(gvB, sB, jB, 0, S);
+        float dks_acc[2][8];
+        if (jA < M) { zero_dks(dks_acc); compute_store(gvA, sA, dks_acc, wave, jA, 0, S); if (a.normalize) finish_dks(dks_acc, jA); }
+        if (jB < M) { zero_dks(dks_acc); compute_store(gvB, sB, dks_acc, wave + 4, jB, 0, S); if (a.normalize) finish_dks(dks_acc, jB); }
+        return;
+    }
+    mix_tile_to_lds<0>(Gt, a.state + sofs, a.njg, a.W, a.ldw, M, jgx * IT, tid);
+    __syncthreads();
+    for (int bi = wave; bi < IT; bi += 4) {
+        const int j = jgx * IT + bi;
+        if (j >= M) continue;
+        float dks_acc[2][8];
+        zero_dks(dks_acc);
+        for (int c0 = 0; c0 < S; c0 += 64) {
+            const int rv = min(64, S - c0);
+            bf16x8 gv[4][2];
+            Side sd;
+            load_blk(gv, sd, j, c0, rv);
+            compute_store(gv, sd, dks_acc, bi, j, c0, rv);
+        }
+        if (a.normalize) finish_dks(dks_acc, j);
+    }
 }
 
 __global__ __launch_bounds__(FT, 2) void k_fs_bwd_dkv(const FsTokArgs a) {
@@ -831,88 +885,104 @@ __global__ __launch_bounds__(FT, 2) void k_fs_bwd_dkv(const FsTokArgs a) {
     const u16 *kb = base(a.k), *vb = base(a.v);
     u16 *dkb = mbase(a.dk), *dvb = mbase(a.dv);
     const long sofs = (long)bh * a.njg * FE * IT;
+    auto load_k = [&](bf16x8 (&kv)[4][2], int j, int c0, int rv) {
+        if (a.relu) load_a64<true>(kv, kb, a.k.sn, a.idx, (long)j * S + c0, rv, a.eps, lane);
+        else        load_a64<false>(kv, kb, a.k.sn, a.idx, (long)j * S + c0, rv, a.eps, lane);
+    };
+    auto compute_store = [&](const bf16x8 (&kv)[4][2], int bi, int j, int c0, int rv) {
+        const long p0 = (long)j * S + c0;
+        u16* Gb = Gt + bi * FD * GLD;
+        const bool last = c0 + 64 >= S;
+        bf16x8 vv[4][2];
+        load_a64<false>(vv, vb, a.v.sn, a.idx, p0, rv, 0.f, lane);
+        // dV first, kept packed as bf16 pairs while dK is computed (both need the intact Gb)
+        unsigned pv[4][4][2];
+        {
+            f32x4 accV[4][4];
+#pragma unroll
+            for (int st = 0; st < 4; ++st)
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn) accV[st][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+            chunk_times_gt<false>(accV, kv, Gb, lane);   // dV[s][d2] = sum_d1 K[s][d1] dKVt[d2][d1]
+#pragma unroll
+            for (int st = 0; st < 4; ++st)
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn) {
+                    pv[st][tn][0] = pack_bf16x2(accV[st][tn][0], accV[st][tn][1]);
+                    pv[st][tn][1] = pack_bf16x2(accV[st][tn][2], accV[st][tn][3]);
+                }
+        }
+        f32x4 accK[4][4];
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn) accK[st][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+        chunk_times_gt<true>(accK, vv, Gb, lane);        // dK[s][d1] = sum_d2 V[s][d2] dKVt[d2][d1]
+        if (a.normalize) {
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn) {
+                const float dk = a.dksum[((long)bh * M + j) * 64 + tn * 16 + n];
+#pragma unroll
+                for (int st = 0; st < 4; ++st)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) accK[st][tn][r] += dk;
+            }
+        }
+        if (last) {
+            wave_lds_fence();
+            stage64(Gb, accK, lane);
+            wave_lds_fence();
+            if (a.relu) store64<true>(dkb, a.dk.sn, a.idx, p0, rv, Gb, kb, a.k.sn, lane);
+            else        store64<false>(dkb, a.dk.sn, a.idx, p0, rv, Gb, nullptr, 0, lane);
+            wave_lds_fence();
+#pragma unroll
+            for (int st = 0; st < 4; ++st)
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        Gb[(st * 16 + kg * 4 + r) * GLD + tn * 16 + n] = (u16)(pv[st][tn][r >> 1] >> ((r & 1) * 16));
+            wave_lds_fence();
+            store64<false>(dvb, a.dv.sn, a.idx, p0, rv, Gb, nullptr, 0, lane);
+        } else {
+            if (a.relu) store64_direct<true>(dkb, a.dk.sn, a.idx, p0, rv, accK, kb, a.k.sn, lane);
+            else        store64_direct<false>(dkb, a.dk.sn, a.idx, p0, rv, accK, nullptr, 0, lane);
+#pragma unroll
+            for (int st = 0; st < 4; ++st)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = st * 16 + kg * 4 + r;
+                    if (row < rv) {
+                        const long tr = tok_row(a.idx, p0 + row);
+#pragma unroll
+                        for (int tn = 0; tn < 4; ++tn)
+                            dvb[tr * a.dv.sn + tn * 16 + n] = (u16)(pv[st][tn][r >> 1] >> ((r & 1) * 16));
+                    }
+                }
+        }
+    };
+
+    if (S <= 64) {
+        const int jA = jgx * IT + wave, jB = jA + 4;
+        bf16x8 kvA[4][2], kvB[4][2];
+        if (jA < M) load_k(kvA, jA, 0, S);
+        mix_tile_to_lds<1>(Gt, a.dstate + sofs, a.njg, a.W, a.ldw, M, jgx * IT, tid);
+        __syncthreads();
+        if (jB < M) load_k(kvB, jB, 0, S);
+        if (jA < M) compute_store(kvA, wave, jA, 0, S);
+        if (jB < M) compute_store(kvB, wave + 4, jB, 0, S);
+        return;
+    }
     mix_tile_to_lds<1>(Gt, a.dstate + sofs, a.njg, a.W, a.ldw, M, jgx * IT, tid);
     __syncthreads();
     for (int bi = wave; bi < IT; bi += 4) {
         const int j = jgx * IT + bi;
         if (j >= M) continue;
-        u16* Gb = Gt + bi * FD * GLD;
         for (int c0 = 0; c0 < S; c0 += 64) {
-            const long p0 = (long)j * S + c0;
             const int rv = min(64, S - c0);
-            const bool last = c0 + 64 >= S;
-            // dV first, kept packed as bf16 pairs while dK is computed (both need the intact Gb)
-            unsigned pv[4][4][2];
-            {
-                f32x4 accV[4][4];
-#pragma unroll
-                for (int st = 0; st < 4; ++st)
-#pragma unroll
-                    for (int tn = 0; tn < 4; ++tn) accV[st][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
-                bf16x8 kv[4][2];
-                if (a.relu) load_a64<true>(kv, kb, a.k.sn, a.idx, p0, rv, a.eps, lane);
-                else        load_a64<false>(kv, kb, a.k.sn, a.idx, p0, rv, a.eps, lane);
-                chunk_times_gt<false>(accV, kv, Gb, lane);   // dV[s][d2] = sum_d1 K[s][d1] dKVt[d2][d1]
-#pragma unroll
-                for (int st = 0; st < 4; ++st)
-#pragma unroll
-                    for (int tn = 0; tn < 4; ++tn) {
-                        pv[st][tn][0] = pack_bf16x2(accV[st][tn][0], accV[st][tn][1]);
-                        pv[st][tn][1] = pack_bf16x2(accV[st][tn][2], accV[st][tn][3]);
-                    }
-            }
-            f32x4 accK[4][4];
-#pragma unroll
-            for (int st = 0; st < 4; ++st)
-#pragma unroll
-                for (int tn = 0; tn < 4; ++tn) accK[st][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
-            {
-                bf16x8 vv[4][2];
-                load_a64<false>(vv, vb, a.v.sn, a.idx, p0, rv, 0.f, lane);
-                chunk_times_gt<true>(accK, vv, Gb, lane);    // dK[s][d1] = sum_d2 V[s][d2] dKVt[d2][d1]
-            }
-            if (a.normalize) {
-#pragma unroll
-                for (int tn = 0; tn < 4; ++tn) {
-                    const float dk = a.dksum[((long)bh * M + j) * 64 + tn * 16 + n];
-#pragma unroll
-                    for (int st = 0; st < 4; ++st)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) accK[st][tn][r] += dk;
-                }
-            }
-            if (last) {
-                wave_lds_fence();
-                stage64(Gb, accK, lane);
-                wave_lds_fence();
-                if (a.relu) store64<true>(dkb, a.dk.sn, a.idx, p0, rv, Gb, kb, a.k.sn, lane);
-                else        store64<false>(dkb, a.dk.sn, a.idx, p0, rv, Gb, nullptr, 0, lane);
-                wave_lds_fence();
-#pragma unroll
-                for (int st = 0; st < 4; ++st)
-#pragma unroll
-                    for (int tn = 0; tn < 4; ++tn)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            Gb[(st * 16 + kg * 4 + r) * GLD + tn * 16 + n] = (u16)(pv[st][tn][r >> 1] >> ((r & 1) * 16));
-                wave_lds_fence();
-                store64<false>(dvb, a.dv.sn, a.idx, p0, rv, Gb, nullptr, 0, lane);
-            } else {
-                if (a.relu) store64_direct<true>(dkb, a.dk.sn, a.idx, p0, rv, accK, kb, a.k.sn, lane);
-                else        store64_direct<false>(dkb, a.dk.sn, a.idx, p0, rv, accK, nullptr, 0, lane);
-#pragma unroll
-                for (int st = 0; st < 4; ++st)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = st * 16 + kg * 4 + r;
-                        if (row < rv) {
-                            const long tr = tok_row(a.idx, p0 + row);
-#pragma unroll
-                            for (int tn = 0; tn < 4; ++tn)
-                                dvb[tr * a.dv.sn + tn * 16 + n] = (u16)(pv[st][tn][r >> 1] >> ((r & 1) * 16));
-                        }
-                    }
-            }
+            bf16x8 kv[4][2];
+            load_k(kv, j, c0, rv);
+            compute_store(kv, bi, j, c0, rv);
         }
     }
 }
