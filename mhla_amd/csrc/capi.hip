@@ -308,13 +308,7 @@ int mhla_blockmix_fwd(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q
         fast::FsOutArgs oa{};
         oa.q = cv(q_num); oa.o = cmv(out); oa.idx = block_index; oa.W = W; oa.ldw = ldw; oa.state = f.state; oa.ninv = f.ninv;
         oa.H = H; oa.M = M; oa.S = S; oa.njg = f.njg; oa.eps = eps; oa.relu = relu; oa.normalize = normalize;
-        { const char* d = getenv("MHLA_DBG"); oa.dbg = d ? atoi(d) : 0; }
-        if (S <= 64 && !(oa.dbg & 4)) {
-            const int ntiles = f.njg * B * H;
-            RC(launch(fast::k_fs_out_ws, dim3(ntiles < 256 ? ntiles : 256), dim3(512), fast::FS_OUT_WS_SMEM, st, "k_fs_out_ws", oa, ntiles));
-        } else {
-            RC(launch(fast::k_fs_out, dim3(f.njg * B * H), dim3(fast::FT), fast::FS_OUT_SMEM, st, "k_fs_out", oa));
-        }
+        RC(launch(fast::k_fs_out, dim3(f.njg * B * H), dim3(fast::FT), fast::FS_OUT_SMEM, st, "k_fs_out", oa));
         return MHLA_OK;
     }
     const BmWs w = bm_carve(ws, B, H, M, S, D);

@@ -537,7 +537,6 @@ struct FsOutArgs {
     int H, M, S, njg;
     float eps;
     int relu, normalize;
-    int dbg;            // ablation switches (MHLA_DBG env, bench experiments only)
 };
 constexpr int FS_GT_BYTES = IT * FD * GLD * 2;
 constexpr int FS_OUT_SMEM = FS_GT_BYTES;
@@ -594,9 +593,8 @@ __global__ __launch_bounds__(FT, 2) void k_fs_out(const FsOutArgs a) {
         bf16x8 avA[4][2], avB[4][2];
         float ninvA = 1.f, ninvB = 1.f;
         if (iA < M) load_blk(avA, ninvA, iA, 0, S);
-        if (!(a.dbg & 1)) mix_tile_to_lds<0>(Gt, state_bh, a.njg, a.W, a.ldw, M, it * IT, tid);
+        mix_tile_to_lds<0>(Gt, state_bh, a.njg, a.W, a.ldw, M, it * IT, tid);
         __syncthreads();
-        if (a.dbg & 2) return;
         if (iB < M) load_blk(avB, ninvB, iB, 0, S);
         if (iA < M) compute_store(avA, ninvA, wave, iA, 0, S);
         if (iB < M) compute_store(avB, ninvB, wave + 4, iB, 0, S);
@@ -615,89 +613,6 @@ __global__ __launch_bounds__(FT, 2) void k_fs_out(const FsOutArgs a) {
             load_blk(av, ninv, i, c0, rv);
             compute_store(av, ninv, bi, i, c0, rv);
         }
-    }
-}
-
-// -------------------------------------------------------------------------------------------------
-// k_fs_out_ws: warp-specialised persistent form of k_fs_out (S <= 64).  512 threads, one workgroup per CU:
-// waves 0-3 mix the summaries of tile t+1 into one Gt buffer (L2-bound) while waves 4-7 turn tile t's
-// buffer into outputs (HBM-bound); one barrier per tile.  Tiles of one (b,h) stay on one XCD.
-// -------------------------------------------------------------------------------------------------
-constexpr int FS_OUT_WS_SMEM = 2 * FS_GT_BYTES;
-
-__global__ __launch_bounds__(512) void k_fs_out_ws(const FsOutArgs a, int ntiles) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    u16* Gt0 = reinterpret_cast<u16*>(smem_raw);
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, kg = lane >> 4;
-    const int role = wave >> 2, w4 = wave & 3, tid4 = tid & 255;
-    const int S = a.S, M = a.M;
-    const int rounds = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-
-    auto tile_of = [&](int r, int& bh, int& it) {
-        const int L = xcd_swizzle((int)blockIdx.x + r * (int)gridDim.x, ntiles);
-        bh = L / a.njg;
-        it = L - bh * a.njg;
-    };
-    auto mix = [&](int r) {
-        int bh, it;
-        tile_of(r, bh, it);
-        mix_tile_to_lds<0>(Gt0 + (r & 1) * (FS_GT_BYTES / 2), a.state + (long)bh * a.njg * FE * IT, a.njg, a.W, a.ldw, M, it * IT, tid4);
-    };
-    auto consume = [&](int r) {
-        int bh, it;
-        tile_of(r, bh, it);
-        const int b = bh / a.H, h = bh - b * a.H;
-        const u16* qb = (const u16*)a.q.ptr + b * a.q.sb + h * a.q.sh;
-        u16* ob = (u16*)a.o.ptr + b * a.o.sb + h * a.o.sh;
-        const float* ninv_bh = a.ninv + (long)bh * M * S;
-        u16* Gt = Gt0 + (r & 1) * (FS_GT_BYTES / 2);
-        bf16x8 av[2][4][2];
-        float ninv[2];
-#pragma unroll
-        for (int x = 0; x < 2; ++x) {   // both blocks' operands in flight at once
-            const int i = it * IT + w4 + 4 * x;
-            ninv[x] = 1.f;
-            if (i < M) {
-                if (a.relu) load_a64<true>(av[x], qb, a.q.sn, a.idx, (long)i * S, S, a.eps, lane);
-                else        load_a64<false>(av[x], qb, a.q.sn, a.idx, (long)i * S, S, a.eps, lane);
-                if (a.normalize && lane < S) ninv[x] = ninv_bh[(long)i * S + lane];
-            }
-        }
-#pragma unroll
-        for (int x = 0; x < 2; ++x) {
-            const int bi = w4 + 4 * x, i = it * IT + bi;
-            if (i >= M) continue;
-            u16* Gb = Gt + bi * FD * GLD;
-            f32x4 acc[4][4];
-#pragma unroll
-            for (int st = 0; st < 4; ++st)
-#pragma unroll
-                for (int tn = 0; tn < 4; ++tn) acc[st][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
-            chunk_times_gt<false>(acc, av[x], Gb, lane);
-#pragma unroll
-            for (int st = 0; st < 4; ++st)
-#pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) {
-                    const float ni = __shfl(ninv[x], st * 16 + kg * 4 + r4, 64);
-#pragma unroll
-                    for (int tn = 0; tn < 4; ++tn) acc[st][tn][r4] *= ni;
-                }
-            wave_lds_fence();
-            stage64(Gb, acc, lane);
-            wave_lds_fence();
-            store64<false>(ob, a.o.sn, a.idx, (long)i * S, S, Gb, nullptr, 0, lane);
-        }
-    };
-
-    if (role == 0) mix(0);
-    __syncthreads();
-    for (int r = 0; r < rounds; ++r) {
-        if (role == 0) {
-            if (r + 1 < rounds) mix(r + 1);
-        } else {
-            consume(r);
-        }
-        __syncthreads();
     }
 }
 
