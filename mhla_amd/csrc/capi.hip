@@ -302,13 +302,13 @@ int mhla_blockmix_fwd(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q
         fast::FsStateArgs sa{};
         sa.x = cv(k_num); sa.y = cv(v); sa.t = cv(q_num); sa.idx = block_index; sa.state = f.state; sa.ksum = f.ksum;
         sa.z_out = f.z; sa.H = H; sa.M = M; sa.S = S; sa.eps = eps; sa.relu = relu; sa.normalize = normalize;
-        RC(launch(fast::k_fs_state<0>, dim3(f.njg, B * H), dim3(fast::FT), fast::FS_STATE_SMEM, st, "k_fs_state<0>", sa));
+        RC(launch(fast::k_fs_state<0>, dim3(f.njg, B * H), dim3(fast::FT8), fast::FS_STATE_SMEM, st, "k_fs_state<0>", sa));
         if (normalize)
             RC(launch(fast::k_fs_wz<0>, dim3((S + 63) / 64, B * H), dim3(fast::FT), 0, st, "k_fs_wz<0>", W, ldw, (const float*)f.z, f.ninv, M, S, eps));
         fast::FsOutArgs oa{};
         oa.q = cv(q_num); oa.o = cmv(out); oa.idx = block_index; oa.W = W; oa.ldw = ldw; oa.state = f.state; oa.ninv = f.ninv;
         oa.H = H; oa.M = M; oa.S = S; oa.njg = f.njg; oa.eps = eps; oa.relu = relu; oa.normalize = normalize;
-        RC(launch(fast::k_fs_out, dim3(f.njg * B * H), dim3(fast::FT), fast::FS_OUT_SMEM, st, "k_fs_out", oa));
+        RC(launch(fast::k_fs_out, dim3(f.njg * B * H), dim3(fast::FT8), fast::FS_OUT_SMEM, st, "k_fs_out", oa));
         return MHLA_OK;
     }
     const BmWs w = bm_carve(ws, B, H, M, S, D);
@@ -360,18 +360,18 @@ int mhla_blockmix_bwd(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q
                 fast::FsStateArgs sa{};
                 sa.x = cv(k_num); sa.y = cv(v); sa.t = cv(q_num); sa.idx = block_index; sa.state = f.state; sa.ksum = f.ksum;
                 sa.z_out = f.z; sa.H = H; sa.M = M; sa.S = S; sa.eps = eps; sa.relu = relu; sa.normalize = normalize;
-                RC(launch(fast::k_fs_state<0>, dim3(f.njg, B * H), dim3(fast::FT), fast::FS_STATE_SMEM, st, "k_fs_state<0>", sa));
+                RC(launch(fast::k_fs_state<0>, dim3(f.njg, B * H), dim3(fast::FT8), fast::FS_STATE_SMEM, st, "k_fs_state<0>", sa));
                 if (normalize)
                     RC(launch(fast::k_fs_wz<0>, dim3((S + 63) / 64, B * H), dim3(fast::FT), 0, st, "k_fs_wz<0>", W, ldw, (const float*)f.z, f.ninv, M, S, eps));
             }
             fast::FsStateArgs ga{};
             ga.x = cv(q_num); ga.y = cv(dout); ga.t = cv(out); ga.idx = block_index; ga.W = W; ga.ldw = ldw; ga.ninv = ninv;
             ga.state = f.dstate; ga.dn = f.dn; ga.H = H; ga.M = M; ga.S = S; ga.eps = eps; ga.relu = relu; ga.normalize = normalize;
-            RC(launch(fast::k_fs_state<1>, dim3(f.njg, B * H), dim3(fast::FT), fast::FS_STATE_SMEM, st, "k_fs_state<1>", ga));
+            RC(launch(fast::k_fs_state<1>, dim3(f.njg, B * H), dim3(fast::FT8), fast::FS_STATE_SMEM, st, "k_fs_state<1>", ga));
             fast::FsDwArgs da{f.dstate, state, normalize ? f.dn : nullptr, z, f.dwp, M, S, f.njg};
             if (normalize)
                 RC(launch(fast::k_fs_wz<1>, dim3((S + 63) / 64, B * H), dim3(fast::FT), 0, st, "k_fs_wz<1>", W, ldw, (const float*)f.dn, f.dz, M, S, 0.f));
-            RC(launch(fast::k_fs_dw, dim3(fast::DW_SPLIT, B * H), dim3(fast::FT), fast::FS_DW_SMEM, st, "k_fs_dw", da));
+            RC(launch(fast::k_fs_dw, dim3(fast::DW_SPLIT, B * H), dim3(fast::FT8), fast::FS_DW_SMEM, st, "k_fs_dw", da));
             const int nparts = B * H * fast::DW_SPLIT, ngroups = (nparts + fast::DWR_G - 1) / fast::DWR_G;
             RC(launch(fast::k_fs_dw_reduce1, dim3(16, ngroups), dim3(256), 0, st, "k_fs_dw_reduce1", (const float*)f.dwp, f.dwt, nparts));
             RC(launch(fast::k_fs_dw_reduce2, dim3((M * M + 255) / 256), dim3(256), 0, st, "k_fs_dw_reduce2", (const float*)f.dwt, dW, M, ngroups));
@@ -381,8 +381,8 @@ int mhla_blockmix_bwd(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q
             ta.dz = f.dz; ta.ksum = ksum; ta.H = H; ta.M = M; ta.S = S; ta.njg = f.njg; ta.eps = eps; ta.relu = relu;
             ta.normalize = normalize;
             ta.dksum = f.dksum;
-            RC(launch(fast::k_fs_bwd_dq, dim3(f.njg * B * H), dim3(fast::FT), fast::FS_TOK_SMEM, st, "k_fs_bwd_dq", ta));
-            RC(launch(fast::k_fs_bwd_dkv, dim3(f.njg * B * H), dim3(fast::FT), fast::FS_TOK_SMEM, st, "k_fs_bwd_dkv", ta));
+            RC(launch(fast::k_fs_bwd_dq, dim3(f.njg * B * H), dim3(fast::FT8), fast::FS_TOK_SMEM, st, "k_fs_bwd_dq", ta));
+            RC(launch(fast::k_fs_bwd_dkv, dim3(f.njg * B * H), dim3(fast::FT8), fast::FS_TOK_SMEM, st, "k_fs_bwd_dkv", ta));
             return MHLA_OK;
         }
     }

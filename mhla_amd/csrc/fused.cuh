@@ -12,7 +12,11 @@
 //
 //   forward : k_fs_state<0> (KV^T, ksum, z)  ->  k_fs_out (mix + n + O)
 //   backward: k_fs_state<1> (dG^T, dn) -> k_fs_dw (dW partials) -> k_fs_bwd_dq (mix G; dQ, dksum) -> k_fs_bwd_dkv (mix dKV; dK, dV)
+// The kernels are bound by per-wave load latency, not bandwidth (PMC: 3-4 TB/s, waves mostly in s_waitcnt), so
+// the streaming kernels run 8-wave workgroups at <= 128 VGPRs: two workgroups = 16 waves per CU keep loads in flight.
 #pragma once
+#include <type_traits>
+
 #include "common.cuh"
 
 namespace mhla {
@@ -29,7 +33,8 @@ constexpr int FE = FD * FD;    // elements of one block summary
 constexpr int TLD = 80;        // LDS row stride (bf16) of [rows][64] token tiles read with ds_read_b64_tr_b16
 constexpr int GLD = 72;        // LDS row stride (bf16) of the mixed summaries Gt[i][d2][d1]
 constexpr int IT = 8;          // blocks per workgroup tile (= interleave factor of the state layout)
-constexpr int FT = 256;        // threads per workgroup
+constexpr int FT = 256;        // threads per workgroup of the small kernels
+constexpr int FT8 = 512;       // 8-wave workgroups of the streaming kernels: <= 128 VGPRs -> 16 waves per CU in flight
 
 #define LDS_S16X4(p) ((__attribute__((address_space(3))) s16x4*)(p))
 
@@ -61,40 +66,7 @@ __device__ __forceinline__ uint4 relu_eps8(uint4 v, float eps) {
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-// Stage rows [p0, p0 + rv) x 64 bf16 of a token view into an LDS tile [rfill][TLD] (rows >= rv zero).
-// 256 threads: thread t -> row t >> 2, 16 columns starting at (t & 3) * 16.
-template <bool RELU>
-__device__ __forceinline__ void stage_rows(u16* __restrict__ dst, const u16* __restrict__ base, long sn,
-                                           const int* __restrict__ idx, long p0, int rv, int rfill, float eps, int tid) {
-    for (int r = tid >> 2; r < rfill; r += FT / 4) {
-        const int c = (tid & 3) * 16;
-        uint4 a = make_uint4(0, 0, 0, 0), b = a;
-        if (r < rv) {
-            const u16* src = base + tok_row(idx, p0 + r) * sn + c;
-            a = *reinterpret_cast<const uint4*>(src);
-            b = *reinterpret_cast<const uint4*>(src + 8);
-            if (RELU) { a = relu_eps8(a, eps); b = relu_eps8(b, eps); }
-        }
-        *reinterpret_cast<uint4*>(dst + r * TLD + c) = a;
-        *reinterpret_cast<uint4*>(dst + r * TLD + c + 8) = b;
-    }
-}
-
 __device__ __forceinline__ float bf(u16 h) { return __uint_as_float(((unsigned)h) << 16); }
-
-// Partial sums of a [M] x [M, S] product for one 64-token chunk: thread (s = tid & 63, q = tid >> 6) adds the
-// terms j = q, q + 4, ...  of  sum_j w[j * wstride] * x[j * S + s]; the four partials of a column are summed
-// by the reader after a barrier (wz_sum).  Used for n_i = W[i,:] z + eps and dz_j = W[:,j]^T dn.
-__device__ __forceinline__ float wz_partial(const float* __restrict__ w, long wstride, const float* __restrict__ x,
-                                            int M, int S, int s, bool valid, int q) {
-    float acc = 0.f;
-    if (valid)
-        for (int j = q; j < M; j += 4) acc += w[(long)j * wstride] * x[(long)j * S + s];
-    return acc;
-}
-__device__ __forceinline__ float wz_sum(const float* __restrict__ part, int row) {
-    return part[row] + part[64 + row] + part[128 + row] + part[192 + row];
-}
 
 // -------------------------------------------------------------------------------------------------
 // k_fs_wz: the two small [M x M] x [M x S] products per (b,h), done once instead of per consumer wave:
@@ -151,6 +123,8 @@ __global__ __launch_bounds__(FT) void k_fs_wz(const float* __restrict__ W, int l
 // k_fs_state: per (block group jg, bh): 8 block summaries in the interleaved transposed layout.
 //   MODE 0 (forward) : state = V_j^T K_j ; ksum_j ; z_j[s] = Q_j[s] . ksum_j
 //   MODE 1 (backward): state = dP_i^T Q_i with dP = dO / n ; dn_i[s] = -(dO_i[s] . O_i[s]) / n_i[s]
+// 8 waves: wave w owns rows d2 = 16 (w & 3) .. and columns d1 = 32 (w >> 2) .. of every summary.
+// Token tiles are fetched two blocks ahead into registers (S <= 64) and committed to LDS when needed.
 // -------------------------------------------------------------------------------------------------
 struct FsStateArgs {
     View x;   // MODE 0: k     MODE 1: q     (B operand: columns d1)
@@ -168,160 +142,198 @@ struct FsStateArgs {
     float eps;
     int relu, normalize;
 };
-constexpr int FS_STATE_SMEM = 3 * 64 * TLD * 2 + (4 * 64 + 64) * 4;
+constexpr int FS_STATE_SMEM = 3 * 64 * TLD * 2 + (8 * 64 + 64) * 4;
 
-struct TileRegs { uint4 x0, x1, y0, y1, t0, t1; };
+struct TileRegs { uint4 x, y, t; };
 
 template <int MODE>
-__global__ __launch_bounds__(FT) void k_fs_state(const FsStateArgs a) {
+__global__ __launch_bounds__(FT8, 4) void k_fs_state(const FsStateArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u16* Xs = reinterpret_cast<u16*>(smem_raw);
     u16* Ys = Xs + 64 * TLD;
     u16* Ts = Ys + 64 * TLD;
-    float* part = reinterpret_cast<float*>(Ts + 64 * TLD);   // [4][64]
-    float* ksum_s = part + 256;                              // [64]
+    float* part = reinterpret_cast<float*>(Ts + 64 * TLD);   // [8][64]
+    float* ksum_s = part + 512;                              // [64]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int dt = wave & 3, th = wave >> 2;
     const int jg = blockIdx.x, bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
     const int S = a.S, M = a.M, njg = gridDim.x;
     const u16* xb = (const u16*)a.x.ptr + b * a.x.sb + h * a.x.sh;
     const u16* yb = (const u16*)a.y.ptr + b * a.y.sb + h * a.y.sh;
     const u16* tb = a.normalize ? (const u16*)a.t.ptr + b * a.t.sb + h * a.t.sh : nullptr;
     const bool single = S <= 64;
-    const int srow = tid >> 2, scol = (tid & 3) * 16;        // staging: thread -> (row, 16 columns)
+    const int srow = tid >> 3, scol = (tid & 7) * 8;         // staging: thread -> (row, 8 columns = 16 bytes)
+    const bool tile_t = a.normalize && (MODE == 1 || single);   // third tile travels with the chunk
 
-    // global -> registers for one 64-row chunk (rows >= rv give zeros); registers -> LDS separately so that
-    // the next chunk's loads are in flight while the current one is being multiplied
-    auto issue = [&](long p, int rv, bool with_t, TileRegs& R) {
-        const uint4 zero = make_uint4(0, 0, 0, 0);
-        R.x0 = R.x1 = R.y0 = R.y1 = R.t0 = R.t1 = zero;
+    auto issue = [&](long p, int rv, TileRegs& R) {
+        R.x = R.y = R.t = make_uint4(0, 0, 0, 0);
         if (srow < rv) {
             const long tr = tok_row(a.idx, p + srow);
-            const u16* px = xb + tr * a.x.sn + scol;
-            const u16* py = yb + tr * a.y.sn + scol;
-            R.x0 = *reinterpret_cast<const uint4*>(px);
-            R.x1 = *reinterpret_cast<const uint4*>(px + 8);
-            R.y0 = *reinterpret_cast<const uint4*>(py);
-            R.y1 = *reinterpret_cast<const uint4*>(py + 8);
-            if (with_t) {
-                const u16* pt = tb + tr * a.t.sn + scol;
-                R.t0 = *reinterpret_cast<const uint4*>(pt);
-                R.t1 = *reinterpret_cast<const uint4*>(pt + 8);
-            }
+            R.x = *reinterpret_cast<const uint4*>(xb + tr * a.x.sn + scol);
+            R.y = *reinterpret_cast<const uint4*>(yb + tr * a.y.sn + scol);
+            if (tile_t) R.t = *reinterpret_cast<const uint4*>(tb + tr * a.t.sn + scol);
         }
     };
-    auto commit = [&](const TileRegs& R, int rv, int rfill, bool with_t) {
+    auto commit = [&](const TileRegs& R, int rv, int rfill) {
         if (srow < rfill) {
-            uint4 x0 = R.x0, x1 = R.x1, t0 = R.t0, t1 = R.t1;
+            uint4 x = R.x, t = R.t;
             if (a.relu && srow < rv) {
-                x0 = relu_eps8(x0, a.eps); x1 = relu_eps8(x1, a.eps);
-                if (MODE == 0 && with_t) { t0 = relu_eps8(t0, a.eps); t1 = relu_eps8(t1, a.eps); }
+                x = relu_eps8(x, a.eps);
+                if (MODE == 0 && tile_t) t = relu_eps8(t, a.eps);
             }
-            *reinterpret_cast<uint4*>(Xs + srow * TLD + scol) = x0;
-            *reinterpret_cast<uint4*>(Xs + srow * TLD + scol + 8) = x1;
-            *reinterpret_cast<uint4*>(Ys + srow * TLD + scol) = R.y0;
-            *reinterpret_cast<uint4*>(Ys + srow * TLD + scol + 8) = R.y1;
-            if (with_t) {
-                *reinterpret_cast<uint4*>(Ts + srow * TLD + scol) = t0;
-                *reinterpret_cast<uint4*>(Ts + srow * TLD + scol + 8) = t1;
-            }
+            *reinterpret_cast<uint4*>(Xs + srow * TLD + scol) = x;
+            *reinterpret_cast<uint4*>(Ys + srow * TLD + scol) = R.y;
+            if (tile_t) *reinterpret_cast<uint4*>(Ts + srow * TLD + scol) = t;
         }
     };
 
-    f32x4 acc[IT][4];
+    f32x4 acc[IT][2];
 #pragma unroll
-    for (int jj = 0; jj < IT; ++jj)
-#pragma unroll
-        for (int tn = 0; tn < 4; ++tn) acc[jj][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int jj = 0; jj < IT; ++jj) acc[jj][0] = acc[jj][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const bool tile_t = a.normalize && (MODE == 1 || single);   // third tile staged with the chunk
-    TileRegs R;
-    if (jg * IT < M) issue((long)jg * IT * S, min(64, S), tile_t, R);
-
+    // one staged 64-row chunk of block jj (tiles in LDS, barrier done): side products + MFMAs
+    auto chunk = [&](auto jjc, int j, int c0, int rv, int rfill, float& ks) {
+        constexpr int jj = decltype(jjc)::value;
+        if (MODE == 0 && a.normalize) {   // column sums of K: thread -> column tid & 63, rows 8 (tid >> 6) ..
+            const int col = tid & 63, pr = tid >> 6;
+            for (int r = pr * 8; r < min(rv, pr * 8 + 8); ++r) ks += bf(Xs[r * TLD + col]);
+        }
+        if (MODE == 1 && a.normalize) {   // dn and dP = dO / n (rounded to bf16); 8 threads per row, 16 bytes each
+            float d = 0.f;
+            uint4 yv = make_uint4(0, 0, 0, 0);
+            if (srow < rv) {
+                yv = *reinterpret_cast<const uint4*>(Ys + srow * TLD + scol);
+                const uint4 ov = *reinterpret_cast<const uint4*>(Ts + srow * TLD + scol);
+                const unsigned yw[4] = {yv.x, yv.y, yv.z, yv.w}, ow[4] = {ov.x, ov.y, ov.z, ov.w};
 #pragma unroll
-    for (int jj = 0; jj < IT; ++jj) {
-        const int j = jg * IT + jj;
-        if (j >= M) continue;
+                for (int i = 0; i < 4; ++i)
+                    d += __uint_as_float(yw[i] << 16) * __uint_as_float(ow[i] << 16) +
+                         __uint_as_float(yw[i] & 0xffff0000u) * __uint_as_float(ow[i] & 0xffff0000u);
+            }
+            d += __shfl_xor(d, 1, 64);
+            d += __shfl_xor(d, 2, 64);
+            d += __shfl_xor(d, 4, 64);
+            if (srow < rv) {
+                const float ni = a.ninv[((long)bh * M + j) * S + c0 + srow];
+                if ((tid & 7) == 0) a.dn[((long)bh * M + j) * S + c0 + srow] = -d * ni;
+                unsigned yw[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    yw[i] = pack_bf16x2(__uint_as_float(yw[i] << 16) * ni, __uint_as_float(yw[i] & 0xffff0000u) * ni);
+                *reinterpret_cast<uint4*>(Ys + srow * TLD + scol) = make_uint4(yw[0], yw[1], yw[2], yw[3]);
+            }
+            __syncthreads();
+        }
+        for (int k0 = 0; k0 < rfill; k0 += 32) {
+            const bf16x8 av = tr_read8(Ys, TLD, k0, dt * 16, lane);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) acc[jj][t] = mfma_bf16(av, tr_read8(Xs, TLD, k0, (2 * th + t) * 16, lane), acc[jj][t]);
+        }
+    };
+    // ksum_j and z_j once all chunks of block j went through (MODE 0)
+    auto finish_block = [&](int j, float ks) {
         const long p0 = (long)j * S;
-        float ks = 0.f;
+        part[(tid >> 6) * 64 + (tid & 63)] = ks;
+        __syncthreads();
+        if (tid < 64) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) sacc += part[p * 64 + tid];
+            ksum_s[tid] = sacc;
+            a.ksum[((long)bh * M + j) * 64 + tid] = sacc;
+        }
+        __syncthreads();
         for (int c0 = 0; c0 < S; c0 += 64) {
-            const int rv = min(64, S - c0), rfill = (rv + 31) & ~31;
-            commit(R, rv, rfill, tile_t);
-            {   // prefetch the next chunk (same block, or the next block of the group)
-                long pn = -1;
-                int rvn = 0;
-                if (c0 + 64 < S) { pn = p0 + c0 + 64; rvn = min(64, S - c0 - 64); }
-                else if (jj + 1 < IT && j + 1 < M) { pn = (long)(j + 1) * S; rvn = min(64, S); }
-                if (pn >= 0) issue(pn, rvn, tile_t, R);
-            }
-            __syncthreads();
-            if (MODE == 0 && a.normalize) {   // column sums of K
-                const int col = tid & 63, pr = tid >> 6;
-                for (int r = pr * 16; r < min(rv, pr * 16 + 16); ++r) ks += bf(Xs[r * TLD + col]);
-            }
-            if (MODE == 1 && a.normalize) {   // dn and dP = dO / n (rounded to bf16)
-                const int r = srow, cq = scol;
-                float d = 0.f;
-                if (r < rv) {
-#pragma unroll
-                    for (int c = 0; c < 16; ++c) d += bf(Ys[r * TLD + cq + c]) * bf(Ts[r * TLD + cq + c]);
-                }
-                d += __shfl_xor(d, 1, 64);
-                d += __shfl_xor(d, 2, 64);
-                if (r < rv) {
-                    const float ni = a.ninv[((long)bh * M + j) * S + c0 + r];
-                    if ((tid & 3) == 0) a.dn[((long)bh * M + j) * S + c0 + r] = -d * ni;
-#pragma unroll
-                    for (int c = 0; c < 16; ++c) Ys[r * TLD + cq + c] = cvt_bf16(bf(Ys[r * TLD + cq + c]) * ni);
-                }
-                __syncthreads();
-            }
-            for (int k0 = 0; k0 < rfill; k0 += 32) {
-                const bf16x8 av = tr_read8(Ys, TLD, k0, wave * 16, lane);
-#pragma unroll
-                for (int tn = 0; tn < 4; ++tn) acc[jj][tn] = mfma_bf16(av, tr_read8(Xs, TLD, k0, tn * 16, lane), acc[jj][tn]);
-            }
-            if (!(MODE == 0 && a.normalize && single)) __syncthreads();   // (single: the z pass below syncs)
-        }
-        if (MODE == 0 && a.normalize) {
-            part[(tid >> 6) * 64 + (tid & 63)] = ks;
-            __syncthreads();
-            if (tid < 64) {
-                const float sacc = part[tid] + part[64 + tid] + part[128 + tid] + part[192 + tid];
-                ksum_s[tid] = sacc;
-                a.ksum[((long)bh * M + j) * 64 + tid] = sacc;
-            }
-            __syncthreads();
-            for (int c0 = 0; c0 < S; c0 += 64) {
-                const int rv = min(64, S - c0);
-                if (!single) {   // (rare) multi-chunk blocks: second pass over Q, synchronous
-                    if (a.relu) stage_rows<true>(Ts, tb, a.t.sn, a.idx, p0 + c0, rv, rv, a.eps, tid);
-                    else        stage_rows<false>(Ts, tb, a.t.sn, a.idx, p0 + c0, rv, rv, 0.f, tid);
-                    __syncthreads();
-                }
-                float d = 0.f;
+            const int rv = min(64, S - c0);
+            if (!single) {   // (rare) multi-chunk blocks: second pass over Q, synchronous
+                uint4 t = make_uint4(0, 0, 0, 0);
                 if (srow < rv) {
-#pragma unroll
-                    for (int c = 0; c < 16; ++c) d += bf(Ts[srow * TLD + scol + c]) * ksum_s[scol + c];
+                    t = *reinterpret_cast<const uint4*>(tb + tok_row(a.idx, p0 + c0 + srow) * a.t.sn + scol);
+                    if (a.relu) t = relu_eps8(t, a.eps);
                 }
-                d += __shfl_xor(d, 1, 64);
-                d += __shfl_xor(d, 2, 64);
-                if (srow < rv && (tid & 3) == 0) a.z_out[((long)bh * M + j) * S + c0 + srow] = d;
+                *reinterpret_cast<uint4*>(Ts + srow * TLD + scol) = t;
                 __syncthreads();
             }
+            float d = 0.f;
+            if (srow < rv) {
+                const uint4 qv = *reinterpret_cast<const uint4*>(Ts + srow * TLD + scol);
+                const unsigned qw[4] = {qv.x, qv.y, qv.z, qv.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    d += __uint_as_float(qw[i] << 16) * ksum_s[scol + 2 * i] + __uint_as_float(qw[i] & 0xffff0000u) * ksum_s[scol + 2 * i + 1];
+            }
+            d += __shfl_xor(d, 1, 64);
+            d += __shfl_xor(d, 2, 64);
+            d += __shfl_xor(d, 4, 64);
+            if (srow < rv && (tid & 7) == 0) a.z_out[((long)bh * M + j) * S + c0 + srow] = d;
+            __syncthreads();
         }
+    };
+
+    if (single) {
+        // software pipeline, two blocks ahead: R[jj & 1] carries block jj
+        TileRegs R0, R1;
+        if (jg * IT < M) issue((long)jg * IT * S, S, R0);
+        if (jg * IT + 1 < M) issue((long)(jg * IT + 1) * S, S, R1);
+        const int rfill = (S + 31) & ~31;
+        auto step = [&](auto jjc, TileRegs& R) {
+            constexpr int jj = decltype(jjc)::value;
+            const int j = jg * IT + jj;
+            if (j >= M) return;
+            commit(R, S, rfill);
+            if (jj + 2 < IT && j + 2 < M) issue((long)(j + 2) * S, S, R);
+            __syncthreads();
+            float ks = 0.f;
+            chunk(jjc, j, 0, S, rfill, ks);
+            if (MODE == 0 && a.normalize) finish_block(j, ks);   // ends with a barrier
+            else __syncthreads();
+        };
+        step(std::integral_constant<int, 0>{}, R0);
+        step(std::integral_constant<int, 1>{}, R1);
+        step(std::integral_constant<int, 2>{}, R0);
+        step(std::integral_constant<int, 3>{}, R1);
+        step(std::integral_constant<int, 4>{}, R0);
+        step(std::integral_constant<int, 5>{}, R1);
+        step(std::integral_constant<int, 6>{}, R0);
+        step(std::integral_constant<int, 7>{}, R1);
+    } else {
+        TileRegs R;
+        auto blockloop = [&](auto jjc) {
+            constexpr int jj = decltype(jjc)::value;
+            const int j = jg * IT + jj;
+            if (j >= M) return;
+            const long p0 = (long)j * S;
+            float ks = 0.f;
+            for (int c0 = 0; c0 < S; c0 += 64) {
+                const int rv = min(64, S - c0), rfill = (rv + 31) & ~31;
+                issue(p0 + c0, rv, R);
+                commit(R, rv, rfill);
+                __syncthreads();
+                chunk(jjc, j, c0, rv, rfill, ks);
+                __syncthreads();
+            }
+            if (MODE == 0 && a.normalize) finish_block(j, ks);
+        };
+        blockloop(std::integral_constant<int, 0>{});
+        blockloop(std::integral_constant<int, 1>{});
+        blockloop(std::integral_constant<int, 2>{});
+        blockloop(std::integral_constant<int, 3>{});
+        blockloop(std::integral_constant<int, 4>{});
+        blockloop(std::integral_constant<int, 5>{});
+        blockloop(std::integral_constant<int, 6>{});
+        blockloop(std::integral_constant<int, 7>{});
     }
 
-    // 16-byte interleaved store: lane -> (d2 = 16 wave + 4 (lane >> 4) + r, d1 = 16 tn + (lane & 15))
+    // 16-byte interleaved store: lane -> (d2 = 16 dt + 4 (lane >> 4) + r, d1 = 16 (2 th + t) + (lane & 15))
     u16* sb = a.state + ((long)bh * njg + jg) * FE * IT;
 #pragma unroll
-    for (int tn = 0; tn < 4; ++tn)
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int d2 = wave * 16 + (lane >> 4) * 4 + r, d1 = tn * 16 + (lane & 15);
+            const int d2 = dt * 16 + (lane >> 4) * 4 + r, d1 = (2 * th + t) * 16 + (lane & 15);
             unsigned w[4];
 #pragma unroll
-            for (int p = 0; p < 4; ++p)
-                w[p] = pack_bf16x2(acc[2 * p][tn][r], acc[2 * p + 1][tn][r]);
+            for (int p = 0; p < 4; ++p) w[p] = pack_bf16x2(acc[2 * p][t][r], acc[2 * p + 1][t][r]);
             *reinterpret_cast<uint4*>(sb + ((long)d2 * FD + d1) * IT) = make_uint4(w[0], w[1], w[2], w[3]);
         }
 }
@@ -331,6 +343,7 @@ __global__ __launch_bounds__(FT) void k_fs_state(const FsStateArgs a) {
 //   TRANSW 0: Wm(i, j) = W[i][j]      TRANSW 1: Wm(i, j) = W[j][i]
 // MFMA: rows = 16 consecutive e' (A operand: one 16-byte global load per lane), cols = the 8 blocks of
 // the tile (B operand: W hi / lo bf16 parts), reduction over j in steps of 32 blocks (M <= 64: 2 steps).
+// All 8 waves; every wave keeps two batches of UN tiles in flight (software double buffer).
 // -------------------------------------------------------------------------------------------------
 template <int TRANSW>
 __device__ __forceinline__ void mix_tile_to_lds(u16* __restrict__ Gt, const u16* __restrict__ state_bh, int njg,
@@ -353,7 +366,7 @@ __device__ __forceinline__ void mix_tile_to_lds(u16* __restrict__ Gt, const u16*
         blo[ks] = __builtin_bit_cast(bf16x8, lo);
     }
     const bool two = njg > 4;
-    constexpr int UN = 4;   // tiles per batch; two batches in flight (software double buffer)
+    constexpr int UN = 4, NW = FT8 / 64;
     const uint4 zero4 = make_uint4(0, 0, 0, 0);
     auto load_batch = [&](uint4 (&av)[UN][2], int et0) {
 #pragma unroll
@@ -384,16 +397,15 @@ __device__ __forceinline__ void mix_tile_to_lds(u16* __restrict__ Gt, const u16*
             }
         }
     };
-    // wave w owns tiles et = 4 UN (w + 4 b) .. : 64 tiles per wave in 16 batches of UN
-    constexpr int NB = FE / 16 / 4 / UN;
+    constexpr int NB = FE / 16 / NW / UN;   // batches per wave (8)
     uint4 bufA[UN][2], bufB[UN][2];
     load_batch(bufA, wave * UN);
 #pragma unroll 1
     for (int bt = 0; bt < NB; bt += 2) {
-        load_batch(bufB, (wave + 4 * (bt + 1)) * UN);
-        do_batch(bufA, (wave + 4 * bt) * UN);
-        if (bt + 2 < NB) load_batch(bufA, (wave + 4 * (bt + 2)) * UN);
-        do_batch(bufB, (wave + 4 * (bt + 1)) * UN);
+        load_batch(bufB, (wave + NW * (bt + 1)) * UN);
+        do_batch(bufA, (wave + NW * bt) * UN);
+        if (bt + 2 < NB) load_batch(bufA, (wave + NW * (bt + 2)) * UN);
+        do_batch(bufB, (wave + NW * (bt + 1)) * UN);
     }
 }
 
@@ -403,14 +415,14 @@ __device__ __forceinline__ int xcd_swizzle(int wg, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
 }
 
-// A operands of a 64-row chunk straight from a token view: a[st][ks] = rows 16 st + (lane & 15),
-// columns 32 ks + 8 (lane >> 4) .. + 7.  Rows >= rv give zeros.
+// A operands of 32 rows (two 16-row tiles) straight from a token view: a[st][ks] = rows 16 st + (lane & 15),
+// columns 32 ks + 8 (lane >> 4) .. + 7.  Rows >= rv (counted from p0) give zeros.
 template <bool RELU>
-__device__ __forceinline__ void load_a64(bf16x8 (&a)[4][2], const u16* __restrict__ base, long sn,
+__device__ __forceinline__ void load_a32(bf16x8 (&a)[2][2], const u16* __restrict__ base, long sn,
                                          const int* __restrict__ idx, long p0, int rv, float eps, int lane) {
     const int m = lane & 15, kg = lane >> 4;
 #pragma unroll
-    for (int st = 0; st < 4; ++st) {
+    for (int st = 0; st < 2; ++st) {
         const int row = st * 16 + m;
         const u16* src = base + (row < rv ? tok_row(idx, p0 + row) : 0) * sn + kg * 8;
 #pragma unroll
@@ -425,11 +437,11 @@ __device__ __forceinline__ void load_a64(bf16x8 (&a)[4][2], const u16* __restric
     }
 }
 
-// acc[st][tn] += A[st] x B  with B from one mixed summary Gb[d2][d1] (GLD stride):
+// acc[st][tn] += A[st] x B  (32 rows) with B from one mixed summary Gb[d2][d1] (GLD stride):
 //   TRB false: B[k = d1][n = d2] = Gb[n][k]  (k contiguous: plain 16-byte LDS reads)
 //   TRB true : B[k = d2][n = d1] = Gb[k][n]  (hardware transpose reads)
 template <bool TRB>
-__device__ __forceinline__ void chunk_times_gt(f32x4 (&acc)[4][4], const bf16x8 (&a)[4][2], const u16* __restrict__ Gb, int lane) {
+__device__ __forceinline__ void rows32_times_gt(f32x4 (&acc)[2][4], const bf16x8 (&a)[2][2], const u16* __restrict__ Gb, int lane) {
     const int n = lane & 15, kg = lane >> 4;
 #pragma unroll
     for (int tn = 0; tn < 4; ++tn) {
@@ -438,9 +450,27 @@ __device__ __forceinline__ void chunk_times_gt(f32x4 (&acc)[4][4], const bf16x8 
             const bf16x8 bv = TRB ? tr_read8(Gb, GLD, ks * 32, tn * 16, lane)
                                   : *reinterpret_cast<const bf16x8*>(Gb + (tn * 16 + n) * GLD + ks * 32 + kg * 8);
 #pragma unroll
-            for (int st = 0; st < 4; ++st) acc[st][tn] = mfma_bf16(a[st][ks], bv, acc[st][tn]);
+            for (int st = 0; st < 2; ++st) acc[st][tn] = mfma_bf16(a[st][ks], bv, acc[st][tn]);
         }
     }
+}
+
+__device__ __forceinline__ void zero_acc(f32x4 (&acc)[2][4]) {
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) acc[st][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// 32 x 64 fp32 results (C layout) packed as bf16 pairs: pk[st][tn][0] = rows (r0, r1), [1] = (r2, r3)
+__device__ __forceinline__ void pack_acc(unsigned (&pk)[2][4][2], const f32x4 (&acc)[2][4]) {
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) {
+            pk[st][tn][0] = pack_bf16x2(acc[st][tn][0], acc[st][tn][1]);
+            pk[st][tn][1] = pack_bf16x2(acc[st][tn][2], acc[st][tn][3]);
+        }
 }
 
 __device__ __forceinline__ void wave_lds_fence() {
@@ -449,15 +479,16 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_wave_barrier();
 }
 
-// Wave-private staging of a 64 x 64 fp32 result (C layout: row = 16 st + 4 (lane >> 4) + r, col = 16 tn + (lane & 15))
-__device__ __forceinline__ void stage64(u16* __restrict__ Os, const f32x4 (&acc)[4][4], int lane) {
+// Wave-private staging of 32 packed rows (row = row0 + 16 st + 4 (lane >> 4) + r, col = 16 tn + (lane & 15))
+__device__ __forceinline__ void stage32(u16* __restrict__ Os, int row0, const unsigned (&pk)[2][4][2], int lane) {
     const int n = lane & 15, kg = lane >> 4;
 #pragma unroll
-    for (int st = 0; st < 4; ++st)
+    for (int st = 0; st < 2; ++st)
 #pragma unroll
         for (int tn = 0; tn < 4; ++tn)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) Os[(st * 16 + kg * 4 + r) * GLD + tn * 16 + n] = cvt_bf16(acc[st][tn][r]);
+            for (int r = 0; r < 4; ++r)
+                Os[(row0 + st * 16 + kg * 4 + r) * GLD + tn * 16 + n] = (u16)(pk[st][tn][r >> 1] >> ((r & 1) * 16));
 }
 
 // zero the bf16 lanes of v where the corresponding element of m is <= 0 (relu gradient mask)
@@ -489,42 +520,31 @@ __device__ __forceinline__ void store64(u16* __restrict__ base, long sn, const i
         }
     }
 }
-// narrow fallback (no free staging slot): direct stores from the C layout
+// narrow fallback (no free staging slot, multi-chunk blocks): direct stores of 32 packed rows from the C layout
 template <bool MASK>
-__device__ __forceinline__ void store64_direct(u16* __restrict__ base, long sn, const int* __restrict__ idx, long p0, int rv,
-                                               const f32x4 (&acc)[4][4], const u16* __restrict__ mbase, long msn, int lane) {
+__device__ __forceinline__ void store32_direct(u16* __restrict__ base, long sn, const int* __restrict__ idx, long p0, int row0,
+                                               int rv, const unsigned (&pk)[2][4][2], const u16* __restrict__ mbase, long msn, int lane) {
     const int n = lane & 15, kg = lane >> 4;
 #pragma unroll
-    for (int st = 0; st < 4; ++st)
+    for (int st = 0; st < 2; ++st)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int row = st * 16 + kg * 4 + r;
+            const int row = row0 + st * 16 + kg * 4 + r;
             if (row < rv) {
                 const long tr = tok_row(idx, p0 + row);
 #pragma unroll
                 for (int tn = 0; tn < 4; ++tn) {
-                    float v = acc[st][tn][r];
-                    if (MASK && !(bf(mbase[tr * msn + tn * 16 + n]) > 0.f)) v = 0.f;
-                    base[tr * sn + tn * 16 + n] = cvt_bf16(v);
+                    u16 v = (u16)(pk[st][tn][r >> 1] >> ((r & 1) * 16));
+                    if (MASK && !(bf(mbase[tr * msn + tn * 16 + n]) > 0.f)) v = 0;
+                    base[tr * sn + tn * 16 + n] = v;
                 }
             }
         }
 }
 
-// lane = row of the chunk: sum_j w[j * wstride] * x[j * S + s]
-__device__ __forceinline__ float col_dot(const float* __restrict__ w, long wstride, const float* __restrict__ x, int M, int S,
-                                         int s, bool valid) {
-    float acc = 0.f;
-    if (valid) {
-#pragma unroll 8
-        for (int j = 0; j < M; ++j) acc += w[(long)j * wstride] * x[(long)j * S + s];
-    }
-    return acc;
-}
-
 // -------------------------------------------------------------------------------------------------
-// k_fs_out: per (tile it, bh): all 4 waves mix the 8 summaries of the tile into LDS; then each wave owns
-// 2 blocks: O_i = (Q_i G_i) / n_i, staged in the block's own (dead) Gt slot -- no block-level barriers.
+// k_fs_out: per (tile it, bh): the 8 waves mix the 8 summaries of the tile into LDS; then wave w owns block w:
+// O_i = (Q_i G_i) / n_i in two 32-row passes, staged in the block's own (dead) Gt slot -- no block barriers.
 // -------------------------------------------------------------------------------------------------
 struct FsOutArgs {
     View q;
@@ -541,7 +561,7 @@ struct FsOutArgs {
 constexpr int FS_GT_BYTES = IT * FD * GLD * 2;
 constexpr int FS_OUT_SMEM = FS_GT_BYTES;
 
-__global__ __launch_bounds__(FT, 2) void k_fs_out(const FsOutArgs a) {
+__global__ __launch_bounds__(FT8, 4) void k_fs_out(const FsOutArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u16* Gt = reinterpret_cast<u16*>(smem_raw);   // [8][64 d2][72]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, kg = lane >> 4;
@@ -551,67 +571,52 @@ __global__ __launch_bounds__(FT, 2) void k_fs_out(const FsOutArgs a) {
     const u16* qb = (const u16*)a.q.ptr + b * a.q.sb + h * a.q.sh;
     u16* ob = (u16*)a.o.ptr + b * a.o.sb + h * a.o.sh;
     const float* ninv_bh = a.ninv + (long)bh * M * S;
+    const int i = it * IT + wave;          // this wave's block
+    u16* Gb = Gt + wave * FD * GLD;
 
-    const u16* state_bh = a.state + (long)bh * a.njg * FE * IT;
-    auto load_blk = [&](bf16x8 (&av)[4][2], float& ninv, int i, int c0, int rv) {
-        const long p0 = (long)i * S + c0;
-        if (a.relu) load_a64<true>(av, qb, a.q.sn, a.idx, p0, rv, a.eps, lane);
-        else        load_a64<false>(av, qb, a.q.sn, a.idx, p0, rv, a.eps, lane);
-        ninv = (a.normalize && lane < rv) ? ninv_bh[(long)i * S + c0 + lane] : 1.f;
+    auto load_half = [&](bf16x8 (&av)[2][2], int c0, int half, int rv) {
+        const long p0 = (long)i * S + c0 + half * 32;
+        if (a.relu) load_a32<true>(av, qb, a.q.sn, a.idx, p0, rv - half * 32, a.eps, lane);
+        else        load_a32<false>(av, qb, a.q.sn, a.idx, p0, rv - half * 32, a.eps, lane);
     };
-    auto compute_store = [&](const bf16x8 (&av)[4][2], float ninv, int bi, int i, int c0, int rv) {
-        const long p0 = (long)i * S + c0;
-        u16* Gb = Gt + bi * FD * GLD;
-        f32x4 acc[4][4];
+    auto half_result = [&](unsigned (&pk)[2][4][2], const bf16x8 (&av)[2][2], float ninv, int half) {
+        f32x4 acc[2][4];
+        zero_acc(acc);
+        rows32_times_gt<false>(acc, av, Gb, lane);
 #pragma unroll
-        for (int st = 0; st < 4; ++st)
-#pragma unroll
-            for (int tn = 0; tn < 4; ++tn) acc[st][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
-        chunk_times_gt<false>(acc, av, Gb, lane);
-#pragma unroll
-        for (int st = 0; st < 4; ++st)
+        for (int st = 0; st < 2; ++st)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float ni = __shfl(ninv, st * 16 + kg * 4 + r, 64);
+                const float ni = __shfl(ninv, half * 32 + st * 16 + kg * 4 + r, 64);
 #pragma unroll
                 for (int tn = 0; tn < 4; ++tn) acc[st][tn][r] *= ni;
             }
+        pack_acc(pk, acc);
+    };
+
+    mix_tile_to_lds<0>(Gt, a.state + (long)bh * a.njg * FE * IT, a.njg, a.W, a.ldw, M, it * IT, tid);
+    __syncthreads();
+    if (i >= M) return;
+
+    for (int c0 = 0; c0 < S; c0 += 64) {
+        const int rv = min(64, S - c0);
+        bf16x8 av0[2][2], av1[2][2];
+        load_half(av0, c0, 0, rv);
+        load_half(av1, c0, 1, rv);
+        const float ninv = (a.normalize && lane < rv) ? ninv_bh[(long)i * S + c0 + lane] : 1.f;
+        unsigned pk0[2][4][2], pk1[2][4][2];
+        half_result(pk0, av0, ninv, 0);
+        half_result(pk1, av1, ninv, 1);
+        const long p0 = (long)i * S + c0;
         if (c0 + 64 >= S) {   // last chunk of the block: its Gt slot is dead for this wave -> staging buffer
             wave_lds_fence();
-            stage64(Gb, acc, lane);
+            stage32(Gb, 0, pk0, lane);
+            stage32(Gb, 32, pk1, lane);
             wave_lds_fence();
             store64<false>(ob, a.o.sn, a.idx, p0, rv, Gb, nullptr, 0, lane);
         } else {
-            store64_direct<false>(ob, a.o.sn, a.idx, p0, rv, acc, nullptr, 0, lane);
-        }
-    };
-
-    if (S <= 64) {
-        // each wave owns blocks (wave, wave + 4): the first block's operands are fetched before the mixing,
-        // the second block's while the first is being multiplied
-        const int iA = it * IT + wave, iB = iA + 4;
-        bf16x8 avA[4][2], avB[4][2];
-        float ninvA = 1.f, ninvB = 1.f;
-        if (iA < M) load_blk(avA, ninvA, iA, 0, S);
-        mix_tile_to_lds<0>(Gt, state_bh, a.njg, a.W, a.ldw, M, it * IT, tid);
-        __syncthreads();
-        if (iB < M) load_blk(avB, ninvB, iB, 0, S);
-        if (iA < M) compute_store(avA, ninvA, wave, iA, 0, S);
-        if (iB < M) compute_store(avB, ninvB, wave + 4, iB, 0, S);
-        return;
-    }
-
-    mix_tile_to_lds<0>(Gt, state_bh, a.njg, a.W, a.ldw, M, it * IT, tid);
-    __syncthreads();
-    for (int bi = wave; bi < IT; bi += 4) {
-        const int i = it * IT + bi;
-        if (i >= M) continue;
-        for (int c0 = 0; c0 < S; c0 += 64) {
-            const int rv = min(64, S - c0);
-            bf16x8 av[4][2];
-            float ninv;
-            load_blk(av, ninv, i, c0, rv);
-            compute_store(av, ninv, bi, i, c0, rv);
+            store32_direct<false>(ob, a.o.sn, a.idx, p0, 0, rv, pk0, nullptr, 0, lane);
+            store32_direct<false>(ob, a.o.sn, a.idx, p0, 32, rv, pk1, nullptr, 0, lane);
         }
     }
 }
@@ -634,23 +639,23 @@ constexpr int DW_SPLIT = 8;                      // e' splits per (b,h)
 constexpr int DW_LDI = 72;
 constexpr int FS_DW_SMEM = 2 * DW_EC * DW_LDI * 2;
 
-__global__ __launch_bounds__(FT) void k_fs_dw(const FsDwArgs a) {
+__global__ __launch_bounds__(FT8) void k_fs_dw(const FsDwArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u16* Ai = reinterpret_cast<u16*>(smem_raw);   // dG image [256 e'][72]
     u16* Bi = Ai + DW_EC * DW_LDI;                // KV image
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 15, kg = lane >> 4;
+    const int wi = wave & 3, wj = wave >> 2;   // wave -> rows i = 16 wi .., columns j = 32 wj ..
     const int qtr = blockIdx.x, bh = blockIdx.y, M = a.M, njg = a.njg;
     const u16* dg = a.dg + (long)bh * njg * FE * IT;
     const u16* kv = a.kv + (long)bh * njg * FE * IT;
-    f32x4 acc[4];
-#pragma unroll
-    for (int tn = 0; tn < 4; ++tn) acc[tn] = f32x4{0.f, 0.f, 0.f, 0.f};
-    constexpr int NP = 2 * DW_EC * 8 / FT;   // 16-byte pieces per thread per chunk
+    f32x4 acc[2];
+    acc[0] = acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int NP = 2 * DW_EC * 8 / FT8;  // 16-byte pieces per thread per chunk
     uint4 pr[NP];
     auto issue = [&](long e0) {
 #pragma unroll
         for (int t = 0; t < NP; ++t) {
-            const int v = tid + t * FT;
+            const int v = tid + t * FT8;
             const int which = v / (DW_EC * 8), rem = v - which * DW_EC * 8, g = rem / DW_EC, r = rem - g * DW_EC;
             pr[t] = (g < njg) ? *reinterpret_cast<const uint4*>((which ? kv : dg) + ((long)g * FE + e0 + r) * IT) : make_uint4(0, 0, 0, 0);
         }
@@ -660,16 +665,16 @@ __global__ __launch_bounds__(FT) void k_fs_dw(const FsDwArgs a) {
     for (int ec = 0; ec < FE / DW_SPLIT; ec += DW_EC) {
 #pragma unroll
         for (int t = 0; t < NP; ++t) {
-            const int v = tid + t * FT;
+            const int v = tid + t * FT8;
             const int which = v / (DW_EC * 8), rem = v - which * DW_EC * 8, g = rem / DW_EC, r = rem - g * DW_EC;
             *reinterpret_cast<uint4*>((which ? Bi : Ai) + r * DW_LDI + g * 8) = pr[t];
         }
         if (ec + DW_EC < FE / DW_SPLIT) issue(ebase + ec + DW_EC);   // next chunk in flight during the MFMAs
         __syncthreads();
         for (int k0 = 0; k0 < DW_EC; k0 += 32) {
-            const bf16x8 av = tr_read8(Ai, DW_LDI, k0, wave * 16, lane);
+            const bf16x8 av = tr_read8(Ai, DW_LDI, k0, wi * 16, lane);
 #pragma unroll
-            for (int tn = 0; tn < 4; ++tn) acc[tn] = mfma_bf16(av, tr_read8(Bi, DW_LDI, k0, tn * 16, lane), acc[tn]);
+            for (int t = 0; t < 2; ++t) acc[t] = mfma_bf16(av, tr_read8(Bi, DW_LDI, k0, (2 * wj + t) * 16, lane), acc[t]);
         }
         __syncthreads();
     }
@@ -680,35 +685,35 @@ __global__ __launch_bounds__(FT) void k_fs_dw(const FsDwArgs a) {
         for (int c0 = 0; c0 < a.S; c0 += 64) {
             const int rv = min(64, a.S - c0);
             __syncthreads();
-            float zr[32];
+            float zr[16];
 #pragma unroll
-            for (int t = 0; t < 32; ++t) {
-                const int v = tid + t * FT, which = v >> 12, row = (v >> 6) & 63, col = v & 63;
+            for (int t = 0; t < 16; ++t) {
+                const int v = tid + t * FT8, which = v >> 12, row = (v >> 6) & 63, col = v & 63;
                 zr[t] = (row < M && col < rv) ? (which ? a.z : a.dn)[((long)bh * M + row) * a.S + c0 + col] : 0.f;
             }
 #pragma unroll
-            for (int t = 0; t < 32; ++t) {
-                const int v = tid + t * FT, which = v >> 12, row = (v >> 6) & 63, col = v & 63;
+            for (int t = 0; t < 16; ++t) {
+                const int v = tid + t * FT8, which = v >> 12, row = (v >> 6) & 63, col = v & 63;
                 (which ? zs : dns)[row * 65 + col] = zr[t];
             }
             __syncthreads();
 #pragma unroll
-            for (int tn = 0; tn < 4; ++tn)
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int i = wave * 16 + kg * 4 + r, j = tn * 16 + n;
+                    const int i = wi * 16 + kg * 4 + r, j = (2 * wj + t) * 16 + n;
                     float v = 0.f;
 #pragma unroll 4
                     for (int c = 0; c < 64; ++c) v += dns[i * 65 + c] * zs[j * 65 + c];
-                    acc[tn][r] += v;
+                    acc[t][r] += v;
                 }
         }
     }
     float* out = a.dwp + ((long)bh * DW_SPLIT + qtr) * 64 * 64;
 #pragma unroll
-    for (int tn = 0; tn < 4; ++tn)
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) out[(wave * 16 + kg * 4 + r) * 64 + tn * 16 + n] = acc[tn][r];
+        for (int r = 0; r < 4; ++r) out[(wi * 16 + kg * 4 + r) * 64 + (2 * wj + t) * 16 + n] = acc[t][r];
 }
 
 // Deterministic two-stage reduction of the partials: stage 1 sums groups of DWR_G partials (grid (16, ngroups)),
@@ -732,9 +737,9 @@ __global__ void k_fs_dw_reduce2(const float* __restrict__ tmp, float* __restrict
 }
 
 // -------------------------------------------------------------------------------------------------
-// k_fs_bwd_tok: per (tile jg, bh); mixing by all 4 waves, then each wave owns 2 blocks (no block barriers):
-//   phase 1: Gt = mix(W, KV)    -> dQ_j = (dO_j G_j^T) / n_j + dz_j (x) ksum_j  (relu mask) ; dksum_j
-//   phase 2: Gt = mix(W^T, dG)  -> dK_j = V_j dKV_j^T + 1 dksum_j^T (relu mask) ; dV_j = K_j dKV_j
+// k_fs_bwd_dq / k_fs_bwd_dkv: per (tile jg, bh); mixing by all 8 waves, then wave w owns block w:
+//   dq : Gt = mix(W, KV)    -> dQ_j = (dO_j G_j^T) / n_j + dz_j (x) ksum_j  (relu mask) ; dksum_j
+//   dkv: Gt = mix(W^T, dG)  -> dK_j = V_j dKV_j^T + 1 dksum_j^T (relu mask) ; dV_j = K_j dKV_j
 // -------------------------------------------------------------------------------------------------
 struct FsTokArgs {
     View q, k, v, dout;
@@ -754,47 +759,39 @@ struct FsTokArgs {
 };
 constexpr int FS_TOK_SMEM = FS_GT_BYTES;
 
-__global__ __launch_bounds__(FT, 2) void k_fs_bwd_dq(const FsTokArgs a) {
+__global__ __launch_bounds__(FT8, 4) void k_fs_bwd_dq(const FsTokArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u16* Gt = reinterpret_cast<u16*>(smem_raw);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 15, kg = lane >> 4;
     const int L = xcd_swizzle(blockIdx.x, gridDim.x);
     const int bh = L / a.njg, jgx = L - bh * a.njg, b = bh / a.H, h = bh - b * a.H;
     const int S = a.S, M = a.M;
-    auto base = [&](const View& w) { return (const u16*)w.ptr + b * w.sb + h * w.sh; };
-    auto mbase = [&](const MView& w) { return (u16*)w.ptr + b * w.sb + h * w.sh; };
-    const u16 *qb = base(a.q), *gb = base(a.dout);
-    u16* dqb = mbase(a.dq);
-    const long sofs = (long)bh * a.njg * FE * IT;
+    const u16* qb = (const u16*)a.q.ptr + b * a.q.sb + h * a.q.sh;
+    const u16* gb = (const u16*)a.dout.ptr + b * a.dout.sb + h * a.dout.sh;
+    u16* dqb = (u16*)a.dq.ptr + b * a.dq.sb + h * a.dq.sh;
+    const int j = jgx * IT + wave;
+    u16* Gb = Gt + wave * FD * GLD;
 
-    struct Side { float ninv, dz, ksum; };
-    auto load_blk = [&](bf16x8 (&gv)[4][2], Side& sd, int j, int c0, int rv) {
-        load_a64<false>(gv, gb, a.dout.sn, a.idx, (long)j * S + c0, rv, 0.f, lane);
-        sd.ninv = 1.f; sd.dz = 0.f;
-        sd.ksum = a.normalize ? a.ksum[((long)bh * M + j) * 64 + lane] : 0.f;   // lane = column d1
-        if (a.normalize && lane < rv) {
-            sd.ninv = a.ninv[((long)bh * M + j) * S + c0 + lane];
-            sd.dz = a.dz[((long)bh * M + j) * S + c0 + lane];
-        }
-    };
-    // one 64-row chunk: dQ rows, and the chunk's contribution to dksum (per-lane partials in the A layout)
-    auto compute_store = [&](const bf16x8 (&gv)[4][2], const Side& sd, float (&dks_acc)[2][8], int bi, int j, int c0, int rv) {
-        const long p0 = (long)j * S + c0;
-        u16* Gb = Gt + bi * FD * GLD;
-        f32x4 acc[4][4];
+    float dks_acc[2][8];
 #pragma unroll
-        for (int st = 0; st < 4; ++st)
+    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int tn = 0; tn < 4; ++tn) acc[st][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
-        chunk_times_gt<true>(acc, gv, Gb, lane);   // (dO G^T)[s][d1] : B[k = d2][n = d1] = Gt[d2][d1]
-        __builtin_amdgcn_sched_barrier(0);         // keep the q loads below the MFMAs (register pressure)
+        for (int t = 0; t < 8; ++t) dks_acc[ks][t] = 0.f;
+
+    // one 32-row half: dQ rows (packed) and the half's contribution to dksum
+    auto half_result = [&](unsigned (&pk)[2][4][2], const bf16x8 (&gv)[2][2], float ninv, float dzv, float ksum_l, int c0,
+                           int half, int rv) {
+        f32x4 acc[2][4];
+        zero_acc(acc);
+        rows32_times_gt<true>(acc, gv, Gb, lane);   // (dO G^T)[s][d1] : B[k = d2][n = d1] = Gt[d2][d1]
         if (a.normalize) {
-            bf16x8 qv[4][2];
-            if (a.relu) load_a64<true>(qv, qb, a.q.sn, a.idx, p0, rv, a.eps, lane);
-            else        load_a64<false>(qv, qb, a.q.sn, a.idx, p0, rv, a.eps, lane);
+            bf16x8 qv[2][2];
+            const long p0 = (long)j * S + c0 + half * 32;
+            if (a.relu) load_a32<true>(qv, qb, a.q.sn, a.idx, p0, rv - half * 32, a.eps, lane);
+            else        load_a32<false>(qv, qb, a.q.sn, a.idx, p0, rv - half * 32, a.eps, lane);
 #pragma unroll
-            for (int st = 0; st < 4; ++st) {
-                const float dzr = __shfl(sd.dz, st * 16 + n, 64);
+            for (int st = 0; st < 2; ++st) {
+                const float dzr = __shfl(dzv, half * 32 + st * 16 + n, 64);
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     const s16x8 qs = __builtin_bit_cast(s16x8, qv[st][ks]);
@@ -803,28 +800,58 @@ __global__ __launch_bounds__(FT, 2) void k_fs_bwd_dq(const FsTokArgs a) {
                 }
             }
 #pragma unroll
-            for (int st = 0; st < 4; ++st)
+            for (int st = 0; st < 2; ++st)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int row = st * 16 + kg * 4 + r;
-                    const float ni = __shfl(sd.ninv, row, 64), dzr = __shfl(sd.dz, row, 64);
+                    const int row = half * 32 + st * 16 + kg * 4 + r;
+                    const float ni = __shfl(ninv, row, 64), dzr = __shfl(dzv, row, 64);
 #pragma unroll
-                    for (int tn = 0; tn < 4; ++tn) acc[st][tn][r] = acc[st][tn][r] * ni + dzr * __shfl(sd.ksum, tn * 16 + n, 64);
+                    for (int tn = 0; tn < 4; ++tn) acc[st][tn][r] = acc[st][tn][r] * ni + dzr * __shfl(ksum_l, tn * 16 + n, 64);
                 }
         }
+        pack_acc(pk, acc);
+    };
+    auto load_half = [&](bf16x8 (&gv)[2][2], int c0, int half, int rv) {
+        load_a32<false>(gv, gb, a.dout.sn, a.idx, (long)j * S + c0 + half * 32, rv - half * 32, 0.f, lane);
+    };
+
+    mix_tile_to_lds<0>(Gt, a.state + (long)bh * a.njg * FE * IT, a.njg, a.W, a.ldw, M, jgx * IT, tid);
+    __syncthreads();
+    if (j >= M) return;
+    const float ksum_l = a.normalize ? a.ksum[((long)bh * M + j) * 64 + lane] : 0.f;   // lane = column d1
+
+    for (int c0 = 0; c0 < S; c0 += 64) {
+        const int rv = min(64, S - c0);
+        bf16x8 gv0[2][2], gv1[2][2];
+        load_half(gv0, c0, 0, rv);
+        load_half(gv1, c0, 1, rv);
+        float ninv = 1.f, dzv = 0.f;
+        if (a.normalize && lane < rv) {
+            ninv = a.ninv[((long)bh * M + j) * S + c0 + lane];
+            dzv = a.dz[((long)bh * M + j) * S + c0 + lane];
+        }
+        unsigned pk0[2][4][2], pk1[2][4][2];
+        half_result(pk0, gv0, ninv, dzv, ksum_l, c0, 0, rv);
+        half_result(pk1, gv1, ninv, dzv, ksum_l, c0, 1, rv);
+        const long p0 = (long)j * S + c0;
         if (c0 + 64 >= S) {
             wave_lds_fence();
-            stage64(Gb, acc, lane);
+            stage32(Gb, 0, pk0, lane);
+            stage32(Gb, 32, pk1, lane);
             wave_lds_fence();
             if (a.relu) store64<true>(dqb, a.dq.sn, a.idx, p0, rv, Gb, qb, a.q.sn, lane);
             else        store64<false>(dqb, a.dq.sn, a.idx, p0, rv, Gb, nullptr, 0, lane);
         } else {
-            if (a.relu) store64_direct<true>(dqb, a.dq.sn, a.idx, p0, rv, acc, qb, a.q.sn, lane);
-            else        store64_direct<false>(dqb, a.dq.sn, a.idx, p0, rv, acc, nullptr, 0, lane);
+            if (a.relu) {
+                store32_direct<true>(dqb, a.dq.sn, a.idx, p0, 0, rv, pk0, qb, a.q.sn, lane);
+                store32_direct<true>(dqb, a.dq.sn, a.idx, p0, 32, rv, pk1, qb, a.q.sn, lane);
+            } else {
+                store32_direct<false>(dqb, a.dq.sn, a.idx, p0, 0, rv, pk0, nullptr, 0, lane);
+                store32_direct<false>(dqb, a.dq.sn, a.idx, p0, 32, rv, pk1, nullptr, 0, lane);
+            }
         }
-    };
-    // dksum[col]: reduce the per-lane partials over the 16 row-lanes (n); columns = 32 ks + 8 kg + t
-    auto finish_dks = [&](const float (&dks_acc)[2][8], int j) {
+    }
+    if (a.normalize) {   // dksum[col]: reduce the per-lane partials over the 16 row-lanes (n); col = 32 ks + 8 kg + t
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -834,155 +861,101 @@ __global__ __launch_bounds__(FT, 2) void k_fs_bwd_dq(const FsTokArgs a) {
                 v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
                 if (n == 0) a.dksum[((long)bh * M + j) * 64 + ks * 32 + kg * 8 + t] = v;
             }
-    };
-    auto zero_dks = [](float (&d)[2][8]) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int t = 0; t < 8; ++t) d[ks][t] = 0.f;
-    };
-
-    if (S <= 64) {   // operands of the wave's first block are fetched before the mixing
-        const int jA = jgx * IT + wave, jB = jA + 4;
-        bf16x8 gvA[4][2], gvB[4][2];
-        Side sA, sB;
-        if (jA < M) load_blk(gvA, sA, jA, 0, S);
-        mix_tile_to_lds<0>(Gt, a.state + sofs, a.njg, a.W, a.ldw, M, jgx * IT, tid);
-        __syncthreads();
-        if (jB < M) load_blk(gvB, sB, jB, 0, S);
-        float dks_acc[2][8];
-        if (jA < M) { zero_dks(dks_acc); compute_store(gvA, sA, dks_acc, wave, jA, 0, S); if (a.normalize) finish_dks(dks_acc, jA); }
-        if (jB < M) { zero_dks(dks_acc); compute_store(gvB, sB, dks_acc, wave + 4, jB, 0, S); if (a.normalize) finish_dks(dks_acc, jB); }
-        return;
-    }
-    mix_tile_to_lds<0>(Gt, a.state + sofs, a.njg, a.W, a.ldw, M, jgx * IT, tid);
-    __syncthreads();
-    for (int bi = wave; bi < IT; bi += 4) {
-        const int j = jgx * IT + bi;
-        if (j >= M) continue;
-        float dks_acc[2][8];
-        zero_dks(dks_acc);
-        for (int c0 = 0; c0 < S; c0 += 64) {
-            const int rv = min(64, S - c0);
-            bf16x8 gv[4][2];
-            Side sd;
-            load_blk(gv, sd, j, c0, rv);
-            compute_store(gv, sd, dks_acc, bi, j, c0, rv);
-        }
-        if (a.normalize) finish_dks(dks_acc, j);
     }
 }
 
-__global__ __launch_bounds__(FT, 2) void k_fs_bwd_dkv(const FsTokArgs a) {
+__global__ __launch_bounds__(FT8, 4) void k_fs_bwd_dkv(const FsTokArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u16* Gt = reinterpret_cast<u16*>(smem_raw);
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 15, kg = lane >> 4;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 15;
     const int L = xcd_swizzle(blockIdx.x, gridDim.x);
     const int bh = L / a.njg, jgx = L - bh * a.njg, b = bh / a.H, h = bh - b * a.H;
     const int S = a.S, M = a.M;
-    auto base = [&](const View& w) { return (const u16*)w.ptr + b * w.sb + h * w.sh; };
-    auto mbase = [&](const MView& w) { return (u16*)w.ptr + b * w.sb + h * w.sh; };
-    const u16 *kb = base(a.k), *vb = base(a.v);
-    u16 *dkb = mbase(a.dk), *dvb = mbase(a.dv);
-    const long sofs = (long)bh * a.njg * FE * IT;
-    auto load_k = [&](bf16x8 (&kv)[4][2], int j, int c0, int rv) {
-        if (a.relu) load_a64<true>(kv, kb, a.k.sn, a.idx, (long)j * S + c0, rv, a.eps, lane);
-        else        load_a64<false>(kv, kb, a.k.sn, a.idx, (long)j * S + c0, rv, a.eps, lane);
+    const u16* kb = (const u16*)a.k.ptr + b * a.k.sb + h * a.k.sh;
+    const u16* vb = (const u16*)a.v.ptr + b * a.v.sb + h * a.v.sh;
+    u16* dkb = (u16*)a.dk.ptr + b * a.dk.sb + h * a.dk.sh;
+    u16* dvb = (u16*)a.dv.ptr + b * a.dv.sb + h * a.dv.sh;
+    const int j = jgx * IT + wave;
+    u16* Gb = Gt + wave * FD * GLD;
+
+    auto load_k = [&](bf16x8 (&kv)[2][2], int c0, int half, int rv) {
+        const long p0 = (long)j * S + c0 + half * 32;
+        if (a.relu) load_a32<true>(kv, kb, a.k.sn, a.idx, p0, rv - half * 32, a.eps, lane);
+        else        load_a32<false>(kv, kb, a.k.sn, a.idx, p0, rv - half * 32, a.eps, lane);
     };
-    auto compute_store = [&](const bf16x8 (&kv)[4][2], int bi, int j, int c0, int rv) {
+    auto load_v = [&](bf16x8 (&vv)[2][2], int c0, int half, int rv) {
+        load_a32<false>(vv, vb, a.v.sn, a.idx, (long)j * S + c0 + half * 32, rv - half * 32, 0.f, lane);
+    };
+
+    mix_tile_to_lds<1>(Gt, a.dstate + (long)bh * a.njg * FE * IT, a.njg, a.W, a.ldw, M, jgx * IT, tid);
+    __syncthreads();
+    if (j >= M) return;
+
+    for (int c0 = 0; c0 < S; c0 += 64) {
+        const int rv = min(64, S - c0);
         const long p0 = (long)j * S + c0;
-        u16* Gb = Gt + bi * FD * GLD;
         const bool last = c0 + 64 >= S;
-        bf16x8 vv[4][2];
-        load_a64<false>(vv, vb, a.v.sn, a.idx, p0, rv, 0.f, lane);
-        // dV first, kept packed as bf16 pairs while dK is computed (both need the intact Gb)
-        unsigned pv[4][4][2];
+        // all four 32-row products need the intact Gb; results stay packed (bf16 pairs) until the last MFMA
+        unsigned pV0[2][4][2], pV1[2][4][2], pK0[2][4][2], pK1[2][4][2];
         {
-            f32x4 accV[4][4];
-#pragma unroll
-            for (int st = 0; st < 4; ++st)
-#pragma unroll
-                for (int tn = 0; tn < 4; ++tn) accV[st][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
-            chunk_times_gt<false>(accV, kv, Gb, lane);   // dV[s][d2] = sum_d1 K[s][d1] dKVt[d2][d1]
-#pragma unroll
-            for (int st = 0; st < 4; ++st)
-#pragma unroll
-                for (int tn = 0; tn < 4; ++tn) {
-                    pv[st][tn][0] = pack_bf16x2(accV[st][tn][0], accV[st][tn][1]);
-                    pv[st][tn][1] = pack_bf16x2(accV[st][tn][2], accV[st][tn][3]);
-                }
+            bf16x8 kv[2][2];
+            f32x4 acc[2][4];
+            load_k(kv, c0, 0, rv);
+            zero_acc(acc);
+            rows32_times_gt<false>(acc, kv, Gb, lane);   // dV[s][d2] = sum_d1 K[s][d1] dKVt[d2][d1]
+            pack_acc(pV0, acc);
+            load_k(kv, c0, 1, rv);
+            zero_acc(acc);
+            rows32_times_gt<false>(acc, kv, Gb, lane);
+            pack_acc(pV1, acc);
         }
-        f32x4 accK[4][4];
-#pragma unroll
-        for (int st = 0; st < 4; ++st)
-#pragma unroll
-            for (int tn = 0; tn < 4; ++tn) accK[st][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
-        chunk_times_gt<true>(accK, vv, Gb, lane);        // dK[s][d1] = sum_d2 V[s][d2] dKVt[d2][d1]
+        float dk[4] = {0.f, 0.f, 0.f, 0.f};
         if (a.normalize) {
 #pragma unroll
-            for (int tn = 0; tn < 4; ++tn) {
-                const float dk = a.dksum[((long)bh * M + j) * 64 + tn * 16 + n];
+            for (int tn = 0; tn < 4; ++tn) dk[tn] = a.dksum[((long)bh * M + j) * 64 + tn * 16 + n];
+        }
+        {
+            bf16x8 vv[2][2];
+            f32x4 acc[2][4];
+            load_v(vv, c0, 0, rv);
+            zero_acc(acc);
+            rows32_times_gt<true>(acc, vv, Gb, lane);    // dK[s][d1] = sum_d2 V[s][d2] dKVt[d2][d1]
 #pragma unroll
-                for (int st = 0; st < 4; ++st)
+            for (int st = 0; st < 2; ++st)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) accK[st][tn][r] += dk;
-            }
+                for (int tn = 0; tn < 4; ++tn) acc[st][tn] += dk[tn];
+            pack_acc(pK0, acc);
+            load_v(vv, c0, 1, rv);
+            zero_acc(acc);
+            rows32_times_gt<true>(acc, vv, Gb, lane);
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn) acc[st][tn] += dk[tn];
+            pack_acc(pK1, acc);
         }
         if (last) {
             wave_lds_fence();
-            stage64(Gb, accK, lane);
+            stage32(Gb, 0, pK0, lane);
+            stage32(Gb, 32, pK1, lane);
             wave_lds_fence();
             if (a.relu) store64<true>(dkb, a.dk.sn, a.idx, p0, rv, Gb, kb, a.k.sn, lane);
             else        store64<false>(dkb, a.dk.sn, a.idx, p0, rv, Gb, nullptr, 0, lane);
             wave_lds_fence();
-#pragma unroll
-            for (int st = 0; st < 4; ++st)
-#pragma unroll
-                for (int tn = 0; tn < 4; ++tn)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        Gb[(st * 16 + kg * 4 + r) * GLD + tn * 16 + n] = (u16)(pv[st][tn][r >> 1] >> ((r & 1) * 16));
+            stage32(Gb, 0, pV0, lane);
+            stage32(Gb, 32, pV1, lane);
             wave_lds_fence();
             store64<false>(dvb, a.dv.sn, a.idx, p0, rv, Gb, nullptr, 0, lane);
         } else {
-            if (a.relu) store64_direct<true>(dkb, a.dk.sn, a.idx, p0, rv, accK, kb, a.k.sn, lane);
-            else        store64_direct<false>(dkb, a.dk.sn, a.idx, p0, rv, accK, nullptr, 0, lane);
-#pragma unroll
-            for (int st = 0; st < 4; ++st)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = st * 16 + kg * 4 + r;
-                    if (row < rv) {
-                        const long tr = tok_row(a.idx, p0 + row);
-#pragma unroll
-                        for (int tn = 0; tn < 4; ++tn)
-                            dvb[tr * a.dv.sn + tn * 16 + n] = (u16)(pv[st][tn][r >> 1] >> ((r & 1) * 16));
-                    }
-                }
-        }
-    };
-
-    if (S <= 64) {
-        const int jA = jgx * IT + wave, jB = jA + 4;
-        bf16x8 kvA[4][2], kvB[4][2];
-        if (jA < M) load_k(kvA, jA, 0, S);
-        mix_tile_to_lds<1>(Gt, a.dstate + sofs, a.njg, a.W, a.ldw, M, jgx * IT, tid);
-        __syncthreads();
-        if (jB < M) load_k(kvB, jB, 0, S);
-        if (jA < M) compute_store(kvA, wave, jA, 0, S);
-        if (jB < M) compute_store(kvB, wave + 4, jB, 0, S);
-        return;
-    }
-    mix_tile_to_lds<1>(Gt, a.dstate + sofs, a.njg, a.W, a.ldw, M, jgx * IT, tid);
-    __syncthreads();
-    for (int bi = wave; bi < IT; bi += 4) {
-        const int j = jgx * IT + bi;
-        if (j >= M) continue;
-        for (int c0 = 0; c0 < S; c0 += 64) {
-            const int rv = min(64, S - c0);
-            bf16x8 kv[4][2];
-            load_k(kv, j, c0, rv);
-            compute_store(kv, bi, j, c0, rv);
+            if (a.relu) {
+                store32_direct<true>(dkb, a.dk.sn, a.idx, p0, 0, rv, pK0, kb, a.k.sn, lane);
+                store32_direct<true>(dkb, a.dk.sn, a.idx, p0, 32, rv, pK1, kb, a.k.sn, lane);
+            } else {
+                store32_direct<false>(dkb, a.dk.sn, a.idx, p0, 0, rv, pK0, nullptr, 0, lane);
+                store32_direct<false>(dkb, a.dk.sn, a.idx, p0, 32, rv, pK1, nullptr, 0, lane);
+            }
+            store32_direct<false>(dvb, a.dv.sn, a.idx, p0, 0, rv, pV0, nullptr, 0, lane);
+            store32_direct<false>(dvb, a.dv.sn, a.idx, p0, 32, rv, pV1, nullptr, 0, lane);
         }
     }
 }
