@@ -142,18 +142,26 @@ struct FsStateArgs {
     float eps;
     int relu, normalize;
 };
-constexpr int FS_STATE_SMEM = 3 * 64 * TLD * 2 + (8 * 64 + 64) * 4;
+constexpr int FS_STATE_SMEM = 2 * 64 * TLD * 2;
 
-struct TileRegs { uint4 x, y, t; };
+struct TileRegs { uint4 x, y, t; float ninv; };
+
+// dot of 8 bf16 pairs held as two uint4
+__device__ __forceinline__ float dot8(uint4 a, uint4 b) {
+    const unsigned aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
+    float d = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        d += __uint_as_float(aw[i] << 16) * __uint_as_float(bw[i] << 16) +
+             __uint_as_float(aw[i] & 0xffff0000u) * __uint_as_float(bw[i] & 0xffff0000u);
+    return d;
+}
 
 template <int MODE>
 __global__ __launch_bounds__(FT8, 4) void k_fs_state(const FsStateArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u16* Xs = reinterpret_cast<u16*>(smem_raw);
     u16* Ys = Xs + 64 * TLD;
-    u16* Ts = Ys + 64 * TLD;
-    float* part = reinterpret_cast<float*>(Ts + 64 * TLD);   // [8][64]
-    float* ksum_s = part + 512;                              // [64]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int dt = wave & 3, th = wave >> 2;
     const int jg = blockIdx.x, bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
@@ -161,29 +169,45 @@ __global__ __launch_bounds__(FT8, 4) void k_fs_state(const FsStateArgs a) {
     const u16* xb = (const u16*)a.x.ptr + b * a.x.sb + h * a.x.sh;
     const u16* yb = (const u16*)a.y.ptr + b * a.y.sb + h * a.y.sh;
     const u16* tb = a.normalize ? (const u16*)a.t.ptr + b * a.t.sb + h * a.t.sh : nullptr;
-    const bool single = S <= 64;
-    const int srow = tid >> 3, scol = (tid & 7) * 8;         // staging: thread -> (row, 8 columns = 16 bytes)
-    const bool tile_t = a.normalize && (MODE == 1 || single);   // third tile travels with the chunk
+    const int srow = tid >> 3, scol = (tid & 7) * 8;   // staging: thread -> (row, 8 columns = 16 bytes)
+    const bf16x8 ones = __builtin_bit_cast(bf16x8, make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u));
 
-    auto issue = [&](long p, int rv, TileRegs& R) {
+    // global -> registers for one 64-row chunk of block j (rows >= rv give zeros)
+    auto issue = [&](int j, int c0, int rv, TileRegs& R) {
         R.x = R.y = R.t = make_uint4(0, 0, 0, 0);
+        R.ninv = 0.f;
         if (srow < rv) {
-            const long tr = tok_row(a.idx, p + srow);
+            const long tr = tok_row(a.idx, (long)j * S + c0 + srow);
             R.x = *reinterpret_cast<const uint4*>(xb + tr * a.x.sn + scol);
             R.y = *reinterpret_cast<const uint4*>(yb + tr * a.y.sn + scol);
-            if (tile_t) R.t = *reinterpret_cast<const uint4*>(tb + tr * a.t.sn + scol);
+            if (a.normalize) {
+                R.t = *reinterpret_cast<const uint4*>(tb + tr * a.t.sn + scol);
+                if (MODE == 1) R.ninv = a.ninv[((long)bh * M + j) * S + c0 + srow];
+            }
         }
     };
-    auto commit = [&](const TileRegs& R, int rv, int rfill) {
+    // registers -> LDS.  MODE 1 folds dn = -(dO . O) / n and dP = dO / n into this step (no LDS pass).
+    auto commit = [&](TileRegs& R, int j, int c0, int rv, int rfill) {
+        uint4 x = R.x, y = R.y;
+        if (a.relu && srow < rv) {
+            x = relu_eps8(x, a.eps);
+            if (MODE == 0 && a.normalize) R.t = relu_eps8(R.t, a.eps);
+        }
+        if (MODE == 1 && a.normalize) {
+            float d = dot8(R.y, R.t);
+            d += __shfl_xor(d, 1, 64);
+            d += __shfl_xor(d, 2, 64);
+            d += __shfl_xor(d, 4, 64);
+            if (srow < rv && (tid & 7) == 0) a.dn[((long)bh * M + j) * S + c0 + srow] = -d * R.ninv;
+            unsigned yw[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                yw[i] = pack_bf16x2(__uint_as_float(yw[i] << 16) * R.ninv, __uint_as_float(yw[i] & 0xffff0000u) * R.ninv);
+            y = make_uint4(yw[0], yw[1], yw[2], yw[3]);
+        }
         if (srow < rfill) {
-            uint4 x = R.x, t = R.t;
-            if (a.relu && srow < rv) {
-                x = relu_eps8(x, a.eps);
-                if (MODE == 0 && tile_t) t = relu_eps8(t, a.eps);
-            }
             *reinterpret_cast<uint4*>(Xs + srow * TLD + scol) = x;
-            *reinterpret_cast<uint4*>(Ys + srow * TLD + scol) = R.y;
-            if (tile_t) *reinterpret_cast<uint4*>(Ts + srow * TLD + scol) = t;
+            *reinterpret_cast<uint4*>(Ys + srow * TLD + scol) = y;
         }
     };
 
@@ -191,102 +215,72 @@ __global__ __launch_bounds__(FT8, 4) void k_fs_state(const FsStateArgs a) {
 #pragma unroll
     for (int jj = 0; jj < IT; ++jj) acc[jj][0] = acc[jj][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // one staged 64-row chunk of block jj (tiles in LDS, barrier done): side products + MFMAs
-    auto chunk = [&](auto jjc, int j, int c0, int rv, int rfill, float& ks) {
+    // one staged chunk (tiles in LDS, barrier done): summaries, and (MODE 0) column sums of K on the MFMA:
+    // ones(16 x 32) . K-tile puts ksum[16 tn + (lane & 15)] into every row of ksacc[tn]
+    auto chunk = [&](auto jjc, int rfill, f32x4 (&ksacc)[4]) {
         constexpr int jj = decltype(jjc)::value;
-        if (MODE == 0 && a.normalize) {   // column sums of K: thread -> column tid & 63, rows 8 (tid >> 6) ..
-            const int col = tid & 63, pr = tid >> 6;
-            for (int r = pr * 8; r < min(rv, pr * 8 + 8); ++r) ks += bf(Xs[r * TLD + col]);
-        }
-        if (MODE == 1 && a.normalize) {   // dn and dP = dO / n (rounded to bf16); 8 threads per row, 16 bytes each
-            float d = 0.f;
-            uint4 yv = make_uint4(0, 0, 0, 0);
-            if (srow < rv) {
-                yv = *reinterpret_cast<const uint4*>(Ys + srow * TLD + scol);
-                const uint4 ov = *reinterpret_cast<const uint4*>(Ts + srow * TLD + scol);
-                const unsigned yw[4] = {yv.x, yv.y, yv.z, yv.w}, ow[4] = {ov.x, ov.y, ov.z, ov.w};
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    d += __uint_as_float(yw[i] << 16) * __uint_as_float(ow[i] << 16) +
-                         __uint_as_float(yw[i] & 0xffff0000u) * __uint_as_float(ow[i] & 0xffff0000u);
-            }
-            d += __shfl_xor(d, 1, 64);
-            d += __shfl_xor(d, 2, 64);
-            d += __shfl_xor(d, 4, 64);
-            if (srow < rv) {
-                const float ni = a.ninv[((long)bh * M + j) * S + c0 + srow];
-                if ((tid & 7) == 0) a.dn[((long)bh * M + j) * S + c0 + srow] = -d * ni;
-                unsigned yw[4] = {yv.x, yv.y, yv.z, yv.w};
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    yw[i] = pack_bf16x2(__uint_as_float(yw[i] << 16) * ni, __uint_as_float(yw[i] & 0xffff0000u) * ni);
-                *reinterpret_cast<uint4*>(Ys + srow * TLD + scol) = make_uint4(yw[0], yw[1], yw[2], yw[3]);
-            }
-            __syncthreads();
-        }
         for (int k0 = 0; k0 < rfill; k0 += 32) {
             const bf16x8 av = tr_read8(Ys, TLD, k0, dt * 16, lane);
+            if (MODE == 0 && a.normalize) {
 #pragma unroll
-            for (int t = 0; t < 2; ++t) acc[jj][t] = mfma_bf16(av, tr_read8(Xs, TLD, k0, (2 * th + t) * 16, lane), acc[jj][t]);
+                for (int tn = 0; tn < 4; ++tn) {
+                    const bf16x8 bv = tr_read8(Xs, TLD, k0, tn * 16, lane);
+                    ksacc[tn] = mfma_bf16(ones, bv, ksacc[tn]);
+                    if (tn == 2 * th) acc[jj][0] = mfma_bf16(av, bv, acc[jj][0]);
+                    if (tn == 2 * th + 1) acc[jj][1] = mfma_bf16(av, bv, acc[jj][1]);
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc[jj][t] = mfma_bf16(av, tr_read8(Xs, TLD, k0, (2 * th + t) * 16, lane), acc[jj][t]);
+            }
         }
     };
-    // ksum_j and z_j once all chunks of block j went through (MODE 0)
-    auto finish_block = [&](int j, float ks) {
-        const long p0 = (long)j * S;
-        part[(tid >> 6) * 64 + (tid & 63)] = ks;
-        __syncthreads();
-        if (tid < 64) {
-            float sacc = 0.f;
+    // ksum[scol .. scol + 7] of this thread's staging columns: lane L first selects ksum[L] from the wave's ksacc
+    // registers (tile L >> 4, column L & 15), then 8 shuffles gather the thread's columns
+    auto ksum8 = [&](const f32x4 (&ksacc)[4], float (&kv)[8]) {
+        const int tl = lane >> 4;
+        const float ksl = tl == 0 ? ksacc[0][0] : tl == 1 ? ksacc[1][0] : tl == 2 ? ksacc[2][0] : ksacc[3][0];
 #pragma unroll
-            for (int p = 0; p < 8; ++p) sacc += part[p * 64 + tid];
-            ksum_s[tid] = sacc;
-            a.ksum[((long)bh * M + j) * 64 + tid] = sacc;
-        }
-        __syncthreads();
-        for (int c0 = 0; c0 < S; c0 += 64) {
-            const int rv = min(64, S - c0);
-            if (!single) {   // (rare) multi-chunk blocks: second pass over Q, synchronous
-                uint4 t = make_uint4(0, 0, 0, 0);
-                if (srow < rv) {
-                    t = *reinterpret_cast<const uint4*>(tb + tok_row(a.idx, p0 + c0 + srow) * a.t.sn + scol);
-                    if (a.relu) t = relu_eps8(t, a.eps);
-                }
-                *reinterpret_cast<uint4*>(Ts + srow * TLD + scol) = t;
-                __syncthreads();
-            }
-            float d = 0.f;
-            if (srow < rv) {
-                const uint4 qv = *reinterpret_cast<const uint4*>(Ts + srow * TLD + scol);
-                const unsigned qw[4] = {qv.x, qv.y, qv.z, qv.w};
+        for (int t = 0; t < 8; ++t) kv[t] = __shfl(ksl, scol + t, 64);
+    };
+    auto write_ksum_z = [&](int j, int c0, int rv, const f32x4 (&ksacc)[4], uint4 tq, bool write_ksum) {
+        if (write_ksum && wave == 0 && lane < 16) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    d += __uint_as_float(qw[i] << 16) * ksum_s[scol + 2 * i] + __uint_as_float(qw[i] & 0xffff0000u) * ksum_s[scol + 2 * i + 1];
-            }
-            d += __shfl_xor(d, 1, 64);
-            d += __shfl_xor(d, 2, 64);
-            d += __shfl_xor(d, 4, 64);
-            if (srow < rv && (tid & 7) == 0) a.z_out[((long)bh * M + j) * S + c0 + srow] = d;
-            __syncthreads();
+            for (int tn = 0; tn < 4; ++tn) a.ksum[((long)bh * M + j) * 64 + tn * 16 + lane] = ksacc[tn][0];
         }
+        float kv[8];
+        ksum8(ksacc, kv);
+        const unsigned qw[4] = {tq.x, tq.y, tq.z, tq.w};
+        float d = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            d += __uint_as_float(qw[i] << 16) * kv[2 * i] + __uint_as_float(qw[i] & 0xffff0000u) * kv[2 * i + 1];
+        d += __shfl_xor(d, 1, 64);
+        d += __shfl_xor(d, 2, 64);
+        d += __shfl_xor(d, 4, 64);
+        if (srow < rv && (tid & 7) == 0) a.z_out[((long)bh * M + j) * S + c0 + srow] = d;
     };
 
-    if (single) {
+    if (S <= 64) {
         // software pipeline, two blocks ahead: R[jj & 1] carries block jj
         TileRegs R0, R1;
-        if (jg * IT < M) issue((long)jg * IT * S, S, R0);
-        if (jg * IT + 1 < M) issue((long)(jg * IT + 1) * S, S, R1);
+        if (jg * IT < M) issue(jg * IT, 0, S, R0);
+        if (jg * IT + 1 < M) issue(jg * IT + 1, 0, S, R1);
         const int rfill = (S + 31) & ~31;
         auto step = [&](auto jjc, TileRegs& R) {
             constexpr int jj = decltype(jjc)::value;
             const int j = jg * IT + jj;
             if (j >= M) return;
-            commit(R, S, rfill);
-            if (jj + 2 < IT && j + 2 < M) issue((long)(j + 2) * S, S, R);
+            commit(R, j, 0, S, rfill);
+            const uint4 tq = R.t;                      // (MODE 0) this thread's piece of Q_j for z_j
+            if (jj + 2 < IT && j + 2 < M) issue(j + 2, 0, S, R);
             __syncthreads();
-            float ks = 0.f;
-            chunk(jjc, j, 0, S, rfill, ks);
-            if (MODE == 0 && a.normalize) finish_block(j, ks);   // ends with a barrier
-            else __syncthreads();
+            f32x4 ksacc[4];
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn) ksacc[tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+            chunk(jjc, rfill, ksacc);
+            if (MODE == 0 && a.normalize) write_ksum_z(j, 0, S, ksacc, tq, true);
+            __syncthreads();
         };
         step(std::integral_constant<int, 0>{}, R0);
         step(std::integral_constant<int, 1>{}, R1);
@@ -297,22 +291,34 @@ __global__ __launch_bounds__(FT8, 4) void k_fs_state(const FsStateArgs a) {
         step(std::integral_constant<int, 6>{}, R0);
         step(std::integral_constant<int, 7>{}, R1);
     } else {
+        // multi-chunk blocks (S > 64): synchronous chunks; z needs the complete ksum -> second pass over Q
         TileRegs R;
         auto blockloop = [&](auto jjc) {
             constexpr int jj = decltype(jjc)::value;
             const int j = jg * IT + jj;
             if (j >= M) return;
-            const long p0 = (long)j * S;
-            float ks = 0.f;
+            f32x4 ksacc[4];
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn) ksacc[tn] = f32x4{0.f, 0.f, 0.f, 0.f};
             for (int c0 = 0; c0 < S; c0 += 64) {
                 const int rv = min(64, S - c0), rfill = (rv + 31) & ~31;
-                issue(p0 + c0, rv, R);
-                commit(R, rv, rfill);
+                issue(j, c0, rv, R);
+                commit(R, j, c0, rv, rfill);
                 __syncthreads();
-                chunk(jjc, j, c0, rv, rfill, ks);
+                chunk(jjc, rfill, ksacc);
                 __syncthreads();
             }
-            if (MODE == 0 && a.normalize) finish_block(j, ks);
+            if (MODE == 0 && a.normalize) {
+                for (int c0 = 0; c0 < S; c0 += 64) {
+                    const int rv = min(64, S - c0);
+                    uint4 tq = make_uint4(0, 0, 0, 0);
+                    if (srow < rv) {
+                        tq = *reinterpret_cast<const uint4*>(tb + tok_row(a.idx, (long)j * S + c0 + srow) * a.t.sn + scol);
+                        if (a.relu) tq = relu_eps8(tq, a.eps);
+                    }
+                    write_ksum_z(j, c0, rv, ksacc, tq, c0 == 0);
+                }
+            }
         };
         blockloop(std::integral_constant<int, 0>{});
         blockloop(std::integral_constant<int, 1>{});
