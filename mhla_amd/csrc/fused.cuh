@@ -142,7 +142,7 @@ struct FsStateArgs {
     float eps;
     int relu, normalize;
 };
-constexpr int FS_STATE_SMEM = 2 * 64 * TLD * 2;
+constexpr int FS_STATE_SMEM = 2 * 64 * TLD * 2 + 8 * 64 * 4;
 
 struct TileRegs { uint4 x, y, t; float ninv; };
 
@@ -162,15 +162,15 @@ __global__ __launch_bounds__(FT8, 4) void k_fs_state(const FsStateArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u16* Xs = reinterpret_cast<u16*>(smem_raw);
     u16* Ys = Xs + 64 * TLD;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int dt = wave & 3, th = wave >> 2;
+    float* part = reinterpret_cast<float*>(Ys + 64 * TLD);   // [8][64] column-sum partials of K (MODE 0)
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int dt = wave & 3, th = wave >> 2;   // wave-uniform (scalar) so branches around MFMAs are scalar branches
     const int jg = blockIdx.x, bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
     const int S = a.S, M = a.M, njg = gridDim.x;
     const u16* xb = (const u16*)a.x.ptr + b * a.x.sb + h * a.x.sh;
     const u16* yb = (const u16*)a.y.ptr + b * a.y.sb + h * a.y.sh;
     const u16* tb = a.normalize ? (const u16*)a.t.ptr + b * a.t.sb + h * a.t.sh : nullptr;
     const int srow = tid >> 3, scol = (tid & 7) * 8;   // staging: thread -> (row, 8 columns = 16 bytes)
-    const bf16x8 ones = __builtin_bit_cast(bf16x8, make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u));
 
     // global -> registers for one 64-row chunk of block j (rows >= rv give zeros)
     auto issue = [&](int j, int c0, int rv, TileRegs& R) {
@@ -215,41 +215,36 @@ __global__ __launch_bounds__(FT8, 4) void k_fs_state(const FsStateArgs a) {
 #pragma unroll
     for (int jj = 0; jj < IT; ++jj) acc[jj][0] = acc[jj][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // one staged chunk (tiles in LDS, barrier done): summaries, and (MODE 0) column sums of K on the MFMA:
-    // ones(16 x 32) . K-tile puts ksum[16 tn + (lane & 15)] into every row of ksacc[tn]
-    auto chunk = [&](auto jjc, int rfill, f32x4 (&ksacc)[4]) {
+    // one staged chunk (tiles in LDS, barrier done): (MODE 0) column-sum partials of K, then the summaries
+    auto chunk = [&](auto jjc, int rv, int rfill, float& ks) {
         constexpr int jj = decltype(jjc)::value;
+        if (MODE == 0 && a.normalize) {   // thread -> column tid & 63, rows 8 (tid >> 6) ..
+            const int col = tid & 63, pr = tid >> 6;
+            for (int r = pr * 8; r < min(rv, pr * 8 + 8); ++r) ks += bf(Xs[r * TLD + col]);
+        }
         for (int k0 = 0; k0 < rfill; k0 += 32) {
             const bf16x8 av = tr_read8(Ys, TLD, k0, dt * 16, lane);
-            if (MODE == 0 && a.normalize) {
 #pragma unroll
-                for (int tn = 0; tn < 4; ++tn) {
-                    const bf16x8 bv = tr_read8(Xs, TLD, k0, tn * 16, lane);
-                    ksacc[tn] = mfma_bf16(ones, bv, ksacc[tn]);
-                    if (tn == 2 * th) acc[jj][0] = mfma_bf16(av, bv, acc[jj][0]);
-                    if (tn == 2 * th + 1) acc[jj][1] = mfma_bf16(av, bv, acc[jj][1]);
-                }
-            } else {
-#pragma unroll
-                for (int t = 0; t < 2; ++t) acc[jj][t] = mfma_bf16(av, tr_read8(Xs, TLD, k0, (2 * th + t) * 16, lane), acc[jj][t]);
-            }
+            for (int t = 0; t < 2; ++t) acc[jj][t] = mfma_bf16(av, tr_read8(Xs, TLD, k0, (2 * th + t) * 16, lane), acc[jj][t]);
         }
     };
-    // ksum[scol .. scol + 7] of this thread's staging columns: lane L first selects ksum[L] from the wave's ksacc
-    // registers (tile L >> 4, column L & 15), then 8 shuffles gather the thread's columns
-    auto ksum8 = [&](const f32x4 (&ksacc)[4], float (&kv)[8]) {
-        const int tl = lane >> 4;
-        const float ksl = tl == 0 ? ksacc[0][0] : tl == 1 ? ksacc[1][0] : tl == 2 ? ksacc[2][0] : ksacc[3][0];
+    // after the partials are in `part` and a barrier: every thread sums the 8 partials of its 8 staging columns
+    auto ksum8 = [&](float (&kv)[8]) {
 #pragma unroll
-        for (int t = 0; t < 8; ++t) kv[t] = __shfl(ksl, scol + t, 64);
-    };
-    auto write_ksum_z = [&](int j, int c0, int rv, const f32x4 (&ksacc)[4], uint4 tq, bool write_ksum) {
-        if (write_ksum && wave == 0 && lane < 16) {
+        for (int t = 0; t < 8; ++t) kv[t] = 0.f;
 #pragma unroll
-            for (int tn = 0; tn < 4; ++tn) a.ksum[((long)bh * M + j) * 64 + tn * 16 + lane] = ksacc[tn][0];
+        for (int p = 0; p < 8; ++p) {
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(part + p * 64 + scol);
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(part + p * 64 + scol + 4);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { kv[t] += lo[t]; kv[4 + t] += hi[t]; }
         }
-        float kv[8];
-        ksum8(ksacc, kv);
+    };
+    auto write_ksum_z = [&](int j, int c0, int rv, const float (&kv)[8], uint4 tq, bool write_ksum) {
+        if (write_ksum && tid < 8) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) a.ksum[((long)bh * M + j) * 64 + scol + t] = kv[t];
+        }
         const unsigned qw[4] = {tq.x, tq.y, tq.z, tq.w};
         float d = 0.f;
 #pragma unroll
@@ -263,9 +258,11 @@ __global__ __launch_bounds__(FT8, 4) void k_fs_state(const FsStateArgs a) {
 
     if (S <= 64) {
         // software pipeline, two blocks ahead: R[jj & 1] carries block jj
+        // (MODE 0 keeps one block in flight: its registers also hold the Q piece and the ksum gather)
+        constexpr int AHEAD = MODE == 1 ? 2 : 1;
         TileRegs R0, R1;
         if (jg * IT < M) issue(jg * IT, 0, S, R0);
-        if (jg * IT + 1 < M) issue(jg * IT + 1, 0, S, R1);
+        if (AHEAD == 2 && jg * IT + 1 < M) issue(jg * IT + 1, 0, S, R1);
         const int rfill = (S + 31) & ~31;
         auto step = [&](auto jjc, TileRegs& R) {
             constexpr int jj = decltype(jjc)::value;
@@ -273,23 +270,26 @@ __global__ __launch_bounds__(FT8, 4) void k_fs_state(const FsStateArgs a) {
             if (j >= M) return;
             commit(R, j, 0, S, rfill);
             const uint4 tq = R.t;                      // (MODE 0) this thread's piece of Q_j for z_j
-            if (jj + 2 < IT && j + 2 < M) issue(j + 2, 0, S, R);
+            if (jj + AHEAD < IT && j + AHEAD < M) issue(j + AHEAD, 0, S, R);
             __syncthreads();
-            f32x4 ksacc[4];
-#pragma unroll
-            for (int tn = 0; tn < 4; ++tn) ksacc[tn] = f32x4{0.f, 0.f, 0.f, 0.f};
-            chunk(jjc, rfill, ksacc);
-            if (MODE == 0 && a.normalize) write_ksum_z(j, 0, S, ksacc, tq, true);
-            __syncthreads();
+            float ks = 0.f;
+            chunk(jjc, S, rfill, ks);
+            if (MODE == 0 && a.normalize) part[tid] = ks;
+            __syncthreads();                           // tiles consumed; partials visible
+            if (MODE == 0 && a.normalize) {
+                float kv[8];
+                ksum8(kv);
+                write_ksum_z(j, 0, S, kv, tq, true);
+            }
         };
         step(std::integral_constant<int, 0>{}, R0);
-        step(std::integral_constant<int, 1>{}, R1);
+        step(std::integral_constant<int, 1>{}, AHEAD == 2 ? R1 : R0);
         step(std::integral_constant<int, 2>{}, R0);
-        step(std::integral_constant<int, 3>{}, R1);
+        step(std::integral_constant<int, 3>{}, AHEAD == 2 ? R1 : R0);
         step(std::integral_constant<int, 4>{}, R0);
-        step(std::integral_constant<int, 5>{}, R1);
+        step(std::integral_constant<int, 5>{}, AHEAD == 2 ? R1 : R0);
         step(std::integral_constant<int, 6>{}, R0);
-        step(std::integral_constant<int, 7>{}, R1);
+        step(std::integral_constant<int, 7>{}, AHEAD == 2 ? R1 : R0);
     } else {
         // multi-chunk blocks (S > 64): synchronous chunks; z needs the complete ksum -> second pass over Q
         TileRegs R;
@@ -297,18 +297,20 @@ __global__ __launch_bounds__(FT8, 4) void k_fs_state(const FsStateArgs a) {
             constexpr int jj = decltype(jjc)::value;
             const int j = jg * IT + jj;
             if (j >= M) return;
-            f32x4 ksacc[4];
-#pragma unroll
-            for (int tn = 0; tn < 4; ++tn) ksacc[tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+            float ks = 0.f;
             for (int c0 = 0; c0 < S; c0 += 64) {
                 const int rv = min(64, S - c0), rfill = (rv + 31) & ~31;
                 issue(j, c0, rv, R);
                 commit(R, j, c0, rv, rfill);
                 __syncthreads();
-                chunk(jjc, rfill, ksacc);
+                chunk(jjc, rv, rfill, ks);
                 __syncthreads();
             }
             if (MODE == 0 && a.normalize) {
+                part[tid] = ks;
+                __syncthreads();
+                float kv[8];
+                ksum8(kv);
                 for (int c0 = 0; c0 < S; c0 += 64) {
                     const int rv = min(64, S - c0);
                     uint4 tq = make_uint4(0, 0, 0, 0);
@@ -316,8 +318,9 @@ __global__ __launch_bounds__(FT8, 4) void k_fs_state(const FsStateArgs a) {
                         tq = *reinterpret_cast<const uint4*>(tb + tok_row(a.idx, (long)j * S + c0 + srow) * a.t.sn + scol);
                         if (a.relu) tq = relu_eps8(tq, a.eps);
                     }
-                    write_ksum_z(j, c0, rv, ksacc, tq, c0 == 0);
+                    write_ksum_z(j, c0, rv, kv, tq, c0 == 0);
                 }
+                __syncthreads();                       // `part` is rewritten by the next block
             }
         };
         blockloop(std::integral_constant<int, 0>{});
