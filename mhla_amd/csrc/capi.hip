@@ -15,6 +15,7 @@
 #include "causal.cuh"
 #include "epilogue.cuh"
 #include "fused.cuh"
+#include "fused_tile16.cuh"
 
 using namespace mhla;
 
@@ -302,13 +303,13 @@ int mhla_blockmix_fwd(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q
         fast::FsStateArgs sa{};
         sa.x = cv(k_num); sa.y = cv(v); sa.t = cv(q_num); sa.idx = block_index; sa.state = f.state; sa.ksum = f.ksum;
         sa.z_out = f.z; sa.H = H; sa.M = M; sa.S = S; sa.eps = eps; sa.relu = relu; sa.normalize = normalize;
-        RC(launch(fast::k_fs_state<0>, dim3(f.njg, B * H), dim3(fast::FT8), fast::FS_STATE_SMEM, st, "k_fs_state<0>", sa));
+        RC(launch(fast::k_fs_state_fwd<0>, dim3(f.njg, B * H), dim3(fast::FT8), fast::FS_STATE_FWD_SMEM, st, "k_fs_state_fwd", sa));
         if (normalize)
             RC(launch(fast::k_fs_wz<0>, dim3((S + 63) / 64, B * H), dim3(fast::FT), 0, st, "k_fs_wz<0>", W, ldw, (const float*)f.z, f.ninv, M, S, eps));
         fast::FsOutArgs oa{};
         oa.q = cv(q_num); oa.o = cmv(out); oa.idx = block_index; oa.W = W; oa.ldw = ldw; oa.state = f.state; oa.ninv = f.ninv;
         oa.H = H; oa.M = M; oa.S = S; oa.njg = f.njg; oa.eps = eps; oa.relu = relu; oa.normalize = normalize;
-        RC(launch(fast::k_fs_out, dim3(f.njg * B * H), dim3(fast::FT8), fast::FS_OUT_SMEM, st, "k_fs_out", oa));
+        RC(launch(fast::k_t16_out, dim3(((f.njg + 1) / 2) * B * H), dim3(fast::FT8), fast::FS_GT16_BYTES, st, "k_t16_out", oa));
         return MHLA_OK;
     }
     const BmWs w = bm_carve(ws, B, H, M, S, D);
@@ -360,7 +361,7 @@ int mhla_blockmix_bwd(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q
                 fast::FsStateArgs sa{};
                 sa.x = cv(k_num); sa.y = cv(v); sa.t = cv(q_num); sa.idx = block_index; sa.state = f.state; sa.ksum = f.ksum;
                 sa.z_out = f.z; sa.H = H; sa.M = M; sa.S = S; sa.eps = eps; sa.relu = relu; sa.normalize = normalize;
-                RC(launch(fast::k_fs_state<0>, dim3(f.njg, B * H), dim3(fast::FT8), fast::FS_STATE_SMEM, st, "k_fs_state<0>", sa));
+                RC(launch(fast::k_fs_state_fwd<0>, dim3(f.njg, B * H), dim3(fast::FT8), fast::FS_STATE_FWD_SMEM, st, "k_fs_state_fwd", sa));
                 if (normalize)
                     RC(launch(fast::k_fs_wz<0>, dim3((S + 63) / 64, B * H), dim3(fast::FT), 0, st, "k_fs_wz<0>", W, ldw, (const float*)f.z, f.ninv, M, S, eps));
             }
@@ -381,8 +382,8 @@ int mhla_blockmix_bwd(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q
             ta.dz = f.dz; ta.ksum = ksum; ta.H = H; ta.M = M; ta.S = S; ta.njg = f.njg; ta.eps = eps; ta.relu = relu;
             ta.normalize = normalize;
             ta.dksum = f.dksum;
-            RC(launch(fast::k_fs_bwd_dq, dim3(f.njg * B * H), dim3(fast::FT8), fast::FS_TOK_SMEM, st, "k_fs_bwd_dq", ta));
-            RC(launch(fast::k_fs_bwd_dkv, dim3(f.njg * B * H), dim3(fast::FT8), fast::FS_TOK_SMEM, st, "k_fs_bwd_dkv", ta));
+            RC(launch(fast::k_t16_bwd_dq, dim3(((f.njg + 1) / 2) * B * H), dim3(fast::FT8), fast::FS_GT16_BYTES, st, "k_t16_bwd_dq", ta));
+            RC(launch(fast::k_t16_bwd_dkv, dim3(((f.njg + 1) / 2) * B * H), dim3(fast::FT8), fast::FS_GT16_BYTES, st, "k_t16_bwd_dkv", ta));
             return MHLA_OK;
         }
     }

@@ -347,6 +347,203 @@ __global__ __launch_bounds__(FT8, 4) void k_fs_state(const FsStateArgs a) {
         }
 }
 
+constexpr int FS_STATE_FWD_SMEM = 3 * 64 * TLD * 2 + (8 * 64 + 64) * 4;
+
+// Forward summaries (MODE 0 only): Q tile staged in LDS with K and V, two blocks ahead in registers.
+struct TileRegs3 { uint4 x, y, t; };
+
+template <int MODE>
+__global__ __launch_bounds__(FT8, 4) void k_fs_state_fwd(const FsStateArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u16* Xs = reinterpret_cast<u16*>(smem_raw);
+    u16* Ys = Xs + 64 * TLD;
+    u16* Ts = Ys + 64 * TLD;
+    float* part = reinterpret_cast<float*>(Ts + 64 * TLD);   // [8][64]
+    float* ksum_s = part + 512;                              // [64]
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int dt = wave & 3, th = wave >> 2;
+    const int jg = blockIdx.x, bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
+    const int S = a.S, M = a.M, njg = gridDim.x;
+    const u16* xb = (const u16*)a.x.ptr + b * a.x.sb + h * a.x.sh;
+    const u16* yb = (const u16*)a.y.ptr + b * a.y.sb + h * a.y.sh;
+    const u16* tb = a.normalize ? (const u16*)a.t.ptr + b * a.t.sb + h * a.t.sh : nullptr;
+    const bool single = S <= 64;
+    const int srow = tid >> 3, scol = (tid & 7) * 8;         // staging: thread -> (row, 8 columns = 16 bytes)
+    const bool tile_t = a.normalize && (MODE == 1 || single);   // third tile travels with the chunk
+
+    auto issue = [&](long p, int rv, TileRegs3& R) {
+        R.x = R.y = R.t = make_uint4(0, 0, 0, 0);
+        if (srow < rv) {
+            const long tr = tok_row(a.idx, p + srow);
+            R.x = *reinterpret_cast<const uint4*>(xb + tr * a.x.sn + scol);
+            R.y = *reinterpret_cast<const uint4*>(yb + tr * a.y.sn + scol);
+            if (tile_t) R.t = *reinterpret_cast<const uint4*>(tb + tr * a.t.sn + scol);
+        }
+    };
+    auto commit = [&](const TileRegs3& R, int rv, int rfill) {
+        if (srow < rfill) {
+            uint4 x = R.x, t = R.t;
+            if (a.relu && srow < rv) {
+                x = relu_eps8(x, a.eps);
+                if (MODE == 0 && tile_t) t = relu_eps8(t, a.eps);
+            }
+            *reinterpret_cast<uint4*>(Xs + srow * TLD + scol) = x;
+            *reinterpret_cast<uint4*>(Ys + srow * TLD + scol) = R.y;
+            if (tile_t) *reinterpret_cast<uint4*>(Ts + srow * TLD + scol) = t;
+        }
+    };
+
+    f32x4 acc[IT][2];
+#pragma unroll
+    for (int jj = 0; jj < IT; ++jj) acc[jj][0] = acc[jj][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // one staged 64-row chunk of block jj (tiles in LDS, barrier done): side products + MFMAs
+    auto chunk = [&](auto jjc, int j, int c0, int rv, int rfill, float& ks) {
+        constexpr int jj = decltype(jjc)::value;
+        if (MODE == 0 && a.normalize) {   // column sums of K: thread -> column tid & 63, rows 8 (tid >> 6) ..
+            const int col = tid & 63, pr = tid >> 6;
+            for (int r = pr * 8; r < min(rv, pr * 8 + 8); ++r) ks += bf(Xs[r * TLD + col]);
+        }
+        if (MODE == 1 && a.normalize) {   // dn and dP = dO / n (rounded to bf16); 8 threads per row, 16 bytes each
+            float d = 0.f;
+            uint4 yv = make_uint4(0, 0, 0, 0);
+            if (srow < rv) {
+                yv = *reinterpret_cast<const uint4*>(Ys + srow * TLD + scol);
+                const uint4 ov = *reinterpret_cast<const uint4*>(Ts + srow * TLD + scol);
+                const unsigned yw[4] = {yv.x, yv.y, yv.z, yv.w}, ow[4] = {ov.x, ov.y, ov.z, ov.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    d += __uint_as_float(yw[i] << 16) * __uint_as_float(ow[i] << 16) +
+                         __uint_as_float(yw[i] & 0xffff0000u) * __uint_as_float(ow[i] & 0xffff0000u);
+            }
+            d += __shfl_xor(d, 1, 64);
+            d += __shfl_xor(d, 2, 64);
+            d += __shfl_xor(d, 4, 64);
+            if (srow < rv) {
+                const float ni = a.ninv[((long)bh * M + j) * S + c0 + srow];
+                if ((tid & 7) == 0) a.dn[((long)bh * M + j) * S + c0 + srow] = -d * ni;
+                unsigned yw[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    yw[i] = pack_bf16x2(__uint_as_float(yw[i] << 16) * ni, __uint_as_float(yw[i] & 0xffff0000u) * ni);
+                *reinterpret_cast<uint4*>(Ys + srow * TLD + scol) = make_uint4(yw[0], yw[1], yw[2], yw[3]);
+            }
+            __syncthreads();
+        }
+        for (int k0 = 0; k0 < rfill; k0 += 32) {
+            const bf16x8 av = tr_read8(Ys, TLD, k0, dt * 16, lane);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) acc[jj][t] = mfma_bf16(av, tr_read8(Xs, TLD, k0, (2 * th + t) * 16, lane), acc[jj][t]);
+        }
+    };
+    // ksum_j and z_j once all chunks of block j went through (MODE 0)
+    auto finish_block = [&](int j, float ks) {
+        const long p0 = (long)j * S;
+        part[(tid >> 6) * 64 + (tid & 63)] = ks;
+        __syncthreads();
+        if (tid < 64) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) sacc += part[p * 64 + tid];
+            ksum_s[tid] = sacc;
+            a.ksum[((long)bh * M + j) * 64 + tid] = sacc;
+        }
+        __syncthreads();
+        for (int c0 = 0; c0 < S; c0 += 64) {
+            const int rv = min(64, S - c0);
+            if (!single) {   // (rare) multi-chunk blocks: second pass over Q, synchronous
+                uint4 t = make_uint4(0, 0, 0, 0);
+                if (srow < rv) {
+                    t = *reinterpret_cast<const uint4*>(tb + tok_row(a.idx, p0 + c0 + srow) * a.t.sn + scol);
+                    if (a.relu) t = relu_eps8(t, a.eps);
+                }
+                *reinterpret_cast<uint4*>(Ts + srow * TLD + scol) = t;
+                __syncthreads();
+            }
+            float d = 0.f;
+            if (srow < rv) {
+                const uint4 qv = *reinterpret_cast<const uint4*>(Ts + srow * TLD + scol);
+                const unsigned qw[4] = {qv.x, qv.y, qv.z, qv.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    d += __uint_as_float(qw[i] << 16) * ksum_s[scol + 2 * i] + __uint_as_float(qw[i] & 0xffff0000u) * ksum_s[scol + 2 * i + 1];
+            }
+            d += __shfl_xor(d, 1, 64);
+            d += __shfl_xor(d, 2, 64);
+            d += __shfl_xor(d, 4, 64);
+            if (srow < rv && (tid & 7) == 0) a.z_out[((long)bh * M + j) * S + c0 + srow] = d;
+            __syncthreads();
+        }
+    };
+
+    if (single) {
+        // software pipeline, two blocks ahead: R[jj & 1] carries block jj
+        TileRegs3 R0, R1;
+        if (jg * IT < M) issue((long)jg * IT * S, S, R0);
+        if (jg * IT + 1 < M) issue((long)(jg * IT + 1) * S, S, R1);
+        const int rfill = (S + 31) & ~31;
+        auto step = [&](auto jjc, TileRegs3& R) {
+            constexpr int jj = decltype(jjc)::value;
+            const int j = jg * IT + jj;
+            if (j >= M) return;
+            commit(R, S, rfill);
+            if (jj + 2 < IT && j + 2 < M) issue((long)(j + 2) * S, S, R);
+            __syncthreads();
+            float ks = 0.f;
+            chunk(jjc, j, 0, S, rfill, ks);
+            if (MODE == 0 && a.normalize) finish_block(j, ks);   // ends with a barrier
+            else __syncthreads();
+        };
+        step(std::integral_constant<int, 0>{}, R0);
+        step(std::integral_constant<int, 1>{}, R1);
+        step(std::integral_constant<int, 2>{}, R0);
+        step(std::integral_constant<int, 3>{}, R1);
+        step(std::integral_constant<int, 4>{}, R0);
+        step(std::integral_constant<int, 5>{}, R1);
+        step(std::integral_constant<int, 6>{}, R0);
+        step(std::integral_constant<int, 7>{}, R1);
+    } else {
+        TileRegs3 R;
+        auto blockloop = [&](auto jjc) {
+            constexpr int jj = decltype(jjc)::value;
+            const int j = jg * IT + jj;
+            if (j >= M) return;
+            const long p0 = (long)j * S;
+            float ks = 0.f;
+            for (int c0 = 0; c0 < S; c0 += 64) {
+                const int rv = min(64, S - c0), rfill = (rv + 31) & ~31;
+                issue(p0 + c0, rv, R);
+                commit(R, rv, rfill);
+                __syncthreads();
+                chunk(jjc, j, c0, rv, rfill, ks);
+                __syncthreads();
+            }
+            if (MODE == 0 && a.normalize) finish_block(j, ks);
+        };
+        blockloop(std::integral_constant<int, 0>{});
+        blockloop(std::integral_constant<int, 1>{});
+        blockloop(std::integral_constant<int, 2>{});
+        blockloop(std::integral_constant<int, 3>{});
+        blockloop(std::integral_constant<int, 4>{});
+        blockloop(std::integral_constant<int, 5>{});
+        blockloop(std::integral_constant<int, 6>{});
+        blockloop(std::integral_constant<int, 7>{});
+    }
+
+    // 16-byte interleaved store: lane -> (d2 = 16 dt + 4 (lane >> 4) + r, d1 = 16 (2 th + t) + (lane & 15))
+    u16* sb = a.state + ((long)bh * njg + jg) * FE * IT;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int d2 = dt * 16 + (lane >> 4) * 4 + r, d1 = (2 * th + t) * 16 + (lane & 15);
+            unsigned w[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) w[p] = pack_bf16x2(acc[2 * p][t][r], acc[2 * p + 1][t][r]);
+            *reinterpret_cast<uint4*>(sb + ((long)d2 * FD + d1) * IT) = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+}
+
 // -------------------------------------------------------------------------------------------------
 // Mixing of one 8-block tile into LDS:  Gt[ii][d2][d1] = sum_j Wm(i0 + ii, j) state[j][d2][d1]
 //   TRANSW 0: Wm(i, j) = W[i][j]      TRANSW 1: Wm(i, j) = W[j][i]
