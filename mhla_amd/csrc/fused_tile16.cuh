@@ -9,7 +9,8 @@ namespace mhla {
 namespace fast {
 
 constexpr int TT = 16;                              // blocks per tile
-constexpr int FS_GT16_BYTES = TT * FD * GLD * 2;    // 147456 B
+constexpr int GSLOT = FD * GLD + 8;                  // elements per mixed-summary slot (+16 B: spreads the 16 blocks over banks)
+constexpr int FS_GT16_BYTES = TT * GSLOT * 2;       // 147712 B
 
 template <int TRANSW>
 __device__ __forceinline__ void mix16_tile_to_lds(u16* __restrict__ Gt, const u16* __restrict__ state_bh, int njg,
@@ -43,22 +44,25 @@ __device__ __forceinline__ void mix16_tile_to_lds(u16* __restrict__ Gt, const u1
         }
     };
     auto do_batch = [&](const uint4 (&av)[UN][2], int et0) {
+        // UN independent accumulator chains, interleaved step by step (no back-to-back dependent MFMAs)
+        f32x4 c[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) c[u] = mfma_bf16(__builtin_bit_cast(bf16x8, av[u][0]), bhi[0], f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+        for (int u = 0; u < UN; ++u) c[u] = mfma_bf16(__builtin_bit_cast(bf16x8, av[u][0]), blo[0], c[u]);
+        if (two) {
+#pragma unroll
+            for (int u = 0; u < UN; ++u) c[u] = mfma_bf16(__builtin_bit_cast(bf16x8, av[u][1]), bhi[1], c[u]);
+#pragma unroll
+            for (int u = 0; u < UN; ++u) c[u] = mfma_bf16(__builtin_bit_cast(bf16x8, av[u][1]), blo[1], c[u]);
+        }
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
-            f32x4 c = {0.f, 0.f, 0.f, 0.f};
-            const bf16x8 a0 = __builtin_bit_cast(bf16x8, av[u][0]);
-            c = mfma_bf16(a0, bhi[0], c);
-            c = mfma_bf16(a0, blo[0], c);
-            if (two) {
-                const bf16x8 a1 = __builtin_bit_cast(bf16x8, av[u][1]);
-                c = mfma_bf16(a1, bhi[1], c);
-                c = mfma_bf16(a1, blo[1], c);
-            }
             const int et = et0 + u, d2 = et >> 2, d1 = (et & 3) * 16 + kg * 4;
             uint2 pk;
-            pk.x = pack_bf16x2(c[0], c[1]);
-            pk.y = pack_bf16x2(c[2], c[3]);
-            *reinterpret_cast<uint2*>(Gt + ((long)(n * FD + d2)) * GLD + d1) = pk;
+            pk.x = pack_bf16x2(c[u][0], c[u][1]);
+            pk.y = pack_bf16x2(c[u][2], c[u][3]);
+            *reinterpret_cast<uint2*>(Gt + (long)n * GSLOT + d2 * GLD + d1) = pk;
         }
     };
     constexpr int NB = FE / 16 / NW / UN;
@@ -166,7 +170,7 @@ __global__ __launch_bounds__(FT8, 2) void k_t16_out(const FsOutArgs a) {
     };
     auto compute_store = [&](const bf16x8 (&av)[4][2], float ninv, int bi, int i, int c0, int rv) {
         const long p0 = (long)i * S + c0;
-        u16* Gb = Gt + bi * FD * GLD;
+        u16* Gb = Gt + bi * GSLOT;
         f32x4 acc[4][4];
 #pragma unroll
         for (int st = 0; st < 4; ++st)
@@ -247,7 +251,7 @@ __global__ __launch_bounds__(FT8, 2) void k_t16_bwd_dq(const FsTokArgs a) {
     // one 64-row chunk: dQ rows, and the chunk's contribution to dksum (per-lane partials in the A layout)
     auto compute_store = [&](const bf16x8 (&gv)[4][2], const Side& sd, float (&dks_acc)[2][8], int bi, int j, int c0, int rv) {
         const long p0 = (long)j * S + c0;
-        u16* Gb = Gt + bi * FD * GLD;
+        u16* Gb = Gt + bi * GSLOT;
         f32x4 acc[4][4];
 #pragma unroll
         for (int st = 0; st < 4; ++st)
@@ -358,7 +362,7 @@ __global__ __launch_bounds__(FT8, 2) void k_t16_bwd_dkv(const FsTokArgs a) {
     };
     auto compute_store = [&](const bf16x8 (&kv)[4][2], int bi, int j, int c0, int rv) {
         const long p0 = (long)j * S + c0;
-        u16* Gb = Gt + bi * FD * GLD;
+        u16* Gb = Gt + bi * GSLOT;
         const bool last = c0 + 64 >= S;
         bf16x8 vv[4][2];
         load_a64<false>(vv, vb, a.v.sn, a.idx, p0, rv, 0.f, lane);

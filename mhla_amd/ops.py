@@ -54,6 +54,13 @@ def _prep(t: torch.Tensor) -> torch.Tensor:
     return t if _strided_ok(t) else t.contiguous()
 
 
+def _alloc_like_tokens(B, N, H, D, ref):
+    import os
+    if os.environ.get("MHLA_HEAD_MAJOR_OUT"):   # experiment: outputs stored [B, H, N, D]
+        return torch.empty((B, H, N, D), dtype=ref.dtype, device=ref.device).permute(0, 2, 1, 3)
+    return torch.empty((B, N, H, D), dtype=ref.dtype, device=ref.device)
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -82,7 +89,7 @@ class _BlockMix(torch.autograd.Function):
         if split:
             q_den, k_den = _prep(q_den), _prep(k_den)
         Wf = W.detach().reshape(M, M).to(torch.float32).contiguous()
-        out = torch.empty((B, N, H, D), dtype=q.dtype, device=q.device)
+        out = _alloc_like_tokens(B, N, H, D, q)
         dt = _dtype_code(q)
         flags = (_lib.FLAG_RELU_EPS if relu_eps else 0) | (_lib.FLAG_FORCE_GENERIC if force_generic else 0)
         ws = _ws(lib.mhla_blockmix_fwd_ws_bytes(B, H, M, S, D, dt, int(split), flags), q.device)
@@ -112,9 +119,9 @@ class _BlockMix(torch.autograd.Function):
         M = Wf.shape[0]
         S = N // M
         dout = _prep(dout.to(q.dtype))
-        dq = torch.empty((B, N, H, D), dtype=q.dtype, device=q.device)
-        dk = torch.empty_like(dq)
-        dv = torch.empty_like(dq)
+        dq = _alloc_like_tokens(B, N, H, D, q)
+        dk = _alloc_like_tokens(B, N, H, D, q)
+        dv = _alloc_like_tokens(B, N, H, D, q)
         dW = torch.empty((M, M), dtype=torch.float32, device=q.device)
         dqd = dkd = None
         if split:
