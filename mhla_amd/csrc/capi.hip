@@ -142,8 +142,8 @@ FastWs fast_carve(void* ws, int B, int H, int M, int S) {
     w.dn = (float*)p; p += al4(bh * M * S) * 4;
     w.dz = (float*)p; p += al4(bh * M * S) * 4;
     w.dksum = (float*)p; p += al4(bh * M * 64) * 4;
-    w.dwp = (float*)p; p += bh * fast::DW_SPLIT * 4096 * 4;
-    w.dwt = (float*)p; p += ((bh * fast::DW_SPLIT + fast::DWR_G - 1) / fast::DWR_G) * 4096 * 4;
+    w.dwp = (float*)p; p += bh * (fast::DW_SPLIT + 1) * 4096 * 4;
+    w.dwt = (float*)p; p += ((bh * (fast::DW_SPLIT + 1) + fast::DWR_G - 1) / fast::DWR_G) * 4096 * 4;
     w.total_bwd = (size_t)(p - (char*)ws);
     return w;
 }
@@ -373,7 +373,8 @@ int mhla_blockmix_bwd(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q
             if (normalize)
                 RC(launch(fast::k_fs_wz<1>, dim3((S + 63) / 64, B * H), dim3(fast::FT), 0, st, "k_fs_wz<1>", W, ldw, (const float*)f.dn, f.dz, M, S, 0.f));
             RC(launch(fast::k_fs_dw, dim3(fast::DW_SPLIT, B * H), dim3(fast::FT8), fast::FS_DW_SMEM, st, "k_fs_dw", da));
-            const int nparts = B * H * fast::DW_SPLIT, ngroups = (nparts + fast::DWR_G - 1) / fast::DWR_G;
+            RC(launch(fast::k_fs_dwz, dim3(B * H), dim3(fast::FT), 0, st, "k_fs_dwz", normalize ? (const float*)f.dn : (const float*)nullptr, z, f.dwp, M, S));
+            const int nparts = B * H * (fast::DW_SPLIT + 1), ngroups = (nparts + fast::DWR_G - 1) / fast::DWR_G;
             RC(launch(fast::k_fs_dw_reduce1, dim3(16, ngroups), dim3(256), 0, st, "k_fs_dw_reduce1", (const float*)f.dwp, f.dwt, nparts));
             RC(launch(fast::k_fs_dw_reduce2, dim3((M * M + 255) / 256), dim3(256), 0, st, "k_fs_dw_reduce2", (const float*)f.dwt, dW, M, ngroups));
             fast::FsTokArgs ta{};

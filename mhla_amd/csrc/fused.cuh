@@ -830,14 +830,14 @@ __global__ __launch_bounds__(FT8, 4) void k_fs_out(const FsOutArgs a) {
 // -------------------------------------------------------------------------------------------------
 // k_fs_dw: dWp[bh][q][i][j] = sum_{e' in quarter q} dG[i][e'] KV[j][e']   (both in the interleaved layout)
 // LDS images [e'][64 blocks] built from 16-byte pieces; both MFMA operands via transpose reads.
-// grid (DW_SPLIT, bh).  The <dn_i, z_j> term is added by split 0 from LDS tiles.
+// grid (DW_SPLIT, bh).  The <dn_i, z_j> term has its own small kernel (k_fs_dwz) so no workgroup runs long.
 // -------------------------------------------------------------------------------------------------
 struct FsDwArgs {
     const u16* dg;
     const u16* kv;
     const float* dn;   // [bh][M][S] or null
     const float* z;
-    float* dwp;        // [bh][DW_SPLIT][64][64]
+    float* dwp;        // [bh][DW_SPLIT + 1][64][64]  (last slot: the <dn_i, z_j> term, k_fs_dwz)
     int M, S, njg;
 };
 constexpr int DW_EC = 128;                       // e' rows per LDS image
@@ -884,42 +884,56 @@ __global__ __launch_bounds__(FT8) void k_fs_dw(const FsDwArgs a) {
         }
         __syncthreads();
     }
-    // <dn_i, z_j> term (quarter 0): stage dn[64][S<=64 chunk] and z[64][chunk] in LDS as fp32
-    if (qtr == 0 && a.dn) {
-        float* dns = reinterpret_cast<float*>(smem_raw);     // [64][65]
-        float* zs = dns + 64 * 65;                           // [64][65]   (2 x 16.6 KB <= the image buffers)
-        for (int c0 = 0; c0 < a.S; c0 += 64) {
-            const int rv = min(64, a.S - c0);
-            __syncthreads();
-            float zr[16];
-#pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const int v = tid + t * FT8, which = v >> 12, row = (v >> 6) & 63, col = v & 63;
-                zr[t] = (row < M && col < rv) ? (which ? a.z : a.dn)[((long)bh * M + row) * a.S + c0 + col] : 0.f;
-            }
-#pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const int v = tid + t * FT8, which = v >> 12, row = (v >> 6) & 63, col = v & 63;
-                (which ? zs : dns)[row * 65 + col] = zr[t];
-            }
-            __syncthreads();
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int i = wi * 16 + kg * 4 + r, j = (2 * wj + t) * 16 + n;
-                    float v = 0.f;
-#pragma unroll 4
-                    for (int c = 0; c < 64; ++c) v += dns[i * 65 + c] * zs[j * 65 + c];
-                    acc[t][r] += v;
-                }
-        }
-    }
-    float* out = a.dwp + ((long)bh * DW_SPLIT + qtr) * 64 * 64;
+    float* out = a.dwp + ((long)bh * (DW_SPLIT + 1) + qtr) * 64 * 64;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) out[(wi * 16 + kg * 4 + r) * 64 + (2 * wj + t) * 16 + n] = acc[t][r];
+}
+
+// dWp[bh][DW_SPLIT][i][j] = sum_s dn[bh][i][s] z[bh][j][s]   (fp32, LDS tiles; one workgroup per (b,h))
+__global__ __launch_bounds__(FT) void k_fs_dwz(const float* __restrict__ dn, const float* __restrict__ z, float* __restrict__ dwp,
+                                               int M, int S) {
+    __shared__ float dns[64 * 65];
+    __shared__ float zs[64 * 65];
+    const int tid = threadIdx.x, bh = blockIdx.x;
+    const int i0 = (tid >> 4) * 4, j0 = (tid & 15) * 4;   // thread -> 4 x 4 outputs
+    float acc[4][4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) acc[x][y] = 0.f;
+    for (int c0 = 0; dn && c0 < S; c0 += 64) {   // dn == nullptr (un-normalised op): the term is zero
+        const int rv = min(64, S - c0);
+        float zr[32];
+#pragma unroll
+        for (int t = 0; t < 32; ++t) {
+            const int v = tid + t * FT, which = v >> 12, row = (v >> 6) & 63, col = v & 63;
+            zr[t] = (row < M && col < rv) ? (which ? z : dn)[((long)bh * M + row) * S + c0 + col] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 32; ++t) {
+            const int v = tid + t * FT, which = v >> 12, row = (v >> 6) & 63, col = v & 63;
+            (which ? zs : dns)[row * 65 + col] = zr[t];
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int c = 0; c < 64; ++c) {
+            float dv[4], zv[4];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) { dv[x] = dns[(i0 + x) * 65 + c]; zv[x] = zs[(j0 + x) * 65 + c]; }
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int y = 0; y < 4; ++y) acc[x][y] += dv[x] * zv[y];
+        }
+    }
+    float* out = dwp + ((long)bh * (DW_SPLIT + 1) + DW_SPLIT) * 64 * 64;
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) out[(i0 + x) * 64 + j0 + y] = acc[x][y];
 }
 
 // Deterministic two-stage reduction of the partials: stage 1 sums groups of DWR_G partials (grid (16, ngroups)),
