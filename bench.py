@@ -136,7 +136,20 @@ def main():
     dom = max(kernels, key=lambda n: kernels[n]["us_per_step"]) if kernels else None
 
     esz = {"bf16": 2, "f16": 2, "f32": 4}[a.dtype]
-    alg_bytes = 12 * a.B * a.H * a.N * a.D * esz            # fwd 4 NDe + bwd 8 NDe per (b, h)
+    nde = a.B * a.H * a.N * a.D * esz                         # one token tensor of this rank's batch
+    alg_bytes = 12 * nde                                      # fwd 4 NDe + bwd 8 NDe per (b, h)
+    # share of the algorithmic token traffic each kernel is responsible for: the dominant kernel's own
+    # roofline fraction is its share / its duration
+    share = {"k_t16_bwd_dkv": 4, "k_t16_bwd_dq": 3, "k_t16_out": 2, "k_fs_state_fwd": 2, "k_fs_state<1>": 3,
+             "k_bm_bwd_tok": 7, "k_bm_state<0>": 2, "k_bm_state<1>": 3, "k_bm_out": 2}
+    # HBM bytes per step from rocprofv3 PMC passes of this same command (tools/pmc_run.sh; profiles/*.json), if committed
+    traffic = None
+    pj = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+    if os.path.exists(pj) and (a.B, a.N, a.H, a.D, a.M, a.dtype) == (8, 4096, 16, 64, 64, "bf16"):
+        try:
+            traffic = json.load(open(pj))["hbm_bytes_per_step"]
+        except Exception:
+            traffic = None
     alg_flops = a.B * a.H * (12 * a.N * a.D * a.D + 6 * a.M * a.M * a.D * a.D)
     achieved = alg_bytes / (gpu_us * 1e-6) / 1e9 if gpu_us else None
 
@@ -151,11 +164,16 @@ def main():
                        "global_batch": a.B * world, "parallelism": f"dp{world} (batch shards, dW all-reduce only)"},
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS if achieved else None, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS if achieved else None, "traffic": traffic,
                 "scope": "whole fwd+bwd step: algorithmic bytes 12*B*H*N*D*e over the sum of all kernel "
                          "durations (HIP events per launch)",
                 "algorithmic_bytes_per_step": alg_bytes, "gpu_us_per_step": gpu_us,
-                "dominant_kernel": dom, "kernels": kernels,
+                "dominant_kernel": None if dom is None else {
+                    "name": dom, "avg_us": kernels[dom]["avg_us"],
+                    "algorithmic_bytes": share.get(dom, 0) * nde or None,
+                    "achieved_GBps": (share.get(dom, 0) * nde / (kernels[dom]["avg_us"] * 1e-6) / 1e9) if share.get(dom) else None,
+                    "frac": (share.get(dom, 0) * nde / (kernels[dom]["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS) if share.get(dom) else None},
+                "kernels": kernels,
                 "mfma_frac_of_bf16_peak": alg_flops / (gpu_us * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS if gpu_us else None,
             },
         }
