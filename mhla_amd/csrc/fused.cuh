@@ -10,8 +10,9 @@
 // O_i = Q_i G_i (forward) or dQ/dK/dV (backward).  W is split into bf16 hi + lo parts (2 MFMAs) so the
 // mixing weights keep ~16 mantissa bits.  All contractions: v_mfma_f32_16x16x32_bf16, fp32 accumulate.
 //
-//   forward : k_fs_state<0> (KV^T, ksum, z)  ->  k_fs_out (mix + n + O)
-//   backward: k_fs_state<1> (dG^T, dn) -> k_fs_dw (dW partials) -> k_fs_bwd_dq (mix G; dQ, dksum) -> k_fs_bwd_dkv (mix dKV; dK, dV)
+//   forward : k_fs_state_fwd (KV^T, ksum, z) -> k_fs_wz<0> (1/n) -> k_t16_out (mix + O)        [fused_tile16.cuh]
+//   backward: k_fs_state<1> (dG^T, dn) -> k_fs_wz<1> (dz) -> k_fs_dw/dwz/reduce (dW) -> k_t16_bwd_dq (mix G; dQ, dksum)
+//             -> k_t16_bwd_dkv (mix dKV; dK, dV)
 // The kernels are bound by per-wave load latency, not bandwidth (PMC: 3-4 TB/s, waves mostly in s_waitcnt), so
 // the streaming kernels run 8-wave workgroups at <= 128 VGPRs: two workgroups = 16 waves per CU keep loads in flight.
 #pragma once
@@ -544,157 +545,16 @@ __global__ __launch_bounds__(FT8, 4) void k_fs_state_fwd(const FsStateArgs a) {
         }
 }
 
-// -------------------------------------------------------------------------------------------------
-// Mixing of one 8-block tile into LDS:  Gt[ii][d2][d1] = sum_j Wm(i0 + ii, j) state[j][d2][d1]
-//   TRANSW 0: Wm(i, j) = W[i][j]      TRANSW 1: Wm(i, j) = W[j][i]
-// MFMA: rows = 16 consecutive e' (A operand: one 16-byte global load per lane), cols = the 8 blocks of
-// the tile (B operand: W hi / lo bf16 parts), reduction over j in steps of 32 blocks (M <= 64: 2 steps).
-// All 8 waves; every wave keeps two batches of UN tiles in flight (software double buffer).
-// -------------------------------------------------------------------------------------------------
-template <int TRANSW>
-__device__ __forceinline__ void mix_tile_to_lds(u16* __restrict__ Gt, const u16* __restrict__ state_bh, int njg,
-                                                const float* __restrict__ W, int ldw, int M, int i0, int tid) {
-    const int wave = tid >> 6, lane = tid & 63, n = lane & 15, kg = lane >> 4;
-    bf16x8 bhi[2], blo[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        s16x8 hi, lo;
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const int j = ks * 32 + kg * 8 + t, i = i0 + n;
-            float w = 0.f;
-            if (n < IT && i < M && j < M) w = TRANSW ? W[(long)j * ldw + i] : W[(long)i * ldw + j];
-            const u16 h = cvt_bf16(w);
-            hi[t] = (short)h;
-            lo[t] = (short)cvt_bf16(w - bf(h));
-        }
-        bhi[ks] = __builtin_bit_cast(bf16x8, hi);
-        blo[ks] = __builtin_bit_cast(bf16x8, lo);
-    }
-    const bool two = njg > 4;
-    constexpr int UN = 4, NW = FT8 / 64;
-    const uint4 zero4 = make_uint4(0, 0, 0, 0);
-    auto load_batch = [&](uint4 (&av)[UN][2], int et0) {
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const long e = (long)(et0 + u) * 16 + n;
-            av[u][0] = (kg < njg) ? *reinterpret_cast<const uint4*>(state_bh + ((long)kg * FE + e) * IT) : zero4;
-            av[u][1] = (two && 4 + kg < njg) ? *reinterpret_cast<const uint4*>(state_bh + ((long)(4 + kg) * FE + e) * IT) : zero4;
-        }
-    };
-    auto do_batch = [&](const uint4 (&av)[UN][2], int et0) {
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            f32x4 c = {0.f, 0.f, 0.f, 0.f};
-            const bf16x8 a0 = __builtin_bit_cast(bf16x8, av[u][0]);
-            c = mfma_bf16(a0, bhi[0], c);
-            c = mfma_bf16(a0, blo[0], c);
-            if (two) {
-                const bf16x8 a1 = __builtin_bit_cast(bf16x8, av[u][1]);
-                c = mfma_bf16(a1, bhi[1], c);
-                c = mfma_bf16(a1, blo[1], c);
-            }
-            if (n < IT) {
-                const int et = et0 + u, d2 = et >> 2, d1 = (et & 3) * 16 + kg * 4;
-                uint2 pk;
-                pk.x = pack_bf16x2(c[0], c[1]);
-                pk.y = pack_bf16x2(c[2], c[3]);
-                *reinterpret_cast<uint2*>(Gt + ((long)(n * FD + d2)) * GLD + d1) = pk;
-            }
-        }
-    };
-    constexpr int NB = FE / 16 / NW / UN;   // batches per wave (8)
-    uint4 bufA[UN][2], bufB[UN][2];
-    load_batch(bufA, wave * UN);
-#pragma unroll 1
-    for (int bt = 0; bt < NB; bt += 2) {
-        load_batch(bufB, (wave + NW * (bt + 1)) * UN);
-        do_batch(bufA, (wave + NW * bt) * UN);
-        if (bt + 2 < NB) load_batch(bufA, (wave + NW * (bt + 2)) * UN);
-        do_batch(bufB, (wave + NW * (bt + 1)) * UN);
-    }
-}
-
 // XCD-aware logical work index (bijective): workgroups that share a (b,h)'s summaries land on one XCD's L2.
 __device__ __forceinline__ int xcd_swizzle(int wg, int nwg) {
     const int xcd = wg & 7, slot = wg >> 3, q = nwg >> 3, r = nwg & 7;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
 }
 
-// A operands of 32 rows (two 16-row tiles) straight from a token view: a[st][ks] = rows 16 st + (lane & 15),
-// columns 32 ks + 8 (lane >> 4) .. + 7.  Rows >= rv (counted from p0) give zeros.
-template <bool RELU>
-__device__ __forceinline__ void load_a32(bf16x8 (&a)[2][2], const u16* __restrict__ base, long sn,
-                                         const int* __restrict__ idx, long p0, int rv, float eps, int lane) {
-    const int m = lane & 15, kg = lane >> 4;
-#pragma unroll
-    for (int st = 0; st < 2; ++st) {
-        const int row = st * 16 + m;
-        const u16* src = base + (row < rv ? tok_row(idx, p0 + row) : 0) * sn + kg * 8;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (row < rv) {
-                v = *reinterpret_cast<const uint4*>(src + ks * 32);
-                if (RELU) v = relu_eps8(v, eps);
-            }
-            a[st][ks] = __builtin_bit_cast(bf16x8, v);
-        }
-    }
-}
-
-// acc[st][tn] += A[st] x B  (32 rows) with B from one mixed summary Gb[d2][d1] (GLD stride):
-//   TRB false: B[k = d1][n = d2] = Gb[n][k]  (k contiguous: plain 16-byte LDS reads)
-//   TRB true : B[k = d2][n = d1] = Gb[k][n]  (hardware transpose reads)
-template <bool TRB>
-__device__ __forceinline__ void rows32_times_gt(f32x4 (&acc)[2][4], const bf16x8 (&a)[2][2], const u16* __restrict__ Gb, int lane) {
-    const int n = lane & 15, kg = lane >> 4;
-#pragma unroll
-    for (int tn = 0; tn < 4; ++tn) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const bf16x8 bv = TRB ? tr_read8(Gb, GLD, ks * 32, tn * 16, lane)
-                                  : *reinterpret_cast<const bf16x8*>(Gb + (tn * 16 + n) * GLD + ks * 32 + kg * 8);
-#pragma unroll
-            for (int st = 0; st < 2; ++st) acc[st][tn] = mfma_bf16(a[st][ks], bv, acc[st][tn]);
-        }
-    }
-}
-
-__device__ __forceinline__ void zero_acc(f32x4 (&acc)[2][4]) {
-#pragma unroll
-    for (int st = 0; st < 2; ++st)
-#pragma unroll
-        for (int tn = 0; tn < 4; ++tn) acc[st][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
-}
-
-// 32 x 64 fp32 results (C layout) packed as bf16 pairs: pk[st][tn][0] = rows (r0, r1), [1] = (r2, r3)
-__device__ __forceinline__ void pack_acc(unsigned (&pk)[2][4][2], const f32x4 (&acc)[2][4]) {
-#pragma unroll
-    for (int st = 0; st < 2; ++st)
-#pragma unroll
-        for (int tn = 0; tn < 4; ++tn) {
-            pk[st][tn][0] = pack_bf16x2(acc[st][tn][0], acc[st][tn][1]);
-            pk[st][tn][1] = pack_bf16x2(acc[st][tn][2], acc[st][tn][3]);
-        }
-}
-
 __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-}
-
-// Wave-private staging of 32 packed rows (row = row0 + 16 st + 4 (lane >> 4) + r, col = 16 tn + (lane & 15))
-__device__ __forceinline__ void stage32(u16* __restrict__ Os, int row0, const unsigned (&pk)[2][4][2], int lane) {
-    const int n = lane & 15, kg = lane >> 4;
-#pragma unroll
-    for (int st = 0; st < 2; ++st)
-#pragma unroll
-        for (int tn = 0; tn < 4; ++tn)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                Os[(row0 + st * 16 + kg * 4 + r) * GLD + tn * 16 + n] = (u16)(pk[st][tn][r >> 1] >> ((r & 1) * 16));
 }
 
 // zero the bf16 lanes of v where the corresponding element of m is <= 0 (relu gradient mask)
@@ -726,31 +586,9 @@ __device__ __forceinline__ void store64(u16* __restrict__ base, long sn, const i
         }
     }
 }
-// narrow fallback (no free staging slot, multi-chunk blocks): direct stores of 32 packed rows from the C layout
-template <bool MASK>
-__device__ __forceinline__ void store32_direct(u16* __restrict__ base, long sn, const int* __restrict__ idx, long p0, int row0,
-                                               int rv, const unsigned (&pk)[2][4][2], const u16* __restrict__ mbase, long msn, int lane) {
-    const int n = lane & 15, kg = lane >> 4;
-#pragma unroll
-    for (int st = 0; st < 2; ++st)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = row0 + st * 16 + kg * 4 + r;
-            if (row < rv) {
-                const long tr = tok_row(idx, p0 + row);
-#pragma unroll
-                for (int tn = 0; tn < 4; ++tn) {
-                    u16 v = (u16)(pk[st][tn][r >> 1] >> ((r & 1) * 16));
-                    if (MASK && !(bf(mbase[tr * msn + tn * 16 + n]) > 0.f)) v = 0;
-                    base[tr * sn + tn * 16 + n] = v;
-                }
-            }
-        }
-}
-
 // -------------------------------------------------------------------------------------------------
-// k_fs_out: per (tile it, bh): the 8 waves mix the 8 summaries of the tile into LDS; then wave w owns block w:
-// O_i = (Q_i G_i) / n_i in two 32-row passes, staged in the block's own (dead) Gt slot -- no block barriers.
+// Arguments of the output kernel (k_t16_out, fused_tile16.cuh): mix the summaries of a tile into LDS, then
+// O_i = (Q_i G_i) / n_i per block, staged in the block's own (dead) LDS slot -- no block barriers.
 // -------------------------------------------------------------------------------------------------
 struct FsOutArgs {
     View q;
@@ -766,66 +604,6 @@ struct FsOutArgs {
 };
 constexpr int FS_GT_BYTES = IT * FD * GLD * 2;
 constexpr int FS_OUT_SMEM = FS_GT_BYTES;
-
-__global__ __launch_bounds__(FT8, 4) void k_fs_out(const FsOutArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    u16* Gt = reinterpret_cast<u16*>(smem_raw);   // [8][64 d2][72]
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, kg = lane >> 4;
-    const int L = xcd_swizzle(blockIdx.x, gridDim.x);
-    const int bh = L / a.njg, it = L - bh * a.njg, b = bh / a.H, h = bh - b * a.H;
-    const int S = a.S, M = a.M;
-    const u16* qb = (const u16*)a.q.ptr + b * a.q.sb + h * a.q.sh;
-    u16* ob = (u16*)a.o.ptr + b * a.o.sb + h * a.o.sh;
-    const float* ninv_bh = a.ninv + (long)bh * M * S;
-    const int i = it * IT + wave;          // this wave's block
-    u16* Gb = Gt + wave * FD * GLD;
-
-    auto load_half = [&](bf16x8 (&av)[2][2], int c0, int half, int rv) {
-        const long p0 = (long)i * S + c0 + half * 32;
-        if (a.relu) load_a32<true>(av, qb, a.q.sn, a.idx, p0, rv - half * 32, a.eps, lane);
-        else        load_a32<false>(av, qb, a.q.sn, a.idx, p0, rv - half * 32, a.eps, lane);
-    };
-    auto half_result = [&](unsigned (&pk)[2][4][2], const bf16x8 (&av)[2][2], float ninv, int half) {
-        f32x4 acc[2][4];
-        zero_acc(acc);
-        rows32_times_gt<false>(acc, av, Gb, lane);
-#pragma unroll
-        for (int st = 0; st < 2; ++st)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float ni = __shfl(ninv, half * 32 + st * 16 + kg * 4 + r, 64);
-#pragma unroll
-                for (int tn = 0; tn < 4; ++tn) acc[st][tn][r] *= ni;
-            }
-        pack_acc(pk, acc);
-    };
-
-    mix_tile_to_lds<0>(Gt, a.state + (long)bh * a.njg * FE * IT, a.njg, a.W, a.ldw, M, it * IT, tid);
-    __syncthreads();
-    if (i >= M) return;
-
-    for (int c0 = 0; c0 < S; c0 += 64) {
-        const int rv = min(64, S - c0);
-        bf16x8 av0[2][2], av1[2][2];
-        load_half(av0, c0, 0, rv);
-        load_half(av1, c0, 1, rv);
-        const float ninv = (a.normalize && lane < rv) ? ninv_bh[(long)i * S + c0 + lane] : 1.f;
-        unsigned pk0[2][4][2], pk1[2][4][2];
-        half_result(pk0, av0, ninv, 0);
-        half_result(pk1, av1, ninv, 1);
-        const long p0 = (long)i * S + c0;
-        if (c0 + 64 >= S) {   // last chunk of the block: its Gt slot is dead for this wave -> staging buffer
-            wave_lds_fence();
-            stage32(Gb, 0, pk0, lane);
-            stage32(Gb, 32, pk1, lane);
-            wave_lds_fence();
-            store64<false>(ob, a.o.sn, a.idx, p0, rv, Gb, nullptr, 0, lane);
-        } else {
-            store32_direct<false>(ob, a.o.sn, a.idx, p0, 0, rv, pk0, nullptr, 0, lane);
-            store32_direct<false>(ob, a.o.sn, a.idx, p0, 32, rv, pk1, nullptr, 0, lane);
-        }
-    }
-}
 
 // -------------------------------------------------------------------------------------------------
 // k_fs_dw: dWp[bh][q][i][j] = sum_{e' in quarter q} dG[i][e'] KV[j][e']   (both in the interleaved layout)
@@ -957,7 +735,7 @@ __global__ void k_fs_dw_reduce2(const float* __restrict__ tmp, float* __restrict
 }
 
 // -------------------------------------------------------------------------------------------------
-// k_fs_bwd_dq / k_fs_bwd_dkv: per (tile jg, bh); mixing by all 8 waves, then wave w owns block w:
+// Arguments of the token-gradient kernels (k_t16_bwd_dq / k_t16_bwd_dkv, fused_tile16.cuh):
 //   dq : Gt = mix(W, KV)    -> dQ_j = (dO_j G_j^T) / n_j + dz_j (x) ksum_j  (relu mask) ; dksum_j
 //   dkv: Gt = mix(W^T, dG)  -> dK_j = V_j dKV_j^T + 1 dksum_j^T (relu mask) ; dV_j = K_j dKV_j
 // -------------------------------------------------------------------------------------------------
@@ -978,207 +756,6 @@ struct FsTokArgs {
     int relu, normalize;
 };
 constexpr int FS_TOK_SMEM = FS_GT_BYTES;
-
-__global__ __launch_bounds__(FT8, 4) void k_fs_bwd_dq(const FsTokArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    u16* Gt = reinterpret_cast<u16*>(smem_raw);
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 15, kg = lane >> 4;
-    const int L = xcd_swizzle(blockIdx.x, gridDim.x);
-    const int bh = L / a.njg, jgx = L - bh * a.njg, b = bh / a.H, h = bh - b * a.H;
-    const int S = a.S, M = a.M;
-    const u16* qb = (const u16*)a.q.ptr + b * a.q.sb + h * a.q.sh;
-    const u16* gb = (const u16*)a.dout.ptr + b * a.dout.sb + h * a.dout.sh;
-    u16* dqb = (u16*)a.dq.ptr + b * a.dq.sb + h * a.dq.sh;
-    const int j = jgx * IT + wave;
-    u16* Gb = Gt + wave * FD * GLD;
-
-    float dks_acc[2][8];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int t = 0; t < 8; ++t) dks_acc[ks][t] = 0.f;
-
-    // one 32-row half: dQ rows (packed) and the half's contribution to dksum
-    auto half_result = [&](unsigned (&pk)[2][4][2], const bf16x8 (&gv)[2][2], float ninv, float dzv, float ksum_l, int c0,
-                           int half, int rv) {
-        f32x4 acc[2][4];
-        zero_acc(acc);
-        rows32_times_gt<true>(acc, gv, Gb, lane);   // (dO G^T)[s][d1] : B[k = d2][n = d1] = Gt[d2][d1]
-        if (a.normalize) {
-            bf16x8 qv[2][2];
-            const long p0 = (long)j * S + c0 + half * 32;
-            if (a.relu) load_a32<true>(qv, qb, a.q.sn, a.idx, p0, rv - half * 32, a.eps, lane);
-            else        load_a32<false>(qv, qb, a.q.sn, a.idx, p0, rv - half * 32, a.eps, lane);
-#pragma unroll
-            for (int st = 0; st < 2; ++st) {
-                const float dzr = __shfl(dzv, half * 32 + st * 16 + n, 64);
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    const s16x8 qs = __builtin_bit_cast(s16x8, qv[st][ks]);
-#pragma unroll
-                    for (int t = 0; t < 8; ++t) dks_acc[ks][t] += dzr * bf((u16)qs[t]);
-                }
-            }
-#pragma unroll
-            for (int st = 0; st < 2; ++st)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = half * 32 + st * 16 + kg * 4 + r;
-                    const float ni = __shfl(ninv, row, 64), dzr = __shfl(dzv, row, 64);
-#pragma unroll
-                    for (int tn = 0; tn < 4; ++tn) acc[st][tn][r] = acc[st][tn][r] * ni + dzr * __shfl(ksum_l, tn * 16 + n, 64);
-                }
-        }
-        pack_acc(pk, acc);
-    };
-    auto load_half = [&](bf16x8 (&gv)[2][2], int c0, int half, int rv) {
-        load_a32<false>(gv, gb, a.dout.sn, a.idx, (long)j * S + c0 + half * 32, rv - half * 32, 0.f, lane);
-    };
-
-    mix_tile_to_lds<0>(Gt, a.state + (long)bh * a.njg * FE * IT, a.njg, a.W, a.ldw, M, jgx * IT, tid);
-    __syncthreads();
-    if (j >= M) return;
-    const float ksum_l = a.normalize ? a.ksum[((long)bh * M + j) * 64 + lane] : 0.f;   // lane = column d1
-
-    for (int c0 = 0; c0 < S; c0 += 64) {
-        const int rv = min(64, S - c0);
-        bf16x8 gv0[2][2], gv1[2][2];
-        load_half(gv0, c0, 0, rv);
-        load_half(gv1, c0, 1, rv);
-        float ninv = 1.f, dzv = 0.f;
-        if (a.normalize && lane < rv) {
-            ninv = a.ninv[((long)bh * M + j) * S + c0 + lane];
-            dzv = a.dz[((long)bh * M + j) * S + c0 + lane];
-        }
-        unsigned pk0[2][4][2], pk1[2][4][2];
-        half_result(pk0, gv0, ninv, dzv, ksum_l, c0, 0, rv);
-        half_result(pk1, gv1, ninv, dzv, ksum_l, c0, 1, rv);
-        const long p0 = (long)j * S + c0;
-        if (c0 + 64 >= S) {
-            wave_lds_fence();
-            stage32(Gb, 0, pk0, lane);
-            stage32(Gb, 32, pk1, lane);
-            wave_lds_fence();
-            if (a.relu) store64<true>(dqb, a.dq.sn, a.idx, p0, rv, Gb, qb, a.q.sn, lane);
-            else        store64<false>(dqb, a.dq.sn, a.idx, p0, rv, Gb, nullptr, 0, lane);
-        } else {
-            if (a.relu) {
-                store32_direct<true>(dqb, a.dq.sn, a.idx, p0, 0, rv, pk0, qb, a.q.sn, lane);
-                store32_direct<true>(dqb, a.dq.sn, a.idx, p0, 32, rv, pk1, qb, a.q.sn, lane);
-            } else {
-                store32_direct<false>(dqb, a.dq.sn, a.idx, p0, 0, rv, pk0, nullptr, 0, lane);
-                store32_direct<false>(dqb, a.dq.sn, a.idx, p0, 32, rv, pk1, nullptr, 0, lane);
-            }
-        }
-    }
-    if (a.normalize) {   // dksum[col]: reduce the per-lane partials over the 16 row-lanes (n); col = 32 ks + 8 kg + t
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                float v = dks_acc[ks][t];
-                v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64);
-                v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-                if (n == 0) a.dksum[((long)bh * M + j) * 64 + ks * 32 + kg * 8 + t] = v;
-            }
-    }
-}
-
-__global__ __launch_bounds__(FT8, 4) void k_fs_bwd_dkv(const FsTokArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    u16* Gt = reinterpret_cast<u16*>(smem_raw);
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 15;
-    const int L = xcd_swizzle(blockIdx.x, gridDim.x);
-    const int bh = L / a.njg, jgx = L - bh * a.njg, b = bh / a.H, h = bh - b * a.H;
-    const int S = a.S, M = a.M;
-    const u16* kb = (const u16*)a.k.ptr + b * a.k.sb + h * a.k.sh;
-    const u16* vb = (const u16*)a.v.ptr + b * a.v.sb + h * a.v.sh;
-    u16* dkb = (u16*)a.dk.ptr + b * a.dk.sb + h * a.dk.sh;
-    u16* dvb = (u16*)a.dv.ptr + b * a.dv.sb + h * a.dv.sh;
-    const int j = jgx * IT + wave;
-    u16* Gb = Gt + wave * FD * GLD;
-
-    auto load_k = [&](bf16x8 (&kv)[2][2], int c0, int half, int rv) {
-        const long p0 = (long)j * S + c0 + half * 32;
-        if (a.relu) load_a32<true>(kv, kb, a.k.sn, a.idx, p0, rv - half * 32, a.eps, lane);
-        else        load_a32<false>(kv, kb, a.k.sn, a.idx, p0, rv - half * 32, a.eps, lane);
-    };
-    auto load_v = [&](bf16x8 (&vv)[2][2], int c0, int half, int rv) {
-        load_a32<false>(vv, vb, a.v.sn, a.idx, (long)j * S + c0 + half * 32, rv - half * 32, 0.f, lane);
-    };
-
-    mix_tile_to_lds<1>(Gt, a.dstate + (long)bh * a.njg * FE * IT, a.njg, a.W, a.ldw, M, jgx * IT, tid);
-    __syncthreads();
-    if (j >= M) return;
-
-    for (int c0 = 0; c0 < S; c0 += 64) {
-        const int rv = min(64, S - c0);
-        const long p0 = (long)j * S + c0;
-        const bool last = c0 + 64 >= S;
-        // all four 32-row products need the intact Gb; results stay packed (bf16 pairs) until the last MFMA
-        unsigned pV0[2][4][2], pV1[2][4][2], pK0[2][4][2], pK1[2][4][2];
-        {
-            bf16x8 kv[2][2];
-            f32x4 acc[2][4];
-            load_k(kv, c0, 0, rv);
-            zero_acc(acc);
-            rows32_times_gt<false>(acc, kv, Gb, lane);   // dV[s][d2] = sum_d1 K[s][d1] dKVt[d2][d1]
-            pack_acc(pV0, acc);
-            load_k(kv, c0, 1, rv);
-            zero_acc(acc);
-            rows32_times_gt<false>(acc, kv, Gb, lane);
-            pack_acc(pV1, acc);
-        }
-        float dk[4] = {0.f, 0.f, 0.f, 0.f};
-        if (a.normalize) {
-#pragma unroll
-            for (int tn = 0; tn < 4; ++tn) dk[tn] = a.dksum[((long)bh * M + j) * 64 + tn * 16 + n];
-        }
-        {
-            bf16x8 vv[2][2];
-            f32x4 acc[2][4];
-            load_v(vv, c0, 0, rv);
-            zero_acc(acc);
-            rows32_times_gt<true>(acc, vv, Gb, lane);    // dK[s][d1] = sum_d2 V[s][d2] dKVt[d2][d1]
-#pragma unroll
-            for (int st = 0; st < 2; ++st)
-#pragma unroll
-                for (int tn = 0; tn < 4; ++tn) acc[st][tn] += dk[tn];
-            pack_acc(pK0, acc);
-            load_v(vv, c0, 1, rv);
-            zero_acc(acc);
-            rows32_times_gt<true>(acc, vv, Gb, lane);
-#pragma unroll
-            for (int st = 0; st < 2; ++st)
-#pragma unroll
-                for (int tn = 0; tn < 4; ++tn) acc[st][tn] += dk[tn];
-            pack_acc(pK1, acc);
-        }
-        if (last) {
-            wave_lds_fence();
-            stage32(Gb, 0, pK0, lane);
-            stage32(Gb, 32, pK1, lane);
-            wave_lds_fence();
-            if (a.relu) store64<true>(dkb, a.dk.sn, a.idx, p0, rv, Gb, kb, a.k.sn, lane);
-            else        store64<false>(dkb, a.dk.sn, a.idx, p0, rv, Gb, nullptr, 0, lane);
-            wave_lds_fence();
-            stage32(Gb, 0, pV0, lane);
-            stage32(Gb, 32, pV1, lane);
-            wave_lds_fence();
-            store64<false>(dvb, a.dv.sn, a.idx, p0, rv, Gb, nullptr, 0, lane);
-        } else {
-            if (a.relu) {
-                store32_direct<true>(dkb, a.dk.sn, a.idx, p0, 0, rv, pK0, kb, a.k.sn, lane);
-                store32_direct<true>(dkb, a.dk.sn, a.idx, p0, 32, rv, pK1, kb, a.k.sn, lane);
-            } else {
-                store32_direct<false>(dkb, a.dk.sn, a.idx, p0, 0, rv, pK0, nullptr, 0, lane);
-                store32_direct<false>(dkb, a.dk.sn, a.idx, p0, 32, rv, pK1, nullptr, 0, lane);
-            }
-            store32_direct<false>(dvb, a.dv.sn, a.idx, p0, 0, rv, pV0, nullptr, 0, lane);
-            store32_direct<false>(dvb, a.dv.sn, a.idx, p0, 32, rv, pV1, nullptr, 0, lane);
-        }
-    }
-}
 
 }  // namespace fast
 }  // namespace mhla
