@@ -97,24 +97,34 @@ template <typename T, int DP, bool RELU>
 __device__ __forceinline__ void load_tile(float* __restrict__ dst, int ld, const T* __restrict__ base, long sn,
                                           const int* __restrict__ idx, long p0, int rows_valid, int rows_fill,
                                           int cols_valid, float eps, int tid, int nthreads) {
-    constexpr int CV = DP / 4;
-    for (int v = tid; v < rows_fill * CV; v += nthreads) {
-        const int r = v / CV, c = (v - r * CV) * 4;
-        f32x4 x = {0.f, 0.f, 0.f, 0.f};
-        if (r < rows_valid && c < cols_valid) {
-            x = Io<T>::ld4(base + tok_row(idx, p0 + r) * sn + c);
-            if (RELU) {
+    constexpr int CV = DP / 4, U = 4;
+    // all global loads of a batch first, LDS stores after: interleaved load/store pairs are serialised by the compiler
+    for (int v0 = tid; v0 < rows_fill * CV; v0 += nthreads * U) {
+        f32x4 x[U];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) x[i] = fmaxf(x[i], 0.f) + eps;
+        for (int u = 0; u < U; ++u) {
+            const int v = v0 + u * nthreads, r = v / CV, c = (v - r * CV) * 4;
+            x[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (v < rows_fill * CV && r < rows_valid && c < cols_valid) {
+                x[u] = Io<T>::ld4(base + tok_row(idx, p0 + r) * sn + c);
+                if (RELU) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) x[u][i] = fmaxf(x[u][i], 0.f) + eps;
+                }
             }
         }
-        float* d = dst + r * ld + c;
-        if ((ld & 3) == 0) {
-            *reinterpret_cast<f32x4*>(d) = x;
-        } else {
-            f32x2 lo = {x[0], x[1]}, hi = {x[2], x[3]};
-            *reinterpret_cast<f32x2*>(d) = lo;
-            *reinterpret_cast<f32x2*>(d + 2) = hi;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int v = v0 + u * nthreads, r = v / CV, c = (v - r * CV) * 4;
+            if (v < rows_fill * CV) {
+                float* d = dst + r * ld + c;
+                if ((ld & 3) == 0) {
+                    *reinterpret_cast<f32x4*>(d) = x[u];
+                } else {
+                    *reinterpret_cast<f32x2*>(d) = f32x2{x[u][0], x[u][1]};
+                    *reinterpret_cast<f32x2*>(d + 2) = f32x2{x[u][2], x[u][3]};
+                }
+            }
         }
     }
 }
@@ -124,27 +134,36 @@ template <int DP>
 __device__ __forceinline__ void load_mat_f32(float* __restrict__ dst, int ld, const float* __restrict__ src,
                                              long src_ld, int rows_valid, int rows_fill, int cols_valid, int tid,
                                              int nthreads, bool vec_ok) {
-    constexpr int CV = DP / 4;
-    for (int v = tid; v < rows_fill * CV; v += nthreads) {
-        const int r = v / CV, c = (v - r * CV) * 4;
-        f32x4 x = {0.f, 0.f, 0.f, 0.f};
-        if (r < rows_valid && c < cols_valid) {
-            const float* s = src + (long)r * src_ld + c;
-            if (vec_ok && c + 3 < cols_valid) {
-                x = *reinterpret_cast<const f32x4*>(s);
-            } else {
+    constexpr int CV = DP / 4, U = 4;
+    for (int v0 = tid; v0 < rows_fill * CV; v0 += nthreads * U) {
+        f32x4 x[U];
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (c + i < cols_valid) x[i] = s[i];
+        for (int u = 0; u < U; ++u) {
+            const int v = v0 + u * nthreads, r = v / CV, c = (v - r * CV) * 4;
+            x[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (v < rows_fill * CV && r < rows_valid && c < cols_valid) {
+                const float* s = src + (long)r * src_ld + c;
+                if (vec_ok && c + 3 < cols_valid) {
+                    x[u] = *reinterpret_cast<const f32x4*>(s);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (c + i < cols_valid) x[u][i] = s[i];
+                }
             }
         }
-        float* d = dst + r * ld + c;
-        if ((ld & 3) == 0) {
-            *reinterpret_cast<f32x4*>(d) = x;
-        } else {
-            f32x2 lo = {x[0], x[1]}, hi = {x[2], x[3]};
-            *reinterpret_cast<f32x2*>(d) = lo;
-            *reinterpret_cast<f32x2*>(d + 2) = hi;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int v = v0 + u * nthreads, r = v / CV, c = (v - r * CV) * 4;
+            if (v < rows_fill * CV) {
+                float* d = dst + r * ld + c;
+                if ((ld & 3) == 0) {
+                    *reinterpret_cast<f32x4*>(d) = x[u];
+                } else {
+                    *reinterpret_cast<f32x2*>(d) = f32x2{x[u][0], x[u][1]};
+                    *reinterpret_cast<f32x2*>(d + 2) = f32x2{x[u][2], x[u][3]};
+                }
+            }
         }
     }
 }

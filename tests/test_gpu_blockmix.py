@@ -216,3 +216,28 @@ def test_full_size_c2_properties_and_sampled_heads():
     mask[5 * S:6 * S] = False
     assert torch.equal(oa[:, mask], ob[:, mask])
     assert not torch.equal(oa[:, ~mask], ob[:, ~mask])
+
+
+def test_full_size_c4_wan_sampled_head():
+    """BASELINE config C4 (Wan2.1-1.3B: N = 31500 = 150 blocks x 210 tokens, H = 12, D = 128, fp32, roped numerator pair
+    / un-roped normaliser pair, raster tokens gathered through the block index): forward on all heads, one head vs oracle."""
+    import mhla_amd
+    B, H, D, layout, grid = 1, 12, 128, (3, 5, 10), (21, 30, 50)
+    N, M = 21 * 30 * 50, 150
+    g = torch.Generator().manual_seed(99)
+    q = torch.relu(torch.randn(B, N, H, D, generator=g)) + 1e-6
+    k = torch.relu(torch.randn(B, N, H, D, generator=g)) + 1e-6
+    v = torch.randn(B, N, H, D, generator=g)
+    qr = q * torch.sign(torch.randn(B, N, H, D, generator=g))
+    kr = k * torch.sign(torch.randn(B, N, H, D, generator=g))
+    W = orc.block_distance_weights(layout, "linear")
+    idx = orc.block_index_3d(grid, layout)
+    out = mhla_amd.mhla_blockmix(qr.to(DEV), kr.to(DEV), v.to(DEV), W.to(DEV), q_den=q.to(DEV), k_den=k.to(DEV),
+                                 block_index=idx.int().to(DEV))
+    h = 7
+    sl = lambda t: t[:, idx][:, :, h:h + 1]
+    want = orc.blockmix_fwd(sl(qr), sl(kr), sl(v), W, 1e-6, q_den=sl(q), k_den=sl(k))
+    check("out", out[:, idx.to(DEV)][:, :, h:h + 1], want, 1e-3)
+    out2 = mhla_amd.mhla_blockmix(qr.to(DEV), kr.to(DEV), v.to(DEV), W.to(DEV), normalize=False, block_index=idx.int().to(DEV))
+    want2 = orc.blockmix_fwd(sl(qr), sl(kr), sl(v), W, 1e-6, normalize=False)
+    check("out_nonorm", out2[:, idx.to(DEV)][:, :, h:h + 1], want2, 1e-3)

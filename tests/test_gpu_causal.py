@@ -111,3 +111,22 @@ def test_golden_fla_neighbours_gate():
     g = load_golden("fla_neighbours")
     y = mhla_amd.rmsnorm_gate(g["o"].to(DEV), g["g"].to(DEV), g["w"].to(DEV), 1e-5)
     check("gated", y, g["gated"], 1e-5)
+
+
+def test_full_size_c5_sampled_head():
+    """BASELINE config C5 shape (fla 340M: T = 8192, H = 4, K = 128, V = 256, 128 chunks), bf16: one (b, h) vs the oracle,
+    forward and backward."""
+    import mhla_amd
+    B, T, H, K, V, L = 2, 8192, 4, 128, 256, 128
+    q, k, v, mix, do = causal_inputs(B, T, H, K, V, L, torch.bfloat16, seed=8, random_mix=False)
+    dq, dk, dv, dm = (t.to(DEV).requires_grad_(True) for t in (q, k, v, mix))
+    out = mhla_amd.mhla_causal(dq, dk, dv, dm)
+    out.backward(do.to(DEV))
+    b, h = 1, 2
+    sl = lambda t: t[b:b + 1, :, h:h + 1].float()
+    want = orc.causal_fwd(sl(q), sl(k), sl(v), mix)
+    wg = orc.causal_bwd(sl(q), sl(k), sl(v), mix, sl(do))
+    check("out", sl(out), want, TOL[torch.bfloat16])
+    check("dq", sl(dq.grad), wg["dq"], GTOL[torch.bfloat16])
+    check("dk", sl(dk.grad), wg["dk"], GTOL[torch.bfloat16])
+    check("dv", sl(dv.grad), wg["dv"], GTOL[torch.bfloat16])
