@@ -19,6 +19,57 @@ constexpr int NTHREADS = 256;
 
 __host__ __device__ constexpr int bm_chunk(int DT) { return DT <= 5 ? 64 : 32; }
 
+// out[bh][r][s] = f(sum_c Wm(r, c) x[bh][c][s])  -- the two small [M x M] x [M x S] products of the normaliser path:
+//   MODE 0: Wm = W,   f(v) = 1 / (eps + v)   -> 1/n      MODE 1: Wm = W^T, f(v) = v -> dz = W^T dn
+// grid (ceil(S/64), ceil(M/64), bh); LDS tiles of 64 x 64, all global loads of a tile issued before the LDS stores.
+template <int MODE>
+__global__ __launch_bounds__(NTHREADS) void k_wz(const float* __restrict__ W, int ldw, const float* __restrict__ x,
+                                                 float* __restrict__ out, int M, int S, float eps) {
+    __shared__ float Ws[64 * 65];
+    __shared__ __attribute__((aligned(16))) float xs[64 * 64];
+    const int tid = threadIdx.x, c0 = blockIdx.x * 64, r0 = blockIdx.y * 64, bh = blockIdx.z, rv = min(64, S - c0);
+    const int sq = tid & 15, rq = tid >> 4;
+    f32x4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < M; k0 += 64) {
+        float wreg[16], xreg[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int v = tid + t * NTHREADS, r = v >> 6, c = v & 63;
+            const int gr = r0 + r, gk = k0 + c;       // Ws[r][c] = Wm(r0 + r, k0 + c)
+            wreg[t] = (gr < M && gk < M) ? (MODE ? W[(long)gk * ldw + gr] : W[(long)gr * ldw + gk]) : 0.f;
+            const int xr = k0 + r;                     // xs[r][c] = x[k0 + r][c0 + c]
+            xreg[t] = (xr < M && c < rv) ? x[((long)bh * M + xr) * S + c0 + c] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int v = tid + t * NTHREADS, r = v >> 6, c = v & 63;
+            Ws[r * 65 + c] = wreg[t];
+            xs[r * 64 + c] = xreg[t];
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int c = 0; c < 64; ++c) {
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(xs + c * 64 + sq * 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] += Ws[(rq + 16 * i) * 65 + c] * xv;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + rq + 16 * i;
+        if (r < M) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int sc = sq * 4 + t;
+                if (sc < rv) out[((long)bh * M + r) * S + c0 + sc] = MODE ? acc[i][t] : 1.f / (eps + acc[i][t]);
+            }
+        }
+    }
+}
+
 struct StateArgs {
     View x, y;        // MODE 0: k_num, v        MODE 1: q_num, dout
     View kd, qd;      // MODE 0: k_den, q_den    (used when normalize)
@@ -26,7 +77,7 @@ struct StateArgs {
     const int* idx;
     const float* W;   // MODE 1
     int ldw;
-    const float* z;   // MODE 1 in  [bh][M][S]
+    const float* ninv;   // MODE 1 in  [bh][M][S]  1 / n  (k_wz<0>)
     float* out;       // [bh][M][D][D]
     float* ksum;      // MODE 0 out [bh][M][D]
     float* zo;        // MODE 0 out [bh][M][S]
@@ -121,14 +172,7 @@ __global__ __launch_bounds__(NTHREADS) void k_bm_state(const StateArgs a) {
             if (a.normalize) {
                 const T* ob = (const T*)a.o.ptr + b * a.o.sb + h * a.o.sh;
                 load_tile<T, DP, false>(Es, LD, ob, a.o.sn, a.idx, p0 + c0, rv, kend, D, 0.f, tid, NTHREADS);
-                // n_i[s] = sum_j W[i][j] z_j[s] + eps
-                for (int r = tid; r < rv; r += NTHREADS) {
-                    const float* zr = a.z + (long)bh * a.M * S + c0 + r;
-                    const float* wr = a.W + (long)blk * a.ldw;
-                    float n = a.eps;
-                    for (int j = 0; j < a.M; ++j) n += wr[j] * zr[(long)j * S];
-                    vecr[r] = 1.f / n;
-                }
+                for (int r = tid; r < rv; r += NTHREADS) vecr[r] = a.ninv[((long)bh * a.M + blk) * S + c0 + r];
             }
             __syncthreads();
             if (a.normalize) {
@@ -291,7 +335,7 @@ struct OutArgs {
     const float* W;
     int ldw;
     const float* g;   // [bh][M][D][D]
-    const float* z;   // [bh][M][S]
+    const float* ninv;   // [bh][M][S]  1 / n  (k_wz<0>)
     int H, M, S, D;
     float eps;
     int relu, normalize;
@@ -347,15 +391,7 @@ __global__ __launch_bounds__(NTHREADS) void k_bm_out(const OutArgs a) {
         if (a.relu) load_tile<T, DP, true>(Qs, LDQ, qb, a.q.sn, a.idx, p0 + c0, rv, rpad, D, a.eps, tid, NTHREADS);
         else        load_tile<T, DP, false>(Qs, LDQ, qb, a.q.sn, a.idx, p0 + c0, rv, rpad, D, a.eps, tid, NTHREADS);
         for (int r = tid; r < rv; r += NTHREADS) {
-            float inv = 1.f;
-            if (a.normalize) {
-                const float* zr = a.z + (long)bh * a.M * S + c0 + r;
-                const float* wr = a.W + (long)blk * a.ldw;
-                float n = a.eps;
-                for (int j = 0; j < a.M; ++j) n += wr[j] * zr[(long)j * S];
-                inv = 1.f / n;
-            }
-            ninv[r] = inv;
+            ninv[r] = a.normalize ? a.ninv[((long)bh * a.M + blk) * S + c0 + r] : 1.f;
         }
         __syncthreads();
         f32x4 acc[NT];
@@ -490,8 +526,8 @@ struct TokArgs {
     int ldw;
     const float* g;      // [bh][M][D][D]
     const float* dkv;    // [bh][M][D][D]
-    const float* z;      // [bh][M][S]
-    const float* dn;     // [bh][M][S]
+    const float* ninv;   // [bh][M][S]  1 / n  (k_wz<0>)
+    const float* dz;     // [bh][M][S]  W^T dn (k_wz<1>)
     const float* ksum;   // [bh][M][D]
     int H, M, S, D;
     float eps;
@@ -535,18 +571,8 @@ __global__ __launch_bounds__(NTHREADS) void k_bm_bwd_tok(const TokArgs a) {
         if (a.relu) load_tile<T, DP, true>(T2, LD, base(a.qd), a.qd.sn, a.idx, p0 + c0, rv, rpad, D, a.eps, tid, NTHREADS);
         else        load_tile<T, DP, false>(T2, LD, base(a.qd), a.qd.sn, a.idx, p0 + c0, rv, rpad, D, a.eps, tid, NTHREADS);
         for (int r = tid; r < rv; r += NTHREADS) {
-            float inv = 1.f, dzv = 0.f;
-            if (a.normalize) {
-                const float* zr = a.z + (long)bh * M * S + c0 + r;
-                const float* dnr = a.dn + (long)bh * M * S + c0 + r;
-                const float* wr = a.W + (long)blk * a.ldw;
-                float n = a.eps;
-                for (int j = 0; j < M; ++j) n += wr[j] * zr[(long)j * S];
-                inv = 1.f / n;
-                for (int i = 0; i < M; ++i) dzv += a.W[(long)i * a.ldw + blk] * dnr[(long)i * S];
-            }
-            ninv[r] = inv;
-            dz[r] = dzv;
+            ninv[r] = a.normalize ? a.ninv[((long)bh * M + blk) * S + c0 + r] : 1.f;
+            dz[r] = a.normalize ? a.dz[((long)bh * M + blk) * S + c0 + r] : 0.f;
         }
         __syncthreads();
         if (a.normalize) {

@@ -100,7 +100,7 @@ int dt_for(int D) { return D <= 32 ? 2 : D <= 64 ? 4 : D <= 80 ? 5 : D <= 96 ? 6
     }
 
 struct BmWs {
-    float *kv, *g, *z, *ksum, *dg, *dkv, *dn, *dwp;
+    float *kv, *g, *z, *ksum, *ninv, *dg, *dkv, *dn, *dz, *dwp;
     size_t total_fwd, total_bwd;
 };
 BmWs bm_carve(void* ws, int B, int H, int M, int S, int D) {
@@ -111,10 +111,12 @@ BmWs bm_carve(void* ws, int B, int H, int M, int S, int D) {
     w.g = p; p += st;
     w.z = p; p += zs;
     w.ksum = p; p += ks;
+    w.ninv = p; p += zs;
     w.total_fwd = (size_t)(p - (float*)ws) * 4;
     w.dg = p; p += st;
     w.dkv = p; p += st;
     w.dn = p; p += zs;
+    w.dz = p; p += zs;
     w.dwp = p; p += al4(bh * M * M);
     w.total_bwd = (size_t)(p - (float*)ws) * 4;
     return w;
@@ -177,6 +179,8 @@ int bm_state_and_mix(const mhla_view& q_num, const mhla_view& k_num, const mhla_
     MixArgs m{W, ldw, w.kv, w.g, M, (long)D * D};
     dim3 grid((unsigned)((m.E + MIX_TE - 1) / MIX_TE), (M + MIX_TI - 1) / MIX_TI, B * H);
     RC(launch(k_mix<0, 0>, grid, dim3(NTHREADS), MIX_SMEM_FLOATS * 4, st, "k_mix<0,0>", m));
+    if (normalize)
+        RC(launch(k_wz<0>, dim3((S + 63) / 64, (M + 63) / 64, B * H), dim3(NTHREADS), 0, st, "k_wz<0>", W, ldw, (const float*)w.z, w.ninv, M, S, eps));
     return MHLA_OK;
 }
 
@@ -318,7 +322,7 @@ int mhla_blockmix_fwd(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q
     DISPATCH_T(dtype, DISPATCH_DT(dt, {
         RC((bm_state_and_mix<ET, DT>(q_num, k_num, v, q_den, k_den, W, ldw, block_index, w, B, H, M, S, D, eps, flags, normalize, split, st)));
         OutArgs o{};
-        o.q = cv(q_num); o.o = cmv(out); o.idx = block_index; o.W = W; o.ldw = ldw; o.g = w.g; o.z = w.z;
+        o.q = cv(q_num); o.o = cmv(out); o.idx = block_index; o.W = W; o.ldw = ldw; o.g = w.g; o.ninv = w.ninv;
         o.H = H; o.M = M; o.S = S; o.D = D; o.eps = eps;
         o.relu = (flags & MHLA_FLAG_RELU_EPS) ? 1 : 0; o.normalize = normalize;
         RC(launch(k_bm_out<ET, DT>, dim3(M, B * H), dim3(NTHREADS), out_smem_floats<DT>() * 4, st, "k_bm_out", o));
@@ -394,10 +398,12 @@ int mhla_blockmix_bwd(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q
         RC((bm_state_and_mix<ET, DT>(q_num, k_num, v, q_den, k_den, W, ldw, block_index, w, B, H, M, S, D, eps, flags, normalize, split, st)));
         // dG_i = Q_i^T (dO_i / n_i), dn_i
         StateArgs a{};
-        a.x = cv(q_num); a.y = cv(dout); a.o = cv(out); a.idx = block_index; a.W = W; a.ldw = ldw; a.z = w.z;
+        a.x = cv(q_num); a.y = cv(dout); a.o = cv(out); a.idx = block_index; a.W = W; a.ldw = ldw; a.ninv = w.ninv;
         a.out = w.dg; a.dn = w.dn; a.H = H; a.M = M; a.S = S; a.D = D; a.eps = eps;
         a.relu = relu; a.normalize = normalize; a.split = split;
         RC(launch(k_bm_state<ET, DT, 1>, dim3(M, B * H), dim3(NTHREADS), state_smem_floats<DT>() * 4, st, "k_bm_state<1>", a));
+        if (normalize)
+            RC(launch(k_wz<1>, dim3((S + 63) / 64, (M + 63) / 64, B * H), dim3(NTHREADS), 0, st, "k_wz<1>", W, ldw, (const float*)w.dn, w.dz, M, S, 0.f));
         // dKV = W^T dG
         MixArgs m{W, ldw, w.dg, w.dkv, M, (long)D * D};
         dim3 mgrid((unsigned)((m.E + MIX_TE - 1) / MIX_TE), (M + MIX_TI - 1) / MIX_TI, B * H);
@@ -412,7 +418,7 @@ int mhla_blockmix_bwd(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q
         TokArgs t{};
         t.q = cv(q_num); t.k = cv(k_num); t.v = cv(v); t.qd = cv(q_den); t.kd = cv(k_den); t.dout = cv(dout);
         t.dq = cmv(dq_num); t.dk = cmv(dk_num); t.dv = cmv(dv); t.dqd = cmv(dq_den); t.dkd = cmv(dk_den);
-        t.idx = block_index; t.W = W; t.ldw = ldw; t.g = w.g; t.dkv = w.dkv; t.z = w.z; t.dn = w.dn; t.ksum = w.ksum;
+        t.idx = block_index; t.W = W; t.ldw = ldw; t.g = w.g; t.dkv = w.dkv; t.ninv = w.ninv; t.dz = w.dz; t.ksum = w.ksum;
         t.H = H; t.M = M; t.S = S; t.D = D; t.eps = eps; t.relu = relu; t.normalize = normalize; t.split = split;
         RC(launch(k_bm_bwd_tok<ET, DT>, dim3(M, B * H), dim3(NTHREADS), tok_smem_floats<DT>() * 4, st, "k_bm_bwd_tok", t));
     }));
