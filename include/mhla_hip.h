@@ -48,6 +48,7 @@ enum {
 /* flags */
 #define MHLA_FLAG_RELU_EPS 1u      /* apply relu(x)+eps to q,k while loading (mhla_dit/mhla/mhla.py:229-230) */
 #define MHLA_FLAG_FORCE_GENERIC 2u /* testing aid: take the generic fp32-MFMA path even where the bf16 fast path applies */
+#define MHLA_FLAG_NO_SMALLN 4u     /* testing aid: skip the single-launch small-sequence path (S = 16, N <= 256) */
 
 /* A token-major view [B, N, H, D]: element strides, D contiguous. */
 typedef struct {
@@ -75,6 +76,8 @@ int mhla_prof_report(char* buf, size_t cap);
  * split: 1 when q_den/k_den do not alias q_num/k_num; flags: the flags of the call). */
 size_t mhla_blockmix_fwd_ws_bytes(int B, int H, int M, int S, int D, int dtype, int split, unsigned flags);
 size_t mhla_blockmix_bwd_ws_bytes(int B, int H, int M, int S, int D, int dtype, int split, unsigned flags);
+/* 1 when the forward leaves reusable block summaries in `ws` (pass that buffer as `fwd_ws` to the backward). */
+int mhla_blockmix_fwd_keeps_state(int B, int H, int M, int S, int D, int dtype, int split, unsigned flags);
 
 /*
  * Forward.  Replaces mhla_dit/mhla/mhla.py:262-268 (identical:

@@ -11,6 +11,7 @@ ABI_VERSION = 2
 F32, BF16, F16 = 0, 1, 2
 FLAG_RELU_EPS = 1
 FLAG_FORCE_GENERIC = 2
+FLAG_NO_SMALLN = 4
 
 
 class View(Structure):
@@ -28,6 +29,7 @@ SIGNATURES = {
     "mhla_prof_report": (c_int, [c_char_p, c_size_t]),
     "mhla_blockmix_fwd_ws_bytes": (c_size_t, [c_int] * 7 + [c_uint]),
     "mhla_blockmix_bwd_ws_bytes": (c_size_t, [c_int] * 7 + [c_uint]),
+    "mhla_blockmix_fwd_keeps_state": (c_int, [c_int] * 7 + [c_uint]),
     "mhla_blockmix_fwd": (c_int, [View, View, View, View, View, c_void_p, c_int, View, c_void_p, c_void_p, c_size_t,
                                   c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_uint, c_void_p]),
     "mhla_blockmix_bwd": (c_int, [View, View, View, View, View, c_void_p, c_int, View, View, View, View, View, View,

@@ -12,7 +12,7 @@ SRC = os.path.join(HERE, "csrc", "capi.hip")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libmhla_hip.so")
 DEPS = [os.path.join(HERE, "csrc", f) for f in ("capi.hip", "common.cuh", "blockmix.cuh", "causal.cuh", "epilogue.cuh",
-                                               "fused.cuh", "fused_tile16.cuh")] + [os.path.join(os.path.dirname(HERE), "include", "mhla_hip.h")]
+                                               "fused.cuh", "fused_tile16.cuh", "smalln.cuh")] + [os.path.join(os.path.dirname(HERE), "include", "mhla_hip.h")]
 
 
 def hipcc_path() -> str:

@@ -16,6 +16,7 @@
 #include "epilogue.cuh"
 #include "fused.cuh"
 #include "fused_tile16.cuh"
+#include "smalln.cuh"
 
 using namespace mhla;
 
@@ -151,13 +152,17 @@ FastWs fast_carve(void* ws, int B, int H, int M, int S) {
 }
 bool view_ok16(const mhla_view& v) { return v.ptr && ((uintptr_t)v.ptr % 16) == 0 && ((v.sb | v.sn | v.sh) & 7) == 0; }
 bool fast_shape_ok(int M, int D, int dtype, bool split) { return dtype == MHLA_BF16 && D == 64 && M <= 64 && !split; }
+// small-sequence single-launch path (smalln.cuh): S = 16 tokens per block, at most 16 blocks, D <= 80
+bool sn_shape_ok(int M, int S, int D, int dtype, bool split) {
+    return dtype == MHLA_BF16 && S == 16 && M <= 16 && D <= 80 && (D & 7) == 0 && !split;
+}
 
 int bm_check(int B, int H, int M, int S, int D, int dtype, unsigned flags, bool normalize, bool split) {
     if (B <= 0 || H <= 0 || M <= 0 || S <= 0 || D <= 0) return fail(MHLA_EINVAL, "non-positive dimension B=%d H=%d M=%d S=%d D=%d", B, H, M, S, D);
     if (D % 4) return fail(MHLA_EINVAL, "D=%d must be a multiple of 4", D);
     if (!dt_for(D)) return fail(MHLA_ENOTSUP, "block-mix head dim D=%d > 128 not supported", D);
     if (dtype < 0 || dtype > 2) return fail(MHLA_EINVAL, "unknown dtype %d", dtype);
-    if (flags & ~(MHLA_FLAG_RELU_EPS | MHLA_FLAG_FORCE_GENERIC)) return fail(MHLA_EINVAL, "unknown flags 0x%x", flags);
+    if (flags & ~(MHLA_FLAG_RELU_EPS | MHLA_FLAG_FORCE_GENERIC | MHLA_FLAG_NO_SMALLN)) return fail(MHLA_EINVAL, "unknown flags 0x%x", flags);
     if ((flags & MHLA_FLAG_RELU_EPS) && split) return fail(MHLA_EINVAL, "MHLA_FLAG_RELU_EPS needs q_den/k_den to alias q_num/k_num");
     if ((size_t)B * H > 65535) return fail(MHLA_ENOTSUP, "B*H=%zu exceeds grid limit 65535", (size_t)B * H);
     (void)normalize;
@@ -276,6 +281,15 @@ int mhla_prof_report(char* buf, size_t cap) {
 }
 const char* mhla_last_error(void) { return g_err; }
 
+// 1 when mhla_blockmix_fwd leaves reusable block summaries in its workspace for this problem (pass it as fwd_ws to the
+// backward), 0 when the forward is stateless (generic recompute / small-sequence path).
+int mhla_blockmix_fwd_keeps_state(int B, int H, int M, int S, int D, int dtype, int split, unsigned flags) {
+    (void)B; (void)H;
+    if (flags & MHLA_FLAG_FORCE_GENERIC) return 0;
+    if (sn_shape_ok(M, S, D, dtype, split != 0) && !(flags & MHLA_FLAG_NO_SMALLN)) return 0;
+    return fast_shape_ok(M, D, dtype, split != 0) ? 1 : 0;
+}
+
 // Upper bound over the paths the library may take for this problem (the fast path needs less).
 size_t mhla_blockmix_fwd_ws_bytes(int B, int H, int M, int S, int D, int dtype, int split, unsigned flags) {
     if (fast_shape_ok(M, D, dtype, split != 0) && !(flags & MHLA_FLAG_FORCE_GENERIC)) return fast_carve(nullptr, B, H, M, S).total_fwd;
@@ -300,6 +314,15 @@ int mhla_blockmix_fwd(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q
     if (!normalize) { q_den = q_num; k_den = k_num; }
     const int relu = (flags & MHLA_FLAG_RELU_EPS) ? 1 : 0;
     const mhla_view outv{out.ptr, out.sb, out.sn, out.sh};
+    if (sn_shape_ok(M, S, D, dtype, split) && !(flags & (MHLA_FLAG_FORCE_GENERIC | MHLA_FLAG_NO_SMALLN)) && view_ok16(q_num) &&
+        view_ok16(k_num) && view_ok16(v) && view_ok16(outv)) {
+        fast::SnArgs sa{};
+        sa.q = cv(q_num); sa.k = cv(k_num); sa.v = cv(v); sa.out = cmv(out); sa.idx = block_index; sa.W = W; sa.ldw = ldw;
+        sa.H = H; sa.M = M; sa.D = D; sa.eps = eps; sa.relu = relu; sa.normalize = normalize;
+        if (D <= 64) RC(launch(fast::k_sn_fwd<4>, dim3(B * H), dim3(fast::SN_T), fast::sn_fwd_smem<4>(), st, "k_sn_fwd<4>", sa));
+        else         RC(launch(fast::k_sn_fwd<5>, dim3(B * H), dim3(fast::SN_T), fast::sn_fwd_smem<5>(), st, "k_sn_fwd<5>", sa));
+        return MHLA_OK;
+    }
     if (fast_shape_ok(M, D, dtype, split) && !(flags & MHLA_FLAG_FORCE_GENERIC) && view_ok16(q_num) && view_ok16(k_num) &&
         view_ok16(v) && view_ok16(outv)) {
         const FastWs f = fast_carve(ws, B, H, M, S);

@@ -74,7 +74,7 @@ def _ws(nbytes: int, device) -> torch.Tensor:
 # ------------------------------------------------------------------------------------------
 class _BlockMix(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q, k, v, W, q_den, k_den, block_index, eps, normalize, relu_eps, force_generic):
+    def forward(ctx, q, k, v, W, q_den, k_den, block_index, eps, normalize, relu_eps, force_generic, no_smalln):
         lib = _lib.load()
         _require_gpu(q, k, v, W, q_den, k_den, block_index)
         B, N, H, D = q.shape
@@ -91,7 +91,8 @@ class _BlockMix(torch.autograd.Function):
         Wf = W.detach().reshape(M, M).to(torch.float32).contiguous()
         out = _alloc_like_tokens(B, N, H, D, q)
         dt = _dtype_code(q)
-        flags = (_lib.FLAG_RELU_EPS if relu_eps else 0) | (_lib.FLAG_FORCE_GENERIC if force_generic else 0)
+        flags = ((_lib.FLAG_RELU_EPS if relu_eps else 0) | (_lib.FLAG_FORCE_GENERIC if force_generic else 0)
+                 | (_lib.FLAG_NO_SMALLN if no_smalln else 0))
         ws = _ws(lib.mhla_blockmix_fwd_ws_bytes(B, H, M, S, D, dt, int(split), flags), q.device)
         qv, kv = _view(q), _view(k)
         if normalize:
@@ -103,18 +104,18 @@ class _BlockMix(torch.autograd.Function):
                                    ws.data_ptr(), ws.numel() * 4, B, H, M, S, D, dt, float(eps), flags, _stream())
         _lib.check(rc, "mhla_blockmix_fwd")
         # keep the forward's block summaries for the backward when they are the compact bf16 ones (fast path)
-        keep = (not force_generic and dt == _lib.BF16 and D == 64 and M <= 64 and not split
+        keep = (lib.mhla_blockmix_fwd_keeps_state(B, H, M, S, D, dt, int(split), flags) == 1
                 and ws.numel() * 4 <= KEEP_STATE_LIMIT_BYTES)
         ctx.save_for_backward(q, k, v, Wf, out, q_den if split else None, k_den if split else None, block_index,
                               ws if keep else None)
-        ctx.cfg = (float(eps), bool(normalize), bool(relu_eps), split, W.shape, W.dtype, bool(force_generic))
+        ctx.cfg = (float(eps), bool(normalize), bool(relu_eps), split, W.shape, W.dtype, flags)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         lib = _lib.load()
         q, k, v, Wf, out, q_den, k_den, block_index, fwd_ws = ctx.saved_tensors
-        eps, normalize, relu_eps, split, w_shape, w_dtype, force_generic = ctx.cfg
+        eps, normalize, relu_eps, split, w_shape, w_dtype, flags = ctx.cfg
         B, N, H, D = q.shape
         M = Wf.shape[0]
         S = N // M
@@ -127,7 +128,6 @@ class _BlockMix(torch.autograd.Function):
         if split:
             dqd, dkd = torch.empty_like(dq), torch.empty_like(dq)
         dt = _dtype_code(q)
-        flags = (_lib.FLAG_RELU_EPS if relu_eps else 0) | (_lib.FLAG_FORCE_GENERIC if force_generic else 0)
         ws = _ws(lib.mhla_blockmix_bwd_ws_bytes(B, H, M, S, D, dt, int(split), flags), q.device)
         qv, kv = _view(q), _view(k)
         if normalize:
@@ -142,13 +142,13 @@ class _BlockMix(torch.autograd.Function):
                                    fwd_ws.data_ptr() if fwd_ws is not None else None, B, H, M, S, D,
                                    dt, eps, flags, _stream())
         _lib.check(rc, "mhla_blockmix_bwd")
-        return dq, dk, dv, dW.reshape(w_shape).to(w_dtype), dqd, dkd, None, None, None, None, None
+        return dq, dk, dv, dW.reshape(w_shape).to(w_dtype), dqd, dkd, None, None, None, None, None, None
 
 
 def mhla_blockmix(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, W: torch.Tensor, *, eps: float = 1e-6,
                   q_den: Optional[torch.Tensor] = None, k_den: Optional[torch.Tensor] = None,
                   normalize: bool = True, block_index: Optional[torch.Tensor] = None,
-                  relu_eps: bool = False, force_generic: bool = False) -> torch.Tensor:
+                  relu_eps: bool = False, force_generic: bool = False, no_smalln: bool = False) -> torch.Tensor:
     """Block-mixing MHLA operator (mhla_dit/mhla/mhla.py:262-268; wan/mhla_utils.py:331-341).
 
     q, k, v : [B, N, H, D] token-major (any batch/token/head strides, e.g. views into a fused QKV
@@ -159,14 +159,15 @@ def mhla_blockmix(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, W: torch.Te
     normalize    : False skips the division (Wan `normalize_out=False`).
     relu_eps     : apply relu(x)+eps to q and k inside the kernels (mhla.py:229-230) -- q, k are then
                    the raw projections and receive the masked gradient.
-    force_generic: testing aid -- take the generic fp32-MFMA kernels where the bf16 fast path would apply.
+    force_generic / no_smalln: testing aids -- take the generic fp32-MFMA kernels / skip the single-launch
+                   small-sequence path where they would otherwise be chosen.
     Returns [B, N, H, D] contiguous, same dtype; differentiable w.r.t. q, k, v, W (and q_den, k_den).
     """
     if (q_den is None) != (k_den is None):
         raise ValueError("q_den and k_den must be given together")
     if block_index is not None and (block_index.dtype != torch.int32 or not block_index.is_contiguous()):
         raise TypeError("block_index must be a contiguous int32 tensor")
-    return _BlockMix.apply(q, k, v, W, q_den, k_den, block_index, eps, normalize, relu_eps, force_generic)
+    return _BlockMix.apply(q, k, v, W, q_den, k_den, block_index, eps, normalize, relu_eps, force_generic, no_smalln)
 
 
 # ------------------------------------------------------------------------------------------

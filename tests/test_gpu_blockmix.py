@@ -76,6 +76,26 @@ def test_fast_path_bf16_d64(M, S):
     run_case(2, 3, M, S, 64, torch.bfloat16, w="rand")
 
 
+@pytest.mark.parametrize("M,D", [(16, 64), (16, 72), (9, 72), (4, 80), (1, 64), (13, 24), (16, 8)])
+def test_small_sequence_path(M, D):
+    """bf16, S = 16, M <= 16, D <= 80 (DiT / ViT regime): single-launch attention-form kernels (smalln.cuh)."""
+    run_case(3, 2, M, 16, D, torch.bfloat16, w="rand")
+    run_case(2, 2, M, 16, D, torch.bfloat16, normalize=False)
+
+
+def test_small_sequence_vs_summary_path_agree():
+    import mhla_amd
+    q, k, v, W, do, _, _ = make_blockmix_inputs(4, 6, 16, 16, 64, torch.bfloat16, seed=3, w="rand")
+    res = []
+    for ns in (False, True):
+        t = [x.clone().requires_grad_(True) for x in to_dev(q, k, v, W)]
+        out = mhla_amd.mhla_blockmix(*t, no_smalln=ns)
+        out.backward(do.to(DEV))
+        res.append([out] + [x.grad for x in t])
+    for name, a_, b_ in zip(("out", "dq", "dk", "dv", "dW"), res[0], res[1]):
+        check(name, a_, b_.float().cpu(), 1.2e-2)
+
+
 @pytest.mark.parametrize("normalize", [True, False])
 def test_fast_path_options(normalize):
     idx = orc.block_index_2d(4, 4).int()
