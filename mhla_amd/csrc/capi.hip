@@ -375,6 +375,20 @@ int mhla_blockmix_bwd(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q
     {
         const mhla_view dqv{dq_num.ptr, dq_num.sb, dq_num.sn, dq_num.sh}, dkv_{dk_num.ptr, dk_num.sb, dk_num.sn, dk_num.sh},
             dvv{dv.ptr, dv.sb, dv.sn, dv.sh};
+        if (sn_shape_ok(M, S, D, dtype, split) && !(flags & (MHLA_FLAG_FORCE_GENERIC | MHLA_FLAG_NO_SMALLN)) && view_ok16(q_num) &&
+            view_ok16(k_num) && view_ok16(v) && view_ok16(dout) && (!normalize || view_ok16(out)) && view_ok16(dqv) &&
+            view_ok16(dkv_) && view_ok16(dvv)) {
+            const size_t need = (size_t)B * H * M * M * 4;
+            if (ws_bytes < need) return fail(MHLA_EINVAL, "workspace too small: %zu < %zu bytes", ws_bytes, need);
+            fast::SnArgs sa{};
+            sa.q = cv(q_num); sa.k = cv(k_num); sa.v = cv(v); sa.o = normalize ? cv(out) : cv(q_num); sa.dout = cv(dout);
+            sa.dq = cmv(dq_num); sa.dk = cmv(dk_num); sa.dv = cmv(dv); sa.idx = block_index; sa.W = W; sa.ldw = ldw;
+            sa.dwp = (float*)ws; sa.H = H; sa.M = M; sa.D = D; sa.eps = eps; sa.relu = relu; sa.normalize = normalize;
+            if (D <= 64) RC(launch(fast::k_sn_bwd<4>, dim3(B * H), dim3(fast::SN_T), fast::sn_bwd_smem<4>(), st, "k_sn_bwd<4>", sa));
+            else         RC(launch(fast::k_sn_bwd<5>, dim3(B * H), dim3(fast::SN_T), fast::sn_bwd_smem<5>(), st, "k_sn_bwd<5>", sa));
+            RC(launch(fast::k_sn_dw_reduce, dim3(M * M), dim3(256), 0, st, "k_sn_dw_reduce", (const float*)ws, dW, M * M, B * H));
+            return MHLA_OK;
+        }
         if (fast_shape_ok(M, D, dtype, split) && !(flags & MHLA_FLAG_FORCE_GENERIC) && view_ok16(q_num) && view_ok16(k_num) &&
             view_ok16(v) && view_ok16(dout) && (!normalize || view_ok16(out)) && view_ok16(dqv) && view_ok16(dkv_) && view_ok16(dvv)) {
             const FastWs f = fast_carve(ws, B, H, M, S);

@@ -216,5 +216,291 @@ __global__ __launch_bounds__(SN_T) void k_sn_fwd(const SnArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// backward: dQ, dK, dV and the per-(b,h) partial of dW, one launch.
+//   pass A (wave owns query blocks i, K / V tiles in LDS):  S^T, dP^T tiles -> dW[i][:], dS -> dQ_i ; dksum_i
+//   pass B (wave owns key blocks j, Q / dO' tiles in LDS):  S, dP tiles -> P^T dO' = dV_j ; dS^T Q = dK_j
+// with S = Q K^T, P = W (.) S, dO' = dO / n, dP = dO' V^T, dS = W (.) dP, dn = -(dO . O) / n, dz = W^T dn.
+// ------------------------------------------------------------------------------------------------------------------
+template <int DT>
+__host__ __device__ constexpr int sn_bwd_smem() {
+    return 2 * 256 * sn_ldr<DT>() * 2 + (2 * 16 * DT * 16 + 5 * 256) * 4 + 4 * 16 * sn_ldr<DT>() * 2;
+}
+
+// 16 staged rows -> global with optional relu mask (raw input > 0)
+template <bool MASK>
+__device__ __forceinline__ void sn_store16(u16* __restrict__ base, long sn, const int* __restrict__ idx, int row0, int D,
+                                           const u16* __restrict__ Os, int ldr, const u16* __restrict__ mbase, long msn, int lane) {
+    const int dv = D >> 3;
+    for (int v = lane; v < 16 * dv; v += 64) {
+        const int r = v / dv, p = v - r * dv;
+        const long tr = tok_row(idx, row0 + r);
+        uint4 x = *reinterpret_cast<const uint4*>(Os + r * ldr + p * 8);
+        if (MASK) x = mask_pos8(x, *reinterpret_cast<const uint4*>(mbase + tr * msn + p * 8));
+        *reinterpret_cast<uint4*>(base + tr * sn + p * 8) = x;
+    }
+}
+
+template <int DT>
+__global__ __launch_bounds__(SN_T) void k_sn_bwd(const SnArgs a) {
+    constexpr int DP = DT * 16, LDR = sn_ldr<DT>(), KS = (DP + 31) / 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u16* T0 = reinterpret_cast<u16*>(smem_raw);          // K, later Q          [N][LDR]
+    u16* T1 = T0 + 256 * LDR;                            // V, later dO' = dO/n
+    float* ksum_s = reinterpret_cast<float*>(T1 + 256 * LDR);   // [M][DP]
+    float* dks_s = ksum_s + 16 * DP;                     // [M][DP]
+    float* zs = dks_s + 16 * DP;                         // [M][16]
+    float* rds = zs + 256;                               // row dots dO . O
+    float* nis = rds + 256;                              // 1 / n
+    float* dns = nis + 256;                              // dn
+    float* dzs = dns + 256;                              // dz
+    u16* Ost = reinterpret_cast<u16*>(dzs + 256);        // [4 waves][16][LDR]
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, n = lane & 15, kg = lane >> 4;
+    const int bh = blockIdx.x, b = bh / a.H, h = bh - b * a.H;
+    const int M = a.M, D = a.D, N = M * 16;
+    auto base = [&](const View& w) { return (const u16*)w.ptr + b * w.sb + h * w.sh; };
+    auto mbase = [&](const MView& w) { return (u16*)w.ptr + b * w.sb + h * w.sh; };
+    const u16 *qb = base(a.q), *kb = base(a.k), *vb = base(a.v), *ob = base(a.o), *gb = base(a.dout);
+    u16 *dqb = mbase(a.dq), *dkb = mbase(a.dk), *dvb = mbase(a.dv);
+    float* dwp = a.dwp + (long)bh * M * M;
+    u16* Os = Ost + wave * 16 * LDR;
+    auto load_q = [&](bf16x8 (&r)[KS], int i) {
+        if (a.relu) sn_load_rows<KS, true>(r, qb, a.q.sn, a.idx, i * 16, D, a.eps, lane);
+        else        sn_load_rows<KS, false>(r, qb, a.q.sn, a.idx, i * 16, D, a.eps, lane);
+    };
+    auto load_k = [&](bf16x8 (&r)[KS], int j) {
+        if (a.relu) sn_load_rows<KS, true>(r, kb, a.k.sn, a.idx, j * 16, D, a.eps, lane);
+        else        sn_load_rows<KS, false>(r, kb, a.k.sn, a.idx, j * 16, D, a.eps, lane);
+    };
+    // dO rows scaled by 1/n (row = lane & 15), rounded to bf16
+    auto load_dop = [&](bf16x8 (&r)[KS], int i) {
+        sn_load_rows<KS, false>(r, gb, a.dout.sn, a.idx, i * 16, D, 0.f, lane);
+        if (a.normalize) {
+            const float ni = nis[i * 16 + n];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const uint4 v = __builtin_bit_cast(uint4, r[ks]);
+                unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    w[t] = pack_bf16x2(__uint_as_float(w[t] << 16) * ni, __uint_as_float(w[t] & 0xffff0000u) * ni);
+                r[ks] = __builtin_bit_cast(bf16x8, make_uint4(w[0], w[1], w[2], w[3]));
+            }
+        }
+    };
+
+    // ---- P0 / P1: K, V tiles; ksum ----
+    if (a.relu) sn_stage<DT, true>(T0, kb, a.k.sn, a.idx, N, D, a.eps, tid);
+    else        sn_stage<DT, false>(T0, kb, a.k.sn, a.idx, N, D, a.eps, tid);
+    sn_stage<DT, false>(T1, vb, a.v.sn, a.idx, N, D, 0.f, tid);
+    __syncthreads();
+    if (a.normalize) {
+        for (int v = tid; v < M * DP; v += SN_T) {
+            const int j = v / DP, d = v - j * DP;
+            float sacc = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc += bf(T0[(j * 16 + r) * LDR + d]);
+            ksum_s[v] = sacc;
+        }
+        __syncthreads();
+        // ---- P2: z_i, row dots (own blocks) ----
+        for (int i = wave; i < M; i += 4) {
+            bf16x8 qa[KS], ga[KS], oa[KS];
+            load_q(qa, i);
+            sn_load_rows<KS, false>(ga, gb, a.dout.sn, a.idx, i * 16, D, 0.f, lane);
+            sn_load_rows<KS, false>(oa, ob, a.o.sn, a.idx, i * 16, D, 0.f, lane);
+            float z = 0.f, rd = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                if (ks * 32 + kg * 8 < D) {
+                    const s16x8 qs = __builtin_bit_cast(s16x8, qa[ks]), gs = __builtin_bit_cast(s16x8, ga[ks]), os = __builtin_bit_cast(s16x8, oa[ks]);
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        z += bf((u16)qs[t]) * ksum_s[i * DP + ks * 32 + kg * 8 + t];
+                        rd += bf((u16)gs[t]) * bf((u16)os[t]);
+                    }
+                }
+            }
+            z += __shfl_xor(z, 16, 64); z += __shfl_xor(z, 32, 64);
+            rd += __shfl_xor(rd, 16, 64); rd += __shfl_xor(rd, 32, 64);
+            if (kg == 0) { zs[i * 16 + n] = z; rds[i * 16 + n] = rd; }
+        }
+        __syncthreads();
+        // ---- P3: 1/n, dn ----
+        for (int v = tid; v < N; v += SN_T) {
+            const int i = v >> 4, sx = v & 15;
+            float nn = a.eps;
+            for (int j = 0; j < M; ++j) nn += a.W[(long)i * a.ldw + j] * zs[j * 16 + sx];
+            const float ni = 1.f / nn;
+            nis[v] = ni;
+            dns[v] = -rds[v] * ni;
+        }
+        __syncthreads();
+        // ---- P4: dz = W^T dn ----
+        for (int v = tid; v < N; v += SN_T) {
+            const int j = v >> 4, sx = v & 15;
+            float dz = 0.f;
+            for (int i = 0; i < M; ++i) dz += a.W[(long)i * a.ldw + j] * dns[i * 16 + sx];
+            dzs[v] = dz;
+        }
+        __syncthreads();
+    }
+
+    // ---- pass A: dQ_i, dW[i][:], dksum_i ----
+    for (int i = wave; i < M; i += 4) {
+        bf16x8 qa[KS], ga[KS];
+        load_q(qa, i);
+        load_dop(ga, i);
+        f32x4 acc[DT];
+#pragma unroll
+        for (int tn = 0; tn < DT; ++tn) acc[tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j0 = 0; j0 < M; j0 += 2) {
+            const bool has1 = j0 + 1 < M;
+            const int j1 = has1 ? j0 + 1 : j0;
+            const float w0 = a.W[(long)i * a.ldw + j0], w1 = has1 ? a.W[(long)i * a.ldw + j1] : 0.f;
+            f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, p0 = s0, p1 = s0;
+            bf16x8 t0[KS], t1[KS];
+            sn_lds_rows<KS>(t0, T0, LDR, j0 * 16, D, lane);
+            sn_lds_rows<KS>(t1, T0, LDR, j1 * 16, D, lane);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) { s0 = mfma_bf16(t0[ks], qa[ks], s0); s1 = mfma_bf16(t1[ks], qa[ks], s1); }   // S^T
+            sn_lds_rows<KS>(t0, T1, LDR, j0 * 16, D, lane);
+            sn_lds_rows<KS>(t1, T1, LDR, j1 * 16, D, lane);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) { p0 = mfma_bf16(t0[ks], ga[ks], p0); p1 = mfma_bf16(t1[ks], ga[ks], p1); }   // dP^T
+            // dW[i][j] = sum(dP . S) + sum_s dn_i[s] z_j[s]
+            float e0 = s0[0] * p0[0] + s0[1] * p0[1] + s0[2] * p0[2] + s0[3] * p0[3];
+            float e1 = s1[0] * p1[0] + s1[1] * p1[1] + s1[2] * p1[2] + s1[3] * p1[3];
+            if (a.normalize && kg == 0) {
+                e0 += dns[i * 16 + n] * zs[j0 * 16 + n];
+                e1 += dns[i * 16 + n] * zs[j1 * 16 + n];
+            }
+            e0 = wave_sum(e0);
+            e1 = wave_sum(e1);
+            if (lane == 0) {
+                dwp[i * M + j0] = e0;
+                if (has1) dwp[i * M + j1] = e1;
+            }
+            const bf16x8 da = sn_pack_pair(p0 * w0, p1 * w1);      // dS^T pair -> A operand (m = s, k-slots = t)
+#pragma unroll
+            for (int tn = 0; tn < DT; ++tn) acc[tn] = mfma_bf16(da, sn_tr_pair(T0, LDR, j0 * 16, j1 * 16, tn * 16, lane), acc[tn]);
+        }
+        // epilogue: + dz (x) ksum ; stage ; masked store
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float dz = a.normalize ? dzs[i * 16 + kg * 4 + r] : 0.f;
+#pragma unroll
+            for (int tn = 0; tn < DT; ++tn) {
+                const float kk = a.normalize ? ksum_s[i * DP + tn * 16 + n] : 0.f;
+                Os[(kg * 4 + r) * LDR + tn * 16 + n] = cvt_bf16(acc[tn][r] + dz * kk);
+            }
+        }
+        wave_lds_fence();
+        if (a.relu) sn_store16<true>(dqb, a.dq.sn, a.idx, i * 16, D, Os, LDR, qb, a.q.sn, lane);
+        else        sn_store16<false>(dqb, a.dq.sn, a.idx, i * 16, D, Os, LDR, nullptr, 0, lane);
+        wave_lds_fence();
+        if (a.normalize) {   // dksum_i[d] = sum_s dz_i[s] q_i[s][d]
+            const float dzn = dzs[i * 16 + n];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const s16x8 qs = __builtin_bit_cast(s16x8, qa[ks]);
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    float v = dzn * bf((u16)qs[t]);
+                    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64);
+                    v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+                    if (n == 0 && ks * 32 + kg * 8 + t < DP) dks_s[i * DP + ks * 32 + kg * 8 + t] = v;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- P5: Q and dO' tiles replace K and V ----
+    if (a.relu) sn_stage<DT, true>(T0, qb, a.q.sn, a.idx, N, D, a.eps, tid);
+    else        sn_stage<DT, false>(T0, qb, a.q.sn, a.idx, N, D, a.eps, tid);
+    {
+        constexpr int PV = DT * 2;
+        const int dv = D >> 3;
+        for (int v = tid; v < N * PV; v += SN_T) {
+            const int r = v / PV, p = v - r * PV;
+            uint4 x = make_uint4(0, 0, 0, 0);
+            if (p < dv) {
+                x = *reinterpret_cast<const uint4*>(gb + tok_row(a.idx, r) * a.dout.sn + p * 8);
+                if (a.normalize) {
+                    const float ni = nis[r];
+                    unsigned w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        w[t] = pack_bf16x2(__uint_as_float(w[t] << 16) * ni, __uint_as_float(w[t] & 0xffff0000u) * ni);
+                    x = make_uint4(w[0], w[1], w[2], w[3]);
+                }
+            }
+            *reinterpret_cast<uint4*>(T1 + r * LDR + p * 8) = x;
+        }
+    }
+    __syncthreads();
+
+    // ---- pass B: dK_j, dV_j ----
+    for (int j = wave; j < M; j += 4) {
+        bf16x8 ka[KS], va[KS];
+        load_k(ka, j);
+        sn_load_rows<KS, false>(va, vb, a.v.sn, a.idx, j * 16, D, 0.f, lane);
+        f32x4 accK[DT], accV[DT];
+#pragma unroll
+        for (int tn = 0; tn < DT; ++tn) accK[tn] = accV[tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i0 = 0; i0 < M; i0 += 2) {
+            const bool has1 = i0 + 1 < M;
+            const int i1 = has1 ? i0 + 1 : i0;
+            const float w0 = a.W[(long)i0 * a.ldw + j], w1 = has1 ? a.W[(long)i1 * a.ldw + j] : 0.f;
+            f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, p0 = s0, p1 = s0;
+            bf16x8 t0[KS], t1[KS];
+            sn_lds_rows<KS>(t0, T0, LDR, i0 * 16, D, lane);
+            sn_lds_rows<KS>(t1, T0, LDR, i1 * 16, D, lane);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) { s0 = mfma_bf16(t0[ks], ka[ks], s0); s1 = mfma_bf16(t1[ks], ka[ks], s1); }   // S: rows s, cols t
+            sn_lds_rows<KS>(t0, T1, LDR, i0 * 16, D, lane);
+            sn_lds_rows<KS>(t1, T1, LDR, i1 * 16, D, lane);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) { p0 = mfma_bf16(t0[ks], va[ks], p0); p1 = mfma_bf16(t1[ks], va[ks], p1); }   // dP
+            const bf16x8 pa = sn_pack_pair(s0 * w0, s1 * w1);      // P pair  -> A operand (m = t, k-slots = s)
+            const bf16x8 da = sn_pack_pair(p0 * w0, p1 * w1);      // dS pair
+#pragma unroll
+            for (int tn = 0; tn < DT; ++tn) {
+                accV[tn] = mfma_bf16(pa, sn_tr_pair(T1, LDR, i0 * 16, i1 * 16, tn * 16, lane), accV[tn]);   // dV += P^T dO'
+                accK[tn] = mfma_bf16(da, sn_tr_pair(T0, LDR, i0 * 16, i1 * 16, tn * 16, lane), accK[tn]);   // dK += dS^T Q
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int tn = 0; tn < DT; ++tn)
+                Os[(kg * 4 + r) * LDR + tn * 16 + n] = cvt_bf16(accK[tn][r] + (a.normalize ? dks_s[j * DP + tn * 16 + n] : 0.f));
+        wave_lds_fence();
+        if (a.relu) sn_store16<true>(dkb, a.dk.sn, a.idx, j * 16, D, Os, LDR, kb, a.k.sn, lane);
+        else        sn_store16<false>(dkb, a.dk.sn, a.idx, j * 16, D, Os, LDR, nullptr, 0, lane);
+        wave_lds_fence();
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int tn = 0; tn < DT; ++tn) Os[(kg * 4 + r) * LDR + tn * 16 + n] = cvt_bf16(accV[tn][r]);
+        wave_lds_fence();
+        sn_store16<false>(dvb, a.dv.sn, a.idx, j * 16, D, Os, LDR, nullptr, 0, lane);
+        wave_lds_fence();
+    }
+}
+
+// dW[i][j] = sum_bh dWp[bh][i][j] : one workgroup per element, fixed-order tree (deterministic)
+__global__ __launch_bounds__(256) void k_sn_dw_reduce(const float* __restrict__ dwp, float* __restrict__ dW, int MM, int BH) {
+    __shared__ float red[4];
+    const int e = blockIdx.x, tid = threadIdx.x;
+    float s = 0.f;
+    for (int b = tid; b < BH; b += 256) s += dwp[(long)b * MM + e];
+    s = wave_sum(s);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) dW[e] = red[0] + red[1] + red[2] + red[3];
+}
+
 }  // namespace fast
 }  // namespace mhla
