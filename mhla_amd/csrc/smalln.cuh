@@ -18,7 +18,8 @@
 namespace mhla {
 namespace fast {
 
-constexpr int SN_T = 256;   // threads
+constexpr int SN_T = 512;   // threads: 8 waves, wave w owns blocks w and w + 8
+constexpr int SN_W = SN_T / 64;
 
 struct SnArgs {
     View q, k, v, o, dout;
@@ -107,21 +108,21 @@ __device__ __forceinline__ bf16x8 sn_pack_pair(f32x4 c0, f32x4 c1) {
 
 template <int DT>
 __host__ __device__ constexpr int sn_fwd_smem() {
-    return 2 * 256 * sn_ldr<DT>() * 2 + (16 * DT * 16 + 256 + 4 * 16 * (DT * 16 + 8) / 2) * 4;
+    return 2 * 256 * sn_ldr<DT>() * 2 + (16 * DT * 16 + 256) * 4 + SN_W * 16 * sn_ldr<DT>() * 2;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------------------------
 template <int DT>
-__global__ __launch_bounds__(SN_T) void k_sn_fwd(const SnArgs a) {
+__global__ __launch_bounds__(SN_T, 2) void k_sn_fwd(const SnArgs a) {
     constexpr int DP = DT * 16, LDR = sn_ldr<DT>(), KS = (DP + 31) / 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u16* Ks = reinterpret_cast<u16*>(smem_raw);          // [N][LDR]
     u16* Vs = Ks + 256 * LDR;                            // [N][LDR]
     float* ksum_s = reinterpret_cast<float*>(Vs + 256 * LDR);   // [M][DP]
     float* zs = ksum_s + 16 * DP;                        // [M][16]
-    u16* Ost = reinterpret_cast<u16*>(zs + 256);         // [4 waves][16][LDR] output staging
+    u16* Ost = reinterpret_cast<u16*>(zs + 256);         // [8 waves][16][LDR] output staging
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, n = lane & 15, kg = lane >> 4;
     const int bh = blockIdx.x, b = bh / a.H, h = bh - b * a.H;
     const int M = a.M, D = a.D, N = M * 16;
@@ -145,10 +146,10 @@ __global__ __launch_bounds__(SN_T) void k_sn_fwd(const SnArgs a) {
         __syncthreads();
     }
     // own blocks: i = wave, wave + 4, ...   Q_i rows as MFMA operands; z_i
-    bf16x8 qa[4][KS];
+    bf16x8 qa[2][KS];
 #pragma unroll
-    for (int x = 0; x < 4; ++x) {
-        const int i = wave + 4 * x;
+    for (int x = 0; x < 2; ++x) {
+        const int i = wave + SN_W * x;
         if (i < M) {
             if (a.relu) sn_load_rows<KS, true>(qa[x], qb, a.q.sn, a.idx, i * 16, D, a.eps, lane);
             else        sn_load_rows<KS, false>(qa[x], qb, a.q.sn, a.idx, i * 16, D, a.eps, lane);
@@ -170,8 +171,8 @@ __global__ __launch_bounds__(SN_T) void k_sn_fwd(const SnArgs a) {
     }
     __syncthreads();
 #pragma unroll
-    for (int x = 0; x < 4; ++x) {
-        const int i = wave + 4 * x;
+    for (int x = 0; x < 2; ++x) {
+        const int i = wave + SN_W * x;
         if (i >= M) continue;
         float ninv = 1.f;   // lane n = row s of the block
         if (a.normalize) {
@@ -182,6 +183,7 @@ __global__ __launch_bounds__(SN_T) void k_sn_fwd(const SnArgs a) {
         f32x4 acc[DT];
 #pragma unroll
         for (int tn = 0; tn < DT; ++tn) acc[tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
         for (int j0 = 0; j0 < M; j0 += 2) {
             const int j1 = j0 + 1 < M ? j0 + 1 : j0;
             const float w0 = a.W[(long)i * a.ldw + j0], w1 = j0 + 1 < M ? a.W[(long)i * a.ldw + j0 + 1] : 0.f;
@@ -224,7 +226,7 @@ __global__ __launch_bounds__(SN_T) void k_sn_fwd(const SnArgs a) {
 // ------------------------------------------------------------------------------------------------------------------
 template <int DT>
 __host__ __device__ constexpr int sn_bwd_smem() {
-    return 2 * 256 * sn_ldr<DT>() * 2 + (2 * 16 * DT * 16 + 5 * 256) * 4 + 4 * 16 * sn_ldr<DT>() * 2;
+    return 2 * 256 * sn_ldr<DT>() * 2 + (2 * 16 * DT * 16 + 5 * 256) * 4 + SN_W * 16 * sn_ldr<DT>() * 2;
 }
 
 // 16 staged rows -> global with optional relu mask (raw input > 0)
@@ -242,7 +244,7 @@ __device__ __forceinline__ void sn_store16(u16* __restrict__ base, long sn, cons
 }
 
 template <int DT>
-__global__ __launch_bounds__(SN_T) void k_sn_bwd(const SnArgs a) {
+__global__ __launch_bounds__(SN_T, 2) void k_sn_bwd(const SnArgs a) {
     constexpr int DP = DT * 16, LDR = sn_ldr<DT>(), KS = (DP + 31) / 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u16* T0 = reinterpret_cast<u16*>(smem_raw);          // K, later Q          [N][LDR]
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(SN_T) void k_sn_bwd(const SnArgs a) {
     float* nis = rds + 256;                              // 1 / n
     float* dns = nis + 256;                              // dn
     float* dzs = dns + 256;                              // dz
-    u16* Ost = reinterpret_cast<u16*>(dzs + 256);        // [4 waves][16][LDR]
+    u16* Ost = reinterpret_cast<u16*>(dzs + 256);        // [8 waves][16][LDR]
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, n = lane & 15, kg = lane >> 4;
     const int bh = blockIdx.x, b = bh / a.H, h = bh - b * a.H;
     const int M = a.M, D = a.D, N = M * 16;
@@ -304,7 +306,7 @@ __global__ __launch_bounds__(SN_T) void k_sn_bwd(const SnArgs a) {
         }
         __syncthreads();
         // ---- P2: z_i, row dots (own blocks) ----
-        for (int i = wave; i < M; i += 4) {
+        for (int i = wave; i < M; i += SN_W) {
             bf16x8 qa[KS], ga[KS], oa[KS];
             load_q(qa, i);
             sn_load_rows<KS, false>(ga, gb, a.dout.sn, a.idx, i * 16, D, 0.f, lane);
@@ -347,13 +349,14 @@ __global__ __launch_bounds__(SN_T) void k_sn_bwd(const SnArgs a) {
     }
 
     // ---- pass A: dQ_i, dW[i][:], dksum_i ----
-    for (int i = wave; i < M; i += 4) {
+    for (int i = wave; i < M; i += SN_W) {
         bf16x8 qa[KS], ga[KS];
         load_q(qa, i);
         load_dop(ga, i);
         f32x4 acc[DT];
 #pragma unroll
         for (int tn = 0; tn < DT; ++tn) acc[tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
         for (int j0 = 0; j0 < M; j0 += 2) {
             const bool has1 = j0 + 1 < M;
             const int j1 = has1 ? j0 + 1 : j0;
@@ -442,13 +445,14 @@ __global__ __launch_bounds__(SN_T) void k_sn_bwd(const SnArgs a) {
     __syncthreads();
 
     // ---- pass B: dK_j, dV_j ----
-    for (int j = wave; j < M; j += 4) {
+    for (int j = wave; j < M; j += SN_W) {
         bf16x8 ka[KS], va[KS];
         load_k(ka, j);
         sn_load_rows<KS, false>(va, vb, a.v.sn, a.idx, j * 16, D, 0.f, lane);
         f32x4 accK[DT], accV[DT];
 #pragma unroll
         for (int tn = 0; tn < DT; ++tn) accK[tn] = accV[tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
         for (int i0 = 0; i0 < M; i0 += 2) {
             const bool has1 = i0 + 1 < M;
             const int i1 = has1 ? i0 + 1 : i0;
