@@ -419,7 +419,7 @@ __global__ __launch_bounds__(NTHREADS) void k_bm_out(const OutArgs a) {
 
 // ---------------------------------------------------------------------------------------------
 // dWp[bh][i][j] = sum_e X[bh][i][e] Y[bh][j][e]  (+ second segment X2/Y2 with row length E2)
-// grid (tile pairs, bh); MASK 1: only j < i (strictly lower; causal dmix off-diagonal).
+// grid (tile pairs, bh, E-slices); MASK 1: only j < i (strictly lower; causal dmix off-diagonal).
 // ---------------------------------------------------------------------------------------------
 struct DwArgs {
     const float* x;
@@ -428,8 +428,9 @@ struct DwArgs {
     const float* x2;
     const float* y2;
     long E2;
-    float* out;   // [bh][M][M]
+    float* out;   // [bh][nsplit][M][M]
     int M, tiles;
+    int nsplit;   // the E range (and E2) is cut into nsplit slices, one workgroup each (blockIdx.z)
 };
 constexpr int DW_LD = 34;
 constexpr int DW_SMEM_FLOATS = 2 * 64 * DW_LD;
@@ -442,7 +443,8 @@ __global__ __launch_bounds__(NTHREADS) void k_dw(const DwArgs a) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r16 = lane & 15, kq = lane >> 4;
     const int it = blockIdx.x / a.tiles, jt = blockIdx.x - it * a.tiles, bh = blockIdx.y, M = a.M;
     const int i0 = it * 64, j0 = jt * 64;
-    float* out = a.out + (long)bh * M * M;
+    const int split = blockIdx.z;
+    float* out = a.out + ((long)bh * a.nsplit + split) * M * M;
     if (MASK == 1 && j0 > i0 + 63) return;   // tile entirely above the diagonal (output is masked by the reducer)
 
     f32x4 acc[4];
@@ -457,21 +459,29 @@ __global__ __launch_bounds__(NTHREADS) void k_dw(const DwArgs a) {
         X += (long)bh * M * E;
         Y += (long)bh * M * E;
         const bool vec_ok = (E & 3) == 0;
-        for (long e0 = 0; e0 < E; e0 += 32) {
-            for (int v = tid; v < 2 * 64 * 8; v += NTHREADS) {
-                const int which = v >> 9, r = (v >> 3) & 63, c = (v & 7) * 4;
+        const long per = ((E + a.nsplit - 1) / a.nsplit + 31) & ~31L;       // slice length, multiple of the 32-wide chunk
+        const long ebeg = (long)split * per, eend = ebeg + per < E ? ebeg + per : E;
+        for (long e0 = ebeg; e0 < eend; e0 += 32) {
+            f32x4 xr[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int v = tid + t * NTHREADS, which = v >> 9, r = (v >> 3) & 63, c = (v & 7) * 4;
                 const int g = (which ? j0 : i0) + r;
                 const float* src = (which ? Y : X) + (long)g * E + e0 + c;
-                f32x4 x = {0.f, 0.f, 0.f, 0.f};
-                if (g < M && e0 + c < E) {
-                    if (vec_ok && e0 + c + 3 < E) x = *reinterpret_cast<const f32x4*>(src);
+                xr[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (g < M && e0 + c < eend) {
+                    if (vec_ok && e0 + c + 3 < eend) xr[t] = *reinterpret_cast<const f32x4*>(src);
                     else
-                        for (int t = 0; t < 4; ++t)
-                            if (e0 + c + t < E) x[t] = src[t];
+                        for (int u = 0; u < 4; ++u)
+                            if (e0 + c + u < eend) xr[t][u] = src[u];
                 }
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int v = tid + t * NTHREADS, which = v >> 9, r = (v >> 3) & 63, c = (v & 7) * 4;
                 float* d = (which ? Ys : Xs) + r * DW_LD + c;
-                *reinterpret_cast<f32x2*>(d) = f32x2{x[0], x[1]};
-                *reinterpret_cast<f32x2*>(d + 2) = f32x2{x[2], x[3]};
+                *reinterpret_cast<f32x2*>(d) = f32x2{xr[t][0], xr[t][1]};
+                *reinterpret_cast<f32x2*>(d + 2) = f32x2{xr[t][2], xr[t][3]};
             }
             __syncthreads();
 #pragma unroll
@@ -494,23 +504,28 @@ __global__ __launch_bounds__(NTHREADS) void k_dw(const DwArgs a) {
     }
 }
 
-// dW[i][j] = sum_bh dWp[bh][i][j]  (fixed order -> deterministic).
-//   MASK 1: j < i from dWp, j == i from diag[bh][i], j > i left untouched.
+// dW[i][j] = sum over parts of dWp[part][i][j]  (parts = (b,h) x E-slices; fixed summation order -> deterministic).
+//   MASK 1: j < i from dWp, j == i from diag[bh][i] (nbh rows), j > i left untouched.
+// 256 threads: 64 elements x 4 part-lanes, then a 4-way LDS reduce.
 template <int MASK>
-__global__ void k_dw_reduce(const float* __restrict__ dwp, const float* __restrict__ diag, float* __restrict__ dW,
-                            int ldd, int M, int BH) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= M * M) return;
-    const int i = e / M, j = e - i * M;
+__global__ __launch_bounds__(256) void k_dw_reduce(const float* __restrict__ dwp, const float* __restrict__ diag,
+                                                   float* __restrict__ dW, int ldd, int M, int nparts, int nbh) {
+    __shared__ float red[4][64];
+    const int el = threadIdx.x & 63, pl = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + el;
+    const int i = e < M * M ? e / M : 0, j = e < M * M ? e - i * M : 0;
     float s = 0.f;
-    if (MASK == 0 || j < i) {
-        for (int b = 0; b < BH; ++b) s += dwp[(long)b * M * M + e];
-    } else if (j == i) {
-        for (int b = 0; b < BH; ++b) s += diag[(long)b * M + i];
-    } else {
-        return;
+    if (e < M * M) {
+        if (MASK == 0 || j < i) {
+#pragma unroll 8
+            for (int p = pl; p < nparts; p += 4) s += dwp[(long)p * M * M + e];
+        } else if (j == i) {
+            for (int b = pl; b < nbh; b += 4) s += diag[(long)b * M + i];
+        }
     }
-    dW[(long)i * ldd + j] = s;
+    red[pl][el] = s;
+    __syncthreads();
+    if (pl == 0 && e < M * M && (MASK == 0 || j <= i)) dW[(long)i * ldd + j] = red[0][el] + red[1][el] + red[2][el] + red[3][el];
 }
 
 // ---------------------------------------------------------------------------------------------

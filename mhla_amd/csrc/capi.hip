@@ -80,6 +80,15 @@ int check_view(const char* name, const void* ptr, int64_t sb, int64_t sn, int64_
 #define CHECK_VIEW(v) do { int rc_ = check_view(#v, (v).ptr, (v).sb, (v).sn, (v).sh, dtype); if (rc_) return rc_; } while (0)
 #define RC(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
 
+// E-slices of the dW GEMM so that the launch has ~1000+ workgroups (at most 16 slices, slices >= 256 columns)
+constexpr int DW_MAX_SPLIT = 16;
+int dw_splits(long wgs, long E) {
+    long ns = (1024 + wgs - 1) / wgs;
+    if (ns > DW_MAX_SPLIT) ns = DW_MAX_SPLIT;
+    while (ns > 1 && E / ns < 256) --ns;
+    return (int)(ns < 1 ? 1 : ns);
+}
+
 int dt_for(int D) { return D <= 32 ? 2 : D <= 64 ? 4 : D <= 80 ? 5 : D <= 96 ? 6 : D <= 128 ? 8 : 0; }
 
 // dispatch on (dtype, DT)
@@ -118,7 +127,7 @@ BmWs bm_carve(void* ws, int B, int H, int M, int S, int D) {
     w.dkv = p; p += st;
     w.dn = p; p += zs;
     w.dz = p; p += zs;
-    w.dwp = p; p += al4(bh * M * M);
+    w.dwp = p; p += al4(bh * M * M * DW_MAX_SPLIT);
     w.total_bwd = (size_t)(p - (float*)ws) * 4;
     return w;
 }
@@ -202,7 +211,7 @@ CsWs cs_carve(void* ws, int B, int T, int H, int K, int V, int chunk) {
     w.total_fwd = (size_t)(p - (float*)ws) * 4;
     w.dP = p; p += st;
     w.dS = p; p += st;
-    w.dwp = p; p += al4(bh * n * n);
+    w.dwp = p; p += al4(bh * n * n * DW_MAX_SPLIT);
     w.diag = p; p += al4(bh * n);
     w.total_bwd = (size_t)(p - (float*)ws) * 4;
     return w;
@@ -447,10 +456,11 @@ int mhla_blockmix_bwd(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q
         RC(launch(k_mix<1, 0>, mgrid, dim3(NTHREADS), MIX_SMEM_FLOATS * 4, st, "k_mix<1,0>", m));
         // dW = sum_bh (<dG_i, KV_j> + <dn_i, z_j>)
         const int tiles = (M + 63) / 64;
-        DwArgs d{w.dg, w.kv, (long)D * D, normalize ? w.dn : nullptr, normalize ? w.z : nullptr, (long)S, w.dwp, M, tiles};
-        RC(launch(k_dw<0>, dim3(tiles * tiles, B * H), dim3(NTHREADS), DW_SMEM_FLOATS * 4, st, "k_dw", d));
-        RC(launch(k_dw_reduce<0>, dim3((M * M + 255) / 256), dim3(256), 0, st, "k_dw_reduce", (const float*)w.dwp,
-                  (const float*)nullptr, dW, M, M, B * H));
+        const int nsplit = dw_splits(tiles * tiles * B * H, (long)D * D);
+        DwArgs d{w.dg, w.kv, (long)D * D, normalize ? w.dn : nullptr, normalize ? w.z : nullptr, (long)S, w.dwp, M, tiles, nsplit};
+        RC(launch(k_dw<0>, dim3(tiles * tiles, B * H, nsplit), dim3(NTHREADS), DW_SMEM_FLOATS * 4, st, "k_dw", d));
+        RC(launch(k_dw_reduce<0>, dim3((M * M + 63) / 64), dim3(256), 0, st, "k_dw_reduce", (const float*)w.dwp,
+                  (const float*)nullptr, dW, M, M, B * H * nsplit, B * H));
         // dQ, dK, dV
         TokArgs t{};
         t.q = cv(q_num); t.k = cv(k_num); t.v = cv(v); t.qd = cv(q_den); t.kd = cv(k_den); t.dout = cv(dout);
@@ -511,10 +521,11 @@ int mhla_causal_bwd(mhla_view q, mhla_view k, mhla_view v, const float* mix, int
         CsTokArgs t{cv(q), cv(k), cv(v), cv(dout), cmv(dq), cmv(dk), cmv(dv), mix, ldmix, w.P, w.dS, w.diag, H, n, K, V, (long)T, scale};
         RC(launch(k_cs_bwd_tok<ET>, dim3(n, B * H), dim3(NTHREADS), CS_TOK_SMEM_FLOATS * 4, st, "k_cs_bwd_tok", t));
         const int tiles = (n + 63) / 64;
-        DwArgs d{w.dP, w.S, (long)K * V, nullptr, nullptr, 0, w.dwp, n, tiles};
-        RC(launch(k_dw<1>, dim3(tiles * tiles, B * H), dim3(NTHREADS), DW_SMEM_FLOATS * 4, st, "k_dw<1>", d));
-        RC(launch(k_dw_reduce<1>, dim3((n * n + 255) / 256), dim3(256), 0, st, "k_dw_reduce<1>", (const float*)w.dwp,
-                  (const float*)w.diag, dmix, lddmix, n, B * H));
+        const int nsplit = dw_splits(tiles * tiles * B * H, (long)K * V);
+        DwArgs d{w.dP, w.S, (long)K * V, nullptr, nullptr, 0, w.dwp, n, tiles, nsplit};
+        RC(launch(k_dw<1>, dim3(tiles * tiles, B * H, nsplit), dim3(NTHREADS), DW_SMEM_FLOATS * 4, st, "k_dw<1>", d));
+        RC(launch(k_dw_reduce<1>, dim3((n * n + 63) / 64), dim3(256), 0, st, "k_dw_reduce<1>", (const float*)w.dwp,
+                  (const float*)w.diag, dmix, lddmix, n, B * H * nsplit, B * H));
     });
     return MHLA_OK;
 }
