@@ -13,6 +13,7 @@
 
 #include "blockmix.cuh"
 #include "causal.cuh"
+#include "causal_bf16.cuh"
 #include "epilogue.cuh"
 #include "fused.cuh"
 #include "fused_tile16.cuh"
@@ -160,6 +161,9 @@ FastWs fast_carve(void* ws, int B, int H, int M, int S) {
     return w;
 }
 bool view_ok16(const mhla_view& v) { return v.ptr && ((uintptr_t)v.ptr % 16) == 0 && ((v.sb | v.sn | v.sh) & 7) == 0; }
+bool view_ok16m(const mhla_mview& v) { return v.ptr && ((uintptr_t)v.ptr % 16) == 0 && ((v.sb | v.sn | v.sh) & 7) == 0; }
+// bf16-MFMA token kernels of the causal operator (causal_bf16.cuh)
+bool cs_bf16_ok(int K, int V, int dtype) { return dtype == MHLA_BF16 && (K & 63) == 0 && (V & 63) == 0 && !getenv("MHLA_CAUSAL_GENERIC"); }
 bool fast_shape_ok(int M, int D, int dtype, bool split) { return dtype == MHLA_BF16 && D == 64 && M <= 64 && !split; }
 // small-sequence single-launch path (smalln.cuh): S = 16 tokens per block, at most 16 blocks, D <= 80
 bool sn_shape_ok(int M, int S, int D, int dtype, bool split) {
@@ -488,9 +492,20 @@ int mhla_causal_fwd(mhla_view q, mhla_view k, mhla_view v, const float* mix, int
     if (!ws || ws_bytes < w.total_fwd) return fail(MHLA_EINVAL, "workspace too small: %zu < %zu bytes", ws_bytes, w.total_fwd);
     if (((uintptr_t)ws) % 16) return fail(MHLA_EINVAL, "workspace not 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
+    const long E = (long)K * V;
+    if (cs_bf16_ok(K, V, dtype) && view_ok16(q) && view_ok16(k) && view_ok16(v) && view_ok16m(out)) {
+        // bf16 pipeline (causal_bf16.cuh): bf16 chunk summaries, bf16 MFMA everywhere
+        fast::CsfStateArgs s{cv(k), cv(v), (uint16_t*)w.S, H, n, K, V, (long)T, 1.f};
+        RC(launch(fast::k_csf_state, dim3(n, B * H, K / 64), dim3(NTHREADS), fast::CSF_STATE_SMEM, st, "k_csf_state", s));
+        fast::CsfMixArgs m{mix, ldmix, (const uint16_t*)w.S, (uint16_t*)w.P, n, E};
+        RC(launch(fast::k_csf_mix<0>, dim3((unsigned)(E / fast::MX_TE), (n + 63) / 64, B * H), dim3(NTHREADS), fast::CSF_MIX_SMEM, st, "k_csf_mix<0>", m));
+        CsOutArgs o{cv(q), cv(k), cv(v), cmv(out), mix, ldmix, w.P, H, n, K, V, (long)T, scale};
+        RC(launch(fast::k_csf_out<uint16_t>, dim3(n, B * H, V / 64), dim3(NTHREADS), fast::CSF_OUT_SMEM, st, "k_csf_out", o));
+        return MHLA_OK;
+    }
     DISPATCH_T(dtype, {
         RC(cs_xty<ET>(k, v, w.S, 1.f, B, T, H, n, K, V, st));
-        MixArgs m{mix, ldmix, w.S, w.P, n, (long)K * V};
+        MixArgs m{mix, ldmix, w.S, w.P, n, E};
         dim3 mgrid((unsigned)((m.E + MIX_TE - 1) / MIX_TE), (n + MIX_TI - 1) / MIX_TI, B * H);
         RC(launch(k_mix<0, 1>, mgrid, dim3(NTHREADS), MIX_SMEM_FLOATS * 4, st, "k_mix<0,1>", m));
         CsOutArgs o{cv(q), cv(k), cv(v), cmv(out), mix, ldmix, w.P, H, n, K, V, (long)T, scale};
@@ -510,19 +525,40 @@ int mhla_causal_bwd(mhla_view q, mhla_view k, mhla_view v, const float* mix, int
     if (!ws || ws_bytes < w.total_bwd) return fail(MHLA_EINVAL, "workspace too small: %zu < %zu bytes", ws_bytes, w.total_bwd);
     if (((uintptr_t)ws) % 16) return fail(MHLA_EINVAL, "workspace not 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
+    const long E = (long)K * V;
+    const int tiles = (n + 63) / 64;
+    const int nsplit = dw_splits(tiles * tiles * B * H, E);
+    if (cs_bf16_ok(K, V, dtype) && view_ok16(q) && view_ok16(k) && view_ok16(v) && view_ok16(dout) && view_ok16m(dq) &&
+        view_ok16m(dk) && view_ok16m(dv)) {
+        uint16_t *S = (uint16_t*)w.S, *P = (uint16_t*)w.P, *dP = (uint16_t*)w.dP, *dS = (uint16_t*)w.dS;
+        const dim3 sgrid(n, B * H, K / 64), mgrid((unsigned)(E / fast::MX_TE), tiles, B * H);
+        fast::CsfStateArgs s{cv(k), cv(v), S, H, n, K, V, (long)T, 1.f};
+        RC(launch(fast::k_csf_state, sgrid, dim3(NTHREADS), fast::CSF_STATE_SMEM, st, "k_csf_state", s));
+        fast::CsfMixArgs m{mix, ldmix, S, P, n, E};
+        RC(launch(fast::k_csf_mix<0>, mgrid, dim3(NTHREADS), fast::CSF_MIX_SMEM, st, "k_csf_mix<0>", m));
+        fast::CsfStateArgs sp{cv(q), cv(dout), dP, H, n, K, V, (long)T, scale};
+        RC(launch(fast::k_csf_state, sgrid, dim3(NTHREADS), fast::CSF_STATE_SMEM, st, "k_csf_state", sp));
+        fast::CsfMixArgs mt{mix, ldmix, dP, dS, n, E};
+        RC(launch(fast::k_csf_mix<1>, mgrid, dim3(NTHREADS), fast::CSF_MIX_SMEM, st, "k_csf_mix<1>", mt));
+        CsTokArgs t{cv(q), cv(k), cv(v), cv(dout), cmv(dq), cmv(dk), cmv(dv), mix, ldmix, w.P, w.dS, w.diag, H, n, K, V, (long)T, scale};
+        RC(launch(fast::k_csf_bwd_tok<uint16_t>, dim3(n, B * H), dim3(NTHREADS), fast::CSF_TOK_SMEM, st, "k_csf_bwd_tok", t));
+        fast::CsfDwArgs d{dP, S, E, w.dwp, n, tiles, nsplit};
+        RC(launch(fast::k_csf_dw, dim3(tiles * tiles, B * H, nsplit), dim3(NTHREADS), fast::CSF_DW_SMEM, st, "k_csf_dw", d));
+        RC(launch(k_dw_reduce<1>, dim3((n * n + 63) / 64), dim3(256), 0, st, "k_dw_reduce<1>", (const float*)w.dwp,
+                  (const float*)w.diag, dmix, lddmix, n, B * H * nsplit, B * H));
+        return MHLA_OK;
+    }
     DISPATCH_T(dtype, {
         RC(cs_xty<ET>(k, v, w.S, 1.f, B, T, H, n, K, V, st));
-        MixArgs m{mix, ldmix, w.S, w.P, n, (long)K * V};
+        MixArgs m{mix, ldmix, w.S, w.P, n, E};
         dim3 mgrid((unsigned)((m.E + MIX_TE - 1) / MIX_TE), (n + MIX_TI - 1) / MIX_TI, B * H);
         RC(launch(k_mix<0, 1>, mgrid, dim3(NTHREADS), MIX_SMEM_FLOATS * 4, st, "k_mix<0,1>", m));
         RC(cs_xty<ET>(q, dout, w.dP, scale, B, T, H, n, K, V, st));
-        MixArgs mt{mix, ldmix, w.dP, w.dS, n, (long)K * V};
+        MixArgs mt{mix, ldmix, w.dP, w.dS, n, E};
         RC(launch(k_mix<1, 1>, mgrid, dim3(NTHREADS), MIX_SMEM_FLOATS * 4, st, "k_mix<1,1>", mt));
         CsTokArgs t{cv(q), cv(k), cv(v), cv(dout), cmv(dq), cmv(dk), cmv(dv), mix, ldmix, w.P, w.dS, w.diag, H, n, K, V, (long)T, scale};
         RC(launch(k_cs_bwd_tok<ET>, dim3(n, B * H), dim3(NTHREADS), CS_TOK_SMEM_FLOATS * 4, st, "k_cs_bwd_tok", t));
-        const int tiles = (n + 63) / 64;
-        const int nsplit = dw_splits(tiles * tiles * B * H, (long)K * V);
-        DwArgs d{w.dP, w.S, (long)K * V, nullptr, nullptr, 0, w.dwp, n, tiles, nsplit};
+        DwArgs d{w.dP, w.S, E, nullptr, nullptr, 0, w.dwp, n, tiles, nsplit};
         RC(launch(k_dw<1>, dim3(tiles * tiles, B * H, nsplit), dim3(NTHREADS), DW_SMEM_FLOATS * 4, st, "k_dw<1>", d));
         RC(launch(k_dw_reduce<1>, dim3((n * n + 63) / 64), dim3(256), 0, st, "k_dw_reduce<1>", (const float*)w.dwp,
                   (const float*)w.diag, dmix, lddmix, n, B * H * nsplit, B * H));

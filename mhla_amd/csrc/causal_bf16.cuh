@@ -1,0 +1,498 @@
+// bf16-MFMA token kernels of the causal chunk-mixing operator (bf16 tensors, K and V multiples of 64).
+// Same structure as k_cs_out / k_cs_bwd_tok (causal.cuh): every contraction is a 64 x 64 x 64 tile product, but the
+// tiles live in LDS as bf16 ([64][72], row-major) and run on v_mfma_f32_16x16x32_bf16: operands whose reduction
+// index is the row index of the staged tile come through the hardware transpose read.
+// The chunk summaries S, P, dP, dS are kept as bf16 [bh][n][K][V] in the workspace (half the HBM traffic of the
+// generic path's fp32 summaries), produced by k_csf_state (X^T Y per chunk), mixed across chunks by k_csf_mix
+// (mixing weights split into bf16 hi + lo so they keep ~16 mantissa bits) and reduced to dmix by k_csf_dw.
+// For bf16 inputs all products are exact and accumulate in fp32; intermediates that feed a second contraction
+// (tril(QK^T), tril(dO V^T), S, P, dP, dS) carry one bf16 rounding each.
+#pragma once
+#include "causal.cuh"
+#include "fused.cuh"
+
+namespace mhla {
+namespace fast {
+
+constexpr int CLD = 72;                 // LDS row stride (bf16) of the 64 x 64 tiles
+constexpr int CT = CS * CLD;            // elements per tile
+
+// 64 token rows x 64 columns (starting at column c0) of a view -> LDS tile; rows >= rv zero.  256 threads.
+__device__ __forceinline__ void cs_stage_tok(u16* __restrict__ dst, const u16* __restrict__ base, long sn, long p0, int rv, int tid) {
+    const int r = tid >> 2, c = (tid & 3) * 16;
+    uint4 x = make_uint4(0, 0, 0, 0), y = x;
+    if (r < rv) {
+        const u16* src = base + (p0 + r) * sn + c;
+        x = *reinterpret_cast<const uint4*>(src);
+        y = *reinterpret_cast<const uint4*>(src + 8);
+    }
+    *reinterpret_cast<uint4*>(dst + r * CLD + c) = x;
+    *reinterpret_cast<uint4*>(dst + r * CLD + c + 8) = y;
+}
+// 64 x 64 fp32 slice (row stride ld) of a chunk summary -> bf16 LDS tile
+__device__ __forceinline__ void cs_stage_state(u16* __restrict__ dst, const float* __restrict__ src, long ld, int tid) {
+    const int r = tid >> 2, c = (tid & 3) * 16;
+    const float* s = src + (long)r * ld + c;
+    f32x4 v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const f32x4*>(s + 4 * i);
+    uint4 x, y;
+    x.x = pack_bf16x2(v[0][0], v[0][1]); x.y = pack_bf16x2(v[0][2], v[0][3]);
+    x.z = pack_bf16x2(v[1][0], v[1][1]); x.w = pack_bf16x2(v[1][2], v[1][3]);
+    y.x = pack_bf16x2(v[2][0], v[2][1]); y.y = pack_bf16x2(v[2][2], v[2][3]);
+    y.z = pack_bf16x2(v[3][0], v[3][1]); y.w = pack_bf16x2(v[3][2], v[3][3]);
+    *reinterpret_cast<uint4*>(dst + r * CLD + c) = x;
+    *reinterpret_cast<uint4*>(dst + r * CLD + c + 8) = y;
+}
+
+// 64 x 64 bf16 slice (row stride ld) of a chunk summary -> LDS tile
+__device__ __forceinline__ void cs_stage_state(u16* __restrict__ dst, const u16* __restrict__ src, long ld, int tid) {
+    const int r = tid >> 2, c = (tid & 3) * 16;
+    const u16* s = src + (long)r * ld + c;
+    const uint4 x = *reinterpret_cast<const uint4*>(s), y = *reinterpret_cast<const uint4*>(s + 8);
+    *reinterpret_cast<uint4*>(dst + r * CLD + c) = x;
+    *reinterpret_cast<uint4*>(dst + r * CLD + c + 8) = y;
+}
+
+// acc[tn] += A B for output rows 16 wave .. and the four 16-column tiles, reduction length 64.
+//   AT false: A[m][k] = Xs[m][k]   AT true: A[m][k] = Xs[k][m]      (Xs, Ys: [64][CLD] bf16 tiles)
+//   BT false: B[k][n] = Ys[n][k]   BT true: B[k][n] = Ys[k][n]
+template <bool AT, bool BT>
+__device__ __forceinline__ void tile_mma(f32x4 (&acc)[4], const u16* __restrict__ Xs, const u16* __restrict__ Ys, int wave, int lane) {
+    const int n = lane & 15, kg = lane >> 4;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 av = AT ? tr_read8(Xs, CLD, ks * 32, wave * 16, lane)
+                             : *reinterpret_cast<const bf16x8*>(Xs + (wave * 16 + n) * CLD + ks * 32 + kg * 8);
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) {
+            const bf16x8 bv = BT ? tr_read8(Ys, CLD, ks * 32, tn * 16, lane)
+                                 : *reinterpret_cast<const bf16x8*>(Ys + (tn * 16 + n) * CLD + ks * 32 + kg * 8);
+            acc[tn] = mfma_bf16(av, bv, acc[tn]);
+        }
+    }
+}
+__device__ __forceinline__ void zero4(f32x4 (&x)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+// C-layout accumulators (row = 16 wave + 4 kg + r, col = 16 tn + n) -> bf16 LDS tile
+__device__ __forceinline__ void cs_put(u16* __restrict__ dst, const f32x4 (&x)[4], float mul, int wave, int lane) {
+    const int n = lane & 15, kg = lane >> 4;
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dst[(wave * 16 + kg * 4 + r) * CLD + tn * 16 + n] = cvt_bf16(mul * x[tn][r]);
+}
+__device__ __forceinline__ void cs_store_tok(u16* __restrict__ base, long sn, long p0, int rv, const u16* __restrict__ Os, int tid) {
+    const int r = tid >> 2, c = (tid & 3) * 16;
+    if (r < rv) {
+        u16* d = base + (p0 + r) * sn + c;
+        *reinterpret_cast<uint4*>(d) = *reinterpret_cast<const uint4*>(Os + r * CLD + c);
+        *reinterpret_cast<uint4*>(d + 8) = *reinterpret_cast<const uint4*>(Os + r * CLD + c + 8);
+    }
+}
+
+constexpr int CSF_OUT_SMEM = 4 * CT * 2;
+
+// O_i[:, v-slice] = scale (Q_i P_i + m_ii tril(Q_i K_i^T) V_i)      grid (n, bh, V / 64)
+template <typename ST>   // ST: element type of the chunk summaries (u16 = bf16, float)
+__global__ __launch_bounds__(NTHREADS) void k_csf_out(const CsOutArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u16* Qs = reinterpret_cast<u16*>(smem_raw);
+    u16* Ks = Qs + CT;
+    u16* Ps = Ks + CT;      // P slice, later the V slice
+    u16* As = Ps + CT;      // m_ii tril(QK^T), later the output staging
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, n = lane & 15, kg = lane >> 4;
+    const int ci = blockIdx.x, bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
+    const int v0 = blockIdx.z * 64;
+    const long p0 = (long)ci * CS;
+    const int rv = (int)min((long)CS, a.T - p0);
+    const u16* qb = (const u16*)a.q.ptr + b * a.q.sb + h * a.q.sh;
+    const u16* kb = (const u16*)a.k.ptr + b * a.k.sb + h * a.k.sh;
+    const u16* vb = (const u16*)a.v.ptr + b * a.v.sb + h * a.v.sh;
+    u16* ob = (u16*)a.o.ptr + b * a.o.sb + h * a.o.sh;
+    const ST* Pi = reinterpret_cast<const ST*>(a.P) + ((long)bh * a.n + ci) * a.K * a.V;
+
+    f32x4 accO[4], accA[4];
+    zero4(accO);
+    zero4(accA);
+    for (int ks = 0; ks < a.K; ks += 64) {
+        cs_stage_tok(Qs, qb + ks, a.q.sn, p0, rv, tid);
+        cs_stage_tok(Ks, kb + ks, a.k.sn, p0, rv, tid);
+        cs_stage_state(Ps, Pi + (long)ks * a.V + v0, a.V, tid);
+        __syncthreads();
+        tile_mma<false, false>(accA, Qs, Ks, wave, lane);   // Q K^T
+        tile_mma<false, true>(accO, Qs, Ps, wave, lane);    // Q P
+        __syncthreads();
+    }
+    const float mii = a.mix[(long)ci * a.ldmix + ci];
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = wave * 16 + kg * 4 + r, col = tn * 16 + n;
+            As[row * CLD + col] = cvt_bf16(col <= row ? mii * accA[tn][r] : 0.f);
+        }
+    cs_stage_tok(Ps, vb + v0, a.v.sn, p0, rv, tid);
+    __syncthreads();
+    tile_mma<false, true>(accO, As, Ps, wave, lane);        // tril(QK^T) V
+    __syncthreads();
+    cs_put(As, accO, a.scale, wave, lane);
+    __syncthreads();
+    cs_store_tok(ob + v0, a.o.sn, p0, rv, As, tid);
+}
+
+constexpr int CSF_TOK_SMEM = 6 * CT * 2 + 16;
+
+template <typename ST>
+__global__ __launch_bounds__(NTHREADS) void k_csf_bwd_tok(const CsTokArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u16* As = reinterpret_cast<u16*>(smem_raw);   // m_ii scale tril(Q K^T)   [c][c']
+    u16* dAs = As + CT;                           // m_ii tril(dO V^T)        [c][c']
+    u16* X1 = dAs + CT;
+    u16* X2 = X1 + CT;
+    u16* B1 = X2 + CT;
+    u16* B2 = B1 + CT;
+    float* red = reinterpret_cast<float*>(B2 + CT);
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, n = lane & 15, kg = lane >> 4;
+    const int ci = blockIdx.x, bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
+    const long p0 = (long)ci * CS;
+    const int rv = (int)min((long)CS, a.T - p0);
+    const int K = a.K, V = a.V;
+    auto base = [&](const View& w) { return (const u16*)w.ptr + b * w.sb + h * w.sh; };
+    auto mbase = [&](const MView& w) { return (u16*)w.ptr + b * w.sb + h * w.sh; };
+    const u16 *qb = base(a.q), *kb = base(a.k), *vb = base(a.v), *gb = base(a.dout);
+    const ST* Pi = reinterpret_cast<const ST*>(a.P) + ((long)bh * a.n + ci) * K * V;
+    const ST* dSi = reinterpret_cast<const ST*>(a.dS) + ((long)bh * a.n + ci) * K * V;
+    const float mii = a.mix[(long)ci * a.ldmix + ci];
+
+    // ---- step 1: A = tril(Q K^T), dA = tril(dO V^T), diag = scale * sum(A . dA) ----
+    f32x4 acc1[4], acc2[4];
+    zero4(acc1);
+    zero4(acc2);
+    for (int ks = 0; ks < K; ks += 64) {
+        cs_stage_tok(X1, qb + ks, a.q.sn, p0, rv, tid);
+        cs_stage_tok(X2, kb + ks, a.k.sn, p0, rv, tid);
+        __syncthreads();
+        tile_mma<false, false>(acc1, X1, X2, wave, lane);
+        __syncthreads();
+    }
+    for (int vs = 0; vs < V; vs += 64) {
+        cs_stage_tok(X1, gb + vs, a.dout.sn, p0, rv, tid);
+        cs_stage_tok(X2, vb + vs, a.v.sn, p0, rv, tid);
+        __syncthreads();
+        tile_mma<false, false>(acc2, X1, X2, wave, lane);
+        __syncthreads();
+    }
+    float dsum = 0.f;
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = wave * 16 + kg * 4 + r, col = tn * 16 + n;
+            const bool keep = col <= row;
+            const float av = keep ? acc1[tn][r] : 0.f, dv = keep ? acc2[tn][r] : 0.f;
+            dsum += av * dv;
+            As[row * CLD + col] = cvt_bf16(mii * a.scale * av);
+            dAs[row * CLD + col] = cvt_bf16(mii * dv);
+        }
+    dsum = wave_sum(dsum);
+    if (lane == 0) red[wave] = dsum;
+    __syncthreads();
+    if (tid == 0) a.diag[(long)bh * a.n + ci] = a.scale * (red[0] + red[1] + red[2] + red[3]);
+
+    // ---- step 2: dQ, dK per K slice ----
+    for (int ks = 0; ks < K; ks += 64) {
+        f32x4 acc3[4];
+        zero4(acc1);   // dO P^T + m_ii dA K
+        zero4(acc2);   // V dS^T
+        zero4(acc3);   // m_ii dA^T Q
+        for (int vs = 0; vs < V; vs += 64) {
+            cs_stage_tok(X1, gb + vs, a.dout.sn, p0, rv, tid);
+            cs_stage_tok(X2, vb + vs, a.v.sn, p0, rv, tid);
+            cs_stage_state(B1, Pi + (long)ks * V + vs, V, tid);
+            cs_stage_state(B2, dSi + (long)ks * V + vs, V, tid);
+            __syncthreads();
+            tile_mma<false, false>(acc1, X1, B1, wave, lane);   // dO P^T : B[k = v][n = kk] = P[kk][v]
+            tile_mma<false, false>(acc2, X2, B2, wave, lane);   // V dS^T
+            __syncthreads();
+        }
+        cs_stage_tok(X1, kb + ks, a.k.sn, p0, rv, tid);
+        cs_stage_tok(X2, qb + ks, a.q.sn, p0, rv, tid);
+        __syncthreads();
+        tile_mma<false, true>(acc1, dAs, X1, wave, lane);       // dA K      : B[k = c'][n = kk] = K[c'][kk]
+        tile_mma<true, true>(acc3, dAs, X2, wave, lane);        // dA^T Q    : A[m = c'][k = c] = dA[c][c']
+        __syncthreads();
+        cs_put(B1, acc1, a.scale, wave, lane);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc2[i] += a.scale * acc3[i];
+        cs_put(B2, acc2, 1.f, wave, lane);
+        __syncthreads();
+        cs_store_tok(mbase(a.dq) + ks, a.dq.sn, p0, rv, B1, tid);
+        cs_store_tok(mbase(a.dk) + ks, a.dk.sn, p0, rv, B2, tid);
+        __syncthreads();
+    }
+
+    // ---- step 3: dV per V slice ----
+    for (int vs = 0; vs < V; vs += 64) {
+        zero4(acc1);
+        for (int ks = 0; ks < K; ks += 64) {
+            cs_stage_tok(X1, kb + ks, a.k.sn, p0, rv, tid);
+            cs_stage_state(B1, dSi + (long)ks * V + vs, V, tid);
+            __syncthreads();
+            tile_mma<false, true>(acc1, X1, B1, wave, lane);    // K dS : B[k = kk][n = v] = dS[kk][v]
+            __syncthreads();
+        }
+        cs_stage_tok(X2, gb + vs, a.dout.sn, p0, rv, tid);
+        __syncthreads();
+        tile_mma<true, true>(acc1, As, X2, wave, lane);         // A^T dO
+        __syncthreads();
+        cs_put(B1, acc1, 1.f, wave, lane);
+        __syncthreads();
+        cs_store_tok(mbase(a.dv) + vs, a.dv.sn, p0, rv, B1, tid);
+        __syncthreads();
+    }
+}
+
+
+// -------------------------------------------------------------------------------------------------
+// k_csf_state: out[bh][ci][kk][v] (bf16) = mul * sum_{c in chunk ci} X[c][kk] Y[c][v]        grid (n, bh, K / 64)
+//   forward: X = K, Y = V (S_j, naive.py:60);  backward: X = Q, Y = dO, mul = scale (dP_i)
+// -------------------------------------------------------------------------------------------------
+struct CsfStateArgs {
+    View x, y;
+    u16* out;
+    int H, n, K, V;
+    long T;
+    float mul;
+};
+constexpr int CSF_STATE_SMEM = 3 * CT * 2;
+
+__global__ __launch_bounds__(NTHREADS) void k_csf_state(const CsfStateArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u16* Xs = reinterpret_cast<u16*>(smem_raw);
+    u16* Ys = Xs + CT;
+    u16* Os = Ys + CT;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int ci = blockIdx.x, bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H, ks = blockIdx.z * 64;
+    const long p0 = (long)ci * CS;
+    const int rv = (int)min((long)CS, a.T - p0);
+    const u16* xb = (const u16*)a.x.ptr + b * a.x.sb + h * a.x.sh + ks;
+    const u16* yb = (const u16*)a.y.ptr + b * a.y.sb + h * a.y.sh;
+    u16* ob = a.out + (((long)bh * a.n + ci) * a.K + ks) * a.V;
+    const int r = tid >> 2, c = (tid & 3) * 16;
+
+    cs_stage_tok(Xs, xb, a.x.sn, p0, rv, tid);
+    uint4 y0 = make_uint4(0, 0, 0, 0), y1 = y0;
+    if (r < rv) {
+        const u16* src = yb + (p0 + r) * a.y.sn + c;
+        y0 = *reinterpret_cast<const uint4*>(src);
+        y1 = *reinterpret_cast<const uint4*>(src + 8);
+    }
+    for (int vs = 0; vs < a.V; vs += 64) {
+        *reinterpret_cast<uint4*>(Ys + r * CLD + c) = y0;
+        *reinterpret_cast<uint4*>(Ys + r * CLD + c + 8) = y1;
+        __syncthreads();
+        if (vs + 64 < a.V && r < rv) {   // next V slice in flight during the tile product
+            const u16* src = yb + (p0 + r) * a.y.sn + vs + 64 + c;
+            y0 = *reinterpret_cast<const uint4*>(src);
+            y1 = *reinterpret_cast<const uint4*>(src + 8);
+        }
+        f32x4 acc[4];
+        zero4(acc);
+        tile_mma<true, true>(acc, Xs, Ys, wave, lane);   // rows kk, columns v, reduction over the chunk's tokens
+        cs_put(Os, acc, a.mul, wave, lane);
+        __syncthreads();
+        u16* d = ob + (long)r * a.V + vs + c;
+        *reinterpret_cast<uint4*>(d) = *reinterpret_cast<const uint4*>(Os + r * CLD + c);
+        *reinterpret_cast<uint4*>(d + 8) = *reinterpret_cast<const uint4*>(Os + r * CLD + c + 8);
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// k_csf_mix: mixing across chunks as a GEMM over the flattened summaries (E = K V elements per chunk):
+//   TRANS 0: out[i][e] = sum_{j < i} m[i][j] in[j][e]      (P_i, naive.py:63-66)
+//   TRANS 1: out[j][e] = sum_{i > j} m[i][j] in[i][e]      (dS_j)
+// grid (E / 256, ceil(n / 64), bh); each wave owns 16 output chunks x 256 elements.  The A operand (mixing
+// weights) is built in registers from the fp32 matrix as bf16 hi + lo; the B operand is a [32 chunks x 256] bf16
+// tile in LDS read through the transpose read; tiles are double buffered with the next one in flight in registers.
+// -------------------------------------------------------------------------------------------------
+struct CsfMixArgs {
+    const float* W;
+    int ldw;
+    const u16* in;
+    u16* out;
+    int n;
+    long E;
+};
+constexpr int MX_TE = 256, MX_LD = MX_TE + 8, MX_KS = 32;
+constexpr int CSF_MIX_SMEM = 64 * MX_LD * 2;   // two [32][MX_LD] input tiles, reused as the [64][MX_LD] output staging
+
+template <int TRANS>
+__global__ __launch_bounds__(NTHREADS, 2) void k_csf_mix(const CsfMixArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u16* Xs = reinterpret_cast<u16*>(smem_raw);
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nl = lane & 15, kg = lane >> 4;
+    const long e0 = (long)blockIdx.x * MX_TE;
+    const int i0 = blockIdx.y * 64, bh = blockIdx.z, n = a.n;
+    const u16* inb = a.in + (long)bh * n * a.E + e0;
+    u16* outb = a.out + (long)bh * n * a.E + e0;
+    const int kbeg = TRANS ? i0 : 0, kend = TRANS ? n : min(n, i0 + 64);
+    const int steps = (kend - kbeg + MX_KS - 1) / MX_KS;
+    const int sr = tid >> 3, sc = (tid & 7) * 8;   // staging: row sr of the tile, 4 x 16 B at columns sc + 64 u
+
+    uint4 pre[4];
+    auto fetch = [&](int step) {
+        const int row = kbeg + step * MX_KS + sr;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) pre[u] = make_uint4(0, 0, 0, 0);
+        if (row < n) {
+            const u16* src = inb + (long)row * a.E + sc;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) pre[u] = *reinterpret_cast<const uint4*>(src + 64 * u);
+        }
+    };
+    auto commit = [&](int buf) {
+        u16* d = Xs + buf * (MX_KS * MX_LD) + sr * MX_LD + sc;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) *reinterpret_cast<uint4*>(d + 64 * u) = pre[u];
+    };
+
+    f32x4 acc[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int orow = i0 + wave * 16 + nl;   // output chunk of this lane's A row
+
+    if (steps > 0) {
+        fetch(0);
+        commit(0);
+    }
+    for (int step = 0; step < steps; ++step) {
+        const int buf = step & 1;
+        __syncthreads();
+        if (step + 1 < steps) fetch(step + 1);
+        // mixing weights for (orow, k0 .. k0 + 7), masked, split into bf16 hi + lo
+        const int k0 = kbeg + step * MX_KS + kg * 8;
+        bf16x8 ah, al;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int kk = k0 + t;
+            float w = 0.f;
+            if (orow < n && kk < n && (TRANS ? kk > orow : kk < orow)) w = TRANS ? a.W[(long)kk * a.ldw + orow] : a.W[(long)orow * a.ldw + kk];
+            const __bf16 hi = (__bf16)w;
+            ah[t] = hi;
+            al[t] = (__bf16)(w - (float)hi);
+        }
+        const u16* tile = Xs + buf * (MX_KS * MX_LD);
+#pragma unroll
+        for (int t4 = 0; t4 < 16; t4 += 4) {
+            bf16x8 bv[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) bv[t] = tr_read8(tile, MX_LD, 0, (t4 + t) * 16, lane);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t4 + t] = mfma_bf16(ah, bv[t], acc[t4 + t]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t4 + t] = mfma_bf16(al, bv[t], acc[t4 + t]);
+        }
+        if (step + 1 < steps) commit(buf ^ 1);
+    }
+    __syncthreads();
+    // C layout (row = 16 wave + 4 kg + r, column = 16 t + nl) -> staging -> 512-byte rows
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Xs[(wave * 16 + kg * 4 + r) * MX_LD + t * 16 + nl] = cvt_bf16(acc[t][r]);
+    __syncthreads();
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        const int row = sr + 32 * rr;
+        if (i0 + row < n) {
+            u16* d = outb + (long)(i0 + row) * a.E + sc;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) *reinterpret_cast<uint4*>(d + 64 * u) = *reinterpret_cast<const uint4*>(Xs + row * MX_LD + sc + 64 * u);
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// k_csf_dw: strictly-lower part of dmix, dwp[bh][split][i][j] = sum_{e in slice} dP_i[e] S_j[e].
+// grid (tile pairs, bh, E-slices) as k_dw<1>; both operands are read straight from HBM in MFMA layout (the
+// reduction index e is contiguous in memory for both).  Each wave takes a quarter of the slice for the whole
+// 64 x 64 tile; the four partial tiles are summed through LDS in a fixed order.
+// -------------------------------------------------------------------------------------------------
+struct CsfDwArgs {
+    const u16* x;   // dP [bh][n][E]
+    const u16* y;   // S  [bh][n][E]
+    long E;
+    float* out;     // [bh][nsplit][n][n]
+    int n, tiles, nsplit;
+};
+constexpr int CSF_DW_LD = 68;
+constexpr int CSF_DW_SMEM = 64 * CSF_DW_LD * 4;
+
+__global__ __launch_bounds__(NTHREADS) void k_csf_dw(const CsfDwArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* Rs = reinterpret_cast<float*>(smem_raw);
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nl = lane & 15, kg = lane >> 4;
+    const int it = blockIdx.x / a.tiles, jt = blockIdx.x - it * a.tiles, bh = blockIdx.y, split = blockIdx.z, n = a.n;
+    const int i0 = it * 64, j0 = jt * 64;
+    if (j0 > i0 + 63) return;   // tile entirely above the diagonal
+    const long per = ((a.E + a.nsplit - 1) / a.nsplit + 255) & ~255L;   // slice: multiple of 4 waves x 64 elements
+    const long ebeg = (long)split * per, eend = min(a.E, ebeg + per);
+    const long wlen = (eend > ebeg ? (eend - ebeg) : 0) / 4;             // E is a multiple of 4096: wlen multiple of 64
+    const long wbeg = ebeg + wave * wlen;
+    // each lane covers 16 consecutive e of a 64-element step: two k-steps of 8 (same permutation for both operands)
+    const u16* xp[4];
+    const u16* yp[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int ri = min(i0 + t * 16 + nl, n - 1), rj = min(j0 + t * 16 + nl, n - 1);
+        xp[t] = a.x + ((long)bh * n + ri) * a.E + wbeg + kg * 16;
+        yp[t] = a.y + ((long)bh * n + rj) * a.E + wbeg + kg * 16;
+    }
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (long e = 0; e < wlen; e += 64) {
+        bf16x8 xa[4][2], yb[4][2];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            xa[t][0] = *reinterpret_cast<const bf16x8*>(xp[t] + e);
+            xa[t][1] = *reinterpret_cast<const bf16x8*>(xp[t] + e + 8);
+            yb[t][0] = *reinterpret_cast<const bf16x8*>(yp[t] + e);
+            yb[t][1] = *reinterpret_cast<const bf16x8*>(yp[t] + e + 8);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma_bf16(xa[i][s], yb[j][s], acc[i][j]);
+    }
+    // sum the four waves' tiles in wave order
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float* d = Rs + (i * 16 + kg * 4 + r) * CSF_DW_LD + j * 16 + nl;
+                        *d = (w == 0 ? 0.f : *d) + acc[i][j][r];
+                    }
+        }
+        __syncthreads();
+    }
+    float* out = a.out + ((long)bh * a.nsplit + split) * n * n;
+    for (int v = tid; v < 64 * 64; v += NTHREADS) {
+        const int r = v >> 6, c = v & 63;
+        if (i0 + r < n && j0 + c < n) out[(long)(i0 + r) * n + j0 + c] = Rs[r * CSF_DW_LD + c];
+    }
+}
+
+}  // namespace fast
+}  // namespace mhla

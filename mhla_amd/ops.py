@@ -204,7 +204,6 @@ class _Causal(torch.autograd.Function):
         B, T, H, K = q.shape
         V = v.shape[-1]
         dout = _prep(dout.to(q.dtype))
-        dq, dk, dv = torch.empty_like(q, memory_format=torch.contiguous_format), None, None
         dk = torch.empty((B, T, H, K), dtype=q.dtype, device=q.device)
         dv = torch.empty((B, T, H, V), dtype=q.dtype, device=q.device)
         dq = torch.empty((B, T, H, K), dtype=q.dtype, device=q.device)

@@ -62,6 +62,50 @@ def test_causal_lowp(dtype):
     run_causal(2, 512, 4, 128, 256, 8, dtype)
 
 
+@pytest.mark.parametrize("T,K,V", [(256, 64, 64), (200, 64, 128), (50, 128, 64), (1000, 128, 256), (129, 256, 512),
+                                   (320, 64, 48), (320, 48, 64)])
+def test_causal_shapes_bf16(T, K, V):
+    """K and V multiples of 64 run the bf16-MFMA token kernels (ragged last chunk included); the others the generic ones."""
+    run_causal(2, T, 2, K, V, max(4, (T + 63) // 64), torch.bfloat16, seed=T + K)
+
+
+def test_causal_bf16_pipeline_vs_generic(monkeypatch):
+    """The bf16 pipeline (bf16 chunk summaries) against the generic fp32-compute kernels on the same bf16 inputs."""
+    import mhla_amd
+    q, k, v, mix, do = causal_inputs(2, 700, 2, 128, 128, 16, torch.bfloat16, seed=77)
+    res = {}
+    for tag in ("fast", "generic"):
+        if tag == "generic":
+            monkeypatch.setenv("MHLA_CAUSAL_GENERIC", "1")
+        dq, dk, dv, dm = (t.to(DEV).requires_grad_(True) for t in (q, k, v, mix.view(16, 16, 1, 1, 1, 1)))
+        out = mhla_amd.naive_chunk_simple_mhla_fixed(q=dq, k=dk, v=dv, mixing_matrix=dm)
+        out.backward(do.to(DEV))
+        res[tag] = (out, dq.grad, dk.grad, dv.grad, dm.grad)
+    for name, a, b in zip(("out", "dq", "dk", "dv", "dmix"), res["fast"], res["generic"]):
+        check(name, a, b.float().cpu(), GTOL[torch.bfloat16])
+
+
+def test_causal_bf16_strided_views():
+    """q/k/v as slices of one fused projection buffer (row stride 3 * H * K): the views stay 16-byte aligned."""
+    import mhla_amd
+    B, T, H, K, L = 2, 300, 3, 64, 8
+    g = torch.Generator().manual_seed(9)
+    qkv = torch.randn(B, T, 3, H, K, generator=g).bfloat16()
+    mix = torch.tril(torch.rand(L, L, generator=g).clamp(1e-5, 1))
+    do = torch.randn(B, T, H, K, generator=g).bfloat16()
+    q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+    want = orc.causal_fwd(q.float(), k.float(), v.float(), mix)
+    wg = orc.causal_bwd(q.float(), k.float(), v.float(), mix, do.float())
+    dqkv = qkv.to(DEV).requires_grad_(True)
+    dm = mix.view(L, L, 1, 1, 1, 1).to(DEV).requires_grad_(True)
+    out = mhla_amd.naive_chunk_simple_mhla_fixed(q=dqkv[:, :, 0], k=dqkv[:, :, 1], v=dqkv[:, :, 2], mixing_matrix=dm)
+    out.backward(do.to(DEV))
+    check("out", out, want, TOL[torch.bfloat16])
+    for i, n in enumerate(("dq", "dk", "dv")):
+        check(n, dqkv.grad[:, :, i], wg[n], GTOL[torch.bfloat16])
+    check("dmix", dm.grad.reshape(L, L), wg["dmix"], GTOL[torch.bfloat16])
+
+
 def test_causal_is_causal_and_recurrent_first_chunk():
     """Future tokens never influence earlier outputs; with T <= 64 the op is the single-chunk
     (token-recurrent) case."""
