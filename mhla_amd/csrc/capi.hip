@@ -18,6 +18,7 @@
 #include "fused.cuh"
 #include "fused_tile16.cuh"
 #include "smalln.cuh"
+#include "split.cuh"
 
 using namespace mhla;
 
@@ -161,6 +162,8 @@ FastWs fast_carve(void* ws, int B, int H, int M, int S) {
     return w;
 }
 bool view_ok16(const mhla_view& v) { return v.ptr && ((uintptr_t)v.ptr % 16) == 0 && ((v.sb | v.sn | v.sh) & 7) == 0; }
+// split-bf16 forward kernels (split.cuh): head dims 64 and 128, any dtype
+bool sp_shape_ok(int D, unsigned flags) { return (D == 64 || D == 128) && !(flags & MHLA_FLAG_FORCE_GENERIC); }
 bool view_ok16m(const mhla_mview& v) { return v.ptr && ((uintptr_t)v.ptr % 16) == 0 && ((v.sb | v.sn | v.sh) & 7) == 0; }
 // bf16-MFMA token kernels of the causal operator (causal_bf16.cuh)
 bool cs_bf16_ok(int K, int V, int dtype) { return dtype == MHLA_BF16 && (K & 63) == 0 && (V & 63) == 0 && !getenv("MHLA_CAUSAL_GENERIC"); }
@@ -193,8 +196,17 @@ int bm_state_and_mix(const mhla_view& q_num, const mhla_view& k_num, const mhla_
     a.out = w.kv; a.ksum = w.ksum; a.zo = w.z;
     a.H = H; a.M = M; a.S = S; a.D = D; a.eps = eps;
     a.relu = (flags & MHLA_FLAG_RELU_EPS) ? 1 : 0; a.normalize = normalize; a.split = split;
-    RC(launch(k_bm_state<T, DT, 0>, dim3(M, B * H), dim3(NTHREADS), state_smem_floats<DT>() * 4, st, "k_bm_state<0>", a));
     MixArgs m{W, ldw, w.kv, w.g, M, (long)D * D};
+    if constexpr (DT == 4 || DT == 8) {
+        if (sp_shape_ok(D, flags)) {   // split-bf16 MFMA kernels (split.cuh)
+            RC(launch(sp::k_sp_state<T, DT>, dim3(M, B * H), dim3(NTHREADS), sp::sp_state_smem<DT>(), st, "k_sp_state", a));
+            RC(launch(sp::k_sp_mix<0>, dim3((unsigned)(m.E / sp::SPM_TE), (M + 63) / 64, B * H), dim3(NTHREADS), sp::SP_MIX_SMEM, st, "k_sp_mix<0>", m));
+            if (normalize)
+                RC(launch(k_wz<0>, dim3((S + 63) / 64, (M + 63) / 64, B * H), dim3(NTHREADS), 0, st, "k_wz<0>", W, ldw, (const float*)w.z, w.ninv, M, S, eps));
+            return MHLA_OK;
+        }
+    }
+    RC(launch(k_bm_state<T, DT, 0>, dim3(M, B * H), dim3(NTHREADS), state_smem_floats<DT>() * 4, st, "k_bm_state<0>", a));
     dim3 grid((unsigned)((m.E + MIX_TE - 1) / MIX_TE), (M + MIX_TI - 1) / MIX_TI, B * H);
     RC(launch(k_mix<0, 0>, grid, dim3(NTHREADS), MIX_SMEM_FLOATS * 4, st, "k_mix<0,0>", m));
     if (normalize)
@@ -361,7 +373,14 @@ int mhla_blockmix_fwd(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q
         o.q = cv(q_num); o.o = cmv(out); o.idx = block_index; o.W = W; o.ldw = ldw; o.g = w.g; o.ninv = w.ninv;
         o.H = H; o.M = M; o.S = S; o.D = D; o.eps = eps;
         o.relu = (flags & MHLA_FLAG_RELU_EPS) ? 1 : 0; o.normalize = normalize;
-        RC(launch(k_bm_out<ET, DT>, dim3(M, B * H), dim3(NTHREADS), out_smem_floats<DT>() * 4, st, "k_bm_out", o));
+        bool done = false;
+        if constexpr (DT == 4 || DT == 8) {
+            if (sp_shape_ok(D, flags)) {
+                RC(launch(sp::k_sp_out<ET, DT>, dim3(M, B * H), dim3(NTHREADS), sp::sp_out_smem<DT>(), st, "k_sp_out", o));
+                done = true;
+            }
+        }
+        if (!done) RC(launch(k_bm_out<ET, DT>, dim3(M, B * H), dim3(NTHREADS), out_smem_floats<DT>() * 4, st, "k_bm_out", o));
     }));
     return MHLA_OK;
 }

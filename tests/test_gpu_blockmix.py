@@ -122,6 +122,26 @@ def test_wan_modes(M, S, D, normalize, split):
     run_case(1, 3, M, S, D, torch.float32, normalize=normalize, split=split, w="rand")
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,S,D,split", [(150, 21, 128, True), (70, 50, 64, False), (9, 210, 128, True), (3, 33, 64, True),
+                                          (65, 16, 128, False)])
+def test_split_operand_path(M, S, D, split, dtype):
+    """Head dims 64 / 128 outside the bf16 D=64 fast path: forward on the split-bf16 MFMA kernels (split.cuh)."""
+    run_case(1, 2, M, S, D, dtype, split=split, w="rand", seed=M + S)
+
+
+def test_split_operand_path_matches_exact_fp32():
+    """fp32 tensors: hi/lo bf16 operands keep 16 mantissa bits -> agreement with the exact fp32-MFMA kernels ~1e-5."""
+    import mhla_amd
+    q, k, v, W, do, qd, kd = make_blockmix_inputs(1, 3, 40, 100, 128, torch.float32, seed=11, w="rand", split=True)
+    idx = torch.randperm(40 * 100, generator=torch.Generator().manual_seed(3)).int()
+    t = to_dev(q, k, v, W, qd, kd)
+    outs = [mhla_amd.mhla_blockmix(t[0], t[1], t[2], t[3], q_den=t[4], k_den=t[5], block_index=idx.to(DEV), force_generic=fg)
+            for fg in (False, True)]
+    check("out", outs[0], outs[1].cpu(), 1e-4)
+    assert (outs[0] != outs[1]).any(), "force_generic selected the same kernels"
+
+
 def test_block_index_gather():
     idx = orc.block_index_3d((4, 6, 8), (2, 3, 4)).int()
     run_case(1, 2, 24, 8, 64, torch.float32, split=True, idx=idx)
