@@ -544,6 +544,7 @@ struct TokArgs {
     const float* ninv;   // [bh][M][S]  1 / n  (k_wz<0>)
     const float* dz;     // [bh][M][S]  W^T dn (k_wz<1>)
     const float* ksum;   // [bh][M][D]
+    float* dks;          // [bh][M][D]  dksum = Qden^T dz (split.cuh: written by the dQ kernel, read by the dK/dV kernel)
     int H, M, S, D;
     float eps;
     int relu, normalize, split;

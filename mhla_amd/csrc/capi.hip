@@ -112,7 +112,7 @@ int dt_for(int D) { return D <= 32 ? 2 : D <= 64 ? 4 : D <= 80 ? 5 : D <= 96 ? 6
     }
 
 struct BmWs {
-    float *kv, *g, *z, *ksum, *ninv, *dg, *dkv, *dn, *dz, *dwp;
+    float *kv, *g, *z, *ksum, *ninv, *dg, *dkv, *dn, *dz, *dks, *dwp;
     size_t total_fwd, total_bwd;
 };
 BmWs bm_carve(void* ws, int B, int H, int M, int S, int D) {
@@ -129,6 +129,7 @@ BmWs bm_carve(void* ws, int B, int H, int M, int S, int D) {
     w.dkv = p; p += st;
     w.dn = p; p += zs;
     w.dz = p; p += zs;
+    w.dks = p; p += ks;
     w.dwp = p; p += al4(bh * M * M * DW_MAX_SPLIT);
     w.total_bwd = (size_t)(p - (float*)ws) * 4;
     return w;
@@ -162,8 +163,8 @@ FastWs fast_carve(void* ws, int B, int H, int M, int S) {
     return w;
 }
 bool view_ok16(const mhla_view& v) { return v.ptr && ((uintptr_t)v.ptr % 16) == 0 && ((v.sb | v.sn | v.sh) & 7) == 0; }
-// split-bf16 forward kernels (split.cuh): head dims 64 and 128, any dtype
-bool sp_shape_ok(int D, unsigned flags) { return (D == 64 || D == 128) && !(flags & MHLA_FLAG_FORCE_GENERIC); }
+// split-bf16 MFMA kernels (split.cuh): head dims that are multiples of 8, any dtype
+bool sp_shape_ok(int D, unsigned flags) { return (D & 7) == 0 && !(flags & MHLA_FLAG_FORCE_GENERIC); }
 bool view_ok16m(const mhla_mview& v) { return v.ptr && ((uintptr_t)v.ptr % 16) == 0 && ((v.sb | v.sn | v.sh) & 7) == 0; }
 // bf16-MFMA token kernels of the causal operator (causal_bf16.cuh)
 bool cs_bf16_ok(int K, int V, int dtype) { return dtype == MHLA_BF16 && (K & 63) == 0 && (V & 63) == 0 && !getenv("MHLA_CAUSAL_GENERIC"); }
@@ -197,14 +198,12 @@ int bm_state_and_mix(const mhla_view& q_num, const mhla_view& k_num, const mhla_
     a.H = H; a.M = M; a.S = S; a.D = D; a.eps = eps;
     a.relu = (flags & MHLA_FLAG_RELU_EPS) ? 1 : 0; a.normalize = normalize; a.split = split;
     MixArgs m{W, ldw, w.kv, w.g, M, (long)D * D};
-    if constexpr (DT == 4 || DT == 8) {
-        if (sp_shape_ok(D, flags)) {   // split-bf16 MFMA kernels (split.cuh)
-            RC(launch(sp::k_sp_state<T, DT>, dim3(M, B * H), dim3(NTHREADS), sp::sp_state_smem<DT>(), st, "k_sp_state", a));
-            RC(launch(sp::k_sp_mix<0>, dim3((unsigned)(m.E / sp::SPM_TE), (M + 63) / 64, B * H), dim3(NTHREADS), sp::SP_MIX_SMEM, st, "k_sp_mix<0>", m));
-            if (normalize)
-                RC(launch(k_wz<0>, dim3((S + 63) / 64, (M + 63) / 64, B * H), dim3(NTHREADS), 0, st, "k_wz<0>", W, ldw, (const float*)w.z, w.ninv, M, S, eps));
-            return MHLA_OK;
-        }
+    if (sp_shape_ok(D, flags)) {   // split-bf16 MFMA kernels (split.cuh)
+        RC(launch(sp::k_sp_state<T, DT, 0>, dim3(M, B * H), dim3(NTHREADS), sp::sp_state_smem<DT>(), st, "k_sp_state", a));
+        RC(launch(sp::k_sp_mix<0>, dim3((unsigned)((m.E + sp::SPM_TE - 1) / sp::SPM_TE), (M + 63) / 64, B * H), dim3(NTHREADS), sp::SP_MIX_SMEM, st, "k_sp_mix<0>", m));
+        if (normalize)
+            RC(launch(k_wz<0>, dim3((S + 63) / 64, (M + 63) / 64, B * H), dim3(NTHREADS), 0, st, "k_wz<0>", W, ldw, (const float*)w.z, w.ninv, M, S, eps));
+        return MHLA_OK;
     }
     RC(launch(k_bm_state<T, DT, 0>, dim3(M, B * H), dim3(NTHREADS), state_smem_floats<DT>() * 4, st, "k_bm_state<0>", a));
     dim3 grid((unsigned)((m.E + MIX_TE - 1) / MIX_TE), (M + MIX_TI - 1) / MIX_TI, B * H);
@@ -373,14 +372,10 @@ int mhla_blockmix_fwd(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q
         o.q = cv(q_num); o.o = cmv(out); o.idx = block_index; o.W = W; o.ldw = ldw; o.g = w.g; o.ninv = w.ninv;
         o.H = H; o.M = M; o.S = S; o.D = D; o.eps = eps;
         o.relu = (flags & MHLA_FLAG_RELU_EPS) ? 1 : 0; o.normalize = normalize;
-        bool done = false;
-        if constexpr (DT == 4 || DT == 8) {
-            if (sp_shape_ok(D, flags)) {
-                RC(launch(sp::k_sp_out<ET, DT>, dim3(M, B * H), dim3(NTHREADS), sp::sp_out_smem<DT>(), st, "k_sp_out", o));
-                done = true;
-            }
-        }
-        if (!done) RC(launch(k_bm_out<ET, DT>, dim3(M, B * H), dim3(NTHREADS), out_smem_floats<DT>() * 4, st, "k_bm_out", o));
+        if (sp_shape_ok(D, flags))
+            RC(launch(sp::k_sp_out<ET, DT>, dim3(M, B * H), dim3(NTHREADS), sp::sp_out_smem<DT>(), st, "k_sp_out", o));
+        else
+            RC(launch(k_bm_out<ET, DT>, dim3(M, B * H), dim3(NTHREADS), out_smem_floats<DT>() * 4, st, "k_bm_out", o));
     }));
     return MHLA_OK;
 }
@@ -470,6 +465,36 @@ int mhla_blockmix_bwd(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q
         a.x = cv(q_num); a.y = cv(dout); a.o = cv(out); a.idx = block_index; a.W = W; a.ldw = ldw; a.ninv = w.ninv;
         a.out = w.dg; a.dn = w.dn; a.H = H; a.M = M; a.S = S; a.D = D; a.eps = eps;
         a.relu = relu; a.normalize = normalize; a.split = split;
+        const int tiles = (M + 63) / 64;
+        TokArgs t{};
+        t.q = cv(q_num); t.k = cv(k_num); t.v = cv(v); t.qd = cv(q_den); t.kd = cv(k_den); t.dout = cv(dout);
+        t.dq = cmv(dq_num); t.dk = cmv(dk_num); t.dv = cmv(dv); t.dqd = cmv(dq_den); t.dkd = cmv(dk_den);
+        t.idx = block_index; t.W = W; t.ldw = ldw; t.g = w.g; t.dkv = w.dkv; t.ninv = w.ninv; t.dz = w.dz; t.ksum = w.ksum;
+        t.dks = w.dks;
+        t.H = H; t.M = M; t.S = S; t.D = D; t.eps = eps; t.relu = relu; t.normalize = normalize; t.split = split;
+        if (sp_shape_ok(D, flags)) {   // split-bf16 MFMA kernels (split.cuh)
+            const long E = (long)D * D;
+            RC(launch(sp::k_sp_state<ET, DT, 1>, dim3(M, B * H), dim3(NTHREADS), sp::sp_state_smem<DT>(), st, "k_sp_state<1>", a));
+            if (normalize)
+                RC(launch(k_wz<1>, dim3((S + 63) / 64, (M + 63) / 64, B * H), dim3(NTHREADS), 0, st, "k_wz<1>", W, ldw, (const float*)w.dn, w.dz, M, S, 0.f));
+            MixArgs m{W, ldw, w.dg, w.dkv, M, E};
+            RC(launch(sp::k_sp_mix<1>, dim3((unsigned)((E + sp::SPM_TE - 1) / sp::SPM_TE), tiles, B * H), dim3(NTHREADS), sp::SP_MIX_SMEM, st, "k_sp_mix<1>", m));
+            int nsplit = dw_splits(tiles * tiles * B * H, E);
+            if (nsplit > DW_MAX_SPLIT - 1) nsplit = DW_MAX_SPLIT - 1;   // one more part per (b, h) holds the <dn_i, z_j> term
+            DwArgs d{w.dg, w.kv, E, nullptr, nullptr, 0, w.dwp, M, tiles, nsplit};
+            RC(launch(sp::k_sp_dw, dim3(tiles * tiles, B * H, nsplit), dim3(NTHREADS), sp::SP_DW_SMEM, st, "k_sp_dw", d));
+            int nparts = B * H * nsplit;
+            if (normalize) {
+                DwArgs dzz{w.dn, w.z, (long)S, nullptr, nullptr, 0, w.dwp + (size_t)nparts * M * M, M, tiles, 1};
+                RC(launch(k_dw<0>, dim3(tiles * tiles, B * H, 1), dim3(NTHREADS), DW_SMEM_FLOATS * 4, st, "k_dw", dzz));
+                nparts += B * H;
+            }
+            RC(launch(k_dw_reduce<0>, dim3((M * M + 63) / 64), dim3(256), 0, st, "k_dw_reduce", (const float*)w.dwp,
+                      (const float*)nullptr, dW, M, M, nparts, B * H));
+            RC(launch(sp::k_sp_bwd_dq<ET, DT>, dim3(M, B * H), dim3(NTHREADS), sp::sp_tok_smem<DT>(), st, "k_sp_bwd_dq", t));
+            RC(launch(sp::k_sp_bwd_dkv<ET, DT>, dim3(M, B * H), dim3(NTHREADS), sp::sp_tok_smem<DT>(), st, "k_sp_bwd_dkv", t));
+            break;
+        }
         RC(launch(k_bm_state<ET, DT, 1>, dim3(M, B * H), dim3(NTHREADS), state_smem_floats<DT>() * 4, st, "k_bm_state<1>", a));
         if (normalize)
             RC(launch(k_wz<1>, dim3((S + 63) / 64, (M + 63) / 64, B * H), dim3(NTHREADS), 0, st, "k_wz<1>", W, ldw, (const float*)w.dn, w.dz, M, S, 0.f));
@@ -478,18 +503,12 @@ int mhla_blockmix_bwd(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q
         dim3 mgrid((unsigned)((m.E + MIX_TE - 1) / MIX_TE), (M + MIX_TI - 1) / MIX_TI, B * H);
         RC(launch(k_mix<1, 0>, mgrid, dim3(NTHREADS), MIX_SMEM_FLOATS * 4, st, "k_mix<1,0>", m));
         // dW = sum_bh (<dG_i, KV_j> + <dn_i, z_j>)
-        const int tiles = (M + 63) / 64;
         const int nsplit = dw_splits(tiles * tiles * B * H, (long)D * D);
         DwArgs d{w.dg, w.kv, (long)D * D, normalize ? w.dn : nullptr, normalize ? w.z : nullptr, (long)S, w.dwp, M, tiles, nsplit};
         RC(launch(k_dw<0>, dim3(tiles * tiles, B * H, nsplit), dim3(NTHREADS), DW_SMEM_FLOATS * 4, st, "k_dw", d));
         RC(launch(k_dw_reduce<0>, dim3((M * M + 63) / 64), dim3(256), 0, st, "k_dw_reduce", (const float*)w.dwp,
                   (const float*)nullptr, dW, M, M, B * H * nsplit, B * H));
         // dQ, dK, dV
-        TokArgs t{};
-        t.q = cv(q_num); t.k = cv(k_num); t.v = cv(v); t.qd = cv(q_den); t.kd = cv(k_den); t.dout = cv(dout);
-        t.dq = cmv(dq_num); t.dk = cmv(dk_num); t.dv = cmv(dv); t.dqd = cmv(dq_den); t.dkd = cmv(dk_den);
-        t.idx = block_index; t.W = W; t.ldw = ldw; t.g = w.g; t.dkv = w.dkv; t.ninv = w.ninv; t.dz = w.dz; t.ksum = w.ksum;
-        t.H = H; t.M = M; t.S = S; t.D = D; t.eps = eps; t.relu = relu; t.normalize = normalize; t.split = split;
         RC(launch(k_bm_bwd_tok<ET, DT>, dim3(M, B * H), dim3(NTHREADS), tok_smem_floats<DT>() * 4, st, "k_bm_bwd_tok", t));
     }));
     return MHLA_OK;

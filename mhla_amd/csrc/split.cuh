@@ -1,5 +1,6 @@
-// Block-mixing forward kernels for head dims 64 and 128 in any dtype (the Wan2.1 shape: fp32, D = 128, M = 150 blocks of
-// 210 tokens; wan/mhla_utils.py:331-341), computing on the bf16 MFMA with split operands.
+// Block-mixing kernels for any head dim D <= 128 with D % 8 == 0 in any dtype (the Wan2.1 shape: fp32, D = 128, M = 150
+// blocks of 210 tokens, wan/mhla_utils.py:331-341; DiT-XL/2: D = 72), computing on the bf16 MFMA with split operands.
+// DT = ceil(D / 16) output tiles per side; LDS tiles are 64 or 128 columns wide with the columns >= D zero.
 //
 // An fp32 value x is carried as two bf16 numbers, hi = bf16(x) and lo = bf16(x - hi), which keep 16 mantissa bits;
 // a product a b is evaluated as a_hi b_hi + a_hi b_lo + a_lo b_hi with fp32 accumulation (the dropped lo*lo term is
@@ -50,44 +51,61 @@ __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, uint4& hi
 }
 __device__ __forceinline__ bf16x8 as_bf16x8(const uint4& v) { return __builtin_bit_cast(bf16x8, v); }
 
+template <int DT> struct Geo {
+    static constexpr int CGS = DT > 4 ? 16 : 8;        // column groups of 8 per tile row
+    static constexpr int DW = CGS * 8;                 // tile width (columns), >= 16 DT
+    static constexpr int LD = DW + 8;                  // LDS row stride (bf16)
+    static constexpr int RPP = NTHREADS / CGS;         // tile rows covered per pass of the 256 threads
+    static constexpr int RT = (DT + 3) / 4;            // 16-row output tiles per wave
+    static constexpr int KST = (DT + 1) / 2;           // reduction steps of 32 over a head dim
+};
+
 template <int DT>
 __host__ __device__ constexpr int sp_state_smem() {
-    constexpr int D = DT * 16;
-    return 4 * 32 * (D + 8) * 2 + (256 / (D / 8)) * D * 4 + D * 4;
+    return 4 * 32 * Geo<DT>::LD * 2 + Geo<DT>::RPP * Geo<DT>::DW * 4 + Geo<DT>::DW * 4;
 }
 
-template <typename T, int DT>
+// MODE 0 (forward):  out = KV_j = K_j^T V_j; ksum_j; z_j                      x = k_num, y = v, kd = k_den, qd = q_den
+// MODE 1 (backward): out = dG_i = Q_i^T (dO_i / n_i); dn_i[s] = -(dO_i[s] . O_i[s]) / n_i[s]     x = q_num, y = dout, o = out
+template <typename T, int DT, int MODE>
 __global__ __launch_bounds__(NTHREADS) void k_sp_state(const StateArgs a) {
-    constexpr int D = DT * 16, LD = D + 8, CGS = D / 8, RPP = NTHREADS / CGS, IT = 32 / RPP, RT = DT / 4, TILE = 32 * LD;
+    constexpr int DW = Geo<DT>::DW, LD = Geo<DT>::LD, CGS = Geo<DT>::CGS, RPP = Geo<DT>::RPP, IT = 32 / RPP, RT = Geo<DT>::RT, TILE = 32 * LD;
     constexpr bool LO = !std::is_same<T, bf16_t>::value;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u16* Kh = reinterpret_cast<u16*>(smem_raw);
     u16* Kl = Kh + TILE;
     u16* Vh = Kl + TILE;
     u16* Vl = Vh + TILE;
-    float* cs = reinterpret_cast<float*>(Vl + TILE);   // [RPP][D] column-sum partials
-    float* vecd = cs + RPP * D;                        // [D] ksum
+    float* cs = reinterpret_cast<float*>(Vl + TILE);   // [RPP][DW] column-sum partials
+    float* vecd = cs + RPP * DW;                       // [DW] ksum
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nl = lane & 15, kg = lane >> 4;
-    const int blk = blockIdx.x, bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H, S = a.S;
+    const int blk = blockIdx.x, bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H, S = a.S, D = a.D;
     const long p0 = (long)blk * S;
     const T* kb = (const T*)a.x.ptr + b * a.x.sb + h * a.x.sh;
     const T* vb = (const T*)a.y.ptr + b * a.y.sb + h * a.y.sh;
-    const T* kdb = (const T*)a.kd.ptr + b * a.kd.sb + h * a.kd.sh;
-    const bool den = a.normalize && a.split;   // the normaliser's keys are a separate tensor
+    const View& third = MODE == 0 ? a.kd : a.o;   // MODE 0: the normaliser's keys; MODE 1: the forward output
+    const T* kdb = (const T*)third.ptr + b * third.sb + h * third.sh;
+    const bool den = a.normalize && (MODE == 1 || a.split);   // a third tensor is read
     const int r0 = tid / CGS, cg = (tid % CGS) * 8;
+    const float* ninvb = a.ninv + ((long)bh * a.M + blk) * S;   // MODE 1
 
     f32x4 kx[IT][2], vx[IT][2], dx[IT][2];
+    float nv[IT];
+    int crow = 0;   // first token of the chunk held in registers
     auto fetch = [&](int c0) {
+        crow = c0;
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
             const int r = c0 + r0 + RPP * it;
             kx[it][0] = kx[it][1] = vx[it][0] = vx[it][1] = dx[it][0] = dx[it][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (r < S) {
+            nv[it] = 1.f;
+            if (r < S && cg < D) {
                 const long row = tok_row(a.idx, p0 + r);
                 ld8(kb + row * a.x.sn + cg, kx[it][0], kx[it][1]);
                 ld8(vb + row * a.y.sn + cg, vx[it][0], vx[it][1]);
                 if (a.relu) relu8(kx[it][0], kx[it][1], a.eps);
-                if (den) ld8(kdb + row * a.kd.sn + cg, dx[it][0], dx[it][1]);
+                if (den) ld8(kdb + row * third.sn + cg, dx[it][0], dx[it][1]);
+                if (MODE == 1 && a.normalize) nv[it] = ninvb[r];
             }
         }
     };
@@ -97,17 +115,30 @@ __global__ __launch_bounds__(NTHREADS) void k_sp_state(const StateArgs a) {
         for (int it = 0; it < IT; ++it) {
             const int off = (r0 + RPP * it) * LD + cg;
             uint4 hi, lo;
+            if (MODE == 1 && a.normalize) {   // dn[s] and the 1/n scaling of dO
+                float d = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) d += vx[it][0][i] * dx[it][0][i] + vx[it][1][i] * dx[it][1][i];
+#pragma unroll
+                for (int o = CGS / 2; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+                const int r = crow + r0 + RPP * it;
+                if (r < S && (tid % CGS) == 0) a.dn[((long)bh * a.M + blk) * S + r] = -d * nv[it];
+                vx[it][0] *= nv[it];
+                vx[it][1] *= nv[it];
+            }
             split8(kx[it][0], kx[it][1], hi, lo);
             *reinterpret_cast<uint4*>(Kh + off) = hi;
             if (LO) *reinterpret_cast<uint4*>(Kl + off) = lo;
             split8(vx[it][0], vx[it][1], hi, lo);
             *reinterpret_cast<uint4*>(Vh + off) = hi;
             if (LO) *reinterpret_cast<uint4*>(Vl + off) = lo;
-            const f32x4* s = den ? dx[it] : kx[it];
+            if (MODE == 0) {
+                const f32x4* s = den ? dx[it] : kx[it];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                ksp[i] += s[0][i];
-                ksp[4 + i] += s[1][i];
+                for (int i = 0; i < 4; ++i) {
+                    ksp[i] += s[0][i];
+                    ksp[4 + i] += s[1][i];
+                }
             }
         }
     };
@@ -125,9 +156,10 @@ __global__ __launch_bounds__(NTHREADS) void k_sp_state(const StateArgs a) {
         if (c0 + 32 < S) fetch(c0 + 32);
         bf16x8 ah[RT], al[RT];
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            ah[rt] = tr_read8(Kh, LD, 0, (wave * RT + rt) * 16, lane);
-            if (LO) al[rt] = tr_read8(Kl, LD, 0, (wave * RT + rt) * 16, lane);
+        for (int rt = 0; rt < RT; ++rt) {   // row tiles past DT read zero / unused columns of the tile: harmless, not stored
+            const int c0 = min(wave * RT + rt, DW / 16 - 1) * 16;
+            ah[rt] = tr_read8(Kh, LD, 0, c0, lane);
+            if (LO) al[rt] = tr_read8(Kl, LD, 0, c0, lane);
         }
 #pragma unroll
         for (int ct = 0; ct < DT; ++ct) {
@@ -152,18 +184,21 @@ __global__ __launch_bounds__(NTHREADS) void k_sp_state(const StateArgs a) {
 #pragma unroll
         for (int ct = 0; ct < DT; ++ct)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ob[(long)((wave * RT + rt) * 16 + kg * 4 + r) * D + ct * 16 + nl] = acc[rt][ct][r];
+            for (int r = 0; r < 4; ++r) {
+                const int row = (wave * RT + rt) * 16 + kg * 4 + r, col = ct * 16 + nl;
+                if (row < D && col < D) ob[(long)row * D + col] = acc[rt][ct][r];
+            }
 
-    if (a.normalize) {
+    if (MODE == 0 && a.normalize) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) cs[r0 * D + cg + i] = ksp[i];
+        for (int i = 0; i < 8; ++i) cs[r0 * DW + cg + i] = ksp[i];
         __syncthreads();
-        if (tid < D) {
+        if (tid < DW) {
             float s = 0.f;
 #pragma unroll 4
-            for (int r = 0; r < RPP; ++r) s += cs[r * D + tid];
+            for (int r = 0; r < RPP; ++r) s += cs[r * DW + tid];
             vecd[tid] = s;
-            a.ksum[((long)bh * a.M + blk) * D + tid] = s;
+            if (tid < D) a.ksum[((long)bh * a.M + blk) * D + tid] = s;
         }
         __syncthreads();
         // z_j[s] = Qden_j[s] . ksum_j : CGS lanes per token row
@@ -174,7 +209,7 @@ __global__ __launch_bounds__(NTHREADS) void k_sp_state(const StateArgs a) {
         for (int rb = 0; rb < S; rb += RPP) {
             const int r = rb + r0;
             float d = 0.f;
-            if (r < S) {
+            if (r < S && cg < D) {
                 f32x4 x0, x1;
                 ld8(qb + tok_row(a.idx, p0 + r) * a.qd.sn + cg, x0, x1);
                 if (a.relu) relu8(x0, x1, a.eps);
@@ -213,10 +248,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_mix(const MixArgs a) {
         if (row < M) {
             const float* src = inb + (long)row * a.E + sc;
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                pre[u][0] = *reinterpret_cast<const f32x4*>(src + 64 * u);
-                pre[u][1] = *reinterpret_cast<const f32x4*>(src + 64 * u + 4);
-            }
+            for (int u = 0; u < 2; ++u)
+                if (e0 + sc + 64 * u < a.E) {   // E is a multiple of 8
+                    pre[u][0] = *reinterpret_cast<const f32x4*>(src + 64 * u);
+                    pre[u][1] = *reinterpret_cast<const f32x4*>(src + 64 * u + 4);
+                }
         }
     };
     auto commit = [&](int buf) {
@@ -280,37 +316,42 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_mix(const MixArgs a) {
 #pragma unroll
     for (int v0 = 0; v0 < 8; ++v0) {
         const int v = tid + v0 * NTHREADS, r = v >> 5, c = (v & 31) * 4;
-        if (i0 + r < M) *reinterpret_cast<f32x4*>(outb + (long)(i0 + r) * a.E + c) = *reinterpret_cast<const f32x4*>(Os + r * (SPM_TE + 4) + c);
+        if (i0 + r < M && e0 + c < a.E) *reinterpret_cast<f32x4*>(outb + (long)(i0 + r) * a.E + c) = *reinterpret_cast<const f32x4*>(Os + r * (SPM_TE + 4) + c);
     }
 }
 
 // -------------------------------------------------------------------------------------------------
 template <int DT>
-__host__ __device__ constexpr int sp_out_smem() { return 2 * DT * 16 * (DT * 16 + 8) * 2; }
+__host__ __device__ constexpr int sp_out_smem() { return 2 * Geo<DT>::KST * 32 * Geo<DT>::LD * 2; }
 
 template <typename T, int DT>
 __global__ __launch_bounds__(NTHREADS, 2) void k_sp_out(const OutArgs a) {
-    constexpr int D = DT * 16, LD = D + 8, CGS = D / 8, RPP = NTHREADS / CGS, KST = D / 32, TILE = D * LD;
+    constexpr int LD = Geo<DT>::LD, CGS = Geo<DT>::CGS, RPP = Geo<DT>::RPP, KST = Geo<DT>::KST, KP = KST * 32, TILE = KP * LD;
     constexpr bool LO = !std::is_same<T, bf16_t>::value;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    u16* Gh = reinterpret_cast<u16*>(smem_raw);   // [d1][d2]
+    u16* Gh = reinterpret_cast<u16*>(smem_raw);   // [d1][d2], rows >= D and columns >= D zero
     u16* Gl = Gh + TILE;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nl = lane & 15, kg = lane >> 4;
-    const int blk = blockIdx.x, bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H, S = a.S;
+    const int blk = blockIdx.x, bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H, S = a.S, D = a.D;
     const long p0 = (long)blk * S;
     const T* qb = (const T*)a.q.ptr + b * a.q.sb + h * a.q.sh;
     T* ob = (T*)a.o.ptr + b * a.o.sb + h * a.o.sh;
     {   // G_i -> LDS as hi / lo
         const float* g = a.g + ((long)bh * a.M + blk) * D * D;
         const int r0 = tid / CGS, cg = (tid % CGS) * 8;
-        constexpr int PASSES = D / RPP, UB = PASSES < 4 ? PASSES : 4;
+        constexpr int PASSES = KP / RPP, UB = PASSES < 4 ? PASSES : (PASSES % 4 == 0 ? 4 : (PASSES % 3 == 0 ? 3 : 2));
+        static_assert(PASSES % UB == 0, "staging batches must tile the passes");
         for (int pb = 0; pb < PASSES; pb += UB) {
             f32x4 x[UB][2];
 #pragma unroll
             for (int u = 0; u < UB; ++u) {
-                const float* src = g + (long)(r0 + RPP * (pb + u)) * D + cg;
-                x[u][0] = *reinterpret_cast<const f32x4*>(src);
-                x[u][1] = *reinterpret_cast<const f32x4*>(src + 4);
+                const int r = r0 + RPP * (pb + u);
+                x[u][0] = x[u][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (r < D && cg < D) {
+                    const float* src = g + (long)r * D + cg;
+                    x[u][0] = *reinterpret_cast<const f32x4*>(src);
+                    x[u][1] = *reinterpret_cast<const f32x4*>(src + 4);
+                }
             }
 #pragma unroll
             for (int u = 0; u < UB; ++u) {
@@ -331,9 +372,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_out(const OutArgs a) {
         bf16x8 qh[KST], ql[KST];
 #pragma unroll
         for (int ks = 0; ks < KST; ++ks) {
-            f32x4 x0, x1;
-            ld8(qrow + ks * 32, x0, x1);
-            if (a.relu) relu8(x0, x1, a.eps);
+            f32x4 x0 = {0.f, 0.f, 0.f, 0.f}, x1 = x0;
+            if (ks * 32 + kg * 8 < D) {
+                ld8(qrow + ks * 32, x0, x1);
+                if (a.relu) relu8(x0, x1, a.eps);
+            }
             uint4 hi, lo;
             split8(x0, x1, hi, lo);
             qh[ks] = as_bf16x8(hi);
@@ -358,10 +401,364 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_out(const OutArgs a) {
                 }
             }
             if (s < S) {
-                Io<T>::st4(orow + ct * 16, c0 * ninv);
-                Io<T>::st4(orow + ct * 16 + 16, c1 * ninv);
+                if (ct * 16 + kg * 4 < D) Io<T>::st4(orow + ct * 16, c0 * ninv);
+                if (ct * 16 + 16 + kg * 4 < D) Io<T>::st4(orow + ct * 16 + 16, c1 * ninv);
             }
         }
+    }
+}
+
+
+// -------------------------------------------------------------------------------------------------
+// k_sp_dw: dwp[bh][split][i][j] = sum_{e in slice} dG_i[e] KV_j[e]  (fp32 operands straight from HBM, split in
+// registers; the reduction index is contiguous for both, lane kg takes e = 8 kg .. 8 kg + 7 of every 32).
+// grid (tile pairs, bh, E-slices) and output layout as k_dw; each wave reduces a quarter of the slice for the whole
+// 64 x 64 tile and the four partial tiles are summed through LDS in wave order.
+// -------------------------------------------------------------------------------------------------
+constexpr int SP_DW_LD = 68;
+constexpr int SP_DW_SMEM = 64 * SP_DW_LD * 4;
+
+__global__ __launch_bounds__(NTHREADS) void k_sp_dw(const DwArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* Rs = reinterpret_cast<float*>(smem_raw);
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nl = lane & 15, kg = lane >> 4;
+    const int it = blockIdx.x / a.tiles, jt = blockIdx.x - it * a.tiles, bh = blockIdx.y, split = blockIdx.z, M = a.M;
+    const int i0 = it * 64, j0 = jt * 64;
+    const long E = a.E;
+    const long per = ((E + a.nsplit - 1) / a.nsplit + 127) & ~127L;   // slice: multiple of 4 waves x 32 elements
+    const long ebeg = (long)split * per, eend = min(E, ebeg + per);
+    const long span = eend > ebeg ? eend - ebeg : 0;
+    const long wper = ((span + 3) / 4 + 31) & ~31L;                    // E is a multiple of 32
+    const long wbeg = ebeg + wave * wper, wend = min(eend, wbeg + wper);
+    const float* xp[4];
+    const float* yp[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int ri = min(i0 + t * 16 + nl, M - 1), rj = min(j0 + t * 16 + nl, M - 1);
+        xp[t] = a.x + ((long)bh * M + ri) * E + kg * 8;
+        yp[t] = a.y + ((long)bh * M + rj) * E + kg * 8;
+    }
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (long e = wbeg; e < wend; e += 32) {
+        uint4 xh[4], xl[4], yh[4], yl[4];
+        f32x4 raw[8][2];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            raw[t][0] = *reinterpret_cast<const f32x4*>(xp[t] + e);
+            raw[t][1] = *reinterpret_cast<const f32x4*>(xp[t] + e + 4);
+            raw[4 + t][0] = *reinterpret_cast<const f32x4*>(yp[t] + e);
+            raw[4 + t][1] = *reinterpret_cast<const f32x4*>(yp[t] + e + 4);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            split8(raw[t][0], raw[t][1], xh[t], xl[t]);
+            split8(raw[4 + t][0], raw[4 + t][1], yh[t], yl[t]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = mfma_bf16(as_bf16x8(xh[i]), as_bf16x8(yh[j]), acc[i][j]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = mfma_bf16(as_bf16x8(xh[i]), as_bf16x8(yl[j]), acc[i][j]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = mfma_bf16(as_bf16x8(xl[i]), as_bf16x8(yh[j]), acc[i][j]);
+    }
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float* d = Rs + (i * 16 + kg * 4 + r) * SP_DW_LD + j * 16 + nl;
+                        *d = (w == 0 ? 0.f : *d) + acc[i][j][r];
+                    }
+        }
+        __syncthreads();
+    }
+    float* out = a.out + ((long)bh * a.nsplit + split) * M * M;
+    for (int v = tid; v < 64 * 64; v += NTHREADS) {
+        const int r = v >> 6, c = v & 63;
+        if (i0 + r < M && j0 + c < M) out[(long)(i0 + r) * M + j0 + c] = Rs[r * SP_DW_LD + c];
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// Token gradients.  Both kernels keep one D x D matrix of the block in LDS as bf16 hi / lo and compute transposed
+// products, so that the token tensors are MFMA B operands read straight from HBM (8 consecutive features per lane) and a
+// lane ends up with 4 consecutive features of one token.
+//   k_sp_bwd_dq : dQ_i = (dO_i / n_i) G_i^T (+ dz_i ksum_i^T) ; dksum_i = Qden_i^T dz_i ; dQden_i = dz_i ksum_i^T (split)
+//   k_sp_bwd_dkv: dK_j = V_j dKV_j^T (+ dksum_j) ; dV_j = K_j dKV_j ; dKden_j = 1 dksum_j^T (split)
+// -------------------------------------------------------------------------------------------------
+template <int DT>
+__host__ __device__ constexpr int sp_tok_smem() { return sp_out_smem<DT>() + Geo<DT>::DW * 4 * 4 + Geo<DT>::DW * 4; }
+
+// D x D fp32 matrix -> LDS [KP][LD] hi / lo (rows, columns >= D zero)
+template <int DT>
+__device__ __forceinline__ void stage_mat_split(u16* __restrict__ Gh, u16* __restrict__ Gl, const float* __restrict__ g, int D, int tid) {
+    constexpr int LD = Geo<DT>::LD, CGS = Geo<DT>::CGS, RPP = Geo<DT>::RPP, KP = Geo<DT>::KST * 32;
+    const int r0 = tid / CGS, cg = (tid % CGS) * 8;
+    constexpr int PASSES = KP / RPP, UB = PASSES < 4 ? PASSES : (PASSES % 4 == 0 ? 4 : (PASSES % 3 == 0 ? 3 : 2));
+    static_assert(PASSES % UB == 0, "staging batches must tile the passes");
+    for (int pb = 0; pb < PASSES; pb += UB) {
+        f32x4 x[UB][2];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int r = r0 + RPP * (pb + u);
+            x[u][0] = x[u][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (r < D && cg < D) {
+                const float* src = g + (long)r * D + cg;
+                x[u][0] = *reinterpret_cast<const f32x4*>(src);
+                x[u][1] = *reinterpret_cast<const f32x4*>(src + 4);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            uint4 hi, lo;
+            split8(x[u][0], x[u][1], hi, lo);
+            const int off = (r0 + RPP * (pb + u)) * LD + cg;
+            *reinterpret_cast<uint4*>(Gh + off) = hi;
+            *reinterpret_cast<uint4*>(Gl + off) = lo;
+        }
+    }
+}
+// A operand with the reduction index along the rows' columns: A[m][k] = T[c0 + m][k0 + 8 kg .. + 7]
+__device__ __forceinline__ bf16x8 row_read8(const u16* tile, int ld, int c0, int k0, int lane) {
+    return *reinterpret_cast<const bf16x8*>(tile + (c0 + (lane & 15)) * ld + k0 + (lane >> 4) * 8);
+}
+
+template <typename T, int DT>
+__global__ __launch_bounds__(NTHREADS, 2) void k_sp_bwd_dq(const TokArgs a) {
+    constexpr int LD = Geo<DT>::LD, DW = Geo<DT>::DW, KST = Geo<DT>::KST, TILE = KST * 32 * LD;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u16* Gh = reinterpret_cast<u16*>(smem_raw);
+    u16* Gl = Gh + TILE;
+    float* dksw = reinterpret_cast<float*>(Gl + TILE);   // [4 waves][DW]
+    float* ksum = dksw + 4 * DW;                          // [DW]
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nl = lane & 15, kg = lane >> 4;
+    const int blk = blockIdx.x, bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H, S = a.S, D = a.D, M = a.M;
+    const long p0 = (long)blk * S;
+    auto base = [&](const View& w) { return (const T*)w.ptr + b * w.sb + h * w.sh; };
+    auto mbase = [&](const MView& w) { return (T*)w.ptr + b * w.sb + h * w.sh; };
+    const T *gb = base(a.dout), *qdb = base(a.qd);
+    T *dqb = mbase(a.dq), *dqdb = a.split ? mbase(a.dqd) : nullptr;
+    const float* ninvb = a.ninv + ((long)bh * M + blk) * S;
+    const float* dzb = a.dz + ((long)bh * M + blk) * S;
+    const bool need_q = a.normalize || a.relu;
+
+    // one 16-token tile of this wave: the lane's token row, its dO features as the MFMA B operand (8 per reduction step) and
+    // its q_den features in output layout (4 per feature tile); fetched one tile ahead of the tile being computed
+    struct Rows {
+        f32x4 g[KST][2];
+        f32x4 qd[DT];
+        float ninv, dz;
+        long row;
+        bool live;
+    } cur, nxt;
+    auto fetch = [&](int tt, Rows& R) {
+        const int s = tt * 16 + nl, sv = min(s, S - 1);
+        R.live = s < S;
+        R.row = tok_row(a.idx, p0 + sv);
+        R.ninv = a.normalize ? ninvb[sv] : 1.f;
+        R.dz = (a.normalize && R.live) ? dzb[sv] : 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KST; ++ks) {
+            R.g[ks][0] = R.g[ks][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (ks * 32 + kg * 8 < D) ld8(gb + R.row * a.dout.sn + ks * 32 + kg * 8, R.g[ks][0], R.g[ks][1]);
+        }
+#pragma unroll
+        for (int ct = 0; ct < DT; ++ct) {
+            R.qd[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (need_q && ct * 16 + kg * 4 < D) R.qd[ct] = Io<T>::ld4(qdb + R.row * a.qd.sn + ct * 16 + kg * 4);
+        }
+    };
+    fetch(wave, cur);   // in flight while G_i is staged
+    stage_mat_split<DT>(Gh, Gl, a.g + ((long)bh * M + blk) * D * D, D, tid);
+    if (tid < DW) ksum[tid] = (a.normalize && tid < D) ? a.ksum[((long)bh * M + blk) * D + tid] : 0.f;
+    __syncthreads();
+    f32x4 dksp[DT];
+#pragma unroll
+    for (int ct = 0; ct < DT; ++ct) dksp[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int tt = wave; tt * 16 < S; tt += 4) {
+        if ((tt + 4) * 16 < S) fetch(tt + 4, nxt);
+        bf16x8 gh[KST], gl[KST];   // dO / n : B[k = d2][n = s]
+#pragma unroll
+        for (int ks = 0; ks < KST; ++ks) {
+            uint4 hi, lo;
+            split8(cur.g[ks][0] * cur.ninv, cur.g[ks][1] * cur.ninv, hi, lo);
+            gh[ks] = as_bf16x8(hi);
+            gl[ks] = as_bf16x8(lo);
+        }
+        auto epilogue = [&](int ct, f32x4 c) {
+            const int d0 = ct * 16 + kg * 4;
+            if (d0 < D) {
+                f32x4 qd = cur.qd[ct];
+                if (a.relu)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) qd[i] = fmaxf(qd[i], 0.f) + a.eps;
+                const f32x4 ks4 = *reinterpret_cast<const f32x4*>(ksum + d0);
+                if (a.normalize) {
+                    dksp[ct] += cur.dz * qd;
+                    if (!a.split) c += cur.dz * ks4;
+                }
+                if (a.relu)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (!(qd[i] > a.eps)) c[i] = 0.f;
+                if (cur.live) {
+                    Io<T>::st4(dqb + cur.row * a.dq.sn + d0, c);
+                    if (a.normalize && a.split) Io<T>::st4(dqdb + cur.row * a.dqd.sn + d0, cur.dz * ks4);
+                }
+            }
+        };
+#pragma unroll
+        for (int ct = 0; ct < DT; ct += 2) {   // two feature tiles at a time: independent MFMA chains, adjacent stores
+            constexpr int LAST = DT - 1;
+            const int c1t = ct + 1 <= LAST ? ct + 1 : LAST;
+            f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
+#pragma unroll
+            for (int ks = 0; ks < KST; ++ks) {
+                const bf16x8 a0h = row_read8(Gh, LD, ct * 16, ks * 32, lane), a0l = row_read8(Gl, LD, ct * 16, ks * 32, lane);
+                const bf16x8 a1h = row_read8(Gh, LD, c1t * 16, ks * 32, lane), a1l = row_read8(Gl, LD, c1t * 16, ks * 32, lane);
+                c0 = mfma_bf16(a0h, gh[ks], c0);
+                c1 = mfma_bf16(a1h, gh[ks], c1);
+                c0 = mfma_bf16(a0l, gh[ks], c0);
+                c1 = mfma_bf16(a1l, gh[ks], c1);
+                c0 = mfma_bf16(a0h, gl[ks], c0);
+                c1 = mfma_bf16(a1h, gl[ks], c1);
+            }
+            epilogue(ct, c0);
+            if (ct + 1 < DT) epilogue(ct + 1, c1);
+            __builtin_amdgcn_sched_barrier(0);   // keep the LDS operand reads of later tiles from being hoisted (register pressure)
+        }
+        cur = nxt;
+    }
+    if (a.normalize) {   // dksum[d] = sum_s dz[s] qden[s][d]: over the 16 token lanes, then over the waves
+#pragma unroll
+        for (int ct = 0; ct < DT; ++ct)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v = dksp[ct][i];
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+                if (nl == 0) dksw[wave * DW + ct * 16 + kg * 4 + i] = v;
+            }
+        __syncthreads();
+        if (tid < D) a.dks[((long)bh * M + blk) * D + tid] = dksw[tid] + dksw[DW + tid] + dksw[2 * DW + tid] + dksw[3 * DW + tid];
+    }
+}
+
+template <typename T, int DT>
+__global__ __launch_bounds__(NTHREADS, 2) void k_sp_bwd_dkv(const TokArgs a) {
+    constexpr int LD = Geo<DT>::LD, DW = Geo<DT>::DW, KST = Geo<DT>::KST, TILE = KST * 32 * LD;
+    constexpr bool LO = !std::is_same<T, bf16_t>::value;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u16* Gh = reinterpret_cast<u16*>(smem_raw);   // dKV_j [d1][d2]
+    u16* Gl = Gh + TILE;
+    float* dks = reinterpret_cast<float*>(Gl + TILE);   // [DW]
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nl = lane & 15, kg = lane >> 4;
+    const int blk = blockIdx.x, bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H, S = a.S, D = a.D, M = a.M;
+    const long p0 = (long)blk * S;
+    auto base = [&](const View& w) { return (const T*)w.ptr + b * w.sb + h * w.sh; };
+    auto mbase = [&](const MView& w) { return (T*)w.ptr + b * w.sb + h * w.sh; };
+    const T *kb = base(a.k), *vb = base(a.v);
+    T *dkb = mbase(a.dk), *dvb = mbase(a.dv), *dkdb = a.split ? mbase(a.dkd) : nullptr;
+
+    struct Rows {
+        f32x4 v[KST][2], k[KST][2];   // B operands: 8 features per reduction step
+        f32x4 km[DT];                 // k in output layout (gradient mask of the relu prologue)
+        long row;
+        bool live;
+    } cur, nxt;
+    auto fetch = [&](int tt, Rows& R) {
+        const int s = tt * 16 + nl, sv = min(s, S - 1);
+        R.live = s < S;
+        R.row = tok_row(a.idx, p0 + sv);
+#pragma unroll
+        for (int ks = 0; ks < KST; ++ks) {
+            R.v[ks][0] = R.v[ks][1] = R.k[ks][0] = R.k[ks][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (ks * 32 + kg * 8 < D) {
+                ld8(vb + R.row * a.v.sn + ks * 32 + kg * 8, R.v[ks][0], R.v[ks][1]);
+                ld8(kb + R.row * a.k.sn + ks * 32 + kg * 8, R.k[ks][0], R.k[ks][1]);
+            }
+        }
+#pragma unroll
+        for (int ct = 0; ct < DT; ++ct) {
+            R.km[ct] = f32x4{1.f, 1.f, 1.f, 1.f};
+            if (a.relu && ct * 16 + kg * 4 < D) R.km[ct] = Io<T>::ld4(kb + R.row * a.k.sn + ct * 16 + kg * 4);
+        }
+    };
+    fetch(wave, cur);
+    stage_mat_split<DT>(Gh, Gl, a.dkv + ((long)bh * M + blk) * D * D, D, tid);
+    if (tid < DW) dks[tid] = (a.normalize && tid < D) ? a.dks[((long)bh * M + blk) * D + tid] : 0.f;
+    __syncthreads();
+
+    for (int tt = wave; tt * 16 < S; tt += 4) {
+        if ((tt + 4) * 16 < S) fetch(tt + 4, nxt);
+        bf16x8 vh[KST], vl[KST], kh[KST], kl[KST];
+        f32x4 dkst[2], dvst[2];
+#pragma unroll
+        for (int ks = 0; ks < KST; ++ks) {
+            uint4 hi, lo;
+            split8(cur.v[ks][0], cur.v[ks][1], hi, lo);
+            vh[ks] = as_bf16x8(hi);
+            vl[ks] = as_bf16x8(lo);
+            f32x4 y0 = cur.k[ks][0], y1 = cur.k[ks][1];
+            if (a.relu && ks * 32 + kg * 8 < D) relu8(y0, y1, a.eps);
+            split8(y0, y1, hi, lo);
+            kh[ks] = as_bf16x8(hi);
+            kl[ks] = as_bf16x8(lo);
+        }
+#pragma unroll
+        for (int ct = 0; ct < DT; ++ct) {
+            f32x4 ck = {0.f, 0.f, 0.f, 0.f}, cv = ck;
+#pragma unroll
+            for (int ks = 0; ks < KST; ++ks) {
+                // dK^T[d1][s] = sum_d2 dKV[d1][d2] V[s][d2]
+                const bf16x8 ah = row_read8(Gh, LD, ct * 16, ks * 32, lane), al = row_read8(Gl, LD, ct * 16, ks * 32, lane);
+                // dV^T[d2][s] = sum_d1 dKV[d1][d2] K[s][d1]
+                const bf16x8 th = tr_read8(Gh, LD, ks * 32, ct * 16, lane), tl = tr_read8(Gl, LD, ks * 32, ct * 16, lane);
+                ck = mfma_bf16(ah, vh[ks], ck);
+                cv = mfma_bf16(th, kh[ks], cv);
+                ck = mfma_bf16(al, vh[ks], ck);
+                cv = mfma_bf16(tl, kh[ks], cv);
+                if (LO) {
+                    ck = mfma_bf16(ah, vl[ks], ck);
+                    cv = mfma_bf16(th, kl[ks], cv);
+                }
+            }
+            const int d0 = ct * 16 + kg * 4;
+            if (a.normalize && !a.split) ck += *reinterpret_cast<const f32x4*>(dks + d0);
+            if (a.relu)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (!(fmaxf(cur.km[ct][i], 0.f) + a.eps > a.eps)) ck[i] = 0.f;
+            dkst[ct & 1] = ck;
+            dvst[ct & 1] = cv;
+            if (((ct & 1) || ct == DT - 1) && cur.live) {   // store pairs of feature tiles: whole 128-byte lines (fp32)
+#pragma unroll
+                for (int u = 0; u <= (ct & 1); ++u) {
+                    const int du = ((ct & ~1) + u) * 16 + kg * 4;
+                    if (du < D) {
+                        Io<T>::st4(dkb + cur.row * a.dk.sn + du, dkst[u]);
+                        Io<T>::st4(dvb + cur.row * a.dv.sn + du, dvst[u]);
+                        if (a.normalize && a.split) Io<T>::st4(dkdb + cur.row * a.dkd.sn + du, *reinterpret_cast<const f32x4*>(dks + du));
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        cur = nxt;
     }
 }
 

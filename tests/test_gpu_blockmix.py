@@ -124,10 +124,36 @@ def test_wan_modes(M, S, D, normalize, split):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M,S,D,split", [(150, 21, 128, True), (70, 50, 64, False), (9, 210, 128, True), (3, 33, 64, True),
-                                          (65, 16, 128, False)])
+                                          (65, 16, 128, False), (16, 64, 72, False), (5, 37, 80, True), (7, 20, 96, False),
+                                          (4, 50, 40, True), (3, 19, 8, False), (6, 45, 104, True), (5, 23, 24, True), (4, 31, 56, False),
+                                          (3, 40, 88, True), (2, 33, 120, False)])
 def test_split_operand_path(M, S, D, split, dtype):
-    """Head dims 64 / 128 outside the bf16 D=64 fast path: forward on the split-bf16 MFMA kernels (split.cuh)."""
+    """Head dims that are multiples of 8, outside the bf16 fast paths: forward and backward on the split-bf16 MFMA
+    kernels (split.cuh), including the zero-padded tile shapes (D = 72, 80, 104 ...)."""
     run_case(1, 2, M, S, D, dtype, split=split, w="rand", seed=M + S)
+
+
+@pytest.mark.parametrize("D", [72, 128])
+def test_split_operand_path_relu_prologue(D):
+    """relu(x) + eps folded into the loads (mhla_dit/mhla/mhla.py:229-230) and its gradient mask, split path."""
+    import mhla_amd
+    g = torch.Generator().manual_seed(D)
+    B, H, M, S = 2, 2, 16, 40
+    q0, k0, v, do = (torch.randn(B, M * S, H, D, generator=g).bfloat16() for _ in range(4))
+    W = orc.block_distance_weights((4, 4), "linear")
+    qf, kf = (orc.relu_eps(t.float(), 1e-6) for t in (q0, k0))
+    want = orc.blockmix_fwd(qf, kf, v.float(), W, 1e-6)
+    leaves = [t.to(DEV).requires_grad_(True) for t in (q0, k0, v)]
+    Wd = W.to(DEV).requires_grad_(True)
+    out = mhla_amd.mhla_blockmix(*leaves, Wd, eps=1e-6, relu_eps=True)
+    out.backward(do.to(DEV))
+    check("out", out, want, TOL[torch.bfloat16])
+    qa, ka, va = (t.float().requires_grad_(True) for t in (q0, k0, v))
+    Wa = W.clone().requires_grad_(True)
+    ref = orc.blockmix_fwd(torch.relu(qa) + 1e-6, torch.relu(ka) + 1e-6, va, Wa, 1e-6)
+    ref.backward(do.float())
+    for name, got, ex in zip(("dq", "dk", "dv", "dW"), [t.grad for t in leaves] + [Wd.grad], (qa.grad, ka.grad, va.grad, Wa.grad)):
+        check(name, got, ex, GTOL[torch.bfloat16])
 
 
 def test_split_operand_path_matches_exact_fp32():
@@ -140,6 +166,16 @@ def test_split_operand_path_matches_exact_fp32():
             for fg in (False, True)]
     check("out", outs[0], outs[1].cpu(), 1e-4)
     assert (outs[0] != outs[1]).any(), "force_generic selected the same kernels"
+    grads = []
+    do = torch.randn(outs[0].shape, generator=torch.Generator().manual_seed(4)).to(DEV)
+    for fg in (False, True):
+        leaves = [x.clone().requires_grad_(True) for x in t]
+        o = mhla_amd.mhla_blockmix(leaves[0], leaves[1], leaves[2], leaves[3], q_den=leaves[4], k_den=leaves[5],
+                                   block_index=idx.to(DEV), force_generic=fg)
+        o.backward(do)
+        grads.append([x.grad for x in leaves])
+    for name, a, b in zip(("dq", "dk", "dv", "dW", "dq_den", "dk_den"), grads[0], grads[1]):
+        check(name, a, b.cpu(), 2e-4)
 
 
 def test_block_index_gather():

@@ -83,5 +83,8 @@ if __name__ == "__main__":
                   torch.float32, (3, 5, 10), bwd=False, split=False, idx=idx, normalize=False)
     blockmix_case("C4 Wan fwd B=1 N=31500 H=12 D=128 M=150 fp32 split, normalised", 1, 31500, 12, 128, 150,
                   torch.float32, (3, 5, 10), bwd=False, split=True, idx=idx)
+    blockmix_case("C4 Wan fwd+bwd B=1 N=31500 H=12 D=128 M=150 fp32 split, normalised", 1, 31500, 12, 128, 150,
+                  torch.float32, (3, 5, 10), bwd=True, split=True, idx=idx)
+    blockmix_case("DiT-XL/2 512x512 op B=16 N=1024 H=16 D=72 M=16 bf16 (generic)", 16, 1024, 16, 72, 16, torch.bfloat16, (4, 4))
     blockmix_case("C2 variant M=16 S=256 bf16 (fast path, multi-chunk blocks)", 8, 4096, 16, 64, 16, torch.bfloat16, (4, 4))
     causal_case("C5 fla 340M causal B=4 T=8192 H=4 K=128 V=256 bf16", 4, 8192, 4, 128, 256, torch.bfloat16)

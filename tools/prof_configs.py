@@ -37,3 +37,19 @@ qq, kk, vv, q2, k2 = mk().abs(), mk().abs(), mk(), mk().abs(), mk().abs()
 W = block_distance_weights((3, 5, 10), "linear").to(DEV)
 idx = block_index_3d((21, 30, 50), (3, 5, 10)).to(DEV)
 prof(lambda: mhla_amd.mhla_blockmix(qq, kk, vv, W, q_den=q2, k_den=k2, block_index=idx), "C4 Wan fwd normalised")
+qs = [t.clone().requires_grad_(True) for t in (qq, kk, vv, q2, k2)]
+Wg = W.clone().requires_grad_(True)
+dd = mk()
+def c4b():
+    o = mhla_amd.mhla_blockmix(qs[0], qs[1], qs[2], Wg, q_den=qs[3], k_den=qs[4], block_index=idx); o.backward(dd)
+    for t in qs + [Wg]: t.grad = None
+prof(c4b, "C4 Wan fwd+bwd normalised")
+B, N, H, D, M = 16, 1024, 16, 72, 16
+mkb = lambda: torch.randn(B, N, H, D, generator=g).abs().bfloat16().to(DEV).requires_grad_(True)
+xq, xk, xv = mkb(), mkb(), mkb()
+xo = torch.randn(B, N, H, D, generator=g).bfloat16().to(DEV)
+W2 = block_distance_weights((4, 4), "linear").to(DEV).requires_grad_(True)
+def xl():
+    o = mhla_amd.mhla_blockmix(xq, xk, xv, W2); o.backward(xo)
+    for t in (xq, xk, xv, W2): t.grad = None
+prof(xl, "DiT-XL/2 512x512 op bf16 D=72 fwd+bwd")
