@@ -629,7 +629,7 @@ __global__ __launch_bounds__(FT8) void k_fs_dw(const FsDwArgs a) {
     u16* Bi = Ai + DW_EC * DW_LDI;                // KV image
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 15, kg = lane >> 4;
     const int wi = wave & 3, wj = wave >> 2;   // wave -> rows i = 16 wi .., columns j = 32 wj ..
-    const int qtr = blockIdx.x, bh = blockIdx.y, M = a.M, njg = a.njg;
+    const int qtr = blockIdx.x, bh = blockIdx.y, njg = a.njg;
     const u16* dg = a.dg + (long)bh * njg * FE * IT;
     const u16* kv = a.kv + (long)bh * njg * FE * IT;
     f32x4 acc[2];

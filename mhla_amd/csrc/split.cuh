@@ -599,27 +599,23 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_bwd_dq(const TokArgs a) {
             gh[ks] = as_bf16x8(hi);
             gl[ks] = as_bf16x8(lo);
         }
-        auto epilogue = [&](int ct, f32x4 c) {
+        // gradient of one feature tile in output layout (4 features of the lane's token) and its q_den companion
+        auto epilogue = [&](int ct, f32x4& c, f32x4& cd) {
             const int d0 = ct * 16 + kg * 4;
-            if (d0 < D) {
-                f32x4 qd = cur.qd[ct];
-                if (a.relu)
+            f32x4 qd = cur.qd[ct];
+            if (a.relu)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) qd[i] = fmaxf(qd[i], 0.f) + a.eps;
-                const f32x4 ks4 = *reinterpret_cast<const f32x4*>(ksum + d0);
-                if (a.normalize) {
-                    dksp[ct] += cur.dz * qd;
-                    if (!a.split) c += cur.dz * ks4;
-                }
-                if (a.relu)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        if (!(qd[i] > a.eps)) c[i] = 0.f;
-                if (cur.live) {
-                    Io<T>::st4(dqb + cur.row * a.dq.sn + d0, c);
-                    if (a.normalize && a.split) Io<T>::st4(dqdb + cur.row * a.dqd.sn + d0, cur.dz * ks4);
-                }
+                for (int i = 0; i < 4; ++i) qd[i] = fmaxf(qd[i], 0.f) + a.eps;
+            const f32x4 ks4 = *reinterpret_cast<const f32x4*>(ksum + d0);
+            cd = cur.dz * ks4;
+            if (a.normalize) {
+                dksp[ct] += cur.dz * qd;
+                if (!a.split) c += cd;
             }
+            if (a.relu)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (!(qd[i] > a.eps)) c[i] = 0.f;
         };
 #pragma unroll
         for (int ct = 0; ct < DT; ct += 2) {   // two feature tiles at a time: independent MFMA chains, adjacent stores
@@ -637,8 +633,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_bwd_dq(const TokArgs a) {
                 c0 = mfma_bf16(a0h, gl[ks], c0);
                 c1 = mfma_bf16(a1h, gl[ks], c1);
             }
-            epilogue(ct, c0);
-            if (ct + 1 < DT) epilogue(ct + 1, c1);
+            f32x4 e0, e1 = {0.f, 0.f, 0.f, 0.f};
+            epilogue(ct, c0, e0);
+            if (ct + 1 < DT) epilogue(ct + 1, c1, e1);
+            // the two 64-byte halves of a 128-byte line go out in consecutive store instructions (write combining):
+            // half-line stores separated in time cost a fill read and a second write per line
+            const int d0 = ct * 16 + kg * 4, d1 = d0 + 16;
+            if (cur.live) {
+                if (d0 < D) Io<T>::st4(dqb + cur.row * a.dq.sn + d0, c0);
+                if (ct + 1 < DT && d1 < D) Io<T>::st4(dqb + cur.row * a.dq.sn + d1, c1);
+                if (a.normalize && a.split) {
+                    if (d0 < D) Io<T>::st4(dqdb + cur.row * a.dqd.sn + d0, e0);
+                    if (ct + 1 < DT && d1 < D) Io<T>::st4(dqdb + cur.row * a.dqd.sn + d1, e1);
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);   // keep the LDS operand reads of later tiles from being hoisted (register pressure)
         }
         cur = nxt;
@@ -746,14 +754,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_bwd_dkv(const TokArgs a) {
             dkst[ct & 1] = ck;
             dvst[ct & 1] = cv;
             if (((ct & 1) || ct == DT - 1) && cur.live) {   // store pairs of feature tiles: whole 128-byte lines (fp32)
-#pragma unroll
-                for (int u = 0; u <= (ct & 1); ++u) {
-                    const int du = ((ct & ~1) + u) * 16 + kg * 4;
-                    if (du < D) {
-                        Io<T>::st4(dkb + cur.row * a.dk.sn + du, dkst[u]);
-                        Io<T>::st4(dvb + cur.row * a.dv.sn + du, dvst[u]);
-                        if (a.normalize && a.split) Io<T>::st4(dkdb + cur.row * a.dkd.sn + du, *reinterpret_cast<const f32x4*>(dks + du));
-                    }
+                const int da = (ct & ~1) * 16 + kg * 4, db = da + 16;
+                const bool sa = da < D, sb = (ct & 1) && db < D;
+                if (sa) Io<T>::st4(dkb + cur.row * a.dk.sn + da, dkst[0]);
+                if (sb) Io<T>::st4(dkb + cur.row * a.dk.sn + db, dkst[1]);
+                if (sa) Io<T>::st4(dvb + cur.row * a.dv.sn + da, dvst[0]);
+                if (sb) Io<T>::st4(dvb + cur.row * a.dv.sn + db, dvst[1]);
+                if (a.normalize && a.split) {
+                    if (sa) Io<T>::st4(dkdb + cur.row * a.dkd.sn + da, *reinterpret_cast<const f32x4*>(dks + da));
+                    if (sb) Io<T>::st4(dkdb + cur.row * a.dkd.sn + db, *reinterpret_cast<const f32x4*>(dks + db));
                 }
             }
             __builtin_amdgcn_sched_barrier(0);

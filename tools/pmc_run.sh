@@ -1,14 +1,16 @@
 #!/bin/bash
 # Collect rocprofv3 PMC counters for bench.py's kernels in separate passes (counters only: no trace domains
 # besides --kernel-trace).  Usage: tools/pmc_run.sh <outdir> [bench args...]
+# PMC_SCRIPT=<path relative to the repo root> profiles that script instead of bench.py (its own arguments follow <outdir>).
 set -u
 OUT=$1; shift
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
+if [ -n "${PMC_SCRIPT:-}" ]; then CMD="$ROOT/$PMC_SCRIPT $*"; else CMD="$ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline $*"; fi
 run() {  # name, counters...
   local name=$1; shift
-  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/$name" -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/$name.log" 2>&1
+  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/$name" -- python3 $CMD > "$OUT/$name.log" 2>&1
 }
 run fetch FETCH_SIZE
 run write WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
