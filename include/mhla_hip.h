@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MHLA_ABI_VERSION 2
+#define MHLA_ABI_VERSION 3
 
 enum { MHLA_F32 = 0, MHLA_BF16 = 1, MHLA_F16 = 2 };
 
@@ -99,6 +99,24 @@ int mhla_blockmix_fwd(mhla_view q_num, mhla_view k_num, mhla_view v,
                       int dtype, float eps, unsigned flags, void* stream);
 
 /*
+ * Forward with the rotary prologue of the Wan host fused in (inference): replaces
+ * wan/mhla_utils.py:314 (rope_apply of q and k, :127-156) + :317-341.  q, k are the un-rotated
+ * tensors; the kernels rotate consecutive channel pairs (2i, 2i+1) of token row n by
+ * (rope_cos[n*ld_rope + i], rope_sin[n*ld_rope + i]) while loading them: rotated k feeds KV,
+ * rotated q the numerator, the plain q, k the normaliser (normalize != 0).  The tables are
+ * [rows of one batch item][D/2] fp32, indexed by the token's memory row (the same index
+ * block_index maps to), shared by all heads and batch items.  No q_rope / k_rope tensors exist.
+ * Workspace: mhla_blockmix_fwd_ws_bytes(..., split = 0, flags).  Needs D % 8 == 0.
+ */
+int mhla_blockmix_rope_fwd(mhla_view q, mhla_view k, mhla_view v, int normalize,
+                           const float* W, int ldw,
+                           const float* rope_cos, const float* rope_sin, int64_t ld_rope,
+                           mhla_mview out, const int32_t* block_index,
+                           void* ws, size_t ws_bytes,
+                           int B, int H, int M, int S, int D,
+                           int dtype, float eps, unsigned flags, void* stream);
+
+/*
  * Backward (autograd of the forward above; hand-derived).
  * Needs only the forward's inputs, its output `out` and the upstream gradient
  * `dout`: the block summaries are recomputed -- unless the caller kept the
@@ -144,6 +162,18 @@ int mhla_causal_bwd(mhla_view q, mhla_view k, mhla_view v, const float* mix, int
                     float* dmix, int lddmix, void* ws, size_t ws_bytes,
                     int B, int T, int H, int K, int V, int chunk,
                     float scale, int dtype, void* stream);
+
+/* ---- prologue: q / k of the Wan host -------------------------------------- */
+
+/*
+ * y = relu(rmsnorm_C(x) * w) + eps  per token row over the whole channel dim C = H*D.
+ * Replaces wan/mhla_utils.py:268-272 (norm_q / norm_k = WanRMSNorm(dim), wan/model.py:181-196,
+ * then relu + eps) after the .float() at :308: x is the projection output in `dtype`, y fp32.
+ * norm == 0 (qk_norm=False): y = relu(x) + eps.  w: fp32 [C] or NULL.  C % 8 == 0, C <= 4096.
+ */
+int mhla_qk_prologue(const void* x, int64_t ldx, const float* w, float* y, int64_t ldy,
+                     int64_t rows, int C, int norm, float norm_eps, float eps,
+                     int dtype, void* stream);
 
 /* ---- epilogue: per-head RMSNorm (x optional swish gate) ----------------- */
 

@@ -7,7 +7,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmhla_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 F32, BF16, F16 = 0, 1, 2
 FLAG_RELU_EPS = 1
 FLAG_FORCE_GENERIC = 2
@@ -32,6 +32,9 @@ SIGNATURES = {
     "mhla_blockmix_fwd_keeps_state": (c_int, [c_int] * 7 + [c_uint]),
     "mhla_blockmix_fwd": (c_int, [View, View, View, View, View, c_void_p, c_int, View, c_void_p, c_void_p, c_size_t,
                                   c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_uint, c_void_p]),
+    "mhla_blockmix_rope_fwd": (c_int, [View, View, View, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int64, View, c_void_p,
+                                       c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_uint,
+                                       c_void_p]),
     "mhla_blockmix_bwd": (c_int, [View, View, View, View, View, c_void_p, c_int, View, View, View, View, View, View,
                                   View, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_int, c_int, c_int, c_int,
                                   c_int, c_int, c_float, c_uint, c_void_p]),
@@ -41,6 +44,8 @@ SIGNATURES = {
                                 c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "mhla_causal_bwd": (c_int, [View, View, View, c_void_p, c_int, View, View, View, View, c_void_p, c_int, c_void_p,
                                 c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
+    "mhla_qk_prologue": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_float, c_float,
+                                 c_int, c_void_p]),
     "mhla_rmsnorm_gate_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p,
                                       c_int64, c_int, c_float, c_int, c_void_p]),
     "mhla_rmsnorm_gate_dw_rows": (c_int64, [c_int64]),

@@ -90,6 +90,10 @@ struct StateArgs {
     int DX, DY;
     long T;
     float alpha;
+    // fused rotary prologue (split.cuh, MODE 0): x feeds KV rotated by the token's angles, cos/sin [rows][D/2] fp32
+    const float* rcos;
+    const float* rsin;
+    long ldr;
 };
 
 template <int DT>
@@ -339,6 +343,9 @@ struct OutArgs {
     int H, M, S, D;
     float eps;
     int relu, normalize;
+    const float* rcos;   // fused rotary prologue (split.cuh): q is rotated while it is loaded
+    const float* rsin;
+    long ldr;
 };
 
 template <int DT>

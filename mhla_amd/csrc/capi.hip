@@ -190,9 +190,11 @@ int bm_check(int B, int H, int M, int S, int D, int dtype, unsigned flags, bool 
 template <typename T, int DT>
 int bm_state_and_mix(const mhla_view& q_num, const mhla_view& k_num, const mhla_view& v, const mhla_view& q_den,
                      const mhla_view& k_den, const float* W, int ldw, const int32_t* idx, const BmWs& w, int B, int H,
-                     int M, int S, int D, float eps, unsigned flags, bool normalize, bool split, hipStream_t st) {
+                     int M, int S, int D, float eps, unsigned flags, bool normalize, bool split, hipStream_t st,
+                     const float* rcos = nullptr, const float* rsin = nullptr, long ldr = 0) {
     (void)q_num;
     StateArgs a{};
+    a.rcos = rcos; a.rsin = rsin; a.ldr = ldr;
     a.x = cv(k_num); a.y = cv(v); a.kd = cv(k_den); a.qd = cv(q_den); a.idx = idx;
     a.out = w.kv; a.ksum = w.ksum; a.zo = w.z;
     a.H = H; a.M = M; a.S = S; a.D = D; a.eps = eps;
@@ -324,9 +326,10 @@ size_t mhla_blockmix_bwd_ws_bytes(int B, int H, int M, int S, int D, int dtype, 
     return bm_carve(nullptr, B, H, M, S, D).total_bwd;
 }
 
-int mhla_blockmix_fwd(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q_den, mhla_view k_den, const float* W,
-                      int ldw, mhla_mview out, const int32_t* block_index, void* ws, size_t ws_bytes, int B, int H,
-                      int M, int S, int D, int dtype, float eps, unsigned flags, void* stream) {
+static int bm_fwd_impl(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q_den, mhla_view k_den, const float* W,
+                       int ldw, mhla_mview out, const int32_t* block_index, void* ws, size_t ws_bytes, int B, int H,
+                       int M, int S, int D, int dtype, float eps, unsigned flags, void* stream, const float* rcos,
+                       const float* rsin, long ldr) {
     const bool normalize = q_den.ptr != nullptr;
     const bool split = normalize && (q_den.ptr != q_num.ptr || k_den.ptr != k_num.ptr);
     RC(bm_check(B, H, M, S, D, dtype, flags, normalize, split));
@@ -338,7 +341,8 @@ int mhla_blockmix_fwd(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q
     if (!normalize) { q_den = q_num; k_den = k_num; }
     const int relu = (flags & MHLA_FLAG_RELU_EPS) ? 1 : 0;
     const mhla_view outv{out.ptr, out.sb, out.sn, out.sh};
-    if (sn_shape_ok(M, S, D, dtype, split) && !(flags & (MHLA_FLAG_FORCE_GENERIC | MHLA_FLAG_NO_SMALLN)) && view_ok16(q_num) &&
+    if (rcos && !sp_shape_ok(D, flags)) return fail(MHLA_ENOTSUP, "fused rotary prologue needs D %% 8 == 0 and the split-operand kernels (D=%d, flags=%u)", D, flags);
+    if (!rcos && sn_shape_ok(M, S, D, dtype, split) && !(flags & (MHLA_FLAG_FORCE_GENERIC | MHLA_FLAG_NO_SMALLN)) && view_ok16(q_num) &&
         view_ok16(k_num) && view_ok16(v) && view_ok16(outv)) {
         fast::SnArgs sa{};
         sa.q = cv(q_num); sa.k = cv(k_num); sa.v = cv(v); sa.out = cmv(out); sa.idx = block_index; sa.W = W; sa.ldw = ldw;
@@ -347,7 +351,7 @@ int mhla_blockmix_fwd(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q
         else         RC(launch(fast::k_sn_fwd<5>, dim3(B * H), dim3(fast::SN_T), fast::sn_fwd_smem<5>(), st, "k_sn_fwd<5>", sa));
         return MHLA_OK;
     }
-    if (fast_shape_ok(M, D, dtype, split) && !(flags & MHLA_FLAG_FORCE_GENERIC) && view_ok16(q_num) && view_ok16(k_num) &&
+    if (!rcos && fast_shape_ok(M, D, dtype, split) && !(flags & MHLA_FLAG_FORCE_GENERIC) && view_ok16(q_num) && view_ok16(k_num) &&
         view_ok16(v) && view_ok16(outv)) {
         const FastWs f = fast_carve(ws, B, H, M, S);
         if (ws_bytes < f.total_fwd) return fail(MHLA_EINVAL, "workspace too small: %zu < %zu bytes", ws_bytes, f.total_fwd);
@@ -367,8 +371,9 @@ int mhla_blockmix_fwd(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q
     if (ws_bytes < w.total_fwd) return fail(MHLA_EINVAL, "workspace too small: %zu < %zu bytes", ws_bytes, w.total_fwd);
     const int dt = dt_for(D);
     DISPATCH_T(dtype, DISPATCH_DT(dt, {
-        RC((bm_state_and_mix<ET, DT>(q_num, k_num, v, q_den, k_den, W, ldw, block_index, w, B, H, M, S, D, eps, flags, normalize, split, st)));
+        RC((bm_state_and_mix<ET, DT>(q_num, k_num, v, q_den, k_den, W, ldw, block_index, w, B, H, M, S, D, eps, flags, normalize, split, st, rcos, rsin, ldr)));
         OutArgs o{};
+        o.rcos = rcos; o.rsin = rsin; o.ldr = ldr;
         o.q = cv(q_num); o.o = cmv(out); o.idx = block_index; o.W = W; o.ldw = ldw; o.g = w.g; o.ninv = w.ninv;
         o.H = H; o.M = M; o.S = S; o.D = D; o.eps = eps;
         o.relu = (flags & MHLA_FLAG_RELU_EPS) ? 1 : 0; o.normalize = normalize;
@@ -378,6 +383,26 @@ int mhla_blockmix_fwd(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q
             RC(launch(k_bm_out<ET, DT>, dim3(M, B * H), dim3(NTHREADS), out_smem_floats<DT>() * 4, st, "k_bm_out", o));
     }));
     return MHLA_OK;
+}
+
+int mhla_blockmix_fwd(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q_den, mhla_view k_den, const float* W,
+                      int ldw, mhla_mview out, const int32_t* block_index, void* ws, size_t ws_bytes, int B, int H,
+                      int M, int S, int D, int dtype, float eps, unsigned flags, void* stream) {
+    return bm_fwd_impl(q_num, k_num, v, q_den, k_den, W, ldw, out, block_index, ws, ws_bytes, B, H, M, S, D, dtype, eps, flags,
+                       stream, nullptr, nullptr, 0);
+}
+
+int mhla_blockmix_rope_fwd(mhla_view q, mhla_view k, mhla_view v, int normalize, const float* W, int ldw,
+                           const float* rope_cos, const float* rope_sin, int64_t ld_rope, mhla_mview out,
+                           const int32_t* block_index, void* ws, size_t ws_bytes, int B, int H, int M, int S, int D,
+                           int dtype, float eps, unsigned flags, void* stream) {
+    if (!rope_cos || !rope_sin) return fail(MHLA_EINVAL, "rope tables null");
+    if (ld_rope < D / 2 || (ld_rope & 3) || ((uintptr_t)rope_cos | (uintptr_t)rope_sin) % 16)
+        return fail(MHLA_EINVAL, "rope tables: ld=%lld must be >= D/2, a multiple of 4, and the tables 16-byte aligned", (long long)ld_rope);
+    if (flags & MHLA_FLAG_RELU_EPS) return fail(MHLA_ENOTSUP, "relu prologue and rotary prologue are not combined (Wan applies relu before the norm output is roped: use mhla_qk_prologue)");
+    const mhla_view none{nullptr, 0, 0, 0};
+    return bm_fwd_impl(q, k, v, normalize ? q : none, normalize ? k : none, W, ldw, out, block_index, ws, ws_bytes, B, H, M, S, D,
+                       dtype, eps, flags, stream, rope_cos, rope_sin, (long)ld_rope);
 }
 
 int mhla_blockmix_bwd(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q_den, mhla_view k_den, const float* W,
@@ -625,6 +650,24 @@ int mhla_rmsnorm_gate_fwd(const void* x, int64_t ldx, const void* g, int64_t ldg
             if (g) RC(launch(k_rmsnorm_gate_fwd<ET, 2, true>, grid, dim3(256), 0, st, "k_rmsnorm_gate_fwd", a));
             else   RC(launch(k_rmsnorm_gate_fwd<ET, 2, false>, grid, dim3(256), 0, st, "k_rmsnorm_gate_fwd", a));
         }
+    });
+    return MHLA_OK;
+}
+
+int mhla_qk_prologue(const void* x, int64_t ldx, const float* w, float* y, int64_t ldy, int64_t rows, int C, int norm,
+                     float norm_eps, float eps, int dtype, void* stream) {
+    if (!x || !y) return fail(MHLA_EINVAL, "null pointer");
+    if (rows <= 0 || C <= 0 || (C & 7) || C > 8 * 64 * 8) return fail(MHLA_EINVAL, "rows=%lld C=%d: need C %% 8 == 0 and C <= 4096", (long long)rows, C);
+    if ((ldx | ldy) & 3) return fail(MHLA_EINVAL, "row strides must be multiples of 4");
+    if (dtype < 0 || dtype > 2) return fail(MHLA_EINVAL, "unknown dtype %d", dtype);
+    PrologueArgs a{x, (long)ldx, w, y, (long)ldy, (long)rows, C, norm_eps, eps, norm ? 1 : 0};
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t gsz = (rows + 3) / 4;
+    const dim3 grid((unsigned)(gsz < 16384 ? gsz : 16384));
+    DISPATCH_T(dtype, {
+        if (C <= 1024)      RC(launch(k_qk_prologue<ET, 2>, grid, dim3(256), 0, st, "k_qk_prologue", a));
+        else if (C <= 2048) RC(launch(k_qk_prologue<ET, 4>, grid, dim3(256), 0, st, "k_qk_prologue", a));
+        else                RC(launch(k_qk_prologue<ET, 8>, grid, dim3(256), 0, st, "k_qk_prologue", a));
     });
     return MHLA_OK;
 }

@@ -138,4 +138,64 @@ __global__ __launch_bounds__(256) void k_rmsnorm_gate_bwd(const NormArgs a) {
         a.dwp[(long)blockIdx.x * a.D + c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
 }
 
+// -------------------------------------------------------------------------------------------------
+// q / k prologue of Wan's MHLA_Video_Uni (mhla_videogen/diffusion/model/wan/mhla_utils.py:268-272 after the
+// .float() at :308):  y = relu(rmsnorm_C(x) * w) + eps over the whole channel dim C = H * D of a token, x in the
+// dtype of the projection (bf16 / fp16 / fp32), y fp32.  One wave per token row, the row stays in registers
+// (C <= 8 * 64 * NV); w == nullptr skips the norm (qk_norm = False: relu(x) + eps).
+// -------------------------------------------------------------------------------------------------
+struct PrologueArgs {
+    const void* x;
+    long ldx;
+    const float* w;
+    float* y;
+    long ldy;
+    long rows;
+    int C;
+    float norm_eps, eps;
+    int norm;
+};
+
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void k_qk_prologue(const PrologueArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long nw = (long)gridDim.x * 4;
+    for (long row = (long)blockIdx.x * 4 + wave; row < a.rows; row += nw) {
+        const T* xr = (const T*)a.x + row * a.ldx;
+        f32x4 xv[NV][2];
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (lane + 64 * i) * 8;
+            xv[i][0] = xv[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (c < a.C) {
+                xv[i][0] = Io<T>::ld4(xr + c);
+                xv[i][1] = Io<T>::ld4(xr + c + 4);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) ss += xv[i][0][t] * xv[i][0][t] + xv[i][1][t] * xv[i][1][t];
+        }
+        float rstd = 1.f;
+        if (a.norm) {
+            ss = wave_sum(ss);
+            rstd = 1.f / sqrtf(ss / (float)a.C + a.norm_eps);
+        }
+        float* yr = a.y + row * a.ldy;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (lane + 64 * i) * 8;
+            if (c < a.C) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    f32x4 y = xv[i][u] * rstd;
+                    if (a.w) y *= *reinterpret_cast<const f32x4*>(a.w + c + 4 * u);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) y[t] = fmaxf(y[t], 0.f) + a.eps;
+                    *reinterpret_cast<f32x4*>(yr + c + 4 * u) = y;
+                }
+            }
+        }
+    }
+}
+
 }  // namespace mhla

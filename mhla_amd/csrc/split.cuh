@@ -50,6 +50,15 @@ __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, uint4& hi
     lo = make_uint4(l[0], l[1], l[2], l[3]);
 }
 __device__ __forceinline__ bf16x8 as_bf16x8(const uint4& v) { return __builtin_bit_cast(bf16x8, v); }
+// rotate the 4 consecutive channel pairs (x[2i], x[2i+1]) held in (a, b) by the angles (c[i], s[i])
+// (rope_apply, wan/mhla_utils.py:127-156: complex multiply of consecutive pairs)
+__device__ __forceinline__ void rope8(f32x4& a, f32x4& b, const f32x4& c, const f32x4& s) {
+    const f32x4 a0 = a, b0 = b;
+    a[0] = a0[0] * c[0] - a0[1] * s[0]; a[1] = a0[0] * s[0] + a0[1] * c[0];
+    a[2] = a0[2] * c[1] - a0[3] * s[1]; a[3] = a0[2] * s[1] + a0[3] * c[1];
+    b[0] = b0[0] * c[2] - b0[1] * s[2]; b[1] = b0[0] * s[2] + b0[1] * c[2];
+    b[2] = b0[2] * c[3] - b0[3] * s[3]; b[3] = b0[2] * s[3] + b0[3] * c[3];
+}
 
 template <int DT> struct Geo {
     static constexpr int CGS = DT > 4 ? 16 : 8;        // column groups of 8 per tile row
@@ -89,8 +98,9 @@ __global__ __launch_bounds__(NTHREADS) void k_sp_state(const StateArgs a) {
     const int r0 = tid / CGS, cg = (tid % CGS) * 8;
     const float* ninvb = a.ninv + ((long)bh * a.M + blk) * S;   // MODE 1
 
-    f32x4 kx[IT][2], vx[IT][2], dx[IT][2];
+    f32x4 kx[IT][2], vx[IT][2], dx[IT][2], rc[IT], rs[IT];
     float nv[IT];
+    const bool rope = MODE == 0 && a.rcos != nullptr;
     int crow = 0;   // first token of the chunk held in registers
     auto fetch = [&](int c0) {
         crow = c0;
@@ -106,6 +116,10 @@ __global__ __launch_bounds__(NTHREADS) void k_sp_state(const StateArgs a) {
                 if (a.relu) relu8(kx[it][0], kx[it][1], a.eps);
                 if (den) ld8(kdb + row * third.sn + cg, dx[it][0], dx[it][1]);
                 if (MODE == 1 && a.normalize) nv[it] = ninvb[r];
+                if (rope) {
+                    rc[it] = *reinterpret_cast<const f32x4*>(a.rcos + row * a.ldr + cg / 2);
+                    rs[it] = *reinterpret_cast<const f32x4*>(a.rsin + row * a.ldr + cg / 2);
+                }
             }
         }
     };
@@ -126,7 +140,13 @@ __global__ __launch_bounds__(NTHREADS) void k_sp_state(const StateArgs a) {
                 vx[it][0] *= nv[it];
                 vx[it][1] *= nv[it];
             }
-            split8(kx[it][0], kx[it][1], hi, lo);
+            if (rope) {   // KV takes the rotated keys, ksum the plain ones
+                f32x4 r0 = kx[it][0], r1 = kx[it][1];
+                rope8(r0, r1, rc[it], rs[it]);
+                split8(r0, r1, hi, lo);
+            } else {
+                split8(kx[it][0], kx[it][1], hi, lo);
+            }
             *reinterpret_cast<uint4*>(Kh + off) = hi;
             if (LO) *reinterpret_cast<uint4*>(Kl + off) = lo;
             split8(vx[it][0], vx[it][1], hi, lo);
@@ -376,6 +396,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_out(const OutArgs a) {
             if (ks * 32 + kg * 8 < D) {
                 ld8(qrow + ks * 32, x0, x1);
                 if (a.relu) relu8(x0, x1, a.eps);
+                if (a.rcos) {
+                    const long ro = row * a.ldr + ks * 16 + kg * 4;
+                    rope8(x0, x1, *reinterpret_cast<const f32x4*>(a.rcos + ro), *reinterpret_cast<const f32x4*>(a.rsin + ro));
+                }
             }
             uint4 hi, lo;
             split8(x0, x1, hi, lo);

@@ -11,7 +11,7 @@ from typing import Dict, Tuple
 import torch
 from torch import nn
 
-from ..ops import mhla_blockmix, rmsnorm_gate
+from ..ops import mhla_blockmix, mhla_blockmix_rope, qk_prologue, rmsnorm_gate
 from ..weights import block_index_3d
 from .blockconv import BlockDistanceConv3D
 
@@ -144,16 +144,27 @@ class MHLA_Video_Uni(nn.Module):
             F_, H_, W_ = grid
             lepe = self.lepe(v.reshape(B, F_, H_, W_, C).permute(0, 4, 1, 2, 3)).permute(0, 2, 3, 4, 1).reshape(B, N, C)
         dtype = q.dtype
-        q, k, v = q.float(), k.float(), v.float()                     # mhla_utils.py:308
-        q = torch.relu(self.norm_q(q)) + self.eps                     # :268-272
-        k = torch.relu(self.norm_k(k)) + self.eps
-        q, k, v = (t.reshape(B, N, H, D) for t in (q, k, v))
-        q_rope, k_rope = rope_apply(q, cos, sin), rope_apply(k, cos, sin)   # :314
         W = self.block_attn.conv.weight
-        if self.normalize_out:
-            out = mhla_blockmix(q_rope, k_rope, v, W, eps=self.eps, q_den=q, k_den=k, block_index=idx)
+        fused = (not (torch.is_grad_enabled() and (x.requires_grad or W.requires_grad or self.q.weight.requires_grad))
+                 and D % 8 == 0 and C <= 4096)
+        if fused:
+            # inference: norm + relu + eps in one kernel per tensor, rotation inside the operator's loads
+            wq = self.norm_q.weight if isinstance(self.norm_q, WanRMSNorm) else None
+            wk = self.norm_k.weight if isinstance(self.norm_k, WanRMSNorm) else None
+            q = qk_prologue(q, wq, getattr(self.norm_q, "eps", 0.0), self.eps).reshape(B, N, H, D)
+            k = qk_prologue(k, wk, getattr(self.norm_k, "eps", 0.0), self.eps).reshape(B, N, H, D)
+            out = mhla_blockmix_rope(q, k, v.float().reshape(B, N, H, D), W, cos, sin, eps=self.eps,
+                                     normalize=self.normalize_out, block_index=idx)
         else:
-            out = mhla_blockmix(q_rope, k_rope, v, W, eps=self.eps, normalize=False, block_index=idx)
+            q, k, v = q.float(), k.float(), v.float()                     # mhla_utils.py:308
+            q = torch.relu(self.norm_q(q)) + self.eps                     # :268-272
+            k = torch.relu(self.norm_k(k)) + self.eps
+            q, k, v = (t.reshape(B, N, H, D) for t in (q, k, v))
+            q_rope, k_rope = rope_apply(q, cos, sin), rope_apply(k, cos, sin)   # :314
+            if self.normalize_out:
+                out = mhla_blockmix(q_rope, k_rope, v, W, eps=self.eps, q_den=q, k_den=k, block_index=idx)
+            else:
+                out = mhla_blockmix(q_rope, k_rope, v, W, eps=self.eps, normalize=False, block_index=idx)
         out = out.to(dtype)                                           # :356
         gate = self.g(x).reshape(B, N, H, D) if self.is_gated else None
         out = rmsnorm_gate(out, gate, self.g_norm.weight, self.g_norm.eps).reshape(B, N, C)   # :357-362

@@ -170,6 +170,61 @@ def mhla_blockmix(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, W: torch.Te
     return _BlockMix.apply(q, k, v, W, q_den, k_den, block_index, eps, normalize, relu_eps, force_generic, no_smalln)
 
 
+def mhla_blockmix_rope(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, W: torch.Tensor, rope_cos: torch.Tensor,
+                       rope_sin: torch.Tensor, *, eps: float = 1e-6, normalize: bool = True,
+                       block_index: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Block-mixing operator with Wan's rotary prologue fused in (wan/mhla_utils.py:314 + :317-341), inference only.
+
+    q, k are the un-rotated tensors ([B, N, H, D]); rope_cos / rope_sin are fp32 [N, D/2] (the multiplier of `rope_apply`
+    per token row).  Rotated k feeds KV, rotated q the numerator, plain q / k the normaliser -- no q_rope / k_rope
+    tensors are materialised.  Not differentiable: raises if an input requires grad while grad mode is on (apply the
+    rotation in the host and call `mhla_blockmix` with q_den / k_den for training)."""
+    lib = _lib.load()
+    if torch.is_grad_enabled() and any(t.requires_grad for t in (q, k, v, W)):
+        raise RuntimeError("mhla_blockmix_rope is forward-only; use mhla_blockmix(q_rope, k_rope, v, W, q_den=q, k_den=k) for training")
+    _require_gpu(q, k, v, W, rope_cos, rope_sin, block_index)
+    if block_index is not None and (block_index.dtype != torch.int32 or not block_index.is_contiguous()):
+        raise TypeError("block_index must be a contiguous int32 tensor")
+    B, N, H, D = q.shape
+    M = W.shape[0]
+    if N % M:
+        raise ValueError(f"N={N} tokens not divisible into M={M} blocks")
+    S = N // M
+    if rope_cos.shape != (N, D // 2) or rope_sin.shape != (N, D // 2) or rope_cos.dtype != torch.float32 or rope_sin.dtype != torch.float32:
+        raise ValueError(f"rope tables must be fp32 [N={N}, D/2={D // 2}]")
+    q, k, v = _prep(q.detach()), _prep(k.detach()), _prep(v.detach())
+    cos, sin = rope_cos.contiguous(), rope_sin.contiguous()
+    Wf = W.detach().reshape(M, M).to(torch.float32).contiguous()
+    out = torch.empty((B, N, H, D), dtype=q.dtype, device=q.device)
+    dt = _dtype_code(q)
+    ws = _ws(lib.mhla_blockmix_fwd_ws_bytes(B, H, M, S, D, dt, 0, 0), q.device)
+    rc = lib.mhla_blockmix_rope_fwd(_view(q), _view(k), _view(v), int(bool(normalize)), Wf.data_ptr(), M, cos.data_ptr(),
+                                    sin.data_ptr(), cos.stride(0), _view(out),
+                                    block_index.data_ptr() if block_index is not None else None, ws.data_ptr(),
+                                    ws.numel() * 4, B, H, M, S, D, dt, float(eps), 0, _stream())
+    _lib.check(rc, "mhla_blockmix_rope_fwd")
+    return out
+
+
+def qk_prologue(x: torch.Tensor, weight: Optional[torch.Tensor], norm_eps: float = 1e-5, eps: float = 1e-6) -> torch.Tensor:
+    """relu(rmsnorm(x) * weight) + eps over the last dim, fp32 output -- the q / k prologue of Wan's MHLA_Video_Uni
+    (wan/mhla_utils.py:268-272 after the .float() at :308), one HIP kernel, forward only.  weight None: relu(x) + eps."""
+    lib = _lib.load()
+    if torch.is_grad_enabled() and (x.requires_grad or (weight is not None and weight.requires_grad)):
+        raise RuntimeError("qk_prologue is forward-only")
+    _require_gpu(x, weight)
+    C = x.shape[-1]
+    x2 = x.detach().reshape(-1, C)
+    if x2.stride(-1) != 1:
+        x2 = x2.contiguous()
+    y = torch.empty(x2.shape, dtype=torch.float32, device=x.device)
+    w = weight.detach().to(torch.float32).contiguous() if weight is not None else None
+    rc = lib.mhla_qk_prologue(x2.data_ptr(), x2.stride(0), w.data_ptr() if w is not None else None, y.data_ptr(), C,
+                              x2.shape[0], C, int(weight is not None), float(norm_eps), float(eps), _dtype_code(x2), _stream())
+    _lib.check(rc, "mhla_qk_prologue")
+    return y.reshape(x.shape)
+
+
 # ------------------------------------------------------------------------------------------
 # causal chunk-mixing MHLA (fla)
 # ------------------------------------------------------------------------------------------

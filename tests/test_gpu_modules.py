@@ -60,6 +60,69 @@ def test_wan_module_matches_reference(tag):
     assert m.block_attn.conv.weight.grad is not None and torch.isfinite(x.grad).all()
 
 
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_wan_module_fused_inference_path(tag):
+    """Under no_grad the module takes the fused prologue (norm + relu + eps kernel, rotation inside the operator's loads):
+    same result as the reference fixture and as the unfused training path."""
+    from mhla_amd import modules
+    g = load_golden("wan_" + tag)
+    B, H, D, M, S, fb, hb, wb, F_, H_, W_, normalize, gated = [int(x) for x in g["meta"]]
+    m = modules.MHLA_Video_Uni(H * D, num_heads=H, block_layout=(fb, hb, wb), normalize_out=bool(normalize),
+                               is_gated=bool(gated))
+    m.load_state_dict(_sd(g), strict=True)
+    m = m.to(DEV).eval()
+    x = g["x"].to(DEV)
+    N = F_ * H_ * W_
+    grid_sizes = torch.tensor([[F_, H_, W_]] * B, dtype=torch.long)
+    import mhla_amd.modules.wan as wanmod
+    calls = []
+    orig = wanmod.mhla_blockmix_rope
+    wanmod.mhla_blockmix_rope = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        with torch.no_grad():
+            y = m(x, torch.tensor([N] * B), grid_sizes, modules.wan_freqs(D))
+    finally:
+        wanmod.mhla_blockmix_rope = orig
+    assert calls, "fused path not taken under no_grad"
+    check("y", y, g["y"], 1e-4)
+    y2 = m(x.clone().requires_grad_(True), torch.tensor([N] * B), grid_sizes, modules.wan_freqs(D))
+    check("fused vs unfused", y, y2.detach().cpu(), 1e-4)
+
+
+def test_qk_prologue_and_rope_op():
+    """mhla_qk_prologue vs the oracle's rms_norm + relu_eps; mhla_blockmix_rope vs rope_apply + the split-pair op."""
+    import mhla_amd
+    g = torch.Generator().manual_seed(21)
+    B, F_, H_, W_, H, D = 1, 4, 6, 10, 3, 64
+    N, C = F_ * H_ * W_, H * D
+    for dtype in (torch.bfloat16, torch.float32):
+        x = torch.randn(B, N, C, generator=g).to(dtype)
+        w = (torch.rand(C, generator=g) + 0.5)
+        want = orc.relu_eps(orc.rms_norm(x.float(), w, 1e-5), 1e-6)
+        got = mhla_amd.qk_prologue(x.to(DEV), w.to(DEV), 1e-5, 1e-6)
+        assert got.dtype == torch.float32
+        check("prologue", got, want, 1e-5)
+        check("prologue no norm", mhla_amd.qk_prologue(x.to(DEV), None, 0.0, 1e-6), torch.relu(x.float()) + 1e-6, 1e-6)
+    q = torch.rand(B, N, H, D, generator=g) + 1e-6
+    k = torch.rand(B, N, H, D, generator=g) + 1e-6
+    v = torch.randn(B, N, H, D, generator=g)
+    layout = (2, 3, 5)
+    W = orc.block_distance_weights(layout, "linear")
+    idx = orc.block_index_3d((F_, H_, W_), layout).int()
+    freqs = orc.wan_freqs(D)
+    qr, kr = orc.wan_rope_apply(q, (F_, H_, W_), freqs), orc.wan_rope_apply(k, (F_, H_, W_), freqs)
+    gather = lambda t: t[:, idx.long()]
+    from mhla_amd.modules.wan import _rope_table
+    cos, sin = _rope_table(freqs, (F_, H_, W_), DEV)
+    for normalize in (True, False):
+        want = orc.blockmix_fwd(gather(qr), gather(kr), gather(v), W, 1e-6, q_den=gather(q), k_den=gather(k), normalize=normalize)
+        got = mhla_amd.mhla_blockmix_rope(q.to(DEV), k.to(DEV), v.to(DEV), W.to(DEV), cos, sin, eps=1e-6, normalize=normalize,
+                                          block_index=idx.to(DEV))
+        check(f"rope op normalize={normalize}", got[:, idx.long().to(DEV)], want, 1e-4)
+    with pytest.raises(RuntimeError):
+        mhla_amd.mhla_blockmix_rope(q.to(DEV).requires_grad_(True), k.to(DEV), v.to(DEV), W.to(DEV), cos, sin)
+
+
 def test_fla_layer_matches_oracle_restatement():
     """The reference fla layer cannot run on CPU (Triton neighbours); it is pinned piecewise by
     golden vectors (rotary, norm-gate, causal op) and the oracle composes them (fla_layer_forward)."""
