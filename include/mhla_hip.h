@@ -175,6 +175,31 @@ int mhla_qk_prologue(const void* x, int64_t ldx, const float* w, float* y, int64
                      int64_t rows, int C, int norm, float norm_eps, float eps,
                      int dtype, void* stream);
 
+/* ---- LePE: depthwise K x K convolution over V on the token layout --------- */
+
+/*
+ * y[b, n, c] = (bias[c]) + sum_taps w_taps[tap][c] * x[b, nbr(n, tap), c] (+ add[b, n, c]).
+ * Replaces the NCHW round trip around nn.Conv2d(dim, dim, K, 1, K/2, groups=dim) at
+ * mhla_dit/mhla/mhla.py:246-247 (+ the add at :271-273) and
+ * mhla_image_classification/models/modules/attention/mhla.py:169 (K = 5).  Tokens are block-major:
+ * n = m*S + s, block m = (py, px) on a pieces_len^2 grid, s = (by, bx) on a block_len^2 grid, pixel
+ * (py*block_len + by, px*block_len + bx); zero padding at the image border.  x, add, y: [B, N, C] with batch /
+ * token strides in elements (x may be the V slice of the fused QKV buffer).  w_taps: fp32 [K*K][C]
+ * (the conv weight [C,1,K,K] transposed), bias: fp32 [C] or NULL, add: NULL or a tensor to add.
+ * flip = 1 correlates with the flipped kernel: the gradient w.r.t. x when `x` is dout.
+ */
+int mhla_lepe2d(const void* x, int64_t x_sb, int64_t x_sn, const float* w_taps, const float* bias,
+                const void* add, int64_t add_sb, int64_t add_sn,
+                void* y, int64_t y_sb, int64_t y_sn,
+                int B, int pieces_len, int block_len, int C, int K, int flip,
+                int dtype, void* stream);
+/* Weight and bias gradient: dwb fp32 [(K*K + 1)][C], rows 0..K*K-1 = dw_taps, row K*K = dbias;
+ * overwritten, deterministic (fixed-order two-stage sum). */
+size_t mhla_lepe2d_wgrad_ws_bytes(int C, int K);
+int mhla_lepe2d_wgrad(const void* x, int64_t x_sb, int64_t x_sn, const void* dout, int64_t g_sb, int64_t g_sn,
+                      float* dwb, void* ws, size_t ws_bytes,
+                      int B, int pieces_len, int block_len, int C, int K, int dtype, void* stream);
+
 /* ---- epilogue: per-head RMSNorm (x optional swish gate) ----------------- */
 
 /*

@@ -16,6 +16,7 @@
 #include "causal_bf16.cuh"
 #include "epilogue.cuh"
 #include "fused.cuh"
+#include "lepe.cuh"
 #include "fused_tile16.cuh"
 #include "smalln.cuh"
 #include "split.cuh"
@@ -651,6 +652,53 @@ int mhla_rmsnorm_gate_fwd(const void* x, int64_t ldx, const void* g, int64_t ldg
             else   RC(launch(k_rmsnorm_gate_fwd<ET, 2, false>, grid, dim3(256), 0, st, "k_rmsnorm_gate_fwd", a));
         }
     });
+    return MHLA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LePE depthwise convolution on the block-major token layout
+// ---------------------------------------------------------------------------------------------
+static int lepe_check(const void* x, const void* y, int B, int pl, int bl, int C, int K, int dtype) {
+    if (!x || !y) return fail(MHLA_EINVAL, "null pointer");
+    if (B <= 0 || pl <= 0 || bl <= 0 || C <= 0 || (C & 7)) return fail(MHLA_EINVAL, "B=%d pieces_len=%d block_len=%d C=%d: need positive sizes and C %% 8 == 0", B, pl, bl, C);
+    if (K != 3 && K != 5) return fail(MHLA_ENOTSUP, "kernel size %d: 3 (DiT) and 5 (ViT) are supported", K);
+    if (dtype < 0 || dtype > 2) return fail(MHLA_EINVAL, "unknown dtype %d", dtype);
+    if (B > 65535) return fail(MHLA_ENOTSUP, "B=%d exceeds grid limit 65535", B);
+    return MHLA_OK;
+}
+constexpr int LEPE_SLICES = 128;
+
+int mhla_lepe2d(const void* x, int64_t x_sb, int64_t x_sn, const float* w_taps, const float* bias, const void* add,
+                int64_t add_sb, int64_t add_sn, void* y, int64_t y_sb, int64_t y_sn, int B, int pieces_len, int block_len,
+                int C, int K, int flip, int dtype, void* stream) {
+    RC(lepe_check(x, y, B, pieces_len, block_len, C, K, dtype));
+    if (!w_taps) return fail(MHLA_EINVAL, "w_taps null");
+    if ((x_sb | x_sn | y_sb | y_sn | (add ? (add_sb | add_sn) : 0)) & 3) return fail(MHLA_EINVAL, "strides must be multiples of 4 elements");
+    LepeArgs a{x, (long)x_sb, (long)x_sn, w_taps, bias, add, (long)add_sb, (long)add_sn, y, (long)y_sb, (long)y_sn, B, pieces_len, block_len, C, K, flip ? 1 : 0};
+    const long N = (long)pieces_len * pieces_len * block_len * block_len, work = N * (C / 8);
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_T(dtype, { RC(launch(k_lepe2d<ET>, dim3((unsigned)((work + 255) / 256), B), dim3(256), 0, st, "k_lepe2d", a)); });
+    return MHLA_OK;
+}
+
+size_t mhla_lepe2d_wgrad_ws_bytes(int C, int K) { return (size_t)LEPE_SLICES * (K * K + 1) * C * 4; }
+
+int mhla_lepe2d_wgrad(const void* x, int64_t x_sb, int64_t x_sn, const void* dout, int64_t g_sb, int64_t g_sn, float* dwb,
+                      void* ws, size_t ws_bytes, int B, int pieces_len, int block_len, int C, int K, int dtype,
+                      void* stream) {
+    RC(lepe_check(x, dout, B, pieces_len, block_len, C, K, dtype));
+    if (!dwb || !ws || ((uintptr_t)ws) % 16) return fail(MHLA_EINVAL, "dwb / workspace null or workspace not 16-byte aligned");
+    if (ws_bytes < mhla_lepe2d_wgrad_ws_bytes(C, K)) return fail(MHLA_EINVAL, "workspace too small: %zu < %zu bytes", ws_bytes, mhla_lepe2d_wgrad_ws_bytes(C, K));
+    if ((x_sb | x_sn | g_sb | g_sn) & 3) return fail(MHLA_EINVAL, "strides must be multiples of 4 elements");
+    LepeWgradArgs a{x, (long)x_sb, (long)x_sn, dout, (long)g_sb, (long)g_sn, (float*)ws, B, pieces_len, block_len, C, K, LEPE_SLICES};
+    hipStream_t st = (hipStream_t)stream;
+    // a workgroup covers 4 waves x 8 channel groups of CH channels (CH = 8 for K = 3, 4 for K = 5)
+    DISPATCH_T(dtype, {
+        if (K == 3) RC(launch(k_lepe2d_wgrad<ET, 3, 8>, dim3((C + 255) / 256, LEPE_SLICES), dim3(256), 0, st, "k_lepe2d_wgrad", a));
+        else        RC(launch(k_lepe2d_wgrad<ET, 5, 4>, dim3((C + 127) / 128, LEPE_SLICES), dim3(256), 0, st, "k_lepe2d_wgrad", a));
+    });
+    const int rows_c = (K * K + 1) * C;
+    RC(launch(k_lepe2d_wgrad_reduce, dim3((rows_c + 63) / 64), dim3(256), 0, st, "k_lepe2d_wgrad_reduce", (const float*)ws, dwb, rows_c, LEPE_SLICES));
     return MHLA_OK;
 }
 

@@ -1,0 +1,167 @@
+// LePE: the depthwise K x K convolution over V that the DiT / ViT hosts add to the operator's output
+// (mhla_dit/mhla/mhla.py:169, 246-247, 271-273: nn.Conv2d(dim, dim, 3, 1, 1, groups=dim);
+//  mhla_image_classification/models/modules/attention/mhla.py:169: 5 x 5), computed directly on the token-major,
+// block-major layout the operator uses: token n = m * S + s with block m = (py, px) on a pl x pl grid and in-block
+// offset s = (by, bx) on a bl x bl grid is pixel (py * bl + by, px * bl + bx).  No NCHW permutes, no im2col.
+// Channels are contiguous, so a thread owns a few consecutive channels of one token and walks the K*K neighbours
+// (L1 / L2 hits: every token row is read K*K times by neighbouring threads).  HBM-bound streaming kernels.
+#pragma once
+#include "common.cuh"
+
+namespace mhla {
+
+struct LepeArgs {
+    const void* x;      // [B, N, C] (strides xsb, xsn)   forward: v            backward-data: dout
+    long xsb, xsn;
+    const float* w;     // [K*K][C] fp32 (tap-major)
+    const float* bias;  // [C] or nullptr
+    const void* add;    // optional [B, N, C] tensor added to the result (the operator's output), or nullptr
+    long asb, asn;
+    void* y;            // [B, N, C]
+    long ysb, ysn;
+    int B, pl, bl, C, K;
+    int flip;           // 1: correlate with the flipped kernel (gradient w.r.t. the input)
+};
+
+__device__ __forceinline__ void lepe_decode(int n, int pl, int bl, int& yy, int& xx) {
+    const int S = bl * bl, m = n / S, s = n - m * S;
+    const int py = m / pl, px = m - py * pl, by = s / bl, bx = s - by * bl;
+    yy = py * bl + by;
+    xx = px * bl + bx;
+}
+__device__ __forceinline__ int lepe_token(int yy, int xx, int pl, int bl) {
+    const int py = yy / bl, by = yy - py * bl, px = xx / bl, bx = xx - px * bl;
+    return (py * pl + px) * bl * bl + by * bl + bx;
+}
+
+// grid (ceil(N * C/8 / 256), B); a thread: 8 channels of one token
+template <typename T>
+__global__ __launch_bounds__(256) void k_lepe2d(const LepeArgs a) {
+    const int CG = a.C / 8, N = a.pl * a.pl * a.bl * a.bl, side = a.pl * a.bl;
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (long)N * CG) return;
+    const int n = (int)(gid / CG), c = (int)(gid - (long)n * CG) * 8, b = blockIdx.y;
+    int yy, xx;
+    lepe_decode(n, a.pl, a.bl, yy, xx);
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+    if (a.bias) {
+        acc0 = *reinterpret_cast<const f32x4*>(a.bias + c);
+        acc1 = *reinterpret_cast<const f32x4*>(a.bias + c + 4);
+    }
+    const T* xb = (const T*)a.x + b * a.xsb + c;
+    const int K = a.K, R = K / 2;
+    for (int dy = 0; dy < K; ++dy) {
+        const int y2 = yy + dy - R;
+        if (y2 < 0 || y2 >= side) continue;
+        for (int dx = 0; dx < K; ++dx) {
+            const int x2 = xx + dx - R;
+            if (x2 < 0 || x2 >= side) continue;
+            const int tap = a.flip ? (K - 1 - dy) * K + (K - 1 - dx) : dy * K + dx;
+            const T* p = xb + (long)lepe_token(y2, x2, a.pl, a.bl) * a.xsn;
+            const f32x4 x0 = Io<T>::ld4(p), x1 = Io<T>::ld4(p + 4);
+            acc0 += x0 * *reinterpret_cast<const f32x4*>(a.w + (long)tap * a.C + c);
+            acc1 += x1 * *reinterpret_cast<const f32x4*>(a.w + (long)tap * a.C + c + 4);
+        }
+    }
+    if (a.add) {
+        const T* p = (const T*)a.add + b * a.asb + (long)n * a.asn + c;
+        acc0 += Io<T>::ld4(p);
+        acc1 += Io<T>::ld4(p + 4);
+    }
+    T* yp = (T*)a.y + b * a.ysb + (long)n * a.ysn + c;
+    Io<T>::st4(yp, acc0);
+    Io<T>::st4(yp + 4, acc1);
+}
+
+// Weight / bias gradient: dw[tap][c] = sum_{b, n} dout[b, n, c] x[b, nbr(n, tap), c], db[c] = sum dout[b, n, c].
+// grid (ceil(C / (8 CH)) / 4 rounded up, slices); a wave = 8 channel groups of CH channels x 8 token lanes; each thread walks
+// every 8th token of its slice, the 8 token lanes are summed by shuffles; partials part[slice][K*K + 1][C] (row K*K = bias)
+// are summed in a fixed order by k_lepe2d_wgrad_reduce: deterministic.
+struct LepeWgradArgs {
+    const void* x;      // v
+    long xsb, xsn;
+    const void* g;      // dout
+    long gsb, gsn;
+    float* part;        // [slices][K*K + 1][C]
+    int B, pl, bl, C, K, slices;
+};
+
+template <typename T, int K, int CH>   // CH: channels per thread (4 or 8)
+__global__ __launch_bounds__(256) void k_lepe2d_wgrad(const LepeWgradArgs a) {
+    constexpr int NV = CH / 4, NA = K * K + 1;
+    const int N = a.pl * a.pl * a.bl * a.bl, side = a.pl * a.bl;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tl = lane >> 3;
+    const int c = ((blockIdx.x * 4 + wave) * 8 + (lane & 7)) * CH, slice = blockIdx.y;
+    const bool live = c < a.C;
+    const long total = (long)a.B * N, per = (total + a.slices - 1) / a.slices;
+    const long t0 = slice * per, t1 = min(total, t0 + per);
+    f32x4 acc[NA][NV];
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int u = 0; u < NV; ++u) acc[i][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (live) {
+        for (long t = t0 + tl; t < t1; t += 8) {
+            const int b = (int)(t / N), n = (int)(t - (long)b * N);
+            int yy, xx;
+            lepe_decode(n, a.pl, a.bl, yy, xx);
+            f32x4 g[NV];
+            const T* gp = (const T*)a.g + b * a.gsb + (long)n * a.gsn + c;
+#pragma unroll
+            for (int u = 0; u < NV; ++u) {
+                g[u] = Io<T>::ld4(gp + 4 * u);
+                acc[K * K][u] += g[u];
+            }
+            const T* xb = (const T*)a.x + b * a.xsb + c;
+#pragma unroll
+            for (int dy = 0; dy < K; ++dy) {
+                const int y2 = yy + dy - K / 2;
+#pragma unroll
+                for (int dx = 0; dx < K; ++dx) {
+                    const int x2 = xx + dx - K / 2;
+                    if (y2 >= 0 && y2 < side && x2 >= 0 && x2 < side) {
+                        const T* p = xb + (long)lepe_token(y2, x2, a.pl, a.bl) * a.xsn;
+#pragma unroll
+                        for (int u = 0; u < NV; ++u) acc[dy * K + dx][u] += g[u] * Io<T>::ld4(p + 4 * u);
+                    }
+                }
+            }
+        }
+    }
+    // sum the 8 token lanes (lane bits 3..5)
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int u = 0; u < NV; ++u)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                float v = acc[i][u][t];
+                v += __shfl_xor(v, 8, 64);
+                v += __shfl_xor(v, 16, 64);
+                v += __shfl_xor(v, 32, 64);
+                acc[i][u][t] = v;
+            }
+    if (live && tl == 0) {
+        float* out = a.part + (long)slice * NA * a.C + c;
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+#pragma unroll
+            for (int u = 0; u < NV; ++u) *reinterpret_cast<f32x4*>(out + (long)i * a.C + 4 * u) = acc[i][u];
+    }
+}
+
+// dwb[(K*K + 1)][C] = sum over slices, fixed order: 64 elements x 4 slice lanes per workgroup, then a 4-way LDS sum
+__global__ __launch_bounds__(256) void k_lepe2d_wgrad_reduce(const float* __restrict__ part, float* __restrict__ dwb, int rows_c, int slices) {
+    __shared__ float red[4][64];
+    const int el = threadIdx.x & 63, pl = threadIdx.x >> 6, i = blockIdx.x * 64 + el;
+    float s = 0.f;
+    if (i < rows_c) {
+        const int per = (slices + 3) / 4, p0 = pl * per, p1 = min(slices, p0 + per);
+        for (int p = p0; p < p1; ++p) s += part[(long)p * rows_c + i];
+    }
+    red[pl][el] = s;
+    __syncthreads();
+    if (pl == 0 && i < rows_c) dwb[i] = (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]);
+}
+
+}  // namespace mhla

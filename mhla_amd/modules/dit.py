@@ -11,7 +11,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from ..ops import mhla_blockmix
+from ..ops import lepe2d, mhla_blockmix
 from .blockconv import BlockDistanceConv
 
 
@@ -75,12 +75,10 @@ class MHLA4DiT(nn.Module):
                 nn.init.zeros_(param)
         return model
 
-    def _lepe(self, v: torch.Tensor, B: int) -> torch.Tensor:
-        """Depthwise conv over V laid out as the raster image (mhla.py:246-247)."""
-        pl, bl, C = self.pieces_len, self.block_len, v.shape[-1]
-        img = v.reshape(B, pl, pl, bl, bl, C).permute(0, 5, 1, 3, 2, 4).reshape(B, C, pl * bl, pl * bl)
-        out = self.lepe(img)
-        return out.reshape(B, C, pl, bl, pl, bl).permute(0, 2, 4, 3, 5, 1).reshape(B, pl * pl, bl * bl, C)
+    def _lepe(self, v: torch.Tensor, attn_out: torch.Tensor) -> torch.Tensor:
+        """attn_out + depthwise conv over V laid out as the raster image (mhla.py:246-247, 271-273), computed by the
+        HIP LePE kernel directly on the block-major token layout (v may be the strided V slice of the fused QKV buffer)."""
+        return lepe2d(v, self.lepe.weight, self.lepe.bias, self.pieces_len, self.block_len, add=attn_out)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """x: [B, M, S, C] (block-major tokens, as the ViT host passes them) or [B, N, C] (the DiT host,
@@ -92,8 +90,6 @@ class MHLA4DiT(nn.Module):
         H, D = self.num_heads, self.head_dim
         x = self.norm(x)
         qkv = self.to_qkv(x).reshape(B, M * S, 3, H, D)                       # mhla.py:245
-        v_full = qkv[:, :, 2].reshape(B, M, S, H * D)
-        lepe = self._lepe(v_full, B)
         W = self.piece_attn.conv.weight
         if self.qk_norm:
             q = torch.relu(self.q_norm(qkv[:, :, 0].reshape(B, M * S, H * D))) + self.eps   # mhla.py:226-230
@@ -101,7 +97,7 @@ class MHLA4DiT(nn.Module):
             out = mhla_blockmix(q.reshape(B, M * S, H, D), k.reshape(B, M * S, H, D), qkv[:, :, 2], W, eps=self.eps)
         else:
             out = mhla_blockmix(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], W, eps=self.eps, relu_eps=True)
-        out = out.reshape(B, M, S, H * D) + lepe                               # mhla.py:271-273
+        out = self._lepe(qkv[:, :, 2].reshape(B, M * S, H * D), out.reshape(B, M * S, H * D)).reshape(B, M, S, H * D)
         out = self.to_out(out)
         return out.reshape(B, M * S, -1) if three_d else out
 

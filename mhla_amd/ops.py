@@ -206,6 +206,75 @@ def mhla_blockmix_rope(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, W: tor
     return out
 
 
+# ------------------------------------------------------------------------------------------
+# LePE: depthwise conv over V on the block-major token layout (DiT / ViT)
+# ------------------------------------------------------------------------------------------
+def _tok3(t: torch.Tensor) -> torch.Tensor:
+    """[B, N, C] view with contiguous channels (copy only if the channels are strided)."""
+    return t if t.stride(-1) == 1 else t.contiguous()
+
+
+class _Lepe2d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, v, weight, bias, add, pieces_len, block_len):
+        lib = _lib.load()
+        _require_gpu(v, weight, bias, add)
+        B, N, C = v.shape
+        K = weight.shape[-1]
+        v = _tok3(v)
+        w_taps = weight.detach().reshape(C, K * K).t().to(torch.float32).contiguous()
+        b32 = bias.detach().to(torch.float32).contiguous() if bias is not None else None
+        addc = _tok3(add) if add is not None else None
+        y = torch.empty((B, N, C), dtype=v.dtype, device=v.device)
+        rc = lib.mhla_lepe2d(v.data_ptr(), v.stride(0), v.stride(1), w_taps.data_ptr(),
+                             b32.data_ptr() if b32 is not None else None,
+                             addc.data_ptr() if addc is not None else None,
+                             addc.stride(0) if addc is not None else 0, addc.stride(1) if addc is not None else 0,
+                             y.data_ptr(), y.stride(0), y.stride(1), B, pieces_len, block_len, C, K, 0, _dtype_code(v), _stream())
+        _lib.check(rc, "mhla_lepe2d")
+        ctx.save_for_backward(v, w_taps)
+        ctx.cfg = (pieces_len, block_len, K, weight.shape, weight.dtype, bias is not None, bias.dtype if bias is not None else None,
+                   add is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        v, w_taps = ctx.saved_tensors
+        pl, bl, K, w_shape, w_dtype, has_bias, b_dtype, has_add = ctx.cfg
+        B, N, C = v.shape
+        dy = _tok3(dy.to(v.dtype))
+        dv = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dv = torch.empty((B, N, C), dtype=v.dtype, device=v.device)
+            rc = lib.mhla_lepe2d(dy.data_ptr(), dy.stride(0), dy.stride(1), w_taps.data_ptr(), None, None, 0, 0,
+                                 dv.data_ptr(), dv.stride(0), dv.stride(1), B, pl, bl, C, K, 1, _dtype_code(v), _stream())
+            _lib.check(rc, "mhla_lepe2d (input gradient)")
+        if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+            dwb = torch.empty((K * K + 1, C), dtype=torch.float32, device=v.device)
+            ws = _ws(lib.mhla_lepe2d_wgrad_ws_bytes(C, K), v.device)
+            rc = lib.mhla_lepe2d_wgrad(v.data_ptr(), v.stride(0), v.stride(1), dy.data_ptr(), dy.stride(0), dy.stride(1),
+                                       dwb.data_ptr(), ws.data_ptr(), ws.numel() * 4, B, pl, bl, C, K, _dtype_code(v), _stream())
+            _lib.check(rc, "mhla_lepe2d_wgrad")
+            dw = dwb[:K * K].t().reshape(w_shape).to(w_dtype)
+            if has_bias:
+                db = dwb[K * K].to(b_dtype)
+        return dv, dw, db, (dy if has_add else None), None, None
+
+
+def lepe2d(v: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], pieces_len: int, block_len: int,
+           add: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Depthwise conv of the DiT / ViT hosts' LePE branch on the operator's own token layout:
+    `conv2d(v as image, weight [C,1,K,K], bias, padding=K//2, groups=C)` (+ `add`), with v, add, result [B, N, C] in
+    block-major token order (N = pieces_len^2 * block_len^2).  Replaces the rearranges + nn.Conv2d at
+    mhla_dit/mhla/mhla.py:246-247 and the add at :271-273.  Differentiable w.r.t. v, weight, bias, add."""
+    if v.dim() != 3 or weight.dim() != 4 or weight.shape[1] != 1 or weight.shape[2] != weight.shape[3]:
+        raise ValueError("v: [B, N, C]; weight: [C, 1, K, K]")
+    if v.shape[1] != (pieces_len * block_len) ** 2 or weight.shape[0] != v.shape[2]:
+        raise ValueError(f"N={v.shape[1]} != (pieces_len*block_len)^2 or channel mismatch")
+    return _Lepe2d.apply(v, weight, bias, add, int(pieces_len), int(block_len))
+
+
 def qk_prologue(x: torch.Tensor, weight: Optional[torch.Tensor], norm_eps: float = 1e-5, eps: float = 1e-6) -> torch.Tensor:
     """relu(rmsnorm(x) * weight) + eps over the last dim, fp32 output -- the q / k prologue of Wan's MHLA_Video_Uni
     (wan/mhla_utils.py:268-272 after the .float() at :308), one HIP kernel, forward only.  weight None: relu(x) + eps."""

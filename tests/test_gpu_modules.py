@@ -89,6 +89,44 @@ def test_wan_module_fused_inference_path(tag):
     check("fused vs unfused", y, y2.detach().cpu(), 1e-4)
 
 
+@pytest.mark.parametrize("K,pl,bl,C,dtype", [(3, 4, 4, 64, torch.float32), (5, 2, 7, 48, torch.float32), (3, 4, 4, 1152, torch.bfloat16),
+                                             (5, 4, 4, 384, torch.bfloat16), (3, 1, 6, 8, torch.float32)])
+def test_lepe2d_matches_conv2d(K, pl, bl, C, dtype):
+    """HIP LePE kernels on the block-major token layout vs nn.Conv2d on the rearranged image (mhla.py:246-247), with
+    V as a strided slice of a fused QKV buffer; gradients w.r.t. v, weight, bias and the added tensor."""
+    import torch.nn.functional as F
+    import mhla_amd
+    g = torch.Generator().manual_seed(K * 100 + C)
+    B, N = 3, (pl * bl) ** 2
+    qkv = torch.randn(B, N, 3, C, generator=g).to(dtype)
+    w = (torch.randn(C, 1, K, K, generator=g) * 0.3).to(dtype)
+    bias = torch.randn(C, generator=g).to(dtype)
+    add = torch.randn(B, N, C, generator=g).to(dtype)
+    dy = torch.randn(B, N, C, generator=g).to(dtype)
+
+    def to_img(t):      # [B, N, C] block-major -> [B, C, side, side]
+        return t.reshape(B, pl, pl, bl, bl, C).permute(0, 5, 1, 3, 2, 4).reshape(B, C, pl * bl, pl * bl)
+
+    def from_img(t):
+        return t.reshape(B, C, pl, bl, pl, bl).permute(0, 2, 4, 3, 5, 1).reshape(B, N, C)
+
+    rv, rw, rb, ra = (t.float().clone().requires_grad_(True) for t in (qkv[:, :, 2], w, bias, add))
+    want = from_img(F.conv2d(to_img(rv), rw, rb, padding=K // 2, groups=C)) + ra
+    want.backward(dy.float())
+    dq = qkv.to(DEV).requires_grad_(True)
+    dw, db, da = (t.to(DEV).requires_grad_(True) for t in (w, bias, add))
+    got = mhla_amd.lepe2d(dq[:, :, 2], dw, db, pl, bl, add=da)
+    assert got.dtype == dtype
+    got.backward(dy.to(DEV))
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    check("y", got, want, tol)
+    check("dv", dq.grad[:, :, 2], rv.grad, tol)
+    assert float(dq.grad[:, :, :2].abs().max()) == 0.0
+    check("dw", dw.grad, rw.grad, tol)
+    check("dbias", db.grad, rb.grad, tol)
+    check("dadd", da.grad, dy, 1e-6)
+
+
 def test_qk_prologue_and_rope_op():
     """mhla_qk_prologue vs the oracle's rms_norm + relu_eps; mhla_blockmix_rope vs rope_apply + the split-pair op."""
     import mhla_amd

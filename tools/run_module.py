@@ -24,7 +24,7 @@ if which == "wan":
         with torch.no_grad():
             return m(x, None, grid, freqs)
 else:
-    m = MHLA4DiT(1152, 16, qkv_bias=True).to(DEV).to(torch.bfloat16)
+    m = MHLA4DiT(1152, 16, qkv_bias=True, block_size=16, embed_len=256).to(DEV).to(torch.bfloat16)
     x = torch.randn(32, 256, 1152, device=DEV, dtype=torch.bfloat16, requires_grad=True)
 
     def step():
