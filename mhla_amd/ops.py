@@ -167,6 +167,8 @@ def mhla_blockmix(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, W: torch.Te
         raise ValueError("q_den and k_den must be given together")
     if block_index is not None and (block_index.dtype != torch.int32 or not block_index.is_contiguous()):
         raise TypeError("block_index must be a contiguous int32 tensor")
+    if q.shape[0] == 0:   # empty batch: nothing to launch; keep the autograd graph connected (all gradients are zero)
+        return torch.zeros_like(v) + 0 * (q.sum() + k.sum() + W.sum()).to(v.dtype)
     return _BlockMix.apply(q, k, v, W, q_den, k_den, block_index, eps, normalize, relu_eps, force_generic, no_smalln)
 
 
@@ -351,6 +353,8 @@ def mhla_causal(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mixing_matrix
         raise ValueError("q, k: [B, T, H, K], v: [B, T, H, V]")
     if scale is None:
         scale = q.shape[-1] ** -0.5
+    if q.shape[0] == 0 or q.shape[1] == 0:   # empty batch / sequence
+        return torch.zeros_like(v) + 0 * (q.sum() + k.sum() + mixing_matrix.sum()).to(v.dtype)
     return _Causal.apply(q, k, v, mixing_matrix, int(chunk_size), scale)
 
 

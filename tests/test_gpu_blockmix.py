@@ -240,6 +240,19 @@ def test_fused_qkv_views_and_relu_prologue():
     check("dW_bf16", Wd.grad, Wr.grad, GTOL[torch.bfloat16])
 
 
+def test_empty_batch():
+    """B = 0 (and T = 0 for the causal op): empty result, zero gradients, no launch."""
+    import mhla_amd
+    q = torch.empty(0, 64, 2, 32, device=DEV, requires_grad=True)
+    W = torch.eye(4, device=DEV, requires_grad=True)
+    out = mhla_amd.mhla_blockmix(q, q, q, W)
+    assert out.shape == (0, 64, 2, 32)
+    out.sum().backward()
+    assert W.grad is not None and float(W.grad.abs().max()) == 0.0
+    qc = torch.empty(2, 0, 2, 16, device=DEV)
+    assert mhla_amd.mhla_causal(qc, qc, qc, torch.ones(4, 4, device=DEV)).shape == (2, 0, 2, 16)
+
+
 def test_errors_fail_loudly():
     import mhla_amd
     q = torch.randn(1, 64, 2, 64, device=DEV)
