@@ -175,6 +175,17 @@ int mhla_qk_prologue(const void* x, int64_t ldx, const float* w, float* y, int64
                      int64_t rows, int C, int norm, float norm_eps, float eps,
                      int dtype, void* stream);
 
+/*
+ * q / k prologue of the fla layer in one pass: feature map (0 identity, 1 relu, 2 elu+1;
+ * mhla_nlp/fla/layers/mhla.py:297-299) then the NeoX-style rotary embedding (:311,
+ * mhla_nlp/fla/modules/rotary.py:45-135): y[i] = f(x[i]) c - f(x[i+K/2]) s, y[i+K/2] = f(x[i+K/2]) c + f(x[i]) s with
+ * (c, s) = (cos, sin)[t_offset + t][i], fp32 math, tables [rows][K/2] in the activation dtype (row stride ld_tab).
+ * backward != 0: x is the upstream gradient, x_saved the forward's input; y receives dL/dx.  x, y: [B, T, H, K] views.
+ */
+int mhla_featmap_rotary(mhla_view x, mhla_view x_saved, const void* cos, const void* sin, int64_t ld_tab,
+                        int64_t t_offset, mhla_mview y, int B, int T, int H, int K,
+                        int feature_map, int backward, int dtype, void* stream);
+
 /* ---- LePE: depthwise K x K convolution over V on the token layout --------- */
 
 /*

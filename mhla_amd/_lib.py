@@ -44,6 +44,8 @@ SIGNATURES = {
                                 c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "mhla_causal_bwd": (c_int, [View, View, View, c_void_p, c_int, View, View, View, View, c_void_p, c_int, c_void_p,
                                 c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
+    "mhla_featmap_rotary": (c_int, [View, View, c_void_p, c_void_p, c_int64, c_int64, View, c_int, c_int, c_int, c_int, c_int,
+                                    c_int, c_int, c_void_p]),
     "mhla_lepe2d": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64,
                             c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "mhla_lepe2d_wgrad_ws_bytes": (c_size_t, [c_int, c_int]),

@@ -720,6 +720,25 @@ int mhla_qk_prologue(const void* x, int64_t ldx, const float* w, float* y, int64
     return MHLA_OK;
 }
 
+int mhla_featmap_rotary(mhla_view x, mhla_view x_saved, const void* cos, const void* sin, int64_t ld_tab, int64_t t_offset,
+                        mhla_mview y, int B, int T, int H, int K, int feature_map, int backward, int dtype, void* stream) {
+    if (B <= 0 || T <= 0 || H <= 0 || K <= 0 || (K & 7)) return fail(MHLA_EINVAL, "B=%d T=%d H=%d K=%d: need positive sizes and K %% 8 == 0", B, T, H, K);
+    if (feature_map < 0 || feature_map > 2) return fail(MHLA_EINVAL, "feature_map %d: 0 identity, 1 relu, 2 elu+1", feature_map);
+    if (dtype < 0 || dtype > 2) return fail(MHLA_EINVAL, "unknown dtype %d", dtype);
+    CHECK_VIEW(x); CHECK_VIEW(y);
+    if (!cos || !sin || ld_tab < K / 2 || (ld_tab & 3) || t_offset < 0) return fail(MHLA_EINVAL, "cos/sin tables null, ld < K/2, ld %% 4 != 0 or negative offset");
+    if (backward && feature_map) CHECK_VIEW(x_saved);
+    FmRotArgs a{cv(x), cv(x_saved), cmv(y), cos, sin, (long)ld_tab, B, T, H, K, feature_map, (long)t_offset};
+    const long total = (long)B * T * H * (K / 8);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)((total + 255) / 256));
+    DISPATCH_T(dtype, {
+        if (backward) RC(launch(k_fmap_rotary<ET, true>, grid, dim3(256), 0, st, "k_fmap_rotary<bwd>", a));
+        else          RC(launch(k_fmap_rotary<ET, false>, grid, dim3(256), 0, st, "k_fmap_rotary", a));
+    });
+    return MHLA_OK;
+}
+
 int mhla_rmsnorm_gate_bwd(const void* x, int64_t ldx, const void* g, int64_t ldg, const float* w, const void* dy,
                           int64_t lddy, void* dx, int64_t lddx, void* dg, int64_t lddg, float* dw_partial, int64_t rows,
                           int D, float eps, int dtype, void* stream) {

@@ -198,4 +198,66 @@ __global__ __launch_bounds__(256) void k_qk_prologue(const PrologueArgs a) {
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// q / k prologue of the fla layer: feature map (mhla_nlp/fla/layers/mhla.py:297-299: relu / identity / elu + 1) followed
+// by the NeoX-style rotary embedding (:311; mhla_nlp/fla/modules/rotary.py:45-135: halves (x[i], x[i + K/2]) rotate by
+// the token's angle, fp32 math on cos / sin tables kept in the activation dtype), in one pass; BWD applies the
+// transposed rotation to the upstream gradient and the feature map's derivative (from the saved input).
+//   forward : a = f(x[i]), b = f(x[i + K/2]);  y[i] = a c - b s;  y[i + K/2] = b c + a s
+//   backward: da = g[i] c + g[i + K/2] s;  db = -g[i] s + g[i + K/2] c;  dx = (da f'(x[i]), db f'(x[i + K/2]))
+// One thread: 4 + 4 elements of one (token, head) row.
+// -------------------------------------------------------------------------------------------------
+struct FmRotArgs {
+    View x;         // forward: input; backward: upstream gradient
+    View xs;        // backward: the forward's input (feature-map derivative)
+    MView y;
+    const void* cos;   // [>= t_off + T][K/2], activation dtype
+    const void* sin;
+    long ldt;
+    int B, T, H, K;
+    int fmap;       // 0 identity, 1 relu, 2 elu + 1
+    long t_off;
+};
+
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void k_fmap_rotary(const FmRotArgs a) {
+    const int G = a.K / 8;   // groups of 4 per half
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x, total = (long)a.B * a.T * a.H * G;
+    if (gid >= total) return;
+    const int g = (int)(gid % G);
+    long r = gid / G;
+    const int h = (int)(r % a.H);
+    r /= a.H;
+    const int t = (int)(r % a.T), b = (int)(r / a.T);
+    const int i = g * 4, half = a.K / 2;
+    const T* xp = (const T*)a.x.ptr + b * a.x.sb + (long)t * a.x.sn + h * a.x.sh + i;
+    f32x4 x0 = Io<T>::ld4(xp), x1 = Io<T>::ld4(xp + half);
+    const f32x4 c = Io<T>::ld4((const T*)a.cos + (a.t_off + t) * a.ldt + i), s = Io<T>::ld4((const T*)a.sin + (a.t_off + t) * a.ldt + i);
+    f32x4 y0, y1;
+    if (!BWD) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (a.fmap == 1) { x0[u] = fmaxf(x0[u], 0.f); x1[u] = fmaxf(x1[u], 0.f); }
+            else if (a.fmap == 2) { x0[u] = x0[u] > 0.f ? x0[u] + 1.f : __expf(x0[u]); x1[u] = x1[u] > 0.f ? x1[u] + 1.f : __expf(x1[u]); }
+        }
+        y0 = x0 * c - x1 * s;
+        y1 = x1 * c + x0 * s;
+    } else {
+        y0 = x0 * c + x1 * s;
+        y1 = x1 * c - x0 * s;
+        if (a.fmap) {
+            const T* sp = (const T*)a.xs.ptr + b * a.xs.sb + (long)t * a.xs.sn + h * a.xs.sh + i;
+            const f32x4 s0 = Io<T>::ld4(sp), s1 = Io<T>::ld4(sp + half);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (a.fmap == 1) { y0[u] = s0[u] > 0.f ? y0[u] : 0.f; y1[u] = s1[u] > 0.f ? y1[u] : 0.f; }
+                else { y0[u] *= s0[u] > 0.f ? 1.f : __expf(s0[u]); y1[u] *= s1[u] > 0.f ? 1.f : __expf(s1[u]); }
+            }
+        }
+    }
+    T* yp = (T*)a.y.ptr + b * a.y.sb + (long)t * a.y.sn + h * a.y.sh + i;
+    Io<T>::st4(yp, y0);
+    Io<T>::st4(yp + half, y1);
+}
+
 }  // namespace mhla

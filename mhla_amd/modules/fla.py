@@ -17,7 +17,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from ..ops import mhla_causal, rmsnorm_gate
+from ..ops import featmap_rotary, mhla_causal, rmsnorm_gate
 from ..weights import causal_mixing_init
 
 
@@ -106,6 +106,7 @@ class MHLA(nn.Module):
         self.head_k_dim = self.key_dim // num_heads
         self.head_v_dim = self.value_dim // num_heads
 
+        self._fmap_name = feature_map
         if feature_map == "relu":
             self.feature_map_q = self.feature_map_k = nn.ReLU()
         elif feature_map == "identity":
@@ -159,11 +160,17 @@ class MHLA(nn.Module):
             v = v.reshape(B, T, self.num_kv_heads, 1, self.head_v_dim).expand(-1, -1, -1, self.num_kv_groups, -1)
         k = k.reshape(B, T, self.num_heads, self.head_k_dim)
         v = v.reshape(B, T, self.num_heads, self.head_v_dim)
-        q, k = self.feature_map_q(q), self.feature_map_k(k)                  # :297-299
         seqlen_offset = 0
         if past_key_values is not None and hasattr(past_key_values, "get_seq_length"):
             seqlen_offset = past_key_values.get_seq_length(self.layer_idx)
-        q, k = self.rotary(q, k, seqlen_offset=seqlen_offset)                # :311
+        if self.head_k_dim % 8 == 0:
+            # feature map (:297-299) + rotary (:311) in one HIP kernel per tensor and direction
+            cos, sin = self.rotary._tables(T + seqlen_offset, q.device, q.dtype)
+            q = featmap_rotary(q, cos, sin, self._fmap_name, seqlen_offset)
+            k = featmap_rotary(k, cos, sin, self._fmap_name, seqlen_offset)
+        else:
+            q, k = self.feature_map_q(q), self.feature_map_k(k)              # :297-299
+            q, k = self.rotary(q, k, seqlen_offset=seqlen_offset)            # :311
         o = mhla_causal(q, k, v, self.mixing_matrix)                         # :318-337 (T <= 64: single chunk)
         if self.use_output_gate:
             g = self.g_proj(hidden_states)

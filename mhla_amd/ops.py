@@ -277,6 +277,53 @@ def lepe2d(v: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], 
     return _Lepe2d.apply(v, weight, bias, add, int(pieces_len), int(block_len))
 
 
+_FMAPS = {None: 0, "identity": 0, "relu": 1, "elu": 2}
+
+
+class _FmapRotary(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, cos, sin, fmap, t_offset):
+        lib = _lib.load()
+        _require_gpu(x, cos, sin)
+        B, T, H, K = x.shape
+        x = _prep(x)
+        y = torch.empty((B, T, H, K), dtype=x.dtype, device=x.device)
+        rc = lib.mhla_featmap_rotary(_view(x), NULL_VIEW, cos.data_ptr(), sin.data_ptr(), cos.stride(0), t_offset, _view(y),
+                                     B, T, H, K, fmap, 0, _dtype_code(x), _stream())
+        _lib.check(rc, "mhla_featmap_rotary")
+        ctx.save_for_backward(x, cos, sin)
+        ctx.cfg = (fmap, t_offset)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, cos, sin = ctx.saved_tensors
+        fmap, t_offset = ctx.cfg
+        B, T, H, K = x.shape
+        dy = _prep(dy.to(x.dtype))
+        dx = torch.empty((B, T, H, K), dtype=x.dtype, device=x.device)
+        rc = lib.mhla_featmap_rotary(_view(dy), _view(x), cos.data_ptr(), sin.data_ptr(), cos.stride(0), t_offset, _view(dx),
+                                     B, T, H, K, fmap, 1, _dtype_code(x), _stream())
+        _lib.check(rc, "mhla_featmap_rotary (backward)")
+        return dx, None, None, None, None
+
+
+def featmap_rotary(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, feature_map: Optional[str] = None,
+                   t_offset: int = 0) -> torch.Tensor:
+    """Feature map (None / "identity", "relu", "elu" = elu + 1) followed by the NeoX-style rotary embedding, one HIP kernel
+    each way (mhla_nlp/fla/layers/mhla.py:297-299 + :311).  x: [B, T, H, K]; cos, sin: [>= t_offset + T, K/2] in x's dtype."""
+    if x.dim() != 4 or x.shape[-1] % 8:
+        raise ValueError("x: [B, T, H, K] with K % 8 == 0")
+    if feature_map not in _FMAPS:
+        raise ValueError(f"feature_map {feature_map!r}: one of {sorted(k for k in _FMAPS if k)} or None")
+    if cos.dtype != x.dtype or sin.dtype != x.dtype or cos.shape[-1] != x.shape[-1] // 2 or cos.shape[0] < t_offset + x.shape[1]:
+        raise ValueError("cos/sin: [>= t_offset + T, K/2] tables in the dtype of x")
+    if cos.stride(-1) != 1 or sin.stride(-1) != 1 or cos.stride(0) != sin.stride(0):
+        cos, sin = cos.contiguous(), sin.contiguous()
+    return _FmapRotary.apply(x, cos, sin, _FMAPS[feature_map], int(t_offset))
+
+
 def qk_prologue(x: torch.Tensor, weight: Optional[torch.Tensor], norm_eps: float = 1e-5, eps: float = 1e-6) -> torch.Tensor:
     """relu(rmsnorm(x) * weight) + eps over the last dim, fp32 output -- the q / k prologue of Wan's MHLA_Video_Uni
     (wan/mhla_utils.py:268-272 after the .float() at :308), one HIP kernel, forward only.  weight None: relu(x) + eps."""

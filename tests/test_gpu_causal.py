@@ -122,6 +122,36 @@ def test_causal_is_causal_and_recurrent_first_chunk():
         mhla_amd.mhla_causal(dq, dk, dv, dm[:4, :4])     # 300 tokens need 5 chunks
 
 
+@pytest.mark.parametrize("fmap", [None, "relu", "elu"])
+@pytest.mark.parametrize("dtype,K,off", [(torch.float32, 64, 0), (torch.bfloat16, 128, 0), (torch.float32, 24, 5)])
+def test_featmap_rotary(fmap, dtype, K, off):
+    """Fused feature map + NeoX rotary (fla layers/mhla.py:297-299, :311) vs the oracle's rotary twin, with gradients."""
+    import torch.nn.functional as F
+    import mhla_amd
+    g = torch.Generator().manual_seed(K + off)
+    B, T, H = 2, 77, 3
+    x = torch.randn(B, T, H, K, generator=g).to(dtype)
+    dy = torch.randn(B, T, H, K, generator=g).to(dtype)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, K, 2, dtype=torch.float32) / K))
+    fr = torch.outer(torch.arange(T + off, dtype=torch.float32), inv)
+    cos, sin = torch.cos(fr).to(dtype), torch.sin(fr).to(dtype)
+    f = {None: lambda t: t, "relu": torch.relu, "elu": lambda t: F.elu(t) + 1}[fmap]
+    xr = x.float().clone().requires_grad_(True)
+    # rotary_embedding_kernel semantics (rotary.py:97-135): fp32 math on the tables as cached in the activation dtype
+    c, s_ = cos.float()[off:off + T][None, :, None, :], sin.float()[off:off + T][None, :, None, :]
+    a, b = f(xr).chunk(2, dim=-1)
+    want = torch.cat((a * c - b * s_, b * c + a * s_), dim=-1)
+    if dtype == torch.float32:
+        check("oracle twin", want.detach(), orc.neox_rotary(f(x.float()), offset=off), 1e-6)
+    want.backward(dy.float())
+    xd = x.detach().to(DEV).requires_grad_(True)
+    got = mhla_amd.featmap_rotary(xd, cos.to(DEV), sin.to(DEV), fmap, off)
+    got.backward(dy.to(DEV))
+    tol = 2e-6 if dtype == torch.float32 else 8e-3
+    check("y", got, want, tol)
+    check("dx", xd.grad, xr.grad, tol)
+
+
 @pytest.mark.parametrize("gate", [True, False])
 @pytest.mark.parametrize("D,dtype", [(256, torch.float32), (128, torch.bfloat16), (512, torch.float32), (24, torch.float32)])
 def test_rmsnorm_gate(D, dtype, gate):

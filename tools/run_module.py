@@ -23,6 +23,17 @@ if which == "wan":
     def step():
         with torch.no_grad():
             return m(x, None, grid, freqs)
+elif which == "fla":
+    from mhla_amd.modules import MHLA
+    m = MHLA(mode="chunk", hidden_size=1024, expand_k=0.5, expand_v=1.0, num_heads=4, feature_map="relu").to(DEV).to(torch.bfloat16)
+    with torch.no_grad():
+        m.mixing_matrix.copy_(torch.tril(torch.rand(32, 32)).clamp(1e-5, 1).view(32, 32, 1, 1, 1, 1))
+    x = torch.randn(16, 2048, 1024, device=DEV, dtype=torch.bfloat16, requires_grad=True)
+
+    def step():
+        y = m(x)[0]
+        y.backward(torch.ones_like(y))
+        return y
 else:
     m = MHLA4DiT(1152, 16, qkv_bias=True, block_size=16, embed_len=256).to(DEV).to(torch.bfloat16)
     x = torch.randn(32, 256, 1152, device=DEV, dtype=torch.bfloat16, requires_grad=True)
