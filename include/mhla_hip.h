@@ -138,8 +138,9 @@ int mhla_blockmix_bwd(mhla_view q_num, mhla_view k_num, mhla_view v,
 
 /* ---- causal chunk-mixing MHLA: fla ------------------------------------- */
 
-size_t mhla_causal_fwd_ws_bytes(int B, int T, int H, int K, int V, int chunk);
-size_t mhla_causal_bwd_ws_bytes(int B, int T, int H, int K, int V, int chunk);
+/* Workspace bytes (the chunk summaries are bf16 for bf16 tensors with K and V multiples of 64, fp32 otherwise). */
+size_t mhla_causal_fwd_ws_bytes(int B, int T, int H, int K, int V, int chunk, int dtype);
+size_t mhla_causal_bwd_ws_bytes(int B, int T, int H, int K, int V, int chunk, int dtype);
 
 /*
  * Forward.  Replaces naive_chunk_simple_mhla_fixed
@@ -156,10 +157,12 @@ int mhla_causal_fwd(mhla_view q, mhla_view k, mhla_view v, const float* mix, int
                     float scale, int dtype, void* stream);
 
 /* Backward.  dmix is [n, n] fp32 with row stride lddmix;
- * only the lower triangle (incl. diagonal) of the leading n x n is written. */
+ * only the lower triangle (incl. diagonal) of the leading n x n is written.
+ * fwd_ws: the workspace mhla_causal_fwd was given for the same arguments, contents untouched
+ * (its chunk summaries S_j and the prefix mixes are reused), or NULL to recompute them. */
 int mhla_causal_bwd(mhla_view q, mhla_view k, mhla_view v, const float* mix, int ldmix,
                     mhla_view dout, mhla_mview dq, mhla_mview dk, mhla_mview dv,
-                    float* dmix, int lddmix, void* ws, size_t ws_bytes,
+                    float* dmix, int lddmix, void* ws, size_t ws_bytes, const void* fwd_ws,
                     int B, int T, int H, int K, int V, int chunk,
                     float scale, int dtype, void* stream);
 

@@ -220,8 +220,9 @@ struct CsWs {
     float *S, *P, *dP, *dS, *dwp, *diag;
     size_t total_fwd, total_bwd;
 };
-CsWs cs_carve(void* ws, int B, int T, int H, int K, int V, int chunk) {
-    const size_t bh = (size_t)B * H, n = (size_t)(T + chunk - 1) / chunk, st = al4(bh * n * K * V);
+// esz: bytes per summary element (2 on the bf16 pipeline, 4 on the generic one)
+CsWs cs_carve(void* ws, int B, int T, int H, int K, int V, int chunk, int esz) {
+    const size_t bh = (size_t)B * H, n = (size_t)(T + chunk - 1) / chunk, st = al4(bh * n * K * V) * esz / 4;
     float* p = (float*)ws;
     CsWs w;
     w.S = p; p += st;
@@ -543,8 +544,12 @@ int mhla_blockmix_bwd(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q
 // ---------------------------------------------------------------------------------------------
 // causal
 // ---------------------------------------------------------------------------------------------
-size_t mhla_causal_fwd_ws_bytes(int B, int T, int H, int K, int V, int chunk) { return cs_carve(nullptr, B, T, H, K, V, chunk).total_fwd; }
-size_t mhla_causal_bwd_ws_bytes(int B, int T, int H, int K, int V, int chunk) { return cs_carve(nullptr, B, T, H, K, V, chunk).total_bwd; }
+size_t mhla_causal_fwd_ws_bytes(int B, int T, int H, int K, int V, int chunk, int dtype) {
+    return cs_carve(nullptr, B, T, H, K, V, chunk, cs_bf16_ok(K, V, dtype) ? 2 : 4).total_fwd;
+}
+size_t mhla_causal_bwd_ws_bytes(int B, int T, int H, int K, int V, int chunk, int dtype) {
+    return cs_carve(nullptr, B, T, H, K, V, chunk, cs_bf16_ok(K, V, dtype) ? 2 : 4).total_bwd;
+}
 
 int mhla_causal_fwd(mhla_view q, mhla_view k, mhla_view v, const float* mix, int ldmix, mhla_mview out, void* ws,
                     size_t ws_bytes, int B, int T, int H, int K, int V, int chunk, float scale, int dtype, void* stream) {
@@ -552,12 +557,15 @@ int mhla_causal_fwd(mhla_view q, mhla_view k, mhla_view v, const float* mix, int
     CHECK_VIEW(q); CHECK_VIEW(k); CHECK_VIEW(v); CHECK_VIEW(out);
     const int n = (T + chunk - 1) / chunk;
     if (!mix || ldmix < n) return fail(MHLA_EINVAL, "mix null or ldmix=%d < n=%d chunks (T=%d)", ldmix, n, T);
-    const CsWs w = cs_carve(ws, B, T, H, K, V, chunk);
+    const bool pipe16 = cs_bf16_ok(K, V, dtype);
+    if (pipe16 && !(view_ok16(q) && view_ok16(k) && view_ok16(v) && view_ok16m(out)))
+        return fail(MHLA_EINVAL, "bf16 tensors with K, V multiples of 64 must be 16-byte aligned views (strides multiples of 8)");
+    const CsWs w = cs_carve(ws, B, T, H, K, V, chunk, pipe16 ? 2 : 4);
     if (!ws || ws_bytes < w.total_fwd) return fail(MHLA_EINVAL, "workspace too small: %zu < %zu bytes", ws_bytes, w.total_fwd);
     if (((uintptr_t)ws) % 16) return fail(MHLA_EINVAL, "workspace not 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     const long E = (long)K * V;
-    if (cs_bf16_ok(K, V, dtype) && view_ok16(q) && view_ok16(k) && view_ok16(v) && view_ok16m(out)) {
+    if (pipe16) {
         // bf16 pipeline (causal_bf16.cuh): bf16 chunk summaries, bf16 MFMA everywhere
         fast::CsfStateArgs s{cv(k), cv(v), (uint16_t*)w.S, H, n, K, V, (long)T, 1.f};
         RC(launch(fast::k_csf_state, dim3(n, B * H, K / 64), dim3(NTHREADS), fast::CSF_STATE_SMEM, st, "k_csf_state", s));
@@ -579,27 +587,36 @@ int mhla_causal_fwd(mhla_view q, mhla_view k, mhla_view v, const float* mix, int
 }
 
 int mhla_causal_bwd(mhla_view q, mhla_view k, mhla_view v, const float* mix, int ldmix, mhla_view dout, mhla_mview dq,
-                    mhla_mview dk, mhla_mview dv, float* dmix, int lddmix, void* ws, size_t ws_bytes, int B, int T,
-                    int H, int K, int V, int chunk, float scale, int dtype, void* stream) {
+                    mhla_mview dk, mhla_mview dv, float* dmix, int lddmix, void* ws, size_t ws_bytes, const void* fwd_ws,
+                    int B, int T, int H, int K, int V, int chunk, float scale, int dtype, void* stream) {
     RC(cs_check(B, T, H, K, V, chunk, dtype));
     CHECK_VIEW(q); CHECK_VIEW(k); CHECK_VIEW(v); CHECK_VIEW(dout); CHECK_VIEW(dq); CHECK_VIEW(dk); CHECK_VIEW(dv);
     const int n = (T + chunk - 1) / chunk;
     if (!mix || ldmix < n || !dmix || lddmix < n) return fail(MHLA_EINVAL, "mix/dmix null or leading dim < n=%d chunks", n);
-    const CsWs w = cs_carve(ws, B, T, H, K, V, chunk);
+    const bool pipe16 = cs_bf16_ok(K, V, dtype);
+    if (pipe16 && !(view_ok16(q) && view_ok16(k) && view_ok16(v) && view_ok16(dout) && view_ok16m(dq) && view_ok16m(dk) && view_ok16m(dv)))
+        return fail(MHLA_EINVAL, "bf16 tensors with K, V multiples of 64 must be 16-byte aligned views (strides multiples of 8)");
+    CsWs w = cs_carve(ws, B, T, H, K, V, chunk, pipe16 ? 2 : 4);
     if (!ws || ws_bytes < w.total_bwd) return fail(MHLA_EINVAL, "workspace too small: %zu < %zu bytes", ws_bytes, w.total_bwd);
-    if (((uintptr_t)ws) % 16) return fail(MHLA_EINVAL, "workspace not 16-byte aligned");
+    if (((uintptr_t)ws) % 16 || ((uintptr_t)fwd_ws) % 16) return fail(MHLA_EINVAL, "workspace not 16-byte aligned");
+    if (fwd_ws) {   // chunk summaries S, P left by mhla_causal_fwd with the same arguments: skip their recomputation
+        const CsWs f = cs_carve(const_cast<void*>(fwd_ws), B, T, H, K, V, chunk, pipe16 ? 2 : 4);
+        w.S = f.S;
+        w.P = f.P;
+    }
     hipStream_t st = (hipStream_t)stream;
     const long E = (long)K * V;
     const int tiles = (n + 63) / 64;
     const int nsplit = dw_splits(tiles * tiles * B * H, E);
-    if (cs_bf16_ok(K, V, dtype) && view_ok16(q) && view_ok16(k) && view_ok16(v) && view_ok16(dout) && view_ok16m(dq) &&
-        view_ok16m(dk) && view_ok16m(dv)) {
+    if (pipe16) {
         uint16_t *S = (uint16_t*)w.S, *P = (uint16_t*)w.P, *dP = (uint16_t*)w.dP, *dS = (uint16_t*)w.dS;
         const dim3 sgrid(n, B * H, K / 64), mgrid((unsigned)(E / fast::MX_TE), tiles, B * H);
-        fast::CsfStateArgs s{cv(k), cv(v), S, H, n, K, V, (long)T, 1.f};
-        RC(launch(fast::k_csf_state, sgrid, dim3(NTHREADS), fast::CSF_STATE_SMEM, st, "k_csf_state", s));
-        fast::CsfMixArgs m{mix, ldmix, S, P, n, E};
-        RC(launch(fast::k_csf_mix<0>, mgrid, dim3(NTHREADS), fast::CSF_MIX_SMEM, st, "k_csf_mix<0>", m));
+        if (!fwd_ws) {
+            fast::CsfStateArgs s{cv(k), cv(v), S, H, n, K, V, (long)T, 1.f};
+            RC(launch(fast::k_csf_state, sgrid, dim3(NTHREADS), fast::CSF_STATE_SMEM, st, "k_csf_state", s));
+            fast::CsfMixArgs m{mix, ldmix, S, P, n, E};
+            RC(launch(fast::k_csf_mix<0>, mgrid, dim3(NTHREADS), fast::CSF_MIX_SMEM, st, "k_csf_mix<0>", m));
+        }
         fast::CsfStateArgs sp{cv(q), cv(dout), dP, H, n, K, V, (long)T, scale};
         RC(launch(fast::k_csf_state, sgrid, dim3(NTHREADS), fast::CSF_STATE_SMEM, st, "k_csf_state", sp));
         fast::CsfMixArgs mt{mix, ldmix, dP, dS, n, E};
@@ -613,10 +630,12 @@ int mhla_causal_bwd(mhla_view q, mhla_view k, mhla_view v, const float* mix, int
         return MHLA_OK;
     }
     DISPATCH_T(dtype, {
-        RC(cs_xty<ET>(k, v, w.S, 1.f, B, T, H, n, K, V, st));
         MixArgs m{mix, ldmix, w.S, w.P, n, E};
         dim3 mgrid((unsigned)((m.E + MIX_TE - 1) / MIX_TE), (n + MIX_TI - 1) / MIX_TI, B * H);
-        RC(launch(k_mix<0, 1>, mgrid, dim3(NTHREADS), MIX_SMEM_FLOATS * 4, st, "k_mix<0,1>", m));
+        if (!fwd_ws) {
+            RC(cs_xty<ET>(k, v, w.S, 1.f, B, T, H, n, K, V, st));
+            RC(launch(k_mix<0, 1>, mgrid, dim3(NTHREADS), MIX_SMEM_FLOATS * 4, st, "k_mix<0,1>", m));
+        }
         RC(cs_xty<ET>(q, dout, w.dP, scale, B, T, H, n, K, V, st));
         MixArgs mt{mix, ldmix, w.dP, w.dS, n, E};
         RC(launch(k_mix<1, 1>, mgrid, dim3(NTHREADS), MIX_SMEM_FLOATS * 4, st, "k_mix<1,1>", mt));

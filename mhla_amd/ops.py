@@ -360,19 +360,21 @@ class _Causal(torch.autograd.Function):
         q, k, v = _prep(q), _prep(k), _prep(v)
         mixf = mix.detach().reshape(L, mix.shape[1]).to(torch.float32).contiguous()
         out = torch.empty((B, T, H, V), dtype=q.dtype, device=q.device)
-        ws = _ws(lib.mhla_causal_fwd_ws_bytes(B, T, H, K, V, chunk_size), q.device)
+        ws = _ws(lib.mhla_causal_fwd_ws_bytes(B, T, H, K, V, chunk_size, _dtype_code(q)), q.device)
         rc = lib.mhla_causal_fwd(_view(q), _view(k), _view(v), mixf.data_ptr(), mixf.shape[1], _view(out),
                                  ws.data_ptr(), ws.numel() * 4, B, T, H, K, V, chunk_size, float(scale),
                                  _dtype_code(q), _stream())
         _lib.check(rc, "mhla_causal_fwd")
-        ctx.save_for_backward(q, k, v, mixf)
+        # keep the chunk summaries (S_j and their prefix mixes) for the backward unless they are very large
+        keep = ws.numel() * 4 <= KEEP_STATE_LIMIT_BYTES and any(ctx.needs_input_grad[:4])
+        ctx.save_for_backward(q, k, v, mixf, ws if keep else None)
         ctx.cfg = (chunk_size, float(scale), mix.shape, mix.dtype)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         lib = _lib.load()
-        q, k, v, mixf = ctx.saved_tensors
+        q, k, v, mixf, fwd_ws = ctx.saved_tensors
         chunk_size, scale, mix_shape, mix_dtype = ctx.cfg
         B, T, H, K = q.shape
         V = v.shape[-1]
@@ -381,11 +383,11 @@ class _Causal(torch.autograd.Function):
         dv = torch.empty((B, T, H, V), dtype=q.dtype, device=q.device)
         dq = torch.empty((B, T, H, K), dtype=q.dtype, device=q.device)
         dmix = torch.zeros(mixf.shape, dtype=torch.float32, device=q.device)
-        ws = _ws(lib.mhla_causal_bwd_ws_bytes(B, T, H, K, V, chunk_size), q.device)
+        ws = _ws(lib.mhla_causal_bwd_ws_bytes(B, T, H, K, V, chunk_size, _dtype_code(q)), q.device)
         rc = lib.mhla_causal_bwd(_view(q), _view(k), _view(v), mixf.data_ptr(), mixf.shape[1], _view(dout),
                                  _view(dq), _view(dk), _view(dv), dmix.data_ptr(), dmix.shape[1],
-                                 ws.data_ptr(), ws.numel() * 4, B, T, H, K, V, chunk_size, scale, _dtype_code(q),
-                                 _stream())
+                                 ws.data_ptr(), ws.numel() * 4, fwd_ws.data_ptr() if fwd_ws is not None else None,
+                                 B, T, H, K, V, chunk_size, scale, _dtype_code(q), _stream())
         _lib.check(rc, "mhla_causal_bwd")
         return dq, dk, dv, dmix.reshape(mix_shape).to(mix_dtype), None, None
 

@@ -85,6 +85,22 @@ def test_causal_bf16_pipeline_vs_generic(monkeypatch):
         check(name, a, b.float().cpu(), GTOL[torch.bfloat16])
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_causal_kept_summaries_match_recompute(dtype, monkeypatch):
+    """The backward reuses the forward's chunk summaries when the workspace is kept; same gradients as recomputing them."""
+    import mhla_amd
+    from mhla_amd import ops
+    q, k, v, mix, do = causal_inputs(2, 300, 2, 64, 128, 8, dtype, seed=5)
+    res = []
+    for limit in (1 << 30, 0):
+        monkeypatch.setattr(ops, "KEEP_STATE_LIMIT_BYTES", limit)
+        t = [x.to(DEV).requires_grad_(True) for x in (q, k, v, mix)]
+        mhla_amd.mhla_causal(*t).backward(do.to(DEV))
+        res.append([x.grad for x in t])
+    for name, a, b in zip(("dq", "dk", "dv", "dmix"), *res):
+        assert torch.equal(a, b), name
+
+
 def test_causal_bf16_strided_views():
     """q/k/v as slices of one fused projection buffer (row stride 3 * H * K): the views stay 16-byte aligned."""
     import mhla_amd

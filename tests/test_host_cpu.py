@@ -27,7 +27,8 @@ def test_library_builds_and_exports_every_declared_symbol():
     bwd = lib.mhla_blockmix_bwd_ws_bytes(8, 16, 64, 64, 64, 0, 0, 0)
     assert lib.mhla_blockmix_fwd_ws_bytes(8, 16, 64, 64, 64, 1, 0, 0) < fwd   # bf16 fast path: compact summaries
     assert 0 < fwd < bwd
-    assert lib.mhla_causal_bwd_ws_bytes(1, 8192, 4, 128, 256, 64) > lib.mhla_causal_fwd_ws_bytes(1, 8192, 4, 128, 256, 64) > 0
+    assert lib.mhla_causal_bwd_ws_bytes(1, 8192, 4, 128, 256, 64, 0) > lib.mhla_causal_fwd_ws_bytes(1, 8192, 4, 128, 256, 64, 0) > 0
+    assert lib.mhla_causal_fwd_ws_bytes(1, 8192, 4, 128, 256, 64, 1) * 2 == lib.mhla_causal_fwd_ws_bytes(1, 8192, 4, 128, 256, 64, 0)
 
 
 def test_argument_validation_without_gpu():
