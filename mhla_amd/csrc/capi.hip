@@ -315,7 +315,8 @@ int mhla_blockmix_fwd_keeps_state(int B, int H, int M, int S, int D, int dtype, 
     (void)B; (void)H;
     if (flags & MHLA_FLAG_FORCE_GENERIC) return 0;
     if (sn_shape_ok(M, S, D, dtype, split != 0) && !(flags & MHLA_FLAG_NO_SMALLN)) return 0;
-    return fast_shape_ok(M, D, dtype, split != 0) ? 1 : 0;
+    if (fast_shape_ok(M, D, dtype, split != 0)) return 1;
+    return sp_shape_ok(D, flags) ? 1 : 0;   // split-operand path: KV, G, z, ksum, 1/n (fp32)
 }
 
 // Upper bound over the paths the library may take for this problem (the fast path needs less).
@@ -483,10 +484,18 @@ int mhla_blockmix_bwd(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q
             return MHLA_OK;
         }
     }
-    const BmWs w = bm_carve(ws, B, H, M, S, D);
+    BmWs w = bm_carve(ws, B, H, M, S, D);
     if (ws_bytes < w.total_bwd) return fail(MHLA_EINVAL, "workspace too small: %zu < %zu bytes", ws_bytes, w.total_bwd);
+    // the forward's KV, G, z, ksum, 1/n are still in its workspace (only when the shape cannot have taken the bf16 fast path,
+    // whose workspace has another layout)
+    const bool reuse = fwd_ws && sp_shape_ok(D, flags) && !fast_shape_ok(M, D, dtype, split);
+    if (reuse) {
+        const BmWs f = bm_carve(const_cast<void*>(fwd_ws), B, H, M, S, D);
+        w.kv = f.kv; w.g = f.g; w.z = f.z; w.ksum = f.ksum; w.ninv = f.ninv;
+    }
     DISPATCH_T(dtype, DISPATCH_DT(dt, {
-        RC((bm_state_and_mix<ET, DT>(q_num, k_num, v, q_den, k_den, W, ldw, block_index, w, B, H, M, S, D, eps, flags, normalize, split, st)));
+        if (!reuse)
+            RC((bm_state_and_mix<ET, DT>(q_num, k_num, v, q_den, k_den, W, ldw, block_index, w, B, H, M, S, D, eps, flags, normalize, split, st)));
         // dG_i = Q_i^T (dO_i / n_i), dn_i
         StateArgs a{};
         a.x = cv(q_num); a.y = cv(dout); a.o = cv(out); a.idx = block_index; a.W = W; a.ldw = ldw; a.ninv = w.ninv;

@@ -178,6 +178,21 @@ def test_split_operand_path_matches_exact_fp32():
         check(name, a, b.cpu(), 2e-4)
 
 
+def test_split_path_kept_summaries_match_recompute(monkeypatch):
+    """Backward with the forward's workspace kept (KV, G, z, ksum, 1/n reused) == backward that recomputes them."""
+    import mhla_amd
+    from mhla_amd import ops
+    q, k, v, W, do, qd, kd = make_blockmix_inputs(1, 2, 20, 40, 128, torch.float32, seed=3, w="rand", split=True)
+    res = []
+    for limit in (1 << 30, 0):
+        monkeypatch.setattr(ops, "KEEP_STATE_LIMIT_BYTES", limit)
+        t = [x.clone().requires_grad_(True) for x in to_dev(q, k, v, W, qd, kd)]
+        mhla_amd.mhla_blockmix(t[0], t[1], t[2], t[3], q_den=t[4], k_den=t[5]).backward(do.to(DEV))
+        res.append([x.grad for x in t])
+    for name, a, b in zip(("dq", "dk", "dv", "dW", "dq_den", "dk_den"), *res):
+        assert torch.equal(a, b), name
+
+
 def test_block_index_gather():
     idx = orc.block_index_3d((4, 6, 8), (2, 3, 4)).int()
     run_case(1, 2, 24, 8, 64, torch.float32, split=True, idx=idx)
