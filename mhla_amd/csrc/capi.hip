@@ -261,9 +261,13 @@ int norm_check(const void* x, const void* y, int64_t rows, int D, int dtype) {
     if (dtype < 0 || dtype > 2) return fail(MHLA_EINVAL, "unknown dtype %d", dtype);
     return MHLA_OK;
 }
-int norm_grid(int64_t rows) {
+int norm_grid(int64_t rows) {   // backward: one dw partial row per workgroup, so the grid is capped
     int64_t g = (rows + 3) / 4;
     return (int)(g < 2048 ? g : 2048);
+}
+int norm_fwd_grid(int64_t rows, int rows_per_wave) {   // forward: a wave per row group, no grid-stride serialisation
+    int64_t g = (rows + 4 * rows_per_wave - 1) / (4 * rows_per_wave);
+    return (int)(g < (1 << 20) ? g : (1 << 20));
 }
 
 }  // namespace
@@ -670,9 +674,17 @@ int mhla_rmsnorm_gate_fwd(const void* x, int64_t ldx, const void* g, int64_t ldg
     NormArgs a{};
     a.x = x; a.ldx = ldx; a.g = g; a.ldg = ldg; a.w = w; a.y = y; a.ldy = ldy; a.rstd = rstd; a.rows = rows; a.D = D; a.eps = eps;
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid(norm_grid(rows));
+    const dim3 grid(norm_fwd_grid(rows, 1));
     DISPATCH_T(dtype, {
-        if (D <= 256) {
+        if (D <= 64) {
+            const dim3 g4(norm_fwd_grid(rows, 4));
+            if (g) RC(launch(k_rmsnorm_gate_fwd_sub<ET, 16, true>, g4, dim3(256), 0, st, "k_rmsnorm_gate_fwd", a));
+            else   RC(launch(k_rmsnorm_gate_fwd_sub<ET, 16, false>, g4, dim3(256), 0, st, "k_rmsnorm_gate_fwd", a));
+        } else if (D <= 128) {
+            const dim3 g2(norm_fwd_grid(rows, 2));
+            if (g) RC(launch(k_rmsnorm_gate_fwd_sub<ET, 32, true>, g2, dim3(256), 0, st, "k_rmsnorm_gate_fwd", a));
+            else   RC(launch(k_rmsnorm_gate_fwd_sub<ET, 32, false>, g2, dim3(256), 0, st, "k_rmsnorm_gate_fwd", a));
+        } else if (D <= 256) {
             if (g) RC(launch(k_rmsnorm_gate_fwd<ET, 1, true>, grid, dim3(256), 0, st, "k_rmsnorm_gate_fwd", a));
             else   RC(launch(k_rmsnorm_gate_fwd<ET, 1, false>, grid, dim3(256), 0, st, "k_rmsnorm_gate_fwd", a));
         } else {

@@ -65,6 +65,37 @@ __global__ __launch_bounds__(256) void k_rmsnorm_gate_fwd(const NormArgs a) {
     }
 }
 
+
+// Narrow rows (D <= 4 * LPR, LPR = 16 or 32 lanes per row): 64 / LPR rows per wave, so that every lane carries data
+// (Wan's per-head norm has D = 128: the one-row-per-wave kernel would leave half the wave idle).
+template <typename T, int LPR, bool GATE>
+__global__ __launch_bounds__(256) void k_rmsnorm_gate_fwd_sub(const NormArgs a) {
+    constexpr int RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane / LPR, c = (lane % LPR) * 4;
+    const long nw = (long)gridDim.x * 4 * RPW;
+    for (long row0 = ((long)blockIdx.x * 4 + wave) * RPW; row0 < a.rows; row0 += nw) {
+        const long row = row0 + sub;
+        const bool live = row < a.rows && c < a.D;
+        f32x4 xv = {0.f, 0.f, 0.f, 0.f};
+        if (live) xv = Io<T>::ld4((const T*)a.x + row * a.ldx + c);
+        float ss = xv[0] * xv[0] + xv[1] * xv[1] + xv[2] * xv[2] + xv[3] * xv[3];
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        const float rstd = 1.f / sqrtf(ss / (float)a.D + a.eps);
+        if (a.rstd && row < a.rows && (lane % LPR) == 0) a.rstd[row] = rstd;
+        if (live) {
+            f32x4 y = xv * rstd;
+            if (a.w) y *= *reinterpret_cast<const f32x4*>(a.w + c);
+            if (GATE) {
+                const f32x4 gv = Io<T>::ld4((const T*)a.g + row * a.ldg + c);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) y[t] *= gv[t] / (1.f + __expf(-gv[t]));
+            }
+            Io<T>::st4((T*)a.y + row * a.ldy + c, y);
+        }
+    }
+}
+
 template <typename T, int NV, bool GATE>
 __global__ __launch_bounds__(256) void k_rmsnorm_gate_bwd(const NormArgs a) {
     __shared__ float red[4][NV * 256];
