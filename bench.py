@@ -90,6 +90,15 @@ def cpu_baseline(a, budget_s=12.0):
                       f"M={a.M}; median of {len(times)} iterations ({med * 1e3:.0f} ms each)"}
 
 
+def _config_name(a):
+    shape = (a.B, a.N, a.H, a.D, a.M, a.dtype)
+    if shape == (8, 4096, 16, 64, 64, "bf16"):
+        return "BASELINE.json configs[1]"
+    if shape[1:] == (256, 16, 72, 16, "bf16"):
+        return "operator shape of BASELINE.json configs[2], DiT-XL/2 256x256"
+    return "custom shape"
+
+
 def main():
     a = parse()
     from mhla_amd import dist as mdist
@@ -160,7 +169,7 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": f"block-mix MHLA op fwd+bwd, per GPU B={a.B} N={a.N} H={a.H} D={a.D} "
-                                   f"M={a.M} S={a.N // a.M} {a.dtype} (BASELINE.json configs[1])",
+                                   f"M={a.M} S={a.N // a.M} {a.dtype} ({_config_name(a)})",
                        "global_batch": a.B * world, "parallelism": f"dp{world} (batch shards, dW all-reduce only)"},
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
