@@ -115,14 +115,22 @@ def main():
     for t in (q, k, v, W):
         t.requires_grad_(True)
 
+    reducer = mdist.OverlappedGradAllReduce()
+
     def step():
         out = mhla_amd.mhla_blockmix(q, k, v, W, eps=1e-6)
         out.backward(do)
-        mdist.allreduce_mean_(W.grad)      # the one real exchange of a data-parallel step on this path (dW)
+        # the one real exchange of a data-parallel step on this path: the mean all-reduce of dW, scheduled like DDP's
+        # reducer (asynchronous, consumed at the next step / the closing synchronisation of the timed region)
+        reducer.issue(W.grad)
         q.grad = k.grad = v.grad = W.grad = None
 
     sync = torch.cuda.synchronize
-    el = mdist.timed_steps(step, a.steps, a.warmup, sync)
+    def sync_all():
+        reducer.wait()
+        sync()
+
+    el = mdist.timed_steps(step, a.steps, a.warmup, sync_all)
     ms_per_step = el / a.steps * 1e3
     tokens_per_step = a.B * a.N * world
     value = tokens_per_step / (el / a.steps)

@@ -40,6 +40,26 @@ def allreduce_mean_(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
+class OverlappedGradAllReduce:
+    """Mean all-reduce of a parameter gradient the way DDP's reducer schedules it: issued as soon as the gradient exists
+    (asynchronously, on the process group's own stream) and waited for only where the optimizer would consume it -- here
+    the start of the next step, or the device synchronisation that closes the timed region.  Keeps the tensor alive."""
+
+    def __init__(self):
+        self._pending = None
+
+    def issue(self, t: torch.Tensor) -> None:
+        self.wait()
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            t.div_(dist.get_world_size())
+            self._pending = (dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True), t)
+
+    def wait(self) -> None:
+        if self._pending is not None:
+            self._pending[0].wait()
+            self._pending = None
+
+
 def timed_steps(step: Callable[[], None], steps: int, warmup: int, sync: Callable[[], None]) -> float:
     """W untimed warm-up steps, then exactly K steps bracketed by barrier + device sync on both sides.
     Returns the MAX over ranks of the elapsed seconds."""

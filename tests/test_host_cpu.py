@@ -146,6 +146,11 @@ dW_local = orc.blockmix_bwd(q[lo:hi], k[lo:hi], v[lo:hi], W, do[lo:hi])["dW"]
 dW = mdist.allreduce_mean_(dW_local.clone())
 full = orc.blockmix_bwd(q, k, v, W, do)["dW"] / world
 assert torch.allclose(dW, full, rtol=1e-4, atol=1e-6), (dW - full).abs().max()
+red = mdist.OverlappedGradAllReduce()
+t2 = dW_local.clone()
+red.issue(t2)          # asynchronous mean all-reduce, as bench.py schedules it
+red.wait()
+assert torch.allclose(t2, full, rtol=1e-4, atol=1e-6)
 calls = []
 el = mdist.timed_steps(lambda: calls.append(1), steps=4, warmup=2, sync=lambda: None)
 assert len(calls) == 6 and el >= 0
