@@ -106,6 +106,7 @@ def main():
     if world != a.gpus and rank == 0:
         print(f"[bench] note: --gpus {a.gpus} but WORLD_SIZE={world}", file=sys.stderr)
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback for the product path)"
+    local = local % torch.cuda.device_count()   # ranks > GPUs only in the shared-GPU harness test (MHLA_DIST_BACKEND=gloo)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import mhla_amd
