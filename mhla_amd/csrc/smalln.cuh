@@ -106,6 +106,41 @@ __device__ __forceinline__ bf16x8 sn_pack_pair(f32x4 c0, f32x4 c1) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
+// Sums 16 per-lane values over the 64 lanes with 17 shuffles (instead of 16 x 6): at each of the first four butterfly steps a
+// lane keeps the half of the values selected by its own lane bit and sends the other half.  Returns the total of value
+// j = 8 b5 + 4 b4 + 2 b3 + b2 (b_k = bit k of the lane); the four lanes of a quad hold the same total.
+__device__ __forceinline__ float wave_reduce16(float (&v)[16], int lane) {
+    {
+        const bool up = lane & 32;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float keep = up ? v[k + 8] : v[k], send = up ? v[k] : v[k + 8];
+            v[k] = keep + __shfl_xor(send, 32, 64);
+        }
+    }
+    {
+        const bool up = lane & 16;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float keep = up ? v[k + 4] : v[k], send = up ? v[k] : v[k + 4];
+            v[k] = keep + __shfl_xor(send, 16, 64);
+        }
+    }
+    {
+        const bool up = lane & 8;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const float keep = up ? v[k + 2] : v[k], send = up ? v[k] : v[k + 2];
+            v[k] = keep + __shfl_xor(send, 8, 64);
+        }
+    }
+    const bool up = lane & 4;
+    float r = (up ? v[1] : v[0]) + __shfl_xor(up ? v[0] : v[1], 4, 64);
+    r += __shfl_xor(r, 2, 64);
+    r += __shfl_xor(r, 1, 64);
+    return r;
+}
+
 template <int DT>
 __host__ __device__ constexpr int sn_fwd_smem() {
     return 2 * 256 * sn_ldr<DT>() * 2 + (16 * DT * 16 + 256) * 4 + SN_W * 16 * sn_ldr<DT>() * 2;
@@ -356,37 +391,43 @@ __global__ __launch_bounds__(SN_T, 2) void k_sn_bwd(const SnArgs a) {
         f32x4 acc[DT];
 #pragma unroll
         for (int tn = 0; tn < DT; ++tn) acc[tn] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
-        for (int j0 = 0; j0 < M; j0 += 2) {
-            const bool has1 = j0 + 1 < M;
-            const int j1 = has1 ? j0 + 1 : j0;
-            const float w0 = a.W[(long)i * a.ldw + j0], w1 = has1 ? a.W[(long)i * a.ldw + j1] : 0.f;
-            f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, p0 = s0, p1 = s0;
-            bf16x8 t0[KS], t1[KS];
-            sn_lds_rows<KS>(t0, T0, LDR, j0 * 16, D, lane);
-            sn_lds_rows<KS>(t1, T0, LDR, j1 * 16, D, lane);
+        float ew[16];   // per-lane partials of dW[i][0..15]
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) { s0 = mfma_bf16(t0[ks], qa[ks], s0); s1 = mfma_bf16(t1[ks], qa[ks], s1); }   // S^T
-            sn_lds_rows<KS>(t0, T1, LDR, j0 * 16, D, lane);
-            sn_lds_rows<KS>(t1, T1, LDR, j1 * 16, D, lane);
+        for (int jp = 0; jp < 8; ++jp) {
+            const int j0 = 2 * jp;
+            ew[j0] = ew[j0 + 1] = 0.f;
+            if (j0 < M) {
+                const bool has1 = j0 + 1 < M;
+                const int j1 = has1 ? j0 + 1 : j0;
+                const float w0 = a.W[(long)i * a.ldw + j0], w1 = has1 ? a.W[(long)i * a.ldw + j1] : 0.f;
+                f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, p0 = s0, p1 = s0;
+                bf16x8 t0[KS], t1[KS];
+                sn_lds_rows<KS>(t0, T0, LDR, j0 * 16, D, lane);
+                sn_lds_rows<KS>(t1, T0, LDR, j1 * 16, D, lane);
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) { p0 = mfma_bf16(t0[ks], ga[ks], p0); p1 = mfma_bf16(t1[ks], ga[ks], p1); }   // dP^T
-            // dW[i][j] = sum(dP . S) + sum_s dn_i[s] z_j[s]
-            float e0 = s0[0] * p0[0] + s0[1] * p0[1] + s0[2] * p0[2] + s0[3] * p0[3];
-            float e1 = s1[0] * p1[0] + s1[1] * p1[1] + s1[2] * p1[2] + s1[3] * p1[3];
-            if (a.normalize && kg == 0) {
-                e0 += dns[i * 16 + n] * zs[j0 * 16 + n];
-                e1 += dns[i * 16 + n] * zs[j1 * 16 + n];
+                for (int ks = 0; ks < KS; ++ks) { s0 = mfma_bf16(t0[ks], qa[ks], s0); s1 = mfma_bf16(t1[ks], qa[ks], s1); }   // S^T
+                sn_lds_rows<KS>(t0, T1, LDR, j0 * 16, D, lane);
+                sn_lds_rows<KS>(t1, T1, LDR, j1 * 16, D, lane);
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) { p0 = mfma_bf16(t0[ks], ga[ks], p0); p1 = mfma_bf16(t1[ks], ga[ks], p1); }   // dP^T
+                // dW[i][j] = sum(dP . S) + sum_s dn_i[s] z_j[s]: lane partials, reduced once per query block below
+                float e0 = s0[0] * p0[0] + s0[1] * p0[1] + s0[2] * p0[2] + s0[3] * p0[3];
+                float e1 = s1[0] * p1[0] + s1[1] * p1[1] + s1[2] * p1[2] + s1[3] * p1[3];
+                if (a.normalize && kg == 0) {
+                    e0 += dns[i * 16 + n] * zs[j0 * 16 + n];
+                    e1 += dns[i * 16 + n] * zs[j1 * 16 + n];
+                }
+                ew[j0] = e0;
+                ew[j0 + 1] = has1 ? e1 : 0.f;
+                const bf16x8 da = sn_pack_pair(p0 * w0, p1 * w1);      // dS^T pair -> A operand (m = s, k-slots = t)
+#pragma unroll
+                for (int tn = 0; tn < DT; ++tn) acc[tn] = mfma_bf16(da, sn_tr_pair(T0, LDR, j0 * 16, j1 * 16, tn * 16, lane), acc[tn]);
             }
-            e0 = wave_sum(e0);
-            e1 = wave_sum(e1);
-            if (lane == 0) {
-                dwp[i * M + j0] = e0;
-                if (has1) dwp[i * M + j1] = e1;
-            }
-            const bf16x8 da = sn_pack_pair(p0 * w0, p1 * w1);      // dS^T pair -> A operand (m = s, k-slots = t)
-#pragma unroll
-            for (int tn = 0; tn < DT; ++tn) acc[tn] = mfma_bf16(da, sn_tr_pair(T0, LDR, j0 * 16, j1 * 16, tn * 16, lane), acc[tn]);
+        }
+        {
+            const float tot = wave_reduce16(ew, lane);
+            const int jw = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
+            if ((lane & 3) == 0 && jw < M) dwp[i * M + jw] = tot;
         }
         // epilogue: + dz (x) ksum ; stage ; masked store
 #pragma unroll
@@ -402,20 +443,6 @@ __global__ __launch_bounds__(SN_T, 2) void k_sn_bwd(const SnArgs a) {
         if (a.relu) sn_store16<true>(dqb, a.dq.sn, a.idx, i * 16, D, Os, LDR, qb, a.q.sn, lane);
         else        sn_store16<false>(dqb, a.dq.sn, a.idx, i * 16, D, Os, LDR, nullptr, 0, lane);
         wave_lds_fence();
-        if (a.normalize) {   // dksum_i[d] = sum_s dz_i[s] q_i[s][d]
-            const float dzn = dzs[i * 16 + n];
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const s16x8 qs = __builtin_bit_cast(s16x8, qa[ks]);
-#pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    float v = dzn * bf((u16)qs[t]);
-                    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64);
-                    v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-                    if (n == 0 && ks * 32 + kg * 8 + t < DP) dks_s[i * DP + ks * 32 + kg * 8 + t] = v;
-                }
-            }
-        }
     }
     __syncthreads();
 
@@ -475,11 +502,31 @@ __global__ __launch_bounds__(SN_T, 2) void k_sn_bwd(const SnArgs a) {
                 accK[tn] = mfma_bf16(da, sn_tr_pair(T0, LDR, i0 * 16, i1 * 16, tn * 16, lane), accK[tn]);   // dK += dS^T Q
             }
         }
+        // dksum_j[d] = sum_s dz_j[s] q_j[s][d] as one MFMA per feature tile: every row of the A operand is dz_j (k-slots of the
+        // first tile of the pair, hi + lo bf16), the B operand the transposed Q_j tile; all rows of the result are equal
+        f32x4 dks[DT];
+#pragma unroll
+        for (int tn = 0; tn < DT; ++tn) dks[tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (a.normalize) {
+            f32x4 dz4, dzl;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                dz4[r] = dzs[j * 16 + kg * 4 + r];
+                dzl[r] = dz4[r] - bf(cvt_bf16(dz4[r]));
+            }
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            const bf16x8 ah = sn_pack_pair(dz4, zero), al = sn_pack_pair(dzl, zero);
+#pragma unroll
+            for (int tn = 0; tn < DT; ++tn) {
+                const bf16x8 bq = sn_tr_pair(T0, LDR, j * 16, j * 16, tn * 16, lane);
+                dks[tn] = mfma_bf16(ah, bq, dks[tn]);
+                dks[tn] = mfma_bf16(al, bq, dks[tn]);
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int tn = 0; tn < DT; ++tn)
-                Os[(kg * 4 + r) * LDR + tn * 16 + n] = cvt_bf16(accK[tn][r] + (a.normalize ? dks_s[j * DP + tn * 16 + n] : 0.f));
+            for (int tn = 0; tn < DT; ++tn) Os[(kg * 4 + r) * LDR + tn * 16 + n] = cvt_bf16(accK[tn][r] + dks[tn][0]);
         wave_lds_fence();
         if (a.relu) sn_store16<true>(dkb, a.dk.sn, a.idx, j * 16, D, Os, LDR, kb, a.k.sn, lane);
         else        sn_store16<false>(dkb, a.dk.sn, a.idx, j * 16, D, Os, LDR, nullptr, 0, lane);
