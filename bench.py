@@ -35,6 +35,7 @@ def parse():
     p.add_argument("--M", type=int, default=64)
     p.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "f16"])
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--graph", action="store_true", help="capture the fwd+bwd step in a HIP graph and replay it (removes the Python launch path)")
     p.add_argument("--head-major", action="store_true", help="experiment: inputs stored [B,H,N,D] (views permuted to [B,N,H,D])")
     return p.parse_args()
 
@@ -127,6 +128,24 @@ def main():
         q.grad = k.grad = v.grad = W.grad = None
 
     sync = torch.cuda.synchronize
+    if a.graph:
+        # whole-step capture: the same launches, replayed by the runtime (static inputs / gradients in the graph's pool)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                mhla_amd.mhla_blockmix(q, k, v, W, eps=1e-6).backward(do)
+        torch.cuda.current_stream().wait_stream(side)
+        q.grad = k.grad = v.grad = W.grad = None
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            mhla_amd.mhla_blockmix(q, k, v, W, eps=1e-6).backward(do)
+        eager_step = step
+
+        def step():   # noqa: F811
+            graph.replay()
+            reducer.issue(W.grad)
+
     def sync_all():
         reducer.wait()
         sync()
@@ -138,6 +157,8 @@ def main():
 
     # ---- per-kernel durations, measured live with HIP events on the launch stream ----
     lib.mhla_prof_enable(1)
+    if a.graph:
+        step = eager_step   # per-kernel event timing needs the eager launches
     for _ in range(a.steps):
         step()
     sync()
@@ -179,7 +200,8 @@ def main():
             "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": f"block-mix MHLA op fwd+bwd, per GPU B={a.B} N={a.N} H={a.H} D={a.D} "
                                    f"M={a.M} S={a.N // a.M} {a.dtype} ({_config_name(a)})",
-                       "global_batch": a.B * world, "parallelism": f"dp{world} (batch shards, dW all-reduce only)"},
+                       "global_batch": a.B * world, "parallelism": f"dp{world} (batch shards, dW all-reduce only)",
+                       "launch": "hipGraph replay of the captured fwd+bwd step" if a.graph else "eager (Python autograd)"},
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS if achieved else None, "traffic": traffic,
