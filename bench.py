@@ -36,7 +36,6 @@ def parse():
     p.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "f16"])
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--graph", action="store_true", help="capture the fwd+bwd step in a HIP graph and replay it (removes the Python launch path)")
-    p.add_argument("--head-major", action="store_true", help="experiment: inputs stored [B,H,N,D] (views permuted to [B,N,H,D])")
     return p.parse_args()
 
 
@@ -49,8 +48,6 @@ def make_inputs(a, device, seed):
     k = (torch.relu(torch.randn(shape, generator=g)) + 1e-6).to(dt).to(device)
     v = torch.randn(shape, generator=g).to(dt).to(device)
     do = torch.randn(shape, generator=g).to(dt).to(device)
-    if a.head_major:
-        q, k, v, do = (t.permute(0, 2, 1, 3).contiguous().permute(0, 2, 1, 3) for t in (q, k, v, do))
     side = int(round(a.M ** 0.5))
     W = block_distance_weights((side, side) if side * side == a.M else (a.M,), "linear").to(device)
     return q, k, v, W, do

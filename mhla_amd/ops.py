@@ -55,9 +55,6 @@ def _prep(t: torch.Tensor) -> torch.Tensor:
 
 
 def _alloc_like_tokens(B, N, H, D, ref):
-    import os
-    if os.environ.get("MHLA_HEAD_MAJOR_OUT"):   # experiment: outputs stored [B, H, N, D]
-        return torch.empty((B, H, N, D), dtype=ref.dtype, device=ref.device).permute(0, 2, 1, 3)
     return torch.empty((B, N, H, D), dtype=ref.dtype, device=ref.device)
 
 
