@@ -1,0 +1,59 @@
+"""GPU parity: seeded random shapes / options through the dispatcher (small-sequence, bf16 fast, split-operand and generic
+kernel families; causal bf16 pipeline and generic) against the oracle.  Sizes keep the oracle at milliseconds per case."""
+import random
+
+import pytest
+import torch
+
+from gpu_util import DEV, GTOL, TOL, check
+from oracle import mhla_oracle as orc
+from test_gpu_blockmix import run_case
+from test_gpu_causal import run_causal
+
+pytestmark = pytest.mark.gpu
+
+_DT = [torch.float32, torch.bfloat16, torch.float16]
+
+
+def _blockmix_cases(n=48, seed=20261001):
+    rnd = random.Random(seed)
+    cases = []
+    for i in range(n):
+        dtype = rnd.choice(_DT)
+        D = rnd.choice([4, 8, 12, 16, 24, 32, 40, 48, 56, 64, 64, 64, 72, 80, 96, 104, 128, 128])
+        M = rnd.choice([1, 2, 3, 4, 5, 9, 16, 16, 25, 33, 64, 70])
+        S = rnd.choice([1, 3, 7, 16, 16, 20, 33, 49, 64])
+        if M * S * D > 400000:
+            S = max(1, 400000 // (M * D))
+        normalize = rnd.random() < 0.8
+        split = normalize and rnd.random() < 0.35
+        use_idx = rnd.random() < 0.3
+        cases.append((i, dtype, M, S, D, normalize, split, use_idx, rnd.choice(["linear", "rand"])))
+    return cases
+
+
+@pytest.mark.parametrize("case", _blockmix_cases(), ids=lambda c: f"{c[0]}-{str(c[1]).split('.')[-1]}-M{c[2]}-S{c[3]}-D{c[4]}-n{int(c[5])}s{int(c[6])}i{int(c[7])}")
+def test_blockmix_fuzz(case):
+    i, dtype, M, S, D, normalize, split, use_idx, w = case
+    idx = None
+    if use_idx:
+        idx = torch.randperm(M * S, generator=torch.Generator().manual_seed(i)).int()
+    run_case(2 if M * S * D < 100000 else 1, 2, M, S, D, dtype, normalize=normalize, split=split, w=w, idx=idx, seed=1000 + i)
+
+
+def _causal_cases(n=16, seed=7):
+    rnd = random.Random(seed)
+    out = []
+    for i in range(n):
+        dtype = rnd.choice(_DT)
+        K = rnd.choice([8, 16, 32, 64, 64, 128, 192])
+        V = rnd.choice([8, 16, 64, 64, 128, 256])
+        T = rnd.choice([1, 17, 63, 64, 65, 130, 200, 333, 512])
+        out.append((i, dtype, T, K, V))
+    return out
+
+
+@pytest.mark.parametrize("case", _causal_cases(), ids=lambda c: f"{c[0]}-{str(c[1]).split('.')[-1]}-T{c[2]}-K{c[3]}-V{c[4]}")
+def test_causal_fuzz(case):
+    i, dtype, T, K, V = case
+    run_causal(2, T, 2, K, V, max(2, (T + 63) // 64 + (i % 3)), dtype, seed=500 + i)
