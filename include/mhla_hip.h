@@ -117,6 +117,23 @@ int mhla_blockmix_rope_fwd(mhla_view q, mhla_view k, mhla_view v, int normalize,
                            int dtype, float eps, unsigned flags, void* stream);
 
 /*
+ * The Wan layer's operator with prologue and epilogue fused (inference): as mhla_blockmix_rope_fwd (rope tables
+ * optional: NULL = no rotation), and the per-head RMSNorm (x SiLU gate) that follows the operator in the host
+ * (wan/mhla_utils.py:356-362: out.to(dtype); g_norm(out) [* silu(g)]) applied to each token's D outputs before
+ * they are stored:  y = rmsnorm_D(round_out_dtype(O)) * norm_w [* gate * sigmoid(gate)].  q, k, v are fp32 (`dtype`
+ * must be MHLA_F32, the host's .float() at :308); `out` and `gate` ([B, N, H, D] views) are in `out_dtype`.
+ * norm_w: fp32 [D] or NULL; gate.ptr NULL = no gate.  The fp32 O tensor is never written.
+ */
+int mhla_blockmix_wan_fwd(mhla_view q, mhla_view k, mhla_view v, int normalize,
+                          const float* W, int ldw,
+                          const float* rope_cos, const float* rope_sin, int64_t ld_rope,
+                          const float* norm_w, float norm_eps, mhla_view gate,
+                          mhla_mview out, int out_dtype, const int32_t* block_index,
+                          void* ws, size_t ws_bytes,
+                          int B, int H, int M, int S, int D,
+                          int dtype, float eps, unsigned flags, void* stream);
+
+/*
  * Backward (autograd of the forward above; hand-derived).
  * Needs only the forward's inputs, its output `out` and the upstream gradient
  * `dout`: the block summaries are recomputed -- unless the caller kept the

@@ -346,6 +346,10 @@ struct OutArgs {
     const float* rcos;   // fused rotary prologue (split.cuh): q is rotated while it is loaded
     const float* rsin;
     long ldr;
+    // fused epilogue (split.cuh, k_sp_out<.., EPI>): y = rmsnorm_D(O) * nw [* silu(gate)] stored in the gate's dtype
+    const float* nw;
+    float neps;
+    View gate;
 };
 
 template <int DT>

@@ -336,7 +336,8 @@ size_t mhla_blockmix_bwd_ws_bytes(int B, int H, int M, int S, int D, int dtype, 
 static int bm_fwd_impl(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q_den, mhla_view k_den, const float* W,
                        int ldw, mhla_mview out, const int32_t* block_index, void* ws, size_t ws_bytes, int B, int H,
                        int M, int S, int D, int dtype, float eps, unsigned flags, void* stream, const float* rcos,
-                       const float* rsin, long ldr) {
+                       const float* rsin, long ldr, bool epi = false, const float* nw = nullptr, float neps = 0.f,
+                       mhla_view gate = mhla_view{nullptr, 0, 0, 0}, int out_dtype = 0) {
     const bool normalize = q_den.ptr != nullptr;
     const bool split = normalize && (q_den.ptr != q_num.ptr || k_den.ptr != k_num.ptr);
     RC(bm_check(B, H, M, S, D, dtype, flags, normalize, split));
@@ -348,8 +349,10 @@ static int bm_fwd_impl(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view 
     if (!normalize) { q_den = q_num; k_den = k_num; }
     const int relu = (flags & MHLA_FLAG_RELU_EPS) ? 1 : 0;
     const mhla_view outv{out.ptr, out.sb, out.sn, out.sh};
+    if (epi && (!sp_shape_ok(D, flags) || dtype != MHLA_F32))
+        return fail(MHLA_ENOTSUP, "fused norm/gate epilogue needs fp32 q, k, v, D %% 8 == 0 and the split-operand kernels (D=%d, dtype=%d)", D, dtype);
     if (rcos && !sp_shape_ok(D, flags)) return fail(MHLA_ENOTSUP, "fused rotary prologue needs D %% 8 == 0 and the split-operand kernels (D=%d, flags=%u)", D, flags);
-    if (!rcos && sn_shape_ok(M, S, D, dtype, split) && !(flags & (MHLA_FLAG_FORCE_GENERIC | MHLA_FLAG_NO_SMALLN)) && view_ok16(q_num) &&
+    if (!rcos && !epi && sn_shape_ok(M, S, D, dtype, split) && !(flags & (MHLA_FLAG_FORCE_GENERIC | MHLA_FLAG_NO_SMALLN)) && view_ok16(q_num) &&
         view_ok16(k_num) && view_ok16(v) && view_ok16(outv)) {
         fast::SnArgs sa{};
         sa.q = cv(q_num); sa.k = cv(k_num); sa.v = cv(v); sa.out = cmv(out); sa.idx = block_index; sa.W = W; sa.ldw = ldw;
@@ -358,7 +361,7 @@ static int bm_fwd_impl(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view 
         else         RC(launch(fast::k_sn_fwd<5>, dim3(B * H), dim3(fast::SN_T), fast::sn_fwd_smem<5>(), st, "k_sn_fwd<5>", sa));
         return MHLA_OK;
     }
-    if (!rcos && fast_shape_ok(M, D, dtype, split) && !(flags & MHLA_FLAG_FORCE_GENERIC) && view_ok16(q_num) && view_ok16(k_num) &&
+    if (!rcos && !epi && fast_shape_ok(M, D, dtype, split) && !(flags & MHLA_FLAG_FORCE_GENERIC) && view_ok16(q_num) && view_ok16(k_num) &&
         view_ok16(v) && view_ok16(outv)) {
         const FastWs f = fast_carve(ws, B, H, M, S);
         if (ws_bytes < f.total_fwd) return fail(MHLA_EINVAL, "workspace too small: %zu < %zu bytes", ws_bytes, f.total_fwd);
@@ -384,8 +387,16 @@ static int bm_fwd_impl(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view 
         o.q = cv(q_num); o.o = cmv(out); o.idx = block_index; o.W = W; o.ldw = ldw; o.g = w.g; o.ninv = w.ninv;
         o.H = H; o.M = M; o.S = S; o.D = D; o.eps = eps;
         o.relu = (flags & MHLA_FLAG_RELU_EPS) ? 1 : 0; o.normalize = normalize;
-        if (sp_shape_ok(D, flags))
-            RC(launch(sp::k_sp_out<ET, DT>, dim3(M, B * H), dim3(NTHREADS), sp::sp_out_smem<DT>(), st, "k_sp_out", o));
+        if (epi) {
+            if constexpr (std::is_same<ET, float>::value) {
+                o.nw = nw; o.neps = neps; o.gate = cv(gate);
+                const dim3 g(M, B * H), blk(sp::SP_OUT_T);
+                if (out_dtype == MHLA_BF16)     RC(launch(sp::k_sp_out<float, DT, bf16_t, true>, g, blk, sp::sp_out_smem<DT>(), st, "k_sp_out<norm>", o));
+                else if (out_dtype == MHLA_F16) RC(launch(sp::k_sp_out<float, DT, f16_t, true>, g, blk, sp::sp_out_smem<DT>(), st, "k_sp_out<norm>", o));
+                else                            RC(launch(sp::k_sp_out<float, DT, float, true>, g, blk, sp::sp_out_smem<DT>(), st, "k_sp_out<norm>", o));
+            }
+        } else if (sp_shape_ok(D, flags))
+            RC(launch(sp::k_sp_out<ET, DT>, dim3(M, B * H), dim3(sp::SP_OUT_T), sp::sp_out_smem<DT>(), st, "k_sp_out", o));
         else
             RC(launch(k_bm_out<ET, DT>, dim3(M, B * H), dim3(NTHREADS), out_smem_floats<DT>() * 4, st, "k_bm_out", o));
     }));
@@ -410,6 +421,25 @@ int mhla_blockmix_rope_fwd(mhla_view q, mhla_view k, mhla_view v, int normalize,
     const mhla_view none{nullptr, 0, 0, 0};
     return bm_fwd_impl(q, k, v, normalize ? q : none, normalize ? k : none, W, ldw, out, block_index, ws, ws_bytes, B, H, M, S, D,
                        dtype, eps, flags, stream, rope_cos, rope_sin, (long)ld_rope);
+}
+
+int mhla_blockmix_wan_fwd(mhla_view q, mhla_view k, mhla_view v, int normalize, const float* W, int ldw,
+                          const float* rope_cos, const float* rope_sin, int64_t ld_rope, const float* norm_w, float norm_eps,
+                          mhla_view gate, mhla_mview out, int out_dtype, const int32_t* block_index, void* ws,
+                          size_t ws_bytes, int B, int H, int M, int S, int D, int dtype, float eps, unsigned flags,
+                          void* stream) {
+    if ((rope_cos == nullptr) != (rope_sin == nullptr)) return fail(MHLA_EINVAL, "rope_cos and rope_sin must be given together");
+    if (rope_cos && (ld_rope < D / 2 || (ld_rope & 3) || ((uintptr_t)rope_cos | (uintptr_t)rope_sin) % 16))
+        return fail(MHLA_EINVAL, "rope tables: ld=%lld must be >= D/2, a multiple of 4, and the tables 16-byte aligned", (long long)ld_rope);
+    if (out_dtype < 0 || out_dtype > 2) return fail(MHLA_EINVAL, "unknown out_dtype %d", out_dtype);
+    if (flags & MHLA_FLAG_RELU_EPS) return fail(MHLA_ENOTSUP, "relu prologue is not combined with the Wan prologue / epilogue (use mhla_qk_prologue)");
+    if (gate.ptr) {
+        if (((uintptr_t)gate.ptr) % 8 || ((gate.sb | gate.sn | gate.sh) & 3)) return fail(MHLA_EINVAL, "gate: pointer must be 8-byte aligned, strides multiples of 4");
+    }
+    if (norm_w && ((uintptr_t)norm_w) % 16) return fail(MHLA_EINVAL, "norm_w must be 16-byte aligned");
+    const mhla_view none{nullptr, 0, 0, 0};
+    return bm_fwd_impl(q, k, v, normalize ? q : none, normalize ? k : none, W, ldw, out, block_index, ws, ws_bytes, B, H, M, S, D,
+                       dtype, eps, flags, stream, rope_cos, rope_sin, (long)ld_rope, true, norm_w, norm_eps, gate, out_dtype);
 }
 
 int mhla_blockmix_bwd(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q_den, mhla_view k_den, const float* W,

@@ -344,9 +344,26 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_mix(const MixArgs a) {
 template <int DT>
 __host__ __device__ constexpr int sp_out_smem() { return 2 * Geo<DT>::KST * 32 * Geo<DT>::LD * 2; }
 
-template <typename T, int DT>
-__global__ __launch_bounds__(NTHREADS, 2) void k_sp_out(const OutArgs a) {
-    constexpr int LD = Geo<DT>::LD, CGS = Geo<DT>::CGS, RPP = Geo<DT>::RPP, KST = Geo<DT>::KST, KP = KST * 32, TILE = KP * LD;
+// EPI: the per-head RMSNorm (x SiLU gate) that follows the operator in the Wan host (wan/mhla_utils.py:356-362) is applied
+// to the token's D outputs before they are stored, in the dtype TO of the host's activations: O is rounded to TO (the
+// `.to(dtype)` at :356), normalised over the head dim in fp32, scaled by the norm weight and the gate, stored once.
+// 4 elements of TO as loaded (packed for 16-bit types) and their conversion to fp32
+template <typename TO> struct Raw4 { typedef uint2 type; };
+template <> struct Raw4<float> { typedef f32x4 type; };
+__device__ __forceinline__ f32x4 raw4_to_f32(bf16_t, uint2 r) {
+    return f32x4{__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u)};
+}
+__device__ __forceinline__ f32x4 raw4_to_f32(f16_t, uint2 r) {
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    const h4 h = __builtin_bit_cast(h4, r);
+    return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+}
+__device__ __forceinline__ f32x4 raw4_to_f32(float, f32x4 r) { return r; }
+
+constexpr int SP_OUT_T = 512;   // 8 waves share the staged G_i: twice the loads in flight per LDS byte
+template <typename T, int DT, typename TO = T, bool EPI = false>
+__global__ __launch_bounds__(SP_OUT_T, 2) void k_sp_out(const OutArgs a) {
+    constexpr int LD = Geo<DT>::LD, CGS = Geo<DT>::CGS, RPP = SP_OUT_T / CGS, KST = Geo<DT>::KST, KP = KST * 32, TILE = KP * LD;
     constexpr bool LO = !std::is_same<T, bf16_t>::value;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u16* Gh = reinterpret_cast<u16*>(smem_raw);   // [d1][d2], rows >= D and columns >= D zero
@@ -355,11 +372,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_out(const OutArgs a) {
     const int blk = blockIdx.x, bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H, S = a.S, D = a.D;
     const long p0 = (long)blk * S;
     const T* qb = (const T*)a.q.ptr + b * a.q.sb + h * a.q.sh;
-    T* ob = (T*)a.o.ptr + b * a.o.sb + h * a.o.sh;
+    TO* ob = (TO*)a.o.ptr + b * a.o.sb + h * a.o.sh;
     {   // G_i -> LDS as hi / lo
         const float* g = a.g + ((long)bh * a.M + blk) * D * D;
         const int r0 = tid / CGS, cg = (tid % CGS) * 8;
-        constexpr int PASSES = KP / RPP, UB = PASSES < 4 ? PASSES : (PASSES % 4 == 0 ? 4 : (PASSES % 3 == 0 ? 3 : 2));
+        constexpr int PASSES = (KP + RPP - 1) / RPP, UB = PASSES < 4 ? PASSES : (PASSES % 4 == 0 ? 4 : (PASSES % 3 == 0 ? 3 : 2));
         static_assert(PASSES % UB == 0, "staging batches must tile the passes");
         for (int pb = 0; pb < PASSES; pb += UB) {
             f32x4 x[UB][2];
@@ -377,15 +394,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_out(const OutArgs a) {
             for (int u = 0; u < UB; ++u) {
                 uint4 hi, lo;
                 split8(x[u][0], x[u][1], hi, lo);
-                const int off = (r0 + RPP * (pb + u)) * LD + cg;
-                *reinterpret_cast<uint4*>(Gh + off) = hi;
-                *reinterpret_cast<uint4*>(Gl + off) = lo;
+                const int r = r0 + RPP * (pb + u), off = r * LD + cg;
+                if (r < KP) {
+                    *reinterpret_cast<uint4*>(Gh + off) = hi;
+                    *reinterpret_cast<uint4*>(Gl + off) = lo;
+                }
             }
         }
     }
     __syncthreads();
     const float* ninvb = a.ninv + ((long)bh * a.M + blk) * S;
-    for (int tt = wave; tt * 16 < S; tt += 4) {
+    for (int tt = wave; tt * 16 < S; tt += SP_OUT_T / 64) {
         const int s = tt * 16 + nl, sv = min(s, S - 1);
         const long row = tok_row(a.idx, p0 + sv);
         const T* qrow = qb + row * a.q.sn + kg * 8;
@@ -407,7 +426,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_out(const OutArgs a) {
             ql[ks] = as_bf16x8(lo);
         }
         const float ninv = a.normalize ? ninvb[sv] : 1.f;
-        T* orow = ob + row * a.o.sn + kg * 4;
+        TO* orow = ob + row * a.o.sn + kg * 4;
+        f32x4 res[EPI ? DT + 1 : 1];
+        // gate values of this lane's features, fetched (packed) before the products: latency off the epilogue
+        typename Raw4<TO>::type gv[EPI ? DT : 1];
+        if constexpr (EPI) {
+            if (a.gate.ptr) {
+                const TO* grow = (const TO*)a.gate.ptr + b * a.gate.sb + row * a.gate.sn + h * a.gate.sh + kg * 4;
+#pragma unroll
+                for (int ct = 0; ct < DT; ++ct)
+                    if (ct * 16 + kg * 4 < D) gv[ct] = *reinterpret_cast<const typename Raw4<TO>::type*>(grow + ct * 16);
+            }
+        }
 #pragma unroll
         for (int ct = 0; ct < DT; ct += 2) {
             f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
@@ -424,9 +454,42 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_out(const OutArgs a) {
                     c1 = mfma_bf16(a1h, ql[ks], c1);
                 }
             }
+            if constexpr (EPI) {
+                res[ct] = c0 * ninv;
+                res[ct + 1] = c1 * ninv;
+            } else if (s < S) {
+                if (ct * 16 + kg * 4 < D) Io<TO>::st4(orow + ct * 16, c0 * ninv);
+                if (ct * 16 + 16 + kg * 4 < D) Io<TO>::st4(orow + ct * 16 + 16, c1 * ninv);
+            }
+        }
+        if constexpr (EPI) {
+            float ss = 0.f;
+#pragma unroll
+            for (int ct = 0; ct < DT; ++ct) {
+                if (!std::is_same<TO, float>::value)   // out.to(dtype) before the norm
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        res[ct][i] = std::is_same<TO, bf16_t>::value ? bf16_to_f32(cvt_bf16(res[ct][i])) : (float)(_Float16)res[ct][i];
+                if (ct * 16 + kg * 4 < D) ss += res[ct][0] * res[ct][0] + res[ct][1] * res[ct][1] + res[ct][2] * res[ct][2] + res[ct][3] * res[ct][3];
+            }
+            ss += __shfl_xor(ss, 16, 64);   // the token's features live in the 4 lanes kg = 0..3
+            ss += __shfl_xor(ss, 32, 64);
+            const float rstd = 1.f / sqrtf(ss / (float)D + a.neps);
             if (s < S) {
-                if (ct * 16 + kg * 4 < D) Io<T>::st4(orow + ct * 16, c0 * ninv);
-                if (ct * 16 + 16 + kg * 4 < D) Io<T>::st4(orow + ct * 16 + 16, c1 * ninv);
+#pragma unroll
+                for (int ct = 0; ct < DT; ++ct) {
+                    const int d0 = ct * 16 + kg * 4;
+                    if (d0 < D) {
+                        f32x4 y = res[ct] * rstd;
+                        if (a.nw) y *= *reinterpret_cast<const f32x4*>(a.nw + d0);
+                        if (a.gate.ptr) {
+                            const f32x4 gf = raw4_to_f32(TO{}, gv[ct]);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) y[i] *= gf[i] / (1.f + __expf(-gf[i]));
+                        }
+                        Io<TO>::st4(orow + ct * 16, y);
+                    }
+                }
             }
         }
     }

@@ -11,7 +11,7 @@ from typing import Dict, Tuple
 import torch
 from torch import nn
 
-from ..ops import mhla_blockmix, mhla_blockmix_rope, qk_prologue, rmsnorm_gate
+from ..ops import mhla_blockmix, mhla_blockmix_wan, qk_prologue, rmsnorm_gate
 from ..weights import block_index_3d
 from .blockconv import BlockDistanceConv3D
 
@@ -153,8 +153,13 @@ class MHLA_Video_Uni(nn.Module):
             wk = self.norm_k.weight if isinstance(self.norm_k, WanRMSNorm) else None
             q = qk_prologue(q, wq, getattr(self.norm_q, "eps", 0.0), self.eps).reshape(B, N, H, D)
             k = qk_prologue(k, wk, getattr(self.norm_k, "eps", 0.0), self.eps).reshape(B, N, H, D)
-            out = mhla_blockmix_rope(q, k, v.float().reshape(B, N, H, D), W, cos, sin, eps=self.eps,
-                                     normalize=self.normalize_out, block_index=idx)
+            # ... and the per-head g_norm (x SiLU gate) applied before the operator stores its output (:356-362)
+            gate = self.g(x).reshape(B, N, H, D) if self.is_gated else None
+            out = mhla_blockmix_wan(q, k, v.float().reshape(B, N, H, D), W, cos, sin, self.g_norm.weight, self.g_norm.eps,
+                                    gate, dtype, eps=self.eps, normalize=self.normalize_out, block_index=idx).reshape(B, N, C)
+            if self.is_lepe:
+                out = out + lepe
+            return self.o(out)
         else:
             q, k, v = q.float(), k.float(), v.float()                     # mhla_utils.py:308
             q = torch.relu(self.norm_q(q)) + self.eps                     # :268-272

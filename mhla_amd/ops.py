@@ -274,6 +274,50 @@ def lepe2d(v: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], 
     return _Lepe2d.apply(v, weight, bias, add, int(pieces_len), int(block_len))
 
 
+def mhla_blockmix_wan(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, W: torch.Tensor, rope_cos: Optional[torch.Tensor],
+                      rope_sin: Optional[torch.Tensor], norm_weight: Optional[torch.Tensor], norm_eps: float,
+                      gate: Optional[torch.Tensor], out_dtype: torch.dtype, *, eps: float = 1e-6, normalize: bool = True,
+                      block_index: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The Wan layer's operator with prologue and epilogue fused (inference): rotary prologue as `mhla_blockmix_rope`
+    (tables optional) and the per-head RMSNorm (x SiLU gate) of wan/mhla_utils.py:356-362 applied before the store.
+    q, k, v: fp32 [B, N, H, D]; gate: [B, N, H, D] in `out_dtype` or None; returns [B, N, H, D] in `out_dtype`."""
+    lib = _lib.load()
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (q, k, v, W, norm_weight, gate)):
+        raise RuntimeError("mhla_blockmix_wan is forward-only")
+    _require_gpu(q, k, v, W, rope_cos, rope_sin, norm_weight, gate, block_index)
+    if q.dtype != torch.float32:
+        raise TypeError("mhla_blockmix_wan takes fp32 q, k, v (the host's .float())")
+    if block_index is not None and (block_index.dtype != torch.int32 or not block_index.is_contiguous()):
+        raise TypeError("block_index must be a contiguous int32 tensor")
+    B, N, H, D = q.shape
+    M = W.shape[0]
+    if N % M:
+        raise ValueError(f"N={N} tokens not divisible into M={M} blocks")
+    S = N // M
+    q, k, v = _prep(q.detach()), _prep(k.detach()), _prep(v.detach())
+    cos = sin = None
+    if rope_cos is not None:
+        if rope_cos.shape != (N, D // 2) or rope_cos.dtype != torch.float32 or rope_sin.shape != (N, D // 2) or rope_sin.dtype != torch.float32:
+            raise ValueError(f"rope tables must be fp32 [N={N}, D/2={D // 2}]")
+        cos, sin = rope_cos.contiguous(), rope_sin.contiguous()
+    if gate is not None:
+        if gate.shape != (B, N, H, D) or gate.dtype != out_dtype:
+            raise ValueError("gate: [B, N, H, D] in out_dtype")
+        gate = _prep(gate.detach())
+    nw = norm_weight.detach().to(torch.float32).contiguous() if norm_weight is not None else None
+    Wf = W.detach().reshape(M, M).to(torch.float32).contiguous()
+    out = torch.empty((B, N, H, D), dtype=out_dtype, device=q.device)
+    ws = _ws(lib.mhla_blockmix_fwd_ws_bytes(B, H, M, S, D, _lib.F32, 0, 0), q.device)
+    rc = lib.mhla_blockmix_wan_fwd(_view(q), _view(k), _view(v), int(bool(normalize)), Wf.data_ptr(), M,
+                                   cos.data_ptr() if cos is not None else None, sin.data_ptr() if sin is not None else None,
+                                   cos.stride(0) if cos is not None else 0, nw.data_ptr() if nw is not None else None,
+                                   float(norm_eps), _view(gate) if gate is not None else NULL_VIEW, _view(out),
+                                   _DTYPES[out_dtype], block_index.data_ptr() if block_index is not None else None,
+                                   ws.data_ptr(), ws.numel() * 4, B, H, M, S, D, _lib.F32, float(eps), 0, _stream())
+    _lib.check(rc, "mhla_blockmix_wan_fwd")
+    return out
+
+
 _FMAPS = {None: 0, "identity": 0, "relu": 1, "elu": 2}
 
 

@@ -76,13 +76,13 @@ def test_wan_module_fused_inference_path(tag):
     grid_sizes = torch.tensor([[F_, H_, W_]] * B, dtype=torch.long)
     import mhla_amd.modules.wan as wanmod
     calls = []
-    orig = wanmod.mhla_blockmix_rope
-    wanmod.mhla_blockmix_rope = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    orig = wanmod.mhla_blockmix_wan
+    wanmod.mhla_blockmix_wan = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
     try:
         with torch.no_grad():
             y = m(x, torch.tensor([N] * B), grid_sizes, modules.wan_freqs(D))
     finally:
-        wanmod.mhla_blockmix_rope = orig
+        wanmod.mhla_blockmix_wan = orig
     assert calls, "fused path not taken under no_grad"
     check("y", y, g["y"], 1e-4)
     y2 = m(x.clone().requires_grad_(True), torch.tensor([N] * B), grid_sizes, modules.wan_freqs(D))
@@ -159,6 +159,17 @@ def test_qk_prologue_and_rope_op():
         check(f"rope op normalize={normalize}", got[:, idx.long().to(DEV)], want, 1e-4)
     with pytest.raises(RuntimeError):
         mhla_amd.mhla_blockmix_rope(q.to(DEV).requires_grad_(True), k.to(DEV), v.to(DEV), W.to(DEV), cos, sin)
+    # prologue + epilogue fused: rotary inside, per-head RMSNorm x SiLU gate before the store, output in the host dtype
+    nw = torch.rand(D, generator=g) + 0.5
+    for odt in (torch.bfloat16, torch.float32):
+        for gated in (True, False):
+            gate = torch.randn(B, N, H, D, generator=g).to(odt) if gated else None
+            o = mhla_amd.mhla_blockmix_rope(q.to(DEV), k.to(DEV), v.to(DEV), W.to(DEV), cos, sin, eps=1e-6, block_index=idx.to(DEV))
+            want = mhla_amd.rmsnorm_gate(o.to(odt), gate.to(DEV) if gated else None, nw.to(DEV), 1e-5)
+            got = mhla_amd.mhla_blockmix_wan(q.to(DEV), k.to(DEV), v.to(DEV), W.to(DEV), cos, sin, nw.to(DEV), 1e-5,
+                                             gate.to(DEV) if gated else None, odt, eps=1e-6, block_index=idx.to(DEV))
+            assert got.dtype == odt
+            check(f"wan fused {odt} gate={gated}", got, want.float().cpu(), 1e-5 if odt == torch.float32 else 8e-3)
 
 
 def test_fla_layer_matches_oracle_restatement():
