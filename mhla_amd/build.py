@@ -11,8 +11,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "capi.hip")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libmhla_hip.so")
-DEPS = [os.path.join(HERE, "csrc", f) for f in ("capi.hip", "common.cuh", "blockmix.cuh", "causal.cuh", "epilogue.cuh",
-                                               "fused.cuh", "fused_tile16.cuh", "smalln.cuh")] + [os.path.join(os.path.dirname(HERE), "include", "mhla_hip.h")]
+import glob  # noqa: E402
+
+# every source / header of the single translation unit: a change to any of them makes the library stale
+DEPS = sorted(glob.glob(os.path.join(HERE, "csrc", "*"))) + [os.path.join(os.path.dirname(HERE), "include", "mhla_hip.h")]
 
 
 def hipcc_path() -> str:

@@ -2,6 +2,7 @@
 // workspace, picks template instantiations and enqueues kernels on the caller's stream.
 #include "../../include/mhla_hip.h"
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -41,15 +42,25 @@ inline size_t al4(size_t n) { return (n + 3) & ~(size_t)3; }
 // kernel, so bench.py can report each kernel's average duration live (not only rocprof offline).
 struct ProfRec { const char* name; hipEvent_t e0, e1; };
 std::mutex g_prof_mu;
-bool g_prof_on = false;
+std::atomic<bool> g_prof_on{false};
 std::vector<ProfRec> g_prof;
 
 template <typename K>
 int launch(K kernel, dim3 grid, dim3 block, size_t smem, hipStream_t stream, const char* name, auto... args) {
     if (smem > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return fail(MHLA_ELAUNCH, "%s: hipFuncSetAttribute(%zu B LDS): %s", name, smem, hipGetErrorString(e));
+        // opt in to > 48 KB of dynamic LDS once per (kernel, device); the driver call is kept off the steady-state launch path
+        static std::mutex mu;
+        static std::map<std::pair<const void*, int>, size_t> done;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const std::pair<const void*, int> key(reinterpret_cast<const void*>(kernel), dev);
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = done.find(key);
+        if (it == done.end() || it->second < smem) {
+            hipError_t e = hipFuncSetAttribute(key.first, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            if (e != hipSuccess) return fail(MHLA_ELAUNCH, "%s: hipFuncSetAttribute(%zu B LDS): %s", name, smem, hipGetErrorString(e));
+            done[key] = smem;
+        }
     }
     ProfRec rec{name, nullptr, nullptr};
     const bool prof = g_prof_on;

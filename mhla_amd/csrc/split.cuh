@@ -108,6 +108,7 @@ __global__ __launch_bounds__(NTHREADS) void k_sp_state(const StateArgs a) {
         for (int it = 0; it < IT; ++it) {
             const int r = c0 + r0 + RPP * it;
             kx[it][0] = kx[it][1] = vx[it][0] = vx[it][1] = dx[it][0] = dx[it][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            rc[it] = rs[it] = f32x4{0.f, 0.f, 0.f, 0.f};   // padded rows: 0 * (uninitialised angle) could be NaN
             nv[it] = 1.f;
             if (r < S && cg < D) {
                 const long row = tok_row(a.idx, p0 + r);

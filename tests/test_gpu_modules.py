@@ -204,3 +204,40 @@ def test_fla_layer_matches_oracle_restatement():
     mask[1, 150:] = 0
     o3, _, _ = m(xd, attention_mask=mask.to(DEV))
     assert o3.shape == o.shape and torch.all(o3[1, 150:] == 0)
+
+
+def test_thin_dit_host_matches_cpu_composition():
+    """The in-repo DiT host on the GPU vs the same host on the CPU with every attention module replaced by
+    the oracle's restatement of MHLA4DiT.forward: checks the block-major adapter, the adaLN plumbing and the module in context."""
+    from mhla_amd.hosts import DiT_MHLA
+    torch.manual_seed(0)
+    m = DiT_MHLA(input_size=16, patch_size=2, in_channels=4, hidden_size=128, depth=2, num_heads=2, num_classes=10,
+                 class_dropout_prob=0.0, block_kwargs={"block_size": 16})
+    with torch.no_grad():
+        for prm in m.parameters():
+            if prm.requires_grad and float(prm.abs().max()) == 0.0:
+                prm.normal_(std=0.05)
+    m.eval()
+    x, t, y = torch.randn(3, 4, 16, 16), torch.tensor([1, 500, 999]), torch.tensor([0, 3, 9])
+    # round trip of the token adapter
+    tok = torch.arange(64)
+    assert torch.equal(tok[m.to_block_major][m.to_raster], tok)
+    assert sorted(m.state_dict())[:3] == ["blocks.0.adaLN_modulation.1.bias", "blocks.0.adaLN_modulation.1.weight", "blocks.0.attn.lepe.bias"]
+
+    import copy
+    ref = copy.deepcopy(m)
+    for blk in ref.blocks:
+        sd = {k: v.detach() for k, v in blk.attn.state_dict().items()}
+        heads, bs, el = blk.attn.num_heads, blk.attn.block_size, blk.attn.embed_len
+        blk.attn.forward = (lambda sd, heads, bs, el: lambda z: orc.dit_module_forward(
+            sd, z.reshape(z.shape[0], el // bs, bs, z.shape[-1]), heads, bs, el).reshape(z.shape))(sd, heads, bs, el)
+    with torch.no_grad():
+        want = ref(x, t, y)
+        got = m.to(DEV)(x.to(DEV), t.to(DEV), y.to(DEV))
+    assert got.shape == (3, 8, 16, 16)
+    check("dit host", got, want, 2e-4)
+    # one training step runs (autograd through the HIP ops, clamp as in mhla_dit/train.py:308-310)
+    m.train()
+    out = m(x.to(DEV), t.to(DEV), y.to(DEV))
+    out.square().mean().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters() if p.requires_grad)

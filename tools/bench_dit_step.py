@@ -1,0 +1,69 @@
+#!/usr/bin/env python
+"""Step-level number for BASELINE.json configs[2]: a DiT training step (forward, MSE loss on the noise half, backward, AdamW)
+with the thin in-repo host (mhla_amd.hosts.DiT_MHLA) around the MHLA4DiT drop-in, synthetic latents, bf16 autocast.
+
+  python tools/bench_dit_step.py [--model DiT-XL/2] [--batch 32] [--steps 10] [--warmup 3]
+  python -m torch.distributed.run --nproc-per-node N ... tools/bench_dit_step.py     (DDP over RCCL, one process per GPU)
+
+Informational (bench.py is the contract benchmark); prints one JSON line on rank 0."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from mhla_amd import dist as mdist  # noqa: E402
+from mhla_amd.hosts import DiT_MHLA, DiT_configs  # noqa: E402
+
+
+def main():
+    p = argparse.ArgumentParser()
+    p.add_argument("--model", default="DiT-XL/2", choices=sorted(DiT_configs()))
+    p.add_argument("--batch", type=int, default=32, help="per-GPU batch")
+    p.add_argument("--image", type=int, default=256, help="image side in pixels (latent side = image / 8)")
+    p.add_argument("--steps", type=int, default=10)
+    p.add_argument("--warmup", type=int, default=3)
+    a = p.parse_args()
+    rank, local, world = mdist.init_from_env()
+    local %= torch.cuda.device_count()
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    torch.manual_seed(1234 + rank)
+    latent = a.image // 8
+    model = DiT_MHLA(input_size=latent, **DiT_configs()[a.model]).to(dev)
+    # zero-initialised adaLN / head would make every block an identity: give the benchmark non-trivial activations
+    with torch.no_grad():
+        for prm in model.parameters():
+            if prm.requires_grad and float(prm.abs().max()) == 0.0:
+                prm.normal_(std=0.02)
+    net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local]) if world > 1 else model
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-4, weight_decay=0.0)
+    x = torch.randn(a.batch, 4, latent, latent, device=dev)
+    noise = torch.randn_like(x)
+    t = torch.randint(0, 1000, (a.batch,), device=dev)
+    y = torch.randint(0, 1000, (a.batch,), device=dev)
+
+    def step():
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = net(x, t, y)
+        loss = torch.nn.functional.mse_loss(out[:, :4].float(), noise)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        for blk in model.blocks:   # the post-step clamp of the mixing weights, mhla_dit/train.py:308-310
+            blk.attn.piece_attn.conv.weight.data.clamp_(min=0)
+
+    el = mdist.timed_steps(step, a.steps, a.warmup, torch.cuda.synchronize)
+    tokens = a.batch * (latent // 2) ** 2 * world
+    if rank == 0:
+        print(json.dumps({"what": f"{a.model} {a.image}x{a.image} training step, thin host, bf16 autocast, AdamW",
+                          "n_gpus": world, "per_gpu_batch": a.batch, "ms_per_step": el / a.steps * 1e3,
+                          "images_per_s": a.batch * world / (el / a.steps), "tokens_per_s": tokens / (el / a.steps),
+                          "params_M": sum(p.numel() for p in model.parameters()) / 1e6}))
+
+
+if __name__ == "__main__":
+    main()
