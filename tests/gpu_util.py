@@ -51,3 +51,11 @@ def check(name, got, want, tol, atol=0.0):
     e, r = rel_err(g, w), rms_ratio(g, w)
     assert e < tol, f"{name}: rel_err {e:.3e} (rms ratio {r:.3e}) exceeds {tol:.1e}"
     return e
+
+
+def poison():
+    """Fill ~350 MB of device memory with NaN and free it again: the next torch.empty() calls of the ops (workspaces,
+    outputs, gradients) start as NaN, and the registers of idle CUs hold NaN -- reads of memory or registers that were never
+    written show up as NaN in the parity checks."""
+    slabs = [torch.full((n,), float("nan"), dtype=torch.float32, device=DEV) for n in (1 << 26, 1 << 24, 1 << 22, 1 << 20)]
+    del slabs

@@ -3,7 +3,7 @@ import pytest
 import torch
 
 from conftest import load_golden
-from gpu_util import DEV, GTOL, TOL, check, make_blockmix_inputs, oracle_blockmix, to_dev
+from gpu_util import poison, DEV, GTOL, TOL, check, make_blockmix_inputs, oracle_blockmix, to_dev
 from oracle import mhla_oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -26,8 +26,10 @@ def run_case(B, H, M, S, D, dtype, normalize=True, split=False, w="linear", idx=
     if split:
         dqd.requires_grad_(True)
         dkd.requires_grad_(True)
+    poison()
     out = mhla_amd.mhla_blockmix(dq_, dk_, dv_, dW_, eps=1e-6, q_den=dqd, k_den=dkd, normalize=normalize,
                                  block_index=None if idx is None else idx.to(DEV), **opkw)
+    poison()
     out.backward(ddo)
     torch.cuda.synchronize()
 

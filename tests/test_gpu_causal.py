@@ -3,7 +3,7 @@ import pytest
 import torch
 
 from conftest import load_golden
-from gpu_util import DEV, GTOL, TOL, check
+from gpu_util import poison, DEV, GTOL, TOL, check
 from oracle import mhla_oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -25,9 +25,12 @@ def run_causal(B, T, H, K, V, L, dtype, seed=1234):
     want = orc.causal_fwd(q.float(), k.float(), v.float(), mix)
     wg = orc.causal_bwd(q.float(), k.float(), v.float(), mix, do.float())
     dq, dk, dv, dm = (t.to(DEV).requires_grad_(True) for t in (q, k, v, mix.view(L, L, 1, 1, 1, 1)))
+    poison()
     out = mhla_amd.naive_chunk_simple_mhla_fixed(q=dq, k=dk, v=dv, mixing_matrix=dm)
     assert out.dtype == dtype and out.shape == (B, T, H, V)
-    out.backward(do.to(DEV))
+    dod = do.to(DEV)
+    poison()
+    out.backward(dod)
     check("out", out, want, TOL[dtype])
     check("dq", dq.grad, wg["dq"], GTOL[dtype])
     check("dk", dk.grad, wg["dk"], GTOL[dtype])
