@@ -194,6 +194,23 @@ int mhla_causal_bwd(mhla_view q, mhla_view k, mhla_view v, const float* mix, int
 int mhla_qk_prologue(const void* x, int64_t ldx, const float* w, float* y, int64_t ldy,
                      int64_t rows, int C, int norm, float norm_eps, float eps,
                      int dtype, void* stream);
+/* The same with a second output y_rope = rope(y) (wan/mhla_utils.py:314, rope_apply :127-156): consecutive channel pairs
+ * of every head (head dim D, C = H*D) rotated by (rope_cos, rope_sin)[row % ntok][pair], tables fp32 [ntok][D/2].  The
+ * training path of the Wan host: y feeds the normaliser, y_rope KV and the numerator.  y_rope NULL = mhla_qk_prologue. */
+int mhla_qk_prologue_rope(const void* x, int64_t ldx, const float* w, float* y, int64_t ldy,
+                          float* y_rope, int64_t ldyr,
+                          const float* rope_cos, const float* rope_sin, int64_t ld_tab, int ntok, int D,
+                          int64_t rows, int C, int norm, float norm_eps, float eps,
+                          int dtype, void* stream);
+/* Backward of the two above: dx (dtype of x) from dy and / or dy_rope (fp32, either may be NULL), and per-workgroup
+ * partial weight gradients dw_partial fp32 [mhla_qk_prologue_dw_rows(rows)][C] (sum the rows; NULL when w is NULL).
+ * C <= 2048. */
+int64_t mhla_qk_prologue_dw_rows(int64_t rows);
+int mhla_qk_prologue_bwd(const void* x, int64_t ldx, const float* w,
+                         const float* dy, int64_t lddy, const float* dy_rope, int64_t lddyr,
+                         const float* rope_cos, const float* rope_sin, int64_t ld_tab, int ntok, int D,
+                         void* dx, int64_t lddx, float* dw_partial,
+                         int64_t rows, int C, int norm, float norm_eps, int dtype, void* stream);
 
 /*
  * q / k prologue of the fla layer in one pass: feature map (0 identity, 1 relu, 2 elu+1;

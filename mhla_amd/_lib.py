@@ -54,6 +54,12 @@ SIGNATURES = {
     "mhla_lepe2d_wgrad_ws_bytes": (c_size_t, [c_int, c_int]),
     "mhla_lepe2d_wgrad": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_size_t,
                                   c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "mhla_qk_prologue_rope": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
+                                      c_int64, c_int, c_int, c_int64, c_int, c_int, c_float, c_float, c_int, c_void_p]),
+    "mhla_qk_prologue_dw_rows": (c_int64, [c_int64]),
+    "mhla_qk_prologue_bwd": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
+                                     c_int64, c_int, c_int, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_float,
+                                     c_int, c_void_p]),
     "mhla_qk_prologue": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_float, c_float,
                                  c_int, c_void_p]),
     "mhla_rmsnorm_gate_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p,

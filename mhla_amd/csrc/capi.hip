@@ -274,7 +274,7 @@ int norm_check(const void* x, const void* y, int64_t rows, int D, int dtype) {
 }
 int norm_grid(int64_t rows) {   // backward: one dw partial row per workgroup, so the grid is capped
     int64_t g = (rows + 3) / 4;
-    return (int)(g < 2048 ? g : 2048);
+    return (int)(g < 8192 ? g : 8192);
 }
 int norm_fwd_grid(int64_t rows, int rows_per_wave) {   // forward: a wave per row group, no grid-stride serialisation
     int64_t g = (rows + 4 * rows_per_wave - 1) / (4 * rows_per_wave);
@@ -783,13 +783,35 @@ int mhla_lepe2d_wgrad(const void* x, int64_t x_sb, int64_t x_sn, const void* dou
     return MHLA_OK;
 }
 
+static int prologue_check(const void* x, int64_t rows, int C, int dtype, int64_t ldx) {
+    if (!x) return fail(MHLA_EINVAL, "null pointer");
+    if (rows <= 0 || C <= 0 || (C & 7) || C > 8 * 64 * 8) return fail(MHLA_EINVAL, "rows=%lld C=%d: need C %% 8 == 0 and C <= 4096", (long long)rows, C);
+    if (ldx & 3) return fail(MHLA_EINVAL, "row strides must be multiples of 4");
+    if (dtype < 0 || dtype > 2) return fail(MHLA_EINVAL, "unknown dtype %d", dtype);
+    return MHLA_OK;
+}
+static int prologue_rope_check(const float* cos, const float* sin, int64_t ld_tab, int ntok, int D, int C) {
+    if (!cos || !sin) return fail(MHLA_EINVAL, "rope tables null");
+    if (D <= 0 || (D & 7) || C % D) return fail(MHLA_EINVAL, "head dim D=%d must be a multiple of 8 dividing C=%d", D, C);
+    if (ntok <= 0 || ld_tab < D / 2 || (ld_tab & 3) || ((uintptr_t)cos | (uintptr_t)sin) % 16)
+        return fail(MHLA_EINVAL, "rope tables: ntok=%d, ld=%lld must be >= D/2 and a multiple of 4, tables 16-byte aligned", ntok, (long long)ld_tab);
+    return MHLA_OK;
+}
+
 int mhla_qk_prologue(const void* x, int64_t ldx, const float* w, float* y, int64_t ldy, int64_t rows, int C, int norm,
                      float norm_eps, float eps, int dtype, void* stream) {
-    if (!x || !y) return fail(MHLA_EINVAL, "null pointer");
-    if (rows <= 0 || C <= 0 || (C & 7) || C > 8 * 64 * 8) return fail(MHLA_EINVAL, "rows=%lld C=%d: need C %% 8 == 0 and C <= 4096", (long long)rows, C);
-    if ((ldx | ldy) & 3) return fail(MHLA_EINVAL, "row strides must be multiples of 4");
-    if (dtype < 0 || dtype > 2) return fail(MHLA_EINVAL, "unknown dtype %d", dtype);
-    PrologueArgs a{x, (long)ldx, w, y, (long)ldy, (long)rows, C, norm_eps, eps, norm ? 1 : 0};
+    return mhla_qk_prologue_rope(x, ldx, w, y, ldy, nullptr, 0, nullptr, nullptr, 0, 0, 0, rows, C, norm, norm_eps, eps, dtype, stream);
+}
+
+int mhla_qk_prologue_rope(const void* x, int64_t ldx, const float* w, float* y, int64_t ldy, float* y_rope, int64_t ldyr,
+                          const float* rope_cos, const float* rope_sin, int64_t ld_tab, int ntok, int D, int64_t rows, int C,
+                          int norm, float norm_eps, float eps, int dtype, void* stream) {
+    RC(prologue_check(x, rows, C, dtype, ldx | ldy | (y_rope ? ldyr : 0)));
+    if (!y) return fail(MHLA_EINVAL, "null pointer");
+    if (y_rope) RC(prologue_rope_check(rope_cos, rope_sin, ld_tab, ntok, D, C));
+    PrologueArgs a{};
+    a.x = x; a.ldx = ldx; a.w = w; a.y = y; a.ldy = ldy; a.rows = rows; a.C = C; a.norm_eps = norm_eps; a.eps = eps; a.norm = norm ? 1 : 0;
+    a.yr = y_rope; a.ldyr = ldyr; a.rcos = rope_cos; a.rsin = rope_sin; a.ldr = ld_tab; a.ntok = ntok > 0 ? ntok : 1; a.D = D > 0 ? D : 8;
     hipStream_t st = (hipStream_t)stream;
     const int64_t gsz = (rows + 3) / 4;
     const dim3 grid((unsigned)(gsz < 16384 ? gsz : 16384));
@@ -797,6 +819,34 @@ int mhla_qk_prologue(const void* x, int64_t ldx, const float* w, float* y, int64
         if (C <= 1024)      RC(launch(k_qk_prologue<ET, 2>, grid, dim3(256), 0, st, "k_qk_prologue", a));
         else if (C <= 2048) RC(launch(k_qk_prologue<ET, 4>, grid, dim3(256), 0, st, "k_qk_prologue", a));
         else                RC(launch(k_qk_prologue<ET, 8>, grid, dim3(256), 0, st, "k_qk_prologue", a));
+    });
+    return MHLA_OK;
+}
+
+static int prologue_bwd_grid(int64_t rows) {   // wide rows (C floats of dw partial each): fewer workgroups than the per-head norm
+    const int64_t g = (rows + 3) / 4;
+    return (int)(g < 2048 ? g : 2048);
+}
+int64_t mhla_qk_prologue_dw_rows(int64_t rows) { return prologue_bwd_grid(rows); }
+
+int mhla_qk_prologue_bwd(const void* x, int64_t ldx, const float* w, const float* dy, int64_t lddy, const float* dy_rope,
+                         int64_t lddyr, const float* rope_cos, const float* rope_sin, int64_t ld_tab, int ntok, int D,
+                         void* dx, int64_t lddx, float* dw_partial, int64_t rows, int C, int norm, float norm_eps, int dtype,
+                         void* stream) {
+    RC(prologue_check(x, rows, C, dtype, ldx | lddx | (dy ? lddy : 0) | (dy_rope ? lddyr : 0)));
+    if (!dx || (!dy && !dy_rope)) return fail(MHLA_EINVAL, "dx null or no upstream gradient");
+    if (C > 2048) return fail(MHLA_ENOTSUP, "backward supports C <= 2048 (C=%d)", C);
+    if (dy_rope) RC(prologue_rope_check(rope_cos, rope_sin, ld_tab, ntok, D, C));
+    if (w && !dw_partial) return fail(MHLA_EINVAL, "dw_partial null");
+    PrologueArgs a{};
+    a.x = x; a.ldx = ldx; a.w = w; a.rows = rows; a.C = C; a.norm_eps = norm_eps; a.norm = norm ? 1 : 0;
+    a.rcos = rope_cos; a.rsin = rope_sin; a.ldr = ld_tab; a.ntok = ntok > 0 ? ntok : 1; a.D = D > 0 ? D : 8;
+    a.dy = dy; a.lddy = lddy; a.dyr = dy_rope; a.lddyr = lddyr; a.dx = dx; a.lddx = lddx; a.dwp = w ? dw_partial : nullptr;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(prologue_bwd_grid(rows));
+    DISPATCH_T(dtype, {
+        if (C <= 1024) RC(launch(k_qk_prologue_bwd<ET, 2>, grid, dim3(256), 0, st, "k_qk_prologue_bwd", a));
+        else           RC(launch(k_qk_prologue_bwd<ET, 4>, grid, dim3(256), 0, st, "k_qk_prologue_bwd", a));
     });
     return MHLA_OK;
 }
@@ -832,7 +882,13 @@ int mhla_rmsnorm_gate_bwd(const void* x, int64_t ldx, const void* g, int64_t ldg
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(norm_grid(rows));
     DISPATCH_T(dtype, {
-        if (D <= 256) {
+        if (D <= 64) {
+            if (g) RC(launch(k_rmsnorm_gate_bwd_sub<ET, 16, true>, grid, dim3(256), 0, st, "k_rmsnorm_gate_bwd", a));
+            else   RC(launch(k_rmsnorm_gate_bwd_sub<ET, 16, false>, grid, dim3(256), 0, st, "k_rmsnorm_gate_bwd", a));
+        } else if (D <= 128) {
+            if (g) RC(launch(k_rmsnorm_gate_bwd_sub<ET, 32, true>, grid, dim3(256), 0, st, "k_rmsnorm_gate_bwd", a));
+            else   RC(launch(k_rmsnorm_gate_bwd_sub<ET, 32, false>, grid, dim3(256), 0, st, "k_rmsnorm_gate_bwd", a));
+        } else if (D <= 256) {
             if (g) RC(launch(k_rmsnorm_gate_bwd<ET, 1, true>, grid, dim3(256), 0, st, "k_rmsnorm_gate_bwd", a));
             else   RC(launch(k_rmsnorm_gate_bwd<ET, 1, false>, grid, dim3(256), 0, st, "k_rmsnorm_gate_bwd", a));
         } else {

@@ -169,6 +169,68 @@ __global__ __launch_bounds__(256) void k_rmsnorm_gate_bwd(const NormArgs a) {
         a.dwp[(long)blockIdx.x * a.D + c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
 }
 
+// Narrow rows in the backward (D <= 4 * LPR): 64 / LPR rows per wave, every lane busy; per-workgroup dw partial row.
+template <typename T, int LPR, bool GATE>
+__global__ __launch_bounds__(256) void k_rmsnorm_gate_bwd_sub(const NormArgs a) {
+    constexpr int RPW = 64 / LPR;
+    __shared__ float red[4 * RPW][LPR * 4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane / LPR, c = (lane % LPR) * 4;
+    const long nw = (long)gridDim.x * 4 * RPW;
+    const bool col = c < a.D;
+    f32x4 w = {1.f, 1.f, 1.f, 1.f};
+    if (a.w && col) w = *reinterpret_cast<const f32x4*>(a.w + c);
+    f32x4 dwacc = {0.f, 0.f, 0.f, 0.f};
+    for (long row0 = ((long)blockIdx.x * 4 + wave) * RPW; row0 < a.rows; row0 += nw) {
+        const long row = row0 + sub;
+        const bool live = row < a.rows && col;
+        f32x4 xv = {0.f, 0.f, 0.f, 0.f}, dyv = xv, gv = xv;
+        if (live) {
+            xv = Io<T>::ld4((const T*)a.x + row * a.ldx + c);
+            dyv = Io<T>::ld4((const T*)a.dy + row * a.lddy + c);
+            if (GATE) gv = Io<T>::ld4((const T*)a.g + row * a.ldg + c);
+        }
+        float ss = xv[0] * xv[0] + xv[1] * xv[1] + xv[2] * xv[2] + xv[3] * xv[3];
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        const float rstd = 1.f / sqrtf(ss / (float)a.D + a.eps);
+        f32x4 uv, xh;
+        float dot = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float s = GATE ? gv[t] / (1.f + __expf(-gv[t])) : 1.f;
+            xh[t] = xv[t] * rstd;
+            uv[t] = dyv[t] * w[t] * s;
+            dot += uv[t] * xh[t];
+            dwacc[t] += dyv[t] * xh[t] * s;
+        }
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
+        dot /= (float)a.D;
+        if (live) {
+            f32x4 dx, dg;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                dx[t] = rstd * (uv[t] - xh[t] * dot);
+                if (GATE) {
+                    const float sg = 1.f / (1.f + __expf(-gv[t]));
+                    dg[t] = dyv[t] * xh[t] * w[t] * sg * (1.f + gv[t] * (1.f - sg));
+                }
+            }
+            Io<T>::st4((T*)a.dx + row * a.lddx + c, dx);
+            if (GATE) Io<T>::st4((T*)a.dg + row * a.lddg + c, dg);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) red[wave * RPW + sub][c + t] = dwacc[t];
+    __syncthreads();
+    for (int cc = threadIdx.x; cc < a.D; cc += 256) {
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4 * RPW; ++r) s += red[r][cc];
+        a.dwp[(long)blockIdx.x * a.D + cc] = s;
+    }
+}
+
 // -------------------------------------------------------------------------------------------------
 // q / k prologue of Wan's MHLA_Video_Uni (mhla_videogen/diffusion/model/wan/mhla_utils.py:268-272 after the
 // .float() at :308):  y = relu(rmsnorm_C(x) * w) + eps over the whole channel dim C = H * D of a token, x in the
@@ -185,7 +247,37 @@ struct PrologueArgs {
     int C;
     float norm_eps, eps;
     int norm;
+    // optional second output: y rotated by the token's rope angles (rope_apply, wan/mhla_utils.py:127-156 / :314):
+    // consecutive channel pairs of every head; cos / sin [ntok][D/2] fp32, token = row % ntok
+    float* yr;
+    long ldyr;
+    const float* rcos;
+    const float* rsin;
+    long ldr;
+    int ntok, D;
+    // backward
+    const float* dy;     // gradient w.r.t. y   (may be nullptr)
+    long lddy;
+    const float* dyr;    // gradient w.r.t. yr  (may be nullptr)
+    long lddyr;
+    void* dx;            // gradient w.r.t. x, dtype of x
+    long lddx;
+    float* dwp;          // [gridDim.x][C] partial weight gradients
 };
+
+// 4 channel pairs starting at channel c of row `row`: rotate (fwd) or apply the transposed rotation (inv)
+__device__ __forceinline__ void prologue_rope8(f32x4& a, f32x4& b, const PrologueArgs& p, long row, int c, bool inv) {
+    const long tok = row % p.ntok;
+    const int col = (c % p.D) >> 1;
+    const f32x4 cs = *reinterpret_cast<const f32x4*>(p.rcos + tok * p.ldr + col);
+    f32x4 sn = *reinterpret_cast<const f32x4*>(p.rsin + tok * p.ldr + col);
+    if (inv) sn = -sn;
+    const f32x4 a0 = a, b0 = b;
+    a[0] = a0[0] * cs[0] - a0[1] * sn[0]; a[1] = a0[0] * sn[0] + a0[1] * cs[0];
+    a[2] = a0[2] * cs[1] - a0[3] * sn[1]; a[3] = a0[2] * sn[1] + a0[3] * cs[1];
+    b[0] = b0[0] * cs[2] - b0[1] * sn[2]; b[1] = b0[0] * sn[2] + b0[1] * cs[2];
+    b[2] = b0[2] * cs[3] - b0[3] * sn[3]; b[3] = b0[2] * sn[3] + b0[3] * cs[3];
+}
 
 template <typename T, int NV>
 __global__ __launch_bounds__(256) void k_qk_prologue(const PrologueArgs a) {
@@ -216,16 +308,110 @@ __global__ __launch_bounds__(256) void k_qk_prologue(const PrologueArgs a) {
         for (int i = 0; i < NV; ++i) {
             const int c = (lane + 64 * i) * 8;
             if (c < a.C) {
+                f32x4 y[2];
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    f32x4 y = xv[i][u] * rstd;
-                    if (a.w) y *= *reinterpret_cast<const f32x4*>(a.w + c + 4 * u);
+                    y[u] = xv[i][u] * rstd;
+                    if (a.w) y[u] *= *reinterpret_cast<const f32x4*>(a.w + c + 4 * u);
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) y[t] = fmaxf(y[t], 0.f) + a.eps;
-                    *reinterpret_cast<f32x4*>(yr + c + 4 * u) = y;
+                    for (int t = 0; t < 4; ++t) y[u][t] = fmaxf(y[u][t], 0.f) + a.eps;
+                    *reinterpret_cast<f32x4*>(yr + c + 4 * u) = y[u];
+                }
+                if (a.yr) {
+                    prologue_rope8(y[0], y[1], a, row, c, false);
+                    *reinterpret_cast<f32x4*>(a.yr + row * a.ldyr + c) = y[0];
+                    *reinterpret_cast<f32x4*>(a.yr + row * a.ldyr + c + 4) = y[1];
                 }
             }
         }
+    }
+}
+
+// Backward of the prologue: g = (dy + R^T dyr) . [u > 0] with u = x rstd w the pre-activation;
+//   norm:  dx = rstd (g w - xhat mean_C(g w xhat)),  dw[c] += g xhat      (xhat = x rstd)
+//   else:  dx = g
+// One wave per row; per-workgroup partial dw rows (fixed order: deterministic), summed by the caller.
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void k_qk_prologue_bwd(const PrologueArgs a) {
+    __shared__ float red[4][NV * 512];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long nw = (long)gridDim.x * 4;
+    f32x4 dwacc[NV][2];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) dwacc[i][0] = dwacc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (long row = (long)blockIdx.x * 4 + wave; row < a.rows; row += nw) {
+        const T* xr = (const T*)a.x + row * a.ldx;
+        f32x4 xv[NV][2], gv[NV][2];
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (lane + 64 * i) * 8;
+            xv[i][0] = xv[i][1] = gv[i][0] = gv[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (c < a.C) {
+                xv[i][0] = Io<T>::ld4(xr + c);
+                xv[i][1] = Io<T>::ld4(xr + c + 4);
+                if (a.dyr) {
+                    gv[i][0] = *reinterpret_cast<const f32x4*>(a.dyr + row * a.lddyr + c);
+                    gv[i][1] = *reinterpret_cast<const f32x4*>(a.dyr + row * a.lddyr + c + 4);
+                    prologue_rope8(gv[i][0], gv[i][1], a, row, c, true);
+                }
+                if (a.dy) {
+                    gv[i][0] += *reinterpret_cast<const f32x4*>(a.dy + row * a.lddy + c);
+                    gv[i][1] += *reinterpret_cast<const f32x4*>(a.dy + row * a.lddy + c + 4);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) ss += xv[i][0][t] * xv[i][0][t] + xv[i][1][t] * xv[i][1][t];
+        }
+        float rstd = 1.f;
+        if (a.norm) {
+            ss = wave_sum(ss);
+            rstd = 1.f / sqrtf(ss / (float)a.C + a.norm_eps);
+        }
+        float dot = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (lane + 64 * i) * 8;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                f32x4 w = {1.f, 1.f, 1.f, 1.f};
+                if (a.w && c < a.C) w = *reinterpret_cast<const f32x4*>(a.w + c + 4 * u);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float xhat = xv[i][u][t] * rstd;
+                    const float g = xhat * w[t] > 0.f ? gv[i][u][t] : 0.f;     // relu mask on the pre-activation
+                    dwacc[i][u][t] += g * xhat;
+                    gv[i][u][t] = g * w[t];
+                    dot += gv[i][u][t] * xhat;
+                }
+            }
+        }
+        if (a.norm) dot = wave_sum(dot) / (float)a.C;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (lane + 64 * i) * 8;
+            if (c < a.C) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    f32x4 dx = gv[i][u];
+                    if (a.norm)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) dx[t] = rstd * (gv[i][u][t] - xv[i][u][t] * rstd * dot);
+                    Io<T>::st4((T*)a.dx + row * a.lddx + c + 4 * u, dx);
+                }
+            }
+        }
+    }
+    if (a.dwp) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) red[wave][(lane + 64 * i) * 8 + 4 * u + t] = dwacc[i][u][t];
+        __syncthreads();
+        for (int c = threadIdx.x; c < a.C; c += 256)
+            a.dwp[(long)blockIdx.x * a.C + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
     }
 }
 

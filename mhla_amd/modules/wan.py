@@ -160,6 +160,17 @@ class MHLA_Video_Uni(nn.Module):
             if self.is_lepe:
                 out = out + lepe
             return self.o(out)
+        elif D % 8 == 0 and C <= 2048:
+            # training: norm + relu + eps and the rotated copy in one kernel per tensor (and one for their backward)
+            wq = self.norm_q.weight if isinstance(self.norm_q, WanRMSNorm) else None
+            wk = self.norm_k.weight if isinstance(self.norm_k, WanRMSNorm) else None
+            q, q_rope = qk_prologue(q, wq, getattr(self.norm_q, "eps", 0.0), self.eps, rope=(cos, sin), head_dim=D)
+            k, k_rope = qk_prologue(k, wk, getattr(self.norm_k, "eps", 0.0), self.eps, rope=(cos, sin), head_dim=D)
+            q, k, q_rope, k_rope, v = (t.reshape(B, N, H, D) for t in (q, k, q_rope, k_rope, v.float()))
+            if self.normalize_out:
+                out = mhla_blockmix(q_rope, k_rope, v, W, eps=self.eps, q_den=q, k_den=k, block_index=idx)
+            else:
+                out = mhla_blockmix(q_rope, k_rope, v, W, eps=self.eps, normalize=False, block_index=idx)
         else:
             q, k, v = q.float(), k.float(), v.float()                     # mhla_utils.py:308
             q = torch.relu(self.norm_q(q)) + self.eps                     # :268-272

@@ -365,23 +365,75 @@ def featmap_rotary(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, featur
     return _FmapRotary.apply(x, cos, sin, _FMAPS[feature_map], int(t_offset))
 
 
-def qk_prologue(x: torch.Tensor, weight: Optional[torch.Tensor], norm_eps: float = 1e-5, eps: float = 1e-6) -> torch.Tensor:
+class _QkPrologue(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, cos, sin, norm_eps, eps, head_dim):
+        lib = _lib.load()
+        _require_gpu(x, weight, cos, sin)
+        C = x.shape[-1]
+        x2 = x.detach().reshape(-1, C)
+        if x2.stride(-1) != 1:
+            x2 = x2.contiguous()
+        rows = x2.shape[0]
+        y = torch.empty((rows, C), dtype=torch.float32, device=x.device)
+        w = weight.detach().to(torch.float32).contiguous() if weight is not None else None
+        rope = cos is not None
+        yr = torch.empty_like(y) if rope else None
+        ntok = cos.shape[0] if rope else 0
+        rc = lib.mhla_qk_prologue_rope(x2.data_ptr(), x2.stride(0), w.data_ptr() if w is not None else None, y.data_ptr(), C,
+                                       yr.data_ptr() if rope else None, C, cos.data_ptr() if rope else None,
+                                       sin.data_ptr() if rope else None, cos.stride(0) if rope else 0, ntok,
+                                       int(head_dim) if rope else 0, rows, C, int(weight is not None), float(norm_eps),
+                                       float(eps), _dtype_code(x2), _stream())
+        _lib.check(rc, "mhla_qk_prologue_rope")
+        ctx.save_for_backward(x2, w, cos, sin)
+        ctx.cfg = (x.shape, float(norm_eps), int(head_dim) if rope else 0, weight.dtype if weight is not None else None)
+        if rope:
+            return y.reshape(x.shape), yr.reshape(x.shape)
+        return y.reshape(x.shape), None
+
+    @staticmethod
+    def backward(ctx, dy, dyr):
+        lib = _lib.load()
+        x2, w, cos, sin = ctx.saved_tensors
+        shape, norm_eps, head_dim, w_dtype = ctx.cfg
+        rows, C = x2.shape
+        f32 = lambda t: None if t is None else t.reshape(rows, C).to(torch.float32).contiguous()
+        dy, dyr = f32(dy), f32(dyr)
+        if dy is None and dyr is None:
+            return None, None, None, None, None, None, None
+        dx = torch.empty((rows, C), dtype=x2.dtype, device=x2.device)
+        dwp = None
+        if w is not None:
+            dwp = torch.empty((lib.mhla_qk_prologue_dw_rows(rows), C), dtype=torch.float32, device=x2.device)
+        rope = dyr is not None
+        rc = lib.mhla_qk_prologue_bwd(x2.data_ptr(), x2.stride(0), w.data_ptr() if w is not None else None,
+                                      dy.data_ptr() if dy is not None else None, C, dyr.data_ptr() if rope else None, C,
+                                      cos.data_ptr() if rope else None, sin.data_ptr() if rope else None,
+                                      cos.stride(0) if rope else 0, cos.shape[0] if rope else 0, head_dim if rope else 0,
+                                      dx.data_ptr(), C, dwp.data_ptr() if dwp is not None else None, rows, C,
+                                      int(w is not None), norm_eps, _dtype_code(x2), _stream())
+        _lib.check(rc, "mhla_qk_prologue_bwd")
+        dw = dwp.sum(0).to(w_dtype) if dwp is not None else None
+        return dx.reshape(shape), dw, None, None, None, None, None
+
+
+def qk_prologue(x: torch.Tensor, weight: Optional[torch.Tensor], norm_eps: float = 1e-5, eps: float = 1e-6,
+                rope=None, head_dim: Optional[int] = None):
     """relu(rmsnorm(x) * weight) + eps over the last dim, fp32 output -- the q / k prologue of Wan's MHLA_Video_Uni
-    (wan/mhla_utils.py:268-272 after the .float() at :308), one HIP kernel, forward only.  weight None: relu(x) + eps."""
-    lib = _lib.load()
-    if torch.is_grad_enabled() and (x.requires_grad or (weight is not None and weight.requires_grad)):
-        raise RuntimeError("qk_prologue is forward-only")
-    _require_gpu(x, weight)
-    C = x.shape[-1]
-    x2 = x.detach().reshape(-1, C)
-    if x2.stride(-1) != 1:
-        x2 = x2.contiguous()
-    y = torch.empty(x2.shape, dtype=torch.float32, device=x.device)
-    w = weight.detach().to(torch.float32).contiguous() if weight is not None else None
-    rc = lib.mhla_qk_prologue(x2.data_ptr(), x2.stride(0), w.data_ptr() if w is not None else None, y.data_ptr(), C,
-                              x2.shape[0], C, int(weight is not None), float(norm_eps), float(eps), _dtype_code(x2), _stream())
-    _lib.check(rc, "mhla_qk_prologue")
-    return y.reshape(x.shape)
+    (wan/mhla_utils.py:268-272 after the .float() at :308) as one HIP kernel each way.  weight None: relu(x) + eps.
+    With `rope=(cos, sin)` (fp32 [N, head_dim/2] tables, token = row % N) a second tensor, the output rotated as by
+    `rope_apply` (:314), is produced in the same pass and `(y, y_rope)` is returned.  Differentiable w.r.t. x and weight."""
+    if x.shape[-1] % 8:
+        raise ValueError("channel dim must be a multiple of 8")
+    if rope is not None:
+        cos, sin = rope
+        if head_dim is None or cos.dtype != torch.float32 or sin.dtype != torch.float32 or cos.shape != sin.shape or \
+                cos.shape[1] != head_dim // 2 or x.shape[-1] % head_dim:
+            raise ValueError("rope: fp32 [N, head_dim/2] cos/sin tables and head_dim dividing the channel dim")
+        y, yr = _QkPrologue.apply(x, weight, cos.contiguous(), sin.contiguous(), norm_eps, eps, head_dim)
+        return y, yr
+    return _QkPrologue.apply(x, weight, None, None, norm_eps, eps, 0)[0]
 
 
 # ------------------------------------------------------------------------------------------

@@ -3,7 +3,7 @@ import pytest
 import torch
 
 from conftest import load_golden
-from gpu_util import DEV, check
+from gpu_util import DEV, check, poison
 from oracle import mhla_oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -170,6 +170,50 @@ def test_qk_prologue_and_rope_op():
                                              gate.to(DEV) if gated else None, odt, eps=1e-6, block_index=idx.to(DEV))
             assert got.dtype == odt
             check(f"wan fused {odt} gate={gated}", got, want.float().cpu(), 1e-5 if odt == torch.float32 else 8e-3)
+
+
+@pytest.mark.parametrize("dtype,C,D,norm", [(torch.float32, 256, 64, True), (torch.bfloat16, 1536, 128, True), (torch.float32, 192, 32, False)])
+def test_qk_prologue_backward_and_rope_output(dtype, C, D, norm):
+    """Differentiable prologue: y = relu(rmsnorm(x) w) + eps and y_rope = rope(y) in one kernel; gradients w.r.t. x and w
+    from both outputs vs autograd through the oracle's rms_norm / relu_eps / wan_rope_apply."""
+    import mhla_amd
+    g = torch.Generator().manual_seed(C + D)
+    B, grid = 2, (2, 3, 5)
+    N = grid[0] * grid[1] * grid[2]
+    H = C // D
+    x = torch.randn(B, N, C, generator=g).to(dtype)
+    w = (torch.rand(C, generator=g) + 0.5) if norm else None
+    dy, dyr = torch.randn(B, N, C, generator=g), torch.randn(B, N, C, generator=g)
+    freqs = orc.wan_freqs(D)
+    from mhla_amd.modules.wan import _rope_table
+    cos, sin = _rope_table(freqs, grid, DEV)
+    xr = x.float().clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True) if norm else None
+    yref = orc.relu_eps(orc.rms_norm(xr, wr, 1e-5) if norm else xr, 1e-6)
+    yrref = orc.wan_rope_apply(yref.reshape(B, N, H, D), grid, freqs).reshape(B, N, C)
+    (yref * dy).sum().backward(retain_graph=True)
+    gx_y, gw_y = xr.grad.clone(), (wr.grad.clone() if norm else None)
+    (yrref * dyr).sum().backward()
+    xd = x.detach().to(DEV).requires_grad_(True)
+    wd = w.to(DEV).requires_grad_(True) if norm else None
+    poison()
+    y, yr = mhla_amd.qk_prologue(xd, wd, 1e-5, 1e-6, rope=(cos, sin), head_dim=D)
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    check("y", y, yref.detach(), 1e-5)
+    check("y_rope", yr, yrref.detach(), 1e-5)
+    poison()
+    ((y * dy.to(DEV)).sum() + (yr * dyr.to(DEV)).sum()).backward()
+    check("dx", xd.grad, xr.grad, tol)
+    if norm:
+        check("dw", wd.grad, wr.grad, tol)
+    # single-output form
+    xd2 = x.detach().to(DEV).requires_grad_(True)
+    wd2 = w.to(DEV).requires_grad_(True) if norm else None
+    y2 = mhla_amd.qk_prologue(xd2, wd2, 1e-5, 1e-6)
+    (y2 * dy.to(DEV)).sum().backward()
+    check("dx (y only)", xd2.grad, gx_y, tol)
+    if norm:
+        check("dw (y only)", wd2.grad, gw_y, tol)
 
 
 def test_fla_layer_matches_oracle_restatement():

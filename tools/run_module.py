@@ -23,6 +23,16 @@ if which == "wan":
     def step():
         with torch.no_grad():
             return m(x, None, grid, freqs)
+elif which == "wanb":   # Wan layer in training mode (unfused prologue, backward through the operator)
+    m = MHLA_Video_Uni(1536, num_heads=12, block_layout=(3, 5, 10), is_gated=True).to(DEV).to(torch.bfloat16)
+    x = torch.randn(1, 21 * 30 * 50, 1536, device=DEV, dtype=torch.bfloat16, requires_grad=True)
+    grid = torch.tensor([[21, 30, 50]])
+    freqs = wan_freqs(128)
+
+    def step():
+        y = m(x, None, grid, freqs)
+        y.backward(torch.ones_like(y))
+        return y
 elif which == "fla":
     from mhla_amd.modules import MHLA
     m = MHLA(mode="chunk", hidden_size=1024, expand_k=0.5, expand_v=1.0, num_heads=4, feature_map="relu").to(DEV).to(torch.bfloat16)
