@@ -11,7 +11,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from ..ops import lepe2d, mhla_blockmix
+from ..ops import lepe2d, mhla_blockmix, mhla_dit_core
 from .blockconv import BlockDistanceConv
 
 
@@ -96,7 +96,11 @@ class MHLA4DiT(nn.Module):
             k = torch.relu(self.k_norm(qkv[:, :, 1].reshape(B, M * S, H * D))) + self.eps
             out = mhla_blockmix(q.reshape(B, M * S, H, D), k.reshape(B, M * S, H, D), qkv[:, :, 2], W, eps=self.eps)
         else:
-            out = mhla_blockmix(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], W, eps=self.eps, relu_eps=True)
+            # operator (relu + eps folded into its loads) and LePE as one autograd node on the packed projection output
+            out = mhla_dit_core(qkv, W, self.lepe.weight, self.lepe.bias, self.pieces_len, self.block_len, eps=self.eps,
+                                relu_eps=True).reshape(B, M, S, H * D)
+            out = self.to_out(out)
+            return out.reshape(B, M * S, -1) if three_d else out
         out = self._lepe(qkv[:, :, 2].reshape(B, M * S, H * D), out.reshape(B, M * S, H * D)).reshape(B, M, S, H * D)
         out = self.to_out(out)
         return out.reshape(B, M * S, -1) if three_d else out

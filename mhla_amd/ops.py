@@ -318,6 +318,92 @@ def mhla_blockmix_wan(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, W: torc
     return out
 
 
+class _DitCore(torch.autograd.Function):
+    """Operator + LePE of the DiT / ViT module as ONE autograd node on the packed QKV projection output
+    (mhla_dit/mhla/mhla.py:245-273): q, k, v are the three slices of `qkv` [B, N, 3, H, D] read in place; the backward writes
+    dq, dk and dv (operator part + LePE part, summed inside the LePE kernel) straight into one [B, N, 3, H, D] gradient --
+    no per-slice gradient tensors, no zero-fill and slice-adds by autograd."""
+
+    @staticmethod
+    def forward(ctx, qkv, W, lepe_w, lepe_b, pieces_len, block_len, eps, relu_eps):
+        lib = _lib.load()
+        _require_gpu(qkv, W, lepe_w, lepe_b)
+        B, N, _, H, D = qkv.shape
+        M, C, K = W.shape[0], H * D, lepe_w.shape[-1]
+        S = N // M
+        qkv = qkv if (qkv.is_contiguous() and _strided_ok(qkv[:, :, 0])) else qkv.contiguous()
+        q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+        Wf = W.detach().reshape(M, M).to(torch.float32).contiguous()
+        dt = _dtype_code(qkv)
+        flags = _lib.FLAG_RELU_EPS if relu_eps else 0
+        attn = torch.empty((B, N, H, D), dtype=qkv.dtype, device=qkv.device)
+        ws = _ws(lib.mhla_blockmix_fwd_ws_bytes(B, H, M, S, D, dt, 0, flags), qkv.device)
+        qv, kv = _view(q), _view(k)
+        rc = lib.mhla_blockmix_fwd(qv, kv, _view(v), qv, kv, Wf.data_ptr(), M, _view(attn), None, ws.data_ptr(), ws.numel() * 4,
+                                   B, H, M, S, D, dt, float(eps), flags, _stream())
+        _lib.check(rc, "mhla_blockmix_fwd")
+        w_taps = lepe_w.detach().reshape(C, K * K).t().to(torch.float32).contiguous()
+        b32 = lepe_b.detach().to(torch.float32).contiguous() if lepe_b is not None else None
+        y = torch.empty((B, N, C), dtype=qkv.dtype, device=qkv.device)
+        v3 = v.reshape(B, N, C)          # view: H and D are adjacent in the packed buffer
+        rc = lib.mhla_lepe2d(v3.data_ptr(), v3.stride(0), v3.stride(1), w_taps.data_ptr(), b32.data_ptr() if b32 is not None else None,
+                             attn.data_ptr(), N * C, C, y.data_ptr(), N * C, C, B, pieces_len, block_len, C, K, 0, dt, _stream())
+        _lib.check(rc, "mhla_lepe2d")
+        keep = (lib.mhla_blockmix_fwd_keeps_state(B, H, M, S, D, dt, 0, flags) == 1 and ws.numel() * 4 <= KEEP_STATE_LIMIT_BYTES)
+        ctx.save_for_backward(qkv, Wf, attn, w_taps, ws if keep else None)
+        ctx.cfg = (pieces_len, block_len, float(eps), flags, W.shape, W.dtype, lepe_w.shape, lepe_w.dtype,
+                   lepe_b.dtype if lepe_b is not None else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        qkv, Wf, attn, w_taps, fwd_ws = ctx.saved_tensors
+        pl, bl, eps, flags, w_shape, w_dtype, lw_shape, lw_dtype, lb_dtype = ctx.cfg
+        B, N, _, H, D = qkv.shape
+        M, C, K = Wf.shape[0], H * D, lw_shape[-1]
+        S = N // M
+        dt = _dtype_code(qkv)
+        dy = dy.to(qkv.dtype).contiguous()
+        dy4 = dy.reshape(B, N, H, D)
+        q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+        dqkv = torch.empty_like(qkv)
+        dv_attn = torch.empty((B, N, H, D), dtype=qkv.dtype, device=qkv.device)
+        dW = torch.empty((M, M), dtype=torch.float32, device=qkv.device)
+        ws = _ws(lib.mhla_blockmix_bwd_ws_bytes(B, H, M, S, D, dt, 0, flags), qkv.device)
+        qv, kv = _view(q), _view(k)
+        rc = lib.mhla_blockmix_bwd(qv, kv, _view(v), qv, kv, Wf.data_ptr(), M, _view(attn), _view(dy4),
+                                   _view(dqkv[:, :, 0]), _view(dqkv[:, :, 1]), _view(dv_attn), NULL_VIEW, NULL_VIEW,
+                                   dW.data_ptr(), None, ws.data_ptr(), ws.numel() * 4,
+                                   fwd_ws.data_ptr() if fwd_ws is not None else None, B, H, M, S, D, dt, eps, flags, _stream())
+        _lib.check(rc, "mhla_blockmix_bwd")
+        # dv = operator part + LePE part (flipped-kernel correlation of dy), written into the V slice of the packed gradient
+        dv3 = dqkv[:, :, 2].reshape(B, N, C)
+        rc = lib.mhla_lepe2d(dy.data_ptr(), N * C, C, w_taps.data_ptr(), None, dv_attn.data_ptr(), N * C, C,
+                             dv3.data_ptr(), dv3.stride(0), dv3.stride(1), B, pl, bl, C, K, 1, dt, _stream())
+        _lib.check(rc, "mhla_lepe2d (input gradient)")
+        dwb = torch.empty((K * K + 1, C), dtype=torch.float32, device=qkv.device)
+        ws2 = _ws(lib.mhla_lepe2d_wgrad_ws_bytes(C, K), qkv.device)
+        v3 = v.reshape(B, N, C)
+        rc = lib.mhla_lepe2d_wgrad(v3.data_ptr(), v3.stride(0), v3.stride(1), dy.data_ptr(), N * C, C, dwb.data_ptr(),
+                                   ws2.data_ptr(), ws2.numel() * 4, B, pl, bl, C, K, dt, _stream())
+        _lib.check(rc, "mhla_lepe2d_wgrad")
+        dlw = dwb[:K * K].t().reshape(lw_shape).to(lw_dtype)
+        dlb = dwb[K * K].to(lb_dtype) if lb_dtype is not None else None
+        return dqkv, dW.reshape(w_shape).to(w_dtype), dlw, dlb, None, None, None, None
+
+
+def mhla_dit_core(qkv: torch.Tensor, W: torch.Tensor, lepe_weight: torch.Tensor, lepe_bias: Optional[torch.Tensor],
+                  pieces_len: int, block_len: int, *, eps: float = 1e-6, relu_eps: bool = True) -> torch.Tensor:
+    """`mhla_blockmix(q, k, v, W) + LePE(v)` of the DiT / ViT module on the packed projection output `qkv` [B, N, 3, H, D]
+    (block-major tokens), returning [B, N, H*D]; one autograd node whose backward emits a single packed gradient."""
+    if qkv.dim() != 5 or qkv.shape[2] != 3:
+        raise ValueError("qkv: [B, N, 3, H, D]")
+    if qkv.shape[1] % W.shape[0] or qkv.shape[1] != (pieces_len * block_len) ** 2:
+        raise ValueError("token count does not match the block layout")
+    return _DitCore.apply(qkv, W, lepe_weight, lepe_bias, int(pieces_len), int(block_len), eps, relu_eps)
+
+
 _FMAPS = {None: 0, "identity": 0, "relu": 1, "elu": 2}
 
 

@@ -127,6 +127,35 @@ def test_lepe2d_matches_conv2d(K, pl, bl, C, dtype):
     check("dadd", da.grad, dy, 1e-6)
 
 
+@pytest.mark.parametrize("H,D,pl,bl,K,dtype", [(16, 72, 4, 4, 3, torch.bfloat16), (2, 64, 2, 7, 5, torch.float32), (4, 64, 8, 8, 3, torch.bfloat16)])
+def test_dit_core_packed_node_matches_composition(H, D, pl, bl, K, dtype):
+    """mhla_dit_core (operator + LePE on the packed QKV buffer, one packed gradient) == mhla_blockmix + lepe2d."""
+    import mhla_amd
+    g = torch.Generator().manual_seed(H * D)
+    B, M, S = 2, pl * pl, bl * bl
+    N, C = M * S, H * D
+    qkv = torch.randn(B, N, 3, H, D, generator=g).to(dtype)
+    W = orc.block_distance_weights((pl, pl), "linear")
+    lw = (torch.randn(C, 1, K, K, generator=g) * 0.2).to(dtype)
+    lb = torch.randn(C, generator=g).to(dtype)
+    dy = torch.randn(B, N, C, generator=g).to(dtype)
+    res = []
+    for packed in (True, False):
+        t = [x.clone().to(DEV).requires_grad_(True) for x in (qkv, W, lw, lb)]
+        poison()
+        if packed:
+            y = mhla_amd.mhla_dit_core(t[0], t[1], t[2], t[3], pl, bl, eps=1e-6, relu_eps=True)
+        else:
+            o = mhla_amd.mhla_blockmix(t[0][:, :, 0], t[0][:, :, 1], t[0][:, :, 2], t[1], eps=1e-6, relu_eps=True)
+            y = mhla_amd.lepe2d(t[0][:, :, 2].reshape(B, N, C), t[2], t[3], pl, bl, add=o.reshape(B, N, C))
+        poison()
+        y.backward(dy.to(DEV))
+        res.append([y] + [x.grad for x in t])
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    for name, a, b in zip(("y", "dqkv", "dW", "dlepe_w", "dlepe_b"), *res):
+        check(name, a, b.float().cpu(), tol)
+
+
 def test_qk_prologue_and_rope_op():
     """mhla_qk_prologue vs the oracle's rms_norm + relu_eps; mhla_blockmix_rope vs rope_apply + the split-pair op."""
     import mhla_amd
