@@ -33,31 +33,47 @@ __device__ __forceinline__ int lepe_token(int yy, int xx, int pl, int bl) {
     const int py = yy / bl, by = yy - py * bl, px = xx / bl, bx = xx - px * bl;
     return (py * pl + px) * bl * bl + by * bl + bx;
 }
+// Block / in-block coordinates of a token and of its neighbours without divisions per tap: one axis at a time, a
+// displacement d moves the in-block coordinate and carries into the block coordinate.
+struct LepePos { int py, px, by, bx; };
+__device__ __forceinline__ LepePos lepe_pos(int n, int pl, int bl) {
+    const int S = bl * bl, m = n / S, s = n - m * S;
+    LepePos p;
+    p.py = m / pl; p.px = m - p.py * pl; p.by = s / bl; p.bx = s - p.by * bl;
+    return p;
+}
+// coordinate (block b, offset o) displaced by d; returns false when it leaves the image
+__device__ __forceinline__ bool lepe_shift(int b, int o, int d, int pl, int bl, int& b2, int& o2) {
+    o2 = o + d;
+    b2 = b;
+    while (o2 < 0) { o2 += bl; --b2; }
+    while (o2 >= bl) { o2 -= bl; ++b2; }
+    return b2 >= 0 && b2 < pl;
+}
 
 // grid (ceil(N * C/8 / 256), B); a thread: 8 channels of one token
 template <typename T>
 __global__ __launch_bounds__(256) void k_lepe2d(const LepeArgs a) {
-    const int CG = a.C / 8, N = a.pl * a.pl * a.bl * a.bl, side = a.pl * a.bl;
+    const int CG = a.C / 8, N = a.pl * a.pl * a.bl * a.bl;
     const long gid = (long)blockIdx.x * 256 + threadIdx.x;
     if (gid >= (long)N * CG) return;
     const int n = (int)(gid / CG), c = (int)(gid - (long)n * CG) * 8, b = blockIdx.y;
-    int yy, xx;
-    lepe_decode(n, a.pl, a.bl, yy, xx);
+    const LepePos pos = lepe_pos(n, a.pl, a.bl);
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
     if (a.bias) {
         acc0 = *reinterpret_cast<const f32x4*>(a.bias + c);
         acc1 = *reinterpret_cast<const f32x4*>(a.bias + c + 4);
     }
     const T* xb = (const T*)a.x + b * a.xsb + c;
-    const int K = a.K, R = K / 2;
+    const int K = a.K, R = K / 2, S = a.bl * a.bl;
     for (int dy = 0; dy < K; ++dy) {
-        const int y2 = yy + dy - R;
-        if (y2 < 0 || y2 >= side) continue;
+        int py2, by2;
+        if (!lepe_shift(pos.py, pos.by, dy - R, a.pl, a.bl, py2, by2)) continue;
         for (int dx = 0; dx < K; ++dx) {
-            const int x2 = xx + dx - R;
-            if (x2 < 0 || x2 >= side) continue;
+            int px2, bx2;
+            if (!lepe_shift(pos.px, pos.bx, dx - R, a.pl, a.bl, px2, bx2)) continue;
             const int tap = a.flip ? (K - 1 - dy) * K + (K - 1 - dx) : dy * K + dx;
-            const T* p = xb + (long)lepe_token(y2, x2, a.pl, a.bl) * a.xsn;
+            const T* p = xb + (long)((py2 * a.pl + px2) * S + by2 * a.bl + bx2) * a.xsn;
             const f32x4 x0 = Io<T>::ld4(p), x1 = Io<T>::ld4(p + 4);
             acc0 += x0 * *reinterpret_cast<const f32x4*>(a.w + (long)tap * a.C + c);
             acc1 += x1 * *reinterpret_cast<const f32x4*>(a.w + (long)tap * a.C + c + 4);
@@ -89,7 +105,7 @@ struct LepeWgradArgs {
 template <typename T, int K, int CH>   // CH: channels per thread (4 or 8)
 __global__ __launch_bounds__(256) void k_lepe2d_wgrad(const LepeWgradArgs a) {
     constexpr int NV = CH / 4, NA = K * K + 1;
-    const int N = a.pl * a.pl * a.bl * a.bl, side = a.pl * a.bl;
+    const int N = a.pl * a.pl * a.bl * a.bl;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tl = lane >> 3;
     const int c = ((blockIdx.x * 4 + wave) * 8 + (lane & 7)) * CH, slice = blockIdx.y;
     const bool live = c < a.C;
@@ -103,8 +119,7 @@ __global__ __launch_bounds__(256) void k_lepe2d_wgrad(const LepeWgradArgs a) {
     if (live) {
         for (long t = t0 + tl; t < t1; t += 8) {
             const int b = (int)(t / N), n = (int)(t - (long)b * N);
-            int yy, xx;
-            lepe_decode(n, a.pl, a.bl, yy, xx);
+            const LepePos pos = lepe_pos(n, a.pl, a.bl);
             f32x4 g[NV];
             const T* gp = (const T*)a.g + b * a.gsb + (long)n * a.gsn + c;
 #pragma unroll
@@ -113,14 +128,16 @@ __global__ __launch_bounds__(256) void k_lepe2d_wgrad(const LepeWgradArgs a) {
                 acc[K * K][u] += g[u];
             }
             const T* xb = (const T*)a.x + b * a.xsb + c;
+            const int S = a.bl * a.bl;
 #pragma unroll
             for (int dy = 0; dy < K; ++dy) {
-                const int y2 = yy + dy - K / 2;
+                int py2, by2;
+                const bool oky = lepe_shift(pos.py, pos.by, dy - K / 2, a.pl, a.bl, py2, by2);
 #pragma unroll
                 for (int dx = 0; dx < K; ++dx) {
-                    const int x2 = xx + dx - K / 2;
-                    if (y2 >= 0 && y2 < side && x2 >= 0 && x2 < side) {
-                        const T* p = xb + (long)lepe_token(y2, x2, a.pl, a.bl) * a.xsn;
+                    int px2, bx2;
+                    if (lepe_shift(pos.px, pos.bx, dx - K / 2, a.pl, a.bl, px2, bx2) && oky) {
+                        const T* p = xb + (long)((py2 * a.pl + px2) * S + by2 * a.bl + bx2) * a.xsn;
 #pragma unroll
                         for (int u = 0; u < NV; ++u) acc[dy * K + dx][u] += g[u] * Io<T>::ld4(p + 4 * u);
                     }
