@@ -214,7 +214,7 @@ int bm_state_and_mix(const mhla_view& q_num, const mhla_view& k_num, const mhla_
     MixArgs m{W, ldw, w.kv, w.g, M, (long)D * D};
     if (sp_shape_ok(D, flags)) {   // split-bf16 MFMA kernels (split.cuh)
         RC(launch(sp::k_sp_state<T, DT, 0>, dim3(M, B * H), dim3(NTHREADS), sp::sp_state_smem<DT>(), st, "k_sp_state", a));
-        RC(launch(sp::k_sp_mix<0>, dim3((unsigned)((m.E + sp::SPM_TE - 1) / sp::SPM_TE), (M + 63) / 64, B * H), dim3(NTHREADS), sp::SP_MIX_SMEM, st, "k_sp_mix<0>", m));
+        RC(launch(sp::k_sp_mix<0, sp::Sum16<T>::value>, dim3((unsigned)((m.E + sp::SPM_TE - 1) / sp::SPM_TE), (M + 63) / 64, B * H), dim3(NTHREADS), sp::SP_MIX_SMEM, st, "k_sp_mix<0>", m));
         if (normalize)
             RC(launch(k_wz<0>, dim3((S + 63) / 64, (M + 63) / 64, B * H), dim3(NTHREADS), 0, st, "k_wz<0>", W, ldw, (const float*)w.z, w.ninv, M, S, eps));
         return MHLA_OK;
@@ -559,11 +559,11 @@ int mhla_blockmix_bwd(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q
             if (normalize)
                 RC(launch(k_wz<1>, dim3((S + 63) / 64, (M + 63) / 64, B * H), dim3(NTHREADS), 0, st, "k_wz<1>", W, ldw, (const float*)w.dn, w.dz, M, S, 0.f));
             MixArgs m{W, ldw, w.dg, w.dkv, M, E};
-            RC(launch(sp::k_sp_mix<1>, dim3((unsigned)((E + sp::SPM_TE - 1) / sp::SPM_TE), tiles, B * H), dim3(NTHREADS), sp::SP_MIX_SMEM, st, "k_sp_mix<1>", m));
+            RC(launch(sp::k_sp_mix<1, sp::Sum16<ET>::value>, dim3((unsigned)((E + sp::SPM_TE - 1) / sp::SPM_TE), tiles, B * H), dim3(NTHREADS), sp::SP_MIX_SMEM, st, "k_sp_mix<1>", m));
             int nsplit = dw_splits(tiles * tiles * B * H, E);
             if (nsplit > DW_MAX_SPLIT - 1) nsplit = DW_MAX_SPLIT - 1;   // one more part per (b, h) holds the <dn_i, z_j> term
             DwArgs d{w.dg, w.kv, E, nullptr, nullptr, 0, w.dwp, M, tiles, nsplit};
-            RC(launch(sp::k_sp_dw, dim3(tiles * tiles, B * H, nsplit), dim3(NTHREADS), sp::SP_DW_SMEM, st, "k_sp_dw", d));
+            RC(launch(sp::k_sp_dw<sp::Sum16<ET>::value>, dim3(tiles * tiles, B * H, nsplit), dim3(NTHREADS), sp::SP_DW_SMEM, st, "k_sp_dw", d));
             int nparts = B * H * nsplit;
             if (normalize) {
                 DwArgs dzz{w.dn, w.z, (long)S, nullptr, nullptr, 0, w.dwp + (size_t)nparts * M * M, M, tiles, 1};

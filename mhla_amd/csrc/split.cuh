@@ -60,6 +60,10 @@ __device__ __forceinline__ void rope8(f32x4& a, f32x4& b, const f32x4& c, const 
     b[2] = b0[2] * c[3] - b0[3] * s[3]; b[3] = b0[2] * s[3] + b0[3] * c[3];
 }
 
+// Block summaries (KV, G, dG, dKV) are fp32 in the workspace, except for bf16 tensors: there they are stored as bf16 (as on
+// the bf16 fast path), which halves the summary traffic -- the larger share of the bytes when S is small -- and needs no lo part.
+template <typename T> struct Sum16 { static constexpr bool value = std::is_same<T, bf16_t>::value; };
+
 template <int DT> struct Geo {
     static constexpr int CGS = DT > 4 ? 16 : 8;        // column groups of 8 per tile row
     static constexpr int DW = CGS * 8;                 // tile width (columns), >= 16 DT
@@ -207,7 +211,10 @@ __global__ __launch_bounds__(NTHREADS) void k_sp_state(const StateArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = (wave * RT + rt) * 16 + kg * 4 + r, col = ct * 16 + nl;
-                if (row < D && col < D) ob[(long)row * D + col] = acc[rt][ct][r];
+                if (row < D && col < D) {
+                    if (Sum16<T>::value) reinterpret_cast<u16*>(a.out)[((long)bh * a.M + blk) * D * D + (long)row * D + col] = cvt_bf16(acc[rt][ct][r]);
+                    else                 ob[(long)row * D + col] = acc[rt][ct][r];
+                }
             }
 
     if (MODE == 0 && a.normalize) {
@@ -249,7 +256,7 @@ constexpr int SPM_TE = 128, SPM_LD = SPM_TE + 8, SPM_TILE = 32 * SPM_LD;
 constexpr int SP_MIX_SMEM = 4 * SPM_TILE * 2;   // two buffers of (hi, lo) [32][SPM_LD] bf16; reused as [64][SPM_TE + 4] fp32 staging
 static_assert(64 * (SPM_TE + 4) * 4 <= SP_MIX_SMEM, "output staging must fit in the input tiles");
 
-template <int TRANS>
+template <int TRANS, bool S16 = false>   // S16: summaries stored as bf16 (no lo part)
 __global__ __launch_bounds__(NTHREADS, 2) void k_sp_mix(const MixArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u16* Xs = reinterpret_cast<u16*>(smem_raw);
@@ -258,21 +265,31 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_mix(const MixArgs a) {
     const int i0 = blockIdx.y * 64, bh = blockIdx.z, M = a.M;
     const float* inb = a.in + (long)bh * M * a.E + e0;
     float* outb = a.out + (long)bh * M * a.E + e0;
+    const u16* inb16 = reinterpret_cast<const u16*>(a.in) + (long)bh * M * a.E + e0;
+    u16* outb16 = reinterpret_cast<u16*>(a.out) + (long)bh * M * a.E + e0;
     const int steps = (M + 31) / 32;
     const int sr = tid >> 3, sc = (tid & 7) * 8;   // staging: row sr, 8 floats at columns sc and sc + 64
 
     f32x4 pre[2][2];
+    uint4 pre16[2];
     auto fetch = [&](int step) {
         const int row = step * 32 + sr;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) pre[u][0] = pre[u][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int u = 0; u < 2; ++u) {
+            pre[u][0] = pre[u][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            pre16[u] = make_uint4(0, 0, 0, 0);
+        }
         if (row < M) {
-            const float* src = inb + (long)row * a.E + sc;
 #pragma unroll
             for (int u = 0; u < 2; ++u)
                 if (e0 + sc + 64 * u < a.E) {   // E is a multiple of 8
-                    pre[u][0] = *reinterpret_cast<const f32x4*>(src + 64 * u);
-                    pre[u][1] = *reinterpret_cast<const f32x4*>(src + 64 * u + 4);
+                    if (S16) {
+                        pre16[u] = *reinterpret_cast<const uint4*>(inb16 + (long)row * a.E + sc + 64 * u);
+                    } else {
+                        const float* src = inb + (long)row * a.E + sc;
+                        pre[u][0] = *reinterpret_cast<const f32x4*>(src + 64 * u);
+                        pre[u][1] = *reinterpret_cast<const f32x4*>(src + 64 * u + 4);
+                    }
                 }
         }
     };
@@ -280,10 +297,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_mix(const MixArgs a) {
         u16* th = Xs + buf * 2 * SPM_TILE + sr * SPM_LD + sc;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            uint4 hi, lo;
-            split8(pre[u][0], pre[u][1], hi, lo);
-            *reinterpret_cast<uint4*>(th + 64 * u) = hi;
-            *reinterpret_cast<uint4*>(th + SPM_TILE + 64 * u) = lo;
+            if (S16) {
+                *reinterpret_cast<uint4*>(th + 64 * u) = pre16[u];
+            } else {
+                uint4 hi, lo;
+                split8(pre[u][0], pre[u][1], hi, lo);
+                *reinterpret_cast<uint4*>(th + 64 * u) = hi;
+                *reinterpret_cast<uint4*>(th + SPM_TILE + 64 * u) = lo;
+            }
         }
     };
 
@@ -316,12 +337,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_mix(const MixArgs a) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 bh_[t] = tr_read8(th, SPM_LD, 0, (t4 + t) * 16, lane);
-                bl_[t] = tr_read8(th + SPM_TILE, SPM_LD, 0, (t4 + t) * 16, lane);
+                if (!S16) bl_[t] = tr_read8(th + SPM_TILE, SPM_LD, 0, (t4 + t) * 16, lane);
             }
 #pragma unroll
             for (int t = 0; t < 4; ++t) acc[t4 + t] = mfma_bf16(ah, bh_[t], acc[t4 + t]);
+            if (!S16)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t4 + t] = mfma_bf16(ah, bl_[t], acc[t4 + t]);
+                for (int t = 0; t < 4; ++t) acc[t4 + t] = mfma_bf16(ah, bl_[t], acc[t4 + t]);
 #pragma unroll
             for (int t = 0; t < 4; ++t) acc[t4 + t] = mfma_bf16(al, bh_[t], acc[t4 + t]);
         }
@@ -337,7 +359,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_mix(const MixArgs a) {
 #pragma unroll
     for (int v0 = 0; v0 < 8; ++v0) {
         const int v = tid + v0 * NTHREADS, r = v >> 5, c = (v & 31) * 4;
-        if (i0 + r < M && e0 + c < a.E) *reinterpret_cast<f32x4*>(outb + (long)(i0 + r) * a.E + c) = *reinterpret_cast<const f32x4*>(Os + r * (SPM_TE + 4) + c);
+        if (i0 + r < M && e0 + c < a.E) {
+            const f32x4 o = *reinterpret_cast<const f32x4*>(Os + r * (SPM_TE + 4) + c);
+            if (S16) *reinterpret_cast<uint2*>(outb16 + (long)(i0 + r) * a.E + c) = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+            else     *reinterpret_cast<f32x4*>(outb + (long)(i0 + r) * a.E + c) = o;
+        }
     }
 }
 
@@ -348,6 +374,49 @@ __host__ __device__ constexpr int sp_out_smem() { return 2 * Geo<DT>::KST * 32 *
 // EPI: the per-head RMSNorm (x SiLU gate) that follows the operator in the Wan host (wan/mhla_utils.py:356-362) is applied
 // to the token's D outputs before they are stored, in the dtype TO of the host's activations: O is rounded to TO (the
 // `.to(dtype)` at :356), normalised over the head dim in fp32, scaled by the norm weight and the gate, stored once.
+// D x D summary matrix (fp32, or bf16 when S16) -> LDS [KP][LD] hi (/ lo) tiles; rows and columns >= D zero.  NT threads.
+template <int DT, bool S16, int NT = NTHREADS>
+__device__ __forceinline__ void stage_mat_split(u16* __restrict__ Gh, u16* __restrict__ Gl, const float* __restrict__ base, long elem_off, int D, int tid) {
+    constexpr int LD = Geo<DT>::LD, CGS = Geo<DT>::CGS, RPP = NT / CGS, KP = Geo<DT>::KST * 32;
+    const int r0 = tid / CGS, cg = (tid % CGS) * 8;
+    constexpr int PASSES = (KP + RPP - 1) / RPP, UB = PASSES < 4 ? PASSES : (PASSES % 4 == 0 ? 4 : (PASSES % 3 == 0 ? 3 : 2));
+    static_assert(PASSES % UB == 0, "staging batches must tile the passes");
+    const float* g = base + elem_off;
+    const u16* g16 = reinterpret_cast<const u16*>(base) + elem_off;
+    for (int pb = 0; pb < PASSES; pb += UB) {
+        f32x4 x[UB][2];
+        uint4 x16[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int r = r0 + RPP * (pb + u);
+            x[u][0] = x[u][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            x16[u] = make_uint4(0, 0, 0, 0);
+            if (r < D && cg < D) {
+                if (S16) {
+                    x16[u] = *reinterpret_cast<const uint4*>(g16 + (long)r * D + cg);
+                } else {
+                    const float* src = g + (long)r * D + cg;
+                    x[u][0] = *reinterpret_cast<const f32x4*>(src);
+                    x[u][1] = *reinterpret_cast<const f32x4*>(src + 4);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int r = r0 + RPP * (pb + u), off = r * LD + cg;
+            if (r < KP) {
+                if (S16) {
+                    *reinterpret_cast<uint4*>(Gh + off) = x16[u];
+                } else {
+                    uint4 hi, lo;
+                    split8(x[u][0], x[u][1], hi, lo);
+                    *reinterpret_cast<uint4*>(Gh + off) = hi;
+                    *reinterpret_cast<uint4*>(Gl + off) = lo;
+                }
+            }
+        }
+    }
+}
 // 4 elements of TO as loaded (packed for 16-bit types) and their conversion to fp32
 template <typename TO> struct Raw4 { typedef uint2 type; };
 template <> struct Raw4<float> { typedef f32x4 type; };
@@ -364,7 +433,7 @@ __device__ __forceinline__ f32x4 raw4_to_f32(float, f32x4 r) { return r; }
 constexpr int SP_OUT_T = 512;   // 8 waves share the staged G_i: twice the loads in flight per LDS byte
 template <typename T, int DT, typename TO = T, bool EPI = false>
 __global__ __launch_bounds__(SP_OUT_T, 2) void k_sp_out(const OutArgs a) {
-    constexpr int LD = Geo<DT>::LD, CGS = Geo<DT>::CGS, RPP = SP_OUT_T / CGS, KST = Geo<DT>::KST, KP = KST * 32, TILE = KP * LD;
+    constexpr int LD = Geo<DT>::LD, KST = Geo<DT>::KST, KP = KST * 32, TILE = KP * LD;
     constexpr bool LO = !std::is_same<T, bf16_t>::value;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u16* Gh = reinterpret_cast<u16*>(smem_raw);   // [d1][d2], rows >= D and columns >= D zero
@@ -374,35 +443,8 @@ __global__ __launch_bounds__(SP_OUT_T, 2) void k_sp_out(const OutArgs a) {
     const long p0 = (long)blk * S;
     const T* qb = (const T*)a.q.ptr + b * a.q.sb + h * a.q.sh;
     TO* ob = (TO*)a.o.ptr + b * a.o.sb + h * a.o.sh;
-    {   // G_i -> LDS as hi / lo
-        const float* g = a.g + ((long)bh * a.M + blk) * D * D;
-        const int r0 = tid / CGS, cg = (tid % CGS) * 8;
-        constexpr int PASSES = (KP + RPP - 1) / RPP, UB = PASSES < 4 ? PASSES : (PASSES % 4 == 0 ? 4 : (PASSES % 3 == 0 ? 3 : 2));
-        static_assert(PASSES % UB == 0, "staging batches must tile the passes");
-        for (int pb = 0; pb < PASSES; pb += UB) {
-            f32x4 x[UB][2];
-#pragma unroll
-            for (int u = 0; u < UB; ++u) {
-                const int r = r0 + RPP * (pb + u);
-                x[u][0] = x[u][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (r < D && cg < D) {
-                    const float* src = g + (long)r * D + cg;
-                    x[u][0] = *reinterpret_cast<const f32x4*>(src);
-                    x[u][1] = *reinterpret_cast<const f32x4*>(src + 4);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < UB; ++u) {
-                uint4 hi, lo;
-                split8(x[u][0], x[u][1], hi, lo);
-                const int r = r0 + RPP * (pb + u), off = r * LD + cg;
-                if (r < KP) {
-                    *reinterpret_cast<uint4*>(Gh + off) = hi;
-                    *reinterpret_cast<uint4*>(Gl + off) = lo;
-                }
-            }
-        }
-    }
+    constexpr bool S16 = Sum16<T>::value;   // G_i stored as bf16: no lo tile
+    stage_mat_split<DT, S16, SP_OUT_T>(Gh, Gl, a.g, ((long)bh * a.M + blk) * D * D, D, tid);
     __syncthreads();
     const float* ninvb = a.ninv + ((long)bh * a.M + blk) * S;
     for (int tt = wave; tt * 16 < S; tt += SP_OUT_T / 64) {
@@ -445,11 +487,13 @@ __global__ __launch_bounds__(SP_OUT_T, 2) void k_sp_out(const OutArgs a) {
 #pragma unroll
             for (int ks = 0; ks < KST; ++ks) {
                 const bf16x8 a0h = tr_read8(Gh, LD, ks * 32, ct * 16, lane), a1h = tr_read8(Gh, LD, ks * 32, ct * 16 + 16, lane);
-                const bf16x8 a0l = tr_read8(Gl, LD, ks * 32, ct * 16, lane), a1l = tr_read8(Gl, LD, ks * 32, ct * 16 + 16, lane);
                 c0 = mfma_bf16(a0h, qh[ks], c0);
                 c1 = mfma_bf16(a1h, qh[ks], c1);
-                c0 = mfma_bf16(a0l, qh[ks], c0);
-                c1 = mfma_bf16(a1l, qh[ks], c1);
+                if (!S16) {
+                    const bf16x8 a0l = tr_read8(Gl, LD, ks * 32, ct * 16, lane), a1l = tr_read8(Gl, LD, ks * 32, ct * 16 + 16, lane);
+                    c0 = mfma_bf16(a0l, qh[ks], c0);
+                    c1 = mfma_bf16(a1l, qh[ks], c1);
+                }
                 if (LO) {
                     c0 = mfma_bf16(a0h, ql[ks], c0);
                     c1 = mfma_bf16(a1h, ql[ks], c1);
@@ -506,6 +550,7 @@ __global__ __launch_bounds__(SP_OUT_T, 2) void k_sp_out(const OutArgs a) {
 constexpr int SP_DW_LD = 68;
 constexpr int SP_DW_SMEM = 64 * SP_DW_LD * 4;
 
+template <bool S16>
 __global__ __launch_bounds__(NTHREADS) void k_sp_dw(const DwArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* Rs = reinterpret_cast<float*>(smem_raw);
@@ -520,11 +565,15 @@ __global__ __launch_bounds__(NTHREADS) void k_sp_dw(const DwArgs a) {
     const long wbeg = ebeg + wave * wper, wend = min(eend, wbeg + wper);
     const float* xp[4];
     const float* yp[4];
+    const u16* xp16[4];
+    const u16* yp16[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int ri = min(i0 + t * 16 + nl, M - 1), rj = min(j0 + t * 16 + nl, M - 1);
         xp[t] = a.x + ((long)bh * M + ri) * E + kg * 8;
         yp[t] = a.y + ((long)bh * M + rj) * E + kg * 8;
+        xp16[t] = reinterpret_cast<const u16*>(a.x) + ((long)bh * M + ri) * E + kg * 8;
+        yp16[t] = reinterpret_cast<const u16*>(a.y) + ((long)bh * M + rj) * E + kg * 8;
     }
     f32x4 acc[4][4];
 #pragma unroll
@@ -532,6 +581,19 @@ __global__ __launch_bounds__(NTHREADS) void k_sp_dw(const DwArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (long e = wbeg; e < wend; e += 32) {
+        if constexpr (S16) {   // bf16 summaries: operands as stored
+            bf16x8 xa[4], ya[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                xa[t] = *reinterpret_cast<const bf16x8*>(xp16[t] + e);
+                ya[t] = *reinterpret_cast<const bf16x8*>(yp16[t] + e);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma_bf16(xa[i], ya[j], acc[i][j]);
+            continue;
+        }
         uint4 xh[4], xl[4], yh[4], yl[4];
         f32x4 raw[8][2];
 #pragma unroll
@@ -590,35 +652,6 @@ __global__ __launch_bounds__(NTHREADS) void k_sp_dw(const DwArgs a) {
 template <int DT>
 __host__ __device__ constexpr int sp_tok_smem() { return sp_out_smem<DT>() + Geo<DT>::DW * 4 * 4 + Geo<DT>::DW * 4; }
 
-// D x D fp32 matrix -> LDS [KP][LD] hi / lo (rows, columns >= D zero)
-template <int DT>
-__device__ __forceinline__ void stage_mat_split(u16* __restrict__ Gh, u16* __restrict__ Gl, const float* __restrict__ g, int D, int tid) {
-    constexpr int LD = Geo<DT>::LD, CGS = Geo<DT>::CGS, RPP = Geo<DT>::RPP, KP = Geo<DT>::KST * 32;
-    const int r0 = tid / CGS, cg = (tid % CGS) * 8;
-    constexpr int PASSES = KP / RPP, UB = PASSES < 4 ? PASSES : (PASSES % 4 == 0 ? 4 : (PASSES % 3 == 0 ? 3 : 2));
-    static_assert(PASSES % UB == 0, "staging batches must tile the passes");
-    for (int pb = 0; pb < PASSES; pb += UB) {
-        f32x4 x[UB][2];
-#pragma unroll
-        for (int u = 0; u < UB; ++u) {
-            const int r = r0 + RPP * (pb + u);
-            x[u][0] = x[u][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (r < D && cg < D) {
-                const float* src = g + (long)r * D + cg;
-                x[u][0] = *reinterpret_cast<const f32x4*>(src);
-                x[u][1] = *reinterpret_cast<const f32x4*>(src + 4);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < UB; ++u) {
-            uint4 hi, lo;
-            split8(x[u][0], x[u][1], hi, lo);
-            const int off = (r0 + RPP * (pb + u)) * LD + cg;
-            *reinterpret_cast<uint4*>(Gh + off) = hi;
-            *reinterpret_cast<uint4*>(Gl + off) = lo;
-        }
-    }
-}
 // A operand with the reduction index along the rows' columns: A[m][k] = T[c0 + m][k0 + 8 kg .. + 7]
 __device__ __forceinline__ bf16x8 row_read8(const u16* tile, int ld, int c0, int k0, int lane) {
     return *reinterpret_cast<const bf16x8*>(tile + (c0 + (lane & 15)) * ld + k0 + (lane >> 4) * 8);
@@ -670,7 +703,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_bwd_dq(const TokArgs a) {
         }
     };
     fetch(wave, cur);   // in flight while G_i is staged
-    stage_mat_split<DT>(Gh, Gl, a.g + ((long)bh * M + blk) * D * D, D, tid);
+    constexpr bool S16 = Sum16<T>::value;
+    stage_mat_split<DT, S16>(Gh, Gl, a.g, ((long)bh * M + blk) * D * D, D, tid);
     if (tid < DW) ksum[tid] = (a.normalize && tid < D) ? a.ksum[((long)bh * M + blk) * D + tid] : 0.f;
     __syncthreads();
     f32x4 dksp[DT];
@@ -712,12 +746,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_bwd_dq(const TokArgs a) {
             f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
 #pragma unroll
             for (int ks = 0; ks < KST; ++ks) {
-                const bf16x8 a0h = row_read8(Gh, LD, ct * 16, ks * 32, lane), a0l = row_read8(Gl, LD, ct * 16, ks * 32, lane);
-                const bf16x8 a1h = row_read8(Gh, LD, c1t * 16, ks * 32, lane), a1l = row_read8(Gl, LD, c1t * 16, ks * 32, lane);
+                const bf16x8 a0h = row_read8(Gh, LD, ct * 16, ks * 32, lane), a1h = row_read8(Gh, LD, c1t * 16, ks * 32, lane);
                 c0 = mfma_bf16(a0h, gh[ks], c0);
                 c1 = mfma_bf16(a1h, gh[ks], c1);
-                c0 = mfma_bf16(a0l, gh[ks], c0);
-                c1 = mfma_bf16(a1l, gh[ks], c1);
+                if (!S16) {
+                    const bf16x8 a0l = row_read8(Gl, LD, ct * 16, ks * 32, lane), a1l = row_read8(Gl, LD, c1t * 16, ks * 32, lane);
+                    c0 = mfma_bf16(a0l, gh[ks], c0);
+                    c1 = mfma_bf16(a1l, gh[ks], c1);
+                }
                 c0 = mfma_bf16(a0h, gl[ks], c0);
                 c1 = mfma_bf16(a1h, gl[ks], c1);
             }
@@ -795,7 +831,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_bwd_dkv(const TokArgs a) {
         }
     };
     fetch(wave, cur);
-    stage_mat_split<DT>(Gh, Gl, a.dkv + ((long)bh * M + blk) * D * D, D, tid);
+    constexpr bool S16 = Sum16<T>::value;
+    stage_mat_split<DT, S16>(Gh, Gl, a.dkv, ((long)bh * M + blk) * D * D, D, tid);
     if (tid < DW) dks[tid] = (a.normalize && tid < D) ? a.dks[((long)bh * M + blk) * D + tid] : 0.f;
     __syncthreads();
 
@@ -821,13 +858,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_bwd_dkv(const TokArgs a) {
 #pragma unroll
             for (int ks = 0; ks < KST; ++ks) {
                 // dK^T[d1][s] = sum_d2 dKV[d1][d2] V[s][d2]
-                const bf16x8 ah = row_read8(Gh, LD, ct * 16, ks * 32, lane), al = row_read8(Gl, LD, ct * 16, ks * 32, lane);
+                const bf16x8 ah = row_read8(Gh, LD, ct * 16, ks * 32, lane);
                 // dV^T[d2][s] = sum_d1 dKV[d1][d2] K[s][d1]
-                const bf16x8 th = tr_read8(Gh, LD, ks * 32, ct * 16, lane), tl = tr_read8(Gl, LD, ks * 32, ct * 16, lane);
+                const bf16x8 th = tr_read8(Gh, LD, ks * 32, ct * 16, lane);
                 ck = mfma_bf16(ah, vh[ks], ck);
                 cv = mfma_bf16(th, kh[ks], cv);
-                ck = mfma_bf16(al, vh[ks], ck);
-                cv = mfma_bf16(tl, kh[ks], cv);
+                if (!S16) {
+                    const bf16x8 al = row_read8(Gl, LD, ct * 16, ks * 32, lane), tl = tr_read8(Gl, LD, ks * 32, ct * 16, lane);
+                    ck = mfma_bf16(al, vh[ks], ck);
+                    cv = mfma_bf16(tl, kh[ks], cv);
+                }
                 if (LO) {
                     ck = mfma_bf16(ah, vl[ks], ck);
                     cv = mfma_bf16(th, kl[ks], cv);
