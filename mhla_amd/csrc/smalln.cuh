@@ -166,6 +166,8 @@ __global__ __launch_bounds__(SN_T, 2) void k_sn_fwd(const SnArgs a) {
     const u16* vb = (const u16*)a.v.ptr + b * a.v.sb + h * a.v.sh;
     u16* ob = (u16*)a.out.ptr + b * a.out.sb + h * a.out.sh;
 
+    __shared__ float Wsh[16 * 17];   // mixing weights (M <= 16): read in the inner loops, so kept off the global-load path
+    if (tid < 256) Wsh[(tid >> 4) * 17 + (tid & 15)] = ((tid >> 4) < M && (tid & 15) < M) ? a.W[(long)(tid >> 4) * a.ldw + (tid & 15)] : 0.f;
     if (a.relu) sn_stage<DT, true>(Ks, kb, a.k.sn, a.idx, N, D, a.eps, tid);
     else        sn_stage<DT, false>(Ks, kb, a.k.sn, a.idx, N, D, a.eps, tid);
     sn_stage<DT, false>(Vs, vb, a.v.sn, a.idx, N, D, 0.f, tid);
@@ -212,7 +214,7 @@ __global__ __launch_bounds__(SN_T, 2) void k_sn_fwd(const SnArgs a) {
         float ninv = 1.f;   // lane n = row s of the block
         if (a.normalize) {
             float nn = a.eps;
-            for (int j = 0; j < M; ++j) nn += a.W[(long)i * a.ldw + j] * zs[j * 16 + n];
+            for (int j = 0; j < M; ++j) nn += Wsh[i * 17 + j] * zs[j * 16 + n];
             ninv = 1.f / nn;
         }
         f32x4 acc[DT];
@@ -221,7 +223,7 @@ __global__ __launch_bounds__(SN_T, 2) void k_sn_fwd(const SnArgs a) {
 #pragma unroll 2
         for (int j0 = 0; j0 < M; j0 += 2) {
             const int j1 = j0 + 1 < M ? j0 + 1 : j0;
-            const float w0 = a.W[(long)i * a.ldw + j0], w1 = j0 + 1 < M ? a.W[(long)i * a.ldw + j0 + 1] : 0.f;
+            const float w0 = Wsh[i * 17 + j0], w1 = j0 + 1 < M ? Wsh[i * 17 + j0 + 1] : 0.f;
             f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
             bf16x8 ka[KS], kb2[KS];
             sn_lds_rows<KS>(ka, Ks, LDR, j0 * 16, D, lane);
@@ -327,6 +329,8 @@ __global__ __launch_bounds__(SN_T, 2) void k_sn_bwd(const SnArgs a) {
     };
 
     // ---- P0 / P1: K, V tiles; ksum ----
+    __shared__ float Wsh[16 * 17];   // mixing weights (M <= 16), read in every inner loop
+    if (tid < 256) Wsh[(tid >> 4) * 17 + (tid & 15)] = ((tid >> 4) < M && (tid & 15) < M) ? a.W[(long)(tid >> 4) * a.ldw + (tid & 15)] : 0.f;
     if (a.relu) sn_stage<DT, true>(T0, kb, a.k.sn, a.idx, N, D, a.eps, tid);
     else        sn_stage<DT, false>(T0, kb, a.k.sn, a.idx, N, D, a.eps, tid);
     sn_stage<DT, false>(T1, vb, a.v.sn, a.idx, N, D, 0.f, tid);
@@ -367,7 +371,7 @@ __global__ __launch_bounds__(SN_T, 2) void k_sn_bwd(const SnArgs a) {
         for (int v = tid; v < N; v += SN_T) {
             const int i = v >> 4, sx = v & 15;
             float nn = a.eps;
-            for (int j = 0; j < M; ++j) nn += a.W[(long)i * a.ldw + j] * zs[j * 16 + sx];
+            for (int j = 0; j < M; ++j) nn += Wsh[i * 17 + j] * zs[j * 16 + sx];
             const float ni = 1.f / nn;
             nis[v] = ni;
             dns[v] = -rds[v] * ni;
@@ -377,7 +381,7 @@ __global__ __launch_bounds__(SN_T, 2) void k_sn_bwd(const SnArgs a) {
         for (int v = tid; v < N; v += SN_T) {
             const int j = v >> 4, sx = v & 15;
             float dz = 0.f;
-            for (int i = 0; i < M; ++i) dz += a.W[(long)i * a.ldw + j] * dns[i * 16 + sx];
+            for (int i = 0; i < M; ++i) dz += Wsh[i * 17 + j] * dns[i * 16 + sx];
             dzs[v] = dz;
         }
         __syncthreads();
@@ -399,7 +403,7 @@ __global__ __launch_bounds__(SN_T, 2) void k_sn_bwd(const SnArgs a) {
             if (j0 < M) {
                 const bool has1 = j0 + 1 < M;
                 const int j1 = has1 ? j0 + 1 : j0;
-                const float w0 = a.W[(long)i * a.ldw + j0], w1 = has1 ? a.W[(long)i * a.ldw + j1] : 0.f;
+                const float w0 = Wsh[i * 17 + j0], w1 = has1 ? Wsh[i * 17 + j1] : 0.f;
                 f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, p0 = s0, p1 = s0;
                 bf16x8 t0[KS], t1[KS];
                 sn_lds_rows<KS>(t0, T0, LDR, j0 * 16, D, lane);
@@ -483,7 +487,7 @@ __global__ __launch_bounds__(SN_T, 2) void k_sn_bwd(const SnArgs a) {
         for (int i0 = 0; i0 < M; i0 += 2) {
             const bool has1 = i0 + 1 < M;
             const int i1 = has1 ? i0 + 1 : i0;
-            const float w0 = a.W[(long)i0 * a.ldw + j], w1 = has1 ? a.W[(long)i1 * a.ldw + j] : 0.f;
+            const float w0 = Wsh[i0 * 17 + j], w1 = has1 ? Wsh[i1 * 17 + j] : 0.f;
             f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, p0 = s0, p1 = s0;
             bf16x8 t0[KS], t1[KS];
             sn_lds_rows<KS>(t0, T0, LDR, i0 * 16, D, lane);

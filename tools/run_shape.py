@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Run a few iterations of one BASELINE.json shape (for rocprofv3):  run_shape.py c4|c4b|c5|xl [iters]"""
+"""Run a few iterations of one BASELINE.json shape (for rocprofv3):  run_shape.py c3|c4|c4b|c5|xl [iters]"""
 import os
 import sys
 
@@ -30,6 +30,16 @@ if which in ("c4", "c4b"):
             o.backward(do)
             for t in ts + [W]:
                 t.grad = None
+elif which == "c3":
+    B, N, H, D = 32, 256, 16, 72
+    ts = [torch.randn(B, N, H, D, generator=g).abs().bfloat16().to(DEV).requires_grad_(True) for _ in range(3)]
+    do = torch.randn(B, N, H, D, generator=g).bfloat16().to(DEV)
+    W = block_distance_weights((4, 4), "linear").to(DEV).requires_grad_(True)
+
+    def step():
+        mhla_amd.mhla_blockmix(ts[0], ts[1], ts[2], W).backward(do)
+        for t in ts + [W]:
+            t.grad = None
 elif which == "xl":
     B, N, H, D = 16, 1024, 16, 72
     ts = [torch.randn(B, N, H, D, generator=g).abs().bfloat16().to(DEV).requires_grad_(True) for _ in range(3)]
