@@ -80,6 +80,29 @@ int launch(K kernel, dim3 grid, dim3 block, size_t smem, hipStream_t stream, con
     return MHLA_OK;
 }
 
+// A per-device side stream for work that is independent of the main chain (the dW reduction of the fast-path backward): forked
+// from and joined back into the caller's stream with events, so the caller still sees one in-order stream (and a hipGraph
+// capture of the caller's stream records the fork and the join).  MHLA_NO_SIDE_STREAM=1 keeps everything on one stream.
+struct SideStream {
+    hipStream_t s = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+};
+std::mutex g_side_mu;   // held while a fork .. join section is enqueued: the events are shared per device
+SideStream* side_stream() {
+    static std::map<int, SideStream> per_dev;
+    static const bool off = getenv("MHLA_NO_SIDE_STREAM") != nullptr;
+    if (off) return nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    SideStream& ss = per_dev[dev];
+    if (!ss.s) {
+        if (hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking) != hipSuccess) { ss.s = nullptr; return nullptr; }
+        if (hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ss.join, hipEventDisableTiming) != hipSuccess) return nullptr;
+    }
+    return &ss;
+}
+
 View cv(const mhla_view& v) { return View{v.ptr, (long)v.sb, (long)v.sn, (long)v.sh}; }
 MView cmv(const mhla_mview& v) { return MView{v.ptr, (long)v.sb, (long)v.sn, (long)v.sh}; }
 
@@ -511,13 +534,20 @@ int mhla_blockmix_bwd(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q
             ga.state = f.dstate; ga.dn = f.dn; ga.H = H; ga.M = M; ga.S = S; ga.eps = eps; ga.relu = relu; ga.normalize = normalize;
             RC(launch(fast::k_fs_state<1>, dim3(f.njg, B * H), dim3(fast::FT8), fast::FS_STATE_SMEM, st, "k_fs_state<1>", ga));
             fast::FsDwArgs da{f.dstate, state, normalize ? f.dn : nullptr, z, f.dwp, M, S, f.njg};
+            // dW needs only dG^T, KV^T, dn and z, all complete here: its four launches (one bandwidth-bound GEMM and three short
+            // latency-bound reductions) go to the side stream and overlap the token-gradient kernels of the main chain
+            std::unique_lock<std::mutex> side_lk(g_side_mu);
+            SideStream* ss = side_stream();
+            hipStream_t sd = st;
+            if (ss && hipEventRecord(ss->fork, st) == hipSuccess && hipStreamWaitEvent(ss->s, ss->fork, 0) == hipSuccess) sd = ss->s;
+            else side_lk.unlock();
+            RC(launch(fast::k_fs_dw, dim3(fast::DW_SPLIT, B * H), dim3(fast::FT8), fast::FS_DW_SMEM, sd, "k_fs_dw", da));
+            RC(launch(fast::k_fs_dwz, dim3(B * H), dim3(fast::FT), 0, sd, "k_fs_dwz", normalize ? (const float*)f.dn : (const float*)nullptr, z, f.dwp, M, S));
+            const int nparts = B * H * (fast::DW_SPLIT + 1), ngroups = (nparts + fast::DWR_G - 1) / fast::DWR_G;
+            RC(launch(fast::k_fs_dw_reduce1, dim3(16, ngroups), dim3(256), 0, sd, "k_fs_dw_reduce1", (const float*)f.dwp, f.dwt, nparts));
+            RC(launch(fast::k_fs_dw_reduce2, dim3((M * M + 255) / 256), dim3(256), 0, sd, "k_fs_dw_reduce2", (const float*)f.dwt, dW, M, ngroups));
             if (normalize)
                 RC(launch(fast::k_fs_wz<1>, dim3((S + 63) / 64, B * H), dim3(fast::FT), 0, st, "k_fs_wz<1>", W, ldw, (const float*)f.dn, f.dz, M, S, 0.f));
-            RC(launch(fast::k_fs_dw, dim3(fast::DW_SPLIT, B * H), dim3(fast::FT8), fast::FS_DW_SMEM, st, "k_fs_dw", da));
-            RC(launch(fast::k_fs_dwz, dim3(B * H), dim3(fast::FT), 0, st, "k_fs_dwz", normalize ? (const float*)f.dn : (const float*)nullptr, z, f.dwp, M, S));
-            const int nparts = B * H * (fast::DW_SPLIT + 1), ngroups = (nparts + fast::DWR_G - 1) / fast::DWR_G;
-            RC(launch(fast::k_fs_dw_reduce1, dim3(16, ngroups), dim3(256), 0, st, "k_fs_dw_reduce1", (const float*)f.dwp, f.dwt, nparts));
-            RC(launch(fast::k_fs_dw_reduce2, dim3((M * M + 255) / 256), dim3(256), 0, st, "k_fs_dw_reduce2", (const float*)f.dwt, dW, M, ngroups));
             fast::FsTokArgs ta{};
             ta.q = cv(q_num); ta.k = cv(k_num); ta.v = cv(v); ta.dout = cv(dout); ta.dq = cmv(dq_num); ta.dk = cmv(dk_num);
             ta.dv = cmv(dv); ta.idx = block_index; ta.W = W; ta.ldw = ldw; ta.state = state; ta.dstate = f.dstate; ta.ninv = ninv;
@@ -526,6 +556,10 @@ int mhla_blockmix_bwd(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q
             ta.dksum = f.dksum;
             RC(launch(fast::k_t16_bwd_dq, dim3(((f.njg + 1) / 2) * B * H), dim3(fast::FT8), fast::FS_GT16_BYTES, st, "k_t16_bwd_dq", ta));
             RC(launch(fast::k_t16_bwd_dkv, dim3(((f.njg + 1) / 2) * B * H), dim3(fast::FT8), fast::FS_GT16_BYTES, st, "k_t16_bwd_dkv", ta));
+            if (sd != st) {   // join: the caller's stream continues only after dW is complete
+                if (hipEventRecord(ss->join, sd) != hipSuccess || hipStreamWaitEvent(st, ss->join, 0) != hipSuccess)
+                    return fail(MHLA_ELAUNCH, "side stream join failed: %s", hipGetErrorString(hipGetLastError()));
+            }
             return MHLA_OK;
         }
     }
