@@ -314,3 +314,21 @@ def test_thin_dit_host_matches_cpu_composition():
     out = m(x.to(DEV), t.to(DEV), y.to(DEV))
     out.square().mean().backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters() if p.requires_grad)
+
+
+def test_minimal_gpt_host_trains_a_step():
+    """The minimal GPT host around the fla MHLA layer: finite loss and gradients for every parameter,
+    causal (logits at position t do not change when later tokens change)."""
+    from mhla_amd.hosts import GPT_MHLA
+    torch.manual_seed(0)
+    m = GPT_MHLA(vocab_size=97, hidden_size=128, num_layers=2, num_heads=2).to(DEV)
+    ids = torch.randint(0, 97, (2, 200), device=DEV)
+    loss = m(ids, labels=ids)
+    loss.backward()
+    assert torch.isfinite(loss) and all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+    with torch.no_grad():
+        a = m(ids)
+        ids2 = ids.clone()
+        ids2[:, 150:] = (ids2[:, 150:] + 1) % 97
+        b = m(ids2)
+    check("causal prefix", a[:, :150], b[:, :150].cpu(), 1e-5)
