@@ -660,7 +660,7 @@ int mhla_causal_fwd(mhla_view q, mhla_view k, mhla_view v, const float* mix, int
         fast::CsfMixArgs m{mix, ldmix, (const uint16_t*)w.S, (uint16_t*)w.P, n, E};
         RC(launch(fast::k_csf_mix<0>, dim3((unsigned)(E / fast::MX_TE), (n + 63) / 64, B * H), dim3(NTHREADS), fast::CSF_MIX_SMEM, st, "k_csf_mix<0>", m));
         CsOutArgs o{cv(q), cv(k), cv(v), cmv(out), mix, ldmix, w.P, H, n, K, V, (long)T, scale};
-        RC(launch(fast::k_csf_out<uint16_t>, dim3(n, B * H, V / 64), dim3(NTHREADS), fast::CSF_OUT_SMEM, st, "k_csf_out", o));
+        RC(launch(fast::k_csf_out<uint16_t>, dim3(n, B * H, (V / 64 + fast::CSF_OUT_VS - 1) / fast::CSF_OUT_VS), dim3(NTHREADS), fast::CSF_OUT_SMEM, st, "k_csf_out", o));
         return MHLA_OK;
     }
     DISPATCH_T(dtype, {

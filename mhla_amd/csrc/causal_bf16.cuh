@@ -95,17 +95,20 @@ __device__ __forceinline__ void cs_store_tok(u16* __restrict__ base, long sn, lo
 
 constexpr int CSF_OUT_SMEM = 4 * CT * 2;
 
-// O_i[:, v-slice] = scale (Q_i P_i + m_ii tril(Q_i K_i^T) V_i)      grid (n, bh, V / 64)
+// O_i = scale (Q_i P_i + m_ii tril(Q_i K_i^T) V_i)      grid (n, bh, ceil(V / 256))
+// A workgroup owns up to four 64-wide V slices of a chunk: Q_i, K_i are staged and tril(Q_i K_i^T) is computed once for all
+// of them (one workgroup per slice re-read Q, K and redid the score tile per slice: 2x the HBM reads of this kernel).
+constexpr int CSF_OUT_VS = 4;
 template <typename ST>   // ST: element type of the chunk summaries (u16 = bf16, float)
 __global__ __launch_bounds__(NTHREADS) void k_csf_out(const CsOutArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    u16* Qs = reinterpret_cast<u16*>(smem_raw);
+    u16* Qs = reinterpret_cast<u16*>(smem_raw);   // Q slice, later the output staging
     u16* Ks = Qs + CT;
     u16* Ps = Ks + CT;      // P slice, later the V slice
-    u16* As = Ps + CT;      // m_ii tril(QK^T), later the output staging
+    u16* As = Ps + CT;      // m_ii tril(QK^T)
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, n = lane & 15, kg = lane >> 4;
     const int ci = blockIdx.x, bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
-    const int v0 = blockIdx.z * 64;
+    const int vbase = blockIdx.z * 64 * CSF_OUT_VS, nv = min(CSF_OUT_VS, (a.V - vbase) / 64);
     const long p0 = (long)ci * CS;
     const int rv = (int)min((long)CS, a.T - p0);
     const u16* qb = (const u16*)a.q.ptr + b * a.q.sb + h * a.q.sh;
@@ -114,17 +117,27 @@ __global__ __launch_bounds__(NTHREADS) void k_csf_out(const CsOutArgs a) {
     u16* ob = (u16*)a.o.ptr + b * a.o.sb + h * a.o.sh;
     const ST* Pi = reinterpret_cast<const ST*>(a.P) + ((long)bh * a.n + ci) * a.K * a.V;
 
-    f32x4 accO[4], accA[4];
-    zero4(accO);
+    f32x4 accO[CSF_OUT_VS][4], accA[4];
+#pragma unroll
+    for (int j = 0; j < CSF_OUT_VS; ++j) zero4(accO[j]);
     zero4(accA);
     for (int ks = 0; ks < a.K; ks += 64) {
         cs_stage_tok(Qs, qb + ks, a.q.sn, p0, rv, tid);
         cs_stage_tok(Ks, kb + ks, a.k.sn, p0, rv, tid);
-        cs_stage_state(Ps, Pi + (long)ks * a.V + v0, a.V, tid);
+        cs_stage_state(Ps, Pi + (long)ks * a.V + vbase, a.V, tid);
         __syncthreads();
         tile_mma<false, false>(accA, Qs, Ks, wave, lane);   // Q K^T
-        tile_mma<false, true>(accO, Qs, Ps, wave, lane);    // Q P
-        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < CSF_OUT_VS; ++j) {
+            if (j < nv) {
+                tile_mma<false, true>(accO[j], Qs, Ps, wave, lane);    // Q P
+                __syncthreads();
+                if (j + 1 < nv) {
+                    cs_stage_state(Ps, Pi + (long)ks * a.V + vbase + 64 * (j + 1), a.V, tid);
+                    __syncthreads();
+                }
+            }
+        }
     }
     const float mii = a.mix[(long)ci * a.ldmix + ci];
 #pragma unroll
@@ -134,13 +147,17 @@ __global__ __launch_bounds__(NTHREADS) void k_csf_out(const CsOutArgs a) {
             const int row = wave * 16 + kg * 4 + r, col = tn * 16 + n;
             As[row * CLD + col] = cvt_bf16(col <= row ? mii * accA[tn][r] : 0.f);
         }
-    cs_stage_tok(Ps, vb + v0, a.v.sn, p0, rv, tid);
-    __syncthreads();
-    tile_mma<false, true>(accO, As, Ps, wave, lane);        // tril(QK^T) V
-    __syncthreads();
-    cs_put(As, accO, a.scale, wave, lane);
-    __syncthreads();
-    cs_store_tok(ob + v0, a.o.sn, p0, rv, As, tid);
+#pragma unroll
+    for (int j = 0; j < CSF_OUT_VS; ++j) {
+        if (j < nv) {
+            cs_stage_tok(Ps, vb + vbase + 64 * j, a.v.sn, p0, rv, tid);
+            __syncthreads();
+            tile_mma<false, true>(accO[j], As, Ps, wave, lane);        // tril(QK^T) V
+            cs_put(Qs, accO[j], a.scale, wave, lane);
+            __syncthreads();
+            cs_store_tok(ob + vbase + 64 * j, a.o.sn, p0, rv, Qs, tid);
+        }
+    }
 }
 
 constexpr int CSF_TOK_SMEM = 6 * CT * 2 + 16;
