@@ -710,7 +710,10 @@ int mhla_causal_bwd(mhla_view q, mhla_view k, mhla_view v, const float* mix, int
         fast::CsfMixArgs mt{mix, ldmix, dP, dS, n, E};
         RC(launch(fast::k_csf_mix<1>, mgrid, dim3(NTHREADS), fast::CSF_MIX_SMEM, st, "k_csf_mix<1>", mt));
         CsTokArgs t{cv(q), cv(k), cv(v), cv(dout), cmv(dq), cmv(dk), cmv(dv), mix, ldmix, w.P, w.dS, w.diag, H, n, K, V, (long)T, scale};
-        RC(launch(fast::k_csf_bwd_tok<uint16_t>, dim3(n, B * H), dim3(NTHREADS), fast::CSF_TOK_SMEM, st, "k_csf_bwd_tok", t));
+        if (V <= 128)      RC(launch(fast::k_csf_bwd_tok2<uint16_t, 2>, dim3(n, B * H), dim3(NTHREADS), fast::CSF_TOK2_SMEM, st, "k_csf_bwd_tok", t));
+        else if (V <= 256) RC(launch(fast::k_csf_bwd_tok2<uint16_t, 4>, dim3(n, B * H), dim3(NTHREADS), fast::CSF_TOK2_SMEM, st, "k_csf_bwd_tok", t));
+        else if (V <= 512) RC(launch(fast::k_csf_bwd_tok2<uint16_t, 8>, dim3(n, B * H), dim3(NTHREADS), fast::CSF_TOK2_SMEM, st, "k_csf_bwd_tok", t));
+        else               RC(launch(fast::k_csf_bwd_tok<uint16_t>, dim3(n, B * H), dim3(NTHREADS), fast::CSF_TOK_SMEM, st, "k_csf_bwd_tok", t));
         fast::CsfDwArgs d{dP, S, E, w.dwp, n, tiles, nsplit};
         RC(launch(fast::k_csf_dw, dim3(tiles * tiles, B * H, nsplit), dim3(NTHREADS), fast::CSF_DW_SMEM, st, "k_csf_dw", d));
         RC(launch(k_dw_reduce<1>, dim3((n * n + 63) / 64), dim3(256), 0, st, "k_dw_reduce<1>", (const float*)w.dwp,

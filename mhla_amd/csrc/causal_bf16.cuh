@@ -273,6 +273,123 @@ __global__ __launch_bounds__(NTHREADS) void k_csf_bwd_tok(const CsTokArgs a) {
 }
 
 
+// The same token gradients with dV accumulated alongside dQ / dK: the K slice of the outer loop stays in LDS and every staged
+// dS slice also feeds dV[v-slice] += K dS, so dS is read once (not twice) and K is not re-read per V slice.  V / 64 <= NVMAX
+// accumulator sets live in registers.
+constexpr int CSF_TOK2_SMEM = 7 * CT * 2 + 16;
+
+template <typename ST, int NVMAX>
+__global__ __launch_bounds__(NTHREADS) void k_csf_bwd_tok2(const CsTokArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u16* As = reinterpret_cast<u16*>(smem_raw);   // m_ii scale tril(Q K^T)   [c][c']
+    u16* dAs = As + CT;                           // m_ii tril(dO V^T)        [c][c']
+    u16* X1 = dAs + CT;
+    u16* X2 = X1 + CT;
+    u16* B1 = X2 + CT;
+    u16* B2 = B1 + CT;
+    u16* X3 = B2 + CT;                            // K slice of the outer loop
+    float* red = reinterpret_cast<float*>(X3 + CT);
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, n = lane & 15, kg = lane >> 4;
+    const int ci = blockIdx.x, bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
+    const long p0 = (long)ci * CS;
+    const int rv = (int)min((long)CS, a.T - p0);
+    const int K = a.K, V = a.V, nvs = V / 64;
+    auto base = [&](const View& w) { return (const u16*)w.ptr + b * w.sb + h * w.sh; };
+    auto mbase = [&](const MView& w) { return (u16*)w.ptr + b * w.sb + h * w.sh; };
+    const u16 *qb = base(a.q), *kb = base(a.k), *vb = base(a.v), *gb = base(a.dout);
+    const ST* Pi = reinterpret_cast<const ST*>(a.P) + ((long)bh * a.n + ci) * K * V;
+    const ST* dSi = reinterpret_cast<const ST*>(a.dS) + ((long)bh * a.n + ci) * K * V;
+    const float mii = a.mix[(long)ci * a.ldmix + ci];
+
+    // ---- step 1: A = tril(Q K^T), dA = tril(dO V^T), diag = scale * sum(A . dA) ----
+    f32x4 acc1[4], acc2[4];
+    zero4(acc1);
+    zero4(acc2);
+    for (int ks = 0; ks < K; ks += 64) {
+        cs_stage_tok(X1, qb + ks, a.q.sn, p0, rv, tid);
+        cs_stage_tok(X2, kb + ks, a.k.sn, p0, rv, tid);
+        __syncthreads();
+        tile_mma<false, false>(acc1, X1, X2, wave, lane);
+        __syncthreads();
+    }
+    for (int vs = 0; vs < V; vs += 64) {
+        cs_stage_tok(X1, gb + vs, a.dout.sn, p0, rv, tid);
+        cs_stage_tok(X2, vb + vs, a.v.sn, p0, rv, tid);
+        __syncthreads();
+        tile_mma<false, false>(acc2, X1, X2, wave, lane);
+        __syncthreads();
+    }
+    float dsum = 0.f;
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = wave * 16 + kg * 4 + r, col = tn * 16 + n;
+            const bool keep = col <= row;
+            const float av = keep ? acc1[tn][r] : 0.f, dv = keep ? acc2[tn][r] : 0.f;
+            dsum += av * dv;
+            As[row * CLD + col] = cvt_bf16(mii * a.scale * av);
+            dAs[row * CLD + col] = cvt_bf16(mii * dv);
+        }
+    dsum = wave_sum(dsum);
+    if (lane == 0) red[wave] = dsum;
+    __syncthreads();
+    if (tid == 0) a.diag[(long)bh * a.n + ci] = a.scale * (red[0] + red[1] + red[2] + red[3]);
+
+    // ---- step 2: dQ, dK per K slice; dV += K dS on the way ----
+    f32x4 accV[NVMAX][4];
+#pragma unroll
+    for (int j = 0; j < NVMAX; ++j) zero4(accV[j]);
+    for (int ks = 0; ks < K; ks += 64) {
+        f32x4 acc3[4];
+        zero4(acc1);   // dO P^T + m_ii dA K
+        zero4(acc2);   // V dS^T
+        zero4(acc3);   // m_ii dA^T Q
+        cs_stage_tok(X3, kb + ks, a.k.sn, p0, rv, tid);
+#pragma unroll
+        for (int j = 0; j < NVMAX; ++j) {
+            if (j < nvs) {
+                const int vs = j * 64;
+                cs_stage_tok(X1, gb + vs, a.dout.sn, p0, rv, tid);
+                cs_stage_tok(X2, vb + vs, a.v.sn, p0, rv, tid);
+                cs_stage_state(B1, Pi + (long)ks * V + vs, V, tid);
+                cs_stage_state(B2, dSi + (long)ks * V + vs, V, tid);
+                __syncthreads();
+                tile_mma<false, false>(acc1, X1, B1, wave, lane);       // dO P^T
+                tile_mma<false, false>(acc2, X2, B2, wave, lane);       // V dS^T
+                tile_mma<false, true>(accV[j], X3, B2, wave, lane);     // K dS : B[k = kk][n = v] = dS[kk][v]
+                __syncthreads();
+            }
+        }
+        cs_stage_tok(X2, qb + ks, a.q.sn, p0, rv, tid);
+        __syncthreads();
+        tile_mma<false, true>(acc1, dAs, X3, wave, lane);       // dA K
+        tile_mma<true, true>(acc3, dAs, X2, wave, lane);        // dA^T Q
+        __syncthreads();
+        cs_put(B1, acc1, a.scale, wave, lane);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc2[i] += a.scale * acc3[i];
+        cs_put(B2, acc2, 1.f, wave, lane);
+        __syncthreads();
+        cs_store_tok(mbase(a.dq) + ks, a.dq.sn, p0, rv, B1, tid);
+        cs_store_tok(mbase(a.dk) + ks, a.dk.sn, p0, rv, B2, tid);
+        __syncthreads();
+    }
+
+    // ---- step 3: dV += A^T dO per V slice ----
+#pragma unroll
+    for (int j = 0; j < NVMAX; ++j) {
+        if (j < nvs) {
+            cs_stage_tok(X2, gb + j * 64, a.dout.sn, p0, rv, tid);
+            __syncthreads();
+            tile_mma<true, true>(accV[j], As, X2, wave, lane);     // A^T dO
+            cs_put(B1, accV[j], 1.f, wave, lane);
+            __syncthreads();
+            cs_store_tok(mbase(a.dv) + j * 64, a.dv.sn, p0, rv, B1, tid);
+        }
+    }
+}
+
 // -------------------------------------------------------------------------------------------------
 // k_csf_state: out[bh][ci][kk][v] (bf16) = mul * sum_{c in chunk ci} X[c][kk] Y[c][v]        grid (n, bh, K / 64)
 //   forward: X = K, Y = V (S_j, naive.py:60);  backward: X = Q, Y = dO, mul = scale (dP_i)
