@@ -324,6 +324,60 @@ def test_full_size_c2_properties_and_sampled_heads():
     assert not torch.equal(oa[:, ~mask], ob[:, ~mask])
 
 
+def test_more_than_2_31_elements_per_tensor():
+    """Maximum sizes: 2.2e9 elements (4.4 GB) per token tensor -- element offsets no longer fit 32 bits.  Inputs are generated
+    on the device; the first, a middle and the last (b, h) slices are checked against the oracle, forward and backward."""
+    import mhla_amd
+    B, N, H, D, M = 528, 4096, 16, 64, 64
+    assert B * N * H * D > 2 ** 31
+    gen = torch.Generator(device=DEV).manual_seed(7)
+    mk = lambda relu: (torch.randn(B, N, H, D, device=DEV, dtype=torch.bfloat16, generator=gen).relu_().add_(1e-3) if relu
+                       else torch.randn(B, N, H, D, device=DEV, dtype=torch.bfloat16, generator=gen))
+    q, k, v, do = mk(True), mk(True), mk(False), mk(False)
+    W = orc.block_distance_weights((8, 8), "linear")
+    Wd = W.to(DEV).requires_grad_(True)
+    for t in (q, k, v):
+        t.requires_grad_(True)
+    out = mhla_amd.mhla_blockmix(q, k, v, Wd)
+    out.backward(do)
+    for (b, h) in [(0, 0), (263, 9), (B - 1, H - 1)]:
+        sl = lambda t: t.detach()[b:b + 1, :, h:h + 1].cpu()
+        want, wg = oracle_blockmix(sl(q), sl(k), sl(v), W, sl(do), None, None, 1e-6, True)
+        check("out", sl(out), want, TOL[torch.bfloat16])
+        check("dq", sl(q.grad), wg["dq"], GTOL[torch.bfloat16])
+        check("dk", sl(k.grad), wg["dk"], GTOL[torch.bfloat16])
+        check("dv", sl(v.grad), wg["dv"], GTOL[torch.bfloat16])
+    assert torch.isfinite(Wd.grad).all()
+    del q, k, v, do, out
+    torch.cuda.empty_cache()
+
+
+def test_more_than_2_31_elements_split_path():
+    """The same on the split-operand path (DiT-XL/2 512x512 shape, D = 72, bf16): 2.15e9 elements per tensor, 29 184 (b, h) pairs."""
+    import mhla_amd
+    B, N, H, D, M = 1824, 1024, 16, 72, 16
+    assert B * N * H * D > 2 ** 31 and B * H <= 65535
+    gen = torch.Generator(device=DEV).manual_seed(11)
+    mk = lambda relu: (torch.randn(B, N, H, D, device=DEV, dtype=torch.bfloat16, generator=gen).relu_().add_(1e-3) if relu
+                       else torch.randn(B, N, H, D, device=DEV, dtype=torch.bfloat16, generator=gen))
+    q, k, v, do = mk(True), mk(True), mk(False), mk(False)
+    W = orc.block_distance_weights((4, 4), "linear")
+    Wd = W.to(DEV).requires_grad_(True)
+    for t in (q, k, v):
+        t.requires_grad_(True)
+    out = mhla_amd.mhla_blockmix(q, k, v, Wd)
+    out.backward(do)
+    for (b, h) in [(0, 0), (B - 1, H - 1)]:
+        sl = lambda t: t.detach()[b:b + 1, :, h:h + 1].cpu()
+        want, wg = oracle_blockmix(sl(q), sl(k), sl(v), W, sl(do), None, None, 1e-6, True)
+        check("out", sl(out), want, TOL[torch.bfloat16])
+        check("dq", sl(q.grad), wg["dq"], GTOL[torch.bfloat16])
+        check("dk", sl(k.grad), wg["dk"], GTOL[torch.bfloat16])
+        check("dv", sl(v.grad), wg["dv"], GTOL[torch.bfloat16])
+    del q, k, v, do, out
+    torch.cuda.empty_cache()
+
+
 def test_full_size_c4_wan_sampled_head():
     """BASELINE config C4 (Wan2.1-1.3B: N = 31500 = 150 blocks x 210 tokens, H = 12, D = 128, fp32, roped numerator pair
     / un-roped normaliser pair, raster tokens gathered through the block index): forward on all heads, one head vs oracle."""

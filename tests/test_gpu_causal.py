@@ -104,6 +104,35 @@ def test_causal_kept_summaries_match_recompute(dtype, monkeypatch):
         assert torch.equal(a, b), name
 
 
+def test_causal_more_than_2_31_elements():
+    """Maximum sizes for the causal operator: V tensors of 2.1e9 elements (B=272, T=8192, H=4, V=256), chunk summaries of
+    8.6 GB each; sampled (b, h) slices vs the oracle, forward and backward."""
+    import mhla_amd
+    B, T, H, K, V = 272, 8192, 4, 128, 256
+    assert B * T * H * V > 2 ** 31
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    mk = lambda d: torch.randn(B, T, H, d, device=DEV, dtype=torch.bfloat16, generator=gen)
+    q, k, v, do = mk(K), mk(K), mk(V), mk(V)
+    n = T // 64
+    mix = torch.tril(torch.rand(n, n, generator=torch.Generator().manual_seed(1)).clamp(1e-5, 1))
+    md = mix.to(DEV).requires_grad_(True)
+    for t in (q, k, v):
+        t.requires_grad_(True)
+    out = mhla_amd.mhla_causal(q, k, v, md)
+    out.backward(do)
+    for (b, h) in [(0, 0), (B - 1, H - 1)]:
+        sl = lambda t: t.detach()[b:b + 1, :, h:h + 1].float().cpu()
+        want = orc.causal_fwd(sl(q), sl(k), sl(v), mix)
+        wg = orc.causal_bwd(sl(q), sl(k), sl(v), mix, sl(do))
+        check("out", sl(out), want, TOL[torch.bfloat16])
+        check("dq", sl(q.grad), wg["dq"], GTOL[torch.bfloat16])
+        check("dk", sl(k.grad), wg["dk"], GTOL[torch.bfloat16])
+        check("dv", sl(v.grad), wg["dv"], GTOL[torch.bfloat16])
+    assert torch.isfinite(md.grad).all()
+    del q, k, v, do, out
+    torch.cuda.empty_cache()
+
+
 def test_causal_bf16_strided_views():
     """q/k/v as slices of one fused projection buffer (row stride 3 * H * K): the views stay 16-byte aligned."""
     import mhla_amd
