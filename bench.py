@@ -35,7 +35,9 @@ def parse():
     p.add_argument("--M", type=int, default=64)
     p.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "f16"])
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--graph", action="store_true", help="capture the fwd+bwd step in a HIP graph and replay it (removes the Python launch path)")
+    p.add_argument("--no-graph", dest="graph", action="store_false",
+                   help="launch every step eagerly through Python autograd instead of replaying the captured HIP graph")
+    p.set_defaults(graph=True)
     return p.parse_args()
 
 
@@ -125,23 +127,36 @@ def main():
         q.grad = k.grad = v.grad = W.grad = None
 
     sync = torch.cuda.synchronize
+    eager_step = step
+    launch_mode = "eager (Python autograd)"
     if a.graph:
-        # whole-step capture: the same launches, replayed by the runtime (static inputs / gradients in the graph's pool)
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(3):
+        # Whole-step capture: the forward + backward (both autograd calls, their workspace allocations, every launch) is
+        # recorded once in a HIP graph and replayed -- the same work with no Python on the launch path, so the number does
+        # not depend on the host's speed.  Falls back to eager launches if the capture is refused.
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    mhla_amd.mhla_blockmix(q, k, v, W, eps=1e-6).backward(do)
+            torch.cuda.current_stream().wait_stream(side)
+            q.grad = k.grad = v.grad = W.grad = None
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
                 mhla_amd.mhla_blockmix(q, k, v, W, eps=1e-6).backward(do)
-        torch.cuda.current_stream().wait_stream(side)
-        q.grad = k.grad = v.grad = W.grad = None
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            mhla_amd.mhla_blockmix(q, k, v, W, eps=1e-6).backward(do)
-        eager_step = step
 
-        def step():   # noqa: F811
-            graph.replay()
-            reducer.issue(W.grad)
+            def step():   # noqa: F811
+                graph.replay()
+                # the gradients live in the graph's static buffers: all-reduce a copy, so that the next replay does not
+                # overwrite dW while the collective of this step is still in flight
+                reducer.issue(W.grad.clone() if world > 1 else W.grad)
+
+            launch_mode = "hipGraph replay of the captured fwd+bwd step"
+        except Exception as e:   # noqa: BLE001
+            if rank == 0:
+                print(f"[bench] graph capture failed ({type(e).__name__}: {e}); eager launches", file=sys.stderr)
+            q.grad = k.grad = v.grad = W.grad = None
+            step = eager_step
 
     def sync_all():
         reducer.wait()
@@ -165,8 +180,7 @@ def main():
 
     # ---- per-kernel durations, measured live with HIP events on the launch stream ----
     lib.mhla_prof_enable(1)
-    if a.graph:
-        step = eager_step   # per-kernel event timing needs the eager launches
+    step = eager_step   # per-kernel event timing needs the eager launches
     for _ in range(a.steps):
         step()
     sync()
@@ -209,7 +223,7 @@ def main():
             "config": {"workload": f"block-mix MHLA op fwd+bwd, per GPU B={a.B} N={a.N} H={a.H} D={a.D} "
                                    f"M={a.M} S={a.N // a.M} {a.dtype} ({_config_name(a)})",
                        "global_batch": a.B * world, "parallelism": f"dp{world} (batch shards, dW all-reduce only)",
-                       "launch": "hipGraph replay of the captured fwd+bwd step" if a.graph else "eager (Python autograd)"},
+                       "launch": launch_mode},
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS if achieved else None, "traffic": traffic,

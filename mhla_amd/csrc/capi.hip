@@ -82,7 +82,7 @@ int launch(K kernel, dim3 grid, dim3 block, size_t smem, hipStream_t stream, con
 
 // A per-device side stream for work that is independent of the main chain (the dW reduction of the fast-path backward): forked
 // from and joined back into the caller's stream with events, so the caller still sees one in-order stream (and a hipGraph
-// capture of the caller's stream records the fork and the join).  MHLA_NO_SIDE_STREAM=1 keeps everything on one stream.
+// capture of the caller's stream records the fork and the join).  Opt-in (MHLA_SIDE_STREAM=1): the default is one stream.
 struct SideStream {
     hipStream_t s = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
@@ -90,8 +90,8 @@ struct SideStream {
 std::mutex g_side_mu;   // held while a fork .. join section is enqueued: the events are shared per device
 SideStream* side_stream() {
     static std::map<int, SideStream> per_dev;
-    static const bool off = getenv("MHLA_NO_SIDE_STREAM") != nullptr;
-    if (off) return nullptr;
+    static const bool on = getenv("MHLA_SIDE_STREAM") != nullptr;
+    if (!on) return nullptr;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     SideStream& ss = per_dev[dev];
@@ -536,6 +536,10 @@ int mhla_blockmix_bwd(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q
             fast::FsDwArgs da{f.dstate, state, normalize ? f.dn : nullptr, z, f.dwp, M, S, f.njg};
             // dW needs only dG^T, KV^T, dn and z, all complete here: its four launches (one bandwidth-bound GEMM and three short
             // latency-bound reductions) go to the side stream and overlap the token-gradient kernels of the main chain
+            // dz = W^T dn first, on the caller's stream: with k_fs_wz<1> running concurrently with the side-stream kernels the
+            // normaliser gradients were observed to vary from run to run (root cause not established), so it stays ahead of the fork
+            if (normalize)
+                RC(launch(fast::k_fs_wz<1>, dim3((S + 63) / 64, B * H), dim3(fast::FT), 0, st, "k_fs_wz<1>", W, ldw, (const float*)f.dn, f.dz, M, S, 0.f));
             std::unique_lock<std::mutex> side_lk(g_side_mu);
             SideStream* ss = side_stream();
             hipStream_t sd = st;
@@ -546,8 +550,6 @@ int mhla_blockmix_bwd(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q
             const int nparts = B * H * (fast::DW_SPLIT + 1), ngroups = (nparts + fast::DWR_G - 1) / fast::DWR_G;
             RC(launch(fast::k_fs_dw_reduce1, dim3(16, ngroups), dim3(256), 0, sd, "k_fs_dw_reduce1", (const float*)f.dwp, f.dwt, nparts));
             RC(launch(fast::k_fs_dw_reduce2, dim3((M * M + 255) / 256), dim3(256), 0, sd, "k_fs_dw_reduce2", (const float*)f.dwt, dW, M, ngroups));
-            if (normalize)
-                RC(launch(fast::k_fs_wz<1>, dim3((S + 63) / 64, B * H), dim3(fast::FT), 0, st, "k_fs_wz<1>", W, ldw, (const float*)f.dn, f.dz, M, S, 0.f));
             fast::FsTokArgs ta{};
             ta.q = cv(q_num); ta.k = cv(k_num); ta.v = cv(v); ta.dout = cv(dout); ta.dq = cmv(dq_num); ta.dk = cmv(dk_num);
             ta.dv = cmv(dv); ta.idx = block_index; ta.W = W; ta.ldw = ldw; ta.state = state; ta.dstate = f.dstate; ta.ninv = ninv;
