@@ -135,6 +135,11 @@ def test_split_operand_path(M, S, D, split, dtype):
     run_case(1, 2, M, S, D, dtype, split=split, w="rand", seed=M + S)
 
 
+def test_c2_variant_256_blocks_of_16():
+    """SURVEY 8(d) C2 variant (M, S) = (256, 16): bf16, D = 64, more than 64 blocks -> split-operand path with bf16 summaries."""
+    run_case(1, 2, 256, 16, 64, torch.bfloat16, w="rand")
+
+
 @pytest.mark.parametrize("D", [72, 128])
 def test_split_operand_path_relu_prologue(D):
     """relu(x) + eps folded into the loads (mhla_dit/mhla/mhla.py:229-230) and its gradient mask, split path."""

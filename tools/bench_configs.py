@@ -89,4 +89,6 @@ if __name__ == "__main__":
     blockmix_case("DiT-S/2 2048x2048 op B=4 N=16384 H=6 D=64 M=64 S=256 bf16 (fast path)", 4, 16384, 6, 64, 64, torch.bfloat16, (8, 8))
     blockmix_case("DiT-S/2 4096x4096 op B=1 N=65536 H=6 D=64 M=256 S=256 bf16 (split path: M > 64)", 1, 65536, 6, 64, 256, torch.bfloat16, (16, 16))
     blockmix_case("C2 variant M=16 S=256 bf16 (fast path, multi-chunk blocks)", 8, 4096, 16, 64, 16, torch.bfloat16, (4, 4))
+    blockmix_case("C2 variant M=256 S=16 bf16 (split path: M > 64)", 8, 4096, 16, 64, 256, torch.bfloat16, (16, 16))
+    causal_case("C5 1.3B-like causal B=2 T=8192 H=4 K=256 V=512 bf16", 2, 8192, 4, 256, 512, torch.bfloat16)
     causal_case("C5 fla 340M causal B=4 T=8192 H=4 K=128 V=256 bf16", 4, 8192, 4, 128, 256, torch.bfloat16)

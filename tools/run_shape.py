@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Run a few iterations of one BASELINE.json shape (for rocprofv3):  run_shape.py c3|c4|c4b|c5|xl [iters]"""
+"""Run a few iterations of one BASELINE.json shape (for rocprofv3):  run_shape.py c3|c4|c4b|c5|c5b|xl|c2b [iters]"""
 import os
 import sys
 
@@ -40,6 +40,16 @@ elif which == "c3":
         mhla_amd.mhla_blockmix(ts[0], ts[1], ts[2], W).backward(do)
         for t in ts + [W]:
             t.grad = None
+elif which == "c2b":   # C2 variant: 256 blocks of 16 tokens
+    B, N, H, D = 8, 4096, 16, 64
+    ts = [torch.randn(B, N, H, D, generator=g).abs().bfloat16().to(DEV).requires_grad_(True) for _ in range(3)]
+    do = torch.randn(B, N, H, D, generator=g).bfloat16().to(DEV)
+    W = block_distance_weights((16, 16), "linear").to(DEV).requires_grad_(True)
+
+    def step():
+        mhla_amd.mhla_blockmix(ts[0], ts[1], ts[2], W).backward(do)
+        for t in ts + [W]:
+            t.grad = None
 elif which == "xl":
     B, N, H, D = 16, 1024, 16, 72
     ts = [torch.randn(B, N, H, D, generator=g).abs().bfloat16().to(DEV).requires_grad_(True) for _ in range(3)]
@@ -51,7 +61,7 @@ elif which == "xl":
         for t in ts + [W]:
             t.grad = None
 else:
-    B, T, H, K, V = 4, 8192, 4, 128, 256
+    B, T, H, K, V = (2, 8192, 4, 256, 512) if which == "c5b" else (4, 8192, 4, 128, 256)
     q = torch.randn(B, T, H, K, generator=g).bfloat16().to(DEV).requires_grad_(True)
     k = torch.randn(B, T, H, K, generator=g).bfloat16().to(DEV).requires_grad_(True)
     v = torch.randn(B, T, H, V, generator=g).bfloat16().to(DEV).requires_grad_(True)
