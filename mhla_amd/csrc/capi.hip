@@ -150,8 +150,9 @@ struct BmWs {
     float *kv, *g, *z, *ksum, *ninv, *dg, *dkv, *dn, *dz, *dks, *dwp;
     size_t total_fwd, total_bwd;
 };
-BmWs bm_carve(void* ws, int B, int H, int M, int S, int D) {
-    const size_t bh = (size_t)B * H, st = al4(bh * M * D * D), zs = al4(bh * M * S), ks = al4(bh * M * D);
+// sum16: the D x D block summaries (KV, G, dG, dKV) are stored as bf16 (split-operand path on bf16 tensors): half the floats
+BmWs bm_carve(void* ws, int B, int H, int M, int S, int D, bool sum16) {
+    const size_t bh = (size_t)B * H, st = al4(sum16 ? (bh * M * D * D + 1) / 2 : bh * M * D * D), zs = al4(bh * M * S), ks = al4(bh * M * D);
     float* p = (float*)ws;
     BmWs w;
     w.kv = p; p += st;
@@ -203,6 +204,7 @@ bool sp_shape_ok(int D, unsigned flags) { return (D & 7) == 0 && !(flags & MHLA_
 bool view_ok16m(const mhla_mview& v) { return v.ptr && ((uintptr_t)v.ptr % 16) == 0 && ((v.sb | v.sn | v.sh) & 7) == 0; }
 // bf16-MFMA token kernels of the causal operator (causal_bf16.cuh)
 bool cs_bf16_ok(int K, int V, int dtype) { return dtype == MHLA_BF16 && (K & 63) == 0 && (V & 63) == 0 && !getenv("MHLA_CAUSAL_GENERIC"); }
+bool bm_sum16(int D, int dtype, unsigned flags) { return dtype == MHLA_BF16 && sp_shape_ok(D, flags); }
 bool fast_shape_ok(int M, int D, int dtype, bool split) { return dtype == MHLA_BF16 && D == 64 && M <= 64 && !split; }
 // small-sequence single-launch path (smalln.cuh): S = 16 tokens per block, at most 16 blocks, D <= 80
 bool sn_shape_ok(int M, int S, int D, int dtype, bool split) {
@@ -237,7 +239,7 @@ int bm_state_and_mix(const mhla_view& q_num, const mhla_view& k_num, const mhla_
     MixArgs m{W, ldw, w.kv, w.g, M, (long)D * D};
     if (sp_shape_ok(D, flags)) {   // split-bf16 MFMA kernels (split.cuh)
         RC(launch(sp::k_sp_state<T, DT, 0>, dim3(M, B * H), dim3(NTHREADS), sp::sp_state_smem<DT>(), st, "k_sp_state", a));
-        RC(launch(sp::k_sp_mix<0, sp::Sum16<T>::value>, dim3((unsigned)((m.E + sp::SPM_TE - 1) / sp::SPM_TE), (M + 63) / 64, B * H), dim3(NTHREADS), sp::SP_MIX_SMEM, st, "k_sp_mix<0>", m));
+        RC(launch(sp::k_sp_mix<0, sp::Sum16<T>::value>, dim3((unsigned)((m.E + sp::SPM_TE - 1) / sp::SPM_TE), (M + 63) / 64, B * H), dim3(NTHREADS), sp::sp_mix_smem<sp::Sum16<T>::value>(), st, "k_sp_mix<0>", m));
         if (normalize)
             RC(launch(k_wz<0>, dim3((S + 63) / 64, (M + 63) / 64, B * H), dim3(NTHREADS), 0, st, "k_wz<0>", W, ldw, (const float*)w.z, w.ninv, M, S, eps));
         return MHLA_OK;
@@ -360,11 +362,11 @@ int mhla_blockmix_fwd_keeps_state(int B, int H, int M, int S, int D, int dtype, 
 // Upper bound over the paths the library may take for this problem (the fast path needs less).
 size_t mhla_blockmix_fwd_ws_bytes(int B, int H, int M, int S, int D, int dtype, int split, unsigned flags) {
     if (fast_shape_ok(M, D, dtype, split != 0) && !(flags & MHLA_FLAG_FORCE_GENERIC)) return fast_carve(nullptr, B, H, M, S).total_fwd;
-    return bm_carve(nullptr, B, H, M, S, D).total_fwd;
+    return bm_carve(nullptr, B, H, M, S, D, bm_sum16(D, dtype, flags)).total_fwd;
 }
 size_t mhla_blockmix_bwd_ws_bytes(int B, int H, int M, int S, int D, int dtype, int split, unsigned flags) {
     if (fast_shape_ok(M, D, dtype, split != 0) && !(flags & MHLA_FLAG_FORCE_GENERIC)) return fast_carve(nullptr, B, H, M, S).total_bwd;
-    return bm_carve(nullptr, B, H, M, S, D).total_bwd;
+    return bm_carve(nullptr, B, H, M, S, D, bm_sum16(D, dtype, flags)).total_bwd;
 }
 
 static int bm_fwd_impl(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q_den, mhla_view k_den, const float* W,
@@ -411,7 +413,7 @@ static int bm_fwd_impl(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view 
         RC(launch(fast::k_t16_out, dim3(((f.njg + 1) / 2) * B * H), dim3(fast::FT8), fast::FS_GT16_BYTES, st, "k_t16_out", oa));
         return MHLA_OK;
     }
-    const BmWs w = bm_carve(ws, B, H, M, S, D);
+    const BmWs w = bm_carve(ws, B, H, M, S, D, bm_sum16(D, dtype, flags));
     if (ws_bytes < w.total_fwd) return fail(MHLA_EINVAL, "workspace too small: %zu < %zu bytes", ws_bytes, w.total_fwd);
     const int dt = dt_for(D);
     DISPATCH_T(dtype, DISPATCH_DT(dt, {
@@ -565,13 +567,13 @@ int mhla_blockmix_bwd(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q
             return MHLA_OK;
         }
     }
-    BmWs w = bm_carve(ws, B, H, M, S, D);
+    BmWs w = bm_carve(ws, B, H, M, S, D, bm_sum16(D, dtype, flags));
     if (ws_bytes < w.total_bwd) return fail(MHLA_EINVAL, "workspace too small: %zu < %zu bytes", ws_bytes, w.total_bwd);
     // the forward's KV, G, z, ksum, 1/n are still in its workspace (only when the shape cannot have taken the bf16 fast path,
     // whose workspace has another layout)
     const bool reuse = fwd_ws && sp_shape_ok(D, flags) && !fast_shape_ok(M, D, dtype, split);
     if (reuse) {
-        const BmWs f = bm_carve(const_cast<void*>(fwd_ws), B, H, M, S, D);
+        const BmWs f = bm_carve(const_cast<void*>(fwd_ws), B, H, M, S, D, bm_sum16(D, dtype, flags));
         w.kv = f.kv; w.g = f.g; w.z = f.z; w.ksum = f.ksum; w.ninv = f.ninv;
     }
     DISPATCH_T(dtype, DISPATCH_DT(dt, {
@@ -595,7 +597,7 @@ int mhla_blockmix_bwd(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q
             if (normalize)
                 RC(launch(k_wz<1>, dim3((S + 63) / 64, (M + 63) / 64, B * H), dim3(NTHREADS), 0, st, "k_wz<1>", W, ldw, (const float*)w.dn, w.dz, M, S, 0.f));
             MixArgs m{W, ldw, w.dg, w.dkv, M, E};
-            RC(launch(sp::k_sp_mix<1, sp::Sum16<ET>::value>, dim3((unsigned)((E + sp::SPM_TE - 1) / sp::SPM_TE), tiles, B * H), dim3(NTHREADS), sp::SP_MIX_SMEM, st, "k_sp_mix<1>", m));
+            RC(launch(sp::k_sp_mix<1, sp::Sum16<ET>::value>, dim3((unsigned)((E + sp::SPM_TE - 1) / sp::SPM_TE), tiles, B * H), dim3(NTHREADS), sp::sp_mix_smem<sp::Sum16<ET>::value>(), st, "k_sp_mix<1>", m));
             int nsplit = dw_splits(tiles * tiles * B * H, E);
             if (nsplit > DW_MAX_SPLIT - 1) nsplit = DW_MAX_SPLIT - 1;   // one more part per (b, h) holds the <dn_i, z_j> term
             DwArgs d{w.dg, w.kv, E, nullptr, nullptr, 0, w.dwp, M, tiles, nsplit};

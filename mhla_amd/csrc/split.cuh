@@ -255,6 +255,10 @@ __global__ __launch_bounds__(NTHREADS) void k_sp_state(const StateArgs a) {
 constexpr int SPM_TE = 128, SPM_LD = SPM_TE + 8, SPM_TILE = 32 * SPM_LD;
 constexpr int SP_MIX_SMEM = 4 * SPM_TILE * 2;   // two buffers of (hi, lo) [32][SPM_LD] bf16; reused as [64][SPM_TE + 4] fp32 staging
 static_assert(64 * (SPM_TE + 4) * 4 <= SP_MIX_SMEM, "output staging must fit in the input tiles");
+// bf16 summaries: no lo tiles and a bf16 output staging [64][SPM_LD]: half the LDS, twice the resident workgroups
+constexpr int SP_MIX_SMEM16 = 2 * SPM_TILE * 2;
+static_assert(64 * SPM_LD * 2 <= SP_MIX_SMEM16, "bf16 output staging must fit in the input tiles");
+template <bool S16> constexpr int sp_mix_smem() { return S16 ? SP_MIX_SMEM16 : SP_MIX_SMEM; }
 
 template <int TRANS, bool S16 = false>   // S16: summaries stored as bf16 (no lo part)
 __global__ __launch_bounds__(NTHREADS, 2) void k_sp_mix(const MixArgs a) {
@@ -294,7 +298,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_mix(const MixArgs a) {
         }
     };
     auto commit = [&](int buf) {
-        u16* th = Xs + buf * 2 * SPM_TILE + sr * SPM_LD + sc;
+        u16* th = Xs + buf * (S16 ? 1 : 2) * SPM_TILE + sr * SPM_LD + sc;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             if (S16) {
@@ -313,24 +317,52 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_mix(const MixArgs a) {
     for (int t = 0; t < 8; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int orow = i0 + wave * 16 + nl;
 
+    // this lane's 8 mixing weights of a step (row orow, columns step * 32 + kg * 8 ..): fetched one step ahead like the tiles,
+    // so their L2 latency is not on the MFMA chain
+    float wc[8], wn[8];
+    const bool wvec = !TRANS && (reinterpret_cast<uintptr_t>(a.W) & 15) == 0 && (a.ldw & 3) == 0;
+    const bool wvec2 = !TRANS && (reinterpret_cast<uintptr_t>(a.W) & 7) == 0 && (a.ldw & 1) == 0;
+    auto fetch_w = [&](int step, float (&w)[8]) {
+        const int k0 = step * 32 + kg * 8;
+        if (wvec && orow < M && k0 + 8 <= M) {   // 8 consecutive weights of one row: two 16-byte loads
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(a.W + (long)orow * a.ldw + k0);
+            const f32x4 w1 = *reinterpret_cast<const f32x4*>(a.W + (long)orow * a.ldw + k0 + 4);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { w[t] = w0[t]; w[4 + t] = w1[t]; }
+            return;
+        }
+        if (wvec2 && orow < M && k0 + 8 <= M) {  // even row stride (M = 150): four 8-byte loads
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float2 wp = *reinterpret_cast<const float2*>(a.W + (long)orow * a.ldw + k0 + 2 * t);
+                w[2 * t] = wp.x; w[2 * t + 1] = wp.y;
+            }
+            return;
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int kk = k0 + t;
+            w[t] = (orow < M && kk < M) ? (TRANS ? a.W[(long)kk * a.ldw + orow] : a.W[(long)orow * a.ldw + kk]) : 0.f;
+        }
+    };
     fetch(0);
+    fetch_w(0, wc);
     commit(0);
     for (int step = 0; step < steps; ++step) {
         const int buf = step & 1;
         __syncthreads();
-        if (step + 1 < steps) fetch(step + 1);
-        const int k0 = step * 32 + kg * 8;
+        if (step + 1 < steps) {
+            fetch(step + 1);
+            fetch_w(step + 1, wn);
+        }
         bf16x8 ah, al;
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
-            const int kk = k0 + t;
-            float w = 0.f;
-            if (orow < M && kk < M) w = TRANS ? a.W[(long)kk * a.ldw + orow] : a.W[(long)orow * a.ldw + kk];
-            const __bf16 hi = (__bf16)w;
+            const __bf16 hi = (__bf16)wc[t];
             ah[t] = hi;
-            al[t] = (__bf16)(w - (float)hi);
+            al[t] = (__bf16)(wc[t] - (float)hi);
         }
-        const u16* th = Xs + buf * 2 * SPM_TILE;
+        const u16* th = Xs + buf * (S16 ? 1 : 2) * SPM_TILE;
 #pragma unroll
         for (int t4 = 0; t4 < 8; t4 += 4) {
             bf16x8 bh_[4], bl_[4];
@@ -347,22 +379,38 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_mix(const MixArgs a) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) acc[t4 + t] = mfma_bf16(al, bh_[t], acc[t4 + t]);
         }
-        if (step + 1 < steps) commit(buf ^ 1);
+        if (step + 1 < steps) {
+            commit(buf ^ 1);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) wc[t] = wn[t];
+        }
     }
     __syncthreads();
-    float* Os = reinterpret_cast<float*>(smem_raw);   // [64][SPM_TE + 4]
+    if constexpr (S16) {
+        u16* Os = Xs;   // [64][SPM_LD] bf16
 #pragma unroll
-    for (int t = 0; t < 8; ++t)
+        for (int t = 0; t < 8; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Os[(wave * 16 + kg * 4 + r) * (SPM_TE + 4) + t * 16 + nl] = acc[t][r];
-    __syncthreads();
+            for (int r = 0; r < 4; ++r) Os[(wave * 16 + kg * 4 + r) * SPM_LD + t * 16 + nl] = cvt_bf16(acc[t][r]);
+        __syncthreads();
 #pragma unroll
-    for (int v0 = 0; v0 < 8; ++v0) {
-        const int v = tid + v0 * NTHREADS, r = v >> 5, c = (v & 31) * 4;
-        if (i0 + r < M && e0 + c < a.E) {
-            const f32x4 o = *reinterpret_cast<const f32x4*>(Os + r * (SPM_TE + 4) + c);
-            if (S16) *reinterpret_cast<uint2*>(outb16 + (long)(i0 + r) * a.E + c) = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
-            else     *reinterpret_cast<f32x4*>(outb + (long)(i0 + r) * a.E + c) = o;
+        for (int v0 = 0; v0 < 4; ++v0) {
+            const int v = tid + v0 * NTHREADS, r = v >> 4, c = (v & 15) * 8;
+            if (i0 + r < M && e0 + c < a.E)   // E is a multiple of 8
+                *reinterpret_cast<uint4*>(outb16 + (long)(i0 + r) * a.E + c) = *reinterpret_cast<const uint4*>(Os + r * SPM_LD + c);
+        }
+    } else {
+        float* Os = reinterpret_cast<float*>(smem_raw);   // [64][SPM_TE + 4]
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Os[(wave * 16 + kg * 4 + r) * (SPM_TE + 4) + t * 16 + nl] = acc[t][r];
+        __syncthreads();
+#pragma unroll
+        for (int v0 = 0; v0 < 8; ++v0) {
+            const int v = tid + v0 * NTHREADS, r = v >> 5, c = (v & 31) * 4;
+            if (i0 + r < M && e0 + c < a.E)
+                *reinterpret_cast<f32x4*>(outb + (long)(i0 + r) * a.E + c) = *reinterpret_cast<const f32x4*>(Os + r * (SPM_TE + 4) + c);
         }
     }
 }
