@@ -75,13 +75,17 @@ template <int DT> struct Geo {
 
 template <int DT>
 __host__ __device__ constexpr int sp_state_smem() {
-    return 4 * 32 * Geo<DT>::LD * 2 + Geo<DT>::RPP * Geo<DT>::DW * 4 + Geo<DT>::DW * 4;
+    // the column-sum partials [RPP][DW] of the epilogue reuse the tiles
+    static_assert(Geo<DT>::RPP * Geo<DT>::DW * 4 <= 4 * 32 * Geo<DT>::LD * 2, "column-sum partials must fit in the tiles");
+    return 4 * 32 * Geo<DT>::LD * 2 + Geo<DT>::DW * 4;
 }
 
 // MODE 0 (forward):  out = KV_j = K_j^T V_j; ksum_j; z_j                      x = k_num, y = v, kd = k_den, qd = q_den
 // MODE 1 (backward): out = dG_i = Q_i^T (dO_i / n_i); dn_i[s] = -(dO_i[s] . O_i[s]) / n_i[s]     x = q_num, y = dout, o = out
-template <typename T, int DT, int MODE>
-__global__ __launch_bounds__(NTHREADS) void k_sp_state(const StateArgs a) {
+// ROPE (MODE 0): the keys of the KV product are rotated on load (a.rcos / a.rsin); a template flag so that the plain variants do
+// not carry the angle registers (3 waves per SIMD need <= 168 VGPRs)
+template <typename T, int DT, int MODE, bool ROPE = false>
+__global__ __launch_bounds__(NTHREADS, ROPE ? 2 : 3) void k_sp_state(const StateArgs a) {
     constexpr int DW = Geo<DT>::DW, LD = Geo<DT>::LD, CGS = Geo<DT>::CGS, RPP = Geo<DT>::RPP, IT = 32 / RPP, RT = Geo<DT>::RT, TILE = 32 * LD;
     constexpr bool LO = !std::is_same<T, bf16_t>::value;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -89,8 +93,8 @@ __global__ __launch_bounds__(NTHREADS) void k_sp_state(const StateArgs a) {
     u16* Kl = Kh + TILE;
     u16* Vh = Kl + TILE;
     u16* Vl = Vh + TILE;
-    float* cs = reinterpret_cast<float*>(Vl + TILE);   // [RPP][DW] column-sum partials
-    float* vecd = cs + RPP * DW;                       // [DW] ksum
+    float* cs = reinterpret_cast<float*>(smem_raw);    // [RPP][DW] column-sum partials: over the tiles, after the last product
+    float* vecd = reinterpret_cast<float*>(Vl + TILE); // [DW] ksum
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nl = lane & 15, kg = lane >> 4;
     const int blk = blockIdx.x, bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H, S = a.S, D = a.D;
     const long p0 = (long)blk * S;
@@ -102,9 +106,9 @@ __global__ __launch_bounds__(NTHREADS) void k_sp_state(const StateArgs a) {
     const int r0 = tid / CGS, cg = (tid % CGS) * 8;
     const float* ninvb = a.ninv + ((long)bh * a.M + blk) * S;   // MODE 1
 
-    f32x4 kx[IT][2], vx[IT][2], dx[IT][2], rc[IT], rs[IT];
+    f32x4 kx[IT][2], vx[IT][2], dx[IT][2], rc[ROPE ? IT : 1], rs[ROPE ? IT : 1];
     float nv[IT];
-    const bool rope = MODE == 0 && a.rcos != nullptr;
+    constexpr bool rope = MODE == 0 && ROPE;
     int crow = 0;   // first token of the chunk held in registers
     auto fetch = [&](int c0) {
         crow = c0;
@@ -112,7 +116,7 @@ __global__ __launch_bounds__(NTHREADS) void k_sp_state(const StateArgs a) {
         for (int it = 0; it < IT; ++it) {
             const int r = c0 + r0 + RPP * it;
             kx[it][0] = kx[it][1] = vx[it][0] = vx[it][1] = dx[it][0] = dx[it][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-            rc[it] = rs[it] = f32x4{0.f, 0.f, 0.f, 0.f};   // padded rows: 0 * (uninitialised angle) could be NaN
+            if constexpr (rope) rc[it] = rs[it] = f32x4{0.f, 0.f, 0.f, 0.f};   // padded rows: 0 * (uninitialised angle) could be NaN
             nv[it] = 1.f;
             if (r < S && cg < D) {
                 const long row = tok_row(a.idx, p0 + r);
@@ -121,7 +125,7 @@ __global__ __launch_bounds__(NTHREADS) void k_sp_state(const StateArgs a) {
                 if (a.relu) relu8(kx[it][0], kx[it][1], a.eps);
                 if (den) ld8(kdb + row * third.sn + cg, dx[it][0], dx[it][1]);
                 if (MODE == 1 && a.normalize) nv[it] = ninvb[r];
-                if (rope) {
+                if constexpr (rope) {
                     rc[it] = *reinterpret_cast<const f32x4*>(a.rcos + row * a.ldr + cg / 2);
                     rs[it] = *reinterpret_cast<const f32x4*>(a.rsin + row * a.ldr + cg / 2);
                 }
@@ -145,7 +149,7 @@ __global__ __launch_bounds__(NTHREADS) void k_sp_state(const StateArgs a) {
                 vx[it][0] *= nv[it];
                 vx[it][1] *= nv[it];
             }
-            if (rope) {   // KV takes the rotated keys, ksum the plain ones
+            if constexpr (rope) {   // KV takes the rotated keys, ksum the plain ones
                 f32x4 r0 = kx[it][0], r1 = kx[it][1];
                 rope8(r0, r1, rc[it], rs[it]);
                 split8(r0, r1, hi, lo);
