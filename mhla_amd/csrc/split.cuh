@@ -238,19 +238,28 @@ __global__ __launch_bounds__(NTHREADS, ROPE ? 2 : 3) void k_sp_state(const State
         float kv8[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) kv8[i] = vecd[cg + i];
-        for (int rb = 0; rb < S; rb += RPP) {
-            const int r = rb + r0;
-            float d = 0.f;
-            if (r < S && cg < D) {
-                f32x4 x0, x1;
-                ld8(qb + tok_row(a.idx, p0 + r) * a.qd.sn + cg, x0, x1);
-                if (a.relu) relu8(x0, x1, a.eps);
+        constexpr int ZB = 4;   // token rows in flight per thread: the loads of a batch are issued before any is used
+        for (int rb = 0; rb < S; rb += RPP * ZB) {
+            f32x4 x0[ZB], x1[ZB];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) d += x0[i] * kv8[i] + x1[i] * kv8[4 + i];
+            for (int u = 0; u < ZB; ++u) {
+                const int r = rb + u * RPP + r0;
+                x0[u] = x1[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (r < S && cg < D) ld8(qb + tok_row(a.idx, p0 + r) * a.qd.sn + cg, x0[u], x1[u]);
             }
 #pragma unroll
-            for (int o = CGS / 2; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
-            if (r < S && (tid % CGS) == 0) a.zo[((long)bh * a.M + blk) * S + r] = d;
+            for (int u = 0; u < ZB; ++u) {
+                const int r = rb + u * RPP + r0;
+                float d = 0.f;
+                if (r < S && cg < D) {
+                    if (a.relu) relu8(x0[u], x1[u], a.eps);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) d += x0[u][i] * kv8[i] + x1[u][i] * kv8[4 + i];
+                }
+#pragma unroll
+                for (int o = CGS / 2; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+                if (r < S && (tid % CGS) == 0) a.zo[((long)bh * a.M + blk) * S + r] = d;
+            }
         }
     }
 }
