@@ -715,7 +715,11 @@ int mhla_causal_bwd(mhla_view q, mhla_view k, mhla_view v, const float* mix, int
         fast::CsfMixArgs mt{mix, ldmix, dP, dS, n, E};
         RC(launch(fast::k_csf_mix<1>, mgrid, dim3(NTHREADS), fast::CSF_MIX_SMEM, st, "k_csf_mix<1>", mt));
         CsTokArgs t{cv(q), cv(k), cv(v), cv(dout), cmv(dq), cmv(dk), cmv(dv), mix, ldmix, w.P, w.dS, w.diag, H, n, K, V, (long)T, scale};
-        if (V <= 128)      RC(launch(fast::k_csf_bwd_tok2<uint16_t, 2>, dim3(n, B * H), dim3(NTHREADS), fast::CSF_TOK2_SMEM, st, "k_csf_bwd_tok", t));
+        const char* tokv = getenv("MHLA_CAUSAL_TOK");   // tuning: "2" forces the K-slice-outer kernels
+        const bool tok3 = !(tokv && tokv[0] == '2');
+        if (tok3 && K <= 128)      RC(launch(fast::k_csf_bwd_tok3<uint16_t, 2>, dim3(n, B * H), dim3(NTHREADS), fast::csf_tok3_smem<2>(), st, "k_csf_bwd_tok3", t));
+        else if (tok3 && K <= 256) RC(launch(fast::k_csf_bwd_tok3<uint16_t, 4>, dim3(n, B * H), dim3(NTHREADS), fast::csf_tok3_smem<4>(), st, "k_csf_bwd_tok3", t));
+        else if (V <= 128) RC(launch(fast::k_csf_bwd_tok2<uint16_t, 2>, dim3(n, B * H), dim3(NTHREADS), fast::CSF_TOK2_SMEM, st, "k_csf_bwd_tok", t));
         else if (V <= 256) RC(launch(fast::k_csf_bwd_tok2<uint16_t, 4>, dim3(n, B * H), dim3(NTHREADS), fast::CSF_TOK2_SMEM, st, "k_csf_bwd_tok", t));
         else if (V <= 512) RC(launch(fast::k_csf_bwd_tok2<uint16_t, 8>, dim3(n, B * H), dim3(NTHREADS), fast::CSF_TOK2_SMEM, st, "k_csf_bwd_tok", t));
         else               RC(launch(fast::k_csf_bwd_tok<uint16_t>, dim3(n, B * H), dim3(NTHREADS), fast::CSF_TOK_SMEM, st, "k_csf_bwd_tok", t));

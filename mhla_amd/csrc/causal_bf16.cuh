@@ -390,6 +390,131 @@ __global__ __launch_bounds__(NTHREADS) void k_csf_bwd_tok2(const CsTokArgs a) {
     }
 }
 
+// Token gradients with the V slices in the outer loop (K <= 64 NK): the chunk's K tiles stay in LDS, dQ / dK accumulate in
+// registers per K slice, and every V slice stages dO, V, P and dS once and feeds all of dA += dO V^T, dV = A^T dO + K dS,
+// dQ += dO P^T, dK += V dS^T from them.  Per chunk the kernel reads Q twice and everything else once (k_csf_bwd_tok2 re-reads
+// dO and V per K slice and again for the score tiles: 416 KB instead of 240 KB per chunk at K = 128, V = 256), and V is not
+// limited by an accumulator count.
+template <int NK>
+__host__ __device__ constexpr int csf_tok3_smem() { return (6 + NK) * CT * 2 + 16; }
+
+template <typename ST, int NK>
+__global__ __launch_bounds__(NTHREADS, NK <= 2 ? 2 : 1) void k_csf_bwd_tok3(const CsTokArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u16* As = reinterpret_cast<u16*>(smem_raw);   // m_ii scale tril(Q K^T)   [c][c']
+    u16* dAs = As + CT;                           // m_ii tril(dO V^T)        [c][c']
+    u16* X1 = dAs + CT;                           // Q slice / dO slice
+    u16* X2 = X1 + CT;                            // V slice / Q slice
+    u16* B1 = X2 + CT;                            // P slice, output staging
+    u16* B2 = B1 + CT;                            // dS slice, output staging
+    u16* KT = B2 + CT;                            // the chunk's K tiles [NK]
+    float* red = reinterpret_cast<float*>(KT + NK * CT);
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, n = lane & 15, kg = lane >> 4;
+    const int ci = blockIdx.x, bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
+    const long p0 = (long)ci * CS;
+    const int rv = (int)min((long)CS, a.T - p0);
+    const int K = a.K, V = a.V, nks = K / 64;
+    auto base = [&](const View& w) { return (const u16*)w.ptr + b * w.sb + h * w.sh; };
+    auto mbase = [&](const MView& w) { return (u16*)w.ptr + b * w.sb + h * w.sh; };
+    const u16 *qb = base(a.q), *kb = base(a.k), *vb = base(a.v), *gb = base(a.dout);
+    const ST* Pi = reinterpret_cast<const ST*>(a.P) + ((long)bh * a.n + ci) * K * V;
+    const ST* dSi = reinterpret_cast<const ST*>(a.dS) + ((long)bh * a.n + ci) * K * V;
+    const float mii = a.mix[(long)ci * a.ldmix + ci];
+
+    // ---- step 1: A = tril(Q K^T); the K tiles stay ----
+    f32x4 accA[4];
+    zero4(accA);
+#pragma unroll
+    for (int kk = 0; kk < NK; ++kk) {
+        if (kk < nks) {
+            cs_stage_tok(X1, qb + kk * 64, a.q.sn, p0, rv, tid);
+            cs_stage_tok(KT + kk * CT, kb + kk * 64, a.k.sn, p0, rv, tid);
+            __syncthreads();
+            tile_mma<false, false>(accA, X1, KT + kk * CT, wave, lane);
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = wave * 16 + kg * 4 + r, col = tn * 16 + n;
+            const float av = col <= row ? accA[tn][r] : 0.f;
+            accA[tn][r] = av;   // kept for the diagonal term
+            As[row * CLD + col] = cvt_bf16(mii * a.scale * av);
+        }
+
+    // ---- step 2: per V slice: dA, dV, and the dQ / dK partials of every K slice ----
+    f32x4 accQ[NK][4], accK[NK][4], accdA[4];
+#pragma unroll
+    for (int kk = 0; kk < NK; ++kk) {
+        zero4(accQ[kk]);
+        zero4(accK[kk]);
+    }
+    zero4(accdA);
+    for (int vs = 0; vs < V; vs += 64) {
+        f32x4 accV[4];
+        zero4(accV);
+        cs_stage_tok(X1, gb + vs, a.dout.sn, p0, rv, tid);
+        cs_stage_tok(X2, vb + vs, a.v.sn, p0, rv, tid);
+#pragma unroll
+        for (int kk = 0; kk < NK; ++kk) {
+            if (kk < nks) {
+                cs_stage_state(B1, Pi + (long)kk * 64 * V + vs, V, tid);
+                cs_stage_state(B2, dSi + (long)kk * 64 * V + vs, V, tid);
+                __syncthreads();
+                if (kk == 0) {
+                    tile_mma<false, false>(accdA, X1, X2, wave, lane);      // dO V^T
+                    tile_mma<true, true>(accV, As, X1, wave, lane);         // A^T dO
+                }
+                tile_mma<false, false>(accQ[kk], X1, B1, wave, lane);       // dO P^T
+                tile_mma<false, false>(accK[kk], X2, B2, wave, lane);       // V dS^T
+                tile_mma<false, true>(accV, KT + kk * CT, B2, wave, lane);  // K dS : B[k = kk][n = v] = dS[kk][v]
+                __syncthreads();
+            }
+        }
+        cs_put(B1, accV, 1.f, wave, lane);
+        __syncthreads();
+        cs_store_tok(mbase(a.dv) + vs, a.dv.sn, p0, rv, B1, tid);
+        __syncthreads();
+    }
+
+    // ---- step 3: dA tile, diagonal term, the m_ii parts of dQ / dK ----
+    float dsum = 0.f;
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = wave * 16 + kg * 4 + r, col = tn * 16 + n;
+            const float dv = col <= row ? accdA[tn][r] : 0.f;
+            dsum += accA[tn][r] * dv;
+            dAs[row * CLD + col] = cvt_bf16(mii * dv);
+        }
+    dsum = wave_sum(dsum);
+    if (lane == 0) red[wave] = dsum;
+    __syncthreads();
+    if (tid == 0) a.diag[(long)bh * a.n + ci] = a.scale * (red[0] + red[1] + red[2] + red[3]);
+#pragma unroll
+    for (int kk = 0; kk < NK; ++kk) {
+        if (kk < nks) {
+            cs_stage_tok(X2, qb + kk * 64, a.q.sn, p0, rv, tid);
+            __syncthreads();
+            f32x4 acc3[4];
+            zero4(acc3);
+            tile_mma<false, true>(accQ[kk], dAs, KT + kk * CT, wave, lane);   // dA K
+            tile_mma<true, true>(acc3, dAs, X2, wave, lane);                  // dA^T Q
+            cs_put(B1, accQ[kk], a.scale, wave, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) accK[kk][i] += a.scale * acc3[i];
+            cs_put(B2, accK[kk], 1.f, wave, lane);
+            __syncthreads();
+            cs_store_tok(mbase(a.dq) + kk * 64, a.dq.sn, p0, rv, B1, tid);
+            cs_store_tok(mbase(a.dk) + kk * 64, a.dk.sn, p0, rv, B2, tid);
+            __syncthreads();
+        }
+    }
+}
+
 // -------------------------------------------------------------------------------------------------
 // k_csf_state: out[bh][ci][kk][v] (bf16) = mul * sum_{c in chunk ci} X[c][kk] Y[c][v]        grid (n, bh, K / 64)
 //   forward: X = K, Y = V (S_j, naive.py:60);  backward: X = Q, Y = dO, mul = scale (dP_i)
