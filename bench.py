@@ -228,8 +228,8 @@ def main():
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS if achieved else None, "traffic": traffic,
                 "scope": "whole fwd+bwd step: algorithmic bytes 12*B*H*N*D*e over the GPU time of one step (HIP events on "
-                         "the launch stream around K steps; kernels on the library's side stream overlap the main chain, "
-                         "so this is less than the sum of the per-kernel durations listed under `kernels`)",
+                         "the launch stream around K steps); `kernels` lists every kernel's own average duration, measured "
+                         "with the library's per-launch event hook in a separate eager pass",
                 "algorithmic_bytes_per_step": alg_bytes, "gpu_us_per_step": step_gpu_us, "sum_of_kernel_us_per_step": gpu_us,
                 "dominant_kernel": None if dom is None else {
                     "name": dom, "avg_us": kernels[dom]["avg_us"],

@@ -694,7 +694,12 @@ __global__ __launch_bounds__(NTHREADS) void k_csf_dw(const CsfDwArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* Rs = reinterpret_cast<float*>(smem_raw);
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nl = lane & 15, kg = lane >> 4;
-    const int it = blockIdx.x / a.tiles, jt = blockIdx.x - it * a.tiles, bh = blockIdx.y, split = blockIdx.z, n = a.n;
+    // the tile pairs of one (b, h, slice) share their operand rows: consecutive logical indices, kept on one XCD (one L2) and
+    // adjacent in dispatch order by xcd_swizzle
+    const int np = gridDim.x, nbh = gridDim.y;
+    const int L = xcd_swizzle(blockIdx.x + np * (blockIdx.y + nbh * blockIdx.z), np * nbh * gridDim.z);
+    const int unit = L / np, pair = L - unit * np, split = unit / nbh, bh = unit - split * nbh, n = a.n;
+    const int it = pair / a.tiles, jt = pair - it * a.tiles;
     const int i0 = it * 64, j0 = jt * 64;
     if (j0 > i0 + 63) return;   // tile entirely above the diagonal
     const long per = ((a.E + a.nsplit - 1) / a.nsplit + 255) & ~255L;   // slice: multiple of 4 waves x 64 elements
