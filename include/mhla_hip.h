@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MHLA_ABI_VERSION 3
+#define MHLA_ABI_VERSION 4
 
 enum { MHLA_F32 = 0, MHLA_BF16 = 1, MHLA_F16 = 2 };
 
@@ -247,6 +247,21 @@ size_t mhla_lepe2d_wgrad_ws_bytes(int C, int K);
 int mhla_lepe2d_wgrad(const void* x, int64_t x_sb, int64_t x_sn, const void* dout, int64_t g_sb, int64_t g_sn,
                       float* dwb, void* ws, size_t ws_bytes,
                       int B, int pieces_len, int block_len, int C, int K, int dtype, void* stream);
+
+/*
+ * 3-D LePE of the Wan host: y = conv3d(x as video, w [C,1,3,3,3], bias, padding 1, groups = C) (+ add), replacing the
+ * 'b (f h w) c -> b c f h w' round trip around nn.Conv3d at wan/mhla_utils.py:199-201, 349-352.  Tokens are in raster
+ * order n = (f*H + h)*W + w.  w_taps: fp32 [27][C], tap = (df*3 + dh)*3 + dw; other arguments as mhla_lepe2d.
+ */
+int mhla_lepe3d(const void* x, int64_t x_sb, int64_t x_sn, const float* w_taps, const float* bias,
+                const void* add, int64_t add_sb, int64_t add_sn,
+                void* y, int64_t y_sb, int64_t y_sn,
+                int B, int F, int H, int W, int C, int flip, int dtype, void* stream);
+/* dwb fp32 [28][C]: rows 0..26 = dw_taps, row 27 = dbias; overwritten, deterministic. */
+size_t mhla_lepe3d_wgrad_ws_bytes(int C);
+int mhla_lepe3d_wgrad(const void* x, int64_t x_sb, int64_t x_sn, const void* dout, int64_t g_sb, int64_t g_sn,
+                      float* dwb, void* ws, size_t ws_bytes,
+                      int B, int F, int H, int W, int C, int dtype, void* stream);
 
 /* ---- epilogue: per-head RMSNorm (x optional swish gate) ----------------- */
 

@@ -7,7 +7,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmhla_hip.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 F32, BF16, F16 = 0, 1, 2
 FLAG_RELU_EPS = 1
 FLAG_FORCE_GENERIC = 2
@@ -53,6 +53,11 @@ SIGNATURES = {
                             c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "mhla_lepe2d_wgrad_ws_bytes": (c_size_t, [c_int, c_int]),
     "mhla_lepe2d_wgrad": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_size_t,
+                                  c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "mhla_lepe3d": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64,
+                            c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "mhla_lepe3d_wgrad_ws_bytes": (c_size_t, [c_int]),
+    "mhla_lepe3d_wgrad": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_size_t,
                                   c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "mhla_qk_prologue_rope": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
                                       c_int64, c_int, c_int, c_int64, c_int, c_int, c_float, c_float, c_int, c_void_p]),

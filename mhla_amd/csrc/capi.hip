@@ -829,6 +829,44 @@ int mhla_lepe2d_wgrad(const void* x, int64_t x_sb, int64_t x_sn, const void* dou
     return MHLA_OK;
 }
 
+static int lepe3d_check(const void* x, const void* y, int B, int F, int H, int W, int C, int dtype) {
+    if (!x || !y) return fail(MHLA_EINVAL, "null pointer");
+    if (B <= 0 || F <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7)) return fail(MHLA_EINVAL, "B=%d F=%d H=%d W=%d C=%d: need positive sizes and C %% 8 == 0", B, F, H, W, C);
+    if ((long)F * H * W > (1L << 30)) return fail(MHLA_ENOTSUP, "F*H*W = %ld tokens exceed 2^30", (long)F * H * W);
+    if (dtype < 0 || dtype > 2) return fail(MHLA_EINVAL, "unknown dtype %d", dtype);
+    if (B > 65535) return fail(MHLA_ENOTSUP, "B=%d exceeds grid limit 65535", B);
+    return MHLA_OK;
+}
+
+int mhla_lepe3d(const void* x, int64_t x_sb, int64_t x_sn, const float* w_taps, const float* bias, const void* add,
+                int64_t add_sb, int64_t add_sn, void* y, int64_t y_sb, int64_t y_sn, int B, int F, int H, int W, int C,
+                int flip, int dtype, void* stream) {
+    RC(lepe3d_check(x, y, B, F, H, W, C, dtype));
+    if (!w_taps) return fail(MHLA_EINVAL, "w_taps null");
+    if ((x_sb | x_sn | y_sb | y_sn | (add ? (add_sb | add_sn) : 0)) & 3) return fail(MHLA_EINVAL, "strides must be multiples of 4 elements");
+    Lepe3dArgs a{x, (long)x_sb, (long)x_sn, w_taps, bias, add, (long)add_sb, (long)add_sn, y, (long)y_sb, (long)y_sn, B, F, H, W, C, flip ? 1 : 0};
+    const long work = (long)F * H * W * (C / 8);
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_T(dtype, { RC(launch(k_lepe3d<ET>, dim3((unsigned)((work + 255) / 256), B), dim3(256), 0, st, "k_lepe3d", a)); });
+    return MHLA_OK;
+}
+
+size_t mhla_lepe3d_wgrad_ws_bytes(int C) { return (size_t)LEPE_SLICES * 28 * C * 4; }
+
+int mhla_lepe3d_wgrad(const void* x, int64_t x_sb, int64_t x_sn, const void* dout, int64_t g_sb, int64_t g_sn, float* dwb,
+                      void* ws, size_t ws_bytes, int B, int F, int H, int W, int C, int dtype, void* stream) {
+    RC(lepe3d_check(x, dout, B, F, H, W, C, dtype));
+    if (!dwb || !ws || ((uintptr_t)ws) % 16) return fail(MHLA_EINVAL, "dwb / workspace null or workspace not 16-byte aligned");
+    if (ws_bytes < mhla_lepe3d_wgrad_ws_bytes(C)) return fail(MHLA_EINVAL, "workspace too small: %zu < %zu bytes", ws_bytes, mhla_lepe3d_wgrad_ws_bytes(C));
+    if ((x_sb | x_sn | g_sb | g_sn) & 3) return fail(MHLA_EINVAL, "strides must be multiples of 4 elements");
+    Lepe3dWgradArgs a{x, (long)x_sb, (long)x_sn, dout, (long)g_sb, (long)g_sn, (float*)ws, B, F, H, W, C, LEPE_SLICES};
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_T(dtype, { RC(launch(k_lepe3d_wgrad<ET>, dim3((C + 127) / 128, LEPE_SLICES), dim3(256), 0, st, "k_lepe3d_wgrad", a)); });
+    const int rows_c = 28 * C;
+    RC(launch(k_lepe2d_wgrad_reduce, dim3((rows_c + 63) / 64), dim3(256), 0, st, "k_lepe2d_wgrad_reduce", (const float*)ws, dwb, rows_c, LEPE_SLICES));
+    return MHLA_OK;
+}
+
 static int prologue_check(const void* x, int64_t rows, int C, int dtype, int64_t ldx) {
     if (!x) return fail(MHLA_EINVAL, "null pointer");
     if (rows <= 0 || C <= 0 || (C & 7) || C > 8 * 64 * 8) return fail(MHLA_EINVAL, "rows=%lld C=%d: need C %% 8 == 0 and C <= 4096", (long long)rows, C);

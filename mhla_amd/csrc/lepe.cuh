@@ -181,4 +181,131 @@ __global__ __launch_bounds__(256) void k_lepe2d_wgrad_reduce(const float* __rest
     if (pl == 0 && i < rows_c) dwb[i] = (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]);
 }
 
+// -------------------------------------------------------------------------------------------------
+// 3-D LePE of the Wan host: nn.Conv3d(dim, dim, (3,3,3), 1, (1,1,1), groups=dim) over V laid out as a video
+// (wan/mhla_utils.py:199-201, 349-352: 'b (f h w) c -> b c f h w' and back).  Wan's tokens are in raster order
+// n = (f * H + h) * W + w, channels contiguous: same scheme as the 2-D kernels, 27 taps, no permutes.
+// -------------------------------------------------------------------------------------------------
+struct Lepe3dArgs {
+    const void* x;      // [B, N, C] (strides xsb, xsn)   forward: v            backward-data: dout
+    long xsb, xsn;
+    const float* w;     // [27][C] fp32 (tap-major: tap = (df * 3 + dh) * 3 + dw)
+    const float* bias;  // [C] or nullptr
+    const void* add;    // optional [B, N, C] tensor added to the result, or nullptr
+    long asb, asn;
+    void* y;
+    long ysb, ysn;
+    int B, F, H, W, C;
+    int flip;           // 1: correlate with the flipped kernel (gradient w.r.t. the input)
+};
+
+// grid (ceil(N * C/8 / 256), B); a thread: 8 channels of one token
+template <typename T>
+__global__ __launch_bounds__(256) void k_lepe3d(const Lepe3dArgs a) {
+    const int CG = a.C / 8, HW = a.H * a.W, N = a.F * HW;
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (long)N * CG) return;
+    const int n = (int)(gid / CG), c = (int)(gid - (long)n * CG) * 8, b = blockIdx.y;
+    const int f = n / HW, hw = n - f * HW, h = hw / a.W, w = hw - h * a.W;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+    if (a.bias) {
+        acc0 = *reinterpret_cast<const f32x4*>(a.bias + c);
+        acc1 = *reinterpret_cast<const f32x4*>(a.bias + c + 4);
+    }
+    const T* xb = (const T*)a.x + b * a.xsb + c;
+#pragma unroll
+    for (int df = 0; df < 3; ++df) {
+        const int f2 = f + df - 1;
+        if (f2 < 0 || f2 >= a.F) continue;
+#pragma unroll
+        for (int dh = 0; dh < 3; ++dh) {
+            const int h2 = h + dh - 1;
+            if (h2 < 0 || h2 >= a.H) continue;
+#pragma unroll
+            for (int dw = 0; dw < 3; ++dw) {
+                const int w2 = w + dw - 1;
+                if (w2 < 0 || w2 >= a.W) continue;
+                const int tap = a.flip ? 26 - ((df * 3 + dh) * 3 + dw) : (df * 3 + dh) * 3 + dw;
+                const T* p = xb + (long)((f2 * a.H + h2) * a.W + w2) * a.xsn;
+                const f32x4 x0 = Io<T>::ld4(p), x1 = Io<T>::ld4(p + 4);
+                acc0 += x0 * *reinterpret_cast<const f32x4*>(a.w + (long)tap * a.C + c);
+                acc1 += x1 * *reinterpret_cast<const f32x4*>(a.w + (long)tap * a.C + c + 4);
+            }
+        }
+    }
+    if (a.add) {
+        const T* p = (const T*)a.add + b * a.asb + (long)n * a.asn + c;
+        acc0 += Io<T>::ld4(p);
+        acc1 += Io<T>::ld4(p + 4);
+    }
+    T* yp = (T*)a.y + b * a.ysb + (long)n * a.ysn + c;
+    Io<T>::st4(yp, acc0);
+    Io<T>::st4(yp + 4, acc1);
+}
+
+// Weight / bias gradient, as k_lepe2d_wgrad: a wave = 8 channel groups of 4 channels x 8 token lanes, every 8th token of the
+// slice per lane, shuffle sum over the token lanes; part[slice][28][C] (row 27 = bias) summed by k_lepe2d_wgrad_reduce.
+struct Lepe3dWgradArgs {
+    const void* x;      // v
+    long xsb, xsn;
+    const void* g;      // dout
+    long gsb, gsn;
+    float* part;        // [slices][28][C]
+    int B, F, H, W, C, slices;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_lepe3d_wgrad(const Lepe3dWgradArgs a) {
+    constexpr int NA = 28;
+    const int HW = a.H * a.W, N = a.F * HW;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tl = lane >> 3;
+    const int c = ((blockIdx.x * 4 + wave) * 8 + (lane & 7)) * 4, slice = blockIdx.y;
+    const bool live = c < a.C;
+    const long total = (long)a.B * N, per = (total + a.slices - 1) / a.slices;
+    const long t0 = slice * per, t1 = min(total, t0 + per);
+    f32x4 acc[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (live) {
+        for (long t = t0 + tl; t < t1; t += 8) {
+            const int b = (int)(t / N), n = (int)(t - (long)b * N);
+            const int f = n / HW, hw = n - f * HW, h = hw / a.W, w = hw - h * a.W;
+            const f32x4 g = Io<T>::ld4((const T*)a.g + b * a.gsb + (long)n * a.gsn + c);
+            acc[27] += g;
+            const T* xb = (const T*)a.x + b * a.xsb + c;
+#pragma unroll
+            for (int df = 0; df < 3; ++df) {
+                const int f2 = f + df - 1;
+                const bool okf = f2 >= 0 && f2 < a.F;
+#pragma unroll
+                for (int dh = 0; dh < 3; ++dh) {
+                    const int h2 = h + dh - 1;
+                    const bool okh = okf && h2 >= 0 && h2 < a.H;
+#pragma unroll
+                    for (int dw = 0; dw < 3; ++dw) {
+                        const int w2 = w + dw - 1;
+                        if (okh && w2 >= 0 && w2 < a.W)
+                            acc[(df * 3 + dh) * 3 + dw] += g * Io<T>::ld4(xb + (long)((f2 * a.H + h2) * a.W + w2) * a.xsn);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float v = acc[i][t];
+            v += __shfl_xor(v, 8, 64);
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            acc[i][t] = v;
+        }
+    if (live && tl == 0) {
+        float* out = a.part + (long)slice * NA * a.C + c;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4*>(out + (long)i * a.C) = acc[i];
+    }
+}
+
 }  // namespace mhla

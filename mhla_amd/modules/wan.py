@@ -11,7 +11,7 @@ from typing import Dict, Tuple
 import torch
 from torch import nn
 
-from ..ops import mhla_blockmix, mhla_blockmix_wan, qk_prologue, rmsnorm_gate
+from ..ops import lepe3d, mhla_blockmix, mhla_blockmix_wan, qk_prologue, rmsnorm_gate
 from ..weights import block_index_3d
 from .blockconv import BlockDistanceConv3D
 
@@ -139,10 +139,8 @@ class MHLA_Video_Uni(nn.Module):
         if idx.numel() != N:
             raise ValueError(f"sequence length {N} != F*H*W = {idx.numel()} (no padding path, as in the reference)")
         q, k, v = self.q(x), self.k(x), self.v(x)
-        lepe = None
-        if self.is_lepe:
-            F_, H_, W_ = grid
-            lepe = self.lepe(v.reshape(B, F_, H_, W_, C).permute(0, 4, 1, 2, 3)).permute(0, 2, 3, 4, 1).reshape(B, N, C)
+        # LePE (mhla_utils.py:283-285, 363-364): depthwise 3x3x3 conv over V on the raster token layout, added to the output
+        v_lepe = v
         dtype = q.dtype
         W = self.block_attn.conv.weight
         fused = (not (torch.is_grad_enabled() and (x.requires_grad or W.requires_grad or self.q.weight.requires_grad))
@@ -158,7 +156,7 @@ class MHLA_Video_Uni(nn.Module):
             out = mhla_blockmix_wan(q, k, v.float().reshape(B, N, H, D), W, cos, sin, self.g_norm.weight, self.g_norm.eps,
                                     gate, dtype, eps=self.eps, normalize=self.normalize_out, block_index=idx).reshape(B, N, C)
             if self.is_lepe:
-                out = out + lepe
+                out = lepe3d(v_lepe, self.lepe.weight, self.lepe.bias, grid, add=out)
             return self.o(out)
         elif D % 8 == 0 and C <= 2048:
             # training: norm + relu + eps and the rotated copy in one kernel per tensor (and one for their backward)
@@ -185,5 +183,5 @@ class MHLA_Video_Uni(nn.Module):
         gate = self.g(x).reshape(B, N, H, D) if self.is_gated else None
         out = rmsnorm_gate(out, gate, self.g_norm.weight, self.g_norm.eps).reshape(B, N, C)   # :357-362
         if self.is_lepe:
-            out = out + lepe
+            out = lepe3d(v_lepe, self.lepe.weight, self.lepe.bias, grid, add=out)
         return self.o(out)

@@ -274,6 +274,66 @@ def lepe2d(v: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], 
     return _Lepe2d.apply(v, weight, bias, add, int(pieces_len), int(block_len))
 
 
+class _Lepe3d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, v, weight, bias, add, grid):
+        lib = _lib.load()
+        _require_gpu(v, weight, bias, add)
+        B, N, C = v.shape
+        F_, H_, W_ = grid
+        v = _tok3(v)
+        w_taps = weight.detach().reshape(C, 27).t().to(torch.float32).contiguous()
+        b32 = bias.detach().to(torch.float32).contiguous() if bias is not None else None
+        addc = _tok3(add) if add is not None else None
+        y = torch.empty((B, N, C), dtype=v.dtype, device=v.device)
+        rc = lib.mhla_lepe3d(v.data_ptr(), v.stride(0), v.stride(1), w_taps.data_ptr(),
+                             b32.data_ptr() if b32 is not None else None,
+                             addc.data_ptr() if addc is not None else None,
+                             addc.stride(0) if addc is not None else 0, addc.stride(1) if addc is not None else 0,
+                             y.data_ptr(), y.stride(0), y.stride(1), B, F_, H_, W_, C, 0, _dtype_code(v), _stream())
+        _lib.check(rc, "mhla_lepe3d")
+        ctx.save_for_backward(v, w_taps)
+        ctx.cfg = (grid, weight.shape, weight.dtype, bias is not None, bias.dtype if bias is not None else None, add is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        v, w_taps = ctx.saved_tensors
+        (F_, H_, W_), w_shape, w_dtype, has_bias, b_dtype, has_add = ctx.cfg
+        B, N, C = v.shape
+        dy = _tok3(dy.to(v.dtype))
+        dv = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dv = torch.empty((B, N, C), dtype=v.dtype, device=v.device)
+            rc = lib.mhla_lepe3d(dy.data_ptr(), dy.stride(0), dy.stride(1), w_taps.data_ptr(), None, None, 0, 0,
+                                 dv.data_ptr(), dv.stride(0), dv.stride(1), B, F_, H_, W_, C, 1, _dtype_code(v), _stream())
+            _lib.check(rc, "mhla_lepe3d (input gradient)")
+        if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+            dwb = torch.empty((28, C), dtype=torch.float32, device=v.device)
+            ws = _ws(lib.mhla_lepe3d_wgrad_ws_bytes(C), v.device)
+            rc = lib.mhla_lepe3d_wgrad(v.data_ptr(), v.stride(0), v.stride(1), dy.data_ptr(), dy.stride(0), dy.stride(1),
+                                       dwb.data_ptr(), ws.data_ptr(), ws.numel() * 4, B, F_, H_, W_, C, _dtype_code(v), _stream())
+            _lib.check(rc, "mhla_lepe3d_wgrad")
+            dw = dwb[:27].t().reshape(w_shape).to(w_dtype)
+            if has_bias:
+                db = dwb[27].to(b_dtype)
+        return dv, dw, db, (dy if has_add else None), None
+
+
+def lepe3d(v: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], grid, add: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Depthwise 3 x 3 x 3 conv of the Wan host's LePE branch on its own token layout:
+    `conv3d(v as video, weight [C,1,3,3,3], bias, padding=1, groups=C)` (+ `add`), with v, add, result [B, N, C] in raster
+    token order n = (f*H + h)*W + w, grid = (F, H, W).  Replaces the rearranges + nn.Conv3d at wan/mhla_utils.py:199-201,
+    349-352 and the add at :363-364.  Differentiable w.r.t. v, weight, bias, add."""
+    F_, H_, W_ = (int(g) for g in grid)
+    if v.dim() != 3 or weight.dim() != 5 or tuple(weight.shape[1:]) != (1, 3, 3, 3):
+        raise ValueError("v: [B, N, C]; weight: [C, 1, 3, 3, 3]")
+    if v.shape[1] != F_ * H_ * W_ or weight.shape[0] != v.shape[2]:
+        raise ValueError(f"N={v.shape[1]} != F*H*W={F_ * H_ * W_} or channel mismatch")
+    return _Lepe3d.apply(v, weight, bias, add, (F_, H_, W_))
+
+
 def mhla_blockmix_wan(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, W: torch.Tensor, rope_cos: Optional[torch.Tensor],
                       rope_sin: Optional[torch.Tensor], norm_weight: Optional[torch.Tensor], norm_eps: float,
                       gate: Optional[torch.Tensor], out_dtype: torch.dtype, *, eps: float = 1e-6, normalize: bool = True,

@@ -152,13 +152,20 @@ def load_wan_utils():
     return _WAN
 
 
-def gen_wan(tag, seed, B, heads, dim_head, layout, grid, normalize_out, is_gated):
+def x_grad_of_sum(m, x, seq_lens, grid_sizes, freqs):
+    """d(sum of the module output)/dx: pins the module-level backward (LePE branch included)."""
+    xg = x.clone().requires_grad_(True)
+    m(xg, seq_lens, grid_sizes, freqs).sum().backward()
+    return xg.grad
+
+
+def gen_wan(tag, seed, B, heads, dim_head, layout, grid, normalize_out, is_gated, is_lepe=False):
     wan = load_wan_utils()
     stub = wan._stub
     torch.manual_seed(seed)
     dim = heads * dim_head
     m = wan.MHLA_Video_Uni(dim, num_heads=heads, block_layout=layout, normalize_out=normalize_out,
-                           is_gated=is_gated)
+                           is_gated=is_gated, is_lepe=is_lepe)
     m.eval()
     M = layout[0] * layout[1] * layout[2]
     with torch.no_grad():
@@ -216,6 +223,8 @@ def gen_wan(tag, seed, B, heads, dim_head, layout, grid, normalize_out, is_gated
         dv=np32(cap["v"].grad.reshape(B, N, heads, dim_head)),
         dW=np32(m.block_attn.conv.weight.grad.reshape(M, M)),
         freqs_re=freqs.real.numpy()[:64], freqs_im=freqs.imag.numpy()[:64],
+        is_lepe=np.array([int(is_lepe)], dtype=np.int64),
+        dx=np32(x_grad_of_sum(m, x, seq_lens, grid_sizes, freqs)) if is_lepe else np.zeros(1, np.float32),
         **{"sd." + k: v for k, v in sd.items()},
     )
 
@@ -304,6 +313,8 @@ if __name__ == "__main__":
             is_gated=False)
     gen_wan("b", seed=22, B=1, heads=2, dim_head=32, layout=(3, 5, 10), grid=(3, 10, 20), normalize_out=False,
             is_gated=True)
+    gen_wan("c", seed=23, B=2, heads=2, dim_head=32, layout=(2, 2, 3), grid=(4, 6, 9), normalize_out=False,
+            is_gated=True, is_lepe=True)
     gen_causal("a", seed=31, B=2, T=256, H=2, K=16, V=24, L=32)
     gen_causal("b", seed=32, B=1, T=200, H=2, K=32, V=16, L=32, random_mix=True)
     gen_causal("c", seed=33, B=2, T=50, H=1, K=16, V=16, L=32)

@@ -89,6 +89,73 @@ def test_wan_module_fused_inference_path(tag):
     check("fused vs unfused", y, y2.detach().cpu(), 1e-4)
 
 
+def test_wan_module_with_lepe_matches_reference():
+    """is_lepe=True (wan/mhla_utils.py:226-231, 283-285, 363-364): the Conv3d branch runs on the HIP 3-D LePE kernels; module
+    output and d(sum y)/dx against the reference fixture, training and fused inference paths."""
+    from mhla_amd import modules
+    g = load_golden("wan_c")
+    assert int(g["is_lepe"][0]) == 1
+    B, H, D, M, S, fb, hb, wb, F_, H_, W_, normalize, gated = [int(x) for x in g["meta"]]
+    m = modules.MHLA_Video_Uni(H * D, num_heads=H, block_layout=(fb, hb, wb), normalize_out=bool(normalize),
+                               is_gated=bool(gated), is_lepe=True)
+    m.load_state_dict(_sd(g), strict=True)
+    m = m.to(DEV).eval()
+    N = F_ * H_ * W_
+    grid_sizes = torch.tensor([[F_, H_, W_]] * B, dtype=torch.long)
+    import mhla_amd.modules.wan as wanmod
+    calls = []
+    orig = wanmod.lepe3d
+    wanmod.lepe3d = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        x = g["x"].to(DEV).requires_grad_(True)
+        y = m(x, torch.tensor([N] * B), grid_sizes, modules.wan_freqs(D))
+        y.sum().backward()
+        with torch.no_grad():
+            y_inf = m(g["x"].to(DEV), torch.tensor([N] * B), grid_sizes, modules.wan_freqs(D))
+    finally:
+        wanmod.lepe3d = orig
+    assert len(calls) == 2, "HIP LePE not on the module's path"
+    check("y", y, g["y"], 1e-4)
+    check("y (fused inference)", y_inf, g["y"], 1e-4)
+    check("dx", x.grad, g["dx"], 2e-4)
+    assert m.lepe.weight.grad is not None and m.lepe.bias.grad is not None
+
+
+@pytest.mark.parametrize("grid,C,dtype", [((4, 6, 9), 64, torch.float32), ((1, 5, 7), 24, torch.float32), ((3, 1, 1), 8, torch.float32),
+                                          ((5, 8, 10), 1536, torch.bfloat16), ((2, 3, 4), 136, torch.float16)])
+def test_lepe3d_matches_conv3d(grid, C, dtype):
+    """HIP 3-D LePE kernels on the raster token layout vs nn.functional.conv3d on the rearranged video
+    (wan/mhla_utils.py:283-285), V as a strided slice of a packed buffer; gradients w.r.t. v, weight, bias, add."""
+    import torch.nn.functional as F
+    import mhla_amd
+    F_, H_, W_ = grid
+    g = torch.Generator().manual_seed(C + F_)
+    B, N = 2, F_ * H_ * W_
+    qkv = torch.randn(B, N, 3, C, generator=g).to(dtype)
+    w = (torch.randn(C, 1, 3, 3, 3, generator=g) * 0.2).to(dtype)
+    bias = torch.randn(C, generator=g).to(dtype)
+    add = torch.randn(B, N, C, generator=g).to(dtype)
+    dy = torch.randn(B, N, C, generator=g).to(dtype)
+    rv, rw, rb, ra = (t.float().clone().requires_grad_(True) for t in (qkv[:, :, 2], w, bias, add))
+    vid = rv.reshape(B, F_, H_, W_, C).permute(0, 4, 1, 2, 3)
+    want = F.conv3d(vid, rw, rb, padding=1, groups=C).permute(0, 2, 3, 4, 1).reshape(B, N, C) + ra
+    want.backward(dy.float())
+    dq = qkv.to(DEV).requires_grad_(True)
+    dw, db, da = (t.to(DEV).requires_grad_(True) for t in (w, bias, add))
+    poison()
+    got = mhla_amd.lepe3d(dq[:, :, 2], dw, db, grid, add=da)
+    assert got.dtype == dtype
+    poison()
+    got.backward(dy.to(DEV))
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    check("y", got, want, tol)
+    check("dv", dq.grad[:, :, 2], rv.grad, tol)
+    assert float(dq.grad[:, :, :2].abs().max()) == 0.0
+    check("dw", dw.grad, rw.grad, tol)
+    check("dbias", db.grad, rb.grad, tol)
+    check("dadd", da.grad, dy, 1e-6)
+
+
 @pytest.mark.parametrize("K,pl,bl,C,dtype", [(3, 4, 4, 64, torch.float32), (5, 2, 7, 48, torch.float32), (3, 4, 4, 1152, torch.bfloat16),
                                              (5, 4, 4, 384, torch.bfloat16), (3, 1, 6, 8, torch.float32)])
 def test_lepe2d_matches_conv2d(K, pl, bl, C, dtype):
