@@ -399,3 +399,40 @@ def test_minimal_gpt_host_trains_a_step():
         ids2[:, 150:] = (ids2[:, 150:] + 1) % 97
         b = m(ids2)
     check("causal prefix", a[:, :150], b[:, :150].cpu(), 1e-5)
+
+
+def test_wan_block_shell():
+    """Thin Wan block host (model.py:1605-1766 shell around MHLA_Video_Uni): reference parameter names, inference (fused)
+    and training paths agree, and with the residual gates at zero only the cross-attention branch remains."""
+    from mhla_amd import modules
+    from mhla_amd.hosts import WanAttentionBlock_MHLA
+    torch.manual_seed(3)
+    dim, heads, grid = 128, 2, (4, 6, 9)
+    N = grid[0] * grid[1] * grid[2]
+    blk = WanAttentionBlock_MHLA(dim=dim, ffn_dim=256, num_heads=heads, block_layout=(2, 2, 3), is_lepe=True).to(DEV).eval()
+    keys = set(blk.state_dict())
+    for k in ("modulation", "norm3.weight", "self_attn.block_attn.conv.weight", "self_attn.lepe.weight", "self_attn.g_norm.weight",
+              "cross_attn.norm_q.weight", "cross_attn.o.bias", "ffn.0.weight", "ffn.2.bias"):
+        assert k in keys, k
+    B = 2
+    x = torch.randn(B, N, dim, device=DEV)
+    e = torch.randn(B, 6, dim, device=DEV) * 0.1
+    ctx = torch.randn(B, 7, dim, device=DEV)
+    gs = torch.tensor([list(grid)] * B, dtype=torch.long)
+    sl = torch.tensor([N] * B)
+    fr = modules.wan_freqs(dim // heads)
+    with torch.no_grad():
+        y_inf = blk(x, e, sl, gs, fr, ctx, torch.tensor([7, 5]))
+    xg = x.clone().requires_grad_(True)
+    y_tr = blk(xg, e, sl, gs, fr, ctx, torch.tensor([7, 5]))
+    assert y_inf.shape == x.shape and torch.isfinite(y_inf).all()
+    check("inference vs training path", y_inf, y_tr.detach().cpu(), 1e-4)
+    y_tr.sum().backward()
+    assert torch.isfinite(xg.grad).all() and blk.self_attn.block_attn.conv.weight.grad is not None
+    e0 = e.clone()
+    e0[:, 2] = -blk.modulation.detach()[0, 2]
+    e0[:, 5] = -blk.modulation.detach()[0, 5]
+    with torch.no_grad():
+        y0 = blk(x, e0, sl, gs, fr, ctx)
+        want = x + blk.cross_attn(blk.norm3(x), ctx)
+    check("gates at zero", y0, want.cpu(), 1e-5)
