@@ -429,8 +429,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_mix(const MixArgs a) {
 }
 
 // -------------------------------------------------------------------------------------------------
+// LDS row stride (bf16) of a staged D x D summary matrix [KST * 32 rows][KST * 32 columns + 8]: the reads cover KST * 32
+// columns, not the DW of the token tiles (D = 72: 104 instead of 136 -> a third workgroup per CU for the fp32 kernels)
 template <int DT>
-__host__ __device__ constexpr int sp_out_smem() { return 2 * Geo<DT>::KST * 32 * Geo<DT>::LD * 2; }
+__host__ __device__ constexpr int mat_ld() { return Geo<DT>::KST * 32 + 8; }
+template <int DT, bool S16 = false>   // bf16 summaries: no lo tile
+__host__ __device__ constexpr int sp_out_smem() { return (S16 ? 1 : 2) * Geo<DT>::KST * 32 * mat_ld<DT>() * 2; }
 
 // EPI: the per-head RMSNorm (x SiLU gate) that follows the operator in the Wan host (wan/mhla_utils.py:356-362) is applied
 // to the token's D outputs before they are stored, in the dtype TO of the host's activations: O is rounded to TO (the
@@ -438,7 +442,7 @@ __host__ __device__ constexpr int sp_out_smem() { return 2 * Geo<DT>::KST * 32 *
 // D x D summary matrix (fp32, or bf16 when S16) -> LDS [KP][LD] hi (/ lo) tiles; rows and columns >= D zero.  NT threads.
 template <int DT, bool S16, int NT = NTHREADS>
 __device__ __forceinline__ void stage_mat_split(u16* __restrict__ Gh, u16* __restrict__ Gl, const float* __restrict__ base, long elem_off, int D, int tid) {
-    constexpr int LD = Geo<DT>::LD, CGS = Geo<DT>::CGS, RPP = NT / CGS, KP = Geo<DT>::KST * 32;
+    constexpr int LD = mat_ld<DT>(), CGS = Geo<DT>::CGS, RPP = NT / CGS, KP = Geo<DT>::KST * 32;
     const int r0 = tid / CGS, cg = (tid % CGS) * 8;
     constexpr int PASSES = (KP + RPP - 1) / RPP, UB = PASSES < 4 ? PASSES : (PASSES % 4 == 0 ? 4 : (PASSES % 3 == 0 ? 3 : 2));
     static_assert(PASSES % UB == 0, "staging batches must tile the passes");
@@ -465,7 +469,7 @@ __device__ __forceinline__ void stage_mat_split(u16* __restrict__ Gh, u16* __res
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
             const int r = r0 + RPP * (pb + u), off = r * LD + cg;
-            if (r < KP) {
+            if (r < KP && cg < KP) {
                 if (S16) {
                     *reinterpret_cast<uint4*>(Gh + off) = x16[u];
                 } else {
@@ -494,7 +498,7 @@ __device__ __forceinline__ f32x4 raw4_to_f32(float, f32x4 r) { return r; }
 constexpr int SP_OUT_T = 512;   // 8 waves share the staged G_i: twice the loads in flight per LDS byte
 template <typename T, int DT, typename TO = T, bool EPI = false>
 __global__ __launch_bounds__(SP_OUT_T, 2) void k_sp_out(const OutArgs a) {
-    constexpr int LD = Geo<DT>::LD, KST = Geo<DT>::KST, KP = KST * 32, TILE = KP * LD;
+    constexpr int LD = mat_ld<DT>(), KST = Geo<DT>::KST, KP = KST * 32, TILE = KP * LD;
     constexpr bool LO = !std::is_same<T, bf16_t>::value;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u16* Gh = reinterpret_cast<u16*>(smem_raw);   // [d1][d2], rows >= D and columns >= D zero
@@ -715,8 +719,8 @@ __global__ __launch_bounds__(NTHREADS) void k_sp_dw(const DwArgs a) {
 //   k_sp_bwd_dq : dQ_i = (dO_i / n_i) G_i^T (+ dz_i ksum_i^T) ; dksum_i = Qden_i^T dz_i ; dQden_i = dz_i ksum_i^T (split)
 //   k_sp_bwd_dkv: dK_j = V_j dKV_j^T (+ dksum_j) ; dV_j = K_j dKV_j ; dKden_j = 1 dksum_j^T (split)
 // -------------------------------------------------------------------------------------------------
-template <int DT>
-__host__ __device__ constexpr int sp_tok_smem() { return sp_out_smem<DT>() + Geo<DT>::DW * 4 * 4 + Geo<DT>::DW * 4; }
+template <int DT, bool S16 = false>
+__host__ __device__ constexpr int sp_tok_smem() { return sp_out_smem<DT, S16>() + Geo<DT>::DW * 4 * 4 + Geo<DT>::DW * 4; }
 
 // A operand with the reduction index along the rows' columns: A[m][k] = T[c0 + m][k0 + 8 kg .. + 7]
 __device__ __forceinline__ bf16x8 row_read8(const u16* tile, int ld, int c0, int k0, int lane) {
@@ -725,11 +729,11 @@ __device__ __forceinline__ bf16x8 row_read8(const u16* tile, int ld, int c0, int
 
 template <typename T, int DT>
 __global__ __launch_bounds__(NTHREADS, 2) void k_sp_bwd_dq(const TokArgs a) {
-    constexpr int LD = Geo<DT>::LD, DW = Geo<DT>::DW, KST = Geo<DT>::KST, TILE = KST * 32 * LD;
+    constexpr int LD = mat_ld<DT>(), DW = Geo<DT>::DW, KST = Geo<DT>::KST, TILE = KST * 32 * LD;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u16* Gh = reinterpret_cast<u16*>(smem_raw);
-    u16* Gl = Gh + TILE;
-    float* dksw = reinterpret_cast<float*>(Gl + TILE);   // [4 waves][DW]
+    u16* Gl = Gh + TILE;                                  // not allocated for bf16 summaries
+    float* dksw = reinterpret_cast<float*>(Gh + (Sum16<T>::value ? 1 : 2) * TILE);   // [4 waves][DW]
     float* ksum = dksw + 4 * DW;                          // [DW]
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nl = lane & 15, kg = lane >> 4;
     const int blk = blockIdx.x, bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H, S = a.S, D = a.D, M = a.M;
@@ -858,12 +862,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_bwd_dq(const TokArgs a) {
 
 template <typename T, int DT>
 __global__ __launch_bounds__(NTHREADS, 2) void k_sp_bwd_dkv(const TokArgs a) {
-    constexpr int LD = Geo<DT>::LD, DW = Geo<DT>::DW, KST = Geo<DT>::KST, TILE = KST * 32 * LD;
+    constexpr int LD = mat_ld<DT>(), DW = Geo<DT>::DW, KST = Geo<DT>::KST, TILE = KST * 32 * LD;
     constexpr bool LO = !std::is_same<T, bf16_t>::value;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u16* Gh = reinterpret_cast<u16*>(smem_raw);   // dKV_j [d1][d2]
-    u16* Gl = Gh + TILE;
-    float* dks = reinterpret_cast<float*>(Gl + TILE);   // [DW]
+    u16* Gl = Gh + TILE;                          // not allocated for bf16 summaries
+    float* dks = reinterpret_cast<float*>(Gh + (Sum16<T>::value ? 1 : 2) * TILE);   // [DW]
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nl = lane & 15, kg = lane >> 4;
     const int blk = blockIdx.x, bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H, S = a.S, D = a.D, M = a.M;
     const long p0 = (long)blk * S;

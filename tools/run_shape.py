@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Run a few iterations of one BASELINE.json shape (for rocprofv3):  run_shape.py c3|c4|c4b|c5|c5b|xl|c2b [iters]"""
+"""Run a few iterations of one BASELINE.json shape (for rocprofv3):  run_shape.py c3|c3f|c4|c4b|c5|c5b|xl|c2b [iters]"""
 import os
 import sys
 
@@ -30,10 +30,11 @@ if which in ("c4", "c4b"):
             o.backward(do)
             for t in ts + [W]:
                 t.grad = None
-elif which == "c3":
+elif which in ("c3", "c3f"):   # c3f: the same op in fp32 (the reference trains without autocast)
     B, N, H, D = 32, 256, 16, 72
-    ts = [torch.randn(B, N, H, D, generator=g).abs().bfloat16().to(DEV).requires_grad_(True) for _ in range(3)]
-    do = torch.randn(B, N, H, D, generator=g).bfloat16().to(DEV)
+    dt = torch.float32 if which == "c3f" else torch.bfloat16
+    ts = [torch.randn(B, N, H, D, generator=g).abs().to(dt).to(DEV).requires_grad_(True) for _ in range(3)]
+    do = torch.randn(B, N, H, D, generator=g).to(dt).to(DEV)
     W = block_distance_weights((4, 4), "linear").to(DEV).requires_grad_(True)
 
     def step():
