@@ -406,3 +406,33 @@ def test_full_size_c4_wan_sampled_head():
     out2 = mhla_amd.mhla_blockmix(qr.to(DEV), kr.to(DEV), v.to(DEV), W.to(DEV), normalize=False, block_index=idx.int().to(DEV))
     want2 = orc.blockmix_fwd(sl(qr), sl(kr), sl(v), W, 1e-6, normalize=False)
     check("out_nonorm", out2[:, idx.to(DEV)][:, :, h:h + 1], want2, 1e-3)
+
+
+def test_side_stream_opt_in_matches_oracle_and_repeats():
+    """MHLA_SIDE_STREAM=1 (dW chain forked onto a side stream) stays correct: a child process with the
+    variable set runs the fast-path case against the oracle and checks that repetitions are bit-identical."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import test_gpu_blockmix as t\n"
+        "t.run_case(2, 3, 64, 64, 64, torch.bfloat16, w='rand')\n"
+        "import mhla_amd\n"
+        "from gpu_util import DEV\n"
+        "g = torch.Generator(device=DEV).manual_seed(5)\n"
+        "mk = lambda: torch.randn(8, 4096, 4, 64, device=DEV, dtype=torch.bfloat16, generator=g).abs_().add_(1e-3)\n"
+        "q, k, v, do = mk(), mk(), mk(), mk()\n"
+        "W = torch.rand(64, 64, device=DEV)\n"
+        "res = []\n"
+        "for rep in range(3):\n"
+        "    ts = [x.clone().requires_grad_(True) for x in (q, k, v, W)]\n"
+        "    mhla_amd.mhla_blockmix(*ts).backward(do)\n"
+        "    torch.cuda.synchronize()\n"
+        "    res.append([x.grad.clone() for x in ts])\n"
+        "assert all(torch.equal(a, b) for r in res[1:] for a, b in zip(res[0], r)), 'side stream: repetitions differ'\n"
+        "print('ok')\n"
+    ) % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, MHLA_SIDE_STREAM="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout[-2000:] + out.stderr[-2000:]
