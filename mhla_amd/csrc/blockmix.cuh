@@ -517,26 +517,33 @@ __global__ __launch_bounds__(NTHREADS) void k_dw(const DwArgs a) {
 
 // dW[i][j] = sum over parts of dWp[part][i][j]  (parts = (b,h) x E-slices; fixed summation order -> deterministic).
 //   MASK 1: j < i from dWp, j == i from diag[bh][i] (nbh rows), j > i left untouched.
-// 256 threads: 64 elements x 4 part-lanes, then a 4-way LDS reduce.
-template <int MASK>
+// 256 threads: EL elements x (256 / EL) part-lanes, then an LDS reduce in lane order.  EL = 64 for large M; EL = 16 when M * M is
+// small and the parts are many (M = 16: 4 workgroups each summing 384 values per thread took 20 us).
+template <int MASK, int EL = 64>
 __global__ __launch_bounds__(256) void k_dw_reduce(const float* __restrict__ dwp, const float* __restrict__ diag,
                                                    float* __restrict__ dW, int ldd, int M, int nparts, int nbh) {
-    __shared__ float red[4][64];
-    const int el = threadIdx.x & 63, pl = threadIdx.x >> 6;
-    const int e = blockIdx.x * 64 + el;
+    constexpr int PL = 256 / EL;
+    __shared__ float red[PL][EL];
+    const int el = threadIdx.x % EL, pl = threadIdx.x / EL;
+    const int e = blockIdx.x * EL + el;
     const int i = e < M * M ? e / M : 0, j = e < M * M ? e - i * M : 0;
     float s = 0.f;
     if (e < M * M) {
         if (MASK == 0 || j < i) {
 #pragma unroll 8
-            for (int p = pl; p < nparts; p += 4) s += dwp[(long)p * M * M + e];
+            for (int p = pl; p < nparts; p += PL) s += dwp[(long)p * M * M + e];
         } else if (j == i) {
-            for (int b = pl; b < nbh; b += 4) s += diag[(long)b * M + i];
+            for (int b = pl; b < nbh; b += PL) s += diag[(long)b * M + i];
         }
     }
     red[pl][el] = s;
     __syncthreads();
-    if (pl == 0 && e < M * M && (MASK == 0 || j <= i)) dW[(long)i * ldd + j] = red[0][el] + red[1][el] + red[2][el] + red[3][el];
+    if (pl == 0 && e < M * M && (MASK == 0 || j <= i)) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < PL; ++q) t += red[q][el];
+        dW[(long)i * ldd + j] = t;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -730,6 +730,7 @@ __global__ void k_fs_dw_reduce2(const float* __restrict__ tmp, float* __restrict
     if (e >= M * M) return;
     const int i = e / M, j = e - i * M;
     float s = 0.f;
+#pragma unroll 8
     for (int g = 0; g < ngroups; ++g) s += tmp[(long)g * 4096 + i * 64 + j];
     dW[(long)i * M + j] = s;
 }
