@@ -615,8 +615,11 @@ __global__ __launch_bounds__(SP_OUT_T, 2) void k_sp_out(const OutArgs a) {
 constexpr int SP_DW_LD = 68;
 constexpr int SP_DW_SMEM = 64 * SP_DW_LD * 4;
 
-template <bool S16>
+// NT: 16-row tiles per side of the output tile (4: 64 x 64; 1 / 2 when M <= 16 / 32, where the full tile would spend 15/16 or 3/4 of
+// its loads and MFMAs on clamped rows); UE = 4 / NT reduction steps per loop iteration keep the same number of loads in flight.
+template <bool S16, int NT = 4>
 __global__ __launch_bounds__(NTHREADS) void k_sp_dw(const DwArgs a) {
+    constexpr int UE = 4 / NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* Rs = reinterpret_cast<float*>(smem_raw);
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nl = lane & 15, kg = lane >> 4;
@@ -633,70 +636,91 @@ __global__ __launch_bounds__(NTHREADS) void k_sp_dw(const DwArgs a) {
     const long span = eend > ebeg ? eend - ebeg : 0;
     const long wper = ((span + 3) / 4 + 31) & ~31L;                    // E is a multiple of 32
     const long wbeg = ebeg + wave * wper, wend = min(eend, wbeg + wper);
-    const float* xp[4];
-    const float* yp[4];
-    const u16* xp16[4];
-    const u16* yp16[4];
+    const float* xp[NT];
+    const float* yp[NT];
+    const u16* xp16[NT];
+    const u16* yp16[NT];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < NT; ++t) {
         const int ri = min(i0 + t * 16 + nl, M - 1), rj = min(j0 + t * 16 + nl, M - 1);
         xp[t] = a.x + ((long)bh * M + ri) * E + kg * 8;
         yp[t] = a.y + ((long)bh * M + rj) * E + kg * 8;
         xp16[t] = reinterpret_cast<const u16*>(a.x) + ((long)bh * M + ri) * E + kg * 8;
         yp16[t] = reinterpret_cast<const u16*>(a.y) + ((long)bh * M + rj) * E + kg * 8;
     }
-    f32x4 acc[4][4];
+    f32x4 acc[NT][NT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NT; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (long e = wbeg; e < wend; e += 32) {
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (long e0 = wbeg; e0 < wend; e0 += 32 * UE) {
         if constexpr (S16) {   // bf16 summaries: operands as stored
-            bf16x8 xa[4], ya[4];
+            bf16x8 xa[UE][NT], ya[UE][NT];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                xa[t] = *reinterpret_cast<const bf16x8*>(xp16[t] + e);
-                ya[t] = *reinterpret_cast<const bf16x8*>(yp16[t] + e);
+            for (int u = 0; u < UE; ++u) {
+                const long e = e0 + 32 * u;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    xa[u][t] = ya[u][t] = __builtin_bit_cast(bf16x8, make_uint4(0, 0, 0, 0));
+                    if (e < wend) {
+                        xa[u][t] = *reinterpret_cast<const bf16x8*>(xp16[t] + e);
+                        ya[u][t] = *reinterpret_cast<const bf16x8*>(yp16[t] + e);
+                    }
+                }
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int u = 0; u < UE; ++u)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = mfma_bf16(xa[i], ya[j], acc[i][j]);
+                for (int i = 0; i < NT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[i][j] = mfma_bf16(xa[u][i], ya[u][j], acc[i][j]);
             continue;
         }
-        uint4 xh[4], xl[4], yh[4], yl[4];
-        f32x4 raw[8][2];
+        uint4 xh[UE][NT], xl[UE][NT], yh[UE][NT], yl[UE][NT];
+        f32x4 raw[UE][2 * NT][2];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            raw[t][0] = *reinterpret_cast<const f32x4*>(xp[t] + e);
-            raw[t][1] = *reinterpret_cast<const f32x4*>(xp[t] + e + 4);
-            raw[4 + t][0] = *reinterpret_cast<const f32x4*>(yp[t] + e);
-            raw[4 + t][1] = *reinterpret_cast<const f32x4*>(yp[t] + e + 4);
+        for (int u = 0; u < UE; ++u) {
+            const long e = e0 + 32 * u;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                raw[u][t][0] = raw[u][t][1] = raw[u][NT + t][0] = raw[u][NT + t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (e < wend) {
+                    raw[u][t][0] = *reinterpret_cast<const f32x4*>(xp[t] + e);
+                    raw[u][t][1] = *reinterpret_cast<const f32x4*>(xp[t] + e + 4);
+                    raw[u][NT + t][0] = *reinterpret_cast<const f32x4*>(yp[t] + e);
+                    raw[u][NT + t][1] = *reinterpret_cast<const f32x4*>(yp[t] + e + 4);
+                }
+            }
         }
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            split8(raw[t][0], raw[t][1], xh[t], xl[t]);
-            split8(raw[4 + t][0], raw[4 + t][1], yh[t], yl[t]);
+        for (int u = 0; u < UE; ++u)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                split8(raw[u][t][0], raw[u][t][1], xh[u][t], xl[u][t]);
+                split8(raw[u][NT + t][0], raw[u][NT + t][1], yh[u][t], yl[u][t]);
+            }
+#pragma unroll
+        for (int u = 0; u < UE; ++u) {
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = mfma_bf16(as_bf16x8(xh[u][i]), as_bf16x8(yh[u][j]), acc[i][j]);
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = mfma_bf16(as_bf16x8(xh[u][i]), as_bf16x8(yl[u][j]), acc[i][j]);
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = mfma_bf16(as_bf16x8(xl[u][i]), as_bf16x8(yh[u][j]), acc[i][j]);
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = mfma_bf16(as_bf16x8(xh[i]), as_bf16x8(yh[j]), acc[i][j]);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = mfma_bf16(as_bf16x8(xh[i]), as_bf16x8(yl[j]), acc[i][j]);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = mfma_bf16(as_bf16x8(xl[i]), as_bf16x8(yh[j]), acc[i][j]);
     }
     for (int w = 0; w < 4; ++w) {
         if (wave == w) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < NT; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < NT; ++j)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float* d = Rs + (i * 16 + kg * 4 + r) * SP_DW_LD + j * 16 + nl;
