@@ -730,7 +730,9 @@ int mhla_causal_bwd(mhla_view q, mhla_view k, mhla_view v, const float* mix, int
         else if (V <= 512) RC(launch(fast::k_csf_bwd_tok2<uint16_t, 8>, dim3(n, B * H), dim3(NTHREADS), fast::CSF_TOK2_SMEM, st, "k_csf_bwd_tok", t));
         else               RC(launch(fast::k_csf_bwd_tok<uint16_t>, dim3(n, B * H), dim3(NTHREADS), fast::CSF_TOK_SMEM, st, "k_csf_bwd_tok", t));
         fast::CsfDwArgs d{dP, S, E, w.dwp, n, tiles, nsplit};
-        RC(launch(fast::k_csf_dw, dim3(tiles * tiles, B * H, nsplit), dim3(NTHREADS), fast::CSF_DW_SMEM, st, "k_csf_dw", d));
+        if (n <= 16)      RC(launch(fast::k_csf_dw<1>, dim3(1, B * H, nsplit), dim3(NTHREADS), fast::CSF_DW_SMEM, st, "k_csf_dw<16>", d));
+        else if (n <= 32) RC(launch(fast::k_csf_dw<2>, dim3(1, B * H, nsplit), dim3(NTHREADS), fast::CSF_DW_SMEM, st, "k_csf_dw<32>", d));
+        else              RC(launch(fast::k_csf_dw<4>, dim3(tiles * tiles, B * H, nsplit), dim3(NTHREADS), fast::CSF_DW_SMEM, st, "k_csf_dw", d));
         RC(launch(k_dw_reduce<1>, dim3((n * n + 63) / 64), dim3(256), 0, st, "k_dw_reduce<1>", (const float*)w.dwp,
                   (const float*)w.diag, dmix, lddmix, n, B * H * nsplit, B * H));
         return MHLA_OK;

@@ -690,6 +690,9 @@ struct CsfDwArgs {
 constexpr int CSF_DW_LD = 68;
 constexpr int CSF_DW_SMEM = 64 * CSF_DW_LD * 4;
 
+// NT: 16-row tiles per side (4: 64 x 64; 2 / 1 for n <= 32 / 16 chunks, e.g. the fla layer's 2048-token sequences: no loads or
+// MFMAs on clamped rows)
+template <int NT = 4>
 __global__ __launch_bounds__(NTHREADS) void k_csf_dw(const CsfDwArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* Rs = reinterpret_cast<float*>(smem_raw);
@@ -707,23 +710,24 @@ __global__ __launch_bounds__(NTHREADS) void k_csf_dw(const CsfDwArgs a) {
     const long wlen = (eend > ebeg ? (eend - ebeg) : 0) / 4;             // E is a multiple of 4096: wlen multiple of 64
     const long wbeg = ebeg + wave * wlen;
     // each lane covers 16 consecutive e of a 64-element step: two k-steps of 8 (same permutation for both operands)
-    const u16* xp[4];
-    const u16* yp[4];
+    const u16* xp[NT];
+    const u16* yp[NT];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < NT; ++t) {
         const int ri = min(i0 + t * 16 + nl, n - 1), rj = min(j0 + t * 16 + nl, n - 1);
         xp[t] = a.x + ((long)bh * n + ri) * a.E + wbeg + kg * 16;
         yp[t] = a.y + ((long)bh * n + rj) * a.E + wbeg + kg * 16;
     }
-    f32x4 acc[4][4];
+    f32x4 acc[NT][NT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NT; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll(4 / NT)
     for (long e = 0; e < wlen; e += 64) {
-        bf16x8 xa[4][2], yb[4][2];
+        bf16x8 xa[NT][2], yb[NT][2];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < NT; ++t) {
             xa[t][0] = *reinterpret_cast<const bf16x8*>(xp[t] + e);
             xa[t][1] = *reinterpret_cast<const bf16x8*>(xp[t] + e + 8);
             yb[t][0] = *reinterpret_cast<const bf16x8*>(yp[t] + e);
@@ -732,17 +736,17 @@ __global__ __launch_bounds__(NTHREADS) void k_csf_dw(const CsfDwArgs a) {
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < NT; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = mfma_bf16(xa[i][s], yb[j][s], acc[i][j]);
+                for (int j = 0; j < NT; ++j) acc[i][j] = mfma_bf16(xa[i][s], yb[j][s], acc[i][j]);
     }
     // sum the four waves' tiles in wave order
     for (int w = 0; w < 4; ++w) {
         if (wave == w) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < NT; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < NT; ++j)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float* d = Rs + (i * 16 + kg * 4 + r) * CSF_DW_LD + j * 16 + nl;
