@@ -102,10 +102,26 @@ def _config_name(a):
 def main():
     a = parse()
     from mhla_amd import dist as mdist
+    if a.gpus > 1 and not mdist.launched_by_rendezvous():
+        # `python bench.py --gpus N` without torch.distributed.run: this parent starts the N ranks as fresh child processes
+        # BEFORE it touches the GPU (device_count() does not initialise it) and only relays their exit status
+        ngpu = torch.cuda.device_count()
+        extra = {}
+        if ngpu < a.gpus:
+            extra = {"MHLA_DIST_BACKEND": "gloo", "MHLA_SHARED_GPU_HARNESS": "1"}
+            print(f"[bench] --gpus {a.gpus} with {ngpu} visible GPU(s): ranks share devices and exchange over gloo -- a test of "
+                  "the multi-rank harness, not a scaling measurement", file=sys.stderr)
+        sys.exit(mdist.spawn_local_ranks(a.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:], extra))
     rank, local, world = mdist.init_from_env()
-    if world != a.gpus and rank == 0:
-        print(f"[bench] note: --gpus {a.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    if world != a.gpus:
+        raise SystemExit(f"[bench] --gpus {a.gpus} but the job has WORLD_SIZE={world} ranks")
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback for the product path)"
+    shared = os.environ.get("MHLA_SHARED_GPU_HARNESS") == "1" or world > torch.cuda.device_count()
+    if world > 1:
+        import torch.distributed as dist
+        assert dist.get_world_size() == a.gpus
+        if not shared:
+            assert dist.get_backend() == "nccl", f"multi-GPU ranks must exchange over RCCL, got {dist.get_backend()}"
     local = local % torch.cuda.device_count()   # ranks > GPUs only in the shared-GPU harness test (MHLA_DIST_BACKEND=gloo)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -223,7 +239,9 @@ def main():
             "config": {"workload": f"block-mix MHLA op fwd+bwd, per GPU B={a.B} N={a.N} H={a.H} D={a.D} "
                                    f"M={a.M} S={a.N // a.M} {a.dtype} ({_config_name(a)})",
                        "global_batch": a.B * world, "parallelism": f"dp{world} (batch shards, dW all-reduce only)",
-                       "launch": launch_mode},
+                       "launch": launch_mode,
+                       **({"shared_gpu_harness": f"{world} ranks on {torch.cuda.device_count()} GPU(s), gloo: harness test, "
+                                                  "not a scaling measurement"} if shared else {})},
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS if achieved else None, "traffic": traffic,

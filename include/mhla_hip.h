@@ -69,6 +69,9 @@ const char* mhla_last_error(void);
  * kernel into buf (NUL-terminated, truncated to cap) and clears the records.  Off by default. */
 void mhla_prof_enable(int on);
 int mhla_prof_report(char* buf, size_t cap);
+/* Debugging aid (tools/trace_tiles.py): when buf is a device buffer of 3 * tile_workgroups * 16 uint64, the three tile
+ * kernels of the bf16 fast path write per-workgroup phase timestamps (s_memtime ticks) into it; NULL switches it off. */
+void mhla_debug_set_trace(void* buf);
 
 /* ---- block-mixing (non-causal) MHLA: DiT / ViT / Wan ------------------- */
 

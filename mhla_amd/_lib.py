@@ -27,6 +27,7 @@ SIGNATURES = {
     "mhla_last_error": (c_char_p, []),
     "mhla_prof_enable": (None, [c_int]),
     "mhla_prof_report": (c_int, [c_char_p, c_size_t]),
+    "mhla_debug_set_trace": (None, [c_void_p]),
     "mhla_blockmix_fwd_ws_bytes": (c_size_t, [c_int] * 7 + [c_uint]),
     "mhla_blockmix_bwd_ws_bytes": (c_size_t, [c_int] * 7 + [c_uint]),
     "mhla_blockmix_fwd_keeps_state": (c_int, [c_int] * 7 + [c_uint]),

@@ -11,7 +11,7 @@
 // All contractions run on the fp32-input MFMA (v_mfma_f32_16x16x4_f32): exact fp32, so the
 // same kernels serve fp32, bf16 and fp16 tensors (converted while staging tiles into LDS).
 #pragma once
-#include "common.cuh"
+#include "common.hpp"
 
 namespace mhla {
 
@@ -90,7 +90,7 @@ struct StateArgs {
     int DX, DY;
     long T;
     float alpha;
-    // fused rotary prologue (split.cuh, MODE 0): x feeds KV rotated by the token's angles, cos/sin [rows][D/2] fp32
+    // fused rotary prologue (split.hpp, MODE 0): x feeds KV rotated by the token's angles, cos/sin [rows][D/2] fp32
     const float* rcos;
     const float* rsin;
     long ldr;
@@ -343,10 +343,10 @@ struct OutArgs {
     int H, M, S, D;
     float eps;
     int relu, normalize;
-    const float* rcos;   // fused rotary prologue (split.cuh): q is rotated while it is loaded
+    const float* rcos;   // fused rotary prologue (split.hpp): q is rotated while it is loaded
     const float* rsin;
     long ldr;
-    // fused epilogue (split.cuh, k_sp_out<.., EPI>): y = rmsnorm_D(O) * nw [* silu(gate)] stored in the gate's dtype
+    // fused epilogue (split.hpp, k_sp_out<.., EPI>): y = rmsnorm_D(O) * nw [* silu(gate)] stored in the gate's dtype
     const float* nw;
     float neps;
     View gate;
@@ -562,7 +562,7 @@ struct TokArgs {
     const float* ninv;   // [bh][M][S]  1 / n  (k_wz<0>)
     const float* dz;     // [bh][M][S]  W^T dn (k_wz<1>)
     const float* ksum;   // [bh][M][D]
-    float* dks;          // [bh][M][D]  dksum = Qden^T dz (split.cuh: written by the dQ kernel, read by the dK/dV kernel)
+    float* dks;          // [bh][M][D]  dksum = Qden^T dz (split.hpp: written by the dQ kernel, read by the dK/dV kernel)
     int H, M, S, D;
     float eps;
     int relu, normalize, split;

@@ -12,15 +12,15 @@
 #include <string>
 #include <vector>
 
-#include "blockmix.cuh"
-#include "causal.cuh"
-#include "causal_bf16.cuh"
-#include "epilogue.cuh"
-#include "fused.cuh"
-#include "lepe.cuh"
-#include "fused_tile16.cuh"
-#include "smalln.cuh"
-#include "split.cuh"
+#include "blockmix.hpp"
+#include "causal.hpp"
+#include "causal_bf16.hpp"
+#include "epilogue.hpp"
+#include "fused.hpp"
+#include "lepe.hpp"
+#include "fused_tile16.hpp"
+#include "smalln.hpp"
+#include "split.hpp"
 
 using namespace mhla;
 
@@ -103,6 +103,9 @@ SideStream* side_stream() {
     return &ss;
 }
 
+// debugging aid: per-workgroup phase timestamps of the tile kernels (mhla_debug_set_trace)
+std::atomic<unsigned long long*> g_trace{nullptr};
+
 View cv(const mhla_view& v) { return View{v.ptr, (long)v.sb, (long)v.sn, (long)v.sh}; }
 MView cmv(const mhla_mview& v) { return MView{v.ptr, (long)v.sb, (long)v.sn, (long)v.sh}; }
 
@@ -171,7 +174,7 @@ BmWs bm_carve(void* ws, int B, int H, int M, int S, int D, bool sum16) {
     return w;
 }
 
-// ---- fast path (bf16, D = 64, M <= 64, q_den aliasing q_num): see fused.cuh ----
+// ---- fast path (bf16, D = 64, M <= 64, q_den aliasing q_num): see fused.hpp ----
 struct FastWs {
     fast::u16 *state, *dstate;
     float *z, *ksum, *ninv, *dn, *dz, *dwp, *dwt, *dksum;
@@ -199,14 +202,14 @@ FastWs fast_carve(void* ws, int B, int H, int M, int S) {
     return w;
 }
 bool view_ok16(const mhla_view& v) { return v.ptr && ((uintptr_t)v.ptr % 16) == 0 && ((v.sb | v.sn | v.sh) & 7) == 0; }
-// split-bf16 MFMA kernels (split.cuh): head dims that are multiples of 8, any dtype
+// split-bf16 MFMA kernels (split.hpp): head dims that are multiples of 8, any dtype
 bool sp_shape_ok(int D, unsigned flags) { return (D & 7) == 0 && !(flags & MHLA_FLAG_FORCE_GENERIC); }
 bool view_ok16m(const mhla_mview& v) { return v.ptr && ((uintptr_t)v.ptr % 16) == 0 && ((v.sb | v.sn | v.sh) & 7) == 0; }
-// bf16-MFMA token kernels of the causal operator (causal_bf16.cuh)
+// bf16-MFMA token kernels of the causal operator (causal_bf16.hpp)
 bool cs_bf16_ok(int K, int V, int dtype) { return dtype == MHLA_BF16 && (K & 63) == 0 && (V & 63) == 0 && !getenv("MHLA_CAUSAL_GENERIC"); }
 bool bm_sum16(int D, int dtype, unsigned flags) { return dtype == MHLA_BF16 && sp_shape_ok(D, flags); }
 bool fast_shape_ok(int M, int D, int dtype, bool split) { return dtype == MHLA_BF16 && D == 64 && M <= 64 && !split; }
-// small-sequence single-launch path (smalln.cuh): S = 16 tokens per block, at most 16 blocks, D <= 80
+// small-sequence single-launch path (smalln.hpp): S = 16 tokens per block, at most 16 blocks, D <= 80
 bool sn_shape_ok(int M, int S, int D, int dtype, bool split) {
     return dtype == MHLA_BF16 && S == 16 && M <= 16 && D <= 80 && (D & 7) == 0 && !split;
 }
@@ -237,7 +240,7 @@ int bm_state_and_mix(const mhla_view& q_num, const mhla_view& k_num, const mhla_
     a.H = H; a.M = M; a.S = S; a.D = D; a.eps = eps;
     a.relu = (flags & MHLA_FLAG_RELU_EPS) ? 1 : 0; a.normalize = normalize; a.split = split;
     MixArgs m{W, ldw, w.kv, w.g, M, (long)D * D};
-    if (sp_shape_ok(D, flags)) {   // split-bf16 MFMA kernels (split.cuh)
+    if (sp_shape_ok(D, flags)) {   // split-bf16 MFMA kernels (split.hpp)
         if (a.rcos) RC(launch(sp::k_sp_state<T, DT, 0, true>, dim3(M, B * H), dim3(NTHREADS), sp::sp_state_smem<DT>(), st, "k_sp_state<rope>", a));
         else        RC(launch(sp::k_sp_state<T, DT, 0>, dim3(M, B * H), dim3(NTHREADS), sp::sp_state_smem<DT>(), st, "k_sp_state", a));
         RC(launch(sp::k_sp_mix<0, sp::Sum16<T>::value>, dim3((unsigned)((m.E + sp::SPM_TE - 1) / sp::SPM_TE), (M + 63) / 64, B * H), dim3(NTHREADS), sp::sp_mix_smem<sp::Sum16<T>::value>(), st, "k_sp_mix<0>", m));
@@ -350,6 +353,8 @@ int mhla_prof_report(char* buf, size_t cap) {
 }
 const char* mhla_last_error(void) { return g_err; }
 
+void mhla_debug_set_trace(void* buf) { g_trace = (unsigned long long*)buf; }
+
 // 1 when mhla_blockmix_fwd leaves reusable block summaries in its workspace for this problem (pass it as fwd_ws to the
 // backward), 0 when the forward is stateless (generic recompute / small-sequence path).
 int mhla_blockmix_fwd_keeps_state(int B, int H, int M, int S, int D, int dtype, int split, unsigned flags) {
@@ -411,6 +416,7 @@ static int bm_fwd_impl(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view 
         fast::FsOutArgs oa{};
         oa.q = cv(q_num); oa.o = cmv(out); oa.idx = block_index; oa.W = W; oa.ldw = ldw; oa.state = f.state; oa.ninv = f.ninv;
         oa.H = H; oa.M = M; oa.S = S; oa.njg = f.njg; oa.eps = eps; oa.relu = relu; oa.normalize = normalize;
+        oa.trace = g_trace.load();
         RC(launch(fast::k_t16_out, dim3(((f.njg + 1) / 2) * B * H), dim3(fast::FT8), fast::FS_GT16_BYTES, st, "k_t16_out", oa));
         return MHLA_OK;
     }
@@ -559,7 +565,11 @@ int mhla_blockmix_bwd(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q
             ta.dz = f.dz; ta.ksum = ksum; ta.H = H; ta.M = M; ta.S = S; ta.njg = f.njg; ta.eps = eps; ta.relu = relu;
             ta.normalize = normalize;
             ta.dksum = f.dksum;
+            const long ntile_wgs = (long)((f.njg + 1) / 2) * B * H;
+            unsigned long long* tr = g_trace.load();   // regions: [0] k_t16_out, [1] k_t16_bwd_dq, [2] k_t16_bwd_dkv
+            ta.trace = tr ? tr + ntile_wgs * fast::TRACE_SLOTS : nullptr;
             RC(launch(fast::k_t16_bwd_dq, dim3(((f.njg + 1) / 2) * B * H), dim3(fast::FT8), fast::FS_GT16_BYTES, st, "k_t16_bwd_dq", ta));
+            ta.trace = tr ? tr + 2 * ntile_wgs * fast::TRACE_SLOTS : nullptr;
             RC(launch(fast::k_t16_bwd_dkv, dim3(((f.njg + 1) / 2) * B * H), dim3(fast::FT8), fast::FS_GT16_BYTES, st, "k_t16_bwd_dkv", ta));
             if (sd != st) {   // join: the caller's stream continues only after dW is complete
                 if (hipEventRecord(ss->join, sd) != hipSuccess || hipStreamWaitEvent(st, ss->join, 0) != hipSuccess)
@@ -592,7 +602,7 @@ int mhla_blockmix_bwd(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q
         t.idx = block_index; t.W = W; t.ldw = ldw; t.g = w.g; t.dkv = w.dkv; t.ninv = w.ninv; t.dz = w.dz; t.ksum = w.ksum;
         t.dks = w.dks;
         t.H = H; t.M = M; t.S = S; t.D = D; t.eps = eps; t.relu = relu; t.normalize = normalize; t.split = split;
-        if (sp_shape_ok(D, flags)) {   // split-bf16 MFMA kernels (split.cuh)
+        if (sp_shape_ok(D, flags)) {   // split-bf16 MFMA kernels (split.hpp)
             const long E = (long)D * D;
             RC(launch(sp::k_sp_state<ET, DT, 1>, dim3(M, B * H), dim3(NTHREADS), sp::sp_state_smem<DT>(), st, "k_sp_state<1>", a));
             if (normalize)
@@ -665,7 +675,7 @@ int mhla_causal_fwd(mhla_view q, mhla_view k, mhla_view v, const float* mix, int
     hipStream_t st = (hipStream_t)stream;
     const long E = (long)K * V;
     if (pipe16) {
-        // bf16 pipeline (causal_bf16.cuh): bf16 chunk summaries, bf16 MFMA everywhere
+        // bf16 pipeline (causal_bf16.hpp): bf16 chunk summaries, bf16 MFMA everywhere
         fast::CsfStateArgs s{cv(k), cv(v), (uint16_t*)w.S, H, n, K, V, (long)T, 1.f};
         RC(launch(fast::k_csf_state, dim3(n, B * H, K / 64), dim3(NTHREADS), fast::CSF_STATE_SMEM, st, "k_csf_state", s));
         fast::CsfMixArgs m{mix, ldmix, (const uint16_t*)w.S, (uint16_t*)w.P, n, E};

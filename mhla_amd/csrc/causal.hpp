@@ -7,7 +7,7 @@
 //             k_dw<1> + k_dw_reduce<1>: dmix ; k_cs_bwd_tok: dQ, dK, dV, diag(dmix).
 // Every contraction is a 64x64x64 fp32-MFMA tile product; K and V are walked in slices of 64.
 #pragma once
-#include "blockmix.cuh"
+#include "blockmix.hpp"
 
 namespace mhla {
 

@@ -1,5 +1,5 @@
 // bf16-MFMA token kernels of the causal chunk-mixing operator (bf16 tensors, K and V multiples of 64).
-// Same structure as k_cs_out / k_cs_bwd_tok (causal.cuh): every contraction is a 64 x 64 x 64 tile product, but the
+// Same structure as k_cs_out / k_cs_bwd_tok (causal.hpp): every contraction is a 64 x 64 x 64 tile product, but the
 // tiles live in LDS as bf16 ([64][72], row-major) and run on v_mfma_f32_16x16x32_bf16: operands whose reduction
 // index is the row index of the staged tile come through the hardware transpose read.
 // The chunk summaries S, P, dP, dS are kept as bf16 [bh][n][K][V] in the workspace (half the HBM traffic of the
@@ -8,8 +8,8 @@
 // For bf16 inputs all products are exact and accumulate in fp32; intermediates that feed a second contraction
 // (tril(QK^T), tril(dO V^T), S, P, dP, dS) carry one bf16 rounding each.
 #pragma once
-#include "causal.cuh"
-#include "fused.cuh"
+#include "causal.hpp"
+#include "fused.hpp"
 
 namespace mhla {
 namespace fast {
@@ -723,7 +723,7 @@ __global__ __launch_bounds__(NTHREADS) void k_csf_dw(const CsfDwArgs a) {
     for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll(4 / NT)
+#pragma unroll 4 / NT
     for (long e = 0; e < wlen; e += 64) {
         bf16x8 xa[NT][2], yb[NT][2];
 #pragma unroll

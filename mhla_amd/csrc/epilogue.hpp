@@ -3,7 +3,7 @@
 // Wan's MHLA_Video_Uni (g_norm [x SiLU(g)], mhla_videogen/diffusion/model/wan/mhla_utils.py:357-362).
 // One wave per row (token, head); fp32 math; HBM-bound streaming kernel with 4-wide vector I/O.
 #pragma once
-#include "common.cuh"
+#include "common.hpp"
 
 namespace mhla {
 

@@ -10,7 +10,7 @@
 // O_i = Q_i G_i (forward) or dQ/dK/dV (backward).  W is split into bf16 hi + lo parts (2 MFMAs) so the
 // mixing weights keep ~16 mantissa bits.  All contractions: v_mfma_f32_16x16x32_bf16, fp32 accumulate.
 //
-//   forward : k_fs_state_fwd (KV^T, ksum, z) -> k_fs_wz<0> (1/n) -> k_t16_out (mix + O)        [fused_tile16.cuh]
+//   forward : k_fs_state_fwd (KV^T, ksum, z) -> k_fs_wz<0> (1/n) -> k_t16_out (mix + O)        [fused_tile16.hpp]
 //   backward: k_fs_state<1> (dG^T, dn) -> k_fs_wz<1> (dz) -> k_fs_dw/dwz/reduce (dW) -> k_t16_bwd_dq (mix G; dQ, dksum)
 //             -> k_t16_bwd_dkv (mix dKV; dK, dV)
 // The kernels are bound by per-wave load latency, not bandwidth (PMC: 3-4 TB/s, waves mostly in s_waitcnt), so
@@ -18,7 +18,7 @@
 #pragma once
 #include <type_traits>
 
-#include "common.cuh"
+#include "common.hpp"
 
 namespace mhla {
 namespace fast {
@@ -587,7 +587,7 @@ __device__ __forceinline__ void store64(u16* __restrict__ base, long sn, const i
     }
 }
 // -------------------------------------------------------------------------------------------------
-// Arguments of the output kernel (k_t16_out, fused_tile16.cuh): mix the summaries of a tile into LDS, then
+// Arguments of the output kernel (k_t16_out, fused_tile16.hpp): mix the summaries of a tile into LDS, then
 // O_i = (Q_i G_i) / n_i per block, staged in the block's own (dead) LDS slot -- no block barriers.
 // -------------------------------------------------------------------------------------------------
 struct FsOutArgs {
@@ -601,7 +601,21 @@ struct FsOutArgs {
     int H, M, S, njg;
     float eps;
     int relu, normalize;
+    unsigned long long* trace;   // debugging aid (mhla_debug_set_trace): per-workgroup phase timestamps, or null
 };
+// phase timestamp k of this workgroup (s_memtime ticks), first lane only; slot 15 of each record holds the XCC id
+constexpr int TRACE_SLOTS = 16;
+__device__ __forceinline__ void trace_mark(unsigned long long* trace, int k) {
+    if (trace && threadIdx.x == 0) {
+        trace[(long)blockIdx.x * TRACE_SLOTS + k] = __builtin_amdgcn_s_memtime();
+        if (k == 0) {
+            unsigned xcc, hwid;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            trace[(long)blockIdx.x * TRACE_SLOTS + 15] = ((unsigned long long)xcc << 32) | hwid;
+        }
+    }
+}
 constexpr int FS_GT_BYTES = IT * FD * GLD * 2;
 constexpr int FS_OUT_SMEM = FS_GT_BYTES;
 
@@ -736,7 +750,7 @@ __global__ void k_fs_dw_reduce2(const float* __restrict__ tmp, float* __restrict
 }
 
 // -------------------------------------------------------------------------------------------------
-// Arguments of the token-gradient kernels (k_t16_bwd_dq / k_t16_bwd_dkv, fused_tile16.cuh):
+// Arguments of the token-gradient kernels (k_t16_bwd_dq / k_t16_bwd_dkv, fused_tile16.hpp):
 //   dq : Gt = mix(W, KV)    -> dQ_j = (dO_j G_j^T) / n_j + dz_j (x) ksum_j  (relu mask) ; dksum_j
 //   dkv: Gt = mix(W^T, dG)  -> dK_j = V_j dKV_j^T + 1 dksum_j^T (relu mask) ; dV_j = K_j dKV_j
 // -------------------------------------------------------------------------------------------------
@@ -755,6 +769,7 @@ struct FsTokArgs {
     int H, M, S, njg;
     float eps;
     int relu, normalize;
+    unsigned long long* trace;
 };
 constexpr int FS_TOK_SMEM = FS_GT_BYTES;
 

@@ -1,9 +1,9 @@
-// 16-block output tiles for the bf16 fast path (see fused.cuh).  The mixing phase is bound by L2 traffic
+// 16-block output tiles for the bf16 fast path (see fused.hpp).  The mixing phase is bound by L2 traffic
 // (every tile workgroup streams the whole (b,h) state: 512 KB); tiles of 16 blocks halve that traffic and
 // use all 16 MFMA columns.  512 threads, one workgroup per CU (LDS: 16 x 9 KB mixed summaries), wave w owns
 // blocks w and w + 8 of the tile; everything else as in the 8-block kernels.
 #pragma once
-#include "fused.cuh"
+#include "fused.hpp"
 
 namespace mhla {
 namespace fast {
@@ -201,12 +201,19 @@ __global__ __launch_bounds__(FT8, 2) void k_t16_out(const FsOutArgs a) {
         const int iA = it * TT + wave, iB = iA + 8;
         bf16x8 avA[4][2], avB[4][2];
         float ninvA = 1.f, ninvB = 1.f;
+        trace_mark(a.trace, 0);
         if (iA < M) load_blk(avA, ninvA, iA, 0, S);
+        trace_mark(a.trace, 1);
         mix16_tile_to_lds<0>(Gt, state_bh, a.njg, a.W, a.ldw, M, it * TT, tid);
+        trace_mark(a.trace, 2);
         __syncthreads();
+        trace_mark(a.trace, 3);
         if (iB < M) load_blk(avB, ninvB, iB, 0, S);
         if (iA < M) compute_store(avA, ninvA, wave, iA, 0, S);
+        trace_mark(a.trace, 4);
         if (iB < M) compute_store(avB, ninvB, wave + 8, iB, 0, S);
+        trace_mark(a.trace, 5);
+        if (a.trace) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); trace_mark(a.trace, 6); }
         return;
     }
 
@@ -317,13 +324,20 @@ __global__ __launch_bounds__(FT8, 2) void k_t16_bwd_dq(const FsTokArgs a) {
         const int jA = jgx * TT + wave, jB = jA + 8;
         bf16x8 gvA[4][2], gvB[4][2];
         Side sA, sB;
+        trace_mark(a.trace, 0);
         if (jA < M) load_blk(gvA, sA, jA, 0, S);
+        trace_mark(a.trace, 1);
         mix16_tile_to_lds<0>(Gt, a.state + sofs, a.njg, a.W, a.ldw, M, jgx * TT, tid);
+        trace_mark(a.trace, 2);
         __syncthreads();
+        trace_mark(a.trace, 3);
         if (jB < M) load_blk(gvB, sB, jB, 0, S);
         float dks_acc[2][8];
         if (jA < M) { zero_dks(dks_acc); compute_store(gvA, sA, dks_acc, wave, jA, 0, S); if (a.normalize) finish_dks(dks_acc, jA); }
+        trace_mark(a.trace, 4);
         if (jB < M) { zero_dks(dks_acc); compute_store(gvB, sB, dks_acc, wave + 8, jB, 0, S); if (a.normalize) finish_dks(dks_acc, jB); }
+        trace_mark(a.trace, 5);
+        if (a.trace) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); trace_mark(a.trace, 6); }
         return;
     }
     mix16_tile_to_lds<0>(Gt, a.state + sofs, a.njg, a.W, a.ldw, M, jgx * TT, tid);
@@ -436,12 +450,19 @@ __global__ __launch_bounds__(FT8, 2) void k_t16_bwd_dkv(const FsTokArgs a) {
     if (S <= 64) {
         const int jA = jgx * TT + wave, jB = jA + 8;
         bf16x8 kvA[4][2], kvB[4][2];
+        trace_mark(a.trace, 0);
         if (jA < M) load_k(kvA, jA, 0, S);
+        trace_mark(a.trace, 1);
         mix16_tile_to_lds<1>(Gt, a.dstate + sofs, a.njg, a.W, a.ldw, M, jgx * TT, tid);
+        trace_mark(a.trace, 2);
         __syncthreads();
+        trace_mark(a.trace, 3);
         if (jB < M) load_k(kvB, jB, 0, S);
         if (jA < M) compute_store(kvA, wave, jA, 0, S);
+        trace_mark(a.trace, 4);
         if (jB < M) compute_store(kvB, wave + 8, jB, 0, S);
+        trace_mark(a.trace, 5);
+        if (a.trace) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); trace_mark(a.trace, 6); }
         return;
     }
     mix16_tile_to_lds<1>(Gt, a.dstate + sofs, a.njg, a.W, a.ldw, M, jgx * TT, tid);

@@ -6,7 +6,7 @@
 // Channels are contiguous, so a thread owns a few consecutive channels of one token and walks the K*K neighbours
 // (L1 / L2 hits: every token row is read K*K times by neighbouring threads).  HBM-bound streaming kernels.
 #pragma once
-#include "common.cuh"
+#include "common.hpp"
 
 namespace mhla {
 

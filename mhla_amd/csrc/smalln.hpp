@@ -13,7 +13,7 @@
 //   O_i += P V     with B = V rows fetched by two hardware transpose reads that follow the same k-slot order.
 // No shuffle or LDS round trip sits between the two contractions.
 #pragma once
-#include "fused.cuh"
+#include "fused.hpp"
 
 namespace mhla {
 namespace fast {

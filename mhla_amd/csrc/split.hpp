@@ -7,15 +7,15 @@
 // below 2^-17 |a b|).  Three v_mfma_f32_16x16x32_bf16 do the work of eight v_mfma_f32_16x16x4_f32 at a sixteenth of the
 // issue cycles each, and a bf16 operand fetch from LDS moves 8 reduction steps per lane instead of 1 -- the generic
 // fp32-MFMA kernels are bound by exactly those two.  bf16 tensors have lo = 0 and skip the extra products.
-// Workspace formats are the generic path's (blockmix.cuh): KV, G fp32 [bh][M][D][D]; ksum [bh][M][D]; z, 1/n [bh][M][S].
+// Workspace formats are the generic path's (blockmix.hpp): KV, G fp32 [bh][M][D][D]; ksum [bh][M][D]; z, 1/n [bh][M][S].
 //   k_sp_state : KV_j = K_j^T V_j, ksum_j, z_j                     grid (M, bh)
 //   k_sp_mix   : G = W . KV  (or W^T .)                            grid (D^2 / 128, ceil(M / 64), bh)
 //   k_sp_out   : O_i = (Q_i G_i) / n_i, computed transposed so that a lane owns 4 consecutive output features
 #pragma once
 #include <type_traits>
 
-#include "blockmix.cuh"
-#include "fused.cuh"
+#include "blockmix.hpp"
+#include "fused.hpp"
 
 namespace mhla {
 namespace sp {

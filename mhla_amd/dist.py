@@ -4,8 +4,12 @@ exchange a data-parallel step has on this path is the all-reduce of the mixing-w
 (an ordinary parameter gradient that DDP would all-reduce) -- issued here with torch.distributed
 ("nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests)."""
 import os
+import signal
+import socket
+import subprocess
+import sys
 import time
-from typing import Callable, Optional, Tuple
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -23,6 +27,65 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
             backend = os.environ.get("MHLA_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local, world
+
+
+def launched_by_rendezvous() -> bool:
+    """True when the process was started as one rank of a job (torch.distributed.run or spawn_local_ranks)."""
+    return "WORLD_SIZE" in os.environ and "RANK" in os.environ
+
+
+def _free_port() -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_local_ranks(n: int, argv: Sequence[str], env_extra: Optional[Dict[str, str]] = None,
+                      timeout: Optional[float] = None) -> int:
+    """Start `argv` n times as ranks 0..n-1 of one single-node job (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR /
+    MASTER_PORT in the environment, rendezvous on 127.0.0.1) and wait for them.  What `bench.py --gpus N` does when it
+    was not started by torch.distributed.run.  The caller must not have initialised the GPU: every rank is a fresh
+    child process (never an exec of this one), which inherits stdout / stderr.  Returns 0 when every rank exits 0;
+    otherwise the first failing rank's code, after ending the remaining ranks by their own PIDs."""
+    if n < 1:
+        raise ValueError("n must be >= 1")
+    env = dict(os.environ)
+    env.update({"WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port()),
+                "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // n)))
+    env.update(env_extra or {})
+    procs: List[subprocess.Popen] = []
+    for r in range(n):
+        procs.append(subprocess.Popen(list(argv), env=dict(env, RANK=str(r), LOCAL_RANK=str(r))))
+    deadline = None if timeout is None else time.monotonic() + timeout
+    rc = 0
+    live = set(range(n))
+    try:
+        while live:
+            for r in sorted(live):
+                code = procs[r].poll()
+                if code is not None:
+                    live.discard(r)
+                    if code != 0 and rc == 0:
+                        rc = code
+                        print(f"[spawn_local_ranks] rank {r} exited with code {code}; stopping the other ranks", file=sys.stderr)
+            if rc != 0 or (deadline is not None and time.monotonic() > deadline):
+                if rc == 0:
+                    rc = 124
+                    print(f"[spawn_local_ranks] timeout after {timeout} s", file=sys.stderr)
+                break
+            time.sleep(0.05)
+    finally:
+        for r in live:
+            if procs[r].poll() is None:
+                procs[r].send_signal(signal.SIGTERM)
+        for r in live:
+            try:
+                procs[r].wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                procs[r].kill()
+                procs[r].wait()
+    return rc
 
 
 def shard_batch(global_batch: int, rank: int, world: int) -> Tuple[int, int]:

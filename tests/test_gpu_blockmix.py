@@ -80,7 +80,7 @@ def test_fast_path_bf16_d64(M, S):
 
 @pytest.mark.parametrize("M,D", [(16, 64), (16, 72), (9, 72), (4, 80), (1, 64), (13, 24), (16, 8)])
 def test_small_sequence_path(M, D):
-    """bf16, S = 16, M <= 16, D <= 80 (DiT / ViT regime): single-launch attention-form kernels (smalln.cuh)."""
+    """bf16, S = 16, M <= 16, D <= 80 (DiT / ViT regime): single-launch attention-form kernels (smalln.hpp)."""
     run_case(3, 2, M, 16, D, torch.bfloat16, w="rand")
     run_case(2, 2, M, 16, D, torch.bfloat16, normalize=False)
 
@@ -131,7 +131,7 @@ def test_wan_modes(M, S, D, normalize, split):
                                           (3, 40, 88, True), (2, 33, 120, False)])
 def test_split_operand_path(M, S, D, split, dtype):
     """Head dims that are multiples of 8, outside the bf16 fast paths: forward and backward on the split-bf16 MFMA
-    kernels (split.cuh), including the zero-padded tile shapes (D = 72, 80, 104 ...)."""
+    kernels (split.hpp), including the zero-padded tile shapes (D = 72, 80, 104 ...)."""
     run_case(1, 2, M, S, D, dtype, split=split, w="rand", seed=M + S)
 
 

@@ -170,3 +170,48 @@ def test_world_size_2_gloo_sharding_and_dw_allreduce(tmp_path):
         assert p.returncode == 0, o
     from mhla_amd.dist import shard_batch
     assert [shard_batch(7, r, 3) for r in range(3)] == [(0, 3), (3, 5), (5, 7)]
+
+
+SPAWN_WORKER = r"""
+import os, sys, torch
+sys.path.insert(0, os.environ["MHLA_ROOT"])
+import torch.distributed as dist
+from mhla_amd import dist as mdist
+assert mdist.launched_by_rendezvous()
+rank, local, world = mdist.init_from_env("gloo")
+t = torch.tensor([float(rank + 1)])
+dist.all_reduce(t)
+assert world == int(sys.argv[1]) and t.item() == world * (world + 1) / 2
+if len(sys.argv) > 2 and rank == int(sys.argv[2]):
+    sys.exit(7)          # a failing rank: the parent must stop the others and report the code
+dist.barrier()
+dist.destroy_process_group()
+if rank == 0:
+    print("SPAWN_OK", world, flush=True)
+"""
+
+
+def test_spawn_local_ranks_starts_fresh_children(tmp_path, capfd):
+    """What `bench.py --gpus N` does without torch.distributed.run: N child ranks, rendezvous on 127.0.0.1, status relayed."""
+    from mhla_amd.dist import spawn_local_ranks
+    script = tmp_path / "spawn_worker.py"
+    script.write_text(SPAWN_WORKER)
+    env = {"MHLA_ROOT": ROOT, "OMP_NUM_THREADS": "1"}
+    assert spawn_local_ranks(2, [sys.executable, str(script), "2"], env, timeout=240) == 0
+    assert "SPAWN_OK 2" in capfd.readouterr().out
+    assert spawn_local_ranks(2, [sys.executable, str(script), "2", "1"], env, timeout=240) == 7
+
+
+def test_bench_gpus_flag_spawns_ranks_before_touching_the_gpu():
+    """On a box without a GPU every spawned rank must fail loudly ("needs a GPU"), once per rank, and the parent relays it --
+    proof that `python bench.py --gpus 2` starts two ranks (RANK 0 and 1) instead of benchmarking one device."""
+    if torch.cuda.is_available():
+        pytest.skip("CPU-side test of the spawn path")
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "ranks share devices" in r.stderr and "needs a GPU" in r.stderr
+    assert "spawn_local_ranks" in r.stderr

@@ -3,6 +3,7 @@
 with the thin in-repo host (mhla_amd.hosts.DiT_MHLA) around the MHLA4DiT drop-in, synthetic latents, bf16 autocast.
 
   python tools/bench_dit_step.py [--model DiT-XL/2] [--batch 32] [--steps 10] [--warmup 3]
+  python tools/bench_dit_step.py --gpus N                                            (starts N ranks itself)
   python -m torch.distributed.run --nproc-per-node N ... tools/bench_dit_step.py     (DDP over RCCL, one process per GPU)
 
 Informational (bench.py is the contract benchmark); prints one JSON line on rank 0."""
@@ -26,7 +27,11 @@ def main():
     p.add_argument("--image", type=int, default=256, help="image side in pixels (latent side = image / 8)")
     p.add_argument("--steps", type=int, default=10)
     p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--gpus", type=int, default=1, help="ranks to start when not launched by torch.distributed.run")
     a = p.parse_args()
+    if a.gpus > 1 and not mdist.launched_by_rendezvous():   # parent: start the ranks before any GPU call, relay the status
+        extra = {"MHLA_DIST_BACKEND": "gloo"} if torch.cuda.device_count() < a.gpus else {}
+        sys.exit(mdist.spawn_local_ranks(a.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:], extra))
     rank, local, world = mdist.init_from_env()
     local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
