@@ -94,6 +94,9 @@ class MHLA4DiT(nn.Module):
         if self.qk_norm:
             q = torch.relu(self.q_norm(qkv[:, :, 0].reshape(B, M * S, H * D))) + self.eps   # mhla.py:226-230
             k = torch.relu(self.k_norm(qkv[:, :, 1].reshape(B, M * S, H * D))) + self.eps
+            # under autocast the norm runs in fp32 while the projection is bf16/fp16: the reference's matmuls cast q, k back to
+            # the autocast dtype, the operator takes one element type for all token tensors
+            q, k = q.to(qkv.dtype), k.to(qkv.dtype)
             out = mhla_blockmix(q.reshape(B, M * S, H, D), k.reshape(B, M * S, H, D), qkv[:, :, 2], W, eps=self.eps)
         else:
             # operator (relu + eps folded into its loads) and LePE as one autograd node on the packed projection output

@@ -6,6 +6,7 @@ a ROCm device and the library must be built, otherwise these functions raise.
 """
 from __future__ import annotations
 
+import functools
 from typing import Optional
 
 import torch
@@ -34,6 +35,48 @@ def _require_gpu(*ts: torch.Tensor):
                 f"{t.device} tensor (there is no CPU fallback)")
 
 
+def _device_guard(fn):
+    """Run `fn` with the device of its first GPU tensor argument current, so that `_stream()` is that device's stream and
+    the library launches on it (a tensor on cuda:1 while cuda:0 is current would otherwise be launched on the wrong GPU)."""
+    @functools.wraps(fn)
+    def wrapped(*args, **kw):
+        dev = next((a.device for a in args if isinstance(a, torch.Tensor) and a.is_cuda), None)
+        if dev is None:
+            return fn(*args, **kw)
+        with torch.cuda.device(dev):
+            return fn(*args, **kw)
+    return wrapped
+
+
+def _check_like(ref: torch.Tensor, what: str, **tensors):
+    """The C ABI receives raw pointers + strides: shape, dtype and device agreement is checked here, where it is cheap.
+    Every named tensor must have `ref`'s dtype and device; a tuple value is (tensor, expected_shape)."""
+    for name, t in tensors.items():
+        shape = None
+        if isinstance(t, tuple):
+            t, shape = t
+        if t is None:
+            continue
+        if t.device != ref.device:
+            raise ValueError(f"{what}: {name} is on {t.device}, expected {ref.device}")
+        if t.dtype != ref.dtype:
+            raise TypeError(f"{what}: {name} has dtype {t.dtype}, expected {ref.dtype} (cast it: the kernels read every "
+                            "token tensor with one element type)")
+        if shape is not None and tuple(t.shape) != tuple(shape):
+            raise ValueError(f"{what}: {name} has shape {tuple(t.shape)}, expected {tuple(shape)}")
+
+
+def _check_block_index(block_index: Optional[torch.Tensor], N: int, ref: torch.Tensor):
+    if block_index is None:
+        return
+    if block_index.dtype != torch.int32 or not block_index.is_contiguous():
+        raise TypeError("block_index must be a contiguous int32 tensor")
+    if block_index.device != ref.device:
+        raise ValueError(f"block_index is on {block_index.device}, expected {ref.device}")
+    if block_index.numel() != N:
+        raise ValueError(f"block_index has {block_index.numel()} entries, expected N={N}")
+
+
 def _view(t: torch.Tensor) -> View:
     """[B, N, H, D] tensor -> mhla_view (element strides; D must be contiguous)."""
     if t.dim() != 4:
@@ -44,9 +87,12 @@ def _view(t: torch.Tensor) -> View:
 
 
 def _strided_ok(t: torch.Tensor) -> bool:
-    esz = t.element_size()
-    return (t.dim() == 4 and t.stride(3) == 1 and all(s % 4 == 0 for s in t.stride()[:3])
-            and t.data_ptr() % (4 * esz) == 0)
+    """Addressable in place by every kernel family: 16-byte aligned base and 16-byte row pieces (strides that are multiples of
+    8 elements for 16-bit types, 4 for fp32) -- what the bf16 fast paths need, so a view never lands on a slower path or on a
+    workspace-size mismatch because of its alignment."""
+    mult = 8 if t.element_size() == 2 else 4
+    return (t.dim() == 4 and t.stride(3) == 1 and all(s % mult == 0 for s in t.stride()[:3])
+            and t.data_ptr() % 16 == 0)
 
 
 def _prep(t: torch.Tensor) -> torch.Tensor:
@@ -71,6 +117,7 @@ def _ws(nbytes: int, device) -> torch.Tensor:
 # ------------------------------------------------------------------------------------------
 class _BlockMix(torch.autograd.Function):
     @staticmethod
+    @_device_guard
     def forward(ctx, q, k, v, W, q_den, k_den, block_index, eps, normalize, relu_eps, force_generic, no_smalln):
         lib = _lib.load()
         _require_gpu(q, k, v, W, q_den, k_den, block_index)
@@ -82,6 +129,10 @@ class _BlockMix(torch.autograd.Function):
         split = q_den is not None
         if split and not normalize:
             raise ValueError("q_den/k_den given but normalize=False")
+        _check_like(q, "mhla_blockmix", k=(k, q.shape), v=(v, q.shape), q_den=(q_den, q.shape), k_den=(k_den, q.shape))
+        _check_block_index(block_index, N, q)
+        if W.device != q.device or W.dim() < 2 or W.shape[1] != M:
+            raise ValueError(f"W must be a [M, M] (or [M, M, 1, 1]) matrix on {q.device}, got {tuple(W.shape)} on {W.device}")
         q, k, v = _prep(q), _prep(k), _prep(v)
         if split:
             q_den, k_den = _prep(q_den), _prep(k_den)
@@ -109,6 +160,7 @@ class _BlockMix(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_device_guard
     def backward(ctx, dout):
         lib = _lib.load()
         q, k, v, Wf, out, q_den, k_den, block_index, fwd_ws = ctx.saved_tensors
@@ -116,6 +168,7 @@ class _BlockMix(torch.autograd.Function):
         B, N, H, D = q.shape
         M = Wf.shape[0]
         S = N // M
+        _check_like(q, "mhla_blockmix backward", dout=(dout.to(q.dtype), q.shape))
         dout = _prep(dout.to(q.dtype))
         dq = _alloc_like_tokens(B, N, H, D, q)
         dk = _alloc_like_tokens(B, N, H, D, q)
@@ -162,13 +215,15 @@ def mhla_blockmix(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, W: torch.Te
     """
     if (q_den is None) != (k_den is None):
         raise ValueError("q_den and k_den must be given together")
-    if block_index is not None and (block_index.dtype != torch.int32 or not block_index.is_contiguous()):
-        raise TypeError("block_index must be a contiguous int32 tensor")
+    if q.dim() != 4:
+        raise ValueError(f"q: expected [B, N, H, D], got {tuple(q.shape)}")
+    _check_block_index(block_index, q.shape[1], q)
     if q.shape[0] == 0:   # empty batch: nothing to launch; keep the autograd graph connected (all gradients are zero)
         return torch.zeros_like(v) + 0 * (q.sum() + k.sum() + W.sum()).to(v.dtype)
     return _BlockMix.apply(q, k, v, W, q_den, k_den, block_index, eps, normalize, relu_eps, force_generic, no_smalln)
 
 
+@_device_guard
 def mhla_blockmix_rope(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, W: torch.Tensor, rope_cos: torch.Tensor,
                        rope_sin: torch.Tensor, *, eps: float = 1e-6, normalize: bool = True,
                        block_index: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -189,6 +244,8 @@ def mhla_blockmix_rope(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, W: tor
     if N % M:
         raise ValueError(f"N={N} tokens not divisible into M={M} blocks")
     S = N // M
+    _check_like(q, "mhla_blockmix_rope", k=(k, q.shape), v=(v, q.shape))
+    _check_block_index(block_index, N, q)
     if rope_cos.shape != (N, D // 2) or rope_sin.shape != (N, D // 2) or rope_cos.dtype != torch.float32 or rope_sin.dtype != torch.float32:
         raise ValueError(f"rope tables must be fp32 [N={N}, D/2={D // 2}]")
     q, k, v = _prep(q.detach()), _prep(k.detach()), _prep(v.detach())
@@ -215,6 +272,7 @@ def _tok3(t: torch.Tensor) -> torch.Tensor:
 
 class _Lepe2d(torch.autograd.Function):
     @staticmethod
+    @_device_guard
     def forward(ctx, v, weight, bias, add, pieces_len, block_len):
         lib = _lib.load()
         _require_gpu(v, weight, bias, add)
@@ -237,6 +295,7 @@ class _Lepe2d(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_device_guard
     def backward(ctx, dy):
         lib = _lib.load()
         v, w_taps = ctx.saved_tensors
@@ -276,6 +335,7 @@ def lepe2d(v: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], 
 
 class _Lepe3d(torch.autograd.Function):
     @staticmethod
+    @_device_guard
     def forward(ctx, v, weight, bias, add, grid):
         lib = _lib.load()
         _require_gpu(v, weight, bias, add)
@@ -297,6 +357,7 @@ class _Lepe3d(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_device_guard
     def backward(ctx, dy):
         lib = _lib.load()
         v, w_taps = ctx.saved_tensors
@@ -334,6 +395,7 @@ def lepe3d(v: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], 
     return _Lepe3d.apply(v, weight, bias, add, (F_, H_, W_))
 
 
+@_device_guard
 def mhla_blockmix_wan(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, W: torch.Tensor, rope_cos: Optional[torch.Tensor],
                       rope_sin: Optional[torch.Tensor], norm_weight: Optional[torch.Tensor], norm_eps: float,
                       gate: Optional[torch.Tensor], out_dtype: torch.dtype, *, eps: float = 1e-6, normalize: bool = True,
@@ -354,6 +416,8 @@ def mhla_blockmix_wan(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, W: torc
     if N % M:
         raise ValueError(f"N={N} tokens not divisible into M={M} blocks")
     S = N // M
+    _check_like(q, "mhla_blockmix_wan", k=(k, q.shape), v=(v, q.shape))
+    _check_block_index(block_index, N, q)
     q, k, v = _prep(q.detach()), _prep(k.detach()), _prep(v.detach())
     cos = sin = None
     if rope_cos is not None:
@@ -385,6 +449,7 @@ class _DitCore(torch.autograd.Function):
     no per-slice gradient tensors, no zero-fill and slice-adds by autograd."""
 
     @staticmethod
+    @_device_guard
     def forward(ctx, qkv, W, lepe_w, lepe_b, pieces_len, block_len, eps, relu_eps):
         lib = _lib.load()
         _require_gpu(qkv, W, lepe_w, lepe_b)
@@ -416,6 +481,7 @@ class _DitCore(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_device_guard
     def backward(ctx, dy):
         lib = _lib.load()
         qkv, Wf, attn, w_taps, fwd_ws = ctx.saved_tensors
@@ -469,6 +535,7 @@ _FMAPS = {None: 0, "identity": 0, "relu": 1, "elu": 2}
 
 class _FmapRotary(torch.autograd.Function):
     @staticmethod
+    @_device_guard
     def forward(ctx, x, cos, sin, fmap, t_offset):
         lib = _lib.load()
         _require_gpu(x, cos, sin)
@@ -483,6 +550,7 @@ class _FmapRotary(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_device_guard
     def backward(ctx, dy):
         lib = _lib.load()
         x, cos, sin = ctx.saved_tensors
@@ -513,6 +581,7 @@ def featmap_rotary(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, featur
 
 class _QkPrologue(torch.autograd.Function):
     @staticmethod
+    @_device_guard
     def forward(ctx, x, weight, cos, sin, norm_eps, eps, head_dim):
         lib = _lib.load()
         _require_gpu(x, weight, cos, sin)
@@ -539,6 +608,7 @@ class _QkPrologue(torch.autograd.Function):
         return y.reshape(x.shape), None
 
     @staticmethod
+    @_device_guard
     def backward(ctx, dy, dyr):
         lib = _lib.load()
         x2, w, cos, sin = ctx.saved_tensors
@@ -587,6 +657,7 @@ def qk_prologue(x: torch.Tensor, weight: Optional[torch.Tensor], norm_eps: float
 # ------------------------------------------------------------------------------------------
 class _Causal(torch.autograd.Function):
     @staticmethod
+    @_device_guard
     def forward(ctx, q, k, v, mix, chunk_size, scale):
         lib = _lib.load()
         _require_gpu(q, k, v, mix)
@@ -596,6 +667,9 @@ class _Causal(torch.autograd.Function):
         L = mix.shape[0]
         if n > L:
             raise IndexError(f"sequence of {T} tokens needs {n} chunks but mixing_matrix has only {L} rows")
+        _check_like(q, "mhla_causal", k=(k, q.shape), v=(v, (B, T, H, V)))
+        if mix.device != q.device or mix.dim() < 2 or mix.shape[1] < n:
+            raise ValueError(f"mixing_matrix must be [L, L(, 1, 1, 1, 1)] with L >= {n} on {q.device}")
         q, k, v = _prep(q), _prep(k), _prep(v)
         mixf = mix.detach().reshape(L, mix.shape[1]).to(torch.float32).contiguous()
         out = torch.empty((B, T, H, V), dtype=q.dtype, device=q.device)
@@ -611,6 +685,7 @@ class _Causal(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_device_guard
     def backward(ctx, dout):
         lib = _lib.load()
         q, k, v, mixf, fwd_ws = ctx.saved_tensors
@@ -658,6 +733,7 @@ def naive_chunk_simple_mhla_fixed(q, k, v, mixing_matrix, output_final_state: bo
 # ------------------------------------------------------------------------------------------
 class _RmsNormGate(torch.autograd.Function):
     @staticmethod
+    @_device_guard
     def forward(ctx, x, g, weight, eps):
         lib = _lib.load()
         _require_gpu(x, g, weight)
@@ -676,6 +752,7 @@ class _RmsNormGate(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_device_guard
     def backward(ctx, dy):
         lib = _lib.load()
         xc, gc, wf = ctx.saved_tensors
