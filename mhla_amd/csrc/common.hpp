@@ -61,6 +61,31 @@ template <> struct Io<f16_t> {
     }
 };
 
+// Loads / stores through an explicit global (address space 1) pointer.  Pointers that come out of an argument struct or a
+// select are generic to the compiler: it then emits flat_load, which counts on vmcnt AND lgkmcnt and may complete out of
+// order, so every use is preceded by s_waitcnt vmcnt(0) lgkmcnt(0) -- software pipelines of loads collapse into
+// load-all / wait-all.  global_load counts on vmcnt only, in order, and the compiler schedules with vmcnt(N).
+#define MHLA_GLOBAL_AS __attribute__((address_space(1)))
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+template <typename T> __device__ __forceinline__ T gld(const void* p) { return *(const MHLA_GLOBAL_AS T*)(p); }
+template <typename T> __device__ __forceinline__ void gst(void* p, T v) { *(MHLA_GLOBAL_AS T*)(p) = v; }
+// uint4 / uint2 are class types (no address-space-qualified copy): go through the native vector types
+template <> __device__ __forceinline__ uint4 gld<uint4>(const void* p) {
+    const u32x4_t v = *(const MHLA_GLOBAL_AS u32x4_t*)(p);
+    return make_uint4(v[0], v[1], v[2], v[3]);
+}
+template <> __device__ __forceinline__ uint2 gld<uint2>(const void* p) {
+    const u32x2_t v = *(const MHLA_GLOBAL_AS u32x2_t*)(p);
+    return make_uint2(v[0], v[1]);
+}
+template <> __device__ __forceinline__ void gst<uint4>(void* p, uint4 v) {
+    *(MHLA_GLOBAL_AS u32x4_t*)(p) = u32x4_t{v.x, v.y, v.z, v.w};
+}
+template <> __device__ __forceinline__ void gst<uint2>(void* p, uint2 v) {
+    *(MHLA_GLOBAL_AS u32x2_t*)(p) = u32x2_t{v.x, v.y};
+}
+
 // Token-major view [B, N, H, D]; element strides; D contiguous.
 struct View {
     const void* ptr;

@@ -12,45 +12,66 @@ constexpr int TT = 16;                              // blocks per tile
 constexpr int GSLOT = FD * GLD + 8;                  // elements per mixed-summary slot (+16 B: spreads the 16 blocks over banks)
 constexpr int FS_GT16_BYTES = TT * GSLOT * 2;       // 147712 B
 
-template <int TRANSW>
-__device__ __forceinline__ void mix16_tile_to_lds(u16* __restrict__ Gt, const u16* __restrict__ state_bh, int njg,
-                                                  const float* __restrict__ W, int ldw, int M, int i0, int tid) {
+// Eight waves stream the (b,h) state through a ring of NBUF register batches (UN e'-tiles of 16 x 64 blocks each): with
+// plain global loads (address space 1, in-order vmcnt) NBUF - 1 batches stay in flight while one is multiplied.  The mixing is
+// bound by the latency of the state's first touch (the four tile workgroups of a (b,h) run in lockstep on one XCD, so every
+// line is an HBM / MALL fetch for all of them): bytes in flight per wave are what counts.
+template <int TRANSW, bool TWO, int NBUF>
+__device__ __forceinline__ void mix16_tile_impl(u16* __restrict__ Gt, const u16* __restrict__ state_bh, int njg,
+                                                const float* __restrict__ W, int ldw, int M, int i0, int tid) {
     const int wave = tid >> 6, lane = tid & 63, n = lane & 15, kg = lane >> 4;
-    bf16x8 bhi[2], blo[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        s16x8 hi, lo;
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const int j = ks * 32 + kg * 8 + t, i = i0 + n;
-            float w = 0.f;
-            if (i < M && j < M) w = TRANSW ? W[(long)j * ldw + i] : W[(long)i * ldw + j];
-            const u16 h = cvt_bf16(w);
-            hi[t] = (short)h;
-            lo[t] = (short)cvt_bf16(w - bf(h));
-        }
-        bhi[ks] = __builtin_bit_cast(bf16x8, hi);
-        blo[ks] = __builtin_bit_cast(bf16x8, lo);
-    }
-    const bool two = njg > 4;
     constexpr int UN = 4, NW = FT8 / 64;
-    const uint4 zero4 = make_uint4(0, 0, 0, 0);
-    auto load_batch = [&](uint4 (&av)[UN][2], int et0) {
+    constexpr int NB = FE / 16 / NW / UN;   // 8 batches per wave
+    // block groups beyond the last one are clamped onto it: their mixing weights are zero and every stored summary is finite
+    // (groups are written completely, blocks beyond M as zeros), so no select is needed
+    const u16* g0 = state_bh + (long)min(kg, njg - 1) * FE * IT + n * IT;
+    const u16* g1 = state_bh + (long)min(4 + kg, njg - 1) * FE * IT + n * IT;
+    auto load_batch = [&](uint4 (&av)[UN][2], int bt) {
+        const long et0 = (long)(wave + NW * bt) * UN;
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
-            const long e = (long)(et0 + u) * 16 + n;
-            av[u][0] = (kg < njg) ? *reinterpret_cast<const uint4*>(state_bh + ((long)kg * FE + e) * IT) : zero4;
-            av[u][1] = (two && 4 + kg < njg) ? *reinterpret_cast<const uint4*>(state_bh + ((long)(4 + kg) * FE + e) * IT) : zero4;
+            av[u][0] = gld<uint4>(g0 + (et0 + u) * 16 * IT);
+            if (TWO) av[u][1] = gld<uint4>(g1 + (et0 + u) * 16 * IT);
         }
     };
-    auto do_batch = [&](const uint4 (&av)[UN][2], int et0) {
+    uint4 buf[NBUF][UN][2];
+#pragma unroll
+    for (int b = 0; b < NBUF - 1; ++b) load_batch(buf[b], b);   // the state stream starts before the weights are fetched
+
+    bf16x8 bhi[2], blo[2];
+    {   // mixing weights of this lane: rows / columns beyond M are clamped for the load and zeroed after (no branches)
+        float wv[2][8];
+        const int i = i0 + n, ic = min(i, M - 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int jc = min(ks * 32 + kg * 8 + t, M - 1);
+                wv[ks][t] = gld<float>(TRANSW ? W + (long)jc * ldw + ic : W + (long)ic * ldw + jc);
+            }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            s16x8 hi, lo;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int j = ks * 32 + kg * 8 + t;
+                const float w = (i < M && j < M) ? wv[ks][t] : 0.f;
+                const u16 h = cvt_bf16(w);
+                hi[t] = (short)h;
+                lo[t] = (short)cvt_bf16(w - bf(h));
+            }
+            bhi[ks] = __builtin_bit_cast(bf16x8, hi);
+            blo[ks] = __builtin_bit_cast(bf16x8, lo);
+        }
+    }
+    auto do_batch = [&](const uint4 (&av)[UN][2], int bt) {
         // UN independent accumulator chains, interleaved step by step (no back-to-back dependent MFMAs)
         f32x4 c[UN];
 #pragma unroll
         for (int u = 0; u < UN; ++u) c[u] = mfma_bf16(__builtin_bit_cast(bf16x8, av[u][0]), bhi[0], f32x4{0.f, 0.f, 0.f, 0.f});
 #pragma unroll
         for (int u = 0; u < UN; ++u) c[u] = mfma_bf16(__builtin_bit_cast(bf16x8, av[u][0]), blo[0], c[u]);
-        if (two) {
+        if (TWO) {
 #pragma unroll
             for (int u = 0; u < UN; ++u) c[u] = mfma_bf16(__builtin_bit_cast(bf16x8, av[u][1]), bhi[1], c[u]);
 #pragma unroll
@@ -58,45 +79,48 @@ __device__ __forceinline__ void mix16_tile_to_lds(u16* __restrict__ Gt, const u1
         }
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
-            const int et = et0 + u, d2 = et >> 2, d1 = (et & 3) * 16 + kg * 4;
+            const int et = (wave + NW * bt) * UN + u, d2 = et >> 2, d1 = (et & 3) * 16 + kg * 4;
             uint2 pk;
             pk.x = pack_bf16x2(c[u][0], c[u][1]);
             pk.y = pack_bf16x2(c[u][2], c[u][3]);
             *reinterpret_cast<uint2*>(Gt + (long)n * GSLOT + d2 * GLD + d1) = pk;
         }
     };
-    constexpr int NB = FE / 16 / NW / UN;
-    uint4 bufA[UN][2], bufB[UN][2];
-    load_batch(bufA, wave * UN);
-#pragma unroll 1
-    for (int bt = 0; bt < NB; bt += 2) {
-        load_batch(bufB, (wave + NW * (bt + 1)) * UN);
-        do_batch(bufA, (wave + NW * bt) * UN);
-        if (bt + 2 < NB) load_batch(bufA, (wave + NW * (bt + 2)) * UN);
-        do_batch(bufB, (wave + NW * (bt + 1)) * UN);
+#pragma unroll
+    for (int bt = 0; bt < NB; ++bt) {   // fully unrolled: the ring slots are registers
+        if (bt + NBUF - 1 < NB) load_batch(buf[(bt + NBUF - 1) % NBUF], bt + NBUF - 1);
+        do_batch(buf[bt % NBUF], bt);
     }
 }
 
-// A operands of a 64-row chunk straight from a token view: a[st][ks] = rows 16 st + (lane & 15),
-// columns 32 ks + 8 (lane >> 4) .. + 7.  Rows >= rv give zeros.
-template <bool RELU>
+template <int TRANSW, int NBUF>
+__device__ __forceinline__ void mix16_tile_to_lds(u16* __restrict__ Gt, const u16* __restrict__ state_bh, int njg,
+                                                  const float* __restrict__ W, int ldw, int M, int i0, int tid) {
+    if (njg > 4) mix16_tile_impl<TRANSW, true, NBUF>(Gt, state_bh, njg, W, ldw, M, i0, tid);
+    else         mix16_tile_impl<TRANSW, false, NBUF>(Gt, state_bh, njg, W, ldw, M, i0, tid);
+}
+
+// A operands of a 64-row chunk straight from a token view: a[st][ks] = rows 16 st + (lane & 15), columns 32 ks + 8 (lane >> 4)
+// .. + 7.  Rows beyond rv read the block's first row (valid memory, finite values): every consumer of these operands produces
+// output rows from operand rows one to one and never stores rows >= rv, and the row weights of the dksum sum (dz) are zero
+// there -- so there is no zeroing, and nothing depends on the loaded data until the MFMAs that consume it.
 __device__ __forceinline__ void load_a64(bf16x8 (&a)[4][2], const u16* __restrict__ base, long sn,
-                                         const int* __restrict__ idx, long p0, int rv, float eps, int lane) {
+                                         const int* __restrict__ idx, long p0, int rv, int lane) {
     const int m = lane & 15, kg = lane >> 4;
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
         const int row = st * 16 + m;
-        const u16* src = base + (row < rv ? tok_row(idx, p0 + row) : 0) * sn + kg * 8;
+        const u16* src = base + tok_row(idx, p0 + (row < rv ? row : 0)) * sn + kg * 8;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (row < rv) {
-                v = *reinterpret_cast<const uint4*>(src + ks * 32);
-                if (RELU) v = relu_eps8(v, eps);
-            }
-            a[st][ks] = __builtin_bit_cast(bf16x8, v);
-        }
+        for (int ks = 0; ks < 2; ++ks) a[st][ks] = __builtin_bit_cast(bf16x8, gld<uint4>(src + ks * 32));
     }
+}
+// relu(x) + eps on loaded operands (MHLA_FLAG_RELU_EPS), applied where they are consumed
+__device__ __forceinline__ void relu_a64(bf16x8 (&a)[4][2], float eps) {
+#pragma unroll
+    for (int st = 0; st < 4; ++st)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) a[st][ks] = __builtin_bit_cast(bf16x8, relu_eps8(__builtin_bit_cast(uint4, a[st][ks]), eps));
 }
 
 // acc[st][tn] += A[st] x B  with B from one mixed summary Gb[d2][d1] (GLD stride):
@@ -116,6 +140,12 @@ __device__ __forceinline__ void chunk_times_gt(f32x4 (&acc)[4][4], const bf16x8 
         }
     }
 }
+__device__ __forceinline__ void zero_acc(f32x4 (&acc)[4][4]) {
+#pragma unroll
+    for (int st = 0; st < 4; ++st)
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) acc[st][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
 
 // Wave-private staging of a 64 x 64 fp32 result (C layout: row = 16 st + 4 (lane >> 4) + r, col = 16 tn + (lane & 15))
 __device__ __forceinline__ void stage64(u16* __restrict__ Os, const f32x4 (&acc)[4][4], int lane) {
@@ -126,6 +156,17 @@ __device__ __forceinline__ void stage64(u16* __restrict__ Os, const f32x4 (&acc)
         for (int tn = 0; tn < 4; ++tn)
 #pragma unroll
             for (int r = 0; r < 4; ++r) Os[(st * 16 + kg * 4 + r) * GLD + tn * 16 + n] = cvt_bf16(acc[st][tn][r]);
+}
+// the same from results kept packed as bf16 pairs (pv[st][tn][0] = rows r = 0, 1; [1] = rows 2, 3)
+__device__ __forceinline__ void stage64_packed(u16* __restrict__ Os, const unsigned (&pv)[4][4][2], int lane) {
+    const int n = lane & 15, kg = lane >> 4;
+#pragma unroll
+    for (int st = 0; st < 4; ++st)
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                Os[(st * 16 + kg * 4 + r) * GLD + tn * 16 + n] = (u16)(pv[st][tn][r >> 1] >> ((r & 1) * 16));
 }
 
 // narrow fallback (no free staging slot): direct stores from the C layout
@@ -152,30 +193,26 @@ __device__ __forceinline__ void store64_direct(u16* __restrict__ base, long sn, 
 
 __global__ __launch_bounds__(FT8, 2) void k_t16_out(const FsOutArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    u16* Gt = reinterpret_cast<u16*>(smem_raw);   // [8][64 d2][72]
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, kg = lane >> 4;
+    u16* Gt = reinterpret_cast<u16*>(smem_raw);   // [16][64 d2][72]
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, kg = lane >> 4;
     const int L = xcd_swizzle(blockIdx.x, gridDim.x);
     const int ntt = (a.njg + 1) / 2, bh = L / ntt, it = L - bh * ntt, b = bh / a.H, h = bh - b * a.H;
     const int S = a.S, M = a.M;
     const u16* qb = (const u16*)a.q.ptr + b * a.q.sb + h * a.q.sh;
     u16* ob = (u16*)a.o.ptr + b * a.o.sb + h * a.o.sh;
     const float* ninv_bh = a.ninv + (long)bh * M * S;
-
     const u16* state_bh = a.state + (long)bh * a.njg * FE * IT;
+
     auto load_blk = [&](bf16x8 (&av)[4][2], float& ninv, int i, int c0, int rv) {
-        const long p0 = (long)i * S + c0;
-        if (a.relu) load_a64<true>(av, qb, a.q.sn, a.idx, p0, rv, a.eps, lane);
-        else        load_a64<false>(av, qb, a.q.sn, a.idx, p0, rv, a.eps, lane);
-        ninv = (a.normalize && lane < rv) ? ninv_bh[(long)i * S + c0 + lane] : 1.f;
+        load_a64(av, qb, a.q.sn, a.idx, (long)i * S + c0, rv, lane);
+        ninv = a.normalize ? gld<float>(ninv_bh + (long)i * S + c0 + min(lane, rv - 1)) : 1.f;   // lanes >= rv: unused rows
     };
-    auto compute_store = [&](const bf16x8 (&av)[4][2], float ninv, int bi, int i, int c0, int rv) {
+    auto compute_store = [&](bf16x8 (&av)[4][2], float ninv, int bi, int i, int c0, int rv) {
         const long p0 = (long)i * S + c0;
         u16* Gb = Gt + bi * GSLOT;
+        if (a.relu) relu_a64(av, a.eps);
         f32x4 acc[4][4];
-#pragma unroll
-        for (int st = 0; st < 4; ++st)
-#pragma unroll
-            for (int tn = 0; tn < 4; ++tn) acc[st][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+        zero_acc(acc);
         chunk_times_gt<false>(acc, av, Gb, lane);
 #pragma unroll
         for (int st = 0; st < 4; ++st)
@@ -196,19 +233,19 @@ __global__ __launch_bounds__(FT8, 2) void k_t16_out(const FsOutArgs a) {
     };
 
     if (S <= 64) {
-        // each wave owns blocks (wave, wave + 4): the first block's operands are fetched before the mixing,
-        // the second block's while the first is being multiplied
+        // each wave owns blocks (wave, wave + 8); the operands of both are fetched before the mixing, whose L2 / MALL-bound
+        // phase hides their HBM latency
         const int iA = it * TT + wave, iB = iA + 8;
         bf16x8 avA[4][2], avB[4][2];
         float ninvA = 1.f, ninvB = 1.f;
         trace_mark(a.trace, 0);
-        if (iA < M) load_blk(avA, ninvA, iA, 0, S);
+        load_blk(avA, ninvA, min(iA, M - 1), 0, S);
+        load_blk(avB, ninvB, min(iB, M - 1), 0, S);
         trace_mark(a.trace, 1);
-        mix16_tile_to_lds<0>(Gt, state_bh, a.njg, a.W, a.ldw, M, it * TT, tid);
+        mix16_tile_to_lds<0, 3>(Gt, state_bh, a.njg, a.W, a.ldw, M, it * TT, tid);
         trace_mark(a.trace, 2);
         __syncthreads();
         trace_mark(a.trace, 3);
-        if (iB < M) load_blk(avB, ninvB, iB, 0, S);
         if (iA < M) compute_store(avA, ninvA, wave, iA, 0, S);
         trace_mark(a.trace, 4);
         if (iB < M) compute_store(avB, ninvB, wave + 8, iB, 0, S);
@@ -217,7 +254,7 @@ __global__ __launch_bounds__(FT8, 2) void k_t16_out(const FsOutArgs a) {
         return;
     }
 
-    mix16_tile_to_lds<0>(Gt, state_bh, a.njg, a.W, a.ldw, M, it * TT, tid);
+    mix16_tile_to_lds<0, 3>(Gt, state_bh, a.njg, a.W, a.ldw, M, it * TT, tid);
     __syncthreads();
     for (int bi = wave; bi < TT; bi += 8) {
         const int i = it * TT + bi;
@@ -235,7 +272,7 @@ __global__ __launch_bounds__(FT8, 2) void k_t16_out(const FsOutArgs a) {
 __global__ __launch_bounds__(FT8, 2) void k_t16_bwd_dq(const FsTokArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u16* Gt = reinterpret_cast<u16*>(smem_raw);
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 15, kg = lane >> 4;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, n = lane & 15, kg = lane >> 4;
     const int L = xcd_swizzle(blockIdx.x, gridDim.x);
     const int ntt = (a.njg + 1) / 2, bh = L / ntt, jgx = L - bh * ntt, b = bh / a.H, h = bh - b * a.H;
     const int S = a.S, M = a.M;
@@ -246,30 +283,32 @@ __global__ __launch_bounds__(FT8, 2) void k_t16_bwd_dq(const FsTokArgs a) {
     const long sofs = (long)bh * a.njg * FE * IT;
 
     struct Side { float ninv, dz, ksum; };
-    auto load_blk = [&](bf16x8 (&gv)[4][2], Side& sd, int j, int c0, int rv) {
-        load_a64<false>(gv, gb, a.dout.sn, a.idx, (long)j * S + c0, rv, 0.f, lane);
-        sd.ninv = 1.f; sd.dz = 0.f;
-        sd.ksum = a.normalize ? a.ksum[((long)bh * M + j) * 64 + lane] : 0.f;   // lane = column d1
-        if (a.normalize && lane < rv) {
-            sd.ninv = a.ninv[((long)bh * M + j) * S + c0 + lane];
-            sd.dz = a.dz[((long)bh * M + j) * S + c0 + lane];
+    // dO rows and the per-row / per-column side values of one chunk; Q rows (normalised operator only: dksum) separately
+    auto load_g = [&](bf16x8 (&gv)[4][2], Side& sd, int j, int c0, int rv) {
+        load_a64(gv, gb, a.dout.sn, a.idx, (long)j * S + c0, rv, lane);
+        sd.ninv = 1.f; sd.dz = 0.f; sd.ksum = 0.f;
+        if (a.normalize) {
+            const long so = ((long)bh * M + j) * S + c0 + min(lane, rv - 1);
+            sd.ksum = gld<float>(a.ksum + ((long)bh * M + j) * 64 + lane);   // lane = column d1
+            sd.ninv = gld<float>(a.ninv + so);
+            sd.dz = gld<float>(a.dz + so);
         }
     };
-    // one 64-row chunk: dQ rows, and the chunk's contribution to dksum (per-lane partials in the A layout)
-    auto compute_store = [&](const bf16x8 (&gv)[4][2], const Side& sd, float (&dks_acc)[2][8], int bi, int j, int c0, int rv) {
+    auto load_q = [&](bf16x8 (&qv)[4][2], int j, int c0, int rv) {
+        if (a.normalize) load_a64(qv, qb, a.q.sn, a.idx, (long)j * S + c0, rv, lane);
+    };
+    // one 64-row chunk in two steps: the products (dO G^T)[s][d1] (B[k = d2][n = d1] = Gt[d2][d1]) ...
+    auto products = [&](f32x4 (&acc)[4][4], const bf16x8 (&gv)[4][2], int bi) {
+        zero_acc(acc);
+        chunk_times_gt<true>(acc, gv, Gt + bi * GSLOT, lane);
+    };
+    // ... then dQ rows (scaling, dz (x) ksum, store) and the chunk's contribution to dksum (per-lane partials in the A layout)
+    auto finish_store = [&](f32x4 (&acc)[4][4], bf16x8 (&qv)[4][2], Side sd, float (&dks_acc)[2][8], int bi, int j, int c0, int rv) {
         const long p0 = (long)j * S + c0;
         u16* Gb = Gt + bi * GSLOT;
-        f32x4 acc[4][4];
-#pragma unroll
-        for (int st = 0; st < 4; ++st)
-#pragma unroll
-            for (int tn = 0; tn < 4; ++tn) acc[st][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
-        chunk_times_gt<true>(acc, gv, Gb, lane);   // (dO G^T)[s][d1] : B[k = d2][n = d1] = Gt[d2][d1]
-        __builtin_amdgcn_sched_barrier(0);         // keep the q loads below the MFMAs (register pressure)
+        if (lane >= rv) sd.dz = 0.f;               // rows beyond the chunk carry another row's data: no weight in dksum
         if (a.normalize) {
-            bf16x8 qv[4][2];
-            if (a.relu) load_a64<true>(qv, qb, a.q.sn, a.idx, p0, rv, a.eps, lane);
-            else        load_a64<false>(qv, qb, a.q.sn, a.idx, p0, rv, a.eps, lane);
+            if (a.relu) relu_a64(qv, a.eps);
 #pragma unroll
             for (int st = 0; st < 4; ++st) {
                 const float dzr = __shfl(sd.dz, st * 16 + n, 64);
@@ -280,6 +319,9 @@ __global__ __launch_bounds__(FT8, 2) void k_t16_bwd_dq(const FsTokArgs a) {
                     for (int t = 0; t < 8; ++t) dks_acc[ks][t] += dzr * bf((u16)qs[t]);
                 }
             }
+            float ksc[4];
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn) ksc[tn] = __shfl(sd.ksum, tn * 16 + n, 64);
 #pragma unroll
             for (int st = 0; st < 4; ++st)
 #pragma unroll
@@ -287,7 +329,7 @@ __global__ __launch_bounds__(FT8, 2) void k_t16_bwd_dq(const FsTokArgs a) {
                     const int row = st * 16 + kg * 4 + r;
                     const float ni = __shfl(sd.ninv, row, 64), dzr = __shfl(sd.dz, row, 64);
 #pragma unroll
-                    for (int tn = 0; tn < 4; ++tn) acc[st][tn][r] = acc[st][tn][r] * ni + dzr * __shfl(sd.ksum, tn * 16 + n, 64);
+                    for (int tn = 0; tn < 4; ++tn) acc[st][tn][r] = acc[st][tn][r] * ni + dzr * ksc[tn];
                 }
         }
         if (c0 + 64 >= S) {
@@ -320,27 +362,37 @@ __global__ __launch_bounds__(FT8, 2) void k_t16_bwd_dq(const FsTokArgs a) {
             for (int t = 0; t < 8; ++t) d[ks][t] = 0.f;
     };
 
-    if (S <= 64) {   // operands of the wave's first block are fetched before the mixing
-        const int jA = jgx * TT + wave, jB = jA + 8;
-        bf16x8 gvA[4][2], gvB[4][2];
+    if (S <= 64) {
+        // first block's operands (dO, Q rows) before the mixing; the second block's dO rows right after the barrier and its Q
+        // rows once the first block's products have freed registers -- both travel while the first block is processed
+        const int jA = jgx * TT + wave, jB = jA + 8, jAc = min(jA, M - 1), jBc = min(jB, M - 1);
+        bf16x8 gvA[4][2], qvA[4][2];
         Side sA, sB;
         trace_mark(a.trace, 0);
-        if (jA < M) load_blk(gvA, sA, jA, 0, S);
+        load_g(gvA, sA, jAc, 0, S);
+        load_q(qvA, jAc, 0, S);
         trace_mark(a.trace, 1);
-        mix16_tile_to_lds<0>(Gt, a.state + sofs, a.njg, a.W, a.ldw, M, jgx * TT, tid);
+        mix16_tile_to_lds<0, 3>(Gt, a.state + sofs, a.njg, a.W, a.ldw, M, jgx * TT, tid);
         trace_mark(a.trace, 2);
         __syncthreads();
         trace_mark(a.trace, 3);
-        if (jB < M) load_blk(gvB, sB, jB, 0, S);
+        bf16x8 gvB[4][2], qvB[4][2];
+        f32x4 acc[4][4];
         float dks_acc[2][8];
-        if (jA < M) { zero_dks(dks_acc); compute_store(gvA, sA, dks_acc, wave, jA, 0, S); if (a.normalize) finish_dks(dks_acc, jA); }
+        load_g(gvB, sB, jBc, 0, S);
+        products(acc, gvA, wave);
+        load_q(qvB, jBc, 0, S);
+        zero_dks(dks_acc);
+        if (jA < M) { finish_store(acc, qvA, sA, dks_acc, wave, jA, 0, S); if (a.normalize) finish_dks(dks_acc, jA); }
         trace_mark(a.trace, 4);
-        if (jB < M) { zero_dks(dks_acc); compute_store(gvB, sB, dks_acc, wave + 8, jB, 0, S); if (a.normalize) finish_dks(dks_acc, jB); }
+        products(acc, gvB, wave + 8);
+        zero_dks(dks_acc);
+        if (jB < M) { finish_store(acc, qvB, sB, dks_acc, wave + 8, jB, 0, S); if (a.normalize) finish_dks(dks_acc, jB); }
         trace_mark(a.trace, 5);
         if (a.trace) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); trace_mark(a.trace, 6); }
         return;
     }
-    mix16_tile_to_lds<0>(Gt, a.state + sofs, a.njg, a.W, a.ldw, M, jgx * TT, tid);
+    mix16_tile_to_lds<0, 3>(Gt, a.state + sofs, a.njg, a.W, a.ldw, M, jgx * TT, tid);
     __syncthreads();
     for (int bi = wave; bi < TT; bi += 8) {
         const int j = jgx * TT + bi;
@@ -349,10 +401,13 @@ __global__ __launch_bounds__(FT8, 2) void k_t16_bwd_dq(const FsTokArgs a) {
         zero_dks(dks_acc);
         for (int c0 = 0; c0 < S; c0 += 64) {
             const int rv = min(64, S - c0);
-            bf16x8 gv[4][2];
+            bf16x8 gv[4][2], qv[4][2];
+            f32x4 acc[4][4];
             Side sd;
-            load_blk(gv, sd, j, c0, rv);
-            compute_store(gv, sd, dks_acc, bi, j, c0, rv);
+            load_g(gv, sd, j, c0, rv);
+            load_q(qv, j, c0, rv);
+            products(acc, gv, bi);
+            finish_store(acc, qv, sd, dks_acc, bi, j, c0, rv);
         }
         if (a.normalize) finish_dks(dks_acc, j);
     }
@@ -361,7 +416,7 @@ __global__ __launch_bounds__(FT8, 2) void k_t16_bwd_dq(const FsTokArgs a) {
 __global__ __launch_bounds__(FT8, 2) void k_t16_bwd_dkv(const FsTokArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u16* Gt = reinterpret_cast<u16*>(smem_raw);
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 15, kg = lane >> 4;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, n = lane & 15;
     const int L = xcd_swizzle(blockIdx.x, gridDim.x);
     const int ntt = (a.njg + 1) / 2, bh = L / ntt, jgx = L - bh * ntt, b = bh / a.H, h = bh - b * a.H;
     const int S = a.S, M = a.M;
@@ -370,24 +425,20 @@ __global__ __launch_bounds__(FT8, 2) void k_t16_bwd_dkv(const FsTokArgs a) {
     const u16 *kb = base(a.k), *vb = base(a.v);
     u16 *dkb = mbase(a.dk), *dvb = mbase(a.dv);
     const long sofs = (long)bh * a.njg * FE * IT;
-    auto load_k = [&](bf16x8 (&kv)[4][2], int j, int c0, int rv) {
-        if (a.relu) load_a64<true>(kv, kb, a.k.sn, a.idx, (long)j * S + c0, rv, a.eps, lane);
-        else        load_a64<false>(kv, kb, a.k.sn, a.idx, (long)j * S + c0, rv, a.eps, lane);
+    auto load_blk = [&](bf16x8 (&kv)[4][2], bf16x8 (&vv)[4][2], int j, int c0, int rv) {
+        load_a64(kv, kb, a.k.sn, a.idx, (long)j * S + c0, rv, lane);
+        load_a64(vv, vb, a.v.sn, a.idx, (long)j * S + c0, rv, lane);
     };
-    auto compute_store = [&](const bf16x8 (&kv)[4][2], int bi, int j, int c0, int rv) {
+    auto compute_store = [&](bf16x8 (&kv)[4][2], const bf16x8 (&vv)[4][2], int bi, int j, int c0, int rv) {
         const long p0 = (long)j * S + c0;
         u16* Gb = Gt + bi * GSLOT;
         const bool last = c0 + 64 >= S;
-        bf16x8 vv[4][2];
-        load_a64<false>(vv, vb, a.v.sn, a.idx, p0, rv, 0.f, lane);
+        if (a.relu) relu_a64(kv, a.eps);
         // dV first, kept packed as bf16 pairs while dK is computed (both need the intact Gb)
         unsigned pv[4][4][2];
         {
             f32x4 accV[4][4];
-#pragma unroll
-            for (int st = 0; st < 4; ++st)
-#pragma unroll
-                for (int tn = 0; tn < 4; ++tn) accV[st][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+            zero_acc(accV);
             chunk_times_gt<false>(accV, kv, Gb, lane);   // dV[s][d2] = sum_d1 K[s][d1] dKVt[d2][d1]
 #pragma unroll
             for (int st = 0; st < 4; ++st)
@@ -398,15 +449,12 @@ __global__ __launch_bounds__(FT8, 2) void k_t16_bwd_dkv(const FsTokArgs a) {
                 }
         }
         f32x4 accK[4][4];
-#pragma unroll
-        for (int st = 0; st < 4; ++st)
-#pragma unroll
-            for (int tn = 0; tn < 4; ++tn) accK[st][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+        zero_acc(accK);
         chunk_times_gt<true>(accK, vv, Gb, lane);        // dK[s][d1] = sum_d2 V[s][d2] dKVt[d2][d1]
         if (a.normalize) {
 #pragma unroll
             for (int tn = 0; tn < 4; ++tn) {
-                const float dk = a.dksum[((long)bh * M + j) * 64 + tn * 16 + n];
+                const float dk = gld<float>(a.dksum + ((long)bh * M + j) * 64 + tn * 16 + n);
 #pragma unroll
                 for (int st = 0; st < 4; ++st)
 #pragma unroll
@@ -420,18 +468,13 @@ __global__ __launch_bounds__(FT8, 2) void k_t16_bwd_dkv(const FsTokArgs a) {
             if (a.relu) store64<true>(dkb, a.dk.sn, a.idx, p0, rv, Gb, kb, a.k.sn, lane);
             else        store64<false>(dkb, a.dk.sn, a.idx, p0, rv, Gb, nullptr, 0, lane);
             wave_lds_fence();
-#pragma unroll
-            for (int st = 0; st < 4; ++st)
-#pragma unroll
-                for (int tn = 0; tn < 4; ++tn)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        Gb[(st * 16 + kg * 4 + r) * GLD + tn * 16 + n] = (u16)(pv[st][tn][r >> 1] >> ((r & 1) * 16));
+            stage64_packed(Gb, pv, lane);
             wave_lds_fence();
             store64<false>(dvb, a.dv.sn, a.idx, p0, rv, Gb, nullptr, 0, lane);
         } else {
             if (a.relu) store64_direct<true>(dkb, a.dk.sn, a.idx, p0, rv, accK, kb, a.k.sn, lane);
             else        store64_direct<false>(dkb, a.dk.sn, a.idx, p0, rv, accK, nullptr, 0, lane);
+            const int kg = lane >> 4;
 #pragma unroll
             for (int st = 0; st < 4; ++st)
 #pragma unroll
@@ -449,32 +492,33 @@ __global__ __launch_bounds__(FT8, 2) void k_t16_bwd_dkv(const FsTokArgs a) {
 
     if (S <= 64) {
         const int jA = jgx * TT + wave, jB = jA + 8;
-        bf16x8 kvA[4][2], kvB[4][2];
+        bf16x8 kvA[4][2], vvA[4][2];
         trace_mark(a.trace, 0);
-        if (jA < M) load_k(kvA, jA, 0, S);
+        load_blk(kvA, vvA, min(jA, M - 1), 0, S);
         trace_mark(a.trace, 1);
-        mix16_tile_to_lds<1>(Gt, a.dstate + sofs, a.njg, a.W, a.ldw, M, jgx * TT, tid);
+        mix16_tile_to_lds<1, 3>(Gt, a.dstate + sofs, a.njg, a.W, a.ldw, M, jgx * TT, tid);
         trace_mark(a.trace, 2);
         __syncthreads();
         trace_mark(a.trace, 3);
-        if (jB < M) load_k(kvB, jB, 0, S);
-        if (jA < M) compute_store(kvA, wave, jA, 0, S);
+        bf16x8 kvB[4][2], vvB[4][2];
+        load_blk(kvB, vvB, min(jB, M - 1), 0, S);
+        if (jA < M) compute_store(kvA, vvA, wave, jA, 0, S);
         trace_mark(a.trace, 4);
-        if (jB < M) compute_store(kvB, wave + 8, jB, 0, S);
+        if (jB < M) compute_store(kvB, vvB, wave + 8, jB, 0, S);
         trace_mark(a.trace, 5);
         if (a.trace) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); trace_mark(a.trace, 6); }
         return;
     }
-    mix16_tile_to_lds<1>(Gt, a.dstate + sofs, a.njg, a.W, a.ldw, M, jgx * TT, tid);
+    mix16_tile_to_lds<1, 3>(Gt, a.dstate + sofs, a.njg, a.W, a.ldw, M, jgx * TT, tid);
     __syncthreads();
     for (int bi = wave; bi < TT; bi += 8) {
         const int j = jgx * TT + bi;
         if (j >= M) continue;
         for (int c0 = 0; c0 < S; c0 += 64) {
             const int rv = min(64, S - c0);
-            bf16x8 kv[4][2];
-            load_k(kv, j, c0, rv);
-            compute_store(kv, bi, j, c0, rv);
+            bf16x8 kv[4][2], vv[4][2];
+            load_blk(kv, vv, j, c0, rv);
+            compute_store(kv, vv, bi, j, c0, rv);
         }
     }
 }
