@@ -17,6 +17,11 @@ import glob  # noqa: E402
 DEPS = sorted(glob.glob(os.path.join(HERE, "csrc", "*"))) + [os.path.join(os.path.dirname(HERE), "include", "mhla_hip.h")]
 
 
+# No packed-fp32 VALU instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) in device code: see DESIGN.md section 5
+# (run-to-run differences in the low halves of packed accumulations when workgroups of different roles share a CU).
+EXTRA_FLAGS = [] if os.environ.get("MHLA_PACKED_FP32") == "1" else ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+
+
 def hipcc_path() -> str:
     for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
         if cand and os.path.exists(cand):
@@ -36,7 +41,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         return LIB
     os.makedirs(LIB_DIR, exist_ok=True)
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++20", "-shared", "-fPIC", "-Wall",
-           "-Wno-unused-function", SRC, "-o", LIB + ".tmp"]
+           "-Wno-unused-function"] + EXTRA_FLAGS + [SRC, "-o", LIB + ".tmp"]
     if verbose:
         print("[mhla_amd.build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

@@ -80,29 +80,6 @@ int launch(K kernel, dim3 grid, dim3 block, size_t smem, hipStream_t stream, con
     return MHLA_OK;
 }
 
-// A per-device side stream for work that is independent of the main chain (the dW reduction of the fast-path backward): forked
-// from and joined back into the caller's stream with events, so the caller still sees one in-order stream (and a hipGraph
-// capture of the caller's stream records the fork and the join).  Opt-in (MHLA_SIDE_STREAM=1): the default is one stream.
-struct SideStream {
-    hipStream_t s = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
-};
-std::mutex g_side_mu;   // held while a fork .. join section is enqueued: the events are shared per device
-SideStream* side_stream() {
-    static std::map<int, SideStream> per_dev;
-    static const bool on = getenv("MHLA_SIDE_STREAM") != nullptr;
-    if (!on) return nullptr;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    SideStream& ss = per_dev[dev];
-    if (!ss.s) {
-        if (hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking) != hipSuccess) { ss.s = nullptr; return nullptr; }
-        if (hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&ss.join, hipEventDisableTiming) != hipSuccess) return nullptr;
-    }
-    return &ss;
-}
-
 // debugging aid: per-workgroup phase timestamps of the tile kernels (mhla_debug_set_trace)
 std::atomic<unsigned long long*> g_trace{nullptr};
 
@@ -177,7 +154,7 @@ BmWs bm_carve(void* ws, int B, int H, int M, int S, int D, bool sum16) {
 // ---- fast path (bf16, D = 64, M <= 64, q_den aliasing q_num): see fused.hpp ----
 struct FastWs {
     fast::u16 *state, *dstate;
-    float *z, *ksum, *ninv, *dn, *dz, *dwp, *dwt, *dksum;
+    float *z, *ksum, *ninv, *dn, *dz, *dwp, *dksum;
     size_t total_fwd, total_bwd;
     int njg;
 };
@@ -196,8 +173,7 @@ FastWs fast_carve(void* ws, int B, int H, int M, int S) {
     w.dn = (float*)p; p += al4(bh * M * S) * 4;
     w.dz = (float*)p; p += al4(bh * M * S) * 4;
     w.dksum = (float*)p; p += al4(bh * M * 64) * 4;
-    w.dwp = (float*)p; p += bh * (fast::DW_SPLIT + 1) * 4096 * 4;
-    w.dwt = (float*)p; p += ((bh * (fast::DW_SPLIT + 1) + fast::DWR_G - 1) / fast::DWR_G) * 4096 * 4;
+    w.dwp = (float*)p; p += bh * fast::DW_SPLIT * 4096 * 4;
     w.total_bwd = (size_t)(p - (char*)ws);
     return w;
 }
@@ -412,7 +388,7 @@ static int bm_fwd_impl(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view 
         sa.z_out = f.z; sa.H = H; sa.M = M; sa.S = S; sa.eps = eps; sa.relu = relu; sa.normalize = normalize;
         RC(launch(fast::k_fs_state_fwd<0>, dim3(f.njg, B * H), dim3(fast::FT8), fast::FS_STATE_FWD_SMEM, st, "k_fs_state_fwd", sa));
         if (normalize)
-            RC(launch(fast::k_fs_wz<0>, dim3((S + 63) / 64, B * H), dim3(fast::FT), 0, st, "k_fs_wz<0>", W, ldw, (const float*)f.z, f.ninv, M, S, eps));
+            RC(launch(fast::k_fs_wz<0>, dim3((S + fast::WZ_C - 1) / fast::WZ_C, B * H), dim3(fast::FT), 0, st, "k_fs_wz<0>", W, ldw, (const float*)f.z, f.ninv, M, S, eps));
         fast::FsOutArgs oa{};
         oa.q = cv(q_num); oa.o = cmv(out); oa.idx = block_index; oa.W = W; oa.ldw = ldw; oa.state = f.state; oa.ninv = f.ninv;
         oa.H = H; oa.M = M; oa.S = S; oa.njg = f.njg; oa.eps = eps; oa.relu = relu; oa.normalize = normalize;
@@ -536,29 +512,19 @@ int mhla_blockmix_bwd(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q
                 sa.z_out = f.z; sa.H = H; sa.M = M; sa.S = S; sa.eps = eps; sa.relu = relu; sa.normalize = normalize;
                 RC(launch(fast::k_fs_state_fwd<0>, dim3(f.njg, B * H), dim3(fast::FT8), fast::FS_STATE_FWD_SMEM, st, "k_fs_state_fwd", sa));
                 if (normalize)
-                    RC(launch(fast::k_fs_wz<0>, dim3((S + 63) / 64, B * H), dim3(fast::FT), 0, st, "k_fs_wz<0>", W, ldw, (const float*)f.z, f.ninv, M, S, eps));
+                    RC(launch(fast::k_fs_wz<0>, dim3((S + fast::WZ_C - 1) / fast::WZ_C, B * H), dim3(fast::FT), 0, st, "k_fs_wz<0>", W, ldw, (const float*)f.z, f.ninv, M, S, eps));
             }
             fast::FsStateArgs ga{};
             ga.x = cv(q_num); ga.y = cv(dout); ga.t = cv(out); ga.idx = block_index; ga.W = W; ga.ldw = ldw; ga.ninv = ninv;
             ga.state = f.dstate; ga.dn = f.dn; ga.H = H; ga.M = M; ga.S = S; ga.eps = eps; ga.relu = relu; ga.normalize = normalize;
             RC(launch(fast::k_fs_state<1>, dim3(f.njg, B * H), dim3(fast::FT8), fast::FS_STATE_SMEM, st, "k_fs_state<1>", ga));
-            fast::FsDwArgs da{f.dstate, state, normalize ? f.dn : nullptr, z, f.dwp, M, S, f.njg};
-            // dW needs only dG^T, KV^T, dn and z, all complete here: its four launches (one bandwidth-bound GEMM and three short
-            // latency-bound reductions) go to the side stream and overlap the token-gradient kernels of the main chain
-            // dz = W^T dn first, on the caller's stream: with k_fs_wz<1> running concurrently with the side-stream kernels the
-            // normaliser gradients were observed to vary from run to run (root cause not established), so it stays ahead of the fork
-            if (normalize)
-                RC(launch(fast::k_fs_wz<1>, dim3((S + 63) / 64, B * H), dim3(fast::FT), 0, st, "k_fs_wz<1>", W, ldw, (const float*)f.dn, f.dz, M, S, 0.f));
-            std::unique_lock<std::mutex> side_lk(g_side_mu);
-            SideStream* ss = side_stream();
+            // dW needs only dG^T, KV^T, dn and z, all complete here; dz = W^T dn (needed by the token-gradient kernels) rides in
+            // the same launch as extra workgroups
+            fast::FsDwArgs da{f.dstate, state, normalize ? f.dn : nullptr, z, f.dwp, M, S, f.njg, W, ldw, f.dz};
             hipStream_t sd = st;
-            if (ss && hipEventRecord(ss->fork, st) == hipSuccess && hipStreamWaitEvent(ss->s, ss->fork, 0) == hipSuccess) sd = ss->s;
-            else side_lk.unlock();
-            RC(launch(fast::k_fs_dw, dim3(fast::DW_SPLIT, B * H), dim3(fast::FT8), fast::FS_DW_SMEM, sd, "k_fs_dw", da));
-            RC(launch(fast::k_fs_dwz, dim3(B * H), dim3(fast::FT), 0, sd, "k_fs_dwz", normalize ? (const float*)f.dn : (const float*)nullptr, z, f.dwp, M, S));
-            const int nparts = B * H * (fast::DW_SPLIT + 1), ngroups = (nparts + fast::DWR_G - 1) / fast::DWR_G;
-            RC(launch(fast::k_fs_dw_reduce1, dim3(16, ngroups), dim3(256), 0, sd, "k_fs_dw_reduce1", (const float*)f.dwp, f.dwt, nparts));
-            RC(launch(fast::k_fs_dw_reduce2, dim3((M * M + 255) / 256), dim3(256), 0, sd, "k_fs_dw_reduce2", (const float*)f.dwt, dW, M, ngroups));
+            const int nwz = normalize ? (S + fast::WZ_C - 1) / fast::WZ_C : 0;
+            RC(launch(fast::k_fs_dw, dim3(fast::DW_SPLIT + nwz, B * H), dim3(fast::FT8), fast::FS_DW_SMEM, sd, "k_fs_dw", da));
+            RC(launch(fast::k_fs_dw_reduce, dim3(256), dim3(fast::FT), 0, sd, "k_fs_dw_reduce", (const float*)f.dwp, dW, M, B * H * fast::DW_SPLIT));
             fast::FsTokArgs ta{};
             ta.q = cv(q_num); ta.k = cv(k_num); ta.v = cv(v); ta.dout = cv(dout); ta.dq = cmv(dq_num); ta.dk = cmv(dk_num);
             ta.dv = cmv(dv); ta.idx = block_index; ta.W = W; ta.ldw = ldw; ta.state = state; ta.dstate = f.dstate; ta.ninv = ninv;
@@ -571,10 +537,6 @@ int mhla_blockmix_bwd(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q
             RC(launch(fast::k_t16_bwd_dq, dim3(((f.njg + 1) / 2) * B * H), dim3(fast::FT8), fast::FS_GT16_BYTES, st, "k_t16_bwd_dq", ta));
             ta.trace = tr ? tr + 2 * ntile_wgs * fast::TRACE_SLOTS : nullptr;
             RC(launch(fast::k_t16_bwd_dkv, dim3(((f.njg + 1) / 2) * B * H), dim3(fast::FT8), fast::FS_GT16_BYTES, st, "k_t16_bwd_dkv", ta));
-            if (sd != st) {   // join: the caller's stream continues only after dW is complete
-                if (hipEventRecord(ss->join, sd) != hipSuccess || hipStreamWaitEvent(st, ss->join, 0) != hipSuccess)
-                    return fail(MHLA_ELAUNCH, "side stream join failed: %s", hipGetErrorString(hipGetLastError()));
-            }
             return MHLA_OK;
         }
     }

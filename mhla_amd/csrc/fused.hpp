@@ -75,49 +75,59 @@ __device__ __forceinline__ float bf(u16 h) { return __uint_as_float(((unsigned)h
 //   MODE 1: dz[j][s]   = sum_i W[i][j] dn[i][s]
 // grid (ceil(S / 64), bh), M <= 64.
 // -------------------------------------------------------------------------------------------------
-template <int MODE>
-__global__ __launch_bounds__(FT) void k_fs_wz(const float* __restrict__ W, int ldw, const float* __restrict__ x,
-                                              float* __restrict__ out, int M, int S, float eps) {
-    __shared__ float Ws[64 * 65];
-    __shared__ __attribute__((aligned(16))) float xs[64 * 64];
-    const int tid = threadIdx.x, c0 = blockIdx.x * 64, bh = blockIdx.y, rv = min(64, S - c0);
-    // all global loads first (16 + 16 per thread in flight), LDS writes after
-    float wreg[16], xreg[16];
+constexpr int WZ_C = 16;   // columns (intra-block positions s) per workgroup: ceil(S / 16) x bh workgroups
+constexpr int WZ_SMEM = (64 * 65 + 64 * WZ_C) * 4;
+// body shared by the stand-alone launch (forward: 1 / n) and the extra workgroups of the dW launch (backward: dz); NT threads
+template <int MODE, int NT>
+__device__ __forceinline__ void wz_body(float* __restrict__ smem, const float* __restrict__ W, int ldw, const float* __restrict__ x,
+                                        float* __restrict__ out, int M, int S, float eps, int cblk, int bh, int tid) {
+    float* Ws = smem;                 // [64][65]
+    float* xs = smem + 64 * 65;       // [64][WZ_C], 16-byte aligned (64 * 65 * 4 = 16640)
+    const int c0 = cblk * WZ_C, rv = min(WZ_C, S - c0);
+    constexpr int NWL = 4096 / NT, NXL = 64 * WZ_C / NT;
+    // all global loads first (clamped indices: no branches), LDS writes after
+    float wreg[NWL], xreg[NXL];
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-        const int v = tid + t * FT, r = v >> 6, c = v & 63;
-        wreg[t] = (r < M && c < M) ? (MODE ? W[(long)c * ldw + r] : W[(long)r * ldw + c]) : 0.f;
-        xreg[t] = (r < M && c < rv) ? x[((long)bh * M + r) * S + c0 + c] : 0.f;
+    for (int t = 0; t < NWL; ++t) {
+        const int v = tid + t * NT, r = min(v >> 6, M - 1), c = min(v & 63, M - 1);
+        wreg[t] = gld<float>(MODE ? W + (long)c * ldw + r : W + (long)r * ldw + c);
     }
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-        const int v = tid + t * FT, r = v >> 6, c = v & 63;
-        Ws[r * 65 + c] = wreg[t];
-        xs[r * 64 + c] = xreg[t];
+    for (int t = 0; t < NXL; ++t) {
+        const int v = tid + t * NT, r = min(v / WZ_C, M - 1), c = min(v % WZ_C, rv - 1);
+        xreg[t] = gld<float>(x + ((long)bh * M + r) * S + c0 + c);
+    }
+#pragma unroll
+    for (int t = 0; t < NWL; ++t) {
+        const int v = tid + t * NT, r = v >> 6, c = v & 63;
+        Ws[r * 65 + c] = (r < M && c < M) ? wreg[t] : 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < NXL; ++t) {
+        const int v = tid + t * NT, r = v / WZ_C, c = v % WZ_C;
+        xs[r * WZ_C + c] = (r < M && c < rv) ? xreg[t] : 0.f;
     }
     __syncthreads();
-    // thread -> 4 rows (r0, r0 + 16, ...) x 4 columns (4 sq ..): W element reused for 4 columns, x read as float4
-    const int sq = tid & 15, r0 = tid >> 4;
-    f32x4 acc[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-    for (int c = 0; c < 64; ++c) {
-        const f32x4 xv = *reinterpret_cast<const f32x4*>(xs + c * 64 + sq * 4);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i] += Ws[(r0 + 16 * i) * 65 + c] * xv;
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = r0 + 16 * i;
+    // thread -> row r = tid >> 2, 4 columns 4 (tid & 3) ..: x read as float4, one W element per step (first 256 threads)
+    if (tid < 256) {
+        const int r = tid >> 2, sq = tid & 3;
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+        for (int c = 0; c < 64; ++c) acc += Ws[r * 65 + c] * *reinterpret_cast<const f32x4*>(xs + c * WZ_C + sq * 4);
         if (r < M) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int sc = sq * 4 + t;
-                if (sc < rv) out[((long)bh * M + r) * S + c0 + sc] = MODE ? acc[i][t] : 1.f / (eps + acc[i][t]);
+                if (sc < rv) out[((long)bh * M + r) * S + c0 + sc] = MODE ? acc[t] : 1.f / (eps + acc[t]);
             }
         }
     }
+}
+template <int MODE>
+__global__ __launch_bounds__(FT) void k_fs_wz(const float* __restrict__ W, int ldw, const float* __restrict__ x,
+                                              float* __restrict__ out, int M, int S, float eps) {
+    __shared__ __attribute__((aligned(16))) float smem[WZ_SMEM / 4];
+    wz_body<MODE, FT>(smem, W, ldw, x, out, M, S, eps, blockIdx.x, blockIdx.y, threadIdx.x);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -622,20 +632,26 @@ constexpr int FS_OUT_SMEM = FS_GT_BYTES;
 // -------------------------------------------------------------------------------------------------
 // k_fs_dw: dWp[bh][q][i][j] = sum_{e' in quarter q} dG[i][e'] KV[j][e']   (both in the interleaved layout)
 // LDS images [e'][64 blocks] built from 16-byte pieces; both MFMA operands via transpose reads.
-// grid (DW_SPLIT, bh).  The <dn_i, z_j> term has its own small kernel (k_fs_dwz) so no workgroup runs long.
+// grid (DW_SPLIT, bh).  The <dn_i, z_j> term (fp32 rows, the reduction index s contiguous) rides in split 0: both operands come
+// straight from global memory in MFMA layout, split into bf16 hi + lo parts (three products: ~16 mantissa bits).
 // -------------------------------------------------------------------------------------------------
 struct FsDwArgs {
     const u16* dg;
     const u16* kv;
     const float* dn;   // [bh][M][S] or null
     const float* z;
-    float* dwp;        // [bh][DW_SPLIT + 1][64][64]  (last slot: the <dn_i, z_j> term, k_fs_dwz)
+    float* dwp;        // [bh][DW_SPLIT][64][64]
     int M, S, njg;
+    // extra workgroups blockIdx.x >= DW_SPLIT of the same launch: dz = W^T dn (k_fs_wz<1>'s work; independent of dW, needed
+    // by the next kernel) -- a latency-bound step that disappears beside the bandwidth-bound one
+    const float* W;
+    int ldw;
+    float* dz;
 };
 constexpr int DW_EC = 128;                       // e' rows per LDS image
 constexpr int DW_SPLIT = 8;                      // e' splits per (b,h)
 constexpr int DW_LDI = 72;
-constexpr int FS_DW_SMEM = 2 * DW_EC * DW_LDI * 2;
+constexpr int FS_DW_SMEM = 2 * DW_EC * DW_LDI * 2;   // 36864 >= WZ_SMEM
 
 __global__ __launch_bounds__(FT8) void k_fs_dw(const FsDwArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -644,6 +660,10 @@ __global__ __launch_bounds__(FT8) void k_fs_dw(const FsDwArgs a) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 15, kg = lane >> 4;
     const int wi = wave & 3, wj = wave >> 2;   // wave -> rows i = 16 wi .., columns j = 32 wj ..
     const int qtr = blockIdx.x, bh = blockIdx.y, njg = a.njg;
+    if (qtr >= DW_SPLIT) {   // workgroup-uniform role switch
+        wz_body<1, FT8>(reinterpret_cast<float*>(smem_raw), a.W, a.ldw, a.dn, a.dz, a.M, a.S, 0.f, qtr - DW_SPLIT, bh, tid);
+        return;
+    }
     const u16* dg = a.dg + (long)bh * njg * FE * IT;
     const u16* kv = a.kv + (long)bh * njg * FE * IT;
     f32x4 acc[2];
@@ -655,9 +675,50 @@ __global__ __launch_bounds__(FT8) void k_fs_dw(const FsDwArgs a) {
         for (int t = 0; t < NP; ++t) {
             const int v = tid + t * FT8;
             const int which = v / (DW_EC * 8), rem = v - which * DW_EC * 8, g = rem / DW_EC, r = rem - g * DW_EC;
-            pr[t] = (g < njg) ? *reinterpret_cast<const uint4*>((which ? kv : dg) + ((long)g * FE + e0 + r) * IT) : make_uint4(0, 0, 0, 0);
+            const uint4 ld = gld<uint4>((which ? kv : dg) + ((long)min(g, njg - 1) * FE + e0 + r) * IT);
+            pr[t] = (g < njg) ? ld : make_uint4(0, 0, 0, 0);
         }
     };
+    // The <dn_i, z_j> term: 32-token steps of the reduction over s are dealt to the splits (step t -> split t % DW_SPLIT).  The
+    // rows are fp32 with s contiguous, i.e. already in MFMA operand order: lane (n, kg) holds s = 32 step + 8 kg .. + 7 of row
+    // i = 16 wi + n (A) / j = 16 (2 wj + t) + n (B).  Loaded first, multiplied last (bf16 hi + lo parts, three products).
+    const int nsteps = (a.S + 31) / 32;
+    float dnr[8], zr[2][8];
+    auto load_row8 = [&](float (&dst)[8], const float* base, int row, int s0) {
+        const bool ok = row < a.M;
+        const float* p = base + ((long)bh * a.M + min(row, a.M - 1)) * a.S;
+        if ((a.S & 7) == 0) {   // whole groups of 8: two 16-byte loads (rows are 32-byte aligned)
+            const int sc = min(s0, a.S - 8);
+            const f32x4 lo = gld<f32x4>(p + sc), hi = gld<f32x4>(p + sc + 4);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { dst[t] = (ok && s0 < a.S) ? lo[t] : 0.f; dst[4 + t] = (ok && s0 < a.S) ? hi[t] : 0.f; }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const float v = gld<float>(p + min(s0 + t, a.S - 1));
+                dst[t] = (ok && s0 + t < a.S) ? v : 0.f;
+            }
+        }
+    };
+    auto load_dnz = [&](int step) {
+        const int s0 = step * 32 + kg * 8;
+        load_row8(dnr, a.dn, wi * 16 + n, step < nsteps ? s0 : a.S);
+        load_row8(zr[0], a.z, (2 * wj) * 16 + n, step < nsteps ? s0 : a.S);
+        load_row8(zr[1], a.z, (2 * wj + 1) * 16 + n, step < nsteps ? s0 : a.S);
+    };
+    auto mma_dnz = [&](const float (&x)[8], const float (&y)[8], f32x4& c) {
+        s16x8 xh, xl, yh, yl;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const u16 a_ = cvt_bf16(x[t]), b_ = cvt_bf16(y[t]);
+            xh[t] = (short)a_; xl[t] = (short)cvt_bf16(x[t] - bf(a_));
+            yh[t] = (short)b_; yl[t] = (short)cvt_bf16(y[t] - bf(b_));
+        }
+        c = mfma_bf16(__builtin_bit_cast(bf16x8, xh), __builtin_bit_cast(bf16x8, yh), c);
+        c = mfma_bf16(__builtin_bit_cast(bf16x8, xh), __builtin_bit_cast(bf16x8, yl), c);
+        c = mfma_bf16(__builtin_bit_cast(bf16x8, xl), __builtin_bit_cast(bf16x8, yh), c);
+    };
+    if (a.dn) load_dnz(qtr);   // steps beyond the last one load clamped addresses and contribute zeros
     const long ebase = (long)qtr * (FE / DW_SPLIT);
     issue(ebase);
     for (int ec = 0; ec < FE / DW_SPLIT; ec += DW_EC) {
@@ -676,77 +737,48 @@ __global__ __launch_bounds__(FT8) void k_fs_dw(const FsDwArgs a) {
         }
         __syncthreads();
     }
-    float* out = a.dwp + ((long)bh * (DW_SPLIT + 1) + qtr) * 64 * 64;
+    if (a.dn) {
+        mma_dnz(dnr, zr[0], acc[0]);
+        mma_dnz(dnr, zr[1], acc[1]);
+        for (int step = qtr + DW_SPLIT; step < nsteps; step += DW_SPLIT) {   // blocks longer than 256 tokens (rare)
+            load_dnz(step);
+            mma_dnz(dnr, zr[0], acc[0]);
+            mma_dnz(dnr, zr[1], acc[1]);
+        }
+    }
+    float* out = a.dwp + ((long)bh * DW_SPLIT + qtr) * 64 * 64;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) out[(wi * 16 + kg * 4 + r) * 64 + (2 * wj + t) * 16 + n] = acc[t][r];
 }
 
-// dWp[bh][DW_SPLIT][i][j] = sum_s dn[bh][i][s] z[bh][j][s]   (fp32, LDS tiles; one workgroup per (b,h))
-__global__ __launch_bounds__(FT) void k_fs_dwz(const float* __restrict__ dn, const float* __restrict__ z, float* __restrict__ dwp,
-                                               int M, int S) {
-    __shared__ float dns[64 * 65];
-    __shared__ float zs[64 * 65];
-    const int tid = threadIdx.x, bh = blockIdx.x;
-    const int i0 = (tid >> 4) * 4, j0 = (tid & 15) * 4;   // thread -> 4 x 4 outputs
-    float acc[4][4];
+// Deterministic single-pass reduction of the per-(b,h, split) partials: workgroup -> 16 consecutive elements of the padded
+// [64][64] matrix (grid 256); 64 part-lanes of 4 threads (16-byte loads), each summing every 64th partial in four independent
+// chains, then a fixed-order sum over the part-lanes through LDS.
+__global__ __launch_bounds__(FT) void k_fs_dw_reduce(const float* __restrict__ dwp, float* __restrict__ dW, int M, int nparts) {
+    __shared__ __attribute__((aligned(16))) float red[64][16];
+    const int tid = threadIdx.x, pl = tid >> 2, q = tid & 3, e0 = blockIdx.x * 16 + q * 4;
+    f32x4 s[4];
 #pragma unroll
-    for (int x = 0; x < 4; ++x)
+    for (int c = 0; c < 4; ++c) s[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int p0 = pl; p0 < nparts; p0 += 256) {
 #pragma unroll
-        for (int y = 0; y < 4; ++y) acc[x][y] = 0.f;
-    for (int c0 = 0; dn && c0 < S; c0 += 64) {   // dn == nullptr (un-normalised op): the term is zero
-        const int rv = min(64, S - c0);
-        float zr[32];
-#pragma unroll
-        for (int t = 0; t < 32; ++t) {
-            const int v = tid + t * FT, which = v >> 12, row = (v >> 6) & 63, col = v & 63;
-            zr[t] = (row < M && col < rv) ? (which ? z : dn)[((long)bh * M + row) * S + c0 + col] : 0.f;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int t = 0; t < 32; ++t) {
-            const int v = tid + t * FT, which = v >> 12, row = (v >> 6) & 63, col = v & 63;
-            (which ? zs : dns)[row * 65 + col] = zr[t];
-        }
-        __syncthreads();
-#pragma unroll 4
-        for (int c = 0; c < 64; ++c) {
-            float dv[4], zv[4];
-#pragma unroll
-            for (int x = 0; x < 4; ++x) { dv[x] = dns[(i0 + x) * 65 + c]; zv[x] = zs[(j0 + x) * 65 + c]; }
-#pragma unroll
-            for (int x = 0; x < 4; ++x)
-#pragma unroll
-                for (int y = 0; y < 4; ++y) acc[x][y] += dv[x] * zv[y];
+        for (int c = 0; c < 4; ++c) {
+            const int p = p0 + 64 * c;
+            const f32x4 v = gld<f32x4>(dwp + (long)min(p, nparts - 1) * 4096 + e0);
+            if (p < nparts) s[c] += v;
         }
     }
-    float* out = dwp + ((long)bh * (DW_SPLIT + 1) + DW_SPLIT) * 64 * 64;
+    *reinterpret_cast<f32x4*>(&red[pl][q * 4]) = (s[0] + s[1]) + (s[2] + s[3]);
+    __syncthreads();
+    if (tid < 16) {
+        float v = 0.f;
 #pragma unroll
-    for (int x = 0; x < 4; ++x)
-#pragma unroll
-        for (int y = 0; y < 4; ++y) out[(i0 + x) * 64 + j0 + y] = acc[x][y];
-}
-
-// Deterministic two-stage reduction of the partials: stage 1 sums groups of DWR_G partials (grid (16, ngroups)),
-// stage 2 (MODE 1) sums the group results into dW[M][M].
-constexpr int DWR_G = 64;
-__global__ void k_fs_dw_reduce1(const float* __restrict__ dwp, float* __restrict__ tmp, int nparts) {
-    const int e = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y;
-    float s = 0.f;
-    const int p1 = min(nparts, (g + 1) * DWR_G);
-#pragma unroll 16
-    for (int p = g * DWR_G; p < p1; ++p) s += dwp[(long)p * 4096 + e];
-    tmp[(long)g * 4096 + e] = s;
-}
-__global__ void k_fs_dw_reduce2(const float* __restrict__ tmp, float* __restrict__ dW, int M, int ngroups) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= M * M) return;
-    const int i = e / M, j = e - i * M;
-    float s = 0.f;
-#pragma unroll 8
-    for (int g = 0; g < ngroups; ++g) s += tmp[(long)g * 4096 + i * 64 + j];
-    dW[(long)i * M + j] = s;
+        for (int k = 0; k < 64; ++k) v += red[k][tid];
+        const int e = blockIdx.x * 16 + tid, i = e >> 6, j = e & 63;
+        if (i < M && j < M) dW[(long)i * M + j] = v;
+    }
 }
 
 // -------------------------------------------------------------------------------------------------

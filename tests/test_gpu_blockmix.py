@@ -408,31 +408,34 @@ def test_full_size_c4_wan_sampled_head():
     check("out_nonorm", out2[:, idx.to(DEV)][:, :, h:h + 1], want2, 1e-3)
 
 
-def test_side_stream_opt_in_matches_oracle_and_repeats():
-    """MHLA_SIDE_STREAM=1 (dW chain forked onto a side stream) stays correct: a child process with the
-    variable set runs the fast-path case against the oracle and checks that repetitions are bit-identical."""
-    import os
-    import subprocess
-    import sys
-    code = (
-        "import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
-        "import test_gpu_blockmix as t\n"
-        "t.run_case(2, 3, 64, 64, 64, torch.bfloat16, w='rand')\n"
-        "import mhla_amd\n"
-        "from gpu_util import DEV\n"
-        "g = torch.Generator(device=DEV).manual_seed(5)\n"
-        "mk = lambda: torch.randn(8, 4096, 4, 64, device=DEV, dtype=torch.bfloat16, generator=g).abs_().add_(1e-3)\n"
-        "q, k, v, do = mk(), mk(), mk(), mk()\n"
-        "W = torch.rand(64, 64, device=DEV)\n"
-        "res = []\n"
-        "for rep in range(3):\n"
-        "    ts = [x.clone().requires_grad_(True) for x in (q, k, v, W)]\n"
-        "    mhla_amd.mhla_blockmix(*ts).backward(do)\n"
-        "    torch.cuda.synchronize()\n"
-        "    res.append([x.grad.clone() for x in ts])\n"
-        "assert all(torch.equal(a, b) for r in res[1:] for a, b in zip(res[0], r)), 'side stream: repetitions differ'\n"
-        "print('ok')\n"
-    ) % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    env = dict(os.environ, MHLA_SIDE_STREAM="1")
-    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout[-2000:] + out.stderr[-2000:]
+def test_repetitions_bit_identical_alone_and_beside_a_second_stream():
+    """Determinism: the backward runs dz = W^T dn and the dW products as workgroups of ONE launch, and a host
+    may run several operators on several streams (DDP buckets, side streams).  Round 1 saw run-to-run differences in the
+    normaliser gradients when two of the library's kernels overlapped; this test repeats the C2-shaped operator alone and
+    with a second instance running concurrently on another stream and demands bit-identical gradients every time."""
+    import mhla_amd
+    g = torch.Generator(device=DEV).manual_seed(5)
+    mk = lambda b: torch.randn(b, 4096, 4, 64, device=DEV, dtype=torch.bfloat16, generator=g).abs_().add_(1e-3)
+    q, k, v, do = mk(8), mk(8), mk(8), mk(8)
+    q2, k2, v2, do2 = mk(6), mk(6), mk(6), mk(6)
+    W = torch.rand(64, 64, device=DEV, generator=g)
+    side = torch.cuda.Stream()
+
+    def run(concurrent):
+        ts = [x.clone().requires_grad_(True) for x in (q, k, v, W)]
+        if concurrent:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                t2 = [x.clone().requires_grad_(True) for x in (q2, k2, v2, W)]
+                for _ in range(2):
+                    mhla_amd.mhla_blockmix(*t2).backward(do2)
+        out = mhla_amd.mhla_blockmix(*ts)
+        out.backward(do)
+        torch.cuda.synchronize()
+        return [out.detach().clone()] + [x.grad.clone() for x in ts]
+
+    ref = run(False)
+    for rep in range(6):
+        got = run(rep % 2 == 1)
+        for name, a_, b_ in zip(["out", "dq", "dk", "dv", "dW"], ref, got):
+            assert torch.equal(a_, b_), f"repetition {rep} ({'two streams' if rep % 2 else 'alone'}): {name} differs"

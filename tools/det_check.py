@@ -1,7 +1,7 @@
 """Run-to-run determinism check of the block-mixing operator: forward + backward REPS times on the C2 shape, every
-output compared bit for bit with the first repetition.  Used to bisect the side-stream hazard:
-  python tools/det_check.py                      # default single stream
-  MHLA_SIDE_STREAM=1 python tools/det_check.py   # with the opt-in fork / join
+output compared bit for bit with the first repetition:
+  python tools/det_check.py              # one stream
+  STREAMS=2 python tools/det_check.py    # a second instance of the operator runs concurrently on another stream
 """
 import os
 import sys
@@ -26,7 +26,16 @@ def mk(relu):
 q, k, v, do = mk(True), mk(True), mk(False), mk(False)
 W = block_distance_weights((8, 8), "linear").to(DEV).requires_grad_(True)
 res = []
+two = os.environ.get("STREAMS", "1") == "2"
+side = torch.cuda.Stream()
+if two:
+    q2, k2, v2, do2 = mk(True)[:32], mk(True)[:32], mk(False)[:32], mk(False)[:32]
 for rep in range(REPS):
+    if two:
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            t2 = [x.clone().requires_grad_(True) for x in (q2, k2, v2)]
+            mhla_amd.mhla_blockmix(*t2, W.detach()).backward(do2)
     for t in (q, k, v):
         t.requires_grad_(True)
         t.grad = None
@@ -41,5 +50,5 @@ for r in range(1, REPS):
     eq = [bool(torch.equal(a, b)) for a, b in zip(res[0], res[r])]
     bad += sum(not e for e in eq)
     print("rep", r, " ".join(f"{n}={'same' if e else 'DIFF'}" for n, e in zip(names, eq)))
-print("side stream:", os.environ.get("MHLA_SIDE_STREAM", "0"), "-> deterministic" if bad == 0 else f"-> {bad} mismatching tensors")
+print("streams:", 2 if two else 1, "-> deterministic" if bad == 0 else f"-> {bad} mismatching tensors")
 sys.exit(1 if bad else 0)
