@@ -5,7 +5,8 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_uint, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmhla_hip.so")
+# MHLA_LIB_PATH: A/B comparison of two builds of the same library (tools); the default is the in-tree build
+LIB_PATH = os.environ.get("MHLA_LIB_PATH") or os.path.join(_HERE, "lib", "libmhla_hip.so")
 
 ABI_VERSION = 4
 F32, BF16, F16 = 0, 1, 2

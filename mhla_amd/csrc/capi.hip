@@ -524,7 +524,6 @@ int mhla_blockmix_bwd(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q
             hipStream_t sd = st;
             const int nwz = normalize ? (S + fast::WZ_C - 1) / fast::WZ_C : 0;
             RC(launch(fast::k_fs_dw, dim3(fast::DW_SPLIT + nwz, B * H), dim3(fast::FT8), fast::FS_DW_SMEM, sd, "k_fs_dw", da));
-            RC(launch(fast::k_fs_dw_reduce, dim3(256), dim3(fast::FT), 0, sd, "k_fs_dw_reduce", (const float*)f.dwp, dW, M, B * H * fast::DW_SPLIT));
             fast::FsTokArgs ta{};
             ta.q = cv(q_num); ta.k = cv(k_num); ta.v = cv(v); ta.dout = cv(dout); ta.dq = cmv(dq_num); ta.dk = cmv(dk_num);
             ta.dv = cmv(dv); ta.idx = block_index; ta.W = W; ta.ldw = ldw; ta.state = state; ta.dstate = f.dstate; ta.ninv = ninv;
@@ -536,7 +535,8 @@ int mhla_blockmix_bwd(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q
             ta.trace = tr ? tr + ntile_wgs * fast::TRACE_SLOTS : nullptr;
             RC(launch(fast::k_t16_bwd_dq, dim3(((f.njg + 1) / 2) * B * H), dim3(fast::FT8), fast::FS_GT16_BYTES, st, "k_t16_bwd_dq", ta));
             ta.trace = tr ? tr + 2 * ntile_wgs * fast::TRACE_SLOTS : nullptr;
-            RC(launch(fast::k_t16_bwd_dkv, dim3(((f.njg + 1) / 2) * B * H), dim3(fast::FT8), fast::FS_GT16_BYTES, st, "k_t16_bwd_dkv", ta));
+            ta.dwp = f.dwp; ta.dW = dW; ta.nparts = B * H * fast::DW_SPLIT; ta.ntiles = (int)ntile_wgs;
+            RC(launch(fast::k_t16_bwd_dkv, dim3((unsigned)ntile_wgs + fast::DWR_WGS), dim3(fast::FT8), fast::FS_GT16_BYTES, st, "k_t16_bwd_dkv", ta));
             return MHLA_OK;
         }
     }

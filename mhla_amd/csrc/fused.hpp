@@ -753,12 +753,14 @@ __global__ __launch_bounds__(FT8) void k_fs_dw(const FsDwArgs a) {
         for (int r = 0; r < 4; ++r) out[(wi * 16 + kg * 4 + r) * 64 + (2 * wj + t) * 16 + n] = acc[t][r];
 }
 
-// Deterministic single-pass reduction of the per-(b,h, split) partials: workgroup -> 16 consecutive elements of the padded
-// [64][64] matrix (grid 256); 64 part-lanes of 4 threads (16-byte loads), each summing every 64th partial in four independent
-// chains, then a fixed-order sum over the part-lanes through LDS.
-__global__ __launch_bounds__(FT) void k_fs_dw_reduce(const float* __restrict__ dwp, float* __restrict__ dW, int M, int nparts) {
-    __shared__ __attribute__((aligned(16))) float red[64][16];
-    const int tid = threadIdx.x, pl = tid >> 2, q = tid & 3, e0 = blockIdx.x * 16 + q * 4;
+// Deterministic reduction of the per-(b,h, split) dW partials, run by the LAST workgroups of the k_t16_bwd_dkv launch (they
+// fill the tail of that launch instead of costing a latency-bound launch of their own): workgroup r -> 32 consecutive elements
+// of the padded [64][64] matrix; 64 part-lanes of 8 threads (16-byte loads), each summing every 64th partial in four
+// independent chains, then a fixed-order sum over the part-lanes through LDS.  512 threads, DWR_WGS workgroups.
+constexpr int DWR_WGS = 128;
+__device__ __forceinline__ void dw_reduce_body(float* __restrict__ red /* [64][32] */, const float* __restrict__ dwp,
+                                               float* __restrict__ dW, int M, int nparts, int r, int tid) {
+    const int pl = tid >> 3, q = tid & 7, e0 = r * 32 + q * 4;
     f32x4 s[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) s[c] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -770,13 +772,13 @@ __global__ __launch_bounds__(FT) void k_fs_dw_reduce(const float* __restrict__ d
             if (p < nparts) s[c] += v;
         }
     }
-    *reinterpret_cast<f32x4*>(&red[pl][q * 4]) = (s[0] + s[1]) + (s[2] + s[3]);
+    *reinterpret_cast<f32x4*>(red + pl * 32 + q * 4) = (s[0] + s[1]) + (s[2] + s[3]);
     __syncthreads();
-    if (tid < 16) {
+    if (tid < 32) {
         float v = 0.f;
 #pragma unroll
-        for (int k = 0; k < 64; ++k) v += red[k][tid];
-        const int e = blockIdx.x * 16 + tid, i = e >> 6, j = e & 63;
+        for (int k = 0; k < 64; ++k) v += red[k * 32 + tid];
+        const int e = r * 32 + tid, i = e >> 6, j = e & 63;
         if (i < M && j < M) dW[(long)i * M + j] = v;
     }
 }
@@ -801,6 +803,10 @@ struct FsTokArgs {
     int H, M, S, njg;
     float eps;
     int relu, normalize;
+    // k_t16_bwd_dkv only: its last DWR_WGS workgroups reduce the dW partials (dw_reduce_body)
+    const float* dwp;
+    float* dW;
+    int nparts, ntiles;
     unsigned long long* trace;
 };
 constexpr int FS_TOK_SMEM = FS_GT_BYTES;

@@ -363,8 +363,8 @@ __global__ __launch_bounds__(FT8, 2) void k_t16_bwd_dq(const FsTokArgs a) {
     };
 
     if (S <= 64) {
-        // first block's operands (dO, Q rows) before the mixing; the second block's dO rows right after the barrier and its Q
-        // rows once the first block's products have freed registers -- both travel while the first block is processed
+        // first block's operands (dO, Q rows) before the mixing; the second block's dO rows right after the barrier (they travel
+        // while the first block is processed) and its Q rows once the first block is done (256 VGPRs: no room earlier)
         const int jA = jgx * TT + wave, jB = jA + 8, jAc = min(jA, M - 1), jBc = min(jB, M - 1);
         bf16x8 gvA[4][2], qvA[4][2];
         Side sA, sB;
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(FT8, 2) void k_t16_bwd_dq(const FsTokArgs a) {
         load_g(gvA, sA, jAc, 0, S);
         load_q(qvA, jAc, 0, S);
         trace_mark(a.trace, 1);
-        mix16_tile_to_lds<0, 3>(Gt, a.state + sofs, a.njg, a.W, a.ldw, M, jgx * TT, tid);
+        mix16_tile_to_lds<0, 2>(Gt, a.state + sofs, a.njg, a.W, a.ldw, M, jgx * TT, tid);
         trace_mark(a.trace, 2);
         __syncthreads();
         trace_mark(a.trace, 3);
@@ -381,10 +381,10 @@ __global__ __launch_bounds__(FT8, 2) void k_t16_bwd_dq(const FsTokArgs a) {
         float dks_acc[2][8];
         load_g(gvB, sB, jBc, 0, S);
         products(acc, gvA, wave);
-        load_q(qvB, jBc, 0, S);
         zero_dks(dks_acc);
         if (jA < M) { finish_store(acc, qvA, sA, dks_acc, wave, jA, 0, S); if (a.normalize) finish_dks(dks_acc, jA); }
         trace_mark(a.trace, 4);
+        load_q(qvB, jBc, 0, S);      // travels during the second block's products
         products(acc, gvB, wave + 8);
         zero_dks(dks_acc);
         if (jB < M) { finish_store(acc, qvB, sB, dks_acc, wave + 8, jB, 0, S); if (a.normalize) finish_dks(dks_acc, jB); }
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(FT8, 2) void k_t16_bwd_dq(const FsTokArgs a) {
         if (a.trace) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); trace_mark(a.trace, 6); }
         return;
     }
-    mix16_tile_to_lds<0, 3>(Gt, a.state + sofs, a.njg, a.W, a.ldw, M, jgx * TT, tid);
+    mix16_tile_to_lds<0, 2>(Gt, a.state + sofs, a.njg, a.W, a.ldw, M, jgx * TT, tid);
     __syncthreads();
     for (int bi = wave; bi < TT; bi += 8) {
         const int j = jgx * TT + bi;
@@ -417,7 +417,11 @@ __global__ __launch_bounds__(FT8, 2) void k_t16_bwd_dkv(const FsTokArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u16* Gt = reinterpret_cast<u16*>(smem_raw);
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, n = lane & 15;
-    const int L = xcd_swizzle(blockIdx.x, gridDim.x);
+    if ((int)blockIdx.x >= a.ntiles) {   // tail workgroups: the dW reduction (dW is complete when the backward's last launch is)
+        dw_reduce_body(reinterpret_cast<float*>(smem_raw), a.dwp, a.dW, a.M, a.nparts, blockIdx.x - a.ntiles, tid);
+        return;
+    }
+    const int L = xcd_swizzle(blockIdx.x, a.ntiles);
     const int ntt = (a.njg + 1) / 2, bh = L / ntt, jgx = L - bh * ntt, b = bh / a.H, h = bh - b * a.H;
     const int S = a.S, M = a.M;
     auto base = [&](const View& w) { return (const u16*)w.ptr + b * w.sb + h * w.sh; };
