@@ -728,6 +728,28 @@ def naive_chunk_simple_mhla_fixed(q, k, v, mixing_matrix, output_final_state: bo
     return mhla_causal(q, k, v, mixing_matrix, chunk_size)
 
 
+def naive_recurrent_mhla(q, k, v, mixing_matrix, chunk_size: int = 64, scale: Optional[float] = None,
+                         initial_state: Optional[torch.Tensor] = None, output_final_state: bool = True):
+    """Drop-in for the reference's token-recurrent form (mhla_nlp/fla/ops/mhla/naive.py:88-142), which the fla layer calls
+    when T <= 64 (layers/mhla.py:247): same arguments, returns `(o, S)`.
+
+    For T <= chunk_size (the only case the layer uses it for) the recurrence is exactly the single-chunk case of the chunk
+    operator, which is what runs here (one HIP launch chain instead of a T-step Python loop).  Documented deviations, both
+    from defects of the reference rather than from its intent: (1) beyond the first chunk the reference prepends a zero state
+    and so reads every earlier chunk's state shifted by one (naive.py:124-127, 133); this function computes the chunk operator
+    `naive_chunk_simple_mhla_fixed` instead; (2) the reference ignores `scale` (naive.py:101 overwrites it with K**-0.5) and
+    `initial_state` only seeds the returned tensor `S`, never the output (naive.py:113-116) -- both reproduced: `scale` is
+    ignored, and `S` is `initial_state` (or zeros) [B, H, K, V] in fp32, `None` when `output_final_state` is False."""
+    o = mhla_causal(q, k, v, mixing_matrix, chunk_size, None)
+    S = None
+    if output_final_state:
+        B, _, H, K = q.shape
+        S = torch.zeros(B, H, K, v.shape[-1], dtype=torch.float32, device=q.device)
+        if initial_state is not None:
+            S = S + initial_state
+    return o, S
+
+
 # ------------------------------------------------------------------------------------------
 # per-head RMSNorm x swish gate
 # ------------------------------------------------------------------------------------------

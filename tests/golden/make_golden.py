@@ -95,8 +95,19 @@ def gen_blockmix_2d(tag, path, cls_name, seed, B, heads, dim_head, block_size, e
         return rearrange(t, "(b h) n w d -> b (n w) h d", b=B)
 
     sd = {k: np32(v) for k, v in m.state_dict().items()}
+    # module-level backward (own generator: the op-level values above keep their random stream): d<y, dY>/dx and the
+    # gradient of every parameter, through the reference's own autograd graph
+    m._process_qkv_impl = orig
+    dW_op = np32(m.piece_attn.conv.weight.grad.reshape(M, M))       # op-level gradient, before the grads are cleared
+    for prm in m.parameters():
+        prm.grad = None
+    dY = torch.randn(y.shape, generator=torch.Generator().manual_seed(seed + 1000))
+    xg = x.clone().requires_grad_(True)
+    (m(xg) * dY).sum().backward()
+    gsd = {k: np32(prm.grad) for k, prm in m.named_parameters() if prm.grad is not None}
     save(
         f"blockmix2d_{tag}",
+        dY=np32(dY), dx_mod=np32(xg.grad), **{"gsd." + k: v for k, v in gsd.items()},
         meta=np.array([B, heads, dim_head, M, block_size, embed_len, int(qk_norm)], dtype=np.int64),
         x=np32(x), y=np32(y),
         q=np32(to_bnhd(cap["q"])), k=np32(to_bnhd(cap["kT"].transpose(-2, -1))), v=np32(to_bnhd(cap["v"])),
@@ -104,7 +115,7 @@ def gen_blockmix_2d(tag, path, cls_name, seed, B, heads, dim_head, block_size, e
         out=np32(to_bnhd(op_out_bh)), dout=np32(to_bnhd(dO)),
         dq=np32(to_bnhd(cap["q"].grad)), dk=np32(to_bnhd(cap["kT"].grad.transpose(-2, -1))),
         dv=np32(to_bnhd(cap["v"].grad)),
-        dW=np32(m.piece_attn.conv.weight.grad.reshape(M, M)),
+        dW=dW_op,
         **{"sd." + k: v for k, v in sd.items()},
     )
 
@@ -212,8 +223,17 @@ def gen_wan(tag, seed, B, heads, dim_head, layout, grid, normalize_out, is_gated
     q_rope, k_rope = cap["rope"]
     v4 = cap["v"].reshape(B, N, heads, dim_head)
     sd = {k: np32(v) for k, v in m.state_dict().items()}
+    m._process_qkv_impl = orig_proc
+    dW_op = np32(m.block_attn.conv.weight.grad.reshape(M, M))        # op-level gradient, before the grads are cleared
+    for prm in m.parameters():
+        prm.grad = None
+    dY = torch.randn(y.shape, generator=torch.Generator().manual_seed(seed + 1000))
+    xg = x.clone().requires_grad_(True)
+    (m(xg, seq_lens, grid_sizes, freqs) * dY).sum().backward()
+    gsd = {k: np32(prm.grad) for k, prm in m.named_parameters() if prm.grad is not None}
     save(
         f"wan_{tag}",
+        dY=np32(dY), dx_mod=np32(xg.grad), **{"gsd." + k: v for k, v in gsd.items()},
         meta=np.array([B, heads, dim_head, M, N // M, *layout, *grid, int(normalize_out), int(is_gated)], dtype=np.int64),
         x=np32(x), y=np32(y),
         q=np32(q_in), k=np32(k_in), v=np32(v4), q_rope=np32(q_rope), k_rope=np32(k_rope),
@@ -221,10 +241,10 @@ def gen_wan(tag, seed, B, heads, dim_head, layout, grid, normalize_out, is_gated
         out=np32(op_out), dout=np32(dO),
         dq=np32(q_in.grad), dk=np32(k_in.grad), dq_rope=np32(q_rope.grad), dk_rope=np32(k_rope.grad),
         dv=np32(cap["v"].grad.reshape(B, N, heads, dim_head)),
-        dW=np32(m.block_attn.conv.weight.grad.reshape(M, M)),
+        dW=dW_op,
         freqs_re=freqs.real.numpy()[:64], freqs_im=freqs.imag.numpy()[:64],
         is_lepe=np.array([int(is_lepe)], dtype=np.int64),
-        dx=np32(x_grad_of_sum(m, x, seq_lens, grid_sizes, freqs)) if is_lepe else np.zeros(1, np.float32),
+        dx=np32(x_grad_of_sum(m, x, seq_lens, grid_sizes, freqs)),
         **{"sd." + k: v for k, v in sd.items()},
     )
 

@@ -308,6 +308,9 @@ def test_full_size_c2_properties_and_sampled_heads():
         check("dq", sl(dq.grad), wg["dq"], GTOL[torch.bfloat16])
         check("dk", sl(dk.grad), wg["dk"], GTOL[torch.bfloat16])
         check("dv", sl(dv.grad), wg["dv"], GTOL[torch.bfloat16])
+    # dW is a sum over all 128 (b, h) pairs: the whole batch through the oracle (a few seconds on the host)
+    _, wg_all = oracle_blockmix(q, k, v, W, do, None, None, 1e-6, True)
+    check("dW (all heads)", dW.grad, wg_all["dW"], GTOL[torch.bfloat16])
     # linearity in v (fp32 so the property is tight)
     qf, kf, vf = dq.detach().float(), dk.detach().float(), dv.detach().float()
     v2 = torch.randn_like(vf)
@@ -327,6 +330,27 @@ def test_full_size_c2_properties_and_sampled_heads():
     mask[5 * S:6 * S] = False
     assert torch.equal(oa[:, mask], ob[:, mask])
     assert not torch.equal(oa[:, ~mask], ob[:, ~mask])
+
+
+def _check_dw_additive(mhla_amd, q, k, v, do, Wd, W, chunk):
+    """dW of the whole (huge) batch = sum of the dW of batch chunks (size-independent property: catches indexing errors of the
+    partial / reduction buffers at large grids), and the first chunk's dW is anchored on the oracle."""
+    full = Wd.grad.detach().double().cpu()
+    acc = torch.zeros_like(full)
+    B = q.shape[0]
+    for b0 in range(0, B, chunk):
+        qs, ks, vs = (t.detach()[b0:b0 + chunk].requires_grad_(True) for t in (q, k, v))
+        Wc = W.to(DEV).requires_grad_(True)
+        mhla_amd.mhla_blockmix(qs, ks, vs, Wc).backward(do[b0:b0 + chunk])
+        acc += Wc.grad.double().cpu()
+        if b0 == 0:
+            f = lambda t: t.detach()[:8].float().cpu()
+            _, wg = oracle_blockmix(f(q), f(k), f(v), W, f(do), None, None, 1e-6, True)
+            Wa = W.to(DEV).requires_grad_(True)
+            mhla_amd.mhla_blockmix(q.detach()[:8].requires_grad_(True), k.detach()[:8], v.detach()[:8], Wa).backward(do[:8])
+            check("dW (first 8 samples vs oracle)", Wa.grad, wg["dW"], GTOL[torch.bfloat16])
+    # fp32 partial sums in different groupings: agreement to fp32 summation noise
+    check("dW additivity over batch chunks", full.float(), acc.float(), 2e-4)
 
 
 def test_more_than_2_31_elements_per_tensor():
@@ -352,7 +376,7 @@ def test_more_than_2_31_elements_per_tensor():
         check("dq", sl(q.grad), wg["dq"], GTOL[torch.bfloat16])
         check("dk", sl(k.grad), wg["dk"], GTOL[torch.bfloat16])
         check("dv", sl(v.grad), wg["dv"], GTOL[torch.bfloat16])
-    assert torch.isfinite(Wd.grad).all()
+    _check_dw_additive(mhla_amd, q, k, v, do, Wd, W, chunk=48)
     del q, k, v, do, out
     torch.cuda.empty_cache()
 
@@ -379,6 +403,7 @@ def test_more_than_2_31_elements_split_path():
         check("dq", sl(q.grad), wg["dq"], GTOL[torch.bfloat16])
         check("dk", sl(k.grad), wg["dk"], GTOL[torch.bfloat16])
         check("dv", sl(v.grad), wg["dv"], GTOL[torch.bfloat16])
+    _check_dw_additive(mhla_amd, q, k, v, do, Wd, W, chunk=152)
     del q, k, v, do, out
     torch.cuda.empty_cache()
 
@@ -406,6 +431,38 @@ def test_full_size_c4_wan_sampled_head():
     out2 = mhla_amd.mhla_blockmix(qr.to(DEV), kr.to(DEV), v.to(DEV), W.to(DEV), normalize=False, block_index=idx.int().to(DEV))
     want2 = orc.blockmix_fwd(sl(qr), sl(kr), sl(v), W, 1e-6, normalize=False)
     check("out_nonorm", out2[:, idx.to(DEV)][:, :, h:h + 1], want2, 1e-3)
+
+
+def test_full_size_c4_wan_backward_sampled_head_and_full_dw():
+    """C4 shape, training direction: forward + backward on all 12 heads (fp32, split q/k pairs, gather map); every token
+    gradient of one head and the mixing-weight gradient summed over ALL heads against the oracle's closed form."""
+    import mhla_amd
+    B, H, D, layout, grid = 1, 12, 128, (3, 5, 10), (21, 30, 50)
+    N = 21 * 30 * 50
+    g = torch.Generator().manual_seed(199)
+    q = torch.relu(torch.randn(B, N, H, D, generator=g)) + 1e-6
+    k = torch.relu(torch.randn(B, N, H, D, generator=g)) + 1e-6
+    v = torch.randn(B, N, H, D, generator=g)
+    do = torch.randn(B, N, H, D, generator=g)
+    qr = q * torch.sign(torch.randn(B, N, H, D, generator=g))
+    kr = k * torch.sign(torch.randn(B, N, H, D, generator=g))
+    W = orc.block_distance_weights(layout, "linear")
+    idx = orc.block_index_3d(grid, layout)
+    leaves = [t.to(DEV).requires_grad_(True) for t in (qr, kr, v, W, q, k)]
+    poison()
+    out = mhla_amd.mhla_blockmix(leaves[0], leaves[1], leaves[2], leaves[3], q_den=leaves[4], k_den=leaves[5],
+                                 block_index=idx.int().to(DEV))
+    poison()
+    out.backward(do.to(DEV))
+    torch.cuda.synchronize()
+    bm = lambda t: t[:, idx]                      # raster -> block-major token order (what the oracle works on)
+    wg = orc.blockmix_bwd(bm(qr), bm(kr), bm(v), W, bm(do), 1e-6, q_den=bm(q), k_den=bm(k))
+    h = 5
+    hd = lambda t: t[:, :, h:h + 1]
+    for name, leaf in zip(("dq", "dk", "dv", None, "dq_den", "dk_den"), leaves):
+        if name:
+            check(name, hd(bm(leaf.grad.cpu())), hd(wg[name]), 1e-3)
+    check("dW (12 heads)", leaves[3].grad, wg["dW"], 1e-3)
 
 
 def test_repetitions_bit_identical_alone_and_beside_a_second_stream():

@@ -52,6 +52,11 @@ def test_golden_causal(tag):
     check("out", out, g["out"], tol)
     for n, t in (("dq", q), ("dk", k), ("dv", v), ("dmix", mix)):
         check(n, t.grad, g[n], 1.5e-2 if bf16 else 2e-4)
+    if "out_recurrent" in g:   # T <= 64: the reference's token-recurrent form (naive.py:88-142), as the fla layer calls it
+        o_rec, S = mhla_amd.naive_recurrent_mhla(q.detach(), k.detach(), v.detach(), mix.detach())
+        check("naive_recurrent_mhla", o_rec, g["out_recurrent"], tol)
+        assert S.shape == (q.shape[0], q.shape[2], q.shape[3], v.shape[3]) and float(S.abs().max()) == 0.0
+        assert mhla_amd.naive_recurrent_mhla(q.detach(), k.detach(), v.detach(), mix.detach(), output_final_state=False)[1] is None
 
 
 @pytest.mark.parametrize("T,K,V", [(256, 64, 64), (200, 32, 16), (50, 16, 24), (64, 128, 256), (1000, 128, 128),
@@ -128,7 +133,20 @@ def test_causal_more_than_2_31_elements():
         check("dq", sl(q.grad), wg["dq"], GTOL[torch.bfloat16])
         check("dk", sl(k.grad), wg["dk"], GTOL[torch.bfloat16])
         check("dv", sl(v.grad), wg["dv"], GTOL[torch.bfloat16])
-    assert torch.isfinite(md.grad).all()
+    # dmix of the whole batch = sum over batch chunks (size-independent), first samples anchored on the oracle
+    full = md.grad.detach().double().cpu()
+    acc = torch.zeros_like(full)
+    for b0 in range(0, B, 34):
+        qs, ks, vs = (t.detach()[b0:b0 + 34].requires_grad_(True) for t in (q, k, v))
+        mc = mix.to(DEV).requires_grad_(True)
+        mhla_amd.mhla_causal(qs, ks, vs, mc).backward(do[b0:b0 + 34])
+        acc += mc.grad.double().cpu()
+    check("dmix additivity over batch chunks", full.float(), acc.float(), 2e-4)
+    f = lambda t: t.detach()[:2].float().cpu()
+    wg2 = orc.causal_bwd(f(q), f(k), f(v), mix, f(do))
+    mc = mix.to(DEV).requires_grad_(True)
+    mhla_amd.mhla_causal(q.detach()[:2], k.detach()[:2], v.detach()[:2], mc).backward(do[:2])
+    check("dmix (first 2 samples vs oracle)", mc.grad, wg2["dmix"], GTOL[torch.bfloat16])
     del q, k, v, do, out
     torch.cuda.empty_cache()
 
@@ -252,3 +270,26 @@ def test_full_size_c5_sampled_head():
     check("dq", sl(dq.grad), wg["dq"], GTOL[torch.bfloat16])
     check("dk", sl(dk.grad), wg["dk"], GTOL[torch.bfloat16])
     check("dv", sl(dv.grad), wg["dv"], GTOL[torch.bfloat16])
+    # dmix sums over every (b, h): the whole batch through the oracle
+    wg_all = orc.causal_bwd(q.float(), k.float(), v.float(), mix, do.float())
+    check("dmix (all heads)", dm.grad, wg_all["dmix"], GTOL[torch.bfloat16])
+
+
+def test_full_size_c5_1p3b_like_shape():
+    """The 1.3B-like fla shape of SURVEY.md 8 (K = 256, V = 512, T = 8192, 128 chunks), bf16: every output and gradient of
+    one (b, h) and dmix over all heads vs the oracle (the K <= 256 token-gradient kernel with four K slices)."""
+    import mhla_amd
+    B, T, H, K, V, L = 1, 8192, 2, 256, 512, 128
+    q, k, v, mix, do = causal_inputs(B, T, H, K, V, L, torch.bfloat16, seed=18, random_mix=True)
+    dq, dk, dv, dm = (t.to(DEV).requires_grad_(True) for t in (q, k, v, mix))
+    poison()
+    out = mhla_amd.mhla_causal(dq, dk, dv, dm)
+    poison()
+    out.backward(do.to(DEV))
+    want = orc.causal_fwd(q.float(), k.float(), v.float(), mix)
+    wg = orc.causal_bwd(q.float(), k.float(), v.float(), mix, do.float())
+    check("out", out, want, TOL[torch.bfloat16])
+    check("dq", dq.grad, wg["dq"], GTOL[torch.bfloat16])
+    check("dk", dk.grad, wg["dk"], GTOL[torch.bfloat16])
+    check("dv", dv.grad, wg["dv"], GTOL[torch.bfloat16])
+    check("dmix", dm.grad, wg["dmix"], GTOL[torch.bfloat16])

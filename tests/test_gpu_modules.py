@@ -13,6 +13,23 @@ def _sd(g):
     return {k[3:]: v for k, v in g.items() if k.startswith("sd.")}
 
 
+def _check_module_grads(m, x, y, g, tol):
+    """Module-level backward against the reference's own autograd (fixtures `dY`, `dx_mod`, `gsd.<param>`): d<y, dY>/dx and
+    the gradient of every parameter."""
+    for prm in m.parameters():
+        prm.grad = None
+    x.grad = None
+    poison()
+    (y * g["dY"].to(DEV)).sum().backward()
+    check("dx (module)", x.grad, g["dx_mod"], tol)
+    want = {k[4:]: v for k, v in g.items() if k.startswith("gsd.")}
+    got = dict(m.named_parameters())
+    assert set(want) <= set(got), sorted(set(want) - set(got))
+    for name, ref in want.items():
+        assert got[name].grad is not None, f"{name}: no gradient"
+        check(f"grad {name}", got[name].grad.reshape(ref.shape), ref, tol, atol=1e-7)
+
+
 @pytest.mark.parametrize("tag,cls,kw", [
     ("dit_a", "MHLA4DiT", dict(heads=2, dim_head=32, block_size=16, embed_len=256, qkv_bias=True, transform="linear")),
     ("dit_b", "MHLA4DiT", dict(heads=1, dim_head=72, block_size=49, embed_len=441, qkv_bias=True, transform="exp")),
@@ -31,8 +48,7 @@ def test_dit_vit_module_matches_reference(tag, cls, kw):
     # 3-D [B, N, C] entry used by the DiT host gives the same tokens
     y3 = m(x.reshape(x.shape[0], -1, x.shape[-1]))
     assert torch.equal(y3.reshape(y.shape), y)
-    y.sum().backward()
-    assert m.piece_attn.conv.weight.grad is not None and torch.isfinite(x.grad).all()
+    _check_module_grads(m, x, y, g, 2e-4)
 
 
 def test_dit_module_initial_weights_match_reference_init():
@@ -56,8 +72,7 @@ def test_wan_module_matches_reference(tag):
     grid_sizes = torch.tensor([[F_, H_, W_]] * B, dtype=torch.long)
     y = m(x, torch.tensor([N] * B), grid_sizes, modules.wan_freqs(D))
     check("y", y, g["y"], 1e-4)
-    y.sum().backward()
-    assert m.block_attn.conv.weight.grad is not None and torch.isfinite(x.grad).all()
+    _check_module_grads(m, x, y, g, 2e-4)
 
 
 @pytest.mark.parametrize("tag", ["a", "b"])
@@ -119,6 +134,8 @@ def test_wan_module_with_lepe_matches_reference():
     check("y (fused inference)", y_inf, g["y"], 1e-4)
     check("dx", x.grad, g["dx"], 2e-4)
     assert m.lepe.weight.grad is not None and m.lepe.bias.grad is not None
+    x2 = g["x"].to(DEV).requires_grad_(True)
+    _check_module_grads(m, x2, m(x2, torch.tensor([N] * B), grid_sizes, modules.wan_freqs(D)), g, 2e-4)
 
 
 @pytest.mark.parametrize("grid,C,dtype", [((4, 6, 9), 64, torch.float32), ((1, 5, 7), 24, torch.float32), ((3, 1, 1), 8, torch.float32),
@@ -330,8 +347,17 @@ def test_fla_layer_matches_oracle_restatement():
     o, attn, cache = m(xd)
     assert attn is None and cache is None
     check("o", o, want, 1e-4)
-    o.sum().backward()
-    assert m.mixing_matrix.grad is not None
+    # layer-level gradients: autograd through the oracle's restatement of the layer (fp64 would change nothing: fp32 ref)
+    dY = torch.randn(o.shape, generator=torch.Generator().manual_seed(9))
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    sdr["mixing_matrix"] = sd["mixing_matrix"].clamp(1e-5, 1).clone().requires_grad_(True)   # the forward's in-place clamp
+    xr = x.clone().requires_grad_(True)
+    (orc.fla_layer_forward(sdr, xr, 2, 64, 128, norm_eps=1e-6) * dY).sum().backward()
+    (o * dY.to(DEV)).sum().backward()
+    check("dx (layer)", xd.grad, xr.grad, 2e-4)
+    for name, prm in m.named_parameters():
+        check(f"grad {name}", prm.grad, sdr[name].grad, 2e-4, atol=1e-7)
+    xd.grad = None
     # forward clamps the mixing weights in place on .data (layers/mhla.py:237); the reference's .tril() there
     # acts on the trailing 1x1 dims of the [32,32,1,1,1,1] parameter, i.e. it is a no-op, reproduced as is
     mm = m.mixing_matrix.detach().reshape(32, 32)
@@ -399,6 +425,17 @@ def test_minimal_gpt_host_trains_a_step():
         ids2[:, 150:] = (ids2[:, 150:] + 1) % 97
         b = m(ids2)
     check("causal prefix", a[:, :150], b[:, :150].cpu(), 1e-5)
+    # parity: the same host on the CPU with every attention layer replaced by the oracle's restatement of the fla layer
+    import copy
+    ref = copy.deepcopy(m).cpu()
+    for blk in ref.layers:
+        sd = {k: v.detach() for k, v in blk.attn.state_dict().items()}
+        lay = blk.attn
+        blk.attn.forward = (lambda sd, lay: lambda z, **kw: (orc.fla_layer_forward(
+            sd, z, lay.num_heads, lay.head_k_dim, lay.head_v_dim, norm_eps=lay.g_norm_swish_gate.eps), None, None))(sd, lay)
+    with torch.no_grad():
+        want = ref(ids.cpu())
+    check("gpt host logits", a, want, 2e-4)
 
 
 def test_wan_block_shell():
