@@ -32,7 +32,9 @@ def load_by_path(name, path):
 
 
 def np32(t):
-    return t.detach().to(torch.float32).cpu().numpy()
+    # always a copy: a float32 CPU tensor would otherwise share its memory with the array, and later backward passes that
+    # accumulate into .grad in place would silently change fixtures already collected
+    return t.detach().to(torch.float32).cpu().numpy().copy()
 
 
 def save(name, **arrs):
