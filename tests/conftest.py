@@ -53,3 +53,30 @@ def _poison_free_gpu_memory(request):
         slabs = [torch.full((n,), float("nan"), dtype=torch.float32, device="cuda") for n in (1 << 26, 1 << 24, 1 << 22, 1 << 20)]
         del slabs
     yield
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """After a -m gpu session: the observed parity errors, per (dtype, quantity class), to gpurun_out/parity_report.json."""
+    try:
+        import gpu_util
+    except Exception:
+        return
+    obs = getattr(gpu_util, "OBSERVED", [])
+    if not obs:
+        return
+    import json
+    agg = {}
+    for test, name, dtype, e, r, tol in obs:
+        kind = "output" if name.split(" ")[0] in ("out", "y", "o", "out_nonorm", "o_short") else "gradient"
+        key = f"{dtype}/{kind}"
+        a = agg.setdefault(key, {"n": 0, "max_rel_err": 0.0, "max_rms_ratio": 0.0, "worst": None, "loosest_tol": 0.0})
+        a["n"] += 1
+        a["max_rms_ratio"] = max(a["max_rms_ratio"], r)
+        a["loosest_tol"] = max(a["loosest_tol"], tol)
+        if e >= a["max_rel_err"]:
+            a["max_rel_err"], a["worst"] = e, f"{test} :: {name} (tol {tol:g})"
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "parity_report.json"), "w") as f:
+        json.dump({"comparisons": len(obs), "by_dtype_and_kind": agg,
+                   "all": [dict(test=t, name=n, dtype=d, rel_err=e, rms_ratio=r, tol=tol) for t, n, d, e, r, tol in obs]}, f, indent=1)

@@ -5,10 +5,12 @@ from conftest import rel_err, rms_ratio
 from oracle import mhla_oracle as orc
 
 DEV = "cuda"
-# north_star: outputs within 1e-3 rel-err (max|a-b| / max|b|) of the reference in fp32-accumulate,
-# fp32-output mode.  bf16 / fp16 OUTPUT adds one rounding of the result (2^-9 / 2^-11 elementwise).
-TOL = {torch.float32: 1e-3, torch.bfloat16: 6e-3, torch.float16: 2e-3}
-GTOL = {torch.float32: 1e-3, torch.bfloat16: 1.2e-2, torch.float16: 3e-3}
+# north_star: outputs within 1e-3 rel-err (max|a-b| / max|b|) of the reference in fp32-accumulate, fp32-output mode; bf16 /
+# fp16 OUTPUT adds one rounding of the result (2^-9 / 2^-11 elementwise).  The bounds below are about twice the largest
+# error observed over the whole -m gpu suite in round 2 (profiles/r2_parity_errors.md: fp32 7.2e-5; bf16 outputs 5.8e-3 --
+# one bf16 rounding of the largest output, nothing to tighten; bf16 gradients 7.7e-3; fp16 4.3e-4 / 6.4e-4).
+TOL = {torch.float32: 2e-4, torch.bfloat16: 6e-3, torch.float16: 1e-3}
+GTOL = {torch.float32: 2e-4, torch.bfloat16: 1.2e-2, torch.float16: 1.5e-3}
 
 
 def make_blockmix_inputs(B, H, M, S, D, dtype, seed=1234, w="linear", split=False):
@@ -43,13 +45,22 @@ def to_dev(*ts):
     return [None if t is None else t.to(DEV) for t in ts]
 
 
+# every comparison of a parity run: (test id, name, dtype of the HIP result, max-normalised error, rms-relative error, tolerance);
+# conftest writes the summary to gpurun_out/parity_report.json at the end of a -m gpu session (profiles/ keeps a copy per round)
+OBSERVED = []
+
+
 def check(name, got, want, tol, atol=0.0):
-    """rel-err = max|got - want| / max|want| < tol (or max|got - want| < atol for ~zero references)."""
+    """rel-err = max|got - want| / max|want| < tol (or max|got - want| < atol for ~zero references); the rms-relative error
+    (which, unlike the max-normalised one, sees errors on small-magnitude elements) must stay below the same bound."""
+    import os
     g, w = got.float().cpu(), want.float()
     if atol and (g - w).abs().max().item() < atol:
         return 0.0
     e, r = rel_err(g, w), rms_ratio(g, w)
+    OBSERVED.append((os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0], name, str(got.dtype).replace("torch.", ""), e, r, tol))
     assert e < tol, f"{name}: rel_err {e:.3e} (rms ratio {r:.3e}) exceeds {tol:.1e}"
+    assert r < 2 * tol, f"{name}: rms ratio {r:.3e} exceeds {2 * tol:.1e} (rel_err {e:.3e})"
     return e
 
 
