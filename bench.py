@@ -35,6 +35,8 @@ def parse():
     p.add_argument("--M", type=int, default=64)
     p.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "f16"])
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-extra-configs", action="store_true",
+                   help="skip the other BASELINE.json shapes (C3 / C4 / C5 / C2 variants) reported as `extra_configs` at N = 1")
     p.add_argument("--no-graph", dest="graph", action="store_false",
                    help="launch every step eagerly through Python autograd instead of replaying the captured HIP graph")
     p.set_defaults(graph=True)
@@ -219,14 +221,24 @@ def main():
     # roofline fraction is its share / its duration
     share = {"k_t16_bwd_dkv": 4, "k_t16_bwd_dq": 3, "k_t16_out": 2, "k_fs_state_fwd": 2, "k_fs_state<1>": 3,
              "k_bm_bwd_tok": 7, "k_bm_state<0>": 2, "k_bm_state<1>": 3, "k_bm_out": 2}
-    # HBM bytes per step from rocprofv3 PMC passes of this same command (tools/pmc_run.sh; profiles/*.json), if committed
-    traffic = None
-    pj = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
-    if os.path.exists(pj) and (a.B, a.N, a.H, a.D, a.M, a.dtype) == (8, 4096, 16, 64, 64, "bf16"):
-        try:
-            traffic = json.load(open(pj))["hbm_bytes_per_step"]
-        except Exception:
-            traffic = None
+    # HBM bytes per step: PMC counters cannot be read from inside this process, so the figure comes from the rocprofv3 PMC
+    # passes of this same command (tools/prof_bench.sh -> profiles/r*_pmc_traffic.json) -- and only when that file was made
+    # from the kernel sources this library was built from (it records their hash); otherwise null
+    traffic, traffic_src = None, None
+    if (a.B, a.N, a.H, a.D, a.M, a.dtype) == (8, 4096, 16, 64, 64, "bf16"):
+        import glob
+        import hashlib
+        hsh = hashlib.sha256()
+        for fn in sorted(glob.glob(os.path.join(ROOT, "mhla_amd", "csrc", "*"))):
+            hsh.update(open(fn, "rb").read())
+        for pj in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+            try:
+                rec = json.load(open(pj))
+                if rec.get("csrc_sha16") == hsh.hexdigest()[:16]:
+                    traffic, traffic_src = rec["hbm_bytes_per_step"], os.path.relpath(pj, ROOT)
+                    break
+            except Exception:   # noqa: BLE001
+                pass
     alg_flops = a.B * a.H * (12 * a.N * a.D * a.D + 6 * a.M * a.M * a.D * a.D)
     achieved = alg_bytes / (step_gpu_us * 1e-6) / 1e9 if step_gpu_us else None
 
@@ -245,6 +257,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS if achieved else None, "traffic": traffic,
+                "traffic_source": traffic_src or "none for these kernel sources: run tools/prof_bench.sh (rocprofv3 PMC passes)",
                 "scope": "whole fwd+bwd step: algorithmic bytes 12*B*H*N*D*e over the GPU time of one step (HIP events on "
                          "the launch stream around K steps); `kernels` lists every kernel's own average duration, measured "
                          "with the library's per-launch event hook in a separate eager pass",
@@ -261,6 +274,14 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(a)
             res["gpu_over_cpu"] = value / res["cpu_baseline"]["value"]
+        if world == 1 and not a.no_extra_configs and _config_name(a) == "BASELINE.json configs[1]":
+            # the other BASELINE.json shapes, measured after (outside) the timed region of the main line
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import bench_configs
+                res["extra_configs"] = bench_configs.run_extra_configs()
+            except Exception as e:   # noqa: BLE001
+                res["extra_configs"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(res))
     if world > 1:
         import torch.distributed as dist

@@ -7,7 +7,7 @@ OUT=$1; shift
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-if [ -n "${PMC_SCRIPT:-}" ]; then CMD="$ROOT/$PMC_SCRIPT $*"; else CMD="$ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline $*"; fi
+if [ -n "${PMC_SCRIPT:-}" ]; then CMD="$ROOT/$PMC_SCRIPT $*"; else CMD="$ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra-configs $*"; fi
 run() {  # name, counters...
   local name=$1; shift
   rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/$name" -- python3 $CMD > "$OUT/$name.log" 2>&1

@@ -44,7 +44,12 @@ for k, d in sorted(data.items()):
         "lds_conflict_frac": d.get("SQ_LDS_BANK_CONFLICT", 0) / d["SQ_LDS_IDX_ACTIVE"] if d.get("SQ_LDS_IDX_ACTIVE") else None,
         "hbm_read_bytes": rd, "hbm_write_bytes": wr, "l2_hit": hit / (hit + miss) if hit + miss else None,
     })
-out = {"kernels": rows, "hbm_read_bytes_per_step": tot_r, "hbm_write_bytes_per_step": tot_w,
+import hashlib
+import os
+_h = hashlib.sha256()
+for _fn in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "mhla_amd", "csrc", "*"))):
+    _h.update(open(_fn, "rb").read())
+out = {"csrc_sha16": _h.hexdigest()[:16], "kernels": rows, "hbm_read_bytes_per_step": tot_r, "hbm_write_bytes_per_step": tot_w,
        "hbm_bytes_per_step": tot_r + tot_w,
        "note": "per launch (= per bench step, one launch of each kernel); read = 2 x FETCH_SIZE KB, write = WRITE_SIZE KB"}
 if "--json" in sys.argv:
