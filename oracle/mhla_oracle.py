@@ -459,6 +459,48 @@ def wan_module_forward(sd: dict, x: torch.Tensor, grid: Tuple[int, int, int], fr
     return F.linear(out, sd["o.weight"], sd["o.bias"])                             # :365
 
 
+def wan_variant_forward(kind: str, sd: dict, x: torch.Tensor, grid: Tuple[int, int, int], freqs: torch.Tensor,
+                        heads: int, layout=(3, 5, 10), eps: float = 1e-6, normalize_out: bool = True) -> torch.Tensor:
+    """The five older Wan MHLA classes (``wan/model.py``): identical operator, different epilogues --
+    ``mhla`` / ``mhla_nope``: ``out_rmsnorm(o(out))`` (:1389, :804); ``gated_mhla``: ``o(g_norm_fulldim(out) * silu(g(x)))``
+    (:614-618); ``mhla_lepe``: ``out_rmsnorm(o(out + lepe))`` (:1203); ``gated_mhla_lepe``:
+    ``o(g_norm_perhead(out) * silu(g(x)) + lepe)`` (:1003-1007).  ``out_rmsnorm`` is present in ``sd`` only when enabled."""
+    B, N, C = x.shape
+    D = C // heads
+    q = F.linear(x, sd["q.weight"], sd["q.bias"])
+    k = F.linear(x, sd["k.weight"], sd["k.bias"])
+    v = F.linear(x, sd["v.weight"], sd["v.bias"])
+    lepe = None
+    if "lepe.weight" in sd:                                                        # :891-892 -- conv over v as a video
+        f, h, w = grid
+        vid = v.reshape(B, f, h, w, C).permute(0, 4, 1, 2, 3)
+        lepe = F.conv3d(vid, sd["lepe.weight"], sd["lepe.bias"], padding=1, groups=C).permute(0, 2, 3, 4, 1).reshape(B, N, C)
+    qf = relu_eps(rms_norm(q.float(), sd["norm_q.weight"], eps), eps).reshape(B, N, heads, D)
+    kf = relu_eps(rms_norm(k.float(), sd["norm_k.weight"], eps), eps).reshape(B, N, heads, D)
+    vf = v.float().reshape(B, N, heads, D)
+    q_rope, k_rope = wan_rope_apply(qf, grid, freqs), wan_rope_apply(kf, grid, freqs)
+    idx = block_index_3d(grid, layout)
+    M = layout[0] * layout[1] * layout[2]
+    W = sd["block_attn.conv.weight"].reshape(M, M)
+    o = blockmix_fwd(q_rope[:, idx], k_rope[:, idx], vf[:, idx], W, eps, q_den=qf[:, idx], k_den=kf[:, idx], normalize=normalize_out)
+    out = torch.empty_like(o)
+    out[:, idx] = o
+    out = out.to(x.dtype).reshape(B, N, C)
+    lin_o = lambda t: F.linear(t, sd["o.weight"], sd["o.bias"])
+    post = (lambda t: rms_norm(t, sd["out_rmsnorm.weight"], eps)) if "out_rmsnorm.weight" in sd else (lambda t: t)
+    if kind in ("mhla", "mhla_nope"):
+        return post(lin_o(out))
+    if kind == "mhla_lepe":
+        return post(lin_o(out + lepe))
+    gate = F.silu(F.linear(x, sd["g.weight"], sd["g.bias"]))
+    if kind == "gated_mhla":
+        return lin_o(rms_norm(out, sd["g_norm.weight"], eps) * gate)
+    if kind == "gated_mhla_lepe":
+        normed = rms_norm(out.reshape(B, N, heads, D), sd["g_norm.weight"], eps).reshape(B, N, C)
+        return lin_o(normed * gate + lepe)
+    raise ValueError(kind)
+
+
 def fla_layer_forward(sd: dict, x: torch.Tensor, heads: int, head_k: int, head_v: int,
                       norm_eps: float = 1e-5, chunk_size: int = 64) -> torch.Tensor:
     """``MHLA.forward`` (fla layer, ``feature_map='relu'``, fused swish gate, no

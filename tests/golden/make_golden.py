@@ -252,6 +252,57 @@ def gen_wan(tag, seed, B, heads, dim_head, layout, grid, normalize_out, is_gated
 
 
 # ---------------------------------------------------------------------------
+# 2b. the five older Wan MHLA classes (wan/model.py:428-1389): each class is AST-extracted from model.py (which cannot be
+#     imported: diffusers / timm / mmcv / flash-attn) together with WanRMSNorm, rope_params and rope_apply, and executed in
+#     a stub namespace that gets BlockDistanceConv3D from the reference's own mhla_utils.py
+# ---------------------------------------------------------------------------
+def load_wan_variant(cls_name):
+    wan = load_wan_utils()
+    src_path = f"{REF}/mhla_videogen/diffusion/model/wan/model.py"
+    tree = ast.parse(open(src_path).read())
+    ns = {}
+    exec("import math\nimport torch\nimport torch.nn as nn\nimport torch.nn.functional as F\nfrom torch.cuda import amp\n"
+         "from einops import rearrange\n", ns)
+    ns["BlockDistanceConv3D"] = wan.BlockDistanceConv3D
+    for node in tree.body:
+        if isinstance(node, (ast.ClassDef, ast.FunctionDef)) and node.name in {"WanRMSNorm", "rope_params", "rope_apply", cls_name}:
+            exec(compile(ast.Module(body=[node], type_ignores=[]), src_path, "exec"), ns)
+    return ns
+
+
+def gen_wan_variant(tag, cls_name, seed, B, heads, dim_head, layout, grid, normalize_out, out_rmsnorm):
+    ns = load_wan_variant(cls_name)
+    torch.manual_seed(seed)
+    dim = heads * dim_head
+    m = ns[cls_name](dim, num_heads=heads, block_layout=layout, normalize_out=normalize_out, out_rmsnorm=out_rmsnorm)
+    m.eval()
+    M = layout[0] * layout[1] * layout[2]
+    with torch.no_grad():       # de-trivialise the norm weights and the mixing weights
+        for name, prm in m.named_parameters():
+            if name.endswith("norm.weight") or name.startswith("norm_") or name == "g_norm.weight" or name == "out_rmsnorm.weight":
+                prm.uniform_(0.5, 1.5)
+        m.block_attn.conv.weight.mul_(torch.rand(M, M, 1, 1) + 0.5)
+    d = dim_head
+    freqs = torch.cat([ns["rope_params"](1024, d - 4 * (d // 6)), ns["rope_params"](1024, 2 * (d // 6)),
+                       ns["rope_params"](1024, 2 * (d // 6))], dim=1)
+    N = grid[0] * grid[1] * grid[2]
+    x = torch.randn(B, N, dim)
+    grid_sizes = torch.tensor([list(grid)] * B, dtype=torch.long)
+    seq_lens = torch.tensor([N] * B, dtype=torch.long)
+    xg = x.clone().requires_grad_(True)
+    y = m(xg, seq_lens, grid_sizes, freqs)
+    dY = torch.randn(y.shape, generator=torch.Generator().manual_seed(seed + 1000))
+    (y * dY).sum().backward()
+    save(
+        f"wanv_{tag}",
+        meta=np.array([B, heads, dim_head, *layout, *grid, int(normalize_out), int(out_rmsnorm)], dtype=np.int64),
+        x=np32(x), y=np32(y), dY=np32(dY), dx_mod=np32(xg.grad),
+        **{"sd." + k: np32(v) for k, v in m.state_dict().items()},
+        **{"gsd." + k: np32(prm.grad) for k, prm in m.named_parameters() if prm.grad is not None},
+    )
+
+
+# ---------------------------------------------------------------------------
 # 3. fla causal op (fla/ops/mhla/naive.py)
 # ---------------------------------------------------------------------------
 def gen_causal(tag, seed, B, T, H, K, V, L, dtype=torch.float32, random_mix=False):
@@ -337,6 +388,16 @@ if __name__ == "__main__":
             is_gated=True)
     gen_wan("c", seed=23, B=2, heads=2, dim_head=32, layout=(2, 2, 3), grid=(4, 6, 9), normalize_out=False,
             is_gated=True, is_lepe=True)
+    gen_wan_variant("mhla", "MHLA_Video", seed=41, B=1, heads=2, dim_head=32, layout=(2, 2, 3), grid=(4, 6, 9),
+                    normalize_out=True, out_rmsnorm=True)
+    gen_wan_variant("mhla_nope", "MHLA_Video_Nope", seed=42, B=1, heads=2, dim_head=32, layout=(2, 3, 2), grid=(4, 6, 8),
+                    normalize_out=False, out_rmsnorm=False)
+    gen_wan_variant("gated_mhla", "Gated_MHLA_Video", seed=43, B=2, heads=2, dim_head=32, layout=(1, 2, 3), grid=(3, 4, 9),
+                    normalize_out=True, out_rmsnorm=False)
+    gen_wan_variant("mhla_lepe", "MHLA_Video_LePE", seed=44, B=1, heads=2, dim_head=32, layout=(2, 2, 3), grid=(4, 6, 9),
+                    normalize_out=True, out_rmsnorm=True)
+    gen_wan_variant("gated_mhla_lepe", "Gated_MHLA_Video_LePE", seed=45, B=1, heads=2, dim_head=32, layout=(2, 2, 3), grid=(4, 6, 9),
+                    normalize_out=False, out_rmsnorm=False)
     gen_causal("a", seed=31, B=2, T=256, H=2, K=16, V=24, L=32)
     gen_causal("b", seed=32, B=1, T=200, H=2, K=32, V=16, L=32, random_mix=True)
     gen_causal("c", seed=33, B=2, T=50, H=1, K=16, V=16, L=32)

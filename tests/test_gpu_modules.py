@@ -104,6 +104,30 @@ def test_wan_module_fused_inference_path(tag):
     check("fused vs unfused", y, y2.detach().cpu(), 1e-4)
 
 
+@pytest.mark.parametrize("kind", ["mhla", "mhla_nope", "gated_mhla", "mhla_lepe", "gated_mhla_lepe"])
+def test_older_wan_variants_match_reference(kind):
+    """the five older Wan MHLA classes behind the registry keys of wan/model.py:1592-1605 -- strict load of the
+    reference class's state dict, module output (training and no_grad paths), d<y, dY>/dx and every parameter gradient against the
+    reference class's own autograd."""
+    from mhla_amd import modules
+    g = load_golden("wanv_" + kind)
+    B, H, D, fb, hb, wb, F_, H_, W_, normalize, out_rms = [int(x) for x in g["meta"]]
+    cls = modules.WAN_SELFATTENTION_CLASSES[kind]
+    m = cls(H * D, num_heads=H, block_layout=(fb, hb, wb), normalize_out=bool(normalize), out_rmsnorm=bool(out_rms))
+    m.load_state_dict(_sd(g), strict=True)
+    m = m.to(DEV).eval()
+    N = F_ * H_ * W_
+    args = (torch.tensor([N] * B), torch.tensor([[F_, H_, W_]] * B, dtype=torch.long), modules.wan_freqs(D))
+    with torch.no_grad():
+        y_inf = m(g["x"].to(DEV), *args)
+    check("y (no_grad path)", y_inf, g["y"], 1e-4)
+    x = g["x"].to(DEV).requires_grad_(True)
+    poison()
+    y = m(x, *args)
+    check("y", y, g["y"], 1e-4)
+    _check_module_grads(m, x, y, g, 2e-4)
+
+
 def test_wan_module_with_lepe_matches_reference():
     """is_lepe=True (wan/mhla_utils.py:226-231, 283-285, 363-364): the Conv3d branch runs on the HIP 3-D LePE kernels; module
     output and d(sum y)/dx against the reference fixture, training and fused inference paths."""

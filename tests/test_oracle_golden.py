@@ -92,6 +92,22 @@ def test_wan_op_module_and_grads(tag):
     assert rel_err(y, g["y"]) < TOL
 
 
+@pytest.mark.parametrize("kind", ["mhla", "mhla_nope", "gated_mhla", "mhla_lepe", "gated_mhla_lepe"])
+def test_older_wan_variants_module_and_grads(kind):
+    """The oracle's restatement of the five older Wan classes vs the reference classes' own outputs and autograd gradients
+    (fixtures made by AST-extracting each class from wan/model.py: tests/golden/make_golden.py section 2b)."""
+    g = load_golden("wanv_" + kind)
+    B, H, D, fb, hb, wb, F_, H_, W_, normalize, _ = [int(x) for x in g["meta"]]
+    sd = {k[3:]: v.clone().requires_grad_(True) for k, v in g.items() if k.startswith("sd.")}
+    x = g["x"].clone().requires_grad_(True)
+    y = orc.wan_variant_forward(kind, sd, x, (F_, H_, W_), orc.wan_freqs(D), H, (fb, hb, wb), 1e-6, bool(normalize))
+    assert rel_err(y.detach(), g["y"]) < TOL
+    (y * g["dY"]).sum().backward()
+    assert rel_err(x.grad, g["dx_mod"]) < 5e-5
+    for name, ref in ((k[4:], v) for k, v in g.items() if k.startswith("gsd.")):
+        assert rel_err(sd[name].grad.reshape(ref.shape), ref) < 5e-5, name
+
+
 @pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
 def test_causal_op_and_grads(tag):
     g = load_golden("causal_" + tag)
