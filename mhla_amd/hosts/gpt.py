@@ -1,8 +1,9 @@
 """A minimal GPT-style host around the fla `MHLA` drop-in: token embedding, pre-norm blocks of
 [RMSNorm -> MHLA layer -> residual -> RMSNorm -> gated MLP -> residual], final norm and a tied-free LM head -- the shape of the
 reference's GLA-family language model (mhla_nlp/fla/models/gla/modeling_gla.py:83-100 builds the attention the same way).
-Plumbing for step-level numbers; stock PyTorch besides the attention layer.  The layer's mixing matrix has 32 chunks
-(layers/mhla.py:196-200), i.e. sequences up to 2048 tokens at chunk 64."""
+Plumbing for step-level numbers; stock PyTorch besides the attention layer.  The reference layer's mixing matrix has 32 chunks
+(layers/mhla.py:196-200: 2048 tokens at chunk 64); `max_seq_len` sizes it for longer sequences (8192 -> 128 chunks, the
+BASELINE.json configs[4] sequence length, through the drop-in layer's `max_chunks`)."""
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -34,11 +35,11 @@ class GatedMLP(nn.Module):
 
 
 class Block(nn.Module):
-    def __init__(self, dim, heads, expand_k, expand_v, layer_idx):
+    def __init__(self, dim, heads, expand_k, expand_v, layer_idx, max_chunks=32):
         super().__init__()
         self.attn_norm = RMSNorm(dim)
         self.attn = MHLA(mode="chunk", hidden_size=dim, expand_k=expand_k, expand_v=expand_v, num_heads=heads,
-                         feature_map="relu", layer_idx=layer_idx)
+                         feature_map="relu", layer_idx=layer_idx, max_chunks=max_chunks)
         self.mlp_norm = RMSNorm(dim)
         self.mlp = GatedMLP(dim)
 
@@ -48,10 +49,12 @@ class Block(nn.Module):
 
 
 class GPT_MHLA(nn.Module):
-    def __init__(self, vocab_size=32000, hidden_size=1024, num_layers=24, num_heads=4, expand_k=0.5, expand_v=1.0):
+    def __init__(self, vocab_size=32000, hidden_size=1024, num_layers=24, num_heads=4, expand_k=0.5, expand_v=1.0,
+                 max_seq_len=2048):
         super().__init__()
         self.embeddings = nn.Embedding(vocab_size, hidden_size)
-        self.layers = nn.ModuleList([Block(hidden_size, num_heads, expand_k, expand_v, i) for i in range(num_layers)])
+        max_chunks = max(32, (max_seq_len + 63) // 64)     # 32 = the reference layer's matrix; 128 for seq_len 8192 (config 5)
+        self.layers = nn.ModuleList([Block(hidden_size, num_heads, expand_k, expand_v, i, max_chunks) for i in range(num_layers)])
         self.norm = RMSNorm(hidden_size)
         self.lm_head = nn.Linear(hidden_size, vocab_size, bias=False)
         for m in self.modules():

@@ -2,7 +2,7 @@
 
 Same constructor, `forward(hidden_states, attention_mask, past_key_values, use_cache,
 output_attentions, **kw) -> (o, None, past_key_values)` and parameter names
-(`q_proj/k_proj/v_proj/g_proj/o_proj.weight`, `mixing_matrix [32,32,1,1,1,1]`,
+(`q_proj/k_proj/v_proj/g_proj/o_proj.weight`, `mixing_matrix [32,32,1,1,1,1]` (side = `max_chunks`),
 `g_norm_swish_gate.weight`).  The causal operator and the per-head RMSNorm x swish gate run as HIP
 kernels; rotary is plain tensor math (NeoX half rotation, rotary.py:20-32) -- no Triton.
 
@@ -17,7 +17,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from ..ops import featmap_rotary, mhla_causal, rmsnorm_gate
+from ..ops import featmap_rotary, mhla_causal, naive_recurrent_mhla, rmsnorm_gate
 from ..weights import causal_mixing_init
 
 
@@ -84,7 +84,10 @@ class MHLA(nn.Module):
                  use_short_conv: bool = False, conv_size: int = 4, conv_bias: bool = False,
                  use_output_gate: bool = True, gate_fn: str = "swish", elementwise_affine: Optional[bool] = True,
                  norm_eps: float = 1e-5, gate_logit_normalizer: int = 16, gate_low_rank_dim: int = 16,
-                 clamp_min: Optional[float] = None, fuse_norm: bool = True, layer_idx: int = None):
+                 clamp_min: Optional[float] = None, fuse_norm: bool = True, layer_idx: int = None, max_chunks: int = 32):
+        """`max_chunks` (not in the reference, default = its hard-coded 32): side of the mixing matrix, i.e. the longest
+        sequence is 64 * max_chunks tokens -- 128 for the 8192-token configuration of BASELINE.json configs[4], which the
+        reference layer itself cannot run (layers/mhla.py:196-200); the operator accepts any [n, n] matrix (naive.py:55)."""
         super().__init__()
         self.mode = mode
         self.hidden_size = hidden_size
@@ -124,7 +127,8 @@ class MHLA(nn.Module):
         self.v_proj = nn.Linear(hidden_size, self.value_dim_per_group, bias=False)
         if self.use_output_gate:
             self.g_proj = nn.Linear(hidden_size, self.value_dim, bias=False)
-        self.mixing_matrix = nn.Parameter(causal_mixing_init(32))           # layers/mhla.py:196-200
+        self.max_chunks = int(max_chunks)
+        self.mixing_matrix = nn.Parameter(causal_mixing_init(self.max_chunks))   # layers/mhla.py:196-200 (32 there)
         self.o_proj = nn.Linear(self.value_dim, hidden_size, bias=False)
         self.fuse_norm_and_gate = gate_fn == "swish" and fuse_norm and use_output_gate
         if self.fuse_norm_and_gate:
@@ -147,31 +151,55 @@ class MHLA(nn.Module):
                 "Expected attention_mask as a 0-1 matrix with shape [batch_size, seq_len] for padding purposes "
                 "(0 indicating padding). Arbitrary attention masks of shape [batch_size, seq_len, seq_len] are not allowed.")
         batch_size, q_len, _ = hidden_states.shape
+        last_state = None
+        if past_key_values is not None and self.layer_idx is not None and len(past_key_values) > self.layer_idx:
+            last_state = past_key_values[self.layer_idx]                      # :249-251
         indices = None
-        if attention_mask is not None:                                       # layers/mhla.py:253-256
-            indices = torch.nonzero(attention_mask[:, -q_len:].flatten(), as_tuple=False).flatten()
+        cu_seqlens = kwargs.get("cu_seqlens", None)
+        if attention_mask is not None:                                       # layers/mhla.py:253-256 (get_unpad_data)
+            m = attention_mask[:, -q_len:]
+            indices = torch.nonzero(m.flatten(), as_tuple=False).flatten()
+            cu_seqlens = F.pad(m.sum(-1, dtype=torch.int32).cumsum(0, dtype=torch.int32), (1, 0))
             hidden_states = hidden_states.reshape(batch_size * q_len, -1).index_select(0, indices).unsqueeze(0)
         B, T, _ = hidden_states.shape
         q = self.q_proj(hidden_states).reshape(B, T, self.num_heads, self.head_k_dim)
         k = self.k_proj(hidden_states)
         v = self.v_proj(hidden_states)
-        if self.num_kv_groups > 1:                                           # :290-292
+        if self.num_kv_groups > 1:                                           # :290-292 (repeat '(h g) d')
             k = k.reshape(B, T, self.num_kv_heads, 1, self.head_k_dim).expand(-1, -1, -1, self.num_kv_groups, -1)
             v = v.reshape(B, T, self.num_kv_heads, 1, self.head_v_dim).expand(-1, -1, -1, self.num_kv_groups, -1)
         k = k.reshape(B, T, self.num_heads, self.head_k_dim)
         v = v.reshape(B, T, self.num_heads, self.head_v_dim)
         seqlen_offset = 0
         if past_key_values is not None and hasattr(past_key_values, "get_seq_length"):
-            seqlen_offset = past_key_values.get_seq_length(self.layer_idx)
+            seqlen_offset = past_key_values.get_seq_length(self.layer_idx)    # :301-303
         if self.head_k_dim % 8 == 0:
             # feature map (:297-299) + rotary (:311) in one HIP kernel per tensor and direction
-            cos, sin = self.rotary._tables(T + seqlen_offset, q.device, q.dtype)
-            q = featmap_rotary(q, cos, sin, self._fmap_name, seqlen_offset)
-            k = featmap_rotary(k, cos, sin, self._fmap_name, seqlen_offset)
+            if cu_seqlens is not None:
+                # packed sequences: positions restart at every sequence start, as the reference's rotary does with cu_seqlens
+                # (rotary.py:68-72) -- per-token rows of the tables, gathered once
+                tpos = torch.arange(T, device=q.device)
+                cu = cu_seqlens.to(q.device).long()
+                pos = tpos - cu[torch.searchsorted(cu, tpos, right=True) - 1] + seqlen_offset
+                cos, sin = self.rotary._tables(int(pos.max().item()) + 1, q.device, q.dtype)
+                cos, sin, t_off = cos.index_select(0, pos), sin.index_select(0, pos), 0
+            else:
+                cos, sin = self.rotary._tables(T + seqlen_offset, q.device, q.dtype)
+                t_off = seqlen_offset
+            q = featmap_rotary(q, cos, sin, self._fmap_name, t_off)
+            k = featmap_rotary(k, cos, sin, self._fmap_name, t_off)
         else:
             q, k = self.feature_map_q(q), self.feature_map_k(k)              # :297-299
             q, k = self.rotary(q, k, seqlen_offset=seqlen_offset)            # :311
-        o = mhla_causal(q, k, v, self.mixing_matrix)                         # :318-337 (T <= 64: single chunk)
+        recurrent_state = last_state["recurrent_state"] if last_state is not None else None
+        if q_len <= 64:                                                      # :247, :318-327: the token-recurrent form
+            o, recurrent_state = naive_recurrent_mhla(q, k, v, self.mixing_matrix, initial_state=recurrent_state,
+                                                      output_final_state=bool(use_cache))
+        else:                                                                # :330-337
+            o = mhla_causal(q, k, v, self.mixing_matrix)
+            recurrent_state = None
+        if past_key_values is not None and hasattr(past_key_values, "update"):   # :339-345
+            past_key_values.update(recurrent_state=recurrent_state, conv_state=None, layer_idx=self.layer_idx, offset=q_len)
         if self.use_output_gate:
             g = self.g_proj(hidden_states)
             if self.fuse_norm_and_gate:

@@ -361,15 +361,17 @@ def wan_rope_apply(x: torch.Tensor, grid: Tuple[int, int, int], freqs: torch.Ten
     return y.float()
 
 
-def neox_rotary(x: torch.Tensor, base: float = 10000.0, offset: int = 0) -> torch.Tensor:
+def neox_rotary(x: torch.Tensor, base: float = 10000.0, offset: int = 0, positions: Optional[torch.Tensor] = None) -> torch.Tensor:
     """NeoX half-rotation rotary, non-interleaved -- ``rotary_embedding_ref``
     (``mhla_nlp/fla/modules/rotary.py:20-32``) with the cos/sin table of
     ``RotaryEmbedding._update_cos_sin_cache`` (``rotary.py:415-431``): fp32
     ``inv_freq = base^(-2i/D)``, ``freqs = outer(t, inv_freq)``, cos/sin cast to
-    the dtype of ``x``.  ``x: [B, T, H, D]``."""
+    the dtype of ``x``.  ``x: [B, T, H, D]``.  ``positions`` ([T] integer) replaces ``offset + arange(T)``: the per-token
+    positions of a packed (varlen) batch, which restart at every sequence start when ``cu_seqlens`` is given
+    (``rotary.py:68-72``)."""
     B, T, H, D = x.shape
     inv_freq = 1.0 / (base ** (torch.arange(0, D, 2, dtype=torch.float32) / D))
-    t = torch.arange(offset, offset + T, dtype=torch.float32)
+    t = torch.arange(offset, offset + T, dtype=torch.float32) if positions is None else positions.to(torch.float32)
     fr = torch.outer(t, inv_freq)
     cos = torch.cos(fr).to(x.dtype)[None, :, None, :]
     sin = torch.sin(fr).to(x.dtype)[None, :, None, :]
@@ -502,9 +504,25 @@ def wan_variant_forward(kind: str, sd: dict, x: torch.Tensor, grid: Tuple[int, i
 
 
 def fla_layer_forward(sd: dict, x: torch.Tensor, heads: int, head_k: int, head_v: int,
-                      norm_eps: float = 1e-5, chunk_size: int = 64) -> torch.Tensor:
+                      norm_eps: float = 1e-5, chunk_size: int = 64, attention_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``MHLA.forward`` (fla layer, ``feature_map='relu'``, fused swish gate, no
-    short conv, no cache) -- ``mhla_nlp/fla/layers/mhla.py:226-365``."""
+    short conv, no cache) -- ``mhla_nlp/fla/layers/mhla.py:226-365``.  With a 0/1 ``attention_mask`` [B, T] the batch is
+    unpadded into ONE packed sequence (:253-256), rotary positions restart per sequence (cu_seqlens, :311), the operator runs
+    over the whole packed sequence (it ignores cu_seqlens: cross-sequence leakage, as in the reference, :330-336) and the
+    result is padded back with zeros (:362-363)."""
+    if attention_mask is not None:
+        Bm, Tm, C = x.shape
+        keep = attention_mask.flatten().nonzero().flatten()
+        lens = attention_mask.sum(-1)
+        pos = torch.cat([torch.arange(int(n)) for n in lens])
+        y = _fla_layer_core(sd, x.reshape(Bm * Tm, C)[keep].unsqueeze(0), heads, head_k, head_v, norm_eps, chunk_size, pos)
+        out = y.new_zeros(Bm * Tm, y.shape[-1])
+        out[keep] = y.squeeze(0)
+        return out.reshape(Bm, Tm, -1)
+    return _fla_layer_core(sd, x, heads, head_k, head_v, norm_eps, chunk_size, None)
+
+
+def _fla_layer_core(sd, x, heads, head_k, head_v, norm_eps, chunk_size, positions):
     B, T, C = x.shape
     # :237 -- clamp(...).tril() on the [L, L, 1, 1, 1, 1] parameter: tril acts on the trailing 1x1 dims, a no-op;
     # the op reads only j <= i anyway
@@ -513,7 +531,7 @@ def fla_layer_forward(sd: dict, x: torch.Tensor, heads: int, head_k: int, head_v
     k = F.linear(x, sd["k_proj.weight"]).reshape(B, T, heads, head_k)
     v = F.linear(x, sd["v_proj.weight"]).reshape(B, T, heads, head_v)
     q, k = torch.relu(q), torch.relu(k)                                            # :297-299
-    q, k = neox_rotary(q), neox_rotary(k)                                          # :311
+    q, k = neox_rotary(q, positions=positions), neox_rotary(k, positions=positions)   # :311
     o = causal_fwd(q, k, v, mix, chunk_size)                                       # :330-336
     g = F.linear(x, sd["g_proj.weight"]).reshape(B, T, heads, head_v)             # :351-352
     o = rms_norm_swish_gate(o, g, sd["g_norm_swish_gate.weight"], norm_eps)        # :353

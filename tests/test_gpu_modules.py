@@ -394,6 +394,40 @@ def test_fla_layer_matches_oracle_restatement():
     mask[1, 150:] = 0
     o3, _, _ = m(xd, attention_mask=mask.to(DEV))
     assert o3.shape == o.shape and torch.all(o3[1, 150:] == 0)
+    # padded batch: one packed sequence, rotary positions restarting per sequence (cu_seqlens), operator over the packed tokens
+    want3 = orc.fla_layer_forward(sd, x, 2, 64, 128, norm_eps=1e-6, attention_mask=mask)
+    check("o_padded", o3, want3, 1e-4)
+    # cache protocol (:339-345): the layer reports its tokens to the cache and hands the recurrent state over for T <= 64
+
+    class Cache:
+        def __init__(self):
+            self.seen, self.states = 0, []
+
+        def __len__(self):
+            return len(self.states)
+
+        def __getitem__(self, i):
+            return self.states[i]
+
+        def get_seq_length(self, layer_idx=0):
+            return self.seen
+
+        def update(self, recurrent_state=None, conv_state=None, layer_idx=0, offset=1):
+            self.states = [dict(recurrent_state=recurrent_state, conv_state=conv_state)]
+            self.seen += offset
+
+    m.layer_idx = 0
+    cache = Cache()
+    o4, _, c4 = m(xd[:, :40], past_key_values=cache, use_cache=True)
+    assert c4 is cache and cache.seen == 40 and cache.states[0]["recurrent_state"].shape == (2, 2, 64, 128)
+    check("o_cached_first_call", o4, orc.fla_layer_forward(sd, x[:, :40], 2, 64, 128, norm_eps=1e-6), 1e-4)
+    # longer sequences than the reference's 32-chunk matrix allows: the max_chunks knob (8192 tokens = 128 chunks)
+    m128 = modules.MHLA(mode="chunk", hidden_size=128, expand_k=0.5, expand_v=1.0, num_heads=2, feature_map="relu", max_chunks=128).to(DEV)
+    assert m128.mixing_matrix.shape == (128, 128, 1, 1, 1, 1)
+    xl = torch.randn(1, 8192, 128, device=DEV)
+    ol, _, _ = m128(xl)
+    sdl = {k: v.detach().cpu() for k, v in m128.state_dict().items()}
+    check("o_8192", ol, orc.fla_layer_forward(sdl, xl.cpu(), 2, 32, 64, norm_eps=1e-5), 1e-4)
 
 
 def test_thin_dit_host_matches_cpu_composition():

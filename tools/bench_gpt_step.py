@@ -5,7 +5,8 @@ the minimal in-repo host (mhla_amd.hosts.GPT_MHLA) around the fla MHLA drop-in, 
   python tools/bench_gpt_step.py [--model 340M] [--batch 8] [--seq 2048] [--steps 5] [--warmup 2]
   python -m torch.distributed.run --nproc-per-node N ... tools/bench_gpt_step.py          (DDP over RCCL)
 
-The layer's mixing matrix has 32 chunks of 64 tokens: seq <= 2048.  Informational; one JSON line on rank 0."""
+`--seq 8192` is the BASELINE.json configs[4] sequence length (the host sizes the layer's mixing matrix: 128 chunks of 64).
+`--gpus N` starts N ranks itself (before any GPU call).  Informational; one JSON line on rank 0."""
 import argparse
 import json
 import os
@@ -25,13 +26,17 @@ def main():
     p.add_argument("--seq", type=int, default=2048)
     p.add_argument("--steps", type=int, default=5)
     p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--gpus", type=int, default=1, help="ranks to start when not launched by torch.distributed.run")
     a = p.parse_args()
+    if a.gpus > 1 and not mdist.launched_by_rendezvous():
+        extra = {"MHLA_DIST_BACKEND": "gloo"} if torch.cuda.device_count() < a.gpus else {}
+        sys.exit(mdist.spawn_local_ranks(a.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:], extra))
     rank, local, world = mdist.init_from_env()
     local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     torch.manual_seed(1234 + rank)
-    model = GPT_MHLA(**GPT_configs()[a.model]).to(dev)
+    model = GPT_MHLA(**GPT_configs()[a.model], max_seq_len=a.seq).to(dev)
     net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local]) if world > 1 else model
     opt = torch.optim.AdamW(net.parameters(), lr=1e-4)
     ids = torch.randint(0, 32000, (a.batch, a.seq), device=dev)
