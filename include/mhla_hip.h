@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MHLA_ABI_VERSION 4
+#define MHLA_ABI_VERSION 5
 
 enum { MHLA_F32 = 0, MHLA_BF16 = 1, MHLA_F16 = 2 };
 
@@ -175,6 +175,18 @@ int mhla_causal_fwd(mhla_view q, mhla_view k, mhla_view v, const float* mix, int
                     mhla_mview out, void* ws, size_t ws_bytes,
                     int B, int T, int H, int K, int V, int chunk,
                     float scale, int dtype, void* stream);
+
+/* N1: the causal operator with the fla layer's epilogue fused into its store --
+ *   y = o * rsqrt(mean(o^2 over V) + norm_eps) * norm_w * gate * sigmoid(gate)
+ * i.e. FusedRMSNormGated over each head's V channels (mhla_nlp/fla/layers/mhla.py:351-355; kernel math
+ * mhla_nlp/fla/modules/fused_norm_gate.py:77-99).  `out` (the operator's own output o) is optional: a NULL ptr skips its
+ * store (inference); training passes it so that the norm's backward (mhla_rmsnorm_gate_bwd) has its input.  `gate` ptr NULL:
+ * no gate; `norm_w` NULL: no affine weight.  bf16 tensors, K % 64 == 0, V % 64 == 0, V <= 256 (one workgroup owns a head's
+ * channels); otherwise MHLA_ENOTSUP and the caller runs mhla_causal_fwd + mhla_rmsnorm_gate_fwd.  Workspace: as
+ * mhla_causal_fwd (usable as `fwd_ws` of mhla_causal_bwd). */
+int mhla_causal_normgate_fwd(mhla_view q, mhla_view k, mhla_view v, const float* mix, int ldmix, mhla_mview out, mhla_view gate,
+                             const float* norm_w, float norm_eps, mhla_mview y, void* ws, size_t ws_bytes, int B, int T, int H,
+                             int K, int V, int chunk, float scale, int dtype, void* stream);
 
 /* Backward.  dmix is [n, n] fp32 with row stride lddmix;
  * only the lower triangle (incl. diagonal) of the leading n x n is written.

@@ -8,7 +8,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # MHLA_LIB_PATH: A/B comparison of two builds of the same library (tools); the default is the in-tree build
 LIB_PATH = os.environ.get("MHLA_LIB_PATH") or os.path.join(_HERE, "lib", "libmhla_hip.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 F32, BF16, F16 = 0, 1, 2
 FLAG_RELU_EPS = 1
 FLAG_FORCE_GENERIC = 2
@@ -47,6 +47,8 @@ SIGNATURES = {
     "mhla_causal_bwd_ws_bytes": (c_size_t, [c_int] * 7),
     "mhla_causal_fwd": (c_int, [View, View, View, c_void_p, c_int, View, c_void_p, c_size_t, c_int, c_int, c_int,
                                 c_int, c_int, c_int, c_float, c_int, c_void_p]),
+    "mhla_causal_normgate_fwd": (c_int, [View, View, View, c_void_p, c_int, View, View, c_void_p, c_float, View, c_void_p,
+                                         c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "mhla_causal_bwd": (c_int, [View, View, View, c_void_p, c_int, View, View, View, View, c_void_p, c_int, c_void_p,
                                 c_size_t, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "mhla_featmap_rotary": (c_int, [View, View, c_void_p, c_void_p, c_int64, c_int64, View, c_int, c_int, c_int, c_int, c_int,

@@ -2,6 +2,7 @@
 // workspace, picks template instantiations and enqueues kernels on the caller's stream.
 #include "../../include/mhla_hip.h"
 
+#include <algorithm>
 #include <atomic>
 #include <cstdarg>
 #include <cstdio>
@@ -182,6 +183,8 @@ bool view_ok16(const mhla_view& v) { return v.ptr && ((uintptr_t)v.ptr % 16) == 
 bool sp_shape_ok(int D, unsigned flags) { return (D & 7) == 0 && !(flags & MHLA_FLAG_FORCE_GENERIC); }
 bool view_ok16m(const mhla_mview& v) { return v.ptr && ((uintptr_t)v.ptr % 16) == 0 && ((v.sb | v.sn | v.sh) & 7) == 0; }
 // bf16-MFMA token kernels of the causal operator (causal_bf16.hpp)
+// MHLA_CAUSAL_GENERIC is a testing aid that the parity tests flip inside one process (bf16 pipeline vs generic kernels on the
+// same inputs), so it is looked up per call: one scan of the environment per operator call, beside five or more launches
 bool cs_bf16_ok(int K, int V, int dtype) { return dtype == MHLA_BF16 && (K & 63) == 0 && (V & 63) == 0 && !getenv("MHLA_CAUSAL_GENERIC"); }
 bool bm_sum16(int D, int dtype, unsigned flags) { return dtype == MHLA_BF16 && sp_shape_ok(D, flags); }
 bool fast_shape_ok(int M, int D, int dtype, bool split) { return dtype == MHLA_BF16 && D == 64 && M <= 64 && !split; }
@@ -342,13 +345,17 @@ int mhla_blockmix_fwd_keeps_state(int B, int H, int M, int S, int D, int dtype, 
 }
 
 // Upper bound over the paths the library may take for this problem (the fast path needs less).
+// (the fast path needs less than the split-operand path, but which one runs also depends on the alignment of the views, which
+// these queries do not see: the bound covers both)
 size_t mhla_blockmix_fwd_ws_bytes(int B, int H, int M, int S, int D, int dtype, int split, unsigned flags) {
-    if (fast_shape_ok(M, D, dtype, split != 0) && !(flags & MHLA_FLAG_FORCE_GENERIC)) return fast_carve(nullptr, B, H, M, S).total_fwd;
-    return bm_carve(nullptr, B, H, M, S, D, bm_sum16(D, dtype, flags)).total_fwd;
+    const size_t gen = bm_carve(nullptr, B, H, M, S, D, bm_sum16(D, dtype, flags)).total_fwd;
+    if (fast_shape_ok(M, D, dtype, split != 0) && !(flags & MHLA_FLAG_FORCE_GENERIC)) return std::max(gen, fast_carve(nullptr, B, H, M, S).total_fwd);
+    return gen;
 }
 size_t mhla_blockmix_bwd_ws_bytes(int B, int H, int M, int S, int D, int dtype, int split, unsigned flags) {
-    if (fast_shape_ok(M, D, dtype, split != 0) && !(flags & MHLA_FLAG_FORCE_GENERIC)) return fast_carve(nullptr, B, H, M, S).total_bwd;
-    return bm_carve(nullptr, B, H, M, S, D, bm_sum16(D, dtype, flags)).total_bwd;
+    const size_t gen = bm_carve(nullptr, B, H, M, S, D, bm_sum16(D, dtype, flags)).total_bwd;
+    if (fast_shape_ok(M, D, dtype, split != 0) && !(flags & MHLA_FLAG_FORCE_GENERIC)) return std::max(gen, fast_carve(nullptr, B, H, M, S).total_bwd);
+    return gen;
 }
 
 static int bm_fwd_impl(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q_den, mhla_view k_den, const float* W,
@@ -622,14 +629,24 @@ size_t mhla_causal_bwd_ws_bytes(int B, int T, int H, int K, int V, int chunk, in
     return cs_carve(nullptr, B, T, H, K, V, chunk, cs_bf16_ok(K, V, dtype) ? 2 : 4).total_bwd;
 }
 
-int mhla_causal_fwd(mhla_view q, mhla_view k, mhla_view v, const float* mix, int ldmix, mhla_mview out, void* ws,
-                    size_t ws_bytes, int B, int T, int H, int K, int V, int chunk, float scale, int dtype, void* stream) {
+static int cs_fwd_impl(mhla_view q, mhla_view k, mhla_view v, const float* mix, int ldmix, mhla_mview out, void* ws,
+                       size_t ws_bytes, int B, int T, int H, int K, int V, int chunk, float scale, int dtype, void* stream,
+                       bool epi, const float* nw, float neps, mhla_view gate, mhla_mview y) {
     RC(cs_check(B, T, H, K, V, chunk, dtype));
-    CHECK_VIEW(q); CHECK_VIEW(k); CHECK_VIEW(v); CHECK_VIEW(out);
+    CHECK_VIEW(q); CHECK_VIEW(k); CHECK_VIEW(v);
+    if (!epi || out.ptr) CHECK_VIEW(out);
+    if (epi) {
+        if (!cs_bf16_ok(K, V, dtype) || V > 64 * fast::CSF_OUT_VS)
+            return fail(MHLA_ENOTSUP, "fused norm x gate epilogue needs bf16 tensors, K %% 64 == 0 and V %% 64 == 0, V <= %d (K=%d V=%d dtype=%d)",
+                        64 * fast::CSF_OUT_VS, K, V, dtype);
+        const mhla_view yv{y.ptr, y.sb, y.sn, y.sh};
+        if (!view_ok16(yv) || (gate.ptr && !view_ok16(gate)) || (out.ptr && !view_ok16m(out)))
+            return fail(MHLA_EINVAL, "fused norm x gate epilogue: y, gate and out must be 16-byte aligned views (strides multiples of 8)");
+    }
     const int n = (T + chunk - 1) / chunk;
     if (!mix || ldmix < n) return fail(MHLA_EINVAL, "mix null or ldmix=%d < n=%d chunks (T=%d)", ldmix, n, T);
     const bool pipe16 = cs_bf16_ok(K, V, dtype);
-    if (pipe16 && !(view_ok16(q) && view_ok16(k) && view_ok16(v) && view_ok16m(out)))
+    if (pipe16 && !(view_ok16(q) && view_ok16(k) && view_ok16(v) && (epi || view_ok16m(out))))
         return fail(MHLA_EINVAL, "bf16 tensors with K, V multiples of 64 must be 16-byte aligned views (strides multiples of 8)");
     const CsWs w = cs_carve(ws, B, T, H, K, V, chunk, pipe16 ? 2 : 4);
     if (!ws || ws_bytes < w.total_fwd) return fail(MHLA_EINVAL, "workspace too small: %zu < %zu bytes", ws_bytes, w.total_fwd);
@@ -642,8 +659,9 @@ int mhla_causal_fwd(mhla_view q, mhla_view k, mhla_view v, const float* mix, int
         RC(launch(fast::k_csf_state, dim3(n, B * H, K / 64), dim3(NTHREADS), fast::CSF_STATE_SMEM, st, "k_csf_state", s));
         fast::CsfMixArgs m{mix, ldmix, (const uint16_t*)w.S, (uint16_t*)w.P, n, E};
         RC(launch(fast::k_csf_mix<0>, dim3((unsigned)(E / fast::MX_TE), (n + 63) / 64, B * H), dim3(NTHREADS), fast::CSF_MIX_SMEM, st, "k_csf_mix<0>", m));
-        CsOutArgs o{cv(q), cv(k), cv(v), cmv(out), mix, ldmix, w.P, H, n, K, V, (long)T, scale};
-        RC(launch(fast::k_csf_out<uint16_t>, dim3(n, B * H, (V / 64 + fast::CSF_OUT_VS - 1) / fast::CSF_OUT_VS), dim3(NTHREADS), fast::CSF_OUT_SMEM, st, "k_csf_out", o));
+        CsOutArgs o{cv(q), cv(k), cv(v), cmv(out), mix, ldmix, w.P, H, n, K, V, (long)T, scale, cmv(y), cv(gate), nw, neps};
+        if (epi) RC(launch(fast::k_csf_out<uint16_t, true>, dim3(n, B * H, 1), dim3(NTHREADS), fast::CSF_OUT_SMEM, st, "k_csf_out<norm>", o));
+        else     RC(launch(fast::k_csf_out<uint16_t>, dim3(n, B * H, (V / 64 + fast::CSF_OUT_VS - 1) / fast::CSF_OUT_VS), dim3(NTHREADS), fast::CSF_OUT_SMEM, st, "k_csf_out", o));
         return MHLA_OK;
     }
     DISPATCH_T(dtype, {
@@ -651,10 +669,23 @@ int mhla_causal_fwd(mhla_view q, mhla_view k, mhla_view v, const float* mix, int
         MixArgs m{mix, ldmix, w.S, w.P, n, E};
         dim3 mgrid((unsigned)((m.E + MIX_TE - 1) / MIX_TE), (n + MIX_TI - 1) / MIX_TI, B * H);
         RC(launch(k_mix<0, 1>, mgrid, dim3(NTHREADS), MIX_SMEM_FLOATS * 4, st, "k_mix<0,1>", m));
-        CsOutArgs o{cv(q), cv(k), cv(v), cmv(out), mix, ldmix, w.P, H, n, K, V, (long)T, scale};
+        CsOutArgs o{cv(q), cv(k), cv(v), cmv(out), mix, ldmix, w.P, H, n, K, V, (long)T, scale, cmv(out), cv(mhla_view{nullptr, 0, 0, 0}), nullptr, 0.f};
         RC(launch(k_cs_out<ET>, dim3(n, B * H, (V + 63) / 64), dim3(NTHREADS), CS_OUT_SMEM_FLOATS * 4, st, "k_cs_out", o));
     });
     return MHLA_OK;
+}
+
+int mhla_causal_fwd(mhla_view q, mhla_view k, mhla_view v, const float* mix, int ldmix, mhla_mview out, void* ws,
+                    size_t ws_bytes, int B, int T, int H, int K, int V, int chunk, float scale, int dtype, void* stream) {
+    return cs_fwd_impl(q, k, v, mix, ldmix, out, ws, ws_bytes, B, T, H, K, V, chunk, scale, dtype, stream, false, nullptr, 0.f,
+                       mhla_view{nullptr, 0, 0, 0}, mhla_mview{nullptr, 0, 0, 0});
+}
+
+int mhla_causal_normgate_fwd(mhla_view q, mhla_view k, mhla_view v, const float* mix, int ldmix, mhla_mview out, mhla_view gate,
+                             const float* norm_w, float norm_eps, mhla_mview y, void* ws, size_t ws_bytes, int B, int T, int H,
+                             int K, int V, int chunk, float scale, int dtype, void* stream) {
+    if (!y.ptr) return fail(MHLA_EINVAL, "y null");
+    return cs_fwd_impl(q, k, v, mix, ldmix, out, ws, ws_bytes, B, T, H, K, V, chunk, scale, dtype, stream, true, norm_w, norm_eps, gate, y);
 }
 
 int mhla_causal_bwd(mhla_view q, mhla_view k, mhla_view v, const float* mix, int ldmix, mhla_view dout, mhla_mview dq,
@@ -693,7 +724,7 @@ int mhla_causal_bwd(mhla_view q, mhla_view k, mhla_view v, const float* mix, int
         fast::CsfMixArgs mt{mix, ldmix, dP, dS, n, E};
         RC(launch(fast::k_csf_mix<1>, mgrid, dim3(NTHREADS), fast::CSF_MIX_SMEM, st, "k_csf_mix<1>", mt));
         CsTokArgs t{cv(q), cv(k), cv(v), cv(dout), cmv(dq), cmv(dk), cmv(dv), mix, ldmix, w.P, w.dS, w.diag, H, n, K, V, (long)T, scale};
-        const char* tokv = getenv("MHLA_CAUSAL_TOK");   // tuning: "2" forces the K-slice-outer kernels
+        static const char* const tokv = getenv("MHLA_CAUSAL_TOK");   // tuning knob, read once: "2" forces the K-slice-outer kernels
         const bool tok3 = !(tokv && tokv[0] == '2');
         if (tok3 && K <= 128)      RC(launch(fast::k_csf_bwd_tok3<uint16_t, 2>, dim3(n, B * H), dim3(NTHREADS), fast::csf_tok3_smem<2>(), st, "k_csf_bwd_tok3", t));
         else if (tok3 && K <= 256) RC(launch(fast::k_csf_bwd_tok3<uint16_t, 4>, dim3(n, B * H), dim3(NTHREADS), fast::csf_tok3_smem<4>(), st, "k_csf_bwd_tok3", t));

@@ -25,6 +25,12 @@ struct CsOutArgs {
     int H, n, K, V;
     long T;
     float scale;
+    // fused epilogue of the fla layer (k_csf_out<ST, true> only; layers/mhla.py:351-355, fused_norm_gate.py:77-99):
+    // y = o * rsqrt(mean(o^2 over V) + neps) * nw * g * sigmoid(g); o itself is stored too when o.ptr is set (training)
+    MView y;
+    View gate;          // ptr null: no gate
+    const float* nw;    // [V] or null
+    float neps;
 };
 constexpr int CS_OUT_SMEM_FLOATS = 3 * CS * CS_LDX + CS * CS_LDK + CS * CS_LDO;
 

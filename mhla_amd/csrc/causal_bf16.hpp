@@ -93,13 +93,45 @@ __device__ __forceinline__ void cs_store_tok(u16* __restrict__ base, long sn, lo
     }
 }
 
+// the same with the swish gate applied on the way out: y = staged * g * sigmoid(g)   (gate rows in the output's token layout)
+__device__ __forceinline__ void cs_store_tok_gate(u16* __restrict__ base, long sn, const u16* __restrict__ gbase, long gsn, long p0,
+                                                  int rv, const u16* __restrict__ Os, int tid) {
+    const int r = tid >> 2, c = (tid & 3) * 16;
+    if (r < rv) {
+        u16* d = base + (p0 + r) * sn + c;
+        uint4 x[2] = {*reinterpret_cast<const uint4*>(Os + r * CLD + c), *reinterpret_cast<const uint4*>(Os + r * CLD + c + 8)};
+        if (gbase) {
+            const u16* gp = gbase + (p0 + r) * gsn + c;
+            const uint4 g[2] = {gld<uint4>(gp), gld<uint4>(gp + 8)};
+#pragma unroll
+            for (int hlf = 0; hlf < 2; ++hlf) {
+                unsigned xw[4] = {x[hlf].x, x[hlf].y, x[hlf].z, x[hlf].w};
+                const unsigned gw[4] = {g[hlf].x, g[hlf].y, g[hlf].z, g[hlf].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float g0 = __uint_as_float(gw[i] << 16), g1 = __uint_as_float(gw[i] & 0xffff0000u);
+                    const float y0 = __uint_as_float(xw[i] << 16) * g0 / (1.f + __expf(-g0));
+                    const float y1 = __uint_as_float(xw[i] & 0xffff0000u) * g1 / (1.f + __expf(-g1));
+                    xw[i] = pack_bf16x2(y0, y1);
+                }
+                x[hlf] = make_uint4(xw[0], xw[1], xw[2], xw[3]);
+            }
+        }
+        *reinterpret_cast<uint4*>(d) = x[0];
+        *reinterpret_cast<uint4*>(d + 8) = x[1];
+    }
+}
+
 constexpr int CSF_OUT_SMEM = 4 * CT * 2;
 
 // O_i = scale (Q_i P_i + m_ii tril(Q_i K_i^T) V_i)      grid (n, bh, ceil(V / 256))
 // A workgroup owns up to four 64-wide V slices of a chunk: Q_i, K_i are staged and tril(Q_i K_i^T) is computed once for all
 // of them (one workgroup per slice re-read Q, K and redid the score tile per slice: 2x the HBM reads of this kernel).
 constexpr int CSF_OUT_VS = 4;
-template <typename ST>   // ST: element type of the chunk summaries (u16 = bf16, float)
+// EPI: the per-head RMSNorm (over the head's V channels) x swish gate of the fla layer applied before the store; needs the
+// workgroup to own every V slice of the head (V <= 256, gridDim.z == 1).  The staged normalised tile carries one bf16 rounding
+// before the gate (the unfused path rounds o to bf16 first, then normalises: same order of error).
+template <typename ST, bool EPI = false>   // ST: element type of the chunk summaries (u16 = bf16, float)
 __global__ __launch_bounds__(NTHREADS) void k_csf_out(const CsOutArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u16* Qs = reinterpret_cast<u16*>(smem_raw);   // Q slice, later the output staging
@@ -147,15 +179,70 @@ __global__ __launch_bounds__(NTHREADS) void k_csf_out(const CsOutArgs a) {
             const int row = wave * 16 + kg * 4 + r, col = tn * 16 + n;
             As[row * CLD + col] = cvt_bf16(col <= row ? mii * accA[tn][r] : 0.f);
         }
+    if constexpr (!EPI) {
 #pragma unroll
-    for (int j = 0; j < CSF_OUT_VS; ++j) {
-        if (j < nv) {
-            cs_stage_tok(Ps, vb + vbase + 64 * j, a.v.sn, p0, rv, tid);
-            __syncthreads();
-            tile_mma<false, true>(accO[j], As, Ps, wave, lane);        // tril(QK^T) V
-            cs_put(Qs, accO[j], a.scale, wave, lane);
-            __syncthreads();
-            cs_store_tok(ob + vbase + 64 * j, a.o.sn, p0, rv, Qs, tid);
+        for (int j = 0; j < CSF_OUT_VS; ++j) {
+            if (j < nv) {
+                cs_stage_tok(Ps, vb + vbase + 64 * j, a.v.sn, p0, rv, tid);
+                __syncthreads();
+                tile_mma<false, true>(accO[j], As, Ps, wave, lane);        // tril(QK^T) V
+                cs_put(Qs, accO[j], a.scale, wave, lane);
+                __syncthreads();
+                cs_store_tok(ob + vbase + 64 * j, a.o.sn, p0, rv, Qs, tid);
+            }
+        }
+    } else {
+        __syncthreads();                                                   // As complete
+#pragma unroll
+        for (int j = 0; j < CSF_OUT_VS; ++j) {
+            if (j < nv) {
+                cs_stage_tok(Ps, vb + vbase + 64 * j, a.v.sn, p0, rv, tid);
+                __syncthreads();
+                tile_mma<false, true>(accO[j], As, Ps, wave, lane);        // tril(QK^T) V
+                __syncthreads();
+            }
+        }
+        // row sums of squares over the head's V channels: lane holds rows 16 wave + 4 kg + r, columns 64 j + 16 tn + n
+        float ss[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < CSF_OUT_VS; ++j)
+            if (j < nv)
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float x = a.scale * accO[j][tn][r];
+                        ss[r] += x * x;
+                    }
+        u16* yb = (u16*)a.y.ptr + b * a.y.sb + h * a.y.sh;
+        const u16* gb = a.gate.ptr ? (const u16*)a.gate.ptr + b * a.gate.sb + h * a.gate.sh : nullptr;
+        float rstd[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float x = ss[r];
+            x += __shfl_xor(x, 1, 64); x += __shfl_xor(x, 2, 64); x += __shfl_xor(x, 4, 64); x += __shfl_xor(x, 8, 64);
+            rstd[r] = rsqrtf(x / (float)a.V + a.neps);
+        }
+#pragma unroll
+        for (int j = 0; j < CSF_OUT_VS; ++j) {
+            if (j < nv) {
+                if (a.o.ptr) {   // training: the operator's own output is kept for the norm's backward
+                    cs_put(Qs, accO[j], a.scale, wave, lane);
+                    __syncthreads();
+                    cs_store_tok(ob + vbase + 64 * j, a.o.sn, p0, rv, Qs, tid);
+                    __syncthreads();
+                }
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn) {
+                    const float w = a.nw ? gld<float>(a.nw + vbase + 64 * j + tn * 16 + n) : 1.f;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) accO[j][tn][r] *= a.scale * rstd[r] * w;
+                }
+                cs_put(Qs, accO[j], 1.f, wave, lane);
+                __syncthreads();
+                cs_store_tok_gate(yb + vbase + 64 * j, a.y.sn, gb ? gb + vbase + 64 * j : nullptr, a.gate.sn, p0, rv, Qs, tid);
+                __syncthreads();
+            }
         }
     }
 }

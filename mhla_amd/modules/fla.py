@@ -17,7 +17,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from ..ops import featmap_rotary, mhla_causal, naive_recurrent_mhla, rmsnorm_gate
+from ..ops import featmap_rotary, mhla_causal, mhla_causal_normgate, naive_recurrent_mhla, rmsnorm_gate
 from ..weights import causal_mixing_init
 
 
@@ -192,7 +192,15 @@ class MHLA(nn.Module):
             q, k = self.feature_map_q(q), self.feature_map_k(k)              # :297-299
             q, k = self.rotary(q, k, seqlen_offset=seqlen_offset)            # :311
         recurrent_state = last_state["recurrent_state"] if last_state is not None else None
-        if q_len <= 64:                                                      # :247, :318-327: the token-recurrent form
+        fused_epilogue = self.use_output_gate and self.fuse_norm_and_gate and q_len > 64
+        if fused_epilogue:
+            # operator + per-head RMSNorm x swish gate (:330-337 + :351-355) as one node: the epilogue runs in the operator's
+            # output kernel where the shape allows, otherwise as the separate HIP kernel (mhla_causal_normgate decides)
+            g = self.g_proj(hidden_states).reshape(B, T, self.num_heads, self.head_v_dim)
+            gn = self.g_norm_swish_gate
+            o = mhla_causal_normgate(q, k, v, self.mixing_matrix, g, gn.weight, gn.eps).reshape(B, T, self.value_dim)
+            recurrent_state = None
+        elif q_len <= 64:                                                    # :247, :318-327: the token-recurrent form
             o, recurrent_state = naive_recurrent_mhla(q, k, v, self.mixing_matrix, initial_state=recurrent_state,
                                                       output_final_state=bool(use_cache))
         else:                                                                # :330-337
@@ -200,7 +208,9 @@ class MHLA(nn.Module):
             recurrent_state = None
         if past_key_values is not None and hasattr(past_key_values, "update"):   # :339-345
             past_key_values.update(recurrent_state=recurrent_state, conv_state=None, layer_idx=self.layer_idx, offset=q_len)
-        if self.use_output_gate:
+        if fused_epilogue:
+            pass
+        elif self.use_output_gate:
             g = self.g_proj(hidden_states)
             if self.fuse_norm_and_gate:
                 o = self.g_norm_swish_gate(o, g.reshape(B, T, self.num_heads, self.head_v_dim))   # :351-355

@@ -14,6 +14,9 @@ import torch
 from . import _lib
 from ._lib import NULL_VIEW, View
 
+# (batch, head) pairs one launch of the library addresses (grid.y); larger batches are sliced by the operators below
+_MAX_GRID_BH = 65535
+
 # forward workspaces up to this size are kept alive for the backward (bf16 block summaries of the fast path)
 KEEP_STATE_LIMIT_BYTES = 1 << 30
 
@@ -220,6 +223,13 @@ def mhla_blockmix(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, W: torch.Te
     _check_block_index(block_index, q.shape[1], q)
     if q.shape[0] == 0:   # empty batch: nothing to launch; keep the autograd graph connected (all gradients are zero)
         return torch.zeros_like(v) + 0 * (q.sum() + k.sum() + W.sum()).to(v.dtype)
+    nb = _MAX_GRID_BH // q.shape[2]
+    if q.shape[0] > nb:
+        # more (batch, head) pairs than one launch addresses (the kernels index them with grid.y <= 65535; the C ABI returns
+        # MHLA_ENOTSUP): batch slices through the same autograd node, the gradient of W accumulates over the slices
+        sl = lambda t, i: None if t is None else t[i:i + nb]
+        return torch.cat([_BlockMix.apply(sl(q, i), sl(k, i), sl(v, i), W, sl(q_den, i), sl(k_den, i), block_index, eps, normalize,
+                                          relu_eps, force_generic, no_smalln) for i in range(0, q.shape[0], nb)], dim=0)
     return _BlockMix.apply(q, k, v, W, q_den, k_den, block_index, eps, normalize, relu_eps, force_generic, no_smalln)
 
 
@@ -718,6 +728,10 @@ def mhla_causal(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mixing_matrix
         scale = q.shape[-1] ** -0.5
     if q.shape[0] == 0 or q.shape[1] == 0:   # empty batch / sequence
         return torch.zeros_like(v) + 0 * (q.sum() + k.sum() + mixing_matrix.sum()).to(v.dtype)
+    nb = _MAX_GRID_BH // q.shape[2]
+    if q.shape[0] > nb:   # see mhla_blockmix
+        return torch.cat([_Causal.apply(q[i:i + nb], k[i:i + nb], v[i:i + nb], mixing_matrix, int(chunk_size), scale)
+                          for i in range(0, q.shape[0], nb)], dim=0)
     return _Causal.apply(q, k, v, mixing_matrix, int(chunk_size), scale)
 
 
@@ -726,6 +740,94 @@ def naive_chunk_simple_mhla_fixed(q, k, v, mixing_matrix, output_final_state: bo
     """Drop-in for the reference op function of the same name (naive.py:11): same arguments,
     returns only `o` (the reference discards the state, naive.py:80)."""
     return mhla_causal(q, k, v, mixing_matrix, chunk_size)
+
+
+class _CausalNormGate(torch.autograd.Function):
+    """Causal operator + per-head RMSNorm x swish gate as ONE node: the forward applies the epilogue inside the operator's
+    output kernel (mhla_causal_normgate_fwd); the backward is the norm's backward kernel followed by the operator's backward."""
+
+    @staticmethod
+    @_device_guard
+    def forward(ctx, q, k, v, mix, gate, weight, chunk_size, scale, norm_eps):
+        lib = _lib.load()
+        _require_gpu(q, k, v, mix, gate, weight)
+        B, T, H, K = q.shape
+        V = v.shape[-1]
+        n = (T + chunk_size - 1) // chunk_size
+        L = mix.shape[0]
+        if n > L:
+            raise IndexError(f"sequence of {T} tokens needs {n} chunks but mixing_matrix has only {L} rows")
+        _check_like(q, "mhla_causal_normgate", k=(k, q.shape), v=(v, (B, T, H, V)), gate=(gate, (B, T, H, V)))
+        q, k, v = _prep(q), _prep(k), _prep(v)
+        gate = _prep(gate) if gate is not None else None
+        mixf = mix.detach().reshape(L, mix.shape[1]).to(torch.float32).contiguous()
+        wf = weight.detach().to(torch.float32).contiguous() if weight is not None else None
+        need_grad = any(ctx.needs_input_grad[:6])
+        out = torch.empty((B, T, H, V), dtype=q.dtype, device=q.device) if need_grad else None
+        y = torch.empty((B, T, H, V), dtype=q.dtype, device=q.device)
+        ws = _ws(lib.mhla_causal_fwd_ws_bytes(B, T, H, K, V, chunk_size, _dtype_code(q)), q.device)
+        rc = lib.mhla_causal_normgate_fwd(_view(q), _view(k), _view(v), mixf.data_ptr(), mixf.shape[1],
+                                          _view(out) if out is not None else NULL_VIEW,
+                                          _view(gate) if gate is not None else NULL_VIEW,
+                                          wf.data_ptr() if wf is not None else None, float(norm_eps), _view(y),
+                                          ws.data_ptr(), ws.numel() * 4, B, T, H, K, V, chunk_size, float(scale),
+                                          _dtype_code(q), _stream())
+        _lib.check(rc, "mhla_causal_normgate_fwd")
+        keep = ws.numel() * 4 <= KEEP_STATE_LIMIT_BYTES and need_grad
+        ctx.save_for_backward(q, k, v, mixf, out, gate, wf, ws if keep else None)
+        ctx.cfg = (chunk_size, float(scale), float(norm_eps), mix.shape, mix.dtype, weight.dtype if weight is not None else None)
+        return y
+
+    @staticmethod
+    @_device_guard
+    def backward(ctx, dy):
+        lib = _lib.load()
+        q, k, v, mixf, out, gate, wf, fwd_ws = ctx.saved_tensors
+        chunk_size, scale, norm_eps, mix_shape, mix_dtype, w_dtype = ctx.cfg
+        B, T, H, K = q.shape
+        V = v.shape[-1]
+        rows = B * T * H
+        dyc = dy.contiguous().to(q.dtype)
+        do = torch.empty_like(out)
+        dg = torch.empty_like(out) if gate is not None else None
+        gc = gate.contiguous() if gate is not None else None
+        dwp = torch.empty((lib.mhla_rmsnorm_gate_dw_rows(rows), V), dtype=torch.float32, device=q.device)
+        rc = lib.mhla_rmsnorm_gate_bwd(out.data_ptr(), V, gc.data_ptr() if gc is not None else None, V,
+                                       wf.data_ptr() if wf is not None else None, dyc.data_ptr(), V, do.data_ptr(), V,
+                                       dg.data_ptr() if dg is not None else None, V, dwp.data_ptr(), rows, V, norm_eps,
+                                       _dtype_code(q), _stream())
+        _lib.check(rc, "mhla_rmsnorm_gate_bwd")
+        dq = torch.empty((B, T, H, K), dtype=q.dtype, device=q.device)
+        dk = torch.empty((B, T, H, K), dtype=q.dtype, device=q.device)
+        dv = torch.empty((B, T, H, V), dtype=q.dtype, device=q.device)
+        dmix = torch.zeros(mixf.shape, dtype=torch.float32, device=q.device)
+        ws = _ws(lib.mhla_causal_bwd_ws_bytes(B, T, H, K, V, chunk_size, _dtype_code(q)), q.device)
+        rc = lib.mhla_causal_bwd(_view(q), _view(k), _view(v), mixf.data_ptr(), mixf.shape[1], _view(do),
+                                 _view(dq), _view(dk), _view(dv), dmix.data_ptr(), dmix.shape[1],
+                                 ws.data_ptr(), ws.numel() * 4, fwd_ws.data_ptr() if fwd_ws is not None else None,
+                                 B, T, H, K, V, chunk_size, scale, _dtype_code(q), _stream())
+        _lib.check(rc, "mhla_causal_bwd")
+        dw = dwp.sum(0).to(w_dtype) if wf is not None else None
+        return dq, dk, dv, dmix.reshape(mix_shape).to(mix_dtype), dg, dw, None, None, None
+
+
+def causal_normgate_fusable(q: torch.Tensor, v: torch.Tensor) -> bool:
+    """Shapes the fused epilogue covers (include/mhla_hip.h, mhla_causal_normgate_fwd): bf16, K % 64 == 0, V % 64 == 0, V <= 256."""
+    return (q.dtype == torch.bfloat16 and q.shape[-1] % 64 == 0 and v.shape[-1] % 64 == 0 and v.shape[-1] <= 256
+            and q.shape[0] * q.shape[2] <= _MAX_GRID_BH and q.shape[0] > 0 and q.shape[1] > 0)
+
+
+def mhla_causal_normgate(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mixing_matrix: torch.Tensor,
+                         gate: Optional[torch.Tensor], weight: Optional[torch.Tensor], norm_eps: float = 1e-5,
+                         chunk_size: int = 64, scale: Optional[float] = None) -> torch.Tensor:
+    """`rmsnorm_gate(mhla_causal(q, k, v, mix), gate, weight, norm_eps)` -- the fla layer's operator + FusedRMSNormGated
+    (mhla_nlp/fla/layers/mhla.py:330-355).  Where the fused epilogue applies (bf16, K, V multiples of 64, V <= 256) the norm x
+    gate runs inside the operator's output kernel; other shapes compose the two HIP operators."""
+    if scale is None:
+        scale = q.shape[-1] ** -0.5
+    if not causal_normgate_fusable(q, v):
+        return rmsnorm_gate(mhla_causal(q, k, v, mixing_matrix, chunk_size, scale), gate, weight, norm_eps)
+    return _CausalNormGate.apply(q, k, v, mixing_matrix, gate, weight, int(chunk_size), scale, norm_eps)
 
 
 def naive_recurrent_mhla(q, k, v, mixing_matrix, chunk_size: int = 64, scale: Optional[float] = None,
