@@ -189,11 +189,11 @@ __global__ __launch_bounds__(FT8, 4) void k_fs_state(const FsStateArgs a) {
         R.ninv = 0.f;
         if (srow < rv) {
             const long tr = tok_row(a.idx, (long)j * S + c0 + srow);
-            R.x = *reinterpret_cast<const uint4*>(xb + tr * a.x.sn + scol);
-            R.y = *reinterpret_cast<const uint4*>(yb + tr * a.y.sn + scol);
+            R.x = gld<uint4>(xb + tr * a.x.sn + scol);
+            R.y = gld<uint4>(yb + tr * a.y.sn + scol);
             if (a.normalize) {
-                R.t = *reinterpret_cast<const uint4*>(tb + tr * a.t.sn + scol);
-                if (MODE == 1) R.ninv = a.ninv[((long)bh * M + j) * S + c0 + srow];
+                R.t = gld<uint4>(tb + tr * a.t.sn + scol);
+                if (MODE == 1) R.ninv = gld<float>(a.ninv + ((long)bh * M + j) * S + c0 + srow);
             }
         }
     };
@@ -386,9 +386,9 @@ __global__ __launch_bounds__(FT8, 4) void k_fs_state_fwd(const FsStateArgs a) {
         R.x = R.y = R.t = make_uint4(0, 0, 0, 0);
         if (srow < rv) {
             const long tr = tok_row(a.idx, p + srow);
-            R.x = *reinterpret_cast<const uint4*>(xb + tr * a.x.sn + scol);
-            R.y = *reinterpret_cast<const uint4*>(yb + tr * a.y.sn + scol);
-            if (tile_t) R.t = *reinterpret_cast<const uint4*>(tb + tr * a.t.sn + scol);
+            R.x = gld<uint4>(xb + tr * a.x.sn + scol);
+            R.y = gld<uint4>(yb + tr * a.y.sn + scol);
+            if (tile_t) R.t = gld<uint4>(tb + tr * a.t.sn + scol);
         }
     };
     auto commit = [&](const TileRegs3& R, int rv, int rfill) {
@@ -488,22 +488,66 @@ __global__ __launch_bounds__(FT8, 4) void k_fs_state_fwd(const FsStateArgs a) {
     };
 
     if (single) {
-        // software pipeline, two blocks ahead: R[jj & 1] carries block jj
+        // software pipeline, two blocks ahead: R[jj & 1] carries block jj.  Two barriers per block: K, V go through LDS (both MFMA
+        // operands via transpose reads); the column sums ksum_j = sum_s K_j[s] ride on the matrix pipe (an all-ones A operand
+        // against the B operand already fetched for KV) and the thread's piece of Q_j never leaves its registers: z_j[s] =
+        // Q_j[s] . ksum_j is a dot with the 8 sums of its columns, read back from LDS after the second barrier.
         TileRegs3 R0, R1;
         if (jg * IT < M) issue((long)jg * IT * S, S, R0);
         if (jg * IT + 1 < M) issue((long)(jg * IT + 1) * S, S, R1);
         const int rfill = (S + 31) & ~31;
+        s16x8 ones_;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) ones_[t] = (short)0x3F80;   // bf16 1.0
+        const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_);
         auto step = [&](auto jjc, TileRegs3& R) {
             constexpr int jj = decltype(jjc)::value;
             const int j = jg * IT + jj;
             if (j >= M) return;
-            commit(R, S, rfill);
+            uint4 tq = R.t;
+            if (srow < rfill) {
+                uint4 x = R.x;
+                if (a.relu && srow < S) {
+                    x = relu_eps8(x, a.eps);
+                    if (a.normalize) tq = relu_eps8(tq, a.eps);
+                }
+                *reinterpret_cast<uint4*>(Xs + srow * TLD + scol) = x;
+                *reinterpret_cast<uint4*>(Ys + srow * TLD + scol) = R.y;
+            }
             if (jj + 2 < IT && j + 2 < M) issue((long)(j + 2) * S, S, R);
             __syncthreads();
-            float ks = 0.f;
-            chunk(jjc, j, 0, S, rfill, ks);
-            if (MODE == 0 && a.normalize) finish_block(j, ks);   // ends with a barrier
-            else __syncthreads();
+            f32x4 ks[2];
+            ks[0] = ks[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int k0 = 0; k0 < rfill; k0 += 32) {
+                const bf16x8 av = tr_read8(Ys, TLD, k0, dt * 16, lane);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const bf16x8 bv = tr_read8(Xs, TLD, k0, (2 * th + t) * 16, lane);
+                    acc[jj][t] = mfma_bf16(av, bv, acc[jj][t]);
+                    if (a.normalize) ks[t] = mfma_bf16(ones, bv, ks[t]);
+                }
+            }
+            if (a.normalize && dt == 0 && lane < 16) {   // every row of the ones-product is the column sum: row 0 lives in lanes 0..15
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int col = (2 * th + t) * 16 + lane;
+                    ksum_s[col] = ks[t][0];
+                    a.ksum[((long)bh * M + j) * 64 + col] = ks[t][0];
+                }
+            }
+            __syncthreads();                           // tiles consumed; column sums visible
+            if (a.normalize) {
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(ksum_s + scol), hi = *reinterpret_cast<const f32x4*>(ksum_s + scol + 4);
+                const unsigned qw[4] = {tq.x, tq.y, tq.z, tq.w};
+                float d = __uint_as_float(qw[0] << 16) * lo[0] + __uint_as_float(qw[0] & 0xffff0000u) * lo[1] +
+                          __uint_as_float(qw[1] << 16) * lo[2] + __uint_as_float(qw[1] & 0xffff0000u) * lo[3] +
+                          __uint_as_float(qw[2] << 16) * hi[0] + __uint_as_float(qw[2] & 0xffff0000u) * hi[1] +
+                          __uint_as_float(qw[3] << 16) * hi[2] + __uint_as_float(qw[3] & 0xffff0000u) * hi[3];
+                d += __shfl_xor(d, 1, 64);
+                d += __shfl_xor(d, 2, 64);
+                d += __shfl_xor(d, 4, 64);
+                if (srow < S && (tid & 7) == 0) a.z_out[((long)bh * M + j) * S + srow] = d;
+            }
         };
         step(std::integral_constant<int, 0>{}, R0);
         step(std::integral_constant<int, 1>{}, R1);
