@@ -499,8 +499,9 @@ int mhla_blockmix_bwd(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q
             sa.q = cv(q_num); sa.k = cv(k_num); sa.v = cv(v); sa.o = normalize ? cv(out) : cv(q_num); sa.dout = cv(dout);
             sa.dq = cmv(dq_num); sa.dk = cmv(dk_num); sa.dv = cmv(dv); sa.idx = block_index; sa.W = W; sa.ldw = ldw;
             sa.dwp = (float*)ws; sa.H = H; sa.M = M; sa.D = D; sa.eps = eps; sa.relu = relu; sa.normalize = normalize;
-            if (D <= 64) RC(launch(fast::k_sn_bwd<4>, dim3(B * H), dim3(fast::SN_T), fast::sn_bwd_smem<4>(), st, "k_sn_bwd<4>", sa));
-            else         RC(launch(fast::k_sn_bwd<5>, dim3(B * H), dim3(fast::SN_T), fast::sn_bwd_smem<5>(), st, "k_sn_bwd<5>", sa));
+            sa.trace = g_trace.load();
+            if (D <= 64) RC(launch(fast::k_sn_bwd<4>, dim3(B * H), dim3(fast::SN_TB), fast::sn_bwd_smem<4>(), st, "k_sn_bwd<4>", sa));
+            else         RC(launch(fast::k_sn_bwd<5>, dim3(B * H), dim3(fast::SN_TB), fast::sn_bwd_smem<5>(), st, "k_sn_bwd<5>", sa));
             RC(launch(fast::k_sn_dw_reduce, dim3(M * M), dim3(256), 0, st, "k_sn_dw_reduce", (const float*)ws, dW, M * M, B * H));
             return MHLA_OK;
         }

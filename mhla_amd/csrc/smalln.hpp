@@ -18,8 +18,14 @@
 namespace mhla {
 namespace fast {
 
-constexpr int SN_T = 512;   // threads: 8 waves, wave w owns blocks w and w + 8
+// forward: 16 waves, wave w owns block w (M <= 16) -- its phases are latency chains (LDS read -> MFMA -> pack -> MFMA per block
+// pair) that 16 waves hide better than 8 waves with two blocks each (42.7 -> 37.8 us at the DiT-XL/2 shape).
+// backward: 8 waves, wave w owns blocks w and w + 8 and processes them JOINTLY: the backward is bound by LDS operand reads (every
+// (i, j) pair re-reads the K / V / Q / dO' rows of block j), and two blocks that share each fetched operand halve that traffic.
+constexpr int SN_T = 1024;
 constexpr int SN_W = SN_T / 64;
+constexpr int SN_TB = 512;
+constexpr int SN_WB = SN_TB / 64;
 
 struct SnArgs {
     View q, k, v, o, dout;
@@ -31,22 +37,23 @@ struct SnArgs {
     int H, M, D;
     float eps;
     int relu, normalize;
+    unsigned long long* trace;   // debugging aid (mhla_debug_set_trace): phase timestamps of k_sn_bwd
 };
 
 template <int DT>
 __host__ __device__ constexpr int sn_ldr() { return DT * 16 + 8; }   // LDS row stride (bf16): 72 (144 B) / 88 (176 B)
 
 // stage `nrows` token rows (D valid columns, zero up to DP) into an LDS tile [nrows][LDR]
-template <int DT, bool RELU>
+template <int DT, bool RELU, int NT = SN_T>
 __device__ __forceinline__ void sn_stage(u16* __restrict__ dst, const u16* __restrict__ base, long sn, const int* __restrict__ idx,
                                          int nrows, int D, float eps, int tid) {
     constexpr int LDR = sn_ldr<DT>(), PV = DT * 2;   // 16-byte pieces per padded row
     const int dv = D >> 3;
-    constexpr int MAXIT = (256 * PV + SN_T - 1) / SN_T;
+    constexpr int MAXIT = (256 * PV + NT - 1) / NT;
     uint4 reg[MAXIT];
 #pragma unroll
     for (int t = 0; t < MAXIT; ++t) {
-        const int v = tid + t * SN_T, r = v / PV, p = v - r * PV;
+        const int v = tid + t * NT, r = v / PV, p = v - r * PV;
         reg[t] = make_uint4(0, 0, 0, 0);
         if (r < nrows && p < dv) {
             reg[t] = *reinterpret_cast<const uint4*>(base + tok_row(idx, r) * sn + p * 8);
@@ -55,7 +62,7 @@ __device__ __forceinline__ void sn_stage(u16* __restrict__ dst, const u16* __res
     }
 #pragma unroll
     for (int t = 0; t < MAXIT; ++t) {
-        const int v = tid + t * SN_T, r = v / PV, p = v - r * PV;
+        const int v = tid + t * NT, r = v / PV, p = v - r * PV;
         if (r < nrows) *reinterpret_cast<uint4*>(dst + r * LDR + p * 8) = reg[t];
     }
 }
@@ -150,7 +157,7 @@ __host__ __device__ constexpr int sn_fwd_smem() {
 // forward
 // ------------------------------------------------------------------------------------------------------------------
 template <int DT>
-__global__ __launch_bounds__(SN_T, 2) void k_sn_fwd(const SnArgs a) {
+__global__ __launch_bounds__(SN_T, SN_T / 256) void k_sn_fwd(const SnArgs a) {
     constexpr int DP = DT * 16, LDR = sn_ldr<DT>(), KS = (DP + 31) / 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u16* Ks = reinterpret_cast<u16*>(smem_raw);          // [N][LDR]
@@ -263,10 +270,9 @@ __global__ __launch_bounds__(SN_T, 2) void k_sn_fwd(const SnArgs a) {
 // ------------------------------------------------------------------------------------------------------------------
 template <int DT>
 __host__ __device__ constexpr int sn_bwd_smem() {
-    return 2 * 256 * sn_ldr<DT>() * 2 + (2 * 16 * DT * 16 + 5 * 256) * 4 + SN_W * 16 * sn_ldr<DT>() * 2;
+    return 2 * 256 * sn_ldr<DT>() * 2 + (2 * 16 * DT * 16 + 5 * 256) * 4 + SN_WB * 16 * sn_ldr<DT>() * 2;
 }
 
-// 16 staged rows -> global with optional relu mask (raw input > 0)
 template <bool MASK>
 __device__ __forceinline__ void sn_store16(u16* __restrict__ base, long sn, const int* __restrict__ idx, int row0, int D,
                                            const u16* __restrict__ Os, int ldr, const u16* __restrict__ mbase, long msn, int lane) {
@@ -281,7 +287,7 @@ __device__ __forceinline__ void sn_store16(u16* __restrict__ base, long sn, cons
 }
 
 template <int DT>
-__global__ __launch_bounds__(SN_T, 2) void k_sn_bwd(const SnArgs a) {
+__global__ __launch_bounds__(SN_TB, 2) void k_sn_bwd(const SnArgs a) {
     constexpr int DP = DT * 16, LDR = sn_ldr<DT>(), KS = (DP + 31) / 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u16* T0 = reinterpret_cast<u16*>(smem_raw);          // K, later Q          [N][LDR]
@@ -303,6 +309,10 @@ __global__ __launch_bounds__(SN_T, 2) void k_sn_bwd(const SnArgs a) {
     u16 *dqb = mbase(a.dq), *dkb = mbase(a.dk), *dvb = mbase(a.dv);
     float* dwp = a.dwp + (long)bh * M * M;
     u16* Os = Ost + wave * 16 * LDR;
+    // the wave's two blocks; with M <= 8 the second one does not exist: it is clamped onto the first (its results are dropped)
+    const int bA = wave, bB = wave + SN_WB;
+    const bool hasA = bA < M, hasB = bB < M;
+    const int blk[2] = {hasA ? bA : 0, hasB ? bB : (hasA ? bA : 0)};
     auto load_q = [&](bf16x8 (&r)[KS], int i) {
         if (a.relu) sn_load_rows<KS, true>(r, qb, a.q.sn, a.idx, i * 16, D, a.eps, lane);
         else        sn_load_rows<KS, false>(r, qb, a.q.sn, a.idx, i * 16, D, a.eps, lane);
@@ -312,8 +322,7 @@ __global__ __launch_bounds__(SN_T, 2) void k_sn_bwd(const SnArgs a) {
         else        sn_load_rows<KS, false>(r, kb, a.k.sn, a.idx, j * 16, D, a.eps, lane);
     };
     // dO rows scaled by 1/n (row = lane & 15), rounded to bf16
-    auto load_dop = [&](bf16x8 (&r)[KS], int i) {
-        sn_load_rows<KS, false>(r, gb, a.dout.sn, a.idx, i * 16, D, 0.f, lane);
+    auto scale_dop = [&](bf16x8 (&r)[KS], int i) {
         if (a.normalize) {
             const float ni = nis[i * 16 + n];
 #pragma unroll
@@ -328,15 +337,24 @@ __global__ __launch_bounds__(SN_T, 2) void k_sn_bwd(const SnArgs a) {
         }
     };
 
+    trace_mark(a.trace, 0);
+    // the wave's own rows of Q and dO (operands of P2 and of pass A) are requested first: they travel while K, V are staged
+    bf16x8 qa[2][KS], ga[2][KS];
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+        load_q(qa[x], blk[x]);
+        sn_load_rows<KS, false>(ga[x], gb, a.dout.sn, a.idx, blk[x] * 16, D, 0.f, lane);
+    }
     // ---- P0 / P1: K, V tiles; ksum ----
     __shared__ float Wsh[16 * 17];   // mixing weights (M <= 16), read in every inner loop
     if (tid < 256) Wsh[(tid >> 4) * 17 + (tid & 15)] = ((tid >> 4) < M && (tid & 15) < M) ? a.W[(long)(tid >> 4) * a.ldw + (tid & 15)] : 0.f;
-    if (a.relu) sn_stage<DT, true>(T0, kb, a.k.sn, a.idx, N, D, a.eps, tid);
-    else        sn_stage<DT, false>(T0, kb, a.k.sn, a.idx, N, D, a.eps, tid);
-    sn_stage<DT, false>(T1, vb, a.v.sn, a.idx, N, D, 0.f, tid);
+    if (a.relu) sn_stage<DT, true, SN_TB>(T0, kb, a.k.sn, a.idx, N, D, a.eps, tid);
+    else        sn_stage<DT, false, SN_TB>(T0, kb, a.k.sn, a.idx, N, D, a.eps, tid);
+    sn_stage<DT, false, SN_TB>(T1, vb, a.v.sn, a.idx, N, D, 0.f, tid);
     __syncthreads();
+    trace_mark(a.trace, 1);
     if (a.normalize) {
-        for (int v = tid; v < M * DP; v += SN_T) {
+        for (int v = tid; v < M * DP; v += SN_TB) {
             const int j = v / DP, d = v - j * DP;
             float sacc = 0.f;
 #pragma unroll
@@ -344,31 +362,35 @@ __global__ __launch_bounds__(SN_T, 2) void k_sn_bwd(const SnArgs a) {
             ksum_s[v] = sacc;
         }
         __syncthreads();
+        trace_mark(a.trace, 2);
         // ---- P2: z_i, row dots (own blocks) ----
-        for (int i = wave; i < M; i += SN_W) {
-            bf16x8 qa[KS], ga[KS], oa[KS];
-            load_q(qa, i);
-            sn_load_rows<KS, false>(ga, gb, a.dout.sn, a.idx, i * 16, D, 0.f, lane);
-            sn_load_rows<KS, false>(oa, ob, a.o.sn, a.idx, i * 16, D, 0.f, lane);
-            float z = 0.f, rd = 0.f;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                if (ks * 32 + kg * 8 < D) {
-                    const s16x8 qs = __builtin_bit_cast(s16x8, qa[ks]), gs = __builtin_bit_cast(s16x8, ga[ks]), os = __builtin_bit_cast(s16x8, oa[ks]);
+        for (int x = 0; x < 2; ++x) {
+            if (x == 0 ? hasA : hasB) {
+                const int i = blk[x];
+                bf16x8 oa[KS];
+                sn_load_rows<KS, false>(oa, ob, a.o.sn, a.idx, i * 16, D, 0.f, lane);
+                float z = 0.f, rd = 0.f;
 #pragma unroll
-                    for (int t = 0; t < 8; ++t) {
-                        z += bf((u16)qs[t]) * ksum_s[i * DP + ks * 32 + kg * 8 + t];
-                        rd += bf((u16)gs[t]) * bf((u16)os[t]);
+                for (int ks = 0; ks < KS; ++ks) {
+                    if (ks * 32 + kg * 8 < D) {
+                        const s16x8 qs = __builtin_bit_cast(s16x8, qa[x][ks]), gs = __builtin_bit_cast(s16x8, ga[x][ks]), os = __builtin_bit_cast(s16x8, oa[ks]);
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) {
+                            z += bf((u16)qs[t]) * ksum_s[i * DP + ks * 32 + kg * 8 + t];
+                            rd += bf((u16)gs[t]) * bf((u16)os[t]);
+                        }
                     }
                 }
+                z += __shfl_xor(z, 16, 64); z += __shfl_xor(z, 32, 64);
+                rd += __shfl_xor(rd, 16, 64); rd += __shfl_xor(rd, 32, 64);
+                if (kg == 0) { zs[i * 16 + n] = z; rds[i * 16 + n] = rd; }
             }
-            z += __shfl_xor(z, 16, 64); z += __shfl_xor(z, 32, 64);
-            rd += __shfl_xor(rd, 16, 64); rd += __shfl_xor(rd, 32, 64);
-            if (kg == 0) { zs[i * 16 + n] = z; rds[i * 16 + n] = rd; }
         }
         __syncthreads();
+        trace_mark(a.trace, 3);
         // ---- P3: 1/n, dn ----
-        for (int v = tid; v < N; v += SN_T) {
+        for (int v = tid; v < N; v += SN_TB) {
             const int i = v >> 4, sx = v & 15;
             float nn = a.eps;
             for (int j = 0; j < M; ++j) nn += Wsh[i * 17 + j] * zs[j * 16 + sx];
@@ -378,7 +400,7 @@ __global__ __launch_bounds__(SN_T, 2) void k_sn_bwd(const SnArgs a) {
         }
         __syncthreads();
         // ---- P4: dz = W^T dn ----
-        for (int v = tid; v < N; v += SN_T) {
+        for (int v = tid; v < N; v += SN_TB) {
             const int j = v >> 4, sx = v & 15;
             float dz = 0.f;
             for (int i = 0; i < M; ++i) dz += Wsh[i * 17 + j] * dns[i * 16 + sx];
@@ -386,77 +408,108 @@ __global__ __launch_bounds__(SN_T, 2) void k_sn_bwd(const SnArgs a) {
         }
         __syncthreads();
     }
+    trace_mark(a.trace, 4);
 
-    // ---- pass A: dQ_i, dW[i][:], dksum_i ----
-    for (int i = wave; i < M; i += SN_W) {
-        bf16x8 qa[KS], ga[KS];
-        load_q(qa, i);
-        load_dop(ga, i);
-        f32x4 acc[DT];
+    // ---- pass A: dQ_i, dW[i][:] for the wave's two query blocks at once (K, V rows and K^T operands fetched once for both) ----
+    {
+        scale_dop(ga[0], blk[0]);
+        scale_dop(ga[1], blk[1]);
+        f32x4 acc[2][DT];
 #pragma unroll
-        for (int tn = 0; tn < DT; ++tn) acc[tn] = f32x4{0.f, 0.f, 0.f, 0.f};
-        float ew[16];   // per-lane partials of dW[i][0..15]
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int tn = 0; tn < DT; ++tn) acc[x][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float ew[2][16];   // per-lane partials of dW[i][0..15]
 #pragma unroll
         for (int jp = 0; jp < 8; ++jp) {
             const int j0 = 2 * jp;
-            ew[j0] = ew[j0 + 1] = 0.f;
+            ew[0][j0] = ew[0][j0 + 1] = ew[1][j0] = ew[1][j0 + 1] = 0.f;
             if (j0 < M) {
                 const bool has1 = j0 + 1 < M;
                 const int j1 = has1 ? j0 + 1 : j0;
-                const float w0 = Wsh[i * 17 + j0], w1 = has1 ? Wsh[i * 17 + j1] : 0.f;
-                f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, p0 = s0, p1 = s0;
+                f32x4 s0[2], s1[2], p0[2], p1[2];
+#pragma unroll
+                for (int x = 0; x < 2; ++x) s0[x] = s1[x] = p0[x] = p1[x] = f32x4{0.f, 0.f, 0.f, 0.f};
                 bf16x8 t0[KS], t1[KS];
                 sn_lds_rows<KS>(t0, T0, LDR, j0 * 16, D, lane);
                 sn_lds_rows<KS>(t1, T0, LDR, j1 * 16, D, lane);
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) { s0 = mfma_bf16(t0[ks], qa[ks], s0); s1 = mfma_bf16(t1[ks], qa[ks], s1); }   // S^T
+                for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                    for (int x = 0; x < 2; ++x) { s0[x] = mfma_bf16(t0[ks], qa[x][ks], s0[x]); s1[x] = mfma_bf16(t1[ks], qa[x][ks], s1[x]); }   // S^T
                 sn_lds_rows<KS>(t0, T1, LDR, j0 * 16, D, lane);
                 sn_lds_rows<KS>(t1, T1, LDR, j1 * 16, D, lane);
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) { p0 = mfma_bf16(t0[ks], ga[ks], p0); p1 = mfma_bf16(t1[ks], ga[ks], p1); }   // dP^T
-                // dW[i][j] = sum(dP . S) + sum_s dn_i[s] z_j[s]: lane partials, reduced once per query block below
-                float e0 = s0[0] * p0[0] + s0[1] * p0[1] + s0[2] * p0[2] + s0[3] * p0[3];
-                float e1 = s1[0] * p1[0] + s1[1] * p1[1] + s1[2] * p1[2] + s1[3] * p1[3];
-                if (a.normalize && kg == 0) {
-                    e0 += dns[i * 16 + n] * zs[j0 * 16 + n];
-                    e1 += dns[i * 16 + n] * zs[j1 * 16 + n];
+                for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                    for (int x = 0; x < 2; ++x) { p0[x] = mfma_bf16(t0[ks], ga[x][ks], p0[x]); p1[x] = mfma_bf16(t1[ks], ga[x][ks], p1[x]); }   // dP^T
+                bf16x8 da[2];
+#pragma unroll
+                for (int x = 0; x < 2; ++x) {
+                    const int i = blk[x];
+                    // dW[i][j] = sum(dP . S) + sum_s dn_i[s] z_j[s]: lane partials, reduced once per query block below
+                    float e0 = s0[x][0] * p0[x][0] + s0[x][1] * p0[x][1] + s0[x][2] * p0[x][2] + s0[x][3] * p0[x][3];
+                    float e1 = s1[x][0] * p1[x][0] + s1[x][1] * p1[x][1] + s1[x][2] * p1[x][2] + s1[x][3] * p1[x][3];
+                    if (a.normalize && kg == 0) {
+                        e0 += dns[i * 16 + n] * zs[j0 * 16 + n];
+                        e1 += dns[i * 16 + n] * zs[j1 * 16 + n];
+                    }
+                    ew[x][j0] = e0;
+                    ew[x][j0 + 1] = has1 ? e1 : 0.f;
+                    const float w0 = Wsh[i * 17 + j0], w1 = has1 ? Wsh[i * 17 + j1] : 0.f;
+                    da[x] = sn_pack_pair(p0[x] * w0, p1[x] * w1);      // dS^T pair -> A operand (m = s, k-slots = t)
                 }
-                ew[j0] = e0;
-                ew[j0 + 1] = has1 ? e1 : 0.f;
-                const bf16x8 da = sn_pack_pair(p0 * w0, p1 * w1);      // dS^T pair -> A operand (m = s, k-slots = t)
 #pragma unroll
-                for (int tn = 0; tn < DT; ++tn) acc[tn] = mfma_bf16(da, sn_tr_pair(T0, LDR, j0 * 16, j1 * 16, tn * 16, lane), acc[tn]);
+                for (int tn = 0; tn < DT; ++tn) {
+                    const bf16x8 bk = sn_tr_pair(T0, LDR, j0 * 16, j1 * 16, tn * 16, lane);
+                    acc[0][tn] = mfma_bf16(da[0], bk, acc[0][tn]);
+                    acc[1][tn] = mfma_bf16(da[1], bk, acc[1][tn]);
+                }
             }
         }
-        {
-            const float tot = wave_reduce16(ew, lane);
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            const int i = blk[x];
+            const bool live = x == 0 ? hasA : hasB;
+            const float tot = wave_reduce16(ew[x], lane);
             const int jw = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
-            if ((lane & 3) == 0 && jw < M) dwp[i * M + jw] = tot;
-        }
-        // epilogue: + dz (x) ksum ; stage ; masked store
+            if (live && (lane & 3) == 0 && jw < M) dwp[i * M + jw] = tot;
+            if (live) {
+                // epilogue: + dz (x) ksum ; stage ; masked store
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float dz = a.normalize ? dzs[i * 16 + kg * 4 + r] : 0.f;
+                for (int r = 0; r < 4; ++r) {
+                    const float dz = a.normalize ? dzs[i * 16 + kg * 4 + r] : 0.f;
 #pragma unroll
-            for (int tn = 0; tn < DT; ++tn) {
-                const float kk = a.normalize ? ksum_s[i * DP + tn * 16 + n] : 0.f;
-                Os[(kg * 4 + r) * LDR + tn * 16 + n] = cvt_bf16(acc[tn][r] + dz * kk);
+                    for (int tn = 0; tn < DT; ++tn) {
+                        const float kk = a.normalize ? ksum_s[i * DP + tn * 16 + n] : 0.f;
+                        Os[(kg * 4 + r) * LDR + tn * 16 + n] = cvt_bf16(acc[x][tn][r] + dz * kk);
+                    }
+                }
+                wave_lds_fence();
+                if (a.relu) sn_store16<true>(dqb, a.dq.sn, a.idx, i * 16, D, Os, LDR, qb, a.q.sn, lane);
+                else        sn_store16<false>(dqb, a.dq.sn, a.idx, i * 16, D, Os, LDR, nullptr, 0, lane);
+                wave_lds_fence();
             }
         }
-        wave_lds_fence();
-        if (a.relu) sn_store16<true>(dqb, a.dq.sn, a.idx, i * 16, D, Os, LDR, qb, a.q.sn, lane);
-        else        sn_store16<false>(dqb, a.dq.sn, a.idx, i * 16, D, Os, LDR, nullptr, 0, lane);
-        wave_lds_fence();
+    }
+    trace_mark(a.trace, 5);
+    // the wave's key-block rows for pass B are requested before the tiles are re-staged
+    bf16x8 ka[2][KS], va[2][KS];
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+        load_k(ka[x], blk[x]);
+        sn_load_rows<KS, false>(va[x], vb, a.v.sn, a.idx, blk[x] * 16, D, 0.f, lane);
     }
     __syncthreads();
+    trace_mark(a.trace, 6);
 
     // ---- P5: Q and dO' tiles replace K and V ----
-    if (a.relu) sn_stage<DT, true>(T0, qb, a.q.sn, a.idx, N, D, a.eps, tid);
-    else        sn_stage<DT, false>(T0, qb, a.q.sn, a.idx, N, D, a.eps, tid);
+    if (a.relu) sn_stage<DT, true, SN_TB>(T0, qb, a.q.sn, a.idx, N, D, a.eps, tid);
+    else        sn_stage<DT, false, SN_TB>(T0, qb, a.q.sn, a.idx, N, D, a.eps, tid);
     {
         constexpr int PV = DT * 2;
         const int dv = D >> 3;
-        for (int v = tid; v < N * PV; v += SN_T) {
+        for (int v = tid; v < N * PV; v += SN_TB) {
             const int r = v / PV, p = v - r * PV;
             uint4 x = make_uint4(0, 0, 0, 0);
             if (p < dv) {
@@ -474,75 +527,97 @@ __global__ __launch_bounds__(SN_T, 2) void k_sn_bwd(const SnArgs a) {
         }
     }
     __syncthreads();
+    trace_mark(a.trace, 7);
 
-    // ---- pass B: dK_j, dV_j ----
-    for (int j = wave; j < M; j += SN_W) {
-        bf16x8 ka[KS], va[KS];
-        load_k(ka, j);
-        sn_load_rows<KS, false>(va, vb, a.v.sn, a.idx, j * 16, D, 0.f, lane);
-        f32x4 accK[DT], accV[DT];
+    // ---- pass B: dK_j, dV_j for the wave's two key blocks at once (Q, dO' rows and their transposes fetched once for both) ----
+    {
+        f32x4 accK[2][DT], accV[2][DT];
 #pragma unroll
-        for (int tn = 0; tn < DT; ++tn) accK[tn] = accV[tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int tn = 0; tn < DT; ++tn) accK[x][tn] = accV[x][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 2
         for (int i0 = 0; i0 < M; i0 += 2) {
             const bool has1 = i0 + 1 < M;
             const int i1 = has1 ? i0 + 1 : i0;
-            const float w0 = Wsh[i0 * 17 + j], w1 = has1 ? Wsh[i1 * 17 + j] : 0.f;
-            f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, p0 = s0, p1 = s0;
+            f32x4 s0[2], s1[2], p0[2], p1[2];
+#pragma unroll
+            for (int x = 0; x < 2; ++x) s0[x] = s1[x] = p0[x] = p1[x] = f32x4{0.f, 0.f, 0.f, 0.f};
             bf16x8 t0[KS], t1[KS];
             sn_lds_rows<KS>(t0, T0, LDR, i0 * 16, D, lane);
             sn_lds_rows<KS>(t1, T0, LDR, i1 * 16, D, lane);
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) { s0 = mfma_bf16(t0[ks], ka[ks], s0); s1 = mfma_bf16(t1[ks], ka[ks], s1); }   // S: rows s, cols t
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int x = 0; x < 2; ++x) { s0[x] = mfma_bf16(t0[ks], ka[x][ks], s0[x]); s1[x] = mfma_bf16(t1[ks], ka[x][ks], s1[x]); }   // S: rows s, cols t
             sn_lds_rows<KS>(t0, T1, LDR, i0 * 16, D, lane);
             sn_lds_rows<KS>(t1, T1, LDR, i1 * 16, D, lane);
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) { p0 = mfma_bf16(t0[ks], va[ks], p0); p1 = mfma_bf16(t1[ks], va[ks], p1); }   // dP
-            const bf16x8 pa = sn_pack_pair(s0 * w0, s1 * w1);      // P pair  -> A operand (m = t, k-slots = s)
-            const bf16x8 da = sn_pack_pair(p0 * w0, p1 * w1);      // dS pair
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int x = 0; x < 2; ++x) { p0[x] = mfma_bf16(t0[ks], va[x][ks], p0[x]); p1[x] = mfma_bf16(t1[ks], va[x][ks], p1[x]); }   // dP
+            bf16x8 pa[2], da[2];
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                const float w0 = Wsh[i0 * 17 + blk[x]], w1 = has1 ? Wsh[i1 * 17 + blk[x]] : 0.f;
+                pa[x] = sn_pack_pair(s0[x] * w0, s1[x] * w1);      // P pair  -> A operand (m = t, k-slots = s)
+                da[x] = sn_pack_pair(p0[x] * w0, p1[x] * w1);      // dS pair
+            }
 #pragma unroll
             for (int tn = 0; tn < DT; ++tn) {
-                accV[tn] = mfma_bf16(pa, sn_tr_pair(T1, LDR, i0 * 16, i1 * 16, tn * 16, lane), accV[tn]);   // dV += P^T dO'
-                accK[tn] = mfma_bf16(da, sn_tr_pair(T0, LDR, i0 * 16, i1 * 16, tn * 16, lane), accK[tn]);   // dK += dS^T Q
-            }
-        }
-        // dksum_j[d] = sum_s dz_j[s] q_j[s][d] as one MFMA per feature tile: every row of the A operand is dz_j (k-slots of the
-        // first tile of the pair, hi + lo bf16), the B operand the transposed Q_j tile; all rows of the result are equal
-        f32x4 dks[DT];
+                const bf16x8 bv = sn_tr_pair(T1, LDR, i0 * 16, i1 * 16, tn * 16, lane);
+                const bf16x8 bq = sn_tr_pair(T0, LDR, i0 * 16, i1 * 16, tn * 16, lane);
 #pragma unroll
-        for (int tn = 0; tn < DT; ++tn) dks[tn] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (a.normalize) {
-            f32x4 dz4, dzl;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                dz4[r] = dzs[j * 16 + kg * 4 + r];
-                dzl[r] = dz4[r] - bf(cvt_bf16(dz4[r]));
-            }
-            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-            const bf16x8 ah = sn_pack_pair(dz4, zero), al = sn_pack_pair(dzl, zero);
-#pragma unroll
-            for (int tn = 0; tn < DT; ++tn) {
-                const bf16x8 bq = sn_tr_pair(T0, LDR, j * 16, j * 16, tn * 16, lane);
-                dks[tn] = mfma_bf16(ah, bq, dks[tn]);
-                dks[tn] = mfma_bf16(al, bq, dks[tn]);
+                for (int x = 0; x < 2; ++x) {
+                    accV[x][tn] = mfma_bf16(pa[x], bv, accV[x][tn]);   // dV += P^T dO'
+                    accK[x][tn] = mfma_bf16(da[x], bq, accK[x][tn]);   // dK += dS^T Q
+                }
             }
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int x = 0; x < 2; ++x) {
+            if (!(x == 0 ? hasA : hasB)) continue;
+            const int j = blk[x];
+            // dksum_j[d] = sum_s dz_j[s] q_j[s][d] as one MFMA per feature tile: every row of the A operand is dz_j (k-slots of the
+            // first tile of the pair, hi + lo bf16), the B operand the transposed Q_j tile; all rows of the result are equal
+            f32x4 dks[DT];
 #pragma unroll
-            for (int tn = 0; tn < DT; ++tn) Os[(kg * 4 + r) * LDR + tn * 16 + n] = cvt_bf16(accK[tn][r] + dks[tn][0]);
-        wave_lds_fence();
-        if (a.relu) sn_store16<true>(dkb, a.dk.sn, a.idx, j * 16, D, Os, LDR, kb, a.k.sn, lane);
-        else        sn_store16<false>(dkb, a.dk.sn, a.idx, j * 16, D, Os, LDR, nullptr, 0, lane);
-        wave_lds_fence();
+            for (int tn = 0; tn < DT; ++tn) dks[tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (a.normalize) {
+                f32x4 dz4, dzl;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+                for (int r = 0; r < 4; ++r) {
+                    dz4[r] = dzs[j * 16 + kg * 4 + r];
+                    dzl[r] = dz4[r] - bf(cvt_bf16(dz4[r]));
+                }
+                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                const bf16x8 ah = sn_pack_pair(dz4, zero), al = sn_pack_pair(dzl, zero);
 #pragma unroll
-            for (int tn = 0; tn < DT; ++tn) Os[(kg * 4 + r) * LDR + tn * 16 + n] = cvt_bf16(accV[tn][r]);
-        wave_lds_fence();
-        sn_store16<false>(dvb, a.dv.sn, a.idx, j * 16, D, Os, LDR, nullptr, 0, lane);
-        wave_lds_fence();
+                for (int tn = 0; tn < DT; ++tn) {
+                    const bf16x8 bq = sn_tr_pair(T0, LDR, j * 16, j * 16, tn * 16, lane);
+                    dks[tn] = mfma_bf16(ah, bq, dks[tn]);
+                    dks[tn] = mfma_bf16(al, bq, dks[tn]);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int tn = 0; tn < DT; ++tn) Os[(kg * 4 + r) * LDR + tn * 16 + n] = cvt_bf16(accK[x][tn][r] + dks[tn][0]);
+            wave_lds_fence();
+            if (a.relu) sn_store16<true>(dkb, a.dk.sn, a.idx, j * 16, D, Os, LDR, kb, a.k.sn, lane);
+            else        sn_store16<false>(dkb, a.dk.sn, a.idx, j * 16, D, Os, LDR, nullptr, 0, lane);
+            wave_lds_fence();
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int tn = 0; tn < DT; ++tn) Os[(kg * 4 + r) * LDR + tn * 16 + n] = cvt_bf16(accV[x][tn][r]);
+            wave_lds_fence();
+            sn_store16<false>(dvb, a.dv.sn, a.idx, j * 16, D, Os, LDR, nullptr, 0, lane);
+            wave_lds_fence();
+        }
     }
+    trace_mark(a.trace, 8);
+    if (a.trace) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); trace_mark(a.trace, 9); }
 }
 
 // dW[i][j] = sum_bh dWp[bh][i][j] : one workgroup per element, fixed-order tree (deterministic)
