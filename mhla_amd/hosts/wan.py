@@ -69,3 +69,22 @@ class WanAttentionBlock_MHLA(nn.Module):
         x = x + self.cross_attn(self.norm3(x), context, context_lens)
         y = self.ffn((self.norm2(x).float() * (1 + e[4]) + e[3]).to(dt))
         return (x.float() + y.float() * e[5]).to(dt)
+
+
+class WanStack_MHLA(nn.Module):
+    """`num_layers` Wan blocks in sequence (30 in Wan2.1-1.3B, wan/model.py:1824-2389 builds `self.blocks` the same way) with a
+    shared time-modulation input -- the self-attention / cross-attention / FFN body of the denoiser without its patch embedding,
+    text encoder and head, so that the per-step cost of BASELINE.json configs[3] (81 frames at 832 x 480 = 31 500 video tokens)
+    can be timed on one GPU.  `attn_type` selects the self-attention class by the reference's registry key."""
+
+    def __init__(self, num_layers=30, dim=1536, ffn_dim=8960, num_heads=12, block_layout=(3, 5, 10), is_gated=True, is_lepe=False,
+                 norm_output=False):
+        super().__init__()
+        self.blocks = nn.ModuleList([WanAttentionBlock_MHLA(dim=dim, ffn_dim=ffn_dim, num_heads=num_heads, block_layout=block_layout,
+                                                            is_gated=is_gated, is_lepe=is_lepe, norm_output=norm_output)
+                                     for _ in range(num_layers)])
+
+    def forward(self, x, e, seq_lens, grid_sizes, freqs, context, context_lens=None):
+        for blk in self.blocks:
+            x = blk(x, e, seq_lens, grid_sizes, freqs, context, context_lens)
+        return x

@@ -11,7 +11,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from ..ops import lepe2d, mhla_blockmix, mhla_dit_core
+from ..ops import qk_prologue, lepe2d, mhla_blockmix, mhla_dit_core
 from .blockconv import BlockDistanceConv
 
 
@@ -92,10 +92,18 @@ class MHLA4DiT(nn.Module):
         qkv = self.to_qkv(x).reshape(B, M * S, 3, H, D)                       # mhla.py:245
         W = self.piece_attn.conv.weight
         if self.qk_norm:
-            q = torch.relu(self.q_norm(qkv[:, :, 0].reshape(B, M * S, H * D))) + self.eps   # mhla.py:226-230
-            k = torch.relu(self.k_norm(qkv[:, :, 1].reshape(B, M * S, H * D))) + self.eps
-            # under autocast the norm runs in fp32 while the projection is bf16/fp16: the reference's matmuls cast q, k back to
-            # the autocast dtype, the operator takes one element type for all token tensors
+            # q_norm / k_norm (nn.RMSNorm over the full channel dim, eps = finfo(dtype).eps as constructed at mhla.py:166-167)
+            # -> relu -> + eps (mhla.py:226-230): one HIP kernel per tensor and direction (mhla_qk_prologue), reading the q / k
+            # slices of the packed projection in place; its fp32 result goes back to the projection dtype, as the reference's
+            # matmuls do under autocast -- the operator takes one element type for all token tensors
+            if (H * D) % 8 == 0 and H * D <= 4096:
+                eq = self.q_norm.eps if self.q_norm.eps is not None else torch.finfo(qkv.dtype).eps
+                ek = self.k_norm.eps if self.k_norm.eps is not None else torch.finfo(qkv.dtype).eps
+                q = qk_prologue(qkv[:, :, 0].reshape(B, M * S, H * D), self.q_norm.weight, eq, self.eps)
+                k = qk_prologue(qkv[:, :, 1].reshape(B, M * S, H * D), self.k_norm.weight, ek, self.eps)
+            else:
+                q = torch.relu(self.q_norm(qkv[:, :, 0].reshape(B, M * S, H * D))) + self.eps
+                k = torch.relu(self.k_norm(qkv[:, :, 1].reshape(B, M * S, H * D))) + self.eps
             q, k = q.to(qkv.dtype), k.to(qkv.dtype)
             out = mhla_blockmix(q.reshape(B, M * S, H, D), k.reshape(B, M * S, H, D), qkv[:, :, 2], W, eps=self.eps)
         else:

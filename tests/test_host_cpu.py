@@ -215,3 +215,41 @@ def test_bench_gpus_flag_spawns_ranks_before_touching_the_gpu():
     assert r.returncode != 0
     assert "ranks share devices" in r.stderr and "needs a GPU" in r.stderr
     assert "spawn_local_ranks" in r.stderr
+
+
+def test_c1_dit_s2_single_latent_cpu_plumbing():
+    """BASELINE.json configs[0]: mhla_dit DiT-S/2, one 256x256 image (32x32x4 latent), eager MHLA on the CPU -- the plumbing
+    configuration.  The thin in-repo host runs on the CPU with every attention module evaluated by the oracle's restatement of
+    MHLA4DiT.forward (the reference's eager op sequence; the product modules have no CPU path), end to end: patch embedding,
+    block-major adapter, 12 adaLN blocks, final layer, unpatchify.  Checks shapes, finiteness, the adapter's inverse and that
+    the class / timestep conditioning reaches the output."""
+    import time
+    from mhla_amd.hosts import DiT_MHLA, DiT_configs
+    from oracle import mhla_oracle as orc
+    torch.manual_seed(0)
+    m = DiT_MHLA(input_size=32, **DiT_configs()["DiT-S/2"])
+    with torch.no_grad():   # adaLN-Zero leaves every block an identity at init: give the plumbing run non-trivial activations
+        for prm in m.parameters():
+            if prm.requires_grad and float(prm.abs().max()) == 0.0:
+                prm.normal_(std=0.02)
+    m.eval()
+    assert len(m.blocks) == 12 and m.blocks[0].attn.num_heads == 6 and m.blocks[0].attn.head_dim == 64
+    assert m.blocks[0].attn.num_pieces == 16 and m.blocks[0].attn.block_size == 16      # block_size = 16: mhla_dit/README.md:23
+    for blk in m.blocks:
+        sd = {k: v.detach() for k, v in blk.attn.state_dict().items()}
+        at = blk.attn
+        blk.attn.forward = (lambda sd, at: lambda z: orc.dit_module_forward(
+            sd, z.reshape(z.shape[0], at.num_pieces, at.block_size, z.shape[-1]), at.num_heads, at.block_size, at.embed_len
+        ).reshape(z.shape))(sd, at)
+    x = torch.randn(1, 4, 32, 32)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        y = m(x, torch.tensor([500]), torch.tensor([7]))
+        y2 = m(x, torch.tensor([500]), torch.tensor([8]))
+        y3 = m(x, torch.tensor([10]), torch.tensor([7]))
+    dt = (time.perf_counter() - t0) / 3
+    assert y.shape == (1, 8, 32, 32) and torch.isfinite(y).all()
+    assert (y - y2).abs().max() > 0 and (y - y3).abs().max() > 0
+    tok = torch.arange(256)
+    assert torch.equal(tok[m.to_block_major][m.to_raster], tok)
+    print(f"C1 DiT-S/2 256x256 single latent, CPU eager (oracle attention): {dt * 1e3:.0f} ms per forward, {256 / dt:.0f} tokens/s")
