@@ -86,6 +86,27 @@ template <> __device__ __forceinline__ void gst<uint2>(void* p, uint2 v) {
     *(MHLA_GLOBAL_AS u32x2_t*)(p) = u32x2_t{v.x, v.y};
 }
 
+// Streaming (touch-once) variants: the nontemporal hint marks the lines evict-first, so that token rows which one workgroup
+// reads once do not displace the block summaries that several workgroups share in L2.  MHLA_NT=0 at build time disables them.
+#ifndef MHLA_NT
+#define MHLA_NT 1
+#endif
+__device__ __forceinline__ uint4 gld_stream16(const void* p) {
+#if MHLA_NT
+    const u32x4_t v = __builtin_nontemporal_load((const MHLA_GLOBAL_AS u32x4_t*)(p));
+    return make_uint4(v[0], v[1], v[2], v[3]);
+#else
+    return gld<uint4>(p);
+#endif
+}
+__device__ __forceinline__ void gst_stream16(void* p, uint4 v) {
+#if MHLA_NT
+    __builtin_nontemporal_store(u32x4_t{v.x, v.y, v.z, v.w}, (MHLA_GLOBAL_AS u32x4_t*)(p));
+#else
+    gst<uint4>(p, v);
+#endif
+}
+
 // Token-major view [B, N, H, D]; element strides; D contiguous.
 struct View {
     const void* ptr;

@@ -189,10 +189,11 @@ __global__ __launch_bounds__(FT8, 4) void k_fs_state(const FsStateArgs a) {
         R.ninv = 0.f;
         if (srow < rv) {
             const long tr = tok_row(a.idx, (long)j * S + c0 + srow);
-            R.x = gld<uint4>(xb + tr * a.x.sn + scol);
-            R.y = gld<uint4>(yb + tr * a.y.sn + scol);
+            // MODE 1: Q and dO are read again by the next kernel (dQ): regular loads; O is not: streaming.  MODE 0: K, V stream.
+            R.x = MODE == 1 ? gld<uint4>(xb + tr * a.x.sn + scol) : gld_stream16(xb + tr * a.x.sn + scol);
+            R.y = MODE == 1 ? gld<uint4>(yb + tr * a.y.sn + scol) : gld_stream16(yb + tr * a.y.sn + scol);
             if (a.normalize) {
-                R.t = gld<uint4>(tb + tr * a.t.sn + scol);
+                R.t = MODE == 1 ? gld_stream16(tb + tr * a.t.sn + scol) : gld<uint4>(tb + tr * a.t.sn + scol);
                 if (MODE == 1) R.ninv = gld<float>(a.ninv + ((long)bh * M + j) * S + c0 + srow);
             }
         }
@@ -386,9 +387,9 @@ __global__ __launch_bounds__(FT8, 4) void k_fs_state_fwd(const FsStateArgs a) {
         R.x = R.y = R.t = make_uint4(0, 0, 0, 0);
         if (srow < rv) {
             const long tr = tok_row(a.idx, p + srow);
-            R.x = gld<uint4>(xb + tr * a.x.sn + scol);
-            R.y = gld<uint4>(yb + tr * a.y.sn + scol);
-            if (tile_t) R.t = gld<uint4>(tb + tr * a.t.sn + scol);
+            R.x = gld_stream16(xb + tr * a.x.sn + scol);                     // K, V: not read again in the forward
+            R.y = gld_stream16(yb + tr * a.y.sn + scol);
+            if (tile_t) R.t = gld<uint4>(tb + tr * a.t.sn + scol);          // Q: the output kernel reads it next
         }
     };
     auto commit = [&](const TileRegs3& R, int rv, int rfill) {
@@ -626,7 +627,9 @@ __device__ __forceinline__ uint4 mask_pos8(uint4 v, uint4 m) {
 }
 
 // One wave stores a staged 64 x 64 bf16 tile: 8 passes of 8 full 128-byte rows.
-template <bool MASK>
+// STREAM: the rows are not read again soon (gradients): nontemporal stores; the forward's output, which the backward's first
+// kernel reads back, goes through the regular path
+template <bool MASK, bool STREAM = true>
 __device__ __forceinline__ void store64(u16* __restrict__ base, long sn, const int* __restrict__ idx, long p0, int rv,
                                         const u16* __restrict__ Os, const u16* __restrict__ mbase, long msn, int lane) {
 #pragma unroll
@@ -636,7 +639,8 @@ __device__ __forceinline__ void store64(u16* __restrict__ base, long sn, const i
             const long tr = tok_row(idx, p0 + row);
             uint4 v = *reinterpret_cast<const uint4*>(Os + row * GLD + c);
             if (MASK) v = mask_pos8(v, *reinterpret_cast<const uint4*>(mbase + tr * msn + c));
-            *reinterpret_cast<uint4*>(base + tr * sn + c) = v;
+            if (STREAM) gst_stream16(base + tr * sn + c, v);
+            else        gst<uint4>(base + tr * sn + c, v);
         }
     }
 }

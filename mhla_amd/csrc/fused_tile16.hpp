@@ -112,7 +112,7 @@ __device__ __forceinline__ void load_a64(bf16x8 (&a)[4][2], const u16* __restric
         const int row = st * 16 + m;
         const u16* src = base + tok_row(idx, p0 + (row < rv ? row : 0)) * sn + kg * 8;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) a[st][ks] = __builtin_bit_cast(bf16x8, gld<uint4>(src + ks * 32));
+        for (int ks = 0; ks < 2; ++ks) a[st][ks] = __builtin_bit_cast(bf16x8, gld_stream16(src + ks * 32));
     }
 }
 // relu(x) + eps on loaded operands (MHLA_FLAG_RELU_EPS), applied where they are consumed
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(FT8, 2) void k_t16_out(const FsOutArgs a) {
             wave_lds_fence();
             stage64(Gb, acc, lane);
             wave_lds_fence();
-            store64<false>(ob, a.o.sn, a.idx, p0, rv, Gb, nullptr, 0, lane);
+            store64<false, false>(ob, a.o.sn, a.idx, p0, rv, Gb, nullptr, 0, lane);
         } else {
             store64_direct<false>(ob, a.o.sn, a.idx, p0, rv, acc, nullptr, 0, lane);
         }
