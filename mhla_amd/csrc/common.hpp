@@ -27,40 +27,6 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
 }
 __device__ __forceinline__ unsigned short cvt_bf16(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
 
-// 4-element vector I/O per dtype (16 B for f32, 8 B for 16-bit types).
-template <typename T> struct Io;
-template <> struct Io<float> {
-    static __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-    static __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
-};
-template <> struct Io<bf16_t> {
-    static __device__ __forceinline__ f32x4 ld4(const bf16_t* p) {
-        uint2 r = *reinterpret_cast<const uint2*>(p);
-        f32x4 v;
-        v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
-        v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
-        return v;
-    }
-    static __device__ __forceinline__ void st4(bf16_t* p, f32x4 v) {
-        uint2 r;
-        r.x = pack_bf16x2(v[0], v[1]);
-        r.y = pack_bf16x2(v[2], v[3]);
-        *reinterpret_cast<uint2*>(p) = r;
-    }
-};
-template <> struct Io<f16_t> {
-    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-    static __device__ __forceinline__ f32x4 ld4(const f16_t* p) {
-        h4 r = *reinterpret_cast<const h4*>(p);
-        f32x4 v; v[0] = (float)r[0]; v[1] = (float)r[1]; v[2] = (float)r[2]; v[3] = (float)r[3];
-        return v;
-    }
-    static __device__ __forceinline__ void st4(f16_t* p, f32x4 v) {
-        h4 r; r[0] = (_Float16)v[0]; r[1] = (_Float16)v[1]; r[2] = (_Float16)v[2]; r[3] = (_Float16)v[3];
-        *reinterpret_cast<h4*>(p) = r;
-    }
-};
-
 // Loads / stores through an explicit global (address space 1) pointer.  Pointers that come out of an argument struct or a
 // select are generic to the compiler: it then emits flat_load, which counts on vmcnt AND lgkmcnt and may complete out of
 // order, so every use is preceded by s_waitcnt vmcnt(0) lgkmcnt(0) -- software pipelines of loads collapse into
@@ -87,7 +53,8 @@ template <> __device__ __forceinline__ void gst<uint2>(void* p, uint2 v) {
 }
 
 // Streaming (touch-once) variants: the nontemporal hint marks the lines evict-first, so that token rows which one workgroup
-// reads once do not displace the block summaries that several workgroups share in L2.  MHLA_NT=0 at build time disables them.
+// reads once do not displace the block summaries that later kernels (or other workgroups) read again.  MHLA_NT=0 at build
+// time disables them.
 #ifndef MHLA_NT
 #define MHLA_NT 1
 #endif
@@ -106,6 +73,41 @@ __device__ __forceinline__ void gst_stream16(void* p, uint4 v) {
     gst<uint4>(p, v);
 #endif
 }
+
+// 4-element vector I/O per dtype (16 B for f32, 8 B for 16-bit types).  (Nontemporal variants of these loads were measured on
+// the split-operand / generic kernels in round 2: 1-11 % slower on every shape, so these paths keep regular loads.)
+template <typename T> struct Io;
+template <> struct Io<float> {
+    static __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+    static __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+};
+template <> struct Io<bf16_t> {
+    static __device__ __forceinline__ f32x4 ld4(const bf16_t* p) {
+        const uint2 r = *reinterpret_cast<const uint2*>(p);
+        f32x4 v;
+        v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
+        v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
+        return v;
+    }
+    static __device__ __forceinline__ void st4(bf16_t* p, f32x4 v) {
+        uint2 r;
+        r.x = pack_bf16x2(v[0], v[1]);
+        r.y = pack_bf16x2(v[2], v[3]);
+        *reinterpret_cast<uint2*>(p) = r;
+    }
+};
+template <> struct Io<f16_t> {
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ f32x4 ld4(const f16_t* p) {
+        const h4 r = *reinterpret_cast<const h4*>(p);
+        f32x4 v; v[0] = (float)r[0]; v[1] = (float)r[1]; v[2] = (float)r[2]; v[3] = (float)r[3];
+        return v;
+    }
+    static __device__ __forceinline__ void st4(f16_t* p, f32x4 v) {
+        h4 r; r[0] = (_Float16)v[0]; r[1] = (_Float16)v[1]; r[2] = (_Float16)v[2]; r[3] = (_Float16)v[3];
+        *reinterpret_cast<h4*>(p) = r;
+    }
+};
 
 // Token-major view [B, N, H, D]; element strides; D contiguous.
 struct View {
