@@ -153,6 +153,17 @@ BmWs bm_carve(void* ws, int B, int H, int M, int S, int D, bool sum16) {
 }
 
 // ---- fast path (bf16, D = 64, M <= 64, q_den aliasing q_num): see fused.hpp ----
+// summaries of single-chunk blocks (S <= 64): the straight-line kernel, instantiated on (gather map, normaliser)
+template <int MODE>
+static int launch_state1c(const fast::FsStateArgs& sa, int njg, int BH, hipStream_t st, const char* name) {
+    const dim3 g(njg, BH), t(fast::FT8);
+    const bool idx = sa.idx != nullptr, norm = sa.normalize != 0;
+    if (idx && norm) return launch(fast::k_fs_state1c<MODE, true, true>, g, t, fast::FS_STATE1C_SMEM, st, name, sa);
+    if (idx) return launch(fast::k_fs_state1c<MODE, true, false>, g, t, fast::FS_STATE1C_SMEM, st, name, sa);
+    if (norm) return launch(fast::k_fs_state1c<MODE, false, true>, g, t, fast::FS_STATE1C_SMEM, st, name, sa);
+    return launch(fast::k_fs_state1c<MODE, false, false>, g, t, fast::FS_STATE1C_SMEM, st, name, sa);
+}
+
 struct FastWs {
     fast::u16 *state, *dstate;
     float *z, *ksum, *ninv, *dn, *dz, *dwp, *dksum;
@@ -393,7 +404,8 @@ static int bm_fwd_impl(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view 
         fast::FsStateArgs sa{};
         sa.x = cv(k_num); sa.y = cv(v); sa.t = cv(q_num); sa.idx = block_index; sa.state = f.state; sa.ksum = f.ksum;
         sa.z_out = f.z; sa.H = H; sa.M = M; sa.S = S; sa.eps = eps; sa.relu = relu; sa.normalize = normalize;
-        RC(launch(fast::k_fs_state_fwd<0>, dim3(f.njg, B * H), dim3(fast::FT8), fast::FS_STATE_FWD_SMEM, st, "k_fs_state_fwd", sa));
+        if (S <= 64) RC(launch_state1c<0>(sa, f.njg, B * H, st, "k_fs_state_fwd"));
+        else RC(launch(fast::k_fs_state_fwd<0>, dim3(f.njg, B * H), dim3(fast::FT8), fast::FS_STATE_FWD_SMEM, st, "k_fs_state_fwd", sa));
         if (normalize)
             RC(launch(fast::k_fs_wz<0>, dim3((S + fast::WZ_C - 1) / fast::WZ_C, B * H), dim3(fast::FT), 0, st, "k_fs_wz<0>", W, ldw, (const float*)f.z, f.ninv, M, S, eps));
         fast::FsOutArgs oa{};
@@ -518,14 +530,16 @@ int mhla_blockmix_bwd(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q
                 fast::FsStateArgs sa{};
                 sa.x = cv(k_num); sa.y = cv(v); sa.t = cv(q_num); sa.idx = block_index; sa.state = f.state; sa.ksum = f.ksum;
                 sa.z_out = f.z; sa.H = H; sa.M = M; sa.S = S; sa.eps = eps; sa.relu = relu; sa.normalize = normalize;
-                RC(launch(fast::k_fs_state_fwd<0>, dim3(f.njg, B * H), dim3(fast::FT8), fast::FS_STATE_FWD_SMEM, st, "k_fs_state_fwd", sa));
+                if (S <= 64) RC(launch_state1c<0>(sa, f.njg, B * H, st, "k_fs_state_fwd"));
+        else RC(launch(fast::k_fs_state_fwd<0>, dim3(f.njg, B * H), dim3(fast::FT8), fast::FS_STATE_FWD_SMEM, st, "k_fs_state_fwd", sa));
                 if (normalize)
                     RC(launch(fast::k_fs_wz<0>, dim3((S + fast::WZ_C - 1) / fast::WZ_C, B * H), dim3(fast::FT), 0, st, "k_fs_wz<0>", W, ldw, (const float*)f.z, f.ninv, M, S, eps));
             }
             fast::FsStateArgs ga{};
             ga.x = cv(q_num); ga.y = cv(dout); ga.t = cv(out); ga.idx = block_index; ga.W = W; ga.ldw = ldw; ga.ninv = ninv;
             ga.state = f.dstate; ga.dn = f.dn; ga.H = H; ga.M = M; ga.S = S; ga.eps = eps; ga.relu = relu; ga.normalize = normalize;
-            RC(launch(fast::k_fs_state<1>, dim3(f.njg, B * H), dim3(fast::FT8), fast::FS_STATE_SMEM, st, "k_fs_state<1>", ga));
+            if (S <= 64) RC(launch_state1c<1>(ga, f.njg, B * H, st, "k_fs_state<1>"));
+            else RC(launch(fast::k_fs_state<1>, dim3(f.njg, B * H), dim3(fast::FT8), fast::FS_STATE_SMEM, st, "k_fs_state<1>", ga));
             // dW needs only dG^T, KV^T, dn and z, all complete here; dz = W^T dn (needed by the token-gradient kernels) rides in
             // the same launch as extra workgroups
             fast::FsDwArgs da{f.dstate, state, normalize ? f.dn : nullptr, z, f.dwp, M, S, f.njg, W, ldw, f.dz};

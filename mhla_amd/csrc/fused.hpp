@@ -364,8 +364,20 @@ constexpr int FS_STATE_FWD_SMEM = 3 * 64 * TLD * 2 + (8 * 64 + 64) * 4;
 // Forward summaries (MODE 0 only): Q tile staged in LDS with K and V, two blocks ahead in registers.
 struct TileRegs3 { uint4 x, y, t; };
 
+#ifndef FSV_NOCOMP
+#define FSV_NOCOMP 0
+#endif
+#ifndef FSV_NOSIDE
+#define FSV_NOSIDE 0
+#endif
+#ifndef FSV_QNT
+#define FSV_QNT 0
+#endif
+#ifndef FSV_LB
+#define FSV_LB 4
+#endif
 template <int MODE>
-__global__ __launch_bounds__(FT8, 4) void k_fs_state_fwd(const FsStateArgs a) {
+__global__ __launch_bounds__(FT8, FSV_LB) void k_fs_state_fwd(const FsStateArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u16* Xs = reinterpret_cast<u16*>(smem_raw);
     u16* Ys = Xs + 64 * TLD;
@@ -389,7 +401,7 @@ __global__ __launch_bounds__(FT8, 4) void k_fs_state_fwd(const FsStateArgs a) {
             const long tr = tok_row(a.idx, p + srow);
             R.x = gld_stream16(xb + tr * a.x.sn + scol);                     // K, V: not read again in the forward
             R.y = gld_stream16(yb + tr * a.y.sn + scol);
-            if (tile_t) R.t = gld<uint4>(tb + tr * a.t.sn + scol);          // Q: the output kernel reads it next
+            if (tile_t) R.t = FSV_QNT ? gld_stream16(tb + tr * a.t.sn + scol) : gld<uint4>(tb + tr * a.t.sn + scol);          // Q: the output kernel reads it next
         }
     };
     auto commit = [&](const TileRegs3& R, int rv, int rfill) {
@@ -506,6 +518,10 @@ __global__ __launch_bounds__(FT8, 4) void k_fs_state_fwd(const FsStateArgs a) {
             const int j = jg * IT + jj;
             if (j >= M) return;
             uint4 tq = R.t;
+#if FSV_NOCOMP >= 2
+            acc[jj][0][0] += __uint_as_float(R.x.x ^ R.y.y);
+            acc[jj][1][1] += __uint_as_float(R.x.z ^ R.y.w);
+#else
             if (srow < rfill) {
                 uint4 x = R.x;
                 if (a.relu && srow < S) {
@@ -515,11 +531,18 @@ __global__ __launch_bounds__(FT8, 4) void k_fs_state_fwd(const FsStateArgs a) {
                 *reinterpret_cast<uint4*>(Xs + srow * TLD + scol) = x;
                 *reinterpret_cast<uint4*>(Ys + srow * TLD + scol) = R.y;
             }
+#endif
             if (jj + 2 < IT && j + 2 < M) issue((long)(j + 2) * S, S, R);
+#if FSV_NOCOMP < 2
             __syncthreads();
+#endif
             f32x4 ks[2];
             ks[0] = ks[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-            for (int k0 = 0; k0 < rfill; k0 += 32) {
+#if FSV_NOCOMP == 1
+            acc[jj][0][0] += bf(Xs[tid]);
+            acc[jj][1][1] += bf(Ys[tid]);
+#endif
+            for (int k0 = 0; k0 < (FSV_NOCOMP ? 0 : rfill); k0 += 32) {
                 const bf16x8 av = tr_read8(Ys, TLD, k0, dt * 16, lane);
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
@@ -528,7 +551,7 @@ __global__ __launch_bounds__(FT8, 4) void k_fs_state_fwd(const FsStateArgs a) {
                     if (a.normalize) ks[t] = mfma_bf16(ones, bv, ks[t]);
                 }
             }
-            if (a.normalize && dt == 0 && lane < 16) {   // every row of the ones-product is the column sum: row 0 lives in lanes 0..15
+            if (a.normalize && !FSV_NOSIDE && dt == 0 && lane < 16) {   // every row of the ones-product is the column sum: row 0 lives in lanes 0..15
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     const int col = (2 * th + t) * 16 + lane;
@@ -536,8 +559,10 @@ __global__ __launch_bounds__(FT8, 4) void k_fs_state_fwd(const FsStateArgs a) {
                     a.ksum[((long)bh * M + j) * 64 + col] = ks[t][0];
                 }
             }
+#if FSV_NOCOMP < 2
             __syncthreads();                           // tiles consumed; column sums visible
-            if (a.normalize) {
+#endif
+            if (a.normalize && !FSV_NOSIDE) {
                 const f32x4 lo = *reinterpret_cast<const f32x4*>(ksum_s + scol), hi = *reinterpret_cast<const f32x4*>(ksum_s + scol + 4);
                 const unsigned qw[4] = {tq.x, tq.y, tq.z, tq.w};
                 float d = __uint_as_float(qw[0] << 16) * lo[0] + __uint_as_float(qw[0] & 0xffff0000u) * lo[1] +
@@ -600,6 +625,171 @@ __global__ __launch_bounds__(FT8, 4) void k_fs_state_fwd(const FsStateArgs a) {
         }
 }
 
+// -------------------------------------------------------------------------------------------------
+// k_fs_state1c<MODE, IDX, NORM>: the summaries of 8 blocks of <= 64 tokens each (the common case S <= 64), both directions, written
+// as straight-line code: every global load of the 8-step pipeline is unconditional (rows / blocks past the end are clamped to valid
+// addresses and zeroed after they arrive), and the small side outputs (ksum, z; dn) are parked in LDS and stored once, with the
+// summaries, after the last block.  The earlier kernels guarded loads and 4-byte side stores with divergent branches inside
+// the pipeline: the compiler then has to assume the worst at every join (s_waitcnt vmcnt(0) right after the prefetch was
+// issued), which serialised the loads -- 63 -> 41 us at C2 for the forward summaries once the side stores were out of the loop.
+//   MODE 0: x = K (relu + eps), y = V, t = Q (relu + eps):  state = V_j^T K_j, ksum_j, z_j[s] = Q_j[s] . ksum_j
+//   MODE 1: x = Q (relu + eps), y = dO, t = O:              state = dP_i^T Q_i, dP = dO / n, dn_i[s] = -(dO_i[s] . O_i[s]) / n_i[s]
+// -------------------------------------------------------------------------------------------------
+constexpr int FS_STATE1C_SMEM = 2 * 64 * TLD * 2 + (64 + 2 * IT * 64) * 4;
+
+template <int MODE, bool IDX, bool NORM>
+__global__ __launch_bounds__(FT8, 4) void k_fs_state1c(const FsStateArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u16* Xs = reinterpret_cast<u16*>(smem_raw);
+    u16* Ys = Xs + 64 * TLD;
+    float* ksum_s = reinterpret_cast<float*>(Ys + 64 * TLD);   // [64]      column sums of the block in flight (MODE 0)
+    float* side = ksum_s + 64;                                  // [8][64]   z (MODE 0) / dn (MODE 1) of the 8 blocks
+    float* ksum_all = side + IT * 64;                           // [8][64]   (MODE 0)
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int dt = wave & 3, th = wave >> 2;
+    const int jg = blockIdx.x, bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
+    const int S = a.S, M = a.M, njg = gridDim.x;
+    const u16* xb = (const u16*)a.x.ptr + b * a.x.sb + h * a.x.sh;
+    const u16* yb = (const u16*)a.y.ptr + b * a.y.sb + h * a.y.sh;
+    const u16* tb = NORM ? (const u16*)a.t.ptr + b * a.t.sb + h * a.t.sh : nullptr;
+    const int srow = tid >> 3, scol = (tid & 7) * 8;            // staging: thread -> (row, 8 columns = 16 bytes)
+    const int lrow = min(srow, S - 1);                          // rows past the block: a valid address, zeroed on arrival
+    const bool valid = srow < S;
+    const int nblk = min(IT, M - jg * IT);                      // blocks of this group (uniform)
+    const int rfill = (S + 31) & ~31;
+
+    // gather map: the 8 blocks' row indices are fetched up front, so the pipeline's loads depend on nothing in flight
+    int tix[IDX ? IT : 1];
+    if (IDX) {
+#pragma unroll
+        for (int jj = 0; jj < IT; ++jj) tix[jj] = gld<int>(a.idx + (long)(jg * IT + min(jj, nblk - 1)) * S + lrow);
+    }
+    auto issue = [&](auto jjc, TileRegs& R) {
+        constexpr int jj = decltype(jjc)::value;
+        const int jb = jg * IT + min(jj, nblk - 1);              // (uniform) blocks past the end: the last one again, never used
+        const long tr = IDX ? (long)tix[IDX ? jj : 0] : (long)jb * S + lrow;
+        // MODE 0: K, V are not read again in the forward (streaming loads); Q is (k_t16_out).  MODE 1: Q, dO are read by the
+        // dQ kernel next; O is not.
+        R.x = MODE == 1 ? gld<uint4>(xb + tr * a.x.sn + scol) : gld_stream16(xb + tr * a.x.sn + scol);
+        R.y = MODE == 1 ? gld<uint4>(yb + tr * a.y.sn + scol) : gld_stream16(yb + tr * a.y.sn + scol);
+        if (NORM) {
+            R.t = MODE == 1 ? gld_stream16(tb + tr * a.t.sn + scol) : gld<uint4>(tb + tr * a.t.sn + scol);
+            if (MODE == 1) R.ninv = gld<float>(a.ninv + ((long)bh * M + jb) * S + lrow);
+        }
+    };
+
+    // accumulators of the block pair in flight; finished pairs are kept packed (bf16 x 2: even block low, odd block high)
+    f32x4 acc[2][2];
+    unsigned pk[IT / 2][2][4];
+    s16x8 ones_;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) ones_[t] = (short)0x3F80;       // bf16 1.0
+    const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_);
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+
+    TileRegs R0, R1;
+    issue(std::integral_constant<int, 0>{}, R0);
+    issue(std::integral_constant<int, 1>{}, R1);
+    auto step = [&](auto jjc, auto fullc, TileRegs& R) {
+        constexpr int jj = decltype(jjc)::value;
+        constexpr bool FULL = decltype(fullc)::value;
+        acc[jj & 1][0] = acc[jj & 1][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (FULL || jj < nblk) {                                // (uniform) short last group
+            uint4 x = R.x, y = R.y, tq = zero4;
+            if (NORM) tq = R.t;
+            if (a.relu) {
+                x = relu_eps8(x, a.eps);
+                if (MODE == 0 && NORM) tq = relu_eps8(tq, a.eps);
+            }
+            if (MODE == 1 && NORM) {                            // dn = -(dO . O) / n and dP = dO / n (rounded to bf16)
+                float d = dot8(y, tq);
+                d += __shfl_xor(d, 1, 64);
+                d += __shfl_xor(d, 2, 64);
+                d += __shfl_xor(d, 4, 64);
+                if ((tid & 7) == 0) side[jj * 64 + srow] = -d * R.ninv;
+                unsigned yw[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    yw[i] = pack_bf16x2(__uint_as_float(yw[i] << 16) * R.ninv, __uint_as_float(yw[i] & 0xffff0000u) * R.ninv);
+                y = make_uint4(yw[0], yw[1], yw[2], yw[3]);
+            }
+            // (component-wise selects: `valid ? x : zero` on the struct type becomes a select of two stack addresses)
+            *reinterpret_cast<uint4*>(Xs + srow * TLD + scol) = make_uint4(valid ? x.x : 0u, valid ? x.y : 0u, valid ? x.z : 0u, valid ? x.w : 0u);
+            *reinterpret_cast<uint4*>(Ys + srow * TLD + scol) = make_uint4(valid ? y.x : 0u, valid ? y.y : 0u, valid ? y.z : 0u, valid ? y.w : 0u);
+            if (jj + 2 < IT) issue(std::integral_constant<int, (jj + 2 < IT ? jj + 2 : 0)>{}, R);
+            __syncthreads();
+            f32x4 ks[2];
+            ks[0] = ks[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int k0 = 0; k0 < rfill; k0 += 32) {
+                const bf16x8 av = tr_read8(Ys, TLD, k0, dt * 16, lane);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const bf16x8 bv = tr_read8(Xs, TLD, k0, (2 * th + t) * 16, lane);
+                    acc[jj & 1][t] = mfma_bf16(av, bv, acc[jj & 1][t]);
+                    if (MODE == 0 && NORM) ks[t] = mfma_bf16(ones, bv, ks[t]);   // column sums of K ride on the matrix pipe
+                }
+            }
+            if (MODE == 0 && NORM && dt == 0 && lane < 16) {    // every row of the ones-product is the column sum
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int col = (2 * th + t) * 16 + lane;
+                    ksum_s[col] = ks[t][0];
+                    ksum_all[jj * 64 + col] = ks[t][0];
+                }
+            }
+            __syncthreads();                                    // tiles consumed; column sums visible
+            if (MODE == 0 && NORM) {                            // z_j[s] = Q_j[s] . ksum_j from the thread's own piece of Q
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(ksum_s + scol), hi = *reinterpret_cast<const f32x4*>(ksum_s + scol + 4);
+                const unsigned qw[4] = {tq.x, tq.y, tq.z, tq.w};
+                float d = __uint_as_float(qw[0] << 16) * lo[0] + __uint_as_float(qw[0] & 0xffff0000u) * lo[1] +
+                          __uint_as_float(qw[1] << 16) * lo[2] + __uint_as_float(qw[1] & 0xffff0000u) * lo[3] +
+                          __uint_as_float(qw[2] << 16) * hi[0] + __uint_as_float(qw[2] & 0xffff0000u) * hi[1] +
+                          __uint_as_float(qw[3] << 16) * hi[2] + __uint_as_float(qw[3] & 0xffff0000u) * hi[3];
+                d += __shfl_xor(d, 1, 64);
+                d += __shfl_xor(d, 2, 64);
+                d += __shfl_xor(d, 4, 64);
+                if ((tid & 7) == 0) side[jj * 64 + srow] = d;
+            }
+        }
+        if (jj & 1) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pk[jj >> 1][t][r] = pack_bf16x2(acc[0][t][r], acc[1][t][r]);
+        }
+    };
+    auto run = [&](auto fullc) {
+        step(std::integral_constant<int, 0>{}, fullc, R0);
+        step(std::integral_constant<int, 1>{}, fullc, R1);
+        step(std::integral_constant<int, 2>{}, fullc, R0);
+        step(std::integral_constant<int, 3>{}, fullc, R1);
+        step(std::integral_constant<int, 4>{}, fullc, R0);
+        step(std::integral_constant<int, 5>{}, fullc, R1);
+        step(std::integral_constant<int, 6>{}, fullc, R0);
+        step(std::integral_constant<int, 7>{}, fullc, R1);
+    };
+    if (nblk == IT) run(std::true_type{});
+    else run(std::false_type{});
+
+    // 16-byte interleaved store: lane -> (d2 = 16 dt + 4 (lane >> 4) + r, d1 = 16 (2 th + t) + (lane & 15))
+    u16* sb = a.state + ((long)bh * njg + jg) * FE * IT;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int d2 = dt * 16 + (lane >> 4) * 4 + r, d1 = (2 * th + t) * 16 + (lane & 15);
+            gst<uint4>(sb + ((long)d2 * FD + d1) * IT, make_uint4(pk[0][t][r], pk[1][t][r], pk[2][t][r], pk[3][t][r]));
+        }
+    if (NORM) {                                                 // side outputs: thread -> (block tid >> 6, position / column tid & 63)
+        __syncthreads();
+        const int jj = tid >> 6, c = tid & 63, j = jg * IT + jj;
+        if (jj < nblk) {
+            if (c < S) gst<float>((MODE == 0 ? a.z_out : a.dn) + ((long)bh * M + j) * S + c, side[jj * 64 + c]);
+            if (MODE == 0) gst<float>(a.ksum + ((long)bh * M + j) * 64 + c, ksum_all[jj * 64 + c]);
+        }
+    }
+}
+
 // XCD-aware logical work index (bijective): workgroups that share a (b,h)'s summaries land on one XCD's L2.
 __device__ __forceinline__ int xcd_swizzle(int wg, int nwg) {
     const int xcd = wg & 7, slot = wg >> 3, q = nwg >> 3, r = nwg & 7;
@@ -632,6 +822,9 @@ __device__ __forceinline__ uint4 mask_pos8(uint4 v, uint4 m) {
 template <bool MASK, bool STREAM = true>
 __device__ __forceinline__ void store64(u16* __restrict__ base, long sn, const int* __restrict__ idx, long p0, int rv,
                                         const u16* __restrict__ Os, const u16* __restrict__ mbase, long msn, int lane) {
+#ifdef T16_NOSTORE
+    if (rv != 12345) return;
+#endif
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
         const int row = p * 8 + (lane >> 3), c = (lane & 7) * 8;

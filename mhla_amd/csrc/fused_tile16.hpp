@@ -18,7 +18,7 @@ constexpr int FS_GT16_BYTES = TT * GSLOT * 2;       // 147712 B
 // line is an HBM / MALL fetch for all of them): bytes in flight per wave are what counts.
 template <int TRANSW, bool TWO, int NBUF>
 __device__ __forceinline__ void mix16_tile_impl(u16* __restrict__ Gt, const u16* __restrict__ state_bh, int njg,
-                                                const float* __restrict__ W, int ldw, int M, int i0, int tid) {
+                                                const float* __restrict__ W, int ldw, int M, int i0, int tid, int rot) {
     const int wave = tid >> 6, lane = tid & 63, n = lane & 15, kg = lane >> 4;
     constexpr int UN = 4, NW = FT8 / 64;
     constexpr int NB = FE / 16 / NW / UN;   // 8 batches per wave
@@ -27,11 +27,16 @@ __device__ __forceinline__ void mix16_tile_impl(u16* __restrict__ Gt, const u16*
     const u16* g0 = state_bh + (long)min(kg, njg - 1) * FE * IT + n * IT;
     const u16* g1 = state_bh + (long)min(4 + kg, njg - 1) * FE * IT + n * IT;
     auto load_batch = [&](uint4 (&av)[UN][2], int bt) {
-        const long et0 = (long)(wave + NW * bt) * UN;
+        const long et0 = (long)(wave + NW * ((bt + rot) & (NB - 1))) * UN;
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
+#ifdef T16_NOMIXLOAD
+            av[u][0] = make_uint4(tid, bt, u, 0x3f803f80u);
+            if (TWO) av[u][1] = make_uint4(tid, bt, u, 0x3f803f80u);
+#else
             av[u][0] = gld<uint4>(g0 + (et0 + u) * 16 * IT);
             if (TWO) av[u][1] = gld<uint4>(g1 + (et0 + u) * 16 * IT);
+#endif
         }
     };
     uint4 buf[NBUF][UN][2];
@@ -79,7 +84,7 @@ __device__ __forceinline__ void mix16_tile_impl(u16* __restrict__ Gt, const u16*
         }
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
-            const int et = (wave + NW * bt) * UN + u, d2 = et >> 2, d1 = (et & 3) * 16 + kg * 4;
+            const int et = (wave + NW * ((bt + rot) & (NB - 1))) * UN + u, d2 = et >> 2, d1 = (et & 3) * 16 + kg * 4;
             uint2 pk;
             pk.x = pack_bf16x2(c[u][0], c[u][1]);
             pk.y = pack_bf16x2(c[u][2], c[u][3]);
@@ -95,10 +100,17 @@ __device__ __forceinline__ void mix16_tile_impl(u16* __restrict__ Gt, const u16*
 
 template <int TRANSW, int NBUF>
 __device__ __forceinline__ void mix16_tile_to_lds(u16* __restrict__ Gt, const u16* __restrict__ state_bh, int njg,
-                                                  const float* __restrict__ W, int ldw, int M, int i0, int tid) {
-    if (njg > 4) mix16_tile_impl<TRANSW, true, NBUF>(Gt, state_bh, njg, W, ldw, M, i0, tid);
-    else         mix16_tile_impl<TRANSW, false, NBUF>(Gt, state_bh, njg, W, ldw, M, i0, tid);
+                                                  const float* __restrict__ W, int ldw, int M, int i0, int tid, int rot) {
+    if (njg > 4) mix16_tile_impl<TRANSW, true, NBUF>(Gt, state_bh, njg, W, ldw, M, i0, tid, rot);
+    else         mix16_tile_impl<TRANSW, false, NBUF>(Gt, state_bh, njg, W, ldw, M, i0, tid, rot);
 }
+// The tile workgroups of one (b,h) run side by side on one XCD and stream the same 512 KB: each starts at a different
+// eighth of it (batch rotation), so that what is in flight towards HBM at any moment are DIFFERENT lines (the others' later
+// requests for them are L2 hits), instead of every line being awaited by all of them at once.
+#ifndef T16_ROT
+#define T16_ROT 0
+#endif
+__device__ __forceinline__ int tile_rot(int it, int ntt) { return T16_ROT ? (it * 8 / ntt) & 7 : 0; }
 
 // A operands of a 64-row chunk straight from a token view: a[st][ks] = rows 16 st + (lane & 15), columns 32 ks + 8 (lane >> 4)
 // .. + 7.  Rows beyond rv read the block's first row (valid memory, finite values): every consumer of these operands produces
@@ -112,7 +124,11 @@ __device__ __forceinline__ void load_a64(bf16x8 (&a)[4][2], const u16* __restric
         const int row = st * 16 + m;
         const u16* src = base + tok_row(idx, p0 + (row < rv ? row : 0)) * sn + kg * 8;
 #pragma unroll
+#ifdef T16_NOTOK
+        for (int ks = 0; ks < 2; ++ks) a[st][ks] = __builtin_bit_cast(bf16x8, make_uint4(lane, (unsigned)(uintptr_t)src, ks, 0x3f803f80u));
+#else
         for (int ks = 0; ks < 2; ++ks) a[st][ks] = __builtin_bit_cast(bf16x8, gld_stream16(src + ks * 32));
+#endif
     }
 }
 // relu(x) + eps on loaded operands (MHLA_FLAG_RELU_EPS), applied where they are consumed
@@ -242,7 +258,7 @@ __global__ __launch_bounds__(FT8, 2) void k_t16_out(const FsOutArgs a) {
         load_blk(avA, ninvA, min(iA, M - 1), 0, S);
         load_blk(avB, ninvB, min(iB, M - 1), 0, S);
         trace_mark(a.trace, 1);
-        mix16_tile_to_lds<0, 3>(Gt, state_bh, a.njg, a.W, a.ldw, M, it * TT, tid);
+        mix16_tile_to_lds<0, 3>(Gt, state_bh, a.njg, a.W, a.ldw, M, it * TT, tid, tile_rot(it, ntt));
         trace_mark(a.trace, 2);
         __syncthreads();
         trace_mark(a.trace, 3);
@@ -254,7 +270,7 @@ __global__ __launch_bounds__(FT8, 2) void k_t16_out(const FsOutArgs a) {
         return;
     }
 
-    mix16_tile_to_lds<0, 3>(Gt, state_bh, a.njg, a.W, a.ldw, M, it * TT, tid);
+    mix16_tile_to_lds<0, 3>(Gt, state_bh, a.njg, a.W, a.ldw, M, it * TT, tid, tile_rot(it, ntt));
     __syncthreads();
     for (int bi = wave; bi < TT; bi += 8) {
         const int i = it * TT + bi;
@@ -372,7 +388,7 @@ __global__ __launch_bounds__(FT8, 2) void k_t16_bwd_dq(const FsTokArgs a) {
         load_g(gvA, sA, jAc, 0, S);
         load_q(qvA, jAc, 0, S);
         trace_mark(a.trace, 1);
-        mix16_tile_to_lds<0, 2>(Gt, a.state + sofs, a.njg, a.W, a.ldw, M, jgx * TT, tid);
+        mix16_tile_to_lds<0, 2>(Gt, a.state + sofs, a.njg, a.W, a.ldw, M, jgx * TT, tid, tile_rot(jgx, ntt));
         trace_mark(a.trace, 2);
         __syncthreads();
         trace_mark(a.trace, 3);
@@ -392,7 +408,7 @@ __global__ __launch_bounds__(FT8, 2) void k_t16_bwd_dq(const FsTokArgs a) {
         if (a.trace) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); trace_mark(a.trace, 6); }
         return;
     }
-    mix16_tile_to_lds<0, 2>(Gt, a.state + sofs, a.njg, a.W, a.ldw, M, jgx * TT, tid);
+    mix16_tile_to_lds<0, 2>(Gt, a.state + sofs, a.njg, a.W, a.ldw, M, jgx * TT, tid, tile_rot(jgx, ntt));
     __syncthreads();
     for (int bi = wave; bi < TT; bi += 8) {
         const int j = jgx * TT + bi;
@@ -500,7 +516,7 @@ __global__ __launch_bounds__(FT8, 2) void k_t16_bwd_dkv(const FsTokArgs a) {
         trace_mark(a.trace, 0);
         load_blk(kvA, vvA, min(jA, M - 1), 0, S);
         trace_mark(a.trace, 1);
-        mix16_tile_to_lds<1, 3>(Gt, a.dstate + sofs, a.njg, a.W, a.ldw, M, jgx * TT, tid);
+        mix16_tile_to_lds<1, 3>(Gt, a.dstate + sofs, a.njg, a.W, a.ldw, M, jgx * TT, tid, tile_rot(jgx, ntt));
         trace_mark(a.trace, 2);
         __syncthreads();
         trace_mark(a.trace, 3);
@@ -513,7 +529,7 @@ __global__ __launch_bounds__(FT8, 2) void k_t16_bwd_dkv(const FsTokArgs a) {
         if (a.trace) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); trace_mark(a.trace, 6); }
         return;
     }
-    mix16_tile_to_lds<1, 3>(Gt, a.dstate + sofs, a.njg, a.W, a.ldw, M, jgx * TT, tid);
+    mix16_tile_to_lds<1, 3>(Gt, a.dstate + sofs, a.njg, a.W, a.ldw, M, jgx * TT, tid, tile_rot(jgx, ntt));
     __syncthreads();
     for (int bi = wave; bi < TT; bi += 8) {
         const int j = jgx * TT + bi;

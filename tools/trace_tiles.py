@@ -3,8 +3,8 @@
 
 Uses the library's debugging hook (mhla_debug_set_trace): wave 0 of every workgroup stamps s_memtime at
   0 start | 1 own-block loads issued | 2 mixing done | 3 barrier passed | 4 first block done | 5 second block done | 6 stores drained
-Prints, per kernel, the median / p90 duration of each phase (in microseconds at 100 MHz s_memtime ticks) and the
-workgroup start-time distribution (dispatch rounds)."""
+Prints, per kernel, the median / p10 / p90 duration of each phase (microseconds at TICKS_PER_US = 2100 shader clocks) and the
+workgroup start-time distribution (dispatch rounds; indicative only, the counters of different CUs are not synchronised)."""
 import os
 import sys
 
@@ -62,8 +62,10 @@ for kI, nm in enumerate(names):
     # s_memtime counters are per XCD: spans and start offsets are taken within each XCD
     spans = [float(x[xcc == c, 6].max() - x[xcc == c, 0].min()) for c in range(8) if (xcc == c).any()]
     span = float(np.median(spans))
-    tick_us = kus.get(nm, float("nan")) * 0.97 / span   # the HIP-event duration includes launch overhead (~3 %)
-    print(f"== {nm}: {nwg} workgroups, {kus.get(nm, float('nan')):.1f} us by HIP events; per-XCD span {span:.0f} ticks -> {1 / tick_us:.1f} ticks/us")
+    # s_memtime counts shader clocks (about 2100 per us under this load); the counters of different CUs are not synchronised,
+    # so only differences within one workgroup are meaningful
+    tick_us = 1.0 / float(os.environ.get("TICKS_PER_US", "2100"))
+    print(f"== {nm}: {nwg} workgroups, {kus.get(nm, float('nan')):.1f} us by HIP events")
     d = np.diff(x[:, :7], axis=1) * tick_us
     life = (x[:, 6] - x[:, 0]) * tick_us
     print(f"   workgroup life median {np.median(life):.2f} p10 {np.percentile(life, 10):.2f} p90 {np.percentile(life, 90):.2f} us")
