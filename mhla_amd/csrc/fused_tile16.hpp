@@ -11,6 +11,8 @@ namespace fast {
 constexpr int TT = 16;                              // blocks per tile
 constexpr int GSLOT = FD * GLD + 8;                  // elements per mixed-summary slot (+16 B: spreads the 16 blocks over banks)
 constexpr int FS_GT16_BYTES = TT * GSLOT * 2;       // 147712 B
+// per-block side values of the tile (1 / n, dz, ksum or dksum: three [16][64] fp32 arrays) behind the mixed summaries
+constexpr int FS_T16_SMEM = FS_GT16_BYTES + 3 * TT * 64 * 4;   // 160000 B
 
 // Eight waves stream the (b,h) state through a ring of NBUF register batches (UN e'-tiles of 16 x 64 blocks each): with
 // plain global loads (address space 1, in-order vmcnt) NBUF - 1 batches stay in flight while one is multiplied.  The mixing is
@@ -104,18 +106,14 @@ __device__ __forceinline__ void mix16_tile_to_lds(u16* __restrict__ Gt, const u1
     if (njg > 4) mix16_tile_impl<TRANSW, true, NBUF>(Gt, state_bh, njg, W, ldw, M, i0, tid, rot);
     else         mix16_tile_impl<TRANSW, false, NBUF>(Gt, state_bh, njg, W, ldw, M, i0, tid, rot);
 }
-// The tile workgroups of one (b,h) run side by side on one XCD and stream the same 512 KB: each starts at a different
-// eighth of it (batch rotation), so that what is in flight towards HBM at any moment are DIFFERENT lines (the others' later
-// requests for them are L2 hits), instead of every line being awaited by all of them at once.
-#ifndef T16_ROT
-#define T16_ROT 0
-#endif
-__device__ __forceinline__ int tile_rot(int it, int ntt) { return T16_ROT ? (it * 8 / ntt) & 7 : 0; }
+// (starting each of a (b,h)'s tile workgroups at a different eighth of the state -- so that the lines in flight towards HBM differ --
+// was measured neutral to slightly slower; rot = 0)
+__device__ __forceinline__ int tile_rot(int, int) { return 0; }
 
-// A operands of a 64-row chunk straight from a token view: a[st][ks] = rows 16 st + (lane & 15), columns 32 ks + 8 (lane >> 4)
-// .. + 7.  Rows beyond rv read the block's first row (valid memory, finite values): every consumer of these operands produces
-// output rows from operand rows one to one and never stores rows >= rv, and the row weights of the dksum sum (dz) are zero
-// there -- so there is no zeroing, and nothing depends on the loaded data until the MFMAs that consume it.
+// Token rows of a 64-row chunk straight from a token view, in MFMA operand layout: a[st][ks] = row 16 st + (lane & 15), columns
+// 32 ks + 8 (lane >> 4) .. + 7.  Rows beyond rv read the block's first row (valid memory, finite values): every consumer of these
+// operands produces output rows from operand rows one to one and never stores rows >= rv, and the row weights of the dksum sum
+// (dz) are zero there -- so there is no zeroing, and nothing depends on the loaded data until the MFMAs that consume it.
 __device__ __forceinline__ void load_a64(bf16x8 (&a)[4][2], const u16* __restrict__ base, long sn,
                                          const int* __restrict__ idx, long p0, int rv, int lane) {
     const int m = lane & 15, kg = lane >> 4;
@@ -123,10 +121,10 @@ __device__ __forceinline__ void load_a64(bf16x8 (&a)[4][2], const u16* __restric
     for (int st = 0; st < 4; ++st) {
         const int row = st * 16 + m;
         const u16* src = base + tok_row(idx, p0 + (row < rv ? row : 0)) * sn + kg * 8;
-#pragma unroll
 #ifdef T16_NOTOK
         for (int ks = 0; ks < 2; ++ks) a[st][ks] = __builtin_bit_cast(bf16x8, make_uint4(lane, (unsigned)(uintptr_t)src, ks, 0x3f803f80u));
 #else
+#pragma unroll
         for (int ks = 0; ks < 2; ++ks) a[st][ks] = __builtin_bit_cast(bf16x8, gld_stream16(src + ks * 32));
 #endif
     }
@@ -139,9 +137,13 @@ __device__ __forceinline__ void relu_a64(bf16x8 (&a)[4][2], float eps) {
         for (int ks = 0; ks < 2; ++ks) a[st][ks] = __builtin_bit_cast(bf16x8, relu_eps8(__builtin_bit_cast(uint4, a[st][ks]), eps));
 }
 
-// acc[st][tn] += A[st] x B  with B from one mixed summary Gb[d2][d1] (GLD stride):
-//   TRB false: B[k = d1][n = d2] = Gb[n][k]  (k contiguous: plain 16-byte LDS reads)
-//   TRB true : B[k = d2][n = d1] = Gb[k][n]  (hardware transpose reads)
+// acc[st][tn] += (X[st] x B)^T for a 64-row chunk X of token rows and one mixed summary Gb[d2][d1] (GLD stride):
+//   TRB false: B[k = d1][c = d2] = Gb[c][k]  (k contiguous: plain 16-byte LDS reads)
+//   TRB true : B[k = d2][c = d1] = Gb[k][c]  (hardware transpose reads)
+// The summary is the MFMA's A operand and the token rows its B operand, i.e. the product comes out TRANSPOSED: lane (n = lane & 15,
+// kg = lane >> 4) holds, for token row 16 st + n, the four consecutive columns 16 tn + 4 kg + 0..3.  Per-row factors (1 / n, dz) are
+// then per-lane scalars, a result row packs into 8-byte pieces (16 LDS stores per block instead of 64 two-byte ones), and the
+// per-column terms (ksum, dksum) are 16-byte reads.
 template <bool TRB>
 __device__ __forceinline__ void chunk_times_gt(f32x4 (&acc)[4][4], const bf16x8 (&a)[4][2], const u16* __restrict__ Gb, int lane) {
     const int n = lane & 15, kg = lane >> 4;
@@ -152,7 +154,7 @@ __device__ __forceinline__ void chunk_times_gt(f32x4 (&acc)[4][4], const bf16x8 
             const bf16x8 bv = TRB ? tr_read8(Gb, GLD, ks * 32, tn * 16, lane)
                                   : *reinterpret_cast<const bf16x8*>(Gb + (tn * 16 + n) * GLD + ks * 32 + kg * 8);
 #pragma unroll
-            for (int st = 0; st < 4; ++st) acc[st][tn] = mfma_bf16(a[st][ks], bv, acc[st][tn]);
+            for (int st = 0; st < 4; ++st) acc[st][tn] = mfma_bf16(bv, a[st][ks], acc[st][tn]);
         }
     }
 }
@@ -162,55 +164,75 @@ __device__ __forceinline__ void zero_acc(f32x4 (&acc)[4][4]) {
 #pragma unroll
         for (int tn = 0; tn < 4; ++tn) acc[st][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
 }
+__device__ __forceinline__ uint2 pack4(const f32x4& v) { return make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])); }
 
-// Wave-private staging of a 64 x 64 fp32 result (C layout: row = 16 st + 4 (lane >> 4) + r, col = 16 tn + (lane & 15))
+// Wave-private staging of a 64 x 64 result in the transposed-product layout, as bf16 rows of GLD stride (conflict-free 8-byte stores)
 __device__ __forceinline__ void stage64(u16* __restrict__ Os, const f32x4 (&acc)[4][4], int lane) {
     const int n = lane & 15, kg = lane >> 4;
 #pragma unroll
     for (int st = 0; st < 4; ++st)
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Os[(st * 16 + kg * 4 + r) * GLD + tn * 16 + n] = cvt_bf16(acc[st][tn][r]);
+        for (int tn = 0; tn < 4; ++tn) *reinterpret_cast<uint2*>(Os + (st * 16 + n) * GLD + tn * 16 + kg * 4) = pack4(acc[st][tn]);
 }
-// the same from results kept packed as bf16 pairs (pv[st][tn][0] = rows r = 0, 1; [1] = rows 2, 3)
-__device__ __forceinline__ void stage64_packed(u16* __restrict__ Os, const unsigned (&pv)[4][4][2], int lane) {
+// the same from results kept packed
+__device__ __forceinline__ void stage64_packed(u16* __restrict__ Os, const uint2 (&pv)[4][4], int lane) {
     const int n = lane & 15, kg = lane >> 4;
 #pragma unroll
     for (int st = 0; st < 4; ++st)
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                Os[(st * 16 + kg * 4 + r) * GLD + tn * 16 + n] = (u16)(pv[st][tn][r >> 1] >> ((r & 1) * 16));
+        for (int tn = 0; tn < 4; ++tn) *reinterpret_cast<uint2*>(Os + (st * 16 + n) * GLD + tn * 16 + kg * 4) = pv[st][tn];
 }
-
-// narrow fallback (no free staging slot): direct stores from the C layout
+// zero the bf16 lanes of v where the corresponding element of m is <= 0 (relu gradient mask), 4 elements
+__device__ __forceinline__ uint2 mask_pos4(uint2 v, uint2 m) {
+    const uint4 r = mask_pos8(make_uint4(v.x, v.y, 0, 0), make_uint4(m.x, m.y, 0, 0));
+    return make_uint2(r.x, r.y);
+}
+// narrow fallback (no free staging slot: inner chunks of multi-chunk blocks): direct 8-byte stores from the packed result
 template <bool MASK>
 __device__ __forceinline__ void store64_direct(u16* __restrict__ base, long sn, const int* __restrict__ idx, long p0, int rv,
-                                               const f32x4 (&acc)[4][4], const u16* __restrict__ mbase, long msn, int lane) {
+                                               const uint2 (&pv)[4][4], const u16* __restrict__ mbase, long msn, int lane) {
     const int n = lane & 15, kg = lane >> 4;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+        const int row = st * 16 + n;
+        if (row < rv) {
+            const long tr = tok_row(idx, p0 + row);
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn) {
+                uint2 v = pv[st][tn];
+                if (MASK) v = mask_pos4(v, *reinterpret_cast<const uint2*>(mbase + tr * msn + tn * 16 + kg * 4));
+                *reinterpret_cast<uint2*>(base + tr * sn + tn * 16 + kg * 4) = v;
+            }
+        }
+    }
+}
+__device__ __forceinline__ void pack_acc(uint2 (&pv)[4][4], const f32x4 (&acc)[4][4]) {
 #pragma unroll
     for (int st = 0; st < 4; ++st)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = st * 16 + kg * 4 + r;
-            if (row < rv) {
-                const long tr = tok_row(idx, p0 + row);
+        for (int tn = 0; tn < 4; ++tn) pv[st][tn] = pack4(acc[st][tn]);
+}
+
+// Side values of the tile's 16 blocks ([16][64] fp32 in LDS): fetched by the whole workgroup before the mixing (two elements per
+// thread: block (tid >> 6) + 8 t, column tid & 63) and written to LDS just before the barrier that follows it.
+struct SideRegs { float v[2]; };
+__device__ __forceinline__ void side_issue(SideRegs& r, const float* __restrict__ src_bh, int stride, int cols, int blk0, int M, int tid) {
 #pragma unroll
-                for (int tn = 0; tn < 4; ++tn) {
-                    float v = acc[st][tn][r];
-                    if (MASK && !(bf(mbase[tr * msn + tn * 16 + n]) > 0.f)) v = 0.f;
-                    base[tr * sn + tn * 16 + n] = cvt_bf16(v);
-                }
-            }
-        }
+    for (int t = 0; t < 2; ++t) {
+        const int blk = min(blk0 + (tid >> 6) + 8 * t, M - 1), c = min(tid & 63, cols - 1);
+        r.v[t] = gld<float>(src_bh + (long)blk * stride + c);
+    }
+}
+__device__ __forceinline__ void side_commit(float* __restrict__ dst, const SideRegs& r, int cols, int tid) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) dst[((tid >> 6) + 8 * t) * 64 + (tid & 63)] = (tid & 63) < cols ? r.v[t] : 0.f;
 }
 
 __global__ __launch_bounds__(FT8, 2) void k_t16_out(const FsOutArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u16* Gt = reinterpret_cast<u16*>(smem_raw);   // [16][64 d2][72]
-    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, kg = lane >> 4;
+    float* sideN = reinterpret_cast<float*>(smem_raw + FS_GT16_BYTES);   // [16][64]  1 / n
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, n = lane & 15;
     const int L = xcd_swizzle(blockIdx.x, gridDim.x);
     const int ntt = (a.njg + 1) / 2, bh = L / ntt, it = L - bh * ntt, b = bh / a.H, h = bh - b * a.H;
     const int S = a.S, M = a.M;
@@ -219,32 +241,30 @@ __global__ __launch_bounds__(FT8, 2) void k_t16_out(const FsOutArgs a) {
     const float* ninv_bh = a.ninv + (long)bh * M * S;
     const u16* state_bh = a.state + (long)bh * a.njg * FE * IT;
 
-    auto load_blk = [&](bf16x8 (&av)[4][2], float& ninv, int i, int c0, int rv) {
-        load_a64(av, qb, a.q.sn, a.idx, (long)i * S + c0, rv, lane);
-        ninv = a.normalize ? gld<float>(ninv_bh + (long)i * S + c0 + min(lane, rv - 1)) : 1.f;   // lanes >= rv: unused rows
-    };
-    auto compute_store = [&](bf16x8 (&av)[4][2], float ninv, int bi, int i, int c0, int rv) {
+    auto compute_store = [&](bf16x8 (&av)[4][2], int bi, int i, int c0, int rv) {
         const long p0 = (long)i * S + c0;
         u16* Gb = Gt + bi * GSLOT;
         if (a.relu) relu_a64(av, a.eps);
         f32x4 acc[4][4];
         zero_acc(acc);
         chunk_times_gt<false>(acc, av, Gb, lane);
+        if (a.normalize) {
 #pragma unroll
-        for (int st = 0; st < 4; ++st)
+            for (int st = 0; st < 4; ++st) {
+                const float ni = sideN[bi * 64 + st * 16 + n];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float ni = __shfl(ninv, st * 16 + kg * 4 + r, 64);
-#pragma unroll
-                for (int tn = 0; tn < 4; ++tn) acc[st][tn][r] *= ni;
+                for (int tn = 0; tn < 4; ++tn) acc[st][tn] *= ni;
             }
+        }
         if (c0 + 64 >= S) {   // last chunk of the block: its Gt slot is dead for this wave -> staging buffer
             wave_lds_fence();
             stage64(Gb, acc, lane);
             wave_lds_fence();
             store64<false, false>(ob, a.o.sn, a.idx, p0, rv, Gb, nullptr, 0, lane);
         } else {
-            store64_direct<false>(ob, a.o.sn, a.idx, p0, rv, acc, nullptr, 0, lane);
+            uint2 pv[4][4];
+            pack_acc(pv, acc);
+            store64_direct<false>(ob, a.o.sn, a.idx, p0, rv, pv, nullptr, 0, lane);
         }
     };
 
@@ -253,24 +273,26 @@ __global__ __launch_bounds__(FT8, 2) void k_t16_out(const FsOutArgs a) {
         // phase hides their HBM latency
         const int iA = it * TT + wave, iB = iA + 8;
         bf16x8 avA[4][2], avB[4][2];
-        float ninvA = 1.f, ninvB = 1.f;
+        SideRegs sn;
         trace_mark(a.trace, 0);
-        load_blk(avA, ninvA, min(iA, M - 1), 0, S);
-        load_blk(avB, ninvB, min(iB, M - 1), 0, S);
+        if (a.normalize) side_issue(sn, ninv_bh, S, S, it * TT, M, tid);
+        load_a64(avA, qb, a.q.sn, a.idx, (long)min(iA, M - 1) * S, S, lane);
+        load_a64(avB, qb, a.q.sn, a.idx, (long)min(iB, M - 1) * S, S, lane);
         trace_mark(a.trace, 1);
-        mix16_tile_to_lds<0, 3>(Gt, state_bh, a.njg, a.W, a.ldw, M, it * TT, tid, tile_rot(it, ntt));
+        mix16_tile_to_lds<0, 3>(Gt, state_bh, a.njg, a.W, a.ldw, M, it * TT, tid, 0);
+        if (a.normalize) side_commit(sideN, sn, S, tid);
         trace_mark(a.trace, 2);
         __syncthreads();
         trace_mark(a.trace, 3);
-        if (iA < M) compute_store(avA, ninvA, wave, iA, 0, S);
+        if (iA < M) compute_store(avA, wave, iA, 0, S);
         trace_mark(a.trace, 4);
-        if (iB < M) compute_store(avB, ninvB, wave + 8, iB, 0, S);
+        if (iB < M) compute_store(avB, wave + 8, iB, 0, S);
         trace_mark(a.trace, 5);
         if (a.trace) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); trace_mark(a.trace, 6); }
         return;
     }
 
-    mix16_tile_to_lds<0, 3>(Gt, state_bh, a.njg, a.W, a.ldw, M, it * TT, tid, tile_rot(it, ntt));
+    mix16_tile_to_lds<0, 3>(Gt, state_bh, a.njg, a.W, a.ldw, M, it * TT, tid, 0);
     __syncthreads();
     for (int bi = wave; bi < TT; bi += 8) {
         const int i = it * TT + bi;
@@ -278,9 +300,13 @@ __global__ __launch_bounds__(FT8, 2) void k_t16_out(const FsOutArgs a) {
         for (int c0 = 0; c0 < S; c0 += 64) {
             const int rv = min(64, S - c0);
             bf16x8 av[4][2];
-            float ninv;
-            load_blk(av, ninv, i, c0, rv);
-            compute_store(av, ninv, bi, i, c0, rv);
+            load_a64(av, qb, a.q.sn, a.idx, (long)i * S + c0, rv, lane);
+            if (a.normalize) {   // the chunk's 1 / n into the wave's own side slot
+                wave_lds_fence();
+                sideN[bi * 64 + lane] = gld<float>(ninv_bh + (long)i * S + c0 + min(lane, rv - 1));
+                wave_lds_fence();
+            }
+            compute_store(av, bi, i, c0, rv);
         }
     }
 }
@@ -288,6 +314,9 @@ __global__ __launch_bounds__(FT8, 2) void k_t16_out(const FsOutArgs a) {
 __global__ __launch_bounds__(FT8, 2) void k_t16_bwd_dq(const FsTokArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u16* Gt = reinterpret_cast<u16*>(smem_raw);
+    float* sideN = reinterpret_cast<float*>(smem_raw + FS_GT16_BYTES);   // [16][64]  1 / n
+    float* sideZ = sideN + TT * 64;                                       // [16][64]  dz (zero beyond the block's rows)
+    float* sideK = sideZ + TT * 64;                                       // [16][64]  ksum
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, n = lane & 15, kg = lane >> 4;
     const int L = xcd_swizzle(blockIdx.x, gridDim.x);
     const int ntt = (a.njg + 1) / 2, bh = L / ntt, jgx = L - bh * ntt, b = bh / a.H, h = bh - b * a.H;
@@ -298,55 +327,33 @@ __global__ __launch_bounds__(FT8, 2) void k_t16_bwd_dq(const FsTokArgs a) {
     u16* dqb = mbase(a.dq);
     const long sofs = (long)bh * a.njg * FE * IT;
 
-    struct Side { float ninv, dz, ksum; };
-    // dO rows and the per-row / per-column side values of one chunk; Q rows (normalised operator only: dksum) separately
-    auto load_g = [&](bf16x8 (&gv)[4][2], Side& sd, int j, int c0, int rv) {
-        load_a64(gv, gb, a.dout.sn, a.idx, (long)j * S + c0, rv, lane);
-        sd.ninv = 1.f; sd.dz = 0.f; sd.ksum = 0.f;
-        if (a.normalize) {
-            const long so = ((long)bh * M + j) * S + c0 + min(lane, rv - 1);
-            sd.ksum = gld<float>(a.ksum + ((long)bh * M + j) * 64 + lane);   // lane = column d1
-            sd.ninv = gld<float>(a.ninv + so);
-            sd.dz = gld<float>(a.dz + so);
-        }
-    };
-    auto load_q = [&](bf16x8 (&qv)[4][2], int j, int c0, int rv) {
-        if (a.normalize) load_a64(qv, qb, a.q.sn, a.idx, (long)j * S + c0, rv, lane);
-    };
-    // one 64-row chunk in two steps: the products (dO G^T)[s][d1] (B[k = d2][n = d1] = Gt[d2][d1]) ...
+    // one 64-row chunk in two steps: the products (dO G^T)[s][d1] (B[k = d2][c = d1] = Gt[d2][d1]) ...
     auto products = [&](f32x4 (&acc)[4][4], const bf16x8 (&gv)[4][2], int bi) {
         zero_acc(acc);
         chunk_times_gt<true>(acc, gv, Gt + bi * GSLOT, lane);
     };
-    // ... then dQ rows (scaling, dz (x) ksum, store) and the chunk's contribution to dksum (per-lane partials in the A layout)
-    auto finish_store = [&](f32x4 (&acc)[4][4], bf16x8 (&qv)[4][2], Side sd, float (&dks_acc)[2][8], int bi, int j, int c0, int rv) {
+    // ... then dQ rows (scaling by 1 / n, + dz (x) ksum, store) and the chunk's contribution to dksum (per-lane partials: this
+    // lane's four rows, columns 32 ks + 8 kg + t)
+    auto finish_store = [&](f32x4 (&acc)[4][4], bf16x8 (&qv)[4][2], float (&dks_acc)[2][8], int bi, int j, int c0, int rv) {
         const long p0 = (long)j * S + c0;
         u16* Gb = Gt + bi * GSLOT;
-        if (lane >= rv) sd.dz = 0.f;               // rows beyond the chunk carry another row's data: no weight in dksum
         if (a.normalize) {
             if (a.relu) relu_a64(qv, a.eps);
+            f32x4 ks4[4];
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn) ks4[tn] = *reinterpret_cast<const f32x4*>(sideK + bi * 64 + tn * 16 + kg * 4);
 #pragma unroll
             for (int st = 0; st < 4; ++st) {
-                const float dzr = __shfl(sd.dz, st * 16 + n, 64);
+                const float dzr = sideZ[bi * 64 + st * 16 + n], ni = sideN[bi * 64 + st * 16 + n];
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     const s16x8 qs = __builtin_bit_cast(s16x8, qv[st][ks]);
 #pragma unroll
                     for (int t = 0; t < 8; ++t) dks_acc[ks][t] += dzr * bf((u16)qs[t]);
                 }
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn) acc[st][tn] = acc[st][tn] * ni + dzr * ks4[tn];
             }
-            float ksc[4];
-#pragma unroll
-            for (int tn = 0; tn < 4; ++tn) ksc[tn] = __shfl(sd.ksum, tn * 16 + n, 64);
-#pragma unroll
-            for (int st = 0; st < 4; ++st)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = st * 16 + kg * 4 + r;
-                    const float ni = __shfl(sd.ninv, row, 64), dzr = __shfl(sd.dz, row, 64);
-#pragma unroll
-                    for (int tn = 0; tn < 4; ++tn) acc[st][tn][r] = acc[st][tn][r] * ni + dzr * ksc[tn];
-                }
         }
         if (c0 + 64 >= S) {
             wave_lds_fence();
@@ -355,21 +362,35 @@ __global__ __launch_bounds__(FT8, 2) void k_t16_bwd_dq(const FsTokArgs a) {
             if (a.relu) store64<true>(dqb, a.dq.sn, a.idx, p0, rv, Gb, qb, a.q.sn, lane);
             else        store64<false>(dqb, a.dq.sn, a.idx, p0, rv, Gb, nullptr, 0, lane);
         } else {
-            if (a.relu) store64_direct<true>(dqb, a.dq.sn, a.idx, p0, rv, acc, qb, a.q.sn, lane);
-            else        store64_direct<false>(dqb, a.dq.sn, a.idx, p0, rv, acc, nullptr, 0, lane);
+            uint2 pv[4][4];
+            pack_acc(pv, acc);
+            if (a.relu) store64_direct<true>(dqb, a.dq.sn, a.idx, p0, rv, pv, qb, a.q.sn, lane);
+            else        store64_direct<false>(dqb, a.dq.sn, a.idx, p0, rv, pv, nullptr, 0, lane);
         }
     };
-    // dksum[col]: reduce the per-lane partials over the 16 row-lanes (n); columns = 32 ks + 8 kg + t
+    // dksum[col]: sum the per-lane partials over the 16 row-lanes n.  Halving butterfly: each step a lane hands half of its
+    // values to its partner and keeps (and completes) the other half -- 15 exchanges instead of 64, and lane n ends up with the
+    // total of value index n = 8 ks + t, i.e. column 32 (n >> 3) + 8 kg + (n & 7): one coalesced store.
     auto finish_dks = [&](const float (&dks_acc)[2][8], int j) {
+        float v8[8], v4[4], v2[2];
+        const bool b8 = n & 8, b4 = n & 4, b2 = n & 2, b1 = n & 1;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int t = 0; t < 8; ++t) {
+            const float send = b8 ? dks_acc[0][t] : dks_acc[1][t], keep = b8 ? dks_acc[1][t] : dks_acc[0][t];
+            v8[t] = keep + __shfl_xor(send, 8, 64);
+        }
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                float v = dks_acc[ks][t];
-                v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64);
-                v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-                if (n == 0) a.dksum[((long)bh * M + j) * 64 + ks * 32 + kg * 8 + t] = v;
-            }
+        for (int t = 0; t < 4; ++t) {
+            const float send = b4 ? v8[t] : v8[t + 4], keep = b4 ? v8[t + 4] : v8[t];
+            v4[t] = keep + __shfl_xor(send, 4, 64);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const float send = b2 ? v4[t] : v4[t + 2], keep = b2 ? v4[t + 2] : v4[t];
+            v2[t] = keep + __shfl_xor(send, 2, 64);
+        }
+        const float send = b1 ? v2[0] : v2[1], keep = b1 ? v2[1] : v2[0];
+        gst<float>(a.dksum + ((long)bh * M + j) * 64 + 32 * (n >> 3) + 8 * kg + (n & 7), keep + __shfl_xor(send, 1, 64));
     };
     auto zero_dks = [](float (&d)[2][8]) {
 #pragma unroll
@@ -383,47 +404,65 @@ __global__ __launch_bounds__(FT8, 2) void k_t16_bwd_dq(const FsTokArgs a) {
         // while the first block is processed) and its Q rows once the first block is done (256 VGPRs: no room earlier)
         const int jA = jgx * TT + wave, jB = jA + 8, jAc = min(jA, M - 1), jBc = min(jB, M - 1);
         bf16x8 gvA[4][2], qvA[4][2];
-        Side sA, sB;
+        SideRegs sn, sz, sk;
         trace_mark(a.trace, 0);
-        load_g(gvA, sA, jAc, 0, S);
-        load_q(qvA, jAc, 0, S);
+        if (a.normalize) {
+            side_issue(sn, a.ninv + (long)bh * M * S, S, S, jgx * TT, M, tid);
+            side_issue(sz, a.dz + (long)bh * M * S, S, S, jgx * TT, M, tid);
+            side_issue(sk, a.ksum + (long)bh * M * 64, 64, 64, jgx * TT, M, tid);
+        }
+        load_a64(gvA, gb, a.dout.sn, a.idx, (long)jAc * S, S, lane);
+        if (a.normalize) load_a64(qvA, qb, a.q.sn, a.idx, (long)jAc * S, S, lane);
         trace_mark(a.trace, 1);
-        mix16_tile_to_lds<0, 2>(Gt, a.state + sofs, a.njg, a.W, a.ldw, M, jgx * TT, tid, tile_rot(jgx, ntt));
+        mix16_tile_to_lds<0, 2>(Gt, a.state + sofs, a.njg, a.W, a.ldw, M, jgx * TT, tid, 0);
+        if (a.normalize) {
+            side_commit(sideN, sn, S, tid);
+            side_commit(sideZ, sz, S, tid);
+            side_commit(sideK, sk, 64, tid);
+        }
         trace_mark(a.trace, 2);
         __syncthreads();
         trace_mark(a.trace, 3);
         bf16x8 gvB[4][2], qvB[4][2];
         f32x4 acc[4][4];
         float dks_acc[2][8];
-        load_g(gvB, sB, jBc, 0, S);
+        load_a64(gvB, gb, a.dout.sn, a.idx, (long)jBc * S, S, lane);
         products(acc, gvA, wave);
         zero_dks(dks_acc);
-        if (jA < M) { finish_store(acc, qvA, sA, dks_acc, wave, jA, 0, S); if (a.normalize) finish_dks(dks_acc, jA); }
+        if (jA < M) { finish_store(acc, qvA, dks_acc, wave, jA, 0, S); if (a.normalize) finish_dks(dks_acc, jA); }
         trace_mark(a.trace, 4);
-        load_q(qvB, jBc, 0, S);      // travels during the second block's products
+        if (a.normalize) load_a64(qvB, qb, a.q.sn, a.idx, (long)jBc * S, S, lane);      // travels during the second block's products
         products(acc, gvB, wave + 8);
         zero_dks(dks_acc);
-        if (jB < M) { finish_store(acc, qvB, sB, dks_acc, wave + 8, jB, 0, S); if (a.normalize) finish_dks(dks_acc, jB); }
+        if (jB < M) { finish_store(acc, qvB, dks_acc, wave + 8, jB, 0, S); if (a.normalize) finish_dks(dks_acc, jB); }
         trace_mark(a.trace, 5);
         if (a.trace) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); trace_mark(a.trace, 6); }
         return;
     }
-    mix16_tile_to_lds<0, 2>(Gt, a.state + sofs, a.njg, a.W, a.ldw, M, jgx * TT, tid, tile_rot(jgx, ntt));
+    mix16_tile_to_lds<0, 2>(Gt, a.state + sofs, a.njg, a.W, a.ldw, M, jgx * TT, tid, 0);
     __syncthreads();
     for (int bi = wave; bi < TT; bi += 8) {
         const int j = jgx * TT + bi;
         if (j >= M) continue;
         float dks_acc[2][8];
         zero_dks(dks_acc);
+        if (a.normalize) sideK[bi * 64 + lane] = gld<float>(a.ksum + ((long)bh * M + j) * 64 + lane);
         for (int c0 = 0; c0 < S; c0 += 64) {
             const int rv = min(64, S - c0);
             bf16x8 gv[4][2], qv[4][2];
             f32x4 acc[4][4];
-            Side sd;
-            load_g(gv, sd, j, c0, rv);
-            load_q(qv, j, c0, rv);
+            load_a64(gv, gb, a.dout.sn, a.idx, (long)j * S + c0, rv, lane);
+            if (a.normalize) {
+                load_a64(qv, qb, a.q.sn, a.idx, (long)j * S + c0, rv, lane);
+                const long so = ((long)bh * M + j) * S + c0 + min(lane, rv - 1);
+                const float ni = gld<float>(a.ninv + so), dz = gld<float>(a.dz + so);
+                wave_lds_fence();
+                sideN[bi * 64 + lane] = ni;
+                sideZ[bi * 64 + lane] = lane < rv ? dz : 0.f;   // rows beyond the chunk carry another row's data: no weight in dksum
+                wave_lds_fence();
+            }
             products(acc, gv, bi);
-            finish_store(acc, qv, sd, dks_acc, bi, j, c0, rv);
+            finish_store(acc, qv, dks_acc, bi, j, c0, rv);
         }
         if (a.normalize) finish_dks(dks_acc, j);
     }
@@ -432,7 +471,8 @@ __global__ __launch_bounds__(FT8, 2) void k_t16_bwd_dq(const FsTokArgs a) {
 __global__ __launch_bounds__(FT8, 2) void k_t16_bwd_dkv(const FsTokArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u16* Gt = reinterpret_cast<u16*>(smem_raw);
-    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, n = lane & 15;
+    float* sideK = reinterpret_cast<float*>(smem_raw + FS_GT16_BYTES);   // [16][64]  dksum (k_t16_bwd_dq)
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, kg = lane >> 4;
     if ((int)blockIdx.x >= a.ntiles) {   // tail workgroups: the dW reduction (dW is complete when the backward's last launch is)
         dw_reduce_body(reinterpret_cast<float*>(smem_raw), a.dwp, a.dW, a.M, a.nparts, blockIdx.x - a.ntiles, tid);
         return;
@@ -454,19 +494,13 @@ __global__ __launch_bounds__(FT8, 2) void k_t16_bwd_dkv(const FsTokArgs a) {
         u16* Gb = Gt + bi * GSLOT;
         const bool last = c0 + 64 >= S;
         if (a.relu) relu_a64(kv, a.eps);
-        // dV first, kept packed as bf16 pairs while dK is computed (both need the intact Gb)
-        unsigned pv[4][4][2];
+        // dV first, kept packed as bf16 while dK is computed (both need the intact Gb)
+        uint2 pv[4][4];
         {
             f32x4 accV[4][4];
             zero_acc(accV);
             chunk_times_gt<false>(accV, kv, Gb, lane);   // dV[s][d2] = sum_d1 K[s][d1] dKVt[d2][d1]
-#pragma unroll
-            for (int st = 0; st < 4; ++st)
-#pragma unroll
-                for (int tn = 0; tn < 4; ++tn) {
-                    pv[st][tn][0] = pack_bf16x2(accV[st][tn][0], accV[st][tn][1]);
-                    pv[st][tn][1] = pack_bf16x2(accV[st][tn][2], accV[st][tn][3]);
-                }
+            pack_acc(pv, accV);
         }
         f32x4 accK[4][4];
         zero_acc(accK);
@@ -474,11 +508,9 @@ __global__ __launch_bounds__(FT8, 2) void k_t16_bwd_dkv(const FsTokArgs a) {
         if (a.normalize) {
 #pragma unroll
             for (int tn = 0; tn < 4; ++tn) {
-                const float dk = gld<float>(a.dksum + ((long)bh * M + j) * 64 + tn * 16 + n);
+                const f32x4 dk = *reinterpret_cast<const f32x4*>(sideK + bi * 64 + tn * 16 + kg * 4);
 #pragma unroll
-                for (int st = 0; st < 4; ++st)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) accK[st][tn][r] += dk;
+                for (int st = 0; st < 4; ++st) accK[st][tn] += dk;
             }
         }
         if (last) {
@@ -492,31 +524,24 @@ __global__ __launch_bounds__(FT8, 2) void k_t16_bwd_dkv(const FsTokArgs a) {
             wave_lds_fence();
             store64<false>(dvb, a.dv.sn, a.idx, p0, rv, Gb, nullptr, 0, lane);
         } else {
-            if (a.relu) store64_direct<true>(dkb, a.dk.sn, a.idx, p0, rv, accK, kb, a.k.sn, lane);
-            else        store64_direct<false>(dkb, a.dk.sn, a.idx, p0, rv, accK, nullptr, 0, lane);
-            const int kg = lane >> 4;
-#pragma unroll
-            for (int st = 0; st < 4; ++st)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = st * 16 + kg * 4 + r;
-                    if (row < rv) {
-                        const long tr = tok_row(a.idx, p0 + row);
-#pragma unroll
-                        for (int tn = 0; tn < 4; ++tn)
-                            dvb[tr * a.dv.sn + tn * 16 + n] = (u16)(pv[st][tn][r >> 1] >> ((r & 1) * 16));
-                    }
-                }
+            uint2 pk[4][4];
+            pack_acc(pk, accK);
+            if (a.relu) store64_direct<true>(dkb, a.dk.sn, a.idx, p0, rv, pk, kb, a.k.sn, lane);
+            else        store64_direct<false>(dkb, a.dk.sn, a.idx, p0, rv, pk, nullptr, 0, lane);
+            store64_direct<false>(dvb, a.dv.sn, a.idx, p0, rv, pv, nullptr, 0, lane);
         }
     };
 
     if (S <= 64) {
         const int jA = jgx * TT + wave, jB = jA + 8;
         bf16x8 kvA[4][2], vvA[4][2];
+        SideRegs sk;
         trace_mark(a.trace, 0);
+        if (a.normalize) side_issue(sk, a.dksum + (long)bh * M * 64, 64, 64, jgx * TT, M, tid);
         load_blk(kvA, vvA, min(jA, M - 1), 0, S);
         trace_mark(a.trace, 1);
-        mix16_tile_to_lds<1, 3>(Gt, a.dstate + sofs, a.njg, a.W, a.ldw, M, jgx * TT, tid, tile_rot(jgx, ntt));
+        mix16_tile_to_lds<1, 3>(Gt, a.dstate + sofs, a.njg, a.W, a.ldw, M, jgx * TT, tid, 0);
+        if (a.normalize) side_commit(sideK, sk, 64, tid);
         trace_mark(a.trace, 2);
         __syncthreads();
         trace_mark(a.trace, 3);
@@ -529,15 +554,17 @@ __global__ __launch_bounds__(FT8, 2) void k_t16_bwd_dkv(const FsTokArgs a) {
         if (a.trace) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); trace_mark(a.trace, 6); }
         return;
     }
-    mix16_tile_to_lds<1, 3>(Gt, a.dstate + sofs, a.njg, a.W, a.ldw, M, jgx * TT, tid, tile_rot(jgx, ntt));
+    mix16_tile_to_lds<1, 3>(Gt, a.dstate + sofs, a.njg, a.W, a.ldw, M, jgx * TT, tid, 0);
     __syncthreads();
     for (int bi = wave; bi < TT; bi += 8) {
         const int j = jgx * TT + bi;
         if (j >= M) continue;
+        if (a.normalize) sideK[bi * 64 + lane] = gld<float>(a.dksum + ((long)bh * M + j) * 64 + lane);
         for (int c0 = 0; c0 < S; c0 += 64) {
             const int rv = min(64, S - c0);
             bf16x8 kv[4][2], vv[4][2];
             load_blk(kv, vv, j, c0, rv);
+            wave_lds_fence();
             compute_store(kv, vv, bi, j, c0, rv);
         }
     }
