@@ -412,7 +412,7 @@ static int bm_fwd_impl(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view 
         oa.q = cv(q_num); oa.o = cmv(out); oa.idx = block_index; oa.W = W; oa.ldw = ldw; oa.state = f.state; oa.ninv = f.ninv;
         oa.H = H; oa.M = M; oa.S = S; oa.njg = f.njg; oa.eps = eps; oa.relu = relu; oa.normalize = normalize;
         oa.trace = g_trace.load();
-        RC(launch(fast::k_t16_out, dim3(((f.njg + 1) / 2) * B * H), dim3(fast::FT8), fast::FS_T16_SMEM, st, "k_t16_out", oa));
+        RC(launch(fast::k_tile_out<16>, dim3(((f.njg + 1) / 2) * B * H), dim3(fast::FT8), fast::tile_smem<16>(), st, "k_t16_out", oa));
         return MHLA_OK;
     }
     const BmWs w = bm_carve(ws, B, H, M, S, D, bm_sum16(D, dtype, flags));
@@ -555,10 +555,10 @@ int mhla_blockmix_bwd(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q
             const long ntile_wgs = (long)((f.njg + 1) / 2) * B * H;
             unsigned long long* tr = g_trace.load();   // regions: [0] k_t16_out, [1] k_t16_bwd_dq, [2] k_t16_bwd_dkv
             ta.trace = tr ? tr + ntile_wgs * fast::TRACE_SLOTS : nullptr;
-            RC(launch(fast::k_t16_bwd_dq, dim3(((f.njg + 1) / 2) * B * H), dim3(fast::FT8), fast::FS_T16_SMEM, st, "k_t16_bwd_dq", ta));
+            RC(launch(fast::k_tile_bwd_dq<16>, dim3((unsigned)ntile_wgs), dim3(fast::FT8), fast::tile_smem<16>(), st, "k_t16_bwd_dq", ta));
             ta.trace = tr ? tr + 2 * ntile_wgs * fast::TRACE_SLOTS : nullptr;
             ta.dwp = f.dwp; ta.dW = dW; ta.nparts = B * H * fast::DW_SPLIT; ta.ntiles = (int)ntile_wgs;
-            RC(launch(fast::k_t16_bwd_dkv, dim3((unsigned)ntile_wgs + fast::DWR_WGS), dim3(fast::FT8), fast::FS_T16_SMEM, st, "k_t16_bwd_dkv", ta));
+            RC(launch(fast::k_tile_bwd_dkv<16>, dim3((unsigned)ntile_wgs + fast::DWR_WGS), dim3(fast::FT8), fast::tile_smem<16>(), st, "k_t16_bwd_dkv", ta));
             return MHLA_OK;
         }
     }

@@ -1,35 +1,44 @@
-// 16-block output tiles for the bf16 fast path (see fused.hpp).  The mixing phase is bound by L2 traffic
-// (every tile workgroup streams the whole (b,h) state: 512 KB); tiles of 16 blocks halve that traffic and
-// use all 16 MFMA columns.  512 threads, one workgroup per CU (LDS: 16 x 9 KB mixed summaries), wave w owns
-// blocks w and w + 8 of the tile; everything else as in the 8-block kernels.
+// Output tiles of the bf16 fast path (see fused.hpp): a workgroup mixes the (b,h)'s summaries for a tile of TTP blocks into LDS
+// (9 KB per block) and its waves then turn token rows into output rows block by block.  512 threads.
+//   TTP = 16: one workgroup per CU (160 KB LDS, <= 256 VGPRs), wave w owns blocks w and w + 8; the state is streamed four times per
+//             (b,h) (from L2 after the first touch) and all 16 MFMA columns carry blocks.
+//   TTP = 8 : two workgroups per CU (80 KB LDS, <= 128 VGPRs), wave w owns block w; the state is streamed eight times per (b,h); the
+//             16 MFMA columns carry the 8 blocks' bf16 hi and lo weight parts side by side (one MFMA instead of two, the halves
+//             added across lanes), so the matrix work per block is the same.  Measured (round 2): the output kernel 52 us against
+//             49 us with 16-block tiles -- the mixing phase is bound by the CU's L2 read rate (about 25 B / clk: 512 KB per tile
+//             workgroup whatever the tile size), so twice the tiles cost what the second workgroup's overlap gains; the two
+//             gradient kernels do not fit 128 VGPRs.  Only TTP = 16 is instantiated.
 #pragma once
 #include "fused.hpp"
 
 namespace mhla {
 namespace fast {
 
-constexpr int TT = 16;                              // blocks per tile
-constexpr int GSLOT = FD * GLD + 8;                  // elements per mixed-summary slot (+16 B: spreads the 16 blocks over banks)
-constexpr int FS_GT16_BYTES = TT * GSLOT * 2;       // 147712 B
-// per-block side values of the tile (1 / n, dz, ksum or dksum: three [16][64] fp32 arrays) behind the mixed summaries
-constexpr int FS_T16_SMEM = FS_GT16_BYTES + 3 * TT * 64 * 4;   // 160000 B
+constexpr int GSLOT = FD * GLD + 8;                  // elements per mixed-summary slot (+16 B: spreads the blocks over banks)
+// LDS: the tile's mixed summaries, then three [TTP][64] fp32 arrays of per-block side values (1 / n, dz, ksum or dksum)
+template <int TTP> constexpr int tile_gt_bytes() { return TTP * GSLOT * 2; }
+template <int TTP> constexpr int tile_smem() { return tile_gt_bytes<TTP>() + 3 * TTP * 64 * 4; }   // 160000 B (16) / 80000 B (8)
 
-// Eight waves stream the (b,h) state through a ring of NBUF register batches (UN e'-tiles of 16 x 64 blocks each): with
-// plain global loads (address space 1, in-order vmcnt) NBUF - 1 batches stay in flight while one is multiplied.  The mixing is
-// bound by the latency of the state's first touch (the four tile workgroups of a (b,h) run in lockstep on one XCD, so every
-// line is an HBM / MALL fetch for all of them): bytes in flight per wave are what counts.
-template <int TRANSW, bool TWO, int NBUF>
-__device__ __forceinline__ void mix16_tile_impl(u16* __restrict__ Gt, const u16* __restrict__ state_bh, int njg,
-                                                const float* __restrict__ W, int ldw, int M, int i0, int tid, int rot) {
+__device__ __forceinline__ float dpp_row_ror8(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));
+}
+
+// Eight waves stream the (b,h) state through a ring of NBUF register batches (UN e'-tiles of 16 x 64 blocks each): with plain
+// global loads (address space 1, in-order vmcnt) NBUF - 1 batches stay in flight while one is multiplied.
+template <int TTP, int TRANSW, bool TWO, int NBUF, int UN>
+__device__ __forceinline__ void mix_tile_impl(u16* __restrict__ Gt, const u16* __restrict__ state_bh, int njg,
+                                              const float* __restrict__ W, int ldw, int M, int i0, int tid) {
     const int wave = tid >> 6, lane = tid & 63, n = lane & 15, kg = lane >> 4;
-    constexpr int UN = 4, NW = FT8 / 64;
-    constexpr int NB = FE / 16 / NW / UN;   // 8 batches per wave
+    constexpr int NW = FT8 / 64;
+    constexpr int NB = FE / 16 / NW / UN;   // batches per wave
+    constexpr bool HL = TTP == 8;           // columns 0..7: the blocks' hi weight parts, 8..15: their lo parts
+    const int nb = HL ? (n & 7) : n;        // block column of this lane
     // block groups beyond the last one are clamped onto it: their mixing weights are zero and every stored summary is finite
     // (groups are written completely, blocks beyond M as zeros), so no select is needed
     const u16* g0 = state_bh + (long)min(kg, njg - 1) * FE * IT + n * IT;
     const u16* g1 = state_bh + (long)min(4 + kg, njg - 1) * FE * IT + n * IT;
     auto load_batch = [&](uint4 (&av)[UN][2], int bt) {
-        const long et0 = (long)(wave + NW * ((bt + rot) & (NB - 1))) * UN;
+        const long et0 = (long)(wave + NW * bt) * UN;
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
 #ifdef T16_NOMIXLOAD
@@ -45,10 +54,10 @@ __device__ __forceinline__ void mix16_tile_impl(u16* __restrict__ Gt, const u16*
 #pragma unroll
     for (int b = 0; b < NBUF - 1; ++b) load_batch(buf[b], b);   // the state stream starts before the weights are fetched
 
-    bf16x8 bhi[2], blo[2];
+    bf16x8 bhi[2], blo[2];                  // (HL: bhi carries this lane's part, blo is unused)
     {   // mixing weights of this lane: rows / columns beyond M are clamped for the load and zeroed after (no branches)
         float wv[2][8];
-        const int i = i0 + n, ic = min(i, M - 1);
+        const int i = i0 + nb, ic = min(i, M - 1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -63,9 +72,9 @@ __device__ __forceinline__ void mix16_tile_impl(u16* __restrict__ Gt, const u16*
             for (int t = 0; t < 8; ++t) {
                 const int j = ks * 32 + kg * 8 + t;
                 const float w = (i < M && j < M) ? wv[ks][t] : 0.f;
-                const u16 h = cvt_bf16(w);
-                hi[t] = (short)h;
-                lo[t] = (short)cvt_bf16(w - bf(h));
+                const u16 h = cvt_bf16(w), l = cvt_bf16(w - bf(h));
+                hi[t] = (short)((HL && n >= 8) ? l : h);
+                lo[t] = (short)l;
             }
             bhi[ks] = __builtin_bit_cast(bf16x8, hi);
             blo[ks] = __builtin_bit_cast(bf16x8, lo);
@@ -76,21 +85,29 @@ __device__ __forceinline__ void mix16_tile_impl(u16* __restrict__ Gt, const u16*
         f32x4 c[UN];
 #pragma unroll
         for (int u = 0; u < UN; ++u) c[u] = mfma_bf16(__builtin_bit_cast(bf16x8, av[u][0]), bhi[0], f32x4{0.f, 0.f, 0.f, 0.f});
+        if (!HL) {
 #pragma unroll
-        for (int u = 0; u < UN; ++u) c[u] = mfma_bf16(__builtin_bit_cast(bf16x8, av[u][0]), blo[0], c[u]);
+            for (int u = 0; u < UN; ++u) c[u] = mfma_bf16(__builtin_bit_cast(bf16x8, av[u][0]), blo[0], c[u]);
+        }
         if (TWO) {
 #pragma unroll
             for (int u = 0; u < UN; ++u) c[u] = mfma_bf16(__builtin_bit_cast(bf16x8, av[u][1]), bhi[1], c[u]);
+            if (!HL) {
 #pragma unroll
-            for (int u = 0; u < UN; ++u) c[u] = mfma_bf16(__builtin_bit_cast(bf16x8, av[u][1]), blo[1], c[u]);
+                for (int u = 0; u < UN; ++u) c[u] = mfma_bf16(__builtin_bit_cast(bf16x8, av[u][1]), blo[1], c[u]);
+            }
         }
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
-            const int et = (wave + NW * ((bt + rot) & (NB - 1))) * UN + u, d2 = et >> 2, d1 = (et & 3) * 16 + kg * 4;
+            if (HL) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) c[u][r] += dpp_row_ror8(c[u][r]);   // hi part (column nb) + lo part (column nb + 8)
+            }
+            const int et = (wave + NW * bt) * UN + u, d2 = et >> 2, d1 = (et & 3) * 16 + kg * 4;
             uint2 pk;
             pk.x = pack_bf16x2(c[u][0], c[u][1]);
             pk.y = pack_bf16x2(c[u][2], c[u][3]);
-            *reinterpret_cast<uint2*>(Gt + (long)n * GSLOT + d2 * GLD + d1) = pk;
+            if (!HL || n < 8) *reinterpret_cast<uint2*>(Gt + (long)nb * GSLOT + d2 * GLD + d1) = pk;
         }
     };
 #pragma unroll
@@ -100,15 +117,15 @@ __device__ __forceinline__ void mix16_tile_impl(u16* __restrict__ Gt, const u16*
     }
 }
 
-template <int TRANSW, int NBUF>
-__device__ __forceinline__ void mix16_tile_to_lds(u16* __restrict__ Gt, const u16* __restrict__ state_bh, int njg,
-                                                  const float* __restrict__ W, int ldw, int M, int i0, int tid, int rot) {
-    if (njg > 4) mix16_tile_impl<TRANSW, true, NBUF>(Gt, state_bh, njg, W, ldw, M, i0, tid, rot);
-    else         mix16_tile_impl<TRANSW, false, NBUF>(Gt, state_bh, njg, W, ldw, M, i0, tid, rot);
+template <int TTP, int TRANSW, int NBUF>
+__device__ __forceinline__ void mix_tile_to_lds(u16* __restrict__ Gt, const u16* __restrict__ state_bh, int njg,
+                                                const float* __restrict__ W, int ldw, int M, int i0, int tid) {
+    constexpr int UN = TTP == 16 ? 4 : 2;
+    if (njg > 4) mix_tile_impl<TTP, TRANSW, true, NBUF, UN>(Gt, state_bh, njg, W, ldw, M, i0, tid);
+    else         mix_tile_impl<TTP, TRANSW, false, NBUF, UN>(Gt, state_bh, njg, W, ldw, M, i0, tid);
 }
 // (starting each of a (b,h)'s tile workgroups at a different eighth of the state -- so that the lines in flight towards HBM differ --
-// was measured neutral to slightly slower; rot = 0)
-__device__ __forceinline__ int tile_rot(int, int) { return 0; }
+// was measured neutral to slightly slower)
 
 // Token rows of a 64-row chunk straight from a token view, in MFMA operand layout: a[st][ks] = row 16 st + (lane & 15), columns
 // 32 ks + 8 (lane >> 4) .. + 7.  Rows beyond rv read the block's first row (valid memory, finite values): every consumer of these
@@ -213,33 +230,37 @@ __device__ __forceinline__ void pack_acc(uint2 (&pv)[4][4], const f32x4 (&acc)[4
         for (int tn = 0; tn < 4; ++tn) pv[st][tn] = pack4(acc[st][tn]);
 }
 
-// Side values of the tile's 16 blocks ([16][64] fp32 in LDS): fetched by the whole workgroup before the mixing (two elements per
+// Side values of the tile's blocks ([TTP][64] fp32 in LDS): fetched by the whole workgroup before the mixing (TTP / 8 elements per
 // thread: block (tid >> 6) + 8 t, column tid & 63) and written to LDS just before the barrier that follows it.
-struct SideRegs { float v[2]; };
-__device__ __forceinline__ void side_issue(SideRegs& r, const float* __restrict__ src_bh, int stride, int cols, int blk0, int M, int tid) {
+template <int TTP> struct SideRegs { float v[TTP / 8]; };
+template <int TTP>
+__device__ __forceinline__ void side_issue(SideRegs<TTP>& r, const float* __restrict__ src_bh, int stride, int cols, int blk0, int M, int tid) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < TTP / 8; ++t) {
         const int blk = min(blk0 + (tid >> 6) + 8 * t, M - 1), c = min(tid & 63, cols - 1);
         r.v[t] = gld<float>(src_bh + (long)blk * stride + c);
     }
 }
-__device__ __forceinline__ void side_commit(float* __restrict__ dst, const SideRegs& r, int cols, int tid) {
+template <int TTP>
+__device__ __forceinline__ void side_commit(float* __restrict__ dst, const SideRegs<TTP>& r, int cols, int tid) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t) dst[((tid >> 6) + 8 * t) * 64 + (tid & 63)] = (tid & 63) < cols ? r.v[t] : 0.f;
+    for (int t = 0; t < TTP / 8; ++t) dst[((tid >> 6) + 8 * t) * 64 + (tid & 63)] = (tid & 63) < cols ? r.v[t] : 0.f;
 }
 
-__global__ __launch_bounds__(FT8, 2) void k_t16_out(const FsOutArgs a) {
+template <int TTP>
+__global__ __launch_bounds__(FT8, TTP == 16 ? 2 : 4) void k_tile_out(const FsOutArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    u16* Gt = reinterpret_cast<u16*>(smem_raw);   // [16][64 d2][72]
-    float* sideN = reinterpret_cast<float*>(smem_raw + FS_GT16_BYTES);   // [16][64]  1 / n
+    u16* Gt = reinterpret_cast<u16*>(smem_raw);   // [TTP][64 d2][72]
+    float* sideN = reinterpret_cast<float*>(smem_raw + tile_gt_bytes<TTP>());   // [TTP][64]  1 / n
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, n = lane & 15;
     const int L = xcd_swizzle(blockIdx.x, gridDim.x);
-    const int ntt = (a.njg + 1) / 2, bh = L / ntt, it = L - bh * ntt, b = bh / a.H, h = bh - b * a.H;
+    const int ntt = (a.njg * IT + TTP - 1) / TTP, bh = L / ntt, it = L - bh * ntt, b = bh / a.H, h = bh - b * a.H;
     const int S = a.S, M = a.M;
     const u16* qb = (const u16*)a.q.ptr + b * a.q.sb + h * a.q.sh;
     u16* ob = (u16*)a.o.ptr + b * a.o.sb + h * a.o.sh;
     const float* ninv_bh = a.ninv + (long)bh * M * S;
     const u16* state_bh = a.state + (long)bh * a.njg * FE * IT;
+    constexpr int NBUF = 3;
 
     auto compute_store = [&](bf16x8 (&av)[4][2], int bi, int i, int c0, int rv) {
         const long p0 = (long)i * S + c0;
@@ -269,33 +290,35 @@ __global__ __launch_bounds__(FT8, 2) void k_t16_out(const FsOutArgs a) {
     };
 
     if (S <= 64) {
-        // each wave owns blocks (wave, wave + 8); the operands of both are fetched before the mixing, whose L2 / MALL-bound
-        // phase hides their HBM latency
-        const int iA = it * TT + wave, iB = iA + 8;
-        bf16x8 avA[4][2], avB[4][2];
-        SideRegs sn;
+        // each wave owns block wave (and wave + 8); their operands are fetched before the mixing, whose L2 / MALL-bound phase
+        // hides their HBM latency
+        const int iA = it * TTP + wave, iB = iA + 8;
+        bf16x8 avA[4][2], avB[TTP == 16 ? 4 : 1][2];
+        SideRegs<TTP> sn;
         trace_mark(a.trace, 0);
-        if (a.normalize) side_issue(sn, ninv_bh, S, S, it * TT, M, tid);
+        if (a.normalize) side_issue<TTP>(sn, ninv_bh, S, S, it * TTP, M, tid);
         load_a64(avA, qb, a.q.sn, a.idx, (long)min(iA, M - 1) * S, S, lane);
-        load_a64(avB, qb, a.q.sn, a.idx, (long)min(iB, M - 1) * S, S, lane);
+        if constexpr (TTP == 16) load_a64(avB, qb, a.q.sn, a.idx, (long)min(iB, M - 1) * S, S, lane);
         trace_mark(a.trace, 1);
-        mix16_tile_to_lds<0, 3>(Gt, state_bh, a.njg, a.W, a.ldw, M, it * TT, tid, 0);
-        if (a.normalize) side_commit(sideN, sn, S, tid);
+        mix_tile_to_lds<TTP, 0, NBUF>(Gt, state_bh, a.njg, a.W, a.ldw, M, it * TTP, tid);
+        if (a.normalize) side_commit<TTP>(sideN, sn, S, tid);
         trace_mark(a.trace, 2);
         __syncthreads();
         trace_mark(a.trace, 3);
         if (iA < M) compute_store(avA, wave, iA, 0, S);
         trace_mark(a.trace, 4);
-        if (iB < M) compute_store(avB, wave + 8, iB, 0, S);
+        if constexpr (TTP == 16) {
+            if (iB < M) compute_store(avB, wave + 8, iB, 0, S);
+        }
         trace_mark(a.trace, 5);
         if (a.trace) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); trace_mark(a.trace, 6); }
         return;
     }
 
-    mix16_tile_to_lds<0, 3>(Gt, state_bh, a.njg, a.W, a.ldw, M, it * TT, tid, 0);
+    mix_tile_to_lds<TTP, 0, NBUF>(Gt, state_bh, a.njg, a.W, a.ldw, M, it * TTP, tid);
     __syncthreads();
-    for (int bi = wave; bi < TT; bi += 8) {
-        const int i = it * TT + bi;
+    for (int bi = wave; bi < TTP; bi += 8) {
+        const int i = it * TTP + bi;
         if (i >= M) continue;
         for (int c0 = 0; c0 < S; c0 += 64) {
             const int rv = min(64, S - c0);
@@ -311,21 +334,23 @@ __global__ __launch_bounds__(FT8, 2) void k_t16_out(const FsOutArgs a) {
     }
 }
 
-__global__ __launch_bounds__(FT8, 2) void k_t16_bwd_dq(const FsTokArgs a) {
+template <int TTP>
+__global__ __launch_bounds__(FT8, TTP == 16 ? 2 : 4) void k_tile_bwd_dq(const FsTokArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u16* Gt = reinterpret_cast<u16*>(smem_raw);
-    float* sideN = reinterpret_cast<float*>(smem_raw + FS_GT16_BYTES);   // [16][64]  1 / n
-    float* sideZ = sideN + TT * 64;                                       // [16][64]  dz (zero beyond the block's rows)
-    float* sideK = sideZ + TT * 64;                                       // [16][64]  ksum
+    float* sideN = reinterpret_cast<float*>(smem_raw + tile_gt_bytes<TTP>());   // [TTP][64]  1 / n
+    float* sideZ = sideN + TTP * 64;                                             // [TTP][64]  dz (zero beyond the block's rows)
+    float* sideK = sideZ + TTP * 64;                                             // [TTP][64]  ksum
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, n = lane & 15, kg = lane >> 4;
     const int L = xcd_swizzle(blockIdx.x, gridDim.x);
-    const int ntt = (a.njg + 1) / 2, bh = L / ntt, jgx = L - bh * ntt, b = bh / a.H, h = bh - b * a.H;
+    const int ntt = (a.njg * IT + TTP - 1) / TTP, bh = L / ntt, jgx = L - bh * ntt, b = bh / a.H, h = bh - b * a.H;
     const int S = a.S, M = a.M;
     auto base = [&](const View& w) { return (const u16*)w.ptr + b * w.sb + h * w.sh; };
     auto mbase = [&](const MView& w) { return (u16*)w.ptr + b * w.sb + h * w.sh; };
     const u16 *qb = base(a.q), *gb = base(a.dout);
     u16* dqb = mbase(a.dq);
     const long sofs = (long)bh * a.njg * FE * IT;
+    constexpr int NBUF = TTP == 16 ? 2 : 3;
 
     // one 64-row chunk in two steps: the products (dO G^T)[s][d1] (B[k = d2][c = d1] = Gt[d2][d1]) ...
     auto products = [&](f32x4 (&acc)[4][4], const bf16x8 (&gv)[4][2], int bi) {
@@ -400,49 +425,58 @@ __global__ __launch_bounds__(FT8, 2) void k_t16_bwd_dq(const FsTokArgs a) {
     };
 
     if (S <= 64) {
-        // first block's operands (dO, Q rows) before the mixing; the second block's dO rows right after the barrier (they travel
-        // while the first block is processed) and its Q rows once the first block is done (256 VGPRs: no room earlier)
-        const int jA = jgx * TT + wave, jB = jA + 8, jAc = min(jA, M - 1), jBc = min(jB, M - 1);
+        // TTP = 16: the first block's operands (dO, Q rows) before the mixing; the second block's dO rows right after the barrier
+        // (they travel while the first block is processed) and its Q rows once the first block is done (256 VGPRs: no room earlier).
+        // TTP = 8 (128 VGPRs): dO rows before the mixing, Q rows right after it.
+        const int jA = jgx * TTP + wave, jB = jA + 8, jAc = min(jA, M - 1), jBc = min(jB, M - 1);
         bf16x8 gvA[4][2], qvA[4][2];
-        SideRegs sn, sz, sk;
+        SideRegs<TTP> sn, sz, sk;
         trace_mark(a.trace, 0);
         if (a.normalize) {
-            side_issue(sn, a.ninv + (long)bh * M * S, S, S, jgx * TT, M, tid);
-            side_issue(sz, a.dz + (long)bh * M * S, S, S, jgx * TT, M, tid);
-            side_issue(sk, a.ksum + (long)bh * M * 64, 64, 64, jgx * TT, M, tid);
+            side_issue<TTP>(sn, a.ninv + (long)bh * M * S, S, S, jgx * TTP, M, tid);
+            side_issue<TTP>(sz, a.dz + (long)bh * M * S, S, S, jgx * TTP, M, tid);
+            side_issue<TTP>(sk, a.ksum + (long)bh * M * 64, 64, 64, jgx * TTP, M, tid);
         }
         load_a64(gvA, gb, a.dout.sn, a.idx, (long)jAc * S, S, lane);
-        if (a.normalize) load_a64(qvA, qb, a.q.sn, a.idx, (long)jAc * S, S, lane);
+        if (TTP == 16 && a.normalize) load_a64(qvA, qb, a.q.sn, a.idx, (long)jAc * S, S, lane);
         trace_mark(a.trace, 1);
-        mix16_tile_to_lds<0, 2>(Gt, a.state + sofs, a.njg, a.W, a.ldw, M, jgx * TT, tid, 0);
+        mix_tile_to_lds<TTP, 0, NBUF>(Gt, a.state + sofs, a.njg, a.W, a.ldw, M, jgx * TTP, tid);
+        if (TTP == 8 && a.normalize) load_a64(qvA, qb, a.q.sn, a.idx, (long)jAc * S, S, lane);
         if (a.normalize) {
-            side_commit(sideN, sn, S, tid);
-            side_commit(sideZ, sz, S, tid);
-            side_commit(sideK, sk, 64, tid);
+            side_commit<TTP>(sideN, sn, S, tid);
+            side_commit<TTP>(sideZ, sz, S, tid);
+            side_commit<TTP>(sideK, sk, 64, tid);
         }
         trace_mark(a.trace, 2);
         __syncthreads();
         trace_mark(a.trace, 3);
-        bf16x8 gvB[4][2], qvB[4][2];
         f32x4 acc[4][4];
         float dks_acc[2][8];
-        load_a64(gvB, gb, a.dout.sn, a.idx, (long)jBc * S, S, lane);
-        products(acc, gvA, wave);
-        zero_dks(dks_acc);
-        if (jA < M) { finish_store(acc, qvA, dks_acc, wave, jA, 0, S); if (a.normalize) finish_dks(dks_acc, jA); }
-        trace_mark(a.trace, 4);
-        if (a.normalize) load_a64(qvB, qb, a.q.sn, a.idx, (long)jBc * S, S, lane);      // travels during the second block's products
-        products(acc, gvB, wave + 8);
-        zero_dks(dks_acc);
-        if (jB < M) { finish_store(acc, qvB, dks_acc, wave + 8, jB, 0, S); if (a.normalize) finish_dks(dks_acc, jB); }
+        if constexpr (TTP == 16) {
+            bf16x8 gvB[4][2], qvB[4][2];
+            load_a64(gvB, gb, a.dout.sn, a.idx, (long)jBc * S, S, lane);
+            products(acc, gvA, wave);
+            zero_dks(dks_acc);
+            if (jA < M) { finish_store(acc, qvA, dks_acc, wave, jA, 0, S); if (a.normalize) finish_dks(dks_acc, jA); }
+            trace_mark(a.trace, 4);
+            if (a.normalize) load_a64(qvB, qb, a.q.sn, a.idx, (long)jBc * S, S, lane);      // travels during the second block's products
+            products(acc, gvB, wave + 8);
+            zero_dks(dks_acc);
+            if (jB < M) { finish_store(acc, qvB, dks_acc, wave + 8, jB, 0, S); if (a.normalize) finish_dks(dks_acc, jB); }
+        } else {
+            products(acc, gvA, wave);
+            zero_dks(dks_acc);
+            if (jA < M) { finish_store(acc, qvA, dks_acc, wave, jA, 0, S); if (a.normalize) finish_dks(dks_acc, jA); }
+            trace_mark(a.trace, 4);
+        }
         trace_mark(a.trace, 5);
         if (a.trace) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); trace_mark(a.trace, 6); }
         return;
     }
-    mix16_tile_to_lds<0, 2>(Gt, a.state + sofs, a.njg, a.W, a.ldw, M, jgx * TT, tid, 0);
+    mix_tile_to_lds<TTP, 0, NBUF>(Gt, a.state + sofs, a.njg, a.W, a.ldw, M, jgx * TTP, tid);
     __syncthreads();
-    for (int bi = wave; bi < TT; bi += 8) {
-        const int j = jgx * TT + bi;
+    for (int bi = wave; bi < TTP; bi += 8) {
+        const int j = jgx * TTP + bi;
         if (j >= M) continue;
         float dks_acc[2][8];
         zero_dks(dks_acc);
@@ -468,27 +502,25 @@ __global__ __launch_bounds__(FT8, 2) void k_t16_bwd_dq(const FsTokArgs a) {
     }
 }
 
-__global__ __launch_bounds__(FT8, 2) void k_t16_bwd_dkv(const FsTokArgs a) {
+template <int TTP>
+__global__ __launch_bounds__(FT8, TTP == 16 ? 2 : 4) void k_tile_bwd_dkv(const FsTokArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u16* Gt = reinterpret_cast<u16*>(smem_raw);
-    float* sideK = reinterpret_cast<float*>(smem_raw + FS_GT16_BYTES);   // [16][64]  dksum (k_t16_bwd_dq)
+    float* sideK = reinterpret_cast<float*>(smem_raw + tile_gt_bytes<TTP>());   // [TTP][64]  dksum (k_tile_bwd_dq)
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, kg = lane >> 4;
     if ((int)blockIdx.x >= a.ntiles) {   // tail workgroups: the dW reduction (dW is complete when the backward's last launch is)
         dw_reduce_body(reinterpret_cast<float*>(smem_raw), a.dwp, a.dW, a.M, a.nparts, blockIdx.x - a.ntiles, tid);
         return;
     }
     const int L = xcd_swizzle(blockIdx.x, a.ntiles);
-    const int ntt = (a.njg + 1) / 2, bh = L / ntt, jgx = L - bh * ntt, b = bh / a.H, h = bh - b * a.H;
+    const int ntt = (a.njg * IT + TTP - 1) / TTP, bh = L / ntt, jgx = L - bh * ntt, b = bh / a.H, h = bh - b * a.H;
     const int S = a.S, M = a.M;
     auto base = [&](const View& w) { return (const u16*)w.ptr + b * w.sb + h * w.sh; };
     auto mbase = [&](const MView& w) { return (u16*)w.ptr + b * w.sb + h * w.sh; };
     const u16 *kb = base(a.k), *vb = base(a.v);
     u16 *dkb = mbase(a.dk), *dvb = mbase(a.dv);
     const long sofs = (long)bh * a.njg * FE * IT;
-    auto load_blk = [&](bf16x8 (&kv)[4][2], bf16x8 (&vv)[4][2], int j, int c0, int rv) {
-        load_a64(kv, kb, a.k.sn, a.idx, (long)j * S + c0, rv, lane);
-        load_a64(vv, vb, a.v.sn, a.idx, (long)j * S + c0, rv, lane);
-    };
+    constexpr int NBUF = 3;
     auto compute_store = [&](bf16x8 (&kv)[4][2], const bf16x8 (&vv)[4][2], int bi, int j, int c0, int rv) {
         const long p0 = (long)j * S + c0;
         u16* Gb = Gt + bi * GSLOT;
@@ -533,37 +565,48 @@ __global__ __launch_bounds__(FT8, 2) void k_t16_bwd_dkv(const FsTokArgs a) {
     };
 
     if (S <= 64) {
-        const int jA = jgx * TT + wave, jB = jA + 8;
+        // TTP = 16: the first block's K and V rows before the mixing, the second block's right after the barrier.
+        // TTP = 8 (128 VGPRs): K rows before the mixing, V rows right after it.
+        const int jA = jgx * TTP + wave, jB = jA + 8, jAc = min(jA, M - 1), jBc = min(jB, M - 1);
         bf16x8 kvA[4][2], vvA[4][2];
-        SideRegs sk;
+        SideRegs<TTP> sk;
         trace_mark(a.trace, 0);
-        if (a.normalize) side_issue(sk, a.dksum + (long)bh * M * 64, 64, 64, jgx * TT, M, tid);
-        load_blk(kvA, vvA, min(jA, M - 1), 0, S);
+        if (a.normalize) side_issue<TTP>(sk, a.dksum + (long)bh * M * 64, 64, 64, jgx * TTP, M, tid);
+        load_a64(kvA, kb, a.k.sn, a.idx, (long)jAc * S, S, lane);
+        if (TTP == 16) load_a64(vvA, vb, a.v.sn, a.idx, (long)jAc * S, S, lane);
         trace_mark(a.trace, 1);
-        mix16_tile_to_lds<1, 3>(Gt, a.dstate + sofs, a.njg, a.W, a.ldw, M, jgx * TT, tid, 0);
-        if (a.normalize) side_commit(sideK, sk, 64, tid);
+        mix_tile_to_lds<TTP, 1, NBUF>(Gt, a.dstate + sofs, a.njg, a.W, a.ldw, M, jgx * TTP, tid);
+        if (TTP == 8) load_a64(vvA, vb, a.v.sn, a.idx, (long)jAc * S, S, lane);
+        if (a.normalize) side_commit<TTP>(sideK, sk, 64, tid);
         trace_mark(a.trace, 2);
         __syncthreads();
         trace_mark(a.trace, 3);
-        bf16x8 kvB[4][2], vvB[4][2];
-        load_blk(kvB, vvB, min(jB, M - 1), 0, S);
-        if (jA < M) compute_store(kvA, vvA, wave, jA, 0, S);
-        trace_mark(a.trace, 4);
-        if (jB < M) compute_store(kvB, vvB, wave + 8, jB, 0, S);
+        if constexpr (TTP == 16) {
+            bf16x8 kvB[4][2], vvB[4][2];
+            load_a64(kvB, kb, a.k.sn, a.idx, (long)jBc * S, S, lane);
+            load_a64(vvB, vb, a.v.sn, a.idx, (long)jBc * S, S, lane);
+            if (jA < M) compute_store(kvA, vvA, wave, jA, 0, S);
+            trace_mark(a.trace, 4);
+            if (jB < M) compute_store(kvB, vvB, wave + 8, jB, 0, S);
+        } else {
+            if (jA < M) compute_store(kvA, vvA, wave, jA, 0, S);
+            trace_mark(a.trace, 4);
+        }
         trace_mark(a.trace, 5);
         if (a.trace) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); trace_mark(a.trace, 6); }
         return;
     }
-    mix16_tile_to_lds<1, 3>(Gt, a.dstate + sofs, a.njg, a.W, a.ldw, M, jgx * TT, tid, 0);
+    mix_tile_to_lds<TTP, 1, NBUF>(Gt, a.dstate + sofs, a.njg, a.W, a.ldw, M, jgx * TTP, tid);
     __syncthreads();
-    for (int bi = wave; bi < TT; bi += 8) {
-        const int j = jgx * TT + bi;
+    for (int bi = wave; bi < TTP; bi += 8) {
+        const int j = jgx * TTP + bi;
         if (j >= M) continue;
         if (a.normalize) sideK[bi * 64 + lane] = gld<float>(a.dksum + ((long)bh * M + j) * 64 + lane);
         for (int c0 = 0; c0 < S; c0 += 64) {
             const int rv = min(64, S - c0);
             bf16x8 kv[4][2], vv[4][2];
-            load_blk(kv, vv, j, c0, rv);
+            load_a64(kv, kb, a.k.sn, a.idx, (long)j * S + c0, rv, lane);
+            load_a64(vv, vb, a.v.sn, a.idx, (long)j * S + c0, rv, lane);
             wave_lds_fence();
             compute_store(kv, vv, bi, j, c0, rv);
         }

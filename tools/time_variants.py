@@ -8,11 +8,15 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# "env:NAME=VALUE" arguments time the shipped library under that environment setting (e.g. env:MHLA_TILE=811)
 names = sys.argv[1:] or sorted(os.path.basename(p)[len("libmhla_"):-3] for p in glob.glob(os.path.join(ROOT, "mhla_amd/lib/variants/libmhla_*.so")))
 rows = []
 for nm in ["shipped"] + names:
     env = dict(os.environ)
-    if nm != "shipped":
+    if nm.startswith("env:"):
+        k_, v_ = nm[4:].split("=", 1)
+        env[k_] = v_
+    elif nm != "shipped":
         env["MHLA_LIB_PATH"] = os.path.join(ROOT, "mhla_amd/lib/variants", f"libmhla_{nm}.so")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-extra-configs", "--steps", "40"],
                          env=env, capture_output=True, text=True)
