@@ -219,7 +219,7 @@ def main():
     alg_bytes = 12 * nde                                      # fwd 4 NDe + bwd 8 NDe per (b, h)
     # share of the algorithmic token traffic each kernel is responsible for: the dominant kernel's own
     # roofline fraction is its share / its duration
-    share = {"k_t16_bwd_dkv": 4, "k_t16_bwd_dq": 3, "k_t16_out": 2, "k_t8_bwd_dkv": 4, "k_t8_bwd_dq": 3, "k_t8_out": 2,
+    share = {"k_t16_bwd": 7, "k_t16_bwd_dkv": 4, "k_t16_bwd_dq": 3, "k_t16_out": 2,
              "k_fs_state_fwd": 2, "k_fs_state<1>": 3,
              "k_bm_bwd_tok": 7, "k_bm_state<0>": 2, "k_bm_state<1>": 3, "k_bm_out": 2}
     # HBM bytes per step: PMC counters cannot be read from inside this process, so the figure comes from the rocprofv3 PMC

@@ -167,6 +167,7 @@ static int launch_state1c(const fast::FsStateArgs& sa, int njg, int BH, hipStrea
 struct FastWs {
     fast::u16 *state, *dstate;
     float *z, *ksum, *ninv, *dn, *dz, *dwp, *dksum;
+    int* done;   // per 16-block tile: dQ done (k_tile_bwd)
     size_t total_fwd, total_bwd;
     int njg;
 };
@@ -186,6 +187,7 @@ FastWs fast_carve(void* ws, int B, int H, int M, int S) {
     w.dz = (float*)p; p += al4(bh * M * S) * 4;
     w.dksum = (float*)p; p += al4(bh * M * 64) * 4;
     w.dwp = (float*)p; p += bh * fast::DW_SPLIT * 4096 * 4;
+    w.done = (int*)p; p += al4(bh * ((w.njg + 1) / 2)) * 4;
     w.total_bwd = (size_t)(p - (char*)ws);
     return w;
 }
@@ -542,7 +544,7 @@ int mhla_blockmix_bwd(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q
             else RC(launch(fast::k_fs_state<1>, dim3(f.njg, B * H), dim3(fast::FT8), fast::FS_STATE_SMEM, st, "k_fs_state<1>", ga));
             // dW needs only dG^T, KV^T, dn and z, all complete here; dz = W^T dn (needed by the token-gradient kernels) rides in
             // the same launch as extra workgroups
-            fast::FsDwArgs da{f.dstate, state, normalize ? f.dn : nullptr, z, f.dwp, M, S, f.njg, W, ldw, f.dz};
+            fast::FsDwArgs da{f.dstate, state, normalize ? f.dn : nullptr, z, f.dwp, M, S, f.njg, W, ldw, f.dz, f.done, (f.njg + 1) / 2};
             hipStream_t sd = st;
             const int nwz = normalize ? (S + fast::WZ_C - 1) / fast::WZ_C : 0;
             RC(launch(fast::k_fs_dw, dim3(fast::DW_SPLIT + nwz, B * H), dim3(fast::FT8), fast::FS_DW_SMEM, sd, "k_fs_dw", da));
@@ -553,12 +555,10 @@ int mhla_blockmix_bwd(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q
             ta.normalize = normalize;
             ta.dksum = f.dksum;
             const long ntile_wgs = (long)((f.njg + 1) / 2) * B * H;
-            unsigned long long* tr = g_trace.load();   // regions: [0] k_t16_out, [1] k_t16_bwd_dq, [2] k_t16_bwd_dkv
+            unsigned long long* tr = g_trace.load();   // regions: [0] k_t16_out, [1] dQ role, [2] dK/dV role (record = ntiles + blockIdx.x)
             ta.trace = tr ? tr + ntile_wgs * fast::TRACE_SLOTS : nullptr;
-            RC(launch(fast::k_tile_bwd_dq<16>, dim3((unsigned)ntile_wgs), dim3(fast::FT8), fast::tile_smem<16>(), st, "k_t16_bwd_dq", ta));
-            ta.trace = tr ? tr + 2 * ntile_wgs * fast::TRACE_SLOTS : nullptr;
-            ta.dwp = f.dwp; ta.dW = dW; ta.nparts = B * H * fast::DW_SPLIT; ta.ntiles = (int)ntile_wgs;
-            RC(launch(fast::k_tile_bwd_dkv<16>, dim3((unsigned)ntile_wgs + fast::DWR_WGS), dim3(fast::FT8), fast::tile_smem<16>(), st, "k_t16_bwd_dkv", ta));
+            ta.dwp = f.dwp; ta.dW = dW; ta.nparts = B * H * fast::DW_SPLIT; ta.ntiles = (int)ntile_wgs; ta.done = f.done;
+            RC(launch(fast::k_tile_bwd<16>, dim3((unsigned)(2 * ntile_wgs) + fast::DWR_WGS), dim3(fast::FT8), fast::tile_smem<16>(), st, "k_t16_bwd", ta));
             return MHLA_OK;
         }
     }

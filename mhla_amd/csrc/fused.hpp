@@ -888,6 +888,9 @@ struct FsDwArgs {
     const float* W;
     int ldw;
     float* dz;
+    // per-tile "dQ done" flags of the token-gradient launch that follows (k_tile_bwd): cleared here, one workgroup per (b,h)
+    int* done;
+    int ntt;
 };
 constexpr int DW_EC = 128;                       // e' rows per LDS image
 constexpr int DW_SPLIT = 8;                      // e' splits per (b,h)
@@ -901,6 +904,7 @@ __global__ __launch_bounds__(FT8) void k_fs_dw(const FsDwArgs a) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 15, kg = lane >> 4;
     const int wi = wave & 3, wj = wave >> 2;   // wave -> rows i = 16 wi .., columns j = 32 wj ..
     const int qtr = blockIdx.x, bh = blockIdx.y, njg = a.njg;
+    if (qtr == 0 && a.done && tid < a.ntt) a.done[bh * a.ntt + tid] = 0;
     if (qtr >= DW_SPLIT) {   // workgroup-uniform role switch
         wz_body<1, FT8>(reinterpret_cast<float*>(smem_raw), a.W, a.ldw, a.dn, a.dz, a.M, a.S, 0.f, qtr - DW_SPLIT, bh, tid);
         return;
@@ -1044,12 +1048,33 @@ struct FsTokArgs {
     int H, M, S, njg;
     float eps;
     int relu, normalize;
-    // k_t16_bwd_dkv only: its last DWR_WGS workgroups reduce the dW partials (dw_reduce_body)
+    // the launch's last DWR_WGS workgroups reduce the dW partials (dw_reduce_body)
     const float* dwp;
     float* dW;
     int nparts, ntiles;
+    int* done;          // [ntiles]: set by a tile's dQ workgroup once its dksum rows are written, awaited by its dK/dV workgroup
     unsigned long long* trace;
 };
+// Hand-over of a tile's dksum rows between two workgroups of one launch (the waiting one has the higher blockIdx: it is dispatched
+// after the signalling one, which never waits itself).  No fences: an agent-scope release / acquire pair writes back and
+// invalidates the XCD's whole L2, which every other workgroup on it pays for (measured: 3.5x the kernel time).  Instead the few
+// values that cross are written and read with agent-coherent accesses (sc1: through to / from the memory side), the writer waits
+// for its stores to be acknowledged (vmcnt(0)) before the flag goes out, and the flag is polled with the same kind of load.
+__device__ __forceinline__ void coherent_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float coherent_load(const float* p) {
+    return __hip_atomic_load(const_cast<float*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void tile_signal(int* flag, int tid) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void tile_wait(int* flag, int tid) {
+    if (tid == 0) {
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(16);
+    }
+    __syncthreads();
+}
 constexpr int FS_TOK_SMEM = FS_GT_BYTES;
 
 }  // namespace fast

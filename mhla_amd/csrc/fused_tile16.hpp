@@ -233,12 +233,12 @@ __device__ __forceinline__ void pack_acc(uint2 (&pv)[4][4], const f32x4 (&acc)[4
 // Side values of the tile's blocks ([TTP][64] fp32 in LDS): fetched by the whole workgroup before the mixing (TTP / 8 elements per
 // thread: block (tid >> 6) + 8 t, column tid & 63) and written to LDS just before the barrier that follows it.
 template <int TTP> struct SideRegs { float v[TTP / 8]; };
-template <int TTP>
+template <int TTP, bool COHERENT = false>
 __device__ __forceinline__ void side_issue(SideRegs<TTP>& r, const float* __restrict__ src_bh, int stride, int cols, int blk0, int M, int tid) {
 #pragma unroll
     for (int t = 0; t < TTP / 8; ++t) {
         const int blk = min(blk0 + (tid >> 6) + 8 * t, M - 1), c = min(tid & 63, cols - 1);
-        r.v[t] = gld<float>(src_bh + (long)blk * stride + c);
+        r.v[t] = COHERENT ? coherent_load(src_bh + (long)blk * stride + c) : gld<float>(src_bh + (long)blk * stride + c);
     }
 }
 template <int TTP>
@@ -334,15 +334,15 @@ __global__ __launch_bounds__(FT8, TTP == 16 ? 2 : 4) void k_tile_out(const FsOut
     }
 }
 
+// dQ role of k_tile_bwd: workgroup wg of nwg
 template <int TTP>
-__global__ __launch_bounds__(FT8, TTP == 16 ? 2 : 4) void k_tile_bwd_dq(const FsTokArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+__device__ __forceinline__ void tile_bwd_dq_body(const FsTokArgs& a, unsigned char* smem_raw, int wg, int nwg) {
     u16* Gt = reinterpret_cast<u16*>(smem_raw);
     float* sideN = reinterpret_cast<float*>(smem_raw + tile_gt_bytes<TTP>());   // [TTP][64]  1 / n
     float* sideZ = sideN + TTP * 64;                                             // [TTP][64]  dz (zero beyond the block's rows)
     float* sideK = sideZ + TTP * 64;                                             // [TTP][64]  ksum
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, n = lane & 15, kg = lane >> 4;
-    const int L = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int L = xcd_swizzle(wg, nwg);
     const int ntt = (a.njg * IT + TTP - 1) / TTP, bh = L / ntt, jgx = L - bh * ntt, b = bh / a.H, h = bh - b * a.H;
     const int S = a.S, M = a.M;
     auto base = [&](const View& w) { return (const u16*)w.ptr + b * w.sb + h * w.sh; };
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(FT8, TTP == 16 ? 2 : 4) void k_tile_bwd_dq(const Fs
             v2[t] = keep + __shfl_xor(send, 2, 64);
         }
         const float send = b1 ? v2[0] : v2[1], keep = b1 ? v2[1] : v2[0];
-        gst<float>(a.dksum + ((long)bh * M + j) * 64 + 32 * (n >> 3) + 8 * kg + (n & 7), keep + __shfl_xor(send, 1, 64));
+        coherent_store(a.dksum + ((long)bh * M + j) * 64 + 32 * (n >> 3) + 8 * kg + (n & 7), keep + __shfl_xor(send, 1, 64));
     };
     auto zero_dks = [](float (&d)[2][8]) {
 #pragma unroll
@@ -471,6 +471,7 @@ __global__ __launch_bounds__(FT8, TTP == 16 ? 2 : 4) void k_tile_bwd_dq(const Fs
         }
         trace_mark(a.trace, 5);
         if (a.trace) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); trace_mark(a.trace, 6); }
+        if (a.normalize) tile_signal(a.done + L, tid);   // this tile's dksum rows are written
         return;
     }
     mix_tile_to_lds<TTP, 0, NBUF>(Gt, a.state + sofs, a.njg, a.W, a.ldw, M, jgx * TTP, tid);
@@ -500,19 +501,17 @@ __global__ __launch_bounds__(FT8, TTP == 16 ? 2 : 4) void k_tile_bwd_dq(const Fs
         }
         if (a.normalize) finish_dks(dks_acc, j);
     }
+    if (a.normalize) tile_signal(a.done + L, tid);
 }
 
+// dK / dV role of k_tile_bwd: workgroup wg of nwg.  The only thing it needs from the dQ role is the tile's dksum rows (awaited just
+// before they are fetched, after the mixing).
 template <int TTP>
-__global__ __launch_bounds__(FT8, TTP == 16 ? 2 : 4) void k_tile_bwd_dkv(const FsTokArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+__device__ __forceinline__ void tile_bwd_dkv_body(const FsTokArgs& a, unsigned char* smem_raw, int wg, int nwg) {
     u16* Gt = reinterpret_cast<u16*>(smem_raw);
-    float* sideK = reinterpret_cast<float*>(smem_raw + tile_gt_bytes<TTP>());   // [TTP][64]  dksum (k_tile_bwd_dq)
+    float* sideK = reinterpret_cast<float*>(smem_raw + tile_gt_bytes<TTP>());   // [TTP][64]  dksum (dQ role)
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, kg = lane >> 4;
-    if ((int)blockIdx.x >= a.ntiles) {   // tail workgroups: the dW reduction (dW is complete when the backward's last launch is)
-        dw_reduce_body(reinterpret_cast<float*>(smem_raw), a.dwp, a.dW, a.M, a.nparts, blockIdx.x - a.ntiles, tid);
-        return;
-    }
-    const int L = xcd_swizzle(blockIdx.x, a.ntiles);
+    const int L = xcd_swizzle(wg, nwg);
     const int ntt = (a.njg * IT + TTP - 1) / TTP, bh = L / ntt, jgx = L - bh * ntt, b = bh / a.H, h = bh - b * a.H;
     const int S = a.S, M = a.M;
     auto base = [&](const View& w) { return (const u16*)w.ptr + b * w.sb + h * w.sh; };
@@ -571,13 +570,16 @@ __global__ __launch_bounds__(FT8, TTP == 16 ? 2 : 4) void k_tile_bwd_dkv(const F
         bf16x8 kvA[4][2], vvA[4][2];
         SideRegs<TTP> sk;
         trace_mark(a.trace, 0);
-        if (a.normalize) side_issue<TTP>(sk, a.dksum + (long)bh * M * 64, 64, 64, jgx * TTP, M, tid);
         load_a64(kvA, kb, a.k.sn, a.idx, (long)jAc * S, S, lane);
         if (TTP == 16) load_a64(vvA, vb, a.v.sn, a.idx, (long)jAc * S, S, lane);
         trace_mark(a.trace, 1);
         mix_tile_to_lds<TTP, 1, NBUF>(Gt, a.dstate + sofs, a.njg, a.W, a.ldw, M, jgx * TTP, tid);
         if (TTP == 8) load_a64(vvA, vb, a.v.sn, a.idx, (long)jAc * S, S, lane);
-        if (a.normalize) side_commit<TTP>(sideK, sk, 64, tid);
+        if (a.normalize) {
+            tile_wait(a.done + L, tid);
+            side_issue<TTP, true>(sk, a.dksum + (long)bh * M * 64, 64, 64, jgx * TTP, M, tid);
+            side_commit<TTP>(sideK, sk, 64, tid);
+        }
         trace_mark(a.trace, 2);
         __syncthreads();
         trace_mark(a.trace, 3);
@@ -597,11 +599,12 @@ __global__ __launch_bounds__(FT8, TTP == 16 ? 2 : 4) void k_tile_bwd_dkv(const F
         return;
     }
     mix_tile_to_lds<TTP, 1, NBUF>(Gt, a.dstate + sofs, a.njg, a.W, a.ldw, M, jgx * TTP, tid);
+    if (a.normalize) tile_wait(a.done + L, tid);
     __syncthreads();
     for (int bi = wave; bi < TTP; bi += 8) {
         const int j = jgx * TTP + bi;
         if (j >= M) continue;
-        if (a.normalize) sideK[bi * 64 + lane] = gld<float>(a.dksum + ((long)bh * M + j) * 64 + lane);
+        if (a.normalize) sideK[bi * 64 + lane] = coherent_load(a.dksum + ((long)bh * M + j) * 64 + lane);
         for (int c0 = 0; c0 < S; c0 += 64) {
             const int rv = min(64, S - c0);
             bf16x8 kv[4][2], vv[4][2];
@@ -611,6 +614,18 @@ __global__ __launch_bounds__(FT8, TTP == 16 ? 2 : 4) void k_tile_bwd_dkv(const F
             compute_store(kv, vv, bi, j, c0, rv);
         }
     }
+}
+
+// The backward's token gradients in ONE launch: workgroups [0, ntiles) compute dQ (and dksum), [ntiles, 2 ntiles) dK and dV, the
+// last DWR_WGS reduce the dW partials.  dQ and dK/dV tiles of 25-30 us each in two rounds per kernel left the chip waiting for the
+// slowest workgroup twice (about 20 us per kernel); as one launch of four rounds the dK/dV tiles fill the dQ tail.
+template <int TTP>
+__global__ __launch_bounds__(FT8, TTP == 16 ? 2 : 4) void k_tile_bwd(const FsTokArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int x = blockIdx.x;
+    if (x < a.ntiles) tile_bwd_dq_body<TTP>(a, smem_raw, x, a.ntiles);
+    else if (x < 2 * a.ntiles) tile_bwd_dkv_body<TTP>(a, smem_raw, x - a.ntiles, a.ntiles);
+    else dw_reduce_body(reinterpret_cast<float*>(smem_raw), a.dwp, a.dW, a.M, a.nparts, x - 2 * a.ntiles, threadIdx.x);
 }
 
 }  // namespace fast
