@@ -26,8 +26,8 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=30)
-    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--steps", type=int, default=200)
+    p.add_argument("--warmup", type=int, default=10)
     p.add_argument("--B", type=int, default=8)
     p.add_argument("--N", type=int, default=4096)
     p.add_argument("--H", type=int, default=16)
@@ -40,6 +40,7 @@ def parse():
     p.add_argument("--no-graph", dest="graph", action="store_false",
                    help="launch every step eagerly through Python autograd instead of replaying the captured HIP graph")
     p.set_defaults(graph=True)
+    p.add_argument("--graph-steps", type=int, default=10, help="whole steps captured per HIP graph on one GPU (1: one step per replay)")
     return p.parse_args()
 
 
@@ -146,6 +147,7 @@ def main():
 
     sync = torch.cuda.synchronize
     eager_step = step
+    step_group, group = None, 1
     launch_mode = "eager (Python autograd)"
     if a.graph:
         # Whole-step capture: the forward + backward (both autograd calls, their workspace allocations, every launch) is
@@ -170,17 +172,28 @@ def main():
                 reducer.issue(W.grad.clone() if world > 1 else W.grad)
 
             launch_mode = "hipGraph replay of the captured fwd+bwd step"
+            if world == 1 and a.graph_steps > 1:
+                # one GPU: no per-step exchange, so several whole steps go into one graph (each replay costs ~15 us of device-side
+                # start-up whatever it holds); every captured step is the complete forward + backward on the same inputs
+                q.grad = k.grad = v.grad = W.grad = None
+                graph_g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph_g):
+                    for _ in range(a.graph_steps):
+                        mhla_amd.mhla_blockmix(q, k, v, W, eps=1e-6).backward(do)
+                        q.grad = k.grad = v.grad = W.grad = None
+                step_group, group = graph_g.replay, a.graph_steps
+                launch_mode = f"hipGraph replay, {a.graph_steps} captured fwd+bwd steps per replay (remainder: one step per replay)"
         except Exception as e:   # noqa: BLE001
             if rank == 0:
                 print(f"[bench] graph capture failed ({type(e).__name__}: {e}); eager launches", file=sys.stderr)
             q.grad = k.grad = v.grad = W.grad = None
-            step = eager_step
+            step, step_group, group = eager_step, None, 1
 
     def sync_all():
         reducer.wait()
         sync()
 
-    el = mdist.timed_steps(step, a.steps, a.warmup, sync_all)
+    el = mdist.timed_steps(step, a.steps, a.warmup, sync_all, step_group, group)
     ms_per_step = el / a.steps * 1e3
     tokens_per_step = a.B * a.N * world
     value = tokens_per_step / (el / a.steps)
@@ -190,8 +203,7 @@ def main():
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     sync_all()
     ev0.record()
-    for _ in range(a.steps):
-        step()
+    mdist.run_steps(step, a.steps, step_group, group)
     ev1.record()
     sync_all()
     step_gpu_us = ev0.elapsed_time(ev1) / a.steps * 1e3

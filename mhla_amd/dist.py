@@ -123,18 +123,28 @@ class OverlappedGradAllReduce:
             self._pending = None
 
 
-def timed_steps(step: Callable[[], None], steps: int, warmup: int, sync: Callable[[], None]) -> float:
+def run_steps(step: Callable[[], None], n: int, step_group: Optional[Callable[[], None]] = None, group: int = 1) -> None:
+    """Exactly n steps: n // group calls of `step_group` (one call = `group` steps, e.g. the replay of a graph that holds
+    `group` captured steps) and the remainder as single steps."""
+    if step_group is not None and group > 1:
+        for _ in range(n // group):
+            step_group()
+        n %= group
+    for _ in range(n):
+        step()
+
+
+def timed_steps(step: Callable[[], None], steps: int, warmup: int, sync: Callable[[], None],
+                step_group: Optional[Callable[[], None]] = None, group: int = 1) -> float:
     """W untimed warm-up steps, then exactly K steps bracketed by barrier + device sync on both sides.
     Returns the MAX over ranks of the elapsed seconds."""
-    for _ in range(warmup):
-        step()
+    run_steps(step, warmup, step_group, group)
     sync()
     if dist.is_initialized():
         dist.barrier()
     sync()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
+    run_steps(step, steps, step_group, group)
     sync()
     if dist.is_initialized():
         dist.barrier()
