@@ -43,10 +43,13 @@ struct SnArgs {
 template <int DT>
 __host__ __device__ constexpr int sn_ldr() { return DT * 16 + 8; }   // LDS row stride (bf16): 72 (144 B) / 88 (176 B)
 
-// stage `nrows` token rows (D valid columns, zero up to DP) into an LDS tile [nrows][LDR]
-template <int DT, bool RELU, int NT = SN_T>
+// stage `nrows` token rows (D valid columns, zero up to DP) into an LDS tile [nrows][LDR]; optionally every row scaled by
+// rowscale[r] (fp32, LDS).  All loads are issued before any is used, from clamped (always valid) addresses with no branch around them
+// -- a load inside `if (r < nrows && p < dv)` makes the compiler wait for it at the end of the branch, one memory latency per piece.
+__device__ __forceinline__ uint4 sel4(bool c, uint4 v) { return make_uint4(c ? v.x : 0u, c ? v.y : 0u, c ? v.z : 0u, c ? v.w : 0u); }
+template <int DT, int NT = SN_T, bool SCALE = false>
 __device__ __forceinline__ void sn_stage(u16* __restrict__ dst, const u16* __restrict__ base, long sn, const int* __restrict__ idx,
-                                         int nrows, int D, float eps, int tid) {
+                                         int nrows, int D, float eps, int tid, bool relu, const float* __restrict__ rowscale = nullptr) {
     constexpr int LDR = sn_ldr<DT>(), PV = DT * 2;   // 16-byte pieces per padded row
     const int dv = D >> 3;
     constexpr int MAXIT = (256 * PV + NT - 1) / NT;
@@ -54,34 +57,54 @@ __device__ __forceinline__ void sn_stage(u16* __restrict__ dst, const u16* __res
 #pragma unroll
     for (int t = 0; t < MAXIT; ++t) {
         const int v = tid + t * NT, r = v / PV, p = v - r * PV;
-        reg[t] = make_uint4(0, 0, 0, 0);
-        if (r < nrows && p < dv) {
-            reg[t] = *reinterpret_cast<const uint4*>(base + tok_row(idx, r) * sn + p * 8);
-            if (RELU) reg[t] = relu_eps8(reg[t], eps);
-        }
+        reg[t] = gld<uint4>(base + tok_row(idx, min(r, nrows - 1)) * sn + min(p, dv - 1) * 8);
     }
 #pragma unroll
     for (int t = 0; t < MAXIT; ++t) {
         const int v = tid + t * NT, r = v / PV, p = v - r * PV;
-        if (r < nrows) *reinterpret_cast<uint4*>(dst + r * LDR + p * 8) = reg[t];
+        if (r < nrows) {
+            uint4 x = reg[t];
+            if (relu) x = relu_eps8(x, eps);   // (uniform)
+            if (SCALE) {
+                const float sc = rowscale[r];
+                unsigned w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    w[u] = pack_bf16x2(__uint_as_float(w[u] << 16) * sc, __uint_as_float(w[u] & 0xffff0000u) * sc);
+                x = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+            *reinterpret_cast<uint4*>(dst + r * LDR + p * 8) = sel4(p < dv, x);
+        }
     }
 }
 
 // 16 rows x KS k-steps of an MFMA operand straight from global: lane (m = lane & 15, kg) -> row0 + m, cols 32 ks + 8 kg ..
-template <int KS, bool RELU>
-__device__ __forceinline__ void sn_load_rows(bf16x8 (&a)[KS], const u16* __restrict__ base, long sn, const int* __restrict__ idx,
-                                             int row0, int D, float eps, int lane) {
+// (columns beyond D: a clamped address, zeroed on arrival).  In two halves, so that a kernel can request all its rows first and touch
+// them (relu + eps, zeroing) only where they are consumed.
+template <int KS>
+__device__ __forceinline__ void sn_issue_rows(uint4 (&v)[KS], const u16* __restrict__ base, long sn, const int* __restrict__ idx,
+                                              int row0, int D, int lane) {
     const int m = lane & 15, kg = lane >> 4;
-    const u16* src = base + tok_row(idx, row0 + m) * sn + kg * 8;
+    const u16* src = base + tok_row(idx, row0 + m) * sn;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) v[ks] = gld<uint4>(src + min(ks * 32 + kg * 8, D - 8));
+}
+template <int KS>
+__device__ __forceinline__ void sn_finish_rows(bf16x8 (&a)[KS], const uint4 (&v)[KS], int D, float eps, int lane, bool relu) {
+    const int kg = lane >> 4;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (ks * 32 + kg * 8 < D) {
-            v = *reinterpret_cast<const uint4*>(src + ks * 32);
-            if (RELU) v = relu_eps8(v, eps);
-        }
-        a[ks] = __builtin_bit_cast(bf16x8, v);
+        uint4 x = v[ks];
+        if (relu) x = relu_eps8(x, eps);   // (uniform; no memory operation inside the branch)
+        a[ks] = __builtin_bit_cast(bf16x8, sel4(ks * 32 + kg * 8 < D, x));
     }
+}
+template <int KS>
+__device__ __forceinline__ void sn_load_rows(bf16x8 (&a)[KS], const u16* __restrict__ base, long sn, const int* __restrict__ idx,
+                                             int row0, int D, float eps, int lane, bool relu = false) {
+    uint4 v[KS];
+    sn_issue_rows<KS>(v, base, sn, idx, row0, D, lane);
+    sn_finish_rows<KS>(a, v, D, eps, lane, relu);
 }
 // the same from an LDS tile [rows][LDR]
 template <int KS>
@@ -166,7 +189,9 @@ __global__ __launch_bounds__(SN_T, SN_T / 256) void k_sn_fwd(const SnArgs a) {
     float* zs = ksum_s + 16 * DP;                        // [M][16]
     u16* Ost = reinterpret_cast<u16*>(zs + 256);         // [8 waves][16][LDR] output staging
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, n = lane & 15, kg = lane >> 4;
-    const int bh = blockIdx.x, b = bh / a.H, h = bh - b * a.H;
+    // (b,h) pairs in XCD-contiguous order: a token's heads are adjacent in memory (144-byte rows for D = 72: neighbouring heads share
+    // cache lines), so the heads of one batch element go to workgroups of ONE XCD, running side by side, and each line is fetched once
+    const int bh = xcd_swizzle(blockIdx.x, gridDim.x), b = bh / a.H, h = bh - b * a.H;
     const int M = a.M, D = a.D, N = M * 16;
     const u16* qb = (const u16*)a.q.ptr + b * a.q.sb + h * a.q.sh;
     const u16* kb = (const u16*)a.k.ptr + b * a.k.sb + h * a.k.sh;
@@ -175,9 +200,12 @@ __global__ __launch_bounds__(SN_T, SN_T / 256) void k_sn_fwd(const SnArgs a) {
 
     __shared__ float Wsh[16 * 17];   // mixing weights (M <= 16): read in the inner loops, so kept off the global-load path
     if (tid < 256) Wsh[(tid >> 4) * 17 + (tid & 15)] = ((tid >> 4) < M && (tid & 15) < M) ? a.W[(long)(tid >> 4) * a.ldw + (tid & 15)] : 0.f;
-    if (a.relu) sn_stage<DT, true>(Ks, kb, a.k.sn, a.idx, N, D, a.eps, tid);
-    else        sn_stage<DT, false>(Ks, kb, a.k.sn, a.idx, N, D, a.eps, tid);
-    sn_stage<DT, false>(Vs, vb, a.v.sn, a.idx, N, D, 0.f, tid);
+    // the wave's own Q rows are requested first: they travel while K, V are staged
+    uint4 qraw[2][KS];
+#pragma unroll
+    for (int x = 0; x < 2; ++x) sn_issue_rows<KS>(qraw[x], qb, a.q.sn, a.idx, min(wave + SN_W * x, M - 1) * 16, D, lane);
+    sn_stage<DT>(Ks, kb, a.k.sn, a.idx, N, D, a.eps, tid, a.relu != 0);
+    sn_stage<DT>(Vs, vb, a.v.sn, a.idx, N, D, 0.f, tid, false);
     __syncthreads();
     if (a.normalize) {
         for (int v = tid; v < M * DP; v += SN_T) {
@@ -195,8 +223,7 @@ __global__ __launch_bounds__(SN_T, SN_T / 256) void k_sn_fwd(const SnArgs a) {
     for (int x = 0; x < 2; ++x) {
         const int i = wave + SN_W * x;
         if (i < M) {
-            if (a.relu) sn_load_rows<KS, true>(qa[x], qb, a.q.sn, a.idx, i * 16, D, a.eps, lane);
-            else        sn_load_rows<KS, false>(qa[x], qb, a.q.sn, a.idx, i * 16, D, a.eps, lane);
+            sn_finish_rows<KS>(qa[x], qraw[x], D, a.eps, lane, a.relu != 0);
             if (a.normalize) {
                 float z = 0.f;
 #pragma unroll
@@ -301,7 +328,9 @@ __global__ __launch_bounds__(SN_TB, 2) void k_sn_bwd(const SnArgs a) {
     float* dzs = dns + 256;                              // dz
     u16* Ost = reinterpret_cast<u16*>(dzs + 256);        // [8 waves][16][LDR]
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, n = lane & 15, kg = lane >> 4;
-    const int bh = blockIdx.x, b = bh / a.H, h = bh - b * a.H;
+    // (b,h) pairs in XCD-contiguous order: a token's heads are adjacent in memory (144-byte rows for D = 72: neighbouring heads share
+    // cache lines), so the heads of one batch element go to workgroups of ONE XCD, running side by side, and each line is fetched once
+    const int bh = xcd_swizzle(blockIdx.x, gridDim.x), b = bh / a.H, h = bh - b * a.H;
     const int M = a.M, D = a.D, N = M * 16;
     auto base = [&](const View& w) { return (const u16*)w.ptr + b * w.sb + h * w.sh; };
     auto mbase = [&](const MView& w) { return (u16*)w.ptr + b * w.sb + h * w.sh; };
@@ -314,12 +343,10 @@ __global__ __launch_bounds__(SN_TB, 2) void k_sn_bwd(const SnArgs a) {
     const bool hasA = bA < M, hasB = bB < M;
     const int blk[2] = {hasA ? bA : 0, hasB ? bB : (hasA ? bA : 0)};
     auto load_q = [&](bf16x8 (&r)[KS], int i) {
-        if (a.relu) sn_load_rows<KS, true>(r, qb, a.q.sn, a.idx, i * 16, D, a.eps, lane);
-        else        sn_load_rows<KS, false>(r, qb, a.q.sn, a.idx, i * 16, D, a.eps, lane);
+        sn_load_rows<KS>(r, qb, a.q.sn, a.idx, i * 16, D, a.eps, lane, a.relu != 0);
     };
     auto load_k = [&](bf16x8 (&r)[KS], int j) {
-        if (a.relu) sn_load_rows<KS, true>(r, kb, a.k.sn, a.idx, j * 16, D, a.eps, lane);
-        else        sn_load_rows<KS, false>(r, kb, a.k.sn, a.idx, j * 16, D, a.eps, lane);
+        sn_load_rows<KS>(r, kb, a.k.sn, a.idx, j * 16, D, a.eps, lane, a.relu != 0);
     };
     // dO rows scaled by 1/n (row = lane & 15), rounded to bf16
     auto scale_dop = [&](bf16x8 (&r)[KS], int i) {
@@ -339,18 +366,25 @@ __global__ __launch_bounds__(SN_TB, 2) void k_sn_bwd(const SnArgs a) {
 
     trace_mark(a.trace, 0);
     // the wave's own rows of Q and dO (operands of P2 and of pass A) are requested first: they travel while K, V are staged
+    // (and, for the row dots, of O): nothing waits for them before the staged tiles are in LDS
     bf16x8 qa[2][KS], ga[2][KS];
+    uint4 qraw[2][KS], graw[2][KS], oraw[2][KS];
 #pragma unroll
     for (int x = 0; x < 2; ++x) {
-        load_q(qa[x], blk[x]);
-        sn_load_rows<KS, false>(ga[x], gb, a.dout.sn, a.idx, blk[x] * 16, D, 0.f, lane);
+        sn_issue_rows<KS>(qraw[x], qb, a.q.sn, a.idx, blk[x] * 16, D, lane);
+        sn_issue_rows<KS>(graw[x], gb, a.dout.sn, a.idx, blk[x] * 16, D, lane);
+        if (a.normalize) sn_issue_rows<KS>(oraw[x], ob, a.o.sn, a.idx, blk[x] * 16, D, lane);
     }
     // ---- P0 / P1: K, V tiles; ksum ----
     __shared__ float Wsh[16 * 17];   // mixing weights (M <= 16), read in every inner loop
     if (tid < 256) Wsh[(tid >> 4) * 17 + (tid & 15)] = ((tid >> 4) < M && (tid & 15) < M) ? a.W[(long)(tid >> 4) * a.ldw + (tid & 15)] : 0.f;
-    if (a.relu) sn_stage<DT, true, SN_TB>(T0, kb, a.k.sn, a.idx, N, D, a.eps, tid);
-    else        sn_stage<DT, false, SN_TB>(T0, kb, a.k.sn, a.idx, N, D, a.eps, tid);
-    sn_stage<DT, false, SN_TB>(T1, vb, a.v.sn, a.idx, N, D, 0.f, tid);
+    sn_stage<DT, SN_TB>(T0, kb, a.k.sn, a.idx, N, D, a.eps, tid, a.relu != 0);
+    sn_stage<DT, SN_TB>(T1, vb, a.v.sn, a.idx, N, D, 0.f, tid, false);
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+        sn_finish_rows<KS>(qa[x], qraw[x], D, a.eps, lane, a.relu != 0);
+        sn_finish_rows<KS>(ga[x], graw[x], D, 0.f, lane, false);
+    }
     __syncthreads();
     trace_mark(a.trace, 1);
     if (a.normalize) {
@@ -369,7 +403,7 @@ __global__ __launch_bounds__(SN_TB, 2) void k_sn_bwd(const SnArgs a) {
             if (x == 0 ? hasA : hasB) {
                 const int i = blk[x];
                 bf16x8 oa[KS];
-                sn_load_rows<KS, false>(oa, ob, a.o.sn, a.idx, i * 16, D, 0.f, lane);
+                sn_finish_rows<KS>(oa, oraw[x], D, 0.f, lane, false);
                 float z = 0.f, rd = 0.f;
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
@@ -498,34 +532,15 @@ __global__ __launch_bounds__(SN_TB, 2) void k_sn_bwd(const SnArgs a) {
 #pragma unroll
     for (int x = 0; x < 2; ++x) {
         load_k(ka[x], blk[x]);
-        sn_load_rows<KS, false>(va[x], vb, a.v.sn, a.idx, blk[x] * 16, D, 0.f, lane);
+        sn_load_rows<KS>(va[x], vb, a.v.sn, a.idx, blk[x] * 16, D, 0.f, lane);
     }
     __syncthreads();
     trace_mark(a.trace, 6);
 
     // ---- P5: Q and dO' tiles replace K and V ----
-    if (a.relu) sn_stage<DT, true, SN_TB>(T0, qb, a.q.sn, a.idx, N, D, a.eps, tid);
-    else        sn_stage<DT, false, SN_TB>(T0, qb, a.q.sn, a.idx, N, D, a.eps, tid);
-    {
-        constexpr int PV = DT * 2;
-        const int dv = D >> 3;
-        for (int v = tid; v < N * PV; v += SN_TB) {
-            const int r = v / PV, p = v - r * PV;
-            uint4 x = make_uint4(0, 0, 0, 0);
-            if (p < dv) {
-                x = *reinterpret_cast<const uint4*>(gb + tok_row(a.idx, r) * a.dout.sn + p * 8);
-                if (a.normalize) {
-                    const float ni = nis[r];
-                    unsigned w[4] = {x.x, x.y, x.z, x.w};
-#pragma unroll
-                    for (int t = 0; t < 4; ++t)
-                        w[t] = pack_bf16x2(__uint_as_float(w[t] << 16) * ni, __uint_as_float(w[t] & 0xffff0000u) * ni);
-                    x = make_uint4(w[0], w[1], w[2], w[3]);
-                }
-            }
-            *reinterpret_cast<uint4*>(T1 + r * LDR + p * 8) = x;
-        }
-    }
+    sn_stage<DT, SN_TB>(T0, qb, a.q.sn, a.idx, N, D, a.eps, tid, a.relu != 0);
+    if (a.normalize) sn_stage<DT, SN_TB, true>(T1, gb, a.dout.sn, a.idx, N, D, 0.f, tid, false, nis);
+    else             sn_stage<DT, SN_TB>(T1, gb, a.dout.sn, a.idx, N, D, 0.f, tid, false);
     __syncthreads();
     trace_mark(a.trace, 7);
 
