@@ -150,6 +150,119 @@ static void run_defer(const char* name, std::vector<char*>& bufs, size_t bytes_p
            (int)LDSHOP, NR, us, gb / us * 1e3);
 }
 
+// the operator's real addressing: tensors are (B, N, H, D) -- a (b,h)'s token rows are 128-byte pieces H * 128 bytes apart; tile =
+// 64 rows of one head; workgroup = 8 consecutive blocks of one (b,h) (STRIDED) vs the same bytes as contiguous 8 KB tiles
+template <int NR, int DEPTH, bool NT, int STRIDED>
+__global__ __launch_bounds__(512) void k_stream_layout(Args a) {
+    constexpr int T = 512, H = 16, NB = 64;          // heads, 64-token blocks per (b,h)
+    constexpr int HP = STRIDED > 1 ? STRIDED : 1;    // adjacent heads read together: rows of HP * 128 contiguous bytes
+    const int wg = blockIdx.x, jg = wg & 7, bh = wg >> 3, b = bh / H, h = bh % H;
+    const int t = threadIdx.x, row = t >> 3, piece = t & 7;
+    u32x4 r[DEPTH][NR], acc[8];
+    auto addr = [&](int blk) -> long {
+        if (STRIDED == 1) return (((long)b * NB * 64 + (long)blk * 64 + row) * H + h) * 128 + piece * 16;
+        if (STRIDED > 1) {   // workgroup = (head group of HP, 8 / HP blocks): step s covers 64 / HP rows of HP heads
+            const int hg = (bh % H) / HP * HP, sub = bh % HP;                 // head group; which share of the blocks
+            const int step = blk - jg * 8, blk2 = jg * 8 + sub * (8 / HP) + step / HP, part = step % HP;
+            const int rr = part * (64 / HP) + t / (8 * HP), pc = t % (8 * HP);
+            return (((long)b * NB * 64 + (long)blk2 * 64 + rr) * H + hg) * 128 + pc * 16;
+        }
+        return (((long)bh * NB + blk) * 64 + row) * 128 + piece * 16;
+    };
+    auto issue = [&](int d, int blk) {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) r[d][i] = ld16<NT>(a.in[i] + addr(blk));
+    };
+#pragma unroll
+    for (int d = 0; d < DEPTH - 1; ++d) issue(d, jg * 8 + d);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const int nx = s + DEPTH - 1;
+        issue((s + DEPTH - 1) % DEPTH, jg * 8 + (nx < 8 ? nx : 0));
+        u32x4 v = r[s % DEPTH][0];
+#pragma unroll
+        for (int i = 1; i < NR; ++i) v ^= r[s % DEPTH][i];
+        acc[s] = v;
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s) st16<false>(a.out[0] + (((long)wg * 8 + s) * T + t) * 16, acc[s]);
+}
+template <int NR, int DEPTH, bool NT, int STRIDED>
+static void run_layout(const char* name, std::vector<char*>& bufs, size_t bytes_per_tensor) {
+    const int wgs = (int)(bytes_per_tensor / (512 * 16) / 8);
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const int nsets = (int)bufs.size() / 5, iters = 24;
+    auto launch = [&](int it) {
+        Args a;
+        char** b = &bufs[(it % nsets) * 5];
+        a.in[0] = b[0]; a.in[1] = b[1]; a.in[2] = b[2]; a.out[0] = b[3]; a.out[1] = b[4];
+        a.tiles = 0; a.tiles_per_wg = 8;
+        hipLaunchKernelGGL((k_stream_layout<NR, DEPTH, NT, STRIDED>), dim3(wgs), dim3(512), 0, 0, a);
+    };
+    for (int i = 0; i < 4; ++i) launch(i);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < iters; ++i) launch(i);
+    CK(hipEventRecord(e1));
+    CK(hipDeviceSynchronize());
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    const double us = ms * 1e3 / iters, gb = (double)(NR + 1) * bytes_per_tensor / 1e9;
+    printf("%-52s wgs=%5d depth=%d nt=%d strided=%d R%d:W1  %7.1f us  %6.2f TB/s\n", name, wgs, DEPTH, (int)NT, (int)STRIDED, NR, us, gb / us * 1e3);
+}
+
+// two adjacent heads per 1024-thread workgroup, each half (8 waves) streaming its own head as above: the two halves' requests for
+// neighbouring 128-byte pieces are issued within the same few hundred cycles
+template <int NR, int DEPTH, bool NT>
+__global__ __launch_bounds__(1024) void k_stream_pair(Args a) {
+    constexpr int T = 512, H = 16, NB = 64;
+    const int wg = blockIdx.x, jg = wg & 7, bhp = wg >> 3, half = threadIdx.x >> 9, bh = bhp * 2 + half, b = bh / H, h = bh % H;
+    const int t = threadIdx.x & 511, row = t >> 3, piece = t & 7;
+    u32x4 r[DEPTH][NR], acc[8];
+    auto addr = [&](int blk) -> long { return (((long)b * NB * 64 + (long)blk * 64 + row) * H + h) * 128 + piece * 16; };
+    auto issue = [&](int d, int blk) {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) r[d][i] = ld16<NT>(a.in[i] + addr(blk));
+    };
+#pragma unroll
+    for (int d = 0; d < DEPTH - 1; ++d) issue(d, jg * 8 + d);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const int nx = s + DEPTH - 1;
+        issue((s + DEPTH - 1) % DEPTH, jg * 8 + (nx < 8 ? nx : 0));
+        u32x4 v = r[s % DEPTH][0];
+#pragma unroll
+        for (int i = 1; i < NR; ++i) v ^= r[s % DEPTH][i];
+        acc[s] = v;
+        __syncthreads();
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s) st16<false>(a.out[0] + ((((long)bh * 8 + jg) * 8 + s) * T + t) * 16, acc[s]);
+}
+template <int NR, int DEPTH, bool NT>
+static void run_pair(const char* name, std::vector<char*>& bufs, size_t bytes_per_tensor) {
+    const int wgs = (int)(bytes_per_tensor / (512 * 16) / 8) / 2;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const int nsets = (int)bufs.size() / 5, iters = 24;
+    auto launch = [&](int it) {
+        Args a;
+        char** b = &bufs[(it % nsets) * 5];
+        a.in[0] = b[0]; a.in[1] = b[1]; a.in[2] = b[2]; a.out[0] = b[3]; a.out[1] = b[4];
+        a.tiles = 0; a.tiles_per_wg = 8;
+        hipLaunchKernelGGL((k_stream_pair<NR, DEPTH, NT>), dim3(wgs), dim3(1024), 0, 0, a);
+    };
+    for (int i = 0; i < 4; ++i) launch(i);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < iters; ++i) launch(i);
+    CK(hipEventRecord(e1));
+    CK(hipDeviceSynchronize());
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    const double us = ms * 1e3 / iters, gb = (double)(NR + 1) * bytes_per_tensor / 1e9;
+    printf("%-52s wgs=%5d depth=%d nt=%d 1024 threads R%d:W1  %7.1f us  %6.2f TB/s\n", name, wgs, DEPTH, (int)NT, NR, us, gb / us * 1e3);
+}
+
 int main() {
     const size_t bytes = 8ull * 16 * 4096 * 64 * 2;      // one C2 token tensor: 67 MB
     const int nsets = 4;                                  // 4 x 5 x 67 MB = 1.34 GB footprint: nothing survives in the 256 MB MALL
@@ -175,6 +288,13 @@ int main() {
     run_defer<512, 3, 3, true, true>("3r1w deferred store depth3 nt ldshop", bufs, bytes);
     run_defer<512, 3, 3, false, true>("3r1w deferred store depth3 ldshop", bufs, bytes);
     run_defer<256, 3, 3, true, true>("3r1w deferred store depth3 nt ldshop T=256", bufs, bytes);
+    run_layout<3, 3, true, 0>("3r1w (b,h)-contiguous tiles, deferred store", bufs, bytes);
+    run_layout<3, 3, true, 1>("3r1w (B,N,H,D) head-strided rows, deferred store", bufs, bytes);
+    run_layout<3, 3, false, 1>("3r1w (B,N,H,D) head-strided rows, no nt", bufs, bytes);
+    run_layout<3, 3, true, 2>("3r1w (B,N,H,D) rows of 2 heads (256 B)", bufs, bytes);
+    run_layout<3, 3, true, 4>("3r1w (B,N,H,D) rows of 4 heads (512 B)", bufs, bytes);
+    run_layout<3, 3, true, 8>("3r1w (B,N,H,D) rows of 8 heads (1 KB)", bufs, bytes);
+    run_pair<3, 3, true>("3r1w (B,N,H,D) head pair per 1024-thread workgroup", bufs, bytes);
     // other mixes
     run<512, 3, 0, 2, true, false>("3r0w depth2 nt", bufs, bytes, 8);
     run<512, 3, 0, 2, false, false>("3r0w depth2", bufs, bytes, 8);
