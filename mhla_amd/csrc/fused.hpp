@@ -131,7 +131,8 @@ __global__ __launch_bounds__(FT) void k_fs_wz(const float* __restrict__ W, int l
 }
 
 // -------------------------------------------------------------------------------------------------
-// k_fs_state: per (block group jg, bh): 8 block summaries in the interleaved transposed layout.
+// k_fs_state / k_fs_state_fwd: the summaries of blocks of MORE than 64 tokens (S > 64: synchronous 64-row chunks; the common case
+// S <= 64 is k_fs_state1c below).  Per (block group jg, bh): 8 block summaries in the interleaved transposed layout.
 //   MODE 0 (forward) : state = V_j^T K_j ; ksum_j ; z_j[s] = Q_j[s] . ksum_j
 //   MODE 1 (backward): state = dP_i^T Q_i with dP = dO / n ; dn_i[s] = -(dO_i[s] . O_i[s]) / n_i[s]
 // 8 waves: wave w owns rows d2 = 16 (w & 3) .. and columns d1 = 32 (w >> 2) .. of every summary.
@@ -268,82 +269,46 @@ __global__ __launch_bounds__(FT8, 4) void k_fs_state(const FsStateArgs a) {
         if (srow < rv && (tid & 7) == 0) a.z_out[((long)bh * M + j) * S + c0 + srow] = d;
     };
 
-    if (S <= 64) {
-        // software pipeline, two blocks ahead: R[jj & 1] carries block jj
-        // (MODE 0 keeps one block in flight: its registers also hold the Q piece and the ksum gather)
-        constexpr int AHEAD = MODE == 1 ? 2 : 1;
-        TileRegs R0, R1;
-        if (jg * IT < M) issue(jg * IT, 0, S, R0);
-        if (AHEAD == 2 && jg * IT + 1 < M) issue(jg * IT + 1, 0, S, R1);
-        const int rfill = (S + 31) & ~31;
-        auto step = [&](auto jjc, TileRegs& R) {
-            constexpr int jj = decltype(jjc)::value;
-            const int j = jg * IT + jj;
-            if (j >= M) return;
-            commit(R, j, 0, S, rfill);
-            const uint4 tq = R.t;                      // (MODE 0) this thread's piece of Q_j for z_j
-            if (jj + AHEAD < IT && j + AHEAD < M) issue(j + AHEAD, 0, S, R);
+    // multi-chunk blocks (S > 64): synchronous chunks; z needs the complete ksum -> second pass over Q
+    TileRegs R;
+    auto blockloop = [&](auto jjc) {
+        constexpr int jj = decltype(jjc)::value;
+        const int j = jg * IT + jj;
+        if (j >= M) return;
+        float ks = 0.f;
+        for (int c0 = 0; c0 < S; c0 += 64) {
+            const int rv = min(64, S - c0), rfill = (rv + 31) & ~31;
+            issue(j, c0, rv, R);
+            commit(R, j, c0, rv, rfill);
             __syncthreads();
-            float ks = 0.f;
-            chunk(jjc, S, rfill, ks);
-            if (MODE == 0 && a.normalize) part[tid] = ks;
-            __syncthreads();                           // tiles consumed; partials visible
-            if (MODE == 0 && a.normalize) {
-                float kv[8];
-                ksum8(kv);
-                write_ksum_z(j, 0, S, kv, tq, true);
-            }
-        };
-        step(std::integral_constant<int, 0>{}, R0);
-        step(std::integral_constant<int, 1>{}, AHEAD == 2 ? R1 : R0);
-        step(std::integral_constant<int, 2>{}, R0);
-        step(std::integral_constant<int, 3>{}, AHEAD == 2 ? R1 : R0);
-        step(std::integral_constant<int, 4>{}, R0);
-        step(std::integral_constant<int, 5>{}, AHEAD == 2 ? R1 : R0);
-        step(std::integral_constant<int, 6>{}, R0);
-        step(std::integral_constant<int, 7>{}, AHEAD == 2 ? R1 : R0);
-    } else {
-        // multi-chunk blocks (S > 64): synchronous chunks; z needs the complete ksum -> second pass over Q
-        TileRegs R;
-        auto blockloop = [&](auto jjc) {
-            constexpr int jj = decltype(jjc)::value;
-            const int j = jg * IT + jj;
-            if (j >= M) return;
-            float ks = 0.f;
+            chunk(jjc, rv, rfill, ks);
+            __syncthreads();
+        }
+        if (MODE == 0 && a.normalize) {
+            part[tid] = ks;
+            __syncthreads();
+            float kv[8];
+            ksum8(kv);
             for (int c0 = 0; c0 < S; c0 += 64) {
-                const int rv = min(64, S - c0), rfill = (rv + 31) & ~31;
-                issue(j, c0, rv, R);
-                commit(R, j, c0, rv, rfill);
-                __syncthreads();
-                chunk(jjc, rv, rfill, ks);
-                __syncthreads();
-            }
-            if (MODE == 0 && a.normalize) {
-                part[tid] = ks;
-                __syncthreads();
-                float kv[8];
-                ksum8(kv);
-                for (int c0 = 0; c0 < S; c0 += 64) {
-                    const int rv = min(64, S - c0);
-                    uint4 tq = make_uint4(0, 0, 0, 0);
-                    if (srow < rv) {
-                        tq = *reinterpret_cast<const uint4*>(tb + tok_row(a.idx, (long)j * S + c0 + srow) * a.t.sn + scol);
-                        if (a.relu) tq = relu_eps8(tq, a.eps);
-                    }
-                    write_ksum_z(j, c0, rv, kv, tq, c0 == 0);
+                const int rv = min(64, S - c0);
+                uint4 tq = make_uint4(0, 0, 0, 0);
+                if (srow < rv) {
+                    tq = *reinterpret_cast<const uint4*>(tb + tok_row(a.idx, (long)j * S + c0 + srow) * a.t.sn + scol);
+                    if (a.relu) tq = relu_eps8(tq, a.eps);
                 }
-                __syncthreads();                       // `part` is rewritten by the next block
+                write_ksum_z(j, c0, rv, kv, tq, c0 == 0);
             }
-        };
-        blockloop(std::integral_constant<int, 0>{});
-        blockloop(std::integral_constant<int, 1>{});
-        blockloop(std::integral_constant<int, 2>{});
-        blockloop(std::integral_constant<int, 3>{});
-        blockloop(std::integral_constant<int, 4>{});
-        blockloop(std::integral_constant<int, 5>{});
-        blockloop(std::integral_constant<int, 6>{});
-        blockloop(std::integral_constant<int, 7>{});
-    }
+            __syncthreads();                       // `part` is rewritten by the next block
+        }
+    };
+    blockloop(std::integral_constant<int, 0>{});
+    blockloop(std::integral_constant<int, 1>{});
+    blockloop(std::integral_constant<int, 2>{});
+    blockloop(std::integral_constant<int, 3>{});
+    blockloop(std::integral_constant<int, 4>{});
+    blockloop(std::integral_constant<int, 5>{});
+    blockloop(std::integral_constant<int, 6>{});
+    blockloop(std::integral_constant<int, 7>{});
 
     // 16-byte interleaved store: lane -> (d2 = 16 dt + 4 (lane >> 4) + r, d1 = 16 (2 th + t) + (lane & 15))
     u16* sb = a.state + ((long)bh * njg + jg) * FE * IT;
@@ -364,20 +329,8 @@ constexpr int FS_STATE_FWD_SMEM = 3 * 64 * TLD * 2 + (8 * 64 + 64) * 4;
 // Forward summaries (MODE 0 only): Q tile staged in LDS with K and V, two blocks ahead in registers.
 struct TileRegs3 { uint4 x, y, t; };
 
-#ifndef FSV_NOCOMP
-#define FSV_NOCOMP 0
-#endif
-#ifndef FSV_NOSIDE
-#define FSV_NOSIDE 0
-#endif
-#ifndef FSV_QNT
-#define FSV_QNT 0
-#endif
-#ifndef FSV_LB
-#define FSV_LB 4
-#endif
 template <int MODE>
-__global__ __launch_bounds__(FT8, FSV_LB) void k_fs_state_fwd(const FsStateArgs a) {
+__global__ __launch_bounds__(FT8, 4) void k_fs_state_fwd(const FsStateArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u16* Xs = reinterpret_cast<u16*>(smem_raw);
     u16* Ys = Xs + 64 * TLD;
@@ -391,9 +344,8 @@ __global__ __launch_bounds__(FT8, FSV_LB) void k_fs_state_fwd(const FsStateArgs 
     const u16* xb = (const u16*)a.x.ptr + b * a.x.sb + h * a.x.sh;
     const u16* yb = (const u16*)a.y.ptr + b * a.y.sb + h * a.y.sh;
     const u16* tb = a.normalize ? (const u16*)a.t.ptr + b * a.t.sb + h * a.t.sh : nullptr;
-    const bool single = S <= 64;
     const int srow = tid >> 3, scol = (tid & 7) * 8;         // staging: thread -> (row, 8 columns = 16 bytes)
-    const bool tile_t = a.normalize && (MODE == 1 || single);   // third tile travels with the chunk
+    const bool tile_t = a.normalize && MODE == 1;   // third tile travels with the chunk
 
     auto issue = [&](long p, int rv, TileRegs3& R) {
         R.x = R.y = R.t = make_uint4(0, 0, 0, 0);
@@ -401,7 +353,7 @@ __global__ __launch_bounds__(FT8, FSV_LB) void k_fs_state_fwd(const FsStateArgs 
             const long tr = tok_row(a.idx, p + srow);
             R.x = gld_stream16(xb + tr * a.x.sn + scol);                     // K, V: not read again in the forward
             R.y = gld_stream16(yb + tr * a.y.sn + scol);
-            if (tile_t) R.t = FSV_QNT ? gld_stream16(tb + tr * a.t.sn + scol) : gld<uint4>(tb + tr * a.t.sn + scol);          // Q: the output kernel reads it next
+            if (tile_t) R.t = gld<uint4>(tb + tr * a.t.sn + scol);          // Q: the output kernel reads it next
         }
     };
     auto commit = [&](const TileRegs3& R, int rv, int rfill) {
@@ -475,7 +427,7 @@ __global__ __launch_bounds__(FT8, FSV_LB) void k_fs_state_fwd(const FsStateArgs 
         __syncthreads();
         for (int c0 = 0; c0 < S; c0 += 64) {
             const int rv = min(64, S - c0);
-            if (!single) {   // (rare) multi-chunk blocks: second pass over Q, synchronous
+            {   // second pass over Q, synchronous
                 uint4 t = make_uint4(0, 0, 0, 0);
                 if (srow < rv) {
                     t = *reinterpret_cast<const uint4*>(tb + tok_row(a.idx, p0 + c0 + srow) * a.t.sn + scol);
@@ -500,116 +452,31 @@ __global__ __launch_bounds__(FT8, FSV_LB) void k_fs_state_fwd(const FsStateArgs 
         }
     };
 
-    if (single) {
-        // software pipeline, two blocks ahead: R[jj & 1] carries block jj.  Two barriers per block: K, V go through LDS (both MFMA
-        // operands via transpose reads); the column sums ksum_j = sum_s K_j[s] ride on the matrix pipe (an all-ones A operand
-        // against the B operand already fetched for KV) and the thread's piece of Q_j never leaves its registers: z_j[s] =
-        // Q_j[s] . ksum_j is a dot with the 8 sums of its columns, read back from LDS after the second barrier.
-        TileRegs3 R0, R1;
-        if (jg * IT < M) issue((long)jg * IT * S, S, R0);
-        if (jg * IT + 1 < M) issue((long)(jg * IT + 1) * S, S, R1);
-        const int rfill = (S + 31) & ~31;
-        s16x8 ones_;
-#pragma unroll
-        for (int t = 0; t < 8; ++t) ones_[t] = (short)0x3F80;   // bf16 1.0
-        const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_);
-        auto step = [&](auto jjc, TileRegs3& R) {
-            constexpr int jj = decltype(jjc)::value;
-            const int j = jg * IT + jj;
-            if (j >= M) return;
-            uint4 tq = R.t;
-#if FSV_NOCOMP >= 2
-            acc[jj][0][0] += __uint_as_float(R.x.x ^ R.y.y);
-            acc[jj][1][1] += __uint_as_float(R.x.z ^ R.y.w);
-#else
-            if (srow < rfill) {
-                uint4 x = R.x;
-                if (a.relu && srow < S) {
-                    x = relu_eps8(x, a.eps);
-                    if (a.normalize) tq = relu_eps8(tq, a.eps);
-                }
-                *reinterpret_cast<uint4*>(Xs + srow * TLD + scol) = x;
-                *reinterpret_cast<uint4*>(Ys + srow * TLD + scol) = R.y;
-            }
-#endif
-            if (jj + 2 < IT && j + 2 < M) issue((long)(j + 2) * S, S, R);
-#if FSV_NOCOMP < 2
+    TileRegs3 R;
+    auto blockloop = [&](auto jjc) {
+        constexpr int jj = decltype(jjc)::value;
+        const int j = jg * IT + jj;
+        if (j >= M) return;
+        const long p0 = (long)j * S;
+        float ks = 0.f;
+        for (int c0 = 0; c0 < S; c0 += 64) {
+            const int rv = min(64, S - c0), rfill = (rv + 31) & ~31;
+            issue(p0 + c0, rv, R);
+            commit(R, rv, rfill);
             __syncthreads();
-#endif
-            f32x4 ks[2];
-            ks[0] = ks[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-#if FSV_NOCOMP == 1
-            acc[jj][0][0] += bf(Xs[tid]);
-            acc[jj][1][1] += bf(Ys[tid]);
-#endif
-            for (int k0 = 0; k0 < (FSV_NOCOMP ? 0 : rfill); k0 += 32) {
-                const bf16x8 av = tr_read8(Ys, TLD, k0, dt * 16, lane);
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const bf16x8 bv = tr_read8(Xs, TLD, k0, (2 * th + t) * 16, lane);
-                    acc[jj][t] = mfma_bf16(av, bv, acc[jj][t]);
-                    if (a.normalize) ks[t] = mfma_bf16(ones, bv, ks[t]);
-                }
-            }
-            if (a.normalize && !FSV_NOSIDE && dt == 0 && lane < 16) {   // every row of the ones-product is the column sum: row 0 lives in lanes 0..15
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const int col = (2 * th + t) * 16 + lane;
-                    ksum_s[col] = ks[t][0];
-                    a.ksum[((long)bh * M + j) * 64 + col] = ks[t][0];
-                }
-            }
-#if FSV_NOCOMP < 2
-            __syncthreads();                           // tiles consumed; column sums visible
-#endif
-            if (a.normalize && !FSV_NOSIDE) {
-                const f32x4 lo = *reinterpret_cast<const f32x4*>(ksum_s + scol), hi = *reinterpret_cast<const f32x4*>(ksum_s + scol + 4);
-                const unsigned qw[4] = {tq.x, tq.y, tq.z, tq.w};
-                float d = __uint_as_float(qw[0] << 16) * lo[0] + __uint_as_float(qw[0] & 0xffff0000u) * lo[1] +
-                          __uint_as_float(qw[1] << 16) * lo[2] + __uint_as_float(qw[1] & 0xffff0000u) * lo[3] +
-                          __uint_as_float(qw[2] << 16) * hi[0] + __uint_as_float(qw[2] & 0xffff0000u) * hi[1] +
-                          __uint_as_float(qw[3] << 16) * hi[2] + __uint_as_float(qw[3] & 0xffff0000u) * hi[3];
-                d += __shfl_xor(d, 1, 64);
-                d += __shfl_xor(d, 2, 64);
-                d += __shfl_xor(d, 4, 64);
-                if (srow < S && (tid & 7) == 0) a.z_out[((long)bh * M + j) * S + srow] = d;
-            }
-        };
-        step(std::integral_constant<int, 0>{}, R0);
-        step(std::integral_constant<int, 1>{}, R1);
-        step(std::integral_constant<int, 2>{}, R0);
-        step(std::integral_constant<int, 3>{}, R1);
-        step(std::integral_constant<int, 4>{}, R0);
-        step(std::integral_constant<int, 5>{}, R1);
-        step(std::integral_constant<int, 6>{}, R0);
-        step(std::integral_constant<int, 7>{}, R1);
-    } else {
-        TileRegs3 R;
-        auto blockloop = [&](auto jjc) {
-            constexpr int jj = decltype(jjc)::value;
-            const int j = jg * IT + jj;
-            if (j >= M) return;
-            const long p0 = (long)j * S;
-            float ks = 0.f;
-            for (int c0 = 0; c0 < S; c0 += 64) {
-                const int rv = min(64, S - c0), rfill = (rv + 31) & ~31;
-                issue(p0 + c0, rv, R);
-                commit(R, rv, rfill);
-                __syncthreads();
-                chunk(jjc, j, c0, rv, rfill, ks);
-                __syncthreads();
-            }
-            if (MODE == 0 && a.normalize) finish_block(j, ks);
-        };
-        blockloop(std::integral_constant<int, 0>{});
-        blockloop(std::integral_constant<int, 1>{});
-        blockloop(std::integral_constant<int, 2>{});
-        blockloop(std::integral_constant<int, 3>{});
-        blockloop(std::integral_constant<int, 4>{});
-        blockloop(std::integral_constant<int, 5>{});
-        blockloop(std::integral_constant<int, 6>{});
-        blockloop(std::integral_constant<int, 7>{});
-    }
+            chunk(jjc, j, c0, rv, rfill, ks);
+            __syncthreads();
+        }
+        if (MODE == 0 && a.normalize) finish_block(j, ks);
+    };
+    blockloop(std::integral_constant<int, 0>{});
+    blockloop(std::integral_constant<int, 1>{});
+    blockloop(std::integral_constant<int, 2>{});
+    blockloop(std::integral_constant<int, 3>{});
+    blockloop(std::integral_constant<int, 4>{});
+    blockloop(std::integral_constant<int, 5>{});
+    blockloop(std::integral_constant<int, 6>{});
+    blockloop(std::integral_constant<int, 7>{});
 
     // 16-byte interleaved store: lane -> (d2 = 16 dt + 4 (lane >> 4) + r, d1 = 16 (2 th + t) + (lane & 15))
     u16* sb = a.state + ((long)bh * njg + jg) * FE * IT;

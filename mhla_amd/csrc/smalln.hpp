@@ -342,9 +342,6 @@ __global__ __launch_bounds__(SN_TB, 2) void k_sn_bwd(const SnArgs a) {
     const int bA = wave, bB = wave + SN_WB;
     const bool hasA = bA < M, hasB = bB < M;
     const int blk[2] = {hasA ? bA : 0, hasB ? bB : (hasA ? bA : 0)};
-    auto load_q = [&](bf16x8 (&r)[KS], int i) {
-        sn_load_rows<KS>(r, qb, a.q.sn, a.idx, i * 16, D, a.eps, lane, a.relu != 0);
-    };
     auto load_k = [&](bf16x8 (&r)[KS], int j) {
         sn_load_rows<KS>(r, kb, a.k.sn, a.idx, j * 16, D, a.eps, lane, a.relu != 0);
     };
