@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Phase timeline of the three tile kernels of the bf16 fast path (k_t16_out, k_t16_bwd_dq, k_t16_bwd_dkv) at C2.
+"""Phase timeline of the tile workgroups of the bf16 fast path (k_t16_out; the dQ and dK/dV roles of k_t16_bwd) at C2.
 
 Uses the library's debugging hook (mhla_debug_set_trace): wave 0 of every workgroup stamps s_memtime at
   0 start | 1 own-block loads issued | 2 mixing done | 3 barrier passed | 4 first block done | 5 second block done | 6 stores drained
@@ -54,7 +54,7 @@ out_dir = os.environ.get("TRACE_OUT")
 if out_dir:
     os.makedirs(out_dir, exist_ok=True)
     np.save(os.path.join(out_dir, "trace.npy"), t)
-names = ["k_t16_out", "k_t16_bwd_dq", "k_t16_bwd_dkv"]
+names = ["k_t16_out", "k_t16_bwd: dQ tiles", "k_t16_bwd: dK/dV tiles"]   # the two backward roles share one launch
 phases = ["issue own loads", "mix", "barrier wait", "block A", "block B", "store drain"]
 for kI, nm in enumerate(names):
     x = t[kI].astype(np.int64)
@@ -65,7 +65,7 @@ for kI, nm in enumerate(names):
     # s_memtime counts shader clocks (about 2100 per us under this load); the counters of different CUs are not synchronised,
     # so only differences within one workgroup are meaningful
     tick_us = 1.0 / float(os.environ.get("TICKS_PER_US", "2100"))
-    print(f"== {nm}: {nwg} workgroups, {kus.get(nm, float('nan')):.1f} us by HIP events")
+    print(f"== {nm}: {nwg} workgroups, {kus.get(nm.split(':')[0], float('nan')):.1f} us by HIP events (whole launch)")
     d = np.diff(x[:, :7], axis=1) * tick_us
     life = (x[:, 6] - x[:, 0]) * tick_us
     print(f"   workgroup life median {np.median(life):.2f} p10 {np.percentile(life, 10):.2f} p90 {np.percentile(life, 90):.2f} us")
