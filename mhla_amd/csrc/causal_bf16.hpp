@@ -54,6 +54,33 @@ __device__ __forceinline__ void cs_stage_state(u16* __restrict__ dst, const u16*
     *reinterpret_cast<uint4*>(dst + r * CLD + c + 8) = y;
 }
 
+// The two stagings in halves (loads now, LDS writes later), for kernels that fetch the next round's tiles while the current
+// round is multiplied.  Rows >= rv read the chunk's first row (a valid address) and are zeroed on the way into LDS.
+struct CsTile { uint4 x, y; };
+__device__ __forceinline__ void cs_issue_tok(CsTile& t, const u16* __restrict__ base, long sn, long p0, int rv, int tid) {
+    const int r = tid >> 2, c = (tid & 3) * 16;
+    const u16* src = base + (p0 + (r < rv ? r : 0)) * sn + c;
+    t.x = gld<uint4>(src);
+    t.y = gld<uint4>(src + 8);
+}
+__device__ __forceinline__ void cs_commit_tok(u16* __restrict__ dst, const CsTile& t, int rv, int tid) {
+    const int r = tid >> 2, c = (tid & 3) * 16;
+    const bool ok = r < rv;
+    *reinterpret_cast<uint4*>(dst + r * CLD + c) = make_uint4(ok ? t.x.x : 0u, ok ? t.x.y : 0u, ok ? t.x.z : 0u, ok ? t.x.w : 0u);
+    *reinterpret_cast<uint4*>(dst + r * CLD + c + 8) = make_uint4(ok ? t.y.x : 0u, ok ? t.y.y : 0u, ok ? t.y.z : 0u, ok ? t.y.w : 0u);
+}
+__device__ __forceinline__ void cs_issue_state(CsTile& t, const u16* __restrict__ src, long ld, int tid) {
+    const int r = tid >> 2, c = (tid & 3) * 16;
+    const u16* s = src + (long)r * ld + c;
+    t.x = gld<uint4>(s);
+    t.y = gld<uint4>(s + 8);
+}
+__device__ __forceinline__ void cs_commit_state(u16* __restrict__ dst, const CsTile& t, int tid) {
+    const int r = tid >> 2, c = (tid & 3) * 16;
+    *reinterpret_cast<uint4*>(dst + r * CLD + c) = t.x;
+    *reinterpret_cast<uint4*>(dst + r * CLD + c + 8) = t.y;
+}
+
 // acc[tn] += A B for output rows 16 wave .. and the four 16-column tiles, reduction length 64.
 //   AT false: A[m][k] = Xs[m][k]   AT true: A[m][k] = Xs[k][m]      (Xs, Ys: [64][CLD] bf16 tiles)
 //   BT false: B[k][n] = Ys[n][k]   BT true: B[k][n] = Ys[k][n]
@@ -539,17 +566,37 @@ __global__ __launch_bounds__(NTHREADS, NK <= 2 ? 2 : 1) void k_csf_bwd_tok3(cons
         zero4(accK[kk]);
     }
     zero4(accdA);
+    // Every (V slice, K slice) round stages a P and a dS tile (and, at its first K slice, the dO and V rows of the V slice): the next
+    // round's tiles are fetched into registers while the current round is multiplied, and written to LDS behind the barrier that
+    // ends it -- the rounds used to be load -> wait -> multiply, about twenty exposed memory latencies per chunk.
+    static_assert(sizeof(ST) == 2, "the prefetching token kernel expects bf16 summaries");
+    CsTile nP, ndS, nG, nV;   // next round's P / dS tiles; next V slice's dO / V rows
+    cs_issue_tok(nG, gb, a.dout.sn, p0, rv, tid);
+    cs_issue_tok(nV, vb, a.v.sn, p0, rv, tid);
+    cs_issue_state(nP, reinterpret_cast<const u16*>(Pi), V, tid);
+    cs_issue_state(ndS, reinterpret_cast<const u16*>(dSi), V, tid);
     for (int vs = 0; vs < V; vs += 64) {
         f32x4 accV[4];
         zero4(accV);
-        cs_stage_tok(X1, gb + vs, a.dout.sn, p0, rv, tid);
-        cs_stage_tok(X2, vb + vs, a.v.sn, p0, rv, tid);
+        cs_commit_tok(X1, nG, rv, tid);
+        cs_commit_tok(X2, nV, rv, tid);
+        if (vs + 64 < V) {   // (uniform) the next V slice's rows travel during this slice's rounds
+            cs_issue_tok(nG, gb + vs + 64, a.dout.sn, p0, rv, tid);
+            cs_issue_tok(nV, vb + vs + 64, a.v.sn, p0, rv, tid);
+        }
 #pragma unroll
         for (int kk = 0; kk < NK; ++kk) {
             if (kk < nks) {
-                cs_stage_state(B1, Pi + (long)kk * 64 * V + vs, V, tid);
-                cs_stage_state(B2, dSi + (long)kk * 64 * V + vs, V, tid);
+                cs_commit_state(B1, nP, tid);
+                cs_commit_state(B2, ndS, tid);
                 __syncthreads();
+                {   // next round: (vs, kk + 1) or (vs + 64, 0); past the last round the chunk's first tiles again (never used)
+                    const bool wrap = kk + 1 >= nks;
+                    const int nkk = wrap ? 0 : kk + 1;
+                    const int nvs = wrap ? (vs + 64 < V ? vs + 64 : 0) : vs;
+                    cs_issue_state(nP, reinterpret_cast<const u16*>(Pi) + (long)nkk * 64 * V + nvs, V, tid);
+                    cs_issue_state(ndS, reinterpret_cast<const u16*>(dSi) + (long)nkk * 64 * V + nvs, V, tid);
+                }
                 if (kk == 0) {
                     tile_mma<false, false>(accdA, X1, X2, wave, lane);      // dO V^T
                     tile_mma<true, true>(accV, As, X1, wave, lane);         // A^T dO
