@@ -526,3 +526,34 @@ def test_repetitions_bit_identical_alone_and_beside_a_second_stream():
         got = run(rep % 2 == 1)
         for name, a_, b_ in zip(["out", "dq", "dk", "dv", "dW"], ref, got):
             assert torch.equal(a_, b_), f"repetition {rep} ({'two streams' if rep % 2 else 'alone'}): {name} differs"
+
+
+@pytest.mark.parametrize("B,H,M,S", [(1, 1, 3, 5), (1, 3, 17, 33), (2, 16, 33, 64), (8, 16, 64, 64), (33, 7, 16, 16), (2, 16, 16, 256)])
+def test_token_gradient_launch_handover_on_two_streams(B, H, M, S):
+    """The backward's token gradients are one launch in which a tile's dK/dV workgroup waits for the flag of its dQ workgroup
+    (DESIGN.md 3b).  Shapes with partly empty tiles, one tile per (b,h), few and many (b,h) pairs, multi-chunk blocks: three
+    repetitions each with a second instance of the operator on another stream, all bit-identical and finite (a lost hand-over
+    would hang -- the suite's timeout -- or read stale dksum rows; tools/stress_fast_path.py is the long version)."""
+    import mhla_amd
+    g = torch.Generator(device=DEV).manual_seed(B * 1000 + M)
+    mk = lambda: torch.randn(B, M * S, H, 64, device=DEV, dtype=torch.bfloat16, generator=g).abs_().add_(1e-3)
+    q, k, v, do = mk(), mk(), mk(), mk()
+    W = torch.rand(M, M, device=DEV, generator=g).add_(0.1)
+    side = torch.cuda.Stream()
+    ref = None
+    for rep in range(3):
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            t2 = [x.flip(0).clone().requires_grad_(True) for x in (q, k, v)]
+            mhla_amd.mhla_blockmix(*t2, W).backward(do)
+        ts = [x.clone().requires_grad_(True) for x in (q, k, v, W)]
+        out = mhla_amd.mhla_blockmix(*ts)
+        out.backward(do)
+        torch.cuda.synchronize()
+        res = [out.detach()] + [x.grad for x in ts]
+        assert all(bool(torch.isfinite(r.float()).all()) for r in res)
+        if ref is None:
+            ref = [r.clone() for r in res]
+        else:
+            for name, a_, b_ in zip(["out", "dq", "dk", "dv", "dW"], ref, res):
+                assert torch.equal(a_, b_), f"repetition {rep}: {name} differs"

@@ -1,0 +1,53 @@
+"""Stress of the bf16 fast path's in-launch hand-over (k_t16_bwd: a tile's dK/dV workgroup waits for its dQ workgroup's flag):
+many shapes -- tiles that are partly empty, a single tile per (b,h), few and many (b,h) pairs -- each run REPS times on two
+streams at once, every result compared bit for bit with the first repetition.  A hang would show as the per-call timeout of the
+caller (run under `timeout`); exits non-zero on any mismatch.
+  timeout 300 python tools/stress_fast_path.py"""
+import itertools
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import mhla_amd  # noqa: E402
+
+DEV = "cuda"
+REPS = int(os.environ.get("REPS", "5"))
+gen = torch.Generator(device=DEV).manual_seed(11)
+side = torch.cuda.Stream()
+bad = 0
+cases = [(B, H, M, S) for (B, H), (M, S) in itertools.product([(1, 1), (1, 3), (2, 16), (8, 16), (33, 7)],
+                                                               [(3, 5), (8, 64), (16, 16), (17, 33), (33, 64), (64, 64), (16, 256), (64, 128)])]
+for B, H, M, S in cases:
+    N = M * S
+    if B * H * N > 8 * 16 * 4096 * 2:
+        continue
+
+    def mk(relu):
+        t = torch.randn(B, N, H, 64, device=DEV, dtype=torch.bfloat16, generator=gen)
+        return t.relu_().add_(1e-3) if relu else t
+
+    q, k, v, do = mk(True), mk(True), mk(False), mk(False)
+    W = torch.rand(M, M, device=DEV, generator=gen).add_(0.1)
+    ref = None
+    for rep in range(REPS):
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):   # a second instance, other data, concurrently
+            t2 = [x.flip(0).clone().requires_grad_(True) for x in (q, k, v)]
+            mhla_amd.mhla_blockmix(*t2, W).backward(do)
+        ts = [x.clone().requires_grad_(True) for x in (q, k, v)]
+        Wg = W.clone().requires_grad_(True)
+        out = mhla_amd.mhla_blockmix(*ts, Wg)
+        out.backward(do)
+        torch.cuda.synchronize()
+        res = [out.detach(), ts[0].grad, ts[1].grad, ts[2].grad, Wg.grad]
+        if not all(bool(torch.isfinite(r.float()).all()) for r in res):
+            print("non-finite result", (B, H, M, S)); bad += 1
+        if ref is None:
+            ref = [r.clone() for r in res]
+        elif not all(bool(torch.equal(a, b)) for a, b in zip(ref, res)):
+            print("MISMATCH", (B, H, M, S), "rep", rep); bad += 1
+    print("ok" if bad == 0 else "..", (B, H, M, S), flush=True)
+print("stress:", "all repetitions identical" if bad == 0 else f"{bad} problems")
+sys.exit(1 if bad else 0)
