@@ -180,11 +180,29 @@ __global__ __launch_bounds__(NTHREADS) void k_csf_out(const CsOutArgs a) {
 #pragma unroll
     for (int j = 0; j < CSF_OUT_VS; ++j) zero4(accO[j]);
     zero4(accA);
+    // Every tile (the K slice's Q and K rows, each P slice, later each V slice) is requested a step ahead into registers and
+    // written to LDS behind the barrier that frees its slot: the products never wait for a load that was only just issued.
+    static_assert(sizeof(ST) == 2, "k_csf_out expects bf16 summaries");
+    const u16* Pb = reinterpret_cast<const u16*>(Pi);
+    CsTile nQ, nK, nP, nVt;
+    auto issueP = [&](int ks, int j) { cs_issue_state(nP, Pb + (long)ks * a.V + vbase + 64 * j, a.V, tid); };
+    cs_issue_tok(nQ, qb, a.q.sn, p0, rv, tid);
+    cs_issue_tok(nK, kb, a.k.sn, p0, rv, tid);
+    issueP(0, 0);
     for (int ks = 0; ks < a.K; ks += 64) {
-        cs_stage_tok(Qs, qb + ks, a.q.sn, p0, rv, tid);
-        cs_stage_tok(Ks, kb + ks, a.k.sn, p0, rv, tid);
-        cs_stage_state(Ps, Pi + (long)ks * a.V + vbase, a.V, tid);
+        cs_commit_tok(Qs, nQ, rv, tid);
+        cs_commit_tok(Ks, nK, rv, tid);
+        cs_commit_state(Ps, nP, tid);
         __syncthreads();
+        const bool more_k = ks + 64 < a.K;   // (uniform)
+        if (nv > 1) issueP(ks, 1);
+        else if (more_k) issueP(ks + 64, 0);
+        if (more_k) {
+            cs_issue_tok(nQ, qb + ks + 64, a.q.sn, p0, rv, tid);
+            cs_issue_tok(nK, kb + ks + 64, a.k.sn, p0, rv, tid);
+        } else {
+            cs_issue_tok(nVt, vb + vbase, a.v.sn, p0, rv, tid);   // the first V slice of the second phase
+        }
         tile_mma<false, false>(accA, Qs, Ks, wave, lane);   // Q K^T
 #pragma unroll
         for (int j = 0; j < CSF_OUT_VS; ++j) {
@@ -192,7 +210,9 @@ __global__ __launch_bounds__(NTHREADS) void k_csf_out(const CsOutArgs a) {
                 tile_mma<false, true>(accO[j], Qs, Ps, wave, lane);    // Q P
                 __syncthreads();
                 if (j + 1 < nv) {
-                    cs_stage_state(Ps, Pi + (long)ks * a.V + vbase + 64 * (j + 1), a.V, tid);
+                    cs_commit_state(Ps, nP, tid);
+                    if (j + 2 < nv) issueP(ks, j + 2);
+                    else if (more_k) issueP(ks + 64, 0);
                     __syncthreads();
                 }
             }
@@ -210,8 +230,9 @@ __global__ __launch_bounds__(NTHREADS) void k_csf_out(const CsOutArgs a) {
 #pragma unroll
         for (int j = 0; j < CSF_OUT_VS; ++j) {
             if (j < nv) {
-                cs_stage_tok(Ps, vb + vbase + 64 * j, a.v.sn, p0, rv, tid);
+                cs_commit_tok(Ps, nVt, rv, tid);
                 __syncthreads();
+                if (j + 1 < nv) cs_issue_tok(nVt, vb + vbase + 64 * (j + 1), a.v.sn, p0, rv, tid);
                 tile_mma<false, true>(accO[j], As, Ps, wave, lane);        // tril(QK^T) V
                 cs_put(Qs, accO[j], a.scale, wave, lane);
                 __syncthreads();
@@ -223,8 +244,9 @@ __global__ __launch_bounds__(NTHREADS) void k_csf_out(const CsOutArgs a) {
 #pragma unroll
         for (int j = 0; j < CSF_OUT_VS; ++j) {
             if (j < nv) {
-                cs_stage_tok(Ps, vb + vbase + 64 * j, a.v.sn, p0, rv, tid);
+                cs_commit_tok(Ps, nVt, rv, tid);
                 __syncthreads();
+                if (j + 1 < nv) cs_issue_tok(nVt, vb + vbase + 64 * (j + 1), a.v.sn, p0, rv, tid);
                 tile_mma<false, true>(accO[j], As, Ps, wave, lane);        // tril(QK^T) V
                 __syncthreads();
             }
