@@ -99,6 +99,15 @@ def test_small_sequence_vs_summary_path_agree():
 
 
 @pytest.mark.parametrize("normalize", [True, False])
+@pytest.mark.parametrize("M,S", [(16, 32), (9, 64), (20, 40)])
+def test_fast_path_gather_map(M, S, normalize):
+    """The bf16 D = 64 summaries / tile kernels with a gather map (the k_fs_state1c<.., IDX> instantiations read the map's rows up
+    front): shapes that are not the small-sequence path's (S != 16), a random token permutation, a short last block group (M = 9, 20)."""
+    idx = torch.randperm(M * S, generator=torch.Generator().manual_seed(M * 100 + S)).int()
+    run_case(2, 3, M, S, 64, torch.bfloat16, normalize=normalize, idx=idx, w="rand")
+
+
+@pytest.mark.parametrize("normalize", [True, False])
 def test_fast_path_options(normalize):
     idx = orc.block_index_2d(4, 4).int()
     run_case(2, 2, 16, 16, 64, torch.bfloat16, normalize=normalize, idx=idx)
