@@ -167,11 +167,32 @@ def main():
 
             def step():   # noqa: F811
                 graph.replay()
-                # the gradients live in the graph's static buffers: all-reduce a copy, so that the next replay does not
-                # overwrite dW while the collective of this step is still in flight
-                reducer.issue(W.grad.clone() if world > 1 else W.grad)
+                reducer.issue(W.grad)
 
             launch_mode = "hipGraph replay of the captured fwd+bwd step"
+            if world > 1:
+                # N ranks: every step is one replay followed by the all-reduce of its dW.  The gradient lives in the graph's static
+                # buffer, so two graphs alternate, each ending with "its" copy of dW / N: the collective of step k runs while
+                # graph (k + 1) % 2 computes, and a buffer is rewritten only after its previous collective was waited for
+                q.grad = k.grad = v.grad = W.grad = None
+                gbufs = [torch.empty_like(W, dtype=torch.float32) for _ in range(2)]
+                graphs = []
+                for gb_ in gbufs:
+                    g_ = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g_):
+                        mhla_amd.mhla_blockmix(q, k, v, W, eps=1e-6).backward(do)
+                        gb_.copy_(W.grad).div_(world)
+                        q.grad = k.grad = v.grad = W.grad = None
+                    graphs.append(g_)
+                phase = [0]
+
+                def step():   # noqa: F811
+                    i = phase[0]
+                    phase[0] = i ^ 1
+                    graphs[i].replay()
+                    reducer.issue(gbufs[i], prescaled=True)
+
+                launch_mode = "hipGraph replay of the captured fwd+bwd step (+ dW / N), then its all-reduce; two graphs alternate"
             if world == 1 and a.graph_steps > 1:
                 # one GPU: no per-step exchange, so several whole steps go into one graph (each replay costs ~15 us of device-side
                 # start-up whatever it holds); every captured step is the complete forward + backward on the same inputs

@@ -111,10 +111,12 @@ class OverlappedGradAllReduce:
     def __init__(self):
         self._pending = None
 
-    def issue(self, t: torch.Tensor) -> None:
+    def issue(self, t: torch.Tensor, prescaled: bool = False) -> None:
+        """`prescaled`: t already holds gradient / world_size (e.g. divided inside a captured graph)."""
         self.wait()
         if dist.is_initialized() and dist.get_world_size() > 1:
-            t.div_(dist.get_world_size())
+            if not prescaled:
+                t.div_(dist.get_world_size())
             self._pending = (dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True), t)
 
     def wait(self) -> None:
