@@ -10,11 +10,12 @@
 // O_i = Q_i G_i (forward) or dQ/dK/dV (backward).  W is split into bf16 hi + lo parts (2 MFMAs) so the
 // mixing weights keep ~16 mantissa bits.  All contractions: v_mfma_f32_16x16x32_bf16, fp32 accumulate.
 //
-//   forward : k_fs_state_fwd (KV^T, ksum, z) -> k_fs_wz<0> (1/n) -> k_t16_out (mix + O)        [fused_tile16.hpp]
-//   backward: k_fs_state<1> (dG^T, dn) -> k_fs_wz<1> (dz) -> k_fs_dw/dwz/reduce (dW) -> k_t16_bwd_dq (mix G; dQ, dksum)
-//             -> k_t16_bwd_dkv (mix dKV; dK, dV)
-// The kernels are bound by per-wave load latency, not bandwidth (PMC: 3-4 TB/s, waves mostly in s_waitcnt), so
-// the streaming kernels run 8-wave workgroups at <= 128 VGPRs: two workgroups = 16 waves per CU keep loads in flight.
+//   forward : k_fs_state1c<0> (KV^T, ksum, z) -> k_fs_wz<0> (1/n) -> k_tile_out (mix + O)                    [fused_tile16.hpp]
+//   backward: k_fs_state1c<1> (dG^T, dn) -> k_fs_dw (dW partials; extra workgroups: dz = W^T dn) -> k_tile_bwd: dQ tiles (mix G;
+//             dQ, dksum), dK/dV tiles (mix dKV; dK, dV), dW reduction -- one launch, three roles
+//   (k_fs_state / k_fs_state_fwd: the summaries of blocks of more than 64 tokens, in synchronous 64-row chunks)
+// The streaming kernels run 8-wave workgroups at <= 128 VGPRs (two workgroups = 16 waves per CU); the tile kernels one 8-wave
+// workgroup per CU (160 KB of LDS).  What bounds each of them is measured in DESIGN.md section 3b.
 #pragma once
 #include <type_traits>
 
@@ -865,7 +866,7 @@ __global__ __launch_bounds__(FT8) void k_fs_dw(const FsDwArgs a) {
         for (int r = 0; r < 4; ++r) out[(wi * 16 + kg * 4 + r) * 64 + (2 * wj + t) * 16 + n] = acc[t][r];
 }
 
-// Deterministic reduction of the per-(b,h, split) dW partials, run by the LAST workgroups of the k_t16_bwd_dkv launch (they
+// Deterministic reduction of the per-(b,h, split) dW partials, run by the LAST workgroups of the k_tile_bwd launch (they
 // fill the tail of that launch instead of costing a latency-bound launch of their own): workgroup r -> 32 consecutive elements
 // of the padded [64][64] matrix; 64 part-lanes of 8 threads (16-byte loads), each summing every 64th partial in four
 // independent chains, then a fixed-order sum over the part-lanes through LDS.  512 threads, DWR_WGS workgroups.
@@ -896,7 +897,7 @@ __device__ __forceinline__ void dw_reduce_body(float* __restrict__ red /* [64][3
 }
 
 // -------------------------------------------------------------------------------------------------
-// Arguments of the token-gradient kernels (k_t16_bwd_dq / k_t16_bwd_dkv, fused_tile16.hpp):
+// Arguments of the token-gradient launch (k_tile_bwd: dQ role, dK/dV role, dW reduction; fused_tile16.hpp):
 //   dq : Gt = mix(W, KV)    -> dQ_j = (dO_j G_j^T) / n_j + dz_j (x) ksum_j  (relu mask) ; dksum_j
 //   dkv: Gt = mix(W^T, dG)  -> dK_j = V_j dKV_j^T + 1 dksum_j^T (relu mask) ; dV_j = K_j dKV_j
 // -------------------------------------------------------------------------------------------------
@@ -909,9 +910,9 @@ struct FsTokArgs {
     const u16* state;   // KV^T
     const u16* dstate;  // dG^T
     const float* ninv;  // [bh][M][S]
-    const float* dz;    // [bh][M][S]  (k_fs_wz<1>)
+    const float* dz;    // [bh][M][S]  (the dz workgroups of k_fs_dw)
     const float* ksum;
-    float* dksum;       // [bh][M][64]: written by k_fs_bwd_dq, read by k_fs_bwd_dkv
+    float* dksum;       // [bh][M][64]: written by the dQ role, read by the dK/dV role
     int H, M, S, njg;
     float eps;
     int relu, normalize;
