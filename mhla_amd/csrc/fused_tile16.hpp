@@ -359,7 +359,7 @@ __device__ __forceinline__ void tile_bwd_dq_body(const FsTokArgs& a, unsigned ch
     };
     // ... then dQ rows (scaling by 1 / n, + dz (x) ksum, store) and the chunk's contribution to dksum (per-lane partials: this
     // lane's four rows, columns 32 ks + 8 kg + t)
-    auto finish_store = [&](f32x4 (&acc)[4][4], bf16x8 (&qv)[4][2], float (&dks_acc)[2][8], int bi, int j, int c0, int rv) {
+    auto finish_store = [&](f32x4 (&acc)[4][4], bf16x8 (&qv)[4][2], float (&dks_acc)[2][8], int bi, int j, int c0, int rv, auto after_q) {
         const long p0 = (long)j * S + c0;
         u16* Gb = Gt + bi * GSLOT;
         if (a.normalize) {
@@ -380,6 +380,7 @@ __device__ __forceinline__ void tile_bwd_dq_body(const FsTokArgs& a, unsigned ch
                 for (int tn = 0; tn < 4; ++tn) acc[st][tn] = acc[st][tn] * ni + dzr * ks4[tn];
             }
         }
+        after_q();   // the chunk's Q rows are dead from here on: the caller may request the next ones into their registers
         if (c0 + 64 >= S) {
             wave_lds_fence();
             stage64(Gb, acc, lane);
@@ -457,16 +458,20 @@ __device__ __forceinline__ void tile_bwd_dq_body(const FsTokArgs& a, unsigned ch
             load_a64(gvB, gb, a.dout.sn, a.idx, (long)jBc * S, S, lane);
             products(acc, gvA, wave);
             zero_dks(dks_acc);
-            if (jA < M) { finish_store(acc, qvA, dks_acc, wave, jA, 0, S); if (a.normalize) finish_dks(dks_acc, jA); }
+            // the second block's Q rows are requested as soon as the first block's are dead (before its staging and stores): they travel
+            // during those and the second block's products
+            auto fetch_qB = [&]() { if (a.normalize) load_a64(qvB, qb, a.q.sn, a.idx, (long)jBc * S, S, lane); };
+            auto nothing = []() {};
+            if (jA < M) { finish_store(acc, qvA, dks_acc, wave, jA, 0, S, fetch_qB); if (a.normalize) finish_dks(dks_acc, jA); }
+            else fetch_qB();
             trace_mark(a.trace, 4);
-            if (a.normalize) load_a64(qvB, qb, a.q.sn, a.idx, (long)jBc * S, S, lane);      // travels during the second block's products
             products(acc, gvB, wave + 8);
             zero_dks(dks_acc);
-            if (jB < M) { finish_store(acc, qvB, dks_acc, wave + 8, jB, 0, S); if (a.normalize) finish_dks(dks_acc, jB); }
+            if (jB < M) { finish_store(acc, qvB, dks_acc, wave + 8, jB, 0, S, nothing); if (a.normalize) finish_dks(dks_acc, jB); }
         } else {
             products(acc, gvA, wave);
             zero_dks(dks_acc);
-            if (jA < M) { finish_store(acc, qvA, dks_acc, wave, jA, 0, S); if (a.normalize) finish_dks(dks_acc, jA); }
+            if (jA < M) { finish_store(acc, qvA, dks_acc, wave, jA, 0, S, []() {}); if (a.normalize) finish_dks(dks_acc, jA); }
             trace_mark(a.trace, 4);
         }
         trace_mark(a.trace, 5);
@@ -497,7 +502,7 @@ __device__ __forceinline__ void tile_bwd_dq_body(const FsTokArgs& a, unsigned ch
                 wave_lds_fence();
             }
             products(acc, gv, bi);
-            finish_store(acc, qv, dks_acc, bi, j, c0, rv);
+            finish_store(acc, qv, dks_acc, bi, j, c0, rv, []() {});
         }
         if (a.normalize) finish_dks(dks_acc, j);
     }
