@@ -16,6 +16,7 @@
 #include "blockmix.hpp"
 #include "causal.hpp"
 #include "causal_bf16.hpp"
+#include "causal_mix.hpp"
 #include "epilogue.hpp"
 #include "fused.hpp"
 #include "lepe.hpp"
@@ -253,8 +254,29 @@ struct CsWs {
     size_t total_fwd, total_bwd;
 };
 // esz: bytes per summary element (2 on the bf16 pipeline, 4 on the generic one)
+// Launch plan of the resident-sequence mixing kernels (causal_mix.hpp): waves per workgroup (16 chunks each), workgroups and
+// slices per workgroup.  One workgroup per CU at 8 waves (132 KB of LDS), two / four at 4 / 2 waves.
+struct Mix2Plan { int nw, te, wgs, spw; long total; };
+Mix2Plan mix2_plan(size_t bh, int n, long E, bool bwd) {
+    static const char* const knob = getenv("MHLA_CAUSAL_MIX_TE");   // tuning knob, read once: forward slice width 128 (default) or 256
+    Mix2Plan p{};
+    p.nw = n <= 32 ? 2 : n <= 64 ? 4 : 8;
+    p.te = (!bwd && knob && knob[0] == '2' && E % 256 == 0) ? 256 : 128;
+    p.total = (long)bh * (E / p.te);
+    // workgroups the chip holds at once: forward 2 tiles of 16 nw rows and 64 nw threads, backward 3 tiles and 128 nw threads
+    const long slots = 256L * (8 / p.nw) * (bwd ? 1 : 256 / p.te);
+    const long wgs = std::min(p.total, slots);
+    p.spw = (int)((p.total + wgs - 1) / std::max(wgs, 1L));
+    p.wgs = (int)((p.total + p.spw - 1) / std::max(p.spw, 1));
+    return p;
+}
+bool cs_mix2_ok(int n, long E) {
+    static const char* const knob = getenv("MHLA_CAUSAL_MIX");   // tuning knob, read once: "old" keeps k_csf_mix / k_csf_dw
+    return n <= 128 && E % fast::MF_TE == 0 && !(knob && knob[0] == 'o');
+}
 CsWs cs_carve(void* ws, int B, int T, int H, int K, int V, int chunk, int esz) {
     const size_t bh = (size_t)B * H, n = (size_t)(T + chunk - 1) / chunk, st = al4(bh * n * K * V) * esz / 4;
+    const size_t parts = std::max(bh * DW_MAX_SPLIT, (size_t)mix2_plan(bh, (int)n, (long)K * V, true).wgs);
     float* p = (float*)ws;
     CsWs w;
     w.S = p; p += st;
@@ -262,7 +284,7 @@ CsWs cs_carve(void* ws, int B, int T, int H, int K, int V, int chunk, int esz) {
     w.total_fwd = (size_t)(p - (float*)ws) * 4;
     w.dP = p; p += st;
     w.dS = p; p += st;
-    w.dwp = p; p += al4(bh * n * n * DW_MAX_SPLIT);
+    w.dwp = p; p += al4(parts * n * n);
     w.diag = p; p += al4(bh * n);
     w.total_bwd = (size_t)(p - (float*)ws) * 4;
     return w;
@@ -644,6 +666,20 @@ size_t mhla_causal_bwd_ws_bytes(int B, int T, int H, int K, int V, int chunk, in
     return cs_carve(nullptr, B, T, H, K, V, chunk, cs_bf16_ok(K, V, dtype) ? 2 : 4).total_bwd;
 }
 
+// P = strictly-lower mix of S (bf16 pipeline)
+static int cs_mix_fwd(const float* mix, int ldmix, const uint16_t* S, uint16_t* P, int BH, int n, long E, hipStream_t st) {
+    if (cs_mix2_ok(n, E)) {
+        const Mix2Plan pl = mix2_plan((size_t)BH, n, E, false);
+        fast::CsfMix2Args mf{mix, ldmix, S, nullptr, P, nullptr, n, E, pl.total, pl.spw};
+#define MIXF(NW, TE) launch(fast::k_csf_mixf<NW, TE>, dim3(pl.wgs), dim3(64 * NW), fast::mixf_smem<NW, TE>(), st, "k_csf_mixf", mf)
+        if (pl.te == 256) return pl.nw == 2 ? MIXF(2, 256) : pl.nw == 4 ? MIXF(4, 256) : MIXF(8, 256);
+        return pl.nw == 2 ? MIXF(2, 128) : pl.nw == 4 ? MIXF(4, 128) : MIXF(8, 128);
+#undef MIXF
+    }
+    fast::CsfMixArgs m{mix, ldmix, S, P, n, E};
+    return launch(fast::k_csf_mix<0>, dim3((unsigned)(E / fast::MX_TE), (n + 63) / 64, BH), dim3(NTHREADS), fast::CSF_MIX_SMEM, st, "k_csf_mix<0>", m);
+}
+
 static int cs_fwd_impl(mhla_view q, mhla_view k, mhla_view v, const float* mix, int ldmix, mhla_mview out, void* ws,
                        size_t ws_bytes, int B, int T, int H, int K, int V, int chunk, float scale, int dtype, void* stream,
                        bool epi, const float* nw, float neps, mhla_view gate, mhla_mview y) {
@@ -672,8 +708,7 @@ static int cs_fwd_impl(mhla_view q, mhla_view k, mhla_view v, const float* mix, 
         // bf16 pipeline (causal_bf16.hpp): bf16 chunk summaries, bf16 MFMA everywhere
         fast::CsfStateArgs s{cv(k), cv(v), (uint16_t*)w.S, H, n, K, V, (long)T, 1.f};
         RC(launch(fast::k_csf_state, dim3(n, B * H, K / 64), dim3(NTHREADS), fast::CSF_STATE_SMEM, st, "k_csf_state", s));
-        fast::CsfMixArgs m{mix, ldmix, (const uint16_t*)w.S, (uint16_t*)w.P, n, E};
-        RC(launch(fast::k_csf_mix<0>, dim3((unsigned)(E / fast::MX_TE), (n + 63) / 64, B * H), dim3(NTHREADS), fast::CSF_MIX_SMEM, st, "k_csf_mix<0>", m));
+        RC(cs_mix_fwd(mix, ldmix, (const uint16_t*)w.S, (uint16_t*)w.P, B * H, n, E, st));
         CsOutArgs o{cv(q), cv(k), cv(v), cmv(out), mix, ldmix, w.P, H, n, K, V, (long)T, scale, cmv(y), cv(gate), nw, neps};
         if (epi) RC(launch(fast::k_csf_out<uint16_t, true>, dim3(n, B * H, 1), dim3(NTHREADS), fast::CSF_OUT_SMEM, st, "k_csf_out<norm>", o));
         else     RC(launch(fast::k_csf_out<uint16_t>, dim3(n, B * H, (V / 64 + fast::CSF_OUT_VS - 1) / fast::CSF_OUT_VS), dim3(NTHREADS), fast::CSF_OUT_SMEM, st, "k_csf_out", o));
@@ -731,13 +766,23 @@ int mhla_causal_bwd(mhla_view q, mhla_view k, mhla_view v, const float* mix, int
         if (!fwd_ws) {
             fast::CsfStateArgs s{cv(k), cv(v), S, H, n, K, V, (long)T, 1.f};
             RC(launch(fast::k_csf_state, sgrid, dim3(NTHREADS), fast::CSF_STATE_SMEM, st, "k_csf_state", s));
-            fast::CsfMixArgs m{mix, ldmix, S, P, n, E};
-            RC(launch(fast::k_csf_mix<0>, mgrid, dim3(NTHREADS), fast::CSF_MIX_SMEM, st, "k_csf_mix<0>", m));
+            RC(cs_mix_fwd(mix, ldmix, S, P, B * H, n, E, st));
         }
         fast::CsfStateArgs sp{cv(q), cv(dout), dP, H, n, K, V, (long)T, scale};
         RC(launch(fast::k_csf_state, sgrid, dim3(NTHREADS), fast::CSF_STATE_SMEM, st, "k_csf_state", sp));
-        fast::CsfMixArgs mt{mix, ldmix, dP, dS, n, E};
-        RC(launch(fast::k_csf_mix<1>, mgrid, dim3(NTHREADS), fast::CSF_MIX_SMEM, st, "k_csf_mix<1>", mt));
+        const bool mix2 = cs_mix2_ok(n, E);
+        int nparts = B * H * nsplit;
+        if (mix2) {   // dS and the dmix partials from one pass over dP and S
+            const Mix2Plan pl = mix2_plan((size_t)B * H, n, E, true);
+            fast::CsfMix2Args mb{mix, ldmix, dP, S, dS, w.dwp, n, E, pl.total, pl.spw};
+#define MIXB(NW) launch(fast::k_csf_mixb<NW>, dim3(pl.wgs), dim3(128 * NW), fast::mixb_smem<NW>(), st, "k_csf_mixb", mb)
+            RC(pl.nw == 2 ? MIXB(2) : pl.nw == 4 ? MIXB(4) : MIXB(8));
+#undef MIXB
+            nparts = pl.wgs;
+        } else {
+            fast::CsfMixArgs mt{mix, ldmix, dP, dS, n, E};
+            RC(launch(fast::k_csf_mix<1>, mgrid, dim3(NTHREADS), fast::CSF_MIX_SMEM, st, "k_csf_mix<1>", mt));
+        }
         CsTokArgs t{cv(q), cv(k), cv(v), cv(dout), cmv(dq), cmv(dk), cmv(dv), mix, ldmix, w.P, w.dS, w.diag, H, n, K, V, (long)T, scale};
         static const char* const tokv = getenv("MHLA_CAUSAL_TOK");   // tuning knob, read once: "2" forces the K-slice-outer kernels
         const bool tok3 = !(tokv && tokv[0] == '2');
@@ -747,12 +792,17 @@ int mhla_causal_bwd(mhla_view q, mhla_view k, mhla_view v, const float* mix, int
         else if (V <= 256) RC(launch(fast::k_csf_bwd_tok2<uint16_t, 4>, dim3(n, B * H), dim3(NTHREADS), fast::CSF_TOK2_SMEM, st, "k_csf_bwd_tok", t));
         else if (V <= 512) RC(launch(fast::k_csf_bwd_tok2<uint16_t, 8>, dim3(n, B * H), dim3(NTHREADS), fast::CSF_TOK2_SMEM, st, "k_csf_bwd_tok", t));
         else               RC(launch(fast::k_csf_bwd_tok<uint16_t>, dim3(n, B * H), dim3(NTHREADS), fast::CSF_TOK_SMEM, st, "k_csf_bwd_tok", t));
-        fast::CsfDwArgs d{dP, S, E, w.dwp, n, tiles, nsplit};
-        if (n <= 16)      RC(launch(fast::k_csf_dw<1>, dim3(1, B * H, nsplit), dim3(NTHREADS), fast::CSF_DW_SMEM, st, "k_csf_dw<16>", d));
-        else if (n <= 32) RC(launch(fast::k_csf_dw<2>, dim3(1, B * H, nsplit), dim3(NTHREADS), fast::CSF_DW_SMEM, st, "k_csf_dw<32>", d));
-        else              RC(launch(fast::k_csf_dw<4>, dim3(tiles * tiles, B * H, nsplit), dim3(NTHREADS), fast::CSF_DW_SMEM, st, "k_csf_dw", d));
-        RC(launch(k_dw_reduce<1>, dim3((n * n + 63) / 64), dim3(256), 0, st, "k_dw_reduce<1>", (const float*)w.dwp,
-                  (const float*)w.diag, dmix, lddmix, n, B * H * nsplit, B * H));
+        if (!mix2) {
+            fast::CsfDwArgs d{dP, S, E, w.dwp, n, tiles, nsplit};
+            if (n <= 16)      RC(launch(fast::k_csf_dw<1>, dim3(1, B * H, nsplit), dim3(NTHREADS), fast::CSF_DW_SMEM, st, "k_csf_dw<16>", d));
+            else if (n <= 32) RC(launch(fast::k_csf_dw<2>, dim3(1, B * H, nsplit), dim3(NTHREADS), fast::CSF_DW_SMEM, st, "k_csf_dw<32>", d));
+            else              RC(launch(fast::k_csf_dw<4>, dim3(tiles * tiles, B * H, nsplit), dim3(NTHREADS), fast::CSF_DW_SMEM, st, "k_csf_dw", d));
+        }
+        // few elements, many partials (short sequences): 16 part-lanes per element instead of 4
+        if (n <= 64) RC(launch(k_dw_reduce<1, 16>, dim3((n * n + 15) / 16), dim3(256), 0, st, "k_dw_reduce<1>", (const float*)w.dwp,
+                               (const float*)w.diag, dmix, lddmix, n, nparts, B * H));
+        else         RC(launch(k_dw_reduce<1>, dim3((n * n + 63) / 64), dim3(256), 0, st, "k_dw_reduce<1>", (const float*)w.dwp,
+                               (const float*)w.diag, dmix, lddmix, n, nparts, B * H));
         return MHLA_OK;
     }
     DISPATCH_T(dtype, {
