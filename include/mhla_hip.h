@@ -189,7 +189,7 @@ int mhla_causal_normgate_fwd(mhla_view q, mhla_view k, mhla_view v, const float*
                              int K, int V, int chunk, float scale, int dtype, void* stream);
 
 /* Backward.  dmix is [n, n] fp32 with row stride lddmix;
- * only the lower triangle (incl. diagonal) of the leading n x n is written.
+ * every entry of the leading n x n is written (zeros above the diagonal).
  * fwd_ws: the workspace mhla_causal_fwd was given for the same arguments, contents untouched
  * (its chunk summaries S_j and the prefix mixes are reused), or NULL to recompute them. */
 int mhla_causal_bwd(mhla_view q, mhla_view k, mhla_view v, const float* mix, int ldmix,

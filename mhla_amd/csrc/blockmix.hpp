@@ -538,7 +538,7 @@ __global__ __launch_bounds__(256) void k_dw_reduce(const float* __restrict__ dwp
     }
     red[pl][el] = s;
     __syncthreads();
-    if (pl == 0 && e < M * M && (MASK == 0 || j <= i)) {
+    if (pl == 0 && e < M * M) {   // MASK: entries above the diagonal are written as zeros (their partial sums are empty)
         float t = 0.f;
 #pragma unroll
         for (int q = 0; q < PL; ++q) t += red[q][el];

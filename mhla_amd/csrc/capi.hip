@@ -265,9 +265,10 @@ Mix2Plan mix2_plan(size_t bh, int n, long E, bool bwd) {
     p.total = (long)bh * (E / p.te);
     // workgroups the chip holds at once: forward 2 tiles of 16 nw rows and 64 nw threads, backward 3 tiles and 128 nw threads
     const long slots = 256L * (8 / p.nw) * (bwd ? 1 : 256 / p.te);
+    if (p.total <= 0) return p;   // (summaries smaller than a slice: the dispatcher does not take this path)
     const long wgs = std::min(p.total, slots);
-    p.spw = (int)((p.total + wgs - 1) / std::max(wgs, 1L));
-    p.wgs = (int)((p.total + p.spw - 1) / std::max(p.spw, 1));
+    p.spw = (int)((p.total + wgs - 1) / wgs);
+    p.wgs = (int)((p.total + p.spw - 1) / p.spw);
     return p;
 }
 bool cs_mix2_ok(int n, long E) {
@@ -666,6 +667,16 @@ size_t mhla_causal_bwd_ws_bytes(int B, int T, int H, int K, int V, int chunk, in
     return cs_carve(nullptr, B, T, H, K, V, chunk, cs_bf16_ok(K, V, dtype) ? 2 : 4).total_bwd;
 }
 
+// chunk summaries X^T Y of the bf16 pipeline (S = K^T V, dP = scale Q^T dO)
+static int cs_state16(const mhla_view& x, const mhla_view& y, uint16_t* out, float mul, int B, int T, int H, int n, int K, int V, hipStream_t st) {
+    static const char* const knob = getenv("MHLA_CAUSAL_STATE");   // tuning knob, read once: "old" keeps the per-K-slice kernel
+    fast::CsfStateArgs s{cv(x), cv(y), out, H, n, K, V, (long)T, mul};
+    if (knob && knob[0] == 'o')
+        return launch(fast::k_csf_state, dim3(n, B * H, K / 64), dim3(NTHREADS), fast::CSF_STATE_SMEM, st, "k_csf_state", s);
+    const int blocks = ((K + fast::ST2_KW - 1) / fast::ST2_KW) * ((V + fast::ST2_VW - 1) / fast::ST2_VW);
+    return launch(fast::k_csf_state2, dim3(n, B * H, blocks), dim3(NTHREADS), fast::CSF_STATE2_SMEM, st, "k_csf_state", s);
+}
+
 // P = strictly-lower mix of S (bf16 pipeline)
 static int cs_mix_fwd(const float* mix, int ldmix, const uint16_t* S, uint16_t* P, int BH, int n, long E, hipStream_t st) {
     if (cs_mix2_ok(n, E)) {
@@ -706,8 +717,7 @@ static int cs_fwd_impl(mhla_view q, mhla_view k, mhla_view v, const float* mix, 
     const long E = (long)K * V;
     if (pipe16) {
         // bf16 pipeline (causal_bf16.hpp): bf16 chunk summaries, bf16 MFMA everywhere
-        fast::CsfStateArgs s{cv(k), cv(v), (uint16_t*)w.S, H, n, K, V, (long)T, 1.f};
-        RC(launch(fast::k_csf_state, dim3(n, B * H, K / 64), dim3(NTHREADS), fast::CSF_STATE_SMEM, st, "k_csf_state", s));
+        RC(cs_state16(k, v, (uint16_t*)w.S, 1.f, B, T, H, n, K, V, st));
         RC(cs_mix_fwd(mix, ldmix, (const uint16_t*)w.S, (uint16_t*)w.P, B * H, n, E, st));
         CsOutArgs o{cv(q), cv(k), cv(v), cmv(out), mix, ldmix, w.P, H, n, K, V, (long)T, scale, cmv(y), cv(gate), nw, neps};
         if (epi) RC(launch(fast::k_csf_out<uint16_t, true>, dim3(n, B * H, 1), dim3(NTHREADS), fast::CSF_OUT_SMEM, st, "k_csf_out<norm>", o));
@@ -762,14 +772,12 @@ int mhla_causal_bwd(mhla_view q, mhla_view k, mhla_view v, const float* mix, int
     const int nsplit = dw_splits(tiles * tiles * B * H, E);
     if (pipe16) {
         uint16_t *S = (uint16_t*)w.S, *P = (uint16_t*)w.P, *dP = (uint16_t*)w.dP, *dS = (uint16_t*)w.dS;
-        const dim3 sgrid(n, B * H, K / 64), mgrid((unsigned)(E / fast::MX_TE), tiles, B * H);
+        const dim3 mgrid((unsigned)(E / fast::MX_TE), tiles, B * H);
         if (!fwd_ws) {
-            fast::CsfStateArgs s{cv(k), cv(v), S, H, n, K, V, (long)T, 1.f};
-            RC(launch(fast::k_csf_state, sgrid, dim3(NTHREADS), fast::CSF_STATE_SMEM, st, "k_csf_state", s));
+            RC(cs_state16(k, v, S, 1.f, B, T, H, n, K, V, st));
             RC(cs_mix_fwd(mix, ldmix, S, P, B * H, n, E, st));
         }
-        fast::CsfStateArgs sp{cv(q), cv(dout), dP, H, n, K, V, (long)T, scale};
-        RC(launch(fast::k_csf_state, sgrid, dim3(NTHREADS), fast::CSF_STATE_SMEM, st, "k_csf_state", sp));
+        RC(cs_state16(q, dout, dP, scale, B, T, H, n, K, V, st));
         const bool mix2 = cs_mix2_ok(n, E);
         int nparts = B * H * nsplit;
         if (mix2) {   // dS and the dmix partials from one pass over dP and S

@@ -17,6 +17,11 @@ namespace fast {
 constexpr int CLD = 72;                 // LDS row stride (bf16) of the 64 x 64 tiles
 constexpr int CT = CS * CLD;            // elements per tile
 
+// The chunk summaries S, P, dP, dS of this pipeline are stored tile-major, [bh][n][K / 64][V / 64][64][64]: every 64 x 64 tile
+// that a kernel produces or stages is one contiguous 8 KB block (row-major [K][V] summaries made it 64 pieces of 128 B, 2 V bytes
+// apart).  The mixing kernels are elementwise across chunks and do not care.
+__device__ __forceinline__ long cs_tile_off(int kk0, int v0, int V) { return ((long)(kk0 >> 6) * (V >> 6) + (v0 >> 6)) * (CS * CS); }
+
 // 64 token rows x 64 columns (starting at column c0) of a view -> LDS tile; rows >= rv zero.  256 threads.
 __device__ __forceinline__ void cs_stage_tok(u16* __restrict__ dst, const u16* __restrict__ base, long sn, long p0, int rv, int tid) {
     const int r = tid >> 2, c = (tid & 3) * 16;
@@ -185,7 +190,7 @@ __global__ __launch_bounds__(NTHREADS) void k_csf_out(const CsOutArgs a) {
     static_assert(sizeof(ST) == 2, "k_csf_out expects bf16 summaries");
     const u16* Pb = reinterpret_cast<const u16*>(Pi);
     CsTile nQ, nK, nP, nVt;
-    auto issueP = [&](int ks, int j) { cs_issue_state(nP, Pb + (long)ks * a.V + vbase + 64 * j, a.V, tid); };
+    auto issueP = [&](int ks, int j) { cs_issue_state(nP, Pb + cs_tile_off(ks, vbase + 64 * j, a.V), CS, tid); };
     cs_issue_tok(nQ, qb, a.q.sn, p0, rv, tid);
     cs_issue_tok(nK, kb, a.k.sn, p0, rv, tid);
     issueP(0, 0);
@@ -364,8 +369,8 @@ __global__ __launch_bounds__(NTHREADS) void k_csf_bwd_tok(const CsTokArgs a) {
         for (int vs = 0; vs < V; vs += 64) {
             cs_stage_tok(X1, gb + vs, a.dout.sn, p0, rv, tid);
             cs_stage_tok(X2, vb + vs, a.v.sn, p0, rv, tid);
-            cs_stage_state(B1, Pi + (long)ks * V + vs, V, tid);
-            cs_stage_state(B2, dSi + (long)ks * V + vs, V, tid);
+            cs_stage_state(B1, Pi + cs_tile_off(ks, vs, V), CS, tid);
+            cs_stage_state(B2, dSi + cs_tile_off(ks, vs, V), CS, tid);
             __syncthreads();
             tile_mma<false, false>(acc1, X1, B1, wave, lane);   // dO P^T : B[k = v][n = kk] = P[kk][v]
             tile_mma<false, false>(acc2, X2, B2, wave, lane);   // V dS^T
@@ -392,7 +397,7 @@ __global__ __launch_bounds__(NTHREADS) void k_csf_bwd_tok(const CsTokArgs a) {
         zero4(acc1);
         for (int ks = 0; ks < K; ks += 64) {
             cs_stage_tok(X1, kb + ks, a.k.sn, p0, rv, tid);
-            cs_stage_state(B1, dSi + (long)ks * V + vs, V, tid);
+            cs_stage_state(B1, dSi + cs_tile_off(ks, vs, V), CS, tid);
             __syncthreads();
             tile_mma<false, true>(acc1, X1, B1, wave, lane);    // K dS : B[k = kk][n = v] = dS[kk][v]
             __syncthreads();
@@ -488,8 +493,8 @@ __global__ __launch_bounds__(NTHREADS) void k_csf_bwd_tok2(const CsTokArgs a) {
                 const int vs = j * 64;
                 cs_stage_tok(X1, gb + vs, a.dout.sn, p0, rv, tid);
                 cs_stage_tok(X2, vb + vs, a.v.sn, p0, rv, tid);
-                cs_stage_state(B1, Pi + (long)ks * V + vs, V, tid);
-                cs_stage_state(B2, dSi + (long)ks * V + vs, V, tid);
+                cs_stage_state(B1, Pi + cs_tile_off(ks, vs, V), CS, tid);
+                cs_stage_state(B2, dSi + cs_tile_off(ks, vs, V), CS, tid);
                 __syncthreads();
                 tile_mma<false, false>(acc1, X1, B1, wave, lane);       // dO P^T
                 tile_mma<false, false>(acc2, X2, B2, wave, lane);       // V dS^T
@@ -595,8 +600,8 @@ __global__ __launch_bounds__(NTHREADS, NK <= 2 ? 2 : 1) void k_csf_bwd_tok3(cons
     CsTile nP, ndS, nG, nV;   // next round's P / dS tiles; next V slice's dO / V rows
     cs_issue_tok(nG, gb, a.dout.sn, p0, rv, tid);
     cs_issue_tok(nV, vb, a.v.sn, p0, rv, tid);
-    cs_issue_state(nP, reinterpret_cast<const u16*>(Pi), V, tid);
-    cs_issue_state(ndS, reinterpret_cast<const u16*>(dSi), V, tid);
+    cs_issue_state(nP, reinterpret_cast<const u16*>(Pi), CS, tid);
+    cs_issue_state(ndS, reinterpret_cast<const u16*>(dSi), CS, tid);
     for (int vs = 0; vs < V; vs += 64) {
         f32x4 accV[4];
         zero4(accV);
@@ -616,8 +621,8 @@ __global__ __launch_bounds__(NTHREADS, NK <= 2 ? 2 : 1) void k_csf_bwd_tok3(cons
                     const bool wrap = kk + 1 >= nks;
                     const int nkk = wrap ? 0 : kk + 1;
                     const int nvs = wrap ? (vs + 64 < V ? vs + 64 : 0) : vs;
-                    cs_issue_state(nP, reinterpret_cast<const u16*>(Pi) + (long)nkk * 64 * V + nvs, V, tid);
-                    cs_issue_state(ndS, reinterpret_cast<const u16*>(dSi) + (long)nkk * 64 * V + nvs, V, tid);
+                    cs_issue_state(nP, reinterpret_cast<const u16*>(Pi) + cs_tile_off(nkk * 64, nvs, V), CS, tid);
+                    cs_issue_state(ndS, reinterpret_cast<const u16*>(dSi) + cs_tile_off(nkk * 64, nvs, V), CS, tid);
                 }
                 if (kk == 0) {
                     tile_mma<false, false>(accdA, X1, X2, wave, lane);      // dO V^T
@@ -695,7 +700,6 @@ __global__ __launch_bounds__(NTHREADS) void k_csf_state(const CsfStateArgs a) {
     const int rv = (int)min((long)CS, a.T - p0);
     const u16* xb = (const u16*)a.x.ptr + b * a.x.sb + h * a.x.sh + ks;
     const u16* yb = (const u16*)a.y.ptr + b * a.y.sb + h * a.y.sh;
-    u16* ob = a.out + (((long)bh * a.n + ci) * a.K + ks) * a.V;
     const int r = tid >> 2, c = (tid & 3) * 16;
 
     cs_stage_tok(Xs, xb, a.x.sn, p0, rv, tid);
@@ -719,9 +723,91 @@ __global__ __launch_bounds__(NTHREADS) void k_csf_state(const CsfStateArgs a) {
         tile_mma<true, true>(acc, Xs, Ys, wave, lane);   // rows kk, columns v, reduction over the chunk's tokens
         cs_put(Os, acc, a.mul, wave, lane);
         __syncthreads();
-        u16* d = ob + (long)r * a.V + vs + c;
+        u16* d = a.out + ((long)bh * a.n + ci) * a.K * a.V + cs_tile_off(ks, vs, a.V) + r * CS + c;
         *reinterpret_cast<uint4*>(d) = *reinterpret_cast<const uint4*>(Os + r * CLD + c);
         *reinterpret_cast<uint4*>(d + 8) = *reinterpret_cast<const uint4*>(Os + r * CLD + c + 8);
+    }
+}
+
+// k_csf_state2: the same summaries, one workgroup per chunk and [128 x 256] block of the summary (the whole summary at
+// K = 128, V = 256).  All of the block's token rows are requested at once (48 KB in flight per workgroup instead of one 8 KB V
+// slice ahead), one barrier, then every wave multiplies its 32 summary rows against all V columns and streams them out through
+// a wave-private staging strip: no further workgroup barrier, 2 KB contiguous per wave store (tile-major layout).
+constexpr int ST2_KW = 128, ST2_VW = 256, ST2_LDX = ST2_KW + 8, ST2_LDY = ST2_VW + 8;
+constexpr int CSF_STATE2_SMEM = (CS * ST2_LDX + CS * ST2_LDY + 4 * 16 * CLD) * 2;
+
+__global__ __launch_bounds__(NTHREADS, 2) void k_csf_state2(const CsfStateArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u16* Xs = reinterpret_cast<u16*>(smem_raw);
+    u16* Ys = Xs + CS * ST2_LDX;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nl = lane & 15, kg = lane >> 4;
+    u16* Ws = Ys + CS * ST2_LDY + wave * 16 * CLD;
+    const int ci = blockIdx.x, bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
+    const int nvb = (a.V + ST2_VW - 1) / ST2_VW, kb = blockIdx.z / nvb, vb = blockIdx.z - kb * nvb;
+    const int k0 = kb * ST2_KW, v0 = vb * ST2_VW, kw = min(ST2_KW, a.K - k0), vw = min(ST2_VW, a.V - v0);
+    const long p0 = (long)ci * CS;
+    const int rv = (int)min((long)CS, a.T - p0);
+    const u16* xb = (const u16*)a.x.ptr + b * a.x.sb + h * a.x.sh + k0;
+    const u16* yb = (const u16*)a.y.ptr + b * a.y.sb + h * a.y.sh + v0;
+    u16* ob = a.out + ((long)bh * a.n + ci) * a.K * a.V;
+
+    // X: 4 passes of 16 rows x 16 pieces; Y: 8 passes of 8 rows x 32 pieces (pieces past the block's width, rows past the chunk: zeros)
+    uint4 xr[4], yr[8];
+    {
+        const int xc = (tid & 15) * 8, yc = (tid & 31) * 8;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int row = (tid >> 4) + 16 * p;
+            const bool ok = row < rv && xc < kw;
+            xr[p] = gld_stream16(xb + (p0 + (ok ? row : 0)) * a.x.sn + (ok ? xc : 0));
+        }
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int row = (tid >> 5) + 8 * p;
+            const bool ok = row < rv && yc < vw;
+            yr[p] = gld_stream16(yb + (p0 + (ok ? row : 0)) * a.y.sn + (ok ? yc : 0));
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int row = (tid >> 4) + 16 * p;
+            const bool ok = row < rv && xc < kw;
+            *reinterpret_cast<uint4*>(Xs + row * ST2_LDX + xc) = make_uint4(ok ? xr[p].x : 0u, ok ? xr[p].y : 0u, ok ? xr[p].z : 0u, ok ? xr[p].w : 0u);
+        }
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int row = (tid >> 5) + 8 * p;
+            const bool ok = row < rv && yc < vw;
+            *reinterpret_cast<uint4*>(Ys + row * ST2_LDY + yc) = make_uint4(ok ? yr[p].x : 0u, ok ? yr[p].y : 0u, ok ? yr[p].z : 0u, ok ? yr[p].w : 0u);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        const int rt = wave * 2 + rr;               // 16 summary rows kk = k0 + 16 rt ..
+        if (rt * 16 < kw) {
+            // the product is formed transposed (m = v, n = kk): a lane ends up with four consecutive v of one summary row
+            const bf16x8 xa0 = tr_read8(Xs, ST2_LDX, 0, rt * 16, lane), xa1 = tr_read8(Xs, ST2_LDX, 32, rt * 16, lane);
+            for (int vt = 0; vt * 64 < vw; ++vt) {
+                f32x4 acc[4];
+                zero4(acc);
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn) {
+                    acc[tn] = mfma_bf16(tr_read8(Ys, ST2_LDY, 0, vt * 64 + tn * 16, lane), xa0, acc[tn]);
+                    acc[tn] = mfma_bf16(tr_read8(Ys, ST2_LDY, 32, vt * 64 + tn * 16, lane), xa1, acc[tn]);
+                }
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn)
+                    *reinterpret_cast<uint2*>(Ws + nl * CLD + tn * 16 + kg * 4) =
+                        make_uint2(pack_bf16x2(a.mul * acc[tn][0], a.mul * acc[tn][1]), pack_bf16x2(a.mul * acc[tn][2], a.mul * acc[tn][3]));
+                wave_lds_fence();
+                const int r = lane >> 2, c = (lane & 3) * 16;
+                const uint4 o0 = *reinterpret_cast<const uint4*>(Ws + r * CLD + c), o1 = *reinterpret_cast<const uint4*>(Ws + r * CLD + c + 8);
+                u16* d = ob + cs_tile_off(k0 + rt * 16, v0 + vt * 64, a.V) + ((rt * 16) & 63) * CS + r * CS + c;
+                gst<uint4>(d, o0);
+                gst<uint4>(d + 8, o1);
+                wave_lds_fence();
+            }
+        }
     }
 }
 

@@ -706,7 +706,9 @@ class _Causal(torch.autograd.Function):
         dk = torch.empty((B, T, H, K), dtype=q.dtype, device=q.device)
         dv = torch.empty((B, T, H, V), dtype=q.dtype, device=q.device)
         dq = torch.empty((B, T, H, K), dtype=q.dtype, device=q.device)
-        dmix = torch.zeros(mixf.shape, dtype=torch.float32, device=q.device)
+        # the library writes every entry of the leading [n, n] block (zeros above the diagonal)
+        n_chunks = (T + chunk_size - 1) // chunk_size
+        dmix = (torch.empty if tuple(mixf.shape) == (n_chunks, n_chunks) else torch.zeros)(mixf.shape, dtype=torch.float32, device=q.device)
         ws = _ws(lib.mhla_causal_bwd_ws_bytes(B, T, H, K, V, chunk_size, _dtype_code(q)), q.device)
         rc = lib.mhla_causal_bwd(_view(q), _view(k), _view(v), mixf.data_ptr(), mixf.shape[1], _view(dout),
                                  _view(dq), _view(dk), _view(dv), dmix.data_ptr(), dmix.shape[1],
@@ -800,7 +802,9 @@ class _CausalNormGate(torch.autograd.Function):
         dq = torch.empty((B, T, H, K), dtype=q.dtype, device=q.device)
         dk = torch.empty((B, T, H, K), dtype=q.dtype, device=q.device)
         dv = torch.empty((B, T, H, V), dtype=q.dtype, device=q.device)
-        dmix = torch.zeros(mixf.shape, dtype=torch.float32, device=q.device)
+        # the library writes every entry of the leading [n, n] block (zeros above the diagonal)
+        n_chunks = (T + chunk_size - 1) // chunk_size
+        dmix = (torch.empty if tuple(mixf.shape) == (n_chunks, n_chunks) else torch.zeros)(mixf.shape, dtype=torch.float32, device=q.device)
         ws = _ws(lib.mhla_causal_bwd_ws_bytes(B, T, H, K, V, chunk_size, _dtype_code(q)), q.device)
         rc = lib.mhla_causal_bwd(_view(q), _view(k), _view(v), mixf.data_ptr(), mixf.shape[1], _view(do),
                                  _view(dq), _view(dk), _view(dv), dmix.data_ptr(), dmix.shape[1],
