@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MHLA_ABI_VERSION 5
+#define MHLA_ABI_VERSION 6
 
 enum { MHLA_F32 = 0, MHLA_BF16 = 1, MHLA_F16 = 2 };
 
@@ -62,6 +62,9 @@ typedef struct {
 } mhla_mview;
 
 int mhla_abi_version(void);
+/* Device-code options the library was compiled with, e.g. "gfx950 -O3 no-packed-fp32" (mhla_amd/build.py); the Python loader
+ * refuses a library built with another set. */
+const char* mhla_build_flags(void);
 const char* mhla_last_error(void);
 
 /* Profiling aid (used by bench.py): when enabled, every kernel launch is bracketed by hipEvents on

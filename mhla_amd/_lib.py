@@ -8,7 +8,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # MHLA_LIB_PATH: A/B comparison of two builds of the same library (tools); the default is the in-tree build
 LIB_PATH = os.environ.get("MHLA_LIB_PATH") or os.path.join(_HERE, "lib", "libmhla_hip.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 F32, BF16, F16 = 0, 1, 2
 FLAG_RELU_EPS = 1
 FLAG_FORCE_GENERIC = 2
@@ -25,6 +25,7 @@ NULL_VIEW = View(None, 0, 0, 0)
 # name -> (restype, argtypes); every symbol include/mhla_hip.h declares
 SIGNATURES = {
     "mhla_abi_version": (c_int, []),
+    "mhla_build_flags": (c_char_p, []),
     "mhla_last_error": (c_char_p, []),
     "mhla_prof_enable": (None, [c_int]),
     "mhla_prof_report": (c_int, [c_char_p, c_size_t]),
@@ -102,6 +103,13 @@ def load():
     v = lib.mhla_abi_version()
     if v != ABI_VERSION:
         raise MhlaLibraryError(f"libmhla_hip.so ABI version {v} != expected {ABI_VERSION}; rebuild")
+    # The shipped build has no packed-fp32 VALU instructions in device code; a library compiled with
+    # another flag set (an older build, a hand-run hipcc command) is refused instead of silently reused.  Variant libraries
+    # given through MHLA_LIB_PATH (tools/build_variant.sh) are taken as they are.
+    flags = lib.mhla_build_flags().decode()
+    if "MHLA_LIB_PATH" not in os.environ and os.environ.get("MHLA_PACKED_FP32") != "1" and "no-packed-fp32" not in flags:
+        raise MhlaLibraryError(f"libmhla_hip.so was built with flags [{flags}], expected a no-packed-fp32 build: "
+                               "rebuild with `python -m mhla_amd.build --force`")
     _lib = lib
     return lib
 

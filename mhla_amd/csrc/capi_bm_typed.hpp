@@ -1,0 +1,159 @@
+// Generic (exact fp32 MFMA) and split-operand block-mix launches for one element type: the body of the (dtype, head-dim tile)
+// dispatch of mhla_blockmix_fwd / _bwd.  Included by capi_bm_f32.hip, capi_bm_bf16.hip, capi_bm_f16.hip, each of which
+// instantiates the two functions for its type -- the three are compiled side by side.
+#pragma once
+#include "capi_common.hpp"
+#include "blockmix.hpp"
+#include "split.hpp"
+
+namespace mhla {
+namespace capi {
+
+// KV/ksum/z, G for the forward and the recompute leg of the backward.
+template <typename T, int DT>
+int bm_state_and_mix(const mhla_view& q_num, const mhla_view& k_num, const mhla_view& v, const mhla_view& q_den,
+                     const mhla_view& k_den, const float* W, int ldw, const int32_t* idx, const BmWs& w, int B, int H,
+                     int M, int S, int D, float eps, unsigned flags, bool normalize, bool split, hipStream_t st,
+                     const float* rcos = nullptr, const float* rsin = nullptr, long ldr = 0) {
+    (void)q_num;
+    StateArgs a{};
+    a.rcos = rcos; a.rsin = rsin; a.ldr = ldr;
+    a.x = cv(k_num); a.y = cv(v); a.kd = cv(k_den); a.qd = cv(q_den); a.idx = idx;
+    a.out = w.kv; a.ksum = w.ksum; a.zo = w.z;
+    a.H = H; a.M = M; a.S = S; a.D = D; a.eps = eps;
+    a.relu = (flags & MHLA_FLAG_RELU_EPS) ? 1 : 0; a.normalize = normalize; a.split = split;
+    MixArgs m{W, ldw, w.kv, w.g, M, (long)D * D};
+    if (sp_shape_ok(D, flags)) {   // split-bf16 MFMA kernels (split.hpp)
+        if (a.rcos) RC(launch(sp::k_sp_state<T, DT, 0, true>, dim3(M, B * H), dim3(NTHREADS), sp::sp_state_smem<DT>(), st, "k_sp_state<rope>", a));
+        else        RC(launch(sp::k_sp_state<T, DT, 0>, dim3(M, B * H), dim3(NTHREADS), sp::sp_state_smem<DT>(), st, "k_sp_state", a));
+        RC(launch(sp::k_sp_mix<0, sp::Sum16<T>::value>, dim3((unsigned)((m.E + sp::SPM_TE - 1) / sp::SPM_TE), (M + 63) / 64, B * H), dim3(NTHREADS), sp::sp_mix_smem<sp::Sum16<T>::value>(), st, "k_sp_mix<0>", m));
+        if (normalize)
+            RC(launch(k_wz<0>, dim3((S + 63) / 64, (M + 63) / 64, B * H), dim3(NTHREADS), 0, st, "k_wz<0>", W, ldw, (const float*)w.z, w.ninv, M, S, eps));
+        return MHLA_OK;
+    }
+    RC(launch(k_bm_state<T, DT, 0>, dim3(M, B * H), dim3(NTHREADS), state_smem_floats<DT>() * 4, st, "k_bm_state<0>", a));
+    dim3 grid((unsigned)((m.E + MIX_TE - 1) / MIX_TE), (M + MIX_TI - 1) / MIX_TI, B * H);
+    RC(launch(k_mix<0, 0>, grid, dim3(NTHREADS), MIX_SMEM_FLOATS * 4, st, "k_mix<0,0>", m));
+    if (normalize)
+        RC(launch(k_wz<0>, dim3((S + 63) / 64, (M + 63) / 64, B * H), dim3(NTHREADS), 0, st, "k_wz<0>", W, ldw, (const float*)w.z, w.ninv, M, S, eps));
+    return MHLA_OK;
+}
+
+template <typename ET>
+int bm_fwd_typed(const BmCall& c) {
+    const mhla_view &q_num = c.q_num, &k_num = c.k_num, &v = c.v, &q_den = c.q_den, &k_den = c.k_den, &dout = c.dout, &gate = c.gate;
+    const mhla_view& out_view = c.outv;
+    const mhla_mview &dq_num = c.dq_num, &dk_num = c.dk_num, &dv = c.dv, &dq_den = c.dq_den, &dk_den = c.dk_den;
+    const float* W = c.W; const int ldw = c.ldw; float* dW = c.dW; const int32_t* block_index = c.block_index;
+    const BmWs& w = c.w;
+    const int B = c.B, H = c.H, M = c.M, S = c.S, D = c.D; const float eps = c.eps; const unsigned flags = c.flags;
+    const bool normalize = c.normalize, split = c.split, reuse = c.reuse, epi = c.epi;
+    hipStream_t st = c.st;
+    const float *rcos = c.rcos, *rsin = c.rsin; const long ldr = c.ldr;
+    const float* nw = c.nw; const float neps = c.neps; const int out_dtype = c.out_dtype;
+    const int dt = dt_for(D), relu = (flags & MHLA_FLAG_RELU_EPS) ? 1 : 0;
+    (void)dout; (void)gate; (void)out_view; (void)dq_num; (void)dk_num; (void)dv; (void)dq_den; (void)dk_den; (void)dW; (void)reuse; (void)epi;
+    (void)rcos; (void)rsin; (void)ldr; (void)nw; (void)neps; (void)out_dtype; (void)relu;
+    DISPATCH_DT(dt, {
+        RC((bm_state_and_mix<ET, DT>(q_num, k_num, v, q_den, k_den, W, ldw, block_index, w, B, H, M, S, D, eps, flags, normalize, split, st, rcos, rsin, ldr)));
+        OutArgs o{};
+        o.rcos = rcos; o.rsin = rsin; o.ldr = ldr;
+        o.q = cv(q_num); o.o = cmv(c.out); o.idx = block_index; o.W = W; o.ldw = ldw; o.g = w.g; o.ninv = w.ninv;
+        o.H = H; o.M = M; o.S = S; o.D = D; o.eps = eps;
+        o.relu = (flags & MHLA_FLAG_RELU_EPS) ? 1 : 0; o.normalize = normalize;
+        if (epi) {
+            if constexpr (std::is_same<ET, float>::value) {
+                o.nw = nw; o.neps = neps; o.gate = cv(gate);
+                const dim3 g(M, B * H), blk(sp::SP_OUT_T);
+                if (out_dtype == MHLA_BF16)     RC(launch(sp::k_sp_out<float, DT, bf16_t, true>, g, blk, sp::sp_out_smem<DT>(), st, "k_sp_out<norm>", o));
+                else if (out_dtype == MHLA_F16) RC(launch(sp::k_sp_out<float, DT, f16_t, true>, g, blk, sp::sp_out_smem<DT>(), st, "k_sp_out<norm>", o));
+                else                            RC(launch(sp::k_sp_out<float, DT, float, true>, g, blk, sp::sp_out_smem<DT>(), st, "k_sp_out<norm>", o));
+            }
+        } else if (sp_shape_ok(D, flags))
+            RC(launch(sp::k_sp_out<ET, DT>, dim3(M, B * H), dim3(sp::SP_OUT_T), sp::sp_out_smem<DT, sp::Sum16<ET>::value>(), st, "k_sp_out", o));
+        else
+            RC(launch(k_bm_out<ET, DT>, dim3(M, B * H), dim3(NTHREADS), out_smem_floats<DT>() * 4, st, "k_bm_out", o));
+    });
+    return MHLA_OK;
+}
+
+template <typename ET>
+int bm_bwd_typed(const BmCall& c) {
+    const mhla_view &q_num = c.q_num, &k_num = c.k_num, &v = c.v, &q_den = c.q_den, &k_den = c.k_den, &dout = c.dout, &gate = c.gate;
+    const mhla_view& out_view = c.outv;
+    const mhla_mview &dq_num = c.dq_num, &dk_num = c.dk_num, &dv = c.dv, &dq_den = c.dq_den, &dk_den = c.dk_den;
+    const float* W = c.W; const int ldw = c.ldw; float* dW = c.dW; const int32_t* block_index = c.block_index;
+    const BmWs& w = c.w;
+    const int B = c.B, H = c.H, M = c.M, S = c.S, D = c.D; const float eps = c.eps; const unsigned flags = c.flags;
+    const bool normalize = c.normalize, split = c.split, reuse = c.reuse, epi = c.epi;
+    hipStream_t st = c.st;
+    const float *rcos = c.rcos, *rsin = c.rsin; const long ldr = c.ldr;
+    const float* nw = c.nw; const float neps = c.neps; const int out_dtype = c.out_dtype;
+    const int dt = dt_for(D), relu = (flags & MHLA_FLAG_RELU_EPS) ? 1 : 0;
+    (void)dout; (void)gate; (void)out_view; (void)dq_num; (void)dk_num; (void)dv; (void)dq_den; (void)dk_den; (void)dW; (void)reuse; (void)epi;
+    (void)rcos; (void)rsin; (void)ldr; (void)nw; (void)neps; (void)out_dtype; (void)relu;
+    DISPATCH_DT(dt, {
+        if (!reuse)
+            RC((bm_state_and_mix<ET, DT>(q_num, k_num, v, q_den, k_den, W, ldw, block_index, w, B, H, M, S, D, eps, flags, normalize, split, st)));
+        // dG_i = Q_i^T (dO_i / n_i), dn_i
+        StateArgs a{};
+        a.x = cv(q_num); a.y = cv(dout); a.o = cv(out_view); a.idx = block_index; a.W = W; a.ldw = ldw; a.ninv = w.ninv;
+        a.out = w.dg; a.dn = w.dn; a.H = H; a.M = M; a.S = S; a.D = D; a.eps = eps;
+        a.relu = relu; a.normalize = normalize; a.split = split;
+        const int tiles = (M + 63) / 64;
+        TokArgs t{};
+        t.q = cv(q_num); t.k = cv(k_num); t.v = cv(v); t.qd = cv(q_den); t.kd = cv(k_den); t.dout = cv(dout);
+        t.dq = cmv(dq_num); t.dk = cmv(dk_num); t.dv = cmv(dv); t.dqd = cmv(dq_den); t.dkd = cmv(dk_den);
+        t.idx = block_index; t.W = W; t.ldw = ldw; t.g = w.g; t.dkv = w.dkv; t.ninv = w.ninv; t.dz = w.dz; t.ksum = w.ksum;
+        t.dks = w.dks;
+        t.H = H; t.M = M; t.S = S; t.D = D; t.eps = eps; t.relu = relu; t.normalize = normalize; t.split = split;
+        if (sp_shape_ok(D, flags)) {   // split-bf16 MFMA kernels (split.hpp)
+            const long E = (long)D * D;
+            RC(launch(sp::k_sp_state<ET, DT, 1>, dim3(M, B * H), dim3(NTHREADS), sp::sp_state_smem<DT>(), st, "k_sp_state<1>", a));
+            if (normalize)
+                RC(launch(k_wz<1>, dim3((S + 63) / 64, (M + 63) / 64, B * H), dim3(NTHREADS), 0, st, "k_wz<1>", W, ldw, (const float*)w.dn, w.dz, M, S, 0.f));
+            MixArgs m{W, ldw, w.dg, w.dkv, M, E};
+            RC(launch(sp::k_sp_mix<1, sp::Sum16<ET>::value>, dim3((unsigned)((E + sp::SPM_TE - 1) / sp::SPM_TE), tiles, B * H), dim3(NTHREADS), sp::sp_mix_smem<sp::Sum16<ET>::value>(), st, "k_sp_mix<1>", m));
+            int nsplit = dw_splits(tiles * tiles * B * H, E);
+            if (nsplit > DW_MAX_SPLIT - 1) nsplit = DW_MAX_SPLIT - 1;   // one more part per (b, h) holds the <dn_i, z_j> term
+            DwArgs d{w.dg, w.kv, E, nullptr, nullptr, 0, w.dwp, M, tiles, nsplit};
+            if (M <= 16)      RC(launch(sp::k_sp_dw<sp::Sum16<ET>::value, 1>, dim3(1, B * H, nsplit), dim3(NTHREADS), sp::SP_DW_SMEM, st, "k_sp_dw<16>", d));
+            else if (M <= 32) RC(launch(sp::k_sp_dw<sp::Sum16<ET>::value, 2>, dim3(1, B * H, nsplit), dim3(NTHREADS), sp::SP_DW_SMEM, st, "k_sp_dw<32>", d));
+            else              RC(launch(sp::k_sp_dw<sp::Sum16<ET>::value>, dim3(tiles * tiles, B * H, nsplit), dim3(NTHREADS), sp::SP_DW_SMEM, st, "k_sp_dw", d));
+            int nparts = B * H * nsplit;
+            if (normalize) {
+                DwArgs dzz{w.dn, w.z, (long)S, nullptr, nullptr, 0, w.dwp + (size_t)nparts * M * M, M, tiles, 1};
+                RC(launch(k_dw<0>, dim3(tiles * tiles, B * H, 1), dim3(NTHREADS), DW_SMEM_FLOATS * 4, st, "k_dw", dzz));
+                nparts += B * H;
+            }
+            if (M * M <= 1024) RC(launch(k_dw_reduce<0, 16>, dim3((M * M + 15) / 16), dim3(256), 0, st, "k_dw_reduce", (const float*)w.dwp,
+                      (const float*)nullptr, dW, M, M, nparts, B * H));
+            else RC(launch(k_dw_reduce<0>, dim3((M * M + 63) / 64), dim3(256), 0, st, "k_dw_reduce", (const float*)w.dwp,
+                      (const float*)nullptr, dW, M, M, nparts, B * H));
+            RC(launch(sp::k_sp_bwd_dq<ET, DT>, dim3(M, B * H), dim3(NTHREADS), sp::sp_tok_smem<DT, sp::Sum16<ET>::value>(), st, "k_sp_bwd_dq", t));
+            RC(launch(sp::k_sp_bwd_dkv<ET, DT>, dim3(M, B * H), dim3(NTHREADS), sp::sp_tok_smem<DT, sp::Sum16<ET>::value>(), st, "k_sp_bwd_dkv", t));
+            break;
+        }
+        RC(launch(k_bm_state<ET, DT, 1>, dim3(M, B * H), dim3(NTHREADS), state_smem_floats<DT>() * 4, st, "k_bm_state<1>", a));
+        if (normalize)
+            RC(launch(k_wz<1>, dim3((S + 63) / 64, (M + 63) / 64, B * H), dim3(NTHREADS), 0, st, "k_wz<1>", W, ldw, (const float*)w.dn, w.dz, M, S, 0.f));
+        // dKV = W^T dG
+        MixArgs m{W, ldw, w.dg, w.dkv, M, (long)D * D};
+        dim3 mgrid((unsigned)((m.E + MIX_TE - 1) / MIX_TE), (M + MIX_TI - 1) / MIX_TI, B * H);
+        RC(launch(k_mix<1, 0>, mgrid, dim3(NTHREADS), MIX_SMEM_FLOATS * 4, st, "k_mix<1,0>", m));
+        // dW = sum_bh (<dG_i, KV_j> + <dn_i, z_j>)
+        const int nsplit = dw_splits(tiles * tiles * B * H, (long)D * D);
+        DwArgs d{w.dg, w.kv, (long)D * D, normalize ? w.dn : nullptr, normalize ? w.z : nullptr, (long)S, w.dwp, M, tiles, nsplit};
+        RC(launch(k_dw<0>, dim3(tiles * tiles, B * H, nsplit), dim3(NTHREADS), DW_SMEM_FLOATS * 4, st, "k_dw", d));
+        if (M * M <= 1024) RC(launch(k_dw_reduce<0, 16>, dim3((M * M + 15) / 16), dim3(256), 0, st, "k_dw_reduce", (const float*)w.dwp,
+                  (const float*)nullptr, dW, M, M, B * H * nsplit, B * H));
+        else RC(launch(k_dw_reduce<0>, dim3((M * M + 63) / 64), dim3(256), 0, st, "k_dw_reduce", (const float*)w.dwp,
+                  (const float*)nullptr, dW, M, M, B * H * nsplit, B * H));
+        // dQ, dK, dV
+        RC(launch(k_bm_bwd_tok<ET, DT>, dim3(M, B * H), dim3(NTHREADS), tok_smem_floats<DT>() * 4, st, "k_bm_bwd_tok", t));
+    });
+    return MHLA_OK;
+}
+
+}  // namespace capi
+}  // namespace mhla

@@ -1,0 +1,194 @@
+// Shared host-side helpers of the C ABI translation units (capi*.hip): error string, launch wrapper with the per-launch event
+// hook, argument checks, workspace carving, dtype / head-dim dispatch.  The library is built from several translation units
+// compiled in parallel (mhla_amd/build.py); state that must be one per library is an inline variable here.
+#pragma once
+#include "../../include/mhla_hip.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+
+namespace mhla {
+namespace capi {
+
+
+inline thread_local char g_err[512] = "";
+
+inline int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+inline size_t al4(size_t n) { return (n + 3) & ~(size_t)3; }
+
+// Optional per-launch timing (mhla_prof_*): hipEvents recorded on the launch stream around every
+// kernel, so bench.py can report each kernel's average duration live (not only rocprof offline).
+struct ProfRec { const char* name; hipEvent_t e0, e1; };
+inline std::mutex g_prof_mu;
+inline std::atomic<bool> g_prof_on{false};
+inline std::vector<ProfRec> g_prof;
+
+template <typename K>
+int launch(K kernel, dim3 grid, dim3 block, size_t smem, hipStream_t stream, const char* name, auto... args) {
+    if (smem > 48 * 1024) {
+        // opt in to > 48 KB of dynamic LDS once per (kernel, device); the driver call is kept off the steady-state launch path
+        static std::mutex mu;
+        static std::map<std::pair<const void*, int>, size_t> done;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const std::pair<const void*, int> key(reinterpret_cast<const void*>(kernel), dev);
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = done.find(key);
+        if (it == done.end() || it->second < smem) {
+            hipError_t e = hipFuncSetAttribute(key.first, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            if (e != hipSuccess) return fail(MHLA_ELAUNCH, "%s: hipFuncSetAttribute(%zu B LDS): %s", name, smem, hipGetErrorString(e));
+            done[key] = smem;
+        }
+    }
+    ProfRec rec{name, nullptr, nullptr};
+    const bool prof = g_prof_on;
+    if (prof) {
+        (void)hipEventCreate(&rec.e0);
+        (void)hipEventCreate(&rec.e1);
+        (void)hipEventRecord(rec.e0, stream);
+    }
+    hipLaunchKernelGGL(kernel, grid, block, smem, stream, args...);
+    if (prof) {
+        (void)hipEventRecord(rec.e1, stream);
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        g_prof.push_back(rec);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(MHLA_ELAUNCH, "%s: launch failed: %s", name, hipGetErrorString(e));
+    return MHLA_OK;
+}
+
+// debugging aid: per-workgroup phase timestamps of the tile kernels (mhla_debug_set_trace)
+inline std::atomic<unsigned long long*> g_trace{nullptr};
+
+inline View cv(const mhla_view& v) { return View{v.ptr, (long)v.sb, (long)v.sn, (long)v.sh}; }
+inline MView cmv(const mhla_mview& v) { return MView{v.ptr, (long)v.sb, (long)v.sn, (long)v.sh}; }
+
+inline int check_view(const char* name, const void* ptr, int64_t sb, int64_t sn, int64_t sh, int dtype) {
+    if (!ptr) return fail(MHLA_EINVAL, "%s: null pointer", name);
+    const int esz = dtype == MHLA_F32 ? 4 : 2;
+    if (((uintptr_t)ptr) % (4 * esz) != 0) return fail(MHLA_EINVAL, "%s: pointer not %d-byte aligned", name, 4 * esz);
+    if ((sb | sn | sh) & 3) return fail(MHLA_EINVAL, "%s: strides (%lld, %lld, %lld) must be multiples of 4 elements", name,
+                                        (long long)sb, (long long)sn, (long long)sh);
+    return MHLA_OK;
+}
+#define CHECK_VIEW(v) do { int rc_ = check_view(#v, (v).ptr, (v).sb, (v).sn, (v).sh, dtype); if (rc_) return rc_; } while (0)
+#define RC(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
+
+// E-slices of the dW GEMM so that the launch has ~1000+ workgroups (at most 16 slices, slices >= 256 columns)
+constexpr int DW_MAX_SPLIT = 16;
+inline int dw_splits(long wgs, long E) {
+    long ns = (1024 + wgs - 1) / wgs;
+    if (ns > DW_MAX_SPLIT) ns = DW_MAX_SPLIT;
+    while (ns > 1 && E / ns < 256) --ns;
+    return (int)(ns < 1 ? 1 : ns);
+}
+
+inline int dt_for(int D) { return D <= 32 ? 2 : D <= 64 ? 4 : D <= 80 ? 5 : D <= 96 ? 6 : D <= 128 ? 8 : 0; }
+
+// dispatch on (dtype, DT)
+#define DISPATCH_T(dtype, ...)                                                   \
+    switch (dtype) {                                                             \
+        case MHLA_F32: { using ET = float; __VA_ARGS__; break; }                  \
+        case MHLA_BF16: { using ET = bf16_t; __VA_ARGS__; break; }                \
+        case MHLA_F16: { using ET = f16_t; __VA_ARGS__; break; }                  \
+        default: return fail(MHLA_EINVAL, "unknown dtype %d", dtype);            \
+    }
+#define DISPATCH_DT(dt, ...)                                                     \
+    switch (dt) {                                                                \
+        case 2: { constexpr int DT = 2; __VA_ARGS__; break; }                    \
+        case 4: { constexpr int DT = 4; __VA_ARGS__; break; }                    \
+        case 5: { constexpr int DT = 5; __VA_ARGS__; break; }                    \
+        case 6: { constexpr int DT = 6; __VA_ARGS__; break; }                    \
+        case 8: { constexpr int DT = 8; __VA_ARGS__; break; }                    \
+        default: return fail(MHLA_ENOTSUP, "head dim tile %d not supported", dt);\
+    }
+
+struct BmWs {
+    float *kv, *g, *z, *ksum, *ninv, *dg, *dkv, *dn, *dz, *dks, *dwp;
+    size_t total_fwd, total_bwd;
+};
+// sum16: the D x D block summaries (KV, G, dG, dKV) are stored as bf16 (split-operand path on bf16 tensors): half the floats
+inline BmWs bm_carve(void* ws, int B, int H, int M, int S, int D, bool sum16) {
+    const size_t bh = (size_t)B * H, st = al4(sum16 ? (bh * M * D * D + 1) / 2 : bh * M * D * D), zs = al4(bh * M * S), ks = al4(bh * M * D);
+    float* p = (float*)ws;
+    BmWs w;
+    w.kv = p; p += st;
+    w.g = p; p += st;
+    w.z = p; p += zs;
+    w.ksum = p; p += ks;
+    w.ninv = p; p += zs;
+    w.total_fwd = (size_t)(p - (float*)ws) * 4;
+    w.dg = p; p += st;
+    w.dkv = p; p += st;
+    w.dn = p; p += zs;
+    w.dz = p; p += zs;
+    w.dks = p; p += ks;
+    w.dwp = p; p += al4(bh * M * M * DW_MAX_SPLIT);
+    w.total_bwd = (size_t)(p - (float*)ws) * 4;
+    return w;
+}
+
+inline bool view_ok16(const mhla_view& v) { return v.ptr && ((uintptr_t)v.ptr % 16) == 0 && ((v.sb | v.sn | v.sh) & 7) == 0; }
+// split-bf16 MFMA kernels (split.hpp): head dims that are multiples of 8, any dtype
+inline bool sp_shape_ok(int D, unsigned flags) { return (D & 7) == 0 && !(flags & MHLA_FLAG_FORCE_GENERIC); }
+inline bool view_ok16m(const mhla_mview& v) { return v.ptr && ((uintptr_t)v.ptr % 16) == 0 && ((v.sb | v.sn | v.sh) & 7) == 0; }
+// bf16-MFMA token kernels of the causal operator (causal_bf16.hpp)
+// MHLA_CAUSAL_GENERIC is a testing aid that the parity tests flip inside one process (bf16 pipeline vs generic kernels on the
+// same inputs), so it is looked up per call: one scan of the environment per operator call, beside five or more launches
+inline bool cs_bf16_ok(int K, int V, int dtype) { return dtype == MHLA_BF16 && (K & 63) == 0 && (V & 63) == 0 && !getenv("MHLA_CAUSAL_GENERIC"); }
+inline bool bm_sum16(int D, int dtype, unsigned flags) { return dtype == MHLA_BF16 && sp_shape_ok(D, flags); }
+inline bool fast_shape_ok(int M, int D, int dtype, bool split) { return dtype == MHLA_BF16 && D == 64 && M <= 64 && !split; }
+// small-sequence single-launch path (smalln.hpp): S = 16 tokens per block, at most 16 blocks, D <= 80
+inline bool sn_shape_ok(int M, int S, int D, int dtype, bool split) {
+    return dtype == MHLA_BF16 && S == 16 && M <= 16 && D <= 80 && (D & 7) == 0 && !split;
+}
+
+inline int bm_check(int B, int H, int M, int S, int D, int dtype, unsigned flags, bool normalize, bool split) {
+    if (B <= 0 || H <= 0 || M <= 0 || S <= 0 || D <= 0) return fail(MHLA_EINVAL, "non-positive dimension B=%d H=%d M=%d S=%d D=%d", B, H, M, S, D);
+    if (D % 4) return fail(MHLA_EINVAL, "D=%d must be a multiple of 4", D);
+    if (!dt_for(D)) return fail(MHLA_ENOTSUP, "block-mix head dim D=%d > 128 not supported", D);
+    if (dtype < 0 || dtype > 2) return fail(MHLA_EINVAL, "unknown dtype %d", dtype);
+    if (flags & ~(MHLA_FLAG_RELU_EPS | MHLA_FLAG_FORCE_GENERIC | MHLA_FLAG_NO_SMALLN)) return fail(MHLA_EINVAL, "unknown flags 0x%x", flags);
+    if ((flags & MHLA_FLAG_RELU_EPS) && split) return fail(MHLA_EINVAL, "MHLA_FLAG_RELU_EPS needs q_den/k_den to alias q_num/k_num");
+    if ((size_t)B * H > 65535) return fail(MHLA_ENOTSUP, "B*H=%zu exceeds grid limit 65535", (size_t)B * H);
+    (void)normalize;
+    return MHLA_OK;
+}
+
+// One call of the generic / split-operand block-mix path, handed from capi.hip to the per-dtype translation units
+// (capi_bm_f32.hip, capi_bm_bf16.hip, capi_bm_f16.hip instantiate bm_fwd_typed / bm_bwd_typed for their element type).
+struct BmCall {
+    mhla_view q_num, k_num, v, q_den, k_den, outv, dout, gate;
+    mhla_mview out, dq_num, dk_num, dv, dq_den, dk_den;
+    const float* W; int ldw; float* dW;
+    const int32_t* block_index;
+    BmWs w;
+    int B, H, M, S, D; float eps; unsigned flags;
+    bool normalize, split, reuse, epi;
+    hipStream_t st;
+    const float *rcos, *rsin; long ldr;
+    const float* nw; float neps; int out_dtype;
+};
+template <typename ET> int bm_fwd_typed(const BmCall& c);
+template <typename ET> int bm_bwd_typed(const BmCall& c);
+
+}  // namespace capi
+}  // namespace mhla

@@ -765,7 +765,7 @@ constexpr int DW_SPLIT = 8;                      // e' splits per (b,h)
 constexpr int DW_LDI = 72;
 constexpr int FS_DW_SMEM = 2 * DW_EC * DW_LDI * 2;   // 36864 >= WZ_SMEM
 
-__global__ __launch_bounds__(FT8) void k_fs_dw(const FsDwArgs a) {
+inline __global__ __launch_bounds__(FT8) void k_fs_dw(const FsDwArgs a) {   // (inline: fused.hpp is part of several translation units)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u16* Ai = reinterpret_cast<u16*>(smem_raw);   // dG image [256 e'][72]
     u16* Bi = Ai + DW_EC * DW_LDI;                // KV image

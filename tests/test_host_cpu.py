@@ -21,7 +21,8 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/mhla_hip.h but not exported"
-    assert lib.mhla_abi_version() == _lib.ABI_VERSION == 5
+    assert lib.mhla_abi_version() == _lib.ABI_VERSION == 6
+    assert b"no-packed-fp32" in lib.mhla_build_flags()
     # workspace sizing is pure host arithmetic: callable without a GPU
     fwd = lib.mhla_blockmix_fwd_ws_bytes(8, 16, 64, 64, 64, 0, 0, 0)
     bwd = lib.mhla_blockmix_bwd_ws_bytes(8, 16, 64, 64, 64, 0, 0, 0)
