@@ -159,6 +159,15 @@ int mhla_blockmix_bwd(mhla_view q_num, mhla_view k_num, mhla_view v,
                       int B, int H, int M, int S, int D,
                       int dtype, float eps, unsigned flags, void* stream);
 
+/* Status of the last mhla_blockmix_bwd that used `ws` (same problem arguments).  The bf16 fast path hands a tile's dksum rows
+ * from its dQ workgroup to its dK/dV workgroup inside one launch through a flag; the wait for that flag is bounded, and a
+ * waiter that gives up raises an error word in the workspace.  This call synchronises `stream`, reads the word and returns
+ * MHLA_ELAUNCH if it is set (dk is then invalid), MHLA_OK otherwise -- also for problems that take another path.
+ * Replaces nothing in the reference (mhla_dit/mhla/mhla.py:262-268 is a sequence of separate kernels); it is the fail-safe
+ * of this library's own fusion.  MHLA_BWD_TWO_LAUNCHES=1 in the environment runs the two roles as two launches instead. */
+int mhla_blockmix_bwd_status(const void* ws, size_t ws_bytes, int B, int H, int M, int S, int D, int dtype, int split,
+                             unsigned flags, void* stream);
+
 /* ---- causal chunk-mixing MHLA: fla ------------------------------------- */
 
 /* Workspace bytes (the chunk summaries are bf16 for bf16 tensors with K and V multiples of 64, fp32 otherwise). */

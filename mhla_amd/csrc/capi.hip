@@ -39,8 +39,9 @@ struct FastWs {
     fast::u16 *state, *dstate;
     float *z, *ksum, *ninv, *dn, *dz, *dwp, *dksum;
     int* done;   // per 16-block tile: dQ done (k_tile_bwd)
+    int* err;    // error word of the token-gradient launch (a hand-over flag that did not arrive)
     size_t total_fwd, total_bwd;
-    int njg;
+    int njg, ntt;
 };
 FastWs fast_carve(void* ws, int B, int H, int M, int S) {
     const size_t bh = (size_t)B * H;
@@ -58,7 +59,9 @@ FastWs fast_carve(void* ws, int B, int H, int M, int S) {
     w.dz = (float*)p; p += al4(bh * M * S) * 4;
     w.dksum = (float*)p; p += al4(bh * M * 64) * 4;
     w.dwp = (float*)p; p += bh * fast::DW_SPLIT * 4096 * 4;
-    w.done = (int*)p; p += al4(bh * ((w.njg + 1) / 2)) * 4;
+    w.ntt = fast::tiles_per_bh(w.njg, 16);
+    w.done = (int*)p; p += al4(bh * w.ntt + 1) * 4;   // per-tile flags + the launch's error word
+    w.err = w.done + bh * w.ntt;
     w.total_bwd = (size_t)(p - (char*)ws);
     return w;
 }
@@ -183,7 +186,7 @@ static int bm_fwd_impl(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view 
         oa.q = cv(q_num); oa.o = cmv(out); oa.idx = block_index; oa.W = W; oa.ldw = ldw; oa.state = f.state; oa.ninv = f.ninv;
         oa.H = H; oa.M = M; oa.S = S; oa.njg = f.njg; oa.eps = eps; oa.relu = relu; oa.normalize = normalize;
         oa.trace = g_trace.load();
-        RC(launch(fast::k_tile_out<16>, dim3(((f.njg + 1) / 2) * B * H), dim3(fast::FT8), fast::tile_smem<16>(), st, "k_t16_out", oa));
+        RC(launch(fast::k_tile_out<16>, dim3(fast::tiles_per_bh(f.njg, 16) * B * H), dim3(fast::FT8), fast::tile_smem<16>(), st, "k_t16_out", oa));
         return MHLA_OK;
     }
     const BmWs w = bm_carve(ws, B, H, M, S, D, bm_sum16(D, dtype, flags));
@@ -301,20 +304,29 @@ int mhla_blockmix_bwd(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q
             else RC(launch(fast::k_fs_state<1>, dim3(f.njg, B * H), dim3(fast::FT8), fast::FS_STATE_SMEM, st, "k_fs_state<1>", ga));
             // dW needs only dG^T, KV^T, dn and z, all complete here; dz = W^T dn (needed by the token-gradient kernels) rides in
             // the same launch as extra workgroups
-            fast::FsDwArgs da{f.dstate, state, normalize ? f.dn : nullptr, z, f.dwp, M, S, f.njg, W, ldw, f.dz, f.done, (f.njg + 1) / 2};
+            fast::FsDwArgs da{f.dstate, state, normalize ? f.dn : nullptr, z, f.dwp, M, S, f.njg, W, ldw, f.dz, f.done, f.ntt};
             hipStream_t sd = st;
             const int nwz = normalize ? (S + fast::WZ_C - 1) / fast::WZ_C : 0;
-            RC(launch(fast::k_fs_dw, dim3(fast::DW_SPLIT + nwz, B * H), dim3(fast::FT8), fast::FS_DW_SMEM, sd, "k_fs_dw", da));
+            RC(launch(fast::k_fs_dw<>, dim3(fast::DW_SPLIT + nwz, B * H), dim3(fast::FT8), fast::FS_DW_SMEM, sd, "k_fs_dw", da));
             fast::FsTokArgs ta{};
             ta.q = cv(q_num); ta.k = cv(k_num); ta.v = cv(v); ta.dout = cv(dout); ta.dq = cmv(dq_num); ta.dk = cmv(dk_num);
             ta.dv = cmv(dv); ta.idx = block_index; ta.W = W; ta.ldw = ldw; ta.state = state; ta.dstate = f.dstate; ta.ninv = ninv;
             ta.dz = f.dz; ta.ksum = ksum; ta.H = H; ta.M = M; ta.S = S; ta.njg = f.njg; ta.eps = eps; ta.relu = relu;
             ta.normalize = normalize;
             ta.dksum = f.dksum;
-            const long ntile_wgs = (long)((f.njg + 1) / 2) * B * H;
+            const long ntile_wgs = (long)f.ntt * B * H;
             unsigned long long* tr = g_trace.load();   // regions: [0] k_t16_out, [1] dQ role, [2] dK/dV role (record = ntiles + blockIdx.x)
             ta.trace = tr ? tr + ntile_wgs * fast::TRACE_SLOTS : nullptr;
             ta.dwp = f.dwp; ta.dW = dW; ta.nparts = B * H * fast::DW_SPLIT; ta.ntiles = (int)ntile_wgs; ta.done = f.done;
+            ta.err = f.err;
+            ta.drop_signal = getenv("MHLA_DEBUG_DROP_SIGNAL") != nullptr;   // testing aid for the bounded wait (looked up per call)
+            const char* const two = getenv("MHLA_BWD_TWO_LAUNCHES");   // fallback (looked up per call): dQ tiles and dK/dV tiles as two launches
+            if (two && two[0] == '1') {   // (the kernel boundary orders dksum and the flags: the wait returns at its first poll)
+                RC(launch(fast::k_tile_bwd<16>, dim3((unsigned)ntile_wgs), dim3(fast::FT8), fast::tile_smem<16>(), st, "k_t16_bwd_dq", ta));
+                ta.x0 = (int)ntile_wgs;
+                RC(launch(fast::k_tile_bwd<16>, dim3((unsigned)ntile_wgs + fast::DWR_WGS), dim3(fast::FT8), fast::tile_smem<16>(), st, "k_t16_bwd_dkv", ta));
+                return MHLA_OK;
+            }
             RC(launch(fast::k_tile_bwd<16>, dim3((unsigned)(2 * ntile_wgs) + fast::DWR_WGS), dim3(fast::FT8), fast::tile_smem<16>(), st, "k_t16_bwd", ta));
             return MHLA_OK;
         }
@@ -339,6 +351,26 @@ int mhla_blockmix_bwd(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q
         case MHLA_F16: return bm_bwd_typed<f16_t>(c);
         default: return fail(MHLA_EINVAL, "unknown dtype %d", dtype);
     }
+}
+
+// Did the last mhla_blockmix_bwd on this workspace run into a hand-over flag that never arrived (fused.hpp, tile_wait)?
+// Synchronises `stream`, reads the launch's error word.  MHLA_OK also for problems that do not take the in-launch hand-over.
+int mhla_blockmix_bwd_status(const void* ws, size_t ws_bytes, int B, int H, int M, int S, int D, int dtype, int split, unsigned flags,
+                             void* stream) {
+    if (!ws) return fail(MHLA_EINVAL, "workspace null");
+    if (!fast_shape_ok(M, D, dtype, split != 0) || (flags & MHLA_FLAG_FORCE_GENERIC) ||
+        (sn_shape_ok(M, S, D, dtype, split != 0) && !(flags & MHLA_FLAG_NO_SMALLN)))
+        return MHLA_OK;
+    const FastWs f = fast_carve(const_cast<void*>(ws), B, H, M, S);
+    if (ws_bytes < f.total_bwd) return fail(MHLA_EINVAL, "workspace too small: %zu < %zu bytes", ws_bytes, f.total_bwd);
+    int word = 0;
+    hipError_t e = hipMemcpyAsync(&word, f.err, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) return fail(MHLA_ELAUNCH, "mhla_blockmix_bwd_status: %s", hipGetErrorString(e));
+    if (word != 0)
+        return fail(MHLA_ELAUNCH, "k_t16_bwd: a dK/dV tile gave up waiting for its dQ tile's dksum rows (hand-over flag never raised); "
+                                  "dk is invalid -- set MHLA_BWD_TWO_LAUNCHES=1 to run the two roles as separate launches");
+    return MHLA_OK;
 }
 
 }  // extern "C"

@@ -765,7 +765,8 @@ constexpr int DW_SPLIT = 8;                      // e' splits per (b,h)
 constexpr int DW_LDI = 72;
 constexpr int FS_DW_SMEM = 2 * DW_EC * DW_LDI * 2;   // 36864 >= WZ_SMEM
 
-inline __global__ __launch_bounds__(FT8) void k_fs_dw(const FsDwArgs a) {   // (inline: fused.hpp is part of several translation units)
+template <int UNIT = 0>   // (a template only so that fused.hpp can be part of several translation units)
+__global__ __launch_bounds__(FT8) void k_fs_dw(const FsDwArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u16* Ai = reinterpret_cast<u16*>(smem_raw);   // dG image [256 e'][72]
     u16* Bi = Ai + DW_EC * DW_LDI;                // KV image
@@ -773,6 +774,7 @@ inline __global__ __launch_bounds__(FT8) void k_fs_dw(const FsDwArgs a) {   // (
     const int wi = wave & 3, wj = wave >> 2;   // wave -> rows i = 16 wi .., columns j = 32 wj ..
     const int qtr = blockIdx.x, bh = blockIdx.y, njg = a.njg;
     if (qtr == 0 && a.done && tid < a.ntt) a.done[bh * a.ntt + tid] = 0;
+    if (qtr == 0 && bh == 0 && a.done && tid == 0) a.done[(long)gridDim.y * a.ntt] = 0;   // the launch's error word follows the flags
     if (qtr >= DW_SPLIT) {   // workgroup-uniform role switch
         wz_body<1, FT8>(reinterpret_cast<float*>(smem_raw), a.W, a.ldw, a.dn, a.dz, a.M, a.S, 0.f, qtr - DW_SPLIT, bh, tid);
         return;
@@ -921,6 +923,9 @@ struct FsTokArgs {
     float* dW;
     int nparts, ntiles;
     int* done;          // [ntiles]: set by a tile's dQ workgroup once its dksum rows are written, awaited by its dK/dV workgroup
+    int* err;           // error word of the launch: raised by a dK/dV workgroup whose flag did not arrive (tile_wait)
+    int x0;             // role offset added to blockIdx.x (0: one launch for all roles; ntiles: the second of two launches)
+    int drop_signal;    // testing aid (MHLA_DEBUG_DROP_SIGNAL=1): the dQ role does not raise its flag
     unsigned long long* trace;
 };
 // Hand-over of a tile's dksum rows between two workgroups of one launch (the waiting one has the higher blockIdx: it is dispatched
@@ -937,12 +942,27 @@ __device__ __forceinline__ void tile_signal(int* flag, int tid) {
     __syncthreads();
     if (tid == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void tile_wait(int* flag, int tid) {
+// The wait is bounded: a flag that never arrives (a dispatch order other than the one this protocol relies on, a wrong flag index)
+// must not hang the GPU.  After TILE_WAIT_POLLS polls (~1 us each: a second or more, against tile lifetimes of ~30 us) the waiter
+// raises the launch's error word and goes on with whatever dksum holds; the host reads the word through mhla_blockmix_bwd_status
+// and reports MHLA_ELAUNCH -- an error code instead of a wedged device.
+constexpr int TILE_WAIT_POLLS = 1 << 20;
+__device__ __forceinline__ void tile_wait(int* flag, int* err, int tid) {
     if (tid == 0) {
-        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(16);
+        int polls = 0;
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+            if (++polls > TILE_WAIT_POLLS) {
+                __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(16);
+        }
     }
     __syncthreads();
 }
+// 16-block (TTP) tiles per (b,h) for njg groups of 8 blocks: the one place the flag array, the flag clearing and the tile
+// launches take their count from
+__host__ __device__ constexpr int tiles_per_bh(int njg, int ttp) { return (njg * IT + ttp - 1) / ttp; }
 constexpr int FS_TOK_SMEM = FS_GT_BYTES;
 
 }  // namespace fast

@@ -476,7 +476,7 @@ __device__ __forceinline__ void tile_bwd_dq_body(const FsTokArgs& a, unsigned ch
         }
         trace_mark(a.trace, 5);
         if (a.trace) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); trace_mark(a.trace, 6); }
-        if (a.normalize) tile_signal(a.done + L, tid);   // this tile's dksum rows are written
+        if (a.normalize && !a.drop_signal) tile_signal(a.done + L, tid);   // this tile's dksum rows are written
         return;
     }
     mix_tile_to_lds<TTP, 0, NBUF>(Gt, a.state + sofs, a.njg, a.W, a.ldw, M, jgx * TTP, tid);
@@ -506,7 +506,7 @@ __device__ __forceinline__ void tile_bwd_dq_body(const FsTokArgs& a, unsigned ch
         }
         if (a.normalize) finish_dks(dks_acc, j);
     }
-    if (a.normalize) tile_signal(a.done + L, tid);
+    if (a.normalize && !a.drop_signal) tile_signal(a.done + L, tid);
 }
 
 // dK / dV role of k_tile_bwd: workgroup wg of nwg.  The only thing it needs from the dQ role is the tile's dksum rows (awaited just
@@ -581,7 +581,7 @@ __device__ __forceinline__ void tile_bwd_dkv_body(const FsTokArgs& a, unsigned c
         mix_tile_to_lds<TTP, 1, NBUF>(Gt, a.dstate + sofs, a.njg, a.W, a.ldw, M, jgx * TTP, tid);
         if (TTP == 8) load_a64(vvA, vb, a.v.sn, a.idx, (long)jAc * S, S, lane);
         if (a.normalize) {
-            tile_wait(a.done + L, tid);
+            tile_wait(a.done + L, a.err, tid);
             side_issue<TTP, true>(sk, a.dksum + (long)bh * M * 64, 64, 64, jgx * TTP, M, tid);
             side_commit<TTP>(sideK, sk, 64, tid);
         }
@@ -604,7 +604,7 @@ __device__ __forceinline__ void tile_bwd_dkv_body(const FsTokArgs& a, unsigned c
         return;
     }
     mix_tile_to_lds<TTP, 1, NBUF>(Gt, a.dstate + sofs, a.njg, a.W, a.ldw, M, jgx * TTP, tid);
-    if (a.normalize) tile_wait(a.done + L, tid);
+    if (a.normalize) tile_wait(a.done + L, a.err, tid);
     __syncthreads();
     for (int bi = wave; bi < TTP; bi += 8) {
         const int j = jgx * TTP + bi;
@@ -627,7 +627,8 @@ __device__ __forceinline__ void tile_bwd_dkv_body(const FsTokArgs& a, unsigned c
 template <int TTP>
 __global__ __launch_bounds__(FT8, TTP == 16 ? 2 : 4) void k_tile_bwd(const FsTokArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int x = blockIdx.x;
+    static_assert(TTP == 16, "the flag array and the role ranges are sized for 16-block tiles (tiles_per_bh(njg, 16))");
+    const int x = blockIdx.x + a.x0;
     if (x < a.ntiles) tile_bwd_dq_body<TTP>(a, smem_raw, x, a.ntiles);
     else if (x < 2 * a.ntiles) tile_bwd_dkv_body<TTP>(a, smem_raw, x - a.ntiles, a.ntiles);
     else dw_reduce_body(reinterpret_cast<float*>(smem_raw), a.dwp, a.dW, a.M, a.nparts, x - 2 * a.ntiles, threadIdx.x);

@@ -7,6 +7,7 @@ a ROCm device and the library must be built, otherwise these functions raise.
 from __future__ import annotations
 
 import functools
+import os
 from typing import Optional
 
 import torch
@@ -118,6 +119,15 @@ def _ws(nbytes: int, device) -> torch.Tensor:
 # ------------------------------------------------------------------------------------------
 # block-mixing MHLA (DiT / ViT / Wan)
 # ------------------------------------------------------------------------------------------
+def _check_handover(lib, ws, B, H, M, S, D, dt, split, flags):
+    """MHLA_CHECK_HANDOVER=1: after every block-mix backward, synchronise and ask the library whether a dK/dV tile of the fused
+    token-gradient launch gave up waiting for its dQ tile (`mhla_blockmix_bwd_status`); raises instead of returning an invalid
+    dk.  Off by default: the check is a device synchronisation (not allowed while a HIP graph is being captured)."""
+    if os.environ.get("MHLA_CHECK_HANDOVER") == "1":
+        rc = lib.mhla_blockmix_bwd_status(ws.data_ptr(), ws.numel() * 4, B, H, M, S, D, dt, split, flags, _stream())
+        _lib.check(rc, "mhla_blockmix_bwd_status")
+
+
 class _BlockMix(torch.autograd.Function):
     @staticmethod
     @_device_guard
@@ -195,6 +205,7 @@ class _BlockMix(torch.autograd.Function):
                                    fwd_ws.data_ptr() if fwd_ws is not None else None, B, H, M, S, D,
                                    dt, eps, flags, _stream())
         _lib.check(rc, "mhla_blockmix_bwd")
+        _check_handover(lib, ws, B, H, M, S, D, dt, int(split), flags)
         return dq, dk, dv, dW.reshape(w_shape).to(w_dtype), dqd, dkd, None, None, None, None, None, None
 
 
@@ -513,6 +524,7 @@ class _DitCore(torch.autograd.Function):
                                    dW.data_ptr(), None, ws.data_ptr(), ws.numel() * 4,
                                    fwd_ws.data_ptr() if fwd_ws is not None else None, B, H, M, S, D, dt, eps, flags, _stream())
         _lib.check(rc, "mhla_blockmix_bwd")
+        _check_handover(lib, ws, B, H, M, S, D, dt, 0, flags)
         # dv = operator part + LePE part (flipped-kernel correlation of dy), written into the V slice of the packed gradient
         dv3 = dqkv[:, :, 2].reshape(B, N, C)
         rc = lib.mhla_lepe2d(dy.data_ptr(), N * C, C, w_taps.data_ptr(), None, dv_attn.data_ptr(), N * C, C,

@@ -538,31 +538,67 @@ def test_repetitions_bit_identical_alone_and_beside_a_second_stream():
 
 
 @pytest.mark.parametrize("B,H,M,S", [(1, 1, 3, 5), (1, 3, 17, 33), (2, 16, 33, 64), (8, 16, 64, 64), (33, 7, 16, 16), (2, 16, 16, 256)])
-def test_token_gradient_launch_handover_on_two_streams(B, H, M, S):
+def test_token_gradient_launch_handover_on_two_streams(B, H, M, S, monkeypatch):
     """The backward's token gradients are one launch in which a tile's dK/dV workgroup waits for the flag of its dQ workgroup
-    (DESIGN.md 3b).  Shapes with partly empty tiles, one tile per (b,h), few and many (b,h) pairs, multi-chunk blocks: three
-    repetitions each with a second instance of the operator on another stream, all bit-identical and finite (a lost hand-over
-    would hang -- the suite's timeout -- or read stale dksum rows; tools/stress_fast_path.py is the long version)."""
+    (DESIGN.md 3b).  Shapes with partly empty tiles, one tile per (b,h), few and many (b,h) pairs, multi-chunk blocks.  Every
+    repetition has its OWN inputs (a waiter that passed early would otherwise read the previous repetition's identical dksum
+    rows out of the recycled workspace and go unnoticed) and its own reference: the same backward with the two roles as two
+    launches (MHLA_BWD_TWO_LAUNCHES=1, the kernel boundary orders the hand-over), alone on the device.  The fused launch then
+    runs beside a second instance of the operator on another stream, must be bit-identical to the reference, and the
+    library's status call must report no expired wait (tools/stress_fast_path.py is the long version)."""
     import mhla_amd
+    from gpu_util import poison
     g = torch.Generator(device=DEV).manual_seed(B * 1000 + M)
+    mk = lambda: torch.randn(B, M * S, H, 64, device=DEV, dtype=torch.bfloat16, generator=g).abs_().add_(1e-3)
+    side = torch.cuda.Stream()
+    for rep in range(3):
+        q, k, v, do = mk(), mk(), mk(), mk()
+        W = torch.rand(M, M, device=DEV, generator=g).add_(0.1)
+
+        def run(beside):
+            if beside:
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    t2 = [x.flip(0).clone().requires_grad_(True) for x in (q, k, v)]
+                    mhla_amd.mhla_blockmix(*t2, W).backward(do)
+            ts = [x.clone().requires_grad_(True) for x in (q, k, v, W)]
+            out = mhla_amd.mhla_blockmix(*ts)
+            out.backward(do)
+            torch.cuda.synchronize()
+            return [out.detach()] + [x.grad for x in ts]
+
+        monkeypatch.setenv("MHLA_BWD_TWO_LAUNCHES", "1")
+        ref = run(False)
+        monkeypatch.delenv("MHLA_BWD_TWO_LAUNCHES")
+        poison()   # the workspace blocks the reference used come back NaN-filled
+        monkeypatch.setenv("MHLA_CHECK_HANDOVER", "1")
+        res = run(True)
+        monkeypatch.delenv("MHLA_CHECK_HANDOVER")
+        assert all(bool(torch.isfinite(r.float()).all()) for r in res)
+        for name, a_, b_ in zip(["out", "dq", "dk", "dv", "dW"], ref, res):
+            assert torch.equal(a_, b_), f"repetition {rep}: {name} of the fused launch differs from the two-launch reference"
+
+
+def test_handover_wait_is_bounded_and_reported(monkeypatch):
+    """A flag that never arrives must end as an error code, not as a hung GPU: with the dQ role's signal suppressed
+    (MHLA_DEBUG_DROP_SIGNAL=1, a testing aid of the library) the backward still returns, and mhla_blockmix_bwd_status --
+    here through MHLA_CHECK_HANDOVER=1 in the autograd function -- reports the expired wait."""
+    import mhla_amd
+    g = torch.Generator(device=DEV).manual_seed(7)
+    B, H, M, S = 1, 2, 16, 64
     mk = lambda: torch.randn(B, M * S, H, 64, device=DEV, dtype=torch.bfloat16, generator=g).abs_().add_(1e-3)
     q, k, v, do = mk(), mk(), mk(), mk()
     W = torch.rand(M, M, device=DEV, generator=g).add_(0.1)
-    side = torch.cuda.Stream()
-    ref = None
-    for rep in range(3):
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            t2 = [x.flip(0).clone().requires_grad_(True) for x in (q, k, v)]
-            mhla_amd.mhla_blockmix(*t2, W).backward(do)
-        ts = [x.clone().requires_grad_(True) for x in (q, k, v, W)]
-        out = mhla_amd.mhla_blockmix(*ts)
+    ts = [x.clone().requires_grad_(True) for x in (q, k, v, W)]
+    out = mhla_amd.mhla_blockmix(*ts)
+    monkeypatch.setenv("MHLA_DEBUG_DROP_SIGNAL", "1")
+    monkeypatch.setenv("MHLA_CHECK_HANDOVER", "1")
+    with pytest.raises(RuntimeError, match="gave up waiting"):
         out.backward(do)
-        torch.cuda.synchronize()
-        res = [out.detach()] + [x.grad for x in ts]
-        assert all(bool(torch.isfinite(r.float()).all()) for r in res)
-        if ref is None:
-            ref = [r.clone() for r in res]
-        else:
-            for name, a_, b_ in zip(["out", "dq", "dk", "dv", "dW"], ref, res):
-                assert torch.equal(a_, b_), f"repetition {rep}: {name} differs"
+    torch.cuda.synchronize()
+    monkeypatch.delenv("MHLA_DEBUG_DROP_SIGNAL")
+    # the next call on the same shapes is clean again (the error word is cleared per launch)
+    ts = [x.clone().requires_grad_(True) for x in (q, k, v, W)]
+    mhla_amd.mhla_blockmix(*ts).backward(do)
+    torch.cuda.synchronize()
+    assert all(bool(torch.isfinite(x.grad.float()).all()) for x in ts)

@@ -1,7 +1,8 @@
 """Stress of the bf16 fast path's in-launch hand-over (k_t16_bwd: a tile's dK/dV workgroup waits for its dQ workgroup's flag):
 many shapes -- tiles that are partly empty, a single tile per (b,h), few and many (b,h) pairs -- each run REPS times on two
-streams at once, every result compared bit for bit with the first repetition.  A hang would show as the per-call timeout of the
-caller (run under `timeout`); exits non-zero on any mismatch.
+streams at once.  Every repetition has fresh inputs and its own reference (the same backward as two launches,
+MHLA_BWD_TWO_LAUNCHES=1, alone on the device): a waiter that passed early cannot hide behind identical recycled workspace
+contents.  The library's status call is made after every backward (MHLA_CHECK_HANDOVER=1).  Exits non-zero on any mismatch.
   timeout 300 python tools/stress_fast_path.py"""
 import itertools
 import os
@@ -28,25 +29,34 @@ for B, H, M, S in cases:
         t = torch.randn(B, N, H, 64, device=DEV, dtype=torch.bfloat16, generator=gen)
         return t.relu_().add_(1e-3) if relu else t
 
-    q, k, v, do = mk(True), mk(True), mk(False), mk(False)
-    W = torch.rand(M, M, device=DEV, generator=gen).add_(0.1)
-    ref = None
     for rep in range(REPS):
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):   # a second instance, other data, concurrently
-            t2 = [x.flip(0).clone().requires_grad_(True) for x in (q, k, v)]
-            mhla_amd.mhla_blockmix(*t2, W).backward(do)
-        ts = [x.clone().requires_grad_(True) for x in (q, k, v)]
-        Wg = W.clone().requires_grad_(True)
-        out = mhla_amd.mhla_blockmix(*ts, Wg)
-        out.backward(do)
-        torch.cuda.synchronize()
-        res = [out.detach(), ts[0].grad, ts[1].grad, ts[2].grad, Wg.grad]
+        q, k, v, do = mk(True), mk(True), mk(False), mk(False)
+        W = torch.rand(M, M, device=DEV, generator=gen).add_(0.1)
+
+        def run(beside):
+            if beside:
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):   # a second instance, other data, concurrently
+                    t2 = [x.flip(0).clone().requires_grad_(True) for x in (q, k, v)]
+                    mhla_amd.mhla_blockmix(*t2, W).backward(do)
+            ts = [x.clone().requires_grad_(True) for x in (q, k, v)]
+            Wg = W.clone().requires_grad_(True)
+            out = mhla_amd.mhla_blockmix(*ts, Wg)
+            out.backward(do)
+            torch.cuda.synchronize()
+            return [out.detach(), ts[0].grad, ts[1].grad, ts[2].grad, Wg.grad]
+
+        os.environ["MHLA_BWD_TWO_LAUNCHES"] = "1"
+        ref = run(False)
+        del os.environ["MHLA_BWD_TWO_LAUNCHES"]
+        junk = torch.full((1 << 26,), float("nan"), device=DEV)   # recycled workspace blocks come back as NaN
+        del junk
+        os.environ["MHLA_CHECK_HANDOVER"] = "1"
+        res = run(True)
+        del os.environ["MHLA_CHECK_HANDOVER"]
         if not all(bool(torch.isfinite(r.float()).all()) for r in res):
             print("non-finite result", (B, H, M, S)); bad += 1
-        if ref is None:
-            ref = [r.clone() for r in res]
-        elif not all(bool(torch.equal(a, b)) for a, b in zip(ref, res)):
+        if not all(bool(torch.equal(a, b)) for a, b in zip(ref, res)):
             print("MISMATCH", (B, H, M, S), "rep", rep); bad += 1
     print("ok" if bad == 0 else "..", (B, H, M, S), flush=True)
 print("stress:", "all repetitions identical" if bad == 0 else f"{bad} problems")
