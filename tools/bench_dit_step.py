@@ -20,36 +20,28 @@ from mhla_amd import dist as mdist  # noqa: E402
 from mhla_amd.hosts import DiT_MHLA, DiT_configs  # noqa: E402
 
 
-def main():
-    p = argparse.ArgumentParser()
-    p.add_argument("--model", default="DiT-XL/2", choices=sorted(DiT_configs()))
-    p.add_argument("--batch", type=int, default=32, help="per-GPU batch")
-    p.add_argument("--image", type=int, default=256, help="image side in pixels (latent side = image / 8)")
-    p.add_argument("--steps", type=int, default=10)
-    p.add_argument("--warmup", type=int, default=3)
-    p.add_argument("--gpus", type=int, default=1, help="ranks to start when not launched by torch.distributed.run")
-    a = p.parse_args()
-    if a.gpus > 1 and not mdist.launched_by_rendezvous():   # parent: start the ranks before any GPU call, relay the status
-        extra = {"MHLA_DIST_BACKEND": "gloo"} if torch.cuda.device_count() < a.gpus else {}
-        sys.exit(mdist.spawn_local_ranks(a.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:], extra))
-    rank, local, world = mdist.init_from_env()
-    local %= torch.cuda.device_count()
-    torch.cuda.set_device(local)
+def run_dit_step(rank, local, world, model_name="DiT-XL/2", batch=32, image=256, steps=10, warmup=3, bucket_cap_mb=25):
+    """Training steps of the thin DiT host on this rank's GPU; with world > 1 the model is wrapped in DistributedDataParallel
+    (the default process group must exist): bucketed RCCL all-reduce of the fp32 gradients (2.7 GB at DiT-XL/2), overlapped
+    with the backward by DDP's reducer.  Returns the result dict on every rank (max-over-ranks time)."""
     dev = torch.device("cuda", local)
     torch.manual_seed(1234 + rank)
-    latent = a.image // 8
-    model = DiT_MHLA(input_size=latent, **DiT_configs()[a.model]).to(dev)
+    latent = image // 8
+    model = DiT_MHLA(input_size=latent, **DiT_configs()[model_name]).to(dev)
     # zero-initialised adaLN / head would make every block an identity: give the benchmark non-trivial activations
     with torch.no_grad():
         for prm in model.parameters():
             if prm.requires_grad and float(prm.abs().max()) == 0.0:
                 prm.normal_(std=0.02)
-    net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local]) if world > 1 else model
+    if world > 1:
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True)
+    else:
+        net = model
     opt = torch.optim.AdamW(net.parameters(), lr=1e-4, weight_decay=0.0)
-    x = torch.randn(a.batch, 4, latent, latent, device=dev)
+    x = torch.randn(batch, 4, latent, latent, device=dev)
     noise = torch.randn_like(x)
-    t = torch.randint(0, 1000, (a.batch,), device=dev)
-    y = torch.randint(0, 1000, (a.batch,), device=dev)
+    t = torch.randint(0, 1000, (batch,), device=dev)
+    y = torch.randint(0, 1000, (batch,), device=dev)
 
     def step():
         with torch.autocast("cuda", dtype=torch.bfloat16):
@@ -61,13 +53,40 @@ def main():
         for blk in model.blocks:   # the post-step clamp of the mixing weights, mhla_dit/train.py:308-310
             blk.attn.piece_attn.conv.weight.data.clamp_(min=0)
 
-    el = mdist.timed_steps(step, a.steps, a.warmup, torch.cuda.synchronize)
-    tokens = a.batch * (latent // 2) ** 2 * world
+    el = mdist.timed_steps(step, steps, warmup, torch.cuda.synchronize)
+    tokens = batch * (latent // 2) ** 2 * world
+    nparam = sum(p.numel() for p in model.parameters())
+    res = {"what": f"{model_name} {image}x{image} training step (fwd, MSE, bwd, AdamW), thin host around the MHLA4DiT drop-in, bf16 autocast",
+           "n_gpus": world, "per_gpu_batch": batch, "steps": steps, "warmup": warmup, "ms_per_step": el / steps * 1e3,
+           "images_per_s": batch * world / (el / steps), "tokens_per_s": tokens / (el / steps),
+           "params_M": nparam / 1e6,
+           "gradient_exchange": ("none (one rank)" if world == 1 else
+                                 f"DistributedDataParallel over {torch.distributed.get_backend()}: {nparam * 4 / 1e9:.2f} GB of fp32 gradients per "
+                                 f"step, bucket_cap_mb={bucket_cap_mb}, gradient_as_bucket_view=True, all-reduce overlapped with backward")}
+    del opt, net, model
+    torch.cuda.empty_cache()
+    return res
+
+
+def main():
+    p = argparse.ArgumentParser()
+    p.add_argument("--model", default="DiT-XL/2", choices=sorted(DiT_configs()))
+    p.add_argument("--batch", type=int, default=32, help="per-GPU batch")
+    p.add_argument("--image", type=int, default=256, help="image side in pixels (latent side = image / 8)")
+    p.add_argument("--steps", type=int, default=10)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--bucket-cap-mb", type=int, default=25)
+    p.add_argument("--gpus", type=int, default=1, help="ranks to start when not launched by torch.distributed.run")
+    a = p.parse_args()
+    if a.gpus > 1 and not mdist.launched_by_rendezvous():   # parent: start the ranks before any GPU call, relay the status
+        extra = {"MHLA_DIST_BACKEND": "gloo"} if torch.cuda.device_count() < a.gpus else {}
+        sys.exit(mdist.spawn_local_ranks(a.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:], extra))
+    rank, local, world = mdist.init_from_env()
+    local %= torch.cuda.device_count()
+    torch.cuda.set_device(local)
+    res = run_dit_step(rank, local, world, a.model, a.batch, a.image, a.steps, a.warmup, a.bucket_cap_mb)
     if rank == 0:
-        print(json.dumps({"what": f"{a.model} {a.image}x{a.image} training step, thin host, bf16 autocast, AdamW",
-                          "n_gpus": world, "per_gpu_batch": a.batch, "ms_per_step": el / a.steps * 1e3,
-                          "images_per_s": a.batch * world / (el / a.steps), "tokens_per_s": tokens / (el / a.steps),
-                          "params_M": sum(p.numel() for p in model.parameters()) / 1e6}))
+        print(json.dumps(res))
 
 
 if __name__ == "__main__":
