@@ -504,35 +504,55 @@ def wan_variant_forward(kind: str, sd: dict, x: torch.Tensor, grid: Tuple[int, i
 
 
 def fla_layer_forward(sd: dict, x: torch.Tensor, heads: int, head_k: int, head_v: int,
-                      norm_eps: float = 1e-5, chunk_size: int = 64, attention_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """``MHLA.forward`` (fla layer, ``feature_map='relu'``, fused swish gate, no
-    short conv, no cache) -- ``mhla_nlp/fla/layers/mhla.py:226-365``.  With a 0/1 ``attention_mask`` [B, T] the batch is
+                      norm_eps: float = 1e-5, chunk_size: int = 64, attention_mask: Optional[torch.Tensor] = None,
+                      num_kv_heads: Optional[int] = None, feature_map: str = "relu", use_output_gate: bool = True,
+                      gate_fn: str = "swish") -> torch.Tensor:
+    """``MHLA.forward`` (fla layer, no short conv, no cache) -- ``mhla_nlp/fla/layers/mhla.py:226-365``.  Defaults: the shipped
+    configuration (``feature_map='relu'``, fused swish gate).  Options restated from the same file: grouped k / v heads
+    (``num_kv_heads``, :290-292), ``feature_map`` in relu / elu (= elu + 1, :130-134) / identity, ``use_output_gate=False``
+    (plain per-head RMSNorm, :357-358), a ``gate_fn`` other than swish (RMSNorm, then ``o * gate_fn(g)``, :355-356).
+    With a 0/1 ``attention_mask`` [B, T] the batch is
     unpadded into ONE packed sequence (:253-256), rotary positions restart per sequence (cu_seqlens, :311), the operator runs
     over the whole packed sequence (it ignores cu_seqlens: cross-sequence leakage, as in the reference, :330-336) and the
     result is padded back with zeros (:362-363)."""
+    opts = dict(num_kv_heads=num_kv_heads, feature_map=feature_map, use_output_gate=use_output_gate, gate_fn=gate_fn)
     if attention_mask is not None:
         Bm, Tm, C = x.shape
         keep = attention_mask.flatten().nonzero().flatten()
         lens = attention_mask.sum(-1)
         pos = torch.cat([torch.arange(int(n)) for n in lens])
-        y = _fla_layer_core(sd, x.reshape(Bm * Tm, C)[keep].unsqueeze(0), heads, head_k, head_v, norm_eps, chunk_size, pos)
+        y = _fla_layer_core(sd, x.reshape(Bm * Tm, C)[keep].unsqueeze(0), heads, head_k, head_v, norm_eps, chunk_size, pos, **opts)
         out = y.new_zeros(Bm * Tm, y.shape[-1])
         out[keep] = y.squeeze(0)
         return out.reshape(Bm, Tm, -1)
-    return _fla_layer_core(sd, x, heads, head_k, head_v, norm_eps, chunk_size, None)
+    return _fla_layer_core(sd, x, heads, head_k, head_v, norm_eps, chunk_size, None, **opts)
 
 
-def _fla_layer_core(sd, x, heads, head_k, head_v, norm_eps, chunk_size, positions):
+def _fla_layer_core(sd, x, heads, head_k, head_v, norm_eps, chunk_size, positions, num_kv_heads=None, feature_map="relu",
+                    use_output_gate=True, gate_fn="swish"):
     B, T, C = x.shape
+    kvh = heads if num_kv_heads is None else num_kv_heads
+    groups = heads // kvh
     # :237 -- clamp(...).tril() on the [L, L, 1, 1, 1, 1] parameter: tril acts on the trailing 1x1 dims, a no-op;
     # the op reads only j <= i anyway
     mix = torch.clamp(sd["mixing_matrix"], 1e-5, 1).tril().reshape(sd["mixing_matrix"].shape[0], -1)
     q = F.linear(x, sd["q_proj.weight"]).reshape(B, T, heads, head_k)             # :281-295
-    k = F.linear(x, sd["k_proj.weight"]).reshape(B, T, heads, head_k)
-    v = F.linear(x, sd["v_proj.weight"]).reshape(B, T, heads, head_v)
-    q, k = torch.relu(q), torch.relu(k)                                            # :297-299
+    k = F.linear(x, sd["k_proj.weight"]).reshape(B, T, kvh, head_k)
+    v = F.linear(x, sd["v_proj.weight"]).reshape(B, T, kvh, head_v)
+    if groups > 1:                                                                 # :290-292  '(h d) -> (h g) d'
+        k = k.repeat_interleave(groups, dim=2)
+        v = v.repeat_interleave(groups, dim=2)
+    fmap = {"relu": torch.relu, "elu": lambda t: F.elu(t) + 1, "identity": lambda t: t}[feature_map]   # :130-142
+    q, k = fmap(q), fmap(k)                                                        # :297-299
     q, k = neox_rotary(q, positions=positions), neox_rotary(k, positions=positions)   # :311
     o = causal_fwd(q, k, v, mix, chunk_size)                                       # :330-336
-    g = F.linear(x, sd["g_proj.weight"]).reshape(B, T, heads, head_v)             # :351-352
-    o = rms_norm_swish_gate(o, g, sd["g_norm_swish_gate.weight"], norm_eps)        # :353
-    return F.linear(o.reshape(B, T, heads * head_v), sd["o_proj.weight"])          # :361
+    if use_output_gate and gate_fn == "swish":                                     # fused norm x swish gate, :351-354
+        g = F.linear(x, sd["g_proj.weight"]).reshape(B, T, heads, head_v)
+        o = rms_norm_swish_gate(o, g, sd["g_norm_swish_gate.weight"], norm_eps)
+        o = o.reshape(B, T, heads * head_v)
+    else:
+        o = rms_norm(o, sd["g_norm.weight"], norm_eps).reshape(B, T, heads * head_v)   # :355-358
+        if use_output_gate:
+            act = {"sigmoid": torch.sigmoid, "silu": F.silu, "relu": F.relu, "gelu": F.gelu}[gate_fn]
+            o = o * act(F.linear(x, sd["g_proj.weight"]))
+    return F.linear(o, sd["o_proj.weight"])                                        # :361

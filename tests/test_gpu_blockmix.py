@@ -85,6 +85,21 @@ def test_small_sequence_path(M, D):
     run_case(2, 2, M, 16, D, torch.bfloat16, normalize=False)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_full_size_c3_dit_xl2_every_head(dtype):
+    """BASELINE.json configs[2] at its full per-GPU size -- B = 32, N = 256 (16 blocks of 16), H = 16, D = 72 -- the north-star
+    shape: the output and every gradient of all 512 (b, h) pairs and the full dW against the oracle.  bf16: the single-launch
+    small-sequence kernels on the benchmarked grid of 512 workgroups (their (b, h) comes from xcd_swizzle(blockIdx, gridDim));
+    fp32 (how the reference trains DiT-XL, mhla_dit/train.py:12-13): the split-operand path."""
+    run_case(32, 16, 16, 16, 72, dtype, w="rand")
+
+
+def test_small_sequence_grid_not_a_multiple_of_8():
+    """B H = 231 workgroups (33 x 7): the XCD-aware (b, h) mapping with a remainder, values checked against the oracle."""
+    run_case(33, 7, 16, 16, 72, torch.bfloat16, w="rand")
+    run_case(33, 7, 16, 16, 64, torch.bfloat16, w="rand", normalize=False)
+
+
 def test_small_sequence_vs_summary_path_agree():
     import mhla_amd
     q, k, v, W, do, _, _ = make_blockmix_inputs(4, 6, 16, 16, 64, torch.bfloat16, seed=3, w="rand")

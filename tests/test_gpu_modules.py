@@ -531,3 +531,91 @@ def test_wan_block_shell():
         y0 = blk(x, e0, sl, gs, fr, ctx)
         want = x + blk.cross_attn(blk.norm3(x), ctx)
     check("gates at zero", y0, want.cpu(), 1e-5)
+
+
+@pytest.mark.parametrize("opts", [
+    dict(num_kv_heads=2),                                   # grouped k / v heads (layers/mhla.py:290-292)
+    dict(use_output_gate=False),                            # plain per-head RMSNorm (:357-358)
+    dict(gate_fn="sigmoid"),                                # RMSNorm, then o * sigmoid(g) (:355-356)
+    dict(feature_map="elu"),                                # elu + 1 (:130-134)
+    dict(num_kv_heads=1, feature_map="identity", gate_fn="sigmoid"),
+])
+def test_fla_layer_options_match_oracle_restatement(opts):
+    """The fla layer's non-default constructor options on the GPU -- GQA, no output gate, a non-swish gate, other feature maps --
+    forward, dx and every parameter gradient against autograd through the oracle's restatement of the layer."""
+    from mhla_amd import modules
+    torch.manual_seed(11)
+    heads, hk, hv = 4, 32, 64
+    m = modules.MHLA(mode="chunk", hidden_size=128, expand_k=1.0, expand_v=2.0, num_heads=heads, norm_eps=1e-6,
+                     **{"feature_map": "relu", **opts})
+    with torch.no_grad():
+        (m.g_norm_swish_gate if hasattr(m, "g_norm_swish_gate") else m.g_norm).weight.uniform_(0.5, 1.5)
+        m.mixing_matrix.copy_(torch.rand(32, 32).view(32, 32, 1, 1, 1, 1).clamp_(1e-5, 1))
+    x = torch.randn(2, 300, 128)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    okw = dict(norm_eps=1e-6, num_kv_heads=opts.get("num_kv_heads"), feature_map=opts.get("feature_map", "relu"),
+               use_output_gate=opts.get("use_output_gate", True), gate_fn=opts.get("gate_fn", "swish"))
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xr = x.clone().requires_grad_(True)
+    want = orc.fla_layer_forward(sdr, xr, heads, hk, hv, **okw)
+    dY = torch.randn(want.shape, generator=torch.Generator().manual_seed(5))
+    (want * dY).sum().backward()
+    m = m.to(DEV)
+    xd = x.to(DEV).requires_grad_(True)
+    o, _, _ = m(xd)
+    check("o", o, want.detach(), 1e-4)
+    (o * dY.to(DEV)).sum().backward()
+    check("dx (layer)", xd.grad, xr.grad, 2e-4)
+    for name, prm in m.named_parameters():
+        check(f"grad {name}", prm.grad, sdr[name].grad, 2e-4, atol=1e-7)
+
+
+def test_wan_block_host_matches_cpu_composition():
+    """The thin Wan block host (hosts/wan.py) on the GPU against the same host on the CPU with its self-attention module
+    replaced by the oracle's restatement of MHLA_Video_Uni (wan_module_forward): block output (inference and training path),
+    dx, and the gradients of the block's parameters -- as the DiT and GPT hosts are checked."""
+    import copy
+    from mhla_amd import modules
+    from mhla_amd.hosts import WanAttentionBlock_MHLA
+    torch.manual_seed(5)
+    dim, heads, grid, layout = 128, 2, (4, 6, 9), (2, 2, 3)
+    N = grid[0] * grid[1] * grid[2]
+    blk = WanAttentionBlock_MHLA(dim=dim, ffn_dim=256, num_heads=heads, block_layout=layout, is_gated=True, is_lepe=False,
+                                 norm_output=True)
+    with torch.no_grad():
+        blk.self_attn.block_attn.conv.weight.copy_(torch.rand_like(blk.self_attn.block_attn.conv.weight))
+        blk.self_attn.g_norm.weight.uniform_(0.5, 1.5)
+    B = 2
+    x = torch.randn(B, N, dim)
+    e = torch.randn(B, 6, dim) * 0.1
+    ctx = torch.randn(B, 7, dim)
+    gs = torch.tensor([list(grid)] * B, dtype=torch.long)
+    sl = torch.tensor([N] * B)
+    clens = torch.tensor([7, 5])
+    ref = copy.deepcopy(blk)
+    sa = ref.self_attn
+    fr_cpu = orc.wan_freqs(dim // heads)
+    ref.self_attn.forward = lambda z, seq_lens, grid_sizes, freqs: orc.wan_module_forward(
+        {k: v for k, v in sa.named_parameters()}, z, grid, fr_cpu, heads, layout=layout, eps=sa.eps if hasattr(sa, "eps") else 1e-6,
+        normalize_out=True, is_gated=True)
+    xr = x.clone().requires_grad_(True)
+    want = ref(xr, e, sl, gs, None, ctx, clens)
+    dY = torch.randn(want.shape, generator=torch.Generator().manual_seed(2))
+    (want * dY).sum().backward()
+    blk = blk.to(DEV)
+    fr = modules.wan_freqs(dim // heads)
+    args = (e.to(DEV), sl, gs, fr, ctx.to(DEV), clens)
+    with torch.no_grad():
+        y_inf = blk(x.to(DEV), *args)
+    check("wan block (inference path)", y_inf, want.detach(), 2e-4)
+    xd = x.to(DEV).requires_grad_(True)
+    y = blk(xd, *args)
+    check("wan block (training path)", y, want.detach(), 2e-4)
+    (y * dY.to(DEV)).sum().backward()
+    check("dx (wan block)", xd.grad, xr.grad, 2e-4)
+    refp = dict(ref.named_parameters())
+    for name, prm in blk.named_parameters():
+        if prm.grad is None:
+            assert refp[name].grad is None or float(refp[name].grad.abs().max()) == 0.0, name
+            continue
+        check(f"grad {name}", prm.grad, refp[name].grad, 2e-4, atol=1e-7)
