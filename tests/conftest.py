@@ -66,10 +66,13 @@ def pytest_sessionfinish(session, exitstatus):
         return
     import json
     agg = {}
-    for test, name, dtype, e, r, tol in obs:
+    for test, name, dtype, e, r, tol, x in obs:
         kind = "output" if name.split(" ")[0] in ("out", "y", "o", "out_nonorm", "o_short") else "gradient"
         key = f"{dtype}/{kind}"
-        a = agg.setdefault(key, {"n": 0, "max_rel_err": 0.0, "max_rms_ratio": 0.0, "worst": None, "loosest_tol": 0.0})
+        a = agg.setdefault(key, {"n": 0, "max_rel_err": 0.0, "max_rms_ratio": 0.0, "worst": None, "loosest_tol": 0.0,
+                                 "max_beyond_final_rounding": 0.0, "worst_beyond_final_rounding": None})
+        if x >= a["max_beyond_final_rounding"]:
+            a["max_beyond_final_rounding"], a["worst_beyond_final_rounding"] = x, f"{test} :: {name}"
         a["n"] += 1
         a["max_rms_ratio"] = max(a["max_rms_ratio"], r)
         a["loosest_tol"] = max(a["loosest_tol"], tol)
@@ -79,4 +82,5 @@ def pytest_sessionfinish(session, exitstatus):
     os.makedirs(out, exist_ok=True)
     with open(os.path.join(out, "parity_report.json"), "w") as f:
         json.dump({"comparisons": len(obs), "by_dtype_and_kind": agg,
-                   "all": [dict(test=t, name=n, dtype=d, rel_err=e, rms_ratio=r, tol=tol) for t, n, d, e, r, tol in obs]}, f, indent=1)
+                   "all": [dict(test=t, name=n, dtype=d, rel_err=e, rms_ratio=r, tol=tol, beyond_final_rounding=x)
+                           for t, n, d, e, r, tol, x in obs]}, f, indent=1)

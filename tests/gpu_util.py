@@ -5,12 +5,23 @@ from conftest import rel_err, rms_ratio
 from oracle import mhla_oracle as orc
 
 DEV = "cuda"
-# north_star: outputs within 1e-3 rel-err (max|a-b| / max|b|) of the reference in fp32-accumulate, fp32-output mode; bf16 /
-# fp16 OUTPUT adds one rounding of the result (2^-9 / 2^-11 elementwise).  The bounds below are about twice the largest
-# error observed over the whole -m gpu suite in round 2 (profiles/r2_parity_errors.md: fp32 7.2e-5; bf16 outputs 5.8e-3 --
-# one bf16 rounding of the largest output, nothing to tighten; bf16 gradients 7.7e-3; fp16 4.3e-4 / 6.4e-4).
-TOL = {torch.float32: 2e-4, torch.bfloat16: 6e-3, torch.float16: 1e-3}
-GTOL = {torch.float32: 2e-4, torch.bfloat16: 1.2e-2, torch.float16: 1.5e-3}
+# Tolerances, derived from the arithmetic rather than fitted to observations.  u = unit roundoff of the
+# tensor dtype (round to nearest: |fl(x) - x| <= u |x|; bf16 has 8 significand bits: u = 2^-8; fp16 11: u = 2^-11).
+#  * fp32 tensors: every product is exact (fp32 MFMA) or split into bf16 hi + lo parts (>= 16 significand bits, 2^-17 per
+#    operand) with fp32 accumulation: 2e-4 of the tensor's maximum, five times under north_star's 1e-3.
+#  * 16-bit tensors: the result is stored in the tensor dtype -- one final rounding, <= u |x| PER ELEMENT, which no
+#    implementation can avoid -- and the kernels keep K intermediate tiles in the same 16-bit format on their way through the
+#    matrix pipe: K = 1 for outputs (the block / chunk summary, or the score tile of the small-sequence path), K = 2 for
+#    gradients (additionally dP = dO / n, resp. the dS / dP summaries).  An intermediate rounding perturbs the result by at most
+#    u times the magnitude of what it feeds, i.e. <= u max|x| when nothing averages (contraction length 1: the S = 1, M <= 4
+#    corner cases of the fuzz tests reach 0.8 u .. 1.7 u) and ~ u / sqrt(L) over a contraction of length L (BASELINE shapes,
+#    L >= 64: 0.2 u .. 0.8 u observed).  Hence, normalised by the tensor's maximum:
+#        max|got - want| <= (1 + K) u max|want|              (TOL = 2 u for outputs, GTOL = 3 u for gradients)
+#        max(|got - want| - u |want|) <= K u max|want|       (the part the kernels add beyond the unavoidable final rounding)
+#    check() asserts both; the second is the sharper statement because the final rounding is charged per element.
+UNIT_ROUNDOFF = {torch.bfloat16: 2.0 ** -8, torch.float16: 2.0 ** -11}
+TOL = {torch.float32: 2e-4, torch.bfloat16: 2 * 2.0 ** -8, torch.float16: 2 * 2.0 ** -11}
+GTOL = {torch.float32: 2e-4, torch.bfloat16: 3 * 2.0 ** -8, torch.float16: 3 * 2.0 ** -11}
 
 
 def make_blockmix_inputs(B, H, M, S, D, dtype, seed=1234, w="linear", split=False):
@@ -58,8 +69,14 @@ def check(name, got, want, tol, atol=0.0):
     if atol and (g - w).abs().max().item() < atol:
         return 0.0
     e, r = rel_err(g, w), rms_ratio(g, w)
-    OBSERVED.append((os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0], name, str(got.dtype).replace("torch.", ""), e, r, tol))
+    # error beyond the final rounding of the result to its own dtype (|err| <= u |want| elementwise is what storing the exact
+    # result in that dtype costs): what the kernels' internal arithmetic adds, normalised like rel_err
+    u = UNIT_ROUNDOFF.get(got.dtype, 0.0)
+    x = ((g.double() - w.double()).abs() - u * w.double().abs()).clamp_min(0).max().item() / max(w.double().abs().max().item(), 1e-30)
+    OBSERVED.append((os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0], name, str(got.dtype).replace("torch.", ""), e, r, tol, x))
     assert e < tol, f"{name}: rel_err {e:.3e} (rms ratio {r:.3e}) exceeds {tol:.1e}"
+    if u and tol > u:
+        assert x < tol - u, f"{name}: error beyond the final {got.dtype} rounding {x:.3e} exceeds {tol - u:.1e} (rel_err {e:.3e})"
     assert r < 2 * tol, f"{name}: rms ratio {r:.3e} exceeds {2 * tol:.1e} (rel_err {e:.3e})"
     return e
 
