@@ -113,8 +113,39 @@ __device__ __forceinline__ void wz_body(float* __restrict__ smem, const float* _
     if (tid < 256) {
         const int r = tid >> 2, sq = tid & 3;
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        // Every LDS operand of a group of eight steps has landed before its first multiply-add.  With packed fp32 math enabled
+        // the straightforward loop (WZ_VARIANT=0: `acc += Ws[..] * x4` unrolled by 8) compiles to v_pk_fma_f32 fed by
+        // ds_read2_b32 / ds_read_b128 behind counted s_waitcnt lgkmcnt(N) waits, and the LOW halves of its results in lanes
+        // 16-31 / 48-63 differ from run to run whenever the dW workgroups of this launch share the CU
+        // (tools/probes/pk_fma_repro.hip reproduces it without the library).  The same loop with scalar
+        // v_fmac_f32 (the shipped build has no packed fp32 ops at all) is bit-stable; so is this form with packed math on.
+#ifndef WZ_VARIANT
+#define WZ_VARIANT 1
+#endif
+#if WZ_VARIANT == 0   // the reproducer's variant
 #pragma unroll 8
         for (int c = 0; c < 64; ++c) acc += Ws[r * 65 + c] * *reinterpret_cast<const f32x4*>(xs + c * WZ_C + sq * 4);
+#elif WZ_VARIANT == 1
+        for (int c0 = 0; c0 < 64; c0 += 8) {
+            float w[8];
+            f32x4 xv[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                w[c] = Ws[r * 65 + c0 + c];
+                xv[c] = *reinterpret_cast<const f32x4*>(xs + (c0 + c) * WZ_C + sq * 4);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int c = 0; c < 8; ++c) acc += w[c] * xv[c];
+        }
+#elif WZ_VARIANT == 2   // W elements read one by one (ds_read_b32 instead of ds_read2_b32 pairs): also bit-stable with packed math
+#pragma unroll 8
+        for (int c = 0; c < 64; ++c) {
+            float w = Ws[r * 65 + c];
+            asm volatile("" : "+v"(w));
+            acc += w * *reinterpret_cast<const f32x4*>(xs + c * WZ_C + sq * 4);
+        }
+#endif
         if (r < M) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -779,6 +810,13 @@ __global__ __launch_bounds__(FT8) void k_fs_dw(const FsDwArgs a) {
         wz_body<1, FT8>(reinterpret_cast<float*>(smem_raw), a.W, a.ldw, a.dn, a.dz, a.M, a.S, 0.f, qtr - DW_SPLIT, bh, tid);
         return;
     }
+#ifdef FS_DW_PROBE_NO_DW_ROLE   // tools/probes/pk_fma_repro.hip: only the dz workgroups do anything (1: dW code compiled out;
+#if FS_DW_PROBE_NO_DW_ROLE == 1 //  2: dW code kept -- same register allocation -- but skipped at run time when dwp is null)
+    return;
+#else
+    if (a.dwp == nullptr) return;
+#endif
+#endif
     const u16* dg = a.dg + (long)bh * njg * FE * IT;
     const u16* kv = a.kv + (long)bh * njg * FE * IT;
     f32x4 acc[2];
