@@ -159,6 +159,18 @@ int mhla_blockmix_bwd(mhla_view q_num, mhla_view k_num, mhla_view v,
                       int B, int H, int M, int S, int D,
                       int dtype, float eps, unsigned flags, void* stream);
 
+/* Backward of mhla_blockmix_rope_fwd (the rope of wan/mhla_utils.py:314 inside the operator's backward).
+ * q, k: the UN-rotated tensors the forward was given (numerator pair = their rotation, normaliser pair = themselves when
+ * normalize != 0); out / dout as in mhla_blockmix_bwd; dq, dk: gradients w.r.t. the un-rotated q, k (the transposed rotation
+ * of the numerator gradients and the normaliser's part are summed inside the kernels) -- replaces autograd through
+ * rope_apply (mhla_utils.py:127-156) and the 5-tensor concat / rearrange (:317-326) in the backward direction.
+ * fp32 tensors, D % 8 == 0.  fwd_ws: workspace of mhla_blockmix_rope_fwd for the same arguments, or NULL. */
+int mhla_blockmix_rope_bwd(mhla_view q, mhla_view k, mhla_view v, int normalize, const float* W, int ldw,
+                           const float* rope_cos, const float* rope_sin, int64_t ld_rope, mhla_view out, mhla_view dout,
+                           mhla_mview dq, mhla_mview dk, mhla_mview dv, float* dW, const int32_t* block_index, void* ws,
+                           size_t ws_bytes, const void* fwd_ws, int B, int H, int M, int S, int D, int dtype, float eps,
+                           unsigned flags, void* stream);
+
 /* Status of the last mhla_blockmix_bwd that used `ws` (same problem arguments).  The bf16 fast path hands a tile's dksum rows
  * from its dQ workgroup to its dK/dV workgroup inside one launch through a flag; the wait for that flag is bounded, and a
  * waiter that gives up raises an error word in the workspace.  This call synchronises `stream`, reads the word and returns

@@ -44,6 +44,9 @@ SIGNATURES = {
     "mhla_blockmix_bwd": (c_int, [View, View, View, View, View, c_void_p, c_int, View, View, View, View, View, View,
                                   View, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_int, c_int, c_int, c_int,
                                   c_int, c_int, c_float, c_uint, c_void_p]),
+    "mhla_blockmix_rope_bwd": (c_int, [View, View, View, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int64, View, View, View, View,
+                                       View, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                       c_int, c_float, c_uint, c_void_p]),
     "mhla_blockmix_bwd_status": (c_int, [c_void_p, c_size_t] + [c_int] * 7 + [c_uint, c_void_p]),
     "mhla_causal_fwd_ws_bytes": (c_size_t, [c_int] * 7),
     "mhla_causal_bwd_ws_bytes": (c_size_t, [c_int] * 7),

@@ -566,6 +566,11 @@ struct TokArgs {
     int H, M, S, D;
     float eps;
     int relu, normalize, split;
+    // fused rotary prologue in the backward (split.hpp, ROPE variants): q / k are the un-rotated tensors; the gradients of the
+    // rotated ones are turned back (transposed rotation) before the normaliser's part is added and they are stored
+    const float* rcos;
+    const float* rsin;
+    long ldr;
 };
 
 template <int DT>

@@ -243,11 +243,11 @@ int mhla_blockmix_wan_fwd(mhla_view q, mhla_view k, mhla_view v, int normalize, 
                        dtype, eps, flags, stream, rope_cos, rope_sin, (long)ld_rope, true, norm_w, norm_eps, gate, out_dtype);
 }
 
-int mhla_blockmix_bwd(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q_den, mhla_view k_den, const float* W,
-                      int ldw, mhla_view out, mhla_view dout, mhla_mview dq_num, mhla_mview dk_num, mhla_mview dv,
-                      mhla_mview dq_den, mhla_mview dk_den, float* dW, const int32_t* block_index, void* ws,
-                      size_t ws_bytes, const void* fwd_ws, int B, int H, int M, int S, int D, int dtype, float eps,
-                      unsigned flags, void* stream) {
+static int bm_bwd_impl(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q_den, mhla_view k_den, const float* W,
+                       int ldw, mhla_view out, mhla_view dout, mhla_mview dq_num, mhla_mview dk_num, mhla_mview dv,
+                       mhla_mview dq_den, mhla_mview dk_den, float* dW, const int32_t* block_index, void* ws,
+                       size_t ws_bytes, const void* fwd_ws, int B, int H, int M, int S, int D, int dtype, float eps,
+                       unsigned flags, void* stream, const float* rcos = nullptr, const float* rsin = nullptr, long ldr = 0) {
     const bool normalize = q_den.ptr != nullptr;
     const bool split = normalize && (q_den.ptr != q_num.ptr || k_den.ptr != k_num.ptr);
     RC(bm_check(B, H, M, S, D, dtype, flags, normalize, split));
@@ -264,7 +264,7 @@ int mhla_blockmix_bwd(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q
     {
         const mhla_view dqv{dq_num.ptr, dq_num.sb, dq_num.sn, dq_num.sh}, dkv_{dk_num.ptr, dk_num.sb, dk_num.sn, dk_num.sh},
             dvv{dv.ptr, dv.sb, dv.sn, dv.sh};
-        if (sn_shape_ok(M, S, D, dtype, split) && !(flags & (MHLA_FLAG_FORCE_GENERIC | MHLA_FLAG_NO_SMALLN)) && view_ok16(q_num) &&
+        if (!rcos && sn_shape_ok(M, S, D, dtype, split) && !(flags & (MHLA_FLAG_FORCE_GENERIC | MHLA_FLAG_NO_SMALLN)) && view_ok16(q_num) &&
             view_ok16(k_num) && view_ok16(v) && view_ok16(dout) && (!normalize || view_ok16(out)) && view_ok16(dqv) &&
             view_ok16(dkv_) && view_ok16(dvv)) {
             const size_t need = (size_t)B * H * M * M * 4;
@@ -279,7 +279,7 @@ int mhla_blockmix_bwd(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q
             RC(launch(fast::k_sn_dw_reduce, dim3(M * M), dim3(256), 0, st, "k_sn_dw_reduce", (const float*)ws, dW, M * M, B * H));
             return MHLA_OK;
         }
-        if (fast_shape_ok(M, D, dtype, split) && !(flags & MHLA_FLAG_FORCE_GENERIC) && view_ok16(q_num) && view_ok16(k_num) &&
+        if (!rcos && fast_shape_ok(M, D, dtype, split) && !(flags & MHLA_FLAG_FORCE_GENERIC) && view_ok16(q_num) && view_ok16(k_num) &&
             view_ok16(v) && view_ok16(dout) && (!normalize || view_ok16(out)) && view_ok16(dqv) && view_ok16(dkv_) && view_ok16(dvv)) {
             const FastWs f = fast_carve(ws, B, H, M, S);
             if (ws_bytes < f.total_bwd) return fail(MHLA_EINVAL, "workspace too small: %zu < %zu bytes", ws_bytes, f.total_bwd);
@@ -335,7 +335,7 @@ int mhla_blockmix_bwd(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q
     if (ws_bytes < w.total_bwd) return fail(MHLA_EINVAL, "workspace too small: %zu < %zu bytes", ws_bytes, w.total_bwd);
     // the forward's KV, G, z, ksum, 1/n are still in its workspace (only when the shape cannot have taken the bf16 fast path,
     // whose workspace has another layout)
-    const bool reuse = fwd_ws && sp_shape_ok(D, flags) && !fast_shape_ok(M, D, dtype, split);
+    const bool reuse = fwd_ws && sp_shape_ok(D, flags) && (rcos || !fast_shape_ok(M, D, dtype, split));
     if (reuse) {
         const BmWs f = bm_carve(const_cast<void*>(fwd_ws), B, H, M, S, D, bm_sum16(D, dtype, flags));
         w.kv = f.kv; w.g = f.g; w.z = f.z; w.ksum = f.ksum; w.ninv = f.ninv;
@@ -344,13 +344,43 @@ int mhla_blockmix_bwd(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q
     c.q_num = q_num; c.k_num = k_num; c.v = v; c.q_den = q_den; c.k_den = k_den; c.outv = out; c.dout = dout;
     c.dq_num = dq_num; c.dk_num = dk_num; c.dv = dv; c.dq_den = dq_den; c.dk_den = dk_den; c.dW = dW;
     c.W = W; c.ldw = ldw; c.block_index = block_index; c.w = w; c.B = B; c.H = H; c.M = M; c.S = S; c.D = D; c.eps = eps; c.flags = flags;
-    c.normalize = normalize; c.split = split; c.reuse = reuse; c.st = st;
+    c.normalize = normalize; c.split = split; c.reuse = reuse; c.st = st; c.rcos = rcos; c.rsin = rsin; c.ldr = ldr;
     switch (dtype) {
         case MHLA_F32: return bm_bwd_typed<float>(c);
         case MHLA_BF16: return bm_bwd_typed<bf16_t>(c);
         case MHLA_F16: return bm_bwd_typed<f16_t>(c);
         default: return fail(MHLA_EINVAL, "unknown dtype %d", dtype);
     }
+}
+
+int mhla_blockmix_bwd(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q_den, mhla_view k_den, const float* W,
+                      int ldw, mhla_view out, mhla_view dout, mhla_mview dq_num, mhla_mview dk_num, mhla_mview dv,
+                      mhla_mview dq_den, mhla_mview dk_den, float* dW, const int32_t* block_index, void* ws,
+                      size_t ws_bytes, const void* fwd_ws, int B, int H, int M, int S, int D, int dtype, float eps,
+                      unsigned flags, void* stream) {
+    return bm_bwd_impl(q_num, k_num, v, q_den, k_den, W, ldw, out, dout, dq_num, dk_num, dv, dq_den, dk_den, dW, block_index, ws,
+                       ws_bytes, fwd_ws, B, H, M, S, D, dtype, eps, flags, stream);
+}
+
+// Backward of mhla_blockmix_rope_fwd: q, k are the UN-rotated tensors the forward was given; the kernels rotate them on load
+// where the rotated ones are needed (dG = Q_rot^T dP, dV = K_rot dKV) and turn the gradients of the rotated tensors back before
+// the normaliser's part is added, so dq / dk are the gradients w.r.t. q / k themselves -- no rotated copies, no second
+// gradient pair.  fp32 tensors, D % 8 == 0 (the split-operand kernels).
+int mhla_blockmix_rope_bwd(mhla_view q, mhla_view k, mhla_view v, int normalize, const float* W, int ldw,
+                           const float* rope_cos, const float* rope_sin, int64_t ld_rope, mhla_view out, mhla_view dout,
+                           mhla_mview dq, mhla_mview dk, mhla_mview dv, float* dW, const int32_t* block_index, void* ws,
+                           size_t ws_bytes, const void* fwd_ws, int B, int H, int M, int S, int D, int dtype, float eps,
+                           unsigned flags, void* stream) {
+    if (!rope_cos || !rope_sin) return fail(MHLA_EINVAL, "rope tables null");
+    if (ld_rope < D / 2 || (ld_rope & 3) || ((uintptr_t)rope_cos | (uintptr_t)rope_sin) % 16)
+        return fail(MHLA_EINVAL, "rope tables: ld=%lld must be >= D/2, a multiple of 4, and the tables 16-byte aligned", (long long)ld_rope);
+    if (dtype != MHLA_F32 || !sp_shape_ok(D, flags))
+        return fail(MHLA_ENOTSUP, "rotary backward needs fp32 tensors and D %% 8 == 0 (D=%d, dtype=%d, flags=%u)", D, dtype, flags);
+    if (flags & MHLA_FLAG_RELU_EPS) return fail(MHLA_ENOTSUP, "relu prologue and rotary prologue are not combined");
+    const mhla_view none{nullptr, 0, 0, 0};
+    const mhla_mview mnone{nullptr, 0, 0, 0};
+    return bm_bwd_impl(q, k, v, normalize ? q : none, normalize ? k : none, W, ldw, out, dout, dq, dk, dv, mnone, mnone, dW, block_index,
+                       ws, ws_bytes, fwd_ws, B, H, M, S, D, dtype, eps, flags, stream, rope_cos, rope_sin, (long)ld_rope);
 }
 
 // Did the last mhla_blockmix_bwd on this workspace run into a hand-over flag that never arrived (fused.hpp, tile_wait)?

@@ -94,7 +94,7 @@ int bm_bwd_typed(const BmCall& c) {
     (void)rcos; (void)rsin; (void)ldr; (void)nw; (void)neps; (void)out_dtype; (void)relu;
     DISPATCH_DT(dt, {
         if (!reuse)
-            RC((bm_state_and_mix<ET, DT>(q_num, k_num, v, q_den, k_den, W, ldw, block_index, w, B, H, M, S, D, eps, flags, normalize, split, st)));
+            RC((bm_state_and_mix<ET, DT>(q_num, k_num, v, q_den, k_den, W, ldw, block_index, w, B, H, M, S, D, eps, flags, normalize, split, st, rcos, rsin, ldr)));
         // dG_i = Q_i^T (dO_i / n_i), dn_i
         StateArgs a{};
         a.x = cv(q_num); a.y = cv(dout); a.o = cv(out_view); a.idx = block_index; a.W = W; a.ldw = ldw; a.ninv = w.ninv;
@@ -109,7 +109,12 @@ int bm_bwd_typed(const BmCall& c) {
         t.H = H; t.M = M; t.S = S; t.D = D; t.eps = eps; t.relu = relu; t.normalize = normalize; t.split = split;
         if (sp_shape_ok(D, flags)) {   // split-bf16 MFMA kernels (split.hpp)
             const long E = (long)D * D;
-            RC(launch(sp::k_sp_state<ET, DT, 1>, dim3(M, B * H), dim3(NTHREADS), sp::sp_state_smem<DT>(), st, "k_sp_state<1>", a));
+            a.rcos = rcos; a.rsin = rsin; a.ldr = ldr;
+            t.rcos = rcos; t.rsin = rsin; t.ldr = ldr;
+            if constexpr (std::is_same<ET, float>::value) {
+                if (rcos) RC(launch(sp::k_sp_state<ET, DT, 1, true>, dim3(M, B * H), dim3(NTHREADS), sp::sp_state_smem<DT>(), st, "k_sp_state<1,rope>", a));
+            }
+            if (!rcos) RC(launch(sp::k_sp_state<ET, DT, 1>, dim3(M, B * H), dim3(NTHREADS), sp::sp_state_smem<DT>(), st, "k_sp_state<1>", a));
             if (normalize)
                 RC(launch(k_wz<1>, dim3((S + 63) / 64, (M + 63) / 64, B * H), dim3(NTHREADS), 0, st, "k_wz<1>", W, ldw, (const float*)w.dn, w.dz, M, S, 0.f));
             MixArgs m{W, ldw, w.dg, w.dkv, M, E};
@@ -130,6 +135,13 @@ int bm_bwd_typed(const BmCall& c) {
                       (const float*)nullptr, dW, M, M, nparts, B * H));
             else RC(launch(k_dw_reduce<0>, dim3((M * M + 63) / 64), dim3(256), 0, st, "k_dw_reduce", (const float*)w.dwp,
                       (const float*)nullptr, dW, M, M, nparts, B * H));
+            if constexpr (std::is_same<ET, float>::value) {
+                if (rcos) {
+                    RC(launch(sp::k_sp_bwd_dq<ET, DT, true>, dim3(M, B * H), dim3(NTHREADS), sp::sp_tok_smem<DT, false>(), st, "k_sp_bwd_dq<rope>", t));
+                    RC(launch(sp::k_sp_bwd_dkv<ET, DT, true>, dim3(M, B * H), dim3(NTHREADS), sp::sp_tok_smem<DT, false>(), st, "k_sp_bwd_dkv<rope>", t));
+                    break;
+                }
+            }
             RC(launch(sp::k_sp_bwd_dq<ET, DT>, dim3(M, B * H), dim3(NTHREADS), sp::sp_tok_smem<DT, sp::Sum16<ET>::value>(), st, "k_sp_bwd_dq", t));
             RC(launch(sp::k_sp_bwd_dkv<ET, DT>, dim3(M, B * H), dim3(NTHREADS), sp::sp_tok_smem<DT, sp::Sum16<ET>::value>(), st, "k_sp_bwd_dkv", t));
             break;

@@ -60,6 +60,13 @@ __device__ __forceinline__ void rope8(f32x4& a, f32x4& b, const f32x4& c, const 
     b[2] = b0[2] * c[3] - b0[3] * s[3]; b[3] = b0[2] * s[3] + b0[3] * c[3];
 }
 
+// transposed rotation of a gradient in output layout: the lane's 4 consecutive features are 2 pairs with angles (c[0], s[0]), (c[1], s[1])
+__device__ __forceinline__ void unrope4(f32x4& g, const f32x2& c, const f32x2& s) {
+    const f32x4 g0 = g;
+    g[0] = g0[0] * c[0] + g0[1] * s[0]; g[1] = g0[1] * c[0] - g0[0] * s[0];
+    g[2] = g0[2] * c[1] + g0[3] * s[1]; g[3] = g0[3] * c[1] - g0[2] * s[1];
+}
+
 // Block summaries (KV, G, dG, dKV) are fp32 in the workspace, except for bf16 tensors: there they are stored as bf16 (as on
 // the bf16 fast path), which halves the summary traffic -- the larger share of the bytes when S is small -- and needs no lo part.
 template <typename T> struct Sum16 { static constexpr bool value = std::is_same<T, bf16_t>::value; };
@@ -82,8 +89,8 @@ __host__ __device__ constexpr int sp_state_smem() {
 
 // MODE 0 (forward):  out = KV_j = K_j^T V_j; ksum_j; z_j                      x = k_num, y = v, kd = k_den, qd = q_den
 // MODE 1 (backward): out = dG_i = Q_i^T (dO_i / n_i); dn_i[s] = -(dO_i[s] . O_i[s]) / n_i[s]     x = q_num, y = dout, o = out
-// ROPE (MODE 0): the keys of the KV product are rotated on load (a.rcos / a.rsin); a template flag so that the plain variants do
-// not carry the angle registers (3 waves per SIMD need <= 168 VGPRs)
+// ROPE: x (the keys of the KV product in MODE 0, the queries of dG = Q^T dP in MODE 1) is rotated on load (a.rcos / a.rsin); a
+// template flag so that the plain variants do not carry the angle registers (3 waves per SIMD need <= 168 VGPRs)
 template <typename T, int DT, int MODE, bool ROPE = false>
 __global__ __launch_bounds__(NTHREADS, ROPE ? 2 : 3) void k_sp_state(const StateArgs a) {
     constexpr int DW = Geo<DT>::DW, LD = Geo<DT>::LD, CGS = Geo<DT>::CGS, RPP = Geo<DT>::RPP, IT = 32 / RPP, RT = Geo<DT>::RT, TILE = 32 * LD;
@@ -108,7 +115,7 @@ __global__ __launch_bounds__(NTHREADS, ROPE ? 2 : 3) void k_sp_state(const State
 
     f32x4 kx[IT][2], vx[IT][2], dx[IT][2], rc[ROPE ? IT : 1], rs[ROPE ? IT : 1];
     float nv[IT];
-    constexpr bool rope = MODE == 0 && ROPE;
+    constexpr bool rope = ROPE;
     int crow = 0;   // first token of the chunk held in registers
     auto fetch = [&](int c0) {
         crow = c0;
@@ -751,7 +758,9 @@ __device__ __forceinline__ bf16x8 row_read8(const u16* tile, int ld, int c0, int
     return *reinterpret_cast<const bf16x8*>(tile + (c0 + (lane & 15)) * ld + k0 + (lane >> 4) * 8);
 }
 
-template <typename T, int DT>
+// ROPE: the numerator pair was rotated inside the forward (q_den aliases the un-rotated q): dQ_rot is turned back by the
+// transposed rotation before dz ksum^T is added, so the one stored tensor is the gradient of the un-rotated q
+template <typename T, int DT, bool ROPE = false>
 __global__ __launch_bounds__(NTHREADS, 2) void k_sp_bwd_dq(const TokArgs a) {
     constexpr int LD = mat_ld<DT>(), DW = Geo<DT>::DW, KST = Geo<DT>::KST, TILE = KST * 32 * LD;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -816,8 +825,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_bwd_dq(const TokArgs a) {
             gl[ks] = as_bf16x8(lo);
         }
         // gradient of one feature tile in output layout (4 features of the lane's token) and its q_den companion
-        auto epilogue = [&](int ct, f32x4& c, f32x4& cd) {
+        auto epilogue = [&](int ct, f32x4& c, f32x4& cd, const f32x2& rc, const f32x2& rs) {
             const int d0 = ct * 16 + kg * 4;
+            if constexpr (ROPE) unrope4(c, rc, rs);
             f32x4 qd = cur.qd[ct];
             if (a.relu)
 #pragma unroll
@@ -838,6 +848,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_bwd_dq(const TokArgs a) {
             constexpr int LAST = DT - 1;
             const int c1t = ct + 1 <= LAST ? ct + 1 : LAST;
             f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
+            f32x2 rc0 = {1.f, 1.f}, rs0 = {0.f, 0.f}, rc1 = rc0, rs1 = rs0;   // the angles of the two tiles' features: in flight during the products
+            if constexpr (ROPE) {
+                const long ro = cur.row * a.ldr + kg * 2;
+                if (ct * 16 + kg * 4 < D) { rc0 = *reinterpret_cast<const f32x2*>(a.rcos + ro + ct * 8); rs0 = *reinterpret_cast<const f32x2*>(a.rsin + ro + ct * 8); }
+                if (c1t * 16 + kg * 4 < D) { rc1 = *reinterpret_cast<const f32x2*>(a.rcos + ro + c1t * 8); rs1 = *reinterpret_cast<const f32x2*>(a.rsin + ro + c1t * 8); }
+            }
 #pragma unroll
             for (int ks = 0; ks < KST; ++ks) {
                 const bf16x8 a0h = row_read8(Gh, LD, ct * 16, ks * 32, lane), a1h = row_read8(Gh, LD, c1t * 16, ks * 32, lane);
@@ -852,8 +868,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_bwd_dq(const TokArgs a) {
                 c1 = mfma_bf16(a1h, gl[ks], c1);
             }
             f32x4 e0, e1 = {0.f, 0.f, 0.f, 0.f};
-            epilogue(ct, c0, e0);
-            if (ct + 1 < DT) epilogue(ct + 1, c1, e1);
+            epilogue(ct, c0, e0, rc0, rs0);
+            if (ct + 1 < DT) epilogue(ct + 1, c1, e1, rc1, rs1);
             // the two 64-byte halves of a 128-byte line go out in consecutive store instructions (write combining):
             // half-line stores separated in time cost a fill read and a second write per line
             const int d0 = ct * 16 + kg * 4, d1 = d0 + 16;
@@ -884,7 +900,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_bwd_dq(const TokArgs a) {
     }
 }
 
-template <typename T, int DT>
+// ROPE: k is the un-rotated tensor: it is rotated on its way into the dV product (KV was formed from the rotated keys), and
+// dK_rot is turned back before dksum is added
+template <typename T, int DT, bool ROPE = false>
 __global__ __launch_bounds__(NTHREADS, 2) void k_sp_bwd_dkv(const TokArgs a) {
     constexpr int LD = mat_ld<DT>(), DW = Geo<DT>::DW, KST = Geo<DT>::KST, TILE = KST * 32 * LD;
     constexpr bool LO = !std::is_same<T, bf16_t>::value;
@@ -902,7 +920,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_bwd_dkv(const TokArgs a) {
 
     struct Rows {
         f32x4 v[KST][2], k[KST][2];   // B operands: 8 features per reduction step
-        f32x4 km[DT];                 // k in output layout (gradient mask of the relu prologue)
+        f32x4 km[ROPE ? 1 : DT];      // k in output layout (gradient mask of the relu prologue; never combined with the rotary one)
+        f32x4 rc[ROPE ? KST : 1], rs[ROPE ? KST : 1];   // angles of the B-operand features (4 pairs per reduction step)
         long row;
         bool live;
     } cur, nxt;
@@ -917,11 +936,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_bwd_dkv(const TokArgs a) {
                 ld8(vb + R.row * a.v.sn + ks * 32 + kg * 8, R.v[ks][0], R.v[ks][1]);
                 ld8(kb + R.row * a.k.sn + ks * 32 + kg * 8, R.k[ks][0], R.k[ks][1]);
             }
+            if constexpr (ROPE) {   // unconditional, clamped: features past D are zeros whatever their angle (a branch or a select
+                const int co = min(ks * 16 + kg * 4, D / 2 - 4);   // of whole vectors here puts the arrays on the stack)
+                R.rc[ks] = *reinterpret_cast<const f32x4*>(a.rcos + R.row * a.ldr + co);
+                R.rs[ks] = *reinterpret_cast<const f32x4*>(a.rsin + R.row * a.ldr + co);
+            }
         }
+        if constexpr (!ROPE) {
 #pragma unroll
-        for (int ct = 0; ct < DT; ++ct) {
-            R.km[ct] = f32x4{1.f, 1.f, 1.f, 1.f};
-            if (a.relu && ct * 16 + kg * 4 < D) R.km[ct] = Io<T>::ld4(kb + R.row * a.k.sn + ct * 16 + kg * 4);
+            for (int ct = 0; ct < DT; ++ct) {
+                R.km[ct] = f32x4{1.f, 1.f, 1.f, 1.f};
+                if (a.relu && ct * 16 + kg * 4 < D) R.km[ct] = Io<T>::ld4(kb + R.row * a.k.sn + ct * 16 + kg * 4);
+            }
         }
     };
     fetch(wave, cur);
@@ -941,7 +967,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_bwd_dkv(const TokArgs a) {
             vh[ks] = as_bf16x8(hi);
             vl[ks] = as_bf16x8(lo);
             f32x4 y0 = cur.k[ks][0], y1 = cur.k[ks][1];
-            if (a.relu && ks * 32 + kg * 8 < D) relu8(y0, y1, a.eps);
+            if constexpr (ROPE) rope8(y0, y1, cur.rc[ks], cur.rs[ks]);
+            else if (a.relu && ks * 32 + kg * 8 < D) relu8(y0, y1, a.eps);
             split8(y0, y1, hi, lo);
             kh[ks] = as_bf16x8(hi);
             kl[ks] = as_bf16x8(lo);
@@ -949,6 +976,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_bwd_dkv(const TokArgs a) {
 #pragma unroll
         for (int ct = 0; ct < DT; ++ct) {
             f32x4 ck = {0.f, 0.f, 0.f, 0.f}, cv = ck;
+            f32x2 urc = {1.f, 1.f}, urs = {0.f, 0.f};
+            if constexpr (ROPE) {
+                if (ct * 16 + kg * 4 < D) {
+                    urc = *reinterpret_cast<const f32x2*>(a.rcos + cur.row * a.ldr + ct * 8 + kg * 2);
+                    urs = *reinterpret_cast<const f32x2*>(a.rsin + cur.row * a.ldr + ct * 8 + kg * 2);
+                }
+            }
 #pragma unroll
             for (int ks = 0; ks < KST; ++ks) {
                 // dK^T[d1][s] = sum_d2 dKV[d1][d2] V[s][d2]
@@ -968,11 +1002,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_bwd_dkv(const TokArgs a) {
                 }
             }
             const int d0 = ct * 16 + kg * 4;
+            if constexpr (ROPE) unrope4(ck, urc, urs);
             if (a.normalize && !a.split) ck += *reinterpret_cast<const f32x4*>(dks + d0);
-            if (a.relu)
+            if constexpr (!ROPE) {
+                if (a.relu)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (!(fmaxf(cur.km[ct][i], 0.f) + a.eps > a.eps)) ck[i] = 0.f;
+                    for (int i = 0; i < 4; ++i)
+                        if (!(fmaxf(cur.km[ct][i], 0.f) + a.eps > a.eps)) ck[i] = 0.f;
+            }
             dkst[ct & 1] = ck;
             dvst[ct & 1] = cv;
             if (((ct & 1) || ct == DT - 1) && cur.live) {   // store pairs of feature tiles: whole 128-byte lines (fp32)

@@ -11,7 +11,7 @@ from typing import Dict, Tuple
 import torch
 from torch import nn
 
-from ..ops import lepe3d, mhla_blockmix, mhla_blockmix_wan, qk_prologue, rmsnorm_gate
+from ..ops import lepe3d, mhla_blockmix, mhla_blockmix_rope, mhla_blockmix_wan, qk_prologue, rmsnorm_gate
 from ..weights import block_index_3d
 from .blockconv import BlockDistanceConv3D
 
@@ -159,16 +159,15 @@ class MHLA_Video_Uni(nn.Module):
                 out = lepe3d(v_lepe, self.lepe.weight, self.lepe.bias, grid, add=out)
             return self.o(out)
         elif D % 8 == 0 and C <= 2048:
-            # training: norm + relu + eps and the rotated copy in one kernel per tensor (and one for their backward)
+            # training: norm + relu + eps in one kernel per tensor (and one for its backward); the rotation happens inside the
+            # operator's kernels in both directions (mhla_blockmix_rope_fwd / _bwd): no q_rope / k_rope tensors, and the
+            # operator's backward returns ONE gradient per tensor (rotated part turned back + normaliser part)
             wq = self.norm_q.weight if isinstance(self.norm_q, WanRMSNorm) else None
             wk = self.norm_k.weight if isinstance(self.norm_k, WanRMSNorm) else None
-            q, q_rope = qk_prologue(q, wq, getattr(self.norm_q, "eps", 0.0), self.eps, rope=(cos, sin), head_dim=D)
-            k, k_rope = qk_prologue(k, wk, getattr(self.norm_k, "eps", 0.0), self.eps, rope=(cos, sin), head_dim=D)
-            q, k, q_rope, k_rope, v = (t.reshape(B, N, H, D) for t in (q, k, q_rope, k_rope, v.float()))
-            if self.normalize_out:
-                out = mhla_blockmix(q_rope, k_rope, v, W, eps=self.eps, q_den=q, k_den=k, block_index=idx)
-            else:
-                out = mhla_blockmix(q_rope, k_rope, v, W, eps=self.eps, normalize=False, block_index=idx)
+            q = qk_prologue(q, wq, getattr(self.norm_q, "eps", 0.0), self.eps).reshape(B, N, H, D)
+            k = qk_prologue(k, wk, getattr(self.norm_k, "eps", 0.0), self.eps).reshape(B, N, H, D)
+            out = mhla_blockmix_rope(q, k, v.float().reshape(B, N, H, D), W, cos, sin, eps=self.eps, normalize=self.normalize_out,
+                                     block_index=idx)
         else:
             q, k, v = q.float(), k.float(), v.float()                     # mhla_utils.py:308
             q = torch.relu(self.norm_q(q)) + self.eps                     # :268-272

@@ -244,19 +244,65 @@ def mhla_blockmix(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, W: torch.Te
     return _BlockMix.apply(q, k, v, W, q_den, k_den, block_index, eps, normalize, relu_eps, force_generic, no_smalln)
 
 
-@_device_guard
+class _BlockMixRope(torch.autograd.Function):
+    """mhla_blockmix_rope_fwd / mhla_blockmix_rope_bwd: the operator with the rotation of q, k inside its kernels, both ways."""
+
+    @staticmethod
+    @_device_guard
+    def forward(ctx, q, k, v, W, cos, sin, eps, normalize, block_index):
+        lib = _lib.load()
+        B, N, H, D = q.shape
+        M = W.shape[0]
+        S = N // M
+        q, k, v = _prep(q.detach()), _prep(k.detach()), _prep(v.detach())
+        Wf = W.detach().reshape(M, M).to(torch.float32).contiguous()
+        out = torch.empty((B, N, H, D), dtype=q.dtype, device=q.device)
+        dt = _dtype_code(q)
+        ws = _ws(lib.mhla_blockmix_fwd_ws_bytes(B, H, M, S, D, dt, 0, 0), q.device)
+        rc = lib.mhla_blockmix_rope_fwd(_view(q), _view(k), _view(v), int(bool(normalize)), Wf.data_ptr(), M, cos.data_ptr(),
+                                        sin.data_ptr(), cos.stride(0), _view(out),
+                                        block_index.data_ptr() if block_index is not None else None, ws.data_ptr(),
+                                        ws.numel() * 4, B, H, M, S, D, dt, float(eps), 0, _stream())
+        _lib.check(rc, "mhla_blockmix_rope_fwd")
+        keep = any(ctx.needs_input_grad[:4]) and ws.numel() * 4 <= KEEP_STATE_LIMIT_BYTES   # KV, G, z, ksum, 1/n for the backward
+        ctx.save_for_backward(q, k, v, Wf, out, cos, sin, block_index, ws if keep else None)
+        ctx.cfg = (float(eps), bool(normalize), W.shape, W.dtype)
+        return out
+
+    @staticmethod
+    @_device_guard
+    def backward(ctx, dout):
+        lib = _lib.load()
+        q, k, v, Wf, out, cos, sin, block_index, fwd_ws = ctx.saved_tensors
+        eps, normalize, w_shape, w_dtype = ctx.cfg
+        B, N, H, D = q.shape
+        M = Wf.shape[0]
+        S = N // M
+        dout = _prep(dout.to(q.dtype))
+        dq = _alloc_like_tokens(B, N, H, D, q)
+        dk = _alloc_like_tokens(B, N, H, D, q)
+        dv = _alloc_like_tokens(B, N, H, D, q)
+        dW = torch.empty((M, M), dtype=torch.float32, device=q.device)
+        dt = _dtype_code(q)
+        ws = _ws(lib.mhla_blockmix_bwd_ws_bytes(B, H, M, S, D, dt, 0, 0), q.device)
+        rc = lib.mhla_blockmix_rope_bwd(_view(q), _view(k), _view(v), int(normalize), Wf.data_ptr(), M, cos.data_ptr(),
+                                        sin.data_ptr(), cos.stride(0), _view(out), _view(dout), _view(dq), _view(dk), _view(dv),
+                                        dW.data_ptr(), block_index.data_ptr() if block_index is not None else None,
+                                        ws.data_ptr(), ws.numel() * 4, fwd_ws.data_ptr() if fwd_ws is not None else None,
+                                        B, H, M, S, D, dt, eps, 0, _stream())
+        _lib.check(rc, "mhla_blockmix_rope_bwd")
+        return dq, dk, dv, dW.reshape(w_shape).to(w_dtype), None, None, None, None, None
+
+
 def mhla_blockmix_rope(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, W: torch.Tensor, rope_cos: torch.Tensor,
                        rope_sin: torch.Tensor, *, eps: float = 1e-6, normalize: bool = True,
                        block_index: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Block-mixing operator with Wan's rotary prologue fused in (wan/mhla_utils.py:314 + :317-341), inference only.
+    """Block-mixing operator with Wan's rotary prologue fused in (wan/mhla_utils.py:314 + :317-341), forward and backward.
 
     q, k are the un-rotated tensors ([B, N, H, D]); rope_cos / rope_sin are fp32 [N, D/2] (the multiplier of `rope_apply`
     per token row).  Rotated k feeds KV, rotated q the numerator, plain q / k the normaliser -- no q_rope / k_rope
-    tensors are materialised.  Not differentiable: raises if an input requires grad while grad mode is on (apply the
-    rotation in the host and call `mhla_blockmix` with q_den / k_den for training)."""
-    lib = _lib.load()
-    if torch.is_grad_enabled() and any(t.requires_grad for t in (q, k, v, W)):
-        raise RuntimeError("mhla_blockmix_rope is forward-only; use mhla_blockmix(q_rope, k_rope, v, W, q_den=q, k_den=k) for training")
+    tensors are materialised, in either direction: the backward rotates q and k again where the rotated ones are needed and
+    returns the gradients w.r.t. the un-rotated tensors (fp32 tensors, D % 8 == 0 for the backward)."""
     _require_gpu(q, k, v, W, rope_cos, rope_sin, block_index)
     if block_index is not None and (block_index.dtype != torch.int32 or not block_index.is_contiguous()):
         raise TypeError("block_index must be a contiguous int32 tensor")
@@ -264,23 +310,14 @@ def mhla_blockmix_rope(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, W: tor
     M = W.shape[0]
     if N % M:
         raise ValueError(f"N={N} tokens not divisible into M={M} blocks")
-    S = N // M
     _check_like(q, "mhla_blockmix_rope", k=(k, q.shape), v=(v, q.shape))
     _check_block_index(block_index, N, q)
     if rope_cos.shape != (N, D // 2) or rope_sin.shape != (N, D // 2) or rope_cos.dtype != torch.float32 or rope_sin.dtype != torch.float32:
         raise ValueError(f"rope tables must be fp32 [N={N}, D/2={D // 2}]")
-    q, k, v = _prep(q.detach()), _prep(k.detach()), _prep(v.detach())
-    cos, sin = rope_cos.contiguous(), rope_sin.contiguous()
-    Wf = W.detach().reshape(M, M).to(torch.float32).contiguous()
-    out = torch.empty((B, N, H, D), dtype=q.dtype, device=q.device)
-    dt = _dtype_code(q)
-    ws = _ws(lib.mhla_blockmix_fwd_ws_bytes(B, H, M, S, D, dt, 0, 0), q.device)
-    rc = lib.mhla_blockmix_rope_fwd(_view(q), _view(k), _view(v), int(bool(normalize)), Wf.data_ptr(), M, cos.data_ptr(),
-                                    sin.data_ptr(), cos.stride(0), _view(out),
-                                    block_index.data_ptr() if block_index is not None else None, ws.data_ptr(),
-                                    ws.numel() * 4, B, H, M, S, D, dt, float(eps), 0, _stream())
-    _lib.check(rc, "mhla_blockmix_rope_fwd")
-    return out
+    if torch.is_grad_enabled() and any(t.requires_grad for t in (q, k, v, W)) and (q.dtype != torch.float32 or D % 8):
+        raise RuntimeError("the backward of mhla_blockmix_rope needs fp32 tensors with D % 8 == 0; rotate in the host and call "
+                           "mhla_blockmix(q_rope, k_rope, v, W, q_den=q, k_den=k) otherwise")
+    return _BlockMixRope.apply(q, k, v, W, rope_cos.contiguous(), rope_sin.contiguous(), eps, normalize, block_index)
 
 
 # ------------------------------------------------------------------------------------------

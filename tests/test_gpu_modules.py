@@ -294,8 +294,24 @@ def test_qk_prologue_and_rope_op():
         got = mhla_amd.mhla_blockmix_rope(q.to(DEV), k.to(DEV), v.to(DEV), W.to(DEV), cos, sin, eps=1e-6, normalize=normalize,
                                           block_index=idx.to(DEV))
         check(f"rope op normalize={normalize}", got[:, idx.long().to(DEV)], want, 1e-4)
-    with pytest.raises(RuntimeError):
-        mhla_amd.mhla_blockmix_rope(q.to(DEV).requires_grad_(True), k.to(DEV), v.to(DEV), W.to(DEV), cos, sin)
+    # backward (mhla_blockmix_rope_bwd): gradients w.r.t. the UN-rotated q, k -- the transposed rotation of the numerator pair's
+    # gradients plus the normaliser pair's -- against autograd through the oracle's rope_apply + split-pair operator
+    do = torch.randn(B, N, H, D, generator=g)
+    for normalize in (True, False):
+        ref = [t.clone().requires_grad_(True) for t in (q, k, v, W)]
+        qr_, kr_ = orc.wan_rope_apply(ref[0], (F_, H_, W_), freqs), orc.wan_rope_apply(ref[1], (F_, H_, W_), freqs)
+        o_ref = orc.blockmix_fwd(gather(qr_), gather(kr_), gather(ref[2]), ref[3], 1e-6, q_den=gather(ref[0]), k_den=gather(ref[1]),
+                                 normalize=normalize)
+        (o_ref * gather(do)).sum().backward()
+        dev = [t.to(DEV).requires_grad_(True) for t in (q, k, v, W)]
+        poison()
+        o = mhla_amd.mhla_blockmix_rope(*dev, cos, sin, eps=1e-6, normalize=normalize, block_index=idx.to(DEV))
+        poison()
+        o.backward(do.to(DEV))
+        for name, a_, b_ in zip(("dq", "dk", "dv", "dW"), dev, ref):
+            check(f"rope op {name} normalize={normalize}", a_.grad, b_.grad, 2e-4)
+    with pytest.raises(RuntimeError):   # the rotary backward is built for fp32 tensors
+        mhla_amd.mhla_blockmix_rope(q.to(DEV).bfloat16().requires_grad_(True), k.to(DEV).bfloat16(), v.to(DEV).bfloat16(), W.to(DEV), cos, sin)
     # prologue + epilogue fused: rotary inside, per-head RMSNorm x SiLU gate before the store, output in the host dtype
     nw = torch.rand(D, generator=g) + 0.5
     for odt in (torch.bfloat16, torch.float32):
