@@ -62,11 +62,22 @@ __device__ __forceinline__ void cs_stage_state(u16* __restrict__ dst, const u16*
 // The two stagings in halves (loads now, LDS writes later), for kernels that fetch the next round's tiles while the current
 // round is multiplied.  Rows >= rv read the chunk's first row (a valid address) and are zeroed on the way into LDS.
 struct CsTile { uint4 x, y; };
+#ifndef CSF_NT_TOK
+#define CSF_NT_TOK 0
+#endif
+#ifndef CSF_NT_STATE
+#define CSF_NT_STATE 0
+#endif
 __device__ __forceinline__ void cs_issue_tok(CsTile& t, const u16* __restrict__ base, long sn, long p0, int rv, int tid) {
     const int r = tid >> 2, c = (tid & 3) * 16;
     const u16* src = base + (p0 + (r < rv ? r : 0)) * sn + c;
+#if CSF_NT_TOK
+    t.x = gld_stream16(src);
+    t.y = gld_stream16(src + 8);
+#else
     t.x = gld<uint4>(src);
     t.y = gld<uint4>(src + 8);
+#endif
 }
 __device__ __forceinline__ void cs_commit_tok(u16* __restrict__ dst, const CsTile& t, int rv, int tid) {
     const int r = tid >> 2, c = (tid & 3) * 16;
@@ -77,8 +88,13 @@ __device__ __forceinline__ void cs_commit_tok(u16* __restrict__ dst, const CsTil
 __device__ __forceinline__ void cs_issue_state(CsTile& t, const u16* __restrict__ src, long ld, int tid) {
     const int r = tid >> 2, c = (tid & 3) * 16;
     const u16* s = src + (long)r * ld + c;
+#if CSF_NT_STATE
+    t.x = gld_stream16(s);
+    t.y = gld_stream16(s + 8);
+#else
     t.x = gld<uint4>(s);
     t.y = gld<uint4>(s + 8);
+#endif
 }
 __device__ __forceinline__ void cs_commit_state(u16* __restrict__ dst, const CsTile& t, int tid) {
     const int r = tid >> 2, c = (tid & 3) * 16;

@@ -102,6 +102,11 @@ class MHLA4DiT(nn.Module):
                 q = qk_prologue(qkv[:, :, 0].reshape(B, M * S, H * D), self.q_norm.weight, eq, self.eps)
                 k = qk_prologue(qkv[:, :, 1].reshape(B, M * S, H * D), self.k_norm.weight, ek, self.eps)
             else:
+                if not getattr(self, "_warned_eager_prologue", False):
+                    import warnings
+                    warnings.warn(f"MHLA module: inner dim {H * D} (not a multiple of 8, or > 4096): q_norm / k_norm + relu + eps run as "
+                                  "eager PyTorch ops instead of the fused HIP prologue", stacklevel=2)
+                    self._warned_eager_prologue = True
                 q = torch.relu(self.q_norm(qkv[:, :, 0].reshape(B, M * S, H * D))) + self.eps
                 k = torch.relu(self.k_norm(qkv[:, :, 1].reshape(B, M * S, H * D))) + self.eps
             q, k = q.to(qkv.dtype), k.to(qkv.dtype)

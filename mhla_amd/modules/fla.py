@@ -8,9 +8,11 @@ kernels; rotary is plain tensor math (NeoX half rotation, rotary.py:20-32) -- no
 
 Deviations, all documented in SURVEY.md: sequences of <= 64 tokens use the single-chunk case of the
 chunk operator (the reference's token-recurrent form equals it only on the first chunk and ignores
-its initial state); `use_short_conv=True` is not supported (the reference's ShortConvolution is a
-separate fla module outside the MHLA path).
+its initial state).  `use_short_conv=True` (off in the shipped configuration; the reference's
+ShortConvolution is a sibling fla module outside the MHLA hot path) is served by a plain-PyTorch
+`ShortConvolution` with the reference's parameters and cache protocol (no HIP kernel: not on the path).
 """
+import warnings
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -61,17 +63,87 @@ class RotaryEmbedding(nn.Module):
             self._cache = c
         return c[3], c[4]
 
-    def forward(self, q, k, seqlen_offset: int = 0, max_seqlen: Optional[int] = None, cu_seqlens=None):
+    def forward(self, q, k, seqlen_offset: int = 0, max_seqlen: Optional[int] = None, cu_seqlens=None, positions=None):
+        """`positions` [T] (long): the rotary position of every token row -- packed sequences restart per sequence
+        (rotary.py:68-72 with cu_seqlens), padded decoding adds each sequence's own offset (layers/mhla.py:305-309)."""
         T = q.shape[1]
-        cos, sin = self._tables(max(max_seqlen or 0, T + seqlen_offset), q.device, q.dtype)
-        cos = cos[seqlen_offset:seqlen_offset + T][None, :, None, :]
-        sin = sin[seqlen_offset:seqlen_offset + T][None, :, None, :]
+        if positions is not None:
+            cos, sin = self._tables(max(max_seqlen or 0, T + int(seqlen_offset if isinstance(seqlen_offset, int) else 0)), q.device, q.dtype)
+            cos, sin = cos.index_select(0, positions)[None, :, None, :], sin.index_select(0, positions)[None, :, None, :]
+        else:
+            cos, sin = self._tables(max(max_seqlen or 0, T + seqlen_offset), q.device, q.dtype)
+            cos = cos[seqlen_offset:seqlen_offset + T][None, :, None, :]
+            sin = sin[seqlen_offset:seqlen_offset + T][None, :, None, :]
 
         def rot(x):
             x1, x2 = x.chunk(2, dim=-1)
             return torch.cat((x1 * cos - x2 * sin, x2 * cos + x1 * sin), dim=-1)
 
         return rot(q), rot(k)
+
+
+class ShortConvolution(nn.Conv1d):
+    """Depthwise causal 1-D convolution (+ SiLU) of `fla/modules/convolution.py:794-1010` in plain PyTorch: parameters
+    `weight [D, 1, W]` (+ `bias`), `forward(x [B, T, D], residual, mask, cache [N, D, W], output_final_state, cu_seqlens)
+    -> (y, cache)`.  y_t = act(sum_i w[i] x[t - (W - 1) + i] + b); positions before a sequence start read the cache's last
+    W - 1 columns (zeros without a cache); with `cu_seqlens` (B = 1) the convolution does not cross sequence boundaries; a
+    single new token per sequence (B T == N) is the decoding step, which rolls the cache in place (:963-1002).  Outside the
+    MHLA hot path (SURVEY.md 2.3 marks it OUT), hence no HIP kernel."""
+
+    def __init__(self, hidden_size: int, kernel_size: int, bias: bool = False, activation: Optional[str] = "silu", **kwargs):
+        super().__init__(hidden_size, hidden_size, kernel_size, groups=hidden_size, bias=bias, padding=kernel_size - 1)
+        self.hidden_size = hidden_size
+        if activation is not None and activation not in ("silu", "swish"):
+            raise ValueError(f"Activation `{activation}` not supported yet.")
+        self.activation = activation
+
+    def _act(self, y):
+        return F.silu(y) if self.activation is not None else y
+
+    def forward(self, x, residual=None, mask=None, cache=None, output_final_state=False, cu_seqlens=None, **kwargs):
+        B, T, D = x.shape
+        W = self.kernel_size[0]
+        N = B if cu_seqlens is None else len(cu_seqlens) - 1
+        if mask is not None:
+            if cu_seqlens is not None:
+                raise ValueError("`mask` and `cu_seqlens` cannot be provided at the same time")
+            x = x * mask.unsqueeze(-1)
+        w = self.weight.squeeze(1)                                           # [D, W]
+        if B * T == N:                                                       # decoding step (:927-935)
+            xt = x.reshape(N, D)
+            if cache is None:
+                cache = x.new_zeros(N, D, W)
+            cache.copy_(torch.cat([cache[..., 1:], xt.unsqueeze(-1)], dim=-1))
+            y = (cache * w).sum(-1)
+            if self.bias is not None:
+                y = y + self.bias
+            y = self._act(y).reshape(x.shape)
+            return (y + residual if residual is not None else y), cache
+
+        def one(seq, init):                                                  # seq [b, t, D], init [b, D, W] or None
+            hist = init[..., 1:] if init is not None else seq.new_zeros(seq.shape[0], D, W - 1)
+            xin = torch.cat([hist.to(seq.dtype), seq.transpose(1, 2)], dim=-1)
+            y = F.conv1d(xin, self.weight, self.bias, groups=D).transpose(1, 2)
+            full = torch.cat([init.to(seq.dtype) if init is not None else seq.new_zeros(seq.shape[0], D, W), seq.transpose(1, 2)], dim=-1)
+            return self._act(y), full[..., -W:]
+
+        if cu_seqlens is None:
+            y, final = one(x, cache)
+        else:
+            ys, finals = [], []
+            cu = [int(c) for c in cu_seqlens]
+            for i in range(N):
+                yi, fi = one(x[:, cu[i]:cu[i + 1]], None if cache is None else cache[i:i + 1])
+                ys.append(yi)
+                finals.append(fi)
+            y, final = torch.cat(ys, dim=1), torch.cat(finals, dim=0)
+        if residual is not None:
+            y = y + residual
+        return y, (final if output_final_state else None)
+
+    @property
+    def state_size(self) -> int:
+        return self.hidden_size * self.kernel_size[0]
 
 
 def _elu1(x):
@@ -118,15 +190,19 @@ class MHLA(nn.Module):
             self.feature_map_q = self.feature_map_k = _elu1
         else:
             raise NotImplementedError(f"Not supported feature map `{feature_map}`.")
-        if use_short_conv:
-            raise NotImplementedError("use_short_conv=True is outside the MHLA path built here")
-        self.use_short_conv = False
+        self.use_short_conv = use_short_conv
+        self.conv_size = conv_size
+        self.conv_bias = conv_bias
 
         self.q_proj = nn.Linear(hidden_size, self.key_dim, bias=False)
         self.k_proj = nn.Linear(hidden_size, self.key_dim_per_group, bias=False)
         self.v_proj = nn.Linear(hidden_size, self.value_dim_per_group, bias=False)
         if self.use_output_gate:
             self.g_proj = nn.Linear(hidden_size, self.value_dim, bias=False)
+        if use_short_conv:                                                   # layers/mhla.py:175-194
+            self.q_conv1d = ShortConvolution(self.key_dim, conv_size, bias=conv_bias, activation="silu")
+            self.k_conv1d = ShortConvolution(self.key_dim_per_group, conv_size, bias=conv_bias, activation="silu")
+            self.v_conv1d = ShortConvolution(self.value_dim_per_group, conv_size, bias=conv_bias, activation="silu")
         self.max_chunks = int(max_chunks)
         self.mixing_matrix = nn.Parameter(causal_mixing_init(self.max_chunks))   # layers/mhla.py:196-200 (32 there)
         self.o_proj = nn.Linear(self.value_dim, hidden_size, bias=False)
@@ -162,9 +238,20 @@ class MHLA(nn.Module):
             cu_seqlens = F.pad(m.sum(-1, dtype=torch.int32).cumsum(0, dtype=torch.int32), (1, 0))
             hidden_states = hidden_states.reshape(batch_size * q_len, -1).index_select(0, indices).unsqueeze(0)
         B, T, _ = hidden_states.shape
-        q = self.q_proj(hidden_states).reshape(B, T, self.num_heads, self.head_k_dim)
-        k = self.k_proj(hidden_states)
-        v = self.v_proj(hidden_states)
+        conv_states = None
+        if self.use_short_conv:                                              # :258-279
+            cq = ck = cv = None
+            if last_state is not None and last_state.get("conv_state") is not None:
+                cq, ck, cv = last_state["conv_state"]
+            q, cq = self.q_conv1d(x=self.q_proj(hidden_states), cache=cq, output_final_state=use_cache, cu_seqlens=cu_seqlens)
+            k, ck = self.k_conv1d(x=self.k_proj(hidden_states), cache=ck, output_final_state=use_cache, cu_seqlens=cu_seqlens)
+            v, cv = self.v_conv1d(x=self.v_proj(hidden_states), cache=cv, output_final_state=use_cache, cu_seqlens=cu_seqlens)
+            conv_states = (cq, ck, cv)
+            q = q.reshape(B, T, self.num_heads, self.head_k_dim)
+        else:
+            q = self.q_proj(hidden_states).reshape(B, T, self.num_heads, self.head_k_dim)
+            k = self.k_proj(hidden_states)
+            v = self.v_proj(hidden_states)
         if self.num_kv_groups > 1:                                           # :290-292 (repeat '(h g) d')
             k = k.reshape(B, T, self.num_kv_heads, 1, self.head_k_dim).expand(-1, -1, -1, self.num_kv_groups, -1)
             v = v.reshape(B, T, self.num_kv_heads, 1, self.head_v_dim).expand(-1, -1, -1, self.num_kv_groups, -1)
@@ -173,24 +260,34 @@ class MHLA(nn.Module):
         seqlen_offset = 0
         if past_key_values is not None and hasattr(past_key_values, "get_seq_length"):
             seqlen_offset = past_key_values.get_seq_length(self.layer_idx)    # :301-303
+        # rotary position of every token row: packed sequences restart at every sequence start (rotary.py:68-72 with cu_seqlens);
+        # with a padding mask AND a cache offset every sequence continues from its own length (prepare_lens_from_mask, :305-309)
+        positions = None
+        if cu_seqlens is not None:
+            tpos = torch.arange(T, device=q.device)
+            cu = cu_seqlens.to(q.device).long()
+            seq = torch.searchsorted(cu, tpos, right=True) - 1
+            offs = seqlen_offset
+            if attention_mask is not None and seqlen_offset > 0:
+                offs = (attention_mask.sum(-1).to(q.device).long() - q_len)[seq]
+            positions = tpos - cu[seq] + offs
+        table_len = T + seqlen_offset if positions is None else (
+            (int(attention_mask.shape[1]) if attention_mask is not None and seqlen_offset > 0 else T + seqlen_offset))
         if self.head_k_dim % 8 == 0:
             # feature map (:297-299) + rotary (:311) in one HIP kernel per tensor and direction
-            if cu_seqlens is not None:
-                # packed sequences: positions restart at every sequence start, as the reference's rotary does with cu_seqlens
-                # (rotary.py:68-72) -- per-token rows of the tables, gathered once
-                tpos = torch.arange(T, device=q.device)
-                cu = cu_seqlens.to(q.device).long()
-                pos = tpos - cu[torch.searchsorted(cu, tpos, right=True) - 1] + seqlen_offset
-                cos, sin = self.rotary._tables(int(pos.max().item()) + 1, q.device, q.dtype)
-                cos, sin, t_off = cos.index_select(0, pos), sin.index_select(0, pos), 0
-            else:
-                cos, sin = self.rotary._tables(T + seqlen_offset, q.device, q.dtype)
-                t_off = seqlen_offset
+            cos, sin = self.rotary._tables(table_len, q.device, q.dtype)
+            t_off = seqlen_offset
+            if positions is not None:   # per-token rows of the tables, gathered once
+                cos, sin, t_off = cos.index_select(0, positions), sin.index_select(0, positions), 0
             q = featmap_rotary(q, cos, sin, self._fmap_name, t_off)
             k = featmap_rotary(k, cos, sin, self._fmap_name, t_off)
         else:
+            if not getattr(self, "_warned_eager_rotary", False):
+                warnings.warn(f"MHLA: head_k_dim={self.head_k_dim} is not a multiple of 8: feature map and rotary run as eager "
+                              "PyTorch ops (about ten elementwise passes per tensor) instead of the fused HIP kernel", stacklevel=2)
+                self._warned_eager_rotary = True
             q, k = self.feature_map_q(q), self.feature_map_k(k)              # :297-299
-            q, k = self.rotary(q, k, seqlen_offset=seqlen_offset)            # :311
+            q, k = self.rotary(q, k, seqlen_offset=seqlen_offset, max_seqlen=table_len, positions=positions)   # :311
         recurrent_state = last_state["recurrent_state"] if last_state is not None else None
         fused_epilogue = self.use_output_gate and self.fuse_norm_and_gate and q_len > 64
         if fused_epilogue:
@@ -201,13 +298,19 @@ class MHLA(nn.Module):
             o = mhla_causal_normgate(q, k, v, self.mixing_matrix, g, gn.weight, gn.eps).reshape(B, T, self.value_dim)
             recurrent_state = None
         elif q_len <= 64:                                                    # :247, :318-327: the token-recurrent form
+            if T > 64 and not getattr(self, "_warned_recurrent_packed", False):
+                warnings.warn(f"MHLA: a padded batch of {batch_size} x {q_len} tokens unpads to one packed sequence of {T} > 64 tokens; "
+                              "the recurrent branch then runs the multi-chunk chunk operator (the reference's recurrent form reads "
+                              "shifted states beyond the first chunk -- not replicated, see naive_recurrent_mhla)", stacklevel=2)
+                self._warned_recurrent_packed = True
             o, recurrent_state = naive_recurrent_mhla(q, k, v, self.mixing_matrix, initial_state=recurrent_state,
                                                       output_final_state=bool(use_cache))
         else:                                                                # :330-337
             o = mhla_causal(q, k, v, self.mixing_matrix)
             recurrent_state = None
         if past_key_values is not None and hasattr(past_key_values, "update"):   # :339-345
-            past_key_values.update(recurrent_state=recurrent_state, conv_state=None, layer_idx=self.layer_idx, offset=q_len)
+            past_key_values.update(recurrent_state=recurrent_state, conv_state=conv_states if self.use_short_conv else None,
+                                   layer_idx=self.layer_idx, offset=q_len)
         if fused_epilogue:
             pass
         elif self.use_output_gate:

@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import functools
 import os
+import warnings
 from typing import Optional
 
 import torch
@@ -895,6 +896,11 @@ def naive_recurrent_mhla(q, k, v, mixing_matrix, chunk_size: int = 64, scale: Op
     `naive_chunk_simple_mhla_fixed` instead; (2) the reference ignores `scale` (naive.py:101 overwrites it with K**-0.5) and
     `initial_state` only seeds the returned tensor `S`, never the output (naive.py:113-116) -- both reproduced: `scale` is
     ignored, and `S` is `initial_state` (or zeros) [B, H, K, V] in fp32, `None` when `output_final_state` is False."""
+    if scale is not None and abs(float(scale) - q.shape[-1] ** -0.5) > 1e-12:
+        warnings.warn("naive_recurrent_mhla ignores `scale` (the reference overwrites it with K**-0.5, naive.py:101)", stacklevel=2)
+    if q.shape[1] > chunk_size:
+        warnings.warn(f"naive_recurrent_mhla on T={q.shape[1]} > chunk_size={chunk_size} tokens runs the chunk operator; the reference's "
+                      "recurrent form reads every earlier chunk's state shifted by one there (naive.py:124-133, not replicated)", stacklevel=2)
     o = mhla_causal(q, k, v, mixing_matrix, chunk_size, None)
     S = None
     if output_final_state:

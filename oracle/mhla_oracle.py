@@ -503,25 +503,56 @@ def wan_variant_forward(kind: str, sd: dict, x: torch.Tensor, grid: Tuple[int, i
     raise ValueError(kind)
 
 
+def short_conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, activation: Optional[str] = "silu",
+               cu_seqlens=None, initial_state: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``ShortConvolution.forward`` -- ``mhla_nlp/fla/modules/convolution.py:889-964`` (torch twin of the Triton kernel):
+    depthwise causal conv, y[t] = act(sum_i w[d, i] x[t - (W - 1) + i] + b[d]); before a sequence start the inputs are the last
+    W - 1 columns of ``initial_state [N, D, W]`` (zeros without one); sequences of a packed batch (``cu_seqlens``) do not see
+    each other.  x: [B, T, D], weight: [D, 1, W] or [D, W]."""
+    w = weight.reshape(weight.shape[0], -1)
+    D, W = w.shape
+    B, T, _ = x.shape
+    bounds = [(b, 0, T) for b in range(B)] if cu_seqlens is None else [(0, int(cu_seqlens[i]), int(cu_seqlens[i + 1])) for i in range(len(cu_seqlens) - 1)]
+    y = torch.zeros_like(x)
+    for n, (b, t0, t1) in enumerate(bounds):
+        for t in range(t0, t1):
+            acc = torch.zeros(D, dtype=x.dtype)
+            for i in range(W):
+                src = t - (W - 1) + i
+                if src >= t0:
+                    acc = acc + w[:, i] * x[b, src]
+                elif initial_state is not None:
+                    acc = acc + w[:, i] * initial_state[n, :, W + (src - t0)]
+            y[b, t] = acc + (bias if bias is not None else 0)
+    return F.silu(y) if activation is not None else y
+
+
 def fla_layer_forward(sd: dict, x: torch.Tensor, heads: int, head_k: int, head_v: int,
                       norm_eps: float = 1e-5, chunk_size: int = 64, attention_mask: Optional[torch.Tensor] = None,
                       num_kv_heads: Optional[int] = None, feature_map: str = "relu", use_output_gate: bool = True,
-                      gate_fn: str = "swish") -> torch.Tensor:
+                      gate_fn: str = "swish", use_short_conv: bool = False,
+                      position_offsets: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``MHLA.forward`` (fla layer, no short conv, no cache) -- ``mhla_nlp/fla/layers/mhla.py:226-365``.  Defaults: the shipped
     configuration (``feature_map='relu'``, fused swish gate).  Options restated from the same file: grouped k / v heads
     (``num_kv_heads``, :290-292), ``feature_map`` in relu / elu (= elu + 1, :130-134) / identity, ``use_output_gate=False``
-    (plain per-head RMSNorm, :357-358), a ``gate_fn`` other than swish (RMSNorm, then ``o * gate_fn(g)``, :355-356).
+    (plain per-head RMSNorm, :357-358), a ``gate_fn`` other than swish (RMSNorm, then ``o * gate_fn(g)``, :355-356),
+    ``use_short_conv`` (q / k / v through ``short_conv`` after their projections, :258-279), ``position_offsets`` [B] (the
+    per-sequence rotary offsets of padded decoding, ``prepare_lens_from_mask(mask) - q_len``, :305-309).
     With a 0/1 ``attention_mask`` [B, T] the batch is
     unpadded into ONE packed sequence (:253-256), rotary positions restart per sequence (cu_seqlens, :311), the operator runs
     over the whole packed sequence (it ignores cu_seqlens: cross-sequence leakage, as in the reference, :330-336) and the
     result is padded back with zeros (:362-363)."""
-    opts = dict(num_kv_heads=num_kv_heads, feature_map=feature_map, use_output_gate=use_output_gate, gate_fn=gate_fn)
+    opts = dict(num_kv_heads=num_kv_heads, feature_map=feature_map, use_output_gate=use_output_gate, gate_fn=gate_fn,
+                use_short_conv=use_short_conv)
     if attention_mask is not None:
         Bm, Tm, C = x.shape
         keep = attention_mask.flatten().nonzero().flatten()
         lens = attention_mask.sum(-1)
-        pos = torch.cat([torch.arange(int(n)) for n in lens])
-        y = _fla_layer_core(sd, x.reshape(Bm * Tm, C)[keep].unsqueeze(0), heads, head_k, head_v, norm_eps, chunk_size, pos, **opts)
+        offs = position_offsets if position_offsets is not None else torch.zeros_like(lens)
+        pos = torch.cat([torch.arange(int(n)) + int(o) for n, o in zip(lens, offs)])
+        cu = F.pad(lens.cumsum(0), (1, 0))
+        y = _fla_layer_core(sd, x.reshape(Bm * Tm, C)[keep].unsqueeze(0), heads, head_k, head_v, norm_eps, chunk_size, pos,
+                            cu_seqlens=cu, **opts)
         out = y.new_zeros(Bm * Tm, y.shape[-1])
         out[keep] = y.squeeze(0)
         return out.reshape(Bm, Tm, -1)
@@ -529,16 +560,19 @@ def fla_layer_forward(sd: dict, x: torch.Tensor, heads: int, head_k: int, head_v
 
 
 def _fla_layer_core(sd, x, heads, head_k, head_v, norm_eps, chunk_size, positions, num_kv_heads=None, feature_map="relu",
-                    use_output_gate=True, gate_fn="swish"):
+                    use_output_gate=True, gate_fn="swish", use_short_conv=False, cu_seqlens=None):
     B, T, C = x.shape
     kvh = heads if num_kv_heads is None else num_kv_heads
     groups = heads // kvh
     # :237 -- clamp(...).tril() on the [L, L, 1, 1, 1, 1] parameter: tril acts on the trailing 1x1 dims, a no-op;
     # the op reads only j <= i anyway
     mix = torch.clamp(sd["mixing_matrix"], 1e-5, 1).tril().reshape(sd["mixing_matrix"].shape[0], -1)
-    q = F.linear(x, sd["q_proj.weight"]).reshape(B, T, heads, head_k)             # :281-295
-    k = F.linear(x, sd["k_proj.weight"]).reshape(B, T, kvh, head_k)
-    v = F.linear(x, sd["v_proj.weight"]).reshape(B, T, kvh, head_v)
+    q, k, v = F.linear(x, sd["q_proj.weight"]), F.linear(x, sd["k_proj.weight"]), F.linear(x, sd["v_proj.weight"])   # :281-283
+    if use_short_conv:                                                             # :258-279
+        q = short_conv(q, sd["q_conv1d.weight"], sd.get("q_conv1d.bias"), "silu", cu_seqlens)
+        k = short_conv(k, sd["k_conv1d.weight"], sd.get("k_conv1d.bias"), "silu", cu_seqlens)
+        v = short_conv(v, sd["v_conv1d.weight"], sd.get("v_conv1d.bias"), "silu", cu_seqlens)
+    q, k, v = q.reshape(B, T, heads, head_k), k.reshape(B, T, kvh, head_k), v.reshape(B, T, kvh, head_v)   # :289-295
     if groups > 1:                                                                 # :290-292  '(h d) -> (h g) d'
         k = k.repeat_interleave(groups, dim=2)
         v = v.repeat_interleave(groups, dim=2)

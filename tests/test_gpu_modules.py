@@ -555,6 +555,8 @@ def test_wan_block_shell():
     dict(gate_fn="sigmoid"),                                # RMSNorm, then o * sigmoid(g) (:355-356)
     dict(feature_map="elu"),                                # elu + 1 (:130-134)
     dict(num_kv_heads=1, feature_map="identity", gate_fn="sigmoid"),
+    dict(use_short_conv=True, conv_size=4),                 # q / k / v through the short convolutions (:258-279)
+    dict(use_short_conv=True, conv_size=3, conv_bias=True, num_kv_heads=2),
 ])
 def test_fla_layer_options_match_oracle_restatement(opts):
     """The fla layer's non-default constructor options on the GPU -- GQA, no output gate, a non-swish gate, other feature maps --
@@ -570,7 +572,10 @@ def test_fla_layer_options_match_oracle_restatement(opts):
     x = torch.randn(2, 300, 128)
     sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
     okw = dict(norm_eps=1e-6, num_kv_heads=opts.get("num_kv_heads"), feature_map=opts.get("feature_map", "relu"),
-               use_output_gate=opts.get("use_output_gate", True), gate_fn=opts.get("gate_fn", "swish"))
+               use_output_gate=opts.get("use_output_gate", True), gate_fn=opts.get("gate_fn", "swish"),
+               use_short_conv=opts.get("use_short_conv", False))
+    if opts.get("use_short_conv"):
+        x = x[:, :140]   # (the oracle's short convolution is a plain Python loop)
     sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     xr = x.clone().requires_grad_(True)
     want = orc.fla_layer_forward(sdr, xr, heads, hk, hv, **okw)
@@ -635,3 +640,40 @@ def test_wan_block_host_matches_cpu_composition():
             assert refp[name].grad is None or float(refp[name].grad.abs().max()) == 0.0, name
             continue
         check(f"grad {name}", prm.grad, refp[name].grad, 2e-4, atol=1e-7)
+
+
+def test_fla_layer_padded_decoding_offsets():
+    """layers/mhla.py:305-309: with a padding mask AND a non-empty cache the rotary offset of every sequence is its own length
+    so far (prepare_lens_from_mask(mask) - q_len), not the cache's scalar length.  A left-aligned mask over [past + new] tokens,
+    a cache that reports `past` tokens; the oracle restatement gets the same per-sequence offsets."""
+    from mhla_amd import modules
+    torch.manual_seed(4)
+    heads, hk, hv, q_len = 2, 32, 64, 96
+    m = modules.MHLA(mode="chunk", hidden_size=64, expand_k=1.0, expand_v=2.0, num_heads=heads, feature_map="relu", norm_eps=1e-6,
+                     layer_idx=0)
+    with torch.no_grad():
+        m.mixing_matrix.copy_(torch.rand(32, 32).view(32, 32, 1, 1, 1, 1).clamp_(1e-5, 1))
+    x = torch.randn(3, q_len, 64)
+    total = torch.tensor([q_len + 40, q_len + 7, q_len + 25])          # tokens each sequence has seen including the new ones
+    mask = (torch.arange(int(total.max()))[None, :] < total[:, None]).long()    # [B, past + new]; the layer looks at the last q_len columns
+
+    class Cache:
+        def __len__(self):
+            return 1
+
+        def __getitem__(self, i):
+            return {"recurrent_state": None, "conv_state": None}
+
+        def get_seq_length(self, layer_idx=0):
+            return 40
+
+        def update(self, **kw):
+            self.last = kw
+
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    new_mask = mask[:, -q_len:]
+    want = orc.fla_layer_forward(sd, x, heads, hk, hv, norm_eps=1e-6, attention_mask=new_mask,
+                                 position_offsets=mask.sum(-1) - q_len)
+    o, _, cache = m.to(DEV)(x.to(DEV), attention_mask=mask.to(DEV), past_key_values=Cache(), use_cache=True)
+    check("o (padded decoding)", o, want, 1e-4)
+    assert cache.last["offset"] == q_len

@@ -254,3 +254,30 @@ def test_c1_dit_s2_single_latent_cpu_plumbing():
     tok = torch.arange(256)
     assert torch.equal(tok[m.to_block_major][m.to_raster], tok)
     print(f"C1 DiT-S/2 256x256 single latent, CPU eager (oracle attention): {dt * 1e3:.0f} ms per forward, {256 / dt:.0f} tokens/s")
+
+
+def test_short_convolution_matches_oracle_restatement():
+    """The fla layer's optional ShortConvolution (plain PyTorch, host side): full sequences, continuation from a cache, the
+    single-token decoding steps and packed sequences, against the oracle's explicit-loop restatement."""
+    import torch
+    from oracle import mhla_oracle as orc
+    from mhla_amd.modules.fla import ShortConvolution
+    torch.manual_seed(0)
+    m = ShortConvolution(12, 4, bias=True)
+    x = torch.randn(2, 9, 12)
+    want = orc.short_conv(x, m.weight, m.bias)
+    y, c = m(x, output_final_state=True)
+    assert (y - want).abs().max() < 1e-6 and c.shape == (2, 12, 4)
+    y1, c1 = m(x[:, :5], output_final_state=True)
+    y2, c2 = m(x[:, 5:], cache=c1, output_final_state=True)
+    assert (torch.cat([y1, y2], 1) - want).abs().max() < 1e-6 and torch.equal(c2, c)
+    assert (y2 - orc.short_conv(x[:, 5:], m.weight, m.bias, initial_state=c1)).abs().max() < 1e-6
+    steps, cc = [], None
+    for t in range(9):
+        yt, cc = m(x[:, t:t + 1], cache=cc, output_final_state=True)
+        steps.append(yt)
+    assert (torch.cat(steps, 1) - want).abs().max() < 1e-6
+    xp, cu = torch.randn(1, 10, 12), torch.tensor([0, 4, 10])
+    yv, cv = m(xp, cu_seqlens=cu, output_final_state=True)
+    assert (yv - orc.short_conv(xp, m.weight, m.bias, cu_seqlens=cu)).abs().max() < 1e-6 and cv.shape == (2, 12, 4)
+    assert sorted(m.state_dict()) == ["bias", "weight"] and m.weight.shape == (12, 1, 4)
