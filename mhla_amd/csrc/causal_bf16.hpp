@@ -578,14 +578,38 @@ __global__ __launch_bounds__(NTHREADS, NK <= 2 ? 2 : 1) void k_csf_bwd_tok3(cons
     const ST* dSi = reinterpret_cast<const ST*>(a.dS) + ((long)bh * a.n + ci) * K * V;
     const float mii = a.mix[(long)ci * a.ldmix + ci];
 
+    // Every row of the chunk that the kernel needs before its first barrier is requested at once (K <= 128): the Q and K tiles of
+    // step 1 (Q stays in registers for step 3: no second read), and the first round's dO, V, P, dS tiles of step 2.  The steps used
+    // to stage Q, K (and Q again) synchronously -- six exposed memory latencies per chunk in a workgroup that lives ~30 us.
+    static_assert(sizeof(ST) == 2, "the prefetching token kernel expects bf16 summaries");
+    constexpr bool PRE = NK <= 2;
+    CsTile qT[PRE ? NK : 1], kT[PRE ? NK : 1];
+    CsTile nP, ndS, nG, nV;   // next round's P / dS tiles; next V slice's dO / V rows
+    if constexpr (PRE) {
+#pragma unroll
+        for (int kk = 0; kk < NK; ++kk) {
+            const int kc = kk < nks ? kk : 0;   // (K = 64: the second pair repeats the first, never committed)
+            cs_issue_tok(qT[kk], qb + kc * 64, a.q.sn, p0, rv, tid);
+            cs_issue_tok(kT[kk], kb + kc * 64, a.k.sn, p0, rv, tid);
+        }
+        cs_issue_tok(nG, gb, a.dout.sn, p0, rv, tid);
+        cs_issue_tok(nV, vb, a.v.sn, p0, rv, tid);
+        cs_issue_state(nP, reinterpret_cast<const u16*>(Pi), CS, tid);
+        cs_issue_state(ndS, reinterpret_cast<const u16*>(dSi), CS, tid);
+    }
     // ---- step 1: A = tril(Q K^T); the K tiles stay ----
     f32x4 accA[4];
     zero4(accA);
 #pragma unroll
     for (int kk = 0; kk < NK; ++kk) {
         if (kk < nks) {
-            cs_stage_tok(X1, qb + kk * 64, a.q.sn, p0, rv, tid);
-            cs_stage_tok(KT + kk * CT, kb + kk * 64, a.k.sn, p0, rv, tid);
+            if constexpr (PRE) {
+                cs_commit_tok(X1, qT[kk], rv, tid);
+                cs_commit_tok(KT + kk * CT, kT[kk], rv, tid);
+            } else {
+                cs_stage_tok(X1, qb + kk * 64, a.q.sn, p0, rv, tid);
+                cs_stage_tok(KT + kk * CT, kb + kk * 64, a.k.sn, p0, rv, tid);
+            }
             __syncthreads();
             tile_mma<false, false>(accA, X1, KT + kk * CT, wave, lane);
             __syncthreads();
@@ -612,12 +636,12 @@ __global__ __launch_bounds__(NTHREADS, NK <= 2 ? 2 : 1) void k_csf_bwd_tok3(cons
     // Every (V slice, K slice) round stages a P and a dS tile (and, at its first K slice, the dO and V rows of the V slice): the next
     // round's tiles are fetched into registers while the current round is multiplied, and written to LDS behind the barrier that
     // ends it -- the rounds used to be load -> wait -> multiply, about twenty exposed memory latencies per chunk.
-    static_assert(sizeof(ST) == 2, "the prefetching token kernel expects bf16 summaries");
-    CsTile nP, ndS, nG, nV;   // next round's P / dS tiles; next V slice's dO / V rows
-    cs_issue_tok(nG, gb, a.dout.sn, p0, rv, tid);
-    cs_issue_tok(nV, vb, a.v.sn, p0, rv, tid);
-    cs_issue_state(nP, reinterpret_cast<const u16*>(Pi), CS, tid);
-    cs_issue_state(ndS, reinterpret_cast<const u16*>(dSi), CS, tid);
+    if constexpr (!PRE) {
+        cs_issue_tok(nG, gb, a.dout.sn, p0, rv, tid);
+        cs_issue_tok(nV, vb, a.v.sn, p0, rv, tid);
+        cs_issue_state(nP, reinterpret_cast<const u16*>(Pi), CS, tid);
+        cs_issue_state(ndS, reinterpret_cast<const u16*>(dSi), CS, tid);
+    }
     for (int vs = 0; vs < V; vs += 64) {
         f32x4 accV[4];
         zero4(accV);
@@ -674,7 +698,8 @@ __global__ __launch_bounds__(NTHREADS, NK <= 2 ? 2 : 1) void k_csf_bwd_tok3(cons
 #pragma unroll
     for (int kk = 0; kk < NK; ++kk) {
         if (kk < nks) {
-            cs_stage_tok(X2, qb + kk * 64, a.q.sn, p0, rv, tid);
+            if constexpr (PRE) cs_commit_tok(X2, qT[kk], rv, tid);
+            else cs_stage_tok(X2, qb + kk * 64, a.q.sn, p0, rv, tid);
             __syncthreads();
             f32x4 acc3[4];
             zero4(acc3);
