@@ -113,14 +113,16 @@ __device__ __forceinline__ void wz_body(float* __restrict__ smem, const float* _
     if (tid < 256) {
         const int r = tid >> 2, sq = tid & 3;
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-        // Every LDS operand of a group of eight steps has landed before its first multiply-add.  With packed fp32 math enabled
-        // the straightforward loop (WZ_VARIANT=0: `acc += Ws[..] * x4` unrolled by 8) compiles to v_pk_fma_f32 fed by
-        // ds_read2_b32 / ds_read_b128 behind counted s_waitcnt lgkmcnt(N) waits, and the LOW halves of its results in lanes
-        // 16-31 / 48-63 differ from run to run whenever the dW workgroups of this launch share the CU
+        // With packed fp32 math enabled the straightforward loop (WZ_VARIANT=0: `acc += Ws[..] * x4` unrolled by 8) compiles to
+        // v_pk_fma_f32 fed by ds_read2_b32 / ds_read_b128 behind counted s_waitcnt lgkmcnt(N) waits, and the LOW halves of its
+        // results in lanes 16-31 / 48-63 differ from run to run whenever the dW workgroups of this launch share the CU
         // (tools/probes/pk_fma_repro.hip reproduces it without the library).  The same loop with scalar
-        // v_fmac_f32 (the shipped build has no packed fp32 ops at all) is bit-stable; so is this form with packed math on.
+        // v_fmac_f32 (the shipped build has no packed fp32 ops at all) is bit-stable.  Shipped: WZ_VARIANT=2, the W elements read
+        // one by one (ds_read_b32, no ds_read2_b32 pairs) -- bit-stable with packed math on as well, and as fast as variant 0
+        // (k_fs_dw 33.4 vs 32.8 us at C2).  Variant 1 (wait for lgkmcnt(0) before each group of eight multiply-adds) is also
+        // stable but doubled k_fs_dw (64 us): the dz workgroups became the launch's critical path.
 #ifndef WZ_VARIANT
-#define WZ_VARIANT 1
+#define WZ_VARIANT 2
 #endif
 #if WZ_VARIANT == 0   // the reproducer's variant
 #pragma unroll 8
@@ -138,7 +140,7 @@ __device__ __forceinline__ void wz_body(float* __restrict__ smem, const float* _
 #pragma unroll
             for (int c = 0; c < 8; ++c) acc += w[c] * xv[c];
         }
-#elif WZ_VARIANT == 2   // W elements read one by one (ds_read_b32 instead of ds_read2_b32 pairs): also bit-stable with packed math
+#elif WZ_VARIANT == 2
 #pragma unroll 8
         for (int c = 0; c < 64; ++c) {
             float w = Ws[r * 65 + c];

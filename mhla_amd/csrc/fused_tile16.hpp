@@ -634,5 +634,11 @@ __global__ __launch_bounds__(FT8, TTP == 16 ? 2 : 4) void k_tile_bwd(const FsTok
     else dw_reduce_body(reinterpret_cast<float*>(smem_raw), a.dwp, a.dW, a.M, a.nparts, x - 2 * a.ntiles, threadIdx.x);
 }
 
+// Measured without gain in round 3 (code not kept): the same three roles behind per-XCD work queues -- one persistent workgroup
+// per CU taking the next tile (atomicAdd on its XCD's counter) when it has finished one, the roles as noinline calls so that the
+// loop does not share their register allocation (inlined: 163 spilled VGPRs).  173.8 us against 130.7 us for the static launch
+// at C2: what the queue gives back in balance it loses several times over in the call frames (the argument struct goes through
+// scratch) and in tiles that no longer start while their predecessors drain their stores.
+
 }  // namespace fast
 }  // namespace mhla

@@ -3,7 +3,7 @@
 // packed-fp32 [64 x 64] x [64 x 16] product on LDS tiles in the extra workgroups) on synthetic inputs, REPS times, and compares
 // dz bit for bit with the first repetition.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++20 -DWZ_VARIANT=0 -o pk_fma_repro pk_fma_repro.hip && ./pk_fma_repro     (differences)
-//   ... -DWZ_VARIANT=1 (the shipped loop) or =2: none;   ... -DWZ_VARIANT=0 -Xclang -target-feature -Xclang -packed-fp32-ops
+//   ... -DWZ_VARIANT=2 (the shipped loop) or =1: none;   ... -DWZ_VARIANT=0 -Xclang -target-feature -Xclang -packed-fp32-ops
 //   (the shipped flag set: no v_pk_*_f32): none;   ... -DWZ_VARIANT=0 -DFS_DW_PROBE_NO_DW_ROLE=1 (dW workgroups compiled out) or =2
 //   (compiled in, same registers, but returning at once): none -- the dW role's waves must really run beside the dz ones.
 //   Measured round 3 (MI355X, ROCm 7.2): 10 700-11 100 of 524 288 dz values differ per repetition, ALL of them at even s (the low
