@@ -270,6 +270,7 @@ def main():
             try:
                 rec = json.load(open(pj))
                 if rec.get("csrc_sha16") == hsh.hexdigest()[:16]:
+                    rec = rec.get("shapes", {}).get("c2", rec)   # round 3: one file for every shape; rounds 1-2: C2 only
                     traffic, traffic_src = rec["hbm_bytes_per_step"], os.path.relpath(pj, ROOT)
                     # share of a wave's life in which the matrix pipe was busy for it (SQ_VALU_MFMA_BUSY_CYCLES per wave over
                     # SQ_WAVE_CYCLES per wave), per kernel: the counter-based "MFMA utilisation" of the same PMC passes

@@ -49,7 +49,33 @@ def kernel_times(fn, iters=5):
     return out
 
 
-def _result(name, what, t, tokens, alg, step, graph_t=None):
+_TRAFFIC = None
+
+
+def pmc_traffic(shape_key):
+    """HBM bytes per step of a shape from the committed rocprofv3 PMC summary (profiles/r*_pmc_traffic.json, written by
+    tools/prof_all.sh + tools/collect_profiles.py) -- only when that file was made from the kernel sources of this build."""
+    global _TRAFFIC
+    if _TRAFFIC is None:
+        import glob
+        import hashlib
+        root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+        h = hashlib.sha256()
+        for fn in sorted(glob.glob(os.path.join(root, "mhla_amd", "csrc", "*"))):
+            h.update(open(fn, "rb").read())
+        _TRAFFIC = {}
+        for pj in sorted(glob.glob(os.path.join(root, "profiles", "r*_pmc_traffic.json")), reverse=True):
+            try:
+                rec = json.load(open(pj))
+            except Exception:   # noqa: BLE001
+                continue
+            if rec.get("csrc_sha16") == h.hexdigest()[:16] and "shapes" in rec:
+                _TRAFFIC = {k: (v["hbm_bytes_per_step"], os.path.basename(pj)) for k, v in rec["shapes"].items()}
+                break
+    return _TRAFFIC.get(shape_key, (None, None))
+
+
+def _result(name, what, t, tokens, alg, step, graph_t=None, key=None):
     ks = kernel_times(step)
     dom = max(ks, key=ks.get) if ks else None
     r = {"shape": name, "what": what, "ms": t * 1e3, "tokens_per_s": tokens / t, "algorithmic_GBps": alg / t / 1e9,
@@ -58,6 +84,11 @@ def _result(name, what, t, tokens, alg, step, graph_t=None):
     if graph_t is not None:
         r["ms_graph_replay"] = graph_t * 1e3
         r["hbm_frac_graph_replay"] = alg / graph_t / HBM_PEAK
+    traffic, src = pmc_traffic(key) if key else (None, None)
+    r["algorithmic_bytes_per_step"] = alg
+    r["traffic"] = traffic                      # HBM bytes per step by PMC counters (null without a same-source profile)
+    r["traffic_over_algorithmic"] = traffic / alg if traffic else None
+    r["traffic_source"] = src
     return r
 
 
@@ -78,7 +109,7 @@ def _graph_time(step, iters=20):
         return None
 
 
-def blockmix_case(name, B, N, H, D, M, dtype, layout, bwd=True, split=False, idx=None, normalize=True, iters=20, graph=False):
+def blockmix_case(name, B, N, H, D, M, dtype, layout, bwd=True, split=False, idx=None, normalize=True, iters=20, graph=False, key=None):
     g = torch.Generator().manual_seed(1)
     mk = lambda relu: ((torch.relu(torch.randn(B, N, H, D, generator=g)) + 1e-6) if relu else torch.randn(B, N, H, D, generator=g)).to(dtype).to(DEV)
     q, k, v, do = mk(True), mk(True), mk(False), mk(False)
@@ -99,10 +130,10 @@ def blockmix_case(name, B, N, H, D, M, dtype, layout, bwd=True, split=False, idx
     t = timeit(step, iters=iters)
     nde = B * H * N * D * q.element_size()
     alg = (12 if bwd else (6 if split else 4)) * nde      # fwd 4 NDe (6 with split q/k), bwd 8 NDe
-    return _result(name, "fwd+bwd" if bwd else "fwd", t, B * N, alg, step, _graph_time(step, iters) if graph else None)
+    return _result(name, "fwd+bwd" if bwd else "fwd", t, B * N, alg, step, _graph_time(step, iters) if graph else None, key)
 
 
-def causal_case(name, B, T, H, K, V, dtype, iters=10):
+def causal_case(name, B, T, H, K, V, dtype, iters=10, key=None):
     g = torch.Generator().manual_seed(1)
     q = torch.randn(B, T, H, K, generator=g).to(dtype).to(DEV).requires_grad_(True)
     k = torch.randn(B, T, H, K, generator=g).to(dtype).to(DEV).requires_grad_(True)
@@ -118,26 +149,26 @@ def causal_case(name, B, T, H, K, V, dtype, iters=10):
 
     t = timeit(step, iters=iters)
     alg = 3 * B * H * T * (2 * K + 2 * V) * q.element_size()   # fwd reads q, k, v, writes o; bwd twice that
-    return _result(name, "fwd+bwd", t, B * T, alg, step)
+    return _result(name, "fwd+bwd", t, B * T, alg, step, None, key)
 
 
 def run_extra_configs(full=False):
     """The BASELINE.json shapes besides C2 (bench.py's main line).  `full` adds the informational shapes of DESIGN.md 3f."""
     out = []
     bf, f32 = torch.bfloat16, torch.float32
-    out.append(blockmix_case("C3 DiT-XL/2 256^2 op B=32 N=256 H=16 D=72 M=16 bf16", 32, 256, 16, 72, 16, bf, (4, 4), graph=True))
-    out.append(blockmix_case("C3 DiT-XL/2 256^2 op B=32 N=256 H=16 D=72 M=16 fp32", 32, 256, 16, 72, 16, f32, (4, 4), graph=True))
+    out.append(blockmix_case("C3 DiT-XL/2 256^2 op B=32 N=256 H=16 D=72 M=16 bf16", 32, 256, 16, 72, 16, bf, (4, 4), graph=True, key="c3"))
+    out.append(blockmix_case("C3 DiT-XL/2 256^2 op B=32 N=256 H=16 D=72 M=16 fp32", 32, 256, 16, 72, 16, f32, (4, 4), graph=True, key="c3f"))
     idx = block_index_3d((21, 30, 50), (3, 5, 10)).to(DEV)
     out.append(blockmix_case("C4 Wan2.1-1.3B fwd B=1 N=31500 H=12 D=128 M=150 fp32, un-normalised (shipped YAML)", 1, 31500, 12, 128, 150,
                              f32, (3, 5, 10), bwd=False, split=False, idx=idx, normalize=False))
     out.append(blockmix_case("C4 Wan2.1-1.3B fwd B=1 N=31500 H=12 D=128 M=150 fp32, normalised split q/k", 1, 31500, 12, 128, 150,
                              f32, (3, 5, 10), bwd=False, split=True, idx=idx))
     out.append(blockmix_case("C4 Wan2.1-1.3B fwd+bwd B=1 N=31500 H=12 D=128 M=150 fp32, normalised split q/k", 1, 31500, 12, 128, 150,
-                             f32, (3, 5, 10), bwd=True, split=True, idx=idx, iters=10))
-    out.append(causal_case("C5 fla 340M causal B=4 T=8192 H=4 K=128 V=256 bf16", 4, 8192, 4, 128, 256, bf))
-    out.append(causal_case("C5 1.3B-like causal B=2 T=8192 H=4 K=256 V=512 bf16", 2, 8192, 4, 256, 512, bf))
+                             f32, (3, 5, 10), bwd=True, split=True, idx=idx, iters=10, key="c4b"))
+    out.append(causal_case("C5 fla 340M causal B=4 T=8192 H=4 K=128 V=256 bf16", 4, 8192, 4, 128, 256, bf, key="c5"))
+    out.append(causal_case("C5 1.3B-like causal B=2 T=8192 H=4 K=256 V=512 bf16", 2, 8192, 4, 256, 512, bf, key="c5b"))
     out.append(blockmix_case("C2 variant M=16 S=256 bf16", 8, 4096, 16, 64, 16, bf, (4, 4)))
-    out.append(blockmix_case("C2 variant M=256 S=16 bf16", 8, 4096, 16, 64, 256, bf, (16, 16), iters=10))
+    out.append(blockmix_case("C2 variant M=256 S=16 bf16", 8, 4096, 16, 64, 256, bf, (16, 16), iters=10, key="c2b"))
     if full:
         out.append(blockmix_case("DiT-S/2-shaped op B=32 N=256 H=6 D=64 M=16 bf16", 32, 256, 6, 64, 16, bf, (4, 4), graph=True))
         out.append(blockmix_case("DiT-XL/2 512^2 op B=16 N=1024 H=16 D=72 M=16 bf16", 16, 1024, 16, 72, 16, bf, (4, 4)))

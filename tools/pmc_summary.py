@@ -11,6 +11,7 @@ import sys
 
 root = sys.argv[1]
 data = collections.defaultdict(dict)
+ndisp = collections.defaultdict(int)   # dispatches per kernel in one pass: kernels launched k times per step count k times
 for f in sorted(glob.glob(root + "/**/*counter_collection.csv", recursive=True)):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     with open(f) as fh:
@@ -23,20 +24,23 @@ for f in sorted(glob.glob(root + "/**/*counter_collection.csv", recursive=True))
     for k in agg:
         for c, v in agg[k].items():
             data[k][c] = sum(v) / len(v)
+            ndisp[k] = max(ndisp[k], len(v))
 
 rows = []
 tot_r = tot_w = 0.0
+base = min(ndisp.values()) if ndisp else 1
 for k, d in sorted(data.items()):
     w = d.get("SQ_WAVES", 0)
     wc = d.get("SQ_WAVE_CYCLES", 0) * 4 / w if w else 0
+    mult = max(1, round(ndisp[k] / base))   # launches of this kernel per step (k_csf_state: S and dP)
     rd = d.get("FETCH_SIZE", 0) * 2 * 1024
     wr = d.get("WRITE_SIZE", 0) * 1024
-    tot_r += rd
-    tot_w += wr
+    tot_r += rd * mult
+    tot_w += wr * mult
     hit = d.get("TCC_HIT_sum", 0)
     miss = d.get("TCC_MISS_sum", 0)
     rows.append({
-        "kernel": k, "waves": int(w), "us_per_wave": wc / 2.4e3 if wc else None,
+        "kernel": k, "launches_per_step": mult, "waves": int(w), "us_per_wave": wc / 2.4e3 if wc else None,
         "active": d.get("SQ_ACTIVE_INST_ANY", 0) * 4 / w / wc if wc else None,
         "wait_any": d.get("SQ_WAIT_ANY", 0) * 4 / w / wc if wc else None,
         "wait_inst": d.get("SQ_WAIT_INST_ANY", 0) * 4 / w / wc if wc else None,
@@ -51,14 +55,14 @@ for _fn in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file_
     _h.update(open(_fn, "rb").read())
 out = {"csrc_sha16": _h.hexdigest()[:16], "kernels": rows, "hbm_read_bytes_per_step": tot_r, "hbm_write_bytes_per_step": tot_w,
        "hbm_bytes_per_step": tot_r + tot_w,
-       "note": "per launch (= per bench step, one launch of each kernel); read = 2 x FETCH_SIZE KB, write = WRITE_SIZE KB"}
+       "note": "per launch; the per-step totals count a kernel launches_per_step times; read = 2 x FETCH_SIZE KB (gfx950), write = WRITE_SIZE KB"}
 if "--json" in sys.argv:
     json.dump(out, open(sys.argv[sys.argv.index("--json") + 1], "w"), indent=1)
-lines = ["| kernel | waves | us/wave | active | wait_any (vmcnt/barrier) | wait_inst (issue) | MFMA busy cyc/wave | LDS conflict frac | HBM read MB | HBM write MB | L2 hit |",
-         "|---|---|---|---|---|---|---|---|---|---|---|"]
+lines = ["| kernel | launches per step | waves | us/wave | active | wait_any (vmcnt/barrier) | wait_inst (issue) | MFMA busy cyc/wave | LDS conflict frac | HBM read MB | HBM write MB | L2 hit |",
+         "|---|---|---|---|---|---|---|---|---|---|---|---|"]
 f2 = lambda x: "" if x is None else f"{x:.2f}"
 for r in rows:
-    lines.append(f"| `{r['kernel']}` | {r['waves']} | {f2(r['us_per_wave'])} | {f2(r['active'])} | {f2(r['wait_any'])} | {f2(r['wait_inst'])} | "
+    lines.append(f"| `{r['kernel']}` | {r['launches_per_step']} | {r['waves']} | {f2(r['us_per_wave'])} | {f2(r['active'])} | {f2(r['wait_any'])} | {f2(r['wait_inst'])} | "
                  f"{'' if r['mfma_busy_cycles_per_wave'] is None else int(r['mfma_busy_cycles_per_wave'])} | {f2(r['lds_conflict_frac'])} | "
                  f"{r['hbm_read_bytes'] / 1e6:.1f} | {r['hbm_write_bytes'] / 1e6:.1f} | {f2(r['l2_hit'])} |")
 lines.append(f"\nTotal HBM traffic per step: read {tot_r / 1e6:.0f} MB + write {tot_w / 1e6:.0f} MB = {(tot_r + tot_w) / 1e6:.0f} MB")
