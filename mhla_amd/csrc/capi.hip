@@ -6,6 +6,7 @@
 #include "fused.hpp"
 #include "fused_tile16.hpp"
 #include "smalln.hpp"
+#include "smalln_f32.hpp"
 
 using namespace mhla;
 using namespace mhla::capi;
@@ -124,7 +125,7 @@ void mhla_debug_set_trace(void* buf) { g_trace = (unsigned long long*)buf; }
 int mhla_blockmix_fwd_keeps_state(int B, int H, int M, int S, int D, int dtype, int split, unsigned flags) {
     (void)B; (void)H;
     if (flags & MHLA_FLAG_FORCE_GENERIC) return 0;
-    if (sn_shape_ok(M, S, D, dtype, split != 0) && !(flags & MHLA_FLAG_NO_SMALLN)) return 0;
+    if ((sn_shape_ok(M, S, D, dtype, split != 0) || snf_shape_ok(M, S, D, dtype, split != 0)) && !(flags & MHLA_FLAG_NO_SMALLN)) return 0;
     if (fast_shape_ok(M, D, dtype, split != 0)) return 1;
     return sp_shape_ok(D, flags) ? 1 : 0;   // split-operand path: KV, G, z, ksum, 1/n (fp32)
 }
@@ -169,6 +170,16 @@ static int bm_fwd_impl(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view 
         sa.H = H; sa.M = M; sa.D = D; sa.eps = eps; sa.relu = relu; sa.normalize = normalize;
         if (D <= 64) RC(launch(fast::k_sn_fwd<4>, dim3(B * H), dim3(fast::SN_T), fast::sn_fwd_smem<4>(), st, "k_sn_fwd<4>", sa));
         else         RC(launch(fast::k_sn_fwd<5>, dim3(B * H), dim3(fast::SN_T), fast::sn_fwd_smem<5>(), st, "k_sn_fwd<5>", sa));
+        return MHLA_OK;
+    }
+    if (!rcos && !epi && snf_shape_ok(M, S, D, dtype, split) && !(flags & (MHLA_FLAG_FORCE_GENERIC | MHLA_FLAG_NO_SMALLN)) && view_ok16(q_num) &&
+        view_ok16(k_num) && view_ok16(v) && view_ok16(outv)) {
+        // fp32 tensors in the DiT / ViT regime: the attention-form kernels with hi + lo bf16 operands (smalln_f32.hpp)
+        fast::SnArgs sa{};
+        sa.q = cv(q_num); sa.k = cv(k_num); sa.v = cv(v); sa.out = cmv(out); sa.idx = block_index; sa.W = W; sa.ldw = ldw;
+        sa.H = H; sa.M = M; sa.D = D; sa.eps = eps; sa.relu = relu; sa.normalize = normalize;
+        if (D <= 64) RC(launch(fast::k_snf_fwd<4>, dim3(B * H), dim3(fast::SNF_T), fast::snf_smem<4>(), st, "k_snf_fwd<4>", sa));
+        else         RC(launch(fast::k_snf_fwd<5>, dim3(B * H), dim3(fast::SNF_T), fast::snf_smem<5>(), st, "k_snf_fwd<5>", sa));
         return MHLA_OK;
     }
     if (!rcos && !epi && fast_shape_ok(M, D, dtype, split) && !(flags & MHLA_FLAG_FORCE_GENERIC) && view_ok16(q_num) && view_ok16(k_num) &&
@@ -264,6 +275,20 @@ static int bm_bwd_impl(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view 
     {
         const mhla_view dqv{dq_num.ptr, dq_num.sb, dq_num.sn, dq_num.sh}, dkv_{dk_num.ptr, dk_num.sb, dk_num.sn, dk_num.sh},
             dvv{dv.ptr, dv.sb, dv.sn, dv.sh};
+        if (!rcos && snf_shape_ok(M, S, D, dtype, split) && !(flags & (MHLA_FLAG_FORCE_GENERIC | MHLA_FLAG_NO_SMALLN)) && view_ok16(q_num) &&
+            view_ok16(k_num) && view_ok16(v) && view_ok16(dout) && (!normalize || view_ok16(out)) && view_ok16(dqv) &&
+            view_ok16(dkv_) && view_ok16(dvv)) {
+            const size_t need = (size_t)B * H * M * M * 4;
+            if (ws_bytes < need) return fail(MHLA_EINVAL, "workspace too small: %zu < %zu bytes", ws_bytes, need);
+            fast::SnArgs sa{};
+            sa.q = cv(q_num); sa.k = cv(k_num); sa.v = cv(v); sa.o = normalize ? cv(out) : cv(q_num); sa.dout = cv(dout);
+            sa.dq = cmv(dq_num); sa.dk = cmv(dk_num); sa.dv = cmv(dv); sa.idx = block_index; sa.W = W; sa.ldw = ldw;
+            sa.dwp = (float*)ws; sa.H = H; sa.M = M; sa.D = D; sa.eps = eps; sa.relu = relu; sa.normalize = normalize;
+            if (D <= 64) RC(launch(fast::k_snf_bwd<4>, dim3(B * H), dim3(fast::SNF_T), fast::snf_smem<4>(), st, "k_snf_bwd<4>", sa));
+            else         RC(launch(fast::k_snf_bwd<5>, dim3(B * H), dim3(fast::SNF_T), fast::snf_smem<5>(), st, "k_snf_bwd<5>", sa));
+            RC(launch(fast::k_sn_dw_reduce, dim3(M * M), dim3(256), 0, st, "k_sn_dw_reduce", (const float*)ws, dW, M * M, B * H));
+            return MHLA_OK;
+        }
         if (!rcos && sn_shape_ok(M, S, D, dtype, split) && !(flags & (MHLA_FLAG_FORCE_GENERIC | MHLA_FLAG_NO_SMALLN)) && view_ok16(q_num) &&
             view_ok16(k_num) && view_ok16(v) && view_ok16(dout) && (!normalize || view_ok16(out)) && view_ok16(dqv) &&
             view_ok16(dkv_) && view_ok16(dvv)) {

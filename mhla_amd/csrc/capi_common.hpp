@@ -161,6 +161,11 @@ inline bool sn_shape_ok(int M, int S, int D, int dtype, bool split) {
     return dtype == MHLA_BF16 && S == 16 && M <= 16 && D <= 80 && (D & 7) == 0 && !split;
 }
 
+// the same regime with fp32 tensors (smalln_f32.hpp: hi + lo bf16 operands)
+inline bool snf_shape_ok(int M, int S, int D, int dtype, bool split) {
+    return dtype == MHLA_F32 && S == 16 && M <= 16 && D <= 80 && (D & 7) == 0 && !split;
+}
+
 inline int bm_check(int B, int H, int M, int S, int D, int dtype, unsigned flags, bool normalize, bool split) {
     if (B <= 0 || H <= 0 || M <= 0 || S <= 0 || D <= 0) return fail(MHLA_EINVAL, "non-positive dimension B=%d H=%d M=%d S=%d D=%d", B, H, M, S, D);
     if (D % 4) return fail(MHLA_EINVAL, "D=%d must be a multiple of 4", D);

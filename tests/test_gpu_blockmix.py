@@ -100,6 +100,27 @@ def test_small_sequence_grid_not_a_multiple_of_8():
     run_case(33, 7, 16, 16, 64, torch.bfloat16, w="rand", normalize=False)
 
 
+@pytest.mark.parametrize("M,D", [(16, 64), (16, 72), (9, 72), (4, 80), (1, 64), (13, 24), (16, 8)])
+def test_small_sequence_path_fp32(M, D):
+    """fp32 tensors, S = 16, M <= 16, D <= 80: the attention-form kernels with hi + lo bf16 operands (smalln_f32.hpp), held to
+    the fp32 tolerance; with and without the normaliser, and with the relu + eps prologue."""
+    run_case(3, 2, M, 16, D, torch.float32, w="rand")
+    run_case(2, 2, M, 16, D, torch.float32, normalize=False)
+
+
+def test_small_sequence_fp32_vs_split_path_agree():
+    import mhla_amd
+    q, k, v, W, do, _, _ = make_blockmix_inputs(4, 6, 16, 16, 72, torch.float32, seed=3, w="rand")
+    res = []
+    for ns in (False, True):
+        t = [x.clone().requires_grad_(True) for x in to_dev(q, k, v, W)]
+        out = mhla_amd.mhla_blockmix(*t, no_smalln=ns)
+        out.backward(do.to(DEV))
+        res.append([out] + [x.grad for x in t])
+    for name, a_, b_ in zip(("out", "dq", "dk", "dv", "dW"), res[0], res[1]):
+        check(name, a_, b_.float().cpu(), 2e-4)
+
+
 def test_small_sequence_vs_summary_path_agree():
     import mhla_amd
     q, k, v, W, do, _, _ = make_blockmix_inputs(4, 6, 16, 16, 64, torch.bfloat16, seed=3, w="rand")
