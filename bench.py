@@ -41,6 +41,7 @@ def parse():
                    help="launch every step eagerly through Python autograd instead of replaying the captured HIP graph")
     p.set_defaults(graph=True)
     p.add_argument("--graph-steps", type=int, default=10, help="whole steps captured per HIP graph on one GPU (1: one step per replay)")
+    p.add_argument("--dit-step-timeout", type=float, default=240.0, help="seconds after which the DiT training-step measurement is abandoned")
     p.add_argument("--no-dit-step", action="store_true",
                    help="skip the second measurement: the DiT-XL/2 256^2 training step of the thin host (DDP over RCCL when N > 1)")
     return p.parse_args()
@@ -283,15 +284,7 @@ def main():
     # step whose exchange is worth measuring (DDP's bucketed all-reduce of 2.7 GB of fp32 gradients over RCCL, overlapped with
     # the backward); the operator line above only exchanges the 16 KB dW.  Every rank takes part.
     dit_step = None
-    if not a.no_dit_step and _config_name(a) == "BASELINE.json configs[1]" and not shared:
-        try:
-            sys.path.insert(0, os.path.join(ROOT, "tools"))
-            import bench_dit_step
-            q = k = v = do = None
-            torch.cuda.empty_cache()
-            dit_step = bench_dit_step.run_dit_step(rank, local, world, "DiT-XL/2", 32, 256, steps=8, warmup=3)
-        except Exception as e:   # noqa: BLE001
-            dit_step = {"error": f"{type(e).__name__}: {e}"}
+    run_dit = not a.no_dit_step and _config_name(a) == "BASELINE.json configs[1]" and not shared
     alg_flops = a.B * a.H * (12 * a.N * a.D * a.D + 6 * a.M * a.M * a.D * a.D)
     # the roofline figure of the line comes from the ONE timed number, ms_per_step (wall clock of the timed region, launch
     # overheads included); the GPU-time bracket of the second pass is listed beside it
@@ -332,8 +325,6 @@ def main():
                 "mfma_frac_of_bf16_peak": alg_flops / (step_gpu_us * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS if step_gpu_us else None,
             },
         }
-        if dit_step is not None:
-            res["dit_xl2_train_step"] = dit_step
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(a)
             res["gpu_over_cpu"] = value / res["cpu_baseline"]["value"]
@@ -357,7 +348,35 @@ def main():
                         "target": ">= 10x the CPU-eager reference on DiT-XL/2 256^2 tokens at 1 GPU"}
             except Exception as e:   # noqa: BLE001
                 res["extra_configs"] = {"error": f"{type(e).__name__}: {e}"}
-        print(json.dumps(res))
+    else:
+        res = None
+    if run_dit:
+        # Every rank takes part (DDP collectives).  The operator line must survive whatever happens here: a watchdog on every
+        # rank prints the line without this measurement (rank 0) and leaves the process if the step has not finished in time.
+        import threading
+
+        def give_up():
+            if rank == 0:
+                res["dit_xl2_train_step"] = {"error": f"not finished within {a.dit_step_timeout} s: abandoned"}
+                print(json.dumps(res), flush=True)
+            os._exit(0)
+
+        dog = threading.Timer(a.dit_step_timeout, give_up)
+        dog.daemon = True
+        dog.start()
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import bench_dit_step
+            q = k = v = do = None
+            torch.cuda.empty_cache()
+            dit_step = bench_dit_step.run_dit_step(rank, local, world, "DiT-XL/2", 32, 256, steps=8, warmup=3)
+        except Exception as e:   # noqa: BLE001
+            dit_step = {"error": f"{type(e).__name__}: {e}"}
+        dog.cancel()
+        if rank == 0:
+            res["dit_xl2_train_step"] = dit_step
+    if rank == 0:
+        print(json.dumps(res), flush=True)
     if world > 1:
         import torch.distributed as dist
         dist.barrier()

@@ -43,7 +43,8 @@ def test_argument_validation_without_gpu():
     assert rc == -22 and b"aligned" in lib.mhla_last_error()
     rc = lib.mhla_blockmix_fwd(ok, ok, ok, ok, ok, 1 << 20, 4, ok, None, 1 << 20, 1 << 30, 1, 1, 4, 16, 192, 0, 1e-6, 0, None)
     assert rc == -95
-    rc = lib.mhla_blockmix_fwd(ok, ok, ok, ok, ok, 1 << 20, 4, ok, None, 1 << 20, 16, 1, 1, 4, 16, 64, 0, 1e-6, 0, None)
+    # (S = 32: blocks of 16 tokens take the single-launch small-sequence kernels, which need no workspace)
+    rc = lib.mhla_blockmix_fwd(ok, ok, ok, ok, ok, 1 << 20, 4, ok, None, 1 << 20, 16, 1, 1, 4, 32, 64, 0, 1e-6, 0, None)
     assert rc == -22 and b"workspace" in lib.mhla_last_error()
     rc = lib.mhla_causal_fwd(ok, ok, ok, 1 << 20, 4, ok, 1 << 20, 1 << 30, 1, 128, 1, 64, 64, 32, 0.125, 0, None)
     assert rc == -95 and b"chunk" in lib.mhla_last_error()
