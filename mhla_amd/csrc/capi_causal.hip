@@ -213,7 +213,11 @@ int mhla_causal_bwd(mhla_view q, mhla_view k, mhla_view v, const float* mix, int
         CsTokArgs t{cv(q), cv(k), cv(v), cv(dout), cmv(dq), cmv(dk), cmv(dv), mix, ldmix, w.P, w.dS, w.diag, H, n, K, V, (long)T, scale};
         static const char* const tokv = getenv("MHLA_CAUSAL_TOK");   // tuning knob, read once: "2" forces the K-slice-outer kernels
         const bool tok3 = !(tokv && tokv[0] == '2');
-        if (tok3 && K <= 128)      RC(launch(fast::k_csf_bwd_tok3<uint16_t, 2>, dim3(n, B * H), dim3(NTHREADS), fast::csf_tok3_smem<2>(), st, "k_csf_bwd_tok3", t));
+        const bool tok4 = !(tokv && tokv[0] == '3');                 // "3": the four-wave kernels
+#define TOK4(NK) launch(fast::k_csf_bwd_tok4<uint16_t, NK>, dim3(n, B * H), dim3(fast::NT4), fast::csf_tok4_smem<NK>(), st, "k_csf_bwd_tok4", t)
+        if (tok3 && tok4 && K <= 256) RC(K == 64 ? TOK4(1) : K == 128 ? TOK4(2) : K == 192 ? TOK4(3) : TOK4(4));
+#undef TOK4
+        else if (tok3 && K <= 128)      RC(launch(fast::k_csf_bwd_tok3<uint16_t, 2>, dim3(n, B * H), dim3(NTHREADS), fast::csf_tok3_smem<2>(), st, "k_csf_bwd_tok3", t));
         else if (tok3 && K <= 256) RC(launch(fast::k_csf_bwd_tok3<uint16_t, 4>, dim3(n, B * H), dim3(NTHREADS), fast::csf_tok3_smem<4>(), st, "k_csf_bwd_tok3", t));
         else if (V <= 128) RC(launch(fast::k_csf_bwd_tok2<uint16_t, 2>, dim3(n, B * H), dim3(NTHREADS), fast::CSF_TOK2_SMEM, st, "k_csf_bwd_tok", t));
         else if (V <= 256) RC(launch(fast::k_csf_bwd_tok2<uint16_t, 4>, dim3(n, B * H), dim3(NTHREADS), fast::CSF_TOK2_SMEM, st, "k_csf_bwd_tok", t));

@@ -578,39 +578,36 @@ __global__ __launch_bounds__(NTHREADS, NK <= 2 ? 2 : 1) void k_csf_bwd_tok3(cons
     const ST* dSi = reinterpret_cast<const ST*>(a.dS) + ((long)bh * a.n + ci) * K * V;
     const float mii = a.mix[(long)ci * a.ldmix + ci];
 
-    // Every row of the chunk that the kernel needs before its first barrier is requested at once (K <= 128): the Q and K tiles of
-    // step 1 (Q stays in registers for step 3: no second read), and the first round's dO, V, P, dS tiles of step 2.  The steps used
-    // to stage Q, K (and Q again) synchronously -- six exposed memory latencies per chunk in a workgroup that lives ~30 us.
+    // A ring of NK register slots per summary set keeps NK (V slice, K slice) rounds of P / dS tiles in flight: the slot a round
+    // commits to LDS is refilled with the same K slice of the NEXT V slice as soon as the barrier behind the commit is passed, so
+    // NK x 16 KB per workgroup travel while a round multiplies (one round ahead left this kernel waiting for memory in every one of
+    // its 2 NK V / 64 rounds: 61 us per wave at K = 256, V = 512).  Before step 1 the same slots carry the chunk's Q and K tiles
+    // (all requested up front), and behind the last V slice the Q tiles again for step 3 -- no staging load is ever waited for
+    // right after it was issued.
     static_assert(sizeof(ST) == 2, "the prefetching token kernel expects bf16 summaries");
-    constexpr bool PRE = NK <= 2;
-    CsTile qT[PRE ? NK : 1], kT[PRE ? NK : 1];
-    CsTile nP, ndS, nG, nV;   // next round's P / dS tiles; next V slice's dO / V rows
-    if constexpr (PRE) {
+    const u16* Pb = reinterpret_cast<const u16*>(Pi);
+    const u16* dSb = reinterpret_cast<const u16*>(dSi);
+    CsTile rP[NK], rdS[NK];
+    CsTile nG, nV;   // next V slice's dO / V rows
 #pragma unroll
-        for (int kk = 0; kk < NK; ++kk) {
-            const int kc = kk < nks ? kk : 0;   // (K = 64: the second pair repeats the first, never committed)
-            cs_issue_tok(qT[kk], qb + kc * 64, a.q.sn, p0, rv, tid);
-            cs_issue_tok(kT[kk], kb + kc * 64, a.k.sn, p0, rv, tid);
-        }
-        cs_issue_tok(nG, gb, a.dout.sn, p0, rv, tid);
-        cs_issue_tok(nV, vb, a.v.sn, p0, rv, tid);
-        cs_issue_state(nP, reinterpret_cast<const u16*>(Pi), CS, tid);
-        cs_issue_state(ndS, reinterpret_cast<const u16*>(dSi), CS, tid);
+    for (int kk = 0; kk < NK; ++kk) {
+        const int kc = kk < nks ? kk : 0;   // (K < 64 NK: the surplus slots repeat the first tile, never committed)
+        cs_issue_tok(rP[kk], qb + kc * 64, a.q.sn, p0, rv, tid);
+        cs_issue_tok(rdS[kk], kb + kc * 64, a.k.sn, p0, rv, tid);
     }
+    cs_issue_tok(nG, gb, a.dout.sn, p0, rv, tid);
+    cs_issue_tok(nV, vb, a.v.sn, p0, rv, tid);
     // ---- step 1: A = tril(Q K^T); the K tiles stay ----
     f32x4 accA[4];
     zero4(accA);
 #pragma unroll
     for (int kk = 0; kk < NK; ++kk) {
         if (kk < nks) {
-            if constexpr (PRE) {
-                cs_commit_tok(X1, qT[kk], rv, tid);
-                cs_commit_tok(KT + kk * CT, kT[kk], rv, tid);
-            } else {
-                cs_stage_tok(X1, qb + kk * 64, a.q.sn, p0, rv, tid);
-                cs_stage_tok(KT + kk * CT, kb + kk * 64, a.k.sn, p0, rv, tid);
-            }
+            cs_commit_tok(X1, rP[kk], rv, tid);
+            cs_commit_tok(KT + kk * CT, rdS[kk], rv, tid);
             __syncthreads();
+            cs_issue_state(rP[kk], Pb + cs_tile_off(kk * 64, 0, V), CS, tid);
+            cs_issue_state(rdS[kk], dSb + cs_tile_off(kk * 64, 0, V), CS, tid);
             tile_mma<false, false>(accA, X1, KT + kk * CT, wave, lane);
             __syncthreads();
         }
@@ -633,36 +630,27 @@ __global__ __launch_bounds__(NTHREADS, NK <= 2 ? 2 : 1) void k_csf_bwd_tok3(cons
         zero4(accK[kk]);
     }
     zero4(accdA);
-    // Every (V slice, K slice) round stages a P and a dS tile (and, at its first K slice, the dO and V rows of the V slice): the next
-    // round's tiles are fetched into registers while the current round is multiplied, and written to LDS behind the barrier that
-    // ends it -- the rounds used to be load -> wait -> multiply, about twenty exposed memory latencies per chunk.
-    if constexpr (!PRE) {
-        cs_issue_tok(nG, gb, a.dout.sn, p0, rv, tid);
-        cs_issue_tok(nV, vb, a.v.sn, p0, rv, tid);
-        cs_issue_state(nP, reinterpret_cast<const u16*>(Pi), CS, tid);
-        cs_issue_state(ndS, reinterpret_cast<const u16*>(dSi), CS, tid);
-    }
     for (int vs = 0; vs < V; vs += 64) {
         f32x4 accV[4];
         zero4(accV);
+        const bool last = vs + 64 >= V;   // (uniform)
         cs_commit_tok(X1, nG, rv, tid);
         cs_commit_tok(X2, nV, rv, tid);
-        if (vs + 64 < V) {   // (uniform) the next V slice's rows travel during this slice's rounds
+        if (!last) {   // the next V slice's rows travel during this slice's rounds
             cs_issue_tok(nG, gb + vs + 64, a.dout.sn, p0, rv, tid);
             cs_issue_tok(nV, vb + vs + 64, a.v.sn, p0, rv, tid);
         }
 #pragma unroll
         for (int kk = 0; kk < NK; ++kk) {
             if (kk < nks) {
-                cs_commit_state(B1, nP, tid);
-                cs_commit_state(B2, ndS, tid);
+                cs_commit_state(B1, rP[kk], tid);
+                cs_commit_state(B2, rdS[kk], tid);
                 __syncthreads();
-                {   // next round: (vs, kk + 1) or (vs + 64, 0); past the last round the chunk's first tiles again (never used)
-                    const bool wrap = kk + 1 >= nks;
-                    const int nkk = wrap ? 0 : kk + 1;
-                    const int nvs = wrap ? (vs + 64 < V ? vs + 64 : 0) : vs;
-                    cs_issue_state(nP, reinterpret_cast<const u16*>(Pi) + cs_tile_off(nkk * 64, nvs, V), CS, tid);
-                    cs_issue_state(ndS, reinterpret_cast<const u16*>(dSi) + cs_tile_off(nkk * 64, nvs, V), CS, tid);
+                if (!last) {
+                    cs_issue_state(rP[kk], Pb + cs_tile_off(kk * 64, vs + 64, V), CS, tid);
+                    cs_issue_state(rdS[kk], dSb + cs_tile_off(kk * 64, vs + 64, V), CS, tid);
+                } else {
+                    cs_issue_tok(rP[kk], qb + kk * 64, a.q.sn, p0, rv, tid);   // step 3's Q tile
                 }
                 if (kk == 0) {
                     tile_mma<false, false>(accdA, X1, X2, wave, lane);      // dO V^T
@@ -698,8 +686,7 @@ __global__ __launch_bounds__(NTHREADS, NK <= 2 ? 2 : 1) void k_csf_bwd_tok3(cons
 #pragma unroll
     for (int kk = 0; kk < NK; ++kk) {
         if (kk < nks) {
-            if constexpr (PRE) cs_commit_tok(X2, qT[kk], rv, tid);
-            else cs_stage_tok(X2, qb + kk * 64, a.q.sn, p0, rv, tid);
+            cs_commit_tok(X2, rP[kk], rv, tid);
             __syncthreads();
             f32x4 acc3[4];
             zero4(acc3);
@@ -712,6 +699,225 @@ __global__ __launch_bounds__(NTHREADS, NK <= 2 ? 2 : 1) void k_csf_bwd_tok3(cons
             __syncthreads();
             cs_store_tok(mbase(a.dq) + kk * 64, a.dq.sn, p0, rv, B1, tid);
             cs_store_tok(mbase(a.dk) + kk * 64, a.dk.sn, p0, rv, B2, tid);
+            __syncthreads();
+        }
+    }
+}
+
+// k_csf_bwd_tok4: the same algorithm as k_csf_bwd_tok3 on EIGHT waves -- every wave owns 16 rows x 32 columns of each 64 x 64 product
+// (row tile = wave & 3, column half = wave >> 2) instead of 16 x 64.  The accumulator set per wave halves (K = 256: 248 -> ~150
+// VGPRs), so two waves share a SIMD and one's LDS operand reads run under the other's MFMAs: with four waves of 248 VGPRs the
+// K = 256 kernel had ONE wave per SIMD and spent its rounds in exposed LDS and MFMA latency (11 % MFMA-busy, 61 us per wave; a
+// deeper prefetch ring alone moved it from 286 to 265 us).  At K <= 128 the kernel fits 128 VGPRs: two workgroups = 16 waves per CU.
+// Every thread moves 16 bytes of a tile (row = tid >> 3), so a ring slot is one uint4.
+constexpr int NT4 = 512;
+__device__ __forceinline__ void cs8_issue_tok(uint4& t, const u16* __restrict__ base, long sn, long p0, int rv, int tid) {
+    const int r = tid >> 3, c = (tid & 7) * 8;
+    t = gld<uint4>(base + (p0 + (r < rv ? r : 0)) * sn + c);
+}
+__device__ __forceinline__ void cs8_commit_tok(u16* __restrict__ dst, const uint4& t, int rv, int tid) {
+    const int r = tid >> 3, c = (tid & 7) * 8;
+    const bool ok = r < rv;
+    *reinterpret_cast<uint4*>(dst + r * CLD + c) = make_uint4(ok ? t.x : 0u, ok ? t.y : 0u, ok ? t.z : 0u, ok ? t.w : 0u);
+}
+__device__ __forceinline__ void cs8_issue_state(uint4& t, const u16* __restrict__ tile, int tid) { t = gld<uint4>(tile + tid * 8); }   // [64][64] contiguous
+__device__ __forceinline__ void cs8_commit_state(u16* __restrict__ dst, const uint4& t, int tid) {
+    *reinterpret_cast<uint4*>(dst + (tid >> 3) * CLD + (tid & 7) * 8) = t;
+}
+#ifndef TOK4_NO_STORE
+#define TOK4_NO_STORE 0
+#endif
+#ifndef TOK4_NO_TOKLOAD
+#define TOK4_NO_TOKLOAD 0
+#endif
+__device__ __forceinline__ void cs8_store_tok(u16* __restrict__ base, long sn, long p0, int rv, const u16* __restrict__ Os, int tid) {
+    const int r = tid >> 3, c = (tid & 7) * 8;
+#if TOK4_NO_STORE
+    if (p0 >= 0) return;
+#endif
+    if (r < rv) *reinterpret_cast<uint4*>(base + (p0 + r) * sn + c) = *reinterpret_cast<const uint4*>(Os + r * CLD + c);
+}
+// acc[tn] += A B for output rows 16 rt .. and columns 32 ch + 16 tn ..   (operand conventions of tile_mma)
+#ifndef TOK4_NO_MMA
+#define TOK4_NO_MMA 0    // ablation switches (tools/build_variant.sh): 1 skips the tile products, TOK4_NO_LOAD the round loads
+#endif
+#ifndef TOK4_NO_LOAD
+#define TOK4_NO_LOAD 0
+#endif
+template <bool AT, bool BT>
+__device__ __forceinline__ void tile_mma8(f32x4 (&acc)[2], const u16* __restrict__ Xs, const u16* __restrict__ Ys, int rt, int ch, int lane) {
+    const int n = lane & 15, kg = lane >> 4;
+#if TOK4_NO_MMA
+    if (Xs != nullptr) return;
+#endif
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 av = AT ? tr_read8(Xs, CLD, ks * 32, rt * 16, lane)
+                             : *reinterpret_cast<const bf16x8*>(Xs + (rt * 16 + n) * CLD + ks * 32 + kg * 8);
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            const int c0 = ch * 32 + tn * 16;
+            const bf16x8 bv = BT ? tr_read8(Ys, CLD, ks * 32, c0, lane)
+                                 : *reinterpret_cast<const bf16x8*>(Ys + (c0 + n) * CLD + ks * 32 + kg * 8);
+            acc[tn] = mfma_bf16(av, bv, acc[tn]);
+        }
+    }
+}
+__device__ __forceinline__ void zero2(f32x4 (&x)[2]) { x[0] = x[1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+__device__ __forceinline__ void cs8_put(u16* __restrict__ dst, const f32x4 (&x)[2], float mul, int rt, int ch, int lane) {
+    const int n = lane & 15, kg = lane >> 4;
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dst[(rt * 16 + kg * 4 + r) * CLD + ch * 32 + tn * 16 + n] = cvt_bf16(mul * x[tn][r]);
+}
+
+template <int NK>
+__host__ __device__ constexpr int csf_tok4_smem() { return (6 + NK) * CT * 2 + 32; }
+
+template <typename ST, int NK>
+__global__ __launch_bounds__(NT4, NK <= 2 ? 4 : 2) void k_csf_bwd_tok4(const CsTokArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u16* As = reinterpret_cast<u16*>(smem_raw);   // m_ii scale tril(Q K^T)   [c][c']
+    u16* dAs = As + CT;                           // m_ii tril(dO V^T)        [c][c']
+    u16* X1 = dAs + CT;                           // Q slice / dO slice
+    u16* X2 = X1 + CT;                            // V slice / Q slice
+    u16* B1 = X2 + CT;                            // P slice, output staging
+    u16* B2 = B1 + CT;                            // dS slice, output staging
+    u16* KT = B2 + CT;                            // the chunk's K tiles [NK]
+    float* red = reinterpret_cast<float*>(KT + NK * CT);
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, n = lane & 15, kg = lane >> 4;
+    const int rt = wave & 3, ch = wave >> 2;
+    const int ci = blockIdx.x, bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
+    const long p0 = (long)ci * CS;
+    const int rv = (int)min((long)CS, a.T - p0);
+    const int K = a.K, V = a.V;   // K == 64 NK
+    auto base = [&](const View& w) { return (const u16*)w.ptr + b * w.sb + h * w.sh; };
+    auto mbase = [&](const MView& w) { return (u16*)w.ptr + b * w.sb + h * w.sh; };
+    const u16 *qb = base(a.q), *kb = base(a.k), *vb = base(a.v), *gb = base(a.dout);
+    static_assert(sizeof(ST) == 2, "the prefetching token kernel expects bf16 summaries");
+    const u16* Pb = reinterpret_cast<const u16*>(a.P) + ((long)bh * a.n + ci) * K * V;
+    const u16* dSb = reinterpret_cast<const u16*>(a.dS) + ((long)bh * a.n + ci) * K * V;
+    const float mii = a.mix[(long)ci * a.ldmix + ci];
+
+    // ring of NK register slots per summary set (see k_csf_bwd_tok3): Q / K tiles first, then P / dS a V slice ahead, then Q again
+    uint4 rP[NK], rdS[NK], nG, nV;
+#pragma unroll
+    for (int kk = 0; kk < NK; ++kk) {
+        cs8_issue_tok(rP[kk], qb + kk * 64, a.q.sn, p0, rv, tid);
+        cs8_issue_tok(rdS[kk], kb + kk * 64, a.k.sn, p0, rv, tid);
+    }
+    cs8_issue_tok(nG, gb, a.dout.sn, p0, rv, tid);
+    cs8_issue_tok(nV, vb, a.v.sn, p0, rv, tid);
+    // ---- step 1: A = tril(Q K^T); the K tiles stay ----
+    f32x4 accA[2];
+    zero2(accA);
+#pragma unroll
+    for (int kk = 0; kk < NK; ++kk) {
+        {
+            cs8_commit_tok(X1, rP[kk], rv, tid);
+            cs8_commit_tok(KT + kk * CT, rdS[kk], rv, tid);
+            __syncthreads();
+            cs8_issue_state(rP[kk], Pb + cs_tile_off(kk * 64, 0, V), tid);
+            cs8_issue_state(rdS[kk], dSb + cs_tile_off(kk * 64, 0, V), tid);
+            tile_mma8<false, false>(accA, X1, KT + kk * CT, rt, ch, lane);
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = rt * 16 + kg * 4 + r, col = ch * 32 + tn * 16 + n;
+            const float av = col <= row ? accA[tn][r] : 0.f;
+            accA[tn][r] = av;   // kept for the diagonal term
+            As[row * CLD + col] = cvt_bf16(mii * a.scale * av);
+        }
+
+    // ---- step 2: per V slice: dA, dV, and the dQ / dK partials of every K slice ----
+    f32x4 accQ[NK][2], accK[NK][2], accdA[2];
+#pragma unroll
+    for (int kk = 0; kk < NK; ++kk) {
+        zero2(accQ[kk]);
+        zero2(accK[kk]);
+    }
+    zero2(accdA);
+    for (int vs = 0; vs < V; vs += 64) {
+        f32x4 accV[2];
+        zero2(accV);
+        const bool last = vs + 64 >= V;   // (uniform)
+        cs8_commit_tok(X1, nG, rv, tid);
+        cs8_commit_tok(X2, nV, rv, tid);
+        // No load of the loop sits behind a branch: hipcc loses count of the loads in flight at every join and waits for ALL of
+        // them (s_waitcnt vmcnt(0) before each refill -- the ring then holds one round, whatever its depth).  Behind the last V
+        // slice the rows of this slice are requested again (never used) and the P slots receive step 3's Q tiles.
+        const int vn = last ? vs : vs + 64;
+#if !TOK4_NO_TOKLOAD
+        cs8_issue_tok(nG, gb + vn, a.dout.sn, p0, rv, tid);
+        cs8_issue_tok(nV, vb + vn, a.v.sn, p0, rv, tid);
+#endif
+#pragma unroll
+        for (int kk = 0; kk < NK; ++kk) {
+            {
+                cs8_commit_state(B1, rP[kk], tid);
+                cs8_commit_state(B2, rdS[kk], tid);
+                __syncthreads();
+#if !TOK4_NO_LOAD
+                {
+                    const int r = tid >> 3, c = (tid & 7) * 8;
+                    const u16* qsrc = qb + kk * 64 + (p0 + (r < rv ? r : 0)) * a.q.sn + c;   // step 3's Q tile
+                    const u16* psrc = Pb + cs_tile_off(kk * 64, vn, V) + tid * 8;
+                    rP[kk] = gld<uint4>(last ? qsrc : psrc);
+                    cs8_issue_state(rdS[kk], dSb + cs_tile_off(kk * 64, vn, V), tid);
+                }
+#endif
+                if (kk == 0) {
+                    tile_mma8<false, false>(accdA, X1, X2, rt, ch, lane);      // dO V^T
+                    tile_mma8<true, true>(accV, As, X1, rt, ch, lane);         // A^T dO
+                }
+                tile_mma8<false, false>(accQ[kk], X1, B1, rt, ch, lane);       // dO P^T
+                tile_mma8<false, false>(accK[kk], X2, B2, rt, ch, lane);       // V dS^T
+                tile_mma8<false, true>(accV, KT + kk * CT, B2, rt, ch, lane);  // K dS
+                __syncthreads();
+            }
+        }
+        cs8_put(B1, accV, 1.f, rt, ch, lane);
+        __syncthreads();
+        cs8_store_tok(mbase(a.dv) + vs, a.dv.sn, p0, rv, B1, tid);
+        __syncthreads();
+    }
+
+    // ---- step 3: dA tile, diagonal term, the m_ii parts of dQ / dK ----
+    float dsum = 0.f;
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = rt * 16 + kg * 4 + r, col = ch * 32 + tn * 16 + n;
+            const float dv = col <= row ? accdA[tn][r] : 0.f;
+            dsum += accA[tn][r] * dv;
+            dAs[row * CLD + col] = cvt_bf16(mii * dv);
+        }
+    dsum = wave_sum(dsum);
+    if (lane == 0) red[wave] = dsum;
+    __syncthreads();
+    if (tid == 0) a.diag[(long)bh * a.n + ci] = a.scale * (((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7])));
+#pragma unroll
+    for (int kk = 0; kk < NK; ++kk) {
+        {
+            cs8_commit_tok(X2, rP[kk], rv, tid);
+            __syncthreads();
+            f32x4 acc3[2];
+            zero2(acc3);
+            tile_mma8<false, true>(accQ[kk], dAs, KT + kk * CT, rt, ch, lane);   // dA K
+            tile_mma8<true, true>(acc3, dAs, X2, rt, ch, lane);                  // dA^T Q
+            cs8_put(B1, accQ[kk], a.scale, rt, ch, lane);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) accK[kk][i] += a.scale * acc3[i];
+            cs8_put(B2, accK[kk], 1.f, rt, ch, lane);
+            __syncthreads();
+            cs8_store_tok(mbase(a.dq) + kk * 64, a.dq.sn, p0, rv, B1, tid);
+            cs8_store_tok(mbase(a.dk) + kk * 64, a.dk.sn, p0, rv, B2, tid);
             __syncthreads();
         }
     }
