@@ -93,7 +93,7 @@ static int cs_state16(const mhla_view& x, const mhla_view& y, uint16_t* out, flo
     if (knob && knob[0] == 'o')
         return launch(fast::k_csf_state, dim3(n, B * H, K / 64), dim3(NTHREADS), fast::CSF_STATE_SMEM, st, "k_csf_state", s);
     const int blocks = ((K + fast::ST2_KW - 1) / fast::ST2_KW) * ((V + fast::ST2_VW - 1) / fast::ST2_VW);
-    return launch(fast::k_csf_state2, dim3(n, B * H, blocks), dim3(NTHREADS), fast::CSF_STATE2_SMEM, st, "k_csf_state", s);
+    return launch(fast::k_csf_state2, dim3((n + fast::ST2_CPW - 1) / fast::ST2_CPW, B * H, blocks), dim3(NTHREADS), fast::CSF_STATE2_SMEM, st, "k_csf_state", s);
 }
 
 // P = strictly-lower mix of S (bf16 pipeline)

@@ -61,6 +61,9 @@ __device__ __forceinline__ void cs_stage_state(u16* __restrict__ dst, const u16*
 
 // The two stagings in halves (loads now, LDS writes later), for kernels that fetch the next round's tiles while the current
 // round is multiplied.  Rows >= rv read the chunk's first row (a valid address) and are zeroed on the way into LDS.
+// A thread moves two 16-byte pieces of a tile: (row tid >> 3, columns 8 (tid & 7) ..) and the same columns 32 rows below, so
+// that every load / store instruction of a wave covers eight FULL 128-byte rows (two adjacent pieces per thread made each
+// instruction touch 16 bytes of every 32: half-line requests, and partial-line writes for the second instruction to complete).
 struct CsTile { uint4 x, y; };
 #ifndef CSF_NT_TOK
 #define CSF_NT_TOK 0
@@ -69,37 +72,38 @@ struct CsTile { uint4 x, y; };
 #define CSF_NT_STATE 0
 #endif
 __device__ __forceinline__ void cs_issue_tok(CsTile& t, const u16* __restrict__ base, long sn, long p0, int rv, int tid) {
-    const int r = tid >> 2, c = (tid & 3) * 16;
-    const u16* src = base + (p0 + (r < rv ? r : 0)) * sn + c;
+    const int r = tid >> 3, c = (tid & 7) * 8;
+    const u16* s0 = base + (p0 + (r < rv ? r : 0)) * sn + c;
+    const u16* s1 = base + (p0 + (r + 32 < rv ? r + 32 : 0)) * sn + c;
 #if CSF_NT_TOK
-    t.x = gld_stream16(src);
-    t.y = gld_stream16(src + 8);
+    t.x = gld_stream16(s0);
+    t.y = gld_stream16(s1);
 #else
-    t.x = gld<uint4>(src);
-    t.y = gld<uint4>(src + 8);
+    t.x = gld<uint4>(s0);
+    t.y = gld<uint4>(s1);
 #endif
 }
 __device__ __forceinline__ void cs_commit_tok(u16* __restrict__ dst, const CsTile& t, int rv, int tid) {
-    const int r = tid >> 2, c = (tid & 3) * 16;
-    const bool ok = r < rv;
-    *reinterpret_cast<uint4*>(dst + r * CLD + c) = make_uint4(ok ? t.x.x : 0u, ok ? t.x.y : 0u, ok ? t.x.z : 0u, ok ? t.x.w : 0u);
-    *reinterpret_cast<uint4*>(dst + r * CLD + c + 8) = make_uint4(ok ? t.y.x : 0u, ok ? t.y.y : 0u, ok ? t.y.z : 0u, ok ? t.y.w : 0u);
+    const int r = tid >> 3, c = (tid & 7) * 8;
+    const bool ok0 = r < rv, ok1 = r + 32 < rv;
+    *reinterpret_cast<uint4*>(dst + r * CLD + c) = make_uint4(ok0 ? t.x.x : 0u, ok0 ? t.x.y : 0u, ok0 ? t.x.z : 0u, ok0 ? t.x.w : 0u);
+    *reinterpret_cast<uint4*>(dst + (r + 32) * CLD + c) = make_uint4(ok1 ? t.y.x : 0u, ok1 ? t.y.y : 0u, ok1 ? t.y.z : 0u, ok1 ? t.y.w : 0u);
 }
 __device__ __forceinline__ void cs_issue_state(CsTile& t, const u16* __restrict__ src, long ld, int tid) {
-    const int r = tid >> 2, c = (tid & 3) * 16;
+    const int r = tid >> 3, c = (tid & 7) * 8;
     const u16* s = src + (long)r * ld + c;
 #if CSF_NT_STATE
     t.x = gld_stream16(s);
-    t.y = gld_stream16(s + 8);
+    t.y = gld_stream16(s + 32 * ld);
 #else
     t.x = gld<uint4>(s);
-    t.y = gld<uint4>(s + 8);
+    t.y = gld<uint4>(s + 32 * ld);
 #endif
 }
 __device__ __forceinline__ void cs_commit_state(u16* __restrict__ dst, const CsTile& t, int tid) {
-    const int r = tid >> 2, c = (tid & 3) * 16;
+    const int r = tid >> 3, c = (tid & 7) * 8;
     *reinterpret_cast<uint4*>(dst + r * CLD + c) = t.x;
-    *reinterpret_cast<uint4*>(dst + r * CLD + c + 8) = t.y;
+    *reinterpret_cast<uint4*>(dst + (r + 32) * CLD + c) = t.y;
 }
 
 // acc[tn] += A B for output rows 16 wave .. and the four 16-column tiles, reduction length 64.
@@ -133,28 +137,24 @@ __device__ __forceinline__ void cs_put(u16* __restrict__ dst, const f32x4 (&x)[4
         for (int r = 0; r < 4; ++r) dst[(wave * 16 + kg * 4 + r) * CLD + tn * 16 + n] = cvt_bf16(mul * x[tn][r]);
 }
 __device__ __forceinline__ void cs_store_tok(u16* __restrict__ base, long sn, long p0, int rv, const u16* __restrict__ Os, int tid) {
-    const int r = tid >> 2, c = (tid & 3) * 16;
-    if (r < rv) {
-        u16* d = base + (p0 + r) * sn + c;
-        *reinterpret_cast<uint4*>(d) = *reinterpret_cast<const uint4*>(Os + r * CLD + c);
-        *reinterpret_cast<uint4*>(d + 8) = *reinterpret_cast<const uint4*>(Os + r * CLD + c + 8);
-    }
+    const int r = tid >> 3, c = (tid & 7) * 8;   // (full rows per store instruction, as the loads)
+    if (r < rv) *reinterpret_cast<uint4*>(base + (p0 + r) * sn + c) = *reinterpret_cast<const uint4*>(Os + r * CLD + c);
+    if (r + 32 < rv) *reinterpret_cast<uint4*>(base + (p0 + r + 32) * sn + c) = *reinterpret_cast<const uint4*>(Os + (r + 32) * CLD + c);
 }
 
 // the same with the swish gate applied on the way out: y = staged * g * sigmoid(g)   (gate rows in the output's token layout)
 __device__ __forceinline__ void cs_store_tok_gate(u16* __restrict__ base, long sn, const u16* __restrict__ gbase, long gsn, long p0,
                                                   int rv, const u16* __restrict__ Os, int tid) {
-    const int r = tid >> 2, c = (tid & 3) * 16;
-    if (r < rv) {
-        u16* d = base + (p0 + r) * sn + c;
-        uint4 x[2] = {*reinterpret_cast<const uint4*>(Os + r * CLD + c), *reinterpret_cast<const uint4*>(Os + r * CLD + c + 8)};
-        if (gbase) {
-            const u16* gp = gbase + (p0 + r) * gsn + c;
-            const uint4 g[2] = {gld<uint4>(gp), gld<uint4>(gp + 8)};
+    const int c = (tid & 7) * 8;
 #pragma unroll
-            for (int hlf = 0; hlf < 2; ++hlf) {
-                unsigned xw[4] = {x[hlf].x, x[hlf].y, x[hlf].z, x[hlf].w};
-                const unsigned gw[4] = {g[hlf].x, g[hlf].y, g[hlf].z, g[hlf].w};
+    for (int hlf = 0; hlf < 2; ++hlf) {
+        const int r = (tid >> 3) + 32 * hlf;
+        if (r < rv) {
+            uint4 x = *reinterpret_cast<const uint4*>(Os + r * CLD + c);
+            if (gbase) {
+                const uint4 g = gld<uint4>(gbase + (p0 + r) * gsn + c);
+                unsigned xw[4] = {x.x, x.y, x.z, x.w};
+                const unsigned gw[4] = {g.x, g.y, g.z, g.w};
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const float g0 = __uint_as_float(gw[i] << 16), g1 = __uint_as_float(gw[i] & 0xffff0000u);
@@ -162,11 +162,10 @@ __device__ __forceinline__ void cs_store_tok_gate(u16* __restrict__ base, long s
                     const float y1 = __uint_as_float(xw[i] & 0xffff0000u) * g1 / (1.f + __expf(-g1));
                     xw[i] = pack_bf16x2(y0, y1);
                 }
-                x[hlf] = make_uint4(xw[0], xw[1], xw[2], xw[3]);
+                x = make_uint4(xw[0], xw[1], xw[2], xw[3]);
             }
+            *reinterpret_cast<uint4*>(base + (p0 + r) * sn + c) = x;
         }
-        *reinterpret_cast<uint4*>(d) = x[0];
-        *reinterpret_cast<uint4*>(d + 8) = x[1];
     }
 }
 
@@ -180,7 +179,7 @@ constexpr int CSF_OUT_VS = 4;
 // workgroup to own every V slice of the head (V <= 256, gridDim.z == 1).  The staged normalised tile carries one bf16 rounding
 // before the gate (the unfused path rounds o to bf16 first, then normalises: same order of error).
 template <typename ST, bool EPI = false>   // ST: element type of the chunk summaries (u16 = bf16, float)
-__global__ __launch_bounds__(NTHREADS) void k_csf_out(const CsOutArgs a) {
+__global__ __launch_bounds__(NTHREADS, 2) void k_csf_out(const CsOutArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u16* Qs = reinterpret_cast<u16*>(smem_raw);   // Q slice, later the output staging
     u16* Ks = Qs + CT;
@@ -763,6 +762,29 @@ __device__ __forceinline__ void tile_mma8(f32x4 (&acc)[2], const u16* __restrict
         }
     }
 }
+// the same with the A operand (the wave's 16 rows x 64 reduction columns) already in registers: operands that several rounds
+// share are read from LDS once
+__device__ __forceinline__ void tile_a8(bf16x8 (&av)[2], const u16* __restrict__ Xs, int rt, int lane) {
+    const int n = lane & 15, kg = lane >> 4;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) av[ks] = *reinterpret_cast<const bf16x8*>(Xs + (rt * 16 + n) * CLD + ks * 32 + kg * 8);
+}
+template <bool BT>
+__device__ __forceinline__ void tile_mma8r(f32x4 (&acc)[2], const bf16x8 (&av)[2], const u16* __restrict__ Ys, int ch, int lane) {
+    const int n = lane & 15, kg = lane >> 4;
+#if TOK4_NO_MMA
+    if (Ys != nullptr) return;
+#endif
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            const int c0 = ch * 32 + tn * 16;
+            const bf16x8 bv = BT ? tr_read8(Ys, CLD, ks * 32, c0, lane)
+                                 : *reinterpret_cast<const bf16x8*>(Ys + (c0 + n) * CLD + ks * 32 + kg * 8);
+            acc[tn] = mfma_bf16(av[ks], bv, acc[tn]);
+        }
+}
 __device__ __forceinline__ void zero2(f32x4 (&x)[2]) { x[0] = x[1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 __device__ __forceinline__ void cs8_put(u16* __restrict__ dst, const f32x4 (&x)[2], float mul, int rt, int ch, int lane) {
     const int n = lane & 15, kg = lane >> 4;
@@ -835,6 +857,14 @@ __global__ __launch_bounds__(NT4, NK <= 2 ? 4 : 2) void k_csf_bwd_tok4(const CsT
         }
 
     // ---- step 2: per V slice: dA, dV, and the dQ / dK partials of every K slice ----
+    // The wave's rows of the K tiles are the A operand of K dS in every round of every V slice, its rows of dO and V of all rounds
+    // of one V slice: they are read from LDS once (the kernel is bound by LDS operand traffic: 18 KB per wave and round before).
+    constexpr bool KREG = NK > 2;   // (K <= 128 runs two workgroups per CU on 128 VGPRs: no room for the K rows)
+    bf16x8 aK[KREG ? NK : 1][2];
+    if constexpr (KREG) {
+#pragma unroll
+        for (int kk = 0; kk < NK; ++kk) tile_a8(aK[kk], KT + kk * CT, rt, lane);
+    }
     f32x4 accQ[NK][2], accK[NK][2], accdA[2];
 #pragma unroll
     for (int kk = 0; kk < NK; ++kk) {
@@ -845,6 +875,7 @@ __global__ __launch_bounds__(NT4, NK <= 2 ? 4 : 2) void k_csf_bwd_tok4(const CsT
     for (int vs = 0; vs < V; vs += 64) {
         f32x4 accV[2];
         zero2(accV);
+        bf16x8 aG[2], aV[2];
         const bool last = vs + 64 >= V;   // (uniform)
         cs8_commit_tok(X1, nG, rv, tid);
         cs8_commit_tok(X2, nV, rv, tid);
@@ -872,12 +903,15 @@ __global__ __launch_bounds__(NT4, NK <= 2 ? 4 : 2) void k_csf_bwd_tok4(const CsT
                 }
 #endif
                 if (kk == 0) {
-                    tile_mma8<false, false>(accdA, X1, X2, rt, ch, lane);      // dO V^T
+                    tile_a8(aG, X1, rt, lane);
+                    tile_a8(aV, X2, rt, lane);
+                    tile_mma8r<false>(accdA, aG, X2, ch, lane);                // dO V^T
                     tile_mma8<true, true>(accV, As, X1, rt, ch, lane);         // A^T dO
                 }
-                tile_mma8<false, false>(accQ[kk], X1, B1, rt, ch, lane);       // dO P^T
-                tile_mma8<false, false>(accK[kk], X2, B2, rt, ch, lane);       // V dS^T
-                tile_mma8<false, true>(accV, KT + kk * CT, B2, rt, ch, lane);  // K dS
+                tile_mma8r<false>(accQ[kk], aG, B1, ch, lane);                 // dO P^T
+                tile_mma8r<false>(accK[kk], aV, B2, ch, lane);                 // V dS^T
+                if constexpr (KREG) tile_mma8r<true>(accV, aK[kk], B2, ch, lane);                  // K dS
+                else                tile_mma8<false, true>(accV, KT + kk * CT, B2, rt, ch, lane);
                 __syncthreads();
             }
         }
@@ -983,76 +1017,85 @@ __global__ __launch_bounds__(NTHREADS) void k_csf_state(const CsfStateArgs a) {
 constexpr int ST2_KW = 128, ST2_VW = 256, ST2_LDX = ST2_KW + 8, ST2_LDY = ST2_VW + 8;
 constexpr int CSF_STATE2_SMEM = (CS * ST2_LDX + CS * ST2_LDY + 4 * 16 * CLD) * 2;
 
+// A workgroup walks ST2_CPW consecutive chunks with the next chunk's rows in flight in registers while the current one is
+// multiplied and stored (one workgroup per chunk lived 8 us, a quarter of it waiting for its first rows with nothing else to do).
+constexpr int ST2_CPW = 4;
 __global__ __launch_bounds__(NTHREADS, 2) void k_csf_state2(const CsfStateArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u16* Xs = reinterpret_cast<u16*>(smem_raw);
     u16* Ys = Xs + CS * ST2_LDX;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nl = lane & 15, kg = lane >> 4;
     u16* Ws = Ys + CS * ST2_LDY + wave * 16 * CLD;
-    const int ci = blockIdx.x, bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
+    const int c0 = blockIdx.x * ST2_CPW, c1 = min(a.n, c0 + ST2_CPW), bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
     const int nvb = (a.V + ST2_VW - 1) / ST2_VW, kb = blockIdx.z / nvb, vb = blockIdx.z - kb * nvb;
     const int k0 = kb * ST2_KW, v0 = vb * ST2_VW, kw = min(ST2_KW, a.K - k0), vw = min(ST2_VW, a.V - v0);
-    const long p0 = (long)ci * CS;
-    const int rv = (int)min((long)CS, a.T - p0);
     const u16* xb = (const u16*)a.x.ptr + b * a.x.sb + h * a.x.sh + k0;
     const u16* yb = (const u16*)a.y.ptr + b * a.y.sb + h * a.y.sh + v0;
-    u16* ob = a.out + ((long)bh * a.n + ci) * a.K * a.V;
 
     // X: 4 passes of 16 rows x 16 pieces; Y: 8 passes of 8 rows x 32 pieces (pieces past the block's width, rows past the chunk: zeros)
+    const int xc = (tid & 15) * 8, yc = (tid & 31) * 8;
+    const bool xok = xc < kw, yok = yc < vw;
     uint4 xr[4], yr[8];
-    {
-        const int xc = (tid & 15) * 8, yc = (tid & 31) * 8;
+    auto issue = [&](int ci) {   // (no load behind a branch: rows past the sequence's end read the chunk's first row)
+        const long p0 = (long)ci * CS;
+        const int rv = (int)min((long)CS, a.T - p0);
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int row = (tid >> 4) + 16 * p;
-            const bool ok = row < rv && xc < kw;
-            xr[p] = gld_stream16(xb + (p0 + (ok ? row : 0)) * a.x.sn + (ok ? xc : 0));
+            xr[p] = gld_stream16(xb + (p0 + (row < rv ? row : 0)) * a.x.sn + (xok ? xc : 0));
         }
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
             const int row = (tid >> 5) + 8 * p;
-            const bool ok = row < rv && yc < vw;
-            yr[p] = gld_stream16(yb + (p0 + (ok ? row : 0)) * a.y.sn + (ok ? yc : 0));
+            yr[p] = gld_stream16(yb + (p0 + (row < rv ? row : 0)) * a.y.sn + (yok ? yc : 0));
         }
+    };
+    issue(c0);
+    for (int ci = c0; ci < c1; ++ci) {
+        const int rv = (int)min((long)CS, a.T - (long)ci * CS);
+        u16* ob = a.out + ((long)bh * a.n + ci) * a.K * a.V;
+        if (ci > c0) __syncthreads();   // the previous chunk's tiles are dead
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int row = (tid >> 4) + 16 * p;
-            const bool ok = row < rv && xc < kw;
+            const bool ok = row < rv && xok;
             *reinterpret_cast<uint4*>(Xs + row * ST2_LDX + xc) = make_uint4(ok ? xr[p].x : 0u, ok ? xr[p].y : 0u, ok ? xr[p].z : 0u, ok ? xr[p].w : 0u);
         }
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
             const int row = (tid >> 5) + 8 * p;
-            const bool ok = row < rv && yc < vw;
+            const bool ok = row < rv && yok;
             *reinterpret_cast<uint4*>(Ys + row * ST2_LDY + yc) = make_uint4(ok ? yr[p].x : 0u, ok ? yr[p].y : 0u, ok ? yr[p].z : 0u, ok ? yr[p].w : 0u);
         }
-    }
-    __syncthreads();
+        __syncthreads();
+        issue(min(ci + 1, c1 - 1));   // behind the last chunk: its own rows again (cache hits, never used)
 #pragma unroll
-    for (int rr = 0; rr < 2; ++rr) {
-        const int rt = wave * 2 + rr;               // 16 summary rows kk = k0 + 16 rt ..
-        if (rt * 16 < kw) {
-            // the product is formed transposed (m = v, n = kk): a lane ends up with four consecutive v of one summary row
-            const bf16x8 xa0 = tr_read8(Xs, ST2_LDX, 0, rt * 16, lane), xa1 = tr_read8(Xs, ST2_LDX, 32, rt * 16, lane);
-            for (int vt = 0; vt * 64 < vw; ++vt) {
-                f32x4 acc[4];
-                zero4(acc);
+        for (int rr = 0; rr < 2; ++rr) {
+            const int rt = wave * 2 + rr;               // 16 summary rows kk = k0 + 16 rt ..
+            if (rt * 16 < kw) {
+                // the product is formed transposed (m = v, n = kk): a lane ends up with four consecutive v of one summary row
+                const bf16x8 xa0 = tr_read8(Xs, ST2_LDX, 0, rt * 16, lane), xa1 = tr_read8(Xs, ST2_LDX, 32, rt * 16, lane);
+                for (int vt = 0; vt * 64 < vw; ++vt) {
+                    f32x4 acc[4];
+                    zero4(acc);
 #pragma unroll
-                for (int tn = 0; tn < 4; ++tn) {
-                    acc[tn] = mfma_bf16(tr_read8(Ys, ST2_LDY, 0, vt * 64 + tn * 16, lane), xa0, acc[tn]);
-                    acc[tn] = mfma_bf16(tr_read8(Ys, ST2_LDY, 32, vt * 64 + tn * 16, lane), xa1, acc[tn]);
+                    for (int tn = 0; tn < 4; ++tn) {
+                        acc[tn] = mfma_bf16(tr_read8(Ys, ST2_LDY, 0, vt * 64 + tn * 16, lane), xa0, acc[tn]);
+                        acc[tn] = mfma_bf16(tr_read8(Ys, ST2_LDY, 32, vt * 64 + tn * 16, lane), xa1, acc[tn]);
+                    }
+#pragma unroll
+                    for (int tn = 0; tn < 4; ++tn)
+                        *reinterpret_cast<uint2*>(Ws + nl * CLD + tn * 16 + kg * 4) =
+                            make_uint2(pack_bf16x2(a.mul * acc[tn][0], a.mul * acc[tn][1]), pack_bf16x2(a.mul * acc[tn][2], a.mul * acc[tn][3]));
+                    wave_lds_fence();
+                    // a store instruction covers eight full 128-byte rows (two half rows per lane pair made it 16 half lines)
+                    const int r = lane >> 3, c = (lane & 7) * 8;
+                    const uint4 o0 = *reinterpret_cast<const uint4*>(Ws + r * CLD + c), o1 = *reinterpret_cast<const uint4*>(Ws + (r + 8) * CLD + c);
+                    u16* d = ob + cs_tile_off(k0 + rt * 16, v0 + vt * 64, a.V) + ((rt * 16) & 63) * CS + r * CS + c;
+                    gst<uint4>(d, o0);
+                    gst<uint4>(d + 8 * CS, o1);
+                    wave_lds_fence();
                 }
-#pragma unroll
-                for (int tn = 0; tn < 4; ++tn)
-                    *reinterpret_cast<uint2*>(Ws + nl * CLD + tn * 16 + kg * 4) =
-                        make_uint2(pack_bf16x2(a.mul * acc[tn][0], a.mul * acc[tn][1]), pack_bf16x2(a.mul * acc[tn][2], a.mul * acc[tn][3]));
-                wave_lds_fence();
-                const int r = lane >> 2, c = (lane & 3) * 16;
-                const uint4 o0 = *reinterpret_cast<const uint4*>(Ws + r * CLD + c), o1 = *reinterpret_cast<const uint4*>(Ws + r * CLD + c + 8);
-                u16* d = ob + cs_tile_off(k0 + rt * 16, v0 + vt * 64, a.V) + ((rt * 16) & 63) * CS + r * CS + c;
-                gst<uint4>(d, o0);
-                gst<uint4>(d + 8, o1);
-                wave_lds_fence();
             }
         }
     }
