@@ -46,7 +46,9 @@ def _device_guard(fn):
     @functools.wraps(fn)
     def wrapped(*args, **kw):
         dev = next((a.device for a in args if isinstance(a, torch.Tensor) and a.is_cuda), None)
-        if dev is None:
+        # (the common case -- the tensor's device is already current -- costs one C call: an eager fwd+bwd of the DiT shape is
+        # bound by the host, tools/host_overhead.py)
+        if dev is None or dev.index == torch._C._cuda_getDevice():
             return fn(*args, **kw)
         with torch.cuda.device(dev):
             return fn(*args, **kw)
@@ -110,7 +112,9 @@ def _alloc_like_tokens(B, N, H, D, ref):
 
 
 def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    # raw handle of the current device's current stream (torch.cuda.current_stream() builds a Stream object through several
+    # Python layers: 20 us per call)
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 def _ws(nbytes: int, device) -> torch.Tensor:
@@ -182,8 +186,10 @@ class _BlockMix(torch.autograd.Function):
         B, N, H, D = q.shape
         M = Wf.shape[0]
         S = N // M
-        _check_like(q, "mhla_blockmix backward", dout=(dout.to(q.dtype), q.shape))
-        dout = _prep(dout.to(q.dtype))
+        if dout.dtype != q.dtype:
+            dout = dout.to(q.dtype)
+        _check_like(q, "mhla_blockmix backward", dout=(dout, q.shape))
+        dout = _prep(dout)
         dq = _alloc_like_tokens(B, N, H, D, q)
         dk = _alloc_like_tokens(B, N, H, D, q)
         dv = _alloc_like_tokens(B, N, H, D, q)
