@@ -139,8 +139,18 @@ static int cs_fwd_impl(mhla_view q, mhla_view k, mhla_view v, const float* mix, 
         RC(cs_state16(k, v, (uint16_t*)w.S, 1.f, B, T, H, n, K, V, st));
         RC(cs_mix_fwd(mix, ldmix, (const uint16_t*)w.S, (uint16_t*)w.P, B * H, n, E, st));
         CsOutArgs o{cv(q), cv(k), cv(v), cmv(out), mix, ldmix, w.P, H, n, K, V, (long)T, scale, cmv(y), cv(gate), nw, neps};
-        if (epi) RC(launch(fast::k_csf_out<uint16_t, true>, dim3(n, B * H, 1), dim3(NTHREADS), fast::CSF_OUT_SMEM, st, "k_csf_out<norm>", o));
-        else     RC(launch(fast::k_csf_out<uint16_t>, dim3(n, B * H, (V / 64 + fast::CSF_OUT_VS - 1) / fast::CSF_OUT_VS), dim3(NTHREADS), fast::CSF_OUT_SMEM, st, "k_csf_out", o));
+        static const char* const outv = getenv("MHLA_CAUSAL_OUT");   // tuning knob, read once: "old" keeps the four-wave kernel
+        if (outv && outv[0] == 'o') {
+            if (epi) RC(launch(fast::k_csf_out<uint16_t, true>, dim3(n, B * H, 1), dim3(NTHREADS), fast::CSF_OUT_SMEM, st, "k_csf_out<norm>", o));
+            else     RC(launch(fast::k_csf_out<uint16_t>, dim3(n, B * H, (V / 64 + fast::CSF_OUT_VS - 1) / fast::CSF_OUT_VS), dim3(NTHREADS), fast::CSF_OUT_SMEM, st, "k_csf_out", o));
+            return MHLA_OK;
+        }
+        // V slices per workgroup: the largest of 4, 3, 2, 1 that divides V / 64 (the fused epilogue owns the head: V / 64 <= 4)
+        const int nvs = V / 64, nv = nvs % 4 == 0 ? 4 : nvs % 3 == 0 ? 3 : nvs % 2 == 0 ? 2 : 1;
+#define OUT4(NV, EPI) launch(fast::k_csf_out4<NV, EPI>, dim3(n, B * H, nvs / NV), dim3(fast::NT4), fast::csf_out4_smem<NV, EPI>(), st, EPI ? "k_csf_out4<norm>" : "k_csf_out4", o)
+        if (epi) RC(nvs == 1 ? OUT4(1, true) : nvs == 2 ? OUT4(2, true) : nvs == 3 ? OUT4(3, true) : OUT4(4, true));
+        else     RC(nv == 1 ? OUT4(1, false) : nv == 2 ? OUT4(2, false) : nv == 3 ? OUT4(3, false) : OUT4(4, false));
+#undef OUT4
         return MHLA_OK;
     }
     DISPATCH_T(dtype, {

@@ -957,6 +957,182 @@ __global__ __launch_bounds__(NT4, NK <= 2 ? 4 : 2) void k_csf_bwd_tok4(const CsT
     }
 }
 
+// k_csf_out4: k_csf_out on eight waves (16 rows x 32 columns of every 64 x 64 product per wave, as k_csf_bwd_tok4), with the loads
+// of its rounds out of every branch.  k_csf_out chose its next tile with if / else chains: hipcc then waits for ALL loads in flight
+// before each staging write (s_waitcnt vmcnt(0)), so its one-step-ahead prefetch was in effect load -> wait -> multiply.  Here a
+// round (K slice ki, V slice j) commits slot j of a register ring to one of two LDS buffers, passes ONE barrier, refills the slot
+// with the same V slice of the next K slice (behind the last K slice: with the V rows of slice j for the second phase) and
+// multiplies; the Q and K tiles of the next K slice travel during the NV rounds of the current one.
+//   grid (n, bh, V / (64 NV)); NV = V slices per workgroup (template: the j loop carries no runtime guard)
+template <int NV, bool EPI>
+__host__ __device__ constexpr int csf_out4_smem() { return 7 * CT * 2 + (EPI ? 2 * 64 * 4 : 0); }
+__device__ __forceinline__ void cs8_store_tok_gate(u16* __restrict__ base, long sn, const u16* __restrict__ gbase, long gsn, long p0,
+                                                   int rv, const u16* __restrict__ Os, int tid) {
+    const int r = tid >> 3, c = (tid & 7) * 8;
+    if (r < rv) {
+        uint4 x = *reinterpret_cast<const uint4*>(Os + r * CLD + c);
+        if (gbase) {
+            const uint4 g = gld<uint4>(gbase + (p0 + r) * gsn + c);
+            unsigned xw[4] = {x.x, x.y, x.z, x.w};
+            const unsigned gw[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float g0 = __uint_as_float(gw[i] << 16), g1 = __uint_as_float(gw[i] & 0xffff0000u);
+                const float y0 = __uint_as_float(xw[i] << 16) * g0 / (1.f + __expf(-g0));
+                const float y1 = __uint_as_float(xw[i] & 0xffff0000u) * g1 / (1.f + __expf(-g1));
+                xw[i] = pack_bf16x2(y0, y1);
+            }
+            x = make_uint4(xw[0], xw[1], xw[2], xw[3]);
+        }
+        *reinterpret_cast<uint4*>(base + (p0 + r) * sn + c) = x;
+    }
+}
+
+template <int NV, bool EPI>
+__global__ __launch_bounds__(NT4, 4) void k_csf_out4(const CsOutArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u16* Qs = reinterpret_cast<u16*>(smem_raw);   // Q tiles [2], later output staging [2]
+    u16* Ks = Qs + 2 * CT;                        // K tiles [2]
+    u16* Ps = Ks + 2 * CT;                        // P tiles [2], later V tiles [2]
+    u16* As = Ps + 2 * CT;                        // m_ii tril(QK^T)
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, n = lane & 15, kg = lane >> 4;
+    const int rt = wave & 3, ch = wave >> 2;
+    const int ci = blockIdx.x, bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
+    const int vbase = blockIdx.z * 64 * NV;
+    const long p0 = (long)ci * CS;
+    const int rv = (int)min((long)CS, a.T - p0);
+    const int V = a.V, nks = a.K / 64;
+    const u16* qb = (const u16*)a.q.ptr + b * a.q.sb + h * a.q.sh;
+    const u16* kb = (const u16*)a.k.ptr + b * a.k.sb + h * a.k.sh;
+    const u16* vb = (const u16*)a.v.ptr + b * a.v.sb + h * a.v.sh + vbase;
+    u16* ob = (u16*)a.o.ptr + b * a.o.sb + h * a.o.sh + vbase;
+    const u16* Pb = reinterpret_cast<const u16*>(a.P) + ((long)bh * a.n + ci) * a.K * V;
+    const int tr = tid >> 3, tc = (tid & 7) * 8;
+    const long trow = p0 + (tr < rv ? tr : 0);   // the thread's token row (rows past the sequence: the chunk's first row, zeroed on commit)
+
+    // The order of these loads must be the order in which the loop re-issues them (Q, K, P slices): hipcc counts the loads in
+    // flight per register and, where the entry and the back edge of the loop disagree, waits for the younger position -- with the
+    // Q / K loads sunk into the loop's preheader behind the P loads it waited for everything at the top of every K slice.
+    uint4 rQ, rK, rP[NV];
+    cs8_issue_tok(rQ, qb, a.q.sn, p0, rv, tid);
+    cs8_issue_tok(rK, kb, a.k.sn, p0, rv, tid);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) cs8_issue_state(rP[j], Pb + cs_tile_off(0, vbase + 64 * j, V), tid);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 accO[NV][2], accA[2];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) zero2(accO[j]);
+    zero2(accA);
+    int ki = 0;
+    do {   // (K >= 64: no branch around the loop for the Q / K loads to sink under)
+        const bool lastk = ki + 1 >= nks;   // (uniform)
+        const int kn = lastk ? ki : ki + 1;
+        u16* Qc = Qs + (ki & 1) * CT;
+        u16* Kc = Ks + (ki & 1) * CT;
+        bf16x8 aQ[2];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            u16* Pc = Ps + ((ki * NV + j) & 1) * CT;
+            if (j == 0) {
+                cs8_commit_tok(Qc, rQ, rv, tid);
+                cs8_commit_tok(Kc, rK, rv, tid);
+            }
+            cs8_commit_state(Pc, rP[j], tid);
+            __syncthreads();
+            if (j == 0) {   // (behind the last K slice: the same tiles again, never used)
+                cs8_issue_tok(rQ, qb + kn * 64, a.q.sn, p0, rv, tid);
+                cs8_issue_tok(rK, kb + kn * 64, a.k.sn, p0, rv, tid);
+            }
+            {
+                const u16* psrc = Pb + cs_tile_off(kn * 64, vbase + 64 * j, V) + tid * 8;
+                const u16* vsrc = vb + 64 * j + trow * a.v.sn + tc;   // second phase's V rows
+                rP[j] = gld<uint4>(lastk ? vsrc : psrc);
+            }
+            if (j == 0) {
+                tile_a8(aQ, Qc, rt, lane);
+                tile_mma8r<false>(accA, aQ, Kc, ch, lane);   // Q K^T
+            }
+            tile_mma8r<true>(accO[j], aQ, Pc, ch, lane);     // Q P
+        }
+    } while (++ki < nks);
+    const float mii = a.mix[(long)ci * a.ldmix + ci];
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = rt * 16 + kg * 4 + r, col = ch * 32 + tn * 16 + n;
+            As[row * CLD + col] = cvt_bf16(col <= row ? mii * accA[tn][r] : 0.f);
+        }
+    __syncthreads();   // the last round's P tile is dead, As is complete
+    if constexpr (!EPI) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            u16* Vc = Ps + (j & 1) * CT;
+            u16* Oc = Qs + (j & 1) * CT;
+            cs8_commit_tok(Vc, rP[j], rv, tid);
+            __syncthreads();
+            tile_mma8<false, true>(accO[j], As, Vc, rt, ch, lane);        // tril(QK^T) V
+            cs8_put(Oc, accO[j], a.scale, rt, ch, lane);
+            __syncthreads();
+            cs8_store_tok(ob + 64 * j, a.o.sn, p0, rv, Oc, tid);
+        }
+    } else {
+        float* red = reinterpret_cast<float*>(As + CT);   // [2 column halves][64 rows] sums of squares
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            u16* Vc = Ps + (j & 1) * CT;
+            cs8_commit_tok(Vc, rP[j], rv, tid);
+            __syncthreads();
+            tile_mma8<false, true>(accO[j], As, Vc, rt, ch, lane);
+        }
+        // row sums of squares over the head's V channels: lane holds rows 16 rt + 4 kg + r, columns 64 j + 32 ch + 16 tn + n
+        float ss[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float x = a.scale * accO[j][tn][r];
+                    ss[r] += x * x;
+                }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float x = ss[r];
+            x += __shfl_xor(x, 1, 64); x += __shfl_xor(x, 2, 64); x += __shfl_xor(x, 4, 64); x += __shfl_xor(x, 8, 64);
+            if (n == 0) red[ch * 64 + rt * 16 + kg * 4 + r] = x;
+        }
+        __syncthreads();
+        u16* yb = (u16*)a.y.ptr + b * a.y.sb + h * a.y.sh + vbase;
+        const u16* gb = a.gate.ptr ? (const u16*)a.gate.ptr + b * a.gate.sb + h * a.gate.sh + vbase : nullptr;
+        float rstd[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = rt * 16 + kg * 4 + r;
+            rstd[r] = rsqrtf((red[row] + red[64 + row]) / (float)V + a.neps);
+        }
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            u16* Oc = Qs + (j & 1) * CT;
+            u16* Yc = Ps + (j & 1) * CT;
+            if (a.o.ptr) {   // training: the operator's own output is kept for the norm's backward
+                cs8_put(Oc, accO[j], a.scale, rt, ch, lane);
+            }
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn) {
+                const float w = a.nw ? gld<float>(a.nw + vbase + 64 * j + ch * 32 + tn * 16 + n) : 1.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) accO[j][tn][r] *= a.scale * rstd[r] * w;
+            }
+            cs8_put(Yc, accO[j], 1.f, rt, ch, lane);
+            __syncthreads();
+            if (a.o.ptr) cs8_store_tok(ob + 64 * j, a.o.sn, p0, rv, Oc, tid);
+            cs8_store_tok_gate(yb + 64 * j, a.y.sn, gb ? gb + 64 * j : nullptr, a.gate.sn, p0, rv, Yc, tid);
+        }
+    }
+}
+
 // -------------------------------------------------------------------------------------------------
 // k_csf_state: out[bh][ci][kk][v] (bf16) = mul * sum_{c in chunk ci} X[c][kk] Y[c][v]        grid (n, bh, K / 64)
 //   forward: X = K, Y = V (S_j, naive.py:60);  backward: X = Q, Y = dO, mul = scale (dP_i)
