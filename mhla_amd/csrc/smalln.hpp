@@ -179,8 +179,13 @@ __host__ __device__ constexpr int sn_fwd_smem() {
 // ------------------------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------------------------
-template <int DT>
+template <int DT, bool GATHER>
 __global__ __launch_bounds__(SN_T, SN_T / 256) void k_sn_fwd(const SnArgs a) {
+    // GATHER: the launch has a block_index map.  As a template parameter the row lookups carry no branch: with `idx ? idx[p] : p`
+    // decided at run time hipcc branched around every map load and waited for ALL loads in flight at each join (s_waitcnt
+    // vmcnt(0) after every group of row loads: the staging became a chain of dependent round trips).
+    const int* const idx = GATHER ? a.idx : nullptr;
+    if constexpr (GATHER) __builtin_assume(idx != nullptr);
     constexpr int DP = DT * 16, LDR = sn_ldr<DT>(), KS = (DP + 31) / 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u16* Ks = reinterpret_cast<u16*>(smem_raw);          // [N][LDR]
@@ -203,9 +208,9 @@ __global__ __launch_bounds__(SN_T, SN_T / 256) void k_sn_fwd(const SnArgs a) {
     // the wave's own Q rows are requested first: they travel while K, V are staged
     uint4 qraw[2][KS];
 #pragma unroll
-    for (int x = 0; x < 2; ++x) sn_issue_rows<KS>(qraw[x], qb, a.q.sn, a.idx, min(wave + SN_W * x, M - 1) * 16, D, lane);
-    sn_stage<DT>(Ks, kb, a.k.sn, a.idx, N, D, a.eps, tid, a.relu != 0);
-    sn_stage<DT>(Vs, vb, a.v.sn, a.idx, N, D, 0.f, tid, false);
+    for (int x = 0; x < 2; ++x) sn_issue_rows<KS>(qraw[x], qb, a.q.sn, idx, min(wave + SN_W * x, M - 1) * 16, D, lane);
+    sn_stage<DT>(Ks, kb, a.k.sn, idx, N, D, a.eps, tid, a.relu != 0);
+    sn_stage<DT>(Vs, vb, a.v.sn, idx, N, D, 0.f, tid, false);
     __syncthreads();
     if (a.normalize) {
         for (int v = tid; v < M * DP; v += SN_T) {
@@ -283,7 +288,7 @@ __global__ __launch_bounds__(SN_T, SN_T / 256) void k_sn_fwd(const SnArgs a) {
         const int dv = D >> 3;
         for (int v = lane; v < 16 * dv; v += 64) {
             const int r = v / dv, p = v - r * dv;
-            *reinterpret_cast<uint4*>(ob + tok_row(a.idx, i * 16 + r) * a.out.sn + p * 8) = *reinterpret_cast<const uint4*>(Os + r * LDR + p * 8);
+            *reinterpret_cast<uint4*>(ob + tok_row(idx, i * 16 + r) * a.out.sn + p * 8) = *reinterpret_cast<const uint4*>(Os + r * LDR + p * 8);
         }
         wave_lds_fence();
     }
@@ -313,8 +318,13 @@ __device__ __forceinline__ void sn_store16(u16* __restrict__ base, long sn, cons
     }
 }
 
-template <int DT>
+template <int DT, bool GATHER>
 __global__ __launch_bounds__(SN_TB, 2) void k_sn_bwd(const SnArgs a) {
+    // GATHER: the launch has a block_index map.  As a template parameter the row lookups carry no branch: with `idx ? idx[p] : p`
+    // decided at run time hipcc branched around every map load and waited for ALL loads in flight at each join (s_waitcnt
+    // vmcnt(0) after every group of row loads: the staging became a chain of dependent round trips).
+    const int* const idx = GATHER ? a.idx : nullptr;
+    if constexpr (GATHER) __builtin_assume(idx != nullptr);
     constexpr int DP = DT * 16, LDR = sn_ldr<DT>(), KS = (DP + 31) / 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u16* T0 = reinterpret_cast<u16*>(smem_raw);          // K, later Q          [N][LDR]
@@ -343,7 +353,7 @@ __global__ __launch_bounds__(SN_TB, 2) void k_sn_bwd(const SnArgs a) {
     const bool hasA = bA < M, hasB = bB < M;
     const int blk[2] = {hasA ? bA : 0, hasB ? bB : (hasA ? bA : 0)};
     auto load_k = [&](bf16x8 (&r)[KS], int j) {
-        sn_load_rows<KS>(r, kb, a.k.sn, a.idx, j * 16, D, a.eps, lane, a.relu != 0);
+        sn_load_rows<KS>(r, kb, a.k.sn, idx, j * 16, D, a.eps, lane, a.relu != 0);
     };
     // dO rows scaled by 1/n (row = lane & 15), rounded to bf16
     auto scale_dop = [&](bf16x8 (&r)[KS], int i) {
@@ -368,15 +378,15 @@ __global__ __launch_bounds__(SN_TB, 2) void k_sn_bwd(const SnArgs a) {
     uint4 qraw[2][KS], graw[2][KS], oraw[2][KS];
 #pragma unroll
     for (int x = 0; x < 2; ++x) {
-        sn_issue_rows<KS>(qraw[x], qb, a.q.sn, a.idx, blk[x] * 16, D, lane);
-        sn_issue_rows<KS>(graw[x], gb, a.dout.sn, a.idx, blk[x] * 16, D, lane);
-        if (a.normalize) sn_issue_rows<KS>(oraw[x], ob, a.o.sn, a.idx, blk[x] * 16, D, lane);
+        sn_issue_rows<KS>(qraw[x], qb, a.q.sn, idx, blk[x] * 16, D, lane);
+        sn_issue_rows<KS>(graw[x], gb, a.dout.sn, idx, blk[x] * 16, D, lane);
+        if (a.normalize) sn_issue_rows<KS>(oraw[x], ob, a.o.sn, idx, blk[x] * 16, D, lane);
     }
     // ---- P0 / P1: K, V tiles; ksum ----
     __shared__ float Wsh[16 * 17];   // mixing weights (M <= 16), read in every inner loop
     if (tid < 256) Wsh[(tid >> 4) * 17 + (tid & 15)] = ((tid >> 4) < M && (tid & 15) < M) ? a.W[(long)(tid >> 4) * a.ldw + (tid & 15)] : 0.f;
-    sn_stage<DT, SN_TB>(T0, kb, a.k.sn, a.idx, N, D, a.eps, tid, a.relu != 0);
-    sn_stage<DT, SN_TB>(T1, vb, a.v.sn, a.idx, N, D, 0.f, tid, false);
+    sn_stage<DT, SN_TB>(T0, kb, a.k.sn, idx, N, D, a.eps, tid, a.relu != 0);
+    sn_stage<DT, SN_TB>(T1, vb, a.v.sn, idx, N, D, 0.f, tid, false);
 #pragma unroll
     for (int x = 0; x < 2; ++x) {
         sn_finish_rows<KS>(qa[x], qraw[x], D, a.eps, lane, a.relu != 0);
@@ -517,8 +527,8 @@ __global__ __launch_bounds__(SN_TB, 2) void k_sn_bwd(const SnArgs a) {
                     }
                 }
                 wave_lds_fence();
-                if (a.relu) sn_store16<true>(dqb, a.dq.sn, a.idx, i * 16, D, Os, LDR, qb, a.q.sn, lane);
-                else        sn_store16<false>(dqb, a.dq.sn, a.idx, i * 16, D, Os, LDR, nullptr, 0, lane);
+                if (a.relu) sn_store16<true>(dqb, a.dq.sn, idx, i * 16, D, Os, LDR, qb, a.q.sn, lane);
+                else        sn_store16<false>(dqb, a.dq.sn, idx, i * 16, D, Os, LDR, nullptr, 0, lane);
                 wave_lds_fence();
             }
         }
@@ -529,15 +539,15 @@ __global__ __launch_bounds__(SN_TB, 2) void k_sn_bwd(const SnArgs a) {
 #pragma unroll
     for (int x = 0; x < 2; ++x) {
         load_k(ka[x], blk[x]);
-        sn_load_rows<KS>(va[x], vb, a.v.sn, a.idx, blk[x] * 16, D, 0.f, lane);
+        sn_load_rows<KS>(va[x], vb, a.v.sn, idx, blk[x] * 16, D, 0.f, lane);
     }
     __syncthreads();
     trace_mark(a.trace, 6);
 
     // ---- P5: Q and dO' tiles replace K and V ----
-    sn_stage<DT, SN_TB>(T0, qb, a.q.sn, a.idx, N, D, a.eps, tid, a.relu != 0);
-    if (a.normalize) sn_stage<DT, SN_TB, true>(T1, gb, a.dout.sn, a.idx, N, D, 0.f, tid, false, nis);
-    else             sn_stage<DT, SN_TB>(T1, gb, a.dout.sn, a.idx, N, D, 0.f, tid, false);
+    sn_stage<DT, SN_TB>(T0, qb, a.q.sn, idx, N, D, a.eps, tid, a.relu != 0);
+    if (a.normalize) sn_stage<DT, SN_TB, true>(T1, gb, a.dout.sn, idx, N, D, 0.f, tid, false, nis);
+    else             sn_stage<DT, SN_TB>(T1, gb, a.dout.sn, idx, N, D, 0.f, tid, false);
     __syncthreads();
     trace_mark(a.trace, 7);
 
@@ -616,15 +626,15 @@ __global__ __launch_bounds__(SN_TB, 2) void k_sn_bwd(const SnArgs a) {
 #pragma unroll
                 for (int tn = 0; tn < DT; ++tn) Os[(kg * 4 + r) * LDR + tn * 16 + n] = cvt_bf16(accK[x][tn][r] + dks[tn][0]);
             wave_lds_fence();
-            if (a.relu) sn_store16<true>(dkb, a.dk.sn, a.idx, j * 16, D, Os, LDR, kb, a.k.sn, lane);
-            else        sn_store16<false>(dkb, a.dk.sn, a.idx, j * 16, D, Os, LDR, nullptr, 0, lane);
+            if (a.relu) sn_store16<true>(dkb, a.dk.sn, idx, j * 16, D, Os, LDR, kb, a.k.sn, lane);
+            else        sn_store16<false>(dkb, a.dk.sn, idx, j * 16, D, Os, LDR, nullptr, 0, lane);
             wave_lds_fence();
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int tn = 0; tn < DT; ++tn) Os[(kg * 4 + r) * LDR + tn * 16 + n] = cvt_bf16(accV[x][tn][r]);
             wave_lds_fence();
-            sn_store16<false>(dvb, a.dv.sn, a.idx, j * 16, D, Os, LDR, nullptr, 0, lane);
+            sn_store16<false>(dvb, a.dv.sn, idx, j * 16, D, Os, LDR, nullptr, 0, lane);
             wave_lds_fence();
         }
     }

@@ -157,8 +157,13 @@ __host__ __device__ constexpr int snf_smem() {
 // ------------------------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------------------------
-template <int DT>
+template <int DT, bool GATHER>
 __global__ __launch_bounds__(SNF_T, 2) void k_snf_fwd(const SnArgs a) {
+    // GATHER: the launch has a block_index map.  As a template parameter the row lookups carry no branch: with `idx ? idx[p] : p`
+    // decided at run time hipcc branched around every map load and waited for ALL loads in flight at each join (s_waitcnt
+    // vmcnt(0) after every group of row loads: the staging became a chain of dependent round trips).
+    const int* const idx = GATHER ? a.idx : nullptr;
+    if constexpr (GATHER) __builtin_assume(idx != nullptr);
     constexpr int DP = DT * 16, LDR = sn_ldr<DT>(), KS = (DP + 31) / 32, PL = SNF_HR * LDR;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u16* Kh = reinterpret_cast<u16*>(smem_raw);
@@ -178,7 +183,7 @@ __global__ __launch_bounds__(SNF_T, 2) void k_snf_fwd(const SnArgs a) {
 
     __shared__ float Wsh[16 * 17];
     if (tid < 256) Wsh[(tid >> 4) * 17 + (tid & 15)] = ((tid >> 4) < M && (tid & 15) < M) ? a.W[(long)(tid >> 4) * a.ldw + (tid & 15)] : 0.f;
-    if (a.normalize) snf_ksum<DT>(ksum_s, kb, a.k.sn, a.idx, M, D, a.eps, tid, relu);
+    if (a.normalize) snf_ksum<DT>(ksum_s, kb, a.k.sn, idx, M, D, a.eps, tid, relu);
 
     f32x4 acc[2][DT];
 #pragma unroll
@@ -190,8 +195,8 @@ __global__ __launch_bounds__(SNF_T, 2) void k_snf_fwd(const SnArgs a) {
     for (int half = 0; half * SNF_HR < N; ++half) {
         const int r0 = half * SNF_HR, nr = min(SNF_HR, N - r0), jb = half * 8;
         __syncthreads();   // the previous half's readers are done (first round: Wsh / ksum_s written)
-        snf_stage<DT, false>(Kh, Kl, kb, a.k.sn, a.idx, r0, nr, D, a.eps, tid, relu, nullptr);
-        snf_stage<DT, false>(Vh, Vl, vb, a.v.sn, a.idx, r0, nr, D, 0.f, tid, false, nullptr);
+        snf_stage<DT, false>(Kh, Kl, kb, a.k.sn, idx, r0, nr, D, a.eps, tid, relu, nullptr);
+        snf_stage<DT, false>(Vh, Vl, vb, a.v.sn, idx, r0, nr, D, 0.f, tid, false, nullptr);
         __syncthreads();
 #pragma unroll
         for (int x = 0; x < 2; ++x) {
@@ -200,7 +205,7 @@ __global__ __launch_bounds__(SNF_T, 2) void k_snf_fwd(const SnArgs a) {
             bf16x8 qh[KS], ql[KS];
             {
                 f32x4 qraw[KS][2];
-                snf_issue_rows<KS>(qraw, qb, a.q.sn, a.idx, i * 16, D, lane);
+                snf_issue_rows<KS>(qraw, qb, a.q.sn, idx, i * 16, D, lane);
                 snf_finish_rows<KS>(qh, ql, qraw, D, a.eps, lane, relu);
             }
             if (half == 0 && a.normalize) {   // z_i[s] = q_i[s] . ksum_i (lane: row n, 8-column pieces kg)
@@ -266,7 +271,7 @@ __global__ __launch_bounds__(SNF_T, 2) void k_snf_fwd(const SnArgs a) {
 #pragma unroll
             for (int tn = 0; tn < DT; ++tn) acc[x][tn][r] *= ni;
         }
-        snf_store16<DT, false>(ob, a.out.sn, a.idx, i * 16, D, acc[x], nullptr, 0, lane);
+        snf_store16<DT, false>(ob, a.out.sn, idx, i * 16, D, acc[x], nullptr, 0, lane);
     }
 }
 
@@ -275,8 +280,13 @@ __global__ __launch_bounds__(SNF_T, 2) void k_snf_fwd(const SnArgs a) {
 //   pass A (wave owns query block i, K / V halves in LDS):  S^T, dP^T tiles -> dW[i][:], dS -> dQ_i
 //   pass B (wave owns key block j, Q / dO' halves in LDS):  S, dP tiles -> P^T dO' = dV_j ; dS^T Q = dK_j ; dksum_j
 // ------------------------------------------------------------------------------------------------------------------
-template <int DT>
+template <int DT, bool GATHER>
 __global__ __launch_bounds__(SNF_T, 2) void k_snf_bwd(const SnArgs a) {
+    // GATHER: the launch has a block_index map.  As a template parameter the row lookups carry no branch: with `idx ? idx[p] : p`
+    // decided at run time hipcc branched around every map load and waited for ALL loads in flight at each join (s_waitcnt
+    // vmcnt(0) after every group of row loads: the staging became a chain of dependent round trips).
+    const int* const idx = GATHER ? a.idx : nullptr;
+    if constexpr (GATHER) __builtin_assume(idx != nullptr);
     constexpr int DP = DT * 16, LDR = sn_ldr<DT>(), KS = (DP + 31) / 32, PL = SNF_HR * LDR;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u16* Ah = reinterpret_cast<u16*>(smem_raw);   // K (pass A) / Q (pass B), hi
@@ -303,7 +313,7 @@ __global__ __launch_bounds__(SNF_T, 2) void k_snf_bwd(const SnArgs a) {
     if (tid < 256) Wsh[(tid >> 4) * 17 + (tid & 15)] = ((tid >> 4) < M && (tid & 15) < M) ? a.W[(long)(tid >> 4) * a.ldw + (tid & 15)] : 0.f;
     for (int v = tid; v < 256; v += SNF_T) { nis[v] = 1.f; dns[v] = 0.f; dzs[v] = 0.f; zs[v] = 0.f; }
     if (a.normalize) {
-        snf_ksum<DT>(ksum_s, kb, a.k.sn, a.idx, M, D, a.eps, tid, relu);
+        snf_ksum<DT>(ksum_s, kb, a.k.sn, idx, M, D, a.eps, tid, relu);
         __syncthreads();
         // z_i, row dots dO . O of the wave's blocks (lane: row n, 8-column pieces kg)
 #pragma unroll
@@ -311,9 +321,9 @@ __global__ __launch_bounds__(SNF_T, 2) void k_snf_bwd(const SnArgs a) {
             const int i = wave + SNF_W * x;
             if (i >= M) continue;
             f32x4 qr[KS][2], gr[KS][2], orr[KS][2];
-            snf_issue_rows<KS>(qr, qb, a.q.sn, a.idx, i * 16, D, lane);
-            snf_issue_rows<KS>(gr, gb, a.dout.sn, a.idx, i * 16, D, lane);
-            snf_issue_rows<KS>(orr, ob, a.o.sn, a.idx, i * 16, D, lane);
+            snf_issue_rows<KS>(qr, qb, a.q.sn, idx, i * 16, D, lane);
+            snf_issue_rows<KS>(gr, gb, a.dout.sn, idx, i * 16, D, lane);
+            snf_issue_rows<KS>(orr, ob, a.o.sn, idx, i * 16, D, lane);
             float z = 0.f, rd = 0.f;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
@@ -359,9 +369,9 @@ __global__ __launch_bounds__(SNF_T, 2) void k_snf_bwd(const SnArgs a) {
         bf16x8 qh[KS], ql[KS], gh[KS], gl[KS];
         {
             f32x4 raw[KS][2];
-            snf_issue_rows<KS>(raw, qb, a.q.sn, a.idx, ic * 16, D, lane);
+            snf_issue_rows<KS>(raw, qb, a.q.sn, idx, ic * 16, D, lane);
             snf_finish_rows<KS>(qh, ql, raw, D, a.eps, lane, relu);
-            snf_issue_rows<KS>(raw, gb, a.dout.sn, a.idx, ic * 16, D, lane);
+            snf_issue_rows<KS>(raw, gb, a.dout.sn, idx, ic * 16, D, lane);
             snf_finish_rows<KS>(gh, gl, raw, D, 0.f, lane, false, nis[ic * 16 + n]);   // dO' = dO / n
         }
         f32x4 acc[DT];
@@ -375,8 +385,8 @@ __global__ __launch_bounds__(SNF_T, 2) void k_snf_bwd(const SnArgs a) {
             if (half * SNF_HR >= N) break;   // (uniform)
             const int r0 = half * SNF_HR, nr = min(SNF_HR, N - r0), jb = half * 8;
             __syncthreads();
-            snf_stage<DT, false>(Ah, Al, kb, a.k.sn, a.idx, r0, nr, D, a.eps, tid, relu, nullptr);
-            snf_stage<DT, false>(Bh, Bl, vb, a.v.sn, a.idx, r0, nr, D, 0.f, tid, false, nullptr);
+            snf_stage<DT, false>(Ah, Al, kb, a.k.sn, idx, r0, nr, D, a.eps, tid, relu, nullptr);
+            snf_stage<DT, false>(Bh, Bl, vb, a.v.sn, idx, r0, nr, D, 0.f, tid, false, nullptr);
             __syncthreads();
             if (live) {
 #pragma unroll
@@ -436,8 +446,8 @@ __global__ __launch_bounds__(SNF_T, 2) void k_snf_bwd(const SnArgs a) {
                     for (int tn = 0; tn < DT; ++tn) acc[tn][r] += dz * ksum_s[i * DP + tn * 16 + n];
                 }
             }
-            if (relu) snf_store16<DT, true>(dqb, a.dq.sn, a.idx, i * 16, D, acc, qb, a.q.sn, lane);
-            else      snf_store16<DT, false>(dqb, a.dq.sn, a.idx, i * 16, D, acc, nullptr, 0, lane);
+            if (relu) snf_store16<DT, true>(dqb, a.dq.sn, idx, i * 16, D, acc, qb, a.q.sn, lane);
+            else      snf_store16<DT, false>(dqb, a.dq.sn, idx, i * 16, D, acc, nullptr, 0, lane);
         }
     }
 
@@ -450,9 +460,9 @@ __global__ __launch_bounds__(SNF_T, 2) void k_snf_bwd(const SnArgs a) {
         bf16x8 kh[KS], kl[KS], vh[KS], vl[KS];
         {
             f32x4 raw[KS][2];
-            snf_issue_rows<KS>(raw, kb, a.k.sn, a.idx, jc * 16, D, lane);
+            snf_issue_rows<KS>(raw, kb, a.k.sn, idx, jc * 16, D, lane);
             snf_finish_rows<KS>(kh, kl, raw, D, a.eps, lane, relu);
-            snf_issue_rows<KS>(raw, vb, a.v.sn, a.idx, jc * 16, D, lane);
+            snf_issue_rows<KS>(raw, vb, a.v.sn, idx, jc * 16, D, lane);
             snf_finish_rows<KS>(vh, vl, raw, D, 0.f, lane, false);
         }
         f32x4 accK[DT], accV[DT];
@@ -463,8 +473,8 @@ __global__ __launch_bounds__(SNF_T, 2) void k_snf_bwd(const SnArgs a) {
             if (half * SNF_HR >= N) break;   // (uniform)
             const int r0 = half * SNF_HR, nr = min(SNF_HR, N - r0), ib = half * 8;
             __syncthreads();
-            snf_stage<DT, false>(Ah, Al, qb, a.q.sn, a.idx, r0, nr, D, a.eps, tid, relu, nullptr);
-            snf_stage<DT, true>(Bh, Bl, gb, a.dout.sn, a.idx, r0, nr, D, 0.f, tid, false, nis);
+            snf_stage<DT, false>(Ah, Al, qb, a.q.sn, idx, r0, nr, D, a.eps, tid, relu, nullptr);
+            snf_stage<DT, true>(Bh, Bl, gb, a.dout.sn, idx, r0, nr, D, 0.f, tid, false, nis);
             __syncthreads();
             if (live) {
 #pragma unroll
@@ -524,9 +534,9 @@ __global__ __launch_bounds__(SNF_T, 2) void k_snf_bwd(const SnArgs a) {
             }
         }
         if (live) {
-            if (relu) snf_store16<DT, true>(dkb, a.dk.sn, a.idx, j * 16, D, accK, kb, a.k.sn, lane);
-            else      snf_store16<DT, false>(dkb, a.dk.sn, a.idx, j * 16, D, accK, nullptr, 0, lane);
-            snf_store16<DT, false>(dvb, a.dv.sn, a.idx, j * 16, D, accV, nullptr, 0, lane);
+            if (relu) snf_store16<DT, true>(dkb, a.dk.sn, idx, j * 16, D, accK, kb, a.k.sn, lane);
+            else      snf_store16<DT, false>(dkb, a.dk.sn, idx, j * 16, D, accK, nullptr, 0, lane);
+            snf_store16<DT, false>(dvb, a.dv.sn, idx, j * 16, D, accV, nullptr, 0, lane);
         }
     }
 }
