@@ -884,8 +884,13 @@ __global__ __launch_bounds__(NT4, NK <= 2 ? 4 : 2) void k_csf_bwd_tok4(const CsT
         // slice the rows of this slice are requested again (never used) and the P slots receive step 3's Q tiles.
         const int vn = last ? vs : vs + 64;
 #if !TOK4_NO_TOKLOAD
-        cs8_issue_tok(nG, gb + vn, a.dout.sn, p0, rv, tid);
-        cs8_issue_tok(nV, vb + vn, a.v.sn, p0, rv, tid);
+        {   // (the fillers behind the last slice read the chunk's first Q tile: lines that step 3 wants anyway)
+            const int r = tid >> 3, c = (tid & 7) * 8;
+            const long row = p0 + (r < rv ? r : 0);
+            const u16* fill = qb + row * a.q.sn + c;
+            nG = gld<uint4>(last ? fill : gb + vn + row * a.dout.sn + c);
+            nV = gld<uint4>(last ? fill : vb + vn + row * a.v.sn + c);
+        }
 #endif
 #pragma unroll
         for (int kk = 0; kk < NK; ++kk) {
@@ -899,17 +904,18 @@ __global__ __launch_bounds__(NT4, NK <= 2 ? 4 : 2) void k_csf_bwd_tok4(const CsT
                     const u16* qsrc = qb + kk * 64 + (p0 + (r < rv ? r : 0)) * a.q.sn + c;   // step 3's Q tile
                     const u16* psrc = Pb + cs_tile_off(kk * 64, vn, V) + tid * 8;
                     rP[kk] = gld<uint4>(last ? qsrc : psrc);
-                    cs8_issue_state(rdS[kk], dSb + cs_tile_off(kk * 64, vn, V), tid);
+                    rdS[kk] = gld<uint4>(last ? qsrc : dSb + cs_tile_off(kk * 64, vn, V) + tid * 8);   // (filler: the same lines)
                 }
 #endif
                 if (kk == 0) {
                     tile_a8(aG, X1, rt, lane);
-                    tile_a8(aV, X2, rt, lane);
+                    if constexpr (KREG) tile_a8(aV, X2, rt, lane);
                     tile_mma8r<false>(accdA, aG, X2, ch, lane);                // dO V^T
                     tile_mma8<true, true>(accV, As, X1, rt, ch, lane);         // A^T dO
                 }
                 tile_mma8r<false>(accQ[kk], aG, B1, ch, lane);                 // dO P^T
-                tile_mma8r<false>(accK[kk], aV, B2, ch, lane);                 // V dS^T
+                if constexpr (KREG) tile_mma8r<false>(accK[kk], aV, B2, ch, lane);                 // V dS^T
+                else                tile_mma8<false, false>(accK[kk], X2, B2, rt, ch, lane);
                 if constexpr (KREG) tile_mma8r<true>(accV, aK[kk], B2, ch, lane);                  // K dS
                 else                tile_mma8<false, true>(accV, KT + kk * CT, B2, rt, ch, lane);
                 __syncthreads();
@@ -1212,9 +1218,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_csf_state2(const CsfStateArgs a
     const int xc = (tid & 15) * 8, yc = (tid & 31) * 8;
     const bool xok = xc < kw, yok = yc < vw;
     uint4 xr[4], yr[8];
-    auto issue = [&](int ci) {   // (no load behind a branch: rows past the sequence's end read the chunk's first row)
-        const long p0 = (long)ci * CS;
-        const int rv = (int)min((long)CS, a.T - p0);
+    auto issue = [&](int ci, bool filler) {   // (no load behind a branch: rows past the sequence's end read the chunk's first row;
+        const long p0 = (long)ci * CS;        //  the filler behind the last chunk reads that one row with every pass)
+        const int rv = filler ? 0 : (int)min((long)CS, a.T - p0);
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int row = (tid >> 4) + 16 * p;
@@ -1226,7 +1232,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_csf_state2(const CsfStateArgs a
             yr[p] = gld_stream16(yb + (p0 + (row < rv ? row : 0)) * a.y.sn + (yok ? yc : 0));
         }
     };
-    issue(c0);
+    issue(c0, false);
     for (int ci = c0; ci < c1; ++ci) {
         const int rv = (int)min((long)CS, a.T - (long)ci * CS);
         u16* ob = a.out + ((long)bh * a.n + ci) * a.K * a.V;
@@ -1244,7 +1250,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_csf_state2(const CsfStateArgs a
             *reinterpret_cast<uint4*>(Ys + row * ST2_LDY + yc) = make_uint4(ok ? yr[p].x : 0u, ok ? yr[p].y : 0u, ok ? yr[p].z : 0u, ok ? yr[p].w : 0u);
         }
         __syncthreads();
-        issue(min(ci + 1, c1 - 1));   // behind the last chunk: its own rows again (cache hits, never used)
+        issue(min(ci + 1, c1 - 1), ci + 1 >= c1);
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr) {
             const int rt = wave * 2 + rr;               // 16 summary rows kk = k0 + 16 rt ..

@@ -248,11 +248,19 @@ __global__ __launch_bounds__(NTHREADS, ROPE ? 2 : 3) void k_sp_state(const State
         constexpr int ZB = 4;   // token rows in flight per thread: the loads of a batch are issued before any is used
         for (int rb = 0; rb < S; rb += RPP * ZB) {
             f32x4 x0[ZB], x1[ZB];
+            int rw[ZB];   // the batch's rows first (the map lookups travel together), then the batch's data loads
+            if (a.idx) {
+#pragma unroll
+                for (int u = 0; u < ZB; ++u) rw[u] = gld<int>(a.idx + p0 + min(rb + u * RPP + r0, S - 1));
+            } else {
+#pragma unroll
+                for (int u = 0; u < ZB; ++u) rw[u] = (int)p0 + min(rb + u * RPP + r0, S - 1);
+            }
 #pragma unroll
             for (int u = 0; u < ZB; ++u) {
                 const int r = rb + u * RPP + r0;
                 x0[u] = x1[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (r < S && cg < D) ld8(qb + tok_row(a.idx, p0 + r) * a.qd.sn + cg, x0[u], x1[u]);
+                if (r < S && cg < D) ld8(qb + (long)rw[u] * a.qd.sn + cg, x0[u], x1[u]);
             }
 #pragma unroll
             for (int u = 0; u < ZB; ++u) {

@@ -23,10 +23,11 @@ def main():
         for k in keys:
             if s.startswith(k): stats[cur][k] += 1
         if s.startswith("s_waitcnt") and "vmcnt(0)" in s: stats[cur]["vmcnt0"] += 1
-        m = re.match(r"\.(vgpr_count|sgpr_count|vgpr_spill_count|private_segment_fixed_size):\s+(\d+)", s)
-        if m: meta.setdefault("pending", {})[m.group(1)] = int(m.group(2))
+        # metadata keys of a kernel are sorted: .name comes BEFORE .private_segment_fixed_size / .sgpr_count / .vgpr_count / ...
         m = re.match(r"\.name:\s+(_Z\w+)", s)
-        if m and "pending" in meta: meta[m.group(1)] = meta.pop("pending")
+        if m: meta["name"] = m.group(1); meta[m.group(1)] = {}
+        m = re.match(r"\.(vgpr_count|sgpr_count|vgpr_spill_count|private_segment_fixed_size):\s+(\d+)", s)
+        if m and "name" in meta: meta[meta["name"]][m.group(1)] = int(m.group(2))
     dm = demangle(list(stats))
     print("| kernel | VGPR | spill | scratch B | flat ld | global ld | flat st | global st | scratch | mfma | tr | ds_r | ds_w | bar | vmcnt(0) | v_pk |")
     print("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
