@@ -71,9 +71,11 @@ def test_causal_lowp(dtype):
 
 
 @pytest.mark.parametrize("T,K,V", [(256, 64, 64), (200, 64, 128), (50, 128, 64), (1000, 128, 256), (129, 256, 512),
-                                   (320, 64, 48), (320, 48, 64)])
+                                   (320, 64, 48), (320, 48, 64), (200, 192, 192), (130, 192, 320), (200, 64, 384)])
 def test_causal_shapes_bf16(T, K, V):
-    """K and V multiples of 64 run the bf16-MFMA token kernels (ragged last chunk included); the others the generic ones."""
+    """K and V multiples of 64 run the bf16-MFMA token kernels (ragged last chunk included); the others the generic ones.
+    The eight-wave kernels are templated on K / 64 (1..4) and on the V slices per workgroup (the largest of 4, 3, 2, 1 dividing
+    V / 64): 192 x 192 -> <3>, <3>; V = 320 -> five workgroups of one slice; V = 384 -> two of three."""
     run_causal(2, T, 2, K, V, max(4, (T + 63) // 64), torch.bfloat16, seed=T + K)
 
 
