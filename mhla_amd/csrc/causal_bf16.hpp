@@ -795,7 +795,7 @@ __device__ __forceinline__ void cs8_put(u16* __restrict__ dst, const f32x4 (&x)[
 }
 
 template <int NK>
-__host__ __device__ constexpr int csf_tok4_smem() { return (6 + NK) * CT * 2 + 32; }
+__host__ __device__ constexpr int csf_tok4_smem() { return (6 + NK + (NK > 2 ? 3 : 0)) * CT * 2 + 32; }   // K > 128: second P / dS buffers + dV staging
 
 template <typename ST, int NK>
 __global__ __launch_bounds__(NT4, NK <= 2 ? 4 : 2) void k_csf_bwd_tok4(const CsTokArgs a) {
@@ -807,7 +807,12 @@ __global__ __launch_bounds__(NT4, NK <= 2 ? 4 : 2) void k_csf_bwd_tok4(const CsT
     u16* B1 = X2 + CT;                            // P slice, output staging
     u16* B2 = B1 + CT;                            // dS slice, output staging
     u16* KT = B2 + CT;                            // the chunk's K tiles [NK]
-    float* red = reinterpret_cast<float*>(KT + NK * CT);
+    // K > 128 (one workgroup per CU whatever the LDS use): a second pair of P / dS buffers and a dV staging tile of its own, so
+    // that a round is commit -> ONE barrier -> refill -> multiply (the products of a round run beside the next round's commit)
+    // and a V slice ends with one barrier instead of two: 60 barriers per chunk instead of 100 at K = 256, V = 512.
+    constexpr bool DBUF = NK > 2;
+    u16* Bx = KT + NK * CT;                       // DBUF: [B1', B2', dV staging]
+    float* red = reinterpret_cast<float*>(Bx + (DBUF ? 3 : 0) * CT);
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, n = lane & 15, kg = lane >> 4;
     const int rt = wave & 3, ch = wave >> 2;
     const int ci = blockIdx.x, bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
@@ -872,11 +877,13 @@ __global__ __launch_bounds__(NT4, NK <= 2 ? 4 : 2) void k_csf_bwd_tok4(const CsT
         zero2(accK[kk]);
     }
     zero2(accdA);
+    int rr = 0;   // round counter (DBUF: its parity picks the P / dS buffers)
     for (int vs = 0; vs < V; vs += 64) {
         f32x4 accV[2];
         zero2(accV);
         bf16x8 aG[2], aV[2];
         const bool last = vs + 64 >= V;   // (uniform)
+        // (DBUF: the wave's dO / V rows were read into registers in the slice's first round, NK - 1 >= 2 barriers ago)
         cs8_commit_tok(X1, nG, rv, tid);
         cs8_commit_tok(X2, nV, rv, tid);
         // No load of the loop sits behind a branch: hipcc loses count of the loads in flight at every join and waits for ALL of
@@ -895,8 +902,11 @@ __global__ __launch_bounds__(NT4, NK <= 2 ? 4 : 2) void k_csf_bwd_tok4(const CsT
 #pragma unroll
         for (int kk = 0; kk < NK; ++kk) {
             {
-                cs8_commit_state(B1, rP[kk], tid);
-                cs8_commit_state(B2, rdS[kk], tid);
+                u16* B1c = DBUF && (rr & 1) ? Bx : B1;
+                u16* B2c = DBUF && (rr & 1) ? Bx + CT : B2;
+                ++rr;
+                cs8_commit_state(B1c, rP[kk], tid);
+                cs8_commit_state(B2c, rdS[kk], tid);
                 __syncthreads();
 #if !TOK4_NO_LOAD
                 {
@@ -913,18 +923,19 @@ __global__ __launch_bounds__(NT4, NK <= 2 ? 4 : 2) void k_csf_bwd_tok4(const CsT
                     tile_mma8r<false>(accdA, aG, X2, ch, lane);                // dO V^T
                     tile_mma8<true, true>(accV, As, X1, rt, ch, lane);         // A^T dO
                 }
-                tile_mma8r<false>(accQ[kk], aG, B1, ch, lane);                 // dO P^T
-                if constexpr (KREG) tile_mma8r<false>(accK[kk], aV, B2, ch, lane);                 // V dS^T
-                else                tile_mma8<false, false>(accK[kk], X2, B2, rt, ch, lane);
-                if constexpr (KREG) tile_mma8r<true>(accV, aK[kk], B2, ch, lane);                  // K dS
-                else                tile_mma8<false, true>(accV, KT + kk * CT, B2, rt, ch, lane);
-                __syncthreads();
+                tile_mma8r<false>(accQ[kk], aG, B1c, ch, lane);                // dO P^T
+                if constexpr (KREG) tile_mma8r<false>(accK[kk], aV, B2c, ch, lane);                // V dS^T
+                else                tile_mma8<false, false>(accK[kk], X2, B2c, rt, ch, lane);
+                if constexpr (KREG) tile_mma8r<true>(accV, aK[kk], B2c, ch, lane);                 // K dS
+                else                tile_mma8<false, true>(accV, KT + kk * CT, B2c, rt, ch, lane);
+                if constexpr (!DBUF) __syncthreads();
             }
         }
-        cs8_put(B1, accV, 1.f, rt, ch, lane);
+        u16* Vst = DBUF ? Bx + 2 * CT : B1;
+        cs8_put(Vst, accV, 1.f, rt, ch, lane);
         __syncthreads();
-        cs8_store_tok(mbase(a.dv) + vs, a.dv.sn, p0, rv, B1, tid);
-        __syncthreads();
+        cs8_store_tok(mbase(a.dv) + vs, a.dv.sn, p0, rv, Vst, tid);
+        if constexpr (!DBUF) __syncthreads();
     }
 
     // ---- step 3: dA tile, diagonal term, the m_ii parts of dQ / dK ----
