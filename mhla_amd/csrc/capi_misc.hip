@@ -82,7 +82,10 @@ int mhla_lepe2d(const void* x, int64_t x_sb, int64_t x_sn, const float* w_taps, 
     LepeArgs a{x, (long)x_sb, (long)x_sn, w_taps, bias, add, (long)add_sb, (long)add_sn, y, (long)y_sb, (long)y_sn, B, pieces_len, block_len, C, K, flip ? 1 : 0};
     const long N = (long)pieces_len * pieces_len * block_len * block_len, work = N * (C / 8);
     hipStream_t st = (hipStream_t)stream;
-    DISPATCH_T(dtype, { RC(launch(k_lepe2d<ET>, dim3((unsigned)((work + 255) / 256), B), dim3(256), 0, st, "k_lepe2d", a)); });
+    DISPATCH_T(dtype, {
+        if (K == 3) RC(launch(k_lepe2d<ET, 3>, dim3((unsigned)((work + 255) / 256), B), dim3(256), 0, st, "k_lepe2d", a));
+        else        RC(launch(k_lepe2d<ET, 5>, dim3((unsigned)((work + 255) / 256), B), dim3(256), 0, st, "k_lepe2d", a));
+    });
     return MHLA_OK;
 }
 

@@ -51,9 +51,12 @@ __device__ __forceinline__ bool lepe_shift(int b, int o, int d, int pl, int bl, 
     return b2 >= 0 && b2 < pl;
 }
 
-// grid (ceil(N * C/8 / 256), B); a thread: 8 channels of one token
-template <typename T>
-__global__ __launch_bounds__(256) void k_lepe2d(const LepeArgs a) {
+// grid (ceil(N * C/8 / 256), B); a thread: 8 channels of one token.
+// Every tap's row is loaded UNCONDITIONALLY (taps that leave the image read the token itself and enter with weight zero): with
+// `continue` around the loads hipcc waited for each load before it issued the next (s_waitcnt vmcnt(0) at every join) -- K * K
+// dependent round trips per token; now the K * K row loads and weight loads of a token travel together.
+template <typename T, int K>
+__global__ __launch_bounds__(256, 4) void k_lepe2d(const LepeArgs a) {
     const int CG = a.C / 8, N = a.pl * a.pl * a.bl * a.bl;
     const long gid = (long)blockIdx.x * 256 + threadIdx.x;
     if (gid >= (long)N * CG) return;
@@ -65,25 +68,47 @@ __global__ __launch_bounds__(256) void k_lepe2d(const LepeArgs a) {
         acc1 = *reinterpret_cast<const f32x4*>(a.bias + c + 4);
     }
     const T* xb = (const T*)a.x + b * a.xsb + c;
-    const int K = a.K, R = K / 2, S = a.bl * a.bl;
-    for (int dy = 0; dy < K; ++dy) {
-        int py2, by2;
-        if (!lepe_shift(pos.py, pos.by, dy - R, a.pl, a.bl, py2, by2)) continue;
-        for (int dx = 0; dx < K; ++dx) {
-            int px2, bx2;
-            if (!lepe_shift(pos.px, pos.bx, dx - R, a.pl, a.bl, px2, bx2)) continue;
-            const int tap = a.flip ? (K - 1 - dy) * K + (K - 1 - dx) : dy * K + dx;
-            const T* p = xb + (long)((py2 * a.pl + px2) * S + by2 * a.bl + bx2) * a.xsn;
-            const f32x4 x0 = Io<T>::ld4(p), x1 = Io<T>::ld4(p + 4);
-            acc0 += x0 * *reinterpret_cast<const f32x4*>(a.w + (long)tap * a.C + c);
-            acc1 += x1 * *reinterpret_cast<const f32x4*>(a.w + (long)tap * a.C + c + 4);
-        }
-    }
+    constexpr int R = K / 2;
+    const int S = a.bl * a.bl;
+    f32x4 ad0 = {0.f, 0.f, 0.f, 0.f}, ad1 = ad0;
     if (a.add) {
         const T* p = (const T*)a.add + b * a.asb + (long)n * a.asn + c;
-        acc0 += Io<T>::ld4(p);
-        acc1 += Io<T>::ld4(p + 4);
+        ad0 = Io<T>::ld4(p);
+        ad1 = Io<T>::ld4(p + 4);
     }
+    constexpr int RB = 1;   // tap rows per batch of loads: one row (all nine taps at once: 131 VGPRs, three waves per SIMD, slower)
+#pragma unroll 1   // (a real loop: unrolled, hipcc hoists every row's loads to the top and spills)
+    for (int d0 = 0; d0 < K; d0 += RB) {
+        f32x4 x0[RB * K], x1[RB * K], w0[RB * K], w1[RB * K];
+        bool ok[RB * K];
+#pragma unroll
+        for (int dr = 0; dr < RB; ++dr) {
+            const int dy = d0 + dr;
+            int py2, by2;
+            const bool oky = lepe_shift(pos.py, pos.by, dy - R, a.pl, a.bl, py2, by2);
+#pragma unroll
+            for (int dx = 0; dx < K; ++dx) {
+                int px2, bx2;
+                const int t = dr * K + dx;
+                ok[t] = lepe_shift(pos.px, pos.bx, dx - R, a.pl, a.bl, px2, bx2) && oky;
+                const int tap = a.flip ? (K - 1 - dy) * K + (K - 1 - dx) : dy * K + dx;
+                const int nb = ok[t] ? (py2 * a.pl + px2) * S + by2 * a.bl + bx2 : n;
+                const T* p = xb + (long)nb * a.xsn;
+                x0[t] = Io<T>::ld4(p);
+                x1[t] = Io<T>::ld4(p + 4);
+                w0[t] = *reinterpret_cast<const f32x4*>(a.w + (long)tap * a.C + c);
+                w1[t] = *reinterpret_cast<const f32x4*>(a.w + (long)tap * a.C + c + 4);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < RB * K; ++t) {
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};   // (a select, not a multiplication by 0: the filler row may hold inf / NaN)
+            acc0 += (ok[t] ? x0[t] : z) * w0[t];
+            acc1 += (ok[t] ? x1[t] : z) * w1[t];
+        }
+    }
+    acc0 += ad0;
+    acc1 += ad1;
     T* yp = (T*)a.y + b * a.ysb + (long)n * a.ysn + c;
     Io<T>::st4(yp, acc0);
     Io<T>::st4(yp + 4, acc1);
@@ -129,6 +154,10 @@ __global__ __launch_bounds__(256) void k_lepe2d_wgrad(const LepeWgradArgs a) {
             }
             const T* xb = (const T*)a.x + b * a.xsb + c;
             const int S = a.bl * a.bl;
+            // all K * K neighbour rows requested before any is used (taps outside the image: the token itself, weight zero) --
+            // behind `if (inside)` every load was waited for before the next was issued: 80 dependent round trips per thread
+            f32x4 xv[K * K][NV];
+            float mk[K * K];
 #pragma unroll
             for (int dy = 0; dy < K; ++dy) {
                 int py2, by2;
@@ -136,13 +165,18 @@ __global__ __launch_bounds__(256) void k_lepe2d_wgrad(const LepeWgradArgs a) {
 #pragma unroll
                 for (int dx = 0; dx < K; ++dx) {
                     int px2, bx2;
-                    if (lepe_shift(pos.px, pos.bx, dx - K / 2, a.pl, a.bl, px2, bx2) && oky) {
-                        const T* p = xb + (long)((py2 * a.pl + px2) * S + by2 * a.bl + bx2) * a.xsn;
+                    const bool ok = lepe_shift(pos.px, pos.bx, dx - K / 2, a.pl, a.bl, px2, bx2) && oky;
+                    const int nb = ok ? (py2 * a.pl + px2) * S + by2 * a.bl + bx2 : n;
+                    const T* p = xb + (long)nb * a.xsn;
+                    mk[dy * K + dx] = ok ? 1.f : 0.f;
 #pragma unroll
-                        for (int u = 0; u < NV; ++u) acc[dy * K + dx][u] += g[u] * Io<T>::ld4(p + 4 * u);
-                    }
+                    for (int u = 0; u < NV; ++u) xv[dy * K + dx][u] = Io<T>::ld4(p + 4 * u);
                 }
             }
+#pragma unroll
+            for (int i = 0; i < K * K; ++i)
+#pragma unroll
+                for (int u = 0; u < NV; ++u) acc[i][u] += g[u] * (mk[i] != 0.f ? xv[i][u] : f32x4{0.f, 0.f, 0.f, 0.f});
         }
     }
     // sum the 8 token lanes (lane bits 3..5)
@@ -201,7 +235,7 @@ struct Lepe3dArgs {
 
 // grid (ceil(N * C/8 / 256), B); a thread: 8 channels of one token
 template <typename T>
-__global__ __launch_bounds__(256) void k_lepe3d(const Lepe3dArgs a) {
+__global__ __launch_bounds__(256, 3) void k_lepe3d(const Lepe3dArgs a) {
     const int CG = a.C / 8, HW = a.H * a.W, N = a.F * HW;
     const long gid = (long)blockIdx.x * 256 + threadIdx.x;
     if (gid >= (long)N * CG) return;
@@ -213,31 +247,44 @@ __global__ __launch_bounds__(256) void k_lepe3d(const Lepe3dArgs a) {
         acc1 = *reinterpret_cast<const f32x4*>(a.bias + c + 4);
     }
     const T* xb = (const T*)a.x + b * a.xsb + c;
-#pragma unroll
+    // one line of three taps at a time, its loads unconditional (taps outside the video: the token itself, selected away)
+    f32x4 ad0 = {0.f, 0.f, 0.f, 0.f}, ad1 = ad0;
+    if (a.add) {
+        const T* p = (const T*)a.add + b * a.asb + (long)n * a.asn + c;
+        ad0 = Io<T>::ld4(p);
+        ad1 = Io<T>::ld4(p + 4);
+    }
+#pragma unroll 1   // (real loops: unrolled, hipcc hoists all 27 taps' loads to the top and spills)
     for (int df = 0; df < 3; ++df) {
         const int f2 = f + df - 1;
-        if (f2 < 0 || f2 >= a.F) continue;
-#pragma unroll
+        const bool okf = f2 >= 0 && f2 < a.F;
+#pragma unroll 1
         for (int dh = 0; dh < 3; ++dh) {
             const int h2 = h + dh - 1;
-            if (h2 < 0 || h2 >= a.H) continue;
+            const bool okh = okf && h2 >= 0 && h2 < a.H;
+            f32x4 x0[3], x1[3], w0[3], w1[3];
+            bool ok[3];
 #pragma unroll
             for (int dw = 0; dw < 3; ++dw) {
                 const int w2 = w + dw - 1;
-                if (w2 < 0 || w2 >= a.W) continue;
+                ok[dw] = okh && w2 >= 0 && w2 < a.W;
                 const int tap = a.flip ? 26 - ((df * 3 + dh) * 3 + dw) : (df * 3 + dh) * 3 + dw;
-                const T* p = xb + (long)((f2 * a.H + h2) * a.W + w2) * a.xsn;
-                const f32x4 x0 = Io<T>::ld4(p), x1 = Io<T>::ld4(p + 4);
-                acc0 += x0 * *reinterpret_cast<const f32x4*>(a.w + (long)tap * a.C + c);
-                acc1 += x1 * *reinterpret_cast<const f32x4*>(a.w + (long)tap * a.C + c + 4);
+                const T* p = xb + (long)(ok[dw] ? (f2 * a.H + h2) * a.W + w2 : n) * a.xsn;
+                x0[dw] = Io<T>::ld4(p);
+                x1[dw] = Io<T>::ld4(p + 4);
+                w0[dw] = *reinterpret_cast<const f32x4*>(a.w + (long)tap * a.C + c);
+                w1[dw] = *reinterpret_cast<const f32x4*>(a.w + (long)tap * a.C + c + 4);
+            }
+#pragma unroll
+            for (int dw = 0; dw < 3; ++dw) {
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                acc0 += (ok[dw] ? x0[dw] : z) * w0[dw];
+                acc1 += (ok[dw] ? x1[dw] : z) * w1[dw];
             }
         }
     }
-    if (a.add) {
-        const T* p = (const T*)a.add + b * a.asb + (long)n * a.asn + c;
-        acc0 += Io<T>::ld4(p);
-        acc1 += Io<T>::ld4(p + 4);
-    }
+    acc0 += ad0;
+    acc1 += ad1;
     T* yp = (T*)a.y + b * a.ysb + (long)n * a.ysn + c;
     Io<T>::st4(yp, acc0);
     Io<T>::st4(yp + 4, acc1);
@@ -274,9 +321,11 @@ __global__ __launch_bounds__(256) void k_lepe3d_wgrad(const Lepe3dWgradArgs a) {
             acc[27] += g;
             const T* xb = (const T*)a.x + b * a.xsb + c;
 #pragma unroll
-            for (int df = 0; df < 3; ++df) {
+            for (int df = 0; df < 3; ++df) {   // one frame plane at a time: its nine loads unconditional and in flight together
                 const int f2 = f + df - 1;
                 const bool okf = f2 >= 0 && f2 < a.F;
+                f32x4 xv[9];
+                float mk[9];
 #pragma unroll
                 for (int dh = 0; dh < 3; ++dh) {
                     const int h2 = h + dh - 1;
@@ -284,10 +333,13 @@ __global__ __launch_bounds__(256) void k_lepe3d_wgrad(const Lepe3dWgradArgs a) {
 #pragma unroll
                     for (int dw = 0; dw < 3; ++dw) {
                         const int w2 = w + dw - 1;
-                        if (okh && w2 >= 0 && w2 < a.W)
-                            acc[(df * 3 + dh) * 3 + dw] += g * Io<T>::ld4(xb + (long)((f2 * a.H + h2) * a.W + w2) * a.xsn);
+                        const bool ok = okh && w2 >= 0 && w2 < a.W;
+                        mk[dh * 3 + dw] = ok ? 1.f : 0.f;
+                        xv[dh * 3 + dw] = Io<T>::ld4(xb + (long)(ok ? (f2 * a.H + h2) * a.W + w2 : n) * a.xsn);
                     }
                 }
+#pragma unroll
+                for (int t = 0; t < 9; ++t) acc[df * 9 + t] += g * (mk[t] != 0.f ? xv[t] : f32x4{0.f, 0.f, 0.f, 0.f});
             }
         }
     }
