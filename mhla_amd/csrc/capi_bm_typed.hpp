@@ -9,6 +9,30 @@
 namespace mhla {
 namespace capi {
 
+// Resident-sequence mixing (sp::k_sp_mixr): 33 <= M <= 256 blocks, summaries in whole 256-byte row pieces.  MHLA_SP_MIX=old keeps
+// the tiled kernel (A/B).
+template <bool S16>
+inline bool sp_mixr_ok(int M, long E) {
+    static const char* const knob = getenv("MHLA_SP_MIX");   // tuning knob, read once
+    return !(knob && knob[0] == 'o') && M > 32 && M <= 256 && E % sp::mixr_te<4, S16>() == 0;
+}
+template <int TRANS, bool S16>
+inline int sp_mixr(const float* W, int ldw, const void* in, void* out, int M, long E, int BH, hipStream_t st) {
+#define MIXR(NW) do { \
+        constexpr int TE = sp::mixr_te<NW, S16>(); \
+        const long total = (long)BH * (E / TE); \
+        const int wgs = (int)std::min<long>(total, 256); \
+        sp::MixrArgs a{W, ldw, in, out, M, E, total, (int)((total + wgs - 1) / wgs)}; \
+        const int gw = (int)((total + a.spw - 1) / a.spw); \
+        return launch(sp::k_sp_mixr<NW, TRANS, S16>, dim3(gw), dim3(64 * NW), sp::sp_mixr_smem<NW, S16>(), st, TRANS ? "k_sp_mixr<1>" : "k_sp_mixr<0>", a); \
+    } while (0)
+    if (M <= 64) MIXR(4);
+    if (M <= 128) MIXR(8);
+    if (M <= 192) MIXR(12);
+    MIXR(16);
+#undef MIXR
+}
+
 // KV/ksum/z, G for the forward and the recompute leg of the backward.
 template <typename T, int DT>
 int bm_state_and_mix(const mhla_view& q_num, const mhla_view& k_num, const mhla_view& v, const mhla_view& q_den,
@@ -26,7 +50,8 @@ int bm_state_and_mix(const mhla_view& q_num, const mhla_view& k_num, const mhla_
     if (sp_shape_ok(D, flags)) {   // split-bf16 MFMA kernels (split.hpp)
         if (a.rcos) RC(launch(sp::k_sp_state<T, DT, 0, true>, dim3(M, B * H), dim3(NTHREADS), sp::sp_state_smem<DT>(), st, "k_sp_state<rope>", a));
         else        RC(launch(sp::k_sp_state<T, DT, 0>, dim3(M, B * H), dim3(NTHREADS), sp::sp_state_smem<DT>(), st, "k_sp_state", a));
-        RC(launch(sp::k_sp_mix<0, sp::Sum16<T>::value>, dim3((unsigned)((m.E + sp::SPM_TE - 1) / sp::SPM_TE), (M + 63) / 64, B * H), dim3(NTHREADS), sp::sp_mix_smem<sp::Sum16<T>::value>(), st, "k_sp_mix<0>", m));
+        if (sp_mixr_ok<sp::Sum16<T>::value>(M, m.E)) RC((sp_mixr<0, sp::Sum16<T>::value>(W, ldw, w.kv, w.g, M, m.E, B * H, st)));
+        else RC(launch(sp::k_sp_mix<0, sp::Sum16<T>::value>, dim3((unsigned)((m.E + sp::SPM_TE - 1) / sp::SPM_TE), (M + 63) / 64, B * H), dim3(NTHREADS), sp::sp_mix_smem<sp::Sum16<T>::value>(), st, "k_sp_mix<0>", m));
         if (normalize)
             RC(launch(k_wz<0>, dim3((S + 63) / 64, (M + 63) / 64, B * H), dim3(NTHREADS), 0, st, "k_wz<0>", W, ldw, (const float*)w.z, w.ninv, M, S, eps));
         return MHLA_OK;
@@ -118,7 +143,8 @@ int bm_bwd_typed(const BmCall& c) {
             if (normalize)
                 RC(launch(k_wz<1>, dim3((S + 63) / 64, (M + 63) / 64, B * H), dim3(NTHREADS), 0, st, "k_wz<1>", W, ldw, (const float*)w.dn, w.dz, M, S, 0.f));
             MixArgs m{W, ldw, w.dg, w.dkv, M, E};
-            RC(launch(sp::k_sp_mix<1, sp::Sum16<ET>::value>, dim3((unsigned)((E + sp::SPM_TE - 1) / sp::SPM_TE), tiles, B * H), dim3(NTHREADS), sp::sp_mix_smem<sp::Sum16<ET>::value>(), st, "k_sp_mix<1>", m));
+            if (sp_mixr_ok<sp::Sum16<ET>::value>(M, E)) RC((sp_mixr<1, sp::Sum16<ET>::value>(W, ldw, w.dg, w.dkv, M, E, B * H, st)));
+            else RC(launch(sp::k_sp_mix<1, sp::Sum16<ET>::value>, dim3((unsigned)((E + sp::SPM_TE - 1) / sp::SPM_TE), tiles, B * H), dim3(NTHREADS), sp::sp_mix_smem<sp::Sum16<ET>::value>(), st, "k_sp_mix<1>", m));
             int nsplit = dw_splits(tiles * tiles * B * H, E);
             if (nsplit > DW_MAX_SPLIT - 1) nsplit = DW_MAX_SPLIT - 1;   // one more part per (b, h) holds the <dn_i, z_j> term
             DwArgs d{w.dg, w.kv, E, nullptr, nullptr, 0, w.dwp, M, tiles, nsplit};

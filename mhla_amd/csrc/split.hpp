@@ -444,6 +444,159 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_mix(const MixArgs a) {
 }
 
 // -------------------------------------------------------------------------------------------------
+// k_sp_mixr<NW, TRANS, S16>: the same mixing with EVERY block of the (b,h) resident in the workgroup (M <= 16 NW <= 256), the
+// causal path's k_csf_mixf for a full matrix.  A workgroup owns slices of 256-byte row pieces (TE = 64 fp32 or 128 bf16 elements):
+// the slice's rows of all blocks sit in LDS (fp32 summaries as bf16 hi + lo tiles), so every summary byte is read from HBM once
+// (k_sp_mix re-reads a slice per 64-row output tile: 1.5x at M = 150, 4x at M = 256) and the mixing weights of a wave's 16 output
+// blocks live in its registers as bf16 hi + lo for the whole launch (k_sp_mix rebuilt them per step and was bound by its LDS
+// operand reads: 3.1 TB/s at the Wan shape, 2.3 TB/s at M = 256).  One wave per 16 output blocks; the summaries enter the MFMA
+// through the transpose read as the A operand, so a lane ends up with four consecutive elements of one output block (16-byte /
+// 8-byte staging writes, full 256-byte rows out); a workgroup walks `spw` consecutive slices with the next slice's rows in
+// flight in registers.  grid: wgs <= 256 persistent workgroups of 64 NW threads.
+//   TRANS 0: out[i][e] = sum_j W[i][j] in[j][e]      TRANS 1: out[j][e] = sum_i W[i][j] in[i][e]
+// -------------------------------------------------------------------------------------------------
+struct MixrArgs {
+    const float* W;
+    int ldw;
+    const void* in;
+    void* out;
+    int M;
+    long E;        // elements per block summary (multiple of the slice width)
+    long total;    // slices = bh * E / TE
+    int spw;       // slices per workgroup
+};
+// slice width: 256-byte row pieces; 128-byte ones for 16 waves (1024 threads on 128 VGPRs: half the accumulators and staging registers)
+template <int NW, bool S16> __host__ __device__ constexpr int mixr_te() { return (S16 ? 128 : 64) / (NW > 12 ? 2 : 1); }
+template <int NW, bool S16>
+__host__ __device__ constexpr int sp_mixr_smem() {
+    constexpr int TE = mixr_te<NW, S16>(), ROWS = 16 * NW;
+    return (S16 ? 1 : 2) * ROWS * (TE + 8) * 2 + (S16 ? ROWS * (TE + 8) * 2 : ROWS * (TE + 4) * 4);
+}
+
+template <int NW, int TRANS, bool S16>
+__global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void k_sp_mixr(const MixrArgs a) {
+    constexpr int TE = mixr_te<NW, S16>(), ROWS = 16 * NW, LD = TE + 8, LDO = TE + 4, NK = (NW + 1) / 2, NT = TE / 16;
+    constexpr int PPR = TE * (S16 ? 2 : 4) / 16;          // 16-byte pieces per row of the slice (16, or 8 with 16 waves)
+    constexpr int NTH = 64 * NW, NP = ROWS * PPR / NTH;   // pieces per thread and slice
+    static_assert(NP * NTH == ROWS * PPR, "pieces must tile the slice");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u16* Th = reinterpret_cast<u16*>(smem_raw);
+    u16* Tl = Th + ROWS * LD;                                        // (fp32 summaries only)
+    unsigned char* Os = smem_raw + (S16 ? 1 : 2) * ROWS * LD * 2;     // bf16 [ROWS][LD] or fp32 [ROWS][LDO]
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nl = lane & 15, kg = lane >> 4;
+    const int M = a.M;
+    const long nsl = a.E / TE;
+    const long s0 = (long)blockIdx.x * a.spw;
+    const int cnt = (int)min((long)a.spw, a.total - s0);
+    if (cnt <= 0) return;
+    // B operand: B[k = r][n = o] = weight of input block r in output block o = 16 wave + nl, r = 32 ks + 8 kg + t
+    bf16x8 wh[NK], wl[NK];
+    const int orow = wave * 16 + nl;
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int r = ks * 32 + kg * 8 + t;
+            const bool ok = orow < M && r < M;
+            const long off = TRANS ? (long)(ok ? r : 0) * a.ldw + (ok ? orow : 0) : (long)(ok ? orow : 0) * a.ldw + (ok ? r : 0);
+            const float x = gld<float>(a.W + off);
+            const float w = ok ? x : 0.f;
+            const __bf16 h = (__bf16)w;
+            wh[ks][t] = h;
+            wl[ks][t] = (__bf16)(w - (float)h);
+        }
+    }
+    constexpr int ESZ = S16 ? 2 : 4;
+    auto slice_off = [&](long sl) { const long bh = sl / nsl, es = sl - bh * nsl; return (bh * M * a.E + es * TE) * ESZ; };   // bytes
+    // the thread's pieces: piece v = tid + p NTH -> row v / PPR, 16 bytes at column piece v % PPR (rows past M: the last row, zeroed)
+    unsigned goff[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int v = tid + p * NTH, row = v / PPR, c = v % PPR;
+        goff[p] = (unsigned)((long)(row < M ? row : M - 1) * a.E * ESZ + c * 16);
+    }
+    uint4 pre[NP];
+    auto issue = [&](long sl) {
+        const char* base = reinterpret_cast<const char*>(a.in) + slice_off(sl);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) pre[p] = gld_stream16(base + goff[p]);
+    };
+    issue(s0);
+    for (int it = 0; it < cnt; ++it) {
+        const long off = slice_off(s0 + it);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int v = tid + p * NTH, row = v / PPR, c = v % PPR;
+            const bool ok = row < M;   // rows past the last block: zeros (their weights are zero too, but 0 x NaN is not)
+            const uint4 x = make_uint4(ok ? pre[p].x : 0u, ok ? pre[p].y : 0u, ok ? pre[p].z : 0u, ok ? pre[p].w : 0u);
+            if constexpr (S16) {
+                *reinterpret_cast<uint4*>(Th + row * LD + c * 8) = x;
+            } else {   // four floats -> four bf16 hi + four bf16 lo
+                const float f[4] = {__uint_as_float(x.x), __uint_as_float(x.y), __uint_as_float(x.z), __uint_as_float(x.w)};
+                float l[4];
+                unsigned short hs[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    hs[i] = cvt_bf16(f[i]);
+                    l[i] = f[i] - __uint_as_float((unsigned)hs[i] << 16);
+                }
+                *reinterpret_cast<uint2*>(Th + row * LD + c * 4) = make_uint2(hs[0] | ((unsigned)hs[1] << 16), hs[2] | ((unsigned)hs[3] << 16));
+                *reinterpret_cast<uint2*>(Tl + row * LD + c * 4) = make_uint2(pack_bf16x2(l[0], l[1]), pack_bf16x2(l[2], l[3]));
+            }
+        }
+        __syncthreads();
+        if (it + 1 < cnt) issue(s0 + it + 1);
+        f32x4 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int kend = (M + 31) / 32;   // (uniform) reduction steps that hold a block
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) {
+            if (ks < kend) {
+                constexpr int TB = NT < 4 ? NT : 4;   // operand tiles per batch
+#pragma unroll
+                for (int t4 = 0; t4 < NT; t4 += TB) {
+                    bf16x8 sv[TB], sl[S16 ? 1 : TB];
+#pragma unroll
+                    for (int t = 0; t < TB; ++t) {
+                        sv[t] = tr_read8(Th, LD, ks * 32, (t4 + t) * 16, lane);
+                        if constexpr (!S16) sl[t] = tr_read8(Tl, LD, ks * 32, (t4 + t) * 16, lane);
+                    }
+#pragma unroll
+                    for (int t = 0; t < TB; ++t) acc[t4 + t] = mfma_bf16(sv[t], wh[ks], acc[t4 + t]);
+                    if constexpr (!S16) {
+#pragma unroll
+                        for (int t = 0; t < TB; ++t) acc[t4 + t] = mfma_bf16(sl[t], wh[ks], acc[t4 + t]);
+                    }
+#pragma unroll
+                    for (int t = 0; t < TB; ++t) acc[t4 + t] = mfma_bf16(sv[t], wl[ks], acc[t4 + t]);
+                }
+            }
+        }
+        // lane: elements 16 t + 4 kg .. + 3 of output block 16 wave + nl -> staging tile [block][element]
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if constexpr (S16)
+                *reinterpret_cast<uint2*>(reinterpret_cast<u16*>(Os) + (wave * 16 + nl) * LD + t * 16 + kg * 4) =
+                    make_uint2(pack_bf16x2(acc[t][0], acc[t][1]), pack_bf16x2(acc[t][2], acc[t][3]));
+            else
+                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(Os) + (wave * 16 + nl) * LDO + t * 16 + kg * 4) = acc[t];
+        }
+        __syncthreads();
+        char* ob = reinterpret_cast<char*>(a.out) + off;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int v = tid + p * NTH, row = v / PPR, c = v % PPR;
+            if (row < M) {
+                const uint4 x = S16 ? *reinterpret_cast<const uint4*>(reinterpret_cast<const u16*>(Os) + row * LD + c * 8)
+                                    : *reinterpret_cast<const uint4*>(reinterpret_cast<const float*>(Os) + row * LDO + c * 4);
+                gst<uint4>(ob + goff[p], x);
+            }
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
 // LDS row stride (bf16) of a staged D x D summary matrix [KST * 32 rows][KST * 32 columns + 8]: the reads cover KST * 32
 // columns, not the DW of the token tiles (D = 72: 104 instead of 136 -> a third workgroup per CU for the fp32 kernels)
 template <int DT>

@@ -80,7 +80,7 @@ def _result(name, what, t, tokens, alg, step, graph_t=None, key=None):
     dom = max(ks, key=ks.get) if ks else None
     r = {"shape": name, "what": what, "ms": t * 1e3, "tokens_per_s": tokens / t, "algorithmic_GBps": alg / t / 1e9,
          "hbm_frac": alg / t / HBM_PEAK, "kernel_us_per_step": sum(ks.values()),
-         "dominant_kernel": dom, "dominant_kernel_us": ks.get(dom) if dom else None, "n_kernels": len(ks)}
+         "dominant_kernel": dom, "dominant_kernel_us": ks.get(dom) if dom else None, "n_kernels": len(ks), "kernel_us": ks}
     if graph_t is not None:
         r["ms_graph_replay"] = graph_t * 1e3
         r["hbm_frac_graph_replay"] = alg / graph_t / HBM_PEAK
