@@ -11,6 +11,13 @@ namespace capi {
 
 // Resident-sequence mixing (sp::k_sp_mixr): 33 <= M <= 256 blocks, summaries in whole 256-byte row pieces.  MHLA_SP_MIX=old keeps
 // the tiled kernel (A/B).
+template <int DT> constexpr int sp_state_threads() {
+#ifdef MHLA_SP_STATE_4WAVES
+    return NTHREADS;
+#else
+    return DT == 8 ? 512 : NTHREADS;
+#endif
+}
 template <bool S16>
 inline bool sp_mixr_ok(int M, long E) {
     static const char* const knob = getenv("MHLA_SP_MIX");   // tuning knob, read once
@@ -48,8 +55,9 @@ int bm_state_and_mix(const mhla_view& q_num, const mhla_view& k_num, const mhla_
     a.relu = (flags & MHLA_FLAG_RELU_EPS) ? 1 : 0; a.normalize = normalize; a.split = split;
     MixArgs m{W, ldw, w.kv, w.g, M, (long)D * D};
     if (sp_shape_ok(D, flags)) {   // split-bf16 MFMA kernels (split.hpp)
-        if (a.rcos) RC(launch(sp::k_sp_state<T, DT, 0, true>, dim3(M, B * H), dim3(NTHREADS), sp::sp_state_smem<DT>(), st, "k_sp_state<rope>", a));
-        else        RC(launch(sp::k_sp_state<T, DT, 0>, dim3(M, B * H), dim3(NTHREADS), sp::sp_state_smem<DT>(), st, "k_sp_state", a));
+        constexpr int SNT = sp_state_threads<DT>();   // eight waves at D = 128 (split.hpp)
+        if (a.rcos) RC(launch(sp::k_sp_state<T, DT, 0, true, SNT>, dim3(M, B * H), dim3(SNT), sp::sp_state_smem<DT>(), st, "k_sp_state<rope>", a));
+        else        RC(launch(sp::k_sp_state<T, DT, 0, false, SNT>, dim3(M, B * H), dim3(SNT), sp::sp_state_smem<DT>(), st, "k_sp_state", a));
         if (sp_mixr_ok<sp::Sum16<T>::value>(M, m.E)) RC((sp_mixr<0, sp::Sum16<T>::value>(W, ldw, w.kv, w.g, M, m.E, B * H, st)));
         else RC(launch(sp::k_sp_mix<0, sp::Sum16<T>::value>, dim3((unsigned)((m.E + sp::SPM_TE - 1) / sp::SPM_TE), (M + 63) / 64, B * H), dim3(NTHREADS), sp::sp_mix_smem<sp::Sum16<T>::value>(), st, "k_sp_mix<0>", m));
         if (normalize)
@@ -136,10 +144,11 @@ int bm_bwd_typed(const BmCall& c) {
             const long E = (long)D * D;
             a.rcos = rcos; a.rsin = rsin; a.ldr = ldr;
             t.rcos = rcos; t.rsin = rsin; t.ldr = ldr;
+            constexpr int SNT = sp_state_threads<DT>();
             if constexpr (std::is_same<ET, float>::value) {
-                if (rcos) RC(launch(sp::k_sp_state<ET, DT, 1, true>, dim3(M, B * H), dim3(NTHREADS), sp::sp_state_smem<DT>(), st, "k_sp_state<1,rope>", a));
+                if (rcos) RC(launch(sp::k_sp_state<ET, DT, 1, true, SNT>, dim3(M, B * H), dim3(SNT), sp::sp_state_smem<DT>(), st, "k_sp_state<1,rope>", a));
             }
-            if (!rcos) RC(launch(sp::k_sp_state<ET, DT, 1>, dim3(M, B * H), dim3(NTHREADS), sp::sp_state_smem<DT>(), st, "k_sp_state<1>", a));
+            if (!rcos) RC(launch(sp::k_sp_state<ET, DT, 1, false, SNT>, dim3(M, B * H), dim3(SNT), sp::sp_state_smem<DT>(), st, "k_sp_state<1>", a));
             if (normalize)
                 RC(launch(k_wz<1>, dim3((S + 63) / 64, (M + 63) / 64, B * H), dim3(NTHREADS), 0, st, "k_wz<1>", W, ldw, (const float*)w.dn, w.dz, M, S, 0.f));
             MixArgs m{W, ldw, w.dg, w.dkv, M, E};

@@ -91,9 +91,16 @@ __host__ __device__ constexpr int sp_state_smem() {
 // MODE 1 (backward): out = dG_i = Q_i^T (dO_i / n_i); dn_i[s] = -(dO_i[s] . O_i[s]) / n_i[s]     x = q_num, y = dout, o = out
 // ROPE: x (the keys of the KV product in MODE 0, the queries of dG = Q^T dP in MODE 1) is rotated on load (a.rcos / a.rsin); a
 // template flag so that the plain variants do not carry the angle registers (3 waves per SIMD need <= 168 VGPRs)
-template <typename T, int DT, int MODE, bool ROPE = false>
-__global__ __launch_bounds__(NTHREADS, ROPE ? 2 : 3) void k_sp_state(const StateArgs a) {
-    constexpr int DW = Geo<DT>::DW, LD = Geo<DT>::LD, CGS = Geo<DT>::CGS, RPP = Geo<DT>::RPP, IT = 32 / RPP, RT = Geo<DT>::RT, TILE = 32 * LD;
+// NT: threads.  512 (D = 128 only): a 32-row chunk is one staging pass and every wave owns ONE 16-row tile of the summary -- half
+// the staging and accumulator registers per thread (<= 128 VGPRs: two workgroups = 16 waves per CU) and half the time per block,
+// which matters at the Wan shape for a second reason: 1 800 blocks on 768 four-wave slots are 2.3 rounds that cost 3, on 512
+// eight-wave slots of half the duration 3.5 rounds that cost 4 (of half the length).
+template <typename T, int DT, int MODE, bool ROPE = false, int NT = NTHREADS>
+__global__ __launch_bounds__(NT, NT == 512 ? 4 : (ROPE ? 2 : 3)) void k_sp_state(const StateArgs a) {
+    constexpr int DW = Geo<DT>::DW, LD = Geo<DT>::LD, CGS = Geo<DT>::CGS, RPP = NT / CGS, IT = 32 / RPP, NWV = NT / 64,
+                  RT = (DT + NWV - 1) / NWV, TILE = 32 * LD;
+    static_assert(IT >= 1 && RPP * IT == 32, "a 32-row chunk must be whole staging passes");
+    static_assert(RPP * DW * 4 <= 4 * 32 * LD * 2, "column-sum partials must fit in the tiles");
     constexpr bool LO = !std::is_same<T, bf16_t>::value;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u16* Kh = reinterpret_cast<u16*>(smem_raw);
