@@ -168,8 +168,8 @@ static int bm_fwd_impl(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view 
         fast::SnArgs sa{};
         sa.q = cv(q_num); sa.k = cv(k_num); sa.v = cv(v); sa.out = cmv(out); sa.idx = block_index; sa.W = W; sa.ldw = ldw;
         sa.H = H; sa.M = M; sa.D = D; sa.eps = eps; sa.relu = relu; sa.normalize = normalize;
-        if (D <= 64) RC(launch(sa.idx ? fast::k_sn_fwd<4, true> : fast::k_sn_fwd<4, false>, dim3(B * H), dim3(fast::SN_T), fast::sn_fwd_smem<4>(), st, "k_sn_fwd<4>", sa));
-        else         RC(launch(sa.idx ? fast::k_sn_fwd<5, true> : fast::k_sn_fwd<5, false>, dim3(B * H), dim3(fast::SN_T), fast::sn_fwd_smem<5>(), st, "k_sn_fwd<5>", sa));
+        if (D <= 64) RC(launch(sa.idx ? fast::k_sn_fwd<4, true> : (M == 16 ? fast::k_sn_fwd<4, false, true> : fast::k_sn_fwd<4, false>), dim3(B * H), dim3(fast::SN_T), fast::sn_fwd_smem<4>(), st, "k_sn_fwd<4>", sa));
+        else         RC(launch(sa.idx ? fast::k_sn_fwd<5, true> : (M == 16 ? fast::k_sn_fwd<5, false, true> : fast::k_sn_fwd<5, false>), dim3(B * H), dim3(fast::SN_T), fast::sn_fwd_smem<5>(), st, "k_sn_fwd<5>", sa));
         return MHLA_OK;
     }
     if (!rcos && !epi && snf_shape_ok(M, S, D, dtype, split) && !(flags & (MHLA_FLAG_FORCE_GENERIC | MHLA_FLAG_NO_SMALLN)) && view_ok16(q_num) &&
@@ -178,8 +178,8 @@ static int bm_fwd_impl(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view 
         fast::SnArgs sa{};
         sa.q = cv(q_num); sa.k = cv(k_num); sa.v = cv(v); sa.out = cmv(out); sa.idx = block_index; sa.W = W; sa.ldw = ldw;
         sa.H = H; sa.M = M; sa.D = D; sa.eps = eps; sa.relu = relu; sa.normalize = normalize;
-        if (D <= 64) RC(launch(sa.idx ? fast::k_snf_fwd<4, true> : fast::k_snf_fwd<4, false>, dim3(B * H), dim3(fast::SNF_T), fast::snf_smem<4>(), st, "k_snf_fwd<4>", sa));
-        else         RC(launch(sa.idx ? fast::k_snf_fwd<5, true> : fast::k_snf_fwd<5, false>, dim3(B * H), dim3(fast::SNF_T), fast::snf_smem<5>(), st, "k_snf_fwd<5>", sa));
+        if (D <= 64) RC(launch(sa.idx ? fast::k_snf_fwd<4, true> : (M == 16 ? fast::k_snf_fwd<4, false, true> : fast::k_snf_fwd<4, false>), dim3(B * H), dim3(fast::SNF_T), fast::snf_smem<4>(), st, "k_snf_fwd<4>", sa));
+        else         RC(launch(sa.idx ? fast::k_snf_fwd<5, true> : (M == 16 ? fast::k_snf_fwd<5, false, true> : fast::k_snf_fwd<5, false>), dim3(B * H), dim3(fast::SNF_T), fast::snf_smem<5>(), st, "k_snf_fwd<5>", sa));
         return MHLA_OK;
     }
     if (!rcos && !epi && fast_shape_ok(M, D, dtype, split) && !(flags & MHLA_FLAG_FORCE_GENERIC) && view_ok16(q_num) && view_ok16(k_num) &&
@@ -284,8 +284,8 @@ static int bm_bwd_impl(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view 
             sa.q = cv(q_num); sa.k = cv(k_num); sa.v = cv(v); sa.o = normalize ? cv(out) : cv(q_num); sa.dout = cv(dout);
             sa.dq = cmv(dq_num); sa.dk = cmv(dk_num); sa.dv = cmv(dv); sa.idx = block_index; sa.W = W; sa.ldw = ldw;
             sa.dwp = (float*)ws; sa.H = H; sa.M = M; sa.D = D; sa.eps = eps; sa.relu = relu; sa.normalize = normalize;
-            if (D <= 64) RC(launch(sa.idx ? fast::k_snf_bwd<4, true> : fast::k_snf_bwd<4, false>, dim3(B * H), dim3(fast::SNF_T), fast::snf_smem<4>(), st, "k_snf_bwd<4>", sa));
-            else         RC(launch(sa.idx ? fast::k_snf_bwd<5, true> : fast::k_snf_bwd<5, false>, dim3(B * H), dim3(fast::SNF_T), fast::snf_smem<5>(), st, "k_snf_bwd<5>", sa));
+            if (D <= 64) RC(launch(sa.idx ? fast::k_snf_bwd<4, true> : (M == 16 ? fast::k_snf_bwd<4, false, true> : fast::k_snf_bwd<4, false>), dim3(B * H), dim3(fast::SNF_T), fast::snf_smem<4>(), st, "k_snf_bwd<4>", sa));
+            else         RC(launch(sa.idx ? fast::k_snf_bwd<5, true> : (M == 16 ? fast::k_snf_bwd<5, false, true> : fast::k_snf_bwd<5, false>), dim3(B * H), dim3(fast::SNF_T), fast::snf_smem<5>(), st, "k_snf_bwd<5>", sa));
             RC(launch(fast::k_sn_dw_reduce, dim3(M * M), dim3(256), 0, st, "k_sn_dw_reduce", (const float*)ws, dW, M * M, B * H));
             return MHLA_OK;
         }
@@ -299,8 +299,8 @@ static int bm_bwd_impl(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view 
             sa.dq = cmv(dq_num); sa.dk = cmv(dk_num); sa.dv = cmv(dv); sa.idx = block_index; sa.W = W; sa.ldw = ldw;
             sa.dwp = (float*)ws; sa.H = H; sa.M = M; sa.D = D; sa.eps = eps; sa.relu = relu; sa.normalize = normalize;
             sa.trace = g_trace.load();
-            if (D <= 64) RC(launch(sa.idx ? fast::k_sn_bwd<4, true> : fast::k_sn_bwd<4, false>, dim3(B * H), dim3(fast::SN_TB), fast::sn_bwd_smem<4>(), st, "k_sn_bwd<4>", sa));
-            else         RC(launch(sa.idx ? fast::k_sn_bwd<5, true> : fast::k_sn_bwd<5, false>, dim3(B * H), dim3(fast::SN_TB), fast::sn_bwd_smem<5>(), st, "k_sn_bwd<5>", sa));
+            if (D <= 64) RC(launch(sa.idx ? fast::k_sn_bwd<4, true> : (M == 16 ? fast::k_sn_bwd<4, false, true> : fast::k_sn_bwd<4, false>), dim3(B * H), dim3(fast::SN_TB), fast::sn_bwd_smem<4>(), st, "k_sn_bwd<4>", sa));
+            else         RC(launch(sa.idx ? fast::k_sn_bwd<5, true> : (M == 16 ? fast::k_sn_bwd<5, false, true> : fast::k_sn_bwd<5, false>), dim3(B * H), dim3(fast::SN_TB), fast::sn_bwd_smem<5>(), st, "k_sn_bwd<5>", sa));
             RC(launch(fast::k_sn_dw_reduce, dim3(M * M), dim3(256), 0, st, "k_sn_dw_reduce", (const float*)ws, dW, M * M, B * H));
             return MHLA_OK;
         }

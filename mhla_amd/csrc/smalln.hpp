@@ -179,7 +179,7 @@ __host__ __device__ constexpr int sn_fwd_smem() {
 // ------------------------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------------------------
-template <int DT, bool GATHER>
+template <int DT, bool GATHER, bool M16 = false>
 __global__ __launch_bounds__(SN_T, SN_T / 256) void k_sn_fwd(const SnArgs a) {
     // GATHER: the launch has a block_index map.  As a template parameter the row lookups carry no branch: with `idx ? idx[p] : p`
     // decided at run time hipcc branched around every map load and waited for ALL loads in flight at each join (s_waitcnt
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(SN_T, SN_T / 256) void k_sn_fwd(const SnArgs a) {
     // (b,h) pairs in XCD-contiguous order: a token's heads are adjacent in memory (144-byte rows for D = 72: neighbouring heads share
     // cache lines), so the heads of one batch element go to workgroups of ONE XCD, running side by side, and each line is fetched once
     const int bh = xcd_swizzle(blockIdx.x, gridDim.x), b = bh / a.H, h = bh - b * a.H;
-    const int M = a.M, D = a.D, N = M * 16;
+    const int M = M16 ? 16 : a.M, D = a.D, N = M * 16;
     const u16* qb = (const u16*)a.q.ptr + b * a.q.sb + h * a.q.sh;
     const u16* kb = (const u16*)a.k.ptr + b * a.k.sb + h * a.k.sh;
     const u16* vb = (const u16*)a.v.ptr + b * a.v.sb + h * a.v.sh;
@@ -318,7 +318,8 @@ __device__ __forceinline__ void sn_store16(u16* __restrict__ base, long sn, cons
     }
 }
 
-template <int DT, bool GATHER>
+// M16: the launch has exactly 16 blocks (the DiT 256^2 grid): the block loops carry no run-time guard, straight-line code
+template <int DT, bool GATHER, bool M16 = false>
 __global__ __launch_bounds__(SN_TB, 2) void k_sn_bwd(const SnArgs a) {
     // GATHER: the launch has a block_index map.  As a template parameter the row lookups carry no branch: with `idx ? idx[p] : p`
     // decided at run time hipcc branched around every map load and waited for ALL loads in flight at each join (s_waitcnt
@@ -341,7 +342,7 @@ __global__ __launch_bounds__(SN_TB, 2) void k_sn_bwd(const SnArgs a) {
     // (b,h) pairs in XCD-contiguous order: a token's heads are adjacent in memory (144-byte rows for D = 72: neighbouring heads share
     // cache lines), so the heads of one batch element go to workgroups of ONE XCD, running side by side, and each line is fetched once
     const int bh = xcd_swizzle(blockIdx.x, gridDim.x), b = bh / a.H, h = bh - b * a.H;
-    const int M = a.M, D = a.D, N = M * 16;
+    const int M = M16 ? 16 : a.M, D = a.D, N = M * 16;
     auto base = [&](const View& w) { return (const u16*)w.ptr + b * w.sb + h * w.sh; };
     auto mbase = [&](const MView& w) { return (u16*)w.ptr + b * w.sb + h * w.sh; };
     const u16 *qb = base(a.q), *kb = base(a.k), *vb = base(a.v), *ob = base(a.o), *gb = base(a.dout);

@@ -157,7 +157,7 @@ __host__ __device__ constexpr int snf_smem() {
 // ------------------------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------------------------
-template <int DT, bool GATHER>
+template <int DT, bool GATHER, bool M16 = false>
 __global__ __launch_bounds__(SNF_T, 2) void k_snf_fwd(const SnArgs a) {
     // GATHER: the launch has a block_index map.  As a template parameter the row lookups carry no branch: with `idx ? idx[p] : p`
     // decided at run time hipcc branched around every map load and waited for ALL loads in flight at each join (s_waitcnt
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(SNF_T, 2) void k_snf_fwd(const SnArgs a) {
     float* zs = ksum_s + 2 * 16 * DP;                     // [M][16]   (the layout of snf_smem is shared with the backward)
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, n = lane & 15, kg = lane >> 4;
     const int bh = xcd_swizzle(blockIdx.x, gridDim.x), b = bh / a.H, h = bh - b * a.H;
-    const int M = a.M, D = a.D, N = M * 16;
+    const int M = M16 ? 16 : a.M, D = a.D, N = M * 16;
     const float* qb = (const float*)a.q.ptr + b * a.q.sb + h * a.q.sh;
     const float* kb = (const float*)a.k.ptr + b * a.k.sb + h * a.k.sh;
     const float* vb = (const float*)a.v.ptr + b * a.v.sb + h * a.v.sh;
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(SNF_T, 2) void k_snf_fwd(const SnArgs a) {
 //   pass A (wave owns query block i, K / V halves in LDS):  S^T, dP^T tiles -> dW[i][:], dS -> dQ_i
 //   pass B (wave owns key block j, Q / dO' halves in LDS):  S, dP tiles -> P^T dO' = dV_j ; dS^T Q = dK_j ; dksum_j
 // ------------------------------------------------------------------------------------------------------------------
-template <int DT, bool GATHER>
+template <int DT, bool GATHER, bool M16 = false>
 __global__ __launch_bounds__(SNF_T, 2) void k_snf_bwd(const SnArgs a) {
     // GATHER: the launch has a block_index map.  As a template parameter the row lookups carry no branch: with `idx ? idx[p] : p`
     // decided at run time hipcc branched around every map load and waited for ALL loads in flight at each join (s_waitcnt
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(SNF_T, 2) void k_snf_bwd(const SnArgs a) {
     float* dzs = dns + 256;                              // dz
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, n = lane & 15, kg = lane >> 4;
     const int bh = xcd_swizzle(blockIdx.x, gridDim.x), b = bh / a.H, h = bh - b * a.H;
-    const int M = a.M, D = a.D, N = M * 16;
+    const int M = M16 ? 16 : a.M, D = a.D, N = M * 16;
     auto base = [&](const View& w) { return (const float*)w.ptr + b * w.sb + h * w.sh; };
     auto mbase = [&](const MView& w) { return (float*)w.ptr + b * w.sb + h * w.sh; };
     const float *qb = base(a.q), *kb = base(a.k), *vb = base(a.v), *ob = base(a.o), *gb = base(a.dout);
