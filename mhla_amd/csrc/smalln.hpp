@@ -78,6 +78,44 @@ __device__ __forceinline__ void sn_stage(u16* __restrict__ dst, const u16* __res
     }
 }
 
+// Two tiles at once: BOTH tensors' loads are issued before either is written to LDS.  Two sn_stage calls in a row cost two
+// memory round trips (the second tensor's loads wait behind the first tensor's s_waitcnt): with an otherwise empty GPU a backward
+// workgroup spent 6.6 us on "stage K, V" -- own-row loads drained for the weights' LDS write, then K, then V, three round trips.
+template <int DT, int NT, bool SCALE1>
+__device__ __forceinline__ void sn_stage2(u16* __restrict__ dst0, const u16* __restrict__ base0, long sn0, float eps0, bool relu0,
+                                          u16* __restrict__ dst1, const u16* __restrict__ base1, long sn1,
+                                          const int* __restrict__ idx, int nrows, int D, int tid, const float* __restrict__ rowscale1 = nullptr) {
+    constexpr int LDR = sn_ldr<DT>(), PV = DT * 2;
+    const int dv = D >> 3;
+    constexpr int MAXIT = (256 * PV + NT - 1) / NT;
+    uint4 r0[MAXIT], r1[MAXIT];
+#pragma unroll
+    for (int t = 0; t < MAXIT; ++t) {
+        const int v = tid + t * NT, r = v / PV, p = v - r * PV;
+        const long row = tok_row(idx, min(r, nrows - 1));
+        r0[t] = gld<uint4>(base0 + row * sn0 + min(p, dv - 1) * 8);
+        r1[t] = gld<uint4>(base1 + row * sn1 + min(p, dv - 1) * 8);
+    }
+#pragma unroll
+    for (int t = 0; t < MAXIT; ++t) {
+        const int v = tid + t * NT, r = v / PV, p = v - r * PV;
+        if (r < nrows) {
+            uint4 x = r0[t], y = r1[t];
+            if (relu0) x = relu_eps8(x, eps0);   // (uniform)
+            if (SCALE1) {
+                const float sc = rowscale1[r];
+                unsigned w[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    w[u] = pack_bf16x2(__uint_as_float(w[u] << 16) * sc, __uint_as_float(w[u] & 0xffff0000u) * sc);
+                y = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+            *reinterpret_cast<uint4*>(dst0 + r * LDR + p * 8) = sel4(p < dv, x);
+            *reinterpret_cast<uint4*>(dst1 + r * LDR + p * 8) = sel4(p < dv, y);
+        }
+    }
+}
+
 // 16 rows x KS k-steps of an MFMA operand straight from global: lane (m = lane & 15, kg) -> row0 + m, cols 32 ks + 8 kg ..
 // (columns beyond D: a clamped address, zeroed on arrival).  In two halves, so that a kernel can request all its rows first and touch
 // them (relu + eps, zeroing) only where they are consumed.
@@ -204,13 +242,16 @@ __global__ __launch_bounds__(SN_T, SN_T / 256) void k_sn_fwd(const SnArgs a) {
     u16* ob = (u16*)a.out.ptr + b * a.out.sb + h * a.out.sh;
 
     __shared__ float Wsh[16 * 17];   // mixing weights (M <= 16): read in the inner loops, so kept off the global-load path
-    if (tid < 256) Wsh[(tid >> 4) * 17 + (tid & 15)] = ((tid >> 4) < M && (tid & 15) < M) ? a.W[(long)(tid >> 4) * a.ldw + (tid & 15)] : 0.f;
-    // the wave's own Q rows are requested first: they travel while K, V are staged
+    // the thread's weight is requested FIRST and parked in LDS behind the staging (a wait for the youngest load drains every load)
+    const int wi = (tid >> 4) & 15, wj = tid & 15;
+    const bool wok = wi < M && wj < M;
+    const float wreg = gld<float>(a.W + (long)(wok ? wi : 0) * a.ldw + (wok ? wj : 0));
+    // the wave's own Q rows are requested next: they travel while K, V are staged
     uint4 qraw[2][KS];
 #pragma unroll
     for (int x = 0; x < 2; ++x) sn_issue_rows<KS>(qraw[x], qb, a.q.sn, idx, min(wave + SN_W * x, M - 1) * 16, D, lane);
-    sn_stage<DT>(Ks, kb, a.k.sn, idx, N, D, a.eps, tid, a.relu != 0);
-    sn_stage<DT>(Vs, vb, a.v.sn, idx, N, D, 0.f, tid, false);
+    sn_stage2<DT, SN_T, false>(Ks, kb, a.k.sn, a.eps, a.relu != 0, Vs, vb, a.v.sn, idx, N, D, tid);
+    if (tid < 256) Wsh[wi * 17 + wj] = wok ? wreg : 0.f;
     __syncthreads();
     if (a.normalize) {
         for (int v = tid; v < M * DP; v += SN_T) {
@@ -373,8 +414,11 @@ __global__ __launch_bounds__(SN_TB, 2) void k_sn_bwd(const SnArgs a) {
     };
 
     trace_mark(a.trace, 0);
-    // the wave's own rows of Q and dO (operands of P2 and of pass A) are requested first: they travel while K, V are staged
-    // (and, for the row dots, of O): nothing waits for them before the staged tiles are in LDS
+    // the thread's mixing weight first (parked in LDS behind the staging: a wait for the youngest load drains every load), then
+    // the wave's own rows of Q and dO (operands of P2 and of pass A; and, for the row dots, of O): they travel while K, V are staged
+    const int wi = (tid >> 4) & 15, wj = tid & 15;
+    const bool wok = wi < M && wj < M;
+    const float wreg = gld<float>(a.W + (long)(wok ? wi : 0) * a.ldw + (wok ? wj : 0));
     bf16x8 qa[2][KS], ga[2][KS];
     uint4 qraw[2][KS], graw[2][KS], oraw[2][KS];
 #pragma unroll
@@ -385,9 +429,8 @@ __global__ __launch_bounds__(SN_TB, 2) void k_sn_bwd(const SnArgs a) {
     }
     // ---- P0 / P1: K, V tiles; ksum ----
     __shared__ float Wsh[16 * 17];   // mixing weights (M <= 16), read in every inner loop
-    if (tid < 256) Wsh[(tid >> 4) * 17 + (tid & 15)] = ((tid >> 4) < M && (tid & 15) < M) ? a.W[(long)(tid >> 4) * a.ldw + (tid & 15)] : 0.f;
-    sn_stage<DT, SN_TB>(T0, kb, a.k.sn, idx, N, D, a.eps, tid, a.relu != 0);
-    sn_stage<DT, SN_TB>(T1, vb, a.v.sn, idx, N, D, 0.f, tid, false);
+    sn_stage2<DT, SN_TB, false>(T0, kb, a.k.sn, a.eps, a.relu != 0, T1, vb, a.v.sn, idx, N, D, tid);
+    if (tid < 256) Wsh[wi * 17 + wj] = wok ? wreg : 0.f;
 #pragma unroll
     for (int x = 0; x < 2; ++x) {
         sn_finish_rows<KS>(qa[x], qraw[x], D, a.eps, lane, a.relu != 0);
@@ -546,9 +589,8 @@ __global__ __launch_bounds__(SN_TB, 2) void k_sn_bwd(const SnArgs a) {
     trace_mark(a.trace, 6);
 
     // ---- P5: Q and dO' tiles replace K and V ----
-    sn_stage<DT, SN_TB>(T0, qb, a.q.sn, idx, N, D, a.eps, tid, a.relu != 0);
-    if (a.normalize) sn_stage<DT, SN_TB, true>(T1, gb, a.dout.sn, idx, N, D, 0.f, tid, false, nis);
-    else             sn_stage<DT, SN_TB>(T1, gb, a.dout.sn, idx, N, D, 0.f, tid, false);
+    if (a.normalize) sn_stage2<DT, SN_TB, true>(T0, qb, a.q.sn, a.eps, a.relu != 0, T1, gb, a.dout.sn, idx, N, D, tid, nis);
+    else             sn_stage2<DT, SN_TB, false>(T0, qb, a.q.sn, a.eps, a.relu != 0, T1, gb, a.dout.sn, idx, N, D, tid);
     __syncthreads();
     trace_mark(a.trace, 7);
 

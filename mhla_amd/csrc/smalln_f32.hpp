@@ -77,6 +77,50 @@ __device__ __forceinline__ void snf_stage(u16* __restrict__ Hh, u16* __restrict_
         }
     }
 }
+// two tensors at once: both tensors' loads are issued before either is split and written (one memory round trip instead of two)
+template <int DT, bool SCALE1>
+__device__ __forceinline__ void snf_stage2(u16* __restrict__ H0h, u16* __restrict__ H0l, const float* __restrict__ base0, long sn0, float eps0, bool relu0,
+                                           u16* __restrict__ H1h, u16* __restrict__ H1l, const float* __restrict__ base1, long sn1,
+                                           const int* __restrict__ idx, int row0, int nrows, int D, int tid, const float* __restrict__ rowscale1) {
+    constexpr int LDR = sn_ldr<DT>(), PV = DT * 2, MAXIT = (SNF_HR * PV + SNF_T - 1) / SNF_T;
+    const int dv = D >> 3;
+    f32x4 ra[MAXIT][2], rb[MAXIT][2];
+#pragma unroll
+    for (int t = 0; t < MAXIT; ++t) {
+        const int v = tid + t * SNF_T, r = v / PV, p = v - r * PV;
+        const long row = tok_row(idx, row0 + min(r, nrows - 1));
+        const float* s0 = base0 + row * sn0 + min(p, dv - 1) * 8;
+        const float* s1 = base1 + row * sn1 + min(p, dv - 1) * 8;
+        ra[t][0] = gld<f32x4>(s0);
+        ra[t][1] = gld<f32x4>(s0 + 4);
+        rb[t][0] = gld<f32x4>(s1);
+        rb[t][1] = gld<f32x4>(s1 + 4);
+    }
+#pragma unroll
+    for (int t = 0; t < MAXIT; ++t) {
+        const int v = tid + t * SNF_T, r = v / PV, p = v - r * PV;
+        if (r < SNF_HR) {
+            f32x4 x0 = ra[t][0], x1 = ra[t][1], y0 = rb[t][0], y1 = rb[t][1];
+            if (relu0) {   // (uniform)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { x0[i] = fmaxf(x0[i], 0.f) + eps0; x1[i] = fmaxf(x1[i], 0.f) + eps0; }
+            }
+            if (SCALE1) {
+                const float sc = rowscale1[row0 + min(r, nrows - 1)];
+                y0 *= sc;
+                y1 *= sc;
+            }
+            const bool ok = r < nrows && p < dv;
+            uint4 hi, lo;
+            snf_split8(x0, x1, hi, lo);
+            *reinterpret_cast<uint4*>(H0h + r * LDR + p * 8) = sel4(ok, hi);
+            *reinterpret_cast<uint4*>(H0l + r * LDR + p * 8) = sel4(ok, lo);
+            snf_split8(y0, y1, hi, lo);
+            *reinterpret_cast<uint4*>(H1h + r * LDR + p * 8) = sel4(ok, hi);
+            *reinterpret_cast<uint4*>(H1l + r * LDR + p * 8) = sel4(ok, lo);
+        }
+    }
+}
 // 16 rows of an fp32 view as an MFMA operand (lane: row lane & 15, columns 32 ks + 8 kg ..), hi + lo; optional relu + eps and a
 // per-row scale (lane's row).  Columns past D: a clamped address, zeroed on arrival.
 template <int KS>
@@ -195,8 +239,7 @@ __global__ __launch_bounds__(SNF_T, 2) void k_snf_fwd(const SnArgs a) {
     for (int half = 0; half * SNF_HR < N; ++half) {
         const int r0 = half * SNF_HR, nr = min(SNF_HR, N - r0), jb = half * 8;
         __syncthreads();   // the previous half's readers are done (first round: Wsh / ksum_s written)
-        snf_stage<DT, false>(Kh, Kl, kb, a.k.sn, idx, r0, nr, D, a.eps, tid, relu, nullptr);
-        snf_stage<DT, false>(Vh, Vl, vb, a.v.sn, idx, r0, nr, D, 0.f, tid, false, nullptr);
+        snf_stage2<DT, false>(Kh, Kl, kb, a.k.sn, a.eps, relu, Vh, Vl, vb, a.v.sn, idx, r0, nr, D, tid, nullptr);
         __syncthreads();
 #pragma unroll
         for (int x = 0; x < 2; ++x) {
@@ -385,8 +428,7 @@ __global__ __launch_bounds__(SNF_T, 2) void k_snf_bwd(const SnArgs a) {
             if (half * SNF_HR >= N) break;   // (uniform)
             const int r0 = half * SNF_HR, nr = min(SNF_HR, N - r0), jb = half * 8;
             __syncthreads();
-            snf_stage<DT, false>(Ah, Al, kb, a.k.sn, idx, r0, nr, D, a.eps, tid, relu, nullptr);
-            snf_stage<DT, false>(Bh, Bl, vb, a.v.sn, idx, r0, nr, D, 0.f, tid, false, nullptr);
+            snf_stage2<DT, false>(Ah, Al, kb, a.k.sn, a.eps, relu, Bh, Bl, vb, a.v.sn, idx, r0, nr, D, tid, nullptr);
             __syncthreads();
             if (live) {
 #pragma unroll
@@ -473,8 +515,7 @@ __global__ __launch_bounds__(SNF_T, 2) void k_snf_bwd(const SnArgs a) {
             if (half * SNF_HR >= N) break;   // (uniform)
             const int r0 = half * SNF_HR, nr = min(SNF_HR, N - r0), ib = half * 8;
             __syncthreads();
-            snf_stage<DT, false>(Ah, Al, qb, a.q.sn, idx, r0, nr, D, a.eps, tid, relu, nullptr);
-            snf_stage<DT, true>(Bh, Bl, gb, a.dout.sn, idx, r0, nr, D, 0.f, tid, false, nis);
+            snf_stage2<DT, true>(Ah, Al, qb, a.q.sn, a.eps, relu, Bh, Bl, gb, a.dout.sn, idx, r0, nr, D, tid, nis);
             __syncthreads();
             if (live) {
 #pragma unroll

@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import mhla_amd  # noqa: E402
 from mhla_amd import _lib, block_distance_weights  # noqa: E402
 
-B, N, H, D, M = 32, 256, 16, int(sys.argv[1]) if len(sys.argv) > 1 else 72, 16
+B, N, H, D, M = int(sys.argv[2]) if len(sys.argv) > 2 else 32, 256, 16, int(sys.argv[1]) if len(sys.argv) > 1 else 72, 16
 dev = "cuda"
 g = torch.Generator().manual_seed(1)
 ts = [torch.randn(B, N, H, D, generator=g).abs().bfloat16().to(dev).requires_grad_(True) for _ in range(3)]
