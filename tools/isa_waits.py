@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Compact trace of a kernel's memory waits from a device ISA listing (tools/isa_dump.sh writes /tmp/<unit>.s):
-L = global load, S = global store, W<n> = s_waitcnt vmcnt(n), B = s_barrier, { / } = loop header label / backward branch.
+L = global load, S = global store, W<n> = s_waitcnt vmcnt(n), M = a run of MFMAs, B = s_barrier, { / } = loop header label /
+backward branch.
 A `W0` right after a `{` or between the `L`s of a loop is the signature of a software pipeline that hipcc collapsed (loads behind
 branches, or a prologue whose load order differs from the loop's): usage: tools/isa_waits.py file.s name-filter"""
 import re
@@ -33,6 +34,9 @@ def main():
             out[cur].append("L")
         elif t.startswith("global_store") or t.startswith("buffer_store"):
             out[cur].append("S")
+        elif t.startswith("v_mfma"):
+            if not out[cur] or out[cur][-1] != "M":
+                out[cur].append("M")   # (a run of matrix instructions, collapsed)
         elif t.startswith("s_barrier"):
             out[cur].append("B")
         elif t.startswith("s_waitcnt"):
