@@ -114,6 +114,95 @@ __global__ __launch_bounds__(256, 4) void k_lepe2d(const LepeArgs a) {
     Io<T>::st4(yp + 4, acc1);
 }
 
+// ---- runs of four tokens (3 x 3, 16-bit tensors, block_len % 4 == 0, 16-byte aligned rows) --------------------------------------
+// Four consecutive tokens of a block row are neighbours in the image and in memory.  A thread that owns 8 channels of such a run
+// reads a 3 x 6 window of rows (18 loads of 16 bytes) and its 9 x 8 weights ONCE for four outputs: 9 load instructions per token
+// where k_lepe2d issues 36 (two 8-byte halves of every tap's row and weights per token) -- the kernels are bound by load issue, not
+// by HBM (57 MB in 26 us at the DiT-XL/2 shape).
+template <typename T> __device__ __forceinline__ void lepe_unpack8(uint4 r, f32x4& a, f32x4& b);
+template <> __device__ __forceinline__ void lepe_unpack8<bf16_t>(uint4 r, f32x4& a, f32x4& b) {
+    a = f32x4{__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u)};
+    b = f32x4{__uint_as_float(r.z << 16), __uint_as_float(r.z & 0xffff0000u), __uint_as_float(r.w << 16), __uint_as_float(r.w & 0xffff0000u)};
+}
+template <> __device__ __forceinline__ void lepe_unpack8<f16_t>(uint4 r, f32x4& a, f32x4& b) {
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    const h8 h = __builtin_bit_cast(h8, r);
+    a = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+    b = f32x4{(float)h[4], (float)h[5], (float)h[6], (float)h[7]};
+}
+// the 3 x 6 window of a run starting at token n0 = (block (py, px), row by, column bx0): packed rows + inside-the-image flags
+template <typename T>
+__device__ __forceinline__ void lepe_window(uint4 (&win)[3][6], bool (&ok)[3][6], const T* __restrict__ xb, long xsn, int n0,
+                                            const LepePos& pos, int pl, int bl) {
+    const int S = bl * bl;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        int py2, by2;
+        const bool oky = lepe_shift(pos.py, pos.by, dy - 1, pl, bl, py2, by2);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            int px2, bx2;
+            ok[dy][j] = lepe_shift(pos.px, pos.bx, j - 1, pl, bl, px2, bx2) && oky;
+            const int nb = ok[dy][j] ? (py2 * pl + px2) * S + by2 * bl + bx2 : n0;   // (outside: the run's first row, selected away)
+            win[dy][j] = gld<uint4>(xb + (long)nb * xsn);
+        }
+    }
+}
+
+// grid (ceil(N / 4 * C / 8 / 256), B); a thread: 8 channels of four consecutive tokens
+template <typename T>
+__global__ __launch_bounds__(256, 2) void k_lepe2d_run4(const LepeArgs a) {
+    const int CG = a.C / 8, N = a.pl * a.pl * a.bl * a.bl;
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (long)(N / 4) * CG) return;
+    const int n0 = (int)(gid / CG) * 4, c = (int)(gid % CG) * 8, b = blockIdx.y;
+    const LepePos pos = lepe_pos(n0, a.pl, a.bl);
+    const T* xb = (const T*)a.x + b * a.xsb + c;
+    uint4 win[3][6];
+    bool ok[3][6];
+    lepe_window<T>(win, ok, xb, a.xsn, n0, pos, a.pl, a.bl);
+    f32x4 w0[9], w1[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int tap = a.flip ? 8 - t : t;
+        w0[t] = *reinterpret_cast<const f32x4*>(a.w + (long)tap * a.C + c);
+        w1[t] = *reinterpret_cast<const f32x4*>(a.w + (long)tap * a.C + c + 4);
+    }
+    f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+    if (a.bias) {
+        b0 = *reinterpret_cast<const f32x4*>(a.bias + c);
+        b1 = *reinterpret_cast<const f32x4*>(a.bias + c + 4);
+    }
+    uint4 addv[4];
+    if (a.add) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) addv[t] = gld<uint4>((const T*)a.add + b * a.asb + (long)(n0 + t) * a.asn + c);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        f32x4 acc0 = b0, acc1 = b1;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                f32x4 x0, x1;
+                lepe_unpack8<T>(win[dy][t + dx], x0, x1);
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};   // (a select, not a multiplication by 0: the filler row may hold inf / NaN)
+                acc0 += (ok[dy][t + dx] ? x0 : z) * w0[dy * 3 + dx];
+                acc1 += (ok[dy][t + dx] ? x1 : z) * w1[dy * 3 + dx];
+            }
+        if (a.add) {
+            f32x4 a0, a1;
+            lepe_unpack8<T>(addv[t], a0, a1);
+            acc0 += a0;
+            acc1 += a1;
+        }
+        T* yp = (T*)a.y + b * a.ysb + (long)(n0 + t) * a.ysn + c;
+        Io<T>::st4(yp, acc0);
+        Io<T>::st4(yp + 4, acc1);
+    }
+}
+
 // Weight / bias gradient: dw[tap][c] = sum_{b, n} dout[b, n, c] x[b, nbr(n, tap), c], db[c] = sum dout[b, n, c].
 // grid (ceil(C / (8 CH)) / 4 rounded up, slices); a wave = 8 channel groups of CH channels x 8 token lanes; each thread walks
 // every 8th token of its slice, the 8 token lanes are summed by shuffles; partials part[slice][K*K + 1][C] (row K*K = bias)
