@@ -147,7 +147,7 @@ static int cs_fwd_impl(mhla_view q, mhla_view k, mhla_view v, const float* mix, 
         }
         // V slices per workgroup: the largest of 4, 3, 2, 1 that divides V / 64 (the fused epilogue owns the head: V / 64 <= 4)
         const int nvs = V / 64, nv = nvs % 4 == 0 ? 4 : nvs % 3 == 0 ? 3 : nvs % 2 == 0 ? 2 : 1;
-#define OUT4(NV, EPI) launch(fast::k_csf_out4<NV, EPI>, dim3(n, B * H, nvs / NV), dim3(fast::NT4), fast::csf_out4_smem<NV, EPI>(), st, EPI ? "k_csf_out4<norm>" : "k_csf_out4", o)
+#define OUT4(NV, EPI) launch(fast::k_csf_out4<NV, EPI>, dim3(EPI ? n : (n + fast::CSF_OUT4_CPW - 1) / fast::CSF_OUT4_CPW, B * H, nvs / NV), dim3(fast::NT4), fast::csf_out4_smem<NV, EPI>(), st, EPI ? "k_csf_out4<norm>" : "k_csf_out4", o)
         if (epi) RC(nvs == 1 ? OUT4(1, true) : nvs == 2 ? OUT4(2, true) : nvs == 3 ? OUT4(3, true) : OUT4(4, true));
         else     RC(nv == 1 ? OUT4(1, false) : nv == 2 ? OUT4(2, false) : nv == 3 ? OUT4(3, false) : OUT4(4, false));
 #undef OUT4

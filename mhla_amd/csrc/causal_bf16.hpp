@@ -972,6 +972,7 @@ __global__ __launch_bounds__(NT4, NK <= 2 ? 4 : 2) void k_csf_bwd_tok4(const CsT
             __syncthreads();
         }
     }
+
 }
 
 // k_csf_out4: k_csf_out on eight waves (16 rows x 32 columns of every 64 x 64 product per wave, as k_csf_bwd_tok4), with the loads
@@ -981,6 +982,10 @@ __global__ __launch_bounds__(NT4, NK <= 2 ? 4 : 2) void k_csf_bwd_tok4(const CsT
 // with the same V slice of the next K slice (behind the last K slice: with the V rows of slice j for the second phase) and
 // multiplies; the Q and K tiles of the next K slice travel during the NV rounds of the current one.
 //   grid (n, bh, V / (64 NV)); NV = V slices per workgroup (template: the j loop carries no runtime guard)
+#ifndef CSF_OUT4_CPW_
+#define CSF_OUT4_CPW_ 4
+#endif
+constexpr int CSF_OUT4_CPW = CSF_OUT4_CPW_;   // chunks per workgroup of k_csf_out4 (plain variant)
 template <int NV, bool EPI>
 __host__ __device__ constexpr int csf_out4_smem() { return 7 * CT * 2 + (EPI ? 2 * 64 * 4 : 0); }
 __device__ __forceinline__ void cs8_store_tok_gate(u16* __restrict__ base, long sn, const u16* __restrict__ gbase, long gsn, long p0,
@@ -1014,29 +1019,47 @@ __global__ __launch_bounds__(NT4, 4) void k_csf_out4(const CsOutArgs a) {
     u16* As = Ps + 2 * CT;                        // m_ii tril(QK^T)
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, n = lane & 15, kg = lane >> 4;
     const int rt = wave & 3, ch = wave >> 2;
-    const int ci = blockIdx.x, bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
+    // A workgroup walks CPW consecutive chunks (the fused-epilogue variant: one): behind a chunk's last K slice the Q / K slots
+    // are refilled with the NEXT chunk's first tiles and, in the second phase, the P slots with its first P tiles -- a chunk's
+    // first loads travel during its predecessor's last rounds instead of being waited for cold (one workgroup per chunk lived 14 us,
+    // a fifth of it in that first wait).
+    constexpr int CPW = EPI ? 1 : CSF_OUT4_CPW;
+    const int c0 = blockIdx.x * CPW, c1 = min(a.n, c0 + CPW), bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
     const int vbase = blockIdx.z * 64 * NV;
-    const long p0 = (long)ci * CS;
-    const int rv = (int)min((long)CS, a.T - p0);
     const int V = a.V, nks = a.K / 64;
     const u16* qb = (const u16*)a.q.ptr + b * a.q.sb + h * a.q.sh;
     const u16* kb = (const u16*)a.k.ptr + b * a.k.sb + h * a.k.sh;
     const u16* vb = (const u16*)a.v.ptr + b * a.v.sb + h * a.v.sh + vbase;
     u16* ob = (u16*)a.o.ptr + b * a.o.sb + h * a.o.sh + vbase;
-    const u16* Pb = reinterpret_cast<const u16*>(a.P) + ((long)bh * a.n + ci) * a.K * V;
+    const long KV = (long)a.K * V;
     const int tr = tid >> 3, tc = (tid & 7) * 8;
-    const long trow = p0 + (tr < rv ? tr : 0);   // the thread's token row (rows past the sequence: the chunk's first row, zeroed on commit)
+    // the thread's token row in chunk c (rows past the sequence: the chunk's first row, zeroed on commit)
+    auto row_of = [&](int c) { const long p = (long)c * CS; return p + (tr < (int)min((long)CS, a.T - p) ? tr : 0); };
 
     // The order of these loads must be the order in which the loop re-issues them (Q, K, P slices): hipcc counts the loads in
     // flight per register and, where the entry and the back edge of the loop disagree, waits for the younger position -- with the
     // Q / K loads sunk into the loop's preheader behind the P loads it waited for everything at the top of every K slice.
     uint4 rQ, rK, rP[NV];
-    cs8_issue_tok(rQ, qb, a.q.sn, p0, rv, tid);
-    cs8_issue_tok(rK, kb, a.k.sn, p0, rv, tid);
-    __builtin_amdgcn_sched_barrier(0);
+    {
+        const long trow0 = row_of(c0);
+        rQ = gld<uint4>(qb + trow0 * a.q.sn + tc);
+        rK = gld<uint4>(kb + trow0 * a.k.sn + tc);
+        __builtin_amdgcn_sched_barrier(0);
+        const u16* Pb0 = reinterpret_cast<const u16*>(a.P) + ((long)bh * a.n + c0) * KV;
 #pragma unroll
-    for (int j = 0; j < NV; ++j) cs8_issue_state(rP[j], Pb + cs_tile_off(0, vbase + 64 * j, V), tid);
-    __builtin_amdgcn_sched_barrier(0);
+        for (int j = 0; j < NV; ++j) cs8_issue_state(rP[j], Pb0 + cs_tile_off(0, vbase + 64 * j, V), tid);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    for (int ci = c0; ci < c1; ++ci) {
+    const long p0 = (long)ci * CS;
+    const int rv = (int)min((long)CS, a.T - p0);
+    const u16* Pb = reinterpret_cast<const u16*>(a.P) + ((long)bh * a.n + ci) * KV;
+    const long trow = row_of(ci);
+    const int cn = ci + 1 < c1 ? ci + 1 : ci;   // next chunk (behind the last one: this chunk again -- hot lines, never used)
+    const long trown = row_of(cn);
+    const u16* Pbn = reinterpret_cast<const u16*>(a.P) + ((long)bh * a.n + cn) * KV;
+    if (ci > c0) __syncthreads();   // the previous chunk's staging tiles are dead
+    const float mii = gld<float>(a.mix + (long)ci * a.ldmix + ci);   // (requested here: a wait for it later would drain the ring)
     f32x4 accO[NV][2], accA[2];
 #pragma unroll
     for (int j = 0; j < NV; ++j) zero2(accO[j]);
@@ -1057,9 +1080,11 @@ __global__ __launch_bounds__(NT4, 4) void k_csf_out4(const CsOutArgs a) {
             }
             cs8_commit_state(Pc, rP[j], tid);
             __syncthreads();
-            if (j == 0) {   // (behind the last K slice: the same tiles again, never used)
-                cs8_issue_tok(rQ, qb + kn * 64, a.q.sn, p0, rv, tid);
-                cs8_issue_tok(rK, kb + kn * 64, a.k.sn, p0, rv, tid);
+            if (j == 0) {   // the next K slice's tiles -- behind the last K slice: the next chunk's first
+                const long rown = lastk ? trown : trow;
+                const int coln = lastk ? 0 : kn * 64;
+                rQ = gld<uint4>(qb + rown * a.q.sn + coln + tc);
+                rK = gld<uint4>(kb + rown * a.k.sn + coln + tc);
             }
             {
                 const u16* psrc = Pb + cs_tile_off(kn * 64, vbase + 64 * j, V) + tid * 8;
@@ -1073,7 +1098,6 @@ __global__ __launch_bounds__(NT4, 4) void k_csf_out4(const CsOutArgs a) {
             tile_mma8r<true>(accO[j], aQ, Pc, ch, lane);     // Q P
         }
     } while (++ki < nks);
-    const float mii = a.mix[(long)ci * a.ldmix + ci];
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
@@ -1089,6 +1113,7 @@ __global__ __launch_bounds__(NT4, 4) void k_csf_out4(const CsOutArgs a) {
             u16* Oc = Qs + (j & 1) * CT;
             cs8_commit_tok(Vc, rP[j], rv, tid);
             __syncthreads();
+            cs8_issue_state(rP[j], Pbn + cs_tile_off(0, vbase + 64 * j, V), tid);   // the next chunk's first P tiles
             tile_mma8<false, true>(accO[j], As, Vc, rt, ch, lane);        // tril(QK^T) V
             cs8_put(Oc, accO[j], a.scale, rt, ch, lane);
             __syncthreads();
@@ -1148,6 +1173,7 @@ __global__ __launch_bounds__(NT4, 4) void k_csf_out4(const CsOutArgs a) {
             cs8_store_tok_gate(yb + 64 * j, a.y.sn, gb ? gb + 64 * j : nullptr, a.gate.sn, p0, rv, Yc, tid);
         }
     }
+    }   // chunks of the workgroup
 }
 
 // -------------------------------------------------------------------------------------------------
