@@ -173,10 +173,11 @@ def test_wan_modes(M, S, D, normalize, split):
 @pytest.mark.parametrize("M,S,D,split", [(150, 21, 128, True), (70, 50, 64, False), (9, 210, 128, True), (3, 33, 64, True),
                                           (65, 16, 128, False), (16, 64, 72, False), (5, 37, 80, True), (7, 20, 96, False),
                                           (4, 50, 40, True), (3, 19, 8, False), (6, 45, 104, True), (5, 23, 24, True), (4, 31, 56, False),
-                                          (3, 40, 88, True), (2, 33, 120, False)])
+                                          (3, 40, 88, True), (2, 33, 120, False), (40, 24, 64, False), (200, 8, 64, True)])
 def test_split_operand_path(M, S, D, split, dtype):
     """Head dims that are multiples of 8, outside the bf16 fast paths: forward and backward on the split-bf16 MFMA
-    kernels (split.hpp), including the zero-padded tile shapes (D = 72, 80, 104 ...)."""
+    kernels (split.hpp), including the zero-padded tile shapes (D = 72, 80, 104 ...).  33 .. 256 blocks run the resident-sequence
+    mixing kernel: M = 40, 65 / 70, 150, 200 instantiate its 4-, 8-, 12- and 16-wave variants (fp32 and bf16 summaries)."""
     run_case(1, 2, M, S, D, dtype, split=split, w="rand", seed=M + S)
 
 
