@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MHLA_ABI_VERSION 6
+#define MHLA_ABI_VERSION 7
 
 enum { MHLA_F32 = 0, MHLA_BF16 = 1, MHLA_F16 = 2 };
 
@@ -49,6 +49,13 @@ enum {
 #define MHLA_FLAG_RELU_EPS 1u      /* apply relu(x)+eps to q,k while loading (mhla_dit/mhla/mhla.py:229-230) */
 #define MHLA_FLAG_FORCE_GENERIC 2u /* testing aid: take the generic fp32-MFMA path even where the bf16 fast path applies */
 #define MHLA_FLAG_NO_SMALLN 4u     /* testing aid: skip the single-launch small-sequence path (S = 16, N <= 256) */
+
+/* flags of the causal entry points (mhla_causal_*) */
+#define MHLA_CAUSAL_FORCE_GENERIC 1u   /* testing aid: the generic kernels (exact fp32 MFMA, fp32 summaries) for every shape */
+#define MHLA_CAUSAL_BF16_SUMMARIES 2u  /* REDUCED PRECISION, opt-in: chunk summaries S, P, dP, dS and the score tiles as single
+                                        * bf16 values (half the summary traffic; 2-3e-3 of the result's maximum).  Default: bf16
+                                        * hi + lo pairs, >= 16 significand bits wherever the reference holds fp32
+                                        * (mhla_nlp/fla/ops/mhla/naive.py:39, :60-78). */
 
 /* A token-major view [B, N, H, D]: element strides, D contiguous. */
 typedef struct {
@@ -182,9 +189,11 @@ int mhla_blockmix_bwd_status(const void* ws, size_t ws_bytes, int B, int H, int 
 
 /* ---- causal chunk-mixing MHLA: fla ------------------------------------- */
 
-/* Workspace bytes (the chunk summaries are bf16 for bf16 tensors with K and V multiples of 64, fp32 otherwise). */
-size_t mhla_causal_fwd_ws_bytes(int B, int T, int H, int K, int V, int chunk, int dtype);
-size_t mhla_causal_bwd_ws_bytes(int B, int T, int H, int K, int V, int chunk, int dtype);
+/* Workspace bytes.  bf16 tensors with K, V multiples of 64, K <= 256 and at most 128 chunks run the 16-bit-MFMA pipeline,
+ * whose chunk summaries are bf16 hi + lo pairs (4 bytes per element; 2 with MHLA_CAUSAL_BF16_SUMMARIES); everything else the
+ * generic kernels with fp32 summaries.  `flags` must be the flags of the calls the workspace is for. */
+size_t mhla_causal_fwd_ws_bytes(int B, int T, int H, int K, int V, int chunk, int dtype, unsigned flags);
+size_t mhla_causal_bwd_ws_bytes(int B, int T, int H, int K, int V, int chunk, int dtype, unsigned flags);
 
 /*
  * Forward.  Replaces naive_chunk_simple_mhla_fixed
@@ -194,33 +203,38 @@ size_t mhla_causal_bwd_ws_bytes(int B, int T, int H, int K, int V, int chunk, in
  *   O_i = Q_i (sum_{j<i} mix[i,j] S_j) + mix[i,i] tril(Q_i K_i^T) V_i.
  * q,k: [B,T,H,K]  v,out: [B,T,H,V]  mix: fp32 [n.., n..] row stride ldmix,
  * n = ceil(T/chunk) rows/cols are read.  chunk must be 64.
+ * Arithmetic: every product accumulates in fp32 and every intermediate that the reference keeps in fp32 (naive.py:39,
+ * :60-78: S_j, the prefix mix, tril(Q K^T)) keeps >= 16 significand bits (exact fp32 MFMA on the generic path, bf16 hi + lo
+ * pairs on the 16-bit pipeline); one rounding to the tensor dtype at the store (naive.py:82).
  */
 int mhla_causal_fwd(mhla_view q, mhla_view k, mhla_view v, const float* mix, int ldmix,
                     mhla_mview out, void* ws, size_t ws_bytes,
                     int B, int T, int H, int K, int V, int chunk,
-                    float scale, int dtype, void* stream);
+                    float scale, int dtype, unsigned flags, void* stream);
 
 /* N1: the causal operator with the fla layer's epilogue fused into its store --
  *   y = o * rsqrt(mean(o^2 over V) + norm_eps) * norm_w * gate * sigmoid(gate)
  * i.e. FusedRMSNormGated over each head's V channels (mhla_nlp/fla/layers/mhla.py:351-355; kernel math
  * mhla_nlp/fla/modules/fused_norm_gate.py:77-99).  `out` (the operator's own output o) is optional: a NULL ptr skips its
  * store (inference); training passes it so that the norm's backward (mhla_rmsnorm_gate_bwd) has its input.  `gate` ptr NULL:
- * no gate; `norm_w` NULL: no affine weight.  bf16 tensors, K % 64 == 0, V % 64 == 0, V <= 256 (one workgroup owns a head's
- * channels); otherwise MHLA_ENOTSUP and the caller runs mhla_causal_fwd + mhla_rmsnorm_gate_fwd.  Workspace: as
- * mhla_causal_fwd (usable as `fwd_ws` of mhla_causal_bwd). */
+ * no gate; `norm_w` NULL: no affine weight.  Covers what mhla_causal_normgate_fusable() reports (bf16 tensors, K % 64 == 0,
+ * K <= 256, V % 64 == 0, V <= 256 -- one workgroup owns a head's channels --, at most 128 chunks); otherwise MHLA_ENOTSUP and
+ * the caller runs mhla_causal_fwd + mhla_rmsnorm_gate_fwd.  Workspace: as mhla_causal_fwd (usable as `fwd_ws` of
+ * mhla_causal_bwd with the same flags). */
+int mhla_causal_normgate_fusable(int T, int K, int V, int chunk, int dtype, unsigned flags);
 int mhla_causal_normgate_fwd(mhla_view q, mhla_view k, mhla_view v, const float* mix, int ldmix, mhla_mview out, mhla_view gate,
                              const float* norm_w, float norm_eps, mhla_mview y, void* ws, size_t ws_bytes, int B, int T, int H,
-                             int K, int V, int chunk, float scale, int dtype, void* stream);
+                             int K, int V, int chunk, float scale, int dtype, unsigned flags, void* stream);
 
-/* Backward.  dmix is [n, n] fp32 with row stride lddmix;
+/* Backward (autograd of naive.py:39-82).  dmix is [n, n] fp32 with row stride lddmix;
  * every entry of the leading n x n is written (zeros above the diagonal).
- * fwd_ws: the workspace mhla_causal_fwd was given for the same arguments, contents untouched
+ * fwd_ws: the workspace mhla_causal_fwd was given for the same arguments and flags, contents untouched
  * (its chunk summaries S_j and the prefix mixes are reused), or NULL to recompute them. */
 int mhla_causal_bwd(mhla_view q, mhla_view k, mhla_view v, const float* mix, int ldmix,
                     mhla_view dout, mhla_mview dq, mhla_mview dk, mhla_mview dv,
                     float* dmix, int lddmix, void* ws, size_t ws_bytes, const void* fwd_ws,
                     int B, int T, int H, int K, int V, int chunk,
-                    float scale, int dtype, void* stream);
+                    float scale, int dtype, unsigned flags, void* stream);
 
 /* ---- prologue: q / k of the Wan host -------------------------------------- */
 

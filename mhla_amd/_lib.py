@@ -8,11 +8,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # MHLA_LIB_PATH: A/B comparison of two builds of the same library (tools); the default is the in-tree build
 LIB_PATH = os.environ.get("MHLA_LIB_PATH") or os.path.join(_HERE, "lib", "libmhla_hip.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 F32, BF16, F16 = 0, 1, 2
 FLAG_RELU_EPS = 1
 FLAG_FORCE_GENERIC = 2
 FLAG_NO_SMALLN = 4
+CAUSAL_FORCE_GENERIC = 1
+CAUSAL_BF16_SUMMARIES = 2
 
 
 class View(Structure):
@@ -48,14 +50,15 @@ SIGNATURES = {
                                        View, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                        c_int, c_float, c_uint, c_void_p]),
     "mhla_blockmix_bwd_status": (c_int, [c_void_p, c_size_t] + [c_int] * 7 + [c_uint, c_void_p]),
-    "mhla_causal_fwd_ws_bytes": (c_size_t, [c_int] * 7),
-    "mhla_causal_bwd_ws_bytes": (c_size_t, [c_int] * 7),
+    "mhla_causal_fwd_ws_bytes": (c_size_t, [c_int] * 7 + [c_uint]),
+    "mhla_causal_bwd_ws_bytes": (c_size_t, [c_int] * 7 + [c_uint]),
+    "mhla_causal_normgate_fusable": (c_int, [c_int] * 5 + [c_uint]),
     "mhla_causal_fwd": (c_int, [View, View, View, c_void_p, c_int, View, c_void_p, c_size_t, c_int, c_int, c_int,
-                                c_int, c_int, c_int, c_float, c_int, c_void_p]),
+                                c_int, c_int, c_int, c_float, c_int, c_uint, c_void_p]),
     "mhla_causal_normgate_fwd": (c_int, [View, View, View, c_void_p, c_int, View, View, c_void_p, c_float, View, c_void_p,
-                                         c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
+                                         c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_uint, c_void_p]),
     "mhla_causal_bwd": (c_int, [View, View, View, c_void_p, c_int, View, View, View, View, c_void_p, c_int, c_void_p,
-                                c_size_t, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
+                                c_size_t, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_uint, c_void_p]),
     "mhla_featmap_rotary": (c_int, [View, View, c_void_p, c_void_p, c_int64, c_int64, View, c_int, c_int, c_int, c_int, c_int,
                                     c_int, c_int, c_void_p]),
     "mhla_lepe2d": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64,

@@ -150,10 +150,6 @@ inline bool view_ok16(const mhla_view& v) { return v.ptr && ((uintptr_t)v.ptr % 
 // split-bf16 MFMA kernels (split.hpp): head dims that are multiples of 8, any dtype
 inline bool sp_shape_ok(int D, unsigned flags) { return (D & 7) == 0 && !(flags & MHLA_FLAG_FORCE_GENERIC); }
 inline bool view_ok16m(const mhla_mview& v) { return v.ptr && ((uintptr_t)v.ptr % 16) == 0 && ((v.sb | v.sn | v.sh) & 7) == 0; }
-// bf16-MFMA token kernels of the causal operator (causal_bf16.hpp)
-// MHLA_CAUSAL_GENERIC is a testing aid that the parity tests flip inside one process (bf16 pipeline vs generic kernels on the
-// same inputs), so it is looked up per call: one scan of the environment per operator call, beside five or more launches
-inline bool cs_bf16_ok(int K, int V, int dtype) { return dtype == MHLA_BF16 && (K & 63) == 0 && (V & 63) == 0 && !getenv("MHLA_CAUSAL_GENERIC"); }
 inline bool bm_sum16(int D, int dtype, unsigned flags) { return dtype == MHLA_BF16 && sp_shape_ok(D, flags); }
 inline bool fast_shape_ok(int M, int D, int dtype, bool split) { return dtype == MHLA_BF16 && D == 64 && M <= 64 && !split; }
 // small-sequence single-launch path (smalln.hpp): S = 16 tokens per block, at most 16 blocks, D <= 80

@@ -4,13 +4,15 @@
 //   backward k_csf_mixb:  dS_j[e] = sum_{i > j} m_ij dP_i[e]   and, from the same two tiles,
 //                         dmix_ij = sum_e dP_i[e] S_j[e]  (j < i)                   (autograd of naive.py:73-78)
 //
-// The summaries are [bh][n][E] (E = K V elements per chunk, bf16).  A workgroup owns slices of MF_TE = 256 elements: the slice's
-// rows of ALL chunks (n x 512 B) sit in LDS, so every summary byte is read from HBM exactly once per direction -- k_csf_mix read
-// a slice's rows once per 64-chunk output tile (1.5x at n = 128) and k_csf_dw read dP and S again for dmix (403 MB at C5).
-// One wave per 16 output chunks; the mixing weights of its chunks live in its registers as bf16 hi + lo (two MFMAs, ~16 mantissa
-// bits) for the whole launch; the summaries enter the MFMA through the hardware transpose read as the A operand, so a lane ends
-// up with four consecutive elements of one output chunk (8-byte staging writes, 512-byte rows out).  A workgroup walks `spw`
-// consecutive slices with the next slice's rows in flight in registers while the current one is multiplied and stored.
+// The summaries are [bh][n][tiles][planes][4096] bf16 (causal_bf16.hpp; planes = hi, lo with HL; E = K V logical elements per
+// chunk).  A workgroup owns slices of TE logical elements: the slice's rows of ALL chunks (n x planes x 2 TE bytes) sit in LDS,
+// so every summary byte is read from HBM exactly once per direction.  One wave per 16 output chunks; the mixing weights of its
+// chunks live in its registers as bf16 hi + lo for the whole launch; the summaries enter the MFMA through the hardware
+// transpose read as the A operand, so a lane ends up with four consecutive elements of one output chunk (8-byte staging
+// writes, full rows out).  HL: x = hi + lo on both sides -- m_hi x_hi + m_lo x_hi + m_hi x_lo, fp32 accumulation, and the
+// result is split into hi + lo again on its way out (>= 16 significand bits end to end, as the reference's fp32 loop keeps).
+// A workgroup walks `spw` consecutive slices with the next slice's rows in flight in registers while the current one is
+// multiplied and stored.
 // dmix: the 16 x 16 tiles on and below the diagonal are dealt round-robin to the waves and accumulated over all slices of the
 // workgroup -- one [n][n] partial per workgroup, summed in a fixed order by k_dw_reduce<1> (deterministic, no atomics).
 #pragma once
@@ -19,7 +21,8 @@
 namespace mhla {
 namespace fast {
 
-constexpr int MF_TE = 128;   // smallest slice (the divisibility the dispatcher checks)
+template <bool HL> __host__ __device__ constexpr int mix_te_fwd() { return HL ? 64 : 128; }
+template <bool HL> __host__ __device__ constexpr int mix_te_bwd() { return HL ? 64 : 128; }
 
 struct CsfMix2Args {
     const float* W;     // mixing matrix [n][ldw]
@@ -29,64 +32,65 @@ struct CsfMix2Args {
     u16* out;           // forward: P        backward: dS
     float* dwp;         // backward: [gridDim.x][n][n] partials of dmix
     int n;
-    long E;             // elements per chunk summary (multiple of MF_TE)
-    long total;         // slices = bh * E / MF_TE
+    long E;             // logical elements per chunk summary (a multiple of 4096)
+    long total;         // slices = bh * E / TE
     int spw;            // slices per workgroup
 };
 
-template <int NW, int TE> __host__ __device__ constexpr int mixf_smem() { return 2 * 16 * NW * (TE + 8) * 2; }
-
-// rows of one slice: TE / 32 passes of (512 NW / TE rows x 2 TE bytes); a thread moves 16 bytes per pass.  The thread's byte
-// offsets inside a (b,h)'s summaries do not depend on the slice: computed once, 32 bits each, added to a wave-uniform base
-// (global_load with an SGPR base: no 64-bit address registers per load).
-template <int NW, int TE>
+// Rows of one slice: every row is PPR = planes TE / 8 pieces of 16 bytes (the hi pieces, then the lo pieces, 8 KB apart in
+// memory); NTHR threads move ROWS rows in ROWS PPR / NTHR passes.  The thread's byte offsets inside a (b,h)'s summaries do not
+// depend on the slice: computed once, 32 bits each, added to a wave-uniform base.
+template <int NTHR, int ROWS, int TE, bool HL>
 struct MixRows {
-    static constexpr int NP = TE / 32, TPR = TE / 8, RPP = 64 * NW / TPR, MF_LD = TE + 8;
+    static constexpr int P = HL ? 2 : 1, PPP = TE / 8, PPR = P * PPP, RPP = NTHR / PPR, NP = ROWS / RPP, MF_LD = TE + 8;
+    static_assert(NTHR % PPR == 0 && ROWS % RPP == 0, "row mover: threads must tile the rows");
     uint4 v[NP];
-    __device__ __forceinline__ void issue(const u16* __restrict__ base, const unsigned (&goff)[NP]) {
+    unsigned goff[NP];
+    __device__ __forceinline__ void offsets(long CSZ, int n, int tid) {   // CSZ: u16 elements per chunk summary
+        const int r0 = tid / PPR, q = tid % PPR, pl = q / PPP, c = (q % PPP) * 8;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int row = p * RPP + r0;   // rows past the last chunk read the last chunk's row: a valid address
+            goff[p] = (unsigned)(((long)(row < n ? row : n - 1) * CSZ + pl * CTE + c) * 2);
+        }
+    }
+    __device__ __forceinline__ void issue(const u16* __restrict__ base) {
 #pragma unroll
         for (int p = 0; p < NP; ++p) v[p] = gld_stream16(reinterpret_cast<const char*>(base) + goff[p]);
     }
-    __device__ __forceinline__ void commit(u16* __restrict__ tile, int n, int tid) const {
-        const int r0 = tid / TPR, c = (tid % TPR) * 8;
+    // tiles: [P][ROWS][MF_LD]
+    __device__ __forceinline__ void commit(u16* __restrict__ tiles, int n, int tid) const {
+        const int r0 = tid / PPR, q = tid % PPR, pl = q / PPP, c = (q % PPP) * 8;
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             const int row = p * RPP + r0;
             const bool ok = row < n;   // rows past the last chunk: zeros (their weights are zero too, but 0 x NaN is not)
-            *reinterpret_cast<uint4*>(tile + row * MF_LD + c) = make_uint4(ok ? v[p].x : 0u, ok ? v[p].y : 0u, ok ? v[p].z : 0u, ok ? v[p].w : 0u);
+            *reinterpret_cast<uint4*>(tiles + (pl * ROWS + row) * MF_LD + c) = make_uint4(ok ? v[p].x : 0u, ok ? v[p].y : 0u, ok ? v[p].z : 0u, ok ? v[p].w : 0u);
+        }
+    }
+    __device__ __forceinline__ void store(u16* __restrict__ base, int n, const u16* __restrict__ tiles, int tid) const {
+        const int r0 = tid / PPR, q = tid % PPR, pl = q / PPP, c = (q % PPP) * 8;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int row = p * RPP + r0;
+            if (row < n) gst<uint4>(reinterpret_cast<char*>(base) + goff[p], *reinterpret_cast<const uint4*>(tiles + (pl * ROWS + row) * MF_LD + c));
         }
     }
 };
-// byte offsets of the thread's pieces (rows past the last chunk read the last chunk's row: a valid address)
-template <int NW, int TE>
-__device__ __forceinline__ void mix_row_offsets(unsigned (&goff)[TE / 32], long E, int n, int tid) {
-    constexpr int NP = TE / 32, TPR = TE / 8, RPP = 64 * NW / TPR;
-    const int r0 = tid / TPR, c = (tid % TPR) * 8;
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-        const int row = p * RPP + r0;
-        goff[p] = (unsigned)(((long)(row < n ? row : n - 1) * E + c) * 2);
-    }
+// offset (u16 elements) of slice s inside the summaries: (b,h) s / nsl, logical elements (s % nsl) TE ..
+template <int TE, bool HL>
+__device__ __forceinline__ long mix_slice_off(long s, long nsl, int n, long CSZ) {
+    const long bh = s / nsl, e0 = (s - bh * nsl) * TE;
+    return bh * n * CSZ + (e0 / CTE) * (CTE * (HL ? 2 : 1)) + (e0 % CTE);
 }
-template <int NW, int TE>
-__device__ __forceinline__ void mix_store_rows(u16* __restrict__ base, const unsigned (&goff)[TE / 32], int n, const u16* __restrict__ tile, int tid) {
-    constexpr int NP = TE / 32, TPR = TE / 8, RPP = 64 * NW / TPR, MF_LD = TE + 8;
-    const int r0 = tid / TPR, c = (tid % TPR) * 8;
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-        const int row = p * RPP + r0;
-        if (row < n) gst<uint4>(reinterpret_cast<char*>(base) + goff[p], *reinterpret_cast<const uint4*>(tile + row * MF_LD + c));
-    }
-}
-// transposed-product accumulators (lane: elements 16 t + 4 kg .. + 3 of chunk 16 wave + nl) -> staging tile [chunk][element]
-template <int TE>
-__device__ __forceinline__ void mix_stage(u16* __restrict__ tile, const f32x4 (&acc)[TE / 16], int wave, int lane) {
-    constexpr int MF_LD = TE + 8;
-    const int nl = lane & 15, kg = lane >> 4;
-#pragma unroll
-    for (int t = 0; t < TE / 16; ++t)
-        *reinterpret_cast<uint2*>(tile + (wave * 16 + nl) * MF_LD + t * 16 + kg * 4) =
-            make_uint2(pack_bf16x2(acc[t][0], acc[t][1]), pack_bf16x2(acc[t][2], acc[t][3]));
+// transposed-product accumulators (lane: elements 16 t + 4 kg .. + 3 of chunk row0 + nl) -> staging tiles [P][ROWS][MF_LD]
+template <int TE, int ROWS, bool HL>
+__device__ __forceinline__ void mix_stage4(u16* __restrict__ tiles, const f32x4& acc, int row, int col) {
+    unsigned h0, h1, l0, l1;
+    split_pack2(acc[0], acc[1], h0, l0);
+    split_pack2(acc[2], acc[3], h1, l1);
+    *reinterpret_cast<uint2*>(tiles + row * (TE + 8) + col) = make_uint2(h0, h1);
+    if constexpr (HL) *reinterpret_cast<uint2*>(tiles + (ROWS + row) * (TE + 8) + col) = make_uint2(l0, l1);
 }
 __device__ __forceinline__ void mix_split(const float (&w)[8], bf16x8& hi, bf16x8& lo) {
 #pragma unroll
@@ -97,16 +101,18 @@ __device__ __forceinline__ void mix_split(const float (&w)[8], bf16x8& hi, bf16x
     }
 }
 
+template <int NW, bool HL> __host__ __device__ constexpr int mixf_smem() { return 2 * (HL ? 2 : 1) * 16 * NW * (mix_te_fwd<HL>() + 8) * 2; }
+
 // NW waves = 16 NW chunk rows (n <= 16 NW); NK = reduction steps of 32 chunks
-template <int NW, int TE>
-__global__ __launch_bounds__(64 * NW, TE == 128 ? 4 : 2) void k_csf_mixf(const CsfMix2Args a) {
-    constexpr int NK = (NW + 1) / 2, MF_LD = TE + 8, NT = TE / 16;
+template <int NW, bool HL>
+__global__ __launch_bounds__(64 * NW, 4) void k_csf_mixf(const CsfMix2Args a) {
+    constexpr int TE = mix_te_fwd<HL>(), P = HL ? 2 : 1, NK = (NW + 1) / 2, MF_LD = TE + 8, NT = TE / 16, ROWS = 16 * NW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    u16* Ts = reinterpret_cast<u16*>(smem_raw);
-    u16* Os = Ts + 16 * NW * MF_LD;
+    u16* Ts = reinterpret_cast<u16*>(smem_raw);   // [P][ROWS][MF_LD]
+    u16* Os = Ts + P * ROWS * MF_LD;              // [P][ROWS][MF_LD]
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nl = lane & 15, kg = lane >> 4;
     const int n = a.n;
-    const long nsl = a.E / TE;
+    const long nsl = a.E / TE, CSZ = a.E * P + CS_CHUNK_PAD;
     const long s0 = (long)blockIdx.x * a.spw;
     const int cnt = (int)min((long)a.spw, a.total - s0);
     if (cnt <= 0) return;
@@ -125,17 +131,15 @@ __global__ __launch_bounds__(64 * NW, TE == 128 ? 4 : 2) void k_csf_mixf(const C
         }
         mix_split(w, wh[ks], wl[ks]);
     }
-    auto slice_off = [&](long s) { const long bh = s / nsl, es = s - bh * nsl; return bh * n * a.E + es * TE; };
-    unsigned goff[TE / 32];
-    mix_row_offsets<NW, TE>(goff, a.E, n, tid);
-    MixRows<NW, TE> pre;
-    pre.issue(a.in + slice_off(s0), goff);
+    MixRows<64 * NW, ROWS, TE, HL> pre;
+    pre.offsets(CSZ, n, tid);
+    pre.issue(a.in + mix_slice_off<TE, HL>(s0, nsl, n, CSZ));
     const int kmax = min(wave / 2, (n - 1) / 32);   // last reduction step with a chunk j < i for this wave's rows
     for (int it = 0; it < cnt; ++it) {
-        const long off = slice_off(s0 + it);
+        const long off = mix_slice_off<TE, HL>(s0 + it, nsl, n, CSZ);
         pre.commit(Ts, n, tid);
         __syncthreads();
-        if (it + 1 < cnt) pre.issue(a.in + slice_off(s0 + it + 1), goff);
+        if (it + 1 < cnt) pre.issue(a.in + mix_slice_off<TE, HL>(s0 + it + 1, nsl, n, CSZ));
         f32x4 acc[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -144,19 +148,28 @@ __global__ __launch_bounds__(64 * NW, TE == 128 ? 4 : 2) void k_csf_mixf(const C
             if (ks <= kmax) {
 #pragma unroll
                 for (int t4 = 0; t4 < NT; t4 += 4) {
-                    bf16x8 sv[4];
+                    bf16x8 sv[4], sl[4];
 #pragma unroll
                     for (int t = 0; t < 4; ++t) sv[t] = tr_read8(Ts, MF_LD, ks * 32, (t4 + t) * 16, lane);
+                    if constexpr (HL) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) sl[t] = tr_read8(Ts + ROWS * MF_LD, MF_LD, ks * 32, (t4 + t) * 16, lane);
+                    }
 #pragma unroll
                     for (int t = 0; t < 4; ++t) acc[t4 + t] = mfma_bf16(sv[t], wh[ks], acc[t4 + t]);
 #pragma unroll
                     for (int t = 0; t < 4; ++t) acc[t4 + t] = mfma_bf16(sv[t], wl[ks], acc[t4 + t]);
+                    if constexpr (HL) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) acc[t4 + t] = mfma_bf16(sl[t], wh[ks], acc[t4 + t]);
+                    }
                 }
             }
         }
-        mix_stage<TE>(Os, acc, wave, lane);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) mix_stage4<TE, ROWS, HL>(Os, acc[t], wave * 16 + nl, t * 16 + kg * 4);
         __syncthreads();
-        mix_store_rows<NW, TE>(a.out + off, goff, n, Os, tid);
+        pre.store(a.out + off, n, Os, tid);
     }
 }
 
@@ -170,59 +183,32 @@ __device__ __forceinline__ void tri_tile(int idx, int& it, int& jt) {
 // Backward: 2 NW waves.  Waves [0, NW) form dS for their 16 chunks j (as the forward does for P); waves [NW, 2 NW) accumulate
 // the dmix tiles -- two roles on disjoint register budgets (the one-role version needed ~150 VGPRs and spilled at the 128 that
 // four waves per SIMD leave), multiplying side by side between the same two barriers.  Every thread helps moving the rows.
-template <int NW> __host__ __device__ constexpr int mixb_smem() { return 3 * 16 * NW * (128 + 8) * 2; }
+template <int NW, bool HL> __host__ __device__ constexpr int mixb_smem() { return 3 * (HL ? 2 : 1) * 16 * NW * (mix_te_bwd<HL>() + 8) * 2; }
 
-template <int NW>
+template <int NW, bool HL>
 __global__ __launch_bounds__(128 * NW) void k_csf_mixb(const CsfMix2Args a) {
-    constexpr int TE = 128, NK = (NW + 1) / 2, MF_LD = TE + 8, NT = TE / 16, NWT = 2 * NW;   // NWT: waves that move rows
+    constexpr int TE = mix_te_bwd<HL>(), P = HL ? 2 : 1, NK = (NW + 1) / 2, MF_LD = TE + 8, NT = TE / 16, ROWS = 16 * NW;
     constexpr int NTL = NW * (NW + 1) / 2, TPW = (NTL + NW - 1) / NW;   // dmix tiles, tiles per wave
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    u16* Tp = reinterpret_cast<u16*>(smem_raw);   // dP rows of the slice
-    u16* Tq = Tp + 16 * NW * MF_LD;                // S rows of the slice
-    u16* Os = Tq + 16 * NW * MF_LD;                // dS staging
+    u16* Tp = reinterpret_cast<u16*>(smem_raw);   // [P][ROWS][MF_LD] dP rows of the slice
+    u16* Tq = Tp + P * ROWS * MF_LD;               // S rows of the slice
+    u16* Os = Tq + P * ROWS * MF_LD;               // dS staging
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nl = lane & 15, kg = lane >> 4;
     const bool mixer = wave < NW;                  // (uniform) dS role; the others: dmix role
     const int rw = mixer ? wave : wave - NW;
     const int n = a.n;
-    const long nsl = a.E / TE;
+    const long nsl = a.E / TE, CSZ = a.E * P + CS_CHUNK_PAD;
     const long s0 = (long)blockIdx.x * a.spw;
     const int cnt = (int)min((long)a.spw, a.total - s0);
     float* part = a.dwp + (long)blockIdx.x * n * n;
-    auto slice_off = [&](long s) { const long bh = s / nsl, es = s - bh * nsl; return bh * n * a.E + es * TE; };
-    unsigned goff[TE / 32 / 2];
-    {   // 2 NW waves move the 16 NW rows: TE / 64 passes
-        constexpr int TPR = TE / 8, RPP = 64 * NWT / TPR;
-        const int r0 = tid / TPR, c = (tid % TPR) * 8;
+    MixRows<128 * NW, ROWS, TE, HL> pp, pq;
+    pp.offsets(CSZ, n, tid);
 #pragma unroll
-        for (int p = 0; p < TE / 64; ++p) {
-            const int row = p * RPP + r0;
-            goff[p] = (unsigned)(((long)(row < n ? row : n - 1) * a.E + c) * 2);
-        }
-    }
-    MixRows<NWT, TE / 2> pp, pq;   // (the struct only sees passes x threads: TE / 64 passes of 64 NWT threads)
+    for (int p = 0; p < pp.NP; ++p) pq.goff[p] = pp.goff[p];
     if (cnt > 0) {
-        pp.issue(a.in + slice_off(s0), goff);
-        pq.issue(a.in2 + slice_off(s0), goff);
+        pp.issue(a.in + mix_slice_off<TE, HL>(s0, nsl, n, CSZ));
+        pq.issue(a.in2 + mix_slice_off<TE, HL>(s0, nsl, n, CSZ));
     }
-    auto commit = [&](u16* tile, const MixRows<NWT, TE / 2>& r) {
-        constexpr int TPR = TE / 8, RPP = 64 * NWT / TPR;
-        const int r0 = tid / TPR, c = (tid % TPR) * 8;
-#pragma unroll
-        for (int p = 0; p < TE / 64; ++p) {
-            const int row = p * RPP + r0;
-            const bool ok = row < n;
-            *reinterpret_cast<uint4*>(tile + row * MF_LD + c) = make_uint4(ok ? r.v[p].x : 0u, ok ? r.v[p].y : 0u, ok ? r.v[p].z : 0u, ok ? r.v[p].w : 0u);
-        }
-    };
-    auto store_rows = [&](u16* base) {
-        constexpr int TPR = TE / 8, RPP = 64 * NWT / TPR;
-        const int r0 = tid / TPR, c = (tid % TPR) * 8;
-#pragma unroll
-        for (int p = 0; p < TE / 64; ++p) {
-            const int row = p * RPP + r0;
-            if (row < n) gst<uint4>(reinterpret_cast<char*>(base) + goff[p], *reinterpret_cast<const uint4*>(Os + row * MF_LD + c));
-        }
-    };
     if (mixer) {
         // B operand: B[k = i][n = j] = m_ij for the wave's chunks j = 16 rw + nl, i = 32 ks + 8 kg + t, i > j
         bf16x8 wh[NK], wl[NK];
@@ -241,12 +227,12 @@ __global__ __launch_bounds__(128 * NW) void k_csf_mixb(const CsfMix2Args a) {
         }
         const int kmin = rw / 2, kend = (n + 31) / 32;   // reduction steps that hold a chunk i > j for this wave's rows
         for (int it = 0; it < cnt; ++it) {
-            commit(Tp, pp);
-            commit(Tq, pq);
+            pp.commit(Tp, n, tid);
+            pq.commit(Tq, n, tid);
             __syncthreads();
             if (it + 1 < cnt) {
-                pp.issue(a.in + slice_off(s0 + it + 1), goff);
-                pq.issue(a.in2 + slice_off(s0 + it + 1), goff);
+                pp.issue(a.in + mix_slice_off<TE, HL>(s0 + it + 1, nsl, n, CSZ));
+                pq.issue(a.in2 + mix_slice_off<TE, HL>(s0 + it + 1, nsl, n, CSZ));
             }
 #pragma unroll
             for (int t4 = 0; t4 < NT; t4 += 4) {
@@ -256,22 +242,28 @@ __global__ __launch_bounds__(128 * NW) void k_csf_mixb(const CsfMix2Args a) {
 #pragma unroll
                 for (int ks = 0; ks < NK; ++ks) {
                     if (ks >= kmin && ks < kend) {
-                        bf16x8 sv[4];
+                        bf16x8 sv[4], sl[4];
 #pragma unroll
                         for (int t = 0; t < 4; ++t) sv[t] = tr_read8(Tp, MF_LD, ks * 32, (t4 + t) * 16, lane);
+                        if constexpr (HL) {
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) sl[t] = tr_read8(Tp + ROWS * MF_LD, MF_LD, ks * 32, (t4 + t) * 16, lane);
+                        }
 #pragma unroll
                         for (int t = 0; t < 4; ++t) acc[t] = mfma_bf16(sv[t], wh[ks], acc[t]);
 #pragma unroll
                         for (int t = 0; t < 4; ++t) acc[t] = mfma_bf16(sv[t], wl[ks], acc[t]);
+                        if constexpr (HL) {
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) acc[t] = mfma_bf16(sl[t], wh[ks], acc[t]);
+                        }
                     }
                 }
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    *reinterpret_cast<uint2*>(Os + (rw * 16 + nl) * MF_LD + (t4 + t) * 16 + kg * 4) =
-                        make_uint2(pack_bf16x2(acc[t][0], acc[t][1]), pack_bf16x2(acc[t][2], acc[t][3]));
+                for (int t = 0; t < 4; ++t) mix_stage4<TE, ROWS, HL>(Os, acc[t], rw * 16 + nl, (t4 + t) * 16 + kg * 4);
             }
             __syncthreads();
-            store_rows(a.out + slice_off(s0 + it));
+            pp.store(a.out + mix_slice_off<TE, HL>(s0 + it, nsl, n, CSZ), n, Os, tid);
         }
     } else {
         int tit[TPW], tjt[TPW];
@@ -284,26 +276,34 @@ __global__ __launch_bounds__(128 * NW) void k_csf_mixb(const CsfMix2Args a) {
             dacc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         for (int it = 0; it < cnt; ++it) {
-            commit(Tp, pp);
-            commit(Tq, pq);
+            pp.commit(Tp, n, tid);
+            pq.commit(Tq, n, tid);
             __syncthreads();
             if (it + 1 < cnt) {
-                pp.issue(a.in + slice_off(s0 + it + 1), goff);
-                pq.issue(a.in2 + slice_off(s0 + it + 1), goff);
+                pp.issue(a.in + mix_slice_off<TE, HL>(s0 + it + 1, nsl, n, CSZ));
+                pq.issue(a.in2 + mix_slice_off<TE, HL>(s0 + it + 1, nsl, n, CSZ));
             }
-            // dmix tiles: A[m = i][k = e] = dP_i[e], B[k = e][n = j] = S_j[e], both 16-byte row reads
+            // dmix tiles: A[m = i][k = e] = dP_i[e], B[k = e][n = j] = S_j[e], both 16-byte row reads (HL: hi hi + hi lo + lo hi)
 #pragma unroll
             for (int u = 0; u < TPW; ++u) {
                 if (tit[u] >= 0) {
                     const u16* ap = Tp + (tit[u] * 16 + nl) * MF_LD + kg * 8;
                     const u16* bp = Tq + (tjt[u] * 16 + nl) * MF_LD + kg * 8;
 #pragma unroll
-                    for (int ks = 0; ks < TE / 32; ++ks)
-                        dacc[u] = mfma_bf16(*reinterpret_cast<const bf16x8*>(ap + ks * 32), *reinterpret_cast<const bf16x8*>(bp + ks * 32), dacc[u]);
+                    for (int ks = 0; ks < TE / 32; ++ks) {
+                        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ap + ks * 32), bh_ = *reinterpret_cast<const bf16x8*>(bp + ks * 32);
+                        dacc[u] = mfma_bf16(ah, bh_, dacc[u]);
+                        if constexpr (HL) {
+                            const bf16x8 al = *reinterpret_cast<const bf16x8*>(ap + ROWS * MF_LD + ks * 32);
+                            const bf16x8 bl = *reinterpret_cast<const bf16x8*>(bp + ROWS * MF_LD + ks * 32);
+                            dacc[u] = mfma_bf16(ah, bl, dacc[u]);
+                            dacc[u] = mfma_bf16(al, bh_, dacc[u]);
+                        }
+                    }
                 }
             }
             __syncthreads();
-            store_rows(a.out + slice_off(s0 + it));
+            pp.store(a.out + mix_slice_off<TE, HL>(s0 + it, nsl, n, CSZ), n, Os, tid);
         }
         // the workgroup's partial of dmix: C[m = i][n = j], lane (i = 16 it + 4 kg + r, j = 16 jt + nl); entries with j >= i are never read
 #pragma unroll

@@ -19,8 +19,9 @@ from ._lib import NULL_VIEW, View
 # (batch, head) pairs one launch of the library addresses (grid.y); larger batches are sliced by the operators below
 _MAX_GRID_BH = 65535
 
-# forward workspaces up to this size are kept alive for the backward (bf16 block summaries of the fast path)
-KEEP_STATE_LIMIT_BYTES = 1 << 30
+# forward workspaces up to this size are kept alive for the backward (block / chunk summaries: the causal pipeline's hi + lo
+# chunk summaries of the 1.3B-like fla shape are 1.07 GB at B = 2; beyond the limit the backward recomputes them)
+KEEP_STATE_LIMIT_BYTES = 4 << 30
 
 _DTYPES = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16, torch.float16: _lib.F16}
 
@@ -724,7 +725,7 @@ def qk_prologue(x: torch.Tensor, weight: Optional[torch.Tensor], norm_eps: float
 class _Causal(torch.autograd.Function):
     @staticmethod
     @_device_guard
-    def forward(ctx, q, k, v, mix, chunk_size, scale):
+    def forward(ctx, q, k, v, mix, chunk_size, scale, flags):
         lib = _lib.load()
         _require_gpu(q, k, v, mix)
         B, T, H, K = q.shape
@@ -739,15 +740,15 @@ class _Causal(torch.autograd.Function):
         q, k, v = _prep(q), _prep(k), _prep(v)
         mixf = mix.detach().reshape(L, mix.shape[1]).to(torch.float32).contiguous()
         out = torch.empty((B, T, H, V), dtype=q.dtype, device=q.device)
-        ws = _ws(lib.mhla_causal_fwd_ws_bytes(B, T, H, K, V, chunk_size, _dtype_code(q)), q.device)
+        ws = _ws(lib.mhla_causal_fwd_ws_bytes(B, T, H, K, V, chunk_size, _dtype_code(q), flags), q.device)
         rc = lib.mhla_causal_fwd(_view(q), _view(k), _view(v), mixf.data_ptr(), mixf.shape[1], _view(out),
                                  ws.data_ptr(), ws.numel() * 4, B, T, H, K, V, chunk_size, float(scale),
-                                 _dtype_code(q), _stream())
+                                 _dtype_code(q), flags, _stream())
         _lib.check(rc, "mhla_causal_fwd")
         # keep the chunk summaries (S_j and their prefix mixes) for the backward unless they are very large
         keep = ws.numel() * 4 <= KEEP_STATE_LIMIT_BYTES and any(ctx.needs_input_grad[:4])
         ctx.save_for_backward(q, k, v, mixf, ws if keep else None)
-        ctx.cfg = (chunk_size, float(scale), mix.shape, mix.dtype)
+        ctx.cfg = (chunk_size, float(scale), mix.shape, mix.dtype, flags)
         return out
 
     @staticmethod
@@ -755,7 +756,7 @@ class _Causal(torch.autograd.Function):
     def backward(ctx, dout):
         lib = _lib.load()
         q, k, v, mixf, fwd_ws = ctx.saved_tensors
-        chunk_size, scale, mix_shape, mix_dtype = ctx.cfg
+        chunk_size, scale, mix_shape, mix_dtype, flags = ctx.cfg
         B, T, H, K = q.shape
         V = v.shape[-1]
         dout = _prep(dout.to(q.dtype))
@@ -765,32 +766,44 @@ class _Causal(torch.autograd.Function):
         # the library writes every entry of the leading [n, n] block (zeros above the diagonal)
         n_chunks = (T + chunk_size - 1) // chunk_size
         dmix = (torch.empty if tuple(mixf.shape) == (n_chunks, n_chunks) else torch.zeros)(mixf.shape, dtype=torch.float32, device=q.device)
-        ws = _ws(lib.mhla_causal_bwd_ws_bytes(B, T, H, K, V, chunk_size, _dtype_code(q)), q.device)
+        ws = _ws(lib.mhla_causal_bwd_ws_bytes(B, T, H, K, V, chunk_size, _dtype_code(q), flags), q.device)
         rc = lib.mhla_causal_bwd(_view(q), _view(k), _view(v), mixf.data_ptr(), mixf.shape[1], _view(dout),
                                  _view(dq), _view(dk), _view(dv), dmix.data_ptr(), dmix.shape[1],
                                  ws.data_ptr(), ws.numel() * 4, fwd_ws.data_ptr() if fwd_ws is not None else None,
-                                 B, T, H, K, V, chunk_size, scale, _dtype_code(q), _stream())
+                                 B, T, H, K, V, chunk_size, scale, _dtype_code(q), flags, _stream())
         _lib.check(rc, "mhla_causal_bwd")
-        return dq, dk, dv, dmix.reshape(mix_shape).to(mix_dtype), None, None
+        return dq, dk, dv, dmix.reshape(mix_shape).to(mix_dtype), None, None, None
+
+
+def _causal_flags(summaries: str, force_generic: bool) -> int:
+    if summaries not in ("split", "bf16"):
+        raise ValueError(f"summaries={summaries!r}: 'split' (bf16 hi + lo pairs, the reference's fp32 arithmetic) or 'bf16'")
+    return (_lib.CAUSAL_BF16_SUMMARIES if summaries == "bf16" else 0) | (_lib.CAUSAL_FORCE_GENERIC if force_generic else 0)
 
 
 def mhla_causal(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mixing_matrix: torch.Tensor,
-                chunk_size: int = 64, scale: Optional[float] = None) -> torch.Tensor:
+                chunk_size: int = 64, scale: Optional[float] = None, *, summaries: str = "split",
+                force_generic: bool = False) -> torch.Tensor:
     """Causal chunk-mixing MHLA operator (naive_chunk_simple_mhla_fixed,
     mhla_nlp/fla/ops/mhla/naive.py:10-83).  q, k: [B, T, H, K]; v: [B, T, H, V];
     mixing_matrix: [L, L] or [L, L, 1, 1, 1, 1], L >= ceil(T / chunk_size).  fp32 compute, output in
-    the dtype of q; `scale` defaults to K**-0.5 as in the reference (naive.py:42)."""
+    the dtype of q; `scale` defaults to K**-0.5 as in the reference (naive.py:42).
+    summaries: how bf16 problems keep the chunk summaries S, P, dP, dS and the score tiles between their two contractions --
+    "split" (default): bf16 hi + lo pairs, >= 16 significand bits, the reference's fp32 arithmetic (naive.py:39, :60-78);
+    "bf16": one bf16 value each -- REDUCED PRECISION (2-3e-3 of the result's maximum), half the summary traffic.
+    force_generic: testing aid -- the generic fp32-MFMA kernels for every shape."""
     if q.dim() != 4 or v.dim() != 4:
         raise ValueError("q, k: [B, T, H, K], v: [B, T, H, V]")
+    flags = _causal_flags(summaries, force_generic)
     if scale is None:
         scale = q.shape[-1] ** -0.5
     if q.shape[0] == 0 or q.shape[1] == 0:   # empty batch / sequence
         return torch.zeros_like(v) + 0 * (q.sum() + k.sum() + mixing_matrix.sum()).to(v.dtype)
     nb = _MAX_GRID_BH // q.shape[2]
     if q.shape[0] > nb:   # see mhla_blockmix
-        return torch.cat([_Causal.apply(q[i:i + nb], k[i:i + nb], v[i:i + nb], mixing_matrix, int(chunk_size), scale)
+        return torch.cat([_Causal.apply(q[i:i + nb], k[i:i + nb], v[i:i + nb], mixing_matrix, int(chunk_size), scale, flags)
                           for i in range(0, q.shape[0], nb)], dim=0)
-    return _Causal.apply(q, k, v, mixing_matrix, int(chunk_size), scale)
+    return _Causal.apply(q, k, v, mixing_matrix, int(chunk_size), scale, flags)
 
 
 def naive_chunk_simple_mhla_fixed(q, k, v, mixing_matrix, output_final_state: bool = False, chunk_size: int = 64,
@@ -806,7 +819,7 @@ class _CausalNormGate(torch.autograd.Function):
 
     @staticmethod
     @_device_guard
-    def forward(ctx, q, k, v, mix, gate, weight, chunk_size, scale, norm_eps):
+    def forward(ctx, q, k, v, mix, gate, weight, chunk_size, scale, norm_eps, flags):
         lib = _lib.load()
         _require_gpu(q, k, v, mix, gate, weight)
         B, T, H, K = q.shape
@@ -823,17 +836,17 @@ class _CausalNormGate(torch.autograd.Function):
         need_grad = any(ctx.needs_input_grad[:6])
         out = torch.empty((B, T, H, V), dtype=q.dtype, device=q.device) if need_grad else None
         y = torch.empty((B, T, H, V), dtype=q.dtype, device=q.device)
-        ws = _ws(lib.mhla_causal_fwd_ws_bytes(B, T, H, K, V, chunk_size, _dtype_code(q)), q.device)
+        ws = _ws(lib.mhla_causal_fwd_ws_bytes(B, T, H, K, V, chunk_size, _dtype_code(q), flags), q.device)
         rc = lib.mhla_causal_normgate_fwd(_view(q), _view(k), _view(v), mixf.data_ptr(), mixf.shape[1],
                                           _view(out) if out is not None else NULL_VIEW,
                                           _view(gate) if gate is not None else NULL_VIEW,
                                           wf.data_ptr() if wf is not None else None, float(norm_eps), _view(y),
                                           ws.data_ptr(), ws.numel() * 4, B, T, H, K, V, chunk_size, float(scale),
-                                          _dtype_code(q), _stream())
+                                          _dtype_code(q), flags, _stream())
         _lib.check(rc, "mhla_causal_normgate_fwd")
         keep = ws.numel() * 4 <= KEEP_STATE_LIMIT_BYTES and need_grad
         ctx.save_for_backward(q, k, v, mixf, out, gate, wf, ws if keep else None)
-        ctx.cfg = (chunk_size, float(scale), float(norm_eps), mix.shape, mix.dtype, weight.dtype if weight is not None else None)
+        ctx.cfg = (chunk_size, float(scale), float(norm_eps), mix.shape, mix.dtype, weight.dtype if weight is not None else None, flags)
         return y
 
     @staticmethod
@@ -841,7 +854,7 @@ class _CausalNormGate(torch.autograd.Function):
     def backward(ctx, dy):
         lib = _lib.load()
         q, k, v, mixf, out, gate, wf, fwd_ws = ctx.saved_tensors
-        chunk_size, scale, norm_eps, mix_shape, mix_dtype, w_dtype = ctx.cfg
+        chunk_size, scale, norm_eps, mix_shape, mix_dtype, w_dtype, flags = ctx.cfg
         B, T, H, K = q.shape
         V = v.shape[-1]
         rows = B * T * H
@@ -861,33 +874,37 @@ class _CausalNormGate(torch.autograd.Function):
         # the library writes every entry of the leading [n, n] block (zeros above the diagonal)
         n_chunks = (T + chunk_size - 1) // chunk_size
         dmix = (torch.empty if tuple(mixf.shape) == (n_chunks, n_chunks) else torch.zeros)(mixf.shape, dtype=torch.float32, device=q.device)
-        ws = _ws(lib.mhla_causal_bwd_ws_bytes(B, T, H, K, V, chunk_size, _dtype_code(q)), q.device)
+        ws = _ws(lib.mhla_causal_bwd_ws_bytes(B, T, H, K, V, chunk_size, _dtype_code(q), flags), q.device)
         rc = lib.mhla_causal_bwd(_view(q), _view(k), _view(v), mixf.data_ptr(), mixf.shape[1], _view(do),
                                  _view(dq), _view(dk), _view(dv), dmix.data_ptr(), dmix.shape[1],
                                  ws.data_ptr(), ws.numel() * 4, fwd_ws.data_ptr() if fwd_ws is not None else None,
-                                 B, T, H, K, V, chunk_size, scale, _dtype_code(q), _stream())
+                                 B, T, H, K, V, chunk_size, scale, _dtype_code(q), flags, _stream())
         _lib.check(rc, "mhla_causal_bwd")
         dw = dwp.sum(0).to(w_dtype) if wf is not None else None
-        return dq, dk, dv, dmix.reshape(mix_shape).to(mix_dtype), dg, dw, None, None, None
+        return dq, dk, dv, dmix.reshape(mix_shape).to(mix_dtype), dg, dw, None, None, None, None
 
 
-def causal_normgate_fusable(q: torch.Tensor, v: torch.Tensor) -> bool:
-    """Shapes the fused epilogue covers (include/mhla_hip.h, mhla_causal_normgate_fwd): bf16, K % 64 == 0, V % 64 == 0, V <= 256."""
-    return (q.dtype == torch.bfloat16 and q.shape[-1] % 64 == 0 and v.shape[-1] % 64 == 0 and v.shape[-1] <= 256
-            and q.shape[0] * q.shape[2] <= _MAX_GRID_BH and q.shape[0] > 0 and q.shape[1] > 0)
+def causal_normgate_fusable(q: torch.Tensor, v: torch.Tensor, chunk_size: int = 64, flags: int = 0) -> bool:
+    """Shapes the fused epilogue covers (the library's own answer, mhla_causal_normgate_fusable: bf16, K % 64 == 0, K <= 256,
+    V % 64 == 0, V <= 256, at most 128 chunks) within one launch's (batch, head) range."""
+    if q.dtype not in _DTYPES or not (q.shape[0] > 0 and q.shape[1] > 0 and q.shape[0] * q.shape[2] <= _MAX_GRID_BH):
+        return False
+    return _lib.load().mhla_causal_normgate_fusable(q.shape[1], q.shape[-1], v.shape[-1], chunk_size, _DTYPES[q.dtype], flags) == 1
 
 
 def mhla_causal_normgate(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mixing_matrix: torch.Tensor,
                          gate: Optional[torch.Tensor], weight: Optional[torch.Tensor], norm_eps: float = 1e-5,
-                         chunk_size: int = 64, scale: Optional[float] = None) -> torch.Tensor:
+                         chunk_size: int = 64, scale: Optional[float] = None, *, summaries: str = "split") -> torch.Tensor:
     """`rmsnorm_gate(mhla_causal(q, k, v, mix), gate, weight, norm_eps)` -- the fla layer's operator + FusedRMSNormGated
-    (mhla_nlp/fla/layers/mhla.py:330-355).  Where the fused epilogue applies (bf16, K, V multiples of 64, V <= 256) the norm x
-    gate runs inside the operator's output kernel; other shapes compose the two HIP operators."""
+    (mhla_nlp/fla/layers/mhla.py:330-355).  Where the fused epilogue applies (bf16, K, V multiples of 64, K, V <= 256, at most
+    128 chunks) the norm x gate runs inside the operator's output kernel; other shapes compose the two HIP operators.
+    `summaries`: see mhla_causal."""
+    flags = _causal_flags(summaries, False)
     if scale is None:
         scale = q.shape[-1] ** -0.5
-    if not causal_normgate_fusable(q, v):
-        return rmsnorm_gate(mhla_causal(q, k, v, mixing_matrix, chunk_size, scale), gate, weight, norm_eps)
-    return _CausalNormGate.apply(q, k, v, mixing_matrix, gate, weight, int(chunk_size), scale, norm_eps)
+    if not causal_normgate_fusable(q, v, chunk_size, flags):
+        return rmsnorm_gate(mhla_causal(q, k, v, mixing_matrix, chunk_size, scale, summaries=summaries), gate, weight, norm_eps)
+    return _CausalNormGate.apply(q, k, v, mixing_matrix, gate, weight, int(chunk_size), scale, norm_eps, flags)
 
 
 def naive_recurrent_mhla(q, k, v, mixing_matrix, chunk_size: int = 64, scale: Optional[float] = None,

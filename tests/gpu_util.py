@@ -22,6 +22,13 @@ DEV = "cuda"
 UNIT_ROUNDOFF = {torch.bfloat16: 2.0 ** -8, torch.float16: 2.0 ** -11}
 TOL = {torch.float32: 2e-4, torch.bfloat16: 2 * 2.0 ** -8, torch.float16: 2 * 2.0 ** -11}
 GTOL = {torch.float32: 2e-4, torch.bfloat16: 3 * 2.0 ** -8, torch.float16: 3 * 2.0 ** -11}
+# The causal operator (round 4): the reference computes it in fp32 throughout (naive.py:39, :60-78) and rounds once (:82), and so
+# do the kernels -- every intermediate that feeds a second contraction keeps >= 16 significand bits (bf16 hi + lo pairs, or
+# exact fp32 on the generic path).  What is left is the ONE final rounding of a 16-bit result (<= u |x| per element) plus
+# north_star's 1e-3 for everything the kernels add; fp32-stored results (dmix) get the 1e-3 alone.  The opt-in reduced
+# precision variant (summaries="bf16") keeps the K-intermediate bounds above.
+CAUSAL_TOL = {torch.float32: 2e-4, torch.bfloat16: 2.0 ** -8 + 1e-3, torch.float16: 2.0 ** -11 + 1e-3}
+CAUSAL_DMIX_TOL = {torch.float32: 2e-4, torch.bfloat16: 1e-3, torch.float16: 1e-3}
 
 
 def make_blockmix_inputs(B, H, M, S, D, dtype, seed=1234, w="linear", split=False):

@@ -3,7 +3,7 @@ import pytest
 import torch
 
 from conftest import load_golden
-from gpu_util import poison, DEV, GTOL, TOL, check
+from gpu_util import poison, DEV, GTOL, TOL, CAUSAL_TOL, CAUSAL_DMIX_TOL, check
 from oracle import mhla_oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -19,23 +19,35 @@ def causal_inputs(B, T, H, K, V, L, dtype, seed=1234, random_mix=True):
     return q, k, v, mix, do
 
 
-def run_causal(B, T, H, K, V, L, dtype, seed=1234):
+def causal_tols(dtype, summaries="split"):
+    """(out / dq / dk / dv tolerance, dmix tolerance): one final rounding + 1e-3 at the reference's arithmetic; the reduced
+    precision variant carries K = 1 (outputs) / 2 (gradients) bf16 intermediates (gpu_util)."""
+    if summaries == "bf16":
+        return TOL[dtype], GTOL[dtype], GTOL[dtype]
+    return CAUSAL_TOL[dtype], CAUSAL_TOL[dtype], CAUSAL_DMIX_TOL[dtype]
+
+
+def run_causal(B, T, H, K, V, L, dtype, seed=1234, summaries="split"):
     import mhla_amd
     q, k, v, mix, do = causal_inputs(B, T, H, K, V, L, dtype, seed)
     want = orc.causal_fwd(q.float(), k.float(), v.float(), mix)
     wg = orc.causal_bwd(q.float(), k.float(), v.float(), mix, do.float())
     dq, dk, dv, dm = (t.to(DEV).requires_grad_(True) for t in (q, k, v, mix.view(L, L, 1, 1, 1, 1)))
     poison()
-    out = mhla_amd.naive_chunk_simple_mhla_fixed(q=dq, k=dk, v=dv, mixing_matrix=dm)
+    if summaries == "split":   # the reference's own call form
+        out = mhla_amd.naive_chunk_simple_mhla_fixed(q=dq, k=dk, v=dv, mixing_matrix=dm)
+    else:
+        out = mhla_amd.mhla_causal(dq, dk, dv, dm, summaries=summaries)
     assert out.dtype == dtype and out.shape == (B, T, H, V)
     dod = do.to(DEV)
     poison()
     out.backward(dod)
-    check("out", out, want, TOL[dtype])
-    check("dq", dq.grad, wg["dq"], GTOL[dtype])
-    check("dk", dk.grad, wg["dk"], GTOL[dtype])
-    check("dv", dv.grad, wg["dv"], GTOL[dtype])
-    check("dmix", dm.grad.reshape(L, L), wg["dmix"], GTOL[dtype])
+    otol, gtol, mtol = causal_tols(dtype, summaries)
+    check("out", out, want, otol)
+    check("dq", dq.grad, wg["dq"], gtol)
+    check("dk", dk.grad, wg["dk"], gtol)
+    check("dv", dv.grad, wg["dv"], gtol)
+    check("dmix", dm.grad.reshape(L, L), wg["dmix"], mtol)
 
 
 @pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
@@ -48,10 +60,21 @@ def test_golden_causal(tag):
     mix = g["mix"].to(DEV).requires_grad_(True)
     out = mhla_amd.mhla_causal(q, k, v, mix)
     out.backward(cast(g["dout"]).to(DEV))
-    tol = 1e-2 if bf16 else 1e-4
+    # Fixture d is the reference's own bf16 call (naive.py:39 upcasts, :82 rounds once): its outputs and gradients are THEMSELVES
+    # bf16-rounded, so a result that differs from the reference's fp32 value by 1e-5 still lands on the neighbouring bf16 number
+    # now and then -- a one-ulp flip, |err| <= 2 u |x| on that element, nothing in between.  Hence: max error within one ulp
+    # (2u + 1e-3), and the rms-relative error -- which counts how OFTEN that happens -- under north_star's 1e-3 (observed 1.5e-4;
+    # single-bf16 summaries flip 40 % of the elements: 3e-3).
+    tol = 2 * 2.0 ** -8 + 1e-3 if bf16 else 1e-4
     check("out", out, g["out"], tol)
-    for n, t in (("dq", q), ("dk", k), ("dv", v), ("dmix", mix)):
-        check(n, t.grad, g[n], 1.5e-2 if bf16 else 2e-4)
+    for n, t in (("dq", q), ("dk", k), ("dv", v)):
+        check(n, t.grad, g[n], tol if bf16 else 2e-4)
+    check("dmix", mix.grad, g["dmix"], CAUSAL_DMIX_TOL[torch.bfloat16] if bf16 else 2e-4)
+    if bf16:
+        from conftest import rms_ratio
+        for n, got in (("out", out), ("dq", q.grad), ("dk", k.grad), ("dv", v.grad)):
+            r = rms_ratio(got.float().cpu(), g[n].float())
+            assert r < 1e-3, f"{n}: rms-relative error {r:.2e} vs the reference's own bf16 result"
     if "out_recurrent" in g:   # T <= 64: the reference's token-recurrent form (naive.py:88-142), as the fla layer calls it
         o_rec, S = mhla_amd.naive_recurrent_mhla(q.detach(), k.detach(), v.detach(), mix.detach())
         check("naive_recurrent_mhla", o_rec, g["out_recurrent"], tol)
@@ -70,29 +93,49 @@ def test_causal_lowp(dtype):
     run_causal(2, 512, 4, 128, 256, 8, dtype)
 
 
-@pytest.mark.parametrize("T,K,V", [(256, 64, 64), (200, 64, 128), (50, 128, 64), (1000, 128, 256), (129, 256, 512),
-                                   (320, 64, 48), (320, 48, 64), (200, 192, 192), (130, 192, 320), (200, 64, 384)])
+BF16_SHAPES = [(256, 64, 64), (200, 64, 128), (50, 128, 64), (1000, 128, 256), (129, 256, 512),
+               (320, 64, 48), (320, 48, 64), (200, 192, 192), (130, 192, 320), (200, 64, 384),
+               # chunk walks of the output / summaries kernels (four chunks per workgroup): a full group followed by a partial
+               # one, ragged and one-token last chunks
+               (330, 128, 256), (449, 128, 256), (321, 64, 64), (8192, 64, 64), (2100, 256, 256)]
+
+
+@pytest.mark.parametrize("T,K,V", BF16_SHAPES)
 def test_causal_shapes_bf16(T, K, V):
-    """K and V multiples of 64 run the bf16-MFMA token kernels (ragged last chunk included); the others the generic ones.
-    The eight-wave kernels are templated on K / 64 (1..4) and on the V slices per workgroup (the largest of 4, 3, 2, 1 dividing
-    V / 64): 192 x 192 -> <3>, <3>; V = 320 -> five workgroups of one slice; V = 384 -> two of three."""
+    """K and V multiples of 64 (K <= 256, at most 128 chunks) run the 16-bit-MFMA pipeline (ragged last chunk included); the
+    others the generic kernels.  The eight-wave kernels are templated on K / 64 (1..4) and on the V slices per workgroup
+    (192 x 192 -> <3>, <3>; V = 320 -> five workgroups of one slice; V = 384 -> two of three).  Tolerance: the reference's
+    arithmetic -- one final rounding + 1e-3."""
     run_causal(2, T, 2, K, V, max(4, (T + 63) // 64), torch.bfloat16, seed=T + K)
 
 
-def test_causal_bf16_pipeline_vs_generic(monkeypatch):
-    """The bf16 pipeline (bf16 chunk summaries) against the generic fp32-compute kernels on the same bf16 inputs."""
+@pytest.mark.parametrize("T,K,V", [(256, 64, 64), (1000, 128, 256), (129, 256, 512), (200, 192, 192), (200, 64, 384), (330, 128, 256)])
+def test_causal_shapes_bf16_reduced_precision_variant(T, K, V):
+    """summaries="bf16" (MHLA_CAUSAL_BF16_SUMMARIES): the opt-in variant with single-bf16 chunk summaries and score tiles, held
+    to the K-intermediate bounds of gpu_util (2u outputs, 3u gradients)."""
+    run_causal(2, T, 2, K, V, max(4, (T + 63) // 64), torch.bfloat16, seed=T + K, summaries="bf16")
+
+
+@pytest.mark.parametrize("T,K,V", [(8256, 64, 64), (300, 320, 64)])
+def test_causal_bf16_beyond_the_pipeline(T, K, V):
+    """bf16 tensors outside the 16-bit pipeline's range (more than 128 chunks; K > 256): the generic fp32-MFMA kernels."""
+    run_causal(1, T, 2, K, V, max(4, (T + 63) // 64), torch.bfloat16, seed=T + K)
+
+
+def test_causal_bf16_pipeline_vs_generic():
+    """The 16-bit pipeline (hi + lo chunk summaries) against the generic fp32-compute kernels on the same bf16 inputs: both
+    carry only the final rounding, so they agree to twice that + 1e-3."""
     import mhla_amd
     q, k, v, mix, do = causal_inputs(2, 700, 2, 128, 128, 16, torch.bfloat16, seed=77)
     res = {}
     for tag in ("fast", "generic"):
-        if tag == "generic":
-            monkeypatch.setenv("MHLA_CAUSAL_GENERIC", "1")
         dq, dk, dv, dm = (t.to(DEV).requires_grad_(True) for t in (q, k, v, mix.view(16, 16, 1, 1, 1, 1)))
-        out = mhla_amd.naive_chunk_simple_mhla_fixed(q=dq, k=dk, v=dv, mixing_matrix=dm)
+        out = mhla_amd.mhla_causal(dq, dk, dv, dm, force_generic=(tag == "generic"))
         out.backward(do.to(DEV))
         res[tag] = (out, dq.grad, dk.grad, dv.grad, dm.grad)
-    for name, a, b in zip(("out", "dq", "dk", "dv", "dmix"), res["fast"], res["generic"]):
-        check(name, a, b.float().cpu(), GTOL[torch.bfloat16])
+    for name, a, b in zip(("out", "dq", "dk", "dv"), res["fast"], res["generic"]):
+        check(name, a, b.float().cpu(), 2 * 2.0 ** -8 + 1e-3)
+    check("dmix", res["fast"][4], res["generic"][4].float().cpu(), 1e-3)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
@@ -131,10 +174,11 @@ def test_causal_more_than_2_31_elements():
         sl = lambda t: t.detach()[b:b + 1, :, h:h + 1].float().cpu()
         want = orc.causal_fwd(sl(q), sl(k), sl(v), mix)
         wg = orc.causal_bwd(sl(q), sl(k), sl(v), mix, sl(do))
-        check("out", sl(out), want, TOL[torch.bfloat16])
-        check("dq", sl(q.grad), wg["dq"], GTOL[torch.bfloat16])
-        check("dk", sl(k.grad), wg["dk"], GTOL[torch.bfloat16])
-        check("dv", sl(v.grad), wg["dv"], GTOL[torch.bfloat16])
+        s16 = lambda t: t.detach()[b:b + 1, :, h:h + 1].cpu()   # (bf16: check() charges the final rounding per element)
+        check("out", s16(out), want, CAUSAL_TOL[torch.bfloat16])
+        check("dq", s16(q.grad), wg["dq"], CAUSAL_TOL[torch.bfloat16])
+        check("dk", s16(k.grad), wg["dk"], CAUSAL_TOL[torch.bfloat16])
+        check("dv", s16(v.grad), wg["dv"], CAUSAL_TOL[torch.bfloat16])
     # dmix of the whole batch = sum over batch chunks (size-independent), first samples anchored on the oracle
     full = md.grad.detach().double().cpu()
     acc = torch.zeros_like(full)
@@ -148,7 +192,7 @@ def test_causal_more_than_2_31_elements():
     wg2 = orc.causal_bwd(f(q), f(k), f(v), mix, f(do))
     mc = mix.to(DEV).requires_grad_(True)
     mhla_amd.mhla_causal(q.detach()[:2], k.detach()[:2], v.detach()[:2], mc).backward(do[:2])
-    check("dmix (first 2 samples vs oracle)", mc.grad, wg2["dmix"], GTOL[torch.bfloat16])
+    check("dmix (first 2 samples vs oracle)", mc.grad, wg2["dmix"], CAUSAL_DMIX_TOL[torch.bfloat16])
     del q, k, v, do, out
     torch.cuda.empty_cache()
 
@@ -168,10 +212,10 @@ def test_causal_bf16_strided_views():
     dm = mix.view(L, L, 1, 1, 1, 1).to(DEV).requires_grad_(True)
     out = mhla_amd.naive_chunk_simple_mhla_fixed(q=dqkv[:, :, 0], k=dqkv[:, :, 1], v=dqkv[:, :, 2], mixing_matrix=dm)
     out.backward(do.to(DEV))
-    check("out", out, want, TOL[torch.bfloat16])
+    check("out", out, want, CAUSAL_TOL[torch.bfloat16])
     for i, n in enumerate(("dq", "dk", "dv")):
-        check(n, dqkv.grad[:, :, i], wg[n], GTOL[torch.bfloat16])
-    check("dmix", dm.grad.reshape(L, L), wg["dmix"], GTOL[torch.bfloat16])
+        check(n, dqkv.grad[:, :, i], wg[n], CAUSAL_TOL[torch.bfloat16])
+    check("dmix", dm.grad.reshape(L, L), wg["dmix"], CAUSAL_DMIX_TOL[torch.bfloat16])
 
 
 def test_causal_is_causal_and_recurrent_first_chunk():
@@ -261,15 +305,26 @@ def test_causal_normgate_fused_epilogue(T, K, V, gate, affine):
     g = torch.randn(B, T, H, V, generator=gen).bfloat16() if gate else None
     w = (torch.rand(V, generator=gen) + 0.5) if affine else None
     assert ops.causal_normgate_fusable(q.to(DEV), v.to(DEV))
-    # oracle: fp32 operator output rounded to bf16 (the layer's dtype), then the norm x gate twin
+    # Oracle with the reference layer's dtype flow (layers/mhla.py:330-355): the operator returns o in the activation dtype
+    # (naive.py:82), FusedRMSNormGated reads that bf16 o, and autograd hands the operator a bf16 do -- `_R16` rounds the value
+    # on the way forward and the gradient on the way back.  Everything else in fp32.
+    class _R16(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x.bfloat16().float()
+
+        @staticmethod
+        def backward(ctx, g):
+            return g.bfloat16().float()
+
     ref = [t.float().clone().requires_grad_(True) for t in (q, k, v, mix)]
     gr = g.float().clone().requires_grad_(True) if gate else None
     wr = w.clone().requires_grad_(True) if affine else None
-    o_ref = orc.causal_fwd(ref[0], ref[1], ref[2], ref[3])
-    if gate:
-        y_ref = orc.rms_norm_swish_gate(o_ref, gr, wr if affine else torch.ones(V), 1e-5)
-    else:
-        y_ref = o_ref * torch.rsqrt(o_ref.pow(2).mean(-1, keepdim=True) + 1e-5) * (wr if affine else 1.0)
+    o_exact = orc.causal_fwd(ref[0], ref[1], ref[2], ref[3])
+    o_ref = _R16.apply(o_exact)
+    norm = lambda o: (orc.rms_norm_swish_gate(o, gr, wr if affine else torch.ones(V), 1e-5) if gate else
+                      o * torch.rsqrt(o.pow(2).mean(-1, keepdim=True) + 1e-5) * (wr if affine else 1.0))
+    y_ref = norm(o_ref)
     (y_ref * do.float()).sum().backward()
     dev = [t.to(DEV).requires_grad_(True) for t in (q, k, v, mix)]
     gd = g.to(DEV).requires_grad_(True) if gate else None
@@ -279,21 +334,27 @@ def test_causal_normgate_fused_epilogue(T, K, V, gate, affine):
     assert y.dtype == torch.bfloat16
     poison()
     y.backward(do.to(DEV))
-    # two operators back to back (u = 2^-8): y carries the rounding of o, the operator's K = 1 and its own final rounding (3 u);
-    # the gradients 8 u = 3.1e-2 -- the norm's backward reads the bf16-rounded o and emits a bf16 do for the operator's
-    # backward, where the oracle stays in fp32 throughout (observed up to 2.4e-2 on dmix, a sum over only B * H = 4 heads)
-    check("y", y, y_ref.detach(), 1e-2)
-    for name, a, b in zip(("dq", "dk", "dv", "dmix"), dev, ref):
-        check(name, a.grad, b.grad, 3e-2)
+    u = 2.0 ** -8
+    # y: the fused kernel normalises the fp32 accumulators (closer to the exact value than the reference flow, which normalises
+    # the bf16-rounded o): against the exact composition one staging rounding of the normalised tile + the final one, 2u + 1e-3;
+    # against the reference flow one more u for its rounding of o.
+    with torch.no_grad():
+        check("y vs exact composition", y, norm(o_exact), 2 * u + 1e-3)
+    check("y", y, y_ref.detach(), 3 * u + 1e-3)
+    # gradients: the norm's backward kernel and the operator's backward see the same rounded o / do as the oracle up to one-ulp
+    # flips of do (a bf16 do that sits on a rounding boundary): one final rounding + 1e-3; fp32-stored ones 1e-3
+    for name, a, b in zip(("dq", "dk", "dv"), dev, ref):
+        check(name, a.grad, b.grad, CAUSAL_TOL[torch.bfloat16])
+    check("dmix", dev[3].grad, ref[3].grad, CAUSAL_DMIX_TOL[torch.bfloat16])
     if gate:
-        check("dgate", gd.grad, gr.grad, 3e-2)
+        check("dgate", gd.grad, gr.grad, CAUSAL_TOL[torch.bfloat16])
     if affine:
-        check("dweight", wd.grad, wr.grad, 3e-2)
+        check("dweight", wd.grad, wr.grad, 1e-3)
     # the unfused composition of the two HIP operators agrees (same kernels downstream, one more bf16 rounding of o)
     with torch.no_grad():
         y2 = mhla_amd.rmsnorm_gate(mhla_amd.mhla_causal(dev[0], dev[1], dev[2], dev[3]), gd, wd, 1e-5)
         y3 = mhla_amd.mhla_causal_normgate(dev[0], dev[1], dev[2], dev[3], gd, wd, 1e-5)   # inference: o is not stored
-    check("fused vs unfused", y3, y2.float().cpu(), 1e-2)
+    check("fused vs unfused", y3, y2.float().cpu(), 3 * u + 1e-3)
     check("inference vs training path", y3, y.detach().float().cpu(), 1e-6)
 
 
@@ -315,15 +376,16 @@ def test_full_size_c5_sampled_head():
     out.backward(do.to(DEV))
     b, h = 1, 2
     sl = lambda t: t[b:b + 1, :, h:h + 1].float()
+    s16 = lambda t: t.detach()[b:b + 1, :, h:h + 1]   # (bf16: check() charges the final rounding per element)
     want = orc.causal_fwd(sl(q), sl(k), sl(v), mix)
     wg = orc.causal_bwd(sl(q), sl(k), sl(v), mix, sl(do))
-    check("out", sl(out), want, TOL[torch.bfloat16])
-    check("dq", sl(dq.grad), wg["dq"], GTOL[torch.bfloat16])
-    check("dk", sl(dk.grad), wg["dk"], GTOL[torch.bfloat16])
-    check("dv", sl(dv.grad), wg["dv"], GTOL[torch.bfloat16])
+    check("out", s16(out), want, CAUSAL_TOL[torch.bfloat16])
+    check("dq", s16(dq.grad), wg["dq"], CAUSAL_TOL[torch.bfloat16])
+    check("dk", s16(dk.grad), wg["dk"], CAUSAL_TOL[torch.bfloat16])
+    check("dv", s16(dv.grad), wg["dv"], CAUSAL_TOL[torch.bfloat16])
     # dmix sums over every (b, h): the whole batch through the oracle
     wg_all = orc.causal_bwd(q.float(), k.float(), v.float(), mix, do.float())
-    check("dmix (all heads)", dm.grad, wg_all["dmix"], GTOL[torch.bfloat16])
+    check("dmix (all heads)", dm.grad, wg_all["dmix"], CAUSAL_DMIX_TOL[torch.bfloat16])
 
 
 def test_full_size_c5_1p3b_like_shape():
@@ -339,8 +401,8 @@ def test_full_size_c5_1p3b_like_shape():
     out.backward(do.to(DEV))
     want = orc.causal_fwd(q.float(), k.float(), v.float(), mix)
     wg = orc.causal_bwd(q.float(), k.float(), v.float(), mix, do.float())
-    check("out", out, want, TOL[torch.bfloat16])
-    check("dq", dq.grad, wg["dq"], GTOL[torch.bfloat16])
-    check("dk", dk.grad, wg["dk"], GTOL[torch.bfloat16])
-    check("dv", dv.grad, wg["dv"], GTOL[torch.bfloat16])
-    check("dmix", dm.grad, wg["dmix"], GTOL[torch.bfloat16])
+    check("out", out, want, CAUSAL_TOL[torch.bfloat16])
+    check("dq", dq.grad, wg["dq"], CAUSAL_TOL[torch.bfloat16])
+    check("dk", dk.grad, wg["dk"], CAUSAL_TOL[torch.bfloat16])
+    check("dv", dv.grad, wg["dv"], CAUSAL_TOL[torch.bfloat16])
+    check("dmix", dm.grad, wg["dmix"], CAUSAL_DMIX_TOL[torch.bfloat16])

@@ -21,15 +21,24 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/mhla_hip.h but not exported"
-    assert lib.mhla_abi_version() == _lib.ABI_VERSION == 6
+    assert lib.mhla_abi_version() == _lib.ABI_VERSION == 7
     assert b"no-packed-fp32" in lib.mhla_build_flags()
     # workspace sizing is pure host arithmetic: callable without a GPU
     fwd = lib.mhla_blockmix_fwd_ws_bytes(8, 16, 64, 64, 64, 0, 0, 0)
     bwd = lib.mhla_blockmix_bwd_ws_bytes(8, 16, 64, 64, 64, 0, 0, 0)
     assert lib.mhla_blockmix_fwd_ws_bytes(8, 16, 64, 64, 64, 1, 0, 0) < fwd   # bf16 fast path: compact summaries
     assert 0 < fwd < bwd
-    assert lib.mhla_causal_bwd_ws_bytes(1, 8192, 4, 128, 256, 64, 0) > lib.mhla_causal_fwd_ws_bytes(1, 8192, 4, 128, 256, 64, 0) > 0
-    assert lib.mhla_causal_fwd_ws_bytes(1, 8192, 4, 128, 256, 64, 1) * 2 == lib.mhla_causal_fwd_ws_bytes(1, 8192, 4, 128, 256, 64, 0)
+    assert lib.mhla_causal_bwd_ws_bytes(1, 8192, 4, 128, 256, 64, 0, 0) > lib.mhla_causal_fwd_ws_bytes(1, 8192, 4, 128, 256, 64, 0, 0) > 0
+    # bf16 tensors: chunk summaries as bf16 hi + lo pairs (as many bytes as fp32); single bf16 only with the opt-in flag
+    f32 = lib.mhla_causal_fwd_ws_bytes(1, 8192, 4, 128, 256, 64, 0, 0)
+    assert lib.mhla_causal_fwd_ws_bytes(1, 8192, 4, 128, 256, 64, 1, 0) == f32
+    assert lib.mhla_causal_fwd_ws_bytes(1, 8192, 4, 128, 256, 64, 1, _lib.CAUSAL_BF16_SUMMARIES) * 2 == f32
+    assert lib.mhla_causal_fwd_ws_bytes(1, 8192, 4, 128, 256, 64, 1, _lib.CAUSAL_FORCE_GENERIC) == f32
+    # the fused norm x gate epilogue: what the 16-bit pipeline covers with V <= 256
+    assert lib.mhla_causal_normgate_fusable(8192, 128, 256, 64, 1, 0) == 1
+    assert lib.mhla_causal_normgate_fusable(8192, 128, 512, 64, 1, 0) == 0
+    assert lib.mhla_causal_normgate_fusable(8256, 128, 256, 64, 1, 0) == 0    # 129 chunks: generic kernels
+    assert lib.mhla_causal_normgate_fusable(8192, 128, 256, 64, 0, 0) == 0    # fp32 tensors
 
 
 def test_argument_validation_without_gpu():
@@ -46,8 +55,10 @@ def test_argument_validation_without_gpu():
     # (S = 32: blocks of 16 tokens take the single-launch small-sequence kernels, which need no workspace)
     rc = lib.mhla_blockmix_fwd(ok, ok, ok, ok, ok, 1 << 20, 4, ok, None, 1 << 20, 16, 1, 1, 4, 32, 64, 0, 1e-6, 0, None)
     assert rc == -22 and b"workspace" in lib.mhla_last_error()
-    rc = lib.mhla_causal_fwd(ok, ok, ok, 1 << 20, 4, ok, 1 << 20, 1 << 30, 1, 128, 1, 64, 64, 32, 0.125, 0, None)
+    rc = lib.mhla_causal_fwd(ok, ok, ok, 1 << 20, 4, ok, 1 << 20, 1 << 30, 1, 128, 1, 64, 64, 32, 0.125, 0, 0, None)
     assert rc == -95 and b"chunk" in lib.mhla_last_error()
+    rc = lib.mhla_causal_fwd(ok, ok, ok, 1 << 20, 4, ok, 1 << 20, 1 << 30, 1, 128, 1, 64, 64, 64, 0.125, 0, 8, None)
+    assert rc == -22 and b"flags" in lib.mhla_last_error()
 
 
 @pytest.mark.parametrize("tr", ["linear", "cos", "exp", "gaussian", "local"])

@@ -133,7 +133,7 @@ def blockmix_case(name, B, N, H, D, M, dtype, layout, bwd=True, split=False, idx
     return _result(name, "fwd+bwd" if bwd else "fwd", t, B * N, alg, step, _graph_time(step, iters) if graph else None, key)
 
 
-def causal_case(name, B, T, H, K, V, dtype, iters=10, key=None):
+def causal_case(name, B, T, H, K, V, dtype, iters=10, key=None, summaries="split", graph=True):
     g = torch.Generator().manual_seed(1)
     q = torch.randn(B, T, H, K, generator=g).to(dtype).to(DEV).requires_grad_(True)
     k = torch.randn(B, T, H, K, generator=g).to(dtype).to(DEV).requires_grad_(True)
@@ -143,13 +143,16 @@ def causal_case(name, B, T, H, K, V, dtype, iters=10, key=None):
     mix = causal_mixing_init(n).reshape(n, n).to(DEV).requires_grad_(True)
 
     def step():
-        out = mhla_amd.mhla_causal(q, k, v, mix)
+        out = mhla_amd.mhla_causal(q, k, v, mix, summaries=summaries)
         out.backward(do)
         q.grad = k.grad = v.grad = mix.grad = None
 
     t = timeit(step, iters=iters)
     alg = 3 * B * H * T * (2 * K + 2 * V) * q.element_size()   # fwd reads q, k, v, writes o; bwd twice that
-    return _result(name, "fwd+bwd", t, B * T, alg, step, None, key)
+    r = _result(name, "fwd+bwd", t, B * T, alg, step, _graph_time(step, iters) if graph else None, key)
+    r["arithmetic"] = ("bf16 hi + lo chunk summaries and score tiles (>= 16 significand bits: the reference's fp32 arithmetic)"
+                       if summaries == "split" else "REDUCED PRECISION: single-bf16 chunk summaries and score tiles (opt-in)")
+    return r
 
 
 def run_extra_configs(full=False):
