@@ -9,8 +9,8 @@
 namespace mhla {
 namespace capi {
 
-// Resident-sequence mixing (sp::k_sp_mixr): 33 <= M <= 256 blocks, summaries in whole 256-byte row pieces.  MHLA_SP_MIX=old keeps
-// the tiled kernel (A/B).
+// Resident-sequence mixing (sp::k_sp_mixr): 33 <= M <= 256 blocks, summaries in whole 256-byte row pieces; other M: the tiled
+// kernel sp::k_sp_mix.
 template <int DT> constexpr int sp_state_threads() {
 #ifdef MHLA_SP_STATE_4WAVES
     return NTHREADS;
@@ -20,8 +20,7 @@ template <int DT> constexpr int sp_state_threads() {
 }
 template <bool S16>
 inline bool sp_mixr_ok(int M, long E) {
-    static const char* const knob = getenv("MHLA_SP_MIX");   // tuning knob, read once
-    return !(knob && knob[0] == 'o') && M > 32 && M <= 256 && E % sp::mixr_te<4, S16>() == 0;
+    return M > 32 && M <= 256 && E % sp::mixr_te<4, S16>() == 0;
 }
 template <int TRANS, bool S16>
 inline int sp_mixr(const float* W, int ldw, const void* in, void* out, int M, long E, int BH, hipStream_t st) {

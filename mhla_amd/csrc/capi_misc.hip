@@ -82,11 +82,10 @@ int mhla_lepe2d(const void* x, int64_t x_sb, int64_t x_sn, const float* w_taps, 
     LepeArgs a{x, (long)x_sb, (long)x_sn, w_taps, bias, add, (long)add_sb, (long)add_sn, y, (long)y_sb, (long)y_sn, B, pieces_len, block_len, C, K, flip ? 1 : 0};
     const long N = (long)pieces_len * pieces_len * block_len * block_len, work = N * (C / 8);
     hipStream_t st = (hipStream_t)stream;
-    // runs of four tokens: 3 x 3, 16-bit tensors, whole runs inside a block row, 16-byte aligned rows (lepe.hpp); MHLA_LEPE=old: A/B
-    static const char* const lk = getenv("MHLA_LEPE");
+    // runs of four tokens: 3 x 3, 16-bit tensors, whole runs inside a block row, 16-byte aligned rows (lepe.hpp)
     const bool al16 = !((x_sb | x_sn | y_sb | y_sn | (add ? (add_sb | add_sn) : 0)) & 7) &&
                       !(((uintptr_t)x | (uintptr_t)y | (uintptr_t)(add ? add : x)) & 15);
-    if (K == 3 && dtype != MHLA_F32 && block_len % 4 == 0 && al16 && !(lk && lk[0] == 'o')) {
+    if (K == 3 && dtype != MHLA_F32 && block_len % 4 == 0 && al16) {
         const long work4 = N / 4 * (C / 8);
         if (dtype == MHLA_BF16) RC(launch(k_lepe2d_run4<bf16_t>, dim3((unsigned)((work4 + 255) / 256), B), dim3(256), 0, st, "k_lepe2d_run4", a));
         else                    RC(launch(k_lepe2d_run4<f16_t>, dim3((unsigned)((work4 + 255) / 256), B), dim3(256), 0, st, "k_lepe2d_run4", a));

@@ -984,21 +984,26 @@ __device__ __forceinline__ void tile_signal(int* flag, int tid) {
 }
 // The wait is bounded: a flag that never arrives (a dispatch order other than the one this protocol relies on, a wrong flag index)
 // must not hang the GPU.  After TILE_WAIT_POLLS polls (~1 us each: a second or more, against tile lifetimes of ~30 us) the waiter
-// raises the launch's error word and goes on with whatever dksum holds; the host reads the word through mhla_blockmix_bwd_status
-// and reports MHLA_ELAUNCH -- an error code instead of a wedged device.
+// raises the launch's error word and reports the expiry to its whole workgroup through `lds_word` (an LDS word of the caller,
+// returned to every thread) -- the caller then poisons its dksum rows with NaN, so that the tile's dk comes out as NaN: loud in
+// the next loss / gradient-norm check without any host synchronisation.  mhla_blockmix_bwd_status is the synchronous form of
+// the same report (MHLA_ELAUNCH).
 constexpr int TILE_WAIT_POLLS = 1 << 20;
-__device__ __forceinline__ void tile_wait(int* flag, int* err, int tid) {
+__device__ __forceinline__ bool tile_wait(int* flag, int* err, int* lds_word, int tid) {
     if (tid == 0) {
-        int polls = 0;
+        int polls = 0, expired = 0;
         while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
             if (++polls > TILE_WAIT_POLLS) {
                 __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                expired = 1;
                 break;
             }
             __builtin_amdgcn_s_sleep(16);
         }
+        *lds_word = expired;
     }
     __syncthreads();
+    return *lds_word != 0;
 }
 // 16-block (TTP) tiles per (b,h) for njg groups of 8 blocks: the one place the flag array, the flag clearing and the tile
 // launches take their count from

@@ -515,6 +515,7 @@ template <int TTP>
 __device__ __forceinline__ void tile_bwd_dkv_body(const FsTokArgs& a, unsigned char* smem_raw, int wg, int nwg) {
     u16* Gt = reinterpret_cast<u16*>(smem_raw);
     float* sideK = reinterpret_cast<float*>(smem_raw + tile_gt_bytes<TTP>());   // [TTP][64]  dksum (dQ role)
+    int* wait_word = reinterpret_cast<int*>(sideK + TTP * 64);                   // (the dQ role's second side array: unused here)
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, kg = lane >> 4;
     const int L = xcd_swizzle(wg, nwg);
     const int ntt = (a.njg * IT + TTP - 1) / TTP, bh = L / ntt, jgx = L - bh * ntt, b = bh / a.H, h = bh - b * a.H;
@@ -581,8 +582,10 @@ __device__ __forceinline__ void tile_bwd_dkv_body(const FsTokArgs& a, unsigned c
         mix_tile_to_lds<TTP, 1, NBUF>(Gt, a.dstate + sofs, a.njg, a.W, a.ldw, M, jgx * TTP, tid);
         if (TTP == 8) load_a64(vvA, vb, a.v.sn, a.idx, (long)jAc * S, S, lane);
         if (a.normalize) {
-            tile_wait(a.done + L, a.err, tid);
+            const bool expired = tile_wait(a.done + L, a.err, wait_word, tid);
             side_issue<TTP, true>(sk, a.dksum + (long)bh * M * 64, 64, 64, jgx * TTP, M, tid);
+#pragma unroll
+            for (int t = 0; t < TTP / 8; ++t) sk.v[t] = expired ? __builtin_nanf("") : sk.v[t];   // (no hand-over: dk = NaN, not garbage)
             side_commit<TTP>(sideK, sk, 64, tid);
         }
         trace_mark(a.trace, 2);
@@ -604,12 +607,15 @@ __device__ __forceinline__ void tile_bwd_dkv_body(const FsTokArgs& a, unsigned c
         return;
     }
     mix_tile_to_lds<TTP, 1, NBUF>(Gt, a.dstate + sofs, a.njg, a.W, a.ldw, M, jgx * TTP, tid);
-    if (a.normalize) tile_wait(a.done + L, a.err, tid);
+    const bool expired = a.normalize ? tile_wait(a.done + L, a.err, wait_word, tid) : false;
     __syncthreads();
     for (int bi = wave; bi < TTP; bi += 8) {
         const int j = jgx * TTP + bi;
         if (j >= M) continue;
-        if (a.normalize) sideK[bi * 64 + lane] = coherent_load(a.dksum + ((long)bh * M + j) * 64 + lane);
+        if (a.normalize) {
+            const float dks = coherent_load(a.dksum + ((long)bh * M + j) * 64 + lane);
+            sideK[bi * 64 + lane] = expired ? __builtin_nanf("") : dks;
+        }
         for (int c0 = 0; c0 < S; c0 += 64) {
             const int rv = min(64, S - c0);
             bf16x8 kv[4][2], vv[4][2];

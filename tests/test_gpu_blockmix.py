@@ -633,6 +633,14 @@ def test_handover_wait_is_bounded_and_reported(monkeypatch):
     with pytest.raises(RuntimeError, match="gave up waiting"):
         out.backward(do)
     torch.cuda.synchronize()
+    # Without the synchronous check (the default: no host sync on the training path) the failure is still loud: the waiter that
+    # gave up poisons its dksum rows, so the tile's dk is NaN -- never a finite, silently wrong gradient.
+    monkeypatch.delenv("MHLA_CHECK_HANDOVER")
+    ts = [x.clone().requires_grad_(True) for x in (q, k, v, W)]
+    mhla_amd.mhla_blockmix(*ts).backward(do)
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(ts[1].grad.float()).all()), "dk of a tile whose hand-over expired must be NaN"
+    assert bool(torch.isfinite(ts[0].grad.float()).all()) and bool(torch.isfinite(ts[2].grad.float()).all())
     monkeypatch.delenv("MHLA_DEBUG_DROP_SIGNAL")
     # the next call on the same shapes is clean again (the error word is cleared per launch)
     ts = [x.clone().requires_grad_(True) for x in (q, k, v, W)]
