@@ -61,9 +61,11 @@ def make_inputs(a, device, seed):
     return q, k, v, W, do
 
 
-def cpu_baseline(a, budget_s=12.0, Bs=1):
+def cpu_baseline(a, budget_s=15.0, Bs=None):
     """The oracle (eager PyTorch restatement of the reference op sequence, fp32) timed on the host cores
-    on a bounded sample: fwd+bwd over B_s samples of the same (N, H, D, M) workload."""
+    on a bounded sample: fwd+bwd over B_s samples of the same (N, H, D, M) workload -- by default the whole per-GPU batch
+    of the step (B = 8 at C2: ~0.6 s per iteration on 64 threads, at least 5 iterations)."""
+    Bs = Bs or a.B
     from oracle import mhla_oracle as orc
     ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     torch.set_num_threads(max(1, min(ncpu, 64)))
@@ -84,7 +86,7 @@ def cpu_baseline(a, budget_s=12.0, Bs=1):
     it()   # warm-up
     times = []
     t_end = time.perf_counter() + budget_s
-    while len(times) < 3 or (time.perf_counter() < t_end and len(times) < 20):
+    while len(times) < 5 or (time.perf_counter() < t_end and len(times) < 20):
         t0 = time.perf_counter()
         it()
         times.append(time.perf_counter() - t0)

@@ -669,10 +669,23 @@ __device__ __forceinline__ f32x4 raw4_to_f32(f16_t, uint2 r) {
     return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
 }
 __device__ __forceinline__ f32x4 raw4_to_f32(float, f32x4 r) { return r; }
+// 8 fp32 values -> one 16-byte piece of a 16-bit type
+__device__ __forceinline__ uint4 pack8_16(bf16_t, f32x4 a, f32x4 b) {
+    return make_uint4(pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(b[0], b[1]), pack_bf16x2(b[2], b[3]));
+}
+__device__ __forceinline__ uint4 pack8_16(f16_t, f32x4 a, f32x4 b) {
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    const h8 h = {(_Float16)a[0], (_Float16)a[1], (_Float16)a[2], (_Float16)a[3], (_Float16)b[0], (_Float16)b[1], (_Float16)b[2], (_Float16)b[3]};
+    return __builtin_bit_cast(uint4, h);
+}
+__device__ __forceinline__ uint4 pack8_16(float, f32x4, f32x4) { return make_uint4(0, 0, 0, 0); }   // (never called: fp32 stores 16-byte pieces already)
 
 constexpr int SP_OUT_T = 512;   // 8 waves share the staged G_i: twice the loads in flight per LDS byte
 template <typename T, int DT, typename TO = T, bool EPI = false>
-__global__ __launch_bounds__(SP_OUT_T, 2) void k_sp_out(const OutArgs a) {
+#ifndef SP_OUT_EPI_WAVES
+#define SP_OUT_EPI_WAVES 2   // the fused-epilogue variant takes 142 VGPRs: one workgroup per CU without spills (157 us at C4) beats two with 28 spilled registers (163 us)
+#endif
+__global__ __launch_bounds__(SP_OUT_T, EPI ? SP_OUT_EPI_WAVES : 2) void k_sp_out(const OutArgs a) {
     constexpr int LD = mat_ld<DT>(), KST = Geo<DT>::KST, KP = KST * 32, TILE = KP * LD;
     constexpr bool LO = !std::is_same<T, bf16_t>::value;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -711,14 +724,38 @@ __global__ __launch_bounds__(SP_OUT_T, 2) void k_sp_out(const OutArgs a) {
         const float ninv = a.normalize ? ninvb[sv] : 1.f;
         TO* orow = ob + row * a.o.sn + kg * 4;
         f32x4 res[EPI ? DT + 1 : 1];
-        // gate values of this lane's features, fetched (packed) before the products: latency off the epilogue
+        // gate values of this lane's features, fetched (packed) before the products: latency off the epilogue.
+        // 16-bit activations with 16-byte aligned rows (WIDE): the epilogue runs in a STORE layout -- lane pairs (kg, kg ^ 1)
+        // swap halves of two neighbouring feature tiles, so that a lane owns 8 consecutive features (one 16-byte piece) of the
+        // token and the four lanes of a token cover 64 contiguous bytes per instruction; gate pieces are read the same way.
+        // (In the product layout a lane owns 4 features: 8-byte pieces, 32 bytes per token and instruction -- the gate read of
+        // 97 MB cost 70 us and every output line was written by four instructions.)
+        constexpr bool WIDE_T = EPI && sizeof(TO) == 2;
+        constexpr int NPAIR = DT / 2;
+        bool wide = false;
+        if constexpr (WIDE_T)
+            wide = (((reinterpret_cast<uintptr_t>(a.o.ptr) | reinterpret_cast<uintptr_t>(a.gate.ptr)) & 15) == 0) &&
+                   (((a.o.sb | a.o.sn | a.o.sh | (a.gate.ptr ? (a.gate.sb | a.gate.sn | a.gate.sh) : 0)) & 7) == 0);
+        const int podd = kg & 1, phalf = (kg >> 1) * 8;   // store layout: tile 2 j + podd, features phalf .. phalf + 7 of it
         typename Raw4<TO>::type gv[EPI ? DT : 1];
+        uint4 gv8[WIDE_T ? (NPAIR ? NPAIR : 1) : 1];
         if constexpr (EPI) {
             if (a.gate.ptr) {
-                const TO* grow = (const TO*)a.gate.ptr + b * a.gate.sb + row * a.gate.sn + h * a.gate.sh + kg * 4;
+                const TO* gtok = (const TO*)a.gate.ptr + b * a.gate.sb + row * a.gate.sn + h * a.gate.sh;
+                if (WIDE_T && wide) {
 #pragma unroll
-                for (int ct = 0; ct < DT; ++ct)
-                    if (ct * 16 + kg * 4 < D) gv[ct] = *reinterpret_cast<const typename Raw4<TO>::type*>(grow + ct * 16);
+                    for (int j = 0; j < NPAIR; ++j) {
+                        const int f0 = (2 * j + podd) * 16 + phalf;
+                        gv8[j] = gld<uint4>(gtok + (f0 < D ? f0 : 0));
+                    }
+                    if (DT & 1) {
+                        if ((DT - 1) * 16 + kg * 4 < D) gv[DT - 1] = *reinterpret_cast<const typename Raw4<TO>::type*>(gtok + kg * 4 + (DT - 1) * 16);
+                    }
+                } else {
+#pragma unroll
+                    for (int ct = 0; ct < DT; ++ct)
+                        if (ct * 16 + kg * 4 < D) gv[ct] = *reinterpret_cast<const typename Raw4<TO>::type*>(gtok + kg * 4 + ct * 16);
+                }
             }
         }
 #pragma unroll
@@ -760,9 +797,42 @@ __global__ __launch_bounds__(SP_OUT_T, 2) void k_sp_out(const OutArgs a) {
             ss += __shfl_xor(ss, 16, 64);   // the token's features live in the 4 lanes kg = 0..3
             ss += __shfl_xor(ss, 32, 64);
             const float rstd = 1.f / sqrtf(ss / (float)D + a.neps);
+            int ct_first = 0;   // tiles below it were stored in the wide layout
+            if constexpr (WIDE_T) {
+                if (wide) {
+                    TO* otok = ob + row * a.o.sn;
+#pragma unroll
+                    for (int j = 0; j < NPAIR; ++j) {
+                        const f32x4 send = podd ? res[2 * j] : res[2 * j + 1], keep = podd ? res[2 * j + 1] : res[2 * j];
+                        f32x4 recv;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) recv[i] = __shfl_xor(send[i], 16, 64);   // (every lane takes part)
+                        const f32x4 lo4 = podd ? recv : keep, hi4 = podd ? keep : recv;
+                        const int f0 = (2 * j + podd) * 16 + phalf;
+                        if (s < S && f0 < D) {
+                            f32x4 y0 = lo4 * rstd, y1 = hi4 * rstd;
+                            if (a.nw) {
+                                y0 *= *reinterpret_cast<const f32x4*>(a.nw + f0);
+                                y1 *= *reinterpret_cast<const f32x4*>(a.nw + f0 + 4);
+                            }
+                            if (a.gate.ptr) {
+                                const f32x4 g0 = raw4_to_f32(TO{}, make_uint2(gv8[j].x, gv8[j].y)), g1 = raw4_to_f32(TO{}, make_uint2(gv8[j].z, gv8[j].w));
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) {
+                                    y0[i] *= g0[i] / (1.f + __expf(-g0[i]));
+                                    y1[i] *= g1[i] / (1.f + __expf(-g1[i]));
+                                }
+                            }
+                            gst<uint4>(otok + f0, pack8_16(TO{}, y0, y1));
+                        }
+                    }
+                    ct_first = 2 * NPAIR;
+                }
+            }
             if (s < S) {
 #pragma unroll
                 for (int ct = 0; ct < DT; ++ct) {
+                    if (ct < ct_first) continue;
                     const int d0 = ct * 16 + kg * 4;
                     if (d0 < D) {
                         f32x4 y = res[ct] * rstd;

@@ -163,15 +163,19 @@ def run_extra_configs(full=False):
     out.append(blockmix_case("C3 DiT-XL/2 256^2 op B=32 N=256 H=16 D=72 M=16 fp32", 32, 256, 16, 72, 16, f32, (4, 4), graph=True, key="c3f"))
     idx = block_index_3d((21, 30, 50), (3, 5, 10)).to(DEV)
     out.append(blockmix_case("C4 Wan2.1-1.3B fwd B=1 N=31500 H=12 D=128 M=150 fp32, un-normalised (shipped YAML)", 1, 31500, 12, 128, 150,
-                             f32, (3, 5, 10), bwd=False, split=False, idx=idx, normalize=False))
+                             f32, (3, 5, 10), bwd=False, split=False, idx=idx, normalize=False, graph=True))
     out.append(blockmix_case("C4 Wan2.1-1.3B fwd B=1 N=31500 H=12 D=128 M=150 fp32, normalised split q/k", 1, 31500, 12, 128, 150,
-                             f32, (3, 5, 10), bwd=False, split=True, idx=idx))
+                             f32, (3, 5, 10), bwd=False, split=True, idx=idx, graph=True))
     out.append(blockmix_case("C4 Wan2.1-1.3B fwd+bwd B=1 N=31500 H=12 D=128 M=150 fp32, normalised split q/k", 1, 31500, 12, 128, 150,
-                             f32, (3, 5, 10), bwd=True, split=True, idx=idx, iters=10, key="c4b"))
+                             f32, (3, 5, 10), bwd=True, split=True, idx=idx, iters=10, key="c4b", graph=True))
     out.append(causal_case("C5 fla 340M causal B=4 T=8192 H=4 K=128 V=256 bf16", 4, 8192, 4, 128, 256, bf, key="c5"))
     out.append(causal_case("C5 1.3B-like causal B=2 T=8192 H=4 K=256 V=512 bf16", 2, 8192, 4, 256, 512, bf, key="c5b"))
-    out.append(blockmix_case("C2 variant M=16 S=256 bf16", 8, 4096, 16, 64, 16, bf, (4, 4)))
-    out.append(blockmix_case("C2 variant M=256 S=16 bf16", 8, 4096, 16, 64, 256, bf, (16, 16), iters=10, key="c2b"))
+    # the opt-in reduced-precision variant of the causal operator (single-bf16 chunk summaries: round 3's arithmetic), for
+    # comparison only -- the lines above are the numbers of record
+    out.append(causal_case("C5 fla 340M causal B=4 T=8192 H=4 K=128 V=256 bf16 [reduced_precision: summaries=bf16]", 4, 8192, 4, 128, 256, bf,
+                           summaries="bf16"))
+    out.append(blockmix_case("C2 variant M=16 S=256 bf16", 8, 4096, 16, 64, 16, bf, (4, 4), graph=True))
+    out.append(blockmix_case("C2 variant M=256 S=16 bf16", 8, 4096, 16, 64, 256, bf, (16, 16), iters=10, key="c2b", graph=True))
     if full:
         out.append(blockmix_case("DiT-S/2-shaped op B=32 N=256 H=6 D=64 M=16 bf16", 32, 256, 6, 64, 16, bf, (4, 4), graph=True))
         out.append(blockmix_case("DiT-XL/2 512^2 op B=16 N=1024 H=16 D=72 M=16 bf16", 16, 1024, 16, 72, 16, bf, (4, 4)))

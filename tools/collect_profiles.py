@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""gpurun_out/r3prof/* (tools/prof_all.sh) -> profiles/r3_<shape>_trace.md, profiles/r3_<shape>_pmc.md and
+"""gpurun_out/r4prof/* (tools/prof_all.sh) -> profiles/r3_<shape>_trace.md, profiles/r3_<shape>_pmc.md and
 profiles/r3_pmc_traffic.json: {csrc_sha16, shapes: {<shape>: {hbm_bytes_per_step, read, write, kernels: [...]}}} -- the file
 bench.py / tools/bench_configs.py take `roofline.traffic` from when it was made from the kernel sources the library was built from."""
 import glob
@@ -9,9 +9,9 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(ROOT, "gpurun_out", "r3prof")
+src = os.path.join(ROOT, "gpurun_out", "r4prof")
 dst = os.path.join(ROOT, "profiles")
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r3"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r4"
 out = {"shapes": {}}
 for js in sorted(glob.glob(os.path.join(src, "*_pmc.json"))):
     shape = os.path.basename(js)[:-len("_pmc.json")]

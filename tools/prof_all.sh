@@ -1,11 +1,11 @@
 #!/bin/bash
 # Round-end evidence for every BASELINE.json shape: rocprofv3 --kernel-trace --stats and the PMC passes (FETCH_SIZE / WRITE_SIZE,
 # SQ busy / wait, MFMA busy, LDS conflicts -- separate runs, counters only) of bench.py (C2) and of tools/run_shape.py for
-# c3 c3f c4b c5 c5b c2b  ->  gpurun_out/r3prof/<shape>_{trace,pmc}.md and <shape>_pmc.json (copied to profiles/r3_* afterwards).
+# c3 c3f c4b c5 c5b c2b  ->  gpurun_out/r4prof/<shape>_{trace,pmc}.md and <shape>_pmc.json (copied to profiles/r4_* afterwards).
 #   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash tools/prof_all.sh'            SHAPES="c5 c5b" limits the set
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-OUT=$ROOT/gpurun_out/r3prof
+OUT=$ROOT/gpurun_out/r4prof
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 for s in ${SHAPES:-c2 c3 c3f c4b c5 c5b c2b}; do
@@ -19,7 +19,7 @@ for s in ${SHAPES:-c2 c3 c3f c4b c5 c5b c2b}; do
     PMC_SCRIPT="tools/run_shape.py" bash "$ROOT/tools/pmc_run.sh" "$OUT/$s.pmc" $s 3 > /dev/null 2>&1
   fi
   db=$(find "$OUT/$s.trace" -name "*.db" | head -1)
-  python3 "$ROOT/tools/rocprof_summary.py" "$db" "$OUT/${s}_trace.md" "$title, round-3 code" > /dev/null 2>&1
+  python3 "$ROOT/tools/rocprof_summary.py" "$db" "$OUT/${s}_trace.md" "$title, round-4 code" > /dev/null 2>&1
   python3 "$ROOT/tools/pmc_summary.py" "$OUT/$s.pmc" --md "$OUT/${s}_pmc.md" --json "$OUT/${s}_pmc.json" > /dev/null 2>&1
   rm -rf "$OUT/$s.trace" "$OUT/$s.pmc"
   echo "== $s"; tail -2 "$OUT/${s}_pmc.md"

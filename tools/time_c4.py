@@ -23,8 +23,14 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     idx = block_index_3d((21, 30, 50), (3, 5, 10)).to(DEV)
     lib = mhla_amd._lib.load()
     out = {}
+    # the Wan layer's inference epilogue (wan/mhla_utils.py:356-362): fused into the output kernel vs the unfused composition
+    gate = torch.randn(B, N, H, D, generator=g).to(torch.bfloat16).to(DEV)
+    nw = (torch.rand(D, generator=g) + 0.5).to(DEV)
+    fused = lambda: mhla_amd.mhla_blockmix_wan(q, k, v, W, None, None, nw, 1e-6, gate, torch.bfloat16, normalize=False, block_index=idx)
+    unfused = lambda: mhla_amd.rmsnorm_gate(mhla_amd.mhla_blockmix(q, k, v, W, normalize=False, block_index=idx).to(torch.bfloat16), gate, nw, 1e-6)
     for name, fn in (("plain", lambda: mhla_amd.mhla_blockmix(q, k, v, W, normalize=False, block_index=idx)),
-                     ("split", lambda: mhla_amd.mhla_blockmix(q, k, v, W, q_den=qd, k_den=kd, block_index=idx))):
+                     ("split", lambda: mhla_amd.mhla_blockmix(q, k, v, W, q_den=qd, k_den=kd, block_index=idx)),
+                     ("wanfused", fused), ("unfused", unfused)):
         with torch.no_grad():
             for _ in range(3):
                 fn()
@@ -40,6 +46,15 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
         for line in buf.value.decode().splitlines():
             nm, cnt, tot = line.rsplit(" ", 2)
             ks[nm] = float(tot) / int(cnt) * 1e3
+        if name in ("wanfused", "unfused"):   # wall time per call (the unfused path has a torch cast kernel the hook does not see)
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            with torch.no_grad():
+                ev0.record()
+                for _ in range(10):
+                    fn()
+                ev1.record()
+            torch.cuda.synchronize()
+            ks["WALL_us_per_call"] = ev0.elapsed_time(ev1) * 100.0
         out[name] = ks
     print(json.dumps(out))
     sys.exit(0)
@@ -55,4 +70,4 @@ for nm in ["shipped"] + names:
         print(nm, "FAILED", r.stderr[-300:])
         continue
     for case, ks in j.items():
-        print(f"{nm:14s} {case:6s} total {sum(ks.values()):7.1f}  " + "  ".join(f"{k}={v:.1f}" for k, v in ks.items()))
+        print(f"{nm:14s} {case:8s} kernels {sum(v for k, v in ks.items() if k != 'WALL_us_per_call'):7.1f}  " + "  ".join(f"{k}={v:.1f}" for k, v in ks.items()))
