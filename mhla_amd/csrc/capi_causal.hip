@@ -111,12 +111,9 @@ int cs_fwd16(const mhla_view& q, const mhla_view& k, const mhla_view& v, const f
     RC(cs_state16<HL>(k, v, (uint16_t*)w.S, 1.f, B, T, H, n, K, V, st));
     RC(cs_mix_fwd<HL>(mix, ldmix, (const uint16_t*)w.S, (uint16_t*)w.P, B * H, n, E, st));
     CsOutArgs o{cv(q), cv(k), cv(v), cmv(out), mix, ldmix, w.P, H, n, K, V, (long)T, scale, cmv(y), cv(gate), nw, neps};
-    // V slices per workgroup: the largest of 4 (single-bf16 summaries only: hi + lo pairs at four slices need more than the 128
-    // VGPRs of two workgroups per CU), 3, 2, 1 that divides V / 64 (the fused epilogue owns the head: V / 64 <= 4)
-#ifndef CSF_OUT4_HL_NV4
-#define CSF_OUT4_HL_NV4 0   // A/B switch (tools/build_variant.sh): 1 = four slices per workgroup with hi + lo pairs too (one workgroup per CU)
-#endif
-    const int nvs = V / 64, nv = ((!HL || CSF_OUT4_HL_NV4) && nvs % 4 == 0) ? 4 : nvs % 3 == 0 ? 3 : nvs % 2 == 0 ? 2 : 1;
+    // V slices per workgroup: the largest of 4, 3, 2, 1 that divides V / 64 (the fused epilogue owns the head: V / 64 <= 4); the
+    // more slices, the fewer times a chunk's Q and K rows and its score tile are fetched / formed
+    const int nvs = V / 64, nv = nvs % 4 == 0 ? 4 : nvs % 3 == 0 ? 3 : nvs % 2 == 0 ? 2 : 1;
 #define OUT4(NV, EPI) launch(fast::k_csf_out4<NV, EPI, HL>, dim3(EPI ? n : (n + fast::CSF_OUT4_CPW - 1) / fast::CSF_OUT4_CPW, B * H, nvs / NV), dim3(fast::NT4), fast::csf_out4_smem<NV, EPI, HL>(), st, EPI ? "k_csf_out4<norm>" : "k_csf_out4", o)
     if (epi) RC(nvs == 1 ? OUT4(1, true) : nvs == 2 ? OUT4(2, true) : nvs == 3 ? OUT4(3, true) : OUT4(4, true));
     else     RC(nv == 1 ? OUT4(1, false) : nv == 2 ? OUT4(2, false) : nv == 3 ? OUT4(3, false) : OUT4(4, false));

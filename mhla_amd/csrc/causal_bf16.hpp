@@ -366,7 +366,10 @@ __host__ __device__ constexpr int csf_out4_smem() { return (4 + 2 * (HL ? 2 : 1)
 // (HL with four V slices per workgroup -- the fused epilogue at V = 256 -- holds 32 ring and 32 accumulator registers beside the
 //  operands: one workgroup per CU on 256 VGPRs instead of 20 spilled registers at 128)
 template <int NV, bool EPI, bool HL>
-__global__ __launch_bounds__(NT4, (HL && NV == 4) ? 2 : 4) void k_csf_out4(const CsOutArgs a) {
+#ifndef CSF_OUT4_NV4_WAVES
+#define CSF_OUT4_NV4_WAVES 4   // four slices with hi + lo pairs: two workgroups per CU at 128 VGPRs and 4 spilled registers (98 us at C5)
+#endif                         // beat one workgroup at 134 (107 us) and two slices per workgroup, which read Q and K twice (108-112 us)
+__global__ __launch_bounds__(NT4, (HL && NV == 4) ? (EPI ? 2 : CSF_OUT4_NV4_WAVES) : 4) void k_csf_out4(const CsOutArgs a) {
     constexpr int P = HL ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u16* Qs = reinterpret_cast<u16*>(smem_raw);

@@ -33,7 +33,25 @@ typedef unsigned short u16;
 constexpr int FD = 64;         // head dim
 constexpr int FE = FD * FD;    // elements of one block summary
 constexpr int TLD = 80;        // LDS row stride (bf16) of [rows][64] token tiles read with ds_read_b64_tr_b16
-constexpr int GLD = 72;        // LDS row stride (bf16) of the mixed summaries Gt[i][d2][d1]
+constexpr int GLD = 64;        // LDS row stride (bf16) of the mixed summaries Gt[i][d2][d1]: unpadded 128-byte rows, 16-byte pieces XOR-swizzled (gt_off)
+// Layout of a mixed-summary slot / staging tile [64 rows][64 columns] bf16 (round 4).  gfx950's LDS has 64 banks and services a
+// wave in instruction-specific lane groups (MI355X_MICROARCH.md, LDS): under that model the round-1 layout (rows of 72 elements,
+// derived for 32 banks) was 2-way conflicted in EVERY access pattern of the tile kernels -- the 16-byte operand reads, the
+// transpose reads, the 8-byte mixing / staging writes and the 16-byte store reads (tools/lds_conflicts.py reproduces the
+// counters' 0.45-0.49).  Rows are now unpadded and the 16-byte piece p of row r is stored at piece p ^ ((r ^ (r >> 1)) & 7):
+// all four read patterns and the (now 16-byte) write patterns are conflict-free in the same model.
+__device__ __forceinline__ int gt_off(int row, int col) {
+    return row * GLD + ((((col >> 3) ^ ((row ^ (row >> 1)) & 7)) << 3) | (col & 7));
+}
+// The swizzled addresses are functions of the lane that hipcc would otherwise compute at kernel entry and carry (in the 256-VGPR
+// tile kernels: spill) across the mixing phase: the helpers that use them launder the lane number first, so the address
+// arithmetic (a handful of VALU operations) is redone where it is used.
+__device__ __forceinline__ int opaque_lane(int lane) {
+    asm volatile("" : "+v"(lane));
+    return lane;
+}
+// transpose read of tr_read8 from a swizzled slot: lane (c = lane & 15, g = lane >> 4) receives T[k0 + 8 g + 0..7][c0 + c]
+__device__ __forceinline__ bf16x8 tr_read8_gt(const u16* tile, int k0, int c0, int lane);
 constexpr int IT = 8;          // blocks per workgroup tile (= interleave factor of the state layout)
 constexpr int FT = 256;        // threads per workgroup of the small kernels
 constexpr int FT8 = 512;       // 8-wave workgroups of the streaming kernels: <= 128 VGPRs -> 16 waves per CU in flight
@@ -55,6 +73,25 @@ __device__ __forceinline__ bf16x8 tr_read8(const u16* tile, int ld, int k0, int 
     r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
     r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
     return __builtin_bit_cast(bf16x8, r);
+}
+
+__device__ __forceinline__ bf16x8 tr_read8_gt(const u16* tile, int k0, int c0, int lane) {
+    const int g = lane >> 4, li = lane & 15, row = k0 + g * 8 + (li >> 2), col = c0 + (li & 3) * 4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_S16X4(tile + gt_off(row, col)));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_S16X4(tile + gt_off(row + 4, col)));
+    s16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return __builtin_bit_cast(bf16x8, r);
+}
+// Two packed 8-byte results (4 columns each) of neighbouring column tiles a, b -> one 16-byte piece per lane: lane pairs
+// (kg, kg ^ 1) swap halves (v_permlane16_swap: odd rows of the first operand <-> even rows of the second), after which lane kg
+// holds columns 8 (kg >> 1) .. + 7 of tile (kg & 1 ? b : a).  8-byte LDS stores of 16 lanes with one column are 2-way
+// conflicted whatever the layout; the 16-byte ones are conflict-free.
+__device__ __forceinline__ uint4 pair_pieces(uint2 a, uint2 b) {
+    const auto x = __builtin_amdgcn_permlane16_swap(a.x, b.x, false, false);
+    const auto y = __builtin_amdgcn_permlane16_swap(a.y, b.y, false, false);
+    return make_uint4(x[0], y[0], x[1], y[1]);
 }
 
 __device__ __forceinline__ uint4 relu_eps8(uint4 v, float eps) {
@@ -726,12 +763,13 @@ __device__ __forceinline__ void store64(u16* __restrict__ base, long sn, const i
 #ifdef T16_NOSTORE
     if (rv != 12345) return;
 #endif
+    const int lane_o = opaque_lane(lane);
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
         const int row = p * 8 + (lane >> 3), c = (lane & 7) * 8;
         if (row < rv) {
             const long tr = tok_row(idx, p0 + row);
-            uint4 v = *reinterpret_cast<const uint4*>(Os + row * GLD + c);
+            uint4 v = *reinterpret_cast<const uint4*>(Os + gt_off(p * 8 + (lane_o >> 3), (lane_o & 7) * 8));
             if (MASK) v = mask_pos8(v, *reinterpret_cast<const uint4*>(mbase + tr * msn + c));
             if (STREAM) gst_stream16(base + tr * sn + c, v);
             else        gst<uint4>(base + tr * sn + c, v);

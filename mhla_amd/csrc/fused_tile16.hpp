@@ -14,7 +14,7 @@
 namespace mhla {
 namespace fast {
 
-constexpr int GSLOT = FD * GLD + 8;                  // elements per mixed-summary slot (+16 B: spreads the blocks over banks)
+constexpr int GSLOT = FD * GLD + 8;                  // elements per mixed-summary slot (+16 B: the 16-byte mixing stores of 8 lanes = 8 blocks cover all banks)
 // LDS: the tile's mixed summaries, then three [TTP][64] fp32 arrays of per-block side values (1 / n, dz, ksum or dksum)
 template <int TTP> constexpr int tile_gt_bytes() { return TTP * GSLOT * 2; }
 template <int TTP> constexpr int tile_smem() { return tile_gt_bytes<TTP>() + 3 * TTP * 64 * 4; }   // 160000 B (16) / 80000 B (8)
@@ -97,17 +97,29 @@ __device__ __forceinline__ void mix_tile_impl(u16* __restrict__ Gt, const u16* _
                 for (int u = 0; u < UN; ++u) c[u] = mfma_bf16(__builtin_bit_cast(bf16x8, av[u][1]), blo[1], c[u]);
             }
         }
+        uint2 pk[UN];
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             if (HL) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) c[u][r] += dpp_row_ror8(c[u][r]);   // hi part (column nb) + lo part (column nb + 8)
             }
-            const int et = (wave + NW * bt) * UN + u, d2 = et >> 2, d1 = (et & 3) * 16 + kg * 4;
-            uint2 pk;
-            pk.x = pack_bf16x2(c[u][0], c[u][1]);
-            pk.y = pack_bf16x2(c[u][2], c[u][3]);
-            if (!HL || n < 8) *reinterpret_cast<uint2*>(Gt + (long)nb * GSLOT + d2 * GLD + d1) = pk;
+            pk[u].x = pack_bf16x2(c[u][0], c[u][1]);
+            pk[u].y = pack_bf16x2(c[u][2], c[u][3]);
+        }
+        if constexpr (!HL && UN % 2 == 0) {
+            // element tiles et = (wave + NW bt) UN + u: with UN = 4 the batch is the four column tiles of summary row d2
+#pragma unroll
+            for (int u = 0; u < UN; u += 2) {
+                const int et = (wave + NW * bt) * UN + u + (kg & 1), d2 = et >> 2, d1 = (et & 3) * 16 + (kg >> 1) * 8;
+                *reinterpret_cast<uint4*>(Gt + (long)nb * GSLOT + gt_off(d2, d1)) = pair_pieces(pk[u], pk[u + 1]);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int et = (wave + NW * bt) * UN + u, d2 = et >> 2, d1 = (et & 3) * 16 + kg * 4;
+                if (!HL || n < 8) *reinterpret_cast<uint2*>(Gt + (long)nb * GSLOT + gt_off(d2, d1)) = pk[u];
+            }
         }
     };
 #pragma unroll
@@ -163,13 +175,14 @@ __device__ __forceinline__ void relu_a64(bf16x8 (&a)[4][2], float eps) {
 // per-column terms (ksum, dksum) are 16-byte reads.
 template <bool TRB>
 __device__ __forceinline__ void chunk_times_gt(f32x4 (&acc)[4][4], const bf16x8 (&a)[4][2], const u16* __restrict__ Gb, int lane) {
+    lane = opaque_lane(lane);
     const int n = lane & 15, kg = lane >> 4;
 #pragma unroll
     for (int tn = 0; tn < 4; ++tn) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            const bf16x8 bv = TRB ? tr_read8(Gb, GLD, ks * 32, tn * 16, lane)
-                                  : *reinterpret_cast<const bf16x8*>(Gb + (tn * 16 + n) * GLD + ks * 32 + kg * 8);
+            const bf16x8 bv = TRB ? tr_read8_gt(Gb, ks * 32, tn * 16, lane)
+                                  : *reinterpret_cast<const bf16x8*>(Gb + gt_off(tn * 16 + n, ks * 32 + kg * 8));
 #pragma unroll
             for (int st = 0; st < 4; ++st) acc[st][tn] = mfma_bf16(bv, a[st][ks], acc[st][tn]);
         }
@@ -183,21 +196,26 @@ __device__ __forceinline__ void zero_acc(f32x4 (&acc)[4][4]) {
 }
 __device__ __forceinline__ uint2 pack4(const f32x4& v) { return make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])); }
 
-// Wave-private staging of a 64 x 64 result in the transposed-product layout, as bf16 rows of GLD stride (conflict-free 8-byte stores)
-__device__ __forceinline__ void stage64(u16* __restrict__ Os, const f32x4 (&acc)[4][4], int lane) {
-    const int n = lane & 15, kg = lane >> 4;
-#pragma unroll
-    for (int st = 0; st < 4; ++st)
-#pragma unroll
-        for (int tn = 0; tn < 4; ++tn) *reinterpret_cast<uint2*>(Os + (st * 16 + n) * GLD + tn * 16 + kg * 4) = pack4(acc[st][tn]);
-}
-// the same from results kept packed
+// Wave-private staging of a 64 x 64 result in the transposed-product layout as bf16 rows of a swizzled slot (gt_off): neighbouring
+// column tiles are paired into 16-byte pieces (pair_pieces) -- 8 conflict-free 16-byte stores per block instead of 16 two-way
+// conflicted 8-byte ones.
 __device__ __forceinline__ void stage64_packed(u16* __restrict__ Os, const uint2 (&pv)[4][4], int lane) {
+    lane = opaque_lane(lane);
     const int n = lane & 15, kg = lane >> 4;
 #pragma unroll
     for (int st = 0; st < 4; ++st)
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn) *reinterpret_cast<uint2*>(Os + (st * 16 + n) * GLD + tn * 16 + kg * 4) = pv[st][tn];
+        for (int tn = 0; tn < 4; tn += 2)
+            *reinterpret_cast<uint4*>(Os + gt_off(st * 16 + n, (tn + (kg & 1)) * 16 + (kg >> 1) * 8)) = pair_pieces(pv[st][tn], pv[st][tn + 1]);
+}
+__device__ __forceinline__ void stage64(u16* __restrict__ Os, const f32x4 (&acc)[4][4], int lane) {
+    lane = opaque_lane(lane);
+    const int n = lane & 15, kg = lane >> 4;
+#pragma unroll
+    for (int st = 0; st < 4; ++st)
+#pragma unroll
+        for (int tn = 0; tn < 4; tn += 2)
+            *reinterpret_cast<uint4*>(Os + gt_off(st * 16 + n, (tn + (kg & 1)) * 16 + (kg >> 1) * 8)) = pair_pieces(pack4(acc[st][tn]), pack4(acc[st][tn + 1]));
 }
 // zero the bf16 lanes of v where the corresponding element of m is <= 0 (relu gradient mask), 4 elements
 __device__ __forceinline__ uint2 mask_pos4(uint2 v, uint2 m) {
