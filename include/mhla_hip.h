@@ -218,7 +218,8 @@ int mhla_causal_fwd(mhla_view q, mhla_view k, mhla_view v, const float* mix, int
  * mhla_nlp/fla/modules/fused_norm_gate.py:77-99).  `out` (the operator's own output o) is optional: a NULL ptr skips its
  * store (inference); training passes it so that the norm's backward (mhla_rmsnorm_gate_bwd) has its input.  `gate` ptr NULL:
  * no gate; `norm_w` NULL: no affine weight.  Covers what mhla_causal_normgate_fusable() reports (bf16 tensors, K % 64 == 0,
- * K <= 256, V % 64 == 0, V <= 256 -- one workgroup owns a head's channels --, at most 128 chunks); otherwise MHLA_ENOTSUP and
+ * K <= 256, V % 64 == 0 with V <= 256 or V = 384 / 512 -- one workgroup owns a head's channels, the wide heads in two halves --,
+ * at most 128 chunks); otherwise MHLA_ENOTSUP and
  * the caller runs mhla_causal_fwd + mhla_rmsnorm_gate_fwd.  Workspace: as mhla_causal_fwd (usable as `fwd_ws` of
  * mhla_causal_bwd with the same flags). */
 int mhla_causal_normgate_fusable(int T, int K, int V, int chunk, int dtype, unsigned flags);

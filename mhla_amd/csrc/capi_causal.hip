@@ -46,6 +46,9 @@ Mix2Plan mix2_plan(size_t bh, int n, long E, bool bwd, bool hl) {
     p.wgs = (int)((p.total + p.spw - 1) / p.spw);
     return p;
 }
+// head widths the fused norm x gate epilogue covers: one workgroup owns a head's V channels -- up to four 64-wide slices at once,
+// or two halves of three / four slices (V = 384, 512) with the first half's outputs parked in LDS
+bool cs_epi_ok(const CsPath& path, int V) { return path.pipe16 && (V <= 256 || V == 384 || V == 512); }
 CsWs cs_carve(void* ws, int B, int T, int H, int K, int V, int chunk, const CsPath& path) {
     // (16-bit pipeline: bf16 planes with the per-chunk padding of cs_chunk_stride)
     const size_t bh = (size_t)B * H, n = (size_t)(T + chunk - 1) / chunk;
@@ -115,9 +118,12 @@ int cs_fwd16(const mhla_view& q, const mhla_view& k, const mhla_view& v, const f
     // more slices, the fewer times a chunk's Q and K rows and its score tile are fetched / formed
     const int nvs = V / 64, nv = nvs % 4 == 0 ? 4 : nvs % 3 == 0 ? 3 : nvs % 2 == 0 ? 2 : 1;
 #define OUT4(NV, EPI) launch(fast::k_csf_out4<NV, EPI, HL>, dim3(EPI ? n : (n + fast::CSF_OUT4_CPW - 1) / fast::CSF_OUT4_CPW, B * H, nvs / NV), dim3(fast::NT4), fast::csf_out4_smem<NV, EPI, HL>(), st, EPI ? "k_csf_out4<norm>" : "k_csf_out4", o)
-    if (epi) RC(nvs == 1 ? OUT4(1, true) : nvs == 2 ? OUT4(2, true) : nvs == 3 ? OUT4(3, true) : OUT4(4, true));
+#define OUT4H2(NV) launch(fast::k_csf_out4<NV, true, HL, 2>, dim3(n, B * H, 1), dim3(fast::NT4), fast::csf_out4_smem<NV, true, HL, 2>(), st, "k_csf_out4<norm,2>", o)
+    if (epi && nvs > 4) RC(nvs == 6 ? OUT4H2(3) : OUT4H2(4));   // V = 384, 512: the head in two halves (cs_epi_ok)
+    else if (epi) RC(nvs == 1 ? OUT4(1, true) : nvs == 2 ? OUT4(2, true) : nvs == 3 ? OUT4(3, true) : OUT4(4, true));
     else     RC(nv == 1 ? OUT4(1, false) : nv == 2 ? OUT4(2, false) : nv == 3 ? OUT4(3, false) : OUT4(4, false));
 #undef OUT4
+#undef OUT4H2
     return MHLA_OK;
 }
 
@@ -158,9 +164,9 @@ int cs_fwd_impl(mhla_view q, mhla_view k, mhla_view v, const float* mix, int ldm
     if (!epi || out.ptr) CHECK_VIEW(out);
     const CsPath path = cs_path(T, K, V, chunk, dtype, flags);
     if (epi) {
-        if (!path.pipe16 || V > 256)
-            return fail(MHLA_ENOTSUP, "fused norm x gate epilogue needs bf16 tensors, K %% 64 == 0, K <= 256, V %% 64 == 0, V <= 256 and "
-                        "at most 128 chunks (T=%d K=%d V=%d dtype=%d flags=0x%x)", T, K, V, dtype, flags);
+        if (!cs_epi_ok(path, V))
+            return fail(MHLA_ENOTSUP, "fused norm x gate epilogue needs bf16 tensors, K %% 64 == 0, K <= 256, V %% 64 == 0, V <= 256 or "
+                        "V = 384 / 512, and at most 128 chunks (T=%d K=%d V=%d dtype=%d flags=0x%x)", T, K, V, dtype, flags);
         const mhla_view yv{y.ptr, y.sb, y.sn, y.sh};
         if (!view_ok16(yv) || (gate.ptr && !view_ok16(gate)) || (out.ptr && !view_ok16m(out)))
             return fail(MHLA_EINVAL, "fused norm x gate epilogue: y, gate and out must be 16-byte aligned views (strides multiples of 8)");
@@ -202,7 +208,7 @@ size_t mhla_causal_bwd_ws_bytes(int B, int T, int H, int K, int V, int chunk, in
     return cs_carve(nullptr, B, T, H, K, V, chunk, cs_path(T, K, V, chunk, dtype, flags)).total_bwd;
 }
 int mhla_causal_normgate_fusable(int T, int K, int V, int chunk, int dtype, unsigned flags) {
-    return cs_path(T, K, V, chunk, dtype, flags).pipe16 && V <= 256 ? 1 : 0;
+    return cs_epi_ok(cs_path(T, K, V, chunk, dtype, flags), V) ? 1 : 0;
 }
 
 int mhla_causal_fwd(mhla_view q, mhla_view k, mhla_view v, const float* mix, int ldmix, mhla_mview out, void* ws,

@@ -360,17 +360,22 @@ __global__ __launch_bounds__(NT4, (NK <= 2 && !HL) ? 4 : 2) void k_csf_bwd_tok4(
 #define CSF_OUT4_CPW_ 4
 #endif
 constexpr int CSF_OUT4_CPW = CSF_OUT4_CPW_;   // chunks per workgroup of k_csf_out4 (plain variant)
-template <int NV, bool EPI, bool HL>
-__host__ __device__ constexpr int csf_out4_smem() { return (4 + 2 * (HL ? 2 : 1)) * CT * 2 + (EPI ? 2 * 64 * 4 : 0); }
+// NH: halves of the head's V channels that one workgroup of the fused-epilogue variant walks (V = 64 NV NH): with NH = 2 (V = 512)
+// the first half's outputs wait as fp32 in an LDS stash (64 KB) until the row sums of squares of the whole head are known.
+template <int NV, bool EPI, bool HL, int NH = 1>
+__host__ __device__ constexpr int csf_out4_smem() {
+    return (4 + 2 * (HL ? 2 : 1)) * CT * 2 + (EPI ? 2 * 64 * 4 : 0) + (NH > 1 ? (NH - 1) * 64 * 64 * NV * 4 : 0);
+}
 
 // (HL with four V slices per workgroup -- the fused epilogue at V = 256 -- holds 32 ring and 32 accumulator registers beside the
 //  operands: one workgroup per CU on 256 VGPRs instead of 20 spilled registers at 128)
-template <int NV, bool EPI, bool HL>
+template <int NV, bool EPI, bool HL, int NH = 1>
 #ifndef CSF_OUT4_NV4_WAVES
 #define CSF_OUT4_NV4_WAVES 4   // four slices with hi + lo pairs: two workgroups per CU at 128 VGPRs and 4 spilled registers (98 us at C5)
 #endif                         // beat one workgroup at 134 (107 us) and two slices per workgroup, which read Q and K twice (108-112 us)
-__global__ __launch_bounds__(NT4, (HL && NV == 4) ? (EPI ? 2 : CSF_OUT4_NV4_WAVES) : 4) void k_csf_out4(const CsOutArgs a) {
+__global__ __launch_bounds__(NT4, NH > 1 ? 2 : (HL && NV == 4) ? (EPI ? 2 : CSF_OUT4_NV4_WAVES) : 4) void k_csf_out4(const CsOutArgs a) {   // (NH > 1: 138 KB of LDS, one workgroup per CU anyway)
     constexpr int P = HL ? 2 : 1;
+    static_assert(NH == 1 || EPI, "only the fused-epilogue variant walks several halves of the head");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u16* Qs = reinterpret_cast<u16*>(smem_raw);
     u16* Ks = Qs + 2 * CT;
@@ -379,13 +384,17 @@ __global__ __launch_bounds__(NT4, (HL && NV == 4) ? (EPI ? 2 : CSF_OUT4_NV4_WAVE
     const int rt = wave & 3, ch = wave >> 2;
     constexpr int CPW = EPI ? 1 : CSF_OUT4_CPW;
     const int c0 = blockIdx.x * CPW, c1 = min(a.n, c0 + CPW), bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
-    const int vbase = blockIdx.z * 64 * NV;
     const int V = a.V, nks = a.K / 64;
     const u16* qb = (const u16*)a.q.ptr + b * a.q.sb + h * a.q.sh;
     const u16* kb = (const u16*)a.k.ptr + b * a.k.sb + h * a.k.sh;
+    const long CSZ = cs_chunk_stride(a.K, V, P);
+    float ss[4] = {0.f, 0.f, 0.f, 0.f};   // (EPI) row sums of squares over the halves walked so far
+#pragma unroll 1
+    for (int hv = 0; hv < NH; ++hv) {
+    const int vbase = (NH > 1 ? hv : (int)blockIdx.z) * 64 * NV;
     const u16* vb = (const u16*)a.v.ptr + b * a.v.sb + h * a.v.sh + vbase;
     u16* ob = (u16*)a.o.ptr + b * a.o.sb + h * a.o.sh + vbase;
-    const long CSZ = cs_chunk_stride(a.K, V, P);
+    if (hv > 0) __syncthreads();   // the previous half's V tiles and score tile are dead
     const int tr = tid >> 3, tc = (tid & 7) * 8;
     // the thread's token row in chunk c (rows past the sequence: the chunk's first row, zeroed on commit)
     auto row_of = [&](int c) { const long p = (long)c * CS; return p + (tr < (int)min((long)CS, a.T - p) ? tr : 0); };
@@ -481,6 +490,7 @@ __global__ __launch_bounds__(NT4, (HL && NV == 4) ? (EPI ? 2 : CSF_OUT4_NV4_WAVE
         }
     } else {
         float* red = reinterpret_cast<float*>(Ps + 2 * P * CT);   // [2 column halves][64 rows] sums of squares
+        float* stash = red + 2 * 64;                               // NH > 1: [NH - 1][NV][2][4][512 threads] fp32 outputs of earlier halves
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             u16* Vc = Ks + (j & 1) * CT;
@@ -490,7 +500,6 @@ __global__ __launch_bounds__(NT4, (HL && NV == 4) ? (EPI ? 2 : CSF_OUT4_NV4_WAVE
             for (int p = 0; p < P; ++p) tile_mma8<false, true>(accO[j], Ao + p * CT, Vc, rt, ch, lane);
         }
         // row sums of squares over the head's V channels: lane holds rows 16 rt + 4 kg + r, columns 64 j + 32 ch + 16 tn + n
-        float ss[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < NV; ++j)
 #pragma unroll
@@ -500,6 +509,15 @@ __global__ __launch_bounds__(NT4, (HL && NV == 4) ? (EPI ? 2 : CSF_OUT4_NV4_WAVE
                     const float x = a.scale * accO[j][tn][r];
                     ss[r] += x * x;
                 }
+        if (hv + 1 < NH) {   // (uniform) more of the head to come: this half's outputs wait in the stash (every thread its own values)
+#pragma unroll
+            for (int j = 0; j < NV; ++j)
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) stash[(((hv * NV + j) * 2 + tn) * 4 + r) * NT4 + tid] = accO[j][tn][r];
+            continue;
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float x = ss[r];
@@ -507,34 +525,50 @@ __global__ __launch_bounds__(NT4, (HL && NV == 4) ? (EPI ? 2 : CSF_OUT4_NV4_WAVE
             if (n == 0) red[ch * 64 + rt * 16 + kg * 4 + r] = x;
         }
         __syncthreads();   // (also: every product of the second phase is done, the V tiles are dead)
-        u16* yb = (u16*)a.y.ptr + b * a.y.sb + h * a.y.sh + vbase;
-        const u16* gb = a.gate.ptr ? (const u16*)a.gate.ptr + b * a.gate.sb + h * a.gate.sh + vbase : nullptr;
         float rstd[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = rt * 16 + kg * 4 + r;
             rstd[r] = rsqrtf((red[row] + red[64 + row]) / (float)V + a.neps);
         }
+        // the halves, last one first (its outputs are still in the accumulators; the earlier ones come back from the stash)
+#pragma unroll 1
+        for (int he = NH - 1; he >= 0; --he) {
+            const int vb_e = (NH > 1 ? he : (int)blockIdx.z) * 64 * NV;
+            u16* ob_e = (u16*)a.o.ptr + b * a.o.sb + h * a.o.sh + vb_e;
+            u16* yb = (u16*)a.y.ptr + b * a.y.sb + h * a.y.sh + vb_e;
+            const u16* gb = a.gate.ptr ? (const u16*)a.gate.ptr + b * a.gate.sb + h * a.gate.sh + vb_e : nullptr;
+            if (he < NH - 1) {
+                __syncthreads();   // the staging tiles of the half stored before are dead
 #pragma unroll
-        for (int j = 0; j < NV; ++j) {
-            u16* Oc = Qs + (j & 1) * CT;
-            u16* Yc = Ks + (j & 1) * CT;
-            if (a.o.ptr) {   // training: the operator's own output is kept for the norm's backward
-                cs8_put(Oc, accO[j], a.scale, rt, ch, lane);
+                for (int j = 0; j < NV; ++j)
+#pragma unroll
+                    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) accO[j][tn][r] = stash[(((he * NV + j) * 2 + tn) * 4 + r) * NT4 + tid];
             }
 #pragma unroll
-            for (int tn = 0; tn < 2; ++tn) {
-                const float w = a.nw ? gld<float>(a.nw + vbase + 64 * j + ch * 32 + tn * 16 + n) : 1.f;
+            for (int j = 0; j < NV; ++j) {
+                u16* Oc = Qs + (j & 1) * CT;
+                u16* Yc = Ks + (j & 1) * CT;
+                if (a.o.ptr) {   // training: the operator's own output is kept for the norm's backward
+                    cs8_put(Oc, accO[j], a.scale, rt, ch, lane);
+                }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) accO[j][tn][r] *= a.scale * rstd[r] * w;
+                for (int tn = 0; tn < 2; ++tn) {
+                    const float w = a.nw ? gld<float>(a.nw + vb_e + 64 * j + ch * 32 + tn * 16 + n) : 1.f;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) accO[j][tn][r] *= a.scale * rstd[r] * w;
+                }
+                cs8_put(Yc, accO[j], 1.f, rt, ch, lane);
+                __syncthreads();
+                if (a.o.ptr) cs8_store_tok(ob_e + 64 * j, a.o.sn, p0, rv, Oc, tid);
+                cs8_store_tok_gate(yb + 64 * j, a.y.sn, gb ? gb + 64 * j : nullptr, a.gate.sn, p0, rv, Yc, tid);
             }
-            cs8_put(Yc, accO[j], 1.f, rt, ch, lane);
-            __syncthreads();
-            if (a.o.ptr) cs8_store_tok(ob + 64 * j, a.o.sn, p0, rv, Oc, tid);
-            cs8_store_tok_gate(yb + 64 * j, a.y.sn, gb ? gb + 64 * j : nullptr, a.gate.sn, p0, rv, Yc, tid);
         }
     }
     }   // chunks of the workgroup
+    }   // halves of the head (fused epilogue with V = 512)
 }
 
 // -------------------------------------------------------------------------------------------------

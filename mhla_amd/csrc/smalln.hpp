@@ -41,7 +41,11 @@ struct SnArgs {
 };
 
 template <int DT>
-__host__ __device__ constexpr int sn_ldr() { return DT * 16 + 8; }   // LDS row stride (bf16): 72 (144 B) / 88 (176 B)
+// LDS row stride (bf16) of the staged token tiles: 80 elements = 160 bytes for D <= 64 and for D <= 80 alike.  In gfx950's
+// 64-bank lane-group model (MI355X_MICROARCH.md; tools/lds_conflicts.py) 160-byte rows make the two operand patterns of these
+// kernels -- 16-byte row reads of 16 consecutive rows, and transpose reads of two 16-row tiles -- conflict-free; the strides of
+// rounds 1-3 (DT * 16 + 8: 144 / 176 bytes, derived for 32 banks) were two-way conflicted in both (counters: 0.33).
+__host__ __device__ constexpr int sn_ldr() { static_assert(DT * 16 <= 80, "row of at most 80 elements"); return 80; }
 
 // stage `nrows` token rows (D valid columns, zero up to DP) into an LDS tile [nrows][LDR]; optionally every row scaled by
 // rowscale[r] (fp32, LDS).  All loads are issued before any is used, from clamped (always valid) addresses with no branch around them

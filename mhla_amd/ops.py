@@ -122,6 +122,21 @@ def _ws(nbytes: int, device) -> torch.Tensor:
     return torch.empty(max(nbytes, 16) // 4 + 4, dtype=torch.float32, device=device)
 
 
+# Workspace sizes are pure functions of the problem: one ctypes round trip per distinct problem, not per call (the eager path of a
+# small operator -- the DiT shape -- is bound by the host, tools/host_overhead.py).
+@functools.lru_cache(maxsize=512)
+def _bm_plan(B, H, M, S, D, dt, split, flags):
+    lib = _lib.load()
+    return (lib.mhla_blockmix_fwd_ws_bytes(B, H, M, S, D, dt, split, flags), lib.mhla_blockmix_bwd_ws_bytes(B, H, M, S, D, dt, split, flags),
+            lib.mhla_blockmix_fwd_keeps_state(B, H, M, S, D, dt, split, flags) == 1)
+
+
+@functools.lru_cache(maxsize=512)
+def _cs_plan(B, T, H, K, V, chunk, dt, flags):
+    lib = _lib.load()
+    return (lib.mhla_causal_fwd_ws_bytes(B, T, H, K, V, chunk, dt, flags), lib.mhla_causal_bwd_ws_bytes(B, T, H, K, V, chunk, dt, flags))
+
+
 # ------------------------------------------------------------------------------------------
 # block-mixing MHLA (DiT / ViT / Wan)
 # ------------------------------------------------------------------------------------------
@@ -160,7 +175,8 @@ class _BlockMix(torch.autograd.Function):
         dt = _dtype_code(q)
         flags = ((_lib.FLAG_RELU_EPS if relu_eps else 0) | (_lib.FLAG_FORCE_GENERIC if force_generic else 0)
                  | (_lib.FLAG_NO_SMALLN if no_smalln else 0))
-        ws = _ws(lib.mhla_blockmix_fwd_ws_bytes(B, H, M, S, D, dt, int(split), flags), q.device)
+        fwd_bytes, _, keeps = _bm_plan(B, H, M, S, D, dt, int(split), flags)
+        ws = _ws(fwd_bytes, q.device)
         qv, kv = _view(q), _view(k)
         if normalize:
             qd, kd = (_view(q_den), _view(k_den)) if split else (qv, kv)
@@ -169,10 +185,10 @@ class _BlockMix(torch.autograd.Function):
         idx_ptr = block_index.data_ptr() if block_index is not None else None
         rc = lib.mhla_blockmix_fwd(qv, kv, _view(v), qd, kd, Wf.data_ptr(), M, _view(out), idx_ptr,
                                    ws.data_ptr(), ws.numel() * 4, B, H, M, S, D, dt, float(eps), flags, _stream())
-        _lib.check(rc, "mhla_blockmix_fwd")
+        if rc:
+            _lib.check(rc, "mhla_blockmix_fwd")
         # keep the forward's block summaries for the backward when they are the compact bf16 ones (fast path)
-        keep = (lib.mhla_blockmix_fwd_keeps_state(B, H, M, S, D, dt, int(split), flags) == 1
-                and ws.numel() * 4 <= KEEP_STATE_LIMIT_BYTES)
+        keep = keeps and ws.numel() * 4 <= KEEP_STATE_LIMIT_BYTES
         ctx.save_for_backward(q, k, v, Wf, out, q_den if split else None, k_den if split else None, block_index,
                               ws if keep else None)
         ctx.cfg = (float(eps), bool(normalize), bool(relu_eps), split, W.shape, W.dtype, flags)
@@ -199,7 +215,7 @@ class _BlockMix(torch.autograd.Function):
         if split:
             dqd, dkd = torch.empty_like(dq), torch.empty_like(dq)
         dt = _dtype_code(q)
-        ws = _ws(lib.mhla_blockmix_bwd_ws_bytes(B, H, M, S, D, dt, int(split), flags), q.device)
+        ws = _ws(_bm_plan(B, H, M, S, D, dt, int(split), flags)[1], q.device)
         qv, kv = _view(q), _view(k)
         if normalize:
             qd, kd = (_view(q_den), _view(k_den)) if split else (qv, kv)
@@ -266,7 +282,7 @@ class _BlockMixRope(torch.autograd.Function):
         Wf = W.detach().reshape(M, M).to(torch.float32).contiguous()
         out = torch.empty((B, N, H, D), dtype=q.dtype, device=q.device)
         dt = _dtype_code(q)
-        ws = _ws(lib.mhla_blockmix_fwd_ws_bytes(B, H, M, S, D, dt, 0, 0), q.device)
+        ws = _ws(_bm_plan(B, H, M, S, D, dt, 0, 0)[0], q.device)
         rc = lib.mhla_blockmix_rope_fwd(_view(q), _view(k), _view(v), int(bool(normalize)), Wf.data_ptr(), M, cos.data_ptr(),
                                         sin.data_ptr(), cos.stride(0), _view(out),
                                         block_index.data_ptr() if block_index is not None else None, ws.data_ptr(),
@@ -292,7 +308,7 @@ class _BlockMixRope(torch.autograd.Function):
         dv = _alloc_like_tokens(B, N, H, D, q)
         dW = torch.empty((M, M), dtype=torch.float32, device=q.device)
         dt = _dtype_code(q)
-        ws = _ws(lib.mhla_blockmix_bwd_ws_bytes(B, H, M, S, D, dt, 0, 0), q.device)
+        ws = _ws(_bm_plan(B, H, M, S, D, dt, 0, 0)[1], q.device)
         rc = lib.mhla_blockmix_rope_bwd(_view(q), _view(k), _view(v), int(normalize), Wf.data_ptr(), M, cos.data_ptr(),
                                         sin.data_ptr(), cos.stride(0), _view(out), _view(dout), _view(dq), _view(dk), _view(dv),
                                         dW.data_ptr(), block_index.data_ptr() if block_index is not None else None,
@@ -497,7 +513,7 @@ def mhla_blockmix_wan(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, W: torc
     nw = norm_weight.detach().to(torch.float32).contiguous() if norm_weight is not None else None
     Wf = W.detach().reshape(M, M).to(torch.float32).contiguous()
     out = torch.empty((B, N, H, D), dtype=out_dtype, device=q.device)
-    ws = _ws(lib.mhla_blockmix_fwd_ws_bytes(B, H, M, S, D, _lib.F32, 0, 0), q.device)
+    ws = _ws(_bm_plan(B, H, M, S, D, _lib.F32, 0, 0)[0], q.device)
     rc = lib.mhla_blockmix_wan_fwd(_view(q), _view(k), _view(v), int(bool(normalize)), Wf.data_ptr(), M,
                                    cos.data_ptr() if cos is not None else None, sin.data_ptr() if sin is not None else None,
                                    cos.stride(0) if cos is not None else 0, nw.data_ptr() if nw is not None else None,
@@ -528,7 +544,7 @@ class _DitCore(torch.autograd.Function):
         dt = _dtype_code(qkv)
         flags = _lib.FLAG_RELU_EPS if relu_eps else 0
         attn = torch.empty((B, N, H, D), dtype=qkv.dtype, device=qkv.device)
-        ws = _ws(lib.mhla_blockmix_fwd_ws_bytes(B, H, M, S, D, dt, 0, flags), qkv.device)
+        ws = _ws(_bm_plan(B, H, M, S, D, dt, 0, flags)[0], qkv.device)
         qv, kv = _view(q), _view(k)
         rc = lib.mhla_blockmix_fwd(qv, kv, _view(v), qv, kv, Wf.data_ptr(), M, _view(attn), None, ws.data_ptr(), ws.numel() * 4,
                                    B, H, M, S, D, dt, float(eps), flags, _stream())
@@ -540,7 +556,7 @@ class _DitCore(torch.autograd.Function):
         rc = lib.mhla_lepe2d(v3.data_ptr(), v3.stride(0), v3.stride(1), w_taps.data_ptr(), b32.data_ptr() if b32 is not None else None,
                              attn.data_ptr(), N * C, C, y.data_ptr(), N * C, C, B, pieces_len, block_len, C, K, 0, dt, _stream())
         _lib.check(rc, "mhla_lepe2d")
-        keep = (lib.mhla_blockmix_fwd_keeps_state(B, H, M, S, D, dt, 0, flags) == 1 and ws.numel() * 4 <= KEEP_STATE_LIMIT_BYTES)
+        keep = _bm_plan(B, H, M, S, D, dt, 0, flags)[2] and ws.numel() * 4 <= KEEP_STATE_LIMIT_BYTES
         ctx.save_for_backward(qkv, Wf, attn, w_taps, ws if keep else None)
         ctx.cfg = (pieces_len, block_len, float(eps), flags, W.shape, W.dtype, lepe_w.shape, lepe_w.dtype,
                    lepe_b.dtype if lepe_b is not None else None)
@@ -562,7 +578,7 @@ class _DitCore(torch.autograd.Function):
         dqkv = torch.empty_like(qkv)
         dv_attn = torch.empty((B, N, H, D), dtype=qkv.dtype, device=qkv.device)
         dW = torch.empty((M, M), dtype=torch.float32, device=qkv.device)
-        ws = _ws(lib.mhla_blockmix_bwd_ws_bytes(B, H, M, S, D, dt, 0, flags), qkv.device)
+        ws = _ws(_bm_plan(B, H, M, S, D, dt, 0, flags)[1], qkv.device)
         qv, kv = _view(q), _view(k)
         rc = lib.mhla_blockmix_bwd(qv, kv, _view(v), qv, kv, Wf.data_ptr(), M, _view(attn), _view(dy4),
                                    _view(dqkv[:, :, 0]), _view(dqkv[:, :, 1]), _view(dv_attn), NULL_VIEW, NULL_VIEW,
@@ -740,7 +756,7 @@ class _Causal(torch.autograd.Function):
         q, k, v = _prep(q), _prep(k), _prep(v)
         mixf = mix.detach().reshape(L, mix.shape[1]).to(torch.float32).contiguous()
         out = torch.empty((B, T, H, V), dtype=q.dtype, device=q.device)
-        ws = _ws(lib.mhla_causal_fwd_ws_bytes(B, T, H, K, V, chunk_size, _dtype_code(q), flags), q.device)
+        ws = _ws(_cs_plan(B, T, H, K, V, chunk_size, _dtype_code(q), flags)[0], q.device)
         rc = lib.mhla_causal_fwd(_view(q), _view(k), _view(v), mixf.data_ptr(), mixf.shape[1], _view(out),
                                  ws.data_ptr(), ws.numel() * 4, B, T, H, K, V, chunk_size, float(scale),
                                  _dtype_code(q), flags, _stream())
@@ -766,7 +782,7 @@ class _Causal(torch.autograd.Function):
         # the library writes every entry of the leading [n, n] block (zeros above the diagonal)
         n_chunks = (T + chunk_size - 1) // chunk_size
         dmix = (torch.empty if tuple(mixf.shape) == (n_chunks, n_chunks) else torch.zeros)(mixf.shape, dtype=torch.float32, device=q.device)
-        ws = _ws(lib.mhla_causal_bwd_ws_bytes(B, T, H, K, V, chunk_size, _dtype_code(q), flags), q.device)
+        ws = _ws(_cs_plan(B, T, H, K, V, chunk_size, _dtype_code(q), flags)[1], q.device)
         rc = lib.mhla_causal_bwd(_view(q), _view(k), _view(v), mixf.data_ptr(), mixf.shape[1], _view(dout),
                                  _view(dq), _view(dk), _view(dv), dmix.data_ptr(), dmix.shape[1],
                                  ws.data_ptr(), ws.numel() * 4, fwd_ws.data_ptr() if fwd_ws is not None else None,
@@ -836,7 +852,7 @@ class _CausalNormGate(torch.autograd.Function):
         need_grad = any(ctx.needs_input_grad[:6])
         out = torch.empty((B, T, H, V), dtype=q.dtype, device=q.device) if need_grad else None
         y = torch.empty((B, T, H, V), dtype=q.dtype, device=q.device)
-        ws = _ws(lib.mhla_causal_fwd_ws_bytes(B, T, H, K, V, chunk_size, _dtype_code(q), flags), q.device)
+        ws = _ws(_cs_plan(B, T, H, K, V, chunk_size, _dtype_code(q), flags)[0], q.device)
         rc = lib.mhla_causal_normgate_fwd(_view(q), _view(k), _view(v), mixf.data_ptr(), mixf.shape[1],
                                           _view(out) if out is not None else NULL_VIEW,
                                           _view(gate) if gate is not None else NULL_VIEW,
@@ -874,7 +890,7 @@ class _CausalNormGate(torch.autograd.Function):
         # the library writes every entry of the leading [n, n] block (zeros above the diagonal)
         n_chunks = (T + chunk_size - 1) // chunk_size
         dmix = (torch.empty if tuple(mixf.shape) == (n_chunks, n_chunks) else torch.zeros)(mixf.shape, dtype=torch.float32, device=q.device)
-        ws = _ws(lib.mhla_causal_bwd_ws_bytes(B, T, H, K, V, chunk_size, _dtype_code(q), flags), q.device)
+        ws = _ws(_cs_plan(B, T, H, K, V, chunk_size, _dtype_code(q), flags)[1], q.device)
         rc = lib.mhla_causal_bwd(_view(q), _view(k), _view(v), mixf.data_ptr(), mixf.shape[1], _view(do),
                                  _view(dq), _view(dk), _view(dv), dmix.data_ptr(), dmix.shape[1],
                                  ws.data_ptr(), ws.numel() * 4, fwd_ws.data_ptr() if fwd_ws is not None else None,

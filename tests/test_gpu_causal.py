@@ -293,7 +293,9 @@ def test_rmsnorm_gate(D, dtype, gate):
 
 
 @pytest.mark.parametrize("T,K,V,gate,affine", [(300, 128, 256, True, True), (129, 64, 64, True, True), (200, 64, 128, False, True),
-                                               (512, 128, 192, True, False)])
+                                               (512, 128, 192, True, False),
+                                               # wide heads: the workgroup walks the head in two halves (V = 512: the 1.3B-like fla shape)
+                                               (330, 256, 512, True, True), (200, 64, 384, True, True), (130, 128, 512, False, False)])
 def test_causal_normgate_fused_epilogue(T, K, V, gate, affine):
     """N1: per-head RMSNorm x swish gate inside the causal operator's output kernel (mhla_causal_normgate_fwd) vs the oracle's
     composition (causal_fwd -> rms_norm_swish_gate), forward and every gradient; and vs the unfused HIP composition."""

@@ -30,13 +30,16 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert 0 < fwd < bwd
     assert lib.mhla_causal_bwd_ws_bytes(1, 8192, 4, 128, 256, 64, 0, 0) > lib.mhla_causal_fwd_ws_bytes(1, 8192, 4, 128, 256, 64, 0, 0) > 0
     # bf16 tensors: chunk summaries as bf16 hi + lo pairs (as many bytes as fp32); single bf16 only with the opt-in flag
+    # (+ 4352 bytes of padding per chunk and summary set on the 16-bit pipeline: cs_chunk_stride)
     f32 = lib.mhla_causal_fwd_ws_bytes(1, 8192, 4, 128, 256, 64, 0, 0)
-    assert lib.mhla_causal_fwd_ws_bytes(1, 8192, 4, 128, 256, 64, 1, 0) == f32
-    assert lib.mhla_causal_fwd_ws_bytes(1, 8192, 4, 128, 256, 64, 1, _lib.CAUSAL_BF16_SUMMARIES) * 2 == f32
+    pad = 2 * 4 * 128 * 4352
+    assert lib.mhla_causal_fwd_ws_bytes(1, 8192, 4, 128, 256, 64, 1, 0) == f32 + pad
+    assert lib.mhla_causal_fwd_ws_bytes(1, 8192, 4, 128, 256, 64, 1, _lib.CAUSAL_BF16_SUMMARIES) == f32 // 2 + pad
     assert lib.mhla_causal_fwd_ws_bytes(1, 8192, 4, 128, 256, 64, 1, _lib.CAUSAL_FORCE_GENERIC) == f32
     # the fused norm x gate epilogue: what the 16-bit pipeline covers with V <= 256
     assert lib.mhla_causal_normgate_fusable(8192, 128, 256, 64, 1, 0) == 1
-    assert lib.mhla_causal_normgate_fusable(8192, 128, 512, 64, 1, 0) == 0
+    assert lib.mhla_causal_normgate_fusable(8192, 256, 512, 64, 1, 0) == 1    # wide heads: two halves per workgroup
+    assert lib.mhla_causal_normgate_fusable(8192, 128, 320, 64, 1, 0) == 0
     assert lib.mhla_causal_normgate_fusable(8256, 128, 256, 64, 1, 0) == 0    # 129 chunks: generic kernels
     assert lib.mhla_causal_normgate_fusable(8192, 128, 256, 64, 0, 0) == 0    # fp32 tensors
 
