@@ -109,6 +109,49 @@ def build(force: bool = False, verbose: bool = True, lib: str = LIB, obj_dir: st
     return lib
 
 
+# ---- the C++ autograd nodes (csrc_torch/mhla_torch.cpp): a host-only library against libtorch, no device code ----
+TORCH_SRC = os.path.join(HERE, "csrc_torch", "mhla_torch.cpp")
+TORCH_LIB = os.path.join(LIB_DIR, "libmhla_torch.so")
+
+
+def _torch_stamp() -> str:
+    import torch
+    h = hashlib.sha256(open(TORCH_SRC, "rb").read())
+    h.update(open(os.path.join(os.path.dirname(HERE), "include", "mhla_hip.h"), "rb").read())
+    h.update(torch.__version__.encode())
+    return h.hexdigest()[:16]
+
+
+def torch_ext_stale() -> bool:
+    tag = TORCH_LIB + ".stamp"
+    return not (os.path.exists(TORCH_LIB) and os.path.exists(tag) and open(tag).read().strip() == _torch_stamp())
+
+
+def build_torch_ext(force: bool = False, verbose: bool = True) -> str:
+    """g++ -shared against the installed libtorch (ROCm build): mhla_amd/lib/libmhla_torch.so.  Loaded with
+    torch.ops.load_library by mhla_amd/_native.py; binds libmhla_hip.so's C ABI with dlopen at run time."""
+    if not force and not torch_ext_stale():
+        return TORCH_LIB
+    import torch
+    from torch.utils import cpp_extension as ce
+    inc = ce.include_paths("cuda") + ["/opt/rocm/include"]
+    libs = ce.library_paths("cuda")
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = (["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+            f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}"] + [f"-I{i}" for i in inc] +
+           [TORCH_SRC, "-o", TORCH_LIB + ".tmp"] + [f"-L{d}" for d in libs] + ["-ltorch", "-ltorch_cpu", "-lc10", "-lc10_hip", "-ltorch_hip", "-ldl"] +
+           [f"-Wl,-rpath,{d}" for d in libs])
+    if verbose:
+        print("[mhla_amd.build]", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    os.replace(TORCH_LIB + ".tmp", TORCH_LIB)
+    with open(TORCH_LIB + ".stamp", "w") as f:
+        f.write(_torch_stamp())
+    return TORCH_LIB
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
     print(LIB)
+    build_torch_ext(force="--force" in sys.argv)
+    print(TORCH_LIB)

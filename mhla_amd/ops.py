@@ -13,8 +13,17 @@ from typing import Optional
 
 import torch
 
-from . import _lib
+from . import _lib, _native
 from ._lib import NULL_VIEW, View
+
+# Autograd nodes in C++ (csrc_torch/mhla_torch.cpp) for the two plain operators when libmhla_torch.so is built: the eager host
+# path of a forward + backward drops from ~180 us to the cost of the allocations and two C calls.  False forces the Python nodes
+# below (same C ABI); MHLA_CHECK_HANDOVER=1 (a debugging aid of the Python nodes) does too.
+USE_NATIVE_NODES = True
+
+
+def _native_nodes() -> bool:
+    return USE_NATIVE_NODES and _native.available() and os.environ.get("MHLA_CHECK_HANDOVER") != "1"
 
 # (batch, head) pairs one launch of the library addresses (grid.y); larger batches are sliced by the operators below
 _MAX_GRID_BH = 65535
@@ -265,6 +274,10 @@ def mhla_blockmix(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, W: torch.Te
         sl = lambda t, i: None if t is None else t[i:i + nb]
         return torch.cat([_BlockMix.apply(sl(q, i), sl(k, i), sl(v, i), W, sl(q_den, i), sl(k_den, i), block_index, eps, normalize,
                                           relu_eps, force_generic, no_smalln) for i in range(0, q.shape[0], nb)], dim=0)
+    if _native_nodes():
+        flags = ((_lib.FLAG_RELU_EPS if relu_eps else 0) | (_lib.FLAG_FORCE_GENERIC if force_generic else 0)
+                 | (_lib.FLAG_NO_SMALLN if no_smalln else 0))
+        return torch.ops.mhla_amd.blockmix(q, k, v, W, q_den, k_den, block_index, float(eps), bool(normalize), flags, KEEP_STATE_LIMIT_BYTES)
     return _BlockMix.apply(q, k, v, W, q_den, k_den, block_index, eps, normalize, relu_eps, force_generic, no_smalln)
 
 
@@ -819,6 +832,8 @@ def mhla_causal(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mixing_matrix
     if q.shape[0] > nb:   # see mhla_blockmix
         return torch.cat([_Causal.apply(q[i:i + nb], k[i:i + nb], v[i:i + nb], mixing_matrix, int(chunk_size), scale, flags)
                           for i in range(0, q.shape[0], nb)], dim=0)
+    if _native_nodes():
+        return torch.ops.mhla_amd.causal(q, k, v, mixing_matrix, int(chunk_size), float(scale), flags, KEEP_STATE_LIMIT_BYTES)
     return _Causal.apply(q, k, v, mixing_matrix, int(chunk_size), scale, flags)
 
 

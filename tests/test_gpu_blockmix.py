@@ -627,9 +627,9 @@ def test_handover_wait_is_bounded_and_reported(monkeypatch):
     q, k, v, do = mk(), mk(), mk(), mk()
     W = torch.rand(M, M, device=DEV, generator=g).add_(0.1)
     ts = [x.clone().requires_grad_(True) for x in (q, k, v, W)]
-    out = mhla_amd.mhla_blockmix(*ts)
     monkeypatch.setenv("MHLA_DEBUG_DROP_SIGNAL", "1")
-    monkeypatch.setenv("MHLA_CHECK_HANDOVER", "1")
+    monkeypatch.setenv("MHLA_CHECK_HANDOVER", "1")   # (selects the Python autograd node, whose backward issues the status call)
+    out = mhla_amd.mhla_blockmix(*ts)
     with pytest.raises(RuntimeError, match="gave up waiting"):
         out.backward(do)
     torch.cuda.synchronize()

@@ -78,3 +78,50 @@ def test_bench_two_rank_launch_path_in_shared_gpu_mode():
     assert res["value"] > 0 and res["roofline"]["frac"] > 0 and "targets" in res
     if torch.cuda.device_count() < 2:
         assert "shared_gpu_harness" in res["config"]
+
+
+def test_cpp_and_python_autograd_nodes_are_the_same_operator(monkeypatch):
+    """mhla_amd/csrc_torch/mhla_torch.cpp (the C++ autograd nodes the eager path uses when libmhla_torch.so is built) and the Python
+    autograd.Functions of ops.py call the same C ABI with the same arguments: bit-identical outputs and gradients, same error
+    types for the same misuse."""
+    import mhla_amd
+    from mhla_amd import _native, ops
+    assert _native.available(), "libmhla_torch.so is part of the build (mhla_amd.build.build_torch_ext)"
+    g = torch.Generator().manual_seed(3)
+    res = {}
+    for native in (True, False):
+        monkeypatch.setattr(ops, "USE_NATIVE_NODES", native)
+        out = []
+        # block-mix: fast path shape, split pairs with a gather map (split-operand path), small-sequence shape
+        for (B, M, S, H, D, dt, split) in ((2, 16, 64, 2, 64, torch.bfloat16, False), (1, 6, 20, 2, 32, torch.float32, True),
+                                           (2, 16, 16, 3, 72, torch.bfloat16, False)):
+            g.manual_seed(B * 100 + M)
+            N = M * S
+            mk = lambda: (torch.rand(B, N, H, D, generator=g) + 0.01).to(dt).to(DEV).requires_grad_(True)
+            q, k, v = mk(), mk(), mk()
+            qd, kd = (mk(), mk()) if split else (None, None)
+            W = torch.rand(M, M, generator=g).to(DEV).requires_grad_(True)
+            idx = torch.randperm(N, generator=g).int().to(DEV) if split else None
+            o = mhla_amd.mhla_blockmix(q, k, v, W, q_den=qd, k_den=kd, block_index=idx)
+            o.backward(torch.randn(B, N, H, D, generator=g).to(dt).to(DEV))
+            out += [o.detach(), q.grad, k.grad, v.grad, W.grad] + ([qd.grad, kd.grad] if split else [])
+        # causal: 16-bit pipeline and generic kernels, [L, L, 1, 1, 1, 1] parameter with L > n
+        for (T, K, V, dt) in ((300, 64, 128, torch.bfloat16), (100, 16, 24, torch.float32)):
+            g.manual_seed(T)
+            mk = lambda d: torch.randn(2, T, 2, d, generator=g).to(dt).to(DEV).requires_grad_(True)
+            q, k, v = mk(K), mk(K), mk(V)
+            mix = torch.tril(torch.rand(8, 8, generator=g)).reshape(8, 8, 1, 1, 1, 1).to(DEV).requires_grad_(True)
+            o = mhla_amd.mhla_causal(q, k, v, mix)
+            o.backward(torch.randn(2, T, 2, V, generator=g).to(dt).to(DEV))
+            out += [o.detach(), q.grad, k.grad, v.grad, mix.grad]
+        res[native] = out
+        x = torch.rand(2, 64, 2, 16, device=DEV)
+        with pytest.raises(ValueError):
+            mhla_amd.mhla_blockmix(x, x, x, torch.eye(5, device=DEV))
+        with pytest.raises(TypeError):
+            mhla_amd.mhla_blockmix(x.double(), x.double(), x.double(), torch.eye(4, device=DEV))
+        with pytest.raises(IndexError):
+            mhla_amd.mhla_causal(x, x, x, torch.eye(1, device=DEV)[:0, :0].reshape(0, 0))
+    assert len(res[True]) == len(res[False])
+    for i, (a, b) in enumerate(zip(res[True], res[False])):
+        assert a.dtype == b.dtype and a.shape == b.shape and torch.equal(a, b), f"result {i} differs between the C++ and the Python node"

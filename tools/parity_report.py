@@ -37,12 +37,12 @@ for k in sorted(agg):
     a = agg[k]
     print(f"| {k} | {a['n']} | {a['max_rel_err']:.2e} | {a.get('max_beyond_final_rounding', float('nan')):.2e} | {a['loosest_tol']:g} |")
 
-fam = rep.get("by_operator_and_dtype", {})
+fam = rep.get("by_baseline_config", {})
 if fam:
-    print("\n| operator family / dtype of the HIP result | comparisons | largest rel-err | largest error beyond the final rounding | worst case |")
+    print("\n| BASELINE.json configuration (full-size tests) | comparisons | 16-bit results: largest error beyond the final rounding | fp32 results: largest rel-err | worst case |")
     print("|---|---|---|---|---|")
     for k in sorted(fam):
         a = fam[k]
-        print(f"| {k} | {a['n']} | {a['max_rel_err']:.2e} | {a['max_beyond_final_rounding']:.2e} | `{(a['worst'] or '').split('::', 1)[-1]}` |")
+        print(f"| {k} | {a['n']} | {a['results_16bit_max_beyond_final_rounding']:.2e} | {a['results_fp32_max_rel_err']:.2e} | `{a['worst']}` |")
     with open(os.path.join(ROOT, "profiles", "r4_parity_summary.json"), "w") as f:
         json.dump({k: v for k, v in rep.items() if k != "all"}, f, indent=1)
