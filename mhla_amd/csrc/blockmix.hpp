@@ -516,7 +516,8 @@ __global__ __launch_bounds__(NTHREADS) void k_dw(const DwArgs a) {
 }
 
 // dW[i][j] = sum over parts of dWp[part][i][j]  (parts = (b,h) x E-slices; fixed summation order -> deterministic).
-//   MASK 1: j < i from dWp, j == i from diag[bh][i] (nbh rows), j > i left untouched.
+//   MASK 1: j < i from dWp, j == i from diag[bh][i] (nbh rows), j > i WRITTEN AS ZERO -- every entry of the leading [M, M] block of
+//   dW is defined after this kernel (mhla_amd/ops.py and the C++ nodes allocate dmix with torch.empty and rely on it).
 // 256 threads: EL elements x (256 / EL) part-lanes, then an LDS reduce in lane order.  EL = 64 for large M; EL = 16 when M * M is
 // small and the parts are many (M = 16: 4 workgroups each summing 384 values per thread took 20 us).
 template <int MASK, int EL = 64>

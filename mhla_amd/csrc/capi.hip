@@ -61,10 +61,23 @@ FastWs fast_carve(void* ws, int B, int H, int M, int S) {
     w.dksum = (float*)p; p += al4(bh * M * 64) * 4;
     w.dwp = (float*)p; p += bh * fast::DW_SPLIT * 4096 * 4;
     w.ntt = fast::tiles_per_bh(w.njg, 16);
-    w.done = (int*)p; p += al4(bh * w.ntt + 1) * 4;   // per-tile flags + the launch's error word
-    w.err = w.done + bh * w.ntt;
+    w.done = (int*)p; p += al4(bh * w.ntt + 1) * 4;   // per-tile flags
+    w.err = nullptr;                                  // (the error word lives at the tail of the workspace: bwd_err_word)
     w.total_bwd = (size_t)(p - (char*)ws);
     return w;
+}
+// Error word of the fused token-gradient launch: the LAST 16 bytes of the backward workspace (mhla_blockmix_bwd_ws_bytes), behind
+// the carve of every path a problem may take.  Every backward of a shape that can take the fast path leaves a defined word there:
+// the fast path clears it in k_fs_dw and raises it in k_tile_bwd; when such a shape falls back to another path (misaligned views,
+// rotary prologue) the dispatcher clears it with a 4-byte memset -- so mhla_blockmix_bwd_status never reads an unrelated word
+// (round-3 ADVICE: it used to infer the path from the shape alone).
+size_t bwd_ws_body_bytes(int B, int H, int M, int S, int D, int dtype, int split, unsigned flags) {
+    const size_t gen = bm_carve(nullptr, B, H, M, S, D, bm_sum16(D, dtype, flags)).total_bwd;
+    const bool fast = fast_shape_ok(M, D, dtype, split != 0) && !(flags & MHLA_FLAG_FORCE_GENERIC);
+    return (std::max(gen, fast ? fast_carve(nullptr, B, H, M, S).total_bwd : (size_t)0) + 15) & ~(size_t)15;
+}
+int* bwd_err_word(void* ws, int B, int H, int M, int S, int D, int dtype, int split, unsigned flags) {
+    return (int*)((char*)ws + bwd_ws_body_bytes(B, H, M, S, D, dtype, split, flags));
 }
 
 }  // namespace
@@ -139,9 +152,7 @@ size_t mhla_blockmix_fwd_ws_bytes(int B, int H, int M, int S, int D, int dtype, 
     return gen;
 }
 size_t mhla_blockmix_bwd_ws_bytes(int B, int H, int M, int S, int D, int dtype, int split, unsigned flags) {
-    const size_t gen = bm_carve(nullptr, B, H, M, S, D, bm_sum16(D, dtype, flags)).total_bwd;
-    if (fast_shape_ok(M, D, dtype, split != 0) && !(flags & MHLA_FLAG_FORCE_GENERIC)) return std::max(gen, fast_carve(nullptr, B, H, M, S).total_bwd);
-    return gen;
+    return bwd_ws_body_bytes(B, H, M, S, D, dtype, split, flags) + 16;   // + the error word of the fused token-gradient launch
 }
 
 static int bm_fwd_impl(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view q_den, mhla_view k_den, const float* W,
@@ -306,8 +317,10 @@ static int bm_bwd_impl(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view 
         }
         if (!rcos && fast_shape_ok(M, D, dtype, split) && !(flags & MHLA_FLAG_FORCE_GENERIC) && view_ok16(q_num) && view_ok16(k_num) &&
             view_ok16(v) && view_ok16(dout) && (!normalize || view_ok16(out)) && view_ok16(dqv) && view_ok16(dkv_) && view_ok16(dvv)) {
-            const FastWs f = fast_carve(ws, B, H, M, S);
-            if (ws_bytes < f.total_bwd) return fail(MHLA_EINVAL, "workspace too small: %zu < %zu bytes", ws_bytes, f.total_bwd);
+            FastWs f = fast_carve(ws, B, H, M, S);
+            const size_t need = mhla_blockmix_bwd_ws_bytes(B, H, M, S, D, dtype, split, flags);
+            if (ws_bytes < need) return fail(MHLA_EINVAL, "workspace too small: %zu < %zu bytes", ws_bytes, need);
+            f.err = bwd_err_word(ws, B, H, M, S, D, dtype, split, flags);
             const fast::u16* state = f.state;
             const float *z = f.z, *ksum = f.ksum, *ninv = f.ninv;
             if (fwd_ws) {   // forward workspace retained by the caller: reuse KV^T, z, ksum, 1/n
@@ -329,7 +342,7 @@ static int bm_bwd_impl(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view 
             else RC(launch(fast::k_fs_state<1>, dim3(f.njg, B * H), dim3(fast::FT8), fast::FS_STATE_SMEM, st, "k_fs_state<1>", ga));
             // dW needs only dG^T, KV^T, dn and z, all complete here; dz = W^T dn (needed by the token-gradient kernels) rides in
             // the same launch as extra workgroups
-            fast::FsDwArgs da{f.dstate, state, normalize ? f.dn : nullptr, z, f.dwp, M, S, f.njg, W, ldw, f.dz, f.done, f.ntt};
+            fast::FsDwArgs da{f.dstate, state, normalize ? f.dn : nullptr, z, f.dwp, M, S, f.njg, W, ldw, f.dz, f.done, f.err, f.ntt};
             hipStream_t sd = st;
             const int nwz = normalize ? (S + fast::WZ_C - 1) / fast::WZ_C : 0;
             RC(launch(fast::k_fs_dw<>, dim3(fast::DW_SPLIT + nwz, B * H), dim3(fast::FT8), fast::FS_DW_SMEM, sd, "k_fs_dw", da));
@@ -358,6 +371,13 @@ static int bm_bwd_impl(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view 
     }
     BmWs w = bm_carve(ws, B, H, M, S, D, bm_sum16(D, dtype, flags));
     if (ws_bytes < w.total_bwd) return fail(MHLA_EINVAL, "workspace too small: %zu < %zu bytes", ws_bytes, w.total_bwd);
+    if (fast_shape_ok(M, D, dtype, split) && !(flags & MHLA_FLAG_FORCE_GENERIC)) {
+        // a fast-path shape on another path (misaligned views, rotary prologue): leave a defined error word for the status call
+        if (ws_bytes < mhla_blockmix_bwd_ws_bytes(B, H, M, S, D, dtype, split, flags))
+            return fail(MHLA_EINVAL, "workspace too small: %zu < %zu bytes", ws_bytes, mhla_blockmix_bwd_ws_bytes(B, H, M, S, D, dtype, split, flags));
+        if (hipMemsetAsync(bwd_err_word(ws, B, H, M, S, D, dtype, split, flags), 0, 4, st) != hipSuccess)
+            return fail(MHLA_ELAUNCH, "hipMemsetAsync of the error word failed");
+    }
     // the forward's KV, G, z, ksum, 1/n are still in its workspace (only when the shape cannot have taken the bf16 fast path,
     // whose workspace has another layout)
     const bool reuse = fwd_ws && sp_shape_ok(D, flags) && (rcos || !fast_shape_ok(M, D, dtype, split));
@@ -416,10 +436,11 @@ int mhla_blockmix_bwd_status(const void* ws, size_t ws_bytes, int B, int H, int 
     if (!fast_shape_ok(M, D, dtype, split != 0) || (flags & MHLA_FLAG_FORCE_GENERIC) ||
         (sn_shape_ok(M, S, D, dtype, split != 0) && !(flags & MHLA_FLAG_NO_SMALLN)))
         return MHLA_OK;
-    const FastWs f = fast_carve(const_cast<void*>(ws), B, H, M, S);
-    if (ws_bytes < f.total_bwd) return fail(MHLA_EINVAL, "workspace too small: %zu < %zu bytes", ws_bytes, f.total_bwd);
+    const size_t need = mhla_blockmix_bwd_ws_bytes(B, H, M, S, D, dtype, split, flags);
+    if (ws_bytes < need) return fail(MHLA_EINVAL, "workspace too small: %zu < %zu bytes", ws_bytes, need);
     int word = 0;
-    hipError_t e = hipMemcpyAsync(&word, f.err, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    hipError_t e = hipMemcpyAsync(&word, bwd_err_word(const_cast<void*>(ws), B, H, M, S, D, dtype, split, flags), sizeof(int),
+                                  hipMemcpyDeviceToHost, (hipStream_t)stream);
     if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
     if (e != hipSuccess) return fail(MHLA_ELAUNCH, "mhla_blockmix_bwd_status: %s", hipGetErrorString(e));
     if (word != 0)

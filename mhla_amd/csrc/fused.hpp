@@ -829,6 +829,7 @@ struct FsDwArgs {
     float* dz;
     // per-tile "dQ done" flags of the token-gradient launch that follows (k_tile_bwd): cleared here, one workgroup per (b,h)
     int* done;
+    int* err;    // the launch's error word, cleared here as well
     int ntt;
 };
 constexpr int DW_EC = 128;                       // e' rows per LDS image
@@ -845,7 +846,7 @@ __global__ __launch_bounds__(FT8) void k_fs_dw(const FsDwArgs a) {
     const int wi = wave & 3, wj = wave >> 2;   // wave -> rows i = 16 wi .., columns j = 32 wj ..
     const int qtr = blockIdx.x, bh = blockIdx.y, njg = a.njg;
     if (qtr == 0 && a.done && tid < a.ntt) a.done[bh * a.ntt + tid] = 0;
-    if (qtr == 0 && bh == 0 && a.done && tid == 0) a.done[(long)gridDim.y * a.ntt] = 0;   // the launch's error word follows the flags
+    if (qtr == 0 && bh == 0 && a.err && tid == 0) *a.err = 0;   // the launch's error word (tail of the workspace: bwd_err_word)
     if (qtr >= DW_SPLIT) {   // workgroup-uniform role switch
         wz_body<1, FT8>(reinterpret_cast<float*>(smem_raw), a.W, a.ldw, a.dn, a.dz, a.M, a.S, 0.f, qtr - DW_SPLIT, bh, tid);
         return;

@@ -125,3 +125,49 @@ def test_cpp_and_python_autograd_nodes_are_the_same_operator(monkeypatch):
     assert len(res[True]) == len(res[False])
     for i, (a, b) in enumerate(zip(res[True], res[False])):
         assert a.dtype == b.dtype and a.shape == b.shape and torch.equal(a, b), f"result {i} differs between the C++ and the Python node"
+
+
+def test_bwd_status_after_a_fast_shape_fell_back_to_another_path():
+    """Round-3 ADVICE: mhla_blockmix_bwd_status inferred the path from the shape alone; a bf16 D = 64 problem whose views are only
+    8-byte aligned runs the split-operand kernels, and the status call then read a word those kernels never wrote.  The error
+    word lives at the tail of the backward workspace now and every backward of such a shape leaves it defined: after the fallback
+    the status is MHLA_OK even when the workspace started out as NaN / garbage, and the gradients match the aligned call."""
+    import ctypes
+    import mhla_amd
+    from mhla_amd import _lib
+    from mhla_amd.ops import _view
+    lib = _lib.load()
+    B, M, S, H, D = 2, 8, 64, 2, 64
+    N = M * S
+    g = torch.Generator().manual_seed(5)
+    mk = lambda: (torch.rand(B * N * H * D + 8, generator=g) + 0.01).to(torch.bfloat16).to(DEV)
+    bufs = [mk() for _ in range(5)]                       # q, k, v, out, dout
+    mis = [b[4:4 + B * N * H * D].view(B, N, H, D) for b in bufs]   # 8-byte aligned, not 16
+    assert all(t.data_ptr() % 16 == 8 for t in mis)
+    W = torch.rand(M, M, generator=g).to(DEV)
+    dt = _lib.BF16
+    fws = torch.empty(lib.mhla_blockmix_fwd_ws_bytes(B, H, M, S, D, dt, 0, 0) // 4 + 4, device=DEV)
+    q, k, v, out, dout = mis
+    rc = lib.mhla_blockmix_fwd(_view(q), _view(k), _view(v), _view(q), _view(k), W.data_ptr(), M, _view(out), None, fws.data_ptr(),
+                               fws.numel() * 4, B, H, M, S, D, dt, 1e-6, 0, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, lib.mhla_last_error()
+    nbytes = lib.mhla_blockmix_bwd_ws_bytes(B, H, M, S, D, dt, 0, 0)
+    ws = torch.full((nbytes // 4 + 4,), float("nan"), device=DEV)      # garbage everywhere, the tail word included
+    grads = [torch.empty(B * N * H * D + 8, dtype=torch.bfloat16, device=DEV)[4:4 + B * N * H * D].view(B, N, H, D) for _ in range(3)]
+    dW = torch.empty(M, M, device=DEV)
+    null = _lib.NULL_VIEW
+    rc = lib.mhla_blockmix_bwd(_view(q), _view(k), _view(v), _view(q), _view(k), W.data_ptr(), M, _view(out), _view(dout),
+                               _view(grads[0]), _view(grads[1]), _view(grads[2]), null, null, dW.data_ptr(), None, ws.data_ptr(),
+                               ws.numel() * 4, None, B, H, M, S, D, dt, 1e-6, 0, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, lib.mhla_last_error()
+    rc = lib.mhla_blockmix_bwd_status(ws.data_ptr(), ws.numel() * 4, B, H, M, S, D, dt, 0, 0, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, lib.mhla_last_error()
+    # same numbers as the aligned call through the operator (fast path): both within the bf16 bounds of each other
+    ts = [t.clone().contiguous().requires_grad_(True) for t in (q, k, v)]
+    Wd = W.clone().requires_grad_(True)
+    o2 = mhla_amd.mhla_blockmix(ts[0], ts[1], ts[2], Wd)
+    o2.backward(dout.clone().contiguous())
+    check("out (split path on misaligned views vs fast path)", out, o2.detach().float().cpu(), 2 * TOL[torch.bfloat16])
+    for name, a, b in zip(("dq", "dk", "dv"), grads, ts):
+        check(name, a, b.grad.float().cpu(), 2 * 3 * 2.0 ** -8)
+    check("dW", dW, Wd.grad.float().cpu(), 2 * 3 * 2.0 ** -8)
