@@ -156,10 +156,14 @@ class MHLA(nn.Module):
                  use_short_conv: bool = False, conv_size: int = 4, conv_bias: bool = False,
                  use_output_gate: bool = True, gate_fn: str = "swish", elementwise_affine: Optional[bool] = True,
                  norm_eps: float = 1e-5, gate_logit_normalizer: int = 16, gate_low_rank_dim: int = 16,
-                 clamp_min: Optional[float] = None, fuse_norm: bool = True, layer_idx: int = None, max_chunks: int = 32):
+                 clamp_min: Optional[float] = None, fuse_norm: bool = True, layer_idx: int = None, max_chunks: int = 32,
+                 summaries: str = "split"):
         """`max_chunks` (not in the reference, default = its hard-coded 32): side of the mixing matrix, i.e. the longest
         sequence is 64 * max_chunks tokens -- 128 for the 8192-token configuration of BASELINE.json configs[4], which the
-        reference layer itself cannot run (layers/mhla.py:196-200); the operator accepts any [n, n] matrix (naive.py:55)."""
+        reference layer itself cannot run (layers/mhla.py:196-200); the operator accepts any [n, n] matrix (naive.py:55).
+        `summaries` (not in the reference): "split" (default) keeps the operator's chunk summaries at the reference's fp32
+        arithmetic (bf16 hi + lo pairs, naive.py:39); "bf16" opts into the reduced-precision variant (half the summary traffic,
+        2-3e-3 of the output's maximum) -- see mhla_amd.mhla_causal."""
         super().__init__()
         self.mode = mode
         self.hidden_size = hidden_size
@@ -174,6 +178,9 @@ class MHLA(nn.Module):
         self.value_dim_per_group = self.value_dim // self.num_kv_groups
         self.clamp_min = clamp_min
         self.layer_idx = layer_idx
+        if summaries not in ("split", "bf16"):
+            raise ValueError(f"summaries={summaries!r}: 'split' or 'bf16'")
+        self.summaries = summaries
         self.use_output_gate = use_output_gate
         assert mode in ["chunk", "fused_recurrent", "fused_chunk"], f"Not supported mode `{mode}`."
         assert self.key_dim % num_heads == 0, f"key dim must be divisible by num_heads of {num_heads}"
@@ -295,7 +302,7 @@ class MHLA(nn.Module):
             # output kernel where the shape allows, otherwise as the separate HIP kernel (mhla_causal_normgate decides)
             g = self.g_proj(hidden_states).reshape(B, T, self.num_heads, self.head_v_dim)
             gn = self.g_norm_swish_gate
-            o = mhla_causal_normgate(q, k, v, self.mixing_matrix, g, gn.weight, gn.eps).reshape(B, T, self.value_dim)
+            o = mhla_causal_normgate(q, k, v, self.mixing_matrix, g, gn.weight, gn.eps, summaries=self.summaries).reshape(B, T, self.value_dim)
             recurrent_state = None
         elif q_len <= 64:                                                    # :247, :318-327: the token-recurrent form
             if T > 64 and not getattr(self, "_warned_recurrent_packed", False):
@@ -306,7 +313,7 @@ class MHLA(nn.Module):
             o, recurrent_state = naive_recurrent_mhla(q, k, v, self.mixing_matrix, initial_state=recurrent_state,
                                                       output_final_state=bool(use_cache))
         else:                                                                # :330-337
-            o = mhla_causal(q, k, v, self.mixing_matrix)
+            o = mhla_causal(q, k, v, self.mixing_matrix, summaries=self.summaries)
             recurrent_state = None
         if past_key_values is not None and hasattr(past_key_values, "update"):   # :339-345
             past_key_values.update(recurrent_state=recurrent_state, conv_state=conv_states if self.use_short_conv else None,
