@@ -21,8 +21,12 @@
 namespace mhla {
 namespace fast {
 
-constexpr int CLD = 72;                 // LDS row stride (bf16) of the 64 x 64 tiles
-constexpr int CT = CS * CLD;            // elements per LDS tile
+// LDS row stride (bf16) of the token kernels' 64 x 64 tiles: 80 elements (160 bytes) where the tiles fit -- in gfx950's 64-bank
+// lane-group model (tools/lds_conflicts.py) the 16-byte row reads of 16 consecutive rows, the most frequent operand fetch of these
+// kernels, are conflict-free at 160 bytes and two-way conflicted at the 144 bytes of rounds 1-3 (k_csf_bwd_tok4 at C5: 211 ->
+// 197 us) -- and 72 where 17 tiles have to share the 160 KB (K = 256 with hi + lo pairs).  Template parameter LD of the helpers.
+template <int LD> __host__ __device__ constexpr int tile_elems() { return CS * LD; }
+constexpr int CLD = 72;                 // strips of k_csf_state2
 constexpr int CTE = CS * CS;            // elements per tile plane in the workspace
 
 template <bool HL>
@@ -60,25 +64,29 @@ __device__ __forceinline__ void cs8_issue_tok(uint4& t, const u16* __restrict__ 
     const int r = tid >> 3, c = (tid & 7) * 8;
     t = gld<uint4>(base + (p0 + (r < rv ? r : 0)) * sn + c);
 }
+template <int LD>
 __device__ __forceinline__ void cs8_commit_tok(u16* __restrict__ dst, const uint4& t, int rv, int tid) {
     const int r = tid >> 3, c = (tid & 7) * 8;
     const bool ok = r < rv;
-    *reinterpret_cast<uint4*>(dst + r * CLD + c) = make_uint4(ok ? t.x : 0u, ok ? t.y : 0u, ok ? t.z : 0u, ok ? t.w : 0u);
+    *reinterpret_cast<uint4*>(dst + r * LD + c) = make_uint4(ok ? t.x : 0u, ok ? t.y : 0u, ok ? t.z : 0u, ok ? t.w : 0u);
 }
 __device__ __forceinline__ void cs8_issue_state(uint4& t, const u16* __restrict__ tile, int tid) { t = gld<uint4>(tile + tid * 8); }   // [64][64] contiguous
+template <int LD>
 __device__ __forceinline__ void cs8_commit_state(u16* __restrict__ dst, const uint4& t, int tid) {
-    *reinterpret_cast<uint4*>(dst + (tid >> 3) * CLD + (tid & 7) * 8) = t;
+    *reinterpret_cast<uint4*>(dst + (tid >> 3) * LD + (tid & 7) * 8) = t;
 }
+template <int LD>
 __device__ __forceinline__ void cs8_store_tok(u16* __restrict__ base, long sn, long p0, int rv, const u16* __restrict__ Os, int tid) {
     const int r = tid >> 3, c = (tid & 7) * 8;
-    if (r < rv) *reinterpret_cast<uint4*>(base + (p0 + r) * sn + c) = *reinterpret_cast<const uint4*>(Os + r * CLD + c);
+    if (r < rv) *reinterpret_cast<uint4*>(base + (p0 + r) * sn + c) = *reinterpret_cast<const uint4*>(Os + r * LD + c);
 }
 // the same with the swish gate applied on the way out: y = staged * g * sigmoid(g)   (gate rows in the output's token layout)
+template <int LD>
 __device__ __forceinline__ void cs8_store_tok_gate(u16* __restrict__ base, long sn, const u16* __restrict__ gbase, long gsn, long p0,
                                                    int rv, const u16* __restrict__ Os, int tid) {
     const int r = tid >> 3, c = (tid & 7) * 8;
     if (r < rv) {
-        uint4 x = *reinterpret_cast<const uint4*>(Os + r * CLD + c);
+        uint4 x = *reinterpret_cast<const uint4*>(Os + r * LD + c);
         if (gbase) {
             const uint4 g = gld<uint4>(gbase + (p0 + r) * gsn + c);
             unsigned xw[4] = {x.x, x.y, x.z, x.w};
@@ -96,32 +104,33 @@ __device__ __forceinline__ void cs8_store_tok_gate(u16* __restrict__ base, long 
     }
 }
 // acc[tn] += A B for output rows 16 rt .. and columns 32 ch + 16 tn ..; reduction length 64.
-//   AT false: A[m][k] = Xs[m][k]   AT true: A[m][k] = Xs[k][m]      (Xs, Ys: [64][CLD] bf16 tiles)
+//   AT false: A[m][k] = Xs[m][k]   AT true: A[m][k] = Xs[k][m]      (Xs, Ys: [64][LD] bf16 tiles)
 //   BT false: B[k][n] = Ys[n][k]   BT true: B[k][n] = Ys[k][n]
-template <bool AT, bool BT>
+template <int LD, bool AT, bool BT>
 __device__ __forceinline__ void tile_mma8(f32x4 (&acc)[2], const u16* __restrict__ Xs, const u16* __restrict__ Ys, int rt, int ch, int lane) {
     const int n = lane & 15, kg = lane >> 4;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-        const bf16x8 av = AT ? tr_read8(Xs, CLD, ks * 32, rt * 16, lane)
-                             : *reinterpret_cast<const bf16x8*>(Xs + (rt * 16 + n) * CLD + ks * 32 + kg * 8);
+        const bf16x8 av = AT ? tr_read8(Xs, LD, ks * 32, rt * 16, lane)
+                             : *reinterpret_cast<const bf16x8*>(Xs + (rt * 16 + n) * LD + ks * 32 + kg * 8);
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn) {
             const int c0 = ch * 32 + tn * 16;
-            const bf16x8 bv = BT ? tr_read8(Ys, CLD, ks * 32, c0, lane)
-                                 : *reinterpret_cast<const bf16x8*>(Ys + (c0 + n) * CLD + ks * 32 + kg * 8);
+            const bf16x8 bv = BT ? tr_read8(Ys, LD, ks * 32, c0, lane)
+                                 : *reinterpret_cast<const bf16x8*>(Ys + (c0 + n) * LD + ks * 32 + kg * 8);
             acc[tn] = mfma_bf16(av, bv, acc[tn]);
         }
     }
 }
 // the same with the A operand (the wave's 16 rows x 64 reduction columns) already in registers: operands that several rounds
 // share are read from LDS once
+template <int LD>
 __device__ __forceinline__ void tile_a8(bf16x8 (&av)[2], const u16* __restrict__ Xs, int rt, int lane) {
     const int n = lane & 15, kg = lane >> 4;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) av[ks] = *reinterpret_cast<const bf16x8*>(Xs + (rt * 16 + n) * CLD + ks * 32 + kg * 8);
+    for (int ks = 0; ks < 2; ++ks) av[ks] = *reinterpret_cast<const bf16x8*>(Xs + (rt * 16 + n) * LD + ks * 32 + kg * 8);
 }
-template <bool BT>
+template <int LD, bool BT>
 __device__ __forceinline__ void tile_mma8r(f32x4 (&acc)[2], const bf16x8 (&av)[2], const u16* __restrict__ Ys, int ch, int lane) {
     const int n = lane & 15, kg = lane >> 4;
 #pragma unroll
@@ -129,32 +138,36 @@ __device__ __forceinline__ void tile_mma8r(f32x4 (&acc)[2], const bf16x8 (&av)[2
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn) {
             const int c0 = ch * 32 + tn * 16;
-            const bf16x8 bv = BT ? tr_read8(Ys, CLD, ks * 32, c0, lane)
-                                 : *reinterpret_cast<const bf16x8*>(Ys + (c0 + n) * CLD + ks * 32 + kg * 8);
+            const bf16x8 bv = BT ? tr_read8(Ys, LD, ks * 32, c0, lane)
+                                 : *reinterpret_cast<const bf16x8*>(Ys + (c0 + n) * LD + ks * 32 + kg * 8);
             acc[tn] = mfma_bf16(av[ks], bv, acc[tn]);
         }
 }
 __device__ __forceinline__ void zero2(f32x4 (&x)[2]) { x[0] = x[1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 // C-layout accumulators (row = 16 rt + 4 kg + r, col = 32 ch + 16 tn + n) -> bf16 LDS tile
+template <int LD>
 __device__ __forceinline__ void cs8_put(u16* __restrict__ dst, const f32x4 (&x)[2], float mul, int rt, int ch, int lane) {
     const int n = lane & 15, kg = lane >> 4;
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dst[(rt * 16 + kg * 4 + r) * CLD + ch * 32 + tn * 16 + n] = cvt_bf16(mul * x[tn][r]);
+        for (int r = 0; r < 4; ++r) dst[(rt * 16 + kg * 4 + r) * LD + ch * 32 + tn * 16 + n] = cvt_bf16(mul * x[tn][r]);
 }
 // one element of a score tile -> its hi (and, HL, lo) plane
-template <bool HL>
-__device__ __forceinline__ void cs8_put_score(u16* __restrict__ tiles, int idx, float x) {
+template <int LD, bool HL>
+__device__ __forceinline__ void cs8_put_score(u16* __restrict__ tiles, int row, int col, float x) {
+    const int idx = row * LD + col;
     const u16 h = cvt_bf16(x);
     tiles[idx] = h;
-    if constexpr (HL) tiles[CT + idx] = cvt_bf16(x - bf16_to_f32(h));
+    if constexpr (HL) tiles[tile_elems<LD>() + idx] = cvt_bf16(x - bf16_to_f32(h));
 }
 
+// row stride of k_csf_bwd_tok4's tiles: 160 bytes unless its 16-17 tiles (K > 128 with hi + lo pairs) would not fit the 160 KB
+template <int NK, bool HL> __host__ __device__ constexpr int csf_tok4_ld() { return (HL && NK > 2) ? 72 : 80; }
 template <int NK, bool HL>
 __host__ __device__ constexpr int csf_tok4_smem() {
     constexpr int P = HL ? 2 : 1, NB = (NK > 2 || HL) ? 2 : 1;
-    return (P + 2 + 2 * NB * P + NK + (NB > 1 ? 1 : 0)) * CT * 2 + 32;
+    return (P + 2 + 2 * NB * P + NK + (NB > 1 ? 1 : 0)) * tile_elems<csf_tok4_ld<NK, HL>()>() * 2 + 32;
 }
 
 // k_csf_bwd_tok4: dQ, dK, dV and diag(dmix) of one chunk.      grid (n, bh), 512 threads
@@ -166,7 +179,7 @@ __host__ __device__ constexpr int csf_tok4_smem() {
 // set of P / dS buffers and a dV staging tile of its own, so that a round is commit -> ONE barrier -> refill -> multiply.
 template <int NK, bool HL>
 __global__ __launch_bounds__(NT4, (NK <= 2 && !HL) ? 4 : 2) void k_csf_bwd_tok4(const CsTokArgs a) {
-    constexpr int P = HL ? 2 : 1;
+    constexpr int P = HL ? 2 : 1, LD = csf_tok4_ld<NK, HL>(), CT = tile_elems<LD>();
     constexpr bool DBUF = NK > 2 || HL;
     constexpr int NB = DBUF ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -205,14 +218,14 @@ __global__ __launch_bounds__(NT4, (NK <= 2 && !HL) ? 4 : 2) void k_csf_bwd_tok4(
     zero2(accA);
 #pragma unroll
     for (int kk = 0; kk < NK; ++kk) {
-        cs8_commit_tok(X1, rP[kk][0], rv, tid);
-        cs8_commit_tok(KT + kk * CT, rdS[kk][0], rv, tid);
+        cs8_commit_tok<LD>(X1, rP[kk][0], rv, tid);
+        cs8_commit_tok<LD>(KT + kk * CT, rdS[kk][0], rv, tid);
         __syncthreads();
 #pragma unroll
         for (int p = 0; p < P; ++p) cs8_issue_state(rP[kk][p], Pb + cs_tile_off<HL>(kk * 64, 0, V) + p * CTE, tid);
 #pragma unroll
         for (int p = 0; p < P; ++p) cs8_issue_state(rdS[kk][p], dSb + cs_tile_off<HL>(kk * 64, 0, V) + p * CTE, tid);
-        tile_mma8<false, false>(accA, X1, KT + kk * CT, rt, ch, lane);
+        tile_mma8<LD, false, false>(accA, X1, KT + kk * CT, rt, ch, lane);
         __syncthreads();
     }
 #pragma unroll
@@ -222,7 +235,7 @@ __global__ __launch_bounds__(NT4, (NK <= 2 && !HL) ? 4 : 2) void k_csf_bwd_tok4(
             const int row = rt * 16 + kg * 4 + r, col = ch * 32 + tn * 16 + n;
             const float av = col <= row ? accA[tn][r] : 0.f;
             accA[tn][r] = av;   // kept for the diagonal term
-            cs8_put_score<HL>(As, row * CLD + col, mii * a.scale * av);
+            cs8_put_score<LD, HL>(As, row, col, mii * a.scale * av);
         }
 
     // ---- step 2: per V slice: dA, dV, and the dQ / dK partials of every K slice ----
@@ -231,7 +244,7 @@ __global__ __launch_bounds__(NT4, (NK <= 2 && !HL) ? 4 : 2) void k_csf_bwd_tok4(
     bf16x8 aK[KREG ? NK : 1][2];
     if constexpr (KREG) {
 #pragma unroll
-        for (int kk = 0; kk < NK; ++kk) tile_a8(aK[kk], KT + kk * CT, rt, lane);
+        for (int kk = 0; kk < NK; ++kk) tile_a8<LD>(aK[kk], KT + kk * CT, rt, lane);
     }
     f32x4 accQ[NK][2], accK[NK][2], accdA[2];
 #pragma unroll
@@ -246,8 +259,8 @@ __global__ __launch_bounds__(NT4, (NK <= 2 && !HL) ? 4 : 2) void k_csf_bwd_tok4(
         zero2(accV);
         bf16x8 aG[2], aV[2];
         const bool last = vs + 64 >= V;   // (uniform)
-        cs8_commit_tok(X1, nG, rv, tid);
-        cs8_commit_tok(X2, nV, rv, tid);
+        cs8_commit_tok<LD>(X1, nG, rv, tid);
+        cs8_commit_tok<LD>(X2, nV, rv, tid);
         // No load of the loop sits behind a branch: hipcc loses count of the loads in flight at every join and waits for ALL of
         // them (s_waitcnt vmcnt(0) before each refill -- the ring then holds one round, whatever its depth).  Behind the last V
         // slice the rows of this slice are requested again (never used) and the P slots receive step 3's Q tiles.
@@ -265,9 +278,9 @@ __global__ __launch_bounds__(NT4, (NK <= 2 && !HL) ? 4 : 2) void k_csf_bwd_tok4(
             u16* B2c = B2 + (DBUF && (rr & 1) ? P * CT : 0);
             ++rr;
 #pragma unroll
-            for (int p = 0; p < P; ++p) cs8_commit_state(B1c + p * CT, rP[kk][p], tid);
+            for (int p = 0; p < P; ++p) cs8_commit_state<LD>(B1c + p * CT, rP[kk][p], tid);
 #pragma unroll
-            for (int p = 0; p < P; ++p) cs8_commit_state(B2c + p * CT, rdS[kk][p], tid);
+            for (int p = 0; p < P; ++p) cs8_commit_state<LD>(B2c + p * CT, rdS[kk][p], tid);
             __syncthreads();
             {
                 const int r = tid >> 3, c = (tid & 7) * 8;
@@ -280,28 +293,28 @@ __global__ __launch_bounds__(NT4, (NK <= 2 && !HL) ? 4 : 2) void k_csf_bwd_tok4(
                 for (int p = 0; p < P; ++p) rdS[kk][p] = gld<uint4>(last ? qsrc : ssrc + p * CTE);   // (filler: the same lines)
             }
             if (kk == 0) {
-                tile_a8(aG, X1, rt, lane);
-                if constexpr (VREG) tile_a8(aV, X2, rt, lane);
-                tile_mma8r<false>(accdA, aG, X2, ch, lane);                                     // dO V^T
+                tile_a8<LD>(aG, X1, rt, lane);
+                if constexpr (VREG) tile_a8<LD>(aV, X2, rt, lane);
+                tile_mma8r<LD, false>(accdA, aG, X2, ch, lane);                                     // dO V^T
 #pragma unroll
-                for (int p = 0; p < P; ++p) tile_mma8<true, true>(accV, As + p * CT, X1, rt, ch, lane);   // A^T dO
+                for (int p = 0; p < P; ++p) tile_mma8<LD, true, true>(accV, As + p * CT, X1, rt, ch, lane);   // A^T dO
             }
             bf16x8 aKk[2];
-            if constexpr (!KREG && HL) tile_a8(aKk, KT + kk * CT, rt, lane);   // (one read for both planes)
+            if constexpr (!KREG && HL) tile_a8<LD>(aKk, KT + kk * CT, rt, lane);   // (one read for both planes)
 #pragma unroll
             for (int p = 0; p < P; ++p) {
-                tile_mma8r<false>(accQ[kk], aG, B1c + p * CT, ch, lane);                        // dO P^T
-                if constexpr (VREG) tile_mma8r<false>(accK[kk], aV, B2c + p * CT, ch, lane);    // V dS^T
-                else                tile_mma8<false, false>(accK[kk], X2, B2c + p * CT, rt, ch, lane);
-                if constexpr (KREG) tile_mma8r<true>(accV, aK[kk], B2c + p * CT, ch, lane);     // K dS
-                else if constexpr (HL) tile_mma8r<true>(accV, aKk, B2c + p * CT, ch, lane);
-                else                tile_mma8<false, true>(accV, KT + kk * CT, B2c + p * CT, rt, ch, lane);
+                tile_mma8r<LD, false>(accQ[kk], aG, B1c + p * CT, ch, lane);                        // dO P^T
+                if constexpr (VREG) tile_mma8r<LD, false>(accK[kk], aV, B2c + p * CT, ch, lane);    // V dS^T
+                else                tile_mma8<LD, false, false>(accK[kk], X2, B2c + p * CT, rt, ch, lane);
+                if constexpr (KREG) tile_mma8r<LD, true>(accV, aK[kk], B2c + p * CT, ch, lane);     // K dS
+                else if constexpr (HL) tile_mma8r<LD, true>(accV, aKk, B2c + p * CT, ch, lane);
+                else                tile_mma8<LD, false, true>(accV, KT + kk * CT, B2c + p * CT, rt, ch, lane);
             }
             if constexpr (!DBUF) __syncthreads();
         }
-        cs8_put(Vst, accV, 1.f, rt, ch, lane);
+        cs8_put<LD>(Vst, accV, 1.f, rt, ch, lane);
         __syncthreads();
-        cs8_store_tok(mbase(a.dv) + vs, a.dv.sn, p0, rv, Vst, tid);
+        cs8_store_tok<LD>(mbase(a.dv) + vs, a.dv.sn, p0, rv, Vst, tid);
         if constexpr (!DBUF) __syncthreads();
     }
 
@@ -316,7 +329,7 @@ __global__ __launch_bounds__(NT4, (NK <= 2 && !HL) ? 4 : 2) void k_csf_bwd_tok4(
             const int row = rt * 16 + kg * 4 + r, col = ch * 32 + tn * 16 + n;
             const float dv = col <= row ? accdA[tn][r] : 0.f;
             dsum += accA[tn][r] * dv;
-            cs8_put_score<HL>(dAs, row * CLD + col, mii * dv);
+            cs8_put_score<LD, HL>(dAs, row, col, mii * dv);
         }
     dsum = wave_sum(dsum);
     if (lane == 0) red[wave] = dsum;
@@ -324,22 +337,22 @@ __global__ __launch_bounds__(NT4, (NK <= 2 && !HL) ? 4 : 2) void k_csf_bwd_tok4(
     if (tid == 0) a.diag[(long)bh * a.n + ci] = a.scale * (((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7])));
 #pragma unroll
     for (int kk = 0; kk < NK; ++kk) {
-        cs8_commit_tok(X2, rP[kk][0], rv, tid);
+        cs8_commit_tok<LD>(X2, rP[kk][0], rv, tid);
         __syncthreads();
         f32x4 acc3[2];
         zero2(acc3);
 #pragma unroll
         for (int p = 0; p < P; ++p) {
-            tile_mma8<false, true>(accQ[kk], dAs + p * CT, KT + kk * CT, rt, ch, lane);   // dA K
-            tile_mma8<true, true>(acc3, dAs + p * CT, X2, rt, ch, lane);                  // dA^T Q
+            tile_mma8<LD, false, true>(accQ[kk], dAs + p * CT, KT + kk * CT, rt, ch, lane);   // dA K
+            tile_mma8<LD, true, true>(acc3, dAs + p * CT, X2, rt, ch, lane);                  // dA^T Q
         }
-        cs8_put(B1, accQ[kk], a.scale, rt, ch, lane);
+        cs8_put<LD>(B1, accQ[kk], a.scale, rt, ch, lane);
 #pragma unroll
         for (int i = 0; i < 2; ++i) accK[kk][i] += a.scale * acc3[i];
-        cs8_put(B2, accK[kk], 1.f, rt, ch, lane);
+        cs8_put<LD>(B2, accK[kk], 1.f, rt, ch, lane);
         __syncthreads();
-        cs8_store_tok(mbase(a.dq) + kk * 64, a.dq.sn, p0, rv, B1, tid);
-        cs8_store_tok(mbase(a.dk) + kk * 64, a.dk.sn, p0, rv, B2, tid);
+        cs8_store_tok<LD>(mbase(a.dq) + kk * 64, a.dq.sn, p0, rv, B1, tid);
+        cs8_store_tok<LD>(mbase(a.dk) + kk * 64, a.dk.sn, p0, rv, B2, tid);
         __syncthreads();
     }
 }
@@ -362,9 +375,10 @@ __global__ __launch_bounds__(NT4, (NK <= 2 && !HL) ? 4 : 2) void k_csf_bwd_tok4(
 constexpr int CSF_OUT4_CPW = CSF_OUT4_CPW_;   // chunks per workgroup of k_csf_out4 (plain variant)
 // NH: halves of the head's V channels that one workgroup of the fused-epilogue variant walks (V = 64 NV NH): with NH = 2 (V = 512)
 // the first half's outputs wait as fp32 in an LDS stash (64 KB) until the row sums of squares of the whole head are known.
+constexpr int CSF_OUT4_LD = 80;   // (8 tiles of 10 KB with hi + lo pairs: two workgroups fill the 160 KB exactly)
 template <int NV, bool EPI, bool HL, int NH = 1>
 __host__ __device__ constexpr int csf_out4_smem() {
-    return (4 + 2 * (HL ? 2 : 1)) * CT * 2 + (EPI ? 2 * 64 * 4 : 0) + (NH > 1 ? (NH - 1) * 64 * 64 * NV * 4 : 0);
+    return (4 + 2 * (HL ? 2 : 1)) * tile_elems<CSF_OUT4_LD>() * 2 + (EPI ? 2 * 64 * 4 : 0) + (NH > 1 ? (NH - 1) * 64 * 64 * NV * 4 : 0);
 }
 
 // (HL with four V slices per workgroup -- the fused epilogue at V = 256 -- holds 32 ring and 32 accumulator registers beside the
@@ -374,7 +388,7 @@ template <int NV, bool EPI, bool HL, int NH = 1>
 #define CSF_OUT4_NV4_WAVES 4   // four slices with hi + lo pairs: two workgroups per CU at 128 VGPRs and 4 spilled registers (98 us at C5)
 #endif                         // beat one workgroup at 134 (107 us) and two slices per workgroup, which read Q and K twice (108-112 us)
 __global__ __launch_bounds__(NT4, NH > 1 ? 2 : (HL && NV == 4) ? (EPI ? 2 : CSF_OUT4_NV4_WAVES) : 4) void k_csf_out4(const CsOutArgs a) {   // (NH > 1: 138 KB of LDS, one workgroup per CU anyway)
-    constexpr int P = HL ? 2 : 1;
+    constexpr int P = HL ? 2 : 1, LD = CSF_OUT4_LD, CT = tile_elems<LD>();
     static_assert(NH == 1 || EPI, "only the fused-epilogue variant walks several halves of the head");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u16* Qs = reinterpret_cast<u16*>(smem_raw);
@@ -439,11 +453,11 @@ __global__ __launch_bounds__(NT4, NH > 1 ? 2 : (HL && NV == 4) ? (EPI ? 2 : CSF_
         for (int j = 0; j < NV; ++j) {
             u16* Pc = Ps + ((ki * NV + j) & 1) * P * CT;
             if (j == 0) {
-                cs8_commit_tok(Qc, rQ, rv, tid);
-                cs8_commit_tok(Kc, rK, rv, tid);
+                cs8_commit_tok<LD>(Qc, rQ, rv, tid);
+                cs8_commit_tok<LD>(Kc, rK, rv, tid);
             }
 #pragma unroll
-            for (int p = 0; p < P; ++p) cs8_commit_state(Pc + p * CT, rP[j][p], tid);
+            for (int p = 0; p < P; ++p) cs8_commit_state<LD>(Pc + p * CT, rP[j][p], tid);
             __syncthreads();
             if (j == 0) {   // the next K slice's tiles -- behind the last K slice: the next chunk's first
                 const long rown = lastk ? trown : trow;
@@ -458,11 +472,11 @@ __global__ __launch_bounds__(NT4, NH > 1 ? 2 : (HL && NV == 4) ? (EPI ? 2 : CSF_
                 for (int p = 0; p < P; ++p) rP[j][p] = gld<uint4>(lastk ? vsrc : psrc + p * CTE);
             }
             if (j == 0) {
-                tile_a8(aQ, Qc, rt, lane);
-                tile_mma8r<false>(accA, aQ, Kc, ch, lane);   // Q K^T
+                tile_a8<LD>(aQ, Qc, rt, lane);
+                tile_mma8r<LD, false>(accA, aQ, Kc, ch, lane);   // Q K^T
             }
 #pragma unroll
-            for (int p = 0; p < P; ++p) tile_mma8r<true>(accO[j], aQ, Pc + p * CT, ch, lane);     // Q P
+            for (int p = 0; p < P; ++p) tile_mma8r<LD, true>(accO[j], aQ, Pc + p * CT, ch, lane);     // Q P
         }
     } while (++ki < nks);
 #pragma unroll
@@ -470,7 +484,7 @@ __global__ __launch_bounds__(NT4, NH > 1 ? 2 : (HL && NV == 4) ? (EPI ? 2 : CSF_
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = rt * 16 + kg * 4 + r, col = ch * 32 + tn * 16 + n;
-            cs8_put_score<HL>(Ao, row * CLD + col, col <= row ? mii * accA[tn][r] : 0.f);
+            cs8_put_score<LD, HL>(Ao, row, col, col <= row ? mii * accA[tn][r] : 0.f);
         }
     __syncthreads();   // the last round's tiles are dead, the score tile is complete
     if constexpr (!EPI) {
@@ -478,15 +492,15 @@ __global__ __launch_bounds__(NT4, NH > 1 ? 2 : (HL && NV == 4) ? (EPI ? 2 : CSF_
         for (int j = 0; j < NV; ++j) {
             u16* Vc = Ks + (j & 1) * CT;
             u16* Oc = Qs + (j & 1) * CT;
-            cs8_commit_tok(Vc, rP[j][0], rv, tid);
+            cs8_commit_tok<LD>(Vc, rP[j][0], rv, tid);
             __syncthreads();
 #pragma unroll
             for (int p = 0; p < P; ++p) cs8_issue_state(rP[j][p], Pbn + cs_tile_off<HL>(0, vbase + 64 * j, V) + p * CTE, tid);   // the next chunk's first P tiles
 #pragma unroll
-            for (int p = 0; p < P; ++p) tile_mma8<false, true>(accO[j], Ao + p * CT, Vc, rt, ch, lane);        // tril(QK^T) V
-            cs8_put(Oc, accO[j], a.scale, rt, ch, lane);
+            for (int p = 0; p < P; ++p) tile_mma8<LD, false, true>(accO[j], Ao + p * CT, Vc, rt, ch, lane);        // tril(QK^T) V
+            cs8_put<LD>(Oc, accO[j], a.scale, rt, ch, lane);
             __syncthreads();
-            cs8_store_tok(ob + 64 * j, a.o.sn, p0, rv, Oc, tid);
+            cs8_store_tok<LD>(ob + 64 * j, a.o.sn, p0, rv, Oc, tid);
         }
     } else {
         float* red = reinterpret_cast<float*>(Ps + 2 * P * CT);   // [2 column halves][64 rows] sums of squares
@@ -494,10 +508,10 @@ __global__ __launch_bounds__(NT4, NH > 1 ? 2 : (HL && NV == 4) ? (EPI ? 2 : CSF_
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             u16* Vc = Ks + (j & 1) * CT;
-            cs8_commit_tok(Vc, rP[j][0], rv, tid);
+            cs8_commit_tok<LD>(Vc, rP[j][0], rv, tid);
             __syncthreads();
 #pragma unroll
-            for (int p = 0; p < P; ++p) tile_mma8<false, true>(accO[j], Ao + p * CT, Vc, rt, ch, lane);
+            for (int p = 0; p < P; ++p) tile_mma8<LD, false, true>(accO[j], Ao + p * CT, Vc, rt, ch, lane);
         }
         // row sums of squares over the head's V channels: lane holds rows 16 rt + 4 kg + r, columns 64 j + 32 ch + 16 tn + n
 #pragma unroll
@@ -552,7 +566,7 @@ __global__ __launch_bounds__(NT4, NH > 1 ? 2 : (HL && NV == 4) ? (EPI ? 2 : CSF_
                 u16* Oc = Qs + (j & 1) * CT;
                 u16* Yc = Ks + (j & 1) * CT;
                 if (a.o.ptr) {   // training: the operator's own output is kept for the norm's backward
-                    cs8_put(Oc, accO[j], a.scale, rt, ch, lane);
+                    cs8_put<LD>(Oc, accO[j], a.scale, rt, ch, lane);
                 }
 #pragma unroll
                 for (int tn = 0; tn < 2; ++tn) {
@@ -560,10 +574,10 @@ __global__ __launch_bounds__(NT4, NH > 1 ? 2 : (HL && NV == 4) ? (EPI ? 2 : CSF_
 #pragma unroll
                     for (int r = 0; r < 4; ++r) accO[j][tn][r] *= a.scale * rstd[r] * w;
                 }
-                cs8_put(Yc, accO[j], 1.f, rt, ch, lane);
+                cs8_put<LD>(Yc, accO[j], 1.f, rt, ch, lane);
                 __syncthreads();
-                if (a.o.ptr) cs8_store_tok(ob_e + 64 * j, a.o.sn, p0, rv, Oc, tid);
-                cs8_store_tok_gate(yb + 64 * j, a.y.sn, gb ? gb + 64 * j : nullptr, a.gate.sn, p0, rv, Yc, tid);
+                if (a.o.ptr) cs8_store_tok<LD>(ob_e + 64 * j, a.o.sn, p0, rv, Oc, tid);
+                cs8_store_tok_gate<LD>(yb + 64 * j, a.y.sn, gb ? gb + 64 * j : nullptr, a.gate.sn, p0, rv, Yc, tid);
             }
         }
     }
