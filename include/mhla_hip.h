@@ -189,7 +189,7 @@ int mhla_blockmix_bwd_status(const void* ws, size_t ws_bytes, int B, int H, int 
 
 /* ---- causal chunk-mixing MHLA: fla ------------------------------------- */
 
-/* Workspace bytes.  bf16 tensors with K, V multiples of 64, K <= 256 and at most 128 chunks run the 16-bit-MFMA pipeline,
+/* Workspace bytes.  bf16 tensors with K, V multiples of 64, K <= 256 and at most 256 chunks run the 16-bit-MFMA pipeline,
  * whose chunk summaries are bf16 hi + lo pairs (4 bytes per element; 2 with MHLA_CAUSAL_BF16_SUMMARIES); everything else the
  * generic kernels with fp32 summaries.  `flags` must be the flags of the calls the workspace is for. */
 size_t mhla_causal_fwd_ws_bytes(int B, int T, int H, int K, int V, int chunk, int dtype, unsigned flags);
@@ -219,7 +219,7 @@ int mhla_causal_fwd(mhla_view q, mhla_view k, mhla_view v, const float* mix, int
  * store (inference); training passes it so that the norm's backward (mhla_rmsnorm_gate_bwd) has its input.  `gate` ptr NULL:
  * no gate; `norm_w` NULL: no affine weight.  Covers what mhla_causal_normgate_fusable() reports (bf16 tensors, K % 64 == 0,
  * K <= 256, V % 64 == 0 with V <= 256 or V = 384 / 512 -- one workgroup owns a head's channels, the wide heads in two halves --,
- * at most 128 chunks); otherwise MHLA_ENOTSUP and
+ * at most 256 chunks); otherwise MHLA_ENOTSUP and
  * the caller runs mhla_causal_fwd + mhla_rmsnorm_gate_fwd.  Workspace: as mhla_causal_fwd (usable as `fwd_ws` of
  * mhla_causal_bwd with the same flags). */
 int mhla_causal_normgate_fusable(int T, int K, int V, int chunk, int dtype, unsigned flags);

@@ -17,15 +17,15 @@ struct CsWs {
     size_t total_fwd, total_bwd;
 };
 // Which kernel family serves a causal problem:
-//   16-bit pipeline (causal_bf16.hpp, causal_mix.hpp): bf16 tensors, K and V multiples of 64, K <= 256, at most 128 chunks
-//   (the mixing kernels keep every chunk of a sequence resident); hl: summaries and score tiles as bf16 hi + lo pairs (the
+//   16-bit pipeline (causal_bf16.hpp, causal_mix.hpp): bf16 tensors, K and V multiples of 64, K <= 256, at most 256 chunks
+//   (the mixing kernels keep every chunk of a sequence resident: 16 waves of 16 chunks); hl: summaries and score tiles as bf16 hi + lo pairs (the
 //   reference's fp32 arithmetic, default), !hl: single bf16 (MHLA_CAUSAL_BF16_SUMMARIES);
 //   everything else: the generic kernels (causal.hpp: exact fp32 MFMA, fp32 summaries).
 struct CsPath { bool pipe16, hl; int esz; };   // esz: bytes per logical summary element
 CsPath cs_path(int T, int K, int V, int chunk, int dtype, unsigned flags) {
     const int n = (T + chunk - 1) / chunk;
     CsPath p{};
-    p.pipe16 = dtype == MHLA_BF16 && (K & 63) == 0 && (V & 63) == 0 && K <= 256 && n <= 128 && !(flags & MHLA_CAUSAL_FORCE_GENERIC);
+    p.pipe16 = dtype == MHLA_BF16 && (K & 63) == 0 && (V & 63) == 0 && K <= 256 && n <= 256 && !(flags & MHLA_CAUSAL_FORCE_GENERIC);
     p.hl = p.pipe16 && !(flags & MHLA_CAUSAL_BF16_SUMMARIES);
     p.esz = p.pipe16 && !p.hl ? 2 : 4;
     return p;
@@ -36,10 +36,10 @@ CsPath cs_path(int T, int K, int V, int chunk, int dtype, unsigned flags) {
 struct Mix2Plan { int nw, te, wgs, spw; long total; };
 Mix2Plan mix2_plan(size_t bh, int n, long E, bool bwd, bool hl) {
     Mix2Plan p{};
-    p.nw = n <= 32 ? 2 : n <= 64 ? 4 : 8;
-    p.te = hl ? 64 : 128;
+    p.nw = n <= 32 ? 2 : n <= 64 ? 4 : n <= 128 ? 8 : 16;
+    p.te = (hl ? 64 : 128) / (p.nw > 8 ? 2 : 1);
     p.total = (long)bh * (E / p.te);
-    const long slots = 256L * (8 / p.nw) * (bwd ? 1 : 2);
+    const long slots = p.nw > 8 ? 256L : 256L * (8 / p.nw) * (bwd ? 1 : 2);   // (16 waves: one workgroup per CU either way)
     if (p.total <= 0) return p;
     const long wgs = std::min(p.total, slots);
     p.spw = (int)((p.total + wgs - 1) / wgs);
@@ -102,7 +102,7 @@ int cs_mix_fwd(const float* mix, int ldmix, const uint16_t* S, uint16_t* P, int 
     const Mix2Plan pl = mix2_plan((size_t)BH, n, E, false, HL);
     fast::CsfMix2Args mf{mix, ldmix, S, nullptr, P, nullptr, n, E, pl.total, pl.spw};
 #define MIXF(NW) launch(fast::k_csf_mixf<NW, HL>, dim3(pl.wgs), dim3(64 * NW), fast::mixf_smem<NW, HL>(), st, "k_csf_mixf", mf)
-    return pl.nw == 2 ? MIXF(2) : pl.nw == 4 ? MIXF(4) : MIXF(8);
+    return pl.nw == 2 ? MIXF(2) : pl.nw == 4 ? MIXF(4) : pl.nw == 8 ? MIXF(8) : MIXF(16);
 #undef MIXF
 }
 
@@ -142,7 +142,12 @@ int cs_bwd16(const mhla_view& q, const mhla_view& k, const mhla_view& v, const f
     const Mix2Plan pl = mix2_plan((size_t)B * H, n, E, true, HL);
     fast::CsfMix2Args mb{mix, ldmix, dP, S, dS, w.dwp, n, E, pl.total, pl.spw};
 #define MIXB(NW) launch(fast::k_csf_mixb<NW, HL>, dim3(pl.wgs), dim3(128 * NW), fast::mixb_smem<NW, HL>(), st, "k_csf_mixb", mb)
-    RC(pl.nw == 2 ? MIXB(2) : pl.nw == 4 ? MIXB(4) : MIXB(8));
+    if (pl.nw <= 8) {
+        RC(pl.nw == 2 ? MIXB(2) : pl.nw == 4 ? MIXB(4) : MIXB(8));
+    } else {   // 129..256 chunks: the two roles as two launches of 16 waves
+        RC(launch(fast::k_csf_mixb<16, HL, 1>, dim3(pl.wgs), dim3(1024), fast::mixb_smem<16, HL>(), st, "k_csf_mixb<dS>", mb));
+        RC(launch(fast::k_csf_mixb<16, HL, 2>, dim3(pl.wgs), dim3(1024), fast::mixb_smem<16, HL>(), st, "k_csf_mixb<dmix>", mb));
+    }
 #undef MIXB
     CsTokArgs t{cv(q), cv(k), cv(v), cv(dout), cmv(dq), cmv(dk), cmv(dv), mix, ldmix, w.P, w.dS, w.diag, H, n, K, V, (long)T, scale};
 #define TOK4(NK) launch(fast::k_csf_bwd_tok4<NK, HL>, dim3(n, B * H), dim3(fast::NT4), fast::csf_tok4_smem<NK, HL>(), st, "k_csf_bwd_tok4", t)
@@ -166,7 +171,7 @@ int cs_fwd_impl(mhla_view q, mhla_view k, mhla_view v, const float* mix, int ldm
     if (epi) {
         if (!cs_epi_ok(path, V))
             return fail(MHLA_ENOTSUP, "fused norm x gate epilogue needs bf16 tensors, K %% 64 == 0, K <= 256, V %% 64 == 0, V <= 256 or "
-                        "V = 384 / 512, and at most 128 chunks (T=%d K=%d V=%d dtype=%d flags=0x%x)", T, K, V, dtype, flags);
+                        "V = 384 / 512, and at most 256 chunks (T=%d K=%d V=%d dtype=%d flags=0x%x)", T, K, V, dtype, flags);
         const mhla_view yv{y.ptr, y.sb, y.sn, y.sh};
         if (!view_ok16(yv) || (gate.ptr && !view_ok16(gate)) || (out.ptr && !view_ok16m(out)))
             return fail(MHLA_EINVAL, "fused norm x gate epilogue: y, gate and out must be 16-byte aligned views (strides multiples of 8)");

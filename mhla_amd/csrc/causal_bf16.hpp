@@ -1,4 +1,4 @@
-// bf16-MFMA kernels of the causal chunk-mixing operator (bf16 tensors, K and V multiples of 64, K <= 256, n <= 128 chunks).
+// bf16-MFMA kernels of the causal chunk-mixing operator (bf16 tensors, K and V multiples of 64, K <= 256, n <= 256 chunks).
 // Same algorithm as k_cs_out / k_cs_bwd_tok (causal.hpp): every contraction is a 64 x 64 x 64 tile product, but the tiles
 // live in LDS as bf16 ([64][72], row-major) and run on v_mfma_f32_16x16x32_bf16; operands whose reduction index is the row
 // index of the staged tile come through the hardware transpose read.

@@ -1,4 +1,4 @@
-// Chunk mixing of the causal operator with every chunk of a sequence resident in one workgroup (n <= 128 chunks).
+// Chunk mixing of the causal operator with every chunk of a sequence resident in one workgroup (n <= 256 chunks: 16 384 tokens).
 //
 //   forward  k_csf_mixf:  P_i[e]  = sum_{j < i} m_ij S_j[e]                         (naive.py:73-75)
 //   backward k_csf_mixb:  dS_j[e] = sum_{i > j} m_ij dP_i[e]   and, from the same two tiles,
@@ -21,8 +21,9 @@
 namespace mhla {
 namespace fast {
 
-template <bool HL> __host__ __device__ constexpr int mix_te_fwd() { return HL ? 64 : 128; }
-template <bool HL> __host__ __device__ constexpr int mix_te_bwd() { return HL ? 64 : 128; }
+// logical elements per slice: the slice's rows of all 16 NW chunks must fit the LDS (forward: input + staging, two workgroups per CU
+// up to 128 chunks; backward: dP, S and the dS staging) -- halved for sequences of 129..256 chunks (NW = 16)
+template <int NW, bool HL> __host__ __device__ constexpr int mix_te() { return (HL ? 64 : 128) / (NW > 8 ? 2 : 1); }
 
 struct CsfMix2Args {
     const float* W;     // mixing matrix [n][ldw]
@@ -101,12 +102,13 @@ __device__ __forceinline__ void mix_split(const float (&w)[8], bf16x8& hi, bf16x
     }
 }
 
-template <int NW, bool HL> __host__ __device__ constexpr int mixf_smem() { return 2 * (HL ? 2 : 1) * 16 * NW * (mix_te_fwd<HL>() + 8) * 2; }
+template <int NW, bool HL> __host__ __device__ constexpr int mixf_smem() { return 2 * (HL ? 2 : 1) * 16 * NW * (mix_te<NW, HL>() + 8) * 2; }
 
 // NW waves = 16 NW chunk rows (n <= 16 NW); NK = reduction steps of 32 chunks
 template <int NW, bool HL>
 __global__ __launch_bounds__(64 * NW, 4) void k_csf_mixf(const CsfMix2Args a) {
-    constexpr int TE = mix_te_fwd<HL>(), P = HL ? 2 : 1, NK = (NW + 1) / 2, MF_LD = TE + 8, NT = TE / 16, ROWS = 16 * NW;
+    constexpr int TE = mix_te<NW, HL>(), P = HL ? 2 : 1, NK = (NW + 1) / 2, MF_LD = TE + 8, NT = TE / 16, ROWS = 16 * NW;
+    constexpr int TB = NT < 4 ? NT : 4;   // element tiles multiplied together
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u16* Ts = reinterpret_cast<u16*>(smem_raw);   // [P][ROWS][MF_LD]
     u16* Os = Ts + P * ROWS * MF_LD;              // [P][ROWS][MF_LD]
@@ -147,21 +149,21 @@ __global__ __launch_bounds__(64 * NW, 4) void k_csf_mixf(const CsfMix2Args a) {
         for (int ks = 0; ks < NK; ++ks) {
             if (ks <= kmax) {
 #pragma unroll
-                for (int t4 = 0; t4 < NT; t4 += 4) {
-                    bf16x8 sv[4], sl[4];
+                for (int t4 = 0; t4 < NT; t4 += TB) {
+                    bf16x8 sv[TB], sl[TB];
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) sv[t] = tr_read8(Ts, MF_LD, ks * 32, (t4 + t) * 16, lane);
+                    for (int t = 0; t < TB; ++t) sv[t] = tr_read8(Ts, MF_LD, ks * 32, (t4 + t) * 16, lane);
                     if constexpr (HL) {
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) sl[t] = tr_read8(Ts + ROWS * MF_LD, MF_LD, ks * 32, (t4 + t) * 16, lane);
+                        for (int t = 0; t < TB; ++t) sl[t] = tr_read8(Ts + ROWS * MF_LD, MF_LD, ks * 32, (t4 + t) * 16, lane);
                     }
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) acc[t4 + t] = mfma_bf16(sv[t], wh[ks], acc[t4 + t]);
+                    for (int t = 0; t < TB; ++t) acc[t4 + t] = mfma_bf16(sv[t], wh[ks], acc[t4 + t]);
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) acc[t4 + t] = mfma_bf16(sv[t], wl[ks], acc[t4 + t]);
+                    for (int t = 0; t < TB; ++t) acc[t4 + t] = mfma_bf16(sv[t], wl[ks], acc[t4 + t]);
                     if constexpr (HL) {
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) acc[t4 + t] = mfma_bf16(sl[t], wh[ks], acc[t4 + t]);
+                        for (int t = 0; t < TB; ++t) acc[t4 + t] = mfma_bf16(sl[t], wh[ks], acc[t4 + t]);
                     }
                 }
             }
@@ -183,31 +185,35 @@ __device__ __forceinline__ void tri_tile(int idx, int& it, int& jt) {
 // Backward: 2 NW waves.  Waves [0, NW) form dS for their 16 chunks j (as the forward does for P); waves [NW, 2 NW) accumulate
 // the dmix tiles -- two roles on disjoint register budgets (the one-role version needed ~150 VGPRs and spilled at the 128 that
 // four waves per SIMD leave), multiplying side by side between the same two barriers.  Every thread helps moving the rows.
-template <int NW, bool HL> __host__ __device__ constexpr int mixb_smem() { return 3 * (HL ? 2 : 1) * 16 * NW * (mix_te_bwd<HL>() + 8) * 2; }
+template <int NW, bool HL> __host__ __device__ constexpr int mixb_smem() { return 3 * (HL ? 2 : 1) * 16 * NW * (mix_te<NW, HL>() + 8) * 2; }
 
-template <int NW, bool HL>
-__global__ __launch_bounds__(128 * NW) void k_csf_mixb(const CsfMix2Args a) {
-    constexpr int TE = mix_te_bwd<HL>(), P = HL ? 2 : 1, NK = (NW + 1) / 2, MF_LD = TE + 8, NT = TE / 16, ROWS = 16 * NW;
+// ROLE 0: both roles in one workgroup of 2 NW waves (NW <= 8).  Sequences of 129..256 chunks (NW = 16) would need 32 waves: the two
+// roles run as two launches of NW waves each, ROLE 1 (dS) and ROLE 2 (dmix); dP is then read twice.
+template <int NW, bool HL, int ROLE = 0>
+__global__ __launch_bounds__((ROLE == 0 ? 128 : 64) * NW) void k_csf_mixb(const CsfMix2Args a) {
+    constexpr int TE = mix_te<NW, HL>(), P = HL ? 2 : 1, NK = (NW + 1) / 2, MF_LD = TE + 8, NT = TE / 16, ROWS = 16 * NW;
+    constexpr int TB = NT < 4 ? NT : 4, NTHR = (ROLE == 0 ? 128 : 64) * NW;
+    static_assert(ROLE != 0 || NW <= 8, "both roles in one workgroup: at most 16 waves");
     constexpr int NTL = NW * (NW + 1) / 2, TPW = (NTL + NW - 1) / NW;   // dmix tiles, tiles per wave
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u16* Tp = reinterpret_cast<u16*>(smem_raw);   // [P][ROWS][MF_LD] dP rows of the slice
     u16* Tq = Tp + P * ROWS * MF_LD;               // S rows of the slice
     u16* Os = Tq + P * ROWS * MF_LD;               // dS staging
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nl = lane & 15, kg = lane >> 4;
-    const bool mixer = wave < NW;                  // (uniform) dS role; the others: dmix role
-    const int rw = mixer ? wave : wave - NW;
+    const bool mixer = ROLE == 1 || (ROLE == 0 && wave < NW);   // (uniform) dS role; the others: dmix role
+    const int rw = (ROLE == 0 && !mixer) ? wave - NW : wave;
     const int n = a.n;
     const long nsl = a.E / TE, CSZ = a.E * P + CS_CHUNK_PAD;
     const long s0 = (long)blockIdx.x * a.spw;
     const int cnt = (int)min((long)a.spw, a.total - s0);
     float* part = a.dwp + (long)blockIdx.x * n * n;
-    MixRows<128 * NW, ROWS, TE, HL> pp, pq;
+    MixRows<NTHR, ROWS, TE, HL> pp, pq;
     pp.offsets(CSZ, n, tid);
 #pragma unroll
     for (int p = 0; p < pp.NP; ++p) pq.goff[p] = pp.goff[p];
     if (cnt > 0) {
         pp.issue(a.in + mix_slice_off<TE, HL>(s0, nsl, n, CSZ));
-        pq.issue(a.in2 + mix_slice_off<TE, HL>(s0, nsl, n, CSZ));
+        if constexpr (ROLE != 1) pq.issue(a.in2 + mix_slice_off<TE, HL>(s0, nsl, n, CSZ));
     }
     if (mixer) {
         // B operand: B[k = i][n = j] = m_ij for the wave's chunks j = 16 rw + nl, i = 32 ks + 8 kg + t, i > j
@@ -228,39 +234,39 @@ __global__ __launch_bounds__(128 * NW) void k_csf_mixb(const CsfMix2Args a) {
         const int kmin = rw / 2, kend = (n + 31) / 32;   // reduction steps that hold a chunk i > j for this wave's rows
         for (int it = 0; it < cnt; ++it) {
             pp.commit(Tp, n, tid);
-            pq.commit(Tq, n, tid);
+            if constexpr (ROLE != 1) pq.commit(Tq, n, tid);
             __syncthreads();
             if (it + 1 < cnt) {
                 pp.issue(a.in + mix_slice_off<TE, HL>(s0 + it + 1, nsl, n, CSZ));
-                pq.issue(a.in2 + mix_slice_off<TE, HL>(s0 + it + 1, nsl, n, CSZ));
+                if constexpr (ROLE != 1) pq.issue(a.in2 + mix_slice_off<TE, HL>(s0 + it + 1, nsl, n, CSZ));
             }
 #pragma unroll
-            for (int t4 = 0; t4 < NT; t4 += 4) {
-                f32x4 acc[4];
+            for (int t4 = 0; t4 < NT; t4 += TB) {
+                f32x4 acc[TB];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int t = 0; t < TB; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ks = 0; ks < NK; ++ks) {
                     if (ks >= kmin && ks < kend) {
-                        bf16x8 sv[4], sl[4];
+                        bf16x8 sv[TB], sl[TB];
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) sv[t] = tr_read8(Tp, MF_LD, ks * 32, (t4 + t) * 16, lane);
+                        for (int t = 0; t < TB; ++t) sv[t] = tr_read8(Tp, MF_LD, ks * 32, (t4 + t) * 16, lane);
                         if constexpr (HL) {
 #pragma unroll
-                            for (int t = 0; t < 4; ++t) sl[t] = tr_read8(Tp + ROWS * MF_LD, MF_LD, ks * 32, (t4 + t) * 16, lane);
+                            for (int t = 0; t < TB; ++t) sl[t] = tr_read8(Tp + ROWS * MF_LD, MF_LD, ks * 32, (t4 + t) * 16, lane);
                         }
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) acc[t] = mfma_bf16(sv[t], wh[ks], acc[t]);
+                        for (int t = 0; t < TB; ++t) acc[t] = mfma_bf16(sv[t], wh[ks], acc[t]);
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) acc[t] = mfma_bf16(sv[t], wl[ks], acc[t]);
+                        for (int t = 0; t < TB; ++t) acc[t] = mfma_bf16(sv[t], wl[ks], acc[t]);
                         if constexpr (HL) {
 #pragma unroll
-                            for (int t = 0; t < 4; ++t) acc[t] = mfma_bf16(sl[t], wh[ks], acc[t]);
+                            for (int t = 0; t < TB; ++t) acc[t] = mfma_bf16(sl[t], wh[ks], acc[t]);
                         }
                     }
                 }
 #pragma unroll
-                for (int t = 0; t < 4; ++t) mix_stage4<TE, ROWS, HL>(Os, acc[t], rw * 16 + nl, (t4 + t) * 16 + kg * 4);
+                for (int t = 0; t < TB; ++t) mix_stage4<TE, ROWS, HL>(Os, acc[t], rw * 16 + nl, (t4 + t) * 16 + kg * 4);
             }
             __syncthreads();
             pp.store(a.out + mix_slice_off<TE, HL>(s0 + it, nsl, n, CSZ), n, Os, tid);
@@ -303,7 +309,7 @@ __global__ __launch_bounds__(128 * NW) void k_csf_mixb(const CsfMix2Args a) {
                 }
             }
             __syncthreads();
-            pp.store(a.out + mix_slice_off<TE, HL>(s0 + it, nsl, n, CSZ), n, Os, tid);
+            if constexpr (ROLE == 0) pp.store(a.out + mix_slice_off<TE, HL>(s0 + it, nsl, n, CSZ), n, Os, tid);
         }
         // the workgroup's partial of dmix: C[m = i][n = j], lane (i = 16 it + 4 kg + r, j = 16 jt + nl); entries with j >= i are never read
 #pragma unroll

@@ -917,7 +917,7 @@ class _CausalNormGate(torch.autograd.Function):
 
 def causal_normgate_fusable(q: torch.Tensor, v: torch.Tensor, chunk_size: int = 64, flags: int = 0) -> bool:
     """Shapes the fused epilogue covers (the library's own answer, mhla_causal_normgate_fusable: bf16, K % 64 == 0, K <= 256,
-    V % 64 == 0, V <= 256, at most 128 chunks) within one launch's (batch, head) range."""
+    V % 64 == 0, V <= 256 or V = 384 / 512, at most 256 chunks) within one launch's (batch, head) range."""
     if q.dtype not in _DTYPES or not (q.shape[0] > 0 and q.shape[1] > 0 and q.shape[0] * q.shape[2] <= _MAX_GRID_BH):
         return False
     return _lib.load().mhla_causal_normgate_fusable(q.shape[1], q.shape[-1], v.shape[-1], chunk_size, _DTYPES[q.dtype], flags) == 1
@@ -927,8 +927,8 @@ def mhla_causal_normgate(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mixi
                          gate: Optional[torch.Tensor], weight: Optional[torch.Tensor], norm_eps: float = 1e-5,
                          chunk_size: int = 64, scale: Optional[float] = None, *, summaries: str = "split") -> torch.Tensor:
     """`rmsnorm_gate(mhla_causal(q, k, v, mix), gate, weight, norm_eps)` -- the fla layer's operator + FusedRMSNormGated
-    (mhla_nlp/fla/layers/mhla.py:330-355).  Where the fused epilogue applies (bf16, K, V multiples of 64, K, V <= 256, at most
-    128 chunks) the norm x gate runs inside the operator's output kernel; other shapes compose the two HIP operators.
+    (mhla_nlp/fla/layers/mhla.py:330-355).  Where the fused epilogue applies (bf16, K, V multiples of 64, K <= 256, V <= 256 or
+    384 / 512, at most 256 chunks) the norm x gate runs inside the operator's output kernel; other shapes compose the two HIP operators.
     `summaries`: see mhla_causal."""
     flags = _causal_flags(summaries, False)
     if scale is None:

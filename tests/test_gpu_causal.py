@@ -97,28 +97,31 @@ BF16_SHAPES = [(256, 64, 64), (200, 64, 128), (50, 128, 64), (1000, 128, 256), (
                (320, 64, 48), (320, 48, 64), (200, 192, 192), (130, 192, 320), (200, 64, 384),
                # chunk walks of the output / summaries kernels (four chunks per workgroup): a full group followed by a partial
                # one, ragged and one-token last chunks
-               (330, 128, 256), (449, 128, 256), (321, 64, 64), (8192, 64, 64), (2100, 256, 256)]
+               (330, 128, 256), (449, 128, 256), (321, 64, 64), (8192, 64, 64), (2100, 256, 256),
+               # 129..256 chunks: the sixteen-wave mixing kernels (dS and dmix as two launches)
+               (8256, 64, 64), (16384, 64, 64), (10000, 128, 128)]
 
 
 @pytest.mark.parametrize("T,K,V", BF16_SHAPES)
 def test_causal_shapes_bf16(T, K, V):
-    """K and V multiples of 64 (K <= 256, at most 128 chunks) run the 16-bit-MFMA pipeline (ragged last chunk included); the
+    """K and V multiples of 64 (K <= 256, at most 256 chunks) run the 16-bit-MFMA pipeline (ragged last chunk included); the
     others the generic kernels.  The eight-wave kernels are templated on K / 64 (1..4) and on the V slices per workgroup
     (192 x 192 -> <3>, <3>; V = 320 -> five workgroups of one slice; V = 384 -> two of three).  Tolerance: the reference's
     arithmetic -- one final rounding + 1e-3."""
     run_causal(2, T, 2, K, V, max(4, (T + 63) // 64), torch.bfloat16, seed=T + K)
 
 
-@pytest.mark.parametrize("T,K,V", [(256, 64, 64), (1000, 128, 256), (129, 256, 512), (200, 192, 192), (200, 64, 384), (330, 128, 256)])
+@pytest.mark.parametrize("T,K,V", [(256, 64, 64), (1000, 128, 256), (129, 256, 512), (200, 192, 192), (200, 64, 384), (330, 128, 256),
+                                   (9000, 64, 128)])
 def test_causal_shapes_bf16_reduced_precision_variant(T, K, V):
     """summaries="bf16" (MHLA_CAUSAL_BF16_SUMMARIES): the opt-in variant with single-bf16 chunk summaries and score tiles, held
     to the K-intermediate bounds of gpu_util (2u outputs, 3u gradients)."""
     run_causal(2, T, 2, K, V, max(4, (T + 63) // 64), torch.bfloat16, seed=T + K, summaries="bf16")
 
 
-@pytest.mark.parametrize("T,K,V", [(8256, 64, 64), (300, 320, 64)])
+@pytest.mark.parametrize("T,K,V", [(16400, 64, 64), (300, 320, 64)])
 def test_causal_bf16_beyond_the_pipeline(T, K, V):
-    """bf16 tensors outside the 16-bit pipeline's range (more than 128 chunks; K > 256): the generic fp32-MFMA kernels."""
+    """bf16 tensors outside the 16-bit pipeline's range (more than 256 chunks; K > 256): the generic fp32-MFMA kernels."""
     run_causal(1, T, 2, K, V, max(4, (T + 63) // 64), torch.bfloat16, seed=T + K)
 
 

@@ -40,7 +40,8 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert lib.mhla_causal_normgate_fusable(8192, 128, 256, 64, 1, 0) == 1
     assert lib.mhla_causal_normgate_fusable(8192, 256, 512, 64, 1, 0) == 1    # wide heads: two halves per workgroup
     assert lib.mhla_causal_normgate_fusable(8192, 128, 320, 64, 1, 0) == 0
-    assert lib.mhla_causal_normgate_fusable(8256, 128, 256, 64, 1, 0) == 0    # 129 chunks: generic kernels
+    assert lib.mhla_causal_normgate_fusable(8256, 128, 256, 64, 1, 0) == 1    # 129 chunks: sixteen-wave mixing kernels
+    assert lib.mhla_causal_normgate_fusable(16448, 128, 256, 64, 1, 0) == 0   # 257 chunks: generic kernels
     assert lib.mhla_causal_normgate_fusable(8192, 128, 256, 64, 0, 0) == 0    # fp32 tensors
 
 
