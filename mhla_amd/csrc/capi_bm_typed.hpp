@@ -5,6 +5,7 @@
 #include "capi_common.hpp"
 #include "blockmix.hpp"
 #include "split.hpp"
+#include "split16.hpp"
 
 namespace mhla {
 namespace capi {
@@ -39,12 +40,40 @@ inline int sp_mixr(const float* W, int ldw, const void* in, void* out, int M, lo
 #undef MIXR
 }
 
+// Blocks of exactly 16 tokens, bf16, D = 64, every row a whole number of 16-byte pieces: the wave-per-block kernels of split16.hpp
+// replace the token kernels (same workspace formats).  `bwd`: the call's gradient views must qualify too.
+template <typename ET, int DT>
+inline bool s16_ok(const BmCall& c, bool bwd) {
+    if constexpr (!std::is_same<ET, bf16_t>::value || DT != 4) {
+        return false;
+    } else {
+        if (c.S != 16 || c.D != 64 || c.split || c.rcos || c.epi || !sp_shape_ok(c.D, c.flags)) return false;
+        if (!(view_ok16(c.q_num) && view_ok16(c.k_num) && view_ok16(c.v))) return false;
+        if (!bwd) return view_ok16m(c.out);
+        return view_ok16(c.dout) && view_ok16(c.outv) && view_ok16m(c.dq_num) && view_ok16m(c.dk_num) && view_ok16m(c.dv);
+    }
+}
+// dW partials with the whole M x M matrix in one workgroup (s16::k_sp_dwr): 64 < M <= 256, 16-bit summaries
+inline bool sp_dwr_ok(int M, long E) { return M > 64 && M <= 256 && E % 64 == 0; }
+inline int sp_dwr_splits(int BH, long E) {
+    int ns = (256 + BH - 1) / BH;
+    if (ns > DW_MAX_SPLIT) ns = DW_MAX_SPLIT;
+    while (ns > 1 && E / ns < 256) --ns;
+    return ns < 1 ? 1 : ns;
+}
+inline int sp_dwr(const void* x, const void* y, long E, const float* x2, const float* y2, int S2, float* out, int M, int BH, int nsplit, hipStream_t st) {
+    s16::DwrArgs d{(const sp::u16*)x, (const sp::u16*)y, E, x2, y2, S2, out, M, nsplit};
+    if (M <= 128) return launch(s16::k_sp_dwr<2>, dim3(nsplit, BH), dim3(256), s16::dwr_smem<2>(), st, "k_sp_dwr<2>", d);
+    if (M <= 192) return launch(s16::k_sp_dwr<3>, dim3(nsplit, BH), dim3(576), s16::dwr_smem<3>(), st, "k_sp_dwr<3>", d);
+    return launch(s16::k_sp_dwr<4>, dim3(nsplit, BH), dim3(1024), s16::dwr_smem<4>(), st, "k_sp_dwr<4>", d);
+}
+
 // KV/ksum/z, G for the forward and the recompute leg of the backward.
 template <typename T, int DT>
 int bm_state_and_mix(const mhla_view& q_num, const mhla_view& k_num, const mhla_view& v, const mhla_view& q_den,
                      const mhla_view& k_den, const float* W, int ldw, const int32_t* idx, const BmWs& w, int B, int H,
                      int M, int S, int D, float eps, unsigned flags, bool normalize, bool split, hipStream_t st,
-                     const float* rcos = nullptr, const float* rsin = nullptr, long ldr = 0) {
+                     const float* rcos = nullptr, const float* rsin = nullptr, long ldr = 0, bool s16 = false) {
     (void)q_num;
     StateArgs a{};
     a.rcos = rcos; a.rsin = rsin; a.ldr = ldr;
@@ -55,7 +84,8 @@ int bm_state_and_mix(const mhla_view& q_num, const mhla_view& k_num, const mhla_
     MixArgs m{W, ldw, w.kv, w.g, M, (long)D * D};
     if (sp_shape_ok(D, flags)) {   // split-bf16 MFMA kernels (split.hpp)
         constexpr int SNT = sp_state_threads<DT>();   // eight waves at D = 128 (split.hpp)
-        if (a.rcos) RC(launch(sp::k_sp_state<T, DT, 0, true, SNT>, dim3(M, B * H), dim3(SNT), sp::sp_state_smem<DT>(), st, "k_sp_state<rope>", a));
+        if (s16)    RC(launch(s16::k_s16_state<0>, dim3((M + s16::WPB - 1) / s16::WPB, B * H), dim3(64 * s16::WPB), s16::state_smem(), st, "k_s16_state<0>", a));
+        else if (a.rcos) RC(launch(sp::k_sp_state<T, DT, 0, true, SNT>, dim3(M, B * H), dim3(SNT), sp::sp_state_smem<DT>(), st, "k_sp_state<rope>", a));
         else        RC(launch(sp::k_sp_state<T, DT, 0, false, SNT>, dim3(M, B * H), dim3(SNT), sp::sp_state_smem<DT>(), st, "k_sp_state", a));
         if (sp_mixr_ok<sp::Sum16<T>::value>(M, m.E)) RC((sp_mixr<0, sp::Sum16<T>::value>(W, ldw, w.kv, w.g, M, m.E, B * H, st)));
         else RC(launch(sp::k_sp_mix<0, sp::Sum16<T>::value>, dim3((unsigned)((m.E + sp::SPM_TE - 1) / sp::SPM_TE), (M + 63) / 64, B * H), dim3(NTHREADS), sp::sp_mix_smem<sp::Sum16<T>::value>(), st, "k_sp_mix<0>", m));
@@ -87,7 +117,8 @@ int bm_fwd_typed(const BmCall& c) {
     (void)dout; (void)gate; (void)out_view; (void)dq_num; (void)dk_num; (void)dv; (void)dq_den; (void)dk_den; (void)dW; (void)reuse; (void)epi;
     (void)rcos; (void)rsin; (void)ldr; (void)nw; (void)neps; (void)out_dtype; (void)relu;
     DISPATCH_DT(dt, {
-        RC((bm_state_and_mix<ET, DT>(q_num, k_num, v, q_den, k_den, W, ldw, block_index, w, B, H, M, S, D, eps, flags, normalize, split, st, rcos, rsin, ldr)));
+        const bool s16 = s16_ok<ET, DT>(c, false);
+        RC((bm_state_and_mix<ET, DT>(q_num, k_num, v, q_den, k_den, W, ldw, block_index, w, B, H, M, S, D, eps, flags, normalize, split, st, rcos, rsin, ldr, s16)));
         OutArgs o{};
         o.rcos = rcos; o.rsin = rsin; o.ldr = ldr;
         o.q = cv(q_num); o.o = cmv(c.out); o.idx = block_index; o.W = W; o.ldw = ldw; o.g = w.g; o.ninv = w.ninv;
@@ -101,7 +132,9 @@ int bm_fwd_typed(const BmCall& c) {
                 else if (out_dtype == MHLA_F16) RC(launch(sp::k_sp_out<float, DT, f16_t, true>, g, blk, sp::sp_out_smem<DT>(), st, "k_sp_out<norm>", o));
                 else                            RC(launch(sp::k_sp_out<float, DT, float, true>, g, blk, sp::sp_out_smem<DT>(), st, "k_sp_out<norm>", o));
             }
-        } else if (sp_shape_ok(D, flags))
+        } else if (s16)
+            RC(launch(s16::k_s16_out<0>, dim3((M + s16::WPB - 1) / s16::WPB, B * H), dim3(64 * s16::WPB), s16::out_smem(), st, "k_s16_out", o));
+        else if (sp_shape_ok(D, flags))
             RC(launch(sp::k_sp_out<ET, DT>, dim3(M, B * H), dim3(sp::SP_OUT_T), sp::sp_out_smem<DT, sp::Sum16<ET>::value>(), st, "k_sp_out", o));
         else
             RC(launch(k_bm_out<ET, DT>, dim3(M, B * H), dim3(NTHREADS), out_smem_floats<DT>() * 4, st, "k_bm_out", o));
@@ -125,8 +158,9 @@ int bm_bwd_typed(const BmCall& c) {
     (void)dout; (void)gate; (void)out_view; (void)dq_num; (void)dk_num; (void)dv; (void)dq_den; (void)dk_den; (void)dW; (void)reuse; (void)epi;
     (void)rcos; (void)rsin; (void)ldr; (void)nw; (void)neps; (void)out_dtype; (void)relu;
     DISPATCH_DT(dt, {
+        const bool s16 = s16_ok<ET, DT>(c, true);
         if (!reuse)
-            RC((bm_state_and_mix<ET, DT>(q_num, k_num, v, q_den, k_den, W, ldw, block_index, w, B, H, M, S, D, eps, flags, normalize, split, st, rcos, rsin, ldr)));
+            RC((bm_state_and_mix<ET, DT>(q_num, k_num, v, q_den, k_den, W, ldw, block_index, w, B, H, M, S, D, eps, flags, normalize, split, st, rcos, rsin, ldr, s16)));
         // dG_i = Q_i^T (dO_i / n_i), dn_i
         StateArgs a{};
         a.x = cv(q_num); a.y = cv(dout); a.o = cv(out_view); a.idx = block_index; a.W = W; a.ldw = ldw; a.ninv = w.ninv;
@@ -147,7 +181,8 @@ int bm_bwd_typed(const BmCall& c) {
             if constexpr (std::is_same<ET, float>::value) {
                 if (rcos) RC(launch(sp::k_sp_state<ET, DT, 1, true, SNT>, dim3(M, B * H), dim3(SNT), sp::sp_state_smem<DT>(), st, "k_sp_state<1,rope>", a));
             }
-            if (!rcos) RC(launch(sp::k_sp_state<ET, DT, 1, false, SNT>, dim3(M, B * H), dim3(SNT), sp::sp_state_smem<DT>(), st, "k_sp_state<1>", a));
+            if (s16) RC(launch(s16::k_s16_state<1>, dim3((M + s16::WPB - 1) / s16::WPB, B * H), dim3(64 * s16::WPB), s16::state_smem(), st, "k_s16_state<1>", a));
+            else if (!rcos) RC(launch(sp::k_sp_state<ET, DT, 1, false, SNT>, dim3(M, B * H), dim3(SNT), sp::sp_state_smem<DT>(), st, "k_sp_state<1>", a));
             if (normalize)
                 RC(launch(k_wz<1>, dim3((S + 63) / 64, (M + 63) / 64, B * H), dim3(NTHREADS), 0, st, "k_wz<1>", W, ldw, (const float*)w.dn, w.dz, M, S, 0.f));
             MixArgs m{W, ldw, w.dg, w.dkv, M, E};
@@ -156,11 +191,15 @@ int bm_bwd_typed(const BmCall& c) {
             int nsplit = dw_splits(tiles * tiles * B * H, E);
             if (nsplit > DW_MAX_SPLIT - 1) nsplit = DW_MAX_SPLIT - 1;   // one more part per (b, h) holds the <dn_i, z_j> term
             DwArgs d{w.dg, w.kv, E, nullptr, nullptr, 0, w.dwp, M, tiles, nsplit};
-            if (M <= 16)      RC(launch(sp::k_sp_dw<sp::Sum16<ET>::value, 1>, dim3(1, B * H, nsplit), dim3(NTHREADS), sp::SP_DW_SMEM, st, "k_sp_dw<16>", d));
+            const bool dwr = sp::Sum16<ET>::value && sp_dwr_ok(M, E);   // whole-matrix workgroups: the <dn_i, z_j> term is one of their stages
+            if (dwr) {
+                nsplit = sp_dwr_splits(B * H, E);
+                RC(sp_dwr(w.dg, w.kv, E, normalize ? w.dn : nullptr, normalize ? w.z : nullptr, S, w.dwp, M, B * H, nsplit, st));
+            } else if (M <= 16)      RC(launch(sp::k_sp_dw<sp::Sum16<ET>::value, 1>, dim3(1, B * H, nsplit), dim3(NTHREADS), sp::SP_DW_SMEM, st, "k_sp_dw<16>", d));
             else if (M <= 32) RC(launch(sp::k_sp_dw<sp::Sum16<ET>::value, 2>, dim3(1, B * H, nsplit), dim3(NTHREADS), sp::SP_DW_SMEM, st, "k_sp_dw<32>", d));
             else              RC(launch(sp::k_sp_dw<sp::Sum16<ET>::value>, dim3(tiles * tiles, B * H, nsplit), dim3(NTHREADS), sp::SP_DW_SMEM, st, "k_sp_dw", d));
             int nparts = B * H * nsplit;
-            if (normalize) {
+            if (normalize && !dwr) {
                 DwArgs dzz{w.dn, w.z, (long)S, nullptr, nullptr, 0, w.dwp + (size_t)nparts * M * M, M, tiles, 1};
                 RC(launch(k_dw<0>, dim3(tiles * tiles, B * H, 1), dim3(NTHREADS), DW_SMEM_FLOATS * 4, st, "k_dw", dzz));
                 nparts += B * H;
@@ -175,6 +214,12 @@ int bm_bwd_typed(const BmCall& c) {
                     RC(launch(sp::k_sp_bwd_dkv<ET, DT, true>, dim3(M, B * H), dim3(NTHREADS), sp::sp_tok_smem<DT, false>(), st, "k_sp_bwd_dkv<rope>", t));
                     break;
                 }
+            }
+            if (s16) {   // (the dK kernel forms dksum itself: no order between the two)
+                const dim3 g16((M + s16::WPB - 1) / s16::WPB, B * H), b16(64 * s16::WPB);
+                RC(launch(s16::k_s16_bwd_dq<0>, g16, b16, 0, st, "k_s16_bwd_dq", t));
+                RC(launch(s16::k_s16_bwd_dkv<0>, g16, b16, s16::dkv_smem(), st, "k_s16_bwd_dkv", t));
+                break;
             }
             RC(launch(sp::k_sp_bwd_dq<ET, DT>, dim3(M, B * H), dim3(NTHREADS), sp::sp_tok_smem<DT, sp::Sum16<ET>::value>(), st, "k_sp_bwd_dq", t));
             RC(launch(sp::k_sp_bwd_dkv<ET, DT>, dim3(M, B * H), dim3(NTHREADS), sp::sp_tok_smem<DT, sp::Sum16<ET>::value>(), st, "k_sp_bwd_dkv", t));

@@ -23,6 +23,7 @@ namespace sp {
 using fast::bf16x8;
 using fast::mfma_bf16;
 using fast::tr_read8;
+using fast::s16x4;
 using fast::u16;
 
 template <typename T>
@@ -474,15 +475,20 @@ struct MixrArgs {
 };
 // slice width: 256-byte row pieces; 128-byte ones for 16 waves (1024 threads on 128 VGPRs: half the accumulators and staging registers)
 template <int NW, bool S16> __host__ __device__ constexpr int mixr_te() { return (S16 ? 128 : 64) / (NW > 12 ? 2 : 1); }
+// 64-element slices of 16-bit summaries: unpadded 128-byte rows with XOR-swizzled 16-byte pieces (fast::gt_off) -- the padded rows
+// (TE + 8) are two-way bank-conflicted in the transposed operand reads, and with sixteen waves each reading the WHOLE slice
+// (512 KB of LDS reads per 32 KB of HBM) the kernel is bound by exactly those reads
+template <int NW, bool S16> __host__ __device__ constexpr bool mixr_swz() { return S16 && mixr_te<NW, S16>() == 64; }
 template <int NW, bool S16>
 __host__ __device__ constexpr int sp_mixr_smem() {
-    constexpr int TE = mixr_te<NW, S16>(), ROWS = 16 * NW;
-    return (S16 ? 1 : 2) * ROWS * (TE + 8) * 2 + (S16 ? ROWS * (TE + 8) * 2 : ROWS * (TE + 4) * 4);
+    constexpr int TE = mixr_te<NW, S16>(), ROWS = 16 * NW, LD = mixr_swz<NW, S16>() ? TE : TE + 8;
+    return (S16 ? 1 : 2) * ROWS * LD * 2 + (S16 ? ROWS * LD * 2 : ROWS * (TE + 4) * 4);
 }
 
 template <int NW, int TRANS, bool S16>
 __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void k_sp_mixr(const MixrArgs a) {
-    constexpr int TE = mixr_te<NW, S16>(), ROWS = 16 * NW, LD = TE + 8, LDO = TE + 4, NK = (NW + 1) / 2, NT = TE / 16;
+    constexpr bool SWZ = mixr_swz<NW, S16>();
+    constexpr int TE = mixr_te<NW, S16>(), ROWS = 16 * NW, LD = SWZ ? TE : TE + 8, LDO = TE + 4, NK = (NW + 1) / 2, NT = TE / 16;
     constexpr int PPR = TE * (S16 ? 2 : 4) / 16;          // 16-byte pieces per row of the slice (16, or 8 with 16 waves)
     constexpr int NTH = 64 * NW, NP = ROWS * PPR / NTH;   // pieces per thread and slice
     static_assert(NP * NTH == ROWS * PPR, "pieces must tile the slice");
@@ -514,7 +520,11 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void k_sp_mixr(const MixrArg
         }
     }
     constexpr int ESZ = S16 ? 2 : 4;
-    auto slice_off = [&](long sl) { const long bh = sl / nsl, es = sl - bh * nsl; return (bh * M * a.E + es * TE) * ESZ; };   // bytes
+    // byte offset of slice (bh, es); a workgroup's slices are consecutive, so the pair is advanced rather than divided out per
+    // slice (the 64-bit division was 150 instructions with branches between the barrier and the next slice's loads)
+    auto slice_off = [&](int bh, int es) { return ((long)bh * M * a.E + (long)es * TE) * ESZ; };
+    auto advance = [&](int& bh, int& es) { if (++es == (int)nsl) { es = 0; ++bh; } };
+    int cbh = (int)(s0 / nsl), ces = (int)(s0 - (long)cbh * nsl), nbh = cbh, nes = ces;
     // the thread's pieces: piece v = tid + p NTH -> row v / PPR, 16 bytes at column piece v % PPR (rows past M: the last row, zeroed)
     unsigned goff[NP];
 #pragma unroll
@@ -522,21 +532,26 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void k_sp_mixr(const MixrArg
         const int v = tid + p * NTH, row = v / PPR, c = v % PPR;
         goff[p] = (unsigned)((long)(row < M ? row : M - 1) * a.E * ESZ + c * 16);
     }
-    uint4 pre[NP];
-    auto issue = [&](long sl) {
-        const char* base = reinterpret_cast<const char*>(a.in) + slice_off(sl);
+    // PF slices in flight per thread.  Two for the sixteen-wave variant: its 32 KB slices (one workgroup per CU) in flight one at
+    // a time are 13 GB/s per CU at the loaded memory latency -- the kernel waited for its prefetch, not for LDS or the matrix pipe
+    constexpr int PF = SWZ ? 2 : 1;
+    uint4 preA[NP], preB[PF == 2 ? NP : 1];
+    auto issue = [&](uint4 (&pre)[NP], long boff) {
+        const char* base = reinterpret_cast<const char*>(a.in) + boff;
 #pragma unroll
         for (int p = 0; p < NP; ++p) pre[p] = gld_stream16(base + goff[p]);
     };
-    issue(s0);
-    for (int it = 0; it < cnt; ++it) {
-        const long off = slice_off(s0 + it);
+    auto body = [&](uint4 (&pre)[NP], int it) {
+        const long off = slice_off(cbh, ces);
+        advance(cbh, ces);
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             const int v = tid + p * NTH, row = v / PPR, c = v % PPR;
             const bool ok = row < M;   // rows past the last block: zeros (their weights are zero too, but 0 x NaN is not)
             const uint4 x = make_uint4(ok ? pre[p].x : 0u, ok ? pre[p].y : 0u, ok ? pre[p].z : 0u, ok ? pre[p].w : 0u);
-            if constexpr (S16) {
+            if constexpr (SWZ) {
+                *reinterpret_cast<uint4*>(Th + fast::gt_off(row, c * 8)) = x;
+            } else if constexpr (S16) {
                 *reinterpret_cast<uint4*>(Th + row * LD + c * 8) = x;
             } else {   // four floats -> four bf16 hi + four bf16 lo
                 const float f[4] = {__uint_as_float(x.x), __uint_as_float(x.y), __uint_as_float(x.z), __uint_as_float(x.w)};
@@ -551,22 +566,54 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void k_sp_mixr(const MixrArg
                 *reinterpret_cast<uint2*>(Tl + row * LD + c * 4) = make_uint2(pack_bf16x2(l[0], l[1]), pack_bf16x2(l[2], l[3]));
             }
         }
+        if (PF == 2 && it + 2 < cnt) {   // the registers just committed take the slice after the one in flight
+            advance(nbh, nes);
+            issue(pre, slice_off(nbh, nes));
+        }
         __syncthreads();
-        if (it + 1 < cnt) issue(s0 + it + 1);
+        if (PF == 1 && it + 1 < cnt) {
+            advance(nbh, nes);
+            issue(pre, slice_off(nbh, nes));
+        }
         f32x4 acc[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // swizzled tiles: the piece permutation depends on the row's low four bits only, so the transposed-read addresses of
+        // reduction step 0 serve every step with a constant offset, and element tile t is tile 0 with bit t of the piece index
+        // flipped (offset ^ 16 t).  Two offsets are kept; the tile's are rebuilt per step behind a laundering asm -- hoisted out
+        // of the loops they cost 8 (64 before the factoring) registers of a 128-register budget, and ONE spilled weight
+        // register reloaded inside the slice loop waits (vmcnt counts in order) for the prefetched next slice: 175 -> 210 us
+        int tr0 = 0, tr1 = 0;
+        if constexpr (SWZ) {
+            const int g = lane >> 4, li = lane & 15;
+            tr0 = fast::gt_off(g * 8 + (li >> 2), (li & 3) * 4);
+            tr1 = fast::gt_off(g * 8 + (li >> 2) + 4, (li & 3) * 4);
+        }
+#ifdef MIXR_NOMFMA   // (experiment builds only: the kernel without its products / without its stores)
+        const int kend = 0;
+#else
         const int kend = (M + 31) / 32;   // (uniform) reduction steps that hold a block
+#endif
 #pragma unroll
         for (int ks = 0; ks < NK; ++ks) {
             if (ks < kend) {
-                constexpr int TB = NT < 4 ? NT : 4;   // operand tiles per batch
+                constexpr int TB = SWZ ? 2 : (NT < 4 ? NT : 4);   // operand tiles per batch (two where the second prefetch buffer needs the registers)
 #pragma unroll
                 for (int t4 = 0; t4 < NT; t4 += TB) {
                     bf16x8 sv[TB], sl[S16 ? 1 : TB];
 #pragma unroll
                     for (int t = 0; t < TB; ++t) {
-                        sv[t] = tr_read8(Th, LD, ks * 32, (t4 + t) * 16, lane);
+                        if constexpr (SWZ) {
+                            const int b0 = fast::opaque_lane(tr0), b1 = fast::opaque_lane(tr1);
+                            const fast::s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_S16X4(Th + ks * 32 * TE + (b0 ^ ((t4 + t) << 4))));
+                            const fast::s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_S16X4(Th + ks * 32 * TE + (b1 ^ ((t4 + t) << 4))));
+                            fast::s16x8 r8;
+                            r8[0] = lo4[0]; r8[1] = lo4[1]; r8[2] = lo4[2]; r8[3] = lo4[3];
+                            r8[4] = hi4[0]; r8[5] = hi4[1]; r8[6] = hi4[2]; r8[7] = hi4[3];
+                            sv[t] = __builtin_bit_cast(bf16x8, r8);
+                        } else {
+                            sv[t] = tr_read8(Th, LD, ks * 32, (t4 + t) * 16, lane);
+                        }
                         if constexpr (!S16) sl[t] = tr_read8(Tl, LD, ks * 32, (t4 + t) * 16, lane);
                     }
 #pragma unroll
@@ -581,8 +628,16 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void k_sp_mixr(const MixrArg
             }
         }
         // lane: elements 16 t + 4 kg .. + 3 of output block 16 wave + nl -> staging tile [block][element]
+        if constexpr (SWZ) {   // neighbouring element tiles paired into 16-byte pieces (8-byte writes of 16 lanes with one column conflict in any layout)
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
+            for (int t = 0; t < NT; t += 2) {
+                const uint4 pc = fast::pair_pieces(make_uint2(pack_bf16x2(acc[t][0], acc[t][1]), pack_bf16x2(acc[t][2], acc[t][3])),
+                                                   make_uint2(pack_bf16x2(acc[t + 1][0], acc[t + 1][1]), pack_bf16x2(acc[t + 1][2], acc[t + 1][3])));
+                *reinterpret_cast<uint4*>(reinterpret_cast<u16*>(Os) + fast::gt_off(wave * 16 + nl, (t + (kg & 1)) * 16 + 8 * (kg >> 1))) = pc;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < (SWZ ? 0 : NT); ++t) {
             if constexpr (S16)
                 *reinterpret_cast<uint2*>(reinterpret_cast<u16*>(Os) + (wave * 16 + nl) * LD + t * 16 + kg * 4) =
                     make_uint2(pack_bf16x2(acc[t][0], acc[t][1]), pack_bf16x2(acc[t][2], acc[t][3]));
@@ -594,12 +649,30 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void k_sp_mixr(const MixrArg
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             const int v = tid + p * NTH, row = v / PPR, c = v % PPR;
+#ifdef MIXR_NOSTORE
+            if (row < M && cnt < 0) {
+#else
             if (row < M) {
-                const uint4 x = S16 ? *reinterpret_cast<const uint4*>(reinterpret_cast<const u16*>(Os) + row * LD + c * 8)
+#endif
+                const uint4 x = SWZ ? *reinterpret_cast<const uint4*>(reinterpret_cast<const u16*>(Os) + fast::gt_off(row, c * 8))
+                              : S16 ? *reinterpret_cast<const uint4*>(reinterpret_cast<const u16*>(Os) + row * LD + c * 8)
                                     : *reinterpret_cast<const uint4*>(reinterpret_cast<const float*>(Os) + row * LDO + c * 4);
                 gst<uint4>(ob + goff[p], x);
             }
         }
+    };
+    issue(preA, slice_off(nbh, nes));
+    if constexpr (PF == 2) {
+        if (cnt > 1) {
+            advance(nbh, nes);
+            issue(reinterpret_cast<uint4 (&)[NP]>(preB), slice_off(nbh, nes));
+        }
+        for (int it = 0; it < cnt; it += 2) {
+            body(preA, it);
+            if (it + 1 < cnt) body(reinterpret_cast<uint4 (&)[NP]>(preB), it + 1);
+        }
+    } else {
+        for (int it = 0; it < cnt; ++it) body(preA, it);
     }
 }
 

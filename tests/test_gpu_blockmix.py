@@ -186,14 +186,38 @@ def test_c2_variant_256_blocks_of_16():
     run_case(1, 2, 256, 16, 64, torch.bfloat16, w="rand")
 
 
-@pytest.mark.parametrize("D", [72, 128])
-def test_split_operand_path_relu_prologue(D):
+@pytest.mark.parametrize("M,normalize,gather", [(65, True, False), (130, False, False), (203, True, True), (256, True, True), (77, False, True)])
+def test_blocks_of_16_tokens_wave_per_block_kernels(M, normalize, gather):
+    """bf16, D = 64, S = 16, more than 64 blocks: the wave-per-block token kernels (split16.hpp) and the whole-matrix dW kernel
+    (M not a multiple of the 4 blocks of a workgroup, with and without the normaliser, with a gather map)."""
+    idx = torch.randperm(M * 16, generator=torch.Generator().manual_seed(M)).int() if gather else None
+    run_case(2, 3, M, 16, 64, torch.bfloat16, normalize=normalize, w="rand", idx=idx, seed=M)
+
+
+def test_blocks_of_16_tokens_views_into_a_packed_projection():
+    """The same kernels on strided views (q, k, v slices of one [B, N, 3, H, D] projection output) and a non-contiguous dout."""
+    import mhla_amd
+    B, H, M, S, D = 2, 4, 96, 16, 64
+    q, k, v, W, do, _, _ = make_blockmix_inputs(B, H, M, S, D, torch.bfloat16, 5, "rand", False)
+    want, wg = oracle_blockmix(q, k, v, W, do, None, None, 1e-6, True)
+    qkv = torch.stack([q, k, v], dim=2).to(DEV).requires_grad_(True)
+    Wd = W.to(DEV).requires_grad_(True)
+    out = mhla_amd.mhla_blockmix(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], Wd, eps=1e-6)
+    out.backward(do.to(DEV))
+    check("out", out, want, TOL[torch.bfloat16])
+    for i, name in enumerate(("dq", "dk", "dv")):
+        check(name, qkv.grad[:, :, i], wg[name], GTOL[torch.bfloat16])
+    check("dW", Wd.grad, wg["dW"], GTOL[torch.bfloat16])
+
+
+@pytest.mark.parametrize("D,grid", [(72, (4, 4)), (128, (4, 4)), (64, (8, 10))])
+def test_split_operand_path_relu_prologue(D, grid):
     """relu(x) + eps folded into the loads (mhla_dit/mhla/mhla.py:229-230) and its gradient mask, split path."""
     import mhla_amd
     g = torch.Generator().manual_seed(D)
-    B, H, M, S = 2, 2, 16, 40
+    B, H, M, S = 2, 2, grid[0] * grid[1], (40 if grid == (4, 4) else 16)   # 80 blocks of 16 at D = 64: the wave-per-block kernels
     q0, k0, v, do = (torch.randn(B, M * S, H, D, generator=g).bfloat16() for _ in range(4))
-    W = orc.block_distance_weights((4, 4), "linear")
+    W = orc.block_distance_weights(grid, "linear")
     qf, kf = (orc.relu_eps(t.float(), 1e-6) for t in (q0, k0))
     want = orc.blockmix_fwd(qf, kf, v.float(), W, 1e-6)
     leaves = [t.to(DEV).requires_grad_(True) for t in (q0, k0, v)]
