@@ -23,20 +23,35 @@ template <bool S16>
 inline bool sp_mixr_ok(int M, long E) {
     return M > 32 && M <= 256 && E % sp::mixr_te<4, S16>() == 0;
 }
+// the normaliser's product (k_wz) rides along in the LDS-DMA mixing kernel: same weights, at most 16 values per block
+template <bool S16>
+inline bool sp_mixr_takes_wz(int M, int S) { return S16 && M > 192 && M <= 256 && S <= 16; }
 template <int TRANS, bool S16>
-inline int sp_mixr(const float* W, int ldw, const void* in, void* out, int M, long E, int BH, hipStream_t st) {
+inline int sp_mixr(const float* W, int ldw, const void* in, void* out, int M, long E, int BH, hipStream_t st,
+                   const float* zin = nullptr, float* zout = nullptr, int S = 0, float eps = 0.f) {
 #define MIXR(NW) do { \
         constexpr int TE = sp::mixr_te<NW, S16>(); \
         const long total = (long)BH * (E / TE); \
         const int wgs = (int)std::min<long>(total, 256); \
-        sp::MixrArgs a{W, ldw, in, out, M, E, total, (int)((total + wgs - 1) / wgs)}; \
+        sp::MixrArgs a{W, ldw, in, out, M, E, total, (int)((total + wgs - 1) / wgs), nullptr, nullptr, 0, 0.f}; \
         const int gw = (int)((total + a.spw - 1) / a.spw); \
         return launch(sp::k_sp_mixr<NW, TRANS, S16>, dim3(gw), dim3(64 * NW), sp::sp_mixr_smem<NW, S16>(), st, TRANS ? "k_sp_mixr<1>" : "k_sp_mixr<0>", a); \
     } while (0)
+    if constexpr (S16) {
+        if (M > 192) {   // eight waves x 32 output blocks, LDS-DMA staging with three slices in flight
+            const long total = (long)BH * (E / 64);
+            const int wgs = (int)std::min<long>(total, 256);
+            const bool wz = zin && sp_mixr_takes_wz<S16>(M, S);
+            sp::MixrArgs a{W, ldw, in, out, M, E, total, (int)((total + wgs - 1) / wgs), wz ? zin : nullptr, wz ? zout : nullptr, S, eps};
+            const int gw = (int)((total + a.spw - 1) / a.spw);
+            return launch(sp::k_sp_mixr_dma<TRANS>, dim3(gw), dim3(sp::MIXR_DMA_T), sp::sp_mixr_dma_smem(), st, TRANS ? "k_sp_mixr_dma<1>" : "k_sp_mixr_dma<0>", a);
+        }
+    }
     if (M <= 64) MIXR(4);
     if (M <= 128) MIXR(8);
     if (M <= 192) MIXR(12);
-    MIXR(16);
+    if constexpr (!S16) MIXR(16);   // (16-bit summaries: taken by the DMA kernel above)
+    return fail(MHLA_EINVAL, "sp_mixr: M=%d out of range", M);
 #undef MIXR
 }
 
@@ -87,9 +102,10 @@ int bm_state_and_mix(const mhla_view& q_num, const mhla_view& k_num, const mhla_
         if (s16)    RC(launch(s16::k_s16_state<0>, dim3((M + s16::WPB - 1) / s16::WPB, B * H), dim3(64 * s16::WPB), s16::state_smem(), st, "k_s16_state<0>", a));
         else if (a.rcos) RC(launch(sp::k_sp_state<T, DT, 0, true, SNT>, dim3(M, B * H), dim3(SNT), sp::sp_state_smem<DT>(), st, "k_sp_state<rope>", a));
         else        RC(launch(sp::k_sp_state<T, DT, 0, false, SNT>, dim3(M, B * H), dim3(SNT), sp::sp_state_smem<DT>(), st, "k_sp_state", a));
-        if (sp_mixr_ok<sp::Sum16<T>::value>(M, m.E)) RC((sp_mixr<0, sp::Sum16<T>::value>(W, ldw, w.kv, w.g, M, m.E, B * H, st)));
+        const bool mixr = sp_mixr_ok<sp::Sum16<T>::value>(M, m.E), wz_fused = mixr && normalize && sp_mixr_takes_wz<sp::Sum16<T>::value>(M, S);
+        if (mixr) RC((sp_mixr<0, sp::Sum16<T>::value>(W, ldw, w.kv, w.g, M, m.E, B * H, st, normalize ? (const float*)w.z : nullptr, w.ninv, S, eps)));
         else RC(launch(sp::k_sp_mix<0, sp::Sum16<T>::value>, dim3((unsigned)((m.E + sp::SPM_TE - 1) / sp::SPM_TE), (M + 63) / 64, B * H), dim3(NTHREADS), sp::sp_mix_smem<sp::Sum16<T>::value>(), st, "k_sp_mix<0>", m));
-        if (normalize)
+        if (normalize && !wz_fused)
             RC(launch(k_wz<0>, dim3((S + 63) / 64, (M + 63) / 64, B * H), dim3(NTHREADS), 0, st, "k_wz<0>", W, ldw, (const float*)w.z, w.ninv, M, S, eps));
         return MHLA_OK;
     }
@@ -183,10 +199,11 @@ int bm_bwd_typed(const BmCall& c) {
             }
             if (s16) RC(launch(s16::k_s16_state<1>, dim3((M + s16::WPB - 1) / s16::WPB, B * H), dim3(64 * s16::WPB), s16::state_smem(), st, "k_s16_state<1>", a));
             else if (!rcos) RC(launch(sp::k_sp_state<ET, DT, 1, false, SNT>, dim3(M, B * H), dim3(SNT), sp::sp_state_smem<DT>(), st, "k_sp_state<1>", a));
-            if (normalize)
+            const bool mixr = sp_mixr_ok<sp::Sum16<ET>::value>(M, E), wz_fused = mixr && normalize && sp_mixr_takes_wz<sp::Sum16<ET>::value>(M, S);
+            if (normalize && !wz_fused)
                 RC(launch(k_wz<1>, dim3((S + 63) / 64, (M + 63) / 64, B * H), dim3(NTHREADS), 0, st, "k_wz<1>", W, ldw, (const float*)w.dn, w.dz, M, S, 0.f));
             MixArgs m{W, ldw, w.dg, w.dkv, M, E};
-            if (sp_mixr_ok<sp::Sum16<ET>::value>(M, E)) RC((sp_mixr<1, sp::Sum16<ET>::value>(W, ldw, w.dg, w.dkv, M, E, B * H, st)));
+            if (mixr) RC((sp_mixr<1, sp::Sum16<ET>::value>(W, ldw, w.dg, w.dkv, M, E, B * H, st, normalize ? (const float*)w.dn : nullptr, w.dz, S, 0.f)));
             else RC(launch(sp::k_sp_mix<1, sp::Sum16<ET>::value>, dim3((unsigned)((E + sp::SPM_TE - 1) / sp::SPM_TE), tiles, B * H), dim3(NTHREADS), sp::sp_mix_smem<sp::Sum16<ET>::value>(), st, "k_sp_mix<1>", m));
             int nsplit = dw_splits(tiles * tiles * B * H, E);
             if (nsplit > DW_MAX_SPLIT - 1) nsplit = DW_MAX_SPLIT - 1;   // one more part per (b, h) holds the <dn_i, z_j> term

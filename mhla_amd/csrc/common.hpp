@@ -74,6 +74,22 @@ __device__ __forceinline__ void gst_stream16(void* p, uint4 v) {
 #endif
 }
 
+// LDS-DMA: 16 bytes per lane from `gsrc` (per lane) to LDS byte address `lds_dst` + 16 lane (`lds_dst` wave-uniform).  Written as
+// asm so that hipcc does not see an LDS write in flight: with the builtin it puts `s_waitcnt vmcnt(0)` in front of every
+// transposed LDS read and every LDS write that follows, which drains the copies the kernel wants to keep in flight.  The copy is
+// therefore NOT in the compiler's wait bookkeeping either: the kernel counts it itself (s_waitcnt vmcnt(N), then a barrier,
+// then the reads).  M0 holds the destination and is restored in the same statement (it is compiler-reserved).
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
+}
+
 // 4-element vector I/O per dtype (16 B for f32, 8 B for 16-bit types).  (Nontemporal variants of these loads were measured on
 // the split-operand / generic kernels in round 2: 1-11 % slower on every shape, so these paths keep regular loads.)
 template <typename T> struct Io;

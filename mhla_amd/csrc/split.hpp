@@ -472,23 +472,24 @@ struct MixrArgs {
     long E;        // elements per block summary (multiple of the slice width)
     long total;    // slices = bh * E / TE
     int spw;       // slices per workgroup
+    // k_sp_mixr_dma only: the normaliser's product with the same weights, out = f(sum_r Wm(o, r) zin[bh][r][s]) for S <= 16 fp32
+    // values per block (k_wz<0>: f = 1 / (eps + .), Wm = W with TRANS 0; k_wz<1>: f = identity, Wm = W^T with TRANS 1); null: none
+    const float* zin;
+    float* zout;
+    int S;
+    float eps;
 };
 // slice width: 256-byte row pieces; 128-byte ones for 16 waves (1024 threads on 128 VGPRs: half the accumulators and staging registers)
 template <int NW, bool S16> __host__ __device__ constexpr int mixr_te() { return (S16 ? 128 : 64) / (NW > 12 ? 2 : 1); }
-// 64-element slices of 16-bit summaries: unpadded 128-byte rows with XOR-swizzled 16-byte pieces (fast::gt_off) -- the padded rows
-// (TE + 8) are two-way bank-conflicted in the transposed operand reads, and with sixteen waves each reading the WHOLE slice
-// (512 KB of LDS reads per 32 KB of HBM) the kernel is bound by exactly those reads
-template <int NW, bool S16> __host__ __device__ constexpr bool mixr_swz() { return S16 && mixr_te<NW, S16>() == 64; }
 template <int NW, bool S16>
 __host__ __device__ constexpr int sp_mixr_smem() {
-    constexpr int TE = mixr_te<NW, S16>(), ROWS = 16 * NW, LD = mixr_swz<NW, S16>() ? TE : TE + 8;
-    return (S16 ? 1 : 2) * ROWS * LD * 2 + (S16 ? ROWS * LD * 2 : ROWS * (TE + 4) * 4);
+    constexpr int TE = mixr_te<NW, S16>(), ROWS = 16 * NW;
+    return (S16 ? 1 : 2) * ROWS * (TE + 8) * 2 + (S16 ? ROWS * (TE + 8) * 2 : ROWS * (TE + 4) * 4);
 }
 
 template <int NW, int TRANS, bool S16>
 __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void k_sp_mixr(const MixrArgs a) {
-    constexpr bool SWZ = mixr_swz<NW, S16>();
-    constexpr int TE = mixr_te<NW, S16>(), ROWS = 16 * NW, LD = SWZ ? TE : TE + 8, LDO = TE + 4, NK = (NW + 1) / 2, NT = TE / 16;
+    constexpr int TE = mixr_te<NW, S16>(), ROWS = 16 * NW, LD = TE + 8, LDO = TE + 4, NK = (NW + 1) / 2, NT = TE / 16;
     constexpr int PPR = TE * (S16 ? 2 : 4) / 16;          // 16-byte pieces per row of the slice (16, or 8 with 16 waves)
     constexpr int NTH = 64 * NW, NP = ROWS * PPR / NTH;   // pieces per thread and slice
     static_assert(NP * NTH == ROWS * PPR, "pieces must tile the slice");
@@ -532,16 +533,14 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void k_sp_mixr(const MixrArg
         const int v = tid + p * NTH, row = v / PPR, c = v % PPR;
         goff[p] = (unsigned)((long)(row < M ? row : M - 1) * a.E * ESZ + c * 16);
     }
-    // PF slices in flight per thread.  Two for the sixteen-wave variant: its 32 KB slices (one workgroup per CU) in flight one at
-    // a time are 13 GB/s per CU at the loaded memory latency -- the kernel waited for its prefetch, not for LDS or the matrix pipe
-    constexpr int PF = SWZ ? 2 : 1;
-    uint4 preA[NP], preB[PF == 2 ? NP : 1];
-    auto issue = [&](uint4 (&pre)[NP], long boff) {
+    uint4 pre[NP];
+    auto issue = [&](long boff) {
         const char* base = reinterpret_cast<const char*>(a.in) + boff;
 #pragma unroll
         for (int p = 0; p < NP; ++p) pre[p] = gld_stream16(base + goff[p]);
     };
-    auto body = [&](uint4 (&pre)[NP], int it) {
+    issue(slice_off(nbh, nes));
+    for (int it = 0; it < cnt; ++it) {
         const long off = slice_off(cbh, ces);
         advance(cbh, ces);
 #pragma unroll
@@ -549,9 +548,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void k_sp_mixr(const MixrArg
             const int v = tid + p * NTH, row = v / PPR, c = v % PPR;
             const bool ok = row < M;   // rows past the last block: zeros (their weights are zero too, but 0 x NaN is not)
             const uint4 x = make_uint4(ok ? pre[p].x : 0u, ok ? pre[p].y : 0u, ok ? pre[p].z : 0u, ok ? pre[p].w : 0u);
-            if constexpr (SWZ) {
-                *reinterpret_cast<uint4*>(Th + fast::gt_off(row, c * 8)) = x;
-            } else if constexpr (S16) {
+            if constexpr (S16) {
                 *reinterpret_cast<uint4*>(Th + row * LD + c * 8) = x;
             } else {   // four floats -> four bf16 hi + four bf16 lo
                 const float f[4] = {__uint_as_float(x.x), __uint_as_float(x.y), __uint_as_float(x.z), __uint_as_float(x.w)};
@@ -566,54 +563,25 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void k_sp_mixr(const MixrArg
                 *reinterpret_cast<uint2*>(Tl + row * LD + c * 4) = make_uint2(pack_bf16x2(l[0], l[1]), pack_bf16x2(l[2], l[3]));
             }
         }
-        if (PF == 2 && it + 2 < cnt) {   // the registers just committed take the slice after the one in flight
-            advance(nbh, nes);
-            issue(pre, slice_off(nbh, nes));
-        }
         __syncthreads();
-        if (PF == 1 && it + 1 < cnt) {
+        if (it + 1 < cnt) {
             advance(nbh, nes);
-            issue(pre, slice_off(nbh, nes));
+            issue(slice_off(nbh, nes));
         }
         f32x4 acc[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // swizzled tiles: the piece permutation depends on the row's low four bits only, so the transposed-read addresses of
-        // reduction step 0 serve every step with a constant offset, and element tile t is tile 0 with bit t of the piece index
-        // flipped (offset ^ 16 t).  Two offsets are kept; the tile's are rebuilt per step behind a laundering asm -- hoisted out
-        // of the loops they cost 8 (64 before the factoring) registers of a 128-register budget, and ONE spilled weight
-        // register reloaded inside the slice loop waits (vmcnt counts in order) for the prefetched next slice: 175 -> 210 us
-        int tr0 = 0, tr1 = 0;
-        if constexpr (SWZ) {
-            const int g = lane >> 4, li = lane & 15;
-            tr0 = fast::gt_off(g * 8 + (li >> 2), (li & 3) * 4);
-            tr1 = fast::gt_off(g * 8 + (li >> 2) + 4, (li & 3) * 4);
-        }
-#ifdef MIXR_NOMFMA   // (experiment builds only: the kernel without its products / without its stores)
-        const int kend = 0;
-#else
         const int kend = (M + 31) / 32;   // (uniform) reduction steps that hold a block
-#endif
 #pragma unroll
         for (int ks = 0; ks < NK; ++ks) {
             if (ks < kend) {
-                constexpr int TB = SWZ ? 2 : (NT < 4 ? NT : 4);   // operand tiles per batch (two where the second prefetch buffer needs the registers)
+                constexpr int TB = NT < 4 ? NT : 4;   // operand tiles per batch
 #pragma unroll
                 for (int t4 = 0; t4 < NT; t4 += TB) {
                     bf16x8 sv[TB], sl[S16 ? 1 : TB];
 #pragma unroll
                     for (int t = 0; t < TB; ++t) {
-                        if constexpr (SWZ) {
-                            const int b0 = fast::opaque_lane(tr0), b1 = fast::opaque_lane(tr1);
-                            const fast::s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_S16X4(Th + ks * 32 * TE + (b0 ^ ((t4 + t) << 4))));
-                            const fast::s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_S16X4(Th + ks * 32 * TE + (b1 ^ ((t4 + t) << 4))));
-                            fast::s16x8 r8;
-                            r8[0] = lo4[0]; r8[1] = lo4[1]; r8[2] = lo4[2]; r8[3] = lo4[3];
-                            r8[4] = hi4[0]; r8[5] = hi4[1]; r8[6] = hi4[2]; r8[7] = hi4[3];
-                            sv[t] = __builtin_bit_cast(bf16x8, r8);
-                        } else {
-                            sv[t] = tr_read8(Th, LD, ks * 32, (t4 + t) * 16, lane);
-                        }
+                        sv[t] = tr_read8(Th, LD, ks * 32, (t4 + t) * 16, lane);
                         if constexpr (!S16) sl[t] = tr_read8(Tl, LD, ks * 32, (t4 + t) * 16, lane);
                     }
 #pragma unroll
@@ -628,16 +596,8 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void k_sp_mixr(const MixrArg
             }
         }
         // lane: elements 16 t + 4 kg .. + 3 of output block 16 wave + nl -> staging tile [block][element]
-        if constexpr (SWZ) {   // neighbouring element tiles paired into 16-byte pieces (8-byte writes of 16 lanes with one column conflict in any layout)
 #pragma unroll
-            for (int t = 0; t < NT; t += 2) {
-                const uint4 pc = fast::pair_pieces(make_uint2(pack_bf16x2(acc[t][0], acc[t][1]), pack_bf16x2(acc[t][2], acc[t][3])),
-                                                   make_uint2(pack_bf16x2(acc[t + 1][0], acc[t + 1][1]), pack_bf16x2(acc[t + 1][2], acc[t + 1][3])));
-                *reinterpret_cast<uint4*>(reinterpret_cast<u16*>(Os) + fast::gt_off(wave * 16 + nl, (t + (kg & 1)) * 16 + 8 * (kg >> 1))) = pc;
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < (SWZ ? 0 : NT); ++t) {
+        for (int t = 0; t < NT; ++t) {
             if constexpr (S16)
                 *reinterpret_cast<uint2*>(reinterpret_cast<u16*>(Os) + (wave * 16 + nl) * LD + t * 16 + kg * 4) =
                     make_uint2(pack_bf16x2(acc[t][0], acc[t][1]), pack_bf16x2(acc[t][2], acc[t][3]));
@@ -649,30 +609,276 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void k_sp_mixr(const MixrArg
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             const int v = tid + p * NTH, row = v / PPR, c = v % PPR;
-#ifdef MIXR_NOSTORE
-            if (row < M && cnt < 0) {
-#else
             if (row < M) {
-#endif
-                const uint4 x = SWZ ? *reinterpret_cast<const uint4*>(reinterpret_cast<const u16*>(Os) + fast::gt_off(row, c * 8))
-                              : S16 ? *reinterpret_cast<const uint4*>(reinterpret_cast<const u16*>(Os) + row * LD + c * 8)
+                const uint4 x = S16 ? *reinterpret_cast<const uint4*>(reinterpret_cast<const u16*>(Os) + row * LD + c * 8)
                                     : *reinterpret_cast<const uint4*>(reinterpret_cast<const float*>(Os) + row * LDO + c * 4);
                 gst<uint4>(ob + goff[p], x);
             }
         }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// k_sp_mixr_dma<TRANS>: resident-sequence mixing for 16-bit summaries and 192 < M <= 256 blocks.
+// k_sp_mixr<16> (sixteen waves, sixteen output blocks each, 64-element slices) ran at 3 TB/s; taken apart at the 256 x 16 shape
+// (tools/build_variant.sh builds without the copies / the stores / the products): copies + stores alone 100 us, the product loop
+// alone 120-145 us, together 190 us.  The product loop is neither LDS-bandwidth nor matrix-pipe bound (half the MFMAs: -20 %;
+// swizzled conflict-free tiles: +-0): sixteen waves in lockstep each read the WHOLE slice through transposed LDS reads, eight
+// reads per wait, two MFMAs per read -- a latency chain per wave -- and the 128-register budget of 1024 threads leaves no room
+// to pipeline it.  This kernel therefore
+//   * runs EIGHT waves with 32 output blocks each (256-register budget): every operand read feeds four MFMAs (two block tiles x
+//     weight hi / lo), the next reduction step's operands are requested before the current step's products, half the LDS reads;
+//   * stages by LDS-DMA (global_load_lds_dwordx4) into FOUR images: three slices (96 KB) in flight while one is multiplied, no
+//     staging registers, no ds_write pass.  The DMA writes lane-linear images (8 rows x 8 pieces per wave instruction); the tile
+//     kernels' bank swizzle (fast::gt_off) is applied to the SOURCE piece index and again by the transposed operand reads.
+// vmcnt counts loads and stores in order: slice k's copy is complete when at most the instructions issued after it are
+// outstanding -- the copies of the next two slices and the stores of up to three earlier slices (counted per iteration).
+// Rows past M repeat the last row (their weights are zero), so every reduction step runs unguarded.
+// -------------------------------------------------------------------------------------------------
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+constexpr int MIXR_DMA_NBUF = 4;
+constexpr int MIXR_DMA_T = 512;
+__host__ __device__ constexpr int sp_mixr_dma_smem() { return (MIXR_DMA_NBUF + 1) * 256 * 64 * 2; }
+
+template <int TRANS>
+__global__ __launch_bounds__(MIXR_DMA_T) void k_sp_mixr_dma(const MixrArgs a) {
+    constexpr int NW = 8, NB = 2, TE = 64, ROWS = 256, NK = 8, NT = 4, NBUF = MIXR_DMA_NBUF, IMG = ROWS * TE, NTH = MIXR_DMA_T, NP = 4;
+    static_assert(NW * NB * 16 == ROWS && NTH == 64 * NW, "eight waves of 32 output blocks");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u16* lds = reinterpret_cast<u16*>(smem_raw);   // [NBUF] input images, then the output staging tile
+    u16* Os = lds + NBUF * IMG;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nl = lane & 15, kg = lane >> 4;
+    const int M = a.M;
+    const long nsl = a.E / TE;
+    const long s0 = (long)blockIdx.x * a.spw;
+    const int cnt = (int)min((long)a.spw, a.total - s0);
+    if (cnt <= 0) return;
+    // B operands: B[k = r][n = o] = weight of input block r in output block o = 32 wave + 16 n + nl, r = 32 ks + 8 kg + t,
+    // as bf16 hi + lo.  Every workgroup needs the whole matrix: it is fetched in four chunks of 64 input blocks with coalesced
+    // 16-byte loads into LDS (the not yet used images) and picked from there -- per-lane dword loads straight from global memory
+    // touched 16 lines per instruction for 16 bytes of each and re-fetched them for every t: 35 us of a 190 us launch.
+    bf16x8 wh[NK][NB], wl[NK][NB];
+    {
+        float* Tf = reinterpret_cast<float*>(smem_raw);
+        // chunk tile: TRANS 0: Tf[o][rr] = W[o][64 c + rr] (256 rows of 64);  TRANS 1: Tf[rr][o] = W[64 c + rr][o] (64 rows of 256)
+        constexpr int TR = TRANS ? 64 : 256, TC = TRANS ? 256 : 64, LDT = TC + 4, PPRW = TC / 4;
+        static_assert(TR * LDT * 4 <= NBUF * IMG * 2, "weight chunk must fit in the images");
+        const bool vec = ((reinterpret_cast<uintptr_t>(a.W) & 15) == 0) && (a.ldw & 3) == 0;
+        for (int c = 0; c < 4; ++c) {
+            __syncthreads();
+            for (int v = tid; v < TR * PPRW; v += NTH) {
+                const int row = v / PPRW, c4 = (v - row * PPRW) * 4;
+                const int gr = TRANS ? c * 64 + row : row, gc = TRANS ? c4 : c * 64 + c4;   // row / first column in W
+                f32x4 x = {0.f, 0.f, 0.f, 0.f};
+                if (gr < M) {
+                    const float* src = a.W + (long)gr * a.ldw + gc;
+                    if (vec && gc + 4 <= M) {
+                        x = gld<f32x4>(src);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (gc + i < M) x[i] = gld<float>(src + i);
+                    }
+                }
+                *reinterpret_cast<f32x4*>(Tf + row * LDT + c4) = x;   // (blocks past M: zero weights)
+            }
+            __syncthreads();
+#pragma unroll
+            for (int n = 0; n < NB; ++n) {
+                const int o = wave * 32 + n * 16 + nl;
+#pragma unroll
+                for (int k2 = 0; k2 < 2; ++k2) {
+                    float w[8];
+                    if (TRANS) {
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) w[t] = Tf[(k2 * 32 + kg * 8 + t) * LDT + o];
+                    } else {
+                        const f32x4 lo4 = *reinterpret_cast<const f32x4*>(Tf + o * LDT + k2 * 32 + kg * 8);
+                        const f32x4 hi4 = *reinterpret_cast<const f32x4*>(Tf + o * LDT + k2 * 32 + kg * 8 + 4);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) { w[t] = lo4[t]; w[4 + t] = hi4[t]; }
+                    }
+                    // (static register index: the chunk loop is unrolled by the switch below)
+                    bf16x8 h8, l8;
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        const __bf16 h = (__bf16)w[t];
+                        h8[t] = h;
+                        l8[t] = (__bf16)(w[t] - (float)h);
+                    }
+                    switch (c) {
+                        case 0: wh[0 + k2][n] = h8; wl[0 + k2][n] = l8; break;
+                        case 1: wh[2 + k2][n] = h8; wl[2 + k2][n] = l8; break;
+                        case 2: wh[4 + k2][n] = h8; wl[4 + k2][n] = l8; break;
+                        default: wh[6 + k2][n] = h8; wl[6 + k2][n] = l8; break;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // the weights are in, and converted before the first copy is issued (the compiler's own waits for them would otherwise sit
+    // behind the prologue's copies and drain them): from here on the outstanding-instruction count is ours
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks)
+#pragma unroll
+        for (int n = 0; n < NB; ++n) asm volatile("" : "+v"(wh[ks][n]), "+v"(wl[ks][n]));
+    wait_vmcnt<0>();
+    auto slice_off = [&](int bh, int es) { return ((long)bh * M * a.E + (long)es * TE) * 2; };   // bytes
+    auto advance = [&](int& bh, int& es) { if (++es == (int)nsl) { es = 0; ++bh; } };
+    int cbh = (int)(s0 / nsl), ces = (int)(s0 - (long)cbh * nsl), nbh = cbh, nes = ces;
+    // The normaliser's small product for every (b, h) whose first slice is this workgroup's: z as bf16 hi + lo in a swizzled tile
+    // [256 r][hi s 0..15 | lo s 16..31], the weights already in registers, three products (hi hi + hi lo + lo hi) per step.
+    // (Two launches of k_wz -- 30 + 37 us at the 256 x 16 shape for 2 MB of z -- become 3 us here.)
+    if (a.zin) {
+        u16* Zt = lds;
+        const int S = a.S;
+        int zbh = cbh + (ces ? 1 : 0);
+        for (long first = (long)zbh * nsl; first < s0 + cnt; first += nsl, ++zbh) {
+            __syncthreads();
+            {
+                const int row = tid >> 1, h8 = (tid & 1) * 8;
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = (row < M && h8 + i < S) ? gld<float>(a.zin + ((long)zbh * M + row) * S + h8 + i) : 0.f;
+                uint4 hi, lo;
+                split8(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]}, hi, lo);
+                *reinterpret_cast<uint4*>(Zt + fast::gt_off(row, h8)) = hi;
+                *reinterpret_cast<uint4*>(Zt + fast::gt_off(row, 16 + h8)) = lo;
+            }
+            __syncthreads();
+            f32x4 za[NB];
+#pragma unroll
+            for (int n = 0; n < NB; ++n) za[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < NK; ++ks) {
+                const bf16x8 zh = fast::tr_read8_gt(Zt, ks * 32, 0, lane), zl = fast::tr_read8_gt(Zt, ks * 32, 16, lane);
+#pragma unroll
+                for (int n = 0; n < NB; ++n) {
+                    za[n] = mfma_bf16(zh, wh[ks][n], za[n]);
+                    za[n] = mfma_bf16(zh, wl[ks][n], za[n]);
+                    za[n] = mfma_bf16(zl, wh[ks][n], za[n]);
+                }
+            }
+            // lane: s = 4 kg .. + 3 of output block o = 32 wave + 16 n + nl
+#pragma unroll
+            for (int n = 0; n < NB; ++n) {
+                const int o = wave * 32 + n * 16 + nl;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int sc = kg * 4 + i;
+                    if (o < M && sc < S) a.zout[((long)zbh * M + o) * S + sc] = TRANS ? za[n][i] : 1.f / (a.eps + za[n][i]);
+                }
+            }
+        }
+        __syncthreads();
+        wait_vmcnt<0>();
+    }
+    // DMA units of a slice: 32 x (8 rows x 128 bytes); wave w copies rows 8 w + 64 p ..; lane -> row + lane / 8,
+    // LDS position lane % 8 <- source piece (lane % 8) ^ swizzle(row)
+    unsigned soff[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int row = p * 64 + wave * 8 + (lane >> 3), piece = (lane & 7) ^ ((row ^ (row >> 1)) & 7);
+        soff[p] = (unsigned)((long)min(row, M - 1) * a.E * 2 + piece * 16);
+    }
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(lds));
+    auto issue = [&](int k, long boff) {
+        const char* base = reinterpret_cast<const char*>(a.in) + boff;
+        const unsigned buf = lds0 + (unsigned)((k % NBUF) * IMG * 2) + (unsigned)(wave * 8 * TE * 2);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) glds16(base + soff[p], buf + (unsigned)(p * 64 * TE * 2));
     };
-    issue(preA, slice_off(nbh, nes));
-    if constexpr (PF == 2) {
-        if (cnt > 1) {
+    // this thread's four 16-byte store pieces: piece v = tid + p NTH -> row v / 8, column piece v % 8
+    unsigned goff[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int v = tid + p * NTH, row = v >> 3, c = v & 7;
+        goff[p] = (unsigned)((long)min(row, M - 1) * a.E * 2 + c * 16);
+    }
+    // transposed operand reads: the piece permutation depends on the row's low four bits only, so the addresses of reduction step 0
+    // serve every step with a constant offset, and element tile t is tile 0 with bit t of the piece index flipped (offset ^ 16 t)
+    const int g = lane >> 4, li = lane & 15;
+    const int tr0 = fast::gt_off(g * 8 + (li >> 2), (li & 3) * 4), tr1 = fast::gt_off(g * 8 + (li >> 2) + 4, (li & 3) * 4);
+    auto operands = [&](const u16* Th, int ks, bf16x8 (&sv)[NT]) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_S16X4(Th + ks * 32 * TE + (tr0 ^ (t << 4))));
+            const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_S16X4(Th + ks * 32 * TE + (tr1 ^ (t << 4))));
+            fast::s16x8 r8;
+            r8[0] = lo4[0]; r8[1] = lo4[1]; r8[2] = lo4[2]; r8[3] = lo4[3];
+            r8[4] = hi4[0]; r8[5] = hi4[1]; r8[6] = hi4[2]; r8[7] = hi4[3];
+            sv[t] = __builtin_bit_cast(bf16x8, r8);
+        }
+    };
+
+    for (int k = 0; k < NBUF - 1 && k < cnt; ++k) {
+        issue(k, slice_off(nbh, nes));
+        advance(nbh, nes);
+    }
+    for (int k = 0; k < cnt; ++k) {
+        const long off = slice_off(cbh, ces);
+        advance(cbh, ces);
+        // instructions issued after slice k's copy: the copies of slices k + 1, k + 2 and the stores of the last min(k, 3) slices
+        const int younger = min(2, cnt - 1 - k) + min(k, 3);   // in units of NP instructions
+        switch (younger) {
+            case 0: wait_vmcnt<0>(); break;
+            case 1: wait_vmcnt<NP>(); break;
+            case 2: wait_vmcnt<2 * NP>(); break;
+            case 3: wait_vmcnt<3 * NP>(); break;
+            case 4: wait_vmcnt<4 * NP>(); break;
+            default: wait_vmcnt<5 * NP>(); break;
+        }
+        __builtin_amdgcn_s_barrier();   // slice k is visible; everyone is done with iteration k - 1 (its image and the staging tile)
+        if (k + NBUF - 1 < cnt) {
+            issue(k + NBUF - 1, slice_off(nbh, nes));
             advance(nbh, nes);
-            issue(reinterpret_cast<uint4 (&)[NP]>(preB), slice_off(nbh, nes));
         }
-        for (int it = 0; it < cnt; it += 2) {
-            body(preA, it);
-            if (it + 1 < cnt) body(reinterpret_cast<uint4 (&)[NP]>(preB), it + 1);
+        const u16* Th = lds + (k % NBUF) * IMG;
+        f32x4 acc[NB][NT];
+#pragma unroll
+        for (int n = 0; n < NB; ++n)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[n][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        bf16x8 svA[NT], svB[NT];
+        operands(Th, 0, svA);
+#pragma unroll
+        for (int ks = 0; ks < NK; ks += 2) {
+            operands(Th, ks + 1, svB);
+#pragma unroll
+            for (int n = 0; n < NB; ++n) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[n][t] = mfma_bf16(svA[t], wh[ks][n], acc[n][t]);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[n][t] = mfma_bf16(svA[t], wl[ks][n], acc[n][t]);
+            }
+            if (ks + 2 < NK) operands(Th, ks + 2, svA);
+#pragma unroll
+            for (int n = 0; n < NB; ++n) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[n][t] = mfma_bf16(svB[t], wh[ks + 1][n], acc[n][t]);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[n][t] = mfma_bf16(svB[t], wl[ks + 1][n], acc[n][t]);
+            }
         }
-    } else {
-        for (int it = 0; it < cnt; ++it) body(preA, it);
+        // lane: elements 16 t + 4 kg .. + 3 of output block 32 wave + 16 n + nl; neighbouring element tiles paired into 16-byte pieces
+#pragma unroll
+        for (int n = 0; n < NB; ++n)
+#pragma unroll
+            for (int t = 0; t < NT; t += 2) {
+                const uint4 pc = fast::pair_pieces(make_uint2(pack_bf16x2(acc[n][t][0], acc[n][t][1]), pack_bf16x2(acc[n][t][2], acc[n][t][3])),
+                                                   make_uint2(pack_bf16x2(acc[n][t + 1][0], acc[n][t + 1][1]), pack_bf16x2(acc[n][t + 1][2], acc[n][t + 1][3])));
+                *reinterpret_cast<uint4*>(Os + fast::gt_off(wave * 32 + n * 16 + nl, (t + (kg & 1)) * 16 + 8 * (kg >> 1))) = pc;
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        char* ob = reinterpret_cast<char*>(a.out) + off;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int v = tid + p * NTH, row = v >> 3, c = v & 7;
+            const uint4 x = *reinterpret_cast<const uint4*>(Os + fast::gt_off(row, c * 8));
+            if (row < M) gst<uint4>(ob + goff[p], x);
+        }
     }
 }
 

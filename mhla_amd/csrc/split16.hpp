@@ -377,7 +377,7 @@ constexpr int DWR_SE = 64;     // elements per stage
 constexpr int DWR_NBUF = 2;    // LDS buffers
 template <int TT> __host__ __device__ constexpr int dwr_smem() { return DWR_NBUF * 2 * 64 * TT * DWR_SE * 2; }
 
-template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+using sp::wait_vmcnt;
 
 template <int TT>
 __global__ __launch_bounds__(64 * TT * TT) void k_sp_dwr(const DwrArgs a) {
