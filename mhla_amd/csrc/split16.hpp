@@ -356,7 +356,8 @@ __global__ __launch_bounds__(64 * WPB) void k_s16_bwd_dkv(const TokArgs a) {
 // buffers: the DMA of stage st + 1 is issued right behind the barrier that releases its buffer and lands while stage st is
 // multiplied -- no staging registers, no ds_write pass.  (Stages of 32 elements in four buffers -- three in flight -- were
 // measured first: the two halves of a line are then requested a stage apart, by which time the line has left the L2 --
-// FETCH_SIZE 1 024 MB for 541 MB of operands, 195 us.)
+// FETCH_SIZE 1 024 MB for 541 MB of operands, 195 us.  Touching the lines of the stage after next -- one dword per half line into a
+// kept register, to have it in the L2 when its copy is issued -- was slower as well: 164 -> 205 us.)
 // The DMA writes lane-linear images (wave-uniform base + 16 lane): a wave instruction fills 8 rows x 8 pieces; the bank
 // swizzle of the tile kernels (fast::gt_off) is applied on the SOURCE side -- LDS position q of row r holds the row's piece
 // q ^ ((r ^ (r >> 1)) & 7) -- and again by the operand reads.
