@@ -43,6 +43,7 @@ struct FastWs {
     int* err;    // error word of the token-gradient launch (a hand-over flag that did not arrive)
     size_t total_fwd, total_bwd;
     int njg, ntt;
+    int cs;      // workgroups per tile and role for blocks of several 64-token chunks (S > 64), 1 otherwise
 };
 FastWs fast_carve(void* ws, int B, int H, int M, int S) {
     const size_t bh = (size_t)B * H;
@@ -58,10 +59,11 @@ FastWs fast_carve(void* ws, int B, int H, int M, int S) {
     w.dstate = (fast::u16*)p; p += st;
     w.dn = (float*)p; p += al4(bh * M * S) * 4;
     w.dz = (float*)p; p += al4(bh * M * S) * 4;
-    w.dksum = (float*)p; p += al4(bh * M * 64) * 4;
+    w.cs = S > 64 ? std::min((S + 63) / 64, 4) : 1;
+    w.dksum = (float*)p; p += al4(bh * M * 64) * 4 * w.cs;   // one share per chunk part
     w.dwp = (float*)p; p += bh * fast::DW_SPLIT * 4096 * 4;
     w.ntt = fast::tiles_per_bh(w.njg, 16);
-    w.done = (int*)p; p += al4(bh * w.ntt + 1) * 4;   // per-tile flags
+    w.done = (int*)p; p += al4(bh * w.ntt * w.cs + 1) * 4;   // per-tile (and part) flags
     w.err = nullptr;                                  // (the error word lives at the tail of the workspace: bwd_err_word)
     w.total_bwd = (size_t)(p - (char*)ws);
     return w;
@@ -208,7 +210,9 @@ static int bm_fwd_impl(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view 
         oa.q = cv(q_num); oa.o = cmv(out); oa.idx = block_index; oa.W = W; oa.ldw = ldw; oa.state = f.state; oa.ninv = f.ninv;
         oa.H = H; oa.M = M; oa.S = S; oa.njg = f.njg; oa.eps = eps; oa.relu = relu; oa.normalize = normalize;
         oa.trace = g_trace.load();
-        RC(launch(fast::k_tile_out<16>, dim3(fast::tiles_per_bh(f.njg, 16) * B * H), dim3(fast::FT8), fast::tile_smem<16>(), st, "k_t16_out", oa));
+        oa.cs = f.cs;
+        if (f.cs > 1) RC(launch(fast::k_tile_out<16, true>, dim3(fast::tiles_per_bh(f.njg, 16) * B * H * f.cs), dim3(fast::FT8), fast::tile_smem<16>(), st, "k_t16_out", oa));
+        else          RC(launch(fast::k_tile_out<16>, dim3(fast::tiles_per_bh(f.njg, 16) * B * H), dim3(fast::FT8), fast::tile_smem<16>(), st, "k_t16_out", oa));
         return MHLA_OK;
     }
     const BmWs w = bm_carve(ws, B, H, M, S, D, bm_sum16(D, dtype, flags));
@@ -342,7 +346,7 @@ static int bm_bwd_impl(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view 
             else RC(launch(fast::k_fs_state<1>, dim3(f.njg, B * H), dim3(fast::FT8), fast::FS_STATE_SMEM, st, "k_fs_state<1>", ga));
             // dW needs only dG^T, KV^T, dn and z, all complete here; dz = W^T dn (needed by the token-gradient kernels) rides in
             // the same launch as extra workgroups
-            fast::FsDwArgs da{f.dstate, state, normalize ? f.dn : nullptr, z, f.dwp, M, S, f.njg, W, ldw, f.dz, f.done, f.err, f.ntt};
+            fast::FsDwArgs da{f.dstate, state, normalize ? f.dn : nullptr, z, f.dwp, M, S, f.njg, W, ldw, f.dz, f.done, f.err, f.ntt * f.cs};
             hipStream_t sd = st;
             const int nwz = normalize ? (S + fast::WZ_C - 1) / fast::WZ_C : 0;
             RC(launch(fast::k_fs_dw<>, dim3(fast::DW_SPLIT + nwz, B * H), dim3(fast::FT8), fast::FS_DW_SMEM, sd, "k_fs_dw", da));
@@ -352,20 +356,22 @@ static int bm_bwd_impl(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view 
             ta.dz = f.dz; ta.ksum = ksum; ta.H = H; ta.M = M; ta.S = S; ta.njg = f.njg; ta.eps = eps; ta.relu = relu;
             ta.normalize = normalize;
             ta.dksum = f.dksum;
-            const long ntile_wgs = (long)f.ntt * B * H;
+            const long ntile_wgs = (long)f.ntt * B * H * f.cs;
+            ta.cs = f.cs; ta.dks_part = (long)al4((size_t)B * H * M * 64);
             unsigned long long* tr = g_trace.load();   // regions: [0] k_t16_out, [1] dQ role, [2] dK/dV role (record = ntiles + blockIdx.x)
             ta.trace = tr ? tr + ntile_wgs * fast::TRACE_SLOTS : nullptr;
             ta.dwp = f.dwp; ta.dW = dW; ta.nparts = B * H * fast::DW_SPLIT; ta.ntiles = (int)ntile_wgs; ta.done = f.done;
             ta.err = f.err;
             ta.drop_signal = getenv("MHLA_DEBUG_DROP_SIGNAL") != nullptr;   // testing aid for the bounded wait (looked up per call)
             const char* const two = getenv("MHLA_BWD_TWO_LAUNCHES");   // fallback (looked up per call): dQ tiles and dK/dV tiles as two launches
+            const auto tile_bwd = f.cs > 1 ? fast::k_tile_bwd<16, true> : fast::k_tile_bwd<16, false>;   // (multi-chunk blocks: cs workgroups per tile)
             if (two && two[0] == '1') {   // (the kernel boundary orders dksum and the flags: the wait returns at its first poll)
-                RC(launch(fast::k_tile_bwd<16>, dim3((unsigned)ntile_wgs), dim3(fast::FT8), fast::tile_smem<16>(), st, "k_t16_bwd_dq", ta));
+                RC(launch(tile_bwd, dim3((unsigned)ntile_wgs), dim3(fast::FT8), fast::tile_smem<16>(), st, "k_t16_bwd_dq", ta));
                 ta.x0 = (int)ntile_wgs;
-                RC(launch(fast::k_tile_bwd<16>, dim3((unsigned)ntile_wgs + fast::DWR_WGS), dim3(fast::FT8), fast::tile_smem<16>(), st, "k_t16_bwd_dkv", ta));
+                RC(launch(tile_bwd, dim3((unsigned)ntile_wgs + fast::DWR_WGS), dim3(fast::FT8), fast::tile_smem<16>(), st, "k_t16_bwd_dkv", ta));
                 return MHLA_OK;
             }
-            RC(launch(fast::k_tile_bwd<16>, dim3((unsigned)(2 * ntile_wgs) + fast::DWR_WGS), dim3(fast::FT8), fast::tile_smem<16>(), st, "k_t16_bwd", ta));
+            RC(launch(tile_bwd, dim3((unsigned)(2 * ntile_wgs) + fast::DWR_WGS), dim3(fast::FT8), fast::tile_smem<16>(), st, "k_t16_bwd", ta));
             return MHLA_OK;
         }
     }

@@ -256,22 +256,27 @@ __global__ __launch_bounds__(FT8, 4) void k_fs_state(const FsStateArgs a) {
     const int srow = tid >> 3, scol = (tid & 7) * 8;   // staging: thread -> (row, 8 columns = 16 bytes)
 
     // global -> registers for one 64-row chunk of block j (rows >= rv give zeros)
+    // (every load unconditional: rows past the chunk's end are clamped onto its last row and zeroed in `commit` -- a load behind a
+    // divergent branch makes the compiler wait for everything at the join, which would drain the one-chunk-ahead prefetch)
     auto issue = [&](int j, int c0, int rv, TileRegs& R) {
-        R.x = R.y = R.t = make_uint4(0, 0, 0, 0);
+        const int sr = min(srow, rv - 1);
+        const long tr = tok_row(a.idx, (long)j * S + c0 + sr);
+        // MODE 1: Q and dO are read again by the next kernel (dQ): regular loads; O is not: streaming.  MODE 0: K, V stream.
+        R.x = MODE == 1 ? gld<uint4>(xb + tr * a.x.sn + scol) : gld_stream16(xb + tr * a.x.sn + scol);
+        R.y = MODE == 1 ? gld<uint4>(yb + tr * a.y.sn + scol) : gld_stream16(yb + tr * a.y.sn + scol);
+        R.t = make_uint4(0, 0, 0, 0);
         R.ninv = 0.f;
-        if (srow < rv) {
-            const long tr = tok_row(a.idx, (long)j * S + c0 + srow);
-            // MODE 1: Q and dO are read again by the next kernel (dQ): regular loads; O is not: streaming.  MODE 0: K, V stream.
-            R.x = MODE == 1 ? gld<uint4>(xb + tr * a.x.sn + scol) : gld_stream16(xb + tr * a.x.sn + scol);
-            R.y = MODE == 1 ? gld<uint4>(yb + tr * a.y.sn + scol) : gld_stream16(yb + tr * a.y.sn + scol);
-            if (a.normalize) {
-                R.t = MODE == 1 ? gld_stream16(tb + tr * a.t.sn + scol) : gld<uint4>(tb + tr * a.t.sn + scol);
-                if (MODE == 1) R.ninv = gld<float>(a.ninv + ((long)bh * M + j) * S + c0 + srow);
-            }
+        if (a.normalize) {   // (uniform)
+            R.t = MODE == 1 ? gld_stream16(tb + tr * a.t.sn + scol) : gld<uint4>(tb + tr * a.t.sn + scol);
+            if (MODE == 1) R.ninv = gld<float>(a.ninv + ((long)bh * M + j) * S + c0 + sr);
         }
     };
     // registers -> LDS.  MODE 1 folds dn = -(dO . O) / n and dP = dO / n into this step (no LDS pass).
     auto commit = [&](TileRegs& R, int j, int c0, int rv, int rfill) {
+        if (srow >= rv) {
+            R.x = R.y = R.t = make_uint4(0, 0, 0, 0);
+            R.ninv = 0.f;
+        }
         uint4 x = R.x, y = R.y;
         if (a.relu && srow < rv) {
             x = relu_eps8(x, a.eps);
@@ -340,8 +345,11 @@ __global__ __launch_bounds__(FT8, 4) void k_fs_state(const FsStateArgs a) {
         if (srow < rv && (tid & 7) == 0) a.z_out[((long)bh * M + j) * S + c0 + srow] = d;
     };
 
-    // multi-chunk blocks (S > 64): synchronous chunks; z needs the complete ksum -> second pass over Q
+    // multi-chunk blocks (S > 64): the next chunk (of this block or the first of the next one) is requested while the current one is
+    // multiplied; z needs the complete ksum -> second pass over Q
     TileRegs R;
+    const int jend = min(M, (jg + 1) * IT);
+    if (jg * IT < M) issue(jg * IT, 0, min(64, S), R);
     auto blockloop = [&](auto jjc) {
         constexpr int jj = decltype(jjc)::value;
         const int j = jg * IT + jj;
@@ -349,9 +357,13 @@ __global__ __launch_bounds__(FT8, 4) void k_fs_state(const FsStateArgs a) {
         float ks = 0.f;
         for (int c0 = 0; c0 < S; c0 += 64) {
             const int rv = min(64, S - c0), rfill = (rv + 31) & ~31;
-            issue(j, c0, rv, R);
             commit(R, j, c0, rv, rfill);
             __syncthreads();
+            {
+                const bool same = c0 + 64 < S;
+                const int j2 = same ? j : j + 1, c2 = same ? c0 + 64 : 0;
+                if (j2 < jend) issue(j2, c2, min(64, S - c2), R);
+            }
             chunk(jjc, rv, rfill, ks);
             __syncthreads();
         }
@@ -418,16 +430,16 @@ __global__ __launch_bounds__(FT8, 4) void k_fs_state_fwd(const FsStateArgs a) {
     const int srow = tid >> 3, scol = (tid & 7) * 8;         // staging: thread -> (row, 8 columns = 16 bytes)
     const bool tile_t = a.normalize && MODE == 1;   // third tile travels with the chunk
 
+    // (every load unconditional: rows past the chunk's end are clamped onto its last row and zeroed in `commit`)
     auto issue = [&](long p, int rv, TileRegs3& R) {
-        R.x = R.y = R.t = make_uint4(0, 0, 0, 0);
-        if (srow < rv) {
-            const long tr = tok_row(a.idx, p + srow);
-            R.x = gld_stream16(xb + tr * a.x.sn + scol);                     // K, V: not read again in the forward
-            R.y = gld_stream16(yb + tr * a.y.sn + scol);
-            if (tile_t) R.t = gld<uint4>(tb + tr * a.t.sn + scol);          // Q: the output kernel reads it next
-        }
+        const long tr = tok_row(a.idx, p + min(srow, rv - 1));
+        R.x = gld_stream16(xb + tr * a.x.sn + scol);                     // K, V: not read again in the forward
+        R.y = gld_stream16(yb + tr * a.y.sn + scol);
+        R.t = make_uint4(0, 0, 0, 0);
+        if (tile_t) R.t = gld<uint4>(tb + tr * a.t.sn + scol);          // Q: the output kernel reads it next
     };
-    auto commit = [&](const TileRegs3& R, int rv, int rfill) {
+    auto commit = [&](TileRegs3& R, int rv, int rfill) {
+        if (srow >= rv) R.x = R.y = R.t = make_uint4(0, 0, 0, 0);
         if (srow < rfill) {
             uint4 x = R.x, t = R.t;
             if (a.relu && srow < rv) {
@@ -523,7 +535,10 @@ __global__ __launch_bounds__(FT8, 4) void k_fs_state_fwd(const FsStateArgs a) {
         }
     };
 
+    // the next chunk (of this block or the first of the next one) is requested while the current one is multiplied
     TileRegs3 R;
+    const int jend = min(M, (jg + 1) * IT);
+    if (jg * IT < M) issue((long)(jg * IT) * S, min(64, S), R);
     auto blockloop = [&](auto jjc) {
         constexpr int jj = decltype(jjc)::value;
         const int j = jg * IT + jj;
@@ -532,9 +547,13 @@ __global__ __launch_bounds__(FT8, 4) void k_fs_state_fwd(const FsStateArgs a) {
         float ks = 0.f;
         for (int c0 = 0; c0 < S; c0 += 64) {
             const int rv = min(64, S - c0), rfill = (rv + 31) & ~31;
-            issue(p0 + c0, rv, R);
             commit(R, rv, rfill);
             __syncthreads();
+            {
+                const bool same = c0 + 64 < S;
+                const int j2 = same ? j : j + 1, c2 = same ? c0 + 64 : 0;
+                if (j2 < jend) issue((long)j2 * S + c2, min(64, S - c2), R);
+            }
             chunk(jjc, j, c0, rv, rfill, ks);
             __syncthreads();
         }
@@ -792,6 +811,7 @@ struct FsOutArgs {
     float eps;
     int relu, normalize;
     unsigned long long* trace;   // debugging aid (mhla_debug_set_trace): per-workgroup phase timestamps, or null
+    int cs;             // blocks of several 64-token chunks (S > 64): `cs` workgroups per tile, part p takes chunks p, p + cs, ..; 1 otherwise
 };
 // phase timestamp k of this workgroup (s_memtime ticks), first lane only; slot 15 of each record holds the XCC id
 constexpr int TRACE_SLOTS = 16;
@@ -1006,6 +1026,11 @@ struct FsTokArgs {
     int x0;             // role offset added to blockIdx.x (0: one launch for all roles; ntiles: the second of two launches)
     int drop_signal;    // testing aid (MHLA_DEBUG_DROP_SIGNAL=1): the dQ role does not raise its flag
     unsigned long long* trace;
+    // blocks of several 64-token chunks (S > 64): `cs` workgroups per tile and role, part p takes chunks p, p + cs, ..; the dQ
+    // parts write their share of dksum to dksum + p * dks_part and raise flag `cs * tile + p`; a dK/dV part waits for all `cs`
+    // flags of its tile and adds the shares in part order (deterministic).  cs = 1 (and ntiles = tiles) when S <= 64.
+    int cs;
+    long dks_part;
 };
 // Hand-over of a tile's dksum rows between two workgroups of one launch (the waiting one has the higher blockIdx: it is dispatched
 // after the signalling one, which never waits itself).  No fences: an agent-scope release / acquire pair writes back and
@@ -1039,6 +1064,24 @@ __device__ __forceinline__ bool tile_wait(int* flag, int* err, int* lds_word, in
             }
             __builtin_amdgcn_s_sleep(16);
         }
+        *lds_word = expired;
+    }
+    __syncthreads();
+    return *lds_word != 0;
+}
+// the same wait for `n` consecutive flags (the dQ parts of a tile with multi-chunk blocks)
+__device__ __forceinline__ bool tile_wait_n(int* flags, int n, int* err, int* lds_word, int tid) {
+    if (tid == 0) {
+        int polls = 0, expired = 0;
+        for (int i = 0; i < n && !expired; ++i)
+            while (__hip_atomic_load(flags + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+                if (++polls > TILE_WAIT_POLLS) {
+                    __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    expired = 1;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(16);
+            }
         *lds_word = expired;
     }
     __syncthreads();

@@ -265,13 +265,14 @@ __device__ __forceinline__ void side_commit(float* __restrict__ dst, const SideR
     for (int t = 0; t < TTP / 8; ++t) dst[((tid >> 6) + 8 * t) * 64 + (tid & 63)] = (tid & 63) < cols ? r.v[t] : 0.f;
 }
 
-template <int TTP>
+// MC: blocks of several 64-token chunks with `a.cs` workgroups per tile (the single-chunk instantiation carries no trace of it)
+template <int TTP, bool MC = false>
 __global__ __launch_bounds__(FT8, TTP == 16 ? 2 : 4) void k_tile_out(const FsOutArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u16* Gt = reinterpret_cast<u16*>(smem_raw);   // [TTP][64 d2][72]
     float* sideN = reinterpret_cast<float*>(smem_raw + tile_gt_bytes<TTP>());   // [TTP][64]  1 / n
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, n = lane & 15;
-    const int L = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int Lp = xcd_swizzle(blockIdx.x, gridDim.x), cs = MC ? a.cs : 1, L = Lp / cs, part = Lp - L * cs;   // (parts of a tile are neighbours: one XCD's L2 serves their state streams)
     const int ntt = (a.njg * IT + TTP - 1) / TTP, bh = L / ntt, it = L - bh * ntt, b = bh / a.H, h = bh - b * a.H;
     const int S = a.S, M = a.M;
     const u16* qb = (const u16*)a.q.ptr + b * a.q.sb + h * a.q.sh;
@@ -295,7 +296,7 @@ __global__ __launch_bounds__(FT8, TTP == 16 ? 2 : 4) void k_tile_out(const FsOut
                 for (int tn = 0; tn < 4; ++tn) acc[st][tn] *= ni;
             }
         }
-        if (c0 + 64 >= S) {   // last chunk of the block: its Gt slot is dead for this wave -> staging buffer
+        if (c0 + 64 * cs >= S) {   // this workgroup's last chunk of the block: its Gt slot is dead for this wave -> staging buffer
             wave_lds_fence();
             stage64(Gb, acc, lane);
             wave_lds_fence();
@@ -338,7 +339,7 @@ __global__ __launch_bounds__(FT8, TTP == 16 ? 2 : 4) void k_tile_out(const FsOut
     for (int bi = wave; bi < TTP; bi += 8) {
         const int i = it * TTP + bi;
         if (i >= M) continue;
-        for (int c0 = 0; c0 < S; c0 += 64) {
+        for (int c0 = part * 64; c0 < S; c0 += 64 * cs) {
             const int rv = min(64, S - c0);
             bf16x8 av[4][2];
             load_a64(av, qb, a.q.sn, a.idx, (long)i * S + c0, rv, lane);
@@ -353,14 +354,14 @@ __global__ __launch_bounds__(FT8, TTP == 16 ? 2 : 4) void k_tile_out(const FsOut
 }
 
 // dQ role of k_tile_bwd: workgroup wg of nwg
-template <int TTP>
+template <int TTP, bool MC>
 __device__ __forceinline__ void tile_bwd_dq_body(const FsTokArgs& a, unsigned char* smem_raw, int wg, int nwg) {
     u16* Gt = reinterpret_cast<u16*>(smem_raw);
     float* sideN = reinterpret_cast<float*>(smem_raw + tile_gt_bytes<TTP>());   // [TTP][64]  1 / n
     float* sideZ = sideN + TTP * 64;                                             // [TTP][64]  dz (zero beyond the block's rows)
     float* sideK = sideZ + TTP * 64;                                             // [TTP][64]  ksum
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, n = lane & 15, kg = lane >> 4;
-    const int L = xcd_swizzle(wg, nwg);
+    const int Lp = xcd_swizzle(wg, nwg), cs = MC ? a.cs : 1, L = Lp / cs, part = Lp - L * cs;
     const int ntt = (a.njg * IT + TTP - 1) / TTP, bh = L / ntt, jgx = L - bh * ntt, b = bh / a.H, h = bh - b * a.H;
     const int S = a.S, M = a.M;
     auto base = [&](const View& w) { return (const u16*)w.ptr + b * w.sb + h * w.sh; };
@@ -399,7 +400,7 @@ __device__ __forceinline__ void tile_bwd_dq_body(const FsTokArgs& a, unsigned ch
             }
         }
         after_q();   // the chunk's Q rows are dead from here on: the caller may request the next ones into their registers
-        if (c0 + 64 >= S) {
+        if (c0 + 64 * cs >= S) {
             wave_lds_fence();
             stage64(Gb, acc, lane);
             wave_lds_fence();
@@ -434,7 +435,7 @@ __device__ __forceinline__ void tile_bwd_dq_body(const FsTokArgs& a, unsigned ch
             v2[t] = keep + __shfl_xor(send, 2, 64);
         }
         const float send = b1 ? v2[0] : v2[1], keep = b1 ? v2[1] : v2[0];
-        coherent_store(a.dksum + ((long)bh * M + j) * 64 + 32 * (n >> 3) + 8 * kg + (n & 7), keep + __shfl_xor(send, 1, 64));
+        coherent_store(a.dksum + part * a.dks_part + ((long)bh * M + j) * 64 + 32 * (n >> 3) + 8 * kg + (n & 7), keep + __shfl_xor(send, 1, 64));
     };
     auto zero_dks = [](float (&d)[2][8]) {
 #pragma unroll
@@ -505,7 +506,7 @@ __device__ __forceinline__ void tile_bwd_dq_body(const FsTokArgs& a, unsigned ch
         float dks_acc[2][8];
         zero_dks(dks_acc);
         if (a.normalize) sideK[bi * 64 + lane] = gld<float>(a.ksum + ((long)bh * M + j) * 64 + lane);
-        for (int c0 = 0; c0 < S; c0 += 64) {
+        for (int c0 = part * 64; c0 < S; c0 += 64 * cs) {
             const int rv = min(64, S - c0);
             bf16x8 gv[4][2], qv[4][2];
             f32x4 acc[4][4];
@@ -524,18 +525,18 @@ __device__ __forceinline__ void tile_bwd_dq_body(const FsTokArgs& a, unsigned ch
         }
         if (a.normalize) finish_dks(dks_acc, j);
     }
-    if (a.normalize && !a.drop_signal) tile_signal(a.done + L, tid);
+    if (a.normalize && !a.drop_signal) tile_signal(a.done + Lp, tid);   // this part's share of the tile's dksum rows is written
 }
 
 // dK / dV role of k_tile_bwd: workgroup wg of nwg.  The only thing it needs from the dQ role is the tile's dksum rows (awaited just
 // before they are fetched, after the mixing).
-template <int TTP>
+template <int TTP, bool MC>
 __device__ __forceinline__ void tile_bwd_dkv_body(const FsTokArgs& a, unsigned char* smem_raw, int wg, int nwg) {
     u16* Gt = reinterpret_cast<u16*>(smem_raw);
     float* sideK = reinterpret_cast<float*>(smem_raw + tile_gt_bytes<TTP>());   // [TTP][64]  dksum (dQ role)
     int* wait_word = reinterpret_cast<int*>(sideK + TTP * 64);                   // (the dQ role's second side array: unused here)
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, kg = lane >> 4;
-    const int L = xcd_swizzle(wg, nwg);
+    const int Lp = xcd_swizzle(wg, nwg), cs = MC ? a.cs : 1, L = Lp / cs, part = Lp - L * cs;
     const int ntt = (a.njg * IT + TTP - 1) / TTP, bh = L / ntt, jgx = L - bh * ntt, b = bh / a.H, h = bh - b * a.H;
     const int S = a.S, M = a.M;
     auto base = [&](const View& w) { return (const u16*)w.ptr + b * w.sb + h * w.sh; };
@@ -547,7 +548,7 @@ __device__ __forceinline__ void tile_bwd_dkv_body(const FsTokArgs& a, unsigned c
     auto compute_store = [&](bf16x8 (&kv)[4][2], const bf16x8 (&vv)[4][2], int bi, int j, int c0, int rv) {
         const long p0 = (long)j * S + c0;
         u16* Gb = Gt + bi * GSLOT;
-        const bool last = c0 + 64 >= S;
+        const bool last = c0 + 64 * cs >= S;
         if (a.relu) relu_a64(kv, a.eps);
         // dV first, kept packed as bf16 while dK is computed (both need the intact Gb)
         uint2 pv[4][4];
@@ -625,16 +626,17 @@ __device__ __forceinline__ void tile_bwd_dkv_body(const FsTokArgs& a, unsigned c
         return;
     }
     mix_tile_to_lds<TTP, 1, NBUF>(Gt, a.dstate + sofs, a.njg, a.W, a.ldw, M, jgx * TTP, tid);
-    const bool expired = a.normalize ? tile_wait(a.done + L, a.err, wait_word, tid) : false;
+    const bool expired = a.normalize ? tile_wait_n(a.done + L * cs, cs, a.err, wait_word, tid) : false;   // every dQ part of the tile
     __syncthreads();
     for (int bi = wave; bi < TTP; bi += 8) {
         const int j = jgx * TTP + bi;
         if (j >= M) continue;
         if (a.normalize) {
-            const float dks = coherent_load(a.dksum + ((long)bh * M + j) * 64 + lane);
+            float dks = 0.f;
+            for (int p = 0; p < cs; ++p) dks += coherent_load(a.dksum + p * a.dks_part + ((long)bh * M + j) * 64 + lane);   // (part order: deterministic)
             sideK[bi * 64 + lane] = expired ? __builtin_nanf("") : dks;
         }
-        for (int c0 = 0; c0 < S; c0 += 64) {
+        for (int c0 = part * 64; c0 < S; c0 += 64 * cs) {
             const int rv = min(64, S - c0);
             bf16x8 kv[4][2], vv[4][2];
             load_a64(kv, kb, a.k.sn, a.idx, (long)j * S + c0, rv, lane);
@@ -648,13 +650,13 @@ __device__ __forceinline__ void tile_bwd_dkv_body(const FsTokArgs& a, unsigned c
 // The backward's token gradients in ONE launch: workgroups [0, ntiles) compute dQ (and dksum), [ntiles, 2 ntiles) dK and dV, the
 // last DWR_WGS reduce the dW partials.  dQ and dK/dV tiles of 25-30 us each in two rounds per kernel left the chip waiting for the
 // slowest workgroup twice (about 20 us per kernel); as one launch of four rounds the dK/dV tiles fill the dQ tail.
-template <int TTP>
+template <int TTP, bool MC = false>
 __global__ __launch_bounds__(FT8, TTP == 16 ? 2 : 4) void k_tile_bwd(const FsTokArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     static_assert(TTP == 16, "the flag array and the role ranges are sized for 16-block tiles (tiles_per_bh(njg, 16))");
     const int x = blockIdx.x + a.x0;
-    if (x < a.ntiles) tile_bwd_dq_body<TTP>(a, smem_raw, x, a.ntiles);
-    else if (x < 2 * a.ntiles) tile_bwd_dkv_body<TTP>(a, smem_raw, x - a.ntiles, a.ntiles);
+    if (x < a.ntiles) tile_bwd_dq_body<TTP, MC>(a, smem_raw, x, a.ntiles);
+    else if (x < 2 * a.ntiles) tile_bwd_dkv_body<TTP, MC>(a, smem_raw, x - a.ntiles, a.ntiles);
     else dw_reduce_body(reinterpret_cast<float*>(smem_raw), a.dwp, a.dW, a.M, a.nparts, x - 2 * a.ntiles, threadIdx.x);
 }
 

@@ -72,7 +72,8 @@ def test_shapes_lowp(M, S, D, dtype):
     run_case(2, 2, M, S, D, dtype)
 
 
-@pytest.mark.parametrize("M,S", [(64, 64), (16, 16), (16, 256), (4, 49), (5, 64), (33, 32), (40, 80), (1, 128), (64, 8)])
+@pytest.mark.parametrize("M,S", [(64, 64), (16, 16), (16, 256), (4, 49), (5, 64), (33, 32), (40, 80), (1, 128), (64, 8),
+                                 (3, 320), (5, 200), (17, 136)])   # blocks of 5 / 4 (ragged) / 3 chunks: chunk parts over several workgroups
 def test_fast_path_bf16_d64(M, S):
     """bf16, D = 64, M <= 64: the bf16-MFMA fast path (interleaved bf16 block summaries, fused mix + output)."""
     run_case(2, 3, M, S, 64, torch.bfloat16, w="rand")

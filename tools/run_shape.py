@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Run a few iterations of one BASELINE.json shape (for rocprofv3):  run_shape.py c3|c3f|c4|c4b|c5|c5b|xl|c2b [iters]"""
+"""Run a few iterations of one BASELINE.json shape (for rocprofv3):  run_shape.py c3|c3f|c4|c4b|c5|c5b|xl|c2b|c2c [iters]"""
 import os
 import sys
 
@@ -46,6 +46,16 @@ elif which == "c2b":   # C2 variant: 256 blocks of 16 tokens
     ts = [torch.randn(B, N, H, D, generator=g).abs().bfloat16().to(DEV).requires_grad_(True) for _ in range(3)]
     do = torch.randn(B, N, H, D, generator=g).bfloat16().to(DEV)
     W = block_distance_weights((16, 16), "linear").to(DEV).requires_grad_(True)
+
+    def step():
+        mhla_amd.mhla_blockmix(ts[0], ts[1], ts[2], W).backward(do)
+        for t in ts + [W]:
+            t.grad = None
+elif which == "c2c":   # C2 variant: 16 blocks of 256 tokens
+    B, N, H, D = 8, 4096, 16, 64
+    ts = [torch.randn(B, N, H, D, generator=g).abs().bfloat16().to(DEV).requires_grad_(True) for _ in range(3)]
+    do = torch.randn(B, N, H, D, generator=g).bfloat16().to(DEV)
+    W = block_distance_weights((4, 4), "linear").to(DEV).requires_grad_(True)
 
     def step():
         mhla_amd.mhla_blockmix(ts[0], ts[1], ts[2], W).backward(do)
