@@ -174,7 +174,7 @@ def run_extra_configs(full=False):
     # comparison only -- the lines above are the numbers of record
     out.append(causal_case("C5 fla 340M causal B=4 T=8192 H=4 K=128 V=256 bf16 [reduced_precision: summaries=bf16]", 4, 8192, 4, 128, 256, bf,
                            summaries="bf16"))
-    out.append(blockmix_case("C2 variant M=16 S=256 bf16", 8, 4096, 16, 64, 16, bf, (4, 4), graph=True))
+    out.append(blockmix_case("C2 variant M=16 S=256 bf16", 8, 4096, 16, 64, 16, bf, (4, 4), graph=True, key="c2c"))
     out.append(blockmix_case("C2 variant M=256 S=16 bf16", 8, 4096, 16, 64, 256, bf, (16, 16), iters=10, key="c2b", graph=True))
     if full:
         out.append(blockmix_case("DiT-S/2-shaped op B=32 N=256 H=6 D=64 M=16 bf16", 32, 256, 6, 64, 16, bf, (4, 4), graph=True))

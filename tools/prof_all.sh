@@ -1,14 +1,14 @@
 #!/bin/bash
 # Round-end evidence for every BASELINE.json shape: rocprofv3 --kernel-trace --stats and the PMC passes (FETCH_SIZE / WRITE_SIZE,
 # SQ busy / wait, MFMA busy, LDS conflicts -- separate runs, counters only) of bench.py (C2) and of tools/run_shape.py for
-# c3 c3f c4b c5 c5b c2b  ->  gpurun_out/r4prof/<shape>_{trace,pmc}.md and <shape>_pmc.json (copied to profiles/r4_* afterwards).
+# c3 c3f c4b c5 c5b c2b c2c  ->  gpurun_out/r4prof/<shape>_{trace,pmc}.md and <shape>_pmc.json (copied to profiles/r4_* afterwards).
 #   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash tools/prof_all.sh'            SHAPES="c5 c5b" limits the set
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/r4prof
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-for s in ${SHAPES:-c2 c3 c3f c4b c5 c5b c2b}; do
+for s in ${SHAPES:-c2 c3 c3f c4b c5 c5b c2b c2c}; do
   if [ "$s" = c2 ]; then
     rocprofv3 --kernel-trace --stats -d "$OUT/$s.trace" -o res -- python3 "$ROOT/bench.py" --steps 20 --warmup 3 --no-cpu-baseline --no-extra-configs --no-dit-step > "$OUT/$s.trace.log" 2>&1
     title="bench.py --steps 20 --warmup 3 (C2: B=8 N=4096 H=16 D=64 bf16 M=64)"
