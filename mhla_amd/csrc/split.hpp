@@ -463,6 +463,67 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_mix(const MixArgs a) {
 // flight in registers.  grid: wgs <= 256 persistent workgroups of 64 NW threads.
 //   TRANS 0: out[i][e] = sum_j W[i][j] in[j][e]      TRANS 1: out[j][e] = sum_i W[i][j] in[i][e]
 // -------------------------------------------------------------------------------------------------
+// Mixing weights of a wave's NB tiles of 16 output blocks as MFMA B operands, bf16 hi + lo:
+//   B[k = r][n = o] = Wm(o, r), o = obase + 16 n + (lane & 15), r = 32 ks + 8 (lane >> 4) + t   (Wm = W, or W^T with TRANS)
+// Every workgroup needs the whole matrix: it is fetched in chunks of 64 input blocks with coalesced 16-byte loads into LDS (`Tf`,
+// any region of ROWS x 68 / 64 x (ROWS + 4) floats that is free before the first slice) and picked from there.  Per-lane dword
+// loads straight from global memory touched 16 lines per instruction for 16 bytes of each and re-fetched them for every t: 35 us
+// of a 190 us launch at M = 256.  Blocks past M get zero weights.  Ends with a barrier (Tf may be reused).
+template <int TRANS, int NTH, int ROWS, int NK, int NB>
+__device__ __forceinline__ void mixr_weights(bf16x8 (&wh)[NK][NB], bf16x8 (&wl)[NK][NB], float* __restrict__ Tf, const float* __restrict__ W,
+                                             int ldw, int M, int obase, int tid) {
+    constexpr int TR = TRANS ? 64 : ROWS, TC = TRANS ? ROWS : 64, LDT = TC + 4, PPRW = TC / 4, NCH = (NK + 1) / 2;
+    const int lane = tid & 63, nl = lane & 15, kg = lane >> 4;
+    const bool vec = ((reinterpret_cast<uintptr_t>(W) & 15) == 0) && (ldw & 3) == 0;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        __syncthreads();
+        for (int v = tid; v < TR * PPRW; v += NTH) {
+            const int row = v / PPRW, c4 = (v - row * PPRW) * 4;
+            const int gr = TRANS ? c * 64 + row : row, gc = TRANS ? c4 : c * 64 + c4;   // row / first column in W
+            f32x4 x = {0.f, 0.f, 0.f, 0.f};
+            if (gr < M) {
+                const float* src = W + (long)gr * ldw + gc;
+                if (vec && gc + 4 <= M) {
+                    x = gld<f32x4>(src);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (gc + i < M) x[i] = gld<float>(src + i);
+                }
+            }
+            *reinterpret_cast<f32x4*>(Tf + row * LDT + c4) = x;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+            const int o = obase + n * 16 + nl;
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+                if (2 * c + k2 < NK) {
+                    float w[8];
+                    if (TRANS) {
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) w[t] = Tf[(k2 * 32 + kg * 8 + t) * LDT + o];
+                    } else {
+                        const f32x4 lo4 = *reinterpret_cast<const f32x4*>(Tf + o * LDT + k2 * 32 + kg * 8);
+                        const f32x4 hi4 = *reinterpret_cast<const f32x4*>(Tf + o * LDT + k2 * 32 + kg * 8 + 4);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) { w[t] = lo4[t]; w[4 + t] = hi4[t]; }
+                    }
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        const __bf16 h = (__bf16)w[t];
+                        wh[2 * c + k2][n][t] = h;
+                        wl[2 * c + k2][n][t] = (__bf16)(w[t] - (float)h);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
 struct MixrArgs {
     const float* W;
     int ldw;
@@ -504,22 +565,9 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void k_sp_mixr(const MixrArg
     const int cnt = (int)min((long)a.spw, a.total - s0);
     if (cnt <= 0) return;
     // B operand: B[k = r][n = o] = weight of input block r in output block o = 16 wave + nl, r = 32 ks + 8 kg + t
-    bf16x8 wh[NK], wl[NK];
-    const int orow = wave * 16 + nl;
-#pragma unroll
-    for (int ks = 0; ks < NK; ++ks) {
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const int r = ks * 32 + kg * 8 + t;
-            const bool ok = orow < M && r < M;
-            const long off = TRANS ? (long)(ok ? r : 0) * a.ldw + (ok ? orow : 0) : (long)(ok ? orow : 0) * a.ldw + (ok ? r : 0);
-            const float x = gld<float>(a.W + off);
-            const float w = ok ? x : 0.f;
-            const __bf16 h = (__bf16)w;
-            wh[ks][t] = h;
-            wl[ks][t] = (__bf16)(w - (float)h);
-        }
-    }
+    bf16x8 wh[NK][1], wl[NK][1];
+    static_assert((TRANS ? 64 * (ROWS + 4) : ROWS * 68) * 4 <= sp_mixr_smem<NW, S16>(), "weight chunk must fit in the tiles");
+    mixr_weights<TRANS, 64 * NW, ROWS, NK, 1>(wh, wl, reinterpret_cast<float*>(smem_raw), a.W, a.ldw, M, wave * 16, tid);
     constexpr int ESZ = S16 ? 2 : 4;
     // byte offset of slice (bh, es); a workgroup's slices are consecutive, so the pair is advanced rather than divided out per
     // slice (the 64-bit division was 150 instructions with branches between the barrier and the next slice's loads)
@@ -585,13 +633,13 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void k_sp_mixr(const MixrArg
                         if constexpr (!S16) sl[t] = tr_read8(Tl, LD, ks * 32, (t4 + t) * 16, lane);
                     }
 #pragma unroll
-                    for (int t = 0; t < TB; ++t) acc[t4 + t] = mfma_bf16(sv[t], wh[ks], acc[t4 + t]);
+                    for (int t = 0; t < TB; ++t) acc[t4 + t] = mfma_bf16(sv[t], wh[ks][0], acc[t4 + t]);
                     if constexpr (!S16) {
 #pragma unroll
-                        for (int t = 0; t < TB; ++t) acc[t4 + t] = mfma_bf16(sl[t], wh[ks], acc[t4 + t]);
+                        for (int t = 0; t < TB; ++t) acc[t4 + t] = mfma_bf16(sl[t], wh[ks][0], acc[t4 + t]);
                     }
 #pragma unroll
-                    for (int t = 0; t < TB; ++t) acc[t4 + t] = mfma_bf16(sv[t], wl[ks], acc[t4 + t]);
+                    for (int t = 0; t < TB; ++t) acc[t4 + t] = mfma_bf16(sv[t], wl[ks][0], acc[t4 + t]);
                 }
             }
         }
@@ -653,70 +701,10 @@ __global__ __launch_bounds__(MIXR_DMA_T) void k_sp_mixr_dma(const MixrArgs a) {
     const long s0 = (long)blockIdx.x * a.spw;
     const int cnt = (int)min((long)a.spw, a.total - s0);
     if (cnt <= 0) return;
-    // B operands: B[k = r][n = o] = weight of input block r in output block o = 32 wave + 16 n + nl, r = 32 ks + 8 kg + t,
-    // as bf16 hi + lo.  Every workgroup needs the whole matrix: it is fetched in four chunks of 64 input blocks with coalesced
-    // 16-byte loads into LDS (the not yet used images) and picked from there -- per-lane dword loads straight from global memory
-    // touched 16 lines per instruction for 16 bytes of each and re-fetched them for every t: 35 us of a 190 us launch.
+    // B operands of the wave's 32 output blocks (hi + lo), through LDS (mixr_weights; the not yet used images)
     bf16x8 wh[NK][NB], wl[NK][NB];
-    {
-        float* Tf = reinterpret_cast<float*>(smem_raw);
-        // chunk tile: TRANS 0: Tf[o][rr] = W[o][64 c + rr] (256 rows of 64);  TRANS 1: Tf[rr][o] = W[64 c + rr][o] (64 rows of 256)
-        constexpr int TR = TRANS ? 64 : 256, TC = TRANS ? 256 : 64, LDT = TC + 4, PPRW = TC / 4;
-        static_assert(TR * LDT * 4 <= NBUF * IMG * 2, "weight chunk must fit in the images");
-        const bool vec = ((reinterpret_cast<uintptr_t>(a.W) & 15) == 0) && (a.ldw & 3) == 0;
-        for (int c = 0; c < 4; ++c) {
-            __syncthreads();
-            for (int v = tid; v < TR * PPRW; v += NTH) {
-                const int row = v / PPRW, c4 = (v - row * PPRW) * 4;
-                const int gr = TRANS ? c * 64 + row : row, gc = TRANS ? c4 : c * 64 + c4;   // row / first column in W
-                f32x4 x = {0.f, 0.f, 0.f, 0.f};
-                if (gr < M) {
-                    const float* src = a.W + (long)gr * a.ldw + gc;
-                    if (vec && gc + 4 <= M) {
-                        x = gld<f32x4>(src);
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            if (gc + i < M) x[i] = gld<float>(src + i);
-                    }
-                }
-                *reinterpret_cast<f32x4*>(Tf + row * LDT + c4) = x;   // (blocks past M: zero weights)
-            }
-            __syncthreads();
-#pragma unroll
-            for (int n = 0; n < NB; ++n) {
-                const int o = wave * 32 + n * 16 + nl;
-#pragma unroll
-                for (int k2 = 0; k2 < 2; ++k2) {
-                    float w[8];
-                    if (TRANS) {
-#pragma unroll
-                        for (int t = 0; t < 8; ++t) w[t] = Tf[(k2 * 32 + kg * 8 + t) * LDT + o];
-                    } else {
-                        const f32x4 lo4 = *reinterpret_cast<const f32x4*>(Tf + o * LDT + k2 * 32 + kg * 8);
-                        const f32x4 hi4 = *reinterpret_cast<const f32x4*>(Tf + o * LDT + k2 * 32 + kg * 8 + 4);
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) { w[t] = lo4[t]; w[4 + t] = hi4[t]; }
-                    }
-                    // (static register index: the chunk loop is unrolled by the switch below)
-                    bf16x8 h8, l8;
-#pragma unroll
-                    for (int t = 0; t < 8; ++t) {
-                        const __bf16 h = (__bf16)w[t];
-                        h8[t] = h;
-                        l8[t] = (__bf16)(w[t] - (float)h);
-                    }
-                    switch (c) {
-                        case 0: wh[0 + k2][n] = h8; wl[0 + k2][n] = l8; break;
-                        case 1: wh[2 + k2][n] = h8; wl[2 + k2][n] = l8; break;
-                        case 2: wh[4 + k2][n] = h8; wl[4 + k2][n] = l8; break;
-                        default: wh[6 + k2][n] = h8; wl[6 + k2][n] = l8; break;
-                    }
-                }
-            }
-        }
-        __syncthreads();
-    }
+    static_assert((TRANS ? 64 * (ROWS + 4) : ROWS * 68) * 4 <= NBUF * IMG * 2, "weight chunk must fit in the images");
+    mixr_weights<TRANS, NTH, ROWS, NK, NB>(wh, wl, reinterpret_cast<float*>(smem_raw), a.W, a.ldw, M, wave * 32, tid);
     // the weights are in, and converted before the first copy is issued (the compiler's own waits for them would otherwise sit
     // behind the prologue's copies and drain them): from here on the outstanding-instruction count is ours
 #pragma unroll
