@@ -241,7 +241,7 @@ __device__ __forceinline__ float dot8(uint4 a, uint4 b) {
 }
 
 template <int MODE>
-__global__ __launch_bounds__(FT8, 4) void k_fs_state(const FsStateArgs a) {
+__global__ __launch_bounds__(FT8, 3) void k_fs_state(const FsStateArgs a) {   // (3: the second register set of the pair loop does not fit 128 VGPRs -- 9 spilled)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u16* Xs = reinterpret_cast<u16*>(smem_raw);
     u16* Ys = Xs + 64 * TLD;
@@ -347,25 +347,40 @@ __global__ __launch_bounds__(FT8, 4) void k_fs_state(const FsStateArgs a) {
 
     // multi-chunk blocks (S > 64): the next chunk (of this block or the first of the next one) is requested while the current one is
     // multiplied; z needs the complete ksum -> second pass over Q
-    TileRegs R;
+    // Blocks of a whole number of 128-token pairs keep TWO chunks in flight (register sets RA / RB alternate inside one loop body, so
+    // their indices stay static); other lengths one.
+    TileRegs RA, RB;
     const int jend = min(M, (jg + 1) * IT);
-    if (jg * IT < M) issue(jg * IT, 0, min(64, S), R);
+    const bool pairs = (S & 127) == 0;
+    if (jg * IT < M) {
+        issue(jg * IT, 0, min(64, S), RA);
+        if (pairs) issue(jg * IT, 64, 64, RB);
+    }
     auto blockloop = [&](auto jjc) {
         constexpr int jj = decltype(jjc)::value;
         const int j = jg * IT + jj;
         if (j >= M) return;
         float ks = 0.f;
-        for (int c0 = 0; c0 < S; c0 += 64) {
+        // one chunk: stage the registers, request the chunk `ahead` steps on into them, multiply
+        auto step = [&](int c0, TileRegs& R, int ahead) {
             const int rv = min(64, S - c0), rfill = (rv + 31) & ~31;
             commit(R, j, c0, rv, rfill);
             __syncthreads();
             {
-                const bool same = c0 + 64 < S;
-                const int j2 = same ? j : j + 1, c2 = same ? c0 + 64 : 0;
+                int c2 = c0 + 64 * ahead, j2 = j;
+                if (c2 >= S) { c2 = ahead == 2 ? c2 - S : 0; ++j2; }   // (pairs: S is a multiple of 128; single steps: S may be ragged)
                 if (j2 < jend) issue(j2, c2, min(64, S - c2), R);
             }
             chunk(jjc, rv, rfill, ks);
             __syncthreads();
+        };
+        if (pairs) {
+            for (int c0 = 0; c0 < S; c0 += 128) {
+                step(c0, RA, 2);
+                step(c0 + 64, RB, 2);
+            }
+        } else {
+            for (int c0 = 0; c0 < S; c0 += 64) step(c0, RA, 1);
         }
         if (MODE == 0 && a.normalize) {
             part[tid] = ks;
@@ -536,26 +551,38 @@ __global__ __launch_bounds__(FT8, 4) void k_fs_state_fwd(const FsStateArgs a) {
     };
 
     // the next chunk (of this block or the first of the next one) is requested while the current one is multiplied
-    TileRegs3 R;
+    // (blocks of a whole number of 128-token pairs: two chunks in flight, register sets RA / RB alternating inside one loop body)
+    TileRegs3 RA, RB;
     const int jend = min(M, (jg + 1) * IT);
-    if (jg * IT < M) issue((long)(jg * IT) * S, min(64, S), R);
+    const bool pairs = (S & 127) == 0;
+    if (jg * IT < M) {
+        issue((long)(jg * IT) * S, min(64, S), RA);
+        if (pairs) issue((long)(jg * IT) * S + 64, 64, RB);
+    }
     auto blockloop = [&](auto jjc) {
         constexpr int jj = decltype(jjc)::value;
         const int j = jg * IT + jj;
         if (j >= M) return;
-        const long p0 = (long)j * S;
         float ks = 0.f;
-        for (int c0 = 0; c0 < S; c0 += 64) {
+        auto step = [&](int c0, TileRegs3& R, int ahead) {
             const int rv = min(64, S - c0), rfill = (rv + 31) & ~31;
             commit(R, rv, rfill);
             __syncthreads();
             {
-                const bool same = c0 + 64 < S;
-                const int j2 = same ? j : j + 1, c2 = same ? c0 + 64 : 0;
+                int c2 = c0 + 64 * ahead, j2 = j;
+                if (c2 >= S) { c2 = ahead == 2 ? c2 - S : 0; ++j2; }   // (pairs: S is a multiple of 128; single steps: S may be ragged)
                 if (j2 < jend) issue((long)j2 * S + c2, min(64, S - c2), R);
             }
             chunk(jjc, j, c0, rv, rfill, ks);
             __syncthreads();
+        };
+        if (pairs) {
+            for (int c0 = 0; c0 < S; c0 += 128) {
+                step(c0, RA, 2);
+                step(c0 + 64, RB, 2);
+            }
+        } else {
+            for (int c0 = 0; c0 < S; c0 += 64) step(c0, RA, 1);
         }
         if (MODE == 0 && a.normalize) finish_block(j, ks);
     };
