@@ -33,7 +33,7 @@ inline int sp_mixr(const float* W, int ldw, const void* in, void* out, int M, lo
         constexpr int TE = sp::mixr_te<NW, S16>(); \
         const long total = (long)BH * (E / TE); \
         const int wgs = (int)std::min<long>(total, 256); \
-        sp::MixrArgs a{W, ldw, in, out, M, E, total, (int)((total + wgs - 1) / wgs), nullptr, nullptr, 0, 0.f}; \
+        sp::MixrArgs a{W, ldw, in, out, M, E, total, (int)((total + wgs - 1) / wgs), nullptr, nullptr, 0, 0.f, nullptr}; \
         const int gw = (int)((total + a.spw - 1) / a.spw); \
         return launch(sp::k_sp_mixr<NW, TRANS, S16>, dim3(gw), dim3(64 * NW), sp::sp_mixr_smem<NW, S16>(), st, TRANS ? "k_sp_mixr<1>" : "k_sp_mixr<0>", a); \
     } while (0)
@@ -42,7 +42,7 @@ inline int sp_mixr(const float* W, int ldw, const void* in, void* out, int M, lo
             const long total = (long)BH * (E / 64);
             const int wgs = (int)std::min<long>(total, 256);
             const bool wz = zin && sp_mixr_takes_wz<S16>(M, S);
-            sp::MixrArgs a{W, ldw, in, out, M, E, total, (int)((total + wgs - 1) / wgs), wz ? zin : nullptr, wz ? zout : nullptr, S, eps};
+            sp::MixrArgs a{W, ldw, in, out, M, E, total, (int)((total + wgs - 1) / wgs), wz ? zin : nullptr, wz ? zout : nullptr, S, eps, g_trace.load()};
             const int gw = (int)((total + a.spw - 1) / a.spw);
             return launch(sp::k_sp_mixr_dma<TRANS>, dim3(gw), dim3(sp::MIXR_DMA_T), sp::sp_mixr_dma_smem(), st, TRANS ? "k_sp_mixr_dma<1>" : "k_sp_mixr_dma<0>", a);
         }

@@ -539,6 +539,7 @@ struct MixrArgs {
     float* zout;
     int S;
     float eps;
+    unsigned long long* trace;   // debugging aid (mhla_debug_set_trace): s_memtime stamps of the first workgroups' slice loop, or null
 };
 // slice width: 256-byte row pieces; 128-byte ones for 16 waves (1024 threads on 128 VGPRs: half the accumulators and staging registers)
 template <int NW, bool S16> __host__ __device__ constexpr int mixr_te() { return (S16 ? 128 : 64) / (NW > 12 ? 2 : 1); }
@@ -676,24 +677,26 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void k_sp_mixr(const MixrArg
 // to pipeline it.  This kernel therefore
 //   * runs EIGHT waves with 32 output blocks each (256-register budget): every operand read feeds four MFMAs (two block tiles x
 //     weight hi / lo), the next reduction step's operands are requested before the current step's products, half the LDS reads;
-//   * stages by LDS-DMA (global_load_lds_dwordx4) into FOUR images: three slices (96 KB) in flight while one is multiplied, no
-//     staging registers, no ds_write pass.  The DMA writes lane-linear images (8 rows x 8 pieces per wave instruction); the tile
+//   * stages by LDS-DMA (global_load_lds_dwordx4) into THREE images: two slices (64 KB) in flight while one is multiplied, no
+//     staging registers, no ds_write pass (four images / three in flight measured the same);
+//   * stages its results in TWO tiles, so that the stores of slice k - 1 are issued at the top of iteration k, beside the request
+//     for slice k + 2, and both travel under the products of slice k: one barrier per slice instead of two.  The DMA writes lane-linear images (8 rows x 8 pieces per wave instruction); the tile
 //     kernels' bank swizzle (fast::gt_off) is applied to the SOURCE piece index and again by the transposed operand reads.
 // vmcnt counts loads and stores in order: slice k's copy is complete when at most the instructions issued after it are
-// outstanding -- the copies of the next two slices and the stores of up to three earlier slices (counted per iteration).
+// outstanding (counted per iteration, see the loop).
 // Rows past M repeat the last row (their weights are zero), so every reduction step runs unguarded.
 // -------------------------------------------------------------------------------------------------
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-constexpr int MIXR_DMA_NBUF = 4;
+constexpr int MIXR_DMA_NBUF = 3;   // input images; two staging tiles follow them
 constexpr int MIXR_DMA_T = 512;
-__host__ __device__ constexpr int sp_mixr_dma_smem() { return (MIXR_DMA_NBUF + 1) * 256 * 64 * 2; }
+__host__ __device__ constexpr int sp_mixr_dma_smem() { return (MIXR_DMA_NBUF + 2) * 256 * 64 * 2; }
 
 template <int TRANS>
 __global__ __launch_bounds__(MIXR_DMA_T) void k_sp_mixr_dma(const MixrArgs a) {
     constexpr int NW = 8, NB = 2, TE = 64, ROWS = 256, NK = 8, NT = 4, NBUF = MIXR_DMA_NBUF, IMG = ROWS * TE, NTH = MIXR_DMA_T, NP = 4;
     static_assert(NW * NB * 16 == ROWS && NTH == 64 * NW, "eight waves of 32 output blocks");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    u16* lds = reinterpret_cast<u16*>(smem_raw);   // [NBUF] input images, then the output staging tile
+    u16* lds = reinterpret_cast<u16*>(smem_raw);   // [NBUF] input images, then two output staging tiles
     u16* Os = lds + NBUF * IMG;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nl = lane & 15, kg = lane >> 4;
     const int M = a.M;
@@ -800,29 +803,47 @@ __global__ __launch_bounds__(MIXR_DMA_T) void k_sp_mixr_dma(const MixrArgs a) {
         }
     };
 
+    // One barrier per slice.  Iteration k: wait for slice k's copy, barrier, THEN store slice k - 1 from its staging tile and request
+    // slice k + 2 -- both travel while slice k is multiplied -- and stage slice k's result in the other staging tile.
+    //   staging tile (k & 1): written at the end of iteration k, read at the top of iteration k + 1, rewritten in k + 2 (barrier k + 2 between)
+    //   image k % 3: refilled by the copy of slice k + 3, issued after barrier k + 1, i.e. after everyone's products of slice k
+    // vmcnt (in order): younger than slice k's copy are the stores of slice k - 2 (k >= 2) and the copy of slice k + 1.
     for (int k = 0; k < NBUF - 1 && k < cnt; ++k) {
         issue(k, slice_off(nbh, nes));
         advance(nbh, nes);
     }
+    auto store_slice = [&](const u16* St, long off) {
+        char* ob = reinterpret_cast<char*>(a.out) + off;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int v = tid + p * NTH, row = v >> 3, c = v & 7;
+            const uint4 x = *reinterpret_cast<const uint4*>(St + fast::gt_off(row, c * 8));
+            if (row < M) gst<uint4>(ob + goff[p], x);
+        }
+    };
+    long off_prev = 0;
     for (int k = 0; k < cnt; ++k) {
         const long off = slice_off(cbh, ces);
         advance(cbh, ces);
-        // instructions issued after slice k's copy: the copies of slices k + 1, k + 2 and the stores of the last min(k, 3) slices
-        const int younger = min(2, cnt - 1 - k) + min(k, 3);   // in units of NP instructions
-        switch (younger) {
-            case 0: wait_vmcnt<0>(); break;
-            case 1: wait_vmcnt<NP>(); break;
-            case 2: wait_vmcnt<2 * NP>(); break;
-            case 3: wait_vmcnt<3 * NP>(); break;
-            case 4: wait_vmcnt<4 * NP>(); break;
-            default: wait_vmcnt<5 * NP>(); break;
-        }
-        __builtin_amdgcn_s_barrier();   // slice k is visible; everyone is done with iteration k - 1 (its image and the staging tile)
+        const int younger = (k + 1 < cnt ? 1 : 0) + (k >= 2 ? 1 : 0);   // in units of NP instructions
+        auto stamp = [&](int i) { if (a.trace && tid == 0 && blockIdx.x < 8 && k < 32) a.trace[(blockIdx.x * 32 + k) * 8 + i] = __builtin_amdgcn_s_memtime(); };
+        stamp(0);
+        if (younger == 2)      wait_vmcnt<2 * NP>();
+        else if (younger == 1) wait_vmcnt<NP>();
+        else                   wait_vmcnt<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (this wave's staging writes of iteration k - 1)
+        stamp(4);
+        __builtin_amdgcn_s_barrier();
+        stamp(1);
+        if (k >= 1) store_slice(Os + ((k - 1) & 1) * IMG, off_prev);
         if (k + NBUF - 1 < cnt) {
             issue(k + NBUF - 1, slice_off(nbh, nes));
             advance(nbh, nes);
         }
+        stamp(2);
+        off_prev = off;
         const u16* Th = lds + (k % NBUF) * IMG;
+        u16* St = Os + (k & 1) * IMG;
         f32x4 acc[NB][NT];
 #pragma unroll
         for (int n = 0; n < NB; ++n)
@@ -856,18 +877,13 @@ __global__ __launch_bounds__(MIXR_DMA_T) void k_sp_mixr_dma(const MixrArgs a) {
             for (int t = 0; t < NT; t += 2) {
                 const uint4 pc = fast::pair_pieces(make_uint2(pack_bf16x2(acc[n][t][0], acc[n][t][1]), pack_bf16x2(acc[n][t][2], acc[n][t][3])),
                                                    make_uint2(pack_bf16x2(acc[n][t + 1][0], acc[n][t + 1][1]), pack_bf16x2(acc[n][t + 1][2], acc[n][t + 1][3])));
-                *reinterpret_cast<uint4*>(Os + fast::gt_off(wave * 32 + n * 16 + nl, (t + (kg & 1)) * 16 + 8 * (kg >> 1))) = pc;
+                *reinterpret_cast<uint4*>(St + fast::gt_off(wave * 32 + n * 16 + nl, (t + (kg & 1)) * 16 + 8 * (kg >> 1))) = pc;
             }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        char* ob = reinterpret_cast<char*>(a.out) + off;
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            const int v = tid + p * NTH, row = v >> 3, c = v & 7;
-            const uint4 x = *reinterpret_cast<const uint4*>(Os + fast::gt_off(row, c * 8));
-            if (row < M) gst<uint4>(ob + goff[p], x);
-        }
+        stamp(3);
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    store_slice(Os + ((cnt - 1) & 1) * IMG, off_prev);
 }
 
 // -------------------------------------------------------------------------------------------------
