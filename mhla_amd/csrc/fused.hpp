@@ -523,31 +523,35 @@ __global__ __launch_bounds__(FT8, 4) void k_fs_state_fwd(const FsStateArgs a) {
             a.ksum[((long)bh * M + j) * 64 + tid] = sacc;
         }
         __syncthreads();
-        for (int c0 = 0; c0 < S; c0 += 64) {
-            const int rv = min(64, S - c0);
-            {   // second pass over Q, synchronous
-                uint4 t = make_uint4(0, 0, 0, 0);
-                if (srow < rv) {
-                    t = *reinterpret_cast<const uint4*>(tb + tok_row(a.idx, p0 + c0 + srow) * a.t.sn + scol);
-                    if (a.relu) t = relu_eps8(t, a.eps);
-                }
-                *reinterpret_cast<uint4*>(Ts + srow * TLD + scol) = t;
-                __syncthreads();
+        // second pass over Q: every thread dots its own 16-byte piece of a row with ksum (no staging: the piece is used by the thread
+        // that loaded it), two chunks' loads in flight, 8 lanes per row reduced by shuffles
+        float kv8[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) kv8[i] = ksum_s[scol + i];
+        for (int c0 = 0; c0 < S; c0 += 128) {
+            uint4 tq[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int cu = min(c0 + 64 * u, S - 1), rv = min(64, S - cu);
+                tq[u] = gld<uint4>(tb + tok_row(a.idx, p0 + cu + min(srow, rv - 1)) * a.t.sn + scol);
             }
-            float d = 0.f;
-            if (srow < rv) {
-                const uint4 qv = *reinterpret_cast<const uint4*>(Ts + srow * TLD + scol);
-                const unsigned qw[4] = {qv.x, qv.y, qv.z, qv.w};
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int cu = c0 + 64 * u, rv = min(64, S - cu);
+                uint4 t = tq[u];
+                if (a.relu) t = relu_eps8(t, a.eps);
+                const unsigned qw[4] = {t.x, t.y, t.z, t.w};
+                float d = 0.f;
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    d += __uint_as_float(qw[i] << 16) * ksum_s[scol + 2 * i] + __uint_as_float(qw[i] & 0xffff0000u) * ksum_s[scol + 2 * i + 1];
+                    d += __uint_as_float(qw[i] << 16) * kv8[2 * i] + __uint_as_float(qw[i] & 0xffff0000u) * kv8[2 * i + 1];
+                d += __shfl_xor(d, 1, 64);
+                d += __shfl_xor(d, 2, 64);
+                d += __shfl_xor(d, 4, 64);
+                if (cu < S && srow < rv && (tid & 7) == 0) a.z_out[((long)bh * M + j) * S + cu + srow] = d;
             }
-            d += __shfl_xor(d, 1, 64);
-            d += __shfl_xor(d, 2, 64);
-            d += __shfl_xor(d, 4, 64);
-            if (srow < rv && (tid & 7) == 0) a.z_out[((long)bh * M + j) * S + c0 + srow] = d;
-            __syncthreads();
         }
+        __syncthreads();   // ksum_s / part are rewritten by the next block
     };
 
     // the next chunk (of this block or the first of the next one) is requested while the current one is multiplied
