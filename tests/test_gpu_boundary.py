@@ -80,6 +80,57 @@ def test_bench_two_rank_launch_path_in_shared_gpu_mode():
         assert "shared_gpu_harness" in res["config"]
 
 
+def test_rccl_process_group_runs_the_dw_exchange_on_this_gpu():
+    """The `nccl` (= RCCL) backend of the multi-GPU legs, on the one GPU a test box has: a one-rank process group is created in a
+    fresh process, the operator's dW goes through `dist.all_reduce(async_op=True)` the way `OverlappedGradAllReduce` issues it
+    (asynchronous, on the process group's stream, waited for before the next step) beside a replayed graph of the step, and the
+    mean over one rank must leave it unchanged.  What it pins: RCCL loads and initialises under this environment
+    (HSA_ENABLE_IPC_MODE_LEGACY=0), and a collective on its stream interleaves with graph replays without a device error."""
+    code = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.getcwd())
+import mhla_amd
+from mhla_amd import block_distance_weights
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29633", RANK="0", WORLD_SIZE="1")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1)
+assert dist.get_backend() == "nccl"
+g = torch.Generator().manual_seed(0)
+q, k, v = (torch.randn(2, 1024, 4, 64, generator=g).abs().bfloat16().cuda().requires_grad_(True) for _ in range(3))
+do = torch.randn(2, 1024, 4, 64, generator=g).bfloat16().cuda()
+W = block_distance_weights((4, 4), "linear").cuda().requires_grad_(True)
+mhla_amd.mhla_blockmix(q, k, v, W).backward(do)
+ref = W.grad.clone()
+q.grad = k.grad = v.grad = W.grad = None
+side = torch.cuda.Stream()
+side.wait_stream(torch.cuda.current_stream())
+with torch.cuda.stream(side):
+    mhla_amd.mhla_blockmix(q, k, v, W).backward(do)
+torch.cuda.current_stream().wait_stream(side)
+q.grad = k.grad = v.grad = W.grad = None
+buf = torch.empty_like(W, dtype=torch.float32)
+graph = torch.cuda.CUDAGraph()
+with torch.cuda.graph(graph):
+    mhla_amd.mhla_blockmix(q, k, v, W).backward(do)
+    buf.copy_(W.grad)
+    q.grad = k.grad = v.grad = W.grad = None
+pending = None
+for _ in range(4):
+    if pending is not None:
+        pending.wait()
+    graph.replay()
+    pending = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
+pending.wait()
+torch.cuda.synchronize()
+assert torch.equal(buf, ref), (buf - ref).abs().max().item()
+dist.destroy_process_group()
+print("RCCL_OK")
+'''
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=ROOT,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")))
+    assert r.returncode == 0 and "RCCL_OK" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
+
+
 def test_cpp_and_python_autograd_nodes_are_the_same_operator(monkeypatch):
     """mhla_amd/csrc_torch/mhla_torch.cpp (the C++ autograd nodes the eager path uses when libmhla_torch.so is built) and the Python
     autograd.Functions of ops.py call the same C ABI with the same arguments: bit-identical outputs and gradients, same error
