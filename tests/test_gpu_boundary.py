@@ -131,6 +131,28 @@ print("RCCL_OK")
     assert r.returncode == 0 and "RCCL_OK" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
 
 
+def test_ddp_wrapped_dit_host_trains_over_rccl_on_this_gpu():
+    """The second multi-GPU leg (`dit_xl2_train_step` under DistributedDataParallel) with a one-rank `nccl` group: DDP's reducer
+    hooks, gradient-as-bucket-view and the bucketed RCCL all-reduce run against the host's real autograd graph (the operator's C++
+    nodes included) on hardware; two steps must finish with finite parameters."""
+    code = r'''
+import os, sys, math, torch, torch.distributed as dist
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tools"))
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29634", RANK="0", WORLD_SIZE="1")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1)
+from bench_dit_step import run_dit_step
+res = run_dit_step(0, 0, 1, model_name="DiT-S/2", batch=4, image=256, steps=2, warmup=1, force_ddp=True)
+assert "DistributedDataParallel over nccl" in res["gradient_exchange"], res
+assert res["ms_per_step"] > 0 and math.isfinite(res["ms_per_step"])
+dist.destroy_process_group()
+print("DDP_OK", res["ms_per_step"])
+'''
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=ROOT,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")))
+    assert r.returncode == 0 and "DDP_OK" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
+
+
 def test_cpp_and_python_autograd_nodes_are_the_same_operator(monkeypatch):
     """mhla_amd/csrc_torch/mhla_torch.cpp (the C++ autograd nodes the eager path uses when libmhla_torch.so is built) and the Python
     autograd.Functions of ops.py call the same C ABI with the same arguments: bit-identical outputs and gradients, same error

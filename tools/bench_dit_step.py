@@ -20,10 +20,11 @@ from mhla_amd import dist as mdist  # noqa: E402
 from mhla_amd.hosts import DiT_MHLA, DiT_configs  # noqa: E402
 
 
-def run_dit_step(rank, local, world, model_name="DiT-XL/2", batch=32, image=256, steps=10, warmup=3, bucket_cap_mb=25):
+def run_dit_step(rank, local, world, model_name="DiT-XL/2", batch=32, image=256, steps=10, warmup=3, bucket_cap_mb=25, force_ddp=False):
     """Training steps of the thin DiT host on this rank's GPU; with world > 1 the model is wrapped in DistributedDataParallel
     (the default process group must exist): bucketed RCCL all-reduce of the fp32 gradients (2.7 GB at DiT-XL/2), overlapped
-    with the backward by DDP's reducer.  Returns the result dict on every rank (max-over-ranks time)."""
+    with the backward by DDP's reducer.  `force_ddp`: wrap the model also in a one-rank group (the test of the DDP + RCCL path on a
+    one-GPU box).  Returns the result dict on every rank (max-over-ranks time)."""
     dev = torch.device("cuda", local)
     torch.manual_seed(1234 + rank)
     latent = image // 8
@@ -33,7 +34,8 @@ def run_dit_step(rank, local, world, model_name="DiT-XL/2", batch=32, image=256,
         for prm in model.parameters():
             if prm.requires_grad and float(prm.abs().max()) == 0.0:
                 prm.normal_(std=0.02)
-    if world > 1:
+    ddp = world > 1 or force_ddp
+    if ddp:
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True)
     else:
         net = model
@@ -60,7 +62,7 @@ def run_dit_step(rank, local, world, model_name="DiT-XL/2", batch=32, image=256,
            "n_gpus": world, "per_gpu_batch": batch, "steps": steps, "warmup": warmup, "ms_per_step": el / steps * 1e3,
            "images_per_s": batch * world / (el / steps), "tokens_per_s": tokens / (el / steps),
            "params_M": nparam / 1e6,
-           "gradient_exchange": ("none (one rank)" if world == 1 else
+           "gradient_exchange": ("none (one rank)" if not ddp else
                                  f"DistributedDataParallel over {torch.distributed.get_backend()}: {nparam * 4 / 1e9:.2f} GB of fp32 gradients per "
                                  f"step, bucket_cap_mb={bucket_cap_mb}, gradient_as_bucket_view=True, all-reduce overlapped with backward")}
     del opt, net, model
