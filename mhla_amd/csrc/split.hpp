@@ -858,16 +858,20 @@ __global__ __launch_bounds__(MIXR_DMA_T) void k_sp_mixr_dma(const MixrArgs a) {
             for (int n = 0; n < NB; ++n) {
 #pragma unroll
                 for (int t = 0; t < NT; ++t) acc[n][t] = mfma_bf16(svA[t], wh[ks][n], acc[n][t]);
+#ifndef MIXR_NOLO   // (experiment builds only, tools/build_variant.sh -DMIXR_NOLO=1: without the weights' lo products -- results are wrong)
 #pragma unroll
                 for (int t = 0; t < NT; ++t) acc[n][t] = mfma_bf16(svA[t], wl[ks][n], acc[n][t]);
+#endif
             }
             if (ks + 2 < NK) operands(Th, ks + 2, svA);
 #pragma unroll
             for (int n = 0; n < NB; ++n) {
 #pragma unroll
                 for (int t = 0; t < NT; ++t) acc[n][t] = mfma_bf16(svB[t], wh[ks + 1][n], acc[n][t]);
+#ifndef MIXR_NOLO
 #pragma unroll
                 for (int t = 0; t < NT; ++t) acc[n][t] = mfma_bf16(svB[t], wl[ks + 1][n], acc[n][t]);
+#endif
             }
         }
         // lane: elements 16 t + 4 kg .. + 3 of output block 32 wave + 16 n + nl; neighbouring element tiles paired into 16-byte pieces
