@@ -125,30 +125,67 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : (ROPE ? 2 : 3)) void k_sp_state
     float nv[IT];
     constexpr bool rope = ROPE;
     int crow = 0;   // first token of the chunk held in registers
+    // Gather map: the rows of a chunk are looked up ONE FETCH EARLIER than they are used (clamped, unconditional), so that a fetch
+    // is one memory round trip, not two (map entry, then the row it names) -- with the map the chunk-ahead prefetch was a chain
+    // of two latencies against one 32-row chunk of products.
+    int nraw[IT], npos[IT];   // the map entry as loaded, and the position it was loaded for (used when there is no map)
+    auto lookup = [&](int c0) {
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const long p = p0 + min(c0 + r0 + RPP * it, S - 1);
+            // (no branch around the load -- hipcc waits for everything in flight where a branch with a load in it joins: without
+            // a map the load reads the first word of x and its result is dropped -- and no use of the loaded value before the next
+            // fetch: a select right here would wait for it, and for the data loads issued before it)
+            nraw[it] = gld<int>(a.idx ? (const void*)(a.idx + p) : a.x.ptr);
+            npos[it] = (int)p;
+        }
+    };
+    lookup(0);
+    // Every load of a fetch is unconditional (rows past the block's end and column groups past D are clamped onto valid ones and
+    // zeroed in `commit`; a tensor the call does not have is replaced by x and its values dropped): a load behind a branch makes
+    // hipcc wait for everything in flight where the branch joins, i.e. before the products the prefetch is meant to overlap.
+    const int cgc = min(cg, D - 8);
+    const T* kdq = den ? kdb : kb;                  // (uniform selects)
+    const long kdsn = den ? third.sn : a.x.sn;
+    const float* nvp = (MODE == 1 && a.normalize) ? ninvb : reinterpret_cast<const float*>(a.x.ptr);
     auto fetch = [&](int c0) {
         crow = c0;
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
-            const int r = c0 + r0 + RPP * it;
-            kx[it][0] = kx[it][1] = vx[it][0] = vx[it][1] = dx[it][0] = dx[it][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if constexpr (rope) rc[it] = rs[it] = f32x4{0.f, 0.f, 0.f, 0.f};   // padded rows: 0 * (uninitialised angle) could be NaN
-            nv[it] = 1.f;
-            if (r < S && cg < D) {
-                const long row = tok_row(a.idx, p0 + r);
-                ld8(kb + row * a.x.sn + cg, kx[it][0], kx[it][1]);
-                ld8(vb + row * a.y.sn + cg, vx[it][0], vx[it][1]);
-                if (a.relu) relu8(kx[it][0], kx[it][1], a.eps);
-                if (den) ld8(kdb + row * third.sn + cg, dx[it][0], dx[it][1]);
-                if (MODE == 1 && a.normalize) nv[it] = ninvb[r];
-                if constexpr (rope) {
-                    rc[it] = *reinterpret_cast<const f32x4*>(a.rcos + row * a.ldr + cg / 2);
-                    rs[it] = *reinterpret_cast<const f32x4*>(a.rsin + row * a.ldr + cg / 2);
-                }
+            const int rcl = min(c0 + r0 + RPP * it, S - 1);
+            const long row = a.idx ? nraw[it] : npos[it];
+            ld8(kb + row * a.x.sn + cgc, kx[it][0], kx[it][1]);
+            ld8(vb + row * a.y.sn + cgc, vx[it][0], vx[it][1]);
+            ld8(kdq + row * kdsn + cgc, dx[it][0], dx[it][1]);
+            nv[it] = gld<float>(nvp + ((MODE == 1 && a.normalize) ? rcl : 0));
+            if constexpr (rope) {
+                rc[it] = *reinterpret_cast<const f32x4*>(a.rcos + row * a.ldr + cgc / 2);
+                rs[it] = *reinterpret_cast<const f32x4*>(a.rsin + row * a.ldr + cgc / 2);
+            }
+        }
+        lookup(c0 + 32);   // (the rows of the next fetch)
+    };
+    // what `fetch` used to do behind its branch: zeros for padded rows / columns, relu + eps on the keys, 1 for an absent 1 / n
+    auto settle = [&]() {
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const bool valid = crow + r0 + RPP * it < S && cg < D;
+            const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+            if (a.relu) relu8(kx[it][0], kx[it][1], a.eps);
+            kx[it][0] = valid ? kx[it][0] : z4; kx[it][1] = valid ? kx[it][1] : z4;
+            vx[it][0] = valid ? vx[it][0] : z4; vx[it][1] = valid ? vx[it][1] : z4;
+            dx[it][0] = (valid && den) ? dx[it][0] : z4; dx[it][1] = (valid && den) ? dx[it][1] : z4;
+            nv[it] = (valid && MODE == 1 && a.normalize) ? nv[it] : 1.f;
+            if constexpr (rope) {   // padded rows: 0 * (uninitialised angle) could be NaN
+                rc[it] = valid ? rc[it] : z4;
+                rs[it] = valid ? rs[it] : z4;
             }
         }
     };
     float ksp[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     auto commit = [&]() {
+        __builtin_amdgcn_sched_barrier(0);   // (the fetched values are not touched before this point: hipcc would hoist `settle` above the products and wait there)
+        settle();
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
             const int off = (r0 + RPP * it) * LD + cg;
