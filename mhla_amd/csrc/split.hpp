@@ -706,19 +706,17 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void k_sp_mixr(const MixrArg
 
 // -------------------------------------------------------------------------------------------------
 // k_sp_mixr_dma<TRANS>: resident-sequence mixing for 16-bit summaries and 192 < M <= 256 blocks.
-// k_sp_mixr<16> (sixteen waves, sixteen output blocks each, 64-element slices) ran at 3 TB/s; taken apart at the 256 x 16 shape
-// (tools/build_variant.sh builds without the copies / the stores / the products): copies + stores alone 100 us, the product loop
-// alone 120-145 us, together 190 us.  The product loop is neither LDS-bandwidth nor matrix-pipe bound (half the MFMAs: -20 %;
-// swizzled conflict-free tiles: +-0): sixteen waves in lockstep each read the WHOLE slice through transposed LDS reads, eight
-// reads per wait, two MFMAs per read -- a latency chain per wave -- and the 128-register budget of 1024 threads leaves no room
-// to pipeline it.  This kernel therefore
+// k_sp_mixr<16> (sixteen waves, sixteen output blocks each, 64-element slices, register staging) ran at 3 TB/s.  This kernel
 //   * runs EIGHT waves with 32 output blocks each (256-register budget): every operand read feeds four MFMAs (two block tiles x
 //     weight hi / lo), the next reduction step's operands are requested before the current step's products, half the LDS reads;
 //   * stages by LDS-DMA (global_load_lds_dwordx4) into THREE images: two slices (64 KB) in flight while one is multiplied, no
-//     staging registers, no ds_write pass (four images / three in flight measured the same);
+//     staging registers, no ds_write pass.  The DMA writes lane-linear images (8 rows x 8 pieces per wave instruction); the tile
+//     kernels' bank swizzle (fast::gt_off) is applied to the SOURCE piece index and again by the transposed operand reads;
 //   * stages its results in TWO tiles, so that the stores of slice k - 1 are issued at the top of iteration k, beside the request
-//     for slice k + 2, and both travel under the products of slice k: one barrier per slice instead of two.  The DMA writes lane-linear images (8 rows x 8 pieces per wave instruction); the tile
-//     kernels' bank swizzle (fast::gt_off) is applied to the SOURCE piece index and again by the transposed operand reads.
+//     for slice k + 2, and both travel under the products of slice k: one barrier per slice;
+//   * fetches the weights once per workgroup through LDS (mixr_weights) and computes the normaliser's small product (k_wz) with them.
+// What it gained is the weight prologue (35 -> 8 us) and the two k_wz launches; the slice loop itself takes the same 170 us in
+// every arrangement tried -- DESIGN.md 3d' has the measurements (tools/trace_mixr.py): the launch runs at the chip's power limit.
 // vmcnt counts loads and stores in order: slice k's copy is complete when at most the instructions issued after it are
 // outstanding (counted per iteration, see the loop).
 // Rows past M repeat the last row (their weights are zero), so every reduction step runs unguarded.
