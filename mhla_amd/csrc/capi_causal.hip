@@ -50,9 +50,9 @@ Mix2Plan mix2_plan(size_t bh, int n, long E, bool bwd, bool hl) {
 // or two halves of three / four slices (V = 384, 512) with the first half's outputs parked in LDS
 bool cs_epi_ok(const CsPath& path, int V) { return path.pipe16 && (V <= 256 || V == 384 || V == 512); }
 CsWs cs_carve(void* ws, int B, int T, int H, int K, int V, int chunk, const CsPath& path) {
-    // (16-bit pipeline: bf16 planes with the per-chunk padding of cs_chunk_stride)
+    // (16-bit pipeline: bf16 planes in the tile-major layout of fast::cs_layout, one 128-byte line of padding per chunk tile)
     const size_t bh = (size_t)B * H, n = (size_t)(T + chunk - 1) / chunk;
-    const size_t st = path.pipe16 ? al4((bh * n * (size_t)fast::cs_chunk_stride(K, V, path.esz / 2) + 1) / 2) : al4(bh * n * K * V);
+    const size_t st = path.pipe16 ? al4((bh * (size_t)fast::cs_layout((int)n, (long)K * V, path.esz / 2).bhs + 1) / 2) : al4(bh * n * K * V);
     const size_t parts = std::max(bh * DW_MAX_SPLIT, path.pipe16 ? (size_t)mix2_plan(bh, (int)n, (long)K * V, true, path.hl).wgs : (size_t)0);
     float* p = (float*)ws;
     CsWs w;

@@ -29,17 +29,29 @@ template <int LD> __host__ __device__ constexpr int tile_elems() { return CS * L
 constexpr int CLD = 72;                 // strips of k_csf_state2
 constexpr int CTE = CS * CS;            // elements per tile plane in the workspace
 
-template <bool HL>
-__host__ __device__ __forceinline__ long cs_tile_off(int kk0, int v0, int V) {
-    return ((long)(kk0 >> 6) * (V >> 6) + (v0 >> 6)) * (CTE * (HL ? 2 : 1));
+// Summary layout of the 16-bit pipeline: [bh][K / 64][V / 64][chunk][plane][64][64] bf16 -- the chunk index INSIDE the tile index.
+// The mixing kernels read the same 128-byte row piece of EVERY chunk of a sequence at once: with the chunk index outermost
+// (rounds 3-4a: [bh][chunk][tile][plane]) those pieces were a whole chunk summary apart (128 KB at K = 128, V = 256; 512 KB at
+// K = 256, V = 512, i.e. every row of a slice in another 2 MB page), and the kernels' rate fell with the head size -- k_csf_mixf
+// 5.2 / 5.1 / 4.9 / 4.1 TB/s and k_csf_mixb 6.0 / 5.7 / 5.0 / 4.2 TB/s at K V = 16 K / 32 K / 64 K / 128 K.  Now a slice's rows are
+// one tile (16 KB with hi + lo planes) apart whatever the head size, and the token kernels, which move whole tiles, find the
+// tiles of a chunk n tiles apart instead of side by side.  CS_CHUNK_PAD (2 176 bytes per chunk tile, 13 % of a hi + lo tile) keeps
+// consecutive chunks from falling on the same HBM channels at the power-of-two tile size: with one 128-byte line of padding the
+// mixing kernels ran 30-40 % SLOWER than in the old layout, from 640 bytes on every padding measured the same (C5 0.72-0.75 ms,
+// the K = 256, V = 512 shape 1.49 -> 1.27-1.29 ms).
+constexpr int CS_CHUNK_PAD = 1088;
+struct CsLayout {
+    long bhs, ts, cst;   // bf16 elements from one (b,h) / one tile / one chunk to the next
+};
+__host__ __device__ __forceinline__ CsLayout cs_layout(int n, long E, int planes) {   // E = K V elements per chunk summary
+    CsLayout L;
+    L.cst = (long)planes * CTE + CS_CHUNK_PAD;
+    L.ts = (long)n * L.cst;
+    L.bhs = (E / CTE) * L.ts;
+    return L;
 }
-// bf16 elements from one chunk's summary to the next.  K V planes is a power of two at the fla shapes (128 KB .. 512 KB), and
-// every kernel walks the chunks of a sequence at that stride (the mixing kernels read the same slice of ALL chunks at once; the
-// summaries kernels of neighbouring workgroups write four chunks apart): at 512 KB (K = 256, V = 512, hi + lo) all of it fell
-// on a fraction of the HBM channels -- k_csf_mixf ran at 1.9 TB/s against 4.9 TB/s at 128 KB.  4352 bytes (4 KB + two lines)
-// of padding per chunk rotate consecutive chunks over the channels.
-constexpr int CS_CHUNK_PAD = 2176;
-__host__ __device__ __forceinline__ long cs_chunk_stride(int K, int V, int planes) { return (long)planes * K * V + CS_CHUNK_PAD; }
+// offset of tile (kk0 / 64, v0 / 64) inside a (b,h)'s summaries (the chunk's cst and the plane's CTE are added by the caller)
+__host__ __device__ __forceinline__ long cs_tile_off(int kk0, int v0, int V, long ts) { return ((long)(kk0 >> 6) * (V >> 6) + (v0 >> 6)) * ts; }
 
 __device__ __forceinline__ float bf_lo16(unsigned w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf_hi16(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
@@ -200,9 +212,9 @@ __global__ __launch_bounds__(NT4, (NK <= 2 && !HL) ? 4 : 2) void k_csf_bwd_tok4(
     auto base = [&](const View& w) { return (const u16*)w.ptr + b * w.sb + h * w.sh; };
     auto mbase = [&](const MView& w) { return (u16*)w.ptr + b * w.sb + h * w.sh; };
     const u16 *qb = base(a.q), *kb = base(a.k), *vb = base(a.v), *gb = base(a.dout);
-    const long CSZ = cs_chunk_stride(64 * NK, V, P);
-    const u16* Pb = reinterpret_cast<const u16*>(a.P) + ((long)bh * a.n + ci) * CSZ;
-    const u16* dSb = reinterpret_cast<const u16*>(a.dS) + ((long)bh * a.n + ci) * CSZ;
+    const CsLayout L = cs_layout(a.n, (long)64 * NK * V, P);
+    const u16* Pb = reinterpret_cast<const u16*>(a.P) + bh * L.bhs + ci * L.cst;
+    const u16* dSb = reinterpret_cast<const u16*>(a.dS) + bh * L.bhs + ci * L.cst;
     const float mii = a.mix[(long)ci * a.ldmix + ci];
 
     uint4 rP[NK][P], rdS[NK][P], nG, nV;
@@ -222,9 +234,9 @@ __global__ __launch_bounds__(NT4, (NK <= 2 && !HL) ? 4 : 2) void k_csf_bwd_tok4(
         cs8_commit_tok<LD>(KT + kk * CT, rdS[kk][0], rv, tid);
         __syncthreads();
 #pragma unroll
-        for (int p = 0; p < P; ++p) cs8_issue_state(rP[kk][p], Pb + cs_tile_off<HL>(kk * 64, 0, V) + p * CTE, tid);
+        for (int p = 0; p < P; ++p) cs8_issue_state(rP[kk][p], Pb + cs_tile_off(kk * 64, 0, V, L.ts) + p * CTE, tid);
 #pragma unroll
-        for (int p = 0; p < P; ++p) cs8_issue_state(rdS[kk][p], dSb + cs_tile_off<HL>(kk * 64, 0, V) + p * CTE, tid);
+        for (int p = 0; p < P; ++p) cs8_issue_state(rdS[kk][p], dSb + cs_tile_off(kk * 64, 0, V, L.ts) + p * CTE, tid);
         tile_mma8<LD, false, false>(accA, X1, KT + kk * CT, rt, ch, lane);
         __syncthreads();
     }
@@ -285,8 +297,8 @@ __global__ __launch_bounds__(NT4, (NK <= 2 && !HL) ? 4 : 2) void k_csf_bwd_tok4(
             {
                 const int r = tid >> 3, c = (tid & 7) * 8;
                 const u16* qsrc = qb + kk * 64 + (p0 + (r < rv ? r : 0)) * a.q.sn + c;   // step 3's Q tile
-                const u16* psrc = Pb + cs_tile_off<HL>(kk * 64, vn, V) + tid * 8;
-                const u16* ssrc = dSb + cs_tile_off<HL>(kk * 64, vn, V) + tid * 8;
+                const u16* psrc = Pb + cs_tile_off(kk * 64, vn, V, L.ts) + tid * 8;
+                const u16* ssrc = dSb + cs_tile_off(kk * 64, vn, V, L.ts) + tid * 8;
 #pragma unroll
                 for (int p = 0; p < P; ++p) rP[kk][p] = gld<uint4>(last ? qsrc : psrc + p * CTE);
 #pragma unroll
@@ -401,7 +413,7 @@ __global__ __launch_bounds__(NT4, NH > 1 ? 2 : (HL && NV == 4) ? (EPI ? 2 : CSF_
     const int V = a.V, nks = a.K / 64;
     const u16* qb = (const u16*)a.q.ptr + b * a.q.sb + h * a.q.sh;
     const u16* kb = (const u16*)a.k.ptr + b * a.k.sb + h * a.k.sh;
-    const long CSZ = cs_chunk_stride(a.K, V, P);
+    const CsLayout L = cs_layout(a.n, (long)a.K * V, P);
     float ss[4] = {0.f, 0.f, 0.f, 0.f};   // (EPI) row sums of squares over the halves walked so far
 #pragma unroll 1
     for (int hv = 0; hv < NH; ++hv) {
@@ -421,21 +433,21 @@ __global__ __launch_bounds__(NT4, NH > 1 ? 2 : (HL && NV == 4) ? (EPI ? 2 : CSF_
         rQ = gld<uint4>(qb + trow0 * a.q.sn + tc);
         rK = gld<uint4>(kb + trow0 * a.k.sn + tc);
         __builtin_amdgcn_sched_barrier(0);
-        const u16* Pb0 = reinterpret_cast<const u16*>(a.P) + ((long)bh * a.n + c0) * CSZ;
+        const u16* Pb0 = reinterpret_cast<const u16*>(a.P) + bh * L.bhs + c0 * L.cst;
 #pragma unroll
         for (int j = 0; j < NV; ++j)
 #pragma unroll
-            for (int p = 0; p < P; ++p) cs8_issue_state(rP[j][p], Pb0 + cs_tile_off<HL>(0, vbase + 64 * j, V) + p * CTE, tid);
+            for (int p = 0; p < P; ++p) cs8_issue_state(rP[j][p], Pb0 + cs_tile_off(0, vbase + 64 * j, V, L.ts) + p * CTE, tid);
         __builtin_amdgcn_sched_barrier(0);
     }
     for (int ci = c0; ci < c1; ++ci) {
     const long p0 = (long)ci * CS;
     const int rv = (int)min((long)CS, a.T - p0);
-    const u16* Pb = reinterpret_cast<const u16*>(a.P) + ((long)bh * a.n + ci) * CSZ;
+    const u16* Pb = reinterpret_cast<const u16*>(a.P) + bh * L.bhs + ci * L.cst;
     const long trow = row_of(ci);
     const int cn = ci + 1 < c1 ? ci + 1 : ci;   // next chunk (behind the last one: this chunk again -- hot lines, never used)
     const long trown = row_of(cn);
-    const u16* Pbn = reinterpret_cast<const u16*>(a.P) + ((long)bh * a.n + cn) * CSZ;
+    const u16* Pbn = reinterpret_cast<const u16*>(a.P) + bh * L.bhs + cn * L.cst;
     if (ci > c0) __syncthreads();   // the previous chunk's staging tiles are dead
     const float mii = gld<float>(a.mix + (long)ci * a.ldmix + ci);   // (requested here: a wait for it later would drain the ring)
     f32x4 accO[NV][2], accA[2];
@@ -466,7 +478,7 @@ __global__ __launch_bounds__(NT4, NH > 1 ? 2 : (HL && NV == 4) ? (EPI ? 2 : CSF_
                 rK = gld<uint4>(kb + rown * a.k.sn + coln + tc);
             }
             {
-                const u16* psrc = Pb + cs_tile_off<HL>(kn * 64, vbase + 64 * j, V) + tid * 8;
+                const u16* psrc = Pb + cs_tile_off(kn * 64, vbase + 64 * j, V, L.ts) + tid * 8;
                 const u16* vsrc = vb + 64 * j + trow * a.v.sn + tc;   // second phase's V rows (lo slot: the same lines, never used)
 #pragma unroll
                 for (int p = 0; p < P; ++p) rP[j][p] = gld<uint4>(lastk ? vsrc : psrc + p * CTE);
@@ -495,7 +507,7 @@ __global__ __launch_bounds__(NT4, NH > 1 ? 2 : (HL && NV == 4) ? (EPI ? 2 : CSF_
             cs8_commit_tok<LD>(Vc, rP[j][0], rv, tid);
             __syncthreads();
 #pragma unroll
-            for (int p = 0; p < P; ++p) cs8_issue_state(rP[j][p], Pbn + cs_tile_off<HL>(0, vbase + 64 * j, V) + p * CTE, tid);   // the next chunk's first P tiles
+            for (int p = 0; p < P; ++p) cs8_issue_state(rP[j][p], Pbn + cs_tile_off(0, vbase + 64 * j, V, L.ts) + p * CTE, tid);   // the next chunk's first P tiles
 #pragma unroll
             for (int p = 0; p < P; ++p) tile_mma8<LD, false, true>(accO[j], Ao + p * CT, Vc, rt, ch, lane);        // tril(QK^T) V
             cs8_put<LD>(Oc, accO[j], a.scale, rt, ch, lane);
@@ -618,7 +630,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_csf_state2(const CsfStateArgs a
     const int k0 = kb * ST2_KW, v0 = vb * ST2_VW, kw = min(ST2_KW, a.K - k0), vw = min(ST2_VW, a.V - v0);
     const u16* xb = (const u16*)a.x.ptr + b * a.x.sb + h * a.x.sh + k0;
     const u16* yb = (const u16*)a.y.ptr + b * a.y.sb + h * a.y.sh + v0;
-    const long CSZ = cs_chunk_stride(a.K, a.V, P);
+    const CsLayout L = cs_layout(a.n, (long)a.K * a.V, P);
 
     // X: 4 passes of 16 rows x 16 pieces; Y: 8 passes of 8 rows x 32 pieces (pieces past the block's width, rows past the chunk: zeros)
     const int xc = (tid & 15) * 8, yc = (tid & 31) * 8;
@@ -641,7 +653,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_csf_state2(const CsfStateArgs a
     issue(c0, false);
     for (int ci = c0; ci < c1; ++ci) {
         const int rv = (int)min((long)CS, a.T - (long)ci * CS);
-        u16* ob = a.out + ((long)bh * a.n + ci) * CSZ;
+        u16* ob = a.out + bh * L.bhs + ci * L.cst;
         if (ci > c0) __syncthreads();   // the previous chunk's tiles are dead
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
@@ -682,7 +694,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_csf_state2(const CsfStateArgs a
                     wave_lds_fence();
                     // a store instruction covers eight full 128-byte rows (two half rows per lane pair made it 16 half lines)
                     const int r = lane >> 3, c = (lane & 7) * 8;
-                    u16* d = ob + cs_tile_off<HL>(k0 + rt * 16, v0 + vt * 64, a.V) + ((rt * 16) & 63) * CS + r * CS + c;
+                    u16* d = ob + cs_tile_off(k0 + rt * 16, v0 + vt * 64, a.V, L.ts) + ((rt * 16) & 63) * CS + r * CS + c;
 #pragma unroll
                     for (int p = 0; p < P; ++p) {
                         const uint4 o0 = *reinterpret_cast<const uint4*>(Ws + p * 16 * CLD + r * CLD + c);

@@ -47,7 +47,7 @@ struct MixRows {
     static_assert(NTHR % PPR == 0 && ROWS % RPP == 0, "row mover: threads must tile the rows");
     uint4 v[NP];
     unsigned goff[NP];
-    __device__ __forceinline__ void offsets(long CSZ, int n, int tid) {   // CSZ: u16 elements per chunk summary
+    __device__ __forceinline__ void offsets(long CSZ, int n, int tid) {   // CSZ: u16 elements from one chunk's tile to the next (CsLayout::cst)
         const int r0 = tid / PPR, q = tid % PPR, pl = q / PPP, c = (q % PPP) * 8;
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
@@ -80,9 +80,9 @@ struct MixRows {
 };
 // offset (u16 elements) of slice s inside the summaries: (b,h) s / nsl, logical elements (s % nsl) TE ..
 template <int TE, bool HL>
-__device__ __forceinline__ long mix_slice_off(long s, long nsl, int n, long CSZ) {
+__device__ __forceinline__ long mix_slice_off(long s, long nsl, const CsLayout& L) {
     const long bh = s / nsl, e0 = (s - bh * nsl) * TE;
-    return bh * n * CSZ + (e0 / CTE) * (CTE * (HL ? 2 : 1)) + (e0 % CTE);
+    return bh * L.bhs + (e0 / CTE) * L.ts + (e0 % CTE);
 }
 // transposed-product accumulators (lane: elements 16 t + 4 kg .. + 3 of chunk row0 + nl) -> staging tiles [P][ROWS][MF_LD]
 template <int TE, int ROWS, bool HL>
@@ -114,7 +114,9 @@ __global__ __launch_bounds__(64 * NW, 4) void k_csf_mixf(const CsfMix2Args a) {
     u16* Os = Ts + P * ROWS * MF_LD;              // [P][ROWS][MF_LD]
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nl = lane & 15, kg = lane >> 4;
     const int n = a.n;
-    const long nsl = a.E / TE, CSZ = a.E * P + CS_CHUNK_PAD;
+    const long nsl = a.E / TE;
+    const CsLayout L = cs_layout(n, a.E, P);
+    const long CSZ = L.cst;
     const long s0 = (long)blockIdx.x * a.spw;
     const int cnt = (int)min((long)a.spw, a.total - s0);
     if (cnt <= 0) return;
@@ -135,13 +137,13 @@ __global__ __launch_bounds__(64 * NW, 4) void k_csf_mixf(const CsfMix2Args a) {
     }
     MixRows<64 * NW, ROWS, TE, HL> pre;
     pre.offsets(CSZ, n, tid);
-    pre.issue(a.in + mix_slice_off<TE, HL>(s0, nsl, n, CSZ));
+    pre.issue(a.in + mix_slice_off<TE, HL>(s0, nsl, L));
     const int kmax = min(wave / 2, (n - 1) / 32);   // last reduction step with a chunk j < i for this wave's rows
     for (int it = 0; it < cnt; ++it) {
-        const long off = mix_slice_off<TE, HL>(s0 + it, nsl, n, CSZ);
+        const long off = mix_slice_off<TE, HL>(s0 + it, nsl, L);
         pre.commit(Ts, n, tid);
         __syncthreads();
-        if (it + 1 < cnt) pre.issue(a.in + mix_slice_off<TE, HL>(s0 + it + 1, nsl, n, CSZ));
+        if (it + 1 < cnt) pre.issue(a.in + mix_slice_off<TE, HL>(s0 + it + 1, nsl, L));
         f32x4 acc[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -203,7 +205,9 @@ __global__ __launch_bounds__((ROLE == 0 ? 128 : 64) * NW) void k_csf_mixb(const 
     const bool mixer = ROLE == 1 || (ROLE == 0 && wave < NW);   // (uniform) dS role; the others: dmix role
     const int rw = (ROLE == 0 && !mixer) ? wave - NW : wave;
     const int n = a.n;
-    const long nsl = a.E / TE, CSZ = a.E * P + CS_CHUNK_PAD;
+    const long nsl = a.E / TE;
+    const CsLayout L = cs_layout(n, a.E, P);
+    const long CSZ = L.cst;
     const long s0 = (long)blockIdx.x * a.spw;
     const int cnt = (int)min((long)a.spw, a.total - s0);
     float* part = a.dwp + (long)blockIdx.x * n * n;
@@ -212,8 +216,8 @@ __global__ __launch_bounds__((ROLE == 0 ? 128 : 64) * NW) void k_csf_mixb(const 
 #pragma unroll
     for (int p = 0; p < pp.NP; ++p) pq.goff[p] = pp.goff[p];
     if (cnt > 0) {
-        pp.issue(a.in + mix_slice_off<TE, HL>(s0, nsl, n, CSZ));
-        if constexpr (ROLE != 1) pq.issue(a.in2 + mix_slice_off<TE, HL>(s0, nsl, n, CSZ));
+        pp.issue(a.in + mix_slice_off<TE, HL>(s0, nsl, L));
+        if constexpr (ROLE != 1) pq.issue(a.in2 + mix_slice_off<TE, HL>(s0, nsl, L));
     }
     if (mixer) {
         // B operand: B[k = i][n = j] = m_ij for the wave's chunks j = 16 rw + nl, i = 32 ks + 8 kg + t, i > j
@@ -237,8 +241,8 @@ __global__ __launch_bounds__((ROLE == 0 ? 128 : 64) * NW) void k_csf_mixb(const 
             if constexpr (ROLE != 1) pq.commit(Tq, n, tid);
             __syncthreads();
             if (it + 1 < cnt) {
-                pp.issue(a.in + mix_slice_off<TE, HL>(s0 + it + 1, nsl, n, CSZ));
-                if constexpr (ROLE != 1) pq.issue(a.in2 + mix_slice_off<TE, HL>(s0 + it + 1, nsl, n, CSZ));
+                pp.issue(a.in + mix_slice_off<TE, HL>(s0 + it + 1, nsl, L));
+                if constexpr (ROLE != 1) pq.issue(a.in2 + mix_slice_off<TE, HL>(s0 + it + 1, nsl, L));
             }
 #pragma unroll
             for (int t4 = 0; t4 < NT; t4 += TB) {
@@ -269,7 +273,7 @@ __global__ __launch_bounds__((ROLE == 0 ? 128 : 64) * NW) void k_csf_mixb(const 
                 for (int t = 0; t < TB; ++t) mix_stage4<TE, ROWS, HL>(Os, acc[t], rw * 16 + nl, (t4 + t) * 16 + kg * 4);
             }
             __syncthreads();
-            pp.store(a.out + mix_slice_off<TE, HL>(s0 + it, nsl, n, CSZ), n, Os, tid);
+            pp.store(a.out + mix_slice_off<TE, HL>(s0 + it, nsl, L), n, Os, tid);
         }
     } else {
         int tit[TPW], tjt[TPW];
@@ -286,8 +290,8 @@ __global__ __launch_bounds__((ROLE == 0 ? 128 : 64) * NW) void k_csf_mixb(const 
             pq.commit(Tq, n, tid);
             __syncthreads();
             if (it + 1 < cnt) {
-                pp.issue(a.in + mix_slice_off<TE, HL>(s0 + it + 1, nsl, n, CSZ));
-                pq.issue(a.in2 + mix_slice_off<TE, HL>(s0 + it + 1, nsl, n, CSZ));
+                pp.issue(a.in + mix_slice_off<TE, HL>(s0 + it + 1, nsl, L));
+                pq.issue(a.in2 + mix_slice_off<TE, HL>(s0 + it + 1, nsl, L));
             }
             // dmix tiles: A[m = i][k = e] = dP_i[e], B[k = e][n = j] = S_j[e], both 16-byte row reads (HL: hi hi + hi lo + lo hi)
 #pragma unroll
@@ -309,7 +313,7 @@ __global__ __launch_bounds__((ROLE == 0 ? 128 : 64) * NW) void k_csf_mixb(const 
                 }
             }
             __syncthreads();
-            if constexpr (ROLE == 0) pp.store(a.out + mix_slice_off<TE, HL>(s0 + it, nsl, n, CSZ), n, Os, tid);
+            if constexpr (ROLE == 0) pp.store(a.out + mix_slice_off<TE, HL>(s0 + it, nsl, L), n, Os, tid);
         }
         // the workgroup's partial of dmix: C[m = i][n = j], lane (i = 16 it + 4 kg + r, j = 16 jt + nl); entries with j >= i are never read
 #pragma unroll

@@ -30,9 +30,10 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert 0 < fwd < bwd
     assert lib.mhla_causal_bwd_ws_bytes(1, 8192, 4, 128, 256, 64, 0, 0) > lib.mhla_causal_fwd_ws_bytes(1, 8192, 4, 128, 256, 64, 0, 0) > 0
     # bf16 tensors: chunk summaries as bf16 hi + lo pairs (as many bytes as fp32); single bf16 only with the opt-in flag
-    # (+ 4352 bytes of padding per chunk and summary set on the 16-bit pipeline: cs_chunk_stride)
+    # (+ 2176 bytes of padding per chunk tile -- 8 tiles of 64 x 64 at K = 128, V = 256 -- and summary set on the 16-bit
+    # pipeline: fast::cs_layout)
     f32 = lib.mhla_causal_fwd_ws_bytes(1, 8192, 4, 128, 256, 64, 0, 0)
-    pad = 2 * 4 * 128 * 4352
+    pad = 2 * 4 * 128 * 8 * 2176
     assert lib.mhla_causal_fwd_ws_bytes(1, 8192, 4, 128, 256, 64, 1, 0) == f32 + pad
     assert lib.mhla_causal_fwd_ws_bytes(1, 8192, 4, 128, 256, 64, 1, _lib.CAUSAL_BF16_SUMMARIES) == f32 // 2 + pad
     assert lib.mhla_causal_fwd_ws_bytes(1, 8192, 4, 128, 256, 64, 1, _lib.CAUSAL_FORCE_GENERIC) == f32
