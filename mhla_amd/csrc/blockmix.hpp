@@ -94,6 +94,7 @@ struct StateArgs {
     const float* rcos;
     const float* rsin;
     long ldr;
+    long es;   // elements from one block's summary to the next in `out` (split.hpp / split16.hpp; the kernels of this file use D D)
 };
 
 template <int DT>
@@ -249,6 +250,7 @@ struct MixArgs {
     float* out;
     int M;
     long E;
+    long es;   // row stride of `in` / `out` in elements (split.hpp: E + padding; the kernels of this file use E)
 };
 constexpr int MIX_TI = 64, MIX_TE = 128, MIX_LDW = 80, MIX_LDI = 144;
 constexpr int MIX_SMEM_FLOATS = 64 * MIX_LDW + 64 * MIX_LDI;
@@ -350,6 +352,7 @@ struct OutArgs {
     const float* nw;
     float neps;
     View gate;
+    long es;   // elements from one block's summary to the next in `g` (split.hpp / split16.hpp)
 };
 
 template <int DT>
@@ -442,6 +445,7 @@ struct DwArgs {
     float* out;   // [bh][nsplit][M][M]
     int M, tiles;
     int nsplit;   // the E range (and E2) is cut into nsplit slices, one workgroup each (blockIdx.z)
+    long es;      // row stride of x / y in elements (split.hpp's k_sp_dw: E + padding; k_dw uses E)
 };
 constexpr int DW_LD = 34;
 constexpr int DW_SMEM_FLOATS = 2 * 64 * DW_LD;
@@ -572,6 +576,7 @@ struct TokArgs {
     const float* rcos;
     const float* rsin;
     long ldr;
+    long es;   // elements from one block's summary to the next in `g` / `dkv` (split.hpp / split16.hpp)
 };
 
 template <int DT>

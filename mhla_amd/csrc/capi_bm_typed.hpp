@@ -27,13 +27,13 @@ inline bool sp_mixr_ok(int M, long E) {
 template <bool S16>
 inline bool sp_mixr_takes_wz(int M, int S) { return S16 && M > 192 && M <= 256 && S <= 16; }
 template <int TRANS, bool S16>
-inline int sp_mixr(const float* W, int ldw, const void* in, void* out, int M, long E, int BH, hipStream_t st,
+inline int sp_mixr(const float* W, int ldw, const void* in, void* out, int M, long E, long es, int BH, hipStream_t st,
                    const float* zin = nullptr, float* zout = nullptr, int S = 0, float eps = 0.f) {
 #define MIXR(NW) do { \
         constexpr int TE = sp::mixr_te<NW, S16>(); \
         const long total = (long)BH * (E / TE); \
         const int wgs = (int)std::min<long>(total, 256); \
-        sp::MixrArgs a{W, ldw, in, out, M, E, total, (int)((total + wgs - 1) / wgs), nullptr, nullptr, 0, 0.f, nullptr}; \
+        sp::MixrArgs a{W, ldw, in, out, M, E, es, total, (int)((total + wgs - 1) / wgs), nullptr, nullptr, 0, 0.f, nullptr}; \
         const int gw = (int)((total + a.spw - 1) / a.spw); \
         return launch(sp::k_sp_mixr<NW, TRANS, S16>, dim3(gw), dim3(64 * NW), sp::sp_mixr_smem<NW, S16>(), st, TRANS ? "k_sp_mixr<1>" : "k_sp_mixr<0>", a); \
     } while (0)
@@ -42,7 +42,7 @@ inline int sp_mixr(const float* W, int ldw, const void* in, void* out, int M, lo
             const long total = (long)BH * (E / 64);
             const int wgs = (int)std::min<long>(total, 256);
             const bool wz = zin && sp_mixr_takes_wz<S16>(M, S);
-            sp::MixrArgs a{W, ldw, in, out, M, E, total, (int)((total + wgs - 1) / wgs), wz ? zin : nullptr, wz ? zout : nullptr, S, eps, g_trace.load()};
+            sp::MixrArgs a{W, ldw, in, out, M, E, es, total, (int)((total + wgs - 1) / wgs), wz ? zin : nullptr, wz ? zout : nullptr, S, eps, g_trace.load()};
             const int gw = (int)((total + a.spw - 1) / a.spw);
             return launch(sp::k_sp_mixr_dma<TRANS>, dim3(gw), dim3(sp::MIXR_DMA_T), sp::sp_mixr_dma_smem(), st, TRANS ? "k_sp_mixr_dma<1>" : "k_sp_mixr_dma<0>", a);
         }
@@ -76,8 +76,8 @@ inline int sp_dwr_splits(int BH, long E) {
     while (ns > 1 && E / ns < 256) --ns;
     return ns < 1 ? 1 : ns;
 }
-inline int sp_dwr(const void* x, const void* y, long E, const float* x2, const float* y2, int S2, float* out, int M, int BH, int nsplit, hipStream_t st) {
-    s16::DwrArgs d{(const sp::u16*)x, (const sp::u16*)y, E, x2, y2, S2, out, M, nsplit};
+inline int sp_dwr(const void* x, const void* y, long E, long es, const float* x2, const float* y2, int S2, float* out, int M, int BH, int nsplit, hipStream_t st) {
+    s16::DwrArgs d{(const sp::u16*)x, (const sp::u16*)y, E, es, x2, y2, S2, out, M, nsplit};
     if (M <= 128) return launch(s16::k_sp_dwr<2>, dim3(nsplit, BH), dim3(256), s16::dwr_smem<2>(), st, "k_sp_dwr<2>", d);
     if (M <= 192) return launch(s16::k_sp_dwr<3>, dim3(nsplit, BH), dim3(576), s16::dwr_smem<3>(), st, "k_sp_dwr<3>", d);
     return launch(s16::k_sp_dwr<4>, dim3(nsplit, BH), dim3(1024), s16::dwr_smem<4>(), st, "k_sp_dwr<4>", d);
@@ -93,17 +93,17 @@ int bm_state_and_mix(const mhla_view& q_num, const mhla_view& k_num, const mhla_
     StateArgs a{};
     a.rcos = rcos; a.rsin = rsin; a.ldr = ldr;
     a.x = cv(k_num); a.y = cv(v); a.kd = cv(k_den); a.qd = cv(q_den); a.idx = idx;
-    a.out = w.kv; a.ksum = w.ksum; a.zo = w.z;
+    a.out = w.kv; a.ksum = w.ksum; a.zo = w.z; a.es = w.es;
     a.H = H; a.M = M; a.S = S; a.D = D; a.eps = eps;
     a.relu = (flags & MHLA_FLAG_RELU_EPS) ? 1 : 0; a.normalize = normalize; a.split = split;
-    MixArgs m{W, ldw, w.kv, w.g, M, (long)D * D};
+    MixArgs m{W, ldw, w.kv, w.g, M, (long)D * D, w.es};
     if (sp_shape_ok(D, flags)) {   // split-bf16 MFMA kernels (split.hpp)
         constexpr int SNT = sp_state_threads<DT>();   // eight waves at D = 128 (split.hpp)
         if (s16)    RC(launch(s16::k_s16_state<0>, dim3((M + s16::WPB - 1) / s16::WPB, B * H), dim3(64 * s16::WPB), s16::state_smem(), st, "k_s16_state<0>", a));
         else if (a.rcos) RC(launch(sp::k_sp_state<T, DT, 0, true, SNT>, dim3(M, B * H), dim3(SNT), sp::sp_state_smem<DT>(), st, "k_sp_state<rope>", a));
         else        RC(launch(sp::k_sp_state<T, DT, 0, false, SNT>, dim3(M, B * H), dim3(SNT), sp::sp_state_smem<DT>(), st, "k_sp_state", a));
         const bool mixr = sp_mixr_ok<sp::Sum16<T>::value>(M, m.E), wz_fused = mixr && normalize && sp_mixr_takes_wz<sp::Sum16<T>::value>(M, S);
-        if (mixr) RC((sp_mixr<0, sp::Sum16<T>::value>(W, ldw, w.kv, w.g, M, m.E, B * H, st, normalize ? (const float*)w.z : nullptr, w.ninv, S, eps)));
+        if (mixr) RC((sp_mixr<0, sp::Sum16<T>::value>(W, ldw, w.kv, w.g, M, m.E, w.es, B * H, st, normalize ? (const float*)w.z : nullptr, w.ninv, S, eps)));
         else RC(launch(sp::k_sp_mix<0, sp::Sum16<T>::value>, dim3((unsigned)((m.E + sp::SPM_TE - 1) / sp::SPM_TE), (M + 63) / 64, B * H), dim3(NTHREADS), sp::sp_mix_smem<sp::Sum16<T>::value>(), st, "k_sp_mix<0>", m));
         if (normalize && !wz_fused)
             RC(launch(k_wz<0>, dim3((S + 63) / 64, (M + 63) / 64, B * H), dim3(NTHREADS), 0, st, "k_wz<0>", W, ldw, (const float*)w.z, w.ninv, M, S, eps));
@@ -138,7 +138,7 @@ int bm_fwd_typed(const BmCall& c) {
         OutArgs o{};
         o.rcos = rcos; o.rsin = rsin; o.ldr = ldr;
         o.q = cv(q_num); o.o = cmv(c.out); o.idx = block_index; o.W = W; o.ldw = ldw; o.g = w.g; o.ninv = w.ninv;
-        o.H = H; o.M = M; o.S = S; o.D = D; o.eps = eps;
+        o.H = H; o.M = M; o.S = S; o.D = D; o.eps = eps; o.es = w.es;
         o.relu = (flags & MHLA_FLAG_RELU_EPS) ? 1 : 0; o.normalize = normalize;
         if (epi) {
             if constexpr (std::is_same<ET, float>::value) {
@@ -180,14 +180,14 @@ int bm_bwd_typed(const BmCall& c) {
         // dG_i = Q_i^T (dO_i / n_i), dn_i
         StateArgs a{};
         a.x = cv(q_num); a.y = cv(dout); a.o = cv(out_view); a.idx = block_index; a.W = W; a.ldw = ldw; a.ninv = w.ninv;
-        a.out = w.dg; a.dn = w.dn; a.H = H; a.M = M; a.S = S; a.D = D; a.eps = eps;
+        a.out = w.dg; a.dn = w.dn; a.es = w.es; a.H = H; a.M = M; a.S = S; a.D = D; a.eps = eps;
         a.relu = relu; a.normalize = normalize; a.split = split;
         const int tiles = (M + 63) / 64;
         TokArgs t{};
         t.q = cv(q_num); t.k = cv(k_num); t.v = cv(v); t.qd = cv(q_den); t.kd = cv(k_den); t.dout = cv(dout);
         t.dq = cmv(dq_num); t.dk = cmv(dk_num); t.dv = cmv(dv); t.dqd = cmv(dq_den); t.dkd = cmv(dk_den);
         t.idx = block_index; t.W = W; t.ldw = ldw; t.g = w.g; t.dkv = w.dkv; t.ninv = w.ninv; t.dz = w.dz; t.ksum = w.ksum;
-        t.dks = w.dks;
+        t.dks = w.dks; t.es = w.es;
         t.H = H; t.M = M; t.S = S; t.D = D; t.eps = eps; t.relu = relu; t.normalize = normalize; t.split = split;
         if (sp_shape_ok(D, flags)) {   // split-bf16 MFMA kernels (split.hpp)
             const long E = (long)D * D;
@@ -202,16 +202,16 @@ int bm_bwd_typed(const BmCall& c) {
             const bool mixr = sp_mixr_ok<sp::Sum16<ET>::value>(M, E), wz_fused = mixr && normalize && sp_mixr_takes_wz<sp::Sum16<ET>::value>(M, S);
             if (normalize && !wz_fused)
                 RC(launch(k_wz<1>, dim3((S + 63) / 64, (M + 63) / 64, B * H), dim3(NTHREADS), 0, st, "k_wz<1>", W, ldw, (const float*)w.dn, w.dz, M, S, 0.f));
-            MixArgs m{W, ldw, w.dg, w.dkv, M, E};
-            if (mixr) RC((sp_mixr<1, sp::Sum16<ET>::value>(W, ldw, w.dg, w.dkv, M, E, B * H, st, normalize ? (const float*)w.dn : nullptr, w.dz, S, 0.f)));
+            MixArgs m{W, ldw, w.dg, w.dkv, M, E, w.es};
+            if (mixr) RC((sp_mixr<1, sp::Sum16<ET>::value>(W, ldw, w.dg, w.dkv, M, E, w.es, B * H, st, normalize ? (const float*)w.dn : nullptr, w.dz, S, 0.f)));
             else RC(launch(sp::k_sp_mix<1, sp::Sum16<ET>::value>, dim3((unsigned)((E + sp::SPM_TE - 1) / sp::SPM_TE), tiles, B * H), dim3(NTHREADS), sp::sp_mix_smem<sp::Sum16<ET>::value>(), st, "k_sp_mix<1>", m));
             int nsplit = dw_splits(tiles * tiles * B * H, E);
             if (nsplit > DW_MAX_SPLIT - 1) nsplit = DW_MAX_SPLIT - 1;   // one more part per (b, h) holds the <dn_i, z_j> term
-            DwArgs d{w.dg, w.kv, E, nullptr, nullptr, 0, w.dwp, M, tiles, nsplit};
+            DwArgs d{w.dg, w.kv, E, nullptr, nullptr, 0, w.dwp, M, tiles, nsplit, w.es};
             const bool dwr = sp::Sum16<ET>::value && sp_dwr_ok(M, E);   // whole-matrix workgroups: the <dn_i, z_j> term is one of their stages
             if (dwr) {
                 nsplit = sp_dwr_splits(B * H, E);
-                RC(sp_dwr(w.dg, w.kv, E, normalize ? w.dn : nullptr, normalize ? w.z : nullptr, S, w.dwp, M, B * H, nsplit, st));
+                RC(sp_dwr(w.dg, w.kv, E, w.es, normalize ? w.dn : nullptr, normalize ? w.z : nullptr, S, w.dwp, M, B * H, nsplit, st));
             } else if (M <= 16)      RC(launch(sp::k_sp_dw<sp::Sum16<ET>::value, 1>, dim3(1, B * H, nsplit), dim3(NTHREADS), sp::SP_DW_SMEM, st, "k_sp_dw<16>", d));
             else if (M <= 32) RC(launch(sp::k_sp_dw<sp::Sum16<ET>::value, 2>, dim3(1, B * H, nsplit), dim3(NTHREADS), sp::SP_DW_SMEM, st, "k_sp_dw<32>", d));
             else              RC(launch(sp::k_sp_dw<sp::Sum16<ET>::value>, dim3(tiles * tiles, B * H, nsplit), dim3(NTHREADS), sp::SP_DW_SMEM, st, "k_sp_dw", d));

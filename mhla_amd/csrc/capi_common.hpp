@@ -124,12 +124,20 @@ inline int dt_for(int D) { return D <= 32 ? 2 : D <= 64 ? 4 : D <= 80 ? 5 : D <=
 struct BmWs {
     float *kv, *g, *z, *ksum, *ninv, *dg, *dkv, *dn, *dz, *dks, *dwp;
     size_t total_fwd, total_bwd;
+    long es;   // elements from one block's D x D summary to the next (D D + padding on the split-operand path)
 };
 // sum16: the D x D block summaries (KV, G, dG, dKV) are stored as bf16 (split-operand path on bf16 tensors): half the floats
-inline BmWs bm_carve(void* ws, int B, int H, int M, int S, int D, bool sum16) {
-    const size_t bh = (size_t)B * H, st = al4(sum16 ? (bh * M * D * D + 1) / 2 : bh * M * D * D), zs = al4(bh * M * S), ks = al4(bh * M * D);
+// padded (split-operand path): every summary row carries 1152 bytes of padding.  The mixing and dW kernels read the same 128-byte
+// piece of EVERY block's summary at once, i.e. at the row stride: at a power-of-two stride (8 KB at D = 64 bf16, 64 KB at D = 128
+// fp32) those requests fall on a fraction of the HBM channels -- k_sp_dwr ran at 3.7 TB/s at D = 64 and at 4.9 / 5.4 TB/s at
+// D = 56 / 72 (the causal pipeline met the same effect, causal_bf16.hpp).  The generic fp32-MFMA kernels keep dense rows.
+inline long bm_row_elems(int D, bool sum16, bool padded) { return (long)D * D + (padded ? (sum16 ? 576 : 288) : 0); }
+inline BmWs bm_carve(void* ws, int B, int H, int M, int S, int D, bool sum16, bool padded) {
+    const size_t es = (size_t)bm_row_elems(D, sum16, padded);
+    const size_t bh = (size_t)B * H, st = al4(sum16 ? (bh * M * es + 1) / 2 : bh * M * es), zs = al4(bh * M * S), ks = al4(bh * M * D);
     float* p = (float*)ws;
     BmWs w;
+    w.es = (long)es;
     w.kv = p; p += st;
     w.g = p; p += st;
     w.z = p; p += zs;

@@ -259,7 +259,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : (ROPE ? 2 : 3)) void k_sp_state
     }
 
     // KV_j -> ws  (C layout: row d1 = 16 tile + 4 kg + r, column d2 = 16 ct + nl)
-    float* ob = a.out + ((long)bh * a.M + blk) * D * D;
+    float* ob = a.out + ((long)bh * a.M + blk) * a.es;
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : (ROPE ? 2 : 3)) void k_sp_state
             for (int r = 0; r < 4; ++r) {
                 const int row = (wave * RT + rt) * 16 + kg * 4 + r, col = ct * 16 + nl;
                 if (row < D && col < D) {
-                    if (Sum16<T>::value) reinterpret_cast<u16*>(a.out)[((long)bh * a.M + blk) * D * D + (long)row * D + col] = cvt_bf16(acc[rt][ct][r]);
+                    if (Sum16<T>::value) reinterpret_cast<u16*>(a.out)[((long)bh * a.M + blk) * a.es + (long)row * D + col] = cvt_bf16(acc[rt][ct][r]);
                     else                 ob[(long)row * D + col] = acc[rt][ct][r];
                 }
             }
@@ -340,10 +340,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_mix(const MixArgs a) {
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nl = lane & 15, kg = lane >> 4;
     const long e0 = (long)blockIdx.x * SPM_TE;
     const int i0 = blockIdx.y * 64, bh = blockIdx.z, M = a.M;
-    const float* inb = a.in + (long)bh * M * a.E + e0;
-    float* outb = a.out + (long)bh * M * a.E + e0;
-    const u16* inb16 = reinterpret_cast<const u16*>(a.in) + (long)bh * M * a.E + e0;
-    u16* outb16 = reinterpret_cast<u16*>(a.out) + (long)bh * M * a.E + e0;
+    const float* inb = a.in + (long)bh * M * a.es + e0;
+    float* outb = a.out + (long)bh * M * a.es + e0;
+    const u16* inb16 = reinterpret_cast<const u16*>(a.in) + (long)bh * M * a.es + e0;
+    u16* outb16 = reinterpret_cast<u16*>(a.out) + (long)bh * M * a.es + e0;
     const int steps = (M + 31) / 32;
     const int sr = tid >> 3, sc = (tid & 7) * 8;   // staging: row sr, 8 floats at columns sc and sc + 64
 
@@ -361,9 +361,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_mix(const MixArgs a) {
             for (int u = 0; u < 2; ++u)
                 if (e0 + sc + 64 * u < a.E) {   // E is a multiple of 8
                     if (S16) {
-                        pre16[u] = *reinterpret_cast<const uint4*>(inb16 + (long)row * a.E + sc + 64 * u);
+                        pre16[u] = *reinterpret_cast<const uint4*>(inb16 + (long)row * a.es + sc + 64 * u);
                     } else {
-                        const float* src = inb + (long)row * a.E + sc;
+                        const float* src = inb + (long)row * a.es + sc;
                         pre[u][0] = *reinterpret_cast<const f32x4*>(src + 64 * u);
                         pre[u][1] = *reinterpret_cast<const f32x4*>(src + 64 * u + 4);
                     }
@@ -470,7 +470,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_mix(const MixArgs a) {
         for (int v0 = 0; v0 < 4; ++v0) {
             const int v = tid + v0 * NTHREADS, r = v >> 4, c = (v & 15) * 8;
             if (i0 + r < M && e0 + c < a.E)   // E is a multiple of 8
-                *reinterpret_cast<uint4*>(outb16 + (long)(i0 + r) * a.E + c) = *reinterpret_cast<const uint4*>(Os + r * SPM_LD + c);
+                *reinterpret_cast<uint4*>(outb16 + (long)(i0 + r) * a.es + c) = *reinterpret_cast<const uint4*>(Os + r * SPM_LD + c);
         }
     } else {
         float* Os = reinterpret_cast<float*>(smem_raw);   // [64][SPM_TE + 4]
@@ -483,7 +483,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_mix(const MixArgs a) {
         for (int v0 = 0; v0 < 8; ++v0) {
             const int v = tid + v0 * NTHREADS, r = v >> 5, c = (v & 31) * 4;
             if (i0 + r < M && e0 + c < a.E)
-                *reinterpret_cast<f32x4*>(outb + (long)(i0 + r) * a.E + c) = *reinterpret_cast<const f32x4*>(Os + r * (SPM_TE + 4) + c);
+                *reinterpret_cast<f32x4*>(outb + (long)(i0 + r) * a.es + c) = *reinterpret_cast<const f32x4*>(Os + r * (SPM_TE + 4) + c);
         }
     }
 }
@@ -568,6 +568,7 @@ struct MixrArgs {
     void* out;
     int M;
     long E;        // elements per block summary (multiple of the slice width)
+    long es;       // row stride of `in` / `out` in elements (E + padding)
     long total;    // slices = bh * E / TE
     int spw;       // slices per workgroup
     // k_sp_mixr_dma only: the normaliser's product with the same weights, out = f(sum_r Wm(o, r) zin[bh][r][s]) for S <= 16 fp32
@@ -609,7 +610,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void k_sp_mixr(const MixrArg
     constexpr int ESZ = S16 ? 2 : 4;
     // byte offset of slice (bh, es); a workgroup's slices are consecutive, so the pair is advanced rather than divided out per
     // slice (the 64-bit division was 150 instructions with branches between the barrier and the next slice's loads)
-    auto slice_off = [&](int bh, int es) { return ((long)bh * M * a.E + (long)es * TE) * ESZ; };
+    auto slice_off = [&](int bh, int es) { return ((long)bh * M * a.es + (long)es * TE) * ESZ; };
     auto advance = [&](int& bh, int& es) { if (++es == (int)nsl) { es = 0; ++bh; } };
     int cbh = (int)(s0 / nsl), ces = (int)(s0 - (long)cbh * nsl), nbh = cbh, nes = ces;
     // the thread's pieces: piece v = tid + p NTH -> row v / PPR, 16 bytes at column piece v % PPR (rows past M: the last row, zeroed)
@@ -617,7 +618,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void k_sp_mixr(const MixrArg
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
         const int v = tid + p * NTH, row = v / PPR, c = v % PPR;
-        goff[p] = (unsigned)((long)(row < M ? row : M - 1) * a.E * ESZ + c * 16);
+        goff[p] = (unsigned)((long)(row < M ? row : M - 1) * a.es * ESZ + c * 16);
     }
     uint4 pre[NP];
     auto issue = [&](long boff) {
@@ -750,7 +751,7 @@ __global__ __launch_bounds__(MIXR_DMA_T) void k_sp_mixr_dma(const MixrArgs a) {
 #pragma unroll
         for (int n = 0; n < NB; ++n) asm volatile("" : "+v"(wh[ks][n]), "+v"(wl[ks][n]));
     wait_vmcnt<0>();
-    auto slice_off = [&](int bh, int es) { return ((long)bh * M * a.E + (long)es * TE) * 2; };   // bytes
+    auto slice_off = [&](int bh, int es) { return ((long)bh * M * a.es + (long)es * TE) * 2; };   // bytes
     auto advance = [&](int& bh, int& es) { if (++es == (int)nsl) { es = 0; ++bh; } };
     int cbh = (int)(s0 / nsl), ces = (int)(s0 - (long)cbh * nsl), nbh = cbh, nes = ces;
     // The normaliser's small product for every (b, h) whose first slice is this workgroup's: z as bf16 hi + lo in a swizzled tile
@@ -806,7 +807,7 @@ __global__ __launch_bounds__(MIXR_DMA_T) void k_sp_mixr_dma(const MixrArgs a) {
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
         const int row = p * 64 + wave * 8 + (lane >> 3), piece = (lane & 7) ^ ((row ^ (row >> 1)) & 7);
-        soff[p] = (unsigned)((long)min(row, M - 1) * a.E * 2 + piece * 16);
+        soff[p] = (unsigned)((long)min(row, M - 1) * a.es * 2 + piece * 16);
     }
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(lds));
     auto issue = [&](int k, long boff) {
@@ -820,7 +821,7 @@ __global__ __launch_bounds__(MIXR_DMA_T) void k_sp_mixr_dma(const MixrArgs a) {
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
         const int v = tid + p * NTH, row = v >> 3, c = v & 7;
-        goff[p] = (unsigned)((long)min(row, M - 1) * a.E * 2 + c * 16);
+        goff[p] = (unsigned)((long)min(row, M - 1) * a.es * 2 + c * 16);
     }
     // transposed operand reads: the piece permutation depends on the row's low four bits only, so the addresses of reduction step 0
     // serve every step with a constant offset, and element tile t is tile 0 with bit t of the piece index flipped (offset ^ 16 t)
@@ -1019,7 +1020,7 @@ __global__ __launch_bounds__(SP_OUT_T, EPI ? SP_OUT_EPI_WAVES : 2) void k_sp_out
     const T* qb = (const T*)a.q.ptr + b * a.q.sb + h * a.q.sh;
     TO* ob = (TO*)a.o.ptr + b * a.o.sb + h * a.o.sh;
     constexpr bool S16 = Sum16<T>::value;   // G_i stored as bf16: no lo tile
-    stage_mat_split<DT, S16, SP_OUT_T>(Gh, Gl, a.g, ((long)bh * a.M + blk) * D * D, D, tid);
+    stage_mat_split<DT, S16, SP_OUT_T>(Gh, Gl, a.g, ((long)bh * a.M + blk) * a.es, D, tid);
     __syncthreads();
     const float* ninvb = a.ninv + ((long)bh * a.M + blk) * S;
     for (int tt = wave; tt * 16 < S; tt += SP_OUT_T / 64) {
@@ -1210,10 +1211,10 @@ __global__ __launch_bounds__(NTHREADS) void k_sp_dw(const DwArgs a) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int ri = min(i0 + t * 16 + nl, M - 1), rj = min(j0 + t * 16 + nl, M - 1);
-        xp[t] = a.x + ((long)bh * M + ri) * E + kg * 8;
-        yp[t] = a.y + ((long)bh * M + rj) * E + kg * 8;
-        xp16[t] = reinterpret_cast<const u16*>(a.x) + ((long)bh * M + ri) * E + kg * 8;
-        yp16[t] = reinterpret_cast<const u16*>(a.y) + ((long)bh * M + rj) * E + kg * 8;
+        xp[t] = a.x + ((long)bh * M + ri) * a.es + kg * 8;
+        yp[t] = a.y + ((long)bh * M + rj) * a.es + kg * 8;
+        xp16[t] = reinterpret_cast<const u16*>(a.x) + ((long)bh * M + ri) * a.es + kg * 8;
+        yp16[t] = reinterpret_cast<const u16*>(a.y) + ((long)bh * M + rj) * a.es + kg * 8;
     }
     f32x4 acc[NT][NT];
 #pragma unroll
@@ -1367,7 +1368,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_bwd_dq(const TokArgs a) {
     };
     fetch(wave, cur);   // in flight while G_i is staged
     constexpr bool S16 = Sum16<T>::value;
-    stage_mat_split<DT, S16>(Gh, Gl, a.g, ((long)bh * M + blk) * D * D, D, tid);
+    stage_mat_split<DT, S16>(Gh, Gl, a.g, ((long)bh * M + blk) * a.es, D, tid);
     if (tid < DW) ksum[tid] = (a.normalize && tid < D) ? a.ksum[((long)bh * M + blk) * D + tid] : 0.f;
     __syncthreads();
     f32x4 dksp[DT];
@@ -1512,7 +1513,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_bwd_dkv(const TokArgs a) {
     };
     fetch(wave, cur);
     constexpr bool S16 = Sum16<T>::value;
-    stage_mat_split<DT, S16>(Gh, Gl, a.dkv, ((long)bh * M + blk) * D * D, D, tid);
+    stage_mat_split<DT, S16>(Gh, Gl, a.dkv, ((long)bh * M + blk) * a.es, D, tid);
     if (tid < DW) dks[tid] = (a.normalize && tid < D) ? a.dks[((long)bh * M + blk) * D + tid] : 0.f;
     __syncthreads();
 

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(64 * WPB) void k_s16_state(const StateArgs a) {
         bx[t] = tr_read4(Xs, t * 16, lane);
         ay[t] = tr_read4(Ys, t * 16, lane);
     }
-    u16* ob = reinterpret_cast<u16*>(a.out) + sb * 4096 + nl * 64;
+    u16* ob = reinterpret_cast<u16*>(a.out) + sb * a.es + nl * 64;
 #pragma unroll
     for (int tn = 0; tn < 4; ++tn)
 #pragma unroll
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(64 * WPB) void k_s16_out(const OutArgs a) {
     u16* Gs = reinterpret_cast<u16*>(smem_raw) + wave * (64 * LD);
     const long p0 = (long)blk * 16, sb = (long)bh * M + blk;
     const int r = lane >> 3, c8 = (lane & 7) * 8;
-    const u16* g = reinterpret_cast<const u16*>(a.g) + sb * 4096 + r * 64 + c8;
+    const u16* g = reinterpret_cast<const u16*>(a.g) + sb * a.es + r * 64 + c8;
     uint4 gv[8];
 #pragma unroll
     for (int p = 0; p < 8; ++p) gv[p] = gld<uint4>(g + p * 8 * 64);
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(64 * WPB) void k_s16_bwd_dq(const TokArgs a) {
     const int blk = blockIdx.x * WPB + wave, bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H, M = a.M;
     if (blk >= M) return;
     const long p0 = (long)blk * 16, sb = (long)bh * M + blk;
-    const u16* g = reinterpret_cast<const u16*>(a.g) + sb * 4096 + nl * 64 + kg * 8;
+    const u16* g = reinterpret_cast<const u16*>(a.g) + sb * a.es + nl * 64 + kg * 8;
     uint4 A[4][2];
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) {
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(64 * WPB) void k_s16_bwd_dkv(const TokArgs a) {
     const long p0 = (long)blk * 16, sb = (long)bh * M + blk;
     // dKV rows in the layout of the dK product's A operand (m = d1 = 16 ct + nl, k = d2 = 32 ks + 8 kg ..): used as loaded,
     // and written to LDS for the transposed reads of the dV product
-    const u16* g = reinterpret_cast<const u16*>(a.dkv) + sb * 4096 + nl * 64 + kg * 8;
+    const u16* g = reinterpret_cast<const u16*>(a.dkv) + sb * a.es + nl * 64 + kg * 8;
     uint4 A[4][2];
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) {
@@ -368,6 +368,7 @@ struct DwrArgs {
     const u16* x;
     const u16* y;
     long E;
+    long es;           // row stride of x / y in elements (E + padding)
     const float* x2;   // [bh][M][S2] or null
     const float* y2;
     int S2;
@@ -403,7 +404,7 @@ __global__ __launch_bounds__(64 * TT * TT) void k_sp_dwr(const DwrArgs a) {
     for (int i = 0; i < UPW; ++i) {
         const int u = (wave + i * NW) % UNITS, mat = u / (R / 8), r0 = (u - mat * (R / 8)) * 8, row = r0 + (lane >> 3);
         const int piece = (lane & 7) ^ ((row ^ (row >> 1)) & 7);
-        src[i] = (mat ? a.y : a.x) + ((long)bh * M + min(row, M - 1)) * a.E + ebeg + piece * 8;
+        src[i] = (mat ? a.y : a.x) + ((long)bh * M + min(row, M - 1)) * a.es + ebeg + piece * 8;
         dst[i] = mat * IMG + r0 * DWR_SE;   // (wave-uniform)
     }
     auto issue = [&](int st) {
