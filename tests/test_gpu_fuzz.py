@@ -41,6 +41,30 @@ def test_blockmix_fuzz(case):
     run_case(2 if M * S * D < 100000 else 1, 2, M, S, D, dtype, normalize=normalize, split=split, w=w, idx=idx, seed=1000 + i)
 
 
+def _round4_cases(n=20, seed=4):
+    """Shapes of the kernels added in round 4: many short blocks (wave-per-block token kernels, whole-matrix dW, LDS-DMA mixing,
+    padded summary rows) and few long ones (chunk parts over several workgroups, pair prefetch of the summary kernels)."""
+    rnd = random.Random(seed)
+    cases = []
+    for i in range(n):
+        if i % 2 == 0:
+            dtype = rnd.choice([torch.bfloat16, torch.bfloat16, torch.float32])
+            M, S, D = rnd.choice([65, 100, 129, 193, 200, 256]), rnd.choice([8, 16, 16]), rnd.choice([32, 64, 64, 72])
+        else:
+            dtype = torch.bfloat16
+            M, S, D = rnd.choice([3, 8, 17, 33]), rnd.choice([65, 128, 130, 192, 256, 320]), 64
+        normalize = rnd.random() < 0.8
+        cases.append((100 + i, dtype, M, S, D, normalize, False, rnd.random() < 0.3, "rand"))
+    return cases
+
+
+@pytest.mark.parametrize("case", _round4_cases(), ids=lambda c: f"{c[0]}-{str(c[1]).split('.')[-1]}-M{c[2]}-S{c[3]}-D{c[4]}-n{int(c[5])}i{int(c[7])}")
+def test_blockmix_fuzz_many_short_and_few_long_blocks(case):
+    i, dtype, M, S, D, normalize, split, use_idx, w = case
+    idx = torch.randperm(M * S, generator=torch.Generator().manual_seed(i)).int() if use_idx else None
+    run_case(2, 3, M, S, D, dtype, normalize=normalize, split=split, w=w, idx=idx, seed=2000 + i)
+
+
 def _causal_cases(n=16, seed=7):
     rnd = random.Random(seed)
     out = []
