@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MHLA_ABI_VERSION 7
+#define MHLA_ABI_VERSION 8
 
 enum { MHLA_F32 = 0, MHLA_BF16 = 1, MHLA_F16 = 2 };
 
@@ -49,6 +49,13 @@ enum {
 #define MHLA_FLAG_RELU_EPS 1u      /* apply relu(x)+eps to q,k while loading (mhla_dit/mhla/mhla.py:229-230) */
 #define MHLA_FLAG_FORCE_GENERIC 2u /* testing aid: take the generic fp32-MFMA path even where the bf16 fast path applies */
 #define MHLA_FLAG_NO_SMALLN 4u     /* testing aid: skip the single-launch small-sequence path (S = 16, N <= 256) */
+#define MHLA_FLAG_BF16_SUMMARIES 8u /* REDUCED PRECISION, opt-in, 16-bit tensors only: every intermediate that feeds a second
+                                    * contraction -- the block summaries KV, G, dG, dKV, dP = dO / n, the score tiles of the
+                                    * small-sequence path -- is kept as ONE bf16 value (what the reference's own matmuls store
+                                    * under bf16 autocast; half the summary traffic; 2-3e-3 of the gradients' maximum).
+                                    * Default: >= 16 significand bits there (fp32 summaries / bf16 hi + lo operands), i.e. the
+                                    * reference's fp32 arithmetic (mhla_dit/mhla/mhla.py:262-268 evaluated as
+                                    * mhla_dit/train.py:12-13 runs it) on the given tensors, one rounding at the store. */
 
 /* flags of the causal entry points (mhla_causal_*) */
 #define MHLA_CAUSAL_FORCE_GENERIC 1u   /* testing aid: the generic kernels (exact fp32 MFMA, fp32 summaries) for every shape */

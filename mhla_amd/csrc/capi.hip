@@ -13,12 +13,14 @@ using namespace mhla::capi;
 
 namespace mhla {
 namespace capi {
-extern template int bm_fwd_typed<float>(const BmCall&);
-extern template int bm_fwd_typed<bf16_t>(const BmCall&);
-extern template int bm_fwd_typed<f16_t>(const BmCall&);
-extern template int bm_bwd_typed<float>(const BmCall&);
-extern template int bm_bwd_typed<bf16_t>(const BmCall&);
-extern template int bm_bwd_typed<f16_t>(const BmCall&);
+extern template int bm_fwd_typed<float, false>(const BmCall&);
+extern template int bm_fwd_typed<bf16_t, true>(const BmCall&);
+extern template int bm_fwd_typed<bf16_t, false>(const BmCall&);
+extern template int bm_fwd_typed<f16_t, false>(const BmCall&);
+extern template int bm_bwd_typed<float, false>(const BmCall&);
+extern template int bm_bwd_typed<bf16_t, true>(const BmCall&);
+extern template int bm_bwd_typed<bf16_t, false>(const BmCall&);
+extern template int bm_bwd_typed<f16_t, false>(const BmCall&);
 }  // namespace capi
 }  // namespace mhla
 
@@ -34,6 +36,16 @@ static int launch_state1c(const fast::FsStateArgs& sa, int njg, int BH, hipStrea
     if (idx) return launch(fast::k_fs_state1c<MODE, true, false>, g, t, fast::FS_STATE1C_SMEM, st, name, sa);
     if (norm) return launch(fast::k_fs_state1c<MODE, false, true>, g, t, fast::FS_STATE1C_SMEM, st, name, sa);
     return launch(fast::k_fs_state1c<MODE, false, false>, g, t, fast::FS_STATE1C_SMEM, st, name, sa);
+}
+
+// small-sequence kernels (smalln.hpp): instantiated on (head-dim tiles, gather map, exactly 16 blocks, hi + lo score tiles)
+template <int DT, bool HL>
+static auto sn_fwd_kernel(bool gather, int M) {
+    return gather ? fast::k_sn_fwd<DT, true, false, HL> : (M == 16 ? fast::k_sn_fwd<DT, false, true, HL> : fast::k_sn_fwd<DT, false, false, HL>);
+}
+template <int DT, bool HL>
+static auto sn_bwd_kernel(bool gather, int M) {
+    return gather ? fast::k_sn_bwd<DT, true, false, HL> : (M == 16 ? fast::k_sn_bwd<DT, false, true, HL> : fast::k_sn_bwd<DT, false, false, HL>);
 }
 
 struct FastWs {
@@ -75,7 +87,7 @@ FastWs fast_carve(void* ws, int B, int H, int M, int S) {
 // (round-3 ADVICE: it used to infer the path from the shape alone).
 size_t bwd_ws_body_bytes(int B, int H, int M, int S, int D, int dtype, int split, unsigned flags) {
     const size_t gen = bm_carve(nullptr, B, H, M, S, D, bm_sum16(D, dtype, flags), sp_shape_ok(D, flags)).total_bwd;
-    const bool fast = fast_shape_ok(M, D, dtype, split != 0) && !(flags & MHLA_FLAG_FORCE_GENERIC);
+    const bool fast = fast_shape_ok(M, D, dtype, split != 0, flags) && !(flags & MHLA_FLAG_FORCE_GENERIC);
     return (std::max(gen, fast ? fast_carve(nullptr, B, H, M, S).total_bwd : (size_t)0) + 15) & ~(size_t)15;
 }
 int* bwd_err_word(void* ws, int B, int H, int M, int S, int D, int dtype, int split, unsigned flags) {
@@ -141,7 +153,7 @@ int mhla_blockmix_fwd_keeps_state(int B, int H, int M, int S, int D, int dtype, 
     (void)B; (void)H;
     if (flags & MHLA_FLAG_FORCE_GENERIC) return 0;
     if ((sn_shape_ok(M, S, D, dtype, split != 0) || snf_shape_ok(M, S, D, dtype, split != 0)) && !(flags & MHLA_FLAG_NO_SMALLN)) return 0;
-    if (fast_shape_ok(M, D, dtype, split != 0)) return 1;
+    if (fast_shape_ok(M, D, dtype, split != 0, flags)) return 1;
     return sp_shape_ok(D, flags) ? 1 : 0;   // split-operand path: KV, G, z, ksum, 1/n (fp32)
 }
 
@@ -150,7 +162,7 @@ int mhla_blockmix_fwd_keeps_state(int B, int H, int M, int S, int D, int dtype, 
 // these queries do not see: the bound covers both)
 size_t mhla_blockmix_fwd_ws_bytes(int B, int H, int M, int S, int D, int dtype, int split, unsigned flags) {
     const size_t gen = bm_carve(nullptr, B, H, M, S, D, bm_sum16(D, dtype, flags), sp_shape_ok(D, flags)).total_fwd;
-    if (fast_shape_ok(M, D, dtype, split != 0) && !(flags & MHLA_FLAG_FORCE_GENERIC)) return std::max(gen, fast_carve(nullptr, B, H, M, S).total_fwd);
+    if (fast_shape_ok(M, D, dtype, split != 0, flags) && !(flags & MHLA_FLAG_FORCE_GENERIC)) return std::max(gen, fast_carve(nullptr, B, H, M, S).total_fwd);
     return gen;
 }
 size_t mhla_blockmix_bwd_ws_bytes(int B, int H, int M, int S, int D, int dtype, int split, unsigned flags) {
@@ -181,8 +193,9 @@ static int bm_fwd_impl(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view 
         fast::SnArgs sa{};
         sa.q = cv(q_num); sa.k = cv(k_num); sa.v = cv(v); sa.out = cmv(out); sa.idx = block_index; sa.W = W; sa.ldw = ldw;
         sa.H = H; sa.M = M; sa.D = D; sa.eps = eps; sa.relu = relu; sa.normalize = normalize;
-        if (D <= 64) RC(launch(sa.idx ? fast::k_sn_fwd<4, true> : (M == 16 ? fast::k_sn_fwd<4, false, true> : fast::k_sn_fwd<4, false>), dim3(B * H), dim3(fast::SN_T), fast::sn_fwd_smem<4>(), st, "k_sn_fwd<4>", sa));
-        else         RC(launch(sa.idx ? fast::k_sn_fwd<5, true> : (M == 16 ? fast::k_sn_fwd<5, false, true> : fast::k_sn_fwd<5, false>), dim3(B * H), dim3(fast::SN_T), fast::sn_fwd_smem<5>(), st, "k_sn_fwd<5>", sa));
+        const bool hl = !(flags & MHLA_FLAG_BF16_SUMMARIES), g = sa.idx != nullptr;
+        if (D <= 64) RC(launch(hl ? sn_fwd_kernel<4, true>(g, M) : sn_fwd_kernel<4, false>(g, M), dim3(B * H), dim3(fast::SN_T), fast::sn_fwd_smem<4>(), st, hl ? "k_sn_fwd<4,hl>" : "k_sn_fwd<4>", sa));
+        else         RC(launch(hl ? sn_fwd_kernel<5, true>(g, M) : sn_fwd_kernel<5, false>(g, M), dim3(B * H), dim3(fast::SN_T), fast::sn_fwd_smem<5>(), st, hl ? "k_sn_fwd<5,hl>" : "k_sn_fwd<5>", sa));
         return MHLA_OK;
     }
     if (!rcos && !epi && snf_shape_ok(M, S, D, dtype, split) && !(flags & (MHLA_FLAG_FORCE_GENERIC | MHLA_FLAG_NO_SMALLN)) && view_ok16(q_num) &&
@@ -195,7 +208,7 @@ static int bm_fwd_impl(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view 
         else         RC(launch(sa.idx ? fast::k_snf_fwd<5, true> : (M == 16 ? fast::k_snf_fwd<5, false, true> : fast::k_snf_fwd<5, false>), dim3(B * H), dim3(fast::SNF_T), fast::snf_smem<5>(), st, "k_snf_fwd<5>", sa));
         return MHLA_OK;
     }
-    if (!rcos && !epi && fast_shape_ok(M, D, dtype, split) && !(flags & MHLA_FLAG_FORCE_GENERIC) && view_ok16(q_num) && view_ok16(k_num) &&
+    if (!rcos && !epi && fast_shape_ok(M, D, dtype, split, flags) && !(flags & MHLA_FLAG_FORCE_GENERIC) && view_ok16(q_num) && view_ok16(k_num) &&
         view_ok16(v) && view_ok16(outv)) {
         const FastWs f = fast_carve(ws, B, H, M, S);
         if (ws_bytes < f.total_fwd) return fail(MHLA_EINVAL, "workspace too small: %zu < %zu bytes", ws_bytes, f.total_fwd);
@@ -223,9 +236,9 @@ static int bm_fwd_impl(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view 
     c.normalize = normalize; c.split = split; c.epi = epi; c.st = st; c.rcos = rcos; c.rsin = rsin; c.ldr = ldr;
     c.nw = nw; c.neps = neps; c.out_dtype = out_dtype;
     switch (dtype) {
-        case MHLA_F32: return bm_fwd_typed<float>(c);
-        case MHLA_BF16: return bm_fwd_typed<bf16_t>(c);
-        case MHLA_F16: return bm_fwd_typed<f16_t>(c);
+        case MHLA_F32: return bm_fwd_typed<float, false>(c);
+        case MHLA_BF16: return bm_sum16(D, dtype, flags) ? bm_fwd_typed<bf16_t, true>(c) : bm_fwd_typed<bf16_t, false>(c);
+        case MHLA_F16: return bm_fwd_typed<f16_t, false>(c);
         default: return fail(MHLA_EINVAL, "unknown dtype %d", dtype);
     }
 }
@@ -314,12 +327,13 @@ static int bm_bwd_impl(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view 
             sa.dq = cmv(dq_num); sa.dk = cmv(dk_num); sa.dv = cmv(dv); sa.idx = block_index; sa.W = W; sa.ldw = ldw;
             sa.dwp = (float*)ws; sa.H = H; sa.M = M; sa.D = D; sa.eps = eps; sa.relu = relu; sa.normalize = normalize;
             sa.trace = g_trace.load();
-            if (D <= 64) RC(launch(sa.idx ? fast::k_sn_bwd<4, true> : (M == 16 ? fast::k_sn_bwd<4, false, true> : fast::k_sn_bwd<4, false>), dim3(B * H), dim3(fast::SN_TB), fast::sn_bwd_smem<4>(), st, "k_sn_bwd<4>", sa));
-            else         RC(launch(sa.idx ? fast::k_sn_bwd<5, true> : (M == 16 ? fast::k_sn_bwd<5, false, true> : fast::k_sn_bwd<5, false>), dim3(B * H), dim3(fast::SN_TB), fast::sn_bwd_smem<5>(), st, "k_sn_bwd<5>", sa));
+            const bool hl = !(flags & MHLA_FLAG_BF16_SUMMARIES), g = sa.idx != nullptr;
+            if (D <= 64) RC(launch(hl ? sn_bwd_kernel<4, true>(g, M) : sn_bwd_kernel<4, false>(g, M), dim3(B * H), dim3(fast::SN_TB), fast::sn_bwd_smem<4>(), st, hl ? "k_sn_bwd<4,hl>" : "k_sn_bwd<4>", sa));
+            else         RC(launch(hl ? sn_bwd_kernel<5, true>(g, M) : sn_bwd_kernel<5, false>(g, M), dim3(B * H), dim3(fast::SN_TB), fast::sn_bwd_smem<5>(), st, hl ? "k_sn_bwd<5,hl>" : "k_sn_bwd<5>", sa));
             RC(launch(fast::k_sn_dw_reduce, dim3(M * M), dim3(256), 0, st, "k_sn_dw_reduce", (const float*)ws, dW, M * M, B * H));
             return MHLA_OK;
         }
-        if (!rcos && fast_shape_ok(M, D, dtype, split) && !(flags & MHLA_FLAG_FORCE_GENERIC) && view_ok16(q_num) && view_ok16(k_num) &&
+        if (!rcos && fast_shape_ok(M, D, dtype, split, flags) && !(flags & MHLA_FLAG_FORCE_GENERIC) && view_ok16(q_num) && view_ok16(k_num) &&
             view_ok16(v) && view_ok16(dout) && (!normalize || view_ok16(out)) && view_ok16(dqv) && view_ok16(dkv_) && view_ok16(dvv)) {
             FastWs f = fast_carve(ws, B, H, M, S);
             const size_t need = mhla_blockmix_bwd_ws_bytes(B, H, M, S, D, dtype, split, flags);
@@ -377,7 +391,7 @@ static int bm_bwd_impl(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view 
     }
     BmWs w = bm_carve(ws, B, H, M, S, D, bm_sum16(D, dtype, flags), sp_shape_ok(D, flags));
     if (ws_bytes < w.total_bwd) return fail(MHLA_EINVAL, "workspace too small: %zu < %zu bytes", ws_bytes, w.total_bwd);
-    if (fast_shape_ok(M, D, dtype, split) && !(flags & MHLA_FLAG_FORCE_GENERIC)) {
+    if (fast_shape_ok(M, D, dtype, split, flags) && !(flags & MHLA_FLAG_FORCE_GENERIC)) {
         // a fast-path shape on another path (misaligned views, rotary prologue): leave a defined error word for the status call
         if (ws_bytes < mhla_blockmix_bwd_ws_bytes(B, H, M, S, D, dtype, split, flags))
             return fail(MHLA_EINVAL, "workspace too small: %zu < %zu bytes", ws_bytes, mhla_blockmix_bwd_ws_bytes(B, H, M, S, D, dtype, split, flags));
@@ -386,7 +400,7 @@ static int bm_bwd_impl(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view 
     }
     // the forward's KV, G, z, ksum, 1/n are still in its workspace (only when the shape cannot have taken the bf16 fast path,
     // whose workspace has another layout)
-    const bool reuse = fwd_ws && sp_shape_ok(D, flags) && (rcos || !fast_shape_ok(M, D, dtype, split));
+    const bool reuse = fwd_ws && sp_shape_ok(D, flags) && (rcos || !fast_shape_ok(M, D, dtype, split, flags));
     if (reuse) {
         const BmWs f = bm_carve(const_cast<void*>(fwd_ws), B, H, M, S, D, bm_sum16(D, dtype, flags), sp_shape_ok(D, flags));
         w.kv = f.kv; w.g = f.g; w.z = f.z; w.ksum = f.ksum; w.ninv = f.ninv;
@@ -397,9 +411,9 @@ static int bm_bwd_impl(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view 
     c.W = W; c.ldw = ldw; c.block_index = block_index; c.w = w; c.B = B; c.H = H; c.M = M; c.S = S; c.D = D; c.eps = eps; c.flags = flags;
     c.normalize = normalize; c.split = split; c.reuse = reuse; c.st = st; c.rcos = rcos; c.rsin = rsin; c.ldr = ldr;
     switch (dtype) {
-        case MHLA_F32: return bm_bwd_typed<float>(c);
-        case MHLA_BF16: return bm_bwd_typed<bf16_t>(c);
-        case MHLA_F16: return bm_bwd_typed<f16_t>(c);
+        case MHLA_F32: return bm_bwd_typed<float, false>(c);
+        case MHLA_BF16: return bm_sum16(D, dtype, flags) ? bm_bwd_typed<bf16_t, true>(c) : bm_bwd_typed<bf16_t, false>(c);
+        case MHLA_F16: return bm_bwd_typed<f16_t, false>(c);
         default: return fail(MHLA_EINVAL, "unknown dtype %d", dtype);
     }
 }
@@ -439,7 +453,7 @@ int mhla_blockmix_rope_bwd(mhla_view q, mhla_view k, mhla_view v, int normalize,
 int mhla_blockmix_bwd_status(const void* ws, size_t ws_bytes, int B, int H, int M, int S, int D, int dtype, int split, unsigned flags,
                              void* stream) {
     if (!ws) return fail(MHLA_EINVAL, "workspace null");
-    if (!fast_shape_ok(M, D, dtype, split != 0) || (flags & MHLA_FLAG_FORCE_GENERIC) ||
+    if (!fast_shape_ok(M, D, dtype, split != 0, flags) || (flags & MHLA_FLAG_FORCE_GENERIC) ||
         (sn_shape_ok(M, S, D, dtype, split != 0) && !(flags & MHLA_FLAG_NO_SMALLN)))
         return MHLA_OK;
     const size_t need = mhla_blockmix_bwd_ws_bytes(B, H, M, S, D, dtype, split, flags);

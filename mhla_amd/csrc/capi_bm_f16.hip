@@ -3,7 +3,7 @@
 
 namespace mhla {
 namespace capi {
-template int bm_fwd_typed<f16_t>(const BmCall&);
-template int bm_bwd_typed<f16_t>(const BmCall&);
+template int bm_fwd_typed<f16_t, false>(const BmCall&);
+template int bm_bwd_typed<f16_t, false>(const BmCall&);
 }  // namespace capi
 }  // namespace mhla

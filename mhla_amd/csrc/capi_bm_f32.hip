@@ -3,7 +3,7 @@
 
 namespace mhla {
 namespace capi {
-template int bm_fwd_typed<float>(const BmCall&);
-template int bm_bwd_typed<float>(const BmCall&);
+template int bm_fwd_typed<float, false>(const BmCall&);
+template int bm_bwd_typed<float, false>(const BmCall&);
 }  // namespace capi
 }  // namespace mhla

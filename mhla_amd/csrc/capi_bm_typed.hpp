@@ -84,7 +84,7 @@ inline int sp_dwr(const void* x, const void* y, long E, long es, const float* x2
 }
 
 // KV/ksum/z, G for the forward and the recompute leg of the backward.
-template <typename T, int DT>
+template <typename T, int DT, bool S16>
 int bm_state_and_mix(const mhla_view& q_num, const mhla_view& k_num, const mhla_view& v, const mhla_view& q_den,
                      const mhla_view& k_den, const float* W, int ldw, const int32_t* idx, const BmWs& w, int B, int H,
                      int M, int S, int D, float eps, unsigned flags, bool normalize, bool split, hipStream_t st,
@@ -100,11 +100,11 @@ int bm_state_and_mix(const mhla_view& q_num, const mhla_view& k_num, const mhla_
     if (sp_shape_ok(D, flags)) {   // split-bf16 MFMA kernels (split.hpp)
         constexpr int SNT = sp_state_threads<DT>();   // eight waves at D = 128 (split.hpp)
         if (s16)    RC(launch(s16::k_s16_state<0>, dim3((M + s16::WPB - 1) / s16::WPB, B * H), dim3(64 * s16::WPB), s16::state_smem(), st, "k_s16_state<0>", a));
-        else if (a.rcos) RC(launch(sp::k_sp_state<T, DT, 0, true, SNT>, dim3(M, B * H), dim3(SNT), sp::sp_state_smem<DT>(), st, "k_sp_state<rope>", a));
-        else        RC(launch(sp::k_sp_state<T, DT, 0, false, SNT>, dim3(M, B * H), dim3(SNT), sp::sp_state_smem<DT>(), st, "k_sp_state", a));
-        const bool mixr = sp_mixr_ok<sp::Sum16<T>::value>(M, m.E), wz_fused = mixr && normalize && sp_mixr_takes_wz<sp::Sum16<T>::value>(M, S);
-        if (mixr) RC((sp_mixr<0, sp::Sum16<T>::value>(W, ldw, w.kv, w.g, M, m.E, w.es, B * H, st, normalize ? (const float*)w.z : nullptr, w.ninv, S, eps)));
-        else RC(launch(sp::k_sp_mix<0, sp::Sum16<T>::value>, dim3((unsigned)((m.E + sp::SPM_TE - 1) / sp::SPM_TE), (M + 63) / 64, B * H), dim3(NTHREADS), sp::sp_mix_smem<sp::Sum16<T>::value>(), st, "k_sp_mix<0>", m));
+        else if (a.rcos) RC(launch(sp::k_sp_state<T, DT, 0, true, SNT, S16>, dim3(M, B * H), dim3(SNT), sp::sp_state_smem<DT>(), st, "k_sp_state<rope>", a));
+        else        RC(launch(sp::k_sp_state<T, DT, 0, false, SNT, S16>, dim3(M, B * H), dim3(SNT), sp::sp_state_smem<DT>(), st, "k_sp_state", a));
+        const bool mixr = sp_mixr_ok<S16>(M, m.E), wz_fused = mixr && normalize && sp_mixr_takes_wz<S16>(M, S);
+        if (mixr) RC((sp_mixr<0, S16>(W, ldw, w.kv, w.g, M, m.E, w.es, B * H, st, normalize ? (const float*)w.z : nullptr, w.ninv, S, eps)));
+        else RC(launch(sp::k_sp_mix<0, S16>, dim3((unsigned)((m.E + sp::SPM_TE - 1) / sp::SPM_TE), (M + 63) / 64, B * H), dim3(NTHREADS), sp::sp_mix_smem<S16>(), st, "k_sp_mix<0>", m));
         if (normalize && !wz_fused)
             RC(launch(k_wz<0>, dim3((S + 63) / 64, (M + 63) / 64, B * H), dim3(NTHREADS), 0, st, "k_wz<0>", W, ldw, (const float*)w.z, w.ninv, M, S, eps));
         return MHLA_OK;
@@ -117,7 +117,8 @@ int bm_state_and_mix(const mhla_view& q_num, const mhla_view& k_num, const mhla_
     return MHLA_OK;
 }
 
-template <typename ET>
+// S16: the block summaries are stored as bf16 (bf16 tensors with MHLA_FLAG_BF16_SUMMARIES); false: fp32 summaries, hi + lo operands
+template <typename ET, bool S16>
 int bm_fwd_typed(const BmCall& c) {
     const mhla_view &q_num = c.q_num, &k_num = c.k_num, &v = c.v, &q_den = c.q_den, &k_den = c.k_den, &dout = c.dout, &gate = c.gate;
     const mhla_view& out_view = c.outv;
@@ -133,8 +134,8 @@ int bm_fwd_typed(const BmCall& c) {
     (void)dout; (void)gate; (void)out_view; (void)dq_num; (void)dk_num; (void)dv; (void)dq_den; (void)dk_den; (void)dW; (void)reuse; (void)epi;
     (void)rcos; (void)rsin; (void)ldr; (void)nw; (void)neps; (void)out_dtype; (void)relu;
     DISPATCH_DT(dt, {
-        const bool s16 = s16_ok<ET, DT>(c, false);
-        RC((bm_state_and_mix<ET, DT>(q_num, k_num, v, q_den, k_den, W, ldw, block_index, w, B, H, M, S, D, eps, flags, normalize, split, st, rcos, rsin, ldr, s16)));
+        const bool s16 = S16 && s16_ok<ET, DT>(c, false);
+        RC((bm_state_and_mix<ET, DT, S16>(q_num, k_num, v, q_den, k_den, W, ldw, block_index, w, B, H, M, S, D, eps, flags, normalize, split, st, rcos, rsin, ldr, s16)));
         OutArgs o{};
         o.rcos = rcos; o.rsin = rsin; o.ldr = ldr;
         o.q = cv(q_num); o.o = cmv(c.out); o.idx = block_index; o.W = W; o.ldw = ldw; o.g = w.g; o.ninv = w.ninv;
@@ -151,14 +152,14 @@ int bm_fwd_typed(const BmCall& c) {
         } else if (s16)
             RC(launch(s16::k_s16_out<0>, dim3((M + s16::WPB - 1) / s16::WPB, B * H), dim3(64 * s16::WPB), s16::out_smem(), st, "k_s16_out", o));
         else if (sp_shape_ok(D, flags))
-            RC(launch(sp::k_sp_out<ET, DT>, dim3(M, B * H), dim3(sp::SP_OUT_T), sp::sp_out_smem<DT, sp::Sum16<ET>::value>(), st, "k_sp_out", o));
+            RC(launch(sp::k_sp_out<ET, DT, ET, false, S16>, dim3(M, B * H), dim3(sp::SP_OUT_T), sp::sp_out_smem<DT, S16>(), st, "k_sp_out", o));
         else
             RC(launch(k_bm_out<ET, DT>, dim3(M, B * H), dim3(NTHREADS), out_smem_floats<DT>() * 4, st, "k_bm_out", o));
     });
     return MHLA_OK;
 }
 
-template <typename ET>
+template <typename ET, bool S16>
 int bm_bwd_typed(const BmCall& c) {
     const mhla_view &q_num = c.q_num, &k_num = c.k_num, &v = c.v, &q_den = c.q_den, &k_den = c.k_den, &dout = c.dout, &gate = c.gate;
     const mhla_view& out_view = c.outv;
@@ -174,9 +175,9 @@ int bm_bwd_typed(const BmCall& c) {
     (void)dout; (void)gate; (void)out_view; (void)dq_num; (void)dk_num; (void)dv; (void)dq_den; (void)dk_den; (void)dW; (void)reuse; (void)epi;
     (void)rcos; (void)rsin; (void)ldr; (void)nw; (void)neps; (void)out_dtype; (void)relu;
     DISPATCH_DT(dt, {
-        const bool s16 = s16_ok<ET, DT>(c, true);
+        const bool s16 = S16 && s16_ok<ET, DT>(c, true);
         if (!reuse)
-            RC((bm_state_and_mix<ET, DT>(q_num, k_num, v, q_den, k_den, W, ldw, block_index, w, B, H, M, S, D, eps, flags, normalize, split, st, rcos, rsin, ldr, s16)));
+            RC((bm_state_and_mix<ET, DT, S16>(q_num, k_num, v, q_den, k_den, W, ldw, block_index, w, B, H, M, S, D, eps, flags, normalize, split, st, rcos, rsin, ldr, s16)));
         // dG_i = Q_i^T (dO_i / n_i), dn_i
         StateArgs a{};
         a.x = cv(q_num); a.y = cv(dout); a.o = cv(out_view); a.idx = block_index; a.W = W; a.ldw = ldw; a.ninv = w.ninv;
@@ -195,26 +196,26 @@ int bm_bwd_typed(const BmCall& c) {
             t.rcos = rcos; t.rsin = rsin; t.ldr = ldr;
             constexpr int SNT = sp_state_threads<DT>();
             if constexpr (std::is_same<ET, float>::value) {
-                if (rcos) RC(launch(sp::k_sp_state<ET, DT, 1, true, SNT>, dim3(M, B * H), dim3(SNT), sp::sp_state_smem<DT>(), st, "k_sp_state<1,rope>", a));
+                if (rcos) RC(launch(sp::k_sp_state<ET, DT, 1, true, SNT, S16>, dim3(M, B * H), dim3(SNT), sp::sp_state_smem<DT>(), st, "k_sp_state<1,rope>", a));
             }
             if (s16) RC(launch(s16::k_s16_state<1>, dim3((M + s16::WPB - 1) / s16::WPB, B * H), dim3(64 * s16::WPB), s16::state_smem(), st, "k_s16_state<1>", a));
-            else if (!rcos) RC(launch(sp::k_sp_state<ET, DT, 1, false, SNT>, dim3(M, B * H), dim3(SNT), sp::sp_state_smem<DT>(), st, "k_sp_state<1>", a));
-            const bool mixr = sp_mixr_ok<sp::Sum16<ET>::value>(M, E), wz_fused = mixr && normalize && sp_mixr_takes_wz<sp::Sum16<ET>::value>(M, S);
+            else if (!rcos) RC(launch(sp::k_sp_state<ET, DT, 1, false, SNT, S16>, dim3(M, B * H), dim3(SNT), sp::sp_state_smem<DT>(), st, "k_sp_state<1>", a));
+            const bool mixr = sp_mixr_ok<S16>(M, E), wz_fused = mixr && normalize && sp_mixr_takes_wz<S16>(M, S);
             if (normalize && !wz_fused)
                 RC(launch(k_wz<1>, dim3((S + 63) / 64, (M + 63) / 64, B * H), dim3(NTHREADS), 0, st, "k_wz<1>", W, ldw, (const float*)w.dn, w.dz, M, S, 0.f));
             MixArgs m{W, ldw, w.dg, w.dkv, M, E, w.es};
-            if (mixr) RC((sp_mixr<1, sp::Sum16<ET>::value>(W, ldw, w.dg, w.dkv, M, E, w.es, B * H, st, normalize ? (const float*)w.dn : nullptr, w.dz, S, 0.f)));
-            else RC(launch(sp::k_sp_mix<1, sp::Sum16<ET>::value>, dim3((unsigned)((E + sp::SPM_TE - 1) / sp::SPM_TE), tiles, B * H), dim3(NTHREADS), sp::sp_mix_smem<sp::Sum16<ET>::value>(), st, "k_sp_mix<1>", m));
+            if (mixr) RC((sp_mixr<1, S16>(W, ldw, w.dg, w.dkv, M, E, w.es, B * H, st, normalize ? (const float*)w.dn : nullptr, w.dz, S, 0.f)));
+            else RC(launch(sp::k_sp_mix<1, S16>, dim3((unsigned)((E + sp::SPM_TE - 1) / sp::SPM_TE), tiles, B * H), dim3(NTHREADS), sp::sp_mix_smem<S16>(), st, "k_sp_mix<1>", m));
             int nsplit = dw_splits(tiles * tiles * B * H, E);
             if (nsplit > DW_MAX_SPLIT - 1) nsplit = DW_MAX_SPLIT - 1;   // one more part per (b, h) holds the <dn_i, z_j> term
             DwArgs d{w.dg, w.kv, E, nullptr, nullptr, 0, w.dwp, M, tiles, nsplit, w.es};
-            const bool dwr = sp::Sum16<ET>::value && sp_dwr_ok(M, E);   // whole-matrix workgroups: the <dn_i, z_j> term is one of their stages
+            const bool dwr = S16 && sp_dwr_ok(M, E);   // whole-matrix workgroups: the <dn_i, z_j> term is one of their stages
             if (dwr) {
                 nsplit = sp_dwr_splits(B * H, E);
                 RC(sp_dwr(w.dg, w.kv, E, w.es, normalize ? w.dn : nullptr, normalize ? w.z : nullptr, S, w.dwp, M, B * H, nsplit, st));
-            } else if (M <= 16)      RC(launch(sp::k_sp_dw<sp::Sum16<ET>::value, 1>, dim3(1, B * H, nsplit), dim3(NTHREADS), sp::SP_DW_SMEM, st, "k_sp_dw<16>", d));
-            else if (M <= 32) RC(launch(sp::k_sp_dw<sp::Sum16<ET>::value, 2>, dim3(1, B * H, nsplit), dim3(NTHREADS), sp::SP_DW_SMEM, st, "k_sp_dw<32>", d));
-            else              RC(launch(sp::k_sp_dw<sp::Sum16<ET>::value>, dim3(tiles * tiles, B * H, nsplit), dim3(NTHREADS), sp::SP_DW_SMEM, st, "k_sp_dw", d));
+            } else if (M <= 16)      RC(launch(sp::k_sp_dw<S16, 1>, dim3(1, B * H, nsplit), dim3(NTHREADS), sp::SP_DW_SMEM, st, "k_sp_dw<16>", d));
+            else if (M <= 32) RC(launch(sp::k_sp_dw<S16, 2>, dim3(1, B * H, nsplit), dim3(NTHREADS), sp::SP_DW_SMEM, st, "k_sp_dw<32>", d));
+            else              RC(launch(sp::k_sp_dw<S16>, dim3(tiles * tiles, B * H, nsplit), dim3(NTHREADS), sp::SP_DW_SMEM, st, "k_sp_dw", d));
             int nparts = B * H * nsplit;
             if (normalize && !dwr) {
                 DwArgs dzz{w.dn, w.z, (long)S, nullptr, nullptr, 0, w.dwp + (size_t)nparts * M * M, M, tiles, 1};
@@ -238,8 +239,8 @@ int bm_bwd_typed(const BmCall& c) {
                 RC(launch(s16::k_s16_bwd_dkv<0>, g16, b16, s16::dkv_smem(), st, "k_s16_bwd_dkv", t));
                 break;
             }
-            RC(launch(sp::k_sp_bwd_dq<ET, DT>, dim3(M, B * H), dim3(NTHREADS), sp::sp_tok_smem<DT, sp::Sum16<ET>::value>(), st, "k_sp_bwd_dq", t));
-            RC(launch(sp::k_sp_bwd_dkv<ET, DT>, dim3(M, B * H), dim3(NTHREADS), sp::sp_tok_smem<DT, sp::Sum16<ET>::value>(), st, "k_sp_bwd_dkv", t));
+            RC(launch(sp::k_sp_bwd_dq<ET, DT, false, S16>, dim3(M, B * H), dim3(NTHREADS), sp::sp_tok_smem<DT, S16>(), st, "k_sp_bwd_dq", t));
+            RC(launch(sp::k_sp_bwd_dkv<ET, DT, false, S16>, dim3(M, B * H), dim3(NTHREADS), sp::sp_tok_smem<DT, S16>(), st, "k_sp_bwd_dkv", t));
             break;
         }
         RC(launch(k_bm_state<ET, DT, 1>, dim3(M, B * H), dim3(NTHREADS), state_smem_floats<DT>() * 4, st, "k_bm_state<1>", a));

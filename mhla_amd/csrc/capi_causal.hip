@@ -23,8 +23,10 @@ struct CsWs {
 //   everything else: the generic kernels (causal.hpp: exact fp32 MFMA, fp32 summaries).
 struct CsPath { bool pipe16, hl; int esz; };   // esz: bytes per logical summary element
 CsPath cs_path(int T, int K, int V, int chunk, int dtype, unsigned flags) {
-    const int n = (T + chunk - 1) / chunk;
     CsPath p{};
+    p.esz = 4;
+    if (chunk <= 0) return p;   // (the size / capability queries reach this before cs_check: the generic path, no division by zero)
+    const int n = (T + chunk - 1) / chunk;
     p.pipe16 = dtype == MHLA_BF16 && (K & 63) == 0 && (V & 63) == 0 && K <= 256 && n <= 256 && !(flags & MHLA_CAUSAL_FORCE_GENERIC);
     p.hl = p.pipe16 && !(flags & MHLA_CAUSAL_BF16_SUMMARIES);
     p.esz = p.pipe16 && !p.hl ? 2 : 4;
@@ -50,7 +52,8 @@ Mix2Plan mix2_plan(size_t bh, int n, long E, bool bwd, bool hl) {
 // or two halves of three / four slices (V = 384, 512) with the first half's outputs parked in LDS
 bool cs_epi_ok(const CsPath& path, int V) { return path.pipe16 && (V <= 256 || V == 384 || V == 512); }
 CsWs cs_carve(void* ws, int B, int T, int H, int K, int V, int chunk, const CsPath& path) {
-    // (16-bit pipeline: bf16 planes in the tile-major layout of fast::cs_layout, one 128-byte line of padding per chunk tile)
+    // (16-bit pipeline: bf16 planes in the tile-major layout of fast::cs_layout, CS_CHUNK_PAD = 2 176 bytes of padding per chunk tile)
+    if (chunk <= 0) { CsWs z{}; return z; }
     const size_t bh = (size_t)B * H, n = (size_t)(T + chunk - 1) / chunk;
     const size_t st = path.pipe16 ? al4((bh * (size_t)fast::cs_layout((int)n, (long)K * V, path.esz / 2).bhs + 1) / 2) : al4(bh * n * K * V);
     const size_t parts = std::max(bh * DW_MAX_SPLIT, path.pipe16 ? (size_t)mix2_plan(bh, (int)n, (long)K * V, true, path.hl).wgs : (size_t)0);

@@ -158,8 +158,12 @@ inline bool view_ok16(const mhla_view& v) { return v.ptr && ((uintptr_t)v.ptr % 
 // split-bf16 MFMA kernels (split.hpp): head dims that are multiples of 8, any dtype
 inline bool sp_shape_ok(int D, unsigned flags) { return (D & 7) == 0 && !(flags & MHLA_FLAG_FORCE_GENERIC); }
 inline bool view_ok16m(const mhla_mview& v) { return v.ptr && ((uintptr_t)v.ptr % 16) == 0 && ((v.sb | v.sn | v.sh) & 7) == 0; }
-inline bool bm_sum16(int D, int dtype, unsigned flags) { return dtype == MHLA_BF16 && sp_shape_ok(D, flags); }
-inline bool fast_shape_ok(int M, int D, int dtype, bool split) { return dtype == MHLA_BF16 && D == 64 && M <= 64 && !split; }
+// bf16 block summaries (and single-bf16 intermediate operands): only when the caller asked for them (MHLA_FLAG_BF16_SUMMARIES)
+inline bool bm_sum16(int D, int dtype, unsigned flags) { return dtype == MHLA_BF16 && sp_shape_ok(D, flags) && (flags & MHLA_FLAG_BF16_SUMMARIES); }
+// the bf16-summary fast path (fused.hpp): its summaries are single bf16 values, so it serves the opt-in arithmetic only
+inline bool fast_shape_ok(int M, int D, int dtype, bool split, unsigned flags) {
+    return dtype == MHLA_BF16 && D == 64 && M <= 64 && !split && (flags & MHLA_FLAG_BF16_SUMMARIES);
+}
 // small-sequence single-launch path (smalln.hpp): S = 16 tokens per block, at most 16 blocks, D <= 80
 inline bool sn_shape_ok(int M, int S, int D, int dtype, bool split) {
     return dtype == MHLA_BF16 && S == 16 && M <= 16 && D <= 80 && (D & 7) == 0 && !split;
@@ -175,7 +179,7 @@ inline int bm_check(int B, int H, int M, int S, int D, int dtype, unsigned flags
     if (D % 4) return fail(MHLA_EINVAL, "D=%d must be a multiple of 4", D);
     if (!dt_for(D)) return fail(MHLA_ENOTSUP, "block-mix head dim D=%d > 128 not supported", D);
     if (dtype < 0 || dtype > 2) return fail(MHLA_EINVAL, "unknown dtype %d", dtype);
-    if (flags & ~(MHLA_FLAG_RELU_EPS | MHLA_FLAG_FORCE_GENERIC | MHLA_FLAG_NO_SMALLN)) return fail(MHLA_EINVAL, "unknown flags 0x%x", flags);
+    if (flags & ~(MHLA_FLAG_RELU_EPS | MHLA_FLAG_FORCE_GENERIC | MHLA_FLAG_NO_SMALLN | MHLA_FLAG_BF16_SUMMARIES)) return fail(MHLA_EINVAL, "unknown flags 0x%x", flags);
     if ((flags & MHLA_FLAG_RELU_EPS) && split) return fail(MHLA_EINVAL, "MHLA_FLAG_RELU_EPS needs q_den/k_den to alias q_num/k_num");
     if ((size_t)B * H > 65535) return fail(MHLA_ENOTSUP, "B*H=%zu exceeds grid limit 65535", (size_t)B * H);
     (void)normalize;
@@ -196,8 +200,8 @@ struct BmCall {
     const float *rcos, *rsin; long ldr;
     const float* nw; float neps; int out_dtype;
 };
-template <typename ET> int bm_fwd_typed(const BmCall& c);
-template <typename ET> int bm_bwd_typed(const BmCall& c);
+template <typename ET, bool S16> int bm_fwd_typed(const BmCall& c);   // S16: bf16 block summaries (bf16 tensors + MHLA_FLAG_BF16_SUMMARIES)
+template <typename ET, bool S16> int bm_bwd_typed(const BmCall& c);
 
 }  // namespace capi
 }  // namespace mhla

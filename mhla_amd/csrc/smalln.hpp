@@ -178,6 +178,20 @@ __device__ __forceinline__ bf16x8 sn_pack_pair(f32x4 c0, f32x4 c1) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
+// the same pair as bf16 hi + lo parts (x = hi + lo, 16 significand bits): the score tile keeps the reference's fp32 accuracy on
+// its way into the second contraction, which then runs on both parts (HL kernels)
+__device__ __forceinline__ void sn_pack_pair_hl(const f32x4& c0, const f32x4& c1, bf16x8& hi, bf16x8& lo) {
+    const float x[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        h[i] = pack_bf16x2(x[2 * i], x[2 * i + 1]);
+        l[i] = pack_bf16x2(x[2 * i] - __uint_as_float(h[i] << 16), x[2 * i + 1] - __uint_as_float(h[i] & 0xffff0000u));
+    }
+    hi = __builtin_bit_cast(bf16x8, make_uint4(h[0], h[1], h[2], h[3]));
+    lo = __builtin_bit_cast(bf16x8, make_uint4(l[0], l[1], l[2], l[3]));
+}
+
 // Sums 16 per-lane values over the 64 lanes with 17 shuffles (instead of 16 x 6): at each of the first four butterfly steps a
 // lane keeps the half of the values selected by its own lane bit and sends the other half.  Returns the total of value
 // j = 8 b5 + 4 b4 + 2 b3 + b2 (b_k = bit k of the lane); the four lanes of a quad hold the same total.
@@ -221,7 +235,10 @@ __host__ __device__ constexpr int sn_fwd_smem() {
 // ------------------------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------------------------
-template <int DT, bool GATHER, bool M16 = false>
+// HL (the default arithmetic): the weighted score tile enters the second contraction as bf16 hi + lo parts (two MFMAs per feature
+// tile) -- the reference keeps it in fp32 (mhla_dit/mhla/mhla.py:262-268 under mhla_dit/train.py:12-13); false: one bf16 value
+// (MHLA_FLAG_BF16_SUMMARIES)
+template <int DT, bool GATHER, bool M16 = false, bool HL = true>
 __global__ __launch_bounds__(SN_T, SN_T / 256) void k_sn_fwd(const SnArgs a) {
     // GATHER: the launch has a block_index map.  As a template parameter the row lookups carry no branch: with `idx ? idx[p] : p`
     // decided at run time hipcc branched around every map load and waited for ALL loads in flight at each join (s_waitcnt
@@ -317,9 +334,20 @@ __global__ __launch_bounds__(SN_T, SN_T / 256) void k_sn_fwd(const SnArgs a) {
                 c0 = mfma_bf16(ka[ks], qa[x][ks], c0);     // S^T tile (j0, i): rows t, cols s
                 c1 = mfma_bf16(kb2[ks], qa[x][ks], c1);
             }
-            const bf16x8 pa = sn_pack_pair(c0 * w0, c1 * w1);
+            if constexpr (HL) {
+                bf16x8 ph, pl;
+                sn_pack_pair_hl(c0 * w0, c1 * w1, ph, pl);
 #pragma unroll
-            for (int tn = 0; tn < DT; ++tn) acc[tn] = mfma_bf16(pa, sn_tr_pair(Vs, LDR, j0 * 16, j1 * 16, tn * 16, lane), acc[tn]);
+                for (int tn = 0; tn < DT; ++tn) {
+                    const bf16x8 bv = sn_tr_pair(Vs, LDR, j0 * 16, j1 * 16, tn * 16, lane);
+                    acc[tn] = mfma_bf16(ph, bv, acc[tn]);
+                    acc[tn] = mfma_bf16(pl, bv, acc[tn]);
+                }
+            } else {
+                const bf16x8 pa = sn_pack_pair(c0 * w0, c1 * w1);
+#pragma unroll
+                for (int tn = 0; tn < DT; ++tn) acc[tn] = mfma_bf16(pa, sn_tr_pair(Vs, LDR, j0 * 16, j1 * 16, tn * 16, lane), acc[tn]);
+            }
         }
         // O rows: C layout lane (col d2 = 16 tn + n, rows s = 4 kg + r); scale by 1/n[s]; stage; coalesced store
         u16* Os = Ost + wave * 16 * LDR;
@@ -364,7 +392,10 @@ __device__ __forceinline__ void sn_store16(u16* __restrict__ base, long sn, cons
 }
 
 // M16: the launch has exactly 16 blocks (the DiT 256^2 grid): the block loops carry no run-time guard, straight-line code
-template <int DT, bool GATHER, bool M16 = false>
+// HL (the default arithmetic): no intermediate is rounded to bf16 on its way into a second contraction -- dO stays the exact tensor
+// (its 1 / n factor is applied to the fp32 tiles it produces: per column in pass A, per row in pass B) and the weighted score tiles
+// P, dS enter the second contractions as bf16 hi + lo parts; false: dO' = dO / n and the tiles as single bf16 values
+template <int DT, bool GATHER, bool M16 = false, bool HL = true>
 __global__ __launch_bounds__(SN_TB, 2) void k_sn_bwd(const SnArgs a) {
     // GATHER: the launch has a block_index map.  As a template parameter the row lookups carry no branch: with `idx ? idx[p] : p`
     // decided at run time hipcc branched around every map load and waited for ALL loads in flight at each join (s_waitcnt
@@ -501,8 +532,12 @@ __global__ __launch_bounds__(SN_TB, 2) void k_sn_bwd(const SnArgs a) {
 
     // ---- pass A: dQ_i, dW[i][:] for the wave's two query blocks at once (K, V rows and K^T operands fetched once for both) ----
     {
-        scale_dop(ga[0], blk[0]);
-        scale_dop(ga[1], blk[1]);
+        if constexpr (!HL) {
+            scale_dop(ga[0], blk[0]);
+            scale_dop(ga[1], blk[1]);
+        }
+        // HL: the factor 1 / n_i[s] of dP^T = V_j (dO_i / n_i)^T is a per-column (= per-lane) scale of the fp32 tile
+        const float niA[2] = {(HL && a.normalize) ? nis[blk[0] * 16 + n] : 1.f, (HL && a.normalize) ? nis[blk[1] * 16 + n] : 1.f};
         f32x4 acc[2][DT];
 #pragma unroll
         for (int x = 0; x < 2; ++x)
@@ -532,10 +567,11 @@ __global__ __launch_bounds__(SN_TB, 2) void k_sn_bwd(const SnArgs a) {
                 for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
                     for (int x = 0; x < 2; ++x) { p0[x] = mfma_bf16(t0[ks], ga[x][ks], p0[x]); p1[x] = mfma_bf16(t1[ks], ga[x][ks], p1[x]); }   // dP^T
-                bf16x8 da[2];
+                bf16x8 da[2], dl[HL ? 2 : 1];
 #pragma unroll
                 for (int x = 0; x < 2; ++x) {
                     const int i = blk[x];
+                    if constexpr (HL) { p0[x] *= niA[x]; p1[x] *= niA[x]; }
                     // dW[i][j] = sum(dP . S) + sum_s dn_i[s] z_j[s]: lane partials, reduced once per query block below
                     float e0 = s0[x][0] * p0[x][0] + s0[x][1] * p0[x][1] + s0[x][2] * p0[x][2] + s0[x][3] * p0[x][3];
                     float e1 = s1[x][0] * p1[x][0] + s1[x][1] * p1[x][1] + s1[x][2] * p1[x][2] + s1[x][3] * p1[x][3];
@@ -546,13 +582,18 @@ __global__ __launch_bounds__(SN_TB, 2) void k_sn_bwd(const SnArgs a) {
                     ew[x][j0] = e0;
                     ew[x][j0 + 1] = has1 ? e1 : 0.f;
                     const float w0 = Wsh[i * 17 + j0], w1 = has1 ? Wsh[i * 17 + j1] : 0.f;
-                    da[x] = sn_pack_pair(p0[x] * w0, p1[x] * w1);      // dS^T pair -> A operand (m = s, k-slots = t)
+                    if constexpr (HL) sn_pack_pair_hl(p0[x] * w0, p1[x] * w1, da[x], dl[x]);
+                    else da[x] = sn_pack_pair(p0[x] * w0, p1[x] * w1);      // dS^T pair -> A operand (m = s, k-slots = t)
                 }
 #pragma unroll
                 for (int tn = 0; tn < DT; ++tn) {
                     const bf16x8 bk = sn_tr_pair(T0, LDR, j0 * 16, j1 * 16, tn * 16, lane);
                     acc[0][tn] = mfma_bf16(da[0], bk, acc[0][tn]);
                     acc[1][tn] = mfma_bf16(da[1], bk, acc[1][tn]);
+                    if constexpr (HL) {
+                        acc[0][tn] = mfma_bf16(dl[0], bk, acc[0][tn]);
+                        acc[1][tn] = mfma_bf16(dl[1], bk, acc[1][tn]);
+                    }
                 }
             }
         }
@@ -593,8 +634,9 @@ __global__ __launch_bounds__(SN_TB, 2) void k_sn_bwd(const SnArgs a) {
     trace_mark(a.trace, 6);
 
     // ---- P5: Q and dO' tiles replace K and V ----
-    if (a.normalize) sn_stage2<DT, SN_TB, true>(T0, qb, a.q.sn, a.eps, a.relu != 0, T1, gb, a.dout.sn, idx, N, D, tid, nis);
-    else             sn_stage2<DT, SN_TB, false>(T0, qb, a.q.sn, a.eps, a.relu != 0, T1, gb, a.dout.sn, idx, N, D, tid);
+    // (HL: dO itself is staged; 1 / n scales the rows of the fp32 tiles below)
+    if (a.normalize && !HL) sn_stage2<DT, SN_TB, true>(T0, qb, a.q.sn, a.eps, a.relu != 0, T1, gb, a.dout.sn, idx, N, D, tid, nis);
+    else                    sn_stage2<DT, SN_TB, false>(T0, qb, a.q.sn, a.eps, a.relu != 0, T1, gb, a.dout.sn, idx, N, D, tid);
     __syncthreads();
     trace_mark(a.trace, 7);
 
@@ -625,12 +667,26 @@ __global__ __launch_bounds__(SN_TB, 2) void k_sn_bwd(const SnArgs a) {
             for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
                 for (int x = 0; x < 2; ++x) { p0[x] = mfma_bf16(t0[ks], va[x][ks], p0[x]); p1[x] = mfma_bf16(t1[ks], va[x][ks], p1[x]); }   // dP
-            bf16x8 pa[2], da[2];
+            bf16x8 pa[2], da[2], pl[HL ? 2 : 1], dl[HL ? 2 : 1];
+            // HL: 1 / n_i[s] of the tiles' rows s = 4 kg + r (dP = diag(1/n) dO V^T; dV = (P diag-scaled)^T dO)
+            f32x4 ni0 = {1.f, 1.f, 1.f, 1.f}, ni1 = ni0;
+            if constexpr (HL) {
+                if (a.normalize) {
+                    ni0 = *reinterpret_cast<const f32x4*>(nis + i0 * 16 + kg * 4);
+                    ni1 = *reinterpret_cast<const f32x4*>(nis + i1 * 16 + kg * 4);
+                }
+            }
 #pragma unroll
             for (int x = 0; x < 2; ++x) {
                 const float w0 = Wsh[i0 * 17 + blk[x]], w1 = has1 ? Wsh[i1 * 17 + blk[x]] : 0.f;
-                pa[x] = sn_pack_pair(s0[x] * w0, s1[x] * w1);      // P pair  -> A operand (m = t, k-slots = s)
-                da[x] = sn_pack_pair(p0[x] * w0, p1[x] * w1);      // dS pair
+                if constexpr (HL) {
+                    const f32x4 f0 = ni0 * w0, f1 = ni1 * w1;
+                    sn_pack_pair_hl(s0[x] * f0, s1[x] * f1, pa[x], pl[x]);   // P diag(1/n) pair -> A operand (m = t, k-slots = s)
+                    sn_pack_pair_hl(p0[x] * f0, p1[x] * f1, da[x], dl[x]);   // dS pair
+                } else {
+                    pa[x] = sn_pack_pair(s0[x] * w0, s1[x] * w1);      // P pair  -> A operand (m = t, k-slots = s)
+                    da[x] = sn_pack_pair(p0[x] * w0, p1[x] * w1);      // dS pair
+                }
             }
 #pragma unroll
             for (int tn = 0; tn < DT; ++tn) {
@@ -640,6 +696,10 @@ __global__ __launch_bounds__(SN_TB, 2) void k_sn_bwd(const SnArgs a) {
                 for (int x = 0; x < 2; ++x) {
                     accV[x][tn] = mfma_bf16(pa[x], bv, accV[x][tn]);   // dV += P^T dO'
                     accK[x][tn] = mfma_bf16(da[x], bq, accK[x][tn]);   // dK += dS^T Q
+                    if constexpr (HL) {
+                        accV[x][tn] = mfma_bf16(pl[x], bv, accV[x][tn]);
+                        accK[x][tn] = mfma_bf16(dl[x], bq, accK[x][tn]);
+                    }
                 }
             }
         }

@@ -96,13 +96,16 @@ __host__ __device__ constexpr int sp_state_smem() {
 // the staging and accumulator registers per thread (<= 128 VGPRs: two workgroups = 16 waves per CU) and half the time per block,
 // which matters at the Wan shape for a second reason: 1 800 blocks on 768 four-wave slots are 2.3 rounds that cost 3, on 512
 // eight-wave slots of half the duration 3.5 rounds that cost 4 (of half the length).
-template <typename T, int DT, int MODE, bool ROPE = false, int NT = NTHREADS>
+// S16: the summary is stored as bf16 (the opt-in MHLA_FLAG_BF16_SUMMARIES arithmetic on bf16 tensors); otherwise fp32, and the
+// one operand that is an INTERMEDIATE (dP = dO / n, MODE 1) is split into hi + lo parts whatever the tensor type
+template <typename T, int DT, int MODE, bool ROPE = false, int NT = NTHREADS, bool S16 = Sum16<T>::value>
 __global__ __launch_bounds__(NT, NT == 512 ? 4 : (ROPE ? 2 : 3)) void k_sp_state(const StateArgs a) {
     constexpr int DW = Geo<DT>::DW, LD = Geo<DT>::LD, CGS = Geo<DT>::CGS, RPP = NT / CGS, IT = 32 / RPP, NWV = NT / 64,
                   RT = (DT + NWV - 1) / NWV, TILE = 32 * LD;
     static_assert(IT >= 1 && RPP * IT == 32, "a 32-row chunk must be whole staging passes");
     static_assert(RPP * DW * 4 <= 4 * 32 * LD * 2, "column-sum partials must fit in the tiles");
-    constexpr bool LO = !std::is_same<T, bf16_t>::value;
+    constexpr bool LO = !std::is_same<T, bf16_t>::value;   // the token operands carry a lo part
+    constexpr bool LOY = LO || (MODE == 1 && !S16);        // ... and so does y = dO / n, unless the reduced-precision form was asked for
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u16* Kh = reinterpret_cast<u16*>(smem_raw);
     u16* Kl = Kh + TILE;
@@ -212,7 +215,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : (ROPE ? 2 : 3)) void k_sp_state
             if (LO) *reinterpret_cast<uint4*>(Kl + off) = lo;
             split8(vx[it][0], vx[it][1], hi, lo);
             *reinterpret_cast<uint4*>(Vh + off) = hi;
-            if (LO) *reinterpret_cast<uint4*>(Vl + off) = lo;
+            if (LOY) *reinterpret_cast<uint4*>(Vl + off) = lo;
             if (MODE == 0) {
                 const f32x4* s = den ? dx[it] : kx[it];
 #pragma unroll
@@ -247,10 +250,12 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : (ROPE ? 2 : 3)) void k_sp_state
             const bf16x8 bh_ = tr_read8(Vh, LD, 0, ct * 16, lane);
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = mfma_bf16(ah[rt], bh_, acc[rt][ct]);
-            if (LO) {
+            if (LOY) {
                 const bf16x8 bl_ = tr_read8(Vl, LD, 0, ct * 16, lane);
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = mfma_bf16(ah[rt], bl_, acc[rt][ct]);
+            }
+            if (LO) {
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = mfma_bf16(al[rt], bh_, acc[rt][ct]);
             }
@@ -268,7 +273,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : (ROPE ? 2 : 3)) void k_sp_state
             for (int r = 0; r < 4; ++r) {
                 const int row = (wave * RT + rt) * 16 + kg * 4 + r, col = ct * 16 + nl;
                 if (row < D && col < D) {
-                    if (Sum16<T>::value) reinterpret_cast<u16*>(a.out)[((long)bh * a.M + blk) * a.es + (long)row * D + col] = cvt_bf16(acc[rt][ct][r]);
+                    if (S16) reinterpret_cast<u16*>(a.out)[((long)bh * a.M + blk) * a.es + (long)row * D + col] = cvt_bf16(acc[rt][ct][r]);
                     else                 ob[(long)row * D + col] = acc[rt][ct][r];
                 }
             }
@@ -1004,7 +1009,7 @@ __device__ __forceinline__ uint4 pack8_16(f16_t, f32x4 a, f32x4 b) {
 __device__ __forceinline__ uint4 pack8_16(float, f32x4, f32x4) { return make_uint4(0, 0, 0, 0); }   // (never called: fp32 stores 16-byte pieces already)
 
 constexpr int SP_OUT_T = 512;   // 8 waves share the staged G_i: twice the loads in flight per LDS byte
-template <typename T, int DT, typename TO = T, bool EPI = false>
+template <typename T, int DT, typename TO = T, bool EPI = false, bool S16 = Sum16<T>::value>
 #ifndef SP_OUT_EPI_WAVES
 #define SP_OUT_EPI_WAVES 2   // the fused-epilogue variant takes 142 VGPRs: one workgroup per CU without spills (157 us at C4) beats two with 28 spilled registers (163 us)
 #endif
@@ -1019,7 +1024,7 @@ __global__ __launch_bounds__(SP_OUT_T, EPI ? SP_OUT_EPI_WAVES : 2) void k_sp_out
     const long p0 = (long)blk * S;
     const T* qb = (const T*)a.q.ptr + b * a.q.sb + h * a.q.sh;
     TO* ob = (TO*)a.o.ptr + b * a.o.sb + h * a.o.sh;
-    constexpr bool S16 = Sum16<T>::value;   // G_i stored as bf16: no lo tile
+    // (S16: G_i stored as bf16: no lo tile)
     stage_mat_split<DT, S16, SP_OUT_T>(Gh, Gl, a.g, ((long)bh * a.M + blk) * a.es, D, tid);
     __syncthreads();
     const float* ninvb = a.ninv + ((long)bh * a.M + blk) * S;
@@ -1321,13 +1326,13 @@ __device__ __forceinline__ bf16x8 row_read8(const u16* tile, int ld, int c0, int
 
 // ROPE: the numerator pair was rotated inside the forward (q_den aliases the un-rotated q): dQ_rot is turned back by the
 // transposed rotation before dz ksum^T is added, so the one stored tensor is the gradient of the un-rotated q
-template <typename T, int DT, bool ROPE = false>
+template <typename T, int DT, bool ROPE = false, bool S16 = Sum16<T>::value>
 __global__ __launch_bounds__(NTHREADS, 2) void k_sp_bwd_dq(const TokArgs a) {
     constexpr int LD = mat_ld<DT>(), DW = Geo<DT>::DW, KST = Geo<DT>::KST, TILE = KST * 32 * LD;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u16* Gh = reinterpret_cast<u16*>(smem_raw);
     u16* Gl = Gh + TILE;                                  // not allocated for bf16 summaries
-    float* dksw = reinterpret_cast<float*>(Gh + (Sum16<T>::value ? 1 : 2) * TILE);   // [4 waves][DW]
+    float* dksw = reinterpret_cast<float*>(Gh + (S16 ? 1 : 2) * TILE);   // [4 waves][DW]
     float* ksum = dksw + 4 * DW;                          // [DW]
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nl = lane & 15, kg = lane >> 4;
     const int blk = blockIdx.x, bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H, S = a.S, D = a.D, M = a.M;
@@ -1367,7 +1372,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_bwd_dq(const TokArgs a) {
         }
     };
     fetch(wave, cur);   // in flight while G_i is staged
-    constexpr bool S16 = Sum16<T>::value;
     stage_mat_split<DT, S16>(Gh, Gl, a.g, ((long)bh * M + blk) * a.es, D, tid);
     if (tid < DW) ksum[tid] = (a.normalize && tid < D) ? a.ksum[((long)bh * M + blk) * D + tid] : 0.f;
     __syncthreads();
@@ -1463,14 +1467,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_bwd_dq(const TokArgs a) {
 
 // ROPE: k is the un-rotated tensor: it is rotated on its way into the dV product (KV was formed from the rotated keys), and
 // dK_rot is turned back before dksum is added
-template <typename T, int DT, bool ROPE = false>
+template <typename T, int DT, bool ROPE = false, bool S16 = Sum16<T>::value>
 __global__ __launch_bounds__(NTHREADS, 2) void k_sp_bwd_dkv(const TokArgs a) {
     constexpr int LD = mat_ld<DT>(), DW = Geo<DT>::DW, KST = Geo<DT>::KST, TILE = KST * 32 * LD;
     constexpr bool LO = !std::is_same<T, bf16_t>::value;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u16* Gh = reinterpret_cast<u16*>(smem_raw);   // dKV_j [d1][d2]
     u16* Gl = Gh + TILE;                          // not allocated for bf16 summaries
-    float* dks = reinterpret_cast<float*>(Gh + (Sum16<T>::value ? 1 : 2) * TILE);   // [DW]
+    float* dks = reinterpret_cast<float*>(Gh + (S16 ? 1 : 2) * TILE);   // [DW]
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nl = lane & 15, kg = lane >> 4;
     const int blk = blockIdx.x, bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H, S = a.S, D = a.D, M = a.M;
     const long p0 = (long)blk * S;
@@ -1512,7 +1516,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_bwd_dkv(const TokArgs a) {
         }
     };
     fetch(wave, cur);
-    constexpr bool S16 = Sum16<T>::value;
     stage_mat_split<DT, S16>(Gh, Gl, a.dkv, ((long)bh * M + blk) * a.es, D, tid);
     if (tid < DW) dks[tid] = (a.normalize && tid < D) ? a.dks[((long)bh * M + blk) * D + tid] : 0.f;
     __syncthreads();

@@ -122,6 +122,7 @@ struct BlockMixFn : public torch::autograd::Function<BlockMixFn> {
         require_gpu(q, "q");
         const c10::hip::HIPGuardMasqueradingAsCUDA device_guard(q.device());   // launches go to the tensors' device, whatever is current
         TORCH_CHECK_VALUE(q.dim() == 4, "q: expected [B, N, H, D], got ", q.sizes());
+        TORCH_CHECK_VALUE(W.dim() >= 2 && W.size(0) > 0, "W must be a non-empty [M, M] (or [M, M, 1, 1]) matrix, got ", W.sizes());
         const int64_t B = q.size(0), N = q.size(1), H = q.size(2), D = q.size(3), M = W.size(0);
         TORCH_CHECK_VALUE(N % M == 0, "N=", N, " tokens not divisible into M=", M, " blocks");
         const int64_t S = N / M;
@@ -216,6 +217,8 @@ struct CausalFn : public torch::autograd::Function<CausalFn> {
         const c10::hip::HIPGuardMasqueradingAsCUDA device_guard(q.device());
         TORCH_CHECK_VALUE(q.dim() == 4 && v.dim() == 4, "q, k: [B, T, H, K], v: [B, T, H, V]");
         const int64_t B = q.size(0), T = q.size(1), H = q.size(2), K = q.size(3), V = v.size(3);
+        TORCH_CHECK_VALUE(chunk > 0, "chunk_size must be positive, got ", chunk);
+        TORCH_CHECK_VALUE(mix.dim() >= 2, "mixing_matrix must be [L, L(, 1, 1, 1, 1)], got ", mix.sizes());
         const int64_t n = (T + chunk - 1) / chunk, L = mix.size(0);
         TORCH_CHECK_INDEX(n <= L, "sequence of ", T, " tokens needs ", n, " chunks but mixing_matrix has only ", L, " rows");
         check_like(q, k, "k", q.sizes());

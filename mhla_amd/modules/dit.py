@@ -54,25 +54,25 @@ class MHLA4DiT(nn.Module):
             exp_sigma=kwargs.get("exp_sigma", 3),
         )
         self.eps = kwargs.get("eps", 1e-6)
+        # not in the reference: "split" (default) keeps the operator's intermediates at fp32 grade on 16-bit tensors, "bf16" is the
+        # opt-in reduced-precision arithmetic (see mhla_amd.mhla_blockmix)
+        self.summaries = kwargs.get("summaries", "split")
         self.to_out = nn.Sequential(nn.Linear(inner_dim, dim), nn.Dropout(dropout))
         if fixed_weight_value is not None:
             self._init_weights_with_fixed_value(fixed_weight_value)
 
-    # reference: mhla.py:193-221 (deterministic-weights debugging aid)
+    # the reference's known-answer aid (mhla.py:193-221: every weight = value, every bias = 0), kept under its two public names
     def _init_weights_with_fixed_value(self, value):
-        for name, param in self.named_parameters():
-            if "weight" in name:
-                nn.init.constant_(param, value)
-            elif "bias" in name and param is not None:
-                nn.init.zeros_(param)
+        MHLA4DiT.init_to_value(self, value)
 
     @staticmethod
     def init_to_value(model, value=1.0):
-        for name, param in model.named_parameters():
-            if "weight" in name:
-                nn.init.constant_(param, value)
-            elif "bias" in name and param is not None:
-                nn.init.zeros_(param)
+        with torch.no_grad():
+            for name, p in model.named_parameters():
+                if "weight" in name:
+                    p.fill_(value)
+                elif "bias" in name:
+                    p.zero_()
         return model
 
     def _lepe(self, v: torch.Tensor, attn_out: torch.Tensor) -> torch.Tensor:
@@ -110,11 +110,12 @@ class MHLA4DiT(nn.Module):
                 q = torch.relu(self.q_norm(qkv[:, :, 0].reshape(B, M * S, H * D))) + self.eps
                 k = torch.relu(self.k_norm(qkv[:, :, 1].reshape(B, M * S, H * D))) + self.eps
             q, k = q.to(qkv.dtype), k.to(qkv.dtype)
-            out = mhla_blockmix(q.reshape(B, M * S, H, D), k.reshape(B, M * S, H, D), qkv[:, :, 2], W, eps=self.eps)
+            out = mhla_blockmix(q.reshape(B, M * S, H, D), k.reshape(B, M * S, H, D), qkv[:, :, 2], W, eps=self.eps,
+                                summaries=self.summaries)
         else:
             # operator (relu + eps folded into its loads) and LePE as one autograd node on the packed projection output
             out = mhla_dit_core(qkv, W, self.lepe.weight, self.lepe.bias, self.pieces_len, self.block_len, eps=self.eps,
-                                relu_eps=True).reshape(B, M, S, H * D)
+                                relu_eps=True, summaries=self.summaries).reshape(B, M, S, H * D)
             out = self.to_out(out)
             return out.reshape(B, M * S, -1) if three_d else out
         out = self._lepe(qkv[:, :, 2].reshape(B, M * S, H * D), out.reshape(B, M * S, H * D)).reshape(B, M, S, H * D)

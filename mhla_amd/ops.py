@@ -158,10 +158,18 @@ def _check_handover(lib, ws, B, H, M, S, D, dt, split, flags):
         _lib.check(rc, "mhla_blockmix_bwd_status")
 
 
+def _bm_flags(relu_eps: bool, force_generic: bool, no_smalln: bool, summaries: str) -> int:
+    if summaries not in ("split", "bf16"):
+        raise ValueError(f"summaries={summaries!r}: 'split' (fp32-grade intermediates: fp32 block summaries / bf16 hi + lo operands, the "
+                         "reference's arithmetic) or 'bf16' (opt-in reduced precision)")
+    return ((_lib.FLAG_RELU_EPS if relu_eps else 0) | (_lib.FLAG_FORCE_GENERIC if force_generic else 0)
+            | (_lib.FLAG_NO_SMALLN if no_smalln else 0) | (_lib.FLAG_BF16_SUMMARIES if summaries == "bf16" else 0))
+
+
 class _BlockMix(torch.autograd.Function):
     @staticmethod
     @_device_guard
-    def forward(ctx, q, k, v, W, q_den, k_den, block_index, eps, normalize, relu_eps, force_generic, no_smalln):
+    def forward(ctx, q, k, v, W, q_den, k_den, block_index, eps, normalize, flags):
         lib = _lib.load()
         _require_gpu(q, k, v, W, q_den, k_den, block_index)
         B, N, H, D = q.shape
@@ -182,8 +190,6 @@ class _BlockMix(torch.autograd.Function):
         Wf = W.detach().reshape(M, M).to(torch.float32).contiguous()
         out = _alloc_like_tokens(B, N, H, D, q)
         dt = _dtype_code(q)
-        flags = ((_lib.FLAG_RELU_EPS if relu_eps else 0) | (_lib.FLAG_FORCE_GENERIC if force_generic else 0)
-                 | (_lib.FLAG_NO_SMALLN if no_smalln else 0))
         fwd_bytes, _, keeps = _bm_plan(B, H, M, S, D, dt, int(split), flags)
         ws = _ws(fwd_bytes, q.device)
         qv, kv = _view(q), _view(k)
@@ -200,7 +206,7 @@ class _BlockMix(torch.autograd.Function):
         keep = keeps and ws.numel() * 4 <= KEEP_STATE_LIMIT_BYTES
         ctx.save_for_backward(q, k, v, Wf, out, q_den if split else None, k_den if split else None, block_index,
                               ws if keep else None)
-        ctx.cfg = (float(eps), bool(normalize), bool(relu_eps), split, W.shape, W.dtype, flags)
+        ctx.cfg = (float(eps), bool(normalize), split, W.shape, W.dtype, flags)
         return out
 
     @staticmethod
@@ -208,7 +214,7 @@ class _BlockMix(torch.autograd.Function):
     def backward(ctx, dout):
         lib = _lib.load()
         q, k, v, Wf, out, q_den, k_den, block_index, fwd_ws = ctx.saved_tensors
-        eps, normalize, relu_eps, split, w_shape, w_dtype, flags = ctx.cfg
+        eps, normalize, split, w_shape, w_dtype, flags = ctx.cfg
         B, N, H, D = q.shape
         M = Wf.shape[0]
         S = N // M
@@ -239,13 +245,14 @@ class _BlockMix(torch.autograd.Function):
                                    dt, eps, flags, _stream())
         _lib.check(rc, "mhla_blockmix_bwd")
         _check_handover(lib, ws, B, H, M, S, D, dt, int(split), flags)
-        return dq, dk, dv, dW.reshape(w_shape).to(w_dtype), dqd, dkd, None, None, None, None, None, None
+        return dq, dk, dv, dW.reshape(w_shape).to(w_dtype), dqd, dkd, None, None, None, None
 
 
 def mhla_blockmix(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, W: torch.Tensor, *, eps: float = 1e-6,
                   q_den: Optional[torch.Tensor] = None, k_den: Optional[torch.Tensor] = None,
                   normalize: bool = True, block_index: Optional[torch.Tensor] = None,
-                  relu_eps: bool = False, force_generic: bool = False, no_smalln: bool = False) -> torch.Tensor:
+                  relu_eps: bool = False, force_generic: bool = False, no_smalln: bool = False,
+                  summaries: str = "split") -> torch.Tensor:
     """Block-mixing MHLA operator (mhla_dit/mhla/mhla.py:262-268; wan/mhla_utils.py:331-341).
 
     q, k, v : [B, N, H, D] token-major (any batch/token/head strides, e.g. views into a fused QKV
@@ -258,6 +265,11 @@ def mhla_blockmix(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, W: torch.Te
                    the raw projections and receive the masked gradient.
     force_generic / no_smalln: testing aids -- take the generic fp32-MFMA kernels / skip the single-launch
                    small-sequence path where they would otherwise be chosen.
+    summaries    : how 16-bit problems keep what feeds a SECOND contraction (the block summaries KV, G, dG, dKV, dP = dO / n,
+                   the score tiles of the 256-token path).  "split" (default): >= 16 significand bits (fp32 summaries, bf16
+                   hi + lo operands) -- the reference's fp32 arithmetic on the given tensors (mhla_dit/train.py:12-13), results
+                   within one final rounding + 1e-3 of it.  "bf16": single bf16 values -- REDUCED PRECISION (2-3e-3 of a
+                   gradient's maximum), half the summary traffic; what the reference's own matmuls store under bf16 autocast.
     Returns [B, N, H, D] contiguous, same dtype; differentiable w.r.t. q, k, v, W (and q_den, k_den).
     """
     if (q_den is None) != (k_den is None):
@@ -265,6 +277,7 @@ def mhla_blockmix(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, W: torch.Te
     if q.dim() != 4:
         raise ValueError(f"q: expected [B, N, H, D], got {tuple(q.shape)}")
     _check_block_index(block_index, q.shape[1], q)
+    flags = _bm_flags(relu_eps, force_generic, no_smalln, summaries)
     if q.shape[0] == 0:   # empty batch: nothing to launch; keep the autograd graph connected (all gradients are zero)
         return torch.zeros_like(v) + 0 * (q.sum() + k.sum() + W.sum()).to(v.dtype)
     nb = _MAX_GRID_BH // q.shape[2]
@@ -273,12 +286,10 @@ def mhla_blockmix(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, W: torch.Te
         # MHLA_ENOTSUP): batch slices through the same autograd node, the gradient of W accumulates over the slices
         sl = lambda t, i: None if t is None else t[i:i + nb]
         return torch.cat([_BlockMix.apply(sl(q, i), sl(k, i), sl(v, i), W, sl(q_den, i), sl(k_den, i), block_index, eps, normalize,
-                                          relu_eps, force_generic, no_smalln) for i in range(0, q.shape[0], nb)], dim=0)
+                                          flags) for i in range(0, q.shape[0], nb)], dim=0)
     if _native_nodes():
-        flags = ((_lib.FLAG_RELU_EPS if relu_eps else 0) | (_lib.FLAG_FORCE_GENERIC if force_generic else 0)
-                 | (_lib.FLAG_NO_SMALLN if no_smalln else 0))
         return torch.ops.mhla_amd.blockmix(q, k, v, W, q_den, k_den, block_index, float(eps), bool(normalize), flags, KEEP_STATE_LIMIT_BYTES)
-    return _BlockMix.apply(q, k, v, W, q_den, k_den, block_index, eps, normalize, relu_eps, force_generic, no_smalln)
+    return _BlockMix.apply(q, k, v, W, q_den, k_den, block_index, eps, normalize, flags)
 
 
 class _BlockMixRope(torch.autograd.Function):
@@ -545,7 +556,7 @@ class _DitCore(torch.autograd.Function):
 
     @staticmethod
     @_device_guard
-    def forward(ctx, qkv, W, lepe_w, lepe_b, pieces_len, block_len, eps, relu_eps):
+    def forward(ctx, qkv, W, lepe_w, lepe_b, pieces_len, block_len, eps, flags):
         lib = _lib.load()
         _require_gpu(qkv, W, lepe_w, lepe_b)
         B, N, _, H, D = qkv.shape
@@ -555,7 +566,6 @@ class _DitCore(torch.autograd.Function):
         q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
         Wf = W.detach().reshape(M, M).to(torch.float32).contiguous()
         dt = _dtype_code(qkv)
-        flags = _lib.FLAG_RELU_EPS if relu_eps else 0
         attn = torch.empty((B, N, H, D), dtype=qkv.dtype, device=qkv.device)
         ws = _ws(_bm_plan(B, H, M, S, D, dt, 0, flags)[0], qkv.device)
         qv, kv = _view(q), _view(k)
@@ -616,14 +626,15 @@ class _DitCore(torch.autograd.Function):
 
 
 def mhla_dit_core(qkv: torch.Tensor, W: torch.Tensor, lepe_weight: torch.Tensor, lepe_bias: Optional[torch.Tensor],
-                  pieces_len: int, block_len: int, *, eps: float = 1e-6, relu_eps: bool = True) -> torch.Tensor:
+                  pieces_len: int, block_len: int, *, eps: float = 1e-6, relu_eps: bool = True, summaries: str = "split") -> torch.Tensor:
     """`mhla_blockmix(q, k, v, W) + LePE(v)` of the DiT / ViT module on the packed projection output `qkv` [B, N, 3, H, D]
-    (block-major tokens), returning [B, N, H*D]; one autograd node whose backward emits a single packed gradient."""
+    (block-major tokens), returning [B, N, H*D]; one autograd node whose backward emits a single packed gradient.
+    `summaries`: see mhla_blockmix."""
     if qkv.dim() != 5 or qkv.shape[2] != 3:
         raise ValueError("qkv: [B, N, 3, H, D]")
     if qkv.shape[1] % W.shape[0] or qkv.shape[1] != (pieces_len * block_len) ** 2:
         raise ValueError("token count does not match the block layout")
-    return _DitCore.apply(qkv, W, lepe_weight, lepe_bias, int(pieces_len), int(block_len), eps, relu_eps)
+    return _DitCore.apply(qkv, W, lepe_weight, lepe_bias, int(pieces_len), int(block_len), eps, _bm_flags(relu_eps, False, False, summaries))
 
 
 _FMAPS = {None: 0, "identity": 0, "relu": 1, "elu": 2}

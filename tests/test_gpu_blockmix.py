@@ -3,14 +3,18 @@ import pytest
 import torch
 
 from conftest import load_golden
-from gpu_util import poison, DEV, GTOL, TOL, check, make_blockmix_inputs, oracle_blockmix, to_dev
+from gpu_util import poison, DEV, GTOL, TOL, DW_TOL, GTOL_BF16SUM, TOL_BF16SUM, bm_tols, check, make_blockmix_inputs, oracle_blockmix, to_dev
 from oracle import mhla_oracle as orc
 
 pytestmark = pytest.mark.gpu
 
 
-def run_case(B, H, M, S, D, dtype, normalize=True, split=False, w="linear", idx=None, seed=1234, **opkw):
+def run_case(B, H, M, S, D, dtype, normalize=True, split=False, w="linear", idx=None, seed=1234, summaries="split", **opkw):
+    """One forward + backward through mhla_amd.mhla_blockmix against the oracle.  summaries="split" (the library's default): the
+    reference's fp32 arithmetic on the given tensors, held to one final rounding + 1e-3 (1e-3 for the fp32-stored dW);
+    "bf16": the opt-in reduced-precision form (single-bf16 summaries / intermediates) at its (1 + K) u bounds."""
     import mhla_amd
+    otol, gtol, wtol = bm_tols(dtype, summaries)
     q, k, v, W, do, qd, kd = make_blockmix_inputs(B, H, M, S, D, dtype, seed, w, split)
     want, wg = oracle_blockmix(q, k, v, W, do, qd, kd, 1e-6, normalize)
     if idx is not None:   # scatter tokens so that block-major position p lives at row idx[p]
@@ -28,22 +32,22 @@ def run_case(B, H, M, S, D, dtype, normalize=True, split=False, w="linear", idx=
         dkd.requires_grad_(True)
     poison()
     out = mhla_amd.mhla_blockmix(dq_, dk_, dv_, dW_, eps=1e-6, q_den=dqd, k_den=dkd, normalize=normalize,
-                                 block_index=None if idx is None else idx.to(DEV), **opkw)
+                                 block_index=None if idx is None else idx.to(DEV), summaries=summaries, **opkw)
     poison()
     out.backward(ddo)
     torch.cuda.synchronize()
 
     def gather(t):
         return t if idx is None else t[:, idx.long().to(t.device)]
-    check("out", gather(out), want, TOL[dtype])
-    check("dq", gather(leaves[0].grad), wg["dq"], GTOL[dtype])
-    check("dk", gather(leaves[1].grad), wg["dk"], GTOL[dtype])
-    check("dv", gather(leaves[2].grad), wg["dv"], GTOL[dtype])
+    check("out", gather(out), want, otol)
+    check("dq", gather(leaves[0].grad), wg["dq"], gtol)
+    check("dk", gather(leaves[1].grad), wg["dk"], gtol)
+    check("dv", gather(leaves[2].grad), wg["dv"], gtol)
     # M == 1: the output does not depend on W (numerator and normaliser scale together), dW ~ 0
-    check("dW", leaves[3].grad, wg["dW"], GTOL[dtype], atol=(1e9 if dtype != torch.float32 else 1e-3) if M == 1 else 0.0)
+    check("dW", leaves[3].grad, wg["dW"], wtol, atol=(1e9 if dtype != torch.float32 else 1e-3) if M == 1 else 0.0)
     if split and normalize:
-        check("dq_den", gather(dqd.grad), wg["dq_den"], GTOL[dtype])
-        check("dk_den", gather(dkd.grad), wg["dk_den"], GTOL[dtype])
+        check("dq_den", gather(dqd.grad), wg["dq_den"], gtol)
+        check("dk_den", gather(dkd.grad), wg["dk_den"], gtol)
 
 
 @pytest.mark.parametrize("tag", ["dit_a", "dit_b", "vit_a"])
@@ -74,16 +78,20 @@ def test_shapes_lowp(M, S, D, dtype):
 
 @pytest.mark.parametrize("M,S", [(64, 64), (16, 16), (16, 256), (4, 49), (5, 64), (33, 32), (40, 80), (1, 128), (64, 8),
                                  (3, 320), (5, 200), (17, 136)])   # blocks of 5 / 4 (ragged) / 3 chunks: chunk parts over several workgroups
-def test_fast_path_bf16_d64(M, S):
-    """bf16, D = 64, M <= 64: the bf16-MFMA fast path (interleaved bf16 block summaries, fused mix + output)."""
-    run_case(2, 3, M, S, 64, torch.bfloat16, w="rand")
+@pytest.mark.parametrize("summaries", ["split", "bf16"])
+def test_fast_path_bf16_d64(M, S, summaries):
+    """bf16, D = 64, M <= 64.  summaries="bf16": the bf16-MFMA fast path (interleaved bf16 block summaries, fused mix + output);
+    default: the same shapes at the reference's arithmetic (fp32 summaries, hi + lo operands)."""
+    run_case(2, 3, M, S, 64, torch.bfloat16, w="rand", summaries=summaries)
 
 
 @pytest.mark.parametrize("M,D", [(16, 64), (16, 72), (9, 72), (4, 80), (1, 64), (13, 24), (16, 8)])
-def test_small_sequence_path(M, D):
-    """bf16, S = 16, M <= 16, D <= 80 (DiT / ViT regime): single-launch attention-form kernels (smalln.hpp)."""
-    run_case(3, 2, M, 16, D, torch.bfloat16, w="rand")
-    run_case(2, 2, M, 16, D, torch.bfloat16, normalize=False)
+@pytest.mark.parametrize("summaries", ["split", "bf16"])
+def test_small_sequence_path(M, D, summaries):
+    """bf16, S = 16, M <= 16, D <= 80 (DiT / ViT regime): single-launch attention-form kernels (smalln.hpp), with hi + lo score
+    tiles (default) and with single-bf16 ones (opt-in)."""
+    run_case(3, 2, M, 16, D, torch.bfloat16, w="rand", summaries=summaries)
+    run_case(2, 2, M, 16, D, torch.bfloat16, normalize=False, summaries=summaries)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
@@ -99,6 +107,15 @@ def test_small_sequence_grid_not_a_multiple_of_8():
     """B H = 231 workgroups (33 x 7): the XCD-aware (b, h) mapping with a remainder, values checked against the oracle."""
     run_case(33, 7, 16, 16, 72, torch.bfloat16, w="rand")
     run_case(33, 7, 16, 16, 64, torch.bfloat16, w="rand", normalize=False)
+    run_case(33, 7, 16, 16, 72, torch.bfloat16, w="rand", summaries="bf16")
+
+
+def test_c1_shape_dit_s2_on_the_gpu():
+    """BASELINE.json configs[0]'s operator shape (DiT-S/2 256x256: B = 1, 6 heads of 64, 16 blocks of 16 tokens; a CPU plumbing
+    configuration in the reference) launched on the GPU as well: six workgroups, fp32 (how the configuration runs) and bf16."""
+    run_case(1, 6, 16, 16, 64, torch.float32)
+    run_case(1, 6, 16, 16, 64, torch.bfloat16)
+    run_case(1, 6, 16, 16, 64, torch.bfloat16, summaries="bf16")
 
 
 @pytest.mark.parametrize("M,D", [(16, 64), (16, 72), (9, 72), (4, 80), (1, 64), (13, 24), (16, 8)])
@@ -122,46 +139,53 @@ def test_small_sequence_fp32_vs_split_path_agree():
         check(name, a_, b_.float().cpu(), 2e-4)
 
 
-def test_small_sequence_vs_summary_path_agree():
+@pytest.mark.parametrize("summaries,tol", [("split", 2 * 2.0 ** -8 + 1e-3), ("bf16", 1.2e-2)])
+def test_small_sequence_vs_summary_path_agree(summaries, tol):
+    """(two bf16-rounded results of the same exact value differ by up to one ulp = 2 u)"""
     import mhla_amd
     q, k, v, W, do, _, _ = make_blockmix_inputs(4, 6, 16, 16, 64, torch.bfloat16, seed=3, w="rand")
     res = []
     for ns in (False, True):
         t = [x.clone().requires_grad_(True) for x in to_dev(q, k, v, W)]
-        out = mhla_amd.mhla_blockmix(*t, no_smalln=ns)
+        out = mhla_amd.mhla_blockmix(*t, no_smalln=ns, summaries=summaries)
         out.backward(do.to(DEV))
         res.append([out] + [x.grad for x in t])
     for name, a_, b_ in zip(("out", "dq", "dk", "dv", "dW"), res[0], res[1]):
-        check(name, a_, b_.float().cpu(), 1.2e-2)
+        check(name, a_, b_.float().cpu(), tol if name != "dW" or summaries == "bf16" else 1e-3)
 
 
+@pytest.mark.parametrize("summaries", ["split", "bf16"])
 @pytest.mark.parametrize("normalize", [True, False])
 @pytest.mark.parametrize("M,S", [(16, 32), (9, 64), (20, 40)])
-def test_fast_path_gather_map(M, S, normalize):
+def test_fast_path_gather_map(M, S, normalize, summaries):
     """The bf16 D = 64 summaries / tile kernels with a gather map (the k_fs_state1c<.., IDX> instantiations read the map's rows up
     front): shapes that are not the small-sequence path's (S != 16), a random token permutation, a short last block group (M = 9, 20)."""
     idx = torch.randperm(M * S, generator=torch.Generator().manual_seed(M * 100 + S)).int()
-    run_case(2, 3, M, S, 64, torch.bfloat16, normalize=normalize, idx=idx, w="rand")
+    run_case(2, 3, M, S, 64, torch.bfloat16, normalize=normalize, idx=idx, w="rand", summaries=summaries)
 
 
 @pytest.mark.parametrize("normalize", [True, False])
 def test_fast_path_options(normalize):
     idx = orc.block_index_2d(4, 4).int()
     run_case(2, 2, 16, 16, 64, torch.bfloat16, normalize=normalize, idx=idx)
+    run_case(2, 2, 16, 16, 64, torch.bfloat16, normalize=normalize, idx=idx, summaries="bf16")
     run_case(1, 2, 64, 64, 64, torch.bfloat16, normalize=normalize, force_generic=True)   # same shape, generic kernels
 
 
-def test_fast_vs_generic_agree():
+@pytest.mark.parametrize("summaries,tol", [("split", 2 * 2.0 ** -8 + 1e-3), ("bf16", 1.2e-2)])
+def test_fast_vs_generic_agree(summaries, tol):
+    """The D = 64 bf16 shape on the kernels the dispatcher picks (split-operand path at the default arithmetic, the bf16-summary
+    fast path with summaries="bf16") against the exact fp32-MFMA kernels."""
     import mhla_amd
     q, k, v, W, do, _, _ = make_blockmix_inputs(2, 4, 64, 64, 64, torch.bfloat16, seed=5, w="rand")
     res = []
     for fg in (False, True):
         t = [x.clone().requires_grad_(True) for x in to_dev(q, k, v, W)]
-        out = mhla_amd.mhla_blockmix(*t, force_generic=fg)
+        out = mhla_amd.mhla_blockmix(*t, force_generic=fg, summaries=summaries)
         out.backward(do.to(DEV))
         res.append([out] + [x.grad for x in t])
     for name, a, b in zip(("out", "dq", "dk", "dv", "dW"), res[0], res[1]):
-        check(name, a, b.float().cpu(), 1.2e-2)
+        check(name, a, b.float().cpu(), tol if name != "dW" or summaries == "bf16" else 1e-3)
 
 
 @pytest.mark.parametrize("normalize,split", [(False, False), (True, True)])
@@ -178,20 +202,27 @@ def test_wan_modes(M, S, D, normalize, split):
 def test_split_operand_path(M, S, D, split, dtype):
     """Head dims that are multiples of 8, outside the bf16 fast paths: forward and backward on the split-bf16 MFMA
     kernels (split.hpp), including the zero-padded tile shapes (D = 72, 80, 104 ...).  33 .. 256 blocks run the resident-sequence
-    mixing kernel: M = 40, 65 / 70, 150, 200 instantiate its 4-, 8-, 12- and 16-wave variants (fp32 and bf16 summaries)."""
+    mixing kernel: M = 40, 65 / 70, 150, 200 instantiate its 4-, 8-, 12- and 16-wave variants (fp32 summaries; bf16 tensors also
+    with the opt-in bf16 summaries)."""
     run_case(1, 2, M, S, D, dtype, split=split, w="rand", seed=M + S)
+    if dtype == torch.bfloat16:
+        run_case(1, 2, M, S, D, dtype, split=split, w="rand", seed=M + S, summaries="bf16")
 
 
-def test_c2_variant_256_blocks_of_16():
-    """SURVEY 8(d) C2 variant (M, S) = (256, 16): bf16, D = 64, more than 64 blocks -> split-operand path with bf16 summaries."""
-    run_case(1, 2, 256, 16, 64, torch.bfloat16, w="rand")
+@pytest.mark.parametrize("summaries", ["split", "bf16"])
+def test_c2_variant_256_blocks_of_16(summaries):
+    """SURVEY 8(d) C2 variant (M, S) = (256, 16): bf16, D = 64, more than 64 blocks -> split-operand path (fp32 summaries by
+    default; summaries="bf16": the wave-per-block kernels with bf16 summaries)."""
+    run_case(1, 2, 256, 16, 64, torch.bfloat16, w="rand", summaries=summaries)
 
 
 @pytest.mark.parametrize("M,normalize,gather", [(65, True, False), (130, False, False), (203, True, True), (256, True, True), (77, False, True)])
 def test_blocks_of_16_tokens_wave_per_block_kernels(M, normalize, gather):
-    """bf16, D = 64, S = 16, more than 64 blocks: the wave-per-block token kernels (split16.hpp) and the whole-matrix dW kernel
-    (M not a multiple of the 4 blocks of a workgroup, with and without the normaliser, with a gather map)."""
+    """bf16, D = 64, S = 16, more than 64 blocks, summaries="bf16": the wave-per-block token kernels (split16.hpp) and the
+    whole-matrix dW kernel (M not a multiple of the 4 blocks of a workgroup, with and without the normaliser, with a gather map);
+    the same shapes at the default arithmetic."""
     idx = torch.randperm(M * 16, generator=torch.Generator().manual_seed(M)).int() if gather else None
+    run_case(2, 3, M, 16, 64, torch.bfloat16, normalize=normalize, w="rand", idx=idx, seed=M, summaries="bf16")
     run_case(2, 3, M, 16, 64, torch.bfloat16, normalize=normalize, w="rand", idx=idx, seed=M)
 
 
@@ -208,7 +239,7 @@ def test_blocks_of_16_tokens_views_into_a_packed_projection():
     check("out", out, want, TOL[torch.bfloat16])
     for i, name in enumerate(("dq", "dk", "dv")):
         check(name, qkv.grad[:, :, i], wg[name], GTOL[torch.bfloat16])
-    check("dW", Wd.grad, wg["dW"], GTOL[torch.bfloat16])
+    check("dW", Wd.grad, wg["dW"], DW_TOL[torch.bfloat16])
 
 
 @pytest.mark.parametrize("D,grid", [(72, (4, 4)), (128, (4, 4)), (64, (8, 10))])
@@ -231,7 +262,7 @@ def test_split_operand_path_relu_prologue(D, grid):
     ref = orc.blockmix_fwd(torch.relu(qa) + 1e-6, torch.relu(ka) + 1e-6, va, Wa, 1e-6)
     ref.backward(do.float())
     for name, got, ex in zip(("dq", "dk", "dv", "dW"), [t.grad for t in leaves] + [Wd.grad], (qa.grad, ka.grad, va.grad, Wa.grad)):
-        check(name, got, ex, GTOL[torch.bfloat16])
+        check(name, got, ex, DW_TOL[torch.bfloat16] if name == "dW" else GTOL[torch.bfloat16])
 
 
 def test_split_operand_path_matches_exact_fp32():
@@ -330,7 +361,7 @@ def test_fused_qkv_views_and_relu_prologue():
     out.backward(do.to(DEV))
     check("out_bf16", out, o_ref.detach(), TOL[torch.bfloat16])
     check("dqkv_bf16", dev.grad, ref.grad, GTOL[torch.bfloat16])
-    check("dW_bf16", Wd.grad, Wr.grad, GTOL[torch.bfloat16])
+    check("dW_bf16", Wd.grad, Wr.grad, DW_TOL[torch.bfloat16])
 
 
 def test_empty_batch():
@@ -361,27 +392,30 @@ def test_errors_fail_loudly():
         mhla_amd.mhla_blockmix(q.double(), q.double(), q.double(), W)
 
 
-def test_full_size_c2_properties_and_sampled_heads():
+@pytest.mark.parametrize("summaries", ["split", "bf16"])
+def test_full_size_c2_properties_and_sampled_heads(summaries):
     """BASELINE config C2 (B=8, N=4096, H=16, D=64, bf16, M=S=64): sampled (b, h) slices vs the oracle,
-    plus size-independent properties: linearity in v, and W = I decouples blocks."""
+    plus size-independent properties: linearity in v, and W = I decouples blocks.  Default arithmetic (the number of record:
+    one final rounding + 1e-3, dW within 1e-3) and the opt-in bf16-summary fast path at its own bounds."""
     import mhla_amd
+    otol, gtol, wtol = bm_tols(torch.bfloat16, summaries)
     B, N, H, D, M = 8, 4096, 16, 64, 64
     q, k, v, W, do, _, _ = make_blockmix_inputs(B, H, M, N // M, D, torch.bfloat16, seed=1234)
     dq, dk, dv, dW, ddo = to_dev(q, k, v, W, do)
     for t in (dq, dk, dv, dW):
         t.requires_grad_(True)
-    out = mhla_amd.mhla_blockmix(dq, dk, dv, dW)
+    out = mhla_amd.mhla_blockmix(dq, dk, dv, dW, summaries=summaries)
     out.backward(ddo)
     for (b, h) in [(0, 0), (3, 7), (7, 15)]:
         sl = lambda t: t[b:b + 1, :, h:h + 1]
         want, wg = oracle_blockmix(sl(q), sl(k), sl(v), W, sl(do), None, None, 1e-6, True)
-        check("out", sl(out), want, TOL[torch.bfloat16])
-        check("dq", sl(dq.grad), wg["dq"], GTOL[torch.bfloat16])
-        check("dk", sl(dk.grad), wg["dk"], GTOL[torch.bfloat16])
-        check("dv", sl(dv.grad), wg["dv"], GTOL[torch.bfloat16])
+        check("out", sl(out), want, otol)
+        check("dq", sl(dq.grad), wg["dq"], gtol)
+        check("dk", sl(dk.grad), wg["dk"], gtol)
+        check("dv", sl(dv.grad), wg["dv"], gtol)
     # dW is a sum over all 128 (b, h) pairs: the whole batch through the oracle (a few seconds on the host)
     _, wg_all = oracle_blockmix(q, k, v, W, do, None, None, 1e-6, True)
-    check("dW (all heads)", dW.grad, wg_all["dW"], GTOL[torch.bfloat16])
+    check("dW (all heads)", dW.grad, wg_all["dW"], wtol)
     # linearity in v (fp32 so the property is tight)
     qf, kf, vf = dq.detach().float(), dk.detach().float(), dv.detach().float()
     v2 = torch.randn_like(vf)
@@ -403,7 +437,7 @@ def test_full_size_c2_properties_and_sampled_heads():
     assert not torch.equal(oa[:, ~mask], ob[:, ~mask])
 
 
-def _check_dw_additive(mhla_amd, q, k, v, do, Wd, W, chunk):
+def _check_dw_additive(mhla_amd, q, k, v, do, Wd, W, chunk, summaries="split"):
     """dW of the whole (huge) batch = sum of the dW of batch chunks (size-independent property: catches indexing errors of the
     partial / reduction buffers at large grids), and the first chunk's dW is anchored on the oracle."""
     full = Wd.grad.detach().double().cpu()
@@ -412,22 +446,24 @@ def _check_dw_additive(mhla_amd, q, k, v, do, Wd, W, chunk):
     for b0 in range(0, B, chunk):
         qs, ks, vs = (t.detach()[b0:b0 + chunk].requires_grad_(True) for t in (q, k, v))
         Wc = W.to(DEV).requires_grad_(True)
-        mhla_amd.mhla_blockmix(qs, ks, vs, Wc).backward(do[b0:b0 + chunk])
+        mhla_amd.mhla_blockmix(qs, ks, vs, Wc, summaries=summaries).backward(do[b0:b0 + chunk])
         acc += Wc.grad.double().cpu()
         if b0 == 0:
             f = lambda t: t.detach()[:8].float().cpu()
             _, wg = oracle_blockmix(f(q), f(k), f(v), W, f(do), None, None, 1e-6, True)
             Wa = W.to(DEV).requires_grad_(True)
-            mhla_amd.mhla_blockmix(q.detach()[:8].requires_grad_(True), k.detach()[:8], v.detach()[:8], Wa).backward(do[:8])
-            check("dW (first 8 samples vs oracle)", Wa.grad, wg["dW"], GTOL[torch.bfloat16])
+            mhla_amd.mhla_blockmix(q.detach()[:8].requires_grad_(True), k.detach()[:8], v.detach()[:8], Wa, summaries=summaries).backward(do[:8])
+            check("dW (first 8 samples vs oracle)", Wa.grad, wg["dW"], bm_tols(torch.bfloat16, summaries)[2])
     # fp32 partial sums in different groupings: agreement to fp32 summation noise
     check("dW additivity over batch chunks", full.float(), acc.float(), 2e-4)
 
 
 def test_more_than_2_31_elements_per_tensor():
     """Maximum sizes: 2.2e9 elements (4.4 GB) per token tensor -- element offsets no longer fit 32 bits.  Inputs are generated
-    on the device; the first, a middle and the last (b, h) slices are checked against the oracle, forward and backward."""
+    on the device; the first, a middle and the last (b, h) slices are checked against the oracle, forward and backward.
+    (summaries="bf16": the fast path's indexing; the split-operand path has its own test below, at the default arithmetic.)"""
     import mhla_amd
+    otol, gtol, _ = bm_tols(torch.bfloat16, "bf16")
     B, N, H, D, M = 528, 4096, 16, 64, 64
     assert B * N * H * D > 2 ** 31
     gen = torch.Generator(device=DEV).manual_seed(7)
@@ -438,16 +474,16 @@ def test_more_than_2_31_elements_per_tensor():
     Wd = W.to(DEV).requires_grad_(True)
     for t in (q, k, v):
         t.requires_grad_(True)
-    out = mhla_amd.mhla_blockmix(q, k, v, Wd)
+    out = mhla_amd.mhla_blockmix(q, k, v, Wd, summaries="bf16")
     out.backward(do)
     for (b, h) in [(0, 0), (263, 9), (B - 1, H - 1)]:
         sl = lambda t: t.detach()[b:b + 1, :, h:h + 1].cpu()
         want, wg = oracle_blockmix(sl(q), sl(k), sl(v), W, sl(do), None, None, 1e-6, True)
-        check("out", sl(out), want, TOL[torch.bfloat16])
-        check("dq", sl(q.grad), wg["dq"], GTOL[torch.bfloat16])
-        check("dk", sl(k.grad), wg["dk"], GTOL[torch.bfloat16])
-        check("dv", sl(v.grad), wg["dv"], GTOL[torch.bfloat16])
-    _check_dw_additive(mhla_amd, q, k, v, do, Wd, W, chunk=48)
+        check("out", sl(out), want, otol)
+        check("dq", sl(q.grad), wg["dq"], gtol)
+        check("dk", sl(k.grad), wg["dk"], gtol)
+        check("dv", sl(v.grad), wg["dv"], gtol)
+    _check_dw_additive(mhla_amd, q, k, v, do, Wd, W, chunk=48, summaries="bf16")
     del q, k, v, do, out
     torch.cuda.empty_cache()
 
@@ -566,7 +602,8 @@ def test_more_batch_head_pairs_than_one_launch_addresses():
     check("dW over slices", leaves[3].grad, acc.cpu(), 1e-4)
 
 
-def test_repetitions_bit_identical_alone_and_beside_a_second_stream():
+@pytest.mark.parametrize("summaries", ["split", "bf16"])
+def test_repetitions_bit_identical_alone_and_beside_a_second_stream(summaries):
     """Determinism: the backward runs dz = W^T dn and the dW products as workgroups of ONE launch, and a host
     may run several operators on several streams (DDP buckets, side streams).  Round 1 saw run-to-run differences in the
     normaliser gradients when two of the library's kernels overlapped; this test repeats the C2-shaped operator alone and
@@ -586,8 +623,8 @@ def test_repetitions_bit_identical_alone_and_beside_a_second_stream():
             with torch.cuda.stream(side):
                 t2 = [x.clone().requires_grad_(True) for x in (q2, k2, v2, W)]
                 for _ in range(2):
-                    mhla_amd.mhla_blockmix(*t2).backward(do2)
-        out = mhla_amd.mhla_blockmix(*ts)
+                    mhla_amd.mhla_blockmix(*t2, summaries=summaries).backward(do2)
+        out = mhla_amd.mhla_blockmix(*ts, summaries=summaries)
         out.backward(do)
         torch.cuda.synchronize()
         return [out.detach().clone()] + [x.grad.clone() for x in ts]
@@ -622,9 +659,9 @@ def test_token_gradient_launch_handover_on_two_streams(B, H, M, S, monkeypatch):
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):
                     t2 = [x.flip(0).clone().requires_grad_(True) for x in (q, k, v)]
-                    mhla_amd.mhla_blockmix(*t2, W).backward(do)
+                    mhla_amd.mhla_blockmix(*t2, W, summaries="bf16").backward(do)
             ts = [x.clone().requires_grad_(True) for x in (q, k, v, W)]
-            out = mhla_amd.mhla_blockmix(*ts)
+            out = mhla_amd.mhla_blockmix(*ts, summaries="bf16")
             out.backward(do)
             torch.cuda.synchronize()
             return [out.detach()] + [x.grad for x in ts]
@@ -654,7 +691,7 @@ def test_handover_wait_is_bounded_and_reported(monkeypatch):
     ts = [x.clone().requires_grad_(True) for x in (q, k, v, W)]
     monkeypatch.setenv("MHLA_DEBUG_DROP_SIGNAL", "1")
     monkeypatch.setenv("MHLA_CHECK_HANDOVER", "1")   # (selects the Python autograd node, whose backward issues the status call)
-    out = mhla_amd.mhla_blockmix(*ts)
+    out = mhla_amd.mhla_blockmix(*ts, summaries="bf16")
     with pytest.raises(RuntimeError, match="gave up waiting"):
         out.backward(do)
     torch.cuda.synchronize()
@@ -662,13 +699,13 @@ def test_handover_wait_is_bounded_and_reported(monkeypatch):
     # gave up poisons its dksum rows, so the tile's dk is NaN -- never a finite, silently wrong gradient.
     monkeypatch.delenv("MHLA_CHECK_HANDOVER")
     ts = [x.clone().requires_grad_(True) for x in (q, k, v, W)]
-    mhla_amd.mhla_blockmix(*ts).backward(do)
+    mhla_amd.mhla_blockmix(*ts, summaries="bf16").backward(do)
     torch.cuda.synchronize()
     assert bool(torch.isnan(ts[1].grad.float()).all()), "dk of a tile whose hand-over expired must be NaN"
     assert bool(torch.isfinite(ts[0].grad.float()).all()) and bool(torch.isfinite(ts[2].grad.float()).all())
     monkeypatch.delenv("MHLA_DEBUG_DROP_SIGNAL")
     # the next call on the same shapes is clean again (the error word is cleared per launch)
     ts = [x.clone().requires_grad_(True) for x in (q, k, v, W)]
-    mhla_amd.mhla_blockmix(*ts).backward(do)
+    mhla_amd.mhla_blockmix(*ts, summaries="bf16").backward(do)
     torch.cuda.synchronize()
     assert all(bool(torch.isfinite(x.grad.float()).all()) for x in ts)

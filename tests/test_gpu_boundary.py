@@ -218,29 +218,29 @@ def test_bwd_status_after_a_fast_shape_fell_back_to_another_path():
     mis = [b[4:4 + B * N * H * D].view(B, N, H, D) for b in bufs]   # 8-byte aligned, not 16
     assert all(t.data_ptr() % 16 == 8 for t in mis)
     W = torch.rand(M, M, generator=g).to(DEV)
-    dt = _lib.BF16
-    fws = torch.empty(lib.mhla_blockmix_fwd_ws_bytes(B, H, M, S, D, dt, 0, 0) // 4 + 4, device=DEV)
+    dt, FL = _lib.BF16, _lib.FLAG_BF16_SUMMARIES   # (the arithmetic whose aligned form is the fast path)
+    fws = torch.empty(lib.mhla_blockmix_fwd_ws_bytes(B, H, M, S, D, dt, 0, FL) // 4 + 4, device=DEV)
     q, k, v, out, dout = mis
     rc = lib.mhla_blockmix_fwd(_view(q), _view(k), _view(v), _view(q), _view(k), W.data_ptr(), M, _view(out), None, fws.data_ptr(),
-                               fws.numel() * 4, B, H, M, S, D, dt, 1e-6, 0, torch.cuda.current_stream().cuda_stream)
+                               fws.numel() * 4, B, H, M, S, D, dt, 1e-6, FL, torch.cuda.current_stream().cuda_stream)
     assert rc == 0, lib.mhla_last_error()
-    nbytes = lib.mhla_blockmix_bwd_ws_bytes(B, H, M, S, D, dt, 0, 0)
+    nbytes = lib.mhla_blockmix_bwd_ws_bytes(B, H, M, S, D, dt, 0, FL)
     ws = torch.full((nbytes // 4 + 4,), float("nan"), device=DEV)      # garbage everywhere, the tail word included
     grads = [torch.empty(B * N * H * D + 8, dtype=torch.bfloat16, device=DEV)[4:4 + B * N * H * D].view(B, N, H, D) for _ in range(3)]
     dW = torch.empty(M, M, device=DEV)
     null = _lib.NULL_VIEW
     rc = lib.mhla_blockmix_bwd(_view(q), _view(k), _view(v), _view(q), _view(k), W.data_ptr(), M, _view(out), _view(dout),
                                _view(grads[0]), _view(grads[1]), _view(grads[2]), null, null, dW.data_ptr(), None, ws.data_ptr(),
-                               ws.numel() * 4, None, B, H, M, S, D, dt, 1e-6, 0, torch.cuda.current_stream().cuda_stream)
+                               ws.numel() * 4, None, B, H, M, S, D, dt, 1e-6, FL, torch.cuda.current_stream().cuda_stream)
     assert rc == 0, lib.mhla_last_error()
-    rc = lib.mhla_blockmix_bwd_status(ws.data_ptr(), ws.numel() * 4, B, H, M, S, D, dt, 0, 0, torch.cuda.current_stream().cuda_stream)
+    rc = lib.mhla_blockmix_bwd_status(ws.data_ptr(), ws.numel() * 4, B, H, M, S, D, dt, 0, FL, torch.cuda.current_stream().cuda_stream)
     assert rc == 0, lib.mhla_last_error()
     # same numbers as the aligned call through the operator (fast path): both within the bf16 bounds of each other
     ts = [t.clone().contiguous().requires_grad_(True) for t in (q, k, v)]
     Wd = W.clone().requires_grad_(True)
-    o2 = mhla_amd.mhla_blockmix(ts[0], ts[1], ts[2], Wd)
+    o2 = mhla_amd.mhla_blockmix(ts[0], ts[1], ts[2], Wd, summaries="bf16")
     o2.backward(dout.clone().contiguous())
-    check("out (split path on misaligned views vs fast path)", out, o2.detach().float().cpu(), 2 * TOL[torch.bfloat16])
+    check("out (split path on misaligned views vs fast path)", out, o2.detach().float().cpu(), 4 * 2.0 ** -8)
     for name, a, b in zip(("dq", "dk", "dv"), grads, ts):
         check(name, a, b.grad.float().cpu(), 2 * 3 * 2.0 ** -8)
     check("dW", dW, Wd.grad.float().cpu(), 2 * 3 * 2.0 ** -8)

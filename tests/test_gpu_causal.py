@@ -3,7 +3,7 @@ import pytest
 import torch
 
 from conftest import load_golden
-from gpu_util import poison, DEV, GTOL, TOL, CAUSAL_TOL, CAUSAL_DMIX_TOL, check
+from gpu_util import poison, DEV, GTOL_BF16SUM, TOL_BF16SUM, CAUSAL_TOL, CAUSAL_DMIX_TOL, check
 from oracle import mhla_oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -23,7 +23,7 @@ def causal_tols(dtype, summaries="split"):
     """(out / dq / dk / dv tolerance, dmix tolerance): one final rounding + 1e-3 at the reference's arithmetic; the reduced
     precision variant carries K = 1 (outputs) / 2 (gradients) bf16 intermediates (gpu_util)."""
     if summaries == "bf16":
-        return TOL[dtype], GTOL[dtype], GTOL[dtype]
+        return TOL_BF16SUM[dtype], GTOL_BF16SUM[dtype], GTOL_BF16SUM[dtype]
     return CAUSAL_TOL[dtype], CAUSAL_TOL[dtype], CAUSAL_DMIX_TOL[dtype]
 
 

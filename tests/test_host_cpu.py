@@ -21,12 +21,17 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/mhla_hip.h but not exported"
-    assert lib.mhla_abi_version() == _lib.ABI_VERSION == 7
+    assert lib.mhla_abi_version() == _lib.ABI_VERSION == 8
     assert b"no-packed-fp32" in lib.mhla_build_flags()
     # workspace sizing is pure host arithmetic: callable without a GPU
     fwd = lib.mhla_blockmix_fwd_ws_bytes(8, 16, 64, 64, 64, 0, 0, 0)
     bwd = lib.mhla_blockmix_bwd_ws_bytes(8, 16, 64, 64, 64, 0, 0, 0)
-    assert lib.mhla_blockmix_fwd_ws_bytes(8, 16, 64, 64, 64, 1, 0, 0) < fwd   # bf16 fast path: compact summaries
+    # bf16 tensors: fp32 block summaries by default (the reference's arithmetic), the compact bf16 ones of the fast path only with
+    # the opt-in flag; the flag means nothing for fp32 tensors
+    assert lib.mhla_blockmix_fwd_ws_bytes(8, 16, 64, 64, 64, 1, 0, 0) == fwd
+    assert lib.mhla_blockmix_fwd_ws_bytes(8, 16, 64, 64, 64, 1, 0, _lib.FLAG_BF16_SUMMARIES) < 0.6 * fwd
+    assert lib.mhla_blockmix_fwd_ws_bytes(8, 16, 64, 64, 64, 0, 0, _lib.FLAG_BF16_SUMMARIES) == fwd
+    assert lib.mhla_blockmix_fwd_keeps_state(8, 16, 64, 64, 64, 1, 0, 0) == 1
     assert 0 < fwd < bwd
     assert lib.mhla_causal_bwd_ws_bytes(1, 8192, 4, 128, 256, 64, 0, 0) > lib.mhla_causal_fwd_ws_bytes(1, 8192, 4, 128, 256, 64, 0, 0) > 0
     # bf16 tensors: chunk summaries as bf16 hi + lo pairs (as many bytes as fp32); single bf16 only with the opt-in flag

@@ -109,7 +109,8 @@ def _graph_time(step, iters=20):
         return None
 
 
-def blockmix_case(name, B, N, H, D, M, dtype, layout, bwd=True, split=False, idx=None, normalize=True, iters=20, graph=False, key=None):
+def blockmix_case(name, B, N, H, D, M, dtype, layout, bwd=True, split=False, idx=None, normalize=True, iters=20, graph=False, key=None,
+                  summaries="split"):
     g = torch.Generator().manual_seed(1)
     mk = lambda relu: ((torch.relu(torch.randn(B, N, H, D, generator=g)) + 1e-6) if relu else torch.randn(B, N, H, D, generator=g)).to(dtype).to(DEV)
     q, k, v, do = mk(True), mk(True), mk(False), mk(False)
@@ -122,7 +123,7 @@ def blockmix_case(name, B, N, H, D, M, dtype, layout, bwd=True, split=False, idx
             t.requires_grad_(True)
 
     def step():
-        out = mhla_amd.mhla_blockmix(q, k, v, W, q_den=qd, k_den=kd, normalize=normalize, block_index=idx)
+        out = mhla_amd.mhla_blockmix(q, k, v, W, q_den=qd, k_den=kd, normalize=normalize, block_index=idx, summaries=summaries)
         if bwd:
             out.backward(do)
             q.grad = k.grad = v.grad = W.grad = None
@@ -130,7 +131,11 @@ def blockmix_case(name, B, N, H, D, M, dtype, layout, bwd=True, split=False, idx
     t = timeit(step, iters=iters)
     nde = B * H * N * D * q.element_size()
     alg = (12 if bwd else (6 if split else 4)) * nde      # fwd 4 NDe (6 with split q/k), bwd 8 NDe
-    return _result(name, "fwd+bwd" if bwd else "fwd", t, B * N, alg, step, _graph_time(step, iters) if graph else None, key)
+    r = _result(name, "fwd+bwd" if bwd else "fwd", t, B * N, alg, step, _graph_time(step, iters) if graph else None, key)
+    if dtype != torch.float32:
+        r["arithmetic"] = ("fp32-grade intermediates (fp32 block summaries / bf16 hi + lo operands and score tiles: the reference's fp32 arithmetic)"
+                           if summaries == "split" else "REDUCED PRECISION: single-bf16 block summaries, dP and score tiles (opt-in)")
+    return r
 
 
 def causal_case(name, B, T, H, K, V, dtype, iters=10, key=None, summaries="split", graph=True):
