@@ -57,6 +57,11 @@ enum {
                                     * reference's fp32 arithmetic (mhla_dit/mhla/mhla.py:262-268 evaluated as
                                     * mhla_dit/train.py:12-13 runs it) on the given tensors, one rounding at the store. */
 
+#define MHLA_FLAG_NO_BWD_STATE 16u  /* mhla_blockmix_fwd: no backward will use this forward's workspace (inference) -- skip what only
+                                    * the backward reads (16-bit tensors, default arithmetic: the bf16 residual O - fl(O) that
+                                    * gives the backward's row dots dO . O an fp32-grade O).  A backward given this flag
+                                    * recomputes it. */
+
 /* flags of the causal entry points (mhla_causal_*) */
 #define MHLA_CAUSAL_FORCE_GENERIC 1u   /* testing aid: the generic kernels (exact fp32 MFMA, fp32 summaries) for every shape */
 #define MHLA_CAUSAL_BF16_SUMMARIES 2u  /* REDUCED PRECISION, opt-in: chunk summaries S, P, dP, dS and the score tiles as single

@@ -14,6 +14,7 @@ FLAG_RELU_EPS = 1
 FLAG_FORCE_GENERIC = 2
 FLAG_NO_SMALLN = 4
 FLAG_BF16_SUMMARIES = 8   # opt-in reduced precision of the block-mixing operator on 16-bit tensors (mhla_hip.h)
+FLAG_NO_BWD_STATE = 16      # forward without a backward to come: skip the state only the backward reads
 CAUSAL_FORCE_GENERIC = 1
 CAUSAL_BF16_SUMMARIES = 2
 

@@ -95,6 +95,9 @@ struct StateArgs {
     const float* rsin;
     long ldr;
     long es;   // elements from one block's summary to the next in `out` (split.hpp / split16.hpp; the kernels of this file use D D)
+    // MODE 1, 16-bit tensors at the default arithmetic: what the forward's store of O rounded away, bf16 [bh][M S][D] in block-major
+    // token order (OutArgs::olo); added to O before the row dot.  Null: the row dot uses O as stored.
+    const unsigned short* olo;
 };
 
 template <int DT>
@@ -178,6 +181,18 @@ __global__ __launch_bounds__(NTHREADS) void k_bm_state(const StateArgs a) {
                 const T* ob = (const T*)a.o.ptr + b * a.o.sb + h * a.o.sh;
                 load_tile<T, DP, false>(Es, LD, ob, a.o.sn, a.idx, p0 + c0, rv, kend, D, 0.f, tid, NTHREADS);
                 for (int r = tid; r < rv; r += NTHREADS) vecr[r] = a.ninv[((long)bh * a.M + blk) * S + c0 + r];
+                if (a.olo) {   // O at fp32 grade: + what its 16-bit store lost (every thread adds to the elements it staged itself)
+                    const unsigned short* lo = a.olo + ((long)bh * a.M * S + p0 + c0) * D;
+                    for (int v = tid; v < rv * (DP / 4); v += NTHREADS) {
+                        const int r = v / (DP / 4), c = (v - r * (DP / 4)) * 4;
+                        if (c < D) {
+                            const uint2 w = *reinterpret_cast<const uint2*>(lo + (long)r * D + c);
+                            float* e = Es + r * LD + c;
+                            e[0] += bf16_to_f32((unsigned short)(w.x & 0xffffu)); e[1] += bf16_to_f32((unsigned short)(w.x >> 16));
+                            e[2] += bf16_to_f32((unsigned short)(w.y & 0xffffu)); e[3] += bf16_to_f32((unsigned short)(w.y >> 16));
+                        }
+                    }
+                }
             }
             __syncthreads();
             if (a.normalize) {
@@ -353,6 +368,11 @@ struct OutArgs {
     float neps;
     View gate;
     long es;   // elements from one block's summary to the next in `g` (split.hpp / split16.hpp)
+    // 16-bit tensors at the default arithmetic, when a backward will follow: O - fl(O) as bf16 [bh][M S][D] (block-major token
+    // order), so that the backward's row dots dO . O see O at fp32 grade; null: not written.  skip_out: ONLY this residual is
+    // written (the backward recomputing it when the forward's workspace was not kept).
+    unsigned short* olo;
+    int skip_out;
 };
 
 template <int DT>
@@ -426,7 +446,14 @@ __global__ __launch_bounds__(NTHREADS) void k_bm_out(const OutArgs a) {
             }
         }
         __syncthreads();
-        store_tile<T, DP>(ob, a.o.sn, a.idx, p0 + c0, Os, LDO, rv, D, tid, NTHREADS);
+        if (!a.skip_out) store_tile<T, DP>(ob, a.o.sn, a.idx, p0 + c0, Os, LDO, rv, D, tid, NTHREADS);
+        if (a.olo) {
+            unsigned short* lo = a.olo + ((long)bh * a.M * S + p0 + c0) * D;
+            for (int v = tid; v < rv * (DP / 4); v += NTHREADS) {
+                const int r = v / (DP / 4), c = (v - r * (DP / 4)) * 4;
+                if (c < D) *reinterpret_cast<uint2*>(lo + (long)r * D + c) = store_residual4<T>(*reinterpret_cast<const f32x4*>(Os + r * LDO + c));
+            }
+        }
         __syncthreads();
     }
 }

@@ -141,6 +141,7 @@ int bm_fwd_typed(const BmCall& c) {
         o.q = cv(q_num); o.o = cmv(c.out); o.idx = block_index; o.W = W; o.ldw = ldw; o.g = w.g; o.ninv = w.ninv;
         o.H = H; o.M = M; o.S = S; o.D = D; o.eps = eps; o.es = w.es;
         o.relu = (flags & MHLA_FLAG_RELU_EPS) ? 1 : 0; o.normalize = normalize;
+        o.olo = (normalize && !epi && !(flags & MHLA_FLAG_NO_BWD_STATE)) ? w.olo : nullptr;   // (16-bit tensors, default arithmetic: BmWs::olo)
         if (epi) {
             if constexpr (std::is_same<ET, float>::value) {
                 o.nw = nw; o.neps = neps; o.gate = cv(gate);
@@ -178,11 +179,24 @@ int bm_bwd_typed(const BmCall& c) {
         const bool s16 = S16 && s16_ok<ET, DT>(c, true);
         if (!reuse)
             RC((bm_state_and_mix<ET, DT, S16>(q_num, k_num, v, q_den, k_den, W, ldw, block_index, w, B, H, M, S, D, eps, flags, normalize, split, st, rcos, rsin, ldr, s16)));
+        const bool want_olo = normalize && w.olo != nullptr;
+        if (want_olo && (!reuse || (flags & MHLA_FLAG_NO_BWD_STATE))) {
+            // what the forward's 16-bit store of O rounded away (BmWs::olo), recomputed: the output kernel without its output
+            OutArgs o{};
+            o.q = cv(q_num); o.o = MView{nullptr, 0, 0, 0}; o.idx = block_index; o.W = W; o.ldw = ldw; o.g = w.g; o.ninv = w.ninv;
+            o.H = H; o.M = M; o.S = S; o.D = D; o.eps = eps; o.es = w.es; o.relu = relu; o.normalize = normalize;
+            o.olo = c.olo_own; o.skip_out = 1;
+            if (sp_shape_ok(D, flags))
+                RC(launch(sp::k_sp_out<ET, DT, ET, false, S16>, dim3(M, B * H), dim3(sp::SP_OUT_T), sp::sp_out_smem<DT, S16>(), st, "k_sp_out<olo>", o));
+            else
+                RC(launch(k_bm_out<ET, DT>, dim3(M, B * H), dim3(NTHREADS), out_smem_floats<DT>() * 4, st, "k_bm_out<olo>", o));
+        }
         // dG_i = Q_i^T (dO_i / n_i), dn_i
         StateArgs a{};
         a.x = cv(q_num); a.y = cv(dout); a.o = cv(out_view); a.idx = block_index; a.W = W; a.ldw = ldw; a.ninv = w.ninv;
         a.out = w.dg; a.dn = w.dn; a.es = w.es; a.H = H; a.M = M; a.S = S; a.D = D; a.eps = eps;
         a.relu = relu; a.normalize = normalize; a.split = split;
+        a.olo = !want_olo ? nullptr : ((!reuse || (flags & MHLA_FLAG_NO_BWD_STATE)) ? c.olo_own : w.olo);
         const int tiles = (M + 63) / 64;
         TokArgs t{};
         t.q = cv(q_num); t.k = cv(k_num); t.v = cv(v); t.qd = cv(q_den); t.kd = cv(k_den); t.dout = cv(dout);

@@ -123,6 +123,7 @@ inline int dt_for(int D) { return D <= 32 ? 2 : D <= 64 ? 4 : D <= 80 ? 5 : D <=
 
 struct BmWs {
     float *kv, *g, *z, *ksum, *ninv, *dg, *dkv, *dn, *dz, *dks, *dwp;
+    unsigned short* olo;   // forward region: O - fl(O) as bf16 [bh][M S][D] (16-bit tensors at the default arithmetic), or null
     size_t total_fwd, total_bwd;
     long es;   // elements from one block's D x D summary to the next (D D + padding on the split-operand path)
 };
@@ -132,7 +133,7 @@ struct BmWs {
 // fp32) those requests fall on a fraction of the HBM channels -- k_sp_dwr ran at 3.7 TB/s at D = 64 and at 4.9 / 5.4 TB/s at
 // D = 56 / 72 (the causal pipeline met the same effect, causal_bf16.hpp).  The generic fp32-MFMA kernels keep dense rows.
 inline long bm_row_elems(int D, bool sum16, bool padded) { return (long)D * D + (padded ? (sum16 ? 576 : 288) : 0); }
-inline BmWs bm_carve(void* ws, int B, int H, int M, int S, int D, bool sum16, bool padded) {
+inline BmWs bm_carve(void* ws, int B, int H, int M, int S, int D, bool sum16, bool padded, bool olo = false) {
     const size_t es = (size_t)bm_row_elems(D, sum16, padded);
     const size_t bh = (size_t)B * H, st = al4(sum16 ? (bh * M * es + 1) / 2 : bh * M * es), zs = al4(bh * M * S), ks = al4(bh * M * D);
     float* p = (float*)ws;
@@ -143,6 +144,8 @@ inline BmWs bm_carve(void* ws, int B, int H, int M, int S, int D, bool sum16, bo
     w.z = p; p += zs;
     w.ksum = p; p += ks;
     w.ninv = p; p += zs;
+    w.olo = nullptr;
+    if (olo) { w.olo = (unsigned short*)p; p += al4((bh * M * S * D + 1) / 2); }
     w.total_fwd = (size_t)(p - (float*)ws) * 4;
     w.dg = p; p += st;
     w.dkv = p; p += st;
@@ -160,6 +163,8 @@ inline bool sp_shape_ok(int D, unsigned flags) { return (D & 7) == 0 && !(flags 
 inline bool view_ok16m(const mhla_mview& v) { return v.ptr && ((uintptr_t)v.ptr % 16) == 0 && ((v.sb | v.sn | v.sh) & 7) == 0; }
 // bf16 block summaries (and single-bf16 intermediate operands): only when the caller asked for them (MHLA_FLAG_BF16_SUMMARIES)
 inline bool bm_sum16(int D, int dtype, unsigned flags) { return dtype == MHLA_BF16 && sp_shape_ok(D, flags) && (flags & MHLA_FLAG_BF16_SUMMARIES); }
+// 16-bit tensors at the default arithmetic: the forward keeps what its store of O rounded away (BmWs::olo) for the backward
+inline bool bm_olo(int D, int dtype, unsigned flags) { return dtype != MHLA_F32 && !bm_sum16(D, dtype, flags); }
 // the bf16-summary fast path (fused.hpp): its summaries are single bf16 values, so it serves the opt-in arithmetic only
 inline bool fast_shape_ok(int M, int D, int dtype, bool split, unsigned flags) {
     return dtype == MHLA_BF16 && D == 64 && M <= 64 && !split && (flags & MHLA_FLAG_BF16_SUMMARIES);
@@ -179,7 +184,7 @@ inline int bm_check(int B, int H, int M, int S, int D, int dtype, unsigned flags
     if (D % 4) return fail(MHLA_EINVAL, "D=%d must be a multiple of 4", D);
     if (!dt_for(D)) return fail(MHLA_ENOTSUP, "block-mix head dim D=%d > 128 not supported", D);
     if (dtype < 0 || dtype > 2) return fail(MHLA_EINVAL, "unknown dtype %d", dtype);
-    if (flags & ~(MHLA_FLAG_RELU_EPS | MHLA_FLAG_FORCE_GENERIC | MHLA_FLAG_NO_SMALLN | MHLA_FLAG_BF16_SUMMARIES)) return fail(MHLA_EINVAL, "unknown flags 0x%x", flags);
+    if (flags & ~(MHLA_FLAG_RELU_EPS | MHLA_FLAG_FORCE_GENERIC | MHLA_FLAG_NO_SMALLN | MHLA_FLAG_BF16_SUMMARIES | MHLA_FLAG_NO_BWD_STATE)) return fail(MHLA_EINVAL, "unknown flags 0x%x", flags);
     if ((flags & MHLA_FLAG_RELU_EPS) && split) return fail(MHLA_EINVAL, "MHLA_FLAG_RELU_EPS needs q_den/k_den to alias q_num/k_num");
     if ((size_t)B * H > 65535) return fail(MHLA_ENOTSUP, "B*H=%zu exceeds grid limit 65535", (size_t)B * H);
     (void)normalize;
@@ -199,6 +204,7 @@ struct BmCall {
     hipStream_t st;
     const float *rcos, *rsin; long ldr;
     const float* nw; float neps; int out_dtype;
+    unsigned short* olo_own;   // backward: the O-residual region of the backward's OWN workspace (w.olo may point into the kept forward workspace)
 };
 template <typename ET, bool S16> int bm_fwd_typed(const BmCall& c);   // S16: bf16 block summaries (bf16 tensors + MHLA_FLAG_BF16_SUMMARIES)
 template <typename ET, bool S16> int bm_bwd_typed(const BmCall& c);

@@ -125,6 +125,18 @@ template <> struct Io<f16_t> {
     }
 };
 
+// What a 16-bit store of x loses: x - fl_T(x), as bf16 (the "lo" half of a result kept at fp32 grade next to its stored value).
+// The block-mix forward writes it for O beside the output tensor when the backward will want the row dots dO . O at the
+// reference's fp32 accuracy (the rounding of O alone costs them 2e-3, which small block counts do not average away).
+template <typename T> __device__ __forceinline__ float stored_value(float x);
+template <> __device__ __forceinline__ float stored_value<float>(float x) { return x; }
+template <> __device__ __forceinline__ float stored_value<bf16_t>(float x) { return bf16_to_f32(cvt_bf16(x)); }
+template <> __device__ __forceinline__ float stored_value<f16_t>(float x) { return (float)(_Float16)x; }
+template <typename T> __device__ __forceinline__ uint2 store_residual4(f32x4 x) {
+    return make_uint2(pack_bf16x2(x[0] - stored_value<T>(x[0]), x[1] - stored_value<T>(x[1])),
+                      pack_bf16x2(x[2] - stored_value<T>(x[2]), x[3] - stored_value<T>(x[3])));
+}
+
 // Token-major view [B, N, H, D]; element strides; D contiguous.
 struct View {
     const void* ptr;

@@ -460,7 +460,7 @@ __global__ __launch_bounds__(SN_TB, 2) void k_sn_bwd(const SnArgs a) {
     for (int x = 0; x < 2; ++x) {
         sn_issue_rows<KS>(qraw[x], qb, a.q.sn, idx, blk[x] * 16, D, lane);
         sn_issue_rows<KS>(graw[x], gb, a.dout.sn, idx, blk[x] * 16, D, lane);
-        if (a.normalize) sn_issue_rows<KS>(oraw[x], ob, a.o.sn, idx, blk[x] * 16, D, lane);
+        if (a.normalize && !HL) sn_issue_rows<KS>(oraw[x], ob, a.o.sn, idx, blk[x] * 16, D, lane);   // (HL: the row dots come out of pass A)
     }
     // ---- P0 / P1: K, V tiles; ksum ----
     __shared__ float Wsh[16 * 17];   // mixing weights (M <= 16), read in every inner loop
@@ -489,16 +489,18 @@ __global__ __launch_bounds__(SN_TB, 2) void k_sn_bwd(const SnArgs a) {
             if (x == 0 ? hasA : hasB) {
                 const int i = blk[x];
                 bf16x8 oa[KS];
-                sn_finish_rows<KS>(oa, oraw[x], D, 0.f, lane, false);
+                if constexpr (!HL) sn_finish_rows<KS>(oa, oraw[x], D, 0.f, lane, false);
                 float z = 0.f, rd = 0.f;
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                     if (ks * 32 + kg * 8 < D) {
-                        const s16x8 qs = __builtin_bit_cast(s16x8, qa[x][ks]), gs = __builtin_bit_cast(s16x8, ga[x][ks]), os = __builtin_bit_cast(s16x8, oa[ks]);
+                        const s16x8 qs = __builtin_bit_cast(s16x8, qa[x][ks]), gs = __builtin_bit_cast(s16x8, ga[x][ks]);
 #pragma unroll
-                        for (int t = 0; t < 8; ++t) {
-                            z += bf((u16)qs[t]) * ksum_s[i * DP + ks * 32 + kg * 8 + t];
-                            rd += bf((u16)gs[t]) * bf((u16)os[t]);
+                        for (int t = 0; t < 8; ++t) z += bf((u16)qs[t]) * ksum_s[i * DP + ks * 32 + kg * 8 + t];
+                        if constexpr (!HL) {
+                            const s16x8 os = __builtin_bit_cast(s16x8, oa[ks]);
+#pragma unroll
+                            for (int t = 0; t < 8; ++t) rd += bf((u16)gs[t]) * bf((u16)os[t]);
                         }
                     }
                 }
@@ -519,14 +521,17 @@ __global__ __launch_bounds__(SN_TB, 2) void k_sn_bwd(const SnArgs a) {
             dns[v] = -rds[v] * ni;
         }
         __syncthreads();
-        // ---- P4: dz = W^T dn ----
-        for (int v = tid; v < N; v += SN_TB) {
-            const int j = v >> 4, sx = v & 15;
-            float dz = 0.f;
-            for (int i = 0; i < M; ++i) dz += Wsh[i * 17 + j] * dns[i * 16 + sx];
-            dzs[v] = dz;
+        // ---- P4: dz = W^T dn ----   (HL: dn = -(dO . O) / n is formed in pass A, from the fp32 score tiles -- the stored, rounded O
+        // would cost the row dots 2e-3 -- and dz follows it)
+        if constexpr (!HL) {
+            for (int v = tid; v < N; v += SN_TB) {
+                const int j = v >> 4, sx = v & 15;
+                float dz = 0.f;
+                for (int i = 0; i < M; ++i) dz += Wsh[i * 17 + j] * dns[i * 16 + sx];
+                dzs[v] = dz;
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
     trace_mark(a.trace, 4);
 
@@ -575,13 +580,13 @@ __global__ __launch_bounds__(SN_TB, 2) void k_sn_bwd(const SnArgs a) {
                     // dW[i][j] = sum(dP . S) + sum_s dn_i[s] z_j[s]: lane partials, reduced once per query block below
                     float e0 = s0[x][0] * p0[x][0] + s0[x][1] * p0[x][1] + s0[x][2] * p0[x][2] + s0[x][3] * p0[x][3];
                     float e1 = s1[x][0] * p1[x][0] + s1[x][1] * p1[x][1] + s1[x][2] * p1[x][2] + s1[x][3] * p1[x][3];
-                    if (a.normalize && kg == 0) {
+                    const float w0 = Wsh[i * 17 + j0], w1 = has1 ? Wsh[i * 17 + j1] : 0.f;
+                    if (!HL && a.normalize && kg == 0) {
                         e0 += dns[i * 16 + n] * zs[j0 * 16 + n];
                         e1 += dns[i * 16 + n] * zs[j1 * 16 + n];
                     }
                     ew[x][j0] = e0;
                     ew[x][j0 + 1] = has1 ? e1 : 0.f;
-                    const float w0 = Wsh[i * 17 + j0], w1 = has1 ? Wsh[i * 17 + j1] : 0.f;
                     if constexpr (HL) sn_pack_pair_hl(p0[x] * w0, p1[x] * w1, da[x], dl[x]);
                     else da[x] = sn_pack_pair(p0[x] * w0, p1[x] * w1);      // dS^T pair -> A operand (m = s, k-slots = t)
                 }
@@ -597,12 +602,53 @@ __global__ __launch_bounds__(SN_TB, 2) void k_sn_bwd(const SnArgs a) {
                 }
             }
         }
+        // HL: per-lane partials of the row dot (dO . O)[s = n] = sum_j W_ij sum_t S[s][t] dP[s][t] -- the lane's dW partials, weighted
+        float rdl[2] = {0.f, 0.f};
+        if constexpr (HL) {
+            asm volatile("" ::: "memory");   // (keeps the 32 weight reads below from being hoisted above the block loop: +32 live registers there, 131 spilled)
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) rdl[x] += Wsh[blk[x] * 17 + j] * ew[x][j];
+        }
+        float totx[2];
+#pragma unroll
+        for (int x = 0; x < 2; ++x) totx[x] = wave_reduce16(ew[x], lane);
+        const int jw = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
+        if constexpr (HL) {
+            if (a.normalize) {   // (uniform)
+#pragma unroll
+                for (int x = 0; x < 2; ++x) {
+                    float rd = rdl[x];
+                    rd += __shfl_xor(rd, 16, 64);
+                    rd += __shfl_xor(rd, 32, 64);
+                    if ((x == 0 ? hasA : hasB) && kg == 0) dns[blk[x] * 16 + n] = -rd * nis[blk[x] * 16 + n];
+                }
+                __syncthreads();
+                for (int v = tid; v < N; v += SN_TB) {   // dz = W^T dn
+                    const int j = v >> 4, sx = v & 15;
+                    float dz = 0.f;
+                    for (int i = 0; i < M; ++i) dz += Wsh[i * 17 + j] * dns[i * 16 + sx];
+                    dzs[v] = dz;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int x = 0; x < 2; ++x) {   // dW[i][jw] += <dn_i, z_jw>: the four lanes of a quad take four positions each
+                    const int i = blk[x], jc = min(jw, M - 1), s4 = (lane & 3) * 4;
+                    float t = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) t += dns[i * 16 + s4 + r] * zs[jc * 16 + s4 + r];
+                    t += __shfl_xor(t, 1, 64);
+                    t += __shfl_xor(t, 2, 64);
+                    totx[x] += t;
+                }
+            }
+        }
 #pragma unroll
         for (int x = 0; x < 2; ++x) {
             const int i = blk[x];
             const bool live = x == 0 ? hasA : hasB;
-            const float tot = wave_reduce16(ew[x], lane);
-            const int jw = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
+            const float tot = totx[x];
             if (live && (lane & 3) == 0 && jw < M) dwp[i * M + jw] = tot;
             if (live) {
                 // epilogue: + dz (x) ksum ; stage ; masked store

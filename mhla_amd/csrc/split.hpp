@@ -151,6 +151,12 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : (ROPE ? 2 : 3)) void k_sp_state
     const T* kdq = den ? kdb : kb;                  // (uniform selects)
     const long kdsn = den ? third.sn : a.x.sn;
     const float* nvp = (MODE == 1 && a.normalize) ? ninvb : reinterpret_cast<const float*>(a.x.ptr);
+    // MODE 1, 16-bit tensors at the default arithmetic: the residual of the forward's store of O (StateArgs::olo), fetched with
+    // the rows (unconditionally: without it, the first bytes of x, dropped in `settle`)
+    constexpr bool OLO = MODE == 1 && !S16 && sizeof(T) == 2;
+    const bool olo_on = OLO && a.normalize && a.olo != nullptr;
+    const u16* olop = olo_on ? a.olo + ((long)bh * a.M * S + p0) * D + cgc : reinterpret_cast<const u16*>(a.x.ptr);
+    uint4 ox[OLO ? IT : 1];
     auto fetch = [&](int c0) {
         crow = c0;
 #pragma unroll
@@ -161,6 +167,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : (ROPE ? 2 : 3)) void k_sp_state
             ld8(vb + row * a.y.sn + cgc, vx[it][0], vx[it][1]);
             ld8(kdq + row * kdsn + cgc, dx[it][0], dx[it][1]);
             nv[it] = gld<float>(nvp + ((MODE == 1 && a.normalize) ? rcl : 0));
+            if constexpr (OLO) ox[it] = gld<uint4>(olop + (olo_on ? (long)rcl * D : 0));
             if constexpr (rope) {
                 rc[it] = *reinterpret_cast<const f32x4*>(a.rcos + row * a.ldr + cgc / 2);
                 rs[it] = *reinterpret_cast<const f32x4*>(a.rsin + row * a.ldr + cgc / 2);
@@ -178,6 +185,17 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : (ROPE ? 2 : 3)) void k_sp_state
             kx[it][0] = valid ? kx[it][0] : z4; kx[it][1] = valid ? kx[it][1] : z4;
             vx[it][0] = valid ? vx[it][0] : z4; vx[it][1] = valid ? vx[it][1] : z4;
             dx[it][0] = (valid && den) ? dx[it][0] : z4; dx[it][1] = (valid && den) ? dx[it][1] : z4;
+            if constexpr (OLO) {   // O = stored value + what the store rounded away
+                const unsigned w[4] = {ox[it].x, ox[it].y, ox[it].z, ox[it].w};
+                const bool on = valid && olo_on;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    dx[it][0][2 * i] += on ? __uint_as_float(w[i] << 16) : 0.f;
+                    dx[it][0][2 * i + 1] += on ? __uint_as_float(w[i] & 0xffff0000u) : 0.f;
+                    dx[it][1][2 * i] += on ? __uint_as_float(w[2 + i] << 16) : 0.f;
+                    dx[it][1][2 * i + 1] += on ? __uint_as_float(w[2 + i] & 0xffff0000u) : 0.f;
+                }
+            }
             nv[it] = (valid && MODE == 1 && a.normalize) ? nv[it] : 1.f;
             if constexpr (rope) {   // padded rows: 0 * (uninitialised angle) could be NaN
                 rc[it] = valid ? rc[it] : z4;
@@ -1108,8 +1126,17 @@ __global__ __launch_bounds__(SP_OUT_T, EPI ? SP_OUT_EPI_WAVES : 2) void k_sp_out
                 res[ct] = c0 * ninv;
                 res[ct + 1] = c1 * ninv;
             } else if (s < S) {
-                if (ct * 16 + kg * 4 < D) Io<TO>::st4(orow + ct * 16, c0 * ninv);
-                if (ct * 16 + 16 + kg * 4 < D) Io<TO>::st4(orow + ct * 16 + 16, c1 * ninv);
+                if (!a.skip_out) {
+                    if (ct * 16 + kg * 4 < D) Io<TO>::st4(orow + ct * 16, c0 * ninv);
+                    if (ct * 16 + 16 + kg * 4 < D) Io<TO>::st4(orow + ct * 16 + 16, c1 * ninv);
+                }
+                if constexpr (sizeof(TO) == 2) {
+                    if (a.olo) {   // what the 16-bit store loses, for the backward's row dots (OutArgs::olo)
+                        u16* lo = a.olo + ((long)bh * a.M * S + p0 + s) * D + kg * 4;
+                        if (ct * 16 + kg * 4 < D) *reinterpret_cast<uint2*>(lo + ct * 16) = store_residual4<TO>(c0 * ninv);
+                        if (ct * 16 + 16 + kg * 4 < D) *reinterpret_cast<uint2*>(lo + ct * 16 + 16) = store_residual4<TO>(c1 * ninv);
+                    }
+                }
             }
         }
         if constexpr (EPI) {

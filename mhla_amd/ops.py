@@ -278,6 +278,8 @@ def mhla_blockmix(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, W: torch.Te
         raise ValueError(f"q: expected [B, N, H, D], got {tuple(q.shape)}")
     _check_block_index(block_index, q.shape[1], q)
     flags = _bm_flags(relu_eps, force_generic, no_smalln, summaries)
+    if not (torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (q, k, v, W, q_den, k_den))):
+        flags |= _lib.FLAG_NO_BWD_STATE   # inference: the forward skips what only a backward would read
     if q.shape[0] == 0:   # empty batch: nothing to launch; keep the autograd graph connected (all gradients are zero)
         return torch.zeros_like(v) + 0 * (q.sum() + k.sum() + W.sum()).to(v.dtype)
     nb = _MAX_GRID_BH // q.shape[2]
@@ -634,7 +636,10 @@ def mhla_dit_core(qkv: torch.Tensor, W: torch.Tensor, lepe_weight: torch.Tensor,
         raise ValueError("qkv: [B, N, 3, H, D]")
     if qkv.shape[1] % W.shape[0] or qkv.shape[1] != (pieces_len * block_len) ** 2:
         raise ValueError("token count does not match the block layout")
-    return _DitCore.apply(qkv, W, lepe_weight, lepe_bias, int(pieces_len), int(block_len), eps, _bm_flags(relu_eps, False, False, summaries))
+    flags = _bm_flags(relu_eps, False, False, summaries)
+    if not (torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (qkv, W, lepe_weight, lepe_bias))):
+        flags |= _lib.FLAG_NO_BWD_STATE
+    return _DitCore.apply(qkv, W, lepe_weight, lepe_bias, int(pieces_len), int(block_len), eps, flags)
 
 
 _FMAPS = {None: 0, "identity": 0, "relu": 1, "elu": 2}
