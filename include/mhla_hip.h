@@ -86,6 +86,13 @@ int mhla_abi_version(void);
 const char* mhla_build_flags(void);
 const char* mhla_last_error(void);
 
+/* Process-wide options.  "bwd_two_launches" (0 / 1): run the two tile roles of the bf16-summary fast path's backward as two
+ * launches instead of one fused launch with an in-launch hand-over; the library sets it itself, asynchronously and without any
+ * synchronisation, after a fused launch reported an expired hand-over (see mhla_blockmix_bwd_status).  "debug_drop_signal" (0 / 1):
+ * testing aid for that bounded wait.  Initial values: MHLA_BWD_TWO_LAUNCHES=1 / MHLA_DEBUG_DROP_SIGNAL in the environment when the
+ * library is loaded.  Returns the previous value, MHLA_EINVAL for an unknown name. */
+int mhla_set_option(const char* name, int value);
+
 /* Profiling aid (used by bench.py): when enabled, every kernel launch is bracketed by hipEvents on
  * its own stream; mhla_prof_report waits for them, writes one "kernel_name count total_ms" line per
  * kernel into buf (NUL-terminated, truncated to cap) and clears the records.  Off by default. */
@@ -195,7 +202,8 @@ int mhla_blockmix_rope_bwd(mhla_view q, mhla_view k, mhla_view v, int normalize,
  * waiter that gives up raises an error word in the workspace.  This call synchronises `stream`, reads the word and returns
  * MHLA_ELAUNCH if it is set (dk is then invalid), MHLA_OK otherwise -- also for problems that take another path.
  * Replaces nothing in the reference (mhla_dit/mhla/mhla.py:262-268 is a sequence of separate kernels); it is the fail-safe
- * of this library's own fusion.  MHLA_BWD_TWO_LAUNCHES=1 in the environment runs the two roles as two launches instead. */
+ * of this library's own fusion.  Without this call the failure is still loud (dk = NaN) and self-healing: the library reads the
+ * word asynchronously after every fused launch and runs the two roles as two launches from the next backward on (mhla_set_option). */
 int mhla_blockmix_bwd_status(const void* ws, size_t ws_bytes, int B, int H, int M, int S, int D, int dtype, int split,
                              unsigned flags, void* stream);
 

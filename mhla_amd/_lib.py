@@ -31,6 +31,7 @@ SIGNATURES = {
     "mhla_abi_version": (c_int, []),
     "mhla_build_flags": (c_char_p, []),
     "mhla_last_error": (c_char_p, []),
+    "mhla_set_option": (c_int, [c_char_p, c_int]),
     "mhla_prof_enable": (None, [c_int]),
     "mhla_prof_report": (c_int, [c_char_p, c_size_t]),
     "mhla_debug_set_trace": (None, [c_void_p]),

@@ -83,6 +83,62 @@ FastWs fast_carve(void* ws, int B, int H, int M, int S) {
     w.total_bwd = (size_t)(p - (char*)ws);
     return w;
 }
+// ---- process-wide options of the fused token-gradient launch (read ONCE, at library load, from the environment; changed afterwards
+// only through mhla_set_option) ----
+std::atomic<int> g_two_launches{[] { const char* e = getenv("MHLA_BWD_TWO_LAUNCHES"); return (e && e[0] == '1') ? 1 : 0; }()};
+std::atomic<int> g_drop_signal{getenv("MHLA_DEBUG_DROP_SIGNAL") != nullptr ? 1 : 0};
+
+// Self-healing of the in-launch hand-over (fused.hpp, tile_wait): every fused launch is followed by an asynchronous copy of its
+// error word into a pinned host slot (+ an event on the same stream); the NEXT backward of this process looks at the slots whose
+// event has completed -- no synchronisation anywhere -- and the first raised word latches the process to the two-launch form
+// (the kernel boundary then orders the hand-over, whatever the dispatch order is) and says so once on stderr.
+struct HandoverWatch {
+    static constexpr int SLOTS = 64;
+    std::mutex mu;
+    int* host = nullptr;              // pinned, SLOTS words
+    hipEvent_t ev[SLOTS] = {};
+    bool pending[SLOTS] = {};
+    int next = 0;
+    bool warned = false;
+    void poll() {   // (mu held)
+        for (int i = 0; i < SLOTS; ++i) {
+            if (!pending[i] || hipEventQuery(ev[i]) != hipSuccess) continue;
+            pending[i] = false;
+            if (host[i] != 0) {
+                g_two_launches.store(1);
+                if (!warned) {
+                    warned = true;
+                    fprintf(stderr, "[mhla] a dK/dV tile of the fused token-gradient launch gave up waiting for its dQ tile's hand-over (that "
+                                    "backward's dk is NaN); this process runs the two roles as two launches from now on\n");
+                }
+            }
+        }
+        (void)hipGetLastError();   // (hipEventQuery's hipErrorNotReady is not an error of the caller)
+    }
+    void watch(const int* err_word, hipStream_t st) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return; }   // a graph cannot adapt anyway
+        std::lock_guard<std::mutex> lk(mu);
+        if (!host && hipHostMalloc((void**)&host, SLOTS * sizeof(int), hipHostMallocDefault) != hipSuccess) { host = nullptr; (void)hipGetLastError(); return; }
+        poll();
+        int i = next;
+        for (int t = 0; t < SLOTS && pending[i]; ++t) i = (i + 1) % SLOTS;
+        if (pending[i]) return;       // every slot still in flight: skip this one
+        next = (i + 1) % SLOTS;
+        if (!ev[i] && hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) { ev[i] = nullptr; (void)hipGetLastError(); return; }
+        host[i] = 0;
+        if (hipMemcpyAsync(&host[i], err_word, sizeof(int), hipMemcpyDeviceToHost, st) == hipSuccess && hipEventRecord(ev[i], st) == hipSuccess)
+            pending[i] = true;
+        else
+            (void)hipGetLastError();
+    }
+    void check() {
+        std::lock_guard<std::mutex> lk(mu);
+        if (host) poll();
+    }
+};
+HandoverWatch g_watch;
+
 // Error word of the fused token-gradient launch: the LAST 16 bytes of the backward workspace (mhla_blockmix_bwd_ws_bytes), behind
 // the carve of every path a problem may take.  Every backward of a shape that can take the fast path leaves a defined word there:
 // the fast path clears it in k_fs_dw and raises it in k_tile_bwd; when such a shape falls back to another path (misaligned views,
@@ -147,6 +203,17 @@ int mhla_prof_report(char* buf, size_t cap) {
     return (int)n;
 }
 const char* mhla_last_error(void) { return g_err; }
+
+// Process-wide options (the two environment variables of the same meaning are read once, when the library is loaded):
+//   "bwd_two_launches"   1: the backward's dQ and dK/dV tile roles as two launches (also latched by the library itself after a
+//                        hand-over expired), 0: one fused launch
+//   "debug_drop_signal"  testing aid: the dQ role does not raise its hand-over flags
+// Returns the previous value, or MHLA_EINVAL for an unknown name.
+int mhla_set_option(const char* name, int value) {
+    if (name && !strcmp(name, "bwd_two_launches")) return g_two_launches.exchange(value != 0);
+    if (name && !strcmp(name, "debug_drop_signal")) return g_drop_signal.exchange(value != 0);
+    return fail(MHLA_EINVAL, "mhla_set_option: unknown option '%s'", name ? name : "(null)");
+}
 
 void mhla_debug_set_trace(void* buf) { g_trace = (unsigned long long*)buf; }
 
@@ -379,16 +446,17 @@ static int bm_bwd_impl(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view 
             ta.trace = tr ? tr + ntile_wgs * fast::TRACE_SLOTS : nullptr;
             ta.dwp = f.dwp; ta.dW = dW; ta.nparts = B * H * fast::DW_SPLIT; ta.ntiles = (int)ntile_wgs; ta.done = f.done;
             ta.err = f.err;
-            ta.drop_signal = getenv("MHLA_DEBUG_DROP_SIGNAL") != nullptr;   // testing aid for the bounded wait (looked up per call)
-            const char* const two = getenv("MHLA_BWD_TWO_LAUNCHES");   // fallback (looked up per call): dQ tiles and dK/dV tiles as two launches
+            ta.drop_signal = g_drop_signal.load();   // testing aid for the bounded wait (mhla_set_option)
+            g_watch.check();                          // did an earlier fused launch of this process report an expired hand-over?
             const auto tile_bwd = f.cs > 1 ? fast::k_tile_bwd<16, true> : fast::k_tile_bwd<16, false>;   // (multi-chunk blocks: cs workgroups per tile)
-            if (two && two[0] == '1') {   // (the kernel boundary orders dksum and the flags: the wait returns at its first poll)
+            if (g_two_launches.load()) {   // (the kernel boundary orders dksum and the flags: the wait returns at its first poll)
                 RC(launch(tile_bwd, dim3((unsigned)ntile_wgs), dim3(fast::FT8), fast::tile_smem<16>(), st, "k_t16_bwd_dq", ta));
                 ta.x0 = (int)ntile_wgs;
                 RC(launch(tile_bwd, dim3((unsigned)ntile_wgs + fast::DWR_WGS), dim3(fast::FT8), fast::tile_smem<16>(), st, "k_t16_bwd_dkv", ta));
                 return MHLA_OK;
             }
             RC(launch(tile_bwd, dim3((unsigned)(2 * ntile_wgs) + fast::DWR_WGS), dim3(fast::FT8), fast::tile_smem<16>(), st, "k_t16_bwd", ta));
+            if (normalize) g_watch.watch(f.err, st);
             return MHLA_OK;
         }
     }
@@ -470,7 +538,7 @@ int mhla_blockmix_bwd_status(const void* ws, size_t ws_bytes, int B, int H, int 
     if (e != hipSuccess) return fail(MHLA_ELAUNCH, "mhla_blockmix_bwd_status: %s", hipGetErrorString(e));
     if (word != 0)
         return fail(MHLA_ELAUNCH, "k_t16_bwd: a dK/dV tile gave up waiting for its dQ tile's dksum rows (hand-over flag never raised); "
-                                  "dk is invalid -- set MHLA_BWD_TWO_LAUNCHES=1 to run the two roles as separate launches");
+                                  "dk is invalid -- the library switches this process to two launches on its own at its next backward (mhla_set_option(\"bwd_two_launches\", 1) forces it)");
     return MHLA_OK;
 }
 

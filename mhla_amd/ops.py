@@ -28,9 +28,24 @@ def _native_nodes() -> bool:
 # (batch, head) pairs one launch of the library addresses (grid.y); larger batches are sliced by the operators below
 _MAX_GRID_BH = 65535
 
-# forward workspaces up to this size are kept alive for the backward (block / chunk summaries: the causal pipeline's hi + lo
-# chunk summaries of the 1.3B-like fla shape are 1.07 GB at B = 2; beyond the limit the backward recomputes them)
+# Forward workspaces up to these sizes are kept alive for the backward (block / chunk summaries); beyond the limit the backward
+# recomputes them.  The memory is held per LAYER between its forward and its backward: the causal pipeline's hi + lo chunk
+# summaries are 0.54 GB per layer at the 340M fla shape (B = 4, T = 8192) and 1.07 GB at the 1.3B-like one (B = 2) -- 13 / 26 GB
+# over 24 layers -- so the causal operator has its own limit; `set_keep_state_limits` (or the fla layer's `keep_state_limit`
+# argument) lowers it where memory matters more than the ~25 % of the backward the recomputation costs.
 KEEP_STATE_LIMIT_BYTES = 4 << 30
+CAUSAL_KEEP_STATE_LIMIT_BYTES = 4 << 30
+
+
+def set_keep_state_limits(blockmix: Optional[int] = None, causal: Optional[int] = None):
+    """Largest forward workspace (bytes) each operator keeps alive for its backward; 0 = always recompute.  Returns the pair in
+    force.  Process-wide defaults; `mhla_causal(..., keep_state_limit=...)` overrides per call."""
+    global KEEP_STATE_LIMIT_BYTES, CAUSAL_KEEP_STATE_LIMIT_BYTES
+    if blockmix is not None:
+        KEEP_STATE_LIMIT_BYTES = int(blockmix)
+    if causal is not None:
+        CAUSAL_KEEP_STATE_LIMIT_BYTES = int(causal)
+    return KEEP_STATE_LIMIT_BYTES, CAUSAL_KEEP_STATE_LIMIT_BYTES
 
 _DTYPES = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16, torch.float16: _lib.F16}
 
@@ -770,7 +785,7 @@ def qk_prologue(x: torch.Tensor, weight: Optional[torch.Tensor], norm_eps: float
 class _Causal(torch.autograd.Function):
     @staticmethod
     @_device_guard
-    def forward(ctx, q, k, v, mix, chunk_size, scale, flags):
+    def forward(ctx, q, k, v, mix, chunk_size, scale, flags, keep_limit):
         lib = _lib.load()
         _require_gpu(q, k, v, mix)
         B, T, H, K = q.shape
@@ -791,7 +806,7 @@ class _Causal(torch.autograd.Function):
                                  _dtype_code(q), flags, _stream())
         _lib.check(rc, "mhla_causal_fwd")
         # keep the chunk summaries (S_j and their prefix mixes) for the backward unless they are very large
-        keep = ws.numel() * 4 <= KEEP_STATE_LIMIT_BYTES and any(ctx.needs_input_grad[:4])
+        keep = ws.numel() * 4 <= keep_limit and any(ctx.needs_input_grad[:4])
         ctx.save_for_backward(q, k, v, mixf, ws if keep else None)
         ctx.cfg = (chunk_size, float(scale), mix.shape, mix.dtype, flags)
         return out
@@ -817,7 +832,7 @@ class _Causal(torch.autograd.Function):
                                  ws.data_ptr(), ws.numel() * 4, fwd_ws.data_ptr() if fwd_ws is not None else None,
                                  B, T, H, K, V, chunk_size, scale, _dtype_code(q), flags, _stream())
         _lib.check(rc, "mhla_causal_bwd")
-        return dq, dk, dv, dmix.reshape(mix_shape).to(mix_dtype), None, None, None
+        return dq, dk, dv, dmix.reshape(mix_shape).to(mix_dtype), None, None, None, None
 
 
 def _causal_flags(summaries: str, force_generic: bool) -> int:
@@ -828,7 +843,7 @@ def _causal_flags(summaries: str, force_generic: bool) -> int:
 
 def mhla_causal(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mixing_matrix: torch.Tensor,
                 chunk_size: int = 64, scale: Optional[float] = None, *, summaries: str = "split",
-                force_generic: bool = False) -> torch.Tensor:
+                force_generic: bool = False, keep_state_limit: Optional[int] = None) -> torch.Tensor:
     """Causal chunk-mixing MHLA operator (naive_chunk_simple_mhla_fixed,
     mhla_nlp/fla/ops/mhla/naive.py:10-83).  q, k: [B, T, H, K]; v: [B, T, H, V];
     mixing_matrix: [L, L] or [L, L, 1, 1, 1, 1], L >= ceil(T / chunk_size).  fp32 compute, output in
@@ -836,9 +851,15 @@ def mhla_causal(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mixing_matrix
     summaries: how bf16 problems keep the chunk summaries S, P, dP, dS and the score tiles between their two contractions --
     "split" (default): bf16 hi + lo pairs, >= 16 significand bits, the reference's fp32 arithmetic (naive.py:39, :60-78);
     "bf16": one bf16 value each -- REDUCED PRECISION (2-3e-3 of the result's maximum), half the summary traffic.
-    force_generic: testing aid -- the generic fp32-MFMA kernels for every shape."""
+    force_generic: testing aid -- the generic fp32-MFMA kernels for every shape.
+    keep_state_limit: largest forward workspace (bytes: the chunk summaries S, P -- 8 B T H K V / 64 bytes with hi + lo pairs)
+    kept alive for the backward; above it the backward recomputes them.  Default: ops.CAUSAL_KEEP_STATE_LIMIT_BYTES
+    (set_keep_state_limits)."""
     if q.dim() != 4 or v.dim() != 4:
         raise ValueError("q, k: [B, T, H, K], v: [B, T, H, V]")
+    if int(chunk_size) <= 0:
+        raise ValueError(f"chunk_size must be positive, got {chunk_size}")
+    keep_limit = CAUSAL_KEEP_STATE_LIMIT_BYTES if keep_state_limit is None else int(keep_state_limit)
     flags = _causal_flags(summaries, force_generic)
     if scale is None:
         scale = q.shape[-1] ** -0.5
@@ -846,11 +867,11 @@ def mhla_causal(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mixing_matrix
         return torch.zeros_like(v) + 0 * (q.sum() + k.sum() + mixing_matrix.sum()).to(v.dtype)
     nb = _MAX_GRID_BH // q.shape[2]
     if q.shape[0] > nb:   # see mhla_blockmix
-        return torch.cat([_Causal.apply(q[i:i + nb], k[i:i + nb], v[i:i + nb], mixing_matrix, int(chunk_size), scale, flags)
+        return torch.cat([_Causal.apply(q[i:i + nb], k[i:i + nb], v[i:i + nb], mixing_matrix, int(chunk_size), scale, flags, keep_limit)
                           for i in range(0, q.shape[0], nb)], dim=0)
     if _native_nodes():
-        return torch.ops.mhla_amd.causal(q, k, v, mixing_matrix, int(chunk_size), float(scale), flags, KEEP_STATE_LIMIT_BYTES)
-    return _Causal.apply(q, k, v, mixing_matrix, int(chunk_size), scale, flags)
+        return torch.ops.mhla_amd.causal(q, k, v, mixing_matrix, int(chunk_size), float(scale), flags, keep_limit)
+    return _Causal.apply(q, k, v, mixing_matrix, int(chunk_size), scale, flags, keep_limit)
 
 
 def naive_chunk_simple_mhla_fixed(q, k, v, mixing_matrix, output_final_state: bool = False, chunk_size: int = 64,
@@ -866,7 +887,7 @@ class _CausalNormGate(torch.autograd.Function):
 
     @staticmethod
     @_device_guard
-    def forward(ctx, q, k, v, mix, gate, weight, chunk_size, scale, norm_eps, flags):
+    def forward(ctx, q, k, v, mix, gate, weight, chunk_size, scale, norm_eps, flags, keep_limit):
         lib = _lib.load()
         _require_gpu(q, k, v, mix, gate, weight)
         B, T, H, K = q.shape
@@ -891,7 +912,7 @@ class _CausalNormGate(torch.autograd.Function):
                                           ws.data_ptr(), ws.numel() * 4, B, T, H, K, V, chunk_size, float(scale),
                                           _dtype_code(q), flags, _stream())
         _lib.check(rc, "mhla_causal_normgate_fwd")
-        keep = ws.numel() * 4 <= KEEP_STATE_LIMIT_BYTES and need_grad
+        keep = ws.numel() * 4 <= keep_limit and need_grad
         ctx.save_for_backward(q, k, v, mixf, out, gate, wf, ws if keep else None)
         ctx.cfg = (chunk_size, float(scale), float(norm_eps), mix.shape, mix.dtype, weight.dtype if weight is not None else None, flags)
         return y
@@ -928,7 +949,7 @@ class _CausalNormGate(torch.autograd.Function):
                                  B, T, H, K, V, chunk_size, scale, _dtype_code(q), flags, _stream())
         _lib.check(rc, "mhla_causal_bwd")
         dw = dwp.sum(0).to(w_dtype) if wf is not None else None
-        return dq, dk, dv, dmix.reshape(mix_shape).to(mix_dtype), dg, dw, None, None, None, None
+        return dq, dk, dv, dmix.reshape(mix_shape).to(mix_dtype), dg, dw, None, None, None, None, None
 
 
 def causal_normgate_fusable(q: torch.Tensor, v: torch.Tensor, chunk_size: int = 64, flags: int = 0) -> bool:
@@ -941,17 +962,22 @@ def causal_normgate_fusable(q: torch.Tensor, v: torch.Tensor, chunk_size: int = 
 
 def mhla_causal_normgate(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mixing_matrix: torch.Tensor,
                          gate: Optional[torch.Tensor], weight: Optional[torch.Tensor], norm_eps: float = 1e-5,
-                         chunk_size: int = 64, scale: Optional[float] = None, *, summaries: str = "split") -> torch.Tensor:
+                         chunk_size: int = 64, scale: Optional[float] = None, *, summaries: str = "split",
+                         keep_state_limit: Optional[int] = None) -> torch.Tensor:
     """`rmsnorm_gate(mhla_causal(q, k, v, mix), gate, weight, norm_eps)` -- the fla layer's operator + FusedRMSNormGated
     (mhla_nlp/fla/layers/mhla.py:330-355).  Where the fused epilogue applies (bf16, K, V multiples of 64, K <= 256, V <= 256 or
     384 / 512, at most 256 chunks) the norm x gate runs inside the operator's output kernel; other shapes compose the two HIP operators.
-    `summaries`: see mhla_causal."""
+    `summaries`, `keep_state_limit`: see mhla_causal."""
+    if int(chunk_size) <= 0:
+        raise ValueError(f"chunk_size must be positive, got {chunk_size}")
     flags = _causal_flags(summaries, False)
     if scale is None:
         scale = q.shape[-1] ** -0.5
     if not causal_normgate_fusable(q, v, chunk_size, flags):
-        return rmsnorm_gate(mhla_causal(q, k, v, mixing_matrix, chunk_size, scale, summaries=summaries), gate, weight, norm_eps)
-    return _CausalNormGate.apply(q, k, v, mixing_matrix, gate, weight, int(chunk_size), scale, norm_eps, flags)
+        return rmsnorm_gate(mhla_causal(q, k, v, mixing_matrix, chunk_size, scale, summaries=summaries, keep_state_limit=keep_state_limit),
+                            gate, weight, norm_eps)
+    keep_limit = CAUSAL_KEEP_STATE_LIMIT_BYTES if keep_state_limit is None else int(keep_state_limit)
+    return _CausalNormGate.apply(q, k, v, mixing_matrix, gate, weight, int(chunk_size), scale, norm_eps, flags, keep_limit)
 
 
 def naive_recurrent_mhla(q, k, v, mixing_matrix, chunk_size: int = 64, scale: Optional[float] = None,

@@ -149,7 +149,7 @@ def test_causal_kept_summaries_match_recompute(dtype, monkeypatch):
     q, k, v, mix, do = causal_inputs(2, 300, 2, 64, 128, 8, dtype, seed=5)
     res = []
     for limit in (1 << 30, 0):
-        monkeypatch.setattr(ops, "KEEP_STATE_LIMIT_BYTES", limit)
+        monkeypatch.setattr(ops, "CAUSAL_KEEP_STATE_LIMIT_BYTES", limit)
         t = [x.to(DEV).requires_grad_(True) for x in (q, k, v, mix)]
         mhla_amd.mhla_causal(*t).backward(do.to(DEV))
         res.append([x.grad for x in t])

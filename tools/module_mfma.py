@@ -1,0 +1,134 @@
+#!/usr/bin/env python
+"""Module-level MFMA figure for north_star's ">= 40 % MFMA utilisation" (the only reading under which the target is
+checkable): the DiT-XL/2 attention module (LayerNorm -> QKV GEMM -> operator + LePE -> out GEMM; mhla_dit/mhla/mhla.py:250-275),
+forward + backward, B = 32 x 256 tokens, dim 1152, 16 heads of 72, bf16.
+
+  python tools/module_mfma.py run [iters]                 the workload (profiled by tools/prof_module_mfma.sh), prints its timing + FLOPs
+  python tools/module_mfma.py summarise <dir> <out.md> <out.json>     per-kernel table from the rocprofv3 CSVs of that script
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+PEAK_BF16_TFLOPS = 2500.0
+B, N, C, H, D, M = 32, 256, 1152, 16, 72, 16
+
+
+def flops():
+    gemm_fwd = 2 * B * N * C * (3 * C) + 2 * B * N * C * C        # to_qkv, to_out
+    gemm = 3 * gemm_fwd                                            # + dgrad + wgrad
+    op = B * H * (12 * N * D * D + 6 * M * M * D * D)              # SURVEY.md 8(d), summary form (algorithmic)
+    return gemm, op
+
+
+def run(iters):
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from mhla_amd.modules import MHLA4DiT
+    torch.manual_seed(0)
+    m = MHLA4DiT(C, H, qkv_bias=True, block_size=16, embed_len=256, dropout=0.0).to("cuda").to(torch.bfloat16)
+    x = torch.randn(B, N, C, device="cuda", dtype=torch.bfloat16, requires_grad=True)
+    dy = torch.randn(B, N, C, device="cuda", dtype=torch.bfloat16)
+    # calibration: one large hipBLASLt GEMM (what a busy matrix pipe looks like in the same counters)
+    a = torch.randn(8192, 8192, device="cuda", dtype=torch.bfloat16)
+    b = torch.randn(8192, 8192, device="cuda", dtype=torch.bfloat16)
+
+    def step():
+        y = m(x)
+        y.backward(dy)
+        x.grad = None
+        for p in m.parameters():
+            p.grad = None
+
+    for _ in range(3):
+        step()
+    (a @ b)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    e0.record()
+    for _ in range(3):
+        (a @ b)
+    e1.record()
+    torch.cuda.synchronize()
+    gms = e0.elapsed_time(e1) / 3
+    gemm, op = flops()
+    print(json.dumps({"module": "MHLA4DiT DiT-XL/2 256^2, B=32, bf16, fwd+bwd (eager)", "ms": ms, "gemm_gflop": gemm / 1e9, "op_gflop": op / 1e9,
+                      "mfma_flop_frac_of_bf16_dense_peak": (gemm + op) / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
+                      "calibration_gemm_8192^3_ms": gms, "calibration_gemm_tflops": 2 * 8192 ** 3 / (gms * 1e-3) / 1e12}))
+
+
+def _short(k):
+    k = k.split("(")[0].replace("void ", "")
+    for p in ("mhla::", "fast::", "sp::", "at::native::", "(anonymous namespace)::"):
+        k = k.replace(p, "")
+    return k[:70]
+
+
+def summarise(root, out_md, out_json):
+    dur = collections.defaultdict(list)
+    for f in glob.glob(root + "/trace/**/*kernel_trace.csv", recursive=True):
+        for row in csv.DictReader(open(f)):
+            dur[_short(row["Kernel_Name"])].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3)
+    cnt = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(root + "/sq*/**/*counter_collection.csv", recursive=True):
+        for row in csv.DictReader(open(f)):
+            cnt[_short(row["Kernel_Name"])][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    timing = {}
+    lg = os.path.join(root, "timing.json")
+    if os.path.exists(lg):
+        for line in open(lg):
+            if line.startswith("{"):
+                timing = json.loads(line)
+    rows = []
+    for k, v in dur.items():
+        c = {n: sum(x) / len(x) for n, x in cnt.get(k, {}).items()}
+        busy, sqb, waves, wc = c.get("SQ_VALU_MFMA_BUSY_CYCLES"), c.get("SQ_BUSY_CYCLES"), c.get("SQ_WAVES"), c.get("SQ_WAVE_CYCLES")
+        rows.append({"kernel": k, "launches": len(v), "avg_us": sum(v) / len(v), "total_us": sum(v),
+                     "mfma_busy_over_sq_busy": busy / sqb if busy is not None and sqb else None,
+                     "mfma_busy_share_of_wave_life": busy / (wc * 4) if busy is not None and wc else None})
+    rows.sort(key=lambda r: -r["total_us"])
+    tot = sum(r["total_us"] for r in rows if "Cijk" not in r["kernel"] or True)
+    cal = [r for r in rows if r["launches"] <= 8 and r["avg_us"] > 300 and "Cijk" in r["kernel"]]   # the 8192^3 calibration GEMM
+    cal_ratio = cal[0]["mfma_busy_over_sq_busy"] if cal else None
+    mod_rows = [r for r in rows if r not in cal]
+    mod_tot = sum(r["total_us"] for r in mod_rows)
+    wsum = sum(r["total_us"] * r["mfma_busy_over_sq_busy"] for r in mod_rows if r["mfma_busy_over_sq_busy"] is not None)
+    res = {"module_timing": timing, "calibration_gemm_mfma_busy_over_sq_busy": cal_ratio,
+           "module_time_weighted_mfma_busy_over_sq_busy": wsum / mod_tot if mod_tot else None,
+           "module_mfma_busy_relative_to_calibration_gemm": (wsum / mod_tot / cal_ratio) if mod_tot and cal_ratio else None,
+           "gemm_share_of_gpu_time": sum(r["total_us"] for r in mod_rows if "Cijk" in r["kernel"]) / mod_tot if mod_tot else None,
+           "mhla_share_of_gpu_time": sum(r["total_us"] for r in mod_rows if r["kernel"].startswith("k_")) / mod_tot if mod_tot else None,
+           "kernels": mod_rows[:24]}
+    json.dump(res, open(out_json, "w"), indent=1)
+    with open(out_md, "w") as f:
+        f.write("# DiT-XL/2 attention module (MHLA4DiT, B=32 x 256 tokens, dim 1152, bf16) forward + backward: module-level MFMA figure\n\n")
+        f.write(f"`tools/prof_module_mfma.sh` (rocprofv3 --kernel-trace, then two counter-only passes).  Timing of the same workload without "
+                f"the profiler: {json.dumps(timing)}\n\n")
+        f.write(f"* FLOP-based: **{timing.get('mfma_flop_frac_of_bf16_dense_peak', float('nan')):.3f} of the 2.5 PFLOP/s dense bf16 peak** "
+                f"(GEMMs {timing.get('gemm_gflop', 0):.0f} GFLOP incl. dgrad + wgrad, operator {timing.get('op_gflop', 0):.1f} GFLOP algorithmic).\n")
+        f.write(f"* Counter-based: SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES, time-weighted over the module's kernels: "
+                f"**{res['module_time_weighted_mfma_busy_over_sq_busy']}**; the same ratio for a lone 8192^3 hipBLASLt GEMM "
+                f"({timing.get('calibration_gemm_tflops', 0):.0f} TFLOP/s): {cal_ratio} -> the module keeps the matrix pipe "
+                f"**{res['module_mfma_busy_relative_to_calibration_gemm']}** as busy as that GEMM does.\n")
+        f.write(f"* GEMM kernels take {res['gemm_share_of_gpu_time']:.2f} of the module's GPU time, the library's kernels {res['mhla_share_of_gpu_time']:.2f}.\n\n")
+        f.write("| kernel | launches | avg us | total us | MFMA busy / SQ busy | MFMA busy share of a wave's life |\n|---|---|---|---|---|---|\n")
+        for r in mod_rows[:24]:
+            fmt = lambda v: "-" if v is None else f"{v:.3f}"
+            f.write(f"| `{r['kernel']}` | {r['launches']} | {r['avg_us']:.1f} | {r['total_us']:.0f} | {fmt(r['mfma_busy_over_sq_busy'])} | {fmt(r['mfma_busy_share_of_wave_life'])} |\n")
+    print(open(out_md).read()[:3000])
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "run":
+        run(int(sys.argv[2]) if len(sys.argv) > 2 else 10)
+    else:
+        summarise(sys.argv[2], sys.argv[3], sys.argv[4])

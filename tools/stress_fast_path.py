@@ -1,7 +1,7 @@
 """Stress of the bf16 fast path's in-launch hand-over (k_t16_bwd: a tile's dK/dV workgroup waits for its dQ workgroup's flag):
 many shapes -- tiles that are partly empty, a single tile per (b,h), few and many (b,h) pairs -- each run REPS times on two
 streams at once.  Every repetition has fresh inputs and its own reference (the same backward as two launches,
-MHLA_BWD_TWO_LAUNCHES=1, alone on the device): a waiter that passed early cannot hide behind identical recycled workspace
+mhla_set_option("bwd_two_launches", 1), alone on the device): a waiter that passed early cannot hide behind identical recycled workspace
 contents.  The library's status call is made after every backward (MHLA_CHECK_HANDOVER=1).  Exits non-zero on any mismatch.
   timeout 300 python tools/stress_fast_path.py"""
 import itertools
@@ -38,17 +38,17 @@ for B, H, M, S in cases:
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):   # a second instance, other data, concurrently
                     t2 = [x.flip(0).clone().requires_grad_(True) for x in (q, k, v)]
-                    mhla_amd.mhla_blockmix(*t2, W).backward(do)
+                    mhla_amd.mhla_blockmix(*t2, W, summaries="bf16").backward(do)
             ts = [x.clone().requires_grad_(True) for x in (q, k, v)]
             Wg = W.clone().requires_grad_(True)
-            out = mhla_amd.mhla_blockmix(*ts, Wg)
+            out = mhla_amd.mhla_blockmix(*ts, Wg, summaries="bf16")
             out.backward(do)
             torch.cuda.synchronize()
             return [out.detach(), ts[0].grad, ts[1].grad, ts[2].grad, Wg.grad]
 
-        os.environ["MHLA_BWD_TWO_LAUNCHES"] = "1"
+        mhla_amd._lib.load().mhla_set_option(b"bwd_two_launches", 1)
         ref = run(False)
-        del os.environ["MHLA_BWD_TWO_LAUNCHES"]
+        mhla_amd._lib.load().mhla_set_option(b"bwd_two_launches", 0)
         junk = torch.full((1 << 26,), float("nan"), device=DEV)   # recycled workspace blocks come back as NaN
         del junk
         os.environ["MHLA_CHECK_HANDOVER"] = "1"
