@@ -34,6 +34,11 @@ def parse():
     p.add_argument("--D", type=int, default=64)
     p.add_argument("--M", type=int, default=64)
     p.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "f16"])
+    p.add_argument("--summaries", default="split", choices=["split", "bf16"],
+                   help="arithmetic on 16-bit tensors: split = fp32-grade intermediates, the reference's arithmetic and the library's default "
+                        "(the number of record); bf16 = the opt-in reduced-precision form (single-bf16 block summaries)")
+    p.add_argument("--no-step-benches", action="store_true",
+                   help="skip the step-level measurements of BASELINE.json configs[3] / [4] (Wan2.1-1.3B forward, GPT training steps)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extra-configs", action="store_true",
                    help="skip the other BASELINE.json shapes (C3 / C4 / C5 / C2 variants) reported as `extra_configs` at N = 1")
@@ -123,21 +128,37 @@ def targets_block(res, world):
                "note": "per BASELINE.json configuration at its full size, HIP path vs the CPU oracle. fp32 results (fp32 tensors, and the "
                        "fp32-stored dW / dmix of bf16 runs): max|got - want| / max|want|. 16-bit results: the part of that error beyond the "
                        "one rounding of the stored value (u = 2^-8 per element for bf16, unavoidable). Causal op (the reference computes "
-                       "in fp32, naive.py:39): chunk summaries and score tiles as bf16 hi + lo pairs. Block-mix op on bf16 tensors: block "
-                       "summaries are bf16 -- what the reference's own matmul outputs are under bf16 autocast (SURVEY.md 7: 5e-3 against "
-                       "its fp32 self)"}
+                       "in fp32, naive.py:39): chunk summaries and score tiles as bf16 hi + lo pairs. Block-mix op on bf16 tensors (round 5): "
+                       "fp32 block summaries / bf16 hi + lo operands and score tiles, and an fp32-grade O in the backward's row dots -- "
+                       "the reference's fp32 arithmetic (mhla_dit/train.py:12-13); the opt-in summaries='bf16' form is listed as its own "
+                       "'[reduced precision]' family and is not what `met` refers to"}
         worst = lambda ks: max([max(fam[k]["results_16bit_max_beyond_final_rounding"], fam[k]["results_fp32_max_rel_err"]) for k in fam if k.split("/")[0] in ks] or [None])
         par["fp32_tensors_c3_c4"] = {"worst": max([max(v["results_16bit_max_beyond_final_rounding"], v["results_fp32_max_rel_err"]) for k, v in fam.items() if "fp32 tensors" in k] or [None])}
         par["causal_bf16_c5"] = {"worst": worst(("c5", "c5_1p3b_like"))}
-        par["blockmix_bf16_c2_c3"] = {"worst": max([max(v["results_16bit_max_beyond_final_rounding"], v["results_fp32_max_rel_err"]) for k, v in fam.items() if "bf16 tensors" in k and k[:2] in ("c2", "c3")] or [None])}
+        par["blockmix_bf16_c2_c3"] = {"worst": max([max(v["results_16bit_max_beyond_final_rounding"], v["results_fp32_max_rel_err"]) for k, v in fam.items() if k.endswith("bf16 tensors") and k[:2] in ("c2", "c3")] or [None])}
         for k in ("fp32_tensors_c3_c4", "causal_bf16_c5", "blockmix_bf16_c2_c3"):
             par[k]["met"] = par[k]["worst"] is not None and par[k]["worst"] <= 1e-3
         break
     t["within_1e-3_rel_err_of_reference"] = par
     rf = res.get("roofline", {})
+    module_level = {"measured": False, "note": "no profiles/r*_module_dit.json (tools/prof_module_mfma.sh)"}
+    for pj in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_module_dit.json")), reverse=True):
+        try:
+            mj = json.load(open(pj))
+            module_level = {"measured": True, "source": os.path.relpath(pj, ROOT),
+                            "what": "DiT-XL/2 attention module (LayerNorm -> QKV GEMM -> operator + LePE -> out GEMM) fwd+bwd, B=32 x 256 tokens, bf16",
+                            "ms": mj["module_timing"].get("ms"),
+                            "mfma_flop_frac_of_bf16_dense_peak": mj["module_timing"].get("mfma_flop_frac_of_bf16_dense_peak"),
+                            "mfma_busy_over_sq_busy_time_weighted": mj.get("module_time_weighted_mfma_busy_over_sq_busy"),
+                            "same_ratio_for_a_lone_8192_cubed_hipblaslt_gemm": mj.get("calibration_gemm_mfma_busy_over_sq_busy"),
+                            "relative_to_that_gemm": mj.get("module_mfma_busy_relative_to_calibration_gemm"),
+                            "gemm_share_of_gpu_time": mj.get("gemm_share_of_gpu_time"), "mhla_share_of_gpu_time": mj.get("mhla_share_of_gpu_time")}
+            break
+        except Exception:   # noqa: BLE001
+            continue
     t["ge_40pct_mfma_utilisation"] = {
         "measured": True, "mfma_flop_frac_of_bf16_dense_peak": rf.get("mfma_frac_of_bf16_peak"),
-        "mfma_pipe_busy_frac_pmc": rf.get("mfma_busy_frac_pmc"), "met": False,
+        "mfma_pipe_busy_frac_pmc": rf.get("mfma_busy_frac_pmc"), "module_level": module_level, "met": False,
         "note": "the operator is HBM-bound at 48 FLOP/B against a ridge of ~300 FLOP/B: at the HBM roofline its MFMA FLOP utilisation "
                 "tops out near 15 % (SURVEY.md 8(d)); 40 % is only reachable at module level with the projections"}
     t["ge_6x_at_8_gpus_vs_1"] = {"measured": False, "n_gpus_of_this_line": world,
@@ -191,7 +212,7 @@ def main():
     reducer = mdist.OverlappedGradAllReduce()
 
     def step():
-        out = mhla_amd.mhla_blockmix(q, k, v, W, eps=1e-6)
+        out = mhla_amd.mhla_blockmix(q, k, v, W, eps=1e-6, summaries=a.summaries)
         out.backward(do)
         # the one real exchange of a data-parallel step on this path: the mean all-reduce of dW, scheduled like DDP's
         # reducer (asynchronous, consumed at the next step / the closing synchronisation of the timed region)
@@ -211,12 +232,12 @@ def main():
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 for _ in range(3):
-                    mhla_amd.mhla_blockmix(q, k, v, W, eps=1e-6).backward(do)
+                    mhla_amd.mhla_blockmix(q, k, v, W, eps=1e-6, summaries=a.summaries).backward(do)
             torch.cuda.current_stream().wait_stream(side)
             q.grad = k.grad = v.grad = W.grad = None
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                mhla_amd.mhla_blockmix(q, k, v, W, eps=1e-6).backward(do)
+                mhla_amd.mhla_blockmix(q, k, v, W, eps=1e-6, summaries=a.summaries).backward(do)
 
             def step():   # noqa: F811
                 graph.replay()
@@ -233,7 +254,7 @@ def main():
                 for gb_ in gbufs:
                     g_ = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g_):
-                        mhla_amd.mhla_blockmix(q, k, v, W, eps=1e-6).backward(do)
+                        mhla_amd.mhla_blockmix(q, k, v, W, eps=1e-6, summaries=a.summaries).backward(do)
                         gb_.copy_(W.grad).div_(world)
                         q.grad = k.grad = v.grad = W.grad = None
                     graphs.append(g_)
@@ -253,7 +274,7 @@ def main():
                 graph_g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph_g):
                     for _ in range(a.graph_steps):
-                        mhla_amd.mhla_blockmix(q, k, v, W, eps=1e-6).backward(do)
+                        mhla_amd.mhla_blockmix(q, k, v, W, eps=1e-6, summaries=a.summaries).backward(do)
                         q.grad = k.grad = v.grad = W.grad = None
                 step_group, group = graph_g.replay, a.graph_steps
                 launch_mode = f"hipGraph replay, {a.graph_steps} captured fwd+bwd steps per replay (remainder: one step per replay)"
@@ -307,6 +328,7 @@ def main():
     # roofline fraction is its share / its duration
     share = {"k_t16_bwd": 7, "k_t16_bwd_dkv": 4, "k_t16_bwd_dq": 3, "k_t16_out": 2,
              "k_fs_state_fwd": 2, "k_fs_state<1>": 3,
+             "k_sp_state": 2, "k_sp_out": 2, "k_sp_state<1>": 3, "k_sp_bwd_dq": 1, "k_sp_bwd_dkv": 4,   # (mixing / dW kernels: summaries only)
              "k_bm_bwd_tok": 7, "k_bm_state<0>": 2, "k_bm_state<1>": 3, "k_bm_out": 2}
     # HBM bytes per step: PMC counters cannot be read from inside this process, so the figure comes from the rocprofv3 PMC
     # passes of this same command (tools/prof_bench.sh -> profiles/r*_pmc_traffic.json) -- and only when that file was made
@@ -352,6 +374,10 @@ def main():
                                    f"M={a.M} S={a.N // a.M} {a.dtype} ({_config_name(a)})",
                        "global_batch": a.B * world, "parallelism": f"dp{world} (batch shards, dW all-reduce only)",
                        "launch": launch_mode,
+                       "arithmetic": ("fp32-grade intermediates on the bf16 tensors (fp32 block summaries, bf16 hi + lo operands, fp32-grade O "
+                                      "in the row dots): the reference's arithmetic (mhla_dit/mhla/mhla.py:262-268 as mhla_dit/train.py:12-13 "
+                                      "runs it), the library's default" if a.summaries == "split" or a.dtype == "f32" else
+                                      "REDUCED PRECISION (--summaries bf16, opt-in MHLA_FLAG_BF16_SUMMARIES): single-bf16 block summaries"),
                        "autograd_nodes": "C++ (libmhla_torch.so)" if mhla_amd.ops._native_nodes() else "Python (ops.py)",
                        **({"shared_gpu_harness": f"{world} ranks on {torch.cuda.device_count()} GPU(s), gloo: harness test, "
                                                   "not a scaling measurement"} if shared else {})},
@@ -377,6 +403,41 @@ def main():
                 "mfma_frac_of_bf16_peak": alg_flops / (step_gpu_us * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS if step_gpu_us else None,
             },
         }
+        if world == 1 and a.summaries == "split" and a.dtype == "bf16" and not a.no_extra_configs:
+            # the opt-in reduced-precision form of the same step (single-bf16 block summaries: rounds 1-4's arithmetic and kernels),
+            # for comparison only -- `value` above is the number of record
+            try:
+                for t_ in (q, k, v, W):
+                    t_.grad = None
+                g2 = torch.cuda.CUDAGraph()
+                side2 = torch.cuda.Stream()
+                side2.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side2):
+                    for _ in range(3):
+                        mhla_amd.mhla_blockmix(q, k, v, W, eps=1e-6, summaries="bf16").backward(do)
+                        q.grad = k.grad = v.grad = W.grad = None
+                torch.cuda.current_stream().wait_stream(side2)
+                with torch.cuda.graph(g2):
+                    for _ in range(a.graph_steps):
+                        mhla_amd.mhla_blockmix(q, k, v, W, eps=1e-6, summaries="bf16").backward(do)
+                        q.grad = k.grad = v.grad = W.grad = None
+                for _ in range(3):
+                    g2.replay()
+                sync()
+                e0_, e1_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0_.record()
+                for _ in range(10):
+                    g2.replay()
+                e1_.record()
+                sync()
+                ms_rp = e0_.elapsed_time(e1_) / (10 * a.graph_steps)
+                res["reduced_precision_bf16_summaries"] = {
+                    "what": "the same step with summaries='bf16' (MHLA_FLAG_BF16_SUMMARIES): single-bf16 block summaries on the bf16 fast "
+                            "path -- REDUCED PRECISION (2-3e-3 of a gradient's maximum beyond the final rounding), not the number of record",
+                    "ms_per_step": ms_rp, "tokens_per_s": a.B * a.N / (ms_rp * 1e-3), "hbm_frac": alg_bytes / (ms_rp * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                del g2
+            except Exception as e:   # noqa: BLE001
+                res["reduced_precision_bf16_summaries"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(a)
             res["gpu_over_cpu"] = value / res["cpu_baseline"]["value"]
@@ -426,8 +487,25 @@ def main():
             q = k = v = do = None
             torch.cuda.empty_cache()
             dit_step = bench_dit_step.run_dit_step(rank, local, world, "DiT-XL/2", 32, 256, steps=8, warmup=3)
+            if isinstance(dit_step, dict):
+                dit_step["rccl_env"] = {k_: os.environ.get(k_) for k_ in ("NCCL_ALGO", "NCCL_PROTO", "NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHANNELS", "NCCL_BUFFSIZE")}
+                dit_step["bucket_cap_mb"] = 25
         except Exception as e:   # noqa: BLE001
             dit_step = {"error": f"{type(e).__name__}: {e}"}
+        # BASELINE.json configs[4] / [3] at step level (tools/bench_steps.py): the GPT-1.3B-shaped training step on every rank (DDP over
+        # RCCL when N > 1); at N = 1 also the 340M model the reference ships a config for and the Wan2.1-1.3B 30-block forward
+        if not a.no_step_benches:
+            try:
+                import bench_steps
+                gpt13 = bench_steps.gpt_step(rank, local, world, "1.3B", batch=1, seq=8192, steps=3, warmup=2)
+                if rank == 0:
+                    res["gpt_1p3b_train_step"] = gpt13
+                if world == 1:
+                    res["gpt_340m_train_step"] = bench_steps.gpt_step(rank, local, world, "340M", batch=2, seq=8192, steps=3, warmup=2)
+                    res["wan_1p3b_forward"] = bench_steps.wan_forward(dev, layers=30, iters=2, warm=1)
+            except Exception as e:   # noqa: BLE001
+                if rank == 0:
+                    res["step_benches_error"] = f"{type(e).__name__}: {e}"
         dog.cancel()
         if not printed.acquire(blocking=False):
             time.sleep(3600)         # the watchdog fired a moment ago and is printing: it ends the process

@@ -90,6 +90,8 @@ def pytest_sessionfinish(session, exitstatus):
         tens = "fp32 tensors" if cfg == "c4" or (cfg == "c3" and "dtype1" in tl) else "bf16 tensors"
         if cfg == "c5" and "1p3b" in tl:
             cfg = "c5_1p3b_like"
+        if tl.endswith("[bf16]") or "[bf16-" in tl or "-bf16]" in tl:             # the opt-in summaries="bf16" parametrisation: its own family
+            tens += " [reduced precision: summaries=bf16]"
         a = fam.setdefault(f"{cfg}/{tens}", {"n": 0, "results_16bit_max_beyond_final_rounding": 0.0, "results_fp32_max_rel_err": 0.0, "worst": None})
         a["n"] += 1
         key = "results_fp32_max_rel_err" if dtype == "float32" else "results_16bit_max_beyond_final_rounding"

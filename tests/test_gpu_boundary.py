@@ -79,6 +79,28 @@ def test_bench_two_rank_launch_path_in_shared_gpu_mode():
     if torch.cuda.device_count() < 2:
         assert "shared_gpu_harness" in res["config"]
 
+def test_bench_eight_rank_launch_path_in_shared_gpu_mode():
+    """The world size the driver's scaling run uses: `python bench.py --gpus 8` on this one-GPU box -- eight fresh ranks (the
+    rank -> device modulo, port selection, rendezvous on 127.0.0.1, gloo because the ranks share a device), every rank in the
+    alternating-graphs launch mode with the asynchronous dW all-reduce, ONE line from rank 0 with n_gpus = 8 and the one-line
+    contract's fields.  A harness test (8-GPU readiness on paper), not a scaling measurement."""
+    env = dict(os.environ, MASTER_PORT="29631")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+                        "--no-dit-step", "--no-extra-configs", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 8 and res["steps"] == 2 and res["warmup"] == 1 and res["scaling"] == "weak"
+    assert res["config"]["global_batch"] == 64 and "dp8" in res["config"]["parallelism"]
+    for key in ("metric", "value", "unit", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data", "roofline", "targets"):
+        assert key in res, key
+    assert res["value"] > 0 and res["dtype"] == "bf16" and res["data"] == "synthetic"
+    if torch.cuda.device_count() < 8:
+        assert "shared_gpu_harness" in res["config"]
+
+
 
 def test_rccl_process_group_runs_the_dw_exchange_on_this_gpu():
     """The `nccl` (= RCCL) backend of the multi-GPU legs, on the one GPU a test box has: a one-rank process group is created in a

@@ -67,8 +67,9 @@ def run(iters):
 
 
 def _short(k):
-    k = k.split("(")[0].replace("void ", "")
-    for p in ("mhla::", "fast::", "sp::", "at::native::", "(anonymous namespace)::"):
+    k = k.replace("(anonymous namespace)::", "").replace("void ", "")
+    k = k.split("(")[0]
+    for p in ("mhla::", "fast::", "sp::", "at::native::"):
         k = k.replace(p, "")
     return k[:70]
 
