@@ -132,7 +132,9 @@ struct HandoverWatch {
         else
             (void)hipGetLastError();
     }
-    void check() {
+    void check(hipStream_t st) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;   // (no event queries while the caller's stream is being captured)
+        if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return; }
         std::lock_guard<std::mutex> lk(mu);
         if (host) poll();
     }
@@ -447,7 +449,7 @@ static int bm_bwd_impl(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view 
             ta.dwp = f.dwp; ta.dW = dW; ta.nparts = B * H * fast::DW_SPLIT; ta.ntiles = (int)ntile_wgs; ta.done = f.done;
             ta.err = f.err;
             ta.drop_signal = g_drop_signal.load();   // testing aid for the bounded wait (mhla_set_option)
-            g_watch.check();                          // did an earlier fused launch of this process report an expired hand-over?
+            g_watch.check(st);                        // did an earlier fused launch of this process report an expired hand-over?
             const auto tile_bwd = f.cs > 1 ? fast::k_tile_bwd<16, true> : fast::k_tile_bwd<16, false>;   // (multi-chunk blocks: cs workgroups per tile)
             if (g_two_launches.load()) {   // (the kernel boundary orders dksum and the flags: the wait returns at its first poll)
                 RC(launch(tile_bwd, dim3((unsigned)ntile_wgs), dim3(fast::FT8), fast::tile_smem<16>(), st, "k_t16_bwd_dq", ta));
