@@ -55,6 +55,25 @@ inline int sp_mixr(const float* W, int ldw, const void* in, void* out, int M, lo
 #undef MIXR
 }
 
+// The backward's mixing dKV = W^T dG with the dW products riding along (sp::k_sp_mixr<.., DW>): fp32 summaries, 33 <= M <= 128.
+// Returns the number of [M][M] partials written to `dwp` (one per workgroup) through `nparts`.
+inline bool sp_mixr_dw_ok(int M, long E) { return sp_mixr_ok<false>(M, E) && M <= 128; }
+inline int sp_mixr_dw(const float* W, int ldw, const void* dg, const void* kv, void* dkv, float* dwp, int M, long E, long es, int BH,
+                      hipStream_t st, int* nparts) {
+#define MIXRDW(NW) do { \
+        constexpr int TE = sp::mixr_te<NW, false>(); \
+        const long total = (long)BH * (E / TE); \
+        const int wgs = (int)std::min<long>(total, 256); \
+        sp::MixrArgs a{W, ldw, dg, dkv, M, E, es, total, (int)((total + wgs - 1) / wgs), nullptr, nullptr, 0, 0.f, nullptr, kv, dwp}; \
+        const int gw = (int)((total + a.spw - 1) / a.spw); \
+        *nparts = gw; \
+        return launch(sp::k_sp_mixr<NW, 1, false, true>, dim3(gw), dim3(64 * NW), sp::sp_mixr_smem<NW, false, true>(), st, "k_sp_mixr<1,dw>", a); \
+    } while (0)
+    if (M <= 64) MIXRDW(4);
+    MIXRDW(8);
+#undef MIXRDW
+}
+
 // Blocks of exactly 16 tokens, bf16, D = 64, every row a whole number of 16-byte pieces: the wave-per-block kernels of split16.hpp
 // replace the token kernels (same workspace formats).  `bwd`: the call's gradient views must qualify too.
 template <typename ET, int DT>
@@ -218,19 +237,26 @@ int bm_bwd_typed(const BmCall& c) {
             if (normalize && !wz_fused)
                 RC(launch(k_wz<1>, dim3((S + 63) / 64, (M + 63) / 64, B * H), dim3(NTHREADS), 0, st, "k_wz<1>", W, ldw, (const float*)w.dn, w.dz, M, S, 0.f));
             MixArgs m{W, ldw, w.dg, w.dkv, M, E, w.es};
-            if (mixr) RC((sp_mixr<1, S16>(W, ldw, w.dg, w.dkv, M, E, w.es, B * H, st, normalize ? (const float*)w.dn : nullptr, w.dz, S, 0.f)));
+            // fp32 summaries, 33 .. 128 blocks: dW's products ride in the mixing kernel (its staged dG slices + the KV slices), one
+            // partial per workgroup -- dG and KV are not read a second time by k_sp_dw
+            const bool dwfused = !S16 && mixr && sp_mixr_dw_ok(M, E);
+            int fused_parts = 0;
+            if (dwfused) RC(sp_mixr_dw(W, ldw, w.dg, w.kv, w.dkv, w.dwp, M, E, w.es, B * H, st, &fused_parts));
+            else if (mixr) RC((sp_mixr<1, S16>(W, ldw, w.dg, w.dkv, M, E, w.es, B * H, st, normalize ? (const float*)w.dn : nullptr, w.dz, S, 0.f)));
             else RC(launch(sp::k_sp_mix<1, S16>, dim3((unsigned)((E + sp::SPM_TE - 1) / sp::SPM_TE), tiles, B * H), dim3(NTHREADS), sp::sp_mix_smem<S16>(), st, "k_sp_mix<1>", m));
             int nsplit = dw_splits(tiles * tiles * B * H, E);
             if (nsplit > DW_MAX_SPLIT - 1) nsplit = DW_MAX_SPLIT - 1;   // one more part per (b, h) holds the <dn_i, z_j> term
             DwArgs d{w.dg, w.kv, E, nullptr, nullptr, 0, w.dwp, M, tiles, nsplit, w.es};
             const bool dwr = S16 && sp_dwr_ok(M, E);   // whole-matrix workgroups: the <dn_i, z_j> term is one of their stages
-            if (dwr) {
+            if (dwfused) {
+                // (nothing to launch: the partials are in w.dwp)
+            } else if (dwr) {
                 nsplit = sp_dwr_splits(B * H, E);
                 RC(sp_dwr(w.dg, w.kv, E, w.es, normalize ? w.dn : nullptr, normalize ? w.z : nullptr, S, w.dwp, M, B * H, nsplit, st));
             } else if (M <= 16)      RC(launch(sp::k_sp_dw<S16, 1>, dim3(1, B * H, nsplit), dim3(NTHREADS), sp::SP_DW_SMEM, st, "k_sp_dw<16>", d));
             else if (M <= 32) RC(launch(sp::k_sp_dw<S16, 2>, dim3(1, B * H, nsplit), dim3(NTHREADS), sp::SP_DW_SMEM, st, "k_sp_dw<32>", d));
             else              RC(launch(sp::k_sp_dw<S16>, dim3(tiles * tiles, B * H, nsplit), dim3(NTHREADS), sp::SP_DW_SMEM, st, "k_sp_dw", d));
-            int nparts = B * H * nsplit;
+            int nparts = dwfused ? fused_parts : B * H * nsplit;
             if (normalize && !dwr) {
                 DwArgs dzz{w.dn, w.z, (long)S, nullptr, nullptr, 0, w.dwp + (size_t)nparts * M * M, M, tiles, 1};
                 RC(launch(k_dw<0>, dim3(tiles * tiles, B * H, 1), dim3(NTHREADS), DW_SMEM_FLOATS * 4, st, "k_dw", dzz));

@@ -26,6 +26,8 @@ using fast::tr_read8;
 using fast::s16x4;
 using fast::u16;
 
+__device__ __forceinline__ bf16x8 row_read8(const u16* tile, int ld, int c0, int k0, int lane);   // (defined with the token-gradient kernels)
+
 template <typename T>
 __device__ __forceinline__ void ld8(const T* p, f32x4& a, f32x4& b) {
     a = Io<T>::ld4(p);
@@ -601,17 +603,27 @@ struct MixrArgs {
     int S;
     float eps;
     unsigned long long* trace;   // debugging aid (mhla_debug_set_trace): s_memtime stamps of the first workgroups' slice loop, or null
+    // k_sp_mixr<.., DW> (backward, fp32 summaries): the OTHER summary set of the dW product (KV, laid out like `in` = dG) and the
+    // per-workgroup partials dwp[workgroup][M][M] of dW[i][j] = sum_bh sum_e dG[i][e] KV[j][e] -- formed from the slice rows this
+    // kernel stages anyway, so that dG is read from HBM once for dKV and dW together
+    const void* in2;
+    float* dwp;
 };
 // slice width: 256-byte row pieces; 128-byte ones for 16 waves (1024 threads on 128 VGPRs: half the accumulators and staging registers)
 template <int NW, bool S16> __host__ __device__ constexpr int mixr_te() { return (S16 ? 128 : 64) / (NW > 12 ? 2 : 1); }
-template <int NW, bool S16>
+template <int NW, bool S16, bool DW = false>
 __host__ __device__ constexpr int sp_mixr_smem() {
     constexpr int TE = mixr_te<NW, S16>(), ROWS = 16 * NW;
-    return (S16 ? 1 : 2) * ROWS * (TE + 8) * 2 + (S16 ? ROWS * (TE + 8) * 2 : ROWS * (TE + 4) * 4);
+    return (S16 ? 1 : (DW ? 4 : 2)) * ROWS * (TE + 8) * 2 + (S16 ? ROWS * (TE + 8) * 2 : ROWS * (TE + 4) * 4);
 }
 
-template <int NW, int TRANS, bool S16>
+// DW (TRANS 1, fp32 summaries, M <= 128): the kernel also stages the KV rows of every slice (hi + lo, two more tiles) and accumulates
+// dW[i][j] += sum_{e in slice} dG[i][e] KV[j][e] over ALL its slices -- every (b,h) it meets: dW is their sum anyway -- in
+// registers (wave w owns rows i = 16 w .. 16 w + 15, all columns: NW tiles); one [M][M] partial per workgroup at the end, summed in a
+// fixed order by k_dw_reduce.  Replaces k_sp_dw, which read dG and KV a second time (C2 at the default arithmetic: 81 us).
+template <int NW, int TRANS, bool S16, bool DW = false>
 __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void k_sp_mixr(const MixrArgs a) {
+    static_assert(!DW || (TRANS == 1 && !S16 && NW <= 8), "dW rides in the backward's fp32 mixing kernel, M <= 128");
     constexpr int TE = mixr_te<NW, S16>(), ROWS = 16 * NW, LD = TE + 8, LDO = TE + 4, NK = (NW + 1) / 2, NT = TE / 16;
     constexpr int PPR = TE * (S16 ? 2 : 4) / 16;          // 16-byte pieces per row of the slice (16, or 8 with 16 waves)
     constexpr int NTH = 64 * NW, NP = ROWS * PPR / NTH;   // pieces per thread and slice
@@ -619,7 +631,9 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void k_sp_mixr(const MixrArg
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u16* Th = reinterpret_cast<u16*>(smem_raw);
     u16* Tl = Th + ROWS * LD;                                        // (fp32 summaries only)
-    unsigned char* Os = smem_raw + (S16 ? 1 : 2) * ROWS * LD * 2;     // bf16 [ROWS][LD] or fp32 [ROWS][LDO]
+    u16* Kh = Tl + ROWS * LD;                                        // (DW only: the KV rows of the slice)
+    u16* Kl = Kh + ROWS * LD;
+    unsigned char* Os = smem_raw + (S16 ? 1 : (DW ? 4 : 2)) * ROWS * LD * 2;     // bf16 [ROWS][LD] or fp32 [ROWS][LDO]
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nl = lane & 15, kg = lane >> 4;
     const int M = a.M;
     const long nsl = a.E / TE;
@@ -628,7 +642,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void k_sp_mixr(const MixrArg
     if (cnt <= 0) return;
     // B operand: B[k = r][n = o] = weight of input block r in output block o = 16 wave + nl, r = 32 ks + 8 kg + t
     bf16x8 wh[NK][1], wl[NK][1];
-    static_assert((TRANS ? 64 * (ROWS + 4) : ROWS * 68) * 4 <= sp_mixr_smem<NW, S16>(), "weight chunk must fit in the tiles");
+    static_assert((TRANS ? 64 * (ROWS + 4) : ROWS * 68) * 4 <= sp_mixr_smem<NW, S16, DW>(), "weight chunk must fit in the tiles");
     mixr_weights<TRANS, 64 * NW, ROWS, NK, 1>(wh, wl, reinterpret_cast<float*>(smem_raw), a.W, a.ldw, M, wave * 16, tid);
     constexpr int ESZ = S16 ? 2 : 4;
     // byte offset of slice (bh, es); a workgroup's slices are consecutive, so the pair is advanced rather than divided out per
@@ -643,11 +657,32 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void k_sp_mixr(const MixrArg
         const int v = tid + p * NTH, row = v / PPR, c = v % PPR;
         goff[p] = (unsigned)((long)(row < M ? row : M - 1) * a.es * ESZ + c * 16);
     }
-    uint4 pre[NP];
+    uint4 pre[NP], pre2[DW ? NP : 1];
     auto issue = [&](long boff) {
         const char* base = reinterpret_cast<const char*>(a.in) + boff;
 #pragma unroll
         for (int p = 0; p < NP; ++p) pre[p] = gld_stream16(base + goff[p]);
+        if constexpr (DW) {
+            const char* base2 = reinterpret_cast<const char*>(a.in2) + boff;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) pre2[p] = gld_stream16(base2 + goff[p]);
+        }
+    };
+    f32x4 dwacc[DW ? NW : 1];
+#pragma unroll
+    for (int t = 0; t < (DW ? NW : 1); ++t) dwacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // four floats -> four bf16 hi + four bf16 lo at tile position (row, 4 c)
+    auto commit_hl = [&](u16* th, u16* tl, const uint4& x, int row, int c) {
+        const float f[4] = {__uint_as_float(x.x), __uint_as_float(x.y), __uint_as_float(x.z), __uint_as_float(x.w)};
+        float l[4];
+        unsigned short hs[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            hs[i] = cvt_bf16(f[i]);
+            l[i] = f[i] - __uint_as_float((unsigned)hs[i] << 16);
+        }
+        *reinterpret_cast<uint2*>(th + row * LD + c * 4) = make_uint2(hs[0] | ((unsigned)hs[1] << 16), hs[2] | ((unsigned)hs[3] << 16));
+        *reinterpret_cast<uint2*>(tl + row * LD + c * 4) = make_uint2(pack_bf16x2(l[0], l[1]), pack_bf16x2(l[2], l[3]));
     };
     issue(slice_off(nbh, nes));
     for (int it = 0; it < cnt; ++it) {
@@ -661,16 +696,11 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void k_sp_mixr(const MixrArg
             if constexpr (S16) {
                 *reinterpret_cast<uint4*>(Th + row * LD + c * 8) = x;
             } else {   // four floats -> four bf16 hi + four bf16 lo
-                const float f[4] = {__uint_as_float(x.x), __uint_as_float(x.y), __uint_as_float(x.z), __uint_as_float(x.w)};
-                float l[4];
-                unsigned short hs[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    hs[i] = cvt_bf16(f[i]);
-                    l[i] = f[i] - __uint_as_float((unsigned)hs[i] << 16);
+                commit_hl(Th, Tl, x, row, c);
+                if constexpr (DW) {
+                    const uint4 y = make_uint4(ok ? pre2[p].x : 0u, ok ? pre2[p].y : 0u, ok ? pre2[p].z : 0u, ok ? pre2[p].w : 0u);
+                    commit_hl(Kh, Kl, y, row, c);
                 }
-                *reinterpret_cast<uint2*>(Th + row * LD + c * 4) = make_uint2(hs[0] | ((unsigned)hs[1] << 16), hs[2] | ((unsigned)hs[3] << 16));
-                *reinterpret_cast<uint2*>(Tl + row * LD + c * 4) = make_uint2(pack_bf16x2(l[0], l[1]), pack_bf16x2(l[2], l[3]));
             }
         }
         __syncthreads();
@@ -705,6 +735,23 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void k_sp_mixr(const MixrArg
                 }
             }
         }
+        if constexpr (DW) {   // dW[i][j] += sum_e dG[i][e] KV[j][e]: rows i of this wave, every column tile that holds a block
+            if (wave * 16 < M) {   // (uniform)
+#pragma unroll
+                for (int k2 = 0; k2 < TE / 32; ++k2) {
+                    const bf16x8 ah = row_read8(Th, LD, wave * 16, k2 * 32, lane), al = row_read8(Tl, LD, wave * 16, k2 * 32, lane);   // A[m = i][k = e]
+#pragma unroll
+                    for (int jt = 0; jt < NW; ++jt) {
+                        if (jt * 16 < M) {   // (uniform)
+                            const bf16x8 bh_ = row_read8(Kh, LD, jt * 16, k2 * 32, lane), bl_ = row_read8(Kl, LD, jt * 16, k2 * 32, lane);   // B[k = e][n = j]
+                            dwacc[jt] = mfma_bf16(ah, bh_, dwacc[jt]);
+                            dwacc[jt] = mfma_bf16(ah, bl_, dwacc[jt]);
+                            dwacc[jt] = mfma_bf16(al, bh_, dwacc[jt]);
+                        }
+                    }
+                }
+            }
+        }
         // lane: elements 16 t + 4 kg .. + 3 of output block 16 wave + nl -> staging tile [block][element]
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -725,6 +772,16 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void k_sp_mixr(const MixrArg
                 gst<uint4>(ob + goff[p], x);
             }
         }
+    }
+    if constexpr (DW) {   // C layout: rows i = 16 wave + 4 kg + r, column j = 16 jt + nl
+        float* dp = a.dwp + (long)blockIdx.x * M * M;
+#pragma unroll
+        for (int jt = 0; jt < NW; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = wave * 16 + kg * 4 + r, j = jt * 16 + nl;
+                if (i < M && j < M) dp[(long)i * M + j] = dwacc[jt][r];
+            }
     }
 }
 
