@@ -623,7 +623,7 @@ __host__ __device__ constexpr int sp_mixr_smem() {
 // fixed order by k_dw_reduce.  Replaces k_sp_dw, which read dG and KV a second time (C2 at the default arithmetic: 81 us).
 template <int NW, int TRANS, bool S16, bool DW = false>
 __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void k_sp_mixr(const MixrArgs a) {
-    static_assert(!DW || (TRANS == 1 && !S16 && NW <= 8), "dW rides in the backward's fp32 mixing kernel, M <= 128");
+    static_assert(!DW || (TRANS == 1 && !S16 && NW <= 8), "dW rides in the backward's fp32 mixing kernel, M <= 128 (twelve waves: 77 spilled registers)");
     constexpr int TE = mixr_te<NW, S16>(), ROWS = 16 * NW, LD = TE + 8, LDO = TE + 4, NK = (NW + 1) / 2, NT = TE / 16;
     constexpr int PPR = TE * (S16 ? 2 : 4) / 16;          // 16-byte pieces per row of the slice (16, or 8 with 16 waves)
     constexpr int NTH = 64 * NW, NP = ROWS * PPR / NTH;   // pieces per thread and slice
@@ -1552,7 +1552,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_bwd_dq(const TokArgs a) {
 // ROPE: k is the un-rotated tensor: it is rotated on its way into the dV product (KV was formed from the rotated keys), and
 // dK_rot is turned back before dksum is added
 template <typename T, int DT, bool ROPE = false, bool S16 = Sum16<T>::value>
-__global__ __launch_bounds__(NTHREADS, 2) void k_sp_bwd_dkv(const TokArgs a) {
+__global__ __launch_bounds__(NTHREADS, (DT <= 4 && !ROPE && std::is_same<T, bf16_t>::value) ? 4 : 2) void k_sp_bwd_dkv(const TokArgs a) {   // (bf16, D <= 64: 128 VGPRs without a spill -> four workgroups per CU; 130 without the bound)
     constexpr int LD = mat_ld<DT>(), DW = Geo<DT>::DW, KST = Geo<DT>::KST, TILE = KST * 32 * LD;
     constexpr bool LO = !std::is_same<T, bf16_t>::value;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
