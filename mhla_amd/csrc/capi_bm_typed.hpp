@@ -279,7 +279,9 @@ int bm_bwd_typed(const BmCall& c) {
                 RC(launch(s16::k_s16_bwd_dkv<0>, g16, b16, s16::dkv_smem(), st, "k_s16_bwd_dkv", t));
                 break;
             }
-            RC(launch(sp::k_sp_bwd_dq<ET, DT, false, S16>, dim3(M, B * H), dim3(NTHREADS), sp::sp_tok_smem<DT, S16>(), st, "k_sp_bwd_dq", t));
+            // (16-bit tensors: q_den in 16-byte pieces when it only feeds dksum; not at D = 72 / 80, where the wider rows cost a wave of occupancy)
+            if (normalize && !relu && sizeof(ET) == 2 && DT != 5) RC(launch(sp::k_sp_bwd_dq<ET, DT, false, S16, true>, dim3(M, B * H), dim3(NTHREADS), sp::sp_tok_smem<DT, S16>(), st, "k_sp_bwd_dq", t));
+            else RC(launch(sp::k_sp_bwd_dq<ET, DT, false, S16>, dim3(M, B * H), dim3(NTHREADS), sp::sp_tok_smem<DT, S16>(), st, "k_sp_bwd_dq", t));
             RC(launch(sp::k_sp_bwd_dkv<ET, DT, false, S16>, dim3(M, B * H), dim3(NTHREADS), sp::sp_tok_smem<DT, S16>(), st, "k_sp_bwd_dkv", t));
             break;
         }

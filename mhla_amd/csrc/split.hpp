@@ -1410,7 +1410,9 @@ __device__ __forceinline__ bf16x8 row_read8(const u16* tile, int ld, int c0, int
 
 // ROPE: the numerator pair was rotated inside the forward (q_den aliases the un-rotated q): dQ_rot is turned back by the
 // transposed rotation before dz ksum^T is added, so the one stored tensor is the gradient of the un-rotated q
-template <typename T, int DT, bool ROPE = false, bool S16 = Sum16<T>::value>
+// WQ: q_den enters only dksum (normaliser on, no relu prologue) and is fetched in 16-byte pieces in the operand layout; otherwise in
+// the output layout, where the relu gradient mask needs it (a template flag: both register sets at once cost the occupancy)
+template <typename T, int DT, bool ROPE = false, bool S16 = Sum16<T>::value, bool WQ = false>
 __global__ __launch_bounds__(NTHREADS, 2) void k_sp_bwd_dq(const TokArgs a) {
     constexpr int LD = mat_ld<DT>(), DW = Geo<DT>::DW, KST = Geo<DT>::KST, TILE = KST * 32 * LD;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1427,13 +1429,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_bwd_dq(const TokArgs a) {
     T *dqb = mbase(a.dq), *dqdb = a.split ? mbase(a.dqd) : nullptr;
     const float* ninvb = a.ninv + ((long)bh * M + blk) * S;
     const float* dzb = a.dz + ((long)bh * M + blk) * S;
-    const bool need_q = a.normalize || a.relu;
+    constexpr bool wide_q = WQ;   // (the launch picks WQ = normalize && !relu)
 
     // one 16-token tile of this wave: the lane's token row, its dO features as the MFMA B operand (8 per reduction step) and
     // its q_den features in output layout (4 per feature tile); fetched one tile ahead of the tile being computed
     struct Rows {
         f32x4 g[KST][2];
-        f32x4 qd[DT];
+        f32x4 qd[WQ ? 1 : DT];         // q_den in output layout (relu prologue: the gradient mask needs it there)
+        f32x4 qw[WQ ? KST : 1][2];     // ... or in the operand layout of g (8 features per reduction step: 16-byte loads), for dksum only
         float ninv, dz;
         long row;
         bool live;
@@ -1449,19 +1452,32 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_bwd_dq(const TokArgs a) {
             R.g[ks][0] = R.g[ks][1] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (ks * 32 + kg * 8 < D) ld8(gb + R.row * a.dout.sn + ks * 32 + kg * 8, R.g[ks][0], R.g[ks][1]);
         }
+        if constexpr (!WQ) {
 #pragma unroll
-        for (int ct = 0; ct < DT; ++ct) {
-            R.qd[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (need_q && ct * 16 + kg * 4 < D) R.qd[ct] = Io<T>::ld4(qdb + R.row * a.qd.sn + ct * 16 + kg * 4);
+            for (int ct = 0; ct < DT; ++ct) {
+                R.qd[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if ((a.normalize || a.relu) && ct * 16 + kg * 4 < D) R.qd[ct] = Io<T>::ld4(qdb + R.row * a.qd.sn + ct * 16 + kg * 4);
+            }
+        }
+        // no relu prologue: q_den is needed for dksum = sum_s dz[s] q[s][:] alone -- 8 features per load, as the dO rows (the 4-feature
+        // pieces of the output layout are 8-byte loads for 16-bit tensors: 0.54-0.70 of the 16-byte rate)
+        if constexpr (WQ) {
+#pragma unroll
+            for (int ks = 0; ks < KST; ++ks) {
+                R.qw[ks][0] = R.qw[ks][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (ks * 32 + kg * 8 < D) ld8(qdb + R.row * a.qd.sn + ks * 32 + kg * 8, R.qw[ks][0], R.qw[ks][1]);
+            }
         }
     };
     fetch(wave, cur);   // in flight while G_i is staged
     stage_mat_split<DT, S16>(Gh, Gl, a.g, ((long)bh * M + blk) * a.es, D, tid);
     if (tid < DW) ksum[tid] = (a.normalize && tid < D) ? a.ksum[((long)bh * M + blk) * D + tid] : 0.f;
     __syncthreads();
-    f32x4 dksp[DT];
+    f32x4 dksp[WQ ? 1 : DT], dksw8[WQ ? KST : 1][2];   // per-lane dksum partials: output layout / operand layout (WQ)
 #pragma unroll
-    for (int ct = 0; ct < DT; ++ct) dksp[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int ct = 0; ct < (WQ ? 1 : DT); ++ct) dksp[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < (WQ ? KST : 1); ++ks) dksw8[ks][0] = dksw8[ks][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     for (int tt = wave; tt * 16 < S; tt += 4) {
         if ((tt + 4) * 16 < S) fetch(tt + 4, nxt);
@@ -1477,14 +1493,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_bwd_dq(const TokArgs a) {
         auto epilogue = [&](int ct, f32x4& c, f32x4& cd, const f32x2& rc, const f32x2& rs) {
             const int d0 = ct * 16 + kg * 4;
             if constexpr (ROPE) unrope4(c, rc, rs);
-            f32x4 qd = cur.qd[ct];
+            f32x4 qd = cur.qd[WQ ? 0 : ct];
             if (a.relu)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) qd[i] = fmaxf(qd[i], 0.f) + a.eps;
             const f32x4 ks4 = *reinterpret_cast<const f32x4*>(ksum + d0);
             cd = cur.dz * ks4;
             if (a.normalize) {
-                dksp[ct] += cur.dz * qd;
+                if constexpr (!WQ) dksp[ct] += cur.dz * qd;
                 if (!a.split) c += cd;
             }
             if (a.relu)
@@ -1532,18 +1548,34 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_bwd_dq(const TokArgs a) {
             }
             __builtin_amdgcn_sched_barrier(0);   // keep the LDS operand reads of later tiles from being hoisted (register pressure)
         }
+        if constexpr (WQ) {
+#pragma unroll
+            for (int ks = 0; ks < KST; ++ks) { dksw8[ks][0] += cur.dz * cur.qw[ks][0]; dksw8[ks][1] += cur.dz * cur.qw[ks][1]; }
+        }
         cur = nxt;
     }
     if (a.normalize) {   // dksum[d] = sum_s dz[s] qden[s][d]: over the 16 token lanes, then over the waves
+        if constexpr (WQ) {   // the lane's features 32 ks + 8 kg + 0..7
 #pragma unroll
-        for (int ct = 0; ct < DT; ++ct)
+            for (int ks = 0; ks < KST; ++ks)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float v = dksp[ct][i];
+                for (int i = 0; i < 8; ++i) {
+                    float v = dksw8[ks][i >> 2][i & 3];
 #pragma unroll
-                for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-                if (nl == 0) dksw[wave * DW + ct * 16 + kg * 4 + i] = v;
-            }
+                    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+                    if (nl == 0 && ks * 32 + kg * 8 + i < DW) dksw[wave * DW + ks * 32 + kg * 8 + i] = v;
+                }
+        } else {
+#pragma unroll
+            for (int ct = 0; ct < (WQ ? 1 : DT); ++ct)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float v = dksp[ct][i];
+#pragma unroll
+                    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+                    if (nl == 0) dksw[wave * DW + ct * 16 + kg * 4 + i] = v;
+                }
+        }
         __syncthreads();
         if (tid < D) a.dks[((long)bh * M + blk) * D + tid] = dksw[tid] + dksw[DW + tid] + dksw[2 * DW + tid] + dksw[3 * DW + tid];
     }
