@@ -1584,7 +1584,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_bwd_dq(const TokArgs a) {
 // ROPE: k is the un-rotated tensor: it is rotated on its way into the dV product (KV was formed from the rotated keys), and
 // dK_rot is turned back before dksum is added
 template <typename T, int DT, bool ROPE = false, bool S16 = Sum16<T>::value>
-__global__ __launch_bounds__(NTHREADS, (DT <= 4 && !ROPE && std::is_same<T, bf16_t>::value) ? 4 : 2) void k_sp_bwd_dkv(const TokArgs a) {   // (bf16, D <= 64: 128 VGPRs without a spill -> four workgroups per CU; 130 without the bound)
+__global__ __launch_bounds__(NTHREADS, 2) void k_sp_bwd_dkv(const TokArgs a) {   // (a bound of 4 -- 128 VGPRs, four workgroups per CU at D <= 64 -- measured: C2 +-0, blocks of 256 tokens 85 -> 94 us)
     constexpr int LD = mat_ld<DT>(), DW = Geo<DT>::DW, KST = Geo<DT>::KST, TILE = KST * 32 * LD;
     constexpr bool LO = !std::is_same<T, bf16_t>::value;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
