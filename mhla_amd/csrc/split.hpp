@@ -1083,6 +1083,34 @@ __device__ __forceinline__ uint4 pack8_16(f16_t, f32x4 a, f32x4 b) {
 }
 __device__ __forceinline__ uint4 pack8_16(float, f32x4, f32x4) { return make_uint4(0, 0, 0, 0); }   // (never called: fp32 stores 16-byte pieces already)
 
+// Two neighbouring feature tiles of a token in the products' output layout (a lane owns features 16 ct + 4 kg .. + 3 of each) -> the
+// token's row.  16-bit tensors on 16-byte aligned rows (`wide`): lane pairs (kg, kg ^ 1) swap halves, a lane then owns 8 consecutive
+// features -- one 16-byte piece -- and the four lanes of a token cover 64 contiguous bytes per instruction (the 8-byte pieces of
+// the plain layout cost k_sp_out 1.47x its bytes in HBM writes at C2).  EVERY lane must call this (shuffles); `live`: the lane's
+// token exists.
+template <typename T>
+__device__ __forceinline__ void store_tile_pair(T* tok, int ct, int ntiles, int D, int kg, const f32x4& v0, const f32x4& v1, bool live, bool wide) {
+    if constexpr (sizeof(T) == 2) {
+        if (wide && ct + 1 < ntiles) {   // (uniform)
+            const int podd = kg & 1;
+            const f32x4 send = podd ? v0 : v1, keep = podd ? v1 : v0;
+            f32x4 recv;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) recv[i] = __shfl_xor(send[i], 16, 64);
+            const int f0 = (ct + podd) * 16 + (kg >> 1) * 8;
+            if (live && f0 < D) gst<uint4>(tok + f0, pack8_16(T{}, podd ? recv : keep, podd ? keep : recv));
+            return;
+        }
+    }
+    if (live) {
+        const int d0 = ct * 16 + kg * 4;
+        if (d0 < D) Io<T>::st4(tok + d0, v0);
+        if (ct + 1 < ntiles && d0 + 16 < D) Io<T>::st4(tok + d0 + 16, v1);
+    }
+}
+template <typename V>
+__device__ __forceinline__ bool view16(const V& w) { return (reinterpret_cast<uintptr_t>(w.ptr) & 15) == 0 && ((w.sb | w.sn | w.sh) & 7) == 0; }
+
 constexpr int SP_OUT_T = 512;   // 8 waves share the staged G_i: twice the loads in flight per LDS byte
 template <typename T, int DT, typename TO = T, bool EPI = false, bool S16 = Sum16<T>::value>
 #ifndef SP_OUT_EPI_WAVES
@@ -1140,6 +1168,9 @@ __global__ __launch_bounds__(SP_OUT_T, EPI ? SP_OUT_EPI_WAVES : 2) void k_sp_out
             wide = (((reinterpret_cast<uintptr_t>(a.o.ptr) | reinterpret_cast<uintptr_t>(a.gate.ptr)) & 15) == 0) &&
                    (((a.o.sb | a.o.sn | a.o.sh | (a.gate.ptr ? (a.gate.sb | a.gate.sn | a.gate.sh) : 0)) & 7) == 0);
         const int podd = kg & 1, phalf = (kg >> 1) * 8;   // store layout: tile 2 j + podd, features phalf .. phalf + 7 of it
+        bool wide2 = false;   // the plain (no-epilogue) store of 16-bit results in the same layout
+        if constexpr (!EPI && sizeof(TO) == 2)
+            wide2 = a.skip_out || ((reinterpret_cast<uintptr_t>(a.o.ptr) & 15) == 0 && ((a.o.sb | a.o.sn | a.o.sh) & 7) == 0);
         typename Raw4<TO>::type gv[EPI ? DT : 1];
         uint4 gv8[WIDE_T ? (NPAIR ? NPAIR : 1) : 1];
         if constexpr (EPI) {
@@ -1182,16 +1213,38 @@ __global__ __launch_bounds__(SP_OUT_T, EPI ? SP_OUT_EPI_WAVES : 2) void k_sp_out
             if constexpr (EPI) {
                 res[ct] = c0 * ninv;
                 res[ct + 1] = c1 * ninv;
-            } else if (s < S) {
-                if (!a.skip_out) {
-                    if (ct * 16 + kg * 4 < D) Io<TO>::st4(orow + ct * 16, c0 * ninv);
-                    if (ct * 16 + 16 + kg * 4 < D) Io<TO>::st4(orow + ct * 16 + 16, c1 * ninv);
-                }
+            } else {
+                const f32x4 o0 = c0 * ninv, o1 = c1 * ninv;
+                bool stored = false;
                 if constexpr (sizeof(TO) == 2) {
-                    if (a.olo) {   // what the 16-bit store loses, for the backward's row dots (OutArgs::olo)
-                        u16* lo = a.olo + ((long)bh * a.M * S + p0 + s) * D + kg * 4;
-                        if (ct * 16 + kg * 4 < D) *reinterpret_cast<uint2*>(lo + ct * 16) = store_residual4<TO>(c0 * ninv);
-                        if (ct * 16 + 16 + kg * 4 < D) *reinterpret_cast<uint2*>(lo + ct * 16 + 16) = store_residual4<TO>(c1 * ninv);
+                    if (wide2 && ct + 1 < DT) {   // (uniform) the store layout of the fused epilogue: 16-byte pieces, 64 contiguous bytes per token and instruction
+                        const f32x4 send = podd ? o0 : o1, keep = podd ? o1 : o0;
+                        f32x4 recv;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) recv[i] = __shfl_xor(send[i], 16, 64);   // (every lane takes part)
+                        const f32x4 lo4 = podd ? recv : keep, hi4 = podd ? keep : recv;
+                        const int f0 = (ct + podd) * 16 + phalf;
+                        if (s < S && f0 < D) {
+                            if (!a.skip_out) gst<uint4>(ob + row * a.o.sn + f0, pack8_16(TO{}, lo4, hi4));
+                            if (a.olo) {   // what the 16-bit store loses, for the backward's row dots (OutArgs::olo)
+                                const uint2 r0 = store_residual4<TO>(lo4), r1 = store_residual4<TO>(hi4);
+                                gst<uint4>(a.olo + ((long)bh * a.M * S + p0 + s) * D + f0, make_uint4(r0.x, r0.y, r1.x, r1.y));
+                            }
+                        }
+                        stored = true;
+                    }
+                }
+                if (!stored && s < S) {
+                    if (!a.skip_out) {
+                        if (ct * 16 + kg * 4 < D) Io<TO>::st4(orow + ct * 16, o0);
+                        if (ct * 16 + 16 + kg * 4 < D) Io<TO>::st4(orow + ct * 16 + 16, o1);
+                    }
+                    if constexpr (sizeof(TO) == 2) {
+                        if (a.olo) {
+                            u16* lo = a.olo + ((long)bh * a.M * S + p0 + s) * D + kg * 4;
+                            if (ct * 16 + kg * 4 < D) *reinterpret_cast<uint2*>(lo + ct * 16) = store_residual4<TO>(o0);
+                            if (ct * 16 + 16 + kg * 4 < D) *reinterpret_cast<uint2*>(lo + ct * 16 + 16) = store_residual4<TO>(o1);
+                        }
                     }
                 }
             }
@@ -1430,6 +1483,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_bwd_dq(const TokArgs a) {
     const float* ninvb = a.ninv + ((long)bh * M + blk) * S;
     const float* dzb = a.dz + ((long)bh * M + blk) * S;
     constexpr bool wide_q = WQ;   // (the launch picks WQ = normalize && !relu)
+    const bool wide_dq = view16(a.dq), wide_dqd = a.split && view16(a.dqd);   // (uniform) 16-byte store layout
 
     // one 16-token tile of this wave: the lane's token row, its dO features as the MFMA B operand (8 per reduction step) and
     // its q_den features in output layout (4 per feature tile); fetched one tile ahead of the tile being computed
@@ -1537,15 +1591,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_bwd_dq(const TokArgs a) {
             if (ct + 1 < DT) epilogue(ct + 1, c1, e1, rc1, rs1);
             // the two 64-byte halves of a 128-byte line go out in consecutive store instructions (write combining):
             // half-line stores separated in time cost a fill read and a second write per line
-            const int d0 = ct * 16 + kg * 4, d1 = d0 + 16;
-            if (cur.live) {
-                if (d0 < D) Io<T>::st4(dqb + cur.row * a.dq.sn + d0, c0);
-                if (ct + 1 < DT && d1 < D) Io<T>::st4(dqb + cur.row * a.dq.sn + d1, c1);
-                if (a.normalize && a.split) {
-                    if (d0 < D) Io<T>::st4(dqdb + cur.row * a.dqd.sn + d0, e0);
-                    if (ct + 1 < DT && d1 < D) Io<T>::st4(dqdb + cur.row * a.dqd.sn + d1, e1);
-                }
-            }
+            store_tile_pair<T>(dqb + cur.row * a.dq.sn, ct, DT, D, kg, c0, c1, cur.live, wide_dq);
+            if (a.normalize && a.split) store_tile_pair<T>(dqdb + cur.row * a.dqd.sn, ct, DT, D, kg, e0, e1, cur.live, wide_dqd);
             __builtin_amdgcn_sched_barrier(0);   // keep the LDS operand reads of later tiles from being hoisted (register pressure)
         }
         if constexpr (WQ) {
@@ -1631,6 +1678,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_bwd_dkv(const TokArgs a) {  
             }
         }
     };
+    const bool wide_dk = view16(a.dk), wide_dv = view16(a.dv);   // (uniform) 16-byte store layout
     fetch(wave, cur);
     stage_mat_split<DT, S16>(Gh, Gl, a.dkv, ((long)bh * M + blk) * a.es, D, tid);
     if (tid < DW) dks[tid] = (a.normalize && tid < D) ? a.dks[((long)bh * M + blk) * D + tid] : 0.f;
@@ -1692,14 +1740,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_bwd_dkv(const TokArgs a) {  
             }
             dkst[ct & 1] = ck;
             dvst[ct & 1] = cv;
-            if (((ct & 1) || ct == DT - 1) && cur.live) {   // store pairs of feature tiles: whole 128-byte lines (fp32)
-                const int da = (ct & ~1) * 16 + kg * 4, db = da + 16;
-                const bool sa = da < D, sb = (ct & 1) && db < D;
-                if (sa) Io<T>::st4(dkb + cur.row * a.dk.sn + da, dkst[0]);
-                if (sb) Io<T>::st4(dkb + cur.row * a.dk.sn + db, dkst[1]);
-                if (sa) Io<T>::st4(dvb + cur.row * a.dv.sn + da, dvst[0]);
-                if (sb) Io<T>::st4(dvb + cur.row * a.dv.sn + db, dvst[1]);
-                if (a.normalize && a.split) {
+            if ((ct & 1) || ct == DT - 1) {   // store pairs of feature tiles: whole 128-byte lines (fp32) / 16-byte pieces (16-bit tensors)
+                const int cta = ct & ~1, nt2 = (ct & 1) ? DT : cta + 1;   // (a lone last tile: no partner)
+                store_tile_pair<T>(dkb + cur.row * a.dk.sn, cta, nt2, D, kg, dkst[0], dkst[1], cur.live, wide_dk);
+                store_tile_pair<T>(dvb + cur.row * a.dv.sn, cta, nt2, D, kg, dvst[0], dvst[1], cur.live, wide_dv);
+                if (a.normalize && a.split && cur.live) {
+                    const int da = cta * 16 + kg * 4, db = da + 16;
+                    const bool sa = da < D, sb = (ct & 1) && db < D;
                     if (sa) Io<T>::st4(dkdb + cur.row * a.dkd.sn + da, *reinterpret_cast<const f32x4*>(dks + da));
                     if (sb) Io<T>::st4(dkdb + cur.row * a.dkd.sn + db, *reinterpret_cast<const f32x4*>(dks + db));
                 }
