@@ -32,7 +32,8 @@ inline int sp_mixr(const float* W, int ldw, const void* in, void* out, int M, lo
 #define MIXR(NW) do { \
         constexpr int TE = sp::mixr_te<NW, S16>(); \
         const long total = (long)BH * (E / TE); \
-        const int wgs = (int)std::min<long>(total, 256); \
+        /* persistent workgroups: as many as fit a CU beside each other (35 KB of LDS at four waves, 70 KB at eight) */ \
+        const int wgs = (int)std::min<long>(total, 256 * (NW <= 4 ? 4 : NW <= 8 ? 2 : 1)); \
         sp::MixrArgs a{W, ldw, in, out, M, E, es, total, (int)((total + wgs - 1) / wgs), nullptr, nullptr, 0, 0.f, nullptr}; \
         const int gw = (int)((total + a.spw - 1) / a.spw); \
         return launch(sp::k_sp_mixr<NW, TRANS, S16>, dim3(gw), dim3(64 * NW), sp::sp_mixr_smem<NW, S16>(), st, TRANS ? "k_sp_mixr<1>" : "k_sp_mixr<0>", a); \
@@ -63,7 +64,7 @@ inline int sp_mixr_dw(const float* W, int ldw, const void* dg, const void* kv, v
 #define MIXRDW(NW) do { \
         constexpr int TE = sp::mixr_te<NW, false>(); \
         const long total = (long)BH * (E / TE); \
-        const int wgs = (int)std::min<long>(total, 256); \
+        const int wgs = (int)std::min<long>(total, 256 * (NW <= 4 ? 2 : 1));   /* 54 KB of LDS at four waves: two per CU */ \
         sp::MixrArgs a{W, ldw, dg, dkv, M, E, es, total, (int)((total + wgs - 1) / wgs), nullptr, nullptr, 0, 0.f, nullptr, kv, dwp}; \
         const int gw = (int)((total + a.spw - 1) / a.spw); \
         *nparts = gw; \

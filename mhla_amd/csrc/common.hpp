@@ -163,6 +163,16 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// Sum over the 16 lanes of a DPP row (lanes 16 r .. 16 r + 15), in every lane: four rotate-and-add steps in the VALU (row_ror:8/4/2/1)
+// instead of four ds_bpermute round trips through the LDS pipe.
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xf, 0xf, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false));
+    return v;
+}
+
 // Row of block-major position p in memory.
 __device__ __forceinline__ long tok_row(const int* __restrict__ idx, long p) { return idx ? (long)idx[p] : p; }
 

@@ -1466,7 +1466,7 @@ __device__ __forceinline__ bf16x8 row_read8(const u16* tile, int ld, int c0, int
 // WQ: q_den enters only dksum (normaliser on, no relu prologue) and is fetched in 16-byte pieces in the operand layout; otherwise in
 // the output layout, where the relu gradient mask needs it (a template flag: both register sets at once cost the occupancy)
 template <typename T, int DT, bool ROPE = false, bool S16 = Sum16<T>::value, bool WQ = false>
-__global__ __launch_bounds__(NTHREADS, 2) void k_sp_bwd_dq(const TokArgs a) {
+__global__ __launch_bounds__(NTHREADS, (DT <= 4 && WQ) ? 4 : 2) void k_sp_bwd_dq(const TokArgs a) {
     constexpr int LD = mat_ld<DT>(), DW = Geo<DT>::DW, KST = Geo<DT>::KST, TILE = KST * 32 * LD;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u16* Gh = reinterpret_cast<u16*>(smem_raw);
@@ -1607,9 +1607,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_bwd_dq(const TokArgs a) {
             for (int ks = 0; ks < KST; ++ks)
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    float v = dksw8[ks][i >> 2][i & 3];
-#pragma unroll
-                    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+                    const float v = row16_sum(dksw8[ks][i >> 2][i & 3]);
                     if (nl == 0 && ks * 32 + kg * 8 + i < DW) dksw[wave * DW + ks * 32 + kg * 8 + i] = v;
                 }
         } else {
@@ -1617,9 +1615,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_bwd_dq(const TokArgs a) {
             for (int ct = 0; ct < (WQ ? 1 : DT); ++ct)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    float v = dksp[ct][i];
-#pragma unroll
-                    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+                    const float v = row16_sum(dksp[ct][i]);
                     if (nl == 0) dksw[wave * DW + ct * 16 + kg * 4 + i] = v;
                 }
         }
