@@ -24,18 +24,21 @@ inline bool sp_mixr_ok(int M, long E) {
     return M > 32 && M <= 256 && E % sp::mixr_te<4, S16>() == 0;
 }
 // the normaliser's product (k_wz) rides along in the LDS-DMA mixing kernel: same weights, at most 16 values per block
+// ... and in the register-staged kernel at fp32 summaries, as extra slices (blocks of a multiple of 4 tokens: 16-byte pieces)
 template <bool S16>
-inline bool sp_mixr_takes_wz(int M, int S) { return S16 && M > 192 && M <= 256 && S <= 16; }
+inline bool sp_mixr_takes_wz(int M, int S) { return S16 ? (M > 192 && M <= 256 && S <= 16) : (S % 4 == 0); }
 template <int TRANS, bool S16>
 inline int sp_mixr(const float* W, int ldw, const void* in, void* out, int M, long E, long es, int BH, hipStream_t st,
                    const float* zin = nullptr, float* zout = nullptr, int S = 0, float eps = 0.f) {
 #define MIXR(NW) do { \
         constexpr int TE = sp::mixr_te<NW, S16>(); \
         const long total = (long)BH * (E / TE); \
+        const bool wz = !S16 && zin && sp_mixr_takes_wz<S16>(M, S); \
+        const long all = total + (wz ? (long)BH * ((S + TE - 1) / TE) : 0); \
         /* persistent workgroups: as many as fit a CU beside each other (35 KB of LDS at four waves, 70 KB at eight) */ \
-        const int wgs = (int)std::min<long>(total, 256 * (NW <= 4 ? 4 : NW <= 8 ? 2 : 1)); \
-        sp::MixrArgs a{W, ldw, in, out, M, E, es, total, (int)((total + wgs - 1) / wgs), nullptr, nullptr, 0, 0.f, nullptr}; \
-        const int gw = (int)((total + a.spw - 1) / a.spw); \
+        const int wgs = (int)std::min<long>(all, 256 * (NW <= 4 ? 4 : NW <= 8 ? 2 : 1)); \
+        sp::MixrArgs a{W, ldw, in, out, M, E, es, total, (int)((all + wgs - 1) / wgs), wz ? zin : nullptr, wz ? zout : nullptr, wz ? S : 0, eps, nullptr, nullptr, nullptr, all - total, nullptr}; \
+        const int gw = (int)((all + a.spw - 1) / a.spw); \
         return launch(sp::k_sp_mixr<NW, TRANS, S16>, dim3(gw), dim3(64 * NW), sp::sp_mixr_smem<NW, S16>(), st, TRANS ? "k_sp_mixr<1>" : "k_sp_mixr<0>", a); \
     } while (0)
     if constexpr (S16) {
@@ -59,14 +62,19 @@ inline int sp_mixr(const float* W, int ldw, const void* in, void* out, int M, lo
 // The backward's mixing dKV = W^T dG with the dW products riding along (sp::k_sp_mixr<.., DW>): fp32 summaries, 33 <= M <= 128.
 // Returns the number of [M][M] partials written to `dwp` (one per workgroup) through `nparts`.
 inline bool sp_mixr_dw_ok(int M, long E) { return sp_mixr_ok<false>(M, E) && M <= 128; }
+// dn / z / dz (null: no normaliser): dz = W^T dn and the <dn_i, z_j> term of dW ride along as extra slices when the block length allows
+// (sp_mixr_takes_wz); `*wz_done` tells the caller whether they did.
 inline int sp_mixr_dw(const float* W, int ldw, const void* dg, const void* kv, void* dkv, float* dwp, int M, long E, long es, int BH,
-                      hipStream_t st, int* nparts) {
+                      hipStream_t st, int* nparts, const float* dn, const float* z, float* dz, int S, bool* wz_done) {
+    const bool wz = dn && z && dz && sp_mixr_takes_wz<false>(M, S);
+    *wz_done = wz;
 #define MIXRDW(NW) do { \
         constexpr int TE = sp::mixr_te<NW, false>(); \
         const long total = (long)BH * (E / TE); \
-        const int wgs = (int)std::min<long>(total, 256 * (NW <= 4 ? 2 : 1));   /* 54 KB of LDS at four waves: two per CU */ \
-        sp::MixrArgs a{W, ldw, dg, dkv, M, E, es, total, (int)((total + wgs - 1) / wgs), nullptr, nullptr, 0, 0.f, nullptr, kv, dwp}; \
-        const int gw = (int)((total + a.spw - 1) / a.spw); \
+        const long all = total + (wz ? (long)BH * ((S + TE - 1) / TE) : 0); \
+        const int wgs = (int)std::min<long>(all, 256 * (NW <= 4 ? 2 : 1));   /* 54 KB of LDS at four waves: two per CU */ \
+        sp::MixrArgs a{W, ldw, dg, dkv, M, E, es, total, (int)((all + wgs - 1) / wgs), wz ? dn : nullptr, wz ? dz : nullptr, wz ? S : 0, 0.f, nullptr, kv, dwp, all - total, wz ? z : nullptr}; \
+        const int gw = (int)((all + a.spw - 1) / a.spw); \
         *nparts = gw; \
         return launch(sp::k_sp_mixr<NW, 1, false, true>, dim3(gw), dim3(64 * NW), sp::sp_mixr_smem<NW, false, true>(), st, "k_sp_mixr<1,dw>", a); \
     } while (0)
@@ -237,12 +245,14 @@ int bm_bwd_typed(const BmCall& c) {
             const bool mixr = sp_mixr_ok<S16>(M, E), wz_fused = mixr && normalize && sp_mixr_takes_wz<S16>(M, S);
             if (normalize && !wz_fused)
                 RC(launch(k_wz<1>, dim3((S + 63) / 64, (M + 63) / 64, B * H), dim3(NTHREADS), 0, st, "k_wz<1>", W, ldw, (const float*)w.dn, w.dz, M, S, 0.f));
+            bool dwz_done = false;   // the <dn_i, z_j> term of dW is in the fused kernel's partials
             MixArgs m{W, ldw, w.dg, w.dkv, M, E, w.es};
             // fp32 summaries, 33 .. 128 blocks: dW's products ride in the mixing kernel (its staged dG slices + the KV slices), one
             // partial per workgroup -- dG and KV are not read a second time by k_sp_dw
             const bool dwfused = !S16 && mixr && sp_mixr_dw_ok(M, E);
             int fused_parts = 0;
-            if (dwfused) RC(sp_mixr_dw(W, ldw, w.dg, w.kv, w.dkv, w.dwp, M, E, w.es, B * H, st, &fused_parts));
+            if (dwfused) RC(sp_mixr_dw(W, ldw, w.dg, w.kv, w.dkv, w.dwp, M, E, w.es, B * H, st, &fused_parts, normalize ? (const float*)w.dn : nullptr,
+                                       normalize ? (const float*)w.z : nullptr, w.dz, S, &dwz_done));
             else if (mixr) RC((sp_mixr<1, S16>(W, ldw, w.dg, w.dkv, M, E, w.es, B * H, st, normalize ? (const float*)w.dn : nullptr, w.dz, S, 0.f)));
             else RC(launch(sp::k_sp_mix<1, S16>, dim3((unsigned)((E + sp::SPM_TE - 1) / sp::SPM_TE), tiles, B * H), dim3(NTHREADS), sp::sp_mix_smem<S16>(), st, "k_sp_mix<1>", m));
             int nsplit = dw_splits(tiles * tiles * B * H, E);
@@ -258,7 +268,7 @@ int bm_bwd_typed(const BmCall& c) {
             else if (M <= 32) RC(launch(sp::k_sp_dw<S16, 2>, dim3(1, B * H, nsplit), dim3(NTHREADS), sp::SP_DW_SMEM, st, "k_sp_dw<32>", d));
             else              RC(launch(sp::k_sp_dw<S16>, dim3(tiles * tiles, B * H, nsplit), dim3(NTHREADS), sp::SP_DW_SMEM, st, "k_sp_dw", d));
             int nparts = dwfused ? fused_parts : B * H * nsplit;
-            if (normalize && !dwr) {
+            if (normalize && !dwr && !dwz_done) {
                 DwArgs dzz{w.dn, w.z, (long)S, nullptr, nullptr, 0, w.dwp + (size_t)nparts * M * M, M, tiles, 1};
                 RC(launch(k_dw<0>, dim3(tiles * tiles, B * H, 1), dim3(NTHREADS), DW_SMEM_FLOATS * 4, st, "k_dw", dzz));
                 nparts += B * H;

@@ -608,6 +608,11 @@ struct MixrArgs {
     // kernel stages anyway, so that dG is read from HBM once for dKV and dW together
     const void* in2;
     float* dwp;
+    // k_sp_mixr, fp32 summaries: the normaliser's product rides along as EXTRA SLICES after the summaries' -- block r's S values zin[bh][r][:]
+    // are one more row set mixed with the same weights (slices of TE values, ztotal = bh * ceil(S / TE) of them; S % 4 == 0), stored
+    // through f into zout.  DW: zin = dn, zin2 = z, and the <dn_i, z_j> term of dW falls out of the same products (k_dw is not launched).
+    long ztotal;
+    const float* zin2;
 };
 // slice width: 256-byte row pieces; 128-byte ones for 16 waves (1024 threads on 128 VGPRs: half the accumulators and staging registers)
 template <int NW, bool S16> __host__ __device__ constexpr int mixr_te() { return (S16 ? 128 : 64) / (NW > 12 ? 2 : 1); }
@@ -638,8 +643,9 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void k_sp_mixr(const MixrArg
     const int M = a.M;
     const long nsl = a.E / TE;
     const long s0 = (long)blockIdx.x * a.spw;
-    const int cnt = (int)min((long)a.spw, a.total - s0);
+    const int cnt = (int)min((long)a.spw, a.total + (S16 ? 0 : a.ztotal) - s0);
     if (cnt <= 0) return;
+    const int nbh_all = (int)(a.total / nsl), nzs = (a.S + TE - 1) / TE;   // (b, h) pairs; normaliser slices per pair
     // B operand: B[k = r][n = o] = weight of input block r in output block o = 16 wave + nl, r = 32 ks + 8 kg + t
     bf16x8 wh[NK][1], wl[NK][1];
     static_assert((TRANS ? 64 * (ROWS + 4) : ROWS * 68) * 4 <= sp_mixr_smem<NW, S16, DW>(), "weight chunk must fit in the tiles");
@@ -647,9 +653,16 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void k_sp_mixr(const MixrArg
     constexpr int ESZ = S16 ? 2 : 4;
     // byte offset of slice (bh, es); a workgroup's slices are consecutive, so the pair is advanced rather than divided out per
     // slice (the 64-bit division was 150 instructions with branches between the barrier and the next slice's loads)
-    auto slice_off = [&](int bh, int es) { return ((long)bh * M * a.es + (long)es * TE) * ESZ; };
-    auto advance = [&](int& bh, int& es) { if (++es == (int)nsl) { es = 0; ++bh; } };
-    int cbh = (int)(s0 / nsl), ces = (int)(s0 - (long)cbh * nsl), nbh = cbh, nes = ces;
+    // (normaliser slices follow the last summary slice: bh >= nbh_all counts them, bh - nbh_all is their (b, h))
+    auto is_z = [&](int bh) { return !S16 && bh >= nbh_all; };
+    auto slice_off = [&](int bh, int es) {
+        return is_z(bh) ? ((long)(bh - nbh_all) * M * a.S + (long)es * TE) * 4 : ((long)bh * M * a.es + (long)es * TE) * ESZ;
+    };
+    auto advance = [&](int& bh, int& es) { if (++es == (is_z(bh) ? nzs : (int)nsl)) { es = 0; ++bh; } };
+    int cbh, ces;
+    if (S16 || s0 < a.total) { cbh = (int)(s0 / nsl); ces = (int)(s0 - (long)cbh * nsl); }
+    else { const long zi = s0 - a.total; cbh = nbh_all + (int)(zi / nzs); ces = (int)(zi % nzs); }
+    int nbh = cbh, nes = ces;
     // the thread's pieces: piece v = tid + p NTH -> row v / PPR, 16 bytes at column piece v % PPR (rows past M: the last row, zeroed)
     unsigned goff[NP];
 #pragma unroll
@@ -658,7 +671,22 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void k_sp_mixr(const MixrArg
         goff[p] = (unsigned)((long)(row < M ? row : M - 1) * a.es * ESZ + c * 16);
     }
     uint4 pre[NP], pre2[DW ? NP : 1];
-    auto issue = [&](long boff) {
+    // a normaliser slice: rows of S floats, pieces past the row's end are not touched (zeros)
+    auto zoff = [&](int p) { const int v = tid + p * NTH, row = v / PPR, c = v % PPR; return (unsigned)((row < M ? row : M - 1) * a.S * 4 + c * 16); };
+    auto zlive = [&](int p, int es) { return ((tid + p * NTH) % PPR) * 4 + es * TE < a.S; };
+    auto issue = [&](int bh, int es) {
+        const long boff = slice_off(bh, es);
+        if (is_z(bh)) {   // (uniform)
+            const char* base = reinterpret_cast<const char*>(a.zin) + boff;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) pre[p] = zlive(p, es) ? gld_stream16(base + zoff(p)) : make_uint4(0u, 0u, 0u, 0u);
+            if constexpr (DW) {
+                const char* base2 = reinterpret_cast<const char*>(a.zin2) + boff;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) pre2[p] = zlive(p, es) ? gld_stream16(base2 + zoff(p)) : make_uint4(0u, 0u, 0u, 0u);
+            }
+            return;
+        }
         const char* base = reinterpret_cast<const char*>(a.in) + boff;
 #pragma unroll
         for (int p = 0; p < NP; ++p) pre[p] = gld_stream16(base + goff[p]);
@@ -684,9 +712,11 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void k_sp_mixr(const MixrArg
         *reinterpret_cast<uint2*>(th + row * LD + c * 4) = make_uint2(hs[0] | ((unsigned)hs[1] << 16), hs[2] | ((unsigned)hs[3] << 16));
         *reinterpret_cast<uint2*>(tl + row * LD + c * 4) = make_uint2(pack_bf16x2(l[0], l[1]), pack_bf16x2(l[2], l[3]));
     };
-    issue(slice_off(nbh, nes));
+    issue(nbh, nes);
     for (int it = 0; it < cnt; ++it) {
         const long off = slice_off(cbh, ces);
+        const bool zslice = is_z(cbh);   // (uniform)
+        const int zes = ces;
         advance(cbh, ces);
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
@@ -706,7 +736,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void k_sp_mixr(const MixrArg
         __syncthreads();
         if (it + 1 < cnt) {
             advance(nbh, nes);
-            issue(slice_off(nbh, nes));
+            issue(nbh, nes);
         }
         f32x4 acc[NT];
 #pragma unroll
@@ -762,6 +792,23 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void k_sp_mixr(const MixrArg
                 *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(Os) + (wave * 16 + nl) * LDO + t * 16 + kg * 4) = acc[t];
         }
         __syncthreads();
+        if constexpr (!S16) {
+            if (zslice) {   // the normaliser's rows: 1 / (eps + .) in the forward, as they are in the backward
+                char* zb = reinterpret_cast<char*>(a.zout) + off;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    const int v = tid + p * NTH, row = v / PPR, c = v % PPR;
+                    if (row < M && zlive(p, zes)) {
+                        f32x4 x = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(Os) + row * LDO + c * 4);
+                        if (TRANS == 0)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) x[i] = 1.f / (a.eps + x[i]);
+                        *reinterpret_cast<f32x4*>(zb + zoff(p)) = x;
+                    }
+                }
+                continue;
+            }
+        }
         char* ob = reinterpret_cast<char*>(a.out) + off;
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
