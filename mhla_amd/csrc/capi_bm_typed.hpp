@@ -273,7 +273,9 @@ int bm_bwd_typed(const BmCall& c) {
                 RC(launch(k_dw<0>, dim3(tiles * tiles, B * H, 1), dim3(NTHREADS), DW_SMEM_FLOATS * 4, st, "k_dw", dzz));
                 nparts += B * H;
             }
-            if (M * M <= 1024) RC(launch(k_dw_reduce<0, 16>, dim3((M * M + 15) / 16), dim3(256), 0, st, "k_dw_reduce", (const float*)w.dwp,
+            // (16 elements x 16 part-lanes per workgroup when the matrix is small or the parts are many: a thread's chain of dependent
+            // load batches is what the kernel takes -- 512 parts of 64 x 64 at 64 x 4: 10 us)
+            if (M * M <= 1024 || nparts >= 128) RC(launch(k_dw_reduce<0, 16>, dim3((M * M + 15) / 16), dim3(256), 0, st, "k_dw_reduce", (const float*)w.dwp,
                       (const float*)nullptr, dW, M, M, nparts, B * H));
             else RC(launch(k_dw_reduce<0>, dim3((M * M + 63) / 64), dim3(256), 0, st, "k_dw_reduce", (const float*)w.dwp,
                       (const float*)nullptr, dW, M, M, nparts, B * H));
@@ -307,7 +309,7 @@ int bm_bwd_typed(const BmCall& c) {
         const int nsplit = dw_splits(tiles * tiles * B * H, (long)D * D);
         DwArgs d{w.dg, w.kv, (long)D * D, normalize ? w.dn : nullptr, normalize ? w.z : nullptr, (long)S, w.dwp, M, tiles, nsplit};
         RC(launch(k_dw<0>, dim3(tiles * tiles, B * H, nsplit), dim3(NTHREADS), DW_SMEM_FLOATS * 4, st, "k_dw", d));
-        if (M * M <= 1024) RC(launch(k_dw_reduce<0, 16>, dim3((M * M + 15) / 16), dim3(256), 0, st, "k_dw_reduce", (const float*)w.dwp,
+        if (M * M <= 1024 || B * H * nsplit >= 128) RC(launch(k_dw_reduce<0, 16>, dim3((M * M + 15) / 16), dim3(256), 0, st, "k_dw_reduce", (const float*)w.dwp,
                   (const float*)nullptr, dW, M, M, B * H * nsplit, B * H));
         else RC(launch(k_dw_reduce<0>, dim3((M * M + 63) / 64), dim3(256), 0, st, "k_dw_reduce", (const float*)w.dwp,
                   (const float*)nullptr, dW, M, M, B * H * nsplit, B * H));

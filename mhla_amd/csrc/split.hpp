@@ -285,6 +285,38 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : (ROPE ? 2 : 3)) void k_sp_state
 
     // KV_j -> ws  (C layout: row d1 = 16 tile + 4 kg + r, column d2 = 16 ct + nl)
     float* ob = a.out + ((long)bh * a.M + blk) * a.es;
+    // fp32 summaries: through a wave-private LDS tile [16][CW + 4] (the operand tiles are free after the last product), so that a lane
+    // stores 16-byte pieces and 16 lanes cover a whole row of the summary -- in the C layout a store instruction wrote four 64-byte
+    // segments (k_sp_state ran at 3.9 TB/s of its bytes at C2)
+    constexpr int CW = (DW > 64 && NWV == 8) ? 64 : DW, LDO = CW + 4, PPRO = CW / 4;
+    static_assert(NWV * 16 * LDO * 4 <= 4 * 32 * LD * 2, "the staging tiles of all waves must fit in the operand tiles");
+    const bool staged = !S16 && (D & 3) == 0 && (a.es & 3) == 0;   // (uniform)
+    if (staged) {
+        float* Os = reinterpret_cast<float*>(smem_raw) + wave * 16 * LDO;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const int tile = wave * RT + rt;
+            if (tile * 16 < D) {   // (uniform)
+#pragma unroll
+                for (int c0 = 0; c0 < DW; c0 += CW) {
+#pragma unroll
+                    for (int ct = c0 / 16; ct < (c0 + CW) / 16; ++ct)
+                        if (ct < DT)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) Os[(kg * 4 + r) * LDO + ct * 16 - c0 + nl] = acc[rt][ct][r];
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int p = 0; p < CW / 16; ++p) {
+                        const int v = lane + 64 * p, row = v / PPRO, c4 = v % PPRO;
+                        const int grow = tile * 16 + row, gcol = c0 + c4 * 4;
+                        if (grow < D && gcol < D) gst<f32x4>(ob + (long)grow * D + gcol, *reinterpret_cast<const f32x4*>(Os + row * LDO + c4 * 4));
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+        }
+        if (MODE == 0 && a.normalize) __syncthreads();   // (the column sums below reuse the tiles)
+    } else {
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -297,6 +329,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : (ROPE ? 2 : 3)) void k_sp_state
                     else                 ob[(long)row * D + col] = acc[rt][ct][r];
                 }
             }
+    }
 
     if (MODE == 0 && a.normalize) {
 #pragma unroll
