@@ -210,10 +210,14 @@ const char* mhla_last_error(void) { return g_err; }
 //   "bwd_two_launches"   1: the backward's dQ and dK/dV tile roles as two launches (also latched by the library itself after a
 //                        hand-over expired), 0: one fused launch
 //   "debug_drop_signal"  testing aid: the dQ role does not raise its hand-over flags
+//   "fp32_summaries"     1: 16-bit tensors at the default arithmetic keep their block summaries as fp32 in the workspace instead of
+//                        24-bit floats (split.hpp p24) -- a measurement aid; set it BETWEEN calls, not between a forward and the
+//                        backward that reuses its state
 // Returns the previous value, or MHLA_EINVAL for an unknown name.
 int mhla_set_option(const char* name, int value) {
     if (name && !strcmp(name, "bwd_two_launches")) return g_two_launches.exchange(value != 0);
     if (name && !strcmp(name, "debug_drop_signal")) return g_drop_signal.exchange(value != 0);
+    if (name && !strcmp(name, "fp32_summaries")) return g_no_p24.exchange(value != 0);
     return fail(MHLA_EINVAL, "mhla_set_option: unknown option '%s'", name ? name : "(null)");
 }
 

@@ -27,7 +27,7 @@ inline bool sp_mixr_ok(int M, long E) {
 // ... and in the register-staged kernel at fp32 summaries, as extra slices (blocks of a multiple of 4 tokens: 16-byte pieces)
 template <bool S16>
 inline bool sp_mixr_takes_wz(int M, int S) { return S16 ? (M > 192 && M <= 256 && S <= 16) : (S % 4 == 0); }
-template <int TRANS, bool S16>
+template <int TRANS, bool S16, bool P24 = false>
 inline int sp_mixr(const float* W, int ldw, const void* in, void* out, int M, long E, long es, int BH, hipStream_t st,
                    const float* zin = nullptr, float* zout = nullptr, int S = 0, float eps = 0.f) {
 #define MIXR(NW) do { \
@@ -39,7 +39,7 @@ inline int sp_mixr(const float* W, int ldw, const void* in, void* out, int M, lo
         const int wgs = (int)std::min<long>(all, 256 * (NW <= 4 ? 4 : NW <= 8 ? 2 : 1)); \
         sp::MixrArgs a{W, ldw, in, out, M, E, es, total, (int)((all + wgs - 1) / wgs), wz ? zin : nullptr, wz ? zout : nullptr, wz ? S : 0, eps, nullptr, nullptr, nullptr, all - total, nullptr}; \
         const int gw = (int)((all + a.spw - 1) / a.spw); \
-        return launch(sp::k_sp_mixr<NW, TRANS, S16>, dim3(gw), dim3(64 * NW), sp::sp_mixr_smem<NW, S16>(), st, TRANS ? "k_sp_mixr<1>" : "k_sp_mixr<0>", a); \
+        return launch(sp::k_sp_mixr<NW, TRANS, S16, false, P24>, dim3(gw), dim3(64 * NW), sp::sp_mixr_smem<NW, S16>(), st, TRANS ? "k_sp_mixr<1>" : "k_sp_mixr<0>", a); \
     } while (0)
     if constexpr (S16) {
         if (M > 192) {   // eight waves x 32 output blocks, LDS-DMA staging with three slices in flight
@@ -53,8 +53,11 @@ inline int sp_mixr(const float* W, int ldw, const void* in, void* out, int M, lo
     }
     if (M <= 64) MIXR(4);
     if (M <= 128) MIXR(8);
+    if constexpr (P24) return fail(MHLA_EINVAL, "sp_mixr: p24 summaries at M=%d", M);   // (bm_p24 admits 33 .. 128 blocks)
+    else {
     if (M <= 192) MIXR(12);
     if constexpr (!S16) MIXR(16);   // (16-bit summaries: taken by the DMA kernel above)
+    }
     return fail(MHLA_EINVAL, "sp_mixr: M=%d out of range", M);
 #undef MIXR
 }
@@ -64,6 +67,7 @@ inline int sp_mixr(const float* W, int ldw, const void* in, void* out, int M, lo
 inline bool sp_mixr_dw_ok(int M, long E) { return sp_mixr_ok<false>(M, E) && M <= 128; }
 // dn / z / dz (null: no normaliser): dz = W^T dn and the <dn_i, z_j> term of dW ride along as extra slices when the block length allows
 // (sp_mixr_takes_wz); `*wz_done` tells the caller whether they did.
+template <bool P24 = false>
 inline int sp_mixr_dw(const float* W, int ldw, const void* dg, const void* kv, void* dkv, float* dwp, int M, long E, long es, int BH,
                       hipStream_t st, int* nparts, const float* dn, const float* z, float* dz, int S, bool* wz_done) {
     const bool wz = dn && z && dz && sp_mixr_takes_wz<false>(M, S);
@@ -76,12 +80,22 @@ inline int sp_mixr_dw(const float* W, int ldw, const void* dg, const void* kv, v
         sp::MixrArgs a{W, ldw, dg, dkv, M, E, es, total, (int)((all + wgs - 1) / wgs), wz ? dn : nullptr, wz ? dz : nullptr, wz ? S : 0, 0.f, nullptr, kv, dwp, all - total, wz ? z : nullptr}; \
         const int gw = (int)((all + a.spw - 1) / a.spw); \
         *nparts = gw; \
-        return launch(sp::k_sp_mixr<NW, 1, false, true>, dim3(gw), dim3(64 * NW), sp::sp_mixr_smem<NW, false, true>(), st, "k_sp_mixr<1,dw>", a); \
+        return launch(sp::k_sp_mixr<NW, 1, false, true, P24>, dim3(gw), dim3(64 * NW), sp::sp_mixr_smem<NW, false, true>(), st, "k_sp_mixr<1,dw>", a); \
     } while (0)
     if (M <= 64) MIXRDW(4);
     MIXRDW(8);
 #undef MIXRDW
 }
+
+// p24 summaries (split.hpp: 24-bit floats, 3 / 4 of the bytes of every summary transfer): 16-bit tensors at the default arithmetic, the range
+// of the resident mixing with its fused dW (33 .. 128 blocks), head dims up to 64, no rotary tables or fused epilogue (fp32-tensor
+// features).  A function of the call's shape, dtype and flags only: a forward and the backward that reuses its state agree.
+template <typename ET, int DT, bool S16>
+inline bool bm_p24(int M, int D, unsigned flags) {
+    if constexpr (S16 || sizeof(ET) != 2 || DT > 4) return false;
+    else return sp_shape_ok(D, flags) && sp_mixr_dw_ok(M, (long)D * D) && !g_no_p24.load();
+}
+inline long bm_p24_es(int D) { return 3L * D * D / 4 + 288; }   // row stride in float units: 3 bytes per element + the padding of bm_row_elems
 
 // Blocks of exactly 16 tokens, bf16, D = 64, every row a whole number of 16-byte pieces: the wave-per-block kernels of split16.hpp
 // replace the token kernels (same workspace formats).  `bwd`: the call's gradient views must qualify too.
@@ -118,15 +132,27 @@ int bm_state_and_mix(const mhla_view& q_num, const mhla_view& k_num, const mhla_
                      int M, int S, int D, float eps, unsigned flags, bool normalize, bool split, hipStream_t st,
                      const float* rcos = nullptr, const float* rsin = nullptr, long ldr = 0, bool s16 = false) {
     (void)q_num;
+    constexpr bool P24OK = !S16 && sizeof(T) == 2 && DT <= 4;
+    const bool p24 = !rcos && bm_p24<T, DT, S16>(M, D, flags);
+    const long es = p24 ? bm_p24_es(D) : w.es;
     StateArgs a{};
     a.rcos = rcos; a.rsin = rsin; a.ldr = ldr;
     a.x = cv(k_num); a.y = cv(v); a.kd = cv(k_den); a.qd = cv(q_den); a.idx = idx;
-    a.out = w.kv; a.ksum = w.ksum; a.zo = w.z; a.es = w.es;
+    a.out = w.kv; a.ksum = w.ksum; a.zo = w.z; a.es = es;
     a.H = H; a.M = M; a.S = S; a.D = D; a.eps = eps;
     a.relu = (flags & MHLA_FLAG_RELU_EPS) ? 1 : 0; a.normalize = normalize; a.split = split;
-    MixArgs m{W, ldw, w.kv, w.g, M, (long)D * D, w.es};
+    MixArgs m{W, ldw, w.kv, w.g, M, (long)D * D, es};
     if (sp_shape_ok(D, flags)) {   // split-bf16 MFMA kernels (split.hpp)
         constexpr int SNT = sp_state_threads<DT>();   // eight waves at D = 128 (split.hpp)
+        if constexpr (P24OK) {
+            if (p24) {
+                RC(launch(sp::k_sp_state<T, DT, 0, false, SNT, false, true>, dim3(M, B * H), dim3(SNT), sp::sp_state_smem<DT>(), st, "k_sp_state", a));
+                RC((sp_mixr<0, false, true>(W, ldw, w.kv, w.g, M, m.E, es, B * H, st, normalize ? (const float*)w.z : nullptr, w.ninv, S, eps)));
+                if (normalize && !sp_mixr_takes_wz<false>(M, S))
+                    RC(launch(k_wz<0>, dim3((S + 63) / 64, (M + 63) / 64, B * H), dim3(NTHREADS), 0, st, "k_wz<0>", W, ldw, (const float*)w.z, w.ninv, M, S, eps));
+                return MHLA_OK;
+            }
+        }
         if (s16)    RC(launch(s16::k_s16_state<0>, dim3((M + s16::WPB - 1) / s16::WPB, B * H), dim3(64 * s16::WPB), s16::state_smem(), st, "k_s16_state<0>", a));
         else if (a.rcos) RC(launch(sp::k_sp_state<T, DT, 0, true, SNT, S16>, dim3(M, B * H), dim3(SNT), sp::sp_state_smem<DT>(), st, "k_sp_state<rope>", a));
         else        RC(launch(sp::k_sp_state<T, DT, 0, false, SNT, S16>, dim3(M, B * H), dim3(SNT), sp::sp_state_smem<DT>(), st, "k_sp_state", a));
@@ -167,7 +193,9 @@ int bm_fwd_typed(const BmCall& c) {
         OutArgs o{};
         o.rcos = rcos; o.rsin = rsin; o.ldr = ldr;
         o.q = cv(q_num); o.o = cmv(c.out); o.idx = block_index; o.W = W; o.ldw = ldw; o.g = w.g; o.ninv = w.ninv;
-        o.H = H; o.M = M; o.S = S; o.D = D; o.eps = eps; o.es = w.es;
+        constexpr bool P24OK = !S16 && sizeof(ET) == 2 && DT <= 4;
+        const bool p24 = !rcos && bm_p24<ET, DT, S16>(M, D, flags);
+        o.H = H; o.M = M; o.S = S; o.D = D; o.eps = eps; o.es = p24 ? bm_p24_es(D) : w.es;
         o.relu = (flags & MHLA_FLAG_RELU_EPS) ? 1 : 0; o.normalize = normalize;
         o.olo = (normalize && !epi && !(flags & MHLA_FLAG_NO_BWD_STATE)) ? w.olo : nullptr;   // (16-bit tensors, default arithmetic: BmWs::olo)
         if (epi) {
@@ -180,7 +208,9 @@ int bm_fwd_typed(const BmCall& c) {
             }
         } else if (s16)
             RC(launch(s16::k_s16_out<0>, dim3((M + s16::WPB - 1) / s16::WPB, B * H), dim3(64 * s16::WPB), s16::out_smem(), st, "k_s16_out", o));
-        else if (sp_shape_ok(D, flags))
+        else if (p24) {
+            if constexpr (P24OK) RC(launch(sp::k_sp_out<ET, DT, ET, false, false, true>, dim3(M, B * H), dim3(sp::SP_OUT_T), sp::sp_out_smem<DT, false>(), st, "k_sp_out", o));
+        } else if (sp_shape_ok(D, flags))
             RC(launch(sp::k_sp_out<ET, DT, ET, false, S16>, dim3(M, B * H), dim3(sp::SP_OUT_T), sp::sp_out_smem<DT, S16>(), st, "k_sp_out", o));
         else
             RC(launch(k_bm_out<ET, DT>, dim3(M, B * H), dim3(NTHREADS), out_smem_floats<DT>() * 4, st, "k_bm_out", o));
@@ -207,14 +237,19 @@ int bm_bwd_typed(const BmCall& c) {
         const bool s16 = S16 && s16_ok<ET, DT>(c, true);
         if (!reuse)
             RC((bm_state_and_mix<ET, DT, S16>(q_num, k_num, v, q_den, k_den, W, ldw, block_index, w, B, H, M, S, D, eps, flags, normalize, split, st, rcos, rsin, ldr, s16)));
+        constexpr bool P24OK = !S16 && sizeof(ET) == 2 && DT <= 4;
+        const bool p24 = !rcos && bm_p24<ET, DT, S16>(M, D, flags);
+        const long es = p24 ? bm_p24_es(D) : w.es;
         const bool want_olo = normalize && w.olo != nullptr;
         if (want_olo && (!reuse || (flags & MHLA_FLAG_NO_BWD_STATE))) {
             // what the forward's 16-bit store of O rounded away (BmWs::olo), recomputed: the output kernel without its output
             OutArgs o{};
             o.q = cv(q_num); o.o = MView{nullptr, 0, 0, 0}; o.idx = block_index; o.W = W; o.ldw = ldw; o.g = w.g; o.ninv = w.ninv;
-            o.H = H; o.M = M; o.S = S; o.D = D; o.eps = eps; o.es = w.es; o.relu = relu; o.normalize = normalize;
+            o.H = H; o.M = M; o.S = S; o.D = D; o.eps = eps; o.es = es; o.relu = relu; o.normalize = normalize;
             o.olo = c.olo_own; o.skip_out = 1;
-            if (sp_shape_ok(D, flags))
+            if (p24) {
+                if constexpr (P24OK) RC(launch(sp::k_sp_out<ET, DT, ET, false, false, true>, dim3(M, B * H), dim3(sp::SP_OUT_T), sp::sp_out_smem<DT, false>(), st, "k_sp_out<olo>", o));
+            } else if (sp_shape_ok(D, flags))
                 RC(launch(sp::k_sp_out<ET, DT, ET, false, S16>, dim3(M, B * H), dim3(sp::SP_OUT_T), sp::sp_out_smem<DT, S16>(), st, "k_sp_out<olo>", o));
             else
                 RC(launch(k_bm_out<ET, DT>, dim3(M, B * H), dim3(NTHREADS), out_smem_floats<DT>() * 4, st, "k_bm_out<olo>", o));
@@ -222,7 +257,7 @@ int bm_bwd_typed(const BmCall& c) {
         // dG_i = Q_i^T (dO_i / n_i), dn_i
         StateArgs a{};
         a.x = cv(q_num); a.y = cv(dout); a.o = cv(out_view); a.idx = block_index; a.W = W; a.ldw = ldw; a.ninv = w.ninv;
-        a.out = w.dg; a.dn = w.dn; a.es = w.es; a.H = H; a.M = M; a.S = S; a.D = D; a.eps = eps;
+        a.out = w.dg; a.dn = w.dn; a.es = es; a.H = H; a.M = M; a.S = S; a.D = D; a.eps = eps;
         a.relu = relu; a.normalize = normalize; a.split = split;
         a.olo = !want_olo ? nullptr : ((!reuse || (flags & MHLA_FLAG_NO_BWD_STATE)) ? c.olo_own : w.olo);
         const int tiles = (M + 63) / 64;
@@ -230,13 +265,33 @@ int bm_bwd_typed(const BmCall& c) {
         t.q = cv(q_num); t.k = cv(k_num); t.v = cv(v); t.qd = cv(q_den); t.kd = cv(k_den); t.dout = cv(dout);
         t.dq = cmv(dq_num); t.dk = cmv(dk_num); t.dv = cmv(dv); t.dqd = cmv(dq_den); t.dkd = cmv(dk_den);
         t.idx = block_index; t.W = W; t.ldw = ldw; t.g = w.g; t.dkv = w.dkv; t.ninv = w.ninv; t.dz = w.dz; t.ksum = w.ksum;
-        t.dks = w.dks; t.es = w.es;
+        t.dks = w.dks; t.es = es;
         t.H = H; t.M = M; t.S = S; t.D = D; t.eps = eps; t.relu = relu; t.normalize = normalize; t.split = split;
         if (sp_shape_ok(D, flags)) {   // split-bf16 MFMA kernels (split.hpp)
             const long E = (long)D * D;
             a.rcos = rcos; a.rsin = rsin; a.ldr = ldr;
             t.rcos = rcos; t.rsin = rsin; t.ldr = ldr;
             constexpr int SNT = sp_state_threads<DT>();
+            if constexpr (P24OK) {
+                if (p24) {   // the same kernels on 24-bit summaries: dG, then dKV = W^T dG with dz and dW riding along, the token gradients
+                    RC(launch(sp::k_sp_state<ET, DT, 1, false, SNT, false, true>, dim3(M, B * H), dim3(SNT), sp::sp_state_smem<DT>(), st, "k_sp_state<1>", a));
+                    int parts = 0;
+                    bool wz_done = false;
+                    RC(sp_mixr_dw<true>(W, ldw, w.dg, w.kv, w.dkv, w.dwp, M, E, es, B * H, st, &parts, normalize ? (const float*)w.dn : nullptr,
+                                        normalize ? (const float*)w.z : nullptr, w.dz, S, &wz_done));
+                    if (normalize && !wz_done) {
+                        RC(launch(k_wz<1>, dim3((S + 63) / 64, (M + 63) / 64, B * H), dim3(NTHREADS), 0, st, "k_wz<1>", W, ldw, (const float*)w.dn, w.dz, M, S, 0.f));
+                        DwArgs dzz{w.dn, w.z, (long)S, nullptr, nullptr, 0, w.dwp + (size_t)parts * M * M, M, tiles, 1};
+                        RC(launch(k_dw<0>, dim3(tiles * tiles, B * H, 1), dim3(NTHREADS), DW_SMEM_FLOATS * 4, st, "k_dw", dzz));
+                        parts += B * H;
+                    }
+                    RC(launch(k_dw_reduce<0, 16>, dim3((M * M + 15) / 16), dim3(256), 0, st, "k_dw_reduce", (const float*)w.dwp, (const float*)nullptr, dW, M, M, parts, B * H));
+                    if (normalize && !relu) RC(launch(sp::k_sp_bwd_dq<ET, DT, false, false, true, true>, dim3(M, B * H), dim3(NTHREADS), sp::sp_tok_smem<DT, false>(), st, "k_sp_bwd_dq", t));
+                    else RC(launch(sp::k_sp_bwd_dq<ET, DT, false, false, false, true>, dim3(M, B * H), dim3(NTHREADS), sp::sp_tok_smem<DT, false>(), st, "k_sp_bwd_dq", t));
+                    RC(launch(sp::k_sp_bwd_dkv<ET, DT, false, false, true>, dim3(M, B * H), dim3(NTHREADS), sp::sp_tok_smem<DT, false>(), st, "k_sp_bwd_dkv", t));
+                    break;
+                }
+            }
             if constexpr (std::is_same<ET, float>::value) {
                 if (rcos) RC(launch(sp::k_sp_state<ET, DT, 1, true, SNT, S16>, dim3(M, B * H), dim3(SNT), sp::sp_state_smem<DT>(), st, "k_sp_state<1,rope>", a));
             }

@@ -77,6 +77,8 @@ int launch(K kernel, dim3 grid, dim3 block, size_t smem, hipStream_t stream, con
 
 // debugging aid: per-workgroup phase timestamps of the tile kernels (mhla_debug_set_trace)
 inline std::atomic<unsigned long long*> g_trace{nullptr};
+// mhla_set_option("fp32_summaries") / MHLA_FP32_SUMMARIES=1 (read once): the resident-mixing pipeline keeps its summaries as fp32 instead of 24-bit floats
+inline std::atomic<int> g_no_p24{[] { const char* e = getenv("MHLA_FP32_SUMMARIES"); return (e && e[0] == '1') ? 1 : 0; }()};
 
 inline View cv(const mhla_view& v) { return View{v.ptr, (long)v.sb, (long)v.sn, (long)v.sh}; }
 inline MView cmv(const mhla_mview& v) { return MView{v.ptr, (long)v.sb, (long)v.sn, (long)v.sh}; }

@@ -70,6 +70,61 @@ __device__ __forceinline__ void unrope4(f32x4& g, const f32x2& c, const f32x2& s
     g[2] = g0[2] * c[1] + g0[3] * s[1]; g[3] = g0[3] * c[1] - g0[2] * s[1];
 }
 
+// -------------------------------------------------------------------------------------------------
+// p24: block summaries as 24-bit floats -- sign, 8 exponent bits, 15 stored mantissa bits: the top three bytes of the fp32, i.e. 16
+// significand bits, which is what the hi + lo bf16 operand pair of the products carries anyway -- in 3 / 4 of the bytes.  A summary row
+// of E elements is two planes: [E x u16: the top two bytes = the bf16 hi operand as it is][E x u8: the third byte].  Whole-block readers
+// and writers see two contiguous runs; a 64-element slice of the resident mixing is one 128-byte line of the hi plane and half a line
+// of the lo plane (its neighbour slice, taken next by the same workgroup, owns the other half).  (192-byte
+// groups of 64 elements -- hi and lo side by side -- put every second hi piece across two lines, and the streaming loads dropped the
+// shared line between slices: the mixing kernels ran 10-25 % slower than on fp32 summaries.)
+// The lo operand, value - hi, has at most 8 significant bits: exact in bf16.  Used by the resident-mixing pipeline on 16-bit tensors
+// (capi_bm_typed.hpp bm_p24); rows keep their stride in float units (BmWs::es), 3 E / 4 + padding.
+// -------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned p24_round(float x) { return (__float_as_uint(x) + 0x80u) & 0xffffff00u; }
+// 8 values -> their hi piece (16 bytes) and lo piece (8 bytes)
+__device__ __forceinline__ void p24_pack8(const f32x4& a, const f32x4& b, uint4& hi, uint2& lo) {
+    unsigned r[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { r[i] = p24_round(a[i]); r[4 + i] = p24_round(b[i]); }
+    hi = make_uint4(__builtin_amdgcn_perm(r[1], r[0], 0x07060302u), __builtin_amdgcn_perm(r[3], r[2], 0x07060302u),
+                    __builtin_amdgcn_perm(r[5], r[4], 0x07060302u), __builtin_amdgcn_perm(r[7], r[6], 0x07060302u));
+    // byte 1 of each value: (r1.b1, r0.b1) -> low half, (r3.b1, r2.b1) -> high half
+    lo = make_uint2(__builtin_amdgcn_perm(__builtin_amdgcn_perm(r[3], r[2], 0x0c0c0501u), __builtin_amdgcn_perm(r[1], r[0], 0x0c0c0501u), 0x05040100u),
+                    __builtin_amdgcn_perm(__builtin_amdgcn_perm(r[7], r[6], 0x0c0c0501u), __builtin_amdgcn_perm(r[5], r[4], 0x0c0c0501u), 0x05040100u));
+}
+// the bf16 lo operands of 8 stored values: (hi | third byte) - hi, exact
+__device__ __forceinline__ uint4 p24_lo8(const uint4& hi, const uint2& lo) {
+    const unsigned hw[4] = {hi.x, hi.y, hi.z, hi.w};
+    const unsigned lw[2] = {lo.x, lo.y};
+    unsigned o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {   // elements 2 j (low half of the word) and 2 j + 1
+        const unsigned l = lw[j >> 1];
+        // v_perm_b32 (S0, S1): selector bytes 0-3 pick from S1, 4-7 from S0, 0x0c is a zero byte
+        const unsigned h0 = hw[j] << 16, h1 = hw[j] & 0xffff0000u;
+        const unsigned f0 = __builtin_amdgcn_perm(hw[j], l, (j & 1) ? 0x05040200u | 0x0cu : 0x05040000u | 0x0cu);
+        const unsigned f1 = __builtin_amdgcn_perm(hw[j], l, (j & 1) ? 0x07060300u | 0x0cu : 0x07060100u | 0x0cu);
+        const float d0 = __uint_as_float(f0) - __uint_as_float(h0), d1 = __uint_as_float(f1) - __uint_as_float(h1);
+        o[j] = __builtin_amdgcn_perm(__float_as_uint(d1), __float_as_uint(d0), 0x07060302u);
+    }
+    return make_uint4(o[0], o[1], o[2], o[3]);
+}
+// the 8 stored values as floats
+__device__ __forceinline__ void p24_unpack8(const uint4& hi, const uint2& lo, f32x4& a, f32x4& b) {
+    const unsigned hw[4] = {hi.x, hi.y, hi.z, hi.w};
+    const unsigned lw[2] = {lo.x, lo.y};
+    float f[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned l = lw[j >> 1];
+        f[2 * j] = __uint_as_float(__builtin_amdgcn_perm(hw[j], l, (j & 1) ? 0x05040200u | 0x0cu : 0x05040000u | 0x0cu));
+        f[2 * j + 1] = __uint_as_float(__builtin_amdgcn_perm(hw[j], l, (j & 1) ? 0x07060300u | 0x0cu : 0x07060100u | 0x0cu));
+    }
+    a = f32x4{f[0], f[1], f[2], f[3]};
+    b = f32x4{f[4], f[5], f[6], f[7]};
+}
+
 // Block summaries (KV, G, dG, dKV) are fp32 in the workspace, except for bf16 tensors: there they are stored as bf16 (as on
 // the bf16 fast path), which halves the summary traffic -- the larger share of the bytes when S is small -- and needs no lo part.
 template <typename T> struct Sum16 { static constexpr bool value = std::is_same<T, bf16_t>::value; };
@@ -100,8 +155,9 @@ __host__ __device__ constexpr int sp_state_smem() {
 // eight-wave slots of half the duration 3.5 rounds that cost 4 (of half the length).
 // S16: the summary is stored as bf16 (the opt-in MHLA_FLAG_BF16_SUMMARIES arithmetic on bf16 tensors); otherwise fp32, and the
 // one operand that is an INTERMEDIATE (dP = dO / n, MODE 1) is split into hi + lo parts whatever the tensor type
-template <typename T, int DT, int MODE, bool ROPE = false, int NT = NTHREADS, bool S16 = Sum16<T>::value>
+template <typename T, int DT, int MODE, bool ROPE = false, int NT = NTHREADS, bool S16 = Sum16<T>::value, bool P24 = false>
 __global__ __launch_bounds__(NT, NT == 512 ? 4 : (ROPE ? 2 : 3)) void k_sp_state(const StateArgs a) {
+    static_assert(!P24 || !S16, "p24 is a format of the fp32-grade summaries");
     constexpr int DW = Geo<DT>::DW, LD = Geo<DT>::LD, CGS = Geo<DT>::CGS, RPP = NT / CGS, IT = 32 / RPP, NWV = NT / 64,
                   RT = (DT + NWV - 1) / NWV, TILE = 32 * LD;
     static_assert(IT >= 1 && RPP * IT == 32, "a 32-row chunk must be whole staging passes");
@@ -290,7 +346,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : (ROPE ? 2 : 3)) void k_sp_state
     // segments (k_sp_state ran at 3.9 TB/s of its bytes at C2)
     constexpr int CW = (DW > 64 && NWV == 8) ? 64 : DW, LDO = CW + 4, PPRO = CW / 4;
     static_assert(NWV * 16 * LDO * 4 <= 4 * 32 * LD * 2, "the staging tiles of all waves must fit in the operand tiles");
-    const bool staged = !S16 && (D & 3) == 0 && (a.es & 3) == 0;   // (uniform)
+    const bool staged = !S16 && (P24 || ((D & 3) == 0 && (a.es & 3) == 0));   // (uniform; p24: D % 8 == 0 by the path's shape test)
     if (staged) {
         float* Os = reinterpret_cast<float*>(smem_raw) + wave * 16 * LDO;
 #pragma unroll
@@ -305,11 +361,28 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : (ROPE ? 2 : 3)) void k_sp_state
 #pragma unroll
                             for (int r = 0; r < 4; ++r) Os[(kg * 4 + r) * LDO + ct * 16 - c0 + nl] = acc[rt][ct][r];
                     __builtin_amdgcn_wave_barrier();
+                    if constexpr (P24) {   // units of 8 elements: a 16-byte piece of the hi plane and an 8-byte piece of the lo plane
+#pragma unroll
+                        for (int p = 0; p < CW / 32; ++p) {
+                            const int v = lane + 64 * p, row = v / (CW / 8), c8 = v % (CW / 8);
+                            const int grow = tile * 16 + row, gcol = c0 + c8 * 8;
+                            if (grow < D && gcol < D) {
+                                const float* src = Os + row * LDO + c8 * 8;
+                                uint4 hi;
+                                uint2 lo;
+                                p24_pack8(*reinterpret_cast<const f32x4*>(src), *reinterpret_cast<const f32x4*>(src + 4), hi, lo);
+                                const int e = grow * D + gcol;
+                                gst<uint4>(reinterpret_cast<char*>(ob) + 2 * e, hi);
+                                gst<uint2>(reinterpret_cast<char*>(ob) + 2 * D * D + e, lo);
+                            }
+                        }
+                    } else {
 #pragma unroll
                     for (int p = 0; p < CW / 16; ++p) {
                         const int v = lane + 64 * p, row = v / PPRO, c4 = v % PPRO;
                         const int grow = tile * 16 + row, gcol = c0 + c4 * 4;
                         if (grow < D && gcol < D) gst<f32x4>(ob + (long)grow * D + gcol, *reinterpret_cast<const f32x4*>(Os + row * LDO + c4 * 4));
+                    }
                     }
                     __builtin_amdgcn_wave_barrier();
                 }
@@ -659,13 +732,17 @@ __host__ __device__ constexpr int sp_mixr_smem() {
 // dW[i][j] += sum_{e in slice} dG[i][e] KV[j][e] over ALL its slices -- every (b,h) it meets: dW is their sum anyway -- in
 // registers (wave w owns rows i = 16 w .. 16 w + 15, all columns: NW tiles); one [M][M] partial per workgroup at the end, summed in a
 // fixed order by k_dw_reduce.  Replaces k_sp_dw, which read dG and KV a second time (C2 at the default arithmetic: 81 us).
-template <int NW, int TRANS, bool S16, bool DW = false>
+// P24: the summaries (in, in2, out) are stored as 24-bit floats in two planes per row (p24_pack8).  A thread's unit is then 8 elements
+// of a row -- one 16-byte piece of the hi plane and one 8-byte piece of the lo plane -- instead of a 16-byte piece of 4 floats.
+template <int NW, int TRANS, bool S16, bool DW = false, bool P24 = false>
 __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void k_sp_mixr(const MixrArgs a) {
     static_assert(!DW || (TRANS == 1 && !S16 && NW <= 8), "dW rides in the backward's fp32 mixing kernel, M <= 128 (twelve waves: 77 spilled registers)");
+    static_assert(!P24 || (!S16 && NW <= 12), "p24: fp32-grade summaries, slices of 64 elements");
     constexpr int TE = mixr_te<NW, S16>(), ROWS = 16 * NW, LD = TE + 8, LDO = TE + 4, NK = (NW + 1) / 2, NT = TE / 16;
     constexpr int PPR = TE * (S16 ? 2 : 4) / 16;          // 16-byte pieces per row of the slice (16, or 8 with 16 waves)
-    constexpr int NTH = 64 * NW, NP = ROWS * PPR / NTH;   // pieces per thread and slice
-    static_assert(NP * NTH == ROWS * PPR, "pieces must tile the slice");
+    constexpr int NTH = 64 * NW, NP = P24 ? ROWS * 8 / NTH : ROWS * PPR / NTH;   // pieces (P24: units of 8 elements) per thread and slice
+    constexpr int UPR = P24 ? 8 : PPR;                    // ... per row
+    static_assert(NP * NTH == ROWS * UPR, "pieces must tile the slice");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u16* Th = reinterpret_cast<u16*>(smem_raw);
     u16* Tl = Th + ROWS * LD;                                        // (fp32 summaries only)
@@ -684,12 +761,15 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void k_sp_mixr(const MixrArg
     static_assert((TRANS ? 64 * (ROWS + 4) : ROWS * 68) * 4 <= sp_mixr_smem<NW, S16, DW>(), "weight chunk must fit in the tiles");
     mixr_weights<TRANS, 64 * NW, ROWS, NK, 1>(wh, wl, reinterpret_cast<float*>(smem_raw), a.W, a.ldw, M, wave * 16, tid);
     constexpr int ESZ = S16 ? 2 : 4;
+    constexpr int SLB = P24 ? 128 : TE * ESZ;             // bytes of a slice in a summary row (P24: of its hi plane)
+    // P24: the lo piece of a unit relative to its hi piece (goff + 16 c of slice es): lo plane at 2 E, slice at 64 es, piece at 8 c
+    auto lo_rel = [&](int es, int c) { return (long)2 * a.E - 64 * es - 8 * c; };
     // byte offset of slice (bh, es); a workgroup's slices are consecutive, so the pair is advanced rather than divided out per
     // slice (the 64-bit division was 150 instructions with branches between the barrier and the next slice's loads)
     // (normaliser slices follow the last summary slice: bh >= nbh_all counts them, bh - nbh_all is their (b, h))
     auto is_z = [&](int bh) { return !S16 && bh >= nbh_all; };
     auto slice_off = [&](int bh, int es) {
-        return is_z(bh) ? ((long)(bh - nbh_all) * M * a.S + (long)es * TE) * 4 : ((long)bh * M * a.es + (long)es * TE) * ESZ;
+        return is_z(bh) ? ((long)(bh - nbh_all) * M * a.S + (long)es * TE) * 4 : (long)bh * M * a.es * ESZ + (long)es * SLB;
     };
     auto advance = [&](int& bh, int& es) { if (++es == (is_z(bh) ? nzs : (int)nsl)) { es = 0; ++bh; } };
     int cbh, ces;
@@ -700,33 +780,56 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void k_sp_mixr(const MixrArg
     unsigned goff[NP];
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
-        const int v = tid + p * NTH, row = v / PPR, c = v % PPR;
-        goff[p] = (unsigned)((long)(row < M ? row : M - 1) * a.es * ESZ + c * 16);
+        const int v = tid + p * NTH, row = v / UPR, c = v % UPR;
+        goff[p] = (unsigned)((long)(row < M ? row : M - 1) * a.es * ESZ + c * 16);   // (P24: the unit's hi piece; its lo piece: lo_rel)
     }
-    uint4 pre[NP], pre2[DW ? NP : 1];
+    // staging registers.  P24: pre = hi piece, prl = lo piece; a normaliser slice (plain floats) takes the unit's 8 floats in pre + prz
+    struct Stage {
+        uint4 pre[NP], pre2[DW ? NP : 1], prz[P24 ? NP : 1], prz2[(P24 && DW) ? NP : 1];
+        u32x2_t prl[P24 ? NP : 1], prl2[(P24 && DW) ? NP : 1];   // (native vectors: an array of uint2 in here stays in scratch)
+    };
+    // (A second slice in flight per workgroup -- two Stage objects, the loop unrolled by two -- gained nothing: hipcc's wait in front of
+    // the commit is vmcnt(0), i.e. for both.  Nor did starting the workgroups of a CU a fraction of an iteration apart, or fetching and
+    // storing the lo pieces of an even / odd slice pair together, whole 128-byte lines at a time.)
+    constexpr int NBUF = 1;
+    Stage sga;
     // a normaliser slice: rows of S floats, pieces past the row's end are not touched (zeros)
-    auto zoff = [&](int p) { const int v = tid + p * NTH, row = v / PPR, c = v % PPR; return (unsigned)((row < M ? row : M - 1) * a.S * 4 + c * 16); };
-    auto zlive = [&](int p, int es) { return ((tid + p * NTH) % PPR) * 4 + es * TE < a.S; };
-    auto issue = [&](int bh, int es) {
+    constexpr int ZPB = P24 ? 32 : 16, ZPF = ZPB / 4;   // bytes / floats of a thread's piece of a normaliser row
+    auto zoff = [&](int p) { const int v = tid + p * NTH, row = v / UPR, c = v % UPR; return (unsigned)((row < M ? row : M - 1) * a.S * 4 + c * ZPB); };
+    auto zlive = [&](int p, int es, int half = 0) { return ((tid + p * NTH) % UPR) * ZPF + half * 4 + es * TE < a.S; };
+    const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+    auto issue = [&](Stage& g, int bh, int es) __attribute__((always_inline)) {
         const long boff = slice_off(bh, es);
         if (is_z(bh)) {   // (uniform)
             const char* base = reinterpret_cast<const char*>(a.zin) + boff;
 #pragma unroll
-            for (int p = 0; p < NP; ++p) pre[p] = zlive(p, es) ? gld_stream16(base + zoff(p)) : make_uint4(0u, 0u, 0u, 0u);
+            for (int p = 0; p < NP; ++p) {
+                g.pre[p] = zlive(p, es) ? gld_stream16(base + zoff(p)) : zero4;
+                if constexpr (P24) g.prz[p] = zlive(p, es, 1) ? gld_stream16(base + zoff(p) + 16) : zero4;
+            }
             if constexpr (DW) {
                 const char* base2 = reinterpret_cast<const char*>(a.zin2) + boff;
 #pragma unroll
-                for (int p = 0; p < NP; ++p) pre2[p] = zlive(p, es) ? gld_stream16(base2 + zoff(p)) : make_uint4(0u, 0u, 0u, 0u);
+                for (int p = 0; p < NP; ++p) {
+                    g.pre2[p] = zlive(p, es) ? gld_stream16(base2 + zoff(p)) : zero4;
+                    if constexpr (P24) g.prz2[p] = zlive(p, es, 1) ? gld_stream16(base2 + zoff(p) + 16) : zero4;
+                }
             }
             return;
         }
         const char* base = reinterpret_cast<const char*>(a.in) + boff;
 #pragma unroll
-        for (int p = 0; p < NP; ++p) pre[p] = gld_stream16(base + goff[p]);
+        for (int p = 0; p < NP; ++p) {
+            g.pre[p] = gld_stream16(base + goff[p]);
+            if constexpr (P24) g.prl[p] = *(const MHLA_GLOBAL_AS u32x2_t*)(base + goff[p] + lo_rel(es, (tid + p * NTH) % UPR));
+        }
         if constexpr (DW) {
             const char* base2 = reinterpret_cast<const char*>(a.in2) + boff;
 #pragma unroll
-            for (int p = 0; p < NP; ++p) pre2[p] = gld_stream16(base2 + goff[p]);
+            for (int p = 0; p < NP; ++p) {
+                g.pre2[p] = gld_stream16(base2 + goff[p]);
+                if constexpr (P24) g.prl2[p] = *(const MHLA_GLOBAL_AS u32x2_t*)(base2 + goff[p] + lo_rel(es, (tid + p * NTH) % UPR));
+            }
         }
     };
     f32x4 dwacc[DW ? NW : 1];
@@ -745,36 +848,115 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void k_sp_mixr(const MixrArg
         *reinterpret_cast<uint2*>(th + row * LD + c * 4) = make_uint2(hs[0] | ((unsigned)hs[1] << 16), hs[2] | ((unsigned)hs[3] << 16));
         *reinterpret_cast<uint2*>(tl + row * LD + c * 4) = make_uint2(pack_bf16x2(l[0], l[1]), pack_bf16x2(l[2], l[3]));
     };
-    issue(nbh, nes);
-    for (int it = 0; it < cnt; ++it) {
+    issue(sga, nbh, nes);
+    // The stores of a slice are issued at the top of the NEXT iteration, after that slice's loads have been committed to LDS: hipcc
+    // waits with vmcnt(0) in front of the commit -- with the stores at the end of the iteration that wait included their
+    // acknowledgement (loads and stores retire in order), a round trip per slice on top of the load's.  The staging tile keeps the
+    // results across the iteration boundary: it is not written again before the barrier that follows the stores.
+    long poff = 0;
+    bool pz = false;
+    int pzes = 0;
+    auto store_slice = [&](long off, bool zslice, int zes) __attribute__((always_inline)) {
+        if constexpr (!S16) {
+            if (zslice) {   // the normaliser's rows: 1 / (eps + .) in the forward, as they are in the backward
+                char* zb = reinterpret_cast<char*>(a.zout) + off;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    const int v = tid + p * NTH, row = v / UPR, c = v % UPR;
+#pragma unroll
+                    for (int hf = 0; hf < ZPF / 4; ++hf) {
+                        if (row < M && zlive(p, zes, hf)) {
+                            f32x4 x = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(Os) + row * LDO + c * ZPF + hf * 4);
+                            if (TRANS == 0)
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) x[i] = 1.f / (a.eps + x[i]);
+                            *reinterpret_cast<f32x4*>(zb + zoff(p) + hf * 16) = x;
+                        }
+                    }
+                }
+                return;
+            }
+        }
+        char* ob = reinterpret_cast<char*>(a.out) + off;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int v = tid + p * NTH, row = v / UPR, c = v % UPR;
+            if constexpr (P24) {
+                if (row < M) {
+                    const float* src = reinterpret_cast<const float*>(Os) + row * LDO + c * 8;
+                    uint4 hi;
+                    uint2 lo;
+                    p24_pack8(*reinterpret_cast<const f32x4*>(src), *reinterpret_cast<const f32x4*>(src + 4), hi, lo);
+                    gst<uint4>(ob + goff[p], hi);
+                    gst<uint2>(ob + goff[p] + lo_rel(zes, c), lo);
+                }
+                continue;
+            }
+            if (row < M) {
+                const uint4 x = S16 ? *reinterpret_cast<const uint4*>(reinterpret_cast<const u16*>(Os) + row * LD + c * 8)
+                                    : *reinterpret_cast<const uint4*>(reinterpret_cast<const float*>(Os) + row * LDO + c * 4);
+                gst<uint4>(ob + goff[p], x);
+            }
+        }
+    };
+    auto body = [&](Stage& g, int it) __attribute__((always_inline)) {
         const long off = slice_off(cbh, ces);
         const bool zslice = is_z(cbh);   // (uniform)
         const int zes = ces;
         advance(cbh, ces);
+#ifdef MIXR_X_NOCOMMIT
+        if (it == 0)
+#endif
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-            const int v = tid + p * NTH, row = v / PPR, c = v % PPR;
+            const int v = tid + p * NTH, row = v / UPR, c = v % UPR;
             const bool ok = row < M;   // rows past the last block: zeros (their weights are zero too, but 0 x NaN is not)
-            const uint4 x = make_uint4(ok ? pre[p].x : 0u, ok ? pre[p].y : 0u, ok ? pre[p].z : 0u, ok ? pre[p].w : 0u);
-            if constexpr (S16) {
+            const uint4 x = make_uint4(ok ? g.pre[p].x : 0u, ok ? g.pre[p].y : 0u, ok ? g.pre[p].z : 0u, ok ? g.pre[p].w : 0u);
+            if constexpr (P24) {
+                if (zslice) {   // (uniform) 8 plain floats
+                    const uint4 x1 = make_uint4(ok ? g.prz[p].x : 0u, ok ? g.prz[p].y : 0u, ok ? g.prz[p].z : 0u, ok ? g.prz[p].w : 0u);
+                    commit_hl(Th, Tl, x, row, 2 * c);
+                    commit_hl(Th, Tl, x1, row, 2 * c + 1);
+                    if constexpr (DW) {
+                        commit_hl(Kh, Kl, make_uint4(ok ? g.pre2[p].x : 0u, ok ? g.pre2[p].y : 0u, ok ? g.pre2[p].z : 0u, ok ? g.pre2[p].w : 0u), row, 2 * c);
+                        commit_hl(Kh, Kl, make_uint4(ok ? g.prz2[p].x : 0u, ok ? g.prz2[p].y : 0u, ok ? g.prz2[p].z : 0u, ok ? g.prz2[p].w : 0u), row, 2 * c + 1);
+                    }
+                } else {   // the hi piece is the operand; the lo operand is rebuilt from the third bytes
+                    const uint2 l = make_uint2(ok ? g.prl[p][0] : 0u, ok ? g.prl[p][1] : 0u);
+                    *reinterpret_cast<uint4*>(Th + row * LD + c * 8) = x;
+                    *reinterpret_cast<uint4*>(Tl + row * LD + c * 8) = p24_lo8(x, l);
+                    if constexpr (DW) {
+                        const uint4 y = make_uint4(ok ? g.pre2[p].x : 0u, ok ? g.pre2[p].y : 0u, ok ? g.pre2[p].z : 0u, ok ? g.pre2[p].w : 0u);
+                        const uint2 yl = make_uint2(ok ? g.prl2[p][0] : 0u, ok ? g.prl2[p][1] : 0u);
+                        *reinterpret_cast<uint4*>(Kh + row * LD + c * 8) = y;
+                        *reinterpret_cast<uint4*>(Kl + row * LD + c * 8) = p24_lo8(y, yl);
+                    }
+                }
+            } else if constexpr (S16) {
                 *reinterpret_cast<uint4*>(Th + row * LD + c * 8) = x;
             } else {   // four floats -> four bf16 hi + four bf16 lo
                 commit_hl(Th, Tl, x, row, c);
                 if constexpr (DW) {
-                    const uint4 y = make_uint4(ok ? pre2[p].x : 0u, ok ? pre2[p].y : 0u, ok ? pre2[p].z : 0u, ok ? pre2[p].w : 0u);
+                    const uint4 y = make_uint4(ok ? g.pre2[p].x : 0u, ok ? g.pre2[p].y : 0u, ok ? g.pre2[p].z : 0u, ok ? g.pre2[p].w : 0u);
                     commit_hl(Kh, Kl, y, row, c);
                 }
             }
         }
+#ifndef MIXR_X_NOSTORE   // (experiment builds only, tools/build_variant.sh: MIXR_X_* drop one phase of the slice loop -- results are wrong)
+        if (it > 0) store_slice(poff, pz, pzes);
+#endif
         __syncthreads();
-        if (it + 1 < cnt) {
+        if (it + NBUF < cnt) {
             advance(nbh, nes);
-            issue(nbh, nes);
+#ifndef MIXR_X_NOLOAD
+            issue(g, nbh, nes);
+#endif
         }
         f32x4 acc[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         const int kend = (M + 31) / 32;   // (uniform) reduction steps that hold a block
+#ifndef MIXR_X_NOMFMA
 #pragma unroll
         for (int ks = 0; ks < NK; ++ks) {
             if (ks < kend) {
@@ -798,6 +980,7 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void k_sp_mixr(const MixrArg
                 }
             }
         }
+#endif
         if constexpr (DW) {   // dW[i][j] += sum_e dG[i][e] KV[j][e]: rows i of this wave, every column tile that holds a block
             if (wave * 16 < M) {   // (uniform)
 #pragma unroll
@@ -825,34 +1008,12 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void k_sp_mixr(const MixrArg
                 *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(Os) + (wave * 16 + nl) * LDO + t * 16 + kg * 4) = acc[t];
         }
         __syncthreads();
-        if constexpr (!S16) {
-            if (zslice) {   // the normaliser's rows: 1 / (eps + .) in the forward, as they are in the backward
-                char* zb = reinterpret_cast<char*>(a.zout) + off;
-#pragma unroll
-                for (int p = 0; p < NP; ++p) {
-                    const int v = tid + p * NTH, row = v / PPR, c = v % PPR;
-                    if (row < M && zlive(p, zes)) {
-                        f32x4 x = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(Os) + row * LDO + c * 4);
-                        if (TRANS == 0)
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) x[i] = 1.f / (a.eps + x[i]);
-                        *reinterpret_cast<f32x4*>(zb + zoff(p)) = x;
-                    }
-                }
-                continue;
-            }
-        }
-        char* ob = reinterpret_cast<char*>(a.out) + off;
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            const int v = tid + p * NTH, row = v / PPR, c = v % PPR;
-            if (row < M) {
-                const uint4 x = S16 ? *reinterpret_cast<const uint4*>(reinterpret_cast<const u16*>(Os) + row * LD + c * 8)
-                                    : *reinterpret_cast<const uint4*>(reinterpret_cast<const float*>(Os) + row * LDO + c * 4);
-                gst<uint4>(ob + goff[p], x);
-            }
-        }
-    }
+        poff = off;
+        pz = zslice;
+        pzes = zes;
+    };
+    for (int it = 0; it < cnt; ++it) body(sga, it);
+    store_slice(poff, pz, pzes);
     if constexpr (DW) {   // C layout: rows i = 16 wave + 4 kg + r, column j = 16 jt + nl
         float* dp = a.dwp + (long)blockIdx.x * M * M;
 #pragma unroll
@@ -1098,7 +1259,7 @@ __host__ __device__ constexpr int sp_out_smem() { return (S16 ? 1 : 2) * Geo<DT>
 // to the token's D outputs before they are stored, in the dtype TO of the host's activations: O is rounded to TO (the
 // `.to(dtype)` at :356), normalised over the head dim in fp32, scaled by the norm weight and the gate, stored once.
 // D x D summary matrix (fp32, or bf16 when S16) -> LDS [KP][LD] hi (/ lo) tiles; rows and columns >= D zero.  NT threads.
-template <int DT, bool S16, int NT = NTHREADS>
+template <int DT, bool S16, int NT = NTHREADS, bool P24 = false>
 __device__ __forceinline__ void stage_mat_split(u16* __restrict__ Gh, u16* __restrict__ Gl, const float* __restrict__ base, long elem_off, int D, int tid) {
     constexpr int LD = mat_ld<DT>(), CGS = Geo<DT>::CGS, RPP = NT / CGS, KP = Geo<DT>::KST * 32;
     const int r0 = tid / CGS, cg = (tid % CGS) * 8;
@@ -1109,13 +1270,20 @@ __device__ __forceinline__ void stage_mat_split(u16* __restrict__ Gh, u16* __res
     for (int pb = 0; pb < PASSES; pb += UB) {
         f32x4 x[UB][2];
         uint4 x16[UB];
+        uint2 xl[UB];
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
             const int r = r0 + RPP * (pb + u);
             x[u][0] = x[u][1] = f32x4{0.f, 0.f, 0.f, 0.f};
             x16[u] = make_uint4(0, 0, 0, 0);
+            xl[u] = make_uint2(0, 0);
             if (r < D && cg < D) {
-                if (S16) {
+                if (P24) {   // 8 elements: a piece of the hi plane and one of the lo plane (elem_off counts floats: the row's start)
+                    const int e = r * D + cg;
+                    const char* rowp = reinterpret_cast<const char*>(base + elem_off);
+                    x16[u] = gld<uint4>(rowp + 2 * e);
+                    xl[u] = gld<uint2>(rowp + 2 * D * D + e);
+                } else if (S16) {
                     x16[u] = *reinterpret_cast<const uint4*>(g16 + (long)r * D + cg);
                 } else {
                     const float* src = g + (long)r * D + cg;
@@ -1128,7 +1296,10 @@ __device__ __forceinline__ void stage_mat_split(u16* __restrict__ Gh, u16* __res
         for (int u = 0; u < UB; ++u) {
             const int r = r0 + RPP * (pb + u), off = r * LD + cg;
             if (r < KP && cg < KP) {
-                if (S16) {
+                if (P24) {
+                    *reinterpret_cast<uint4*>(Gh + off) = x16[u];
+                    *reinterpret_cast<uint4*>(Gl + off) = p24_lo8(x16[u], xl[u]);
+                } else if (S16) {
                     *reinterpret_cast<uint4*>(Gh + off) = x16[u];
                 } else {
                     uint4 hi, lo;
@@ -1192,7 +1363,7 @@ template <typename V>
 __device__ __forceinline__ bool view16(const V& w) { return (reinterpret_cast<uintptr_t>(w.ptr) & 15) == 0 && ((w.sb | w.sn | w.sh) & 7) == 0; }
 
 constexpr int SP_OUT_T = 512;   // 8 waves share the staged G_i: twice the loads in flight per LDS byte
-template <typename T, int DT, typename TO = T, bool EPI = false, bool S16 = Sum16<T>::value>
+template <typename T, int DT, typename TO = T, bool EPI = false, bool S16 = Sum16<T>::value, bool P24 = false>
 #ifndef SP_OUT_EPI_WAVES
 #define SP_OUT_EPI_WAVES 2   // the fused-epilogue variant takes 142 VGPRs: one workgroup per CU without spills (157 us at C4) beats two with 28 spilled registers (163 us)
 #endif
@@ -1208,7 +1379,7 @@ __global__ __launch_bounds__(SP_OUT_T, EPI ? SP_OUT_EPI_WAVES : 2) void k_sp_out
     const T* qb = (const T*)a.q.ptr + b * a.q.sb + h * a.q.sh;
     TO* ob = (TO*)a.o.ptr + b * a.o.sb + h * a.o.sh;
     // (S16: G_i stored as bf16: no lo tile)
-    stage_mat_split<DT, S16, SP_OUT_T>(Gh, Gl, a.g, ((long)bh * a.M + blk) * a.es, D, tid);
+    stage_mat_split<DT, S16, SP_OUT_T, P24>(Gh, Gl, a.g, ((long)bh * a.M + blk) * a.es, D, tid);
     __syncthreads();
     const float* ninvb = a.ninv + ((long)bh * a.M + blk) * S;
     for (int tt = wave; tt * 16 < S; tt += SP_OUT_T / 64) {
@@ -1545,7 +1716,7 @@ __device__ __forceinline__ bf16x8 row_read8(const u16* tile, int ld, int c0, int
 // transposed rotation before dz ksum^T is added, so the one stored tensor is the gradient of the un-rotated q
 // WQ: q_den enters only dksum (normaliser on, no relu prologue) and is fetched in 16-byte pieces in the operand layout; otherwise in
 // the output layout, where the relu gradient mask needs it (a template flag: both register sets at once cost the occupancy)
-template <typename T, int DT, bool ROPE = false, bool S16 = Sum16<T>::value, bool WQ = false>
+template <typename T, int DT, bool ROPE = false, bool S16 = Sum16<T>::value, bool WQ = false, bool P24 = false>
 __global__ __launch_bounds__(NTHREADS, (DT <= 4 && WQ) ? 4 : 2) void k_sp_bwd_dq(const TokArgs a) {
     constexpr int LD = mat_ld<DT>(), DW = Geo<DT>::DW, KST = Geo<DT>::KST, TILE = KST * 32 * LD;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1604,7 +1775,7 @@ __global__ __launch_bounds__(NTHREADS, (DT <= 4 && WQ) ? 4 : 2) void k_sp_bwd_dq
         }
     };
     fetch(wave, cur);   // in flight while G_i is staged
-    stage_mat_split<DT, S16>(Gh, Gl, a.g, ((long)bh * M + blk) * a.es, D, tid);
+    stage_mat_split<DT, S16, NTHREADS, P24>(Gh, Gl, a.g, ((long)bh * M + blk) * a.es, D, tid);
     if (tid < DW) ksum[tid] = (a.normalize && tid < D) ? a.ksum[((long)bh * M + blk) * D + tid] : 0.f;
     __syncthreads();
     f32x4 dksp[WQ ? 1 : DT], dksw8[WQ ? KST : 1][2];   // per-lane dksum partials: output layout / operand layout (WQ)
@@ -1706,7 +1877,7 @@ __global__ __launch_bounds__(NTHREADS, (DT <= 4 && WQ) ? 4 : 2) void k_sp_bwd_dq
 
 // ROPE: k is the un-rotated tensor: it is rotated on its way into the dV product (KV was formed from the rotated keys), and
 // dK_rot is turned back before dksum is added
-template <typename T, int DT, bool ROPE = false, bool S16 = Sum16<T>::value>
+template <typename T, int DT, bool ROPE = false, bool S16 = Sum16<T>::value, bool P24 = false>
 __global__ __launch_bounds__(NTHREADS, 2) void k_sp_bwd_dkv(const TokArgs a) {   // (a bound of 4 -- 128 VGPRs, four workgroups per CU at D <= 64 -- measured: C2 +-0, blocks of 256 tokens 85 -> 94 us)
     constexpr int LD = mat_ld<DT>(), DW = Geo<DT>::DW, KST = Geo<DT>::KST, TILE = KST * 32 * LD;
     constexpr bool LO = !std::is_same<T, bf16_t>::value;
@@ -1756,7 +1927,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_bwd_dkv(const TokArgs a) {  
     };
     const bool wide_dk = view16(a.dk), wide_dv = view16(a.dv);   // (uniform) 16-byte store layout
     fetch(wave, cur);
-    stage_mat_split<DT, S16>(Gh, Gl, a.dkv, ((long)bh * M + blk) * a.es, D, tid);
+    stage_mat_split<DT, S16, NTHREADS, P24>(Gh, Gl, a.dkv, ((long)bh * M + blk) * a.es, D, tid);
     if (tid < DW) dks[tid] = (a.normalize && tid < D) ? a.dks[((long)bh * M + blk) * D + tid] : 0.f;
     __syncthreads();
 

@@ -287,6 +287,49 @@ def test_split_operand_path_matches_exact_fp32():
         check(name, a, b.cpu(), 2e-4)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,S,D,normalize", [(64, 64, 64, True), (33, 20, 64, True), (128, 8, 64, True), (50, 37, 56, True), (100, 12, 32, False),
+                                              (64, 16, 64, True), (70, 50, 64, False)])
+def test_24_bit_summaries_vs_fp32_summaries(M, S, D, normalize, dtype):
+    """16-bit tensors, 33 .. 128 blocks, D <= 64: the block summaries travel as 24-bit floats (split.hpp p24).  Both forms meet the
+    oracle at the default tolerance, and they agree with each other far inside it (16 significand bits either way)."""
+    import mhla_amd
+    from mhla_amd import _lib
+    lib = _lib.load()
+    res = []
+    try:
+        for fp32 in (0, 1):
+            lib.mhla_set_option(b"fp32_summaries", fp32)
+            run_case(2, 3, M, S, D, dtype, normalize=normalize, w="rand")
+            q, k, v, W, do, _, _ = make_blockmix_inputs(2, 3, M, S, D, dtype, 77, "rand", False)
+            t = [x.requires_grad_(True) for x in to_dev(q, k, v, W)]
+            out = mhla_amd.mhla_blockmix(t[0], t[1], t[2], t[3], normalize=normalize)
+            out.backward(do.to(DEV))
+            res.append([out.detach()] + [x.grad for x in t])
+    finally:
+        lib.mhla_set_option(b"fp32_summaries", 0)
+    for name, a, b in zip(("out", "dq", "dk", "dv", "dW"), *res):
+        check(name, a, b.cpu(), 2.0 ** -7 if name != "dW" else 2e-4)   # (16-bit results: at most a rounding step of the output apart)
+
+
+def test_24_bit_summaries_kept_state_and_gather_map(monkeypatch):
+    """The forward's kept workspace (24-bit KV / G) feeds the backward bit-identically to a recompute, through a gather map too."""
+    import mhla_amd
+    from mhla_amd import ops
+    B, H, M, S, D = 1, 4, 40, 24, 64
+    q, k, v, W, do, _, _ = make_blockmix_inputs(B, H, M, S, D, torch.bfloat16, seed=5, w="rand", split=False)
+    idx = torch.randperm(M * S, generator=torch.Generator().manual_seed(1)).int()
+    run_case(B, H, M, S, D, torch.bfloat16, w="rand", idx=idx)
+    res = []
+    for limit in (1 << 30, 0):
+        monkeypatch.setattr(ops, "KEEP_STATE_LIMIT_BYTES", limit)
+        t = [x.clone().requires_grad_(True) for x in to_dev(q, k, v, W)]
+        mhla_amd.mhla_blockmix(t[0], t[1], t[2], t[3]).backward(do.to(DEV))
+        res.append([x.grad for x in t])
+    for name, a, b in zip(("dq", "dk", "dv", "dW"), *res):
+        assert torch.equal(a, b), name
+
+
 def test_split_path_kept_summaries_match_recompute(monkeypatch):
     """Backward with the forward's workspace kept (KV, G, z, ksum, 1/n reused) == backward that recomputes them."""
     import mhla_amd

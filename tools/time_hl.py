@@ -19,9 +19,12 @@ SHAPES = {
 }
 
 if __name__ == "__main__":
-    keys = sys.argv[1:] or ["c2", "c3"]
+    from mhla_amd import _lib
+    ab = "--ab" in sys.argv   # also time the default arithmetic with fp32 summaries in the workspace (mhla_set_option "fp32_summaries")
+    keys = [k for k in sys.argv[1:] if not k.startswith("--")] or ["c2", "c3"]
     for key in keys:
         name, B, N, H, D, M, layout = SHAPES[key]
-        for summ in ("split", "bf16"):
-            r = blockmix_case(f"{name} bf16 [{summ}]", B, N, H, D, M, torch.bfloat16, layout, graph=True, summaries=summ)
+        for summ in ("split", "split-fp32", "bf16") if ab else ("split", "bf16"):
+            _lib.load().mhla_set_option(b"fp32_summaries", 1 if summ == "split-fp32" else 0)
+            r = blockmix_case(f"{name} bf16 [{summ}]", B, N, H, D, M, torch.bfloat16, layout, graph=True, summaries=summ.split("-")[0])
             print(json.dumps({k: r[k] for k in ("shape", "ms", "ms_graph_replay", "hbm_frac", "kernel_us_per_step", "kernel_us")}), flush=True)

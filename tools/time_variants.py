@@ -18,7 +18,7 @@ for nm in ["shipped"] + names:
         env[k_] = v_
     elif nm != "shipped":
         env["MHLA_LIB_PATH"] = os.path.join(ROOT, "mhla_amd/lib/variants", f"libmhla_{nm}.so")
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-extra-configs", "--steps", "40"],
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-extra-configs", "--no-step-benches", "--steps", "40"],
                          env=env, capture_output=True, text=True)
     try:
         j = json.loads(out.stdout.strip().splitlines()[-1])
