@@ -331,7 +331,7 @@ def main():
              "k_sp_state": 2, "k_sp_out": 2, "k_sp_state<1>": 3, "k_sp_bwd_dq": 1, "k_sp_bwd_dkv": 4,   # (mixing / dW kernels: summaries only)
              "k_bm_bwd_tok": 7, "k_bm_state<0>": 2, "k_bm_state<1>": 3, "k_bm_out": 2}
     # HBM bytes per step: PMC counters cannot be read from inside this process, so the figure comes from the rocprofv3 PMC
-    # passes of this same command (tools/prof_bench.sh -> profiles/r*_pmc_traffic.json) -- and only when that file was made
+    # passes of this same command (tools/prof_all.sh + tools/collect_profiles.py -> profiles/r*_pmc_traffic.json) -- and only when that file was made
     # from the kernel sources this library was built from (it records their hash); otherwise null
     traffic, traffic_src, mfma_busy = None, None, None
     if (a.B, a.N, a.H, a.D, a.M, a.dtype) == (8, 4096, 16, 64, 64, "bf16"):
@@ -387,7 +387,7 @@ def main():
                 "traffic_over_algorithmic": traffic / alg_bytes if traffic else None,
                 "frac_from_gpu_events": achieved_gpu / HBM_PEAK_GBS if achieved_gpu else None,
                 "mfma_busy_frac_pmc": mfma_busy,
-                "traffic_source": traffic_src or "none for these kernel sources: run tools/prof_bench.sh (rocprofv3 PMC passes)",
+                "traffic_source": traffic_src or "none for these kernel sources: run tools/prof_all.sh, then tools/collect_profiles.py (rocprofv3 PMC passes)",
                 "scope": "whole fwd+bwd step: `achieved` / `frac` = algorithmic bytes 12*B*H*N*D*e over ms_per_step (the timed "
                          "region); `frac_from_gpu_events` = the same bytes over the GPU time of one step (HIP events on the launch "
                          "stream around K more steps); `dominant_kernel` carries that kernel's own algorithmic share over its own "

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""gpurun_out/r4prof/* (tools/prof_all.sh) -> profiles/r3_<shape>_trace.md, profiles/r3_<shape>_pmc.md and
-profiles/r3_pmc_traffic.json: {csrc_sha16, shapes: {<shape>: {hbm_bytes_per_step, read, write, kernels: [...]}}} -- the file
+"""gpurun_out/<round>prof/* (tools/prof_all.sh) -> profiles/<round>_<shape>_trace.md, profiles/<round>_<shape>_pmc.md and
+profiles/<round>_pmc_traffic.json (round = argv[1], default r5): {csrc_sha16, shapes: {<shape>: {hbm_bytes_per_step, read, write, kernels: [...]}}} -- the file
 bench.py / tools/bench_configs.py take `roofline.traffic` from when it was made from the kernel sources the library was built from."""
 import glob
 import json
@@ -9,9 +9,9 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(ROOT, "gpurun_out", "r4prof")
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r5"
+src = os.path.join(ROOT, "gpurun_out", f"{rnd}prof")
 dst = os.path.join(ROOT, "profiles")
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r4"
 out = {"shapes": {}}
 for js in sorted(glob.glob(os.path.join(src, "*_pmc.json"))):
     shape = os.path.basename(js)[:-len("_pmc.json")]
