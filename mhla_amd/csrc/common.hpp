@@ -79,7 +79,15 @@ __device__ __forceinline__ void gst_stream16(void* p, uint4 v) {
 // transposed LDS read and every LDS write that follows, which drains the copies the kernel wants to keep in flight.  The copy is
 // therefore NOT in the compiler's wait bookkeeping either: the kernel counts it itself (s_waitcnt vmcnt(N), then a barrier,
 // then the reads).  M0 holds the destination and is restored in the same statement (it is compiler-reserved).
+// Used by ONE kernel (sp::k_sp_mixr_dma), whose wait sites count their outstanding copies in comments next to each wait_vmcnt<N>.
+// Validated with AMD clang 22.0.0git (roc-7.2.0, HIP 7.2.26015): the GPU suite, and bit for bit against the compiler-managed form --
+// build with -DMHLA_GLDS_BUILTIN=1 (tools/build_variant.sh glds -DMHLA_GLDS_BUILTIN=1; tools/glds_check.py compares the two
+// libraries' results on the 256 x 16 shape), where the copy is the builtin and hipcc inserts its own (conservative) waits.
 __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+#ifdef MHLA_GLDS_BUILTIN
+    __builtin_amdgcn_global_load_lds((const MHLA_GLOBAL_AS void*)gsrc, (__attribute__((address_space(3))) void*)(uintptr_t)lds_dst, 16, 0, 0);
+    return;
+#endif
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
