@@ -24,9 +24,9 @@ inline bool sp_mixr_ok(int M, long E) {
     return M > 32 && M <= 256 && E % sp::mixr_te<4, S16>() == 0;
 }
 // the normaliser's product (k_wz) rides along in the LDS-DMA mixing kernel: same weights, at most 16 values per block
-// ... and in the register-staged kernel at fp32 summaries, as extra slices (blocks of a multiple of 4 tokens: 16-byte pieces)
+// ... and in the register-staged kernel at fp32 summaries, as extra slices (blocks of an even number of tokens: 16- or 8-byte pieces)
 template <bool S16>
-inline bool sp_mixr_takes_wz(int M, int S) { return S16 ? (M > 192 && M <= 256 && S <= 16) : (S % 4 == 0); }
+inline bool sp_mixr_takes_wz(int M, int S) { return S16 ? (M > 192 && M <= 256 && S <= 16) : (S % 2 == 0); }
 template <int TRANS, bool S16, bool P24 = false>
 inline int sp_mixr(const float* W, int ldw, const void* in, void* out, int M, long E, long es, int BH, hipStream_t st,
                    const float* zin = nullptr, float* zout = nullptr, int S = 0, float eps = 0.f) {
@@ -34,11 +34,11 @@ inline int sp_mixr(const float* W, int ldw, const void* in, void* out, int M, lo
         constexpr int TE = sp::mixr_te<NW, S16>(); \
         const long total = (long)BH * (E / TE); \
         const bool wz = !S16 && zin && sp_mixr_takes_wz<S16>(M, S); \
-        const long all = total + (wz ? (long)BH * ((S + TE - 1) / TE) : 0); \
+        const long zt = wz ? (long)BH * ((S + TE - 1) / TE) : 0;   /* normaliser slices: dealt round-robin over the workgroups */ \
         /* persistent workgroups: as many as fit a CU beside each other (35 KB of LDS at four waves, 70 KB at eight) */ \
-        const int wgs = (int)std::min<long>(all, 256 * (NW <= 4 ? 4 : NW <= 8 ? 2 : 1)); \
-        sp::MixrArgs a{W, ldw, in, out, M, E, es, total, (int)((all + wgs - 1) / wgs), wz ? zin : nullptr, wz ? zout : nullptr, wz ? S : 0, eps, nullptr, nullptr, nullptr, all - total, nullptr}; \
-        const int gw = (int)((all + a.spw - 1) / a.spw); \
+        const int wgs = (int)std::min<long>(total, 256 * (NW <= 4 ? 4 : NW <= 8 ? 2 : 1)); \
+        sp::MixrArgs a{W, ldw, in, out, M, E, es, total, (int)((total + wgs - 1) / wgs), wz ? zin : nullptr, wz ? zout : nullptr, wz ? S : 0, eps, nullptr, nullptr, nullptr, zt, nullptr}; \
+        const int gw = (int)((total + a.spw - 1) / a.spw); \
         return launch(sp::k_sp_mixr<NW, TRANS, S16, false, P24>, dim3(gw), dim3(64 * NW), sp::sp_mixr_smem<NW, S16>(), st, TRANS ? "k_sp_mixr<1>" : "k_sp_mixr<0>", a); \
     } while (0)
     if constexpr (S16) {
@@ -75,10 +75,10 @@ inline int sp_mixr_dw(const float* W, int ldw, const void* dg, const void* kv, v
 #define MIXRDW(NW) do { \
         constexpr int TE = sp::mixr_te<NW, false>(); \
         const long total = (long)BH * (E / TE); \
-        const long all = total + (wz ? (long)BH * ((S + TE - 1) / TE) : 0); \
-        const int wgs = (int)std::min<long>(all, 256 * (NW <= 4 ? 2 : 1));   /* 54 KB of LDS at four waves: two per CU */ \
-        sp::MixrArgs a{W, ldw, dg, dkv, M, E, es, total, (int)((all + wgs - 1) / wgs), wz ? dn : nullptr, wz ? dz : nullptr, wz ? S : 0, 0.f, nullptr, kv, dwp, all - total, wz ? z : nullptr}; \
-        const int gw = (int)((all + a.spw - 1) / a.spw); \
+        const long zt = wz ? (long)BH * ((S + TE - 1) / TE) : 0; \
+        const int wgs = (int)std::min<long>(total, 256 * (NW <= 4 ? 2 : 1));   /* 54 KB of LDS at four waves: two per CU */ \
+        sp::MixrArgs a{W, ldw, dg, dkv, M, E, es, total, (int)((total + wgs - 1) / wgs), wz ? dn : nullptr, wz ? dz : nullptr, wz ? S : 0, 0.f, nullptr, kv, dwp, zt, wz ? z : nullptr}; \
+        const int gw = (int)((total + a.spw - 1) / a.spw); \
         *nparts = gw; \
         return launch(sp::k_sp_mixr<NW, 1, false, true, P24>, dim3(gw), dim3(64 * NW), sp::sp_mixr_smem<NW, false, true>(), st, "k_sp_mixr<1,dw>", a); \
     } while (0)

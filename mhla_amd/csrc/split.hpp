@@ -753,9 +753,9 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void k_sp_mixr(const MixrArg
     const int M = a.M;
     const long nsl = a.E / TE;
     const long s0 = (long)blockIdx.x * a.spw;
-    const int cnt = (int)min((long)a.spw, a.total + (S16 ? 0 : a.ztotal) - s0);
-    if (cnt <= 0) return;
-    const int nbh_all = (int)(a.total / nsl), nzs = (a.S + TE - 1) / TE;   // (b, h) pairs; normaliser slices per pair
+    const int cnt_s = (int)max(0L, min((long)a.spw, a.total - s0));   // this workgroup's summary slices: a consecutive range
+    const int nzs = (a.S + TE - 1) / TE;                              // normaliser slices per (b, h): dealt round-robin, see the loops
+    if (cnt_s <= 0 && (S16 || (long)blockIdx.x >= a.ztotal)) return;
     // B operand: B[k = r][n = o] = weight of input block r in output block o = 16 wave + nl, r = 32 ks + 8 kg + t
     bf16x8 wh[NK][1], wl[NK][1];
     static_assert((TRANS ? 64 * (ROWS + 4) : ROWS * 68) * 4 <= sp_mixr_smem<NW, S16, DW>(), "weight chunk must fit in the tiles");
@@ -766,16 +766,9 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void k_sp_mixr(const MixrArg
     auto lo_rel = [&](int es, int c) { return (long)2 * a.E - 64 * es - 8 * c; };
     // byte offset of slice (bh, es); a workgroup's slices are consecutive, so the pair is advanced rather than divided out per
     // slice (the 64-bit division was 150 instructions with branches between the barrier and the next slice's loads)
-    // (normaliser slices follow the last summary slice: bh >= nbh_all counts them, bh - nbh_all is their (b, h))
-    auto is_z = [&](int bh) { return !S16 && bh >= nbh_all; };
-    auto slice_off = [&](int bh, int es) {
-        return is_z(bh) ? ((long)(bh - nbh_all) * M * a.S + (long)es * TE) * 4 : (long)bh * M * a.es * ESZ + (long)es * SLB;
-    };
-    auto advance = [&](int& bh, int& es) { if (++es == (is_z(bh) ? nzs : (int)nsl)) { es = 0; ++bh; } };
-    int cbh, ces;
-    if (S16 || s0 < a.total) { cbh = (int)(s0 / nsl); ces = (int)(s0 - (long)cbh * nsl); }
-    else { const long zi = s0 - a.total; cbh = nbh_all + (int)(zi / nzs); ces = (int)(zi % nzs); }
-    int nbh = cbh, nes = ces;
+    auto slice_off = [&](int bh, int es) { return (long)bh * M * a.es * ESZ + (long)es * SLB; };
+    auto zslice_off = [&](int bh, int es) { return ((long)bh * M * a.S + (long)es * TE) * 4; };   // (normaliser rows: S plain floats)
+    auto advance = [&](int& bh, int& es) { if (++es == (int)nsl) { es = 0; ++bh; } };
     // the thread's pieces: piece v = tid + p NTH -> row v / PPR, 16 bytes at column piece v % PPR (rows past M: the last row, zeroed)
     unsigned goff[NP];
 #pragma unroll
@@ -798,21 +791,42 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void k_sp_mixr(const MixrArg
     auto zoff = [&](int p) { const int v = tid + p * NTH, row = v / UPR, c = v % UPR; return (unsigned)((row < M ? row : M - 1) * a.S * 4 + c * ZPB); };
     auto zlive = [&](int p, int es, int half = 0) { return ((tid + p * NTH) % UPR) * ZPF + half * 4 + es * TE < a.S; };
     const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
-    auto issue = [&](Stage& g, int bh, int es) __attribute__((always_inline)) {
-        const long boff = slice_off(bh, es);
-        if (is_z(bh)) {   // (uniform)
+    // four floats of a normaliser row (piece `half` of unit p): one 16-byte load when rows are multiples of 4 floats, two 8-byte loads
+    // when they are only even (S = 210: rows start on 8-byte boundaries), each half on its own side of the row's end
+    // Unconditional, from clamped addresses -- a load behind a lane-dependent branch makes hipcc wait for everything in flight where the
+    // branch joins (eight serial round trips per normaliser slice, and those workgroups were the kernel's tail); floats past the row's end
+    // are zeroed at the commit (zmask).
+    const bool zwide = (a.S & 3) == 0;   // (uniform)
+    auto zf0 = [&](int p, int es, int half) { return ((tid + p * NTH) % UPR) * ZPF + half * 4 + es * TE; };
+    auto zld = [&](const char* base, int p, int es, int half) __attribute__((always_inline)) {
+        const int f0 = zf0(p, es, half);
+        const char* src = base + zoff(p) + half * 16;
+        if (zwide) return gld_stream16(f0 < a.S ? src : base);
+        const uint2 lo = gld<uint2>(f0 < a.S ? src : base), hi = gld<uint2>(f0 + 2 < a.S ? src + 8 : base);
+        return make_uint4(lo.x, lo.y, hi.x, hi.y);
+    };
+    auto zmask = [&](const uint4& x, bool ok, int p, int es, int half) {
+        const int f0 = zf0(p, es, half);
+        return make_uint4((ok && f0 < a.S) ? x.x : 0u, (ok && f0 + 1 < a.S) ? x.y : 0u, (ok && f0 + 2 < a.S) ? x.z : 0u, (ok && f0 + 3 < a.S) ? x.w : 0u);
+    };
+    // ZS: a normaliser slice.  A compile-time flag, and the summary slices and the normaliser slices of a workgroup are two loops:
+    // with both kinds of loads behind one runtime branch, writing the same staging registers, hipcc waited for ALL loads right after
+    // issuing them (`L L L L W0 M M`: k_sp_mixr<1,dw> 78 -> 121 us at C2).
+    auto issue = [&]<bool ZS>(std::bool_constant<ZS>, Stage& g, int bh, int es) __attribute__((always_inline)) {
+        const long boff = ZS ? zslice_off(bh, es) : slice_off(bh, es);
+        if constexpr (ZS) {
             const char* base = reinterpret_cast<const char*>(a.zin) + boff;
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
-                g.pre[p] = zlive(p, es) ? gld_stream16(base + zoff(p)) : zero4;
-                if constexpr (P24) g.prz[p] = zlive(p, es, 1) ? gld_stream16(base + zoff(p) + 16) : zero4;
+                g.pre[p] = zld(base, p, es, 0);
+                if constexpr (P24) g.prz[p] = zld(base, p, es, 1);
             }
             if constexpr (DW) {
                 const char* base2 = reinterpret_cast<const char*>(a.zin2) + boff;
 #pragma unroll
                 for (int p = 0; p < NP; ++p) {
-                    g.pre2[p] = zlive(p, es) ? gld_stream16(base2 + zoff(p)) : zero4;
-                    if constexpr (P24) g.prz2[p] = zlive(p, es, 1) ? gld_stream16(base2 + zoff(p) + 16) : zero4;
+                    g.pre2[p] = zld(base2, p, es, 0);
+                    if constexpr (P24) g.prz2[p] = zld(base2, p, es, 1);
                 }
             }
             return;
@@ -848,7 +862,6 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void k_sp_mixr(const MixrArg
         *reinterpret_cast<uint2*>(th + row * LD + c * 4) = make_uint2(hs[0] | ((unsigned)hs[1] << 16), hs[2] | ((unsigned)hs[3] << 16));
         *reinterpret_cast<uint2*>(tl + row * LD + c * 4) = make_uint2(pack_bf16x2(l[0], l[1]), pack_bf16x2(l[2], l[3]));
     };
-    issue(sga, nbh, nes);
     // The stores of a slice are issued at the top of the NEXT iteration, after that slice's loads have been committed to LDS: hipcc
     // waits with vmcnt(0) in front of the commit -- with the stores at the end of the iteration that wait included their
     // acknowledgement (loads and stores retire in order), a round trip per slice on top of the load's.  The staging tile keeps the
@@ -870,7 +883,12 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void k_sp_mixr(const MixrArg
                             if (TRANS == 0)
 #pragma unroll
                                 for (int i = 0; i < 4; ++i) x[i] = 1.f / (a.eps + x[i]);
-                            *reinterpret_cast<f32x4*>(zb + zoff(p) + hf * 16) = x;
+                            if (zwide) {
+                                *reinterpret_cast<f32x4*>(zb + zoff(p) + hf * 16) = x;
+                            } else {   // (even rows: 8-byte pieces, the second one only inside the row)
+                                *reinterpret_cast<f32x2*>(zb + zoff(p) + hf * 16) = f32x2{x[0], x[1]};
+                                if (((tid + p * NTH) % UPR) * ZPF + hf * 4 + zes * TE + 2 < a.S) *reinterpret_cast<f32x2*>(zb + zoff(p) + hf * 16 + 8) = f32x2{x[2], x[3]};
+                            }
                         }
                     }
                 }
@@ -899,13 +917,13 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void k_sp_mixr(const MixrArg
             }
         }
     };
-    auto body = [&](Stage& g, int it) __attribute__((always_inline)) {
-        const long off = slice_off(cbh, ces);
-        const bool zslice = is_z(cbh);   // (uniform)
-        const int zes = ces;
-        advance(cbh, ces);
+    // it: the slice's position in this phase; first: nothing to store yet; more: another slice of the SAME kind follows (prefetch it)
+    auto body = [&]<bool ZS>(std::bool_constant<ZS> zs, Stage& g, bool first, bool more, int bh, int es, int nbh, int nes) __attribute__((always_inline)) {
+        const long off = ZS ? zslice_off(bh, es) : slice_off(bh, es);
+        constexpr bool zslice = ZS;
+        const int zes = es;
 #ifdef MIXR_X_NOCOMMIT
-        if (it == 0)
+        if (first)
 #endif
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
@@ -913,13 +931,12 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void k_sp_mixr(const MixrArg
             const bool ok = row < M;   // rows past the last block: zeros (their weights are zero too, but 0 x NaN is not)
             const uint4 x = make_uint4(ok ? g.pre[p].x : 0u, ok ? g.pre[p].y : 0u, ok ? g.pre[p].z : 0u, ok ? g.pre[p].w : 0u);
             if constexpr (P24) {
-                if (zslice) {   // (uniform) 8 plain floats
-                    const uint4 x1 = make_uint4(ok ? g.prz[p].x : 0u, ok ? g.prz[p].y : 0u, ok ? g.prz[p].z : 0u, ok ? g.prz[p].w : 0u);
-                    commit_hl(Th, Tl, x, row, 2 * c);
-                    commit_hl(Th, Tl, x1, row, 2 * c + 1);
+                if (zslice) {   // 8 plain floats
+                    commit_hl(Th, Tl, zmask(g.pre[p], ok, p, zes, 0), row, 2 * c);
+                    commit_hl(Th, Tl, zmask(g.prz[p], ok, p, zes, 1), row, 2 * c + 1);
                     if constexpr (DW) {
-                        commit_hl(Kh, Kl, make_uint4(ok ? g.pre2[p].x : 0u, ok ? g.pre2[p].y : 0u, ok ? g.pre2[p].z : 0u, ok ? g.pre2[p].w : 0u), row, 2 * c);
-                        commit_hl(Kh, Kl, make_uint4(ok ? g.prz2[p].x : 0u, ok ? g.prz2[p].y : 0u, ok ? g.prz2[p].z : 0u, ok ? g.prz2[p].w : 0u), row, 2 * c + 1);
+                        commit_hl(Kh, Kl, zmask(g.pre2[p], ok, p, zes, 0), row, 2 * c);
+                        commit_hl(Kh, Kl, zmask(g.prz2[p], ok, p, zes, 1), row, 2 * c + 1);
                     }
                 } else {   // the hi piece is the operand; the lo operand is rebuilt from the third bytes
                     const uint2 l = make_uint2(ok ? g.prl[p][0] : 0u, ok ? g.prl[p][1] : 0u);
@@ -934,6 +951,9 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void k_sp_mixr(const MixrArg
                 }
             } else if constexpr (S16) {
                 *reinterpret_cast<uint4*>(Th + row * LD + c * 8) = x;
+            } else if (zslice) {   // (fp32 summaries: the unit is the 16-byte piece)
+                commit_hl(Th, Tl, zmask(g.pre[p], ok, p, zes, 0), row, c);
+                if constexpr (DW) commit_hl(Kh, Kl, zmask(g.pre2[p], ok, p, zes, 0), row, c);
             } else {   // four floats -> four bf16 hi + four bf16 lo
                 commit_hl(Th, Tl, x, row, c);
                 if constexpr (DW) {
@@ -943,13 +963,12 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void k_sp_mixr(const MixrArg
             }
         }
 #ifndef MIXR_X_NOSTORE   // (experiment builds only, tools/build_variant.sh: MIXR_X_* drop one phase of the slice loop -- results are wrong)
-        if (it > 0) store_slice(poff, pz, pzes);
+        if (!first) store_slice(poff, pz, pzes);
 #endif
         __syncthreads();
-        if (it + NBUF < cnt) {
-            advance(nbh, nes);
+        if (more) {
 #ifndef MIXR_X_NOLOAD
-            issue(g, nbh, nes);
+            issue(zs, g, nbh, nes);
 #endif
         }
         f32x4 acc[NT];
@@ -1012,7 +1031,29 @@ __global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void k_sp_mixr(const MixrArg
         pz = zslice;
         pzes = zes;
     };
-    for (int it = 0; it < cnt; ++it) body(sga, it);
+    // The workgroup's summary slices (a consecutive range), then its share of the normaliser slices: slice zi goes to workgroup
+    // zi % gridDim.x -- at C2 one of them for a quarter of the workgroups -- so that no workgroup is left with a tail of them (as a
+    // range behind the summaries they were 17 latency-bound iterations for the last eight workgroups).
+    if (cnt_s > 0) {
+        int bh = (int)(s0 / nsl), es = (int)(s0 - (long)bh * nsl);
+        issue(std::false_type{}, sga, bh, es);
+        for (int it = 0; it < cnt_s; ++it) {
+            int nb = bh, ne = es;
+            advance(nb, ne);
+            body(std::false_type{}, sga, it == 0, it + 1 < cnt_s, bh, es, nb, ne);
+            bh = nb;
+            es = ne;
+        }
+    }
+    if constexpr (!S16) {
+        bool firstz = cnt_s <= 0;
+        for (long zi = blockIdx.x; zi < a.ztotal; zi += gridDim.x) {   // (the first one is not prefetched under the last summary slice)
+            const long nzi = zi + gridDim.x;
+            if (zi == (long)blockIdx.x) issue(std::true_type{}, sga, (int)(zi / nzs), (int)(zi % nzs));
+            body(std::true_type{}, sga, firstz, nzi < a.ztotal, (int)(zi / nzs), (int)(zi % nzs), (int)(nzi / nzs), (int)(nzi % nzs));
+            firstz = false;
+        }
+    }
     store_slice(poff, pz, pzes);
     if constexpr (DW) {   // C layout: rows i = 16 wave + 4 kg + r, column j = 16 jt + nl
         float* dp = a.dwp + (long)blockIdx.x * M * M;
