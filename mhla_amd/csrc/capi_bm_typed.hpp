@@ -53,11 +53,9 @@ inline int sp_mixr(const float* W, int ldw, const void* in, void* out, int M, lo
     }
     if (M <= 64) MIXR(4);
     if (M <= 128) MIXR(8);
-    if constexpr (P24) return fail(MHLA_EINVAL, "sp_mixr: p24 summaries at M=%d", M);   // (bm_p24 admits 33 .. 128 blocks)
-    else {
     if (M <= 192) MIXR(12);
-    if constexpr (!S16) MIXR(16);   // (16-bit summaries: taken by the DMA kernel above)
-    }
+    if constexpr (P24) return fail(MHLA_EINVAL, "sp_mixr: p24 summaries at M=%d", M);   // (bm_p24 admits 33 .. 192 blocks)
+    else if constexpr (!S16) MIXR(16);   // (16-bit summaries: taken by the DMA kernel above)
     return fail(MHLA_EINVAL, "sp_mixr: M=%d out of range", M);
 #undef MIXR
 }
@@ -87,13 +85,16 @@ inline int sp_mixr_dw(const float* W, int ldw, const void* dg, const void* kv, v
 #undef MIXRDW
 }
 
-// p24 summaries (split.hpp: 24-bit floats, 3 / 4 of the bytes of every summary transfer): 16-bit tensors at the default arithmetic, the range
-// of the resident mixing with its fused dW (33 .. 128 blocks), head dims up to 64, no rotary tables or fused epilogue (fp32-tensor
-// features).  A function of the call's shape, dtype and flags only: a forward and the backward that reuses its state agree.
+// p24 summaries (split.hpp: 24-bit floats, 3 / 4 of the bytes of every summary transfer) on the resident-mixing pipeline: 16-bit tensors
+// with head dims up to 64 and 33 .. 128 blocks (the fused dW), and fp32 tensors at head dims 113 .. 128 with 33 .. 192 blocks (the Wan
+// shape, rotary tables and fused epilogue included: the operands are bf16 hi + lo pairs there too, 16 significand bits either way).  A
+// function of the call's shape, dtype and flags only: a forward and the backward that reuses its state agree.
+template <typename ET, int DT, bool S16>
+constexpr bool bm_p24_built() { return !S16 && ((sizeof(ET) == 2 && DT <= 4) || (std::is_same<ET, float>::value && DT == 8)); }
 template <typename ET, int DT, bool S16>
 inline bool bm_p24(int M, int D, unsigned flags) {
-    if constexpr (S16 || sizeof(ET) != 2 || DT > 4) return false;
-    else return sp_shape_ok(D, flags) && sp_mixr_dw_ok(M, (long)D * D) && !g_no_p24.load();
+    if constexpr (!bm_p24_built<ET, DT, S16>()) return false;
+    else return sp_shape_ok(D, flags) && sp_mixr_ok<false>(M, (long)D * D) && M <= (sizeof(ET) == 2 ? 128 : 192) && !g_no_p24.load();
 }
 inline long bm_p24_es(int D) { return 3L * D * D / 4 + 288; }   // row stride in float units: 3 bytes per element + the padding of bm_row_elems
 
@@ -132,8 +133,8 @@ int bm_state_and_mix(const mhla_view& q_num, const mhla_view& k_num, const mhla_
                      int M, int S, int D, float eps, unsigned flags, bool normalize, bool split, hipStream_t st,
                      const float* rcos = nullptr, const float* rsin = nullptr, long ldr = 0, bool s16 = false) {
     (void)q_num;
-    constexpr bool P24OK = !S16 && sizeof(T) == 2 && DT <= 4;
-    const bool p24 = !rcos && bm_p24<T, DT, S16>(M, D, flags);
+    constexpr bool P24OK = bm_p24_built<T, DT, S16>();
+    const bool p24 = bm_p24<T, DT, S16>(M, D, flags);
     const long es = p24 ? bm_p24_es(D) : w.es;
     StateArgs a{};
     a.rcos = rcos; a.rsin = rsin; a.ldr = ldr;
@@ -146,7 +147,11 @@ int bm_state_and_mix(const mhla_view& q_num, const mhla_view& k_num, const mhla_
         constexpr int SNT = sp_state_threads<DT>();   // eight waves at D = 128 (split.hpp)
         if constexpr (P24OK) {
             if (p24) {
-                RC(launch(sp::k_sp_state<T, DT, 0, false, SNT, false, true>, dim3(M, B * H), dim3(SNT), sp::sp_state_smem<DT>(), st, "k_sp_state", a));
+                if (a.rcos) {
+                    if constexpr (std::is_same<T, float>::value)
+                        RC(launch(sp::k_sp_state<T, DT, 0, true, SNT, false, true>, dim3(M, B * H), dim3(SNT), sp::sp_state_smem<DT>(), st, "k_sp_state<rope>", a));
+                } else
+                    RC(launch(sp::k_sp_state<T, DT, 0, false, SNT, false, true>, dim3(M, B * H), dim3(SNT), sp::sp_state_smem<DT>(), st, "k_sp_state", a));
                 RC((sp_mixr<0, false, true>(W, ldw, w.kv, w.g, M, m.E, es, B * H, st, normalize ? (const float*)w.z : nullptr, w.ninv, S, eps)));
                 if (normalize && !sp_mixr_takes_wz<false>(M, S))
                     RC(launch(k_wz<0>, dim3((S + 63) / 64, (M + 63) / 64, B * H), dim3(NTHREADS), 0, st, "k_wz<0>", W, ldw, (const float*)w.z, w.ninv, M, S, eps));
@@ -193,8 +198,8 @@ int bm_fwd_typed(const BmCall& c) {
         OutArgs o{};
         o.rcos = rcos; o.rsin = rsin; o.ldr = ldr;
         o.q = cv(q_num); o.o = cmv(c.out); o.idx = block_index; o.W = W; o.ldw = ldw; o.g = w.g; o.ninv = w.ninv;
-        constexpr bool P24OK = !S16 && sizeof(ET) == 2 && DT <= 4;
-        const bool p24 = !rcos && bm_p24<ET, DT, S16>(M, D, flags);
+        constexpr bool P24OK = bm_p24_built<ET, DT, S16>();
+        const bool p24 = bm_p24<ET, DT, S16>(M, D, flags);
         o.H = H; o.M = M; o.S = S; o.D = D; o.eps = eps; o.es = p24 ? bm_p24_es(D) : w.es;
         o.relu = (flags & MHLA_FLAG_RELU_EPS) ? 1 : 0; o.normalize = normalize;
         o.olo = (normalize && !epi && !(flags & MHLA_FLAG_NO_BWD_STATE)) ? w.olo : nullptr;   // (16-bit tensors, default arithmetic: BmWs::olo)
@@ -202,6 +207,13 @@ int bm_fwd_typed(const BmCall& c) {
             if constexpr (std::is_same<ET, float>::value) {
                 o.nw = nw; o.neps = neps; o.gate = cv(gate);
                 const dim3 g(M, B * H), blk(sp::SP_OUT_T);
+                if (p24) {
+                    if constexpr (P24OK) {
+                        if (out_dtype == MHLA_BF16)     RC(launch(sp::k_sp_out<float, DT, bf16_t, true, false, true>, g, blk, sp::sp_out_smem<DT>(), st, "k_sp_out<norm>", o));
+                        else if (out_dtype == MHLA_F16) RC(launch(sp::k_sp_out<float, DT, f16_t, true, false, true>, g, blk, sp::sp_out_smem<DT>(), st, "k_sp_out<norm>", o));
+                        else                            RC(launch(sp::k_sp_out<float, DT, float, true, false, true>, g, blk, sp::sp_out_smem<DT>(), st, "k_sp_out<norm>", o));
+                    }
+                } else
                 if (out_dtype == MHLA_BF16)     RC(launch(sp::k_sp_out<float, DT, bf16_t, true>, g, blk, sp::sp_out_smem<DT>(), st, "k_sp_out<norm>", o));
                 else if (out_dtype == MHLA_F16) RC(launch(sp::k_sp_out<float, DT, f16_t, true>, g, blk, sp::sp_out_smem<DT>(), st, "k_sp_out<norm>", o));
                 else                            RC(launch(sp::k_sp_out<float, DT, float, true>, g, blk, sp::sp_out_smem<DT>(), st, "k_sp_out<norm>", o));
@@ -237,8 +249,8 @@ int bm_bwd_typed(const BmCall& c) {
         const bool s16 = S16 && s16_ok<ET, DT>(c, true);
         if (!reuse)
             RC((bm_state_and_mix<ET, DT, S16>(q_num, k_num, v, q_den, k_den, W, ldw, block_index, w, B, H, M, S, D, eps, flags, normalize, split, st, rcos, rsin, ldr, s16)));
-        constexpr bool P24OK = !S16 && sizeof(ET) == 2 && DT <= 4;
-        const bool p24 = !rcos && bm_p24<ET, DT, S16>(M, D, flags);
+        constexpr bool P24OK = bm_p24_built<ET, DT, S16>();
+        const bool p24 = bm_p24<ET, DT, S16>(M, D, flags);
         const long es = p24 ? bm_p24_es(D) : w.es;
         const bool want_olo = normalize && w.olo != nullptr;
         if (want_olo && (!reuse || (flags & MHLA_FLAG_NO_BWD_STATE))) {
@@ -273,20 +285,44 @@ int bm_bwd_typed(const BmCall& c) {
             t.rcos = rcos; t.rsin = rsin; t.ldr = ldr;
             constexpr int SNT = sp_state_threads<DT>();
             if constexpr (P24OK) {
-                if (p24) {   // the same kernels on 24-bit summaries: dG, then dKV = W^T dG with dz and dW riding along, the token gradients
-                    RC(launch(sp::k_sp_state<ET, DT, 1, false, SNT, false, true>, dim3(M, B * H), dim3(SNT), sp::sp_state_smem<DT>(), st, "k_sp_state<1>", a));
+                if (p24) {   // the same kernels on 24-bit summaries: dG, then dKV = W^T dG with dz (and, up to 128 blocks, dW) riding along, the token gradients
+                    constexpr bool F32 = std::is_same<ET, float>::value;
+                    const bool rope = F32 && rcos != nullptr;
+                    if (rope) {
+                        if constexpr (F32) RC(launch(sp::k_sp_state<ET, DT, 1, true, SNT, false, true>, dim3(M, B * H), dim3(SNT), sp::sp_state_smem<DT>(), st, "k_sp_state<1,rope>", a));
+                    } else
+                        RC(launch(sp::k_sp_state<ET, DT, 1, false, SNT, false, true>, dim3(M, B * H), dim3(SNT), sp::sp_state_smem<DT>(), st, "k_sp_state<1>", a));
                     int parts = 0;
-                    bool wz_done = false;
-                    RC(sp_mixr_dw<true>(W, ldw, w.dg, w.kv, w.dkv, w.dwp, M, E, es, B * H, st, &parts, normalize ? (const float*)w.dn : nullptr,
-                                        normalize ? (const float*)w.z : nullptr, w.dz, S, &wz_done));
-                    if (normalize && !wz_done) {
+                    bool wz_done = false, dwz_done = false;   // dz = W^T dn formed / the <dn_i, z_j> term of dW included
+                    if (sp_mixr_dw_ok(M, E)) {
+                        RC(sp_mixr_dw<true>(W, ldw, w.dg, w.kv, w.dkv, w.dwp, M, E, es, B * H, st, &parts, normalize ? (const float*)w.dn : nullptr,
+                                            normalize ? (const float*)w.z : nullptr, w.dz, S, &wz_done));
+                        dwz_done = wz_done;
+                    } else {   // 129 .. 192 blocks: twelve waves have no registers for the dW tiles -- k_sp_dw reads dG and KV again
+                        wz_done = normalize && sp_mixr_takes_wz<false>(M, S);
+                        RC((sp_mixr<1, false, true>(W, ldw, w.dg, w.dkv, M, E, es, B * H, st, normalize ? (const float*)w.dn : nullptr, w.dz, S, 0.f)));
+                        int nsplit = dw_splits(tiles * tiles * B * H, E);
+                        if (nsplit > DW_MAX_SPLIT - 1) nsplit = DW_MAX_SPLIT - 1;
+                        DwArgs d{w.dg, w.kv, E, nullptr, nullptr, 0, w.dwp, M, tiles, nsplit, es};
+                        RC(launch(sp::k_sp_dw<false, 4, true>, dim3(tiles * tiles, B * H, nsplit), dim3(NTHREADS), sp::SP_DW_SMEM, st, "k_sp_dw", d));
+                        parts = B * H * nsplit;
+                    }
+                    if (normalize && !wz_done)
                         RC(launch(k_wz<1>, dim3((S + 63) / 64, (M + 63) / 64, B * H), dim3(NTHREADS), 0, st, "k_wz<1>", W, ldw, (const float*)w.dn, w.dz, M, S, 0.f));
+                    if (normalize && !dwz_done) {
                         DwArgs dzz{w.dn, w.z, (long)S, nullptr, nullptr, 0, w.dwp + (size_t)parts * M * M, M, tiles, 1};
                         RC(launch(k_dw<0>, dim3(tiles * tiles, B * H, 1), dim3(NTHREADS), DW_SMEM_FLOATS * 4, st, "k_dw", dzz));
                         parts += B * H;
                     }
                     RC(launch(k_dw_reduce<0, 16>, dim3((M * M + 15) / 16), dim3(256), 0, st, "k_dw_reduce", (const float*)w.dwp, (const float*)nullptr, dW, M, M, parts, B * H));
-                    if (normalize && !relu) RC(launch(sp::k_sp_bwd_dq<ET, DT, false, false, true, true>, dim3(M, B * H), dim3(NTHREADS), sp::sp_tok_smem<DT, false>(), st, "k_sp_bwd_dq", t));
+                    if (rope) {
+                        if constexpr (F32) {
+                            RC(launch(sp::k_sp_bwd_dq<ET, DT, true, false, false, true>, dim3(M, B * H), dim3(NTHREADS), sp::sp_tok_smem<DT, false>(), st, "k_sp_bwd_dq<rope>", t));
+                            RC(launch(sp::k_sp_bwd_dkv<ET, DT, true, false, true>, dim3(M, B * H), dim3(NTHREADS), sp::sp_tok_smem<DT, false>(), st, "k_sp_bwd_dkv<rope>", t));
+                        }
+                        break;
+                    }
+                    if (normalize && !relu && sizeof(ET) == 2) RC(launch(sp::k_sp_bwd_dq<ET, DT, false, false, true, true>, dim3(M, B * H), dim3(NTHREADS), sp::sp_tok_smem<DT, false>(), st, "k_sp_bwd_dq", t));
                     else RC(launch(sp::k_sp_bwd_dq<ET, DT, false, false, false, true>, dim3(M, B * H), dim3(NTHREADS), sp::sp_tok_smem<DT, false>(), st, "k_sp_bwd_dq", t));
                     RC(launch(sp::k_sp_bwd_dkv<ET, DT, false, false, true>, dim3(M, B * H), dim3(NTHREADS), sp::sp_tok_smem<DT, false>(), st, "k_sp_bwd_dkv", t));
                     break;

@@ -1619,7 +1619,8 @@ constexpr int SP_DW_SMEM = 64 * SP_DW_LD * 4;
 
 // NT: 16-row tiles per side of the output tile (4: 64 x 64; 1 / 2 when M <= 16 / 32, where the full tile would spend 15/16 or 3/4 of
 // its loads and MFMAs on clamped rows); UE = 4 / NT reduction steps per loop iteration keep the same number of loads in flight.
-template <bool S16, int NT = 4>
+// P24: both summary sets are 24-bit floats in two planes per row (the hi plane is the hi operand; the lo operand is rebuilt, p24_lo8)
+template <bool S16, int NT = 4, bool P24 = false>
 __global__ __launch_bounds__(NTHREADS) void k_sp_dw(const DwArgs a) {
     constexpr int UE = 4 / NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1679,6 +1680,34 @@ __global__ __launch_bounds__(NTHREADS) void k_sp_dw(const DwArgs a) {
             continue;
         }
         uint4 xh[UE][NT], xl[UE][NT], yh[UE][NT], yl[UE][NT];
+        if constexpr (P24) {   // 8 elements: 16 bytes of the hi plane at 2 e, 8 bytes of the lo plane at 2 E + e
+            uint2 xb[UE][NT], yb[UE][NT];
+#pragma unroll
+            for (int u = 0; u < UE; ++u) {
+                const long e = e0 + 32 * u;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    xh[u][t] = yh[u][t] = make_uint4(0, 0, 0, 0);
+                    xb[u][t] = yb[u][t] = make_uint2(0, 0);
+                    if (e < wend) {
+                        const char* xr = reinterpret_cast<const char*>(xp[t] - kg * 8);   // (the row's first byte)
+                        const char* yr = reinterpret_cast<const char*>(yp[t] - kg * 8);
+                        const long ee = e + kg * 8;
+                        xh[u][t] = gld<uint4>(xr + 2 * ee);
+                        xb[u][t] = gld<uint2>(xr + 2 * E + ee);
+                        yh[u][t] = gld<uint4>(yr + 2 * ee);
+                        yb[u][t] = gld<uint2>(yr + 2 * E + ee);
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UE; ++u)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    xl[u][t] = p24_lo8(xh[u][t], xb[u][t]);
+                    yl[u][t] = p24_lo8(yh[u][t], yb[u][t]);
+                }
+        } else {
         f32x4 raw[UE][2 * NT][2];
 #pragma unroll
         for (int u = 0; u < UE; ++u) {
@@ -1701,6 +1730,7 @@ __global__ __launch_bounds__(NTHREADS) void k_sp_dw(const DwArgs a) {
                 split8(raw[u][t][0], raw[u][t][1], xh[u][t], xl[u][t]);
                 split8(raw[u][NT + t][0], raw[u][NT + t][1], yh[u][t], yl[u][t]);
             }
+        }
 #pragma unroll
         for (int u = 0; u < UE; ++u) {
 #pragma unroll
