@@ -374,7 +374,7 @@ def main():
                                    f"M={a.M} S={a.N // a.M} {a.dtype} ({_config_name(a)})",
                        "global_batch": a.B * world, "parallelism": f"dp{world} (batch shards, dW all-reduce only)",
                        "launch": launch_mode,
-                       "arithmetic": ("fp32-grade intermediates on the bf16 tensors (fp32 block summaries, bf16 hi + lo operands, fp32-grade O "
+                       "arithmetic": ("fp32-grade intermediates on the bf16 tensors (block summaries as 24-bit floats: 16 significand bits; bf16 hi + lo operands, fp32-grade O "
                                       "in the row dots): the reference's arithmetic (mhla_dit/mhla/mhla.py:262-268 as mhla_dit/train.py:12-13 "
                                       "runs it), the library's default" if a.summaries == "split" or a.dtype == "f32" else
                                       "REDUCED PRECISION (--summaries bf16, opt-in MHLA_FLAG_BF16_SUMMARIES): single-bf16 block summaries"),
