@@ -21,7 +21,7 @@ template <int DT> constexpr int sp_state_threads() {
 }
 template <bool S16>
 inline bool sp_mixr_ok(int M, long E) {
-    return M > 32 && M <= 256 && E % sp::mixr_te<4, S16>() == 0;
+    return (M > 32 || !S16) && M <= 256 && E % sp::mixr_te<4, S16>() == 0;   // (fp32-grade summaries: two waves for up to 32 blocks)
 }
 // the normaliser's product (k_wz) rides along in the LDS-DMA mixing kernel: same weights, at most 16 values per block
 // ... and in the register-staged kernel at fp32 summaries, as extra slices (blocks of an even number of tokens: 16- or 8-byte pieces)
@@ -36,7 +36,7 @@ inline int sp_mixr(const float* W, int ldw, const void* in, void* out, int M, lo
         const bool wz = !S16 && zin && sp_mixr_takes_wz<S16>(M, S); \
         const long zt = wz ? (long)BH * ((S + TE - 1) / TE) : 0;   /* normaliser slices: dealt round-robin over the workgroups */ \
         /* persistent workgroups: as many as fit a CU beside each other (35 KB of LDS at four waves, 70 KB at eight) */ \
-        const int wgs = (int)std::min<long>(total, 256 * (NW <= 4 ? 4 : NW <= 8 ? 2 : 1)); \
+        const int wgs = (int)std::min<long>(total, 256 * (NW <= 2 ? 8 : NW <= 4 ? 4 : NW <= 8 ? 2 : 1)); \
         sp::MixrArgs a{W, ldw, in, out, M, E, es, total, (int)((total + wgs - 1) / wgs), wz ? zin : nullptr, wz ? zout : nullptr, wz ? S : 0, eps, nullptr, nullptr, nullptr, zt, nullptr}; \
         const int gw = (int)((total + a.spw - 1) / a.spw); \
         return launch(sp::k_sp_mixr<NW, TRANS, S16, false, P24>, dim3(gw), dim3(64 * NW), sp::sp_mixr_smem<NW, S16>(), st, TRANS ? "k_sp_mixr<1>" : "k_sp_mixr<0>", a); \
@@ -50,6 +50,9 @@ inline int sp_mixr(const float* W, int ldw, const void* in, void* out, int M, lo
             const int gw = (int)((total + a.spw - 1) / a.spw);
             return launch(sp::k_sp_mixr_dma<TRANS>, dim3(gw), dim3(sp::MIXR_DMA_T), sp::sp_mixr_dma_smem(), st, TRANS ? "k_sp_mixr_dma<1>" : "k_sp_mixr_dma<0>", a);
         }
+    }
+    if constexpr (!S16) {
+        if (M <= 32) MIXR(2);
     }
     if (M <= 64) MIXR(4);
     if (M <= 128) MIXR(8);
@@ -74,12 +77,13 @@ inline int sp_mixr_dw(const float* W, int ldw, const void* dg, const void* kv, v
         constexpr int TE = sp::mixr_te<NW, false>(); \
         const long total = (long)BH * (E / TE); \
         const long zt = wz ? (long)BH * ((S + TE - 1) / TE) : 0; \
-        const int wgs = (int)std::min<long>(total, 256 * (NW <= 4 ? 2 : 1));   /* 54 KB of LDS at four waves: two per CU */ \
+        const int wgs = (int)std::min<long>(total, 256 * (NW <= 2 ? 4 : NW <= 4 ? 2 : 1));   /* 54 KB of LDS at four waves: two per CU; 27 KB at two waves */ \
         sp::MixrArgs a{W, ldw, dg, dkv, M, E, es, total, (int)((total + wgs - 1) / wgs), wz ? dn : nullptr, wz ? dz : nullptr, wz ? S : 0, 0.f, nullptr, kv, dwp, zt, wz ? z : nullptr}; \
         const int gw = (int)((total + a.spw - 1) / a.spw); \
         *nparts = gw; \
         return launch(sp::k_sp_mixr<NW, 1, false, true, P24>, dim3(gw), dim3(64 * NW), sp::sp_mixr_smem<NW, false, true>(), st, "k_sp_mixr<1,dw>", a); \
     } while (0)
+    if (M <= 32) MIXRDW(2);
     if (M <= 64) MIXRDW(4);
     MIXRDW(8);
 #undef MIXRDW

@@ -154,8 +154,8 @@ inline BmWs bm_carve(void* ws, int B, int H, int M, int S, int D, bool sum16, bo
     w.dn = p; p += zs;
     w.dz = p; p += zs;
     w.dks = p; p += ks;
-    // dW partials: (b, h) x E-slices of k_sp_dw / k_dw, or one per workgroup of the fused mixing + dW kernel (<= 512) + one per (b, h)
-    w.dwp = p; p += al4(std::max(bh * DW_MAX_SPLIT, M <= 128 ? bh + 512 : (size_t)0) * M * M);
+    // dW partials: (b, h) x E-slices of k_sp_dw / k_dw, or one per workgroup of the fused mixing + dW kernel (<= 512; <= 1024 of up to 32 x 32 at two waves) + one per (b, h)
+    w.dwp = p; p += al4(std::max(bh * DW_MAX_SPLIT, M <= 32 ? bh + 1024 : M <= 128 ? bh + 512 : (size_t)0) * M * M);
     w.total_bwd = (size_t)(p - (float*)ws) * 4;
     return w;
 }
