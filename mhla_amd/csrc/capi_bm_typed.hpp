@@ -90,11 +90,11 @@ inline int sp_mixr_dw(const float* W, int ldw, const void* dg, const void* kv, v
 }
 
 // p24 summaries (split.hpp: 24-bit floats, 3 / 4 of the bytes of every summary transfer) on the resident-mixing pipeline: 16-bit tensors
-// with head dims up to 64 and 33 .. 128 blocks (the fused dW), and fp32 tensors at head dims 113 .. 128 with 33 .. 192 blocks (the Wan
+// with head dims up to 96 and up to 128 blocks (the fused dW), and fp32 tensors at head dims 113 .. 128 with 33 .. 192 blocks (the Wan
 // shape, rotary tables and fused epilogue included: the operands are bf16 hi + lo pairs there too, 16 significand bits either way).  A
 // function of the call's shape, dtype and flags only: a forward and the backward that reuses its state agree.
 template <typename ET, int DT, bool S16>
-constexpr bool bm_p24_built() { return !S16 && ((sizeof(ET) == 2 && DT <= 4) || (std::is_same<ET, float>::value && DT == 8)); }
+constexpr bool bm_p24_built() { return !S16 && ((sizeof(ET) == 2 && DT <= 6) || (std::is_same<ET, float>::value && DT == 8)); }
 template <typename ET, int DT, bool S16>
 inline bool bm_p24(int M, int D, unsigned flags) {
     if constexpr (!bm_p24_built<ET, DT, S16>()) return false;
@@ -326,7 +326,7 @@ int bm_bwd_typed(const BmCall& c) {
                         }
                         break;
                     }
-                    if (normalize && !relu && sizeof(ET) == 2) RC(launch(sp::k_sp_bwd_dq<ET, DT, false, false, true, true>, dim3(M, B * H), dim3(NTHREADS), sp::sp_tok_smem<DT, false>(), st, "k_sp_bwd_dq", t));
+                    if (normalize && !relu && sizeof(ET) == 2 && DT != 5) RC(launch(sp::k_sp_bwd_dq<ET, DT, false, false, true, true>, dim3(M, B * H), dim3(NTHREADS), sp::sp_tok_smem<DT, false>(), st, "k_sp_bwd_dq", t));
                     else RC(launch(sp::k_sp_bwd_dq<ET, DT, false, false, false, true>, dim3(M, B * H), dim3(NTHREADS), sp::sp_tok_smem<DT, false>(), st, "k_sp_bwd_dq", t));
                     RC(launch(sp::k_sp_bwd_dkv<ET, DT, false, false, true>, dim3(M, B * H), dim3(NTHREADS), sp::sp_tok_smem<DT, false>(), st, "k_sp_bwd_dkv", t));
                     break;
