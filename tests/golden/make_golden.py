@@ -137,6 +137,68 @@ def gen_weight_inits():
     save("weight_init", **arrs)
 
 
+def gen_blockmix_bf16(tag, path, cls_name, seed, B, heads, dim_head, block_size, embed_len):
+    """bf16 fixture of the block-mixing operator (verdict r4 item 1): the reference module's operator evaluated IN FP32 ON
+    BF16-ROUNDED q, k, v, dO -- what an implementation that takes bf16 tensors and keeps fp32-grade intermediates must
+    reproduce up to the final rounding -- and, beside it, the same module run literally in bf16 (`module.bfloat16()`), whose
+    operator output shows what the reference's own bf16 arithmetic loses."""
+    from einops import rearrange
+    mod = load_by_path(f"ref_{tag}", path)
+    cls = getattr(mod, cls_name)
+    torch.manual_seed(seed)
+    dim = heads * dim_head
+    m = cls(dim, heads=heads, dim_head=dim_head, dropout=0.0, qk_norm=False, transform="linear", qkv_bias=True,
+            embed_len=embed_len, block_size=block_size)
+    m.eval()
+    M = embed_len // block_size
+    with torch.no_grad():
+        m.lepe.weight.normal_(0, 0.2)
+        m.lepe.bias.normal_(0, 0.1)
+        m.piece_attn.conv.weight.copy_(torch.rand(M, M, 1, 1))
+    x = torch.randn(B, M, block_size, dim)
+    dO = torch.randn(B * heads, M, block_size, dim_head).bfloat16().float()
+    rnd = lambda t: t.detach().bfloat16().float().requires_grad_(True)
+    cap = {}
+    orig = m._process_qkv_impl
+
+    def wrapped(q, k, v, B_, N_, H_, D_):
+        q2, kT, v2 = orig(q, k, v, B_, N_, H_, D_)
+        cap["q"], cap["kT"], cap["v"] = rnd(q2), rnd(kT), rnd(v2)       # leaves holding bf16 values, everything after them in fp32
+        return cap["q"], cap["kT"], cap["v"]
+
+    m._process_qkv_impl = wrapped
+    m.lepe.register_forward_hook(lambda mod_, inp, out: cap.__setitem__("lepe_img", out))
+    m.to_out.register_forward_pre_hook(lambda mod_, inp: cap.__setitem__("pre_out", inp[0]))
+    m(x)
+    pl, bl = m.pieces_len, int(block_size ** 0.5)
+    lepe = rearrange(cap["lepe_img"], "b d (h p1) (w p2) -> b (h w) (p1 p2) d", h=pl, w=pl, p1=bl, p2=bl)
+    op_out_bh = rearrange(cap["pre_out"] - lepe, "b n w (h d) -> (b h) n w d", h=heads)
+    (op_out_bh * dO).sum().backward()
+    to_bnhd = lambda t: rearrange(t, "(b h) n w d -> b (n w) h d", b=B)
+    fx = dict(q=np32(to_bnhd(cap["q"])), k=np32(to_bnhd(cap["kT"].transpose(-2, -1))), v=np32(to_bnhd(cap["v"])),
+              W=np32(m.piece_attn.get_weight_matrix()), out=np32(to_bnhd(op_out_bh)), dout=np32(to_bnhd(dO)),
+              dq=np32(to_bnhd(cap["q"].grad)), dk=np32(to_bnhd(cap["kT"].grad.transpose(-2, -1))), dv=np32(to_bnhd(cap["v"].grad)),
+              dW=np32(m.piece_attn.conv.weight.grad.reshape(M, M)))
+    # the literal bf16 run of the same module on the same (bf16-rounded) operator inputs
+    mb = cls(dim, heads=heads, dim_head=dim_head, dropout=0.0, qk_norm=False, transform="linear", qkv_bias=True,
+             embed_len=embed_len, block_size=block_size)
+    mb.load_state_dict(m.state_dict())
+    mb = mb.eval().bfloat16()
+    capb = {}
+    q0, k0, v0 = cap["q"].detach().bfloat16(), cap["kT"].detach().bfloat16(), cap["v"].detach().bfloat16()
+    mb._process_qkv_impl = lambda q, k, v, B_, N_, H_, D_: (q0, k0, v0)
+    mb.lepe.register_forward_hook(lambda mod_, inp, out: capb.__setitem__("lepe_img", out))
+    mb.to_out.register_forward_pre_hook(lambda mod_, inp: capb.__setitem__("pre_out", inp[0]))
+    with torch.no_grad():
+        mb(x.bfloat16())
+    lepeb = rearrange(capb["lepe_img"].float(), "b d (h p1) (w p2) -> b (h w) (p1 p2) d", h=pl, w=pl, p1=bl, p2=bl)
+    outb = rearrange(capb["pre_out"].float() - lepeb, "b n w (h d) -> (b h) n w d", h=heads)
+    fx["out_reference_module_in_bf16"] = np32(to_bnhd(outb))
+    err = (outb - op_out_bh.detach()).abs().max() / op_out_bh.detach().abs().max()
+    print(f"   the reference module run in bf16 is {err.item():.2e} of the maximum away from its fp32 operator output")
+    save(f"blockmix2d_{tag}", meta=np.array([B, heads, dim_head, M, block_size, embed_len, 0], dtype=np.int64), **fx)
+
+
 # ---------------------------------------------------------------------------
 # 2. Wan MHLA_Video_Uni (wan/mhla_utils.py) -- stub module for its lazy import
 # ---------------------------------------------------------------------------
@@ -382,6 +444,7 @@ if __name__ == "__main__":
     gen_blockmix_2d("vit_a", f"{REF}/mhla_image_classification/models/modules/attention/mhla.py",
                     "MHLA_Normed_Torch", seed=13, B=1, heads=2, dim_head=64, block_size=16, embed_len=256,
                     transform="cos", qk_norm=True, size_kw="window_size", perturb_w=False)
+    gen_blockmix_bf16("dit_c", f"{REF}/mhla_dit/mhla/mhla.py", "MHLA4DiT", seed=13, B=1, heads=3, dim_head=64, block_size=16, embed_len=256)
     gen_wan("a", seed=21, B=1, heads=2, dim_head=128, layout=(2, 3, 4), grid=(4, 6, 8), normalize_out=True,
             is_gated=False)
     gen_wan("b", seed=22, B=1, heads=2, dim_head=32, layout=(3, 5, 10), grid=(3, 10, 20), normalize_out=False,

@@ -36,6 +36,21 @@ def test_blockmix2d_op_and_grads(tag):
         assert rel_err(grads[name], g[name]) < 5e-5, name
 
 
+
+def test_blockmix2d_bf16_fixture_fp32_evaluation_of_bf16_inputs():
+    """`dit_c`: the reference module's operator evaluated in fp32 on bf16-rounded q, k, v, dO (make_golden.gen_blockmix_bf16).  The oracle
+    reproduces it like the fp32 fixtures; the reference module run literally in bf16 is two orders of magnitude further away."""
+    g = load_golden("blockmix2d_dit_c")
+    q, k, v, W, do = (g[n] for n in ("q", "k", "v", "W", "dout"))
+    for t in (q, k, v, do):
+        assert torch.equal(t, t.bfloat16().float())   # the fixture's operator inputs ARE bf16 values
+    out = orc.blockmix_fwd(q, k, v, W, eps=1e-6)
+    assert rel_err(out, g["out"]) < 1e-5
+    gr = orc.blockmix_bwd(q, k, v, W, do, eps=1e-6)
+    for n in ("dq", "dk", "dv", "dW"):
+        assert rel_err(gr[n], g[n]) < 2e-5, n
+    assert rel_err(g["out_reference_module_in_bf16"], g["out"]) > 3e-3
+
 @pytest.mark.parametrize("tag", ["dit_a", "dit_b", "vit_a"])
 def test_blockmix2d_closed_form_matches_autograd_fp64(tag):
     g = load_golden("blockmix2d_" + tag)
