@@ -74,6 +74,7 @@ struct StateArgs {
     View x, y;        // MODE 0: k_num, v        MODE 1: q_num, dout
     View kd, qd;      // MODE 0: k_den, q_den    (used when normalize)
     View o;           // MODE 1: forward output (row dot with dout)
+    const float* g;   // MODE 1, split.hpp's row-dots-from-G variant: the mixed summaries G (24-bit floats) instead of o
     const int* idx;
     const float* W;   // MODE 1
     int ldw;

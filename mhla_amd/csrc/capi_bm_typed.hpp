@@ -292,10 +292,12 @@ int bm_bwd_typed(const BmCall& c) {
                 if (p24) {   // the same kernels on 24-bit summaries: dG, then dKV = W^T dG with dz (and, up to 128 blocks, dW) riding along, the token gradients
                     constexpr bool F32 = std::is_same<ET, float>::value;
                     const bool rope = F32 && rcos != nullptr;
+                    a.g = w.g;   // (16-bit tensors, D <= 64: the row dots come from G_i; two more LDS tiles)
+                    constexpr int SM1 = (sizeof(ET) == 2 && DT <= 4) ? sp::sp_state_rd_smem<DT>() : sp::sp_state_smem<DT>();
                     if (rope) {
                         if constexpr (F32) RC(launch(sp::k_sp_state<ET, DT, 1, true, SNT, false, true>, dim3(M, B * H), dim3(SNT), sp::sp_state_smem<DT>(), st, "k_sp_state<1,rope>", a));
                     } else
-                        RC(launch(sp::k_sp_state<ET, DT, 1, false, SNT, false, true>, dim3(M, B * H), dim3(SNT), sp::sp_state_smem<DT>(), st, "k_sp_state<1>", a));
+                        RC(launch(sp::k_sp_state<ET, DT, 1, false, SNT, false, true>, dim3(M, B * H), dim3(SNT), SM1, st, "k_sp_state<1>", a));
                     int parts = 0;
                     bool wz_done = false, dwz_done = false;   // dz = W^T dn formed / the <dn_i, z_j> term of dW included
                     if (sp_mixr_dw_ok(M, E)) {

@@ -166,8 +166,14 @@ inline bool sp_shape_ok(int D, unsigned flags) { return (D & 7) == 0 && !(flags 
 inline bool view_ok16m(const mhla_mview& v) { return v.ptr && ((uintptr_t)v.ptr % 16) == 0 && ((v.sb | v.sn | v.sh) & 7) == 0; }
 // bf16 block summaries (and single-bf16 intermediate operands): only when the caller asked for them (MHLA_FLAG_BF16_SUMMARIES)
 inline bool bm_sum16(int D, int dtype, unsigned flags) { return dtype == MHLA_BF16 && sp_shape_ok(D, flags) && (flags & MHLA_FLAG_BF16_SUMMARIES); }
-// 16-bit tensors at the default arithmetic: the forward keeps what its store of O rounded away (BmWs::olo) for the backward
-inline bool bm_olo(int D, int dtype, unsigned flags) { return dtype != MHLA_F32 && !bm_sum16(D, dtype, flags); }
+// 16-bit tensors on the 24-bit-summary pipeline with head dims up to 64 (capi_bm_typed.hpp bm_p24, restated for the workspace carve): the
+// backward forms its row dots dO . O from G_i itself -- dO' . (Q_i G_i), one more small product in k_sp_state<1> -- and reads neither
+// the stored output nor a residual of it
+inline bool bm_rowdots_from_g(int M, int D, int dtype, unsigned flags) {
+    return dtype != MHLA_F32 && !bm_sum16(D, dtype, flags) && sp_shape_ok(D, flags) && D <= 64 && M <= 128 && ((long)D * D) % 64 == 0 && !g_no_p24.load();
+}
+// other 16-bit tensors at the default arithmetic: the forward keeps what its store of O rounded away (BmWs::olo) for the backward
+inline bool bm_olo(int M, int D, int dtype, unsigned flags) { return dtype != MHLA_F32 && !bm_sum16(D, dtype, flags) && !bm_rowdots_from_g(M, D, dtype, flags); }
 // the bf16-summary fast path (fused.hpp): its summaries are single bf16 values, so it serves the opt-in arithmetic only
 inline bool fast_shape_ok(int M, int D, int dtype, bool split, unsigned flags) {
     return dtype == MHLA_BF16 && D == 64 && M <= 64 && !split && (flags & MHLA_FLAG_BF16_SUMMARIES);

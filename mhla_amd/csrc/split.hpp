@@ -138,12 +138,81 @@ template <int DT> struct Geo {
     static constexpr int KST = (DT + 1) / 2;           // reduction steps of 32 over a head dim
 };
 
+// (used by k_sp_state's row-dots-from-G variant as well as by the output and token-gradient kernels further down)
+// LDS row stride (bf16) of a staged D x D summary matrix [KST * 32 rows][KST * 32 columns + 8]: the reads cover KST * 32
+// columns, not the DW of the token tiles (D = 72: 104 instead of 136 -> a third workgroup per CU for the fp32 kernels)
+template <int DT>
+__host__ __device__ constexpr int mat_ld() { return Geo<DT>::KST * 32 + 8; }
+template <int DT, bool S16 = false>   // bf16 summaries: no lo tile
+__host__ __device__ constexpr int sp_out_smem() { return (S16 ? 1 : 2) * Geo<DT>::KST * 32 * mat_ld<DT>() * 2; }
+
+// EPI: the per-head RMSNorm (x SiLU gate) that follows the operator in the Wan host (wan/mhla_utils.py:356-362) is applied
+// to the token's D outputs before they are stored, in the dtype TO of the host's activations: O is rounded to TO (the
+// `.to(dtype)` at :356), normalised over the head dim in fp32, scaled by the norm weight and the gate, stored once.
+// D x D summary matrix (fp32, or bf16 when S16) -> LDS [KP][LD] hi (/ lo) tiles; rows and columns >= D zero.  NT threads.
+template <int DT, bool S16, int NT = NTHREADS, bool P24 = false>
+__device__ __forceinline__ void stage_mat_split(u16* __restrict__ Gh, u16* __restrict__ Gl, const float* __restrict__ base, long elem_off, int D, int tid) {
+    constexpr int LD = mat_ld<DT>(), CGS = Geo<DT>::CGS, RPP = NT / CGS, KP = Geo<DT>::KST * 32;
+    const int r0 = tid / CGS, cg = (tid % CGS) * 8;
+    constexpr int PASSES = (KP + RPP - 1) / RPP, UB = PASSES < 4 ? PASSES : (PASSES % 4 == 0 ? 4 : (PASSES % 3 == 0 ? 3 : 2));
+    static_assert(PASSES % UB == 0, "staging batches must tile the passes");
+    const float* g = base + elem_off;
+    const u16* g16 = reinterpret_cast<const u16*>(base) + elem_off;
+    for (int pb = 0; pb < PASSES; pb += UB) {
+        f32x4 x[UB][2];
+        uint4 x16[UB];
+        uint2 xl[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int r = r0 + RPP * (pb + u);
+            x[u][0] = x[u][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            x16[u] = make_uint4(0, 0, 0, 0);
+            xl[u] = make_uint2(0, 0);
+            if (r < D && cg < D) {
+                if (P24) {   // 8 elements: a piece of the hi plane and one of the lo plane (elem_off counts floats: the row's start)
+                    const int e = r * D + cg;
+                    const char* rowp = reinterpret_cast<const char*>(base + elem_off);
+                    x16[u] = gld<uint4>(rowp + 2 * e);
+                    xl[u] = gld<uint2>(rowp + 2 * D * D + e);
+                } else if (S16) {
+                    x16[u] = *reinterpret_cast<const uint4*>(g16 + (long)r * D + cg);
+                } else {
+                    const float* src = g + (long)r * D + cg;
+                    x[u][0] = *reinterpret_cast<const f32x4*>(src);
+                    x[u][1] = *reinterpret_cast<const f32x4*>(src + 4);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int r = r0 + RPP * (pb + u), off = r * LD + cg;
+            if (r < KP && cg < KP) {
+                if (P24) {
+                    *reinterpret_cast<uint4*>(Gh + off) = x16[u];
+                    *reinterpret_cast<uint4*>(Gl + off) = p24_lo8(x16[u], xl[u]);
+                } else if (S16) {
+                    *reinterpret_cast<uint4*>(Gh + off) = x16[u];
+                } else {
+                    uint4 hi, lo;
+                    split8(x[u][0], x[u][1], hi, lo);
+                    *reinterpret_cast<uint4*>(Gh + off) = hi;
+                    *reinterpret_cast<uint4*>(Gl + off) = lo;
+                }
+            }
+        }
+    }
+}
+
 template <int DT>
 __host__ __device__ constexpr int sp_state_smem() {
     // the column-sum partials [RPP][DW] of the epilogue reuse the tiles
     static_assert(Geo<DT>::RPP * Geo<DT>::DW * 4 <= 4 * 32 * Geo<DT>::LD * 2, "column-sum partials must fit in the tiles");
     return 4 * 32 * Geo<DT>::LD * 2 + Geo<DT>::DW * 4;
 }
+
+// MODE 1 on 16-bit tensors with 24-bit summaries and D <= 64 (RD): the row dots dO . O come from G_i -- two more tiles (G_i as hi / lo,
+// [64][72] bf16 each) and the partial dots of a 32-token chunk
+template <int DT> __host__ __device__ constexpr int sp_state_rd_smem() { return sp_state_smem<DT>() + 2 * Geo<DT>::KST * 32 * (Geo<DT>::KST * 32 + 8) * 2 + 2 * 32 * 4; }
 
 // MODE 0 (forward):  out = KV_j = K_j^T V_j; ksum_j; z_j                      x = k_num, y = v, kd = k_den, qd = q_den
 // MODE 1 (backward): out = dG_i = Q_i^T (dO_i / n_i); dn_i[s] = -(dO_i[s] . O_i[s]) / n_i[s]     x = q_num, y = dout, o = out
@@ -164,6 +233,10 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : (ROPE ? 2 : 3)) void k_sp_state
     static_assert(RPP * DW * 4 <= 4 * 32 * LD * 2, "column-sum partials must fit in the tiles");
     constexpr bool LO = !std::is_same<T, bf16_t>::value;   // the token operands carry a lo part
     constexpr bool LOY = LO || (MODE == 1 && !S16);        // ... and so does y = dO / n, unless the reduced-precision form was asked for
+    // RD: the row dots dO . O = dO' . (Q G_i) are formed from the mixed summary G_i (staged as hi / lo tiles beside the operand tiles): the
+    // stored output and its residual are not read, and the forward does not write the residual (capi_common.hpp bm_rowdots_from_g)
+    constexpr bool RD = MODE == 1 && P24 && sizeof(T) == 2 && DT <= 4 && !ROPE;
+    constexpr int GLD = mat_ld<DT>(), GT = Geo<DT>::KST * 32 * GLD;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u16* Kh = reinterpret_cast<u16*>(smem_raw);
     u16* Kl = Kh + TILE;
@@ -171,6 +244,9 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : (ROPE ? 2 : 3)) void k_sp_state
     u16* Vl = Vh + TILE;
     float* cs = reinterpret_cast<float*>(smem_raw);    // [RPP][DW] column-sum partials: over the tiles, after the last product
     float* vecd = reinterpret_cast<float*>(Vl + TILE); // [DW] ksum
+    u16* Gh = reinterpret_cast<u16*>(vecd + DW);       // RD: G_i [d1][d2] hi, lo ([KST * 32][GLD] each), then the chunk's partial row dots [2][32]
+    u16* Gl = Gh + GT;
+    float* rdp = reinterpret_cast<float*>(Gl + GT);
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nl = lane & 15, kg = lane >> 4;
     const int blk = blockIdx.x, bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H, S = a.S, D = a.D;
     const long p0 = (long)blk * S;
@@ -178,7 +254,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : (ROPE ? 2 : 3)) void k_sp_state
     const T* vb = (const T*)a.y.ptr + b * a.y.sb + h * a.y.sh;
     const View& third = MODE == 0 ? a.kd : a.o;   // MODE 0: the normaliser's keys; MODE 1: the forward output
     const T* kdb = (const T*)third.ptr + b * third.sb + h * third.sh;
-    const bool den = a.normalize && (MODE == 1 || a.split);   // a third tensor is read
+    const bool den = a.normalize && ((MODE == 1 && !RD) || (MODE == 0 && a.split));   // a third tensor is read
     const int r0 = tid / CGS, cg = (tid % CGS) * 8;
     const float* ninvb = a.ninv + ((long)bh * a.M + blk) * S;   // MODE 1
 
@@ -211,7 +287,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : (ROPE ? 2 : 3)) void k_sp_state
     const float* nvp = (MODE == 1 && a.normalize) ? ninvb : reinterpret_cast<const float*>(a.x.ptr);
     // MODE 1, 16-bit tensors at the default arithmetic: the residual of the forward's store of O (StateArgs::olo), fetched with
     // the rows (unconditionally: without it, the first bytes of x, dropped in `settle`)
-    constexpr bool OLO = MODE == 1 && !S16 && sizeof(T) == 2;
+    constexpr bool OLO = MODE == 1 && !S16 && sizeof(T) == 2 && !RD;
     const bool olo_on = OLO && a.normalize && a.olo != nullptr;
     const u16* olop = olo_on ? a.olo + ((long)bh * a.M * S + p0) * D + cgc : reinterpret_cast<const u16*>(a.x.ptr);
     uint4 ox[OLO ? IT : 1];
@@ -262,6 +338,8 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : (ROPE ? 2 : 3)) void k_sp_state
         }
     };
     float ksp[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float nvc[IT];   // RD: 1 / n and the first row of the chunk whose row dots are in flight
+    int crowc = 0;
     auto commit = [&]() {
         __builtin_amdgcn_sched_barrier(0);   // (the fetched values are not touched before this point: hipcc would hoist `settle` above the products and wait there)
         settle();
@@ -270,13 +348,18 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : (ROPE ? 2 : 3)) void k_sp_state
             const int off = (r0 + RPP * it) * LD + cg;
             uint4 hi, lo;
             if (MODE == 1 && a.normalize) {   // dn[s] and the 1/n scaling of dO
-                float d = 0.f;
+                if constexpr (!RD) {
+                    float d = 0.f;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) d += vx[it][0][i] * dx[it][0][i] + vx[it][1][i] * dx[it][1][i];
+                    for (int i = 0; i < 4; ++i) d += vx[it][0][i] * dx[it][0][i] + vx[it][1][i] * dx[it][1][i];
 #pragma unroll
-                for (int o = CGS / 2; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
-                const int r = crow + r0 + RPP * it;
-                if (r < S && (tid % CGS) == 0) a.dn[((long)bh * a.M + blk) * S + r] = -d * nv[it];
+                    for (int o = CGS / 2; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+                    const int r = crow + r0 + RPP * it;
+                    if (r < S && (tid % CGS) == 0) a.dn[((long)bh * a.M + blk) * S + r] = -d * nv[it];
+                } else {
+                    nvc[it] = nv[it];   // (the next fetch overwrites nv and crow before this chunk's dots are complete)
+                    crowc = crow;
+                }
                 vx[it][0] *= nv[it];
                 vx[it][1] *= nv[it];
             }
@@ -310,10 +393,52 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : (ROPE ? 2 : 3)) void k_sp_state
         for (int j = 0; j < DT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     fetch(0);
+    if constexpr (RD) {   // (its loads travel with the first chunk's; the loop's first barrier covers the tiles)
+        if (a.normalize) stage_mat_split<DT, false, NT, true>(Gh, Gl, a.g, ((long)bh * a.M + blk) * a.es, D, tid);
+    }
     for (int c0 = 0; c0 < S; c0 += 32) {
         commit();
         __syncthreads();
         if (c0 + 32 < S) fetch(c0 + 32);
+        if constexpr (RD) {
+            // dots[s] = sum_d1 q[s][d1] T[d1][s],  T = G_i dO'^T (transposed product: a lane gets T[16 ct + 4 kg + r][s = nl]); wave w takes
+            // token tile w & 1 of the chunk and the feature tiles of half w >> 1, the two halves meet in LDS after the loop's barrier
+            if (a.normalize) {
+                constexpr int KSTG = Geo<DT>::KST, CTH = (DT + 1) / 2;
+                const int tt = wave & 1, hf = wave >> 1;
+                bf16x8 bh_[KSTG], bl_[KSTG];
+#pragma unroll
+                for (int ks = 0; ks < KSTG; ++ks) {
+                    bh_[ks] = row_read8(Vh, LD, tt * 16, ks * 32, lane);
+                    bl_[ks] = row_read8(Vl, LD, tt * 16, ks * 32, lane);
+                }
+                float dot = 0.f;
+#pragma unroll
+                for (int c = 0; c < CTH; ++c) {
+                    const int ct = hf * CTH + c;
+                    if (ct < DT) {   // (uniform)
+                        f32x4 t4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int ks = 0; ks < KSTG; ++ks) {
+                            const bf16x8 gh = row_read8(Gh, GLD, ct * 16, ks * 32, lane), gl = row_read8(Gl, GLD, ct * 16, ks * 32, lane);
+                            t4 = mfma_bf16(gh, bh_[ks], t4);
+                            t4 = mfma_bf16(gl, bh_[ks], t4);
+                            t4 = mfma_bf16(gh, bl_[ks], t4);
+                        }
+                        const uint2 qr = *reinterpret_cast<const uint2*>(Kh + (tt * 16 + nl) * LD + ct * 16 + kg * 4);   // q[s][16 ct + 4 kg ..]: hi part
+                        f32x4 q4 = {__uint_as_float(qr.x << 16), __uint_as_float(qr.x & 0xffff0000u), __uint_as_float(qr.y << 16), __uint_as_float(qr.y & 0xffff0000u)};
+                        if (LO) {   // (fp16 tensors: + lo part; bf16 values are their hi part)
+                            const uint2 ql = *reinterpret_cast<const uint2*>(Kl + (tt * 16 + nl) * LD + ct * 16 + kg * 4);
+                            q4 += f32x4{__uint_as_float(ql.x << 16), __uint_as_float(ql.x & 0xffff0000u), __uint_as_float(ql.y << 16), __uint_as_float(ql.y & 0xffff0000u)};
+                        }
+                        dot += t4[0] * q4[0] + t4[1] * q4[1] + t4[2] * q4[2] + t4[3] * q4[3];
+                    }
+                }
+                dot += __shfl_xor(dot, 16, 64);
+                dot += __shfl_xor(dot, 32, 64);
+                if (kg == 0) rdp[hf * 32 + tt * 16 + nl] = dot;
+            }
+        }
         bf16x8 ah[RT], al[RT];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {   // row tiles past DT read zero / unused columns of the tile: harmless, not stored
@@ -337,6 +462,15 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : (ROPE ? 2 : 3)) void k_sp_state
             }
         }
         __syncthreads();
+        if constexpr (RD) {   // dn[s] = -(dO . O)[s] / n[s] from the two halves of the chunk's row dots
+            if (a.normalize && (tid % CGS) == 0) {
+#pragma unroll
+                for (int it = 0; it < IT; ++it) {
+                    const int lr = r0 + RPP * it, r = crowc + lr;
+                    if (r < S) a.dn[((long)bh * a.M + blk) * S + r] = -(rdp[lr] + rdp[32 + lr]) * nvc[it];
+                }
+            }
+        }
     }
 
     // KV_j -> ws  (C layout: row d1 = 16 tile + 4 kg + r, column d2 = 16 ct + nl)
@@ -1289,69 +1423,6 @@ __global__ __launch_bounds__(MIXR_DMA_T) void k_sp_mixr_dma(const MixrArgs a) {
 }
 
 // -------------------------------------------------------------------------------------------------
-// LDS row stride (bf16) of a staged D x D summary matrix [KST * 32 rows][KST * 32 columns + 8]: the reads cover KST * 32
-// columns, not the DW of the token tiles (D = 72: 104 instead of 136 -> a third workgroup per CU for the fp32 kernels)
-template <int DT>
-__host__ __device__ constexpr int mat_ld() { return Geo<DT>::KST * 32 + 8; }
-template <int DT, bool S16 = false>   // bf16 summaries: no lo tile
-__host__ __device__ constexpr int sp_out_smem() { return (S16 ? 1 : 2) * Geo<DT>::KST * 32 * mat_ld<DT>() * 2; }
-
-// EPI: the per-head RMSNorm (x SiLU gate) that follows the operator in the Wan host (wan/mhla_utils.py:356-362) is applied
-// to the token's D outputs before they are stored, in the dtype TO of the host's activations: O is rounded to TO (the
-// `.to(dtype)` at :356), normalised over the head dim in fp32, scaled by the norm weight and the gate, stored once.
-// D x D summary matrix (fp32, or bf16 when S16) -> LDS [KP][LD] hi (/ lo) tiles; rows and columns >= D zero.  NT threads.
-template <int DT, bool S16, int NT = NTHREADS, bool P24 = false>
-__device__ __forceinline__ void stage_mat_split(u16* __restrict__ Gh, u16* __restrict__ Gl, const float* __restrict__ base, long elem_off, int D, int tid) {
-    constexpr int LD = mat_ld<DT>(), CGS = Geo<DT>::CGS, RPP = NT / CGS, KP = Geo<DT>::KST * 32;
-    const int r0 = tid / CGS, cg = (tid % CGS) * 8;
-    constexpr int PASSES = (KP + RPP - 1) / RPP, UB = PASSES < 4 ? PASSES : (PASSES % 4 == 0 ? 4 : (PASSES % 3 == 0 ? 3 : 2));
-    static_assert(PASSES % UB == 0, "staging batches must tile the passes");
-    const float* g = base + elem_off;
-    const u16* g16 = reinterpret_cast<const u16*>(base) + elem_off;
-    for (int pb = 0; pb < PASSES; pb += UB) {
-        f32x4 x[UB][2];
-        uint4 x16[UB];
-        uint2 xl[UB];
-#pragma unroll
-        for (int u = 0; u < UB; ++u) {
-            const int r = r0 + RPP * (pb + u);
-            x[u][0] = x[u][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-            x16[u] = make_uint4(0, 0, 0, 0);
-            xl[u] = make_uint2(0, 0);
-            if (r < D && cg < D) {
-                if (P24) {   // 8 elements: a piece of the hi plane and one of the lo plane (elem_off counts floats: the row's start)
-                    const int e = r * D + cg;
-                    const char* rowp = reinterpret_cast<const char*>(base + elem_off);
-                    x16[u] = gld<uint4>(rowp + 2 * e);
-                    xl[u] = gld<uint2>(rowp + 2 * D * D + e);
-                } else if (S16) {
-                    x16[u] = *reinterpret_cast<const uint4*>(g16 + (long)r * D + cg);
-                } else {
-                    const float* src = g + (long)r * D + cg;
-                    x[u][0] = *reinterpret_cast<const f32x4*>(src);
-                    x[u][1] = *reinterpret_cast<const f32x4*>(src + 4);
-                }
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < UB; ++u) {
-            const int r = r0 + RPP * (pb + u), off = r * LD + cg;
-            if (r < KP && cg < KP) {
-                if (P24) {
-                    *reinterpret_cast<uint4*>(Gh + off) = x16[u];
-                    *reinterpret_cast<uint4*>(Gl + off) = p24_lo8(x16[u], xl[u]);
-                } else if (S16) {
-                    *reinterpret_cast<uint4*>(Gh + off) = x16[u];
-                } else {
-                    uint4 hi, lo;
-                    split8(x[u][0], x[u][1], hi, lo);
-                    *reinterpret_cast<uint4*>(Gh + off) = hi;
-                    *reinterpret_cast<uint4*>(Gl + off) = lo;
-                }
-            }
-        }
-    }
-}
 // 4 elements of TO as loaded (packed for 16-bit types) and their conversion to fp32
 template <typename TO> struct Raw4 { typedef uint2 type; };
 template <> struct Raw4<float> { typedef f32x4 type; };

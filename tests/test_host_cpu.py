@@ -28,8 +28,11 @@ def test_library_builds_and_exports_every_declared_symbol():
     bwd = lib.mhla_blockmix_bwd_ws_bytes(8, 16, 64, 64, 64, 0, 0, 0)
     # bf16 tensors: fp32 block summaries by default (the reference's arithmetic), the compact bf16 ones of the fast path only with
     # the opt-in flag; the flag means nothing for fp32 tensors
-    # (+ the bf16 residual of the forward's store of O, B N H D * 2 bytes, kept for the backward's row dots)
-    assert lib.mhla_blockmix_fwd_ws_bytes(8, 16, 64, 64, 64, 1, 0, 0) == fwd + 8 * 4096 * 16 * 64 * 2
+    # (C2-like shapes -- D <= 64, up to 128 blocks -- form the backward's row dots from G and keep nothing else; elsewhere the forward
+    # keeps the bf16 residual of its store of O, B N H D * 2 bytes: here D = 72)
+    assert lib.mhla_blockmix_fwd_ws_bytes(8, 16, 64, 64, 64, 1, 0, 0) == fwd
+    f72 = lib.mhla_blockmix_fwd_ws_bytes(8, 16, 64, 64, 72, 0, 0, 0)
+    assert lib.mhla_blockmix_fwd_ws_bytes(8, 16, 64, 64, 72, 1, 0, 0) == f72 + 8 * 4096 * 16 * 72 * 2
     assert lib.mhla_blockmix_fwd_ws_bytes(8, 16, 64, 64, 64, 1, 0, _lib.FLAG_BF16_SUMMARIES) < 0.6 * fwd
     assert lib.mhla_blockmix_fwd_ws_bytes(8, 16, 64, 64, 64, 0, 0, _lib.FLAG_BF16_SUMMARIES) == fwd
     assert lib.mhla_blockmix_fwd_keeps_state(8, 16, 64, 64, 64, 1, 0, 0) == 1
