@@ -89,8 +89,11 @@ const char* mhla_last_error(void);
 /* Process-wide options.  "bwd_two_launches" (0 / 1): run the two tile roles of the bf16-summary fast path's backward as two
  * launches instead of one fused launch with an in-launch hand-over; the library sets it itself, asynchronously and without any
  * synchronisation, after a fused launch reported an expired hand-over (see mhla_blockmix_bwd_status).  "debug_drop_signal" (0 / 1):
- * testing aid for that bounded wait.  Initial values: MHLA_BWD_TWO_LAUNCHES=1 / MHLA_DEBUG_DROP_SIGNAL in the environment when the
- * library is loaded.  Returns the previous value, MHLA_EINVAL for an unknown name. */
+ * testing aid for that bounded wait.  "fp32_summaries" (0 / 1): the block-mixing operator's default arithmetic keeps its block
+ * summaries as fp32 words in the workspace instead of 24-bit floats (a measurement aid: same 16-significand-bit operands either
+ * way; set it between calls, not between a forward and the backward that reuses its workspace).  Initial values:
+ * MHLA_BWD_TWO_LAUNCHES=1 / MHLA_DEBUG_DROP_SIGNAL=1 / MHLA_FP32_SUMMARIES=1 in the environment when the library is loaded.
+ * Returns the previous value, MHLA_EINVAL for an unknown name. */
 int mhla_set_option(const char* name, int value);
 
 /* Profiling aid (used by bench.py): when enabled, every kernel launch is bracketed by hipEvents on

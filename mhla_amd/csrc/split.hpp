@@ -849,7 +849,7 @@ struct MixrArgs {
     const void* in2;
     float* dwp;
     // k_sp_mixr, fp32 summaries: the normaliser's product rides along as EXTRA SLICES after the summaries' -- block r's S values zin[bh][r][:]
-    // are one more row set mixed with the same weights (slices of TE values, ztotal = bh * ceil(S / TE) of them; S % 4 == 0), stored
+    // are one more row set mixed with the same weights (slices of TE values, ztotal = bh * ceil(S / TE) of them, dealt round-robin over the workgroups; S even), stored
     // through f into zout.  DW: zin = dn, zin2 = z, and the <dn_i, z_j> term of dW falls out of the same products (k_dw is not launched).
     long ztotal;
     const float* zin2;
