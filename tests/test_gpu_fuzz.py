@@ -65,6 +65,36 @@ def test_blockmix_fuzz_many_short_and_few_long_blocks(case):
     run_case(2, 3, M, S, D, dtype, normalize=normalize, split=split, w=w, idx=idx, seed=2000 + i)
 
 
+def _round5_cases(n=28, seed=5):
+    """Shapes of the round-5 kernels: the resident mixing at two, four and eight waves with the fused dW and the normaliser slices (even
+    and odd block lengths, a few and many (b, h) pairs), 24-bit summaries on 16-bit tensors (head dims 8 .. 96) and on fp32 tensors at
+    head dim 128 with up to 192 blocks (k_sp_dw on the two planes above 128), the row dots from G (D <= 64), split q / k pairs, gather maps."""
+    rnd = random.Random(seed)
+    cases = []
+    for i in range(n):
+        if i % 4 == 3:
+            dtype, D = torch.float32, rnd.choice([120, 128, 128])
+            M, S = rnd.choice([33, 40, 100, 129, 150, 192]), rnd.choice([5, 6, 10, 14])
+        else:
+            dtype = rnd.choice([torch.bfloat16, torch.bfloat16, torch.float16])
+            D = rnd.choice([8, 16, 24, 40, 56, 64, 64, 72, 80, 96])
+            M = rnd.choice([2, 5, 16, 17, 31, 32, 33, 50, 64, 65, 100, 128])
+            S = rnd.choice([2, 6, 7, 20, 30, 33, 64, 66, 130])
+        if M * S * D > 500000:
+            S = max(2, 500000 // (M * D))
+        normalize = rnd.random() < 0.85
+        split = normalize and rnd.random() < 0.3
+        cases.append((200 + i, dtype, M, S, D, normalize, split, rnd.random() < 0.3, "rand", rnd.choice([1, 2, 5])))
+    return cases
+
+
+@pytest.mark.parametrize("case", _round5_cases(), ids=lambda c: f"{c[0]}-{str(c[1]).split('.')[-1]}-M{c[2]}-S{c[3]}-D{c[4]}-n{int(c[5])}s{int(c[6])}i{int(c[7])}-B{c[9]}")
+def test_blockmix_fuzz_resident_mixing_and_24_bit_summaries(case):
+    i, dtype, M, S, D, normalize, split, use_idx, w, B = case
+    idx = torch.randperm(M * S, generator=torch.Generator().manual_seed(i)).int() if use_idx else None
+    run_case(B, 3, M, S, D, dtype, normalize=normalize, split=split, w=w, idx=idx, seed=3000 + i)
+
+
 def _causal_cases(n=16, seed=7):
     rnd = random.Random(seed)
     out = []
