@@ -310,7 +310,7 @@ int bm_bwd_typed(const BmCall& c) {
                         int nsplit = dw_splits(tiles * tiles * B * H, E);
                         if (nsplit > DW_MAX_SPLIT - 1) nsplit = DW_MAX_SPLIT - 1;
                         DwArgs d{w.dg, w.kv, E, nullptr, nullptr, 0, w.dwp, M, tiles, nsplit, es};
-                        RC(launch(sp::k_sp_dw<false, 4, true>, dim3(tiles * tiles, B * H, nsplit), dim3(NTHREADS), sp::SP_DW_SMEM, st, "k_sp_dw", d));
+                        RC(launch(sp::k_sp_dwt<true>, dim3(tiles * tiles, B * H, nsplit), dim3(NTHREADS), sp::SP_DWT_SMEM, st, "k_sp_dwt", d));
                         parts = B * H * nsplit;
                     }
                     if (normalize && !wz_done)

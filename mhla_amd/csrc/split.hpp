@@ -1840,6 +1840,134 @@ __global__ __launch_bounds__(NTHREADS) void k_sp_dw(const DwArgs a) {
 }
 
 // -------------------------------------------------------------------------------------------------
+// k_sp_dwt<P24>: the same partials as k_sp_dw for fp32-grade summaries (fp32 words or 24-bit floats) and more than 128 blocks, with the
+// operand rows STAGED THROUGH LDS: k_sp_dw's lanes fetch their MFMA operands straight from memory -- 16 rows x 64 bytes (32 for the lo
+// plane) per load instruction -- and ran at 2.1-2.6 TB/s of its bytes (C4: 127 us, the 256 x 16 variant: 490 us).  Here a workgroup walks
+// its E-slice in chunks of 64 elements: 64 rows of dG and 64 rows of KV as 256-byte (128 + 64) row pieces, 16 or 8 lanes per row, the
+// next chunk in flight in registers while the current one is multiplied from hi / lo tiles ([64][72] bf16 x 4: 37 KB); wave w owns the
+// 32 x 32 quadrant (w >> 1, w & 1) of the 64 x 64 output tile, so there is no reduction across waves.  Grid and output as k_sp_dw.
+// Used on the 24-bit summaries of the Wan shape (E = 16 384, 9 tile pairs: 124 -> 92 us); on fp32 summaries with E = 4 096 and 16 tile
+// pairs (the 256 x 16 variant) its 64 chunks of two barriers and 24 products per wave each ran 773 us against k_sp_dw's 490 -- that
+// shape keeps k_sp_dw, whose waves multiply whole 64 x 64 tiles from registers.
+// -------------------------------------------------------------------------------------------------
+constexpr int SP_DWT_LD = 72, SP_DWT_SMEM = 4 * 64 * SP_DWT_LD * 2;
+template <bool P24>
+__global__ __launch_bounds__(NTHREADS, 2) void k_sp_dwt(const DwArgs a) {
+    constexpr int LD = SP_DWT_LD, CE = 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u16* Xh = reinterpret_cast<u16*>(smem_raw);
+    u16* Xl = Xh + 64 * LD;
+    u16* Yh = Xl + 64 * LD;
+    u16* Yl = Yh + 64 * LD;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nl = lane & 15, kg = lane >> 4;
+    const int np = gridDim.x, nbh = gridDim.y;
+    const int L = fast::xcd_swizzle(blockIdx.x + np * (blockIdx.y + nbh * blockIdx.z), np * nbh * gridDim.z);
+    const int unit = L / np, pair = L - unit * np, split = unit / nbh, bh = unit - split * nbh, M = a.M;
+    const int it = pair / a.tiles, jt = pair - it * a.tiles;
+    const int i0 = it * 64, j0 = jt * 64;
+    const long E = a.E;
+    const long per = ((E + a.nsplit - 1) / a.nsplit + CE - 1) / CE * CE;   // slice: whole chunks (E is a multiple of 64)
+    const long ebeg = (long)split * per, eend = min(E, ebeg + per);
+    // the thread's two units per operand: unit v = tid + 256 p -> row v / 8, elements 8 (v % 8) .. + 7 of the chunk
+    const char* xr[2];
+    const char* yr[2];
+    int urow[2], ucol[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int v = tid + p * NTHREADS;
+        urow[p] = v >> 3;
+        ucol[p] = (v & 7) * 8;
+        xr[p] = reinterpret_cast<const char*>(a.x + ((long)bh * M + min(i0 + urow[p], M - 1)) * a.es);
+        yr[p] = reinterpret_cast<const char*>(a.y + ((long)bh * M + min(j0 + urow[p], M - 1)) * a.es);
+    }
+    uint4 xa[2], xb[2], ya[2], yb[2];   // fp32: the unit's 8 floats; P24: xa = hi piece, xb.xy = lo piece
+    auto issue = [&](long e0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const long e = e0 + ucol[p];
+            if constexpr (P24) {
+                xa[p] = gld_stream16(xr[p] + 2 * e);
+                ya[p] = gld_stream16(yr[p] + 2 * e);
+                const uint2 lx = gld<uint2>(xr[p] + 2 * E + e), ly = gld<uint2>(yr[p] + 2 * E + e);
+                xb[p] = make_uint4(lx.x, lx.y, 0u, 0u);
+                yb[p] = make_uint4(ly.x, ly.y, 0u, 0u);
+            } else {
+                xa[p] = gld_stream16(xr[p] + 4 * e);
+                xb[p] = gld_stream16(xr[p] + 4 * e + 16);
+                ya[p] = gld_stream16(yr[p] + 4 * e);
+                yb[p] = gld_stream16(yr[p] + 4 * e + 16);
+            }
+        }
+    };
+    auto commit = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const bool okx = i0 + urow[p] < M, oky = j0 + urow[p] < M;   // rows past the last block: zeros
+            const int off = urow[p] * LD + ucol[p];
+            uint4 hx, lx, hy, ly;
+            if constexpr (P24) {
+                hx = xa[p];
+                lx = p24_lo8(xa[p], make_uint2(xb[p].x, xb[p].y));
+                hy = ya[p];
+                ly = p24_lo8(ya[p], make_uint2(yb[p].x, yb[p].y));
+            } else {
+                split8(__builtin_bit_cast(f32x4, xa[p]), __builtin_bit_cast(f32x4, xb[p]), hx, lx);
+                split8(__builtin_bit_cast(f32x4, ya[p]), __builtin_bit_cast(f32x4, yb[p]), hy, ly);
+            }
+            // (component-wise: a select of whole uint4 structs goes through the stack)
+            auto sel = [](bool ok, const uint4& v) { return make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u); };
+            *reinterpret_cast<uint4*>(Xh + off) = sel(okx, hx);
+            *reinterpret_cast<uint4*>(Xl + off) = sel(okx, lx);
+            *reinterpret_cast<uint4*>(Yh + off) = sel(oky, hy);
+            *reinterpret_cast<uint4*>(Yl + off) = sel(oky, ly);
+        }
+    };
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int wi = wave >> 1, wj = wave & 1;
+    if (ebeg < eend) issue(ebeg);
+    for (long e0 = ebeg; e0 < eend; e0 += CE) {
+        commit();
+        __syncthreads();
+        if (e0 + CE < eend) issue(e0 + CE);
+#pragma unroll
+        for (int ks = 0; ks < CE / 32; ++ks) {
+            bf16x8 ah[2], al[2], bh_[2], bl_[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                ah[t] = row_read8(Xh, LD, (2 * wi + t) * 16, ks * 32, lane);
+                al[t] = row_read8(Xl, LD, (2 * wi + t) * 16, ks * 32, lane);
+                bh_[t] = row_read8(Yh, LD, (2 * wj + t) * 16, ks * 32, lane);
+                bl_[t] = row_read8(Yl, LD, (2 * wj + t) * 16, ks * 32, lane);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = mfma_bf16(ah[i], bh_[j], acc[i][j]);
+                    acc[i][j] = mfma_bf16(ah[i], bl_[j], acc[i][j]);
+                    acc[i][j] = mfma_bf16(al[i], bh_[j], acc[i][j]);
+                }
+        }
+        __syncthreads();
+    }
+    // C layout: rows i = 32 wi + 16 ti + 4 kg + r, column j = 32 wj + 16 tj + nl
+    float* out = a.out + ((long)bh * a.nsplit + split) * M * M;
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = i0 + 32 * wi + 16 * ti + 4 * kg + r, j = j0 + 32 * wj + 16 * tj + nl;
+                if (i < M && j < M) out[(long)i * M + j] = acc[ti][tj][r];
+            }
+}
+
+// -------------------------------------------------------------------------------------------------
 // Token gradients.  Both kernels keep one D x D matrix of the block in LDS as bf16 hi / lo and compute transposed
 // products, so that the token tensors are MFMA B operands read straight from HBM (8 consecutive features per lane) and a
 // lane ends up with 4 consecutive features of one token.
