@@ -869,7 +869,7 @@ __host__ __device__ constexpr int sp_mixr_smem() {
 // P24: the summaries (in, in2, out) are stored as 24-bit floats in two planes per row (p24_pack8).  A thread's unit is then 8 elements
 // of a row -- one 16-byte piece of the hi plane and one 8-byte piece of the lo plane -- instead of a 16-byte piece of 4 floats.
 template <int NW, int TRANS, bool S16, bool DW = false, bool P24 = false>
-__global__ __launch_bounds__(64 * NW, (NW + 3) / 4) void k_sp_mixr(const MixrArgs a) {
+__global__ __launch_bounds__(64 * NW, (NW == 8 && !DW && P24) ? 4 : (NW + 3) / 4) void k_sp_mixr(const MixrArgs a) {   // (eight waves on 24-bit summaries without dW: 128 VGPRs, two workgroups per CU instead of one at 136)
     static_assert(!DW || (TRANS == 1 && !S16 && NW <= 8), "dW rides in the backward's fp32 mixing kernel, M <= 128 (twelve waves: 77 spilled registers)");
     static_assert(!P24 || (!S16 && NW <= 12), "p24: fp32-grade summaries, slices of 64 elements");
     constexpr int TE = mixr_te<NW, S16>(), ROWS = 16 * NW, LD = TE + 8, LDO = TE + 4, NK = (NW + 1) / 2, NT = TE / 16;
