@@ -112,6 +112,9 @@ class MHLA4DiT(nn.Module):
             q, k = q.to(qkv.dtype), k.to(qkv.dtype)
             out = mhla_blockmix(q.reshape(B, M * S, H, D), k.reshape(B, M * S, H, D), qkv[:, :, 2], W, eps=self.eps,
                                 summaries=self.summaries)
+        elif D > 128:
+            # head dims the kernels do not cover: the operator composes itself from slices (ops._blockmix_wide_head), LePE separately
+            out = mhla_blockmix(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], W, eps=self.eps, relu_eps=True, summaries=self.summaries)
         else:
             # operator (relu + eps folded into its loads) and LePE as one autograd node on the packed projection output
             out = mhla_dit_core(qkv, W, self.lepe.weight, self.lepe.bias, self.pieces_len, self.block_len, eps=self.eps,

@@ -292,6 +292,8 @@ def mhla_blockmix(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, W: torch.Te
     if q.dim() != 4:
         raise ValueError(f"q: expected [B, N, H, D], got {tuple(q.shape)}")
     _check_block_index(block_index, q.shape[1], q)
+    if q.shape[-1] > 128:
+        return _blockmix_wide_head(q, k, v, W, eps, q_den, k_den, normalize, block_index, relu_eps, force_generic, no_smalln, summaries)
     flags = _bm_flags(relu_eps, force_generic, no_smalln, summaries)
     if not (torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (q, k, v, W, q_den, k_den))):
         flags |= _lib.FLAG_NO_BWD_STATE   # inference: the forward skips what only a backward would read
@@ -307,6 +309,65 @@ def mhla_blockmix(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, W: torch.Te
     if _native_nodes():
         return torch.ops.mhla_amd.blockmix(q, k, v, W, q_den, k_den, block_index, float(eps), bool(normalize), flags, KEEP_STATE_LIMIT_BYTES)
     return _BlockMix.apply(q, k, v, W, q_den, k_den, block_index, eps, normalize, flags)
+
+
+def _wide_head_chunk(D: int) -> int:
+    """Largest divisor of D in [32, 128] that is a multiple of 8 (the kernels' head dims), or 0."""
+    for c in range(128, 31, -8):
+        if D % c == 0:
+            return c
+    return 0
+
+
+def _blockmix_wide_head(q, k, v, W, eps, q_den, k_den, normalize, block_index, relu_eps, force_generic, no_smalln, summaries):
+    """Head dims above 128 (the reference module takes any dim_head, mhla_dit/mhla/mhla.py:155-158; the kernels stop at 128, where a
+    block summary is 64 KB): the D x D summary is a (D / c)^2 grid of c x c blocks, and the operator is linear in them --
+        O[:, b] = sum_a Q[:, a] G[a, b],   G[a, b] = W (K[:, a]^T V[:, b])
+    -- so the numerator is (D / c)^2 un-normalised calls of the operator on c-wide slices, and the normaliser, which couples all D
+    features of a token (n_i[s] = sum_j W_ij q_j[s] . ksum_j + eps), a few [B, M, S, H] tensor ops.  Everything stays differentiable
+    (the slices' autograd nodes and eager PyTorch); no BASELINE shape comes here."""
+    B, N, H, D = q.shape
+    out_dtype = v.dtype
+    c = _wide_head_chunk(D)
+    if not c:
+        raise NotImplementedError(f"mhla_blockmix: head dim {D} > 128 has no divisor in [32, 128] that is a multiple of 8")
+    Wm = W.reshape(W.shape[0], W.shape[1]) if W.dim() == 4 else W
+    M = Wm.shape[0]
+    if N % M:
+        raise ValueError(f"N={N} tokens not divisible into M={M} blocks")
+    S = N // M
+    # (16-bit tensors: everything below runs on ONE fp32 copy of each tensor -- the partial products O_ab and the gradient pieces of the
+    # slices would otherwise each carry their own 16-bit rounding into their sums -- and results / gradients are rounded once)
+    q, k, v = q.float(), k.float(), v.float()
+    if q_den is not None:
+        q_den, k_den = q_den.float(), k_den.float()
+    sl = lambda t, a: t[..., a * c:(a + 1) * c].contiguous()
+    kw = dict(eps=eps, normalize=False, block_index=block_index, relu_eps=relu_eps, force_generic=force_generic, no_smalln=no_smalln,
+              summaries=summaries)
+    nc = D // c
+    cols = []
+    for b in range(nc):
+        acc = None
+        for a in range(nc):
+            o = mhla_blockmix(sl(q, a), sl(k, a), sl(v, b), W, **kw)
+            acc = o if acc is None else acc + o
+        cols.append(acc)
+    out = torch.cat(cols, dim=-1)
+    if normalize:
+        qd, kd = (q, k) if q_den is None else (q_den, k_den)
+        if relu_eps:
+            qd, kd = torch.relu(qd) + eps, torch.relu(kd) + eps
+        if block_index is not None:   # block-major position p lives at row block_index[p]
+            rows = block_index.long()
+            qd, kd = qd[:, rows], kd[:, rows]
+        ksum = kd.reshape(B, M, S, H, D).sum(2)                                  # [B, M, H, D]
+        z = (qd.reshape(B, M, S, H, D) * ksum[:, :, None]).sum(-1)               # [B, M, S, H]
+        n = torch.einsum("ij,bjsh->bish", Wm.float(), z) + eps                   # the quirk normaliser: same offset s in every block j
+        n = n.reshape(B, N, H)
+        if block_index is not None:   # back to the tensors' row order
+            n = torch.zeros_like(n).index_copy(1, block_index.long(), n)
+        out = out / n[..., None]
+    return out.to(out_dtype)
 
 
 class _BlockMixRope(torch.autograd.Function):

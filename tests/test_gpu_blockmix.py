@@ -431,6 +431,16 @@ def test_fused_qkv_views_and_relu_prologue():
     check("dW_bf16", Wd.grad, Wr.grad, DW_TOL[torch.bfloat16])
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,S,D,normalize,split,gather", [(16, 16, 256, True, False, False), (9, 20, 192, True, True, True), (33, 12, 160, False, False, False),
+                                                           (4, 49, 144, True, False, True)])
+def test_head_dims_above_128_compose_from_slices(M, S, D, normalize, split, gather, dtype):
+    """dim_head > 128 (the reference module takes any, mhla_dit/mhla/mhla.py:155-158): (D / c)^2 un-normalised calls on c-wide slices of
+    q / k and v plus the normaliser in tensor ops (ops._blockmix_wide_head) -- outputs and every gradient against the oracle."""
+    idx = torch.randperm(M * S, generator=torch.Generator().manual_seed(M)).int() if gather else None
+    run_case(1, 2, M, S, D, dtype, normalize=normalize, split=split, w="rand", idx=idx, seed=D)
+
+
 def test_empty_batch():
     """B = 0 (and T = 0 for the causal op): empty result, zero gradients, no launch."""
     import mhla_amd
@@ -452,9 +462,9 @@ def test_errors_fail_loudly():
         mhla_amd.mhla_blockmix(q.cpu(), q.cpu(), q.cpu(), W.cpu())            # no CPU fallback
     with pytest.raises(ValueError):
         mhla_amd.mhla_blockmix(q, q, q, torch.eye(5, device=DEV))             # N not divisible by M
-    big = torch.randn(1, 64, 2, 192, device=DEV)
-    with pytest.raises(RuntimeError, match="not supported"):
-        mhla_amd.mhla_blockmix(big, big, big, W)                              # D > 128
+    big = torch.randn(1, 64, 2, 136, device=DEV)
+    with pytest.raises(NotImplementedError):
+        mhla_amd.mhla_blockmix(big, big, big, W)                              # D > 128 with no slice width in [32, 128] (136 = 17 x 8)
     with pytest.raises(TypeError):
         mhla_amd.mhla_blockmix(q.double(), q.double(), q.double(), W)
 

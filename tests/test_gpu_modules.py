@@ -51,6 +51,36 @@ def test_dit_vit_module_matches_reference(tag, cls, kw):
     _check_module_grads(m, x, y, g, 2e-4)
 
 
+def test_dit_module_with_head_dim_above_128_matches_oracle_restatement():
+    """dim_head = 192 (the reference module takes any): the drop-in routes the operator through the sliced composition
+    (ops._blockmix_wide_head) and LePE separately; output, dx and every parameter gradient against the oracle's module restatement
+    run under autograd on the CPU."""
+    from mhla_amd import modules
+    torch.manual_seed(3)
+    heads, dh, bs, el = 2, 192, 16, 64
+    m = modules.MHLA4DiT(heads * dh, heads=heads, dim_head=dh, block_size=bs, embed_len=el, qkv_bias=True, transform="linear")
+    with torch.no_grad():
+        m.lepe.weight.normal_(0, 0.2)
+        m.piece_attn.conv.weight.copy_(torch.rand_like(m.piece_attn.conv.weight))
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    x = torch.randn(2, el // bs, bs, heads * dh)
+    dy = torch.randn(2, el // bs, bs, heads * dh)
+    # oracle restatement on the CPU, gradients by autograd
+    sdr = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    xr = x.clone().requires_grad_(True)
+    yr = orc.dit_module_forward(sdr, xr, heads, bs, el)
+    (yr * dy).sum().backward()
+    m = m.to(DEV).eval()
+    xg = x.to(DEV).requires_grad_(True)
+    y = m(xg)
+    (y * dy.to(DEV)).sum().backward()
+    check("y", y, yr.detach(), 2e-4)
+    check("dx", xg.grad, xr.grad, 5e-4)
+    for name, prm in m.named_parameters():
+        if sdr[name].grad is not None:
+            check(f"grad {name}", prm.grad, sdr[name].grad, 5e-4, atol=1e-7)
+
+
 def test_dit_module_initial_weights_match_reference_init():
     from mhla_amd import modules
     g = load_golden("weight_init")
