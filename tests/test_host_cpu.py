@@ -307,3 +307,39 @@ def test_short_convolution_matches_oracle_restatement():
     yv, cv = m(xp, cu_seqlens=cu, output_final_state=True)
     assert (yv - orc.short_conv(xp, m.weight, m.bias, cu_seqlens=cu)).abs().max() < 1e-6 and cv.shape == (2, 12, 4)
     assert sorted(m.state_dict()) == ["bias", "weight"] and m.weight.shape == (12, 1, 4)
+
+
+def test_bench_line_is_small_strict_json():
+    """The driver parses the LAST stdout line of bench.py; round 5's 20.6 KB line did not parse.  The line is now built by
+    bench.compact_line() from the full record: contract keys only, strict JSON (no NaN), under 4 KB -- whatever the record holds."""
+    import copy
+    import json
+    import bench
+    full = json.loads(open(os.path.join(ROOT, "profiles", "r5_bench.json")).read().strip().splitlines()[-1])   # a real 20.6 KB record
+    assert len(json.dumps(full)) > 16000
+    line = bench.compact_line(copy.deepcopy(full))
+    assert len(line) < 4096 and "\n" not in line
+    got = json.loads(line, parse_constant=lambda c: (_ for _ in ()).throw(ValueError(c)))   # NaN / Infinity would raise
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in got, k
+    assert got["value"] == pytest.approx(full["value"], rel=1e-5) and got["ms_per_step"] == pytest.approx(full["ms_per_step"], rel=1e-5)
+    assert got["config"]["workload"] == full["config"]["workload"] and "model" not in got["config"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in got["roofline"], k
+    assert got["roofline"]["frac"] == pytest.approx(full["roofline"]["frac"], rel=1e-5)
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in got["cpu_baseline"], k
+    assert set(got["targets"]) == {"ge_10x_cpu_on_dit_xl2_256", "within_1e-3_of_reference", "ge_40pct_mfma", "ge_6x_at_8_gpus"}
+    # a hostile record: NaNs, infinities, bloated strings and blocks -- still one small strict line
+    bad = copy.deepcopy(full)
+    bad["roofline"]["traffic"] = float("nan")
+    bad["roofline"]["frac_from_gpu_events"] = float("inf")
+    bad["config"]["launch"] = "x" * 5000
+    bad["config"]["arithmetic"] = "y" * 5000
+    bad["cpu_baseline"]["sample"] = "z" * 5000
+    bad["dit_xl2_train_step"] = {"error": "e" * 9000}
+    line = bench.compact_line(bad)
+    assert len(line) < 4096
+    got = json.loads(line, parse_constant=lambda c: (_ for _ in ()).throw(ValueError(c)))
+    assert got["roofline"]["traffic"] is None and got["value"] == pytest.approx(full["value"], rel=1e-5)
