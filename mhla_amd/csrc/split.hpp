@@ -125,6 +125,55 @@ __device__ __forceinline__ void p24_unpack8(const uint4& hi, const uint2& lo, f3
     b = f32x4{f[4], f[5], f[6], f[7]};
 }
 
+// -------------------------------------------------------------------------------------------------
+// h16 (summary format 2, round 6): block summaries as an fp16 payload x ONE power-of-two multiplier per block row -- 11 significand
+// bits, the precision the reference's own products run at (TF32: mhla_dit/train.py:12-13 turns allow_tf32 on for the matmul / 1x1-conv
+// of mhla_dit/mhla/mhla.py:262-263) -- in 2 bytes per element where p24 takes 3.  A summary row of E elements is [E x fp16][fp32
+// multiplier m at byte 2 E]: value = payload * m.  The kernels that own a whole row (k_sp_state) take m from the row's measured
+// maximum (payload maximum in [2^14, 2^15)); the mixing kernels, whose output rows are spread over workgroups, take it from the bound
+// |out_o[e]| <= sum_r |W(o, r)| 2^15 m_r, which every workgroup computes alike from the input rows' multipliers -- a loose bound costs
+// nothing: fp16 keeps 11 bits over 29 binades.  Consumers decode to the same bf16 hi + lo operand pair as every other fp32-grade format
+// (hi = top 16 bits of payload * m, lo = the remaining 3 significand bits: exact).  16-bit tensors with blocks of >= 16 tokens
+// (capi_common.hpp bm_sumfmt); tools/sim_h16.py is the CPU model of its error (<= 4e-4 of a result's maximum on every BASELINE shape).
+// -------------------------------------------------------------------------------------------------
+// decode multiplier of a row whose largest magnitude is mx: 2^(floor(log2 mx) - 14), exponent field clamped to [1, 240]
+__device__ __forceinline__ float h16_mult_from_max(float mx) {
+    const unsigned e = (__float_as_uint(mx) >> 23) & 0xffu;
+    return __uint_as_float((e < 15u ? 1u : (e > 254u ? 240u : e - 14u)) << 23);
+}
+// ... of a row bounded by 2^15 beta: the power of two >= beta, field clamped to [1, 253]
+__device__ __forceinline__ float h16_mult_from_bound(float beta) {
+    unsigned f = (__float_as_uint(beta) + 0x7fffffu) >> 23;
+    f = f < 1u ? 1u : (f > 253u ? 253u : f);
+    return __uint_as_float(f << 23);
+}
+__device__ __forceinline__ float h16_inv(float m) { return __uint_as_float(0x7f000000u - __float_as_uint(m)); }   // 1 / m, exact (field 254 - f)
+typedef _Float16 h16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned h16_pack2(float a, float b) {
+    const h16x2_t h = {(_Float16)a, (_Float16)b};   // (round to nearest even)
+    return __builtin_bit_cast(unsigned, h);
+}
+// 8 values -> their 16-byte payload piece (inv = 1 / m)
+__device__ __forceinline__ uint4 h16_pack8(const f32x4& a, const f32x4& b, float inv) {
+    return make_uint4(h16_pack2(a[0] * inv, a[1] * inv), h16_pack2(a[2] * inv, a[3] * inv), h16_pack2(b[0] * inv, b[1] * inv), h16_pack2(b[2] * inv, b[3] * inv));
+}
+// the bf16 hi / lo operands of 8 stored values: x = payload * m, hi = its top 16 bits, lo = x - hi (<= 3 significant bits: exact)
+__device__ __forceinline__ void h16_split8(const uint4& pay, float m, uint4& hi, uint4& lo) {
+    const unsigned w[4] = {pay.x, pay.y, pay.z, pay.w};
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const h16x2_t p = __builtin_bit_cast(h16x2_t, w[j]);
+        const float x0 = (float)p[0] * m, x1 = (float)p[1] * m;
+        const unsigned u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
+        h[j] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+        const float d0 = x0 - __uint_as_float(u0 & 0xffff0000u), d1 = x1 - __uint_as_float(u1 & 0xffff0000u);
+        l[j] = __builtin_amdgcn_perm(__float_as_uint(d1), __float_as_uint(d0), 0x07060302u);
+    }
+    hi = make_uint4(h[0], h[1], h[2], h[3]);
+    lo = make_uint4(l[0], l[1], l[2], l[3]);
+}
+
 // Block summaries (KV, G, dG, dKV) are fp32 in the workspace, except for bf16 tensors: there they are stored as bf16 (as on
 // the bf16 fast path), which halves the summary traffic -- the larger share of the bytes when S is small -- and needs no lo part.
 template <typename T> struct Sum16 { static constexpr bool value = std::is_same<T, bf16_t>::value; };
@@ -150,7 +199,7 @@ __host__ __device__ constexpr int sp_out_smem() { return (S16 ? 1 : 2) * Geo<DT>
 // to the token's D outputs before they are stored, in the dtype TO of the host's activations: O is rounded to TO (the
 // `.to(dtype)` at :356), normalised over the head dim in fp32, scaled by the norm weight and the gate, stored once.
 // D x D summary matrix (fp32, or bf16 when S16) -> LDS [KP][LD] hi (/ lo) tiles; rows and columns >= D zero.  NT threads.
-template <int DT, bool S16, int NT = NTHREADS, bool P24 = false>
+template <int DT, bool S16, int NT = NTHREADS, int P24 = 0>   // P24: 0 fp32 words (or bf16 when S16), 1 24-bit floats, 2 h16
 __device__ __forceinline__ void stage_mat_split(u16* __restrict__ Gh, u16* __restrict__ Gl, const float* __restrict__ base, long elem_off, int D, int tid) {
     constexpr int LD = mat_ld<DT>(), CGS = Geo<DT>::CGS, RPP = NT / CGS, KP = Geo<DT>::KST * 32;
     const int r0 = tid / CGS, cg = (tid % CGS) * 8;
@@ -158,6 +207,8 @@ __device__ __forceinline__ void stage_mat_split(u16* __restrict__ Gh, u16* __res
     static_assert(PASSES % UB == 0, "staging batches must tile the passes");
     const float* g = base + elem_off;
     const u16* g16 = reinterpret_cast<const u16*>(base) + elem_off;
+    float hm = 0.f;   // h16: the row's multiplier
+    if constexpr (P24 == 2) hm = gld<float>(reinterpret_cast<const char*>(base + elem_off) + 2 * D * D);
     for (int pb = 0; pb < PASSES; pb += UB) {
         f32x4 x[UB][2];
         uint4 x16[UB];
@@ -173,7 +224,7 @@ __device__ __forceinline__ void stage_mat_split(u16* __restrict__ Gh, u16* __res
                     const int e = r * D + cg;
                     const char* rowp = reinterpret_cast<const char*>(base + elem_off);
                     x16[u] = gld<uint4>(rowp + 2 * e);
-                    xl[u] = gld<uint2>(rowp + 2 * D * D + e);
+                    if constexpr (P24 == 1) xl[u] = gld<uint2>(rowp + 2 * D * D + e);
                 } else if (S16) {
                     x16[u] = *reinterpret_cast<const uint4*>(g16 + (long)r * D + cg);
                 } else {
@@ -187,7 +238,12 @@ __device__ __forceinline__ void stage_mat_split(u16* __restrict__ Gh, u16* __res
         for (int u = 0; u < UB; ++u) {
             const int r = r0 + RPP * (pb + u), off = r * LD + cg;
             if (r < KP && cg < KP) {
-                if (P24) {
+                if (P24 == 2) {
+                    uint4 hi, lo;
+                    h16_split8(x16[u], hm, hi, lo);
+                    *reinterpret_cast<uint4*>(Gh + off) = hi;
+                    *reinterpret_cast<uint4*>(Gl + off) = lo;
+                } else if (P24) {
                     *reinterpret_cast<uint4*>(Gh + off) = x16[u];
                     *reinterpret_cast<uint4*>(Gl + off) = p24_lo8(x16[u], xl[u]);
                 } else if (S16) {
@@ -224,7 +280,7 @@ template <int DT> __host__ __device__ constexpr int sp_state_rd_smem() { return 
 // eight-wave slots of half the duration 3.5 rounds that cost 4 (of half the length).
 // S16: the summary is stored as bf16 (the opt-in MHLA_FLAG_BF16_SUMMARIES arithmetic on bf16 tensors); otherwise fp32, and the
 // one operand that is an INTERMEDIATE (dP = dO / n, MODE 1) is split into hi + lo parts whatever the tensor type
-template <typename T, int DT, int MODE, bool ROPE = false, int NT = NTHREADS, bool S16 = Sum16<T>::value, bool P24 = false>
+template <typename T, int DT, int MODE, bool ROPE = false, int NT = NTHREADS, bool S16 = Sum16<T>::value, int P24 = 0>
 __global__ __launch_bounds__(NT, NT == 512 ? 4 : (ROPE ? 2 : 3)) void k_sp_state(const StateArgs a) {
     static_assert(!P24 || !S16, "p24 is a format of the fp32-grade summaries");
     constexpr int DW = Geo<DT>::DW, LD = Geo<DT>::LD, CGS = Geo<DT>::CGS, RPP = NT / CGS, IT = 32 / RPP, NWV = NT / 64,
@@ -394,7 +450,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : (ROPE ? 2 : 3)) void k_sp_state
 
     fetch(0);
     if constexpr (RD) {   // (its loads travel with the first chunk's; the loop's first barrier covers the tiles)
-        if (a.normalize) stage_mat_split<DT, false, NT, true>(Gh, Gl, a.g, ((long)bh * a.M + blk) * a.es, D, tid);
+        if (a.normalize) stage_mat_split<DT, false, NT, P24>(Gh, Gl, a.g, ((long)bh * a.M + blk) * a.es, D, tid);
     }
     for (int c0 = 0; c0 < S; c0 += 32) {
         commit();
@@ -481,6 +537,27 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : (ROPE ? 2 : 3)) void k_sp_state
     constexpr int CW = (DW > 64 && NWV == 8) ? 64 : DW, LDO = CW + 4, PPRO = CW / 4;
     static_assert(NWV * 16 * LDO * 4 <= 4 * 32 * LD * 2, "the staging tiles of all waves must fit in the operand tiles");
     const bool staged = !S16 && (P24 || ((D & 3) == 0 && (a.es & 3) == 0));   // (uniform; p24: D % 8 == 0 by the path's shape test)
+    float hinv = 0.f;   // h16: 1 / the row's multiplier
+    if constexpr (P24 == 2) {
+        // the row's multiplier from the summary's largest magnitude: lane -> wave (shuffles) -> workgroup (NWV floats in `vecd`, free until
+        // the column sums); padded rows / columns are zero products and do not matter
+        float mx = 0.f;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < DT; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, fabsf(acc[rt][ct][r]));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        if (lane == 0) vecd[wave] = mx;
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) mx = fmaxf(mx, vecd[w]);
+        const float hm = h16_mult_from_max(mx);
+        hinv = h16_inv(hm);
+        if (tid == 0) gst<float>(reinterpret_cast<char*>(ob) + 2 * D * D, hm);
+    }
     if (staged) {
         float* Os = reinterpret_cast<float*>(smem_raw) + wave * 16 * LDO;
 #pragma unroll
@@ -502,12 +579,16 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : (ROPE ? 2 : 3)) void k_sp_state
                             const int grow = tile * 16 + row, gcol = c0 + c8 * 8;
                             if (grow < D && gcol < D) {
                                 const float* src = Os + row * LDO + c8 * 8;
+                                const int e = grow * D + gcol;
+                                if constexpr (P24 == 2) {
+                                    gst<uint4>(reinterpret_cast<char*>(ob) + 2 * e, h16_pack8(*reinterpret_cast<const f32x4*>(src), *reinterpret_cast<const f32x4*>(src + 4), hinv));
+                                } else {
                                 uint4 hi;
                                 uint2 lo;
                                 p24_pack8(*reinterpret_cast<const f32x4*>(src), *reinterpret_cast<const f32x4*>(src + 4), hi, lo);
-                                const int e = grow * D + gcol;
                                 gst<uint4>(reinterpret_cast<char*>(ob) + 2 * e, hi);
                                 gst<uint2>(reinterpret_cast<char*>(ob) + 2 * D * D + e, lo);
+                                }
                             }
                         }
                     } else {
@@ -859,7 +940,8 @@ template <int NW, bool S16> __host__ __device__ constexpr int mixr_te() { return
 template <int NW, bool S16, bool DW = false>
 __host__ __device__ constexpr int sp_mixr_smem() {
     constexpr int TE = mixr_te<NW, S16>(), ROWS = 16 * NW;
-    return (S16 ? 1 : (DW ? 4 : 2)) * ROWS * (TE + 8) * 2 + (S16 ? ROWS * (TE + 8) * 2 : ROWS * (TE + 4) * 4);
+    // (fp32-grade summaries: + the rows' h16 multipliers, input and output, [2][ROWS] floats behind the staging tile)
+    return (S16 ? 1 : (DW ? 4 : 2)) * ROWS * (TE + 8) * 2 + (S16 ? ROWS * (TE + 8) * 2 : ROWS * (TE + 4) * 4 + 2 * ROWS * 4);
 }
 
 // DW (TRANS 1, fp32 summaries, M <= 128): the kernel also stages the KV rows of every slice (hi + lo, two more tiles) and accumulates
@@ -868,7 +950,8 @@ __host__ __device__ constexpr int sp_mixr_smem() {
 // fixed order by k_dw_reduce.  Replaces k_sp_dw, which read dG and KV a second time (C2 at the default arithmetic: 81 us).
 // P24: the summaries (in, in2, out) are stored as 24-bit floats in two planes per row (p24_pack8).  A thread's unit is then 8 elements
 // of a row -- one 16-byte piece of the hi plane and one 8-byte piece of the lo plane -- instead of a 16-byte piece of 4 floats.
-template <int NW, int TRANS, bool S16, bool DW = false, bool P24 = false>
+// P24 = 2 (h16): fp16 payload, one multiplier per row (decoded at the commit, the output rows' multipliers from the bound of the inputs')
+template <int NW, int TRANS, bool S16, bool DW = false, int P24 = 0>
 __global__ __launch_bounds__(64 * NW, (NW == 8 && !DW && P24) ? 4 : (NW + 3) / 4) void k_sp_mixr(const MixrArgs a) {   // (eight waves on 24-bit summaries without dW: 128 VGPRs, two workgroups per CU instead of one at 136)
     static_assert(!DW || (TRANS == 1 && !S16 && NW <= 8), "dW rides in the backward's fp32 mixing kernel, M <= 128 (twelve waves: 77 spilled registers)");
     static_assert(!P24 || (!S16 && NW <= 12), "p24: fp32-grade summaries, slices of 64 elements");
@@ -883,6 +966,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && !DW && P24) ? 4 : (NW + 3) / 4
     u16* Kh = Tl + ROWS * LD;                                        // (DW only: the KV rows of the slice)
     u16* Kl = Kh + ROWS * LD;
     unsigned char* Os = smem_raw + (S16 ? 1 : (DW ? 4 : 2)) * ROWS * LD * 2;     // bf16 [ROWS][LD] or fp32 [ROWS][LDO]
+    constexpr bool H16 = P24 == 2;
+    float* ms = reinterpret_cast<float*>(Os + ROWS * LDO * 4);   // h16: the input rows' multipliers [ROWS] (rows past M: 0), then the output rows'
+    float* mo = ms + ROWS;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nl = lane & 15, kg = lane >> 4;
     const int M = a.M;
     const long nsl = a.E / TE;
@@ -898,6 +984,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && !DW && P24) ? 4 : (NW + 3) / 4
     constexpr int SLB = P24 ? 128 : TE * ESZ;             // bytes of a slice in a summary row (P24: of its hi plane)
     // P24: the lo piece of a unit relative to its hi piece (goff + 16 c of slice es): lo plane at 2 E, slice at 64 es, piece at 8 c
     auto lo_rel = [&](int es, int c) { return (long)2 * a.E - 64 * es - 8 * c; };
+    // h16: the row's multiplier (byte 2 E of the row) relative to a unit's payload piece (goff + 16 c of slice es, 128 bytes per slice)
+    auto hm_rel = [&](int es, int c) { return (long)2 * a.E - 128 * es - 16 * c; };
     // byte offset of slice (bh, es); a workgroup's slices are consecutive, so the pair is advanced rather than divided out per
     // slice (the 64-bit division was 150 instructions with branches between the barrier and the next slice's loads)
     auto slice_off = [&](int bh, int es) { return (long)bh * M * a.es * ESZ + (long)es * SLB; };
@@ -913,7 +1001,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && !DW && P24) ? 4 : (NW + 3) / 4
     // staging registers.  P24: pre = hi piece, prl = lo piece; a normaliser slice (plain floats) takes the unit's 8 floats in pre + prz
     struct Stage {
         uint4 pre[NP], pre2[DW ? NP : 1], prz[P24 ? NP : 1], prz2[(P24 && DW) ? NP : 1];
-        u32x2_t prl[P24 ? NP : 1], prl2[(P24 && DW) ? NP : 1];   // (native vectors: an array of uint2 in here stays in scratch)
+        u32x2_t prl[P24 == 1 ? NP : 1], prl2[(P24 == 1 && DW) ? NP : 1];   // (native vectors: an array of uint2 in here stays in scratch)
+        float prs[H16 ? NP : 1], prs2[(H16 && DW) ? NP : 1];              // h16: the unit's row multiplier (in / in2)
     };
     // (A second slice in flight per workgroup -- two Stage objects, the loop unrolled by two -- gained nothing: hipcc's wait in front of
     // the commit is vmcnt(0), i.e. for both.  Nor did starting the workgroups of a CU a fraction of an iteration apart, or fetching and
@@ -969,14 +1058,16 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && !DW && P24) ? 4 : (NW + 3) / 4
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             g.pre[p] = gld_stream16(base + goff[p]);
-            if constexpr (P24) g.prl[p] = *(const MHLA_GLOBAL_AS u32x2_t*)(base + goff[p] + lo_rel(es, (tid + p * NTH) % UPR));
+            if constexpr (P24 == 1) g.prl[p] = *(const MHLA_GLOBAL_AS u32x2_t*)(base + goff[p] + lo_rel(es, (tid + p * NTH) % UPR));
+            if constexpr (H16) g.prs[p] = gld<float>(base + goff[p] + hm_rel(es, (tid + p * NTH) % UPR));
         }
         if constexpr (DW) {
             const char* base2 = reinterpret_cast<const char*>(a.in2) + boff;
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
                 g.pre2[p] = gld_stream16(base2 + goff[p]);
-                if constexpr (P24) g.prl2[p] = *(const MHLA_GLOBAL_AS u32x2_t*)(base2 + goff[p] + lo_rel(es, (tid + p * NTH) % UPR));
+                if constexpr (P24 == 1) g.prl2[p] = *(const MHLA_GLOBAL_AS u32x2_t*)(base2 + goff[p] + lo_rel(es, (tid + p * NTH) % UPR));
+                if constexpr (H16) g.prs2[p] = gld<float>(base2 + goff[p] + hm_rel(es, (tid + p * NTH) % UPR));
             }
         }
     };
@@ -1033,7 +1124,15 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && !DW && P24) ? 4 : (NW + 3) / 4
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             const int v = tid + p * NTH, row = v / UPR, c = v % UPR;
-            if constexpr (P24) {
+            if constexpr (H16) {
+                if (row < M) {
+                    const float* src = reinterpret_cast<const float*>(Os) + row * LDO + c * 8;
+                    const float om = mo[row];
+                    gst<uint4>(ob + goff[p], h16_pack8(*reinterpret_cast<const f32x4*>(src), *reinterpret_cast<const f32x4*>(src + 4), h16_inv(om)));
+                    if (zes == 0 && c == 0) gst<float>(ob + goff[p] + hm_rel(0, 0), om);   // (the workgroup that holds a (b, h)'s first slice writes its rows' multipliers)
+                }
+                continue;
+            } else if constexpr (P24) {
                 if (row < M) {
                     const float* src = reinterpret_cast<const float*>(Os) + row * LDO + c * 8;
                     uint4 hi;
@@ -1071,6 +1170,19 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && !DW && P24) ? 4 : (NW + 3) / 4
                     if constexpr (DW) {
                         commit_hl(Kh, Kl, zmask(g.pre2[p], ok, p, zes, 0), row, 2 * c);
                         commit_hl(Kh, Kl, zmask(g.prz2[p], ok, p, zes, 1), row, 2 * c + 1);
+                    }
+                } else if constexpr (H16) {   // payload x the row's multiplier -> hi + lo operands
+                    const float m = ok ? g.prs[p] : 0.f;
+                    uint4 hi, lo;
+                    h16_split8(x, m, hi, lo);
+                    *reinterpret_cast<uint4*>(Th + row * LD + c * 8) = hi;
+                    *reinterpret_cast<uint4*>(Tl + row * LD + c * 8) = lo;
+                    if (c == 0) ms[row] = m;
+                    if constexpr (DW) {
+                        const uint4 y = make_uint4(ok ? g.pre2[p].x : 0u, ok ? g.pre2[p].y : 0u, ok ? g.pre2[p].z : 0u, ok ? g.pre2[p].w : 0u);
+                        h16_split8(y, ok ? g.prs2[p] : 0.f, hi, lo);
+                        *reinterpret_cast<uint4*>(Kh + row * LD + c * 8) = hi;
+                        *reinterpret_cast<uint4*>(Kl + row * LD + c * 8) = lo;
                     }
                 } else {   // the hi piece is the operand; the lo operand is rebuilt from the third bytes
                     const uint2 l = make_uint2(ok ? g.prl[p][0] : 0u, ok ? g.prl[p][1] : 0u);
@@ -1150,6 +1262,25 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && !DW && P24) ? 4 : (NW + 3) / 4
                     }
                 }
             }
+        }
+        if constexpr (H16 && !ZS) {
+            // the output rows' multipliers: |out_o[e]| <= sum_r |w(o, r)| 2^15 m_r =: 2^15 beta_o, m_o = the power of two >= beta_o.  Lane:
+            // output block o = 16 wave + nl, input blocks r = 32 ks + 8 kg + t (its B-operand registers); the four kg lanes meet by shuffles
+            float beta = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < NK; ++ks) {
+                if (ks < kend) {
+                    const f32x4 m0 = *reinterpret_cast<const f32x4*>(ms + ks * 32 + kg * 8), m1 = *reinterpret_cast<const f32x4*>(ms + ks * 32 + kg * 8 + 4);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        beta += fabsf((float)wh[ks][0][t] + (float)wl[ks][0][t]) * m0[t];
+                        beta += fabsf((float)wh[ks][0][4 + t] + (float)wl[ks][0][4 + t]) * m1[t];
+                    }
+                }
+            }
+            beta += __shfl_xor(beta, 16, 64);
+            beta += __shfl_xor(beta, 32, 64);
+            if (kg == 0) mo[wave * 16 + nl] = h16_mult_from_bound(beta);
         }
         // lane: elements 16 t + 4 kg .. + 3 of output block 16 wave + nl -> staging tile [block][element]
 #pragma unroll
@@ -1475,7 +1606,7 @@ template <typename V>
 __device__ __forceinline__ bool view16(const V& w) { return (reinterpret_cast<uintptr_t>(w.ptr) & 15) == 0 && ((w.sb | w.sn | w.sh) & 7) == 0; }
 
 constexpr int SP_OUT_T = 512;   // 8 waves share the staged G_i: twice the loads in flight per LDS byte
-template <typename T, int DT, typename TO = T, bool EPI = false, bool S16 = Sum16<T>::value, bool P24 = false>
+template <typename T, int DT, typename TO = T, bool EPI = false, bool S16 = Sum16<T>::value, int P24 = 0>
 #ifndef SP_OUT_EPI_WAVES
 #define SP_OUT_EPI_WAVES 2   // the fused-epilogue variant takes 142 VGPRs: one workgroup per CU without spills (157 us at C4) beats two with 28 spilled registers (163 us)
 #endif
@@ -1986,7 +2117,7 @@ __device__ __forceinline__ bf16x8 row_read8(const u16* tile, int ld, int c0, int
 // transposed rotation before dz ksum^T is added, so the one stored tensor is the gradient of the un-rotated q
 // WQ: q_den enters only dksum (normaliser on, no relu prologue) and is fetched in 16-byte pieces in the operand layout; otherwise in
 // the output layout, where the relu gradient mask needs it (a template flag: both register sets at once cost the occupancy)
-template <typename T, int DT, bool ROPE = false, bool S16 = Sum16<T>::value, bool WQ = false, bool P24 = false>
+template <typename T, int DT, bool ROPE = false, bool S16 = Sum16<T>::value, bool WQ = false, int P24 = 0>
 __global__ __launch_bounds__(NTHREADS, (DT <= 4 && WQ) ? 4 : 2) void k_sp_bwd_dq(const TokArgs a) {
     constexpr int LD = mat_ld<DT>(), DW = Geo<DT>::DW, KST = Geo<DT>::KST, TILE = KST * 32 * LD;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -2147,7 +2278,7 @@ __global__ __launch_bounds__(NTHREADS, (DT <= 4 && WQ) ? 4 : 2) void k_sp_bwd_dq
 
 // ROPE: k is the un-rotated tensor: it is rotated on its way into the dV product (KV was formed from the rotated keys), and
 // dK_rot is turned back before dksum is added
-template <typename T, int DT, bool ROPE = false, bool S16 = Sum16<T>::value, bool P24 = false>
+template <typename T, int DT, bool ROPE = false, bool S16 = Sum16<T>::value, int P24 = 0>
 __global__ __launch_bounds__(NTHREADS, 2) void k_sp_bwd_dkv(const TokArgs a) {   // (a bound of 4 -- 128 VGPRs, four workgroups per CU at D <= 64 -- measured: C2 +-0, blocks of 256 tokens 85 -> 94 us)
     constexpr int LD = mat_ld<DT>(), DW = Geo<DT>::DW, KST = Geo<DT>::KST, TILE = KST * 32 * LD;
     constexpr bool LO = !std::is_same<T, bf16_t>::value;
