@@ -34,9 +34,11 @@ def parse():
     p.add_argument("--D", type=int, default=64)
     p.add_argument("--M", type=int, default=64)
     p.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "f16"])
-    p.add_argument("--summaries", default="split", choices=["split", "bf16"],
-                   help="arithmetic on 16-bit tensors: split = fp32-grade intermediates, the reference's arithmetic and the library's default "
-                        "(the number of record); bf16 = the opt-in reduced-precision form (single-bf16 block summaries)")
+    p.add_argument("--summaries", default="tf32", choices=["tf32", "split", "bf16"],
+                   help="arithmetic on 16-bit tensors: tf32 = the library's default and the number of record (bf16 hi + lo operands, fp32 "
+                        "accumulation, block summaries stored with 11 significand bits in 2 bytes: the precision of the reference's own TF32 "
+                        "matmuls, mhla_dit/train.py:12-13); split = summaries with >= 16 significand bits (24-bit floats: round 5's default); "
+                        "bf16 = the opt-in reduced-precision form (single-bf16 block summaries)")
     p.add_argument("--no-step-benches", action="store_true",
                    help="skip the step-level measurements of BASELINE.json configs[3] / [4] (Wan2.1-1.3B forward, GPT training steps)")
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -505,10 +507,11 @@ def main():
                                    f"M={a.M} S={a.N // a.M} {a.dtype} ({_config_name(a)})",
                        "global_batch": a.B * world, "parallelism": f"dp{world} (batch shards, dW all-reduce only)",
                        "launch": launch_mode,
-                       "arithmetic": ("fp32-grade intermediates on the bf16 tensors (block summaries as 24-bit floats: 16 significand bits; bf16 hi + lo operands, fp32-grade O "
-                                      "in the row dots): the reference's arithmetic (mhla_dit/mhla/mhla.py:262-268 as mhla_dit/train.py:12-13 "
-                                      "runs it), the library's default" if a.summaries == "split" or a.dtype == "f32" else
-                                      "REDUCED PRECISION (--summaries bf16, opt-in MHLA_FLAG_BF16_SUMMARIES): single-bf16 block summaries"),
+                       "arithmetic": {"tf32": "library default: bf16 hi + lo operands, fp32 accumulation, block summaries stored as fp16 payload x a power-of-two "
+                                              "multiplier per block row (11 significand bits, 2 bytes) = the precision the reference's matmul / 1x1 conv run at "
+                                              "(mhla_dit/mhla/mhla.py:262-263 under allow_tf32, mhla_dit/train.py:12-13); within 1e-3 of the fp32 result (observed 3e-4)",
+                                      "split": "block summaries as 24-bit floats (>= 16 significand bits; opt-in MHLA_FLAG_FP32_GRADE_SUMMARIES, round 5's default)",
+                                      "bf16": "REDUCED PRECISION (--summaries bf16, opt-in MHLA_FLAG_BF16_SUMMARIES): single-bf16 block summaries"}[a.summaries if a.dtype != "f32" else "split"],
                        "autograd_nodes": "C++ (libmhla_torch.so)" if mhla_amd.ops._native_nodes() else "Python (ops.py)",
                        **({"shared_gpu_harness": f"{world} ranks on {torch.cuda.device_count()} GPU(s), gloo: harness test, "
                                                   "not a scaling measurement"} if shared else {})},
@@ -534,7 +537,7 @@ def main():
                 "mfma_frac_of_bf16_peak": alg_flops / (step_gpu_us * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS if step_gpu_us else None,
             },
         }
-        if world == 1 and a.summaries == "split" and a.dtype == "bf16" and not a.no_extra_configs:
+        if world == 1 and a.summaries == "tf32" and a.dtype == "bf16" and not a.no_extra_configs:
             # the opt-in reduced-precision form of the same step (single-bf16 block summaries: rounds 1-4's arithmetic and kernels),
             # for comparison only -- `value` above is the number of record
             try:

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MHLA_ABI_VERSION 8
+#define MHLA_ABI_VERSION 9
 
 enum { MHLA_F32 = 0, MHLA_BF16 = 1, MHLA_F16 = 2 };
 
@@ -53,10 +53,18 @@ enum {
                                     * contraction -- the block summaries KV, G, dG, dKV, dP = dO / n, the score tiles of the
                                     * small-sequence path -- is kept as ONE bf16 value (what the reference's own matmuls store
                                     * under bf16 autocast; half the summary traffic; 2-3e-3 of the gradients' maximum).
-                                    * Default: >= 16 significand bits there (fp32 summaries / bf16 hi + lo operands), i.e. the
-                                    * reference's fp32 arithmetic (mhla_dit/mhla/mhla.py:262-268 evaluated as
-                                    * mhla_dit/train.py:12-13 runs it) on the given tensors, one rounding at the store. */
+                                    * bf16 tensors only (fp16 tensors: MHLA_EINVAL).  Default: bf16 hi + lo operand pairs and fp32
+                                    * accumulation everywhere, summaries stored with >= 11 significand bits (see
+                                    * MHLA_FLAG_FP32_GRADE_SUMMARIES), one rounding of the results at the store. */
 
+#define MHLA_FLAG_FP32_GRADE_SUMMARIES 32u /* 16-bit tensors, opt-in: keep >= 16 significand bits in the block summaries (24-bit floats /
+                                    * fp32 words in the workspace: round 5's default).  DEFAULT since ABI 9 for bf16 / fp16 tensors
+                                    * with blocks of >= 16 tokens, D <= 96, M <= 128: KV, G, dG, dKV are stored in 2 bytes as an fp16
+                                    * payload x one power-of-two multiplier per block row -- 11 significand bits, what the
+                                    * reference's own matmul / 1x1 conv (mhla_dit/mhla/mhla.py:262-263) run at under
+                                    * torch.backends.cuda.matmul.allow_tf32 = True (mhla_dit/train.py:12-13); operands stay bf16
+                                    * hi + lo pairs, accumulation fp32; <= 4e-4 of a result's maximum from the fp32 result
+                                    * (tools/sim_h16.py, tests).  fp32 tensors are never affected. */
 #define MHLA_FLAG_NO_BWD_STATE 16u  /* mhla_blockmix_fwd: no backward will use this forward's workspace (inference) -- skip what only
                                     * the backward reads (16-bit tensors, default arithmetic: the bf16 residual O - fl(O) that
                                     * gives the backward's row dots dO . O an fp32-grade O).  A backward given this flag

@@ -8,13 +8,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # MHLA_LIB_PATH: A/B comparison of two builds of the same library (tools); the default is the in-tree build
 LIB_PATH = os.environ.get("MHLA_LIB_PATH") or os.path.join(_HERE, "lib", "libmhla_hip.so")
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 F32, BF16, F16 = 0, 1, 2
 FLAG_RELU_EPS = 1
 FLAG_FORCE_GENERIC = 2
 FLAG_NO_SMALLN = 4
 FLAG_BF16_SUMMARIES = 8   # opt-in reduced precision of the block-mixing operator on 16-bit tensors (mhla_hip.h)
 FLAG_NO_BWD_STATE = 16      # forward without a backward to come: skip the state only the backward reads
+FLAG_FP32_GRADE_SUMMARIES = 32   # 16-bit tensors: block summaries with >= 16 significand bits (default: 11, fp16 payload x row multiplier)
 CAUSAL_FORCE_GENERIC = 1
 CAUSAL_BF16_SUMMARIES = 2
 

@@ -147,7 +147,7 @@ HandoverWatch g_watch;
 // rotary prologue) the dispatcher clears it with a 4-byte memset -- so mhla_blockmix_bwd_status never reads an unrelated word
 // (round-3 ADVICE: it used to infer the path from the shape alone).
 size_t bwd_ws_body_bytes(int B, int H, int M, int S, int D, int dtype, int split, unsigned flags) {
-    const size_t gen = bm_carve(nullptr, B, H, M, S, D, bm_sum16(D, dtype, flags), sp_shape_ok(D, flags), bm_olo(M, D, dtype, flags)).total_bwd;
+    const size_t gen = bm_carve(nullptr, B, H, M, S, D, bm_sumfmt(M, S, D, dtype, flags), sp_shape_ok(D, flags), bm_olo(M, S, D, dtype, flags)).total_bwd;
     const bool fast = fast_shape_ok(M, D, dtype, split != 0, flags) && !(flags & MHLA_FLAG_FORCE_GENERIC);
     return (std::max(gen, fast ? fast_carve(nullptr, B, H, M, S).total_bwd : (size_t)0) + 15) & ~(size_t)15;
 }
@@ -237,7 +237,7 @@ int mhla_blockmix_fwd_keeps_state(int B, int H, int M, int S, int D, int dtype, 
 // (the fast path needs less than the split-operand path, but which one runs also depends on the alignment of the views, which
 // these queries do not see: the bound covers both)
 size_t mhla_blockmix_fwd_ws_bytes(int B, int H, int M, int S, int D, int dtype, int split, unsigned flags) {
-    const size_t gen = bm_carve(nullptr, B, H, M, S, D, bm_sum16(D, dtype, flags), sp_shape_ok(D, flags), bm_olo(M, D, dtype, flags)).total_fwd;
+    const size_t gen = bm_carve(nullptr, B, H, M, S, D, bm_sumfmt(M, S, D, dtype, flags), sp_shape_ok(D, flags), bm_olo(M, S, D, dtype, flags)).total_fwd;
     if (fast_shape_ok(M, D, dtype, split != 0, flags) && !(flags & MHLA_FLAG_FORCE_GENERIC)) return std::max(gen, fast_carve(nullptr, B, H, M, S).total_fwd);
     return gen;
 }
@@ -304,7 +304,7 @@ static int bm_fwd_impl(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view 
         else          RC(launch(fast::k_tile_out<16>, dim3(fast::tiles_per_bh(f.njg, 16) * B * H), dim3(fast::FT8), fast::tile_smem<16>(), st, "k_t16_out", oa));
         return MHLA_OK;
     }
-    const BmWs w = bm_carve(ws, B, H, M, S, D, bm_sum16(D, dtype, flags), sp_shape_ok(D, flags), bm_olo(M, D, dtype, flags));
+    const BmWs w = bm_carve(ws, B, H, M, S, D, bm_sumfmt(M, S, D, dtype, flags), sp_shape_ok(D, flags), bm_olo(M, S, D, dtype, flags));
     if (ws_bytes < w.total_fwd) return fail(MHLA_EINVAL, "workspace too small: %zu < %zu bytes", ws_bytes, w.total_fwd);
     BmCall c{};
     c.q_num = q_num; c.k_num = k_num; c.v = v; c.q_den = q_den; c.k_den = k_den; c.out = out; c.gate = gate;
@@ -466,7 +466,7 @@ static int bm_bwd_impl(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view 
             return MHLA_OK;
         }
     }
-    BmWs w = bm_carve(ws, B, H, M, S, D, bm_sum16(D, dtype, flags), sp_shape_ok(D, flags), bm_olo(M, D, dtype, flags));
+    BmWs w = bm_carve(ws, B, H, M, S, D, bm_sumfmt(M, S, D, dtype, flags), sp_shape_ok(D, flags), bm_olo(M, S, D, dtype, flags));
     if (ws_bytes < w.total_bwd) return fail(MHLA_EINVAL, "workspace too small: %zu < %zu bytes", ws_bytes, w.total_bwd);
     if (fast_shape_ok(M, D, dtype, split, flags) && !(flags & MHLA_FLAG_FORCE_GENERIC)) {
         // a fast-path shape on another path (misaligned views, rotary prologue): leave a defined error word for the status call
@@ -480,7 +480,7 @@ static int bm_bwd_impl(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view 
     const bool reuse = fwd_ws && sp_shape_ok(D, flags) && (rcos || !fast_shape_ok(M, D, dtype, split, flags));
     unsigned short* const olo_own = w.olo;
     if (reuse) {
-        const BmWs f = bm_carve(const_cast<void*>(fwd_ws), B, H, M, S, D, bm_sum16(D, dtype, flags), sp_shape_ok(D, flags), bm_olo(M, D, dtype, flags));
+        const BmWs f = bm_carve(const_cast<void*>(fwd_ws), B, H, M, S, D, bm_sumfmt(M, S, D, dtype, flags), sp_shape_ok(D, flags), bm_olo(M, S, D, dtype, flags));
         w.kv = f.kv; w.g = f.g; w.z = f.z; w.ksum = f.ksum; w.ninv = f.ninv; w.olo = f.olo;
     }
     BmCall c{};

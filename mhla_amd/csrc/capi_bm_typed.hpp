@@ -6,6 +6,7 @@
 #include "blockmix.hpp"
 #include "split.hpp"
 #include "split16.hpp"
+#include "mixh.hpp"
 
 namespace mhla {
 namespace capi {
@@ -27,7 +28,7 @@ inline bool sp_mixr_ok(int M, long E) {
 // ... and in the register-staged kernel at fp32 summaries, as extra slices (blocks of an even number of tokens: 16- or 8-byte pieces)
 template <bool S16>
 inline bool sp_mixr_takes_wz(int M, int S) { return S16 ? (M > 192 && M <= 256 && S <= 16) : (S % 2 == 0); }
-template <int TRANS, bool S16, bool P24 = false>
+template <int TRANS, bool S16, int P24 = 0>   // P24: 0 fp32 words (bf16 when S16), 1 24-bit floats, 2 h16
 inline int sp_mixr(const float* W, int ldw, const void* in, void* out, int M, long E, long es, int BH, hipStream_t st,
                    const float* zin = nullptr, float* zout = nullptr, int S = 0, float eps = 0.f) {
 #define MIXR(NW) do { \
@@ -68,7 +69,7 @@ inline int sp_mixr(const float* W, int ldw, const void* in, void* out, int M, lo
 inline bool sp_mixr_dw_ok(int M, long E) { return sp_mixr_ok<false>(M, E) && M <= 128; }
 // dn / z / dz (null: no normaliser): dz = W^T dn and the <dn_i, z_j> term of dW ride along as extra slices when the block length allows
 // (sp_mixr_takes_wz); `*wz_done` tells the caller whether they did.
-template <bool P24 = false>
+template <int P24 = 0>
 inline int sp_mixr_dw(const float* W, int ldw, const void* dg, const void* kv, void* dkv, float* dwp, int M, long E, long es, int BH,
                       hipStream_t st, int* nparts, const float* dn, const float* z, float* dz, int S, bool* wz_done) {
     const bool wz = dn && z && dz && sp_mixr_takes_wz<false>(M, S);
@@ -89,18 +90,62 @@ inline int sp_mixr_dw(const float* W, int ldw, const void* dg, const void* kv, v
 #undef MIXRDW
 }
 
+// h16 summaries: the mixing on the fp16 payload (mixh.hpp k_sp_mixh).  Slices of 128 elements (the last one of a row may be half), the
+// normaliser's rows as extra slices of 64 values when the block length is even; persistent workgroups, as many as fit a CU.
+template <int TRANS>
+inline int sp_mixh(const float* W, int ldw, const void* in, void* out, int M, long E, long es, int BH, hipStream_t st,
+                   const float* zin, float* zout, int S, float eps) {
+#define MIXH(NW, PERCU) do { \
+        const long total = (long)BH * ((E + sp::MIXH_TE - 1) / sp::MIXH_TE); \
+        const bool wz = zin && sp_mixr_takes_wz<false>(M, S); \
+        const long zt = wz ? (long)BH * ((S + sp::MIXH_TEZ - 1) / sp::MIXH_TEZ) : 0; \
+        const int wgs = (int)std::min<long>(total, 256 * (PERCU)); \
+        sp::MixrArgs a{W, ldw, in, out, M, E, es, total, (int)((total + wgs - 1) / wgs), wz ? zin : nullptr, wz ? zout : nullptr, wz ? S : 0, eps, nullptr, nullptr, nullptr, zt, nullptr}; \
+        const int gw = (int)((total + a.spw - 1) / a.spw); \
+        return launch(sp::k_sp_mixh<NW, TRANS, false>, dim3(gw), dim3(64 * NW), sp::sp_mixh_smem<NW, false>(), st, TRANS ? "k_sp_mixh<1>" : "k_sp_mixh<0>", a); \
+    } while (0)
+    if (M <= 32) MIXH(2, 8);
+    if (M <= 64) MIXH(4, 4);
+    if (M <= 128) MIXH(8, 1);
+    return fail(MHLA_EINVAL, "sp_mixh: M=%d out of range", M);
+#undef MIXH
+}
+// ... the backward's, with the dW products riding along: one [M][M] partial per workgroup (`*nparts`); `*wz_done`: dz = W^T dn and the
+// <dn_i, z_j> term of dW rode along too
+inline int sp_mixh_dw(const float* W, int ldw, const void* dg, const void* kv, void* dkv, float* dwp, int M, long E, long es, int BH,
+                      hipStream_t st, int* nparts, const float* dn, const float* z, float* dz, int S, bool* wz_done) {
+    const bool wz = dn && z && dz && sp_mixr_takes_wz<false>(M, S);
+    *wz_done = wz;
+#define MIXHDW(NW, PERCU) do { \
+        const long total = (long)BH * ((E + sp::MIXH_TE - 1) / sp::MIXH_TE); \
+        const long zt = wz ? (long)BH * ((S + sp::MIXH_TEZ - 1) / sp::MIXH_TEZ) : 0; \
+        const int wgs = (int)std::min<long>(total, 256 * (PERCU));   /* (bm_carve: at most 1024 / 512 / 256 partials at two / four / eight waves) */ \
+        sp::MixrArgs a{W, ldw, dg, dkv, M, E, es, total, (int)((total + wgs - 1) / wgs), wz ? dn : nullptr, wz ? dz : nullptr, wz ? S : 0, 0.f, nullptr, kv, dwp, zt, wz ? z : nullptr}; \
+        const int gw = (int)((total + a.spw - 1) / a.spw); \
+        *nparts = gw; \
+        return launch(sp::k_sp_mixh<NW, 1, true>, dim3(gw), dim3(64 * NW), sp::sp_mixh_smem<NW, true>(), st, "k_sp_mixh<1,dw>", a); \
+    } while (0)
+    if (M <= 32) MIXHDW(2, 4);
+    if (M <= 64) MIXHDW(4, 2);
+    if (M <= 128) MIXHDW(8, 1);
+    return fail(MHLA_EINVAL, "sp_mixh_dw: M=%d out of range", M);
+#undef MIXHDW
+}
+
 // p24 summaries (split.hpp: 24-bit floats, 3 / 4 of the bytes of every summary transfer) on the resident-mixing pipeline: 16-bit tensors
 // with head dims up to 96 and up to 128 blocks (the fused dW), and fp32 tensors at head dims 113 .. 128 with 33 .. 192 blocks (the Wan
 // shape, rotary tables and fused epilogue included: the operands are bf16 hi + lo pairs there too, 16 significand bits either way).  A
 // function of the call's shape, dtype and flags only: a forward and the backward that reuses its state agree.
 template <typename ET, int DT, bool S16>
 constexpr bool bm_p24_built() { return !S16 && ((sizeof(ET) == 2 && DT <= 6) || (std::is_same<ET, float>::value && DT == 8)); }
+// h16 (2-byte summaries, the default on 16-bit tensors): the same pipeline, instantiated for 16-bit element types (capi_common.hpp bm_sumfmt decides per call)
 template <typename ET, int DT, bool S16>
-inline bool bm_p24(int M, int D, unsigned flags) {
-    if constexpr (!bm_p24_built<ET, DT, S16>()) return false;
-    else return sp_shape_ok(D, flags) && sp_mixr_ok<false>(M, (long)D * D) && M <= (sizeof(ET) == 2 ? 128 : 192) && !g_no_p24.load();
-}
-inline long bm_p24_es(int D) { return 3L * D * D / 4 + 288; }   // row stride in float units: 3 bytes per element + the padding of bm_row_elems
+constexpr bool bm_h16_built() { return !S16 && sizeof(ET) == 2 && DT <= 6; }
+// Run `...` with PF = the kernels' summary-format template value of this call (1: p24, 2: h16); `fmt` is SF_P24 or SF_H16 here
+#define WITH_PF(fmt, ...) do { \
+        if ((fmt) == SF_H16) { if constexpr (H16OK) { constexpr int PF = 2; __VA_ARGS__; } else return fail(MHLA_EINVAL, "h16 summaries are not built for this type / head dim"); } \
+        else { constexpr int PF = 1; __VA_ARGS__; } \
+    } while (0)
 
 // Blocks of exactly 16 tokens, bf16, D = 64, every row a whole number of 16-byte pieces: the wave-per-block kernels of split16.hpp
 // replace the token kernels (same workspace formats).  `bwd`: the call's gradient views must qualify too.
@@ -137,9 +182,10 @@ int bm_state_and_mix(const mhla_view& q_num, const mhla_view& k_num, const mhla_
                      int M, int S, int D, float eps, unsigned flags, bool normalize, bool split, hipStream_t st,
                      const float* rcos = nullptr, const float* rsin = nullptr, long ldr = 0, bool s16 = false) {
     (void)q_num;
-    constexpr bool P24OK = bm_p24_built<T, DT, S16>();
-    const bool p24 = bm_p24<T, DT, S16>(M, D, flags);
-    const long es = p24 ? bm_p24_es(D) : w.es;
+    constexpr bool P24OK = bm_p24_built<T, DT, S16>(), H16OK = bm_h16_built<T, DT, S16>();
+    const bool p24 = w.fmt == SF_P24 || w.fmt == SF_H16;   // (capi_common.hpp bm_sumfmt; the row stride w.es is the format's)
+    const long es = w.es;
+    (void)H16OK;
     StateArgs a{};
     a.rcos = rcos; a.rsin = rsin; a.ldr = ldr;
     a.x = cv(k_num); a.y = cv(v); a.kd = cv(k_den); a.qd = cv(q_den); a.idx = idx;
@@ -153,10 +199,11 @@ int bm_state_and_mix(const mhla_view& q_num, const mhla_view& k_num, const mhla_
             if (p24) {
                 if (a.rcos) {
                     if constexpr (std::is_same<T, float>::value)
-                        RC(launch(sp::k_sp_state<T, DT, 0, true, SNT, false, true>, dim3(M, B * H), dim3(SNT), sp::sp_state_smem<DT>(), st, "k_sp_state<rope>", a));
+                        RC(launch(sp::k_sp_state<T, DT, 0, true, SNT, false, 1>, dim3(M, B * H), dim3(SNT), sp::sp_state_smem<DT>(), st, "k_sp_state<rope>", a));
                 } else
-                    RC(launch(sp::k_sp_state<T, DT, 0, false, SNT, false, true>, dim3(M, B * H), dim3(SNT), sp::sp_state_smem<DT>(), st, "k_sp_state", a));
-                RC((sp_mixr<0, false, true>(W, ldw, w.kv, w.g, M, m.E, es, B * H, st, normalize ? (const float*)w.z : nullptr, w.ninv, S, eps)));
+                    WITH_PF(w.fmt, RC(launch(sp::k_sp_state<T, DT, 0, false, SNT, false, PF>, dim3(M, B * H), dim3(SNT), sp::sp_state_smem<DT>(), st, "k_sp_state", a)));
+                if (w.fmt == SF_H16) RC(sp_mixh<0>(W, ldw, w.kv, w.g, M, m.E, es, B * H, st, normalize ? (const float*)w.z : nullptr, w.ninv, S, eps));
+                else RC((sp_mixr<0, false, 1>(W, ldw, w.kv, w.g, M, m.E, es, B * H, st, normalize ? (const float*)w.z : nullptr, w.ninv, S, eps)));
                 if (normalize && !sp_mixr_takes_wz<false>(M, S))
                     RC(launch(k_wz<0>, dim3((S + 63) / 64, (M + 63) / 64, B * H), dim3(NTHREADS), 0, st, "k_wz<0>", W, ldw, (const float*)w.z, w.ninv, M, S, eps));
                 return MHLA_OK;
@@ -202,9 +249,10 @@ int bm_fwd_typed(const BmCall& c) {
         OutArgs o{};
         o.rcos = rcos; o.rsin = rsin; o.ldr = ldr;
         o.q = cv(q_num); o.o = cmv(c.out); o.idx = block_index; o.W = W; o.ldw = ldw; o.g = w.g; o.ninv = w.ninv;
-        constexpr bool P24OK = bm_p24_built<ET, DT, S16>();
-        const bool p24 = bm_p24<ET, DT, S16>(M, D, flags);
-        o.H = H; o.M = M; o.S = S; o.D = D; o.eps = eps; o.es = p24 ? bm_p24_es(D) : w.es;
+        constexpr bool P24OK = bm_p24_built<ET, DT, S16>(), H16OK = bm_h16_built<ET, DT, S16>();
+        const bool p24 = w.fmt == SF_P24 || w.fmt == SF_H16;
+        (void)H16OK;
+        o.H = H; o.M = M; o.S = S; o.D = D; o.eps = eps; o.es = w.es;
         o.relu = (flags & MHLA_FLAG_RELU_EPS) ? 1 : 0; o.normalize = normalize;
         o.olo = (normalize && !epi && !(flags & MHLA_FLAG_NO_BWD_STATE)) ? w.olo : nullptr;   // (16-bit tensors, default arithmetic: BmWs::olo)
         if (epi) {
@@ -213,9 +261,9 @@ int bm_fwd_typed(const BmCall& c) {
                 const dim3 g(M, B * H), blk(sp::SP_OUT_T);
                 if (p24) {
                     if constexpr (P24OK) {
-                        if (out_dtype == MHLA_BF16)     RC(launch(sp::k_sp_out<float, DT, bf16_t, true, false, true>, g, blk, sp::sp_out_smem<DT>(), st, "k_sp_out<norm>", o));
-                        else if (out_dtype == MHLA_F16) RC(launch(sp::k_sp_out<float, DT, f16_t, true, false, true>, g, blk, sp::sp_out_smem<DT>(), st, "k_sp_out<norm>", o));
-                        else                            RC(launch(sp::k_sp_out<float, DT, float, true, false, true>, g, blk, sp::sp_out_smem<DT>(), st, "k_sp_out<norm>", o));
+                        if (out_dtype == MHLA_BF16)     RC(launch(sp::k_sp_out<float, DT, bf16_t, true, false, 1>, g, blk, sp::sp_out_smem<DT>(), st, "k_sp_out<norm>", o));
+                        else if (out_dtype == MHLA_F16) RC(launch(sp::k_sp_out<float, DT, f16_t, true, false, 1>, g, blk, sp::sp_out_smem<DT>(), st, "k_sp_out<norm>", o));
+                        else                            RC(launch(sp::k_sp_out<float, DT, float, true, false, 1>, g, blk, sp::sp_out_smem<DT>(), st, "k_sp_out<norm>", o));
                     }
                 } else
                 if (out_dtype == MHLA_BF16)     RC(launch(sp::k_sp_out<float, DT, bf16_t, true>, g, blk, sp::sp_out_smem<DT>(), st, "k_sp_out<norm>", o));
@@ -225,7 +273,7 @@ int bm_fwd_typed(const BmCall& c) {
         } else if (s16)
             RC(launch(s16::k_s16_out<0>, dim3((M + s16::WPB - 1) / s16::WPB, B * H), dim3(64 * s16::WPB), s16::out_smem(), st, "k_s16_out", o));
         else if (p24) {
-            if constexpr (P24OK) RC(launch(sp::k_sp_out<ET, DT, ET, false, false, true>, dim3(M, B * H), dim3(sp::SP_OUT_T), sp::sp_out_smem<DT, false>(), st, "k_sp_out", o));
+            if constexpr (P24OK) WITH_PF(w.fmt, RC(launch(sp::k_sp_out<ET, DT, ET, false, false, PF>, dim3(M, B * H), dim3(sp::SP_OUT_T), sp::sp_out_smem<DT, false>(), st, "k_sp_out", o)));
         } else if (sp_shape_ok(D, flags))
             RC(launch(sp::k_sp_out<ET, DT, ET, false, S16>, dim3(M, B * H), dim3(sp::SP_OUT_T), sp::sp_out_smem<DT, S16>(), st, "k_sp_out", o));
         else
@@ -253,9 +301,10 @@ int bm_bwd_typed(const BmCall& c) {
         const bool s16 = S16 && s16_ok<ET, DT>(c, true);
         if (!reuse)
             RC((bm_state_and_mix<ET, DT, S16>(q_num, k_num, v, q_den, k_den, W, ldw, block_index, w, B, H, M, S, D, eps, flags, normalize, split, st, rcos, rsin, ldr, s16)));
-        constexpr bool P24OK = bm_p24_built<ET, DT, S16>();
-        const bool p24 = bm_p24<ET, DT, S16>(M, D, flags);
-        const long es = p24 ? bm_p24_es(D) : w.es;
+        constexpr bool P24OK = bm_p24_built<ET, DT, S16>(), H16OK = bm_h16_built<ET, DT, S16>();
+        const bool p24 = w.fmt == SF_P24 || w.fmt == SF_H16;
+        const long es = w.es;
+        (void)H16OK;
         const bool want_olo = normalize && w.olo != nullptr;
         if (want_olo && (!reuse || (flags & MHLA_FLAG_NO_BWD_STATE))) {
             // what the forward's 16-bit store of O rounded away (BmWs::olo), recomputed: the output kernel without its output
@@ -264,7 +313,7 @@ int bm_bwd_typed(const BmCall& c) {
             o.H = H; o.M = M; o.S = S; o.D = D; o.eps = eps; o.es = es; o.relu = relu; o.normalize = normalize;
             o.olo = c.olo_own; o.skip_out = 1;
             if (p24) {
-                if constexpr (P24OK) RC(launch(sp::k_sp_out<ET, DT, ET, false, false, true>, dim3(M, B * H), dim3(sp::SP_OUT_T), sp::sp_out_smem<DT, false>(), st, "k_sp_out<olo>", o));
+                if constexpr (P24OK) WITH_PF(w.fmt, RC(launch(sp::k_sp_out<ET, DT, ET, false, false, PF>, dim3(M, B * H), dim3(sp::SP_OUT_T), sp::sp_out_smem<DT, false>(), st, "k_sp_out<olo>", o)));
             } else if (sp_shape_ok(D, flags))
                 RC(launch(sp::k_sp_out<ET, DT, ET, false, S16>, dim3(M, B * H), dim3(sp::SP_OUT_T), sp::sp_out_smem<DT, S16>(), st, "k_sp_out<olo>", o));
             else
@@ -295,18 +344,20 @@ int bm_bwd_typed(const BmCall& c) {
                     a.g = w.g;   // (16-bit tensors, D <= 64: the row dots come from G_i; two more LDS tiles)
                     constexpr int SM1 = (sizeof(ET) == 2 && DT <= 4) ? sp::sp_state_rd_smem<DT>() : sp::sp_state_smem<DT>();
                     if (rope) {
-                        if constexpr (F32) RC(launch(sp::k_sp_state<ET, DT, 1, true, SNT, false, true>, dim3(M, B * H), dim3(SNT), sp::sp_state_smem<DT>(), st, "k_sp_state<1,rope>", a));
+                        if constexpr (F32) RC(launch(sp::k_sp_state<ET, DT, 1, true, SNT, false, 1>, dim3(M, B * H), dim3(SNT), sp::sp_state_smem<DT>(), st, "k_sp_state<1,rope>", a));
                     } else
-                        RC(launch(sp::k_sp_state<ET, DT, 1, false, SNT, false, true>, dim3(M, B * H), dim3(SNT), SM1, st, "k_sp_state<1>", a));
+                        WITH_PF(w.fmt, RC(launch(sp::k_sp_state<ET, DT, 1, false, SNT, false, PF>, dim3(M, B * H), dim3(SNT), SM1, st, "k_sp_state<1>", a)));
                     int parts = 0;
                     bool wz_done = false, dwz_done = false;   // dz = W^T dn formed / the <dn_i, z_j> term of dW included
                     if (sp_mixr_dw_ok(M, E)) {
-                        RC(sp_mixr_dw<true>(W, ldw, w.dg, w.kv, w.dkv, w.dwp, M, E, es, B * H, st, &parts, normalize ? (const float*)w.dn : nullptr,
+                        if (w.fmt == SF_H16) RC(sp_mixh_dw(W, ldw, w.dg, w.kv, w.dkv, w.dwp, M, E, es, B * H, st, &parts, normalize ? (const float*)w.dn : nullptr,
+                                                           normalize ? (const float*)w.z : nullptr, w.dz, S, &wz_done));
+                        else RC(sp_mixr_dw<1>(W, ldw, w.dg, w.kv, w.dkv, w.dwp, M, E, es, B * H, st, &parts, normalize ? (const float*)w.dn : nullptr,
                                             normalize ? (const float*)w.z : nullptr, w.dz, S, &wz_done));
                         dwz_done = wz_done;
                     } else {   // 129 .. 192 blocks: twelve waves have no registers for the dW tiles -- k_sp_dw reads dG and KV again
                         wz_done = normalize && sp_mixr_takes_wz<false>(M, S);
-                        RC((sp_mixr<1, false, true>(W, ldw, w.dg, w.dkv, M, E, es, B * H, st, normalize ? (const float*)w.dn : nullptr, w.dz, S, 0.f)));
+                        RC((sp_mixr<1, false, 1>(W, ldw, w.dg, w.dkv, M, E, es, B * H, st, normalize ? (const float*)w.dn : nullptr, w.dz, S, 0.f)));
                         int nsplit = dw_splits(tiles * tiles * B * H, E);
                         if (nsplit > DW_MAX_SPLIT - 1) nsplit = DW_MAX_SPLIT - 1;
                         DwArgs d{w.dg, w.kv, E, nullptr, nullptr, 0, w.dwp, M, tiles, nsplit, es};
@@ -323,14 +374,14 @@ int bm_bwd_typed(const BmCall& c) {
                     RC(launch(k_dw_reduce<0, 16>, dim3((M * M + 15) / 16), dim3(256), 0, st, "k_dw_reduce", (const float*)w.dwp, (const float*)nullptr, dW, M, M, parts, B * H));
                     if (rope) {
                         if constexpr (F32) {
-                            RC(launch(sp::k_sp_bwd_dq<ET, DT, true, false, false, true>, dim3(M, B * H), dim3(NTHREADS), sp::sp_tok_smem<DT, false>(), st, "k_sp_bwd_dq<rope>", t));
-                            RC(launch(sp::k_sp_bwd_dkv<ET, DT, true, false, true>, dim3(M, B * H), dim3(NTHREADS), sp::sp_tok_smem<DT, false>(), st, "k_sp_bwd_dkv<rope>", t));
+                            RC(launch(sp::k_sp_bwd_dq<ET, DT, true, false, false, 1>, dim3(M, B * H), dim3(NTHREADS), sp::sp_tok_smem<DT, false>(), st, "k_sp_bwd_dq<rope>", t));
+                            RC(launch(sp::k_sp_bwd_dkv<ET, DT, true, false, 1>, dim3(M, B * H), dim3(NTHREADS), sp::sp_tok_smem<DT, false>(), st, "k_sp_bwd_dkv<rope>", t));
                         }
                         break;
                     }
-                    if (normalize && !relu && sizeof(ET) == 2 && DT != 5) RC(launch(sp::k_sp_bwd_dq<ET, DT, false, false, true, true>, dim3(M, B * H), dim3(NTHREADS), sp::sp_tok_smem<DT, false>(), st, "k_sp_bwd_dq", t));
-                    else RC(launch(sp::k_sp_bwd_dq<ET, DT, false, false, false, true>, dim3(M, B * H), dim3(NTHREADS), sp::sp_tok_smem<DT, false>(), st, "k_sp_bwd_dq", t));
-                    RC(launch(sp::k_sp_bwd_dkv<ET, DT, false, false, true>, dim3(M, B * H), dim3(NTHREADS), sp::sp_tok_smem<DT, false>(), st, "k_sp_bwd_dkv", t));
+                    if (normalize && !relu && sizeof(ET) == 2 && DT != 5) WITH_PF(w.fmt, RC(launch(sp::k_sp_bwd_dq<ET, DT, false, false, true, PF>, dim3(M, B * H), dim3(NTHREADS), sp::sp_tok_smem<DT, false>(), st, "k_sp_bwd_dq", t)));
+                    else WITH_PF(w.fmt, RC(launch(sp::k_sp_bwd_dq<ET, DT, false, false, false, PF>, dim3(M, B * H), dim3(NTHREADS), sp::sp_tok_smem<DT, false>(), st, "k_sp_bwd_dq", t)));
+                    WITH_PF(w.fmt, RC(launch(sp::k_sp_bwd_dkv<ET, DT, false, false, PF>, dim3(M, B * H), dim3(NTHREADS), sp::sp_tok_smem<DT, false>(), st, "k_sp_bwd_dkv", t)));
                     break;
                 }
             }

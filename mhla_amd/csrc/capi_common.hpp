@@ -123,23 +123,39 @@ inline int dt_for(int D) { return D <= 32 ? 2 : D <= 64 ? 4 : D <= 80 ? 5 : D <=
         default: return fail(MHLA_ENOTSUP, "head dim tile %d not supported", dt);\
     }
 
+// Storage format of the D x D block summaries KV, G, dG, dKV in the workspace (bm_sumfmt: a function of the call's shape, dtype and
+// flags -- and of the process-wide "fp32_summaries" option -- so that a forward and the backward that reuses its state agree)
+enum { SF_F32 = 0,    // fp32 words
+       SF_P24 = 1,    // 24-bit floats in two planes per row (split.hpp p24): 16 significand bits, 3 bytes
+       SF_H16 = 2,    // fp16 payload x one power-of-two multiplier per row (split.hpp h16): 11 significand bits, 2 bytes -- the default for 16-bit tensors
+       SF_BF16 = 3 }; // single bf16 values (MHLA_FLAG_BF16_SUMMARIES: reduced precision, opt-in)
 struct BmWs {
     float *kv, *g, *z, *ksum, *ninv, *dg, *dkv, *dn, *dz, *dks, *dwp;
     unsigned short* olo;   // forward region: O - fl(O) as bf16 [bh][M S][D] (16-bit tensors at the default arithmetic), or null
     size_t total_fwd, total_bwd;
-    long es;   // elements from one block's D x D summary to the next (D D + padding on the split-operand path)
+    long es;   // from one block's D x D summary to the next, in floats (SF_BF16: in 16-bit elements): the format's row + padding
+    int fmt;   // SF_*
 };
 // sum16: the D x D block summaries (KV, G, dG, dKV) are stored as bf16 (split-operand path on bf16 tensors): half the floats
 // padded (split-operand path): every summary row carries 1152 bytes of padding.  The mixing and dW kernels read the same 128-byte
 // piece of EVERY block's summary at once, i.e. at the row stride: at a power-of-two stride (8 KB at D = 64 bf16, 64 KB at D = 128
 // fp32) those requests fall on a fraction of the HBM channels -- k_sp_dwr ran at 3.7 TB/s at D = 64 and at 4.9 / 5.4 TB/s at
 // D = 56 / 72 (the causal pipeline met the same effect, causal_bf16.hpp).  The generic fp32-MFMA kernels keep dense rows.
-inline long bm_row_elems(int D, bool sum16, bool padded) { return (long)D * D + (padded ? (sum16 ? 576 : 288) : 0); }
-inline BmWs bm_carve(void* ws, int B, int H, int M, int S, int D, bool sum16, bool padded, bool olo = false) {
-    const size_t es = (size_t)bm_row_elems(D, sum16, padded);
-    const size_t bh = (size_t)B * H, st = al4(sum16 ? (bh * M * es + 1) / 2 : bh * M * es), zs = al4(bh * M * S), ks = al4(bh * M * D);
+inline long bm_row_elems(int D, int fmt, bool padded) {
+    const long E = (long)D * D;
+    switch (fmt) {
+        case SF_BF16: return E + (padded ? 576 : 0);        // (16-bit elements)
+        case SF_P24: return 3 * E / 4 + 288;                // two planes: E x u16, E x u8
+        case SF_H16: return E / 2 + 4 + 288;                // E x fp16, the row's multiplier (16 bytes keep the next row aligned)
+        default: return E + (padded ? 288 : 0);
+    }
+}
+inline BmWs bm_carve(void* ws, int B, int H, int M, int S, int D, int fmt, bool padded, bool olo = false) {
+    const size_t es = (size_t)bm_row_elems(D, fmt, padded);
+    const size_t bh = (size_t)B * H, st = al4(fmt == SF_BF16 ? (bh * M * es + 1) / 2 : bh * M * es), zs = al4(bh * M * S), ks = al4(bh * M * D);
     float* p = (float*)ws;
     BmWs w;
+    w.fmt = fmt;
     w.es = (long)es;
     w.kv = p; p += st;
     w.g = p; p += st;
@@ -166,14 +182,32 @@ inline bool sp_shape_ok(int D, unsigned flags) { return (D & 7) == 0 && !(flags 
 inline bool view_ok16m(const mhla_mview& v) { return v.ptr && ((uintptr_t)v.ptr % 16) == 0 && ((v.sb | v.sn | v.sh) & 7) == 0; }
 // bf16 block summaries (and single-bf16 intermediate operands): only when the caller asked for them (MHLA_FLAG_BF16_SUMMARIES)
 inline bool bm_sum16(int D, int dtype, unsigned flags) { return dtype == MHLA_BF16 && sp_shape_ok(D, flags) && (flags & MHLA_FLAG_BF16_SUMMARIES); }
-// 16-bit tensors on the 24-bit-summary pipeline with head dims up to 64 (capi_bm_typed.hpp bm_p24, restated for the workspace carve): the
-// backward forms its row dots dO . O from G_i itself -- dO' . (Q_i G_i), one more small product in k_sp_state<1> -- and reads neither
-// the stored output nor a residual of it
-inline bool bm_rowdots_from_g(int M, int D, int dtype, unsigned flags) {
-    return dtype != MHLA_F32 && !bm_sum16(D, dtype, flags) && sp_shape_ok(D, flags) && D <= 64 && M <= 128 && ((long)D * D) % 64 == 0 && !g_no_p24.load();
+// The summary format of a block-mix call on the generic / split-operand path.  h16 and p24 live on the resident-mixing pipeline
+// (split.hpp k_sp_mixr: up to 256 blocks, summaries of whole 64-element slices):
+//   h16: 16-bit tensors, head dims 32 .. 96, 4 .. 128 blocks (the fused dW) of at least 16 tokens (11-bit summaries lean on averaging
+//        over the block, the head dim and the blocks: in the model, tools/sim_h16.py, 2 blocks reach 5e-3 in dW -- a difference
+//        of nearly equal terms there -- head dim 8 reaches 7e-4, a 2 x 1-token case 1.4e-3; inside the rule: <= 6e-4) -- unless
+//        the caller asks for >= 16 significand bits
+//        (MHLA_FLAG_FP32_GRADE_SUMMARIES) or the process keeps fp32 words ("fp32_summaries");
+//   p24: the same 16-bit shapes when h16 is declined, and fp32 tensors at head dims 97 .. 128 with up to 192 blocks (the Wan shape).
+inline int bm_sumfmt(int M, int S, int D, int dtype, unsigned flags) {
+    if (!sp_shape_ok(D, flags)) return SF_F32;
+    if (bm_sum16(D, dtype, flags)) return SF_BF16;
+    const bool mixr = M <= 256 && ((long)D * D) % 64 == 0;
+    if (!mixr || g_no_p24.load()) return SF_F32;
+    if (dtype != MHLA_F32 && D <= 96 && M <= 128)
+        return (S >= 16 && M >= 4 && D >= 32 && !(flags & MHLA_FLAG_FP32_GRADE_SUMMARIES)) ? SF_H16 : SF_P24;
+    if (dtype == MHLA_F32 && D > 96 && M <= 192) return SF_P24;
+    return SF_F32;
+}
+// 16-bit tensors on the h16 / p24 pipeline with head dims up to 64: the backward forms its row dots dO . O from G_i itself --
+// dO' . (Q_i G_i), one more small product in k_sp_state<1> -- and reads neither the stored output nor a residual of it
+inline bool bm_rowdots_from_g(int M, int S, int D, int dtype, unsigned flags) {
+    const int f = bm_sumfmt(M, S, D, dtype, flags);
+    return dtype != MHLA_F32 && (f == SF_H16 || f == SF_P24) && D <= 64;
 }
 // other 16-bit tensors at the default arithmetic: the forward keeps what its store of O rounded away (BmWs::olo) for the backward
-inline bool bm_olo(int M, int D, int dtype, unsigned flags) { return dtype != MHLA_F32 && !bm_sum16(D, dtype, flags) && !bm_rowdots_from_g(M, D, dtype, flags); }
+inline bool bm_olo(int M, int S, int D, int dtype, unsigned flags) { return dtype != MHLA_F32 && !bm_sum16(D, dtype, flags) && !bm_rowdots_from_g(M, S, D, dtype, flags); }
 // the bf16-summary fast path (fused.hpp): its summaries are single bf16 values, so it serves the opt-in arithmetic only
 inline bool fast_shape_ok(int M, int D, int dtype, bool split, unsigned flags) {
     return dtype == MHLA_BF16 && D == 64 && M <= 64 && !split && (flags & MHLA_FLAG_BF16_SUMMARIES);
@@ -193,7 +227,8 @@ inline int bm_check(int B, int H, int M, int S, int D, int dtype, unsigned flags
     if (D % 4) return fail(MHLA_EINVAL, "D=%d must be a multiple of 4", D);
     if (!dt_for(D)) return fail(MHLA_ENOTSUP, "block-mix head dim D=%d > 128 not supported", D);
     if (dtype < 0 || dtype > 2) return fail(MHLA_EINVAL, "unknown dtype %d", dtype);
-    if (flags & ~(MHLA_FLAG_RELU_EPS | MHLA_FLAG_FORCE_GENERIC | MHLA_FLAG_NO_SMALLN | MHLA_FLAG_BF16_SUMMARIES | MHLA_FLAG_NO_BWD_STATE)) return fail(MHLA_EINVAL, "unknown flags 0x%x", flags);
+    if (flags & ~(MHLA_FLAG_RELU_EPS | MHLA_FLAG_FORCE_GENERIC | MHLA_FLAG_NO_SMALLN | MHLA_FLAG_BF16_SUMMARIES | MHLA_FLAG_NO_BWD_STATE | MHLA_FLAG_FP32_GRADE_SUMMARIES)) return fail(MHLA_EINVAL, "unknown flags 0x%x", flags);
+    if ((flags & MHLA_FLAG_BF16_SUMMARIES) && (flags & MHLA_FLAG_FP32_GRADE_SUMMARIES)) return fail(MHLA_EINVAL, "MHLA_FLAG_BF16_SUMMARIES and MHLA_FLAG_FP32_GRADE_SUMMARIES exclude each other");
     if ((flags & MHLA_FLAG_RELU_EPS) && split) return fail(MHLA_EINVAL, "MHLA_FLAG_RELU_EPS needs q_den/k_den to alias q_num/k_num");
     if ((size_t)B * H > 65535) return fail(MHLA_ENOTSUP, "B*H=%zu exceeds grid limit 65535", (size_t)B * H);
     (void)normalize;

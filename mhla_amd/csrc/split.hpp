@@ -952,7 +952,7 @@ __host__ __device__ constexpr int sp_mixr_smem() {
 // of a row -- one 16-byte piece of the hi plane and one 8-byte piece of the lo plane -- instead of a 16-byte piece of 4 floats.
 // P24 = 2 (h16): fp16 payload, one multiplier per row (decoded at the commit, the output rows' multipliers from the bound of the inputs')
 template <int NW, int TRANS, bool S16, bool DW = false, int P24 = 0>
-__global__ __launch_bounds__(64 * NW, (NW == 8 && !DW && P24) ? 4 : (NW + 3) / 4) void k_sp_mixr(const MixrArgs a) {   // (eight waves on 24-bit summaries without dW: 128 VGPRs, two workgroups per CU instead of one at 136)
+__global__ __launch_bounds__(64 * NW, (NW == 8 && !DW && P24 == 1) ? 4 : ((NW == 4 && !DW && P24 == 2) ? 4 : (NW + 3) / 4)) void k_sp_mixr(const MixrArgs a) {   // (eight waves on 24-bit summaries without dW: 128 VGPRs, two workgroups per CU instead of one at 136)
     static_assert(!DW || (TRANS == 1 && !S16 && NW <= 8), "dW rides in the backward's fp32 mixing kernel, M <= 128 (twelve waves: 77 spilled registers)");
     static_assert(!P24 || (!S16 && NW <= 12), "p24: fp32-grade summaries, slices of 64 elements");
     constexpr int TE = mixr_te<NW, S16>(), ROWS = 16 * NW, LD = TE + 8, LDO = TE + 4, NK = (NW + 1) / 2, NT = TE / 16;

@@ -56,7 +56,7 @@ class MHLA4DiT(nn.Module):
         self.eps = kwargs.get("eps", 1e-6)
         # not in the reference: "split" (default) keeps the operator's intermediates at fp32 grade on 16-bit tensors, "bf16" is the
         # opt-in reduced-precision arithmetic (see mhla_amd.mhla_blockmix)
-        self.summaries = kwargs.get("summaries", "split")
+        self.summaries = kwargs.get("summaries", "tf32")
         self.to_out = nn.Sequential(nn.Linear(inner_dim, dim), nn.Dropout(dropout))
         if fixed_weight_value is not None:
             self._init_weights_with_fixed_value(fixed_weight_value)

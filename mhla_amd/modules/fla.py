@@ -178,8 +178,8 @@ class MHLA(nn.Module):
         self.value_dim_per_group = self.value_dim // self.num_kv_groups
         self.clamp_min = clamp_min
         self.layer_idx = layer_idx
-        if summaries not in ("split", "bf16"):
-            raise ValueError(f"summaries={summaries!r}: 'split' or 'bf16'")
+        if summaries not in ("tf32", "split", "bf16"):
+            raise ValueError(f"summaries={summaries!r}: 'tf32', 'split' or 'bf16'")
         self.summaries = summaries
         self.use_output_gate = use_output_gate
         assert mode in ["chunk", "fused_recurrent", "fused_chunk"], f"Not supported mode `{mode}`."

@@ -173,12 +173,27 @@ def _check_handover(lib, ws, B, H, M, S, D, dt, split, flags):
         _lib.check(rc, "mhla_blockmix_bwd_status")
 
 
+SUMMARIES = ("tf32", "split", "bf16")
+
+
 def _bm_flags(relu_eps: bool, force_generic: bool, no_smalln: bool, summaries: str) -> int:
-    if summaries not in ("split", "bf16"):
-        raise ValueError(f"summaries={summaries!r}: 'split' (fp32-grade intermediates: fp32 block summaries / bf16 hi + lo operands, the "
-                         "reference's arithmetic) or 'bf16' (opt-in reduced precision)")
+    if summaries not in SUMMARIES:
+        raise ValueError(f"summaries={summaries!r}: 'tf32' (default: 2-byte block summaries with 11 significand bits, the precision of the "
+                         "reference's TF32 matmuls), 'split' (>= 16 significand bits: 24-bit / fp32 summaries) or 'bf16' (opt-in reduced precision)")
     return ((_lib.FLAG_RELU_EPS if relu_eps else 0) | (_lib.FLAG_FORCE_GENERIC if force_generic else 0)
-            | (_lib.FLAG_NO_SMALLN if no_smalln else 0) | (_lib.FLAG_BF16_SUMMARIES if summaries == "bf16" else 0))
+            | (_lib.FLAG_NO_SMALLN if no_smalln else 0) | (_lib.FLAG_BF16_SUMMARIES if summaries == "bf16" else 0)
+            | (_lib.FLAG_FP32_GRADE_SUMMARIES if summaries == "split" else 0))
+
+
+def set_option(name: str, value: int) -> int:
+    """mhla_set_option through the package: the process-wide options change what the workspace-size queries return
+    ("fp32_summaries"), so the cached plans are dropped with every change.  Returns the previous value."""
+    rc = _lib.load().mhla_set_option(name.encode(), int(value))
+    if rc < 0:
+        _lib.check(rc, "mhla_set_option")
+    _bm_plan.cache_clear()
+    _cs_plan.cache_clear()
+    return rc
 
 
 class _BlockMix(torch.autograd.Function):
@@ -267,7 +282,7 @@ def mhla_blockmix(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, W: torch.Te
                   q_den: Optional[torch.Tensor] = None, k_den: Optional[torch.Tensor] = None,
                   normalize: bool = True, block_index: Optional[torch.Tensor] = None,
                   relu_eps: bool = False, force_generic: bool = False, no_smalln: bool = False,
-                  summaries: str = "split") -> torch.Tensor:
+                  summaries: str = "tf32") -> torch.Tensor:
     """Block-mixing MHLA operator (mhla_dit/mhla/mhla.py:262-268; wan/mhla_utils.py:331-341).
 
     q, k, v : [B, N, H, D] token-major (any batch/token/head strides, e.g. views into a fused QKV
@@ -281,10 +296,13 @@ def mhla_blockmix(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, W: torch.Te
     force_generic / no_smalln: testing aids -- take the generic fp32-MFMA kernels / skip the single-launch
                    small-sequence path where they would otherwise be chosen.
     summaries    : how 16-bit problems keep what feeds a SECOND contraction (the block summaries KV, G, dG, dKV, dP = dO / n,
-                   the score tiles of the 256-token path).  "split" (default): >= 16 significand bits (fp32 summaries, bf16
-                   hi + lo operands) -- the reference's fp32 arithmetic on the given tensors (mhla_dit/train.py:12-13), results
-                   within one final rounding + 1e-3 of it.  "bf16": single bf16 values -- REDUCED PRECISION (2-3e-3 of a
-                   gradient's maximum), half the summary traffic; what the reference's own matmuls store under bf16 autocast.
+                   the score tiles of the 256-token path).  Operands are bf16 hi + lo pairs with fp32 accumulation in every case but
+                   "bf16".  "tf32" (default): the summaries are STORED with 11 significand bits (fp16 payload x one power-of-two
+                   multiplier per block row, 2 bytes) -- the precision the reference's own matmul / 1x1 conv run at under
+                   allow_tf32 (mhla_dit/train.py:12-13) -- where the kernels have the format (blocks of >= 16 tokens, D <= 96,
+                   M <= 128), >= 16 bits elsewhere; results within one final rounding + 1e-3 of the fp32 result (observed 4e-4).
+                   "split": >= 16 significand bits everywhere (24-bit / fp32 summaries; 1e-5).  "bf16" (bf16 tensors only):
+                   single bf16 values -- REDUCED PRECISION (2-3e-3 of a gradient's maximum).
     Returns [B, N, H, D] contiguous, same dtype; differentiable w.r.t. q, k, v, W (and q_den, k_den).
     """
     if (q_den is None) != (k_den is None):
@@ -704,7 +722,7 @@ class _DitCore(torch.autograd.Function):
 
 
 def mhla_dit_core(qkv: torch.Tensor, W: torch.Tensor, lepe_weight: torch.Tensor, lepe_bias: Optional[torch.Tensor],
-                  pieces_len: int, block_len: int, *, eps: float = 1e-6, relu_eps: bool = True, summaries: str = "split") -> torch.Tensor:
+                  pieces_len: int, block_len: int, *, eps: float = 1e-6, relu_eps: bool = True, summaries: str = "tf32") -> torch.Tensor:
     """`mhla_blockmix(q, k, v, W) + LePE(v)` of the DiT / ViT module on the packed projection output `qkv` [B, N, 3, H, D]
     (block-major tokens), returning [B, N, H*D]; one autograd node whose backward emits a single packed gradient.
     `summaries`: see mhla_blockmix."""
@@ -897,8 +915,8 @@ class _Causal(torch.autograd.Function):
 
 
 def _causal_flags(summaries: str, force_generic: bool) -> int:
-    if summaries not in ("split", "bf16"):
-        raise ValueError(f"summaries={summaries!r}: 'split' (bf16 hi + lo pairs, the reference's fp32 arithmetic) or 'bf16'")
+    if summaries not in SUMMARIES:
+        raise ValueError(f"summaries={summaries!r}: 'tf32' / 'split' (bf16 hi + lo pairs, the reference's fp32 arithmetic) or 'bf16'")
     return (_lib.CAUSAL_BF16_SUMMARIES if summaries == "bf16" else 0) | (_lib.CAUSAL_FORCE_GENERIC if force_generic else 0)
 
 

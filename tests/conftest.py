@@ -92,6 +92,8 @@ def pytest_sessionfinish(session, exitstatus):
             cfg = "c5_1p3b_like"
         if tl.endswith("[bf16]") or "[bf16-" in tl or "-bf16]" in tl:             # the opt-in summaries="bf16" parametrisation: its own family
             tens += " [reduced precision: summaries=bf16]"
+        elif tl.endswith("[split]") or "[split-" in tl or "-split]" in tl:        # the opt-in summaries="split" parametrisation (>= 16-bit summaries)
+            tens += " [summaries=split: 24-bit / fp32 summaries]"
         a = fam.setdefault(f"{cfg}/{tens}", {"n": 0, "results_16bit_max_beyond_final_rounding": 0.0, "results_fp32_max_rel_err": 0.0, "worst": None})
         a["n"] += 1
         key = "results_fp32_max_rel_err" if dtype == "float32" else "results_16bit_max_beyond_final_rounding"

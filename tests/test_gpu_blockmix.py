@@ -9,9 +9,10 @@ from oracle import mhla_oracle as orc
 pytestmark = pytest.mark.gpu
 
 
-def run_case(B, H, M, S, D, dtype, normalize=True, split=False, w="linear", idx=None, seed=1234, summaries="split", **opkw):
-    """One forward + backward through mhla_amd.mhla_blockmix against the oracle.  summaries="split" (the library's default): the
-    reference's fp32 arithmetic on the given tensors, held to one final rounding + 1e-3 (1e-3 for the fp32-stored dW);
+def run_case(B, H, M, S, D, dtype, normalize=True, split=False, w="linear", idx=None, seed=1234, summaries="tf32", **opkw):
+    """One forward + backward through mhla_amd.mhla_blockmix against the oracle.  summaries="tf32" (the library's default: block
+    summaries stored with 11 significand bits where the kernels have the 2-byte format, >= 16 elsewhere) and "split" (>= 16 bits
+    everywhere): the reference's arithmetic on the given tensors, held to one final rounding + 1e-3 (1e-3 for the fp32-stored dW);
     "bf16": the opt-in reduced-precision form (single-bf16 summaries / intermediates) at its (1 + K) u bounds."""
     import mhla_amd
     otol, gtol, wtol = bm_tols(dtype, summaries)
@@ -102,7 +103,7 @@ def test_shapes_lowp(M, S, D, dtype):
 
 @pytest.mark.parametrize("M,S", [(64, 64), (16, 16), (16, 256), (4, 49), (5, 64), (33, 32), (40, 80), (1, 128), (64, 8),
                                  (3, 320), (5, 200), (17, 136)])   # blocks of 5 / 4 (ragged) / 3 chunks: chunk parts over several workgroups
-@pytest.mark.parametrize("summaries", ["split", "bf16"])
+@pytest.mark.parametrize("summaries", ["tf32", "split", "bf16"])
 def test_fast_path_bf16_d64(M, S, summaries):
     """bf16, D = 64, M <= 64.  summaries="bf16": the bf16-MFMA fast path (interleaved bf16 block summaries, fused mix + output);
     default: the same shapes at the reference's arithmetic (fp32 summaries, hi + lo operands)."""
@@ -178,7 +179,7 @@ def test_small_sequence_vs_summary_path_agree(summaries, tol):
         check(name, a_, b_.float().cpu(), tol if name != "dW" or summaries == "bf16" else 1e-3)
 
 
-@pytest.mark.parametrize("summaries", ["split", "bf16"])
+@pytest.mark.parametrize("summaries", ["tf32", "split", "bf16"])
 @pytest.mark.parametrize("normalize", [True, False])
 @pytest.mark.parametrize("M,S", [(16, 32), (9, 64), (20, 40)])
 def test_fast_path_gather_map(M, S, normalize, summaries):
@@ -315,40 +316,42 @@ def test_split_operand_path_matches_exact_fp32():
 @pytest.mark.parametrize("M,S,D,normalize", [(64, 64, 64, True), (33, 20, 64, True), (128, 8, 64, True), (50, 37, 56, True), (100, 12, 32, False),
                                               (64, 16, 64, True), (70, 50, 64, False)])
 def test_24_bit_summaries_vs_fp32_summaries(M, S, D, normalize, dtype):
-    """16-bit tensors, 33 .. 128 blocks, D <= 64: the block summaries travel as 24-bit floats (split.hpp p24).  Both forms meet the
-    oracle at the default tolerance, and they agree with each other far inside it (16 significand bits either way)."""
+    """16-bit tensors, 33 .. 128 blocks, D <= 64: the three storage formats of the block summaries on the resident-mixing pipeline --
+    h16 (summaries="tf32", the default: fp16 payload x row multiplier, 11 significand bits; blocks of >= 16 tokens), 24-bit floats
+    (summaries="split") and fp32 words (the process option "fp32_summaries").  All meet the oracle at the default tolerance; the two
+    16-bit-grade forms agree with each other far inside it, h16 stays within 1e-3 (+ a rounding step of the output) of them."""
     import mhla_amd
-    from mhla_amd import _lib
-    lib = _lib.load()
-    res = []
+    res = {}
     try:
-        for fp32 in (0, 1):
-            lib.mhla_set_option(b"fp32_summaries", fp32)
-            run_case(2, 3, M, S, D, dtype, normalize=normalize, w="rand")
+        for form, summ, fp32 in (("h16", "tf32", 0), ("p24", "split", 0), ("fp32", "split", 1)):
+            mhla_amd.set_option("fp32_summaries", fp32)
+            run_case(2, 3, M, S, D, dtype, normalize=normalize, w="rand", summaries=summ)
             q, k, v, W, do, _, _ = make_blockmix_inputs(2, 3, M, S, D, dtype, 77, "rand", False)
             t = [x.requires_grad_(True) for x in to_dev(q, k, v, W)]
-            out = mhla_amd.mhla_blockmix(t[0], t[1], t[2], t[3], normalize=normalize)
+            out = mhla_amd.mhla_blockmix(t[0], t[1], t[2], t[3], normalize=normalize, summaries=summ)
             out.backward(do.to(DEV))
-            res.append([out.detach()] + [x.grad for x in t])
+            res[form] = [out.detach()] + [x.grad for x in t]
     finally:
-        lib.mhla_set_option(b"fp32_summaries", 0)
-    for name, a, b in zip(("out", "dq", "dk", "dv", "dW"), *res):
-        check(name, a, b.cpu(), 2.0 ** -7 if name != "dW" else 2e-4)   # (16-bit results: at most a rounding step of the output apart)
+        mhla_amd.set_option("fp32_summaries", 0)
+    for name, a, b, c in zip(("out", "dq", "dk", "dv", "dW"), res["h16"], res["p24"], res["fp32"]):
+        check(name + " (p24 vs fp32)", b, c.cpu(), 2.0 ** -7 if name != "dW" else 2e-4)   # (16-bit results: at most a rounding step of the output apart)
+        check(name + " (h16 vs fp32)", a, c.cpu(), 2.0 ** -7 + 1e-3 if name != "dW" else 1e-3)
 
 
-def test_24_bit_summaries_kept_state_and_gather_map(monkeypatch):
-    """The forward's kept workspace (24-bit KV / G) feeds the backward bit-identically to a recompute, through a gather map too."""
+@pytest.mark.parametrize("summaries", ["tf32", "split"])
+def test_24_bit_summaries_kept_state_and_gather_map(monkeypatch, summaries):
+    """The forward's kept workspace (h16 / 24-bit KV, G) feeds the backward bit-identically to a recompute, through a gather map too."""
     import mhla_amd
     from mhla_amd import ops
     B, H, M, S, D = 1, 4, 40, 24, 64
     q, k, v, W, do, _, _ = make_blockmix_inputs(B, H, M, S, D, torch.bfloat16, seed=5, w="rand", split=False)
     idx = torch.randperm(M * S, generator=torch.Generator().manual_seed(1)).int()
-    run_case(B, H, M, S, D, torch.bfloat16, w="rand", idx=idx)
+    run_case(B, H, M, S, D, torch.bfloat16, w="rand", idx=idx, summaries=summaries)
     res = []
     for limit in (1 << 30, 0):
         monkeypatch.setattr(ops, "KEEP_STATE_LIMIT_BYTES", limit)
         t = [x.clone().requires_grad_(True) for x in to_dev(q, k, v, W)]
-        mhla_amd.mhla_blockmix(t[0], t[1], t[2], t[3]).backward(do.to(DEV))
+        mhla_amd.mhla_blockmix(t[0], t[1], t[2], t[3], summaries=summaries).backward(do.to(DEV))
         res.append([x.grad for x in t])
     for name, a, b in zip(("dq", "dk", "dv", "dW"), *res):
         assert torch.equal(a, b), name
@@ -469,7 +472,7 @@ def test_errors_fail_loudly():
         mhla_amd.mhla_blockmix(q.double(), q.double(), q.double(), W)
 
 
-@pytest.mark.parametrize("summaries", ["split", "bf16"])
+@pytest.mark.parametrize("summaries", ["tf32", "split", "bf16"])
 def test_full_size_c2_properties_and_sampled_heads(summaries):
     """BASELINE config C2 (B=8, N=4096, H=16, D=64, bf16, M=S=64): sampled (b, h) slices vs the oracle,
     plus size-independent properties: linearity in v, and W = I decouples blocks.  Default arithmetic (the number of record:

@@ -21,20 +21,31 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/mhla_hip.h but not exported"
-    assert lib.mhla_abi_version() == _lib.ABI_VERSION == 8
+    assert lib.mhla_abi_version() == _lib.ABI_VERSION == 9
     assert b"no-packed-fp32" in lib.mhla_build_flags()
     # workspace sizing is pure host arithmetic: callable without a GPU
     fwd = lib.mhla_blockmix_fwd_ws_bytes(8, 16, 64, 64, 64, 0, 0, 0)
     bwd = lib.mhla_blockmix_bwd_ws_bytes(8, 16, 64, 64, 64, 0, 0, 0)
-    # bf16 tensors: fp32 block summaries by default (the reference's arithmetic), the compact bf16 ones of the fast path only with
-    # the opt-in flag; the flag means nothing for fp32 tensors
+    # The workspace follows the summary format of the call (capi_common.hpp bm_sumfmt).  fp32 tensors, D = 64: fp32 words (4 bytes per
+    # summary element + 1152 bytes of row padding).  bf16 tensors: 2 bytes by default (fp16 payload + the row's multiplier), 3 bytes
+    # (24-bit floats) with MHLA_FLAG_FP32_GRADE_SUMMARIES, 2 bytes (single bf16, reduced precision) with MHLA_FLAG_BF16_SUMMARIES;
+    # the flags mean nothing for fp32 tensors.
+    rows, small = 8 * 16 * 64, lambda M, S, D: 4 * (2 * 8 * 16 * M * S + 8 * 16 * M * D)     # summary rows per set; z, 1/n, ksum
+    assert fwd == 2 * rows * (4096 + 288) * 4 + small(64, 64, 64)
+    h16 = lib.mhla_blockmix_fwd_ws_bytes(8, 16, 64, 64, 64, 1, 0, 0)
+    assert h16 == 2 * rows * (2048 + 4 + 288) * 4 + small(64, 64, 64)
+    assert lib.mhla_blockmix_fwd_ws_bytes(8, 16, 64, 64, 64, 2, 0, 0) == h16                    # fp16 tensors alike
+    assert lib.mhla_blockmix_fwd_ws_bytes(8, 16, 64, 64, 64, 1, 0, _lib.FLAG_FP32_GRADE_SUMMARIES) == 2 * rows * (3072 + 288) * 4 + small(64, 64, 64)
+    assert lib.mhla_blockmix_fwd_ws_bytes(8, 16, 512, 8, 64, 1, 0, 0) > lib.mhla_blockmix_fwd_ws_bytes(8, 16, 512, 8, 64, 0, 0, 0) * 0.99   # > 256 blocks: fp32 words for every dtype
+    assert lib.mhla_blockmix_fwd_ws_bytes(8, 16, 64, 8, 64, 1, 0, 0) == 2 * rows * (3072 + 288) * 4 + small(64, 8, 64)   # blocks of < 16 tokens: 24-bit floats
     # (C2-like shapes -- D <= 64, up to 128 blocks -- form the backward's row dots from G and keep nothing else; elsewhere the forward
     # keeps the bf16 residual of its store of O, B N H D * 2 bytes: here D = 72)
-    assert lib.mhla_blockmix_fwd_ws_bytes(8, 16, 64, 64, 64, 1, 0, 0) == fwd
     f72 = lib.mhla_blockmix_fwd_ws_bytes(8, 16, 64, 64, 72, 0, 0, 0)
-    assert lib.mhla_blockmix_fwd_ws_bytes(8, 16, 64, 64, 72, 1, 0, 0) == f72 + 8 * 4096 * 16 * 72 * 2
+    assert f72 == 2 * rows * (5184 + 288) * 4 + small(64, 64, 72)
+    assert lib.mhla_blockmix_fwd_ws_bytes(8, 16, 64, 64, 72, 1, 0, 0) == 2 * rows * (2592 + 4 + 288) * 4 + small(64, 64, 72) + 8 * 4096 * 16 * 72 * 2
     assert lib.mhla_blockmix_fwd_ws_bytes(8, 16, 64, 64, 64, 1, 0, _lib.FLAG_BF16_SUMMARIES) < 0.6 * fwd
     assert lib.mhla_blockmix_fwd_ws_bytes(8, 16, 64, 64, 64, 0, 0, _lib.FLAG_BF16_SUMMARIES) == fwd
+    assert lib.mhla_blockmix_fwd_ws_bytes(8, 16, 64, 64, 64, 0, 0, _lib.FLAG_FP32_GRADE_SUMMARIES) == fwd
     assert lib.mhla_blockmix_fwd_keeps_state(8, 16, 64, 64, 64, 1, 0, 0) == 1
     assert 0 < fwd < bwd
     assert lib.mhla_causal_bwd_ws_bytes(1, 8192, 4, 128, 256, 64, 0, 0) > lib.mhla_causal_fwd_ws_bytes(1, 8192, 4, 128, 256, 64, 0, 0) > 0
