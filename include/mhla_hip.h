@@ -77,6 +77,13 @@ enum {
                                         * hi + lo pairs, >= 16 significand bits wherever the reference holds fp32
                                         * (mhla_nlp/fla/ops/mhla/naive.py:39, :60-78). */
 
+#define MHLA_CAUSAL_FP32_GRADE_SUMMARIES 4u /* opt-in: chunk summaries as bf16 hi + lo pairs (>= 16 significand bits, 4 bytes per element: round
+                                        * 5's default).  DEFAULT since ABI 9 on the 16-bit pipeline: S, P, dP, dS are stored as an fp16
+                                        * payload x one power-of-two multiplier per 16-row strip of a 64 x 64 chunk tile -- 11
+                                        * significand bits (TF32 grade), 2 bytes; score tiles and operands stay bf16 hi + lo pairs with
+                                        * fp32 accumulation; <= 4.4e-4 of a result's maximum from the fp32 result
+                                        * (tools/sim_h16_causal.py, tests). */
+
 /* A token-major view [B, N, H, D]: element strides, D contiguous. */
 typedef struct {
     const void* ptr;

@@ -18,6 +18,7 @@ FLAG_NO_BWD_STATE = 16      # forward without a backward to come: skip the state
 FLAG_FP32_GRADE_SUMMARIES = 32   # 16-bit tensors: block summaries with >= 16 significand bits (default: 11, fp16 payload x row multiplier)
 CAUSAL_FORCE_GENERIC = 1
 CAUSAL_BF16_SUMMARIES = 2
+CAUSAL_FP32_GRADE_SUMMARIES = 4   # chunk summaries as bf16 hi + lo pairs (default: h16, 11 significand bits in 2 bytes)
 
 
 class View(Structure):

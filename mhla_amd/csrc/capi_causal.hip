@@ -21,22 +21,24 @@ struct CsWs {
 //   (the mixing kernels keep every chunk of a sequence resident: 16 waves of 16 chunks); hl: summaries and score tiles as bf16 hi + lo pairs (the
 //   reference's fp32 arithmetic, default), !hl: single bf16 (MHLA_CAUSAL_BF16_SUMMARIES);
 //   everything else: the generic kernels (causal.hpp: exact fp32 MFMA, fp32 summaries).
-struct CsPath { bool pipe16, hl; int esz; };   // esz: bytes per logical summary element
+struct CsPath { bool pipe16; int hl, esz; };   // hl: the summaries' format on the 16-bit pipeline (causal_bf16.hpp: 0 single bf16, 1 bf16 hi + lo, 2 h16); esz: bytes per logical summary element
 CsPath cs_path(int T, int K, int V, int chunk, int dtype, unsigned flags) {
     CsPath p{};
     p.esz = 4;
     if (chunk <= 0) return p;   // (the size / capability queries reach this before cs_check: the generic path, no division by zero)
     const int n = (T + chunk - 1) / chunk;
     p.pipe16 = dtype == MHLA_BF16 && (K & 63) == 0 && (V & 63) == 0 && K <= 256 && n <= 256 && !(flags & MHLA_CAUSAL_FORCE_GENERIC);
-    p.hl = p.pipe16 && !(flags & MHLA_CAUSAL_BF16_SUMMARIES);
-    p.esz = p.pipe16 && !p.hl ? 2 : 4;
+    // default: h16 (fp16 payload x a multiplier per 16-row strip of a chunk tile: 11 significand bits, 2 bytes); opt-in: hi + lo pairs
+    // (>= 16 bits, 4 bytes: MHLA_CAUSAL_FP32_GRADE_SUMMARIES) or single bf16 (reduced precision: MHLA_CAUSAL_BF16_SUMMARIES)
+    p.hl = !p.pipe16 ? 0 : (flags & MHLA_CAUSAL_BF16_SUMMARIES) ? 0 : (flags & MHLA_CAUSAL_FP32_GRADE_SUMMARIES) ? 1 : 2;
+    p.esz = p.pipe16 && p.hl != 1 ? 2 : 4;
     return p;
 }
 // Launch plan of the resident-sequence mixing kernels (causal_mix.hpp): waves per workgroup (16 chunks each), workgroups and
 // slices per workgroup.  Forward: two workgroups per CU at 8 waves (70-74 KB of LDS each), four / eight at 4 / 2 waves;
 // backward: one workgroup of 16 waves per CU (104-111 KB), two / four at 8 / 4.
 struct Mix2Plan { int nw, te, wgs, spw; long total; };
-Mix2Plan mix2_plan(size_t bh, int n, long E, bool bwd, bool hl) {
+Mix2Plan mix2_plan(size_t bh, int n, long E, bool bwd, bool hl) {   // hl: two planes per slice row in LDS (format 1)
     Mix2Plan p{};
     p.nw = n <= 32 ? 2 : n <= 64 ? 4 : n <= 128 ? 8 : 16;
     p.te = (hl ? 64 : 128) / (p.nw > 8 ? 2 : 1);
@@ -56,7 +58,7 @@ CsWs cs_carve(void* ws, int B, int T, int H, int K, int V, int chunk, const CsPa
     if (chunk <= 0) { CsWs z{}; return z; }
     const size_t bh = (size_t)B * H, n = (size_t)(T + chunk - 1) / chunk;
     const size_t st = path.pipe16 ? al4((bh * (size_t)fast::cs_layout((int)n, (long)K * V, path.esz / 2).bhs + 1) / 2) : al4(bh * n * K * V);
-    const size_t parts = std::max(bh * DW_MAX_SPLIT, path.pipe16 ? (size_t)mix2_plan(bh, (int)n, (long)K * V, true, path.hl).wgs : (size_t)0);
+    const size_t parts = std::max(bh * DW_MAX_SPLIT, path.pipe16 ? (size_t)mix2_plan(bh, (int)n, (long)K * V, true, path.hl == 1).wgs : (size_t)0);
     float* p = (float*)ws;
     CsWs w;
     w.S = p; p += st;
@@ -74,7 +76,8 @@ int cs_check(int B, int T, int H, int K, int V, int chunk, int dtype, unsigned f
     if (chunk != 64) return fail(MHLA_ENOTSUP, "chunk=%d: only 64 is supported", chunk);
     if ((K | V) & 3) return fail(MHLA_EINVAL, "K=%d and V=%d must be multiples of 4", K, V);
     if (dtype < 0 || dtype > 2) return fail(MHLA_EINVAL, "unknown dtype %d", dtype);
-    if (flags & ~(MHLA_CAUSAL_FORCE_GENERIC | MHLA_CAUSAL_BF16_SUMMARIES)) return fail(MHLA_EINVAL, "unknown causal flags 0x%x", flags);
+    if (flags & ~(MHLA_CAUSAL_FORCE_GENERIC | MHLA_CAUSAL_BF16_SUMMARIES | MHLA_CAUSAL_FP32_GRADE_SUMMARIES)) return fail(MHLA_EINVAL, "unknown causal flags 0x%x", flags);
+    if ((flags & MHLA_CAUSAL_BF16_SUMMARIES) && (flags & MHLA_CAUSAL_FP32_GRADE_SUMMARIES)) return fail(MHLA_EINVAL, "MHLA_CAUSAL_BF16_SUMMARIES and MHLA_CAUSAL_FP32_GRADE_SUMMARIES exclude each other");
     if ((size_t)B * H > 65535) return fail(MHLA_ENOTSUP, "B*H=%zu exceeds grid limit 65535", (size_t)B * H);
     return MHLA_OK;
 }
@@ -91,7 +94,7 @@ int cs_xty(const mhla_view& x, const mhla_view& y, float* out, float alpha, int 
 }
 
 // chunk summaries X^T Y of the 16-bit pipeline (S = K^T V, dP = scale Q^T dO)
-template <bool HL>
+template <int HL>
 int cs_state16(const mhla_view& x, const mhla_view& y, uint16_t* out, float mul, int B, int T, int H, int n, int K, int V, hipStream_t st) {
     fast::CsfStateArgs s{cv(x), cv(y), out, H, n, K, V, (long)T, mul};
     const int blocks = ((K + fast::ST2_KW - 1) / fast::ST2_KW) * ((V + fast::ST2_VW - 1) / fast::ST2_VW);
@@ -100,16 +103,16 @@ int cs_state16(const mhla_view& x, const mhla_view& y, uint16_t* out, float mul,
 }
 
 // P = strictly-lower mix of S
-template <bool HL>
+template <int HL>
 int cs_mix_fwd(const float* mix, int ldmix, const uint16_t* S, uint16_t* P, int BH, int n, long E, hipStream_t st) {
-    const Mix2Plan pl = mix2_plan((size_t)BH, n, E, false, HL);
+    const Mix2Plan pl = mix2_plan((size_t)BH, n, E, false, HL == 1);
     fast::CsfMix2Args mf{mix, ldmix, S, nullptr, P, nullptr, n, E, pl.total, pl.spw};
 #define MIXF(NW) launch(fast::k_csf_mixf<NW, HL>, dim3(pl.wgs), dim3(64 * NW), fast::mixf_smem<NW, HL>(), st, "k_csf_mixf", mf)
     return pl.nw == 2 ? MIXF(2) : pl.nw == 4 ? MIXF(4) : pl.nw == 8 ? MIXF(8) : MIXF(16);
 #undef MIXF
 }
 
-template <bool HL>
+template <int HL>
 int cs_fwd16(const mhla_view& q, const mhla_view& k, const mhla_view& v, const float* mix, int ldmix, const mhla_mview& out,
              const CsWs& w, int B, int T, int H, int K, int V, int n, float scale, hipStream_t st, bool epi, const float* nw,
              float neps, const mhla_view& gate, const mhla_mview& y) {
@@ -130,7 +133,7 @@ int cs_fwd16(const mhla_view& q, const mhla_view& k, const mhla_view& v, const f
     return MHLA_OK;
 }
 
-template <bool HL>
+template <int HL>
 int cs_bwd16(const mhla_view& q, const mhla_view& k, const mhla_view& v, const float* mix, int ldmix, const mhla_view& dout,
              const mhla_mview& dq, const mhla_mview& dk, const mhla_mview& dv, float* dmix, int lddmix, const CsWs& w, bool have_fwd,
              int B, int T, int H, int K, int V, int n, float scale, hipStream_t st) {
@@ -142,7 +145,7 @@ int cs_bwd16(const mhla_view& q, const mhla_view& k, const mhla_view& v, const f
     }
     RC(cs_state16<HL>(q, dout, dP, scale, B, T, H, n, K, V, st));
     // dS and the dmix partials from one pass over dP and S
-    const Mix2Plan pl = mix2_plan((size_t)B * H, n, E, true, HL);
+    const Mix2Plan pl = mix2_plan((size_t)B * H, n, E, true, HL == 1);
     fast::CsfMix2Args mb{mix, ldmix, dP, S, dS, w.dwp, n, E, pl.total, pl.spw};
 #define MIXB(NW) launch(fast::k_csf_mixb<NW, HL>, dim3(pl.wgs), dim3(128 * NW), fast::mixb_smem<NW, HL>(), st, "k_csf_mixb", mb)
     if (pl.nw <= 8) {
@@ -188,8 +191,9 @@ int cs_fwd_impl(mhla_view q, mhla_view k, mhla_view v, const float* mix, int ldm
     if (((uintptr_t)ws) % 16) return fail(MHLA_EINVAL, "workspace not 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     if (path.pipe16)
-        return path.hl ? cs_fwd16<true>(q, k, v, mix, ldmix, out, w, B, T, H, K, V, n, scale, st, epi, nw, neps, gate, y)
-                       : cs_fwd16<false>(q, k, v, mix, ldmix, out, w, B, T, H, K, V, n, scale, st, epi, nw, neps, gate, y);
+        return path.hl == 2 ? cs_fwd16<2>(q, k, v, mix, ldmix, out, w, B, T, H, K, V, n, scale, st, epi, nw, neps, gate, y)
+             : path.hl == 1 ? cs_fwd16<1>(q, k, v, mix, ldmix, out, w, B, T, H, K, V, n, scale, st, epi, nw, neps, gate, y)
+                            : cs_fwd16<0>(q, k, v, mix, ldmix, out, w, B, T, H, K, V, n, scale, st, epi, nw, neps, gate, y);
     const long E = (long)K * V;
     DISPATCH_T(dtype, {
         RC(cs_xty<ET>(k, v, w.S, 1.f, B, T, H, n, K, V, st));
@@ -252,8 +256,9 @@ int mhla_causal_bwd(mhla_view q, mhla_view k, mhla_view v, const float* mix, int
     }
     hipStream_t st = (hipStream_t)stream;
     if (path.pipe16)
-        return path.hl ? cs_bwd16<true>(q, k, v, mix, ldmix, dout, dq, dk, dv, dmix, lddmix, w, fwd_ws != nullptr, B, T, H, K, V, n, scale, st)
-                       : cs_bwd16<false>(q, k, v, mix, ldmix, dout, dq, dk, dv, dmix, lddmix, w, fwd_ws != nullptr, B, T, H, K, V, n, scale, st);
+        return path.hl == 2 ? cs_bwd16<2>(q, k, v, mix, ldmix, dout, dq, dk, dv, dmix, lddmix, w, fwd_ws != nullptr, B, T, H, K, V, n, scale, st)
+             : path.hl == 1 ? cs_bwd16<1>(q, k, v, mix, ldmix, dout, dq, dk, dv, dmix, lddmix, w, fwd_ws != nullptr, B, T, H, K, V, n, scale, st)
+                            : cs_bwd16<0>(q, k, v, mix, ldmix, dout, dq, dk, dv, dmix, lddmix, w, fwd_ws != nullptr, B, T, H, K, V, n, scale, st);
     const long E = (long)K * V;
     const int tiles = (n + 63) / 64;
     const int nsplit = dw_splits(tiles * tiles * B * H, E);

@@ -11,6 +11,13 @@
 // HL = false is the reduced-precision variant (one bf16 rounding per intermediate: half the summary traffic, 2-3e-3 of the
 // result's maximum), selected only by MHLA_CAUSAL_BF16_SUMMARIES.
 //
+// HL = 2 (round 6, the default): the SUMMARIES S, P, dP, dS are stored in the h16 format (common.hpp) -- one plane of fp16 payload per
+// 64 x 64 tile and chunk, one power-of-two multiplier per 16-row strip of the tile (four floats right behind the plane, in the chunk
+// tile's padding): 11 significand bits, the precision of the reference's TF32 matmuls, in 2 bytes per element instead of 4.  Producers
+// (k_csf_state2) take a strip's multiplier from its measured maximum, the mixing kernels (causal_mix.hpp) from the bound of their inputs';
+// the token kernels decode a tile into the same bf16 hi + lo LDS planes as HL = 1 while committing it, so their products and the
+// score tiles (hi + lo pairs in LDS only) are unchanged.  tools/sim_h16_causal.py: <= 4.4e-4 of a result's maximum.
+//
 // Summary layout in the workspace: tile-major [bh][n][K / 64][V / 64][planes][64][64] bf16, planes = (hi, lo) -- every 64 x 64
 // tile a kernel produces or stages is one contiguous 8 KB block per plane.  The mixing kernels (causal_mix.hpp) are
 // elementwise across chunks and only need to agree on it.
@@ -40,6 +47,11 @@ constexpr int CTE = CS * CS;            // elements per tile plane in the worksp
 // mixing kernels ran 30-40 % SLOWER than in the old layout, from 640 bytes on every padding measured the same (C5 0.72-0.75 ms,
 // the K = 256, V = 512 shape 1.49 -> 1.27-1.29 ms).
 constexpr int CS_CHUNK_PAD = 1088;
+// memory planes / LDS planes of a summary tile per format HL (0: single bf16, 1: bf16 hi + lo, 2: h16 payload)
+__host__ __device__ constexpr int cs_mplanes(int HL) { return HL == 1 ? 2 : 1; }
+__host__ __device__ constexpr int cs_lplanes(int HL) { return HL ? 2 : 1; }
+// h16: the thread's piece of a tile (cs8_issue_state: 16 bytes of row tid >> 3) and the multiplier of that row's 16-row strip
+__device__ __forceinline__ float cs8_issue_mult(const u16* __restrict__ tile, int tid) { return gld<float>(reinterpret_cast<const float*>(tile + CS * CS) + (tid >> 7)); }
 struct CsLayout {
     long bhs, ts, cst;   // bf16 elements from one (b,h) / one tile / one chunk to the next
 };
@@ -166,7 +178,7 @@ __device__ __forceinline__ void cs8_put(u16* __restrict__ dst, const f32x4 (&x)[
         for (int r = 0; r < 4; ++r) dst[(rt * 16 + kg * 4 + r) * LD + ch * 32 + tn * 16 + n] = cvt_bf16(mul * x[tn][r]);
 }
 // one element of a score tile -> its hi (and, HL, lo) plane
-template <int LD, bool HL>
+template <int LD, int HL>
 __device__ __forceinline__ void cs8_put_score(u16* __restrict__ tiles, int row, int col, float x) {
     const int idx = row * LD + col;
     const u16 h = cvt_bf16(x);
@@ -175,8 +187,8 @@ __device__ __forceinline__ void cs8_put_score(u16* __restrict__ tiles, int row, 
 }
 
 // row stride of k_csf_bwd_tok4's tiles: 160 bytes unless its 16-17 tiles (K > 128 with hi + lo pairs) would not fit the 160 KB
-template <int NK, bool HL> __host__ __device__ constexpr int csf_tok4_ld() { return (HL && NK > 2) ? 72 : 80; }
-template <int NK, bool HL>
+template <int NK, int HL> __host__ __device__ constexpr int csf_tok4_ld() { return (HL && NK > 2) ? 72 : 80; }
+template <int NK, int HL>
 __host__ __device__ constexpr int csf_tok4_smem() {
     constexpr int P = HL ? 2 : 1, NB = (NK > 2 || HL) ? 2 : 1;
     return (P + 2 + 2 * NB * P + NK + (NB > 1 ? 1 : 0)) * tile_elems<csf_tok4_ld<NK, HL>()>() * 2 + 32;
@@ -189,9 +201,10 @@ __host__ __device__ constexpr int csf_tok4_smem() {
 // register slots per summary set (and plane) keeps NK rounds of P / dS tiles in flight, the same slots carry the Q / K tiles
 // before step 1 and the Q tiles again for step 3.  DBUF (K > 128, or HL: one workgroup per CU whatever the LDS use): a second
 // set of P / dS buffers and a dV staging tile of its own, so that a round is commit -> ONE barrier -> refill -> multiply.
-template <int NK, bool HL>
+template <int NK, int HL>
 __global__ __launch_bounds__(NT4, (NK <= 2 && !HL) ? 4 : 2) void k_csf_bwd_tok4(const CsTokArgs a) {
-    constexpr int P = HL ? 2 : 1, LD = csf_tok4_ld<NK, HL>(), CT = tile_elems<LD>();
+    constexpr int P = HL ? 2 : 1, MP = cs_mplanes(HL), LD = csf_tok4_ld<NK, HL>(), CT = tile_elems<LD>();   // P: LDS planes, MP: planes in memory
+    constexpr bool H16 = HL == 2;
     constexpr bool DBUF = NK > 2 || HL;
     constexpr int NB = DBUF ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -212,12 +225,25 @@ __global__ __launch_bounds__(NT4, (NK <= 2 && !HL) ? 4 : 2) void k_csf_bwd_tok4(
     auto base = [&](const View& w) { return (const u16*)w.ptr + b * w.sb + h * w.sh; };
     auto mbase = [&](const MView& w) { return (u16*)w.ptr + b * w.sb + h * w.sh; };
     const u16 *qb = base(a.q), *kb = base(a.k), *vb = base(a.v), *gb = base(a.dout);
-    const CsLayout L = cs_layout(a.n, (long)64 * NK * V, P);
+    const CsLayout L = cs_layout(a.n, (long)64 * NK * V, MP);
     const u16* Pb = reinterpret_cast<const u16*>(a.P) + bh * L.bhs + ci * L.cst;
     const u16* dSb = reinterpret_cast<const u16*>(a.dS) + bh * L.bhs + ci * L.cst;
     const float mii = a.mix[(long)ci * a.ldmix + ci];
 
-    uint4 rP[NK][P], rdS[NK][P], nG, nV;
+    uint4 rP[NK][MP], rdS[NK][MP], nG, nV;
+    float mP[H16 ? NK : 1], mdS[H16 ? NK : 1];   // h16: the multiplier of the thread's row strip of each tile in flight
+    // a summary tile from its ring slot into its LDS planes (h16: decoded into hi + lo while it is written)
+    auto commit_sum = [&](u16* dst, const uint4 (&r)[MP], float m) __attribute__((always_inline)) {
+        if constexpr (H16) {
+            uint4 hi, lo;
+            h16_split8(r[0], m, hi, lo);
+            cs8_commit_state<LD>(dst, hi, tid);
+            cs8_commit_state<LD>(dst + CT, lo, tid);
+        } else {
+#pragma unroll
+            for (int p = 0; p < MP; ++p) cs8_commit_state<LD>(dst + p * CT, r[p], tid);
+        }
+    };
 #pragma unroll
     for (int kk = 0; kk < NK; ++kk) {
         cs8_issue_tok(rP[kk][0], qb + kk * 64, a.q.sn, p0, rv, tid);
@@ -234,9 +260,13 @@ __global__ __launch_bounds__(NT4, (NK <= 2 && !HL) ? 4 : 2) void k_csf_bwd_tok4(
         cs8_commit_tok<LD>(KT + kk * CT, rdS[kk][0], rv, tid);
         __syncthreads();
 #pragma unroll
-        for (int p = 0; p < P; ++p) cs8_issue_state(rP[kk][p], Pb + cs_tile_off(kk * 64, 0, V, L.ts) + p * CTE, tid);
+        for (int p = 0; p < MP; ++p) cs8_issue_state(rP[kk][p], Pb + cs_tile_off(kk * 64, 0, V, L.ts) + p * CTE, tid);
 #pragma unroll
-        for (int p = 0; p < P; ++p) cs8_issue_state(rdS[kk][p], dSb + cs_tile_off(kk * 64, 0, V, L.ts) + p * CTE, tid);
+        for (int p = 0; p < MP; ++p) cs8_issue_state(rdS[kk][p], dSb + cs_tile_off(kk * 64, 0, V, L.ts) + p * CTE, tid);
+        if constexpr (H16) {
+            mP[kk] = cs8_issue_mult(Pb + cs_tile_off(kk * 64, 0, V, L.ts), tid);
+            mdS[kk] = cs8_issue_mult(dSb + cs_tile_off(kk * 64, 0, V, L.ts), tid);
+        }
         tile_mma8<LD, false, false>(accA, X1, KT + kk * CT, rt, ch, lane);
         __syncthreads();
     }
@@ -289,10 +319,8 @@ __global__ __launch_bounds__(NT4, (NK <= 2 && !HL) ? 4 : 2) void k_csf_bwd_tok4(
             u16* B1c = B1 + (DBUF && (rr & 1) ? P * CT : 0);
             u16* B2c = B2 + (DBUF && (rr & 1) ? P * CT : 0);
             ++rr;
-#pragma unroll
-            for (int p = 0; p < P; ++p) cs8_commit_state<LD>(B1c + p * CT, rP[kk][p], tid);
-#pragma unroll
-            for (int p = 0; p < P; ++p) cs8_commit_state<LD>(B2c + p * CT, rdS[kk][p], tid);
+            commit_sum(B1c, rP[kk], mP[H16 ? kk : 0]);
+            commit_sum(B2c, rdS[kk], mdS[H16 ? kk : 0]);
             __syncthreads();
             {
                 const int r = tid >> 3, c = (tid & 7) * 8;
@@ -300,9 +328,13 @@ __global__ __launch_bounds__(NT4, (NK <= 2 && !HL) ? 4 : 2) void k_csf_bwd_tok4(
                 const u16* psrc = Pb + cs_tile_off(kk * 64, vn, V, L.ts) + tid * 8;
                 const u16* ssrc = dSb + cs_tile_off(kk * 64, vn, V, L.ts) + tid * 8;
 #pragma unroll
-                for (int p = 0; p < P; ++p) rP[kk][p] = gld<uint4>(last ? qsrc : psrc + p * CTE);
+                for (int p = 0; p < MP; ++p) rP[kk][p] = gld<uint4>(last ? qsrc : psrc + p * CTE);
 #pragma unroll
-                for (int p = 0; p < P; ++p) rdS[kk][p] = gld<uint4>(last ? qsrc : ssrc + p * CTE);   // (filler: the same lines)
+                for (int p = 0; p < MP; ++p) rdS[kk][p] = gld<uint4>(last ? qsrc : ssrc + p * CTE);   // (filler: the same lines)
+                if constexpr (H16) {   // (filler: a word of the same line, never used)
+                    mP[kk] = gld<float>(last ? reinterpret_cast<const float*>(qsrc) : reinterpret_cast<const float*>(psrc - tid * 8 + CTE) + (tid >> 7));
+                    mdS[kk] = gld<float>(last ? reinterpret_cast<const float*>(qsrc) : reinterpret_cast<const float*>(ssrc - tid * 8 + CTE) + (tid >> 7));
+                }
             }
             if (kk == 0) {
                 tile_a8<LD>(aG, X1, rt, lane);
@@ -388,19 +420,20 @@ constexpr int CSF_OUT4_CPW = CSF_OUT4_CPW_;   // chunks per workgroup of k_csf_o
 // NH: halves of the head's V channels that one workgroup of the fused-epilogue variant walks (V = 64 NV NH): with NH = 2 (V = 512)
 // the first half's outputs wait as fp32 in an LDS stash (64 KB) until the row sums of squares of the whole head are known.
 constexpr int CSF_OUT4_LD = 80;   // (8 tiles of 10 KB with hi + lo pairs: two workgroups fill the 160 KB exactly)
-template <int NV, bool EPI, bool HL, int NH = 1>
+template <int NV, bool EPI, int HL, int NH = 1>
 __host__ __device__ constexpr int csf_out4_smem() {
     return (4 + 2 * (HL ? 2 : 1)) * tile_elems<CSF_OUT4_LD>() * 2 + (EPI ? 2 * 64 * 4 : 0) + (NH > 1 ? (NH - 1) * 64 * 64 * NV * 4 : 0);
 }
 
 // (HL with four V slices per workgroup -- the fused epilogue at V = 256 -- holds 32 ring and 32 accumulator registers beside the
 //  operands: one workgroup per CU on 256 VGPRs instead of 20 spilled registers at 128)
-template <int NV, bool EPI, bool HL, int NH = 1>
+template <int NV, bool EPI, int HL, int NH = 1>
 #ifndef CSF_OUT4_NV4_WAVES
 #define CSF_OUT4_NV4_WAVES 4   // four slices with hi + lo pairs: two workgroups per CU at 128 VGPRs and 4 spilled registers (98 us at C5)
 #endif                         // beat one workgroup at 134 (107 us) and two slices per workgroup, which read Q and K twice (108-112 us)
 __global__ __launch_bounds__(NT4, NH > 1 ? 2 : (HL && NV == 4) ? (EPI ? 2 : CSF_OUT4_NV4_WAVES) : 4) void k_csf_out4(const CsOutArgs a) {   // (NH > 1: 138 KB of LDS, one workgroup per CU anyway)
-    constexpr int P = HL ? 2 : 1, LD = CSF_OUT4_LD, CT = tile_elems<LD>();
+    constexpr int P = HL ? 2 : 1, MP = cs_mplanes(HL), LD = CSF_OUT4_LD, CT = tile_elems<LD>();   // P: LDS planes, MP: planes in memory
+    constexpr bool H16 = HL == 2;
     static_assert(NH == 1 || EPI, "only the fused-epilogue variant walks several halves of the head");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u16* Qs = reinterpret_cast<u16*>(smem_raw);
@@ -413,7 +446,7 @@ __global__ __launch_bounds__(NT4, NH > 1 ? 2 : (HL && NV == 4) ? (EPI ? 2 : CSF_
     const int V = a.V, nks = a.K / 64;
     const u16* qb = (const u16*)a.q.ptr + b * a.q.sb + h * a.q.sh;
     const u16* kb = (const u16*)a.k.ptr + b * a.k.sb + h * a.k.sh;
-    const CsLayout L = cs_layout(a.n, (long)a.K * V, P);
+    const CsLayout L = cs_layout(a.n, (long)a.K * V, MP);
     float ss[4] = {0.f, 0.f, 0.f, 0.f};   // (EPI) row sums of squares over the halves walked so far
 #pragma unroll 1
     for (int hv = 0; hv < NH; ++hv) {
@@ -427,7 +460,8 @@ __global__ __launch_bounds__(NT4, NH > 1 ? 2 : (HL && NV == 4) ? (EPI ? 2 : CSF_
     // the score tile's buffer: the P buffer that the last round (nks NV - 1) does not read
     u16* Ao = Ps + ((((nks * NV - 1) & 1) ^ 1)) * P * CT;
 
-    uint4 rQ, rK, rP[NV][P];
+    uint4 rQ, rK, rP[NV][MP];
+    float mP[H16 ? NV : 1];   // h16: the multiplier of the thread's row strip of each P tile in flight
     {
         const long trow0 = row_of(c0);
         rQ = gld<uint4>(qb + trow0 * a.q.sn + tc);
@@ -437,7 +471,11 @@ __global__ __launch_bounds__(NT4, NH > 1 ? 2 : (HL && NV == 4) ? (EPI ? 2 : CSF_
 #pragma unroll
         for (int j = 0; j < NV; ++j)
 #pragma unroll
-            for (int p = 0; p < P; ++p) cs8_issue_state(rP[j][p], Pb0 + cs_tile_off(0, vbase + 64 * j, V, L.ts) + p * CTE, tid);
+            for (int p = 0; p < MP; ++p) cs8_issue_state(rP[j][p], Pb0 + cs_tile_off(0, vbase + 64 * j, V, L.ts) + p * CTE, tid);
+        if constexpr (H16) {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) mP[j] = cs8_issue_mult(Pb0 + cs_tile_off(0, vbase + 64 * j, V, L.ts), tid);
+        }
         __builtin_amdgcn_sched_barrier(0);
     }
     for (int ci = c0; ci < c1; ++ci) {
@@ -468,8 +506,15 @@ __global__ __launch_bounds__(NT4, NH > 1 ? 2 : (HL && NV == 4) ? (EPI ? 2 : CSF_
                 cs8_commit_tok<LD>(Qc, rQ, rv, tid);
                 cs8_commit_tok<LD>(Kc, rK, rv, tid);
             }
+            if constexpr (H16) {   // (decoded into the hi + lo planes while it is written)
+                uint4 hi, lo;
+                h16_split8(rP[j][0], mP[j], hi, lo);
+                cs8_commit_state<LD>(Pc, hi, tid);
+                cs8_commit_state<LD>(Pc + CT, lo, tid);
+            } else {
 #pragma unroll
-            for (int p = 0; p < P; ++p) cs8_commit_state<LD>(Pc + p * CT, rP[j][p], tid);
+                for (int p = 0; p < MP; ++p) cs8_commit_state<LD>(Pc + p * CT, rP[j][p], tid);
+            }
             __syncthreads();
             if (j == 0) {   // the next K slice's tiles -- behind the last K slice: the next chunk's first
                 const long rown = lastk ? trown : trow;
@@ -481,7 +526,8 @@ __global__ __launch_bounds__(NT4, NH > 1 ? 2 : (HL && NV == 4) ? (EPI ? 2 : CSF_
                 const u16* psrc = Pb + cs_tile_off(kn * 64, vbase + 64 * j, V, L.ts) + tid * 8;
                 const u16* vsrc = vb + 64 * j + trow * a.v.sn + tc;   // second phase's V rows (lo slot: the same lines, never used)
 #pragma unroll
-                for (int p = 0; p < P; ++p) rP[j][p] = gld<uint4>(lastk ? vsrc : psrc + p * CTE);
+                for (int p = 0; p < MP; ++p) rP[j][p] = gld<uint4>(lastk ? vsrc : psrc + p * CTE);
+                if constexpr (H16) mP[j] = gld<float>(lastk ? reinterpret_cast<const float*>(vsrc) : reinterpret_cast<const float*>(psrc - tid * 8 + CTE) + (tid >> 7));
             }
             if (j == 0) {
                 tile_a8<LD>(aQ, Qc, rt, lane);
@@ -507,7 +553,8 @@ __global__ __launch_bounds__(NT4, NH > 1 ? 2 : (HL && NV == 4) ? (EPI ? 2 : CSF_
             cs8_commit_tok<LD>(Vc, rP[j][0], rv, tid);
             __syncthreads();
 #pragma unroll
-            for (int p = 0; p < P; ++p) cs8_issue_state(rP[j][p], Pbn + cs_tile_off(0, vbase + 64 * j, V, L.ts) + p * CTE, tid);   // the next chunk's first P tiles
+            for (int p = 0; p < MP; ++p) cs8_issue_state(rP[j][p], Pbn + cs_tile_off(0, vbase + 64 * j, V, L.ts) + p * CTE, tid);   // the next chunk's first P tiles
+            if constexpr (H16) mP[j] = cs8_issue_mult(Pbn + cs_tile_off(0, vbase + 64 * j, V, L.ts), tid);
 #pragma unroll
             for (int p = 0; p < P; ++p) tile_mma8<LD, false, true>(accO[j], Ao + p * CT, Vc, rt, ch, lane);        // tril(QK^T) V
             cs8_put<LD>(Oc, accO[j], a.scale, rt, ch, lane);
@@ -614,12 +661,12 @@ struct CsfStateArgs {
     float mul;
 };
 constexpr int ST2_KW = 128, ST2_VW = 256, ST2_LDX = ST2_KW + 8, ST2_LDY = ST2_VW + 8;
-template <bool HL> __host__ __device__ constexpr int csf_state2_smem() { return (CS * ST2_LDX + CS * ST2_LDY + 4 * (HL ? 2 : 1) * 16 * CLD) * 2; }
+template <int HL> __host__ __device__ constexpr int csf_state2_smem() { return (CS * ST2_LDX + CS * ST2_LDY + 4 * cs_mplanes(HL) * 16 * CLD) * 2; }
 constexpr int ST2_CPW = 4;
 
-template <bool HL>
+template <int HL>
 __global__ __launch_bounds__(NTHREADS, 2) void k_csf_state2(const CsfStateArgs a) {
-    constexpr int P = HL ? 2 : 1;
+    constexpr int P = cs_mplanes(HL);   // planes written
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u16* Xs = reinterpret_cast<u16*>(smem_raw);
     u16* Ys = Xs + CS * ST2_LDX;
@@ -683,13 +730,30 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_csf_state2(const CsfStateArgs a
                         acc[tn] = mfma_bf16(tr_read8(Ys, ST2_LDY, 0, vt * 64 + tn * 16, lane), xa0, acc[tn]);
                         acc[tn] = mfma_bf16(tr_read8(Ys, ST2_LDY, 32, vt * 64 + tn * 16, lane), xa1, acc[tn]);
                     }
+                    if constexpr (HL == 2) {
+                        // h16: the strip's multiplier from its largest magnitude (the wave holds the whole 16 x 64 strip), the payload as fp16
+                        float mx = 0.f;
+#pragma unroll
+                        for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, fabsf(acc[tn][r]));
+#pragma unroll
+                        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+                        const float hm = h16_mult_from_max(fabsf(a.mul) * mx), hs = a.mul * h16_inv(hm);
+#pragma unroll
+                        for (int tn = 0; tn < 4; ++tn)
+                            *reinterpret_cast<uint2*>(Ws + nl * CLD + tn * 16 + kg * 4) = make_uint2(h16_pack2(hs * acc[tn][0], hs * acc[tn][1]), h16_pack2(hs * acc[tn][2], hs * acc[tn][3]));
+                        if (lane == 0)
+                            gst<float>(reinterpret_cast<float*>(ob + cs_tile_off(k0 + rt * 16, v0 + vt * 64, a.V, L.ts) + CTE) + (rt & 3), hm);
+                    } else {
 #pragma unroll
                     for (int tn = 0; tn < 4; ++tn) {
                         unsigned h0, h1, l0, l1;
                         split_pack2(a.mul * acc[tn][0], a.mul * acc[tn][1], h0, l0);
                         split_pack2(a.mul * acc[tn][2], a.mul * acc[tn][3], h1, l1);
                         *reinterpret_cast<uint2*>(Ws + nl * CLD + tn * 16 + kg * 4) = make_uint2(h0, h1);
-                        if constexpr (HL) *reinterpret_cast<uint2*>(Ws + 16 * CLD + nl * CLD + tn * 16 + kg * 4) = make_uint2(l0, l1);
+                        if constexpr (HL == 1) *reinterpret_cast<uint2*>(Ws + 16 * CLD + nl * CLD + tn * 16 + kg * 4) = make_uint2(l0, l1);
+                    }
                     }
                     wave_lds_fence();
                     // a store instruction covers eight full 128-byte rows (two half rows per lane pair made it 16 half lines)

@@ -145,6 +145,46 @@ template <typename T> __device__ __forceinline__ uint2 store_residual4(f32x4 x) 
                       pack_bf16x2(x[2] - stored_value<T>(x[2]), x[3] - stored_value<T>(x[3])));
 }
 
+// h16: a 2-byte storage format of block / chunk summaries -- an fp16 payload x one power-of-two multiplier per group (a block row of
+// the block-mixing operator, split.hpp; a 16 x 64 strip of a chunk tile of the causal operator, causal_bf16.hpp): 11 significand bits.
+// decode multiplier of a row whose largest magnitude is mx: 2^(floor(log2 mx) - 14), exponent field clamped to [1, 240]
+__device__ __forceinline__ float h16_mult_from_max(float mx) {
+    const unsigned e = (__float_as_uint(mx) >> 23) & 0xffu;
+    return __uint_as_float((e < 15u ? 1u : (e > 254u ? 240u : e - 14u)) << 23);
+}
+// ... of a row bounded by 2^15 beta: the power of two >= beta, field clamped to [1, 253]
+__device__ __forceinline__ float h16_mult_from_bound(float beta) {
+    unsigned f = (__float_as_uint(beta) + 0x7fffffu) >> 23;
+    f = f < 1u ? 1u : (f > 253u ? 253u : f);
+    return __uint_as_float(f << 23);
+}
+__device__ __forceinline__ float h16_inv(float m) { return __uint_as_float(0x7f000000u - __float_as_uint(m)); }   // 1 / m, exact (field 254 - f)
+typedef _Float16 h16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned h16_pack2(float a, float b) {
+    const h16x2_t h = {(_Float16)a, (_Float16)b};   // (round to nearest even)
+    return __builtin_bit_cast(unsigned, h);
+}
+// 8 values -> their 16-byte payload piece (inv = 1 / m)
+__device__ __forceinline__ uint4 h16_pack8(const f32x4& a, const f32x4& b, float inv) {
+    return make_uint4(h16_pack2(a[0] * inv, a[1] * inv), h16_pack2(a[2] * inv, a[3] * inv), h16_pack2(b[0] * inv, b[1] * inv), h16_pack2(b[2] * inv, b[3] * inv));
+}
+// the bf16 hi / lo operands of 8 stored values: x = payload * m, hi = its top 16 bits, lo = x - hi (<= 3 significant bits: exact)
+__device__ __forceinline__ void h16_split8(const uint4& pay, float m, uint4& hi, uint4& lo) {
+    const unsigned w[4] = {pay.x, pay.y, pay.z, pay.w};
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const h16x2_t p = __builtin_bit_cast(h16x2_t, w[j]);
+        const float x0 = (float)p[0] * m, x1 = (float)p[1] * m;
+        const unsigned u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
+        h[j] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+        const float d0 = x0 - __uint_as_float(u0 & 0xffff0000u), d1 = x1 - __uint_as_float(u1 & 0xffff0000u);
+        l[j] = __builtin_amdgcn_perm(__float_as_uint(d1), __float_as_uint(d0), 0x07060302u);
+    }
+    hi = make_uint4(h[0], h[1], h[2], h[3]);
+    lo = make_uint4(l[0], l[1], l[2], l[3]);
+}
+
 // Token-major view [B, N, H, D]; element strides; D contiguous.
 struct View {
     const void* ptr;

@@ -61,6 +61,10 @@ constexpr int FT8 = 512;       // 8-wave workgroups of the streaming kernels: <=
 __device__ __forceinline__ f32x4 mfma_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
+// ... on fp16 operands (the h16 summary payloads, common.hpp): same shapes and lane layout
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x4 mfma_f16(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f16x8 as_f16x8(const bf16x8& v) { return __builtin_bit_cast(f16x8, v); }
 
 // MFMA operand from a row-major LDS tile T[k][c] (k = reduction index): lane (c = lane & 15, g = lane >> 4)
 // receives T[k0 + 8 g + 0..7][c0 + c].  Two hardware transpose reads of a 4 x 16 block each.

@@ -20,9 +20,9 @@
 namespace mhla {
 namespace sp {
 
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ f32x4 mfma_f16(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
-__device__ __forceinline__ f16x8 as_f16x8(const bf16x8& v) { return __builtin_bit_cast(f16x8, v); }
+using fast::f16x8;
+using fast::mfma_f16;
+using fast::as_f16x8;
 
 constexpr int MIXH_TE = 128, MIXH_TEZ = 64;
 template <int NW, bool DW>

@@ -157,13 +157,13 @@ class MHLA(nn.Module):
                  use_output_gate: bool = True, gate_fn: str = "swish", elementwise_affine: Optional[bool] = True,
                  norm_eps: float = 1e-5, gate_logit_normalizer: int = 16, gate_low_rank_dim: int = 16,
                  clamp_min: Optional[float] = None, fuse_norm: bool = True, layer_idx: int = None, max_chunks: int = 32,
-                 summaries: str = "split"):
+                 summaries: str = "tf32"):
         """`max_chunks` (not in the reference, default = its hard-coded 32): side of the mixing matrix, i.e. the longest
         sequence is 64 * max_chunks tokens -- 128 for the 8192-token configuration of BASELINE.json configs[4], which the
         reference layer itself cannot run (layers/mhla.py:196-200); the operator accepts any [n, n] matrix (naive.py:55).
-        `summaries` (not in the reference): "split" (default) keeps the operator's chunk summaries at the reference's fp32
-        arithmetic (bf16 hi + lo pairs, naive.py:39); "bf16" opts into the reduced-precision variant (half the summary traffic,
-        2-3e-3 of the output's maximum) -- see mhla_amd.mhla_causal."""
+        `summaries` (not in the reference): "tf32" (default) stores the operator's chunk summaries with 11 significand bits in 2
+        bytes (the precision of the reference's TF32 matmuls), "split" with >= 16 bits in 4 bytes (bf16 hi + lo pairs, naive.py:39);
+        "bf16" opts into the reduced-precision variant (2-3e-3 of the output's maximum) -- see mhla_amd.mhla_causal."""
         super().__init__()
         self.mode = mode
         self.hidden_size = hidden_size

@@ -917,21 +917,25 @@ class _Causal(torch.autograd.Function):
 def _causal_flags(summaries: str, force_generic: bool) -> int:
     if summaries not in SUMMARIES:
         raise ValueError(f"summaries={summaries!r}: 'tf32' / 'split' (bf16 hi + lo pairs, the reference's fp32 arithmetic) or 'bf16'")
-    return (_lib.CAUSAL_BF16_SUMMARIES if summaries == "bf16" else 0) | (_lib.CAUSAL_FORCE_GENERIC if force_generic else 0)
+    return ((_lib.CAUSAL_BF16_SUMMARIES if summaries == "bf16" else 0) | (_lib.CAUSAL_FP32_GRADE_SUMMARIES if summaries == "split" else 0)
+            | (_lib.CAUSAL_FORCE_GENERIC if force_generic else 0))
 
 
 def mhla_causal(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mixing_matrix: torch.Tensor,
-                chunk_size: int = 64, scale: Optional[float] = None, *, summaries: str = "split",
+                chunk_size: int = 64, scale: Optional[float] = None, *, summaries: str = "tf32",
                 force_generic: bool = False, keep_state_limit: Optional[int] = None) -> torch.Tensor:
     """Causal chunk-mixing MHLA operator (naive_chunk_simple_mhla_fixed,
     mhla_nlp/fla/ops/mhla/naive.py:10-83).  q, k: [B, T, H, K]; v: [B, T, H, V];
     mixing_matrix: [L, L] or [L, L, 1, 1, 1, 1], L >= ceil(T / chunk_size).  fp32 compute, output in
     the dtype of q; `scale` defaults to K**-0.5 as in the reference (naive.py:42).
-    summaries: how bf16 problems keep the chunk summaries S, P, dP, dS and the score tiles between their two contractions --
-    "split" (default): bf16 hi + lo pairs, >= 16 significand bits, the reference's fp32 arithmetic (naive.py:39, :60-78);
-    "bf16": one bf16 value each -- REDUCED PRECISION (2-3e-3 of the result's maximum), half the summary traffic.
+    summaries: how bf16 problems keep the chunk summaries S, P, dP, dS between their two contractions (score tiles and operands are
+    bf16 hi + lo pairs with fp32 accumulation in every case but "bf16") -- "tf32" (default): STORED with 11 significand bits (fp16
+    payload x one power-of-two multiplier per 16-row strip of a chunk tile, 2 bytes per element), the precision of the reference's
+    matmuls under allow_tf32; within one final rounding + 1e-3 of the fp32 result (observed 4e-4); "split": bf16 hi + lo pairs,
+    >= 16 significand bits (naive.py:39, :60-78; 4 bytes per element); "bf16": one bf16 value each, score tiles too -- REDUCED
+    PRECISION (2-3e-3 of the result's maximum).
     force_generic: testing aid -- the generic fp32-MFMA kernels for every shape.
-    keep_state_limit: largest forward workspace (bytes: the chunk summaries S, P -- 8 B T H K V / 64 bytes with hi + lo pairs)
+    keep_state_limit: largest forward workspace (bytes: the chunk summaries S, P -- 4 B T H K V / 64 bytes at the default, 8 with hi + lo pairs)
     kept alive for the backward; above it the backward recomputes them.  Default: ops.CAUSAL_KEEP_STATE_LIMIT_BYTES
     (set_keep_state_limits)."""
     if q.dim() != 4 or v.dim() != 4:
@@ -1041,7 +1045,7 @@ def causal_normgate_fusable(q: torch.Tensor, v: torch.Tensor, chunk_size: int = 
 
 def mhla_causal_normgate(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mixing_matrix: torch.Tensor,
                          gate: Optional[torch.Tensor], weight: Optional[torch.Tensor], norm_eps: float = 1e-5,
-                         chunk_size: int = 64, scale: Optional[float] = None, *, summaries: str = "split",
+                         chunk_size: int = 64, scale: Optional[float] = None, *, summaries: str = "tf32",
                          keep_state_limit: Optional[int] = None) -> torch.Tensor:
     """`rmsnorm_gate(mhla_causal(q, k, v, mix), gate, weight, norm_eps)` -- the fla layer's operator + FusedRMSNormGated
     (mhla_nlp/fla/layers/mhla.py:330-355).  Where the fused epilogue applies (bf16, K, V multiples of 64, K <= 256, V <= 256 or

@@ -19,7 +19,7 @@ def causal_inputs(B, T, H, K, V, L, dtype, seed=1234, random_mix=True):
     return q, k, v, mix, do
 
 
-def causal_tols(dtype, summaries="split"):
+def causal_tols(dtype, summaries="tf32"):
     """(out / dq / dk / dv tolerance, dmix tolerance): one final rounding + 1e-3 at the reference's arithmetic; the reduced
     precision variant carries K = 1 (outputs) / 2 (gradients) bf16 intermediates (gpu_util)."""
     if summaries == "bf16":
@@ -27,14 +27,14 @@ def causal_tols(dtype, summaries="split"):
     return CAUSAL_TOL[dtype], CAUSAL_TOL[dtype], CAUSAL_DMIX_TOL[dtype]
 
 
-def run_causal(B, T, H, K, V, L, dtype, seed=1234, summaries="split"):
+def run_causal(B, T, H, K, V, L, dtype, seed=1234, summaries="tf32"):
     import mhla_amd
     q, k, v, mix, do = causal_inputs(B, T, H, K, V, L, dtype, seed)
     want = orc.causal_fwd(q.float(), k.float(), v.float(), mix)
     wg = orc.causal_bwd(q.float(), k.float(), v.float(), mix, do.float())
     dq, dk, dv, dm = (t.to(DEV).requires_grad_(True) for t in (q, k, v, mix.view(L, L, 1, 1, 1, 1)))
     poison()
-    if summaries == "split":   # the reference's own call form
+    if summaries == "tf32":   # the reference's own call form (the library's default arithmetic)
         out = mhla_amd.naive_chunk_simple_mhla_fixed(q=dq, k=dk, v=dv, mixing_matrix=dm)
     else:
         out = mhla_amd.mhla_causal(dq, dk, dv, dm, summaries=summaries)
@@ -119,6 +119,14 @@ def test_causal_shapes_bf16_reduced_precision_variant(T, K, V):
     run_causal(2, T, 2, K, V, max(4, (T + 63) // 64), torch.bfloat16, seed=T + K, summaries="bf16")
 
 
+@pytest.mark.parametrize("T,K,V", [(256, 64, 64), (1000, 128, 256), (129, 256, 512), (200, 192, 192), (200, 64, 384), (330, 128, 256), (2100, 256, 256),
+                                   (9000, 64, 128)])
+def test_causal_shapes_bf16_hi_lo_summaries(T, K, V):
+    """summaries="split" (MHLA_CAUSAL_FP32_GRADE_SUMMARIES): chunk summaries as bf16 hi + lo pairs (>= 16 significand bits, round 5's
+    default) instead of the 2-byte h16 form, at the same tolerance."""
+    run_causal(2, T, 2, K, V, max(4, (T + 63) // 64), torch.bfloat16, seed=T + K, summaries="split")
+
+
 @pytest.mark.parametrize("T,K,V", [(16400, 64, 64), (300, 320, 64)])
 def test_causal_bf16_beyond_the_pipeline(T, K, V):
     """bf16 tensors outside the 16-bit pipeline's range (more than 256 chunks; K > 256): the generic fp32-MFMA kernels."""
@@ -141,8 +149,9 @@ def test_causal_bf16_pipeline_vs_generic():
     check("dmix", res["fast"][4], res["generic"][4].float().cpu(), 1e-3)
 
 
+@pytest.mark.parametrize("summaries", ["tf32", "split"])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
-def test_causal_kept_summaries_match_recompute(dtype, monkeypatch):
+def test_causal_kept_summaries_match_recompute(dtype, summaries, monkeypatch):
     """The backward reuses the forward's chunk summaries when the workspace is kept; same gradients as recomputing them."""
     import mhla_amd
     from mhla_amd import ops
@@ -151,7 +160,7 @@ def test_causal_kept_summaries_match_recompute(dtype, monkeypatch):
     for limit in (1 << 30, 0):
         monkeypatch.setattr(ops, "CAUSAL_KEEP_STATE_LIMIT_BYTES", limit)
         t = [x.to(DEV).requires_grad_(True) for x in (q, k, v, mix)]
-        mhla_amd.mhla_causal(*t).backward(do.to(DEV))
+        mhla_amd.mhla_causal(*t, summaries=summaries).backward(do.to(DEV))
         res.append([x.grad for x in t])
     for name, a, b in zip(("dq", "dk", "dv", "dmix"), *res):
         assert torch.equal(a, b), name
@@ -299,7 +308,8 @@ def test_rmsnorm_gate(D, dtype, gate):
                                                (512, 128, 192, True, False),
                                                # wide heads: the workgroup walks the head in two halves (V = 512: the 1.3B-like fla shape)
                                                (330, 256, 512, True, True), (200, 64, 384, True, True), (130, 128, 512, False, False)])
-def test_causal_normgate_fused_epilogue(T, K, V, gate, affine):
+@pytest.mark.parametrize("summaries", ["tf32", "split"])
+def test_causal_normgate_fused_epilogue(T, K, V, gate, affine, summaries):
     """N1: per-head RMSNorm x swish gate inside the causal operator's output kernel (mhla_causal_normgate_fwd) vs the oracle's
     composition (causal_fwd -> rms_norm_swish_gate), forward and every gradient; and vs the unfused HIP composition."""
     import mhla_amd
@@ -335,7 +345,7 @@ def test_causal_normgate_fused_epilogue(T, K, V, gate, affine):
     gd = g.to(DEV).requires_grad_(True) if gate else None
     wd = w.to(DEV).requires_grad_(True) if affine else None
     poison()
-    y = mhla_amd.mhla_causal_normgate(dev[0], dev[1], dev[2], dev[3], gd, wd, 1e-5)
+    y = mhla_amd.mhla_causal_normgate(dev[0], dev[1], dev[2], dev[3], gd, wd, 1e-5, summaries=summaries)
     assert y.dtype == torch.bfloat16
     poison()
     y.backward(do.to(DEV))
@@ -351,17 +361,25 @@ def test_causal_normgate_fused_epilogue(T, K, V, gate, affine):
     # bf16 number (the two sides evaluate exp / rsqrt differently in the last fp32 bits), a perturbation of 2u of that element
     # which the reference's own Triton kernel has against eager PyTorch as well.  Observed: <= 1.1e-3 beyond the final rounding
     # (1.0e-3 on dmix over B H = 4 heads); bound: one final rounding + 2e-3, fp32-stored results 2e-3.
+    # summaries="tf32" (the default, 11-bit summaries): the operator's o is delta = 3e-4 of its maximum away from the fp32 result
+    # instead of 1e-5, so delta / u = 8 % of its bf16 elements land on the neighbouring bf16 number instead of 0.3 % -- each a
+    # perturbation of 2u of that element, an rms of sqrt(delta u) = 1.1e-3 on the rounded o that the norm's backward and the
+    # operator's backward then see (any 11-bit arithmetic in front of a bf16 store does this; it is the layered bf16 flow of
+    # layers/mhla.py:330-355, not the operator, that amplifies).  Bound: + 2e-3 on top of the above; dmix, a difference of nearly
+    # equal terms behind a norm (the loss does not depend on the scale of o), 6e-3 (observed 3.7e-3 on four chunks).  The operator
+    # alone is held to one rounding + 1e-3 on the same shapes in test_causal_shapes_bf16.
+    extra = 2e-3 if summaries == "tf32" else 0.0
     for name, a, b in zip(("dq", "dk", "dv"), dev, ref):
-        check(name, a.grad, b.grad, u + 2e-3)
-    check("dmix", dev[3].grad, ref[3].grad, 2e-3)
+        check(name, a.grad, b.grad, u + 2e-3 + extra)
+    check("dmix", dev[3].grad, ref[3].grad, 2e-3 + 2 * extra)
     if gate:
-        check("dgate", gd.grad, gr.grad, u + 2e-3)
+        check("dgate", gd.grad, gr.grad, u + 2e-3 + extra)
     if affine:
-        check("dweight", wd.grad, wr.grad, 2e-3)
+        check("dweight", wd.grad, wr.grad, 2e-3 + extra)
     # the unfused composition of the two HIP operators agrees (same kernels downstream, one more bf16 rounding of o)
     with torch.no_grad():
-        y2 = mhla_amd.rmsnorm_gate(mhla_amd.mhla_causal(dev[0], dev[1], dev[2], dev[3]), gd, wd, 1e-5)
-        y3 = mhla_amd.mhla_causal_normgate(dev[0], dev[1], dev[2], dev[3], gd, wd, 1e-5)   # inference: o is not stored
+        y2 = mhla_amd.rmsnorm_gate(mhla_amd.mhla_causal(dev[0], dev[1], dev[2], dev[3], summaries=summaries), gd, wd, 1e-5)
+        y3 = mhla_amd.mhla_causal_normgate(dev[0], dev[1], dev[2], dev[3], gd, wd, 1e-5, summaries=summaries)   # inference: o is not stored
     check("fused vs unfused", y3, y2.float().cpu(), 3 * u + 1e-3)
     check("inference vs training path", y3, y.detach().float().cpu(), 1e-6)
 
@@ -373,14 +391,15 @@ def test_golden_fla_neighbours_gate():
     check("gated", y, g["gated"], 1e-5)
 
 
-def test_full_size_c5_sampled_head():
+@pytest.mark.parametrize("summaries", ["tf32", "split"])
+def test_full_size_c5_sampled_head(summaries):
     """BASELINE config C5 shape (fla 340M: T = 8192, H = 4, K = 128, V = 256, 128 chunks), bf16: one (b, h) vs the oracle,
     forward and backward."""
     import mhla_amd
     B, T, H, K, V, L = 2, 8192, 4, 128, 256, 128
     q, k, v, mix, do = causal_inputs(B, T, H, K, V, L, torch.bfloat16, seed=8, random_mix=False)
     dq, dk, dv, dm = (t.to(DEV).requires_grad_(True) for t in (q, k, v, mix))
-    out = mhla_amd.mhla_causal(dq, dk, dv, dm)
+    out = mhla_amd.mhla_causal(dq, dk, dv, dm, summaries=summaries)
     out.backward(do.to(DEV))
     b, h = 1, 2
     sl = lambda t: t[b:b + 1, :, h:h + 1].float()
@@ -396,7 +415,8 @@ def test_full_size_c5_sampled_head():
     check("dmix (all heads)", dm.grad, wg_all["dmix"], CAUSAL_DMIX_TOL[torch.bfloat16])
 
 
-def test_full_size_c5_1p3b_like_shape():
+@pytest.mark.parametrize("summaries", ["tf32", "split"])
+def test_full_size_c5_1p3b_like_shape(summaries):
     """The 1.3B-like fla shape of SURVEY.md 8 (K = 256, V = 512, T = 8192, 128 chunks), bf16: every output and gradient of
     one (b, h) and dmix over all heads vs the oracle (the K <= 256 token-gradient kernel with four K slices)."""
     import mhla_amd
@@ -404,7 +424,7 @@ def test_full_size_c5_1p3b_like_shape():
     q, k, v, mix, do = causal_inputs(B, T, H, K, V, L, torch.bfloat16, seed=18, random_mix=True)
     dq, dk, dv, dm = (t.to(DEV).requires_grad_(True) for t in (q, k, v, mix))
     poison()
-    out = mhla_amd.mhla_causal(dq, dk, dv, dm)
+    out = mhla_amd.mhla_causal(dq, dk, dv, dm, summaries=summaries)
     poison()
     out.backward(do.to(DEV))
     want = orc.causal_fwd(q.float(), k.float(), v.float(), mix)

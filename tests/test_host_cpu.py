@@ -49,12 +49,13 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert lib.mhla_blockmix_fwd_keeps_state(8, 16, 64, 64, 64, 1, 0, 0) == 1
     assert 0 < fwd < bwd
     assert lib.mhla_causal_bwd_ws_bytes(1, 8192, 4, 128, 256, 64, 0, 0) > lib.mhla_causal_fwd_ws_bytes(1, 8192, 4, 128, 256, 64, 0, 0) > 0
-    # bf16 tensors: chunk summaries as bf16 hi + lo pairs (as many bytes as fp32); single bf16 only with the opt-in flag
+    # bf16 tensors: chunk summaries in 2 bytes by default (h16), as bf16 hi + lo pairs (as many bytes as fp32) or single bf16 with the opt-in flags
     # (+ 2176 bytes of padding per chunk tile -- 8 tiles of 64 x 64 at K = 128, V = 256 -- and summary set on the 16-bit
     # pipeline: fast::cs_layout)
     f32 = lib.mhla_causal_fwd_ws_bytes(1, 8192, 4, 128, 256, 64, 0, 0)
     pad = 2 * 4 * 128 * 8 * 2176
-    assert lib.mhla_causal_fwd_ws_bytes(1, 8192, 4, 128, 256, 64, 1, 0) == f32 + pad
+    assert lib.mhla_causal_fwd_ws_bytes(1, 8192, 4, 128, 256, 64, 1, _lib.CAUSAL_FP32_GRADE_SUMMARIES) == f32 + pad
+    assert lib.mhla_causal_fwd_ws_bytes(1, 8192, 4, 128, 256, 64, 1, 0) == f32 // 2 + pad      # default: 2-byte h16 summaries (the strip multipliers sit in the padding)
     assert lib.mhla_causal_fwd_ws_bytes(1, 8192, 4, 128, 256, 64, 1, _lib.CAUSAL_BF16_SUMMARIES) == f32 // 2 + pad
     assert lib.mhla_causal_fwd_ws_bytes(1, 8192, 4, 128, 256, 64, 1, _lib.CAUSAL_FORCE_GENERIC) == f32
     # the fused norm x gate epilogue: what the 16-bit pipeline covers with V <= 256

@@ -110,7 +110,7 @@ def _graph_time(step, iters=20):
 
 
 def blockmix_case(name, B, N, H, D, M, dtype, layout, bwd=True, split=False, idx=None, normalize=True, iters=20, graph=False, key=None,
-                  summaries="split"):
+                  summaries="tf32"):
     g = torch.Generator().manual_seed(1)
     mk = lambda relu: ((torch.relu(torch.randn(B, N, H, D, generator=g)) + 1e-6) if relu else torch.randn(B, N, H, D, generator=g)).to(dtype).to(DEV)
     q, k, v, do = mk(True), mk(True), mk(False), mk(False)

@@ -13,7 +13,7 @@ import mhla_amd  # noqa: E402
 from mhla_amd import causal_mixing_init  # noqa: E402
 
 
-def case(B, T, H, K, V, summaries="split"):
+def case(B, T, H, K, V, summaries="tf32"):
     r = causal_case(f"causal B={B} T={T} H={H} K={K} V={V} bf16 {summaries}", B, T, H, K, V, torch.bfloat16, summaries=summaries)
     g = torch.Generator().manual_seed(1)
     q = torch.randn(B, T, H, K, generator=g).to(torch.bfloat16).cuda().requires_grad_(True)
@@ -32,8 +32,8 @@ def case(B, T, H, K, V, summaries="split"):
 
 
 if __name__ == "__main__":
-    args = [a for a in sys.argv[1:] if a not in ("split", "bf16")]
-    modes = [a for a in sys.argv[1:] if a in ("split", "bf16")] or ["split", "bf16"]
+    args = [a for a in sys.argv[1:] if a not in ("tf32", "split", "bf16")]
+    modes = [a for a in sys.argv[1:] if a in ("tf32", "split", "bf16")] or ["tf32", "split", "bf16"]
     shapes = [tuple(int(x) for x in a.split(",")) for a in args] or [(4, 8192, 4, 128, 256), (2, 8192, 4, 256, 512), (16, 2048, 4, 128, 256)]
     for s in shapes:
         for m in modes:
