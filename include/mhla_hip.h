@@ -184,6 +184,30 @@ int mhla_blockmix_wan_fwd(mhla_view q, mhla_view k, mhla_view v, int normalize,
                           int dtype, float eps, unsigned flags, void* stream);
 
 /*
+ * mhla_blockmix_wan_fwd with the q / k prologue of the Wan layer (wan/mhla_utils.py:268-272 after the .float() at :308:
+ * relu(rmsnorm_C(x) * w) + eps over the full channel dim C = H * D) folded into the operator's loads ("read directly
+ * from the QKV GEMM output").  q, k, v: the 16-bit projection outputs [B, N, H, D] (`dtype` MHLA_BF16 / MHLA_F16, 16-byte aligned
+ * views), read in place; rstd_q / rstd_k: fp32 [B * N], 1 / sqrt(mean_C(x^2) + norm_eps) per token from mhla_rms_rstd (NULL: no
+ * norm); wq / wk: fp32 [H * D] RMSNorm weights (NULL: 1).  The kernels form relu(x * rstd * w) + eps in fp32 while loading -- the
+ * values mhla_qk_prologue writes as fp32 tensors -- then rotate (rope tables optional), multiply with bf16 hi + lo operands, and
+ * apply the per-head norm x gate epilogue; the fp32 q / k / v tensors never exist.  Workspace: mhla_blockmix_fwd_ws_bytes(..,
+ * MHLA_F32, 0, 0).  mhla_blockmix_wan_pro_ok: 1 when this entry point serves the problem (16-bit tensors, 96 < D <= 128, D % 8 == 0,
+ * at most 192 blocks); otherwise MHLA_ENOTSUP and the caller composes mhla_qk_prologue + mhla_blockmix_wan_fwd.
+ */
+int mhla_blockmix_wan_pro_ok(int M, int S, int D, int dtype, unsigned flags);
+int mhla_blockmix_wan_pro_fwd(mhla_view q, mhla_view k, mhla_view v,
+                              const float* rstd_q, const float* rstd_k, const float* wq, const float* wk, int normalize,
+                              const float* W, int ldw,
+                              const float* rope_cos, const float* rope_sin, int64_t ld_rope,
+                              const float* norm_w, float norm_eps, mhla_view gate,
+                              mhla_mview out, int out_dtype, const int32_t* block_index,
+                              void* ws, size_t ws_bytes,
+                              int B, int H, int M, int S, int D,
+                              int dtype, float eps, unsigned flags, void* stream);
+/* rstd[row] = 1 / sqrt(mean(x[row][0 .. C)^2) + norm_eps): x [rows][ldx] in `dtype`, C % 8 == 0, rstd fp32 [rows]. */
+int mhla_rms_rstd(const void* x, int64_t ldx, float* rstd, int64_t rows, int C, float norm_eps, int dtype, void* stream);
+
+/*
  * Backward (autograd of the forward above; hand-derived).
  * Needs only the forward's inputs, its output `out` and the upstream gradient
  * `dout`: the block summaries are recomputed -- unless the caller kept the

@@ -99,6 +99,11 @@ struct StateArgs {
     // MODE 1, 16-bit tensors at the default arithmetic: what the forward's store of O rounded away, bf16 [bh][M S][D] in block-major
     // token order (OutArgs::olo); added to O before the row dot.  Null: the row dot uses O as stored.
     const unsigned short* olo;
+    // split.hpp PRO (Wan inference, mhla_blockmix_wan_pro_fwd): x (keys) and qd (queries) are the 16-bit PROJECTION outputs; the q / k
+    // prologue of wan/mhla_utils.py:268-272 -- relu(x * rstd[token] * w[channel]) + eps, fp32 -- is applied while they are loaded.
+    // rstd [B][pro_n] = 1 / sqrt(mean_C(x^2) + norm_eps) per token (null: 1), w [H D] the RMSNorm weights (null: 1)
+    const float *pro_rk, *pro_wk, *pro_rq, *pro_wq;
+    long pro_n;
 };
 
 template <int DT>
@@ -374,6 +379,8 @@ struct OutArgs {
     // written (the backward recomputing it when the forward's workspace was not kept).
     unsigned short* olo;
     int skip_out;
+    const float *pro_rq, *pro_wq;   // split.hpp PRO: the q prologue on load (StateArgs)
+    long pro_n;
 };
 
 template <int DT>

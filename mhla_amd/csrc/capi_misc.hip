@@ -197,6 +197,18 @@ int mhla_qk_prologue_rope(const void* x, int64_t ldx, const float* w, float* y, 
     return MHLA_OK;
 }
 
+int mhla_rms_rstd(const void* x, int64_t ldx, float* rstd, int64_t rows, int C, float norm_eps, int dtype, void* stream) {
+    if (!x || !rstd) return fail(MHLA_EINVAL, "null pointer");
+    if (rows <= 0 || C <= 0 || (C & 7)) return fail(MHLA_EINVAL, "rows=%lld C=%d: need C %% 8 == 0", (long long)rows, C);
+    if ((ldx & 3) || ((uintptr_t)x) % 8) return fail(MHLA_EINVAL, "row stride must be a multiple of 4, x 8-byte aligned");
+    if (dtype < 0 || dtype > 2) return fail(MHLA_EINVAL, "unknown dtype %d", dtype);
+    RstdArgs a{x, (long)ldx, rstd, (long)rows, C, norm_eps};
+    const int64_t gsz = (rows + 3) / 4;
+    const dim3 grid((unsigned)(gsz < 16384 ? gsz : 16384));
+    DISPATCH_T(dtype, { RC(launch(k_rms_rstd<ET>, grid, dim3(256), 0, (hipStream_t)stream, "k_rms_rstd", a)); });
+    return MHLA_OK;
+}
+
 static int prologue_bwd_grid(int64_t rows) {   // wide rows (C floats of dw partial each): fewer workgroups than the per-head norm
     const int64_t g = (rows + 3) / 4;
     return (int)(g < 2048 ? g : 2048);

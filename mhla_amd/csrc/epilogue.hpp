@@ -327,6 +327,34 @@ __global__ __launch_bounds__(256) void k_qk_prologue(const PrologueArgs a) {
     }
 }
 
+// rstd[row] = 1 / sqrt(mean_C(x[row]^2) + norm_eps): the one number per token that the RMSNorm of the q / k prologue needs.  With it the
+// operator's kernels apply relu(x rstd w) + eps while they load the 16-bit projection (split.hpp PRO): the fp32 q / k tensors of
+// k_qk_prologue are never written (mhla_blockmix_wan_pro_fwd).  One wave per token row, 16-byte loads.
+struct RstdArgs {
+    const void* x;
+    long ldx;
+    float* rstd;
+    long rows;
+    int C;
+    float norm_eps;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void k_rms_rstd(const RstdArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long nw = (long)gridDim.x * 4;
+    for (long row = (long)blockIdx.x * 4 + wave; row < a.rows; row += nw) {
+        const T* xr = (const T*)a.x + row * a.ldx;
+        float ss = 0.f;
+        for (int c = lane * 8; c < a.C; c += 512) {
+            const f32x4 x0 = Io<T>::ld4(xr + c), x1 = Io<T>::ld4(xr + c + 4);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) ss += x0[t] * x0[t] + x1[t] * x1[t];
+        }
+        ss = wave_sum(ss);
+        if (lane == 0) a.rstd[row] = 1.f / sqrtf(ss / (float)a.C + a.norm_eps);
+    }
+}
+
 // Backward of the prologue: g = (dy + R^T dyr) . [u > 0] with u = x rstd w the pre-activation;
 //   norm:  dx = rstd (g w - xhat mean_C(g w xhat)),  dw[c] += g xhat      (xhat = x rstd)
 //   else:  dx = g

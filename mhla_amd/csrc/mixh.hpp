@@ -99,7 +99,6 @@ __global__ __launch_bounds__(64 * NW, DW ? (NW + 3) / 4 : (NW <= 4 ? 4 : (NW + 3
     if (cnt_s <= 0 && (long)blockIdx.x >= a.ztotal) return;
     float wf[NK][8];
     static_assert((TRANS ? 64 * (ROWS + 4) : ROWS * 68) * 4 <= sp_mixh_smem<NW, DW>(), "weight chunk must fit in the tiles");
-    mixh_weights<TRANS, NTH, ROWS, NK>(wf, reinterpret_cast<float*>(smem_raw), a.W, a.ldw, M, wave * 16, tid);
     const int kend = (M + 31) / 32;   // (uniform) reduction steps that hold a block
     // the thread's units: unit v = tid + p NTH -> row v / 16, piece v % 16 (rows past M: the last row, zeroed at the commit)
     unsigned goff[NP];
@@ -346,9 +345,12 @@ __global__ __launch_bounds__(64 * NW, DW ? (NW + 3) / 4 : (NW <= 4 ? 4 : (NW + 3
         pz = ZS;
     };
     // The workgroup's summary slices (a consecutive range), then its share of the normaliser slices (slice zi -> workgroup zi % gridDim.x)
+    // (the first slice's rows are requested before the weights are fetched through LDS: with four slices per workgroup at the C2 shape the
+    // prologue's two round trips were a fifth of the kernel)
+    if (cnt_s > 0) issue(std::false_type{}, sga, (int)(s0 / nsl), (int)(s0 - (long)(s0 / nsl) * nsl));
+    mixh_weights<TRANS, NTH, ROWS, NK>(wf, reinterpret_cast<float*>(smem_raw), a.W, a.ldw, M, wave * 16, tid);
     if (cnt_s > 0) {
         int bh = (int)(s0 / nsl), es = (int)(s0 - (long)bh * nsl);
-        issue(std::false_type{}, sga, bh, es);
         for (int it = 0; it < cnt_s; ++it) {
             int nb = bh, ne = es;
             advance(nb, ne);

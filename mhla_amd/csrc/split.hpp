@@ -244,15 +244,18 @@ template <int DT> __host__ __device__ constexpr int sp_state_rd_smem() { return 
 // eight-wave slots of half the duration 3.5 rounds that cost 4 (of half the length).
 // S16: the summary is stored as bf16 (the opt-in MHLA_FLAG_BF16_SUMMARIES arithmetic on bf16 tensors); otherwise fp32, and the
 // one operand that is an INTERMEDIATE (dP = dO / n, MODE 1) is split into hi + lo parts whatever the tensor type
-template <typename T, int DT, int MODE, bool ROPE = false, int NT = NTHREADS, bool S16 = Sum16<T>::value, int P24 = 0>
+// PRO (MODE 0, Wan inference): x and qd are 16-bit projection outputs; relu(x * rstd[token] * w[channel]) + eps is applied on load
+// (StateArgs::pro_*), the values then carry a lo part like fp32 tensors
+template <typename T, int DT, int MODE, bool ROPE = false, int NT = NTHREADS, bool S16 = Sum16<T>::value, int P24 = 0, bool PRO = false>
 __global__ __launch_bounds__(NT, NT == 512 ? 4 : (ROPE ? 2 : 3)) void k_sp_state(const StateArgs a) {
+    static_assert(!PRO || (MODE == 0 && !S16), "the prologue on load serves the forward's summary kernel");
     static_assert(!P24 || !S16, "p24 is a format of the fp32-grade summaries");
     constexpr int DW = Geo<DT>::DW, LD = Geo<DT>::LD, CGS = Geo<DT>::CGS, RPP = NT / CGS, IT = 32 / RPP, NWV = NT / 64,
                   RT = (DT + NWV - 1) / NWV, TILE = 32 * LD;
     static_assert(IT >= 1 && RPP * IT == 32, "a 32-row chunk must be whole staging passes");
     static_assert(RPP * DW * 4 <= 4 * 32 * LD * 2, "column-sum partials must fit in the tiles");
-    constexpr bool LO = !std::is_same<T, bf16_t>::value;   // the token operands carry a lo part
-    constexpr bool LOY = LO || (MODE == 1 && !S16);        // ... and so does y = dO / n, unless the reduced-precision form was asked for
+    constexpr bool LO = !std::is_same<T, bf16_t>::value || PRO;   // the token operands carry a lo part
+    constexpr bool LOY = !std::is_same<T, bf16_t>::value || (MODE == 1 && !S16);   // ... and so does y = dO / n, unless the reduced-precision form was asked for
     // RD: the row dots dO . O = dO' . (Q G_i) are formed from the mixed summary G_i (staged as hi / lo tiles beside the operand tiles): the
     // stored output and its residual are not read, and the forward does not write the residual (capi_common.hpp bm_rowdots_from_g)
     constexpr bool RD = MODE == 1 && P24 && sizeof(T) == 2 && DT <= 4 && !ROPE;
@@ -280,6 +283,8 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : (ROPE ? 2 : 3)) void k_sp_state
 
     f32x4 kx[IT][2], vx[IT][2], dx[IT][2], rc[ROPE ? IT : 1], rs[ROPE ? IT : 1];
     float nv[IT];
+    float prr[PRO ? IT : 1];   // PRO: the rows' rstd
+    f32x4 pw[PRO ? 2 : 1];     // ... and the norm weights of the thread's 8 channels
     constexpr bool rope = ROPE;
     int crow = 0;   // first token of the chunk held in registers
     // Gather map: the rows of a chunk are looked up ONE FETCH EARLIER than they are used (clamped, unconditional), so that a fetch
@@ -302,6 +307,13 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : (ROPE ? 2 : 3)) void k_sp_state
     // zeroed in `commit`; a tensor the call does not have is replaced by x and its values dropped): a load behind a branch makes
     // hipcc wait for everything in flight where the branch joins, i.e. before the products the prefetch is meant to overlap.
     const int cgc = min(cg, D - 8);
+    if constexpr (PRO) {
+        pw[0] = pw[1] = f32x4{1.f, 1.f, 1.f, 1.f};
+        if (a.pro_wk) {
+            pw[0] = *reinterpret_cast<const f32x4*>(a.pro_wk + h * D + cgc);
+            pw[1] = *reinterpret_cast<const f32x4*>(a.pro_wk + h * D + cgc + 4);
+        }
+    }
     const T* kdq = den ? kdb : kb;                  // (uniform selects)
     const long kdsn = den ? third.sn : a.x.sn;
     const float* nvp = (MODE == 1 && a.normalize) ? ninvb : reinterpret_cast<const float*>(a.x.ptr);
@@ -321,6 +333,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : (ROPE ? 2 : 3)) void k_sp_state
             ld8(vb + row * a.y.sn + cgc, vx[it][0], vx[it][1]);
             ld8(kdq + row * kdsn + cgc, dx[it][0], dx[it][1]);
             nv[it] = gld<float>(nvp + ((MODE == 1 && a.normalize) ? rcl : 0));
+            if constexpr (PRO) prr[it] = gld<float>(a.pro_rk ? a.pro_rk + b * a.pro_n + row : reinterpret_cast<const float*>(a.x.ptr));
             if constexpr (OLO) ox[it] = gld<uint4>(olop + (olo_on ? (long)rcl * D : 0));
             if constexpr (rope) {
                 rc[it] = *reinterpret_cast<const f32x4*>(a.rcos + row * a.ldr + cgc / 2);
@@ -335,6 +348,11 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : (ROPE ? 2 : 3)) void k_sp_state
         for (int it = 0; it < IT; ++it) {
             const bool valid = crow + r0 + RPP * it < S && cg < D;
             const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (PRO) {
+                const float r = a.pro_rk ? prr[it] : 1.f;   // ((x rstd) w: the order of k_qk_prologue, so that the two paths agree bit for bit)
+                kx[it][0] = (kx[it][0] * r) * pw[0];
+                kx[it][1] = (kx[it][1] * r) * pw[1];
+            }
             if (a.relu) relu8(kx[it][0], kx[it][1], a.eps);
             kx[it][0] = valid ? kx[it][0] : z4; kx[it][1] = valid ? kx[it][1] : z4;
             vx[it][0] = valid ? vx[it][0] : z4; vx[it][1] = valid ? vx[it][1] : z4;
@@ -600,6 +618,14 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : (ROPE ? 2 : 3)) void k_sp_state
         float kv8[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) kv8[i] = vecd[cg + i];
+        f32x4 qw[PRO ? 2 : 1];   // PRO: the q norm weights of the thread's channels
+        if constexpr (PRO) {
+            qw[0] = qw[1] = f32x4{1.f, 1.f, 1.f, 1.f};
+            if (a.pro_wq && cg < D) {
+                qw[0] = *reinterpret_cast<const f32x4*>(a.pro_wq + h * D + cg);
+                qw[1] = *reinterpret_cast<const f32x4*>(a.pro_wq + h * D + cg + 4);
+            }
+        }
         constexpr int ZB = 4;   // token rows in flight per thread: the loads of a batch are issued before any is used
         for (int rb = 0; rb < S; rb += RPP * ZB) {
             f32x4 x0[ZB], x1[ZB];
@@ -622,6 +648,11 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : (ROPE ? 2 : 3)) void k_sp_state
                 const int r = rb + u * RPP + r0;
                 float d = 0.f;
                 if (r < S && cg < D) {
+                    if constexpr (PRO) {
+                        const float rq = a.pro_rq ? a.pro_rq[b * a.pro_n + rw[u]] : 1.f;
+                        x0[u] = (x0[u] * rq) * qw[0];
+                        x1[u] = (x1[u] * rq) * qw[1];
+                    }
                     if (a.relu) relu8(x0[u], x1[u], a.eps);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) d += x0[u][i] * kv8[i] + x1[u][i] * kv8[4 + i];
@@ -1570,13 +1601,13 @@ template <typename V>
 __device__ __forceinline__ bool view16(const V& w) { return (reinterpret_cast<uintptr_t>(w.ptr) & 15) == 0 && ((w.sb | w.sn | w.sh) & 7) == 0; }
 
 constexpr int SP_OUT_T = 512;   // 8 waves share the staged G_i: twice the loads in flight per LDS byte
-template <typename T, int DT, typename TO = T, bool EPI = false, bool S16 = Sum16<T>::value, int P24 = 0>
+template <typename T, int DT, typename TO = T, bool EPI = false, bool S16 = Sum16<T>::value, int P24 = 0, bool PRO = false>   // PRO: the q prologue on load (OutArgs::pro_*)
 #ifndef SP_OUT_EPI_WAVES
 #define SP_OUT_EPI_WAVES 2   // the fused-epilogue variant takes 142 VGPRs: one workgroup per CU without spills (157 us at C4) beats two with 28 spilled registers (163 us)
 #endif
 __global__ __launch_bounds__(SP_OUT_T, EPI ? SP_OUT_EPI_WAVES : 2) void k_sp_out(const OutArgs a) {
     constexpr int LD = mat_ld<DT>(), KST = Geo<DT>::KST, KP = KST * 32, TILE = KP * LD;
-    constexpr bool LO = !std::is_same<T, bf16_t>::value;
+    constexpr bool LO = !std::is_same<T, bf16_t>::value || PRO;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u16* Gh = reinterpret_cast<u16*>(smem_raw);   // [d1][d2], rows >= D and columns >= D zero
     u16* Gl = Gh + TILE;
@@ -1585,24 +1616,76 @@ __global__ __launch_bounds__(SP_OUT_T, EPI ? SP_OUT_EPI_WAVES : 2) void k_sp_out
     const long p0 = (long)blk * S;
     const T* qb = (const T*)a.q.ptr + b * a.q.sb + h * a.q.sh;
     TO* ob = (TO*)a.o.ptr + b * a.o.sb + h * a.o.sh;
+    // The lane's token row of a 16-token tile as loaded: 8 q features per reduction step, 1 / n, (PRO) the token's rstd.  The first tile's
+    // rows are requested BEFORE G_i is staged (one memory round trip per workgroup instead of two: a workgroup of the C2 step has one
+    // tile per wave); 16-bit tensors also keep the wave's next tile in flight under the products (8 registers per reduction step).
+    // Every load is unconditional, from clamped addresses (rows past the block: its last row; columns past D: the row's first piece).
+    constexpr bool DBL = sizeof(T) == 2;
+    // (fused-epilogue variants -- the Wan inference kernels, one workgroup per CU on up to 256 VGPRs -- also fetch the token's rope angles
+    // with its rows: loaded where they are used they were one more memory round trip per tile, in front of the products)
+    struct QRows {
+        typename Raw4<T>::type x[KST][2];
+        f32x4 rc[EPI ? KST : 1], rs[EPI ? KST : 1];
+        float ninv, rq;
+        long row;
+    };
+    QRows cur, nxt;
+    const float* ninvb = a.ninv + ((long)bh * a.M + blk) * S;
+    auto fetch = [&](int tt, QRows& R) __attribute__((always_inline)) {
+        const int sv = min(tt * 16 + nl, S - 1);
+        R.row = tok_row(a.idx, p0 + sv);
+        const T* qrow = qb + R.row * a.q.sn;
+#pragma unroll
+        for (int ks = 0; ks < KST; ++ks) {
+            const int c = ks * 32 + kg * 8 < D ? ks * 32 + kg * 8 : 0;
+            R.x[ks][0] = *reinterpret_cast<const typename Raw4<T>::type*>(qrow + c);
+            R.x[ks][1] = *reinterpret_cast<const typename Raw4<T>::type*>(qrow + c + 4);
+        }
+        if constexpr (EPI) {
+#pragma unroll
+            for (int ks = 0; ks < KST; ++ks) {
+                const long ro = a.rcos ? R.row * a.ldr + (ks * 32 + kg * 8 < D ? ks * 16 + kg * 4 : 0) : 0;
+                R.rc[ks] = *reinterpret_cast<const f32x4*>((a.rcos ? a.rcos : a.g) + ro);
+                R.rs[ks] = *reinterpret_cast<const f32x4*>((a.rcos ? a.rsin : a.g) + ro);
+            }
+        }
+        R.ninv = gld<float>(a.normalize ? ninvb + sv : a.W);
+        R.rq = 1.f;
+        if constexpr (PRO) R.rq = gld<float>(a.pro_rq ? a.pro_rq + b * a.pro_n + R.row : a.W);
+    };
+    fetch(wave, cur);
     // (S16: G_i stored as bf16: no lo tile)
     stage_mat_split<DT, S16, SP_OUT_T, P24>(Gh, Gl, a.g, ((long)bh * a.M + blk) * a.es, D, tid);
     __syncthreads();
-    const float* ninvb = a.ninv + ((long)bh * a.M + blk) * S;
     for (int tt = wave; tt * 16 < S; tt += SP_OUT_T / 64) {
+        if constexpr (DBL) fetch(tt + SP_OUT_T / 64, nxt);
+        else if (tt != wave) fetch(tt, cur);   // (uniform)
         const int s = tt * 16 + nl, sv = min(s, S - 1);
-        const long row = tok_row(a.idx, p0 + sv);
-        const T* qrow = qb + row * a.q.sn + kg * 8;
+        const long row = cur.row;
         bf16x8 qh[KST], ql[KST];
 #pragma unroll
         for (int ks = 0; ks < KST; ++ks) {
             f32x4 x0 = {0.f, 0.f, 0.f, 0.f}, x1 = x0;
             if (ks * 32 + kg * 8 < D) {
-                ld8(qrow + ks * 32, x0, x1);
+                x0 = raw4_to_f32(T{}, cur.x[ks][0]);
+                x1 = raw4_to_f32(T{}, cur.x[ks][1]);
+                if constexpr (PRO) {   // relu(q rstd[token] w[channel]) + eps: the values k_qk_prologue used to materialise
+                    const float rq = a.pro_rq ? cur.rq : 1.f;
+                    x0 *= rq;
+                    x1 *= rq;
+                    if (a.pro_wq) {
+                        x0 *= *reinterpret_cast<const f32x4*>(a.pro_wq + h * D + ks * 32 + kg * 8);
+                        x1 *= *reinterpret_cast<const f32x4*>(a.pro_wq + h * D + ks * 32 + kg * 8 + 4);
+                    }
+                }
                 if (a.relu) relu8(x0, x1, a.eps);
                 if (a.rcos) {
-                    const long ro = row * a.ldr + ks * 16 + kg * 4;
-                    rope8(x0, x1, *reinterpret_cast<const f32x4*>(a.rcos + ro), *reinterpret_cast<const f32x4*>(a.rsin + ro));
+                    if constexpr (EPI) {
+                        rope8(x0, x1, cur.rc[ks], cur.rs[ks]);
+                    } else {
+                        const long ro = row * a.ldr + ks * 16 + kg * 4;
+                        rope8(x0, x1, *reinterpret_cast<const f32x4*>(a.rcos + ro), *reinterpret_cast<const f32x4*>(a.rsin + ro));
+                    }
                 }
             }
             uint4 hi, lo;
@@ -1610,7 +1693,8 @@ __global__ __launch_bounds__(SP_OUT_T, EPI ? SP_OUT_EPI_WAVES : 2) void k_sp_out
             qh[ks] = as_bf16x8(hi);
             ql[ks] = as_bf16x8(lo);
         }
-        const float ninv = a.normalize ? ninvb[sv] : 1.f;
+        (void)sv;
+        const float ninv = a.normalize ? cur.ninv : 1.f;
         TO* orow = ob + row * a.o.sn + kg * 4;
         f32x4 res[EPI ? DT + 1 : 1];
         // gate values of this lane's features, fetched (packed) before the products: latency off the epilogue.
@@ -1770,6 +1854,7 @@ __global__ __launch_bounds__(SP_OUT_T, EPI ? SP_OUT_EPI_WAVES : 2) void k_sp_out
                 }
             }
         }
+        if constexpr (DBL) cur = nxt;
     }
 }
 

@@ -11,7 +11,7 @@ from typing import Dict, Tuple
 import torch
 from torch import nn
 
-from ..ops import lepe3d, mhla_blockmix, mhla_blockmix_rope, mhla_blockmix_wan, qk_prologue, rmsnorm_gate
+from ..ops import lepe3d, mhla_blockmix, mhla_blockmix_rope, mhla_blockmix_wan, mhla_blockmix_wan_pro, qk_prologue, rmsnorm_gate, wan_pro_supported
 from ..weights import block_index_3d
 from .blockconv import BlockDistanceConv3D
 
@@ -149,10 +149,19 @@ class MHLA_Video_Uni(nn.Module):
             # inference: norm + relu + eps in one kernel per tensor, rotation inside the operator's loads
             wq = self.norm_q.weight if isinstance(self.norm_q, WanRMSNorm) else None
             wk = self.norm_k.weight if isinstance(self.norm_k, WanRMSNorm) else None
+            gate = self.g(x).reshape(B, N, H, D) if self.is_gated else None
+            if wan_pro_supported(q.reshape(B, N, H, D), self.num_blocks):
+                # the prologue inside the operator's loads: q, k, v stay the 16-bit projection outputs, no fp32 copies
+                out = mhla_blockmix_wan_pro(q.reshape(B, N, H, D), k.reshape(B, N, H, D), v.reshape(B, N, H, D), wq, wk,
+                                            getattr(self.norm_q, "eps", 0.0), W, cos, sin, self.g_norm.weight, self.g_norm.eps, gate,
+                                            eps=self.eps, normalize=self.normalize_out, block_index=idx,
+                                            qk_norm=isinstance(self.norm_q, WanRMSNorm)).reshape(B, N, C)
+                if self.is_lepe:
+                    out = lepe3d(v_lepe, self.lepe.weight, self.lepe.bias, grid, add=out)
+                return self.o(out)
             q = qk_prologue(q, wq, getattr(self.norm_q, "eps", 0.0), self.eps).reshape(B, N, H, D)
             k = qk_prologue(k, wk, getattr(self.norm_k, "eps", 0.0), self.eps).reshape(B, N, H, D)
             # ... and the per-head g_norm (x SiLU gate) applied before the operator stores its output (:356-362)
-            gate = self.g(x).reshape(B, N, H, D) if self.is_gated else None
             out = mhla_blockmix_wan(q, k, v.float().reshape(B, N, H, D), W, cos, sin, self.g_norm.weight, self.g_norm.eps,
                                     gate, dtype, eps=self.eps, normalize=self.normalize_out, block_index=idx).reshape(B, N, C)
             if self.is_lepe:

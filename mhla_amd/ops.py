@@ -644,6 +644,71 @@ def mhla_blockmix_wan(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, W: torc
     return out
 
 
+def wan_pro_supported(q: torch.Tensor, M: int) -> bool:
+    """True when `mhla_blockmix_wan_pro` serves q [B, N, H, D] with M blocks (16-bit tensors, 96 < D <= 128, at most 192 blocks)."""
+    if q.dim() != 4 or q.dtype not in (torch.bfloat16, torch.float16) or not q.is_cuda or q.shape[1] % M:
+        return False
+    return _lib.load().mhla_blockmix_wan_pro_ok(M, q.shape[1] // M, q.shape[3], _dtype_code(q), 0) == 1
+
+
+def mhla_blockmix_wan_pro(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, wq: Optional[torch.Tensor], wk: Optional[torch.Tensor],
+                          qk_norm_eps: float, W: torch.Tensor, rope_cos: Optional[torch.Tensor], rope_sin: Optional[torch.Tensor],
+                          norm_weight: Optional[torch.Tensor], norm_eps: float, gate: Optional[torch.Tensor], *, eps: float = 1e-6,
+                          normalize: bool = True, block_index: Optional[torch.Tensor] = None, qk_norm: bool = True) -> torch.Tensor:
+    """The Wan layer's inference operator with the q / k prologue folded into its loads (mhla_blockmix_wan_pro_fwd): q, k, v are the
+    16-bit projection outputs [B, N, H, D] (views of [B, N, C] are fine), wq / wk the full-dim RMSNorm weights [H * D] (None: no affine),
+    `qk_norm=False`: no norm at all (relu(x) + eps).  One small kernel per tensor computes the per-token rstd; the operator's kernels
+    apply relu(x * rstd * w) + eps, the rotation, and the per-head norm x gate epilogue.  Same numbers as
+    `mhla_blockmix_wan(qk_prologue(q), qk_prologue(k), v.float(), ...)` without the three fp32 tensors.  Forward only; returns
+    [B, N, H, D] in the dtype of q."""
+    lib = _lib.load()
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (q, k, v, W, wq, wk, norm_weight, gate)):
+        raise RuntimeError("mhla_blockmix_wan_pro is forward-only")
+    _require_gpu(q, k, v, W, wq, wk, rope_cos, rope_sin, norm_weight, gate, block_index)
+    B, N, H, D = q.shape
+    M = W.shape[0]
+    if N % M:
+        raise ValueError(f"N={N} tokens not divisible into M={M} blocks")
+    S = N // M
+    _check_like(q, "mhla_blockmix_wan_pro", k=(k, q.shape), v=(v, q.shape))
+    _check_block_index(block_index, N, q)
+    q, k, v = _prep(q.detach()), _prep(k.detach()), _prep(v.detach())
+    dt = _dtype_code(q)
+    C = H * D
+    f32 = lambda t: None if t is None else t.detach().to(torch.float32).contiguous()
+    wq, wk, nw = f32(wq), f32(wk), f32(norm_weight)
+    rq = rk = None
+    if qk_norm:
+        if not (q.stride(2) == D and k.stride(2) == D):
+            raise ValueError("q, k: the heads of a token must be contiguous (views of the [B, N, H * D] projection)")
+        rq = torch.empty(B * N, dtype=torch.float32, device=q.device)
+        rk = torch.empty(B * N, dtype=torch.float32, device=q.device)
+        for x, r in ((q, rq), (k, rk)):
+            if x.stride(0) != N * x.stride(1):
+                raise ValueError("q, k: batch stride must be N * token stride")
+            _lib.check(lib.mhla_rms_rstd(x.data_ptr(), x.stride(1), r.data_ptr(), B * N, C, float(qk_norm_eps), dt, _stream()), "mhla_rms_rstd")
+    cos = sin = None
+    if rope_cos is not None:
+        if rope_cos.shape != (N, D // 2) or rope_cos.dtype != torch.float32 or rope_sin.shape != (N, D // 2) or rope_sin.dtype != torch.float32:
+            raise ValueError(f"rope tables must be fp32 [N={N}, D/2={D // 2}]")
+        cos, sin = rope_cos.contiguous(), rope_sin.contiguous()
+    if gate is not None:
+        if gate.shape != (B, N, H, D) or gate.dtype != q.dtype:
+            raise ValueError("gate: [B, N, H, D] in the dtype of q")
+        gate = _prep(gate.detach())
+    Wf = W.detach().reshape(M, M).to(torch.float32).contiguous()
+    out = torch.empty((B, N, H, D), dtype=q.dtype, device=q.device)
+    ws = _ws(_bm_plan(B, H, M, S, D, _lib.F32, 0, 0)[0], q.device)
+    p = lambda t: t.data_ptr() if t is not None else None
+    rc = lib.mhla_blockmix_wan_pro_fwd(_view(q), _view(k), _view(v), p(rq), p(rk), p(wq), p(wk), int(bool(normalize)), Wf.data_ptr(), M,
+                                       p(cos), p(sin), cos.stride(0) if cos is not None else 0, p(nw), float(norm_eps),
+                                       _view(gate) if gate is not None else NULL_VIEW, _view(out), dt,
+                                       block_index.data_ptr() if block_index is not None else None, ws.data_ptr(), ws.numel() * 4,
+                                       B, H, M, S, D, dt, float(eps), 0, _stream())
+    _lib.check(rc, "mhla_blockmix_wan_pro_fwd")
+    return out
+
+
 class _DitCore(torch.autograd.Function):
     """Operator + LePE of the DiT / ViT module as ONE autograd node on the packed QKV projection output
     (mhla_dit/mhla/mhla.py:245-273): q, k, v are the three slices of `qkv` [B, N, 3, H, D] read in place; the backward writes

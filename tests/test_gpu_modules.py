@@ -3,7 +3,7 @@ import pytest
 import torch
 
 from conftest import load_golden
-from gpu_util import DEV, check, poison
+from gpu_util import DEV, TOL, UNIT_ROUNDOFF as UNIT, check, poison
 from oracle import mhla_oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -132,6 +132,91 @@ def test_wan_module_fused_inference_path(tag):
     check("y", y, g["y"], 1e-4)
     y2 = m(x.clone().requires_grad_(True), torch.tensor([N] * B), grid_sizes, modules.wan_freqs(D))
     check("fused vs unfused", y, y2.detach().cpu(), 1e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,S,gate,rope,norm,normalize,gather", [(6, 40, True, True, True, True, True), (40, 21, False, True, True, False, False),
+                                                                 (150, 6, True, False, True, True, True), (9, 33, True, True, False, True, False)])
+def test_wan_prologue_on_load_matches_materialised_prologue(M, S, gate, rope, norm, normalize, gather, dtype):
+    """SURVEY N2 / VERDICT r5 item 3: mhla_blockmix_wan_pro reads the 16-bit q, k, v projections in place and applies
+    relu(rmsnorm_C(x) w) + eps while loading (mhla_rms_rstd gives the per-token rstd) -- against the composition it replaces,
+    mhla_qk_prologue (fp32 q, k materialised) + v.float() + mhla_blockmix_wan: the same fp32 numbers in the same order, so the two
+    agree to the last bit of the 16-bit output; and against the oracle's module arithmetic (wan/mhla_utils.py:268-272, :308-362)."""
+    import mhla_amd
+    from mhla_amd import ops
+    B, H, D = 2, 3, 128
+    N, C = M * S, H * D
+    g = torch.Generator().manual_seed(M * 1000 + S)
+    q, k, v = (torch.randn(B, N, C, generator=g).to(dtype).to(DEV) for _ in range(3))
+    wq, wk = (torch.rand(C, generator=g) + 0.5).to(DEV), (torch.rand(C, generator=g) + 0.5).to(DEV)
+    W = torch.rand(M, M, generator=g).to(DEV)
+    nw = (torch.rand(D, generator=g) + 0.5).to(DEV)
+    gt = torch.randn(B, N, H, D, generator=g).to(dtype).to(DEV) if gate else None
+    cos = sin = None
+    if rope:
+        ang = torch.rand(N, D // 2, generator=g) * 6.28
+        cos, sin = torch.cos(ang).to(DEV), torch.sin(ang).to(DEV)
+    idx = torch.randperm(N, generator=torch.Generator().manual_seed(3)).int().to(DEV) if gather else None
+    r4 = lambda t: t.reshape(B, N, H, D)
+    assert ops.wan_pro_supported(r4(q), M)
+    poison()
+    y = mhla_amd.mhla_blockmix_wan_pro(r4(q), r4(k), r4(v), wq if norm else None, wk if norm else None, 1e-6, W, cos, sin, nw, 1e-6, gt,
+                                       eps=1e-6, normalize=normalize, block_index=idx, qk_norm=norm)
+    assert y.dtype == dtype and y.shape == (B, N, H, D)
+    qf = r4(mhla_amd.qk_prologue(q, wq if norm else None, 1e-6, 1e-6))
+    kf = r4(mhla_amd.qk_prologue(k, wk if norm else None, 1e-6, 1e-6))
+    y2 = mhla_amd.mhla_blockmix_wan(qf, kf, r4(v).float(), W, cos, sin, nw, 1e-6, gt, dtype, eps=1e-6, normalize=normalize, block_index=idx)
+    assert torch.equal(y, y2), f"prologue on load differs from the materialised prologue: max |diff| {(y.float() - y2.float()).abs().max().item():.3e}"
+    # ... and the oracle: fp32 prologue, rope, operator (gather map undone), per-head norm x gate
+    qc, kc, vc = q.float().cpu(), k.float().cpu(), v.float().cpu()
+    if norm:
+        qc = orc.rms_norm(qc, wq.cpu(), 1e-6)
+        kc = orc.rms_norm(kc, wk.cpu(), 1e-6)
+    qc, kc = r4(torch.relu(qc) + 1e-6), r4(torch.relu(kc) + 1e-6)
+    vc = r4(vc)
+
+    def rot(x):
+        if not rope:
+            return x
+        xs = x.reshape(B, N, H, D // 2, 2)
+        c, s_ = cos.cpu()[None, :, None, :], sin.cpu()[None, :, None, :]
+        return torch.stack((xs[..., 0] * c - xs[..., 1] * s_, xs[..., 0] * s_ + xs[..., 1] * c), dim=-1).reshape(B, N, H, D)
+    perm = idx.long().cpu() if gather else torch.arange(N)
+    bm = lambda t: t[:, perm]            # block-major order
+    o = orc.blockmix_fwd(bm(rot(qc)), bm(rot(kc)), bm(vc), W.cpu(), 1e-6, bm(qc) if normalize else None, bm(kc) if normalize else None, normalize)
+    o = o.to(dtype).float()
+    want_bm = orc.rms_norm_swish_gate(o, bm(gt.float().cpu()), nw.cpu(), 1e-6) if gate else orc.rms_norm(o, nw.cpu(), 1e-6)
+    want = torch.empty_like(want_bm)
+    want[:, perm] = want_bm
+    check("y vs oracle", y, want, TOL[dtype] + UNIT[dtype])   # (the host rounds O to the activation dtype before the norm: one more rounding)
+
+
+def test_wan_module_bf16_inference_takes_the_prologue_on_load_path():
+    """A bf16 MHLA_Video_Uni under no_grad (the Wan2.1 inference configuration) routes through mhla_blockmix_wan_pro -- no k_qk_prologue,
+    no fp32 q / k / v -- and agrees with the same module's materialising path."""
+    from mhla_amd import modules
+    import mhla_amd.modules.wan as wanmod
+    B, H, D, layout, grid = 1, 4, 128, (2, 2, 3), (4, 6, 9)
+    N = grid[0] * grid[1] * grid[2]
+    torch.manual_seed(5)
+    m = modules.MHLA_Video_Uni(H * D, num_heads=H, block_layout=layout, is_gated=True).to(DEV).to(torch.bfloat16).eval()
+    x = torch.randn(B, N, H * D, device=DEV, dtype=torch.bfloat16)
+    args = (torch.tensor([N] * B), torch.tensor([list(grid)] * B, dtype=torch.long), modules.wan_freqs(D))
+    calls = []
+    orig = wanmod.mhla_blockmix_wan_pro
+    wanmod.mhla_blockmix_wan_pro = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        with torch.no_grad():
+            y = m(x, *args)
+            wanmod.wan_pro_supported, keep = (lambda *a, **k: False), wanmod.wan_pro_supported
+            try:
+                y2 = m(x, *args)
+            finally:
+                wanmod.wan_pro_supported = keep
+    finally:
+        wanmod.mhla_blockmix_wan_pro = orig
+    assert len(calls) == 1, "the prologue-on-load path was not taken"
+    assert torch.equal(y, y2)
 
 
 @pytest.mark.parametrize("kind", ["mhla", "mhla_nope", "gated_mhla", "mhla_lepe", "gated_mhla_lepe"])

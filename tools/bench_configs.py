@@ -138,7 +138,7 @@ def blockmix_case(name, B, N, H, D, M, dtype, layout, bwd=True, split=False, idx
     return r
 
 
-def causal_case(name, B, T, H, K, V, dtype, iters=10, key=None, summaries="split", graph=True):
+def causal_case(name, B, T, H, K, V, dtype, iters=10, key=None, summaries="tf32", graph=True):
     g = torch.Generator().manual_seed(1)
     q = torch.randn(B, T, H, K, generator=g).to(dtype).to(DEV).requires_grad_(True)
     k = torch.randn(B, T, H, K, generator=g).to(dtype).to(DEV).requires_grad_(True)
