@@ -111,6 +111,14 @@ const char* mhla_last_error(void);
  * Returns the previous value, MHLA_EINVAL for an unknown name. */
 int mhla_set_option(const char* name, int value);
 
+/* Which kernel family, block-summary format and launch sequence serve a block-mix / causal problem, as text:
+ * "family=...; summaries=...; fwd=k1 k2 ...; bwd=k1 k2 ..." (kernel names as mhla_prof_report prints them, separated by blanks; the
+ * dispatcher's own predicates; 16-byte aligned views assumed).
+ * Writes at most cap - 1 characters + NUL into buf (buf may be NULL), returns the full length or a negative error code.  The
+ * table in DESIGN.md section 0a lists the same for every BASELINE.json configuration. */
+int mhla_describe_dispatch(int B, int H, int M, int S, int D, int dtype, int split, unsigned flags, char* buf, size_t cap);
+int mhla_causal_describe_dispatch(int T, int K, int V, int chunk, int dtype, unsigned flags, char* buf, size_t cap);
+
 /* Profiling aid (used by bench.py): when enabled, every kernel launch is bracketed by hipEvents on
  * its own stream; mhla_prof_report waits for them, writes one "kernel_name count total_ms" line per
  * kernel into buf (NUL-terminated, truncated to cap) and clears the records.  Off by default. */

@@ -52,6 +52,8 @@ SIGNATURES = {
     "mhla_blockmix_wan_pro_fwd": (c_int, [View, View, View, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p,
                                           c_int64, c_void_p, c_float, View, View, c_int, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int,
                                           c_int, c_int, c_int, c_float, c_uint, c_void_p]),
+    "mhla_describe_dispatch": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_uint, c_char_p, c_size_t]),
+    "mhla_causal_describe_dispatch": (c_int, [c_int, c_int, c_int, c_int, c_int, c_uint, c_char_p, c_size_t]),
     "mhla_rms_rstd": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_float, c_int, c_void_p]),
     "mhla_blockmix_bwd": (c_int, [View, View, View, View, View, c_void_p, c_int, View, View, View, View, View, View,
                                   View, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_int, c_int, c_int, c_int,

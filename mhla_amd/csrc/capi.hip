@@ -93,18 +93,28 @@ std::atomic<int> g_drop_signal{getenv("MHLA_DEBUG_DROP_SIGNAL") != nullptr ? 1 :
 // event has completed -- no synchronisation anywhere -- and the first raised word latches the process to the two-launch form
 // (the kernel boundary then orders the hand-over, whatever the dispatch order is) and says so once on stderr.
 struct HandoverWatch {
-    static constexpr int SLOTS = 64;
+    static constexpr int SLOTS = 64, MAXDEV = 16;
     std::mutex mu;
-    int* host = nullptr;              // pinned, SLOTS words
-    hipEvent_t ev[SLOTS] = {};
-    bool pending[SLOTS] = {};
-    int next = 0;
-    bool warned = false;
-    void poll() {   // (mu held)
+    int* host = nullptr;              // pinned (portable: visible to every device's streams), MAXDEV x SLOTS words
+    hipEvent_t ev[MAXDEV][SLOTS] = {};   // an event belongs to the device it was created on: one set per device
+    bool pending[MAXDEV][SLOTS] = {};
+    int next[MAXDEV] = {};
+    bool warned = false, unarmed_said = false;
+    void unarmed(const char* why) {   // (mu held) say once that the watch cannot arm; the fused launch still runs, only the self-healing is off
+        if (!unarmed_said) {
+            unarmed_said = true;
+            fprintf(stderr, "[mhla] the hand-over watch of the fused token-gradient launch could not be armed (%s): an expired hand-over will only "
+                            "show through mhla_blockmix_bwd_status\n", why);
+        }
+        (void)hipGetLastError();
+    }
+    void poll(int dev) {   // (mu held) event queries are allowed while another thread captures a stream in global mode only in relaxed mode
+        hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+        (void)hipThreadExchangeStreamCaptureMode(&mode);
         for (int i = 0; i < SLOTS; ++i) {
-            if (!pending[i] || hipEventQuery(ev[i]) != hipSuccess) continue;
-            pending[i] = false;
-            if (host[i] != 0) {
+            if (!pending[dev][i] || hipEventQuery(ev[dev][i]) != hipSuccess) continue;
+            pending[dev][i] = false;
+            if (host[dev * SLOTS + i] != 0) {
                 g_two_launches.store(1);
                 if (!warned) {
                     warned = true;
@@ -113,30 +123,35 @@ struct HandoverWatch {
                 }
             }
         }
+        (void)hipThreadExchangeStreamCaptureMode(&mode);
         (void)hipGetLastError();   // (hipEventQuery's hipErrorNotReady is not an error of the caller)
     }
+    static int device_of() { int d = 0; (void)hipGetDevice(&d); return d; }   // (the caller's current device: the one its stream and workspace live on)
     void watch(const int* err_word, hipStream_t st) {
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return; }   // a graph cannot adapt anyway
+        const int dev = device_of();
         std::lock_guard<std::mutex> lk(mu);
-        if (!host && hipHostMalloc((void**)&host, SLOTS * sizeof(int), hipHostMallocDefault) != hipSuccess) { host = nullptr; (void)hipGetLastError(); return; }
-        poll();
-        int i = next;
-        for (int t = 0; t < SLOTS && pending[i]; ++t) i = (i + 1) % SLOTS;
-        if (pending[i]) return;       // every slot still in flight: skip this one
-        next = (i + 1) % SLOTS;
-        if (!ev[i] && hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) { ev[i] = nullptr; (void)hipGetLastError(); return; }
-        host[i] = 0;
-        if (hipMemcpyAsync(&host[i], err_word, sizeof(int), hipMemcpyDeviceToHost, st) == hipSuccess && hipEventRecord(ev[i], st) == hipSuccess)
-            pending[i] = true;
+        if (dev < 0 || dev >= MAXDEV) { unarmed("device index beyond the watch's table"); return; }
+        if (!host && hipHostMalloc((void**)&host, MAXDEV * SLOTS * sizeof(int), hipHostMallocPortable) != hipSuccess) { host = nullptr; unarmed("no pinned host memory"); return; }
+        poll(dev);
+        int i = next[dev];
+        for (int t = 0; t < SLOTS && pending[dev][i]; ++t) i = (i + 1) % SLOTS;
+        if (pending[dev][i]) return;       // every slot still in flight: skip this one
+        next[dev] = (i + 1) % SLOTS;
+        if (!ev[dev][i] && hipEventCreateWithFlags(&ev[dev][i], hipEventDisableTiming) != hipSuccess) { ev[dev][i] = nullptr; unarmed("hipEventCreate failed"); return; }
+        host[dev * SLOTS + i] = 0;
+        if (hipMemcpyAsync(&host[dev * SLOTS + i], err_word, sizeof(int), hipMemcpyDeviceToHost, st) == hipSuccess && hipEventRecord(ev[dev][i], st) == hipSuccess)
+            pending[dev][i] = true;
         else
-            (void)hipGetLastError();
+            unarmed("copy / event record on the launch stream failed");
     }
     void check(hipStream_t st) {
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;   // (no event queries while the caller's stream is being captured)
         if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return; }
+        const int dev = device_of();
         std::lock_guard<std::mutex> lk(mu);
-        if (host) poll();
+        if (host && dev >= 0 && dev < MAXDEV) poll(dev);
     }
 };
 HandoverWatch g_watch;
@@ -236,8 +251,10 @@ int mhla_blockmix_fwd_keeps_state(int B, int H, int M, int S, int D, int dtype, 
 // Upper bound over the paths the library may take for this problem (the fast path needs less).
 // (the fast path needs less than the split-operand path, but which one runs also depends on the alignment of the views, which
 // these queries do not see: the bound covers both)
+// (MHLA_FLAG_NO_BWD_STATE: the forward neither writes nor carves the O-residual region)
+static bool fwd_olo(int M, int S, int D, int dtype, unsigned flags) { return bm_olo(M, S, D, dtype, flags) && !(flags & MHLA_FLAG_NO_BWD_STATE); }
 size_t mhla_blockmix_fwd_ws_bytes(int B, int H, int M, int S, int D, int dtype, int split, unsigned flags) {
-    const size_t gen = bm_carve(nullptr, B, H, M, S, D, bm_sumfmt(M, S, D, dtype, flags), sp_shape_ok(D, flags), bm_olo(M, S, D, dtype, flags)).total_fwd;
+    const size_t gen = bm_carve(nullptr, B, H, M, S, D, bm_sumfmt(M, S, D, dtype, flags), sp_shape_ok(D, flags), fwd_olo(M, S, D, dtype, flags)).total_fwd;
     if (fast_shape_ok(M, D, dtype, split != 0, flags) && !(flags & MHLA_FLAG_FORCE_GENERIC)) return std::max(gen, fast_carve(nullptr, B, H, M, S).total_fwd);
     return gen;
 }
@@ -304,7 +321,7 @@ static int bm_fwd_impl(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view 
         else          RC(launch(fast::k_tile_out<16>, dim3(fast::tiles_per_bh(f.njg, 16) * B * H), dim3(fast::FT8), fast::tile_smem<16>(), st, "k_t16_out", oa));
         return MHLA_OK;
     }
-    const BmWs w = bm_carve(ws, B, H, M, S, D, bm_sumfmt(M, S, D, dtype, flags), sp_shape_ok(D, flags), bm_olo(M, S, D, dtype, flags));
+    const BmWs w = bm_carve(ws, B, H, M, S, D, bm_sumfmt(M, S, D, dtype, flags), sp_shape_ok(D, flags), fwd_olo(M, S, D, dtype, flags));
     if (ws_bytes < w.total_fwd) return fail(MHLA_EINVAL, "workspace too small: %zu < %zu bytes", ws_bytes, w.total_fwd);
     BmCall c{};
     c.q_num = q_num; c.k_num = k_num; c.v = v; c.q_den = q_den; c.k_den = k_den; c.out = out; c.gate = gate;
@@ -480,8 +497,9 @@ static int bm_bwd_impl(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view 
     const bool reuse = fwd_ws && sp_shape_ok(D, flags) && (rcos || !fast_shape_ok(M, D, dtype, split, flags));
     unsigned short* const olo_own = w.olo;
     if (reuse) {
-        const BmWs f = bm_carve(const_cast<void*>(fwd_ws), B, H, M, S, D, bm_sumfmt(M, S, D, dtype, flags), sp_shape_ok(D, flags), bm_olo(M, S, D, dtype, flags));
-        w.kv = f.kv; w.g = f.g; w.z = f.z; w.ksum = f.ksum; w.ninv = f.ninv; w.olo = f.olo;
+        const BmWs f = bm_carve(const_cast<void*>(fwd_ws), B, H, M, S, D, bm_sumfmt(M, S, D, dtype, flags), sp_shape_ok(D, flags), fwd_olo(M, S, D, dtype, flags));
+        w.kv = f.kv; w.g = f.g; w.z = f.z; w.ksum = f.ksum; w.ninv = f.ninv;
+        if (f.olo) w.olo = f.olo;   // (a forward given MHLA_FLAG_NO_BWD_STATE has no residual region: the backward recomputes it into its own)
     }
     BmCall c{};
     c.olo_own = olo_own;
@@ -525,6 +543,62 @@ int mhla_blockmix_rope_bwd(mhla_view q, mhla_view k, mhla_view v, int normalize,
     const mhla_mview mnone{nullptr, 0, 0, 0};
     return bm_bwd_impl(q, k, v, normalize ? q : none, normalize ? k : none, W, ldw, out, dout, dq, dk, dv, mnone, mnone, dW, block_index,
                        ws, ws_bytes, fwd_ws, B, H, M, S, D, dtype, eps, flags, stream, rope_cos, rope_sin, (long)ld_rope);
+}
+
+// Which kernel family, summary format and launch sequence serve a block-mix problem (16-byte aligned views assumed; a misaligned view
+// of a small-sequence / fast-path shape falls through to the split-operand family): the dispatcher's own predicates, as text --
+// "family=...; summaries=...; fwd=k1,k2,...; bwd=k1,k2,..." -- so that tests and tools can assert the path a BASELINE configuration
+// takes instead of inferring it from timings (DESIGN.md section 0a is the same table).  Returns the length written (without the NUL).
+int mhla_describe_dispatch(int B, int H, int M, int S, int D, int dtype, int split, unsigned flags, char* buf, size_t cap) {
+    RC(bm_check(B, H, M, S, D, dtype, flags, true, split != 0));
+    std::string fam, sum, fwd, bwd;
+    const bool gen = (flags & MHLA_FLAG_FORCE_GENERIC) != 0, nosn = gen || (flags & MHLA_FLAG_NO_SMALLN);
+    if (!nosn && snf_shape_ok(M, S, D, dtype, split != 0)) {
+        fam = "small-sequence fp32 (attention form, one launch per direction)";
+        sum = "none (score tiles in LDS as bf16 hi + lo pairs)";
+        fwd = "k_snf_fwd"; bwd = "k_snf_bwd k_sn_dw_reduce";
+    } else if (!nosn && sn_shape_ok(M, S, D, dtype, split != 0)) {
+        fam = "small-sequence bf16 (attention form, one launch per direction)";
+        const bool hl = !(flags & MHLA_FLAG_BF16_SUMMARIES);
+        sum = hl ? "none (score tiles in LDS as bf16 hi + lo pairs)" : "none (score tiles as single bf16: reduced precision)";
+        fwd = hl ? "k_sn_fwd<hl>" : "k_sn_fwd"; bwd = hl ? "k_sn_bwd<hl> k_sn_dw_reduce" : "k_sn_bwd k_sn_dw_reduce";
+    } else if (!gen && fast_shape_ok(M, D, dtype, split != 0, flags)) {
+        fam = "bf16 fast path (fused mixing + token tiles)";
+        sum = "bf16 (single bf16 values, 8-block interleaved: reduced precision, opt-in)";
+        fwd = "k_fs_state_fwd k_fs_wz<0> k_t16_out"; bwd = "k_fs_state<1> k_fs_dw k_t16_bwd";
+    } else if (sp_shape_ok(D, flags)) {
+        const int fmt = bm_sumfmt(M, S, D, dtype, flags);
+        const long E = (long)D * D;
+        const bool s16 = fmt == SF_BF16, mixr = (M > 32 || !s16) && M <= 256 && E % (s16 ? 128 : 64) == 0, evenS = (S % 2) == 0;
+        fam = "split-operand (bf16 hi + lo MFMA operands)";
+        sum = fmt == SF_H16 ? "h16 (fp16 payload x row multiplier: 11 significand bits, 2 bytes)" : fmt == SF_P24 ? "p24 (24-bit floats: 16 significand bits, 3 bytes)"
+              : fmt == SF_BF16 ? "bf16 (single bf16 values: reduced precision, opt-in)" : "fp32 words";
+        const bool wave16 = s16 && S == 16 && D == 64 && !split;
+        const std::string st0 = wave16 ? "k_s16_state<0>" : "k_sp_state", out = wave16 ? "k_s16_out" : "k_sp_out";
+        std::string mix0, mix1, dw;
+        if (fmt == SF_H16) { mix0 = "k_sp_mixh<0>"; mix1 = "k_sp_mixh<1,dw>"; dw = ""; }
+        else if (s16 && M > 192 && mixr) { mix0 = "k_sp_mixr_dma<0>"; mix1 = "k_sp_mixr_dma<1>"; dw = "k_sp_dwr"; }
+        else if (mixr) {
+            mix0 = "k_sp_mixr<0>";
+            if (!s16 && M <= 128) { mix1 = "k_sp_mixr<1,dw>"; dw = ""; }
+            else { mix1 = "k_sp_mixr<1>"; dw = s16 ? (M > 64 ? "k_sp_dwr" : "k_sp_dw") : (fmt == SF_P24 ? "k_sp_dwt" : "k_sp_dw"); }
+        } else { mix0 = "k_sp_mix<0>"; mix1 = "k_sp_mix<1>"; dw = s16 && M > 64 && M <= 256 && E % 64 == 0 ? "k_sp_dwr" : "k_sp_dw"; }
+        const bool wzf = fmt == SF_BF16 ? (M > 192 && M <= 256 && S <= 16 && mixr) : (mixr && evenS);   // the normaliser's product rides in the mixing kernel
+        fwd = st0 + " " + mix0 + (wzf ? "" : " k_wz<0>") + " " + out;
+        bwd = std::string(wave16 ? "k_s16_state<1>" : "k_sp_state<1>") + " " + mix1 + (wzf ? "" : " k_wz<1>") + (dw.empty() ? "" : " " + dw) +
+              ((dw.empty() && wzf) || dw == "k_sp_dwr" ? "" : " k_dw") + " k_dw_reduce " + (wave16 ? "k_s16_bwd_dq k_s16_bwd_dkv" : "k_sp_bwd_dq k_sp_bwd_dkv");
+    } else {
+        fam = "generic (exact fp32 MFMA)";
+        sum = "fp32 words (dense rows)";
+        fwd = "k_bm_state<0> k_mix<0,0> k_wz<0> k_bm_out"; bwd = "k_bm_state<1> k_wz<1> k_mix<1,0> k_dw k_dw_reduce k_bm_bwd_tok";
+    }
+    const std::string txt = "family=" + fam + "; summaries=" + sum + "; fwd=" + fwd + "; bwd=" + bwd;
+    if (buf && cap) {
+        const size_t n = txt.size() < cap - 1 ? txt.size() : cap - 1;
+        memcpy(buf, txt.data(), n);
+        buf[n] = 0;
+    }
+    return (int)txt.size();
 }
 
 // Did the last mhla_blockmix_bwd on this workspace run into a hand-over flag that never arrived (fused.hpp, tile_wait)?

@@ -58,7 +58,7 @@ inline int sp_mixr(const float* W, int ldw, const void* in, void* out, int M, lo
     if (M <= 64) MIXR(4);
     if (M <= 128) MIXR(8);
     if (M <= 192) MIXR(12);
-    if constexpr (P24) return fail(MHLA_EINVAL, "sp_mixr: p24 summaries at M=%d", M);   // (bm_p24 admits 33 .. 192 blocks)
+    if constexpr (P24) return fail(MHLA_EINVAL, "sp_mixr: p24 summaries at M=%d", M);   // (capi_common.hpp bm_sumfmt admits up to 192 blocks)
     else if constexpr (!S16) MIXR(16);   // (16-bit summaries: taken by the DMA kernel above)
     return fail(MHLA_EINVAL, "sp_mixr: M=%d out of range", M);
 #undef MIXR

@@ -7,6 +7,8 @@
 #include "causal_bf16.hpp"
 #include "causal_mix.hpp"
 
+#include <string>
+
 using namespace mhla;
 using namespace mhla::capi;
 
@@ -221,6 +223,28 @@ size_t mhla_causal_bwd_ws_bytes(int B, int T, int H, int K, int V, int chunk, in
 }
 int mhla_causal_normgate_fusable(int T, int K, int V, int chunk, int dtype, unsigned flags) {
     return cs_epi_ok(cs_path(T, K, V, chunk, dtype, flags), V) ? 1 : 0;
+}
+
+// The causal operator's kernel family and summary format as text (see mhla_describe_dispatch).
+int mhla_causal_describe_dispatch(int T, int K, int V, int chunk, int dtype, unsigned flags, char* buf, size_t cap) {
+    RC(cs_check(1, T, 1, K, V, chunk, dtype, flags));
+    const CsPath p = cs_path(T, K, V, chunk, dtype, flags);
+    const int n = (T + chunk - 1) / chunk;
+    std::string txt;
+    if (p.pipe16) {
+        txt = std::string("family=16-bit pipeline (chunk summaries tile-major, resident-sequence mixing); summaries=") +
+              (p.hl == 2 ? "h16 (fp16 payload x strip multiplier: 11 significand bits, 2 bytes)" : p.hl == 1 ? "bf16 hi + lo pairs (16 significand bits, 4 bytes)"
+                                                                                                            : "bf16 (single bf16 values: reduced precision, opt-in)") +
+              "; fwd=k_csf_state k_csf_mixf k_csf_out4; bwd=k_csf_state " + (n > 128 ? "k_csf_mixb<dS> k_csf_mixb<dmix>" : "k_csf_mixb") + " k_csf_bwd_tok4 k_dw_reduce<1>";
+    } else {
+        txt = "family=generic (exact fp32 MFMA); summaries=fp32 words; fwd=k_bm_state<2> k_mix<0,1> k_cs_out; bwd=k_bm_state<2> k_mix<1,1> k_cs_bwd_tok k_dw<1> k_dw_reduce<1>";
+    }
+    if (buf && cap) {
+        const size_t nn = txt.size() < cap - 1 ? txt.size() : cap - 1;
+        memcpy(buf, txt.data(), nn);
+        buf[nn] = 0;
+    }
+    return (int)txt.size();
 }
 
 int mhla_causal_fwd(mhla_view q, mhla_view k, mhla_view v, const float* mix, int ldmix, mhla_mview out, void* ws,

@@ -229,6 +229,7 @@ inline int bm_check(int B, int H, int M, int S, int D, int dtype, unsigned flags
     if (dtype < 0 || dtype > 2) return fail(MHLA_EINVAL, "unknown dtype %d", dtype);
     if (flags & ~(MHLA_FLAG_RELU_EPS | MHLA_FLAG_FORCE_GENERIC | MHLA_FLAG_NO_SMALLN | MHLA_FLAG_BF16_SUMMARIES | MHLA_FLAG_NO_BWD_STATE | MHLA_FLAG_FP32_GRADE_SUMMARIES)) return fail(MHLA_EINVAL, "unknown flags 0x%x", flags);
     if ((flags & MHLA_FLAG_BF16_SUMMARIES) && (flags & MHLA_FLAG_FP32_GRADE_SUMMARIES)) return fail(MHLA_EINVAL, "MHLA_FLAG_BF16_SUMMARIES and MHLA_FLAG_FP32_GRADE_SUMMARIES exclude each other");
+    if ((flags & MHLA_FLAG_BF16_SUMMARIES) && dtype == MHLA_F16) return fail(MHLA_EINVAL, "MHLA_FLAG_BF16_SUMMARIES (single-bf16 summaries) serves bf16 tensors only");
     if ((flags & MHLA_FLAG_RELU_EPS) && split) return fail(MHLA_EINVAL, "MHLA_FLAG_RELU_EPS needs q_den/k_den to alias q_num/k_num");
     if ((size_t)B * H > 65535) return fail(MHLA_ENOTSUP, "B*H=%zu exceeds grid limit 65535", (size_t)B * H);
     (void)normalize;

@@ -185,6 +185,37 @@ def _bm_flags(relu_eps: bool, force_generic: bool, no_smalln: bool, summaries: s
             | (_lib.FLAG_FP32_GRADE_SUMMARIES if summaries == "split" else 0))
 
 
+def describe_dispatch(B: int, H: int, M: int, S: int, D: int, dtype, *, split: bool = False, summaries: str = "tf32", relu_eps: bool = False,
+                      force_generic: bool = False, no_smalln: bool = False) -> dict:
+    """Which kernel family, summary format and launches serve a block-mix problem (mhla_describe_dispatch; no GPU needed):
+    {"family": ..., "summaries": ..., "fwd": [...], "bwd": [...]}.  dtype: a torch dtype."""
+    import ctypes
+    lib = _lib.load()
+    buf = ctypes.create_string_buffer(1024)
+    rc = lib.mhla_describe_dispatch(B, H, M, S, D, _DTYPES[dtype], int(split), _bm_flags(relu_eps, force_generic, no_smalln, summaries), buf, len(buf))
+    if rc < 0:
+        _lib.check(rc, "mhla_describe_dispatch")
+    return _parse_dispatch(buf.value.decode())
+
+
+def describe_causal_dispatch(T: int, K: int, V: int, dtype, *, chunk_size: int = 64, summaries: str = "tf32", force_generic: bool = False) -> dict:
+    """The same for the causal operator (mhla_causal_describe_dispatch)."""
+    import ctypes
+    lib = _lib.load()
+    buf = ctypes.create_string_buffer(1024)
+    rc = lib.mhla_causal_describe_dispatch(T, K, V, chunk_size, _DTYPES[dtype], _causal_flags(summaries, force_generic), buf, len(buf))
+    if rc < 0:
+        _lib.check(rc, "mhla_causal_describe_dispatch")
+    return _parse_dispatch(buf.value.decode())
+
+
+def _parse_dispatch(txt: str) -> dict:
+    d = dict(part.split("=", 1) for part in txt.split("; "))
+    d["fwd"], d["bwd"] = d["fwd"].split(" "), d["bwd"].split(" ")
+    d["text"] = txt
+    return d
+
+
 def set_option(name: str, value: int) -> int:
     """mhla_set_option through the package: the process-wide options change what the workspace-size queries return
     ("fp32_summaries"), so the cached plans are dropped with every change.  Returns the previous value."""
@@ -330,11 +361,12 @@ def mhla_blockmix(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, W: torch.Te
 
 
 def _wide_head_chunk(D: int) -> int:
-    """Largest divisor of D in [32, 128] that is a multiple of 8 (the kernels' head dims), or 0."""
+    """Slice width for a head dim above 128: the largest divisor of D in [32, 128] that is a multiple of 8 (the kernels' head dims);
+    without one (D = 132, 136, 152, 184, ...) the width in [64, 128] that needs the fewest slices and then the least zero padding."""
     for c in range(128, 31, -8):
         if D % c == 0:
             return c
-    return 0
+    return min(range(64, 129, 8), key=lambda c: (-(-D // c), -(-D // c) * c - D))
 
 
 def _blockmix_wide_head(q, k, v, W, eps, q_den, k_den, normalize, block_index, relu_eps, force_generic, no_smalln, summaries):
@@ -346,9 +378,9 @@ def _blockmix_wide_head(q, k, v, W, eps, q_den, k_den, normalize, block_index, r
     (the slices' autograd nodes and eager PyTorch); no BASELINE shape comes here."""
     B, N, H, D = q.shape
     out_dtype = v.dtype
+    if relu_eps and q_den is not None:
+        raise ValueError("relu_eps needs q_den / k_den to alias q / k (as for head dims up to 128: MHLA_FLAG_RELU_EPS)")
     c = _wide_head_chunk(D)
-    if not c:
-        raise NotImplementedError(f"mhla_blockmix: head dim {D} > 128 has no divisor in [32, 128] that is a multiple of 8")
     Wm = W.reshape(W.shape[0], W.shape[1]) if W.dim() == 4 else W
     M = Wm.shape[0]
     if N % M:
@@ -359,22 +391,24 @@ def _blockmix_wide_head(q, k, v, W, eps, q_den, k_den, normalize, block_index, r
     q, k, v = q.float(), k.float(), v.float()
     if q_den is not None:
         q_den, k_den = q_den.float(), k_den.float()
-    sl = lambda t, a: t[..., a * c:(a + 1) * c].contiguous()
-    kw = dict(eps=eps, normalize=False, block_index=block_index, relu_eps=relu_eps, force_generic=force_generic, no_smalln=no_smalln,
+    if relu_eps:   # (in PyTorch, before any padding: a padded column must stay 0, not become eps)
+        q, k = torch.relu(q) + eps, torch.relu(k) + eps
+    nc = -(-D // c)
+    pad = nc * c - D   # zero columns add nothing to either product (no divisor of D among the kernels' head dims)
+    qp, kp, vp = (torch.nn.functional.pad(t, (0, pad)) if pad else t for t in (q, k, v))
+    qs, ks_, vs = ([t[..., a * c:(a + 1) * c].contiguous() for a in range(nc)] for t in (qp, kp, vp))   # sliced once
+    kw = dict(eps=eps, normalize=False, block_index=block_index, relu_eps=False, force_generic=force_generic, no_smalln=no_smalln,
               summaries=summaries)
-    nc = D // c
     cols = []
     for b in range(nc):
         acc = None
         for a in range(nc):
-            o = mhla_blockmix(sl(q, a), sl(k, a), sl(v, b), W, **kw)
+            o = mhla_blockmix(qs[a], ks_[a], vs[b], W, **kw)
             acc = o if acc is None else acc + o
         cols.append(acc)
-    out = torch.cat(cols, dim=-1)
+    out = torch.cat(cols, dim=-1)[..., :D]
     if normalize:
         qd, kd = (q, k) if q_den is None else (q_den, k_den)
-        if relu_eps:
-            qd, kd = torch.relu(qd) + eps, torch.relu(kd) + eps
         if block_index is not None:   # block-major position p lives at row block_index[p]
             rows = block_index.long()
             qd, kd = qd[:, rows], kd[:, rows]

@@ -315,13 +315,15 @@ def test_split_operand_path_matches_exact_fp32():
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M,S,D,normalize", [(64, 64, 64, True), (33, 20, 64, True), (128, 8, 64, True), (50, 37, 56, True), (100, 12, 32, False),
                                               (64, 16, 64, True), (70, 50, 64, False)])
-def test_24_bit_summaries_vs_fp32_summaries(M, S, D, normalize, dtype):
+def test_24_bit_summaries_vs_fp32_summaries(M, S, D, normalize, dtype, monkeypatch):
     """16-bit tensors, 33 .. 128 blocks, D <= 64: the three storage formats of the block summaries on the resident-mixing pipeline --
     h16 (summaries="tf32", the default: fp16 payload x row multiplier, 11 significand bits; blocks of >= 16 tokens), 24-bit floats
     (summaries="split") and fp32 words (the process option "fp32_summaries").  All meet the oracle at the default tolerance; the two
     16-bit-grade forms agree with each other far inside it, h16 stays within 1e-3 (+ a rounding step of the output) of them."""
     import mhla_amd
-    res = {}
+    from mhla_amd import ops
+    monkeypatch.setattr(ops, "_native_nodes", lambda: False)   # the Python autograd nodes: their workspace plans are cached per shape and
+    res = {}                                                    # flags -- set_option drops the plans when the process-wide format changes
     try:
         for form, summ, fp32 in (("h16", "tf32", 0), ("p24", "split", 0), ("fp32", "split", 1)):
             mhla_amd.set_option("fp32_summaries", fp32)
@@ -436,12 +438,33 @@ def test_fused_qkv_views_and_relu_prologue():
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("M,S,D,normalize,split,gather", [(16, 16, 256, True, False, False), (9, 20, 192, True, True, True), (33, 12, 160, False, False, False),
-                                                           (4, 49, 144, True, False, True)])
+                                                           (4, 49, 144, True, False, True),
+                                                           # no divisor among the kernels' head dims: zero-padded slices (136 = 2 x 72 - 8, 184 = 2 x 96 - 8)
+                                                           (6, 20, 136, True, False, False), (5, 16, 184, True, True, True)])
 def test_head_dims_above_128_compose_from_slices(M, S, D, normalize, split, gather, dtype):
     """dim_head > 128 (the reference module takes any, mhla_dit/mhla/mhla.py:155-158): (D / c)^2 un-normalised calls on c-wide slices of
     q / k and v plus the normaliser in tensor ops (ops._blockmix_wide_head) -- outputs and every gradient against the oracle."""
     idx = torch.randperm(M * S, generator=torch.Generator().manual_seed(M)).int() if gather else None
     run_case(1, 2, M, S, D, dtype, normalize=normalize, split=split, w="rand", idx=idx, seed=D)
+
+
+def test_head_dims_above_128_relu_prologue_and_padding():
+    """dim_head > 128 with the relu + eps prologue (applied before the zero padding of a slice: padded columns stay 0) against the oracle."""
+    import mhla_amd
+    B, H, M, S, D = 1, 2, 6, 20, 136
+    g = torch.Generator().manual_seed(3)
+    q, k, v, do = (torch.randn(B, M * S, H, D, generator=g) for _ in range(4))
+    W = torch.rand(M, M, generator=g)
+    want, wg = oracle_blockmix(torch.relu(q) + 1e-6, torch.relu(k) + 1e-6, v, W, do, None, None, 1e-6, True)
+    t = [x.requires_grad_(True) for x in to_dev(q, k, v, W)]
+    out = mhla_amd.mhla_blockmix(*t, relu_eps=True)
+    out.backward(do.to(DEV))
+    check("out", out, want, TOL[torch.float32])
+    check("dv", t[2].grad, wg["dv"], GTOL[torch.float32])
+    check("dW", t[3].grad, wg["dW"], DW_TOL[torch.float32])
+    mask = lambda gq, x: gq * (x > 0)
+    check("dq", t[0].grad, mask(wg["dq"], q), GTOL[torch.float32])
+    check("dk", t[1].grad, mask(wg["dk"], k), GTOL[torch.float32])
 
 
 def test_empty_batch():
@@ -465,9 +488,9 @@ def test_errors_fail_loudly():
         mhla_amd.mhla_blockmix(q.cpu(), q.cpu(), q.cpu(), W.cpu())            # no CPU fallback
     with pytest.raises(ValueError):
         mhla_amd.mhla_blockmix(q, q, q, torch.eye(5, device=DEV))             # N not divisible by M
-    big = torch.randn(1, 64, 2, 136, device=DEV)
-    with pytest.raises(NotImplementedError):
-        mhla_amd.mhla_blockmix(big, big, big, W)                              # D > 128 with no slice width in [32, 128] (136 = 17 x 8)
+    big = torch.randn(1, 64, 2, 160, device=DEV)
+    with pytest.raises(ValueError):
+        mhla_amd.mhla_blockmix(big, big, big, W, q_den=big, k_den=big, relu_eps=True)   # relu prologue with a separate normaliser pair (as for D <= 128)
     with pytest.raises(TypeError):
         mhla_amd.mhla_blockmix(q.double(), q.double(), q.double(), W)
 

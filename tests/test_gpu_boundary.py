@@ -267,3 +267,40 @@ def test_bwd_status_after_a_fast_shape_fell_back_to_another_path():
     for name, a, b in zip(("dq", "dk", "dv"), grads, ts):
         check(name, a, b.grad.float().cpu(), 2 * 3 * 2.0 ** -8)
     check("dW", dW, Wd.grad.float().cpu(), 2 * 3 * 2.0 ** -8)
+
+
+@pytest.mark.parametrize("case", ["c2", "c2_split", "c2_256x16", "odd_s", "c4_small", "fp32_64", "generic", "c3", "causal", "causal_129"])
+def test_described_dispatch_is_the_dispatch_that_runs(case):
+    """mhla_describe_dispatch against the library's own per-launch hook: the kernels it names are the kernels a forward + backward of the
+    problem launches, in order (block-mix shapes of every family and summary format, the causal pipeline with one and two mixing launches)."""
+    import ctypes
+    import mhla_amd
+    from gpu_util import make_blockmix_inputs, to_dev
+    bf, f32 = torch.bfloat16, torch.float32
+    lib = mhla_amd._lib.load()
+    causal = case.startswith("causal")
+    if causal:
+        T = 8256 if case == "causal_129" else 512
+        n = (T + 63) // 64
+        want = mhla_amd.describe_causal_dispatch(T, 64, 64, bf)
+        g = torch.Generator().manual_seed(0)
+        t = [torch.randn(1, T, 1, 64, generator=g).to(bf).to(DEV).requires_grad_(True) for _ in range(3)] + [mhla_amd.causal_mixing_init(n).reshape(n, n).to(DEV).requires_grad_(True)]
+        run = lambda: mhla_amd.mhla_causal(*t).sum().backward()
+    else:
+        B, H, M, S, D, dt, kw = {"c2": (1, 2, 64, 64, 64, bf, {}), "c2_split": (1, 2, 64, 64, 64, bf, {"summaries": "split"}),
+                                 "c2_256x16": (1, 2, 256, 16, 64, bf, {}), "odd_s": (1, 2, 40, 21, 64, bf, {}), "c4_small": (1, 2, 150, 6, 128, f32, {}),
+                                 "fp32_64": (1, 2, 64, 32, 64, f32, {}), "generic": (1, 2, 16, 16, 36, f32, {}), "c3": (2, 2, 16, 16, 72, bf, {})}[case]
+        want = mhla_amd.describe_dispatch(B, H, M, S, D, dt, **kw)
+        q, k, v, W, do, _, _ = make_blockmix_inputs(B, H, M, S, D, dt, 1, "rand", False)
+        t = [x.requires_grad_(True) for x in to_dev(q, k, v, W)]
+        run = lambda: mhla_amd.mhla_blockmix(*t, **kw).sum().backward()
+    run()   # (first call: plans, LDS opt-ins)
+    torch.cuda.synchronize()
+    lib.mhla_prof_enable(1)
+    run()
+    torch.cuda.synchronize()
+    lib.mhla_prof_enable(0)
+    buf = ctypes.create_string_buffer(1 << 14)
+    lib.mhla_prof_report(buf, len(buf))
+    ran = sorted(line.rsplit(" ", 2)[0] for line in buf.value.decode().splitlines() for _ in range(int(line.rsplit(" ", 2)[1])))
+    assert ran == sorted(want["fwd"] + want["bwd"]), (want["text"], ran)

@@ -85,6 +85,18 @@ def test_argument_validation_without_gpu():
     assert rc == -95 and b"chunk" in lib.mhla_last_error()
     rc = lib.mhla_causal_fwd(ok, ok, ok, 1 << 20, 4, ok, 1 << 20, 1 << 30, 1, 128, 1, 64, 64, 64, 0.125, 0, 8, None)
     assert rc == -22 and b"flags" in lib.mhla_last_error()
+    # the summary-format flags: single-bf16 summaries serve bf16 tensors only; the two opt-ins exclude each other
+    rc = lib.mhla_blockmix_fwd(ok, ok, ok, ok, ok, 1 << 20, 4, ok, None, 1 << 20, 1 << 30, 1, 1, 4, 32, 64, _lib.F16, 1e-6, _lib.FLAG_BF16_SUMMARIES, None)
+    assert rc == -22 and b"bf16 tensors only" in lib.mhla_last_error()
+    rc = lib.mhla_blockmix_fwd(ok, ok, ok, ok, ok, 1 << 20, 4, ok, None, 1 << 20, 1 << 30, 1, 1, 4, 32, 64, _lib.BF16, 1e-6,
+                               _lib.FLAG_BF16_SUMMARIES | _lib.FLAG_FP32_GRADE_SUMMARIES, None)
+    assert rc == -22 and b"exclude" in lib.mhla_last_error()
+    rc = lib.mhla_causal_fwd(ok, ok, ok, 1 << 20, 4, ok, 1 << 20, 1 << 30, 1, 128, 1, 64, 64, 64, 0.125, _lib.BF16,
+                             _lib.CAUSAL_BF16_SUMMARIES | _lib.CAUSAL_FP32_GRADE_SUMMARIES, None)
+    assert rc == -22 and b"exclude" in lib.mhla_last_error()
+    # the forward of an inference call (MHLA_FLAG_NO_BWD_STATE) does not carve the O-residual region (D = 72: outside the row-dots-from-G shapes)
+    assert (lib.mhla_blockmix_fwd_ws_bytes(8, 16, 64, 64, 72, _lib.BF16, 0, 0) - lib.mhla_blockmix_fwd_ws_bytes(8, 16, 64, 64, 72, _lib.BF16, 0, _lib.FLAG_NO_BWD_STATE)
+            == 8 * 4096 * 16 * 72 * 2)
 
 
 @pytest.mark.parametrize("tr", ["linear", "cos", "exp", "gaussian", "local"])
@@ -355,3 +367,35 @@ def test_bench_line_is_small_strict_json():
     assert len(line) < 4096
     got = json.loads(line, parse_constant=lambda c: (_ for _ in ()).throw(ValueError(c)))
     assert got["roofline"]["traffic"] is None and got["value"] == pytest.approx(full["value"], rel=1e-5)
+
+
+def test_describe_dispatch_names_the_path_of_every_baseline_config():
+    """mhla_describe_dispatch / mhla_causal_describe_dispatch (pure host logic): the kernel family and block-summary format a
+    BASELINE.json configuration takes, asserted instead of inferred from timings."""
+    import mhla_amd
+    bf, f32, f16 = torch.bfloat16, torch.float32, torch.float16
+    c2 = mhla_amd.describe_dispatch(8, 16, 64, 64, 64, bf)                                      # configs[1]
+    assert c2["family"].startswith("split-operand") and c2["summaries"].startswith("h16")
+    assert c2["fwd"] == ["k_sp_state", "k_sp_mixh<0>", "k_sp_out"]
+    assert c2["bwd"] == ["k_sp_state<1>", "k_sp_mixh<1,dw>", "k_dw_reduce", "k_sp_bwd_dq", "k_sp_bwd_dkv"]
+    assert mhla_amd.describe_dispatch(8, 16, 64, 64, 64, bf, summaries="split")["summaries"].startswith("p24")
+    assert mhla_amd.describe_dispatch(8, 16, 64, 64, 64, f16)["summaries"].startswith("h16")
+    assert mhla_amd.describe_dispatch(8, 16, 64, 64, 64, bf, summaries="bf16")["family"].startswith("bf16 fast path")
+    assert mhla_amd.describe_dispatch(8, 16, 64, 64, 64, f32)["summaries"] == "fp32 words"
+    assert mhla_amd.describe_dispatch(8, 16, 16, 256, 64, bf)["summaries"].startswith("h16")   # C2 variant 16 x 256
+    assert mhla_amd.describe_dispatch(8, 16, 256, 16, 64, bf)["summaries"] == "fp32 words"     # C2 variant 256 x 16: more than 128 blocks
+    assert mhla_amd.describe_dispatch(8, 16, 64, 8, 64, bf)["summaries"].startswith("p24")     # blocks of fewer than 16 tokens
+    assert mhla_amd.describe_dispatch(8, 16, 2, 64, 64, bf)["summaries"].startswith("p24")     # fewer than 4 blocks
+    c3 = mhla_amd.describe_dispatch(32, 16, 16, 16, 72, bf)                                     # configs[2]: DiT-XL/2 256^2
+    assert c3["family"].startswith("small-sequence bf16") and c3["fwd"] == ["k_sn_fwd<hl>"] and c3["bwd"][0] == "k_sn_bwd<hl>"
+    assert mhla_amd.describe_dispatch(32, 16, 16, 16, 72, f32)["family"].startswith("small-sequence fp32")
+    assert mhla_amd.describe_dispatch(32, 16, 16, 16, 72, bf, no_smalln=True)["summaries"].startswith("h16")
+    c4 = mhla_amd.describe_dispatch(1, 12, 150, 210, 128, f32, split=True)                     # configs[3]: Wan2.1-1.3B
+    assert c4["summaries"].startswith("p24") and "k_sp_mixr<0>" in c4["fwd"] and "k_sp_dwt" in c4["bwd"]
+    assert mhla_amd.describe_dispatch(2, 2, 16, 16, 36, f32)["family"].startswith("generic")   # D % 8 != 0
+    for K, V in ((128, 256), (256, 512)):                                                      # configs[4]: fla 340M / 1.3B-like
+        c5 = mhla_amd.describe_causal_dispatch(8192, K, V, bf)
+        assert c5["family"].startswith("16-bit pipeline") and c5["summaries"].startswith("h16") and c5["bwd"][1] == "k_csf_mixb"
+    assert mhla_amd.describe_causal_dispatch(8192, 128, 256, bf, summaries="split")["summaries"].startswith("bf16 hi + lo")
+    assert mhla_amd.describe_causal_dispatch(8192, 128, 256, f32)["family"].startswith("generic")
+    assert mhla_amd.describe_causal_dispatch(16448, 64, 64, bf)["family"].startswith("generic")   # 257 chunks
