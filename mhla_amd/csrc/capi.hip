@@ -556,12 +556,13 @@ int mhla_describe_dispatch(int B, int H, int M, int S, int D, int dtype, int spl
     if (!nosn && snf_shape_ok(M, S, D, dtype, split != 0)) {
         fam = "small-sequence fp32 (attention form, one launch per direction)";
         sum = "none (score tiles in LDS as bf16 hi + lo pairs)";
-        fwd = "k_snf_fwd"; bwd = "k_snf_bwd k_sn_dw_reduce";
+        fwd = D <= 64 ? "k_snf_fwd<4>" : "k_snf_fwd<5>"; bwd = std::string(D <= 64 ? "k_snf_bwd<4>" : "k_snf_bwd<5>") + " k_sn_dw_reduce";
     } else if (!nosn && sn_shape_ok(M, S, D, dtype, split != 0)) {
         fam = "small-sequence bf16 (attention form, one launch per direction)";
         const bool hl = !(flags & MHLA_FLAG_BF16_SUMMARIES);
         sum = hl ? "none (score tiles in LDS as bf16 hi + lo pairs)" : "none (score tiles as single bf16: reduced precision)";
-        fwd = hl ? "k_sn_fwd<hl>" : "k_sn_fwd"; bwd = hl ? "k_sn_bwd<hl> k_sn_dw_reduce" : "k_sn_bwd k_sn_dw_reduce";
+        const std::string dt = D <= 64 ? "4" : "5";
+        fwd = "k_sn_fwd<" + dt + (hl ? ",hl>" : ">"); bwd = "k_sn_bwd<" + dt + (hl ? ",hl>" : ">") + " k_sn_dw_reduce";
     } else if (!gen && fast_shape_ok(M, D, dtype, split != 0, flags)) {
         fam = "bf16 fast path (fused mixing + token tiles)";
         sum = "bf16 (single bf16 values, 8-block interleaved: reduced precision, opt-in)";
@@ -590,7 +591,7 @@ int mhla_describe_dispatch(int B, int H, int M, int S, int D, int dtype, int spl
     } else {
         fam = "generic (exact fp32 MFMA)";
         sum = "fp32 words (dense rows)";
-        fwd = "k_bm_state<0> k_mix<0,0> k_wz<0> k_bm_out"; bwd = "k_bm_state<1> k_wz<1> k_mix<1,0> k_dw k_dw_reduce k_bm_bwd_tok";
+        fwd = "k_bm_state<0> k_mix<0,0> k_wz<0> k_bm_out"; bwd = "k_bm_state<0> k_mix<0,0> k_wz<0> k_bm_state<1> k_wz<1> k_mix<1,0> k_dw k_dw_reduce k_bm_bwd_tok";   // (no state is kept: the backward recomputes KV, G, 1 / n)
     }
     const std::string txt = "family=" + fam + "; summaries=" + sum + "; fwd=" + fwd + "; bwd=" + bwd;
     if (buf && cap) {

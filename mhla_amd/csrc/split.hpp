@@ -2385,6 +2385,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_bwd_dkv(const TokArgs a) {  
         if ((tt + 4) * 16 < S) fetch(tt + 4, nxt);
         bf16x8 vh[KST], vl[KST], kh[KST], kl[KST];
         f32x4 dkst[2], dvst[2];
+        constexpr bool LATE = false;   // (measured, round 6: a token's dK pieces then its dV pieces stored behind the tile loop -- 79.6 -> 85.3 us at C2: the stores start later)
+        f32x4 dkall[LATE ? DT : 1], dvall[LATE ? DT : 1];
 #pragma unroll
         for (int ks = 0; ks < KST; ++ks) {
             uint4 hi, lo;
@@ -2435,6 +2437,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_bwd_dkv(const TokArgs a) {  
                     for (int i = 0; i < 4; ++i)
                         if (!(fmaxf(cur.km[ct][i], 0.f) + a.eps > a.eps)) ck[i] = 0.f;
             }
+            if constexpr (LATE) {
+                dkall[ct] = ck;
+                dvall[ct] = cv;
+            } else {
             dkst[ct & 1] = ck;
             dvst[ct & 1] = cv;
             if ((ct & 1) || ct == DT - 1) {   // store pairs of feature tiles: whole 128-byte lines (fp32) / 16-byte pieces (16-bit tensors)
@@ -2448,7 +2454,24 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_bwd_dkv(const TokArgs a) {  
                     if (sb) Io<T>::st4(dkdb + cur.row * a.dkd.sn + db, *reinterpret_cast<const f32x4*>(dks + db));
                 }
             }
+            }
             __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (LATE) {
+            // 16-bit rows of up to 128 bytes: all of a token's dK pieces, then all of its dV pieces, in consecutive store instructions -- the
+            // two 64-byte halves of a line written with the other tensor's store and two tiles of products between them left the L2 as
+            // partial lines (WRITE_SIZE 154 MB for 134 MB of results, and the fill reads on top)
+#pragma unroll
+            for (int cta = 0; cta < DT; cta += 2) store_tile_pair<T>(dkb + cur.row * a.dk.sn, cta, DT, D, kg, dkall[cta], dkall[cta + 1 < DT ? cta + 1 : cta], cur.live, wide_dk);
+#pragma unroll
+            for (int cta = 0; cta < DT; cta += 2) store_tile_pair<T>(dvb + cur.row * a.dv.sn, cta, DT, D, kg, dvall[cta], dvall[cta + 1 < DT ? cta + 1 : cta], cur.live, wide_dv);
+            if (a.normalize && a.split && cur.live) {
+#pragma unroll
+                for (int ct = 0; ct < DT; ++ct) {
+                    const int da = ct * 16 + kg * 4;
+                    if (da < D) Io<T>::st4(dkdb + cur.row * a.dkd.sn + da, *reinterpret_cast<const f32x4*>(dks + da));
+                }
+            }
         }
         cur = nxt;
     }

@@ -33,7 +33,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     rows, small = 8 * 16 * 64, lambda M, S, D: 4 * (2 * 8 * 16 * M * S + 8 * 16 * M * D)     # summary rows per set; z, 1/n, ksum
     assert fwd == 2 * rows * (4096 + 288) * 4 + small(64, 64, 64)
     h16 = lib.mhla_blockmix_fwd_ws_bytes(8, 16, 64, 64, 64, 1, 0, 0)
-    assert h16 == 2 * rows * (2048 + 4 + 288) * 4 + small(64, 64, 64)
+    assert h16 == 2 * rows * (2048 + 288) * 4 + small(64, 64, 64)
     assert lib.mhla_blockmix_fwd_ws_bytes(8, 16, 64, 64, 64, 2, 0, 0) == h16                    # fp16 tensors alike
     assert lib.mhla_blockmix_fwd_ws_bytes(8, 16, 64, 64, 64, 1, 0, _lib.FLAG_FP32_GRADE_SUMMARIES) == 2 * rows * (3072 + 288) * 4 + small(64, 64, 64)
     assert lib.mhla_blockmix_fwd_ws_bytes(8, 16, 512, 8, 64, 1, 0, 0) > lib.mhla_blockmix_fwd_ws_bytes(8, 16, 512, 8, 64, 0, 0, 0) * 0.99   # > 256 blocks: fp32 words for every dtype
@@ -42,7 +42,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     # keeps the bf16 residual of its store of O, B N H D * 2 bytes: here D = 72)
     f72 = lib.mhla_blockmix_fwd_ws_bytes(8, 16, 64, 64, 72, 0, 0, 0)
     assert f72 == 2 * rows * (5184 + 288) * 4 + small(64, 64, 72)
-    assert lib.mhla_blockmix_fwd_ws_bytes(8, 16, 64, 64, 72, 1, 0, 0) == 2 * rows * (2592 + 4 + 288) * 4 + small(64, 64, 72) + 8 * 4096 * 16 * 72 * 2
+    assert lib.mhla_blockmix_fwd_ws_bytes(8, 16, 64, 64, 72, 1, 0, 0) == 2 * rows * (2592 + 288) * 4 + small(64, 64, 72) + 8 * 4096 * 16 * 72 * 2
     assert lib.mhla_blockmix_fwd_ws_bytes(8, 16, 64, 64, 64, 1, 0, _lib.FLAG_BF16_SUMMARIES) < 0.6 * fwd
     assert lib.mhla_blockmix_fwd_ws_bytes(8, 16, 64, 64, 64, 0, 0, _lib.FLAG_BF16_SUMMARIES) == fwd
     assert lib.mhla_blockmix_fwd_ws_bytes(8, 16, 64, 64, 64, 0, 0, _lib.FLAG_FP32_GRADE_SUMMARIES) == fwd
@@ -387,7 +387,7 @@ def test_describe_dispatch_names_the_path_of_every_baseline_config():
     assert mhla_amd.describe_dispatch(8, 16, 64, 8, 64, bf)["summaries"].startswith("p24")     # blocks of fewer than 16 tokens
     assert mhla_amd.describe_dispatch(8, 16, 2, 64, 64, bf)["summaries"].startswith("p24")     # fewer than 4 blocks
     c3 = mhla_amd.describe_dispatch(32, 16, 16, 16, 72, bf)                                     # configs[2]: DiT-XL/2 256^2
-    assert c3["family"].startswith("small-sequence bf16") and c3["fwd"] == ["k_sn_fwd<hl>"] and c3["bwd"][0] == "k_sn_bwd<hl>"
+    assert c3["family"].startswith("small-sequence bf16") and c3["fwd"] == ["k_sn_fwd<5,hl>"] and c3["bwd"][0] == "k_sn_bwd<5,hl>"
     assert mhla_amd.describe_dispatch(32, 16, 16, 16, 72, f32)["family"].startswith("small-sequence fp32")
     assert mhla_amd.describe_dispatch(32, 16, 16, 16, 72, bf, no_smalln=True)["summaries"].startswith("h16")
     c4 = mhla_amd.describe_dispatch(1, 12, 150, 210, 128, f32, split=True)                     # configs[3]: Wan2.1-1.3B
