@@ -1621,11 +1621,10 @@ __global__ __launch_bounds__(SP_OUT_T, EPI ? SP_OUT_EPI_WAVES : 2) void k_sp_out
     // tile per wave); 16-bit tensors also keep the wave's next tile in flight under the products (8 registers per reduction step).
     // Every load is unconditional, from clamped addresses (rows past the block: its last row; columns past D: the row's first piece).
     constexpr bool DBL = sizeof(T) == 2;
-    // (fused-epilogue variants -- the Wan inference kernels, one workgroup per CU on up to 256 VGPRs -- also fetch the token's rope angles
-    // with its rows: loaded where they are used they were one more memory round trip per tile, in front of the products)
+    // (Fetching the token's rope angles with its rows too -- 64 more registers in the fused-epilogue variants, which have them -- was
+    // measured and lost: k_sp_out<norm,pro> 189 -> 218 us per Wan layer, the fp32 variant 176 -> 184.)
     struct QRows {
         typename Raw4<T>::type x[KST][2];
-        f32x4 rc[EPI ? KST : 1], rs[EPI ? KST : 1];
         float ninv, rq;
         long row;
     };
@@ -1640,14 +1639,6 @@ __global__ __launch_bounds__(SP_OUT_T, EPI ? SP_OUT_EPI_WAVES : 2) void k_sp_out
             const int c = ks * 32 + kg * 8 < D ? ks * 32 + kg * 8 : 0;
             R.x[ks][0] = *reinterpret_cast<const typename Raw4<T>::type*>(qrow + c);
             R.x[ks][1] = *reinterpret_cast<const typename Raw4<T>::type*>(qrow + c + 4);
-        }
-        if constexpr (EPI) {
-#pragma unroll
-            for (int ks = 0; ks < KST; ++ks) {
-                const long ro = a.rcos ? R.row * a.ldr + (ks * 32 + kg * 8 < D ? ks * 16 + kg * 4 : 0) : 0;
-                R.rc[ks] = *reinterpret_cast<const f32x4*>((a.rcos ? a.rcos : a.g) + ro);
-                R.rs[ks] = *reinterpret_cast<const f32x4*>((a.rcos ? a.rsin : a.g) + ro);
-            }
         }
         R.ninv = gld<float>(a.normalize ? ninvb + sv : a.W);
         R.rq = 1.f;
@@ -1680,12 +1671,8 @@ __global__ __launch_bounds__(SP_OUT_T, EPI ? SP_OUT_EPI_WAVES : 2) void k_sp_out
                 }
                 if (a.relu) relu8(x0, x1, a.eps);
                 if (a.rcos) {
-                    if constexpr (EPI) {
-                        rope8(x0, x1, cur.rc[ks], cur.rs[ks]);
-                    } else {
-                        const long ro = row * a.ldr + ks * 16 + kg * 4;
-                        rope8(x0, x1, *reinterpret_cast<const f32x4*>(a.rcos + ro), *reinterpret_cast<const f32x4*>(a.rsin + ro));
-                    }
+                    const long ro = row * a.ldr + ks * 16 + kg * 4;
+                    rope8(x0, x1, *reinterpret_cast<const f32x4*>(a.rcos + ro), *reinterpret_cast<const f32x4*>(a.rsin + ro));
                 }
             }
             uint4 hi, lo;
