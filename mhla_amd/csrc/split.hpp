@@ -935,8 +935,7 @@ template <int NW, bool S16> __host__ __device__ constexpr int mixr_te() { return
 template <int NW, bool S16, bool DW = false>
 __host__ __device__ constexpr int sp_mixr_smem() {
     constexpr int TE = mixr_te<NW, S16>(), ROWS = 16 * NW;
-    // (fp32-grade summaries: + the rows' h16 multipliers, input and output, [2][ROWS] floats behind the staging tile)
-    return (S16 ? 1 : (DW ? 4 : 2)) * ROWS * (TE + 8) * 2 + (S16 ? ROWS * (TE + 8) * 2 : ROWS * (TE + 4) * 4 + 2 * ROWS * 4);
+    return (S16 ? 1 : (DW ? 4 : 2)) * ROWS * (TE + 8) * 2 + (S16 ? ROWS * (TE + 8) * 2 : ROWS * (TE + 4) * 4);
 }
 
 // DW (TRANS 1, fp32 summaries, M <= 128): the kernel also stages the KV rows of every slice (hi + lo, two more tiles) and accumulates
@@ -945,11 +944,12 @@ __host__ __device__ constexpr int sp_mixr_smem() {
 // fixed order by k_dw_reduce.  Replaces k_sp_dw, which read dG and KV a second time (C2 at the default arithmetic: 81 us).
 // P24: the summaries (in, in2, out) are stored as 24-bit floats in two planes per row (p24_pack8).  A thread's unit is then 8 elements
 // of a row -- one 16-byte piece of the hi plane and one 8-byte piece of the lo plane -- instead of a 16-byte piece of 4 floats.
-// P24 = 2 (h16): fp16 payload, one multiplier per row (decoded at the commit, the output rows' multipliers from the bound of the inputs')
+// (h16 summaries are mixed by k_sp_mixh, mixh.hpp: on the payload, with the fp16 MFMA.  A decode-at-the-commit variant of THIS kernel was
+// built first in round 6 and was no faster than p24: 2-byte rows in 64-element slices put fewer bytes in flight per workgroup.)
 template <int NW, int TRANS, bool S16, bool DW = false, int P24 = 0>
-__global__ __launch_bounds__(64 * NW, (NW == 8 && !DW && P24 == 1) ? 4 : ((NW == 4 && !DW && P24 == 2) ? 4 : (NW + 3) / 4)) void k_sp_mixr(const MixrArgs a) {   // (eight waves on 24-bit summaries without dW: 128 VGPRs, two workgroups per CU instead of one at 136)
+__global__ __launch_bounds__(64 * NW, (NW == 8 && !DW && P24 == 1) ? 4 : (NW + 3) / 4) void k_sp_mixr(const MixrArgs a) {   // (eight waves on 24-bit summaries without dW: 128 VGPRs, two workgroups per CU instead of one at 136)
     static_assert(!DW || (TRANS == 1 && !S16 && NW <= 8), "dW rides in the backward's fp32 mixing kernel, M <= 128 (twelve waves: 77 spilled registers)");
-    static_assert(!P24 || (!S16 && NW <= 12), "p24: fp32-grade summaries, slices of 64 elements");
+    static_assert(P24 == 0 || (P24 == 1 && !S16 && NW <= 12), "p24: fp32-grade summaries, slices of 64 elements");
     constexpr int TE = mixr_te<NW, S16>(), ROWS = 16 * NW, LD = TE + 8, LDO = TE + 4, NK = (NW + 1) / 2, NT = TE / 16;
     constexpr int PPR = TE * (S16 ? 2 : 4) / 16;          // 16-byte pieces per row of the slice (16, or 8 with 16 waves)
     constexpr int NTH = 64 * NW, NP = P24 ? ROWS * 8 / NTH : ROWS * PPR / NTH;   // pieces (P24: units of 8 elements) per thread and slice
@@ -961,9 +961,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && !DW && P24 == 1) ? 4 : ((NW ==
     u16* Kh = Tl + ROWS * LD;                                        // (DW only: the KV rows of the slice)
     u16* Kl = Kh + ROWS * LD;
     unsigned char* Os = smem_raw + (S16 ? 1 : (DW ? 4 : 2)) * ROWS * LD * 2;     // bf16 [ROWS][LD] or fp32 [ROWS][LDO]
-    constexpr bool H16 = P24 == 2;
-    float* ms = reinterpret_cast<float*>(Os + ROWS * LDO * 4);   // h16: the input rows' multipliers [ROWS] (rows past M: 0), then the output rows'
-    float* mo = ms + ROWS;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nl = lane & 15, kg = lane >> 4;
     const int M = a.M;
     const long nsl = a.E / TE;
@@ -979,8 +976,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && !DW && P24 == 1) ? 4 : ((NW ==
     constexpr int SLB = P24 ? 128 : TE * ESZ;             // bytes of a slice in a summary row (P24: of its hi plane)
     // P24: the lo piece of a unit relative to its hi piece (goff + 16 c of slice es): lo plane at 2 E, slice at 64 es, piece at 8 c
     auto lo_rel = [&](int es, int c) { return (long)2 * a.E - 64 * es - 8 * c; };
-    // h16: the row's multiplier (byte 2 E of the row) relative to a unit's payload piece (goff + 16 c of slice es, 128 bytes per slice)
-    auto hm_rel = [&](int es, int c) { return (long)2 * a.E - 128 * es - 16 * c; };
     // byte offset of slice (bh, es); a workgroup's slices are consecutive, so the pair is advanced rather than divided out per
     // slice (the 64-bit division was 150 instructions with branches between the barrier and the next slice's loads)
     auto slice_off = [&](int bh, int es) { return (long)bh * M * a.es * ESZ + (long)es * SLB; };
@@ -996,8 +991,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && !DW && P24 == 1) ? 4 : ((NW ==
     // staging registers.  P24: pre = hi piece, prl = lo piece; a normaliser slice (plain floats) takes the unit's 8 floats in pre + prz
     struct Stage {
         uint4 pre[NP], pre2[DW ? NP : 1], prz[P24 ? NP : 1], prz2[(P24 && DW) ? NP : 1];
-        u32x2_t prl[P24 == 1 ? NP : 1], prl2[(P24 == 1 && DW) ? NP : 1];   // (native vectors: an array of uint2 in here stays in scratch)
-        float prs[H16 ? NP : 1], prs2[(H16 && DW) ? NP : 1];              // h16: the unit's row multiplier (in / in2)
+        u32x2_t prl[P24 ? NP : 1], prl2[(P24 && DW) ? NP : 1];   // (native vectors: an array of uint2 in here stays in scratch)
     };
     // (A second slice in flight per workgroup -- two Stage objects, the loop unrolled by two -- gained nothing: hipcc's wait in front of
     // the commit is vmcnt(0), i.e. for both.  Nor did starting the workgroups of a CU a fraction of an iteration apart, or fetching and
@@ -1053,16 +1047,14 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && !DW && P24 == 1) ? 4 : ((NW ==
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             g.pre[p] = gld_stream16(base + goff[p]);
-            if constexpr (P24 == 1) g.prl[p] = *(const MHLA_GLOBAL_AS u32x2_t*)(base + goff[p] + lo_rel(es, (tid + p * NTH) % UPR));
-            if constexpr (H16) g.prs[p] = gld<float>(base + goff[p] + hm_rel(es, (tid + p * NTH) % UPR));
+            if constexpr (P24) g.prl[p] = *(const MHLA_GLOBAL_AS u32x2_t*)(base + goff[p] + lo_rel(es, (tid + p * NTH) % UPR));
         }
         if constexpr (DW) {
             const char* base2 = reinterpret_cast<const char*>(a.in2) + boff;
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
                 g.pre2[p] = gld_stream16(base2 + goff[p]);
-                if constexpr (P24 == 1) g.prl2[p] = *(const MHLA_GLOBAL_AS u32x2_t*)(base2 + goff[p] + lo_rel(es, (tid + p * NTH) % UPR));
-                if constexpr (H16) g.prs2[p] = gld<float>(base2 + goff[p] + hm_rel(es, (tid + p * NTH) % UPR));
+                if constexpr (P24) g.prl2[p] = *(const MHLA_GLOBAL_AS u32x2_t*)(base2 + goff[p] + lo_rel(es, (tid + p * NTH) % UPR));
             }
         }
     };
@@ -1119,15 +1111,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && !DW && P24 == 1) ? 4 : ((NW ==
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             const int v = tid + p * NTH, row = v / UPR, c = v % UPR;
-            if constexpr (H16) {
-                if (row < M) {
-                    const float* src = reinterpret_cast<const float*>(Os) + row * LDO + c * 8;
-                    const float om = mo[row];
-                    gst<uint4>(ob + goff[p], h16_pack8(*reinterpret_cast<const f32x4*>(src), *reinterpret_cast<const f32x4*>(src + 4), h16_inv(om)));
-                    if (zes == 0 && c == 0) gst<float>(ob + goff[p] + hm_rel(0, 0), om);   // (the workgroup that holds a (b, h)'s first slice writes its rows' multipliers)
-                }
-                continue;
-            } else if constexpr (P24) {
+            if constexpr (P24) {
                 if (row < M) {
                     const float* src = reinterpret_cast<const float*>(Os) + row * LDO + c * 8;
                     uint4 hi;
@@ -1165,19 +1149,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && !DW && P24 == 1) ? 4 : ((NW ==
                     if constexpr (DW) {
                         commit_hl(Kh, Kl, zmask(g.pre2[p], ok, p, zes, 0), row, 2 * c);
                         commit_hl(Kh, Kl, zmask(g.prz2[p], ok, p, zes, 1), row, 2 * c + 1);
-                    }
-                } else if constexpr (H16) {   // payload x the row's multiplier -> hi + lo operands
-                    const float m = ok ? g.prs[p] : 0.f;
-                    uint4 hi, lo;
-                    h16_split8(x, m, hi, lo);
-                    *reinterpret_cast<uint4*>(Th + row * LD + c * 8) = hi;
-                    *reinterpret_cast<uint4*>(Tl + row * LD + c * 8) = lo;
-                    if (c == 0) ms[row] = m;
-                    if constexpr (DW) {
-                        const uint4 y = make_uint4(ok ? g.pre2[p].x : 0u, ok ? g.pre2[p].y : 0u, ok ? g.pre2[p].z : 0u, ok ? g.pre2[p].w : 0u);
-                        h16_split8(y, ok ? g.prs2[p] : 0.f, hi, lo);
-                        *reinterpret_cast<uint4*>(Kh + row * LD + c * 8) = hi;
-                        *reinterpret_cast<uint4*>(Kl + row * LD + c * 8) = lo;
                     }
                 } else {   // the hi piece is the operand; the lo operand is rebuilt from the third bytes
                     const uint2 l = make_uint2(ok ? g.prl[p][0] : 0u, ok ? g.prl[p][1] : 0u);
@@ -1257,25 +1228,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && !DW && P24 == 1) ? 4 : ((NW ==
                     }
                 }
             }
-        }
-        if constexpr (H16 && !ZS) {
-            // the output rows' multipliers: |out_o[e]| <= sum_r |w(o, r)| 2^15 m_r =: 2^15 beta_o, m_o = the power of two >= beta_o.  Lane:
-            // output block o = 16 wave + nl, input blocks r = 32 ks + 8 kg + t (its B-operand registers); the four kg lanes meet by shuffles
-            float beta = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < NK; ++ks) {
-                if (ks < kend) {
-                    const f32x4 m0 = *reinterpret_cast<const f32x4*>(ms + ks * 32 + kg * 8), m1 = *reinterpret_cast<const f32x4*>(ms + ks * 32 + kg * 8 + 4);
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        beta += fabsf((float)wh[ks][0][t] + (float)wl[ks][0][t]) * m0[t];
-                        beta += fabsf((float)wh[ks][0][4 + t] + (float)wl[ks][0][4 + t]) * m1[t];
-                    }
-                }
-            }
-            beta += __shfl_xor(beta, 16, 64);
-            beta += __shfl_xor(beta, 32, 64);
-            if (kg == 0) mo[wave * 16 + nl] = h16_mult_from_bound(beta);
         }
         // lane: elements 16 t + 4 kg .. + 3 of output block 16 wave + nl -> staging tile [block][element]
 #pragma unroll

@@ -467,6 +467,32 @@ def test_head_dims_above_128_relu_prologue_and_padding():
     check("dk", t[1].grad, mask(wg["dk"], k), GTOL[torch.float32])
 
 
+@pytest.mark.parametrize("vscale,doscale", [(1e-18, 1e12), (3e14, 1e-25), (1.0, 1.0)])
+def test_h16_summaries_keep_their_precision_at_extreme_scales(vscale, doscale):
+    """The 2-byte summaries carry one power-of-two multiplier per block row (measured maximum in k_sp_state, bound of the inputs in the
+    mixing kernels): v or dO scaled by 1e-18 .. 3e14 -- far outside what a bare fp16 holds -- leave the relative error where it was;
+    an all-zero block (its row multiplier clamps at 2^-126) and a block 2^40 above the others ride along."""
+    import mhla_amd
+    B, H, M, S, D = 1, 2, 16, 32, 64
+    q, k, v, W, do, _, _ = make_blockmix_inputs(B, H, M, S, D, torch.float32, 11, "rand", False)
+    v = v * vscale
+    v[:, 3 * S:4 * S] = 0.0                       # a block whose KV summary is exactly zero
+    v[:, 5 * S:6 * S] *= 2.0 ** 40                # ... and one that dwarfs the others
+    do = do * doscale
+    q, k, v, do = (t.to(torch.bfloat16) for t in (q, k, v, do))
+    assert mhla_amd.describe_dispatch(B, H, M, S, D, torch.bfloat16)["summaries"].startswith("h16")
+    want, wg = oracle_blockmix(q, k, v, W, do, None, None, 1e-6, True)
+    t = [x.requires_grad_(True) for x in to_dev(q, k, v, W)]
+    out = mhla_amd.mhla_blockmix(*t)
+    out.backward(do.to(DEV))
+    otol, gtol, wtol = bm_tols(torch.bfloat16)
+    check("out", out, want, otol)
+    check("dq", t[0].grad, wg["dq"], gtol)
+    check("dk", t[1].grad, wg["dk"], gtol)
+    check("dv", t[2].grad, wg["dv"], gtol)
+    check("dW", t[3].grad, wg["dW"], wtol)
+
+
 def test_empty_batch():
     """B = 0 (and T = 0 for the causal op): empty result, zero gradients, no launch."""
     import mhla_amd

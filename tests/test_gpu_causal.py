@@ -127,6 +127,31 @@ def test_causal_shapes_bf16_hi_lo_summaries(T, K, V):
     run_causal(2, T, 2, K, V, max(4, (T + 63) // 64), torch.bfloat16, seed=T + K, summaries="split")
 
 
+@pytest.mark.parametrize("vscale,doscale", [(1e-18, 1e12), (3e14, 1e-25)])
+def test_causal_h16_summaries_at_extreme_scales(vscale, doscale):
+    """The chunk summaries' strip multipliers absorb the scale of v and dO (1e-18 .. 3e14); a zero chunk and one 2^40 above the rest included."""
+    import mhla_amd
+    B, T, H, K, V, L = 1, 512, 2, 64, 128, 8
+    q, k, v, mix, do = causal_inputs(B, T, H, K, V, L, torch.float32, seed=21)
+    v = v * vscale
+    v[:, 64:128] = 0.0
+    v[:, 192:256] *= 2.0 ** 40
+    do = do * doscale
+    q, k, v, do = (t.to(torch.bfloat16) for t in (q, k, v, do))
+    assert mhla_amd.describe_causal_dispatch(T, K, V, torch.bfloat16)["summaries"].startswith("h16")
+    want = orc.causal_fwd(q.float(), k.float(), v.float(), mix)
+    wg = orc.causal_bwd(q.float(), k.float(), v.float(), mix, do.float())
+    dq, dk, dv, dm = (t.to(DEV).requires_grad_(True) for t in (q, k, v, mix))
+    out = mhla_amd.mhla_causal(dq, dk, dv, dm)
+    out.backward(do.to(DEV))
+    otol, gtol, mtol = causal_tols(torch.bfloat16)
+    check("out", out, want, otol)
+    check("dq", dq.grad, wg["dq"], gtol)
+    check("dk", dk.grad, wg["dk"], gtol)
+    check("dv", dv.grad, wg["dv"], gtol)
+    check("dmix", dm.grad, wg["dmix"], mtol)
+
+
 @pytest.mark.parametrize("T,K,V", [(16400, 64, 64), (300, 320, 64)])
 def test_causal_bf16_beyond_the_pipeline(T, K, V):
     """bf16 tensors outside the 16-bit pipeline's range (more than 256 chunks; K > 256): the generic fp32-MFMA kernels."""
