@@ -2094,7 +2094,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_dwt(const DwArgs a) {
 //   k_sp_bwd_dkv: dK_j = V_j dKV_j^T (+ dksum_j) ; dV_j = K_j dKV_j ; dKden_j = 1 dksum_j^T (split)
 // -------------------------------------------------------------------------------------------------
 template <int DT, bool S16 = false>
-__host__ __device__ constexpr int sp_tok_smem() { return sp_out_smem<DT, S16>() + Geo<DT>::DW * 4 * 4 + Geo<DT>::DW * 4; }
+__host__ __device__ constexpr int sp_tok_smem() {
+    // (+ k_sp_bwd_dkv's row staging for 16-bit tensors with rows of up to 128 bytes: [4 waves][dK, dV][16 tokens][DW + 8] 16-bit values)
+    return sp_out_smem<DT, S16>() + Geo<DT>::DW * 4 * 4 + Geo<DT>::DW * 4 + (DT <= 4 ? 4 * 2 * 16 * (Geo<DT>::DW + 8) * 2 : 0);
+}
 
 // A operand with the reduction index along the rows' columns: A[m][k] = T[c0 + m][k0 + 8 kg .. + 7]
 __device__ __forceinline__ bf16x8 row_read8(const u16* tile, int ld, int c0, int k0, int lane) {
@@ -2324,7 +2327,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_bwd_dkv(const TokArgs a) {  
         if ((tt + 4) * 16 < S) fetch(tt + 4, nxt);
         bf16x8 vh[KST], vl[KST], kh[KST], kl[KST];
         f32x4 dkst[2], dvst[2];
-        constexpr bool LATE = false;   // (measured, round 6: a token's dK pieces then its dV pieces stored behind the tile loop -- 79.6 -> 85.3 us at C2: the stores start later)
+        // ROWST (16-bit tensors, rows of up to 128 bytes): the wave's dK and dV tiles go through a wave-private LDS strip and leave as WHOLE
+        // rows -- 8 lanes x 16 bytes per token, eight rows per store instruction.  In the product layout a store covered 16 half rows (64
+        // bytes each) of two alternating output streams, and the L2 wrote a quarter of the lines twice (WRITE_SIZE 165 MB for 134 MB of
+        // results at C2, with the fill reads on top).  (Keeping the tiles in registers and storing a row's pieces back to back behind the
+        // loop -- no LDS -- was measured first: 79.6 -> 85.3 us, the stores start later.)
+        constexpr bool ROWST = sizeof(T) == 2 && DT <= 4;
+        constexpr int SLD = DW + 8;
+        u16* stk = reinterpret_cast<u16*>(dks + DW) + wave * 2 * 16 * SLD;   // [dK, dV][16][SLD]
+        constexpr bool LATE = false;
         f32x4 dkall[LATE ? DT : 1], dvall[LATE ? DT : 1];
 #pragma unroll
         for (int ks = 0; ks < KST; ++ks) {
@@ -2376,7 +2387,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_bwd_dkv(const TokArgs a) {  
                     for (int i = 0; i < 4; ++i)
                         if (!(fmaxf(cur.km[ct][i], 0.f) + a.eps > a.eps)) ck[i] = 0.f;
             }
-            if constexpr (LATE) {
+            if constexpr (ROWST) {
+                const uint2 pk = std::is_same<T, bf16_t>::value ? make_uint2(pack_bf16x2(ck[0], ck[1]), pack_bf16x2(ck[2], ck[3])) : make_uint2(h16_pack2(ck[0], ck[1]), h16_pack2(ck[2], ck[3]));
+                const uint2 pv = std::is_same<T, bf16_t>::value ? make_uint2(pack_bf16x2(cv[0], cv[1]), pack_bf16x2(cv[2], cv[3])) : make_uint2(h16_pack2(cv[0], cv[1]), h16_pack2(cv[2], cv[3]));
+                *reinterpret_cast<uint2*>(stk + nl * SLD + ct * 16 + kg * 4) = pk;
+                *reinterpret_cast<uint2*>(stk + 16 * SLD + nl * SLD + ct * 16 + kg * 4) = pv;
+            } else if constexpr (LATE) {
                 dkall[ct] = ck;
                 dvall[ct] = cv;
             } else {
@@ -2396,7 +2412,37 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_bwd_dkv(const TokArgs a) {  
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if constexpr (LATE) {
+        if constexpr (ROWST) {
+            __builtin_amdgcn_wave_barrier();
+            const bool wide = wide_dk && wide_dv;   // (uniform) 16-byte aligned rows: whole-row stores; otherwise 8-byte pieces from the strip
+#pragma unroll
+            for (int ps = 0; ps < 2; ++ps) {
+                const int r = (lane >> 3) + 8 * ps, c = (lane & 7) * 8;   // token r of the tile, features c .. c + 7
+                const long grow = __shfl(cur.row, r, 64);                 // (lanes 0 .. 15 hold the rows of tokens 0 .. 15)
+                const bool glive = __shfl((int)cur.live, r, 64) != 0;
+                if (wide) {
+                    if (glive && c < D) {
+                        gst<uint4>(dkb + grow * a.dk.sn + c, *reinterpret_cast<const uint4*>(stk + r * SLD + c));
+                        gst<uint4>(dvb + grow * a.dv.sn + c, *reinterpret_cast<const uint4*>(stk + 16 * SLD + r * SLD + c));
+                    }
+                } else if (glive) {
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf)
+                        if (c + 4 * hf < D) {
+                            *reinterpret_cast<uint2*>(dkb + grow * a.dk.sn + c + 4 * hf) = *reinterpret_cast<const uint2*>(stk + r * SLD + c + 4 * hf);
+                            *reinterpret_cast<uint2*>(dvb + grow * a.dv.sn + c + 4 * hf) = *reinterpret_cast<const uint2*>(stk + 16 * SLD + r * SLD + c + 4 * hf);
+                        }
+                }
+            }
+            if (a.normalize && a.split && cur.live) {
+#pragma unroll
+                for (int ct = 0; ct < DT; ++ct) {
+                    const int da = ct * 16 + kg * 4;
+                    if (da < D) Io<T>::st4(dkdb + cur.row * a.dkd.sn + da, *reinterpret_cast<const f32x4*>(dks + da));
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        } else if constexpr (LATE) {
             // 16-bit rows of up to 128 bytes: all of a token's dK pieces, then all of its dV pieces, in consecutive store instructions -- the
             // two 64-byte halves of a line written with the other tensor's store and two tiles of products between them left the L2 as
             // partial lines (WRITE_SIZE 154 MB for 134 MB of results, and the fill reads on top)

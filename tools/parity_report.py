@@ -1,8 +1,8 @@
 #!/usr/bin/env python
 """profiles/r*_parity_errors.md from gpurun_out/parity_report.json (written by tests/conftest.py at the end of a `-m gpu` session):
 the observed errors grouped by the tolerance each comparison ran under.
-  python tools/parity_report.py [gpurun_out/parity_report.json] > profiles/r5_parity_errors.md
-Also writes profiles/r5_parity_summary.json: the report without its per-comparison list (what bench.py's `targets` block reads)."""
+  python tools/parity_report.py [gpurun_out/parity_report.json] > profiles/r6_parity_errors.md
+Also writes profiles/r6_parity_summary.json: the report without its per-comparison list (what bench.py's `targets` block reads)."""
 import collections
 import json
 import os
@@ -16,7 +16,7 @@ tests = {r["test"] for r in rows}
 by_tol = collections.defaultdict(list)
 for r in rows:
     by_tol[r["tol"]].append(r)
-print(f"# Observed parity errors, round 5 (`python -m pytest tests -m gpu` on one MI355X, {len(tests)} tests with recorded comparisons, "
+print(f"# Observed parity errors, round 6 (`python -m pytest tests -m gpu` on one MI355X, {len(tests)} tests with recorded comparisons, "
       f"{len(rows)} comparisons)\n")
 print("Every `check()` of the GPU suite records `max|got - want| / max|want|` (the rel-err the north-star bound is stated in) and fla's\n"
       "rms-relative error; `tests/conftest.py` writes them to `gpurun_out/parity_report.json` at the end of the session and\n"
@@ -44,5 +44,5 @@ if fam:
     for k in sorted(fam):
         a = fam[k]
         print(f"| {k} | {a['n']} | {a['results_16bit_max_beyond_final_rounding']:.2e} | {a['results_fp32_max_rel_err']:.2e} | `{a['worst']}` |")
-    with open(os.path.join(ROOT, "profiles", "r5_parity_summary.json"), "w") as f:
+    with open(os.path.join(ROOT, "profiles", "r6_parity_summary.json"), "w") as f:
         json.dump({k: v for k, v in rep.items() if k != "all"}, f, indent=1)
