@@ -577,17 +577,18 @@ int mhla_describe_dispatch(int B, int H, int M, int S, int D, int dtype, int spl
         const bool wave16 = s16 && S == 16 && D == 64 && !split;
         const std::string st0 = wave16 ? "k_s16_state<0>" : "k_sp_state", out = wave16 ? "k_s16_out" : "k_sp_out";
         std::string mix0, mix1, dw;
-        if (fmt == SF_H16) { mix0 = "k_sp_mixh<0>"; mix1 = "k_sp_mixh<1,dw>"; dw = ""; }
-        else if (s16 && M > 192 && mixr) { mix0 = "k_sp_mixr_dma<0>"; mix1 = "k_sp_mixr_dma<1>"; dw = "k_sp_dwr"; }
+        const std::string dwr = std::string("k_sp_dwr<") + (M <= 128 ? "2" : M <= 192 ? "3" : "4") + (fmt == SF_H16 ? ",h16>" : ">");   // whole-matrix dW kernel (incl. the <dn, z> term)
+        if (fmt == SF_H16) { mix0 = "k_sp_mixh<0>"; mix1 = M <= 128 ? "k_sp_mixh<1,dw>" : "k_sp_mixh<1>"; dw = M <= 128 ? "" : dwr; }
+        else if (s16 && M > 192 && mixr) { mix0 = "k_sp_mixr_dma<0>"; mix1 = "k_sp_mixr_dma<1>"; dw = dwr; }
         else if (mixr) {
             mix0 = "k_sp_mixr<0>";
             if (!s16 && M <= 128) { mix1 = "k_sp_mixr<1,dw>"; dw = ""; }
-            else { mix1 = "k_sp_mixr<1>"; dw = s16 ? (M > 64 ? "k_sp_dwr" : "k_sp_dw") : (fmt == SF_P24 ? "k_sp_dwt" : "k_sp_dw"); }
-        } else { mix0 = "k_sp_mix<0>"; mix1 = "k_sp_mix<1>"; dw = s16 && M > 64 && M <= 256 && E % 64 == 0 ? "k_sp_dwr" : "k_sp_dw"; }
+            else { mix1 = "k_sp_mixr<1>"; dw = s16 ? (M > 64 ? dwr : (M <= 16 ? "k_sp_dw<16>" : M <= 32 ? "k_sp_dw<32>" : "k_sp_dw")) : (fmt == SF_P24 ? "k_sp_dwt" : "k_sp_dw"); }
+        } else { mix0 = "k_sp_mix<0>"; mix1 = "k_sp_mix<1>"; dw = s16 && M > 64 && M <= 256 && E % 64 == 0 ? dwr : (M <= 16 ? "k_sp_dw<16>" : M <= 32 ? "k_sp_dw<32>" : "k_sp_dw"); }
         const bool wzf = fmt == SF_BF16 ? (M > 192 && M <= 256 && S <= 16 && mixr) : (mixr && evenS);   // the normaliser's product rides in the mixing kernel
         fwd = st0 + " " + mix0 + (wzf ? "" : " k_wz<0>") + " " + out;
         bwd = std::string(wave16 ? "k_s16_state<1>" : "k_sp_state<1>") + " " + mix1 + (wzf ? "" : " k_wz<1>") + (dw.empty() ? "" : " " + dw) +
-              ((dw.empty() && wzf) || dw == "k_sp_dwr" ? "" : " k_dw") + " k_dw_reduce " + (wave16 ? "k_s16_bwd_dq k_s16_bwd_dkv" : "k_sp_bwd_dq k_sp_bwd_dkv");
+              ((dw.empty() && wzf) || dw == dwr ? "" : " k_dw") + " k_dw_reduce " + (wave16 ? "k_s16_bwd_dq k_s16_bwd_dkv" : "k_sp_bwd_dq k_sp_bwd_dkv");
     } else {
         fam = "generic (exact fp32 MFMA)";
         sum = "fp32 words (dense rows)";

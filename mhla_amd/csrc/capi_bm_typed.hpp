@@ -96,9 +96,9 @@ template <int TRANS>
 inline int sp_mixh(const float* W, int ldw, const void* in, void* out, int M, long E, long es, int BH, hipStream_t st,
                    const float* zin, float* zout, int S, float eps) {
 #define MIXH(NW, PERCU) do { \
-        const long total = (long)BH * ((E + sp::MIXH_TE - 1) / sp::MIXH_TE); \
+        const long total = (long)BH * ((E + sp::mixh_te<NW>() - 1) / sp::mixh_te<NW>()); \
         const bool wz = zin && sp_mixr_takes_wz<false>(M, S); \
-        const long zt = wz ? (long)BH * ((S + sp::MIXH_TEZ - 1) / sp::MIXH_TEZ) : 0; \
+        const long zt = wz ? (long)BH * ((S + sp::mixh_tez<NW>() - 1) / sp::mixh_tez<NW>()) : 0; \
         const int wgs = (int)std::min<long>(total, 256 * (PERCU)); \
         sp::MixrArgs a{W, ldw, in, out, M, E, es, total, (int)((total + wgs - 1) / wgs), wz ? zin : nullptr, wz ? zout : nullptr, wz ? S : 0, eps, nullptr, nullptr, nullptr, zt, nullptr}; \
         const int gw = (int)((total + a.spw - 1) / a.spw); \
@@ -107,6 +107,8 @@ inline int sp_mixh(const float* W, int ldw, const void* in, void* out, int M, lo
     if (M <= 32) MIXH(2, 8);
     if (M <= 64) MIXH(4, 4);
     if (M <= 128) MIXH(8, 1);
+    if (M <= 192) MIXH(12, 1);   // (129 .. 256 blocks: 64-element slices, one workgroup per CU; dW by k_sp_dwr<.., h16>)
+    if (M <= 256) MIXH(16, 1);
     return fail(MHLA_EINVAL, "sp_mixh: M=%d out of range", M);
 #undef MIXH
 }
@@ -117,8 +119,8 @@ inline int sp_mixh_dw(const float* W, int ldw, const void* dg, const void* kv, v
     const bool wz = dn && z && dz && sp_mixr_takes_wz<false>(M, S);
     *wz_done = wz;
 #define MIXHDW(NW, PERCU) do { \
-        const long total = (long)BH * ((E + sp::MIXH_TE - 1) / sp::MIXH_TE); \
-        const long zt = wz ? (long)BH * ((S + sp::MIXH_TEZ - 1) / sp::MIXH_TEZ) : 0; \
+        const long total = (long)BH * ((E + sp::mixh_te<NW>() - 1) / sp::mixh_te<NW>()); \
+        const long zt = wz ? (long)BH * ((S + sp::mixh_tez<NW>() - 1) / sp::mixh_tez<NW>()) : 0; \
         const int wgs = (int)std::min<long>(total, 256 * (PERCU));   /* (bm_carve: at most 1024 / 512 / 256 partials at two / four / eight waves) */ \
         sp::MixrArgs a{W, ldw, dg, dkv, M, E, es, total, (int)((total + wgs - 1) / wgs), wz ? dn : nullptr, wz ? dz : nullptr, wz ? S : 0, 0.f, nullptr, kv, dwp, zt, wz ? z : nullptr}; \
         const int gw = (int)((total + a.spw - 1) / a.spw); \
@@ -168,8 +170,15 @@ inline int sp_dwr_splits(int BH, long E) {
     while (ns > 1 && E / ns < 256) --ns;
     return ns < 1 ? 1 : ns;
 }
-inline int sp_dwr(const void* x, const void* y, long E, long es, const float* x2, const float* y2, int S2, float* out, int M, int BH, int nsplit, hipStream_t st) {
+// (`es`: row stride in 16-bit elements.  h16: the rows are fp16 payload with their multiplier behind the E elements -- products on the fp16 MFMA)
+inline int sp_dwr(const void* x, const void* y, long E, long es, const float* x2, const float* y2, int S2, float* out, int M, int BH, int nsplit, hipStream_t st,
+                  bool h16 = false) {
     s16::DwrArgs d{(const sp::u16*)x, (const sp::u16*)y, E, es, x2, y2, S2, out, M, nsplit};
+    if (h16) {
+        if (M <= 128) return launch(s16::k_sp_dwr<2, true>, dim3(nsplit, BH), dim3(256), s16::dwr_smem<2>(), st, "k_sp_dwr<2,h16>", d);
+        if (M <= 192) return launch(s16::k_sp_dwr<3, true>, dim3(nsplit, BH), dim3(576), s16::dwr_smem<3>(), st, "k_sp_dwr<3,h16>", d);
+        return launch(s16::k_sp_dwr<4, true>, dim3(nsplit, BH), dim3(1024), s16::dwr_smem<4>(), st, "k_sp_dwr<4,h16>", d);
+    }
     if (M <= 128) return launch(s16::k_sp_dwr<2>, dim3(nsplit, BH), dim3(256), s16::dwr_smem<2>(), st, "k_sp_dwr<2>", d);
     if (M <= 192) return launch(s16::k_sp_dwr<3>, dim3(nsplit, BH), dim3(576), s16::dwr_smem<3>(), st, "k_sp_dwr<3>", d);
     return launch(s16::k_sp_dwr<4>, dim3(nsplit, BH), dim3(1024), s16::dwr_smem<4>(), st, "k_sp_dwr<4>", d);
@@ -355,6 +364,13 @@ int bm_bwd_typed(const BmCall& c) {
                         else RC(sp_mixr_dw<1>(W, ldw, w.dg, w.kv, w.dkv, w.dwp, M, E, es, B * H, st, &parts, normalize ? (const float*)w.dn : nullptr,
                                             normalize ? (const float*)w.z : nullptr, w.dz, S, &wz_done));
                         dwz_done = wz_done;
+                    } else if (w.fmt == SF_H16) {   // 129 .. 256 blocks on h16: the mixing without the dW tiles, dW (and its <dn, z> term) by the
+                        wz_done = normalize && sp_mixr_takes_wz<false>(M, S);   // whole-matrix kernel on the two payload sets
+                        RC(sp_mixh<1>(W, ldw, w.dg, w.dkv, M, E, es, B * H, st, normalize ? (const float*)w.dn : nullptr, w.dz, S, 0.f));
+                        const int nsplit = sp_dwr_splits(B * H, E);
+                        RC(sp_dwr(w.dg, w.kv, E, 2 * es, normalize ? w.dn : nullptr, normalize ? w.z : nullptr, S, w.dwp, M, B * H, nsplit, st, true));
+                        parts = B * H * nsplit;
+                        dwz_done = true;
                     } else {   // 129 .. 192 blocks: twelve waves have no registers for the dW tiles -- k_sp_dw reads dG and KV again
                         wz_done = normalize && sp_mixr_takes_wz<false>(M, S);
                         RC((sp_mixr<1, false, 1>(W, ldw, w.dg, w.dkv, M, E, es, B * H, st, normalize ? (const float*)w.dn : nullptr, w.dz, S, 0.f)));

@@ -188,7 +188,7 @@ inline bool view_ok16m(const mhla_mview& v) { return v.ptr && ((uintptr_t)v.ptr 
 inline bool bm_sum16(int D, int dtype, unsigned flags) { return dtype == MHLA_BF16 && sp_shape_ok(D, flags) && (flags & MHLA_FLAG_BF16_SUMMARIES); }
 // The summary format of a block-mix call on the generic / split-operand path.  h16 and p24 live on the resident-mixing pipeline
 // (split.hpp k_sp_mixr: up to 256 blocks, summaries of whole 64-element slices):
-//   h16: 16-bit tensors, head dims 32 .. 96, 4 .. 128 blocks (the fused dW) of at least 16 tokens (11-bit summaries lean on averaging
+//   h16: 16-bit tensors, head dims 32 .. 96, 4 .. 256 blocks (up to 128: dW fused into the mixing; beyond: k_sp_dwr) of at least 16 tokens (11-bit summaries lean on averaging
 //        over the block, the head dim and the blocks: in the model, tools/sim_h16.py, 2 blocks reach 5e-3 in dW -- a difference
 //        of nearly equal terms there -- head dim 8 reaches 7e-4, a 2 x 1-token case 1.4e-3; inside the rule: <= 6e-4) -- unless
 //        the caller asks for >= 16 significand bits
@@ -199,8 +199,8 @@ inline int bm_sumfmt(int M, int S, int D, int dtype, unsigned flags) {
     if (bm_sum16(D, dtype, flags)) return SF_BF16;
     const bool mixr = M <= 256 && ((long)D * D) % 64 == 0;
     if (!mixr || g_no_p24.load()) return SF_F32;
-    if (dtype != MHLA_F32 && D <= 96 && M <= 128)
-        return (S >= 16 && M >= 4 && D >= 32 && !(flags & MHLA_FLAG_FP32_GRADE_SUMMARIES)) ? SF_H16 : SF_P24;
+    if (dtype != MHLA_F32 && D <= 96 && S >= 16 && M >= 4 && D >= 32 && !(flags & MHLA_FLAG_FP32_GRADE_SUMMARIES)) return SF_H16;   // (M <= 256: mixr)
+    if (dtype != MHLA_F32 && D <= 96 && M <= 128) return SF_P24;
     if (dtype == MHLA_F32 && D > 96 && M <= 192) return SF_P24;
     return SF_F32;
 }

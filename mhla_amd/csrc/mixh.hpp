@@ -24,9 +24,12 @@ using fast::f16x8;
 using fast::mfma_f16;
 using fast::as_f16x8;
 
-constexpr int MIXH_TE = 128, MIXH_TEZ = 64;
+// slice width in summary elements (256-byte row pieces; 128-byte ones above eight waves: 129 .. 256 blocks, where 8 NK fp32 weights per
+// lane -- 48 / 64 registers -- leave room for four accumulator tiles, not eight) and in normaliser values (half: bf16 hi | lo halves)
+template <int NW> __host__ __device__ constexpr int mixh_te() { return NW > 8 ? 64 : 128; }
+template <int NW> __host__ __device__ constexpr int mixh_tez() { return mixh_te<NW>() / 2; }
 template <int NW, bool DW>
-__host__ __device__ constexpr int sp_mixh_smem() { return (DW ? 3 : 2) * 16 * NW * (MIXH_TE + 8) * 2 + 3 * 16 * NW * 4; }
+__host__ __device__ constexpr int sp_mixh_smem() { return (DW ? 3 : 2) * 16 * NW * (mixh_te<NW>() + 8) * 2 + 3 * 16 * NW * 4; }
 
 // The workgroup's mixing weights as fp32 B-operand fragments: wf[ks][t] = weight of input block r = 32 ks + 8 kg + t in output block
 // o = obase + nl (TRANS: W[r][o], else W[o][r]); blocks past M: 0.  Fetched through LDS like mixr_weights.  Ends with a barrier.
@@ -74,14 +77,14 @@ __device__ __forceinline__ void mixh_weights(float (&wf)[NK][8], float* __restri
     __syncthreads();
 }
 
-// MixrArgs as for k_sp_mixr: total = bh * ceil(E / 128) summary slices, ztotal = bh * ceil(S / 64) normaliser slices.
+// MixrArgs as for k_sp_mixr: total = bh * ceil(E / TE) summary slices, ztotal = bh * ceil(S / TEZ) normaliser slices.
 template <int NW, int TRANS, bool DW>
 // (launch bounds: four waves per SIMD -- 128 VGPRs -- up to four waves per workgroup, i.e. 8 / 4 workgroups per CU; eight waves would spill
 // 30 registers there and run one workgroup per CU; the dW variants hold NW more accumulator tiles and two staged sets: 2 / 1 per CU)
 __global__ __launch_bounds__(64 * NW, DW ? (NW + 3) / 4 : (NW <= 4 ? 4 : (NW + 3) / 4)) void k_sp_mixh(const MixrArgs a) {
     static_assert(!DW || (TRANS == 1 && NW <= 8), "dW rides in the backward's mixing kernel, M <= 128");
-    constexpr int TE = MIXH_TE, TEZ = MIXH_TEZ, ROWS = 16 * NW, LD = TE + 8, LDZ = LD / 2, NK = (NW + 1) / 2, NT = TE / 16, NTH = 64 * NW;
-    constexpr int UPR = 16, NP = ROWS * UPR / NTH;   // 16-byte units per row of a slice (8 payload elements; normaliser: 4 floats), per thread
+    constexpr int TE = mixh_te<NW>(), TEZ = mixh_tez<NW>(), ROWS = 16 * NW, LD = TE + 8, LDZ = LD / 2, NK = (NW + 1) / 2, NT = TE / 16, NTH = 64 * NW;
+    constexpr int UPR = TE / 8, NP = ROWS * UPR / NTH;   // 16-byte units per row of a slice (8 payload elements; normaliser: 4 floats), per thread
     static_assert(NP * NTH == ROWS * UPR, "units must tile the slice");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u16* Th = reinterpret_cast<u16*>(smem_raw);                  // the slice's input rows [ROWS][LD] (payload; normaliser: bf16 hi | lo halves)

@@ -21,6 +21,7 @@
 //   summary row is read ONCE per (b, h) (k_sp_dw: once per 64-column tile of dW, i.e. four times through L2 at M = 256), rows
 //   staged through LDS in whole 128-byte lines, the <dn_i, z_j> term is one more stage of the same loop.
 #pragma once
+#include <type_traits>
 #include "split.hpp"
 
 namespace mhla {
@@ -381,7 +382,9 @@ template <int TT> __host__ __device__ constexpr int dwr_smem() { return DWR_NBUF
 
 using sp::wait_vmcnt;
 
-template <int TT>
+// H16: x and y are h16 payload rows (fp16, the row's fp32 multiplier right behind its E elements, split.hpp): the products run on the fp16
+// MFMA (exact in the fp32 accumulators) and the partial is scaled by mult_x[i] mult_y[j] once, before the fp32 stages of (x2, y2) join.
+template <int TT, bool H16 = false>
 __global__ __launch_bounds__(64 * TT * TT) void k_sp_dwr(const DwrArgs a) {
     constexpr int NW = TT * TT, R = 64 * TT, UNITS = 2 * R / 8, UPW = (UNITS + NW - 1) / NW;   // unit: 8 rows of x or of y = one DMA instruction
     constexpr int IMG = R * DWR_SE;   // elements of one matrix image
@@ -422,7 +425,7 @@ __global__ __launch_bounds__(64 * TT * TT) void k_sp_dwr(const DwrArgs a) {
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     // operand read of row 16 t + nl (+ 64 ti), pieces 4 ks + kg: the swizzle term depends on nl only
     const int sw = (nl ^ (nl >> 1)) & 7, rd0 = nl * DWR_SE + ((kg ^ sw) << 3), rd1 = nl * DWR_SE + (((4 + kg) ^ sw) << 3);
-    auto compute = [&](const u16* buf) {
+    auto compute = [&]<bool F16>(std::bool_constant<F16>, const u16* buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const u16* xs = buf + (ti * 64) * DWR_SE + (ks ? rd1 : rd0);
@@ -434,7 +437,10 @@ __global__ __launch_bounds__(64 * TT * TT) void k_sp_dwr(const DwrArgs a) {
             for (int j = 0; j < 4; ++j) {
                 const bf16x8 ya = *reinterpret_cast<const bf16x8*>(ys + j * 16 * DWR_SE);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i][j] = mfma_bf16(xa[i], ya, acc[i][j]);
+                for (int i = 0; i < 4; ++i) {
+                    if constexpr (F16) acc[i][j] = fast::mfma_f16(fast::as_f16x8(xa[i]), fast::as_f16x8(ya), acc[i][j]);
+                    else acc[i][j] = mfma_bf16(xa[i], ya, acc[i][j]);
+                }
             }
         }
     };
@@ -446,7 +452,20 @@ __global__ __launch_bounds__(64 * TT * TT) void k_sp_dwr(const DwrArgs a) {
         wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         if (st + 1 < nst) issue(st + 1);
-        compute(lds + (st % DWR_NBUF) * (2 * IMG));
+        compute(std::bool_constant<H16>{}, lds + (st % DWR_NBUF) * (2 * IMG));
+    }
+    if constexpr (H16) {   // payload products -> values: rows i = 64 ti + 16 i + 4 kg + r of x, columns j = 64 tj + 16 j + nl of y
+        float my[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) my[j] = gld<float>(a.y + ((long)bh * M + min(tj * 64 + j * 16 + nl, M - 1)) * a.es + a.E);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float mx = gld<float>(a.x + ((long)bh * M + min(ti * 64 + i * 16 + kg * 4 + r, M - 1)) * a.es + a.E);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j][r] *= mx * my[j];
+            }
     }
     // fp32 stages: 16 values of (x2, y2) each; thread -> (row, 4 values)
     for (int st = 0; st < nst2; ++st) {
@@ -479,7 +498,7 @@ __global__ __launch_bounds__(64 * TT * TT) void k_sp_dwr(const DwrArgs a) {
             *reinterpret_cast<uint2*>(xd + fast::gt_off(row, 48 + q4)) = Z;  *reinterpret_cast<uint2*>(yd + fast::gt_off(row, 48 + q4)) = Z;
         }
         __syncthreads();
-        compute(lds);
+        compute(std::false_type{}, lds);
     }
     float* out = a.out + ((long)bh * a.nsplit + split) * M * M;
 #pragma unroll

@@ -383,7 +383,9 @@ def test_describe_dispatch_names_the_path_of_every_baseline_config():
     assert mhla_amd.describe_dispatch(8, 16, 64, 64, 64, bf, summaries="bf16")["family"].startswith("bf16 fast path")
     assert mhla_amd.describe_dispatch(8, 16, 64, 64, 64, f32)["summaries"] == "fp32 words"
     assert mhla_amd.describe_dispatch(8, 16, 16, 256, 64, bf)["summaries"].startswith("h16")   # C2 variant 16 x 256
-    assert mhla_amd.describe_dispatch(8, 16, 256, 16, 64, bf)["summaries"] == "fp32 words"     # C2 variant 256 x 16: more than 128 blocks
+    c2b = mhla_amd.describe_dispatch(8, 16, 256, 16, 64, bf)                                    # C2 variant 256 x 16: more than 128 blocks
+    assert c2b["summaries"].startswith("h16") and c2b["bwd"][1:3] == ["k_sp_mixh<1>", "k_sp_dwr<4,h16>"]
+    assert mhla_amd.describe_dispatch(8, 16, 320, 16, 64, bf)["summaries"] == "fp32 words"     # more than 256 blocks: the tiled mixing
     assert mhla_amd.describe_dispatch(8, 16, 64, 8, 64, bf)["summaries"].startswith("p24")     # blocks of fewer than 16 tokens
     assert mhla_amd.describe_dispatch(8, 16, 2, 64, 64, bf)["summaries"].startswith("p24")     # fewer than 4 blocks
     c3 = mhla_amd.describe_dispatch(32, 16, 16, 16, 72, bf)                                     # configs[2]: DiT-XL/2 256^2
