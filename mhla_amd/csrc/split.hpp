@@ -24,6 +24,7 @@ using fast::bf16x8;
 using fast::mfma_bf16;
 using fast::tr_read8;
 using fast::s16x4;
+using fast::s16x8;
 using fast::u16;
 
 __device__ __forceinline__ bf16x8 row_read8(const u16* tile, int ld, int c0, int k0, int lane);   // (defined with the token-gradient kernels)
@@ -145,7 +146,8 @@ template <typename T> struct Sum16 { static constexpr bool value = std::is_same<
 template <int DT> struct Geo {
     static constexpr int CGS = DT > 4 ? 16 : 8;        // column groups of 8 per tile row
     static constexpr int DW = CGS * 8;                 // tile width (columns), >= 16 DT
-    static constexpr int LD = DW + 8;                  // LDS row stride (bf16)
+    static constexpr int LD = DW + 16;                 // LDS row stride (bf16) of k_sp_state's token tiles (row r at mat_row(r), below) ...
+    static constexpr int LDR = DW + 8;                 // ... except in its row-dots-from-G variant, whose fourth workgroup per CU needs the 2 KB
     static constexpr int RPP = NTHREADS / CGS;         // tile rows covered per pass of the 256 threads
     static constexpr int RT = (DT + 3) / 4;            // 16-row output tiles per wave
     static constexpr int KST = (DT + 1) / 2;           // reduction steps of 32 over a head dim
@@ -154,8 +156,43 @@ template <int DT> struct Geo {
 // (used by k_sp_state's row-dots-from-G variant as well as by the output and token-gradient kernels further down)
 // LDS row stride (bf16) of a staged D x D summary matrix [KST * 32 rows][KST * 32 columns + 8]: the reads cover KST * 32
 // columns, not the DW of the token tiles (D = 72: 104 instead of 136 -> a third workgroup per CU for the fp32 kernels)
+// Bank layout (round 6).  gfx950's LDS has 64 banks and serves the 16-byte row reads in groups of 16 lanes, the transpose reads in groups
+// of 32 (MI355X_MICROARCH.md, LDS): with the round-1 padding of 8 elements (derived for 32 banks) every operand read of these kernels is
+// 2-way conflicted (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.28 - 0.44 at C2; `tools/lds_conflicts.py split` reproduces it).  In the
+// new layout rows are padded by 16 elements (consecutive rows 8 banks apart) and matrix row r is kept at LDS row mat_row(r) = r with bits
+// 2 and 3 swapped: the 32 lanes of a transpose read (rows 8 g + j, g = 0, 1) then touch 8 consecutive LDS rows = all 64 banks once, and a
+// 16-byte row read's lane groups keep their sets of rows.  Counters after: 0.00 (k_sp_out, k_sp_bwd_dq), 0.16 (k_sp_bwd_dkv: its strip
+// stores).  What it buys is small, because these kernels wait for HBM, not for the LDS: C2 step 0.382 -> 0.373 ms (k_sp_bwd_dkv 81.8 ->
+// 76.6 us; at 256 blocks of 16 tokens 214 -> 191 us), nothing at D = 72 .. 96, and at D = 128 the Wan inference output kernel LOSES 11 %
+// (5.69 -> 6.3 ms per forward, twice) -- so the staged matrices take it for D <= 64 only (MAT_NEW_MAX_DT; `tools/ab_configs.sh` is the
+// A/B), k_sp_state's token tiles always except in the row-dots-from-G variant (whose fourth workgroup per CU needs the 2 KB).
+// Everything that touches a staged matrix goes through mat_row / mat_tr_read8 / mat_row_read8.
+#ifndef MAT_NEW_MAX_DT
+#define MAT_NEW_MAX_DT 4
+#endif
+template <int DT> __host__ __device__ constexpr bool mat_new() { return DT <= MAT_NEW_MAX_DT; }
 template <int DT>
-__host__ __device__ constexpr int mat_ld() { return Geo<DT>::KST * 32 + 8; }
+__host__ __device__ constexpr int mat_ld() { return Geo<DT>::KST * 32 + (mat_new<DT>() ? 16 : 8); }
+template <bool NEW = true>
+__host__ __device__ constexpr int mat_row(int r) { return NEW ? ((r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1)) : r; }
+// tr_read8 of a staged matrix: lane (c = lane & 15, g = lane >> 4) receives T[k0 + 8 g + 0..7][c0 + c]   (k0 a multiple of 32)
+template <bool NEW = true>
+__device__ __forceinline__ bf16x8 mat_tr_read8(const u16* tile, int ld, int k0, int c0, int lane) {
+    if constexpr (!NEW) return tr_read8(tile, ld, k0, c0, lane);
+    const int g = lane >> 4, li = lane & 15;
+    const u16* p = tile + (k0 + (g >> 1) * 16 + (g & 1) * 4 + (li >> 2)) * ld + c0 + (li & 3) * 4;   // = mat_row(k0 + 8 g + (li >> 2))
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_S16X4(p));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_S16X4(p + 8 * ld));                  // = mat_row(.. + 4)
+    s16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return __builtin_bit_cast(bf16x8, r);
+}
+// row_read8 of a staged matrix: A[m][k] = T[c0 + m][k0 + 8 kg .. + 7]   (c0 a multiple of 16)
+template <bool NEW = true>
+__device__ __forceinline__ bf16x8 mat_row_read8(const u16* tile, int ld, int c0, int k0, int lane) {
+    return *reinterpret_cast<const bf16x8*>(tile + (c0 + mat_row<NEW>(lane & 15)) * ld + k0 + (lane >> 4) * 8);
+}
 template <int DT, bool S16 = false>   // bf16 summaries: no lo tile
 __host__ __device__ constexpr int sp_out_smem() { return (S16 ? 1 : 2) * Geo<DT>::KST * 32 * mat_ld<DT>() * 2; }
 
@@ -200,7 +237,7 @@ __device__ __forceinline__ void stage_mat_split(u16* __restrict__ Gh, u16* __res
         }
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
-            const int r = r0 + RPP * (pb + u), off = r * LD + cg;
+            const int r = r0 + RPP * (pb + u), off = mat_row<mat_new<DT>()>(r) * LD + cg;
             if (r < KP && cg < KP) {
                 if (P24 == 2) {
                     uint4 hi, lo;
@@ -232,7 +269,9 @@ __host__ __device__ constexpr int sp_state_smem() {
 
 // MODE 1 on 16-bit tensors with 24-bit summaries and D <= 64 (RD): the row dots dO . O come from G_i -- two more tiles (G_i as hi / lo,
 // [64][72] bf16 each) and the partial dots of a 32-token chunk
-template <int DT> __host__ __device__ constexpr int sp_state_rd_smem() { return sp_state_smem<DT>() + 2 * Geo<DT>::KST * 32 * (Geo<DT>::KST * 32 + 8) * 2 + 2 * 32 * 4; }
+template <int DT> __host__ __device__ constexpr int sp_state_rd_smem() {   // (its token tiles keep the rows of DW + 8: four workgroups per CU)
+    return 4 * 32 * Geo<DT>::LDR * 2 + Geo<DT>::DW * 4 + 2 * Geo<DT>::KST * 32 * mat_ld<DT>() * 2 + 2 * 32 * 4;
+}
 
 // MODE 0 (forward):  out = KV_j = K_j^T V_j; ksum_j; z_j                      x = k_num, y = v, kd = k_den, qd = q_den
 // MODE 1 (backward): out = dG_i = Q_i^T (dO_i / n_i); dn_i[s] = -(dO_i[s] . O_i[s]) / n_i[s]     x = q_num, y = dout, o = out
@@ -250,15 +289,16 @@ template <typename T, int DT, int MODE, bool ROPE = false, int NT = NTHREADS, bo
 __global__ __launch_bounds__(NT, NT == 512 ? 4 : (ROPE ? 2 : 3)) void k_sp_state(const StateArgs a) {
     static_assert(!PRO || (MODE == 0 && !S16), "the prologue on load serves the forward's summary kernel");
     static_assert(!P24 || !S16, "p24 is a format of the fp32-grade summaries");
-    constexpr int DW = Geo<DT>::DW, LD = Geo<DT>::LD, CGS = Geo<DT>::CGS, RPP = NT / CGS, IT = 32 / RPP, NWV = NT / 64,
+    // RD: the row dots dO . O = dO' . (Q G_i) are formed from the mixed summary G_i (staged as hi / lo tiles beside the operand tiles): the
+    // stored output and its residual are not read, and the forward does not write the residual (capi_common.hpp bm_rowdots_from_g)
+    constexpr bool RD = MODE == 1 && P24 && sizeof(T) == 2 && DT <= 4 && !ROPE;
+    constexpr bool TN = !RD;   // the token tiles in the conflict-free layout (Geo::LD, mat_row)
+    constexpr int DW = Geo<DT>::DW, LD = TN ? Geo<DT>::LD : Geo<DT>::LDR, CGS = Geo<DT>::CGS, RPP = NT / CGS, IT = 32 / RPP, NWV = NT / 64,
                   RT = (DT + NWV - 1) / NWV, TILE = 32 * LD;
     static_assert(IT >= 1 && RPP * IT == 32, "a 32-row chunk must be whole staging passes");
     static_assert(RPP * DW * 4 <= 4 * 32 * LD * 2, "column-sum partials must fit in the tiles");
     constexpr bool LO = !std::is_same<T, bf16_t>::value || PRO;   // the token operands carry a lo part
     constexpr bool LOY = !std::is_same<T, bf16_t>::value || (MODE == 1 && !S16);   // ... and so does y = dO / n, unless the reduced-precision form was asked for
-    // RD: the row dots dO . O = dO' . (Q G_i) are formed from the mixed summary G_i (staged as hi / lo tiles beside the operand tiles): the
-    // stored output and its residual are not read, and the forward does not write the residual (capi_common.hpp bm_rowdots_from_g)
-    constexpr bool RD = MODE == 1 && P24 && sizeof(T) == 2 && DT <= 4 && !ROPE;
     constexpr int GLD = mat_ld<DT>(), GT = Geo<DT>::KST * 32 * GLD;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u16* Kh = reinterpret_cast<u16*>(smem_raw);
@@ -383,7 +423,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : (ROPE ? 2 : 3)) void k_sp_state
         settle();
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
-            const int off = (r0 + RPP * it) * LD + cg;
+            const int off = mat_row<TN>(r0 + RPP * it) * LD + cg;
             uint4 hi, lo;
             if (MODE == 1 && a.normalize) {   // dn[s] and the 1/n scaling of dO
                 if constexpr (!RD) {
@@ -447,8 +487,8 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : (ROPE ? 2 : 3)) void k_sp_state
                 bf16x8 bh_[KSTG], bl_[KSTG];
 #pragma unroll
                 for (int ks = 0; ks < KSTG; ++ks) {
-                    bh_[ks] = row_read8(Vh, LD, tt * 16, ks * 32, lane);
-                    bl_[ks] = row_read8(Vl, LD, tt * 16, ks * 32, lane);
+                    bh_[ks] = mat_row_read8<TN>(Vh, LD, tt * 16, ks * 32, lane);
+                    bl_[ks] = mat_row_read8<TN>(Vl, LD, tt * 16, ks * 32, lane);
                 }
                 float dot = 0.f;
 #pragma unroll
@@ -458,15 +498,15 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : (ROPE ? 2 : 3)) void k_sp_state
                         f32x4 t4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                         for (int ks = 0; ks < KSTG; ++ks) {
-                            const bf16x8 gh = row_read8(Gh, GLD, ct * 16, ks * 32, lane), gl = row_read8(Gl, GLD, ct * 16, ks * 32, lane);
+                            const bf16x8 gh = mat_row_read8<mat_new<DT>()>(Gh, GLD, ct * 16, ks * 32, lane), gl = mat_row_read8<mat_new<DT>()>(Gl, GLD, ct * 16, ks * 32, lane);
                             t4 = mfma_bf16(gh, bh_[ks], t4);
                             t4 = mfma_bf16(gl, bh_[ks], t4);
                             t4 = mfma_bf16(gh, bl_[ks], t4);
                         }
-                        const uint2 qr = *reinterpret_cast<const uint2*>(Kh + (tt * 16 + nl) * LD + ct * 16 + kg * 4);   // q[s][16 ct + 4 kg ..]: hi part
+                        const uint2 qr = *reinterpret_cast<const uint2*>(Kh + (tt * 16 + mat_row<TN>(nl)) * LD + ct * 16 + kg * 4);   // q[s][16 ct + 4 kg ..]: hi part
                         f32x4 q4 = {__uint_as_float(qr.x << 16), __uint_as_float(qr.x & 0xffff0000u), __uint_as_float(qr.y << 16), __uint_as_float(qr.y & 0xffff0000u)};
                         if (LO) {   // (fp16 tensors: + lo part; bf16 values are their hi part)
-                            const uint2 ql = *reinterpret_cast<const uint2*>(Kl + (tt * 16 + nl) * LD + ct * 16 + kg * 4);
+                            const uint2 ql = *reinterpret_cast<const uint2*>(Kl + (tt * 16 + mat_row<TN>(nl)) * LD + ct * 16 + kg * 4);
                             q4 += f32x4{__uint_as_float(ql.x << 16), __uint_as_float(ql.x & 0xffff0000u), __uint_as_float(ql.y << 16), __uint_as_float(ql.y & 0xffff0000u)};
                         }
                         dot += t4[0] * q4[0] + t4[1] * q4[1] + t4[2] * q4[2] + t4[3] * q4[3];
@@ -481,16 +521,16 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : (ROPE ? 2 : 3)) void k_sp_state
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {   // row tiles past DT read zero / unused columns of the tile: harmless, not stored
             const int c0 = min(wave * RT + rt, DW / 16 - 1) * 16;
-            ah[rt] = tr_read8(Kh, LD, 0, c0, lane);
-            if (LO) al[rt] = tr_read8(Kl, LD, 0, c0, lane);
+            ah[rt] = mat_tr_read8<TN>(Kh, LD, 0, c0, lane);
+            if (LO) al[rt] = mat_tr_read8<TN>(Kl, LD, 0, c0, lane);
         }
 #pragma unroll
         for (int ct = 0; ct < DT; ++ct) {
-            const bf16x8 bh_ = tr_read8(Vh, LD, 0, ct * 16, lane);
+            const bf16x8 bh_ = mat_tr_read8<TN>(Vh, LD, 0, ct * 16, lane);
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = mfma_bf16(ah[rt], bh_, acc[rt][ct]);
             if (LOY) {
-                const bf16x8 bl_ = tr_read8(Vl, LD, 0, ct * 16, lane);
+                const bf16x8 bl_ = mat_tr_read8<TN>(Vl, LD, 0, ct * 16, lane);
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = mfma_bf16(ah[rt], bl_, acc[rt][ct]);
             }
@@ -1678,11 +1718,11 @@ __global__ __launch_bounds__(SP_OUT_T, EPI ? SP_OUT_EPI_WAVES : 2) void k_sp_out
             f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
 #pragma unroll
             for (int ks = 0; ks < KST; ++ks) {
-                const bf16x8 a0h = tr_read8(Gh, LD, ks * 32, ct * 16, lane), a1h = tr_read8(Gh, LD, ks * 32, ct * 16 + 16, lane);
+                const bf16x8 a0h = mat_tr_read8<mat_new<DT>()>(Gh, LD, ks * 32, ct * 16, lane), a1h = mat_tr_read8<mat_new<DT>()>(Gh, LD, ks * 32, ct * 16 + 16, lane);
                 c0 = mfma_bf16(a0h, qh[ks], c0);
                 c1 = mfma_bf16(a1h, qh[ks], c1);
                 if (!S16) {
-                    const bf16x8 a0l = tr_read8(Gl, LD, ks * 32, ct * 16, lane), a1l = tr_read8(Gl, LD, ks * 32, ct * 16 + 16, lane);
+                    const bf16x8 a0l = mat_tr_read8<mat_new<DT>()>(Gl, LD, ks * 32, ct * 16, lane), a1l = mat_tr_read8<mat_new<DT>()>(Gl, LD, ks * 32, ct * 16 + 16, lane);
                     c0 = mfma_bf16(a0l, qh[ks], c0);
                     c1 = mfma_bf16(a1l, qh[ks], c1);
                 }
@@ -2218,11 +2258,11 @@ __global__ __launch_bounds__(NTHREADS, (DT <= 4 && WQ) ? 4 : 2) void k_sp_bwd_dq
             }
 #pragma unroll
             for (int ks = 0; ks < KST; ++ks) {
-                const bf16x8 a0h = row_read8(Gh, LD, ct * 16, ks * 32, lane), a1h = row_read8(Gh, LD, c1t * 16, ks * 32, lane);
+                const bf16x8 a0h = mat_row_read8<mat_new<DT>()>(Gh, LD, ct * 16, ks * 32, lane), a1h = mat_row_read8<mat_new<DT>()>(Gh, LD, c1t * 16, ks * 32, lane);
                 c0 = mfma_bf16(a0h, gh[ks], c0);
                 c1 = mfma_bf16(a1h, gh[ks], c1);
                 if (!S16) {
-                    const bf16x8 a0l = row_read8(Gl, LD, ct * 16, ks * 32, lane), a1l = row_read8(Gl, LD, c1t * 16, ks * 32, lane);
+                    const bf16x8 a0l = mat_row_read8<mat_new<DT>()>(Gl, LD, ct * 16, ks * 32, lane), a1l = mat_row_read8<mat_new<DT>()>(Gl, LD, c1t * 16, ks * 32, lane);
                     c0 = mfma_bf16(a0l, gh[ks], c0);
                     c1 = mfma_bf16(a1l, gh[ks], c1);
                 }
@@ -2363,13 +2403,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_bwd_dkv(const TokArgs a) {  
 #pragma unroll
             for (int ks = 0; ks < KST; ++ks) {
                 // dK^T[d1][s] = sum_d2 dKV[d1][d2] V[s][d2]
-                const bf16x8 ah = row_read8(Gh, LD, ct * 16, ks * 32, lane);
+                const bf16x8 ah = mat_row_read8<mat_new<DT>()>(Gh, LD, ct * 16, ks * 32, lane);
                 // dV^T[d2][s] = sum_d1 dKV[d1][d2] K[s][d1]
-                const bf16x8 th = tr_read8(Gh, LD, ks * 32, ct * 16, lane);
+                const bf16x8 th = mat_tr_read8<mat_new<DT>()>(Gh, LD, ks * 32, ct * 16, lane);
                 ck = mfma_bf16(ah, vh[ks], ck);
                 cv = mfma_bf16(th, kh[ks], cv);
                 if (!S16) {
-                    const bf16x8 al = row_read8(Gl, LD, ct * 16, ks * 32, lane), tl = tr_read8(Gl, LD, ks * 32, ct * 16, lane);
+                    const bf16x8 al = mat_row_read8<mat_new<DT>()>(Gl, LD, ct * 16, ks * 32, lane), tl = mat_tr_read8<mat_new<DT>()>(Gl, LD, ks * 32, ct * 16, lane);
                     ck = mfma_bf16(al, vh[ks], ck);
                     cv = mfma_bf16(tl, kh[ks], cv);
                 }

@@ -13,6 +13,7 @@ round-1 layout) and after (0.00) the round-4 layout change of the tile kernels (
 
   python tools/lds_conflicts.py            table of the layouts in use and of the ones they replaced
   python tools/lds_conflicts.py search     brute force over row strides / piece swizzles for a [64][64] bf16 tile
+  python tools/lds_conflicts.py split      the staged matrices / token tiles of the split kernels (split.hpp mat_ld, mat_row): round-1 vs round-6 layout
 """
 import sys
 
@@ -70,7 +71,23 @@ def show(name, pats):
     print(f"    {'all patterns':22s} conflict fraction {(tot - ideal) / tot:.2f}")
 
 
+def split_table():
+    """the staged D x D matrices of k_sp_out / k_sp_bwd_dq / k_sp_bwd_dkv and k_sp_state's token tiles: transpose reads (tr_read8: rows
+    k0 + 8 g + j, + 4), 16-byte row reads (row_read8) and the 16-byte staging stores, with rows of KP + pad elements and row r kept at P(r)"""
+    swap23 = lambda r: (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1)
+    for kp, cgs in ((64, 8), (96, 16), (128, 16)):
+        for pad, name, P in ((8, "round 1: pad 8", lambda r: r), (16, "pad 16", lambda r: r), (16, "round 6: pad 16, row bits 2 <-> 3", swap23)):
+            sb = (kp + pad) * 2
+            tr = max(cycles([P(ks * 32 + (l >> 4) * 8 + ((l & 15) >> 2) + 4 * h) * sb + (tn * 16 + (l & 3) * 4) * 2 for l in LANES], 8, G2x32, 64)
+                     for ks in range(kp // 32) for tn in range(kp // 16) for h in range(2))
+            rr = max(cycles([P(tn * 16 + (l & 15)) * sb + (ks * 32 + (l >> 4) * 8) * 2 for l in LANES], 16, G128, 64) for tn in range(kp // 16) for ks in range(kp // 32))
+            st = max(cycles([P(base + l // cgs) * sb + (l % cgs) * 16 for l in LANES], 16, G8x8, 32) for base in range(0, kp, 64 // cgs))
+            print(f"[{kp}][{kp}+{pad}] {name:36s} transpose read {tr} (ideal 2)   row read b128 {rr} (ideal 4)   staging store b128 {st} (ideal 8)")
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "split":
+        return split_table()
     if len(sys.argv) > 1 and sys.argv[1] == "search":
         cands = [("none", lambda r: 0)] + [(f"(r>>{a})&{m}", (lambda a, m: (lambda r: (r >> a) & m))(a, m)) for a in range(4) for m in (1, 3, 7)] + \
                 [(f"((r>>{a})^(r>>{b}))&7", (lambda a, b: (lambda r: ((r >> a) ^ (r >> b)) & 7))(a, b)) for a in range(3) for b in range(a + 1, 5)]
