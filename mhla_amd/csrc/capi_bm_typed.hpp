@@ -38,7 +38,7 @@ inline int sp_mixr(const float* W, int ldw, const void* in, void* out, int M, lo
         const long zt = wz ? (long)BH * ((S + TE - 1) / TE) : 0;   /* normaliser slices: dealt round-robin over the workgroups */ \
         /* persistent workgroups: as many as fit a CU beside each other (35 KB of LDS at four waves, 70 KB at eight) */ \
         const int wgs = (int)std::min<long>(total, 256 * (NW <= 2 ? 8 : NW <= 4 ? 4 : NW <= 8 ? 2 : 1)); \
-        sp::MixrArgs a{W, ldw, in, out, M, E, es, total, (int)((total + wgs - 1) / wgs), wz ? zin : nullptr, wz ? zout : nullptr, wz ? S : 0, eps, nullptr, nullptr, nullptr, zt, nullptr}; \
+        sp::MixrArgs a{W, ldw, in, out, M, E, es, total, (int)((total + wgs - 1) / wgs), wz ? zin : nullptr, wz ? zout : nullptr, wz ? S : 0, eps, g_trace.load(), nullptr, nullptr, zt, nullptr}; \
         const int gw = (int)((total + a.spw - 1) / a.spw); \
         return launch(sp::k_sp_mixr<NW, TRANS, S16, false, P24>, dim3(gw), dim3(64 * NW), sp::sp_mixr_smem<NW, S16>(), st, TRANS ? "k_sp_mixr<1>" : "k_sp_mixr<0>", a); \
     } while (0)
@@ -100,7 +100,7 @@ inline int sp_mixh(const float* W, int ldw, const void* in, void* out, int M, lo
         const bool wz = zin && sp_mixr_takes_wz<false>(M, S); \
         const long zt = wz ? (long)BH * ((S + sp::mixh_tez<NW>() - 1) / sp::mixh_tez<NW>()) : 0; \
         const int wgs = (int)std::min<long>(total, 256 * (PERCU)); \
-        sp::MixrArgs a{W, ldw, in, out, M, E, es, total, (int)((total + wgs - 1) / wgs), wz ? zin : nullptr, wz ? zout : nullptr, wz ? S : 0, eps, nullptr, nullptr, nullptr, zt, nullptr}; \
+        sp::MixrArgs a{W, ldw, in, out, M, E, es, total, (int)((total + wgs - 1) / wgs), wz ? zin : nullptr, wz ? zout : nullptr, wz ? S : 0, eps, g_trace.load(), nullptr, nullptr, zt, nullptr}; \
         const int gw = (int)((total + a.spw - 1) / a.spw); \
         return launch(sp::k_sp_mixh<NW, TRANS, false>, dim3(gw), dim3(64 * NW), sp::sp_mixh_smem<NW, false>(), st, TRANS ? "k_sp_mixh<1>" : "k_sp_mixh<0>", a); \
     } while (0)

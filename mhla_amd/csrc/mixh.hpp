@@ -215,7 +215,18 @@ __global__ __launch_bounds__(64 * NW, DW ? (NW + 3) / 4 : (NW <= 4 ? 4 : (NW + 3
             }
         }
     };
+    // MIXH_TRACE builds (tools/trace_mixh.py): s_memtime stamps of the first eight workgroups' summary slices -- 0 entry | 1 commit + previous
+    // slice's stores issued | 2 barrier | 3 next slice requested | 4 weights rescaled | 5 products | 6 staged | 7 barrier
+    int tk = 0;
+    auto stamp = [&](int i) {
+#ifdef MIXH_TRACE
+        if (a.trace && tid == 0 && blockIdx.x < 8 && tk < 32) a.trace[(blockIdx.x * 32 + tk) * 8 + i] = __builtin_amdgcn_s_memtime();
+#else
+        (void)i;
+#endif
+    };
     auto body = [&]<bool ZS>(std::bool_constant<ZS> zs, Stage& g, bool first, bool more, int bh, int es, int nbh, int nes) __attribute__((always_inline)) {
+        if constexpr (!ZS) stamp(0);
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             const int row = urow(p), c = ucol(p);
@@ -234,8 +245,11 @@ __global__ __launch_bounds__(64 * NW, DW ? (NW + 3) / 4 : (NW <= 4 ? 4 : (NW + 3
             }
         }
         if (!first) store_slice(pbh, pes, pz);
+        if constexpr (!ZS) stamp(1);
         __syncthreads();
+        if constexpr (!ZS) stamp(2);
         if (more) issue(zs, g, nbh, nes);
+        if constexpr (!ZS) stamp(3);
         f32x4 acc[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -293,6 +307,7 @@ __global__ __launch_bounds__(64 * NW, DW ? (NW + 3) / 4 : (NW <= 4 ? 4 : (NW + 3
             beta += __shfl_xor(beta, 32, 64);
             const float om = h16_mult_from_bound(beta), oinv = h16_inv(om);
             if (kg == 0) mo[wave * 16 + nl] = om;
+            stamp(4);
 #pragma unroll
             for (int ks = 0; ks < NK; ++ks) {
                 if (ks < kend) {
@@ -314,6 +329,7 @@ __global__ __launch_bounds__(64 * NW, DW ? (NW + 3) / 4 : (NW <= 4 ? 4 : (NW + 3
                     }
                 }
             }
+            stamp(5);
             if constexpr (DW) {   // dW[i][j] += m_i m'_j sum_e pay_i[e] pay'_j[e]: rows i of this wave, every column tile that holds a block
                 if (wave * 16 < M) {   // (uniform)
                     f32x4 tmp[NW];
@@ -342,7 +358,9 @@ __global__ __launch_bounds__(64 * NW, DW ? (NW + 3) / 4 : (NW <= 4 ? 4 : (NW + 3
             for (int t = 0; t < NT; ++t)
                 *reinterpret_cast<uint2*>(Os + (wave * 16 + nl) * LD + t * 16 + kg * 4) = make_uint2(h16_pack2(acc[t][0], acc[t][1]), h16_pack2(acc[t][2], acc[t][3]));
         }
+        if constexpr (!ZS) stamp(6);
         __syncthreads();
+        if constexpr (!ZS) { stamp(7); ++tk; }
         pbh = bh;
         pes = es;
         pz = ZS;
