@@ -43,11 +43,15 @@ template <int DT, bool HL>
 static auto sn_fwd_kernel(bool gather, int M) {
     return gather ? fast::k_sn_fwd<DT, true, false, HL> : (M == 16 ? fast::k_sn_fwd<DT, false, true, HL> : fast::k_sn_fwd<DT, false, false, HL>);
 }
+#ifndef SN_BWD_NB
+#define SN_BWD_NB 1   // blocks per wave of the default-arithmetic small-sequence backward (smalln.hpp k_sn_bwd): sixteen waves with one block each
+                      // beat eight with two by 3.5 % at C3 (107.0 -> 103.0 us, twice each; workgroup life 91 400 -> 80 000 cycles in tools/trace_smalln.py)
+#endif
 template <int DT, bool HL>
 static auto sn_bwd_kernel(bool gather, int M) {
     // (HL: the run-time-guarded block loops also for exactly 16 blocks -- fully unrolled, pass A becomes one basic block whose
     // schedule needs 100-135 registers more than the 256 there are; the guarded form allocates 187 / 230 without a spill)
-    if constexpr (HL) return gather ? fast::k_sn_bwd<DT, true, false, true> : fast::k_sn_bwd<DT, false, false, true>;
+    if constexpr (HL) return gather ? fast::k_sn_bwd<DT, true, false, true, SN_BWD_NB> : fast::k_sn_bwd<DT, false, false, true, SN_BWD_NB>;
     else return gather ? fast::k_sn_bwd<DT, true, false, false> : (M == 16 ? fast::k_sn_bwd<DT, false, true, false> : fast::k_sn_bwd<DT, false, false, false>);
 }
 
@@ -421,8 +425,9 @@ static int bm_bwd_impl(mhla_view q_num, mhla_view k_num, mhla_view v, mhla_view 
             sa.dwp = (float*)ws; sa.H = H; sa.M = M; sa.D = D; sa.eps = eps; sa.relu = relu; sa.normalize = normalize;
             sa.trace = g_trace.load();
             const bool hl = !(flags & MHLA_FLAG_BF16_SUMMARIES), g = sa.idx != nullptr;
-            if (D <= 64) RC(launch(hl ? sn_bwd_kernel<4, true>(g, M) : sn_bwd_kernel<4, false>(g, M), dim3(B * H), dim3(fast::SN_TB), fast::sn_bwd_smem<4>(), st, hl ? "k_sn_bwd<4,hl>" : "k_sn_bwd<4>", sa));
-            else         RC(launch(hl ? sn_bwd_kernel<5, true>(g, M) : sn_bwd_kernel<5, false>(g, M), dim3(B * H), dim3(fast::SN_TB), fast::sn_bwd_smem<5>(), st, hl ? "k_sn_bwd<5,hl>" : "k_sn_bwd<5>", sa));
+            const int nth = hl ? fast::SN_TB * (3 - SN_BWD_NB) : fast::SN_TB;
+            if (D <= 64) RC(launch(hl ? sn_bwd_kernel<4, true>(g, M) : sn_bwd_kernel<4, false>(g, M), dim3(B * H), dim3(nth), hl ? fast::sn_bwd_smem<4, SN_BWD_NB>() : fast::sn_bwd_smem<4>(), st, hl ? "k_sn_bwd<4,hl>" : "k_sn_bwd<4>", sa));
+            else         RC(launch(hl ? sn_bwd_kernel<5, true>(g, M) : sn_bwd_kernel<5, false>(g, M), dim3(B * H), dim3(nth), hl ? fast::sn_bwd_smem<5, SN_BWD_NB>() : fast::sn_bwd_smem<5>(), st, hl ? "k_sn_bwd<5,hl>" : "k_sn_bwd<5>", sa));
             RC(launch(fast::k_sn_dw_reduce, dim3(M * M), dim3(256), 0, st, "k_sn_dw_reduce", (const float*)ws, dW, M * M, B * H));
             return MHLA_OK;
         }

@@ -20,8 +20,11 @@ namespace fast {
 
 // forward: 16 waves, wave w owns block w (M <= 16) -- its phases are latency chains (LDS read -> MFMA -> pack -> MFMA per block
 // pair) that 16 waves hide better than 8 waves with two blocks each (42.7 -> 37.8 us at the DiT-XL/2 shape).
-// backward: 8 waves, wave w owns blocks w and w + 8 and processes them JOINTLY: the backward is bound by LDS operand reads (every
-// (i, j) pair re-reads the K / V / Q / dO' rows of block j), and two blocks that share each fetched operand halve that traffic.
+// backward: 8 waves, wave w owns blocks w and w + 8 and processes them JOINTLY (every (i, j) pair re-reads the K / V / Q / dO' rows of
+// block j, and two blocks that share each fetched operand halve that LDS traffic) -- the reduced-precision kernel; the default-arithmetic
+// one (hi + lo score tiles: 187 / 230 registers with two blocks) runs 16 waves with one block each (template parameter NB), 3.5 % faster at
+// C3: per block pair and SIMD its MFMAs (~1 500 cycles), its VALU work (~800) and the LDS reads (~1 000 - 2 000) add up to the ~3 500
+// measured either way -- the passes are bound by the SUM of the three pipes, not by latency (tools/trace_smalln.py).
 constexpr int SN_T = 1024;
 constexpr int SN_W = SN_T / 64;
 constexpr int SN_TB = 512;
@@ -373,9 +376,9 @@ __global__ __launch_bounds__(SN_T, SN_T / 256) void k_sn_fwd(const SnArgs a) {
 //   pass B (wave owns key blocks j, Q / dO' tiles in LDS):  S, dP tiles -> P^T dO' = dV_j ; dS^T Q = dK_j
 // with S = Q K^T, P = W (.) S, dO' = dO / n, dP = dO' V^T, dS = W (.) dP, dn = -(dO . O) / n, dz = W^T dn.
 // ------------------------------------------------------------------------------------------------------------------
-template <int DT>
+template <int DT, int NB = 2>
 __host__ __device__ constexpr int sn_bwd_smem() {
-    return 2 * 256 * sn_ldr<DT>() * 2 + (2 * 16 * DT * 16 + 5 * 256) * 4 + SN_WB * 16 * sn_ldr<DT>() * 2;
+    return 2 * 256 * sn_ldr<DT>() * 2 + (2 * 16 * DT * 16 + 5 * 256) * 4 + (NB == 2 ? SN_WB : 2 * SN_WB) * 16 * sn_ldr<DT>() * 2;
 }
 
 template <bool MASK>
@@ -395,8 +398,12 @@ __device__ __forceinline__ void sn_store16(u16* __restrict__ base, long sn, cons
 // HL (the default arithmetic): no intermediate is rounded to bf16 on its way into a second contraction -- dO stays the exact tensor
 // (its 1 / n factor is applied to the fp32 tiles it produces: per column in pass A, per row in pass B) and the weighted score tiles
 // P, dS enter the second contractions as bf16 hi + lo parts; false: dO' = dO / n and the tiles as single bf16 values
-template <int DT, bool GATHER, bool M16 = false, bool HL = true>
-__global__ __launch_bounds__(SN_TB, 2) void k_sn_bwd(const SnArgs a) {
+// NB: blocks per wave.  2: eight waves, wave w owns blocks w and w + 8 and works on them jointly (each fetched operand serves both);
+// 1: sixteen waves, one block each -- twice the LDS operand traffic, but four waves per SIMD to overlap each other's LDS read -> MFMA ->
+// pack -> MFMA chains (the choice the forward made)
+template <int DT, bool GATHER, bool M16 = false, bool HL = true, int NB = 2>
+__global__ __launch_bounds__(NB == 2 ? SN_TB : 2 * SN_TB, NB == 2 ? 2 : 4) void k_sn_bwd(const SnArgs a) {
+    constexpr int NTH = NB == 2 ? SN_TB : 2 * SN_TB, NWV = NTH / 64;
     // GATHER: the launch has a block_index map.  As a template parameter the row lookups carry no branch: with `idx ? idx[p] : p`
     // decided at run time hipcc branched around every map load and waited for ALL loads in flight at each join (s_waitcnt
     // vmcnt(0) after every group of row loads: the staging became a chain of dependent round trips).
@@ -413,7 +420,7 @@ __global__ __launch_bounds__(SN_TB, 2) void k_sn_bwd(const SnArgs a) {
     float* nis = rds + 256;                              // 1 / n
     float* dns = nis + 256;                              // dn
     float* dzs = dns + 256;                              // dz
-    u16* Ost = reinterpret_cast<u16*>(dzs + 256);        // [8 waves][16][LDR]
+    u16* Ost = reinterpret_cast<u16*>(dzs + 256);        // [NWV waves][16][LDR]
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, n = lane & 15, kg = lane >> 4;
     // (b,h) pairs in XCD-contiguous order: a token's heads are adjacent in memory (144-byte rows for D = 72: neighbouring heads share
     // cache lines), so the heads of one batch element go to workgroups of ONE XCD, running side by side, and each line is fetched once
@@ -426,9 +433,12 @@ __global__ __launch_bounds__(SN_TB, 2) void k_sn_bwd(const SnArgs a) {
     float* dwp = a.dwp + (long)bh * M * M;
     u16* Os = Ost + wave * 16 * LDR;
     // the wave's two blocks; with M <= 8 the second one does not exist: it is clamped onto the first (its results are dropped)
-    const int bA = wave, bB = wave + SN_WB;
-    const bool hasA = bA < M, hasB = bB < M;
-    const int blk[2] = {hasA ? bA : 0, hasB ? bB : (hasA ? bA : 0)};
+    const int bA = wave, bB = wave + NWV;
+    const bool hasA = bA < M, hasB = NB == 2 && bB < M;
+    int blk[NB];
+    blk[0] = hasA ? bA : 0;
+    if constexpr (NB == 2) blk[1] = hasB ? bB : (hasA ? bA : 0);
+    auto has = [&](int x) { return x == 0 ? hasA : hasB; };
     auto load_k = [&](bf16x8 (&r)[KS], int j) {
         sn_load_rows<KS>(r, kb, a.k.sn, idx, j * 16, D, a.eps, lane, a.relu != 0);
     };
@@ -454,27 +464,27 @@ __global__ __launch_bounds__(SN_TB, 2) void k_sn_bwd(const SnArgs a) {
     const int wi = (tid >> 4) & 15, wj = tid & 15;
     const bool wok = wi < M && wj < M;
     const float wreg = gld<float>(a.W + (long)(wok ? wi : 0) * a.ldw + (wok ? wj : 0));
-    bf16x8 qa[2][KS], ga[2][KS];
-    uint4 qraw[2][KS], graw[2][KS], oraw[2][KS];
+    bf16x8 qa[NB][KS], ga[NB][KS];
+    uint4 qraw[NB][KS], graw[NB][KS], oraw[NB][KS];
 #pragma unroll
-    for (int x = 0; x < 2; ++x) {
+    for (int x = 0; x < NB; ++x) {
         sn_issue_rows<KS>(qraw[x], qb, a.q.sn, idx, blk[x] * 16, D, lane);
         sn_issue_rows<KS>(graw[x], gb, a.dout.sn, idx, blk[x] * 16, D, lane);
         if (a.normalize && !HL) sn_issue_rows<KS>(oraw[x], ob, a.o.sn, idx, blk[x] * 16, D, lane);   // (HL: the row dots come out of pass A)
     }
     // ---- P0 / P1: K, V tiles; ksum ----
     __shared__ float Wsh[16 * 17];   // mixing weights (M <= 16), read in every inner loop
-    sn_stage2<DT, SN_TB, false>(T0, kb, a.k.sn, a.eps, a.relu != 0, T1, vb, a.v.sn, idx, N, D, tid);
+    sn_stage2<DT, NTH, false>(T0, kb, a.k.sn, a.eps, a.relu != 0, T1, vb, a.v.sn, idx, N, D, tid);
     if (tid < 256) Wsh[wi * 17 + wj] = wok ? wreg : 0.f;
 #pragma unroll
-    for (int x = 0; x < 2; ++x) {
+    for (int x = 0; x < NB; ++x) {
         sn_finish_rows<KS>(qa[x], qraw[x], D, a.eps, lane, a.relu != 0);
         sn_finish_rows<KS>(ga[x], graw[x], D, 0.f, lane, false);
     }
     __syncthreads();
     trace_mark(a.trace, 1);
     if (a.normalize) {
-        for (int v = tid; v < M * DP; v += SN_TB) {
+        for (int v = tid; v < M * DP; v += NTH) {
             const int j = v / DP, d = v - j * DP;
             float sacc = 0.f;
 #pragma unroll
@@ -485,8 +495,8 @@ __global__ __launch_bounds__(SN_TB, 2) void k_sn_bwd(const SnArgs a) {
         trace_mark(a.trace, 2);
         // ---- P2: z_i, row dots (own blocks) ----
 #pragma unroll
-        for (int x = 0; x < 2; ++x) {
-            if (x == 0 ? hasA : hasB) {
+        for (int x = 0; x < NB; ++x) {
+            if (has(x)) {
                 const int i = blk[x];
                 bf16x8 oa[KS];
                 if constexpr (!HL) sn_finish_rows<KS>(oa, oraw[x], D, 0.f, lane, false);
@@ -512,7 +522,7 @@ __global__ __launch_bounds__(SN_TB, 2) void k_sn_bwd(const SnArgs a) {
         __syncthreads();
         trace_mark(a.trace, 3);
         // ---- P3: 1/n, dn ----
-        for (int v = tid; v < N; v += SN_TB) {
+        for (int v = tid; v < N; v += NTH) {
             const int i = v >> 4, sx = v & 15;
             float nn = a.eps;
             for (int j = 0; j < M; ++j) nn += Wsh[i * 17 + j] * zs[j * 16 + sx];
@@ -524,7 +534,7 @@ __global__ __launch_bounds__(SN_TB, 2) void k_sn_bwd(const SnArgs a) {
         // ---- P4: dz = W^T dn ----   (HL: dn = -(dO . O) / n is formed in pass A, from the fp32 score tiles -- the stored, rounded O
         // would cost the row dots 2e-3 -- and dz follows it)
         if constexpr (!HL) {
-            for (int v = tid; v < N; v += SN_TB) {
+            for (int v = tid; v < N; v += NTH) {
                 const int j = v >> 4, sx = v & 15;
                 float dz = 0.f;
                 for (int i = 0; i < M; ++i) dz += Wsh[i * 17 + j] * dns[i * 16 + sx];
@@ -538,43 +548,46 @@ __global__ __launch_bounds__(SN_TB, 2) void k_sn_bwd(const SnArgs a) {
     // ---- pass A: dQ_i, dW[i][:] for the wave's two query blocks at once (K, V rows and K^T operands fetched once for both) ----
     {
         if constexpr (!HL) {
-            scale_dop(ga[0], blk[0]);
-            scale_dop(ga[1], blk[1]);
+#pragma unroll
+            for (int x = 0; x < NB; ++x) scale_dop(ga[x], blk[x]);
         }
         // HL: the factor 1 / n_i[s] of dP^T = V_j (dO_i / n_i)^T is a per-column (= per-lane) scale of the fp32 tile
-        const float niA[2] = {(HL && a.normalize) ? nis[blk[0] * 16 + n] : 1.f, (HL && a.normalize) ? nis[blk[1] * 16 + n] : 1.f};
-        f32x4 acc[2][DT];
+        float niA[NB];
 #pragma unroll
-        for (int x = 0; x < 2; ++x)
+        for (int x = 0; x < NB; ++x) niA[x] = (HL && a.normalize) ? nis[blk[x] * 16 + n] : 1.f;
+        f32x4 acc[NB][DT];
+#pragma unroll
+        for (int x = 0; x < NB; ++x)
 #pragma unroll
             for (int tn = 0; tn < DT; ++tn) acc[x][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
-        float ew[2][16];   // per-lane partials of dW[i][0..15]
+        float ew[NB][16];   // per-lane partials of dW[i][0..15]
 #pragma unroll
         for (int jp = 0; jp < 8; ++jp) {
             const int j0 = 2 * jp;
-            ew[0][j0] = ew[0][j0 + 1] = ew[1][j0] = ew[1][j0 + 1] = 0.f;
+            #pragma unroll
+            for (int x = 0; x < NB; ++x) ew[x][j0] = ew[x][j0 + 1] = 0.f;
             if (j0 < M) {
                 const bool has1 = j0 + 1 < M;
                 const int j1 = has1 ? j0 + 1 : j0;
-                f32x4 s0[2], s1[2], p0[2], p1[2];
+                f32x4 s0[NB], s1[NB], p0[NB], p1[NB];
 #pragma unroll
-                for (int x = 0; x < 2; ++x) s0[x] = s1[x] = p0[x] = p1[x] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int x = 0; x < NB; ++x) s0[x] = s1[x] = p0[x] = p1[x] = f32x4{0.f, 0.f, 0.f, 0.f};
                 bf16x8 t0[KS], t1[KS];
                 sn_lds_rows<KS>(t0, T0, LDR, j0 * 16, D, lane);
                 sn_lds_rows<KS>(t1, T0, LDR, j1 * 16, D, lane);
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                    for (int x = 0; x < 2; ++x) { s0[x] = mfma_bf16(t0[ks], qa[x][ks], s0[x]); s1[x] = mfma_bf16(t1[ks], qa[x][ks], s1[x]); }   // S^T
+                    for (int x = 0; x < NB; ++x) { s0[x] = mfma_bf16(t0[ks], qa[x][ks], s0[x]); s1[x] = mfma_bf16(t1[ks], qa[x][ks], s1[x]); }   // S^T
                 sn_lds_rows<KS>(t0, T1, LDR, j0 * 16, D, lane);
                 sn_lds_rows<KS>(t1, T1, LDR, j1 * 16, D, lane);
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                    for (int x = 0; x < 2; ++x) { p0[x] = mfma_bf16(t0[ks], ga[x][ks], p0[x]); p1[x] = mfma_bf16(t1[ks], ga[x][ks], p1[x]); }   // dP^T
-                bf16x8 da[2], dl[HL ? 2 : 1];
+                    for (int x = 0; x < NB; ++x) { p0[x] = mfma_bf16(t0[ks], ga[x][ks], p0[x]); p1[x] = mfma_bf16(t1[ks], ga[x][ks], p1[x]); }   // dP^T
+                bf16x8 da[NB], dl[HL ? NB : 1];
 #pragma unroll
-                for (int x = 0; x < 2; ++x) {
+                for (int x = 0; x < NB; ++x) {
                     const int i = blk[x];
                     if constexpr (HL) { p0[x] *= niA[x]; p1[x] *= niA[x]; }
                     // dW[i][j] = sum(dP . S) + sum_s dn_i[s] z_j[s]: lane partials, reduced once per query block below
@@ -593,39 +606,39 @@ __global__ __launch_bounds__(SN_TB, 2) void k_sn_bwd(const SnArgs a) {
 #pragma unroll
                 for (int tn = 0; tn < DT; ++tn) {
                     const bf16x8 bk = sn_tr_pair(T0, LDR, j0 * 16, j1 * 16, tn * 16, lane);
-                    acc[0][tn] = mfma_bf16(da[0], bk, acc[0][tn]);
-                    acc[1][tn] = mfma_bf16(da[1], bk, acc[1][tn]);
+#pragma unroll
+                    for (int x = 0; x < NB; ++x) acc[x][tn] = mfma_bf16(da[x], bk, acc[x][tn]);
                     if constexpr (HL) {
-                        acc[0][tn] = mfma_bf16(dl[0], bk, acc[0][tn]);
-                        acc[1][tn] = mfma_bf16(dl[1], bk, acc[1][tn]);
+#pragma unroll
+                        for (int x = 0; x < NB; ++x) acc[x][tn] = mfma_bf16(dl[x], bk, acc[x][tn]);
                     }
                 }
             }
         }
         // HL: per-lane partials of the row dot (dO . O)[s = n] = sum_j W_ij sum_t S[s][t] dP[s][t] -- the lane's dW partials, weighted
-        float rdl[2] = {0.f, 0.f};
+        float rdl[NB] = {};
         if constexpr (HL) {
             asm volatile("" ::: "memory");   // (keeps the 32 weight reads below from being hoisted above the block loop: +32 live registers there, 131 spilled)
 #pragma unroll
-            for (int x = 0; x < 2; ++x)
+            for (int x = 0; x < NB; ++x)
 #pragma unroll
                 for (int j = 0; j < 16; ++j) rdl[x] += Wsh[blk[x] * 17 + j] * ew[x][j];
         }
-        float totx[2];
+        float totx[NB];
 #pragma unroll
-        for (int x = 0; x < 2; ++x) totx[x] = wave_reduce16(ew[x], lane);
+        for (int x = 0; x < NB; ++x) totx[x] = wave_reduce16(ew[x], lane);
         const int jw = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
         if constexpr (HL) {
             if (a.normalize) {   // (uniform)
 #pragma unroll
-                for (int x = 0; x < 2; ++x) {
+                for (int x = 0; x < NB; ++x) {
                     float rd = rdl[x];
                     rd += __shfl_xor(rd, 16, 64);
                     rd += __shfl_xor(rd, 32, 64);
-                    if ((x == 0 ? hasA : hasB) && kg == 0) dns[blk[x] * 16 + n] = -rd * nis[blk[x] * 16 + n];
+                    if (has(x) && kg == 0) dns[blk[x] * 16 + n] = -rd * nis[blk[x] * 16 + n];
                 }
                 __syncthreads();
-                for (int v = tid; v < N; v += SN_TB) {   // dz = W^T dn
+                for (int v = tid; v < N; v += NTH) {   // dz = W^T dn
                     const int j = v >> 4, sx = v & 15;
                     float dz = 0.f;
                     for (int i = 0; i < M; ++i) dz += Wsh[i * 17 + j] * dns[i * 16 + sx];
@@ -633,7 +646,7 @@ __global__ __launch_bounds__(SN_TB, 2) void k_sn_bwd(const SnArgs a) {
                 }
                 __syncthreads();
 #pragma unroll
-                for (int x = 0; x < 2; ++x) {   // dW[i][jw] += <dn_i, z_jw>: the four lanes of a quad take four positions each
+                for (int x = 0; x < NB; ++x) {   // dW[i][jw] += <dn_i, z_jw>: the four lanes of a quad take four positions each
                     const int i = blk[x], jc = min(jw, M - 1), s4 = (lane & 3) * 4;
                     float t = 0.f;
 #pragma unroll
@@ -645,9 +658,9 @@ __global__ __launch_bounds__(SN_TB, 2) void k_sn_bwd(const SnArgs a) {
             }
         }
 #pragma unroll
-        for (int x = 0; x < 2; ++x) {
+        for (int x = 0; x < NB; ++x) {
             const int i = blk[x];
-            const bool live = x == 0 ? hasA : hasB;
+            const bool live = has(x);
             const float tot = totx[x];
             if (live && (lane & 3) == 0 && jw < M) dwp[i * M + jw] = tot;
             if (live) {
@@ -670,9 +683,9 @@ __global__ __launch_bounds__(SN_TB, 2) void k_sn_bwd(const SnArgs a) {
     }
     trace_mark(a.trace, 5);
     // the wave's key-block rows for pass B are requested before the tiles are re-staged
-    bf16x8 ka[2][KS], va[2][KS];
+    bf16x8 ka[NB][KS], va[NB][KS];
 #pragma unroll
-    for (int x = 0; x < 2; ++x) {
+    for (int x = 0; x < NB; ++x) {
         load_k(ka[x], blk[x]);
         sn_load_rows<KS>(va[x], vb, a.v.sn, idx, blk[x] * 16, D, 0.f, lane);
     }
@@ -681,39 +694,39 @@ __global__ __launch_bounds__(SN_TB, 2) void k_sn_bwd(const SnArgs a) {
 
     // ---- P5: Q and dO' tiles replace K and V ----
     // (HL: dO itself is staged; 1 / n scales the rows of the fp32 tiles below)
-    if (a.normalize && !HL) sn_stage2<DT, SN_TB, true>(T0, qb, a.q.sn, a.eps, a.relu != 0, T1, gb, a.dout.sn, idx, N, D, tid, nis);
-    else                    sn_stage2<DT, SN_TB, false>(T0, qb, a.q.sn, a.eps, a.relu != 0, T1, gb, a.dout.sn, idx, N, D, tid);
+    if (a.normalize && !HL) sn_stage2<DT, NTH, true>(T0, qb, a.q.sn, a.eps, a.relu != 0, T1, gb, a.dout.sn, idx, N, D, tid, nis);
+    else                    sn_stage2<DT, NTH, false>(T0, qb, a.q.sn, a.eps, a.relu != 0, T1, gb, a.dout.sn, idx, N, D, tid);
     __syncthreads();
     trace_mark(a.trace, 7);
 
     // ---- pass B: dK_j, dV_j for the wave's two key blocks at once (Q, dO' rows and their transposes fetched once for both) ----
     {
-        f32x4 accK[2][DT], accV[2][DT];
+        f32x4 accK[NB][DT], accV[NB][DT];
 #pragma unroll
-        for (int x = 0; x < 2; ++x)
+        for (int x = 0; x < NB; ++x)
 #pragma unroll
             for (int tn = 0; tn < DT; ++tn) accK[x][tn] = accV[x][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 2
         for (int i0 = 0; i0 < M; i0 += 2) {
             const bool has1 = i0 + 1 < M;
             const int i1 = has1 ? i0 + 1 : i0;
-            f32x4 s0[2], s1[2], p0[2], p1[2];
+            f32x4 s0[NB], s1[NB], p0[NB], p1[NB];
 #pragma unroll
-            for (int x = 0; x < 2; ++x) s0[x] = s1[x] = p0[x] = p1[x] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int x = 0; x < NB; ++x) s0[x] = s1[x] = p0[x] = p1[x] = f32x4{0.f, 0.f, 0.f, 0.f};
             bf16x8 t0[KS], t1[KS];
             sn_lds_rows<KS>(t0, T0, LDR, i0 * 16, D, lane);
             sn_lds_rows<KS>(t1, T0, LDR, i1 * 16, D, lane);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                for (int x = 0; x < 2; ++x) { s0[x] = mfma_bf16(t0[ks], ka[x][ks], s0[x]); s1[x] = mfma_bf16(t1[ks], ka[x][ks], s1[x]); }   // S: rows s, cols t
+                for (int x = 0; x < NB; ++x) { s0[x] = mfma_bf16(t0[ks], ka[x][ks], s0[x]); s1[x] = mfma_bf16(t1[ks], ka[x][ks], s1[x]); }   // S: rows s, cols t
             sn_lds_rows<KS>(t0, T1, LDR, i0 * 16, D, lane);
             sn_lds_rows<KS>(t1, T1, LDR, i1 * 16, D, lane);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                for (int x = 0; x < 2; ++x) { p0[x] = mfma_bf16(t0[ks], va[x][ks], p0[x]); p1[x] = mfma_bf16(t1[ks], va[x][ks], p1[x]); }   // dP
-            bf16x8 pa[2], da[2], pl[HL ? 2 : 1], dl[HL ? 2 : 1];
+                for (int x = 0; x < NB; ++x) { p0[x] = mfma_bf16(t0[ks], va[x][ks], p0[x]); p1[x] = mfma_bf16(t1[ks], va[x][ks], p1[x]); }   // dP
+            bf16x8 pa[NB], da[NB], pl[HL ? NB : 1], dl[HL ? NB : 1];
             // HL: 1 / n_i[s] of the tiles' rows s = 4 kg + r (dP = diag(1/n) dO V^T; dV = (P diag-scaled)^T dO)
             f32x4 ni0 = {1.f, 1.f, 1.f, 1.f}, ni1 = ni0;
             if constexpr (HL) {
@@ -723,7 +736,7 @@ __global__ __launch_bounds__(SN_TB, 2) void k_sn_bwd(const SnArgs a) {
                 }
             }
 #pragma unroll
-            for (int x = 0; x < 2; ++x) {
+            for (int x = 0; x < NB; ++x) {
                 const float w0 = Wsh[i0 * 17 + blk[x]], w1 = has1 ? Wsh[i1 * 17 + blk[x]] : 0.f;
                 if constexpr (HL) {
                     const f32x4 f0 = ni0 * w0, f1 = ni1 * w1;
@@ -739,7 +752,7 @@ __global__ __launch_bounds__(SN_TB, 2) void k_sn_bwd(const SnArgs a) {
                 const bf16x8 bv = sn_tr_pair(T1, LDR, i0 * 16, i1 * 16, tn * 16, lane);
                 const bf16x8 bq = sn_tr_pair(T0, LDR, i0 * 16, i1 * 16, tn * 16, lane);
 #pragma unroll
-                for (int x = 0; x < 2; ++x) {
+                for (int x = 0; x < NB; ++x) {
                     accV[x][tn] = mfma_bf16(pa[x], bv, accV[x][tn]);   // dV += P^T dO'
                     accK[x][tn] = mfma_bf16(da[x], bq, accK[x][tn]);   // dK += dS^T Q
                     if constexpr (HL) {
@@ -750,8 +763,8 @@ __global__ __launch_bounds__(SN_TB, 2) void k_sn_bwd(const SnArgs a) {
             }
         }
 #pragma unroll
-        for (int x = 0; x < 2; ++x) {
-            if (!(x == 0 ? hasA : hasB)) continue;
+        for (int x = 0; x < NB; ++x) {
+            if (!has(x)) continue;
             const int j = blk[x];
             // dksum_j[d] = sum_s dz_j[s] q_j[s][d] as one MFMA per feature tile: every row of the A operand is dz_j (k-slots of the
             // first tile of the pair, hi + lo bf16), the B operand the transposed Q_j tile; all rows of the result are equal
