@@ -6,7 +6,7 @@
 #include "blockmix.hpp"
 #include "split.hpp"
 #include "split16.hpp"
-#include "mixh.hpp"
+#include "mixh2.hpp"
 
 namespace mhla {
 namespace capi {
@@ -92,6 +92,15 @@ inline int sp_mixr_dw(const float* W, int ldw, const void* dg, const void* kv, v
 
 // h16 summaries: the mixing on the fp16 payload (mixh.hpp k_sp_mixh).  Slices of 128 elements (the last one of a row may be half), the
 // normaliser's rows as extra slices of 64 values when the block length is even; persistent workgroups, as many as fit a CU.
+#ifndef SP_MIXH2_TE
+#define SP_MIXH2_TE 64   // slice width of k_sp_mixh2 in summary elements
+#endif
+#ifndef SP_MIXH2_IH
+#define SP_MIXH2_IH 2   // 193 .. 256 blocks: the output rows of k_sp_mixh2 in this many workgroups (each reads the whole slice)
+#endif
+#ifndef SP_MIXH2_RT
+#define SP_MIXH2_RT 1   // 16-row output tiles per wave of k_sp_mixh2 (1: twelve / sixteen waves, 2: six / eight)
+#endif
 template <int TRANS>
 inline int sp_mixh(const float* W, int ldw, const void* in, void* out, int M, long E, long es, int BH, hipStream_t st,
                    const float* zin, float* zout, int S, float eps) {
@@ -107,8 +116,25 @@ inline int sp_mixh(const float* W, int ldw, const void* in, void* out, int M, lo
     if (M <= 32) MIXH(2, 8);
     if (M <= 64) MIXH(4, 4);
     if (M <= 128) MIXH(8, 1);
-    if (M <= 192) MIXH(12, 1);   // (129 .. 256 blocks: 64-element slices, one workgroup per CU; dW by k_sp_dwr<.., h16>)
+    // 129 .. 256 blocks: 64-element slices, one workgroup per CU; dW by k_sp_dwr<.., h16>.  With eight or more slices per workgroup the
+    // re-cut kernel (mixh2.hpp: half the waves, two output tiles each, the rescaled weights kept per (b, h))
+#define MIXH2(NW, RT, IH) do { \
+        const long total = (long)BH * ((E + SP_MIXH2_TE - 1) / SP_MIXH2_TE); \
+        const bool wz = zin && sp_mixr_takes_wz<false>(M, S); \
+        const long zt = wz ? (long)BH * ((S + SP_MIXH2_TE / 2 - 1) / (SP_MIXH2_TE / 2)) : 0; \
+        const int wgs = (int)std::min<long>(total, 256); \
+        const int spw = (int)((total + wgs - 1) / wgs); \
+        if (SP_MIXH2_TE == 64 ? sp_mixh2_applies(M, E, BH) : spw >= SP_MIXH2_MIN_SLICES) { \
+            sp::MixrArgs a{W, ldw, in, out, M, E, es, total, spw, wz ? zin : nullptr, wz ? zout : nullptr, wz ? S : 0, eps, nullptr, nullptr, nullptr, zt, nullptr}; \
+            const int gw = (int)((total + a.spw - 1) / a.spw); \
+            return launch(sp::k_sp_mixh2<NW, RT, TRANS, SP_MIXH2_TE, IH>, dim3(gw, IH), dim3(64 * NW), sp::sp_mixh2_smem<NW, RT, SP_MIXH2_TE, IH>(), st, TRANS ? "k_sp_mixh2<1>" : "k_sp_mixh2<0>", a); \
+        } \
+    } while (0)
+    if (M <= 192) MIXH2(12 / SP_MIXH2_RT, SP_MIXH2_RT, 1);
+    if (M <= 192) MIXH(12, 1);
+    if (M <= 256) MIXH2(16 / SP_MIXH2_RT / SP_MIXH2_IH, SP_MIXH2_RT, SP_MIXH2_IH);
     if (M <= 256) MIXH(16, 1);
+#undef MIXH2
     return fail(MHLA_EINVAL, "sp_mixh: M=%d out of range", M);
 #undef MIXH
 }

@@ -77,6 +77,18 @@ int launch(K kernel, dim3 grid, dim3 block, size_t smem, hipStream_t stream, con
 
 // debugging aid: per-workgroup phase timestamps of the tile kernels (mhla_debug_set_trace)
 inline std::atomic<unsigned long long*> g_trace{nullptr};
+
+// h16 summaries of 129 .. 256 blocks: the re-cut resident mixing kernel (mixh2.hpp k_sp_mixh2: the rescaled weights kept per (b, h)) serves
+// launches whose workgroups get at least this many 64-element slices each -- fewer do not pay for its rebuilds (capi_bm_typed.hpp sp_mixh;
+// capi.hip mhla_describe_dispatch)
+#ifndef SP_MIXH2_MIN_SLICES
+#define SP_MIXH2_MIN_SLICES 8
+#endif
+inline bool sp_mixh2_applies(int M, long E, long BH) {
+    if (M <= 128 || M > 256) return false;
+    const long total = BH * ((E + 63) / 64), wgs = std::min<long>(total, 256);
+    return wgs > 0 && (total + wgs - 1) / wgs >= SP_MIXH2_MIN_SLICES;
+}
 // mhla_set_option("fp32_summaries") / MHLA_FP32_SUMMARIES=1 (read once): the resident-mixing pipeline keeps its summaries as fp32 instead of 24-bit floats
 inline std::atomic<int> g_no_p24{[] { const char* e = getenv("MHLA_FP32_SUMMARIES"); return (e && e[0] == '1') ? 1 : 0; }()};
 

@@ -384,7 +384,8 @@ def test_describe_dispatch_names_the_path_of_every_baseline_config():
     assert mhla_amd.describe_dispatch(8, 16, 64, 64, 64, f32)["summaries"] == "fp32 words"
     assert mhla_amd.describe_dispatch(8, 16, 16, 256, 64, bf)["summaries"].startswith("h16")   # C2 variant 16 x 256
     c2b = mhla_amd.describe_dispatch(8, 16, 256, 16, 64, bf)                                    # C2 variant 256 x 16: more than 128 blocks
-    assert c2b["summaries"].startswith("h16") and c2b["bwd"][1:3] == ["k_sp_mixh<1>", "k_sp_dwr<4,h16>"]
+    assert c2b["summaries"].startswith("h16") and c2b["bwd"][1:3] == ["k_sp_mixh2<1>", "k_sp_dwr<4,h16>"]   # 32 slices per workgroup: the re-cut mixing kernel
+    assert mhla_amd.describe_dispatch(1, 6, 256, 256, 64, bf)["bwd"][1] == "k_sp_mixh<1>"                 # ... two slices per workgroup: not worth its rebuilds
     assert mhla_amd.describe_dispatch(8, 16, 320, 16, 64, bf)["summaries"] == "fp32 words"     # more than 256 blocks: the tiled mixing
     assert mhla_amd.describe_dispatch(8, 16, 64, 8, 64, bf)["summaries"].startswith("p24")     # blocks of fewer than 16 tokens
     assert mhla_amd.describe_dispatch(8, 16, 2, 64, 64, bf)["summaries"].startswith("p24")     # fewer than 4 blocks
