@@ -397,7 +397,11 @@ __global__ __launch_bounds__(64 * TT * TT) void k_sp_dwr(const DwrArgs a) {
     const long per = ((a.E / DWR_SE + a.nsplit - 1) / a.nsplit) * DWR_SE;
     const long ebeg = (long)split * per, eend = min(a.E, ebeg + per);
     const int nst = eend > ebeg ? (int)((eend - ebeg) / DWR_SE) : 0;
-    const int nst2 = (split == 0 && a.x2) ? (a.S2 + 15) / 16 : 0;
+    // the fp32 stages of (x2, y2) are dealt over the E-slices' workgroups like the payload stages (all in slice 0 they were a chain of S2 / 16
+    // load -> LDS -> barrier -> product round trips on ONE workgroup per (b, h): 16 of them at 256 tokens per block, 101 us of a 385 us step
+    // at the DiT-S/2 4096^2 shape)
+    const int tot2 = a.x2 ? (a.S2 + 15) / 16 : 0, per2 = (tot2 + a.nsplit - 1) / a.nsplit;
+    const int st2b = min(tot2, split * per2), st2e = min(tot2, st2b + per2);
 
     // the wave's DMA units: unit u -> matrix u / (R / 8), rows 8 (u % (R / 8)) ..; lane -> row + lane / 8, LDS position lane % 8.
     // (units past the last wrap around: a duplicate copy of identical bytes keeps the instruction count per stage the same for every wave)
@@ -468,17 +472,26 @@ __global__ __launch_bounds__(64 * TT * TT) void k_sp_dwr(const DwrArgs a) {
             }
     }
     // fp32 stages: 16 values of (x2, y2) each; thread -> (row, 4 values)
-    for (int st = 0; st < nst2; ++st) {
+    const bool vec2 = (a.S2 & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.x2) | reinterpret_cast<uintptr_t>(a.y2)) & 15) == 0;   // (uniform)
+    for (int st = st2b; st < st2e; ++st) {
         __syncthreads();
         const int s0 = st * 16;
         for (int v = tid; v < R * 4; v += 64 * NW) {
             const int row = v >> 2, q4 = (v & 3) * 4, rr = min(row, M - 1);
             float xv[4], yv[4];
+            if (vec2) {   // (S2 % 4 == 0: the four values are one aligned piece, inside the row or wholly past it)
+                const long o = ((long)bh * M + rr) * a.S2 + min(s0 + q4, a.S2 - 4);
+                const f32x4 xq = gld<f32x4>(a.x2 + o), yq = gld<f32x4>(a.y2 + o);
+                const bool in = s0 + q4 < a.S2;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int s = s0 + q4 + i;
-                xv[i] = s < a.S2 ? gld<float>(a.x2 + ((long)bh * M + rr) * a.S2 + s) : 0.f;
-                yv[i] = s < a.S2 ? gld<float>(a.y2 + ((long)bh * M + rr) * a.S2 + s) : 0.f;
+                for (int i = 0; i < 4; ++i) { xv[i] = in ? xq[i] : 0.f; yv[i] = in ? yq[i] : 0.f; }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int s = s0 + q4 + i;
+                    xv[i] = s < a.S2 ? gld<float>(a.x2 + ((long)bh * M + rr) * a.S2 + s) : 0.f;
+                    yv[i] = s < a.S2 ? gld<float>(a.y2 + ((long)bh * M + rr) * a.S2 + s) : 0.f;
+                }
             }
             unsigned xh[2], xl[2], yh[2], yl[2];
 #pragma unroll
