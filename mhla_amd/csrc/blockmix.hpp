@@ -381,6 +381,7 @@ struct OutArgs {
     int skip_out;
     const float *pro_rq, *pro_wq;   // split.hpp PRO: the q prologue on load (StateArgs)
     long pro_n;
+    int nbh;   // split.hpp k_sp_out<.., FLAT>: B * H (the launch's grid no longer says)
 };
 
 template <int DT>

@@ -260,6 +260,43 @@ __device__ __forceinline__ void stage_mat_split(u16* __restrict__ Gh, u16* __res
     }
 }
 
+// stage_mat_split in two halves for 24-bit summaries staged in ONE batch (D = 128 by 512 threads: four passes): the loads are requested,
+// the workgroup multiplies a round of token tiles, then the pieces are committed (k_sp_out<.., FLAT>)
+template <int DT, int NT>
+struct MatStage {
+    static constexpr int PASSES = (Geo<DT>::KST * 32 + NT / Geo<DT>::CGS - 1) / (NT / Geo<DT>::CGS);
+    uint4 x16[PASSES];
+    uint2 xl[PASSES];
+};
+template <int DT, int NT>
+__device__ __forceinline__ void stage_mat_issue(MatStage<DT, NT>& g, const float* __restrict__ base, long elem_off, int D, int tid) {
+    constexpr int CGS = Geo<DT>::CGS, RPP = NT / CGS;
+    const int r0 = tid / CGS, cg = (tid % CGS) * 8;
+    const char* rowp = reinterpret_cast<const char*>(base + elem_off);
+#pragma unroll
+    for (int u = 0; u < MatStage<DT, NT>::PASSES; ++u) {   // (unconditional, from clamped addresses: rows / columns past D are zeroed at the commit)
+        const int r = min(r0 + RPP * u, D - 1), c = min(cg, D - 8), e = r * D + c;
+        g.x16[u] = gld<uint4>(rowp + 2 * e);
+        g.xl[u] = gld<uint2>(rowp + 2 * D * D + e);
+    }
+}
+template <int DT, int NT>
+__device__ __forceinline__ void stage_mat_commit(u16* __restrict__ Gh, u16* __restrict__ Gl, const MatStage<DT, NT>& g, int D, int tid) {
+    constexpr int LD = mat_ld<DT>(), CGS = Geo<DT>::CGS, RPP = NT / CGS, KP = Geo<DT>::KST * 32;
+    const int r0 = tid / CGS, cg = (tid % CGS) * 8;
+#pragma unroll
+    for (int u = 0; u < MatStage<DT, NT>::PASSES; ++u) {
+        const int r = r0 + RPP * u, off = mat_row<mat_new<DT>()>(r) * LD + cg;
+        const bool in = r < D && cg < D;
+        const uint4 hi = in ? g.x16[u] : make_uint4(0, 0, 0, 0);
+        const uint2 lo = in ? g.xl[u] : make_uint2(0, 0);
+        if (r < KP && cg < KP) {
+            *reinterpret_cast<uint4*>(Gh + off) = hi;
+            *reinterpret_cast<uint4*>(Gl + off) = p24_lo8(hi, lo);
+        }
+    }
+}
+
 template <int DT>
 __host__ __device__ constexpr int sp_state_smem() {
     // the column-sum partials [RPP][DW] of the epilogue reuse the tiles
@@ -1593,7 +1630,13 @@ template <typename V>
 __device__ __forceinline__ bool view16(const V& w) { return (reinterpret_cast<uintptr_t>(w.ptr) & 15) == 0 && ((w.sb | w.sn | w.sh) & 7) == 0; }
 
 constexpr int SP_OUT_T = 512;   // 8 waves share the staged G_i: twice the loads in flight per LDS byte
-template <typename T, int DT, typename TO = T, bool EPI = false, bool S16 = Sum16<T>::value, int P24 = 0, bool PRO = false>   // PRO: the q prologue on load (OutArgs::pro_*)
+// FLAT (24-bit summaries, 16-bit tensors): the launch is one persistent workgroup per CU and the token tiles of ALL blocks are one flat list
+// cut into gridDim.x equal ranges; a workgroup walks its range in rounds of eight consecutive tiles (one per wave) with the summaries of
+// the (at most two) blocks a round touches in two LDS buffers, the next block's pieces requested a round ahead.  A block per workgroup
+// quantises twice at the Wan shape -- 14 tiles on 8 waves are two rounds (87.5 %), 1 800 workgroups on 256 CUs are eight waves of
+// workgroups for 7.03 (88 %) -- 77 % together; the flat list leaves the last round of a range (98.4 tiles in 13 rounds: 94.6 %).
+// OutArgs::nbh = B H; needs at least 8 tiles per block (a round then spans at most two blocks, the next round at most one more).
+template <typename T, int DT, typename TO = T, bool EPI = false, bool S16 = Sum16<T>::value, int P24 = 0, bool PRO = false, bool FLAT = false>   // PRO: the q prologue on load (OutArgs::pro_*)
 #ifndef SP_OUT_EPI_WAVES
 #define SP_OUT_EPI_WAVES 2   // the fused-epilogue variant takes 142 VGPRs: one workgroup per CU without spills (157 us at C4) beats two with 28 spilled registers (163 us)
 #endif
@@ -1601,11 +1644,14 @@ __global__ __launch_bounds__(SP_OUT_T, EPI ? SP_OUT_EPI_WAVES : 2) void k_sp_out
     constexpr int LD = mat_ld<DT>(), KST = Geo<DT>::KST, KP = KST * 32, TILE = KP * LD;
     constexpr bool LO = !std::is_same<T, bf16_t>::value || PRO;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    u16* Gh = reinterpret_cast<u16*>(smem_raw);   // [d1][d2], rows >= D and columns >= D zero
+    static_assert(!FLAT || (P24 == 1 && sizeof(T) == 2 && !S16), "the flat tile list serves 16-bit tensors with 24-bit summaries");
+    u16* Gh = reinterpret_cast<u16*>(smem_raw);   // [d1][d2], rows >= D and columns >= D zero   (FLAT: two (hi, lo) pairs, block parity)
     u16* Gl = Gh + TILE;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nl = lane & 15, kg = lane >> 4;
-    const int blk = blockIdx.x, bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H, S = a.S, D = a.D;
-    const long p0 = (long)blk * S;
+    const int S = a.S, D = a.D;
+    // the block in hand (FLAT: of the wave's tile of this round)
+    int blk = blockIdx.x, bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
+    long p0 = (long)blk * S;
     const T* qb = (const T*)a.q.ptr + b * a.q.sb + h * a.q.sh;
     TO* ob = (TO*)a.o.ptr + b * a.o.sb + h * a.o.sh;
     // The lane's token row of a 16-token tile as loaded: 8 q features per reduction step, 1 / n, (PRO) the token's rstd.  The first tile's
@@ -1621,29 +1667,31 @@ __global__ __launch_bounds__(SP_OUT_T, EPI ? SP_OUT_EPI_WAVES : 2) void k_sp_out
         long row;
     };
     QRows cur, nxt;
-    const float* ninvb = a.ninv + ((long)bh * a.M + blk) * S;
-    auto fetch = [&](int tt, QRows& R) __attribute__((always_inline)) {
+    // FLAT: tile g of the flat list = tile g % TPI of block g / TPI (blocks in the order of the summaries: (b, h) major)
+    const int TPI = (S + 15) / 16;
+    auto fetch = [&](int tt, QRows& R) __attribute__((always_inline)) {   // (FLAT: tt is the tile's place in the flat list)
+        int fb = b, fh = h, fbh = bh, fblk = blk;
+        if constexpr (FLAT) {
+            const int item = tt / TPI;
+            tt -= item * TPI;
+            fbh = item / a.M; fblk = item - fbh * a.M; fb = fbh / a.H; fh = fbh - fb * a.H;
+        }
         const int sv = min(tt * 16 + nl, S - 1);
-        R.row = tok_row(a.idx, p0 + sv);
-        const T* qrow = qb + R.row * a.q.sn;
+        R.row = tok_row(a.idx, (long)fblk * S + sv);
+        const T* qrow = (const T*)a.q.ptr + fb * a.q.sb + fh * a.q.sh + R.row * a.q.sn;
 #pragma unroll
         for (int ks = 0; ks < KST; ++ks) {
             const int c = ks * 32 + kg * 8 < D ? ks * 32 + kg * 8 : 0;
             R.x[ks][0] = *reinterpret_cast<const typename Raw4<T>::type*>(qrow + c);
             R.x[ks][1] = *reinterpret_cast<const typename Raw4<T>::type*>(qrow + c + 4);
         }
-        R.ninv = gld<float>(a.normalize ? ninvb + sv : a.W);
+        R.ninv = gld<float>(a.normalize ? a.ninv + ((long)fbh * a.M + fblk) * S + sv : a.W);
         R.rq = 1.f;
-        if constexpr (PRO) R.rq = gld<float>(a.pro_rq ? a.pro_rq + b * a.pro_n + R.row : a.W);
+        if constexpr (PRO) R.rq = gld<float>(a.pro_rq ? a.pro_rq + fb * a.pro_n + R.row : a.W);
     };
-    fetch(wave, cur);
-    // (S16: G_i stored as bf16: no lo tile)
-    stage_mat_split<DT, S16, SP_OUT_T, P24>(Gh, Gl, a.g, ((long)bh * a.M + blk) * a.es, D, tid);
-    __syncthreads();
-    for (int tt = wave; tt * 16 < S; tt += SP_OUT_T / 64) {
-        if constexpr (DBL) fetch(tt + SP_OUT_T / 64, nxt);
-        else if (tt != wave) fetch(tt, cur);   // (uniform)
-        const int s = tt * 16 + nl, sv = min(s, S - 1);
+    // the products, epilogue and stores of one tile of the block in hand, from `cur`; `live`: the tile exists (every lane runs this: shuffles)
+    auto tile = [&](int tt, bool live) __attribute__((always_inline)) {
+        const int s = live ? tt * 16 + nl : S, sv = min(s, S - 1);
         const long row = cur.row;
         bf16x8 qh[KST], ql[KST];
 #pragma unroll
@@ -1833,7 +1881,52 @@ __global__ __launch_bounds__(SP_OUT_T, EPI ? SP_OUT_EPI_WAVES : 2) void k_sp_out
                 }
             }
         }
-        if constexpr (DBL) cur = nxt;
+    };
+    if constexpr (!FLAT) {
+        fetch(wave, cur);
+        // (S16: G_i stored as bf16: no lo tile)
+        stage_mat_split<DT, S16, SP_OUT_T, P24>(Gh, Gl, a.g, ((long)bh * a.M + blk) * a.es, D, tid);
+        __syncthreads();
+        for (int tt = wave; tt * 16 < S; tt += SP_OUT_T / 64) {
+            if constexpr (DBL) fetch(tt + SP_OUT_T / 64, nxt);
+            else if (tt != wave) fetch(tt, cur);   // (uniform)
+            tile(tt, true);
+            if constexpr (DBL) cur = nxt;
+        }
+    } else {
+        constexpr int NWV = SP_OUT_T / 64;
+        u16* const G0 = Gh;
+        const long total = (long)a.nbh * a.M * TPI;
+        const int g0 = (int)(total * blockIdx.x / gridDim.x), g1 = (int)(total * (blockIdx.x + 1) / gridDim.x);
+        if (g1 <= g0) return;
+        const int nrounds = (g1 - g0 + NWV - 1) / NWV;
+        MatStage<DT, SP_OUT_T> stg;
+        int staged = g0 / TPI;   // the last block whose summary is in LDS (or on its way)
+        fetch(min(g0 + wave, g1 - 1), cur);
+        stage_mat_issue<DT, SP_OUT_T>(stg, a.g, (long)staged * a.es, D, tid);
+        stage_mat_commit<DT, SP_OUT_T>(G0 + (staged & 1) * 2 * TILE, G0 + (staged & 1) * 2 * TILE + TILE, stg, D, tid);
+        __syncthreads();
+        for (int r = 0; r < nrounds; ++r) {
+            const int g = g0 + r * NWV + wave, gc = min(g, g1 - 1), item = gc / TPI;
+            // the block a later round needs first: requested now, committed behind this round's products (uniform)
+            const bool ahead = r + 1 < nrounds && min(g0 + (r + 1) * NWV + NWV - 1, g1 - 1) / TPI > staged;
+            if (ahead) stage_mat_issue<DT, SP_OUT_T>(stg, a.g, (long)(staged + 1) * a.es, D, tid);
+            fetch(min(g + NWV, g1 - 1), nxt);
+            bh = item / a.M; blk = item - bh * a.M; b = bh / a.H; h = bh - b * a.H;
+            p0 = (long)blk * S;
+            qb = (const T*)a.q.ptr + b * a.q.sb + h * a.q.sh;
+            ob = (TO*)a.o.ptr + b * a.o.sb + h * a.o.sh;
+            Gh = G0 + (item & 1) * 2 * TILE;
+            Gl = Gh + TILE;
+            tile(gc - item * TPI, g < g1);
+            cur = nxt;
+            if (ahead) {   // (the buffer it goes to held the block before the previous one: this round may still have read it)
+                __syncthreads();
+                ++staged;
+                stage_mat_commit<DT, SP_OUT_T>(G0 + (staged & 1) * 2 * TILE, G0 + (staged & 1) * 2 * TILE + TILE, stg, D, tid);
+                __syncthreads();
+            }
+        }
     }
 }
 
