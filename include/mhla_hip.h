@@ -106,8 +106,10 @@ const char* mhla_last_error(void);
  * synchronisation, after a fused launch reported an expired hand-over (see mhla_blockmix_bwd_status).  "debug_drop_signal" (0 / 1):
  * testing aid for that bounded wait.  "fp32_summaries" (0 / 1): the block-mixing operator's default arithmetic keeps its block
  * summaries as fp32 words in the workspace instead of 24-bit floats (a measurement aid: same 16-significand-bit operands either
- * way; set it between calls, not between a forward and the backward that reuses its workspace).  Initial values:
- * MHLA_BWD_TWO_LAUNCHES=1 / MHLA_DEBUG_DROP_SIGNAL=1 / MHLA_FP32_SUMMARIES=1 in the environment when the library is loaded.
+ * way; set it between calls, not between a forward and the backward that reuses its workspace).  "recut_kernels" (1 / 0): 0 runs the
+ * kernels that two re-cut ones replaced -- the twelve / sixteen-wave payload mixing at 129 .. 256 blocks, the block-per-workgroup Wan
+ * inference output kernel -- with bit-identical results (A/B timing, equality tests).  Initial values:
+ * MHLA_BWD_TWO_LAUNCHES=1 / MHLA_DEBUG_DROP_SIGNAL=1 / MHLA_FP32_SUMMARIES=1 / MHLA_RECUT=0 in the environment when the library is loaded.
  * Returns the previous value, MHLA_EINVAL for an unknown name. */
 int mhla_set_option(const char* name, int value);
 

@@ -237,6 +237,7 @@ int mhla_set_option(const char* name, int value) {
     if (name && !strcmp(name, "bwd_two_launches")) return g_two_launches.exchange(value != 0);
     if (name && !strcmp(name, "debug_drop_signal")) return g_drop_signal.exchange(value != 0);
     if (name && !strcmp(name, "fp32_summaries")) return g_no_p24.exchange(value != 0);
+    if (name && !strcmp(name, "recut_kernels")) return g_recut.exchange(value != 0);
     return fail(MHLA_EINVAL, "mhla_set_option: unknown option '%s'", name ? name : "(null)");
 }
 

@@ -36,11 +36,10 @@ int wan_pro_fwd(const mhla_view& q, const mhla_view& k, const mhla_view& v, cons
     o.pro_rq = rstd_q; o.pro_wq = wq; o.pro_n = (long)M * S;
     const dim3 g(M, B * H), blk(sp::SP_OUT_T);
     // the flat tile list (split.hpp k_sp_out<.., FLAT>): one persistent workgroup per CU, when the blocks are long enough for its rounds and
-    // there are enough tiles to cut (MHLA_WAN_FLAT=0 in the environment: the block-per-workgroup launch, for A/B timing)
+    // there are enough tiles to cut (mhla_set_option("recut_kernels", 0) / MHLA_WAN_FLAT=0: the block-per-workgroup launch, for A/B)
     o.nbh = B * H;
-    static const bool flat_on = [] { const char* e = getenv("MHLA_WAN_FLAT"); return !(e && e[0] == '0'); }();
     const int tpi = (S + 15) / 16;
-    if (flat_on && tpi >= 8 && (long)B * H * M * tpi >= 256L * 32) {
+    if (g_recut.load() && tpi >= 8 && (long)B * H * M * tpi >= 256L * 32) {
         const dim3 gf(256);
         if (out_dtype == MHLA_BF16)     RC(launch(sp::k_sp_out<ET, DT, bf16_t, true, false, 1, true, true>, gf, blk, 2 * sp::sp_out_smem<DT>(), st, "k_sp_out<norm,pro,flat>", o));
         else if (out_dtype == MHLA_F16) RC(launch(sp::k_sp_out<ET, DT, f16_t, true, false, 1, true, true>, gf, blk, 2 * sp::sp_out_smem<DT>(), st, "k_sp_out<norm,pro,flat>", o));

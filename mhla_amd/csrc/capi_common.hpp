@@ -84,8 +84,11 @@ inline std::atomic<unsigned long long*> g_trace{nullptr};
 #ifndef SP_MIXH2_MIN_SLICES
 #define SP_MIXH2_MIN_SLICES 8
 #endif
+// (mhla_set_option("recut_kernels", 0): the kernels they replaced -- k_sp_mixh at twelve / sixteen waves, the block-per-workgroup Wan output
+// kernel -- for A/B timing and for the bit-equality tests; MHLA_WAN_FLAT=0 / MHLA_RECUT=0 in the environment set the start value)
+inline std::atomic<int> g_recut{[] { const char* e = getenv("MHLA_RECUT"); const char* f = getenv("MHLA_WAN_FLAT"); return ((e && e[0] == '0') || (f && f[0] == '0')) ? 0 : 1; }()};
 inline bool sp_mixh2_applies(int M, long E, long BH) {
-    if (M <= 128 || M > 256) return false;
+    if (M <= 128 || M > 256 || !g_recut.load()) return false;
     const long total = BH * ((E + 63) / 64), wgs = std::min<long>(total, 256);
     return wgs > 0 && (total + wgs - 1) / wgs >= SP_MIXH2_MIN_SLICES;
 }

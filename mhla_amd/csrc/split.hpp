@@ -1905,6 +1905,11 @@ __global__ __launch_bounds__(SP_OUT_T, EPI ? SP_OUT_EPI_WAVES : 2) void k_sp_out
         fetch(min(g0 + wave, g1 - 1), cur);
         stage_mat_issue<DT, SP_OUT_T>(stg, a.g, (long)staged * a.es, D, tid);
         stage_mat_commit<DT, SP_OUT_T>(G0 + (staged & 1) * 2 * TILE, G0 + (staged & 1) * 2 * TILE + TILE, stg, D, tid);
+        if (min(g0 + NWV - 1, g1 - 1) / TPI > staged) {   // (uniform) the first round already ends in the next block
+            ++staged;
+            stage_mat_issue<DT, SP_OUT_T>(stg, a.g, (long)staged * a.es, D, tid);
+            stage_mat_commit<DT, SP_OUT_T>(G0 + (staged & 1) * 2 * TILE, G0 + (staged & 1) * 2 * TILE + TILE, stg, D, tid);
+        }
         __syncthreads();
         for (int r = 0; r < nrounds; ++r) {
             const int g = g0 + r * NWV + wave, gc = min(g, g1 - 1), item = gc / TPI;

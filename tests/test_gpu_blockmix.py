@@ -862,3 +862,36 @@ def test_handover_wait_is_bounded_and_reported(monkeypatch):
     finally:
         lib.mhla_set_option(b"debug_drop_signal", 0)
         lib.mhla_set_option(b"bwd_two_launches", 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M", [256, 192, 160])
+def test_recut_mixing_kernel_is_bit_identical_to_the_one_it_replaced(M):
+    """129 .. 256 blocks with enough slices per workgroup run k_sp_mixh2 (mixh2.hpp: the rescaled weight pairs kept per (b, h), output rows of
+    256 blocks in two workgroups); mhla_set_option("recut_kernels", 0) runs k_sp_mixh instead.  Same expressions in the same order: every
+    output and gradient must agree bit for bit, and the dispatcher must say which one ran."""
+    import mhla_amd
+    B, H, D, S = 8, 16, 64, 16
+    N = M * S
+    g = torch.Generator().manual_seed(M)
+    q, k, v = (torch.randn(B, N, H, D, generator=g).bfloat16().cuda() for _ in range(3))
+    W = torch.rand(M, M, generator=g).cuda()
+    do = torch.randn(B, N, H, D, generator=g).bfloat16().cuda()
+
+    def run():
+        ts = [t.clone().requires_grad_(True) for t in (q, k, v, W)]
+        out = mhla_amd.mhla_blockmix(ts[0].abs(), ts[1].abs(), ts[2], ts[3])
+        out.backward(do)
+        torch.cuda.synchronize()
+        return [out.detach()] + [t.grad for t in ts]
+
+    assert mhla_amd.describe_dispatch(B, H, M, S, D, torch.bfloat16)["fwd"][1] == "k_sp_mixh2<0>"
+    new = run()
+    prev = mhla_amd.set_option("recut_kernels", 0)
+    try:
+        assert mhla_amd.describe_dispatch(B, H, M, S, D, torch.bfloat16)["fwd"][1] == "k_sp_mixh<0>"
+        old = run()
+    finally:
+        mhla_amd.set_option("recut_kernels", prev)
+    for name, a, b in zip(("out", "dq", "dk", "dv", "dW"), new, old):
+        assert torch.equal(a, b), f"{name} differs between k_sp_mixh2 and k_sp_mixh at M={M}"

@@ -134,6 +134,50 @@ def test_wan_module_fused_inference_path(tag):
     check("fused vs unfused", y, y2.detach().cpu(), 1e-4)
 
 
+@pytest.mark.parametrize("dtype,out_rows_partial", [(torch.bfloat16, False), (torch.float16, True)])
+@pytest.mark.parametrize("M,S,gate,rope,gather", [(50, 210, True, True, False), (80, 130, False, False, True), (44, 251, True, True, True)])
+def test_wan_flat_tile_list_matches_the_block_per_workgroup_kernel(M, S, gate, rope, gather, dtype, out_rows_partial):
+    """The Wan inference output kernel as one persistent workgroup per CU over a flat list of token tiles (split.hpp k_sp_out<.., FLAT>:
+    blocks of at least 128 tokens, enough tiles to cut) against the block-per-workgroup launch it replaced
+    (mhla_set_option("recut_kernels", 0)) and against the materialising composition: per tile the same numbers in the same order, so all
+    three agree to the last bit.  Block lengths that are not multiples of 16 (210, 130, 251: partial last tiles), ranges that start and end
+    inside blocks, a gather map."""
+    import mhla_amd
+    from mhla_amd import ops
+    B, H, D = 1, 12, 128
+    N, C = M * S, H * D
+    g = torch.Generator().manual_seed(M * 1000 + S)
+    q, k, v = (torch.randn(B, N, C, generator=g).to(dtype).to(DEV) for _ in range(3))
+    wq, wk = (torch.rand(C, generator=g) + 0.5).to(DEV), (torch.rand(C, generator=g) + 0.5).to(DEV)
+    W = torch.rand(M, M, generator=g).to(DEV)
+    nw = (torch.rand(D, generator=g) + 0.5).to(DEV)
+    gt = torch.randn(B, N, H, D, generator=g).to(dtype).to(DEV) if gate else None
+    cos = sin = None
+    if rope:
+        ang = torch.rand(N, D // 2, generator=g) * 6.28
+        cos, sin = torch.cos(ang).to(DEV), torch.sin(ang).to(DEV)
+    idx = torch.randperm(N, generator=torch.Generator().manual_seed(3)).int().to(DEV) if gather else None
+    r4 = lambda t: t.reshape(B, N, H, D)
+    assert ops.wan_pro_supported(r4(q), M)
+    assert B * H * M * ((S + 15) // 16) >= 256 * 32 and S >= 113, "the shape must take the flat tile list"
+    run = lambda: mhla_amd.mhla_blockmix_wan_pro(r4(q), r4(k), r4(v), wq, wk, 1e-6, W, cos, sin, nw, 1e-6, gt, eps=1e-6, normalize=True,
+                                                 block_index=idx, qk_norm=True)
+    poison()
+    y = run()
+    prev = mhla_amd.set_option("recut_kernels", 0)
+    try:
+        poison()
+        y0 = run()
+    finally:
+        mhla_amd.set_option("recut_kernels", prev)
+    assert torch.equal(y, y0), f"flat tile list differs from the block-per-workgroup kernel: max |diff| {(y.float() - y0.float()).abs().max().item():.3e}"
+    qf = r4(mhla_amd.qk_prologue(q, wq, 1e-6, 1e-6))
+    kf = r4(mhla_amd.qk_prologue(k, wk, 1e-6, 1e-6))
+    y2 = mhla_amd.mhla_blockmix_wan(qf, kf, r4(v).float(), W, cos, sin, nw, 1e-6, gt, dtype, eps=1e-6, normalize=True, block_index=idx)
+    assert torch.equal(y, y2), f"flat tile list differs from the materialised prologue: max |diff| {(y.float() - y2.float()).abs().max().item():.3e}"
+    assert torch.isfinite(y.float()).all()
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M,S,gate,rope,norm,normalize,gather", [(6, 40, True, True, True, True, True), (40, 21, False, True, True, False, False),
                                                                  (150, 6, True, False, True, True, True), (9, 33, True, True, False, True, False)])
