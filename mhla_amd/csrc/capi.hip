@@ -585,7 +585,7 @@ int mhla_describe_dispatch(int B, int H, int M, int S, int D, int dtype, int spl
         std::string mix0, mix1, dw;
         const std::string dwr = std::string("k_sp_dwr<") + (M <= 128 ? "2" : M <= 192 ? "3" : "4") + (fmt == SF_H16 ? ",h16>" : ">");   // whole-matrix dW kernel (incl. the <dn, z> term)
         if (fmt == SF_H16) {
-            const bool m2 = sp_mixh2_applies(M, E, (long)B * H);
+            const bool m2 = sp_mixh2_applies(M, E, (long)B * H, S);
             mix0 = m2 ? "k_sp_mixh2<0>" : "k_sp_mixh<0>"; mix1 = M <= 128 ? "k_sp_mixh<1,dw>" : (m2 ? "k_sp_mixh2<1>" : "k_sp_mixh<1>"); dw = M <= 128 ? "" : dwr;
         }
         else if (s16 && M > 192 && mixr) { mix0 = "k_sp_mixr_dma<0>"; mix1 = "k_sp_mixr_dma<1>"; dw = dwr; }

@@ -124,7 +124,7 @@ inline int sp_mixh(const float* W, int ldw, const void* in, void* out, int M, lo
         const long zt = wz ? (long)BH * ((S + SP_MIXH2_TE / 2 - 1) / (SP_MIXH2_TE / 2)) : 0; \
         const int wgs = (int)std::min<long>(total, 256); \
         const int spw = (int)((total + wgs - 1) / wgs); \
-        if (SP_MIXH2_TE == 64 ? sp_mixh2_applies(M, E, BH) : spw >= SP_MIXH2_MIN_SLICES) { \
+        if (SP_MIXH2_TE == 64 ? sp_mixh2_applies(M, E, BH, S) : spw >= SP_MIXH2_MIN_SLICES) { \
             sp::MixrArgs a{W, ldw, in, out, M, E, es, total, spw, wz ? zin : nullptr, wz ? zout : nullptr, wz ? S : 0, eps, nullptr, nullptr, nullptr, zt, nullptr}; \
             const int gw = (int)((total + a.spw - 1) / a.spw); \
             return launch(sp::k_sp_mixh2<NW, RT, TRANS, SP_MIXH2_TE, IH>, dim3(gw, IH), dim3(64 * NW), sp::sp_mixh2_smem<NW, RT, SP_MIXH2_TE, IH>(), st, TRANS ? "k_sp_mixh2<1>" : "k_sp_mixh2<0>", a); \

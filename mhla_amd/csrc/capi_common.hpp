@@ -87,8 +87,10 @@ inline std::atomic<unsigned long long*> g_trace{nullptr};
 // (mhla_set_option("recut_kernels", 0): the kernels they replaced -- k_sp_mixh at twelve / sixteen waves, the block-per-workgroup Wan output
 // kernel -- for A/B timing and for the bit-equality tests; MHLA_WAN_FLAT=0 / MHLA_RECUT=0 in the environment set the start value)
 inline std::atomic<int> g_recut{[] { const char* e = getenv("MHLA_RECUT"); const char* f = getenv("MHLA_WAN_FLAT"); return ((e && e[0] == '0') || (f && f[0] == '0')) ? 0 : 1; }()};
-inline bool sp_mixh2_applies(int M, long E, long BH) {
+inline bool sp_mixh2_applies(int M, long E, long BH, long S = 0) {
     if (M <= 128 || M > 256 || !g_recut.load()) return false;
+    // (its buffer descriptors address 32-bit byte offsets: the (b, h)'s summary rows -- E / 2 + 288 floats each -- and normaliser rows must fit)
+    if (BH * M * (E / 2 + 288) * 4 >= (1L << 31) || BH * M * S * 4 >= (1L << 31)) return false;
     const long total = BH * ((E + 63) / 64), wgs = std::min<long>(total, 256);
     return wgs > 0 && (total + wgs - 1) / wgs >= SP_MIXH2_MIN_SLICES;
 }

@@ -865,13 +865,23 @@ def test_handover_wait_is_bounded_and_reported(monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("M", [256, 192, 160])
-def test_recut_mixing_kernel_is_bit_identical_to_the_one_it_replaced(M):
+@pytest.mark.parametrize("M,S", [(160, 64), (256, 48), (130, 130)])
+def test_more_than_128_blocks_of_many_tokens_dw_stages(M, S):
+    """More than 128 blocks with blocks longer than 16 tokens: the whole-matrix dW kernel (k_sp_dwr<.., h16>) deals the fp32 stages of the
+    <dn, z> term over its E-slice workgroups (S / 16 of them; all on slice 0 they were one serial chain) -- against the oracle, with a
+    block length that is not a multiple of 4 among them (scalar loads)."""
+    run_case(1, 2, M, S, 64, torch.bfloat16, w="rand", seed=M + S)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,B,H,D", [(256, 8, 16, 64), (192, 8, 16, 64), (160, 8, 16, 64), (256, 5, 20, 64), (144, 4, 24, 72)])
+def test_recut_mixing_kernel_is_bit_identical_to_the_one_it_replaced(M, B, H, D):
     """129 .. 256 blocks with enough slices per workgroup run k_sp_mixh2 (mixh2.hpp: the rescaled weight pairs kept per (b, h), output rows of
     256 blocks in two workgroups); mhla_set_option("recut_kernels", 0) runs k_sp_mixh instead.  Same expressions in the same order: every
-    output and gradient must agree bit for bit, and the dispatcher must say which one ran."""
+    output and gradient must agree bit for bit, and the dispatcher must say which one ran.  (5 x 20 and 4 x 24 (b, h): 25 resp. 31 slices per
+    workgroup of 64 / 81 per (b, h) -- ranges that cross (b, h) boundaries, i.e. the mid-range rebuild with its flush.)"""
     import mhla_amd
-    B, H, D, S = 8, 16, 64, 16
+    S = 16
     N = M * S
     g = torch.Generator().manual_seed(M)
     q, k, v = (torch.randn(B, N, H, D, generator=g).bfloat16().cuda() for _ in range(3))
