@@ -223,6 +223,7 @@ __global__ __launch_bounds__(64 * NW, DW ? (NW + 3) / 4 : (NW <= 4 ? 4 : (NW + 3
         if (a.trace && tid == 0 && blockIdx.x < 8 && tk < 32) a.trace[(blockIdx.x * 32 + tk) * 8 + i] = __builtin_amdgcn_s_memtime();
 #else
         (void)i;
+        (void)tk;
 #endif
     };
     auto body = [&]<bool ZS>(std::bool_constant<ZS> zs, Stage& g, bool first, bool more, int bh, int es, int nbh, int nes) __attribute__((always_inline)) {

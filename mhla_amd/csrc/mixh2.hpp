@@ -5,11 +5,17 @@
 //   * the weights were rescaled into fp16 hi + lo pairs for EVERY slice -- ~70 VALU operations per reduction step and lane, eight steps,
 //     four waves per SIMD: 9 200 ticks per SIMD and slice, against 4 100 for the slice's MFMAs;
 //   * every wave read the whole staged slice for one 16-row output tile (16 x 32 KB of LDS reads per slice).
-// Here a workgroup has HALF the waves (six / eight: 256 registers each, nothing spills), a wave owns TWO 16-row output tiles (each
-// transpose read feeds four MFMAs instead of two), and the rescaled pairs are KEPT -- 16 NK registers per lane, rebuilt when the (b, h)
-// changes (the weights then come through the tiles again: the previous slice's stores are flushed first).  The rows' multipliers are
-// read where they are needed (the rebuild), not with every slice.  Results are bit-identical to k_sp_mixh's: the same expressions in the
-// same order.  Used when a workgroup has enough slices of one (b, h) to pay for the rebuilds (capi_bm_typed.hpp sp_mixh).
+// Here the rescaled pairs are KEPT -- rebuilt, with the weights streamed through the tiles one reduction step at a time (8 temporaries), only
+// when the (b, h) changes (the previous slice's stores are flushed first); the rows' multipliers are read where they are needed (the
+// rebuild), not with every slice; memory is addressed through buffer descriptors (uniform base and slice offset in SGPRs, one 32-bit
+// register per unit and lane); and the cut is chosen so that the pairs FIT: twelve waves x one 16-row output tile for 129 .. 192 blocks
+// (48 registers of pairs under a 168-register budget), and for 193 .. 256 blocks the output rows in TWO workgroups of eight waves that each
+// read the whole input slice (IH = 2: 64 registers of pairs under 256; the input rows are read twice, the second reader mostly from the
+// L2 / MALL).  Sixteen waves x one tile (128-register budget) and eight waves x two tiles (128 registers of pairs) both spill under hipcc
+// 7.2 -- and what it spills is the prefetched rows, i.e. the prefetch (DESIGN_APPENDIX.md, "Round 6: measured and not kept").
+// Results are bit-identical to k_sp_mixh's: the same expressions in the same order (tests/test_gpu_blockmix.py
+// test_recut_mixing_kernel_is_bit_identical_to_the_one_it_replaced).  Used when a workgroup has at least eight slices to pay for the
+// rebuilds (capi_common.hpp sp_mixh2_applies).
 #pragma once
 #include "mixh.hpp"
 
