@@ -1903,12 +1903,16 @@ __global__ __launch_bounds__(SP_OUT_T, EPI ? SP_OUT_EPI_WAVES : 2) void k_sp_out
         MatStage<DT, SP_OUT_T> stg;
         int staged = g0 / TPI;   // the last block whose summary is in LDS (or on its way)
         fetch(min(g0 + wave, g1 - 1), cur);
-        stage_mat_issue<DT, SP_OUT_T>(stg, a.g, (long)staged * a.es, D, tid);
-        stage_mat_commit<DT, SP_OUT_T>(G0 + (staged & 1) * 2 * TILE, G0 + (staged & 1) * 2 * TILE + TILE, stg, D, tid);
-        if (min(g0 + NWV - 1, g1 - 1) / TPI > staged) {   // (uniform) the first round already ends in the next block
-            ++staged;
+        {   // the first round's blocks: one, or -- when it already ends in the next block -- two, requested together (one round trip)
+            const bool two = min(g0 + NWV - 1, g1 - 1) / TPI > staged;   // (uniform)
+            MatStage<DT, SP_OUT_T> stg2;
             stage_mat_issue<DT, SP_OUT_T>(stg, a.g, (long)staged * a.es, D, tid);
+            stage_mat_issue<DT, SP_OUT_T>(stg2, a.g, (long)(staged + (two ? 1 : 0)) * a.es, D, tid);
             stage_mat_commit<DT, SP_OUT_T>(G0 + (staged & 1) * 2 * TILE, G0 + (staged & 1) * 2 * TILE + TILE, stg, D, tid);
+            if (two) {
+                ++staged;
+                stage_mat_commit<DT, SP_OUT_T>(G0 + (staged & 1) * 2 * TILE, G0 + (staged & 1) * 2 * TILE + TILE, stg2, D, tid);
+            }
         }
         __syncthreads();
         for (int r = 0; r < nrounds; ++r) {
