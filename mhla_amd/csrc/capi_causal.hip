@@ -100,7 +100,7 @@ template <int HL>
 int cs_state16(const mhla_view& x, const mhla_view& y, uint16_t* out, float mul, int B, int T, int H, int n, int K, int V, hipStream_t st) {
     fast::CsfStateArgs s{cv(x), cv(y), out, H, n, K, V, (long)T, mul};
     const int blocks = ((K + fast::ST2_KW - 1) / fast::ST2_KW) * ((V + fast::ST2_VW - 1) / fast::ST2_VW);
-    return launch(fast::k_csf_state2<HL>, dim3((n + fast::ST2_CPW - 1) / fast::ST2_CPW, B * H, blocks), dim3(NTHREADS),
+    return launch(fast::k_csf_state2<HL>, dim3((n + fast::ST2_CPW - 1) / fast::ST2_CPW, B * H, blocks), dim3(ST2_T),
                   fast::csf_state2_smem<HL>(), st, "k_csf_state", s);
 }
 

@@ -661,12 +661,20 @@ struct CsfStateArgs {
     float mul;
 };
 constexpr int ST2_KW = 128, ST2_VW = 256, ST2_LDX = ST2_KW + 8, ST2_LDY = ST2_VW + 8;
-template <int HL> __host__ __device__ constexpr int csf_state2_smem() { return (CS * ST2_LDX + CS * ST2_LDY + 4 * cs_mplanes(HL) * 16 * CLD) * 2; }
-constexpr int ST2_CPW = 4;
+#ifndef ST2_T
+#define ST2_T 512   // threads: eight waves with one 16-row strip of the summary each (four waves with two: 100 -> 92-94 us for the two launches at C5,
+                    // 177 -> 162 at K = 256, V = 512 -- twice the waves per CU at the same tiles; two chunks per workgroup instead of four: no gain)
+#endif
+#ifndef ST2_CPW_
+#define ST2_CPW_ 4
+#endif
+template <int HL> __host__ __device__ constexpr int csf_state2_smem() { return (CS * ST2_LDX + CS * ST2_LDY + (ST2_T / 64) * cs_mplanes(HL) * 16 * CLD) * 2; }
+constexpr int ST2_CPW = ST2_CPW_;
 
 template <int HL>
-__global__ __launch_bounds__(NTHREADS, 2) void k_csf_state2(const CsfStateArgs a) {
+__global__ __launch_bounds__(ST2_T, 2) void k_csf_state2(const CsfStateArgs a) {
     constexpr int P = cs_mplanes(HL);   // planes written
+    constexpr int XP = 4 * 256 / ST2_T, YP = 8 * 256 / ST2_T, XR = 64 / XP, YR = 64 / YP, RRS = 8 / (ST2_T / 64);   // staging passes, rows per pass, strips per wave
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u16* Xs = reinterpret_cast<u16*>(smem_raw);
     u16* Ys = Xs + CS * ST2_LDX;
@@ -682,18 +690,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_csf_state2(const CsfStateArgs a
     // X: 4 passes of 16 rows x 16 pieces; Y: 8 passes of 8 rows x 32 pieces (pieces past the block's width, rows past the chunk: zeros)
     const int xc = (tid & 15) * 8, yc = (tid & 31) * 8;
     const bool xok = xc < kw, yok = yc < vw;
-    uint4 xr[4], yr[8];
+    uint4 xr[XP], yr[YP];
     auto issue = [&](int ci, bool filler) {   // (no load behind a branch: rows past the sequence's end read the chunk's first row;
         const long p0 = (long)ci * CS;        //  the filler behind the last chunk reads that one row with every pass)
         const int rv = filler ? 0 : (int)min((long)CS, a.T - p0);
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int row = (tid >> 4) + 16 * p;
+        for (int p = 0; p < XP; ++p) {
+            const int row = (tid >> 4) + XR * p;
             xr[p] = gld_stream16(xb + (p0 + (row < rv ? row : 0)) * a.x.sn + (xok ? xc : 0));
         }
 #pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            const int row = (tid >> 5) + 8 * p;
+        for (int p = 0; p < YP; ++p) {
+            const int row = (tid >> 5) + YR * p;
             yr[p] = gld_stream16(yb + (p0 + (row < rv ? row : 0)) * a.y.sn + (yok ? yc : 0));
         }
     };
@@ -703,22 +711,22 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_csf_state2(const CsfStateArgs a
         u16* ob = a.out + bh * L.bhs + ci * L.cst;
         if (ci > c0) __syncthreads();   // the previous chunk's tiles are dead
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int row = (tid >> 4) + 16 * p;
+        for (int p = 0; p < XP; ++p) {
+            const int row = (tid >> 4) + XR * p;
             const bool ok = row < rv && xok;
             *reinterpret_cast<uint4*>(Xs + row * ST2_LDX + xc) = make_uint4(ok ? xr[p].x : 0u, ok ? xr[p].y : 0u, ok ? xr[p].z : 0u, ok ? xr[p].w : 0u);
         }
 #pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            const int row = (tid >> 5) + 8 * p;
+        for (int p = 0; p < YP; ++p) {
+            const int row = (tid >> 5) + YR * p;
             const bool ok = row < rv && yok;
             *reinterpret_cast<uint4*>(Ys + row * ST2_LDY + yc) = make_uint4(ok ? yr[p].x : 0u, ok ? yr[p].y : 0u, ok ? yr[p].z : 0u, ok ? yr[p].w : 0u);
         }
         __syncthreads();
         issue(min(ci + 1, c1 - 1), ci + 1 >= c1);
 #pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-            const int rt = wave * 2 + rr;               // 16 summary rows kk = k0 + 16 rt ..
+        for (int rr = 0; rr < RRS; ++rr) {
+            const int rt = wave * RRS + rr;             // 16 summary rows kk = k0 + 16 rt ..
             if (rt * 16 < kw) {
                 // the product is formed transposed (m = v, n = kk): a lane ends up with four consecutive v of one summary row
                 const bf16x8 xa0 = tr_read8(Xs, ST2_LDX, 0, rt * 16, lane), xa1 = tr_read8(Xs, ST2_LDX, 32, rt * 16, lane);
