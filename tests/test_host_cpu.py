@@ -386,6 +386,12 @@ def test_describe_dispatch_names_the_path_of_every_baseline_config():
     c2b = mhla_amd.describe_dispatch(8, 16, 256, 16, 64, bf)                                    # C2 variant 256 x 16: more than 128 blocks
     assert c2b["summaries"].startswith("h16") and c2b["bwd"][1:3] == ["k_sp_mixh2<1>", "k_sp_dwr<4,h16>"]   # 32 slices per workgroup: the re-cut mixing kernel
     assert mhla_amd.describe_dispatch(1, 6, 256, 256, 64, bf)["bwd"][1] == "k_sp_mixh<1>"                 # ... two slices per workgroup: not worth its rebuilds
+    prev = mhla_amd.set_option("recut_kernels", 0)                                               # the A/B switch of the re-cut kernels (mhla_hip.h)
+    try:
+        assert mhla_amd.describe_dispatch(8, 16, 256, 16, 64, bf)["bwd"][1] == "k_sp_mixh<1>"
+    finally:
+        assert mhla_amd.set_option("recut_kernels", prev) == 0
+    assert mhla_amd.describe_dispatch(8, 16, 256, 16, 64, bf)["fwd"][1] == "k_sp_mixh2<0>"
     assert mhla_amd.describe_dispatch(8, 16, 320, 16, 64, bf)["summaries"] == "fp32 words"     # more than 256 blocks: the tiled mixing
     assert mhla_amd.describe_dispatch(8, 16, 64, 8, 64, bf)["summaries"].startswith("p24")     # blocks of fewer than 16 tokens
     assert mhla_amd.describe_dispatch(8, 16, 2, 64, 64, bf)["summaries"].startswith("p24")     # fewer than 4 blocks
