@@ -268,14 +268,15 @@ struct MatStage {
     uint4 x16[PASSES];
     uint2 xl[PASSES];
 };
+// (real = false: the loads are issued all the same -- no branch around them -- but every lane reads the matrix's first piece)
 template <int DT, int NT>
-__device__ __forceinline__ void stage_mat_issue(MatStage<DT, NT>& g, const float* __restrict__ base, long elem_off, int D, int tid) {
+__device__ __forceinline__ void stage_mat_issue(MatStage<DT, NT>& g, const float* __restrict__ base, long elem_off, int D, int tid, bool real = true) {
     constexpr int CGS = Geo<DT>::CGS, RPP = NT / CGS;
     const int r0 = tid / CGS, cg = (tid % CGS) * 8;
     const char* rowp = reinterpret_cast<const char*>(base + elem_off);
 #pragma unroll
     for (int u = 0; u < MatStage<DT, NT>::PASSES; ++u) {   // (unconditional, from clamped addresses: rows / columns past D are zeroed at the commit)
-        const int r = min(r0 + RPP * u, D - 1), c = min(cg, D - 8), e = r * D + c;
+        const int r = min(r0 + RPP * u, D - 1), c = min(cg, D - 8), e = real ? r * D + c : 0;
         g.x16[u] = gld<uint4>(rowp + 2 * e);
         g.xl[u] = gld<uint2>(rowp + 2 * D * D + e);
     }
@@ -1669,7 +1670,20 @@ __global__ __launch_bounds__(SP_OUT_T, EPI ? SP_OUT_EPI_WAVES : 2) void k_sp_out
     QRows cur, nxt;
     // FLAT: tile g of the flat list = tile g % TPI of block g / TPI (blocks in the order of the summaries: (b, h) major)
     const int TPI = (S + 15) / 16;
-    auto fetch = [&](int tt, QRows& R) __attribute__((always_inline)) {   // (FLAT: tt is the tile's place in the flat list)
+    // the gather map's entry for the lane's row of a tile: looked up ONE FETCH AHEAD of the rows it names (unconditional: without a map the
+    // load reads the summaries' first word and is dropped) -- looked up inside the fetch it was a dependent round trip in front of every
+    // tile's loads, and behind `idx ? idx[p] : p` a branch with a load in it
+    auto look = [&](int tt) __attribute__((always_inline)) {
+        int fblk = blk;
+        if constexpr (FLAT) {
+            const int item = tt / TPI;
+            tt -= item * TPI;
+            fblk = item % a.M;
+        }
+        const long p = (long)fblk * S + min(tt * 16 + nl, S - 1);
+        return gld<int>(a.idx ? a.idx + p : reinterpret_cast<const int*>(a.g));
+    };
+    auto fetch = [&](int tt, QRows& R, int looked) __attribute__((always_inline)) {   // (FLAT: tt is the tile's place in the flat list)
         int fb = b, fh = h, fbh = bh, fblk = blk;
         if constexpr (FLAT) {
             const int item = tt / TPI;
@@ -1677,7 +1691,7 @@ __global__ __launch_bounds__(SP_OUT_T, EPI ? SP_OUT_EPI_WAVES : 2) void k_sp_out
             fbh = item / a.M; fblk = item - fbh * a.M; fb = fbh / a.H; fh = fbh - fb * a.H;
         }
         const int sv = min(tt * 16 + nl, S - 1);
-        R.row = tok_row(a.idx, (long)fblk * S + sv);
+        R.row = a.idx ? (long)looked : (long)fblk * S + sv;
         const T* qrow = (const T*)a.q.ptr + fb * a.q.sb + fh * a.q.sh + R.row * a.q.sn;
 #pragma unroll
         for (int ks = 0; ks < KST; ++ks) {
@@ -1689,6 +1703,34 @@ __global__ __launch_bounds__(SP_OUT_T, EPI ? SP_OUT_EPI_WAVES : 2) void k_sp_out
         R.rq = 1.f;
         if constexpr (PRO) R.rq = gld<float>(a.pro_rq ? a.pro_rq + fb * a.pro_n + R.row : a.W);
     };
+    // EARLY (the fused-epilogue variants: Wan): the prologue's channel weights and the rope angles of ALL reduction steps are requested
+        // first, unconditionally (a table the call does not have is replaced by the summaries, its values dropped).  Fetched where they are
+        // used -- behind `if (column < D)`, `if (a.pro_wq)`, `if (a.rcos)` -- every step's pieces were a round trip of their own (hipcc waits
+        // for everything in flight where a branch with a load in it joins): ~17 serial L2 round trips per 16-token tile with the norm
+        // weights of the epilogue, 12 us of a 13 us tile (tools/isa_waits.py: `L L W1 W0` x 8).
+    // (`early` is called for the tile in hand BEFORE the next tile's rows and the next block's summary are requested: the wait for its values
+    // then leaves those in flight -- the counter retires in order)
+    constexpr bool EARLY = EPI;
+    f32x4 pw[(EARLY && PRO) ? KST : 1][2], rcv[EARLY ? KST : 1], rsv[EARLY ? KST : 1];
+    auto early = [&]() __attribute__((always_inline)) {
+        if constexpr (EARLY) {
+            const long row = cur.row;
+            const float* standin = a.g;   // (always there, readable well past any offset used below)
+            const float* pwb = (PRO && a.pro_wq) ? a.pro_wq + h * D : standin;
+            const float* rcb = a.rcos ? a.rcos + row * a.ldr : standin;
+            const float* rsb = a.rcos ? a.rsin + row * a.ldr : standin;
+#pragma unroll
+            for (int ks = 0; ks < KST; ++ks) {
+                const int c = ks * 32 + kg * 8 < D ? ks * 32 + kg * 8 : 0;
+                if constexpr (PRO) {
+                    pw[ks][0] = gld<f32x4>(pwb + c);
+                    pw[ks][1] = gld<f32x4>(pwb + c + 4);
+                }
+                rcv[ks] = gld<f32x4>(rcb + c / 2);
+                rsv[ks] = gld<f32x4>(rsb + c / 2);
+            }
+        }
+    };
     // the products, epilogue and stores of one tile of the block in hand, from `cur`; `live`: the tile exists (every lane runs this: shuffles)
     auto tile = [&](int tt, bool live) __attribute__((always_inline)) {
         const int s = live ? tt * 16 + nl : S, sv = min(s, S - 1);
@@ -1697,7 +1739,24 @@ __global__ __launch_bounds__(SP_OUT_T, EPI ? SP_OUT_EPI_WAVES : 2) void k_sp_out
 #pragma unroll
         for (int ks = 0; ks < KST; ++ks) {
             f32x4 x0 = {0.f, 0.f, 0.f, 0.f}, x1 = x0;
-            if (ks * 32 + kg * 8 < D) {
+            if constexpr (EARLY) {   // (no branch: selects)
+                const bool in = ks * 32 + kg * 8 < D;
+                x0 = raw4_to_f32(T{}, cur.x[ks][0]);
+                x1 = raw4_to_f32(T{}, cur.x[ks][1]);
+                if constexpr (PRO) {   // relu(q rstd[token] w[channel]) + eps: the values k_qk_prologue used to materialise
+                    const float rq = a.pro_rq ? cur.rq : 1.f;
+                    x0 *= rq;
+                    x1 *= rq;
+                    const f32x4 one = {1.f, 1.f, 1.f, 1.f};
+                    x0 *= a.pro_wq ? pw[ks][0] : one;
+                    x1 *= a.pro_wq ? pw[ks][1] : one;
+                }
+                if (a.relu) relu8(x0, x1, a.eps);
+                if (a.rcos) rope8(x0, x1, rcv[ks], rsv[ks]);   // (uniform; no memory operation inside)
+                const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+                x0 = in ? x0 : z4;
+                x1 = in ? x1 : z4;
+            } else if (ks * 32 + kg * 8 < D) {
                 x0 = raw4_to_f32(T{}, cur.x[ks][0]);
                 x1 = raw4_to_f32(T{}, cur.x[ks][1]);
                 if constexpr (PRO) {   // relu(q rstd[token] w[channel]) + eps: the values k_qk_prologue used to materialise
@@ -1742,15 +1801,24 @@ __global__ __launch_bounds__(SP_OUT_T, EPI ? SP_OUT_EPI_WAVES : 2) void k_sp_out
             wide2 = a.skip_out || ((reinterpret_cast<uintptr_t>(a.o.ptr) & 15) == 0 && ((a.o.sb | a.o.sn | a.o.sh) & 7) == 0);
         typename Raw4<TO>::type gv[EPI ? DT : 1];
         uint4 gv8[WIDE_T ? (NPAIR ? NPAIR : 1) : 1];
+        f32x4 nwv[WIDE_T ? (NPAIR ? NPAIR : 1) : 1][2];   // the norm weights of the lane's pieces (wide layout), requested with the gate
+        if constexpr (WIDE_T) {
+            if (wide) {   // (uniform; every load inside is unconditional)
+                const TO* gtok = a.gate.ptr ? (const TO*)a.gate.ptr + b * a.gate.sb + row * a.gate.sn + h * a.gate.sh : reinterpret_cast<const TO*>(a.g);
+                const float* nwb = a.nw ? a.nw : a.g;
+#pragma unroll
+                for (int j = 0; j < NPAIR; ++j) {
+                    const int f0 = (2 * j + podd) * 16 + phalf, fc = f0 < D ? f0 : 0;
+                    gv8[j] = gld<uint4>(gtok + fc);
+                    nwv[j][0] = gld<f32x4>(nwb + fc);
+                    nwv[j][1] = gld<f32x4>(nwb + fc + 4);
+                }
+            }
+        }
         if constexpr (EPI) {
             if (a.gate.ptr) {
                 const TO* gtok = (const TO*)a.gate.ptr + b * a.gate.sb + row * a.gate.sn + h * a.gate.sh;
                 if (WIDE_T && wide) {
-#pragma unroll
-                    for (int j = 0; j < NPAIR; ++j) {
-                        const int f0 = (2 * j + podd) * 16 + phalf;
-                        gv8[j] = gld<uint4>(gtok + (f0 < D ? f0 : 0));
-                    }
                     if (DT & 1) {
                         if ((DT - 1) * 16 + kg * 4 < D) gv[DT - 1] = *reinterpret_cast<const typename Raw4<TO>::type*>(gtok + kg * 4 + (DT - 1) * 16);
                     }
@@ -1845,9 +1913,9 @@ __global__ __launch_bounds__(SP_OUT_T, EPI ? SP_OUT_EPI_WAVES : 2) void k_sp_out
                         const int f0 = (2 * j + podd) * 16 + phalf;
                         if (s < S && f0 < D) {
                             f32x4 y0 = lo4 * rstd, y1 = hi4 * rstd;
-                            if (a.nw) {
-                                y0 *= *reinterpret_cast<const f32x4*>(a.nw + f0);
-                                y1 *= *reinterpret_cast<const f32x4*>(a.nw + f0 + 4);
+                            if (a.nw) {   // (uniform; the values were requested before the products)
+                                y0 *= nwv[j][0];
+                                y1 *= nwv[j][1];
                             }
                             if (a.gate.ptr) {
                                 const f32x4 g0 = raw4_to_f32(TO{}, make_uint2(gv8[j].x, gv8[j].y)), g1 = raw4_to_f32(TO{}, make_uint2(gv8[j].z, gv8[j].w));
@@ -1883,13 +1951,24 @@ __global__ __launch_bounds__(SP_OUT_T, EPI ? SP_OUT_EPI_WAVES : 2) void k_sp_out
         }
     };
     if constexpr (!FLAT) {
-        fetch(wave, cur);
+        constexpr int NWV = SP_OUT_T / 64;
+        fetch(wave, cur, look(wave));
+        int lk = look(wave + NWV);   // (for the next fetch)
         // (S16: G_i stored as bf16: no lo tile)
         stage_mat_split<DT, S16, SP_OUT_T, P24>(Gh, Gl, a.g, ((long)bh * a.M + blk) * a.es, D, tid);
         __syncthreads();
-        for (int tt = wave; tt * 16 < S; tt += SP_OUT_T / 64) {
-            if constexpr (DBL) fetch(tt + SP_OUT_T / 64, nxt);
-            else if (tt != wave) fetch(tt, cur);   // (uniform)
+        for (int tt = wave; tt * 16 < S; tt += NWV) {
+            if constexpr (DBL) {
+                early();
+                fetch(tt + NWV, nxt, lk);
+                lk = look(tt + 2 * NWV);
+            } else {
+                if (tt != wave) {   // (uniform)
+                    fetch(tt, cur, lk);
+                    lk = look(tt + NWV);
+                }
+                early();
+            }
             tile(tt, true);
             if constexpr (DBL) cur = nxt;
         }
@@ -1902,7 +1981,8 @@ __global__ __launch_bounds__(SP_OUT_T, EPI ? SP_OUT_EPI_WAVES : 2) void k_sp_out
         const int nrounds = (g1 - g0 + NWV - 1) / NWV;
         MatStage<DT, SP_OUT_T> stg;
         int staged = g0 / TPI;   // the last block whose summary is in LDS (or on its way)
-        fetch(min(g0 + wave, g1 - 1), cur);
+        fetch(min(g0 + wave, g1 - 1), cur, look(min(g0 + wave, g1 - 1)));
+        int lk = look(min(g0 + wave + NWV, g1 - 1));   // (for the next fetch)
         {   // the first round's blocks: one, or -- when it already ends in the next block -- two, requested together (one round trip)
             const bool two = min(g0 + NWV - 1, g1 - 1) / TPI > staged;   // (uniform)
             MatStage<DT, SP_OUT_T> stg2;
@@ -1919,14 +1999,16 @@ __global__ __launch_bounds__(SP_OUT_T, EPI ? SP_OUT_EPI_WAVES : 2) void k_sp_out
             const int g = g0 + r * NWV + wave, gc = min(g, g1 - 1), item = gc / TPI;
             // the block a later round needs first: requested now, committed behind this round's products (uniform)
             const bool ahead = r + 1 < nrounds && min(g0 + (r + 1) * NWV + NWV - 1, g1 - 1) / TPI > staged;
-            if (ahead) stage_mat_issue<DT, SP_OUT_T>(stg, a.g, (long)(staged + 1) * a.es, D, tid);
-            fetch(min(g + NWV, g1 - 1), nxt);
             bh = item / a.M; blk = item - bh * a.M; b = bh / a.H; h = bh - b * a.H;
             p0 = (long)blk * S;
             qb = (const T*)a.q.ptr + b * a.q.sb + h * a.q.sh;
             ob = (TO*)a.o.ptr + b * a.o.sb + h * a.o.sh;
             Gh = G0 + (item & 1) * 2 * TILE;
             Gl = Gh + TILE;
+            early();   // this tile's channel weights and rope angles first, then what is needed later
+            fetch(min(g + NWV, g1 - 1), nxt, lk);
+            lk = look(min(g + 2 * NWV, g1 - 1));
+            stage_mat_issue<DT, SP_OUT_T>(stg, a.g, (long)(staged + (ahead ? 1 : 0)) * a.es, D, tid, ahead);   // (no branch around the loads)
             tile(gc - item * TPI, g < g1);
             cur = nxt;
             if (ahead) {   // (the buffer it goes to held the block before the previous one: this round may still have read it)
