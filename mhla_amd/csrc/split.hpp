@@ -216,28 +216,33 @@ __device__ __forceinline__ void stage_mat_split(u16* __restrict__ Gh, u16* __res
         uint2 xl[UB];
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
-            const int r = r0 + RPP * (pb + u);
+            // (every load unconditional, from a clamped position: rows / columns past D are zeroed below.  Behind `if (r < D && cg < D)` the
+            // pieces of a batch were round trips of their own -- hipcc waits for everything in flight where a branch with a load in it joins)
+            const int r = min(r0 + RPP * (pb + u), D - 1), c = min(cg, D - 8);
             x[u][0] = x[u][1] = f32x4{0.f, 0.f, 0.f, 0.f};
             x16[u] = make_uint4(0, 0, 0, 0);
             xl[u] = make_uint2(0, 0);
-            if (r < D && cg < D) {
-                if (P24) {   // 8 elements: a piece of the hi plane and one of the lo plane (elem_off counts floats: the row's start)
-                    const int e = r * D + cg;
-                    const char* rowp = reinterpret_cast<const char*>(base + elem_off);
-                    x16[u] = gld<uint4>(rowp + 2 * e);
-                    if constexpr (P24 == 1) xl[u] = gld<uint2>(rowp + 2 * D * D + e);
-                } else if (S16) {
-                    x16[u] = *reinterpret_cast<const uint4*>(g16 + (long)r * D + cg);
-                } else {
-                    const float* src = g + (long)r * D + cg;
-                    x[u][0] = *reinterpret_cast<const f32x4*>(src);
-                    x[u][1] = *reinterpret_cast<const f32x4*>(src + 4);
-                }
+            if (P24) {   // 8 elements: a piece of the hi plane and one of the lo plane (elem_off counts floats: the row's start)
+                const int e = r * D + c;
+                const char* rowp = reinterpret_cast<const char*>(base + elem_off);
+                x16[u] = gld<uint4>(rowp + 2 * e);
+                if constexpr (P24 == 1) xl[u] = gld<uint2>(rowp + 2 * D * D + e);
+            } else if (S16) {
+                x16[u] = gld<uint4>(g16 + (long)r * D + c);
+            } else {
+                const float* src = g + (long)r * D + c;
+                x[u][0] = gld<f32x4>(src);
+                x[u][1] = gld<f32x4>(src + 4);
             }
         }
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
             const int r = r0 + RPP * (pb + u), off = mat_row<mat_new<DT>()>(r) * LD + cg;
+            if (!(r < D && cg < D)) {   // (no memory operation in here)
+                x[u][0] = x[u][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                x16[u] = make_uint4(0, 0, 0, 0);
+                xl[u] = make_uint2(0, 0);
+            }
             if (r < KP && cg < KP) {
                 if (P24 == 2) {
                     uint4 hi, lo;
@@ -1952,8 +1957,10 @@ __global__ __launch_bounds__(SP_OUT_T, EPI ? SP_OUT_EPI_WAVES : 2) void k_sp_out
     };
     if constexpr (!FLAT) {
         constexpr int NWV = SP_OUT_T / 64;
-        fetch(wave, cur, look(wave));
-        int lk = look(wave + NWV);   // (for the next fetch)
+        int lk = 0;
+        if (a.idx) lk = gld<int>(a.idx + p0 + min(wave * 16 + nl, S - 1));   // (uniform branch; nothing is in flight yet)
+        fetch(wave, cur, lk);
+        lk = look(wave + NWV);   // (for the next fetch)
         // (S16: G_i stored as bf16: no lo tile)
         stage_mat_split<DT, S16, SP_OUT_T, P24>(Gh, Gl, a.g, ((long)bh * a.M + blk) * a.es, D, tid);
         __syncthreads();
@@ -1981,8 +1988,10 @@ __global__ __launch_bounds__(SP_OUT_T, EPI ? SP_OUT_EPI_WAVES : 2) void k_sp_out
         const int nrounds = (g1 - g0 + NWV - 1) / NWV;
         MatStage<DT, SP_OUT_T> stg;
         int staged = g0 / TPI;   // the last block whose summary is in LDS (or on its way)
-        fetch(min(g0 + wave, g1 - 1), cur, look(min(g0 + wave, g1 - 1)));
-        int lk = look(min(g0 + wave + NWV, g1 - 1));   // (for the next fetch)
+        int lk = 0;
+        if (a.idx) lk = look(min(g0 + wave, g1 - 1));   // (uniform branch; nothing is in flight yet)
+        fetch(min(g0 + wave, g1 - 1), cur, lk);
+        lk = look(min(g0 + wave + NWV, g1 - 1));   // (for the next fetch)
         {   // the first round's blocks: one, or -- when it already ends in the next block -- two, requested together (one round trip)
             const bool two = min(g0 + NWV - 1, g1 - 1) / TPI > staged;   // (uniform)
             MatStage<DT, SP_OUT_T> stg2;
@@ -2354,45 +2363,54 @@ __global__ __launch_bounds__(NTHREADS, (DT <= 4 && WQ) ? 4 : 2) void k_sp_bwd_dq
 
     // one 16-token tile of this wave: the lane's token row, its dO features as the MFMA B operand (8 per reduction step) and
     // its q_den features in output layout (4 per feature tile); fetched one tile ahead of the tile being computed
+    // (the rows AS LOADED, every load unconditional from a clamped address, nothing touched before the tile that consumes it, the gather
+    // map looked up one fetch ahead: see k_sp_bwd_dkv)
     struct Rows {
-        f32x4 g[KST][2];
-        f32x4 qd[WQ ? 1 : DT];         // q_den in output layout (relu prologue: the gradient mask needs it there)
-        f32x4 qw[WQ ? KST : 1][2];     // ... or in the operand layout of g (8 features per reduction step: 16-byte loads), for dksum only
+        typename Raw4<T>::type g[KST][2];
+        typename Raw4<T>::type qd[WQ ? 1 : DT];         // q_den in output layout (relu prologue: the gradient mask needs it there)
+        typename Raw4<T>::type qw[WQ ? KST : 1][2];     // ... or in the operand layout of g (8 features per reduction step: 16-byte loads), for dksum only
         float ninv, dz;
         long row;
         bool live;
     } cur, nxt;
-    auto fetch = [&](int tt, Rows& R) {
+    const float* standin = a.g;
+    auto look = [&](int tt) { return gld<int>(a.idx ? a.idx + p0 + min(tt * 16 + nl, S - 1) : reinterpret_cast<const int*>(a.g)); };
+    auto fetch = [&](int tt, Rows& R, int looked) __attribute__((always_inline)) {
         const int s = tt * 16 + nl, sv = min(s, S - 1);
         R.live = s < S;
-        R.row = tok_row(a.idx, p0 + sv);
-        R.ninv = a.normalize ? ninvb[sv] : 1.f;
-        R.dz = (a.normalize && R.live) ? dzb[sv] : 0.f;
+        R.row = a.idx ? (long)looked : p0 + sv;
+        R.ninv = gld<float>(a.normalize ? ninvb + sv : standin);   // (1 / 0 are selected where the values are used)
+        R.dz = gld<float>(a.normalize ? dzb + sv : standin);
+        const T* grow = gb + R.row * a.dout.sn;
+        const T* qrow = qdb + R.row * a.qd.sn;
 #pragma unroll
         for (int ks = 0; ks < KST; ++ks) {
-            R.g[ks][0] = R.g[ks][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (ks * 32 + kg * 8 < D) ld8(gb + R.row * a.dout.sn + ks * 32 + kg * 8, R.g[ks][0], R.g[ks][1]);
+            const int c = ks * 32 + kg * 8 < D ? ks * 32 + kg * 8 : 0;
+            R.g[ks][0] = gld<typename Raw4<T>::type>(grow + c);
+            R.g[ks][1] = gld<typename Raw4<T>::type>(grow + c + 4);
         }
         if constexpr (!WQ) {
 #pragma unroll
-            for (int ct = 0; ct < DT; ++ct) {
-                R.qd[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if ((a.normalize || a.relu) && ct * 16 + kg * 4 < D) R.qd[ct] = Io<T>::ld4(qdb + R.row * a.qd.sn + ct * 16 + kg * 4);
-            }
+            for (int ct = 0; ct < DT; ++ct) R.qd[ct] = gld<typename Raw4<T>::type>(qrow + (ct * 16 + kg * 4 < D ? ct * 16 + kg * 4 : 0));
         }
         // no relu prologue: q_den is needed for dksum = sum_s dz[s] q[s][:] alone -- 8 features per load, as the dO rows (the 4-feature
         // pieces of the output layout are 8-byte loads for 16-bit tensors: 0.54-0.70 of the 16-byte rate)
         if constexpr (WQ) {
 #pragma unroll
             for (int ks = 0; ks < KST; ++ks) {
-                R.qw[ks][0] = R.qw[ks][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (ks * 32 + kg * 8 < D) ld8(qdb + R.row * a.qd.sn + ks * 32 + kg * 8, R.qw[ks][0], R.qw[ks][1]);
+                const int c = ks * 32 + kg * 8 < D ? ks * 32 + kg * 8 : 0;
+                R.qw[ks][0] = gld<typename Raw4<T>::type>(qrow + c);
+                R.qw[ks][1] = gld<typename Raw4<T>::type>(qrow + c + 4);
             }
         }
     };
-    fetch(wave, cur);   // in flight while G_i is staged
+    int lk = 0;
+    if (a.idx) lk = gld<int>(a.idx + p0 + min(wave * 16 + nl, S - 1));   // (uniform branch; nothing is in flight yet)
+    fetch(wave, cur, lk);   // in flight while G_i is staged
+    lk = look(wave + 4);
+    const float ksum_v = gld<float>(a.normalize ? a.ksum + ((long)bh * M + blk) * D + min(tid, D - 1) : standin);
     stage_mat_split<DT, S16, NTHREADS, P24>(Gh, Gl, a.g, ((long)bh * M + blk) * a.es, D, tid);
-    if (tid < DW) ksum[tid] = (a.normalize && tid < D) ? a.ksum[((long)bh * M + blk) * D + tid] : 0.f;
+    if (tid < DW) ksum[tid] = (a.normalize && tid < D) ? ksum_v : 0.f;
     __syncthreads();
     f32x4 dksp[WQ ? 1 : DT], dksw8[WQ ? KST : 1][2];   // per-lane dksum partials: output layout / operand layout (WQ)
 #pragma unroll
@@ -2400,13 +2418,15 @@ __global__ __launch_bounds__(NTHREADS, (DT <= 4 && WQ) ? 4 : 2) void k_sp_bwd_dq
 #pragma unroll
     for (int ks = 0; ks < (WQ ? KST : 1); ++ks) dksw8[ks][0] = dksw8[ks][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int tt = wave; tt * 16 < S; tt += 4) {
-        if ((tt + 4) * 16 < S) fetch(tt + 4, nxt);
+    auto tile = [&]() __attribute__((always_inline)) {
+        const float cninv = a.normalize ? cur.ninv : 1.f, cdz = (a.normalize && cur.live) ? cur.dz : 0.f;
         bf16x8 gh[KST], gl[KST];   // dO / n : B[k = d2][n = s]
 #pragma unroll
         for (int ks = 0; ks < KST; ++ks) {
             uint4 hi, lo;
-            split8(cur.g[ks][0] * cur.ninv, cur.g[ks][1] * cur.ninv, hi, lo);
+            const bool in = ks * 32 + kg * 8 < D;
+            const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+            split8((in ? raw4_to_f32(T{}, cur.g[ks][0]) : z4) * cninv, (in ? raw4_to_f32(T{}, cur.g[ks][1]) : z4) * cninv, hi, lo);
             gh[ks] = as_bf16x8(hi);
             gl[ks] = as_bf16x8(lo);
         }
@@ -2414,14 +2434,17 @@ __global__ __launch_bounds__(NTHREADS, (DT <= 4 && WQ) ? 4 : 2) void k_sp_bwd_dq
         auto epilogue = [&](int ct, f32x4& c, f32x4& cd, const f32x2& rc, const f32x2& rs) {
             const int d0 = ct * 16 + kg * 4;
             if constexpr (ROPE) unrope4(c, rc, rs);
-            f32x4 qd = cur.qd[WQ ? 0 : ct];
+            f32x4 qd = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (!WQ) {
+                if ((a.normalize || a.relu) && d0 < D) qd = raw4_to_f32(T{}, cur.qd[ct]);   // (uniform / lane select; no memory operation)
+            }
             if (a.relu)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) qd[i] = fmaxf(qd[i], 0.f) + a.eps;
             const f32x4 ks4 = *reinterpret_cast<const f32x4*>(ksum + d0);
-            cd = cur.dz * ks4;
+            cd = cdz * ks4;
             if (a.normalize) {
-                if constexpr (!WQ) dksp[ct] += cur.dz * qd;
+                if constexpr (!WQ) dksp[ct] += cdz * qd;
                 if (!a.split) c += cd;
             }
             if (a.relu)
@@ -2464,8 +2487,18 @@ __global__ __launch_bounds__(NTHREADS, (DT <= 4 && WQ) ? 4 : 2) void k_sp_bwd_dq
         }
         if constexpr (WQ) {
 #pragma unroll
-            for (int ks = 0; ks < KST; ++ks) { dksw8[ks][0] += cur.dz * cur.qw[ks][0]; dksw8[ks][1] += cur.dz * cur.qw[ks][1]; }
+            for (int ks = 0; ks < KST; ++ks) {
+                const bool in = ks * 32 + kg * 8 < D;
+                const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+                dksw8[ks][0] += cdz * (in ? raw4_to_f32(T{}, cur.qw[ks][0]) : z4);
+                dksw8[ks][1] += cdz * (in ? raw4_to_f32(T{}, cur.qw[ks][1]) : z4);
+            }
         }
+    };
+    for (int tt = wave; tt * 16 < S; tt += 4) {
+        fetch((tt + 4) * 16 < S ? tt + 4 : tt, nxt, lk);   // (unconditional; the wave's last tile: itself again -- lines it has just read)
+        lk = look(tt + 8);
+        tile();
         cur = nxt;
     }
     if (a.normalize) {   // dksum[d] = sum_s dz[s] qden[s][d]: over the 16 token lanes, then over the waves
@@ -2509,46 +2542,59 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_bwd_dkv(const TokArgs a) {  
     const T *kb = base(a.k), *vb = base(a.v);
     T *dkb = mbase(a.dk), *dvb = mbase(a.dv), *dkdb = a.split ? mbase(a.dkd) : nullptr;
 
+    // A tile's rows AS LOADED (converted, masked and relu'd where they are used): every load of a fetch is unconditional, from clamped
+    // addresses, and nothing touches a loaded value before the tile that consumes it.  The fetch used to convert on arrival, sit behind
+    // `if (column < D)` / `if (a.relu)` and look its gather-map entry up itself: in the listing every piece was `load, s_waitcnt vmcnt(0)`
+    // -- ten serial round trips in front of the first tile and seven per prefetch (tools/isa_waits.py).
     struct Rows {
-        f32x4 v[KST][2], k[KST][2];   // B operands: 8 features per reduction step
-        f32x4 km[ROPE ? 1 : DT];      // k in output layout (gradient mask of the relu prologue; never combined with the rotary one)
+        typename Raw4<T>::type v[KST][2], k[KST][2];   // B operands: 8 features per reduction step
+        typename Raw4<T>::type km[ROPE ? 1 : DT];      // k in output layout (gradient mask of the relu prologue; never combined with the rotary one)
         f32x4 rc[ROPE ? KST : 1], rs[ROPE ? KST : 1];   // angles of the B-operand features (4 pairs per reduction step)
         long row;
         bool live;
     } cur, nxt;
-    auto fetch = [&](int tt, Rows& R) {
+    // the gather map's entry of the lane's row, looked up one fetch ahead (without a map: the summaries' first word, dropped)
+    // (a wave whose tile is the block's last prefetches ITS OWN tile again -- lines it has just read; re-reading the block's last tile cost
+    // the L2 a second pass over K and V, and a stand-in address selected by `has a next tile` became a branch around the loads.  A loop-free
+    // second copy of the tile body for blocks of one tile per wave cost 30 registers and the fourth workgroup per CU)
+    auto look = [&](int tt) { return gld<int>(a.idx ? a.idx + p0 + min(tt * 16 + nl, S - 1) : reinterpret_cast<const int*>(a.dkv)); };
+    auto fetch = [&](int tt, Rows& R, int looked) __attribute__((always_inline)) {
         const int s = tt * 16 + nl, sv = min(s, S - 1);
         R.live = s < S;
-        R.row = tok_row(a.idx, p0 + sv);
+        R.row = a.idx ? (long)looked : p0 + sv;
+        const T* vrow = vb + R.row * a.v.sn;
+        const T* krow = kb + R.row * a.k.sn;
 #pragma unroll
         for (int ks = 0; ks < KST; ++ks) {
-            R.v[ks][0] = R.v[ks][1] = R.k[ks][0] = R.k[ks][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (ks * 32 + kg * 8 < D) {
-                ld8(vb + R.row * a.v.sn + ks * 32 + kg * 8, R.v[ks][0], R.v[ks][1]);
-                ld8(kb + R.row * a.k.sn + ks * 32 + kg * 8, R.k[ks][0], R.k[ks][1]);
-            }
+            const int c = ks * 32 + kg * 8 < D ? ks * 32 + kg * 8 : 0;
+            R.v[ks][0] = gld<typename Raw4<T>::type>(vrow + c);
+            R.v[ks][1] = gld<typename Raw4<T>::type>(vrow + c + 4);
+            R.k[ks][0] = gld<typename Raw4<T>::type>(krow + c);
+            R.k[ks][1] = gld<typename Raw4<T>::type>(krow + c + 4);
             if constexpr (ROPE) {   // unconditional, clamped: features past D are zeros whatever their angle (a branch or a select
                 const int co = min(ks * 16 + kg * 4, D / 2 - 4);   // of whole vectors here puts the arrays on the stack)
                 R.rc[ks] = *reinterpret_cast<const f32x4*>(a.rcos + R.row * a.ldr + co);
                 R.rs[ks] = *reinterpret_cast<const f32x4*>(a.rsin + R.row * a.ldr + co);
             }
         }
-        if constexpr (!ROPE) {
+        if constexpr (!ROPE) {   // (pieces of lines the operand loads fetch anyway; used under the relu prologue only)
+            if (DT <= 4 || a.relu) {   // (head dims above 64: 32 registers of fp32 pieces -- only when they are used)
 #pragma unroll
-            for (int ct = 0; ct < DT; ++ct) {
-                R.km[ct] = f32x4{1.f, 1.f, 1.f, 1.f};
-                if (a.relu && ct * 16 + kg * 4 < D) R.km[ct] = Io<T>::ld4(kb + R.row * a.k.sn + ct * 16 + kg * 4);
+                for (int ct = 0; ct < DT; ++ct) R.km[ct] = gld<typename Raw4<T>::type>(krow + (ct * 16 + kg * 4 < D ? ct * 16 + kg * 4 : 0));
             }
         }
     };
     const bool wide_dk = view16(a.dk), wide_dv = view16(a.dv);   // (uniform) 16-byte store layout
-    fetch(wave, cur);
+    int lk = 0;
+    if (a.idx) lk = gld<int>(a.idx + p0 + min(wave * 16 + nl, S - 1));   // (uniform branch; nothing is in flight yet)
+    fetch(wave, cur, lk);
+    lk = look(wave + 4);
+    const float dks_v = gld<float>(a.normalize ? a.dks + ((long)bh * M + blk) * D + min(tid, D - 1) : reinterpret_cast<const float*>(a.dkv));
     stage_mat_split<DT, S16, NTHREADS, P24>(Gh, Gl, a.dkv, ((long)bh * M + blk) * a.es, D, tid);
-    if (tid < DW) dks[tid] = (a.normalize && tid < D) ? a.dks[((long)bh * M + blk) * D + tid] : 0.f;
+    if (tid < DW) dks[tid] = (a.normalize && tid < D) ? dks_v : 0.f;
     __syncthreads();
 
-    for (int tt = wave; tt * 16 < S; tt += 4) {
-        if ((tt + 4) * 16 < S) fetch(tt + 4, nxt);
+    auto tile = [&]() __attribute__((always_inline)) {
         bf16x8 vh[KST], vl[KST], kh[KST], kl[KST];
         f32x4 dkst[2], dvst[2];
         // ROWST (16-bit tensors, rows of up to 128 bytes): the wave's dK and dV tiles go through a wave-private LDS strip and leave as WHOLE
@@ -2564,12 +2610,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_bwd_dkv(const TokArgs a) {  
 #pragma unroll
         for (int ks = 0; ks < KST; ++ks) {
             uint4 hi, lo;
-            split8(cur.v[ks][0], cur.v[ks][1], hi, lo);
+            const bool in = ks * 32 + kg * 8 < D;
+            const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+            split8(in ? raw4_to_f32(T{}, cur.v[ks][0]) : z4, in ? raw4_to_f32(T{}, cur.v[ks][1]) : z4, hi, lo);
             vh[ks] = as_bf16x8(hi);
             vl[ks] = as_bf16x8(lo);
-            f32x4 y0 = cur.k[ks][0], y1 = cur.k[ks][1];
+            f32x4 y0 = in ? raw4_to_f32(T{}, cur.k[ks][0]) : z4, y1 = in ? raw4_to_f32(T{}, cur.k[ks][1]) : z4;
             if constexpr (ROPE) rope8(y0, y1, cur.rc[ks], cur.rs[ks]);
-            else if (a.relu && ks * 32 + kg * 8 < D) relu8(y0, y1, a.eps);
+            else if (a.relu && in) relu8(y0, y1, a.eps);
             split8(y0, y1, hi, lo);
             kh[ks] = as_bf16x8(hi);
             kl[ks] = as_bf16x8(lo);
@@ -2606,10 +2654,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_bwd_dkv(const TokArgs a) {  
             if constexpr (ROPE) unrope4(ck, urc, urs);
             if (a.normalize && !a.split) ck += *reinterpret_cast<const f32x4*>(dks + d0);
             if constexpr (!ROPE) {
-                if (a.relu)
+                if (a.relu && ct * 16 + kg * 4 < D) {
+                    const f32x4 kmf = raw4_to_f32(T{}, cur.km[ct]);
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
-                        if (!(fmaxf(cur.km[ct][i], 0.f) + a.eps > a.eps)) ck[i] = 0.f;
+                        if (!(fmaxf(kmf[i], 0.f) + a.eps > a.eps)) ck[i] = 0.f;
+                }
             }
             if constexpr (ROWST) {
                 const uint2 pk = std::is_same<T, bf16_t>::value ? make_uint2(pack_bf16x2(ck[0], ck[1]), pack_bf16x2(ck[2], ck[3])) : make_uint2(h16_pack2(ck[0], ck[1]), h16_pack2(ck[2], ck[3]));
@@ -2682,6 +2732,21 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_sp_bwd_dkv(const TokArgs a) {  
                 }
             }
         }
+    };
+    for (int tt = wave; tt * 16 < S; tt += 4) {
+#ifdef DKV_UNCOND_PREFETCH
+        fetch((tt + 4) * 16 < S ? tt + 4 : tt, nxt, lk);   // (unconditional; the wave's last tile: itself again -- lines it has just read)
+        lk = look(tt + 8);
+#else
+        // (a branch around the prefetch: where it joins hipcc waits for the prefetch itself, so blocks of more than 64 tokens do not overlap it
+        // with the products -- but the unconditional form, which re-reads the wave's own tile when there is no next one, measured slower here
+        // at every block length but 16: twelve row pieces and the mask pieces per lane are a lot of requests to issue twice)
+        if ((tt + 4) * 16 < S) {
+            fetch(tt + 4, nxt, lk);
+            lk = look(tt + 8);
+        }
+#endif
+        tile();
         cur = nxt;
     }
 }
