@@ -34,6 +34,18 @@ __device__ __forceinline__ void ld8(const T* p, f32x4& a, f32x4& b) {
     a = Io<T>::ld4(p);
     b = Io<T>::ld4(p + 4);
 }
+// 4 elements of TO as loaded (packed for 16-bit types) and their conversion to fp32
+template <typename TO> struct Raw4 { typedef uint2 type; };
+template <> struct Raw4<float> { typedef f32x4 type; };
+__device__ __forceinline__ f32x4 raw4_to_f32(bf16_t, uint2 r) {
+    return f32x4{__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u)};
+}
+__device__ __forceinline__ f32x4 raw4_to_f32(f16_t, uint2 r) {
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    const h4 h = __builtin_bit_cast(h4, r);
+    return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+}
+__device__ __forceinline__ f32x4 raw4_to_f32(float, f32x4 r) { return r; }
 __device__ __forceinline__ void relu8(f32x4& a, f32x4& b, float eps) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -364,6 +376,9 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : (ROPE ? 2 : 3)) void k_sp_state
     const int r0 = tid / CGS, cg = (tid % CGS) * 8;
     const float* ninvb = a.ninv + ((long)bh * a.M + blk) * S;   // MODE 1
 
+    // the chunk's rows AS LOADED (kr, vr, dr): converted in `settle`, at the commit -- `ld8` converted them as they arrived, i.e. the wait for
+    // the next chunk sat right behind its request, in front of this chunk's products (tools/isa_waits.py: `L L L L W3 W2` at the loop top)
+    typename Raw4<T>::type kr[IT][2], vr[IT][2], dr[IT][2];
     f32x4 kx[IT][2], vx[IT][2], dx[IT][2], rc[ROPE ? IT : 1], rs[ROPE ? IT : 1];
     float nv[IT];
     float prr[PRO ? IT : 1];   // PRO: the rows' rstd
@@ -374,7 +389,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : (ROPE ? 2 : 3)) void k_sp_state
     // is one memory round trip, not two (map entry, then the row it names) -- with the map the chunk-ahead prefetch was a chain
     // of two latencies against one 32-row chunk of products.
     int nraw[IT], npos[IT];   // the map entry as loaded, and the position it was loaded for (used when there is no map)
-    auto lookup = [&](int c0) {
+    auto lookup = [&](int c0) __attribute__((always_inline)) {
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
             const long p = p0 + min(c0 + r0 + RPP * it, S - 1);
@@ -406,15 +421,18 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : (ROPE ? 2 : 3)) void k_sp_state
     const bool olo_on = OLO && a.normalize && a.olo != nullptr;
     const u16* olop = olo_on ? a.olo + ((long)bh * a.M * S + p0) * D + cgc : reinterpret_cast<const u16*>(a.x.ptr);
     uint4 ox[OLO ? IT : 1];
-    auto fetch = [&](int c0) {
+    auto fetch = [&](int c0) __attribute__((always_inline)) {
         crow = c0;
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
             const int rcl = min(c0 + r0 + RPP * it, S - 1);
             const long row = a.idx ? nraw[it] : npos[it];
-            ld8(kb + row * a.x.sn + cgc, kx[it][0], kx[it][1]);
-            ld8(vb + row * a.y.sn + cgc, vx[it][0], vx[it][1]);
-            ld8(kdq + row * kdsn + cgc, dx[it][0], dx[it][1]);
+            kr[it][0] = gld<typename Raw4<T>::type>(kb + row * a.x.sn + cgc);
+            kr[it][1] = gld<typename Raw4<T>::type>(kb + row * a.x.sn + cgc + 4);
+            vr[it][0] = gld<typename Raw4<T>::type>(vb + row * a.y.sn + cgc);
+            vr[it][1] = gld<typename Raw4<T>::type>(vb + row * a.y.sn + cgc + 4);
+            dr[it][0] = gld<typename Raw4<T>::type>(kdq + row * kdsn + cgc);
+            dr[it][1] = gld<typename Raw4<T>::type>(kdq + row * kdsn + cgc + 4);
             nv[it] = gld<float>(nvp + ((MODE == 1 && a.normalize) ? rcl : 0));
             if constexpr (PRO) prr[it] = gld<float>(a.pro_rk ? a.pro_rk + b * a.pro_n + row : reinterpret_cast<const float*>(a.x.ptr));
             if constexpr (OLO) ox[it] = gld<uint4>(olop + (olo_on ? (long)rcl * D : 0));
@@ -426,11 +444,18 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : (ROPE ? 2 : 3)) void k_sp_state
         lookup(c0 + 32);   // (the rows of the next fetch)
     };
     // what `fetch` used to do behind its branch: zeros for padded rows / columns, relu + eps on the keys, 1 for an absent 1 / n
-    auto settle = [&]() {
+    auto settle = [&]() __attribute__((always_inline)) {   // (two call sites since the loop's last chunk was peeled: left to the inliner's size
+                                                            //  heuristics, the register arrays these lambdas share went to scratch)
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
             const bool valid = crow + r0 + RPP * it < S && cg < D;
             const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                kx[it][hf] = raw4_to_f32(T{}, kr[it][hf]);
+                vx[it][hf] = raw4_to_f32(T{}, vr[it][hf]);
+                dx[it][hf] = raw4_to_f32(T{}, dr[it][hf]);
+            }
             if constexpr (PRO) {
                 const float r = a.pro_rk ? prr[it] : 1.f;   // ((x rstd) w: the order of k_qk_prologue, so that the two paths agree bit for bit)
                 kx[it][0] = (kx[it][0] * r) * pw[0];
@@ -461,7 +486,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : (ROPE ? 2 : 3)) void k_sp_state
     float ksp[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float nvc[IT];   // RD: 1 / n and the first row of the chunk whose row dots are in flight
     int crowc = 0;
-    auto commit = [&]() {
+    auto commit = [&]() __attribute__((always_inline)) {
         __builtin_amdgcn_sched_barrier(0);   // (the fetched values are not touched before this point: hipcc would hoist `settle` above the products and wait there)
         settle();
 #pragma unroll
@@ -517,10 +542,12 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : (ROPE ? 2 : 3)) void k_sp_state
     if constexpr (RD) {   // (its loads travel with the first chunk's; the loop's first barrier covers the tiles)
         if (a.normalize) stage_mat_split<DT, false, NT, P24>(Gh, Gl, a.g, ((long)bh * a.M + blk) * a.es, D, tid);
     }
-    for (int c0 = 0; c0 < S; c0 += 32) {
+    // one 32-token chunk: commit, request the next one (PF: there is one -- a compile-time fact of the call site, so that no branch sits
+    // around the request: where such a branch joins hipcc waits for the loads in it), products
+    auto chunk = [&]<bool PF>(std::bool_constant<PF>, int c0) __attribute__((always_inline)) {
         commit();
         __syncthreads();
-        if (c0 + 32 < S) fetch(c0 + 32);
+        if constexpr (PF) fetch(c0 + 32);
         if constexpr (RD) {
             // dots[s] = sum_d1 q[s][d1] T[d1][s],  T = G_i dO'^T (transposed product: a lane gets T[16 ct + 4 kg + r][s = nl]); wave w takes
             // token tile w & 1 of the chunk and the feature tiles of half w >> 1, the two halves meet in LDS after the loop's barrier
@@ -592,7 +619,10 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : (ROPE ? 2 : 3)) void k_sp_state
                 }
             }
         }
-    }
+    };
+    int c0 = 0;
+    for (; c0 + 32 < S; c0 += 32) chunk(std::true_type{}, c0);
+    chunk(std::false_type{}, c0);   // (the block's last chunk)
 
     // KV_j -> ws  (C layout: row d1 = 16 tile + 4 kg + r, column d2 = 16 ct + nl)
     float* ob = a.out + ((long)bh * a.M + blk) * a.es;
@@ -1584,18 +1614,6 @@ __global__ __launch_bounds__(MIXR_DMA_T) void k_sp_mixr_dma(const MixrArgs a) {
 }
 
 // -------------------------------------------------------------------------------------------------
-// 4 elements of TO as loaded (packed for 16-bit types) and their conversion to fp32
-template <typename TO> struct Raw4 { typedef uint2 type; };
-template <> struct Raw4<float> { typedef f32x4 type; };
-__device__ __forceinline__ f32x4 raw4_to_f32(bf16_t, uint2 r) {
-    return f32x4{__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u)};
-}
-__device__ __forceinline__ f32x4 raw4_to_f32(f16_t, uint2 r) {
-    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-    const h4 h = __builtin_bit_cast(h4, r);
-    return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
-}
-__device__ __forceinline__ f32x4 raw4_to_f32(float, f32x4 r) { return r; }
 // 8 fp32 values -> one 16-byte piece of a 16-bit type
 __device__ __forceinline__ uint4 pack8_16(bf16_t, f32x4 a, f32x4 b) {
     return make_uint4(pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(b[0], b[1]), pack_bf16x2(b[2], b[3]));
