@@ -135,6 +135,11 @@ int cs_fwd16(const mhla_view& q, const mhla_view& k, const mhla_view& v, const f
     return MHLA_OK;
 }
 
+inline int csf_tok4_walk(int most, int n, int bh) {
+    int cpw = 1;
+    while (cpw * 2 <= most && (long)((n + cpw * 2 - 1) / (cpw * 2)) * bh >= 256) cpw *= 2;
+    return cpw;
+}
 template <int HL>
 int cs_bwd16(const mhla_view& q, const mhla_view& k, const mhla_view& v, const float* mix, int ldmix, const mhla_view& dout,
              const mhla_mview& dq, const mhla_mview& dk, const mhla_mview& dv, float* dmix, int lddmix, const CsWs& w, bool have_fwd,
@@ -158,7 +163,9 @@ int cs_bwd16(const mhla_view& q, const mhla_view& k, const mhla_view& v, const f
     }
 #undef MIXB
     CsTokArgs t{cv(q), cv(k), cv(v), cv(dout), cmv(dq), cmv(dk), cmv(dv), mix, ldmix, w.P, w.dS, w.diag, H, n, K, V, (long)T, scale};
-#define TOK4(NK) launch(fast::k_csf_bwd_tok4<NK, HL>, dim3(n, B * H), dim3(fast::NT4), fast::csf_tok4_smem<NK, HL>(), st, "k_csf_bwd_tok4", t)
+    // chunks per workgroup: the largest power of two (<= the variant's limit) that still leaves every CU a workgroup
+#define TOK4(NK) (t.cpw = csf_tok4_walk(fast::csf_tok4_cpw<NK, HL>(), n, B * H), \
+                  launch(fast::k_csf_bwd_tok4<NK, HL>, dim3((n + t.cpw - 1) / t.cpw, B * H), dim3(fast::NT4), fast::csf_tok4_smem<NK, HL>(), st, "k_csf_bwd_tok4", t))
     RC(K == 64 ? TOK4(1) : K == 128 ? TOK4(2) : K == 192 ? TOK4(3) : TOK4(4));
 #undef TOK4
     // few elements, many partials (short sequences): 16 part-lanes per element instead of 4

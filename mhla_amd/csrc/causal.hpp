@@ -102,6 +102,7 @@ struct CsTokArgs {
     int H, n, K, V;
     long T;
     float scale;
+    int cpw = 1;       // k_csf_bwd_tok4: consecutive chunks per workgroup (its grid is ceil(n / cpw) x bh)
 };
 constexpr int CS_TOK_SMEM_FLOATS = 6 * CS * CS_LDX + CS * CS_LDO + 8;
 

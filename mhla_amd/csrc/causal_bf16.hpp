@@ -186,6 +186,15 @@ __device__ __forceinline__ void cs8_put_score(u16* __restrict__ tiles, int row, 
     if constexpr (HL) tiles[tile_elems<LD>() + idx] = cvt_bf16(x - bf16_to_f32(h));
 }
 
+#ifndef CSF_TOK4_CPW
+#define CSF_TOK4_CPW 8   // most chunks per workgroup of k_csf_bwd_tok4 (the launch takes the largest power of two that leaves a workgroup per CU)
+#endif
+// (K = 256: the chunk walk's addresses do not fit beside four rings of summary tiles -- 256 VGPRs and 13-42 spilled; single-bf16 summaries
+//  at K <= 128: two workgroups per CU overlap each other and have 128 VGPRs each.  Both keep one chunk per workgroup.)
+#ifndef CSF_TOK4_WALK_NK
+#define CSF_TOK4_WALK_NK 3
+#endif
+template <int NK, int HL> __host__ __device__ constexpr int csf_tok4_cpw() { return (NK <= CSF_TOK4_WALK_NK && (HL || NK > 2)) ? CSF_TOK4_CPW : 1; }
 // row stride of k_csf_bwd_tok4's tiles: 160 bytes unless its 16-17 tiles (K > 128 with hi + lo pairs) would not fit the 160 KB
 template <int NK, int HL> __host__ __device__ constexpr int csf_tok4_ld() { return (HL && NK > 2) ? 72 : 80; }
 template <int NK, int HL>
@@ -194,7 +203,9 @@ __host__ __device__ constexpr int csf_tok4_smem() {
     return (P + 2 + 2 * NB * P + NK + (NB > 1 ? 1 : 0)) * tile_elems<csf_tok4_ld<NK, HL>()>() * 2 + 32;
 }
 
-// k_csf_bwd_tok4: dQ, dK, dV and diag(dmix) of one chunk.      grid (n, bh), 512 threads
+// k_csf_bwd_tok4: dQ, dK, dV and diag(dmix) of a.cpw <= csf_tok4_cpw<NK, HL>() consecutive chunks.      grid (ceil(n / a.cpw), bh), 512 threads
+// (one workgroup per CU at the h16 / hi + lo arithmetic: a chunk's first tiles are requested during the chunk before it -- behind the
+//  last V slice and in step 3, in the slots that held fillers -- so that only the workgroup's first chunk waits for a cold request)
 //   dA = tril(dO V^T), A = tril(Q K^T);  dQ = scale (dO P^T + m_ii dA K);  dK = V dS^T + scale m_ii dA^T Q;
 //   dV = K dS + scale m_ii A^T dO;  dmix_ii = scale sum(A . dA)                              (autograd of naive.py:71-78)
 // V slices outermost, the chunk's K tiles resident in LDS, NK = K / 64 exact (no guard in the unrolled K loop); a ring of NK
@@ -218,17 +229,14 @@ __global__ __launch_bounds__(NT4, (NK <= 2 && !HL) ? 4 : 2) void k_csf_bwd_tok4(
     float* red = reinterpret_cast<float*>(KT + (NK + (DBUF ? 1 : 0)) * CT);
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, n = lane & 15, kg = lane >> 4;
     const int rt = wave & 3, ch = wave >> 2;
-    const int ci = blockIdx.x, bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
-    const long p0 = (long)ci * CS;
-    const int rv = (int)min((long)CS, a.T - p0);
+    constexpr bool WALK = csf_tok4_cpw<NK, HL>() > 1;
+    const int c_first = WALK ? blockIdx.x * a.cpw : blockIdx.x, c_last = WALK ? min(c_first + a.cpw, a.n) - 1 : c_first;   // the workgroup's chunks
+    const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
     const int V = a.V;   // K == 64 NK
     auto base = [&](const View& w) { return (const u16*)w.ptr + b * w.sb + h * w.sh; };
     auto mbase = [&](const MView& w) { return (u16*)w.ptr + b * w.sb + h * w.sh; };
     const u16 *qb = base(a.q), *kb = base(a.k), *vb = base(a.v), *gb = base(a.dout);
     const CsLayout L = cs_layout(a.n, (long)64 * NK * V, MP);
-    const u16* Pb = reinterpret_cast<const u16*>(a.P) + bh * L.bhs + ci * L.cst;
-    const u16* dSb = reinterpret_cast<const u16*>(a.dS) + bh * L.bhs + ci * L.cst;
-    const float mii = a.mix[(long)ci * a.ldmix + ci];
 
     uint4 rP[NK][MP], rdS[NK][MP], nG, nV;
     float mP[H16 ? NK : 1], mdS[H16 ? NK : 1];   // h16: the multiplier of the thread's row strip of each tile in flight
@@ -244,13 +252,27 @@ __global__ __launch_bounds__(NT4, (NK <= 2 && !HL) ? 4 : 2) void k_csf_bwd_tok4(
             for (int p = 0; p < MP; ++p) cs8_commit_state<LD>(dst + p * CT, r[p], tid);
         }
     };
+    {   // the first chunk's Q / K tiles and first dO / V slices; every later chunk's travel during the chunk before it
+        const long p0 = (long)c_first * CS;
+        const int rv = (int)min((long)CS, a.T - p0);
 #pragma unroll
-    for (int kk = 0; kk < NK; ++kk) {
-        cs8_issue_tok(rP[kk][0], qb + kk * 64, a.q.sn, p0, rv, tid);
-        cs8_issue_tok(rdS[kk][0], kb + kk * 64, a.k.sn, p0, rv, tid);
+        for (int kk = 0; kk < NK; ++kk) {
+            cs8_issue_tok(rP[kk][0], qb + kk * 64, a.q.sn, p0, rv, tid);
+            cs8_issue_tok(rdS[kk][0], kb + kk * 64, a.k.sn, p0, rv, tid);
+        }
+        cs8_issue_tok(nG, gb, a.dout.sn, p0, rv, tid);
+        cs8_issue_tok(nV, vb, a.v.sn, p0, rv, tid);
     }
-    cs8_issue_tok(nG, gb, a.dout.sn, p0, rv, tid);
-    cs8_issue_tok(nV, vb, a.v.sn, p0, rv, tid);
+    for (int ci = c_first; ci <= c_last; ++ci) {
+    const long p0 = (long)ci * CS;
+    const int rv = (int)min((long)CS, a.T - p0);
+    // the chunk whose first tiles are requested while this one is worked on (the workgroup's last chunk: itself again, dropped --
+    // no load behind a branch)
+    const long p0n = (long)min(ci + 1, c_last) * CS;
+    const int rvn = (int)min((long)CS, a.T - p0n);
+    const u16* Pb = reinterpret_cast<const u16*>(a.P) + bh * L.bhs + ci * L.cst;
+    const u16* dSb = reinterpret_cast<const u16*>(a.dS) + bh * L.bhs + ci * L.cst;
+    const float mii = a.mix[(long)ci * a.ldmix + ci];
     // ---- step 1: A = tril(Q K^T); the K tiles stay ----
     f32x4 accA[2];
     zero2(accA);
@@ -305,14 +327,16 @@ __global__ __launch_bounds__(NT4, (NK <= 2 && !HL) ? 4 : 2) void k_csf_bwd_tok4(
         cs8_commit_tok<LD>(X2, nV, rv, tid);
         // No load of the loop sits behind a branch: hipcc loses count of the loads in flight at every join and waits for ALL of
         // them (s_waitcnt vmcnt(0) before each refill -- the ring then holds one round, whatever its depth).  Behind the last V
-        // slice the rows of this slice are requested again (never used) and the P slots receive step 3's Q tiles.
+        // slice the dO / V slots and the dS slots receive the NEXT chunk's first slices and K tiles, the P slots step 3's Q tiles.
         const int vn = last ? vs : vs + 64;
-        {   // (the fillers behind the last slice read the chunk's first Q tile: lines that step 3 wants anyway)
-            const int r = tid >> 3, c = (tid & 7) * 8;
-            const long row = p0 + (r < rv ? r : 0);
-            const u16* fill = qb + row * a.q.sn + c;
-            nG = gld<uint4>(last ? fill : gb + vn + row * a.dout.sn + c);
-            nV = gld<uint4>(last ? fill : vb + vn + row * a.v.sn + c);
+        const int rowt = tid >> 3, colt = (tid & 7) * 8;
+        const long rown = p0n + (rowt < rvn ? rowt : 0);
+        {
+            const long row = p0 + (rowt < rv ? rowt : 0);
+            // (one chunk per workgroup: fillers -- the chunk's first Q tile, lines that step 3 wants anyway)
+            const u16* fill = qb + row * a.q.sn + colt;
+            nG = gld<uint4>(last ? (WALK ? gb + rown * a.dout.sn + colt : fill) : gb + vn + row * a.dout.sn + colt);
+            nV = gld<uint4>(last ? (WALK ? vb + rown * a.v.sn + colt : fill) : vb + vn + row * a.v.sn + colt);
         }
 #pragma unroll
         for (int kk = 0; kk < NK; ++kk) {
@@ -330,7 +354,8 @@ __global__ __launch_bounds__(NT4, (NK <= 2 && !HL) ? 4 : 2) void k_csf_bwd_tok4(
 #pragma unroll
                 for (int p = 0; p < MP; ++p) rP[kk][p] = gld<uint4>(last ? qsrc : psrc + p * CTE);
 #pragma unroll
-                for (int p = 0; p < MP; ++p) rdS[kk][p] = gld<uint4>(last ? qsrc : ssrc + p * CTE);   // (filler: the same lines)
+                for (int p = 0; p < MP; ++p)   // (behind the last slice: the next chunk's K tile; a second plane's slot gets a filler)
+                    rdS[kk][p] = gld<uint4>(last ? ((WALK && p == 0) ? kb + kk * 64 + rown * a.k.sn + colt : qsrc) : ssrc + p * CTE);
                 if constexpr (H16) {   // (filler: a word of the same line, never used)
                     mP[kk] = gld<float>(last ? reinterpret_cast<const float*>(qsrc) : reinterpret_cast<const float*>(psrc - tid * 8 + CTE) + (tid >> 7));
                     mdS[kk] = gld<float>(last ? reinterpret_cast<const float*>(qsrc) : reinterpret_cast<const float*>(ssrc - tid * 8 + CTE) + (tid >> 7));
@@ -382,6 +407,7 @@ __global__ __launch_bounds__(NT4, (NK <= 2 && !HL) ? 4 : 2) void k_csf_bwd_tok4(
 #pragma unroll
     for (int kk = 0; kk < NK; ++kk) {
         cs8_commit_tok<LD>(X2, rP[kk][0], rv, tid);
+        if constexpr (WALK) cs8_issue_tok(rP[kk][0], qb + kk * 64, a.q.sn, p0n, rvn, tid);   // the next chunk's Q tile
         __syncthreads();
         f32x4 acc3[2];
         zero2(acc3);
@@ -399,6 +425,7 @@ __global__ __launch_bounds__(NT4, (NK <= 2 && !HL) ? 4 : 2) void k_csf_bwd_tok4(
         cs8_store_tok<LD>(mbase(a.dk) + kk * 64, a.dk.sn, p0, rv, B2, tid);
         __syncthreads();
     }
+    }   // (chunks)
 }
 
 // k_csf_out4: O_i = scale (Q_i P_i + m_ii tril(Q_i K_i^T) V_i)                         (naive.py:71-78)
