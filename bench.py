@@ -452,8 +452,6 @@ def main():
         kernels[name] = {"launches_per_step": int(cnt) / a.steps, "avg_us": float(tot) / int(cnt) * 1e3,
                          "us_per_step": float(tot) / a.steps * 1e3}
     gpu_us = sum(kv["us_per_step"] for kv in kernels.values())
-    dom = max(kernels, key=lambda n: kernels[n]["us_per_step"]) if kernels else None
-
     esz = {"bf16": 2, "f16": 2, "f32": 4}[a.dtype]
     nde = a.B * a.H * a.N * a.D * esz                         # one token tensor of this rank's batch
     alg_bytes = 12 * nde                                      # fwd 4 NDe + bwd 8 NDe per (b, h)
@@ -463,6 +461,12 @@ def main():
              "k_fs_state_fwd": 2, "k_fs_state<1>": 3,
              "k_sp_state": 2, "k_sp_out": 2, "k_sp_state<1>": 3, "k_sp_bwd_dq": 1, "k_sp_bwd_dkv": 4,   # (mixing / dW kernels: summaries only)
              "k_bm_bwd_tok": 7, "k_bm_state<0>": 2, "k_bm_state<1>": 3, "k_bm_out": 2}
+    # the dominant kernel: the longest one; the four token kernels of the backward are within a few per cent of each other, so among the
+    # kernels within 5 % of the longest the one responsible for the most token traffic is named (a stable choice from run to run)
+    dom = None
+    if kernels:
+        top = max(v["us_per_step"] for v in kernels.values())
+        dom = max((n for n in kernels if kernels[n]["us_per_step"] >= 0.95 * top), key=lambda n: (share.get(n, 0), kernels[n]["us_per_step"]))
     # HBM bytes per step: PMC counters cannot be read from inside this process, so the figure comes from the rocprofv3 PMC
     # passes of this same command (tools/prof_all.sh + tools/collect_profiles.py -> profiles/r*_pmc_traffic.json) -- and only when that file was made
     # from the kernel sources this library was built from (it records their hash); otherwise null
