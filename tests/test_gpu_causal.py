@@ -99,7 +99,11 @@ BF16_SHAPES = [(256, 64, 64), (200, 64, 128), (50, 128, 64), (1000, 128, 256), (
                # one, ragged and one-token last chunks
                (330, 128, 256), (449, 128, 256), (321, 64, 64), (8192, 64, 64), (2100, 256, 256),
                # 129..256 chunks: the sixteen-wave mixing kernels (dS and dmix as two launches)
-               (8256, 64, 64), (16384, 64, 64), (10000, 128, 128)]
+               (8256, 64, 64), (16384, 64, 64), (10000, 128, 128),
+               # the token-gradient kernel's chunk walk (k_csf_bwd_tok4: with B H = 4 here, two chunks per workgroup from 128 chunks on and
+               # four at 256 -- the shapes above cover K = 64 / 128 with an odd chunk count and a ragged tail; the full-size C5 test walks
+               # eight): K = 192, an odd count and a 8-token last chunk
+               (8200, 192, 192)]
 
 
 @pytest.mark.parametrize("T,K,V", BF16_SHAPES)
