@@ -168,8 +168,12 @@ int cs_bwd16(const mhla_view& q, const mhla_view& k, const mhla_view& v, const f
                   launch(fast::k_csf_bwd_tok4<NK, HL>, dim3((n + t.cpw - 1) / t.cpw, B * H), dim3(fast::NT4), fast::csf_tok4_smem<NK, HL>(), st, "k_csf_bwd_tok4", t))
     RC(K == 64 ? TOK4(1) : K == 128 ? TOK4(2) : K == 192 ? TOK4(3) : TOK4(4));
 #undef TOK4
-    // few elements, many partials (short sequences): 16 part-lanes per element instead of 4
-    if (n <= 64) RC(launch(k_dw_reduce<1, 16>, dim3((n * n + 15) / 16), dim3(256), 0, st, "k_dw_reduce<1>", (const float*)w.dwp,
+    // up to 128 chunks: 16 part-lanes per element instead of 4 -- a thread's chain of dependent load batches is what the kernel takes
+    // (128 chunks, 256 partials: 64 loads per thread 10.8 us, 16 loads 8.3 us)
+#ifndef CS_RED16_MAX_N
+#define CS_RED16_MAX_N 128
+#endif
+    if (n <= CS_RED16_MAX_N) RC(launch(k_dw_reduce<1, 16>, dim3((n * n + 15) / 16), dim3(256), 0, st, "k_dw_reduce<1>", (const float*)w.dwp,
                            (const float*)w.diag, dmix, lddmix, n, pl.wgs, B * H));
     else         RC(launch(k_dw_reduce<1>, dim3((n * n + 63) / 64), dim3(256), 0, st, "k_dw_reduce<1>", (const float*)w.dwp,
                            (const float*)w.diag, dmix, lddmix, n, pl.wgs, B * H));
